@@ -1,0 +1,237 @@
+"""ctypes binding of libcutadapt_hip.so (the C ABI in include/cutadapt_hip.h).
+
+There is no CPU fallback: if the library is missing or no HIP device is usable, every
+operation raises.  (cffi is not installed in this image, hence ctypes.)
+"""
+import ctypes as C
+import os
+from typing import List, Optional, Sequence, Tuple
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcutadapt_hip.so")
+
+CAH_OK, CAH_EINVAL, CAH_ETYPE, CAH_EHIP, CAH_ENOMEM, CAH_EUNSUPPORTED = 0, 1, 2, 3, 4, 5
+NONE, MATCH, INVALID = 0, 1, 2
+KIND_ALIGNER, KIND_PREFIX, KIND_SUFFIX, KIND_KMER_ONLY = 0, 1, 2, 3
+MAX_ADAPTER_LEN = 64
+PROF_FILTER, PROF_DP, PROF_COMPARER, PROF_N = 0, 1, 2, 3
+
+# every symbol include/cutadapt_hip.h declares (tests check the library exports them all)
+EXPORTED_SYMBOLS = [
+    "cah_abi_version", "cah_last_error", "cah_device_count", "cah_set_device", "cah_device_info",
+    "cah_plan_create", "cah_plan_destroy", "cah_plan_n_adapters", "cah_plan_effective_length",
+    "cah_plan_n_kmer_entries", "cah_locate_batch", "cah_kmers_present_batch", "cah_match_batch",
+    "cah_workspace_bytes", "cah_validate_ascii_batch", "cah_locate_batch_host",
+    "cah_kmers_present_batch_host", "cah_match_batch_host", "cah_profile_enable",
+    "cah_profile_reset", "cah_profile_read", "cah_synth_reads",
+]
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+class UnsupportedByHipPath(ValueError):
+    """Input outside the limits of this build (e.g. adapter longer than 64 characters)."""
+
+
+class KmerSetC(C.Structure):
+    _fields_ = [("start", C.c_int64), ("stop", C.c_int64),
+                ("kmers", C.POINTER(C.c_char_p)), ("n_kmers", C.c_int32)]
+
+
+class AdapterDescC(C.Structure):
+    _fields_ = [("sequence", C.c_char_p), ("length", C.c_int32), ("max_error_rate", C.c_double),
+                ("flags", C.c_int32), ("wildcard_ref", C.c_int32), ("wildcard_query", C.c_int32),
+                ("indel_cost", C.c_int32), ("min_overlap", C.c_int32), ("kind", C.c_int32),
+                ("kmer_sets", C.POINTER(KmerSetC)), ("n_kmer_sets", C.c_int32),
+                ("kmer_ref_wildcards", C.c_int32), ("kmer_query_wildcards", C.c_int32)]
+
+
+_lib = None
+
+
+def lib():
+    """Load the shared library (once).  Raises HipLibraryMissing if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryMissing(
+            f"{LIB_PATH} not found: build it with `python -m cutadapt_amd.build` "
+            "(the HIP path has no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    L.cah_abi_version.restype = C.c_int
+    L.cah_last_error.argtypes = [C.c_char_p, C.c_size_t]
+    L.cah_last_error.restype = None
+    L.cah_device_count.argtypes = [C.POINTER(C.c_int)]
+    L.cah_set_device.argtypes = [C.c_int]
+    L.cah_device_info.argtypes = [C.c_int, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t,
+                                  C.POINTER(C.c_int), C.POINTER(i64)]
+    L.cah_plan_create.argtypes = [C.POINTER(AdapterDescC), i32, C.POINTER(vp)]
+    L.cah_plan_destroy.argtypes = [vp]
+    L.cah_plan_destroy.restype = None
+    L.cah_plan_n_adapters.argtypes = [vp]
+    L.cah_plan_effective_length.argtypes = [vp, i32, C.POINTER(i32)]
+    L.cah_plan_n_kmer_entries.argtypes = [vp, i32, C.POINTER(i32)]
+    L.cah_locate_batch.argtypes = [vp, i32, vp, vp, vp, i64, vp, vp, vp, C.c_size_t, vp]
+    L.cah_kmers_present_batch.argtypes = [vp, i32, vp, vp, vp, i64, vp, vp]
+    L.cah_match_batch.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp, vp, C.c_size_t, vp]
+    L.cah_workspace_bytes.argtypes = [i64]
+    L.cah_workspace_bytes.restype = C.c_size_t
+    L.cah_validate_ascii_batch.argtypes = [vp, vp, vp, i64, vp, vp]
+    L.cah_locate_batch_host.argtypes = [vp, i32, vp, vp, i64, vp, vp]
+    L.cah_kmers_present_batch_host.argtypes = [vp, i32, vp, vp, i64, vp]
+    L.cah_match_batch_host.argtypes = [vp, vp, vp, i64, vp, vp, vp]
+    L.cah_profile_enable.argtypes = [C.c_int]
+    L.cah_profile_reset.argtypes = []
+    L.cah_profile_read.argtypes = [C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(i64)]
+    L.cah_synth_reads.argtypes = [C.c_uint64, i64, i64, i32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                  C.c_char_p, C.POINTER(i32), i32, vp, vp, vp]
+    for name in EXPORTED_SYMBOLS:
+        fn = getattr(L, name)
+        if fn.restype is C.c_int and name not in ("cah_abi_version", "cah_plan_n_adapters"):
+            pass
+    _lib = L
+    return L
+
+
+def last_error() -> str:
+    buf = C.create_string_buffer(1024)
+    lib().cah_last_error(buf, len(buf))
+    return buf.value.decode("utf-8", "replace")
+
+
+def check(rc: int) -> None:
+    """Map a C status to the exception the reference would raise."""
+    if rc == CAH_OK:
+        return
+    msg = last_error()
+    if rc == CAH_EINVAL:
+        raise ValueError(msg)
+    if rc == CAH_ETYPE:
+        raise TypeError(msg)
+    if rc == CAH_EUNSUPPORTED:
+        raise UnsupportedByHipPath(msg)
+    if rc == CAH_ENOMEM:
+        raise MemoryError(msg)
+    raise RuntimeError(msg)
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    rc = lib().cah_device_count(C.byref(n))
+    return n.value if rc == CAH_OK else 0
+
+
+def device_info(device: int = 0) -> dict:
+    name = C.create_string_buffer(256)
+    arch = C.create_string_buffer(256)
+    cus = C.c_int(0)
+    mem = C.c_int64(0)
+    check(lib().cah_device_info(device, name, 256, arch, 256, C.byref(cus), C.byref(mem)))
+    return {"name": name.value.decode(), "arch": arch.value.decode(),
+            "compute_units": cus.value, "hbm_bytes": mem.value}
+
+
+def _ascii(s: str, what: str = "String") -> bytes:
+    if not isinstance(s, str):
+        raise TypeError(f"{what} must be a str, not {type(s).__name__}")
+    try:
+        return s.encode("ascii")
+    except UnicodeEncodeError:
+        raise ValueError("String must contain only ASCII characters")
+
+
+class MatcherSpec:
+    """Python-side description of one matcher (one cah_adapter_desc)."""
+
+    def __init__(self, sequence: str = "", max_error_rate: float = 0.0, flags: int = 15,
+                 wildcard_ref: bool = False, wildcard_query: bool = False, indel_cost: int = 1,
+                 min_overlap: int = 1, kind: int = KIND_ALIGNER,
+                 kmer_sets: Optional[Sequence[Tuple[int, Optional[int], Sequence[str]]]] = None,
+                 kmer_ref_wildcards: bool = False, kmer_query_wildcards: bool = False):
+        self.sequence = sequence
+        self.max_error_rate = float(max_error_rate)
+        self.flags = int(flags)
+        self.wildcard_ref = bool(wildcard_ref)
+        self.wildcard_query = bool(wildcard_query)
+        self.indel_cost = int(indel_cost)
+        self.min_overlap = int(min_overlap)
+        self.kind = int(kind)
+        self.kmer_sets = None if kmer_sets is None else [
+            (int(start), stop, list(kmers)) for start, stop, kmers in kmer_sets]
+        self.kmer_ref_wildcards = bool(kmer_ref_wildcards)
+        self.kmer_query_wildcards = bool(kmer_query_wildcards)
+
+
+class Plan:
+    """An immutable device plan (cah_plan): tables of one or more matchers in HBM."""
+
+    def __init__(self, specs: Sequence[MatcherSpec]):
+        self._h = None
+        self.specs = list(specs)
+        n = len(self.specs)
+        descs = (AdapterDescC * n)()
+        keep = []   # keep ctypes buffers alive during the call
+        for i, sp in enumerate(self.specs):
+            d = descs[i]
+            seq = _ascii(sp.sequence)
+            keep.append(seq)
+            d.sequence = seq
+            d.length = len(seq)
+            d.max_error_rate = sp.max_error_rate
+            d.flags = sp.flags
+            d.wildcard_ref = int(sp.wildcard_ref)
+            d.wildcard_query = int(sp.wildcard_query)
+            d.indel_cost = sp.indel_cost
+            d.min_overlap = sp.min_overlap
+            d.kind = sp.kind
+            d.kmer_ref_wildcards = int(sp.kmer_ref_wildcards)
+            d.kmer_query_wildcards = int(sp.kmer_query_wildcards)
+            if sp.kmer_sets is None:
+                d.n_kmer_sets = -1
+                d.kmer_sets = None
+            else:
+                sets = (KmerSetC * max(len(sp.kmer_sets), 1))()
+                for j, (start, stop, kmers) in enumerate(sp.kmer_sets):
+                    enc = []
+                    for k in kmers:
+                        if type(k) is not str:
+                            raise TypeError(f"Kmer should be a string not {type(k)}")
+                        try:
+                            enc.append(k.encode("ascii"))
+                        except UnicodeEncodeError:
+                            raise ValueError("Only ASCII strings are supported")
+                    arr = (C.c_char_p * max(len(enc), 1))(*enc)
+                    keep.extend([enc, arr])
+                    sets[j].start = start
+                    sets[j].stop = 0 if stop is None else int(stop)
+                    sets[j].kmers = arr
+                    sets[j].n_kmers = len(enc)
+                keep.append(sets)
+                d.kmer_sets = sets
+                d.n_kmer_sets = len(sp.kmer_sets)
+        h = C.c_void_p()
+        check(lib().cah_plan_create(descs, n, C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None:
+            _lib.cah_plan_destroy(h)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def effective_length(self, adapter: int = 0) -> int:
+        out = C.c_int32(0)
+        check(lib().cah_plan_effective_length(self._h, adapter, C.byref(out)))
+        return out.value
+
+    def n_kmer_entries(self, adapter: int = 0) -> int:
+        out = C.c_int32(0)
+        check(lib().cah_plan_n_kmer_entries(self._h, adapter, C.byref(out)))
+        return out.value

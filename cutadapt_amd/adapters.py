@@ -1,0 +1,859 @@
+"""Adapter classes with the reference's ``match_to()`` API plus batch forms, on the HIP path.
+
+Mirrors the matching part of reference src/cutadapt/adapters.py:
+  Where flag table :39-53, Match types :292-493, SingleAdapter :533-681 and its subclasses
+  :684-1089 (Front/Back/Anywhere/NonInternal*/Prefix/Suffix/Rightmost*), LinkedAdapter
+  :1181-1243 with LinkedMatch :1092-1178, MultipleAdapters :1246-1286.
+Out of scope here: statistics classes (:71-289) and AdapterIndex
+(:1289-1571).
+
+``match_to(sequence: str)`` keeps the reference's per-read contract (returns a Match or
+None) by running a batch of one through the fused kernel path; ``match_to_batch(ReadBatch)``
+is the form that feeds the GPU properly and returns array results, Match objects are
+created on demand only.
+"""
+from abc import ABC, abstractmethod
+from enum import IntFlag
+from typing import List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+from . import _lib
+from ._kmer_finder import KmerFinder
+from .align import Aligner, EndSkip, PrefixComparer, SuffixComparer
+from .kmer_heuristic import create_positions_and_kmers
+
+
+class MockKmerFinder:
+    """Stand-in used when the prefilter cannot be applied (reference adapters.py:29-31)."""
+
+    def kmers_present(self, sequence: str):
+        return True
+
+
+class InvalidCharacter(Exception):
+    pass
+
+
+class Where(IntFlag):
+    """Aligner flag combinations per adapter type (reference adapters.py:39-53)."""
+
+    BACK = EndSkip.QUERY_START | EndSkip.QUERY_STOP | EndSkip.REFERENCE_END
+    FRONT = EndSkip.QUERY_START | EndSkip.QUERY_STOP | EndSkip.REFERENCE_START
+    PREFIX = EndSkip.QUERY_STOP
+    SUFFIX = EndSkip.QUERY_START
+    FRONT_NOT_INTERNAL = EndSkip.REFERENCE_START | EndSkip.QUERY_STOP
+    BACK_NOT_INTERNAL = EndSkip.QUERY_START | EndSkip.REFERENCE_END
+    ANYWHERE = EndSkip.SEMIGLOBAL
+
+
+# -------------------------------------------------------------------------------------------------
+# Match objects (reference adapters.py:292-493)
+# -------------------------------------------------------------------------------------------------
+class Match(ABC):
+    adapter: "Adapter"
+
+    @abstractmethod
+    def remainder_interval(self) -> Tuple[int, int]:
+        pass
+
+    @abstractmethod
+    def retained_adapter_interval(self) -> Tuple[int, int]:
+        pass
+
+    @abstractmethod
+    def trimmed(self, read):
+        pass
+
+    @abstractmethod
+    def match_sequence(self):
+        pass
+
+
+class SingleMatch(Match, ABC):
+    """One adapter matched to one string (reference adapters.py:316-424)."""
+
+    __slots__ = ["astart", "astop", "rstart", "rstop", "score", "errors", "adapter", "sequence", "length"]
+
+    def __init__(self, astart: int, astop: int, rstart: int, rstop: int, score: int, errors: int,
+                 adapter: "SingleAdapter", sequence: str):
+        self.astart = astart
+        self.astop = astop
+        self.rstart = rstart
+        self.rstop = rstop
+        self.score = score
+        self.errors = errors
+        self.adapter = adapter
+        self.sequence = sequence
+        self.length = astop - astart   # aligned adapter characters
+
+    def __repr__(self):
+        return (f"{self.__class__.__name__}(astart={self.astart}, astop={self.astop}, "
+                f"rstart={self.rstart}, rstop={self.rstop}, score={self.score}, errors={self.errors})")
+
+    def __eq__(self, other) -> bool:
+        return (other.__class__ is self.__class__ and self.astart == other.astart
+                and self.astop == other.astop and self.rstart == other.rstart
+                and self.rstop == other.rstop and self.score == other.score
+                and self.errors == other.errors and self.adapter is other.adapter
+                and self.sequence == other.sequence)
+
+    def astuple(self) -> Tuple[int, int, int, int, int, int]:
+        return (self.astart, self.astop, self.rstart, self.rstop, self.score, self.errors)
+
+    def wildcards(self, wildcard_char: str = "N") -> str:
+        """Characters of the read aligned to wildcard characters of the adapter
+        (reference adapters.py:378-393; unreliable with indels, as in the reference)."""
+        return "".join(
+            self.sequence[self.rstart + i] for i in range(self.length)
+            if self.adapter.sequence[self.astart + i] == wildcard_char
+            and self.rstart + i < len(self.sequence))
+
+    def get_info_records(self, read) -> List[List]:
+        seq, qualities = read.sequence, read.qualities
+        info = ["", self.errors, self.rstart, self.rstop, seq[0:self.rstart],
+                seq[self.rstart:self.rstop], seq[self.rstop:], self.adapter.name]
+        if qualities:
+            info += [qualities[0:self.rstart], qualities[self.rstart:self.rstop], qualities[self.rstop:]]
+        else:
+            info += ["", "", ""]
+        return [info]
+
+    def match_sequence(self):
+        return self.sequence[self.rstart:self.rstop]
+
+    @abstractmethod
+    def removed_sequence_length(self) -> int:
+        pass
+
+
+class RemoveBeforeMatch(SingleMatch):
+    """A match that removes the sequence before it (5' adapters; reference :427-457)."""
+
+    def rest(self) -> str:
+        return self.sequence[:self.rstart]
+
+    def remainder_interval(self) -> Tuple[int, int]:
+        return self.rstop, len(self.sequence)
+
+    def retained_adapter_interval(self) -> Tuple[int, int]:
+        return self.rstart, len(self.sequence)
+
+    def trim_slice(self):
+        return slice(self.rstop, None)
+
+    def trimmed(self, read):
+        return read[self.rstop:]
+
+    def removed_sequence_length(self) -> int:
+        return self.rstop
+
+
+class RemoveAfterMatch(SingleMatch):
+    """A match that removes the sequence after it (3' adapters; reference :460-493)."""
+
+    def rest(self) -> str:
+        return self.sequence[self.rstop:]
+
+    def remainder_interval(self) -> Tuple[int, int]:
+        return 0, self.rstart
+
+    def retained_adapter_interval(self) -> Tuple[int, int]:
+        return 0, self.rstop
+
+    def trim_slice(self):
+        return slice(None, self.rstart)
+
+    def trimmed(self, read):
+        return read[:self.rstart]
+
+    def adjacent_base(self) -> str:
+        return self.sequence[self.rstart - 1:self.rstart]
+
+    def removed_sequence_length(self) -> int:
+        return len(self.sequence) - self.rstart
+
+
+_name_counter = [1]
+
+
+def _generate_adapter_name() -> str:
+    name = str(_name_counter[0])
+    _name_counter[0] += 1
+    return name
+
+
+# -------------------------------------------------------------------------------------------------
+# batch results
+# -------------------------------------------------------------------------------------------------
+class BatchMatches:
+    """Array-form result of ``match_to_batch``: per read the 6-tuple in *match coordinates*
+    (astart, astop, rstart, rstop, score, errors), a found flag, which adapter won and whether
+    the match removes the sequence before (True) or after (False) it.  Everything is numpy on
+    the host; ``match(i)`` builds the reference-style Match object for one read on demand."""
+
+    def __init__(self, coords: np.ndarray, found: np.ndarray, adapter_index: np.ndarray,
+                 adapters: Sequence["SingleAdapter"], remove_before: np.ndarray, reads=None):
+        self.coords = coords
+        self.found = found
+        self.adapter_index = adapter_index
+        self.adapters = list(adapters)
+        self.remove_before = remove_before
+        self._reads = reads          # ReadBatch or list[str]; needed only for Match objects
+        self._strings = None
+
+    def __len__(self):
+        return len(self.found)
+
+    def _sequence(self, i: int) -> str:
+        if self._strings is None:
+            self._strings = self._reads if isinstance(self._reads, list) else self._reads.to_strings()
+        return self._strings[i]
+
+    def match(self, i: int) -> Optional[SingleMatch]:
+        if not self.found[i]:
+            return None
+        adapter = self.adapters[int(self.adapter_index[i])]
+        cls = RemoveBeforeMatch if self.remove_before[i] else RemoveAfterMatch
+        return cls(*(int(v) for v in self.coords[i]), adapter=adapter, sequence=self._sequence(i))
+
+    def matches(self) -> List[Optional[SingleMatch]]:
+        return [self.match(i) for i in range(len(self))]
+
+    def tuples(self):
+        return [tuple(int(v) for v in self.coords[i]) if self.found[i] else None for i in range(len(self))]
+
+
+def _raise_if_invalid(status: np.ndarray):
+    if (status == _lib.INVALID).any():
+        raise ValueError("String must contain only ASCII characters")
+
+
+# -------------------------------------------------------------------------------------------------
+# adapters
+# -------------------------------------------------------------------------------------------------
+class Matchable(ABC):
+    def __init__(self, name: Optional[str], *args, **kwargs):
+        self.name = name
+
+    @abstractmethod
+    def match_to(self, sequence: str):
+        pass
+
+
+class Adapter(Matchable, ABC):
+    description = "adapter with one component"
+
+    @abstractmethod
+    def spec(self) -> str:
+        pass
+
+    @abstractmethod
+    def descriptive_identifier(self) -> str:
+        pass
+
+
+class SingleAdapter(Adapter, ABC):
+    """One adapter: sequence, error rate, type (reference adapters.py:533-681).
+
+    ``max_errors`` < 1 is a rate, otherwise an absolute number divided by the number of non-N
+    characters; ``min_overlap`` is clamped to the adapter length; ``indels=False`` is expressed
+    as indel_cost 100000 (reference :605)."""
+
+    allows_partial_matches: bool = True
+    _reverse_reads = False           # Rightmost* adapters match the reversed read
+    _remove_before = False           # which Match type a hit produces
+
+    def __init__(self, sequence: str, max_errors: float = 0.1, min_overlap: int = 3,
+                 read_wildcards: bool = False, adapter_wildcards: bool = True,
+                 name: Optional[str] = None, indels: bool = True):
+        self.name: str = _generate_adapter_name() if name is None else name
+        super().__init__(self.name)
+        self._debug = False
+        self.sequence: str = sequence.upper().replace("U", "T").replace("I", "N")
+        if not self.sequence:
+            raise ValueError("Adapter sequence is empty")
+        if max_errors >= 1 and self.sequence.count("N") != len(self.sequence):
+            max_errors /= len(self.sequence) - self.sequence.count("N")
+        self.max_error_rate: float = max_errors
+        self.min_overlap: int = min(min_overlap, len(self.sequence))
+        iupac = frozenset("ABCDGHKMNRSTUVWXY")
+        if adapter_wildcards and not set(self.sequence) <= iupac:
+            for c in self.sequence:
+                if c not in iupac:
+                    raise InvalidCharacter(
+                        f"Character '{c}' in adapter sequence '{self.sequence}' is "
+                        f"not a valid IUPAC code. Use only characters 'ABCDGHIKMNRSTUVWXY'.")
+        # non-wildcard matching if the adapter is plain ACGT (reference :592-595)
+        self.adapter_wildcards: bool = adapter_wildcards and not set(self.sequence) <= set("ACGT")
+        self.read_wildcards: bool = read_wildcards
+        self.indels: bool = indels
+        self.aligner = self._aligner()
+        self.kmer_finder = self._kmer_finder()
+        # fused plan: this adapter's aligner + its prefilter as ONE matcher, so that
+        # match_to()/match_to_batch() are a single library call
+        self._fused_plan = _lib.Plan([self.matcher_spec()])
+
+    # -- construction helpers ---------------------------------------------------------------
+    def _make_aligner(self, sequence: str, flags: int) -> Aligner:
+        indel_cost = 1 if self.indels else 100000
+        return Aligner(sequence, self.max_error_rate, flags=flags, wildcard_ref=self.adapter_wildcards,
+                       wildcard_query=self.read_wildcards, indel_cost=indel_cost,
+                       min_overlap=self.min_overlap)
+
+    def _make_kmer_finder(self, sequence: str, back_adapter: bool, front_adapter: bool,
+                          internal: bool = True) -> Union[KmerFinder, MockKmerFinder]:
+        positions_and_kmers = create_positions_and_kmers(
+            sequence, self.min_overlap, self.max_error_rate, back_adapter, front_adapter, internal)
+        try:
+            return KmerFinder(positions_and_kmers, self.adapter_wildcards, self.read_wildcards)
+        except ValueError:
+            return MockKmerFinder()     # k-mers too long (reference :633-639)
+
+    def matcher_spec(self) -> _lib.MatcherSpec:
+        """aligner + prefilter as one cah_adapter_desc"""
+        if isinstance(self.kmer_finder, KmerFinder):
+            return self.aligner.spec(self.kmer_finder.positions_and_kmers,
+                                     self.kmer_finder.ref_wildcards, self.kmer_finder.query_wildcards)
+        return self.aligner.spec(None)
+
+    def __repr__(self):
+        return ("<{cls}(name={name!r}, sequence={sequence!r}, max_error_rate={max_error_rate}, "
+                "min_overlap={min_overlap}, read_wildcards={read_wildcards}, "
+                "adapter_wildcards={adapter_wildcards}, indels={indels})>").format(
+                    cls=self.__class__.__name__, name=self.name, sequence=self.sequence,
+                    max_error_rate=self.max_error_rate, min_overlap=self.min_overlap,
+                    read_wildcards=self.read_wildcards, adapter_wildcards=self.adapter_wildcards,
+                    indels=self.indels)
+
+    @property
+    def effective_length(self) -> int:
+        return self.aligner.effective_length
+
+    def enable_debug(self) -> None:
+        self._debug = True
+        self.aligner.enable_debug()
+
+    @abstractmethod
+    def _aligner(self):
+        pass
+
+    @abstractmethod
+    def _kmer_finder(self):
+        pass
+
+    def __len__(self) -> int:
+        return len(self.sequence)
+
+    # -- matching ---------------------------------------------------------------------------------
+    def _wrap(self, alignment, sequence: str):
+        cls = RemoveBeforeMatch if self._remove_before else RemoveAfterMatch
+        return cls(*alignment, adapter=self, sequence=sequence)
+
+    def _mirror(self, t, seq_len: int):
+        """map a hit on the reversed read / reversed adapter back (reference :777-785)"""
+        ref_start, ref_end, query_start, query_end, score, errors = t
+        m = len(self.sequence)
+        return (m - ref_end, m - ref_start, seq_len - query_end, seq_len - query_start, score, errors)
+
+    def _locate_fused(self, sequence: str):
+        """kmers_present -> locate for one read in a single library call"""
+        q = _lib._ascii(sequence)
+        seqs = np.frombuffer(q, dtype=np.uint8)
+        offsets = np.array([0, len(q)], dtype=np.int64)
+        out6 = np.zeros(6, dtype=np.int32)
+        status = np.zeros(1, dtype=np.uint8)
+        _lib.check(_lib.lib().cah_match_batch_host(
+            self._fused_plan.handle, seqs.ctypes.data if len(q) else None, offsets.ctypes.data, 1,
+            out6.ctypes.data, None, status.ctypes.data))
+        _raise_if_invalid(status)
+        return tuple(int(v) for v in out6) if status[0] == _lib.MATCH else None
+
+    def match_to(self, sequence: str):
+        """Match this adapter to one read; a Match or None (reference e.g. :707-724, :815-832)."""
+        if self._reverse_reads:
+            alignment = self._locate_fused(sequence[::-1])
+            if alignment is None:
+                return None
+            alignment = self._mirror(alignment, len(sequence))
+        else:
+            alignment = self._locate_fused(sequence)
+            if alignment is None:
+                return None
+        return self._wrap(alignment, sequence)
+
+    def match_to_batch(self, batch) -> BatchMatches:
+        """Match this adapter to every read of a ReadBatch."""
+        from . import batch as _b
+        work = _reverse_batch(batch) if self._reverse_reads else batch
+        res = _b.match_batch(self._fused_plan, work)
+        out6, status, _ = res.cpu()
+        _raise_if_invalid(status)
+        found = status == _lib.MATCH
+        coords = out6.astype(np.int64)
+        if self._reverse_reads:
+            lens = batch.lengths().cpu().numpy()
+            m = len(self.sequence)
+            mirrored = np.stack([m - coords[:, 1], m - coords[:, 0], lens - coords[:, 3],
+                                 lens - coords[:, 2], coords[:, 4], coords[:, 5]], axis=1)
+            coords = np.where(found[:, None], mirrored, 0)
+        n = len(found)
+        return BatchMatches(coords, found, np.zeros(n, dtype=np.int32), [self],
+                            self._remove_before_array(coords, found), reads=batch)
+
+    def _remove_before_array(self, coords, found) -> np.ndarray:
+        return np.full(len(found), self._remove_before, dtype=bool)
+
+
+def _reverse_batch(batch):
+    """Per-read reversed copy of a ReadBatch (device-side gather; Rightmost* adapters search the
+    reversed read with the reversed adapter, reference adapters.py:766, :870)."""
+    import torch
+    from .batch import ReadBatch
+    lens = batch.lengths()
+    n = batch.n_reads
+    new_offsets = torch.zeros(n + 1, dtype=torch.int64, device=batch.device)
+    torch.cumsum(lens, 0, out=new_offsets[1:])
+    total = int(new_offsets[-1].item()) if n else 0
+    if total == 0:
+        return ReadBatch(torch.zeros(0, dtype=torch.uint8, device=batch.device), new_offsets, validated=batch.validated)
+    read_of = torch.repeat_interleave(torch.arange(n, device=batch.device), lens)
+    pos = torch.arange(total, device=batch.device) - new_offsets[read_of]
+    src = batch.offsets[:n][read_of] + (lens[read_of] - 1 - pos)
+    return ReadBatch(batch.seqs[src], new_offsets, validated=batch.validated)
+
+
+class FrontAdapter(SingleAdapter):
+    """A 5' adapter (reference adapters.py:684-730)."""
+
+    description = "regular 5'"
+    _remove_before = True
+
+    def __init__(self, *args, **kwargs):
+        self._force_anywhere = kwargs.pop("force_anywhere", False)
+        super().__init__(*args, **kwargs)
+
+    def descriptive_identifier(self) -> str:
+        return "regular_five_prime"
+
+    def _aligner(self):
+        return self._make_aligner(self.sequence, Where.ANYWHERE.value if self._force_anywhere else Where.FRONT.value)
+
+    def _kmer_finder(self):
+        return self._make_kmer_finder(self.sequence, back_adapter=self._force_anywhere, front_adapter=True)
+
+    def spec(self) -> str:
+        return f"{self.sequence}..."
+
+
+class RightmostFrontAdapter(FrontAdapter):
+    """A 5' adapter that prefers rightmost matches (reference :733-789)."""
+
+    description = "rightmost 5'"
+    _reverse_reads = True
+
+    def descriptive_identifier(self) -> str:
+        return "rightmost_five_prime"
+
+    def _aligner(self):
+        return self._make_aligner(self.sequence[::-1],
+                                  Where.ANYWHERE.value if self._force_anywhere else Where.BACK.value)
+
+    def _kmer_finder(self):
+        return self._make_kmer_finder(self.sequence[::-1], back_adapter=True, front_adapter=self._force_anywhere)
+
+    def spec(self) -> str:
+        return f"{self.sequence}...;rightmost"
+
+
+class BackAdapter(SingleAdapter):
+    """A 3' adapter (reference adapters.py:792-838)."""
+
+    description = "regular 3'"
+    _remove_before = False
+
+    def __init__(self, *args, **kwargs):
+        self._force_anywhere = kwargs.pop("force_anywhere", False)
+        super().__init__(*args, **kwargs)
+
+    def descriptive_identifier(self) -> str:
+        return "regular_three_prime"
+
+    def _aligner(self):
+        return self._make_aligner(self.sequence, Where.ANYWHERE.value if self._force_anywhere else Where.BACK.value)
+
+    def _kmer_finder(self):
+        return self._make_kmer_finder(self.sequence, back_adapter=True, front_adapter=self._force_anywhere)
+
+    def spec(self) -> str:
+        return f"{self.sequence}"
+
+
+class RightmostBackAdapter(BackAdapter):
+    """A 3' adapter that prefers rightmost matches (reference :841-893)."""
+
+    description = "rightmost 3'"
+    _reverse_reads = True
+
+    def descriptive_identifier(self) -> str:
+        return "rightmost_three_prime"
+
+    def _aligner(self):
+        return self._make_aligner(self.sequence[::-1],
+                                  Where.ANYWHERE.value if self._force_anywhere else Where.FRONT.value)
+
+    def _kmer_finder(self):
+        return self._make_kmer_finder(self.sequence[::-1], back_adapter=self._force_anywhere, front_adapter=True)
+
+    def spec(self) -> str:
+        return f"{self.sequence};rightmost"
+
+
+class AnywhereAdapter(SingleAdapter):
+    """5' or 3': a match that starts at read position 0 is treated as a 5' adapter
+    (reference adapters.py:896-941)."""
+
+    description = "variable 5'/3'"
+
+    def descriptive_identifier(self) -> str:
+        return "anywhere"
+
+    def _aligner(self):
+        return self._make_aligner(self.sequence, Where.ANYWHERE.value)
+
+    def _kmer_finder(self):
+        return self._make_kmer_finder(self.sequence, back_adapter=True, front_adapter=True)
+
+    def _wrap(self, alignment, sequence: str):
+        # the reference upper-cases the read before locate (:925); every table used by the
+        # kernels is case-insensitive on the read side, so that step is a no-op here
+        cls = RemoveBeforeMatch if alignment[2] == 0 else RemoveAfterMatch   # index 2 is rstart
+        return cls(*alignment, adapter=self, sequence=sequence)
+
+    def _remove_before_array(self, coords, found) -> np.ndarray:
+        return found & (coords[:, 2] == 0)
+
+    def spec(self) -> str:
+        return f"...{self.sequence}..."
+
+
+class NonInternalFrontAdapter(FrontAdapter):
+    """A non-internal 5' adapter (reference adapters.py:944-978)."""
+
+    description = "non-internal 5'"
+
+    def descriptive_identifier(self) -> str:
+        return "noninternal_five_prime"
+
+    def _aligner(self):
+        return self._make_aligner(self.sequence, Where.FRONT_NOT_INTERNAL.value)
+
+    def _kmer_finder(self):
+        return self._make_kmer_finder(self.sequence, front_adapter=True, back_adapter=self._force_anywhere,
+                                      internal=False)
+
+    def spec(self) -> str:
+        return f"X{self.sequence}..."
+
+
+class NonInternalBackAdapter(BackAdapter):
+    """A non-internal 3' adapter (reference adapters.py:981-1015)."""
+
+    description = "non-internal 3'"
+
+    def descriptive_identifier(self) -> str:
+        return "noninternal_three_prime"
+
+    def _aligner(self):
+        return self._make_aligner(self.sequence, Where.BACK_NOT_INTERNAL.value)
+
+    def _kmer_finder(self):
+        return self._make_kmer_finder(self.sequence, back_adapter=True, front_adapter=self._force_anywhere,
+                                      internal=False)
+
+    def spec(self) -> str:
+        return f"{self.sequence}X"
+
+
+class PrefixAdapter(NonInternalFrontAdapter):
+    """An anchored 5' adapter (reference adapters.py:1018-1052)."""
+
+    description = "anchored 5'"
+    allows_partial_matches = False
+
+    def __init__(self, sequence: str, *args, **kwargs):
+        kwargs["min_overlap"] = len(sequence)
+        super().__init__(sequence, *args, **kwargs)
+
+    def descriptive_identifier(self) -> str:
+        return "anchored_five_prime"
+
+    def _aligner(self):
+        if not self.indels:
+            return PrefixComparer(self.sequence, self.max_error_rate, wildcard_ref=self.adapter_wildcards,
+                                  wildcard_query=self.read_wildcards, min_overlap=self.min_overlap)
+        return self._make_aligner(self.sequence, Where.PREFIX.value)
+
+    def _kmer_finder(self):
+        if isinstance(self.aligner, PrefixComparer):
+            return MockKmerFinder()      # no DP to save (reference :1043-1049)
+        return super()._kmer_finder()
+
+    def spec(self) -> str:
+        return f"^{self.sequence}..."
+
+
+class SuffixAdapter(NonInternalBackAdapter):
+    """An anchored 3' adapter (reference adapters.py:1055-1089)."""
+
+    description = "anchored 3'"
+    allows_partial_matches = False
+
+    def __init__(self, sequence: str, *args, **kwargs):
+        kwargs["min_overlap"] = len(sequence)
+        super().__init__(sequence, *args, **kwargs)
+
+    def descriptive_identifier(self) -> str:
+        return "anchored_three_prime"
+
+    def _aligner(self):
+        if not self.indels:
+            return SuffixComparer(self.sequence, self.max_error_rate, wildcard_ref=self.adapter_wildcards,
+                                  wildcard_query=self.read_wildcards, min_overlap=self.min_overlap)
+        return self._make_aligner(self.sequence, Where.SUFFIX.value)
+
+    def _kmer_finder(self):
+        if isinstance(self.aligner, SuffixComparer):
+            return MockKmerFinder()
+        return super()._kmer_finder()
+
+    def spec(self) -> str:
+        return f"{self.sequence}$"
+
+
+# -------------------------------------------------------------------------------------------------
+# linked adapters (reference adapters.py:1092-1243)
+# -------------------------------------------------------------------------------------------------
+class LinkedMatch(Match):
+    def __init__(self, front_match: Optional[RemoveBeforeMatch], back_match: Optional[RemoveAfterMatch],
+                 adapter: "LinkedAdapter"):
+        assert front_match is not None or back_match is not None
+        self.front_match = front_match
+        self.back_match = back_match
+        self.adapter = adapter
+
+    def __repr__(self):
+        return "<LinkedMatch(front_match={!r}, back_match={}, adapter={})>".format(
+            self.front_match, self.back_match, self.adapter)
+
+    @property
+    def score(self):
+        return sum(m.score for m in (self.front_match, self.back_match) if m is not None)
+
+    @property
+    def errors(self):
+        return sum(m.errors for m in (self.front_match, self.back_match) if m is not None)
+
+    def trimmed(self, read):
+        if self.front_match:
+            read = self.front_match.trimmed(read)
+        if self.back_match:
+            read = self.back_match.trimmed(read)
+        return read
+
+    def remainder_interval(self) -> Tuple[int, int]:
+        matches = [m for m in (self.front_match, self.back_match) if m is not None]
+        return remainder(matches)
+
+    def retained_adapter_interval(self) -> Tuple[int, int]:
+        if self.front_match:
+            start, offset = self.front_match.rstart, self.front_match.rstop
+        else:
+            start = offset = 0
+        end = self.back_match.rstop + offset if self.back_match else len(self.front_match.sequence)
+        return start, end
+
+    def match_sequence(self):
+        return ((self.front_match.match_sequence() if self.front_match else "") + ","
+                + (self.back_match.match_sequence() if self.back_match else ""))
+
+
+def remainder(matches: Sequence[Match]) -> Tuple[int, int]:
+    """Interval of the original read that remains after applying the matches in order
+    (reference adapters.py:1588-1602)."""
+    if not matches:
+        raise ValueError("matches must not be empty")
+    start = 0
+    for match in matches:
+        match_start, match_stop = match.remainder_interval()
+        start += match_start
+    length = match_stop - match_start
+    return (start, start + length)
+
+
+class LinkedBatchMatches:
+    """Array-form result of LinkedAdapter.match_to_batch: front and back stage results plus
+    the per-read verdict of the required/optional rule (reference adapters.py:1219-1227).
+    Back coordinates are relative to the read *after* front trimming, like the reference's
+    second match_to call."""
+
+    def __init__(self, front: BatchMatches, back: BatchMatches, found: np.ndarray,
+                 adapter: "LinkedAdapter", reads):
+        self.front = front
+        self.back = back
+        self.found = found
+        self.adapter = adapter
+        self._reads = reads
+        self._strings = None
+
+    def __len__(self):
+        return len(self.found)
+
+    def match(self, i: int) -> Optional[LinkedMatch]:
+        if not self.found[i]:
+            return None
+        if self._strings is None:
+            self._strings = self._reads.to_strings()
+        seq = self._strings[i]
+        fm = bm = None
+        if self.front.found[i]:
+            fm = RemoveBeforeMatch(*(int(v) for v in self.front.coords[i]),
+                                   adapter=self.adapter.front_adapter, sequence=seq)
+            seq = seq[fm.trim_slice()]
+        if self.back.found[i]:
+            bm = RemoveAfterMatch(*(int(v) for v in self.back.coords[i]),
+                                  adapter=self.adapter.back_adapter, sequence=seq)
+        return LinkedMatch(fm, bm, self.adapter)
+
+    def matches(self):
+        return [self.match(i) for i in range(len(self))]
+
+
+class LinkedAdapter(Adapter):
+    """A 5' adapter combined with a 3' adapter (reference adapters.py:1181-1243)."""
+
+    description = "linked"
+
+    def __init__(self, front_adapter: SingleAdapter, back_adapter: SingleAdapter,
+                 front_required: bool, back_required: bool, name: Optional[str]):
+        super().__init__(name)
+        self.front_required = front_required
+        self.back_required = back_required
+        self.where = "linked"
+        self.name: str = _generate_adapter_name() if name is None else name
+        self.front_adapter = front_adapter
+        self.front_adapter.name = self.name
+        self.back_adapter = back_adapter
+
+    def __repr__(self):
+        return f"{self.__class__.__name__}(front_adapter={self.front_adapter}, back_adapter={self.back_adapter})"
+
+    def descriptive_identifier(self) -> str:
+        return "linked"
+
+    def match_to(self, sequence: str) -> Optional[LinkedMatch]:
+        front_match = self.front_adapter.match_to(sequence)
+        if self.front_required and front_match is None:
+            return None
+        if front_match is not None:
+            sequence = sequence[front_match.trim_slice()]
+        back_match = self.back_adapter.match_to(sequence)
+        if back_match is None and (self.back_required or front_match is None):
+            return None
+        return LinkedMatch(front_match, back_match, self)
+
+    def match_to_batch(self, batch) -> LinkedBatchMatches:
+        """Two dependent stages: the back adapter is searched in the suffix after the front
+        match (device-side view, no copy)."""
+        import torch
+        front = self.front_adapter.match_to_batch(batch)
+        lens = batch.lengths()
+        rstop = torch.from_numpy(np.where(front.found, front.coords[:, 3], 0)).to(batch.device)
+        view = batch.view(rstop, lens - rstop)
+        back = self.back_adapter.match_to_batch(view)
+        ok = np.ones(len(front), dtype=bool)
+        if self.front_required:
+            ok &= front.found
+        ok &= back.found | ~(np.full(len(front), self.back_required) | ~front.found)
+        # reads rejected by the front_required rule never had a meaningful back stage
+        back.found = back.found & ok
+        front.found = front.found & ok
+        return LinkedBatchMatches(front, back, ok, self, batch)
+
+    @property
+    def sequence(self):
+        return self.front_adapter.sequence + "..." + self.back_adapter.sequence
+
+    @property
+    def remove(self):
+        return None
+
+    def spec(self) -> str:
+        return f"{self.front_adapter.spec()}...{self.back_adapter.spec()}"
+
+
+# -------------------------------------------------------------------------------------------------
+# several adapters (reference adapters.py:1246-1286)
+# -------------------------------------------------------------------------------------------------
+class MultipleAdapters(Matchable):
+    """Best match over several adapters: higher score wins, then fewer errors, then the
+    adapter that comes first (reference adapters.py:1278-1285)."""
+
+    def __init__(self, adapters: Sequence[Matchable]):
+        super().__init__(name="multiple_adapters")
+        self._adapters = list(adapters)
+        self._fusable = all(isinstance(a, SingleAdapter) and not a._reverse_reads for a in self._adapters)
+        self._plan = None
+
+    def __getitem__(self, item):
+        return self._adapters[item]
+
+    def __len__(self):
+        return len(self._adapters)
+
+    def match_to(self, sequence: str):
+        best_match = None
+        for adapter in self._adapters:
+            match = adapter.match_to(sequence)
+            if match is None:
+                continue
+            if (best_match is None or match.score > best_match.score
+                    or (match.score == best_match.score and match.errors < best_match.errors)):
+                best_match = match
+        return best_match
+
+    def match_to_batch(self, batch) -> BatchMatches:
+        """All adapters in one fused library call (one plan holding every matcher; the kernels
+        keep the best match per read on the device)."""
+        from . import batch as _b
+        if not self._fusable:
+            return self._match_to_batch_unfused(batch)
+        if self._plan is None:
+            self._plan = _lib.Plan([a.matcher_spec() for a in self._adapters])
+        res = _b.match_batch(self._plan, batch)
+        out6, status, best = res.cpu()
+        _raise_if_invalid(status)
+        found = status == _lib.MATCH
+        coords = out6.astype(np.int64)
+        best = np.where(found, best, 0).astype(np.int32)
+        before_by_adapter = np.array([a._remove_before for a in self._adapters], dtype=bool)
+        remove_before = before_by_adapter[best]
+        anywhere = np.array([isinstance(a, AnywhereAdapter) for a in self._adapters], dtype=bool)
+        remove_before = np.where(anywhere[best], found & (coords[:, 2] == 0), remove_before)
+        return BatchMatches(coords, found, best, self._adapters, remove_before, reads=batch)
+
+    def _match_to_batch_unfused(self, batch) -> BatchMatches:
+        n = batch.n_reads
+        coords = np.zeros((n, 6), dtype=np.int64)
+        found = np.zeros(n, dtype=bool)
+        best = np.zeros(n, dtype=np.int32)
+        remove_before = np.zeros(n, dtype=bool)
+        for idx, adapter in enumerate(self._adapters):
+            r = adapter.match_to_batch(batch)
+            better = r.found & (~found | (r.coords[:, 4] > coords[:, 4])
+                                | ((r.coords[:, 4] == coords[:, 4]) & (r.coords[:, 5] < coords[:, 5])))
+            coords[better] = r.coords[better]
+            best[better] = idx
+            remove_before[better] = r.remove_before[better]
+            found |= better
+        return BatchMatches(coords, found, best, self._adapters, remove_before, reads=batch)

@@ -1,0 +1,147 @@
+"""Aligner / PrefixComparer / SuffixComparer with the reference's Python API, backed by the
+HIP kernels (no CPU fallback).
+
+Mirrors reference src/cutadapt/_align.pyx (Aligner :93-591, PrefixComparer :594-693,
+SuffixComparer :696-714; type stubs _align.pyi:10-27) and src/cutadapt/align.py:24-34
+(EndSkip).  ``locate(str)`` keeps the per-read signature by sending a batch of one through
+the same kernel; ``locate_batch(ReadBatch)`` is the form the pipeline should use.
+"""
+import ctypes as C
+from enum import IntFlag
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+
+__all__ = ["EndSkip", "Aligner", "PrefixComparer", "SuffixComparer"]
+
+AlignmentTuple = Tuple[int, int, int, int, int, int]
+
+
+class EndSkip(IntFlag):
+    """Which ends may be skipped at no cost (reference align.py:24-34)."""
+
+    REFERENCE_START = 1
+    QUERY_START = 2
+    REFERENCE_END = 4
+    QUERY_STOP = 8
+    SEMIGLOBAL = 15
+
+
+def _locate_one(plan: _lib.Plan, query: str) -> Optional[AlignmentTuple]:
+    q = _lib._ascii(query)
+    seqs = np.frombuffer(q, dtype=np.uint8)
+    offsets = np.array([0, len(q)], dtype=np.int64)
+    out6 = np.zeros(6, dtype=np.int32)
+    status = np.zeros(1, dtype=np.uint8)
+    _lib.check(_lib.lib().cah_locate_batch_host(
+        plan.handle, 0, seqs.ctypes.data if len(q) else None, offsets.ctypes.data, 1,
+        out6.ctypes.data, status.ctypes.data))
+    if status[0] == _lib.INVALID:
+        raise ValueError("String must contain only ASCII characters")
+    if status[0] != _lib.MATCH:
+        return None
+    return tuple(int(v) for v in out6)  # type: ignore[return-value]
+
+
+class Aligner:
+    """Find a full or partial occurrence of ``reference`` (the adapter) in a query (the read)
+    allowing mismatches and indels; see reference _align.pyx:94-169 for the semantics.
+
+    Result of ``locate``: (ref_start, ref_stop, query_start, query_stop, score, errors) or None.
+    """
+
+    def __init__(self, reference: str, max_error_rate: float, flags: int = 15,
+                 wildcard_ref: bool = False, wildcard_query: bool = False,
+                 indel_cost: int = 1, min_overlap: int = 1):
+        self.reference = reference
+        self.max_error_rate = float(max_error_rate)
+        self._flags = int(flags) & 15
+        self.wildcard_ref = bool(wildcard_ref)
+        self.wildcard_query = bool(wildcard_query)
+        self._indel_cost = int(indel_cost)
+        self._min_overlap = int(min_overlap)
+        self._plan = _lib.Plan([self.spec()])
+        self.effective_length = self._plan.effective_length(0)
+
+    def spec(self, kmer_sets=None, kmer_ref_wildcards=False, kmer_query_wildcards=False) -> _lib.MatcherSpec:
+        return _lib.MatcherSpec(self.reference, self.max_error_rate, self._flags, self.wildcard_ref,
+                                self.wildcard_query, self._indel_cost, self._min_overlap,
+                                _lib.KIND_ALIGNER, kmer_sets, kmer_ref_wildcards, kmer_query_wildcards)
+
+    def __reduce__(self):
+        # pipelines are pickled into worker processes (reference _align.pyx:239-240)
+        return (Aligner, (self.reference, self.max_error_rate, self._flags, self.wildcard_ref,
+                          self.wildcard_query, self._indel_cost, self._min_overlap))
+
+    def __repr__(self):
+        return (f"Aligner(reference='{self.reference}', max_error_rate={self.max_error_rate}, "
+                f"flags={self._flags}, wildcard_ref={self.wildcard_ref}, "
+                f"wildcard_query={self.wildcard_query}, indel_cost={self._indel_cost}, "
+                f"min_overlap={self._min_overlap})")
+
+    def locate(self, query: str) -> Optional[AlignmentTuple]:
+        return _locate_one(self._plan, query)
+
+    def locate_batch(self, batch):
+        from . import batch as _b
+        return _b.locate_batch(self._plan, 0, batch)
+
+    def enable_debug(self):
+        raise NotImplementedError(
+            "the HIP aligner keeps the DP column in registers and never materialises the DP "
+            "matrix; dpmatrix/scorematrix debugging is not available on this path")
+
+    @property
+    def dpmatrix(self):
+        return None
+
+    @property
+    def scorematrix(self):
+        return None
+
+
+class PrefixComparer:
+    """Hamming-distance comparison of an anchored 5' adapter with the start of the read
+    (reference _align.pyx:594-693)."""
+
+    _kind = _lib.KIND_PREFIX
+
+    def __init__(self, reference: str, max_error_rate: float, wildcard_ref: bool = False,
+                 wildcard_query: bool = False, min_overlap: int = 1):
+        self._reference = reference
+        self.max_error_rate = float(max_error_rate)
+        self.wildcard_ref = bool(wildcard_ref)
+        self.wildcard_query = bool(wildcard_query)
+        self.min_overlap = int(min_overlap)
+        self._plan = _lib.Plan([self.spec()])
+        self.effective_length = self._plan.effective_length(0)
+        self.max_k = int(self.max_error_rate * self.effective_length)
+
+    def spec(self, kmer_sets=None, kmer_ref_wildcards=False, kmer_query_wildcards=False) -> _lib.MatcherSpec:
+        return _lib.MatcherSpec(self._reference, self.max_error_rate, 0, self.wildcard_ref,
+                                self.wildcard_query, 1, self.min_overlap, self._kind, kmer_sets,
+                                kmer_ref_wildcards, kmer_query_wildcards)
+
+    def __reduce__(self):
+        return (type(self), (self._reference, self.max_error_rate, self.wildcard_ref,
+                             self.wildcard_query, self.min_overlap))
+
+    def __repr__(self):
+        return "{}(reference={!r}, max_k={}, wildcard_ref={}, wildcard_query={})".format(
+            self.__class__.__name__, self._reference, self.max_k, self.wildcard_ref,
+            self.wildcard_query)
+
+    def locate(self, query: str) -> Optional[AlignmentTuple]:
+        return _locate_one(self._plan, query)
+
+    def locate_batch(self, batch):
+        from . import batch as _b
+        return _b.locate_batch(self._plan, 0, batch)
+
+
+class SuffixComparer(PrefixComparer):
+    """Anchored 3' variant (reference _align.pyx:696-714)."""
+
+    _kind = _lib.KIND_SUFFIX

@@ -1,0 +1,237 @@
+"""Packed read batches resident in HBM, and batch results.
+
+The reference hands reads to the matcher one Python ``str`` at a time
+(reference src/cutadapt/pipeline.py:60-69 -> modifiers.py:200-261 -> adapters.py:815-832).
+The GPU path works on *batches*: all sequences of a chunk back to back in one uint8 buffer
+plus an int64 offsets array (the same shape a 4 MiB FASTQ chunk of
+reference runners.py:116-126 has once its sequence lines are concatenated).
+
+PyTorch is used only as the owner of device memory and streams; the kernels are reached
+through the C ABI with raw pointers.
+"""
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _stream_ptr() -> int:
+    return int(_torch().cuda.current_stream().cuda_stream)
+
+
+def pack_strings(reads: Sequence[str]) -> Tuple[np.ndarray, np.ndarray]:
+    """list[str] -> (uint8[total], int64[n+1]).  Non-ASCII characters raise ValueError like
+    the reference's translate() (reference _align.pyx:44-45)."""
+    encoded = []
+    for r in reads:
+        if not isinstance(r, str):
+            raise TypeError(f"sequence must be str, not {type(r).__name__}")
+        try:
+            encoded.append(r.encode("ascii"))
+        except UnicodeEncodeError:
+            raise ValueError("String must contain only ASCII characters")
+    offsets = np.zeros(len(encoded) + 1, dtype=np.int64)
+    if encoded:
+        np.cumsum([len(e) for e in encoded], out=offsets[1:])
+    seqs = np.frombuffer(b"".join(encoded), dtype=np.uint8)
+    return seqs, offsets
+
+
+class ReadBatch:
+    """n reads packed in HBM: ``seqs`` uint8[total], ``offsets`` int64[n+1] (or int64[n] plus
+    ``lens`` int32[n] for sub-sequence views)."""
+
+    def __init__(self, seqs, offsets, lens=None, n_reads: Optional[int] = None, validated: bool = False):
+        torch = _torch()
+        if not (seqs.is_cuda and offsets.is_cuda):
+            raise ValueError("ReadBatch needs CUDA/HIP tensors; use from_strings()/from_host()")
+        if seqs.dtype != torch.uint8 or offsets.dtype != torch.int64:
+            raise TypeError("seqs must be uint8 and offsets int64")
+        if lens is not None and lens.dtype != torch.int32:
+            raise TypeError("lens must be int32")
+        self.seqs = seqs.contiguous()
+        self.offsets = offsets.contiguous()
+        self.lens = None if lens is None else lens.contiguous()
+        if n_reads is None:
+            n_reads = int(lens.numel()) if lens is not None else int(offsets.numel()) - 1
+        self.n_reads = int(n_reads)
+        self.validated = validated
+        self._workspace = None
+
+    # ---- constructors ---------------------------------------------------------------------
+    @classmethod
+    def from_host(cls, seqs: np.ndarray, offsets: np.ndarray, device=None, validated: bool = False):
+        torch = _torch()
+        device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        s = torch.from_numpy(np.ascontiguousarray(seqs, dtype=np.uint8).copy()).to(device)
+        o = torch.from_numpy(np.ascontiguousarray(offsets, dtype=np.int64).copy()).to(device)
+        return cls(s, o, validated=validated)
+
+    @classmethod
+    def from_strings(cls, reads: Sequence[str], device=None):
+        seqs, offsets = pack_strings(reads)      # str.encode already rejected non-ASCII
+        return cls.from_host(seqs, offsets, device=device, validated=True)
+
+    @classmethod
+    def synthetic(cls, n_reads: int, read_len: int, adapters: Sequence[str], seed: int = 2,
+                  first_index: int = 0, p_adapter: float = 0.25, p_edit: float = 0.02,
+                  p_n: float = 0.005, device=None):
+        """Generate the synthetic workload of SURVEY.md section 8(d) directly in HBM."""
+        torch = _torch()
+        device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        seqs = torch.empty(n_reads * read_len, dtype=torch.uint8, device=device)
+        offsets = torch.empty(n_reads + 1, dtype=torch.int64, device=device)
+        ads = [a.encode("ascii") for a in adapters]
+        off = (C.c_int32 * (len(ads) + 1))()
+        for i, a in enumerate(ads):
+            off[i + 1] = off[i] + len(a)
+        with torch.cuda.device(device):
+            _lib.check(_lib.lib().cah_synth_reads(
+                seed, first_index, n_reads, read_len, prob_u32(p_adapter), prob_u32(p_edit),
+                prob_u16(p_n), b"".join(ads), off, len(ads), seqs.data_ptr(), offsets.data_ptr(),
+                _stream_ptr()))
+        return cls(seqs, offsets, validated=True)
+
+    # ---- helpers ----------------------------------------------------------------------------
+    def __len__(self):
+        return self.n_reads
+
+    @property
+    def device(self):
+        return self.seqs.device
+
+    def _lens_ptr(self):
+        return self.lens.data_ptr() if self.lens is not None else None
+
+    def workspace(self):
+        """Per-batch device scratch for the work queue / counters (never shared between
+        batches, so batches on different streams do not interfere)."""
+        torch = _torch()
+        need = int(_lib.lib().cah_workspace_bytes(self.n_reads))
+        if self._workspace is None or self._workspace.numel() < need:
+            self._workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._workspace
+
+    def validate_ascii(self) -> None:
+        """Raise ValueError if any read holds a byte >= 0x80 (the reference rejects such
+        strings before matching, reference _align.pyx:44-45, _kmer_finder.pyx:182-183)."""
+        if self.validated or self.n_reads == 0:
+            self.validated = True
+            return
+        torch = _torch()
+        bad = torch.zeros(1, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().cah_validate_ascii_batch(
+                self.seqs.data_ptr(), self.offsets.data_ptr(), self._lens_ptr(), self.n_reads,
+                bad.data_ptr(), _stream_ptr()))
+        if int(bad.item()) != 0:
+            raise ValueError("String must contain only ASCII characters")
+        self.validated = True
+
+    def view(self, starts, lens) -> "ReadBatch":
+        """Sub-sequence view: read r becomes seqs[offsets[r]+starts[r] : ... + lens[r]).
+        Used for the second stage of linked adapters (reference adapters.py:1222-1224)."""
+        torch = _torch()
+        base = self.offsets[: self.n_reads]
+        return ReadBatch(self.seqs, base + starts.to(torch.int64), lens.to(torch.int32),
+                         n_reads=self.n_reads, validated=self.validated)
+
+    def lengths(self):
+        torch = _torch()
+        if self.lens is not None:
+            return self.lens.to(torch.int64)
+        return self.offsets[1:] - self.offsets[:-1]
+
+    def to_strings(self) -> List[str]:
+        seqs = self.seqs.cpu().numpy().tobytes()
+        offs = self.offsets.cpu().numpy()
+        if self.lens is not None:
+            ls = self.lens.cpu().numpy()
+            return [seqs[int(o):int(o) + int(l)].decode("latin-1") for o, l in zip(offs, ls)]
+        return [seqs[int(offs[i]):int(offs[i + 1])].decode("latin-1") for i in range(self.n_reads)]
+
+
+class BatchResult:
+    """Per-read results of a batch call: ``out6`` int32[n,6] =
+    (ref_start, ref_stop, query_start, query_stop, score, errors) -- the tuple
+    Aligner.locate returns (reference _align.pyx:587) -- ``status`` uint8[n]
+    (0 None, 1 match, 2 invalid input) and optionally ``best_adapter`` int32[n]."""
+
+    def __init__(self, out6, status, best_adapter=None):
+        self.out6 = out6
+        self.status = status
+        self.best_adapter = best_adapter
+
+    def cpu(self):
+        out6 = self.out6.cpu().numpy()
+        status = self.status.cpu().numpy()
+        best = None if self.best_adapter is None else self.best_adapter.cpu().numpy()
+        return out6, status, best
+
+    def tuples(self) -> List[Optional[Tuple[int, int, int, int, int, int]]]:
+        out6, status, _ = self.cpu()
+        if (status == _lib.INVALID).any():
+            raise ValueError("String must contain only ASCII characters")
+        return [tuple(int(v) for v in out6[i]) if status[i] == _lib.MATCH else None
+                for i in range(len(status))]
+
+
+def prob_u32(p: float) -> int:
+    return min(int(round(p * 4294967296.0)), 4294967295)
+
+
+def prob_u16(p: float) -> int:
+    return min(int(round(p * 65536.0)), 65535)
+
+
+# ---- thin launch helpers (device pointers) ------------------------------------------------------
+def locate_batch(plan: "_lib.Plan", adapter: int, batch: ReadBatch) -> BatchResult:
+    torch = _torch()
+    n = batch.n_reads
+    out6 = torch.empty((n, 6), dtype=torch.int32, device=batch.device)
+    status = torch.empty(n, dtype=torch.uint8, device=batch.device)
+    if n:
+        ws = batch.workspace()
+        with torch.cuda.device(batch.device):
+            _lib.check(_lib.lib().cah_locate_batch(
+                plan.handle, adapter, batch.seqs.data_ptr(), batch.offsets.data_ptr(),
+                batch._lens_ptr(), n, out6.data_ptr(), status.data_ptr(), ws.data_ptr(),
+                ws.numel(), _stream_ptr()))
+    return BatchResult(out6, status)
+
+
+def kmers_present_batch(plan: "_lib.Plan", adapter: int, batch: ReadBatch):
+    torch = _torch()
+    n = batch.n_reads
+    present = torch.empty(n, dtype=torch.uint8, device=batch.device)
+    if n:
+        with torch.cuda.device(batch.device):
+            _lib.check(_lib.lib().cah_kmers_present_batch(
+                plan.handle, adapter, batch.seqs.data_ptr(), batch.offsets.data_ptr(),
+                batch._lens_ptr(), n, present.data_ptr(), _stream_ptr()))
+    return present
+
+
+def match_batch(plan: "_lib.Plan", batch: ReadBatch, out: Optional[BatchResult] = None) -> BatchResult:
+    """Fused prefilter -> compaction -> DP -> best-adapter for every matcher of ``plan``."""
+    torch = _torch()
+    n = batch.n_reads
+    if out is None:
+        out = BatchResult(torch.empty((n, 6), dtype=torch.int32, device=batch.device),
+                          torch.empty(n, dtype=torch.uint8, device=batch.device),
+                          torch.empty(n, dtype=torch.int32, device=batch.device))
+    if n:
+        ws = batch.workspace()
+        with torch.cuda.device(batch.device):
+            _lib.check(_lib.lib().cah_match_batch(
+                plan.handle, batch.seqs.data_ptr(), batch.offsets.data_ptr(), batch._lens_ptr(), n,
+                out.out6.data_ptr(), out.best_adapter.data_ptr() if out.best_adapter is not None else None,
+                out.status.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr()))
+    return out

@@ -1,0 +1,63 @@
+"""Build libcutadapt_hip.so (HIP kernels + C ABI) for gfx950, in-tree.
+
+    python -m cutadapt_amd.build [--force]
+
+hipcc cross-compiles without a GPU; the resulting .so sits next to this file so that it
+travels with the gpurun snapshot and is what the Python layer loads (never a JIT cache).
+"""
+import os
+import subprocess
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(_HERE, "libcutadapt_hip.so")
+SOURCES = ["api.cpp", "kernels.hip", "synth_kernel.hip"]
+HEADERS = ["cah_device.h", "kernels.h", os.path.join("..", "..", "include", "cutadapt_hip.h")]
+ARCH = "gfx950"
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    return "hipcc"
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    if not force and not needs_build():
+        return LIB_PATH
+    objs = []
+    obj_dir = os.path.join(_HERE, "csrc", "_obj")
+    os.makedirs(obj_dir, exist_ok=True)
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(obj_dir, src + ".o")
+        objs.append(obj)
+        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-x", "hip",
+               "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{out.decode(errors='replace')}")
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    path = build_library(force="--force" in sys.argv, verbose=True)
+    print("built", path)

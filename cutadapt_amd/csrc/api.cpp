@@ -1,0 +1,727 @@
+// api.cpp -- host side of libcutadapt_hip.so: plan construction (character tables, k-mer
+// packing) and the C-ABI entry points declared in include/cutadapt_hip.h.
+//
+// Plan construction restates, in table form, what the reference does at object creation:
+//   Aligner.__cinit__/_set_reference      reference src/cutadapt/_align.pyx:195-277
+//   PrefixComparer.__init__               reference src/cutadapt/_align.pyx:615-642
+//   KmerFinder.__cinit__                  reference src/cutadapt/_kmer_finder.pyx:106-165
+//   character tables / match lists        reference src/cutadapt/_match_tables.py:4-98
+// The per-read work (translate() + compare per DP cell) is folded into one 64-bit "row
+// bitset" per read character, so the kernels never compare characters.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/cutadapt_hip.h"
+#include "cah_device.h"
+#include "kernels.h"
+
+// ---------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+static int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                    \
+    do {                                                                                 \
+        hipError_t e__ = (expr);                                                         \
+        if (e__ != hipSuccess)                                                           \
+            return fail(CAH_EHIP, "%s failed: %s", #expr, hipGetErrorString(e__));       \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// character tables (_match_tables.py)
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct CharTables {
+    uint8_t acgt[256], iupac[256], upper[256];
+    CharTables() {
+        // A=1 C=2 G=4 T=U=8, everything else 0x80 (_match_tables.py:4-17)
+        memset(acgt, 0x80, sizeof(acgt));
+        const char* bases = "ACGTU";
+        const uint8_t codes[5] = {1, 2, 4, 8, 8};
+        for (int i = 0; i < 5; i++) both(acgt, bases[i], codes[i]);
+        // IUPAC nibble sets; N additionally has 0x80 so that it matches non-ACGT characters
+        // encoded with the ACGT table; X and unknown characters are 0 (:20-61)
+        memset(iupac, 0, sizeof(iupac));
+        struct { char c; uint8_t v; } codes_iupac[] = {
+            {'X', 0}, {'A', 1}, {'C', 2}, {'G', 4}, {'T', 8}, {'U', 8}, {'R', 1 | 4}, {'Y', 2 | 8},
+            {'S', 4 | 2}, {'W', 1 | 8}, {'K', 4 | 8}, {'M', 1 | 2}, {'B', 2 | 4 | 8},
+            {'D', 1 | 4 | 8}, {'H', 1 | 2 | 8}, {'V', 1 | 2 | 4}, {'N', 0x8F}};
+        for (auto& e : codes_iupac) both(iupac, e.c, e.v);
+        for (int i = 0; i < 256; i++) upper[i] = (uint8_t)((i >= 'a' && i <= 'z') ? i - 32 : i);
+    }
+    static void both(uint8_t* t, char c, uint8_t v) {
+        t[(uint8_t)c] = v;
+        t[(uint8_t)(c + 32)] = v;   // lower case
+    }
+};
+
+const CharTables& tables() {
+    static CharTables t;
+    return t;
+}
+
+bool is_ascii(const char* s, size_t n) {
+    for (size_t i = 0; i < n; i++)
+        if ((uint8_t)s[i] & 0x80) return false;
+    return true;
+}
+
+// Does read character `qc` match adapter character `rc` inside Aligner.locate?
+// reference encoding (_align.pyx:272-276) x query encoding (:322-328) x compare (:442-445).
+// NB: without wildcards the adapter is compared as given (NOT upper-cased), the read is.
+bool aligner_chars_match(uint8_t rc, uint8_t qc, bool wildcard_ref, bool wildcard_query) {
+    const CharTables& t = tables();
+    if (wildcard_query) {
+        const uint8_t r = wildcard_ref ? t.iupac[rc] : t.acgt[rc];
+        return (r & t.iupac[qc]) != 0;
+    }
+    if (wildcard_ref) return (t.iupac[rc] & t.acgt[qc]) != 0;
+    return rc == t.upper[qc];
+}
+
+// PrefixComparer encodes its reference with the upper table when no wildcards are used
+// (_align.pyx:637-642), unlike Aligner.
+bool comparer_chars_match(uint8_t rc, uint8_t qc, bool wildcard_ref, bool wildcard_query) {
+    const CharTables& t = tables();
+    if (wildcard_query) {
+        const uint8_t r = wildcard_ref ? t.iupac[rc] : t.acgt[rc];
+        return (r & t.iupac[qc]) != 0;
+    }
+    if (wildcard_ref) return (t.iupac[rc] & t.acgt[qc]) != 0;
+    return t.upper[rc] == t.upper[qc];
+}
+
+// KmerFinder's match lists (_match_tables.py:81-98; NUL never matches, :73-78)
+bool kmer_chars_match(uint8_t rc, uint8_t qc, bool ref_wc, bool query_wc) {
+    const CharTables& t = tables();
+    if (qc == 0 || qc >= 128) return false;
+    if (!ref_wc && !query_wc) return t.upper[rc] == t.upper[qc];
+    if (ref_wc && !query_wc) return (t.iupac[rc] & t.acgt[qc]) != 0;
+    if (!ref_wc && query_wc) return (t.acgt[rc] & t.iupac[qc]) != 0;
+    return (t.iupac[rc] & t.iupac[qc]) != 0;
+}
+
+int clamp_floor(double x) {
+    if (!(x == x)) return -1;            // NaN: `cost <= NaN` is false in the reference
+    double f = std::floor(x);
+    if (f > 2147483000.0) return 2147483000;
+    if (f < -2147483000.0) return -2147483000;
+    return (int)f;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// plan
+// ---------------------------------------------------------------------------------------------
+#define CAH_MAX_DEVICES 64
+
+struct PlanDeviceCopy {
+    bool ready = false;
+    int n_cus = 256;
+    CahMatcher* d_matchers = nullptr;     // HBM
+    CahKmerWord* d_words = nullptr;
+};
+
+// Host tables are built (and validated) at creation; the HBM copy for a device is made the
+// first time the plan is used on that device, so one plan serves every GPU of the node.
+struct cah_plan {
+    std::vector<CahMatcher> matchers;     // host copies
+    std::vector<CahKmerWord> words;
+    mutable std::mutex mu;
+    mutable PlanDeviceCopy dev[CAH_MAX_DEVICES];
+};
+
+// returns the copy of the plan's tables on the current device (uploading on first use)
+static int plan_on_device(const cah_plan* plan, const PlanDeviceCopy** out) {
+    int device = 0;
+    HIP_TRY(hipGetDevice(&device));
+    if (device < 0 || device >= CAH_MAX_DEVICES) return fail(CAH_EUNSUPPORTED, "device index %d too large", device);
+    std::lock_guard<std::mutex> lk(plan->mu);
+    PlanDeviceCopy& dc = plan->dev[device];
+    if (!dc.ready) {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device));
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+            return fail(CAH_EUNSUPPORTED, "device %d is %s; this library is built for gfx950 (MI355X) only",
+                        device, prop.gcnArchName);
+        dc.n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        HIP_TRY(hipMalloc((void**)&dc.d_matchers, sizeof(CahMatcher) * plan->matchers.size()));
+        HIP_TRY(hipMemcpy(dc.d_matchers, plan->matchers.data(), sizeof(CahMatcher) * plan->matchers.size(),
+                          hipMemcpyHostToDevice));
+        if (!plan->words.empty()) {
+            HIP_TRY(hipMalloc((void**)&dc.d_words, sizeof(CahKmerWord) * plan->words.size()));
+            HIP_TRY(hipMemcpy(dc.d_words, plan->words.data(), sizeof(CahKmerWord) * plan->words.size(),
+                              hipMemcpyHostToDevice));
+        }
+        dc.ready = true;
+    }
+    *out = &dc;
+    return CAH_OK;
+}
+
+static int build_matcher(const cah_adapter_desc& d, int index, CahMatcher& mt,
+                         std::vector<CahKmerWord>& words) {
+    memset(&mt, 0, sizeof(mt));
+    if (d.kind < CAH_KIND_ALIGNER || d.kind > CAH_KIND_KMER_ONLY)
+        return fail(CAH_EINVAL, "adapter %d: unknown kind %d", index, d.kind);
+    const int m = d.length;
+    const bool has_aligner = d.kind != CAH_KIND_KMER_ONLY;
+    mt.kind = d.kind;
+    if (has_aligner) {
+        if (m < 0 || (m > 0 && !d.sequence))
+            return fail(CAH_EINVAL, "adapter %d: bad sequence", index);
+        if (m > CAH_MAX_ADAPTER_LEN)
+            return fail(CAH_EUNSUPPORTED, "adapter %d: length %d exceeds the %d-character limit of this build",
+                        index, m, CAH_MAX_ADAPTER_LEN);
+        if (!is_ascii(d.sequence, (size_t)m))
+            return fail(CAH_EINVAL, "String must contain only ASCII characters");
+        const bool wr = d.wildcard_ref != 0, wq = d.wildcard_query != 0;
+        const double rate = d.max_error_rate;
+        mt.m = m;
+        mt.flags = d.flags & 15;
+        mt.min_overlap = d.min_overlap;
+        mt.wildcard_ref = wr;
+        mt.indel_cost = d.indel_cost;
+        const char* seq = d.sequence;
+        if (d.kind == CAH_KIND_ALIGNER) {
+            // _align.pyx:250-277
+            int nn = 0;
+            for (int i = 0; i < m; i++) {
+                mt.n_counts[i] = nn;
+                if (seq[i] == 'N' || seq[i] == 'n') nn++;
+            }
+            mt.n_counts[m] = nn;
+            for (int i = m + 1; i <= CAH_MAX_M; i++) mt.n_counts[i] = nn;
+            mt.effective_length = m;
+            if (wr) {
+                mt.effective_length = m - nn;
+                if (mt.effective_length == 0)
+                    return fail(CAH_EINVAL, "Cannot have only N wildcards in the sequence");
+            }
+            if (d.indel_cost < 1) return fail(CAH_EINVAL, "indel_cost must be at least 1");
+            if (d.indel_cost > CAH_MAX_INDEL_COST)
+                return fail(CAH_EUNSUPPORTED, "indel_cost above %d is not supported", CAH_MAX_INDEL_COST);
+            if (!(rate == rate) || std::fabs(rate) > 1e6)
+                return fail(CAH_EINVAL, "max_error_rate is not a usable number");
+            mt.k = (int)(rate * m);                                     // :343
+            for (int L = 0; L <= CAH_MAX_M; L++) mt.thr[L] = clamp_floor(L * rate);   // :513, :559
+            for (int ch = 0; ch < CAH_TABLE_CHARS; ch++) {
+                uint64_t bits = 0;
+                for (int i = 0; i < m; i++)
+                    if (aligner_chars_match((uint8_t)seq[i], (uint8_t)ch, wr, wq)) bits |= 1ull << i;
+                mt.rowmask[ch] = bits;
+            }
+        } else {
+            // PrefixComparer / SuffixComparer (_align.pyx:615-642, :698-706)
+            int eff = m;
+            if (wr) {
+                int nN = 0, nn = 0;
+                for (int i = 0; i < m; i++) { nN += seq[i] == 'N'; nn += seq[i] == 'n'; }
+                eff -= nN - nn;                                         // quirk kept (:628)
+                if (eff == 0) return fail(CAH_EINVAL, "Cannot have only N wildcards in the sequence");
+            }
+            if (!(rate >= 0.0 && rate <= 1.0))
+                return fail(CAH_EINVAL, "max_error_rate must be between 0 and 1");
+            if (d.min_overlap < 1) return fail(CAH_EINVAL, "min_overlap must be at least 1");
+            mt.effective_length = eff;
+            mt.cmp_max_k = (int)(rate * eff);                           // :633
+            const bool suffix = d.kind == CAH_KIND_SUFFIX;
+            for (int ch = 0; ch < CAH_TABLE_CHARS; ch++) {
+                uint64_t bits = 0;
+                for (int i = 0; i < m; i++) {
+                    // the suffix variant compares reversed reference against reversed query
+                    const uint8_t rc = (uint8_t)seq[suffix ? m - 1 - i : i];
+                    if (comparer_chars_match(rc, (uint8_t)ch, wr, wq)) bits |= 1ull << i;
+                }
+                mt.rowmask[ch] = bits;
+            }
+        }
+    }
+
+    // ---- prefilter: pack k-mers into 64-bit shift-and words (_kmer_finder.pyx:121-164) -------
+    mt.first_word = (int32_t)words.size();
+    mt.has_filter = d.n_kmer_sets >= 0 ? 1 : 0;
+    if (d.n_kmer_sets > 0 && !d.kmer_sets) return fail(CAH_EINVAL, "adapter %d: kmer_sets is NULL", index);
+    const bool rwc = d.kmer_ref_wildcards != 0, qwc = d.kmer_query_wildcards != 0;
+    for (int s = 0; s < d.n_kmer_sets; s++) {
+        const cah_kmer_set& ks = d.kmer_sets[s];
+        int idx = 0;
+        while (idx < ks.n_kmers) {
+            uint8_t word[64];
+            memset(word, 0, sizeof(word));
+            size_t off = 0;
+            CahKmerWord kw;
+            memset(&kw, 0, sizeof(kw));
+            while (idx < ks.n_kmers) {
+                const char* kmer = ks.kmers[idx];
+                if (!kmer) return fail(CAH_ETYPE, "Kmer should be a string");
+                const size_t len = strlen(kmer);
+                if (!is_ascii(kmer, len)) return fail(CAH_EINVAL, "Only ASCII strings are supported");
+                if (len > 64)
+                    return fail(CAH_EINVAL, "%s of length %zu is longer than the maximum of 64.", kmer, len);
+                if (off + len > 64) break;
+                kw.init_mask |= 1ull << off;
+                memcpy(word + off, kmer, len);
+                kw.found_mask |= 1ull << (off + len - 1);
+                off += len;
+                idx++;
+            }
+            kw.start = ks.start;
+            kw.stop = ks.stop;
+            for (size_t p = 0; p < off; p++) {
+                if (word[p] == 0) continue;
+                for (int qc = 0; qc < CAH_TABLE_CHARS; qc++)
+                    if (kmer_chars_match(word[p], (uint8_t)qc, rwc, qwc)) kw.mask[qc] |= 1ull << p;
+            }
+            words.push_back(kw);
+        }
+    }
+    mt.n_words = (int32_t)words.size() - mt.first_word;
+    return CAH_OK;
+}
+
+extern "C" {
+
+int cah_abi_version(void) { return CAH_ABI_VERSION; }
+
+void cah_last_error(char* buf, size_t buflen) {
+    if (!buf || !buflen) return;
+    snprintf(buf, buflen, "%s", g_last_error.c_str());
+}
+
+int cah_device_count(int* count) {
+    if (!count) return fail(CAH_EINVAL, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return fail(CAH_EHIP, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *count = n;
+    return CAH_OK;
+}
+
+int cah_set_device(int device) {
+    HIP_TRY(hipSetDevice(device));
+    return CAH_OK;
+}
+
+int cah_device_info(int device, char* name, size_t name_len, char* arch, size_t arch_len,
+                    int* compute_units, int64_t* hbm_bytes) {
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (name && name_len) snprintf(name, name_len, "%s", prop.name);
+    if (arch && arch_len) snprintf(arch, arch_len, "%s", prop.gcnArchName);
+    if (compute_units) *compute_units = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+    return CAH_OK;
+}
+
+int cah_plan_create(const cah_adapter_desc* adapters, int32_t n_adapters, cah_plan** out) {
+    if (!out) return fail(CAH_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (n_adapters < 1 || !adapters) return fail(CAH_EINVAL, "need at least one adapter");
+    cah_plan* plan = new cah_plan();
+    plan->matchers.resize((size_t)n_adapters);
+    for (int i = 0; i < n_adapters; i++) {
+        int rc = build_matcher(adapters[i], i, plan->matchers[(size_t)i], plan->words);
+        if (rc != CAH_OK) { delete plan; return rc; }
+    }
+    *out = plan;
+    return CAH_OK;
+}
+
+void cah_plan_destroy(cah_plan* plan) {
+    if (!plan) return;
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    for (int d = 0; d < CAH_MAX_DEVICES; d++) {
+        PlanDeviceCopy& dc = plan->dev[d];
+        if (!dc.ready) continue;
+        (void)hipSetDevice(d);
+        if (dc.d_matchers) (void)hipFree(dc.d_matchers);
+        if (dc.d_words) (void)hipFree(dc.d_words);
+    }
+    if (cur >= 0) (void)hipSetDevice(cur);
+    delete plan;
+}
+
+int cah_plan_n_adapters(const cah_plan* plan) { return plan ? (int)plan->matchers.size() : 0; }
+
+static int check_adapter(const cah_plan* plan, int32_t adapter) {
+    if (!plan) return fail(CAH_EINVAL, "plan is NULL");
+    if (adapter < 0 || (size_t)adapter >= plan->matchers.size())
+        return fail(CAH_EINVAL, "adapter index %d out of range", adapter);
+    return CAH_OK;
+}
+
+int cah_plan_effective_length(const cah_plan* plan, int32_t adapter, int32_t* out) {
+    int rc = check_adapter(plan, adapter);
+    if (rc) return rc;
+    *out = plan->matchers[(size_t)adapter].effective_length;
+    return CAH_OK;
+}
+
+int cah_plan_n_kmer_entries(const cah_plan* plan, int32_t adapter, int32_t* out) {
+    int rc = check_adapter(plan, adapter);
+    if (rc) return rc;
+    *out = plan->matchers[(size_t)adapter].n_words;
+    return CAH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// profiling (HIP events on the launch stream)
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct ProfRec { hipEvent_t a, b; int family; int64_t units; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+std::mutex g_prof_mu;
+
+struct ProfScope {
+    hipStream_t s; int family; int64_t units; hipEvent_t a = nullptr, b = nullptr; bool on;
+    ProfScope(hipStream_t s_, int family_, int64_t units_) : s(s_), family(family_), units(units_), on(g_prof_on) {
+        if (on) {
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
+            (void)hipEventRecord(a, s);
+        }
+    }
+    ~ProfScope() {
+        if (on) {
+            (void)hipEventRecord(b, s);
+            std::lock_guard<std::mutex> lk(g_prof_mu);
+            g_prof.push_back({a, b, family, units});
+        }
+    }
+};
+}  // namespace
+
+int cah_profile_enable(int enable) { g_prof_on = enable != 0; return CAH_OK; }
+
+int cah_profile_reset(void) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    g_prof.clear();
+    return CAH_OK;
+}
+
+int cah_profile_read(double ms[CAH_PROF_N], int64_t launches[CAH_PROF_N], int64_t units[CAH_PROF_N]) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (int i = 0; i < CAH_PROF_N; i++) { ms[i] = 0; launches[i] = 0; units[i] = 0; }
+    for (auto& r : g_prof) {
+        HIP_TRY(hipEventSynchronize(r.b));
+        float t = 0;
+        HIP_TRY(hipEventElapsedTime(&t, r.a, r.b));
+        ms[r.family] += t;
+        launches[r.family] += 1;
+        units[r.family] += r.units;
+    }
+    return CAH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// batch entry points
+// ---------------------------------------------------------------------------------------------
+// workspace layout: [0,8) work counter A | [8,16) queue count | [16,24) work counter B |
+//                   [64, 64 + 4*n_reads) queue
+static const size_t WS_HEADER = 64;
+
+size_t cah_workspace_bytes(int64_t n_reads) {
+    if (n_reads < 0) n_reads = 0;
+    return WS_HEADER + sizeof(int32_t) * (size_t)n_reads + 64;
+}
+
+static int check_batch(const cah_plan* plan, const void* d_seqs, const void* d_offsets, int64_t n_reads) {
+    if (!plan) return fail(CAH_EINVAL, "plan is NULL");
+    if (n_reads < 0 || n_reads > 2147483647LL) return fail(CAH_EINVAL, "n_reads out of range (0..2^31-1)");
+    if (n_reads > 0 && (!d_offsets)) return fail(CAH_EINVAL, "offsets is NULL");
+    (void)d_seqs;
+    return CAH_OK;
+}
+
+static int run_aligner(const cah_plan* plan, const PlanDeviceCopy* pd, int32_t adapter, const uint8_t* d_seqs,
+                       const int64_t* d_offsets, const int32_t* d_lens, int64_t n_reads,
+                       const int32_t* d_queue, const unsigned long long* d_queue_count,
+                       unsigned long long* d_work_counter, int32_t* d_out6, uint8_t* d_status,
+                       int32_t* d_best, int merge_best, hipStream_t s) {
+    const CahMatcher& mt = plan->matchers[(size_t)adapter];
+    DpArgs a;
+    a.matcher = pd->d_matchers + adapter;
+    a.seqs = d_seqs; a.offsets = d_offsets; a.lens = d_lens; a.n_reads = n_reads;
+    a.max_read_len = CAH_MAX_READ_LEN;
+    a.queue = d_queue; a.queue_count = d_queue_count; a.work_counter = d_work_counter;
+    a.out6 = d_out6; a.status = d_status; a.best_adapter = d_best;
+    a.adapter_index = adapter; a.merge_best = merge_best;
+    HIP_TRY(hipMemsetAsync(d_work_counter, 0, sizeof(unsigned long long), s));
+    if (mt.kind == CAH_KIND_ALIGNER) {
+        ProfScope ps(s, CAH_PROF_DP, n_reads);
+        HIP_TRY(launch_dp(a, mt.m, n_reads, pd->n_cus, s));
+    } else {
+        ProfScope ps(s, CAH_PROF_COMPARER, n_reads);
+        HIP_TRY(launch_comparer(a, n_reads, pd->n_cus, s));
+    }
+    return CAH_OK;
+}
+
+int cah_locate_batch(const cah_plan* plan, int32_t adapter, const uint8_t* d_seqs,
+                     const int64_t* d_offsets, const int32_t* d_lens, int64_t n_reads,
+                     int32_t* d_out6, uint8_t* d_status, void* d_workspace, size_t workspace_bytes,
+                     void* stream) {
+    int rc = check_batch(plan, d_seqs, d_offsets, n_reads);
+    if (rc) return rc;
+    rc = check_adapter(plan, adapter);
+    if (rc) return rc;
+    if (plan->matchers[(size_t)adapter].kind == CAH_KIND_KMER_ONLY)
+        return fail(CAH_EINVAL, "adapter %d has no aligner", adapter);
+    if (n_reads == 0) return CAH_OK;
+    if (!d_out6 || !d_status) return fail(CAH_EINVAL, "output pointers are NULL");
+    if (!d_workspace || workspace_bytes < cah_workspace_bytes(n_reads))
+        return fail(CAH_EINVAL, "workspace too small: need %zu bytes", cah_workspace_bytes(n_reads));
+    unsigned long long* counters = (unsigned long long*)d_workspace;
+    const PlanDeviceCopy* pd = nullptr;
+    rc = plan_on_device(plan, &pd);
+    if (rc) return rc;
+    return run_aligner(plan, pd, adapter, d_seqs, d_offsets, d_lens, n_reads, nullptr, nullptr,
+                       counters + 0, d_out6, d_status, nullptr, 0, (hipStream_t)stream);
+}
+
+static int run_filter(const cah_plan* plan, const PlanDeviceCopy* pd, int32_t adapter, const uint8_t* d_seqs,
+                      const int64_t* d_offsets, const int32_t* d_lens, int64_t n_reads, int mode,
+                      uint8_t* d_present, uint8_t* d_status, int32_t* d_queue,
+                      unsigned long long* d_queue_count, unsigned long long* d_work_counter,
+                      hipStream_t s) {
+    const CahMatcher& mt = plan->matchers[(size_t)adapter];
+    FilterArgs f;
+    f.words = pd->d_words + mt.first_word;
+    f.n_words = mt.n_words;
+    f.seqs = d_seqs; f.offsets = d_offsets; f.lens = d_lens; f.n_reads = n_reads;
+    f.max_read_len = CAH_MAX_READ_LEN;
+    f.work_counter = d_work_counter;
+    f.present = d_present; f.status = d_status; f.queue = d_queue; f.queue_count = d_queue_count;
+    HIP_TRY(hipMemsetAsync(d_work_counter, 0, sizeof(unsigned long long), s));
+    if (d_queue_count) HIP_TRY(hipMemsetAsync(d_queue_count, 0, sizeof(unsigned long long), s));
+    ProfScope ps(s, CAH_PROF_FILTER, n_reads);
+    HIP_TRY(launch_filter(f, mode, pd->n_cus, s));
+    return CAH_OK;
+}
+
+int cah_kmers_present_batch(const cah_plan* plan, int32_t adapter, const uint8_t* d_seqs,
+                            const int64_t* d_offsets, const int32_t* d_lens, int64_t n_reads,
+                            uint8_t* d_present, void* stream) {
+    int rc = check_batch(plan, d_seqs, d_offsets, n_reads);
+    if (rc) return rc;
+    rc = check_adapter(plan, adapter);
+    if (rc) return rc;
+    if (n_reads == 0) return CAH_OK;
+    if (!d_present) return fail(CAH_EINVAL, "present is NULL");
+    hipStream_t s = (hipStream_t)stream;
+    const CahMatcher& mt = plan->matchers[(size_t)adapter];
+    if (!mt.has_filter) {   // MockKmerFinder: always present
+        HIP_TRY(hipMemsetAsync(d_present, 1, (size_t)n_reads, s));
+        return CAH_OK;
+    }
+    const PlanDeviceCopy* pd = nullptr;
+    rc = plan_on_device(plan, &pd);
+    if (rc) return rc;
+    // small private counter: allocate per call (kmers_present_batch is not the fused hot path)
+    unsigned long long* d_counter = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_counter, sizeof(unsigned long long)));
+    rc = run_filter(plan, pd, adapter, d_seqs, d_offsets, d_lens, n_reads, 0, d_present, nullptr, nullptr,
+                    nullptr, d_counter, s);
+    hipError_t e = hipStreamSynchronize(s);
+    (void)hipFree(d_counter);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(CAH_EHIP, "k_filter failed: %s", hipGetErrorString(e));
+    return CAH_OK;
+}
+
+int cah_match_batch(const cah_plan* plan, const uint8_t* d_seqs, const int64_t* d_offsets,
+                    const int32_t* d_lens, int64_t n_reads, int32_t* d_out6, int32_t* d_best_adapter,
+                    uint8_t* d_status, void* d_workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_batch(plan, d_seqs, d_offsets, n_reads);
+    if (rc) return rc;
+    if (n_reads == 0) return CAH_OK;
+    if (!d_out6 || !d_status) return fail(CAH_EINVAL, "output pointers are NULL");
+    if (!d_workspace || workspace_bytes < cah_workspace_bytes(n_reads))
+        return fail(CAH_EINVAL, "workspace too small: need %zu bytes", cah_workspace_bytes(n_reads));
+    hipStream_t s = (hipStream_t)stream;
+    const PlanDeviceCopy* pd = nullptr;
+    rc = plan_on_device(plan, &pd);
+    if (rc) return rc;
+    unsigned long long* counters = (unsigned long long*)d_workspace;
+    int32_t* d_queue = (int32_t*)((char*)d_workspace + WS_HEADER);
+    HIP_TRY(hipMemsetAsync(d_status, 0, (size_t)n_reads, s));
+    HIP_TRY(hipMemsetAsync(d_out6, 0, sizeof(int32_t) * 6 * (size_t)n_reads, s));
+    if (d_best_adapter) HIP_TRY(launch_init_best(d_best_adapter, n_reads, pd->n_cus, s));
+    for (int32_t ad = 0; ad < (int32_t)plan->matchers.size(); ad++) {
+        const CahMatcher& mt = plan->matchers[(size_t)ad];
+        if (mt.kind == CAH_KIND_KMER_ONLY) continue;
+        if (mt.has_filter) {
+            // prefilter -> queue of surviving reads -> DP on dense waves
+            rc = run_filter(plan, pd, ad, d_seqs, d_offsets, d_lens, n_reads, 1, nullptr, d_status, d_queue,
+                            counters + 1, counters + 0, s);
+            if (rc) return rc;
+            rc = run_aligner(plan, pd, ad, d_seqs, d_offsets, d_lens, n_reads, d_queue, counters + 1,
+                             counters + 2, d_out6, d_status, d_best_adapter, 1, s);
+        } else {
+            rc = run_aligner(plan, pd, ad, d_seqs, d_offsets, d_lens, n_reads, nullptr, nullptr, counters + 2,
+                             d_out6, d_status, d_best_adapter, 1, s);
+        }
+        if (rc) return rc;
+    }
+    return CAH_OK;
+}
+
+int cah_validate_ascii_batch(const uint8_t* d_seqs, const int64_t* d_offsets, const int32_t* d_lens,
+                             int64_t n_reads, int32_t* d_bad, void* stream) {
+    if (!d_bad) return fail(CAH_EINVAL, "d_bad is NULL");
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(d_bad, 0, sizeof(int32_t), s));
+    if (n_reads <= 0) return CAH_OK;
+    int dev = 0, n_cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n_cus = v;
+    }
+    HIP_TRY(launch_validate(d_seqs, d_offsets, d_lens, n_reads, d_bad, n_cus, s));
+    return CAH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-pointer conveniences
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
+};
+
+struct HostBatch {
+    DevBuf seqs, offsets, out6, status, best, ws;
+    int64_t n_reads = 0;
+    size_t ws_bytes = 0;
+    int upload(const uint8_t* h_seqs, const int64_t* h_offsets, int64_t n) {
+        n_reads = n;
+        const int64_t total = n > 0 ? h_offsets[n] : 0;
+        if (n > 0 && (h_offsets[0] != 0 && !h_seqs)) return fail(CAH_EINVAL, "seqs is NULL");
+        for (int64_t i = 0; i < n; i++)
+            if (h_offsets[i + 1] < h_offsets[i]) return fail(CAH_EINVAL, "offsets must be non-decreasing");
+        HIP_TRY(seqs.alloc((size_t)total));
+        HIP_TRY(offsets.alloc(sizeof(int64_t) * (size_t)(n + 1)));
+        if (total > 0) HIP_TRY(hipMemcpy(seqs.p, h_seqs, (size_t)total, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(offsets.p, h_offsets, sizeof(int64_t) * (size_t)(n + 1), hipMemcpyHostToDevice));
+        ws_bytes = cah_workspace_bytes(n);
+        HIP_TRY(ws.alloc(ws_bytes));
+        return CAH_OK;
+    }
+};
+}  // namespace
+
+int cah_locate_batch_host(const cah_plan* plan, int32_t adapter, const uint8_t* seqs,
+                          const int64_t* offsets, int64_t n_reads, int32_t* out6, uint8_t* status) {
+    int rc = check_batch(plan, seqs, offsets, n_reads);
+    if (rc) return rc;
+    if (n_reads == 0) return CAH_OK;
+    HostBatch hb;
+    rc = hb.upload(seqs, offsets, n_reads);
+    if (rc) return rc;
+    HIP_TRY(hb.out6.alloc(sizeof(int32_t) * 6 * (size_t)n_reads));
+    HIP_TRY(hb.status.alloc((size_t)n_reads));
+    rc = cah_locate_batch(plan, adapter, (const uint8_t*)hb.seqs.p, (const int64_t*)hb.offsets.p, nullptr,
+                          n_reads, (int32_t*)hb.out6.p, (uint8_t*)hb.status.p, hb.ws.p, hb.ws_bytes, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out6, hb.out6.p, sizeof(int32_t) * 6 * (size_t)n_reads, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(status, hb.status.p, (size_t)n_reads, hipMemcpyDeviceToHost));
+    return CAH_OK;
+}
+
+int cah_kmers_present_batch_host(const cah_plan* plan, int32_t adapter, const uint8_t* seqs,
+                                 const int64_t* offsets, int64_t n_reads, uint8_t* present) {
+    int rc = check_batch(plan, seqs, offsets, n_reads);
+    if (rc) return rc;
+    if (n_reads == 0) return CAH_OK;
+    HostBatch hb;
+    rc = hb.upload(seqs, offsets, n_reads);
+    if (rc) return rc;
+    HIP_TRY(hb.status.alloc((size_t)n_reads));
+    rc = cah_kmers_present_batch(plan, adapter, (const uint8_t*)hb.seqs.p, (const int64_t*)hb.offsets.p,
+                                 nullptr, n_reads, (uint8_t*)hb.status.p, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(present, hb.status.p, (size_t)n_reads, hipMemcpyDeviceToHost));
+    return CAH_OK;
+}
+
+int cah_match_batch_host(const cah_plan* plan, const uint8_t* seqs, const int64_t* offsets,
+                         int64_t n_reads, int32_t* out6, int32_t* best_adapter, uint8_t* status) {
+    int rc = check_batch(plan, seqs, offsets, n_reads);
+    if (rc) return rc;
+    if (n_reads == 0) return CAH_OK;
+    HostBatch hb;
+    rc = hb.upload(seqs, offsets, n_reads);
+    if (rc) return rc;
+    HIP_TRY(hb.out6.alloc(sizeof(int32_t) * 6 * (size_t)n_reads));
+    HIP_TRY(hb.status.alloc((size_t)n_reads));
+    HIP_TRY(hb.best.alloc(sizeof(int32_t) * (size_t)n_reads));
+    rc = cah_match_batch(plan, (const uint8_t*)hb.seqs.p, (const int64_t*)hb.offsets.p, nullptr, n_reads,
+                         (int32_t*)hb.out6.p, (int32_t*)hb.best.p, (uint8_t*)hb.status.p, hb.ws.p,
+                         hb.ws_bytes, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out6, hb.out6.p, sizeof(int32_t) * 6 * (size_t)n_reads, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(status, hb.status.p, (size_t)n_reads, hipMemcpyDeviceToHost));
+    if (best_adapter)
+        HIP_TRY(hipMemcpy(best_adapter, hb.best.p, sizeof(int32_t) * (size_t)n_reads, hipMemcpyDeviceToHost));
+    return CAH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// synthetic reads
+// ---------------------------------------------------------------------------------------------
+int cah_synth_reads(uint64_t seed, int64_t first_index, int64_t n_reads, int32_t read_len,
+                    uint32_t p_adapter_u32, uint32_t p_edit_u32, uint32_t p_n_u16, const char* adapters,
+                    const int32_t* adapter_off, int32_t n_adapters, uint8_t* d_seqs, int64_t* d_offsets,
+                    void* stream) {
+    if (n_reads < 0 || read_len < 0) return fail(CAH_EINVAL, "negative size");
+    if (n_adapters < 0 || n_adapters > 4096) return fail(CAH_EINVAL, "n_adapters out of range");
+    if (n_adapters > 0 && (!adapters || !adapter_off)) return fail(CAH_EINVAL, "adapters is NULL");
+    if (!d_seqs || !d_offsets) return fail(CAH_EINVAL, "output pointers are NULL");
+    hipStream_t s = (hipStream_t)stream;
+    DevBuf d_ad, d_off;
+    const int total = n_adapters > 0 ? adapter_off[n_adapters] : 0;
+    HIP_TRY(d_ad.alloc((size_t)total));
+    HIP_TRY(d_off.alloc(sizeof(int32_t) * (size_t)(n_adapters + 1)));
+    if (total > 0) HIP_TRY(hipMemcpyAsync(d_ad.p, adapters, (size_t)total, hipMemcpyHostToDevice, s));
+    int32_t zero = 0;
+    HIP_TRY(hipMemcpyAsync(d_off.p, n_adapters > 0 ? adapter_off : &zero, sizeof(int32_t) * (size_t)(n_adapters + 1),
+                           hipMemcpyHostToDevice, s));
+    int dev = 0, n_cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n_cus = v;
+    }
+    HIP_TRY(launch_synth(seed, first_index, n_reads, read_len, p_adapter_u32, p_edit_u32, p_n_u16,
+                         (const char*)d_ad.p, (const int32_t*)d_off.p, n_adapters, d_seqs, d_offsets, n_cus, s));
+    HIP_TRY(hipStreamSynchronize(s));   // d_ad/d_off are freed on return
+    return CAH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,49 @@
+// cah_device.h -- structures shared by the host plan builder and the gfx950 kernels.
+//
+// HBM layout of a plan (all immutable after cah_plan_create):
+//   CahMatcher  matchers[n_adapters]   one per adapter: DP constants + char->row-bitset table
+//   CahKmerWord kmer_words[total]      packed shift-and words of all adapters' prefilters
+// A kernel launch works on ONE matcher (wave-uniform constants live in SGPRs); it copies the
+// tables it needs into LDS once per workgroup.
+#pragma once
+#include <stdint.h>
+
+#define CAH_MAX_M 64           // adapter length limit: one 64-bit row bitset per read char
+#define CAH_TABLE_CHARS 128    // ASCII; bytes >= 0x80 are invalid input
+
+// Packed DP cell payload (one VGPR): ((origin + CAH_ORIGIN_BIAS) << 12) + (score + CAH_SCORE_BIAS)
+// origin in [-64, 1e6], score in [-2048, 2047] (bounds derived in DESIGN.md); match/mismatch/
+// indel score updates are the inline constants +1/-1/-2 on the low field.
+#define CAH_SCORE_BITS 12
+#define CAH_SCORE_BIAS 2048
+#define CAH_ORIGIN_BIAS 128
+
+struct CahMatcher {
+    int32_t kind;              // CAH_KIND_*
+    int32_t m;                 // adapter length
+    int32_t k;                 // (int)(max_error_rate * m)              _align.pyx:343
+    int32_t flags;             // EndSkip bits
+    int32_t indel_cost;        // insertion == deletion cost            _align.pyx:219-220
+    int32_t min_overlap;
+    int32_t wildcard_ref;
+    int32_t effective_length;  // m - #N when wildcard_ref              _align.pyx:268-271
+    int32_t cmp_max_k;         // comparers: (int)(rate * effective_length)  _align.pyx:633
+    int32_t has_filter;        // 0 = MockKmerFinder (always present)
+    int32_t first_word;        // index into kmer_words
+    int32_t n_words;
+    int32_t n_counts[CAH_MAX_M + 1];   // #N/n in adapter[:i]            _align.pyx:261-266
+    int32_t thr[CAH_MAX_M + 1];        // thr[L] = floor(L * max_error_rate): integer form of
+                                       // `cost <= cur_effective_length * max_error_rate` (:513, :559)
+    int32_t pad_[2];
+    uint64_t rowmask[CAH_TABLE_CHARS]; // bit i set <=> adapter[i] matches this read character
+                                       // (folds translate() + the three compare modes, :322-328, :442-445;
+                                       //  for comparers bit i refers to the i-th compared position)
+};
+
+struct CahKmerWord {
+    int64_t start;             // search window, KmerFinder semantics (stop == 0: to the end)
+    int64_t stop;
+    uint64_t init_mask;        // bit at every k-mer start           _kmer_finder.pyx:143
+    uint64_t found_mask;       // bit at every k-mer end             _kmer_finder.pyx:147
+    uint64_t mask[CAH_TABLE_CHARS];
+};

@@ -1,0 +1,49 @@
+// kernels.h -- launch interface between api.cpp (host) and kernels.hip (device).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "cah_device.h"
+
+struct FilterArgs {
+    const CahKmerWord* words;        // this adapter's packed shift-and words (HBM)
+    int32_t n_words;
+    const uint8_t* seqs;
+    const int64_t* offsets;
+    const int32_t* lens;             // may be NULL
+    int64_t n_reads;
+    int64_t max_read_len;
+    unsigned long long* work_counter;   // zeroed before launch
+    uint8_t* present;                // MODE 0
+    uint8_t* status;                 // MODE 1: only written for invalid reads
+    int32_t* queue;                  // MODE 1: surviving read indices
+    unsigned long long* queue_count; // MODE 1: zeroed before launch
+};
+
+struct DpArgs {
+    const CahMatcher* matcher;
+    const uint8_t* seqs;
+    const int64_t* offsets;
+    const int32_t* lens;             // may be NULL
+    int64_t n_reads;
+    int64_t max_read_len;
+    const int32_t* queue;            // NULL: process reads 0..n_reads-1
+    const unsigned long long* queue_count;   // NULL: n_reads
+    unsigned long long* work_counter;        // zeroed before launch
+    int32_t* out6;
+    uint8_t* status;
+    int32_t* best_adapter;           // may be NULL
+    int32_t adapter_index;
+    int32_t merge_best;              // 0: overwrite (locate_batch); 1: keep best (match_batch)
+};
+
+hipError_t launch_filter(const FilterArgs& a, int mode, int n_cus, hipStream_t s);
+hipError_t launch_dp(const DpArgs& a, int m, int64_t max_items, int n_cus, hipStream_t s);
+hipError_t launch_comparer(const DpArgs& a, int64_t max_items, int n_cus, hipStream_t s);
+hipError_t launch_validate(const uint8_t* seqs, const int64_t* offsets, const int32_t* lens,
+                           int64_t n_reads, int32_t* bad, int n_cus, hipStream_t s);
+hipError_t launch_init_best(int32_t* best_adapter, int64_t n_reads, int n_cus, hipStream_t s);
+hipError_t launch_synth(uint64_t seed, int64_t first_index, int64_t n_reads, int32_t read_len,
+                        uint32_t p_adapter_u32, uint32_t p_edit_u32, uint32_t p_n_u16,
+                        const char* d_adapters, const int32_t* d_adapter_off, int32_t n_adapters,
+                        uint8_t* d_seqs, int64_t* d_offsets, int n_cus, hipStream_t s);

@@ -1,0 +1,495 @@
+// kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the adapter-matching hot path.
+//
+//   k_filter      KmerFinder.kmers_present          reference _kmer_finder.pyx:170-257
+//   k_dp<ROWS>    Aligner.locate                    reference _align.pyx:298-587
+//   k_comparer    Prefix/SuffixComparer.locate      reference _align.pyx:651-714
+//   k_validate    "only ASCII" precondition         reference _align.pyx:44-45
+//
+// Execution model: ONE READ PER LANE, 64 reads per wavefront.  The DP column of the short
+// adapter (m <= 64) lives entirely in VGPRs (two registers per row: cost and a packed
+// score|origin payload), the row loop is fully unrolled and predicated per lane by the
+// Ukkonen band limit `last`; the compiler turns the nested predicates into exec masks and
+// skips row blocks no lane needs (s_cbranch_execz).  Per-character adapter match bitsets
+// (64-bit, one bit per adapter row) come from a 1 KiB LDS table, so the inner loop has no
+// byte compares at all.  Integer only -- no MFMA (this is a min/compare recurrence, not a
+// contraction).
+//
+// Bit-exactness includes the reference's accidental behaviour: cells outside the band keep
+// stale values, the last-column scan compares against a stale `origin`, tie-breaks are
+// mismatch >= deletion >= insertion.  See DESIGN.md "Exactness notes".
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "cah_device.h"
+#include "kernels.h"
+
+#define WAVE 64
+
+__device__ __forceinline__ int wave_lane() { return threadIdx.x & (WAVE - 1); }
+
+__device__ __forceinline__ int pack_cell(int origin, int score) {
+    return ((origin + CAH_ORIGIN_BIAS) << CAH_SCORE_BITS) + (score + CAH_SCORE_BIAS);
+}
+__device__ __forceinline__ int cell_origin(int p) {
+    return (int)((unsigned)p >> CAH_SCORE_BITS) - CAH_ORIGIN_BIAS;
+}
+__device__ __forceinline__ int cell_score(int p) {
+    return (p & ((1 << CAH_SCORE_BITS) - 1)) - CAH_SCORE_BIAS;
+}
+
+// Where does read `r` live?  (packed layout, see include/cutadapt_hip.h)
+__device__ __forceinline__ void read_extent(const int64_t* offsets, const int32_t* lens, int64_t r,
+                                            int64_t& off, int64_t& n) {
+    off = offsets[r];
+    n = lens ? (int64_t)lens[r] : offsets[r + 1] - off;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Work distribution: waves pull chunks of 64 work items from a device counter ("dequeue",
+// the cheapest cross-CU primitive on this chip) so that long and short reads balance.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int64_t wave_dequeue(unsigned long long* counter) {
+    unsigned long long base = 0;
+    if (wave_lane() == 0) base = atomicAdd(counter, (unsigned long long)WAVE);
+    unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)base);
+    unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
+    return (int64_t)(((unsigned long long)hi << 32) | lo);
+}
+
+// =============================================================================================
+// k_filter: multi-pattern shift-and prefilter.  One read per lane; the packed k-mer words of
+// the adapter are wave-uniform, their 128 x 64-bit character masks sit in LDS.
+// MODE 0: write present[r];  MODE 1: append surviving read indices to the DP work queue with
+// one ballot + popcount + a single atomic per wave.
+// =============================================================================================
+#define FILTER_LDS_WORDS 32
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_filter(FilterArgs a) {
+    __shared__ uint64_t s_mask[FILTER_LDS_WORDS * CAH_TABLE_CHARS];
+    const CahKmerWord* words = a.words;
+    const int n_words = a.n_words;
+    const int lds_words = n_words < FILTER_LDS_WORDS ? n_words : FILTER_LDS_WORDS;
+    for (int i = threadIdx.x; i < lds_words * CAH_TABLE_CHARS; i += blockDim.x)
+        s_mask[i] = words[i / CAH_TABLE_CHARS].mask[i % CAH_TABLE_CHARS];
+    __syncthreads();
+
+    const int lane = wave_lane();
+    for (;;) {
+        const int64_t base = wave_dequeue(a.work_counter);
+        if (base >= a.n_reads) break;
+        const int64_t r = base + lane;
+        const bool valid = r < a.n_reads;
+        int64_t off = 0, n = 0;
+        if (valid) read_extent(a.offsets, a.lens, r, off, n);
+        const uint8_t* q = a.seqs + off;
+        bool hit = false, invalid = false;
+        if (n > a.max_read_len) { invalid = true; n = 0; }
+
+        for (int w = 0; w < n_words; ++w) {
+            // window of this word on this lane's read (_kmer_finder.pyx:188-204)
+            int64_t start = words[w].start, stop = words[w].stop;
+            bool skip = !valid || hit;
+            if (start < 0) { start += n; if (start < 0) start = 0; }
+            else if (start > n) skip = true;
+            if (stop < 0) { stop += n; if (stop <= 0) skip = true; }
+            else if (stop == 0) stop = n;
+            if (stop > n) stop = n;  // the reference reads past the buffer here (UB); clamp
+            int64_t len = skip ? 0 : stop - start;
+            const uint64_t init = words[w].init_mask, found = words[w].found_mask;
+            const uint64_t* tbl_g = words[w].mask;
+            const uint64_t* tbl_s = s_mask + w * CAH_TABLE_CHARS;
+            const bool in_lds = w < lds_words;
+            uint64_t R = 0;
+            for (int64_t t = 0; __any(t < len && !hit); ++t) {
+                if (t < len && !hit) {
+                    const unsigned ch = q[start + t];
+                    uint64_t mk = 0;
+                    if (ch < CAH_TABLE_CHARS) mk = in_lds ? tbl_s[ch] : tbl_g[ch];
+                    else invalid = true;
+                    R = ((R << 1) | init) & mk;
+                    hit = (R & found) != 0;
+                }
+            }
+            if (__all(hit || !valid)) break;
+        }
+
+        if (MODE == 0) {
+            if (valid) a.present[r] = invalid ? (uint8_t)2 : (hit ? (uint8_t)1 : (uint8_t)0);
+        } else {
+            if (valid && invalid) a.status[r] = 2;
+            const bool push = valid && hit && !invalid;
+            const unsigned long long bal = __ballot(push);
+            if (bal) {
+                unsigned long long qb = 0;
+                if (lane == 0) qb = atomicAdd(a.queue_count, (unsigned long long)__popcll(bal));
+                unsigned qlo = __builtin_amdgcn_readfirstlane((unsigned)qb);
+                unsigned qhi = __builtin_amdgcn_readfirstlane((unsigned)(qb >> 32));
+                const unsigned long long qbase = ((unsigned long long)qhi << 32) | qlo;
+                if (push) {
+                    const int rank = __popcll(bal & ((1ull << lane) - 1ull));
+                    a.queue[qbase + rank] = (int32_t)r;
+                }
+            }
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// One DP column, rows I..ROWS, as a compile-time recursion: guarantees full unrolling (so the
+// column arrays stay in VGPRs) and yields *nested* per-lane predicates -- a lane whose band
+// ends at row `last` drops out of exec for the rest of the column, and once exec is empty the
+// remaining rows are skipped with one scalar branch.
+// ---------------------------------------------------------------------------------------------
+template <int I, int ROWS>
+__device__ __forceinline__ void dp_rows(int (&c)[ROWS + 1], int (&p)[ROWS + 1], const uint64_t mk,
+                                        int dc, int dp, int& nl, int& cm_c, int& cm_p,
+                                        const int last, const int m, const int k, const int D) {
+    if constexpr (I <= ROWS) {
+        // every 4 rows: leave the column as soon as no lane of the wave has band left
+        if constexpr ((I & 3) == 1) {
+            if (!__any(last >= I)) return;
+        }
+        // Straight-line, select-only cell update (no exec-mask regions: lanes whose band ended
+        // compute a value that is discarded by the final select, so stale cells stay stale).
+        // (:446-476) match: take the diagonal unconditionally; otherwise min of {diag+1, del,
+        // ins} with ties resolved mismatch >= deletion >= insertion.
+        const int oc = c[I], op = p[I];
+        const int cprev = c[I - 1], pprev = p[I - 1];
+        const unsigned mword = (I - 1) < 32 ? (unsigned)mk : (unsigned)(mk >> 32);
+        const int eqm = (int)(mword << (31 - ((I - 1) & 31))) >> 31;   // v_bfe_i32: -1 if match
+        const int c_diag = dc + 1;
+        const int c_indel = min(cprev, oc) + D;           // min(c_del, c_ins)
+        const bool mis = c_diag <= c_indel;
+        const bool del = cprev <= oc;                     // c_del <= c_ins
+        const int p_indel = (del ? pprev : op) - 2;
+        const int p_ne = mis ? dp - 1 : p_indel;
+        const int c_ne = min(c_diag, c_indel);
+        const int cost = (eqm & dc) | (~eqm & c_ne);      // v_bfi_b32
+        const int pay = (eqm & (dp + 1)) | (~eqm & p_ne);
+        const bool in_band = I <= last;                   // per lane: Ukkonen band (last <= m)
+        c[I] = in_band ? cost : oc;
+        p[I] = in_band ? pay : op;
+        nl = (in_band && cost <= k) ? I : nl;
+        if constexpr (I > ROWS - 8) {                     // m is in (ROWS-8, ROWS]: wave-uniform capture
+            if (I == m) { cm_c = cost; cm_p = pay; }
+        }
+        dp_rows<I + 1, ROWS>(c, p, mk, oc, op, nl, cm_c, cm_p, last, m, k, D);   // diag := old cell (:479)
+    }
+}
+
+// =============================================================================================
+// k_dp<ROWS>: the banded semi-global aligner, one read per lane, column in VGPRs.
+// =============================================================================================
+template <int ROWS>
+__global__ __launch_bounds__(256) void k_dp(DpArgs a) {
+    __shared__ uint64_t s_rowmask[CAH_TABLE_CHARS];
+    __shared__ int s_ncnt[CAH_MAX_M + 1];
+    __shared__ int s_thr[CAH_MAX_M + 1];
+    const CahMatcher* mt = a.matcher;
+    for (int i = threadIdx.x; i < CAH_TABLE_CHARS; i += blockDim.x) s_rowmask[i] = mt->rowmask[i];
+    for (int i = threadIdx.x; i <= CAH_MAX_M; i += blockDim.x) {
+        s_ncnt[i] = mt->n_counts[i];
+        s_thr[i] = mt->thr[i];
+    }
+    __syncthreads();
+
+    // wave-uniform adapter constants (SGPRs)
+    const int m = mt->m, k = mt->k, D = mt->indel_cost;
+    const int flags = mt->flags;
+    const bool start_in_ref = flags & 1, start_in_query = flags & 2;
+    const bool stop_in_ref = flags & 4, stop_in_query = flags & 8;
+    const int min_overlap = mt->min_overlap;
+    const bool wildcard_ref = mt->wildcard_ref != 0;
+    const int eff_full = mt->effective_length;
+    const int half_m = m / 2;
+    // row 0 update per column (_align.pyx:413-415, :438-440), in packed form
+    const int row0_cost_inc = start_in_query ? 0 : D;
+    const int row0_pay_inc = start_in_query ? (1 << CAH_SCORE_BITS) : -2;
+    // first-column weights (see below)
+    const int init_org_lo = start_in_ref ? -(1 << 24) : 0, init_org_hi = start_in_query ? (1 << 24) : 0;
+    const int w_max = (!start_in_ref && !start_in_query) ? 1 : 0, w_min = (start_in_ref && start_in_query) ? 1 : 0;
+    const int w_y = (start_in_ref && !start_in_query) ? 1 : 0, w_x = (!start_in_ref && start_in_query) ? 1 : 0;
+    const int init_score_mul = start_in_ref ? 0 : -2;
+
+    const int lane = wave_lane();
+    int64_t total = a.n_reads;
+    if (a.queue_count) total = (int64_t)(*a.queue_count);
+
+    for (;;) {
+        const int64_t base = wave_dequeue(a.work_counter);
+        if (base >= total) break;
+        const int64_t idx = base + lane;
+        const bool valid = idx < total;
+        int64_t r = 0;
+        if (valid) r = a.queue ? (int64_t)a.queue[idx] : idx;
+        int64_t off = 0, n64 = 0;
+        if (valid) read_extent(a.offsets, a.lens, r, off, n64);
+        bool invalid = false;
+        if (n64 > a.max_read_len) { invalid = true; n64 = 0; }
+        const int n = (int)n64;
+        const uint8_t* q = a.seqs + off;
+
+        // columns to compute (_align.pyx:346-352)
+        int max_n = n, min_n = 0;
+        if (!start_in_query) max_n = min(n, m + k);
+        if (!stop_in_query) min_n = max(0, n - m - k);
+
+        // first column (_align.pyx:364-383).  The four (start_in_reference, start_in_query)
+        // cases are folded into wave-uniform weights/clamps so that no branch is needed:
+        //   origin = clamp(min_n - i, start_in_ref ? -inf : 0, start_in_query ? +inf : 0)
+        //   cost   = D * {max(i,min_n) | min_n | i | min(i,min_n)},  score = start_in_ref ? 0 : -2i
+        int c[ROWS + 1], p[ROWS + 1];
+#pragma unroll
+        for (int i = 0; i <= ROWS; ++i) {
+            const int d = min_n - i;
+            const int org = min(max(d, init_org_lo), init_org_hi);
+            const int co = (w_max * max(i, min_n) + w_min * min(i, min_n) + w_y * min_n + w_x * i) * D;
+            c[i] = co;
+            p[i] = pack_cell(org, init_score_mul * i);
+        }
+
+        const int SENT = m + n + 1;                       // :394
+        int b_cost = SENT, b_pay = pack_cell(0, 0), b_refstop = m, b_qstop = n;
+
+        int last = start_in_ref ? m : min(m, k + 1);      // :399-401
+        int last_filled = 0;   // `last_filled_i` of the most recent column
+        int lf_ran = 0;        // ... of the most recent column whose row loop wrote a cell
+        int j = min_n;
+        bool done = !valid;
+
+        for (;;) {
+            const bool act = !done && j < max_n;
+            if (!__any(act)) break;
+            if (act) {
+                ++j;
+                const unsigned ch = q[j - 1];
+                uint64_t mk = 0;
+                if (ch < CAH_TABLE_CHARS) mk = s_rowmask[ch]; else invalid = true;
+
+                int dc = c[0], dp = p[0];                 // diagonal for row 1
+                c[0] += row0_cost_inc;
+                p[0] += row0_pay_inc;
+                int nl = c[0] <= k ? 0 : -1;              // largest computed row with cost <= k
+                int cm_c = c[0], cm_p = p[0];             // cell (m, j), captured for the candidate test
+                                                          // (row 0 itself when m == 0)
+                dp_rows<1, ROWS>(c, p, mk, dc, dp, nl, cm_c, cm_p, last, m, k, D);
+                last_filled = last;                       // :484
+                if (last >= 1) lf_ran = last;
+                // band update (:490-495)
+                if (nl < m) {
+                    last = nl + 1;
+                } else {
+                    last = m;
+                    if (stop_in_query) {                  // candidate in the last row (:496-533)
+                        const int cost = cm_c, origin = cell_origin(cm_p), score = cell_score(cm_p);
+                        const int length = m + min(origin, 0);
+                        int eff = length;
+                        if (wildcard_ref)
+                            eff = length < m ? length - (s_ncnt[m] - s_ncnt[m - length]) : eff_full;
+                        const bool ok = length >= min_overlap && cost <= s_thr[eff];
+                        const int b_origin = cell_origin(b_pay), b_score = cell_score(b_pay);
+                        const int best_len = m + min(b_origin, 0);
+                        if (ok && (b_cost == SENT || (origin <= b_origin + half_m && score > b_score) ||
+                                   (length > best_len && score > b_score))) {
+                            b_cost = cost; b_pay = cm_p; b_refstop = m; b_qstop = j;
+                            if (cost == 0 && origin >= 0) done = true;   // exact match: stop early
+                        }
+                    }
+                }
+            }
+        }
+
+        // last column (:536-572).  The update test uses the *stale* scalar `origin`: the origin
+        // of the last cell the row loop wrote, i.e. cell lf_ran of the column it last ran in.
+        if (valid && max_n == n) {
+            int stale_origin = 0;
+#pragma unroll
+            for (int i = 1; i <= ROWS; ++i)
+                if (i == lf_ran) stale_origin = cell_origin(p[i]);
+            const int first_i = stop_in_ref ? 0 : m;
+#pragma unroll
+            for (int i = ROWS; i >= 0; --i) {
+                if (i <= last_filled && i >= first_i) {
+                    const int o_i = cell_origin(p[i]), score = cell_score(p[i]), cost = c[i];
+                    const int ref_start = -min(o_i, 0);
+                    const int length = i - ref_start;
+                    int eff = length;
+                    if (wildcard_ref)
+                        eff = length < m ? length - (s_ncnt[i] - s_ncnt[ref_start]) : eff_full;
+                    const bool ok = length >= min_overlap && cost <= s_thr[eff];
+                    const int b_origin = cell_origin(b_pay), b_score = cell_score(b_pay);
+                    const int best_len = b_refstop + min(b_origin, 0);
+                    if (ok && (b_cost == SENT || (stale_origin <= b_origin + half_m && score > b_score) ||
+                               (length > best_len && score > b_score))) {
+                        b_cost = cost; b_pay = p[i]; b_refstop = i; b_qstop = n;
+                    }
+                }
+            }
+        }
+
+        if (valid) {
+            const bool found = b_cost != SENT && !invalid;
+            const int origin = cell_origin(b_pay), score = cell_score(b_pay);
+            int32_t* o = a.out6 + r * 6;
+            if (a.merge_best) {
+                // MultipleAdapters.match_to (adapters.py:1278-1285): adapters are launched in
+                // order on one stream; a later adapter replaces the current best only if strictly
+                // better (higher score, or equal score and fewer errors).
+                if (invalid) {
+                    a.status[r] = 2;
+                } else if (found) {
+                    const bool had = a.status[r] == 1;
+                    if (a.status[r] != 2 && (!had || score > o[4] || (score == o[4] && b_cost < o[5]))) {
+                        o[0] = origin >= 0 ? 0 : -origin; o[1] = b_refstop;
+                        o[2] = origin >= 0 ? origin : 0;  o[3] = b_qstop;
+                        o[4] = score; o[5] = b_cost;
+                        a.status[r] = 1;
+                        if (a.best_adapter) a.best_adapter[r] = a.adapter_index;
+                    }
+                }
+            } else {
+                a.status[r] = invalid ? (uint8_t)2 : (found ? (uint8_t)1 : (uint8_t)0);
+                if (found) {
+                    o[0] = origin >= 0 ? 0 : -origin; o[1] = b_refstop;
+                    o[2] = origin >= 0 ? origin : 0;  o[3] = b_qstop;
+                    o[4] = score; o[5] = b_cost;
+                } else {
+                    o[0] = o[1] = o[2] = o[3] = o[4] = o[5] = 0;
+                }
+            }
+        }
+    }
+}
+
+// =============================================================================================
+// k_comparer: PrefixComparer / SuffixComparer.locate -- Hamming distance over min(m, n)
+// characters, again via the per-character bitset table (bit i = i-th compared position).
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_comparer(DpArgs a) {
+    __shared__ uint64_t s_rowmask[CAH_TABLE_CHARS];
+    const CahMatcher* mt = a.matcher;
+    for (int i = threadIdx.x; i < CAH_TABLE_CHARS; i += blockDim.x) s_rowmask[i] = mt->rowmask[i];
+    __syncthreads();
+    const int m = mt->m, max_k = mt->cmp_max_k, min_overlap = mt->min_overlap;
+    const bool suffix = mt->kind == 2;
+    const int lane = wave_lane();
+    int64_t total = a.n_reads;
+    if (a.queue_count) total = (int64_t)(*a.queue_count);
+    for (;;) {
+        const int64_t base = wave_dequeue(a.work_counter);
+        if (base >= total) break;
+        const int64_t idx = base + lane;
+        if (idx >= total) continue;
+        const int64_t r = a.queue ? (int64_t)a.queue[idx] : idx;
+        int64_t off, n64;
+        read_extent(a.offsets, a.lens, r, off, n64);
+        bool invalid = false;
+        if (n64 > a.max_read_len) { invalid = true; n64 = 0; }
+        const int n = (int)n64;
+        const uint8_t* q = a.seqs + off;
+        const int length = min(m, n);
+        int errors = 0;
+        for (int i = 0; i < length; ++i) {
+            const unsigned ch = q[suffix ? n - 1 - i : i];
+            uint64_t mk = 0;
+            if (ch < CAH_TABLE_CHARS) mk = s_rowmask[ch]; else invalid = true;
+            errors += ((mk >> i) & 1ull) ? 0 : 1;
+        }
+        const bool found = !invalid && !(errors > max_k || length < min_overlap);   // :690-691
+        const int score = length - 2 * errors;                                     // :692
+        int32_t* o = a.out6 + r * 6;
+        int t0, t1, t2, t3;
+        if (!suffix) { t0 = 0; t1 = length; t2 = 0; t3 = length; }
+        else { t0 = m - length; t1 = m; t2 = n - length; t3 = n; }                  // :714
+        if (a.merge_best) {
+            if (invalid) a.status[r] = 2;
+            else if (found) {
+                const bool had = a.status[r] == 1;
+                if (a.status[r] != 2 && (!had || score > o[4] || (score == o[4] && errors < o[5]))) {
+                    o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3; o[4] = score; o[5] = errors;
+                    a.status[r] = 1;
+                    if (a.best_adapter) a.best_adapter[r] = a.adapter_index;
+                }
+            }
+        } else {
+            a.status[r] = invalid ? (uint8_t)2 : (found ? (uint8_t)1 : (uint8_t)0);
+            if (found) { o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3; o[4] = score; o[5] = errors; }
+            else { o[0] = o[1] = o[2] = o[3] = o[4] = o[5] = 0; }
+        }
+    }
+}
+
+// =============================================================================================
+// k_validate: count reads that hold a byte >= 0x80.
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_validate(const uint8_t* seqs, const int64_t* offsets,
+                                                  const int32_t* lens, int64_t n_reads, int32_t* bad) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += stride) {
+        int64_t off, n;
+        read_extent(offsets, lens, r, off, n);
+        unsigned acc = 0;
+        for (int64_t i = 0; i < n; ++i) acc |= seqs[off + i];
+        if (acc & 0x80u) atomicAdd(bad, 1);
+    }
+}
+
+__global__ void k_init_best(int32_t* best_adapter, int64_t n_reads) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += stride)
+        best_adapter[r] = -1;
+}
+
+// =============================================================================================
+// launchers (called from api.cpp)
+// =============================================================================================
+static int grid_for(int64_t n_items, int blocks_per_cu, int n_cus) {
+    int64_t need = (n_items + 255) / 256;
+    int64_t cap = (int64_t)blocks_per_cu * n_cus;
+    if (need < 1) need = 1;
+    return (int)(need < cap ? need : cap);
+}
+
+hipError_t launch_filter(const FilterArgs& a, int mode, int n_cus, hipStream_t s) {
+    const int grid = grid_for(a.n_reads, 8, n_cus);
+    if (mode == 0) hipLaunchKernelGGL(k_filter<0>, dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_filter<1>, dim3(grid), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_dp(const DpArgs& a, int m, int64_t max_items, int n_cus, hipStream_t s) {
+    const int grid = grid_for(max_items, 8, n_cus);
+#define CAH_DP_CASE(R) \
+    if (m <= R) { hipLaunchKernelGGL(k_dp<R>, dim3(grid), dim3(256), 0, s, a); return hipGetLastError(); }
+    CAH_DP_CASE(8)
+    CAH_DP_CASE(16)
+    CAH_DP_CASE(24)
+    CAH_DP_CASE(32)
+    CAH_DP_CASE(40)
+    CAH_DP_CASE(48)
+    CAH_DP_CASE(56)
+    CAH_DP_CASE(64)
+#undef CAH_DP_CASE
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_comparer(const DpArgs& a, int64_t max_items, int n_cus, hipStream_t s) {
+    const int grid = grid_for(max_items, 8, n_cus);
+    hipLaunchKernelGGL(k_comparer, dim3(grid), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_validate(const uint8_t* seqs, const int64_t* offsets, const int32_t* lens,
+                           int64_t n_reads, int32_t* bad, int n_cus, hipStream_t s) {
+    const int grid = grid_for(n_reads, 8, n_cus);
+    hipLaunchKernelGGL(k_validate, dim3(grid), dim3(256), 0, s, seqs, offsets, lens, n_reads, bad);
+    return hipGetLastError();
+}
+
+hipError_t launch_init_best(int32_t* best_adapter, int64_t n_reads, int n_cus, hipStream_t s) {
+    const int grid = grid_for(n_reads, 8, n_cus);
+    hipLaunchKernelGGL(k_init_best, dim3(grid), dim3(256), 0, s, best_adapter, n_reads);
+    return hipGetLastError();
+}

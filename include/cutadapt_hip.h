@@ -1,0 +1,196 @@
+/*
+ * cutadapt_hip.h -- C ABI of libcutadapt_hip.so: cutadapt's error-tolerant adapter
+ * matching (Aligner.locate + k-mer prefilter + match_to) on AMD Instinct MI355X (gfx950).
+ *
+ * The reference has no FFI/plugin seam of its own; the seam this library replaces is the
+ * Cython extension-module API that reference src/cutadapt/adapters.py calls:
+ *
+ *   cutadapt._align.Aligner(...).locate(query)             _align.pyx:195-204, 298-587
+ *   cutadapt._align.PrefixComparer / SuffixComparer        _align.pyx:594-714
+ *   cutadapt._kmer_finder.KmerFinder(...).kmers_present()  _kmer_finder.pyx:106-213
+ *   *Adapter.match_to() = kmers_present -> locate          adapters.py:707-724, 815-832
+ *   MultipleAdapters.match_to() = argmax over adapters     adapters.py:1265-1286
+ *
+ * Conventions
+ *   - plain C types only; every function returns an int status (CAH_OK == 0) and never
+ *     throws; cah_last_error() returns the message of the calling thread's last failure.
+ *   - a *plan* is immutable after creation and may be shared by any number of streams /
+ *     threads; all per-launch scratch is passed in by the caller (workspace) so that calls
+ *     on different streams never share state (the reference Aligner is NOT re-entrant,
+ *     _align.pyx:172/317 -- this ABI is).
+ *   - reads are *packed*: one uint8 buffer `seqs` with all sequences back to back and
+ *     `offsets` (int64, n_reads + 1 entries); read r is seqs[offsets[r] : offsets[r+1]).
+ *     If `lens` is non-NULL, read r is seqs[offsets[r] : offsets[r] + lens[r]) instead and
+ *     `offsets` needs only n_reads entries (used for the second stage of linked adapters,
+ *     adapters.py:1222-1224, where the 3' adapter is searched in a suffix of the read).
+ *   - results: `out6` is int32[n_reads][6] = (ref_start, ref_stop, query_start, query_stop,
+ *     score, errors), exactly the tuple Aligner.locate returns (_align.pyx:587);
+ *     `status` is uint8[n_reads]: CAH_NONE (locate() -> None), CAH_MATCH, or CAH_INVALID
+ *     (a byte >= 0x80 was met: the reference raises ValueError, _align.pyx:44-45).
+ *     out6 rows of non-matching reads are zero.
+ *   - pointers named d_* are DEVICE pointers (HBM) on the current HIP device and the call
+ *     is asynchronous on `stream` (a hipStream_t passed as void*, NULL = default stream).
+ *     The *_host variants take host pointers, stage through HBM and synchronise.
+ */
+#ifndef CUTADAPT_HIP_H
+#define CUTADAPT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CAH_ABI_VERSION 1
+
+/* status codes */
+#define CAH_OK 0
+#define CAH_EINVAL 1        /* bad argument (ValueError in the reference) */
+#define CAH_ETYPE 2         /* wrong type (TypeError in the reference) */
+#define CAH_EHIP 3          /* HIP runtime failure, message has the hipError string */
+#define CAH_ENOMEM 4
+#define CAH_EUNSUPPORTED 5  /* outside this build's limits (adapter > 64 chars, ...) */
+
+/* per-read result status */
+#define CAH_NONE 0
+#define CAH_MATCH 1
+#define CAH_INVALID 2
+
+/* matcher kinds */
+#define CAH_KIND_ALIGNER 0   /* Aligner: banded semi-global DP       (_align.pyx:93)  */
+#define CAH_KIND_PREFIX 1    /* PrefixComparer: Hamming, 5' anchored (_align.pyx:594) */
+#define CAH_KIND_SUFFIX 2    /* SuffixComparer: Hamming, 3' anchored (_align.pyx:696) */
+#define CAH_KIND_KMER_ONLY 3 /* a bare KmerFinder, no aligner                          */
+
+/* limits of this build */
+#define CAH_MAX_ADAPTER_LEN 64   /* DP column lives in VGPRs; match masks are 64-bit */
+#define CAH_MAX_READ_LEN 1000000 /* origin is carried in 20 bits of the packed DP cell */
+#define CAH_MAX_INDEL_COST 10000000
+
+/* One k-mer search set = (start, stop, [kmers]) of KmerFinder's positions_and_kmers
+ * (_kmer_finder.pyx:106, :121); stop == 0 encodes Python's None (:156-157). */
+typedef struct cah_kmer_set {
+    int64_t start;
+    int64_t stop;
+    const char *const *kmers; /* n_kmers NUL-terminated ASCII strings, each <= 64 chars */
+    int32_t n_kmers;
+} cah_kmer_set;
+
+/* One matcher = what one *Adapter object holds: an aligner (or comparer) plus an optional
+ * k-mer prefilter.  Mirrors the constructor arguments of Aligner (_align.pyx:195-204),
+ * PrefixComparer (:615-622) and KmerFinder (_kmer_finder.pyx:106). */
+typedef struct cah_adapter_desc {
+    const char *sequence;  /* the aligner's `reference` (adapter) string, not NUL-terminated */
+    int32_t length;        /* m */
+    double max_error_rate;
+    int32_t flags;         /* EndSkip bits: 1 REFERENCE_START, 2 QUERY_START,
+                              4 REFERENCE_END, 8 QUERY_STOP (align.py:24-34) */
+    int32_t wildcard_ref;
+    int32_t wildcard_query;
+    int32_t indel_cost;    /* 1, or 100000 for "no indels" (adapters.py:605) */
+    int32_t min_overlap;
+    int32_t kind;          /* CAH_KIND_* */
+    /* prefilter; n_kmer_sets < 0 means "no prefilter" (MockKmerFinder, adapters.py:29-31) */
+    const cah_kmer_set *kmer_sets;
+    int32_t n_kmer_sets;
+    int32_t kmer_ref_wildcards;   /* KmerFinder(ref_wildcards=...) */
+    int32_t kmer_query_wildcards; /* KmerFinder(query_wildcards=...) */
+} cah_adapter_desc;
+
+typedef struct cah_plan cah_plan;
+
+/* ---- library / device ---------------------------------------------------------------- */
+int cah_abi_version(void);
+/* copies the calling thread's last error message (NUL-terminated) into buf */
+void cah_last_error(char *buf, size_t buflen);
+int cah_device_count(int *count);
+int cah_set_device(int device);
+/* name of the HIP device and its gcnArchName, e.g. "gfx950:sramecc+:xnack-" */
+int cah_device_info(int device, char *name, size_t name_len, char *arch, size_t arch_len,
+                    int *compute_units, int64_t *hbm_bytes);
+
+/* ---- plans ---------------------------------------------------------------------------- */
+/* Validates like the reference constructors do (CAH_EINVAL for: only-N reference with
+ * wildcard_ref, indel_cost < 1, comparer rate outside [0,1], comparer min_overlap < 1,
+ * non-ASCII characters, k-mer longer than 64) and uploads the immutable tables to the
+ * current device.  Replaces Aligner.__cinit__/_set_reference (_align.pyx:195-277),
+ * PrefixComparer.__init__ (:615-642) and KmerFinder.__cinit__ (_kmer_finder.pyx:106-165). */
+int cah_plan_create(const cah_adapter_desc *adapters, int32_t n_adapters, cah_plan **out);
+void cah_plan_destroy(cah_plan *plan);
+int cah_plan_n_adapters(const cah_plan *plan);
+/* Aligner.effective_length / PrefixComparer.effective_length (_align.pyx:188, :611) */
+int cah_plan_effective_length(const cah_plan *plan, int32_t adapter, int32_t *out);
+/* number of packed 64-bit shift-and words (KmerFinder.number_of_searches) */
+int cah_plan_n_kmer_entries(const cah_plan *plan, int32_t adapter, int32_t *out);
+
+/* ---- batch entry points (device pointers, asynchronous) --------------------------------- */
+/* Aligner.locate / PrefixComparer.locate / SuffixComparer.locate over a batch.
+ * d_workspace: at least cah_workspace_bytes(n_reads) bytes of device scratch. */
+int cah_locate_batch(const cah_plan *plan, int32_t adapter, const uint8_t *d_seqs,
+                     const int64_t *d_offsets, const int32_t *d_lens, int64_t n_reads,
+                     int32_t *d_out6, uint8_t *d_status, void *d_workspace,
+                     size_t workspace_bytes, void *stream);
+
+/* KmerFinder.kmers_present over a batch: d_present[r] = 0 / 1 (or CAH_INVALID). */
+int cah_kmers_present_batch(const cah_plan *plan, int32_t adapter, const uint8_t *d_seqs,
+                            const int64_t *d_offsets, const int32_t *d_lens, int64_t n_reads,
+                            uint8_t *d_present, void *stream);
+
+/* Fused hot path: for every adapter of the plan (in order) prefilter -> wave-compact the
+ * survivors into a work queue -> DP on dense waves -> keep the best match per read with
+ * MultipleAdapters' rule (higher score, then fewer errors, then first adapter;
+ * adapters.py:1278-1285).  d_best_adapter (int32[n_reads], may be NULL) receives the index
+ * of the winning adapter or -1. */
+int cah_match_batch(const cah_plan *plan, const uint8_t *d_seqs, const int64_t *d_offsets,
+                    const int32_t *d_lens, int64_t n_reads, int32_t *d_out6,
+                    int32_t *d_best_adapter, uint8_t *d_status, void *d_workspace,
+                    size_t workspace_bytes, void *stream);
+
+/* bytes of device scratch the calls above need for n_reads reads */
+size_t cah_workspace_bytes(int64_t n_reads);
+
+/* d_bad[0] (int32) is set to the number of reads holding a byte >= 0x80 (the reference
+ * rejects such strings up front, _align.pyx:44-45 / _kmer_finder.pyx:182-183). */
+int cah_validate_ascii_batch(const uint8_t *d_seqs, const int64_t *d_offsets,
+                             const int32_t *d_lens, int64_t n_reads, int32_t *d_bad,
+                             void *stream);
+
+/* ---- host-pointer conveniences (synchronous; stage through HBM internally) -------------- */
+int cah_locate_batch_host(const cah_plan *plan, int32_t adapter, const uint8_t *seqs,
+                          const int64_t *offsets, int64_t n_reads, int32_t *out6,
+                          uint8_t *status);
+int cah_kmers_present_batch_host(const cah_plan *plan, int32_t adapter, const uint8_t *seqs,
+                                 const int64_t *offsets, int64_t n_reads, uint8_t *present);
+int cah_match_batch_host(const cah_plan *plan, const uint8_t *seqs, const int64_t *offsets,
+                         int64_t n_reads, int32_t *out6, int32_t *best_adapter,
+                         uint8_t *status);
+
+/* ---- measurement ------------------------------------------------------------------------ */
+/* When enabled, every batch call brackets its kernels with HIP events on the launch stream;
+ * cah_profile_read() synchronises those events and returns the accumulated kernel time and
+ * launch count per kernel family since the last cah_profile_reset().  Not thread-safe; meant
+ * for bench.py (roofline.achieved needs the dominant kernel's own duration). */
+#define CAH_PROF_FILTER 0
+#define CAH_PROF_DP 1
+#define CAH_PROF_COMPARER 2
+#define CAH_PROF_N 3
+int cah_profile_enable(int enable);
+int cah_profile_reset(void);
+int cah_profile_read(double ms[CAH_PROF_N], int64_t launches[CAH_PROF_N],
+                     int64_t units[CAH_PROF_N]);
+
+/* ---- synthetic workloads (benchmark utility) -------------------------------------------- */
+/* Fills d_seqs (n_reads * read_len bytes) and d_offsets (n_reads + 1) with the synthetic
+ * read model of SURVEY.md section 8(d); read r is a pure function of (seed, first_index + r).
+ * Probabilities are fixed point: p_adapter and p_edit as p * 2^32, p_n as p * 2^16.
+ * The CPU twin is oracle/synth_reads.c. */
+int cah_synth_reads(uint64_t seed, int64_t first_index, int64_t n_reads, int32_t read_len,
+                    uint32_t p_adapter_u32, uint32_t p_edit_u32, uint32_t p_n_u16,
+                    const char *adapters, const int32_t *adapter_off, int32_t n_adapters,
+                    uint8_t *d_seqs, int64_t *d_offsets, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CUTADAPT_HIP_H */
