@@ -51,11 +51,25 @@ class AdapterDescC(C.Structure):
 _lib = None
 
 
+def _share_hip_runtime_with_torch() -> None:
+    """PyTorch's ROCm wheel bundles its own libamdhip64.so (same SONAME libamdhip64.so.7 as
+    /opt/rocm's).  Two HIP runtimes in one process fight over the device ("no ROCm-capable
+    device is detected" in whichever initialises second), so make sure torch's copy is mapped
+    first: the dynamic loader then resolves this library's NEEDED libamdhip64.so.7 to the
+    already-loaded runtime and device pointers / streams can be exchanged with torch.  All HIP
+    symbols this library uses are the long-stable hip_4.2 / hip_6.0 versions."""
+    try:
+        import torch  # noqa: F401
+    except Exception:   # torch absent: the system runtime is used on its own
+        pass
+
+
 def lib():
     """Load the shared library (once).  Raises HipLibraryMissing if it has not been built."""
     global _lib
     if _lib is not None:
         return _lib
+    _share_hip_runtime_with_torch()
     if not os.path.exists(LIB_PATH):
         raise HipLibraryMissing(
             f"{LIB_PATH} not found: build it with `python -m cutadapt_amd.build` "

@@ -1,0 +1,82 @@
+"""CPU baseline for bench.py (TEST/MEASUREMENT INFRASTRUCTURE -- never the product path).
+
+Times the reference's own hot path -- ``BackAdapter.match_to()`` of the compiled reference in
+oracle/_ref (kind "reference"), or the C restatement in oracle/cutadapt_oracle.c when the
+compiled reference is not available (kind "port") -- on the host cores with one worker
+process per core, the same data-parallel shape as the reference's ParallelPipelineRunner
+(reference src/cutadapt/runners.py:275-412): every worker holds its own adapter object and
+a contiguous shard of pre-generated reads; only the matching loop is timed (no FASTQ I/O),
+throughput = reads / slowest worker.
+"""
+import multiprocessing as mp
+import os
+import time
+
+
+def available_cores() -> int:
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def _worker(args):
+    kind, seed, first, n_reads, read_len, adapter_seq, max_errors, min_overlap, gen = args
+    import numpy as np  # noqa: F401
+    from oracle import oracle as orc
+    seqs, offsets = orc.synth_reads(seed, first, n_reads, read_len, [adapter_seq],
+                                    gen["p_adapter"], gen["p_edit"], gen["p_n"])
+    if kind == "reference":
+        from oracle import ref_loader
+        ref = ref_loader.load()
+        adapter = ref.adapters.BackAdapter(adapter_seq, max_errors=max_errors, min_overlap=min_overlap)
+        raw = seqs.tobytes()
+        reads = [raw[i * read_len:(i + 1) * read_len].decode("ascii") for i in range(n_reads)]
+        match_to = adapter.match_to
+        t0 = time.perf_counter()
+        hits = 0
+        for r in reads:
+            if match_to(r) is not None:
+                hits += 1
+        dt = time.perf_counter() - t0
+    else:
+        from cutadapt_amd.kmer_heuristic import create_positions_and_kmers
+        a = orc.Aligner(adapter_seq, max_errors, 14, False, False, 1, min_overlap)
+        f = orc.KmerFinder(create_positions_and_kmers(adapter_seq, min_overlap, max_errors, True, False))
+        t0 = time.perf_counter()
+        _, status = orc.match_batch(a, f, seqs, offsets)
+        dt = time.perf_counter() - t0
+        hits = int((status == 1).sum())
+    return dt, hits
+
+
+def run(seed: int, read_len: int, adapter_seq: str, max_errors: float, min_overlap: int, gen: dict,
+        target_seconds: float = 12.0, max_reads: int = 50_000_000):
+    """Returns dict(value=Mreads/s, cores=..., kind=..., sample=...)."""
+    from oracle import oracle as orc
+    from oracle import ref_loader
+    orc.lib()
+    kind = "reference" if ref_loader.load() is not None else "port"
+    cores = available_cores()
+    # calibrate on one core, then size the sample for ~target_seconds on all cores
+    probe = 20000
+    dt, _ = _worker((kind, seed, 0, probe, read_len, adapter_seq, max_errors, min_overlap, gen))
+    rate1 = probe / max(dt, 1e-6)
+    per_worker = int(min(max(rate1 * target_seconds, 20000), max_reads / cores))
+    ctx = mp.get_context("spawn")
+    jobs = [(kind, seed, w * per_worker, per_worker, read_len, adapter_seq, max_errors, min_overlap, gen)
+            for w in range(cores)]
+    with ctx.Pool(cores) as pool:
+        results = pool.map(_worker, jobs)
+    slowest = max(r[0] for r in results)
+    total = per_worker * cores
+    return {
+        "value": total / slowest / 1e6,
+        "unit": "Mreads/s",
+        "cores": cores,
+        "kind": kind,
+        "sample": f"{total} reads of the same synthetic workload (read indices 0..{total - 1}), "
+                  f"{cores} worker processes x {per_worker} reads, match_to() loop only; "
+                  f"1-core probe {rate1 / 1e6:.3f} Mreads/s",
+        "hit_fraction": sum(r[1] for r in results) / total,
+    }

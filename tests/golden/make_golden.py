@@ -190,6 +190,45 @@ ADAPTER_CLASSES = ["FrontAdapter", "BackAdapter", "AnywhereAdapter", "NonInterna
                    "RightmostFrontAdapter", "RightmostBackAdapter"]
 
 
+class _NeverPresent:
+    def kmers_present(self, sequence):
+        return False
+
+
+def safe_match_to(ref, adapter, read):
+    """adapter.match_to(read) restricted to DEFINED behaviour of the reference: its
+    kmers_present reads past the end of the string when a search window has a positive stop
+    beyond len(read) (reference _kmer_finder.pyx:196-205; front-adapter sets use positive
+    stops, kmer_heuristic.py:159) and the result then depends on heap garbage.  For such
+    reads the windows are clamped to the read first -- what the memory-safe reading of the
+    algorithm gives and what the HIP kernel and the oracle implement."""
+    kf = getattr(adapter, "kmer_finder", None)
+    sets = getattr(kf, "positions_and_kmers", None)
+    n = len(read)
+    if sets is not None and any(stop is not None and stop > n for _, stop, _ in sets):
+        clamped = [(s, (min(e, n) if e is not None else None), k) for s, e, k in sets]
+        clamped = [(s, e, k) for s, e, k in clamped if e is None or e > 0]   # empty windows never match
+        adapter.kmer_finder = ref.KmerFinder(clamped, kf.ref_wildcards, kf.query_wildcards) \
+            if clamped else _NeverPresent()
+        try:
+            return adapter.match_to(read)
+        finally:
+            adapter.kmer_finder = kf
+    return adapter.match_to(read)
+
+
+def safe_linked_match_to(ref, linked, read):
+    """LinkedAdapter.match_to (reference adapters.py:1215-1227) with safe_match_to stages"""
+    front = safe_match_to(ref, linked.front_adapter, read)
+    if linked.front_required and front is None:
+        return None, None, False
+    seq = read[front.trim_slice()] if front is not None else read
+    back = safe_match_to(ref, linked.back_adapter, seq)
+    if back is None and (linked.back_required or front is None):
+        return None, None, False
+    return front, back, True
+
+
 def match_to_json(match):
     if match is None:
         return None
@@ -221,7 +260,7 @@ def gen_adapters(ref, rng, count):
             read = read_with_adapter(rng, adapter.sequence, "ACGTN" if rng.random() < 0.3 else "ACGT", n)
             if rng.random() < 0.2:
                 read = read.lower()
-            reads.append([read, match_to_json(adapter.match_to(read))])
+            reads.append([read, match_to_json(safe_match_to(ref, adapter, read))])
         cases.append({"cls": cls_name, "sequence": seq, "kwargs": kwargs, "reads": reads})
     return cases
 
@@ -244,9 +283,9 @@ def gen_linked_and_multiple(ref, rng):
             b = mutate(rng, bseq, "ACGT", rng.choice([0, 0, 1, 2])) if rng.random() < 0.7 else ""
             pre = "" if anchored else rs(rng, rng.randint(0, 5), "ACGT")
             read = pre + f + core + b + rs(rng, rng.randint(0, 10), "ACGT")
-            mt = linked.match_to(read)
-            reads.append([read, None if mt is None else
-                          {"front": match_to_json(mt.front_match), "back": match_to_json(mt.back_match)}])
+            fm, bm, ok = safe_linked_match_to(ref, linked, read)
+            reads.append([read, None if not ok else
+                          {"front": match_to_json(fm), "back": match_to_json(bm)}])
         out["linked"].append({"front_cls": fcls, "front": fseq, "back": bseq, "front_required": freq,
                               "back_required": breq, "reads": reads})
     for _ in range(40):
