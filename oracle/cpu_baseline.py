@@ -7,10 +7,17 @@ process per core, the same data-parallel shape as the reference's ParallelPipeli
 (reference src/cutadapt/runners.py:275-412): every worker holds its own adapter object and
 a contiguous shard of pre-generated reads; only the matching loop is timed (no FASTQ I/O),
 throughput = reads / slowest worker.
+
+Workers are plain subprocesses (``python -m oracle.cpu_baseline --worker ...``) with a hard
+timeout, so a broken worker can never hang the benchmark.
 """
-import multiprocessing as mp
+import json
 import os
+import subprocess
+import sys
 import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def available_cores() -> int:
@@ -20,15 +27,18 @@ def available_cores() -> int:
         return os.cpu_count() or 1
 
 
-def _worker(args):
-    kind, seed, first, n_reads, read_len, adapter_seq, max_errors, min_overlap, gen = args
-    import numpy as np  # noqa: F401
+def worker(kind, seed, first, n_reads, read_len, adapter_seq, max_errors, min_overlap, gen):
+    """generate reads [first, first+n_reads) and time the matching loop; returns (seconds, hits)"""
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
     from oracle import oracle as orc
     seqs, offsets = orc.synth_reads(seed, first, n_reads, read_len, [adapter_seq],
                                     gen["p_adapter"], gen["p_edit"], gen["p_n"])
     if kind == "reference":
         from oracle import ref_loader
         ref = ref_loader.load()
+        if ref is None:
+            raise RuntimeError("oracle/_ref not available")
         adapter = ref.adapters.BackAdapter(adapter_seq, max_errors=max_errors, min_overlap=min_overlap)
         raw = seqs.tobytes()
         reads = [raw[i * read_len:(i + 1) * read_len].decode("ascii") for i in range(n_reads)]
@@ -50,25 +60,45 @@ def _worker(args):
     return dt, hits
 
 
+def _spawn(job: dict):
+    env = dict(os.environ)
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    # workers never touch the GPU
+    env["HIP_VISIBLE_DEVICES"] = ""
+    env["CUDA_VISIBLE_DEVICES"] = ""
+    return subprocess.Popen([sys.executable, "-m", "oracle.cpu_baseline", "--worker", json.dumps(job)],
+                            cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+
+
 def run(seed: int, read_len: int, adapter_seq: str, max_errors: float, min_overlap: int, gen: dict,
-        target_seconds: float = 12.0, max_reads: int = 50_000_000):
+        target_seconds: float = 12.0, max_reads: int = 50_000_000, timeout: float = 180.0):
     """Returns dict(value=Mreads/s, cores=..., kind=..., sample=...)."""
     from oracle import oracle as orc
     from oracle import ref_loader
     orc.lib()
     kind = "reference" if ref_loader.load() is not None else "port"
     cores = available_cores()
-    # calibrate on one core, then size the sample for ~target_seconds on all cores
+    # calibrate on one core in-process, then size the sample for ~target_seconds on all cores
     probe = 20000
-    dt, _ = _worker((kind, seed, 0, probe, read_len, adapter_seq, max_errors, min_overlap, gen))
+    dt, _ = worker(kind, seed, 0, probe, read_len, adapter_seq, max_errors, min_overlap, gen)
     rate1 = probe / max(dt, 1e-6)
     per_worker = int(min(max(rate1 * target_seconds, 20000), max_reads / cores))
-    ctx = mp.get_context("spawn")
-    jobs = [(kind, seed, w * per_worker, per_worker, read_len, adapter_seq, max_errors, min_overlap, gen)
-            for w in range(cores)]
-    with ctx.Pool(cores) as pool:
-        results = pool.map(_worker, jobs)
-    slowest = max(r[0] for r in results)
+    base = {"kind": kind, "seed": seed, "n_reads": per_worker, "read_len": read_len,
+            "adapter_seq": adapter_seq, "max_errors": max_errors, "min_overlap": min_overlap, "gen": gen}
+    procs = [_spawn(dict(base, first=w * per_worker)) for w in range(cores)]
+    deadline = time.time() + timeout
+    results = []
+    try:
+        for p in procs:
+            out, err = p.communicate(timeout=max(1.0, deadline - time.time()))
+            if p.returncode != 0:
+                raise RuntimeError("cpu_baseline worker failed: " + err.decode(errors="replace")[-500:])
+            results.append(json.loads(out.decode().strip().splitlines()[-1]))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    slowest = max(r["seconds"] for r in results)
     total = per_worker * cores
     return {
         "value": total / slowest / 1e6,
@@ -78,5 +108,17 @@ def run(seed: int, read_len: int, adapter_seq: str, max_errors: float, min_overl
         "sample": f"{total} reads of the same synthetic workload (read indices 0..{total - 1}), "
                   f"{cores} worker processes x {per_worker} reads, match_to() loop only; "
                   f"1-core probe {rate1 / 1e6:.3f} Mreads/s",
-        "hit_fraction": sum(r[1] for r in results) / total,
+        "hit_fraction": sum(r["hits"] for r in results) / total,
     }
+
+
+if __name__ == "__main__":
+    if len(sys.argv) == 3 and sys.argv[1] == "--worker":
+        j = json.loads(sys.argv[2])
+        seconds, hits = worker(j["kind"], j["seed"], j["first"], j["n_reads"], j["read_len"],
+                               j["adapter_seq"], j["max_errors"], j["min_overlap"], j["gen"])
+        print(json.dumps({"seconds": seconds, "hits": hits}))
+    else:
+        res = run(2, 150, "AGATCGGAAGAGCACACGTCTGAACTCCAGTCA", 0.1, 3,
+                  {"p_adapter": 0.25, "p_edit": 0.02, "p_n": 0.005}, target_seconds=3.0)
+        print(json.dumps(res))
