@@ -8,7 +8,8 @@ import os
 from typing import List, Optional, Sequence, Tuple
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcutadapt_hip.so")
+# CAH_LIB_PATH: developer knob to A/B-test a differently built kernel library
+LIB_PATH = os.environ.get("CAH_LIB_PATH") or os.path.join(_HERE, "libcutadapt_hip.so")
 
 CAH_OK, CAH_EINVAL, CAH_ETYPE, CAH_EHIP, CAH_ENOMEM, CAH_EUNSUPPORTED = 0, 1, 2, 3, 4, 5
 NONE, MATCH, INVALID = 0, 1, 2

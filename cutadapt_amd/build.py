@@ -32,18 +32,26 @@ def needs_build() -> bool:
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force: bool = False, verbose: bool = False) -> str:
+def build_library(force: bool = False, verbose: bool = False, extra_flags=None, out_path=None) -> str:
+    """extra_flags/out_path: developer knobs for A/B builds of kernel variants (e.g.
+    ["-DCAH_SCHED_ROWS=4"]); the product build uses neither."""
+    if extra_flags or out_path:
+        return _build(extra_flags or [], out_path or LIB_PATH, verbose, tag="_" + str(abs(hash(tuple(extra_flags or []))) % 100000))
     if not force and not needs_build():
         return LIB_PATH
+    return _build([], LIB_PATH, verbose, tag="")
+
+
+def _build(extra_flags, lib_path, verbose, tag) -> str:
     objs = []
-    obj_dir = os.path.join(_HERE, "csrc", "_obj")
+    obj_dir = os.path.join(_HERE, "csrc", "_obj" + tag)
     os.makedirs(obj_dir, exist_ok=True)
     procs = []
     for src in SOURCES:
         obj = os.path.join(obj_dir, src + ".o")
         objs.append(obj)
-        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-x", "hip",
-               "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-x", "hip"] + list(extra_flags) + \
+              ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -51,11 +59,11 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{out.decode(errors='replace')}")
-    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", lib_path] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
-    return LIB_PATH
+    return lib_path
 
 
 if __name__ == "__main__":

@@ -24,6 +24,9 @@
 #include "kernels.h"
 
 #define WAVE 64
+#ifndef CAH_SCHED_ROWS
+#define CAH_SCHED_ROWS 1
+#endif
 
 __device__ __forceinline__ int wave_lane() { return threadIdx.x & (WAVE - 1); }
 
@@ -54,6 +57,64 @@ __device__ __forceinline__ int64_t wave_dequeue(unsigned long long* counter) {
     unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)base);
     unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
     return (int64_t)(((unsigned long long)hi << 32) | lo);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Read bytes: 16 characters per lane per global load, held in four VGPRs.
+// Reads are packed back to back, so a read starts at an arbitrary byte; gfx950 executes
+// unaligned global_load_dwordx4.  load_chunk never touches memory outside q[0, n):
+//   interior chunk  -> one 16-byte load at q + pos
+//   last chunk      -> the 16 bytes that END at the read end, funnel-shifted down
+//   reads < 16 bytes-> assembled from byte loads
+// Characters at positions >= limit come back as NUL (which matches nothing in any table).
+// ---------------------------------------------------------------------------------------------
+struct Chunk { unsigned w[4]; };
+
+struct __attribute__((packed, aligned(1))) Unaligned16 { unsigned w[4]; };
+
+__device__ __forceinline__ Chunk load_chunk(const uint8_t* q, int pos, int n, int limit) {
+    Chunk c;
+    c.w[0] = c.w[1] = c.w[2] = c.w[3] = 0;
+    if (pos >= limit) return c;
+    if (pos + 16 <= n) {
+        Unaligned16 u;
+        __builtin_memcpy(&u, q + pos, 16);
+        c.w[0] = u.w[0]; c.w[1] = u.w[1]; c.w[2] = u.w[2]; c.w[3] = u.w[3];
+    } else if (n >= 16) {
+        Unaligned16 u;
+        __builtin_memcpy(&u, q + (n - 16), 16);
+        const int s = pos - (n - 16);                     // 1..15 bytes to drop
+        const int dw = s >> 2, sh = (s & 3) * 8;
+        unsigned x0 = u.w[0], x1 = u.w[1], x2 = u.w[2], x3 = u.w[3];
+        if (dw >= 2) { x0 = x2; x1 = x3; x2 = 0; x3 = 0; }
+        if (dw & 1) { x0 = x1; x1 = x2; x2 = x3; x3 = 0; }
+        c.w[0] = (unsigned)((((unsigned long long)x1 << 32) | x0) >> sh);
+        c.w[1] = (unsigned)((((unsigned long long)x2 << 32) | x1) >> sh);
+        c.w[2] = (unsigned)((((unsigned long long)x3 << 32) | x2) >> sh);
+        c.w[3] = x3 >> sh;
+    } else {
+#pragma unroll
+        for (int t = 0; t < 15; ++t)                      // static indices: the chunk stays in VGPRs
+            if (pos + t < n) c.w[t >> 2] |= (unsigned)q[pos + t] << ((t & 3) * 8);
+    }
+    const int keep = limit - pos;                         // characters of this chunk inside [pos, limit)
+    if (keep < 16) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int v = keep - 4 * i;                   // valid bytes in dword i
+            const unsigned msk = v >= 4 ? 0xFFFFFFFFu : (v <= 0 ? 0u : ((1u << (8 * v)) - 1u));
+            c.w[i] &= msk;
+        }
+    }
+    return c;
+}
+
+// byte t (0..15) of a chunk; t is wave-uniform or a compile-time constant
+__device__ __forceinline__ unsigned chunk_byte(const Chunk& c, int t) {
+    const int d = t >> 2;
+    const unsigned w = d == 0 ? c.w[0] : (d == 1 ? c.w[1] : (d == 2 ? c.w[2] : c.w[3]));
+    return (w >> ((t & 3) * 8)) & 0xFFu;
 }
 
 // =============================================================================================
@@ -100,17 +161,27 @@ __global__ __launch_bounds__(256) void k_filter(FilterArgs a) {
             const uint64_t* tbl_g = words[w].mask;
             const uint64_t* tbl_s = s_mask + w * CAH_TABLE_CHARS;
             const bool in_lds = w < lds_words;
-            uint64_t R = 0;
-            for (int64_t t = 0; __any(t < len && !hit); ++t) {
-                if (t < len && !hit) {
-                    const unsigned ch = q[start + t];
-                    uint64_t mk = 0;
-                    if (ch < CAH_TABLE_CHARS) mk = in_lds ? tbl_s[ch] : tbl_g[ch];
-                    else invalid = true;
-                    R = ((R << 1) | init) & mk;
-                    hit = (R & found) != 0;
+            // shift-and over the window, 16 characters per global load; the hit test is
+            // accumulated and looked at once per chunk (early-out granularity 16 characters)
+            const int wstart = (int)start, wstop = (int)(start + len);
+            const int ni = (int)n;
+            uint64_t R = 0, acc = 0;
+            unsigned seen = 0;
+            for (int pos = wstart; __any(pos < wstop && !hit); pos += 16) {
+                if (pos < wstop && !hit) {
+                    const Chunk ck = load_chunk(q, pos, ni, wstop);
+                    seen |= ck.w[0] | ck.w[1] | ck.w[2] | ck.w[3];
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) {
+                        const unsigned ch = chunk_byte(ck, t) & (CAH_TABLE_CHARS - 1);
+                        const uint64_t mk = in_lds ? tbl_s[ch] : tbl_g[ch];
+                        R = ((R << 1) | init) & mk;
+                        acc |= R & found;
+                    }
+                    hit = acc != 0;
                 }
             }
+            if (seen & 0x80808080u) invalid = true;
             if (__all(hit || !valid)) break;
         }
 
@@ -175,6 +246,7 @@ __device__ __forceinline__ void dp_rows(int (&c)[ROWS + 1], int (&p)[ROWS + 1], 
         if constexpr (I > ROWS - 8) {                     // m is in (ROWS-8, ROWS]: wave-uniform capture
             if (I == m) { cm_c = cost; cm_p = pay; }
         }
+        if constexpr ((I % CAH_SCHED_ROWS) == 0) __builtin_amdgcn_sched_barrier(0);
         dp_rows<I + 1, ROWS>(c, p, mk, oc, op, nl, cm_c, cm_p, last, m, k, D);   // diag := old cell (:479)
     }
 }
@@ -182,8 +254,35 @@ __device__ __forceinline__ void dp_rows(int (&c)[ROWS + 1], int (&p)[ROWS + 1], 
 // =============================================================================================
 // k_dp<ROWS>: the banded semi-global aligner, one read per lane, column in VGPRs.
 // =============================================================================================
+
+// Row i (wave-uniform) of the register-resident column, via a scalar switch.
+#define CAH_ROW_CASE(K) case K: if constexpr (K <= ROWS) { ci = c[K]; pi = p[K]; } break;
 template <int ROWS>
-__global__ __launch_bounds__(256) void k_dp(DpArgs a) {
+__device__ __forceinline__ void get_row(const int (&c)[ROWS + 1], const int (&p)[ROWS + 1], int i, int& ci, int& pi) {
+    ci = 0; pi = 0;
+    switch (__builtin_amdgcn_readfirstlane(i)) {
+        CAH_ROW_CASE(0) CAH_ROW_CASE(1) CAH_ROW_CASE(2) CAH_ROW_CASE(3) CAH_ROW_CASE(4) CAH_ROW_CASE(5) CAH_ROW_CASE(6) CAH_ROW_CASE(7)
+        CAH_ROW_CASE(8) CAH_ROW_CASE(9) CAH_ROW_CASE(10) CAH_ROW_CASE(11) CAH_ROW_CASE(12) CAH_ROW_CASE(13) CAH_ROW_CASE(14) CAH_ROW_CASE(15)
+        CAH_ROW_CASE(16) CAH_ROW_CASE(17) CAH_ROW_CASE(18) CAH_ROW_CASE(19) CAH_ROW_CASE(20) CAH_ROW_CASE(21) CAH_ROW_CASE(22) CAH_ROW_CASE(23)
+        CAH_ROW_CASE(24) CAH_ROW_CASE(25) CAH_ROW_CASE(26) CAH_ROW_CASE(27) CAH_ROW_CASE(28) CAH_ROW_CASE(29) CAH_ROW_CASE(30) CAH_ROW_CASE(31)
+        CAH_ROW_CASE(32) CAH_ROW_CASE(33) CAH_ROW_CASE(34) CAH_ROW_CASE(35) CAH_ROW_CASE(36) CAH_ROW_CASE(37) CAH_ROW_CASE(38) CAH_ROW_CASE(39)
+        CAH_ROW_CASE(40) CAH_ROW_CASE(41) CAH_ROW_CASE(42) CAH_ROW_CASE(43) CAH_ROW_CASE(44) CAH_ROW_CASE(45) CAH_ROW_CASE(46) CAH_ROW_CASE(47)
+        CAH_ROW_CASE(48) CAH_ROW_CASE(49) CAH_ROW_CASE(50) CAH_ROW_CASE(51) CAH_ROW_CASE(52) CAH_ROW_CASE(53) CAH_ROW_CASE(54) CAH_ROW_CASE(55)
+        CAH_ROW_CASE(56) CAH_ROW_CASE(57) CAH_ROW_CASE(58) CAH_ROW_CASE(59) CAH_ROW_CASE(60) CAH_ROW_CASE(61) CAH_ROW_CASE(62) CAH_ROW_CASE(63)
+        CAH_ROW_CASE(64)
+        default: break;
+    }
+}
+
+// Register budget: 2*(ROWS+1) VGPRs hold the column; ask the register allocator for an occupancy
+// that leaves room for that plus ~40 temporaries (without the bound the scheduler hoists all the
+// chain-independent work of a column up front and lands at 256 VGPRs = 1 wave per SIMD).
+#ifndef CAH_DP_WAVES
+#define CAH_DP_WAVES(ROWS) ((ROWS) <= 16 ? 5 : ((ROWS) <= 40 ? 4 : ((ROWS) <= 56 ? 3 : 2)))
+#endif
+
+template <int ROWS>
+__global__ __launch_bounds__(256, CAH_DP_WAVES(ROWS)) void k_dp(DpArgs a) {
     __shared__ uint64_t s_rowmask[CAH_TABLE_CHARS];
     __shared__ int s_ncnt[CAH_MAX_M + 1];
     __shared__ int s_thr[CAH_MAX_M + 1];
@@ -259,72 +358,94 @@ __global__ __launch_bounds__(256) void k_dp(DpArgs a) {
         int j = min_n;
         bool done = !valid;
 
+        // Columns are walked in lock step by all lanes (lane-local column j = min_n + 1 + step);
+        // the read characters arrive 16 per global load and the next chunk is requested before
+        // the current one is consumed, so its latency hides behind 16 columns of DP.
+        int pos = min_n;
+        Chunk cur = load_chunk(q, pos, n, valid ? max_n : 0);
         for (;;) {
-            const bool act = !done && j < max_n;
-            if (!__any(act)) break;
-            if (act) {
-                ++j;
-                const unsigned ch = q[j - 1];
-                uint64_t mk = 0;
-                if (ch < CAH_TABLE_CHARS) mk = s_rowmask[ch]; else invalid = true;
+            if (!__any(!done && j < max_n)) break;
+            const Chunk nxt = load_chunk(q, pos + 16, n, (!done) ? max_n : 0);
+#pragma unroll 1
+            for (int t = 0; t < 16; ++t) {                // t is wave-uniform
+                const bool act = !done && j < max_n;
+                if (!__any(act)) break;
+                if (act) {
+                    ++j;
+                    const unsigned ch = chunk_byte(cur, t);
+                    uint64_t mk = 0;
+                    if (ch < CAH_TABLE_CHARS) mk = s_rowmask[ch]; else invalid = true;
 
-                int dc = c[0], dp = p[0];                 // diagonal for row 1
-                c[0] += row0_cost_inc;
-                p[0] += row0_pay_inc;
-                int nl = c[0] <= k ? 0 : -1;              // largest computed row with cost <= k
-                int cm_c = c[0], cm_p = p[0];             // cell (m, j), captured for the candidate test
-                                                          // (row 0 itself when m == 0)
-                dp_rows<1, ROWS>(c, p, mk, dc, dp, nl, cm_c, cm_p, last, m, k, D);
-                last_filled = last;                       // :484
-                if (last >= 1) lf_ran = last;
-                // band update (:490-495)
-                if (nl < m) {
-                    last = nl + 1;
-                } else {
-                    last = m;
-                    if (stop_in_query) {                  // candidate in the last row (:496-533)
-                        const int cost = cm_c, origin = cell_origin(cm_p), score = cell_score(cm_p);
-                        const int length = m + min(origin, 0);
-                        int eff = length;
-                        if (wildcard_ref)
-                            eff = length < m ? length - (s_ncnt[m] - s_ncnt[m - length]) : eff_full;
-                        const bool ok = length >= min_overlap && cost <= s_thr[eff];
-                        const int b_origin = cell_origin(b_pay), b_score = cell_score(b_pay);
-                        const int best_len = m + min(b_origin, 0);
-                        if (ok && (b_cost == SENT || (origin <= b_origin + half_m && score > b_score) ||
-                                   (length > best_len && score > b_score))) {
-                            b_cost = cost; b_pay = cm_p; b_refstop = m; b_qstop = j;
-                            if (cost == 0 && origin >= 0) done = true;   // exact match: stop early
+                    int dc = c[0], dp = p[0];                 // diagonal for row 1
+                    c[0] += row0_cost_inc;
+                    p[0] += row0_pay_inc;
+                    int nl = c[0] <= k ? 0 : -1;              // largest computed row with cost <= k
+                    int cm_c = c[0], cm_p = p[0];             // cell (m, j), captured for the candidate test
+                                                              // (row 0 itself when m == 0)
+                    dp_rows<1, ROWS>(c, p, mk, dc, dp, nl, cm_c, cm_p, last, m, k, D);
+                    last_filled = last;                       // :484
+                    if (last >= 1) lf_ran = last;
+                    // band update (:490-495)
+                    if (nl < m) {
+                        last = nl + 1;
+                    } else {
+                        last = m;
+                        if (stop_in_query) {                  // candidate in the last row (:496-533)
+                            const int cost = cm_c, origin = cell_origin(cm_p), score = cell_score(cm_p);
+                            const int length = m + min(origin, 0);
+                            int eff = length;
+                            if (wildcard_ref)
+                                eff = length < m ? length - (s_ncnt[m] - s_ncnt[m - length]) : eff_full;
+                            const bool ok = length >= min_overlap && cost <= s_thr[eff];
+                            const int b_origin = cell_origin(b_pay), b_score = cell_score(b_pay);
+                            const int best_len = m + min(b_origin, 0);
+                            if (ok && (b_cost == SENT || (origin <= b_origin + half_m && score > b_score) ||
+                                       (length > best_len && score > b_score))) {
+                                b_cost = cost; b_pay = cm_p; b_refstop = m; b_qstop = j;
+                                if (cost == 0 && origin >= 0) done = true;   // exact match: stop early
+                            }
                         }
                     }
                 }
             }
+            pos += 16;
+            cur = nxt;
         }
 
         // last column (:536-572).  The update test uses the *stale* scalar `origin`: the origin
         // of the last cell the row loop wrote, i.e. cell lf_ran of the column it last ran in.
-        if (valid && max_n == n) {
-            int stale_origin = 0;
+        int stale_origin = 0, scan_lo = 0;
+        {
+            int stale_p = pack_cell(0, 0);
 #pragma unroll
-            for (int i = 1; i <= ROWS; ++i)
-                if (i == lf_ran) stale_origin = cell_origin(p[i]);
+            for (int i = 1; i <= ROWS; ++i) stale_p = (i == lf_ran) ? p[i] : stale_p;
+            stale_origin = cell_origin(stale_p);
             const int first_i = stop_in_ref ? 0 : m;
-#pragma unroll
-            for (int i = ROWS; i >= 0; --i) {
-                if (i <= last_filled && i >= first_i) {
-                    const int o_i = cell_origin(p[i]), score = cell_score(p[i]), cost = c[i];
-                    const int ref_start = -min(o_i, 0);
-                    const int length = i - ref_start;
-                    int eff = length;
-                    if (wildcard_ref)
-                        eff = length < m ? length - (s_ncnt[i] - s_ncnt[ref_start]) : eff_full;
-                    const bool ok = length >= min_overlap && cost <= s_thr[eff];
-                    const int b_origin = cell_origin(b_pay), b_score = cell_score(b_pay);
-                    const int best_len = b_refstop + min(b_origin, 0);
-                    if (ok && (b_cost == SENT || (stale_origin <= b_origin + half_m && score > b_score) ||
-                               (length > best_len && score > b_score))) {
-                        b_cost = cost; b_pay = p[i]; b_refstop = i; b_qstop = n;
-                    }
+            scan_lo = first_i;
+        }
+        // The scan itself is a ROLLED loop over a wave-uniform row index; the row is fetched
+        // from the register column with a scalar switch.  (Unrolling it 65 times makes the
+        // compiler keep hundreds of temporaries alive and spill inside the DP loop.)
+        const bool scan_lane = valid && max_n == n;
+#pragma unroll 1
+        for (int i = m; i >= 0; --i) {
+            const bool want = scan_lane && i <= last_filled && i >= scan_lo;
+            if (!__any(want)) continue;
+            int ci, pi;
+            get_row<ROWS>(c, p, i, ci, pi);
+            if (want) {
+                const int o_i = cell_origin(pi), score = cell_score(pi), cost = ci;
+                const int ref_start = -min(o_i, 0);
+                const int length = i - ref_start;
+                int eff = length;
+                if (wildcard_ref)
+                    eff = length < m ? length - (s_ncnt[i] - s_ncnt[ref_start]) : eff_full;
+                const bool ok = length >= min_overlap && cost <= s_thr[eff];
+                const int b_origin = cell_origin(b_pay), b_score = cell_score(b_pay);
+                const int best_len = b_refstop + min(b_origin, 0);
+                if (ok && (b_cost == SENT || (stale_origin <= b_origin + half_m && score > b_score) ||
+                           (length > best_len && score > b_score))) {
+                    b_cost = cost; b_pay = pi; b_refstop = i; b_qstop = n;
                 }
             }
         }
