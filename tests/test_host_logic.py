@@ -1,0 +1,146 @@
+"""Host-side logic and the C-ABI surface -- CPU only (no kernel is launched here)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def norm(sets):
+    return sorted([[s, e, sorted(k)] for s, e, k in sets], key=lambda x: (x[0], -1 if x[1] is None else x[1]))
+
+
+def test_kmer_heuristic_matches_reference_golden(golden):
+    from cutadapt_amd.kmer_heuristic import create_positions_and_kmers
+    cases = golden("heuristic.json")
+    assert len(cases) >= 300
+    for c in cases:
+        got = create_positions_and_kmers(c["adapter"], c["min_overlap"], c["error_rate"],
+                                         c["back"], c["front"], c["internal"])
+        assert norm(got) == c["result"], c
+
+
+def test_kmer_heuristic_known_sets():
+    """the TruSeq / e=0.1 / O=3 search sets quoted in SURVEY.md section 8(a) a10"""
+    from cutadapt_amd.kmer_heuristic import create_positions_and_kmers, kmer_chunks
+    assert kmer_chunks("AABCABCABC", 3) == {"AABC", "ABC"}         # reference kmer_heuristic.py:8-9
+    sets = create_positions_and_kmers("AGATCGGAAGAGCACACGTCTGAACTCCAGTCA", 3, 0.1, True, False)
+    d = {(s, e): sorted(k) for s, e, k in sets}
+    assert d[(-3, None)] == ["AGA"] and d[(-4, None)] == ["AGAT"]
+    assert d[(-19, None)] == ["AGATC", "GGAAG"]
+    assert len(d[(-29, None)]) == 3 and len(d[(-33, None)]) == 4 and len(d[(0, None)]) == 4
+    assert "".join(sorted(d[(0, None)], key="AGATCGGAAGAGCACACGTCTGAACTCCAGTCA".index)) == \
+        "AGATCGGAAGAGCACACGTCTGAACTCCAGTCA"
+    # front adapters mirror the windows to the read start
+    fs = create_positions_and_kmers("ACGTACGTAC", 3, 0.1, False, True)
+    assert all(s == 0 for s, _, _ in fs)
+
+
+def test_library_is_built_and_exports_every_declared_symbol():
+    """every function include/cutadapt_hip.h declares is exported by the in-tree .so"""
+    from cutadapt_amd import _lib
+    header = open(os.path.join(ROOT, "include", "cutadapt_hip.h")).read()
+    declared = set(re.findall(r"\b(cah_[a-z0-9_]+)\s*\(", header))
+    declared -= {"cah_plan", "cah_kmer_set", "cah_adapter_desc"}
+    assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
+    assert os.path.exists(_lib.LIB_PATH), "build the library first: python -m cutadapt_amd.build"
+    L = _lib.lib()
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.cah_abi_version() == 1
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (cah_[a-z0-9_]+)", out))
+    assert declared <= exported
+    # the hot-path library must not depend on the oracle or on libtorch
+    ldd = subprocess.run(["ldd", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in ldd and "torch" not in ldd
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "cutadapt_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f), errors="replace").read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
+                assert "cutadapt_oracle" not in src and "orc_" not in src, f
+
+
+def test_plan_validation_matches_reference_errors():
+    """constructor errors are raised on the host, before any device is touched
+    (reference _align.pyx:217-218, :270-271, :631-636; _kmer_finder.pyx:133-140)"""
+    from cutadapt_amd import _lib
+    S = _lib.MatcherSpec
+    with pytest.raises(ValueError, match="only N wildcards"):
+        _lib.Plan([S("NNNN", 0.1, wildcard_ref=True)])
+    with pytest.raises(ValueError, match="indel_cost"):
+        _lib.Plan([S("ACGT", 0.1, indel_cost=0)])
+    with pytest.raises(ValueError, match="between 0 and 1"):
+        _lib.Plan([S("ACGT", 1.5, kind=_lib.KIND_PREFIX)])
+    with pytest.raises(ValueError, match="min_overlap"):
+        _lib.Plan([S("ACGT", 0.1, min_overlap=0, kind=_lib.KIND_SUFFIX)])
+    with pytest.raises(ValueError, match="longer than the maximum"):
+        _lib.Plan([S(kind=_lib.KIND_KMER_ONLY, kmer_sets=[(0, None, ["A" * 65])])])
+    with pytest.raises(TypeError):
+        _lib.Plan([S(kind=_lib.KIND_KMER_ONLY, kmer_sets=[(0, None, [b"ACGT"])])])
+    with pytest.raises(ValueError, match="ASCII"):
+        _lib.Plan([S("ACGÜ", 0.1)])
+    with pytest.raises(_lib.UnsupportedByHipPath):
+        _lib.Plan([S("A" * 65, 0.1)])
+    # valid plans are built on the host without a GPU; tables are uploaded lazily per device
+    plan = _lib.Plan([S("AGGNNNNNNNNNNNNNNTTC", 0.1, 14, wildcard_ref=True, min_overlap=3),
+                      S("CNNNNNNNNGTT", 0.25, wildcard_ref=True, kind=_lib.KIND_PREFIX),
+                      S(kind=_lib.KIND_KMER_ONLY,
+                        kmer_sets=[(0, None, ["ACGT" * 10] * 3), (-5, None, ["AC", "GT"])])])
+    assert plan.effective_length(0) == 6          # reference tests/test_align.py:336
+    assert plan.effective_length(1) == 4
+    assert plan.n_kmer_entries(2) == 4            # 3 x 40 chars need 3 words (+1 for the second set)
+    assert plan.n_kmer_entries(0) == 0
+
+
+def test_no_silent_cpu_fallback_without_gpu():
+    """without a HIP device the batch entry points fail loudly"""
+    from cutadapt_amd import _lib
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is present")
+    from cutadapt_amd.align import Aligner
+    a = Aligner("ACGTACGT", 0.1)               # host-only construction works
+    with pytest.raises(RuntimeError):
+        a.locate("TTACGTACGTTT")
+
+
+def test_pack_strings_and_ascii_check():
+    from cutadapt_amd.batch import pack_strings
+    seqs, offsets = pack_strings(["ACGT", "", "TTGCA"])
+    assert offsets.tolist() == [0, 4, 4, 9] and bytes(seqs) == b"ACGTTTGCA"
+    with pytest.raises(ValueError):
+        pack_strings(["ACGÜ"])
+    with pytest.raises(TypeError):
+        pack_strings([b"ACGT"])
+
+
+def test_adapter_parameter_normalisation():
+    """SingleAdapter.__init__ rules (reference adapters.py:577-595) -- pure host logic"""
+    from cutadapt_amd import adapters as A
+    a = A.BackAdapter("acgun", max_errors=2, min_overlap=10)
+    assert a.sequence == "ACGTN" and a.min_overlap == 5
+    assert a.max_error_rate == 2 / 4           # absolute errors / non-N characters
+    assert a.adapter_wildcards is True
+    assert A.BackAdapter("ACGT").adapter_wildcards is False      # plain ACGT: no wildcard mode
+    with pytest.raises(ValueError):
+        A.BackAdapter("")
+    with pytest.raises(A.InvalidCharacter):
+        A.BackAdapter("ACGZ")
+    assert A.Where.BACK == 14 and A.Where.FRONT == 11 and A.Where.PREFIX == 8 and A.Where.SUFFIX == 2
+    assert A.Where.FRONT_NOT_INTERNAL == 9 and A.Where.BACK_NOT_INTERNAL == 6 and A.Where.ANYWHERE == 15
+    p = A.PrefixAdapter("ACGTACGT", indels=False)
+    assert type(p.aligner).__name__ == "PrefixComparer" and isinstance(p.kmer_finder, A.MockKmerFinder)
+    assert type(A.SuffixAdapter("ACGTACGT").aligner).__name__ == "Aligner"
+    long_ad = A.BackAdapter("ACGT" * 16)            # 64 chars: k-mers fit
+    assert long_ad.kmer_finder is not None
+    m = A.RemoveAfterMatch(0, 4, 10, 14, 4, 0, adapter=a, sequence="ACGTACGTAAACGTTT")
+    assert m.trimmed("ACGTACGTAAACGTTT") == "ACGTACGTAA" and m.rest() == "TT"
+    assert m.remainder_interval() == (0, 10) and m.removed_sequence_length() == 6
