@@ -109,7 +109,7 @@ def main():
     dp_ms = ms[_lib.PROF_DP] / max(launches[_lib.PROF_DP], 1)
     # reads the DP kernel actually processed = survivors of the prefilter (queue length)
     ws = batch.workspace()
-    survivors = int(ws[8:16].view(torch.int64).item())
+    survivors = int(ws[256:264].view(torch.int64).item())     # queue count (workspace layout, api.cpp)
     status = out.status
     n_match = int((status == 1).sum().item())
     n_invalid = int((status == 2).sum().item())

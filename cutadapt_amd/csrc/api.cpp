@@ -438,13 +438,15 @@ int cah_profile_read(double ms[CAH_PROF_N], int64_t launches[CAH_PROF_N], int64_
 // ---------------------------------------------------------------------------------------------
 // batch entry points
 // ---------------------------------------------------------------------------------------------
-// workspace layout: [0,8) work counter A | [8,16) queue count | [16,24) work counter B |
-//                   [64, 64 + 4*n_reads) queue
-static const size_t WS_HEADER = 64;
+// workspace layout: three counters, each on its own 256-byte line (they are hammered by
+// different kernels), then the survivor queue:
+//   [0,8) filter tile counter | [256,264) queue count | [512,520) DP work counter | [1024, +4n) queue
+static const size_t WS_HEADER = 1024;
+static const size_t WS_QCOUNT = 256 / sizeof(unsigned long long), WS_DPWORK = 512 / sizeof(unsigned long long);
 
 size_t cah_workspace_bytes(int64_t n_reads) {
     if (n_reads < 0) n_reads = 0;
-    return WS_HEADER + sizeof(int32_t) * (size_t)n_reads + 64;
+    return WS_HEADER + sizeof(int32_t) * (size_t)n_reads + 256;
 }
 
 static int check_batch(const cah_plan* plan, const void* d_seqs, const void* d_offsets, int64_t n_reads) {
@@ -575,12 +577,12 @@ int cah_match_batch(const cah_plan* plan, const uint8_t* d_seqs, const int64_t* 
         if (mt.has_filter) {
             // prefilter -> queue of surviving reads -> DP on dense waves
             rc = run_filter(plan, pd, ad, d_seqs, d_offsets, d_lens, n_reads, 1, nullptr, d_status, d_queue,
-                            counters + 1, counters + 0, s);
+                            counters + WS_QCOUNT, counters + 0, s);
             if (rc) return rc;
-            rc = run_aligner(plan, pd, ad, d_seqs, d_offsets, d_lens, n_reads, d_queue, counters + 1,
-                             counters + 2, d_out6, d_status, d_best_adapter, 1, s);
+            rc = run_aligner(plan, pd, ad, d_seqs, d_offsets, d_lens, n_reads, d_queue, counters + WS_QCOUNT,
+                             counters + WS_DPWORK, d_out6, d_status, d_best_adapter, 1, s);
         } else {
-            rc = run_aligner(plan, pd, ad, d_seqs, d_offsets, d_lens, n_reads, nullptr, nullptr, counters + 2,
+            rc = run_aligner(plan, pd, ad, d_seqs, d_offsets, d_lens, n_reads, nullptr, nullptr, counters + WS_DPWORK,
                              d_out6, d_status, d_best_adapter, 1, s);
         }
         if (rc) return rc;

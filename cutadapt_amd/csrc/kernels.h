@@ -5,6 +5,8 @@
 
 #include "cah_device.h"
 
+#define CAH_QUEUE_BINS 64          // survivor queue is ordered by min(first-hit position / 16, 63)
+
 struct FilterArgs {
     const CahKmerWord* words;        // this adapter's packed shift-and words (HBM)
     int32_t n_words;
@@ -16,7 +18,7 @@ struct FilterArgs {
     unsigned long long* work_counter;   // zeroed before launch
     uint8_t* present;                // MODE 0
     uint8_t* status;                 // MODE 1: only written for invalid reads
-    int32_t* queue;                  // MODE 1: surviving read indices
+    int32_t* queue;                  // MODE 1: surviving read indices, in runs ordered by hit position
     unsigned long long* queue_count; // MODE 1: zeroed before launch
 };
 

@@ -118,94 +118,199 @@ __device__ __forceinline__ unsigned chunk_byte(const Chunk& c, int t) {
 }
 
 // =============================================================================================
-// k_filter: multi-pattern shift-and prefilter.  One read per lane; the packed k-mer words of
-// the adapter are wave-uniform, their 128 x 64-bit character masks sit in LDS.
-// MODE 0: write present[r];  MODE 1: append surviving read indices to the DP work queue with
-// one ballot + popcount + a single atomic per wave.
+// k_filter: multi-pattern shift-and prefilter (KmerFinder.kmers_present).
+//
+// One read per lane, ONE pass over the read: characters arrive 16 per global load (next chunk
+// requested before the current one is consumed) and every packed word whose window overlaps
+// the chunk is advanced on it, its shift-and state R and an OR-accumulator living in VGPRs
+// (up to FILTER_SLOTS words at a time).  Because (OR_t R_t) & found == OR_t (R_t & found), the
+// hit test is done once per chunk instead of per character.  Character masks (1 KiB per word)
+// are in LDS.  Windows follow _kmer_finder.pyx:188-204 per read; a positive stop beyond the
+// read end is clamped (the reference reads out of bounds there).
+// MODE 0: write present[r].   MODE 1: append survivors to the DP work queue (one ballot +
+// popcount + a single atomic per wave) together with a key = chunk index of the first hit,
+// and count keys per bin so that the queue can be ordered by approximate adapter position.
 // =============================================================================================
-#define FILTER_LDS_WORDS 32
+#define FILTER_SLOTS 8
 
-template <int MODE>
-__global__ __launch_bounds__(256) void k_filter(FilterArgs a) {
-    __shared__ uint64_t s_mask[FILTER_LDS_WORDS * CAH_TABLE_CHARS];
+__device__ __forceinline__ void word_window(const int64_t wstart, const int64_t wstop, const int n,
+                                            int& ws, int& we) {
+    int64_t start = wstart, stop = wstop;
+    bool empty = false;
+    if (start < 0) { start += n; if (start < 0) start = 0; }
+    else if (start > n) empty = true;
+    if (stop < 0) { stop += n; if (stop <= 0) empty = true; }
+    else if (stop == 0) stop = n;
+    if (stop > n) stop = n;
+    if (stop <= start) empty = true;
+    ws = empty ? 0 : (int)start;
+    we = empty ? 0 : (int)stop;
+}
+
+template <bool MASKED>
+__device__ __forceinline__ void filter_word_chunk(const Chunk& ck, const uint64_t* tbl, const uint64_t init,
+                                                  uint64_t& R, uint64_t& acc, const int lo, const int hi) {
+    // lo/hi: first / one-past-last chunk character (0..16) inside this word's window (MASKED only)
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const unsigned ch = chunk_byte(ck, t) & (CAH_TABLE_CHARS - 1);
+        uint64_t mk = tbl[ch];
+        if (MASKED) mk = (t >= lo && t < hi) ? mk : 0ull;
+        R = ((R << 1) | init) & mk;
+        acc |= R;
+    }
+}
+
+// Work is handed out in TILES of FILTER_TILE reads per workgroup (one global atomic per tile:
+// a single hot counter sustains only ~90 atomics/us on this chip, so per-wave dequeues and
+// per-wave queue appends would bound the whole kernel).  Survivors of a tile are collected in
+// LDS, ordered by key with an LDS counting sort and appended to the global queue as one run.
+// The DP kernel takes 64 consecutive queue entries per wave, so its lanes hold reads whose
+// adapters sit at similar columns and their Ukkonen bands widen and narrow together.
+#define FILTER_TILE 4096
+#define FILTER_WAVES 4
+
+template <int MODE, bool LDS_TABLES>
+__global__ __launch_bounds__(256, 4) void k_filter(FilterArgs a) {
+    // all LDS is carved from the dynamic region (16-byte aligned offsets; a static __shared__
+    // in front of it could misalign the 8-byte table reads):
+    //   [tables: n_words KiB] [s_idx: 16 KiB] [s_key: 4 KiB] [s_hist] [s_cursor] [scalars]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const CahKmerWord* words = a.words;
     const int n_words = a.n_words;
-    const int lds_words = n_words < FILTER_LDS_WORDS ? n_words : FILTER_LDS_WORDS;
-    for (int i = threadIdx.x; i < lds_words * CAH_TABLE_CHARS; i += blockDim.x)
-        s_mask[i] = words[i / CAH_TABLE_CHARS].mask[i % CAH_TABLE_CHARS];
-    __syncthreads();
-
+    uint64_t* s_mask = reinterpret_cast<uint64_t*>(smem);
+    unsigned char* sp = smem + (LDS_TABLES ? (size_t)n_words * CAH_TABLE_CHARS * sizeof(uint64_t) : 0);
+    int32_t* s_idx = reinterpret_cast<int32_t*>(sp);             sp += FILTER_TILE * sizeof(int32_t);
+    uint8_t* s_key = sp;                                         sp += FILTER_TILE;
+    unsigned* s_hist = reinterpret_cast<unsigned*>(sp);          sp += CAH_QUEUE_BINS * sizeof(unsigned);
+    unsigned* s_cursor = reinterpret_cast<unsigned*>(sp);        sp += CAH_QUEUE_BINS * sizeof(unsigned);
+    unsigned long long& s_qbase = *reinterpret_cast<unsigned long long*>(sp);
+    long long& s_tile = *reinterpret_cast<long long*>(sp + 8);
+    unsigned& s_count = *reinterpret_cast<unsigned*>(sp + 16);
+    if (LDS_TABLES) {
+        for (int i = threadIdx.x; i < n_words * CAH_TABLE_CHARS; i += blockDim.x)
+            s_mask[i] = words[i / CAH_TABLE_CHARS].mask[i % CAH_TABLE_CHARS];
+    }
     const int lane = wave_lane();
-    for (;;) {
-        const int64_t base = wave_dequeue(a.work_counter);
-        if (base >= a.n_reads) break;
-        const int64_t r = base + lane;
-        const bool valid = r < a.n_reads;
-        int64_t off = 0, n = 0;
-        if (valid) read_extent(a.offsets, a.lens, r, off, n);
-        const uint8_t* q = a.seqs + off;
-        bool hit = false, invalid = false;
-        if (n > a.max_read_len) { invalid = true; n = 0; }
+    const int wave = threadIdx.x >> 6;
 
-        for (int w = 0; w < n_words; ++w) {
-            // window of this word on this lane's read (_kmer_finder.pyx:188-204)
-            int64_t start = words[w].start, stop = words[w].stop;
-            bool skip = !valid || hit;
-            if (start < 0) { start += n; if (start < 0) start = 0; }
-            else if (start > n) skip = true;
-            if (stop < 0) { stop += n; if (stop <= 0) skip = true; }
-            else if (stop == 0) stop = n;
-            if (stop > n) stop = n;  // the reference reads past the buffer here (UB); clamp
-            int64_t len = skip ? 0 : stop - start;
-            const uint64_t init = words[w].init_mask, found = words[w].found_mask;
-            const uint64_t* tbl_g = words[w].mask;
-            const uint64_t* tbl_s = s_mask + w * CAH_TABLE_CHARS;
-            const bool in_lds = w < lds_words;
-            // shift-and over the window, 16 characters per global load; the hit test is
-            // accumulated and looked at once per chunk (early-out granularity 16 characters)
-            const int wstart = (int)start, wstop = (int)(start + len);
-            const int ni = (int)n;
-            uint64_t R = 0, acc = 0;
+    for (;;) {
+        __syncthreads();                                 // previous tile fully flushed
+        if (threadIdx.x == 0) {
+            s_tile = (long long)atomicAdd(a.work_counter, (unsigned long long)FILTER_TILE);
+            s_count = 0;
+        }
+        if (threadIdx.x < CAH_QUEUE_BINS) { s_hist[threadIdx.x] = 0; s_cursor[threadIdx.x] = 0; }
+        __syncthreads();
+        const int64_t tile_base = s_tile;
+        if (tile_base >= a.n_reads) break;
+
+        for (int sub = wave; sub < FILTER_TILE / WAVE; sub += FILTER_WAVES) {
+            const int64_t base = tile_base + (int64_t)sub * WAVE;
+            if (base >= a.n_reads) break;
+            const int64_t r = base + lane;
+            const bool valid = r < a.n_reads;
+            int64_t off = 0, n64 = 0;
+            if (valid) read_extent(a.offsets, a.lens, r, off, n64);
+            const uint8_t* q = a.seqs + off;
+            bool hit = false, invalid = false;
+            if (n64 > a.max_read_len) { invalid = true; n64 = 0; }
+            const int n = (int)n64;
+            int hit_pos = 0;
             unsigned seen = 0;
-            for (int pos = wstart; __any(pos < wstop && !hit); pos += 16) {
-                if (pos < wstop && !hit) {
-                    const Chunk ck = load_chunk(q, pos, ni, wstop);
-                    seen |= ck.w[0] | ck.w[1] | ck.w[2] | ck.w[3];
-#pragma unroll
-                    for (int t = 0; t < 16; ++t) {
-                        const unsigned ch = chunk_byte(ck, t) & (CAH_TABLE_CHARS - 1);
-                        const uint64_t mk = in_lds ? tbl_s[ch] : tbl_g[ch];
-                        R = ((R << 1) | init) & mk;
-                        acc |= R & found;
+
+            for (int g = 0; g < n_words; g += FILTER_SLOTS) {
+                if (!__any(valid && !hit)) break;
+                // union of this group's windows on this lane's read
+                int lo = n, hi = 0;
+    #pragma unroll
+                for (int s = 0; s < FILTER_SLOTS; ++s) {
+                    if (g + s < n_words) {
+                        int ws, we;
+                        word_window(words[g + s].start, words[g + s].stop, n, ws, we);
+                        if (we > ws) { lo = min(lo, ws); hi = max(hi, we); }
                     }
-                    hit = acc != 0;
+                }
+                if (!valid) { lo = 0; hi = 0; }
+                uint64_t R[FILTER_SLOTS], acc[FILTER_SLOTS];
+    #pragma unroll
+                for (int s = 0; s < FILTER_SLOTS; ++s) { R[s] = 0; acc[s] = 0; }
+
+                int pos = lo;
+                Chunk cur = load_chunk(q, pos, n, hi);
+                for (;;) {
+                    const bool live = !hit && pos < hi;
+                    if (!__any(live)) break;
+                    const Chunk nxt = load_chunk(q, pos + 16, n, live ? hi : 0);
+                    seen |= cur.w[0] | cur.w[1] | cur.w[2] | cur.w[3];
+                    uint64_t any_found = 0;
+    #pragma unroll
+                    for (int s = 0; s < FILTER_SLOTS; ++s) {
+                        if (g + s >= n_words) break;                     // wave-uniform
+                        const CahKmerWord* wd = words + (g + s);
+                        int ws, we;
+                        word_window(wd->start, wd->stop, n, ws, we);
+                        const bool act = live && pos < we && pos + 16 > ws;
+                        if (!__any(act)) continue;
+                        const uint64_t* tbl = LDS_TABLES ? (s_mask + (g + s) * CAH_TABLE_CHARS) : wd->mask;
+                        const uint64_t init = wd->init_mask;
+                        // masking is needed where a window starts inside the chunk or stops before
+                        // the end of the read inside it (beyond the read end the chunk is NUL-padded)
+                        const bool partial = act && (ws > pos || (we < pos + 16 && we < n));
+                        if (__any(partial) || !__all(act || !live)) {
+                            if (act) filter_word_chunk<true>(cur, tbl, init, R[s], acc[s], ws - pos, we - pos);
+                        } else {
+                            if (act) filter_word_chunk<false>(cur, tbl, init, R[s], acc[s], 0, 16);
+                        }
+                        any_found |= acc[s] & wd->found_mask;
+                    }
+                    if (live && any_found != 0) { hit = true; hit_pos = pos; }
+                    pos += 16;
+                    cur = nxt;
                 }
             }
             if (seen & 0x80808080u) invalid = true;
-            if (__all(hit || !valid)) break;
+
+            if (MODE == 0) {
+                if (valid) a.present[r] = invalid ? (uint8_t)2 : (hit ? (uint8_t)1 : (uint8_t)0);
+            } else {
+                if (valid && invalid) a.status[r] = 2;
+                const bool push = valid && hit && !invalid;
+                const unsigned long long bal = __ballot(push);
+                if (bal) {
+                    unsigned slot = 0;
+                    if (lane == 0) slot = atomicAdd(&s_count, (unsigned)__popcll(bal));    // LDS atomic
+                    slot = __builtin_amdgcn_readfirstlane(slot);
+                    if (push) {
+                        const int e = (int)slot + __popcll(bal & ((1ull << lane) - 1ull));
+                        const int key = min(hit_pos >> 4, CAH_QUEUE_BINS - 1);
+                        s_idx[e] = (int32_t)r;
+                        s_key[e] = (uint8_t)key;
+                        atomicAdd(&s_hist[key], 1u);
+                    }
+                }
+            }
         }
 
-        if (MODE == 0) {
-            if (valid) a.present[r] = invalid ? (uint8_t)2 : (hit ? (uint8_t)1 : (uint8_t)0);
-        } else {
-            if (valid && invalid) a.status[r] = 2;
-            const bool push = valid && hit && !invalid;
-            const unsigned long long bal = __ballot(push);
-            if (bal) {
-                unsigned long long qb = 0;
-                if (lane == 0) qb = atomicAdd(a.queue_count, (unsigned long long)__popcll(bal));
-                unsigned qlo = __builtin_amdgcn_readfirstlane((unsigned)qb);
-                unsigned qhi = __builtin_amdgcn_readfirstlane((unsigned)(qb >> 32));
-                const unsigned long long qbase = ((unsigned long long)qhi << 32) | qlo;
-                if (push) {
-                    const int rank = __popcll(bal & ((1ull << lane) - 1ull));
-                    a.queue[qbase + rank] = (int32_t)r;
-                }
+        if (MODE == 1) {
+            // flush the tile: counting sort by key in LDS, one global atomic for the whole run
+            __syncthreads();
+            const unsigned count = s_count;
+            if (threadIdx.x == 0) {
+                unsigned run = 0;
+                for (int bkt = 0; bkt < CAH_QUEUE_BINS; ++bkt) { const unsigned c = s_hist[bkt]; s_hist[bkt] = run; run += c; }
+                s_qbase = count ? atomicAdd(a.queue_count, (unsigned long long)count) : 0ull;
+            }
+            __syncthreads();
+            const unsigned long long qbase = s_qbase;
+            for (unsigned e = threadIdx.x; e < count; e += blockDim.x) {
+                const unsigned key = s_key[e];
+                const unsigned p = s_hist[key] + atomicAdd(&s_cursor[key], 1u);
+                a.queue[qbase + p] = s_idx[e];
             }
         }
     }
 }
-
 
 // ---------------------------------------------------------------------------------------------
 // One DP column, rows I..ROWS, as a compile-time recursion: guarantees full unrolling (so the
@@ -573,10 +678,20 @@ static int grid_for(int64_t n_items, int blocks_per_cu, int n_cus) {
     return (int)(need < cap ? need : cap);
 }
 
+#define FILTER_MAX_LDS_WORDS 32
+
 hipError_t launch_filter(const FilterArgs& a, int mode, int n_cus, hipStream_t s) {
-    const int grid = grid_for(a.n_reads, 8, n_cus);
-    if (mode == 0) hipLaunchKernelGGL(k_filter<0>, dim3(grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(k_filter<1>, dim3(grid), dim3(256), 0, s, a);
+    const int grid = grid_for(a.n_reads, 4, n_cus);
+    const bool in_lds = a.n_words <= FILTER_MAX_LDS_WORDS;
+    const size_t lds = (in_lds ? (size_t)a.n_words * CAH_TABLE_CHARS * sizeof(uint64_t) : 0) +
+                       FILTER_TILE * 5 + CAH_QUEUE_BINS * 8 + 64;
+    if (mode == 0) {
+        if (in_lds) hipLaunchKernelGGL((k_filter<0, true>), dim3(grid), dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((k_filter<0, false>), dim3(grid), dim3(256), lds, s, a);
+    } else {
+        if (in_lds) hipLaunchKernelGGL((k_filter<1, true>), dim3(grid), dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((k_filter<1, false>), dim3(grid), dim3(256), lds, s, a);
+    }
     return hipGetLastError();
 }
 
