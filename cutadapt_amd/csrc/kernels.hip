@@ -27,6 +27,9 @@
 #ifndef CAH_SCHED_ROWS
 #define CAH_SCHED_ROWS 1
 #endif
+#ifndef CAH_SKIP_ROWS
+#define CAH_SKIP_ROWS 2          // rows between two wave-uniform "any band left?" checks
+#endif
 
 __device__ __forceinline__ int wave_lane() { return threadIdx.x & (WAVE - 1); }
 
@@ -94,9 +97,17 @@ __device__ __forceinline__ Chunk load_chunk(const uint8_t* q, int pos, int n, in
         c.w[2] = (unsigned)((((unsigned long long)x3 << 32) | x2) >> sh);
         c.w[3] = x3 >> sh;
     } else {
-#pragma unroll
-        for (int t = 0; t < 15; ++t)                      // static indices: the chunk stays in VGPRs
-            if (pos + t < n) c.w[t >> 2] |= (unsigned)q[pos + t] << ((t & 3) * 8);
+        // read shorter than 16 bytes: push its bytes in from the top, last byte first (a rolled
+        // loop over four named registers: no dynamic register indexing, tiny register footprint)
+        unsigned x0 = 0, x1 = 0, x2 = 0, x3 = 0;
+#pragma unroll 1
+        for (int t = n - 1; t >= pos; --t) {
+            x3 = (x3 << 8) | (x2 >> 24);
+            x2 = (x2 << 8) | (x1 >> 24);
+            x1 = (x1 << 8) | (x0 >> 24);
+            x0 = (x0 << 8) | (unsigned)q[t];
+        }
+        c.w[0] = x0; c.w[1] = x1; c.w[2] = x2; c.w[3] = x3;
     }
     const int keep = limit - pos;                         // characters of this chunk inside [pos, limit)
     if (keep < 16) {
@@ -318,13 +329,13 @@ __global__ __launch_bounds__(256, 4) void k_filter(FilterArgs a) {
 // ends at row `last` drops out of exec for the rest of the column, and once exec is empty the
 // remaining rows are skipped with one scalar branch.
 // ---------------------------------------------------------------------------------------------
-template <int I, int ROWS>
+template <int I, int ROWS, bool UNIT>
 __device__ __forceinline__ void dp_rows(int (&c)[ROWS + 1], int (&p)[ROWS + 1], const uint64_t mk,
                                         int dc, int dp, int& nl, int& cm_c, int& cm_p,
-                                        const int last, const int m, const int k, const int D) {
+                                        const int last, const int m, const int k, const int Dm1) {
     if constexpr (I <= ROWS) {
         // every 4 rows: leave the column as soon as no lane of the wave has band left
-        if constexpr ((I & 3) == 1) {
+        if constexpr ((I % CAH_SKIP_ROWS) == 1 || CAH_SKIP_ROWS == 1) {
             if (!__any(last >= I)) return;
         }
         // Straight-line, select-only cell update (no exec-mask regions: lanes whose band ended
@@ -334,25 +345,33 @@ __device__ __forceinline__ void dp_rows(int (&c)[ROWS + 1], int (&p)[ROWS + 1], 
         const int oc = c[I], op = p[I];
         const int cprev = c[I - 1], pprev = p[I - 1];
         const unsigned mword = (I - 1) < 32 ? (unsigned)mk : (unsigned)(mk >> 32);
-        const int eqm = (int)(mword << (31 - ((I - 1) & 31))) >> 31;   // v_bfe_i32: -1 if match
-        const int c_diag = dc + 1;
-        const int c_indel = min(cprev, oc) + D;           // min(c_del, c_ins)
-        const bool mis = c_diag <= c_indel;
-        const bool del = cprev <= oc;                     // c_del <= c_ins
-        const int p_indel = (del ? pprev : op) - 2;
-        const int p_ne = mis ? dp - 1 : p_indel;
-        const int c_ne = min(c_diag, c_indel);
-        const int cost = (eqm & dc) | (~eqm & c_ne);      // v_bfi_b32
-        const int pay = (eqm & (dp + 1)) | (~eqm & p_ne);
+        // --- independent of the cell above (can be issued while its result is in flight) -------
+        const bool eq = (mword & (1u << ((I - 1) & 31))) != 0;
         const bool in_band = I <= last;                   // per lane: Ukkonen band (last <= m)
-        c[I] = in_band ? cost : oc;
-        p[I] = in_band ? pay : op;
+        const int c_keep = in_band ? dc : oc;             // match takes the diagonal; out of band keeps stale
+        const int p_diag = dp + (eq ? 1 : -1);            // diagonal payload: +1 match / -1 mismatch
+        const int p_ins = op - 2;
+        // --- the serial part: cost through the cell above ------------------------------------
+        // x = min(c_del, c_ins) - 1 with c_del = cprev + D, c_ins = oc + D  (Dm1 = D - 1, wave-uniform;
+        // UNIT = unit indel cost, the default: one add less per cell)
+        const int x = UNIT ? min(cprev, oc) : min(cprev, oc) + Dm1;
+        const int c_ne = min(dc, x) + 1;                  // min(c_diag, c_del, c_ins)
+        const bool mis = dc <= x;                         // c_diag <= c_del && c_diag <= c_ins
+        const bool del = cprev <= oc;                     // c_del <= c_ins
+        const int cost = (in_band && !eq) ? c_ne : c_keep;
+        // payload: diag (match/mismatch) | deletion (cell above, -2) | insertion (old cell, -2)
+        const bool diag = eq || mis;
+        const int p_other = in_band ? (diag ? p_diag : p_ins) : op;
+        const int pay = (in_band && !diag && del) ? pprev - 2 : p_other;
+        c[I] = cost;
+        p[I] = pay;
         nl = (in_band && cost <= k) ? I : nl;
         if constexpr (I > ROWS - 8) {                     // m is in (ROWS-8, ROWS]: wave-uniform capture
+            // (row capacities come in steps of 4; 8 keeps the smallest kernel, m <= 8, correct)
             if (I == m) { cm_c = cost; cm_p = pay; }
         }
         if constexpr ((I % CAH_SCHED_ROWS) == 0) __builtin_amdgcn_sched_barrier(0);
-        dp_rows<I + 1, ROWS>(c, p, mk, oc, op, nl, cm_c, cm_p, last, m, k, D);   // diag := old cell (:479)
+        dp_rows<I + 1, ROWS, UNIT>(c, p, mk, oc, op, nl, cm_c, cm_p, last, m, k, Dm1);   // diag := old cell (:479)
     }
 }
 
@@ -386,7 +405,7 @@ __device__ __forceinline__ void get_row(const int (&c)[ROWS + 1], const int (&p)
 #define CAH_DP_WAVES(ROWS) ((ROWS) <= 16 ? 5 : ((ROWS) <= 40 ? 4 : ((ROWS) <= 56 ? 3 : 2)))
 #endif
 
-template <int ROWS>
+template <int ROWS, bool UNIT>
 __global__ __launch_bounds__(256, CAH_DP_WAVES(ROWS)) void k_dp(DpArgs a) {
     __shared__ uint64_t s_rowmask[CAH_TABLE_CHARS];
     __shared__ int s_ncnt[CAH_MAX_M + 1];
@@ -487,7 +506,7 @@ __global__ __launch_bounds__(256, CAH_DP_WAVES(ROWS)) void k_dp(DpArgs a) {
                     int nl = c[0] <= k ? 0 : -1;              // largest computed row with cost <= k
                     int cm_c = c[0], cm_p = p[0];             // cell (m, j), captured for the candidate test
                                                               // (row 0 itself when m == 0)
-                    dp_rows<1, ROWS>(c, p, mk, dc, dp, nl, cm_c, cm_p, last, m, k, D);
+                    dp_rows<1, ROWS, UNIT>(c, p, mk, dc, dp, nl, cm_c, cm_p, last, m, k, D - 1);
                     last_filled = last;                       // :484
                     if (last >= 1) lf_ran = last;
                     // band update (:490-495)
@@ -695,17 +714,29 @@ hipError_t launch_filter(const FilterArgs& a, int mode, int n_cus, hipStream_t s
     return hipGetLastError();
 }
 
-hipError_t launch_dp(const DpArgs& a, int m, int64_t max_items, int n_cus, hipStream_t s) {
+hipError_t launch_dp(const DpArgs& a, int m, bool unit, int64_t max_items, int n_cus, hipStream_t s) {
     const int grid = grid_for(max_items, 8, n_cus);
-#define CAH_DP_CASE(R) \
-    if (m <= R) { hipLaunchKernelGGL(k_dp<R>, dim3(grid), dim3(256), 0, s, a); return hipGetLastError(); }
+    // UNIT: unit indel cost (the default); the general kernel carries D in an SGPR
+#define CAH_DP_CASE(R)                                                                          \
+    if (m <= R) {                                                                               \
+        if (unit) hipLaunchKernelGGL((k_dp<R, true>), dim3(grid), dim3(256), 0, s, a);          \
+        else hipLaunchKernelGGL((k_dp<R, false>), dim3(grid), dim3(256), 0, s, a);              \
+        return hipGetLastError();                                                               \
+    }
     CAH_DP_CASE(8)
+    CAH_DP_CASE(12)
     CAH_DP_CASE(16)
+    CAH_DP_CASE(20)
     CAH_DP_CASE(24)
+    CAH_DP_CASE(28)
     CAH_DP_CASE(32)
+    CAH_DP_CASE(36)
     CAH_DP_CASE(40)
+    CAH_DP_CASE(44)
     CAH_DP_CASE(48)
+    CAH_DP_CASE(52)
     CAH_DP_CASE(56)
+    CAH_DP_CASE(60)
     CAH_DP_CASE(64)
 #undef CAH_DP_CASE
     return hipErrorInvalidValue;
