@@ -27,37 +27,45 @@ def available_cores() -> int:
         return os.cpu_count() or 1
 
 
+CHUNK = 200_000   # reads generated / converted / matched at a time inside a worker (bounds memory)
+
+
 def worker(kind, seed, first, n_reads, read_len, adapter_seq, max_errors, min_overlap, gen):
-    """generate reads [first, first+n_reads) and time the matching loop; returns (seconds, hits)"""
+    """match reads [first, first+n_reads) chunk by chunk; only the matching loops are timed.
+    Returns (seconds, hits)."""
     if ROOT not in sys.path:
         sys.path.insert(0, ROOT)
     from oracle import oracle as orc
-    seqs, offsets = orc.synth_reads(seed, first, n_reads, read_len, [adapter_seq],
-                                    gen["p_adapter"], gen["p_edit"], gen["p_n"])
     if kind == "reference":
         from oracle import ref_loader
         ref = ref_loader.load()
         if ref is None:
             raise RuntimeError("oracle/_ref not available")
         adapter = ref.adapters.BackAdapter(adapter_seq, max_errors=max_errors, min_overlap=min_overlap)
-        raw = seqs.tobytes()
-        reads = [raw[i * read_len:(i + 1) * read_len].decode("ascii") for i in range(n_reads)]
         match_to = adapter.match_to
-        t0 = time.perf_counter()
-        hits = 0
-        for r in reads:
-            if match_to(r) is not None:
-                hits += 1
-        dt = time.perf_counter() - t0
     else:
         from cutadapt_amd.kmer_heuristic import create_positions_and_kmers
         a = orc.Aligner(adapter_seq, max_errors, 14, False, False, 1, min_overlap)
         f = orc.KmerFinder(create_positions_and_kmers(adapter_seq, min_overlap, max_errors, True, False))
-        t0 = time.perf_counter()
-        _, status = orc.match_batch(a, f, seqs, offsets)
-        dt = time.perf_counter() - t0
-        hits = int((status == 1).sum())
-    return dt, hits
+    total_dt, hits = 0.0, 0
+    for start in range(0, n_reads, CHUNK):
+        cnt = min(CHUNK, n_reads - start)
+        seqs, offsets = orc.synth_reads(seed, first + start, cnt, read_len, [adapter_seq],
+                                        gen["p_adapter"], gen["p_edit"], gen["p_n"])
+        if kind == "reference":
+            raw = seqs.tobytes()
+            reads = [raw[i * read_len:(i + 1) * read_len].decode("ascii") for i in range(cnt)]
+            t0 = time.perf_counter()
+            for r in reads:
+                if match_to(r) is not None:
+                    hits += 1
+            total_dt += time.perf_counter() - t0
+        else:
+            t0 = time.perf_counter()
+            _, status = orc.match_batch(a, f, seqs, offsets)
+            total_dt += time.perf_counter() - t0
+            hits += int((status == 1).sum())
+    return total_dt, hits
 
 
 def _spawn(job: dict):
@@ -71,7 +79,7 @@ def _spawn(job: dict):
 
 
 def run(seed: int, read_len: int, adapter_seq: str, max_errors: float, min_overlap: int, gen: dict,
-        target_seconds: float = 12.0, max_reads: int = 50_000_000, timeout: float = 180.0):
+        target_seconds: float = 12.0, max_reads: int = 4_000_000_000, timeout: float = 240.0):
     """Returns dict(value=Mreads/s, cores=..., kind=..., sample=...)."""
     from oracle import oracle as orc
     from oracle import ref_loader
