@@ -195,9 +195,13 @@ def main():
     }
     if world == 1 and not args.no_cpu_baseline:
         from oracle import cpu_baseline
-        result["cpu_baseline"] = cpu_baseline.run(SEED, READ_LEN, TRUSEQ, 0.1, 3, GEN,
-                                                  target_seconds=args.cpu_seconds)
-        result["gpu_over_cpu"] = value / result["cpu_baseline"]["value"]
+        try:
+            result["cpu_baseline"] = cpu_baseline.run(SEED, READ_LEN, TRUSEQ, 0.1, 3, GEN,
+                                                      target_seconds=args.cpu_seconds)
+            result["gpu_over_cpu"] = value / result["cpu_baseline"]["value"]
+        except Exception as exc:        # the GPU numbers must survive a host-side hiccup
+            result["cpu_baseline"] = {"value": None, "unit": "Mreads/s", "cores": cpu_baseline.available_cores(),
+                                      "kind": "reference", "sample": f"failed: {exc!r}"[:300]}
     print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
