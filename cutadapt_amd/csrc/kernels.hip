@@ -482,23 +482,37 @@ __global__ __launch_bounds__(256, CAH_DP_WAVES(ROWS)) void k_dp(DpArgs a) {
         int j = min_n;
         bool done = !valid;
 
-        // Columns are walked in lock step by all lanes (lane-local column j = min_n + 1 + step);
-        // the read characters arrive 16 per global load and the next chunk is requested before
-        // the current one is consumed, so its latency hides behind 16 columns of DP.
+        // Columns are walked in lock step by all lanes (lane-local column j = min_n + 1 + step).
+        // The read characters arrive 16 per global load (next chunk requested one chunk ahead);
+        // the chunk is consumed by shifting it down one byte per column, and the LDS lookup of
+        // the NEXT column's row bitset is issued before the current column is computed, so
+        // neither the global nor the LDS latency sits on the column's critical path.
         int pos = min_n;
         Chunk cur = load_chunk(q, pos, n, valid ? max_n : 0);
+        Chunk nxt = load_chunk(q, pos + 16, n, valid ? max_n : 0);
+        int left = 16;                                    // characters left in `cur` (wave-uniform)
+        unsigned bad_chars = cur.w[0] | cur.w[1] | cur.w[2] | cur.w[3];
+        uint64_t mk_next = s_rowmask[cur.w[0] & (CAH_TABLE_CHARS - 1)];
         for (;;) {
-            if (!__any(!done && j < max_n)) break;
-            const Chunk nxt = load_chunk(q, pos + 16, n, (!done) ? max_n : 0);
-#pragma unroll 1
-            for (int t = 0; t < 16; ++t) {                // t is wave-uniform
+            {
                 const bool act = !done && j < max_n;
                 if (!__any(act)) break;
+                const uint64_t mk = mk_next;
+                // advance the character stream by one byte and start the next lookup
+                cur.w[0] = (cur.w[0] >> 8) | (cur.w[1] << 24);
+                cur.w[1] = (cur.w[1] >> 8) | (cur.w[2] << 24);
+                cur.w[2] = (cur.w[2] >> 8) | (cur.w[3] << 24);
+                cur.w[3] >>= 8;
+                if (--left == 0) {
+                    cur = nxt;
+                    bad_chars |= cur.w[0] | cur.w[1] | cur.w[2] | cur.w[3];
+                    pos += 16;
+                    nxt = load_chunk(q, pos + 16, n, (!done) ? max_n : 0);
+                    left = 16;
+                }
+                mk_next = s_rowmask[cur.w[0] & (CAH_TABLE_CHARS - 1)];
                 if (act) {
                     ++j;
-                    const unsigned ch = chunk_byte(cur, t);
-                    uint64_t mk = 0;
-                    if (ch < CAH_TABLE_CHARS) mk = s_rowmask[ch]; else invalid = true;
 
                     int dc = c[0], dp = p[0];                 // diagonal for row 1
                     c[0] += row0_cost_inc;
@@ -532,9 +546,8 @@ __global__ __launch_bounds__(256, CAH_DP_WAVES(ROWS)) void k_dp(DpArgs a) {
                     }
                 }
             }
-            pos += 16;
-            cur = nxt;
         }
+        if (bad_chars & 0x80808080u) invalid = true;
 
         // last column (:536-572).  The update test uses the *stale* scalar `origin`: the origin
         // of the last cell the row loop wrote, i.e. cell lf_ran of the column it last ran in.

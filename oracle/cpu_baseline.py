@@ -20,11 +20,37 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def available_cores() -> int:
+def cgroup_cpu_limit():
+    """CPUs' worth of time the container may use (cgroup v2 cpu.max / v1 cfs quota) or None."""
     try:
-        return len(os.sched_getaffinity(0))
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            return float(quota) / float(period)
+    except Exception:
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            quota = int(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            period = int(f.read())
+        if quota > 0:
+            return quota / period
+    except Exception:
+        pass
+    return None
+
+
+def available_cores() -> int:
+    """hardware threads this process may actually use: affinity mask, capped by the cgroup quota"""
+    try:
+        n = len(os.sched_getaffinity(0))
     except AttributeError:
-        return os.cpu_count() or 1
+        n = os.cpu_count() or 1
+    lim = cgroup_cpu_limit()
+    if lim is not None:
+        n = max(1, min(n, int(lim + 0.5)))
+    return n
 
 
 CHUNK = 200_000   # reads generated / converted / matched at a time inside a worker (bounds memory)
