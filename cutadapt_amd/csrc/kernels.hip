@@ -142,7 +142,7 @@ __device__ __forceinline__ unsigned chunk_byte(const Chunk& c, int t) {
 // popcount + a single atomic per wave) together with a key = chunk index of the first hit,
 // and count keys per bin so that the queue can be ordered by approximate adapter position.
 // =============================================================================================
-#define FILTER_SLOTS 8
+#define FILTER_SLOTS 6
 
 __device__ __forceinline__ void word_window(const int64_t wstart, const int64_t wstop, const int n,
                                             int& ws, int& we) {
@@ -160,15 +160,26 @@ __device__ __forceinline__ void word_window(const int64_t wstart, const int64_t 
 
 template <bool MASKED>
 __device__ __forceinline__ void filter_word_chunk(const Chunk& ck, const uint64_t* tbl, const uint64_t init,
-                                                  uint64_t& R, uint64_t& acc, const int lo, const int hi) {
-    // lo/hi: first / one-past-last chunk character (0..16) inside this word's window (MASKED only)
+                                                  uint64_t& R, uint64_t& acc, const int lo, const int hi,
+                                                  const bool act) {
+    // lo/hi: first / one-past-last chunk character (0..16) inside this word's window.
+    // The 16 characters are handled in four groups of four; a group no lane needs is skipped
+    // (short suffix windows such as the 3- and 4-character overlap searches touch one group).
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        const unsigned ch = chunk_byte(ck, t) & (CAH_TABLE_CHARS - 1);
-        uint64_t mk = tbl[ch];
-        if (MASKED) mk = (t >= lo && t < hi) ? mk : 0ull;
-        R = ((R << 1) | init) & mk;
-        acc |= R;
+    for (int g4 = 0; g4 < 4; ++g4) {
+        if (MASKED) {
+            if (!__any(act && lo < 4 * g4 + 4 && hi > 4 * g4)) continue;
+        }
+        if (act) {
+#pragma unroll
+            for (int t = 4 * g4; t < 4 * g4 + 4; ++t) {
+                const unsigned ch = chunk_byte(ck, t) & (CAH_TABLE_CHARS - 1);
+                uint64_t mk = tbl[ch];
+                if (MASKED) mk = (t >= lo && t < hi) ? mk : 0ull;
+                R = ((R << 1) | init) & mk;
+                acc |= R;
+            }
+        }
     }
 }
 
@@ -232,14 +243,15 @@ __global__ __launch_bounds__(256, 4) void k_filter(FilterArgs a) {
 
             for (int g = 0; g < n_words; g += FILTER_SLOTS) {
                 if (!__any(valid && !hit)) break;
-                // union of this group's windows on this lane's read
+                // this lane's window of every word of the group, and their union
+                int wsv[FILTER_SLOTS], wev[FILTER_SLOTS];
                 int lo = n, hi = 0;
     #pragma unroll
                 for (int s = 0; s < FILTER_SLOTS; ++s) {
+                    wsv[s] = 0; wev[s] = 0;
                     if (g + s < n_words) {
-                        int ws, we;
-                        word_window(words[g + s].start, words[g + s].stop, n, ws, we);
-                        if (we > ws) { lo = min(lo, ws); hi = max(hi, we); }
+                        word_window(words[g + s].start, words[g + s].stop, n, wsv[s], wev[s]);
+                        if (wev[s] > wsv[s]) { lo = min(lo, wsv[s]); hi = max(hi, wev[s]); }
                     }
                 }
                 if (!valid) { lo = 0; hi = 0; }
@@ -259,8 +271,7 @@ __global__ __launch_bounds__(256, 4) void k_filter(FilterArgs a) {
                     for (int s = 0; s < FILTER_SLOTS; ++s) {
                         if (g + s >= n_words) break;                     // wave-uniform
                         const CahKmerWord* wd = words + (g + s);
-                        int ws, we;
-                        word_window(wd->start, wd->stop, n, ws, we);
+                        const int ws = wsv[s], we = wev[s];
                         const bool act = live && pos < we && pos + 16 > ws;
                         if (!__any(act)) continue;
                         const uint64_t* tbl = LDS_TABLES ? (s_mask + (g + s) * CAH_TABLE_CHARS) : wd->mask;
@@ -268,10 +279,10 @@ __global__ __launch_bounds__(256, 4) void k_filter(FilterArgs a) {
                         // masking is needed where a window starts inside the chunk or stops before
                         // the end of the read inside it (beyond the read end the chunk is NUL-padded)
                         const bool partial = act && (ws > pos || (we < pos + 16 && we < n));
-                        if (__any(partial) || !__all(act || !live)) {
-                            if (act) filter_word_chunk<true>(cur, tbl, init, R[s], acc[s], ws - pos, we - pos);
+                        if (__any(partial)) {
+                            filter_word_chunk<true>(cur, tbl, init, R[s], acc[s], ws - pos, we - pos, act);
                         } else {
-                            if (act) filter_word_chunk<false>(cur, tbl, init, R[s], acc[s], 0, 16);
+                            filter_word_chunk<false>(cur, tbl, init, R[s], acc[s], 0, 16, act);
                         }
                         any_found |= acc[s] & wd->found_mask;
                     }
