@@ -144,9 +144,9 @@ __device__ __forceinline__ unsigned chunk_byte(const Chunk& c, int t) {
 // =============================================================================================
 #define FILTER_SLOTS 6
 
-__device__ __forceinline__ void word_window(const int64_t wstart, const int64_t wstop, const int n,
+__device__ __forceinline__ void word_window(const int wstart, const int wstop, const int n,
                                             int& ws, int& we) {
-    int64_t start = wstart, stop = wstop;
+    int start = wstart, stop = wstop;
     bool empty = false;
     if (start < 0) { start += n; if (start < 0) start = 0; }
     else if (start > n) empty = true;
@@ -154,8 +154,8 @@ __device__ __forceinline__ void word_window(const int64_t wstart, const int64_t 
     else if (stop == 0) stop = n;
     if (stop > n) stop = n;
     if (stop <= start) empty = true;
-    ws = empty ? 0 : (int)start;
-    we = empty ? 0 : (int)stop;
+    ws = empty ? 0 : start;
+    we = empty ? 0 : stop;
 }
 
 template <bool MASKED>
@@ -197,6 +197,7 @@ __global__ __launch_bounds__(256, 4) void k_filter(FilterArgs a) {
     // all LDS is carved from the dynamic region (16-byte aligned offsets; a static __shared__
     // in front of it could misalign the 8-byte table reads):
     //   [tables: n_words KiB] [s_idx: 16 KiB] [s_key: 4 KiB] [s_hist] [s_cursor] [scalars]
+    //   [per-word init/found masks and windows: 24 B x n_words]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const CahKmerWord* words = a.words;
     const int n_words = a.n_words;
@@ -209,6 +210,20 @@ __global__ __launch_bounds__(256, 4) void k_filter(FilterArgs a) {
     unsigned long long& s_qbase = *reinterpret_cast<unsigned long long*>(sp);
     long long& s_tile = *reinterpret_cast<long long*>(sp + 8);
     unsigned& s_count = *reinterpret_cast<unsigned*>(sp + 16);
+    sp += 64;
+    // word parameters are read from LDS inside the loops (the compiler would otherwise re-load
+    // them from global memory per chunk: stores to the queue may alias as far as it knows)
+    uint64_t* s_winit = reinterpret_cast<uint64_t*>(sp);         sp += (size_t)n_words * sizeof(uint64_t);
+    uint64_t* s_wfound = reinterpret_cast<uint64_t*>(sp);        sp += (size_t)n_words * sizeof(uint64_t);
+    int* s_wstart = reinterpret_cast<int*>(sp);                  sp += (size_t)n_words * sizeof(int);
+    int* s_wstop = reinterpret_cast<int*>(sp);
+    for (int i = threadIdx.x; i < n_words; i += blockDim.x) {
+        s_winit[i] = words[i].init_mask;
+        s_wfound[i] = words[i].found_mask;
+        const int64_t st = words[i].start, sp_ = words[i].stop;      // clamp to int (reads are <= 1e6 long)
+        s_wstart[i] = (int)(st < -(1 << 30) ? -(1 << 30) : (st > (1 << 30) ? (1 << 30) : st));
+        s_wstop[i] = (int)(sp_ < -(1 << 30) ? -(1 << 30) : (sp_ > (1 << 30) ? (1 << 30) : sp_));
+    }
     if (LDS_TABLES) {
         for (int i = threadIdx.x; i < n_words * CAH_TABLE_CHARS; i += blockDim.x)
             s_mask[i] = words[i / CAH_TABLE_CHARS].mask[i % CAH_TABLE_CHARS];
@@ -250,7 +265,7 @@ __global__ __launch_bounds__(256, 4) void k_filter(FilterArgs a) {
                 for (int s = 0; s < FILTER_SLOTS; ++s) {
                     wsv[s] = 0; wev[s] = 0;
                     if (g + s < n_words) {
-                        word_window(words[g + s].start, words[g + s].stop, n, wsv[s], wev[s]);
+                        word_window(s_wstart[g + s], s_wstop[g + s], n, wsv[s], wev[s]);
                         if (wev[s] > wsv[s]) { lo = min(lo, wsv[s]); hi = max(hi, wev[s]); }
                     }
                 }
@@ -275,7 +290,7 @@ __global__ __launch_bounds__(256, 4) void k_filter(FilterArgs a) {
                         const bool act = live && pos < we && pos + 16 > ws;
                         if (!__any(act)) continue;
                         const uint64_t* tbl = LDS_TABLES ? (s_mask + (g + s) * CAH_TABLE_CHARS) : wd->mask;
-                        const uint64_t init = wd->init_mask;
+                        const uint64_t init = s_winit[g + s];
                         // masking is needed where a window starts inside the chunk or stops before
                         // the end of the read inside it (beyond the read end the chunk is NUL-padded)
                         const bool partial = act && (ws > pos || (we < pos + 16 && we < n));
@@ -284,7 +299,7 @@ __global__ __launch_bounds__(256, 4) void k_filter(FilterArgs a) {
                         } else {
                             filter_word_chunk<false>(cur, tbl, init, R[s], acc[s], 0, 16, act);
                         }
-                        any_found |= acc[s] & wd->found_mask;
+                        any_found |= acc[s] & s_wfound[g + s];
                     }
                     if (live && any_found != 0) { hit = true; hit_pos = pos; }
                     pos += 16;
@@ -727,7 +742,7 @@ hipError_t launch_filter(const FilterArgs& a, int mode, int n_cus, hipStream_t s
     const int grid = grid_for(a.n_reads, 4, n_cus);
     const bool in_lds = a.n_words <= FILTER_MAX_LDS_WORDS;
     const size_t lds = (in_lds ? (size_t)a.n_words * CAH_TABLE_CHARS * sizeof(uint64_t) : 0) +
-                       FILTER_TILE * 5 + CAH_QUEUE_BINS * 8 + 64;
+                       FILTER_TILE * 5 + CAH_QUEUE_BINS * 8 + 64 + (size_t)a.n_words * 24;
     if (mode == 0) {
         if (in_lds) hipLaunchKernelGGL((k_filter<0, true>), dim3(grid), dim3(256), lds, s, a);
         else hipLaunchKernelGGL((k_filter<0, false>), dim3(grid), dim3(256), lds, s, a);
