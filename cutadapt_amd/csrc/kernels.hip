@@ -192,8 +192,12 @@ __device__ __forceinline__ void filter_word_chunk(const Chunk& ck, const uint64_
 #define FILTER_TILE 4096
 #define FILTER_WAVES 4
 
+#ifndef CAH_FILTER_WAVES
+#define CAH_FILTER_WAVES 4
+#endif
+
 template <int MODE, bool LDS_TABLES>
-__global__ __launch_bounds__(256, 4) void k_filter(FilterArgs a) {
+__global__ __launch_bounds__(256, CAH_FILTER_WAVES) void k_filter(FilterArgs a) {
     // all LDS is carved from the dynamic region (16-byte aligned offsets; a static __shared__
     // in front of it could misalign the 8-byte table reads):
     //   [tables: n_words KiB] [s_idx: 16 KiB] [s_key: 4 KiB] [s_hist] [s_cursor] [scalars]
