@@ -10,6 +10,7 @@
 // bitset" per read character, so the kernels never compare characters.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -296,6 +297,47 @@ static int build_matcher(const cah_adapter_desc& d, int index, CahMatcher& mt,
         }
     }
     mt.n_words = (int32_t)words.size() - mt.first_word;
+    // Whole-read words (window 0..end) go first: the prefilter scans words in groups of
+    // CAH_FILTER_SLOTS and a read leaves at its first hit, so only words of the FIRST group are
+    // guaranteed to have been scanned up to the hit position (kmers_present is an OR over all
+    // words; their order is free).
+    std::stable_partition(words.begin() + mt.first_word, words.end(),
+                          [](const CahKmerWord& w) { return w.start == 0 && w.stop == 0; });
+    int n_whole_read_words = 0;
+    for (size_t i = (size_t)mt.first_word; i < words.size(); i++)
+        n_whole_read_words += words[i].start == 0 && words[i].stop == 0;
+
+    // ---- may the DP skip the columns before the first k-mer hit? -------------------------------
+    // Only for 3' adapters (flags == QUERY_START|QUERY_STOP|REFERENCE_END) and only if this very
+    // plan's prefilter provably has the pigeonhole property the argument needs: a search set over
+    // the whole read (start 0, stop None) that contains every one of the k+1 consecutive chunks
+    // of the adapter (reference kmer_heuristic.py:161-163 builds exactly that), matched with the
+    // same wildcard relation as the aligner.  Hand-made k-mer sets that lack it keep skip_ok = 0.
+    mt.skip_ok = 0;
+    if (d.kind == CAH_KIND_ALIGNER && mt.flags == 14 && d.n_kmer_sets > 0 && m >= 1 &&
+        n_whole_read_words <= CAH_FILTER_SLOTS &&
+        (d.kmer_ref_wildcards != 0) == (d.wildcard_ref != 0) &&
+        (d.kmer_query_wildcards != 0) == (d.wildcard_query != 0)) {
+        const int chunks = mt.k + 1;
+        if (chunks <= m) {
+            const int base = m / chunks, extra = m % chunks;
+            for (int s = 0; s < d.n_kmer_sets && !mt.skip_ok; s++) {
+                const cah_kmer_set& ks = d.kmer_sets[s];
+                if (ks.start != 0 || ks.stop != 0) continue;
+                bool all = true;
+                int pos = 0;
+                for (int cidx = 0; cidx < chunks && all; cidx++) {
+                    const int len = base + (cidx < extra ? 1 : 0);
+                    bool present = false;
+                    for (int t = 0; t < ks.n_kmers && !present; t++)
+                        present = (int)strlen(ks.kmers[t]) == len && strncmp(ks.kmers[t], d.sequence + pos, (size_t)len) == 0;
+                    all = present;
+                    pos += len;
+                }
+                if (all) mt.skip_ok = 1;
+            }
+        }
+    }
     return CAH_OK;
 }
 
@@ -439,14 +481,17 @@ int cah_profile_read(double ms[CAH_PROF_N], int64_t launches[CAH_PROF_N], int64_
 // batch entry points
 // ---------------------------------------------------------------------------------------------
 // workspace layout: three counters, each on its own 256-byte line (they are hammered by
-// different kernels), then the survivor queue:
-//   [0,8) filter tile counter | [256,264) queue count | [512,520) DP work counter | [1024, +4n) queue
+// different kernels), then the survivor queue and its per-entry keys:
+//   [0,8) filter tile counter | [256,264) queue count | [512,520) DP work counter |
+//   [1024, +4n) queue | [.., +n) queue keys
 static const size_t WS_HEADER = 1024;
 static const size_t WS_QCOUNT = 256 / sizeof(unsigned long long), WS_DPWORK = 512 / sizeof(unsigned long long);
 
+static size_t ws_queue_bytes(int64_t n_reads) { return (sizeof(int32_t) * (size_t)n_reads + 255) & ~(size_t)255; }
+
 size_t cah_workspace_bytes(int64_t n_reads) {
     if (n_reads < 0) n_reads = 0;
-    return WS_HEADER + sizeof(int32_t) * (size_t)n_reads + 256;
+    return WS_HEADER + ws_queue_bytes(n_reads) + (size_t)n_reads + 256;
 }
 
 static int check_batch(const cah_plan* plan, const void* d_seqs, const void* d_offsets, int64_t n_reads) {
@@ -460,14 +505,14 @@ static int check_batch(const cah_plan* plan, const void* d_seqs, const void* d_o
 static int run_aligner(const cah_plan* plan, const PlanDeviceCopy* pd, int32_t adapter, const uint8_t* d_seqs,
                        const int64_t* d_offsets, const int32_t* d_lens, int64_t n_reads,
                        const int32_t* d_queue, const unsigned long long* d_queue_count,
-                       unsigned long long* d_work_counter, int32_t* d_out6, uint8_t* d_status,
-                       int32_t* d_best, int merge_best, hipStream_t s) {
+                       const uint8_t* d_queue_keys, unsigned long long* d_work_counter, int32_t* d_out6,
+                       uint8_t* d_status, int32_t* d_best, int merge_best, hipStream_t s) {
     const CahMatcher& mt = plan->matchers[(size_t)adapter];
     DpArgs a;
     a.matcher = pd->d_matchers + adapter;
     a.seqs = d_seqs; a.offsets = d_offsets; a.lens = d_lens; a.n_reads = n_reads;
     a.max_read_len = CAH_MAX_READ_LEN;
-    a.queue = d_queue; a.queue_count = d_queue_count; a.work_counter = d_work_counter;
+    a.queue = d_queue; a.queue_count = d_queue_count; a.queue_keys = d_queue_keys; a.work_counter = d_work_counter;
     a.out6 = d_out6; a.status = d_status; a.best_adapter = d_best;
     a.adapter_index = adapter; a.merge_best = merge_best;
     HIP_TRY(hipMemsetAsync(d_work_counter, 0, sizeof(unsigned long long), s));
@@ -499,15 +544,15 @@ int cah_locate_batch(const cah_plan* plan, int32_t adapter, const uint8_t* d_seq
     const PlanDeviceCopy* pd = nullptr;
     rc = plan_on_device(plan, &pd);
     if (rc) return rc;
-    return run_aligner(plan, pd, adapter, d_seqs, d_offsets, d_lens, n_reads, nullptr, nullptr,
+    return run_aligner(plan, pd, adapter, d_seqs, d_offsets, d_lens, n_reads, nullptr, nullptr, nullptr,
                        counters + 0, d_out6, d_status, nullptr, 0, (hipStream_t)stream);
 }
 
 static int run_filter(const cah_plan* plan, const PlanDeviceCopy* pd, int32_t adapter, const uint8_t* d_seqs,
                       const int64_t* d_offsets, const int32_t* d_lens, int64_t n_reads, int mode,
                       uint8_t* d_present, uint8_t* d_status, int32_t* d_queue,
-                      unsigned long long* d_queue_count, unsigned long long* d_work_counter,
-                      hipStream_t s) {
+                      unsigned long long* d_queue_count, uint8_t* d_queue_keys,
+                      unsigned long long* d_work_counter, hipStream_t s) {
     const CahMatcher& mt = plan->matchers[(size_t)adapter];
     FilterArgs f;
     f.words = pd->d_words + mt.first_word;
@@ -516,6 +561,7 @@ static int run_filter(const cah_plan* plan, const PlanDeviceCopy* pd, int32_t ad
     f.max_read_len = CAH_MAX_READ_LEN;
     f.work_counter = d_work_counter;
     f.present = d_present; f.status = d_status; f.queue = d_queue; f.queue_count = d_queue_count;
+    f.queue_keys = d_queue_keys;
     HIP_TRY(hipMemsetAsync(d_work_counter, 0, sizeof(unsigned long long), s));
     if (d_queue_count) HIP_TRY(hipMemsetAsync(d_queue_count, 0, sizeof(unsigned long long), s));
     ProfScope ps(s, CAH_PROF_FILTER, n_reads);
@@ -545,7 +591,7 @@ int cah_kmers_present_batch(const cah_plan* plan, int32_t adapter, const uint8_t
     unsigned long long* d_counter = nullptr;
     HIP_TRY(hipMalloc((void**)&d_counter, sizeof(unsigned long long)));
     rc = run_filter(plan, pd, adapter, d_seqs, d_offsets, d_lens, n_reads, 0, d_present, nullptr, nullptr,
-                    nullptr, d_counter, s);
+                    nullptr, nullptr, d_counter, s);
     hipError_t e = hipStreamSynchronize(s);
     (void)hipFree(d_counter);
     if (rc) return rc;
@@ -568,6 +614,7 @@ int cah_match_batch(const cah_plan* plan, const uint8_t* d_seqs, const int64_t* 
     if (rc) return rc;
     unsigned long long* counters = (unsigned long long*)d_workspace;
     int32_t* d_queue = (int32_t*)((char*)d_workspace + WS_HEADER);
+    uint8_t* d_keys = (uint8_t*)d_workspace + WS_HEADER + ws_queue_bytes(n_reads);
     HIP_TRY(hipMemsetAsync(d_status, 0, (size_t)n_reads, s));
     HIP_TRY(hipMemsetAsync(d_out6, 0, sizeof(int32_t) * 6 * (size_t)n_reads, s));
     if (d_best_adapter) HIP_TRY(launch_init_best(d_best_adapter, n_reads, pd->n_cus, s));
@@ -577,13 +624,13 @@ int cah_match_batch(const cah_plan* plan, const uint8_t* d_seqs, const int64_t* 
         if (mt.has_filter) {
             // prefilter -> queue of surviving reads -> DP on dense waves
             rc = run_filter(plan, pd, ad, d_seqs, d_offsets, d_lens, n_reads, 1, nullptr, d_status, d_queue,
-                            counters + WS_QCOUNT, counters + 0, s);
+                            counters + WS_QCOUNT, d_keys, counters + 0, s);
             if (rc) return rc;
             rc = run_aligner(plan, pd, ad, d_seqs, d_offsets, d_lens, n_reads, d_queue, counters + WS_QCOUNT,
-                             counters + WS_DPWORK, d_out6, d_status, d_best_adapter, 1, s);
+                             d_keys, counters + WS_DPWORK, d_out6, d_status, d_best_adapter, 1, s);
         } else {
-            rc = run_aligner(plan, pd, ad, d_seqs, d_offsets, d_lens, n_reads, nullptr, nullptr, counters + WS_DPWORK,
-                             d_out6, d_status, d_best_adapter, 1, s);
+            rc = run_aligner(plan, pd, ad, d_seqs, d_offsets, d_lens, n_reads, nullptr, nullptr, nullptr,
+                             counters + WS_DPWORK, d_out6, d_status, d_best_adapter, 1, s);
         }
         if (rc) return rc;
     }

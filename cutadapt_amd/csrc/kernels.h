@@ -20,6 +20,7 @@ struct FilterArgs {
     uint8_t* status;                 // MODE 1: only written for invalid reads
     int32_t* queue;                  // MODE 1: surviving read indices, in runs ordered by hit position
     unsigned long long* queue_count; // MODE 1: zeroed before launch
+    uint8_t* queue_keys;             // MODE 1: per queue entry, min(first-hit position / 16, 63)
 };
 
 struct DpArgs {
@@ -31,6 +32,7 @@ struct DpArgs {
     int64_t max_read_len;
     const int32_t* queue;            // NULL: process reads 0..n_reads-1
     const unsigned long long* queue_count;   // NULL: n_reads
+    const uint8_t* queue_keys;       // NULL, or per queue entry the first-hit chunk (lower bound of any k-mer hit)
     unsigned long long* work_counter;        // zeroed before launch
     int32_t* out6;
     uint8_t* status;

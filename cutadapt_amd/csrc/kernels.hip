@@ -142,7 +142,7 @@ __device__ __forceinline__ unsigned chunk_byte(const Chunk& c, int t) {
 // popcount + a single atomic per wave) together with a key = chunk index of the first hit,
 // and count keys per bin so that the queue can be ordered by approximate adapter position.
 // =============================================================================================
-#define FILTER_SLOTS 6
+#define FILTER_SLOTS CAH_FILTER_SLOTS
 
 __device__ __forceinline__ void word_window(const int wstart, const int wstop, const int n,
                                             int& ws, int& we) {
@@ -348,6 +348,7 @@ __global__ __launch_bounds__(256, CAH_FILTER_WAVES) void k_filter(FilterArgs a) 
                 const unsigned key = s_key[e];
                 const unsigned p = s_hist[key] + atomicAdd(&s_cursor[key], 1u);
                 a.queue[qbase + p] = s_idx[e];
+                a.queue_keys[qbase + p] = (uint8_t)key;
             }
         }
     }
@@ -469,6 +470,7 @@ __global__ __launch_bounds__(256, CAH_DP_WAVES(ROWS)) void k_dp(DpArgs a) {
     const int lane = wave_lane();
     int64_t total = a.n_reads;
     if (a.queue_count) total = (int64_t)(*a.queue_count);
+    const bool skip_cols = a.queue && a.queue_keys && mt->skip_ok != 0;
 
     for (;;) {
         const int64_t base = wave_dequeue(a.work_counter);
@@ -488,6 +490,15 @@ __global__ __launch_bounds__(256, CAH_DP_WAVES(ROWS)) void k_dp(DpArgs a) {
         int max_n = n, min_n = 0;
         if (!start_in_query) max_n = min(n, m + k);
         if (!stop_in_query) min_n = max(0, n - m - k);
+        // Column skipping (3' adapters with a verified pigeonhole prefilter only, skip_ok): no
+        // k-mer of the prefilter occurs before character `first_hit`, hence no full-length match
+        // can end before it, and every cell that can influence the result (cost <= k+1, at or
+        // after column first_hit) has all its optimal paths inside columns >= first_hit-m-k-1.
+        // Starting the banded DP there with the plain first column gives bit-identical results
+        // ("Column skipping").
+        int skip_to = 0;
+        if (skip_cols && valid) skip_to = max(0, (int)a.queue_keys[idx] * 16 - m - k - 1);
+        if (skip_to > 0) min_n = skip_to;
 
         // first column (_align.pyx:364-383).  The four (start_in_reference, start_in_query)
         // cases are folded into wave-uniform weights/clamps so that no branch is needed:
@@ -499,8 +510,8 @@ __global__ __launch_bounds__(256, CAH_DP_WAVES(ROWS)) void k_dp(DpArgs a) {
             const int d = min_n - i;
             const int org = min(max(d, init_org_lo), init_org_hi);
             const int co = (w_max * max(i, min_n) + w_min * min(i, min_n) + w_y * min_n + w_x * i) * D;
-            c[i] = co;
-            p[i] = pack_cell(org, init_score_mul * i);
+            c[i] = skip_to > 0 ? i * D : co;
+            p[i] = pack_cell(skip_to > 0 ? skip_to : org, init_score_mul * i);
         }
 
         const int SENT = m + n + 1;                       // :394

@@ -437,3 +437,93 @@ def test_multi_adapter_plan_vs_oracle(hip, orc):
         got = (int(bm.adapter_index[i]), tuple(int(v) for v in bm.coords[i])) if bm.found[i] else None
         assert got == best[i], (reads[i], got, best[i])
     assert sum(b is not None for b in best) > 1000
+
+
+def test_column_skipping_is_exact(hip, orc):
+    """3' adapters whose prefilter has the pigeonhole property let the DP start shortly before
+    the first k-mer hit (DESIGN.md "Column skipping").  The fused path must stay bit-identical to
+    the oracle, which always computes every column: random adapters / rates / indel costs /
+    wildcard modes, reads with several (partial, edited, repeated) adapter copies at all
+    positions, long reads (keys are clipped at 63 chunks)."""
+    from cutadapt_amd import adapters as A
+    from cutadapt_amd.batch import ReadBatch
+    rng = random.Random(777)
+    total = hits = 0
+    for it in range(70):
+        m = rng.choice([8, 12, 17, 20, 25, 30, 33, 34, 40, 48, 57, 64])
+        al = "ACGT" if rng.random() < 0.7 else "ACGTN"
+        seq = rs(rng, m, al)
+        if rng.random() < 0.15:
+            seq = (seq[:max(2, m // 4)] * 5)[:m]                  # repetitive adapter
+        kwargs = {"max_errors": rng.choice([0, 0.05, 0.1, 0.1, 0.15, 0.2, 0.3]),
+                  "min_overlap": rng.randint(1, 6), "read_wildcards": rng.random() < 0.25,
+                  "indels": rng.random() < 0.8}
+        ad = A.BackAdapter(seq, **kwargs)
+        reads = []
+        for _ in range(1500):
+            n = rng.choice([rng.randint(0, 40), rng.randint(100, 200), 150, 150, rng.randint(900, 1300)])
+            r = list(rs(rng, n, "ACGT"))
+            for _copy in range(rng.choice([0, 1, 1, 1, 2, 3])):
+                a0 = rng.randint(0, m - 1) if rng.random() < 0.2 else 0
+                piece = list(ad.sequence[a0:a0 + rng.randint(1, m)])
+                for _e in range(rng.choice([0, 0, 0, 1, 1, 2, 3])):
+                    if piece:
+                        x = rng.randrange(len(piece))
+                        op = rng.randint(0, 2)
+                        if op == 0:
+                            piece[x] = rng.choice("ACGT")
+                        elif op == 1:
+                            piece.insert(x, rng.choice("ACGT"))
+                        else:
+                            del piece[x]
+                p0 = rng.randint(0, len(r))
+                r[p0:p0] = piece
+            if rng.random() < 0.2:
+                r = [c if rng.random() > 0.02 else "N" for c in r]
+            reads.append("".join(r)[:rng.choice([len(r), 150, len(r)])])
+        bm = ad.match_to_batch(ReadBatch.from_strings(reads))
+        spec = ad.matcher_spec()
+        oa = orc.Aligner(spec.sequence, spec.max_error_rate, spec.flags, spec.wildcard_ref, spec.wildcard_query,
+                         spec.indel_cost, spec.min_overlap)
+        of = orc.KmerFinder(spec.kmer_sets, spec.kmer_ref_wildcards, spec.kmer_query_wildcards)
+        seqs, offsets = orc.pack_reads(reads)
+        want6, want_st = orc.match_batch(oa, of, seqs, offsets)
+        found = want_st == 1
+        assert np.array_equal(bm.found, found), (seq, kwargs, np.nonzero(bm.found != found)[0][:5])
+        bad = np.nonzero((bm.coords != want6.astype(np.int64)).any(axis=1) & found)[0]
+        assert len(bad) == 0, (seq, kwargs, reads[bad[0]], bm.coords[bad[0]], want6[bad[0]])
+        total += len(reads)
+        hits += int(found.sum())
+    assert total >= 100000 and hits > 30000
+
+
+def test_column_skipping_equals_full_dp_large(hip):
+    """GPU vs GPU at scale: fused path (prefilter -> ordered queue -> DP that may skip columns)
+    against kmers_present_batch AND locate_batch (full DP over every column, itself checked
+    against the oracle above) on ~6 M synthetic reads over random 3' adapters."""
+    import torch
+    from cutadapt_amd import adapters as A
+    from cutadapt_amd.batch import ReadBatch, match_batch
+    rng = random.Random(2718)
+    n = 150_000
+    checked = 0
+    for it in range(40):
+        m = rng.choice([10, 16, 21, 28, 33, 33, 36, 45, 52, 64])
+        seq = rs(rng, m, "ACGT")
+        if it % 7 == 0:
+            seq = (seq[:5] * 20)[:m]
+        ad = A.BackAdapter(seq, max_errors=rng.choice([0.05, 0.1, 0.1, 0.2, 0.25]), min_overlap=rng.randint(1, 5),
+                           indels=rng.random() < 0.85)
+        L = rng.choice([50, 100, 150, 150, 251])
+        batch = ReadBatch.synthetic(n, L, [ad.sequence], seed=1000 + it, p_adapter=rng.choice([0.3, 0.6, 0.9]),
+                                    p_edit=rng.choice([0.0, 0.02, 0.05, 0.1]), p_n=rng.choice([0.0, 0.005, 0.02]))
+        fused = match_batch(ad._fused_plan, batch)
+        present = ad.kmer_finder.kmers_present_batch(batch)
+        full = ad.aligner.locate_batch(batch)
+        torch.cuda.synchronize()
+        want_found = (present == 1) & (full.status == 1)
+        assert torch.equal(fused.status == 1, want_found), (seq, it)
+        assert torch.equal(fused.out6[want_found], full.out6[want_found]), (seq, it)
+        assert int(fused.out6[~want_found].abs().sum()) == 0
+        checked += int(want_found.sum())
+    assert checked > 1_000_000
