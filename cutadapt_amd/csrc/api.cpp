@@ -554,6 +554,9 @@ static int run_filter(const cah_plan* plan, const PlanDeviceCopy* pd, int32_t ad
                       unsigned long long* d_queue_count, uint8_t* d_queue_keys,
                       unsigned long long* d_work_counter, hipStream_t s) {
     const CahMatcher& mt = plan->matchers[(size_t)adapter];
+    if (mt.n_words > 1024)
+        return fail(CAH_EUNSUPPORTED, "adapter %d: %d packed k-mer words exceed the 1024-word limit of the prefilter kernel",
+                    adapter, mt.n_words);
     FilterArgs f;
     f.words = pd->d_words + mt.first_word;
     f.n_words = mt.n_words;

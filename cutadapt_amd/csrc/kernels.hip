@@ -192,6 +192,9 @@ __device__ __forceinline__ void filter_word_chunk(const Chunk& ck, const uint64_
 #define FILTER_TILE 4096
 #define FILTER_WAVES 4
 
+#ifndef CAH_FILTER_PREFETCH
+#define CAH_FILTER_PREFETCH 1      // chunks requested ahead of the one being processed
+#endif
 #ifndef CAH_FILTER_WAVES
 #define CAH_FILTER_WAVES 4
 #endif
@@ -280,10 +283,17 @@ __global__ __launch_bounds__(256, CAH_FILTER_WAVES) void k_filter(FilterArgs a) 
 
                 int pos = lo;
                 Chunk cur = load_chunk(q, pos, n, hi);
+#if CAH_FILTER_PREFETCH == 2
+                Chunk nxt = load_chunk(q, pos + 16, n, hi);
+#endif
                 for (;;) {
                     const bool live = !hit && pos < hi;
                     if (!__any(live)) break;
+#if CAH_FILTER_PREFETCH == 2
+                    const Chunk nxt2 = load_chunk(q, pos + 32, n, live ? hi : 0);    // two chunks ahead
+#else
                     const Chunk nxt = load_chunk(q, pos + 16, n, live ? hi : 0);
+#endif
                     seen |= cur.w[0] | cur.w[1] | cur.w[2] | cur.w[3];
                     uint64_t any_found = 0;
     #pragma unroll
@@ -308,6 +318,9 @@ __global__ __launch_bounds__(256, CAH_FILTER_WAVES) void k_filter(FilterArgs a) 
                     if (live && any_found != 0) { hit = true; hit_pos = pos; }
                     pos += 16;
                     cur = nxt;
+#if CAH_FILTER_PREFETCH == 2
+                    nxt = nxt2;
+#endif
                 }
             }
             if (seen & 0x80808080u) invalid = true;
