@@ -25,6 +25,7 @@ EXPORTED_SYMBOLS = [
     "cah_workspace_bytes", "cah_validate_ascii_batch", "cah_locate_batch_host",
     "cah_kmers_present_batch_host", "cah_match_batch_host", "cah_profile_enable",
     "cah_profile_reset", "cah_profile_read", "cah_synth_reads",
+    "cah_fastq_scan", "cah_pack_sequences", "cah_fastq_write_trimmed",
 ]
 
 
@@ -104,10 +105,11 @@ def lib():
     L.cah_profile_read.argtypes = [C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(i64)]
     L.cah_synth_reads.argtypes = [C.c_uint64, i64, i64, i32, C.c_uint32, C.c_uint32, C.c_uint32,
                                   C.c_char_p, C.POINTER(i32), i32, vp, vp, vp]
+    L.cah_fastq_scan.argtypes = [vp, i64, C.c_int, i64, vp, C.POINTER(i64), C.POINTER(i64)]
+    L.cah_pack_sequences.argtypes = [vp, vp, i64, vp, vp]
+    L.cah_fastq_write_trimmed.argtypes = [vp, vp, i64, vp, vp, vp, vp, i64, C.POINTER(i64)]
     for name in EXPORTED_SYMBOLS:
-        fn = getattr(L, name)
-        if fn.restype is C.c_int and name not in ("cah_abi_version", "cah_plan_n_adapters"):
-            pass
+        getattr(L, name)
     _lib = L
     return L
 

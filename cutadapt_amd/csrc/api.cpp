@@ -38,6 +38,9 @@ static int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+// for the other translation units of the library
+int cah_set_error_(int code, const char* msg) { return fail(code, "%s", msg); }
+
 #define HIP_TRY(expr)                                                                    \
     do {                                                                                 \
         hipError_t e__ = (expr);                                                         \

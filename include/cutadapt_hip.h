@@ -190,6 +190,28 @@ int cah_synth_reads(uint64_t seed, int64_t first_index, int64_t n_reads, int32_t
                     const char *adapters, const int32_t *adapter_off, int32_t n_adapters,
                     uint8_t *d_seqs, int64_t *d_offsets, void *stream);
 
+/* ---- "next" rows of SURVEY.md section 8(f): the data formats either side of the path ------- */
+/* Host-side FASTQ chunk handling (no GPU needed).  Replaces, for the batch pipeline, what the
+ * reference does through the third-party dnaio package: record-aligned chunks
+ * (runners.py:116-126), per-read SequenceRecord parsing (files.py:108-114), string slicing for
+ * trimming (adapters.py:453-454, :486-487) and FASTQ formatting of the output.
+ *
+ * cah_fastq_scan: index complete 4-line records of a chunk.  rec[i*6..i*6+5] = (name_beg,
+ *   name_end, seq_beg, seq_end, qual_beg, qual_end) byte offsets into buf ('@', "\n" and "\r\n"
+ *   excluded).  *consumed = bytes covered by complete records; the caller prepends the rest to the
+ *   next chunk.  is_final: the chunk ends the file (a last line without newline is accepted,
+ *   leftovers are a format error).  CAH_EINVAL + message on malformed records. */
+int cah_fastq_scan(const uint8_t *buf, int64_t len, int is_final, int64_t max_records,
+                   int64_t *rec, int64_t *n_records, int64_t *consumed);
+/* sequence lines packed back to back + offsets[n+1]: the layout of cah_match_batch */
+int cah_pack_sequences(const uint8_t *buf, const int64_t *rec, int64_t n_records,
+                       uint8_t *out_seqs, int64_t *out_offsets);
+/* "@name\nSEQ[keep_beg:keep_end]\n+\nQUAL[keep_beg:keep_end]\n" for every record with
+ * keep[i] != 0 (keep may be NULL = all). */
+int cah_fastq_write_trimmed(const uint8_t *buf, const int64_t *rec, int64_t n_records,
+                            const int32_t *keep_beg, const int32_t *keep_end, const uint8_t *keep,
+                            uint8_t *out, int64_t out_cap, int64_t *out_len);
+
 #ifdef __cplusplus
 }
 #endif
