@@ -75,26 +75,34 @@ class FastqChunk:
 def read_fastq_chunks(path_or_file: Union[str, BinaryIO], chunk_bytes: int = DEFAULT_CHUNK_BYTES) -> Iterator[FastqChunk]:
     """Record-aligned chunks of a (possibly gzip-compressed) FASTQ file: the job dnaio.read_chunks
     does for the reference's ReaderProcess (runners.py:116-126).  A partial record at the end of a
-    buffer is carried over to the next one."""
+    buffer is carried over to the next one.  Each chunk gets its own buffer (read straight into it;
+    only the short carried tail is copied)."""
     f = _open_maybe_gz(path_or_file)
     L = _lib.lib()
     carry = b""
     while True:
-        block = f.read(chunk_bytes)
-        final = len(block) == 0
-        data = carry + block
-        if not data:
+        buf = np.empty(len(carry) + chunk_bytes, dtype=np.uint8)
+        if carry:
+            buf[:len(carry)] = np.frombuffer(carry, dtype=np.uint8)
+        got = f.readinto(memoryview(buf)[len(carry):]) if hasattr(f, "readinto") else None
+        if got is None:                                   # file objects without readinto
+            block = f.read(chunk_bytes)
+            got = len(block)
+            buf[len(carry):len(carry) + got] = np.frombuffer(block, dtype=np.uint8)
+        total = len(carry) + got
+        final = got == 0
+        if total == 0:
             break
-        buf = np.frombuffer(data, dtype=np.uint8)
-        max_rec = data.count(b"\n") // 4 + 2
+        data = buf[:total]
+        max_rec = int(np.count_nonzero(data == 10)) // 4 + 2
         rec = np.empty((max_rec, 6), dtype=np.int64)
         n = C.c_int64(0)
         consumed = C.c_int64(0)
-        _lib.check(L.cah_fastq_scan(buf.ctypes.data, len(data), int(final), max_rec, rec.ctypes.data,
+        _lib.check(L.cah_fastq_scan(data.ctypes.data, total, int(final), max_rec, rec.ctypes.data,
                                     C.byref(n), C.byref(consumed)))
+        carry = data[consumed.value:].tobytes()
         if n.value:
-            yield FastqChunk(buf[:consumed.value].copy() if consumed.value < len(data) else buf, rec[:n.value].copy())
-        carry = data[consumed.value:]
+            yield FastqChunk(data[:consumed.value], rec[:n.value])
         if final:
             break
         if not n.value and len(carry) > 64 * chunk_bytes:
