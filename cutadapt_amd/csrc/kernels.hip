@@ -27,8 +27,8 @@
 #ifndef CAH_SCHED_ROWS
 #define CAH_SCHED_ROWS 1
 #endif
-#ifndef CAH_SKIP_ROWS
-#define CAH_SKIP_ROWS 2          // rows between two wave-uniform "any band left?" checks
+#ifndef CAH_SKIP_CHECK
+#define CAH_SKIP_CHECK(I) (((I) & 1) == 1)      // rows in front of which the wave asks "any band left?"
 #endif
 
 __device__ __forceinline__ int wave_lane() { return threadIdx.x & (WAVE - 1); }
@@ -379,7 +379,9 @@ __device__ __forceinline__ void dp_rows(int (&c)[ROWS + 1], int (&p)[ROWS + 1], 
                                         const int last, const int m, const int k, const int Dm1) {
     if constexpr (I <= ROWS) {
         // every 4 rows: leave the column as soon as no lane of the wave has band left
-        if constexpr ((I % CAH_SKIP_ROWS) == 1 || CAH_SKIP_ROWS == 1) {
+        // band-left checks: dense near the top (the narrow phase keeps 6-12 rows alive), sparse
+        // further down (a wave that gets there usually needs the whole column)
+        if constexpr (CAH_SKIP_CHECK(I)) {
             if (!__any(last >= I)) return;
         }
         // Straight-line, select-only cell update (no exec-mask regions: lanes whose band ended

@@ -527,3 +527,59 @@ def test_column_skipping_equals_full_dp_large(hip):
         assert int(fused.out6[~want_found].abs().sum()) == 0
         checked += int(want_found.sum())
     assert checked > 1_000_000
+
+
+def test_edge_cases_through_the_batch_api(hip, orc):
+    """empty batch, empty reads, a very long read, reads beyond the length limit, views,
+    ASCII validation, workspace too small"""
+    import torch
+    from cutadapt_amd import _lib
+    from cutadapt_amd.adapters import BackAdapter
+    from cutadapt_amd.batch import ReadBatch, match_batch, locate_batch
+    ad = BackAdapter(TRUSEQ, max_errors=0.1, min_overlap=3)
+    # empty batch
+    empty = ReadBatch.from_strings([])
+    r = match_batch(ad._fused_plan, empty)
+    assert r.status.numel() == 0 and r.out6.shape == (0, 6)
+    assert ad.match_to_batch(empty).tuples() == []
+    # only empty reads / one-character reads
+    b = ReadBatch.from_strings(["", "", "A", ""])
+    assert ad.match_to_batch(b).tuples() == [None, None, None, None]
+    # a long read with the adapter far inside, next to short ones (ragged batch)
+    rng = random.Random(9)
+    long_read = rs(rng, 200_000, "ACGT") + TRUSEQ + rs(rng, 1000, "ACGT")
+    reads = ["ACGT" * 10 + TRUSEQ[:12], long_read, "", TRUSEQ, rs(rng, 5000, "ACGT")]
+    got = ad.match_to_batch(ReadBatch.from_strings(reads)).tuples()
+    oa = orc.Aligner(TRUSEQ, 0.1, BACK, False, False, 1, 3)
+    of = orc.KmerFinder(ad.kmer_finder.positions_and_kmers)
+    want = [oa.locate(x) if of.kmers_present(x) else None for x in reads]
+    assert got == want and got[1][2] == 200_000 and got[3] == (0, 33, 0, 33, 33, 0)
+    # beyond CAH_MAX_READ_LEN: flagged invalid, not silently mishandled
+    too_long = ReadBatch.from_strings(["ACGT", "A" * 1_000_001])
+    res = locate_batch(ad.aligner._plan, 0, too_long)
+    torch.cuda.synchronize()
+    assert res.status.cpu().tolist()[1] == 2
+    with pytest.raises(ValueError):
+        ad.match_to_batch(too_long)
+    # sub-sequence views (second stage of linked adapters): same result as slicing on the host
+    base = ReadBatch.from_strings(reads)
+    starts = torch.tensor([3, 150_000, 0, 1, 10], device=base.device)
+    lens = base.lengths() - starts
+    got_v = ad.match_to_batch(base.view(starts, lens)).tuples()
+    want_v = [oa.locate(x[s:]) if of.kmers_present(x[s:]) else None for x, s in zip(reads, starts.cpu().tolist())]
+    assert got_v == want_v
+    # ASCII validation of externally supplied buffers
+    raw = np.frombuffer(b"ACGT" + b"AC\xffT" + b"ACGT", dtype=np.uint8)
+    bad = ReadBatch.from_host(raw, np.array([0, 4, 8, 12], dtype=np.int64))
+    with pytest.raises(ValueError):
+        bad.validate_ascii()
+    ReadBatch.from_host(raw[:4], np.array([0, 4], dtype=np.int64)).validate_ascii()
+    # workspace too small is an error, not a crash
+    n = 1000
+    bb = ReadBatch.synthetic(n, 150, [TRUSEQ], seed=3)
+    out6 = torch.empty((n, 6), dtype=torch.int32, device=bb.device)
+    st = torch.empty(n, dtype=torch.uint8, device=bb.device)
+    small = torch.empty(64, dtype=torch.uint8, device=bb.device)
+    rc = _lib.lib().cah_match_batch(ad._fused_plan.handle, bb.seqs.data_ptr(), bb.offsets.data_ptr(), None, n,
+                                    out6.data_ptr(), None, st.data_ptr(), small.data_ptr(), small.numel(), None)
+    assert rc == _lib.CAH_EINVAL and "workspace" in _lib.last_error()
