@@ -704,13 +704,29 @@ __global__ __launch_bounds__(256) void k_comparer(DpArgs a) {
         const int n = (int)n64;
         const uint8_t* q = a.seqs + off;
         const int length = min(m, n);
+        // compared region of the read: its first (prefix) or last (suffix) `length` characters,
+        // fetched 16 per global load; compared position i is bit i of the row bitset
+        const int qbeg = suffix ? n - length : 0;
         int errors = 0;
-        for (int i = 0; i < length; ++i) {
-            const unsigned ch = q[suffix ? n - 1 - i : i];
-            uint64_t mk = 0;
-            if (ch < CAH_TABLE_CHARS) mk = s_rowmask[ch]; else invalid = true;
-            errors += ((mk >> i) & 1ull) ? 0 : 1;
+        unsigned seen = 0;
+#pragma unroll 1
+        for (int c0 = 0; c0 < CAH_MAX_M; c0 += 16) {
+            if (!__any(c0 < length)) break;
+            if (c0 < length) {
+                const Chunk ck = load_chunk(q, qbeg + c0, n, qbeg + length);
+                seen |= ck.w[0] | ck.w[1] | ck.w[2] | ck.w[3];
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const int rel = c0 + t;                               // offset inside the region
+                    const int i = suffix ? length - 1 - rel : rel;        // compared position
+                    const unsigned ch = chunk_byte(ck, t) & (CAH_TABLE_CHARS - 1);
+                    const uint64_t mk = s_rowmask[ch];
+                    const bool inside = rel < length;
+                    errors += (inside && !((mk >> (inside ? i : 0)) & 1ull)) ? 1 : 0;
+                }
+            }
         }
+        if (seen & 0x80808080u) invalid = true;
         const bool found = !invalid && !(errors > max_k || length < min_overlap);   // :690-691
         const int score = length - 2 * errors;                                     // :692
         int32_t* o = a.out6 + r * 6;
