@@ -394,9 +394,7 @@ __device__ __forceinline__ void dp_rows(int (&c)[ROWS + 1], int (&p)[ROWS + 1], 
         // --- independent of the cell above (can be issued while its result is in flight) -------
         const bool eq = (mword & (1u << ((I - 1) & 31))) != 0;
         const bool in_band = I <= last;                   // per lane: Ukkonen band (last <= m)
-        const int c_keep = in_band ? dc : oc;             // match takes the diagonal; out of band keeps stale
         const int p_diag = dp + (eq ? 1 : -1);            // diagonal payload: +1 match / -1 mismatch
-        const int p_ins = op - 2;
         // --- the serial part: cost through the cell above ------------------------------------
         // x = min(c_del, c_ins) - 1 with c_del = cprev + D, c_ins = oc + D  (Dm1 = D - 1, wave-uniform;
         // UNIT = unit indel cost, the default: one add less per cell)
@@ -404,14 +402,15 @@ __device__ __forceinline__ void dp_rows(int (&c)[ROWS + 1], int (&p)[ROWS + 1], 
         const int c_ne = min(dc, x) + 1;                  // min(c_diag, c_del, c_ins)
         const bool mis = dc <= x;                         // c_diag <= c_del && c_diag <= c_ins
         const bool del = cprev <= oc;                     // c_del <= c_ins
-        const int cost = (in_band && !eq) ? c_ne : c_keep;
+        const int cost = eq ? dc : c_ne;                  // match takes the diagonal unconditionally
         // payload: diag (match/mismatch) | deletion (cell above, -2) | insertion (old cell, -2)
-        const bool diag = eq || mis;
-        const int p_other = in_band ? (diag ? p_diag : p_ins) : op;
-        const int pay = (in_band && !diag && del) ? pprev - 2 : p_other;
-        c[I] = cost;
-        p[I] = pay;
-        nl = (in_band && cost <= k) ? I : nl;
+        const int p_indel = (del ? pprev : op) - 2;
+        const int pay = (eq || mis) ? p_diag : p_indel;
+        c[I] = in_band ? cost : oc;                       // out of band: the stale cell stays
+        p[I] = in_band ? pay : op;
+        // A cell outside the band has cost > k (it left the band that way, or is an initial
+        // cell below row k+1), so testing the stored value needs no "in_band &&".
+        nl = c[I] <= k ? I : nl;
         if constexpr (I > ROWS - 8) {                     // m is in (ROWS-8, ROWS]: wave-uniform capture
             // (row capacities come in steps of 4; 8 keeps the smallest kernel, m <= 8, correct)
             if (I == m) { cm_c = cost; cm_p = pay; }
@@ -525,7 +524,7 @@ __global__ __launch_bounds__(256, CAH_DP_WAVES(ROWS)) void k_dp(DpArgs a) {
             const int d = min_n - i;
             const int org = min(max(d, init_org_lo), init_org_hi);
             const int co = (w_max * max(i, min_n) + w_min * min(i, min_n) + w_y * min_n + w_x * i) * D;
-            c[i] = skip_to > 0 ? i * D : co;
+            c[i] = i > m ? (1 << 28) : (skip_to > 0 ? i * D : co);   // rows beyond the adapter: never <= k
             p[i] = pack_cell(skip_to > 0 ? skip_to : org, init_score_mul * i);
         }
 
