@@ -521,7 +521,7 @@ static int run_aligner(const cah_plan* plan, const PlanDeviceCopy* pd, int32_t a
     HIP_TRY(hipMemsetAsync(d_work_counter, 0, sizeof(unsigned long long), s));
     if (mt.kind == CAH_KIND_ALIGNER) {
         ProfScope ps(s, CAH_PROF_DP, n_reads);
-        HIP_TRY(launch_dp(a, mt.m, mt.indel_cost == 1, n_reads, pd->n_cus, s));
+        HIP_TRY(launch_dp(a, mt.m, mt.indel_cost == 1, mt.flags == 14, n_reads, pd->n_cus, s));
     } else {
         ProfScope ps(s, CAH_PROF_COMPARER, n_reads);
         HIP_TRY(launch_comparer(a, n_reads, pd->n_cus, s));

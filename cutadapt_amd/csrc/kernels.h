@@ -42,7 +42,8 @@ struct DpArgs {
 };
 
 hipError_t launch_filter(const FilterArgs& a, int mode, int n_cus, hipStream_t s);
-hipError_t launch_dp(const DpArgs& a, int m, bool unit_indel_cost, int64_t max_items, int n_cus, hipStream_t s);
+hipError_t launch_dp(const DpArgs& a, int m, bool unit_indel_cost, bool back_adapter, int64_t max_items, int n_cus,
+                     hipStream_t s);
 hipError_t launch_comparer(const DpArgs& a, int64_t max_items, int n_cus, hipStream_t s);
 hipError_t launch_validate(const uint8_t* seqs, const int64_t* offsets, const int32_t* lens,
                            int64_t n_reads, int32_t* bad, int n_cus, hipStream_t s);

@@ -677,6 +677,271 @@ __global__ __launch_bounds__(256, CAH_DP_WAVES(ROWS)) void k_dp(DpArgs a) {
 }
 
 // =============================================================================================
+// k_dp_packed<ROWS>: Aligner.locate for the common case -- a 3' adapter (flags = QUERY_START |
+// QUERY_STOP | REFERENCE_END, reference Where.BACK) with unit indel cost -- with ONE 32-bit word
+// per DP cell:
+//
+//      bits 20..27  cost          (<= 64: a cell of row i costs at most i, by i deletions)
+//      bits 18..19  priority      (only inside the 3-way minimum, cleared afterwards)
+//      bits  9..17  rel = j - origin, the number of read columns the alignment spans so far
+//                   (<= i + cost <= 128; row 0 is the constant (0, 0, 0))
+//      bits  0..8   score + 256   (in [-128, 64])
+//
+// On gfx950 v_min/v_cmp/v_cndmask issue at 4 cycles per wave64, v_add/v_and at 2 (measured,
+// DESIGN.md), so the cell is organised around adds and ONE v_min3_u32: the three candidates
+// are predecessor + constant (cost step, score step, rel step and a priority code 0 / 1 / 2 for
+// mismatch / deletion / insertion), and the unsigned minimum picks the cheapest candidate and,
+// among equal costs, the reference's order mismatch >= deletion >= insertion (_align.pyx:462-476)
+// together with its payload.  A matching character takes the diagonal unconditionally
+// (:446-453).  One VGPR per adapter row instead of two.
+// Everything around the cell (band, candidate rules, last-column scan, early exit, column
+// skipping) is the same as in k_dp; origin = j - rel is decoded where the reference reads it.
+// =============================================================================================
+#define PK_COST_SHIFT 20
+#define PK_PRIO_SHIFT 18
+#define PK_REL_SHIFT 9
+#define PK_SCORE_BIAS 256
+#define PK_PRIO_MASK (3u << PK_PRIO_SHIFT)
+#define PK_D_MATCH ((1u << PK_REL_SHIFT) + 1u)
+#define PK_D_MIS ((1u << PK_COST_SHIFT) + (1u << PK_REL_SHIFT) - 1u)
+#define PK_D_DEL ((1u << PK_COST_SHIFT) + (1u << PK_PRIO_SHIFT) - 2u)
+#define PK_D_INS ((1u << PK_COST_SHIFT) + (2u << PK_PRIO_SHIFT) + (1u << PK_REL_SHIFT) - 2u)
+
+__device__ __forceinline__ unsigned pk_cell(int cost, int rel, int score) {
+    return ((unsigned)cost << PK_COST_SHIFT) | ((unsigned)rel << PK_REL_SHIFT) | (unsigned)(score + PK_SCORE_BIAS);
+}
+__device__ __forceinline__ int pk_cost(unsigned w) { return (int)(w >> PK_COST_SHIFT); }
+__device__ __forceinline__ int pk_rel(unsigned w) { return (int)((w >> PK_REL_SHIFT) & 0x1FFu); }
+__device__ __forceinline__ int pk_score(unsigned w) { return (int)(w & 0x1FFu) - PK_SCORE_BIAS; }
+
+template <int I, int ROWS>
+__device__ __forceinline__ void dp_rows_packed(unsigned (&w)[ROWS + 1], const uint64_t mk, unsigned wd,
+                                               int& nl, unsigned& cm_w, const int last, const int m,
+                                               const unsigned klim) {
+    if constexpr (I <= ROWS) {
+        if constexpr (CAH_SKIP_CHECK(I)) {
+            if (!__any(last >= I)) return;
+        }
+        const unsigned wold = w[I];
+        const unsigned wprev = w[I - 1];
+        const unsigned mword = (I - 1) < 32 ? (unsigned)mk : (unsigned)(mk >> 32);
+        const bool eq = (mword & (1u << ((I - 1) & 31))) != 0;
+        const bool in_band = I <= last;
+        const unsigned a = wd + PK_D_MIS;                 // mismatch: from the diagonal
+        const unsigned b = wprev + PK_D_DEL;              // deletion: from the cell above (this column)
+        const unsigned c3 = wold + PK_D_INS;              // insertion: from this row, previous column
+        const unsigned mn = min(min(a, b), c3) & ~PK_PRIO_MASK;
+        const unsigned e = wd + PK_D_MATCH;
+        const unsigned wn = eq ? e : mn;
+        w[I] = in_band ? wn : wold;                       // out of band: the stale cell stays
+        nl = w[I] < klim ? I : nl;                        // stale cells cost > k (see k_dp)
+        if constexpr (I > ROWS - 8) {
+            if (I == m) cm_w = wn;                        // wave-uniform capture of cell (m, j)
+        }
+        if constexpr ((I % CAH_SCHED_ROWS) == 0) __builtin_amdgcn_sched_barrier(0);
+        dp_rows_packed<I + 1, ROWS>(w, mk, wold, nl, cm_w, last, m, klim);
+    }
+}
+
+#define CAH_ROWP_CASE(K) case K: if constexpr (K <= ROWS) { wi = w[K]; } break;
+template <int ROWS>
+__device__ __forceinline__ unsigned get_row_packed(const unsigned (&w)[ROWS + 1], int i) {
+    unsigned wi = 0;
+    switch (__builtin_amdgcn_readfirstlane(i)) {
+        CAH_ROWP_CASE(0) CAH_ROWP_CASE(1) CAH_ROWP_CASE(2) CAH_ROWP_CASE(3) CAH_ROWP_CASE(4) CAH_ROWP_CASE(5) CAH_ROWP_CASE(6) CAH_ROWP_CASE(7)
+        CAH_ROWP_CASE(8) CAH_ROWP_CASE(9) CAH_ROWP_CASE(10) CAH_ROWP_CASE(11) CAH_ROWP_CASE(12) CAH_ROWP_CASE(13) CAH_ROWP_CASE(14) CAH_ROWP_CASE(15)
+        CAH_ROWP_CASE(16) CAH_ROWP_CASE(17) CAH_ROWP_CASE(18) CAH_ROWP_CASE(19) CAH_ROWP_CASE(20) CAH_ROWP_CASE(21) CAH_ROWP_CASE(22) CAH_ROWP_CASE(23)
+        CAH_ROWP_CASE(24) CAH_ROWP_CASE(25) CAH_ROWP_CASE(26) CAH_ROWP_CASE(27) CAH_ROWP_CASE(28) CAH_ROWP_CASE(29) CAH_ROWP_CASE(30) CAH_ROWP_CASE(31)
+        CAH_ROWP_CASE(32) CAH_ROWP_CASE(33) CAH_ROWP_CASE(34) CAH_ROWP_CASE(35) CAH_ROWP_CASE(36) CAH_ROWP_CASE(37) CAH_ROWP_CASE(38) CAH_ROWP_CASE(39)
+        CAH_ROWP_CASE(40) CAH_ROWP_CASE(41) CAH_ROWP_CASE(42) CAH_ROWP_CASE(43) CAH_ROWP_CASE(44) CAH_ROWP_CASE(45) CAH_ROWP_CASE(46) CAH_ROWP_CASE(47)
+        CAH_ROWP_CASE(48) CAH_ROWP_CASE(49) CAH_ROWP_CASE(50) CAH_ROWP_CASE(51) CAH_ROWP_CASE(52) CAH_ROWP_CASE(53) CAH_ROWP_CASE(54) CAH_ROWP_CASE(55)
+        CAH_ROWP_CASE(56) CAH_ROWP_CASE(57) CAH_ROWP_CASE(58) CAH_ROWP_CASE(59) CAH_ROWP_CASE(60) CAH_ROWP_CASE(61) CAH_ROWP_CASE(62) CAH_ROWP_CASE(63)
+        CAH_ROWP_CASE(64)
+        default: break;
+    }
+    return wi;
+}
+
+#ifndef CAH_DPP_WAVES
+#define CAH_DPP_WAVES(ROWS) ((ROWS) <= 24 ? 8 : ((ROWS) <= 44 ? 6 : 5))
+#endif
+
+template <int ROWS>
+__global__ __launch_bounds__(256, CAH_DPP_WAVES(ROWS)) void k_dp_packed(DpArgs a) {
+    __shared__ uint64_t s_rowmask[CAH_TABLE_CHARS];
+    __shared__ int s_ncnt[CAH_MAX_M + 1];
+    __shared__ int s_thr[CAH_MAX_M + 1];
+    const CahMatcher* mt = a.matcher;
+    for (int i = threadIdx.x; i < CAH_TABLE_CHARS; i += blockDim.x) s_rowmask[i] = mt->rowmask[i];
+    for (int i = threadIdx.x; i <= CAH_MAX_M; i += blockDim.x) {
+        s_ncnt[i] = mt->n_counts[i];
+        s_thr[i] = mt->thr[i];
+    }
+    __syncthreads();
+
+    const int m = mt->m, k = mt->k;
+    const int min_overlap = mt->min_overlap;
+    const bool wildcard_ref = mt->wildcard_ref != 0;
+    const int eff_full = mt->effective_length;
+    const int half_m = m / 2;
+    // cost <= k  <=>  word < (k+1) << 20 (priority bits are clear in stored cells); costs never
+    // exceed 64 here, so any k >= 200 behaves the same
+    const unsigned klim = (unsigned)(min(k, 200) + 1) << PK_COST_SHIFT;
+
+    const int lane = wave_lane();
+    int64_t total = a.n_reads;
+    if (a.queue_count) total = (int64_t)(*a.queue_count);
+    const bool skip_cols = a.queue && a.queue_keys && mt->skip_ok != 0;
+
+    for (;;) {
+        const int64_t base = wave_dequeue(a.work_counter);
+        if (base >= total) break;
+        const int64_t idx = base + lane;
+        const bool valid = idx < total;
+        int64_t r = 0;
+        if (valid) r = a.queue ? (int64_t)a.queue[idx] : idx;
+        int64_t off = 0, n64 = 0;
+        if (valid) read_extent(a.offsets, a.lens, r, off, n64);
+        bool invalid = false;
+        if (n64 > a.max_read_len) { invalid = true; n64 = 0; }
+        const int n = (int)n64;
+        const uint8_t* q = a.seqs + off;
+
+        // flags = BACK: every column 1..n (_align.pyx:346-352), unless the prefilter proves the
+        // first columns irrelevant (column skipping, see k_dp / DESIGN.md)
+        const int max_n = n;
+        int min_n = 0;
+        if (skip_cols && valid) min_n = max(0, (int)a.queue_keys[idx] * 16 - m - k - 1);
+
+        // first column (:374-378): cost i, score -2i, origin = this column (rel 0)
+        unsigned w[ROWS + 1];
+#pragma unroll
+        for (int i = 0; i <= ROWS; ++i) w[i] = i > m ? pk_cell(255, 0, 0) : pk_cell(i, 0, -2 * i);
+        const unsigned w_row0 = pk_cell(0, 0, 0);         // row 0 of every column: cost 0, origin j
+
+        const int SENT = m + n + 1;                       // :394
+        int b_cost = SENT, b_origin = 0, b_score = 0, b_refstop = m, b_qstop = n;
+
+        int last = min(m, k + 1);                         // :399
+        int last_filled = 0, lf_ran = 0;
+        int j = min_n;
+        bool done = !valid;
+
+        int pos = min_n;
+        Chunk cur = load_chunk(q, pos, n, valid ? max_n : 0);
+        Chunk nxt = load_chunk(q, pos + 16, n, valid ? max_n : 0);
+        int left = 16;
+        unsigned bad_chars = cur.w[0] | cur.w[1] | cur.w[2] | cur.w[3];
+        uint64_t mk_next = s_rowmask[cur.w[0] & (CAH_TABLE_CHARS - 1)];
+        for (;;) {
+            const bool act = !done && j < max_n;
+            if (!__any(act)) break;
+            const uint64_t mk = mk_next;
+            cur.w[0] = (cur.w[0] >> 8) | (cur.w[1] << 24);
+            cur.w[1] = (cur.w[1] >> 8) | (cur.w[2] << 24);
+            cur.w[2] = (cur.w[2] >> 8) | (cur.w[3] << 24);
+            cur.w[3] >>= 8;
+            if (--left == 0) {
+                cur = nxt;
+                bad_chars |= cur.w[0] | cur.w[1] | cur.w[2] | cur.w[3];
+                pos += 16;
+                nxt = load_chunk(q, pos + 16, n, (!done) ? max_n : 0);
+                left = 16;
+            }
+            mk_next = s_rowmask[cur.w[0] & (CAH_TABLE_CHARS - 1)];
+            if (act) {
+                ++j;
+                // row 0 is the same in every column (start_in_query: cost 0, score 0, origin j);
+                // it is also the diagonal of row 1
+                int nl = 0;                               // row 0 always has cost 0 <= k
+                unsigned cm_w = w_row0;                   // (m == 0: the candidate cell is row 0)
+                dp_rows_packed<1, ROWS>(w, mk, w_row0, nl, cm_w, last, m, klim);
+                last_filled = last;                       // :484
+                if (last >= 1) lf_ran = last;
+                if (nl < m) {                             // band update (:490-495)
+                    last = nl + 1;
+                } else {
+                    last = m;
+                    // candidate in the last row (:496-533); stop_in_query is set for BACK
+                    const int cost = pk_cost(cm_w), origin = j - pk_rel(cm_w), score = pk_score(cm_w);
+                    const int length = m + min(origin, 0);
+                    int eff = length;
+                    if (wildcard_ref)
+                        eff = length < m ? length - (s_ncnt[m] - s_ncnt[m - length]) : eff_full;
+                    const bool ok = length >= min_overlap && cost <= s_thr[eff];
+                    const int best_len = m + min(b_origin, 0);
+                    if (ok && (b_cost == SENT || (origin <= b_origin + half_m && score > b_score) ||
+                               (length > best_len && score > b_score))) {
+                        b_cost = cost; b_origin = origin; b_score = score; b_refstop = m; b_qstop = j;
+                        if (cost == 0 && origin >= 0) done = true;       // exact match: stop early
+                    }
+                }
+            }
+        }
+        if (bad_chars & 0x80808080u) invalid = true;
+
+        // last column (:536-572); max_n == n always for BACK.  Cells were written in column j (the
+        // last one processed), so origin = j - rel.  The stale `origin` of :565 is that of the
+        // last cell the row loop wrote (row lf_ran).
+        int stale_origin = 0;
+        {
+            unsigned stale_w = w_row0;
+#pragma unroll
+            for (int i = 1; i <= ROWS; ++i) stale_w = (i == lf_ran) ? w[i] : stale_w;
+            stale_origin = lf_ran >= 1 ? j - pk_rel(stale_w) : 0;
+        }
+#pragma unroll 1
+        for (int i = m; i >= 0; --i) {
+            const bool want = valid && i <= last_filled;
+            if (!__any(want)) continue;
+            const unsigned wi = i == 0 ? w_row0 : get_row_packed<ROWS>(w, i);
+            if (want) {
+                const int o_i = j - pk_rel(wi), score = pk_score(wi), cost = pk_cost(wi);
+                const int ref_start = -min(o_i, 0);
+                const int length = i - ref_start;
+                int eff = length;
+                if (wildcard_ref)
+                    eff = length < m ? length - (s_ncnt[i] - s_ncnt[ref_start]) : eff_full;
+                const bool ok = length >= min_overlap && cost <= s_thr[eff];
+                const int best_len = b_refstop + min(b_origin, 0);
+                if (ok && (b_cost == SENT || (stale_origin <= b_origin + half_m && score > b_score) ||
+                           (length > best_len && score > b_score))) {
+                    b_cost = cost; b_origin = o_i; b_score = score; b_refstop = i; b_qstop = n;
+                }
+            }
+        }
+
+        if (valid) {
+            const bool found = b_cost != SENT && !invalid;
+            int32_t* o = a.out6 + r * 6;
+            if (a.merge_best) {
+                if (invalid) {
+                    a.status[r] = 2;
+                } else if (found) {
+                    const bool had = a.status[r] == 1;
+                    if (a.status[r] != 2 && (!had || b_score > o[4] || (b_score == o[4] && b_cost < o[5]))) {
+                        o[0] = b_origin >= 0 ? 0 : -b_origin; o[1] = b_refstop;
+                        o[2] = b_origin >= 0 ? b_origin : 0;  o[3] = b_qstop;
+                        o[4] = b_score; o[5] = b_cost;
+                        a.status[r] = 1;
+                        if (a.best_adapter) a.best_adapter[r] = a.adapter_index;
+                    }
+                }
+            } else {
+                a.status[r] = invalid ? (uint8_t)2 : (found ? (uint8_t)1 : (uint8_t)0);
+                if (found) {
+                    o[0] = b_origin >= 0 ? 0 : -b_origin; o[1] = b_refstop;
+                    o[2] = b_origin >= 0 ? b_origin : 0;  o[3] = b_qstop;
+                    o[4] = b_score; o[5] = b_cost;
+                } else {
+                    o[0] = o[1] = o[2] = o[3] = o[4] = o[5] = 0;
+                }
+            }
+        }
+    }
+}
+
+// =============================================================================================
 // k_comparer: PrefixComparer / SuffixComparer.locate -- Hamming distance over min(m, n)
 // characters, again via the per-character bitset table (bit i = i-th compared position).
 // =============================================================================================
@@ -798,8 +1063,18 @@ hipError_t launch_filter(const FilterArgs& a, int mode, int n_cus, hipStream_t s
     return hipGetLastError();
 }
 
-hipError_t launch_dp(const DpArgs& a, int m, bool unit, int64_t max_items, int n_cus, hipStream_t s) {
+hipError_t launch_dp(const DpArgs& a, int m, bool unit, bool back_adapter, int64_t max_items, int n_cus,
+                     hipStream_t s) {
     const int grid = grid_for(max_items, 8, n_cus);
+    if (unit && back_adapter) {
+        // the common case: 3' adapter, unit costs -> one-word-per-cell kernel
+#define CAH_DPP_CASE(R) \
+        if (m <= R) { hipLaunchKernelGGL((k_dp_packed<R>), dim3(grid), dim3(256), 0, s, a); return hipGetLastError(); }
+        CAH_DPP_CASE(8) CAH_DPP_CASE(12) CAH_DPP_CASE(16) CAH_DPP_CASE(20) CAH_DPP_CASE(24) CAH_DPP_CASE(28)
+        CAH_DPP_CASE(32) CAH_DPP_CASE(36) CAH_DPP_CASE(40) CAH_DPP_CASE(44) CAH_DPP_CASE(48) CAH_DPP_CASE(52)
+        CAH_DPP_CASE(56) CAH_DPP_CASE(60) CAH_DPP_CASE(64)
+#undef CAH_DPP_CASE
+    }
     // UNIT: unit indel cost (the default); the general kernel carries D in an SGPR
 #define CAH_DP_CASE(R)                                                                          \
     if (m <= R) {                                                                               \
