@@ -266,6 +266,15 @@ static int build_matcher(const cah_adapter_desc& d, int index, CahMatcher& mt,
     mt.has_filter = d.n_kmer_sets >= 0 ? 1 : 0;
     if (d.n_kmer_sets > 0 && !d.kmer_sets) return fail(CAH_EINVAL, "adapter %d: kmer_sets is NULL", index);
     const bool rwc = d.kmer_ref_wildcards != 0, qwc = d.kmer_query_wildcards != 0;
+    // Word width: the reference packs k-mers greedily into 64-bit words (_kmer_finder.pyx:131-149).
+    // kmers_present is an OR over all k-mers, so the packing is free; 32-bit words halve the
+    // kernel's work per character, so they are used whenever every k-mer is <= 32 characters.
+    size_t longest_kmer = 0;
+    for (int s = 0; s < d.n_kmer_sets; s++)
+        for (int t = 0; t < d.kmer_sets[s].n_kmers; t++)
+            if (d.kmer_sets[s].kmers[t]) longest_kmer = std::max(longest_kmer, strlen(d.kmer_sets[s].kmers[t]));
+    const size_t word_bits = longest_kmer <= 32 ? 32 : 64;
+    mt.narrow_words = word_bits == 32 ? 1 : 0;
     for (int s = 0; s < d.n_kmer_sets; s++) {
         const cah_kmer_set& ks = d.kmer_sets[s];
         int idx = 0;
@@ -282,7 +291,7 @@ static int build_matcher(const cah_adapter_desc& d, int index, CahMatcher& mt,
                 if (!is_ascii(kmer, len)) return fail(CAH_EINVAL, "Only ASCII strings are supported");
                 if (len > 64)
                     return fail(CAH_EINVAL, "%s of length %zu is longer than the maximum of 64.", kmer, len);
-                if (off + len > 64) break;
+                if (off + len > word_bits) break;
                 kw.init_mask |= 1ull << off;
                 memcpy(word + off, kmer, len);
                 kw.found_mask |= 1ull << (off + len - 1);
@@ -318,7 +327,7 @@ static int build_matcher(const cah_adapter_desc& d, int index, CahMatcher& mt,
     // same wildcard relation as the aligner.  Hand-made k-mer sets that lack it keep skip_ok = 0.
     mt.skip_ok = 0;
     if (d.kind == CAH_KIND_ALIGNER && mt.flags == 14 && d.n_kmer_sets > 0 && m >= 1 &&
-        n_whole_read_words <= CAH_FILTER_SLOTS &&
+        n_whole_read_words <= (mt.narrow_words ? CAH_FILTER_SLOTS_NARROW : CAH_FILTER_SLOTS) &&
         (d.kmer_ref_wildcards != 0) == (d.wildcard_ref != 0) &&
         (d.kmer_query_wildcards != 0) == (d.wildcard_query != 0)) {
         const int chunks = mt.k + 1;
@@ -571,7 +580,7 @@ static int run_filter(const cah_plan* plan, const PlanDeviceCopy* pd, int32_t ad
     HIP_TRY(hipMemsetAsync(d_work_counter, 0, sizeof(unsigned long long), s));
     if (d_queue_count) HIP_TRY(hipMemsetAsync(d_queue_count, 0, sizeof(unsigned long long), s));
     ProfScope ps(s, CAH_PROF_FILTER, n_reads);
-    HIP_TRY(launch_filter(f, mode, pd->n_cus, s));
+    HIP_TRY(launch_filter(f, mode, mt.narrow_words != 0, pd->n_cus, s));
     return CAH_OK;
 }
 

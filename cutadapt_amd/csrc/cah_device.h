@@ -10,7 +10,8 @@
 
 #define CAH_MAX_M 64           // adapter length limit: one 64-bit row bitset per read char
 #define CAH_TABLE_CHARS 128    // ASCII; bytes >= 0x80 are invalid input
-#define CAH_FILTER_SLOTS 6      // packed k-mer words the prefilter advances together (state in VGPRs)
+#define CAH_FILTER_SLOTS 6      // packed 64-bit k-mer words the prefilter advances together (state in VGPRs)
+#define CAH_FILTER_SLOTS_NARROW 8   // ... when every word of the plan fits 32 bits
 
 // Packed DP cell payload (one VGPR): ((origin + CAH_ORIGIN_BIAS) << 12) + (score + CAH_SCORE_BIAS)
 // origin in [-64, 1e6], score in [-2048, 2047] (bounds derived in DESIGN.md); match/mismatch/
@@ -36,7 +37,7 @@ struct CahMatcher {
     int32_t thr[CAH_MAX_M + 1];        // thr[L] = floor(L * max_error_rate): integer form of
                                        // `cost <= cur_effective_length * max_error_rate` (:513, :559)
     int32_t skip_ok;           // 1: DP may start at (first k-mer hit) - m - k - 1 (see api.cpp)
-    int32_t pad_[1];
+    int32_t narrow_words;      // 1: every packed k-mer word of this matcher fits 32 bits
     uint64_t rowmask[CAH_TABLE_CHARS]; // bit i set <=> adapter[i] matches this read character
                                        // (folds translate() + the three compare modes, :322-328, :442-445;
                                        //  for comparers bit i refers to the i-th compared position)

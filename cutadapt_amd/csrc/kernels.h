@@ -41,7 +41,7 @@ struct DpArgs {
     int32_t merge_best;              // 0: overwrite (locate_batch); 1: keep best (match_batch)
 };
 
-hipError_t launch_filter(const FilterArgs& a, int mode, int n_cus, hipStream_t s);
+hipError_t launch_filter(const FilterArgs& a, int mode, bool narrow_words, int n_cus, hipStream_t s);
 hipError_t launch_dp(const DpArgs& a, int m, bool unit_indel_cost, bool back_adapter, int64_t max_items, int n_cus,
                      hipStream_t s);
 hipError_t launch_comparer(const DpArgs& a, int64_t max_items, int n_cus, hipStream_t s);

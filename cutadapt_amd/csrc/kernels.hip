@@ -142,7 +142,7 @@ __device__ __forceinline__ unsigned chunk_byte(const Chunk& c, int t) {
 // popcount + a single atomic per wave) together with a key = chunk index of the first hit,
 // and count keys per bin so that the queue can be ordered by approximate adapter position.
 // =============================================================================================
-#define FILTER_SLOTS CAH_FILTER_SLOTS
+#include <type_traits>
 
 __device__ __forceinline__ void word_window(const int wstart, const int wstop, const int n,
                                             int& ws, int& we) {
@@ -158,13 +158,14 @@ __device__ __forceinline__ void word_window(const int wstart, const int wstop, c
     we = empty ? 0 : stop;
 }
 
-template <bool MASKED>
-__device__ __forceinline__ void filter_word_chunk(const Chunk& ck, const uint64_t* tbl, const uint64_t init,
-                                                  uint64_t& R, uint64_t& acc, const int lo, const int hi,
+template <bool MASKED, typename W, typename T>
+__device__ __forceinline__ void filter_word_chunk(const Chunk& ck, const T* tbl, const W init,
+                                                  W& R, W& acc, const int lo, const int hi,
                                                   const bool act) {
     // lo/hi: first / one-past-last chunk character (0..16) inside this word's window.
     // The 16 characters are handled in four groups of four; a group no lane needs is skipped
     // (short suffix windows such as the 3- and 4-character overlap searches touch one group).
+    // R << 1 is written R + R: on gfx950 v_add_u32 issues in 2 cycles, v_lshlrev_b32 in 4.
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
         if (MASKED) {
@@ -174,9 +175,9 @@ __device__ __forceinline__ void filter_word_chunk(const Chunk& ck, const uint64_
 #pragma unroll
             for (int t = 4 * g4; t < 4 * g4 + 4; ++t) {
                 const unsigned ch = chunk_byte(ck, t) & (CAH_TABLE_CHARS - 1);
-                uint64_t mk = tbl[ch];
-                if (MASKED) mk = (t >= lo && t < hi) ? mk : 0ull;
-                R = ((R << 1) | init) & mk;
+                W mk = (W)tbl[ch];
+                if (MASKED) mk = (t >= lo && t < hi) ? mk : (W)0;
+                R = ((R + R) | init) & mk;
                 acc |= R;
             }
         }
@@ -199,8 +200,13 @@ __device__ __forceinline__ void filter_word_chunk(const Chunk& ck, const uint64_
 #define CAH_FILTER_WAVES 4
 #endif
 
-template <int MODE, bool LDS_TABLES>
+// NARROW: every packed word of the plan fits 32 bits (cah_plan_create packs k-mers of <= 32
+// characters that way): shift-and state, accumulators and LDS tables are 32-bit, which halves
+// the VALU work per character and word.
+template <int MODE, bool LDS_TABLES, bool NARROW>
 __global__ __launch_bounds__(256, CAH_FILTER_WAVES) void k_filter(FilterArgs a) {
+    typedef typename std::conditional<NARROW, uint32_t, uint64_t>::type word_t;
+    constexpr int SLOTS = NARROW ? CAH_FILTER_SLOTS_NARROW : CAH_FILTER_SLOTS;
     // all LDS is carved from the dynamic region (16-byte aligned offsets; a static __shared__
     // in front of it could misalign the 8-byte table reads):
     //   [tables: n_words KiB] [s_idx: 16 KiB] [s_key: 4 KiB] [s_hist] [s_cursor] [scalars]
@@ -208,8 +214,8 @@ __global__ __launch_bounds__(256, CAH_FILTER_WAVES) void k_filter(FilterArgs a) 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const CahKmerWord* words = a.words;
     const int n_words = a.n_words;
-    uint64_t* s_mask = reinterpret_cast<uint64_t*>(smem);
-    unsigned char* sp = smem + (LDS_TABLES ? (size_t)n_words * CAH_TABLE_CHARS * sizeof(uint64_t) : 0);
+    word_t* s_mask = reinterpret_cast<word_t*>(smem);
+    unsigned char* sp = smem + (LDS_TABLES ? (size_t)n_words * CAH_TABLE_CHARS * sizeof(word_t) : 0);
     int32_t* s_idx = reinterpret_cast<int32_t*>(sp);             sp += FILTER_TILE * sizeof(int32_t);
     uint8_t* s_key = sp;                                         sp += FILTER_TILE;
     unsigned* s_hist = reinterpret_cast<unsigned*>(sp);          sp += CAH_QUEUE_BINS * sizeof(unsigned);
@@ -233,7 +239,7 @@ __global__ __launch_bounds__(256, CAH_FILTER_WAVES) void k_filter(FilterArgs a) 
     }
     if (LDS_TABLES) {
         for (int i = threadIdx.x; i < n_words * CAH_TABLE_CHARS; i += blockDim.x)
-            s_mask[i] = words[i / CAH_TABLE_CHARS].mask[i % CAH_TABLE_CHARS];
+            s_mask[i] = (word_t)words[i / CAH_TABLE_CHARS].mask[i % CAH_TABLE_CHARS];
     }
     const int lane = wave_lane();
     const int wave = threadIdx.x >> 6;
@@ -263,13 +269,13 @@ __global__ __launch_bounds__(256, CAH_FILTER_WAVES) void k_filter(FilterArgs a) 
             int hit_pos = 0;
             unsigned seen = 0;
 
-            for (int g = 0; g < n_words; g += FILTER_SLOTS) {
+            for (int g = 0; g < n_words; g += SLOTS) {
                 if (!__any(valid && !hit)) break;
                 // this lane's window of every word of the group, and their union
-                int wsv[FILTER_SLOTS], wev[FILTER_SLOTS];
+                int wsv[SLOTS], wev[SLOTS];
                 int lo = n, hi = 0;
     #pragma unroll
-                for (int s = 0; s < FILTER_SLOTS; ++s) {
+                for (int s = 0; s < SLOTS; ++s) {
                     wsv[s] = 0; wev[s] = 0;
                     if (g + s < n_words) {
                         word_window(s_wstart[g + s], s_wstop[g + s], n, wsv[s], wev[s]);
@@ -277,9 +283,9 @@ __global__ __launch_bounds__(256, CAH_FILTER_WAVES) void k_filter(FilterArgs a) 
                     }
                 }
                 if (!valid) { lo = 0; hi = 0; }
-                uint64_t R[FILTER_SLOTS], acc[FILTER_SLOTS];
+                word_t R[SLOTS], acc[SLOTS];
     #pragma unroll
-                for (int s = 0; s < FILTER_SLOTS; ++s) { R[s] = 0; acc[s] = 0; }
+                for (int s = 0; s < SLOTS; ++s) { R[s] = 0; acc[s] = 0; }
 
                 int pos = lo;
                 Chunk cur = load_chunk(q, pos, n, hi);
@@ -295,25 +301,28 @@ __global__ __launch_bounds__(256, CAH_FILTER_WAVES) void k_filter(FilterArgs a) 
                     const Chunk nxt = load_chunk(q, pos + 16, n, live ? hi : 0);
 #endif
                     seen |= cur.w[0] | cur.w[1] | cur.w[2] | cur.w[3];
-                    uint64_t any_found = 0;
+                    word_t any_found = 0;
     #pragma unroll
-                    for (int s = 0; s < FILTER_SLOTS; ++s) {
+                    for (int s = 0; s < SLOTS; ++s) {
                         if (g + s >= n_words) break;                     // wave-uniform
                         const CahKmerWord* wd = words + (g + s);
                         const int ws = wsv[s], we = wev[s];
                         const bool act = live && pos < we && pos + 16 > ws;
                         if (!__any(act)) continue;
-                        const uint64_t* tbl = LDS_TABLES ? (s_mask + (g + s) * CAH_TABLE_CHARS) : wd->mask;
-                        const uint64_t init = s_winit[g + s];
+                        const word_t init = (word_t)s_winit[g + s];
                         // masking is needed where a window starts inside the chunk or stops before
                         // the end of the read inside it (beyond the read end the chunk is NUL-padded)
                         const bool partial = act && (ws > pos || (we < pos + 16 && we < n));
-                        if (__any(partial)) {
-                            filter_word_chunk<true>(cur, tbl, init, R[s], acc[s], ws - pos, we - pos, act);
+                        if (LDS_TABLES) {
+                            const word_t* tbl = s_mask + (g + s) * CAH_TABLE_CHARS;
+                            if (__any(partial)) filter_word_chunk<true, word_t>(cur, tbl, init, R[s], acc[s], ws - pos, we - pos, act);
+                            else filter_word_chunk<false, word_t>(cur, tbl, init, R[s], acc[s], 0, 16, act);
                         } else {
-                            filter_word_chunk<false>(cur, tbl, init, R[s], acc[s], 0, 16, act);
+                            const uint64_t* tbl = wd->mask;      // plans with too many words: tables stay in HBM/L2
+                            if (__any(partial)) filter_word_chunk<true, word_t>(cur, tbl, init, R[s], acc[s], ws - pos, we - pos, act);
+                            else filter_word_chunk<false, word_t>(cur, tbl, init, R[s], acc[s], 0, 16, act);
                         }
-                        any_found |= acc[s] & s_wfound[g + s];
+                        any_found |= acc[s] & (word_t)s_wfound[g + s];
                     }
                     if (live && any_found != 0) { hit = true; hit_pos = pos; }
                     pos += 16;
@@ -763,7 +772,7 @@ __device__ __forceinline__ unsigned get_row_packed(const unsigned (&w)[ROWS + 1]
 }
 
 #ifndef CAH_DPP_WAVES
-#define CAH_DPP_WAVES(ROWS) ((ROWS) <= 24 ? 8 : ((ROWS) <= 44 ? 6 : 5))
+#define CAH_DPP_WAVES(ROWS) ((ROWS) <= 24 ? 6 : 4)
 #endif
 
 template <int ROWS>
@@ -1046,20 +1055,23 @@ static int grid_for(int64_t n_items, int blocks_per_cu, int n_cus) {
     return (int)(need < cap ? need : cap);
 }
 
-#define FILTER_MAX_LDS_WORDS 32
+#define FILTER_MAX_LDS_TABLE_BYTES (32 * 1024)
 
-hipError_t launch_filter(const FilterArgs& a, int mode, int n_cus, hipStream_t s) {
+hipError_t launch_filter(const FilterArgs& a, int mode, bool narrow, int n_cus, hipStream_t s) {
     const int grid = grid_for(a.n_reads, 4, n_cus);
-    const bool in_lds = a.n_words <= FILTER_MAX_LDS_WORDS;
-    const size_t lds = (in_lds ? (size_t)a.n_words * CAH_TABLE_CHARS * sizeof(uint64_t) : 0) +
+    const size_t entry = narrow ? sizeof(uint32_t) : sizeof(uint64_t);
+    const bool in_lds = (size_t)a.n_words * CAH_TABLE_CHARS * entry <= FILTER_MAX_LDS_TABLE_BYTES;
+    const size_t lds = (in_lds ? (size_t)a.n_words * CAH_TABLE_CHARS * entry : 0) +
                        FILTER_TILE * 5 + CAH_QUEUE_BINS * 8 + 64 + (size_t)a.n_words * 24;
+#define CAH_FILTER_LAUNCH(M, L, N) hipLaunchKernelGGL((k_filter<M, L, N>), dim3(grid), dim3(256), lds, s, a)
     if (mode == 0) {
-        if (in_lds) hipLaunchKernelGGL((k_filter<0, true>), dim3(grid), dim3(256), lds, s, a);
-        else hipLaunchKernelGGL((k_filter<0, false>), dim3(grid), dim3(256), lds, s, a);
+        if (in_lds) { if (narrow) CAH_FILTER_LAUNCH(0, true, true); else CAH_FILTER_LAUNCH(0, true, false); }
+        else { if (narrow) CAH_FILTER_LAUNCH(0, false, true); else CAH_FILTER_LAUNCH(0, false, false); }
     } else {
-        if (in_lds) hipLaunchKernelGGL((k_filter<1, true>), dim3(grid), dim3(256), lds, s, a);
-        else hipLaunchKernelGGL((k_filter<1, false>), dim3(grid), dim3(256), lds, s, a);
+        if (in_lds) { if (narrow) CAH_FILTER_LAUNCH(1, true, true); else CAH_FILTER_LAUNCH(1, true, false); }
+        else { if (narrow) CAH_FILTER_LAUNCH(1, false, true); else CAH_FILTER_LAUNCH(1, false, false); }
     }
+#undef CAH_FILTER_LAUNCH
     return hipGetLastError();
 }
 
