@@ -5,7 +5,10 @@
 
 #include "cah_device.h"
 
-#define CAH_QUEUE_BINS 64          // survivor queue is ordered by min(first-hit position / 16, 63)
+#ifndef CAH_KEY_SHIFT
+#define CAH_KEY_SHIFT 2            // key resolution: 1 << CAH_KEY_SHIFT read columns (2 or 4)
+#endif
+#define CAH_QUEUE_BINS 256         // survivor queue is ordered by key = min(first-hit position >> CAH_KEY_SHIFT, 255)
 
 struct FilterArgs {
     const CahKmerWord* words;        // this adapter's packed shift-and words (HBM)

@@ -144,6 +144,10 @@ __device__ __forceinline__ unsigned chunk_byte(const Chunk& c, int t) {
 // =============================================================================================
 #include <type_traits>
 
+#ifndef CAH_SUBCHUNK
+#define CAH_SUBCHUNK 1          // resolve the first hit to a 4-column group inside its 16-column chunk
+#endif
+
 __device__ __forceinline__ void word_window(const int wstart, const int wstop, const int n,
                                             int& ws, int& we) {
     int start = wstart, stop = wstop;
@@ -160,16 +164,18 @@ __device__ __forceinline__ void word_window(const int wstart, const int wstop, c
 
 template <bool MASKED, typename W, typename T>
 __device__ __forceinline__ void filter_word_chunk(const Chunk& ck, const T* tbl, const W init,
-                                                  W& R, W& acc, const int lo, const int hi,
-                                                  const bool act) {
+                                                  W& R, W& acc, W (&gg)[3], const W found,
+                                                  const int lo, const int hi, const bool act) {
     // lo/hi: first / one-past-last chunk character (0..16) inside this word's window.
     // The 16 characters are handled in four groups of four; a group no lane needs is skipped
     // (short suffix windows such as the 3- and 4-character overlap searches touch one group).
     // R << 1 is written R + R: on gfx950 v_add_u32 issues in 2 cycles, v_lshlrev_b32 in 4.
+    // gg[g] collects (over all words of the chunk) the found bits seen up to group g: lets the
+    // caller name the 4-column group of a first hit without a second pass.
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
         if (MASKED) {
-            if (!__any(act && lo < 4 * g4 + 4 && hi > 4 * g4)) continue;
+            if (!__any(act && lo < 4 * g4 + 4 && hi > 4 * g4)) continue;    // acc unchanged: gg[g4] may stay behind
         }
         if (act) {
 #pragma unroll
@@ -180,6 +186,7 @@ __device__ __forceinline__ void filter_word_chunk(const Chunk& ck, const T* tbl,
                 R = ((R + R) | init) & mk;
                 acc |= R;
             }
+            if (CAH_SUBCHUNK && g4 < 3 && (CAH_KEY_SHIFT == 2 || g4 <= 1)) gg[CAH_KEY_SHIFT == 2 ? g4 : 1] |= acc & found;
         }
     }
 }
@@ -190,7 +197,9 @@ __device__ __forceinline__ void filter_word_chunk(const Chunk& ck, const T* tbl,
 // LDS, ordered by key with an LDS counting sort and appended to the global queue as one run.
 // The DP kernel takes 64 consecutive queue entries per wave, so its lanes hold reads whose
 // adapters sit at similar columns and their Ukkonen bands widen and narrow together.
-#define FILTER_TILE 4096
+#ifndef FILTER_TILE
+#define FILTER_TILE 8192
+#endif
 #define FILTER_WAVES 4
 
 #ifndef CAH_FILTER_PREFETCH
@@ -209,14 +218,14 @@ __global__ __launch_bounds__(256, CAH_FILTER_WAVES) void k_filter(FilterArgs a) 
     constexpr int SLOTS = NARROW ? CAH_FILTER_SLOTS_NARROW : CAH_FILTER_SLOTS;
     // all LDS is carved from the dynamic region (16-byte aligned offsets; a static __shared__
     // in front of it could misalign the 8-byte table reads):
-    //   [tables: n_words KiB] [s_idx: 16 KiB] [s_key: 4 KiB] [s_hist] [s_cursor] [scalars]
+    //   [tables: n_words KiB] [s_idx: 16 KiB, 16-bit tile-relative] [s_key: 8 KiB] [s_hist] [s_cursor] [scalars]
     //   [per-word init/found masks and windows: 24 B x n_words]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const CahKmerWord* words = a.words;
     const int n_words = a.n_words;
     word_t* s_mask = reinterpret_cast<word_t*>(smem);
     unsigned char* sp = smem + (LDS_TABLES ? (size_t)n_words * CAH_TABLE_CHARS * sizeof(word_t) : 0);
-    int32_t* s_idx = reinterpret_cast<int32_t*>(sp);             sp += FILTER_TILE * sizeof(int32_t);
+    uint16_t* s_idx = reinterpret_cast<uint16_t*>(sp);           sp += FILTER_TILE * sizeof(uint16_t);   // tile-relative
     uint8_t* s_key = sp;                                         sp += FILTER_TILE;
     unsigned* s_hist = reinterpret_cast<unsigned*>(sp);          sp += CAH_QUEUE_BINS * sizeof(unsigned);
     unsigned* s_cursor = reinterpret_cast<unsigned*>(sp);        sp += CAH_QUEUE_BINS * sizeof(unsigned);
@@ -250,7 +259,7 @@ __global__ __launch_bounds__(256, CAH_FILTER_WAVES) void k_filter(FilterArgs a) 
             s_tile = (long long)atomicAdd(a.work_counter, (unsigned long long)FILTER_TILE);
             s_count = 0;
         }
-        if (threadIdx.x < CAH_QUEUE_BINS) { s_hist[threadIdx.x] = 0; s_cursor[threadIdx.x] = 0; }
+        for (int i = threadIdx.x; i < CAH_QUEUE_BINS; i += blockDim.x) { s_hist[i] = 0; s_cursor[i] = 0; }
         __syncthreads();
         const int64_t tile_base = s_tile;
         if (tile_base >= a.n_reads) break;
@@ -302,6 +311,7 @@ __global__ __launch_bounds__(256, CAH_FILTER_WAVES) void k_filter(FilterArgs a) 
 #endif
                     seen |= cur.w[0] | cur.w[1] | cur.w[2] | cur.w[3];
                     word_t any_found = 0;
+                    word_t gg[3] = {0, 0, 0};             // found bits after 4 / 8 / 12 characters of the chunk
     #pragma unroll
                     for (int s = 0; s < SLOTS; ++s) {
                         if (g + s >= n_words) break;                     // wave-uniform
@@ -313,18 +323,24 @@ __global__ __launch_bounds__(256, CAH_FILTER_WAVES) void k_filter(FilterArgs a) 
                         // masking is needed where a window starts inside the chunk or stops before
                         // the end of the read inside it (beyond the read end the chunk is NUL-padded)
                         const bool partial = act && (ws > pos || (we < pos + 16 && we < n));
+                        const word_t fnd = (word_t)s_wfound[g + s];
                         if (LDS_TABLES) {
                             const word_t* tbl = s_mask + (g + s) * CAH_TABLE_CHARS;
-                            if (__any(partial)) filter_word_chunk<true, word_t>(cur, tbl, init, R[s], acc[s], ws - pos, we - pos, act);
-                            else filter_word_chunk<false, word_t>(cur, tbl, init, R[s], acc[s], 0, 16, act);
+                            if (__any(partial)) filter_word_chunk<true, word_t>(cur, tbl, init, R[s], acc[s], gg, fnd, ws - pos, we - pos, act);
+                            else filter_word_chunk<false, word_t>(cur, tbl, init, R[s], acc[s], gg, fnd, 0, 16, act);
                         } else {
                             const uint64_t* tbl = wd->mask;      // plans with too many words: tables stay in HBM/L2
-                            if (__any(partial)) filter_word_chunk<true, word_t>(cur, tbl, init, R[s], acc[s], ws - pos, we - pos, act);
-                            else filter_word_chunk<false, word_t>(cur, tbl, init, R[s], acc[s], 0, 16, act);
+                            if (__any(partial)) filter_word_chunk<true, word_t>(cur, tbl, init, R[s], acc[s], gg, fnd, ws - pos, we - pos, act);
+                            else filter_word_chunk<false, word_t>(cur, tbl, init, R[s], acc[s], gg, fnd, 0, 16, act);
                         }
-                        any_found |= acc[s] & (word_t)s_wfound[g + s];
+                        any_found |= acc[s] & fnd;
                     }
-                    if (live && any_found != 0) { hit = true; hit_pos = pos; }
+                    if (live && any_found != 0) {
+                        // a lane leaves at its first hit, so no found bit was set before this chunk:
+                        // the first group accumulator that shows one names the 4-column group
+                        hit = true;
+                        hit_pos = pos + (!CAH_SUBCHUNK ? 0 : CAH_KEY_SHIFT == 2 ? (gg[0] ? 0 : gg[1] ? 4 : gg[2] ? 8 : 12) : (gg[1] ? 0 : 8));
+                    }
                     pos += 16;
                     cur = nxt;
 #if CAH_FILTER_PREFETCH == 2
@@ -346,8 +362,8 @@ __global__ __launch_bounds__(256, CAH_FILTER_WAVES) void k_filter(FilterArgs a) 
                     slot = __builtin_amdgcn_readfirstlane(slot);
                     if (push) {
                         const int e = (int)slot + __popcll(bal & ((1ull << lane) - 1ull));
-                        const int key = min(hit_pos >> 4, CAH_QUEUE_BINS - 1);
-                        s_idx[e] = (int32_t)r;
+                        const int key = min(hit_pos >> CAH_KEY_SHIFT, CAH_QUEUE_BINS - 1);
+                        s_idx[e] = (uint16_t)(r - tile_base);
                         s_key[e] = (uint8_t)key;
                         atomicAdd(&s_hist[key], 1u);
                     }
@@ -369,7 +385,7 @@ __global__ __launch_bounds__(256, CAH_FILTER_WAVES) void k_filter(FilterArgs a) 
             for (unsigned e = threadIdx.x; e < count; e += blockDim.x) {
                 const unsigned key = s_key[e];
                 const unsigned p = s_hist[key] + atomicAdd(&s_cursor[key], 1u);
-                a.queue[qbase + p] = s_idx[e];
+                a.queue[qbase + p] = (int32_t)(tile_base + s_idx[e]);
                 a.queue_keys[qbase + p] = (uint8_t)key;
             }
         }
@@ -520,7 +536,7 @@ __global__ __launch_bounds__(256, CAH_DP_WAVES(ROWS)) void k_dp(DpArgs a) {
         // Starting the banded DP there with the plain first column gives bit-identical results
         // ("Column skipping").
         int skip_to = 0;
-        if (skip_cols && valid) skip_to = max(0, (int)a.queue_keys[idx] * 16 - m - k - 1);
+        if (skip_cols && valid) skip_to = max(0, ((int)a.queue_keys[idx] << CAH_KEY_SHIFT) - m - k - 1);
         if (skip_to > 0) min_n = skip_to;
 
         // first column (_align.pyx:364-383).  The four (start_in_reference, start_in_query)
@@ -820,7 +836,7 @@ __global__ __launch_bounds__(256, CAH_DPP_WAVES(ROWS)) void k_dp_packed(DpArgs a
         // first columns irrelevant (column skipping, see k_dp / DESIGN.md)
         const int max_n = n;
         int min_n = 0;
-        if (skip_cols && valid) min_n = max(0, (int)a.queue_keys[idx] * 16 - m - k - 1);
+        if (skip_cols && valid) min_n = max(0, ((int)a.queue_keys[idx] << CAH_KEY_SHIFT) - m - k - 1);
 
         // first column (:374-378): cost i, score -2i, origin = this column (rel 0)
         unsigned w[ROWS + 1];
@@ -1062,7 +1078,7 @@ hipError_t launch_filter(const FilterArgs& a, int mode, bool narrow, int n_cus, 
     const size_t entry = narrow ? sizeof(uint32_t) : sizeof(uint64_t);
     const bool in_lds = (size_t)a.n_words * CAH_TABLE_CHARS * entry <= FILTER_MAX_LDS_TABLE_BYTES;
     const size_t lds = (in_lds ? (size_t)a.n_words * CAH_TABLE_CHARS * entry : 0) +
-                       FILTER_TILE * 5 + CAH_QUEUE_BINS * 8 + 64 + (size_t)a.n_words * 24;
+                       FILTER_TILE * 3 + CAH_QUEUE_BINS * 8 + 64 + (size_t)a.n_words * 24;
 #define CAH_FILTER_LAUNCH(M, L, N) hipLaunchKernelGGL((k_filter<M, L, N>), dim3(grid), dim3(256), lds, s, a)
     if (mode == 0) {
         if (in_lds) { if (narrow) CAH_FILTER_LAUNCH(0, true, true); else CAH_FILTER_LAUNCH(0, true, false); }
