@@ -37,6 +37,9 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=100_000_000, help="reads per GPU (default: the C2 size)")
+    ap.add_argument("--p-adapter", type=float, default=None,
+                    help="override the adapter fraction of the read model (SURVEY 8(d): 0 and 1 are the extremes; "
+                         "the headline number uses the default 0.25)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--check-reads", type=int, default=50_000, help="reads compared with the oracle (untimed)")
@@ -45,6 +48,8 @@ def parse_args():
 
 def main():
     args = parse_args()
+    if args.p_adapter is not None:
+        GEN["p_adapter"] = float(args.p_adapter)
     import torch
     import torch.distributed as dist
 

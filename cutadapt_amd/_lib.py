@@ -26,6 +26,7 @@ EXPORTED_SYMBOLS = [
     "cah_kmers_present_batch_host", "cah_match_batch_host", "cah_profile_enable",
     "cah_profile_reset", "cah_profile_read", "cah_synth_reads",
     "cah_fastq_scan", "cah_pack_sequences", "cah_fastq_write_trimmed",
+    "cah_fasta_scan", "cah_records_write", "cah_info_write",
 ]
 
 
@@ -108,6 +109,9 @@ def lib():
     L.cah_fastq_scan.argtypes = [vp, i64, C.c_int, i64, vp, C.POINTER(i64), C.POINTER(i64)]
     L.cah_pack_sequences.argtypes = [vp, vp, i64, vp, vp]
     L.cah_fastq_write_trimmed.argtypes = [vp, vp, i64, vp, vp, vp, vp, i64, C.POINTER(i64)]
+    L.cah_fasta_scan.argtypes = [vp, i64, C.c_int, i64, vp, C.POINTER(i64), C.POINTER(i64)]
+    L.cah_records_write.argtypes = [vp, vp, i64, vp, vp, vp, vp, vp, C.c_int, vp, i64, C.POINTER(i64)]
+    L.cah_info_write.argtypes = [vp, vp, i64, vp, vp, vp, i64, vp, vp, i64, vp, i64, C.POINTER(i64)]
     for name in EXPORTED_SYMBOLS:
         getattr(L, name)
     _lib = L

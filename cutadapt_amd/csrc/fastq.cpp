@@ -105,9 +105,16 @@ int cah_pack_sequences(const uint8_t* buf, const int64_t* rec, int64_t n_records
         out_offsets[i] = pos;
         if (e > b) {
             if (!out_seqs) return cah_set_error_(CAH_EINVAL, "cah_pack_sequences: out_seqs is NULL");
-            memcpy(out_seqs + pos, buf + b, (size_t)(e - b));
+            if (rec[i * 6 + 4] >= 0) {                     // FASTQ: one sequence line
+                memcpy(out_seqs + pos, buf + b, (size_t)(e - b));
+                pos += e - b;
+            } else {                                       // FASTA: the sequence may span several lines
+                for (int64_t q = b; q < e; q++) {
+                    const uint8_t c = buf[q];
+                    if (c != '\n' && c != '\r') out_seqs[pos++] = c;
+                }
+            }
         }
-        pos += e - b;
     }
     out_offsets[n_records] = pos;
     return CAH_OK;
@@ -141,6 +148,167 @@ int cah_fastq_write_trimmed(const uint8_t* buf, const int64_t* rec, int64_t n_re
         memcpy(out + pos, buf + r[4] + a, (size_t)(b - a)); pos += b - a;
         out[pos++] = '\n';
     }
+    *out_len = pos;
+    return CAH_OK;
+}
+
+// FASTA twin of cah_fastq_scan: records are ">name" + one or more sequence lines.  rec has the same
+// six columns; seq_beg..seq_end spans the raw sequence lines (line breaks included,
+// cah_pack_sequences strips them) and qual_beg = qual_end = -1 marks "no qualities".  A record is
+// complete when the next '>' line (or, with is_final, the end of the data) has been seen.
+int cah_fasta_scan(const uint8_t* buf, int64_t len, int is_final, int64_t max_records, int64_t* rec,
+                   int64_t* n_records, int64_t* consumed) {
+    if (!n_records || !consumed || (len > 0 && !buf) || (max_records > 0 && !rec))
+        return cah_set_error_(CAH_EINVAL, "cah_fasta_scan: NULL argument");
+    const uint8_t* const end = buf + len;
+    const uint8_t* p = buf;
+    int64_t n = 0;
+    *n_records = 0;
+    *consumed = 0;
+    while (p < end && (*p == '\n' || *p == '\r')) p++;          // blank lines before a header
+    while (p < end && n < max_records) {
+        if (*p != '>') {
+            char msg[160];
+            snprintf(msg, sizeof(msg), "FASTA format error in record %lld: expected '>' at the start of a record",
+                     (long long)n);
+            return cah_set_error_(CAH_EINVAL, msg);
+        }
+        const uint8_t* nl = find_nl(p, end);
+        if (!nl && !is_final) break;                            // header line incomplete
+        const uint8_t* name_end = nl ? ((nl > p && nl[-1] == '\r') ? nl - 1 : nl) : end;
+        const uint8_t* seq_beg = nl ? nl + 1 : end;
+        // the sequence runs to the next line that starts with '>'
+        const uint8_t* q = seq_beg;
+        bool closed = false;
+        while (q < end) {
+            if (*q == '>') { closed = true; break; }
+            const uint8_t* l = find_nl(q, end);
+            if (!l) { q = end; break; }
+            q = l + 1;
+        }
+        if (!closed && !is_final) break;                        // may continue in the next chunk
+        const uint8_t* seq_end = q;
+        while (seq_end > seq_beg && (seq_end[-1] == '\n' || seq_end[-1] == '\r')) seq_end--;
+        int64_t* r = rec + n * 6;
+        r[0] = (p + 1) - buf; r[1] = name_end - buf;
+        r[2] = seq_beg - buf; r[3] = seq_end - buf;
+        r[4] = -1;            r[5] = -1;
+        n++;
+        p = q;
+    }
+    *n_records = n;
+    *consumed = p - buf;
+    return CAH_OK;
+}
+
+// Output formatting for every AdapterCutter action (reference modifiers.py:170-198, :236-251).
+// The sequence comes from the packed buffer (seqs/offsets, the batch the GPU matched), names and
+// qualities from the raw chunk.  For record i with keep[i] != 0 (keep NULL = all) and interval
+// [beg[i], end[i]) relative to the read:
+//   mode CAH_WRITE_SLICE      sequence and qualities sliced to the interval (trim / retain / crop;
+//                             the whole read for action None)
+//   mode CAH_WRITE_MASK       bases outside the interval replaced by 'N', qualities unchanged
+//   mode CAH_WRITE_LOWERCASE  bases outside the interval lower-cased, inside upper-cased
+// FASTQ records are written as "@name\nSEQ\n+\nQUAL\n", FASTA records (qual_beg < 0) as ">name\nSEQ\n".
+int cah_records_write(const uint8_t* buf, const int64_t* rec, int64_t n_records, const uint8_t* seqs,
+                      const int64_t* offsets, const int32_t* beg, const int32_t* end, const uint8_t* keep,
+                      int mode, uint8_t* out, int64_t out_cap, int64_t* out_len) {
+    if (!out_len || (n_records > 0 && (!buf || !rec || !offsets || !beg || !end || !out)))
+        return cah_set_error_(CAH_EINVAL, "cah_records_write: NULL argument");
+    if (mode < CAH_WRITE_SLICE || mode > CAH_WRITE_LOWERCASE)
+        return cah_set_error_(CAH_EINVAL, "cah_records_write: unknown mode");
+    int64_t pos = 0;
+    for (int64_t i = 0; i < n_records; i++) {
+        if (keep && !keep[i]) continue;
+        const int64_t* r = rec + i * 6;
+        const bool fastq = r[4] >= 0;
+        const int64_t name_len = r[1] - r[0], seq_len = offsets[i + 1] - offsets[i];
+        int64_t a = beg[i], b = end[i];
+        if (a < 0) a = 0;
+        if (b > seq_len) b = seq_len;
+        if (b < a) b = a;
+        const int64_t body = mode == CAH_WRITE_SLICE ? b - a : seq_len;
+        const int64_t need = 1 + name_len + 1 + body + 1 + (fastq ? 2 + body + 1 : 0);
+        if (pos + need > out_cap) return cah_set_error_(CAH_ENOMEM, "cah_records_write: output buffer too small");
+        const uint8_t* s = seqs + offsets[i];
+        out[pos++] = fastq ? '@' : '>';
+        memcpy(out + pos, buf + r[0], (size_t)name_len); pos += name_len;
+        out[pos++] = '\n';
+        if (mode == CAH_WRITE_SLICE) {
+            memcpy(out + pos, s + a, (size_t)(b - a)); pos += b - a;
+        } else if (mode == CAH_WRITE_MASK) {
+            memset(out + pos, 'N', (size_t)a);
+            memcpy(out + pos + a, s + a, (size_t)(b - a));
+            memset(out + pos + b, 'N', (size_t)(seq_len - b));
+            pos += seq_len;
+        } else {
+            for (int64_t q = 0; q < seq_len; q++) {
+                const uint8_t c = s[q];
+                const bool inside = q >= a && q < b;
+                out[pos + q] = inside ? ((c >= 'a' && c <= 'z') ? (uint8_t)(c - 32) : c)
+                                      : ((c >= 'A' && c <= 'Z') ? (uint8_t)(c + 32) : c);
+            }
+            pos += seq_len;
+        }
+        out[pos++] = '\n';
+        if (fastq) {
+            out[pos++] = '+'; out[pos++] = '\n';
+            const int64_t qa = mode == CAH_WRITE_SLICE ? a : 0;
+            memcpy(out + pos, buf + r[4] + qa, (size_t)body); pos += body;
+            out[pos++] = '\n';
+        }
+    }
+    *out_len = pos;
+    return CAH_OK;
+}
+
+// Info-file rows (reference steps.py:232-253 + adapters.py:395-417, linked records :1157-1171).
+// rows[k*7..] = (read, errors, rstart, rstop, wbeg, wend, name_idx), sorted by read and, within a
+// read, in match order; rstart/rstop are relative to the read as it was when that match was made,
+// i.e. to original[wbeg:wend].  Reads without a row get the "-1" line.  names = concatenated adapter
+// names, name_off[n_names+1].  Every match row ends with an empty reverse-complement column.
+int cah_info_write(const uint8_t* buf, const int64_t* rec, int64_t n_records, const uint8_t* seqs,
+                   const int64_t* offsets, const int64_t* rows, int64_t n_rows, const char* names,
+                   const int64_t* name_off, int64_t n_names, uint8_t* out, int64_t out_cap, int64_t* out_len) {
+    if (!out_len || (n_records > 0 && (!buf || !rec || !offsets || !out)) || (n_rows > 0 && (!rows || !names || !name_off)))
+        return cah_set_error_(CAH_EINVAL, "cah_info_write: NULL argument");
+    int64_t pos = 0, k = 0;
+    auto put = [&](const uint8_t* src, int64_t len) { memcpy(out + pos, src, (size_t)len); pos += len; };
+    auto put_int = [&](long long v) { pos += snprintf(reinterpret_cast<char*>(out + pos), 24, "%lld", v); };
+    for (int64_t i = 0; i < n_records; i++) {
+        const int64_t* r = rec + i * 6;
+        const bool fastq = r[4] >= 0;
+        const int64_t name_len = r[1] - r[0], seq_len = offsets[i + 1] - offsets[i];
+        const uint8_t* s = seqs + offsets[i];
+        const uint8_t* qual = fastq ? buf + r[4] : nullptr;
+        if (k >= n_rows || rows[k * 7] != i) {
+            if (k < n_rows && rows[k * 7] < i) return cah_set_error_(CAH_EINVAL, "cah_info_write: rows are not sorted by read");
+            if (pos + name_len + 2 * seq_len + 16 > out_cap) return cah_set_error_(CAH_ENOMEM, "cah_info_write: output buffer too small");
+            put(buf + r[0], name_len); out[pos++] = '\t'; out[pos++] = '-'; out[pos++] = '1'; out[pos++] = '\t';
+            put(s, seq_len); out[pos++] = '\t';
+            if (fastq) put(qual, seq_len);
+            out[pos++] = '\n';
+            continue;
+        }
+        for (; k < n_rows && rows[k * 7] == i; k++) {
+            const int64_t* m = rows + k * 7;
+            const int64_t wb = m[4], we = m[5], ni = m[6];
+            if (wb < 0 || we > seq_len || wb > we || ni < 0 || ni >= n_names || m[2] < 0 || m[3] < m[2] || m[3] > we - wb)
+                return cah_set_error_(CAH_EINVAL, "cah_info_write: row outside its read");
+            const int64_t nlen = name_off[ni + 1] - name_off[ni];
+            if (pos + name_len + nlen + 2 * (we - wb) + 96 > out_cap) return cah_set_error_(CAH_ENOMEM, "cah_info_write: output buffer too small");
+            const int64_t a = wb + m[2], b = wb + m[3];
+            put(buf + r[0], name_len); out[pos++] = '\t';
+            put_int(m[1]); out[pos++] = '\t'; put_int(m[2]); out[pos++] = '\t'; put_int(m[3]); out[pos++] = '\t';
+            put(s + wb, a - wb); out[pos++] = '\t'; put(s + a, b - a); out[pos++] = '\t'; put(s + b, we - b); out[pos++] = '\t';
+            put(reinterpret_cast<const uint8_t*>(names) + name_off[ni], nlen); out[pos++] = '\t';
+            if (fastq) { put(qual + wb, a - wb); out[pos++] = '\t'; put(qual + a, b - a); out[pos++] = '\t'; put(qual + b, we - b); }
+            else { out[pos++] = '\t'; out[pos++] = '\t'; }
+            out[pos++] = '\t';                                  // reverse-complement flag: "" (not searched)
+            out[pos++] = '\n';
+        }
+    }
+    if (k != n_rows) return cah_set_error_(CAH_EINVAL, "cah_info_write: rows refer to reads outside the chunk");
     *out_len = pos;
     return CAH_OK;
 }

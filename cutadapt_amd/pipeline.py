@@ -1,4 +1,4 @@
-"""Batch-aware pipeline stage: FASTQ chunks in, adapter-trimmed FASTQ out
+"""Batch-aware pipeline stage: FASTA/FASTQ chunks in, adapter-processed records out
 (SURVEY.md section 8(f), rows 1 and 2 -- the callers and data formats either side of the
 matching path).
 
@@ -6,24 +6,30 @@ The reference walks reads one at a time (reference src/cutadapt/pipeline.py:60-6
 modifiers.py:200-261 ``AdapterCutter`` -> adapters ``match_to`` -> ``match.trimmed(read)``),
 getting record-aligned 4 MiB chunks from dnaio.read_chunks (runners.py:116-126, :306).  Here a
 chunk is indexed once by the C++ scanner (csrc/fastq.cpp), its sequences are packed and matched
-in ONE GPU batch call, and the trimmed records are written straight from the raw chunk; no
-per-read Python objects are created.
+in GPU batch calls -- one per search round -- and the output records, the info file and the
+statistics are produced from arrays; no per-read Python objects are created.
 
-Scope of this slice: single-end FASTQ, ``AdapterCutter`` with ``times=1`` and ``action='trim'``
-(the reference's fast path, modifiers.py:118-119, :253-261) over single or multiple adapters.
+Scope of this slice: single-end FASTA/FASTQ, ``AdapterCutter`` with every action
+(trim / retain / crop / mask / lowercase / None, modifiers.py:170-198, :236-251), ``times``
+rounds (:225-231), single, multiple and linked adapters, ``--discard-untrimmed`` /
+``--discard-trimmed`` (steps.py DiscardUntrimmed/DiscardTrimmed), the ``--info-file`` rows
+(steps.py:232-253) and the per-adapter ``errors[removed_length][errors]`` statistics
+(adapters.py:185-199, :233-247).
 """
 import ctypes as C
 import gzip
-import io
-from typing import BinaryIO, Dict, Iterator, Optional, Tuple, Union
+from typing import BinaryIO, Dict, Iterator, List, Optional, Sequence, Tuple, Union
 
 import numpy as np
 
 from . import _lib
-from .adapters import MultipleAdapters, SingleAdapter
+from .adapters import (BatchMatches, LinkedAdapter, LinkedBatchMatches, MultipleAdapters, SingleAdapter,
+                       AnywhereAdapter, BackAdapter, FrontAdapter, NonInternalBackAdapter,
+                       NonInternalFrontAdapter, PrefixAdapter, SuffixAdapter)
 from .sharding import MatchHistogram
 
 DEFAULT_CHUNK_BYTES = 4 * 1024 * 1024     # reference runners.py:306 buffer_size
+ACTIONS = ("trim", "mask", "lowercase", "retain", "crop", None)
 
 
 def _open_maybe_gz(path_or_file: Union[str, BinaryIO]) -> BinaryIO:
@@ -39,26 +45,31 @@ def _open_maybe_gz(path_or_file: Union[str, BinaryIO]) -> BinaryIO:
 
 class FastqChunk:
     """One record-aligned chunk: the raw bytes plus rec[n,6] = (name_beg, name_end, seq_beg,
-    seq_end, qual_beg, qual_end) byte offsets (csrc/fastq.cpp: cah_fastq_scan)."""
+    seq_end, qual_beg, qual_end) byte offsets (csrc/fastq.cpp: cah_fastq_scan / cah_fasta_scan;
+    FASTA records have qual_beg = qual_end = -1)."""
 
     def __init__(self, buf: np.ndarray, rec: np.ndarray):
         self.buf = buf
         self.rec = rec
+        self._packed: Optional[Tuple[np.ndarray, np.ndarray]] = None
 
     def __len__(self):
         return len(self.rec)
 
     def pack_sequences(self) -> Tuple[np.ndarray, np.ndarray]:
-        n = len(self.rec)
-        total = int((self.rec[:, 3] - self.rec[:, 2]).sum()) if n else 0
-        seqs = np.empty(total, dtype=np.uint8)
-        offsets = np.zeros(n + 1, dtype=np.int64)
-        _lib.check(_lib.lib().cah_pack_sequences(
-            self.buf.ctypes.data, self.rec.ctypes.data, n, seqs.ctypes.data if total else None,
-            offsets.ctypes.data))
-        return seqs, offsets
+        if self._packed is None:
+            n = len(self.rec)
+            cap = int((self.rec[:, 3] - self.rec[:, 2]).sum()) if n else 0     # upper bound for FASTA
+            seqs = np.empty(cap, dtype=np.uint8)
+            offsets = np.zeros(n + 1, dtype=np.int64)
+            _lib.check(_lib.lib().cah_pack_sequences(
+                self.buf.ctypes.data, self.rec.ctypes.data, n, seqs.ctypes.data if cap else None,
+                offsets.ctypes.data))
+            self._packed = (seqs[:int(offsets[-1])], offsets)
+        return self._packed
 
     def write_trimmed(self, keep_beg: np.ndarray, keep_end: np.ndarray, keep: Optional[np.ndarray] = None) -> bytes:
+        """FASTQ only, straight from the raw chunk (the times=1 / action='trim' fast path)."""
         n = len(self.rec)
         cap = int(len(self.buf)) + 4 * n + 16
         out = np.empty(cap, dtype=np.uint8)
@@ -71,15 +82,52 @@ class FastqChunk:
             kp.ctypes.data if kp is not None else None, out.ctypes.data, cap, C.byref(out_len)))
         return out[:out_len.value].tobytes()
 
+    def write_records(self, beg: np.ndarray, end: np.ndarray, keep: Optional[np.ndarray] = None,
+                      mode: int = 0) -> bytes:
+        """Any action, FASTA or FASTQ (cah_records_write): mode 0 slice, 1 mask, 2 lowercase."""
+        n = len(self.rec)
+        seqs, offsets = self.pack_sequences()
+        cap = int(len(self.buf)) + 4 * n + 16
+        out = np.empty(cap, dtype=np.uint8)
+        out_len = C.c_int64(0)
+        kb = np.ascontiguousarray(beg, dtype=np.int32)
+        ke = np.ascontiguousarray(end, dtype=np.int32)
+        kp = None if keep is None else np.ascontiguousarray(keep, dtype=np.uint8)
+        _lib.check(_lib.lib().cah_records_write(
+            self.buf.ctypes.data, self.rec.ctypes.data, n, seqs.ctypes.data if len(seqs) else None,
+            offsets.ctypes.data, kb.ctypes.data, ke.ctypes.data,
+            kp.ctypes.data if kp is not None else None, int(mode), out.ctypes.data, cap, C.byref(out_len)))
+        return out[:out_len.value].tobytes()
+
+    def write_info(self, rows: np.ndarray, names: Sequence[str]) -> bytes:
+        """--info-file rows for this chunk; rows int64[k,7] as cah_info_write takes them."""
+        n = len(self.rec)
+        seqs, offsets = self.pack_sequences()
+        rows = np.ascontiguousarray(rows, dtype=np.int64).reshape(-1, 7)
+        blob = "".join(names).encode("ascii")
+        name_off = np.zeros(len(names) + 1, dtype=np.int64)
+        np.cumsum([len(x) for x in names], out=name_off[1:])
+        longest = max([len(x) for x in names], default=0)
+        cap = 3 * int(len(self.buf)) * max(1, 1 + len(rows) // max(n, 1)) + (len(rows) + n) * (96 + longest) + 64
+        out = np.empty(cap, dtype=np.uint8)
+        out_len = C.c_int64(0)
+        _lib.check(_lib.lib().cah_info_write(
+            self.buf.ctypes.data, self.rec.ctypes.data, n, seqs.ctypes.data if len(seqs) else None,
+            offsets.ctypes.data, rows.ctypes.data if len(rows) else None, len(rows), blob,
+            name_off.ctypes.data, len(names), out.ctypes.data, cap, C.byref(out_len)))
+        return out[:out_len.value].tobytes()
+
 
 def read_fastq_chunks(path_or_file: Union[str, BinaryIO], chunk_bytes: int = DEFAULT_CHUNK_BYTES) -> Iterator[FastqChunk]:
-    """Record-aligned chunks of a (possibly gzip-compressed) FASTQ file: the job dnaio.read_chunks
-    does for the reference's ReaderProcess (runners.py:116-126).  A partial record at the end of a
-    buffer is carried over to the next one.  Each chunk gets its own buffer (read straight into it;
-    only the short carried tail is copied)."""
+    """Record-aligned chunks of a (possibly gzip-compressed) FASTA or FASTQ file: the job
+    dnaio.read_chunks does for the reference's ReaderProcess (runners.py:116-126).  The format is
+    taken from the first byte ('@' FASTQ, '>' FASTA).  A partial record at the end of a buffer is
+    carried over to the next one.  Each chunk gets its own buffer (read straight into it; only the
+    short carried tail is copied)."""
     f = _open_maybe_gz(path_or_file)
     L = _lib.lib()
     carry = b""
+    scan = None
     while True:
         buf = np.empty(len(carry) + chunk_bytes, dtype=np.uint8)
         if carry:
@@ -94,81 +142,369 @@ def read_fastq_chunks(path_or_file: Union[str, BinaryIO], chunk_bytes: int = DEF
         if total == 0:
             break
         data = buf[:total]
-        max_rec = int(np.count_nonzero(data == 10)) // 4 + 2
+        if scan is None:
+            scan = L.cah_fasta_scan if data[0] == ord(">") else L.cah_fastq_scan
+        fasta = scan is L.cah_fasta_scan
+        max_rec = (int(np.count_nonzero(data == ord(">"))) + 2) if fasta else int(np.count_nonzero(data == 10)) // 4 + 2
         rec = np.empty((max_rec, 6), dtype=np.int64)
         n = C.c_int64(0)
         consumed = C.c_int64(0)
-        _lib.check(L.cah_fastq_scan(data.ctypes.data, total, int(final), max_rec, rec.ctypes.data,
-                                    C.byref(n), C.byref(consumed)))
+        _lib.check(scan(data.ctypes.data, total, int(final), max_rec, rec.ctypes.data,
+                        C.byref(n), C.byref(consumed)))
         carry = data[consumed.value:].tobytes()
         if n.value:
             yield FastqChunk(data[:consumed.value], rec[:n.value])
         if final:
             break
         if not n.value and len(carry) > 64 * chunk_bytes:
-            raise ValueError("FASTQ record larger than 64 chunks: not a FASTQ file?")
+            raise ValueError("record larger than 64 chunks: not a FASTA/FASTQ file?")
+
+
+# -------------------------------------------------------------------------------------------------
+# one search round in array form
+# -------------------------------------------------------------------------------------------------
+class _Round:
+    """Result of matching one Matchable unit against n (current) reads, reduced to what the
+    pipeline needs: per read a found flag, score/errors for the best-of rule, the three
+    intervals an action may use (all relative to the current read) and the info/statistics
+    rows (k rows: read, errors, rstart, rstop, window offset inside the current read, name id,
+    statistics slot, removed length)."""
+
+    def __init__(self, n: int):
+        z = lambda: np.zeros(n, dtype=np.int64)
+        self.found = np.zeros(n, dtype=bool)
+        self.score, self.errors = z(), z()
+        self.rem_beg, self.rem_end = z(), z()
+        self.ret_beg, self.ret_end = z(), z()
+        self.crop_beg, self.crop_end = z(), z()
+        self.can_crop = np.ones(n, dtype=bool)
+        # rows: columns (read, errors, rstart, rstop, rel_wbeg, rel_wend, name_id, stat_slot, removed_len, order)
+        self.rows = np.zeros((0, 10), dtype=np.int64)
+
+    def take_better(self, other: "_Round") -> None:
+        """MultipleAdapters' rule (reference adapters.py:1278-1285): higher score, then fewer
+        errors; the unit that comes first keeps ties."""
+        better = other.found & (~self.found | (other.score > self.score)
+                                | ((other.score == self.score) & (other.errors < self.errors)))
+        if not better.any():
+            return
+        for name in ("score", "errors", "rem_beg", "rem_end", "ret_beg", "ret_end", "crop_beg", "crop_end", "can_crop"):
+            getattr(self, name)[better] = getattr(other, name)[better]
+        self.found |= better
+        keep_own = ~better[self.rows[:, 0]] if len(self.rows) else np.zeros(0, dtype=bool)
+        take = better[other.rows[:, 0]] if len(other.rows) else np.zeros(0, dtype=bool)
+        self.rows = np.concatenate([self.rows[keep_own], other.rows[take]])
+
+
+def _rows_for(idx: np.ndarray, errors, rstart, rstop, rel_wbeg, rel_wend, name_id, stat_slot, removed, order: int):
+    k = len(idx)
+    rows = np.empty((k, 10), dtype=np.int64)
+    rows[:, 0] = idx
+    rows[:, 1] = errors
+    rows[:, 2] = rstart
+    rows[:, 3] = rstop
+    rows[:, 4] = rel_wbeg
+    rows[:, 5] = rel_wend
+    rows[:, 6] = name_id
+    rows[:, 7] = stat_slot
+    rows[:, 8] = removed
+    rows[:, 9] = order
+    return rows
 
 
 class BatchAdapterCutter:
-    """``AdapterCutter(adapters, times=1, action='trim')`` over whole chunks
-    (reference modifiers.py:82-261, fast path :253-261): best match of all adapters per read,
-    5' matches keep read[rstop:], 3' matches keep read[:rstart] (adapters.py:453-454, :486-487)."""
+    """``AdapterCutter(adapters, times, action, index=False)`` over whole chunks (reference
+    modifiers.py:82-261).  In every round the best match of all adapters is taken per read
+    (``MultipleAdapters``), the read shrinks to the remainder and only reads that matched go into
+    the next round.  Results are intervals on the original read + info rows + statistics."""
 
-    def __init__(self, adapters, device=None):
+    def __init__(self, adapters, times: int = 1, action: Optional[str] = "trim", device=None):
         if isinstance(adapters, MultipleAdapters):
-            self.adapters = adapters
+            adapters = list(adapters._adapters)
+        elif isinstance(adapters, (SingleAdapter, LinkedAdapter)):
+            adapters = [adapters]
         else:
-            adapters = list(adapters) if not isinstance(adapters, SingleAdapter) else [adapters]
-            self.adapters = MultipleAdapters(adapters)
+            adapters = list(adapters)
+        if action not in ACTIONS:
+            raise ValueError(f"unknown action {action!r}")
+        if action in ("retain", "crop") and times > 1:
+            raise ValueError("'retain' and 'crop' cannot be combined with times > 1")
+        self.all_adapters = adapters
+        self.adapters = MultipleAdapters(adapters)          # the reference attribute
+        self.times = int(times)
+        self.action = action
         self.device = device
-        self.histogram = MatchHistogram(len(self.adapters))
+        # units: runs of consecutive fusable single adapters become one fused plan; anything else
+        # (linked adapters, rightmost adapters) is matched on its own.  Unit order = adapter order,
+        # so "first adapter wins ties" is preserved.
+        self._units: List[Tuple[str, object, List[int]]] = []
+        run: List[int] = []
+        for i, a in enumerate(adapters):
+            if isinstance(a, SingleAdapter) and not a._reverse_reads:
+                run.append(i)
+                continue
+            if run:
+                self._units.append(("fused", MultipleAdapters([adapters[j] for j in run]), run))
+                run = []
+            self._units.append(("linked" if isinstance(a, LinkedAdapter) else "single", a, [i]))
+        if run:
+            self._units.append(("fused", MultipleAdapters([adapters[j] for j in run]), run))
+        # info-file names and statistics slots: one slot per single adapter, two per linked one
+        self.names: List[str] = []
+        self._slot: Dict[Tuple[int, int], int] = {}
+        self.stat_labels: List[Tuple[str, str]] = []
+        for i, a in enumerate(adapters):
+            if isinstance(a, LinkedAdapter):
+                base = "none" if a.name is None else a.name
+                for part, suffix in ((0, ";1"), (1, ";2")):
+                    self._slot[(i, part)] = len(self.names)
+                    self.names.append(base + suffix)
+                    self.stat_labels.append((a.name, "front" if part == 0 else "back"))
+            else:
+                self._slot[(i, 0)] = len(self.names)
+                self.names.append(a.name)
+                self.stat_labels.append((a.name, "end"))
+        self.histogram = MatchHistogram(len(self.names))
         self.reads = 0
         self.with_adapters = 0
         self.bp_in = 0
         self.bp_out = 0
 
-    def cut_intervals(self, seqs: np.ndarray, offsets: np.ndarray):
-        """-> (keep_beg, keep_end, BatchMatches) for packed reads"""
+    # ---- one unit, one round ----------------------------------------------------------------
+    def _single_round(self, bm: BatchMatches, lens: np.ndarray, adapter_ids: Sequence[int]) -> _Round:
+        n = len(lens)
+        r = _Round(n)
+        f = bm.found
+        c = bm.coords
+        before = bm.remove_before
+        r.found = f.copy()
+        r.score = np.where(f, c[:, 4], 0)
+        r.errors = np.where(f, c[:, 5], 0)
+        rstart, rstop = c[:, 2], c[:, 3]
+        r.rem_beg = np.where(before, rstop, 0)
+        r.rem_end = np.where(before, lens, rstart)
+        r.ret_beg = np.where(before, rstart, 0)
+        r.ret_end = np.where(before, lens, rstop)
+        r.crop_beg, r.crop_end = rstart.copy(), rstop.copy()
+        idx = np.flatnonzero(f)
+        ids = np.asarray(adapter_ids, dtype=np.int64)[bm.adapter_index[idx].astype(np.int64)]
+        slots = np.array([self._slot[(int(a), 0)] for a in ids], dtype=np.int64) if len(ids) else np.zeros(0, np.int64)
+        removed = np.where(before[idx], rstop[idx], lens[idx] - rstart[idx])     # removed_sequence_length()
+        r.rows = _rows_for(idx, c[idx, 5], rstart[idx], rstop[idx], 0, lens[idx], slots, slots, removed, 0)
+        return r
+
+    def _linked_round(self, lm: LinkedBatchMatches, lens: np.ndarray, adapter_id: int) -> _Round:
+        n = len(lens)
+        r = _Round(n)
+        ff, bf = lm.front.found & lm.found, lm.back.found & lm.found
+        fc, bc = lm.front.coords, lm.back.coords
+        off = np.where(ff, fc[:, 3], 0)                      # the back stage saw read[off:]
+        r.found = lm.found.copy()
+        r.score = np.where(ff, fc[:, 4], 0) + np.where(bf, bc[:, 4], 0)
+        r.errors = np.where(ff, fc[:, 5], 0) + np.where(bf, bc[:, 5], 0)
+        # remainder([front, back]) (reference adapters.py:1588-1602, :1139-1143)
+        r.rem_beg = off
+        r.rem_end = np.where(bf, off + bc[:, 2], lens)
+        # retained_adapter_interval (:1145-1155)
+        r.ret_beg = np.where(ff, fc[:, 2], 0)
+        r.ret_end = np.where(bf, bc[:, 3] + off, lens)
+        r.can_crop[:] = False                                # LinkedMatch has no rstart/rstop
+        fi, bi = np.flatnonzero(ff), np.flatnonzero(bf)
+        s1, s2 = self._slot[(adapter_id, 0)], self._slot[(adapter_id, 1)]
+        rows1 = _rows_for(fi, fc[fi, 5], fc[fi, 2], fc[fi, 3], 0, lens[fi], s1, s1, fc[fi, 3], 0)
+        rows2 = _rows_for(bi, bc[bi, 5], bc[bi, 2], bc[bi, 3], off[bi], lens[bi], s2, s2,
+                          (lens[bi] - off[bi]) - bc[bi, 2], 1)
+        r.rows = np.concatenate([rows1, rows2])
+        return r
+
+    def _match_round(self, batch, lens: np.ndarray) -> _Round:
+        best = None
+        for kind, unit, ids in self._units:
+            if kind == "linked":
+                rr = self._linked_round(unit.match_to_batch(batch), lens, ids[0])
+            else:
+                rr = self._single_round(unit.match_to_batch(batch), lens, ids if kind == "fused" else [ids[0]])
+            if best is None:
+                best = rr
+            else:
+                best.take_better(rr)
+        return best
+
+    # ---- all rounds of a chunk --------------------------------------------------------------
+    def process_arrays(self, seqs: np.ndarray, offsets: np.ndarray):
+        """-> dict(beg, end, matched, rows): the interval of every read the chosen action keeps
+        or marks (relative to the original read), whether any adapter was found, and the info
+        rows int64[k,7] = (read, errors, rstart, rstop, wbeg, wend, name_id)."""
+        import torch
         from .batch import ReadBatch
         n = len(offsets) - 1
         lens = (offsets[1:] - offsets[:-1]).astype(np.int64)
-        if n == 0:
-            z = np.zeros(0, dtype=np.int32)
-            return z, z, None
-        batch = ReadBatch.from_host(seqs, offsets, device=self.device)
-        batch.validate_ascii()
-        bm = self.adapters.match_to_batch(batch)
-        beg = np.zeros(n, dtype=np.int64)
-        end = lens.copy()
-        f = bm.found
-        before = f & bm.remove_before
-        after = f & ~bm.remove_before
-        beg[before] = bm.coords[before, 3]          # rstop
-        end[after] = bm.coords[after, 2]            # rstart
-        self.histogram.add_batch(bm.coords, f, bm.adapter_index)
+        wbeg = np.zeros(n, dtype=np.int64)
+        wend = lens.copy()
+        matched = np.zeros(n, dtype=bool)
+        last_ret = (np.zeros(n, np.int64), lens.copy())
+        last_crop = (np.zeros(n, np.int64), lens.copy())
+        all_rows = []
+        if n:
+            base = ReadBatch.from_host(seqs, offsets, device=self.device)
+            base.validate_ascii()
+            dev_off = base.offsets[:n]
+            active = np.arange(n)
+            for rnd in range(self.times):
+                if rnd == 0:
+                    batch, cur_len = base, lens
+                else:
+                    ia = torch.from_numpy(active).to(base.device)
+                    starts = dev_off[ia] + torch.from_numpy(wbeg[active]).to(base.device)
+                    cur_len = wend[active] - wbeg[active]
+                    batch = ReadBatch(base.seqs, starts, torch.from_numpy(cur_len.astype(np.int32)).to(base.device),
+                                      n_reads=len(active), validated=True)
+                rr = self._match_round(batch, cur_len)
+                hit = rr.found
+                if not hit.any():
+                    break
+                g = active[hit]
+                if self.action == "crop" and not rr.can_crop[hit].all():
+                    raise AttributeError("'LinkedMatch' object has no attribute 'rstart'")     # as the reference
+                rows = rr.rows
+                if len(rows):
+                    rows = rows[np.lexsort((rows[:, 9], rows[:, 0]))]
+                    self.histogram.add_rows(rows[:, 7], rows[:, 8], rows[:, 1])
+                    out = np.empty((len(rows), 8), dtype=np.int64)
+                    gi = active[rows[:, 0]]
+                    out[:, 0] = gi
+                    out[:, 1:4] = rows[:, 1:4]
+                    out[:, 4] = wbeg[gi] + rows[:, 4]
+                    out[:, 5] = wbeg[gi] + rows[:, 5]
+                    out[:, 6] = rows[:, 6]
+                    out[:, 7] = rnd * 2 + rows[:, 9]
+                    all_rows.append(out)
+                last_ret = (last_ret[0].copy(), last_ret[1].copy())
+                last_ret[0][g], last_ret[1][g] = wbeg[g] + rr.ret_beg[hit], wbeg[g] + rr.ret_end[hit]
+                last_crop[0][g], last_crop[1][g] = wbeg[g] + rr.crop_beg[hit], wbeg[g] + rr.crop_end[hit]
+                new_beg = wbeg[g] + rr.rem_beg[hit]
+                new_end = wbeg[g] + rr.rem_end[hit]
+                wbeg[g], wend[g] = new_beg, new_end
+                matched[g] = True
+                active = g
+        if self.action == "retain":
+            beg, end = last_ret
+        elif self.action == "crop":
+            beg, end = last_crop
+        elif self.action is None:
+            beg, end = np.zeros(n, np.int64), lens.copy()
+        else:                                                # trim, mask, lowercase: the remainder
+            beg, end = wbeg, wend
+        rows = np.concatenate(all_rows) if all_rows else np.zeros((0, 8), dtype=np.int64)
+        if len(rows):
+            rows = rows[np.lexsort((rows[:, 7], rows[:, 0]))]
         self.reads += n
-        self.with_adapters += int(f.sum())
+        self.with_adapters += int(matched.sum())
         self.bp_in += int(lens.sum())
-        self.bp_out += int((end - beg).sum())
-        return beg.astype(np.int32), end.astype(np.int32), bm
+        self.bp_out += int((end - beg).sum()) if self.action in ("trim", "retain", "crop") else int(lens.sum())
+        return {"beg": beg.astype(np.int32), "end": end.astype(np.int32), "matched": matched,
+                "rows": np.ascontiguousarray(rows[:, :7])}
 
-    def process_chunk(self, chunk: FastqChunk) -> bytes:
+    # ---- compatibility with the first slice (times=1, trim) ---------------------------------
+    def cut_intervals(self, seqs: np.ndarray, offsets: np.ndarray):
+        """-> (keep_beg, keep_end, matched) for packed reads"""
+        res = self.process_arrays(seqs, offsets)
+        return res["beg"], res["end"], res["matched"]
+
+    def process_chunk(self, chunk: FastqChunk, discard_untrimmed: bool = False, discard_trimmed: bool = False,
+                      info: Optional[list] = None) -> bytes:
         seqs, offsets = chunk.pack_sequences()
-        beg, end, _ = self.cut_intervals(seqs, offsets)
-        return chunk.write_trimmed(beg, end)
+        res = self.process_arrays(seqs, offsets)
+        if info is not None:
+            info.append(chunk.write_info(res["rows"], self.names))
+        keep = None
+        if discard_untrimmed:
+            keep = res["matched"]
+        elif discard_trimmed:
+            keep = ~res["matched"]
+        mode = {"mask": 1, "lowercase": 2}.get(self.action, 0)
+        return chunk.write_records(res["beg"], res["end"], keep, mode)
 
 
-def trim_fastq(inpath: Union[str, BinaryIO], outpath: Union[str, BinaryIO], adapters,
-               chunk_bytes: int = DEFAULT_CHUNK_BYTES, device=None) -> Dict[str, int]:
-    """``cutadapt <adapter options> -o outpath inpath`` for the supported slice; returns the
-    read/basepair counters the reference reports (reference report.py:62-80)."""
-    cutter = BatchAdapterCutter(adapters, device=device)
+def trim_fastq(inpath: Union[str, BinaryIO], outpath: Union[str, BinaryIO], adapters, times: int = 1,
+               action: Optional[str] = "trim", discard_untrimmed: bool = False, discard_trimmed: bool = False,
+               info_file: Union[None, str, BinaryIO] = None, chunk_bytes: int = DEFAULT_CHUNK_BYTES,
+               device=None) -> Dict[str, object]:
+    """``cutadapt <adapter options> [--times N] [--action A] [--discard-(un)trimmed]
+    [--info-file F] -o outpath inpath`` for the supported slice; returns the read/basepair
+    counters the reference reports (reference report.py:62-80) and the cutter (statistics)."""
+    cutter = BatchAdapterCutter(adapters, times=times, action=action, device=device)
     out = outpath if hasattr(outpath, "write") else open(outpath, "wb")
+    inf = None if info_file is None else (info_file if hasattr(info_file, "write") else open(info_file, "wb"))
     try:
         for chunk in read_fastq_chunks(inpath, chunk_bytes):
-            out.write(cutter.process_chunk(chunk))
+            info: Optional[list] = [] if inf is not None else None
+            out.write(cutter.process_chunk(chunk, discard_untrimmed, discard_trimmed, info))
+            if inf is not None:
+                inf.write(b"".join(info))
     finally:
         if out is not outpath:
             out.close()
+        if inf is not None and inf is not info_file:
+            inf.close()
     return {"reads": cutter.reads, "with_adapters": cutter.with_adapters,
-            "bp_in": cutter.bp_in, "bp_out": cutter.bp_out}
+            "bp_in": cutter.bp_in, "bp_out": cutter.bp_out, "cutter": cutter}
+
+
+# -------------------------------------------------------------------------------------------------
+# adapter specifications ("-a ^FRONT...BACK$" etc.), the subset of reference parser.py the
+# golden command lines use (:203-300 restrictions, :472-522 linked adapters)
+# -------------------------------------------------------------------------------------------------
+def _single_from_spec(spec: str, adapter_type: str, name: Optional[str], params: dict):
+    if "=" in spec.split(";")[0] and name is None:
+        name, spec = spec.split("=", 1)
+    spec = spec.split(";")[0]
+    front_restriction = back_restriction = None
+    if spec.startswith("^"):
+        front_restriction, spec = "anchored", spec[1:]
+    elif spec.startswith("X"):
+        front_restriction, spec = "noninternal", spec.lstrip("X")
+    if spec.endswith("$"):
+        back_restriction, spec = "anchored", spec[:-1]
+    elif spec.endswith("X"):
+        back_restriction, spec = "noninternal", spec.rstrip("X")
+    if adapter_type == "front":
+        if back_restriction:
+            raise ValueError("a 5' adapter cannot be restricted at its 3' end")
+        cls = {None: FrontAdapter, "anchored": PrefixAdapter, "noninternal": NonInternalFrontAdapter}[front_restriction]
+    elif adapter_type == "back":
+        if front_restriction:
+            raise ValueError("a 3' adapter cannot be restricted at its 5' end")
+        cls = {None: BackAdapter, "anchored": SuffixAdapter, "noninternal": NonInternalBackAdapter}[back_restriction]
+    else:
+        if front_restriction or back_restriction:
+            raise ValueError("'anywhere' (-b) adapters may not be anchored")
+        cls = AnywhereAdapter
+    return cls(spec, name=name, **params), (front_restriction or back_restriction) is not None
+
+
+def adapter_from_spec(spec: str, adapter_type: str = "back", **params):
+    """``-a SPEC`` (adapter_type 'back'), ``-g SPEC`` ('front') or ``-b SPEC`` ('anywhere') ->
+    adapter object; understands ``name=``, ``^``/``$`` anchoring, ``X`` non-internal markers and
+    ``FRONT...BACK`` linked adapters (required/optional rules of reference parser.py:496-503)."""
+    name = None
+    if "=" in spec.split("...")[0].split(";")[0]:
+        name, spec = spec.split("=", 1)
+    if "..." in spec:
+        front_spec, back_spec = spec.split("...", 1)
+        if front_spec and back_spec:
+            if adapter_type == "anywhere":
+                raise ValueError("'anywhere' (-b) adapters may not be linked")
+            front, front_anchored = _single_from_spec(front_spec, "front", "linked_front", dict(params))
+            back, back_anchored = _single_from_spec(back_spec, "back", "linked_back", dict(params))
+            if adapter_type == "front":
+                front_required = back_required = True
+            else:
+                front_required, back_required = front_anchored, back_anchored
+            return LinkedAdapter(front, back, front_required, back_required, name)
+        # "ADAPTER..." / "...ADAPTER": plain 5' / 3' adapter (parser.py _normalize_ellipsis)
+        if front_spec:
+            adapter_type, spec = "front", front_spec
+        else:
+            adapter_type, spec = "back", back_spec
+    return _single_from_spec(spec, adapter_type, name, dict(params))[0]

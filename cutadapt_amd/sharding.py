@@ -65,10 +65,33 @@ class MatchHistogram:
         flat = (ad * shape[1] + length) * shape[2] + errors
         self.counts += np.bincount(flat, minlength=self.counts.size).reshape(shape)
 
+    def add_rows(self, slot: np.ndarray, removed_length: np.ndarray, errors: np.ndarray) -> None:
+        """The reference's own key: errors[removed_sequence_length][errors] per adapter end
+        (adapters.py:185-199, linked :233-247).  The length axis grows on demand."""
+        if len(slot) == 0:
+            return
+        slot = np.asarray(slot, dtype=np.int64)
+        length = np.asarray(removed_length, dtype=np.int64)
+        errors = np.asarray(errors, dtype=np.int64)
+        need_len, need_err = int(length.max()) + 1, int(errors.max()) + 1
+        if need_len > self.counts.shape[1] or need_err > self.counts.shape[2]:
+            grown = np.zeros((self.counts.shape[0], max(need_len, self.counts.shape[1]),
+                              max(need_err, self.counts.shape[2])), dtype=np.int64)
+            grown[:, :self.counts.shape[1], :self.counts.shape[2]] = self.counts
+            self.counts = grown
+        shape = self.counts.shape
+        flat = (slot * shape[1] + length) * shape[2] + errors
+        self.counts += np.bincount(flat, minlength=self.counts.size).reshape(shape)
+
     def __iadd__(self, other: "MatchHistogram") -> "MatchHistogram":
-        if self.counts.shape != other.counts.shape:
+        if self.counts.shape[0] != other.counts.shape[0]:
             raise ValueError("incompatible histograms")
-        self.counts += other.counts
+        if self.counts.shape != other.counts.shape:
+            shape = tuple(max(a, b) for a, b in zip(self.counts.shape, other.counts.shape))
+            grown = np.zeros(shape, dtype=np.int64)
+            grown[:, :self.counts.shape[1], :self.counts.shape[2]] = self.counts
+            self.counts = grown
+        self.counts[:, :other.counts.shape[1], :other.counts.shape[2]] += other.counts
         return self
 
     def total(self) -> int:

@@ -212,6 +212,30 @@ int cah_fastq_write_trimmed(const uint8_t *buf, const int64_t *rec, int64_t n_re
                             const int32_t *keep_beg, const int32_t *keep_end, const uint8_t *keep,
                             uint8_t *out, int64_t out_cap, int64_t *out_len);
 
+/* FASTA twin of cah_fastq_scan (">name" + one or more sequence lines).  Same rec columns;
+ * seq_beg..seq_end spans the raw sequence lines (cah_pack_sequences strips the line breaks) and
+ * qual_beg = qual_end = -1 marks a record without qualities. */
+int cah_fasta_scan(const uint8_t *buf, int64_t len, int is_final, int64_t max_records,
+                   int64_t *rec, int64_t *n_records, int64_t *consumed);
+/* Output formatting for every AdapterCutter action (modifiers.py:170-198, :236-251): sequence from
+ * the packed batch (seqs/offsets), names and qualities from the raw chunk; interval [beg,end) per
+ * read.  SLICE: sequence+qualities sliced (trim, retain, crop; whole read for action None);
+ * MASK: bases outside the interval become 'N'; LOWERCASE: outside lower-, inside upper-case. */
+#define CAH_WRITE_SLICE 0
+#define CAH_WRITE_MASK 1
+#define CAH_WRITE_LOWERCASE 2
+int cah_records_write(const uint8_t *buf, const int64_t *rec, int64_t n_records,
+                      const uint8_t *seqs, const int64_t *offsets, const int32_t *beg,
+                      const int32_t *end, const uint8_t *keep, int mode, uint8_t *out,
+                      int64_t out_cap, int64_t *out_len);
+/* --info-file rows (steps.py:232-253, adapters.py:395-417, linked :1157-1171).  rows[k*7..] =
+ * (read, errors, rstart, rstop, wbeg, wend, name_idx) sorted by read then match order; rstart and
+ * rstop are relative to original[wbeg:wend], the read as it was when the match was made. */
+int cah_info_write(const uint8_t *buf, const int64_t *rec, int64_t n_records, const uint8_t *seqs,
+                   const int64_t *offsets, const int64_t *rows, int64_t n_rows, const char *names,
+                   const int64_t *name_off, int64_t n_names, uint8_t *out, int64_t out_cap,
+                   int64_t *out_len);
+
 #ifdef __cplusplus
 }
 #endif

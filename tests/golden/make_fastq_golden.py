@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
-"""Copy the small FASTQ inputs and expected outputs of the reference's command-line tests into
-tests/golden/fastq/ (run in the build container; the GPU box has no /root/reference).
+"""Copy the small FASTA/FASTQ inputs and expected outputs of the reference's command-line tests
+into tests/golden/fastq/ (run in the build container; the GPU box has no /root/reference).
 
-Each case below is one `run(params, expected, input)` of reference tests/test_commandline.py
-(file:line given); `expected` comes from tests/cut/, `input` from tests/data/.
+Each case below is one `run(params, expected, input)` of reference tests/test_commandline.py or
+tests/test_info_file.py (file:line given); `expected` (and `info`) come from tests/cut/, `input`
+from tests/data/.  Only test DATA is copied; the command lines are restated as
+(option, adapter specification) pairs plus the AdapterCutter options they set.
 """
 import json
 import os
@@ -13,24 +15,50 @@ REF = os.environ.get("CUTADAPT_REFERENCE", "/root/reference") + "/tests"
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(HERE, "fastq")
 
+T = "test_commandline.py"
+I = "test_info_file.py"
 CASES = [
-    # (name, reference test line, adapter kind, adapter sequence(s), extra, input, expected)
-    ("small", "test_commandline.py:79", "back", ["TTAGACATATCTCCGTCG"], {}, "small.fastq", "small.fastq"),
-    ("empty", "test_commandline.py:91", "back", ["TTAGACATATCTCCGTCG"], {}, "empty.fastq", "empty.fastq"),
-    ("dos", "test_commandline.py:104", "back", ["TTAGACATATCTCCGTCG"], {"max_errors": 0.12}, "dos.fastq", "dos.fastq"),
-    ("lowercase", "test_commandline.py:109", "back", ["ttagacatatctccgtcg"], {}, "small.fastq", "lowercase.fastq"),
-    ("illumina_iupac", "test_commandline.py:376", "back", ["VCCGAMCYUCKHRKDCUBBCNUWNSGHCGU"], {}, "illumina.fastq.gz", "illumina.fastq"),
-    ("illumina_u", "test_commandline.py:456", "back", ["GCCGAACUUCUUAGACUGCCUUAAGGACGU"], {}, "illumina.fastq.gz", "illumina.fastq"),
-    ("small_anywhere_gz", "test_commandline.py:776", "anywhere", ["TTAGACATATCTCCGTCG"], {}, "small.fastq.gz", "small.fastq"),
+    # name, reference test, adapters [(option, spec)], options, input, expected, expected info file
+    ("small", f"{T}:79", [("-a", "TTAGACATATCTCCGTCG")], {}, "small.fastq", "small.fastq", None),
+    ("empty", f"{T}:91", [("-a", "TTAGACATATCTCCGTCG")], {}, "empty.fastq", "empty.fastq", None),
+    ("dos", f"{T}:104", [("-a", "TTAGACATATCTCCGTCG")], {"max_errors": 0.12}, "dos.fastq", "dos.fastq", None),
+    ("lowercase", f"{T}:109", [("-a", "ttagacatatctccgtcg")], {}, "small.fastq", "lowercase.fastq", None),
+    ("discard_trimmed", f"{T}:127", [("-b", "TTAGACATATCTCCGTCG")], {"discard_trimmed": True}, "small.fastq", "discard.fastq", None),
+    ("discard_untrimmed", f"{T}:132", [("-b", "CAAGAT")], {"discard_untrimmed": True}, "small.fastq", "discard-untrimmed.fastq", None),
+    ("twoadapters", f"{T}:261", [("-a", "AATTTCAGGAATT"), ("-a", "GTTCTCTAGTTCT")], {}, "twoadapters.fasta", "twoadapters.fasta", None),
+    ("action_none", f"{T}:289", [("-a", "CCCTAGTTAAAC")], {"action": None, "discard_untrimmed": True}, "small.fastq", "no-trim.fastq", None),
+    ("action_mask", f"{T}:303", [("-b", "CAAG")], {"times": 3, "action": "mask"}, "anywhere_repeat.fastq", "anywhere_repeat.fastq", None),
+    ("action_lowercase", f"{T}:308", [("-b", "CAAG")], {"times": 3, "action": "lowercase"}, "action_lowercase.fasta", "action_lowercase.fasta", None),
+    ("action_retain", f"{T}:316", [("-g", "GGTTAACC"), ("-a", "CAAG")], {"action": "retain"}, "action_retain.fasta", "action_retain.fasta", None),
+    ("action_crop", f"{T}:329", [("-g", "GGTTAA"), ("-a", "CAAG")], {"action": "crop", "discard_untrimmed": True}, "action_retain.fasta", "action_crop.fasta", None),
+    ("illumina_iupac", f"{T}:376", [("-a", "VCCGAMCYUCKHRKDCUBBCNUWNSGHCGU")], {}, "illumina.fastq.gz", "illumina.fastq", None),
+    ("illumina_u", f"{T}:456", [("-a", "GCCGAACUUCUUAGACUGCCUUAAGGACGU")], {}, "illumina.fastq.gz", "illumina.fastq", None),
+    ("linked_explicitly_anchored", f"{T}:668", [("-a", "^AAAAAAAAAA...TTTTTTTTTT")], {}, "linked.fasta", "linked.fasta", None),
+    ("linked_multiple", f"{T}:672", [("-a", "^AAAAAAAAAA...TTTTTTTTTT"), ("-a", "^AAAAAAAAAA...GCGCGCGCGC")], {}, "linked.fasta", "linked.fasta", None),
+    ("linked_both_anchored", f"{T}:680", [("-a", "^AAAAAAAAAA...TTTTT$")], {}, "linked.fasta", "linked-anchored.fasta", None),
+    ("linked_5p_not_anchored", f"{T}:684", [("-g", "AAAAAAAAAA...TTTTTTTTTT")], {}, "linked.fasta", "linked-not-anchored.fasta", None),
+    ("linked_discard_untrimmed", f"{T}:688", [("-a", "^AAAAAAAAAA...TTTTTTTTTT")], {"discard_untrimmed": True}, "linked.fasta", "linked-discard.fasta", None),
+    ("linked_discard_untrimmed_g", f"{T}:696", [("-g", "AAAAAAAAAA...TTTTTTTTTT")], {"discard_untrimmed": True}, "linked.fasta", "linked-discard-g.fasta", None),
+    ("linked_lowercase", f"{T}:705", [("-a", "^AACCGGTTTT...GGGGGGG$"), ("-a", "^AAAA...TTTT$")], {"times": 2, "action": "lowercase"}, "linked.fasta", "linked-lowercase.fasta", None),
+    ("small_anywhere_gz", f"{T}:776", [("-b", "TTAGACATATCTCCGTCG")], {}, "small.fastq.gz", "small.fastq", None),
+    ("info_file", f"{I}:14", [("-a", "adapt=GCCGAACTTCTTAGACTGCCTTAAGGACGT")], {}, "illumina.fastq.gz", "illumina.fastq", "illumina.info.txt"),
+    ("info_file_times", f"{I}:35", [("-a", "adapt=GCCGAACTTCTTA"), ("-a", "adapt2=GACTGCCTTAAGGACGT")], {"times": 2}, "illumina5.fastq", "illumina5.fastq", "illumina5.info.txt"),
+    ("linked_info_file", f"{I}:119", [("-a", "linkedadapter=^AAAAAAAAAA...TTTTTTTTTT")], {}, "linked.fasta", None, "linked-info.txt"),
 ]
 
 os.makedirs(OUT, exist_ok=True)
 manifest = []
-for name, where, kind, seqs, extra, inp, exp in CASES:
+for name, where, adapters, options, inp, exp, info in CASES:
     shutil.copyfile(os.path.join(REF, "data", inp), os.path.join(OUT, "in_" + inp))
-    shutil.copyfile(os.path.join(REF, "cut", exp), os.path.join(OUT, "out_" + exp))
-    manifest.append({"name": name, "reference_test": where, "kind": kind, "adapters": seqs, "extra": extra,
-                     "input": "in_" + inp, "expected": "out_" + exp})
+    entry = {"name": name, "reference_test": where, "adapters": [list(a) for a in adapters], "options": options,
+             "input": "in_" + inp, "expected": None, "info": None}
+    if exp is not None:
+        shutil.copyfile(os.path.join(REF, "cut", exp), os.path.join(OUT, "out_" + exp))
+        entry["expected"] = "out_" + exp
+    if info is not None:
+        shutil.copyfile(os.path.join(REF, "cut", info), os.path.join(OUT, "info_" + info))
+        entry["info"] = "info_" + info
+    manifest.append(entry)
 with open(os.path.join(OUT, "manifest.json"), "w") as f:
     json.dump(manifest, f, indent=1)
 print("wrote", len(manifest), "cases to", OUT)

@@ -73,22 +73,155 @@ def test_pack_and_write_roundtrip():
     assert lines[3] == recs[1][2][len(recs[1][1]) // 4:len(recs[1][1]) // 2]
 
 
+def _strip_trailing_space(data: bytes) -> bytes:
+    """diff --ignore-trailing-space, as the reference's info-file comparisons use"""
+    return b"\n".join(line.rstrip() for line in data.split(b"\n"))
+
+
+def test_fasta_scan_and_writers():
+    """multi-line FASTA records, chunk boundaries, the three output modes and the info rows
+    (host-only entry points: no GPU needed)"""
+    from cutadapt_amd.pipeline import read_fastq_chunks
+    data = b">r1 first\nACGTAC\nGTAA\n>r2\n\n>r3\r\nttgacc\r\n>r4\nAC"
+    for chunk_bytes in (1 << 20, 7):
+        chunks = list(read_fastq_chunks(io.BytesIO(data), chunk_bytes=chunk_bytes))
+        names, seqs_ = [], []
+        for c in chunks:
+            seqs, offsets = c.pack_sequences()
+            for j in range(len(c)):
+                names.append(bytes(c.buf[c.rec[j, 0]:c.rec[j, 1]]).decode())
+                seqs_.append(bytes(seqs[offsets[j]:offsets[j + 1]]).decode())
+        assert names == ["r1 first", "r2", "r3", "r4"]
+        assert seqs_ == ["ACGTACGTAA", "", "ttgacc", "AC"]
+    c = list(read_fastq_chunks(io.BytesIO(data)))[0]        # r4 completes only at EOF: second chunk
+    assert len(c) == 3
+    beg, end = np.array([2, 0, 1], np.int32), np.array([5, 0, 4], np.int32)
+    assert c.write_records(beg, end, mode=0) == b">r1 first\nGTA\n>r2\n\n>r3\ntga\n"
+    assert c.write_records(beg, end, mode=1) == b">r1 first\nNNGTANNNNN\n>r2\n\n>r3\nNtgaNN\n"
+    assert c.write_records(beg, end, mode=2) == b">r1 first\nacGTAcgtaa\n>r2\n\n>r3\ntTGAcc\n"
+    assert c.write_records(beg, end, keep=np.array([0, 1, 1], np.uint8)) == b">r2\n\n>r3\ntga\n"
+    rows = np.array([[0, 1, 2, 5, 0, 10, 0], [0, 0, 1, 2, 0, 2, 1], [2, 0, 0, 2, 1, 5, 0]], np.int64)
+    info = c.write_info(rows, ["ad", "other"])
+    assert info == (b"r1 first\t1\t2\t5\tAC\tGTA\tCGTAA\tad\t\t\t\t\n"
+                    b"r1 first\t0\t1\t2\tA\tC\t\tother\t\t\t\t\n"
+                    b"r2\t-1\t\t\n" b"r3\t0\t0\t2\t\ttg\tac\tad\t\t\t\t\n")
+    fq = list(read_fastq_chunks(io.BytesIO(b"@q\nACGTT\n+\nIIHGF\n")))[0]
+    assert fq.write_records(np.array([1], np.int32), np.array([3], np.int32), mode=1) == b"@q\nNCGNN\n+\nIIHGF\n"
+    assert fq.write_info(np.array([[0, 0, 1, 3, 0, 5, 0]], np.int64), ["x"]) == b"q\t0\t1\t3\tA\tCG\tTT\tx\tI\tIH\tGF\t\n"
+    with pytest.raises(ValueError):
+        fq.write_info(np.array([[0, 0, 1, 9, 0, 5, 0]], np.int64), ["x"])
+
+
+def test_adapter_specs():
+    from cutadapt_amd import adapters as A
+    from cutadapt_amd.pipeline import adapter_from_spec
+    a = adapter_from_spec("name=ACGT", "back")
+    assert isinstance(a, A.BackAdapter) and a.name == "name" and a.sequence == "ACGT"
+    assert isinstance(adapter_from_spec("^ACGT", "front"), A.PrefixAdapter)
+    assert isinstance(adapter_from_spec("ACGT$", "back"), A.SuffixAdapter)
+    assert isinstance(adapter_from_spec("XACGT", "front"), A.NonInternalFrontAdapter)
+    assert isinstance(adapter_from_spec("ACGTX", "back"), A.NonInternalBackAdapter)
+    assert isinstance(adapter_from_spec("ACGT", "anywhere"), A.AnywhereAdapter)
+    assert isinstance(adapter_from_spec("ACGT...", "back"), A.FrontAdapter)
+    la = adapter_from_spec("l=^AAAA...TTTT", "back")
+    assert isinstance(la, A.LinkedAdapter) and la.name == "l" and la.front_required and not la.back_required
+    assert isinstance(la.front_adapter, A.PrefixAdapter) and isinstance(la.back_adapter, A.BackAdapter)
+    lg = adapter_from_spec("AAAA...TTTT", "front")
+    assert lg.front_required and lg.back_required and isinstance(lg.front_adapter, A.FrontAdapter)
+    with pytest.raises(ValueError):
+        adapter_from_spec("AAA...TTT", "anywhere")
+
+
 @pytest.mark.gpu
 def test_reference_commandline_goldens(hip):
-    """cutadapt -a/-b ADAPTER in.fastq -o out.fastq for the simple single-end cases of reference
-    tests/test_commandline.py (manifest.json lists test line, options, input, expected)."""
-    from cutadapt_amd import adapters as A
-    from cutadapt_amd.pipeline import trim_fastq
+    """The single-end adapter-trimming command lines of reference tests/test_commandline.py and
+    tests/test_info_file.py (manifest.json lists test line, adapter options, AdapterCutter options,
+    input, expected output and expected info file): every action, --times, linked and multiple
+    adapters, --discard-(un)trimmed, FASTA and FASTQ, with one big and many tiny chunks."""
+    from cutadapt_amd.pipeline import adapter_from_spec, trim_fastq
     manifest = json.load(open(os.path.join(FQ, "manifest.json")))
-    assert len(manifest) >= 7
+    assert len(manifest) >= 25
+    kinds = {"-a": "back", "-g": "front", "-b": "anywhere"}
     for case in manifest:
-        cls = {"back": A.BackAdapter, "front": A.FrontAdapter, "anywhere": A.AnywhereAdapter}[case["kind"]]
-        ads = [cls(s, **case["extra"]) for s in case["adapters"]]
-        out = io.BytesIO()
+        opts = dict(case["options"])
+        params = {"max_errors": opts.pop("max_errors")} if "max_errors" in opts else {}
         for chunk_bytes in (4 << 20, 512):          # 512 forces many chunks (reference --buffer-size=512 tests)
-            out = io.BytesIO()
-            stats = trim_fastq(os.path.join(FQ, case["input"]), out, ads, chunk_bytes=chunk_bytes)
-            expected = open(os.path.join(FQ, case["expected"]), "rb").read()
-            assert out.getvalue() == expected, (case["name"], chunk_bytes)
+            ads = [adapter_from_spec(spec, kinds[opt], **params) for opt, spec in case["adapters"]]
+            out, info = io.BytesIO(), io.BytesIO()
+            stats = trim_fastq(os.path.join(FQ, case["input"]), out, ads, chunk_bytes=chunk_bytes,
+                               info_file=info if case["info"] else None, **opts)
+            if case["expected"]:
+                expected = open(os.path.join(FQ, case["expected"]), "rb").read()
+                assert out.getvalue() == expected, (case["name"], chunk_bytes)
+            if case["info"]:
+                expected = open(os.path.join(FQ, case["info"]), "rb").read()
+                assert _strip_trailing_space(info.getvalue()) == _strip_trailing_space(expected), (case["name"], chunk_bytes)
         if case["name"] == "illumina_iupac":
             assert stats["reads"] == 100 and stats["with_adapters"] == 56
+            # errors[removed_length][errors] sums to the number of matches (adapters.py:185-199)
+            assert stats["cutter"].histogram.total() == 56
+
+
+@pytest.mark.gpu
+def test_pipeline_rounds_against_reference_adapter_cutter_semantics(hip, orc):
+    """times > 1 and every action against a straightforward per-read restatement of
+    AdapterCutter.match_and_trim (reference modifiers.py:209-251) driven by the oracle's
+    match_to; random reads with several adapter copies."""
+    import random
+    from cutadapt_amd import adapters as A
+    from cutadapt_amd.pipeline import BatchAdapterCutter, FastqChunk, read_fastq_chunks
+    rng = random.Random(11)
+    ad_seqs = ["ACGTTGCA", "GGATCCAA"]
+    reads = []
+    for i in range(400):
+        s = "".join(rng.choice("ACGT") for _ in range(rng.randint(0, 60)))
+        for _ in range(rng.randint(0, 3)):
+            p = rng.randint(0, len(s))
+            s = s[:p] + rng.choice(ad_seqs) + s[p:]
+        reads.append(s)
+    fq = "".join(f"@r{i}\n{s}\n+\n{'I' * len(s)}\n" for i, s in enumerate(reads)).encode()
+    chunk = list(read_fastq_chunks(io.BytesIO(fq)))[0]
+    seqs, offsets = chunk.pack_sequences()
+
+    def expected_intervals(times, action):
+        out = []
+        for s in reads:
+            wb, we, ms = 0, len(s), []
+            for _ in range(times):
+                best = None
+                for seq, kind in ((ad_seqs[0], "back"), (ad_seqs[1], "front")):
+                    flags = 14 if kind == "back" else 11
+                    # the oracle's match_to: k-mer prefilter is lossless, so locate alone decides
+                    t = orc.Aligner(seq, 0.1, flags=flags, wildcard_ref=True, min_overlap=3).locate(s[wb:we])
+                    if t is None:
+                        continue
+                    if best is None or t[4] > best[0][4] or (t[4] == best[0][4] and t[5] < best[0][5]):
+                        best = (t, kind)
+                if best is None:
+                    break
+                t, kind = best
+                ms.append((t, kind, wb, we))
+                if kind == "back":
+                    we = wb + t[2]
+                else:
+                    wb = wb + t[3]
+            if not ms:
+                out.append((0, len(s), False))
+            elif action == "retain":
+                t, kind, b0, e0 = ms[-1]
+                out.append(((0, t[3], True) if kind == "back" else (t[2], len(s), True)))
+            elif action == "crop":
+                t = ms[-1][0]
+                out.append((t[2], t[3], True))
+            elif action is None:
+                out.append((0, len(s), True))
+            else:
+                out.append((wb, we, True))
+        return out
+
+    for times, action in ((1, "trim"), (3, "trim"), (2, "mask"), (3, "lowercase"), (1, "retain"), (1, "crop"), (2, None)):
+        ads = [A.BackAdapter(ad_seqs[0]), A.FrontAdapter(ad_seqs[1])]
+        res = BatchAdapterCutter(ads, times=times, action=action).process_arrays(seqs, offsets)
+        exp = expected_intervals(times, action)
+        got = list(zip(res["beg"].tolist(), res["end"].tolist(), res["matched"].tolist()))
+        assert got == exp, (times, action, [(i, g, e) for i, (g, e) in enumerate(zip(got, exp)) if g != e][:3])
