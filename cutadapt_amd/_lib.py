@@ -27,6 +27,8 @@ EXPORTED_SYMBOLS = [
     "cah_profile_reset", "cah_profile_read", "cah_synth_reads",
     "cah_fastq_scan", "cah_pack_sequences", "cah_fastq_write_trimmed",
     "cah_fasta_scan", "cah_records_write", "cah_info_write",
+    "cah_index_create", "cah_index_destroy", "cah_index_info", "cah_index_get",
+    "cah_index_lookup_batch", "cah_index_lookup_batch_host",
 ]
 
 
@@ -49,6 +51,11 @@ class AdapterDescC(C.Structure):
                 ("indel_cost", C.c_int32), ("min_overlap", C.c_int32), ("kind", C.c_int32),
                 ("kmer_sets", C.POINTER(KmerSetC)), ("n_kmer_sets", C.c_int32),
                 ("kmer_ref_wildcards", C.c_int32), ("kmer_query_wildcards", C.c_int32)]
+
+
+class IndexAdapterC(C.Structure):
+    _fields_ = [("sequence", C.c_char_p), ("length", C.c_int32), ("max_error_rate", C.c_double),
+                ("indels", C.c_int32), ("kmer_sets", C.POINTER(KmerSetC)), ("n_kmer_sets", C.c_int32)]
 
 
 _lib = None
@@ -112,6 +119,13 @@ def lib():
     L.cah_fasta_scan.argtypes = [vp, i64, C.c_int, i64, vp, C.POINTER(i64), C.POINTER(i64)]
     L.cah_records_write.argtypes = [vp, vp, i64, vp, vp, vp, vp, vp, C.c_int, vp, i64, C.POINTER(i64)]
     L.cah_info_write.argtypes = [vp, vp, i64, vp, vp, vp, i64, vp, vp, i64, vp, i64, C.POINTER(i64)]
+    L.cah_index_create.argtypes = [C.POINTER(IndexAdapterC), i32, i32, C.POINTER(vp)]
+    L.cah_index_destroy.argtypes = [vp]
+    L.cah_index_destroy.restype = None
+    L.cah_index_info.argtypes = [vp, C.POINTER(i64), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    L.cah_index_get.argtypes = [vp, C.c_char_p, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    L.cah_index_lookup_batch.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp, vp]
+    L.cah_index_lookup_batch_host.argtypes = [vp, vp, vp, i64, vp, vp, vp]
     for name in EXPORTED_SYMBOLS:
         getattr(L, name)
     _lib = L
@@ -256,3 +270,68 @@ class Plan:
         out = C.c_int32(0)
         check(lib().cah_plan_n_kmer_entries(self._h, adapter, C.byref(out)))
         return out.value
+
+
+class Index:
+    """An immutable adapter index (cah_index): the AdapterIndex dictionary as a hash table."""
+
+    def __init__(self, adapters: Sequence[tuple], prefix: bool):
+        """adapters: (sequence, max_error_rate, indels[, kmer_sets]) per adapter; kmer_sets is the
+        adapter's positions_and_kmers list or None (no prefilter)"""
+        self._h = None
+        n = len(adapters)
+        descs = (IndexAdapterC * max(n, 1))()
+        keep = []
+        for i, spec in enumerate(adapters):
+            seq, rate, indels = spec[:3]
+            kmer_sets = spec[3] if len(spec) > 3 else None
+            b = _ascii(seq)
+            keep.append(b)
+            descs[i].sequence = b
+            descs[i].length = len(b)
+            descs[i].max_error_rate = float(rate)
+            descs[i].indels = int(bool(indels))
+            if kmer_sets is None:
+                descs[i].kmer_sets = None
+                descs[i].n_kmer_sets = -1
+            else:
+                sets = (KmerSetC * max(len(kmer_sets), 1))()
+                for j, (start, stop, kmers) in enumerate(kmer_sets):
+                    enc = [_ascii(k, "Kmer") for k in kmers]
+                    arr = (C.c_char_p * max(len(enc), 1))(*enc)
+                    keep.extend([enc, arr])
+                    sets[j].start = start
+                    sets[j].stop = 0 if stop is None else int(stop)
+                    sets[j].kmers = arr
+                    sets[j].n_kmers = len(enc)
+                keep.append(sets)
+                descs[i].kmer_sets = sets
+                descs[i].n_kmer_sets = len(kmer_sets)
+        h = C.c_void_p()
+        check(lib().cah_index_create(descs, n, int(bool(prefix)), C.byref(h)))
+        self._h = h
+        n_strings, n_amb, n_len = C.c_int64(0), C.c_int32(0), C.c_int32(0)
+        lengths = (C.c_int32 * 64)()
+        check(lib().cah_index_info(h, C.byref(n_strings), C.byref(n_amb), lengths, C.byref(n_len)))
+        self.n_strings = n_strings.value
+        self.n_ambiguous = n_amb.value
+        self.lengths = [int(lengths[i]) for i in range(n_len.value)]
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None:
+            _lib.cah_index_destroy(h)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def get(self, s: str):
+        """-> (adapter index, errors, matches) or None: the dictionary entry of one string"""
+        try:
+            b = s.encode("ascii")
+        except UnicodeEncodeError:
+            return None
+        found, ad, e, m = C.c_int32(0), C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        check(lib().cah_index_get(self._h, b, len(b), C.byref(found), C.byref(ad), C.byref(e), C.byref(m)))
+        return (ad.value, e.value, m.value) if found.value else None

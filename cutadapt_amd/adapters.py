@@ -793,6 +793,130 @@ class LinkedAdapter(Adapter):
 
 
 # -------------------------------------------------------------------------------------------------
+# index of anchored adapters (reference adapters.py:1289-1567)
+# -------------------------------------------------------------------------------------------------
+class AdapterIndex:
+    """Index of multiple anchored adapters of one kind (reference adapters.py:1289-1551).
+
+    The dictionary {string within k errors of an adapter: (adapter, errors, matches)} is built and
+    held by the library (``cah_index_create``; hash table in HBM), reads are matched with one lookup
+    kernel (``cah_index_lookup_batch``).  Restrictions as in the reference (:1296-1299): at most 3
+    errors, no wildcards in adapters or reads; this build additionally wants plain ACGT adapters
+    of at most 60 characters (``is_acceptable`` says so)."""
+
+    def __init__(self, adapters, prefix: bool):
+        if not adapters:
+            raise ValueError("Adapter list is empty")
+        for adapter in adapters:
+            self._accept(adapter, prefix)
+        self._adapters = list(adapters)
+        self._prefix = bool(prefix)
+        self._h = _lib.Index(
+            [(a.sequence, a.max_error_rate, a.indels,
+              a.kmer_finder.positions_and_kmers if isinstance(a.kmer_finder, KmerFinder) else None)
+             for a in self._adapters], prefix)
+        self._lengths = list(self._h.lengths)
+        self._ambiguous = self._h.n_ambiguous
+
+    def __repr__(self):
+        return f"{self.__class__.__name__}(adapters={self._adapters!r})"
+
+    def __len__(self):
+        return self._h.n_strings
+
+    @classmethod
+    def _accept(cls, adapter, prefix: bool):
+        """Raise a ValueError if the adapter is not acceptable (reference :1373-1386)"""
+        if prefix and not isinstance(adapter, PrefixAdapter):
+            raise ValueError("Only 5' anchored adapters are allowed")
+        elif not prefix and not isinstance(adapter, SuffixAdapter):
+            raise ValueError("Only 3' anchored adapters are allowed")
+        if adapter.read_wildcards:
+            raise ValueError("Wildcards in the read not supported")
+        if adapter.adapter_wildcards:
+            raise ValueError("Wildcards in the adapter not supported")
+        k = int(len(adapter) * adapter.max_error_rate)
+        if k > 3:
+            raise ValueError("Error rate too high")
+        if not set(adapter.sequence) <= set("ACGT") or len(adapter.sequence) > 60:
+            raise ValueError("Only A, C, G, T adapters of up to 60 characters can be indexed by this build")
+
+    @classmethod
+    def is_acceptable(cls, adapter, prefix: bool) -> bool:
+        try:
+            cls._accept(adapter, prefix)
+        except ValueError:
+            return False
+        return True
+
+    def lookup(self, string: str):
+        """The dictionary entry of one string: (adapter, errors, matches) or None."""
+        r = self._h.get(string)
+        return None if r is None else (self._adapters[r[0]], r[1], r[2])
+
+    def match_to_batch(self, batch) -> BatchMatches:
+        import torch
+        n = batch.n_reads
+        dev = batch.device
+        out6 = torch.zeros((n, 6), dtype=torch.int32, device=dev)
+        status = torch.zeros(n, dtype=torch.uint8, device=dev)
+        best = torch.zeros(n, dtype=torch.int32, device=dev)
+        if n:
+            with torch.cuda.device(dev):
+                _lib.check(_lib.lib().cah_index_lookup_batch(
+                    self._h.handle, batch.seqs.data_ptr(), batch.offsets.data_ptr(), batch._lens_ptr(), n,
+                    out6.data_ptr(), best.data_ptr(), status.data_ptr(),
+                    torch.cuda.current_stream(dev).cuda_stream))
+        status = status.cpu().numpy()
+        _raise_if_invalid(status)
+        found = status == _lib.MATCH
+        coords = out6.cpu().numpy().astype(np.int64)
+        best = np.where(found, best.cpu().numpy(), 0).astype(np.int32)
+        return BatchMatches(coords, found, best, self._adapters, np.full(n, self._prefix, dtype=bool), reads=batch)
+
+    def match_to(self, sequence: str):
+        """Best match over all indexed adapters or None (reference :1468-1530)"""
+        seqs = np.frombuffer(_lib._ascii(sequence), dtype=np.uint8)
+        offsets = np.array([0, len(seqs)], dtype=np.int64)
+        out6 = np.zeros(6, dtype=np.int32)
+        best = np.zeros(1, dtype=np.int32)
+        status = np.zeros(1, dtype=np.uint8)
+        _lib.check(_lib.lib().cah_index_lookup_batch_host(
+            self._h.handle, seqs.ctypes.data if len(seqs) else None, offsets.ctypes.data, 1,
+            out6.ctypes.data, best.ctypes.data, status.ctypes.data))
+        if status[0] != _lib.MATCH:
+            return None
+        cls = RemoveBeforeMatch if self._prefix else RemoveAfterMatch
+        return cls(*(int(v) for v in out6), adapter=self._adapters[int(best[0])], sequence=sequence)
+
+
+class IndexedPrefixAdapters(Matchable):
+    def __init__(self, adapters):
+        super().__init__(name="indexed_prefix_adapters")
+        self._index = AdapterIndex(adapters, prefix=True)
+        self._adapters = self._index._adapters
+
+    def match_to(self, sequence: str):
+        return self._index.match_to(sequence)
+
+    def match_to_batch(self, batch) -> BatchMatches:
+        return self._index.match_to_batch(batch)
+
+
+class IndexedSuffixAdapters(Matchable):
+    def __init__(self, adapters):
+        super().__init__(name="indexed_suffix_adapters")
+        self._index = AdapterIndex(adapters, prefix=False)
+        self._adapters = self._index._adapters
+
+    def match_to(self, sequence: str):
+        return self._index.match_to(sequence)
+
+    def match_to_batch(self, batch) -> BatchMatches:
+        return self._index.match_to_batch(batch)
+
+
+# -------------------------------------------------------------------------------------------------
 # several adapters (reference adapters.py:1246-1286)
 # -------------------------------------------------------------------------------------------------
 class MultipleAdapters(Matchable):

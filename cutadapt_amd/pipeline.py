@@ -23,9 +23,10 @@ from typing import BinaryIO, Dict, Iterator, List, Optional, Sequence, Tuple, Un
 import numpy as np
 
 from . import _lib
-from .adapters import (BatchMatches, LinkedAdapter, LinkedBatchMatches, MultipleAdapters, SingleAdapter,
-                       AnywhereAdapter, BackAdapter, FrontAdapter, NonInternalBackAdapter,
-                       NonInternalFrontAdapter, PrefixAdapter, SuffixAdapter)
+from .adapters import (AdapterIndex, BatchMatches, IndexedPrefixAdapters, IndexedSuffixAdapters, LinkedAdapter,
+                       LinkedBatchMatches, MultipleAdapters, SingleAdapter, AnywhereAdapter, BackAdapter,
+                       FrontAdapter, NonInternalBackAdapter, NonInternalFrontAdapter, PrefixAdapter,
+                       SuffixAdapter)
 from .sharding import MatchHistogram
 
 DEFAULT_CHUNK_BYTES = 4 * 1024 * 1024     # reference runners.py:306 buffer_size
@@ -213,12 +214,15 @@ def _rows_for(idx: np.ndarray, errors, rstart, rstop, rel_wbeg, rel_wend, name_i
 
 
 class BatchAdapterCutter:
-    """``AdapterCutter(adapters, times, action, index=False)`` over whole chunks (reference
-    modifiers.py:82-261).  In every round the best match of all adapters is taken per read
+    """``AdapterCutter(adapters, times, action, index)`` over whole chunks (reference
+    modifiers.py:82-261).  With ``index=True`` (the reference default) two or more indexable
+    anchored 5' (3') adapters are regrouped behind one ``IndexedPrefixAdapters``
+    (``IndexedSuffixAdapters``) exactly as :124-141 does, which also moves them behind the
+    remaining adapters.  In every round the best match of all adapters is taken per read
     (``MultipleAdapters``), the read shrinks to the remainder and only reads that matched go into
     the next round.  Results are intervals on the original read + info rows + statistics."""
 
-    def __init__(self, adapters, times: int = 1, action: Optional[str] = "trim", device=None):
+    def __init__(self, adapters, times: int = 1, action: Optional[str] = "trim", index: bool = True, device=None):
         if isinstance(adapters, MultipleAdapters):
             adapters = list(adapters._adapters)
         elif isinstance(adapters, (SingleAdapter, LinkedAdapter)):
@@ -229,8 +233,19 @@ class BatchAdapterCutter:
             raise ValueError(f"unknown action {action!r}")
         if action in ("retain", "crop") and times > 1:
             raise ValueError("'retain' and 'crop' cannot be combined with times > 1")
+        groups: List[Tuple[str, list]] = [("plain", adapters)]
+        if index:                                           # _regroup_into_indexed_adapters (:124-141)
+            prefix = [a for a in adapters if isinstance(a, SingleAdapter) and AdapterIndex.is_acceptable(a, True)]
+            suffix = [a for a in adapters if isinstance(a, SingleAdapter) and a not in prefix
+                      and AdapterIndex.is_acceptable(a, False)]
+            if len(prefix) > 1 or len(suffix) > 1:
+                single = [a for a in adapters if a not in prefix and a not in suffix]
+                groups = [("plain", single)]
+                groups.append(("prefix", prefix) if len(prefix) > 1 else ("plain", prefix))
+                groups.append(("suffix", suffix) if len(suffix) > 1 else ("plain", suffix))
+                adapters = single + prefix + suffix
         self.all_adapters = adapters
-        self.adapters = MultipleAdapters(adapters)          # the reference attribute
+        self.adapters = MultipleAdapters(adapters)          # the reference attribute (un-indexed view)
         self.times = int(times)
         self.action = action
         self.device = device
@@ -238,17 +253,27 @@ class BatchAdapterCutter:
         # (linked adapters, rightmost adapters) is matched on its own.  Unit order = adapter order,
         # so "first adapter wins ties" is preserved.
         self._units: List[Tuple[str, object, List[int]]] = []
-        run: List[int] = []
-        for i, a in enumerate(adapters):
-            if isinstance(a, SingleAdapter) and not a._reverse_reads:
-                run.append(i)
+        pos = 0
+        for gkind, members in groups:
+            ids = list(range(pos, pos + len(members)))
+            pos += len(members)
+            if gkind == "prefix":
+                self._units.append(("fused", IndexedPrefixAdapters(members), ids))
                 continue
+            if gkind == "suffix":
+                self._units.append(("fused", IndexedSuffixAdapters(members), ids))
+                continue
+            run: List[int] = []
+            for i, a in zip(ids, members):
+                if isinstance(a, SingleAdapter) and not a._reverse_reads:
+                    run.append(i)
+                    continue
+                if run:
+                    self._units.append(("fused", MultipleAdapters([adapters[j] for j in run]), run))
+                    run = []
+                self._units.append(("linked" if isinstance(a, LinkedAdapter) else "single", a, [i]))
             if run:
                 self._units.append(("fused", MultipleAdapters([adapters[j] for j in run]), run))
-                run = []
-            self._units.append(("linked" if isinstance(a, LinkedAdapter) else "single", a, [i]))
-        if run:
-            self._units.append(("fused", MultipleAdapters([adapters[j] for j in run]), run))
         # info-file names and statistics slots: one slot per single adapter, two per linked one
         self.names: List[str] = []
         self._slot: Dict[Tuple[int, int], int] = {}
@@ -429,11 +454,11 @@ class BatchAdapterCutter:
 def trim_fastq(inpath: Union[str, BinaryIO], outpath: Union[str, BinaryIO], adapters, times: int = 1,
                action: Optional[str] = "trim", discard_untrimmed: bool = False, discard_trimmed: bool = False,
                info_file: Union[None, str, BinaryIO] = None, chunk_bytes: int = DEFAULT_CHUNK_BYTES,
-               device=None) -> Dict[str, object]:
+               index: bool = True, device=None) -> Dict[str, object]:
     """``cutadapt <adapter options> [--times N] [--action A] [--discard-(un)trimmed]
     [--info-file F] -o outpath inpath`` for the supported slice; returns the read/basepair
     counters the reference reports (reference report.py:62-80) and the cutter (statistics)."""
-    cutter = BatchAdapterCutter(adapters, times=times, action=action, device=device)
+    cutter = BatchAdapterCutter(adapters, times=times, action=action, index=index, device=device)
     out = outpath if hasattr(outpath, "write") else open(outpath, "wb")
     inf = None if info_file is None else (info_file if hasattr(info_file, "write") else open(info_file, "wb"))
     try:

@@ -236,6 +236,48 @@ int cah_info_write(const uint8_t *buf, const int64_t *rec, int64_t n_records, co
                    const int64_t *name_off, int64_t n_names, uint8_t *out, int64_t out_cap,
                    int64_t *out_len);
 
+/* ---- AdapterIndex (adapters.py:1289-1551) on the GPU ---------- */
+/* Many anchored adapters of one kind (all 5' "^ADAPTER" or all 3' "ADAPTER$", no wildcards, at most
+ * 3 errors) are matched with one dictionary lookup per read: every string within k errors of any
+ * adapter (_align.pyx:784-882 edit_environment with indels, :717-781 hamming_sphere without) maps to
+ * (adapter, errors, matches); collisions keep the entry with more matches, equal matches make the
+ * string ambiguous and remove it (adapters.py:1425-1464).  cah_index_create builds that dictionary
+ * on the host and stores it as a hash table of 2-bit packed strings; cah_index_lookup_batch probes
+ * it with one GPU lane per read (multi-length rule :1487-1530, 'N' re-alignment :1532-1551) and
+ * writes the same outputs as cah_match_batch: out6 = (0, len(adapter), rstart, rstop, matches,
+ * errors), best_adapter (index into the adapter list, -1 = none), status.
+ * Limits of this build: adapters of 1..60 upper-case A/C/G/T characters (CAH_EUNSUPPORTED otherwise;
+ * the reference also accepts other characters, which can never match a read there).
+ * Errors: CAH_EINVAL "Adapter list is empty" / "Error rate too high" (adapters.py:1309, :1385). */
+typedef struct cah_index cah_index;
+typedef struct cah_index_adapter {
+    const char *sequence;       /* upper-case, as SingleAdapter stores it */
+    int32_t length;
+    double max_error_rate;
+    int32_t indels;             /* 0: Hamming distance only (--no-indels) */
+    /* the adapter's own k-mer prefilter (what its match_to() asks first, adapters.py:707-724);
+     * consulted only when a read's affix contains 'N' and the adapter has to be re-aligned
+     * (:1543-1551).  n_kmer_sets < 0: no prefilter (MockKmerFinder, e.g. --no-indels). */
+    const cah_kmer_set *kmer_sets;
+    int32_t n_kmer_sets;
+} cah_index_adapter;
+int cah_index_create(const cah_index_adapter *adapters, int32_t n_adapters, int32_t prefix,
+                     cah_index **out);
+void cah_index_destroy(cah_index *index);
+/* number of strings, number of ambiguous strings dropped, indexed string lengths (longest first;
+ * lengths must have room for 64 entries) */
+int cah_index_info(const cah_index *index, int64_t *n_strings, int32_t *n_ambiguous,
+                   int32_t *lengths, int32_t *n_lengths);
+/* host-side dictionary query of one string (introspection / tests) */
+int cah_index_get(const cah_index *index, const char *s, int32_t len, int32_t *found,
+                  int32_t *adapter, int32_t *errors, int32_t *matches);
+int cah_index_lookup_batch(const cah_index *index, const uint8_t *d_seqs, const int64_t *d_offsets,
+                           const int32_t *d_lens, int64_t n_reads, int32_t *d_out6,
+                           int32_t *d_best_adapter, uint8_t *d_status, void *stream);
+int cah_index_lookup_batch_host(const cah_index *index, const uint8_t *seqs, const int64_t *offsets,
+                                int64_t n_reads, int32_t *out6, int32_t *best_adapter,
+                                uint8_t *status);
+
 #ifdef __cplusplus
 }
 #endif
