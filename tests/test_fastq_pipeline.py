@@ -183,6 +183,14 @@ def test_pipeline_rounds_against_reference_adapter_cutter_semantics(hip, orc):
     chunk = list(read_fastq_chunks(io.BytesIO(fq)))[0]
     seqs, offsets = chunk.pack_sequences()
 
+    from cutadapt_amd.kmer_heuristic import create_positions_and_kmers
+    # match_to() = k-mer prefilter, then locate (reference adapters.py:707-724, :815-832); the
+    # prefilter is part of the semantics (it is not lossless for every adapter kind)
+    finders = {
+        "back": orc.KmerFinder(create_positions_and_kmers(ad_seqs[0], 3, 0.1, True, False), False, False),
+        "front": orc.KmerFinder(create_positions_and_kmers(ad_seqs[1], 3, 0.1, False, True), False, False),
+    }
+
     def expected_intervals(times, action):
         out = []
         for s in reads:
@@ -191,8 +199,9 @@ def test_pipeline_rounds_against_reference_adapter_cutter_semantics(hip, orc):
                 best = None
                 for seq, kind in ((ad_seqs[0], "back"), (ad_seqs[1], "front")):
                     flags = 14 if kind == "back" else 11
-                    # the oracle's match_to: k-mer prefilter is lossless, so locate alone decides
-                    t = orc.Aligner(seq, 0.1, flags=flags, wildcard_ref=True, min_overlap=3).locate(s[wb:we])
+                    if not finders[kind].kmers_present(s[wb:we]):
+                        continue
+                    t = orc.Aligner(seq, 0.1, flags=flags, wildcard_ref=False, min_overlap=3).locate(s[wb:we])
                     if t is None:
                         continue
                     if best is None or t[4] > best[0][4] or (t[4] == best[0][4] and t[5] < best[0][5]):
