@@ -29,6 +29,7 @@ EXPORTED_SYMBOLS = [
     "cah_fasta_scan", "cah_records_write", "cah_info_write",
     "cah_index_create", "cah_index_destroy", "cah_index_info", "cah_index_get",
     "cah_index_lookup_batch", "cah_index_lookup_batch_host",
+    "cah_quality_trim_batch", "cah_nextseq_trim_batch", "cah_poly_a_trim_batch", "cah_expected_errors_batch",
 ]
 
 
@@ -126,6 +127,10 @@ def lib():
     L.cah_index_get.argtypes = [vp, C.c_char_p, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.cah_index_lookup_batch.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp, vp]
     L.cah_index_lookup_batch_host.argtypes = [vp, vp, vp, i64, vp, vp, vp]
+    L.cah_quality_trim_batch.argtypes = [vp, vp, vp, i64, i32, i32, i32, vp, vp]
+    L.cah_nextseq_trim_batch.argtypes = [vp, vp, vp, vp, i64, i32, i32, vp, vp]
+    L.cah_poly_a_trim_batch.argtypes = [vp, vp, vp, i64, i32, vp, vp]
+    L.cah_expected_errors_batch.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp]
     for name in EXPORTED_SYMBOLS:
         getattr(L, name)
     _lib = L

@@ -1,0 +1,223 @@
+// qualtrim.hip -- quality / NextSeq / poly-A trimming positions and expected errors for a batch
+// (the O(n) per-read scans that run just before adapter matching,
+// reference src/cutadapt/qualtrim.pyx:22-190, expected_errors.h:103-140, applied by
+// modifiers.py:825-879).  One read per lane; the scans stop early exactly where the reference's
+// loops break, so a lane usually touches only the first / last few characters.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cmath>
+#include <cstdio>
+
+#include "../../include/cutadapt_hip.h"
+
+extern int cah_set_error_(int code, const char* msg);   // api.cpp
+
+#define QT_TRY(expr)                                                                   \
+    do {                                                                               \
+        hipError_t e__ = (expr);                                                       \
+        if (e__ != hipSuccess) {                                                       \
+            char b__[256];                                                             \
+            snprintf(b__, sizeof(b__), "%s failed: %s", #expr, hipGetErrorString(e__)); \
+            return cah_set_error_(CAH_EHIP, b__);                                      \
+        }                                                                              \
+    } while (0)
+
+namespace {
+
+__device__ __forceinline__ void qt_extent(const int64_t* offsets, const int32_t* lens, int64_t r, int64_t& off, int& n) {
+    off = offsets[r];
+    const int64_t n64 = lens ? (int64_t)lens[r] : offsets[r + 1] - off;
+    n = (int)(n64 > 0x7FFFFFFF ? 0x7FFFFFFF : n64);
+}
+
+// quality_trim_index (qualtrim.pyx:22-70): BWA-style partial sums from both ends; the quality
+// bytes are read as C `char` (signed), like the reference does.
+__global__ __launch_bounds__(256) void k_quality_trim(const uint8_t* quals, const int64_t* offsets, const int32_t* lens,
+                                                      int64_t n_reads, int cutoff_front, int cutoff_back, int base,
+                                                      int32_t* start_stop) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    int64_t off; int n;
+    qt_extent(offsets, lens, r, off, n);
+    const signed char* q = reinterpret_cast<const signed char*>(quals + off);
+    int start = 0, stop = n;
+    int s = 0, max_qual = 0;
+    for (int i = 0; i < n; i++) {                                    // :50-57
+        s += cutoff_front - ((int)q[i] - base);
+        if (s < 0) break;
+        if (s > max_qual) { max_qual = s; start = i + 1; }
+    }
+    max_qual = 0; s = 0;
+    for (int i = n - 1; i >= 0; i--) {                               // :60-67
+        s += cutoff_back - ((int)q[i] - base);
+        if (s < 0) break;
+        if (s > max_qual) { max_qual = s; stop = i; }
+    }
+    if (start >= stop) { start = 0; stop = 0; }                      // :68-69
+    start_stop[2 * r] = start;
+    start_stop[2 * r + 1] = stop;
+}
+
+// nextseq_trim_index (qualtrim.pyx:73-113): as above from the 3' end, 'G' counts as cutoff - 1
+__global__ __launch_bounds__(256) void k_nextseq_trim(const uint8_t* seqs, const uint8_t* quals, const int64_t* offsets,
+                                                      const int32_t* lens, int64_t n_reads, int cutoff, int base,
+                                                      int32_t* stop_out) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    int64_t off; int n;
+    qt_extent(offsets, lens, r, off, n);
+    const signed char* q = reinterpret_cast<const signed char*>(quals + off);
+    const uint8_t* b = seqs + off;
+    int s = 0, max_qual = 0, max_i = n;
+    for (int i = n - 1; i >= 0; i--) {
+        int qv = (int)q[i] - base;
+        if (b[i] == 'G') qv = cutoff - 1;
+        s += cutoff - qv;
+        if (s < 0) break;
+        if (s > max_qual) { max_qual = s; max_i = i; }
+    }
+    stop_out[r] = max_i;
+}
+
+// poly_a_trim_index (qualtrim.pyx:116-165): +1 per A (T with revcomp), -2 otherwise, error rate <= 0.2,
+// tails shorter than 3 ignored.  No early exit in the reference: the whole read is scanned.
+__global__ __launch_bounds__(256) void k_poly_a_trim(const uint8_t* seqs, const int64_t* offsets, const int32_t* lens,
+                                                     int64_t n_reads, int revcomp, int32_t* index_out) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    int64_t off; int n;
+    qt_extent(offsets, lens, r, off, n);
+    const uint8_t* b = seqs + off;
+    int best_score = 0, score = 0, errors = 0, best_index;
+    if (revcomp) {
+        best_index = 0;
+        for (int i = 0; i < n; i++) {
+            if (b[i] == 'T') score += 1; else { score -= 2; errors += 1; }
+            if (score > best_score && errors * 5 <= i + 1) { best_score = score; best_index = i + 1; }
+        }
+        if (best_index < 3) best_index = 0;
+    } else {
+        best_index = n;
+        for (int i = n - 1; i >= 0; i--) {
+            if (b[i] == 'A') score += 1; else { score -= 2; errors += 1; }
+            if (score > best_score && errors * 5 <= n - i) { best_score = score; best_index = i; }
+        }
+        if (best_index > n - 3) best_index = n;
+    }
+    index_out[r] = best_index;
+}
+
+// expected_errors (qualtrim.pyx:168-190, expected_errors.h:103-140): sum of 10^(-q/10) with the
+// reference's FOUR interleaved double accumulators and its final e0+e1+e2+e3, so the double result
+// is bit-identical.  An invalid phred value (byte < base or > 126) gives status CAH_INVALID.
+__global__ __launch_bounds__(256) void k_expected_errors(const uint8_t* quals, const int64_t* offsets, const int32_t* lens,
+                                                         int64_t n_reads, int base, const double* table, double* out,
+                                                         uint8_t* status) {
+    __shared__ double s_tab[94];
+    if (threadIdx.x < 94) s_tab[threadIdx.x] = table[threadIdx.x];
+    __syncthreads();
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    int64_t off; int n;
+    qt_extent(offsets, lens, r, off, n);
+    const uint8_t* q = quals + off;
+    const uint8_t ubase = (uint8_t)base;
+    const uint8_t max_phred = (uint8_t)(126 - ubase);
+    double e0 = 0.0, e1 = 0.0, e2 = 0.0, e3 = 0.0;
+    bool bad = false;
+    int i = 0;
+    for (; i + 3 < n; i += 4) {
+        const uint8_t p0 = (uint8_t)(q[i] - ubase), p1 = (uint8_t)(q[i + 1] - ubase);
+        const uint8_t p2 = (uint8_t)(q[i + 2] - ubase), p3 = (uint8_t)(q[i + 3] - ubase);
+        if (p0 > max_phred || p1 > max_phred || p2 > max_phred || p3 > max_phred) { bad = true; break; }
+        e0 += s_tab[p0]; e1 += s_tab[p1]; e2 += s_tab[p2]; e3 += s_tab[p3];
+    }
+    if (!bad) {
+        for (; i < n; i++) {
+            const uint8_t p = (uint8_t)(q[i] - ubase);
+            if (p > max_phred) { bad = true; break; }
+            e0 += s_tab[p];
+        }
+    }
+    out[r] = bad ? -1.0 : e0 + e1 + e2 + e3;
+    if (status) status[r] = bad ? CAH_INVALID : CAH_MATCH;
+}
+
+// SCORE_TO_ERROR_RATE of expected_errors.h:6-101 is 10^(-q/10) in double; one copy per device
+struct ErrTable {
+    double* d[64] = {nullptr};
+};
+ErrTable g_tab;
+
+int error_table_on_device(const double** out) {
+    int device = 0;
+    QT_TRY(hipGetDevice(&device));
+    if (device < 0 || device >= 64) return cah_set_error_(CAH_EUNSUPPORTED, "device index too large");
+    if (!g_tab.d[device]) {
+        double h[94];
+        for (int q = 0; q < 94; q++) h[q] = std::pow(10.0, -(double)q / 10.0);
+        double* p = nullptr;
+        QT_TRY(hipMalloc((void**)&p, sizeof(h)));
+        QT_TRY(hipMemcpy(p, h, sizeof(h), hipMemcpyHostToDevice));
+        g_tab.d[device] = p;
+    }
+    *out = g_tab.d[device];
+    return CAH_OK;
+}
+
+inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256); }
+
+}  // namespace
+
+extern "C" {
+
+int cah_quality_trim_batch(const uint8_t* d_quals, const int64_t* d_offsets, const int32_t* d_lens, int64_t n_reads,
+                           int32_t cutoff_front, int32_t cutoff_back, int32_t base, int32_t* d_start_stop, void* stream) {
+    if (n_reads < 0) return cah_set_error_(CAH_EINVAL, "n_reads < 0");
+    if (n_reads == 0) return CAH_OK;
+    if (!d_offsets || !d_start_stop) return cah_set_error_(CAH_EINVAL, "cah_quality_trim_batch: NULL argument");
+    hipLaunchKernelGGL(k_quality_trim, dim3(blocks_for(n_reads)), dim3(256), 0, (hipStream_t)stream, d_quals, d_offsets,
+                       d_lens, n_reads, cutoff_front, cutoff_back, base, d_start_stop);
+    QT_TRY(hipGetLastError());
+    return CAH_OK;
+}
+
+int cah_nextseq_trim_batch(const uint8_t* d_seqs, const uint8_t* d_quals, const int64_t* d_offsets, const int32_t* d_lens,
+                           int64_t n_reads, int32_t cutoff, int32_t base, int32_t* d_stop, void* stream) {
+    if (n_reads < 0) return cah_set_error_(CAH_EINVAL, "n_reads < 0");
+    if (n_reads == 0) return CAH_OK;
+    if (!d_offsets || !d_stop) return cah_set_error_(CAH_EINVAL, "cah_nextseq_trim_batch: NULL argument");
+    hipLaunchKernelGGL(k_nextseq_trim, dim3(blocks_for(n_reads)), dim3(256), 0, (hipStream_t)stream, d_seqs, d_quals,
+                       d_offsets, d_lens, n_reads, cutoff, base, d_stop);
+    QT_TRY(hipGetLastError());
+    return CAH_OK;
+}
+
+int cah_poly_a_trim_batch(const uint8_t* d_seqs, const int64_t* d_offsets, const int32_t* d_lens, int64_t n_reads,
+                          int32_t revcomp, int32_t* d_index, void* stream) {
+    if (n_reads < 0) return cah_set_error_(CAH_EINVAL, "n_reads < 0");
+    if (n_reads == 0) return CAH_OK;
+    if (!d_offsets || !d_index) return cah_set_error_(CAH_EINVAL, "cah_poly_a_trim_batch: NULL argument");
+    hipLaunchKernelGGL(k_poly_a_trim, dim3(blocks_for(n_reads)), dim3(256), 0, (hipStream_t)stream, d_seqs, d_offsets,
+                       d_lens, n_reads, revcomp, d_index);
+    QT_TRY(hipGetLastError());
+    return CAH_OK;
+}
+
+int cah_expected_errors_batch(const uint8_t* d_quals, const int64_t* d_offsets, const int32_t* d_lens, int64_t n_reads,
+                              int32_t base, double* d_expected, uint8_t* d_status, void* stream) {
+    if (n_reads < 0) return cah_set_error_(CAH_EINVAL, "n_reads < 0");
+    if (base < 0 || base > 126) return cah_set_error_(CAH_EINVAL, "quality base out of range");
+    if (n_reads == 0) return CAH_OK;
+    if (!d_offsets || !d_expected) return cah_set_error_(CAH_EINVAL, "cah_expected_errors_batch: NULL argument");
+    const double* tab = nullptr;
+    int rc = error_table_on_device(&tab);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_expected_errors, dim3(blocks_for(n_reads)), dim3(256), 0, (hipStream_t)stream, d_quals, d_offsets,
+                       d_lens, n_reads, base, tab, d_expected, d_status);
+    QT_TRY(hipGetLastError());
+    return CAH_OK;
+}
+
+}  // extern "C"

@@ -69,6 +69,17 @@ class FastqChunk:
             self._packed = (seqs[:int(offsets[-1])], offsets)
         return self._packed
 
+    def pack_qualities(self) -> Optional[np.ndarray]:
+        """quality lines packed with the same offsets as the sequences; None for FASTA"""
+        n = len(self.rec)
+        if n == 0 or self.rec[0, 4] < 0:
+            return None
+        seqs, offsets = self.pack_sequences()
+        out = np.empty(len(seqs), dtype=np.uint8)
+        idx = np.repeat(self.rec[:, 4] - offsets[:-1], offsets[1:] - offsets[:-1]) + np.arange(len(seqs))
+        np.take(self.buf, idx, out=out)
+        return out
+
     def write_trimmed(self, keep_beg: np.ndarray, keep_end: np.ndarray, keep: Optional[np.ndarray] = None) -> bytes:
         """FASTQ only, straight from the raw chunk (the times=1 / action='trim' fast path)."""
         n = len(self.rec)
@@ -356,27 +367,33 @@ class BatchAdapterCutter:
         return best
 
     # ---- all rounds of a chunk --------------------------------------------------------------
-    def process_arrays(self, seqs: np.ndarray, offsets: np.ndarray):
+    def process_arrays(self, seqs: np.ndarray, offsets: np.ndarray, base=None, window=None):
         """-> dict(beg, end, matched, rows): the interval of every read the chosen action keeps
         or marks (relative to the original read), whether any adapter was found, and the info
-        rows int64[k,7] = (read, errors, rstart, rstop, wbeg, wend, name_id)."""
+        rows int64[k,7] = (read, errors, rstart, rstop, wbeg, wend, name_id).
+        ``base``: the chunk already in HBM (ReadBatch); ``window`` = (beg, end) arrays: the part of
+        every read earlier modifiers (quality trimming ...) left, which is what gets searched."""
         import torch
         from .batch import ReadBatch
         n = len(offsets) - 1
         lens = (offsets[1:] - offsets[:-1]).astype(np.int64)
-        wbeg = np.zeros(n, dtype=np.int64)
-        wend = lens.copy()
+        if window is None:
+            wbeg, wend = np.zeros(n, dtype=np.int64), lens.copy()
+        else:
+            wbeg, wend = np.asarray(window[0], dtype=np.int64).copy(), np.asarray(window[1], dtype=np.int64).copy()
+        w0beg, w0end = wbeg.copy(), wend.copy()
         matched = np.zeros(n, dtype=bool)
-        last_ret = (np.zeros(n, np.int64), lens.copy())
-        last_crop = (np.zeros(n, np.int64), lens.copy())
+        last_ret = (w0beg.copy(), w0end.copy())
+        last_crop = (w0beg.copy(), w0end.copy())
         all_rows = []
         if n:
-            base = ReadBatch.from_host(seqs, offsets, device=self.device)
+            if base is None:
+                base = ReadBatch.from_host(seqs, offsets, device=self.device)
             base.validate_ascii()
             dev_off = base.offsets[:n]
             active = np.arange(n)
             for rnd in range(self.times):
-                if rnd == 0:
+                if rnd == 0 and window is None:
                     batch, cur_len = base, lens
                 else:
                     ia = torch.from_numpy(active).to(base.device)
@@ -417,7 +434,7 @@ class BatchAdapterCutter:
         elif self.action == "crop":
             beg, end = last_crop
         elif self.action is None:
-            beg, end = np.zeros(n, np.int64), lens.copy()
+            beg, end = w0beg, w0end
         else:                                                # trim, mask, lowercase: the remainder
             beg, end = wbeg, wend
         rows = np.concatenate(all_rows) if all_rows else np.zeros((0, 8), dtype=np.int64)
@@ -451,20 +468,133 @@ class BatchAdapterCutter:
         return chunk.write_records(res["beg"], res["end"], keep, mode)
 
 
-def trim_fastq(inpath: Union[str, BinaryIO], outpath: Union[str, BinaryIO], adapters, times: int = 1,
+class BatchTrimmer:
+    """The read-modifying part of a single-end pipeline in the reference's order (cli.py:938-987):
+    NextSeq trimming, quality trimming, adapter cutting, poly-A trimming -- all on windows
+    (offset, length) into ONE copy of the chunk in HBM.  Statistics as the reference keeps them
+    (``trimmed_bases`` of modifiers.py:829/845, PolyATrimmer's length histogram :865)."""
+
+    def __init__(self, adapters=(), times: int = 1, action: Optional[str] = "trim", index: bool = True,
+                 nextseq_trim: Optional[int] = None, quality_cutoff: Optional[Tuple[int, int]] = None,
+                 quality_base: int = 33, poly_a: bool = False, max_expected_errors: Optional[float] = None,
+                 device=None):
+        adapters = list(adapters._adapters) if isinstance(adapters, MultipleAdapters) else \
+            ([adapters] if isinstance(adapters, (SingleAdapter, LinkedAdapter)) else list(adapters))
+        self.cutter = BatchAdapterCutter(adapters, times=times, action=action, index=index, device=device) if adapters else None
+        self.action = action
+        self.nextseq_trim = nextseq_trim
+        self.quality_cutoff = quality_cutoff
+        self.quality_base = quality_base
+        self.poly_a = poly_a
+        self.max_expected_errors = max_expected_errors
+        self.too_many_expected_errors = 0
+        self.device = device
+        pre = nextseq_trim is not None or quality_cutoff is not None
+        if (pre or poly_a) and action in ("mask", "lowercase"):
+            raise NotImplementedError("mask/lowercase together with quality or poly-A trimming is not built yet")
+        self.nextseq_trimmed_bases = 0
+        self.quality_trimmed_bases = 0
+        self.poly_a_trimmed_lengths: Dict[int, int] = {}
+        self.reads = 0
+        self.bp_in = 0
+        self.bp_out = 0
+
+    def process_chunk(self, chunk: FastqChunk, discard_untrimmed: bool = False, discard_trimmed: bool = False,
+                      info: Optional[list] = None) -> bytes:
+        import torch
+        from . import qualtrim as qt
+        from .batch import ReadBatch
+        seqs, offsets = chunk.pack_sequences()
+        n = len(offsets) - 1
+        lens = (offsets[1:] - offsets[:-1]).astype(np.int64)
+        wbeg, wend = np.zeros(n, dtype=np.int64), lens.copy()
+        pre = self.nextseq_trim is not None or self.quality_cutoff is not None
+        if info is not None and (pre or self.poly_a):
+            raise NotImplementedError("--info-file together with quality or poly-A trimming is not built yet")
+        base = ReadBatch.from_host(seqs, offsets, device=self.device) if n else None
+        quals = None
+        if pre and n:
+            q = chunk.pack_qualities()
+            if q is None:
+                raise qt.HasNoQualities("Cannot do quality trimming when no qualities are available")
+            quals = torch.from_numpy(q).to(base.device)
+
+        def view_args():
+            o = base.offsets[:n] + torch.from_numpy(wbeg).to(base.device)
+            l = torch.from_numpy((wend - wbeg).astype(np.int32)).to(base.device)
+            return o, l
+
+        if self.nextseq_trim is not None and n:
+            o, l = view_args()
+            stop = qt.nextseq_trim_batch(base.seqs, quals, o, l, n, self.nextseq_trim, self.quality_base).astype(np.int64)
+            self.nextseq_trimmed_bases += int(((wend - wbeg) - stop).sum())
+            wend = wbeg + stop
+        if self.quality_cutoff is not None and n:
+            o, l = view_args()
+            ss = qt.quality_trim_batch(quals, o, l, n, self.quality_cutoff[0], self.quality_cutoff[1],
+                                       self.quality_base).astype(np.int64)
+            self.quality_trimmed_bases += int(((wend - wbeg) - (ss[:, 1] - ss[:, 0])).sum())
+            wbeg, wend = wbeg + ss[:, 0], wbeg + ss[:, 1]
+        matched = np.zeros(n, dtype=bool)
+        mode = 0
+        if self.cutter is not None:
+            res = self.cutter.process_arrays(seqs, offsets, base=base, window=(wbeg, wend) if pre else None)
+            wbeg, wend, matched = res["beg"].astype(np.int64), res["end"].astype(np.int64), res["matched"]
+            mode = {"mask": 1, "lowercase": 2}.get(self.action, 0)
+            if info is not None:
+                info.append(chunk.write_info(res["rows"], self.cutter.names))
+        elif info is not None:
+            info.append(chunk.write_info(np.zeros((0, 7), np.int64), []))
+        if self.poly_a and n:
+            o, l = view_args()
+            idx = qt.poly_a_trim_batch(base.seqs, o, l, n, False).astype(np.int64)
+            removed, counts = np.unique((wend - wbeg) - idx, return_counts=True)
+            for k, c in zip(removed.tolist(), counts.tolist()):
+                self.poly_a_trimmed_lengths[k] = self.poly_a_trimmed_lengths.get(k, 0) + c
+            wend = wbeg + idx
+        keep = matched if discard_untrimmed else (~matched if discard_trimmed else None)
+        if self.max_expected_errors is not None and n:
+            # TooManyExpectedErrors (reference predicates.py): the filter sees the read as trimmed so far
+            if quals is None:
+                q = chunk.pack_qualities()
+                if q is None:
+                    raise qt.HasNoQualities("expected errors need qualities")
+                quals = torch.from_numpy(q).to(base.device)
+            o, l = view_args()
+            ee, valid = qt.expected_errors_batch(quals, o, l, n, 33)      # the reference calls expected_errors(q) with its default base
+            if not valid.all():
+                bad = int(np.flatnonzero(~valid)[0])
+                raise ValueError(f"Not a valid phred value in the qualities of read {bad} of the chunk")
+            too_many = ee > self.max_expected_errors
+            passed = ~too_many if keep is None else (keep & ~too_many)
+            self.too_many_expected_errors += int((too_many if keep is None else (too_many & keep)).sum())
+            keep = passed
+        self.reads += n
+        self.bp_in += int(lens.sum())
+        self.bp_out += int((wend - wbeg).sum()) if mode == 0 else int(lens.sum())
+        return chunk.write_records(wbeg.astype(np.int32), wend.astype(np.int32), keep, mode)
+
+
+def trim_fastq(inpath: Union[str, BinaryIO], outpath: Union[str, BinaryIO], adapters=(), times: int = 1,
                action: Optional[str] = "trim", discard_untrimmed: bool = False, discard_trimmed: bool = False,
                info_file: Union[None, str, BinaryIO] = None, chunk_bytes: int = DEFAULT_CHUNK_BYTES,
-               index: bool = True, device=None) -> Dict[str, object]:
-    """``cutadapt <adapter options> [--times N] [--action A] [--discard-(un)trimmed]
-    [--info-file F] -o outpath inpath`` for the supported slice; returns the read/basepair
-    counters the reference reports (reference report.py:62-80) and the cutter (statistics)."""
-    cutter = BatchAdapterCutter(adapters, times=times, action=action, index=index, device=device)
+               index: bool = True, nextseq_trim: Optional[int] = None,
+               quality_cutoff: Optional[Tuple[int, int]] = None, quality_base: int = 33, poly_a: bool = False,
+               max_expected_errors: Optional[float] = None, device=None) -> Dict[str, object]:
+    """``cutadapt [--nextseq-trim N] [-q [FRONT,]BACK] [--quality-base B] <adapter options> [--times N]
+    [--action A] [--poly-a] [--max-ee E] [--discard-(un)trimmed] [--info-file F] -o outpath inpath`` for the
+    supported slice; returns the read/basepair counters the reference reports (reference
+    report.py:62-80), the adapter cutter (statistics) and the trimmer."""
+    trimmer = BatchTrimmer(adapters, times=times, action=action, index=index, nextseq_trim=nextseq_trim,
+                           quality_cutoff=quality_cutoff, quality_base=quality_base, poly_a=poly_a,
+                           max_expected_errors=max_expected_errors, device=device)
+    cutter = trimmer.cutter
     out = outpath if hasattr(outpath, "write") else open(outpath, "wb")
     inf = None if info_file is None else (info_file if hasattr(info_file, "write") else open(info_file, "wb"))
     try:
         for chunk in read_fastq_chunks(inpath, chunk_bytes):
             info: Optional[list] = [] if inf is not None else None
-            out.write(cutter.process_chunk(chunk, discard_untrimmed, discard_trimmed, info))
+            out.write(trimmer.process_chunk(chunk, discard_untrimmed, discard_trimmed, info))
             if inf is not None:
                 inf.write(b"".join(info))
     finally:
@@ -472,8 +602,8 @@ def trim_fastq(inpath: Union[str, BinaryIO], outpath: Union[str, BinaryIO], adap
             out.close()
         if inf is not None and inf is not info_file:
             inf.close()
-    return {"reads": cutter.reads, "with_adapters": cutter.with_adapters,
-            "bp_in": cutter.bp_in, "bp_out": cutter.bp_out, "cutter": cutter}
+    return {"reads": trimmer.reads, "with_adapters": cutter.with_adapters if cutter else 0,
+            "bp_in": trimmer.bp_in, "bp_out": trimmer.bp_out, "cutter": cutter, "trimmer": trimmer}
 
 
 # -------------------------------------------------------------------------------------------------
@@ -484,6 +614,9 @@ def _single_from_spec(spec: str, adapter_type: str, name: Optional[str], params:
     if "=" in spec.split(";")[0] and name is None:
         name, spec = spec.split("=", 1)
     spec = spec.split(";")[0]
+    if len(spec.strip("X")) == 0:                  # only X characters: kept as a plain adapter (parser.py:243-246)
+        cls = {"front": FrontAdapter, "back": BackAdapter, "anywhere": AnywhereAdapter}[adapter_type]
+        return cls(spec, name=name, **params), False
     front_restriction = back_restriction = None
     if spec.startswith("^"):
         front_restriction, spec = "anchored", spec[1:]

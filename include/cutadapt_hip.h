@@ -278,6 +278,28 @@ int cah_index_lookup_batch_host(const cah_index *index, const uint8_t *seqs, con
                                 int64_t n_reads, int32_t *out6, int32_t *best_adapter,
                                 uint8_t *status);
 
+/* ---- quality / NextSeq / poly-A trimming, expected errors ------ */
+/* The O(n) per-read scans that run just before adapter matching (cli.py:938-954), for a batch
+ * whose qualities are packed with the SAME offsets as the sequences.  All device pointers;
+ * d_lens as in cah_match_batch (NULL = offsets[r+1]-offsets[r]).
+ *   cah_quality_trim_batch   quality_trim_index (qualtrim.pyx:22-70)  -> d_start_stop int32[n,2]
+ *   cah_nextseq_trim_batch   nextseq_trim_index (:73-113)             -> d_stop int32[n]
+ *   cah_poly_a_trim_batch    poly_a_trim_index (:116-165)             -> d_index int32[n]
+ *   cah_expected_errors_batch expected_errors (:168-190, expected_errors.h:103-140) -> double[n],
+ *                            bit-identical (same accumulation order); an invalid phred value gives
+ *                            -1.0 and d_status[r] = CAH_INVALID (the reference raises ValueError). */
+int cah_quality_trim_batch(const uint8_t *d_quals, const int64_t *d_offsets, const int32_t *d_lens,
+                           int64_t n_reads, int32_t cutoff_front, int32_t cutoff_back,
+                           int32_t base, int32_t *d_start_stop, void *stream);
+int cah_nextseq_trim_batch(const uint8_t *d_seqs, const uint8_t *d_quals, const int64_t *d_offsets,
+                           const int32_t *d_lens, int64_t n_reads, int32_t cutoff, int32_t base,
+                           int32_t *d_stop, void *stream);
+int cah_poly_a_trim_batch(const uint8_t *d_seqs, const int64_t *d_offsets, const int32_t *d_lens,
+                          int64_t n_reads, int32_t revcomp, int32_t *d_index, void *stream);
+int cah_expected_errors_batch(const uint8_t *d_quals, const int64_t *d_offsets,
+                              const int32_t *d_lens, int64_t n_reads, int32_t base,
+                              double *d_expected, uint8_t *d_status, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -8,6 +8,7 @@ leg may use this.  The product package (cutadapt_amd) never imports it.
     ref.KmerFinder                                            (reference _kmer_finder.pyx)
     ref.create_positions_and_kmers                            (reference kmer_heuristic.py)
     ref.adapters                                              (reference adapters.py module)
+    ref.qualtrim                                              (reference qualtrim.pyx module, or None)
 or None when oracle/_ref has not been built (see oracle/build_ref.py).
 """
 import importlib
@@ -47,6 +48,10 @@ def load():
         mt = importlib.import_module("cutadapt._match_tables")
     except ImportError:
         return None
+    try:
+        qualtrim = importlib.import_module("cutadapt.qualtrim")
+    except ImportError:
+        qualtrim = None
     ns = types.SimpleNamespace(
         adapters=adapters,
         align=align,
@@ -57,6 +62,7 @@ def load():
         KmerFinder=kf.KmerFinder,
         create_positions_and_kmers=kh.create_positions_and_kmers,
         match_tables=mt,
+        qualtrim=qualtrim,
     )
     _cached = ns
     return ns

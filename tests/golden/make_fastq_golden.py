@@ -41,6 +41,12 @@ CASES = [
     ("linked_discard_untrimmed_g", f"{T}:696", [("-g", "AAAAAAAAAA...TTTTTTTTTT")], {"discard_untrimmed": True}, "linked.fasta", "linked-discard-g.fasta", None),
     ("linked_lowercase", f"{T}:705", [("-a", "^AACCGGTTTT...GGGGGGG$"), ("-a", "^AAAA...TTTT$")], {"times": 2, "action": "lowercase"}, "linked.fasta", "linked-lowercase.fasta", None),
     ("small_anywhere_gz", f"{T}:776", [("-b", "TTAGACATATCTCCGTCG")], {}, "small.fastq.gz", "small.fastq", None),
+    ("qualtrim", f"{T}:246", [("-a", "XXXXXX")], {"quality_cutoff": [0, 10]}, "lowqual.fastq", "lowqual.fastq", None),
+    ("qualbase", f"{T}:251", [("-a", "XXXXXX")], {"quality_cutoff": [0, 10], "quality_base": 64}, "illumina64.fastq", "illumina64.fastq", None),
+    ("quality_trim_only", f"{T}:256", [], {"quality_cutoff": [0, 10], "quality_base": 64}, "illumina64.fastq", "illumina64.fastq", None),
+    ("poly_a", f"{T}:280", [], {"poly_a": True}, "polya.1.fasta", "polya.1.fasta", None),
+    ("nextseq", f"{T}:666", [], {"nextseq_trim": 22}, "nextseq.fastq", "nextseq.fastq", None),
+    ("max_expected_errors", f"{T}:837", [], {"max_expected_errors": 0.9}, "maxee.fastq", "maxee.fastq", None),
     ("info_file", f"{I}:14", [("-a", "adapt=GCCGAACTTCTTAGACTGCCTTAAGGACGT")], {}, "illumina.fastq.gz", "illumina.fastq", "illumina.info.txt"),
     ("info_file_times", f"{I}:35", [("-a", "adapt=GCCGAACTTCTTA"), ("-a", "adapt2=GACTGCCTTAAGGACGT")], {"times": 2}, "illumina5.fastq", "illumina5.fastq", "illumina5.info.txt"),
     ("linked_info_file", f"{I}:119", [("-a", "linkedadapter=^AAAAAAAAAA...TTTTTTTTTT")], {}, "linked.fasta", None, "linked-info.txt"),

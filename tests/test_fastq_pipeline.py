@@ -140,11 +140,13 @@ def test_reference_commandline_goldens(hip):
     adapters, --discard-(un)trimmed, FASTA and FASTQ, with one big and many tiny chunks."""
     from cutadapt_amd.pipeline import adapter_from_spec, trim_fastq
     manifest = json.load(open(os.path.join(FQ, "manifest.json")))
-    assert len(manifest) >= 25
+    assert len(manifest) >= 31
     kinds = {"-a": "back", "-g": "front", "-b": "anywhere"}
     for case in manifest:
         opts = dict(case["options"])
         params = {"max_errors": opts.pop("max_errors")} if "max_errors" in opts else {}
+        if "quality_cutoff" in opts:
+            opts["quality_cutoff"] = tuple(opts["quality_cutoff"])
         for chunk_bytes in (4 << 20, 512):          # 512 forces many chunks (reference --buffer-size=512 tests)
             ads = [adapter_from_spec(spec, kinds[opt], **params) for opt, spec in case["adapters"]]
             out, info = io.BytesIO(), io.BytesIO()
@@ -160,6 +162,8 @@ def test_reference_commandline_goldens(hip):
             assert stats["reads"] == 100 and stats["with_adapters"] == 56
             # errors[removed_length][errors] sums to the number of matches (adapters.py:185-199)
             assert stats["cutter"].histogram.total() == 56
+        if case["name"] == "max_expected_errors":
+            assert stats["trimmer"].too_many_expected_errors == 2          # reference test_commandline.py:839
 
 
 @pytest.mark.gpu
