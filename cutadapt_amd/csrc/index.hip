@@ -360,8 +360,19 @@ __global__ __launch_bounds__(256) void k_index_lookup(IndexArgs a) {
     uint64_t lo = 0, hi = 0;
     int first_n = IDX_MAX_STRING + 1, first_bad = IDX_MAX_STRING + 1;
     bool non_ascii = n64 > CAH_MAX_READ_LEN;
+    // the first 16 characters from the anchored end arrive in one (unaligned) 16-byte load
+    struct __attribute__((packed, aligned(1))) U16 { uint32_t w[4]; };
+    U16 c16 = {{0, 0, 0, 0}};
+    const bool have16 = n >= 16;
+    if (have16) c16 = *reinterpret_cast<const U16*>(prefix ? q : q + (n - 16));
     for (int t = 0; t < la; t++) {
-        const uint8_t raw = prefix ? q[t] : q[n - 1 - t];
+        uint8_t raw;
+        if (have16 && t < 16) {
+            const int bi = prefix ? t : 15 - t;
+            raw = (uint8_t)(c16.w[bi >> 2] >> ((bi & 3) * 8));
+        } else {
+            raw = prefix ? q[t] : q[n - 1 - t];
+        }
         non_ascii |= raw >= 0x80;
         const uint8_t c = dev_upper(raw);
         int code = 0;

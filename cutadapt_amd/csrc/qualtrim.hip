@@ -31,6 +31,13 @@ __device__ __forceinline__ void qt_extent(const int64_t* offsets, const int32_t*
     n = (int)(n64 > 0x7FFFFFFF ? 0x7FFFFFFF : n64);
 }
 
+// 16 characters per global load: reads are packed back to back, so a chunk starts at an arbitrary
+// byte; gfx950 executes unaligned dwordx4 loads natively.  The caller guarantees p[0..15] is inside
+// the read.
+struct __attribute__((packed, aligned(1))) QtUnaligned16 { uint32_t w[4]; };
+__device__ __forceinline__ QtUnaligned16 qt_load16(const uint8_t* p) { return *reinterpret_cast<const QtUnaligned16*>(p); }
+__device__ __forceinline__ uint8_t qt_byte(const QtUnaligned16& c, int t) { return (uint8_t)(c.w[t >> 2] >> ((t & 3) * 8)); }
+
 // quality_trim_index (qualtrim.pyx:22-70): BWA-style partial sums from both ends; the quality
 // bytes are read as C `char` (signed), like the reference does.
 __global__ __launch_bounds__(256) void k_quality_trim(const uint8_t* quals, const int64_t* offsets, const int32_t* lens,
@@ -43,16 +50,39 @@ __global__ __launch_bounds__(256) void k_quality_trim(const uint8_t* quals, cons
     const signed char* q = reinterpret_cast<const signed char*>(quals + off);
     int start = 0, stop = n;
     int s = 0, max_qual = 0;
-    for (int i = 0; i < n; i++) {                                    // :50-57
-        s += cutoff_front - ((int)q[i] - base);
-        if (s < 0) break;
-        if (s > max_qual) { max_qual = s; start = i + 1; }
+    const uint8_t* qb = quals + off;
+    {                                                                // 5' end, :50-57
+        auto step = [&](const signed char c, const int i) -> bool {
+            s += cutoff_front - ((int)c - base);
+            if (s < 0) return true;
+            if (s > max_qual) { max_qual = s; start = i + 1; }
+            return false;
+        };
+        int i = 0;
+        bool done = false;
+        for (; i + 16 <= n && !done; i += 16) {
+            const QtUnaligned16 c = qt_load16(qb + i);
+#pragma unroll
+            for (int t = 0; t < 16; t++) if (!done) done = step((signed char)qt_byte(c, t), i + t);
+        }
+        for (; i < n && !done; i++) done = step(q[i], i);
     }
     max_qual = 0; s = 0;
-    for (int i = n - 1; i >= 0; i--) {                               // :60-67
-        s += cutoff_back - ((int)q[i] - base);
-        if (s < 0) break;
-        if (s > max_qual) { max_qual = s; stop = i; }
+    {                                                                // 3' end, :60-67
+        auto step = [&](const signed char c, const int i) -> bool {
+            s += cutoff_back - ((int)c - base);
+            if (s < 0) return true;
+            if (s > max_qual) { max_qual = s; stop = i; }
+            return false;
+        };
+        int i = n;
+        bool done = false;
+        for (; i >= 16 && !done; i -= 16) {
+            const QtUnaligned16 c = qt_load16(qb + i - 16);
+#pragma unroll
+            for (int t = 15; t >= 0; t--) if (!done) done = step((signed char)qt_byte(c, t), i - 16 + t);
+        }
+        for (i = i - 1; i >= 0 && !done; i--) done = step(q[i], i);
     }
     if (start >= stop) { start = 0; stop = 0; }                      // :68-69
     start_stop[2 * r] = start;
@@ -70,13 +100,23 @@ __global__ __launch_bounds__(256) void k_nextseq_trim(const uint8_t* seqs, const
     const signed char* q = reinterpret_cast<const signed char*>(quals + off);
     const uint8_t* b = seqs + off;
     int s = 0, max_qual = 0, max_i = n;
-    for (int i = n - 1; i >= 0; i--) {
-        int qv = (int)q[i] - base;
-        if (b[i] == 'G') qv = cutoff - 1;
+    auto step = [&](const signed char qc, const uint8_t bc, const int i) -> bool {
+        int qv = (int)qc - base;
+        if (bc == 'G') qv = cutoff - 1;
         s += cutoff - qv;
-        if (s < 0) break;
+        if (s < 0) return true;
         if (s > max_qual) { max_qual = s; max_i = i; }
+        return false;
+    };
+    int i = n;
+    bool done = false;
+    for (; i >= 16 && !done; i -= 16) {
+        const QtUnaligned16 cq = qt_load16(quals + off + i - 16);
+        const QtUnaligned16 cb = qt_load16(b + i - 16);
+#pragma unroll
+        for (int t = 15; t >= 0; t--) if (!done) done = step((signed char)qt_byte(cq, t), qt_byte(cb, t), i - 16 + t);
     }
+    for (i = i - 1; i >= 0 && !done; i--) done = step(q[i], b[i], i);
     stop_out[r] = max_i;
 }
 
@@ -92,17 +132,31 @@ __global__ __launch_bounds__(256) void k_poly_a_trim(const uint8_t* seqs, const 
     int best_score = 0, score = 0, errors = 0, best_index;
     if (revcomp) {
         best_index = 0;
-        for (int i = 0; i < n; i++) {
-            if (b[i] == 'T') score += 1; else { score -= 2; errors += 1; }
+        auto step = [&](const uint8_t c, const int i) {
+            if (c == 'T') score += 1; else { score -= 2; errors += 1; }
             if (score > best_score && errors * 5 <= i + 1) { best_score = score; best_index = i + 1; }
+        };
+        int i = 0;
+        for (; i + 16 <= n; i += 16) {
+            const QtUnaligned16 c = qt_load16(b + i);
+#pragma unroll
+            for (int t = 0; t < 16; t++) step(qt_byte(c, t), i + t);
         }
+        for (; i < n; i++) step(b[i], i);
         if (best_index < 3) best_index = 0;
     } else {
         best_index = n;
-        for (int i = n - 1; i >= 0; i--) {
-            if (b[i] == 'A') score += 1; else { score -= 2; errors += 1; }
+        auto step = [&](const uint8_t c, const int i) {
+            if (c == 'A') score += 1; else { score -= 2; errors += 1; }
             if (score > best_score && errors * 5 <= n - i) { best_score = score; best_index = i; }
+        };
+        int i = n;                                                   // positions i-1, i-2, ... are still to do
+        for (; i >= 16; i -= 16) {
+            const QtUnaligned16 c = qt_load16(b + i - 16);
+#pragma unroll
+            for (int t = 15; t >= 0; t--) step(qt_byte(c, t), i - 16 + t);
         }
+        for (i = i - 1; i >= 0; i--) step(b[i], i);
         if (best_index > n - 3) best_index = n;
     }
     index_out[r] = best_index;
@@ -127,7 +181,18 @@ __global__ __launch_bounds__(256) void k_expected_errors(const uint8_t* quals, c
     double e0 = 0.0, e1 = 0.0, e2 = 0.0, e3 = 0.0;
     bool bad = false;
     int i = 0;
-    for (; i + 3 < n; i += 4) {
+    // 16 characters = four of the reference's groups of four (accumulator = position mod 4)
+    for (; i + 16 <= n && !bad; i += 16) {
+        const QtUnaligned16 c = qt_load16(q + i);
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const uint8_t p0 = (uint8_t)(qt_byte(c, 4 * g) - ubase), p1 = (uint8_t)(qt_byte(c, 4 * g + 1) - ubase);
+            const uint8_t p2 = (uint8_t)(qt_byte(c, 4 * g + 2) - ubase), p3 = (uint8_t)(qt_byte(c, 4 * g + 3) - ubase);
+            if (p0 > max_phred || p1 > max_phred || p2 > max_phred || p3 > max_phred) { bad = true; break; }
+            e0 += s_tab[p0]; e1 += s_tab[p1]; e2 += s_tab[p2]; e3 += s_tab[p3];
+        }
+    }
+    for (; i + 3 < n && !bad; i += 4) {
         const uint8_t p0 = (uint8_t)(q[i] - ubase), p1 = (uint8_t)(q[i + 1] - ubase);
         const uint8_t p2 = (uint8_t)(q[i + 2] - ubase), p3 = (uint8_t)(q[i + 3] - ubase);
         if (p0 > max_phred || p1 > max_phred || p2 > max_phred || p3 > max_phred) { bad = true; break; }
