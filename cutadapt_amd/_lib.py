@@ -26,7 +26,7 @@ EXPORTED_SYMBOLS = [
     "cah_kmers_present_batch_host", "cah_match_batch_host", "cah_profile_enable",
     "cah_profile_reset", "cah_profile_read", "cah_synth_reads",
     "cah_fastq_scan", "cah_pack_sequences", "cah_fastq_write_trimmed",
-    "cah_fasta_scan", "cah_records_write", "cah_info_write",
+    "cah_fasta_scan", "cah_records_write", "cah_info_write", "cah_record_boundary",
     "cah_index_create", "cah_index_destroy", "cah_index_info", "cah_index_get",
     "cah_index_lookup_batch", "cah_index_lookup_batch_host",
     "cah_quality_trim_batch", "cah_nextseq_trim_batch", "cah_poly_a_trim_batch", "cah_expected_errors_batch",
@@ -120,6 +120,7 @@ def lib():
     L.cah_fasta_scan.argtypes = [vp, i64, C.c_int, i64, vp, C.POINTER(i64), C.POINTER(i64)]
     L.cah_records_write.argtypes = [vp, vp, i64, vp, vp, vp, vp, vp, C.c_int, vp, i64, C.POINTER(i64)]
     L.cah_info_write.argtypes = [vp, vp, i64, vp, vp, vp, i64, vp, vp, i64, vp, i64, C.POINTER(i64)]
+    L.cah_record_boundary.argtypes = [vp, i64, C.c_int, C.POINTER(i64)]
     L.cah_index_create.argtypes = [C.POINTER(IndexAdapterC), i32, i32, C.POINTER(vp)]
     L.cah_index_destroy.argtypes = [vp]
     L.cah_index_destroy.restype = None

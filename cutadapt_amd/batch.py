@@ -70,8 +70,17 @@ class ReadBatch:
     def from_host(cls, seqs: np.ndarray, offsets: np.ndarray, device=None, validated: bool = False):
         torch = _torch()
         device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
-        s = torch.from_numpy(np.ascontiguousarray(seqs, dtype=np.uint8).copy()).to(device)
-        o = torch.from_numpy(np.ascontiguousarray(offsets, dtype=np.int64).copy()).to(device)
+        # .to(device) copies synchronously out of the (pageable) host arrays: no defensive host copy
+        s_host = np.ascontiguousarray(seqs, dtype=np.uint8)
+        o_host = np.ascontiguousarray(offsets, dtype=np.int64)
+        if len(s_host) == 0:
+            s_host = np.zeros(1, dtype=np.uint8)          # an empty batch still needs a valid pointer
+        if not s_host.flags.writeable:
+            s_host = s_host.copy()                        # torch.from_numpy wants a writeable array
+        if not o_host.flags.writeable:
+            o_host = o_host.copy()
+        s = torch.from_numpy(s_host).to(device)
+        o = torch.from_numpy(o_host).to(device)
         return cls(s, o, validated=validated)
 
     @classmethod

@@ -313,4 +313,32 @@ int cah_info_write(const uint8_t* buf, const int64_t* rec, int64_t n_records, co
     return CAH_OK;
 }
 
+// Cheap record boundary for the threaded pipeline: the reader thread only has to cut the byte
+// stream at a record start, the full scan (cah_fastq_scan / cah_fasta_scan) runs in a worker
+// (dnaio.read_chunks does the same kind of backwards search for the reference's reader process,
+// runners.py:116-126).  Returns in *cut the largest offset <= len that starts a record, 0 if none
+// beyond the first was found.  FASTQ: a line starting with '@' whose next-but-one line starts
+// with '+' (a quality line that happens to start with '@' is followed, two lines later, by a
+// sequence line, never by '+').  FASTA: a line starting with '>'.
+int cah_record_boundary(const uint8_t* buf, int64_t len, int is_fasta, int64_t* cut) {
+    if (!cut || (len > 0 && !buf)) return cah_set_error_(CAH_EINVAL, "cah_record_boundary: NULL argument");
+    *cut = 0;
+    int64_t p = len;
+    while (p > 0) {
+        // start of the line that contains byte p-1
+        const void* nl = memrchr(buf, '\n', (size_t)(p - 1));
+        const int64_t ls = nl ? (const uint8_t*)nl - buf + 1 : 0;
+        if (ls == 0) return CAH_OK;                         // the first record start is not a useful cut
+        if (is_fasta) {
+            if (buf[ls] == '>') { *cut = ls; return CAH_OK; }
+        } else if (buf[ls] == '@') {
+            const uint8_t* l1 = find_nl(buf + ls, buf + len);
+            const uint8_t* l2 = l1 ? find_nl(l1 + 1, buf + len) : nullptr;
+            if (l2 && l2 + 1 < buf + len && l2[1] == '+') { *cut = ls; return CAH_OK; }
+        }
+        p = ls;                                             // continue with the previous line
+    }
+    return CAH_OK;
+}
+
 }  // extern "C"

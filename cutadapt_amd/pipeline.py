@@ -44,6 +44,40 @@ def _open_maybe_gz(path_or_file: Union[str, BinaryIO]) -> BinaryIO:
     return f
 
 
+class _BufferPool:
+    """Recycles the large byte buffers of the threaded pipeline (input chunks, packed sequences,
+    formatted output).  Fresh 32 MiB allocations are mmap + first-touch page faults, and page
+    faults of threads of one process serialise in the kernel; recycled buffers cost nothing."""
+
+    def __init__(self, max_free: int = 96):
+        import threading
+        self._free: List[np.ndarray] = []
+        self._lock = threading.Lock()
+        self._max_free = max_free
+
+    def get(self, nbytes: int) -> np.ndarray:
+        with self._lock:
+            best = -1
+            for i, a in enumerate(self._free):
+                if len(a) >= nbytes and (best < 0 or len(a) < len(self._free[best])):
+                    best = i
+            if best >= 0:
+                return self._free.pop(best)
+        return np.empty(max(int(nbytes), 1), dtype=np.uint8)
+
+    def put(self, arr) -> None:
+        while isinstance(arr, np.ndarray) and arr.base is not None and isinstance(arr.base, np.ndarray):
+            arr = arr.base                                  # views go back as their owning buffer
+        if not isinstance(arr, np.ndarray) or arr.dtype != np.uint8 or arr.ndim != 1:
+            return
+        with self._lock:
+            if len(self._free) < self._max_free:
+                self._free.append(arr)
+
+
+POOL = _BufferPool()
+
+
 class FastqChunk:
     """One record-aligned chunk: the raw bytes plus rec[n,6] = (name_beg, name_end, seq_beg,
     seq_end, qual_beg, qual_end) byte offsets (csrc/fastq.cpp: cah_fastq_scan / cah_fasta_scan;
@@ -53,6 +87,15 @@ class FastqChunk:
         self.buf = buf
         self.rec = rec
         self._packed: Optional[Tuple[np.ndarray, np.ndarray]] = None
+        self.pooled = False            # threaded pipeline: big buffers come from / go back to POOL
+
+    def release(self) -> None:
+        """hand the input and packed buffers back to the pool (the chunk is dead afterwards)"""
+        if self.pooled:
+            POOL.put(self.buf)
+            if self._packed is not None:
+                POOL.put(self._packed[0])
+        self.buf = self._packed = None
 
     def __len__(self):
         return len(self.rec)
@@ -61,7 +104,7 @@ class FastqChunk:
         if self._packed is None:
             n = len(self.rec)
             cap = int((self.rec[:, 3] - self.rec[:, 2]).sum()) if n else 0     # upper bound for FASTA
-            seqs = np.empty(cap, dtype=np.uint8)
+            seqs = POOL.get(cap) if self.pooled else np.empty(cap, dtype=np.uint8)
             offsets = np.zeros(n + 1, dtype=np.int64)
             _lib.check(_lib.lib().cah_pack_sequences(
                 self.buf.ctypes.data, self.rec.ctypes.data, n, seqs.ctypes.data if cap else None,
@@ -100,7 +143,7 @@ class FastqChunk:
         n = len(self.rec)
         seqs, offsets = self.pack_sequences()
         cap = int(len(self.buf)) + 4 * n + 16
-        out = np.empty(cap, dtype=np.uint8)
+        out = POOL.get(cap) if self.pooled else np.empty(cap, dtype=np.uint8)
         out_len = C.c_int64(0)
         kb = np.ascontiguousarray(beg, dtype=np.int32)
         ke = np.ascontiguousarray(end, dtype=np.int32)
@@ -108,8 +151,8 @@ class FastqChunk:
         _lib.check(_lib.lib().cah_records_write(
             self.buf.ctypes.data, self.rec.ctypes.data, n, seqs.ctypes.data if len(seqs) else None,
             offsets.ctypes.data, kb.ctypes.data, ke.ctypes.data,
-            kp.ctypes.data if kp is not None else None, int(mode), out.ctypes.data, cap, C.byref(out_len)))
-        return out[:out_len.value].tobytes()
+            kp.ctypes.data if kp is not None else None, int(mode), out.ctypes.data, len(out), C.byref(out_len)))
+        return memoryview(out)[:out_len.value]            # no copy; bytes-like (write(), ==, b"".join all take it)
 
     def write_info(self, rows: np.ndarray, names: Sequence[str]) -> bytes:
         """--info-file rows for this chunk; rows int64[k,7] as cah_info_write takes them."""
@@ -170,6 +213,55 @@ def read_fastq_chunks(path_or_file: Union[str, BinaryIO], chunk_bytes: int = DEF
             break
         if not n.value and len(carry) > 64 * chunk_bytes:
             raise ValueError("record larger than 64 chunks: not a FASTA/FASTQ file?")
+
+
+def read_raw_chunks(path_or_file: Union[str, BinaryIO], chunk_bytes: int = DEFAULT_CHUNK_BYTES) -> Iterator[Tuple[np.ndarray, bool]]:
+    """Record-aligned but UNPARSED chunks: (bytes, is_fasta).  The reader only looks for a record
+    start near the end of each buffer (cah_record_boundary); parsing is left to the consumer
+    (``scan_chunk``), so that several worker threads can do it."""
+    f = _open_maybe_gz(path_or_file)
+    L = _lib.lib()
+    carry = b""
+    fasta = None
+    while True:
+        buf = POOL.get(len(carry) + chunk_bytes)
+        if carry:
+            buf[:len(carry)] = np.frombuffer(carry, dtype=np.uint8)
+        got = f.readinto(memoryview(buf)[len(carry):]) if hasattr(f, "readinto") else None
+        if got is None:
+            block = f.read(chunk_bytes)
+            got = len(block)
+            buf[len(carry):len(carry) + got] = np.frombuffer(block, dtype=np.uint8)
+        total = len(carry) + got
+        if total == 0:
+            POOL.put(buf)
+            break
+        data = buf[:total]
+        if fasta is None:
+            fasta = bool(data[0] == ord(">"))
+        if got == 0:                                      # end of input: everything that is left
+            yield data, fasta
+            break
+        cut = C.c_int64(0)
+        _lib.check(L.cah_record_boundary(data.ctypes.data, total, int(fasta), C.byref(cut)))
+        carry = data[cut.value:].tobytes()
+        if cut.value:
+            yield data[:cut.value], fasta
+        elif len(carry) > 64 * chunk_bytes:
+            raise ValueError("record larger than 64 chunks: not a FASTA/FASTQ file?")
+
+
+def scan_chunk(data: np.ndarray, fasta: bool) -> FastqChunk:
+    """Full record index of a record-aligned chunk (the whole chunk must parse)."""
+    L = _lib.lib()
+    total = len(data)
+    max_rec = (int(np.count_nonzero(data == ord(">"))) + 2) if fasta else int(np.count_nonzero(data == 10)) // 4 + 2
+    rec = np.empty((max_rec, 6), dtype=np.int64)
+    n = C.c_int64(0)
+    consumed = C.c_int64(0)
+    _lib.check((L.cah_fasta_scan if fasta else L.cah_fastq_scan)(
+        data.ctypes.data, total, 1, max_rec, rec.ctypes.data, C.byref(n), C.byref(consumed)))
+    return FastqChunk(data, rec[:n.value])
 
 
 # -------------------------------------------------------------------------------------------------
@@ -300,6 +392,7 @@ class BatchAdapterCutter:
                 self._slot[(i, 0)] = len(self.names)
                 self.names.append(a.name)
                 self.stat_labels.append((a.name, "end"))
+        self._slot_of_adapter = np.array([self._slot[(i, 0)] for i in range(len(adapters))], dtype=np.int64)
         self.histogram = MatchHistogram(len(self.names))
         self.reads = 0
         self.with_adapters = 0
@@ -324,7 +417,7 @@ class BatchAdapterCutter:
         r.crop_beg, r.crop_end = rstart.copy(), rstop.copy()
         idx = np.flatnonzero(f)
         ids = np.asarray(adapter_ids, dtype=np.int64)[bm.adapter_index[idx].astype(np.int64)]
-        slots = np.array([self._slot[(int(a), 0)] for a in ids], dtype=np.int64) if len(ids) else np.zeros(0, np.int64)
+        slots = self._slot_of_adapter[ids]
         removed = np.where(before[idx], rstop[idx], lens[idx] - rstart[idx])     # removed_sequence_length()
         r.rows = _rows_for(idx, c[idx, 5], rstart[idx], rstop[idx], 0, lens[idx], slots, slots, removed, 0)
         return r
@@ -499,6 +592,17 @@ class BatchTrimmer:
         self.bp_in = 0
         self.bp_out = 0
 
+    def merge(self, other: "BatchTrimmer") -> None:
+        """add another worker's statistics (the reference sums Statistics objects, report.py:81-126)"""
+        for name in ("nextseq_trimmed_bases", "quality_trimmed_bases", "too_many_expected_errors", "reads", "bp_in", "bp_out"):
+            setattr(self, name, getattr(self, name) + getattr(other, name))
+        for k, c in other.poly_a_trimmed_lengths.items():
+            self.poly_a_trimmed_lengths[k] = self.poly_a_trimmed_lengths.get(k, 0) + c
+        if self.cutter is not None and other.cutter is not None:
+            self.cutter.histogram += other.cutter.histogram
+            for name in ("reads", "with_adapters", "bp_in", "bp_out"):
+                setattr(self.cutter, name, getattr(self.cutter, name) + getattr(other.cutter, name))
+
     def process_chunk(self, chunk: FastqChunk, discard_untrimmed: bool = False, discard_trimmed: bool = False,
                       info: Optional[list] = None) -> bytes:
         import torch
@@ -580,30 +684,84 @@ def trim_fastq(inpath: Union[str, BinaryIO], outpath: Union[str, BinaryIO], adap
                info_file: Union[None, str, BinaryIO] = None, chunk_bytes: int = DEFAULT_CHUNK_BYTES,
                index: bool = True, nextseq_trim: Optional[int] = None,
                quality_cutoff: Optional[Tuple[int, int]] = None, quality_base: int = 33, poly_a: bool = False,
-               max_expected_errors: Optional[float] = None, device=None) -> Dict[str, object]:
+               max_expected_errors: Optional[float] = None, threads: int = 1, device=None) -> Dict[str, object]:
     """``cutadapt [--nextseq-trim N] [-q [FRONT,]BACK] [--quality-base B] <adapter options> [--times N]
     [--action A] [--poly-a] [--max-ee E] [--discard-(un)trimmed] [--info-file F] -o outpath inpath`` for the
     supported slice; returns the read/basepair counters the reference reports (reference
     report.py:62-80), the adapter cutter (statistics) and the trimmer."""
-    trimmer = BatchTrimmer(adapters, times=times, action=action, index=index, nextseq_trim=nextseq_trim,
-                           quality_cutoff=quality_cutoff, quality_base=quality_base, poly_a=poly_a,
-                           max_expected_errors=max_expected_errors, device=device)
-    cutter = trimmer.cutter
+    def make_trimmer():
+        return BatchTrimmer(adapters, times=times, action=action, index=index, nextseq_trim=nextseq_trim,
+                            quality_cutoff=quality_cutoff, quality_base=quality_base, poly_a=poly_a,
+                            max_expected_errors=max_expected_errors, device=device)
+
+    trimmer = make_trimmer()
     out = outpath if hasattr(outpath, "write") else open(outpath, "wb")
     inf = None if info_file is None else (info_file if hasattr(info_file, "write") else open(info_file, "wb"))
     try:
-        for chunk in read_fastq_chunks(inpath, chunk_bytes):
-            info: Optional[list] = [] if inf is not None else None
-            out.write(trimmer.process_chunk(chunk, discard_untrimmed, discard_trimmed, info))
-            if inf is not None:
-                inf.write(b"".join(info))
+        if threads <= 1:
+            for chunk in read_fastq_chunks(inpath, chunk_bytes):
+                info: Optional[list] = [] if inf is not None else None
+                out.write(trimmer.process_chunk(chunk, discard_untrimmed, discard_trimmed, info))
+                if inf is not None:
+                    inf.write(b"".join(info))
+        else:
+            _trim_threaded(inpath, out, inf, trimmer, make_trimmer, threads, chunk_bytes, discard_untrimmed,
+                           discard_trimmed)
     finally:
         if out is not outpath:
             out.close()
         if inf is not None and inf is not info_file:
             inf.close()
+    cutter = trimmer.cutter
     return {"reads": trimmer.reads, "with_adapters": cutter.with_adapters if cutter else 0,
             "bp_in": trimmer.bp_in, "bp_out": trimmer.bp_out, "cutter": cutter, "trimmer": trimmer}
+
+
+def _trim_threaded(inpath, out, inf, trimmer: "BatchTrimmer", make_trimmer, threads: int, chunk_bytes: int,
+                   discard_untrimmed: bool, discard_trimmed: bool) -> None:
+    """The reference's reader -> workers -> ordered writer layout (runners.py:96-245) with threads
+    instead of processes: the calling thread cuts the input into record-aligned raw chunks and
+    writes results in chunk order, ``threads`` workers parse, pack, match (each on its own HIP
+    stream) and format.  Parsing, packing and formatting are C calls that release the GIL."""
+    import threading
+    from collections import deque
+    from concurrent.futures import ThreadPoolExecutor
+    import torch
+    local = threading.local()
+    workers: List["BatchTrimmer"] = []
+    lock = threading.Lock()
+
+    def work(data: np.ndarray, fasta: bool):
+        if not hasattr(local, "trimmer"):
+            local.trimmer = make_trimmer()
+            local.stream = torch.cuda.Stream(device=trimmer.device)
+            with lock:
+                workers.append(local.trimmer)
+        chunk = scan_chunk(data, fasta)
+        chunk.pooled = True
+        info: Optional[list] = [] if inf is not None else None
+        try:
+            with torch.cuda.stream(local.stream):
+                res = local.trimmer.process_chunk(chunk, discard_untrimmed, discard_trimmed, info)
+        finally:
+            chunk.release()
+        return res, (b"".join(info) if info is not None else None)
+
+    pending: deque = deque()
+    with ThreadPoolExecutor(max_workers=threads) as pool:
+        def drain(limit: int) -> None:
+            while len(pending) > limit:
+                res, info = pending.popleft().result()
+                out.write(res)
+                POOL.put(res.obj)                           # the formatted chunk's buffer is free again
+                if inf is not None:
+                    inf.write(info)
+        for data, fasta in read_raw_chunks(inpath, chunk_bytes):
+            pending.append(pool.submit(work, data, fasta))
+            drain(2 * threads)
+        drain(0)
+    for w in workers:                                       # merge the workers' statistics
+        trimmer.merge(w)
 
 
 # -------------------------------------------------------------------------------------------------

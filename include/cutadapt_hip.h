@@ -217,6 +217,9 @@ int cah_fastq_write_trimmed(const uint8_t *buf, const int64_t *rec, int64_t n_re
  * qual_beg = qual_end = -1 marks a record without qualities. */
 int cah_fasta_scan(const uint8_t *buf, int64_t len, int is_final, int64_t max_records,
                    int64_t *rec, int64_t *n_records, int64_t *consumed);
+/* Largest offset <= len at which a record starts (0 if only the first record start was seen): lets
+ * a reader thread cut the byte stream without parsing it; the full scan runs in a worker. */
+int cah_record_boundary(const uint8_t *buf, int64_t len, int is_fasta, int64_t *cut);
 /* Output formatting for every AdapterCutter action (modifiers.py:170-198, :236-251): sequence from
  * the packed batch (seqs/offsets), names and qualities from the raw chunk; interval [beg,end) per
  * read.  SLICE: sequence+qualities sliced (trim, retain, crop; whole read for action None);

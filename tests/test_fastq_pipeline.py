@@ -112,6 +112,35 @@ def test_fasta_scan_and_writers():
         fq.write_info(np.array([[0, 0, 1, 9, 0, 5, 0]], np.int64), ["x"])
 
 
+def test_raw_chunks_cut_at_record_starts():
+    """the reader thread's cheap boundary search (cah_record_boundary) must give the same records
+    as the parsing reader, also with '@' and '+' as first quality characters"""
+    import random
+    from cutadapt_amd.pipeline import read_fastq_chunks, read_raw_chunks, scan_chunk
+    rng = random.Random(3)
+    recs = []
+    for i in range(300):
+        n = rng.randint(0, 40)
+        seq = "".join(rng.choice("ACGT") for _ in range(n))
+        qual = "".join(rng.choice("@+I#5") for _ in range(n))
+        recs.append((f"r{i} x", seq, qual))
+    fq = "".join(f"@{h}\n{s}\n+\n{q}\n" for h, s, q in recs).encode()
+    fa = "".join(f">{h}\n{s[:len(s) // 2]}\n{s[len(s) // 2:]}\n" for h, s, _ in recs).encode()
+    for data in (fq, fa, fq[:-1]):
+        for chunk_bytes in (64, 333, 1 << 20):
+            ref_recs = []
+            for c in read_fastq_chunks(io.BytesIO(data), chunk_bytes):
+                seqs, off = c.pack_sequences()
+                ref_recs += [(bytes(c.buf[c.rec[j, 0]:c.rec[j, 1]]), bytes(seqs[off[j]:off[j + 1]])) for j in range(len(c))]
+            got, total = [], 0
+            for raw, fasta in read_raw_chunks(io.BytesIO(data), chunk_bytes):
+                total += len(raw)
+                c = scan_chunk(raw, fasta)
+                seqs, off = c.pack_sequences()
+                got += [(bytes(c.buf[c.rec[j, 0]:c.rec[j, 1]]), bytes(seqs[off[j]:off[j + 1]])) for j in range(len(c))]
+            assert total == len(data) and got == ref_recs and len(got) == 300
+
+
 def test_adapter_specs():
     from cutadapt_amd import adapters as A
     from cutadapt_amd.pipeline import adapter_from_spec
@@ -158,6 +187,16 @@ def test_reference_commandline_goldens(hip):
             if case["info"]:
                 expected = open(os.path.join(FQ, case["info"]), "rb").read()
                 assert _strip_trailing_space(info.getvalue()) == _strip_trailing_space(expected), (case["name"], chunk_bytes)
+            if chunk_bytes == 512:                      # reader + 3 worker threads + ordered writer
+                out3, info3 = io.BytesIO(), io.BytesIO()
+                stats3 = trim_fastq(os.path.join(FQ, case["input"]), out3, ads, chunk_bytes=chunk_bytes,
+                                    info_file=info3 if case["info"] else None, threads=3, **opts)
+                assert out3.getvalue() == out.getvalue() and info3.getvalue() == info.getvalue(), case["name"]
+                assert (stats3["reads"], stats3["with_adapters"], stats3["bp_out"]) == \
+                       (stats["reads"], stats["with_adapters"], stats["bp_out"]), case["name"]
+                if stats["cutter"] is not None:
+                    a, b = stats3["cutter"].histogram.counts, stats["cutter"].histogram.counts
+                    assert a.sum() == b.sum()
         if case["name"] == "illumina_iupac":
             assert stats["reads"] == 100 and stats["with_adapters"] == 56
             # errors[removed_length][errors] sums to the number of matches (adapters.py:185-199)
