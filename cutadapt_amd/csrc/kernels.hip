@@ -739,19 +739,27 @@ __device__ __forceinline__ int pk_cost(unsigned w) { return (int)(w >> PK_COST_S
 __device__ __forceinline__ int pk_rel(unsigned w) { return (int)((w >> PK_REL_SHIFT) & 0x1FFu); }
 __device__ __forceinline__ int pk_score(unsigned w) { return (int)(w & 0x1FFu) - PK_SCORE_BIAS; }
 
+#ifdef CAH_DP_COUNT
+__device__ unsigned long long g_dp_dbg[8];      // debug build only: lock-step accounting of k_dp_packed
+#endif
+#ifndef CAH_DPP_PIPELINE
+#define CAH_DPP_PIPELINE 1          // issue the next row's predicates between a compare and its select
+#endif
 template <int I, int ROWS>
-__device__ __forceinline__ void dp_rows_packed(unsigned (&w)[ROWS + 1], const uint64_t mk, unsigned wd,
-                                               int& nl, unsigned& cm_w, const int last, const int m,
-                                               const unsigned klim) {
+__device__ __forceinline__ void dp_rows_packed(unsigned (&w)[ROWS + 1], const unsigned mk_lo, const unsigned mk_hi,
+                                               unsigned wd, int& nl, unsigned& cm_w, const int last, const int m,
+                                               const unsigned klim, const bool eq, const bool in_band) {
+    // eq / in_band: this row's predicates, computed at the end of the previous row.  On gfx950 a VALU
+    // compare result (VCC / SGPR pair) cannot feed the very next VALU instruction (the compiler pads
+    // with s_nop), so the compares of row I+1 are issued between row I's `cost <= k` compare and the
+    // select that consumes it; the match bits are tested on 32-bit halves (a 64-bit mask makes the
+    // compiler emit v_cmp_eq_u64).
     if constexpr (I <= ROWS) {
         if constexpr (CAH_SKIP_CHECK(I)) {
-            if (!__any(last >= I)) return;
+            if (!__any(in_band)) return;                  // no lane has band left
         }
         const unsigned wold = w[I];
         const unsigned wprev = w[I - 1];
-        const unsigned mword = (I - 1) < 32 ? (unsigned)mk : (unsigned)(mk >> 32);
-        const bool eq = (mword & (1u << ((I - 1) & 31))) != 0;
-        const bool in_band = I <= last;
         const unsigned a = wd + PK_D_MIS;                 // mismatch: from the diagonal
         const unsigned b = wprev + PK_D_DEL;              // deletion: from the cell above (this column)
         const unsigned c3 = wold + PK_D_INS;              // insertion: from this row, previous column
@@ -759,12 +767,19 @@ __device__ __forceinline__ void dp_rows_packed(unsigned (&w)[ROWS + 1], const ui
         const unsigned e = wd + PK_D_MATCH;
         const unsigned wn = eq ? e : mn;
         w[I] = in_band ? wn : wold;                       // out of band: the stale cell stays
-        nl = w[I] < klim ? I : nl;                        // stale cells cost > k (see k_dp)
         if constexpr (I > ROWS - 8) {
             if (I == m) cm_w = wn;                        // wave-uniform capture of cell (m, j)
         }
+        const bool ok = w[I] < klim;                      // stale cells cost > k (see k_dp)
+        const unsigned mword = I < 32 ? mk_lo : mk_hi;    // predicates of row I + 1
+        const bool eq_next = (mword & (1u << (I & 31))) != 0u;
+        const bool band_next = I + 1 <= last;
+#if CAH_DPP_PIPELINE
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        nl = ok ? I : nl;
         if constexpr ((I % CAH_SCHED_ROWS) == 0) __builtin_amdgcn_sched_barrier(0);
-        dp_rows_packed<I + 1, ROWS>(w, mk, wold, nl, cm_w, last, m, klim);
+        dp_rows_packed<I + 1, ROWS>(w, mk_lo, mk_hi, wold, nl, cm_w, last, m, klim, eq_next, band_next);
     }
 }
 
@@ -856,6 +871,9 @@ __global__ __launch_bounds__(256, CAH_DPP_WAVES(ROWS)) void k_dp_packed(DpArgs a
         Chunk cur = load_chunk(q, pos, n, valid ? max_n : 0);
         Chunk nxt = load_chunk(q, pos + 16, n, valid ? max_n : 0);
         int left = 16;
+#ifdef CAH_DP_COUNT
+        int dbg_cols = 0, dbg_rows = 0, dbg_ideal = 0;
+#endif
         unsigned bad_chars = cur.w[0] | cur.w[1] | cur.w[2] | cur.w[3];
         uint64_t mk_next = s_rowmask[cur.w[0] & (CAH_TABLE_CHARS - 1)];
         for (;;) {
@@ -878,9 +896,17 @@ __global__ __launch_bounds__(256, CAH_DPP_WAVES(ROWS)) void k_dp_packed(DpArgs a
                 ++j;
                 // row 0 is the same in every column (start_in_query: cost 0, score 0, origin j);
                 // it is also the diagonal of row 1
+#ifdef CAH_DP_COUNT
+                {
+                    int wmax = 0;
+                    for (int t = ROWS; t >= 1; --t) if (__any(last >= t)) { wmax = t; break; }
+                    dbg_cols += 1; dbg_rows += min(ROWS, wmax + (wmax & 1)); dbg_ideal += last;
+                }
+#endif
                 int nl = 0;                               // row 0 always has cost 0 <= k
                 unsigned cm_w = w_row0;                   // (m == 0: the candidate cell is row 0)
-                dp_rows_packed<1, ROWS>(w, mk, w_row0, nl, cm_w, last, m, klim);
+                dp_rows_packed<1, ROWS>(w, (unsigned)mk, (unsigned)(mk >> 32), w_row0, nl, cm_w, last, m, klim,
+                                        ((unsigned)mk & 1u) != 0u, 1 <= last);
                 last_filled = last;                       // :484
                 if (last >= 1) lf_ran = last;
                 if (nl < m) {                             // band update (:490-495)
@@ -904,6 +930,13 @@ __global__ __launch_bounds__(256, CAH_DPP_WAVES(ROWS)) void k_dp_packed(DpArgs a
             }
         }
         if (bad_chars & 0x80808080u) invalid = true;
+#ifdef CAH_DP_COUNT
+        if (valid) { atomicAdd(&g_dp_dbg[2], (unsigned long long)dbg_ideal); atomicAdd(&g_dp_dbg[3], 1ull);
+                     atomicAdd(&g_dp_dbg[5], (unsigned long long)(j - min_n)); }
+        if (lane == 0) { atomicAdd(&g_dp_dbg[0], (unsigned long long)__builtin_amdgcn_readfirstlane(dbg_cols));
+                         atomicAdd(&g_dp_dbg[1], (unsigned long long)__builtin_amdgcn_readfirstlane(dbg_rows));
+                         atomicAdd(&g_dp_dbg[4], 1ull); }
+#endif
 
         // last column (:536-572); max_n == n always for BACK.  Cells were written in column j (the
         // last one processed), so origin = j - rel.  The stale `origin` of :565 is that of the
@@ -1147,3 +1180,12 @@ hipError_t launch_init_best(int32_t* best_adapter, int64_t n_reads, int n_cus, h
     hipLaunchKernelGGL(k_init_best, dim3(grid), dim3(256), 0, s, best_adapter, n_reads);
     return hipGetLastError();
 }
+
+#ifdef CAH_DP_COUNT
+extern "C" int cah_debug_dp_counters(unsigned long long* out8, int reset) {
+    unsigned long long z[8] = {0};
+    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_dp_dbg), sizeof(z)) != hipSuccess) return 1;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_dp_dbg), z, sizeof(z)) != hipSuccess) return 1;
+    return 0;
+}
+#endif
