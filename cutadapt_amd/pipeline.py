@@ -570,7 +570,7 @@ class BatchTrimmer:
     def __init__(self, adapters=(), times: int = 1, action: Optional[str] = "trim", index: bool = True,
                  nextseq_trim: Optional[int] = None, quality_cutoff: Optional[Tuple[int, int]] = None,
                  quality_base: int = 33, poly_a: bool = False, max_expected_errors: Optional[float] = None,
-                 device=None):
+                 cut: Sequence[int] = (), length: Optional[int] = None, device=None):
         adapters = list(adapters._adapters) if isinstance(adapters, MultipleAdapters) else \
             ([adapters] if isinstance(adapters, (SingleAdapter, LinkedAdapter)) else list(adapters))
         self.cutter = BatchAdapterCutter(adapters, times=times, action=action, index=index, device=device) if adapters else None
@@ -582,9 +582,16 @@ class BatchTrimmer:
         self.max_expected_errors = max_expected_errors
         self.too_many_expected_errors = 0
         self.device = device
-        pre = nextseq_trim is not None or quality_cutoff is not None
+        self.cut = [int(c) for c in cut if int(c) != 0]       # UnconditionalCutter(s), modifiers.py:55-79
+        if len(self.cut) > 2:
+            raise ValueError("You cannot remove bases from more than two ends.")
+        if len(self.cut) == 2 and self.cut[0] * self.cut[1] > 0:
+            raise ValueError("You cannot remove bases from the same end twice.")
+        self.length = length                                   # Shortener, modifiers.py:882-899
+        pre = nextseq_trim is not None or quality_cutoff is not None or bool(self.cut)
         if (pre or poly_a) and action in ("mask", "lowercase"):
             raise NotImplementedError("mask/lowercase together with quality or poly-A trimming is not built yet")
+        self.filtered: Dict[str, int] = {}
         self.nextseq_trimmed_bases = 0
         self.quality_trimmed_bases = 0
         self.poly_a_trimmed_lengths: Dict[int, int] = {}
@@ -598,13 +605,17 @@ class BatchTrimmer:
             setattr(self, name, getattr(self, name) + getattr(other, name))
         for k, c in other.poly_a_trimmed_lengths.items():
             self.poly_a_trimmed_lengths[k] = self.poly_a_trimmed_lengths.get(k, 0) + c
+        for k, c in other.filtered.items():
+            self.filtered[k] = self.filtered.get(k, 0) + c
         if self.cutter is not None and other.cutter is not None:
             self.cutter.histogram += other.cutter.histogram
             for name in ("reads", "with_adapters", "bp_in", "bp_out"):
                 setattr(self.cutter, name, getattr(self.cutter, name) + getattr(other.cutter, name))
 
-    def process_chunk(self, chunk: FastqChunk, discard_untrimmed: bool = False, discard_trimmed: bool = False,
-                      info: Optional[list] = None) -> bytes:
+    def modify(self, chunk: FastqChunk, info: Optional[list] = None) -> Dict[str, object]:
+        """All read-modifying steps for one chunk -> per-read arrays: the window (beg, end) of the
+        original read that is left, whether an adapter was found, the output mode and (with
+        --max-ee) the expected errors of what is left."""
         import torch
         from . import qualtrim as qt
         from .batch import ReadBatch
@@ -612,12 +623,12 @@ class BatchTrimmer:
         n = len(offsets) - 1
         lens = (offsets[1:] - offsets[:-1]).astype(np.int64)
         wbeg, wend = np.zeros(n, dtype=np.int64), lens.copy()
-        pre = self.nextseq_trim is not None or self.quality_cutoff is not None
-        if info is not None and (pre or self.poly_a):
-            raise NotImplementedError("--info-file together with quality or poly-A trimming is not built yet")
+        pre = self.nextseq_trim is not None or self.quality_cutoff is not None or bool(self.cut)
+        if info is not None and (pre or self.poly_a or self.length is not None):
+            raise NotImplementedError("--info-file together with other modifiers is not built yet")
         base = ReadBatch.from_host(seqs, offsets, device=self.device) if n else None
         quals = None
-        if pre and n:
+        if (self.nextseq_trim is not None or self.quality_cutoff is not None) and n:
             q = chunk.pack_qualities()
             if q is None:
                 raise qt.HasNoQualities("Cannot do quality trimming when no qualities are available")
@@ -628,6 +639,12 @@ class BatchTrimmer:
             l = torch.from_numpy((wend - wbeg).astype(np.int32)).to(base.device)
             return o, l
 
+        for c in self.cut:                                   # read[c:] / read[:c]
+            cur = wend - wbeg
+            if c > 0:
+                wbeg = wbeg + np.minimum(c, cur)
+            else:
+                wend = wbeg + np.maximum(cur + c, 0)
         if self.nextseq_trim is not None and n:
             o, l = view_args()
             stop = qt.nextseq_trim_batch(base.seqs, quals, o, l, n, self.nextseq_trim, self.quality_base).astype(np.int64)
@@ -656,9 +673,15 @@ class BatchTrimmer:
             for k, c in zip(removed.tolist(), counts.tolist()):
                 self.poly_a_trimmed_lengths[k] = self.poly_a_trimmed_lengths.get(k, 0) + c
             wend = wbeg + idx
-        keep = matched if discard_untrimmed else (~matched if discard_trimmed else None)
+        if self.length is not None:
+            cur = wend - wbeg
+            if self.length >= 0:
+                wend = wbeg + np.minimum(cur, self.length)
+            else:
+                wbeg = wend - np.minimum(cur, -self.length)
+        ee = None
         if self.max_expected_errors is not None and n:
-            # TooManyExpectedErrors (reference predicates.py): the filter sees the read as trimmed so far
+            # TooManyExpectedErrors (reference predicates.py:55-71): the filter sees the read as trimmed so far
             if quals is None:
                 q = chunk.pack_qualities()
                 if q is None:
@@ -669,14 +692,64 @@ class BatchTrimmer:
             if not valid.all():
                 bad = int(np.flatnonzero(~valid)[0])
                 raise ValueError(f"Not a valid phred value in the qualities of read {bad} of the chunk")
-            too_many = ee > self.max_expected_errors
-            passed = ~too_many if keep is None else (keep & ~too_many)
-            self.too_many_expected_errors += int((too_many if keep is None else (too_many & keep)).sum())
-            keep = passed
         self.reads += n
         self.bp_in += int(lens.sum())
-        self.bp_out += int((wend - wbeg).sum()) if mode == 0 else int(lens.sum())
-        return chunk.write_records(wbeg.astype(np.int32), wend.astype(np.int32), keep, mode)
+        return {"beg": wbeg, "end": wend, "matched": matched, "mode": mode, "ee": ee, "lens": lens}
+
+    def process_chunk(self, chunk: FastqChunk, discard_untrimmed: bool = False, discard_trimmed: bool = False,
+                      info: Optional[list] = None, minimum_length: Optional[int] = None,
+                      maximum_length: Optional[int] = None) -> bytes:
+        res = self.modify(chunk, info)
+        keep = filter_reads([res], [self], discard_untrimmed, discard_trimmed, (minimum_length,), (maximum_length,), "any")
+        return self.write(chunk, res, keep)
+
+    def write(self, chunk: FastqChunk, res: Dict[str, object], keep: Optional[np.ndarray]):
+        beg, end = res["beg"], res["end"]
+        out_len = (end - beg) if res["mode"] == 0 else res["lens"]
+        self.bp_out += int(out_len.sum() if keep is None else out_len[keep].sum())
+        return chunk.write_records(beg.astype(np.int32), end.astype(np.int32), keep, res["mode"])
+
+
+def filter_reads(results: Sequence[Dict[str, object]], trimmers: Sequence["BatchTrimmer"], discard_untrimmed: bool,
+                 discard_trimmed: bool, minimum_length: Sequence[Optional[int]], maximum_length: Sequence[Optional[int]],
+                 pair_filter: str = "any", untrimmed_pair_filter: Optional[str] = None) -> Optional[np.ndarray]:
+    """The filtering steps in the reference's order (cli.py:735-912): too short, too long, too many
+    expected errors, then --discard-trimmed / --discard-untrimmed.  ``results`` holds one entry
+    (single-end) or two (a read pair: both mates are kept or dropped together; a predicate combines
+    over the mates by ``pair_filter`` = any / both / first like PairedEndFilter, steps.py).  A mate
+    whose limit is None takes no part in that predicate.  Returns the keep mask (None = keep all)."""
+    n = len(results[0]["beg"])
+    keep = np.ones(n, dtype=bool)
+
+    def combine(preds, mode):
+        preds = [p for p in preds if p is not None]
+        if not preds:
+            return None
+        if mode == "first":
+            return preds[0]
+        out = preds[0].copy()
+        for p in preds[1:]:
+            out = (out | p) if mode == "any" else (out & p)
+        return out
+
+    lens = [r["end"] - r["beg"] if r["mode"] == 0 else r["lens"] for r in results]
+    short = combine([None if m is None else (l < m) for l, m in zip(lens, minimum_length)], pair_filter)
+    long_ = combine([None if m is None else (l > m) for l, m in zip(lens, maximum_length)], pair_filter)
+    ee = combine([None if (t.max_expected_errors is None or r["ee"] is None) else (r["ee"] > t.max_expected_errors)
+                  for r, t in zip(results, trimmers)], pair_filter)
+    for name, pred in (("too_short", short), ("too_long", long_), ("too_many_expected_errors", ee)):
+        if pred is not None:
+            hit = keep & pred
+            if name == "too_many_expected_errors":
+                trimmers[0].too_many_expected_errors += int(hit.sum())
+            else:
+                trimmers[0].filtered[name] = trimmers[0].filtered.get(name, 0) + int(hit.sum())
+            keep &= ~pred
+    if discard_trimmed:
+        keep &= ~combine([r["matched"] for r in results], pair_filter)
+    elif discard_untrimmed:
+        keep &= ~combine([~r["matched"] for r in results], untrimmed_pair_filter or pair_filter)
+    return None if keep.all() else keep
 
 
 def trim_fastq(inpath: Union[str, BinaryIO], outpath: Union[str, BinaryIO], adapters=(), times: int = 1,
@@ -684,7 +757,9 @@ def trim_fastq(inpath: Union[str, BinaryIO], outpath: Union[str, BinaryIO], adap
                info_file: Union[None, str, BinaryIO] = None, chunk_bytes: int = DEFAULT_CHUNK_BYTES,
                index: bool = True, nextseq_trim: Optional[int] = None,
                quality_cutoff: Optional[Tuple[int, int]] = None, quality_base: int = 33, poly_a: bool = False,
-               max_expected_errors: Optional[float] = None, threads: int = 1, device=None) -> Dict[str, object]:
+               max_expected_errors: Optional[float] = None, threads: int = 1, cut: Sequence[int] = (),
+               length: Optional[int] = None, minimum_length: Optional[int] = None,
+               maximum_length: Optional[int] = None, device=None) -> Dict[str, object]:
     """``cutadapt [--nextseq-trim N] [-q [FRONT,]BACK] [--quality-base B] <adapter options> [--times N]
     [--action A] [--poly-a] [--max-ee E] [--discard-(un)trimmed] [--info-file F] -o outpath inpath`` for the
     supported slice; returns the read/basepair counters the reference reports (reference
@@ -692,7 +767,7 @@ def trim_fastq(inpath: Union[str, BinaryIO], outpath: Union[str, BinaryIO], adap
     def make_trimmer():
         return BatchTrimmer(adapters, times=times, action=action, index=index, nextseq_trim=nextseq_trim,
                             quality_cutoff=quality_cutoff, quality_base=quality_base, poly_a=poly_a,
-                            max_expected_errors=max_expected_errors, device=device)
+                            max_expected_errors=max_expected_errors, cut=cut, length=length, device=device)
 
     trimmer = make_trimmer()
     out = outpath if hasattr(outpath, "write") else open(outpath, "wb")
@@ -701,12 +776,13 @@ def trim_fastq(inpath: Union[str, BinaryIO], outpath: Union[str, BinaryIO], adap
         if threads <= 1:
             for chunk in read_fastq_chunks(inpath, chunk_bytes):
                 info: Optional[list] = [] if inf is not None else None
-                out.write(trimmer.process_chunk(chunk, discard_untrimmed, discard_trimmed, info))
+                out.write(trimmer.process_chunk(chunk, discard_untrimmed, discard_trimmed, info, minimum_length,
+                                                maximum_length))
                 if inf is not None:
                     inf.write(b"".join(info))
         else:
             _trim_threaded(inpath, out, inf, trimmer, make_trimmer, threads, chunk_bytes, discard_untrimmed,
-                           discard_trimmed)
+                           discard_trimmed, minimum_length, maximum_length)
     finally:
         if out is not outpath:
             out.close()
@@ -718,7 +794,8 @@ def trim_fastq(inpath: Union[str, BinaryIO], outpath: Union[str, BinaryIO], adap
 
 
 def _trim_threaded(inpath, out, inf, trimmer: "BatchTrimmer", make_trimmer, threads: int, chunk_bytes: int,
-                   discard_untrimmed: bool, discard_trimmed: bool) -> None:
+                   discard_untrimmed: bool, discard_trimmed: bool, minimum_length: Optional[int] = None,
+                   maximum_length: Optional[int] = None) -> None:
     """The reference's reader -> workers -> ordered writer layout (runners.py:96-245) with threads
     instead of processes: the calling thread cuts the input into record-aligned raw chunks and
     writes results in chunk order, ``threads`` workers parse, pack, match (each on its own HIP
@@ -742,7 +819,8 @@ def _trim_threaded(inpath, out, inf, trimmer: "BatchTrimmer", make_trimmer, thre
         info: Optional[list] = [] if inf is not None else None
         try:
             with torch.cuda.stream(local.stream):
-                res = local.trimmer.process_chunk(chunk, discard_untrimmed, discard_trimmed, info)
+                res = local.trimmer.process_chunk(chunk, discard_untrimmed, discard_trimmed, info, minimum_length,
+                                                  maximum_length)
         finally:
             chunk.release()
         return res, (b"".join(info) if info is not None else None)
@@ -762,6 +840,102 @@ def _trim_threaded(inpath, out, inf, trimmer: "BatchTrimmer", make_trimmer, thre
         drain(0)
     for w in workers:                                       # merge the workers' statistics
         trimmer.merge(w)
+
+
+# -------------------------------------------------------------------------------------------------
+# paired-end (reference PairedEndPipeline, pipeline.py:76-158; PairedEndModifierWrapper,
+# modifiers.py:51-79; PairedEndFilter, steps.py)
+# -------------------------------------------------------------------------------------------------
+def read_paired_chunks(path1, path2, chunk_bytes: int = DEFAULT_CHUNK_BYTES) -> Iterator[Tuple[FastqChunk, FastqChunk]]:
+    """Chunks of two files with the SAME number of records (the job of dnaio.read_paired_chunks,
+    runners.py:104-113): each side is read and indexed on its own, the shorter record count wins and
+    the surplus records of the other side are carried over to the next round."""
+    L = _lib.lib()
+    files = [_open_maybe_gz(path1), _open_maybe_gz(path2)]
+    carry = [b"", b""]
+    eof = [False, False]
+    fasta: List[Optional[bool]] = [None, None]
+    while True:
+        scanned = []
+        for k in (0, 1):
+            block = b"" if eof[k] else files[k].read(chunk_bytes)
+            if not block:
+                eof[k] = True
+            data = np.frombuffer(carry[k] + block, dtype=np.uint8)
+            if fasta[k] is None and len(data):
+                fasta[k] = bool(data[0] == ord(">"))
+            if len(data) == 0:
+                scanned.append((data, np.zeros((0, 6), np.int64), 0))
+                continue
+            max_rec = (int(np.count_nonzero(data == ord(">"))) + 2) if fasta[k] else int(np.count_nonzero(data == 10)) // 4 + 2
+            rec = np.empty((max_rec, 6), dtype=np.int64)
+            n = C.c_int64(0)
+            consumed = C.c_int64(0)
+            _lib.check((L.cah_fasta_scan if fasta[k] else L.cah_fastq_scan)(
+                data.ctypes.data, len(data), int(eof[k]), max_rec, rec.ctypes.data, C.byref(n), C.byref(consumed)))
+            scanned.append((data, rec[:n.value], consumed.value))
+        n = min(len(scanned[0][1]), len(scanned[1][1]))
+        if n == 0:
+            if eof[0] and eof[1]:
+                if len(scanned[0][1]) != len(scanned[1][1]):
+                    raise ValueError("Reads are improperly paired. There are more reads in one file than in the other.")
+                break
+            if all(len(sc[0]) > 64 * chunk_bytes for sc in scanned):
+                raise ValueError("record larger than 64 chunks: not a FASTA/FASTQ file?")
+            carry = [sc[0].tobytes() for sc in scanned]
+            continue
+        pair = []
+        for k in (0, 1):
+            data, rec, consumed = scanned[k]
+            # bytes covered by the first n records: up to the start of record n (its marker character)
+            cut = consumed if n == len(rec) else int(rec[n, 0]) - 1
+            carry[k] = data[cut:].tobytes()
+            pair.append(FastqChunk(data[:cut], rec[:n]))
+        yield pair[0], pair[1]
+
+
+def trim_fastq_paired(in1, in2, out1, out2, r1: Optional[dict] = None, r2: Optional[dict] = None,
+                      pair_filter: Optional[str] = None, minimum_length=None, maximum_length=None,
+                      discard_untrimmed: bool = False, discard_trimmed: bool = False,
+                      chunk_bytes: int = DEFAULT_CHUNK_BYTES, device=None) -> Dict[str, object]:
+    """``cutadapt <R1 options> <R2 options: -A/-G/-B, -U, -Q, -L ...> -o out1 -p out2 in1 in2``:
+    ``r1`` / ``r2`` are BatchTrimmer keyword arguments for the two mates (adapters, times, action,
+    cut, nextseq_trim, quality_cutoff, quality_base, poly_a, length, max_expected_errors).
+    ``minimum_length`` / ``maximum_length``: one number for both mates or a pair (None = no limit
+    for that mate, reference ``-m 5:7``).  Pairs are filtered as a unit with ``--pair-filter``
+    any (default) / both / first; like the reference (cli.py:861-892), --discard-untrimmed uses
+    'both' when only one mate has adapters."""
+    r1, r2 = dict(r1 or {}), dict(r2 or {})
+    t1, t2 = BatchTrimmer(device=device, **r1), BatchTrimmer(device=device, **r2)
+
+    def both(v):
+        return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+
+    min_len, max_len = both(minimum_length), both(maximum_length)
+    mode = "any" if pair_filter is None else pair_filter
+    if mode not in ("any", "both", "first"):
+        raise ValueError("pair_filter must be any, both or first")
+    one_sided = t1.cutter is None or t2.cutter is None
+    untrimmed_mode = "both" if (one_sided and discard_untrimmed) else mode
+    o1 = out1 if hasattr(out1, "write") else open(out1, "wb")
+    o2 = out2 if hasattr(out2, "write") else open(out2, "wb")
+    pairs = kept = 0
+    try:
+        for c1, c2 in read_paired_chunks(in1, in2, chunk_bytes):
+            res1, res2 = t1.modify(c1), t2.modify(c2)
+            keep = filter_reads([res1, res2], [t1, t2], discard_untrimmed, discard_trimmed, min_len, max_len, mode,
+                                untrimmed_mode)
+            o1.write(t1.write(c1, res1, keep))
+            o2.write(t2.write(c2, res2, keep))
+            pairs += len(c1)
+            kept += len(c1) if keep is None else int(keep.sum())
+    finally:
+        if o1 is not out1:
+            o1.close()
+        if o2 is not out2:
+            o2.close()
+    return {"pairs": pairs, "pairs_written": kept, "trimmers": (t1, t2), "filtered": dict(t1.filtered),
+            "with_adapters": (t1.cutter.with_adapters if t1.cutter else 0, t2.cutter.with_adapters if t2.cutter else 0)}
 
 
 # -------------------------------------------------------------------------------------------------

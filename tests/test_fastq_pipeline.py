@@ -277,3 +277,53 @@ def test_pipeline_rounds_against_reference_adapter_cutter_semantics(hip, orc):
         exp = expected_intervals(times, action)
         got = list(zip(res["beg"].tolist(), res["end"].tolist(), res["matched"].tolist()))
         assert got == exp, (times, action, [(i, g, e) for i, (g, e) in enumerate(zip(got, exp)) if g != e][:3])
+
+
+def test_paired_chunks_stay_in_step():
+    """host only: two files cut into chunks with equal record counts, whatever the chunk size"""
+    from cutadapt_amd.pipeline import read_paired_chunks
+    r1 = "".join(f"@p{i}/1\n{'ACGT' * (i % 7)}\n+\n{'IIII' * (i % 7)}\n" for i in range(200)).encode()
+    r2 = "".join(f"@p{i}/2\n{'TTGCA' * (i % 11)}\n+\n{'#####' * (i % 11)}\n" for i in range(200)).encode()
+    for chunk_bytes in (50, 777, 1 << 20):
+        total = 0
+        for c1, c2 in read_paired_chunks(io.BytesIO(r1), io.BytesIO(r2), chunk_bytes):
+            assert len(c1) == len(c2) and len(c1) > 0
+            for j in range(len(c1)):
+                a = bytes(c1.buf[c1.rec[j, 0]:c1.rec[j, 1]]); b = bytes(c2.buf[c2.rec[j, 0]:c2.rec[j, 1]])
+                assert a[:-2] == b[:-2] and a.endswith(b"/1") and b.endswith(b"/2")
+            total += len(c1)
+        assert total == 200
+    with pytest.raises(ValueError, match="improperly paired"):
+        list(read_paired_chunks(io.BytesIO(r1), io.BytesIO(r2[: len(r2) // 2].rsplit(b"@", 1)[0]), 1 << 20))
+
+
+@pytest.mark.gpu
+def test_reference_paired_goldens(hip):
+    """20 command lines of reference tests/test_paired.py: per-mate adapters, -q/-Q, -u/-U, -l/-L,
+    --nextseq-trim, -m/-M, --pair-filter, --discard-(un)trimmed; both outputs byte for byte"""
+    from cutadapt_amd.pipeline import adapter_from_spec, trim_fastq_paired
+    PD = os.path.join(os.path.dirname(FQ), "paired")
+    manifest = json.load(open(os.path.join(PD, "manifest.json")))
+    assert len(manifest) >= 20
+    kinds = {"-a": "back", "-g": "front", "-b": "anywhere"}
+
+    def mate(opts):
+        opts = dict(opts)
+        params = opts.pop("params", {})
+        ads = [adapter_from_spec(spec, kinds[o], **params) for o, spec in opts.pop("adapters", [])]
+        if "quality_cutoff" in opts:
+            opts["quality_cutoff"] = tuple(opts["quality_cutoff"])
+        return dict(adapters=ads, **opts)
+
+    for case in manifest:
+        for chunk_bytes in (4 << 20, 300):
+            o1, o2 = io.BytesIO(), io.BytesIO()
+            stats = trim_fastq_paired(os.path.join(PD, case["in1"]), os.path.join(PD, case["in2"]), o1, o2,
+                                      mate(case["r1"]), mate(case["r2"]), chunk_bytes=chunk_bytes, **case["top"])
+            assert o1.getvalue() == open(os.path.join(PD, case["exp1"]), "rb").read(), (case["name"], chunk_bytes, 1)
+            assert o2.getvalue() == open(os.path.join(PD, case["exp2"]), "rb").read(), (case["name"], chunk_bytes, 2)
+        exp = open(os.path.join(PD, case["exp1"]), "rb").read()
+        n_out = exp.count(b">") if exp.startswith(b">") else exp.count(b"\n") // 4
+        assert stats["pairs_written"] == n_out, case["name"]
+        if case["name"] == "paired_end":
+            assert stats["pairs"] - stats["pairs_written"] == stats["filtered"].get("too_short", 0) == 1
