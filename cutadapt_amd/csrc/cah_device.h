@@ -10,8 +10,12 @@
 
 #define CAH_MAX_M 64           // adapter length limit: one 64-bit row bitset per read char
 #define CAH_TABLE_CHARS 128    // ASCII; bytes >= 0x80 are invalid input
+#ifndef CAH_FILTER_SLOTS
 #define CAH_FILTER_SLOTS 6      // packed 64-bit k-mer words the prefilter advances together (state in VGPRs)
+#endif
+#ifndef CAH_FILTER_SLOTS_NARROW
 #define CAH_FILTER_SLOTS_NARROW 8   // ... when every word of the plan fits 32 bits
+#endif
 
 // Packed DP cell payload (one VGPR): ((origin + CAH_ORIGIN_BIAS) << 12) + (score + CAH_SCORE_BIAS)
 // origin in [-64, 1e6], score in [-2048, 2047] (bounds derived in DESIGN.md); match/mismatch/
