@@ -144,6 +144,9 @@ __device__ __forceinline__ unsigned chunk_byte(const Chunk& c, int t) {
 // =============================================================================================
 #include <type_traits>
 
+#ifndef CAH_FILTER_ADD_TRICK
+#define CAH_FILTER_ADD_TRICK 1
+#endif
 #ifndef CAH_SUBCHUNK
 #define CAH_SUBCHUNK 1          // resolve the first hit to a 4-column group inside its 16-column chunk
 #endif
@@ -183,7 +186,19 @@ __device__ __forceinline__ void filter_word_chunk(const Chunk& ck, const T* tbl,
                 const unsigned ch = chunk_byte(ck, t) & (CAH_TABLE_CHARS - 1);
                 W mk = (W)tbl[ch];
                 if (MASKED) mk = (t >= lo && t < hi) ? mk : (W)0;
+#if CAH_FILTER_ADD_TRICK
+                if constexpr (sizeof(W) == 4) {
+                    // R << 1 as an explicit add: the compiler canonicalises R + R into v_lshlrev_b32
+                    // (4 issue cycles on gfx950), v_add_u32 takes 2
+                    unsigned dbl;
+                    asm("v_add_u32 %0, %1, %1" : "=v"(dbl) : "v"((unsigned)R));
+                    R = (W)((dbl | (unsigned)init) & (unsigned)mk);
+                } else {
+                    R = ((R + R) | init) & mk;
+                }
+#else
                 R = ((R + R) | init) & mk;
+#endif
                 acc |= R;
             }
             if (CAH_SUBCHUNK && g4 < 3 && (CAH_KEY_SHIFT == 2 || g4 <= 1)) gg[CAH_KEY_SHIFT == 2 ? g4 : 1] |= acc & found;
