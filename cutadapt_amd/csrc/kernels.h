@@ -5,9 +5,7 @@
 
 #include "cah_device.h"
 
-#ifndef CAH_KEY_SHIFT
-#define CAH_KEY_SHIFT 2            // key resolution: 1 << CAH_KEY_SHIFT read columns (2 or 4)
-#endif
+#define CAH_KEY_SHIFT 2            // queue key resolution: 4 read columns
 #define CAH_QUEUE_BINS 256         // survivor queue is ordered by key = min(first-hit position >> CAH_KEY_SHIFT, 255)
 
 struct FilterArgs {

@@ -144,12 +144,6 @@ __device__ __forceinline__ unsigned chunk_byte(const Chunk& c, int t) {
 // =============================================================================================
 #include <type_traits>
 
-#ifndef CAH_FILTER_ADD_TRICK
-#define CAH_FILTER_ADD_TRICK 1
-#endif
-#ifndef CAH_SUBCHUNK
-#define CAH_SUBCHUNK 1          // resolve the first hit to a 4-column group inside its 16-column chunk
-#endif
 
 __device__ __forceinline__ void word_window(const int wstart, const int wstop, const int n,
                                             int& ws, int& we) {
@@ -186,7 +180,6 @@ __device__ __forceinline__ void filter_word_chunk(const Chunk& ck, const T* tbl,
                 const unsigned ch = chunk_byte(ck, t) & (CAH_TABLE_CHARS - 1);
                 W mk = (W)tbl[ch];
                 if (MASKED) mk = (t >= lo && t < hi) ? mk : (W)0;
-#if CAH_FILTER_ADD_TRICK
                 if constexpr (sizeof(W) == 4) {
                     // R << 1 as an explicit add: the compiler canonicalises R + R into v_lshlrev_b32
                     // (4 issue cycles on gfx950), v_add_u32 takes 2
@@ -196,12 +189,9 @@ __device__ __forceinline__ void filter_word_chunk(const Chunk& ck, const T* tbl,
                 } else {
                     R = ((R + R) | init) & mk;
                 }
-#else
-                R = ((R + R) | init) & mk;
-#endif
                 acc |= R;
             }
-            if (CAH_SUBCHUNK && g4 < 3 && (CAH_KEY_SHIFT == 2 || g4 <= 1)) gg[CAH_KEY_SHIFT == 2 ? g4 : 1] |= acc & found;
+            if (g4 < 3) gg[g4] |= acc & found;
         }
     }
 }
@@ -217,9 +207,6 @@ __device__ __forceinline__ void filter_word_chunk(const Chunk& ck, const T* tbl,
 #endif
 #define FILTER_WAVES 4
 
-#ifndef CAH_FILTER_PREFETCH
-#define CAH_FILTER_PREFETCH 1      // chunks requested ahead of the one being processed
-#endif
 #ifndef CAH_FILTER_WAVES
 #define CAH_FILTER_WAVES 4
 #endif
@@ -313,17 +300,10 @@ __global__ __launch_bounds__(256, CAH_FILTER_WAVES) void k_filter(FilterArgs a) 
 
                 int pos = lo;
                 Chunk cur = load_chunk(q, pos, n, hi);
-#if CAH_FILTER_PREFETCH == 2
-                Chunk nxt = load_chunk(q, pos + 16, n, hi);
-#endif
                 for (;;) {
                     const bool live = !hit && pos < hi;
                     if (!__any(live)) break;
-#if CAH_FILTER_PREFETCH == 2
-                    const Chunk nxt2 = load_chunk(q, pos + 32, n, live ? hi : 0);    // two chunks ahead
-#else
-                    const Chunk nxt = load_chunk(q, pos + 16, n, live ? hi : 0);
-#endif
+                    const Chunk nxt = load_chunk(q, pos + 16, n, live ? hi : 0);      // one chunk ahead
                     seen |= cur.w[0] | cur.w[1] | cur.w[2] | cur.w[3];
                     word_t any_found = 0;
                     word_t gg[3] = {0, 0, 0};             // found bits after 4 / 8 / 12 characters of the chunk
@@ -354,13 +334,10 @@ __global__ __launch_bounds__(256, CAH_FILTER_WAVES) void k_filter(FilterArgs a) 
                         // a lane leaves at its first hit, so no found bit was set before this chunk:
                         // the first group accumulator that shows one names the 4-column group
                         hit = true;
-                        hit_pos = pos + (!CAH_SUBCHUNK ? 0 : CAH_KEY_SHIFT == 2 ? (gg[0] ? 0 : gg[1] ? 4 : gg[2] ? 8 : 12) : (gg[1] ? 0 : 8));
+                        hit_pos = pos + (gg[0] ? 0 : gg[1] ? 4 : gg[2] ? 8 : 12);
                     }
                     pos += 16;
                     cur = nxt;
-#if CAH_FILTER_PREFETCH == 2
-                    nxt = nxt2;
-#endif
                 }
             }
             if (seen & 0x80808080u) invalid = true;
@@ -757,9 +734,6 @@ __device__ __forceinline__ int pk_score(unsigned w) { return (int)(w & 0x1FFu) -
 #ifdef CAH_DP_COUNT
 __device__ unsigned long long g_dp_dbg[8];      // debug build only: lock-step accounting of k_dp_packed
 #endif
-#ifndef CAH_DPP_PIPELINE
-#define CAH_DPP_PIPELINE 1          // issue the next row's predicates between a compare and its select
-#endif
 template <int I, int ROWS>
 __device__ __forceinline__ void dp_rows_packed(unsigned (&w)[ROWS + 1], const unsigned mk_lo, const unsigned mk_hi,
                                                unsigned wd, int& nl, unsigned& cm_w, const int last, const int m,
@@ -789,9 +763,7 @@ __device__ __forceinline__ void dp_rows_packed(unsigned (&w)[ROWS + 1], const un
         const unsigned mword = I < 32 ? mk_lo : mk_hi;    // predicates of row I + 1
         const bool eq_next = (mword & (1u << (I & 31))) != 0u;
         const bool band_next = I + 1 <= last;
-#if CAH_DPP_PIPELINE
         __builtin_amdgcn_sched_barrier(0);
-#endif
         nl = ok ? I : nl;
         if constexpr ((I % CAH_SCHED_ROWS) == 0) __builtin_amdgcn_sched_barrier(0);
         dp_rows_packed<I + 1, ROWS>(w, mk_lo, mk_hi, wold, nl, cm_w, last, m, klim, eq_next, band_next);
