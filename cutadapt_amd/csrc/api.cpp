@@ -143,6 +143,7 @@ struct PlanDeviceCopy {
     int n_cus = 256;
     CahMatcher* d_matchers = nullptr;     // HBM
     CahKmerWord* d_words = nullptr;
+    CahLeanFilter* d_lean = nullptr;      // one per matcher (ok = 0 where the lean prefilter does not apply)
 };
 
 // Host tables are built (and validated) at creation; the HBM copy for a device is made the
@@ -150,6 +151,7 @@ struct PlanDeviceCopy {
 struct cah_plan {
     std::vector<CahMatcher> matchers;     // host copies
     std::vector<CahKmerWord> words;
+    std::vector<CahLeanFilter> lean;
     mutable std::mutex mu;
     mutable PlanDeviceCopy dev[CAH_MAX_DEVICES];
 };
@@ -176,10 +178,63 @@ static int plan_on_device(const cah_plan* plan, const PlanDeviceCopy** out) {
             HIP_TRY(hipMemcpy(dc.d_words, plan->words.data(), sizeof(CahKmerWord) * plan->words.size(),
                               hipMemcpyHostToDevice));
         }
+        HIP_TRY(hipMalloc((void**)&dc.d_lean, sizeof(CahLeanFilter) * plan->lean.size()));
+        HIP_TRY(hipMemcpy(dc.d_lean, plan->lean.data(), sizeof(CahLeanFilter) * plan->lean.size(), hipMemcpyHostToDevice));
         dc.ready = true;
     }
     *out = &dc;
     return CAH_OK;
+}
+
+// The lean prefilter of a matcher (see CahLeanFilter): possible when every search set is a whole-read
+// set (0, None) or a tail set (-L, None), every k-mer fits 32 bits and the packing fits the kernel's
+// word and gate counts.  Same matches as the generic packing: kmers_present is an OR over k-mers, a
+// k-mer of (-L, None) is found iff it occurs with start >= n - L, which is what a gated start bit says.
+static void build_lean_filter(const cah_adapter_desc& d, CahLeanFilter& lf) {
+    memset(&lf, 0, sizeof(lf));
+    if (d.n_kmer_sets <= 0 || !d.kmer_sets) return;
+    const bool rwc = d.kmer_ref_wildcards != 0, qwc = d.kmer_query_wildcards != 0;
+    struct Item { const char* kmer; int len; int L; };            // L = 0: whole read
+    std::vector<Item> lead, tail;
+    for (int s = 0; s < d.n_kmer_sets; s++) {
+        const cah_kmer_set& ks = d.kmer_sets[s];
+        if (ks.stop != 0 || ks.start > 0 || ks.start < -(int64_t)CAH_MAX_READ_LEN) return;
+        for (int t = 0; t < ks.n_kmers; t++) {
+            const char* k = ks.kmers[t];
+            if (!k) return;
+            const size_t len = strlen(k);
+            if (len == 0 || len > 32 || !is_ascii(k, len)) return;
+            (ks.start == 0 ? lead : tail).push_back(Item{k, (int)len, (int)-ks.start});
+        }
+    }
+    std::stable_sort(tail.begin(), tail.end(), [](const Item& a, const Item& b) { return a.L > b.L; });
+    int w = -1, used = 32;
+    auto place = [&](const Item& it, bool is_lead) -> bool {
+        if (used + it.len > 32) {
+            if (++w >= CAH_LEAN_WORDS) return false;
+            used = 0;
+        }
+        const uint32_t start_bit = 1u << used;
+        for (int p = 0; p < it.len; p++)
+            for (int qc = 0; qc < CAH_TABLE_CHARS; qc++)
+                if (kmer_chars_match((uint8_t)it.kmer[p], (uint8_t)qc, rwc, qwc)) lf.mask[w][qc] |= 1u << (used + p);
+        lf.found[w] |= 1u << (used + it.len - 1);
+        if (is_lead) {
+            lf.lead_init[w] |= start_bit;
+        } else {
+            if (it.L > CAH_LEAN_SPAN) return false;
+            for (int dist = 1; dist <= it.L; dist++) lf.init_by_dist[w][dist] |= start_bit;
+            lf.tail_span = std::max(lf.tail_span, it.L);
+        }
+        used += it.len;
+        return true;
+    };
+    for (const Item& it : lead) if (!place(it, true)) return;
+    lf.n_lead = w + 1;
+    used = 32;                                                   // tail k-mers start a new word
+    for (const Item& it : tail) if (!place(it, false)) return;
+    lf.n_words = w + 1;
+    lf.ok = lf.n_words >= 1 ? 1 : 0;
 }
 
 static int build_matcher(const cah_adapter_desc& d, int index, CahMatcher& mt,
@@ -393,9 +448,14 @@ int cah_plan_create(const cah_adapter_desc* adapters, int32_t n_adapters, cah_pl
     if (n_adapters < 1 || !adapters) return fail(CAH_EINVAL, "need at least one adapter");
     cah_plan* plan = new cah_plan();
     plan->matchers.resize((size_t)n_adapters);
+    plan->lean.resize((size_t)n_adapters);
     for (int i = 0; i < n_adapters; i++) {
         int rc = build_matcher(adapters[i], i, plan->matchers[(size_t)i], plan->words);
         if (rc != CAH_OK) { delete plan; return rc; }
+        build_lean_filter(adapters[i], plan->lean[(size_t)i]);
+#ifdef CAH_NO_LEAN
+        plan->lean[(size_t)i].ok = 0;                 // A/B builds
+#endif
     }
     *out = plan;
     return CAH_OK;
@@ -411,6 +471,7 @@ void cah_plan_destroy(cah_plan* plan) {
         (void)hipSetDevice(d);
         if (dc.d_matchers) (void)hipFree(dc.d_matchers);
         if (dc.d_words) (void)hipFree(dc.d_words);
+        if (dc.d_lean) (void)hipFree(dc.d_lean);
     }
     if (cur >= 0) (void)hipSetDevice(cur);
     delete plan;
@@ -498,6 +559,7 @@ int cah_profile_read(double ms[CAH_PROF_N], int64_t launches[CAH_PROF_N], int64_
 //   [1024, +4n) queue | [.., +n) queue keys
 static const size_t WS_HEADER = 1024;
 static const size_t WS_QCOUNT = 256 / sizeof(unsigned long long), WS_DPWORK = 512 / sizeof(unsigned long long);
+static const size_t WS_UFLAG = 768 / sizeof(unsigned long long);    // 0 after the check: all reads of the batch have one length
 
 static size_t ws_queue_bytes(int64_t n_reads) { return (sizeof(int32_t) * (size_t)n_reads + 255) & ~(size_t)255; }
 
@@ -564,7 +626,7 @@ static int run_filter(const cah_plan* plan, const PlanDeviceCopy* pd, int32_t ad
                       const int64_t* d_offsets, const int32_t* d_lens, int64_t n_reads, int mode,
                       uint8_t* d_present, uint8_t* d_status, int32_t* d_queue,
                       unsigned long long* d_queue_count, uint8_t* d_queue_keys,
-                      unsigned long long* d_work_counter, hipStream_t s) {
+                      unsigned long long* d_work_counter, const unsigned long long* d_batch_flag, hipStream_t s) {
     const CahMatcher& mt = plan->matchers[(size_t)adapter];
     if (mt.n_words > 1024)
         return fail(CAH_EUNSUPPORTED, "adapter %d: %d packed k-mer words exceed the 1024-word limit of the prefilter kernel",
@@ -577,9 +639,18 @@ static int run_filter(const cah_plan* plan, const PlanDeviceCopy* pd, int32_t ad
     f.work_counter = d_work_counter;
     f.present = d_present; f.status = d_status; f.queue = d_queue; f.queue_count = d_queue_count;
     f.queue_keys = d_queue_keys;
+    f.batch_flag = nullptr;
+    f.lean = nullptr;
     HIP_TRY(hipMemsetAsync(d_work_counter, 0, sizeof(unsigned long long), s));
     if (d_queue_count) HIP_TRY(hipMemsetAsync(d_queue_count, 0, sizeof(unsigned long long), s));
     ProfScope ps(s, CAH_PROF_FILTER, n_reads);
+    if (d_batch_flag && !d_lens && plan->lean[(size_t)adapter].ok) {
+        // two launches, one of them leaves at once: the lean kernel runs when the batch check found all
+        // reads to have one length (*d_batch_flag == 0), the general kernel otherwise -- no host sync
+        f.batch_flag = d_batch_flag;
+        f.lean = pd->d_lean + adapter;
+        HIP_TRY(launch_filter_lean(f, mode, pd->n_cus, s));
+    }
     HIP_TRY(launch_filter(f, mode, mt.narrow_words != 0, pd->n_cus, s));
     return CAH_OK;
 }
@@ -606,7 +677,7 @@ int cah_kmers_present_batch(const cah_plan* plan, int32_t adapter, const uint8_t
     unsigned long long* d_counter = nullptr;
     HIP_TRY(hipMalloc((void**)&d_counter, sizeof(unsigned long long)));
     rc = run_filter(plan, pd, adapter, d_seqs, d_offsets, d_lens, n_reads, 0, d_present, nullptr, nullptr,
-                    nullptr, nullptr, d_counter, s);
+                    nullptr, nullptr, d_counter, nullptr, s);
     hipError_t e = hipStreamSynchronize(s);
     (void)hipFree(d_counter);
     if (rc) return rc;
@@ -633,13 +704,25 @@ int cah_match_batch(const cah_plan* plan, const uint8_t* d_seqs, const int64_t* 
     HIP_TRY(hipMemsetAsync(d_status, 0, (size_t)n_reads, s));
     HIP_TRY(hipMemsetAsync(d_out6, 0, sizeof(int32_t) * 6 * (size_t)n_reads, s));
     if (d_best_adapter) HIP_TRY(launch_init_best(d_best_adapter, n_reads, pd->n_cus, s));
+    // one pass over the offsets decides, on the device, which prefilter kernel works on this batch
+    const unsigned long long* d_batch_flag = nullptr;
+    if (!d_lens) {
+        bool any_lean = false;
+        for (size_t ad = 0; ad < plan->matchers.size(); ad++)
+            any_lean |= plan->matchers[ad].has_filter && plan->matchers[ad].kind != CAH_KIND_KMER_ONLY && plan->lean[ad].ok;
+        if (any_lean) {
+            HIP_TRY(hipMemsetAsync(counters + WS_UFLAG, 0, sizeof(unsigned long long), s));
+            HIP_TRY(launch_uniform_check(d_offsets, n_reads, CAH_MAX_READ_LEN, counters + WS_UFLAG, pd->n_cus, s));
+            d_batch_flag = counters + WS_UFLAG;
+        }
+    }
     for (int32_t ad = 0; ad < (int32_t)plan->matchers.size(); ad++) {
         const CahMatcher& mt = plan->matchers[(size_t)ad];
         if (mt.kind == CAH_KIND_KMER_ONLY) continue;
         if (mt.has_filter) {
             // prefilter -> queue of surviving reads -> DP on dense waves
             rc = run_filter(plan, pd, ad, d_seqs, d_offsets, d_lens, n_reads, 1, nullptr, d_status, d_queue,
-                            counters + WS_QCOUNT, d_keys, counters + 0, s);
+                            counters + WS_QCOUNT, d_keys, counters + 0, d_batch_flag, s);
             if (rc) return rc;
             rc = run_aligner(plan, pd, ad, d_seqs, d_offsets, d_lens, n_reads, d_queue, counters + WS_QCOUNT,
                              d_keys, counters + WS_DPWORK, d_out6, d_status, d_best_adapter, 1, s);

@@ -54,3 +54,27 @@ struct CahKmerWord {
     uint64_t found_mask;       // bit at every k-mer end             _kmer_finder.pyx:147
     uint64_t mask[CAH_TABLE_CHARS];
 };
+
+// ---------------------------------------------------------------------------------------------
+// Lean prefilter for plans whose search sets are all "whole read" (start 0, stop None) or "last L
+// characters" (start -L, stop None) -- what kmer_heuristic builds for 3' adapters -- on batches
+// whose reads all have the same length.  Tail k-mers of ALL window lengths share words: a k-mer of
+// the set (-L, None) may only START at positions >= n - L, so its start bit is injected only there
+// (a start-bit table indexed by the distance from the read end); no per-lane window bookkeeping and
+// no per-character masks are left.
+// ---------------------------------------------------------------------------------------------
+#define CAH_LEAN_WORDS 6
+#define CAH_LEAN_SPAN 64                          // longest tail window the lean kernel takes
+struct CahLeanFilter {
+    int32_t ok;                                   // 1: this matcher can use k_filter_lean
+    int32_t n_words;                              // lead words first, then tail words
+    int32_t n_lead;
+    int32_t tail_span;                            // longest tail window
+    uint32_t found[CAH_LEAN_WORDS];               // bit at every k-mer end
+    uint32_t lead_init[CAH_LEAN_WORDS];           // start bits of a lead word (0 for tail words)
+    // start bits of a tail word that are open at distance d = n - p from the read end (d = 1 is the
+    // last character): the k-mers of every set (-L, None) with L >= d; entry 0 and entries beyond the
+    // span are 0
+    uint32_t init_by_dist[CAH_LEAN_WORDS][CAH_LEAN_SPAN + 2];
+    uint32_t mask[CAH_LEAN_WORDS][CAH_TABLE_CHARS];
+};

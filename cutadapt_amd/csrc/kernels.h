@@ -21,7 +21,10 @@ struct FilterArgs {
     uint8_t* status;                 // MODE 1: only written for invalid reads
     int32_t* queue;                  // MODE 1: surviving read indices, in runs ordered by hit position
     unsigned long long* queue_count; // MODE 1: zeroed before launch
-    uint8_t* queue_keys;             // MODE 1: per queue entry, min(first-hit position / 16, 63)
+    uint8_t* queue_keys;             // MODE 1: per queue entry, min(first-hit position >> CAH_KEY_SHIFT, 255)
+    const unsigned long long* batch_flag;   // may be NULL; k_filter leaves at once if *batch_flag == 0 (all reads
+                                            // have one length: k_filter_lean took the batch), k_filter_lean if != 0
+    const CahLeanFilter* lean;       // k_filter_lean only
 };
 
 struct DpArgs {
@@ -42,6 +45,9 @@ struct DpArgs {
     int32_t merge_best;              // 0: overwrite (locate_batch); 1: keep best (match_batch)
 };
 
+hipError_t launch_filter_lean(const FilterArgs& a, int mode, int n_cus, hipStream_t s);
+hipError_t launch_uniform_check(const int64_t* offsets, int64_t n_reads, int64_t max_read_len, unsigned long long* flag,
+                                int n_cus, hipStream_t s);
 hipError_t launch_filter(const FilterArgs& a, int mode, bool narrow_words, int n_cus, hipStream_t s);
 hipError_t launch_dp(const DpArgs& a, int m, bool unit_indel_cost, bool back_adapter, int64_t max_items, int n_cus,
                      hipStream_t s);

@@ -223,6 +223,7 @@ __global__ __launch_bounds__(256, CAH_FILTER_WAVES) void k_filter(FilterArgs a) 
     //   [tables: n_words KiB] [s_idx: 16 KiB, 16-bit tile-relative] [s_key: 8 KiB] [s_hist] [s_cursor] [scalars]
     //   [per-word init/found masks and windows: 24 B x n_words]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (a.batch_flag && *a.batch_flag == 0ull) return;     // k_filter_lean handles equal-length batches
     const CahKmerWord* words = a.words;
     const int n_words = a.n_words;
     word_t* s_mask = reinterpret_cast<word_t*>(smem);
@@ -365,6 +366,186 @@ __global__ __launch_bounds__(256, CAH_FILTER_WAVES) void k_filter(FilterArgs a) 
 
         if (MODE == 1) {
             // flush the tile: counting sort by key in LDS, one global atomic for the whole run
+            __syncthreads();
+            const unsigned count = s_count;
+            if (threadIdx.x == 0) {
+                unsigned run = 0;
+                for (int bkt = 0; bkt < CAH_QUEUE_BINS; ++bkt) { const unsigned c = s_hist[bkt]; s_hist[bkt] = run; run += c; }
+                s_qbase = count ? atomicAdd(a.queue_count, (unsigned long long)count) : 0ull;
+            }
+            __syncthreads();
+            const unsigned long long qbase = s_qbase;
+            for (unsigned e = threadIdx.x; e < count; e += blockDim.x) {
+                const unsigned key = s_key[e];
+                const unsigned p = s_hist[key] + atomicAdd(&s_cursor[key], 1u);
+                a.queue[qbase + p] = (int32_t)(tile_base + s_idx[e]);
+                a.queue_keys[qbase + p] = (uint8_t)key;
+            }
+        }
+    }
+}
+
+// =============================================================================================
+// k_filter_lean: the prefilter for the common shape -- a 3' adapter's search sets (whole read +
+// "last L characters", see CahLeanFilter) on a batch whose reads all have the same length n.
+// Everything that k_filter keeps per lane (windows, activity masks, per-character masks) is a
+// wave-uniform scalar here; tail k-mers of all window lengths share words through gated start bits.
+// Same outputs as k_filter (present[] / key-ordered survivor queue), same key semantics.
+// =============================================================================================
+__global__ void k_uniform_check(const int64_t* offsets, int64_t n_reads, int64_t max_read_len, unsigned long long* flag) {
+    // *flag != 0  <=>  the reads do NOT all have the length offsets[1] - offsets[0] (or it is out of range)
+    const int64_t n = offsets[1] - offsets[0];
+    bool bad = n < 0 || n > max_read_len;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_reads && !bad; r += (int64_t)gridDim.x * blockDim.x)
+        bad = offsets[r + 1] - offsets[r] != n;
+    if (__any(bad) && wave_lane() == 0) atomicOr(flag, 1ull);
+}
+
+#ifndef LEAN_TILE
+#define LEAN_TILE 8192
+#endif
+#ifndef LEAN_WAVES
+#define LEAN_WAVES 5               // 31 KB of LDS per workgroup
+#endif
+
+template <int MODE>
+__global__ __launch_bounds__(256, LEAN_WAVES) void k_filter_lean(FilterArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (*a.batch_flag != 0ull) return;                       // ragged batch: k_filter does it
+    const CahLeanFilter* lf = a.lean;
+    const int n_words = lf->n_words, n_lead = lf->n_lead, tail_span = lf->tail_span;
+    uint32_t* s_mask = reinterpret_cast<uint32_t*>(smem);
+    unsigned char* sp = smem + (size_t)CAH_LEAN_WORDS * CAH_TABLE_CHARS * sizeof(uint32_t);
+    uint32_t* s_dist = reinterpret_cast<uint32_t*>(sp);          sp += (size_t)CAH_LEAN_WORDS * (CAH_LEAN_SPAN + 2) * sizeof(uint32_t);
+    uint16_t* s_idx = reinterpret_cast<uint16_t*>(sp);           sp += LEAN_TILE * sizeof(uint16_t);
+    uint8_t* s_key = sp;                                         sp += LEAN_TILE;
+    unsigned* s_hist = reinterpret_cast<unsigned*>(sp);          sp += CAH_QUEUE_BINS * sizeof(unsigned);
+    unsigned* s_cursor = reinterpret_cast<unsigned*>(sp);        sp += CAH_QUEUE_BINS * sizeof(unsigned);
+    unsigned long long& s_qbase = *reinterpret_cast<unsigned long long*>(sp);
+    long long& s_tile = *reinterpret_cast<long long*>(sp + 8);
+    unsigned& s_count = *reinterpret_cast<unsigned*>(sp + 16);
+    for (int i = threadIdx.x; i < n_words * CAH_TABLE_CHARS; i += blockDim.x)
+        s_mask[i] = lf->mask[i / CAH_TABLE_CHARS][i % CAH_TABLE_CHARS];
+    for (int i = threadIdx.x; i < CAH_LEAN_WORDS * (CAH_LEAN_SPAN + 2); i += blockDim.x)
+        s_dist[i] = lf->init_by_dist[i / (CAH_LEAN_SPAN + 2)][i % (CAH_LEAN_SPAN + 2)];
+    // per-word constants live in registers: inside the loops the compiler would re-load anything read
+    // through a pointer (the queue stores may alias as far as it knows)
+    uint32_t c_init[CAH_LEAN_WORDS], c_found[CAH_LEAN_WORDS];
+#pragma unroll
+    for (int w = 0; w < CAH_LEAN_WORDS; ++w) { c_init[w] = lf->lead_init[w]; c_found[w] = lf->found[w]; }
+    const int64_t first = a.offsets[0];
+    const int n = (int)(a.offsets[1] - first);                   // every read has this length
+    const int lane = wave_lane();
+    const int wave = threadIdx.x >> 6;
+
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            s_tile = (long long)atomicAdd(a.work_counter, (unsigned long long)LEAN_TILE);
+            s_count = 0;
+        }
+        for (int i = threadIdx.x; i < CAH_QUEUE_BINS; i += blockDim.x) { s_hist[i] = 0; s_cursor[i] = 0; }
+        __syncthreads();
+        const int64_t tile_base = s_tile;
+        if (tile_base >= a.n_reads) break;
+
+        for (int sub = wave; sub < LEAN_TILE / WAVE; sub += FILTER_WAVES) {
+            const int64_t base = tile_base + (int64_t)sub * WAVE;
+            if (base >= a.n_reads) break;
+            const int64_t r = base + lane;
+            const bool valid = r < a.n_reads;
+            const uint8_t* q = a.seqs + first + (valid ? r : base) * (int64_t)n;
+            bool hit = false;
+            int hit_pos = 0;
+            unsigned seen = 0;
+            uint32_t R[CAH_LEAN_WORDS], acc[CAH_LEAN_WORDS];
+#pragma unroll
+            for (int w = 0; w < CAH_LEAN_WORDS; ++w) { R[w] = 0; acc[w] = 0; }
+
+            Chunk cur = load_chunk(q, 0, n, valid ? n : 0);
+            for (int pos = 0; pos < n; pos += 16) {                  // pos is wave-uniform
+                const bool live = valid && !hit;
+                if (!__any(live)) break;
+                const Chunk nxt = load_chunk(q, pos + 16, n, live ? n : 0);
+                seen |= cur.w[0] | cur.w[1] | cur.w[2] | cur.w[3];
+                uint32_t lead_found = 0, tail_found = 0;
+                uint32_t gg[3] = {0, 0, 0};
+                if (live) {
+                    // ---- whole-read words: constant start bits ----------------------------------
+#pragma unroll
+                    for (int w = 0; w < CAH_LEAN_WORDS; ++w) {
+                        if (w >= n_lead) break;                      // wave-uniform
+                        const uint32_t init = c_init[w], fnd = c_found[w];
+                        const uint32_t* tbl = s_mask + w * CAH_TABLE_CHARS;
+#pragma unroll
+                        for (int t = 0; t < 16; ++t) {
+                            const uint32_t mk = tbl[chunk_byte(cur, t) & (CAH_TABLE_CHARS - 1)];
+                            unsigned dbl;
+                            asm("v_add_u32 %0, %1, %1" : "=v"(dbl) : "v"(R[w]));
+                            R[w] = (dbl | init) & mk;
+                            acc[w] |= R[w];
+                            if ((t & 3) == 3 && t < 15) gg[t >> 2] |= acc[w] & fnd;
+                        }
+                        lead_found |= acc[w] & fnd;
+                    }
+                    // ---- tail words: a k-mer of the set (-L, None) may start at p >= n - L ----------
+                    if (pos + 16 > n - tail_span) {                  // wave-uniform
+#pragma unroll
+                        for (int w = 0; w < CAH_LEAN_WORDS; ++w) {
+                            if (w < n_lead) continue;
+                            if (w >= n_words) break;
+                            const uint32_t fnd = c_found[w];
+                            const uint32_t* tbl = s_mask + w * CAH_TABLE_CHARS;
+                            const uint32_t* dist = s_dist + w * (CAH_LEAN_SPAN + 2);
+#pragma unroll
+                            for (int t = 0; t < 16; ++t) {
+                                // start bits open at this character's distance from the read end (wave-uniform
+                                // index; characters past the end are NUL and match nothing)
+                                const int d = min(max(n - (pos + t), 0), CAH_LEAN_SPAN + 1);
+                                const uint32_t init = dist[d];
+                                const uint32_t mk = tbl[chunk_byte(cur, t) & (CAH_TABLE_CHARS - 1)];
+                                unsigned dbl;
+                                asm("v_add_u32 %0, %1, %1" : "=v"(dbl) : "v"(R[w]));
+                                R[w] = (dbl | init) & mk;
+                                acc[w] |= R[w];
+                                if ((t & 3) == 3 && t < 15) gg[t >> 2] |= acc[w] & fnd;
+                            }
+                            tail_found |= acc[w] & fnd;
+                        }
+                    }
+                    if ((lead_found | tail_found) != 0) {
+                        // key semantics as in k_filter: the 4-column group of the first hit of any word (no
+                        // whole-read k-mer ended before it: those words were scanned through this chunk)
+                        hit = true;
+                        hit_pos = pos + (gg[0] ? 0 : gg[1] ? 4 : gg[2] ? 8 : 12);
+                    }
+                }
+                cur = nxt;
+            }
+            const bool invalid = (seen & 0x80808080u) != 0;
+
+            if (MODE == 0) {
+                if (valid) a.present[r] = invalid ? (uint8_t)2 : (hit ? (uint8_t)1 : (uint8_t)0);
+            } else {
+                if (valid && invalid) a.status[r] = 2;
+                const bool push = valid && hit && !invalid;
+                const unsigned long long bal = __ballot(push);
+                if (bal) {
+                    unsigned slot = 0;
+                    if (lane == 0) slot = atomicAdd(&s_count, (unsigned)__popcll(bal));
+                    slot = __builtin_amdgcn_readfirstlane(slot);
+                    if (push) {
+                        const int e = (int)slot + __popcll(bal & ((1ull << lane) - 1ull));
+                        const int key = min(hit_pos >> CAH_KEY_SHIFT, CAH_QUEUE_BINS - 1);
+                        s_idx[e] = (uint16_t)(r - tile_base);
+                        s_key[e] = (uint8_t)key;
+                        atomicAdd(&s_hist[key], 1u);
+                    }
+                }
+            }
+        }
+
+        if (MODE == 1) {
             __syncthreads();
             const unsigned count = s_count;
             if (threadIdx.x == 0) {
@@ -1108,6 +1289,23 @@ hipError_t launch_filter(const FilterArgs& a, int mode, bool narrow, int n_cus, 
         else { if (narrow) CAH_FILTER_LAUNCH(1, false, true); else CAH_FILTER_LAUNCH(1, false, false); }
     }
 #undef CAH_FILTER_LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t launch_filter_lean(const FilterArgs& a, int mode, int n_cus, hipStream_t s) {
+    const int grid = grid_for(a.n_reads, LEAN_WAVES, n_cus);
+    const size_t lds = (size_t)CAH_LEAN_WORDS * CAH_TABLE_CHARS * sizeof(uint32_t) +
+                       (size_t)CAH_LEAN_WORDS * (CAH_LEAN_SPAN + 2) * sizeof(uint32_t) + (size_t)LEAN_TILE * 3 +
+                       CAH_QUEUE_BINS * 8 + 64;
+    if (mode == 0) hipLaunchKernelGGL((k_filter_lean<0>), dim3(grid), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((k_filter_lean<1>), dim3(grid), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_uniform_check(const int64_t* offsets, int64_t n_reads, int64_t max_read_len, unsigned long long* flag,
+                                int n_cus, hipStream_t s) {
+    const int grid = grid_for(n_reads, 8, n_cus);
+    hipLaunchKernelGGL(k_uniform_check, dim3(grid), dim3(256), 0, s, offsets, n_reads, max_read_len, flag);
     return hipGetLastError();
 }
 
