@@ -583,3 +583,51 @@ def test_edge_cases_through_the_batch_api(hip, orc):
     rc = _lib.lib().cah_match_batch(ad._fused_plan.handle, bb.seqs.data_ptr(), bb.offsets.data_ptr(), None, n,
                                     out6.data_ptr(), None, st.data_ptr(), small.data_ptr(), small.numel(), None)
     assert rc == _lib.CAH_EINVAL and "workspace" in _lib.last_error()
+
+
+@pytest.mark.gpu
+def test_lean_prefilter_equals_general_prefilter(hip, orc):
+    """Equal-length batches of 3' adapters go through k_filter_lean, the same reads passed as a view
+    (explicit lens) through k_filter: identical results, and both equal the oracle.  Read lengths
+    around every boundary of the tail windows and the 16-character chunks."""
+    import random
+    import torch
+    from cutadapt_amd import adapters as A
+    from cutadapt_amd.batch import ReadBatch, match_batch
+    rng = random.Random(77)
+    for it in range(14):
+        m = rng.choice([8, 13, 20, 33, 33, 40, 57, 64])
+        seq = rs(rng, m, "ACGT") if it % 4 else rs(rng, m, "ACGTN")
+        ad = A.BackAdapter(seq, max_errors=rng.choice([0.0, 0.1, 0.1, 0.2]), min_overlap=rng.randint(1, 6),
+                           read_wildcards=rng.random() < 0.2, indels=rng.random() < 0.8)
+        for n in sorted({0, 1, 2, 5, 15, 16, 17, rng.randint(18, 31), 32, 33, 47, 48, 49, 64, rng.randint(65, 140), 150}):
+            reads = []
+            for _ in range(300):
+                r = list(rs(rng, n, "ACGT"))
+                if n and rng.random() < 0.6:
+                    p = rng.randint(0, n - 1)
+                    piece = list(ad.sequence[:rng.randint(1, m)])
+                    for _e in range(rng.choice([0, 0, 1, 2])):
+                        if piece:
+                            piece[rng.randrange(len(piece))] = rng.choice("ACGT")
+                    r[p:p + len(piece)] = piece
+                    r = r[:n]
+                if n and rng.random() < 0.1:
+                    r[rng.randrange(n)] = "N"
+                reads.append("".join(r))
+            batch = ReadBatch.from_strings(reads)
+            lean = match_batch(ad._fused_plan, batch).cpu()
+            lens = torch.full((len(reads),), n, dtype=torch.int32, device=batch.device)
+            view = ReadBatch(batch.seqs, batch.offsets[:len(reads)].clone(), lens, n_reads=len(reads), validated=True)
+            general = match_batch(ad._fused_plan, view).cpu()
+            assert np.array_equal(lean[1], general[1]) and np.array_equal(lean[0], general[0]), (seq, n)
+            finder = orc.KmerFinder(ad.kmer_finder.positions_and_kmers, ad.adapter_wildcards, ad.read_wildcards) \
+                if hasattr(ad.kmer_finder, "positions_and_kmers") else None
+            al = ad.aligner
+            oal = orc.Aligner(ad.sequence, ad.max_error_rate, flags=14, wildcard_ref=ad.adapter_wildcards,
+                              wildcard_query=ad.read_wildcards, indel_cost=1 if ad.indels else 100000,
+                              min_overlap=ad.min_overlap)
+            for i, r in enumerate(reads):
+                exp = oal.locate(r) if (finder is None or finder.kmers_present(r)) else None
+                got = tuple(int(v) for v in lean[0][i]) if lean[1][i] == 1 else None
+                assert got == exp, (seq, n, r, got, exp)
