@@ -63,7 +63,9 @@ struct CahKmerWord {
 // (a start-bit table indexed by the distance from the read end); no per-lane window bookkeeping and
 // no per-character masks are left.
 // ---------------------------------------------------------------------------------------------
+#ifndef CAH_LEAN_WORDS
 #define CAH_LEAN_WORDS 6
+#endif
 #define CAH_LEAN_SPAN 64                          // longest tail window the lean kernel takes
 struct CahLeanFilter {
     int32_t ok;                                   // 1: this matcher can use k_filter_lean
