@@ -27,9 +27,6 @@
 #ifndef CAH_SCHED_ROWS
 #define CAH_SCHED_ROWS 1
 #endif
-#ifndef CAH_SKIP_CHECK
-#define CAH_SKIP_CHECK(I) (((I) & 1) == 1)      // rows in front of which the wave asks "any band left?"
-#endif
 
 __device__ __forceinline__ int wave_lane() { return threadIdx.x & (WAVE - 1); }
 
@@ -576,12 +573,8 @@ __device__ __forceinline__ void dp_rows(int (&c)[ROWS + 1], int (&p)[ROWS + 1], 
                                         int dc, int dp, int& nl, int& cm_c, int& cm_p,
                                         const int last, const int m, const int k, const int Dm1) {
     if constexpr (I <= ROWS) {
-        // every 4 rows: leave the column as soon as no lane of the wave has band left
-        // band-left checks: dense near the top (the narrow phase keeps 6-12 rows alive), sparse
-        // further down (a wave that gets there usually needs the whole column)
-        if constexpr (CAH_SKIP_CHECK(I)) {
-            if (!__any(last >= I)) return;
-        }
+        // leave the column as soon as no lane of the wave has band left
+        if (!__any(last >= I)) return;                    // in front of every row (+3 % over every other row)
         // Straight-line, select-only cell update (no exec-mask regions: lanes whose band ended
         // compute a value that is discarded by the final select, so stale cells stay stale).
         // (:446-476) match: take the diagonal unconditionally; otherwise min of {diag+1, del,
