@@ -644,12 +644,14 @@ static int run_filter(const cah_plan* plan, const PlanDeviceCopy* pd, int32_t ad
     HIP_TRY(hipMemsetAsync(d_work_counter, 0, sizeof(unsigned long long), s));
     if (d_queue_count) HIP_TRY(hipMemsetAsync(d_queue_count, 0, sizeof(unsigned long long), s));
     ProfScope ps(s, CAH_PROF_FILTER, n_reads);
-    if (d_batch_flag && !d_lens && plan->lean[(size_t)adapter].ok) {
-        // two launches, one of them leaves at once: the lean kernel runs when the batch check found all
-        // reads to have one length (*d_batch_flag == 0), the general kernel otherwise -- no host sync
-        f.batch_flag = d_batch_flag;
+    if (plan->lean[(size_t)adapter].ok) {
+        // 3' adapter plans: k_filter_lean.  For a packed batch the device-side batch check (*d_batch_flag)
+        // picks its equal-length or its ragged variant -- both are launched, one leaves at once, no host
+        // sync; views (explicit lengths) and calls without a check take the ragged variant.
+        f.batch_flag = d_lens ? nullptr : d_batch_flag;
         f.lean = pd->d_lean + adapter;
         HIP_TRY(launch_filter_lean(f, mode, pd->n_cus, s));
+        return CAH_OK;
     }
     HIP_TRY(launch_filter(f, mode, mt.narrow_words != 0, pd->n_cus, s));
     return CAH_OK;

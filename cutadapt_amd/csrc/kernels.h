@@ -22,8 +22,8 @@ struct FilterArgs {
     int32_t* queue;                  // MODE 1: surviving read indices, in runs ordered by hit position
     unsigned long long* queue_count; // MODE 1: zeroed before launch
     uint8_t* queue_keys;             // MODE 1: per queue entry, min(first-hit position >> CAH_KEY_SHIFT, 255)
-    const unsigned long long* batch_flag;   // may be NULL; k_filter leaves at once if *batch_flag == 0 (all reads
-                                            // have one length: k_filter_lean took the batch), k_filter_lean if != 0
+    const unsigned long long* batch_flag;   // k_filter_lean: *batch_flag == 0 <=> all reads have one length (its
+                                            // UNIFORM variant works, the ragged one leaves); NULL = no check made
     const CahLeanFilter* lean;       // k_filter_lean only
 };
 

@@ -220,7 +220,6 @@ __global__ __launch_bounds__(256, CAH_FILTER_WAVES) void k_filter(FilterArgs a) 
     //   [tables: n_words KiB] [s_idx: 16 KiB, 16-bit tile-relative] [s_key: 8 KiB] [s_hist] [s_cursor] [scalars]
     //   [per-word init/found masks and windows: 24 B x n_words]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if (a.batch_flag && *a.batch_flag == 0ull) return;     // k_filter_lean handles equal-length batches
     const CahKmerWord* words = a.words;
     const int n_words = a.n_words;
     word_t* s_mask = reinterpret_cast<word_t*>(smem);
@@ -405,10 +404,14 @@ __global__ void k_uniform_check(const int64_t* offsets, int64_t n_reads, int64_t
 #define LEAN_WAVES 4               // measured: 2 -> 2.56 ms, 3 -> 2.03, 4 -> 1.85, 5 -> 2.01, 8 -> 2.61 (20 M reads)
 #endif
 
-template <int MODE>
+// UNIFORM: every read of the batch has the length offsets[1] - offsets[0] (position, length and tail
+// distances are scalars, reads need no offsets); otherwise the length, the read pointer and the tail
+// distance are per lane (the distance table is then gathered per lane instead of broadcast).
+template <int MODE, bool UNIFORM>
 __global__ __launch_bounds__(256, LEAN_WAVES) void k_filter_lean(FilterArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if (*a.batch_flag != 0ull) return;                       // ragged batch: k_filter does it
+    // the batch check decides which variant works (no check was made for views: they count as ragged)
+    if (a.batch_flag ? (*a.batch_flag != 0ull) == UNIFORM : UNIFORM) return;
     const CahLeanFilter* lf = a.lean;
     const int n_words = lf->n_words, n_lead = lf->n_lead, tail_span = lf->tail_span;
     uint32_t* s_mask = reinterpret_cast<uint32_t*>(smem);
@@ -430,8 +433,8 @@ __global__ __launch_bounds__(256, LEAN_WAVES) void k_filter_lean(FilterArgs a) {
     uint32_t c_init[CAH_LEAN_WORDS], c_found[CAH_LEAN_WORDS];
 #pragma unroll
     for (int w = 0; w < CAH_LEAN_WORDS; ++w) { c_init[w] = lf->lead_init[w]; c_found[w] = lf->found[w]; }
-    const int64_t first = a.offsets[0];
-    const int n = (int)(a.offsets[1] - first);                   // every read has this length
+    const int64_t first = UNIFORM ? a.offsets[0] : 0;
+    const int n_uniform = UNIFORM ? (int)(a.offsets[1] - first) : 0;   // every read has this length
     const int lane = wave_lane();
     const int wave = threadIdx.x >> 6;
 
@@ -451,7 +454,23 @@ __global__ __launch_bounds__(256, LEAN_WAVES) void k_filter_lean(FilterArgs a) {
             if (base >= a.n_reads) break;
             const int64_t r = base + lane;
             const bool valid = r < a.n_reads;
-            const uint8_t* q = a.seqs + first + (valid ? r : base) * (int64_t)n;
+            // n, n_max: this lane's read length and the longest of the wave (both n_uniform if UNIFORM)
+            int n = n_uniform, n_max = n_uniform;
+            const uint8_t* q;
+            bool too_long = false;
+            if constexpr (UNIFORM) {
+                q = a.seqs + first + (valid ? r : base) * (int64_t)n;
+            } else {
+                int64_t off = 0, n64 = 0;
+                if (valid) read_extent(a.offsets, a.lens, r, off, n64);
+                if (n64 > a.max_read_len) { too_long = true; n64 = 0; }
+                n = (int)n64;
+                q = a.seqs + off;
+                n_max = n;
+#pragma unroll
+                for (int d = 1; d < WAVE; d <<= 1) n_max = max(n_max, __shfl_xor(n_max, d, WAVE));
+                n_max = __builtin_amdgcn_readfirstlane(n_max);
+            }
             bool hit = false;
             int hit_pos = 0;
             unsigned seen = 0;
@@ -460,8 +479,8 @@ __global__ __launch_bounds__(256, LEAN_WAVES) void k_filter_lean(FilterArgs a) {
             for (int w = 0; w < CAH_LEAN_WORDS; ++w) { R[w] = 0; acc[w] = 0; }
 
             Chunk cur = load_chunk(q, 0, n, valid ? n : 0);
-            for (int pos = 0; pos < n; pos += 16) {                  // pos is wave-uniform
-                const bool live = valid && !hit;
+            for (int pos = 0; pos < n_max; pos += 16) {              // pos is wave-uniform
+                const bool live = valid && !hit && (UNIFORM || pos < n);
                 if (!__any(live)) break;
                 const Chunk nxt = load_chunk(q, pos + 16, n, live ? n : 0);
                 seen |= cur.w[0] | cur.w[1] | cur.w[2] | cur.w[3];
@@ -486,7 +505,7 @@ __global__ __launch_bounds__(256, LEAN_WAVES) void k_filter_lean(FilterArgs a) {
                         lead_found |= acc[w] & fnd;
                     }
                     // ---- tail words: a k-mer of the set (-L, None) may start at p >= n - L ----------
-                    if (pos + 16 > n - tail_span) {                  // wave-uniform
+                    if (UNIFORM ? pos + 16 > n - tail_span : __any(pos + 16 > n - tail_span)) {
 #pragma unroll
                         for (int w = 0; w < CAH_LEAN_WORDS; ++w) {
                             if (w < n_lead) continue;
@@ -496,8 +515,8 @@ __global__ __launch_bounds__(256, LEAN_WAVES) void k_filter_lean(FilterArgs a) {
                             const uint32_t* dist = s_dist + w * (CAH_LEAN_SPAN + 2);
 #pragma unroll
                             for (int t = 0; t < 16; ++t) {
-                                // start bits open at this character's distance from the read end (wave-uniform
-                                // index; characters past the end are NUL and match nothing)
+                                // start bits open at this character's distance from the read end (a wave-uniform
+                                // index if UNIFORM; characters past the end are NUL and match nothing)
                                 const int d = min(max(n - (pos + t), 0), CAH_LEAN_SPAN + 1);
                                 const uint32_t init = dist[d];
                                 const uint32_t mk = tbl[chunk_byte(cur, t) & (CAH_TABLE_CHARS - 1)];
@@ -519,7 +538,7 @@ __global__ __launch_bounds__(256, LEAN_WAVES) void k_filter_lean(FilterArgs a) {
                 }
                 cur = nxt;
             }
-            const bool invalid = (seen & 0x80808080u) != 0;
+            const bool invalid = (seen & 0x80808080u) != 0 || too_long;
 
             if (MODE == 0) {
                 if (valid) a.present[r] = invalid ? (uint8_t)2 : (hit ? (uint8_t)1 : (uint8_t)0);
@@ -1289,8 +1308,14 @@ hipError_t launch_filter_lean(const FilterArgs& a, int mode, int n_cus, hipStrea
     const size_t lds = (size_t)CAH_LEAN_WORDS * CAH_TABLE_CHARS * sizeof(uint32_t) +
                        (size_t)CAH_LEAN_WORDS * (CAH_LEAN_SPAN + 2) * sizeof(uint32_t) + (size_t)LEAN_TILE * 3 +
                        CAH_QUEUE_BINS * 8 + 64;
-    if (mode == 0) hipLaunchKernelGGL((k_filter_lean<0>), dim3(grid), dim3(256), lds, s, a);
-    else hipLaunchKernelGGL((k_filter_lean<1>), dim3(grid), dim3(256), lds, s, a);
+    // both variants are launched for a packed batch (one of them returns at once, see batch_flag);
+    // views (explicit lengths) have no batch check and go to the ragged variant directly
+    if (a.batch_flag) {
+        if (mode == 0) hipLaunchKernelGGL((k_filter_lean<0, true>), dim3(grid), dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((k_filter_lean<1, true>), dim3(grid), dim3(256), lds, s, a);
+    }
+    if (mode == 0) hipLaunchKernelGGL((k_filter_lean<0, false>), dim3(grid), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((k_filter_lean<1, false>), dim3(grid), dim3(256), lds, s, a);
     return hipGetLastError();
 }
 

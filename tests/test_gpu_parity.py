@@ -587,9 +587,10 @@ def test_edge_cases_through_the_batch_api(hip, orc):
 
 @pytest.mark.gpu
 def test_lean_prefilter_equals_general_prefilter(hip, orc):
-    """Equal-length batches of 3' adapters go through k_filter_lean, the same reads passed as a view
-    (explicit lens) through k_filter: identical results, and both equal the oracle.  Read lengths
-    around every boundary of the tail windows and the 16-character chunks."""
+    """Equal-length batches of 3' adapters go through k_filter_lean<UNIFORM>, the same reads passed as a
+    view (explicit lens) through its ragged variant: identical results, and both equal the oracle
+    (plans that are not eligible -- 5' / anywhere adapters, wide k-mers -- keep using k_filter and are
+    covered by the other tests).  Read lengths around every boundary of the tail windows and chunks."""
     import random
     import torch
     from cutadapt_amd import adapters as A
