@@ -187,52 +187,63 @@ static int plan_on_device(const cah_plan* plan, const PlanDeviceCopy** out) {
 }
 
 // The lean prefilter of a matcher (see CahLeanFilter): possible when every search set is a whole-read
-// set (0, None) or a tail set (-L, None), every k-mer fits 32 bits and the packing fits the kernel's
-// word and gate counts.  Same matches as the generic packing: kmers_present is an OR over k-mers, a
+// set (0, None), a tail set (-L, None) or a head set (start, stop) within the first CAH_LEAN_SPAN
+// characters, every k-mer fits 32 bits and the packing fits the kernel's word count.  Same matches as the generic packing: kmers_present is an OR over k-mers, a
 // k-mer of (-L, None) is found iff it occurs with start >= n - L, which is what a gated start bit says.
 static void build_lean_filter(const cah_adapter_desc& d, CahLeanFilter& lf) {
     memset(&lf, 0, sizeof(lf));
     if (d.n_kmer_sets <= 0 || !d.kmer_sets) return;
     const bool rwc = d.kmer_ref_wildcards != 0, qwc = d.kmer_query_wildcards != 0;
-    struct Item { const char* kmer; int len; int L; };            // L = 0: whole read
-    std::vector<Item> lead, tail;
+    struct Item { const char* kmer; int len; int L; int start, stop; };   // L: tail window; start/stop: head window
+    std::vector<Item> lead, tail, head;
     for (int s = 0; s < d.n_kmer_sets; s++) {
         const cah_kmer_set& ks = d.kmer_sets[s];
-        if (ks.stop != 0 || ks.start > 0 || ks.start < -(int64_t)CAH_MAX_READ_LEN) return;
+        int kind;                                                 // 0 lead, 1 tail, 2 head
+        if (ks.start == 0 && ks.stop == 0) kind = 0;
+        else if (ks.start < 0 && ks.stop == 0 && ks.start >= -(int64_t)CAH_LEAN_SPAN) kind = 1;
+        else if (ks.start >= 0 && ks.stop > ks.start && ks.stop <= CAH_LEAN_SPAN) kind = 2;
+        else return;
         for (int t = 0; t < ks.n_kmers; t++) {
             const char* k = ks.kmers[t];
             if (!k) return;
             const size_t len = strlen(k);
             if (len == 0 || len > 32 || !is_ascii(k, len)) return;
-            (ks.start == 0 ? lead : tail).push_back(Item{k, (int)len, (int)-ks.start});
+            const Item it{k, (int)len, (int)-ks.start, (int)ks.start, (int)ks.stop};
+            (kind == 0 ? lead : kind == 1 ? tail : head).push_back(it);
         }
     }
     std::stable_sort(tail.begin(), tail.end(), [](const Item& a, const Item& b) { return a.L > b.L; });
     int w = -1, used = 32;
-    auto place = [&](const Item& it, bool is_lead) -> bool {
+    auto place = [&](const Item& it, int kind) -> bool {
         if (used + it.len > 32) {
             if (++w >= CAH_LEAN_WORDS) return false;
             used = 0;
         }
-        const uint32_t start_bit = 1u << used;
+        const uint32_t start_bit = 1u << used, end_bit = 1u << (used + it.len - 1);
         for (int p = 0; p < it.len; p++)
             for (int qc = 0; qc < CAH_TABLE_CHARS; qc++)
                 if (kmer_chars_match((uint8_t)it.kmer[p], (uint8_t)qc, rwc, qwc)) lf.mask[w][qc] |= 1u << (used + p);
-        lf.found[w] |= 1u << (used + it.len - 1);
-        if (is_lead) {
+        lf.found[w] |= end_bit;
+        if (kind == 0) {
             lf.lead_init[w] |= start_bit;
-        } else {
-            if (it.L > CAH_LEAN_SPAN) return false;
+        } else if (kind == 1) {
             for (int dist = 1; dist <= it.L; dist++) lf.init_by_dist[w][dist] |= start_bit;
             lf.tail_span = std::max(lf.tail_span, it.L);
+        } else {
+            for (int p = it.start; p + it.len <= it.stop; p++) lf.head_init_by_pos[w][p] |= start_bit;
+            for (int p = it.start + it.len - 1; p < it.stop; p++) lf.head_found_by_pos[w][p] |= end_bit;
+            lf.head_span = std::max(lf.head_span, it.stop);
         }
         used += it.len;
         return true;
     };
-    for (const Item& it : lead) if (!place(it, true)) return;
+    for (const Item& it : lead) if (!place(it, 0)) return;
     lf.n_lead = w + 1;
-    used = 32;                                                   // tail k-mers start a new word
-    for (const Item& it : tail) if (!place(it, false)) return;
+    used = 32;                                                   // every kind starts a new word
+    for (const Item& it : tail) if (!place(it, 1)) return;
+    lf.n_tail = w + 1 - lf.n_lead;
+    used = 32;
+    for (const Item& it : head) if (!place(it, 2)) return;
     lf.n_words = w + 1;
     lf.ok = lf.n_words >= 1 ? 1 : 0;
 }
@@ -650,7 +661,7 @@ static int run_filter(const cah_plan* plan, const PlanDeviceCopy* pd, int32_t ad
         // sync; views (explicit lengths) and calls without a check take the ragged variant.
         f.batch_flag = d_lens ? nullptr : d_batch_flag;
         f.lean = pd->d_lean + adapter;
-        HIP_TRY(launch_filter_lean(f, mode, pd->n_cus, s));
+        HIP_TRY(launch_filter_lean(f, mode, plan->lean[(size_t)adapter].n_words, pd->n_cus, s));
         return CAH_OK;
     }
     HIP_TRY(launch_filter(f, mode, mt.narrow_words != 0, pd->n_cus, s));

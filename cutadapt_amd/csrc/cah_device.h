@@ -56,27 +56,34 @@ struct CahKmerWord {
 };
 
 // ---------------------------------------------------------------------------------------------
-// Lean prefilter for plans whose search sets are all "whole read" (start 0, stop None) or "last L
-// characters" (start -L, stop None) -- what kmer_heuristic builds for 3' adapters -- on batches
-// whose reads all have the same length.  Tail k-mers of ALL window lengths share words: a k-mer of
+// Lean prefilter for plans whose search sets are all "whole read" (start 0, stop None), "last L
+// characters" (start -L, stop None) or "characters start..stop" near the 5' end -- everything
+// kmer_heuristic builds for 3', 5' and anywhere adapters.  Tail k-mers of ALL window lengths share words: a k-mer of
 // the set (-L, None) may only START at positions >= n - L, so its start bit is injected only there
 // (a start-bit table indexed by the distance from the read end); no per-lane window bookkeeping and
 // no per-character masks are left.
 // ---------------------------------------------------------------------------------------------
 #ifndef CAH_LEAN_WORDS
-#define CAH_LEAN_WORDS 6
+#define CAH_LEAN_WORDS 8
 #endif
 #define CAH_LEAN_SPAN 64                          // longest tail window the lean kernel takes
 struct CahLeanFilter {
     int32_t ok;                                   // 1: this matcher can use k_filter_lean
-    int32_t n_words;                              // lead words first, then tail words
+    int32_t n_words;                              // lead words first, then tail words, then head words
     int32_t n_lead;
+    int32_t n_tail;
     int32_t tail_span;                            // longest tail window
+    int32_t head_span;                            // largest stop of a head window
     uint32_t found[CAH_LEAN_WORDS];               // bit at every k-mer end
     uint32_t lead_init[CAH_LEAN_WORDS];           // start bits of a lead word (0 for tail words)
     // start bits of a tail word that are open at distance d = n - p from the read end (d = 1 is the
     // last character): the k-mers of every set (-L, None) with L >= d; entry 0 and entries beyond the
     // span are 0
     uint32_t init_by_dist[CAH_LEAN_WORDS][CAH_LEAN_SPAN + 2];
+    // head words (sets (start, stop) with 0 <= start < stop <= CAH_LEAN_SPAN: what kmer_heuristic builds
+    // for 5' adapters): a k-mer may start at p in [start, stop - len] and is found when it ends at
+    // p in [start + len - 1, stop - 1]; both gates are indexed by the position p, entries past the span 0
+    uint32_t head_init_by_pos[CAH_LEAN_WORDS][CAH_LEAN_SPAN + 2];
+    uint32_t head_found_by_pos[CAH_LEAN_WORDS][CAH_LEAN_SPAN + 2];
     uint32_t mask[CAH_LEAN_WORDS][CAH_TABLE_CHARS];
 };

@@ -45,7 +45,7 @@ struct DpArgs {
     int32_t merge_best;              // 0: overwrite (locate_batch); 1: keep best (match_batch)
 };
 
-hipError_t launch_filter_lean(const FilterArgs& a, int mode, int n_cus, hipStream_t s);
+hipError_t launch_filter_lean(const FilterArgs& a, int mode, int n_words, int n_cus, hipStream_t s);
 hipError_t launch_uniform_check(const int64_t* offsets, int64_t n_reads, int64_t max_read_len, unsigned long long* flag,
                                 int n_cus, hipStream_t s);
 hipError_t launch_filter(const FilterArgs& a, int mode, bool narrow_words, int n_cus, hipStream_t s);
