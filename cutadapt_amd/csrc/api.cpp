@@ -17,6 +17,8 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <memory>
+#include <new>
 #include <vector>
 
 #include "../../include/cutadapt_hip.h"
@@ -453,22 +455,35 @@ int cah_device_info(int device, char* name, size_t name_len, char* arch, size_t 
     return CAH_OK;
 }
 
+static int plan_create_impl(const cah_adapter_desc* adapters, int32_t n_adapters, cah_plan** out);
+
 int cah_plan_create(const cah_adapter_desc* adapters, int32_t n_adapters, cah_plan** out) {
+    try {                                                    // nothing may be thrown across the C ABI
+        return plan_create_impl(adapters, n_adapters, out);
+    } catch (const std::bad_alloc&) {
+        return fail(CAH_ENOMEM, "cah_plan_create: out of memory");
+    } catch (...) {
+        return fail(CAH_EINVAL, "cah_plan_create: internal error");
+    }
+}
+
+static int plan_create_impl(const cah_adapter_desc* adapters, int32_t n_adapters, cah_plan** out) {
     if (!out) return fail(CAH_EINVAL, "out is NULL");
     *out = nullptr;
     if (n_adapters < 1 || !adapters) return fail(CAH_EINVAL, "need at least one adapter");
-    cah_plan* plan = new cah_plan();
+    std::unique_ptr<cah_plan> holder(new cah_plan());
+    cah_plan* plan = holder.get();
     plan->matchers.resize((size_t)n_adapters);
     plan->lean.resize((size_t)n_adapters);
     for (int i = 0; i < n_adapters; i++) {
         int rc = build_matcher(adapters[i], i, plan->matchers[(size_t)i], plan->words);
-        if (rc != CAH_OK) { delete plan; return rc; }
+        if (rc != CAH_OK) return rc;
         build_lean_filter(adapters[i], plan->lean[(size_t)i]);
 #ifdef CAH_NO_LEAN
         plan->lean[(size_t)i].ok = 0;                 // A/B builds
 #endif
     }
-    *out = plan;
+    *out = holder.release();
     return CAH_OK;
 }
 

@@ -466,7 +466,19 @@ int index_on_device(const cah_index* ix, const IdxDeviceCopy** out) {
 
 extern "C" {
 
+static int index_create_impl(const cah_index_adapter* adapters, int32_t n_adapters, int32_t prefix, cah_index** out);
+
 int cah_index_create(const cah_index_adapter* adapters, int32_t n_adapters, int32_t prefix, cah_index** out) {
+    try {                                                    // nothing may be thrown across the C ABI
+        return index_create_impl(adapters, n_adapters, prefix, out);
+    } catch (const std::bad_alloc&) {
+        return cah_set_error_(CAH_ENOMEM, "cah_index_create: out of memory (the index of long adapters with 3 errors is large)");
+    } catch (...) {
+        return cah_set_error_(CAH_EINVAL, "cah_index_create: internal error");
+    }
+}
+
+static int index_create_impl(const cah_index_adapter* adapters, int32_t n_adapters, int32_t prefix, cah_index** out) {
     if (!out) return cah_set_error_(CAH_EINVAL, "cah_index_create: out is NULL");
     *out = nullptr;
     if (!adapters || n_adapters <= 0) return cah_set_error_(CAH_EINVAL, "Adapter list is empty");

@@ -8,6 +8,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <mutex>
 
 #include "../../include/cutadapt_hip.h"
 
@@ -212,6 +213,7 @@ __global__ __launch_bounds__(256) void k_expected_errors(const uint8_t* quals, c
 // SCORE_TO_ERROR_RATE of expected_errors.h:6-101 is 10^(-q/10) in double; one copy per device
 struct ErrTable {
     double* d[64] = {nullptr};
+    std::mutex mu;                      // the pipeline calls in from several threads
 };
 ErrTable g_tab;
 
@@ -219,6 +221,7 @@ int error_table_on_device(const double** out) {
     int device = 0;
     QT_TRY(hipGetDevice(&device));
     if (device < 0 || device >= 64) return cah_set_error_(CAH_EUNSUPPORTED, "device index too large");
+    std::lock_guard<std::mutex> lk(g_tab.mu);
     if (!g_tab.d[device]) {
         double h[94];
         for (int q = 0; q < 94; q++) h[q] = std::pow(10.0, -(double)q / 10.0);
