@@ -21,7 +21,7 @@ PROF_FILTER, PROF_DP, PROF_COMPARER, PROF_N = 0, 1, 2, 3
 EXPORTED_SYMBOLS = [
     "cah_abi_version", "cah_last_error", "cah_device_count", "cah_set_device", "cah_device_info",
     "cah_plan_create", "cah_plan_destroy", "cah_plan_n_adapters", "cah_plan_effective_length",
-    "cah_plan_n_kmer_entries", "cah_locate_batch", "cah_kmers_present_batch", "cah_match_batch",
+    "cah_plan_n_kmer_entries", "cah_plan_prefilter_kind", "cah_locate_batch", "cah_kmers_present_batch", "cah_match_batch",
     "cah_workspace_bytes", "cah_validate_ascii_batch", "cah_locate_batch_host",
     "cah_kmers_present_batch_host", "cah_match_batch_host", "cah_profile_enable",
     "cah_profile_reset", "cah_profile_read", "cah_synth_reads",
@@ -100,6 +100,7 @@ def lib():
     L.cah_plan_n_adapters.argtypes = [vp]
     L.cah_plan_effective_length.argtypes = [vp, i32, C.POINTER(i32)]
     L.cah_plan_n_kmer_entries.argtypes = [vp, i32, C.POINTER(i32)]
+    L.cah_plan_prefilter_kind.argtypes = [vp, i32, C.POINTER(i32)]
     L.cah_locate_batch.argtypes = [vp, i32, vp, vp, vp, i64, vp, vp, vp, C.c_size_t, vp]
     L.cah_kmers_present_batch.argtypes = [vp, i32, vp, vp, vp, i64, vp, vp]
     L.cah_match_batch.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp, vp, C.c_size_t, vp]
@@ -271,6 +272,12 @@ class Plan:
         out = C.c_int32(0)
         check(lib().cah_plan_effective_length(self._h, adapter, C.byref(out)))
         return out.value
+
+    def prefilter_kind(self, adapter: int = 0) -> str:
+        """'none', 'general' or 'lean': the prefilter kernel that serves this adapter"""
+        out = C.c_int32(0)
+        check(lib().cah_plan_prefilter_kind(self._h, adapter, C.byref(out)))
+        return ("none", "general", "lean")[out.value]
 
     def n_kmer_entries(self, adapter: int = 0) -> int:
         out = C.c_int32(0)

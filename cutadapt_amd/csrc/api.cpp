@@ -519,6 +519,15 @@ int cah_plan_effective_length(const cah_plan* plan, int32_t adapter, int32_t* ou
     return CAH_OK;
 }
 
+int cah_plan_prefilter_kind(const cah_plan* plan, int32_t adapter, int32_t* out) {
+    int rc = check_adapter(plan, adapter);
+    if (rc) return rc;
+    if (!out) return fail(CAH_EINVAL, "out is NULL");
+    const CahMatcher& mt = plan->matchers[(size_t)adapter];
+    *out = !mt.has_filter ? CAH_PREFILTER_NONE : (plan->lean[(size_t)adapter].ok ? CAH_PREFILTER_LEAN : CAH_PREFILTER_GENERAL);
+    return CAH_OK;
+}
+
 int cah_plan_n_kmer_entries(const cah_plan* plan, int32_t adapter, int32_t* out) {
     int rc = check_adapter(plan, adapter);
     if (rc) return rc;

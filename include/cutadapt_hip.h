@@ -123,6 +123,12 @@ int cah_plan_n_adapters(const cah_plan *plan);
 int cah_plan_effective_length(const cah_plan *plan, int32_t adapter, int32_t *out);
 /* number of packed 64-bit shift-and words (KmerFinder.number_of_searches) */
 int cah_plan_n_kmer_entries(const cah_plan *plan, int32_t adapter, int32_t *out);
+/* which prefilter kernel serves this adapter: none (MockKmerFinder), the general shift-and kernel, or
+ * the lean kernel (all search sets are whole-read / last-L / first-L windows, k-mers <= 32) */
+#define CAH_PREFILTER_NONE 0
+#define CAH_PREFILTER_GENERAL 1
+#define CAH_PREFILTER_LEAN 2
+int cah_plan_prefilter_kind(const cah_plan *plan, int32_t adapter, int32_t *out);
 
 /* ---- batch entry points (device pointers, asynchronous) --------------------------------- */
 /* Aligner.locate / PrefixComparer.locate / SuffixComparer.locate over a batch.

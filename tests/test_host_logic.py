@@ -144,3 +144,22 @@ def test_adapter_parameter_normalisation():
     m = A.RemoveAfterMatch(0, 4, 10, 14, 4, 0, adapter=a, sequence="ACGTACGTAAACGTTT")
     assert m.trimmed("ACGTACGTAAACGTTT") == "ACGTACGTAA" and m.rest() == "TT"
     assert m.remainder_interval() == (0, 10) and m.removed_sequence_length() == 6
+
+
+def test_prefilter_kernel_selection():
+    """which prefilter kernel a plan gets (host-side decision of cah_plan_create): everything
+    kmer_heuristic builds is 'lean', hand-made windows and long k-mers stay 'general'"""
+    from cutadapt_amd import adapters as A
+    from cutadapt_amd._kmer_finder import KmerFinder
+    T = "AGATCGGAAGAGCACACGTCTGAACTCCAGTCA"
+    assert A.BackAdapter(T)._fused_plan.prefilter_kind() == "lean"
+    assert A.FrontAdapter(T)._fused_plan.prefilter_kind() == "lean"
+    assert A.AnywhereAdapter(T)._fused_plan.prefilter_kind() == "lean"
+    assert A.NonInternalBackAdapter(T)._fused_plan.prefilter_kind() == "lean"
+    assert A.BackAdapter("ACGTNNACGTRYACGT", max_errors=0.2)._fused_plan.prefilter_kind() == "lean"      # IUPAC adapters too
+    assert A.PrefixAdapter(T, indels=False)._fused_plan.prefilter_kind() == "none"                      # comparer: MockKmerFinder
+    assert KmerFinder([(5, 40, ["ACGTACG"])])._plan.prefilter_kind() == "lean"                          # head window inside the span
+    assert KmerFinder([(5, 80, ["ACGTACG"])])._plan.prefilter_kind() == "general"                       # window beyond 64 characters
+    assert KmerFinder([(0, -3, ["ACGTACG"])])._plan.prefilter_kind() == "general"                       # negative stop
+    assert KmerFinder([(0, None, ["A" * 40])])._plan.prefilter_kind() == "general"                      # k-mer longer than 32
+    assert KmerFinder([(-80, None, ["ACGT"])])._plan.prefilter_kind() == "general"                      # tail window beyond the span
