@@ -1,21 +1,27 @@
 #!/usr/bin/env python3
-"""bench.py -- Mreads/s of the adapter-matching hot path on MI355X (BASELINE.json metric).
+"""bench.py -- throughput of the adapter-matching hot path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--reads R]
+    python bench.py [--config C2|C3|C4|C5] [--gpus N] [--steps K] [--warmup W] [--reads R]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload = BASELINE.json configs[1] ("C2"): 100 M synthetic 150 bp
-reads per GPU, single 3' adapter (-a, 33 bp Illumina TruSeq), e = 0.1, min_overlap 3; 25 % of
-the reads carry an (edited) adapter copy, 0.5 % of the bases are N.  A *step* is one pass of
-the hot path (k-mer prefilter -> survivor queue -> banded DP -> 6-tuple per read) over the
-whole batch, with reads and results resident in HBM.  Reads shard embarrassingly across
-GPUs (rank r generates and matches read indices [r*R, (r+1)*R)); there is no data-path
-collective -- torch.distributed is used for the start/stop barriers and the max-over-ranks
-time only.  Prints ONE JSON line on rank 0.
+Default workload = BASELINE.json configs[1] ("C2"): 100 M synthetic 150 bp reads per
+GPU, single 3' adapter (TruSeq, 33 bp), e = 0.1, min_overlap 3; 25 % of the reads carry an (edited)
+adapter copy, 0.5 % of the bases are N.  --config selects the other BASELINE configs (C3 linked adapter
+with IUPAC wildcards, C4 96 adapters, C5 paired-end 2 x 2 adapters); each prints the same JSON shape.
+A *step* is one pass of the hot path over the whole batch (k-mer prefilter -> survivor queue -> cost scan
+-> banded DP -> 6-tuple per read), reads and results resident in HBM.
+
+Multi-GPU: reads shard embarrassingly (rank r owns read indices [r*R, (r+1)*R)), there is NO data-path
+collective and no RCCL: the ranks only meet at the start/stop barriers and for the max-over-ranks time,
+over a gloo process group on 127.0.0.1.  `python bench.py --gpus N` without a launcher starts the N ranks
+itself (one process per device) and refuses when fewer than N devices are visible.
+Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,61 +29,190 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-TRUSEQ = "AGATCGGAAGAGCACACGTCTGAACTCCAGTCA"
-READ_LEN = 150
-GEN = {"p_adapter": 0.25, "p_edit": 0.02, "p_n": 0.005}
-SEED = 2
-ALGO_BYTES_PER_READ = 178          # 150 bases + 4 offset + 24 result
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8.0 TB/s spec
+N_SIMD = 256 * 4                   # MI355X: 256 CUs x 4 SIMDs
+CLOCK_GHZ = 2.4
+DEFAULT_READS = {"C2": 100_000_000, "C3": 100_000_000, "C4": 100_000_000, "C5": 125_000_000}
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="C2", choices=["C2", "C3", "C4", "C5"])
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=100_000_000, help="reads per GPU (default: the C2 size)")
+    ap.add_argument("--reads", type=int, default=None,
+                    help="units (reads, or read pairs for C5) per GPU; default: the BASELINE size of the config")
     ap.add_argument("--p-adapter", type=float, default=None,
                     help="override the adapter fraction of the read model (SURVEY 8(d): 0 and 1 are the extremes; "
                          "the headline number uses the default 0.25)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--check-reads", type=int, default=50_000, help="reads compared with the oracle (untimed)")
-    return ap.parse_args()
+    ap.add_argument("--check-reads", type=int, default=200_000, help="reads compared with the oracle (untimed)")
+    return ap.parse_args(argv)
+
+
+# -------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` without torchrun starts the N ranks itself
+# -------------------------------------------------------------------------------------------------
+def self_launch(args) -> int:
+    import torch
+    visible = torch.cuda.device_count()
+    if visible < args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} requested but only {visible} HIP device(s) are visible; "
+                         f"refusing to run a {args.gpus}-GPU benchmark on fewer devices")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, p.wait())
+    return rc
+
+
+# -------------------------------------------------------------------------------------------------
+# per-config steps (device-resident)
+# -------------------------------------------------------------------------------------------------
+class Workload:
+    def __init__(self, config, n, rank, device, gen):
+        import torch
+        from cutadapt_amd import _lib, workloads
+        from cutadapt_amd import adapters as A
+        from cutadapt_amd.batch import BatchResult
+        self.config, self.n, self.spec = config, n, workloads.SPECS[config]
+        kind = self.spec["kind"]
+        first = rank * n
+
+        def result():
+            return BatchResult(torch.empty((n, 6), dtype=torch.int32, device=device),
+                               torch.empty(n, dtype=torch.uint8, device=device),
+                               torch.empty(n, dtype=torch.int32, device=device))
+        back = [A.BackAdapter(s, max_errors=0.1, min_overlap=3) for s in self.spec["adapters"]]
+        self.adapters = back
+        self.batches = [workloads.device_batch(config, n, first, 0, device, gen)]
+        self.outs = [result()]
+        if kind == "single":
+            self.plans = [back[0]._fused_plan]
+        elif kind == "linked":
+            self.front = A.PrefixAdapter(self.spec["front"], max_errors=0.1)
+            self.plans = [self.front._fused_plan, back[0]._fused_plan]
+            self.outs.append(result())
+        elif kind == "multi":
+            self.plans = [_lib.Plan([a.matcher_spec() for a in back])]
+        elif kind == "paired":
+            self.adapters2 = [A.BackAdapter(s, max_errors=0.1, min_overlap=3) for s in self.spec["adapters2"]]
+            self.plans = [_lib.Plan([a.matcher_spec() for a in back]), _lib.Plan([a.matcher_spec() for a in self.adapters2])]
+            self.batches.append(workloads.device_batch(config, n, first, 1, device, gen))
+            self.outs.append(result())
+        for b in self.batches:
+            b.workspace()
+
+    def step(self):
+        from cutadapt_amd.batch import linked_match_batch, match_batch
+        kind = self.spec["kind"]
+        if kind == "linked":
+            linked_match_batch(self.plans[0], self.plans[1], self.batches[0], self.outs[0], self.outs[1])
+        elif kind == "paired":
+            match_batch(self.plans[0], self.batches[0], self.outs[0])
+            match_batch(self.plans[1], self.batches[1], self.outs[1])
+        else:
+            match_batch(self.plans[0], self.batches[0], self.outs[0])
+
+    # ---- parity sample: the first m reads of rank 0, bit-compared with the oracle --------------------
+    def parity(self, m):
+        import numpy as np
+        from oracle import host_workloads
+        from oracle import oracle as orc
+        kind = self.spec["kind"]
+        m = min(m, self.n)
+        gen = self.gen
+        checked = []
+
+        def oracle_multi(adapters, seqs, offsets):
+            want6 = np.zeros((m, 6), dtype=np.int32)
+            want_st = np.zeros(m, dtype=np.uint8)
+            want_best = np.full(m, -1, dtype=np.int32)
+            for idx, ad in enumerate(adapters):
+                oa = orc.Aligner(ad.sequence, ad.max_error_rate, 14, False, False, 1, ad.min_overlap)
+                of = orc.KmerFinder(ad.kmer_finder.positions_and_kmers)
+                c6, st = orc.match_batch(oa, of, seqs, offsets)
+                f = st == 1
+                better = f & ((want_st == 0) | (c6[:, 4] > want6[:, 4]) | ((c6[:, 4] == want6[:, 4]) & (c6[:, 5] < want6[:, 5])))
+                want6[better] = c6[better]
+                want_best[better] = idx
+                want_st[better] = 1
+            return want6, want_st, want_best
+
+        def same(out, want6, want_st, what, want_best=None):
+            ok = np.array_equal(out.out6[:m].cpu().numpy(), want6) and np.array_equal(out.status[:m].cpu().numpy(), want_st)
+            if ok and want_best is not None:
+                ok = np.array_equal(out.best_adapter[:m].cpu().numpy()[want_st == 1], want_best[want_st == 1])
+            checked.append(f"{what}: {'ok' if ok else 'MISMATCH'}")
+            return ok
+
+        ok = True
+        for mate, batch in enumerate(self.batches):
+            seqs, offsets = host_workloads.host_reads(self.config, 0, m, mate, gen)
+            ok &= np.array_equal(batch.seqs[: m * 150].cpu().numpy(), seqs)       # generator twin
+            if kind in ("single", "multi", "paired"):
+                ads = self.adapters if mate == 0 else self.adapters2
+                want6, want_st, want_best = oracle_multi(ads, seqs, offsets)
+                ok &= same(self.outs[mate], want6, want_st, f"mate {mate + 1}" if kind == "paired" else "tuples",
+                           want_best if len(ads) > 1 else None)
+            else:
+                fs = self.front.matcher_spec()
+                ofa = orc.Aligner(fs.sequence, fs.max_error_rate, fs.flags, fs.wildcard_ref, fs.wildcard_query,
+                                  fs.indel_cost, fs.min_overlap)
+                off = orc.KmerFinder(fs.kmer_sets, fs.kmer_ref_wildcards, fs.kmer_query_wildcards) if fs.kmer_sets is not None else None
+                f6, fst = orc.match_batch(ofa, off, seqs, offsets)
+                ok &= same(self.outs[0], f6, fst, "front stage")
+                # back stage on read[rstop:] (reference adapters.py:1222-1224)
+                starts = np.where(fst == 1, f6[:, 3], 0).astype(np.int64)
+                subs = [bytes(seqs[offsets[i] + starts[i]:offsets[i + 1]]) for i in range(m)]
+                s2, o2 = orc.pack_reads(subs)
+                b6, bst, _ = oracle_multi(self.adapters, s2, o2)
+                ok &= same(self.outs[1], b6, bst, "back stage")
+        return ok, f"{'ok' if ok else 'MISMATCH'} ({m} reads{' per mate' if kind == 'paired' else ''} bit-compared with the oracle: {', '.join(checked)})"
 
 
 def main():
     args = parse_args()
-    if args.p_adapter is not None:
-        GEN["p_adapter"] = float(args.p_adapter)
-    import torch
-    import torch.distributed as dist
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    import torch.distributed as dist
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} wants device {local_rank} but only {torch.cuda.device_count()} "
+                         f"device(s) are visible")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)     # barriers only: no RCCL on this path
 
-    from cutadapt_amd import _lib
-    from cutadapt_amd.adapters import BackAdapter
-    from cutadapt_amd.batch import BatchResult, ReadBatch, match_batch
-
+    from cutadapt_amd import _lib, workloads
     L = _lib.lib()
-    n = args.reads
-    adapter = BackAdapter(TRUSEQ, max_errors=0.1, min_overlap=3)
-    plan = adapter._fused_plan
+    gen = dict(workloads.GEN)
+    if args.p_adapter is not None:
+        gen["p_adapter"] = float(args.p_adapter)
+    spec = workloads.SPECS[args.config]
+    n = args.reads if args.reads is not None else DEFAULT_READS[args.config]
 
-    # ---- inputs resident in HBM before the timed region ------------------------------------
-    batch = ReadBatch.synthetic(n, READ_LEN, [TRUSEQ], seed=SEED, first_index=rank * n, **GEN)
-    out = BatchResult(torch.empty((n, 6), dtype=torch.int32, device=device),
-                      torch.empty(n, dtype=torch.uint8, device=device),
-                      torch.empty(n, dtype=torch.int32, device=device))
-    batch.workspace()
+    # ---- inputs resident in HBM before the timed region ------------------------------------------
+    wl = Workload(args.config, n, rank, device, gen)
+    wl.gen = gen
     torch.cuda.synchronize()
 
     def barrier():
@@ -87,81 +222,96 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        match_batch(plan, batch, out)
+        wl.step()
     barrier()
     L.cah_profile_reset()
     L.cah_profile_enable(1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        match_batch(plan, batch, out)
+        wl.step()
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    elapsed_local = time.perf_counter() - t0
     barrier()
     L.cah_profile_enable(0)
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    elapsed = elapsed_local
+    per_rank = [n * args.steps / elapsed_local / 1e6]
     if world > 1:
+        t = torch.tensor([elapsed_local], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+        elapsed = float(t.item())
+        gathered = [None] * world
+        dist.all_gather_object(gathered, per_rank[0])
+        per_rank = gathered
 
-    # ---- per-kernel durations from the HIP events recorded on the launch stream ------------
+    # ---- per-kernel durations from the HIP events recorded on the launch stream ------------------
     import ctypes as C
     ms = (C.c_double * _lib.PROF_N)()
     launches = (C.c_int64 * _lib.PROF_N)()
     units = (C.c_int64 * _lib.PROF_N)()
     _lib.check(L.cah_profile_read(ms, launches, units))
     L.cah_profile_reset()
-    filter_ms = ms[_lib.PROF_FILTER] / max(launches[_lib.PROF_FILTER], 1)
-    dp_ms = ms[_lib.PROF_DP] / max(launches[_lib.PROF_DP], 1)
-    # reads the DP kernel actually processed = survivors of the prefilter (queue length)
-    ws = batch.workspace()
-    survivors = int(ws[256:264].view(torch.int64).item())     # queue count (workspace layout, api.cpp)
-    status = out.status
+    fam = {"k_filter": _lib.PROF_FILTER, "k_back_scan": _lib.PROF_SCAN, "k_dp": _lib.PROF_DP, "k_comparer": _lib.PROF_COMPARER}
+    step_ms = {k: ms[i] / args.steps for k, i in fam.items()}
+    per_launch_ms = {k: ms[i] / max(launches[i], 1) for k, i in fam.items()}
+    launches_per_step = {k: launches[i] / args.steps for k, i in fam.items()}
+    status = wl.outs[-1].status if spec["kind"] == "linked" else wl.outs[0].status
     n_match = int((status == 1).sum().item())
     n_invalid = int((status == 2).sum().item())
+    survivors, dp_reads = None, None
+    if spec["kind"] == "single":
+        ws = wl.batches[0].workspace()
+        survivors = int(ws[256:264].view(torch.int64).item())         # queue count (workspace layout, api.cpp)
+        dp_reads = int(ws[768:776].view(torch.int64).item()) + int(ws[896:904].view(torch.int64).item())
 
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
 
-    # ---- untimed parity spot check against the oracle ---------------------------------------
+    # ---- untimed parity check against the oracle ---------------------------------------------------
     parity = None
     if args.check_reads > 0:
-        import numpy as np
-        from oracle import oracle as orc
-        m = min(args.check_reads, n)
-        seqs, offsets = orc.synth_reads(SEED, 0, m, READ_LEN, [TRUSEQ], **GEN)
-        oa = orc.Aligner(TRUSEQ, 0.1, 14, False, False, 1, 3)
-        of = orc.KmerFinder(adapter.kmer_finder.positions_and_kmers)
-        want6, want_st = orc.match_batch(oa, of, seqs, offsets)
-        ok = np.array_equal(out.out6[:m].cpu().numpy(), want6) and np.array_equal(out.status[:m].cpu().numpy(), want_st)
-        parity = f"{'ok' if ok else 'MISMATCH'} ({m} reads bit-compared with the oracle)"
+        ok, parity = wl.parity(args.check_reads)
         if not ok:
             raise SystemExit("parity check against the oracle FAILED: " + parity)
 
-    total_reads = n * world * args.steps
-    value = total_reads / elapsed / 1e6
-    # dominant kernel: whichever of filter / DP took longer per launch
-    if dp_ms >= filter_ms:
-        dom, dom_ms, dom_units = "k_dp", dp_ms, survivors
-    else:
-        dom, dom_ms, dom_units = "k_filter", filter_ms, n
-    achieved = dom_units * ALGO_BYTES_PER_READ / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-    step_gbs = n * ALGO_BYTES_PER_READ / ((filter_ms + dp_ms) * 1e-3) / 1e9 if filter_ms + dp_ms > 0 else 0.0
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    bytes_per_unit = spec["bytes_per_unit"]
+    total_units = n * world * args.steps
+    value = total_units / elapsed / 1e6
+    # dominant kernel family: the one with the largest share of a step
+    dom = max(step_ms, key=lambda k: step_ms[k])
+    dom_launch_ms = per_launch_ms[dom]
+    reads_per_launch = n
+    if spec["kind"] == "single":
+        reads_per_launch = {"k_filter": n, "k_back_scan": survivors, "k_dp": dp_reads if dp_reads else survivors,
+                            "k_comparer": n}[dom]
+    per_read_bytes = 178 if spec["kind"] != "multi" else 182
+    achieved = reads_per_launch * per_read_bytes / (dom_launch_ms * 1e-3) / 1e9 if dom_launch_ms > 0 else 0.0
+    kernel_sum = sum(step_ms.values())
+    step_gbs = n * bytes_per_unit / (kernel_sum * 1e-3) / 1e9 if kernel_sum > 0 else 0.0
+    traffic, valu = None, None
+    tpath = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if os.path.exists(tpath):
         try:
             with open(tpath) as f:
-                tj = json.load(f)
-            if tj.get("reads_per_gpu") == n and tj.get("kernel") == dom:
-                traffic = tj.get("bytes_per_launch")
+                tj = json.load(f).get(args.config, {})
+            if tj.get("reads_per_gpu") == n:
+                k = tj.get("kernels", {}).get(dom)
+                if k:
+                    traffic = k.get("hbm_bytes_per_launch")
+                    if k.get("valu_insts_per_launch") and dom_launch_ms > 0:
+                        # wave64 VALU instructions x measured issue cycles (2-4, DESIGN.md: ~3 on this mix)
+                        # over the SIMD cycles the launch had
+                        cyc = k.get("cycles_per_valu_inst", 3.0)
+                        valu = {"insts_per_launch": k["valu_insts_per_launch"], "cycles_per_inst": cyc,
+                                "util": k["valu_insts_per_launch"] * cyc / (N_SIMD * CLOCK_GHZ * 1e9 * dom_launch_ms * 1e-3),
+                                "source": tj.get("source")}
         except Exception:
-            traffic = None
+            traffic, valu = None, None
     result = {
-        "metric": "Mreads/s (150 bp, 1 adapter, e=0.1)",
+        "metric": spec["metric"],
         "value": value,
-        "unit": "Mreads/s",
+        "unit": spec["unit"],
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
@@ -172,14 +322,17 @@ def main():
         "dtype": "int32",
         "data": "synthetic",
         "config": {
-            "workload": f"C2: {n} x {READ_LEN} bp synthetic reads per GPU, single 3' adapter (TruSeq 33 bp), "
-                        f"e=0.1, min_overlap=3, p_adapter={GEN['p_adapter']}, p_edit={GEN['p_edit']}, p_N={GEN['p_n']}",
-            "reads_per_gpu": n,
-            "read_len": READ_LEN,
-            "adapter": TRUSEQ,
-            "sharding": f"{world} x contiguous read ranges, no collective on the data path",
+            "workload": f"{args.config}: {n} x {'2 x ' if spec['kind'] == 'paired' else ''}{workloads.READ_LEN} bp synthetic "
+                        f"{'read pairs' if spec['kind'] == 'paired' else 'reads'} per GPU, {spec['what']}, "
+                        f"p_adapter={gen['p_adapter']}, p_edit={gen['p_edit']}, p_N={gen['p_n']}",
+            "units_per_gpu": n,
+            "read_len": workloads.READ_LEN,
+            "n_adapters": len(spec["adapters"]) + len(spec.get("adapters2", [])),
+            "sharding": f"{world} x contiguous read ranges, no collective on the data path (gloo barriers only)",
+            "per_rank_rate": per_rank,
             "matched_fraction": n_match / n,
-            "prefilter_pass_fraction": survivors / n,
+            "prefilter_pass_fraction": None if survivors is None else survivors / n,
+            "cell_dp_fraction_of_survivors": None if not survivors else dp_reads / survivors,
             "invalid_reads": n_invalid,
             "parity_check": parity,
         },
@@ -191,23 +344,35 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
-            "kernel_ms": {"k_filter": filter_ms, "k_dp": dp_ms},
-            "units_per_launch": {"k_filter": n, "k_dp": survivors},
-            "algorithmic_bytes_per_read": ALGO_BYTES_PER_READ,
+            "valu": valu,
+            "kernel_ms_per_step": step_ms,
+            "kernel_ms_per_launch": per_launch_ms,
+            "launches_per_step": launches_per_step,
+            "reads_per_launch": reads_per_launch,
+            "algorithmic_bytes_per_unit": bytes_per_unit,
             "whole_step_GBps": step_gbs,
-            "note": "integer DP is VALU-bound, not HBM-bound (see DESIGN.md); frac is reported against the HBM roof as the contract asks",
+            "whole_step_frac": step_gbs / HBM_PEAK_GBS,
+            "note": "integer shift-and / bit-vector / DP kernels are VALU-bound, not HBM-bound (DESIGN.md); frac is "
+                    "reported against the HBM roof as the contract asks, valu.util against the VALU issue roof",
         },
     }
     if world == 1 and not args.no_cpu_baseline:
         from oracle import cpu_baseline
         try:
-            result["cpu_baseline"] = cpu_baseline.run(SEED, READ_LEN, TRUSEQ, 0.1, 3, GEN,
-                                                      target_seconds=args.cpu_seconds)
-            result["gpu_over_cpu"] = value / result["cpu_baseline"]["value"]
+            result["cpu_baseline"] = cpu_baseline.run(args.config, gen, target_seconds=args.cpu_seconds)
+            cb = result["cpu_baseline"]
+            result["gpu_over_cpu"] = {
+                "measured": value / cb["value"],
+                "vs_all_host_threads_linear_extrapolation": value / (cb["value"] / cb["cores"] * cb["host_logical_cpus"]),
+                "note": f"measured on {cb['cores']} worker processes (cgroup quota of this container); the second figure "
+                        f"scales that linearly to all {cb['host_logical_cpus']} hardware threads of the host (an upper "
+                        f"bound for the CPU: SMT siblings and memory bandwidth do not scale linearly)",
+            }
         except Exception as exc:        # the GPU numbers must survive a host-side hiccup
-            result["cpu_baseline"] = {"value": None, "unit": "Mreads/s", "cores": cpu_baseline.available_cores(),
+            result["cpu_baseline"] = {"value": None, "unit": spec["unit"], "cores": cpu_baseline.available_cores(),
                                       "kind": "reference", "sample": f"failed: {exc!r}"[:300]}
     print(json.dumps(result))
+    sys.stdout.flush()
     if world > 1:
         dist.destroy_process_group()
 

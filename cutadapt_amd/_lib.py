@@ -15,13 +15,13 @@ CAH_OK, CAH_EINVAL, CAH_ETYPE, CAH_EHIP, CAH_ENOMEM, CAH_EUNSUPPORTED = 0, 1, 2,
 NONE, MATCH, INVALID = 0, 1, 2
 KIND_ALIGNER, KIND_PREFIX, KIND_SUFFIX, KIND_KMER_ONLY = 0, 1, 2, 3
 MAX_ADAPTER_LEN = 64
-PROF_FILTER, PROF_DP, PROF_COMPARER, PROF_N = 0, 1, 2, 3
+PROF_FILTER, PROF_DP, PROF_COMPARER, PROF_SCAN, PROF_N = 0, 1, 2, 3, 4
 
 # every symbol include/cutadapt_hip.h declares (tests check the library exports them all)
 EXPORTED_SYMBOLS = [
     "cah_abi_version", "cah_last_error", "cah_device_count", "cah_set_device", "cah_device_info",
     "cah_plan_create", "cah_plan_destroy", "cah_plan_n_adapters", "cah_plan_effective_length",
-    "cah_plan_n_kmer_entries", "cah_plan_prefilter_kind", "cah_locate_batch", "cah_kmers_present_batch", "cah_match_batch",
+    "cah_plan_n_kmer_entries", "cah_plan_prefilter_kind", "cah_plan_debug_matcher", "cah_locate_batch", "cah_kmers_present_batch", "cah_match_batch",
     "cah_workspace_bytes", "cah_validate_ascii_batch", "cah_locate_batch_host",
     "cah_kmers_present_batch_host", "cah_match_batch_host", "cah_profile_enable",
     "cah_profile_reset", "cah_profile_read", "cah_synth_reads",
@@ -101,6 +101,7 @@ def lib():
     L.cah_plan_effective_length.argtypes = [vp, i32, C.POINTER(i32)]
     L.cah_plan_n_kmer_entries.argtypes = [vp, i32, C.POINTER(i32)]
     L.cah_plan_prefilter_kind.argtypes = [vp, i32, C.POINTER(i32)]
+    L.cah_plan_debug_matcher.argtypes = [vp, i32, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.cah_locate_batch.argtypes = [vp, i32, vp, vp, vp, i64, vp, vp, vp, C.c_size_t, vp]
     L.cah_kmers_present_batch.argtypes = [vp, i32, vp, vp, vp, i64, vp, vp]
     L.cah_match_batch.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp, vp, C.c_size_t, vp]

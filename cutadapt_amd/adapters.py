@@ -386,7 +386,10 @@ class SingleAdapter(Adapter, ABC):
         """Match this adapter to every read of a ReadBatch."""
         from . import batch as _b
         work = _reverse_batch(batch) if self._reverse_reads else batch
-        res = _b.match_batch(self._fused_plan, work)
+        return self._batch_matches(_b.match_batch(self._fused_plan, work), batch)
+
+    def _batch_matches(self, res, batch) -> BatchMatches:
+        """device result of this adapter's fused plan -> host arrays in match coordinates"""
         out6, status, _ = res.cpu()
         _raise_if_invalid(status)
         found = status == _lib.MATCH
@@ -765,12 +768,20 @@ class LinkedAdapter(Adapter):
     def match_to_batch(self, batch) -> LinkedBatchMatches:
         """Two dependent stages: the back adapter is searched in the suffix after the front
         match (device-side view, no copy)."""
-        import torch
-        front = self.front_adapter.match_to_batch(batch)
-        lens = batch.lengths()
-        rstop = torch.from_numpy(np.where(front.found, front.coords[:, 3], 0)).to(batch.device)
-        view = batch.view(rstop, lens - rstop)
-        back = self.back_adapter.match_to_batch(view)
+        fa, ba = self.front_adapter, self.back_adapter
+        if fa._reverse_reads or ba._reverse_reads:
+            # Rightmost* parts work on reversed copies: stage by stage through the adapter classes
+            import torch
+            front = fa.match_to_batch(batch)
+            lens = batch.lengths()
+            rstop = torch.from_numpy(np.where(front.found, front.coords[:, 3], 0)).to(batch.device)
+            view = batch.view(rstop, lens - rstop)
+            back = ba.match_to_batch(view)
+        else:
+            from . import batch as _b
+            f_res, b_res, view = _b.linked_match_batch(fa._fused_plan, ba._fused_plan, batch)
+            front = fa._batch_matches(f_res, batch)
+            back = ba._batch_matches(b_res, view)
         ok = np.ones(len(front), dtype=bool)
         if self.front_required:
             ok &= front.found

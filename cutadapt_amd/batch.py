@@ -149,8 +149,10 @@ class ReadBatch:
         Used for the second stage of linked adapters (reference adapters.py:1222-1224)."""
         torch = _torch()
         base = self.offsets[: self.n_reads]
-        return ReadBatch(self.seqs, base + starts.to(torch.int64), lens.to(torch.int32),
-                         n_reads=self.n_reads, validated=self.validated)
+        v = ReadBatch(self.seqs, base + starts.to(torch.int64), lens.to(torch.int32),
+                      n_reads=self.n_reads, validated=self.validated)
+        v._workspace = self._workspace       # same reads, same stream order: the scratch can be shared
+        return v
 
     def lengths(self):
         torch = _torch()
@@ -244,3 +246,19 @@ def match_batch(plan: "_lib.Plan", batch: ReadBatch, out: Optional[BatchResult] 
                 out.out6.data_ptr(), out.best_adapter.data_ptr() if out.best_adapter is not None else None,
                 out.status.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr()))
     return out
+
+
+def linked_match_batch(front_plan: "_lib.Plan", back_plan: "_lib.Plan", batch: ReadBatch,
+                       out_front: Optional[BatchResult] = None, out_back: Optional[BatchResult] = None):
+    """LinkedAdapter.match_to over a batch, entirely on the device (reference adapters.py:1215-1227):
+    the 5' adapter on the reads, then the 3' adapter on the part after the 5' match -- a view
+    (start = rstop of the front match, or 0) into the same HBM buffer.  Returns (front, back, view);
+    the required/optional verdict is the caller's (it needs only the two status arrays)."""
+    torch = _torch()
+    front = match_batch(front_plan, batch, out_front)
+    rstop = torch.where(front.status == 1, front.out6[:, 3], torch.zeros((), dtype=torch.int32, device=batch.device))
+    lens = batch.lengths()
+    batch.workspace()
+    view = batch.view(rstop, lens - rstop.to(torch.int64))
+    back = match_batch(back_plan, view, out_back)
+    return front, back, view

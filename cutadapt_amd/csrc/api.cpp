@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -123,6 +124,13 @@ bool kmer_chars_match(uint8_t rc, uint8_t qc, bool ref_wc, bool query_wc) {
     if (ref_wc && !query_wc) return (t.iupac[rc] & t.acgt[qc]) != 0;
     if (!ref_wc && query_wc) return (t.acgt[rc] & t.iupac[qc]) != 0;
     return (t.iupac[rc] & t.iupac[qc]) != 0;
+}
+
+// CAH_NO_SCAN=1 (read at plan creation): the plan is built without the cost scan (A/B measurements,
+// parity tests of the scan against the plain cell kernel)
+bool scan_disabled() {
+    const char* e = getenv("CAH_NO_SCAN");
+    return e && *e && *e != '0';
 }
 
 int clamp_floor(double x) {
@@ -301,6 +309,29 @@ static int build_matcher(const cah_adapter_desc& d, int index, CahMatcher& mt,
                 for (int i = 0; i < m; i++)
                     if (aligner_chars_match((uint8_t)seq[i], (uint8_t)ch, wr, wq)) bits |= 1ull << i;
                 mt.rowmask[ch] = bits;
+            }
+            // ---- bit-parallel cost scan in front of the cell DP (back_scan.h) ---------------------
+            // 3' adapters (Where.BACK) with unit costs and an ordinary error budget: 0 <= k < m,
+            // rate in [0, 1], min_overlap >= 1.  Everything else keeps the plain cell kernels.
+            mt.scan_ok = 0;
+            if (mt.flags == 14 && d.indel_cost == 1 && m >= 1 && m <= CAH_MAX_M && mt.k >= 0 && mt.k < m &&
+                rate >= 0.0 && rate <= 1.0 && d.min_overlap >= 1 && !scan_disabled()) {
+                mt.scan_ok = 1;
+                // a last-row candidate spans the whole adapter: effective length (:504-510)
+                mt.kacc = m >= d.min_overlap ? mt.thr[mt.effective_length] : -1;
+                if (mt.kacc > mt.k) mt.kacc = mt.k;
+                // row i of the last column: origin >= 0 for a 3' adapter, so length = i and the
+                // effective length is i minus the N's of adapter[0:i] (:543-553)
+                for (int i = 0; i <= CAH_MAX_M; i++) {
+                    int eff = i;
+                    if (wr) eff = i < m ? i - (mt.n_counts[std::min(i, m)] - mt.n_counts[0]) : mt.effective_length;
+                    if (i > m) eff = 0;
+                    mt.thr_last[i] = i <= m ? mt.thr[eff] : -1;
+                }
+                const int pad = 64 - m;
+                const uint64_t low = pad == 0 ? 0ull : ((1ull << pad) - 1ull);
+                for (int ch = 0; ch < CAH_TABLE_CHARS; ch++)
+                    mt.scanmask[ch] = (pad == 64 ? 0ull : (mt.rowmask[ch] << pad)) | low;
             }
         } else {
             // PrefixComparer / SuffixComparer (_align.pyx:615-642, :698-706)
@@ -528,6 +559,17 @@ int cah_plan_prefilter_kind(const cah_plan* plan, int32_t adapter, int32_t* out)
     return CAH_OK;
 }
 
+int cah_plan_debug_matcher(const cah_plan* plan, int32_t adapter, void* buf, size_t buflen, size_t* need) {
+    int rc = check_adapter(plan, adapter);
+    if (rc) return rc;
+    if (need) *need = sizeof(CahMatcher);
+    if (buf) {
+        if (buflen < sizeof(CahMatcher)) return fail(CAH_EINVAL, "buffer too small: need %zu bytes", sizeof(CahMatcher));
+        memcpy(buf, &plan->matchers[(size_t)adapter], sizeof(CahMatcher));
+    }
+    return CAH_OK;
+}
+
 int cah_plan_n_kmer_entries(const cah_plan* plan, int32_t adapter, int32_t* out) {
     int rc = check_adapter(plan, adapter);
     if (rc) return rc;
@@ -588,20 +630,43 @@ int cah_profile_read(double ms[CAH_PROF_N], int64_t launches[CAH_PROF_N], int64_
 // ---------------------------------------------------------------------------------------------
 // batch entry points
 // ---------------------------------------------------------------------------------------------
-// workspace layout: three counters, each on its own 256-byte line (they are hammered by
-// different kernels), then the survivor queue and its per-entry keys:
-//   [0,8) filter tile counter | [256,264) queue count | [512,520) DP work counter |
-//   [1024, +4n) queue | [.., +n) queue keys
+// workspace layout: counters, each on its own line (they are hammered by different kernels), then the
+// survivor queue with its per-entry keys and the cell-DP work list the cost scan writes:
+//   [0,8) filter tile counter | [128,136) uniform-batch flag | [256,264) queue count |
+//   [512,520) DP work counter | [640,648) scan tile counter | [768,776) DP list front count |
+//   [896,904) DP list back count |
+//   [1024, +4n) queue | [.., +n) queue keys | [.., +4n) DP work list | [.., +8n) its column windows
 static const size_t WS_HEADER = 1024;
+static const size_t WS_UFLAG = 128 / sizeof(unsigned long long);    // 0 after the check: all reads of the batch have one length
 static const size_t WS_QCOUNT = 256 / sizeof(unsigned long long), WS_DPWORK = 512 / sizeof(unsigned long long);
-static const size_t WS_UFLAG = 768 / sizeof(unsigned long long);    // 0 after the check: all reads of the batch have one length
+static const size_t WS_SCANWORK = 640 / sizeof(unsigned long long), WS_DPFRONT = 768 / sizeof(unsigned long long);
+static const size_t WS_DPBACK = 896 / sizeof(unsigned long long);
 
 static size_t ws_queue_bytes(int64_t n_reads) { return (sizeof(int32_t) * (size_t)n_reads + 255) & ~(size_t)255; }
+static size_t ws_keys_bytes(int64_t n_reads) { return ((size_t)n_reads + 255) & ~(size_t)255; }
 
 size_t cah_workspace_bytes(int64_t n_reads) {
     if (n_reads < 0) n_reads = 0;
-    return WS_HEADER + ws_queue_bytes(n_reads) + (size_t)n_reads + 256;
+    return WS_HEADER + 2 * ws_queue_bytes(n_reads) + ws_keys_bytes(n_reads) + 2 * ws_queue_bytes(n_reads) + 256;
 }
+
+namespace {
+struct Workspace {
+    unsigned long long* counters;
+    int32_t* queue;
+    uint8_t* keys;
+    int32_t* dp_queue;
+    int32_t* dp_win;
+    Workspace(void* base, int64_t n_reads) {
+        char* p = (char*)base;
+        counters = (unsigned long long*)p;              p += WS_HEADER;
+        queue = (int32_t*)p;                            p += ws_queue_bytes(n_reads);
+        keys = (uint8_t*)p;                             p += ws_keys_bytes(n_reads);
+        dp_queue = (int32_t*)p;                         p += ws_queue_bytes(n_reads);
+        dp_win = (int32_t*)p;
+    }
+};
+}  // namespace
 
 static int check_batch(const cah_plan* plan, const void* d_seqs, const void* d_offsets, int64_t n_reads) {
     if (!plan) return fail(CAH_EINVAL, "plan is NULL");
@@ -611,21 +676,47 @@ static int check_batch(const cah_plan* plan, const void* d_seqs, const void* d_o
     return CAH_OK;
 }
 
+// Aligner / comparer over a work list (d_queue == NULL: all reads).  3' adapters with unit costs go
+// through the cost scan first (k_back_scan finishes most reads, the rest reach k_dp_packed with an exact
+// column window); everything else runs the cell kernel directly.
 static int run_aligner(const cah_plan* plan, const PlanDeviceCopy* pd, int32_t adapter, const uint8_t* d_seqs,
                        const int64_t* d_offsets, const int32_t* d_lens, int64_t n_reads,
                        const int32_t* d_queue, const unsigned long long* d_queue_count,
-                       const uint8_t* d_queue_keys, unsigned long long* d_work_counter, int32_t* d_out6,
+                       const uint8_t* d_queue_keys, const Workspace& ws, int32_t* d_out6,
                        uint8_t* d_status, int32_t* d_best, int merge_best, hipStream_t s) {
     const CahMatcher& mt = plan->matchers[(size_t)adapter];
     DpArgs a;
     a.matcher = pd->d_matchers + adapter;
     a.seqs = d_seqs; a.offsets = d_offsets; a.lens = d_lens; a.n_reads = n_reads;
     a.max_read_len = CAH_MAX_READ_LEN;
-    a.queue = d_queue; a.queue_count = d_queue_count; a.queue_keys = d_queue_keys; a.work_counter = d_work_counter;
+    a.queue = d_queue; a.queue_count = d_queue_count; a.queue_keys = d_queue_keys;
+    a.work_counter = ws.counters + WS_DPWORK;
     a.out6 = d_out6; a.status = d_status; a.best_adapter = d_best;
     a.adapter_index = adapter; a.merge_best = merge_best;
-    HIP_TRY(hipMemsetAsync(d_work_counter, 0, sizeof(unsigned long long), s));
+    a.win = nullptr; a.queue_count_back = nullptr; a.queue_cap = 0;
+    // DP work counter, scan tile counter, DP list counts: one memset over their lines
+    HIP_TRY(hipMemsetAsync(ws.counters + WS_DPWORK, 0, WS_HEADER - WS_DPWORK * sizeof(unsigned long long), s));
     if (mt.kind == CAH_KIND_ALIGNER) {
+        if (mt.scan_ok) {
+            ScanArgs sa;
+            sa.matcher = a.matcher;
+            sa.seqs = d_seqs; sa.offsets = d_offsets; sa.lens = d_lens; sa.n_reads = n_reads;
+            sa.max_read_len = CAH_MAX_READ_LEN;
+            sa.queue = d_queue; sa.queue_count = d_queue_count; sa.queue_keys = d_queue_keys;
+            sa.work_counter = ws.counters + WS_SCANWORK;
+            sa.out6 = d_out6; sa.status = d_status; sa.best_adapter = d_best;
+            sa.adapter_index = adapter; sa.merge_best = merge_best;
+            sa.dp_queue = ws.dp_queue; sa.dp_win = ws.dp_win;
+            sa.dp_count_front = ws.counters + WS_DPFRONT; sa.dp_count_back = ws.counters + WS_DPBACK;
+            sa.dp_cap = n_reads;
+            {
+                ProfScope ps(s, CAH_PROF_SCAN, n_reads);
+                HIP_TRY(launch_back_scan(sa, n_reads, pd->n_cus, s));
+            }
+            a.queue = ws.dp_queue; a.queue_keys = nullptr; a.win = ws.dp_win;
+            a.queue_count = ws.counters + WS_DPFRONT; a.queue_count_back = ws.counters + WS_DPBACK;
+            a.queue_cap = n_reads;
+        }
         ProfScope ps(s, CAH_PROF_DP, n_reads);
         HIP_TRY(launch_dp(a, mt.m, mt.indel_cost == 1, mt.flags == 14, n_reads, pd->n_cus, s));
     } else {
@@ -649,12 +740,12 @@ int cah_locate_batch(const cah_plan* plan, int32_t adapter, const uint8_t* d_seq
     if (!d_out6 || !d_status) return fail(CAH_EINVAL, "output pointers are NULL");
     if (!d_workspace || workspace_bytes < cah_workspace_bytes(n_reads))
         return fail(CAH_EINVAL, "workspace too small: need %zu bytes", cah_workspace_bytes(n_reads));
-    unsigned long long* counters = (unsigned long long*)d_workspace;
+    const Workspace ws(d_workspace, n_reads);
     const PlanDeviceCopy* pd = nullptr;
     rc = plan_on_device(plan, &pd);
     if (rc) return rc;
     return run_aligner(plan, pd, adapter, d_seqs, d_offsets, d_lens, n_reads, nullptr, nullptr, nullptr,
-                       counters + 0, d_out6, d_status, nullptr, 0, (hipStream_t)stream);
+                       ws, d_out6, d_status, nullptr, 0, (hipStream_t)stream);
 }
 
 static int run_filter(const cah_plan* plan, const PlanDeviceCopy* pd, int32_t adapter, const uint8_t* d_seqs,
@@ -735,9 +826,8 @@ int cah_match_batch(const cah_plan* plan, const uint8_t* d_seqs, const int64_t* 
     const PlanDeviceCopy* pd = nullptr;
     rc = plan_on_device(plan, &pd);
     if (rc) return rc;
-    unsigned long long* counters = (unsigned long long*)d_workspace;
-    int32_t* d_queue = (int32_t*)((char*)d_workspace + WS_HEADER);
-    uint8_t* d_keys = (uint8_t*)d_workspace + WS_HEADER + ws_queue_bytes(n_reads);
+    const Workspace ws(d_workspace, n_reads);
+    unsigned long long* counters = ws.counters;
     HIP_TRY(hipMemsetAsync(d_status, 0, (size_t)n_reads, s));
     HIP_TRY(hipMemsetAsync(d_out6, 0, sizeof(int32_t) * 6 * (size_t)n_reads, s));
     if (d_best_adapter) HIP_TRY(launch_init_best(d_best_adapter, n_reads, pd->n_cus, s));
@@ -757,15 +847,15 @@ int cah_match_batch(const cah_plan* plan, const uint8_t* d_seqs, const int64_t* 
         const CahMatcher& mt = plan->matchers[(size_t)ad];
         if (mt.kind == CAH_KIND_KMER_ONLY) continue;
         if (mt.has_filter) {
-            // prefilter -> queue of surviving reads -> DP on dense waves
-            rc = run_filter(plan, pd, ad, d_seqs, d_offsets, d_lens, n_reads, 1, nullptr, d_status, d_queue,
-                            counters + WS_QCOUNT, d_keys, counters + 0, d_batch_flag, s);
+            // prefilter -> queue of surviving reads -> (cost scan ->) DP on dense waves
+            rc = run_filter(plan, pd, ad, d_seqs, d_offsets, d_lens, n_reads, 1, nullptr, d_status, ws.queue,
+                            counters + WS_QCOUNT, ws.keys, counters + 0, d_batch_flag, s);
             if (rc) return rc;
-            rc = run_aligner(plan, pd, ad, d_seqs, d_offsets, d_lens, n_reads, d_queue, counters + WS_QCOUNT,
-                             d_keys, counters + WS_DPWORK, d_out6, d_status, d_best_adapter, 1, s);
+            rc = run_aligner(plan, pd, ad, d_seqs, d_offsets, d_lens, n_reads, ws.queue, counters + WS_QCOUNT,
+                             ws.keys, ws, d_out6, d_status, d_best_adapter, 1, s);
         } else {
             rc = run_aligner(plan, pd, ad, d_seqs, d_offsets, d_lens, n_reads, nullptr, nullptr, nullptr,
-                             counters + WS_DPWORK, d_out6, d_status, d_best_adapter, 1, s);
+                             ws, d_out6, d_status, d_best_adapter, 1, s);
         }
         if (rc) return rc;
     }

@@ -1,0 +1,143 @@
+// back_scan.h -- bit-parallel COST scan of a 3' adapter (flags = QUERY_START | QUERY_STOP |
+// REFERENCE_END, unit costs) over one read, and the classification built on it.
+//
+// Why: Aligner.locate (reference src/cutadapt/_align.pyx:298-587) spends its time filling DP cells
+// with (cost, score, origin).  The COSTS alone follow Myers'/Hyyro's bit-vector recurrence -- one
+// 64-bit word holds a whole column of vertical deltas -- at ~1/10 of the instructions of the cell
+// loop, independent of the band.  From the costs alone one can decide, exactly:
+//
+//   * which columns j have C(m, j) <= k          -> where the reference evaluates a candidate in the
+//                                                   last row (:496-533)
+//   * which rows i of the last column are acceptable (cost <= thr, i >= min_overlap; :536-572)
+//
+// and that is enough to finish most reads without any cell DP:
+//
+//   NONE        no acceptable candidate anywhere                        -> locate() returns None
+//   EXACT_FULL  the first column whose row-m cost is 0 (the adapter occurs unedited) wins and the
+//               reference `break`s there (:531-533); a cost-0 alignment has no indels, so
+//               score = m, origin = j - m                               -> (0, m, j-m, j, m, 0)
+//   EXACT_TAIL  no acceptable last-row candidate, and the LARGEST acceptable row i of the last
+//               column costs 0 (the read ends with adapter[0:i]); smaller rows have score <= their
+//               row < i and cannot replace it (:563-567)                -> (0, i, n-i, n, i, 0)
+//   DP          everything else: the cell kernel runs, but only over the columns that can matter:
+//               from (first acceptable candidate column, or n) - m - k - 1 -- the windowing argument
+//               of DESIGN.md "Column skipping" with the exact position instead of the k-mer hit --
+//               and, when no row of the last column is acceptable, only up to the last acceptable
+//               candidate column (the last-column scan would change nothing and is skipped).
+//
+// The recurrence (Hyyro 2003, "search" variant: row 0 costs 0 in every column = QUERY_START):
+//     Xv = Eq | VN;  Xh = (((Eq & VP) + VP) ^ VP) | Eq
+//     HP = VN | ~(Xh | VP);  HN = VP & Xh
+//     VP' = (HN << 1) | ~(Xv | (HP << 1));  VN' = (HP << 1) & Xv
+// The adapter sits in the TOP m bits of the word; the 64 - m bits below it are "rows" that match
+// every character (Eq bit 1, vertical delta 0): they cost 0 in every column, exactly like row 0, so
+// row m is always bit 63 and its horizontal delta is the sign of the high half.
+//
+// The same code is compiled by hipcc into k_back_scan (kernels.hip) and by g++ into the host model
+// that tests/test_back_scan_model.py fuzzes against the oracle (test infrastructure; the product has
+// no CPU path).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define CAH_HD __host__ __device__ __forceinline__
+#else
+#define CAH_HD inline
+#endif
+
+enum { BS_NONE = 0, BS_EXACT_FULL = 1, BS_EXACT_TAIL = 2, BS_DP = 3 };
+
+struct BackScanParams {
+    int m;            // adapter length, 1..64
+    int k;            // (int)(rate * m), 0 <= k < m
+    int kacc;         // thr[effective_length]: a last-row candidate is acceptable iff cost <= kacc (<= k);
+                      // -1 when m < min_overlap (never acceptable)
+    int min_overlap;  // >= 1
+    int half_m;       // m / 2
+};
+
+struct BackScanState {
+    uint64_t VP, VN;
+    int cm;           // C(m, j) of the column just processed
+    int jfa, jla;     // first / last column with cm <= kacc (-1: none)
+    int jf_any;       // first column with cm <= k (diagnostic; equals the first column where the reference's
+                      // band reaches row m)
+};
+
+CAH_HD uint64_t bs_shl1(uint64_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // 64-bit shifts are slow on gfx950; by one bit: low half doubles, high half is a funnel shift
+    const unsigned lo = (unsigned)x, hi = (unsigned)(x >> 32);
+    const unsigned nhi = __builtin_amdgcn_alignbit(hi, lo, 31);
+    return ((uint64_t)nhi << 32) | (uint64_t)(lo + lo);
+#else
+    return x << 1;
+#endif
+}
+
+// first column of the window: costs 0 (pad rows), 1, 2, ..., m
+CAH_HD void bs_init(BackScanState& s, const BackScanParams& p) {
+    const int pad = 64 - p.m;
+    s.VP = pad == 0 ? ~0ull : ~((1ull << pad) - 1ull);
+    s.VN = 0;
+    s.cm = p.m;
+    s.jfa = -1; s.jla = -1; s.jf_any = -1;
+}
+
+// One column.  eq: the padded match word of this read character (CahMatcher::scanmask[c]).
+// Returns true when the read is finished as EXACT_FULL at this column.
+CAH_HD bool bs_step(BackScanState& s, const uint64_t eq, const int j, const BackScanParams& p) {
+    const uint64_t VP = s.VP, VN = s.VN;
+    const uint64_t Xv = eq | VN;
+    const uint64_t Xh = (((eq & VP) + VP) ^ VP) | eq;
+    const uint64_t HP = VN | ~(Xh | VP);
+    const uint64_t HN = VP & Xh;
+    // row m is bit 63: horizontal delta +1 / -1
+    s.cm += (int)(HP >> 63) - (int)(HN >> 63);
+    const uint64_t HPs = bs_shl1(HP), HNs = bs_shl1(HN);
+    s.VP = HNs | ~(Xv | HPs);
+    s.VN = HPs & Xv;
+    if (s.cm <= p.k && s.jf_any < 0) s.jf_any = j;
+    if (s.cm <= p.kacc) {
+        if (s.jfa < 0) s.jfa = j;
+        s.jla = j;
+        // (:521-533) a cost-0 candidate has score m, more than any earlier best (those cost >= 1: the
+        // first cost-0 column ends the loop), so it replaces the best iff it is the first or
+        // origin = j - m <= best.origin + m/2.  Every earlier acceptable candidate sits at a column
+        // >= jfa and spans rel <= m + kacc columns, i.e. best.origin >= jfa - m - kacc.
+        if (s.cm == 0 && j - s.jfa <= p.half_m - p.kacc) return true;
+    }
+    return false;
+}
+
+// After the last column (j == n) without EXACT_FULL.  thr_last(i): error threshold of row i in the last
+// column = thr[effective length of adapter[0:i]] (CahMatcher::thr_last).  j0 = first column of the window
+// (the cost scan itself started there).  Outputs: o0/o1 = (row i, -) for EXACT_TAIL, (first DP column,
+// last DP column * 2 + scan flag) for DP.
+template <class ThrLast>
+CAH_HD int bs_finish(const BackScanState& s, const int n, const int j0, const BackScanParams& p,
+                     ThrLast thr_last, int& o0, int& o1) {
+    // absolute costs of the last column, rows 1..m (row 0 costs 0); the largest acceptable row
+    const int pad = 64 - p.m;
+    uint64_t vp = pad == 0 ? s.VP : (s.VP >> pad), vn = pad == 0 ? s.VN : (s.VN >> pad);
+    int c = 0, best_i = 0, best_c = 0;
+    for (int i = 1; i <= p.m; ++i) {
+        c += (int)(vp & 1ull) - (int)(vn & 1ull);
+        vp >>= 1; vn >>= 1;
+        if (i >= p.min_overlap && c <= thr_last(i)) { best_i = i; best_c = c; }
+    }
+    o0 = 0; o1 = 0;
+    const int reach = p.m + p.k + 1;
+    if (s.jfa < 0) {
+        if (best_i == 0) return BS_NONE;
+        if (best_c == 0) { o0 = best_i; return BS_EXACT_TAIL; }
+        const int s0 = n - reach;
+        o0 = s0 > j0 ? s0 : j0;
+        o1 = n * 2 + 1;
+        return BS_DP;
+    }
+    const int s0 = s.jfa - reach;
+    o0 = s0 > j0 ? s0 : j0;
+    o1 = best_i == 0 ? s.jla * 2 : n * 2 + 1;
+    return BS_DP;
+}

@@ -45,6 +45,11 @@ struct CahMatcher {
     uint64_t rowmask[CAH_TABLE_CHARS]; // bit i set <=> adapter[i] matches this read character
                                        // (folds translate() + the three compare modes, :322-328, :442-445;
                                        //  for comparers bit i refers to the i-th compared position)
+    // ---- bit-parallel cost scan (back_scan.h; 3' adapters with unit costs) ------------------------
+    int32_t scan_ok;           // 1: k_back_scan may classify reads before the cell DP
+    int32_t kacc;              // thr[effective_length] (-1 if m < min_overlap): acceptable last-row cost
+    int32_t thr_last[CAH_MAX_M + 1];   // thr[effective length of adapter[0:i]]: threshold of row i in the last column
+    uint64_t scanmask[CAH_TABLE_CHARS]; // rowmask << (64 - m) | ones below: the adapter in the top m bits
 };
 
 struct CahKmerWord {

@@ -43,6 +43,37 @@ struct DpArgs {
     int32_t* best_adapter;           // may be NULL
     int32_t adapter_index;
     int32_t merge_best;              // 0: overwrite (locate_batch); 1: keep best (match_batch)
+    // Windowed work list written by k_back_scan (k_dp_packed only; all NULL/0 otherwise): `queue` is filled
+    // from both ends -- [0, *queue_count) holds reads with a bounded column window, the last
+    // *queue_count_back slots of its queue_cap slots hold reads whose DP runs to the read end -- and
+    // win[2*slot] = first column, win[2*slot+1] = last column * 2 + (1: do the last-column scan).
+    const int32_t* win;
+    const unsigned long long* queue_count_back;
+    int64_t queue_cap;
+};
+
+// k_back_scan: bit-parallel cost scan + classification (back_scan.h) of the reads of a work list
+struct ScanArgs {
+    const CahMatcher* matcher;
+    const uint8_t* seqs;
+    const int64_t* offsets;
+    const int32_t* lens;             // may be NULL
+    int64_t n_reads;
+    int64_t max_read_len;
+    const int32_t* queue;            // NULL: reads 0..n_reads-1
+    const unsigned long long* queue_count;
+    const uint8_t* queue_keys;       // NULL, or the first-hit group of every queue entry (column skipping)
+    unsigned long long* work_counter;        // zeroed before launch
+    int32_t* out6;
+    uint8_t* status;
+    int32_t* best_adapter;           // may be NULL
+    int32_t adapter_index;
+    int32_t merge_best;
+    int32_t* dp_queue;               // out: reads that need the cell DP (filled from both ends, see DpArgs)
+    int32_t* dp_win;
+    unsigned long long* dp_count_front;      // zeroed before launch
+    unsigned long long* dp_count_back;
+    int64_t dp_cap;
 };
 
 hipError_t launch_filter_lean(const FilterArgs& a, int mode, int n_words, int n_cus, hipStream_t s);
@@ -51,6 +82,7 @@ hipError_t launch_uniform_check(const int64_t* offsets, int64_t n_reads, int64_t
 hipError_t launch_filter(const FilterArgs& a, int mode, bool narrow_words, int n_cus, hipStream_t s);
 hipError_t launch_dp(const DpArgs& a, int m, bool unit_indel_cost, bool back_adapter, int64_t max_items, int n_cus,
                      hipStream_t s);
+hipError_t launch_back_scan(const ScanArgs& a, int64_t max_items, int n_cus, hipStream_t s);
 hipError_t launch_comparer(const DpArgs& a, int64_t max_items, int n_cus, hipStream_t s);
 hipError_t launch_validate(const uint8_t* seqs, const int64_t* offsets, const int32_t* lens,
                            int64_t n_reads, int32_t* bad, int n_cus, hipStream_t s);

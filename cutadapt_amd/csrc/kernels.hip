@@ -22,6 +22,7 @@
 
 #include "cah_device.h"
 #include "kernels.h"
+#include "back_scan.h"
 
 #define WAVE 64
 #ifndef CAH_SCHED_ROWS
@@ -51,9 +52,9 @@ __device__ __forceinline__ void read_extent(const int64_t* offsets, const int32_
 // Work distribution: waves pull chunks of 64 work items from a device counter ("dequeue",
 // the cheapest cross-CU primitive on this chip) so that long and short reads balance.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int64_t wave_dequeue(unsigned long long* counter) {
+__device__ __forceinline__ int64_t wave_dequeue(unsigned long long* counter, unsigned items = WAVE) {
     unsigned long long base = 0;
-    if (wave_lane() == 0) base = atomicAdd(counter, (unsigned long long)WAVE);
+    if (wave_lane() == 0) base = atomicAdd(counter, (unsigned long long)items);
     unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)base);
     unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
     return (int64_t)(((unsigned long long)hi << 32) | lo);
@@ -1015,6 +1016,9 @@ __device__ __forceinline__ unsigned get_row_packed(const unsigned (&w)[ROWS + 1]
 #ifndef CAH_DPP_WAVES
 #define CAH_DPP_WAVES(ROWS) ((ROWS) <= 24 ? 6 : 4)
 #endif
+#ifndef PK_DEQUEUE
+#define PK_DEQUEUE 4
+#endif
 
 template <int ROWS>
 __global__ __launch_bounds__(256, CAH_DPP_WAVES(ROWS)) void k_dp_packed(DpArgs a) {
@@ -1039,17 +1043,28 @@ __global__ __launch_bounds__(256, CAH_DPP_WAVES(ROWS)) void k_dp_packed(DpArgs a
     const unsigned klim = (unsigned)(min(k, 200) + 1) << PK_COST_SHIFT;
 
     const int lane = wave_lane();
-    int64_t total = a.n_reads;
-    if (a.queue_count) total = (int64_t)(*a.queue_count);
+    int64_t total = a.n_reads, front = a.n_reads;
+    if (a.queue_count) {
+        front = (int64_t)(*a.queue_count);
+        total = front + (a.queue_count_back ? (int64_t)(*a.queue_count_back) : 0);
+    }
     const bool skip_cols = a.queue && a.queue_keys && mt->skip_ok != 0;
 
+    // a wave takes PK_DEQUEUE x 64 consecutive work items per atomic (a single hot counter sustains
+    // ~90 atomics/us on this chip)
     for (;;) {
-        const int64_t base = wave_dequeue(a.work_counter);
+      const int64_t base0 = wave_dequeue(a.work_counter, PK_DEQUEUE * WAVE);
+      if (base0 >= total) break;
+#pragma unroll 1
+      for (int sub = 0; sub < PK_DEQUEUE; ++sub) {
+        const int64_t base = base0 + (int64_t)sub * WAVE;
         if (base >= total) break;
         const int64_t idx = base + lane;
         const bool valid = idx < total;
+        // the windowed work list is filled from both ends (see DpArgs)
+        const int64_t slot = idx < front ? idx : a.queue_cap - 1 - (idx - front);
         int64_t r = 0;
-        if (valid) r = a.queue ? (int64_t)a.queue[idx] : idx;
+        if (valid) r = a.queue ? (int64_t)a.queue[slot] : idx;
         int64_t off = 0, n64 = 0;
         if (valid) read_extent(a.offsets, a.lens, r, off, n64);
         bool invalid = false;
@@ -1058,10 +1073,21 @@ __global__ __launch_bounds__(256, CAH_DPP_WAVES(ROWS)) void k_dp_packed(DpArgs a
         const uint8_t* q = a.seqs + off;
 
         // flags = BACK: every column 1..n (_align.pyx:346-352), unless the prefilter proves the
-        // first columns irrelevant (column skipping, see k_dp / DESIGN.md)
-        const int max_n = n;
+        // first columns irrelevant (column skipping, see k_dp / DESIGN.md) or the cost scan gave the
+        // exact window (back_scan.h)
+        int max_n = n;
         int min_n = 0;
-        if (skip_cols && valid) min_n = max(0, ((int)a.queue_keys[idx] << CAH_KEY_SHIFT) - m - k - 1);
+        bool do_scan = true;
+        if (a.win) {
+            if (valid) {
+                min_n = a.win[2 * slot];
+                const int e2 = a.win[2 * slot + 1];
+                max_n = min(n, e2 >> 1);
+                do_scan = (e2 & 1) != 0;
+            }
+        } else if (skip_cols && valid) {
+            min_n = max(0, ((int)a.queue_keys[idx] << CAH_KEY_SHIFT) - m - k - 1);
+        }
 
         // first column (:374-378): cost i, score -2i, origin = this column (rel 0)
         unsigned w[ROWS + 1];
@@ -1160,7 +1186,7 @@ __global__ __launch_bounds__(256, CAH_DPP_WAVES(ROWS)) void k_dp_packed(DpArgs a
         }
 #pragma unroll 1
         for (int i = m; i >= 0; --i) {
-            const bool want = valid && i <= last_filled;
+            const bool want = valid && do_scan && i <= last_filled;
             if (!__any(want)) continue;
             const unsigned wi = i == 0 ? w_row0 : get_row_packed<ROWS>(w, i);
             if (want) {
@@ -1205,6 +1231,188 @@ __global__ __launch_bounds__(256, CAH_DPP_WAVES(ROWS)) void k_dp_packed(DpArgs a
                     o[0] = o[1] = o[2] = o[3] = o[4] = o[5] = 0;
                 }
             }
+        }
+      }
+    }
+}
+
+// =============================================================================================
+// k_back_scan: bit-parallel cost scan + classification of 3' adapter reads (back_scan.h) in front of
+// k_dp_packed.  One read per lane; the whole column of vertical deltas is one 64-bit word, so a
+// column costs ~40 VALU instructions whatever the band -- about a tenth of the cell loop -- and all
+// lanes of a wave do the same work (no band divergence).  Reads that end as NONE / EXACT_FULL /
+// EXACT_TAIL are finished here; the rest go to the cell DP with an exact column window.
+// Work is taken in tiles of SCAN_TILE entries per workgroup (one atomic per tile); the DP work list of
+// a tile is collected in LDS and appended with two atomics: entries with a bounded window from the
+// front, entries that run to the read end from the back (lanes of one DP wave then do alike work).
+// =============================================================================================
+#ifndef SCAN_TILE
+#define SCAN_TILE 1024
+#endif
+
+__device__ __forceinline__ void store_result(int32_t* out6, uint8_t* status, int32_t* best_adapter,
+                                             const int adapter_index, const int merge_best, const int64_t r,
+                                             const bool invalid, const bool found, const int t0, const int t1,
+                                             const int t2, const int t3, const int score, const int cost) {
+    int32_t* o = out6 + r * 6;
+    if (merge_best) {
+        // MultipleAdapters.match_to (adapters.py:1278-1285), see k_dp
+        if (invalid) {
+            status[r] = 2;
+        } else if (found) {
+            const bool had = status[r] == 1;
+            if (status[r] != 2 && (!had || score > o[4] || (score == o[4] && cost < o[5]))) {
+                o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3; o[4] = score; o[5] = cost;
+                status[r] = 1;
+                if (best_adapter) best_adapter[r] = adapter_index;
+            }
+        }
+    } else {
+        status[r] = invalid ? (uint8_t)2 : (found ? (uint8_t)1 : (uint8_t)0);
+        if (found && !invalid) { o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3; o[4] = score; o[5] = cost; }
+        else { o[0] = o[1] = o[2] = o[3] = o[4] = o[5] = 0; }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_back_scan(ScanArgs a) {
+    __shared__ uint64_t s_scanmask[CAH_TABLE_CHARS];
+    __shared__ int s_thr_last[CAH_MAX_M + 1];
+    __shared__ int s_list[SCAN_TILE * 3];          // (read, first column, last column * 2 + scan): front entries
+                                                   // from slot 0 up, back entries from the last slot down
+    __shared__ unsigned s_nf, s_nb;
+    __shared__ long long s_tile;
+    __shared__ unsigned long long s_gf, s_gb;
+    const CahMatcher* mt = a.matcher;
+    for (int i = threadIdx.x; i < CAH_TABLE_CHARS; i += blockDim.x) s_scanmask[i] = mt->scanmask[i];
+    for (int i = threadIdx.x; i <= CAH_MAX_M; i += blockDim.x) s_thr_last[i] = mt->thr_last[i];
+    BackScanParams p;
+    p.m = mt->m; p.k = mt->k; p.kacc = mt->kacc; p.min_overlap = mt->min_overlap; p.half_m = mt->m / 2;
+    const int lane = wave_lane();
+    const int wave = threadIdx.x >> 6;
+    int64_t total = a.n_reads;
+    if (a.queue_count) total = (int64_t)(*a.queue_count);
+    const bool skip_cols = a.queue && a.queue_keys && mt->skip_ok != 0;
+
+    for (;;) {
+        __syncthreads();                                   // previous tile flushed
+        if (threadIdx.x == 0) {
+            s_tile = (long long)atomicAdd(a.work_counter, (unsigned long long)SCAN_TILE);
+            s_nf = 0; s_nb = 0;
+        }
+        __syncthreads();
+        const int64_t tile_base = s_tile;
+        if (tile_base >= total) break;
+
+        for (int sub = wave; sub < SCAN_TILE / WAVE; sub += 4) {
+            const int64_t base = tile_base + (int64_t)sub * WAVE;
+            if (base >= total) break;
+            const int64_t idx = base + lane;
+            const bool valid = idx < total;
+            int64_t r = 0;
+            if (valid) r = a.queue ? (int64_t)a.queue[idx] : idx;
+            int64_t off = 0, n64 = 0;
+            if (valid) read_extent(a.offsets, a.lens, r, off, n64);
+            bool invalid = false;
+            if (n64 > a.max_read_len) { invalid = true; n64 = 0; }
+            const int n = (int)n64;
+            const uint8_t* q = a.seqs + off;
+            // first column of the window (column skipping): nothing of the whole-read k-mer set
+            // ends before 4 * key, so no row-m cost <= k occurs before it
+            int j0 = 0;
+            if (skip_cols && valid) j0 = max(0, ((int)a.queue_keys[idx] << CAH_KEY_SHIFT) - p.m - p.k - 1);
+
+            BackScanState st;
+            bs_init(st, p);
+            int j = j0;
+            bool done = !valid, exact = false;
+            int pos = j0;
+            Chunk cur = load_chunk(q, pos, n, valid ? n : 0);
+            Chunk nxt = load_chunk(q, pos + 16, n, valid ? n : 0);
+            int left = 16;
+            unsigned bad_chars = cur.w[0] | cur.w[1] | cur.w[2] | cur.w[3];
+            uint64_t eq_next = s_scanmask[cur.w[0] & (CAH_TABLE_CHARS - 1)];
+            for (;;) {
+                const bool act = !done && j < n;
+                if (!__any(act)) break;
+                const uint64_t eq = eq_next;
+                cur.w[0] = (cur.w[0] >> 8) | (cur.w[1] << 24);
+                cur.w[1] = (cur.w[1] >> 8) | (cur.w[2] << 24);
+                cur.w[2] = (cur.w[2] >> 8) | (cur.w[3] << 24);
+                cur.w[3] >>= 8;
+                if (--left == 0) {
+                    cur = nxt;
+                    bad_chars |= cur.w[0] | cur.w[1] | cur.w[2] | cur.w[3];
+                    pos += 16;
+                    nxt = load_chunk(q, pos + 16, n, (!done) ? n : 0);
+                    left = 16;
+                }
+                eq_next = s_scanmask[cur.w[0] & (CAH_TABLE_CHARS - 1)];
+                if (act) {
+                    ++j;
+                    if (bs_step(st, eq, j, p)) { exact = true; done = true; }
+                }
+            }
+            if (bad_chars & 0x80808080u) invalid = true;
+
+            int o0 = 0, o1 = 0;
+            int cls = bs_finish(st, n, j0, p, [&](int i) { return s_thr_last[i]; }, o0, o1);
+            if (exact) { cls = BS_EXACT_FULL; o0 = j; }
+            if (valid) {
+                if (invalid || cls == BS_NONE) {
+                    store_result(a.out6, a.status, a.best_adapter, a.adapter_index, a.merge_best, r, invalid, false,
+                                 0, 0, 0, 0, 0, 0);
+                } else if (cls == BS_EXACT_FULL) {
+                    store_result(a.out6, a.status, a.best_adapter, a.adapter_index, a.merge_best, r, false, true,
+                                 0, p.m, o0 - p.m, o0, p.m, 0);
+                } else if (cls == BS_EXACT_TAIL) {
+                    store_result(a.out6, a.status, a.best_adapter, a.adapter_index, a.merge_best, r, false, true,
+                                 0, o0, n - o0, n, o0, 0);
+                }
+            }
+            const bool to_dp = valid && !invalid && cls == BS_DP;
+            const bool to_back = to_dp && (o1 & 1);
+            const bool to_front = to_dp && !(o1 & 1);
+            const unsigned long long bf = __ballot(to_front), bb = __ballot(to_back);
+            if (bf | bb) {
+                unsigned sf = 0, sb = 0;
+                if (lane == 0) {
+                    if (bf) sf = atomicAdd(&s_nf, (unsigned)__popcll(bf));
+                    if (bb) sb = atomicAdd(&s_nb, (unsigned)__popcll(bb));
+                }
+                sf = __builtin_amdgcn_readfirstlane(sf);
+                sb = __builtin_amdgcn_readfirstlane(sb);
+                const unsigned long long below = (1ull << lane) - 1ull;
+                if (to_front) {
+                    const int e = (int)sf + __popcll(bf & below);
+                    s_list[3 * e] = (int)r; s_list[3 * e + 1] = o0; s_list[3 * e + 2] = o1;
+                } else if (to_back) {
+                    const int e = SCAN_TILE - 1 - ((int)sb + __popcll(bb & below));
+                    s_list[3 * e] = (int)r; s_list[3 * e + 1] = o0; s_list[3 * e + 2] = o1;
+                }
+            }
+        }
+
+        // flush the tile's DP work list
+        __syncthreads();
+        const unsigned nf = s_nf, nb = s_nb;
+        if (threadIdx.x == 0) {
+            s_gf = nf ? atomicAdd(a.dp_count_front, (unsigned long long)nf) : 0ull;
+            s_gb = nb ? atomicAdd(a.dp_count_back, (unsigned long long)nb) : 0ull;
+        }
+        __syncthreads();
+        const unsigned long long gf = s_gf, gb = s_gb;
+        for (unsigned e = threadIdx.x; e < nf; e += blockDim.x) {
+            const int64_t slot = (int64_t)(gf + e);
+            a.dp_queue[slot] = s_list[3 * e];
+            a.dp_win[2 * slot] = s_list[3 * e + 1];
+            a.dp_win[2 * slot + 1] = s_list[3 * e + 2];
+        }
+        for (unsigned e = threadIdx.x; e < nb; e += blockDim.x) {
+            const int64_t slot = a.dp_cap - 1 - (int64_t)(gb + e);
+            const int le = SCAN_TILE - 1 - (int)e;
+            a.dp_queue[slot] = s_list[3 * le];
+            a.dp_win[2 * slot] = s_list[3 * le + 1];
+            a.dp_win[2 * slot + 1] = s_list[3 * le + 2];
         }
     }
 }
@@ -1403,6 +1611,14 @@ hipError_t launch_dp(const DpArgs& a, int m, bool unit, bool back_adapter, int64
     CAH_DP_CASE(64)
 #undef CAH_DP_CASE
     return hipErrorInvalidValue;
+}
+
+hipError_t launch_back_scan(const ScanArgs& a, int64_t max_items, int n_cus, hipStream_t s) {
+    int64_t need = (max_items + SCAN_TILE - 1) / SCAN_TILE;
+    if (need < 1) need = 1;
+    const int64_t cap = (int64_t)8 * n_cus;
+    hipLaunchKernelGGL(k_back_scan, dim3((unsigned)(need < cap ? need : cap)), dim3(256), 0, s, a);
+    return hipGetLastError();
 }
 
 hipError_t launch_comparer(const DpArgs& a, int64_t max_items, int n_cus, hipStream_t s) {

@@ -129,6 +129,11 @@ int cah_plan_n_kmer_entries(const cah_plan *plan, int32_t adapter, int32_t *out)
 #define CAH_PREFILTER_GENERAL 1
 #define CAH_PREFILTER_LEAN 2
 int cah_plan_prefilter_kind(const cah_plan *plan, int32_t adapter, int32_t *out);
+/* Introspection for tests: copies the host-side matcher table of an adapter (struct CahMatcher of
+ * cutadapt_amd/csrc/cah_device.h: DP constants, row bitsets, cost-scan tables) into buf; *need receives
+ * its size.  The layout is internal to the library version. */
+int cah_plan_debug_matcher(const cah_plan *plan, int32_t adapter, void *buf, size_t buflen,
+                           size_t *need);
 
 /* ---- batch entry points (device pointers, asynchronous) --------------------------------- */
 /* Aligner.locate / PrefixComparer.locate / SuffixComparer.locate over a batch.
@@ -180,7 +185,8 @@ int cah_match_batch_host(const cah_plan *plan, const uint8_t *seqs, const int64_
 #define CAH_PROF_FILTER 0
 #define CAH_PROF_DP 1
 #define CAH_PROF_COMPARER 2
-#define CAH_PROF_N 3
+#define CAH_PROF_SCAN 3   /* k_back_scan: bit-parallel cost scan in front of the cell DP */
+#define CAH_PROF_N 4
 int cah_profile_enable(int enable);
 int cah_profile_reset(void);
 int cah_profile_read(double ms[CAH_PROF_N], int64_t launches[CAH_PROF_N],

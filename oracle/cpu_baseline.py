@@ -1,8 +1,9 @@
 """CPU baseline for bench.py (TEST/MEASUREMENT INFRASTRUCTURE -- never the product path).
 
-Times the reference's own hot path -- ``BackAdapter.match_to()`` of the compiled reference in
-oracle/_ref (kind "reference"), or the C restatement in oracle/cutadapt_oracle.c when the
-compiled reference is not available (kind "port") -- on the host cores with one worker
+Times the reference's own hot path -- ``match_to()`` of the compiled reference's adapter objects in
+oracle/_ref (kind "reference": BackAdapter for C2, LinkedAdapter for C3, MultipleAdapters for C4 and
+for each mate of C5), or for C2 the C restatement in oracle/cutadapt_oracle.c when the compiled
+reference is not available (kind "port") -- on the host cores with one worker
 process per core, the same data-parallel shape as the reference's ParallelPipelineRunner
 (reference src/cutadapt/runners.py:275-412): every worker holds its own adapter object and
 a contiguous shard of pre-generated reads; only the matching loop is timed (no FASTQ I/O),
@@ -53,50 +54,74 @@ def available_cores() -> int:
     return n
 
 
-CHUNK = 200_000   # reads generated / converted / matched at a time inside a worker (bounds memory)
+CHUNK = 100_000   # units generated / converted / matched at a time inside a worker (bounds memory)
 
 
-def worker(kind, seed, first, n_reads, read_len, adapter_seq, max_errors, min_overlap, gen,
-           budget_seconds=None):
-    """match reads [first, first+n_reads) chunk by chunk; only the matching loops are timed.
+def _reference_matchers(ref, config):
+    """the reference's adapter objects for a config: a list with one match_to callable per mate"""
+    from cutadapt_amd.workloads import SPECS
+    spec = SPECS[config]
+    A = ref.adapters
+    backs = [A.BackAdapter(s, max_errors=0.1, min_overlap=3) for s in spec["adapters"]]
+    if spec["kind"] == "single":
+        return [backs[0].match_to]
+    if spec["kind"] == "linked":
+        front = A.PrefixAdapter(spec["front"], max_errors=0.1)
+        return [A.LinkedAdapter(front, backs[0], front_required=True, back_required=False, name="c3").match_to]
+    if spec["kind"] == "multi":
+        return [A.MultipleAdapters(backs).match_to]
+    backs2 = [A.BackAdapter(s, max_errors=0.1, min_overlap=3) for s in spec["adapters2"]]
+    return [A.MultipleAdapters(backs).match_to, A.MultipleAdapters(backs2).match_to]
+
+
+def worker(kind, config, first, n_units, gen, budget_seconds=None):
+    """match units [first, first+n_units) chunk by chunk; only the matching loops are timed.
     With budget_seconds the worker stops after that much matching time (or 3x that much wall
-    time), whatever it has processed by then.  Returns (seconds, hits, reads_done)."""
+    time), whatever it has processed by then.  Returns (seconds, hits, units_done)."""
     if ROOT not in sys.path:
         sys.path.insert(0, ROOT)
+    from oracle import host_workloads
     from oracle import oracle as orc
+    from cutadapt_amd.workloads import READ_LEN, SPECS
+    spec = SPECS[config]
+    n_mates = 2 if spec["kind"] == "paired" else 1
     if kind == "reference":
         from oracle import ref_loader
         ref = ref_loader.load()
         if ref is None:
             raise RuntimeError("oracle/_ref not available")
-        adapter = ref.adapters.BackAdapter(adapter_seq, max_errors=max_errors, min_overlap=min_overlap)
-        match_to = adapter.match_to
+        matchers = _reference_matchers(ref, config)
     else:
+        if spec["kind"] != "single":
+            raise RuntimeError("the C port times only the single-adapter config; build oracle/_ref for the others")
         from cutadapt_amd.kmer_heuristic import create_positions_and_kmers
-        a = orc.Aligner(adapter_seq, max_errors, 14, False, False, 1, min_overlap)
-        f = orc.KmerFinder(create_positions_and_kmers(adapter_seq, min_overlap, max_errors, True, False))
+        ad = spec["adapters"][0]
+        a = orc.Aligner(ad, 0.1, 14, False, False, 1, 3)
+        f = orc.KmerFinder(create_positions_and_kmers(ad, 3, 0.1, True, False))
     total_dt, hits, done = 0.0, 0, 0
     wall0 = time.perf_counter()
-    for start in range(0, n_reads, CHUNK):
+    chunk = max(1000, CHUNK // (50 if spec["kind"] == "multi" else 1))
+    for start in range(0, n_units, chunk):
         if budget_seconds is not None and (total_dt >= budget_seconds or
                                            time.perf_counter() - wall0 >= 3 * budget_seconds):
             break
-        cnt = min(CHUNK, n_reads - start)
-        seqs, offsets = orc.synth_reads(seed, first + start, cnt, read_len, [adapter_seq],
-                                        gen["p_adapter"], gen["p_edit"], gen["p_n"])
-        if kind == "reference":
-            raw = seqs.tobytes()
-            reads = [raw[i * read_len:(i + 1) * read_len].decode("ascii") for i in range(cnt)]
-            t0 = time.perf_counter()
-            for r in reads:
-                if match_to(r) is not None:
-                    hits += 1
-            total_dt += time.perf_counter() - t0
-        else:
-            t0 = time.perf_counter()
-            _, status = orc.match_batch(a, f, seqs, offsets)
-            total_dt += time.perf_counter() - t0
-            hits += int((status == 1).sum())
+        cnt = min(chunk, n_units - start)
+        for mate in range(n_mates):
+            seqs, offsets = host_workloads.host_reads(config, first + start, cnt, mate, gen)
+            if kind == "reference":
+                raw = seqs.tobytes()
+                reads = [raw[i * READ_LEN:(i + 1) * READ_LEN].decode("ascii") for i in range(cnt)]
+                match_to = matchers[mate]
+                t0 = time.perf_counter()
+                for r in reads:
+                    if match_to(r) is not None:
+                        hits += 1
+                total_dt += time.perf_counter() - t0
+            else:
+                t0 = time.perf_counter()
+                _, status = orc.match_batch(a, f, seqs, offsets)
+                total_dt += time.perf_counter() - t0
+                hits += int((status == 1).sum())
         done += cnt
     return total_dt, hits, done
 
@@ -111,23 +136,22 @@ def _spawn(job: dict):
                             cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
 
 
-def run(seed: int, read_len: int, adapter_seq: str, max_errors: float, min_overlap: int, gen: dict,
-        target_seconds: float = 12.0, max_reads: int = 4_000_000_000, timeout: float = 150.0):
-    """Returns dict(value=Mreads/s, cores=..., kind=..., sample=...)."""
+def run(config: str, gen: dict, target_seconds: float = 12.0, max_units: int = 4_000_000_000, timeout: float = 150.0):
+    """Returns dict(value=M units/s on all usable cores, cores, host_logical_cpus, cgroup_cpu_quota,
+    one_core, kind, sample)."""
     from oracle import oracle as orc
     from oracle import ref_loader
+    from cutadapt_amd.workloads import SPECS
     orc.lib()
     kind = "reference" if ref_loader.load() is not None else "port"
     cores = available_cores()
-    # calibrate on one core in-process, then size the sample for ~target_seconds on all cores
-    probe = 20000
-    dt, _, _ = worker(kind, seed, 0, probe, read_len, adapter_seq, max_errors, min_overlap, gen)
-    rate1 = probe / max(dt, 1e-6)
+    # P = 1: calibrate on one core in-process, then size the sample for ~target_seconds on all cores
+    probe = 300 if SPECS[config]["kind"] == "multi" else 20000
+    dt, _, done = worker(kind, config, 0, probe, gen)
+    rate1 = done / max(dt, 1e-6)
     # every worker gets a disjoint range big enough for the time budget and stops on the clock
-    per_worker = int(min(max(rate1 * target_seconds * 1.5, 20000), max_reads / cores))
-    base = {"kind": kind, "seed": seed, "n_reads": per_worker, "read_len": read_len,
-            "adapter_seq": adapter_seq, "max_errors": max_errors, "min_overlap": min_overlap, "gen": gen,
-            "budget_seconds": target_seconds}
+    per_worker = int(min(max(rate1 * target_seconds * 1.5, 2000), max_units / cores))
+    base = {"kind": kind, "config": config, "n_units": per_worker, "gen": gen, "budget_seconds": target_seconds}
     procs = [_spawn(dict(base, first=w * per_worker)) for w in range(cores)]
     deadline = time.time() + timeout
     results = []
@@ -142,16 +166,21 @@ def run(seed: int, read_len: int, adapter_seq: str, max_errors: float, min_overl
             if p.poll() is None:
                 p.kill()
     # workers run concurrently for the same time budget: aggregate rate = sum of per-worker rates
-    total = sum(r["reads"] for r in results)
-    value = sum(r["reads"] / max(r["seconds"], 1e-9) for r in results) / 1e6
+    total = sum(r["units"] for r in results)
+    value = sum(r["units"] / max(r["seconds"], 1e-9) for r in results) / 1e6
+    unit = SPECS[config]["unit"]
     return {
         "value": value,
-        "unit": "Mreads/s",
+        "unit": unit,
         "cores": cores,
+        "host_logical_cpus": os.cpu_count() or cores,
+        "cgroup_cpu_quota": cgroup_cpu_limit(),
+        "one_core": {"value": rate1 / 1e6, "unit": unit, "cores": 1},
         "kind": kind,
-        "sample": f"{total} reads of the same synthetic workload, {cores} concurrent worker processes each "
-                  f"matching its own read range for ~{target_seconds:.0f} s (match_to() loop only, no I/O); "
-                  f"sum of per-worker rates; 1-core probe {rate1 / 1e6:.3f} Mreads/s",
+        "sample": f"{total} units of the same synthetic workload ({config}), P = {cores} concurrent worker processes "
+                  f"(the container's CPU quota; the host has {os.cpu_count()} hardware threads) each matching its own "
+                  f"range for ~{target_seconds:.0f} s (match_to() loops of the reference's adapter objects only, no I/O); "
+                  f"sum of per-worker rates; P = 1 probe {rate1 / 1e6:.4f} {unit}",
         "hit_fraction": sum(r["hits"] for r in results) / max(total, 1),
     }
 
@@ -159,11 +188,8 @@ def run(seed: int, read_len: int, adapter_seq: str, max_errors: float, min_overl
 if __name__ == "__main__":
     if len(sys.argv) == 3 and sys.argv[1] == "--worker":
         j = json.loads(sys.argv[2])
-        seconds, hits, done = worker(j["kind"], j["seed"], j["first"], j["n_reads"], j["read_len"],
-                                     j["adapter_seq"], j["max_errors"], j["min_overlap"], j["gen"],
-                                     j.get("budget_seconds"))
-        print(json.dumps({"seconds": seconds, "hits": hits, "reads": done}))
+        seconds, hits, done = worker(j["kind"], j["config"], j["first"], j["n_units"], j["gen"], j.get("budget_seconds"))
+        print(json.dumps({"seconds": seconds, "hits": hits, "units": done}))
     else:
-        res = run(2, 150, "AGATCGGAAGAGCACACGTCTGAACTCCAGTCA", 0.1, 3,
-                  {"p_adapter": 0.25, "p_edit": 0.02, "p_n": 0.005}, target_seconds=3.0)
-        print(json.dumps(res))
+        cfg = sys.argv[1] if len(sys.argv) > 1 else "C2"
+        print(json.dumps(run(cfg, {"p_adapter": 0.25, "p_edit": 0.02, "p_n": 0.005}, target_seconds=3.0)))

@@ -1,0 +1,171 @@
+// back_model.cpp -- HOST MODEL of the GPU fast path for 3' adapters.  TEST INFRASTRUCTURE ONLY.
+//
+// Compiles the product's own classification code (cutadapt_amd/csrc/back_scan.h, the header that
+// k_back_scan is built from) with g++ and pairs it with a plain C++ restatement of what k_dp_packed does
+// for a windowed work item (banded cell DP started at column s0 with the plain first column, stopped at
+// column e, last-column scan optional).  tests/test_back_scan_model.py fuzzes
+//     classify -> {NONE, EXACT_FULL, EXACT_TAIL, DP(window)}
+// against the oracle's Aligner.locate on the FULL read: the exactness arguments of back_scan.h and of
+// DESIGN.md "Column skipping" are checked on millions of cases without a GPU.  The product never loads
+// this file; the GPU kernels are compared with the oracle separately (tests/test_gpu_parity.py).
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../cutadapt_amd/csrc/back_scan.h"
+#include "../../cutadapt_amd/csrc/cah_device.h"
+
+namespace {
+
+struct Cell { int cost, score, origin; };
+
+// Aligner.locate for flags = 14, unit costs (reference _align.pyx:298-587) on columns (s0, e], first
+// column = (cost i, score -2i, origin s0); the last-column scan only if `scan`.
+int dp_window(const CahMatcher& mt, const uint8_t* q, int n, int s0, int e, bool scan, int out6[6]) {
+    const int m = mt.m, k = mt.k;
+    std::vector<Cell> col((size_t)m + 1);
+    for (int i = 0; i <= m; i++) col[(size_t)i] = {i, -2 * i, s0};
+    const int SENT = m + n + 1;
+    int b_cost = SENT, b_origin = 0, b_score = 0, b_refstop = m, b_qstop = n;
+    int last = std::min(m, k + 1), last_filled = 0;
+    int cost = 0, score = 0, origin = 0;
+    int j = s0;
+    for (j = s0 + 1; j <= e; j++) {
+        Cell diag = col[0];
+        col[0].origin += 1;
+        const uint64_t mk = mt.rowmask[q[j - 1] & 127];
+        for (int i = 1; i <= last; i++) {
+            const bool eq = (mk >> (i - 1)) & 1ull;
+            if (eq) {
+                cost = diag.cost; origin = diag.origin; score = diag.score + 1;
+            } else {
+                const int cd = diag.cost + 1, ci = col[(size_t)i].cost + 1, cdel = col[(size_t)i - 1].cost + 1;
+                if (cd <= cdel && cd <= ci) { cost = cd; origin = diag.origin; score = diag.score - 1; }
+                else if (cdel <= ci) { cost = cdel; origin = col[(size_t)i - 1].origin; score = col[(size_t)i - 1].score - 2; }
+                else { cost = ci; origin = col[(size_t)i].origin; score = col[(size_t)i].score - 2; }
+            }
+            diag = col[(size_t)i];
+            col[(size_t)i] = {cost, score, origin};
+        }
+        last_filled = last;
+        while (last >= 0 && col[(size_t)last].cost > k) last--;
+        if (last < m) {
+            last++;
+        } else {
+            cost = col[(size_t)m].cost; score = col[(size_t)m].score; origin = col[(size_t)m].origin;
+            const int length = m + std::min(origin, 0);
+            int eff = length;
+            if (mt.wildcard_ref) eff = length < m ? length - (mt.n_counts[m] - mt.n_counts[m - length]) : mt.effective_length;
+            const bool ok = length >= mt.min_overlap && cost <= mt.thr[eff];
+            const int best_len = m + std::min(b_origin, 0);
+            if (ok && (b_cost == SENT || (origin <= b_origin + m / 2 && score > b_score) ||
+                       (length > best_len && score > b_score))) {
+                b_score = score; b_cost = cost; b_origin = origin; b_refstop = m; b_qstop = j;
+                if (cost == 0 && origin >= 0) break;
+            }
+        }
+    }
+    if (scan) {
+        for (int i = last_filled; i >= 0; i--) {
+            const Cell& c = col[(size_t)i];
+            const int length = i + std::min(c.origin, 0);
+            const int lo = -std::min(c.origin, 0);
+            int eff = length;
+            if (mt.wildcard_ref) eff = length < m ? length - (mt.n_counts[i] - mt.n_counts[lo]) : mt.effective_length;
+            const bool ok = length >= mt.min_overlap && c.cost <= mt.thr[eff];
+            const int best_len = b_refstop + std::min(b_origin, 0);
+            if (ok && (b_cost == SENT || (origin <= b_origin + m / 2 && c.score > b_score) ||
+                       (length > best_len && c.score > b_score))) {
+                b_score = c.score; b_cost = c.cost; b_origin = c.origin; b_refstop = i; b_qstop = n;
+            }
+        }
+    }
+    if (b_cost == SENT) return 0;
+    out6[0] = b_origin >= 0 ? 0 : -b_origin; out6[1] = b_refstop;
+    out6[2] = b_origin >= 0 ? b_origin : 0; out6[3] = b_qstop; out6[4] = b_score; out6[5] = b_cost;
+    return 1;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Runs the fast path on a packed batch.  j0s: per-read first window column (NULL = 0).  cls_out (may be
+// NULL) receives the class of every read; win_out (may be NULL) the (first, last*2+scan) window of DP reads.
+// Returns 0, or 1 if the matcher is not scan-eligible.
+int bm_locate_batch(const void* matcher_blob, const uint8_t* seqs, const int64_t* offsets, int64_t n_reads,
+                    const int32_t* j0s, int32_t* out6, uint8_t* status, uint8_t* cls_out, int32_t* win_out) {
+    CahMatcher mt;
+    memcpy(&mt, matcher_blob, sizeof(mt));
+    if (!mt.scan_ok) return 1;
+    BackScanParams p;
+    p.m = mt.m; p.k = mt.k; p.kacc = mt.kacc; p.min_overlap = mt.min_overlap; p.half_m = mt.m / 2;
+    for (int64_t r = 0; r < n_reads; r++) {
+        const uint8_t* q = seqs + offsets[r];
+        const int n = (int)(offsets[r + 1] - offsets[r]);
+        const int j0 = j0s ? j0s[r] : 0;
+        BackScanState st;
+        bs_init(st, p);
+        bool exact = false;
+        int j = j0;
+        while (j < n) {
+            ++j;
+            if (bs_step(st, mt.scanmask[q[j - 1] & 127], j, p)) { exact = true; break; }
+        }
+        int o0 = 0, o1 = 0, cls;
+        if (exact) { cls = BS_EXACT_FULL; o0 = j; }
+        else cls = bs_finish(st, n, j0, p, [&](int i) { return mt.thr_last[i]; }, o0, o1);
+        int32_t* o = out6 + r * 6;
+        for (int t = 0; t < 6; t++) o[t] = 0;
+        status[r] = 0;
+        if (cls == BS_EXACT_FULL) {
+            o[0] = 0; o[1] = p.m; o[2] = o0 - p.m; o[3] = o0; o[4] = p.m; o[5] = 0; status[r] = 1;
+        } else if (cls == BS_EXACT_TAIL) {
+            o[0] = 0; o[1] = o0; o[2] = n - o0; o[3] = n; o[4] = o0; o[5] = 0; status[r] = 1;
+        } else if (cls == BS_DP) {
+            int t6[6];
+            if (dp_window(mt, q, n, o0, std::min(n, o1 >> 1), (o1 & 1) != 0, t6)) {
+                for (int t = 0; t < 6; t++) o[t] = t6[t];
+                status[r] = 1;
+            }
+        }
+        if (cls_out) cls_out[r] = (uint8_t)cls;
+        if (win_out) { win_out[2 * r] = o0; win_out[2 * r + 1] = o1; }
+    }
+    return 0;
+}
+
+size_t bm_matcher_size(void) { return sizeof(CahMatcher); }
+
+// The window start the prefilter's survivor key would give (DESIGN.md "Column skipping"): the adapter is cut
+// into k+1 consecutive chunks (kmer_heuristic's whole-read search set); e = index of the read character at
+// which the first chunk occurrence ends (n-1 if there is none: the latest a tail k-mer could hit);
+// key = e >> 2; j0 = max(0, 4*key - m - k - 1).  Plain adapters only (case-insensitive equality).
+void bm_skip_columns(const char* adapter, int m, int k, const uint8_t* seqs, const int64_t* offsets,
+                     int64_t n_reads, int32_t* j0s) {
+    const int chunks = k + 1, base = m / chunks, extra = m % chunks;
+    for (int64_t r = 0; r < n_reads; r++) {
+        const uint8_t* q = seqs + offsets[r];
+        const int n = (int)(offsets[r + 1] - offsets[r]);
+        int first_end = n - 1;
+        int pos = 0;
+        for (int c = 0; c < chunks; c++) {
+            const int len = base + (c < extra ? 1 : 0);
+            for (int st = 0; st + len <= n; st++) {
+                bool ok = true;
+                for (int t = 0; t < len && ok; t++) {
+                    uint8_t ch = q[st + t];
+                    if (ch >= 'a' && ch <= 'z') ch = (uint8_t)(ch - 32);
+                    ok = ch == (uint8_t)adapter[pos + t];
+                }
+                if (ok) { first_end = std::min(first_end, st + len - 1); break; }
+            }
+            pos += len;
+        }
+        if (first_end < 0) first_end = 0;
+        j0s[r] = std::max(0, ((first_end >> 2) << 2) - m - k - 1);
+    }
+}
+
+}  // extern "C"

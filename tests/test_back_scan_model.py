@@ -1,0 +1,182 @@
+"""Host-model fuzz of the cost scan's classification (cutadapt_amd/csrc/back_scan.h) against the oracle.
+
+No GPU: the header k_back_scan is built from is compiled with g++ (tests/host_model/back_model.cpp,
+together with a plain restatement of the windowed cell DP) and every read's result --
+NONE / EXACT_FULL / EXACT_TAIL shortcut or windowed DP -- must equal the oracle's Aligner.locate on the
+whole read.  The matcher tables come from the product's own plan builder (cah_plan_debug_matcher)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from cutadapt_amd import _lib
+from oracle import oracle as orc
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "host_model", "back_model.cpp")
+SO = os.path.join(HERE, "host_model", "libback_model.so")
+TRUSEQ = "AGATCGGAAGAGCACACGTCTGAACTCCAGTCA"
+
+
+@pytest.fixture(scope="module")
+def model():
+    deps = [SRC, os.path.join(HERE, "..", "cutadapt_amd", "csrc", "back_scan.h"),
+            os.path.join(HERE, "..", "cutadapt_amd", "csrc", "cah_device.h")]
+    if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", SRC, "-o", SO], check=True)
+    L = C.CDLL(SO)
+    vp, i64 = C.c_void_p, C.c_int64
+    L.bm_locate_batch.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp, vp]
+    L.bm_skip_columns.argtypes = [C.c_char_p, C.c_int, C.c_int, vp, vp, i64, vp]
+    L.bm_matcher_size.restype = C.c_size_t
+    return L
+
+
+def matcher_blob(adapter, rate, min_overlap, wildcard_ref=False, wildcard_query=False):
+    spec = _lib.MatcherSpec(adapter, rate, 14, wildcard_ref, wildcard_query, 1, min_overlap)
+    plan = _lib.Plan([spec])
+    L = _lib.lib()
+    need = C.c_size_t(0)
+    _lib.check(L.cah_plan_debug_matcher(plan.handle, 0, None, 0, C.byref(need)))
+    buf = (C.c_uint8 * need.value)()
+    _lib.check(L.cah_plan_debug_matcher(plan.handle, 0, buf, need.value, C.byref(need)))
+    return buf, need.value
+
+
+def run_model(L, blob, seqs, offsets, j0s=None):
+    n = len(offsets) - 1
+    out6 = np.zeros((n, 6), dtype=np.int32)
+    status = np.zeros(n, dtype=np.uint8)
+    cls = np.zeros(n, dtype=np.uint8)
+    rc = L.bm_locate_batch(blob, seqs.ctypes.data, offsets.ctypes.data, n,
+                           None if j0s is None else j0s.ctypes.data, out6.ctypes.data, status.ctypes.data,
+                           cls.ctypes.data, None)
+    return rc, out6, status, cls
+
+
+def compare(L, adapter, rate, min_overlap, seqs, offsets, wr=False, wq=False, skip=False, label=""):
+    blob, size = matcher_blob(adapter, rate, min_overlap, wr, wq)
+    assert size == L.bm_matcher_size()
+    oa = orc.Aligner(adapter, rate, 14, wr, wq, 1, min_overlap)
+    want6, want_st = oa.locate_batch(seqs, offsets)
+    j0s = None
+    if skip:
+        n = len(offsets) - 1
+        j0s = np.zeros(n, dtype=np.int32)
+        L.bm_skip_columns(adapter.encode(), len(adapter), int(rate * len(adapter)), seqs.ctypes.data,
+                          offsets.ctypes.data, n, j0s.ctypes.data)
+    rc, out6, status, cls = run_model(L, blob, seqs, offsets, j0s)
+    if rc == 1:
+        return None                                  # matcher not scan-eligible: nothing to check
+    bad = np.nonzero((status != want_st) | (out6 != want6).any(axis=1))[0]
+    if len(bad):
+        r = int(bad[0])
+        read = bytes(seqs[offsets[r]:offsets[r + 1]]).decode("latin-1")
+        raise AssertionError(f"{label}: {len(bad)} of {len(want_st)} reads differ; first: read {r} {read!r} adapter "
+                             f"{adapter} rate {rate} O {min_overlap} wr {wr} wq {wq} j0 {None if j0s is None else j0s[r]} "
+                             f"class {cls[r]} model {status[r]} {out6[r].tolist()} oracle {want_st[r]} {want6[r].tolist()}")
+    return np.bincount(cls, minlength=4)
+
+
+def random_reads(rng, adapter, n_reads, max_len, p_edit, p_n, alphabet="ACGT"):
+    """ragged reads with 0-2 (edited, possibly truncated) adapter copies"""
+    reads = []
+    bases = np.array(list(alphabet))
+    for _ in range(n_reads):
+        n = int(rng.integers(0, max_len + 1))
+        s = list(rng.choice(bases, size=n))
+        for _copy in range(int(rng.integers(0, 3))):
+            ad = []
+            for c in adapter:
+                u = rng.random()
+                if u < p_edit / 2:
+                    ad.append(str(rng.choice(bases)))
+                elif u < p_edit * 0.75:
+                    ad.append(str(rng.choice(bases))); ad.append(c)
+                elif u < p_edit:
+                    pass
+                else:
+                    ad.append(c)
+            pos = int(rng.integers(0, n + 1))
+            s[pos:pos + len(ad)] = ad
+            s = s[:n]
+        if p_n:
+            for i in range(len(s)):
+                if rng.random() < p_n:
+                    s[i] = "N"
+        reads.append("".join(s))
+    return orc.pack_reads(reads)
+
+
+def test_truseq_bulk(model):
+    """the benchmark shape: TruSeq, e=0.1, O=3, 150 bp synthetic reads (with and without window skipping)"""
+    for seed, gen in ((2, dict(p_adapter=0.25, p_edit=0.02, p_n=0.005)), (5, dict(p_adapter=0.9, p_edit=0.08, p_n=0.02)),
+                      (6, dict(p_adapter=0.0, p_edit=0.0, p_n=0.0))):
+        seqs, offsets = orc.synth_reads(seed, 0, 150_000, 150, [TRUSEQ], **gen)
+        for skip in (False, True):
+            counts = compare(model, TRUSEQ, 0.1, 3, seqs, offsets, skip=skip, label=f"truseq seed {seed} skip {skip}")
+            assert counts is not None
+    # most reads must be finished without the cell DP
+    seqs, offsets = orc.synth_reads(2, 0, 100_000, 150, [TRUSEQ])
+    counts = compare(model, TRUSEQ, 0.1, 3, seqs, offsets)
+    assert counts[3] < 0.15 * counts.sum(), counts
+
+
+def test_random_adapters(model):
+    rng = np.random.default_rng(11)
+    done = 0
+    for it in range(160):
+        m = int(rng.integers(1, 65))
+        adapter = "".join(rng.choice(list("ACGT"), size=m))
+        rate = float(rng.choice([0.0, 0.05, 0.1, 0.15, 0.2, 0.3, 0.5]))
+        min_overlap = int(rng.choice([1, 2, 3, 5, m, m + 2]))
+        seqs, offsets = random_reads(rng, adapter, 700, int(rng.choice([12, 40, 90, 170])),
+                                     float(rng.choice([0.0, 0.03, 0.1, 0.2])), float(rng.choice([0.0, 0.01, 0.1])))
+        for skip in (False, True):
+            if compare(model, adapter, rate, min_overlap, seqs, offsets, skip=skip, label=f"random {it} skip {skip}") is not None:
+                done += 1
+    assert done > 150
+
+
+def test_wildcards_and_case(model):
+    rng = np.random.default_rng(12)
+    for it in range(80):
+        m = int(rng.integers(3, 50))
+        letters = list("ACGT") * 4 + list("NRYSWKMBDHV") + ["n", "a", "X"]
+        adapter = "".join(rng.choice(letters, size=m))
+        wr = bool(rng.integers(0, 2))
+        wq = bool(rng.integers(0, 2))
+        if wr and all(c in "Nn" for c in adapter):
+            continue
+        rate = float(rng.choice([0.05, 0.1, 0.2, 0.34]))
+        seqs, offsets = random_reads(rng, adapter.upper() if not wr else adapter.upper().replace("X", "A"), 500,
+                                     int(rng.choice([30, 80, 160])), float(rng.choice([0.0, 0.05, 0.15])),
+                                     float(rng.choice([0.0, 0.05, 0.3])), alphabet="ACGTacgtNRY")
+        compare(model, adapter, rate, int(rng.choice([1, 3, 8])), seqs, offsets, wr=wr, wq=wq, label=f"wild {it}")
+
+
+def test_two_copies_and_repeats(model):
+    """several candidate clusters per read: the shortcut must give way to the DP when its bound fails"""
+    rng = np.random.default_rng(13)
+    for it in range(60):
+        unit = "".join(rng.choice(list("ACGT"), size=int(rng.integers(1, 5))))
+        m = int(rng.integers(6, 40))
+        adapter = (unit * 40)[:m] if it % 2 else "".join(rng.choice(list("ACGT"), size=m))
+        reads = []
+        for _ in range(400):
+            parts = []
+            for _c in range(int(rng.integers(1, 4))):
+                parts.append("".join(rng.choice(list("ACGT"), size=int(rng.integers(0, 30)))))
+                ad = list(adapter)
+                for _e in range(int(rng.integers(0, 4))):
+                    if ad:
+                        ad[int(rng.integers(0, len(ad)))] = str(rng.choice(list("ACGT")))
+                cut = int(rng.integers(0, len(ad) + 1)) if rng.random() < 0.3 else len(ad)
+                parts.append("".join(ad[:cut]))
+            reads.append("".join(parts))
+        seqs, offsets = orc.pack_reads(reads)
+        for skip in (False, True):
+            compare(model, adapter, float(rng.choice([0.1, 0.2, 0.3])), int(rng.choice([1, 3])), seqs, offsets, skip=skip,
+                    label=f"copies {it}")
