@@ -15,14 +15,14 @@ CAH_OK, CAH_EINVAL, CAH_ETYPE, CAH_EHIP, CAH_ENOMEM, CAH_EUNSUPPORTED = 0, 1, 2,
 NONE, MATCH, INVALID = 0, 1, 2
 KIND_ALIGNER, KIND_PREFIX, KIND_SUFFIX, KIND_KMER_ONLY = 0, 1, 2, 3
 MAX_ADAPTER_LEN = 64
-PROF_FILTER, PROF_DP, PROF_COMPARER, PROF_SCAN, PROF_N = 0, 1, 2, 3, 4
+PROF_FILTER, PROF_DP, PROF_COMPARER, PROF_SCAN, PROF_MERGE, PROF_N = 0, 1, 2, 3, 4, 5
 
 # every symbol include/cutadapt_hip.h declares (tests check the library exports them all)
 EXPORTED_SYMBOLS = [
     "cah_abi_version", "cah_last_error", "cah_device_count", "cah_set_device", "cah_device_info",
     "cah_plan_create", "cah_plan_destroy", "cah_plan_n_adapters", "cah_plan_effective_length",
     "cah_plan_n_kmer_entries", "cah_plan_prefilter_kind", "cah_plan_debug_matcher", "cah_locate_batch", "cah_kmers_present_batch", "cah_match_batch",
-    "cah_workspace_bytes", "cah_validate_ascii_batch", "cah_locate_batch_host",
+    "cah_workspace_bytes", "cah_plan_workspace_bytes", "cah_validate_ascii_batch", "cah_locate_batch_host",
     "cah_kmers_present_batch_host", "cah_match_batch_host", "cah_profile_enable",
     "cah_profile_reset", "cah_profile_read", "cah_synth_reads",
     "cah_fastq_scan", "cah_pack_sequences", "cah_fastq_write_trimmed",
@@ -107,6 +107,8 @@ def lib():
     L.cah_match_batch.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp, vp, C.c_size_t, vp]
     L.cah_workspace_bytes.argtypes = [i64]
     L.cah_workspace_bytes.restype = C.c_size_t
+    L.cah_plan_workspace_bytes.argtypes = [vp, i64]
+    L.cah_plan_workspace_bytes.restype = C.c_size_t
     L.cah_validate_ascii_batch.argtypes = [vp, vp, vp, i64, vp, vp]
     L.cah_locate_batch_host.argtypes = [vp, i32, vp, vp, i64, vp, vp]
     L.cah_kmers_present_batch_host.argtypes = [vp, i32, vp, vp, i64, vp]

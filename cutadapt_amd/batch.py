@@ -119,11 +119,15 @@ class ReadBatch:
     def _lens_ptr(self):
         return self.lens.data_ptr() if self.lens is not None else None
 
-    def workspace(self):
+    def workspace(self, plan=None):
         """Per-batch device scratch for the work queue / counters (never shared between
-        batches, so batches on different streams do not interfere)."""
+        batches, so batches on different streams do not interfere).  With ``plan`` the scratch is sized
+        for that plan (cah_plan_workspace_bytes: the fused multi-adapter path needs more)."""
         torch = _torch()
-        need = int(_lib.lib().cah_workspace_bytes(self.n_reads))
+        if plan is not None:
+            need = int(_lib.lib().cah_plan_workspace_bytes(plan.handle, self.n_reads))
+        else:
+            need = int(_lib.lib().cah_workspace_bytes(self.n_reads))
         if self._workspace is None or self._workspace.numel() < need:
             self._workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._workspace
@@ -239,7 +243,7 @@ def match_batch(plan: "_lib.Plan", batch: ReadBatch, out: Optional[BatchResult] 
                           torch.empty(n, dtype=torch.uint8, device=batch.device),
                           torch.empty(n, dtype=torch.int32, device=batch.device))
     if n:
-        ws = batch.workspace()
+        ws = batch.workspace(plan)
         with torch.cuda.device(batch.device):
             _lib.check(_lib.lib().cah_match_batch(
                 plan.handle, batch.seqs.data_ptr(), batch.offsets.data_ptr(), batch._lens_ptr(), n,

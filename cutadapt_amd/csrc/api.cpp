@@ -154,6 +154,23 @@ struct PlanDeviceCopy {
     CahMatcher* d_matchers = nullptr;     // HBM
     CahKmerWord* d_words = nullptr;
     CahLeanFilter* d_lean = nullptr;      // one per matcher (ok = 0 where the lean prefilter does not apply)
+    // fused multi-adapter path (hdr.ok only)
+    CahMultiHeader* d_mhdr = nullptr;
+    CahMultiDir* d_mdir = nullptr;
+    CahMultiEntry* d_mentries = nullptr;
+    uint32_t* d_mbitmap = nullptr;
+    uint64_t* d_mscan = nullptr;          // [n_adapters][CAH_MULTI_TAB_STRIDE] padded match words (cost scan)
+    uint64_t* d_mrow = nullptr;           // ... row bitsets (cell DP)
+};
+
+// host tables of the fused multi-adapter path (see CahMultiHeader)
+struct MultiPlan {
+    CahMultiHeader hdr;
+    std::vector<CahMultiDir> dir;
+    std::vector<CahMultiEntry> entries;
+    std::vector<uint32_t> bitmap;
+    std::vector<uint64_t> scan_tab, row_tab;
+    MultiPlan() { memset(&hdr, 0, sizeof(hdr)); }
 };
 
 // Host tables are built (and validated) at creation; the HBM copy for a device is made the
@@ -162,6 +179,7 @@ struct cah_plan {
     std::vector<CahMatcher> matchers;     // host copies
     std::vector<CahKmerWord> words;
     std::vector<CahLeanFilter> lean;
+    MultiPlan multi;
     mutable std::mutex mu;
     mutable PlanDeviceCopy dev[CAH_MAX_DEVICES];
 };
@@ -190,6 +208,20 @@ static int plan_on_device(const cah_plan* plan, const PlanDeviceCopy** out) {
         }
         HIP_TRY(hipMalloc((void**)&dc.d_lean, sizeof(CahLeanFilter) * plan->lean.size()));
         HIP_TRY(hipMemcpy(dc.d_lean, plan->lean.data(), sizeof(CahLeanFilter) * plan->lean.size(), hipMemcpyHostToDevice));
+        const MultiPlan& mp = plan->multi;
+        if (mp.hdr.ok) {
+#define CAH_UPLOAD(dst, vec)                                                                              \
+            HIP_TRY(hipMalloc((void**)&(dst), sizeof((vec)[0]) * std::max<size_t>((vec).size(), 1)));      \
+            if (!(vec).empty()) HIP_TRY(hipMemcpy((dst), (vec).data(), sizeof((vec)[0]) * (vec).size(), hipMemcpyHostToDevice));
+            HIP_TRY(hipMalloc((void**)&dc.d_mhdr, sizeof(CahMultiHeader)));
+            HIP_TRY(hipMemcpy(dc.d_mhdr, &mp.hdr, sizeof(CahMultiHeader), hipMemcpyHostToDevice));
+            CAH_UPLOAD(dc.d_mdir, mp.dir)
+            CAH_UPLOAD(dc.d_mentries, mp.entries)
+            CAH_UPLOAD(dc.d_mbitmap, mp.bitmap)
+            CAH_UPLOAD(dc.d_mscan, mp.scan_tab)
+            CAH_UPLOAD(dc.d_mrow, mp.row_tab)
+#undef CAH_UPLOAD
+        }
         dc.ready = true;
     }
     *out = &dc;
@@ -452,6 +484,110 @@ static int build_matcher(const cah_adapter_desc& d, int index, CahMatcher& mt,
     return CAH_OK;
 }
 
+
+// The fused multi-adapter path (CahMultiHeader): possible when the plan holds 2..CAH_MULTI_MAX_ADAPTERS
+// matchers that are all plain-ACGT 3' adapters of ONE shape (same length, error thresholds and
+// min_overlap -- then only the match tables differ between lanes), every one scan-eligible, and every
+// k-mer set is a whole-read set (0, None) or a tail set (-L, None) of ACGT k-mers of 1..32 characters
+// matched without wildcards: exactly what `-a file:` with equally long adapters gives (BASELINE C4).
+// Anything else keeps the one-adapter-at-a-time loop.  CAH_NO_MULTI=1 disables it (A/B, parity tests).
+static void build_multi(const cah_adapter_desc* descs, int n, cah_plan* plan) {
+    MultiPlan& mp = plan->multi;
+    const char* off = getenv("CAH_NO_MULTI");
+    if (off && *off && *off != '0') return;
+    if (n < 2 || n > CAH_MULTI_MAX_ADAPTERS) return;
+    const CahMatcher& m0 = plan->matchers[0];
+    auto base2 = [](char c) -> int { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : -1; };
+    struct Item { uint64_t code; uint32_t adapter; int q; int window; };
+    std::vector<Item> items;
+    bool skip_all = true;
+    for (int a = 0; a < n; a++) {
+        const cah_adapter_desc& d = descs[a];
+        const CahMatcher& mt = plan->matchers[(size_t)a];
+        if (d.kind != CAH_KIND_ALIGNER || !mt.scan_ok || d.wildcard_ref || d.wildcard_query) return;
+        if (mt.m != m0.m || mt.k != m0.k || mt.kacc != m0.kacc || mt.min_overlap != m0.min_overlap) return;
+        if (memcmp(mt.thr, m0.thr, sizeof(mt.thr)) != 0 || memcmp(mt.thr_last, m0.thr_last, sizeof(mt.thr_last)) != 0) return;
+        for (int i = 0; i < mt.m; i++) if (base2(d.sequence[i]) < 0) return;
+        if (d.n_kmer_sets <= 0 || !d.kmer_sets || d.kmer_ref_wildcards || d.kmer_query_wildcards) return;
+        skip_all = skip_all && mt.skip_ok != 0;
+        for (int si = 0; si < d.n_kmer_sets; si++) {
+            const cah_kmer_set& ks = d.kmer_sets[si];
+            int window;
+            if (ks.start == 0 && ks.stop == 0) window = 0;
+            else if (ks.start < 0 && ks.stop == 0 && ks.start >= -255) window = (int)-ks.start;
+            else return;
+            for (int t = 0; t < ks.n_kmers; t++) {
+                const char* kmer = ks.kmers[t];
+                if (!kmer) return;
+                const size_t q = strlen(kmer);
+                if (q < 1 || q > 32) return;
+                uint64_t code = 0;
+                for (size_t i = 0; i < q; i++) {
+                    const int b = base2(kmer[i]);
+                    if (b < 0) return;
+                    code = (code << 2) | (uint64_t)b;
+                }
+                items.push_back({code, (uint32_t)a, (int)q, window});
+            }
+        }
+    }
+    if (items.empty()) return;
+    CahMultiHeader& h = mp.hdr;
+    h.n_adapters = n;
+    h.skip_ok = skip_all ? 1 : 0;
+    auto cls_of = [](int q) { return q < 8 ? q : 8; };
+    auto key_of = [](const Item& it) -> uint32_t { return it.q < 8 ? (uint32_t)it.code : (uint32_t)(it.code & 0xFFFFu); };
+    for (const Item& it : items) {
+        const int c = cls_of(it.q);
+        h.class_present[c] = 1;
+        if (it.window == 0) h.class_everywhere[c] = 1;
+        else h.class_lmax[c] = std::max(h.class_lmax[c], it.window);
+    }
+    uint32_t dir_total = 0, bm_total = 0;
+    for (int c = 1; c <= 8; c++) {
+        h.dir_off[c] = dir_total; h.bm_off[c] = bm_total;
+        if (!h.class_present[c]) continue;
+        const uint32_t keys = c < 8 ? (1u << (2 * c)) : 65536u;
+        dir_total += keys;
+        bm_total += (keys + 31) / 32;
+    }
+    h.bm_words = bm_total;
+    mp.dir.assign(dir_total, CahMultiDir{0, 0});
+    mp.bitmap.assign(bm_total, 0u);
+    std::stable_sort(items.begin(), items.end(), [&](const Item& x, const Item& y) {
+        const int cx = cls_of(x.q), cy = cls_of(y.q);
+        if (cx != cy) return cx < cy;
+        return key_of(x) < key_of(y);
+    });
+    mp.entries.reserve(items.size());
+    for (const Item& it : items) {
+        const int c = cls_of(it.q);
+        const uint32_t key = key_of(it);
+        CahMultiDir& d = mp.dir[h.dir_off[c] + key];
+        if (d.count == 0) d.begin = (uint32_t)mp.entries.size();
+        d.count++;
+        mp.bitmap[h.bm_off[c] + (key >> 5)] |= 1u << (key & 31);
+        CahMultiEntry en;
+        memset(&en, 0, sizeof(en));
+        en.code = it.code; en.adapter = it.adapter; en.q = (uint8_t)it.q; en.window = (uint8_t)it.window;
+        mp.entries.push_back(en);
+    }
+    h.n_entries = (uint32_t)mp.entries.size();
+    // per-adapter match tables indexed by (read character & 31): only A/C/G/T (either case) match anything
+    mp.scan_tab.assign((size_t)n * CAH_MULTI_TAB_STRIDE, 0);
+    mp.row_tab.assign((size_t)n * CAH_MULTI_TAB_STRIDE, 0);
+    for (int a = 0; a < n; a++) {
+        const CahMatcher& mt = plan->matchers[(size_t)a];
+        for (int i = 0; i < CAH_MULTI_TAB; i++) {
+            const bool letter = i == 1 || i == 3 || i == 7 || i == 20;                 // A C G T
+            const int ch = 64 + i;
+            mp.scan_tab[(size_t)a * CAH_MULTI_TAB_STRIDE + i] = letter ? mt.scanmask[ch] : mt.scanmask[0];
+            mp.row_tab[(size_t)a * CAH_MULTI_TAB_STRIDE + i] = letter ? mt.rowmask[ch] : 0ull;
+        }
+    }
+    h.ok = 1;
+}
+
 extern "C" {
 
 int cah_abi_version(void) { return CAH_ABI_VERSION; }
@@ -514,6 +650,7 @@ static int plan_create_impl(const cah_adapter_desc* adapters, int32_t n_adapters
         plan->lean[(size_t)i].ok = 0;                 // A/B builds
 #endif
     }
+    build_multi(adapters, n_adapters, plan);
     *out = holder.release();
     return CAH_OK;
 }
@@ -529,6 +666,12 @@ void cah_plan_destroy(cah_plan* plan) {
         if (dc.d_matchers) (void)hipFree(dc.d_matchers);
         if (dc.d_words) (void)hipFree(dc.d_words);
         if (dc.d_lean) (void)hipFree(dc.d_lean);
+        if (dc.d_mhdr) (void)hipFree(dc.d_mhdr);
+        if (dc.d_mdir) (void)hipFree(dc.d_mdir);
+        if (dc.d_mentries) (void)hipFree(dc.d_mentries);
+        if (dc.d_mbitmap) (void)hipFree(dc.d_mbitmap);
+        if (dc.d_mscan) (void)hipFree(dc.d_mscan);
+        if (dc.d_mrow) (void)hipFree(dc.d_mrow);
     }
     if (cur >= 0) (void)hipSetDevice(cur);
     delete plan;
@@ -650,6 +793,27 @@ size_t cah_workspace_bytes(int64_t n_reads) {
     return WS_HEADER + 2 * ws_queue_bytes(n_reads) + ws_keys_bytes(n_reads) + 2 * ws_queue_bytes(n_reads) + 256;
 }
 
+// ---- extra scratch of the fused multi-adapter path: [best key 8n] [pairs 8*cap] [DP list 4*cap] [windows 8*cap]
+// cap = pairs one chunk of reads can produce in the worst case (every adapter on every read), bounded by
+// CAH_MULTI_PAIR_CAP (default 256 M pairs = 5 GB of scratch); larger batches are processed in chunks of
+// cap / n_adapters reads.
+static int64_t multi_pair_cap(const cah_plan* plan, int64_t n_reads) {
+    int64_t limit = 256ll << 20;
+    if (const char* e = getenv("CAH_MULTI_PAIR_CAP")) { const long long v = atoll(e); if (v > 0) limit = v; }
+    const int64_t A = (int64_t)plan->matchers.size();
+    if (limit < A) limit = A;
+    const int64_t worst = n_reads * A;
+    return worst < limit ? worst : limit;
+}
+static size_t ws_key_bytes(int64_t n_reads) { return (sizeof(unsigned long long) * (size_t)n_reads + 255) & ~(size_t)255; }
+
+size_t cah_plan_workspace_bytes(const cah_plan* plan, int64_t n_reads) {
+    if (n_reads < 0) n_reads = 0;
+    size_t need = cah_workspace_bytes(n_reads);
+    if (plan && plan->multi.hdr.ok) need += ws_key_bytes(n_reads) + (size_t)multi_pair_cap(plan, n_reads) * 20 + 256;
+    return need;
+}
+
 namespace {
 struct Workspace {
     unsigned long long* counters;
@@ -694,6 +858,7 @@ static int run_aligner(const cah_plan* plan, const PlanDeviceCopy* pd, int32_t a
     a.out6 = d_out6; a.status = d_status; a.best_adapter = d_best;
     a.adapter_index = adapter; a.merge_best = merge_best;
     a.win = nullptr; a.queue_count_back = nullptr; a.queue_cap = 0;
+    a.pairs = nullptr; a.tab = nullptr; a.n_adapters = 0; a.best_key = nullptr;
     // DP work counter, scan tile counter, DP list counts: one memset over their lines
     HIP_TRY(hipMemsetAsync(ws.counters + WS_DPWORK, 0, WS_HEADER - WS_DPWORK * sizeof(unsigned long long), s));
     if (mt.kind == CAH_KIND_ALIGNER) {
@@ -706,6 +871,7 @@ static int run_aligner(const cah_plan* plan, const PlanDeviceCopy* pd, int32_t a
             sa.work_counter = ws.counters + WS_SCANWORK;
             sa.out6 = d_out6; sa.status = d_status; sa.best_adapter = d_best;
             sa.adapter_index = adapter; sa.merge_best = merge_best;
+            sa.pairs = nullptr; sa.tab = nullptr; sa.n_adapters = 0; sa.multi_skip_ok = 0; sa.best_key = nullptr;
             sa.dp_queue = ws.dp_queue; sa.dp_win = ws.dp_win;
             sa.dp_count_front = ws.counters + WS_DPFRONT; sa.dp_count_back = ws.counters + WS_DPBACK;
             sa.dp_cap = n_reads;
@@ -813,6 +979,76 @@ int cah_kmers_present_batch(const cah_plan* plan, int32_t adapter, const uint8_t
     return CAH_OK;
 }
 
+// The fused multi-adapter path: ONE prefilter pass emits the (read, adapter) pairs whose kmers_present is
+// true, the cost scan and the cell DP run over pairs (the adapter's match table is looked up per lane) and
+// every match is merged into the read's best key with an atomic max (MultipleAdapters' order,
+// kernels.h: pack_best); a last kernel decodes the keys.  status/out6/best_adapter were initialised by
+// the caller; `extra` is the scratch behind the base workspace (cah_plan_workspace_bytes).
+static int match_batch_multi(const cah_plan* plan, const PlanDeviceCopy* pd, const uint8_t* d_seqs,
+                             const int64_t* d_offsets, const int32_t* d_lens, int64_t n_reads, int32_t* d_out6,
+                             int32_t* d_best_adapter, uint8_t* d_status, const Workspace& ws, char* extra,
+                             hipStream_t s) {
+    const MultiPlan& mp = plan->multi;
+    const int64_t A = (int64_t)plan->matchers.size();
+    const int64_t cap = multi_pair_cap(plan, n_reads);
+    const int64_t chunk = std::max<int64_t>(1, cap / A);
+    unsigned long long* d_best_key = (unsigned long long*)extra;     extra += ws_key_bytes(n_reads);
+    uint64_t* d_pairs = (uint64_t*)extra;                            extra += (size_t)cap * 8;
+    int32_t* d_dpq = (int32_t*)extra;                                extra += (size_t)cap * 4;
+    int32_t* d_win = (int32_t*)extra;
+    unsigned long long* counters = ws.counters;
+    const CahMatcher& m0 = plan->matchers[0];
+    HIP_TRY(hipMemsetAsync(d_best_key, 0, sizeof(unsigned long long) * (size_t)n_reads, s));
+    for (int64_t lo = 0; lo < n_reads; lo += chunk) {
+        const int64_t cnt = std::min(chunk, n_reads - lo);
+        HIP_TRY(hipMemsetAsync(counters, 0, WS_HEADER, s));
+        {
+            MultiFilterArgs f;
+            f.hdr = pd->d_mhdr; f.dir = pd->d_mdir; f.entries = pd->d_mentries; f.bitmap = pd->d_mbitmap;
+            f.seqs = d_seqs; f.offsets = d_offsets; f.lens = d_lens;
+            f.first_read = lo; f.n_reads = cnt; f.max_read_len = CAH_MAX_READ_LEN;
+            f.work_counter = counters + 0; f.status = d_status;
+            f.pairs = d_pairs; f.pair_count = counters + WS_QCOUNT; f.pair_cap = cap;
+            ProfScope ps(s, CAH_PROF_FILTER, cnt);
+            HIP_TRY(launch_multi_filter(f, mp.hdr, pd->n_cus, s));
+        }
+        {
+            ScanArgs sa;
+            sa.matcher = pd->d_matchers;
+            sa.seqs = d_seqs; sa.offsets = d_offsets; sa.lens = d_lens; sa.n_reads = cnt * A;
+            sa.max_read_len = CAH_MAX_READ_LEN;
+            sa.queue = nullptr; sa.queue_count = counters + WS_QCOUNT; sa.queue_keys = nullptr;
+            sa.work_counter = counters + WS_SCANWORK;
+            sa.out6 = d_out6; sa.status = d_status; sa.best_adapter = d_best_adapter;
+            sa.adapter_index = 0; sa.merge_best = 1;
+            sa.pairs = d_pairs; sa.tab = pd->d_mscan; sa.n_adapters = (int32_t)A; sa.multi_skip_ok = mp.hdr.skip_ok;
+            sa.best_key = d_best_key;
+            sa.dp_queue = d_dpq; sa.dp_win = d_win;
+            sa.dp_count_front = counters + WS_DPFRONT; sa.dp_count_back = counters + WS_DPBACK;
+            sa.dp_cap = cap;
+            ProfScope ps(s, CAH_PROF_SCAN, cnt);
+            HIP_TRY(launch_back_scan(sa, cnt * A, pd->n_cus, s));
+        }
+        {
+            DpArgs a;
+            a.matcher = pd->d_matchers;
+            a.seqs = d_seqs; a.offsets = d_offsets; a.lens = d_lens; a.n_reads = cnt * A;
+            a.max_read_len = CAH_MAX_READ_LEN;
+            a.queue = d_dpq; a.queue_count = counters + WS_DPFRONT; a.queue_keys = nullptr;
+            a.work_counter = counters + WS_DPWORK;
+            a.out6 = d_out6; a.status = d_status; a.best_adapter = d_best_adapter;
+            a.adapter_index = 0; a.merge_best = 1;
+            a.win = d_win; a.queue_count_back = counters + WS_DPBACK; a.queue_cap = cap;
+            a.pairs = d_pairs; a.tab = pd->d_mrow; a.n_adapters = (int32_t)A; a.best_key = d_best_key;
+            ProfScope ps(s, CAH_PROF_DP, cnt);
+            HIP_TRY(launch_dp(a, m0.m, true, true, cnt * A, pd->n_cus, s));
+        }
+    }
+    ProfScope ps(s, CAH_PROF_MERGE, n_reads);
+    HIP_TRY(launch_multi_decode(d_best_key, n_reads, d_out6, d_status, d_best_adapter, pd->n_cus, s));
+    return CAH_OK;
+}
+
 int cah_match_batch(const cah_plan* plan, const uint8_t* d_seqs, const int64_t* d_offsets,
                     const int32_t* d_lens, int64_t n_reads, int32_t* d_out6, int32_t* d_best_adapter,
                     uint8_t* d_status, void* d_workspace, size_t workspace_bytes, void* stream) {
@@ -843,6 +1079,9 @@ int cah_match_batch(const cah_plan* plan, const uint8_t* d_seqs, const int64_t* 
             d_batch_flag = counters + WS_UFLAG;
         }
     }
+    if (plan->multi.hdr.ok && workspace_bytes >= cah_plan_workspace_bytes(plan, n_reads))
+        return match_batch_multi(plan, pd, d_seqs, d_offsets, d_lens, n_reads, d_out6, d_best_adapter, d_status, ws,
+                                 (char*)d_workspace + cah_workspace_bytes(n_reads), s);
     for (int32_t ad = 0; ad < (int32_t)plan->matchers.size(); ad++) {
         const CahMatcher& mt = plan->matchers[(size_t)ad];
         if (mt.kind == CAH_KIND_KMER_ONLY) continue;

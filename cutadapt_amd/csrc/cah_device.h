@@ -92,3 +92,40 @@ struct CahLeanFilter {
     uint32_t head_found_by_pos[CAH_LEAN_WORDS][CAH_LEAN_SPAN + 2];
     uint32_t mask[CAH_LEAN_WORDS][CAH_TABLE_CHARS];
 };
+
+// ---------------------------------------------------------------------------------------------
+// Fused multi-adapter path (MultipleAdapters.match_to over many 3' adapters of one shape, e.g.
+// `-a file:` with 96 adapters; reference adapters.py:1265-1286).  One pass over the reads finds, for
+// every read, exactly the adapters whose KmerFinder.kmers_present() is true: the k-mers of ALL adapters
+// are indexed by their last min(q, 8) characters (2 bits per base) in direct-address tables -- classes
+// 1..7 hold the k-mers of exactly that length, class 8 every k-mer of 8..32 characters under its last
+// 8 -- with one presence bitmap per class in LDS.  A bitmap hit is resolved through the directory
+// (HBM/L2) to the entries of that key; an entry is verified against the read's rolling 2-bit code
+// (all q characters, search window) before the (read, adapter) pair is emitted.
+// ---------------------------------------------------------------------------------------------
+#define CAH_MULTI_MAX_ADAPTERS 128      // per fused class pass (per-lane "already emitted" bitset: 16 B of LDS)
+#define CAH_MULTI_CLASSES 9             // index 1..8 used
+#define CAH_MULTI_TAB 32                // per-adapter match table: index = read character & 31 (letters only)
+
+struct CahMultiEntry {
+    uint64_t code;        // the k-mer, 2 bits per base, last character in the low bits
+    uint32_t adapter;
+    uint8_t q;            // k-mer length 1..32
+    uint8_t window;       // 0: whole read; L: the k-mer must start within the last L characters
+    uint16_t pad;
+};
+
+struct CahMultiDir { uint32_t begin, count; };
+
+struct CahMultiHeader {
+    int32_t ok;                               // 1: the plan has a fused multi-adapter path
+    int32_t n_adapters;
+    int32_t skip_ok;                          // every adapter's whole-read set has the pigeonhole property
+    int32_t class_present[CAH_MULTI_CLASSES];
+    int32_t class_everywhere[CAH_MULTI_CLASSES];   // some whole-read k-mer falls in this class
+    int32_t class_lmax[CAH_MULTI_CLASSES];         // widest tail window of the class's tail k-mers (0: none)
+    uint32_t dir_off[CAH_MULTI_CLASSES];           // first directory slot of the class
+    uint32_t bm_off[CAH_MULTI_CLASSES];            // first bitmap word of the class
+    uint32_t bm_words;                             // bitmap words in total
+    uint32_t n_entries;
+};

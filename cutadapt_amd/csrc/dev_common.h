@@ -1,0 +1,94 @@
+// dev_common.h -- device helpers shared by the kernels of libcutadapt_hip.so (kernels.hip, multi.hip):
+// wave constants, the packed read layout, work dequeue and the 16-characters-per-load chunk reader.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define WAVE 64
+__device__ __forceinline__ int wave_lane() { return threadIdx.x & (WAVE - 1); }
+
+// Where does read `r` live?  (packed layout, see include/cutadapt_hip.h)
+__device__ __forceinline__ void read_extent(const int64_t* offsets, const int32_t* lens, int64_t r,
+                                            int64_t& off, int64_t& n) {
+    off = offsets[r];
+    n = lens ? (int64_t)lens[r] : offsets[r + 1] - off;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Work distribution: waves pull chunks of 64 work items from a device counter ("dequeue",
+// the cheapest cross-CU primitive on this chip) so that long and short reads balance.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int64_t wave_dequeue(unsigned long long* counter, unsigned items = WAVE) {
+    unsigned long long base = 0;
+    if (wave_lane() == 0) base = atomicAdd(counter, (unsigned long long)items);
+    unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)base);
+    unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
+    return (int64_t)(((unsigned long long)hi << 32) | lo);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Read bytes: 16 characters per lane per global load, held in four VGPRs.
+// Reads are packed back to back, so a read starts at an arbitrary byte; gfx950 executes
+// unaligned global_load_dwordx4.  load_chunk never touches memory outside q[0, n):
+//   interior chunk  -> one 16-byte load at q + pos
+//   last chunk      -> the 16 bytes that END at the read end, funnel-shifted down
+//   reads < 16 bytes-> assembled from byte loads
+// Characters at positions >= limit come back as NUL (which matches nothing in any table).
+// ---------------------------------------------------------------------------------------------
+struct Chunk { unsigned w[4]; };
+
+struct __attribute__((packed, aligned(1))) Unaligned16 { unsigned w[4]; };
+
+__device__ __forceinline__ Chunk load_chunk(const uint8_t* q, int pos, int n, int limit) {
+    Chunk c;
+    c.w[0] = c.w[1] = c.w[2] = c.w[3] = 0;
+    if (pos >= limit) return c;
+    if (pos + 16 <= n) {
+        Unaligned16 u;
+        __builtin_memcpy(&u, q + pos, 16);
+        c.w[0] = u.w[0]; c.w[1] = u.w[1]; c.w[2] = u.w[2]; c.w[3] = u.w[3];
+    } else if (n >= 16) {
+        Unaligned16 u;
+        __builtin_memcpy(&u, q + (n - 16), 16);
+        const int s = pos - (n - 16);                     // 1..15 bytes to drop
+        const int dw = s >> 2, sh = (s & 3) * 8;
+        unsigned x0 = u.w[0], x1 = u.w[1], x2 = u.w[2], x3 = u.w[3];
+        if (dw >= 2) { x0 = x2; x1 = x3; x2 = 0; x3 = 0; }
+        if (dw & 1) { x0 = x1; x1 = x2; x2 = x3; x3 = 0; }
+        c.w[0] = (unsigned)((((unsigned long long)x1 << 32) | x0) >> sh);
+        c.w[1] = (unsigned)((((unsigned long long)x2 << 32) | x1) >> sh);
+        c.w[2] = (unsigned)((((unsigned long long)x3 << 32) | x2) >> sh);
+        c.w[3] = x3 >> sh;
+    } else {
+        // read shorter than 16 bytes: push its bytes in from the top, last byte first (a rolled
+        // loop over four named registers: no dynamic register indexing, tiny register footprint)
+        unsigned x0 = 0, x1 = 0, x2 = 0, x3 = 0;
+#pragma unroll 1
+        for (int t = n - 1; t >= pos; --t) {
+            x3 = (x3 << 8) | (x2 >> 24);
+            x2 = (x2 << 8) | (x1 >> 24);
+            x1 = (x1 << 8) | (x0 >> 24);
+            x0 = (x0 << 8) | (unsigned)q[t];
+        }
+        c.w[0] = x0; c.w[1] = x1; c.w[2] = x2; c.w[3] = x3;
+    }
+    const int keep = limit - pos;                         // characters of this chunk inside [pos, limit)
+    if (keep < 16) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int v = keep - 4 * i;                   // valid bytes in dword i
+            const unsigned msk = v >= 4 ? 0xFFFFFFFFu : (v <= 0 ? 0u : ((1u << (8 * v)) - 1u));
+            c.w[i] &= msk;
+        }
+    }
+    return c;
+}
+
+// byte t (0..15) of a chunk; t is wave-uniform or a compile-time constant
+__device__ __forceinline__ unsigned chunk_byte(const Chunk& c, int t) {
+    const int d = t >> 2;
+    const unsigned w = d == 0 ? c.w[0] : (d == 1 ? c.w[1] : (d == 2 ? c.w[2] : c.w[3]));
+    return (w >> ((t & 3) * 8)) & 0xFFu;
+}
+

@@ -50,7 +50,28 @@ struct DpArgs {
     const int32_t* win;
     const unsigned long long* queue_count_back;
     int64_t queue_cap;
+    // Fused multi-adapter mode (k_dp_packed<ROWS, true>): queue entries index `pairs` (read << 32 | adapter << 8
+    // | key), the match table of the lane's adapter comes from tab[adapter * CAH_MULTI_TAB_STRIDE + (c & 31)]
+    // and results are merged with one 64-bit atomic max per match (pack_best) instead of out6 rows.
+    const uint64_t* pairs;
+    const uint64_t* tab;
+    int32_t n_adapters;
+    unsigned long long* best_key;
 };
+
+#define CAH_MULTI_TAB_STRIDE 33   // 32 entries + 1 of padding: spreads the adapters' tables over the LDS banks
+
+// MultipleAdapters' order (adapters.py:1278-1285: higher score, then fewer errors, then the first adapter)
+// as ONE unsigned 64-bit key with the match itself in the low bits, so that the best match of a read over
+// any number of adapters processed in any order is atomicMax(key):
+//   [score + 128 : 8 @54][127 - errors : 7 @47][4095 - adapter : 12 @35][ref_stop : 7 @28][query_start : 20 @8]
+//   [query_stop - query_start : 8 @0]        (3' adapters: ref_start = 0; a match always gives key != 0)
+__host__ __device__ inline unsigned long long pack_best(int score, int errors, int adapter, int ref_stop,
+                                                         int query_start, int query_stop) {
+    return ((unsigned long long)(unsigned)(score + 128) << 54) | ((unsigned long long)(unsigned)(127 - errors) << 47) |
+           ((unsigned long long)(unsigned)(4095 - adapter) << 35) | ((unsigned long long)(unsigned)ref_stop << 28) |
+           ((unsigned long long)(unsigned)query_start << 8) | (unsigned long long)(unsigned)(query_stop - query_start);
+}
 
 // k_back_scan: bit-parallel cost scan + classification (back_scan.h) of the reads of a work list
 struct ScanArgs {
@@ -69,6 +90,12 @@ struct ScanArgs {
     int32_t* best_adapter;           // may be NULL
     int32_t adapter_index;
     int32_t merge_best;
+    // fused multi-adapter mode (k_back_scan<true>), see DpArgs; dp_queue then receives pair indices
+    const uint64_t* pairs;
+    const uint64_t* tab;
+    int32_t n_adapters;
+    int32_t multi_skip_ok;
+    unsigned long long* best_key;
     int32_t* dp_queue;               // out: reads that need the cell DP (filled from both ends, see DpArgs)
     int32_t* dp_win;
     unsigned long long* dp_count_front;      // zeroed before launch
@@ -83,6 +110,27 @@ hipError_t launch_filter(const FilterArgs& a, int mode, bool narrow_words, int n
 hipError_t launch_dp(const DpArgs& a, int m, bool unit_indel_cost, bool back_adapter, int64_t max_items, int n_cus,
                      hipStream_t s);
 hipError_t launch_back_scan(const ScanArgs& a, int64_t max_items, int n_cus, hipStream_t s);
+
+// multi.hip: the fused multi-adapter prefilter and the final decode of the per-read best keys
+struct MultiFilterArgs {
+    const CahMultiHeader* hdr;
+    const CahMultiDir* dir;
+    const CahMultiEntry* entries;
+    const uint32_t* bitmap;
+    const uint8_t* seqs;
+    const int64_t* offsets;
+    const int32_t* lens;             // may be NULL
+    int64_t first_read, n_reads;     // this launch handles reads [first_read, first_read + n_reads)
+    int64_t max_read_len;
+    unsigned long long* work_counter;        // zeroed before launch
+    uint8_t* status;                 // only written for invalid reads
+    uint64_t* pairs;                 // out: (read << 32 | adapter << 8 | key), runs ordered by key
+    unsigned long long* pair_count;  // zeroed before launch
+    int64_t pair_cap;
+};
+hipError_t launch_multi_filter(const MultiFilterArgs& a, const CahMultiHeader& host_hdr, int n_cus, hipStream_t s);
+hipError_t launch_multi_decode(const unsigned long long* best_key, int64_t n_reads, int32_t* out6, uint8_t* status,
+                               int32_t* best_adapter, int n_cus, hipStream_t s);
 hipError_t launch_comparer(const DpArgs& a, int64_t max_items, int n_cus, hipStream_t s);
 hipError_t launch_validate(const uint8_t* seqs, const int64_t* offsets, const int32_t* lens,
                            int64_t n_reads, int32_t* bad, int n_cus, hipStream_t s);

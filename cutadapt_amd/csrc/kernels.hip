@@ -23,13 +23,11 @@
 #include "cah_device.h"
 #include "kernels.h"
 #include "back_scan.h"
+#include "dev_common.h"
 
-#define WAVE 64
 #ifndef CAH_SCHED_ROWS
 #define CAH_SCHED_ROWS 1
 #endif
-
-__device__ __forceinline__ int wave_lane() { return threadIdx.x & (WAVE - 1); }
 
 __device__ __forceinline__ int pack_cell(int origin, int score) {
     return ((origin + CAH_ORIGIN_BIAS) << CAH_SCORE_BITS) + (score + CAH_SCORE_BIAS);
@@ -39,91 +37,6 @@ __device__ __forceinline__ int cell_origin(int p) {
 }
 __device__ __forceinline__ int cell_score(int p) {
     return (p & ((1 << CAH_SCORE_BITS) - 1)) - CAH_SCORE_BIAS;
-}
-
-// Where does read `r` live?  (packed layout, see include/cutadapt_hip.h)
-__device__ __forceinline__ void read_extent(const int64_t* offsets, const int32_t* lens, int64_t r,
-                                            int64_t& off, int64_t& n) {
-    off = offsets[r];
-    n = lens ? (int64_t)lens[r] : offsets[r + 1] - off;
-}
-
-// ---------------------------------------------------------------------------------------------
-// Work distribution: waves pull chunks of 64 work items from a device counter ("dequeue",
-// the cheapest cross-CU primitive on this chip) so that long and short reads balance.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int64_t wave_dequeue(unsigned long long* counter, unsigned items = WAVE) {
-    unsigned long long base = 0;
-    if (wave_lane() == 0) base = atomicAdd(counter, (unsigned long long)items);
-    unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)base);
-    unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
-    return (int64_t)(((unsigned long long)hi << 32) | lo);
-}
-
-
-// ---------------------------------------------------------------------------------------------
-// Read bytes: 16 characters per lane per global load, held in four VGPRs.
-// Reads are packed back to back, so a read starts at an arbitrary byte; gfx950 executes
-// unaligned global_load_dwordx4.  load_chunk never touches memory outside q[0, n):
-//   interior chunk  -> one 16-byte load at q + pos
-//   last chunk      -> the 16 bytes that END at the read end, funnel-shifted down
-//   reads < 16 bytes-> assembled from byte loads
-// Characters at positions >= limit come back as NUL (which matches nothing in any table).
-// ---------------------------------------------------------------------------------------------
-struct Chunk { unsigned w[4]; };
-
-struct __attribute__((packed, aligned(1))) Unaligned16 { unsigned w[4]; };
-
-__device__ __forceinline__ Chunk load_chunk(const uint8_t* q, int pos, int n, int limit) {
-    Chunk c;
-    c.w[0] = c.w[1] = c.w[2] = c.w[3] = 0;
-    if (pos >= limit) return c;
-    if (pos + 16 <= n) {
-        Unaligned16 u;
-        __builtin_memcpy(&u, q + pos, 16);
-        c.w[0] = u.w[0]; c.w[1] = u.w[1]; c.w[2] = u.w[2]; c.w[3] = u.w[3];
-    } else if (n >= 16) {
-        Unaligned16 u;
-        __builtin_memcpy(&u, q + (n - 16), 16);
-        const int s = pos - (n - 16);                     // 1..15 bytes to drop
-        const int dw = s >> 2, sh = (s & 3) * 8;
-        unsigned x0 = u.w[0], x1 = u.w[1], x2 = u.w[2], x3 = u.w[3];
-        if (dw >= 2) { x0 = x2; x1 = x3; x2 = 0; x3 = 0; }
-        if (dw & 1) { x0 = x1; x1 = x2; x2 = x3; x3 = 0; }
-        c.w[0] = (unsigned)((((unsigned long long)x1 << 32) | x0) >> sh);
-        c.w[1] = (unsigned)((((unsigned long long)x2 << 32) | x1) >> sh);
-        c.w[2] = (unsigned)((((unsigned long long)x3 << 32) | x2) >> sh);
-        c.w[3] = x3 >> sh;
-    } else {
-        // read shorter than 16 bytes: push its bytes in from the top, last byte first (a rolled
-        // loop over four named registers: no dynamic register indexing, tiny register footprint)
-        unsigned x0 = 0, x1 = 0, x2 = 0, x3 = 0;
-#pragma unroll 1
-        for (int t = n - 1; t >= pos; --t) {
-            x3 = (x3 << 8) | (x2 >> 24);
-            x2 = (x2 << 8) | (x1 >> 24);
-            x1 = (x1 << 8) | (x0 >> 24);
-            x0 = (x0 << 8) | (unsigned)q[t];
-        }
-        c.w[0] = x0; c.w[1] = x1; c.w[2] = x2; c.w[3] = x3;
-    }
-    const int keep = limit - pos;                         // characters of this chunk inside [pos, limit)
-    if (keep < 16) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int v = keep - 4 * i;                   // valid bytes in dword i
-            const unsigned msk = v >= 4 ? 0xFFFFFFFFu : (v <= 0 ? 0u : ((1u << (8 * v)) - 1u));
-            c.w[i] &= msk;
-        }
-    }
-    return c;
-}
-
-// byte t (0..15) of a chunk; t is wave-uniform or a compile-time constant
-__device__ __forceinline__ unsigned chunk_byte(const Chunk& c, int t) {
-    const int d = t >> 2;
-    const unsigned w = d == 0 ? c.w[0] : (d == 1 ? c.w[1] : (d == 2 ? c.w[2] : c.w[3]));
-    return (w >> ((t & 3) * 8)) & 0xFFu;
 }
 
 // =============================================================================================
@@ -939,6 +852,10 @@ __global__ __launch_bounds__(256, CAH_DP_WAVES(ROWS)) void k_dp(DpArgs a) {
 // Everything around the cell (band, candidate rules, last-column scan, early exit, column
 // skipping) is the same as in k_dp; origin = j - rel is decoded where the reference reads it.
 // =============================================================================================
+// index of a read character in an adapter's 32-entry match table (fused multi-adapter mode): letters only
+// (bit 6 set), by their low five bits; everything else takes entry 0, which matches nothing
+__device__ __forceinline__ unsigned multi_tab_index(unsigned c) { return (c & 0x40u) ? (c & 31u) : 0u; }
+
 #define PK_COST_SHIFT 20
 #define PK_PRIO_SHIFT 18
 #define PK_REL_SHIFT 9
@@ -1020,13 +937,17 @@ __device__ __forceinline__ unsigned get_row_packed(const unsigned (&w)[ROWS + 1]
 #define PK_DEQUEUE 4
 #endif
 
-template <int ROWS>
+template <int ROWS, bool MULTI>
 __global__ __launch_bounds__(256, CAH_DPP_WAVES(ROWS)) void k_dp_packed(DpArgs a) {
-    __shared__ uint64_t s_rowmask[CAH_TABLE_CHARS];
+    extern __shared__ __attribute__((aligned(16))) uint64_t s_rowmask[];     // [128], or [n_adapters * CAH_MULTI_TAB_STRIDE]
     __shared__ int s_ncnt[CAH_MAX_M + 1];
     __shared__ int s_thr[CAH_MAX_M + 1];
     const CahMatcher* mt = a.matcher;
-    for (int i = threadIdx.x; i < CAH_TABLE_CHARS; i += blockDim.x) s_rowmask[i] = mt->rowmask[i];
+    if (MULTI) {
+        for (int i = threadIdx.x; i < a.n_adapters * CAH_MULTI_TAB_STRIDE; i += blockDim.x) s_rowmask[i] = a.tab[i];
+    } else {
+        for (int i = threadIdx.x; i < CAH_TABLE_CHARS; i += blockDim.x) s_rowmask[i] = mt->rowmask[i];
+    }
     for (int i = threadIdx.x; i <= CAH_MAX_M; i += blockDim.x) {
         s_ncnt[i] = mt->n_counts[i];
         s_thr[i] = mt->thr[i];
@@ -1064,7 +985,20 @@ __global__ __launch_bounds__(256, CAH_DPP_WAVES(ROWS)) void k_dp_packed(DpArgs a
         // the windowed work list is filled from both ends (see DpArgs)
         const int64_t slot = idx < front ? idx : a.queue_cap - 1 - (idx - front);
         int64_t r = 0;
-        if (valid) r = a.queue ? (int64_t)a.queue[slot] : idx;
+        unsigned tab_base = 0, adapter = 0;
+        if (MULTI) {
+            if (valid) {
+                const uint64_t pr = a.pairs[a.queue[slot]];
+                r = (int64_t)(pr >> 32);
+                adapter = (unsigned)(pr >> 8) & 0xFFFFu;
+                tab_base = adapter * CAH_MULTI_TAB_STRIDE;
+            }
+        } else if (valid) {
+            r = a.queue ? (int64_t)a.queue[slot] : idx;
+        }
+        auto table_index = [&](unsigned c) -> unsigned {
+            return MULTI ? tab_base + multi_tab_index(c & 0xFFu) : (c & (CAH_TABLE_CHARS - 1));
+        };
         int64_t off = 0, n64 = 0;
         if (valid) read_extent(a.offsets, a.lens, r, off, n64);
         bool invalid = false;
@@ -1111,7 +1045,7 @@ __global__ __launch_bounds__(256, CAH_DPP_WAVES(ROWS)) void k_dp_packed(DpArgs a
         int dbg_cols = 0, dbg_rows = 0, dbg_ideal = 0;
 #endif
         unsigned bad_chars = cur.w[0] | cur.w[1] | cur.w[2] | cur.w[3];
-        uint64_t mk_next = s_rowmask[cur.w[0] & (CAH_TABLE_CHARS - 1)];
+        uint64_t mk_next = s_rowmask[table_index(cur.w[0])];
         for (;;) {
             const bool act = !done && j < max_n;
             if (!__any(act)) break;
@@ -1127,7 +1061,7 @@ __global__ __launch_bounds__(256, CAH_DPP_WAVES(ROWS)) void k_dp_packed(DpArgs a
                 nxt = load_chunk(q, pos + 16, n, (!done) ? max_n : 0);
                 left = 16;
             }
-            mk_next = s_rowmask[cur.w[0] & (CAH_TABLE_CHARS - 1)];
+            mk_next = s_rowmask[table_index(cur.w[0])];
             if (act) {
                 ++j;
                 // row 0 is the same in every column (start_in_query: cost 0, score 0, origin j);
@@ -1205,7 +1139,10 @@ __global__ __launch_bounds__(256, CAH_DPP_WAVES(ROWS)) void k_dp_packed(DpArgs a
             }
         }
 
-        if (valid) {
+        if (MULTI) {
+            if (valid && b_cost != SENT && !invalid)
+                atomicMax(a.best_key + r, pack_best(b_score, b_cost, (int)adapter, b_refstop, max(b_origin, 0), b_qstop));
+        } else if (valid) {
             const bool found = b_cost != SENT && !invalid;
             int32_t* o = a.out6 + r * 6;
             if (a.merge_best) {
@@ -1274,8 +1211,11 @@ __device__ __forceinline__ void store_result(int32_t* out6, uint8_t* status, int
     }
 }
 
+// MULTI: the work list holds (read, adapter, key) pairs of the fused multi-adapter prefilter; all adapters
+// have one shape (m, k, thresholds: matcher 0), only the match table differs per lane.
+template <bool MULTI>
 __global__ __launch_bounds__(256) void k_back_scan(ScanArgs a) {
-    __shared__ uint64_t s_scanmask[CAH_TABLE_CHARS];
+    extern __shared__ __attribute__((aligned(16))) uint64_t s_scanmask[];   // [128], or [n_adapters * CAH_MULTI_TAB_STRIDE]
     __shared__ int s_thr_last[CAH_MAX_M + 1];
     __shared__ int s_list[SCAN_TILE * 3];          // (read, first column, last column * 2 + scan): front entries
                                                    // from slot 0 up, back entries from the last slot down
@@ -1283,7 +1223,11 @@ __global__ __launch_bounds__(256) void k_back_scan(ScanArgs a) {
     __shared__ long long s_tile;
     __shared__ unsigned long long s_gf, s_gb;
     const CahMatcher* mt = a.matcher;
-    for (int i = threadIdx.x; i < CAH_TABLE_CHARS; i += blockDim.x) s_scanmask[i] = mt->scanmask[i];
+    if (MULTI) {
+        for (int i = threadIdx.x; i < a.n_adapters * CAH_MULTI_TAB_STRIDE; i += blockDim.x) s_scanmask[i] = a.tab[i];
+    } else {
+        for (int i = threadIdx.x; i < CAH_TABLE_CHARS; i += blockDim.x) s_scanmask[i] = mt->scanmask[i];
+    }
     for (int i = threadIdx.x; i <= CAH_MAX_M; i += blockDim.x) s_thr_last[i] = mt->thr_last[i];
     BackScanParams p;
     p.m = mt->m; p.k = mt->k; p.kacc = mt->kacc; p.min_overlap = mt->min_overlap; p.half_m = mt->m / 2;
@@ -1291,7 +1235,7 @@ __global__ __launch_bounds__(256) void k_back_scan(ScanArgs a) {
     const int wave = threadIdx.x >> 6;
     int64_t total = a.n_reads;
     if (a.queue_count) total = (int64_t)(*a.queue_count);
-    const bool skip_cols = a.queue && a.queue_keys && mt->skip_ok != 0;
+    const bool skip_cols = MULTI ? a.multi_skip_ok != 0 : (a.queue && a.queue_keys && mt->skip_ok != 0);
 
     for (;;) {
         __syncthreads();                                   // previous tile flushed
@@ -1309,7 +1253,19 @@ __global__ __launch_bounds__(256) void k_back_scan(ScanArgs a) {
             const int64_t idx = base + lane;
             const bool valid = idx < total;
             int64_t r = 0;
-            if (valid) r = a.queue ? (int64_t)a.queue[idx] : idx;
+            unsigned tab_base = 0, adapter = 0, key = 0;
+            if (MULTI) {
+                if (valid) {
+                    const uint64_t pr = a.pairs[idx];
+                    r = (int64_t)(pr >> 32);
+                    adapter = (unsigned)(pr >> 8) & 0xFFFFu;
+                    key = (unsigned)pr & 0xFFu;
+                    tab_base = adapter * CAH_MULTI_TAB_STRIDE;
+                }
+            } else {
+                if (valid) r = a.queue ? (int64_t)a.queue[idx] : idx;
+                if (skip_cols && valid) key = a.queue_keys[idx];
+            }
             int64_t off = 0, n64 = 0;
             if (valid) read_extent(a.offsets, a.lens, r, off, n64);
             bool invalid = false;
@@ -1319,7 +1275,10 @@ __global__ __launch_bounds__(256) void k_back_scan(ScanArgs a) {
             // first column of the window (column skipping): nothing of the whole-read k-mer set
             // ends before 4 * key, so no row-m cost <= k occurs before it
             int j0 = 0;
-            if (skip_cols && valid) j0 = max(0, ((int)a.queue_keys[idx] << CAH_KEY_SHIFT) - p.m - p.k - 1);
+            if (skip_cols && valid) j0 = max(0, ((int)key << CAH_KEY_SHIFT) - p.m - p.k - 1);
+            auto table_index = [&](unsigned c) -> unsigned {
+                return MULTI ? tab_base + multi_tab_index(c & 0xFFu) : (c & (CAH_TABLE_CHARS - 1));
+            };
 
             BackScanState st;
             bs_init(st, p);
@@ -1330,7 +1289,7 @@ __global__ __launch_bounds__(256) void k_back_scan(ScanArgs a) {
             Chunk nxt = load_chunk(q, pos + 16, n, valid ? n : 0);
             int left = 16;
             unsigned bad_chars = cur.w[0] | cur.w[1] | cur.w[2] | cur.w[3];
-            uint64_t eq_next = s_scanmask[cur.w[0] & (CAH_TABLE_CHARS - 1)];
+            uint64_t eq_next = s_scanmask[table_index(cur.w[0])];
             for (;;) {
                 const bool act = !done && j < n;
                 if (!__any(act)) break;
@@ -1346,7 +1305,7 @@ __global__ __launch_bounds__(256) void k_back_scan(ScanArgs a) {
                     nxt = load_chunk(q, pos + 16, n, (!done) ? n : 0);
                     left = 16;
                 }
-                eq_next = s_scanmask[cur.w[0] & (CAH_TABLE_CHARS - 1)];
+                eq_next = s_scanmask[table_index(cur.w[0])];
                 if (act) {
                     ++j;
                     if (bs_step(st, eq, j, p)) { exact = true; done = true; }
@@ -1357,7 +1316,14 @@ __global__ __launch_bounds__(256) void k_back_scan(ScanArgs a) {
             int o0 = 0, o1 = 0;
             int cls = bs_finish(st, n, j0, p, [&](int i) { return s_thr_last[i]; }, o0, o1);
             if (exact) { cls = BS_EXACT_FULL; o0 = j; }
-            if (valid) {
+            if (MULTI) {
+                // invalid reads were flagged by the prefilter (it sees every character); matches are merged
+                // with one atomic max on the read's best key
+                if (valid && !invalid) {
+                    if (cls == BS_EXACT_FULL) atomicMax(a.best_key + r, pack_best(p.m, 0, (int)adapter, p.m, o0 - p.m, o0));
+                    else if (cls == BS_EXACT_TAIL) atomicMax(a.best_key + r, pack_best(o0, 0, (int)adapter, o0, n - o0, n));
+                }
+            } else if (valid) {
                 if (invalid || cls == BS_NONE) {
                     store_result(a.out6, a.status, a.best_adapter, a.adapter_index, a.merge_best, r, invalid, false,
                                  0, 0, 0, 0, 0, 0);
@@ -1382,12 +1348,13 @@ __global__ __launch_bounds__(256) void k_back_scan(ScanArgs a) {
                 sf = __builtin_amdgcn_readfirstlane(sf);
                 sb = __builtin_amdgcn_readfirstlane(sb);
                 const unsigned long long below = (1ull << lane) - 1ull;
+                const int item = MULTI ? (int)idx : (int)r;          // multi: the cell DP looks the pair up again
                 if (to_front) {
                     const int e = (int)sf + __popcll(bf & below);
-                    s_list[3 * e] = (int)r; s_list[3 * e + 1] = o0; s_list[3 * e + 2] = o1;
+                    s_list[3 * e] = item; s_list[3 * e + 1] = o0; s_list[3 * e + 2] = o1;
                 } else if (to_back) {
                     const int e = SCAN_TILE - 1 - ((int)sb + __popcll(bb & below));
-                    s_list[3 * e] = (int)r; s_list[3 * e + 1] = o0; s_list[3 * e + 2] = o1;
+                    s_list[3 * e] = item; s_list[3 * e + 1] = o0; s_list[3 * e + 2] = o1;
                 }
             }
         }
@@ -1580,8 +1547,13 @@ hipError_t launch_dp(const DpArgs& a, int m, bool unit, bool back_adapter, int64
     const int grid = grid_for(max_items, 8, n_cus);
     if (unit && back_adapter) {
         // the common case: 3' adapter, unit costs -> one-word-per-cell kernel
-#define CAH_DPP_CASE(R) \
-        if (m <= R) { hipLaunchKernelGGL((k_dp_packed<R>), dim3(grid), dim3(256), 0, s, a); return hipGetLastError(); }
+#define CAH_DPP_CASE(R)                                                                                            \
+        if (m <= R) {                                                                                              \
+            if (a.pairs) hipLaunchKernelGGL((k_dp_packed<R, true>), dim3(grid), dim3(256),                         \
+                                            sizeof(uint64_t) * (size_t)a.n_adapters * CAH_MULTI_TAB_STRIDE, s, a); \
+            else hipLaunchKernelGGL((k_dp_packed<R, false>), dim3(grid), dim3(256), sizeof(uint64_t) * CAH_TABLE_CHARS, s, a); \
+            return hipGetLastError();                                                                              \
+        }
         CAH_DPP_CASE(8) CAH_DPP_CASE(12) CAH_DPP_CASE(16) CAH_DPP_CASE(20) CAH_DPP_CASE(24) CAH_DPP_CASE(28)
         CAH_DPP_CASE(32) CAH_DPP_CASE(36) CAH_DPP_CASE(40) CAH_DPP_CASE(44) CAH_DPP_CASE(48) CAH_DPP_CASE(52)
         CAH_DPP_CASE(56) CAH_DPP_CASE(60) CAH_DPP_CASE(64)
@@ -1617,7 +1589,13 @@ hipError_t launch_back_scan(const ScanArgs& a, int64_t max_items, int n_cus, hip
     int64_t need = (max_items + SCAN_TILE - 1) / SCAN_TILE;
     if (need < 1) need = 1;
     const int64_t cap = (int64_t)8 * n_cus;
-    hipLaunchKernelGGL(k_back_scan, dim3((unsigned)(need < cap ? need : cap)), dim3(256), 0, s, a);
+    const dim3 grid((unsigned)(need < cap ? need : cap));
+    if (a.pairs) {
+        const size_t lds = sizeof(uint64_t) * (size_t)a.n_adapters * CAH_MULTI_TAB_STRIDE;
+        hipLaunchKernelGGL(k_back_scan<true>, grid, dim3(256), lds, s, a);
+    } else {
+        hipLaunchKernelGGL(k_back_scan<false>, grid, dim3(256), sizeof(uint64_t) * CAH_TABLE_CHARS, s, a);
+    }
     return hipGetLastError();
 }
 

@@ -160,6 +160,11 @@ int cah_match_batch(const cah_plan *plan, const uint8_t *d_seqs, const int64_t *
 
 /* bytes of device scratch the calls above need for n_reads reads */
 size_t cah_workspace_bytes(int64_t n_reads);
+/* ... for THIS plan: plans of many equally shaped 3' adapters (e.g. `-a file:` with 96 adapters) have a fused
+ * multi-adapter path -- one prefilter pass for all adapters instead of one per adapter -- that needs more
+ * scratch (pair queue + per-read best keys).  cah_match_batch takes that path when workspace_bytes is at
+ * least this value and otherwise matches one adapter after the other (same results). */
+size_t cah_plan_workspace_bytes(const cah_plan *plan, int64_t n_reads);
 
 /* d_bad[0] (int32) is set to the number of reads holding a byte >= 0x80 (the reference
  * rejects such strings up front, _align.pyx:44-45 / _kmer_finder.pyx:182-183). */
@@ -186,7 +191,8 @@ int cah_match_batch_host(const cah_plan *plan, const uint8_t *seqs, const int64_
 #define CAH_PROF_DP 1
 #define CAH_PROF_COMPARER 2
 #define CAH_PROF_SCAN 3   /* k_back_scan: bit-parallel cost scan in front of the cell DP */
-#define CAH_PROF_N 4
+#define CAH_PROF_MERGE 4  /* k_multi_decode: best keys -> tuples (fused multi-adapter path) */
+#define CAH_PROF_N 5
 int cah_profile_enable(int enable);
 int cah_profile_reset(void);
 int cah_profile_read(double ms[CAH_PROF_N], int64_t launches[CAH_PROF_N],
