@@ -38,7 +38,7 @@ def plan_for(adapters, rate, min_overlap, fused=True):
     from cutadapt_amd import _lib
     from cutadapt_amd import adapters as A
     ads = [A.BackAdapter(s, max_errors=rate, min_overlap=min_overlap) for s in adapters]
-    with env(CAH_NO_MULTI=None if fused else "1"):
+    with env(CAH_NO_MULTI=None if fused else "1", CAH_MULTI_MIN="2"):
         return _lib.Plan([a.matcher_spec() for a in ads]), ads
 
 
