@@ -213,7 +213,7 @@ def locate_batch(plan: "_lib.Plan", adapter: int, batch: ReadBatch) -> BatchResu
     out6 = torch.empty((n, 6), dtype=torch.int32, device=batch.device)
     status = torch.empty(n, dtype=torch.uint8, device=batch.device)
     if n:
-        ws = batch.workspace()
+        ws = batch.workspace(plan)
         with torch.cuda.device(batch.device):
             _lib.check(_lib.lib().cah_locate_batch(
                 plan.handle, adapter, batch.seqs.data_ptr(), batch.offsets.data_ptr(),

@@ -148,6 +148,18 @@ int clamp_floor(double x) {
 // ---------------------------------------------------------------------------------------------
 #define CAH_MAX_DEVICES 64
 
+// adapters longer than CAH_MAX_M characters (long.hip)
+struct LongTables {
+    CahLongMatcher lm;
+    std::vector<uint8_t> ref;
+    std::vector<int32_t> ncnt;
+};
+struct LongDeviceCopy {
+    CahLongMatcher* d_lm = nullptr;
+    uint8_t* d_ref = nullptr;
+    int32_t* d_ncnt = nullptr;
+};
+
 struct PlanDeviceCopy {
     bool ready = false;
     int n_cus = 256;
@@ -161,6 +173,7 @@ struct PlanDeviceCopy {
     uint32_t* d_mbitmap = nullptr;
     uint64_t* d_mscan = nullptr;          // [n_adapters][CAH_MULTI_TAB_STRIDE] padded match words (cost scan)
     uint64_t* d_mrow = nullptr;           // ... row bitsets (cell DP)
+    std::vector<LongDeviceCopy> d_long;   // one per matcher (null pointers unless long_dp)
 };
 
 // host tables of the fused multi-adapter path (see CahMultiHeader)
@@ -180,6 +193,8 @@ struct cah_plan {
     std::vector<CahKmerWord> words;
     std::vector<CahLeanFilter> lean;
     MultiPlan multi;
+    std::vector<LongTables> long_tabs;    // one per matcher (empty tables unless long_dp)
+    int max_long_m = 0;                   // longest long_dp adapter (0: none): sizes the column scratch
     mutable std::mutex mu;
     mutable PlanDeviceCopy dev[CAH_MAX_DEVICES];
 };
@@ -208,6 +223,18 @@ static int plan_on_device(const cah_plan* plan, const PlanDeviceCopy** out) {
         }
         HIP_TRY(hipMalloc((void**)&dc.d_lean, sizeof(CahLeanFilter) * plan->lean.size()));
         HIP_TRY(hipMemcpy(dc.d_lean, plan->lean.data(), sizeof(CahLeanFilter) * plan->lean.size(), hipMemcpyHostToDevice));
+        dc.d_long.resize(plan->matchers.size());
+        for (size_t i = 0; i < plan->matchers.size(); i++) {
+            if (!plan->matchers[i].long_dp) continue;
+            const LongTables& lt = plan->long_tabs[i];
+            LongDeviceCopy& ld = dc.d_long[i];
+            HIP_TRY(hipMalloc((void**)&ld.d_lm, sizeof(CahLongMatcher)));
+            HIP_TRY(hipMemcpy(ld.d_lm, &lt.lm, sizeof(CahLongMatcher), hipMemcpyHostToDevice));
+            HIP_TRY(hipMalloc((void**)&ld.d_ref, lt.ref.size()));
+            HIP_TRY(hipMemcpy(ld.d_ref, lt.ref.data(), lt.ref.size(), hipMemcpyHostToDevice));
+            HIP_TRY(hipMalloc((void**)&ld.d_ncnt, sizeof(int32_t) * lt.ncnt.size()));
+            HIP_TRY(hipMemcpy(ld.d_ncnt, lt.ncnt.data(), sizeof(int32_t) * lt.ncnt.size(), hipMemcpyHostToDevice));
+        }
         const MultiPlan& mp = plan->multi;
         if (mp.hdr.ok) {
 #define CAH_UPLOAD(dst, vec)                                                                              \
@@ -290,8 +317,67 @@ static void build_lean_filter(const cah_adapter_desc& d, CahLeanFilter& lf) {
     lf.ok = lf.n_words >= 1 ? 1 : 0;
 }
 
+#define CAH_LONG_ADAPTER_LIMIT 100000     // sanity bound for the HBM column of k_dp_long (3 x 4 B per row and lane)
+
+// m > CAH_MAX_M: constants + encoded adapter for k_dp_long (the reference's own representation:
+// _align.pyx:250-277 for Aligner, :615-642 for the comparers)
+static int build_long(const cah_adapter_desc& d, int index, CahMatcher& mt, LongTables& lt) {
+    const CharTables& t = tables();
+    const int m = d.length;
+    const char* seq = d.sequence;
+    const bool wr = d.wildcard_ref != 0, wq = d.wildcard_query != 0;
+    const double rate = d.max_error_rate;
+    if (m > CAH_LONG_ADAPTER_LIMIT)
+        return fail(CAH_EUNSUPPORTED, "adapter %d: length %d exceeds %d characters", index, m, CAH_LONG_ADAPTER_LIMIT);
+    CahLongMatcher& lm = lt.lm;
+    memset(&lm, 0, sizeof(lm));
+    lm.kind = d.kind; lm.m = m; lm.flags = d.flags & 15; lm.indel_cost = d.indel_cost; lm.min_overlap = d.min_overlap;
+    lm.wildcard_ref = wr; lm.rate = rate;
+    lt.ref.resize((size_t)m);
+    lt.ncnt.assign((size_t)m + 1, 0);
+    // read character -> encoding (:322-328); adapter encoding (:272-276, comparers :637-642)
+    const uint8_t* qsrc = wq ? t.iupac : (wr ? t.acgt : t.upper);
+    for (int c = 0; c < CAH_TABLE_CHARS; c++) lm.qtab[c] = qsrc[c];
+    lm.cmp_equal = (!wq && !wr) ? 1 : 0;
+    if (d.kind == CAH_KIND_ALIGNER) {
+        int nn = 0;
+        for (int i = 0; i < m; i++) { lt.ncnt[(size_t)i] = nn; if (seq[i] == 'N' || seq[i] == 'n') nn++; }
+        lt.ncnt[(size_t)m] = nn;
+        lm.effective_length = m;
+        if (wr) {
+            lm.effective_length = m - nn;
+            if (lm.effective_length == 0) return fail(CAH_EINVAL, "Cannot have only N wildcards in the sequence");
+        }
+        if (d.indel_cost < 1) return fail(CAH_EINVAL, "indel_cost must be at least 1");
+        if (d.indel_cost > CAH_MAX_INDEL_COST)
+            return fail(CAH_EUNSUPPORTED, "indel_cost above %d is not supported", CAH_MAX_INDEL_COST);
+        if (!(rate == rate) || std::fabs(rate) > 1e6) return fail(CAH_EINVAL, "max_error_rate is not a usable number");
+        lm.k = (int)(rate * m);
+        for (int i = 0; i < m; i++)
+            lt.ref[(size_t)i] = wr ? t.iupac[(uint8_t)seq[i]] : (wq ? t.acgt[(uint8_t)seq[i]] : (uint8_t)seq[i]);   // raw, NOT upper-cased
+    } else {
+        int eff = m;
+        if (wr) {
+            int nN = 0, nn = 0;
+            for (int i = 0; i < m; i++) { nN += seq[i] == 'N'; nn += seq[i] == 'n'; }
+            eff -= nN - nn;                                                 // quirk kept (:628)
+            if (eff == 0) return fail(CAH_EINVAL, "Cannot have only N wildcards in the sequence");
+        }
+        if (!(rate >= 0.0 && rate <= 1.0)) return fail(CAH_EINVAL, "max_error_rate must be between 0 and 1");
+        if (d.min_overlap < 1) return fail(CAH_EINVAL, "min_overlap must be at least 1");
+        lm.effective_length = eff;
+        lm.cmp_max_k = (int)(rate * eff);
+        for (int i = 0; i < m; i++)
+            lt.ref[(size_t)i] = wr ? t.iupac[(uint8_t)seq[i]] : (wq ? t.acgt[(uint8_t)seq[i]] : t.upper[(uint8_t)seq[i]]);
+    }
+    mt.long_dp = 1;
+    mt.m = m; mt.k = lm.k; mt.flags = lm.flags; mt.min_overlap = d.min_overlap; mt.wildcard_ref = wr;
+    mt.indel_cost = d.indel_cost; mt.effective_length = lm.effective_length; mt.cmp_max_k = lm.cmp_max_k;
+    return CAH_OK;
+}
+
 static int build_matcher(const cah_adapter_desc& d, int index, CahMatcher& mt,
-                         std::vector<CahKmerWord>& words) {
+                         std::vector<CahKmerWord>& words, LongTables& lt) {
     memset(&mt, 0, sizeof(mt));
     if (d.kind < CAH_KIND_ALIGNER || d.kind > CAH_KIND_KMER_ONLY)
         return fail(CAH_EINVAL, "adapter %d: unknown kind %d", index, d.kind);
@@ -301,9 +387,6 @@ static int build_matcher(const cah_adapter_desc& d, int index, CahMatcher& mt,
     if (has_aligner) {
         if (m < 0 || (m > 0 && !d.sequence))
             return fail(CAH_EINVAL, "adapter %d: bad sequence", index);
-        if (m > CAH_MAX_ADAPTER_LEN)
-            return fail(CAH_EUNSUPPORTED, "adapter %d: length %d exceeds the %d-character limit of this build",
-                        index, m, CAH_MAX_ADAPTER_LEN);
         if (!is_ascii(d.sequence, (size_t)m))
             return fail(CAH_EINVAL, "String must contain only ASCII characters");
         const bool wr = d.wildcard_ref != 0, wq = d.wildcard_query != 0;
@@ -314,7 +397,10 @@ static int build_matcher(const cah_adapter_desc& d, int index, CahMatcher& mt,
         mt.wildcard_ref = wr;
         mt.indel_cost = d.indel_cost;
         const char* seq = d.sequence;
-        if (d.kind == CAH_KIND_ALIGNER) {
+        if (m > CAH_MAX_M) {
+            const int rc = build_long(d, index, mt, lt);
+            if (rc != CAH_OK) return rc;
+        } else if (d.kind == CAH_KIND_ALIGNER) {
             // _align.pyx:250-277
             int nn = 0;
             for (int i = 0; i < m; i++) {
@@ -457,7 +543,7 @@ static int build_matcher(const cah_adapter_desc& d, int index, CahMatcher& mt,
     // of the adapter (reference kmer_heuristic.py:161-163 builds exactly that), matched with the
     // same wildcard relation as the aligner.  Hand-made k-mer sets that lack it keep skip_ok = 0.
     mt.skip_ok = 0;
-    if (d.kind == CAH_KIND_ALIGNER && mt.flags == 14 && d.n_kmer_sets > 0 && m >= 1 &&
+    if (d.kind == CAH_KIND_ALIGNER && mt.flags == 14 && d.n_kmer_sets > 0 && m >= 1 && m <= CAH_MAX_M &&
         n_whole_read_words <= (mt.narrow_words ? CAH_FILTER_SLOTS_NARROW : CAH_FILTER_SLOTS) &&
         (d.kmer_ref_wildcards != 0) == (d.wildcard_ref != 0) &&
         (d.kmer_query_wildcards != 0) == (d.wildcard_query != 0)) {
@@ -646,9 +732,11 @@ static int plan_create_impl(const cah_adapter_desc* adapters, int32_t n_adapters
     cah_plan* plan = holder.get();
     plan->matchers.resize((size_t)n_adapters);
     plan->lean.resize((size_t)n_adapters);
+    plan->long_tabs.resize((size_t)n_adapters);
     for (int i = 0; i < n_adapters; i++) {
-        int rc = build_matcher(adapters[i], i, plan->matchers[(size_t)i], plan->words);
+        int rc = build_matcher(adapters[i], i, plan->matchers[(size_t)i], plan->words, plan->long_tabs[(size_t)i]);
         if (rc != CAH_OK) return rc;
+        if (plan->matchers[(size_t)i].long_dp) plan->max_long_m = std::max(plan->max_long_m, plan->matchers[(size_t)i].m);
         build_lean_filter(adapters[i], plan->lean[(size_t)i]);
 #ifdef CAH_NO_LEAN
         plan->lean[(size_t)i].ok = 0;                 // A/B builds
@@ -676,6 +764,11 @@ void cah_plan_destroy(cah_plan* plan) {
         if (dc.d_mbitmap) (void)hipFree(dc.d_mbitmap);
         if (dc.d_mscan) (void)hipFree(dc.d_mscan);
         if (dc.d_mrow) (void)hipFree(dc.d_mrow);
+        for (LongDeviceCopy& ld : dc.d_long) {
+            if (ld.d_lm) (void)hipFree(ld.d_lm);
+            if (ld.d_ref) (void)hipFree(ld.d_ref);
+            if (ld.d_ncnt) (void)hipFree(ld.d_ncnt);
+        }
     }
     if (cur >= 0) (void)hipSetDevice(cur);
     delete plan;
@@ -811,10 +904,17 @@ static int64_t multi_pair_cap(const cah_plan* plan, int64_t n_reads) {
 }
 static size_t ws_key_bytes(int64_t n_reads) { return (sizeof(unsigned long long) * (size_t)n_reads + 255) & ~(size_t)255; }
 
+// column scratch of k_dp_long: 3 int32 per row and lane, for as many lanes as the kernel is launched with
+// (sized for a 256-CU device; fewer lanes are launched if the caller's workspace is smaller)
+static size_t long_scratch_bytes(const cah_plan* plan, int64_t lanes) {
+    return (size_t)lanes * 3 * sizeof(int32_t) * ((size_t)plan->max_long_m + 1);
+}
+
 size_t cah_plan_workspace_bytes(const cah_plan* plan, int64_t n_reads) {
     if (n_reads < 0) n_reads = 0;
     size_t need = cah_workspace_bytes(n_reads);
     if (plan && plan->multi.hdr.ok) need += ws_key_bytes(n_reads) + (size_t)multi_pair_cap(plan, n_reads) * 20 + 256;
+    if (plan && plan->max_long_m > 0) need += long_scratch_bytes(plan, long_scratch_lanes(n_reads, 256)) + 256;
     return need;
 }
 
@@ -825,7 +925,11 @@ struct Workspace {
     uint8_t* keys;
     int32_t* dp_queue;
     int32_t* dp_win;
-    Workspace(void* base, int64_t n_reads) {
+    char* extra = nullptr;            // scratch behind the base layout (cah_plan_workspace_bytes), if any
+    size_t extra_bytes = 0;
+    Workspace(void* base, int64_t n_reads, size_t total_bytes = 0) {
+        const size_t base_bytes = cah_workspace_bytes(n_reads);
+        if (total_bytes > base_bytes) { extra = (char*)base + base_bytes; extra_bytes = total_bytes - base_bytes; }
         char* p = (char*)base;
         counters = (unsigned long long*)p;              p += WS_HEADER;
         queue = (int32_t*)p;                            p += ws_queue_bytes(n_reads);
@@ -865,6 +969,25 @@ static int run_aligner(const cah_plan* plan, const PlanDeviceCopy* pd, int32_t a
     a.pairs = nullptr; a.tab = nullptr; a.n_adapters = 0; a.best_key = nullptr;
     // DP work counter, scan tile counter, DP list counts: one memset over their lines
     HIP_TRY(hipMemsetAsync(ws.counters + WS_DPWORK, 0, WS_HEADER - WS_DPWORK * sizeof(unsigned long long), s));
+    if (mt.long_dp) {
+        // adapter longer than 64 characters: column in HBM scratch (long.hip)
+        int64_t lanes = long_scratch_lanes(n_reads, pd->n_cus);
+        const size_t per_lane = long_scratch_bytes(plan, 1);
+        if (ws.extra_bytes / per_lane < (size_t)lanes) lanes = (int64_t)(ws.extra_bytes / per_lane) / 256 * 256;
+        if (lanes < 256)
+            return fail(CAH_EINVAL, "workspace too small for an adapter of %d characters: need cah_plan_workspace_bytes() = %zu bytes",
+                        mt.m, cah_plan_workspace_bytes(plan, n_reads));
+        const LongDeviceCopy& ld = pd->d_long[(size_t)adapter];
+        LongArgs la;
+        la.lm = ld.d_lm; la.ref = ld.d_ref; la.ncnt = ld.d_ncnt;
+        la.seqs = d_seqs; la.offsets = d_offsets; la.lens = d_lens; la.n_reads = n_reads; la.max_read_len = CAH_MAX_READ_LEN;
+        la.queue = d_queue; la.queue_count = d_queue_count; la.work_counter = ws.counters + WS_DPWORK;
+        la.scratch = (int32_t*)ws.extra;
+        la.out6 = d_out6; la.status = d_status; la.best_adapter = d_best; la.adapter_index = adapter; la.merge_best = merge_best;
+        ProfScope ps(s, mt.kind == CAH_KIND_ALIGNER ? CAH_PROF_DP : CAH_PROF_COMPARER, n_reads);
+        HIP_TRY(launch_dp_long(la, lanes, s));
+        return CAH_OK;
+    }
     if (mt.kind == CAH_KIND_ALIGNER) {
         if (mt.scan_ok) {
             ScanArgs sa;
@@ -910,7 +1033,7 @@ int cah_locate_batch(const cah_plan* plan, int32_t adapter, const uint8_t* d_seq
     if (!d_out6 || !d_status) return fail(CAH_EINVAL, "output pointers are NULL");
     if (!d_workspace || workspace_bytes < cah_workspace_bytes(n_reads))
         return fail(CAH_EINVAL, "workspace too small: need %zu bytes", cah_workspace_bytes(n_reads));
-    const Workspace ws(d_workspace, n_reads);
+    const Workspace ws(d_workspace, n_reads, workspace_bytes);
     const PlanDeviceCopy* pd = nullptr;
     rc = plan_on_device(plan, &pd);
     if (rc) return rc;
@@ -971,13 +1094,20 @@ int cah_kmers_present_batch(const cah_plan* plan, int32_t adapter, const uint8_t
     const PlanDeviceCopy* pd = nullptr;
     rc = plan_on_device(plan, &pd);
     if (rc) return rc;
-    // small private counter: allocate per call (kmers_present_batch is not the fused hot path)
-    unsigned long long* d_counter = nullptr;
-    HIP_TRY(hipMalloc((void**)&d_counter, sizeof(unsigned long long)));
+    // private counter line: a per-thread, per-device allocation made once (the call synchronises the stream
+    // before it returns, so consecutive calls of a thread never overlap)
+    static thread_local unsigned long long* t_counter = nullptr;
+    static thread_local int t_counter_device = -1;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (!t_counter || t_counter_device != dev) {
+        t_counter = nullptr;
+        HIP_TRY(hipMalloc((void**)&t_counter, 256));
+        t_counter_device = dev;
+    }
     rc = run_filter(plan, pd, adapter, d_seqs, d_offsets, d_lens, n_reads, 0, d_present, nullptr, nullptr,
-                    nullptr, nullptr, d_counter, nullptr, s);
+                    nullptr, nullptr, t_counter, nullptr, s);
     hipError_t e = hipStreamSynchronize(s);
-    (void)hipFree(d_counter);
     if (rc) return rc;
     if (e != hipSuccess) return fail(CAH_EHIP, "k_filter failed: %s", hipGetErrorString(e));
     return CAH_OK;
@@ -1066,7 +1196,7 @@ int cah_match_batch(const cah_plan* plan, const uint8_t* d_seqs, const int64_t* 
     const PlanDeviceCopy* pd = nullptr;
     rc = plan_on_device(plan, &pd);
     if (rc) return rc;
-    const Workspace ws(d_workspace, n_reads);
+    const Workspace ws(d_workspace, n_reads, workspace_bytes);
     unsigned long long* counters = ws.counters;
     HIP_TRY(hipMemsetAsync(d_status, 0, (size_t)n_reads, s));
     HIP_TRY(hipMemsetAsync(d_out6, 0, sizeof(int32_t) * 6 * (size_t)n_reads, s));
@@ -1130,61 +1260,115 @@ struct DevBuf {
     hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
 };
 
-struct HostBatch {
-    DevBuf seqs, offsets, out6, status, best, ws;
-    int64_t n_reads = 0;
-    size_t ws_bytes = 0;
-    int upload(const uint8_t* h_seqs, const int64_t* h_offsets, int64_t n) {
-        n_reads = n;
-        const int64_t total = n > 0 ? h_offsets[n] : 0;
-        if (n > 0 && (h_offsets[0] != 0 && !h_seqs)) return fail(CAH_EINVAL, "seqs is NULL");
-        for (int64_t i = 0; i < n; i++)
-            if (h_offsets[i + 1] < h_offsets[i]) return fail(CAH_EINVAL, "offsets must be non-decreasing");
-        HIP_TRY(seqs.alloc((size_t)total));
-        HIP_TRY(offsets.alloc(sizeof(int64_t) * (size_t)(n + 1)));
-        if (total > 0) HIP_TRY(hipMemcpy(seqs.p, h_seqs, (size_t)total, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(offsets.p, h_offsets, sizeof(int64_t) * (size_t)(n + 1), hipMemcpyHostToDevice));
-        ws_bytes = cah_workspace_bytes(n);
-        HIP_TRY(ws.alloc(ws_bytes));
+// Per-thread persistent staging for the host-pointer conveniences: one grow-only device buffer, one pinned
+// host buffer and a private stream, so that a small batch -- the per-read match_to()/locate() calls of the
+// Python mirror classes send batches of one -- costs one H2D copy, the kernels and one D2H copy: no
+// hipMalloc / hipFree / hipDeviceSynchronize per call.
+struct HostScratch {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    char* dev = nullptr;  size_t dev_cap = 0;
+    char* pin = nullptr;  size_t pin_cap = 0;
+    int ensure(size_t dev_bytes, size_t pin_bytes) {
+        int cur = 0;
+        HIP_TRY(hipGetDevice(&cur));
+        if (cur != device) { release(); device = cur; }
+        if (!stream) HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        if (dev_bytes > dev_cap) {
+            if (dev) (void)hipFree(dev);
+            dev = nullptr; dev_cap = 0;
+            const size_t want = dev_bytes + dev_bytes / 2 + 4096;
+            HIP_TRY(hipMalloc((void**)&dev, want));
+            dev_cap = want;
+        }
+        if (pin_bytes > pin_cap) {
+            if (pin) (void)hipHostFree(pin);
+            pin = nullptr; pin_cap = 0;
+            const size_t want = pin_bytes + pin_bytes / 2 + 4096;
+            HIP_TRY(hipHostMalloc((void**)&pin, want, hipHostMallocDefault));
+            pin_cap = want;
+        }
         return CAH_OK;
     }
+    void release() {
+        if (dev) (void)hipFree(dev);
+        if (pin) (void)hipHostFree(pin);
+        if (stream) (void)hipStreamDestroy(stream);
+        dev = nullptr; pin = nullptr; stream = nullptr; dev_cap = pin_cap = 0;
+    }
+    // no destructor work: at thread / process exit the HIP runtime may already be gone
 };
+thread_local HostScratch g_host_scratch;
+
+static size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+enum { HOST_LOCATE = 0, HOST_PRESENT = 1, HOST_MATCH = 2 };
+
+// seqs/offsets in, (out6, best, status | present) out; everything staged through g_host_scratch
+static int host_call(int mode, const cah_plan* plan, int32_t adapter, const uint8_t* seqs, const int64_t* offsets,
+                     int64_t n, int32_t* out6, int32_t* best_adapter, uint8_t* status) {
+    const int64_t total = offsets[n];
+    if (offsets[0] != 0) return fail(CAH_EINVAL, "offsets[0] must be 0");
+    if (total > 0 && !seqs) return fail(CAH_EINVAL, "seqs is NULL");
+    for (int64_t i = 0; i < n; i++)
+        if (offsets[i + 1] < offsets[i]) return fail(CAH_EINVAL, "offsets must be non-decreasing");
+    const size_t off_bytes = sizeof(int64_t) * (size_t)(n + 1);
+    const size_t in_bytes = align16(off_bytes + (size_t)total);
+    const size_t o6_bytes = sizeof(int32_t) * 6 * (size_t)n, best_bytes = sizeof(int32_t) * (size_t)n;
+    const size_t out_bytes = align16(o6_bytes + best_bytes + (size_t)n);
+    // the host conveniences keep to the base scratch unless the plan cannot do without more (long adapters)
+    const size_t ws_bytes = plan->max_long_m > 0 ? cah_plan_workspace_bytes(plan, n) : cah_workspace_bytes(n);
+    HostScratch& hs = g_host_scratch;
+    int rc = hs.ensure(in_bytes + out_bytes + 256 + ws_bytes, in_bytes + out_bytes);
+    if (rc) return rc;
+    memcpy(hs.pin, offsets, off_bytes);
+    if (total > 0) memcpy(hs.pin + off_bytes, seqs, (size_t)total);
+    char* d_in = hs.dev;
+    char* d_out = hs.dev + in_bytes;
+    char* d_ws = hs.dev + ((in_bytes + out_bytes + 255) & ~(size_t)255);
+    HIP_TRY(hipMemcpyAsync(d_in, hs.pin, off_bytes + (size_t)total, hipMemcpyHostToDevice, hs.stream));
+    const int64_t* d_offsets = (const int64_t*)d_in;
+    const uint8_t* d_seqs = (const uint8_t*)(d_in + off_bytes);
+    int32_t* d_out6 = (int32_t*)d_out;
+    int32_t* d_best = (int32_t*)(d_out + o6_bytes);
+    uint8_t* d_status = (uint8_t*)(d_out + o6_bytes + best_bytes);
+    if (mode == HOST_LOCATE)
+        rc = cah_locate_batch(plan, adapter, d_seqs, d_offsets, nullptr, n, d_out6, d_status, d_ws, ws_bytes, hs.stream);
+    else if (mode == HOST_PRESENT)
+        rc = cah_kmers_present_batch(plan, adapter, d_seqs, d_offsets, nullptr, n, d_status, hs.stream);
+    else
+        rc = cah_match_batch(plan, d_seqs, d_offsets, nullptr, n, d_out6, d_best, d_status, d_ws, ws_bytes, hs.stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(hs.pin + in_bytes, d_out, o6_bytes + best_bytes + (size_t)n, hipMemcpyDeviceToHost, hs.stream));
+    HIP_TRY(hipStreamSynchronize(hs.stream));
+    const char* h_out = hs.pin + in_bytes;
+    if (out6) memcpy(out6, h_out, o6_bytes);
+    if (best_adapter) memcpy(best_adapter, h_out + o6_bytes, best_bytes);
+    if (status) memcpy(status, h_out + o6_bytes + best_bytes, (size_t)n);
+    return CAH_OK;
+}
 }  // namespace
 
 int cah_locate_batch_host(const cah_plan* plan, int32_t adapter, const uint8_t* seqs,
                           const int64_t* offsets, int64_t n_reads, int32_t* out6, uint8_t* status) {
     int rc = check_batch(plan, seqs, offsets, n_reads);
     if (rc) return rc;
+    rc = check_adapter(plan, adapter);
+    if (rc) return rc;
     if (n_reads == 0) return CAH_OK;
-    HostBatch hb;
-    rc = hb.upload(seqs, offsets, n_reads);
-    if (rc) return rc;
-    HIP_TRY(hb.out6.alloc(sizeof(int32_t) * 6 * (size_t)n_reads));
-    HIP_TRY(hb.status.alloc((size_t)n_reads));
-    rc = cah_locate_batch(plan, adapter, (const uint8_t*)hb.seqs.p, (const int64_t*)hb.offsets.p, nullptr,
-                          n_reads, (int32_t*)hb.out6.p, (uint8_t*)hb.status.p, hb.ws.p, hb.ws_bytes, nullptr);
-    if (rc) return rc;
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out6, hb.out6.p, sizeof(int32_t) * 6 * (size_t)n_reads, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(status, hb.status.p, (size_t)n_reads, hipMemcpyDeviceToHost));
-    return CAH_OK;
+    if (!out6 || !status) return fail(CAH_EINVAL, "output pointers are NULL");
+    return host_call(HOST_LOCATE, plan, adapter, seqs, offsets, n_reads, out6, nullptr, status);
 }
 
 int cah_kmers_present_batch_host(const cah_plan* plan, int32_t adapter, const uint8_t* seqs,
                                  const int64_t* offsets, int64_t n_reads, uint8_t* present) {
     int rc = check_batch(plan, seqs, offsets, n_reads);
     if (rc) return rc;
+    rc = check_adapter(plan, adapter);
+    if (rc) return rc;
     if (n_reads == 0) return CAH_OK;
-    HostBatch hb;
-    rc = hb.upload(seqs, offsets, n_reads);
-    if (rc) return rc;
-    HIP_TRY(hb.status.alloc((size_t)n_reads));
-    rc = cah_kmers_present_batch(plan, adapter, (const uint8_t*)hb.seqs.p, (const int64_t*)hb.offsets.p,
-                                 nullptr, n_reads, (uint8_t*)hb.status.p, nullptr);
-    if (rc) return rc;
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(present, hb.status.p, (size_t)n_reads, hipMemcpyDeviceToHost));
-    return CAH_OK;
+    if (!present) return fail(CAH_EINVAL, "present is NULL");
+    return host_call(HOST_PRESENT, plan, adapter, seqs, offsets, n_reads, nullptr, nullptr, present);
 }
 
 int cah_match_batch_host(const cah_plan* plan, const uint8_t* seqs, const int64_t* offsets,
@@ -1192,22 +1376,8 @@ int cah_match_batch_host(const cah_plan* plan, const uint8_t* seqs, const int64_
     int rc = check_batch(plan, seqs, offsets, n_reads);
     if (rc) return rc;
     if (n_reads == 0) return CAH_OK;
-    HostBatch hb;
-    rc = hb.upload(seqs, offsets, n_reads);
-    if (rc) return rc;
-    HIP_TRY(hb.out6.alloc(sizeof(int32_t) * 6 * (size_t)n_reads));
-    HIP_TRY(hb.status.alloc((size_t)n_reads));
-    HIP_TRY(hb.best.alloc(sizeof(int32_t) * (size_t)n_reads));
-    rc = cah_match_batch(plan, (const uint8_t*)hb.seqs.p, (const int64_t*)hb.offsets.p, nullptr, n_reads,
-                         (int32_t*)hb.out6.p, (int32_t*)hb.best.p, (uint8_t*)hb.status.p, hb.ws.p,
-                         hb.ws_bytes, nullptr);
-    if (rc) return rc;
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out6, hb.out6.p, sizeof(int32_t) * 6 * (size_t)n_reads, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(status, hb.status.p, (size_t)n_reads, hipMemcpyDeviceToHost));
-    if (best_adapter)
-        HIP_TRY(hipMemcpy(best_adapter, hb.best.p, sizeof(int32_t) * (size_t)n_reads, hipMemcpyDeviceToHost));
-    return CAH_OK;
+    if (!out6 || !status) return fail(CAH_EINVAL, "output pointers are NULL");
+    return host_call(HOST_MATCH, plan, -1, seqs, offsets, n_reads, out6, best_adapter, status);
 }
 
 // ---------------------------------------------------------------------------------------------

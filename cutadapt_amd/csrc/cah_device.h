@@ -46,6 +46,8 @@ struct CahMatcher {
                                        // (folds translate() + the three compare modes, :322-328, :442-445;
                                        //  for comparers bit i refers to the i-th compared position)
     // ---- bit-parallel cost scan (back_scan.h; 3' adapters with unit costs) ------------------------
+    int32_t long_dp;           // 1: m > CAH_MAX_M -- the aligner / comparer runs in k_dp_long (column in HBM scratch);
+                               // rowmask, n_counts, thr of this struct are unused then
     int32_t scan_ok;           // 1: k_back_scan may classify reads before the cell DP
     int32_t kacc;              // thr[effective_length] (-1 if m < min_overlap): acceptable last-row cost
     int32_t thr_last[CAH_MAX_M + 1];   // thr[effective length of adapter[0:i]]: threshold of row i in the last column
@@ -128,4 +130,15 @@ struct CahMultiHeader {
     uint32_t bm_off[CAH_MULTI_CLASSES];            // first bitmap word of the class
     uint32_t bm_words;                             // bitmap words in total
     uint32_t n_entries;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Adapters longer than CAH_MAX_M characters (long.hip): the scalar constants; the encoded adapter and its
+// n_counts live in separate HBM arrays of the plan.
+// ---------------------------------------------------------------------------------------------
+struct CahLongMatcher {
+    int32_t kind, m, k, flags, indel_cost, min_overlap, wildcard_ref, effective_length, cmp_max_k;
+    int32_t cmp_equal;          // 1: characters are compared for equality, 0: encoded sets are ANDed (:442-445)
+    double rate;                // max_error_rate: `cost <= effective_length * rate` is evaluated in double (:513)
+    uint8_t qtab[CAH_TABLE_CHARS];   // read character -> encoding (IUPAC / ACGT / upper case, :322-328)
 };

@@ -131,6 +131,28 @@ struct MultiFilterArgs {
 hipError_t launch_multi_filter(const MultiFilterArgs& a, const CahMultiHeader& host_hdr, int n_cus, hipStream_t s);
 hipError_t launch_multi_decode(const unsigned long long* best_key, int64_t n_reads, int32_t* out6, uint8_t* status,
                                int32_t* best_adapter, int n_cus, hipStream_t s);
+// long.hip: adapters longer than 64 characters (column in HBM scratch)
+struct LongArgs {
+    const CahLongMatcher* lm;
+    const uint8_t* ref;              // encoded adapter, m bytes
+    const int32_t* ncnt;             // n_counts, m + 1 entries
+    const uint8_t* seqs;
+    const int64_t* offsets;
+    const int32_t* lens;             // may be NULL
+    int64_t n_reads;
+    int64_t max_read_len;
+    const int32_t* queue;            // NULL: reads 0..n_reads-1
+    const unsigned long long* queue_count;
+    unsigned long long* work_counter;        // zeroed before launch
+    int32_t* scratch;                // 3 * (m + 1) * lanes int32
+    int32_t* out6;
+    uint8_t* status;
+    int32_t* best_adapter;
+    int32_t adapter_index;
+    int32_t merge_best;
+};
+int64_t long_scratch_lanes(int64_t max_items, int n_cus);      // threads k_dp_long is launched with (each owns a column)
+hipError_t launch_dp_long(const LongArgs& a, int64_t lanes, hipStream_t s);
 hipError_t launch_comparer(const DpArgs& a, int64_t max_items, int n_cus, hipStream_t s);
 hipError_t launch_validate(const uint8_t* seqs, const int64_t* offsets, const int32_t* lens,
                            int64_t n_reads, int32_t* bad, int n_cus, hipStream_t s);

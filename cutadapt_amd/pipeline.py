@@ -26,7 +26,7 @@ from . import _lib
 from .adapters import (AdapterIndex, BatchMatches, IndexedPrefixAdapters, IndexedSuffixAdapters, LinkedAdapter,
                        LinkedBatchMatches, MultipleAdapters, SingleAdapter, AnywhereAdapter, BackAdapter,
                        FrontAdapter, NonInternalBackAdapter, NonInternalFrontAdapter, PrefixAdapter,
-                       SuffixAdapter)
+                       RightmostBackAdapter, RightmostFrontAdapter, SuffixAdapter)
 from .sharding import MatchHistogram
 
 DEFAULT_CHUNK_BYTES = 4 * 1024 * 1024     # reference runners.py:306 buffer_size
@@ -570,7 +570,7 @@ class BatchTrimmer:
     def __init__(self, adapters=(), times: int = 1, action: Optional[str] = "trim", index: bool = True,
                  nextseq_trim: Optional[int] = None, quality_cutoff: Optional[Tuple[int, int]] = None,
                  quality_base: int = 33, poly_a: bool = False, max_expected_errors: Optional[float] = None,
-                 cut: Sequence[int] = (), length: Optional[int] = None, device=None):
+                 cut: Sequence[int] = (), length: Optional[int] = None, device=None, poly_a_revcomp: bool = False):
         adapters = list(adapters._adapters) if isinstance(adapters, MultipleAdapters) else \
             ([adapters] if isinstance(adapters, (SingleAdapter, LinkedAdapter)) else list(adapters))
         self.cutter = BatchAdapterCutter(adapters, times=times, action=action, index=index, device=device) if adapters else None
@@ -579,6 +579,9 @@ class BatchTrimmer:
         self.quality_cutoff = quality_cutoff
         self.quality_base = quality_base
         self.poly_a = poly_a
+        # the second mate of a pair loses a poly-T HEAD instead of a poly-A tail: the reference builds
+        # (PolyATrimmer(), PolyATrimmer(revcomp=True)) for paired-end data (cli.py, modifiers.py:861-879)
+        self.poly_a_revcomp = poly_a_revcomp
         self.max_expected_errors = max_expected_errors
         self.too_many_expected_errors = 0
         self.device = device
@@ -668,11 +671,15 @@ class BatchTrimmer:
             info.append(chunk.write_info(np.zeros((0, 7), np.int64), []))
         if self.poly_a and n:
             o, l = view_args()
-            idx = qt.poly_a_trim_batch(base.seqs, o, l, n, False).astype(np.int64)
-            removed, counts = np.unique((wend - wbeg) - idx, return_counts=True)
+            idx = qt.poly_a_trim_batch(base.seqs, o, l, n, self.poly_a_revcomp).astype(np.int64)
+            # tail: record[:index], removed length len - index; head (revcomp): record[index:], removed index
+            removed, counts = np.unique(idx if self.poly_a_revcomp else (wend - wbeg) - idx, return_counts=True)
             for k, c in zip(removed.tolist(), counts.tolist()):
                 self.poly_a_trimmed_lengths[k] = self.poly_a_trimmed_lengths.get(k, 0) + c
-            wend = wbeg + idx
+            if self.poly_a_revcomp:
+                wbeg = wbeg + idx
+            else:
+                wend = wbeg + idx
         if self.length is not None:
             cur = wend - wbeg
             if self.length >= 0:
@@ -906,6 +913,8 @@ def trim_fastq_paired(in1, in2, out1, out2, r1: Optional[dict] = None, r2: Optio
     any (default) / both / first; like the reference (cli.py:861-892), --discard-untrimmed uses
     'both' when only one mate has adapters."""
     r1, r2 = dict(r1 or {}), dict(r2 or {})
+    if r2.get("poly_a"):
+        r2.setdefault("poly_a_revcomp", True)      # --poly-a on paired data: poly-T head of R2
     t1, t2 = BatchTrimmer(device=device, **r1), BatchTrimmer(device=device, **r2)
 
     def both(v):
@@ -939,62 +948,180 @@ def trim_fastq_paired(in1, in2, out1, out2, r1: Optional[dict] = None, r2: Optio
 
 
 # -------------------------------------------------------------------------------------------------
-# adapter specifications ("-a ^FRONT...BACK$" etc.), the subset of reference parser.py the
-# golden command lines use (:203-300 restrictions, :472-522 linked adapters)
+# adapter specifications ("-a name=^FRONT...BACK$;e=0.2;o=5" etc.): the grammar of reference parser.py
+# (:28-86 search parameters, :89-126 brace expansion, :203-300 placement restrictions, :322-361 class choice,
+# :472-522 linked adapters, :525-551 single adapters)
 # -------------------------------------------------------------------------------------------------
-def _single_from_spec(spec: str, adapter_type: str, name: Optional[str], params: dict):
-    if "=" in spec.split(";")[0] and name is None:
+_PARAMETER_ALIASES = {"e": "max_errors", "error_rate": "max_errors", "max_error_rate": "max_errors", "o": "min_overlap"}
+_PARAMETER_NAMES = {"max_errors", "min_overlap", "anywhere", "required", "optional", "indels", "noindels", "rightmost"}
+
+
+def parse_search_parameters(text: str) -> dict:
+    """``key=value;key;...`` -> dict (abbreviations resolved, flags True, numbers int or float)"""
+    result = {}
+    for field in text.split(";"):
+        field = field.strip()
+        if not field:
+            continue
+        key, eq, value = field.partition("=")
+        key = _PARAMETER_ALIASES.get(key.strip(), key.strip())
+        if key not in _PARAMETER_NAMES:
+            raise KeyError(f"Unknown parameter '{field.partition('=')[0].strip()}'")
+        if eq and value == "":
+            raise ValueError(f"No value given for key '{key}'")
+        value = value.strip()
+        if value == "":
+            parsed = True
+        else:
+            try:
+                parsed = int(value)
+            except ValueError:
+                parsed = float(value)
+        if key in result:
+            raise KeyError(f"Key '{key}' specified twice")
+        result[key] = parsed
+    if "optional" in result and "required" in result:
+        raise ValueError("'optional' and 'required' cannot be specified at the same time")
+    if "indels" in result and "noindels" in result:
+        raise ValueError("'indels' and 'noindels' cannot be specified at the same time")
+    if result.pop("optional", None) is not None:
+        result["required"] = False
+    if result.pop("noindels", None) is not None:
+        result["indels"] = False
+    return result
+
+
+def expand_braces(sequence: str) -> str:
+    """``TGA{5}CT`` -> ``TGAAAAACT``"""
+    out = []
+    i = 0
+    repeatable = False                      # the previous token is a plain character
+    while i < len(sequence):
+        c = sequence[i]
+        if c == "}":
+            raise ValueError('"}" cannot be used here')
+        if c == "{":
+            if not repeatable:
+                raise ValueError('"{" must be used after a character')
+            close = sequence.find("}", i)
+            if close < 0:
+                raise ValueError("Unterminated expression")
+            count = int(sequence[i + 1:close])
+            if not 0 <= count <= 10000:
+                raise ValueError(f"Value {count} invalid")
+            last = out.pop()
+            out.append(last * count)
+            i = close + 1
+            repeatable = False
+            continue
+        out.append(c)
+        repeatable = True
+        i += 1
+    return "".join(out)
+
+
+def _parse_single_spec(spec: str, adapter_type: str):
+    """-> (name, restriction, sequence, parameters, rightmost) of one adapter (not linked)"""
+    spec, _, parameter_text = spec.partition(";")
+    name = None
+    if "=" in spec:
         name, spec = spec.split("=", 1)
-    spec = spec.split(";")[0]
-    if len(spec.strip("X")) == 0:                  # only X characters: kept as a plain adapter (parser.py:243-246)
-        cls = {"front": FrontAdapter, "back": BackAdapter, "anywhere": AnywhereAdapter}[adapter_type]
-        return cls(spec, name=name, **params), False
-    front_restriction = back_restriction = None
+        name = name.strip()
+    spec = expand_braces(spec.strip())
+    parameters = parse_search_parameters(parameter_text)
+    rightmost = bool(parameters.pop("rightmost", False))
+    if len(spec.strip("X")) == 0:                  # only X characters: a plain adapter (parser.py:243-246)
+        return name, None, spec, {}, False
+    front = back = None
     if spec.startswith("^"):
-        front_restriction, spec = "anchored", spec[1:]
-    elif spec.startswith("X"):
-        front_restriction, spec = "noninternal", spec.lstrip("X")
+        front, spec = "anchored", spec[1:]
+    if spec.upper().startswith("X"):
+        if front is not None:
+            front = "conflict"
+        else:
+            front, spec = "noninternal", spec.lstrip("xX")
     if spec.endswith("$"):
-        back_restriction, spec = "anchored", spec[:-1]
-    elif spec.endswith("X"):
-        back_restriction, spec = "noninternal", spec.rstrip("X")
+        back, spec = "anchored", spec[:-1]
+    if spec.upper().endswith("X"):
+        if back is not None:
+            back = "conflict"
+        else:
+            back, spec = "noninternal", spec.rstrip("xX")
+    if "conflict" in (front, back) or (front and back):
+        raise ValueError("You cannot use multiple placement restrictions for an adapter at the same time. "
+                         "Choose one of ^ADAPTER, ADAPTER$, XADAPTER or ADAPTERX")
+    if adapter_type == "front" and back:
+        raise ValueError("Allowed placement restrictions for a 5' adapter are XADAPTER and ^ADAPTER")
+    if adapter_type == "back" and front:
+        raise ValueError("Allowed placement restrictions for a 3' adapter are ADAPTERX and ADAPTER$")
+    restriction = front if front is not None else back
+    if adapter_type == "anywhere" and restriction is not None:
+        raise ValueError("Placement restrictions (with X, ^, $) not supported for 'anywhere' (-b) adapters")
+    if "min_overlap" in parameters and restriction == "anchored":
+        raise ValueError("Setting 'min_overlap=' (or 'o=') for anchored adapters is not possible because "
+                         "anchored adapters always need to match in full.")
+    if parameters.get("min_overlap", 0) > len(spec):
+        parameters["min_overlap"] = len(spec)
+    if rightmost and (adapter_type not in ("front", "back") or restriction is not None):
+        raise ValueError("'rightmost' only allowed with regular 5' and 3' adapters")
+    return name, restriction, spec, parameters, rightmost
+
+
+def _adapter_class(adapter_type: str, restriction, rightmost: bool):
     if adapter_type == "front":
-        if back_restriction:
-            raise ValueError("a 5' adapter cannot be restricted at its 3' end")
-        cls = {None: FrontAdapter, "anchored": PrefixAdapter, "noninternal": NonInternalFrontAdapter}[front_restriction]
-    elif adapter_type == "back":
-        if front_restriction:
-            raise ValueError("a 3' adapter cannot be restricted at its 5' end")
-        cls = {None: BackAdapter, "anchored": SuffixAdapter, "noninternal": NonInternalBackAdapter}[back_restriction]
-    else:
-        if front_restriction or back_restriction:
-            raise ValueError("'anywhere' (-b) adapters may not be anchored")
-        cls = AnywhereAdapter
-    return cls(spec, name=name, **params), (front_restriction or back_restriction) is not None
+        if rightmost:
+            return RightmostFrontAdapter
+        return {None: FrontAdapter, "anchored": PrefixAdapter, "noninternal": NonInternalFrontAdapter}[restriction]
+    if adapter_type == "back":
+        if rightmost:
+            return RightmostBackAdapter
+        return {None: BackAdapter, "anchored": SuffixAdapter, "noninternal": NonInternalBackAdapter}[restriction]
+    return AnywhereAdapter
 
 
 def adapter_from_spec(spec: str, adapter_type: str = "back", **params):
-    """``-a SPEC`` (adapter_type 'back'), ``-g SPEC`` ('front') or ``-b SPEC`` ('anywhere') ->
-    adapter object; understands ``name=``, ``^``/``$`` anchoring, ``X`` non-internal markers and
-    ``FRONT...BACK`` linked adapters (required/optional rules of reference parser.py:496-503)."""
-    name = None
-    if "=" in spec.split("...")[0].split(";")[0]:
-        name, spec = spec.split("=", 1)
-    if "..." in spec:
-        front_spec, back_spec = spec.split("...", 1)
-        if front_spec and back_spec:
-            if adapter_type == "anywhere":
-                raise ValueError("'anywhere' (-b) adapters may not be linked")
-            front, front_anchored = _single_from_spec(front_spec, "front", "linked_front", dict(params))
-            back, back_anchored = _single_from_spec(back_spec, "back", "linked_back", dict(params))
-            if adapter_type == "front":
-                front_required = back_required = True
-            else:
-                front_required, back_required = front_anchored, back_anchored
-            return LinkedAdapter(front, back, front_required, back_required, name)
-        # "ADAPTER..." / "...ADAPTER": plain 5' / 3' adapter (parser.py _normalize_ellipsis)
-        if front_spec:
-            adapter_type, spec = "front", front_spec
+    """``-a SPEC`` (adapter_type 'back'), ``-g SPEC`` ('front') or ``-b SPEC`` ('anywhere') -> adapter object.
+    Understands ``name=``, ``^``/``$`` anchoring, ``X`` non-internal markers, ``{n}`` repeats, ``FRONT...BACK``
+    linked adapters and the per-adapter search parameters ``;e=`` / ``;max_error_rate=``, ``;o=`` /
+    ``;min_overlap=``, ``;noindels``, ``;anywhere``, ``;rightmost`` and, inside linked adapters, ``;required`` /
+    ``;optional``; ``params`` are the command line's defaults, which the spec's own parameters override."""
+    if adapter_type not in ("front", "back", "anywhere"):
+        raise ValueError("adapter_type must be front, back or anywhere")
+    spec1, middle, spec2 = spec.partition("...")
+    if middle and spec1 and spec2:
+        if adapter_type == "anywhere":
+            raise ValueError("'anywhere' (-b) adapters may not be linked")
+        fname, frestr, fseq, fparams, fright = _parse_single_spec(spec1, "front")
+        _bname, brestr, bseq, bparams, bright = _parse_single_spec(spec2, "back")
+        front_parameters = dict(params, **fparams)
+        back_parameters = dict(params, **bparams)
+        if adapter_type == "front":            # -g requires both parts
+            front_required = back_required = True
+        else:                                  # -a requires only the anchored parts
+            front_required, back_required = frestr is not None, brestr is not None
+        front_required = front_parameters.pop("required", front_required)
+        back_required = back_parameters.pop("required", back_required)
+        front_parameters.pop("anywhere", None)
+        back_parameters.pop("anywhere", None)
+        front = _adapter_class("front", frestr, fright)(fseq, name="linked_front", **front_parameters)
+        back = _adapter_class("back", brestr, bright)(bseq, name="linked_back", **back_parameters)
+        return LinkedAdapter(front, back, front_required, back_required, fname)
+    if middle:
+        # "ADAPTER..." is a 5' adapter, "...ADAPTER" a 3' adapter (parser.py:129-152)
+        if adapter_type == "anywhere":
+            raise ValueError('No ellipsis ("...") allowed in "anywhere" adapters')
+        if spec1:
+            if adapter_type == "back":
+                adapter_type = "front"         # -a ADAPTER...  ->  -g ADAPTER
+            spec = spec1
         else:
-            adapter_type, spec = "back", back_spec
-    return _single_from_spec(spec, adapter_type, name, dict(params))[0]
+            if adapter_type == "front":
+                raise ValueError("Invalid adapter specification")
+            spec = spec2
+    name, restriction, seq, parameters, rightmost = _parse_single_spec(spec, adapter_type)
+    cls = _adapter_class(adapter_type, restriction, rightmost)
+    if parameters.pop("anywhere", False) and cls in (FrontAdapter, BackAdapter, RightmostFrontAdapter, RightmostBackAdapter):
+        parameters["force_anywhere"] = True
+    if "required" in parameters:
+        raise ValueError("'required' and 'optional' can only be used within linked adapters")
+    return cls(seq, name=name, **dict(params, **parameters))

@@ -101,8 +101,22 @@ class MatchHistogram:
         """Sum over all ranks (control plane; no read data is exchanged)."""
         import torch
         import torch.distributed as dist
-        t = torch.from_numpy(self.counts)
-        if dist.get_backend(group) == "nccl":
+        on_gpu = dist.get_backend(group) == "nccl"
+        # add_rows grows the length / error axes with the data, so ranks may hold different shapes: agree on
+        # the largest one first (a sum over unequal tensors would hang or corrupt the result)
+        shape = torch.tensor(self.counts.shape, dtype=torch.int64)
+        if on_gpu:
+            shape = shape.cuda()
+        dist.all_reduce(shape, op=dist.ReduceOp.MAX, group=group)
+        shape = tuple(int(v) for v in shape.cpu().tolist())
+        if shape[0] != self.counts.shape[0]:
+            raise ValueError("incompatible histograms: ranks disagree on the number of adapter slots")
+        if shape != self.counts.shape:
+            grown = np.zeros(shape, dtype=np.int64)
+            grown[:, :self.counts.shape[1], :self.counts.shape[2]] = self.counts
+            self.counts = grown
+        t = torch.from_numpy(np.ascontiguousarray(self.counts))
+        if on_gpu:
             t = t.cuda()
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
         self.counts = t.cpu().numpy()

@@ -50,7 +50,7 @@ extern "C" {
 #define CAH_ETYPE 2         /* wrong type (TypeError in the reference) */
 #define CAH_EHIP 3          /* HIP runtime failure, message has the hipError string */
 #define CAH_ENOMEM 4
-#define CAH_EUNSUPPORTED 5  /* outside this build's limits (adapter > 64 chars, ...) */
+#define CAH_EUNSUPPORTED 5  /* outside this build's limits (read > 1e6 characters, device is not gfx950, ...) */
 
 /* per-read result status */
 #define CAH_NONE 0
@@ -64,7 +64,9 @@ extern "C" {
 #define CAH_KIND_KMER_ONLY 3 /* a bare KmerFinder, no aligner                          */
 
 /* limits of this build */
-#define CAH_MAX_ADAPTER_LEN 64   /* DP column lives in VGPRs; match masks are 64-bit */
+/* adapters of any length are accepted, as in the reference (_align.pyx:250-257): up to 64 characters the DP
+ * column lives in VGPRs and the match relation in 64-bit bitsets, longer ones run with the column in HBM
+ * scratch (size it with cah_plan_workspace_bytes) */
 #define CAH_MAX_READ_LEN 1000000 /* origin is carried in 20 bits of the packed DP cell */
 #define CAH_MAX_INDEL_COST 10000000
 

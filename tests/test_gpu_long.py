@@ -1,0 +1,143 @@
+"""Adapters longer than 64 characters (k_dp_long, column in HBM scratch): bit-identical to the oracle for
+aligners of every flag combination and for both comparers; the reference's own long-adapter case
+(reference tests/test_adapters.py:697-705, issue 749).  GPU only."""
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def rs(rng, n, al="ACGT"):
+    return "".join(rng.choice(al) for _ in range(n))
+
+
+def mutate(rng, s, n_edits):
+    s = list(s)
+    for _ in range(n_edits):
+        if not s:
+            break
+        x = rng.randrange(len(s))
+        op = rng.randint(0, 2)
+        if op == 0:
+            s[x] = rng.choice("ACGT")
+        elif op == 1:
+            s.insert(x, rng.choice("ACGT"))
+        else:
+            del s[x]
+    return "".join(s)
+
+
+def test_very_long_adapter_issue_749(hip):
+    from cutadapt_amd.adapters import BackAdapter
+    adapter = BackAdapter("A" * 70, max_errors=0)
+    match = adapter.match_to("GATTAC" + 20 * "A")
+    assert match is not None
+    assert (match.rstart, match.rstop, match.astart, match.astop, match.errors) == (6, 26, 0, 20, 0)
+    # the k-mer finder gives up on k-mers > 64 like the reference (MockKmerFinder), the aligner does not
+    assert type(adapter.kmer_finder).__name__ == "MockKmerFinder"
+
+
+def test_long_aligner_fuzz_vs_oracle(hip, orc):
+    from cutadapt_amd import _lib
+    from cutadapt_amd.batch import ReadBatch, locate_batch
+    rng = random.Random(6500)
+    total = 0
+    for it in range(48):
+        m = rng.choice([65, 66, 100, 127, 200, 301])
+        flags = it % 16
+        wr, wq = rng.random() < 0.3, rng.random() < 0.3
+        al = "ACGT" * 5 + ("NRYKM" if wr else "")
+        adapter = rs(rng, m, al)
+        rate = rng.choice([0.0, 0.05, 0.1, 0.2])
+        indel_cost = rng.choice([1, 1, 2, 100000])
+        min_overlap = rng.choice([1, 3, 20])
+        reads = []
+        for _ in range(300):
+            n = rng.randint(0, 400)
+            r = rs(rng, n, "ACGTN" if wq else "ACGT")
+            if rng.random() < 0.7:
+                piece = mutate(rng, "".join(c if c in "ACGT" else rng.choice("ACGT") for c in adapter), rng.randint(0, int(m * rate) + 2))
+                cut = rng.random()
+                if cut < 0.3:
+                    piece = piece[:rng.randint(1, len(piece))]
+                elif cut < 0.6:
+                    piece = piece[rng.randint(0, len(piece) - 1):]
+                pos = rng.choice([0, rng.randint(0, n), max(0, n - len(piece))])
+                r = (r[:pos] + piece + r[pos:])[:max(n, rng.randint(0, 500))]
+            reads.append(r)
+        seqs, offsets = orc.pack_reads(reads)
+        oa = orc.Aligner(adapter, rate, flags, wr, wq, indel_cost, min_overlap)
+        want6, want_st = oa.locate_batch(seqs, offsets)
+        plan = _lib.Plan([_lib.MatcherSpec(adapter, rate, flags, wr, wq, indel_cost, min_overlap)])
+        res = locate_batch(plan, 0, ReadBatch.from_host(seqs, offsets))
+        got6, got_st, _ = res.cpu()
+        what = f"it {it} m {m} flags {flags} wr {wr} wq {wq} D {indel_cost} rate {rate}"
+        assert np.array_equal(got_st, want_st), (what, np.nonzero(got_st != want_st)[0][:5])
+        bad = np.nonzero((got6 != want6).any(axis=1))[0]
+        assert len(bad) == 0, (what, bad[:5], got6[bad[:2]], want6[bad[:2]])
+        total += int((want_st == 1).sum())
+    assert total > 2000
+
+
+def test_long_comparers_and_adapters_vs_oracle(hip, orc):
+    from cutadapt_amd import _lib
+    from cutadapt_amd.batch import ReadBatch, locate_batch
+    rng = random.Random(6501)
+    for it in range(20):
+        m = rng.choice([65, 90, 150])
+        wr, wq = rng.random() < 0.3, rng.random() < 0.3
+        adapter = rs(rng, m, "ACGT" * 4 + ("N" if wr else ""))
+        rate = rng.choice([0.0, 0.1, 0.2])
+        reads = [mutate(rng, "".join(c if c != "N" else "A" for c in adapter), rng.randint(0, 12))[:rng.randint(0, m + 20)] if rng.random() < 0.6
+                 else rs(rng, rng.randint(0, 200)) for _ in range(300)]
+        reads = [r if rng.random() < 0.5 else rs(rng, rng.randint(0, 30)) + r for r in reads]
+        seqs, offsets = orc.pack_reads(reads)
+        for kind, cls in ((_lib.KIND_PREFIX, orc.PrefixComparer), (_lib.KIND_SUFFIX, orc.SuffixComparer)):
+            oc = cls(adapter, rate, wr, wq, 3)
+            want6, want_st = oc.locate_batch(seqs, offsets)
+            plan = _lib.Plan([_lib.MatcherSpec(adapter, rate, 0, wr, wq, 1, 3, kind=kind)])
+            got6, got_st, _ = locate_batch(plan, 0, ReadBatch.from_host(seqs, offsets)).cpu()
+            assert np.array_equal(got_st, want_st), (it, kind)
+            assert np.array_equal(got6, want6), (it, kind)
+
+
+def test_long_adapter_through_the_adapter_classes(hip, orc):
+    """a 100-character 3' adapter whose k-mers still fit the prefilter (rate 0.1 -> 11 chunks of 9-10
+    characters): prefilter + long aligner, batch API and MultipleAdapters merge with a short adapter"""
+    from cutadapt_amd import adapters as A
+    from cutadapt_amd.batch import ReadBatch
+    rng = random.Random(6502)
+    long_seq, short_seq = rs(rng, 100), rs(rng, 30)
+    long_ad = A.BackAdapter(long_seq, max_errors=0.1, min_overlap=3)
+    short_ad = A.BackAdapter(short_seq, max_errors=0.1, min_overlap=3)
+    assert type(long_ad.kmer_finder).__name__ == "KmerFinder"
+    reads = []
+    for _ in range(3000):
+        r = rs(rng, rng.randint(20, 150))
+        u = rng.random()
+        if u < 0.4:
+            r += mutate(rng, long_seq, rng.randint(0, 8))[:rng.randint(3, 110)]
+        elif u < 0.7:
+            r += mutate(rng, short_seq, rng.randint(0, 3))[:rng.randint(3, 35)]
+        reads.append(r)
+    batch = ReadBatch.from_strings(reads)
+    multi = A.MultipleAdapters([long_ad, short_ad])
+    bm = multi.match_to_batch(batch)
+    seqs, offsets = orc.pack_reads(reads)
+    n = len(reads)
+    want6 = np.zeros((n, 6), dtype=np.int64); found = np.zeros(n, dtype=bool); best = np.zeros(n, dtype=np.int64)
+    for idx, ad in enumerate((long_ad, short_ad)):
+        oa = orc.Aligner(ad.sequence, ad.max_error_rate, 14, False, False, 1, ad.min_overlap)
+        of = orc.KmerFinder(ad.kmer_finder.positions_and_kmers)
+        c6, st = orc.match_batch(oa, of, seqs, offsets)
+        f = st == 1
+        better = f & (~found | (c6[:, 4] > want6[:, 4]) | ((c6[:, 4] == want6[:, 4]) & (c6[:, 5] < want6[:, 5])))
+        want6[better] = c6[better]; best[better] = idx; found |= better
+    assert np.array_equal(bm.found, found)
+    assert np.array_equal(bm.coords[found], want6[found])
+    assert np.array_equal(bm.adapter_index[found], best[found])
+    assert found.sum() > 1500
+    m = long_ad.match_to(reads[int(np.nonzero(found & (best == 0))[0][0])])
+    assert m is not None

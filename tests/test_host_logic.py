@@ -88,8 +88,13 @@ def test_plan_validation_matches_reference_errors():
         _lib.Plan([S(kind=_lib.KIND_KMER_ONLY, kmer_sets=[(0, None, [b"ACGT"])])])
     with pytest.raises(ValueError, match="ASCII"):
         _lib.Plan([S("ACGÜ", 0.1)])
+    # adapters longer than 64 characters are accepted (reference _align.pyx:250-257: any length) and ask
+    # for column scratch in the plan's workspace
+    long_plan = _lib.Plan([S("ACGT" * 40, 0.1)])
+    L = _lib.lib()
+    assert L.cah_plan_workspace_bytes(long_plan.handle, 1000) > L.cah_workspace_bytes(1000)
     with pytest.raises(_lib.UnsupportedByHipPath):
-        _lib.Plan([S("A" * 65, 0.1)])
+        _lib.Plan([S("A" * 100001, 0.1)])
     # valid plans are built on the host without a GPU; tables are uploaded lazily per device
     plan = _lib.Plan([S("AGGNNNNNNNNNNNNNNTTC", 0.1, 14, wildcard_ref=True, min_overlap=3),
                       S("CNNNNNNNNGTT", 0.25, wildcard_ref=True, kind=_lib.KIND_PREFIX),
@@ -163,3 +168,59 @@ def test_prefilter_kernel_selection():
     assert KmerFinder([(0, -3, ["ACGTACG"])])._plan.prefilter_kind() == "general"                       # negative stop
     assert KmerFinder([(0, None, ["A" * 40])])._plan.prefilter_kind() == "general"                      # k-mer longer than 32
     assert KmerFinder([(-80, None, ["ACGT"])])._plan.prefilter_kind() == "general"                      # tail window beyond the span
+
+
+def test_adapter_specifications_follow_the_reference_grammar():
+    """per-adapter search parameters, placement restrictions, brace repeats and linked adapters
+    (reference parser.py:28-86, :203-300, :472-551; known answers of reference tests/test_parser.py)"""
+    from cutadapt_amd import adapters as A
+    from cutadapt_amd.pipeline import adapter_from_spec, expand_braces, parse_search_parameters
+    assert parse_search_parameters("e=0.1") == {"max_errors": 0.1}
+    assert parse_search_parameters("error_rate=0.1") == {"max_errors": 0.1}
+    assert parse_search_parameters("max_errors=2") == {"max_errors": 2}
+    assert parse_search_parameters("o=5") == {"min_overlap": 5}
+    assert parse_search_parameters("o=7; e=0.4") == {"min_overlap": 7, "max_errors": 0.4}
+    assert parse_search_parameters("anywhere") == {"anywhere": True}
+    assert parse_search_parameters("required") == {"required": True}
+    assert parse_search_parameters("optional") == {"required": False}
+    assert parse_search_parameters("noindels") == {"indels": False}
+    assert parse_search_parameters("indels") == {"indels": True}
+    assert parse_search_parameters("rightmost") == {"rightmost": True}
+    for bad, exc in (("e=hallo", ValueError), ("bla=0.1", KeyError), ("e=", ValueError), ("e=0.1;e=0.1", KeyError),
+                     ("e=0.1;max_errors=0.1", KeyError), ("optional; required", ValueError), ("indels; noindels", ValueError)):
+        with pytest.raises(exc):
+            parse_search_parameters(bad)
+    assert expand_braces("TGA{5}CT") == "TGAAAAACT" and expand_braces("GG{2}TGA{5}CT") == "GGGTGAAAAACT"
+    assert expand_braces("A{0}") == "" and expand_braces("TGA{0}CT") == "TGCT"
+    for bad in ("{", "}", "{}", "{5", "{1}", "A{-7}", "A{", "A{1", "N{7", "AN{7", "A{4{}", "A{4}{3}", "A{b}", "A{6X}", "A{X6}", "A}A"):
+        with pytest.raises(ValueError):
+            expand_braces(bad)
+    d = dict(max_errors=0.1, min_overlap=3)
+    a = adapter_from_spec("a_name=ADAPTER;e=0.2;o=5".replace("ADAPTER", "ACGTACGTAC"), "back", **d)
+    assert type(a) is A.BackAdapter and a.name == "a_name" and a.max_error_rate == 0.2 and a.min_overlap == 5
+    assert type(adapter_from_spec("ACGT;noindels", "back", **d)) is A.BackAdapter and not adapter_from_spec("ACGT;noindels", "back", **d).indels
+    assert adapter_from_spec("ACGTACGT;anywhere", "back", **d)._force_anywhere
+    assert type(adapter_from_spec("ACGTACGT;rightmost", "front", **d)) is A.RightmostFrontAdapter
+    assert type(adapter_from_spec("ACGTACGT;rightmost", "back", **d)) is A.RightmostBackAdapter
+    assert type(adapter_from_spec("^ACGT", "front", **d)) is A.PrefixAdapter
+    assert type(adapter_from_spec("ACGT$", "back", **d)) is A.SuffixAdapter
+    assert type(adapter_from_spec("XACGT", "front", **d)) is A.NonInternalFrontAdapter
+    assert type(adapter_from_spec("ACGTX", "back", **d)) is A.NonInternalBackAdapter
+    assert type(adapter_from_spec("ACGT...", "back", **d)) is A.FrontAdapter
+    assert type(adapter_from_spec("...ACGT", "back", **d)) is A.BackAdapter
+    assert adapter_from_spec("A{10}C", "back", **d).sequence == "AAAAAAAAAAC"
+    assert adapter_from_spec("ACGT;o=15", "back", **d).min_overlap == 4            # clamped to the adapter length
+    for bad, t in (("^ACGT;o=3", "front"), ("^ACGT$", "front"), ("^XACGT", "front"), ("ACGT$", "front"), ("^ACGT", "back"),
+                   ("^ACGT", "anywhere"), ("ACGT;rightmost", "anywhere"), ("^ACGT;rightmost", "front"),
+                   ("ACGT;required", "back"), ("ACGT...TGCA", "anywhere"), ("...ACGT", "front")):
+        with pytest.raises(ValueError):
+            adapter_from_spec(bad, t, **d)
+    linked = adapter_from_spec("ACGT;o=2...TTTTAAAA;e=0.3", "back", **d)
+    assert type(linked) is A.LinkedAdapter and not linked.front_required and not linked.back_required
+    assert linked.front_adapter.min_overlap == 2 and linked.back_adapter.max_error_rate == 0.3
+    linked = adapter_from_spec("^ACGT...TTTTAAAA;required", "back", **d)
+    assert linked.front_required and linked.back_required and type(linked.front_adapter) is A.PrefixAdapter
+    linked = adapter_from_spec("ACGT;optional...TTTTAAAA", "front", **d)
+    assert not linked.front_required and linked.back_required
+    linked = adapter_from_spec("name=ACGT...TTTTAAAA$", "back", **d)
+    assert linked.name == "name" and not linked.front_required and linked.back_required

@@ -189,7 +189,7 @@ def test_differential_vs_reference(orc, ref):
     n = 0
     for _ in range(6000):
         al = rng.choice(alphabets)
-        m = rng.randint(1, 45)
+        m = rng.randint(1, 64) if rng.random() < 0.85 else rng.choice([65, 80, 130])   # the whole range the kernels serve
         adapter = "".join(rng.choice(al) for _ in range(m))
         args = (adapter, rng.choice([0, 0.1, 0.2, 0.35, 1.0, rng.random()]), rng.randint(0, 15),
                 rng.random() < 0.3, rng.random() < 0.3, rng.choice([1, 1, 3, 100000]), rng.randint(1, min(m, 5)))
@@ -201,13 +201,93 @@ def test_differential_vs_reference(orc, ref):
             continue
         oa = orc.Aligner(*args)
         for _ in range(3):
-            q = "".join(rng.choice(al) for _ in range(rng.randint(0, 90)))
+            q = "".join(rng.choice(al) for _ in range(rng.randint(0, 170)))
             if rng.random() < 0.6 and q:
                 p = rng.randint(0, len(q))
                 q = q[:p] + adapter[rng.randint(0, m - 1):] + q[p:]
             assert ra.locate(q) == oa.locate(q), (args, q)
             n += 1
     assert n > 10000
+
+
+def test_differential_kmer_finder_and_comparers_vs_reference(orc, ref):
+    """KmerFinder.kmers_present and both comparers of the oracle against the compiled reference"""
+    if ref is None:
+        pytest.skip("oracle/_ref not built here (the reference only exists in the build container)")
+    rng = random.Random(199)
+    alphabets = ["ACGT", "ACGTN", "ACGTNRYacgtn", "ACGTXNSWKMBDHVU"]
+    n = 0
+    for _ in range(1500):
+        al = rng.choice(alphabets)
+        rw, qw = rng.random() < 0.3, rng.random() < 0.3
+        sets = []
+        for _s in range(rng.randint(1, 5)):
+            kind = rng.random()
+            kmers = ["".join(rng.choice(al) for _ in range(rng.randint(1, 64 if rng.random() < 0.1 else 12)))
+                     for _k in range(rng.randint(1, 9))]
+            if kind < 0.4:
+                sets.append((0, None, kmers))
+            elif kind < 0.7:
+                sets.append((-rng.randint(1, 70), None, kmers))
+            else:
+                start = rng.randint(0, 20)
+                sets.append((start, start + rng.randint(1, 60), kmers))
+        rf, of = ref.KmerFinder(sets, rw, qw), orc.KmerFinder(sets, rw, qw)
+        for _q in range(6):
+            # windows are kept inside the read: beyond it the reference reads out of bounds (SURVEY.md section 7)
+            q = "".join(rng.choice(al) for _ in range(rng.randint(80, 200)))
+            if rng.random() < 0.5:
+                kmer = rng.choice(rng.choice(sets)[2])
+                pos = rng.randint(0, len(q))
+                q = q[:pos] + kmer + q[pos:]
+            assert rf.kmers_present(q) == of.kmers_present(q), (sets, rw, qw, q)
+            n += 1
+    for _ in range(3000):
+        al = rng.choice(alphabets)
+        m = rng.randint(1, 80)
+        adapter = "".join(rng.choice(al) for _ in range(m))
+        args = (adapter, rng.choice([0, 0.1, 0.2, 0.5, 1.0]), rng.random() < 0.3, rng.random() < 0.3, rng.randint(1, 6))
+        for rcls, ocls in ((ref.PrefixComparer, orc.PrefixComparer), (ref.SuffixComparer, orc.SuffixComparer)):
+            try:
+                rc = rcls(*args)
+            except ValueError:
+                with pytest.raises(ValueError):
+                    ocls(*args)
+                continue
+            oc = ocls(*args)
+            assert rc.effective_length == oc.effective_length
+            for _q in range(3):
+                q = "".join(rng.choice(al) for _ in range(rng.randint(0, 100)))
+                if rng.random() < 0.6:
+                    q = (adapter[:rng.randint(1, m)] + q) if rcls is ref.PrefixComparer else (q + adapter[rng.randint(0, m - 1):])
+                assert rc.locate(q) == oc.locate(q), (args, q)
+                n += 1
+    assert n > 20000
+
+
+def test_reference_own_tests_pass_on_the_compiled_reference(ref):
+    """DESIGN.md section 6 as a committed fact: the reference's OWN tests of this path
+    (/root/reference/tests/test_align.py, test_kmer_finder.py, test_kmer_heuristic.py) pass against
+    oracle/_ref, the build the oracle and the goldens are pinned to.  Build container only."""
+    import os
+    import subprocess
+    import sys
+    tests_dir = "/root/reference/tests"
+    if ref is None or not os.path.isdir(tests_dir):
+        pytest.skip("needs /root/reference and oracle/_ref (build container only)")
+    ref_root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref")
+    env = dict(os.environ, PYTHONPATH=ref_root + os.pathsep + tests_dir)
+    # --noconftest: the reference conftest imports cutadapt.cli (needs dnaio, not installed); these three test
+    # modules use none of its fixtures
+    cmd = [sys.executable, "-m", "pytest", "-q", "-p", "no:cacheprovider", "--noconftest", "--rootdir", "/tmp", "-c", "/dev/null",
+           os.path.join(tests_dir, "test_align.py"), os.path.join(tests_dir, "test_kmer_finder.py"),
+           os.path.join(tests_dir, "test_kmer_heuristic.py")]
+    out = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    tail = out.stdout.decode(errors="replace")[-1500:]
+    assert out.returncode == 0, tail
+    import re
+    m = re.search(r"(\d+) passed", tail)
+    assert m and int(m.group(1)) >= 85, tail
 
 
 def test_synth_reads_are_deterministic_and_shardable(orc):

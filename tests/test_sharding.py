@@ -65,6 +65,12 @@ def _worker(rank, world, port, n_total, out_dir):
     hist = S.MatchHistogram(1)
     hist.add_batch(out6.astype(np.int64), status == 1, np.zeros(count, dtype=np.int32))
     hist.all_reduce_()
+    # add_rows histograms grow with the data: the ranks hold DIFFERENT shapes before the sum
+    rows = S.MatchHistogram(2)
+    rows.add_rows(np.array([0, 1]), np.array([5 + 100 * rank, 3]), np.array([rank, 0]))
+    rows.all_reduce_()
+    if rank == 0:
+        np.save(os.path.join(out_dir, "rows.npy"), rows.counts)
     full = S.gather_ordered(np.concatenate([out6, status[:, None].astype(np.int32)], axis=1), first)
     if rank == 0:
         np.save(os.path.join(out_dir, "full.npy"), full)
@@ -91,3 +97,6 @@ def test_two_rank_gloo_matches_single_process(tmp_path, orc):
     ref_hist = S.MatchHistogram(1)
     ref_hist.add_batch(out6.astype(np.int64), status == 1, np.zeros(n_total, dtype=np.int32))
     assert np.array_equal(hist, ref_hist.counts) and ref_hist.total() == int((status == 1).sum()) > 4000
+    rows = np.load(tmp_path / "rows.npy")
+    assert rows.shape[1] == 106 and rows.sum() == 4          # rank 1 grew its length axis, rank 0 did not
+    assert rows[0, 5, 0] == 1 and rows[0, 105, 1] == 1 and rows[1, 3, 0] == 2
