@@ -161,3 +161,30 @@ def test_scan_ragged_and_views(hip, orc):
     of = orc.KmerFinder(create_positions_and_kmers(TRUSEQ, 3, 0.1, back_adapter=True, front_adapter=False))
     w6, wst = orc.match_batch(oa, of, vs, vo)
     _same(got6, got_st, w6, wst, "views")
+
+
+def test_one_plan_on_every_visible_device(hip, orc):
+    """plans replicate their tables per device on first use (api.cpp plan_on_device): the same plan object
+    serves every GPU of the node from one process -- each device matches its own shard of the reads"""
+    import torch
+    from cutadapt_amd import _lib
+    from cutadapt_amd.batch import ReadBatch, match_batch
+    from cutadapt_amd.kmer_heuristic import create_positions_and_kmers
+    n_dev = _lib.device_count()
+    assert n_dev >= 1
+    plan = _plan(TRUSEQ, 0.1, 3)
+    oa = orc.Aligner(TRUSEQ, 0.1, 14, False, False, 1, 3)
+    of = orc.KmerFinder(create_positions_and_kmers(TRUSEQ, 3, 0.1, back_adapter=True, front_adapter=False))
+    per = 30_000
+    results = []
+    for d in range(n_dev):
+        with torch.cuda.device(d):
+            batch = ReadBatch.synthetic(per, 150, [TRUSEQ], seed=9, first_index=d * per, device=torch.device("cuda", d))
+            results.append((d, match_batch(plan, batch)))
+    for d, res in results:
+        with torch.cuda.device(d):
+            torch.cuda.synchronize()
+            got6, got_st, _ = res.cpu()
+        seqs, offsets = orc.synth_reads(9, d * per, per, 150, [TRUSEQ])
+        w6, wst = orc.match_batch(oa, of, seqs, offsets)
+        _same(got6, got_st, w6, wst, f"device {d}")
