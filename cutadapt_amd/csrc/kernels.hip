@@ -1284,32 +1284,29 @@ __global__ __launch_bounds__(256) void k_back_scan(ScanArgs a) {
             bs_init(st, p);
             int j = j0;
             bool done = !valid, exact = false;
+            // one 16-character chunk per iteration (per lane: its own window start), the next chunk requested
+            // before this one is consumed, the LDS lookup of the next column's match word issued one column
+            // ahead; bytes are taken with constant shifts (v_bfe), the "any lane left?" test costs one scalar
+            // branch per chunk
             int pos = j0;
             Chunk cur = load_chunk(q, pos, n, valid ? n : 0);
-            Chunk nxt = load_chunk(q, pos + 16, n, valid ? n : 0);
-            int left = 16;
-            unsigned bad_chars = cur.w[0] | cur.w[1] | cur.w[2] | cur.w[3];
-            uint64_t eq_next = s_scanmask[table_index(cur.w[0])];
+            unsigned bad_chars = 0;
             for (;;) {
-                const bool act = !done && j < n;
-                if (!__any(act)) break;
-                const uint64_t eq = eq_next;
-                cur.w[0] = (cur.w[0] >> 8) | (cur.w[1] << 24);
-                cur.w[1] = (cur.w[1] >> 8) | (cur.w[2] << 24);
-                cur.w[2] = (cur.w[2] >> 8) | (cur.w[3] << 24);
-                cur.w[3] >>= 8;
-                if (--left == 0) {
-                    cur = nxt;
-                    bad_chars |= cur.w[0] | cur.w[1] | cur.w[2] | cur.w[3];
-                    pos += 16;
-                    nxt = load_chunk(q, pos + 16, n, (!done) ? n : 0);
-                    left = 16;
+                if (!__any(!done && j < n)) break;
+                const Chunk nxt = load_chunk(q, pos + 16, n, (!done) ? n : 0);
+                bad_chars |= cur.w[0] | cur.w[1] | cur.w[2] | cur.w[3];
+                uint64_t eq_next = s_scanmask[table_index(chunk_byte(cur, 0))];
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const uint64_t eq = eq_next;
+                    if (t < 15) eq_next = s_scanmask[table_index(chunk_byte(cur, t + 1))];
+                    if (!done && j < n) {
+                        ++j;
+                        if (bs_step(st, eq, j, p)) { exact = true; done = true; }
+                    }
                 }
-                eq_next = s_scanmask[table_index(cur.w[0])];
-                if (act) {
-                    ++j;
-                    if (bs_step(st, eq, j, p)) { exact = true; done = true; }
-                }
+                pos += 16;
+                cur = nxt;
             }
             if (bad_chars & 0x80808080u) invalid = true;
 

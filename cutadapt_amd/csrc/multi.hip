@@ -10,8 +10,13 @@
 #include "kernels.h"
 #include "dev_common.h"
 
-#define MF_TILE 512                // reads per workgroup tile
-#define MF_STAGE 4096              // pairs staged in LDS per tile (more go straight to HBM, unsorted)
+#ifndef MF_TILE
+#define MF_TILE 256                // reads per workgroup tile (one 64-read block per wave)
+#endif
+#ifndef MF_STAGE
+#define MF_STAGE 2048              // pairs staged in LDS per tile, 4 bytes each: tile-relative read | adapter | key
+                                   // (more go straight to HBM, unsorted)
+#endif
 
 // One read per lane, one pass, 16 characters per global load.  Per character: 2-bit base code (LDS byte
 // table; anything but ACGT/acgt is invalid and breaks every k-mer, as in KmerFinder without wildcards:
@@ -27,8 +32,8 @@ __global__ __launch_bounds__(256) void k_multi_filter(MultiFilterArgs a) {
     const CahMultiHeader* hd = a.hdr;
     const uint32_t bm_words = hd->bm_words;
     uint32_t* s_bm = smem;                                   // [bm_words]
-    uint32_t* s_stage = s_bm + ((bm_words + 3) & ~3u);       // [2 * MF_STAGE] pairs as (lo, hi)
-    uint32_t* s_seen = s_stage + 2 * MF_STAGE;               // [256 * 4] per-lane "adapter already emitted"
+    uint32_t* s_stage = s_bm + ((bm_words + 3) & ~3u);       // [MF_STAGE] pairs: read - tile_base << 16 | adapter << 8 | key
+    uint32_t* s_seen = s_stage + MF_STAGE;                   // [256 * 4] per-lane "adapter already emitted"
     uint32_t* s_hist = s_seen + 256 * 4;                     // [256]
     uint32_t* s_cursor = s_hist + 256;                       // [256]
     uint32_t* s_b2 = s_cursor + 256;                         // [32] = 128 bytes: base code of every ASCII character
@@ -48,6 +53,12 @@ __global__ __launch_bounds__(256) void k_multi_filter(MultiFilterArgs a) {
 #pragma unroll
     for (int q = 1; q <= 7; ++q) { present[q] = hd->class_present[q]; everywhere[q] = hd->class_everywhere[q]; lmax[q] = hd->class_lmax[q]; }
     const int present8 = hd->class_present[8];
+    int lmax_all = 0;
+    bool short_everywhere = false;
+#pragma unroll
+    for (int q = 1; q <= 7; ++q) {
+        if (present[q]) { lmax_all = max(lmax_all, lmax[q]); short_everywhere = short_everywhere || everywhere[q]; }
+    }
     const int lane = wave_lane();
     const int wave = threadIdx.x >> 6;
     const uint8_t* b2 = reinterpret_cast<const uint8_t*>(s_b2);
@@ -76,10 +87,16 @@ __global__ __launch_bounds__(256) void k_multi_filter(MultiFilterArgs a) {
             if (n64 > a.max_read_len) { too_long = true; n64 = 0; }
             const int n = (int)n64;
             const uint8_t* q = a.seqs + off;
-            int n_max = n;
+            int n_max = n, n_min = valid ? n : 0x7fffffff;
 #pragma unroll
-            for (int d = 1; d < WAVE; d <<= 1) n_max = max(n_max, __shfl_xor(n_max, d, WAVE));
+            for (int d = 1; d < WAVE; d <<= 1) {
+                n_max = max(n_max, __shfl_xor(n_max, d, WAVE));
+                n_min = min(n_min, __shfl_xor(n_min, d, WAVE));
+            }
             n_max = __builtin_amdgcn_readfirstlane(n_max);
+            n_min = __builtin_amdgcn_readfirstlane(n_min);
+            // first position at which a tail k-mer of any short class can end in some lane of the wave
+            const int tail_from = n_min - lmax_all;
             uint32_t* seen_bits = s_seen + threadIdx.x * 4;
             seen_bits[0] = seen_bits[1] = seen_bits[2] = seen_bits[3] = 0;
 
@@ -105,6 +122,7 @@ __global__ __launch_bounds__(256) void k_multi_filter(MultiFilterArgs a) {
                         const unsigned w = s_bm[bm_off[8] + (k8 >> 5)];
                         hits |= (run >= 8 && ((w >> (k8 & 31)) & 1u)) ? (1u << 8) : 0u;
                     }
+                    if (short_everywhere || p >= tail_from)                 // wave-uniform: most positions skip all short classes
 #pragma unroll
                     for (int cq = 1; cq <= 7; ++cq) {
                         if (!present[cq]) continue;                          // wave-uniform
@@ -136,14 +154,13 @@ __global__ __launch_bounds__(256) void k_multi_filter(MultiFilterArgs a) {
                                 if (word & wbit) continue;
                                 seen_bits[ad >> 5] = word | wbit;
                                 const unsigned key = min(p >> CAH_KEY_SHIFT, CAH_QUEUE_BINS - 1);
-                                const unsigned p_lo = (ad << 8) | key, p_hi = (unsigned)r;
                                 const unsigned slot = atomicAdd(&s_misc[0], 1u);
                                 if (slot < MF_STAGE) {
-                                    s_stage[2 * slot] = p_lo; s_stage[2 * slot + 1] = p_hi;
+                                    s_stage[slot] = ((unsigned)(r - tile_base) << 16) | (ad << 8) | key;
                                     atomicAdd(&s_hist[key], 1u);
                                 } else {
                                     const unsigned long long g = atomicAdd(a.pair_count, 1ull);
-                                    if ((int64_t)g < a.pair_cap) a.pairs[g] = ((uint64_t)p_hi << 32) | p_lo;
+                                    if ((int64_t)g < a.pair_cap) a.pairs[g] = ((uint64_t)(unsigned)r << 32) | (ad << 8) | key;
                                 }
                             }
                         }
@@ -166,10 +183,11 @@ __global__ __launch_bounds__(256) void k_multi_filter(MultiFilterArgs a) {
         __syncthreads();
         const unsigned long long qbase = ((unsigned long long)s_misc[4] << 32) | s_misc[3];
         for (unsigned e = threadIdx.x; e < count; e += blockDim.x) {
-            const unsigned p_lo = s_stage[2 * e], p_hi = s_stage[2 * e + 1];
-            const unsigned key = p_lo & 0xFFu;
+            const unsigned st = s_stage[e];
+            const unsigned key = st & 0xFFu;
             const unsigned dst = s_hist[key] + atomicAdd(&s_cursor[key], 1u);
-            if ((int64_t)(qbase + dst) < a.pair_cap) a.pairs[qbase + dst] = ((uint64_t)p_hi << 32) | p_lo;
+            const uint64_t read = (uint64_t)(tile_base + (int64_t)(st >> 16));
+            if ((int64_t)(qbase + dst) < a.pair_cap) a.pairs[qbase + dst] = (read << 32) | (st & 0xFFFFu);
         }
     }
 }
@@ -192,10 +210,10 @@ __global__ __launch_bounds__(256) void k_multi_decode(const unsigned long long* 
 }
 
 hipError_t launch_multi_filter(const MultiFilterArgs& a, const CahMultiHeader& host_hdr, int n_cus, hipStream_t s) {
-    const size_t lds = sizeof(uint32_t) * ((size_t)((host_hdr.bm_words + 3) & ~3u) + 2 * MF_STAGE + 256 * 4 + 256 + 256 + 32 + 8);
+    const size_t lds = sizeof(uint32_t) * ((size_t)((host_hdr.bm_words + 3) & ~3u) + MF_STAGE + 256 * 4 + 256 + 256 + 32 + 8);
     int64_t need = (a.n_reads + MF_TILE - 1) / MF_TILE;
     if (need < 1) need = 1;
-    const int64_t cap = (int64_t)3 * n_cus;
+    const int64_t cap = (int64_t)8 * n_cus;
     hipLaunchKernelGGL(k_multi_filter, dim3((unsigned)(need < cap ? need : cap)), dim3(256), lds, s, a);
     return hipGetLastError();
 }

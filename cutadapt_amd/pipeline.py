@@ -619,6 +619,23 @@ class BatchTrimmer:
         """All read-modifying steps for one chunk -> per-read arrays: the window (beg, end) of the
         original read that is left, whether an adapter was found, the output mode and (with
         --max-ee) the expected errors of what is left."""
+        gen = self._modify_steps(chunk, info)
+        request = next(gen)                                 # everything in front of the adapter step is done
+        res = None
+        if request is not None and self.cutter is not None:
+            res = self.cutter.process_arrays(request["seqs"], request["offsets"], base=request["base"],
+                                             window=request["window"])
+        try:
+            gen.send(res)
+        except StopIteration as stop:
+            return stop.value
+        raise RuntimeError("modify: the step generator did not finish")
+
+    def _modify_steps(self, chunk: FastqChunk, info: Optional[list] = None):
+        """modify() as a two-phase generator: runs the modifiers in front of the adapter step, yields what the
+        adapter step needs (packed reads, the chunk in HBM, the window left so far), receives the adapter step's
+        result (BatchAdapterCutter.process_arrays, or the paired cutter's for --pair-adapters, where both
+        mates must reach this point before either is matched) and finishes with the remaining modifiers."""
         import torch
         from . import qualtrim as qt
         from .batch import ReadBatch
@@ -661,8 +678,9 @@ class BatchTrimmer:
             wbeg, wend = wbeg + ss[:, 0], wbeg + ss[:, 1]
         matched = np.zeros(n, dtype=bool)
         mode = 0
-        if self.cutter is not None:
-            res = self.cutter.process_arrays(seqs, offsets, base=base, window=(wbeg, wend) if pre else None)
+        res = yield {"seqs": seqs, "offsets": offsets, "base": base, "window": (wbeg, wend) if pre else None,
+                     "lens": lens, "n": n}
+        if res is not None:
             wbeg, wend, matched = res["beg"].astype(np.int64), res["end"].astype(np.int64), res["matched"]
             mode = {"mask": 1, "lowercase": 2}.get(self.action, 0)
             if info is not None:
@@ -766,15 +784,20 @@ def trim_fastq(inpath: Union[str, BinaryIO], outpath: Union[str, BinaryIO], adap
                quality_cutoff: Optional[Tuple[int, int]] = None, quality_base: int = 33, poly_a: bool = False,
                max_expected_errors: Optional[float] = None, threads: int = 1, cut: Sequence[int] = (),
                length: Optional[int] = None, minimum_length: Optional[int] = None,
-               maximum_length: Optional[int] = None, device=None) -> Dict[str, object]:
-    """``cutadapt [--nextseq-trim N] [-q [FRONT,]BACK] [--quality-base B] <adapter options> [--times N]
+               maximum_length: Optional[int] = None, device=None, devices=None) -> Dict[str, object]:
+    """``devices``: with ``threads`` > 1 the GPUs the worker threads are dealt to, round-robin -- a list of device
+    indices or "all" for every visible GPU (the reference's reader -> workers -> ordered writer layout,
+    runners.py:116-134, :224-245, with one HIP stream per worker and the workers spread over the node's GPUs;
+    plans replicate their tables on each device on first use).  Default: the one ``device``.
+
+    ``cutadapt [--nextseq-trim N] [-q [FRONT,]BACK] [--quality-base B] <adapter options> [--times N]
     [--action A] [--poly-a] [--max-ee E] [--discard-(un)trimmed] [--info-file F] -o outpath inpath`` for the
     supported slice; returns the read/basepair counters the reference reports (reference
     report.py:62-80), the adapter cutter (statistics) and the trimmer."""
-    def make_trimmer():
+    def make_trimmer(dev=device):
         return BatchTrimmer(adapters, times=times, action=action, index=index, nextseq_trim=nextseq_trim,
                             quality_cutoff=quality_cutoff, quality_base=quality_base, poly_a=poly_a,
-                            max_expected_errors=max_expected_errors, cut=cut, length=length, device=device)
+                            max_expected_errors=max_expected_errors, cut=cut, length=length, device=dev)
 
     trimmer = make_trimmer()
     out = outpath if hasattr(outpath, "write") else open(outpath, "wb")
@@ -789,7 +812,7 @@ def trim_fastq(inpath: Union[str, BinaryIO], outpath: Union[str, BinaryIO], adap
                     inf.write(b"".join(info))
         else:
             _trim_threaded(inpath, out, inf, trimmer, make_trimmer, threads, chunk_bytes, discard_untrimmed,
-                           discard_trimmed, minimum_length, maximum_length)
+                           discard_trimmed, minimum_length, maximum_length, devices)
     finally:
         if out is not outpath:
             out.close()
@@ -802,11 +825,13 @@ def trim_fastq(inpath: Union[str, BinaryIO], outpath: Union[str, BinaryIO], adap
 
 def _trim_threaded(inpath, out, inf, trimmer: "BatchTrimmer", make_trimmer, threads: int, chunk_bytes: int,
                    discard_untrimmed: bool, discard_trimmed: bool, minimum_length: Optional[int] = None,
-                   maximum_length: Optional[int] = None) -> None:
+                   maximum_length: Optional[int] = None, devices=None) -> None:
     """The reference's reader -> workers -> ordered writer layout (runners.py:96-245) with threads
     instead of processes: the calling thread cuts the input into record-aligned raw chunks and
     writes results in chunk order, ``threads`` workers parse, pack, match (each on its own HIP
-    stream) and format.  Parsing, packing and formatting are C calls that release the GIL."""
+    stream) and format.  Parsing, packing and formatting are C calls that release the GIL.
+    Workers are dealt round-robin to ``devices`` (chunks therefore go round-robin to the GPUs, like the
+    reference deals chunks to its worker processes, runners.py:116-134); results come back in chunk order."""
     import threading
     from collections import deque
     from concurrent.futures import ThreadPoolExecutor
@@ -814,13 +839,27 @@ def _trim_threaded(inpath, out, inf, trimmer: "BatchTrimmer", make_trimmer, thre
     local = threading.local()
     workers: List["BatchTrimmer"] = []
     lock = threading.Lock()
+    if devices == "all":
+        devices = list(range(torch.cuda.device_count()))
+    elif devices is None:
+        devices = [trimmer.device]
+    devices = list(devices)
+    if not devices:
+        raise ValueError("devices must name at least one GPU")
 
     def work(data: np.ndarray, fasta: bool):
         if not hasattr(local, "trimmer"):
-            local.trimmer = make_trimmer()
-            local.stream = torch.cuda.Stream(device=trimmer.device)
             with lock:
-                workers.append(local.trimmer)
+                dev = devices[len(workers) % len(devices)]
+                workers.append(None)                        # reserve the slot: the next worker gets the next device
+                slot = len(workers) - 1
+            if dev is not None:
+                dev = torch.device("cuda", dev) if isinstance(dev, int) else torch.device(dev)
+                torch.cuda.set_device(dev)                  # per thread: the C ABI works on the current device
+            local.trimmer = make_trimmer(dev)
+            local.stream = torch.cuda.Stream(device=dev)
+            with lock:
+                workers[slot] = local.trimmer
         chunk = scan_chunk(data, fasta)
         chunk.pooled = True
         info: Optional[list] = [] if inf is not None else None
@@ -846,7 +885,130 @@ def _trim_threaded(inpath, out, inf, trimmer: "BatchTrimmer", make_trimmer, thre
             drain(2 * threads)
         drain(0)
     for w in workers:                                       # merge the workers' statistics
-        trimmer.merge(w)
+        if w is not None:
+            trimmer.merge(w)
+    trimmer.devices_used = sorted({str(w.device) for w in workers if w is not None})
+
+
+# -------------------------------------------------------------------------------------------------
+# --pair-adapters (reference PairedAdapterCutter, modifiers.py:412-503)
+# -------------------------------------------------------------------------------------------------
+class BatchPairedAdapterCutter:
+    """Trim adapters in pairs: adapters1[i] must be found in R1 AND adapters2[i] in R2; of all pairs that are,
+    the one with the highest total score wins, then the fewest total errors, then the first
+    (reference ``_find_best_match_pair``, modifiers.py:480-503).  One fused library call per adapter and mate;
+    the best pair is kept per read pair ON THE DEVICE (score / error sums, strict improvement so that the
+    first pair wins ties), and only the winning tuples come back."""
+
+    def __init__(self, adapters1, adapters2, action: Optional[str] = "trim"):
+        adapters1, adapters2 = list(adapters1), list(adapters2)
+        if len(adapters1) != len(adapters2):
+            raise ValueError("The number of adapters to trim from R1 and R2 must be the same. "
+                             "Given: {} for R1, {} for R2".format(len(adapters1), len(adapters2)))
+        if not adapters1:
+            raise ValueError("No adapters given")
+        for a in adapters1 + adapters2:
+            if not isinstance(a, SingleAdapter):
+                raise ValueError("--pair-adapters works with single (not linked) adapters")
+        if action not in ("trim", "mask", "lowercase", "retain", None):
+            raise ValueError(f"action {action!r} is not available with paired adapters")
+        self.pairs = list(zip(adapters1, adapters2))
+        self.action = action
+        self.with_adapters = 0
+        self.histograms = (MatchHistogram(len(adapters1)), MatchHistogram(len(adapters2)))
+        self.names = ([a.name for a in adapters1], [a.name for a in adapters2])
+
+    def _views(self, request):
+        """the ReadBatch an adapter step searches: the chunk, or the windows earlier modifiers left"""
+        import torch
+        from .batch import ReadBatch
+        base, n = request["base"], request["n"]
+        if request["window"] is None:
+            return base, np.zeros(n, dtype=np.int64), request["lens"]
+        wbeg, wend = request["window"]
+        starts = base.offsets[:n] + torch.from_numpy(wbeg).to(base.device)
+        cur = (wend - wbeg).astype(np.int64)
+        return (ReadBatch(base.seqs, starts, torch.from_numpy(cur.astype(np.int32)).to(base.device), n_reads=n,
+                          validated=True), wbeg.astype(np.int64), cur)
+
+    def best_pairs(self, batch1, batch2):
+        """-> (found[n], pair index[n], coords1[n,6], coords2[n,6]) as numpy; the merge runs on the device"""
+        import torch
+        from . import batch as _b
+        n = batch1.n_reads
+        dev = batch1.device
+        have = torch.zeros(n, dtype=torch.bool, device=dev)
+        best_score = torch.zeros(n, dtype=torch.int32, device=dev)
+        best_err = torch.zeros(n, dtype=torch.int32, device=dev)
+        best_idx = torch.zeros(n, dtype=torch.int32, device=dev)
+        c1 = torch.zeros((n, 6), dtype=torch.int32, device=dev)
+        c2 = torch.zeros((n, 6), dtype=torch.int32, device=dev)
+        for i, (a1, a2) in enumerate(self.pairs):
+            r1 = self._match(a1, batch1)
+            r2 = self._match(a2, batch2)
+            if (r1.status == _lib.INVALID).any() or (r2.status == _lib.INVALID).any():
+                raise ValueError("String must contain only ASCII characters")
+            both = (r1.status == _lib.MATCH) & (r2.status == _lib.MATCH)
+            score = r1.out6[:, 4] + r2.out6[:, 4]
+            err = r1.out6[:, 5] + r2.out6[:, 5]
+            better = both & (~have | (score > best_score) | ((score == best_score) & (err < best_err)))
+            have |= better
+            best_score = torch.where(better, score, best_score)
+            best_err = torch.where(better, err, best_err)
+            best_idx = torch.where(better, torch.full_like(best_idx, i), best_idx)
+            c1 = torch.where(better[:, None], r1.out6, c1)
+            c2 = torch.where(better[:, None], r2.out6, c2)
+        return (have.cpu().numpy(), best_idx.cpu().numpy().astype(np.int64), c1.cpu().numpy().astype(np.int64),
+                c2.cpu().numpy().astype(np.int64))
+
+    @staticmethod
+    def _match(adapter, batch):
+        """device-resident (out6, status) of one adapter in match coordinates"""
+        import torch
+        from . import batch as _b
+        if not adapter._reverse_reads:
+            return _b.match_batch(adapter._fused_plan, batch)
+        bm = adapter.match_to_batch(batch)                   # Rightmost*: mirrored on the host
+        out6 = torch.from_numpy(bm.coords.astype(np.int32)).to(batch.device)
+        status = torch.from_numpy(bm.found.astype(np.uint8)).to(batch.device)
+        return _b.BatchResult(out6, status)
+
+    def process(self, request1, request2):
+        """the adapter step of both mates: -> (res1, res2) like BatchAdapterCutter.process_arrays"""
+        n = request1["n"]
+        if n != request2["n"]:
+            raise ValueError("Reads are improperly paired")
+        if n == 0:
+            empty = {"beg": np.zeros(0, np.int32), "end": np.zeros(0, np.int32), "matched": np.zeros(0, bool),
+                     "rows": np.zeros((0, 7), np.int64)}
+            return empty, dict(empty)
+        v1, w1, l1 = self._views(request1)
+        v2, w2, l2 = self._views(request2)
+        found, idx, c1, c2 = self.best_pairs(v1, v2)
+        self.with_adapters += int(found.sum())
+        out = []
+        for k, (c, wbeg, cur) in enumerate(((c1, w1, l1), (c2, w2, l2))):
+            ads = [p[k] for p in self.pairs]
+            before = np.array([a._remove_before for a in ads], dtype=bool)[idx]
+            anywhere = np.array([isinstance(a, AnywhereAdapter) for a in ads], dtype=bool)[idx]
+            before = np.where(anywhere, c[:, 2] == 0, before)
+            rstart, rstop = c[:, 2], c[:, 3]
+            if self.action == "retain":                      # trim_but_retain_adapter (modifiers.py:184-198)
+                beg = np.where(before, rstart, 0)
+                end = np.where(before, cur, rstop)
+            elif self.action is None:
+                beg, end = np.zeros(n, np.int64), cur.copy()
+            else:                                            # trim / mask / lowercase: what Match.trimmed() leaves
+                beg = np.where(before, rstop, 0)
+                end = np.where(before, cur, rstart)
+            beg = np.where(found, beg, 0)
+            end = np.where(found, end, cur)
+            f = np.flatnonzero(found)
+            removed = np.where(before[f], rstop[f], cur[f] - rstart[f])
+            self.histograms[k].add_rows(idx[f], removed, c[f, 5])
+            out.append({"beg": (wbeg + beg).astype(np.int32), "end": (wbeg + end).astype(np.int32),
+                        "matched": found.copy(), "rows": np.zeros((0, 7), np.int64)})
+        return out[0], out[1]
 
 
 # -------------------------------------------------------------------------------------------------
@@ -904,7 +1066,7 @@ def read_paired_chunks(path1, path2, chunk_bytes: int = DEFAULT_CHUNK_BYTES) -> 
 def trim_fastq_paired(in1, in2, out1, out2, r1: Optional[dict] = None, r2: Optional[dict] = None,
                       pair_filter: Optional[str] = None, minimum_length=None, maximum_length=None,
                       discard_untrimmed: bool = False, discard_trimmed: bool = False,
-                      chunk_bytes: int = DEFAULT_CHUNK_BYTES, device=None) -> Dict[str, object]:
+                      chunk_bytes: int = DEFAULT_CHUNK_BYTES, device=None, pair_adapters: bool = False) -> Dict[str, object]:
     """``cutadapt <R1 options> <R2 options: -A/-G/-B, -U, -Q, -L ...> -o out1 -p out2 in1 in2``:
     ``r1`` / ``r2`` are BatchTrimmer keyword arguments for the two mates (adapters, times, action,
     cut, nextseq_trim, quality_cutoff, quality_base, poly_a, length, max_expected_errors).
@@ -915,6 +1077,14 @@ def trim_fastq_paired(in1, in2, out1, out2, r1: Optional[dict] = None, r2: Optio
     r1, r2 = dict(r1 or {}), dict(r2 or {})
     if r2.get("poly_a"):
         r2.setdefault("poly_a_revcomp", True)      # --poly-a on paired data: poly-T head of R2
+    paired_cutter = None
+    if pair_adapters:
+        # --pair-adapters (cli.py:594-632): adapter i of R1 is only removed together with adapter i of R2
+        if r1.get("times", 1) != 1 or r2.get("times", 1) != 1:
+            raise ValueError("--pair-adapters cannot be used with --times")
+        action = r1.get("action", "trim")
+        paired_cutter = BatchPairedAdapterCutter(r1.pop("adapters", ()), r2.pop("adapters", ()), action)
+        r1["action"] = r2["action"] = action
     t1, t2 = BatchTrimmer(device=device, **r1), BatchTrimmer(device=device, **r2)
 
     def both(v):
@@ -924,14 +1094,28 @@ def trim_fastq_paired(in1, in2, out1, out2, r1: Optional[dict] = None, r2: Optio
     mode = "any" if pair_filter is None else pair_filter
     if mode not in ("any", "both", "first"):
         raise ValueError("pair_filter must be any, both or first")
-    one_sided = t1.cutter is None or t2.cutter is None
+    one_sided = (t1.cutter is None or t2.cutter is None) and paired_cutter is None
     untrimmed_mode = "both" if (one_sided and discard_untrimmed) else mode
     o1 = out1 if hasattr(out1, "write") else open(out1, "wb")
     o2 = out2 if hasattr(out2, "write") else open(out2, "wb")
     pairs = kept = 0
     try:
         for c1, c2 in read_paired_chunks(in1, in2, chunk_bytes):
-            res1, res2 = t1.modify(c1), t2.modify(c2)
+            if paired_cutter is None:
+                res1, res2 = t1.modify(c1), t2.modify(c2)
+            else:
+                g1, g2 = t1._modify_steps(c1), t2._modify_steps(c2)
+                a1, a2 = paired_cutter.process(next(g1), next(g2))
+                res = []
+                for g, a in ((g1, a1), (g2, a2)):
+                    try:
+                        g.send(a)
+                        raise RuntimeError("modify: the step generator did not finish")
+                    except StopIteration as stop:
+                        res.append(stop.value)
+                res1, res2 = res
+                mode_code = {"mask": 1, "lowercase": 2}.get(paired_cutter.action, 0)
+                res1["mode"] = res2["mode"] = mode_code
             keep = filter_reads([res1, res2], [t1, t2], discard_untrimmed, discard_trimmed, min_len, max_len, mode,
                                 untrimmed_mode)
             o1.write(t1.write(c1, res1, keep))
@@ -943,8 +1127,12 @@ def trim_fastq_paired(in1, in2, out1, out2, r1: Optional[dict] = None, r2: Optio
             o1.close()
         if o2 is not out2:
             o2.close()
+    if paired_cutter is not None:
+        with_adapters = (paired_cutter.with_adapters, paired_cutter.with_adapters)
+    else:
+        with_adapters = (t1.cutter.with_adapters if t1.cutter else 0, t2.cutter.with_adapters if t2.cutter else 0)
     return {"pairs": pairs, "pairs_written": kept, "trimmers": (t1, t2), "filtered": dict(t1.filtered),
-            "with_adapters": (t1.cutter.with_adapters if t1.cutter else 0, t2.cutter.with_adapters if t2.cutter else 0)}
+            "with_adapters": with_adapters, "paired_cutter": paired_cutter}
 
 
 # -------------------------------------------------------------------------------------------------

@@ -189,8 +189,10 @@ def test_reference_commandline_goldens(hip):
                 assert _strip_trailing_space(info.getvalue()) == _strip_trailing_space(expected), (case["name"], chunk_bytes)
             if chunk_bytes == 512:                      # reader + 3 worker threads + ordered writer
                 out3, info3 = io.BytesIO(), io.BytesIO()
+                # ... with the workers dealt round-robin over every visible GPU
                 stats3 = trim_fastq(os.path.join(FQ, case["input"]), out3, ads, chunk_bytes=chunk_bytes,
-                                    info_file=info3 if case["info"] else None, threads=3, **opts)
+                                    info_file=info3 if case["info"] else None, threads=3, devices="all", **opts)
+                assert len(stats3["trimmer"].devices_used) >= 1 or stats3["reads"] == 0
                 assert out3.getvalue() == out.getvalue() and info3.getvalue() == info.getvalue(), case["name"]
                 assert (stats3["reads"], stats3["with_adapters"], stats3["bp_out"]) == \
                        (stats["reads"], stats["with_adapters"], stats["bp_out"]), case["name"]

@@ -150,3 +150,54 @@ def test_c5_paired_end(hip, orc):
         assert np.array_equal(bm.coords[found], coords[found])
         assert np.array_equal(bm.adapter_index[found], best[found])
         assert 0.2 * n < found.sum() < 0.4 * n
+
+
+def test_paired_adapter_cutter_best_pair(hip, orc):
+    """--pair-adapters as a batch op (reference PairedAdapterCutter._find_best_match_pair,
+    modifiers.py:480-503): adapter i must be in R1 AND adapter i in R2; highest total score, then fewest total
+    errors, then the first pair.  Oracle: the rule restated over per-adapter oracle results."""
+    from cutadapt_amd import adapters as A
+    from cutadapt_amd.batch import ReadBatch
+    from cutadapt_amd.pipeline import BatchPairedAdapterCutter
+    rng = random.Random(909)
+    n_pairs = 5
+    s1 = [rs(rng, 20) for _ in range(n_pairs)]
+    s2 = [rs(rng, 20) for _ in range(n_pairs)]
+    s1[3] = s1[1]                      # equal adapters: ties between pairs -> the first pair wins
+    s2[3] = s2[1]
+    ads1 = [A.BackAdapter(s, max_errors=0.1, min_overlap=3) for s in s1]
+    ads2 = [A.FrontAdapter(s, max_errors=0.1, min_overlap=3) if i == 2 else A.BackAdapter(s, max_errors=0.1, min_overlap=3)
+            for i, s in enumerate(s2)]
+    reads1, reads2 = [], []
+    for _ in range(6000):
+        i, j = rng.randrange(n_pairs), rng.randrange(n_pairs)
+        if rng.random() < 0.6:
+            j = i
+        r1 = rs(rng, rng.randint(20, 100)) + (mutate(rng, s1[i], rng.choice([0, 0, 1, 2]))[:rng.randint(3, 20)] if rng.random() < 0.8 else "")
+        if isinstance(ads2[j], A.FrontAdapter):
+            r2 = (mutate(rng, s2[j], rng.choice([0, 1]))[-rng.randint(3, 20):] if rng.random() < 0.8 else "") + rs(rng, rng.randint(20, 100))
+        else:
+            r2 = rs(rng, rng.randint(20, 100)) + (mutate(rng, s2[j], rng.choice([0, 0, 1, 2]))[:rng.randint(3, 20)] if rng.random() < 0.8 else "")
+        reads1.append(r1 + rs(rng, rng.randint(0, 5)))
+        reads2.append(r2)
+    pc = BatchPairedAdapterCutter(ads1, ads2)
+    found, idx, c1, c2 = pc.best_pairs(ReadBatch.from_strings(reads1), ReadBatch.from_strings(reads2))
+    n = len(reads1)
+    want_found = np.zeros(n, dtype=bool)
+    want_idx = np.zeros(n, dtype=np.int64)
+    w1, w2 = np.zeros((n, 6), dtype=np.int64), np.zeros((n, 6), dtype=np.int64)
+    best_score = np.zeros(n, dtype=np.int64)
+    best_err = np.zeros(n, dtype=np.int64)
+    for i in range(n_pairs):
+        a6, af = oracle_single(orc, ads1[i], reads1)
+        b6, bf = oracle_single(orc, ads2[i], reads2)
+        both = af & bf
+        score, err = a6[:, 4] + b6[:, 4], a6[:, 5] + b6[:, 5]
+        better = both & (~want_found | (score > best_score) | ((score == best_score) & (err < best_err)))
+        want_found |= better
+        best_score[better], best_err[better], want_idx[better] = score[better], err[better], i
+        w1[better], w2[better] = a6[better], b6[better]
+    assert np.array_equal(found, want_found)
+    assert np.array_equal(idx[found], want_idx[found])
+    assert np.array_equal(c1[found], w1[found]) and np.array_equal(c2[found], w2[found])
+    assert found.sum() > 800 and len(set(want_idx[found].tolist())) >= 4 and 3 not in set(want_idx[found].tolist())
