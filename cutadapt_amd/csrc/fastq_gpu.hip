@@ -1,0 +1,433 @@
+// fastq_gpu.hip -- FASTQ record indexing and trimmed-record formatting ON THE GPU (SURVEY.md section 8(f)
+// rows 1-2: the data formats either side of the matching path).
+//
+// The host-side twins (fastq.cpp: cah_fastq_scan, cah_pack_sequences, cah_records_write) parse and format
+// at a few hundred MB/s per core; with the matcher at several Greads/s they bound the end-to-end rate
+// (round 1: 21 Mreads/s with 16 threads, GPU idle > 95 %).  Here the raw chunk goes to HBM as it is:
+//   1. k_nl_count / k_tile_scan / k_nl_write   positions of all line feeds (16-byte loads, exact
+//                                              zero-byte mask, tile counts + one-block scan)
+//   2. k_records                               four lines = one record: offsets of name, sequence and
+//                                              qualities ("\r\n" accepted), format checks of
+//                                              dnaio / fastq.cpp (leading '@' and '+', equal lengths)
+//   3. (matching works directly on the raw chunk: read r = buf[seq_off[r] : +seq_len[r]], the `lens` view
+//      of the C ABI -- nothing is packed or copied)
+//   4. k_out_len / scan / k_format             "@name\nSEQ[beg:end]\n+\nQUAL[beg:end]\n" of every kept
+//                                              record, written at its exclusive-scan offset
+// so that only raw FASTQ bytes go in over PCIe and only trimmed FASTQ bytes come out; the host cuts chunks
+// at record starts (cah_record_boundary) and does nothing per read.
+// Reference: dnaio.read_chunks + SequenceRecord parsing (reference src/cutadapt/files.py:108-114,
+// runners.py:116-126), Match.trimmed() slicing (adapters.py:453-454, :486-487), dnaio's FASTQ writer.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cstdio>
+
+#include "../../include/cutadapt_hip.h"
+
+extern int cah_set_error_(int code, const char* msg);   // api.cpp
+
+namespace {
+
+#define NL_TILE_BYTES 16384          // one 256-thread block: 64 bytes per thread
+#define SCAN_ELEMS 2048              // elements per block of the generic int64 scan (8 per thread)
+
+// exact mask (bit 7 of each byte) of the bytes of v that equal c
+__device__ __forceinline__ unsigned eq_mask(unsigned v, unsigned c4) {
+    const unsigned x = v ^ c4;
+    const unsigned t = (x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+    return ~(t | x | 0x7F7F7F7Fu);
+}
+
+// the 64 bytes of thread t of tile `tile`, zero beyond len; w[16]
+__device__ __forceinline__ void load64(const uint8_t* buf, int64_t len, int64_t base, unsigned (&w)[16]) {
+    if (base + 64 <= len && ((uintptr_t)(buf + base) & 15) == 0) {
+        const uint4* p = reinterpret_cast<const uint4*>(buf + base);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const uint4 v = p[i]; w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            unsigned v = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int64_t q = base + 4 * i + b;
+                if (q < len) v |= (unsigned)buf[q] << (8 * b);
+            }
+            w[i] = v;
+        }
+    }
+}
+
+__device__ __forceinline__ int block_reduce_sum(int v, int* s_red) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const int total = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    __syncthreads();
+    return total;
+}
+
+__global__ __launch_bounds__(256) void k_nl_count(const uint8_t* buf, int64_t len, int64_t n_tiles, int64_t* tile_counts) {
+    __shared__ int s_red[4];
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        unsigned w[16];
+        load64(buf, len, tile * NL_TILE_BYTES + (int64_t)threadIdx.x * 64, w);
+        int c = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) c += __popc(eq_mask(w[i], 0x0A0A0A0Au));
+        const int total = block_reduce_sum(c, s_red);
+        if (threadIdx.x == 0) tile_counts[tile] = total;
+    }
+}
+
+// exclusive scan of counts[0..n) in place, total to *total (one block; n is a few thousand)
+__global__ __launch_bounds__(1024) void k_tile_scan(int64_t* counts, int64_t n, int64_t* total) {
+    __shared__ int64_t s_part[1024];
+    __shared__ int64_t s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < n; base += 1024) {
+        const int64_t i = base + threadIdx.x;
+        const int64_t v = i < n ? counts[i] : 0;
+        s_part[threadIdx.x] = v;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {                // Hillis-Steele inclusive scan
+            const int64_t add = threadIdx.x >= d ? s_part[threadIdx.x - d] : 0;
+            __syncthreads();
+            s_part[threadIdx.x] += add;
+            __syncthreads();
+        }
+        const int64_t incl = s_part[threadIdx.x];
+        if (i < n) counts[i] = s_carry + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry += incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && total) *total = s_carry;
+}
+
+// positions of the line feeds, in order: nl_pos[k] = offset of the k-th '\n'
+__global__ __launch_bounds__(256) void k_nl_write(const uint8_t* buf, int64_t len, int64_t n_tiles, const int64_t* tile_base,
+                                                  int64_t* nl_pos, int64_t cap) {
+    __shared__ int s_cnt[256];
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        unsigned w[16];
+        const int64_t base = tile * NL_TILE_BYTES + (int64_t)threadIdx.x * 64;
+        load64(buf, len, base, w);
+        int c = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) c += __popc(eq_mask(w[i], 0x0A0A0A0Au));
+        s_cnt[threadIdx.x] = c;
+        __syncthreads();
+        for (int d = 1; d < 256; d <<= 1) {
+            const int add = threadIdx.x >= d ? s_cnt[threadIdx.x - d] : 0;
+            __syncthreads();
+            s_cnt[threadIdx.x] += add;
+            __syncthreads();
+        }
+        int64_t k = tile_base[tile] + (s_cnt[threadIdx.x] - c);
+        __syncthreads();
+        if (c) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                unsigned m = eq_mask(w[i], 0x0A0A0A0Au);
+                while (m) {
+                    const int b = (__ffs((int)m) - 1) >> 3;
+                    m &= m - 1;
+                    if (k < cap) nl_pos[k] = base + 4 * i + b;
+                    ++k;
+                }
+            }
+        }
+    }
+}
+
+// Record r = lines 4r .. 4r+3.  info[1] = first bad record + 1 (0: none), info[2] = its error code.
+//   1: name line does not start with '@'   2: third line does not start with '+'   3: lengths differ
+__global__ __launch_bounds__(256) void k_records(const uint8_t* buf, int64_t len, const int64_t* nl_pos, int64_t n_newlines,
+                                                 int64_t n_records, int64_t* rec6, int64_t* seq_off, int32_t* seq_len,
+                                                 unsigned long long* info) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_records; r += stride) {
+        int64_t ls[4], le[4];
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            const int64_t li = 4 * r + l;
+            ls[l] = li == 0 ? 0 : nl_pos[li - 1] + 1;
+            int64_t e = li < n_newlines ? nl_pos[li] : len;        // the last line of a file may lack its line feed
+            if (e > ls[l] && buf[e - 1] == '\r') --e;
+            le[l] = e;
+        }
+        int err = 0;
+        if (le[0] == ls[0] || buf[ls[0]] != '@') err = 1;
+        else if (le[2] == ls[2] || buf[ls[2]] != '+') err = 2;
+        else if (le[1] - ls[1] != le[3] - ls[3]) err = 3;
+        if (err) {
+            const unsigned long long code = ((unsigned long long)(r + 1) << 8) | (unsigned)err;
+            atomicMin(&info[1], code);
+        }
+        int64_t* o = rec6 + r * 6;
+        o[0] = ls[0] + 1; o[1] = le[0]; o[2] = ls[1]; o[3] = le[1]; o[4] = ls[3]; o[5] = le[3];
+        seq_off[r] = ls[1];
+        seq_len[r] = (int32_t)(le[1] - ls[1]);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_out_len(const int64_t* rec6, int64_t n_records, const int32_t* beg, const int32_t* end,
+                                                 const uint8_t* keep, int64_t* out_len) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_records; r += stride) {
+        int64_t v = 0;
+        if (!keep || keep[r]) {
+            const int64_t* o = rec6 + r * 6;
+            const int64_t seq_len = o[3] - o[2];
+            int64_t a = beg[r], b = end[r];
+            if (a < 0) a = 0;
+            if (b > seq_len) b = seq_len;
+            if (b < a) b = a;
+            v = 1 + (o[1] - o[0]) + 1 + (b - a) + 1 + 2 + (b - a) + 1;
+        }
+        out_len[r] = v;
+    }
+}
+
+// generic exclusive scan over int64, SCAN_ELEMS per block: block sums, one-block scan of the sums, apply
+__global__ __launch_bounds__(256) void k_scan_sums(const int64_t* in, int64_t n, int64_t* block_sums) {
+    __shared__ int64_t s_red[4];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_ELEMS;
+    int64_t v = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ELEMS / 256; ++i) {
+        const int64_t q = base + (int64_t)threadIdx.x * (SCAN_ELEMS / 256) + i;
+        if (q < n) v += in[q];
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+}
+
+__global__ __launch_bounds__(256) void k_scan_apply(const int64_t* in, int64_t n, const int64_t* block_base, int64_t* out) {
+    __shared__ int64_t s_part[256];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_ELEMS + (int64_t)threadIdx.x * (SCAN_ELEMS / 256);
+    int64_t loc[SCAN_ELEMS / 256];
+    int64_t sum = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ELEMS / 256; ++i) { loc[i] = base + i < n ? in[base + i] : 0; sum += loc[i]; }
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        const int64_t add = threadIdx.x >= d ? s_part[threadIdx.x - d] : 0;
+        __syncthreads();
+        s_part[threadIdx.x] += add;
+        __syncthreads();
+    }
+    int64_t run = block_base[blockIdx.x] + s_part[threadIdx.x] - sum;
+#pragma unroll
+    for (int i = 0; i < SCAN_ELEMS / 256; ++i) {
+        if (base + i < n) out[base + i] = run;
+        run += loc[i];
+    }
+}
+
+// one wave per record (round-robin inside a block): "@name\nSEQ[a:b]\n+\nQUAL[a:b]\n"
+__global__ __launch_bounds__(256) void k_format(const uint8_t* buf, const int64_t* rec6, int64_t n_records, const int32_t* beg,
+                                                const int32_t* end, const uint8_t* keep, const int64_t* out_off,
+                                                uint8_t* out, int64_t out_cap) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    for (int64_t r = wave; r < n_records; r += n_waves) {
+        if (keep && !keep[r]) continue;
+        const int64_t* o = rec6 + r * 6;
+        const int64_t name_len = o[1] - o[0], seq_len = o[3] - o[2];
+        int64_t a = beg[r], b = end[r];
+        if (a < 0) a = 0;
+        if (b > seq_len) b = seq_len;
+        if (b < a) b = a;
+        const int64_t body = b - a;
+        int64_t pos = out_off[r];
+        if (pos + 1 + name_len + 1 + body + 3 + body + 1 > out_cap) continue;       // never: the caller sizes out for the input
+        uint8_t* w = out + pos;
+        if (lane == 0) w[0] = '@';
+        for (int64_t k = lane; k < name_len; k += 64) w[1 + k] = buf[o[0] + k];
+        w += 1 + name_len;
+        if (lane == 0) w[0] = '\n';
+        for (int64_t k = lane; k < body; k += 64) w[1 + k] = buf[o[2] + a + k];
+        w += 1 + body;
+        if (lane == 0) { w[0] = '\n'; w[1] = '+'; w[2] = '\n'; }
+        for (int64_t k = lane; k < body; k += 64) w[3 + k] = buf[o[4] + a + k];
+        if (lane == 0) w[3 + body] = '\n';
+    }
+}
+
+// What is left of every read after its best match, and whether the record is written: Match.trimmed() (read[rstop:]
+// for a 5' match, read[:rstart] for a 3' match; an "anywhere" adapter counts as 5' when the match starts at
+// position 0: reference adapters.py:453-454, :486-487, :931), then the filters in the reference's order
+// (cli.py:735-912: too short, too long, --discard-trimmed / --discard-untrimmed).
+// counters: [0] reads [1] with adapters [2] bp in [3] bp out (kept records) [4] too short [5] too long [6] invalid reads
+__global__ __launch_bounds__(256) void k_trim_decide(const int32_t* out6, const uint8_t* status, const int32_t* best_adapter,
+                                                     const int32_t* seq_len, int64_t n, const uint8_t* adapter_kind,
+                                                     int32_t min_len, int32_t max_len, int32_t discard_trimmed,
+                                                     int32_t discard_untrimmed, int32_t* beg, int32_t* end, uint8_t* keep,
+                                                     unsigned long long* counters) {
+    __shared__ unsigned long long s_acc[7];
+    if (threadIdx.x < 7) s_acc[threadIdx.x] = 0;
+    __syncthreads();
+    unsigned long long acc[7] = {0, 0, 0, 0, 0, 0, 0};
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += stride) {
+        const int len = seq_len[r];
+        const uint8_t st = status[r];
+        const bool found = st == 1;
+        int b = 0, e = len;
+        if (found) {
+            const int ad = best_adapter ? best_adapter[r] : 0;
+            const uint8_t kind = adapter_kind[ad < 0 ? 0 : ad];       // 0: 3' (remove after), 1: 5' (remove before), 2: anywhere
+            const int rstart = out6[r * 6 + 2], rstop = out6[r * 6 + 3];
+            const bool before = kind == 1 || (kind == 2 && rstart == 0);
+            if (before) b = rstop; else e = rstart;
+        }
+        const int out_len = e - b;
+        bool k = true;
+        if (min_len >= 0 && out_len < min_len) { acc[4] += 1; k = false; }
+        if (k && max_len >= 0 && out_len > max_len) { acc[5] += 1; k = false; }
+        if (discard_trimmed) k = k && !found;
+        else if (discard_untrimmed) k = k && found;
+        beg[r] = b; end[r] = e; keep[r] = k ? 1 : 0;
+        acc[0] += 1; acc[1] += found ? 1 : 0; acc[2] += (unsigned)len; acc[3] += k ? (unsigned)out_len : 0u;
+        acc[6] += st == 2 ? 1 : 0;
+    }
+#pragma unroll
+    for (int i = 0; i < 7; ++i) if (acc[i]) atomicAdd(&s_acc[i], acc[i]);
+    __syncthreads();
+    if (threadIdx.x < 7 && s_acc[threadIdx.x]) atomicAdd(&counters[threadIdx.x], s_acc[threadIdx.x]);
+}
+
+int cus() {
+    int dev = 0, v = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int c = 0;
+        if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && c > 0) v = c;
+    }
+    return v;
+}
+
+int hip_fail(const char* what, hipError_t e) {
+    char msg[256];
+    snprintf(msg, sizeof(msg), "%s failed: %s", what, hipGetErrorString(e));
+    return cah_set_error_(CAH_EHIP, msg);
+}
+#define GPU_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return hip_fail(#expr, e__); } while (0)
+
+int64_t n_tiles_of(int64_t len) { return (len + NL_TILE_BYTES - 1) / NL_TILE_BYTES; }
+int64_t n_scan_blocks(int64_t n) { return (n + SCAN_ELEMS - 1) / SCAN_ELEMS; }
+
+}  // namespace
+
+extern "C" {
+
+size_t cah_fastq_device_scratch_bytes(int64_t chunk_bytes, int64_t max_records) {
+    if (chunk_bytes < 0) chunk_bytes = 0;
+    if (max_records < 0) max_records = 0;
+    // [tile counts][line-feed positions 8 * (4 * records + 4)][per-record output lengths + offsets][scan block sums]
+    return 256 + 8 * (size_t)(n_tiles_of(chunk_bytes) + 8) + 8 * (size_t)(4 * max_records + 8) + 16 * (size_t)(max_records + 8) +
+           8 * (size_t)(n_scan_blocks(max_records) + 8) + 1024;
+}
+
+// Step 1: count the line feeds of the chunk.  d_info[0] = number of '\n' (read it after synchronising the
+// stream: the host sizes the record arrays from it).  d_scratch keeps the tile counts for step 2.
+int cah_fastq_count_lines_device(const uint8_t* d_buf, int64_t len, void* d_scratch, size_t scratch_bytes,
+                                 int64_t* d_info, void* stream) {
+    if (len < 0 || (len > 0 && !d_buf) || !d_scratch || !d_info) return cah_set_error_(CAH_EINVAL, "cah_fastq_count_lines_device: bad argument");
+    if (scratch_bytes < cah_fastq_device_scratch_bytes(len, 0)) return cah_set_error_(CAH_EINVAL, "cah_fastq_count_lines_device: scratch too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n_tiles = n_tiles_of(len);
+    int64_t* tile_counts = (int64_t*)d_scratch;
+    GPU_TRY(hipMemsetAsync(d_info, 0, 8 * sizeof(int64_t), s));
+    if (n_tiles == 0) return CAH_OK;
+    const int grid = (int)(n_tiles < 8 * cus() ? n_tiles : 8 * cus());
+    hipLaunchKernelGGL(k_nl_count, dim3(grid), dim3(256), 0, s, d_buf, len, n_tiles, tile_counts);
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, tile_counts, n_tiles, d_info);
+    GPU_TRY(hipGetLastError());
+    return CAH_OK;
+}
+
+// Step 2: index n_records = n_lines / 4 records (n_newlines as counted by step 1; a last line without line feed
+// counts as a line).  Writes d_rec6 (name_beg, name_end, seq_beg, seq_end, qual_beg, qual_end per record, the
+// columns of cah_fastq_scan), d_seq_off / d_seq_len (the `offsets` + `lens` view of the reads inside the raw
+// chunk that cah_match_batch takes) and d_info[1] = (first bad record + 1) << 8 | error code, or ~0 if the
+// chunk is well formed (codes: 1 no '@', 2 no '+', 3 sequence and quality lengths differ).
+int cah_fastq_index_device(const uint8_t* d_buf, int64_t len, int64_t n_newlines, int64_t n_records,
+                           void* d_scratch, size_t scratch_bytes, int64_t* d_rec6, int64_t* d_seq_off,
+                           int32_t* d_seq_len, int64_t* d_info, void* stream) {
+    if (len < 0 || n_records < 0 || n_newlines < 0 || !d_scratch || !d_info) return cah_set_error_(CAH_EINVAL, "cah_fastq_index_device: bad argument");
+    if (scratch_bytes < cah_fastq_device_scratch_bytes(len, n_records)) return cah_set_error_(CAH_EINVAL, "cah_fastq_index_device: scratch too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n_tiles = n_tiles_of(len);
+    int64_t* tile_base = (int64_t*)d_scratch;                                  // exclusive scan left by step 1
+    int64_t* nl_pos = tile_base + n_tiles + 8;
+    GPU_TRY(hipMemsetAsync(d_info + 1, 0xFF, sizeof(int64_t), s));            // "no bad record"
+    if (n_records == 0 || n_tiles == 0) return CAH_OK;
+    if (!d_rec6 || !d_seq_off || !d_seq_len) return cah_set_error_(CAH_EINVAL, "cah_fastq_index_device: output pointers are NULL");
+    const int grid = (int)(n_tiles < 8 * cus() ? n_tiles : 8 * cus());
+    hipLaunchKernelGGL(k_nl_write, dim3(grid), dim3(256), 0, s, d_buf, len, n_tiles, tile_base, nl_pos, 4 * n_records + 4);
+    const int64_t rb = (n_records + 255) / 256;
+    hipLaunchKernelGGL(k_records, dim3((unsigned)(rb < 8 * cus() ? rb : 8 * cus())), dim3(256), 0, s, d_buf, len, nl_pos, n_newlines,
+                       n_records, d_rec6, d_seq_off, d_seq_len, (unsigned long long*)d_info);
+    GPU_TRY(hipGetLastError());
+    return CAH_OK;
+}
+
+// Step 3b: kept interval and keep flag of every read from the match results (see k_trim_decide).  adapter_kind[a]:
+// 0 = 3' adapter, 1 = 5' adapter, 2 = anywhere; min_len / max_len < 0: no limit.  d_counters: uint64[8], accumulated
+// (NOT reset) -- reads, with adapters, bp in, bp out, too short, too long, invalid reads.
+int cah_trim_decide_device(const int32_t* d_out6, const uint8_t* d_status, const int32_t* d_best_adapter,
+                           const int32_t* d_seq_len, int64_t n_reads, const uint8_t* d_adapter_kind, int32_t min_len,
+                           int32_t max_len, int32_t discard_trimmed, int32_t discard_untrimmed, int32_t* d_beg,
+                           int32_t* d_end, uint8_t* d_keep, uint64_t* d_counters, void* stream) {
+    if (n_reads < 0) return cah_set_error_(CAH_EINVAL, "cah_trim_decide_device: bad argument");
+    if (n_reads == 0) return CAH_OK;
+    if (!d_out6 || !d_status || !d_seq_len || !d_adapter_kind || !d_beg || !d_end || !d_keep || !d_counters)
+        return cah_set_error_(CAH_EINVAL, "cah_trim_decide_device: NULL argument");
+    const int64_t rb = (n_reads + 255) / 256;
+    hipLaunchKernelGGL(k_trim_decide, dim3((unsigned)(rb < 4 * cus() ? rb : 4 * cus())), dim3(256), 0, (hipStream_t)stream, d_out6,
+                       d_status, d_best_adapter, d_seq_len, n_reads, d_adapter_kind, min_len, max_len, discard_trimmed,
+                       discard_untrimmed, d_beg, d_end, d_keep, (unsigned long long*)d_counters);
+    GPU_TRY(hipGetLastError());
+    return CAH_OK;
+}
+
+// Step 4: the trimmed records of a chunk, formatted on the device: record r (if d_keep is NULL or d_keep[r] != 0)
+// as "@name\nSEQ[beg:end]\n+\nQUAL[beg:end]\n" at the exclusive-scan offset of its length (record order is kept).
+// d_info[3] = total bytes written.  out_cap >= chunk length + 4 * n_records always suffices.
+int cah_fastq_format_device(const uint8_t* d_buf, const int64_t* d_rec6, int64_t n_records, const int32_t* d_beg,
+                            const int32_t* d_end, const uint8_t* d_keep, void* d_scratch, size_t scratch_bytes,
+                            int64_t chunk_bytes, uint8_t* d_out, int64_t out_cap, int64_t* d_info, void* stream) {
+    if (n_records < 0 || !d_scratch || !d_info) return cah_set_error_(CAH_EINVAL, "cah_fastq_format_device: bad argument");
+    if (scratch_bytes < cah_fastq_device_scratch_bytes(chunk_bytes, n_records)) return cah_set_error_(CAH_EINVAL, "cah_fastq_format_device: scratch too small");
+    hipStream_t s = (hipStream_t)stream;
+    GPU_TRY(hipMemsetAsync(d_info + 3, 0, sizeof(int64_t), s));
+    if (n_records == 0) return CAH_OK;
+    if (!d_buf || !d_rec6 || !d_beg || !d_end || !d_out) return cah_set_error_(CAH_EINVAL, "cah_fastq_format_device: NULL argument");
+    int64_t* p = (int64_t*)d_scratch + n_tiles_of(chunk_bytes) + 8 + 4 * n_records + 8;
+    int64_t* out_len = p;                        p += n_records + 8;
+    int64_t* out_off = p;                        p += n_records + 8;
+    int64_t* block_sums = p;
+    const int64_t rb = (n_records + 255) / 256;
+    const int64_t sb = n_scan_blocks(n_records);
+    hipLaunchKernelGGL(k_out_len, dim3((unsigned)(rb < 8 * cus() ? rb : 8 * cus())), dim3(256), 0, s, d_rec6, n_records, d_beg, d_end,
+                       d_keep, out_len);
+    hipLaunchKernelGGL(k_scan_sums, dim3((unsigned)sb), dim3(256), 0, s, out_len, n_records, block_sums);
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, block_sums, sb, d_info + 3);
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)sb), dim3(256), 0, s, out_len, n_records, block_sums, out_off);
+    const int64_t fb = (n_records + 3) / 4;
+    hipLaunchKernelGGL(k_format, dim3((unsigned)(fb < 16 * cus() ? fb : 16 * cus())), dim3(256), 0, s, d_buf, d_rec6, n_records, d_beg,
+                       d_end, d_keep, out_off, d_out, out_cap);
+    GPU_TRY(hipGetLastError());
+    return CAH_OK;
+}
+
+}  // extern "C"

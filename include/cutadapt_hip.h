@@ -259,6 +259,40 @@ int cah_info_write(const uint8_t *buf, const int64_t *rec, int64_t n_records, co
                    const int64_t *name_off, int64_t n_names, uint8_t *out, int64_t out_cap,
                    int64_t *out_len);
 
+/* ---- the same formats ON THE DEVICE (fastq_gpu.hip): the raw FASTQ chunk goes to HBM as it is, records are
+ * indexed and the trimmed records formatted there, so that the host does nothing per read.  All pointers are
+ * device pointers, all calls asynchronous on `stream`.  Scratch: cah_fastq_device_scratch_bytes(chunk, records),
+ * shared by the three steps of one chunk (step 2 and 3 read what the earlier steps left there).
+ *   1. cah_fastq_count_lines_device   d_info[0] = number of line feeds; the host synchronises, derives
+ *                                     n_records = n_lines / 4 (a last line without line feed counts) and sizes
+ *                                     the per-record arrays
+ *   2. cah_fastq_index_device         d_rec6 (the columns of cah_fastq_scan), d_seq_off / d_seq_len = the reads as an
+ *                                     offsets + lens view INTO THE RAW CHUNK (what cah_match_batch takes: nothing is
+ *                                     packed), d_info[1] = (first bad record + 1) << 8 | code or ~0 (1: no '@',
+ *                                     2: no '+', 3: sequence and quality lengths differ)
+ *   3. cah_fastq_format_device        "@name\nSEQ[beg:end]\n+\nQUAL[beg:end]\n" of every kept record in record
+ *                                     order, d_info[3] = bytes written (<= chunk bytes + 4 * n_records)
+ * d_info: int64[8]. */
+size_t cah_fastq_device_scratch_bytes(int64_t chunk_bytes, int64_t max_records);
+int cah_fastq_count_lines_device(const uint8_t *d_buf, int64_t len, void *d_scratch, size_t scratch_bytes,
+                                 int64_t *d_info, void *stream);
+int cah_fastq_index_device(const uint8_t *d_buf, int64_t len, int64_t n_newlines, int64_t n_records,
+                           void *d_scratch, size_t scratch_bytes, int64_t *d_rec6, int64_t *d_seq_off,
+                           int32_t *d_seq_len, int64_t *d_info, void *stream);
+/* between 2 and 3: what is left of every read after its best match (Match.trimmed(), adapters.py:453-454, :486-487)
+ * and whether the record is written (filters of cli.py:735-912: too short, too long, --discard-(un)trimmed).
+ * d_adapter_kind[a]: 0 = 3' adapter, 1 = 5' adapter, 2 = anywhere (5' iff the match starts at 0); min_len / max_len
+ * < 0 = no limit; d_counters: uint64[8], accumulated: reads, with adapters, bp in, bp out, too short, too long,
+ * invalid reads. */
+int cah_trim_decide_device(const int32_t *d_out6, const uint8_t *d_status, const int32_t *d_best_adapter,
+                           const int32_t *d_seq_len, int64_t n_reads, const uint8_t *d_adapter_kind,
+                           int32_t min_len, int32_t max_len, int32_t discard_trimmed,
+                           int32_t discard_untrimmed, int32_t *d_beg, int32_t *d_end, uint8_t *d_keep,
+                           uint64_t *d_counters, void *stream);
+int cah_fastq_format_device(const uint8_t *d_buf, const int64_t *d_rec6, int64_t n_records, const int32_t *d_beg,
+                            const int32_t *d_end, const uint8_t *d_keep, void *d_scratch, size_t scratch_bytes,
+                            int64_t chunk_bytes, uint8_t *d_out, int64_t out_cap, int64_t *d_info, void *stream);
+
 /* ---- AdapterIndex (adapters.py:1289-1551) on the GPU ---------- */
 /* Many anchored adapters of one kind (all 5' "^ADAPTER" or all 3' "ADAPTER$", no wildcards, at most
  * 3 errors) are matched with one dictionary lookup per read: every string within k errors of any

@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""End to end, host-fed: FASTQ bytes in host memory -> trimmed FASTQ bytes in host memory, one MI355X.
+Records are parsed, matched and formatted on the GPU (cutadapt_amd/gpu_pipeline.py); the host only cuts the
+input at record starts and moves bytes.  Compared with the host-side batch pipeline (pipeline.trim_fastq,
+parse/format on CPU threads).  Usage: python profiles/scripts/e2e_gpu.py [n_reads] > profiles/r02/e2e_gpu.json"""
+import io
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import torch
+
+from cutadapt_amd import workloads
+from cutadapt_amd.adapters import BackAdapter
+from cutadapt_amd.gpu_pipeline import trim_fastq_gpu
+from cutadapt_amd.pipeline import trim_fastq
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 30_000_000
+dev = torch.device("cuda", 0)
+batch = workloads.device_batch("C2", n, device=dev)
+seqs = batch.seqs.view(n, 150)
+idx = torch.arange(n, dtype=torch.int64, device=dev)
+name = torch.empty((n, 13), dtype=torch.uint8, device=dev)
+name[:, 0] = ord("@"); name[:, 1] = ord("r"); name[:, 12] = 10
+for k in range(10):
+    name[:, 11 - k] = ((idx // (10 ** k)) % 10 + 48).to(torch.uint8)
+rec = torch.empty((n, 317), dtype=torch.uint8, device=dev)
+rec[:, :13] = name
+rec[:, 13:163] = seqs
+rec[:, 163] = 10; rec[:, 164] = ord("+"); rec[:, 165] = 10
+rec[:, 166:316] = ord("I")
+rec[:, 316] = 10
+fastq = torch.empty(n * 317, dtype=torch.uint8).pin_memory()
+fastq.copy_(rec.view(-1))
+del rec, name, idx, batch, seqs
+torch.cuda.empty_cache()
+adapter = BackAdapter(workloads.TRUSEQ_R1, max_errors=0.1, min_overlap=3)
+out = {"reads": n, "fastq_bytes": int(fastq.numel()), "record_bytes": 317, "runs": []}
+
+
+def timed(label, fn, reps=2):
+    best = None
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        stats = fn()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    out["runs"].append({"what": label, "seconds": best, "Mreads_per_s": n / best / 1e6,
+                        "GB_per_s_in": fastq.numel() / best / 1e9, "with_adapters": stats["with_adapters"],
+                        "bytes_out": stats.get("bytes_out")})
+    print(out["runs"][-1], file=sys.stderr)
+    return stats
+
+
+trim_fastq_gpu(fastq[: 317 * 200_000], None, [adapter], threads=2)          # warm-up
+for threads, chunk_mib in ((1, 64), (2, 64), (3, 64), (4, 64), (6, 64), (8, 64), (4, 32), (4, 128)):
+    timed(f"GPU parse+match+format, pinned input, no sink, {threads} worker thread(s) x {chunk_mib} MiB chunks",
+          lambda: trim_fastq_gpu(fastq, None, [adapter], threads=threads, chunk_bytes=chunk_mib << 20))
+devnull = open(os.devnull, "wb")
+timed("GPU parse+match+format, pinned input, output written to /dev/null, 4 worker threads",
+      lambda: trim_fastq_gpu(fastq, devnull, [adapter], threads=4))
+pageable = fastq.numpy().copy()
+timed("GPU parse+match+format, pageable numpy input (staged through pinned buffers), no sink, 4 worker threads",
+      lambda: trim_fastq_gpu(pageable, None, [adapter], threads=4), reps=1)
+del pageable
+sub = fastq[: 317 * min(n, 4_000_000)].numpy().tobytes()
+n_sub = min(n, 4_000_000)
+t0 = time.perf_counter()
+st = trim_fastq(io.BytesIO(sub), devnull, [adapter], threads=16)
+dt = time.perf_counter() - t0
+out["runs"].append({"what": "host-side batch pipeline (parse/format on 16 CPU threads), same data, /dev/null",
+                    "seconds": dt, "Mreads_per_s": n_sub / dt / 1e6, "with_adapters_fraction": st["with_adapters"] / n_sub})
+print(json.dumps(out, indent=1))

@@ -1,0 +1,111 @@
+"""FASTQ parsed, matched and formatted on the device (cutadapt_amd/gpu_pipeline.py, csrc/fastq_gpu.hip) must
+write the same bytes as the host-side batch pipeline (pipeline.trim_fastq, itself pinned to the reference's
+command-line goldens) and as the reference's golden files themselves.  GPU only."""
+import io
+import json
+import os
+import random
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FQ = os.path.join(HERE, "golden", "fastq")
+
+
+def _fastq(rng, n, adapters, crlf=False, final_newline=True, lower=False):
+    recs = []
+    for i in range(n):
+        L = rng.randint(0, 160)
+        s = "".join(rng.choice("ACGT") for _ in range(L))
+        if rng.random() < 0.6 and adapters:
+            ad = rng.choice(adapters)
+            ad = ad[:rng.randint(1, len(ad))] if rng.random() < 0.5 else ad
+            pos = rng.randint(0, L)
+            s = (s[:pos] + ad + s[pos:])[:max(L, 1)] if rng.random() < 0.5 else s[:pos] + ad
+        if rng.random() < 0.1:
+            s = "".join(c if rng.random() > 0.05 else "N" for c in s)
+        if lower and rng.random() < 0.3:
+            s = s.lower()
+        q = "".join(chr(rng.randint(33, 73)) for _ in s)
+        name = f"read{i}" + (" some comment:" + "x" * rng.randint(0, 30) if rng.random() < 0.3 else "")
+        recs.append(f"@{name}\n{s}\n+{name if rng.random() < 0.1 else ''}\n{q}\n")
+    text = "".join(recs)
+    if crlf:
+        text = text.replace("\n", "\r\n")
+    if not final_newline and text.endswith("\n"):
+        text = text[:-2] if crlf else text[:-1]
+    return text.encode()
+
+
+def test_device_fastq_equals_host_pipeline(hip):
+    import numpy as np
+    from cutadapt_amd import adapters as A
+    from cutadapt_amd.gpu_pipeline import trim_fastq_gpu
+    from cutadapt_amd.pipeline import trim_fastq
+    rng = random.Random(2024)
+    ad_seqs = ["AGATCGGAAGAGCACACGTCTGAACTCCAGTCA", "TGGAATTCTCGGGTGCCAAGG", "ACGTACGTTT"]
+    cases = [
+        ([A.BackAdapter(ad_seqs[0])], {}),
+        ([A.BackAdapter(ad_seqs[0]), A.FrontAdapter(ad_seqs[1]), A.AnywhereAdapter(ad_seqs[2])], {}),
+        ([A.PrefixAdapter(ad_seqs[2]), A.SuffixAdapter(ad_seqs[1])], {"discard_untrimmed": True}),
+        ([A.BackAdapter(ad_seqs[0])], {"minimum_length": 30, "maximum_length": 120}),
+        ([A.NonInternalBackAdapter(ad_seqs[1]), A.BackAdapter(ad_seqs[0])], {"discard_trimmed": True}),
+    ]
+    for ci, (ads, opts) in enumerate(cases):
+        for crlf, final_nl, chunk in ((False, True, 1 << 20), (True, True, 4096), (False, False, 700)):
+            data = _fastq(rng, 3000, ad_seqs, crlf=crlf, final_newline=final_nl, lower=ci == 1)
+            want = io.BytesIO()
+            ws = trim_fastq(io.BytesIO(data), want, ads, index=False, **opts)
+            for source in (io.BytesIO(data), np.frombuffer(data, dtype=np.uint8)):
+                got = io.BytesIO()
+                gs = trim_fastq_gpu(source, got, ads, chunk_bytes=chunk, threads=2, devices="all", **opts)
+                assert got.getvalue() == want.getvalue(), (ci, crlf, final_nl, chunk)
+                assert (gs["reads"], gs["with_adapters"], gs["bp_in"], gs["bp_out"]) == \
+                       (ws["reads"], ws["with_adapters"], ws["bp_in"], ws["bp_out"]), (ci, gs, ws["reads"])
+            assert gs["bytes_out"] == len(want.getvalue())
+    # malformed input is reported, not silently processed
+    from cutadapt_amd.gpu_pipeline import trim_fastq_gpu as g
+    for bad in (b"@r\nACGT\n-\nIIII\n", b"@r\nACGT\n+\nIII\n", b"r\nACGT\n+\nIIII\n", b"@r\nACGT\n+\n"):
+        with pytest.raises(ValueError):
+            g(np.frombuffer(bad, dtype=np.uint8), io.BytesIO(), [A.BackAdapter(ad_seqs[0])])
+    assert g(np.zeros(0, dtype=np.uint8), io.BytesIO(), [A.BackAdapter(ad_seqs[0])])["reads"] == 0
+
+
+def test_device_fastq_reference_goldens(hip):
+    """the reference's command-line goldens that fall into this stage's scope (plain FASTQ, --times 1, action
+    trim, no info file): byte for byte from the device-side path"""
+    from cutadapt_amd.gpu_pipeline import trim_fastq_gpu
+    from cutadapt_amd.pipeline import adapter_from_spec
+    manifest = json.load(open(os.path.join(FQ, "manifest.json")))
+    kinds = {"-a": "back", "-g": "front", "-b": "anywhere"}
+    done = 0
+    for case in manifest:
+        opts = dict(case.get("options", {}))
+        params = {"max_errors": opts.pop("max_errors")} if "max_errors" in opts else {}
+        if case.get("info") or not case.get("expected") or not case["input"].endswith((".fastq", ".fq")):
+            continue
+        if opts.get("times", 1) != 1 or opts.get("action", "trim") != "trim":
+            continue
+        allowed = {"times", "action", "discard_untrimmed", "discard_trimmed", "minimum_length", "maximum_length"}
+        if not set(opts) <= allowed:
+            continue
+        try:
+            ads = [adapter_from_spec(spec, kinds[o], **params) for o, spec in case["adapters"]]
+        except Exception:
+            continue
+        from cutadapt_amd.adapters import SingleAdapter
+        if not ads or not all(isinstance(a, SingleAdapter) and not a._reverse_reads for a in ads):
+            continue
+        from cutadapt_amd.adapters import PrefixAdapter, SuffixAdapter
+        if sum(isinstance(a, (PrefixAdapter, SuffixAdapter)) for a in ads) > 1:
+            continue                     # the reference regroups several anchored adapters behind an index
+        opts.pop("times", None); opts.pop("action", None)
+        expected = open(os.path.join(FQ, case["expected"]), "rb").read()
+        for chunk in (1 << 20, 512):
+            out = io.BytesIO()
+            trim_fastq_gpu(os.path.join(FQ, case["input"]), out, ads, chunk_bytes=chunk, threads=2, **opts)
+            assert out.getvalue() == expected, (case["name"], chunk)
+        done += 1
+    assert done >= 5, done
