@@ -173,7 +173,7 @@ struct PlanDeviceCopy {
     uint32_t* d_mbitmap = nullptr;
     uint64_t* d_mscan = nullptr;          // [n_adapters][CAH_MULTI_TAB_STRIDE] padded match words (cost scan)
     uint64_t* d_mrow = nullptr;           // ... row bitsets (cell DP)
-    std::vector<LongDeviceCopy> d_long;   // one per matcher (null pointers unless long_dp)
+    std::vector<LongDeviceCopy> d_long;   // one per matcher (null pointers for bare k-mer finders)
 };
 
 // host tables of the fused multi-adapter path (see CahMultiHeader)
@@ -230,8 +230,8 @@ static int plan_on_device(const cah_plan* plan, const PlanDeviceCopy** out) {
             LongDeviceCopy& ld = dc.d_long[i];
             HIP_TRY(hipMalloc((void**)&ld.d_lm, sizeof(CahLongMatcher)));
             HIP_TRY(hipMemcpy(ld.d_lm, &lt.lm, sizeof(CahLongMatcher), hipMemcpyHostToDevice));
-            HIP_TRY(hipMalloc((void**)&ld.d_ref, lt.ref.size()));
-            HIP_TRY(hipMemcpy(ld.d_ref, lt.ref.data(), lt.ref.size(), hipMemcpyHostToDevice));
+            HIP_TRY(hipMalloc((void**)&ld.d_ref, std::max<size_t>(lt.ref.size(), 1)));
+            if (!lt.ref.empty()) HIP_TRY(hipMemcpy(ld.d_ref, lt.ref.data(), lt.ref.size(), hipMemcpyHostToDevice));
             HIP_TRY(hipMalloc((void**)&ld.d_ncnt, sizeof(int32_t) * lt.ncnt.size()));
             HIP_TRY(hipMemcpy(ld.d_ncnt, lt.ncnt.data(), sizeof(int32_t) * lt.ncnt.size(), hipMemcpyHostToDevice));
         }
@@ -370,9 +370,11 @@ static int build_long(const cah_adapter_desc& d, int index, CahMatcher& mt, Long
         for (int i = 0; i < m; i++)
             lt.ref[(size_t)i] = wr ? t.iupac[(uint8_t)seq[i]] : (wq ? t.acgt[(uint8_t)seq[i]] : t.upper[(uint8_t)seq[i]]);
     }
-    mt.long_dp = 1;
-    mt.m = m; mt.k = lm.k; mt.flags = lm.flags; mt.min_overlap = d.min_overlap; mt.wildcard_ref = wr;
-    mt.indel_cost = d.indel_cost; mt.effective_length = lm.effective_length; mt.cmp_max_k = lm.cmp_max_k;
+    if (m > CAH_MAX_M) {
+        mt.long_dp = 1;
+        mt.m = m; mt.k = lm.k; mt.flags = lm.flags; mt.min_overlap = d.min_overlap; mt.wildcard_ref = wr;
+        mt.indel_cost = d.indel_cost; mt.effective_length = lm.effective_length; mt.cmp_max_k = lm.cmp_max_k;
+    }
     return CAH_OK;
 }
 
@@ -948,6 +950,14 @@ static int check_batch(const cah_plan* plan, const void* d_seqs, const void* d_o
     return CAH_OK;
 }
 
+// Tiny batches (the per-read calls of the Python mirror classes send batches of one) are launch-bound: the
+// entry points then zero the whole counter header with ONE memset and the helpers below skip theirs
+// (t_header_fresh), and the host conveniences clear their contiguous output block with one memset
+// (t_outputs_ready) instead of status / out6 / best_adapter separately.
+#define CAH_TINY_BATCH 64
+static thread_local bool t_header_fresh = false;
+static thread_local bool t_outputs_ready = false;
+
 // Aligner / comparer over a work list (d_queue == NULL: all reads).  3' adapters with unit costs go
 // through the cost scan first (k_back_scan finishes most reads, the rest reach k_dp_packed with an exact
 // column window); everything else runs the cell kernel directly.
@@ -968,7 +978,8 @@ static int run_aligner(const cah_plan* plan, const PlanDeviceCopy* pd, int32_t a
     a.win = nullptr; a.queue_count_back = nullptr; a.queue_cap = 0;
     a.pairs = nullptr; a.tab = nullptr; a.n_adapters = 0; a.best_key = nullptr;
     // DP work counter, scan tile counter, DP list counts: one memset over their lines
-    HIP_TRY(hipMemsetAsync(ws.counters + WS_DPWORK, 0, WS_HEADER - WS_DPWORK * sizeof(unsigned long long), s));
+    if (!t_header_fresh)
+        HIP_TRY(hipMemsetAsync(ws.counters + WS_DPWORK, 0, WS_HEADER - WS_DPWORK * sizeof(unsigned long long), s));
     if (mt.long_dp) {
         // adapter longer than 64 characters: column in HBM scratch (long.hip)
         int64_t lanes = long_scratch_lanes(n_reads, pd->n_cus);
@@ -1038,7 +1049,7 @@ int cah_locate_batch(const cah_plan* plan, int32_t adapter, const uint8_t* d_seq
     rc = plan_on_device(plan, &pd);
     if (rc) return rc;
     return run_aligner(plan, pd, adapter, d_seqs, d_offsets, d_lens, n_reads, nullptr, nullptr, nullptr,
-                       ws, d_out6, d_status, nullptr, 0, (hipStream_t)stream);
+                       ws, d_out6, d_status, nullptr, 0, (hipStream_t)stream);      // (its one memset is the header's)
 }
 
 static int run_filter(const cah_plan* plan, const PlanDeviceCopy* pd, int32_t adapter, const uint8_t* d_seqs,
@@ -1060,8 +1071,10 @@ static int run_filter(const cah_plan* plan, const PlanDeviceCopy* pd, int32_t ad
     f.queue_keys = d_queue_keys;
     f.batch_flag = nullptr;
     f.lean = nullptr;
-    HIP_TRY(hipMemsetAsync(d_work_counter, 0, sizeof(unsigned long long), s));
-    if (d_queue_count) HIP_TRY(hipMemsetAsync(d_queue_count, 0, sizeof(unsigned long long), s));
+    if (!t_header_fresh) {
+        HIP_TRY(hipMemsetAsync(d_work_counter, 0, sizeof(unsigned long long), s));
+        if (d_queue_count) HIP_TRY(hipMemsetAsync(d_queue_count, 0, sizeof(unsigned long long), s));
+    }
     ProfScope ps(s, CAH_PROF_FILTER, n_reads);
     if (plan->lean[(size_t)adapter].ok) {
         // 3' adapter plans: k_filter_lean.  For a packed batch the device-side batch check (*d_batch_flag)
@@ -1198,12 +1211,21 @@ int cah_match_batch(const cah_plan* plan, const uint8_t* d_seqs, const int64_t* 
     if (rc) return rc;
     const Workspace ws(d_workspace, n_reads, workspace_bytes);
     unsigned long long* counters = ws.counters;
-    HIP_TRY(hipMemsetAsync(d_status, 0, (size_t)n_reads, s));
-    HIP_TRY(hipMemsetAsync(d_out6, 0, sizeof(int32_t) * 6 * (size_t)n_reads, s));
-    if (d_best_adapter) HIP_TRY(launch_init_best(d_best_adapter, n_reads, pd->n_cus, s));
+    if (!t_outputs_ready) {
+        HIP_TRY(hipMemsetAsync(d_status, 0, (size_t)n_reads, s));
+        HIP_TRY(hipMemsetAsync(d_out6, 0, sizeof(int32_t) * 6 * (size_t)n_reads, s));
+        if (d_best_adapter) HIP_TRY(launch_init_best(d_best_adapter, n_reads, pd->n_cus, s));
+    }
+    // tiny single-adapter batches: one memset for all counters, no batch check (the ragged prefilter serves them)
+    const bool tiny = n_reads <= CAH_TINY_BATCH && plan->matchers.size() == 1;
+    struct FreshGuard { bool on; ~FreshGuard() { if (on) t_header_fresh = false; } } guard{tiny};
+    if (tiny) {
+        HIP_TRY(hipMemsetAsync(counters, 0, WS_HEADER, s));
+        t_header_fresh = true;
+    }
     // one pass over the offsets decides, on the device, which prefilter kernel works on this batch
     const unsigned long long* d_batch_flag = nullptr;
-    if (!d_lens) {
+    if (!d_lens && !tiny) {
         bool any_lean = false;
         for (size_t ad = 0; ad < plan->matchers.size(); ad++)
             any_lean |= plan->matchers[ad].has_filter && plan->matchers[ad].kind != CAH_KIND_KMER_ONLY && plan->lean[ad].ok;
@@ -1336,15 +1358,26 @@ static int host_call(int mode, const cah_plan* plan, int32_t adapter, const uint
         rc = cah_locate_batch(plan, adapter, d_seqs, d_offsets, nullptr, n, d_out6, d_status, d_ws, ws_bytes, hs.stream);
     else if (mode == HOST_PRESENT)
         rc = cah_kmers_present_batch(plan, adapter, d_seqs, d_offsets, nullptr, n, d_status, hs.stream);
-    else
+    else {
+        // one memset clears out6 / best / status (they are contiguous here); "no adapter" (-1) is filled in below
+        HIP_TRY(hipMemsetAsync(d_out, 0, o6_bytes + best_bytes + (size_t)n, hs.stream));
+        t_outputs_ready = true;
         rc = cah_match_batch(plan, d_seqs, d_offsets, nullptr, n, d_out6, d_best, d_status, d_ws, ws_bytes, hs.stream);
+        t_outputs_ready = false;
+    }
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(hs.pin + in_bytes, d_out, o6_bytes + best_bytes + (size_t)n, hipMemcpyDeviceToHost, hs.stream));
     HIP_TRY(hipStreamSynchronize(hs.stream));
     const char* h_out = hs.pin + in_bytes;
     if (out6) memcpy(out6, h_out, o6_bytes);
-    if (best_adapter) memcpy(best_adapter, h_out + o6_bytes, best_bytes);
     if (status) memcpy(status, h_out + o6_bytes + best_bytes, (size_t)n);
+    if (best_adapter) {
+        memcpy(best_adapter, h_out + o6_bytes, best_bytes);
+        if (mode == HOST_MATCH) {
+            const uint8_t* st = (const uint8_t*)(h_out + o6_bytes + best_bytes);
+            for (int64_t i = 0; i < n; i++) if (st[i] != CAH_MATCH) best_adapter[i] = -1;
+        }
+    }
     return CAH_OK;
 }
 }  // namespace

@@ -27,40 +27,19 @@ struct Column {
     __device__ __forceinline__ int& origin(int i) const { return base[(int64_t)(i * 3 + 2) * stride]; }
 };
 
-}  // namespace
 
-__global__ __launch_bounds__(256) void k_dp_long(LongArgs a) {
-    __shared__ uint8_t s_qtab[CAH_TABLE_CHARS];
-    const CahLongMatcher* lm = a.lm;
-    for (int i = threadIdx.x; i < CAH_TABLE_CHARS; i += blockDim.x) s_qtab[i] = lm->qtab[i];
-    __syncthreads();
+// Aligner.locate / PrefixComparer.locate / SuffixComparer.locate of ONE read, written as in the reference; the DP
+// column lives wherever `col` points (HBM scratch).  `seen` ORs the bytes looked at (bit 7 set = non-ASCII input).
+struct LongResult { bool found; int t0, t1, t2, t3, score, cost; unsigned seen; };
+
+__device__ __forceinline__ LongResult long_locate(const CahLongMatcher* lm, const uint8_t* ref, const int32_t* ncnt,
+                                                  const uint8_t* s_qtab, const Column& col, const uint8_t* q, const int n) {
     const int m = lm->m, k = lm->k, D = lm->indel_cost, kind = lm->kind;
     const bool start_in_ref = lm->flags & 1, start_in_query = lm->flags & 2;
     const bool stop_in_ref = lm->flags & 4, stop_in_query = lm->flags & 8;
     const bool cmp_equal = lm->cmp_equal != 0, wildcard_ref = lm->wildcard_ref != 0;
     const int min_overlap = lm->min_overlap, eff_full = lm->effective_length;
     const double rate = lm->rate;
-    const uint8_t* ref = a.ref;
-    const int32_t* ncnt = a.ncnt;
-    Column col;
-    col.stride = (int64_t)gridDim.x * blockDim.x;
-    col.base = a.scratch + ((int64_t)blockIdx.x * blockDim.x + threadIdx.x);
-    const int lane = wave_lane();
-    int64_t total = a.n_reads;
-    if (a.queue_count) total = (int64_t)(*a.queue_count);
-
-    for (;;) {
-        const int64_t base = wave_dequeue(a.work_counter);
-        if (base >= total) break;
-        const int64_t idx = base + lane;
-        if (idx >= total) continue;
-        const int64_t r = a.queue ? (int64_t)a.queue[idx] : idx;
-        int64_t off, n64;
-        read_extent(a.offsets, a.lens, r, off, n64);
-        bool invalid = false;
-        if (n64 > a.max_read_len) { invalid = true; n64 = 0; }
-        const int n = (int)n64;
-        const uint8_t* q = a.seqs + off;
         bool found = false;
         int t0 = 0, t1 = 0, t2 = 0, t3 = 0, r_score = 0, r_cost = 0;
         unsigned seen = 0;
@@ -164,6 +143,43 @@ __global__ __launch_bounds__(256) void k_dp_long(LongArgs a) {
             t2 = b_origin >= 0 ? b_origin : 0;  t3 = b_qstop;
             r_score = b_score; r_cost = b_cost;
         }
+        LongResult res;
+        res.found = found; res.t0 = t0; res.t1 = t1; res.t2 = t2; res.t3 = t3; res.score = r_score; res.cost = r_cost; res.seen = seen;
+        return res;
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(256) void k_dp_long(LongArgs a) {
+    __shared__ uint8_t s_qtab[CAH_TABLE_CHARS];
+    const CahLongMatcher* lm = a.lm;
+    for (int i = threadIdx.x; i < CAH_TABLE_CHARS; i += blockDim.x) s_qtab[i] = lm->qtab[i];
+    __syncthreads();
+    const uint8_t* ref = a.ref;
+    const int32_t* ncnt = a.ncnt;
+    Column col;
+    col.stride = (int64_t)gridDim.x * blockDim.x;
+    col.base = a.scratch + ((int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+    const int lane = wave_lane();
+    int64_t total = a.n_reads;
+    if (a.queue_count) total = (int64_t)(*a.queue_count);
+
+    for (;;) {
+        const int64_t base = wave_dequeue(a.work_counter);
+        if (base >= total) break;
+        const int64_t idx = base + lane;
+        if (idx >= total) continue;
+        const int64_t r = a.queue ? (int64_t)a.queue[idx] : idx;
+        int64_t off, n64;
+        read_extent(a.offsets, a.lens, r, off, n64);
+        bool invalid = false;
+        if (n64 > a.max_read_len) { invalid = true; n64 = 0; }
+        const int n = (int)n64;
+        const uint8_t* q = a.seqs + off;
+        const LongResult lr = long_locate(lm, ref, ncnt, s_qtab, col, q, n);
+        const bool found = lr.found;
+        const int t0 = lr.t0, t1 = lr.t1, t2 = lr.t2, t3 = lr.t3, r_score = lr.score, r_cost = lr.cost;
+        const unsigned seen = lr.seen;
         if (seen & 0x80u) invalid = true;
 
         int32_t* o = a.out6 + r * 6;
