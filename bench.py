@@ -254,6 +254,7 @@ def main():
     step_ms = {k: ms[i] / args.steps for k, i in fam.items()}
     per_launch_ms = {k: ms[i] / max(launches[i], 1) for k, i in fam.items()}
     launches_per_step = {k: launches[i] / args.steps for k, i in fam.items()}
+    units_per_launch = {k: units[i] / max(launches[i], 1) for k, i in fam.items()}     # reads handed to one launch
     status = wl.outs[-1].status if spec["kind"] == "linked" else wl.outs[0].status
     n_match = int((status == 1).sum().item())
     n_invalid = int((status == 2).sum().item())
@@ -281,7 +282,7 @@ def main():
     # dominant kernel family: the one with the largest share of a step
     dom = max(step_ms, key=lambda k: step_ms[k])
     dom_launch_ms = per_launch_ms[dom]
-    reads_per_launch = n
+    reads_per_launch = units_per_launch[dom]        # (the fused multi-adapter path works in chunks of reads)
     if spec["kind"] == "single":
         reads_per_launch = {"k_filter": n, "k_back_scan": survivors, "k_dp": dp_reads if dp_reads else survivors,
                             "k_comparer": n}[dom]
