@@ -49,6 +49,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--check-reads", type=int, default=200_000, help="reads compared with the oracle (untimed)")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="TEST ONLY: let ranks share devices (rank r uses device r mod visible) so that the multi-rank "
+                         "path can be exercised on a box with fewer GPUs; such a line is not a measurement")
     return ap.parse_args(argv)
 
 
@@ -58,7 +61,7 @@ def parse_args(argv=None):
 def self_launch(args) -> int:
     import torch
     visible = torch.cuda.device_count()
-    if visible < args.gpus:
+    if visible < args.gpus and not (args.oversubscribe and visible >= 1):
         raise SystemExit(f"bench.py: --gpus {args.gpus} requested but only {visible} HIP device(s) are visible; "
                          f"refusing to run a {args.gpus}-GPU benchmark on fewer devices")
     with socket.socket() as s:
@@ -193,6 +196,8 @@ def main():
 
     import torch
     import torch.distributed as dist
+    if args.oversubscribe and torch.cuda.device_count() >= 1:
+        local_rank = local_rank % torch.cuda.device_count()
     if local_rank >= torch.cuda.device_count():
         raise SystemExit(f"bench.py: rank {rank} wants device {local_rank} but only {torch.cuda.device_count()} "
                          f"device(s) are visible")
@@ -329,7 +334,8 @@ def main():
             "units_per_gpu": n,
             "read_len": workloads.READ_LEN,
             "n_adapters": len(spec["adapters"]) + len(spec.get("adapters2", [])),
-            "sharding": f"{world} x contiguous read ranges, no collective on the data path (gloo barriers only)",
+            "sharding": f"{world} x contiguous read ranges, no collective on the data path (gloo barriers only)"
+                        + (" -- OVERSUBSCRIBED TEST RUN, ranks share devices: not a measurement" if args.oversubscribe else ""),
             "per_rank_rate": per_rank,
             "matched_fraction": n_match / n,
             "prefilter_pass_fraction": None if survivors is None else survivors / n,

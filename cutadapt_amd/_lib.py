@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("CAH_LIB_PATH") or os.path.join(_HERE, "libcutadapt_hi
 
 CAH_OK, CAH_EINVAL, CAH_ETYPE, CAH_EHIP, CAH_ENOMEM, CAH_EUNSUPPORTED = 0, 1, 2, 3, 4, 5
 NONE, MATCH, INVALID = 0, 1, 2
+MAX_READ_LEN = 1000000        # CAH_MAX_READ_LEN of include/cutadapt_hip.h
 KIND_ALIGNER, KIND_PREFIX, KIND_SUFFIX, KIND_KMER_ONLY = 0, 1, 2, 3
 MAX_ADAPTER_LEN = 64
 PROF_FILTER, PROF_DP, PROF_COMPARER, PROF_SCAN, PROF_MERGE, PROF_N = 0, 1, 2, 3, 4, 5

@@ -224,8 +224,12 @@ class BatchMatches:
         return [tuple(int(v) for v in self.coords[i]) if self.found[i] else None for i in range(len(self))]
 
 
-def _raise_if_invalid(status: np.ndarray):
+def _raise_if_invalid(status: np.ndarray, batch=None):
+    """status 2 = the kernels refused a read: a byte >= 0x80 (the reference raises the same ValueError,
+    _align.pyx:44-45) or -- a limit of this build, said as such -- a read longer than CAH_MAX_READ_LEN"""
     if (status == _lib.INVALID).any():
+        if batch is not None and batch.n_reads and int(batch.lengths().max().item()) > _lib.MAX_READ_LEN:
+            raise _lib.UnsupportedByHipPath(f"reads longer than {_lib.MAX_READ_LEN} characters are not supported by this build")
         raise ValueError("String must contain only ASCII characters")
 
 
@@ -391,7 +395,7 @@ class SingleAdapter(Adapter, ABC):
     def _batch_matches(self, res, batch) -> BatchMatches:
         """device result of this adapter's fused plan -> host arrays in match coordinates"""
         out6, status, _ = res.cpu()
-        _raise_if_invalid(status)
+        _raise_if_invalid(status, batch)
         found = status == _lib.MATCH
         coords = out6.astype(np.int64)
         if self._reverse_reads:
@@ -967,7 +971,7 @@ class MultipleAdapters(Matchable):
             self._plan = _lib.Plan([a.matcher_spec() for a in self._adapters])
         res = _b.match_batch(self._plan, batch)
         out6, status, best = res.cpu()
-        _raise_if_invalid(status)
+        _raise_if_invalid(status, batch)
         found = status == _lib.MATCH
         coords = out6.astype(np.int64)
         best = np.where(found, best, 0).astype(np.int32)

@@ -510,6 +510,8 @@ static int build_matcher(const cah_adapter_desc& d, int index, CahMatcher& mt,
                 if (!is_ascii(kmer, len)) return fail(CAH_EINVAL, "Only ASCII strings are supported");
                 if (len > 64)
                     return fail(CAH_EINVAL, "%s of length %zu is longer than the maximum of 64.", kmer, len);
+                if (len == 0)        // the reference shifts by -1 here (undefined behaviour, _kmer_finder.pyx:147)
+                    return fail(CAH_EINVAL, "adapter %d: empty k-mer in a search set", index);
                 if (off + len > word_bits) break;
                 kw.init_mask |= 1ull << off;
                 memcpy(word + off, kmer, len);
