@@ -257,8 +257,9 @@ static int plan_on_device(const cah_plan* plan, const PlanDeviceCopy** out) {
 
 // The lean prefilter of a matcher (see CahLeanFilter): possible when every search set is a whole-read
 // set (0, None), a tail set (-L, None) or a head set (start, stop) within the first CAH_LEAN_SPAN
-// characters, every k-mer fits 32 bits and the packing fits the kernel's word count.  Same matches as the generic packing: kmers_present is an OR over k-mers, a
-// k-mer of (-L, None) is found iff it occurs with start >= n - L, which is what a gated start bit says.
+// characters, every k-mer fits 32 bits and the packing fits the largest kernel class.  Same matches as the
+// generic packing: kmers_present is an OR over k-mers, a k-mer of (-L, None) is found iff it occurs with
+// start >= n - L, which is what a gated start bit says.
 static void build_lean_filter(const cah_adapter_desc& d, CahLeanFilter& lf) {
     memset(&lf, 0, sizeof(lf));
     if (d.n_kmer_sets <= 0 || !d.kmer_sets) return;
@@ -282,39 +283,60 @@ static void build_lean_filter(const cah_adapter_desc& d, CahLeanFilter& lf) {
         }
     }
     std::stable_sort(tail.begin(), tail.end(), [](const Item& a, const Item& b) { return a.L > b.L; });
-    int w = -1, used = 32;
+    // words a greedy packing of these k-mers needs when every k-mer takes `extra` more bits
+    auto words_needed = [](const std::vector<Item>& items, int extra) {
+        int w = 0, used = 32;
+        for (const Item& it : items) {
+            if (it.len + extra > 32) return 1 << 20;
+            if (used + it.len + extra > 32) { ++w; used = 0; }
+            used += it.len + extra;
+        }
+        return w;
+    };
+    const int delay = words_needed(lead, CAH_LEAN_DELAY) == words_needed(lead, 0) ? CAH_LEAN_DELAY : 0;
+    int w = -1, used = 32, cap = 0;
+    uint32_t (*mask)[CAH_TABLE_CHARS] = nullptr;
     auto place = [&](const Item& it, int kind) -> bool {
-        if (used + it.len > 32) {
-            if (++w >= CAH_LEAN_WORDS) return false;
+        const int extra = kind == 0 ? delay : 0;
+        if (used + it.len + extra > 32) {
+            if (++w >= cap) return false;
             used = 0;
         }
         const uint32_t start_bit = 1u << used, end_bit = 1u << (used + it.len - 1);
         for (int p = 0; p < it.len; p++)
             for (int qc = 0; qc < CAH_TABLE_CHARS; qc++)
-                if (kmer_chars_match((uint8_t)it.kmer[p], (uint8_t)qc, rwc, qwc)) lf.mask[w][qc] |= 1u << (used + p);
-        lf.found[w] |= end_bit;
+                if (kmer_chars_match((uint8_t)it.kmer[p], (uint8_t)qc, rwc, qwc)) mask[w][qc] |= 1u << (used + p);
         if (kind == 0) {
             lf.lead_init[w] |= start_bit;
+            lf.lead_found[w] |= end_bit;
+            for (int j = 1; j <= delay; j++) {
+                lf.lead_found[w] |= end_bit << j;
+                lf.lead_pass[w] |= end_bit << j;
+            }
         } else if (kind == 1) {
-            for (int dist = 1; dist <= it.L; dist++) lf.init_by_dist[w][dist] |= start_bit;
+            // distance d = n - p from the read end: 1 is the last character; idx = CAH_GATE_ZERO - d
+            for (int dist = 1; dist <= it.L; dist++) lf.gate_init[w][CAH_GATE_ZERO - dist] |= start_bit;
+            lf.gated_found[w] |= end_bit;
             lf.tail_span = std::max(lf.tail_span, it.L);
         } else {
-            for (int p = it.start; p + it.len <= it.stop; p++) lf.head_init_by_pos[w][p] |= start_bit;
-            for (int p = it.start + it.len - 1; p < it.stop; p++) lf.head_found_by_pos[w][p] |= end_bit;
+            for (int p = it.start; p + it.len <= it.stop; p++) lf.gate_init[w][p] |= start_bit;
+            lf.gated_found[w] |= end_bit;
             lf.head_span = std::max(lf.head_span, it.stop);
         }
-        used += it.len;
+        used += it.len + extra;
         return true;
     };
+    cap = CAH_LEAN_MAX_LEAD; mask = lf.lead_mask;
     for (const Item& it : lead) if (!place(it, 0)) return;
     lf.n_lead = w + 1;
-    used = 32;                                                   // every kind starts a new word
+    lf.lead_delay = delay;
+    w = -1; used = 32; cap = CAH_LEAN_MAX_GATED; mask = lf.gated_mask;
     for (const Item& it : tail) if (!place(it, 1)) return;
-    lf.n_tail = w + 1 - lf.n_lead;
-    used = 32;
+    lf.n_tail = w + 1;
+    used = 32;                                                   // head words start a new word
     for (const Item& it : head) if (!place(it, 2)) return;
-    lf.n_words = w + 1;
-    lf.ok = lf.n_words >= 1 ? 1 : 0;
+    lf.n_gated = w + 1;
+    lf.ok = (lf.n_lead + lf.n_gated) >= 1 ? 1 : 0;
 }
 
 #define CAH_LONG_ADAPTER_LIMIT 100000     // sanity bound for the HBM column of k_dp_long (3 x 4 B per row and lane)
@@ -1073,6 +1095,7 @@ static int run_filter(const cah_plan* plan, const PlanDeviceCopy* pd, int32_t ad
     f.queue_keys = d_queue_keys;
     f.batch_flag = nullptr;
     f.lean = nullptr;
+    f.stream_n_lo = 0; f.stream_n_hi = -1;
     if (!t_header_fresh) {
         HIP_TRY(hipMemsetAsync(d_work_counter, 0, sizeof(unsigned long long), s));
         if (d_queue_count) HIP_TRY(hipMemsetAsync(d_queue_count, 0, sizeof(unsigned long long), s));
@@ -1084,7 +1107,8 @@ static int run_filter(const cah_plan* plan, const PlanDeviceCopy* pd, int32_t ad
         // sync; views (explicit lengths) and calls without a check take the ragged variant.
         f.batch_flag = d_lens ? nullptr : d_batch_flag;
         f.lean = pd->d_lean + adapter;
-        HIP_TRY(launch_filter_lean(f, mode, plan->lean[(size_t)adapter].n_words, pd->n_cus, s));
+        HIP_TRY(launch_filter_lean(f, mode, plan->lean[(size_t)adapter].n_lead, plan->lean[(size_t)adapter].n_gated,
+                                   plan->lean[(size_t)adapter].lead_delay, pd->n_cus, s));
         return CAH_OK;
     }
     HIP_TRY(launch_filter(f, mode, mt.narrow_words != 0, pd->n_cus, s));

@@ -65,34 +65,45 @@ struct CahKmerWord {
 // ---------------------------------------------------------------------------------------------
 // Lean prefilter for plans whose search sets are all "whole read" (start 0, stop None), "last L
 // characters" (start -L, stop None) or "characters start..stop" near the 5' end -- everything
-// kmer_heuristic builds for 3', 5' and anywhere adapters.  Tail k-mers of ALL window lengths share words: a k-mer of
-// the set (-L, None) may only START at positions >= n - L, so its start bit is injected only there
-// (a start-bit table indexed by the distance from the read end); no per-lane window bookkeeping and
-// no per-character masks are left.
+// kmer_heuristic builds for 3', 5' and anywhere adapters.
+//   lead words   whole-read k-mers: constant start bits, every k-mer end counts
+//   gated words  tail k-mers (sets (-L, None)) of ALL window lengths share words: a k-mer of (-L, None) may only
+//                START at positions >= n - L, so its start bit is injected only there; head k-mers (sets
+//                (start, stop)) may start at p in [start, stop - len] and count when they END at p in
+//                [start + len - 1, stop - 1].  Both are one mechanism: per word a start-bit gate and a found-bit
+//                gate, tables indexed by idx = p + base(word) -- base = CAH_GATE_ZERO - n for a tail word (the
+//                index runs with the distance from the read end), 0 for a head word (the position itself).
+// No per-lane window bookkeeping and no per-character window masks are left.  The kernels come in classes
+// <NL lead slots, NG gated slots> with every loop bound a compile-time constant; a plan takes the smallest class
+// that holds its words (unused slots have empty masks and closed gates).
 // ---------------------------------------------------------------------------------------------
-#ifndef CAH_LEAN_WORDS
-#define CAH_LEAN_WORDS 8
-#endif
-#define CAH_LEAN_SPAN 64                          // longest tail window the lean kernel takes
+#define CAH_LEAN_MAX_LEAD 3
+#define CAH_LEAN_MAX_GATED 6
+#define CAH_LEAN_SPAN 64                          // longest tail window / largest head stop the lean kernels take
+#define CAH_LEAN_DELAY 3                          // delay bits behind a lead k-mer (see lead_delay)
+#define CAH_GATE_PAD 16                           // a 16-character chunk may begin this far before a window / end after it
+#define CAH_GATE_ZERO (CAH_LEAN_SPAN + CAH_GATE_PAD)     // tail words: index of distance 0 (one past the last character)
+#define CAH_GATE_LEN (CAH_LEAN_SPAN + 2 * CAH_GATE_PAD)  // entries per gate table
 struct CahLeanFilter {
-    int32_t ok;                                   // 1: this matcher can use k_filter_lean
-    int32_t n_words;                              // lead words first, then tail words, then head words
-    int32_t n_lead;
-    int32_t n_tail;
-    int32_t tail_span;                            // longest tail window
-    int32_t head_span;                            // largest stop of a head window
-    uint32_t found[CAH_LEAN_WORDS];               // bit at every k-mer end
-    uint32_t lead_init[CAH_LEAN_WORDS];           // start bits of a lead word (0 for tail words)
-    // start bits of a tail word that are open at distance d = n - p from the read end (d = 1 is the
-    // last character): the k-mers of every set (-L, None) with L >= d; entry 0 and entries beyond the
-    // span are 0
-    uint32_t init_by_dist[CAH_LEAN_WORDS][CAH_LEAN_SPAN + 2];
-    // head words (sets (start, stop) with 0 <= start < stop <= CAH_LEAN_SPAN: what kmer_heuristic builds
-    // for 5' adapters): a k-mer may start at p in [start, stop - len] and is found when it ends at
-    // p in [start + len - 1, stop - 1]; both gates are indexed by the position p, entries past the span 0
-    uint32_t head_init_by_pos[CAH_LEAN_WORDS][CAH_LEAN_SPAN + 2];
-    uint32_t head_found_by_pos[CAH_LEAN_WORDS][CAH_LEAN_SPAN + 2];
-    uint32_t mask[CAH_LEAN_WORDS][CAH_TABLE_CHARS];
+    int32_t ok;                                   // 1: this matcher can use the lean kernels
+    int32_t n_lead, n_gated;                      // words in use
+    int32_t n_tail;                               // gated words [0, n_tail) are tail words, [n_tail, n_gated) head words
+    int32_t tail_span;                            // longest tail window (0: none)
+    int32_t head_span;                            // largest stop of a head window (0: none)
+    // CAH_LEAN_DELAY if every lead k-mer is followed by that many delay bits (they pass every byte, so a k-mer end
+    // stays visible for three more characters and the kernel tests the state once per 4-character group instead of
+    // accumulating it per character; used whenever it does not cost an extra word), else 0
+    int32_t lead_delay;
+    uint32_t lead_init[CAH_LEAN_MAX_LEAD];        // start bits of a lead word
+    uint32_t lead_found[CAH_LEAN_MAX_LEAD];       // bit at every k-mer end (and its delay bits)
+    uint32_t lead_pass[CAH_LEAN_MAX_LEAD];        // the delay bits: set in the mask of every byte value
+    uint32_t gated_found[CAH_LEAN_MAX_GATED];     // bit at every k-mer end
+    uint32_t lead_mask[CAH_LEAN_MAX_LEAD][CAH_TABLE_CHARS];
+    uint32_t gated_mask[CAH_LEAN_MAX_GATED][CAH_TABLE_CHARS];
+    // START-bit gates.  Tail word, idx = CAH_GATE_ZERO - d (d = n - p: 1 is the last character): the start bits of
+    // every set (-L, None) with L >= d.  Head word, idx = p: the start bits of every set (start, stop) with
+    // start <= p <= stop - len.  Everything else is 0 (closed).
+    uint32_t gate_init[CAH_LEAN_MAX_GATED][CAH_GATE_LEN];
 };
 
 // ---------------------------------------------------------------------------------------------

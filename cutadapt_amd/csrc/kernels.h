@@ -24,7 +24,9 @@ struct FilterArgs {
     uint8_t* queue_keys;             // MODE 1: per queue entry, min(first-hit position >> CAH_KEY_SHIFT, 255)
     const unsigned long long* batch_flag;   // k_filter_lean: *batch_flag == 0 <=> all reads have one length (its
                                             // UNIFORM variant works, the ragged one leaves); NULL = no check made
-    const CahLeanFilter* lean;       // k_filter_lean only
+    const CahLeanFilter* lean;       // k_filter_lean / k_filter_stream only
+    int32_t stream_n_lo, stream_n_hi;   // equally long reads of these lengths are k_filter_stream's (an instance
+                                        // takes its own range, the per-lane uniform kernel leaves the union alone)
 };
 
 struct DpArgs {
@@ -103,7 +105,7 @@ struct ScanArgs {
     int64_t dp_cap;
 };
 
-hipError_t launch_filter_lean(const FilterArgs& a, int mode, int n_words, int n_cus, hipStream_t s);
+hipError_t launch_filter_lean(const FilterArgs& a, int mode, int n_lead, int n_gated, int delay, int n_cus, hipStream_t s);
 hipError_t launch_uniform_check(const int64_t* offsets, int64_t n_reads, int64_t max_read_len, unsigned long long* flag,
                                 int n_cus, hipStream_t s);
 hipError_t launch_filter(const FilterArgs& a, int mode, bool narrow_words, int n_cus, hipStream_t s);

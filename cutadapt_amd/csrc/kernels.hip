@@ -54,6 +54,8 @@ __device__ __forceinline__ int cell_score(int p) {
 // and count keys per bin so that the queue can be ordered by approximate adapter position.
 // =============================================================================================
 #include <type_traits>
+#include <algorithm>
+#include <cstdlib>
 
 
 __device__ __forceinline__ void word_window(const int wstart, const int wstop, const int n,
@@ -318,25 +320,362 @@ __global__ void k_uniform_check(const int64_t* offsets, int64_t n_reads, int64_t
 #define LEAN_WAVES 4               // measured: 2 -> 2.56 ms, 3 -> 2.03, 4 -> 1.85, 5 -> 2.01, 8 -> 2.61 (20 M reads)
 #endif
 
-// UNIFORM: every read of the batch has the length offsets[1] - offsets[0] (position, length and tail
-// distances are scalars, reads need no offsets); otherwise the length, the read pointer and the tail
-// distance are per lane (the distance table is then gathered per lane instead of broadcast).
-// NW: word capacity of this instance (register arrays and unrolled loops are sized by it; the launcher
-// picks the smallest instance that holds the plan's words: 5 words run 8 % faster in the 5-word
-// instance than in the 8-word one).
-template <int MODE, bool UNIFORM, int NW>
+// Constant-address-space view of plan tables that no kernel writes: a wave-uniform index then becomes a scalar
+// load (s_load_dword through the scalar cache) instead of a per-lane LDS/VMEM access.
+typedef const __attribute__((address_space(4))) uint32_t* cah_const_u32;
+
+// ---------------------------------------------------------------------------------------------
+// The lean prefilter's word machinery, shared by k_filter_lean (per-lane global loads) and k_filter_stream
+// (reads staged through LDS).  Class <NL, NG>: NL lead slots, NG gated slots, every loop bound a compile-time
+// constant -- straight-line code, no per-word branches (slots a plan does not use have empty masks and closed
+// gates: they cost instructions, never results).
+//   * character masks: 256-entry tables in a STATIC LDS allocation (its address is a compile-time constant that
+//     folds into the ds_read offsets; a table offset is "byte << 2", one SDWA instruction per character; bytes
+//     >= 0x80 find zeros), lead tables first
+//   * gates of equally long reads are scalar loads (wave-uniform index), of ragged batches LDS gathers
+//   * LDS latency is hidden by software pipelining: the masks of the NEXT eight characters' lead words are
+//     requested before the current eight are matched (the kernels were waiting, not computing: 55 % of the wave
+//     cycles in s_waitcnt with one batch of ds_reads per word and chunk)
+// ---------------------------------------------------------------------------------------------
+template <int NL, int NG>
+struct LeanWords {
+    int n_tail, tail_span, head_span;
+    uint32_t l_init[NL], l_init2[NL], l_found[NL], g_found[NG];     // l_init2 = (l_init << 1) | l_init
+    const unsigned char* s_lead;                                 // LDS: lead table(s), then gated table (LeanLayout)
+    const uint32_t* s_ginit;                                     // LDS: the start-bit gates of the NG gated words
+};
+
+// Mask tables in LDS: ONE entry per byte value holds the masks of all lead words (padded to 1, 2 or 4 words), a
+// second table the masks of all gated words (2, 4 or 8 words), so that a character costs one wide LDS read per
+// table (ds_read_b64 / b128 move twice the bytes per LDS cycle of ds_read_b32: the kernels were LDS-bound with
+// one b32 read per word and character).  128 entries: a byte >= 0x80 reads whatever follows the table -- its
+// read is flagged invalid and its matches are never used.
+__host__ __device__ constexpr int lean_pow2(int n) { return n <= 1 ? 1 : (n <= 2 ? 2 : (n <= 4 ? 4 : 8)); }
+__host__ __device__ constexpr int lean_log2(int p) { return p == 1 ? 0 : (p == 2 ? 1 : (p == 4 ? 2 : 3)); }
+// DL > 0 (delay bits, see lean_lead8): the lead words advance TWO characters per step,
+//   R2 = ((R << 2) | I2) & M1[c1] & M[c2],   I2 = (START << 1) | START,   M1[c] = (M[c] << 1) | START
+// (two single steps R' = ((R << 1) | START) & M[c] written out: (x & a) | s == (x | s) & (a | s)), so the lead
+// table comes twice: M1 for the first character of a pair, M for the second.
+template <int DL, int NL, int NG> struct LeanLayout {
+    static constexpr int NLP = lean_pow2(NL), NGP = lean_pow2(NG);
+    static constexpr int LEAD_SHIFT = 2 + lean_log2(NLP), GATED_SHIFT = 2 + lean_log2(NGP);
+    static constexpr int LEAD_TABLE = CAH_TABLE_CHARS * NLP * 4;                 // bytes of one lead table
+    static constexpr int LEAD_BYTES = LEAD_TABLE * (DL > 0 ? 2 : 1);             // M, then M1
+    static constexpr int GATED_BYTES = CAH_TABLE_CHARS * NGP * 4;
+    static constexpr int WORDS = (LEAD_BYTES + GATED_BYTES) / 4;                 // uint32 words of all tables
+};
+
+template <int DL, int NL, int NG>
+__device__ __forceinline__ void lean_tables_to_lds(const CahLeanFilter* lf, uint32_t* s_tab) {
+    typedef LeanLayout<DL, NL, NG> LY;
+    constexpr int LW = CAH_TABLE_CHARS * LY::NLP;                                // words of one lead table
+    for (int i = threadIdx.x; i < LY::WORDS; i += blockDim.x) {
+        uint32_t v = 0;
+        if (i < LY::LEAD_BYTES / 4) {
+            const int j = i % LW, c = j / LY::NLP, w = j % LY::NLP;
+            if (w < NL && w < lf->n_lead) {
+                // the delay bits of a lead word pass EVERY byte (a k-mer end must survive until its group is checked)
+                v = lf->lead_mask[w][c] | lf->lead_pass[w];
+                if (i >= LW) v = (v << 1) | lf->lead_init[w];                    // M1
+            }
+        } else {
+            const int j = i - LY::LEAD_BYTES / 4;
+            const int c = j / LY::NGP, w = j % LY::NGP;
+            if (w < NG && w < lf->n_gated) v = lf->gated_mask[w][c];
+        }
+        s_tab[i] = v;
+    }
+}
+
+template <int NL, int NG>
+__device__ __forceinline__ void lean_words_init(LeanWords<NL, NG>& L, const CahLeanFilter* lf, const uint32_t* s_tab,
+                                                const uint32_t* s_ginit) {
+    L.n_tail = lf->n_tail; L.tail_span = lf->tail_span; L.head_span = lf->head_span;
+    // per-word constants live in registers: inside the loops the compiler would re-load anything read
+    // through a pointer (the queue stores may alias as far as it knows)
+#pragma unroll
+    for (int w = 0; w < NL; ++w) {
+        L.l_init[w] = w < lf->n_lead ? lf->lead_init[w] : 0u;
+        L.l_init2[w] = (L.l_init[w] << 1) | L.l_init[w];
+        L.l_found[w] = w < lf->n_lead ? lf->lead_found[w] : 0u;
+    }
+#pragma unroll
+    for (int w = 0; w < NG; ++w) L.g_found[w] = w < lf->n_gated ? lf->gated_found[w] : 0u;
+    L.s_lead = reinterpret_cast<const unsigned char*>(s_tab);
+    L.s_ginit = s_ginit;
+}
+
+// per-lane state of a read
+template <int NL, int NG>
+struct LeanState {
+    uint32_t RL[NL], accL[NL], RG[NG], accG[NG];
+    uint32_t mk0[8][NL];                                         // lead masks of the current chunk's characters 0..7
+};
+
+// entry offsets ("byte << SHIFT": one SDWA instruction each) of the eight characters of two dwords
+template <int SHIFT>
+__device__ __forceinline__ void lean_addr8(unsigned (&ad)[8], unsigned w0, unsigned w1) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { ad[t] = ((w0 >> (8 * t)) & 0xFFu) << SHIFT; ad[4 + t] = ((w1 >> (8 * t)) & 0xFFu) << SHIFT; }
+}
+
+// the first N words of a table entry with one LDS read (N = 1, 2, 4; 8 = two reads)
+template <int N, int NP>
+__device__ __forceinline__ void lean_read_entry(uint32_t (&out)[N], const unsigned char* p) {
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    if constexpr (NP == 1) {
+        out[0] = *reinterpret_cast<const uint32_t*>(p);
+    } else if constexpr (NP == 2) {
+        const u32x2 v = *reinterpret_cast<const u32x2*>(p);
+        out[0] = v.x;
+        if constexpr (N > 1) out[1] = v.y;
+    } else {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(p);
+        out[0] = v.x;
+        if constexpr (N > 1) out[1] = v.y;
+        if constexpr (N > 2) out[2] = v.z;
+        if constexpr (N > 3) out[3] = v.w;
+        if constexpr (NP == 8 && N > 4) {
+            const u32x4 u = *reinterpret_cast<const u32x4*>(p + 16);
+            out[4] = u.x;
+            if constexpr (N > 5) out[5] = u.y;
+            if constexpr (N > 6) out[6] = u.z;
+            if constexpr (N > 7) out[7] = u.w;
+        }
+    }
+}
+
+template <int DL, int NL, int NG>
+__device__ __forceinline__ void lean_issue_lead(const LeanWords<NL, NG>& L, uint32_t (&mk)[8][NL], const unsigned (&ad)[8]) {
+    typedef LeanLayout<DL, NL, NG> LY;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)                                  // DL > 0: the first character of a pair reads M1
+        lean_read_entry<NL, LY::NLP>(mk[t], L.s_lead + ((DL > 0 && (t & 1) == 0) ? LY::LEAD_TABLE : 0) + ad[t]);
+}
+
+// Eight characters of the lead words; f4 / f8: found bits seen up to the 4th / 8th of them.
+// DL == 0: an accumulator ORs every state (one more instruction per two characters and word).  DL == 3: every
+// k-mer is followed by three delay bits that pass every byte, so a k-mer end is still visible three characters
+// later and the state itself is tested once per 4-character group (l_found then covers end + delay bits).
+template <int DL, int NL, int NG>
+__device__ __forceinline__ void lean_lead8(const LeanWords<NL, NG>& L, LeanState<NL, NG>& S, const uint32_t (&mk)[8][NL],
+                                           uint32_t& f4, uint32_t& f8) {
+    if constexpr (DL > 0) {
+        // two characters per step (see LeanLayout); the state is looked at after every 4-character group
+#pragma unroll
+        for (int t = 0; t < 8; t += 2) {
+#pragma unroll
+            for (int l = 0; l < NL; ++l)
+                S.RL[l] = ((S.RL[l] << 2) | L.l_init2[l]) & mk[t][l] & mk[t + 1][l];
+            if (t == 2) {
+#pragma unroll
+                for (int l = 0; l < NL; ++l) f4 |= S.RL[l] & L.l_found[l];
+            }
+        }
+#pragma unroll
+        for (int l = 0; l < NL; ++l) f8 |= S.RL[l] & L.l_found[l];
+    } else {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+#pragma unroll
+            for (int l = 0; l < NL; ++l) {
+                unsigned dbl;
+                asm("v_add_u32 %0, %1, %1" : "=v"(dbl) : "v"(S.RL[l]));      // R + R: the compiler makes it a 4-cycle shift
+                S.RL[l] = (dbl | L.l_init[l]) & mk[t][l];
+                S.accL[l] |= S.RL[l];
+            }
+            if (t == 3) {
+#pragma unroll
+                for (int l = 0; l < NL; ++l) f4 |= S.accL[l] & L.l_found[l];
+            }
+        }
+#pragma unroll
+        for (int l = 0; l < NL; ++l) f8 |= S.accL[l] & L.l_found[l];
+    }
+}
+
+// Eight characters (positions p0 .. p0+7 of a read of length n) of the gated words, four at a time (the masks of
+// four characters x NG words and their start-bit gates are requested together).  Only the START bits are gated: a
+// k-mer that started inside its gate ends inside its window (tail sets: before the read's end, past which
+// characters are NUL; head sets: the gate closes len - 1 before `stop`), and an end bit can only leak into the next
+// k-mer's start after a genuine end has been recorded -- so every recorded end counts.
+// The gates sit in LDS.  Equally long reads index them wave-uniformly: four consecutive gates of a word are two
+// broadcast ds_read2_b32 (scalar loads would share the lgkmcnt counter with the LDS reads and return out of
+// order, so waiting for them drains every prefetched mask; 48 gates per chunk do not fit the SGPRs either).
+// Ragged batches gather them per lane.
+template <bool UNIFORM, int DL, int NL, int NG>
+__device__ __forceinline__ void lean_gated8(const LeanWords<NL, NG>& L, LeanState<NL, NG>& S, const unsigned (&ad)[8],
+                                            const int p0, const int n, uint32_t& f4, uint32_t& f8) {
+    // gate index: tail words run with the distance from the read end, head words with the position
+    const int tail_base = CAH_GATE_ZERO - n + p0;              // scalar if UNIFORM, per lane otherwise
+    // equally long reads: clamped once per call -- below CAH_GATE_PAD a tail table is constant (closed), from
+    // CAH_LEAN_SPAN on a head table is, so the eight indices stay equivalent
+    const int tail_u = max(tail_base, 0), head_u = min(p0, CAH_GATE_LEN - 8);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        uint32_t mk[4][NG], gt[4][NG];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            lean_read_entry<NG, LeanLayout<DL, NL, NG>::NGP>(mk[t], L.s_lead + LeanLayout<DL, NL, NG>::LEAD_BYTES + ad[4 * h + t]);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if constexpr (UNIFORM) {
+                const uint32_t* gp = L.s_ginit + g * CAH_GATE_LEN + (g < L.n_tail ? tail_u : head_u) + 4 * h;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) gt[t][g] = gp[t];
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int it = min(max(tail_base + 4 * h + t, 0), CAH_GATE_LEN - 1);
+                    const int ih = min(p0 + 4 * h + t, CAH_GATE_LEN - 1);
+                    gt[t][g] = L.s_ginit[g * CAH_GATE_LEN + (g < L.n_tail ? it : ih)];
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                unsigned dbl;
+                asm("v_add_u32 %0, %1, %1" : "=v"(dbl) : "v"(S.RG[g]));
+                S.RG[g] = (dbl | gt[t][g]) & mk[t][g];
+                S.accG[g] |= S.RG[g];
+            }
+        }
+        if (h == 0) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) f4 |= S.accG[g] & L.g_found[g];
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) f8 |= S.accG[g] & L.g_found[g];
+}
+
+// One chunk (positions pos .. pos+15 of a read of length n; characters past a read's end are NUL).  `nxt` is the
+// following chunk (its first eight characters' lead masks are requested here).  Every lane runs the words
+// (wave-uniform control flow only: a lane that is done or idle computes values nobody reads).  GATED: the chunk
+// may touch a window of the gated words (the callers run the chunks in front of / between the windows with
+// GATED = false: straight-line code, nothing but lead words).  Returns the found bits seen so far; gg[i]: the same
+// after the chunk's 4-character groups 0..2.
+template <bool UNIFORM, bool GATED, int DL, int NL, int NG, class NextFn>
+__device__ __forceinline__ uint32_t lean_chunk(const LeanWords<NL, NG>& L, LeanState<NL, NG>& S, const Chunk& cur,
+                                               NextFn next_chunk, Chunk& nxt, const int pos, const int n,
+                                               uint32_t (&gg)[3]) {
+    typedef LeanLayout<DL, NL, NG> LY;
+    uint32_t f0 = 0, f1 = 0, f2 = 0, f3 = 0;
+    unsigned ad_hi[8];
+    uint32_t mk1[8][NL];
+    lean_addr8<LY::LEAD_SHIFT>(ad_hi, cur.w[2], cur.w[3]);
+    lean_issue_lead<DL, NL, NG>(L, mk1, ad_hi);
+    lean_lead8<DL, NL, NG>(L, S, S.mk0, f0, f1);
+    if constexpr (GATED) {
+        unsigned ad_g[8];
+        lean_addr8<LY::GATED_SHIFT>(ad_g, cur.w[0], cur.w[1]);
+        lean_gated8<UNIFORM, DL, NL, NG>(L, S, ad_g, pos, n, f0, f1);
+    }
+    f1 |= f0;
+    nxt = next_chunk();                                          // requested earlier by the caller, needed from here on
+    {
+        unsigned ad_n[8];
+        lean_addr8<LY::LEAD_SHIFT>(ad_n, nxt.w[0], nxt.w[1]);
+        lean_issue_lead<DL, NL, NG>(L, S.mk0, ad_n);
+    }
+    f2 = f1; f3 = f1;
+    lean_lead8<DL, NL, NG>(L, S, mk1, f2, f3);
+    if constexpr (GATED) {
+        unsigned ad_g[8];
+        lean_addr8<LY::GATED_SHIFT>(ad_g, cur.w[2], cur.w[3]);
+        lean_gated8<UNIFORM, DL, NL, NG>(L, S, ad_g, pos + 8, n, f2, f3);
+    }
+    f3 |= f2;
+    gg[0] = f0; gg[1] = f1; gg[2] = f2;
+    return f3;
+}
+
+// Is the chunk at `pos` (16 characters) clear of every window of the gated words?  (tail windows: the last
+// tail_span characters of a read of length n; head windows: the first head_span.)  Wave-uniform.  Once a chunk
+// touches a tail window every later chunk does, and only the first chunks touch a head window.
+template <bool UNIFORM, int NL, int NG>
+__device__ __forceinline__ bool lean_chunk_ungated(const LeanWords<NL, NG>& L, int pos, int n) {
+    const bool tail = L.tail_span > 0 && (UNIFORM ? pos + 16 > n - L.tail_span : __any(pos + 16 > n - L.tail_span));
+    return !tail && pos >= L.head_span;
+}
+
+// The survivors of a tile, staged in LDS with their keys, leave as one key-ordered run: exclusive scan of the
+// 256-bin histogram (one thread per bin), one atomic for the run, counting sort into the global queue.
+// blockDim.x >= 256 == CAH_QUEUE_BINS (a multiple of 64).  s_scratch: 8 words.
+__device__ __forceinline__ void flush_tile_queue(const FilterArgs& a, int64_t tile_base, const uint16_t* s_idx,
+                                                 const uint8_t* s_key, unsigned* s_hist, unsigned* s_cursor,
+                                                 const unsigned count, unsigned* s_scratch,
+                                                 unsigned long long& s_qbase) {
+    const int lane = wave_lane(), wave = threadIdx.x >> 6;
+    const bool bin = threadIdx.x < CAH_QUEUE_BINS;
+    const unsigned c = bin ? s_hist[threadIdx.x] : 0u;
+    unsigned incl = c;
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        const unsigned o = __shfl_up(incl, d, WAVE);
+        if (lane >= d) incl += o;
+    }
+    if (bin && lane == WAVE - 1) s_scratch[wave] = incl;
+    if (threadIdx.x == 0) s_qbase = count ? atomicAdd(a.queue_count, (unsigned long long)count) : 0ull;
+    __syncthreads();
+    if (bin) {
+        unsigned before = 0;
+#pragma unroll
+        for (int w = 0; w < 3; ++w) if (w < wave) before += s_scratch[w];
+        s_hist[threadIdx.x] = before + incl - c;
+    }
+    __syncthreads();
+    const unsigned long long qbase = s_qbase;
+    for (unsigned e = threadIdx.x; e < count; e += blockDim.x) {
+        const unsigned key = s_key[e];
+        const unsigned p = s_hist[key] + atomicAdd(&s_cursor[key], 1u);
+        a.queue[qbase + p] = (int32_t)(tile_base + s_idx[e]);
+        a.queue_keys[qbase + p] = (uint8_t)key;
+    }
+}
+
+// a read's verdict: present[] (mode 0: a.present is set) or a slot of the tile's survivor staging (mode 1)
+__device__ __forceinline__ void lean_emit(const FilterArgs& a, int64_t r, int64_t tile_base, bool valid, bool hit,
+                                          bool invalid, int hit_pos, uint16_t* s_idx, uint8_t* s_key,
+                                          unsigned* s_hist, unsigned& s_count) {
+    if (a.present) {
+        if (valid) a.present[r] = invalid ? (uint8_t)2 : (hit ? (uint8_t)1 : (uint8_t)0);
+    } else {
+        if (valid && invalid) a.status[r] = 2;
+        const bool push = valid && hit && !invalid;
+        const unsigned long long bal = __ballot(push);
+        if (bal) {
+            const int lane = wave_lane();
+            unsigned slot = 0;
+            if (lane == 0) slot = atomicAdd(&s_count, (unsigned)__popcll(bal));
+            slot = __builtin_amdgcn_readfirstlane(slot);
+            if (push) {
+                const int e = (int)slot + __popcll(bal & ((1ull << lane) - 1ull));
+                const int key = min(hit_pos >> CAH_KEY_SHIFT, CAH_QUEUE_BINS - 1);
+                s_idx[e] = (uint16_t)(r - tile_base);
+                s_key[e] = (uint8_t)key;
+                atomicAdd(&s_hist[key], 1u);
+            }
+        }
+    }
+}
+
+// UNIFORM: every read of the batch has the length offsets[1] - offsets[0] (position, length and gate
+// indices are scalars, reads need no offsets); otherwise the length, the read pointer and the tail words'
+// gate index are per lane (the gate tables are then gathered from LDS instead of loaded by the scalar unit).
+// NL, NG: slot capacities of this instance (the launcher picks the smallest class that holds the plan's words).
+template <bool UNIFORM, int DL, int NL, int NG>
 __global__ __launch_bounds__(256, LEAN_WAVES) void k_filter_lean(FilterArgs a) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_tab[LeanLayout<DL, NL, NG>::WORDS];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // the batch check decides which variant works (no check was made for views: they count as ragged)
     if (a.batch_flag ? (*a.batch_flag != 0ull) == UNIFORM : UNIFORM) return;
     const CahLeanFilter* lf = a.lean;
-    const int n_words = lf->n_words, n_lead = lf->n_lead, tail_span = lf->tail_span;
-    const int n_tail_end = lf->n_lead + lf->n_tail, head_span = lf->head_span;     // head words: [n_tail_end, n_words)
-    uint32_t* s_mask = reinterpret_cast<uint32_t*>(smem);
-    unsigned char* sp = smem + (size_t)CAH_LEAN_WORDS * CAH_TABLE_CHARS * sizeof(uint32_t);
-    uint32_t* s_dist = reinterpret_cast<uint32_t*>(sp);          sp += (size_t)CAH_LEAN_WORDS * (CAH_LEAN_SPAN + 2) * sizeof(uint32_t);
-    uint32_t* s_hinit = reinterpret_cast<uint32_t*>(sp);         sp += (size_t)CAH_LEAN_WORDS * (CAH_LEAN_SPAN + 2) * sizeof(uint32_t);
-    uint32_t* s_hfound = reinterpret_cast<uint32_t*>(sp);        sp += (size_t)CAH_LEAN_WORDS * (CAH_LEAN_SPAN + 2) * sizeof(uint32_t);
+    unsigned char* sp = smem;
+    uint32_t* s_ginit = reinterpret_cast<uint32_t*>(sp);         sp += (size_t)CAH_LEAN_MAX_GATED * CAH_GATE_LEN * sizeof(uint32_t);
     uint16_t* s_idx = reinterpret_cast<uint16_t*>(sp);           sp += LEAN_TILE * sizeof(uint16_t);
     uint8_t* s_key = sp;                                         sp += LEAN_TILE;
     unsigned* s_hist = reinterpret_cast<unsigned*>(sp);          sp += CAH_QUEUE_BINS * sizeof(unsigned);
@@ -344,20 +683,16 @@ __global__ __launch_bounds__(256, LEAN_WAVES) void k_filter_lean(FilterArgs a) {
     unsigned long long& s_qbase = *reinterpret_cast<unsigned long long*>(sp);
     long long& s_tile = *reinterpret_cast<long long*>(sp + 8);
     unsigned& s_count = *reinterpret_cast<unsigned*>(sp + 16);
-    for (int i = threadIdx.x; i < n_words * CAH_TABLE_CHARS; i += blockDim.x)
-        s_mask[i] = lf->mask[i / CAH_TABLE_CHARS][i % CAH_TABLE_CHARS];
-    for (int i = threadIdx.x; i < CAH_LEAN_WORDS * (CAH_LEAN_SPAN + 2); i += blockDim.x) {
-        s_dist[i] = lf->init_by_dist[i / (CAH_LEAN_SPAN + 2)][i % (CAH_LEAN_SPAN + 2)];
-        s_hinit[i] = lf->head_init_by_pos[i / (CAH_LEAN_SPAN + 2)][i % (CAH_LEAN_SPAN + 2)];
-        s_hfound[i] = lf->head_found_by_pos[i / (CAH_LEAN_SPAN + 2)][i % (CAH_LEAN_SPAN + 2)];
-    }
-    // per-word constants live in registers: inside the loops the compiler would re-load anything read
-    // through a pointer (the queue stores may alias as far as it knows)
-    uint32_t c_init[NW], c_found[NW];
-#pragma unroll
-    for (int w = 0; w < NW; ++w) { c_init[w] = lf->lead_init[w]; c_found[w] = lf->found[w]; }
+    unsigned* s_scratch = reinterpret_cast<unsigned*>(sp + 32);
     const int64_t first = UNIFORM ? a.offsets[0] : 0;
     const int n_uniform = UNIFORM ? (int)(a.offsets[1] - first) : 0;   // every read has this length
+    // equally long short reads are the streaming kernel's (k_filter_stream)
+    if (UNIFORM && n_uniform >= a.stream_n_lo && n_uniform <= a.stream_n_hi && a.n_reads * (int64_t)n_uniform >= 16) return;
+    lean_tables_to_lds<DL, NL, NG>(lf, s_tab);
+    for (int i = threadIdx.x; i < NG * CAH_GATE_LEN; i += blockDim.x)
+        s_ginit[i] = lf->gate_init[i / CAH_GATE_LEN][i % CAH_GATE_LEN];
+    LeanWords<NL, NG> L;
+    lean_words_init<NL, NG>(L, lf, s_tab, s_ginit);
     const int lane = wave_lane();
     const int wave = threadIdx.x >> 6;
 
@@ -397,131 +732,279 @@ __global__ __launch_bounds__(256, LEAN_WAVES) void k_filter_lean(FilterArgs a) {
             bool hit = false;
             int hit_pos = 0;
             unsigned seen = 0;
-            uint32_t R[NW], acc[NW];
+            LeanState<NL, NG> S;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) { R[w] = 0; acc[w] = 0; }
+            for (int w = 0; w < NL; ++w) { S.RL[w] = 0; S.accL[w] = 0; }
+#pragma unroll
+            for (int w = 0; w < NG; ++w) { S.RG[w] = 0; S.accG[w] = 0; }
 
+            // two chunks are in flight ahead of the one being matched (the next one's first masks are requested
+            // half a chunk early)
             Chunk cur = load_chunk(q, 0, n, valid ? n : 0);
-            for (int pos = 0; pos < n_max; pos += 16) {              // pos is wave-uniform
-                const bool live = valid && !hit && (UNIFORM || pos < n);
-                if (!__any(live)) break;
-                const Chunk nxt = load_chunk(q, pos + 16, n, live ? n : 0);
-                seen |= cur.w[0] | cur.w[1] | cur.w[2] | cur.w[3];
-                uint32_t lead_found = 0, tail_found = 0;
-                uint32_t gg[3] = {0, 0, 0};
-                if (live) {
-                    // ---- whole-read words: constant start bits ----------------------------------
-#pragma unroll
-                    for (int w = 0; w < NW; ++w) {
-                        if (w >= n_lead) break;                      // wave-uniform
-                        const uint32_t init = c_init[w], fnd = c_found[w];
-                        const uint32_t* tbl = s_mask + w * CAH_TABLE_CHARS;
-#pragma unroll
-                        for (int t = 0; t < 16; ++t) {
-                            const uint32_t mk = tbl[chunk_byte(cur, t) & (CAH_TABLE_CHARS - 1)];
-                            unsigned dbl;
-                            asm("v_add_u32 %0, %1, %1" : "=v"(dbl) : "v"(R[w]));
-                            R[w] = (dbl | init) & mk;
-                            acc[w] |= R[w];
-                            if ((t & 3) == 3 && t < 15) gg[t >> 2] |= acc[w] & fnd;
-                        }
-                        lead_found |= acc[w] & fnd;
-                    }
-                    // ---- tail words: a k-mer of the set (-L, None) may start at p >= n - L ----------
-                    if (UNIFORM ? pos + 16 > n - tail_span : __any(pos + 16 > n - tail_span)) {
-#pragma unroll
-                        for (int w = 0; w < NW; ++w) {
-                            if (w < n_lead) continue;
-                            if (w >= n_tail_end) break;
-                            const uint32_t fnd = c_found[w];
-                            const uint32_t* tbl = s_mask + w * CAH_TABLE_CHARS;
-                            const uint32_t* dist = s_dist + w * (CAH_LEAN_SPAN + 2);
-#pragma unroll
-                            for (int t = 0; t < 16; ++t) {
-                                // start bits open at this character's distance from the read end (a wave-uniform
-                                // index if UNIFORM; characters past the end are NUL and match nothing)
-                                const int d = min(max(n - (pos + t), 0), CAH_LEAN_SPAN + 1);
-                                const uint32_t init = dist[d];
-                                const uint32_t mk = tbl[chunk_byte(cur, t) & (CAH_TABLE_CHARS - 1)];
-                                unsigned dbl;
-                                asm("v_add_u32 %0, %1, %1" : "=v"(dbl) : "v"(R[w]));
-                                R[w] = (dbl | init) & mk;
-                                acc[w] |= R[w];
-                                if ((t & 3) == 3 && t < 15) gg[t >> 2] |= acc[w] & fnd;
-                            }
-                            tail_found |= acc[w] & fnd;
-                        }
-                    }
-                    // ---- head words: windows near the 5' end, gated by the (wave-uniform) position ------
-                    if (pos < head_span) {
-#pragma unroll
-                        for (int w = 0; w < NW; ++w) {
-                            if (w < n_tail_end) continue;
-                            if (w >= n_words) break;
-                            const uint32_t* tbl = s_mask + w * CAH_TABLE_CHARS;
-                            const uint32_t* hin = s_hinit + w * (CAH_LEAN_SPAN + 2);
-                            const uint32_t* hfo = s_hfound + w * (CAH_LEAN_SPAN + 2);
-#pragma unroll
-                            for (int t = 0; t < 16; ++t) {
-                                const int pidx = min(pos + t, CAH_LEAN_SPAN + 1);
-                                const uint32_t mk = tbl[chunk_byte(cur, t) & (CAH_TABLE_CHARS - 1)];
-                                unsigned dbl;
-                                asm("v_add_u32 %0, %1, %1" : "=v"(dbl) : "v"(R[w]));
-                                R[w] = (dbl | hin[pidx]) & mk;
-                                acc[w] |= R[w] & hfo[pidx];          // only k-mers that end inside their window count
-                                if ((t & 3) == 3 && t < 15) gg[t >> 2] |= acc[w];
-                            }
-                            tail_found |= acc[w];
-                        }
-                    }
-                    if ((lead_found | tail_found) != 0) {
-                        // key semantics as in k_filter: the 4-column group of the first hit of any word (no
-                        // whole-read k-mer ended before it: those words were scanned through this chunk)
-                        hit = true;
-                        hit_pos = pos + (gg[0] ? 0 : gg[1] ? 4 : gg[2] ? 8 : 12);
-                    }
-                }
-                cur = nxt;
+            Chunk nxt = load_chunk(q, 16, n, valid ? n : 0);
+            {
+                unsigned ad[8];
+                lean_addr8<LeanLayout<DL, NL, NG>::LEAD_SHIFT>(ad, cur.w[0], cur.w[1]);
+                lean_issue_lead<DL, NL, NG>(L, S.mk0, ad);
             }
+            // one chunk; false: every lane is done
+            auto step = [&](auto gated, int pos) -> bool {
+                const bool live = valid && !hit && (UNIFORM || pos < n);
+                if (!__any(live)) return false;
+                const Chunk nx2 = load_chunk(q, pos + 32, n, live ? n : 0);
+                seen |= cur.w[0] | cur.w[1] | cur.w[2] | cur.w[3];
+                uint32_t gg[3];
+                Chunk got;
+                const uint32_t found = lean_chunk<UNIFORM, decltype(gated)::value, DL, NL, NG>(
+                    L, S, cur, [&]() { return nxt; }, got, pos, n, gg);
+                if (live && found != 0) {
+                    // key semantics as in k_filter: the 4-column group of the first hit of any word (no
+                    // whole-read k-mer ended before it: those words were scanned through this chunk)
+                    hit = true;
+                    hit_pos = pos + (gg[0] ? 0 : gg[1] ? 4 : gg[2] ? 8 : 12);
+                }
+                cur = got;
+                nxt = nx2;
+                return true;
+            };
+            // chunks at the head windows, the stretch without windows (lead words only), chunks at the tail windows
+            int pos = 0;                                             // wave-uniform
+            bool more = true;
+            for (; more && pos < n_max && pos < L.head_span; pos += 16) more = step(std::true_type{}, pos);
+            for (; more && pos < n_max && lean_chunk_ungated<UNIFORM, NL, NG>(L, pos, n); pos += 16)
+                more = step(std::false_type{}, pos);
+            for (; more && pos < n_max; pos += 16) more = step(std::true_type{}, pos);
             const bool invalid = (seen & 0x80808080u) != 0 || too_long;
+            lean_emit(a, r, tile_base, valid, hit, invalid, hit_pos, s_idx, s_key, s_hist, s_count);
+        }
 
-            if (MODE == 0) {
-                if (valid) a.present[r] = invalid ? (uint8_t)2 : (hit ? (uint8_t)1 : (uint8_t)0);
-            } else {
-                if (valid && invalid) a.status[r] = 2;
-                const bool push = valid && hit && !invalid;
-                const unsigned long long bal = __ballot(push);
-                if (bal) {
-                    unsigned slot = 0;
-                    if (lane == 0) slot = atomicAdd(&s_count, (unsigned)__popcll(bal));
-                    slot = __builtin_amdgcn_readfirstlane(slot);
-                    if (push) {
-                        const int e = (int)slot + __popcll(bal & ((1ull << lane) - 1ull));
-                        const int key = min(hit_pos >> CAH_KEY_SHIFT, CAH_QUEUE_BINS - 1);
-                        s_idx[e] = (uint16_t)(r - tile_base);
-                        s_key[e] = (uint8_t)key;
-                        atomicAdd(&s_hist[key], 1u);
-                    }
+        if (!a.present) {
+            __syncthreads();
+            flush_tile_queue(a, tile_base, s_idx, s_key, s_hist, s_cursor, s_count, s_scratch, s_qbase);
+        }
+    }
+}
+
+// =============================================================================================
+// k_filter_stream: the lean prefilter for batches of equally long SHORT reads (the sequencer's output; BASELINE
+// C2-C5).  A wave's 64 reads are one contiguous piece of HBM (64 * n bytes).  k_filter_lean fetches them with one
+// 16-byte load per lane and chunk, so every cache line is touched by ~9 separate loads and the kernel lives on
+// all waves' lines staying in L2 (4.9 MB per XCD at 4 waves/SIMD against its 4 MB: measured, removing all
+// matching work makes that kernel SLOWER).  Here the wave copies its piece with coalesced loads -- lane i of
+// load k takes 16-byte unit u = 64 k + i of the piece, i.e. unit u % U of read u / U (U = units per read), so
+// every cache line crosses the memory system once -- into its own LDS slot, one 16-byte aligned row per read
+// (row stride: an odd number of units, which spreads the lanes' ds_read_b128 over all banks), and every lane
+// then reads its characters with one aligned ds_read_b128 per chunk.  The copy of the NEXT piece is in flight in
+// NU x 4 VGPRs while the current one is matched.  Work is dealt statically (tiles of STREAM_TILE reads
+// round-robin over the blocks: equal reads, equal work), which is what lets a wave know its next piece.  Same
+// words, same outputs and queue keys as k_filter_lean.
+// NU: row stride in 16-byte units (odd); UM <= NU: units of a read the instance copies, i.e. it takes reads of up
+// to 16 * UM characters (the copy registers are sized by UM).
+// =============================================================================================
+// One block of 12 waves per CU (3 per SIMD: the LDS slots allow no more): a single block shares ONE survivor
+// staging area, which leaves room for tiles of 6144 reads -- the DP behind the queue wants long key-ordered runs
+// (with 1024-read tiles of three 4-wave blocks, scan + DP lost 1.1 ms per 100 M reads of lock-step efficiency).
+#ifndef STREAM_BLOCK_WAVES
+#define STREAM_BLOCK_WAVES 12
+#endif
+#define STREAM_WAVES 3             // waves per SIMD
+// reads per block tile (survivor staging: 3 B each; a multiple of 64 * 12); the classes with six gated words have
+// larger mask and gate tables and take a smaller tile to stay inside the CU's 160 KiB
+__host__ __device__ constexpr int stream_tile(int ng) { return ng <= 3 ? 6144 : 4608; }
+__host__ __device__ constexpr int stream_piece_bytes(int nu) { return WAVE * nu * 16; }
+__host__ __device__ constexpr int stream_max_len(int um) { return um * 16; }
+
+template <int DL, int NL, int NG, int NU, int UM>
+__global__ __launch_bounds__(STREAM_BLOCK_WAVES * WAVE, STREAM_WAVES) void k_filter_stream(FilterArgs a) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_tab[LeanLayout<DL, NL, NG>::WORDS];
+    __shared__ __attribute__((aligned(16))) unsigned char s_piece[STREAM_BLOCK_WAVES * stream_piece_bytes(NU)];
+    __shared__ uint32_t s_gate[NG * CAH_GATE_LEN];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int TILE = stream_tile(NG), SUBS = TILE / WAVE / STREAM_BLOCK_WAVES;
+    if (a.batch_flag ? *a.batch_flag != 0ull : false) return;           // ragged batch: k_filter_lean<false, ..>
+    const CahLeanFilter* lf = a.lean;
+    const int64_t first = a.offsets[0];
+    const int n = (int)(a.offsets[1] - first);                          // every read has this length
+    if (n < a.stream_n_lo || n > a.stream_n_hi) return;                 // another instance's (or k_filter_lean's) batch
+    const int64_t total = a.n_reads * (int64_t)n;                       // bytes of the batch
+    if (total < 16) return;                                             // k_filter_lean<true, ..> takes it (same test there)
+    unsigned char* sp = smem;
+    uint16_t* s_idx = reinterpret_cast<uint16_t*>(sp);           sp += TILE * sizeof(uint16_t);
+    uint8_t* s_key = sp;                                         sp += TILE;
+    unsigned* s_hist = reinterpret_cast<unsigned*>(sp);          sp += CAH_QUEUE_BINS * sizeof(unsigned);
+    unsigned* s_cursor = reinterpret_cast<unsigned*>(sp);        sp += CAH_QUEUE_BINS * sizeof(unsigned);
+    unsigned long long& s_qbase = *reinterpret_cast<unsigned long long*>(sp);
+    unsigned& s_count = *reinterpret_cast<unsigned*>(sp + 16);
+    unsigned* s_scratch = reinterpret_cast<unsigned*>(sp + 32);
+    lean_tables_to_lds<DL, NL, NG>(lf, s_tab);
+    for (int i = threadIdx.x; i < NG * CAH_GATE_LEN; i += blockDim.x)
+        s_gate[i] = lf->gate_init[i / CAH_GATE_LEN][i % CAH_GATE_LEN];
+    LeanWords<NL, NG> L;
+    lean_words_init<NL, NG>(L, lf, s_tab, s_gate);
+    const int lane = wave_lane();
+    const int wave = threadIdx.x >> 6;
+    unsigned char* const piece = s_piece + wave * stream_piece_bytes(NU);   // this wave's LDS slot
+    const unsigned char* const row = piece + lane * (NU * 16);             // this lane's read in it
+
+    // Copy plan of a lane: load k takes unit u = 64 k + lane of the piece = unit c of read r, r = u / U, c = u % U
+    // (U = ceil(n / 16) units per read; the last unit of a read runs into the next read -- masked when used).
+    // goff: its byte offset from the piece's first byte in HBM, (r * NU + c) * 16: in the LDS slot.  u / U as a multiply
+    // (exact for u < 64 * 16, U <= 16: checked exhaustively by tests/test_host_logic.py).
+    const int U = (n + 15) >> 4;                                        // <= UM
+    const unsigned magic = U ? (65536u + (unsigned)U - 1u) / (unsigned)U : 0u;
+    // Both are recomputed where they are used (a handful of instructions per unit and piece; keeping them would
+    // cost 2 x UM registers that the kernel does not have).
+    auto unit_rc = [&](int k, unsigned& r, unsigned& c) {
+        unsigned ln = (unsigned)lane;
+        asm volatile("" : "+v"(ln));                                    // keeps the compiler from hoisting (and keeping) the results
+        const unsigned u = (unsigned)(k * WAVE) + ln;
+        r = __umul24(u, magic) >> 16;                                   // 24-bit multiplies: u < 2^10, magic <= 2^16
+        c = u - __umul24(r, (unsigned)U);
+    };
+    // piece `it` of this wave: sub-tile wave + 12 * (it % SUBS) of tile blockIdx.x + (it / SUBS) * gridDim.x
+    auto piece_base = [&](int64_t it) -> int64_t {
+        return ((int64_t)blockIdx.x + (it / SUBS) * (int64_t)gridDim.x) * TILE +
+               ((int64_t)wave + STREAM_BLOCK_WAVES * (it % SUBS)) * WAVE;
+    };
+    // the units of the piece starting at read `base`, into VGPRs.  Nothing outside the batch is touched: a unit
+    // that would run past the batch's last byte is fetched as the 16 bytes that END there and shifted down.
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 pre[UM];
+    const uint8_t* const batch0 = a.seqs + first;
+    auto prefetch = [&](int64_t base) {
+        const int64_t left = a.n_reads - base;                          // wave-uniform
+        const int64_t pbyte = base * (int64_t)n;                        // the piece's first byte within the batch
+        const uint8_t* const src = batch0 + pbyte;
+        if (left >= WAVE && pbyte + (int64_t)WAVE * n + 16 <= total) {
+            // a whole piece with 16 bytes of the batch behind it (all but the last pieces): unit u = 64 k + lane
+            // exists iff k < U, no lane needs a check
+#pragma unroll
+            for (int k = 0; k < UM; ++k) {
+                pre[k] = (u32x4)(0u);
+                if (k < U) {
+                    unsigned ur, uc;
+                    unit_rc(k, ur, uc);
+                    Unaligned16 v;
+                    __builtin_memcpy(&v, src + (__umul24(ur, (unsigned)n) + 16u * uc), 16);
+                    pre[k] = (u32x4){v.w[0], v.w[1], v.w[2], v.w[3]};
+                }
+            }
+            return;
+        }
+        const int units = left <= 0 ? 0 : (int)(left < WAVE ? left : (int64_t)WAVE) * U;
+#pragma unroll
+        for (int k = 0; k < UM; ++k) {
+            pre[k] = (u32x4)(0u);
+            if (k * WAVE + lane < units) {
+                unsigned ur, uc;
+                unit_rc(k, ur, uc);
+                const unsigned goff = __umul24(ur, (unsigned)n) + 16u * uc;
+                if (pbyte + goff + 16 <= total) {
+                    Unaligned16 v;
+                    __builtin_memcpy(&v, src + goff, 16);
+                    pre[k] = (u32x4){v.w[0], v.w[1], v.w[2], v.w[3]};
+                } else {
+                    Unaligned16 v;
+                    __builtin_memcpy(&v, batch0 + (total - 16), 16);
+                    const int sft = (int)(pbyte + goff + 16 - total);   // 1..15 bytes to drop
+                    const int dw = sft >> 2, sh = (sft & 3) * 8;
+                    unsigned x0 = v.w[0], x1 = v.w[1], x2 = v.w[2], x3 = v.w[3];
+                    if (dw >= 2) { x0 = x2; x1 = x3; x2 = 0; x3 = 0; }
+                    if (dw & 1) { x0 = x1; x1 = x2; x2 = x3; x3 = 0; }
+                    pre[k] = (u32x4){(unsigned)((((unsigned long long)x1 << 32) | x0) >> sh),
+                                     (unsigned)((((unsigned long long)x2 << 32) | x1) >> sh),
+                                     (unsigned)((((unsigned long long)x3 << 32) | x2) >> sh), x3 >> sh};
                 }
             }
         }
+    };
+    // the 16 characters at positions pos .. pos+15 of this lane's read; characters past its end come back as NUL
+    auto finish = [&](u32x4 v, int pos) -> Chunk {
+        Chunk c;
+        c.w[0] = v.x; c.w[1] = v.y; c.w[2] = v.z; c.w[3] = v.w;
+        if (pos + 16 > n) {
+            // the last chunk (or none at all): what follows in the row is the next read's or stale
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int keep = n - pos - 4 * i;                       // characters of dword i inside the read
+                c.w[i] &= keep >= 4 ? 0xFFFFFFFFu : (keep <= 0 ? 0u : ((1u << (8 * keep)) - 1u));
+            }
+        }
+        return c;
+    };
 
-        if (MODE == 1) {
-            __syncthreads();
-            const unsigned count = s_count;
-            if (threadIdx.x == 0) {
-                unsigned run = 0;
-                for (int bkt = 0; bkt < CAH_QUEUE_BINS; ++bkt) { const unsigned c = s_hist[bkt]; s_hist[bkt] = run; run += c; }
-                s_qbase = count ? atomicAdd(a.queue_count, (unsigned long long)count) : 0ull;
+    int64_t it = 0;
+    prefetch(piece_base(0));
+    for (int64_t k = 0;; ++k) {
+        const int64_t tile_base = ((int64_t)blockIdx.x + k * (int64_t)gridDim.x) * TILE;
+        if (tile_base >= a.n_reads) break;                              // block-uniform
+        __syncthreads();
+        if (threadIdx.x == 0) s_count = 0;
+        for (int i = threadIdx.x; i < CAH_QUEUE_BINS; i += blockDim.x) { s_hist[i] = 0; s_cursor[i] = 0; }
+        __syncthreads();
+
+        for (int j = 0; j < SUBS; ++j, ++it) {
+            const int64_t base = tile_base + ((int64_t)wave + STREAM_BLOCK_WAVES * j) * WAVE;
+            // the piece in the registers goes to the LDS slot (every lane is done with the previous piece: LDS
+            // operations of a wave execute in order); then the next piece's loads are issued
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < UM; ++q)
+                if (q < U) {                                            // unit 64 q + lane exists iff q < U
+                    unsigned ur, uc;
+                    unit_rc(q, ur, uc);
+                    *reinterpret_cast<u32x4*>(piece + (__umul24(ur, (unsigned)NU) + uc) * 16u) = pre[q];
+                }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            prefetch(piece_base(it + 1));
+            if (base >= a.n_reads) continue;                            // wave-uniform; nothing left in this tile
+            const int64_t r = base + lane;
+            const bool valid = r < a.n_reads;
+            int hit_pos = -1;                                           // >= 0: a k-mer was found, in this 4-column group
+            unsigned seen = 0;
+            LeanState<NL, NG> S;
+#pragma unroll
+            for (int w = 0; w < NL; ++w) { S.RL[w] = 0; S.accL[w] = 0; }
+#pragma unroll
+            for (int w = 0; w < NG; ++w) { S.RG[w] = 0; S.accG[w] = 0; }
+            Chunk cur = finish(*reinterpret_cast<const u32x4*>(row), 0);
+            {
+                unsigned ad[8];
+                lean_addr8<LeanLayout<DL, NL, NG>::LEAD_SHIFT>(ad, cur.w[0], cur.w[1]);
+                lean_issue_lead<DL, NL, NG>(L, S.mk0, ad);
             }
+            // one chunk; false: every lane is done
+            auto step = [&](auto gated, int pos) -> bool {
+                const bool live = valid && hit_pos < 0;
+                if (!__any(live)) return false;
+                // the next chunk is requested now and looked at half a chunk later (a row has NU units: the
+                // request stays inside it while pos + 16 < n)
+                u32x4 raw = (u32x4)(0u);
+                if (pos + 16 < n) raw = *reinterpret_cast<const u32x4*>(row + pos + 16);
+                seen |= cur.w[0] | cur.w[1] | cur.w[2] | cur.w[3];
+                uint32_t gg[3];
+                Chunk nxt;
+                const uint32_t found = lean_chunk<true, decltype(gated)::value, DL, NL, NG>(
+                    L, S, cur, [&]() { return finish(raw, pos + 16); }, nxt, pos, n, gg);
+                if (live && found != 0) hit_pos = pos + (gg[0] ? 0 : gg[1] ? 4 : gg[2] ? 8 : 12);
+                cur = nxt;
+                return true;
+            };
+            // chunks at the head windows, the stretch without windows (lead words only), chunks at the tail windows
+            int pos = 0;                                                // wave-uniform
+            bool more = true;
+            for (; more && pos < n && pos < L.head_span; pos += 16) more = step(std::true_type{}, pos);
+            for (; more && pos < n && lean_chunk_ungated<true, NL, NG>(L, pos, n); pos += 16) more = step(std::false_type{}, pos);
+            for (; more && pos < n; pos += 16) more = step(std::true_type{}, pos);
+            const bool invalid = (seen & 0x80808080u) != 0;
+            lean_emit(a, r, tile_base, valid, hit_pos >= 0, invalid, hit_pos, s_idx, s_key, s_hist, s_count);
+        }
+
+        if (!a.present) {
             __syncthreads();
-            const unsigned long long qbase = s_qbase;
-            for (unsigned e = threadIdx.x; e < count; e += blockDim.x) {
-                const unsigned key = s_key[e];
-                const unsigned p = s_hist[key] + atomicAdd(&s_cursor[key], 1u);
-                a.queue[qbase + p] = (int32_t)(tile_base + s_idx[e]);
-                a.queue_keys[qbase + p] = (uint8_t)key;
-            }
+            flush_tile_queue(a, tile_base, s_idx, s_key, s_hist, s_cursor, s_count, s_scratch, s_qbase);
         }
     }
 }
@@ -1506,29 +1989,63 @@ hipError_t launch_filter(const FilterArgs& a, int mode, bool narrow, int n_cus, 
     return hipGetLastError();
 }
 
-hipError_t launch_filter_lean(const FilterArgs& a, int mode, int n_words, int n_cus, hipStream_t s) {
+static int getenv_flag(const char* name) {
+    const char* e = getenv(name);
+    return e && *e && *e != '0';
+}
+
+// streaming instances <row stride in 16-byte units (odd), units copied>: equally long reads of up to 112 / 160 characters
+#define STREAM_NU_A 7
+#define STREAM_UM_A 7
+#define STREAM_NU_B 11
+#define STREAM_UM_B 10
+
+hipError_t launch_filter_lean(const FilterArgs& a_in, int mode, int n_lead, int n_gated, int delay, int n_cus, hipStream_t s) {
+    FilterArgs a = a_in;
+    if (mode != 0) a.present = nullptr;                   // the kernels tell the modes apart by `present`
     const int grid = grid_for(a.n_reads, LEAN_WAVES, n_cus);
-    const size_t lds = (size_t)CAH_LEAN_WORDS * CAH_TABLE_CHARS * sizeof(uint32_t) +
-                       3 * (size_t)CAH_LEAN_WORDS * (CAH_LEAN_SPAN + 2) * sizeof(uint32_t) + (size_t)LEAN_TILE * 3 +
+    // dynamic part only (start gates of the ragged variant, tile staging, histogram); the character masks
+    // are a static allocation of the kernel
+    const size_t lds = (size_t)CAH_LEAN_MAX_GATED * CAH_GATE_LEN * sizeof(uint32_t) + (size_t)LEAN_TILE * 3 +
                        CAH_QUEUE_BINS * 8 + 64;
-    // both variants are launched for a packed batch (one of them returns at once, see batch_flag);
-    // views (explicit lengths) have no batch check and go to the ragged variant directly
-#define CAH_LEAN_LAUNCH(U, N)                                                                                       \
+    // A packed batch gets every variant (all but one return at once, see batch_flag and the length ranges: no
+    // host synchronisation): the streaming kernel for equally long short reads, the per-lane uniform kernel for
+    // equally long longer reads, the ragged kernel for everything else.  Views (explicit lengths) have no batch
+    // check and go to the ragged variant directly.
+    const bool stream = a.batch_flag != nullptr && getenv_flag("CAH_NO_STREAM") == 0;
+#define CAH_STREAM_LAUNCH(DL, NL, NG, NU, UM, LO)                                                                   \
     do {                                                                                                            \
-        if (mode == 0) hipLaunchKernelGGL((k_filter_lean<0, U, N>), dim3(grid), dim3(256), lds, s, a);              \
-        else hipLaunchKernelGGL((k_filter_lean<1, U, N>), dim3(grid), dim3(256), lds, s, a);                        \
+        const int tiles = (int)((a.n_reads + stream_tile(NG) - 1) / stream_tile(NG));                               \
+        const int sgrid = std::max(1, std::min(tiles, n_cus));                                                      \
+        const size_t slds = (size_t)stream_tile(NG) * 3 + CAH_QUEUE_BINS * 8 + 64;                                  \
+        FilterArgs b = a;                                                                                           \
+        b.stream_n_lo = (LO); b.stream_n_hi = stream_max_len(UM);                                                   \
+        hipLaunchKernelGGL((k_filter_stream<DL, NL, NG, NU, UM>), dim3(sgrid), dim3(STREAM_BLOCK_WAVES * WAVE), slds, s, b); \
     } while (0)
-#define CAH_LEAN_BOTH(N)                                                                                            \
+#define CAH_LEAN_ALL(DL, NL, NG)                                                                                    \
     do {                                                                                                            \
-        if (a.batch_flag) CAH_LEAN_LAUNCH(true, N);                                                                 \
-        CAH_LEAN_LAUNCH(false, N);                                                                                  \
+        if (stream) {                                                                                               \
+            CAH_STREAM_LAUNCH(DL, NL, NG, STREAM_NU_A, STREAM_UM_A, 0);                                             \
+            CAH_STREAM_LAUNCH(DL, NL, NG, STREAM_NU_B, STREAM_UM_B, stream_max_len(STREAM_UM_A) + 1);               \
+        }                                                                                                           \
+        if (a.batch_flag) hipLaunchKernelGGL((k_filter_lean<true, DL, NL, NG>), dim3(grid), dim3(256), lds, s, a);  \
+        hipLaunchKernelGGL((k_filter_lean<false, DL, NL, NG>), dim3(grid), dim3(256), lds, s, a);                   \
     } while (0)
-    if (n_words <= 3) CAH_LEAN_BOTH(3);
-    else if (n_words <= 5) CAH_LEAN_BOTH(5);
-    else if (n_words <= 6) CAH_LEAN_BOTH(6);
-    else CAH_LEAN_BOTH(CAH_LEAN_WORDS);
-#undef CAH_LEAN_BOTH
-#undef CAH_LEAN_LAUNCH
+#define CAH_LEAN_CLASS(NL, NG)                                                                                      \
+    do {                                                                                                            \
+        if (delay) CAH_LEAN_ALL(CAH_LEAN_DELAY, NL, NG); else CAH_LEAN_ALL(0, NL, NG);                              \
+    } while (0)
+    // the per-lane uniform kernel leaves the streaming kernels' lengths alone
+    a.stream_n_lo = 0;
+    a.stream_n_hi = stream ? stream_max_len(STREAM_UM_B) : -1;
+    // slot classes <lead, gated>: TruSeq / e = 0.1 is <2, 3> as a 3' or 5' adapter, <2, 6> as an anywhere adapter
+    if (n_lead <= 1 && n_gated <= 2) CAH_LEAN_CLASS(1, 2);
+    else if (n_lead <= 2 && n_gated <= 3) CAH_LEAN_CLASS(2, 3);
+    else if (n_lead <= 2) CAH_LEAN_CLASS(2, 6);
+    else CAH_LEAN_CLASS(3, 6);
+#undef CAH_LEAN_CLASS
+#undef CAH_LEAN_ALL
+#undef CAH_STREAM_LAUNCH
     return hipGetLastError();
 }
 

@@ -1,0 +1,189 @@
+"""k_filter_stream (equally long short reads: the wave's 64 reads copied HBM -> LDS with full-width loads) against
+the oracle and against the per-lane kernels (CAH_NO_STREAM=1) -- through the C ABI like every GPU test.
+
+Covered: every length around the instances' limits (111/112, 159/160) and the chunk / tail-window boundaries,
+batches that end inside a wave, inside a tile and after several tiles per block, a batch whose first read does not
+start at byte 0 of an unaligned buffer, 3', 5' and anywhere adapters (lead, tail and head words), invalid bytes,
+MODE 0 (kmers_present_batch) and MODE 1 (the survivor queue feeding scan + DP).
+Reference semantics: src/cutadapt/_kmer_finder.pyx:170-257 (kmers_present), adapters.py:815-832 (match_to).
+"""
+import os
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TRUSEQ = "AGATCGGAAGAGCACACGTCTGAACTCCAGTCA"
+
+
+def rs(rng, n, alphabet="ACGT"):
+    return "".join(rng.choice(alphabet) for _ in range(n))
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from cutadapt_amd import _lib
+    _lib.lib()
+    return _lib
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle as o
+    o.build()
+    return o
+
+
+def make_reads(rng, n, count, adapter, p_adapter=0.5):
+    reads = []
+    m = len(adapter)
+    for _ in range(count):
+        r = list(rs(rng, n))
+        if n and rng.random() < p_adapter:
+            p = rng.randint(max(0, n - m - 5), n - 1) if rng.random() < 0.5 else rng.randint(0, n - 1)
+            piece = list(adapter[:rng.randint(1, m)])
+            for _e in range(rng.choice([0, 0, 0, 1, 2])):
+                piece[rng.randrange(len(piece))] = rng.choice("ACGT")
+            r[p:p + len(piece)] = piece
+            r = r[:n]
+        if n and rng.random() < 0.05:
+            r[rng.randrange(n)] = rng.choice("Nn")
+        reads.append("".join(r))
+    return reads
+
+
+class no_stream:
+    def __enter__(self):
+        os.environ["CAH_NO_STREAM"] = "1"
+
+    def __exit__(self, *a):
+        os.environ.pop("CAH_NO_STREAM", None)
+
+
+def oracle_expect(orc, ad, reads):
+    from cutadapt_amd.adapters import Where
+    flags = int({"BackAdapter": Where.BACK, "FrontAdapter": Where.FRONT, "AnywhereAdapter": Where.ANYWHERE}[type(ad).__name__])
+    finder = orc.KmerFinder(ad.kmer_finder.positions_and_kmers, ad.adapter_wildcards, ad.read_wildcards)
+    oal = orc.Aligner(ad.sequence, ad.max_error_rate, flags=flags, wildcard_ref=ad.adapter_wildcards,
+                      wildcard_query=ad.read_wildcards, indel_cost=1 if ad.indels else 100000,
+                      min_overlap=ad.min_overlap)
+    return [oal.locate(r) if finder.kmers_present(r) else None for r in reads], finder
+
+
+def test_stream_lengths_vs_oracle_and_per_lane_kernels(hip, orc):
+    import torch
+    from cutadapt_amd import adapters as A
+    from cutadapt_amd.batch import ReadBatch, match_batch
+    rng = random.Random(4242)
+    ad = A.BackAdapter(TRUSEQ, max_errors=0.1, min_overlap=3)
+    lengths = sorted({0, 1, 3, 4, 15, 16, 17, 31, 32, 33, 34, 36, 50, 63, 64, 65, 75, 100, 101, 110, 111, 112, 113,
+                      125, 127, 128, 129, 144, 145, 149, 150, 151, 152, 158, 159, 160, 161, 170})
+    for n in lengths:
+        count = rng.choice([1, 63, 64, 65, 300, 1024, 1025, 2500])
+        reads = make_reads(rng, n, count, TRUSEQ)
+        batch = ReadBatch.from_strings(reads)
+        got = match_batch(ad._fused_plan, batch).cpu()
+        with no_stream():
+            ref = match_batch(ad._fused_plan, ReadBatch.from_strings(reads)).cpu()
+        assert np.array_equal(got[1], ref[1]) and np.array_equal(got[0], ref[0]), n
+        if count <= 300:
+            exp, _ = oracle_expect(orc, ad, reads)
+            for i, e in enumerate(exp):
+                g = tuple(int(v) for v in got[0][i]) if got[1][i] == 1 else None
+                assert g == e, (n, reads[i], g, e)
+
+
+def test_stream_many_tiles_per_block_and_present_mode(hip, orc):
+    """More tiles than blocks (several pieces per wave, the prefetch crossing tile borders), MODE 0."""
+    import torch
+    from cutadapt_amd import adapters as A
+    from cutadapt_amd.batch import ReadBatch, match_batch
+    rng = random.Random(99)
+    ad = A.BackAdapter(TRUSEQ, max_errors=0.1, min_overlap=3)
+    L = hip.lib()
+    for n, count in ((150, 1_500_000), (101, 1_200_037), (36, 900_001)):
+        batch = ReadBatch.synthetic(count, n, [TRUSEQ], seed=rng.randint(1, 1 << 30))
+        got = match_batch(ad._fused_plan, batch)
+        pres = torch.empty(count, dtype=torch.uint8, device=batch.device)
+        hip.check(L.cah_kmers_present_batch(ad._fused_plan.handle, 0, batch.seqs.data_ptr(), batch.offsets.data_ptr(),
+                                            None, count, pres.data_ptr(), None))
+        with no_stream():
+            ref = match_batch(ad._fused_plan, batch)
+            pres_ref = torch.empty(count, dtype=torch.uint8, device=batch.device)
+            hip.check(L.cah_kmers_present_batch(ad._fused_plan.handle, 0, batch.seqs.data_ptr(),
+                                                batch.offsets.data_ptr(), None, count, pres_ref.data_ptr(), None))
+        torch.cuda.synchronize()
+        assert torch.equal(got.out6, ref.out6) and torch.equal(got.status, ref.status), (n, count)
+        assert torch.equal(pres, pres_ref), (n, count)
+        assert int(pres.sum()) > count // 10
+        # a sample against the oracle
+        seqs = batch.seqs[:2000 * n].cpu().numpy().tobytes().decode()
+        reads = [seqs[i * n:(i + 1) * n] for i in range(2000)]
+        exp, finder = oracle_expect(orc, ad, reads)
+        g6, gs, _ = got.cpu()
+        p = pres[:2000].cpu().numpy()
+        for i, e in enumerate(exp):
+            g = tuple(int(v) for v in g6[i]) if gs[i] == 1 else None
+            assert g == e, (n, reads[i], g, e)
+            assert bool(p[i]) == bool(finder.kmers_present(reads[i]))
+
+
+def test_stream_unaligned_start_and_other_adapter_kinds(hip, orc):
+    """The batch starts in the middle of an unaligned buffer (offsets[0] != 0, odd base address); 5' and anywhere
+    adapters (head words) and random 3' adapters with wildcards take the same kernel."""
+    import torch
+    from cutadapt_amd import adapters as A
+    from cutadapt_amd.batch import ReadBatch, match_batch
+    rng = random.Random(7)
+    for it in range(10):
+        m = rng.choice([8, 13, 20, 33, 40, 57, 64])
+        seq = rs(rng, m, "ACGT") if it % 3 else rs(rng, m, "ACGTN")
+        cls = [A.BackAdapter, A.FrontAdapter, A.AnywhereAdapter][it % 3]
+        ad = cls(seq, max_errors=rng.choice([0.0, 0.1, 0.2]), min_overlap=rng.randint(1, 6),
+                 read_wildcards=rng.random() < 0.2, indels=rng.random() < 0.8)
+        n = rng.choice([30, 48, 75, 100, 112, 150, 159])
+        count = rng.choice([200, 300])
+        reads = make_reads(rng, n, count, seq)
+        junk = rng.randint(1, 37)
+        from cutadapt_amd.batch import pack_strings
+        seqs, offsets = pack_strings(reads)
+        buf = np.concatenate([np.frombuffer(rs(rng, junk).encode(), dtype=np.uint8), seqs])
+        dev = torch.device("cuda", torch.cuda.current_device())
+        big = torch.from_numpy(buf.copy()).to(dev)
+        pad = rng.randint(1, 7)
+        shifted = torch.empty(big.numel() + pad, dtype=torch.uint8, device=dev)
+        shifted[pad:] = big
+        view = shifted[pad:]                       # base address = allocation + pad (not 16-byte aligned)
+        assert view.data_ptr() % 16 != 0 or pad % 16 == 0
+        offs = torch.from_numpy(offsets + junk).to(dev)
+        batch = ReadBatch(view, offs, validated=True)
+        got = match_batch(ad._fused_plan, batch).cpu()
+        exp, _ = oracle_expect(orc, ad, reads)
+        for i, e in enumerate(exp):
+            g = tuple(int(v) for v in got[0][i]) if got[1][i] == 1 else None
+            assert g == e, (type(ad).__name__, seq, n, reads[i], g, e)
+
+
+def test_stream_flags_invalid_bytes(hip):
+    import torch
+    from cutadapt_amd import adapters as A
+    from cutadapt_amd.batch import ReadBatch, match_batch
+    rng = random.Random(5)
+    ad = A.BackAdapter(TRUSEQ, max_errors=0.1, min_overlap=3)
+    n, count = 150, 700
+    reads = make_reads(rng, n, count, TRUSEQ)
+    from cutadapt_amd.batch import pack_strings
+    seqs, offsets = pack_strings(reads)
+    seqs = seqs.copy()
+    bad = sorted(rng.sample(range(count), 9))
+    for i, r in enumerate(bad):
+        seqs[r * n + [0, n - 1, rng.randrange(n)][i % 3]] = 0xC3
+    batch = ReadBatch.from_host(seqs, offsets, validated=True)
+    got = match_batch(ad._fused_plan, batch).cpu()
+    st = got[1]
+    assert sorted(np.nonzero(st == 2)[0].tolist()) == bad

@@ -224,3 +224,13 @@ def test_adapter_specifications_follow_the_reference_grammar():
     assert not linked.front_required and linked.back_required
     linked = adapter_from_spec("name=ACGT...TTTTAAAA$", "back", **d)
     assert linked.name == "name" and not linked.front_required and linked.back_required
+
+
+def test_stream_copy_plan_division_is_exact():
+    """k_filter_stream (csrc/kernels.hip) maps the 16-byte unit u of a wave's piece to read u // U and unit u % U
+    with a multiply: r = (u * ceil(65536 / U)) >> 16.  Exhaustive over the kernel's range (u < 64 * 16, U <= 16)."""
+    for U in range(1, 17):
+        magic = (65536 + U - 1) // U
+        for u in range(64 * 16):
+            r = (u * magic) >> 16
+            assert r == u // U and u * magic < 2 ** 32, (U, u)
