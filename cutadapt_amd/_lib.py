@@ -24,7 +24,7 @@ EXPORTED_SYMBOLS = [
     "cah_plan_create", "cah_plan_destroy", "cah_plan_n_adapters", "cah_plan_effective_length",
     "cah_plan_n_kmer_entries", "cah_plan_prefilter_kind", "cah_plan_debug_matcher", "cah_locate_batch", "cah_kmers_present_batch", "cah_match_batch",
     "cah_workspace_bytes", "cah_plan_workspace_bytes", "cah_validate_ascii_batch", "cah_locate_batch_host",
-    "cah_kmers_present_batch_host", "cah_match_batch_host", "cah_profile_enable",
+    "cah_kmers_present_batch_host", "cah_match_batch_host", "cah_locate_debug_host", "cah_profile_enable",
     "cah_profile_reset", "cah_profile_read", "cah_synth_reads",
     "cah_fastq_scan", "cah_pack_sequences", "cah_fastq_write_trimmed",
     "cah_fasta_scan", "cah_records_write", "cah_info_write", "cah_record_boundary",
@@ -115,6 +115,7 @@ def lib():
     L.cah_locate_batch_host.argtypes = [vp, i32, vp, vp, i64, vp, vp]
     L.cah_kmers_present_batch_host.argtypes = [vp, i32, vp, vp, i64, vp]
     L.cah_match_batch_host.argtypes = [vp, vp, vp, i64, vp, vp, vp]
+    L.cah_locate_debug_host.argtypes = [vp, vp, i64, vp, vp, vp, vp]
     L.cah_profile_enable.argtypes = [C.c_int]
     L.cah_profile_reset.argtypes = []
     L.cah_profile_read.argtypes = [C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(i64)]
@@ -294,6 +295,41 @@ class Plan:
         out = C.c_int32(0)
         check(lib().cah_plan_n_kmer_entries(self._h, adapter, C.byref(out)))
         return out.value
+
+
+def locate_debug(spec: MatcherSpec, query: str):
+    """Aligner.locate(query) with the DP matrices of Aligner.enable_debug() (reference _align.pyx:279-296):
+    returns (tuple or None, cost rows, score rows); rows[i][j] is None where the banded algorithm computed nothing."""
+    import numpy as np
+    seq = _ascii(spec.sequence)
+    q = _ascii(query)
+    d = AdapterDescC()
+    d.sequence = seq
+    d.length = len(seq)
+    d.max_error_rate = spec.max_error_rate
+    d.flags = spec.flags
+    d.wildcard_ref = int(spec.wildcard_ref)
+    d.wildcard_query = int(spec.wildcard_query)
+    d.indel_cost = spec.indel_cost
+    d.min_overlap = spec.min_overlap
+    d.kind = spec.kind
+    d.n_kmer_sets = -1
+    d.kmer_sets = None
+    m, n = len(seq), len(q)
+    none = np.iinfo(np.int32).min
+    cost = np.full((m + 1, n + 1), none, dtype=np.int32)
+    score = np.full((m + 1, n + 1), none, dtype=np.int32)
+    out6 = np.zeros(6, dtype=np.int32)
+    status = np.zeros(1, dtype=np.uint8)
+    qbuf = np.frombuffer(q, dtype=np.uint8) if n else np.zeros(1, dtype=np.uint8)
+    check(lib().cah_locate_debug_host(C.byref(d), qbuf.ctypes.data, n, out6.ctypes.data, status.ctypes.data,
+                                      cost.ctypes.data, score.ctypes.data))
+    if status[0] == INVALID:
+        raise ValueError("String must contain only ASCII characters")
+
+    def rows(a):
+        return [[None if v == none else int(v) for v in row] for row in a]
+    return (tuple(int(v) for v in out6) if status[0] == MATCH else None), rows(cost), rows(score)
 
 
 class Index:

@@ -373,8 +373,26 @@ class SingleAdapter(Adapter, ABC):
         _raise_if_invalid(status)
         return tuple(int(v) for v in out6) if status[0] == _lib.MATCH else None
 
+    def _locate_debug(self, sequence: str):
+        """enable_debug(): the reference's two steps, kmers_present then locate, with the aligner collecting its
+        matrices, which are printed like the reference does (adapters.py:62-67, :772-773, :876-877)"""
+        if not self.kmer_finder.kmers_present(sequence):
+            return None
+        alignment = self.aligner.locate(sequence)
+        print("Edit distances:")
+        print(self.aligner.dpmatrix)
+        print("Scores:")
+        print(self.aligner.scorematrix)
+        return alignment
+
     def match_to(self, sequence: str):
         """Match this adapter to one read; a Match or None (reference e.g. :707-724, :815-832)."""
+        if self._debug:
+            work = sequence[::-1] if self._reverse_reads else sequence
+            alignment = self._locate_debug(work)
+            if alignment is None:
+                return None
+            return self._wrap(self._mirror(alignment, len(sequence)) if self._reverse_reads else alignment, sequence)
         if self._reverse_reads:
             alignment = self._locate_fused(sequence[::-1])
             if alignment is None:

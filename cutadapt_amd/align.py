@@ -64,6 +64,9 @@ class Aligner:
         self._min_overlap = int(min_overlap)
         self._plan = _lib.Plan([self.spec()])
         self.effective_length = self._plan.effective_length(0)
+        self._debug = False
+        self._dpmatrix = None
+        self._scorematrix = None
 
     def spec(self, kmer_sets=None, kmer_ref_wildcards=False, kmer_query_wildcards=False) -> _lib.MatcherSpec:
         return _lib.MatcherSpec(self.reference, self.max_error_rate, self._flags, self.wildcard_ref,
@@ -82,6 +85,12 @@ class Aligner:
                 f"min_overlap={self._min_overlap})")
 
     def locate(self, query: str) -> Optional[AlignmentTuple]:
+        if self._debug:
+            # one read through the statement-by-statement kernel, which writes the matrices out (same tuple)
+            result, cost, score = _lib.locate_debug(self.spec(), query)
+            self._dpmatrix = DPMatrix(self.reference, query, cost)
+            self._scorematrix = DPMatrix(self.reference, query, score)
+            return result
         return _locate_one(self._plan, query)
 
     def locate_batch(self, batch):
@@ -89,17 +98,41 @@ class Aligner:
         return _b.locate_batch(self._plan, 0, batch)
 
     def enable_debug(self):
-        raise NotImplementedError(
-            "the HIP aligner keeps the DP column in registers and never materialises the DP "
-            "matrix; dpmatrix/scorematrix debugging is not available on this path")
+        """Store the dynamic programming matrices while running the locate() method and make them available in
+        the .dpmatrix and .scorematrix attributes (reference _align.pyx:291-296).  The register-resident kernels
+        never hold a matrix, so a debugging aligner sends its reads one at a time through the kernel that keeps
+        the column in memory (csrc/long.hip), which writes every computed cell out."""
+        self._debug = True
 
     @property
     def dpmatrix(self):
-        return None
+        """The dynamic programming matrix as a DPMatrix object; None unless debugging has been enabled with
+        enable_debug() (reference _align.pyx:279-285)."""
+        return self._dpmatrix
 
     @property
     def scorematrix(self):
-        return None
+        return self._scorematrix
+
+
+class DPMatrix:
+    """Representation of the dynamic-programming matrix (reference _align.pyx:58-92): entries may be None, in
+    which case that value was not computed."""
+
+    def __init__(self, reference, query, rows=None):
+        m, n = len(reference), len(query)
+        self._rows = rows if rows is not None else [[None] * (n + 1) for _ in range(m + 1)]
+        self.reference = reference
+        self.query = query
+
+    def set_entry(self, i: int, j: int, cost):
+        self._rows[i][j] = cost
+
+    def __str__(self):
+        rows = ["     " + " ".join(c.rjust(2) for c in self.query)]
+        for c, row in zip(" " + self.reference, self._rows):
+            rows.append(c + " " + " ".join("  " if v is None else "{:2d}".format(v) for v in row))
+        return "\n".join(rows)
 
 
 class PrefixComparer:

@@ -1019,6 +1019,7 @@ static int run_aligner(const cah_plan* plan, const PlanDeviceCopy* pd, int32_t a
         la.queue = d_queue; la.queue_count = d_queue_count; la.work_counter = ws.counters + WS_DPWORK;
         la.scratch = (int32_t*)ws.extra;
         la.out6 = d_out6; la.status = d_status; la.best_adapter = d_best; la.adapter_index = adapter; la.merge_best = merge_best;
+        la.dbg_cost = nullptr; la.dbg_score = nullptr;
         ProfScope ps(s, mt.kind == CAH_KIND_ALIGNER ? CAH_PROF_DP : CAH_PROF_COMPARER, n_reads);
         HIP_TRY(launch_dp_long(la, lanes, s));
         return CAH_OK;
@@ -1437,6 +1438,78 @@ int cah_match_batch_host(const cah_plan* plan, const uint8_t* seqs, const int64_
     if (n_reads == 0) return CAH_OK;
     if (!out6 || !status) return fail(CAH_EINVAL, "output pointers are NULL");
     return host_call(HOST_MATCH, plan, -1, seqs, offsets, n_reads, out6, best_adapter, status);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Aligner.enable_debug(): one read through the statement-by-statement kernel (long.hip, any adapter length) with
+// the DP matrices written out -- the reference fills DPMatrix objects while locate() runs (_align.pyx:58-92,
+// :279-296, :385-390, :485-489).  Synchronous, allocates what it needs: a debugging aid, not a hot path.
+// ---------------------------------------------------------------------------------------------
+int cah_locate_debug_host(const cah_adapter_desc* adapter, const uint8_t* seq, int64_t n, int32_t* out6,
+                          uint8_t* status, int32_t* cost_matrix, int32_t* score_matrix) {
+    try {
+        if (!adapter || !out6 || !status || !cost_matrix || !score_matrix || (n > 0 && !seq))
+            return fail(CAH_EINVAL, "cah_locate_debug_host: NULL argument");
+        if (adapter->kind != CAH_KIND_ALIGNER) return fail(CAH_EINVAL, "only an Aligner has DP matrices");
+        if (n < 0 || n > CAH_MAX_READ_LEN) return fail(CAH_EINVAL, "read length out of range");
+        if (adapter->length < 0 || (adapter->length > 0 && !adapter->sequence)) return fail(CAH_EINVAL, "bad sequence");
+        if (!is_ascii(adapter->sequence, (size_t)adapter->length)) return fail(CAH_EINVAL, "String must contain only ASCII characters");
+        CahMatcher mt;
+        memset(&mt, 0, sizeof(mt));
+        LongTables lt;
+        const int rc = build_long(*adapter, 0, mt, lt);
+        if (rc != CAH_OK) return rc;
+        int device = 0;
+        HIP_TRY(hipGetDevice(&device));
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device));
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+            return fail(CAH_EUNSUPPORTED, "device %d is %s; this library is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+        const int m = adapter->length;
+        const size_t cells = (size_t)(m + 1) * (size_t)(n + 1);
+        const int64_t lanes = 256;
+        struct Bufs {
+            void* p[10] = {nullptr};
+            ~Bufs() { for (void* q : p) if (q) (void)hipFree(q); }
+        } b;
+        auto dev = [&](int slot, size_t bytes) -> int { HIP_TRY(hipMalloc(&b.p[slot], std::max<size_t>(bytes, 16))); return CAH_OK; };
+        int e;
+        if ((e = dev(0, sizeof(CahLongMatcher))) || (e = dev(1, lt.ref.size())) || (e = dev(2, sizeof(int32_t) * lt.ncnt.size())) ||
+            (e = dev(3, (size_t)n)) || (e = dev(4, 2 * sizeof(int64_t))) || (e = dev(5, sizeof(unsigned long long))) ||
+            (e = dev(6, sizeof(int32_t) * 3 * (size_t)(m + 1) * (size_t)lanes)) || (e = dev(7, 6 * sizeof(int32_t) + 16)) ||
+            (e = dev(8, sizeof(int32_t) * cells)) || (e = dev(9, sizeof(int32_t) * cells)))
+            return e;
+        HIP_TRY(hipMemcpy(b.p[0], &lt.lm, sizeof(CahLongMatcher), hipMemcpyHostToDevice));
+        if (!lt.ref.empty()) HIP_TRY(hipMemcpy(b.p[1], lt.ref.data(), lt.ref.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(b.p[2], lt.ncnt.data(), sizeof(int32_t) * lt.ncnt.size(), hipMemcpyHostToDevice));
+        if (n) HIP_TRY(hipMemcpy(b.p[3], seq, (size_t)n, hipMemcpyHostToDevice));
+        const int64_t offs[2] = {0, n};
+        HIP_TRY(hipMemcpy(b.p[4], offs, sizeof(offs), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemset(b.p[5], 0, sizeof(unsigned long long)));
+        // the caller's matrices go down as they are: cells the algorithm does not compute keep the caller's marker
+        HIP_TRY(hipMemcpy(b.p[8], cost_matrix, sizeof(int32_t) * cells, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(b.p[9], score_matrix, sizeof(int32_t) * cells, hipMemcpyHostToDevice));
+        LongArgs la;
+        la.lm = (const CahLongMatcher*)b.p[0]; la.ref = (const uint8_t*)b.p[1]; la.ncnt = (const int32_t*)b.p[2];
+        la.seqs = (const uint8_t*)b.p[3]; la.offsets = (const int64_t*)b.p[4]; la.lens = nullptr;
+        la.n_reads = 1; la.max_read_len = CAH_MAX_READ_LEN;
+        la.queue = nullptr; la.queue_count = nullptr; la.work_counter = (unsigned long long*)b.p[5];
+        la.scratch = (int32_t*)b.p[6];
+        la.out6 = (int32_t*)b.p[7]; la.status = (uint8_t*)b.p[7] + 6 * sizeof(int32_t);
+        la.best_adapter = nullptr; la.adapter_index = 0; la.merge_best = 0;
+        la.dbg_cost = (int32_t*)b.p[8]; la.dbg_score = (int32_t*)b.p[9];
+        HIP_TRY(launch_dp_long(la, lanes, nullptr));
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(out6, b.p[7], 6 * sizeof(int32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(status, (uint8_t*)b.p[7] + 6 * sizeof(int32_t), 1, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(cost_matrix, b.p[8], sizeof(int32_t) * cells, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(score_matrix, b.p[9], sizeof(int32_t) * cells, hipMemcpyDeviceToHost));
+        return CAH_OK;
+    } catch (const std::exception& ex) {
+        return fail(CAH_EINVAL, "cah_locate_debug_host: %s", ex.what());
+    } catch (...) {
+        return fail(CAH_EINVAL, "cah_locate_debug_host: unknown error");
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

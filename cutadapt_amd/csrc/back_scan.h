@@ -19,6 +19,17 @@
 //   EXACT_TAIL  no acceptable last-row candidate, and the LARGEST acceptable row i of the last
 //               column costs 0 (the read ends with adapter[0:i]); smaller rows have score <= their
 //               row < i and cannot replace it (:563-567)                -> (0, i, n-i, n, i, 0)
+//   SUBS_FULL   the adapter occurs with substitutions only -- what sequencing errors are: c = the smallest row-m
+//               cost of any column, 1 <= c <= kacc, first reached at column e, and the diagonal that ends in
+//               (m, e) is "clean": every cell on it whose characters differ costs one more than its diagonal
+//               predecessor (bit-vector D0 = 0 there), so the reference's cells on it take the diagonal
+//               (match: unconditionally, :446-453; mismatch: the diagonal candidate is minimal and wins ties,
+//               :462-476) and (m, e) carries origin e - m and score m - 2c.  Any alignment of the whole adapter
+//               with cost x scores at most m - 2x (score = m - 2 mismatches - 3 deletions - 2 insertions), so
+//               earlier acceptable columns (cost >= c + 1) score less and column e replaces them when
+//               e - jfa <= m/2 - kacc (the origin clause, as for EXACT_FULL); later columns (cost >= c) cannot
+//               score more; a row i of the last column could only win with i - 2 C(i, n) > m - 2c, which is
+//               checked.  No `break` (cost > 0).                          -> (0, m, e-m, e, m-2c, c)
 //   DP          everything else: the cell kernel runs, but only over the columns that can matter:
 //               from (first acceptable candidate column, or n) - m - k - 1 -- the windowing argument
 //               of DESIGN.md "Column skipping" with the exact position instead of the k-mer hit --
@@ -45,7 +56,7 @@
 #define CAH_HD inline
 #endif
 
-enum { BS_NONE = 0, BS_EXACT_FULL = 1, BS_EXACT_TAIL = 2, BS_DP = 3 };
+enum { BS_NONE = 0, BS_EXACT_FULL = 1, BS_EXACT_TAIL = 2, BS_DP = 3, BS_SUBS_FULL = 4 };
 
 struct BackScanParams {
     int m;            // adapter length, 1..64
@@ -60,8 +71,13 @@ struct BackScanState {
     uint64_t VP, VN;
     int cm;           // C(m, j) of the column just processed
     int jfa, jla;     // first / last column with cm <= kacc (-1: none)
-    int jf_any;       // first column with cm <= k (diagnostic; equals the first column where the reference's
-                      // band reaches row m)
+    // SUBS_FULL: A accumulates, along every diagonal, the cells whose diagonal delta is 0 although their characters
+    // differ (an insertion / deletion path is as cheap as the diagonal): bit 63 = the diagonal ending in row m of the
+    // current column.  cmin / je: smallest acceptable row-m cost so far and the first column that reached it;
+    // eclean: that column's diagonal was clean.
+    uint64_t A;
+    int cmin, je;
+    bool eclean;
 };
 
 CAH_HD uint64_t bs_shl1(uint64_t x) {
@@ -81,11 +97,15 @@ CAH_HD void bs_init(BackScanState& s, const BackScanParams& p) {
     s.VP = pad == 0 ? ~0ull : ~((1ull << pad) - 1ull);
     s.VN = 0;
     s.cm = p.m;
-    s.jfa = -1; s.jla = -1; s.jf_any = -1;
+    s.jfa = -1; s.jla = -1;
+    s.A = 0; s.cmin = 1 << 20; s.je = -1; s.eclean = false;
 }
 
 // One column.  eq: the padded match word of this read character (CahMatcher::scanmask[c]).
 // Returns true when the read is finished as EXACT_FULL at this column.
+// SUBS = false leaves the SUBS_FULL bookkeeping out (the class then never applies): the fused multi-adapter scan
+// runs ~6 (read, adapter) pairs per read, most of them ending as NONE, and is cheaper without it.
+template <bool SUBS = true>
 CAH_HD bool bs_step(BackScanState& s, const uint64_t eq, const int j, const BackScanParams& p) {
     const uint64_t VP = s.VP, VN = s.VN;
     const uint64_t Xv = eq | VN;
@@ -97,10 +117,12 @@ CAH_HD bool bs_step(BackScanState& s, const uint64_t eq, const int j, const Back
     const uint64_t HPs = bs_shl1(HP), HNs = bs_shl1(HN);
     s.VP = HNs | ~(Xv | HPs);
     s.VN = HPs & Xv;
-    if (s.cm <= p.k && s.jf_any < 0) s.jf_any = j;
+    // D0 = Xh | VN: C(i, j) == C(i-1, j-1); set where the characters differ = an indel path is as cheap
+    if (SUBS) s.A = bs_shl1(s.A) | ((Xh | VN) & ~eq);
     if (s.cm <= p.kacc) {
         if (s.jfa < 0) s.jfa = j;
         s.jla = j;
+        if (SUBS && s.cm < s.cmin) { s.cmin = s.cm; s.je = j; s.eclean = (s.A >> 63) == 0; }
         // (:521-533) a cost-0 candidate has score m, more than any earlier best (those cost >= 1: the
         // first cost-0 column ends the loop), so it replaces the best iff it is the first or
         // origin = j - m <= best.origin + m/2.  Every earlier acceptable candidate sits at a column
@@ -121,10 +143,14 @@ CAH_HD int bs_finish(const BackScanState& s, const int n, const int j0, const Ba
     const int pad = 64 - p.m;
     uint64_t vp = pad == 0 ? s.VP : (s.VP >> pad), vn = pad == 0 ? s.VN : (s.VN >> pad);
     int c = 0, best_i = 0, best_c = 0;
+    bool tail_may_win = false;       // an acceptable row of the last column that could outscore m - 2 * cmin
     for (int i = 1; i <= p.m; ++i) {
         c += (int)(vp & 1ull) - (int)(vn & 1ull);
         vp >>= 1; vn >>= 1;
-        if (i >= p.min_overlap && c <= thr_last(i)) { best_i = i; best_c = c; }
+        if (i >= p.min_overlap && c <= thr_last(i)) {
+            best_i = i; best_c = c;
+            if (i - 2 * c > p.m - 2 * s.cmin) tail_may_win = true;
+        }
     }
     o0 = 0; o1 = 0;
     const int reach = p.m + p.k + 1;
@@ -135,6 +161,11 @@ CAH_HD int bs_finish(const BackScanState& s, const int n, const int j0, const Ba
         o0 = s0 > j0 ? s0 : j0;
         o1 = n * 2 + 1;
         return BS_DP;
+    }
+    // substitutions only (see the header): the diagonal (0, je - m) .. (m, je) lies inside the window
+    if (s.cmin >= 1 && s.eclean && s.je - p.m >= j0 && s.je - s.jfa <= p.half_m - p.kacc && !tail_may_win) {
+        o0 = s.je; o1 = s.cmin;
+        return BS_SUBS_FULL;
     }
     const int s0 = s.jfa - reach;
     o0 = s0 > j0 ? s0 : j0;

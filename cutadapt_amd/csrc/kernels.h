@@ -152,6 +152,8 @@ struct LongArgs {
     int32_t* best_adapter;
     int32_t adapter_index;
     int32_t merge_best;
+    int32_t* dbg_cost;               // NULL, or (cah_locate_debug_host: ONE read) the DP cost / score matrices
+    int32_t* dbg_score;
 };
 int64_t long_scratch_lanes(int64_t max_items, int n_cus);      // threads k_dp_long is launched with (each owns a column)
 hipError_t launch_dp_long(const LongArgs& a, int64_t lanes, hipStream_t s);

@@ -1785,7 +1785,7 @@ __global__ __launch_bounds__(256) void k_back_scan(ScanArgs a) {
                     if (t < 15) eq_next = s_scanmask[table_index(chunk_byte(cur, t + 1))];
                     if (!done && j < n) {
                         ++j;
-                        if (bs_step(st, eq, j, p)) { exact = true; done = true; }
+                        if (bs_step<!MULTI>(st, eq, j, p)) { exact = true; done = true; }
                     }
                 }
                 pos += 16;
@@ -1802,6 +1802,7 @@ __global__ __launch_bounds__(256) void k_back_scan(ScanArgs a) {
                 if (valid && !invalid) {
                     if (cls == BS_EXACT_FULL) atomicMax(a.best_key + r, pack_best(p.m, 0, (int)adapter, p.m, o0 - p.m, o0));
                     else if (cls == BS_EXACT_TAIL) atomicMax(a.best_key + r, pack_best(o0, 0, (int)adapter, o0, n - o0, n));
+                    else if (cls == BS_SUBS_FULL) atomicMax(a.best_key + r, pack_best(p.m - 2 * o1, o1, (int)adapter, p.m, o0 - p.m, o0));
                 }
             } else if (valid) {
                 if (invalid || cls == BS_NONE) {
@@ -1813,6 +1814,9 @@ __global__ __launch_bounds__(256) void k_back_scan(ScanArgs a) {
                 } else if (cls == BS_EXACT_TAIL) {
                     store_result(a.out6, a.status, a.best_adapter, a.adapter_index, a.merge_best, r, false, true,
                                  0, o0, n - o0, n, o0, 0);
+                } else if (cls == BS_SUBS_FULL) {
+                    store_result(a.out6, a.status, a.best_adapter, a.adapter_index, a.merge_best, r, false, true,
+                                 0, p.m, o0 - p.m, o0, p.m - 2 * o1, o1);
                 }
             }
             const bool to_dp = valid && !invalid && cls == BS_DP;

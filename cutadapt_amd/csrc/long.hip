@@ -32,8 +32,11 @@ struct Column {
 // column lives wherever `col` points (HBM scratch).  `seen` ORs the bytes looked at (bit 7 set = non-ASCII input).
 struct LongResult { bool found; int t0, t1, t2, t3, score, cost; unsigned seen; };
 
+// dbg_cost / dbg_score (NULL in production): the matrices of Aligner.enable_debug() (_align.pyx:385-390, :485-489),
+// (m + 1) x (n + 1) row-major, entries the algorithm never computes keep what the caller put there.
 __device__ __forceinline__ LongResult long_locate(const CahLongMatcher* lm, const uint8_t* ref, const int32_t* ncnt,
-                                                  const uint8_t* s_qtab, const Column& col, const uint8_t* q, const int n) {
+                                                  const uint8_t* s_qtab, const Column& col, const uint8_t* q, const int n,
+                                                  int32_t* dbg_cost = nullptr, int32_t* dbg_score = nullptr) {
     const int m = lm->m, k = lm->k, D = lm->indel_cost, kind = lm->kind;
     const bool start_in_ref = lm->flags & 1, start_in_query = lm->flags & 2;
     const bool stop_in_ref = lm->flags & 4, stop_in_query = lm->flags & 8;
@@ -72,6 +75,7 @@ __device__ __forceinline__ LongResult long_locate(const CahLongMatcher* lm, cons
                 else if (!start_in_ref && start_in_query) { sc = -2 * i; co = i * D; og = max(0, min_n - i); }
                 else { sc = 0; co = min(i, min_n) * D; og = min_n - i; }
                 col.cost(i) = co; col.score(i) = sc; col.origin(i) = og;
+                if (dbg_cost) { dbg_cost[(int64_t)i * (n + 1) + min_n] = co; dbg_score[(int64_t)i * (n + 1) + min_n] = sc; }
             }
             const int SENT = m + n + 1;                                    // :394
             int b_refstop = m, b_qstop = n, b_cost = SENT, b_origin = 0, b_score = 0;
@@ -104,6 +108,11 @@ __device__ __forceinline__ LongResult long_locate(const CahLongMatcher* lm, cons
                     pc = cost; ps = score; po = origin;
                 }
                 last_filled = last;                                        // :484
+                if (dbg_cost)                                              // :485-489
+                    for (int i = 0; i <= last; ++i) {
+                        dbg_cost[(int64_t)i * (n + 1) + j] = col.cost(i);
+                        dbg_score[(int64_t)i * (n + 1) + j] = col.score(i);
+                    }
                 while (last >= 0 && col.cost(last) > k) --last;            // :490-491
                 if (last < m) {
                     ++last;
@@ -176,7 +185,7 @@ __global__ __launch_bounds__(256) void k_dp_long(LongArgs a) {
         if (n64 > a.max_read_len) { invalid = true; n64 = 0; }
         const int n = (int)n64;
         const uint8_t* q = a.seqs + off;
-        const LongResult lr = long_locate(lm, ref, ncnt, s_qtab, col, q, n);
+        const LongResult lr = long_locate(lm, ref, ncnt, s_qtab, col, q, n, a.dbg_cost, a.dbg_score);
         const bool found = lr.found;
         const int t0 = lr.t0, t1 = lr.t1, t2 = lr.t2, t3 = lr.t3, r_score = lr.score, r_cost = lr.cost;
         const unsigned seen = lr.seen;

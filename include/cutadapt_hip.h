@@ -174,6 +174,14 @@ int cah_validate_ascii_batch(const uint8_t *d_seqs, const int64_t *d_offsets,
                              const int32_t *d_lens, int64_t n_reads, int32_t *d_bad,
                              void *stream);
 
+/* Aligner.enable_debug() (_align.pyx:279-296): locate() of ONE read with the dynamic-programming matrices the
+ * reference collects in DPMatrix objects (:58-92, filled at :385-390 and :485-489).  cost_matrix / score_matrix:
+ * (length + 1) x (n + 1) int32, row-major (row = adapter position, column = read position); the call only writes
+ * the cells the banded algorithm computes, so the caller pre-fills them with its "not computed" marker.
+ * Host pointers, synchronous, any adapter length; runs the statement-by-statement kernel of long.hip. */
+int cah_locate_debug_host(const cah_adapter_desc *adapter, const uint8_t *seq, int64_t n, int32_t *out6,
+                          uint8_t *status, int32_t *cost_matrix, int32_t *score_matrix);
+
 /* ---- host-pointer conveniences (synchronous; stage through HBM internally) -------------- */
 int cah_locate_batch_host(const cah_plan *plan, int32_t adapter, const uint8_t *seqs,
                           const int64_t *offsets, int64_t n_reads, int32_t *out6,

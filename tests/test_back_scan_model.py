@@ -77,7 +77,7 @@ def compare(L, adapter, rate, min_overlap, seqs, offsets, wr=False, wq=False, sk
         raise AssertionError(f"{label}: {len(bad)} of {len(want_st)} reads differ; first: read {r} {read!r} adapter "
                              f"{adapter} rate {rate} O {min_overlap} wr {wr} wq {wq} j0 {None if j0s is None else j0s[r]} "
                              f"class {cls[r]} model {status[r]} {out6[r].tolist()} oracle {want_st[r]} {want6[r].tolist()}")
-    return np.bincount(cls, minlength=4)
+    return np.bincount(cls, minlength=5)
 
 
 def random_reads(rng, adapter, n_reads, max_len, p_edit, p_n, alphabet="ACGT"):
@@ -180,3 +180,50 @@ def test_two_copies_and_repeats(model):
         for skip in (False, True):
             compare(model, adapter, float(rng.choice([0.1, 0.2, 0.3])), int(rng.choice([1, 3])), seqs, offsets, skip=skip,
                     label=f"copies {it}")
+
+
+def test_substitution_class(model):
+    """SUBS_FULL (the adapter with substitutions only): adapters of every kind -- random, low-complexity (where an
+    insertion + deletion can cost as little as two substitutions), with a second, possibly better copy or a partial
+    copy at the read end -- must either get exactly the reference's tuple or fall back to the DP."""
+    rng = np.random.default_rng(21)
+    subs_total = 0
+    for it in range(120):
+        m = int(rng.integers(4, 65))
+        kind = it % 4
+        if kind == 0:
+            adapter = "".join(rng.choice(list("ACGT"), size=m))
+        elif kind == 1:
+            unit = "".join(rng.choice(list("ACGT"), size=int(rng.integers(1, 4))))
+            adapter = (unit * 70)[:m]
+        elif kind == 2:
+            adapter = "".join(rng.choice(list("AC"), size=m))
+        else:
+            adapter = "".join(rng.choice(list("ACGT"), size=m // 2)) * 2 + "A" * (m % 2)
+        rate = float(rng.choice([0.05, 0.1, 0.15, 0.2, 0.3]))
+        min_overlap = int(rng.choice([1, 3, 5, m]))
+        reads = []
+        for _ in range(600):
+            n = int(rng.integers(m, 3 * m + 40))
+            s = list(rng.choice(list("ACGT") if kind != 2 else list("ACCA"), size=n))
+            for _copy in range(int(rng.integers(1, 3))):
+                ad = list(adapter)
+                for _e in range(int(rng.integers(0, 5))):
+                    ad[int(rng.integers(0, m))] = str(rng.choice(list("ACGT")))
+                if rng.random() < 0.15:
+                    del ad[int(rng.integers(0, len(ad)))]
+                if rng.random() < 0.15:
+                    ad.insert(int(rng.integers(0, len(ad) + 1)), str(rng.choice(list("ACGT"))))
+                pos = int(rng.integers(0, n + 1)) if rng.random() < 0.7 else n - int(rng.integers(1, m + 1))
+                pos = max(pos, 0)
+                s[pos:pos + len(ad)] = ad
+                s = s[:n]
+            if rng.random() < 0.1:
+                s[int(rng.integers(0, len(s)))] = "N"
+            reads.append("".join(s))
+        seqs, offsets = orc.pack_reads(reads)
+        for skip in (False, True):
+            counts = compare(model, adapter, rate, min_overlap, seqs, offsets, skip=skip, label=f"subs {it} skip {skip}")
+            if counts is not None:
+                subs_total += int(counts[4])
+    assert subs_total > 5000, subs_total
