@@ -4,6 +4,7 @@ There is no CPU fallback: if the library is missing or no HIP device is usable, 
 operation raises.  (cffi is not installed in this image, hence ctypes.)
 """
 import ctypes as C
+import threading
 import os
 from typing import List, Optional, Sequence, Tuple
 
@@ -24,7 +25,7 @@ EXPORTED_SYMBOLS = [
     "cah_plan_create", "cah_plan_destroy", "cah_plan_n_adapters", "cah_plan_effective_length",
     "cah_plan_n_kmer_entries", "cah_plan_prefilter_kind", "cah_plan_debug_matcher", "cah_locate_batch", "cah_kmers_present_batch", "cah_match_batch",
     "cah_workspace_bytes", "cah_plan_workspace_bytes", "cah_validate_ascii_batch", "cah_locate_batch_host",
-    "cah_kmers_present_batch_host", "cah_match_batch_host", "cah_locate_debug_host", "cah_profile_enable",
+    "cah_kmers_present_batch_host", "cah_match_batch_host", "cah_locate_debug_host", "cah_match_one_host", "cah_locate_one_host", "cah_profile_enable",
     "cah_profile_reset", "cah_profile_read", "cah_synth_reads",
     "cah_fastq_scan", "cah_pack_sequences", "cah_fastq_write_trimmed",
     "cah_fasta_scan", "cah_records_write", "cah_info_write", "cah_record_boundary",
@@ -116,6 +117,8 @@ def lib():
     L.cah_kmers_present_batch_host.argtypes = [vp, i32, vp, vp, i64, vp]
     L.cah_match_batch_host.argtypes = [vp, vp, vp, i64, vp, vp, vp]
     L.cah_locate_debug_host.argtypes = [vp, vp, i64, vp, vp, vp, vp]
+    L.cah_match_one_host.argtypes = [vp, C.c_char_p, i64, vp, vp]
+    L.cah_locate_one_host.argtypes = [vp, C.c_char_p, i64, vp, vp]
     L.cah_profile_enable.argtypes = [C.c_int]
     L.cah_profile_reset.argtypes = []
     L.cah_profile_read.argtypes = [C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(i64)]
@@ -295,6 +298,40 @@ class Plan:
         out = C.c_int32(0)
         check(lib().cah_plan_n_kmer_entries(self._h, adapter, C.byref(out)))
         return out.value
+
+
+class _OneReadBuffers(threading.local):
+    """per-thread output buffers of the one-read calls"""
+
+    def __init__(self):
+        self.out6 = (C.c_int32 * 6)()
+        self.status = (C.c_uint8 * 1)()
+        self.p6 = C.addressof(self.out6)
+        self.ps = C.addressof(self.status)
+
+
+_one = _OneReadBuffers()
+
+
+def one_read(fn, plan_handle, sequence: str):
+    """fn = lib().cah_match_one_host / cah_locate_one_host: the tuple of one read or None"""
+    if type(sequence) is not str:
+        raise TypeError(f"sequence must be a str, not {type(sequence).__name__}")
+    try:
+        q = sequence.encode("ascii")
+    except UnicodeEncodeError:
+        raise ValueError("String must contain only ASCII characters")
+    b = _one
+    rc = fn(plan_handle, q, len(q), b.p6, b.ps)
+    if rc != CAH_OK:
+        check(rc)
+    st = b.status[0]
+    if st == MATCH:
+        o = b.out6
+        return (o[0], o[1], o[2], o[3], o[4], o[5])
+    if st == INVALID:
+        raise ValueError("String must contain only ASCII characters")
+    return None
 
 
 def locate_debug(spec: MatcherSpec, query: str):

@@ -362,16 +362,7 @@ class SingleAdapter(Adapter, ABC):
 
     def _locate_fused(self, sequence: str):
         """kmers_present -> locate for one read in a single library call"""
-        q = _lib._ascii(sequence)
-        seqs = np.frombuffer(q, dtype=np.uint8)
-        offsets = np.array([0, len(q)], dtype=np.int64)
-        out6 = np.zeros(6, dtype=np.int32)
-        status = np.zeros(1, dtype=np.uint8)
-        _lib.check(_lib.lib().cah_match_batch_host(
-            self._fused_plan.handle, seqs.ctypes.data if len(q) else None, offsets.ctypes.data, 1,
-            out6.ctypes.data, None, status.ctypes.data))
-        _raise_if_invalid(status)
-        return tuple(int(v) for v in out6) if status[0] == _lib.MATCH else None
+        return _lib.one_read(_lib.lib().cah_match_one_host, self._fused_plan.handle, sequence)
 
     def _locate_debug(self, sequence: str):
         """enable_debug(): the reference's two steps, kmers_present then locate, with the aligner collecting its

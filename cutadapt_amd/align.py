@@ -30,19 +30,8 @@ class EndSkip(IntFlag):
 
 
 def _locate_one(plan: _lib.Plan, query: str) -> Optional[AlignmentTuple]:
-    q = _lib._ascii(query)
-    seqs = np.frombuffer(q, dtype=np.uint8)
-    offsets = np.array([0, len(q)], dtype=np.int64)
-    out6 = np.zeros(6, dtype=np.int32)
-    status = np.zeros(1, dtype=np.uint8)
-    _lib.check(_lib.lib().cah_locate_batch_host(
-        plan.handle, 0, seqs.ctypes.data if len(q) else None, offsets.ctypes.data, 1,
-        out6.ctypes.data, status.ctypes.data))
-    if status[0] == _lib.INVALID:
-        raise ValueError("String must contain only ASCII characters")
-    if status[0] != _lib.MATCH:
-        return None
-    return tuple(int(v) for v in out6)  # type: ignore[return-value]
+    """one read through the library's one-read entry point (no arrays are built for it)"""
+    return _lib.one_read(_lib.lib().cah_locate_one_host, plan.handle, query)
 
 
 class Aligner:

@@ -17,6 +17,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <chrono>
+#include <atomic>
 #include <string>
 #include <memory>
 #include <new>
@@ -981,6 +983,10 @@ static int check_batch(const cah_plan* plan, const void* d_seqs, const void* d_o
 #define CAH_TINY_BATCH 64
 static thread_local bool t_header_fresh = false;
 static thread_local bool t_outputs_ready = false;
+// the one-read path (host_call_one) clears the counters of ITS workspace for the next call as soon as the kernels of
+// the current one are queued -- the memset then runs while the host is busy elsewhere instead of in front of the
+// next call's first kernel; the workspace it vouches for
+static thread_local const void* t_precleaned_ws = nullptr;
 
 // Aligner / comparer over a work list (d_queue == NULL: all reads).  3' adapters with unit costs go
 // through the cost scan first (k_back_scan finishes most reads, the rest reach k_dp_packed with an exact
@@ -1247,7 +1253,7 @@ int cah_match_batch(const cah_plan* plan, const uint8_t* d_seqs, const int64_t* 
     const bool tiny = n_reads <= CAH_TINY_BATCH && plan->matchers.size() == 1;
     struct FreshGuard { bool on; ~FreshGuard() { if (on) t_header_fresh = false; } } guard{tiny};
     if (tiny) {
-        HIP_TRY(hipMemsetAsync(counters, 0, WS_HEADER, s));
+        if (t_precleaned_ws != d_workspace) HIP_TRY(hipMemsetAsync(counters, 0, WS_HEADER, s));
         t_header_fresh = true;
     }
     // one pass over the offsets decides, on the device, which prefilter kernel works on this batch
@@ -1334,7 +1340,7 @@ struct HostScratch {
             if (pin) (void)hipHostFree(pin);
             pin = nullptr; pin_cap = 0;
             const size_t want = pin_bytes + pin_bytes / 2 + 4096;
-            HIP_TRY(hipHostMalloc((void**)&pin, want, hipHostMallocDefault));
+            HIP_TRY(hipHostMalloc((void**)&pin, want, hipHostMallocMapped));       // the one-read path lets the kernels read / write it
             pin_cap = want;
         }
         return CAH_OK;
@@ -1353,9 +1359,120 @@ static size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
 enum { HOST_LOCATE = 0, HOST_PRESENT = 1, HOST_MATCH = 2 };
 
+// ONE read through a one-adapter plan -- what Adapter.match_to(str) / Aligner.locate(str) of the reference's per-read
+// API amount to.  No copies are queued at all: the kernels read the read from, and write the tuple to, mapped pinned
+// host memory; the workspace lives at a fixed place of the thread's device scratch and its counters are cleared for
+// the NEXT call while the host is away.  What is left on the critical path: the kernel launches and one stream wait.
+static int host_call_one(int mode, const cah_plan* plan, const uint8_t* seq, int64_t n, int32_t* out6, uint8_t* status) {
+    const size_t in_bytes = align16(2 * sizeof(int64_t) + (size_t)n);
+    const size_t out_bytes = 64;                                 // out6 (24) + best (4) + status (1)
+    const size_t ws_bytes = plan->max_long_m > 0 ? cah_plan_workspace_bytes(plan, 1) : cah_workspace_bytes(1);
+    HostScratch& hs = g_host_scratch;
+    const char* dev_before = hs.dev;
+    int rc = hs.ensure(ws_bytes + 256, in_bytes + out_bytes);
+    if (rc) return rc;
+    if (hs.dev != dev_before) t_precleaned_ws = nullptr;
+    int64_t* h_off = (int64_t*)hs.pin;
+    h_off[0] = 0; h_off[1] = n;
+    if (n > 0) memcpy(hs.pin + 2 * sizeof(int64_t), seq, (size_t)n);
+    char* h_out = hs.pin + in_bytes;
+    memset(h_out, 0, out_bytes);
+    char* d_pin = nullptr;
+    HIP_TRY(hipHostGetDevicePointer((void**)&d_pin, hs.pin, 0));
+    const int64_t* d_offsets = (const int64_t*)d_pin;
+    const uint8_t* d_seqs = (const uint8_t*)(d_pin + 2 * sizeof(int64_t));
+    int32_t* d_out6 = (int32_t*)(d_pin + in_bytes);
+    int32_t* d_best = (int32_t*)(d_pin + in_bytes + 24);
+    uint8_t* d_status = (uint8_t*)(d_pin + in_bytes + 28);
+    char* d_ws = hs.dev;                                         // always the same place: the marker below stays valid
+    // One 3' aligner with the cost scan (every plain -a adapter): prefilter + scan in ONE single-wave launch
+    // (k_tiny); only a read the scan cannot finish costs a second launch (the cell DP over the list k_tiny left).
+    const CahMatcher& mt0 = plan->matchers[0];
+    if (mt0.kind == CAH_KIND_ALIGNER && mt0.scan_ok && !mt0.long_dp &&
+        (mode == HOST_LOCATE || !mt0.has_filter || plan->lean[0].ok) && !getenv("CAH_NO_TINY")) {
+        const PlanDeviceCopy* pd = nullptr;
+        rc = plan_on_device(plan, &pd);
+        if (rc) return rc;
+        const Workspace ws(d_ws, 1, ws_bytes);
+        t_precleaned_ws = nullptr;                               // k_tiny sets the counters it and the cell DP use itself
+        int32_t* h_need = (int32_t*)(h_out + 32);
+        TinyArgs ta;
+        const bool filter = mode == HOST_MATCH && mt0.has_filter;
+        ta.lean = filter ? pd->d_lean : nullptr;
+        ta.matcher = pd->d_matchers;
+        ta.seqs = d_seqs; ta.offsets = d_offsets; ta.n_reads = 1; ta.max_read_len = CAH_MAX_READ_LEN;
+        ta.out6 = d_out6; ta.status = d_status;
+        ta.dp_queue = ws.dp_queue; ta.dp_win = ws.dp_win;
+        ta.dp_count_front = ws.counters + WS_DPFRONT; ta.dp_count_back = ws.counters + WS_DPBACK;
+        ta.dp_work = ws.counters + WS_DPWORK; ta.dp_cap = 1;
+        ta.need_dp = (int32_t*)(d_pin + in_bytes + 32);
+        const CahLeanFilter& lf = plan->lean[0];
+        // completion: a kernel's last store is a ticket in the mapped block; polling it costs a fraction of a
+        // stream wait (which stays as the fallback)
+        static thread_local int32_t t_ticket = 0;
+        volatile int32_t* h_done = (volatile int32_t*)(h_out + 36);
+        int32_t* d_done = (int32_t*)(d_pin + in_bytes + 36);
+        auto wait_ticket = [&](int32_t ticket) -> int {
+            const auto t0 = std::chrono::steady_clock::now();
+            unsigned spins = 0;
+            while (*h_done != ticket) {
+                if ((++spins & 0xFFFu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
+                    HIP_TRY(hipStreamSynchronize(hs.stream));
+                    break;
+                }
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+            return CAH_OK;
+        };
+        t_ticket = t_ticket >= 0x7ffffff0 ? 1 : t_ticket + 1;
+        ta.done = d_done; ta.ticket = t_ticket;
+        HIP_TRY(launch_tiny(ta, filter ? lf.n_lead : 1, filter ? lf.n_gated : 1, filter ? lf.lead_delay : 0, hs.stream));
+        if ((rc = wait_ticket(t_ticket))) return rc;
+        if (*h_need > 0) {
+            DpArgs a;
+            a.matcher = pd->d_matchers;
+            a.seqs = d_seqs; a.offsets = d_offsets; a.lens = nullptr; a.n_reads = 1; a.max_read_len = CAH_MAX_READ_LEN;
+            a.queue = ws.dp_queue; a.queue_keys = nullptr; a.win = ws.dp_win;
+            a.queue_count = ws.counters + WS_DPFRONT; a.queue_count_back = ws.counters + WS_DPBACK; a.queue_cap = 1;
+            a.work_counter = ws.counters + WS_DPWORK;
+            a.out6 = d_out6; a.status = d_status; a.best_adapter = nullptr; a.adapter_index = 0; a.merge_best = 0;
+            a.pairs = nullptr; a.tab = nullptr; a.n_adapters = 0; a.best_key = nullptr;
+            HIP_TRY(launch_dp(a, mt0.m, mt0.indel_cost == 1, mt0.flags == 14, 1, pd->n_cus, hs.stream));
+            t_ticket += 1;
+            HIP_TRY(launch_ticket(d_done, t_ticket, hs.stream));
+            if ((rc = wait_ticket(t_ticket))) return rc;
+        }
+        memcpy(out6, h_out, 24);
+        *status = *(const uint8_t*)(h_out + 28);
+        return CAH_OK;
+    }
+    if (mode == HOST_LOCATE) {
+        t_precleaned_ws = nullptr;                               // run_aligner clears what it needs itself
+        rc = cah_locate_batch(plan, 0, d_seqs, d_offsets, nullptr, 1, d_out6, d_status, d_ws, ws_bytes, hs.stream);
+    } else {
+        t_outputs_ready = true;
+        rc = cah_match_batch(plan, d_seqs, d_offsets, nullptr, 1, d_out6, d_best, d_status, d_ws, ws_bytes, hs.stream);
+        t_outputs_ready = false;
+        // the next call's counters (tiny path of cah_match_batch), off its critical path
+        if (rc == CAH_OK && hipMemsetAsync(d_ws, 0, WS_HEADER, hs.stream) == hipSuccess) t_precleaned_ws = d_ws;
+        else t_precleaned_ws = nullptr;
+    }
+    if (rc) { t_precleaned_ws = nullptr; return rc; }
+    // the memset queued above is not waited for: an event after the kernels would do, but the stream wait below is
+    // cheaper than creating one -- it covers the memset as well (a few hundred nanoseconds of GPU time)
+    HIP_TRY(hipStreamSynchronize(hs.stream));
+    memcpy(out6, h_out, 24);
+    *status = *(const uint8_t*)(h_out + 28);
+    return CAH_OK;
+}
+
 // seqs/offsets in, (out6, best, status | present) out; everything staged through g_host_scratch
 static int host_call(int mode, const cah_plan* plan, int32_t adapter, const uint8_t* seqs, const int64_t* offsets,
                      int64_t n, int32_t* out6, int32_t* best_adapter, uint8_t* status) {
+    if (n == 1 && plan->matchers.size() == 1 && !best_adapter && offsets[0] == 0 && offsets[1] >= 0 &&
+        (mode == HOST_MATCH || (mode == HOST_LOCATE && adapter == 0)) && (offsets[1] == 0 || seqs))
+        return host_call_one(mode, plan, seqs, offsets[1], out6, status);
+    t_precleaned_ws = nullptr;                                   // this path lays the device scratch out differently
     const int64_t total = offsets[n];
     if (offsets[0] != 0) return fail(CAH_EINVAL, "offsets[0] must be 0");
     if (total > 0 && !seqs) return fail(CAH_EINVAL, "seqs is NULL");
@@ -1438,6 +1555,22 @@ int cah_match_batch_host(const cah_plan* plan, const uint8_t* seqs, const int64_
     if (n_reads == 0) return CAH_OK;
     if (!out6 || !status) return fail(CAH_EINVAL, "output pointers are NULL");
     return host_call(HOST_MATCH, plan, -1, seqs, offsets, n_reads, out6, best_adapter, status);
+}
+
+// Adapter.match_to(str) / Aligner.locate(str): one read, no offsets array (see host_call_one)
+int cah_match_one_host(const cah_plan* plan, const uint8_t* seq, int64_t n, int32_t* out6, uint8_t* status) {
+    if (!plan) return fail(CAH_EINVAL, "plan is NULL");
+    if (n < 0 || (n > 0 && !seq) || !out6 || !status) return fail(CAH_EINVAL, "cah_match_one_host: bad argument");
+    if (plan->matchers.size() != 1) return fail(CAH_EINVAL, "cah_match_one_host: the plan must hold one adapter");
+    return host_call_one(HOST_MATCH, plan, seq, n, out6, status);
+}
+
+int cah_locate_one_host(const cah_plan* plan, const uint8_t* seq, int64_t n, int32_t* out6, uint8_t* status) {
+    if (!plan) return fail(CAH_EINVAL, "plan is NULL");
+    if (n < 0 || (n > 0 && !seq) || !out6 || !status) return fail(CAH_EINVAL, "cah_locate_one_host: bad argument");
+    if (plan->matchers.size() != 1) return fail(CAH_EINVAL, "cah_locate_one_host: the plan must hold one adapter");
+    if (plan->matchers[0].kind == CAH_KIND_KMER_ONLY) return fail(CAH_EINVAL, "adapter 0 has no aligner");
+    return host_call_one(HOST_LOCATE, plan, seq, n, out6, status);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -105,6 +105,28 @@ struct ScanArgs {
     int64_t dp_cap;
 };
 
+// k_tiny: prefilter + cost scan of <= 64 reads in one launch of one wave (the per-read API)
+struct TinyArgs {
+    const CahLeanFilter* lean;       // NULL: no prefilter (Aligner.locate)
+    const CahMatcher* matcher;       // scan_ok
+    const uint8_t* seqs;
+    const int64_t* offsets;
+    int64_t n_reads;                 // <= 64
+    int64_t max_read_len;
+    int32_t* out6;
+    uint8_t* status;
+    int32_t* dp_queue;               // the cell DP's work list, as k_back_scan leaves it
+    int32_t* dp_win;
+    unsigned long long* dp_count_front;
+    unsigned long long* dp_count_back;
+    unsigned long long* dp_work;     // the cell-DP kernel's work counter: zeroed by k_tiny
+    int64_t dp_cap;
+    int32_t* need_dp;                // out: number of reads on that list
+    int32_t* done;                   // out (mapped host memory): set to `ticket` when everything above is written
+    int32_t ticket;
+};
+hipError_t launch_tiny(const TinyArgs& a, int n_lead, int n_gated, int delay, hipStream_t s);
+hipError_t launch_ticket(int32_t* done, int32_t ticket, hipStream_t s);
 hipError_t launch_filter_lean(const FilterArgs& a, int mode, int n_lead, int n_gated, int delay, int n_cus, hipStream_t s);
 hipError_t launch_uniform_check(const int64_t* offsets, int64_t n_reads, int64_t max_read_len, unsigned long long* flag,
                                 int n_cus, hipStream_t s);

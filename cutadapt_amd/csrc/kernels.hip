@@ -1869,6 +1869,181 @@ __global__ __launch_bounds__(256) void k_back_scan(ScanArgs a) {
 }
 
 // =============================================================================================
+// k_tiny: prefilter + cost scan of up to 64 reads in ONE launch of one wave -- the per-read API of the reference
+// (Adapter.match_to(read), Aligner.locate(read)) is a batch of one, and three launches (prefilter, scan, cell DP)
+// plus their queues cost more than the work.  Lane = read.  The prefilter is the ragged lean machinery, the scan
+// the same bs_* code as k_back_scan; reads the scan cannot finish go to the DP work list exactly as k_back_scan
+// leaves them, and *need_dp (mapped host memory) tells the host whether the cell-DP kernel has anything to do.
+// lean == NULL: no prefilter (Aligner.locate).  Eligible plans: one 3' aligner with the cost scan (scan_ok).
+// =============================================================================================
+// completion ticket behind other kernels of a stream (the host polls mapped memory instead of waiting on the stream)
+__global__ void k_ticket(int32_t* done, int32_t ticket) {
+    __threadfence_system();
+    __hip_atomic_store(done, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+#define TINY_STAGE_BYTES 4096
+template <int DL, int NL, int NG>
+__global__ __launch_bounds__(64) void k_tiny(TinyArgs a) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_tab[LeanLayout<DL, NL, NG>::WORDS];
+    __shared__ uint32_t s_gate[NG * CAH_GATE_LEN];
+    __shared__ __attribute__((aligned(16))) uint64_t s_scanmask[CAH_TABLE_CHARS];
+    __shared__ int s_thr_last[CAH_MAX_M + 1];
+    const CahMatcher* mt = a.matcher;
+    const CahLeanFilter* lf = a.lean;
+    if (lf) {
+        lean_tables_to_lds<DL, NL, NG>(lf, s_tab);
+        for (int i = threadIdx.x; i < NG * CAH_GATE_LEN; i += blockDim.x)
+            s_gate[i] = lf->gate_init[i / CAH_GATE_LEN][i % CAH_GATE_LEN];
+    }
+    for (int i = threadIdx.x; i < CAH_TABLE_CHARS; i += blockDim.x) s_scanmask[i] = mt->scanmask[i];
+    for (int i = threadIdx.x; i <= CAH_MAX_M; i += blockDim.x) s_thr_last[i] = mt->thr_last[i];
+    __syncthreads();
+    const int lane = wave_lane();
+    const int64_t r = lane;
+    const bool valid = r < a.n_reads;
+    int64_t off = 0, n64 = 0;
+    if (valid) read_extent(a.offsets, nullptr, r, off, n64);
+    bool invalid = false;
+    if (n64 > a.max_read_len) { invalid = true; n64 = 0; }
+    const int n = (int)n64;
+    // The reads may sit in mapped HOST memory (the one-read path queues no copies): every load from there is a
+    // trip over PCIe, so a small batch is brought into LDS once, with the whole wave, and matched from there.
+    __shared__ __attribute__((aligned(16))) uint8_t s_stage[TINY_STAGE_BYTES + 32];
+    const int64_t batch_bytes = a.offsets[a.n_reads] - a.offsets[0];
+    const bool staged = batch_bytes <= TINY_STAGE_BYTES;
+    if (staged) {
+        const uint8_t* src = a.seqs + a.offsets[0];
+        for (int i = threadIdx.x; i < (int)batch_bytes; i += blockDim.x) s_stage[i] = src[i];
+        __syncthreads();
+    }
+    const uint8_t* q = staged ? (const uint8_t*)s_stage + (off - a.offsets[0]) : a.seqs + off;
+
+    // ---- prefilter (the loop of k_filter_lean<false, ..>) ------------------------------------------------
+    bool hit = valid && !invalid;
+    int hit_pos = 0;
+    if (lf) {
+        LeanWords<NL, NG> L;
+        lean_words_init<NL, NG>(L, lf, s_tab, s_gate);
+        int n_max = n;
+#pragma unroll
+        for (int d = 1; d < WAVE; d <<= 1) n_max = max(n_max, __shfl_xor(n_max, d, WAVE));
+        n_max = __builtin_amdgcn_readfirstlane(n_max);
+        hit = false;
+        unsigned seen = 0;
+        LeanState<NL, NG> S;
+#pragma unroll
+        for (int w = 0; w < NL; ++w) { S.RL[w] = 0; S.accL[w] = 0; }
+#pragma unroll
+        for (int w = 0; w < NG; ++w) { S.RG[w] = 0; S.accG[w] = 0; }
+        Chunk cur = load_chunk(q, 0, n, valid ? n : 0);
+        Chunk nxt = load_chunk(q, 16, n, valid ? n : 0);
+        {
+            unsigned ad[8];
+            lean_addr8<LeanLayout<DL, NL, NG>::LEAD_SHIFT>(ad, cur.w[0], cur.w[1]);
+            lean_issue_lead<DL, NL, NG>(L, S.mk0, ad);
+        }
+        auto step = [&](auto gated, int pos) -> bool {
+            const bool live = valid && !hit && pos < n;
+            if (!__any(live)) return false;
+            const Chunk nx2 = load_chunk(q, pos + 32, n, live ? n : 0);
+            seen |= cur.w[0] | cur.w[1] | cur.w[2] | cur.w[3];
+            uint32_t gg[3];
+            Chunk got;
+            const uint32_t found = lean_chunk<false, decltype(gated)::value, DL, NL, NG>(
+                L, S, cur, [&]() { return nxt; }, got, pos, n, gg);
+            if (live && found != 0) {
+                hit = true;
+                hit_pos = pos + (gg[0] ? 0 : gg[1] ? 4 : gg[2] ? 8 : 12);
+            }
+            cur = got;
+            nxt = nx2;
+            return true;
+        };
+        int pos = 0;
+        bool more = true;
+        for (; more && pos < n_max && pos < L.head_span; pos += 16) more = step(std::true_type{}, pos);
+        for (; more && pos < n_max && lean_chunk_ungated<false, NL, NG>(L, pos, n); pos += 16) more = step(std::false_type{}, pos);
+        for (; more && pos < n_max; pos += 16) more = step(std::true_type{}, pos);
+        if (seen & 0x80808080u) invalid = true;
+        hit = hit && !invalid;
+    }
+
+    // ---- cost scan (the body of k_back_scan<false>) -------------------------------------------------------
+    BackScanParams p;
+    p.m = mt->m; p.k = mt->k; p.kacc = mt->kacc; p.min_overlap = mt->min_overlap; p.half_m = mt->m / 2;
+    const bool scanning = hit;                                   // lanes whose read goes on
+    int j0 = 0;
+    if (lf && mt->skip_ok != 0 && scanning)
+        j0 = max(0, (min(hit_pos >> CAH_KEY_SHIFT, CAH_QUEUE_BINS - 1) << CAH_KEY_SHIFT) - p.m - p.k - 1);
+    BackScanState st;
+    bs_init(st, p);
+    int j = j0, exact_j = 0;
+    bool done = !scanning, exact = false;
+    {
+        int pos = j0;
+        Chunk cur = load_chunk(q, pos, n, scanning ? n : 0);
+        unsigned bad_chars = 0;
+        for (;;) {
+            if (!__any(!done && j < n)) break;
+            const Chunk nxt = load_chunk(q, pos + 16, n, (!done) ? n : 0);
+            bad_chars |= cur.w[0] | cur.w[1] | cur.w[2] | cur.w[3];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const uint64_t eq = s_scanmask[chunk_byte(cur, t) & (CAH_TABLE_CHARS - 1)];
+                if (!done && j < n) {
+                    ++j;
+                    if (bs_step<true>(st, eq, j, p)) { exact = true; exact_j = j; done = true; }
+                }
+            }
+            pos += 16;
+            cur = nxt;
+        }
+        if (bad_chars & 0x80808080u) invalid = true;
+    }
+    int o0 = 0, o1 = 0;
+    int cls = bs_finish(st, n, j0, p, [&](int i) { return s_thr_last[i]; }, o0, o1);
+    if (exact) { cls = BS_EXACT_FULL; o0 = exact_j; }
+    if (!scanning) cls = BS_NONE;
+
+    // ---- results ----------------------------------------------------------------------------------------------
+    if (valid) {
+        if (invalid || cls == BS_NONE)
+            store_result(a.out6, a.status, nullptr, 0, 0, r, invalid, false, 0, 0, 0, 0, 0, 0);
+        else if (cls == BS_EXACT_FULL)
+            store_result(a.out6, a.status, nullptr, 0, 0, r, false, true, 0, p.m, o0 - p.m, o0, p.m, 0);
+        else if (cls == BS_EXACT_TAIL)
+            store_result(a.out6, a.status, nullptr, 0, 0, r, false, true, 0, o0, n - o0, n, o0, 0);
+        else if (cls == BS_SUBS_FULL)
+            store_result(a.out6, a.status, nullptr, 0, 0, r, false, true, 0, p.m, o0 - p.m, o0, p.m - 2 * o1, o1);
+        else
+            store_result(a.out6, a.status, nullptr, 0, 0, r, false, false, 0, 0, 0, 0, 0, 0);   // the cell DP decides
+    }
+    const bool to_dp = valid && !invalid && cls == BS_DP;
+    const bool to_back = to_dp && (o1 & 1), to_front = to_dp && !(o1 & 1);
+    const unsigned long long bf = __ballot(to_front), bb = __ballot(to_back);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (to_front) {
+        const int64_t slot = __popcll(bf & below);
+        a.dp_queue[slot] = (int32_t)r; a.dp_win[2 * slot] = o0; a.dp_win[2 * slot + 1] = o1;
+    } else if (to_back) {
+        const int64_t slot = a.dp_cap - 1 - __popcll(bb & below);
+        a.dp_queue[slot] = (int32_t)r; a.dp_win[2 * slot] = o0; a.dp_win[2 * slot + 1] = o1;
+    }
+    if (lane == 0) {
+        // the three counters the cell-DP kernel looks at: written here, so that the path needs no memset at all
+        *a.dp_count_front = (unsigned long long)__popcll(bf);
+        *a.dp_count_back = (unsigned long long)__popcll(bb);
+        *a.dp_work = 0ull;
+        *a.need_dp = (int32_t)(__popcll(bf) + __popcll(bb));
+    }
+    // the host polls `done` (mapped host memory) instead of paying for a stream wait: everything above is visible
+    // system-wide before the ticket is
+    __threadfence_system();
+    if (lane == 0) __hip_atomic_store(a.done, a.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// =============================================================================================
 // k_comparer: PrefixComparer / SuffixComparer.locate -- Hamming distance over min(m, n)
 // characters, again via the per-character bitset table (bit i = i-th compared position).
 // =============================================================================================
@@ -2114,6 +2289,25 @@ hipError_t launch_back_scan(const ScanArgs& a, int64_t max_items, int n_cus, hip
     } else {
         hipLaunchKernelGGL(k_back_scan<false>, grid, dim3(256), sizeof(uint64_t) * CAH_TABLE_CHARS, s, a);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_tiny(const TinyArgs& a, int n_lead, int n_gated, int delay, hipStream_t s) {
+#define CAH_TINY_CLASS(NL, NG)                                                                                      \
+    do {                                                                                                            \
+        if (delay) hipLaunchKernelGGL((k_tiny<CAH_LEAN_DELAY, NL, NG>), dim3(1), dim3(64), 0, s, a);                \
+        else hipLaunchKernelGGL((k_tiny<0, NL, NG>), dim3(1), dim3(64), 0, s, a);                                   \
+    } while (0)
+    if (n_lead <= 1 && n_gated <= 2) CAH_TINY_CLASS(1, 2);
+    else if (n_lead <= 2 && n_gated <= 3) CAH_TINY_CLASS(2, 3);
+    else if (n_lead <= 2) CAH_TINY_CLASS(2, 6);
+    else CAH_TINY_CLASS(3, 6);
+#undef CAH_TINY_CLASS
+    return hipGetLastError();
+}
+
+hipError_t launch_ticket(int32_t* done, int32_t ticket, hipStream_t s) {
+    hipLaunchKernelGGL(k_ticket, dim3(1), dim3(1), 0, s, done, ticket);
     return hipGetLastError();
 }
 

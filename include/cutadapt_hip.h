@@ -174,6 +174,13 @@ int cah_validate_ascii_batch(const uint8_t *d_seqs, const int64_t *d_offsets,
                              const int32_t *d_lens, int64_t n_reads, int32_t *d_bad,
                              void *stream);
 
+/* The per-read API of the reference -- Adapter.match_to(read) (adapters.py:684-1089) / Aligner.locate(read)
+ * (_align.pyx:298) -- for a plan of ONE adapter and one read, without an offsets array.  Same results as the
+ * *_batch_host calls with n_reads = 1; the library queues no copies for it (the kernels read the read from, and
+ * write the tuple to, mapped pinned memory) and prepares its scratch for the next call while the caller is away. */
+int cah_match_one_host(const cah_plan *plan, const uint8_t *seq, int64_t n, int32_t *out6, uint8_t *status);
+int cah_locate_one_host(const cah_plan *plan, const uint8_t *seq, int64_t n, int32_t *out6, uint8_t *status);
+
 /* Aligner.enable_debug() (_align.pyx:279-296): locate() of ONE read with the dynamic-programming matrices the
  * reference collects in DPMatrix objects (:58-92, filled at :385-390 and :485-489).  cost_matrix / score_matrix:
  * (length + 1) x (n + 1) int32, row-major (row = adapter position, column = read position); the call only writes

@@ -118,3 +118,66 @@ def test_small_batches_vs_oracle_and_batch_kernels(hip, orc):
     seqs, offsets = orc.pack_reads([b"ACGT\xc3\xa9ACGT", b"ACGT"])
     _, st, _ = _host("match", plan, seqs, offsets)
     assert st[0] == 2 and st[1] != 2
+
+
+def test_one_read_calls_vs_oracle(hip, orc):
+    """Adapter.match_to(str) / Aligner.locate(str): the one-read entry points (k_tiny: prefilter + cost scan of the
+    read in one single-wave launch, the cell DP only when the scan leaves the read to it) against the oracle and
+    against the general path (CAH_NO_TINY=1), over 3' adapters of every slot class, reads of every class of the
+    scan (none / exact / substitutions / indels / partial at the end), empty and non-ASCII reads."""
+    from cutadapt_amd import adapters as A
+    from cutadapt_amd.align import Aligner
+    rng = random.Random(909)
+    checked = dp_like = 0
+    for it in range(40):
+        m = rng.choice([3, 8, 13, 20, 33, 33, 40, 57, 64])
+        adapter = rs(rng, m)
+        kw = dict(max_errors=rng.choice([0.0, 0.1, 0.1, 0.2]), min_overlap=rng.randint(1, 5),
+                  read_wildcards=rng.random() < 0.2, indels=rng.random() < 0.85)
+        ad = A.BackAdapter(adapter, **kw)
+        spec = ad.matcher_spec()
+        oa = orc.Aligner(spec.sequence, spec.max_error_rate, spec.flags, spec.wildcard_ref, spec.wildcard_query,
+                         spec.indel_cost, spec.min_overlap)
+        of = orc.KmerFinder(spec.kmer_sets, spec.kmer_ref_wildcards, spec.kmer_query_wildcards)
+        al = Aligner(adapter, kw["max_errors"], flags=14, wildcard_query=kw["read_wildcards"],
+                     indel_cost=1 if kw["indels"] else 100000, min_overlap=kw["min_overlap"])
+        oal = orc.Aligner(adapter, kw["max_errors"], 14, False, kw["read_wildcards"], 1 if kw["indels"] else 100000,
+                          kw["min_overlap"])
+        for _ in range(60):
+            n = rng.choice([0, 1, 5, 20, 75, 150, 150, 301])
+            r = list(rs(rng, n, "ACGTN" if rng.random() < 0.2 else "ACGT"))
+            if n and rng.random() < 0.8:
+                piece = list(adapter[:rng.randint(1, m)] if rng.random() < 0.3 else adapter)
+                for _e in range(rng.choice([0, 0, 1, 1, 2, 3])):
+                    x = rng.randrange(len(piece))
+                    op = rng.random()
+                    if op < 0.6:
+                        piece[x] = rng.choice("ACGT")
+                    elif op < 0.8:
+                        piece.insert(x, rng.choice("ACGT"))
+                    elif len(piece) > 1:
+                        del piece[x]
+                pos = rng.randint(0, n)
+                r[pos:pos + len(piece)] = piece
+                r = r[:n]
+            read = "".join(r)
+            want = oa.locate(read) if of.kmers_present(read) else None
+            got = ad.match_to(read)
+            sig = None if got is None else (got.astart, got.astop, got.rstart, got.rstop, got.score, got.errors)
+            assert sig == want, (adapter, kw, read, sig, want)
+            os.environ["CAH_NO_TINY"] = "1"
+            try:
+                got2 = ad.match_to(read)
+            finally:
+                os.environ.pop("CAH_NO_TINY", None)
+            sig2 = None if got2 is None else (got2.astart, got2.astop, got2.rstart, got2.rstop, got2.score, got2.errors)
+            assert sig2 == want
+            assert al.locate(read) == oal.locate(read), (adapter, kw, read)
+            checked += 1
+            dp_like += want is not None and want[5] > 0
+    assert checked == 2400 and dp_like > 200
+    ad = A.BackAdapter("AGATCGGAAGAGC", max_errors=0.1, min_overlap=3)
+    with pytest.raises(ValueError):
+        ad.match_to("ACGTéACGT")
+    with pytest.raises(TypeError):
+        ad.match_to(b"ACGT")
