@@ -162,6 +162,8 @@ class _Worker:
                     -1 if o["maximum_length"] is None else int(o["maximum_length"]),
                     int(bool(o["discard_trimmed"])), int(bool(o["discard_untrimmed"])),
                     self.beg.data_ptr(), self.end.data_ptr(), self.keep.data_ptr(), self.counters.data_ptr(), sp))
+            if o.get("assemble") == "host":
+                return self._assemble_on_host(data, n_bytes, n)
             # ---- step 4: format on the device, bring the bytes back ---------------------------------------------
             _lib.check(L.cah_fastq_format_device(self.d_in.data_ptr(), self.rec6.data_ptr(), n, self.beg.data_ptr(),
                                                  self.end.data_ptr(), self.keep.data_ptr(), self.d_scratch.data_ptr(),
@@ -183,6 +185,46 @@ class _Worker:
             h_out[:total].copy_(self.d_out[:total], non_blocking=True)
             self.stream.synchronize()
         return h_out, total
+
+
+    def _assemble_on_host(self, data, n_bytes: int, n: int):
+        """Step 4, other half of the trade: only the record index and the kept intervals (57 bytes per record
+        instead of the ~280 of a formatted record) come back over PCIe, and the trimmed FASTQ is put together from
+        the chunk, which is in host memory anyway -- records kept whole are copied in runs
+        (``cah_fastq_write_trimmed``).  Byte-identical to the device formatter; leaves the outbound PCIe direction
+        almost idle at the price of one memcpy pass per chunk on a host core."""
+        torch = self.torch
+        L = _lib.lib()
+        if getattr(self, "_h_cap", 0) < n:
+            cap = int(n * 1.25) + 1024
+            self._h_rec6 = torch.empty((cap, 6), dtype=torch.int64).pin_memory()
+            self._h_beg = torch.empty(cap, dtype=torch.int32).pin_memory()
+            self._h_end = torch.empty(cap, dtype=torch.int32).pin_memory()
+            self._h_keep = torch.empty(cap, dtype=torch.uint8).pin_memory()
+            self._h_cap = cap
+        self.d_info[4:5].copy_(self.counters[6:7], non_blocking=True)
+        self.h_info.copy_(self.d_info, non_blocking=True)
+        if n:
+            self._h_rec6[:n].copy_(self.rec6[:n], non_blocking=True)
+            self._h_beg[:n].copy_(self.beg[:n], non_blocking=True)
+            self._h_end[:n].copy_(self.end[:n], non_blocking=True)
+            self._h_keep[:n].copy_(self.keep[:n], non_blocking=True)
+        self.stream.synchronize()
+        err = int(self.h_info[1])
+        if err != -1:
+            code, record = err & 0xFF, (err >> 8) - 1
+            what = {1: "line expected to start with '@'", 2: "third line expected to start with '+'",
+                    3: "length of sequence and qualities differ"}.get(code, "malformed record")
+            raise ValueError(f"FASTQ format error in record {record} of the chunk: {what}")
+        if int(self.h_info[4]) != self.invalid_seen:
+            raise ValueError("String must contain only ASCII characters")
+        h_out = self.pool.get(n_bytes + 4 * n + 64)
+        out_len = C.c_int64(0)
+        src_ptr = data.data_ptr() if isinstance(data, torch.Tensor) else data.ctypes.data
+        _lib.check(L.cah_fastq_write_trimmed(src_ptr, self._h_rec6.data_ptr(), n, self._h_beg.data_ptr(),
+                                             self._h_end.data_ptr(), self._h_keep.data_ptr(), h_out.data_ptr(),
+                                             h_out.numel(), C.byref(out_len)))
+        return h_out, int(out_len.value)
 
 
 # buffers outlive a call: pinning host memory and growing device buffers cost tens of milliseconds, more than a
@@ -275,17 +317,24 @@ def _chunks(source, chunk_bytes: int):
 def trim_fastq_gpu(source: Union[str, BinaryIO, np.ndarray], out: Union[str, BinaryIO, None], adapters,
                    discard_untrimmed: bool = False, discard_trimmed: bool = False,
                    minimum_length: Optional[int] = None, maximum_length: Optional[int] = None,
-                   chunk_bytes: int = DEFAULT_GPU_CHUNK_BYTES, threads: int = 3, devices=None) -> Dict[str, object]:
+                   chunk_bytes: int = DEFAULT_GPU_CHUNK_BYTES, threads: int = 3, devices=None,
+                   assemble: str = "device") -> Dict[str, object]:
     """``cutadapt <adapter options> [-m N] [-M N] [--discard-(un)trimmed] -o out in.fastq`` with the records
     indexed, matched, filtered and formatted on the GPU(s).  ``out``: path, binary file, or None (the output is
     produced and counted but not kept: measures the pipeline without a sink).  ``threads`` workers, each with
     its own stream and pinned buffers, dealt round-robin over ``devices`` (list of indices, "all", or None =
-    current device).  Returns the reference's counters (report.py:62-80)."""
+    current device).  ``assemble``: "device" formats the trimmed records on the GPU and brings the bytes back;
+    "host" brings back only the record index and kept intervals and copies the records together on the worker's
+    host core (same bytes; trades the outbound PCIe traffic for host memcpy); "mixed" lets every other worker do
+    that.  Returns the reference's counters
+    (report.py:62-80)."""
     import torch
+    if assemble not in ("device", "host", "mixed", "mixed3"):
+        raise ValueError("assemble must be 'device', 'host', 'mixed' or 'mixed3'")
     adapters, plan, kinds = _plan_for(adapters)
     pinned = _PINNED
     opts = {"discard_untrimmed": discard_untrimmed, "discard_trimmed": discard_trimmed,
-            "minimum_length": minimum_length, "maximum_length": maximum_length}
+            "minimum_length": minimum_length, "maximum_length": maximum_length, "assemble": assemble}
     if devices == "all":
         devices = list(range(torch.cuda.device_count()))
     elif devices is None:
@@ -302,7 +351,15 @@ def trim_fastq_gpu(source: Union[str, BinaryIO, np.ndarray], out: Union[str, Bin
                 dev = devices[len(workers) % len(devices)]
                 workers.append(None)
                 slot = len(workers) - 1
-            local.w = _take_worker(plan, kinds, dev, opts)
+            # "mixed": every other worker assembles on its host core -- the outbound PCIe traffic and the host's
+            # memcpy work are both halved (measured best when neither direction of the link is to be the bound)
+            # ("mixed3": two of three workers)
+            wopts = opts
+            if assemble == "mixed":
+                wopts = dict(opts, assemble="host" if slot % 2 else "device")
+            elif assemble == "mixed3":
+                wopts = dict(opts, assemble="host" if slot % 3 else "device")
+            local.w = _take_worker(plan, kinds, dev, wopts)
             with lock:
                 workers[slot] = local.w
         res = local.w.run(data, is_final)

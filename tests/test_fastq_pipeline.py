@@ -329,3 +329,58 @@ def test_reference_paired_goldens(hip):
         assert stats["pairs_written"] == n_out, case["name"]
         if case["name"] == "paired_end":
             assert stats["pairs"] - stats["pairs_written"] == stats["filtered"].get("too_short", 0) == 1
+
+
+def test_write_trimmed_runs_equal_piecewise_formatting():
+    """cah_fastq_write_trimmed copies records that are kept whole and already canonical in runs; the bytes must be
+    what formatting every record piece by piece gives -- LF / CRLF input, bare and repeated '+' lines, a file
+    without final line feed, dropped and trimmed records in between.  (Host code: no GPU needed.)"""
+    import ctypes as C
+    import random
+    import numpy as np
+    from cutadapt_amd import _lib
+    L = _lib.lib()
+    rng = random.Random(5)
+    for it in range(60):
+        crlf = it % 5 == 4
+        recs, parsed = [], []
+        for i in range(rng.randint(1, 300)):
+            n = rng.randint(0, 120)
+            s = "".join(rng.choice("ACGTN") for _ in range(n))
+            q = "".join(chr(rng.randint(33, 73)) for _ in range(n))
+            name = f"r{i}" + (" c" * rng.randint(0, 3))
+            plus = "+" + (name if rng.random() < 0.15 else "")
+            recs.append(f"@{name}\n{s}\n{plus}\n{q}\n")
+            parsed.append((name, s, q))
+        text = "".join(recs)
+        if crlf:
+            text = text.replace("\n", "\r\n")
+        if it % 7 == 3:
+            text = text.rstrip("\r\n")
+        buf = np.frombuffer(text.encode(), dtype=np.uint8)
+        n = len(parsed)
+        rec = np.zeros((n, 6), dtype=np.int64)
+        nrec, consumed = C.c_int64(0), C.c_int64(0)
+        _lib.check(L.cah_fastq_scan(buf.ctypes.data, len(buf), 1, n, rec.ctypes.data, C.byref(nrec), C.byref(consumed)))
+        assert nrec.value == n
+        beg = np.zeros(n, dtype=np.int32)
+        end = np.zeros(n, dtype=np.int32)
+        keep = np.ones(n, dtype=np.uint8)
+        want = []
+        for i, (name, s, q) in enumerate(parsed):
+            a, b = 0, len(s)
+            u = rng.random()
+            if u < 0.25 and len(s):
+                b = rng.randint(0, len(s))
+            elif u < 0.3 and len(s):
+                a = rng.randint(0, len(s))
+            elif u < 0.4:
+                keep[i] = 0
+            beg[i], end[i] = a, b
+            if keep[i]:
+                want.append(f"@{name}\n{s[a:b]}\n+\n{q[a:b]}\n")
+        out = np.zeros(len(buf) + 4 * n + 64, dtype=np.uint8)
+        out_len = C.c_int64(0)
+        _lib.check(L.cah_fastq_write_trimmed(buf.ctypes.data, rec.ctypes.data, n, beg.ctypes.data, end.ctypes.data,
+                                             keep.ctypes.data, out.ctypes.data, len(out), C.byref(out_len)))
+        assert bytes(out[:out_len.value]) == "".join(want).encode(), (it, crlf)

@@ -58,10 +58,12 @@ def test_device_fastq_equals_host_pipeline(hip):
             data = _fastq(rng, 3000, ad_seqs, crlf=crlf, final_newline=final_nl, lower=ci == 1)
             want = io.BytesIO()
             ws = trim_fastq(io.BytesIO(data), want, ads, index=False, **opts)
-            for source in (io.BytesIO(data), np.frombuffer(data, dtype=np.uint8)):
+            for source, assemble in ((io.BytesIO(data), "device"), (np.frombuffer(data, dtype=np.uint8), "device"),
+                                     (io.BytesIO(data), "host"), (np.frombuffer(data, dtype=np.uint8), "mixed")):
                 got = io.BytesIO()
-                gs = trim_fastq_gpu(source, got, ads, chunk_bytes=chunk, threads=2, devices="all", **opts)
-                assert got.getvalue() == want.getvalue(), (ci, crlf, final_nl, chunk)
+                gs = trim_fastq_gpu(source, got, ads, chunk_bytes=chunk, threads=2, devices="all", assemble=assemble,
+                                    **opts)
+                assert got.getvalue() == want.getvalue(), (ci, crlf, final_nl, chunk, assemble)
                 assert (gs["reads"], gs["with_adapters"], gs["bp_in"], gs["bp_out"]) == \
                        (ws["reads"], ws["with_adapters"], ws["bp_in"], ws["bp_out"]), (ci, gs, ws["reads"])
             assert gs["bytes_out"] == len(want.getvalue())
