@@ -1705,11 +1705,14 @@ __global__ __launch_bounds__(256) void k_back_scan(ScanArgs a) {
     __shared__ unsigned s_nf, s_nb;
     __shared__ long long s_tile;
     __shared__ unsigned long long s_gf, s_gb;
+    // one adapter: a STATIC 256-entry table (its address folds into the ds_read offset, the entry offset is
+    // "byte << 3": one SDWA instruction per column; bytes >= 0x80 find zeros and are flagged anyway)
+    __shared__ __attribute__((aligned(16))) uint64_t s_sm256[MULTI ? 1 : 256];
     const CahMatcher* mt = a.matcher;
     if (MULTI) {
         for (int i = threadIdx.x; i < a.n_adapters * CAH_MULTI_TAB_STRIDE; i += blockDim.x) s_scanmask[i] = a.tab[i];
     } else {
-        for (int i = threadIdx.x; i < CAH_TABLE_CHARS; i += blockDim.x) s_scanmask[i] = mt->scanmask[i];
+        for (int i = threadIdx.x; i < 256; i += blockDim.x) s_sm256[i] = i < CAH_TABLE_CHARS ? mt->scanmask[i] : 0ull;
     }
     for (int i = threadIdx.x; i <= CAH_MAX_M; i += blockDim.x) s_thr_last[i] = mt->thr_last[i];
     BackScanParams p;
@@ -1759,13 +1762,19 @@ __global__ __launch_bounds__(256) void k_back_scan(ScanArgs a) {
             // ends before 4 * key, so no row-m cost <= k occurs before it
             int j0 = 0;
             if (skip_cols && valid) j0 = max(0, ((int)key << CAH_KEY_SHIFT) - p.m - p.k - 1);
-            auto table_index = [&](unsigned c) -> unsigned {
-                return MULTI ? tab_base + multi_tab_index(c & 0xFFu) : (c & (CAH_TABLE_CHARS - 1));
+            // the match word of character t of a chunk
+            auto eq_of = [&](const Chunk& ck, int t) -> uint64_t {
+                if constexpr (MULTI) {
+                    return s_scanmask[tab_base + multi_tab_index(chunk_byte(ck, t) & 0xFFu)];
+                } else {
+                    const unsigned byte_off = ((ck.w[t >> 2] >> (8 * (t & 3))) & 0xFFu) << 3;
+                    return *reinterpret_cast<const uint64_t*>(reinterpret_cast<const unsigned char*>(s_sm256) + byte_off);
+                }
             };
 
             BackScanState st;
             bs_init(st, p);
-            int j = j0;
+            int j = j0, exact_j = 0;
             bool done = !valid, exact = false;
             // one 16-character chunk per iteration (per lane: its own window start), the next chunk requested
             // before this one is consumed, the LDS lookup of the next column's match word issued one column
@@ -1778,14 +1787,28 @@ __global__ __launch_bounds__(256) void k_back_scan(ScanArgs a) {
                 if (!__any(!done && j < n)) break;
                 const Chunk nxt = load_chunk(q, pos + 16, n, (!done) ? n : 0);
                 bad_chars |= cur.w[0] | cur.w[1] | cur.w[2] | cur.w[3];
-                uint64_t eq_next = s_scanmask[table_index(chunk_byte(cur, 0))];
+                uint64_t eq_next = eq_of(cur, 0);
+                if (__all(done || j + 16 <= n)) {
+                    // every lane still at work has the whole chunk ahead of it (the queue is ordered by window
+                    // start, so this is the rule): no per-column guards.  Lanes that are done -- as EXACT_FULL, or
+                    // idle from the start -- step along on NUL chunks; their state is not looked at again.
 #pragma unroll
-                for (int t = 0; t < 16; ++t) {
-                    const uint64_t eq = eq_next;
-                    if (t < 15) eq_next = s_scanmask[table_index(chunk_byte(cur, t + 1))];
-                    if (!done && j < n) {
+                    for (int t = 0; t < 16; ++t) {
+                        const uint64_t eq = eq_next;
+                        if (t < 15) eq_next = eq_of(cur, t + 1);
                         ++j;
-                        if (bs_step<!MULTI>(st, eq, j, p)) { exact = true; done = true; }
+                        if (bs_step<!MULTI>(st, eq, j, p) && !exact) { exact = true; exact_j = j; }
+                    }
+                    if (exact) done = true;
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) {
+                        const uint64_t eq = eq_next;
+                        if (t < 15) eq_next = eq_of(cur, t + 1);
+                        if (!done && j < n) {
+                            ++j;
+                            if (bs_step<!MULTI>(st, eq, j, p)) { exact = true; exact_j = j; done = true; }
+                        }
                     }
                 }
                 pos += 16;
@@ -1795,7 +1818,7 @@ __global__ __launch_bounds__(256) void k_back_scan(ScanArgs a) {
 
             int o0 = 0, o1 = 0;
             int cls = bs_finish(st, n, j0, p, [&](int i) { return s_thr_last[i]; }, o0, o1);
-            if (exact) { cls = BS_EXACT_FULL; o0 = j; }
+            if (exact) { cls = BS_EXACT_FULL; o0 = exact_j; }
             if (MULTI) {
                 // invalid reads were flagged by the prefilter (it sees every character); matches are merged
                 // with one atomic max on the read's best key
