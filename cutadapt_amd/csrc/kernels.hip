@@ -593,6 +593,24 @@ __device__ __forceinline__ uint32_t lean_chunk(const LeanWords<NL, NG>& L, LeanS
     return f3;
 }
 
+// The last chunk of a read when at most eight of its characters are left (150 = 9 x 16 + 6): only the first half,
+// whose lead masks are waiting in S.mk0 -- nothing is requested, nothing of a next chunk is looked at.
+template <bool UNIFORM, bool GATED, int DL, int NL, int NG>
+__device__ __forceinline__ uint32_t lean_half_chunk(const LeanWords<NL, NG>& L, LeanState<NL, NG>& S, const Chunk& cur,
+                                                    const int pos, const int n, uint32_t (&gg)[3]) {
+    typedef LeanLayout<DL, NL, NG> LY;
+    uint32_t f0 = 0, f1 = 0;
+    lean_lead8<DL, NL, NG>(L, S, S.mk0, f0, f1);
+    if constexpr (GATED) {
+        unsigned ad_g[8];
+        lean_addr8<LY::GATED_SHIFT>(ad_g, cur.w[0], cur.w[1]);
+        lean_gated8<UNIFORM, DL, NL, NG>(L, S, ad_g, pos, n, f0, f1);
+    }
+    f1 |= f0;
+    gg[0] = f0; gg[1] = f1; gg[2] = f1;
+    return f1;
+}
+
 // Is the chunk at `pos` (16 characters) clear of every window of the gated words?  (tail windows: the last
 // tail_span characters of a read of length n; head windows: the first head_span.)  Wave-uniform.  Once a chunk
 // touches a tail window every later chunk does, and only the first chunks touch a head window.
@@ -995,9 +1013,20 @@ __global__ __launch_bounds__(STREAM_BLOCK_WAVES * WAVE, STREAM_WAVES) void k_fil
             // chunks at the head windows, the stretch without windows (lead words only), chunks at the tail windows
             int pos = 0;                                                // wave-uniform
             bool more = true;
-            for (; more && pos < n && pos < L.head_span; pos += 16) more = step(std::true_type{}, pos);
-            for (; more && pos < n && lean_chunk_ungated<true, NL, NG>(L, pos, n); pos += 16) more = step(std::false_type{}, pos);
-            for (; more && pos < n; pos += 16) more = step(std::true_type{}, pos);
+            const int n_full = n - 8;                                   // chunks starting below it have > 8 characters
+            for (; more && pos < n_full && pos < L.head_span; pos += 16) more = step(std::true_type{}, pos);
+            for (; more && pos < n_full && lean_chunk_ungated<true, NL, NG>(L, pos, n); pos += 16) more = step(std::false_type{}, pos);
+            for (; more && pos < n_full; pos += 16) more = step(std::true_type{}, pos);
+            if (more && pos < n && __any(valid && hit_pos < 0)) {
+                // at most eight characters left: half a chunk
+                const bool live = valid && hit_pos < 0;
+                seen |= cur.w[0] | cur.w[1] | cur.w[2] | cur.w[3];
+                uint32_t gg[3];
+                uint32_t found;
+                if (lean_chunk_ungated<true, NL, NG>(L, pos, n)) found = lean_half_chunk<true, false, DL, NL, NG>(L, S, cur, pos, n, gg);
+                else found = lean_half_chunk<true, true, DL, NL, NG>(L, S, cur, pos, n, gg);
+                if (live && found != 0) hit_pos = pos + (gg[0] ? 0 : 4);
+            }
             const bool invalid = (seen & 0x80808080u) != 0;
             lean_emit(a, r, tile_base, valid, hit_pos >= 0, invalid, hit_pos, s_idx, s_key, s_hist, s_count);
         }
