@@ -1960,27 +1960,50 @@ __global__ __launch_bounds__(64) void k_tiny(TinyArgs a) {
     if (n64 > a.max_read_len) { invalid = true; n64 = 0; }
     const int n = (int)n64;
     // The reads may sit in mapped HOST memory (the one-read path queues no copies): every load from there is a
-    // trip over PCIe, so a small batch is brought into LDS once, with the whole wave, and matched from there.
-    __shared__ __attribute__((aligned(16))) uint8_t s_stage[TINY_STAGE_BYTES + 32];
+    // trip over PCIe, so a small batch is brought into LDS once, with the whole wave, and matched from there
+    // (behind 32 NUL bytes: see the one-read prefilter below).
+    __shared__ __attribute__((aligned(16))) uint8_t s_stage[32 + TINY_STAGE_BYTES + 32];
     const int64_t batch_bytes = a.offsets[a.n_reads] - a.offsets[0];
     const bool staged = batch_bytes <= TINY_STAGE_BYTES;
     if (staged) {
         const uint8_t* src = a.seqs + a.offsets[0];
-        for (int i = threadIdx.x; i < (int)batch_bytes; i += blockDim.x) s_stage[i] = src[i];
+        if (threadIdx.x < 32) s_stage[threadIdx.x] = 0;
+        for (int i = threadIdx.x; i < (int)batch_bytes; i += blockDim.x) s_stage[32 + i] = src[i];
         __syncthreads();
     }
-    const uint8_t* q = staged ? (const uint8_t*)s_stage + (off - a.offsets[0]) : a.seqs + off;
+    const uint8_t* q = staged ? (const uint8_t*)s_stage + 32 + (off - a.offsets[0]) : a.seqs + off;
 
     // ---- prefilter (the loop of k_filter_lean<false, ..>) ------------------------------------------------
+    // ONE read (the per-read API): all 64 lanes work on it -- lane l owns characters [16 l, 16 l + 16) and warms its
+    // words up on the 32 characters in front of them (a k-mer is at most 32 characters long, so after them every
+    // state bit is exact; in front of the read there are NULs).  To the word machinery that is a batch of 64
+    // "reads": the suffix of (32 NULs + read) from 16 l on, of which only three chunks are run and only the third
+    // one's ends count.  The tail gates look at the distance from the true end, which the suffix keeps.  An end
+    // counted again by a later lane (accumulated words) names a later position; the earliest one is taken.
+    // Needs no head windows (3' adapters have none).
+    const int n0 = (int)(a.offsets[1] - a.offsets[0]);                     // wave-uniform
+    const bool par = lf && a.n_reads == 1 && staged && n0 > 16 && n0 <= 1008 && lf->head_span == 0 &&
+                     n0 <= a.max_read_len;
     bool hit = valid && !invalid;
     int hit_pos = 0;
     if (lf) {
         LeanWords<NL, NG> L;
         lean_words_init<NL, NG>(L, lf, s_tab, s_gate);
-        int n_max = n;
+        // the filter's view of "its" read
+        const uint8_t* qf = q;
+        int nf = n;
+        bool validf = valid;
+        if (par) {
+            qf = (const uint8_t*)s_stage + 16 * lane;
+            nf = n0 + 32 - 16 * lane;
+            validf = 16 * lane < n0;
+            if (!validf) nf = 0;
+        }
+        int n_max = nf;
 #pragma unroll
         for (int d = 1; d < WAVE; d <<= 1) n_max = max(n_max, __shfl_xor(n_max, d, WAVE));
         n_max = __builtin_amdgcn_readfirstlane(n_max);
+        if (par) n_max = min(n_max, 48);
         hit = false;
         unsigned seen = 0;
         LeanState<NL, NG> S;
@@ -1988,23 +2011,23 @@ __global__ __launch_bounds__(64) void k_tiny(TinyArgs a) {
         for (int w = 0; w < NL; ++w) { S.RL[w] = 0; S.accL[w] = 0; }
 #pragma unroll
         for (int w = 0; w < NG; ++w) { S.RG[w] = 0; S.accG[w] = 0; }
-        Chunk cur = load_chunk(q, 0, n, valid ? n : 0);
-        Chunk nxt = load_chunk(q, 16, n, valid ? n : 0);
+        Chunk cur = load_chunk(qf, 0, nf, validf ? nf : 0);
+        Chunk nxt = load_chunk(qf, 16, nf, validf ? nf : 0);
         {
             unsigned ad[8];
             lean_addr8<LeanLayout<DL, NL, NG>::LEAD_SHIFT>(ad, cur.w[0], cur.w[1]);
             lean_issue_lead<DL, NL, NG>(L, S.mk0, ad);
         }
         auto step = [&](auto gated, int pos) -> bool {
-            const bool live = valid && !hit && pos < n;
+            const bool live = validf && !hit && pos < nf;
             if (!__any(live)) return false;
-            const Chunk nx2 = load_chunk(q, pos + 32, n, live ? n : 0);
-            seen |= cur.w[0] | cur.w[1] | cur.w[2] | cur.w[3];
+            const Chunk nx2 = load_chunk(qf, pos + 32, nf, live ? nf : 0);
+            if (!par || pos == 32) seen |= cur.w[0] | cur.w[1] | cur.w[2] | cur.w[3];
             uint32_t gg[3];
             Chunk got;
             const uint32_t found = lean_chunk<false, decltype(gated)::value, DL, NL, NG>(
-                L, S, cur, [&]() { return nxt; }, got, pos, n, gg);
-            if (live && found != 0) {
+                L, S, cur, [&]() { return nxt; }, got, pos, nf, gg);
+            if (live && found != 0 && (!par || pos == 32)) {
                 hit = true;
                 hit_pos = pos + (gg[0] ? 0 : gg[1] ? 4 : gg[2] ? 8 : 12);
             }
@@ -2015,8 +2038,19 @@ __global__ __launch_bounds__(64) void k_tiny(TinyArgs a) {
         int pos = 0;
         bool more = true;
         for (; more && pos < n_max && pos < L.head_span; pos += 16) more = step(std::true_type{}, pos);
-        for (; more && pos < n_max && lean_chunk_ungated<false, NL, NG>(L, pos, n); pos += 16) more = step(std::false_type{}, pos);
+        for (; more && pos < n_max && lean_chunk_ungated<false, NL, NG>(L, pos, nf); pos += 16) more = step(std::false_type{}, pos);
         for (; more && pos < n_max; pos += 16) more = step(std::true_type{}, pos);
+        if (par) {
+            // back to one read on lane 0: any end, the earliest position, every byte seen
+            int first = hit ? 16 * lane + (hit_pos - 32) : 0x7fffffff;
+#pragma unroll
+            for (int d = 1; d < WAVE; d <<= 1) {
+                first = min(first, __shfl_xor(first, d, WAVE));
+                seen |= __shfl_xor(seen, d, WAVE);
+            }
+            hit = lane == 0 && first != 0x7fffffff;
+            hit_pos = hit ? first : 0;
+        }
         if (seen & 0x80808080u) invalid = true;
         hit = hit && !invalid;
     }
