@@ -825,8 +825,9 @@ class AdapterIndex:
     The dictionary {string within k errors of an adapter: (adapter, errors, matches)} is built and
     held by the library (``cah_index_create``; hash table in HBM), reads are matched with one lookup
     kernel (``cah_index_lookup_batch``).  Restrictions as in the reference (:1296-1299): at most 3
-    errors, no wildcards in adapters or reads; this build additionally wants plain ACGT adapters
-    of at most 60 characters (``is_acceptable`` says so)."""
+    errors, no wildcards in adapters or reads.  Plain ACGT adapters of up to 60 characters get the
+    2-bit packed table; longer ones (up to 1000 characters) and adapters with other characters
+    (possible with ``adapter_wildcards=False``) a table of hashed byte strings."""
 
     def __init__(self, adapters, prefix: bool):
         if not adapters:
@@ -862,8 +863,8 @@ class AdapterIndex:
         k = int(len(adapter) * adapter.max_error_rate)
         if k > 3:
             raise ValueError("Error rate too high")
-        if not set(adapter.sequence) <= set("ACGT") or len(adapter.sequence) > 60:
-            raise ValueError("Only A, C, G, T adapters of up to 60 characters can be indexed by this build")
+        if len(adapter.sequence) > 1000:
+            raise ValueError("Adapters of more than 1000 characters cannot be indexed by this build")
 
     @classmethod
     def is_acceptable(cls, adapter, prefix: bool) -> bool:

@@ -8,9 +8,21 @@
 //
 // Here the dictionary is built on the host by cah_index_create (same strings, same
 // errors/matches, same collision and ambiguity rules), stored as an open-addressing hash table
-// of 2-bit packed strings and probed by one GPU lane per read (k_index_lookup).  The rare reads
-// whose affix contains 'N' take the reference's re-alignment path (_lookup_with_n, :1532-1551)
-// inside the same kernel with a scalar per-lane restatement of Aligner.locate / the comparers.
+// and probed by one GPU lane per read (k_index_lookup).  The rare reads whose affix contains 'N'
+// take the reference's re-alignment path (_lookup_with_n, :1532-1551) inside the same kernel with
+// a scalar per-lane restatement of Aligner.locate / the comparers.
+//
+// Two table layouts:
+//   packed  every adapter is plain ACGT and at most 60 characters long (barcodes, primers): the
+//           key IS the string, two bits per character in 2 x 64 bits -- no verification needed;
+//   wide    anything else the reference accepts (adapters.py:1373-1386 has no length or alphabet
+//           rule): adapters of up to 1000 characters and of any ASCII characters.  Keys are byte
+//           strings (walked from the anchored end) in a pool; an entry holds the 64-bit FNV-1a
+//           hash, which is a PREFIX hash -- one walk over the read yields the hash of every
+//           indexed length -- and a hit is verified against the pool.  Non-ACGT characters only
+//           survive in keys of --no-indels adapters (hamming_sphere keeps them, _align.pyx:717-781;
+//           edit_environment emits ACGT only and counts them as mismatches, :794, :835) and match
+//           a read holding the very same character there.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -44,6 +56,8 @@ namespace {
 
 constexpr int IDX_MAX_ADAPTER = 60;        // strings up to 60 + 3 characters fit 2 x 64 bits
 constexpr int IDX_MAX_STRING = 64;
+constexpr int IDX_WIDE_MAX_ADAPTER = 1000; // wide layout: the re-alignment columns of one wave live in LDS
+constexpr uint64_t IDX_FNV_OFFSET = 0xCBF29CE484222325ull, IDX_FNV_PRIME = 0x100000001B3ull;
 constexpr int IDX_MAX_LENGTHS = 64;
 constexpr int IDX_MAX_DEVICES = 16;
 constexpr uint32_t IDX_EMPTY = 0xFFFFFFFFu;
@@ -52,6 +66,14 @@ struct IdxEntry {             // 24 bytes
     uint64_t lo, hi;          // characters 0..31 / 32..63, two bits each (A0 C1 G2 T3), unused bits 0
     uint32_t len;             // IDX_EMPTY marks a free slot
     uint32_t val;             // adapter << 12 | errors << 8 | matches
+};
+
+struct IdxWideEntry {         // 24 bytes
+    uint64_t hash;            // idx_wide_hash(FNV-1a state after len characters, len)
+    uint32_t off;             // key characters in the pool, walked from the anchored end
+    uint32_t len;             // IDX_EMPTY marks a free slot
+    uint32_t adapter;
+    uint32_t em;              // errors << 16 | matches
 };
 
 struct IdxAdapter {
@@ -66,6 +88,8 @@ struct IdxKmer { int32_t off, len; };                             // into the k-
 struct IdxDeviceCopy {
     bool ready = false;
     IdxEntry* d_table = nullptr;
+    IdxWideEntry* d_wtable = nullptr;
+    uint8_t* d_pool = nullptr;
     int32_t* d_lengths = nullptr;
     IdxAdapter* d_adapters = nullptr;
     uint8_t* d_seqs = nullptr;
@@ -83,6 +107,14 @@ __host__ __device__ inline uint64_t idx_hash(uint64_t lo, uint64_t hi, uint32_t 
     return h;
 }
 
+__host__ __device__ inline uint64_t idx_wide_hash(uint64_t state, uint32_t len) {
+    uint64_t h = state ^ ((uint64_t)len * 0x9E3779B97F4A7C15ull);
+    h ^= h >> 31;
+    h *= 0xBF58476D1CE4E5B9ull;
+    h ^= h >> 29;
+    return h;
+}
+
 inline int code_of(char c) {
     switch (c) {
         case 'A': return 0;
@@ -97,7 +129,10 @@ inline int code_of(char c) {
 
 struct cah_index {
     bool prefix = true;
+    bool wide = false;                      // see the header: packed 2-bit keys or hashed byte strings
     std::vector<IdxEntry> table;
+    std::vector<IdxWideEntry> wtable;
+    std::string pool;
     uint64_t mask = 0;
     std::vector<int32_t> lengths;           // descending (adapters.py:1482)
     std::vector<IdxAdapter> adapters;
@@ -200,6 +235,8 @@ void hamming_sphere(const std::string& s, int k, F&& emit) {
 // ---------------------------------------------------------------------------------------------
 struct IndexArgs {
     const IdxEntry* table;
+    const IdxWideEntry* wtable;
+    const uint8_t* pool;
     uint64_t mask;
     const int32_t* lengths;
     int n_lengths;
@@ -223,11 +260,12 @@ __device__ __forceinline__ uint8_t dev_upper(uint8_t c) { return (c >= 'a' && c 
 // Scalar restatement of Aligner.locate (_align.pyx:298-587) for one lane: no wildcards (bytes
 // compared for equality after upper-casing the query, :322-328), unit indel cost, min_overlap = m
 // (anchored adapters), flags = QUERY_STOP (PrefixAdapter) or QUERY_START (SuffixAdapter).
-// Returns true and (score, errors) for a match.  Column arrays live in scratch memory: this is
-// the rare 'N in the affix' path.
+// Returns true and (score, errors) for a match.  C, S, O: the column (m + 1 entries each) -- scratch
+// memory in the packed kernel, the wave's LDS in the wide one: this is the rare 'N in the affix' path.
+template <class IntPtr>
 __device__ bool dev_locate_anchored(const uint8_t* ref, const int m, const double rate, const bool is_prefix,
-                                    const uint8_t* query, const int n, int& out_score, int& out_errors) {
-    int C[IDX_MAX_ADAPTER + 1], S[IDX_MAX_ADAPTER + 1], O[IDX_MAX_ADAPTER + 1];
+                                    const uint8_t* query, const int n, int& out_score, int& out_errors,
+                                    IntPtr C, IntPtr S, IntPtr O) {
     const bool start_in_query = !is_prefix, stop_in_query = is_prefix;      // Where.SUFFIX = 2, Where.PREFIX = 8
     const int k = (int)(rate * m);                                          // :343
     int max_n = n, min_n = 0;
@@ -402,7 +440,9 @@ __global__ __launch_bounds__(256) void k_index_lookup(IndexArgs a) {
             const uint8_t* affix = prefix ? q : q + (n - lq);
             int sc = 0, er = 0;
             if (A.set_end >= 0 && !dev_kmers_present(a, A, affix, lq)) continue;     // match_to() -> None
-            const bool ok = A.indels ? dev_locate_anchored(a.adapter_seqs + A.off, A.m, A.rate, prefix, affix, lq, sc, er)
+            int C[IDX_MAX_ADAPTER + 1], S[IDX_MAX_ADAPTER + 1], O[IDX_MAX_ADAPTER + 1];
+            const bool ok = A.indels ? dev_locate_anchored(a.adapter_seqs + A.off, A.m, A.rate, prefix, affix, lq, sc, er,
+                                                           &C[0], &S[0], &O[0])
                                      : dev_compare_anchored(a.adapter_seqs + A.off, A.m, A.max_k, prefix, affix, lq, sc, er);
             if (!ok) continue;
             e = er; m = sc;
@@ -415,6 +455,100 @@ __global__ __launch_bounds__(256) void k_index_lookup(IndexArgs a) {
     if (best_ad < 0) { a.status[r] = CAH_NONE; if (a.best_adapter) a.best_adapter[r] = -1; return; }
     // _make_prefix_match / _make_suffix_match (:1345-1371): the INDEXED length is reported, even for
     // a shorter read
+    o[0] = 0;
+    o[1] = a.adapters[best_ad].m;
+    o[2] = prefix ? 0 : n - best_len;
+    o[3] = prefix ? best_len : n;
+    o[4] = best_m;
+    o[5] = best_e;
+    a.status[r] = CAH_MATCH;
+    if (a.best_adapter) a.best_adapter[r] = best_ad;
+}
+
+// The wide layout (see the header).  One read per lane; the read is walked once from its anchored end, the
+// FNV-1a state after t characters is the key hash of the affix of length t, so every indexed length is probed
+// on the way -- shortest first.  The reference tries the longest first and keeps a later candidate only if it
+// is strictly better (more matches, or as many with fewer errors; :1516-1524), its early exit (:1503-1505) skips
+// lengths that cannot have as many matches as the best: the winner is the LONGEST length among the best
+// (matches, errors), which going upwards is "replace unless strictly worse".
+// Reads shorter than an indexed length L are looked up whole (s[:L] / s[-L:] of a shorter string) and still
+// reported with the length L (_make_*_match, :1345-1371).
+// 'N' re-alignment: the column arrays of Aligner.locate need m + 1 entries; they live in LDS, one set per wave,
+// and the lanes that need them take turns (reads with 'N' in the affix are rare).
+constexpr int IDX_WIDE_COLS = IDX_WIDE_MAX_ADAPTER + 1;
+
+__global__ __launch_bounds__(256) void k_index_lookup_wide(IndexArgs a) {
+    __shared__ int s_cols[4][3][IDX_WIDE_COLS];
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.n_reads) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t off = a.offsets[r];
+    const int64_t n64 = a.lens ? (int64_t)a.lens[r] : a.offsets[r + 1] - off;
+    const int n = (int)(n64 > CAH_MAX_READ_LEN ? 0 : n64);
+    const uint8_t* q = a.seqs + off;
+    const bool prefix = a.prefix != 0;
+    const int lmax = a.lengths[0];
+    const int la = min(lmax, n);
+    bool non_ascii = n64 > CAH_MAX_READ_LEN;
+    int first_n = 1 << 30;
+    int best_m = -1, best_e = 1000, best_len = 0, best_ad = -1;
+    uint64_t state = IDX_FNV_OFFSET;
+    int li = a.n_lengths - 1;                                                // shortest indexed length
+    // the character at distance t from the anchored end as the dictionary sees it: upper case (:1471, :1492),
+    // 'N' looked up as 'A' (:1535)
+    auto key_char = [&](const int t) -> uint8_t {
+        const uint8_t c = dev_upper(prefix ? q[t] : q[n - 1 - t]);
+        return c == 'N' ? (uint8_t)'A' : c;
+    };
+    auto probe = [&](const int lq, const int L) {
+        const uint64_t h = idx_wide_hash(state, (uint32_t)lq);
+        uint64_t slot = h & a.mask;
+        for (;;) {
+            const IdxWideEntry e = a.wtable[slot];
+            if (e.len == IDX_EMPTY) return;
+            if (e.hash == h && e.len == (uint32_t)lq) {
+                const uint8_t* key = a.pool + e.off;
+                int t = 0;
+                while (t < lq && key[t] == key_char(t)) t++;
+                if (t == lq) {
+                    int ad = (int)e.adapter, er = (int)(e.em >> 16), m = (int)(e.em & 0xFFFF);
+                    bool ok = true;
+                    bool redo = first_n < lq;        // the counts assume 'A' where the read has 'N' (:1543-1551)
+                    while (redo) {
+                        if (lane == __builtin_amdgcn_readfirstlane(lane)) {
+                            const IdxAdapter A = a.adapters[ad];
+                            const uint8_t* affix = prefix ? q : q + (n - lq);
+                            int sc = 0, e2 = 0;
+                            if (A.set_end >= 0 && !dev_kmers_present(a, A, affix, lq)) ok = false;   // match_to() -> None
+                            else
+                                ok = A.indels ? dev_locate_anchored(a.adapter_seqs + A.off, A.m, A.rate, prefix, affix, lq, sc, e2,
+                                                                    &s_cols[wave][0][0], &s_cols[wave][1][0], &s_cols[wave][2][0])
+                                              : dev_compare_anchored(a.adapter_seqs + A.off, A.m, A.max_k, prefix, affix, lq, sc, e2);
+                            er = e2; m = sc;
+                            redo = false;
+                        }
+                    }
+                    if (ok && (m > best_m || (m == best_m && er <= best_e))) { best_ad = ad; best_e = er; best_m = m; best_len = L; }
+                    return;
+                }
+            }
+            slot = (slot + 1) & a.mask;
+        }
+    };
+    for (int t = 0;; t++) {
+        while (li >= 0 && a.lengths[li] == t) { probe(t, t); li--; }
+        if (t >= la) break;
+        const uint8_t raw = prefix ? q[t] : q[n - 1 - t];
+        non_ascii |= raw >= 0x80;
+        const uint8_t c = dev_upper(raw);
+        if (c == 'N') first_n = min(first_n, t);
+        state = (state ^ (uint64_t)(c == 'N' ? (uint8_t)'A' : c)) * IDX_FNV_PRIME;
+    }
+    // the indexed lengths beyond the read's own: all look the whole read up, the longest reports
+    if (li >= 0) probe(n, a.lengths[0]);
+    int32_t* o = a.out6 + r * 6;
+    if (non_ascii) { a.status[r] = CAH_INVALID; if (a.best_adapter) a.best_adapter[r] = -1; return; }
+    if (best_ad < 0) { a.status[r] = CAH_NONE; if (a.best_adapter) a.best_adapter[r] = -1; return; }
     o[0] = 0;
     o[1] = a.adapters[best_ad].m;
     o[2] = prefix ? 0 : n - best_len;
@@ -443,8 +577,15 @@ int index_on_device(const cah_index* ix, const IdxDeviceCopy** out) {
         if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
             return cah_set_error_(CAH_EUNSUPPORTED, "this library is built for gfx950 (MI355X) only");
         dc.n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        IDX_TRY(hipMalloc((void**)&dc.d_table, sizeof(IdxEntry) * ix->table.size()));
-        IDX_TRY(hipMemcpy(dc.d_table, ix->table.data(), sizeof(IdxEntry) * ix->table.size(), hipMemcpyHostToDevice));
+        if (ix->wide) {
+            IDX_TRY(hipMalloc((void**)&dc.d_wtable, sizeof(IdxWideEntry) * ix->wtable.size()));
+            IDX_TRY(hipMemcpy(dc.d_wtable, ix->wtable.data(), sizeof(IdxWideEntry) * ix->wtable.size(), hipMemcpyHostToDevice));
+            IDX_TRY(hipMalloc((void**)&dc.d_pool, ix->pool.size() + 1));
+            IDX_TRY(hipMemcpy(dc.d_pool, ix->pool.data(), ix->pool.size(), hipMemcpyHostToDevice));
+        } else {
+            IDX_TRY(hipMalloc((void**)&dc.d_table, sizeof(IdxEntry) * ix->table.size()));
+            IDX_TRY(hipMemcpy(dc.d_table, ix->table.data(), sizeof(IdxEntry) * ix->table.size(), hipMemcpyHostToDevice));
+        }
         IDX_TRY(hipMalloc((void**)&dc.d_lengths, sizeof(int32_t) * ix->lengths.size()));
         IDX_TRY(hipMemcpy(dc.d_lengths, ix->lengths.data(), sizeof(int32_t) * ix->lengths.size(), hipMemcpyHostToDevice));
         IDX_TRY(hipMalloc((void**)&dc.d_adapters, sizeof(IdxAdapter) * ix->adapters.size()));
@@ -491,18 +632,17 @@ static int index_create_impl(const cah_index_adapter* adapters, int32_t n_adapte
     for (int32_t a = 0; a < n_adapters; a++) {
         const cah_index_adapter& d = adapters[a];
         if (d.length <= 0 || !d.sequence) return cah_set_error_(CAH_EINVAL, "cah_index_create: empty adapter sequence");
-        if (d.length > IDX_MAX_ADAPTER) {
+        if (d.length > IDX_WIDE_MAX_ADAPTER) {
             char msg[128];
-            snprintf(msg, sizeof(msg), "adapter %d: length %d exceeds the %d-character limit of the index", a, d.length, IDX_MAX_ADAPTER);
+            snprintf(msg, sizeof(msg), "adapter %d: length %d exceeds the %d-character limit of the index", a, d.length, IDX_WIDE_MAX_ADAPTER);
             return cah_set_error_(CAH_EUNSUPPORTED, msg);
         }
         const std::string seq(d.sequence, (size_t)d.length);
-        for (char c : seq)
-            if (code_of(c) < 0) {
-                char msg[160];
-                snprintf(msg, sizeof(msg), "adapter %d: only upper-case A, C, G, T can be indexed (found '%c')", a, c);
-                return cah_set_error_(CAH_EUNSUPPORTED, msg);
-            }
+        if (d.length > IDX_MAX_ADAPTER) ix->wide = true;
+        for (char c : seq) {
+            if ((unsigned char)c >= 0x80 || c == 0) return cah_set_error_(CAH_EINVAL, "cah_index_create: adapter sequences must be ASCII");
+            if (code_of(c) < 0) ix->wide = true;
+        }
         const int k = (int)(d.length * d.max_error_rate);                    // adapters.py:1383
         if (k > 3 || k < 0) return cah_set_error_(CAH_EINVAL, "Error rate too high");
         IdxAdapter ia;
@@ -559,13 +699,40 @@ static int index_create_impl(const cah_index_adapter* adapters, int32_t n_adapte
     }
     ix->n_ambiguous = (int32_t)ambiguous.size();
     for (const std::string& s : ambiguous) index.erase(s);                   // :1463-1464
-    if (lengths.empty() || *lengths.rbegin() > IDX_MAX_STRING - 1 || (int)lengths.size() > IDX_MAX_LENGTHS)
+    // (an adapter with a non-ACGT character, indels and k = 0 contributes no string at all: lengths may be empty)
+    if ((int)lengths.size() > IDX_MAX_LENGTHS)
+        return cah_set_error_(CAH_EUNSUPPORTED, "more than 64 different string lengths in one index");
+    if (!ix->wide && !lengths.empty() && *lengths.rbegin() > IDX_MAX_STRING - 1)
         return cah_set_error_(CAH_EUNSUPPORTED, "index string lengths out of range");
     ix->lengths.assign(lengths.rbegin(), lengths.rend());                    // sorted, longest first (:1482)
     ix->n_strings = (int64_t)index.size();
     uint64_t cap = 16;
     while (cap < 2 * (uint64_t)index.size() + 2) cap <<= 1;
     ix->mask = cap - 1;
+    if (ix->wide) {
+        ix->wtable.assign(cap, IdxWideEntry{0, 0, IDX_EMPTY, 0, 0});
+        size_t total = 0;
+        for (const auto& kv : index) total += kv.first.size();
+        if (total >= 0xFFFFFFFFull) return cah_set_error_(CAH_EUNSUPPORTED, "the index strings exceed 4 GiB");
+        ix->pool.reserve(total + 1);
+        for (const auto& kv : index) {
+            const std::string& str = kv.first;
+            const uint32_t len = (uint32_t)str.size(), off = (uint32_t)ix->pool.size();
+            uint64_t st = IDX_FNV_OFFSET;
+            for (uint32_t t = 0; t < len; t++) {
+                const uint8_t c = (uint8_t)(ix->prefix ? str[t] : str[len - 1 - t]);
+                ix->pool.push_back((char)c);
+                st = (st ^ (uint64_t)c) * IDX_FNV_PRIME;
+            }
+            const uint64_t hsh = idx_wide_hash(st, len);
+            uint64_t slot = hsh & ix->mask;
+            while (ix->wtable[slot].len != IDX_EMPTY) slot = (slot + 1) & ix->mask;
+            ix->wtable[slot] = IdxWideEntry{hsh, off, len, (uint32_t)kv.second.adapter,
+                                            ((uint32_t)kv.second.errors << 16) | (uint32_t)kv.second.matches};
+        }
+        *out = ix.release();
+        return CAH_OK;
+    }
     ix->table.assign(cap, IdxEntry{0, 0, IDX_EMPTY, 0});
     for (const auto& kv : index) {
         uint64_t lo, hi;
@@ -588,7 +755,7 @@ void cah_index_destroy(cah_index* ix) {
         int cur = 0;
         if (hipGetDevice(&cur) != hipSuccess) cur = -1;
         if (hipSetDevice(d) == hipSuccess) {
-            (void)hipFree(dc.d_table); (void)hipFree(dc.d_lengths); (void)hipFree(dc.d_adapters); (void)hipFree(dc.d_seqs);
+            (void)hipFree(dc.d_table); (void)hipFree(dc.d_wtable); (void)hipFree(dc.d_pool); (void)hipFree(dc.d_lengths); (void)hipFree(dc.d_adapters); (void)hipFree(dc.d_seqs);
             (void)hipFree(dc.d_sets); (void)hipFree(dc.d_kmers); (void)hipFree(dc.d_kmer_chars);
         }
         if (cur >= 0) (void)hipSetDevice(cur);
@@ -610,7 +777,28 @@ int cah_index_get(const cah_index* ix, const char* s, int32_t len, int32_t* foun
                   int32_t* errors, int32_t* matches) {
     if (!ix || !found || (len > 0 && !s)) return cah_set_error_(CAH_EINVAL, "cah_index_get: NULL argument");
     *found = 0;
-    if (len < 0 || len >= IDX_MAX_STRING) return CAH_OK;
+    if (len < 0) return CAH_OK;
+    if (ix->wide) {
+        uint64_t st = IDX_FNV_OFFSET;
+        std::string key((size_t)len, 'A');
+        for (int32_t t = 0; t < len; t++) {
+            key[(size_t)t] = ix->prefix ? s[t] : s[len - 1 - t];
+            st = (st ^ (uint64_t)(uint8_t)key[(size_t)t]) * IDX_FNV_PRIME;
+        }
+        const uint64_t hsh = idx_wide_hash(st, (uint32_t)len);
+        for (uint64_t slot = hsh & ix->mask;; slot = (slot + 1) & ix->mask) {
+            const IdxWideEntry& e = ix->wtable[slot];
+            if (e.len == IDX_EMPTY) return CAH_OK;
+            if (e.hash == hsh && e.len == (uint32_t)len && memcmp(ix->pool.data() + e.off, key.data(), (size_t)len) == 0) {
+                *found = 1;
+                if (adapter) *adapter = (int32_t)e.adapter;
+                if (errors) *errors = (int32_t)(e.em >> 16);
+                if (matches) *matches = (int32_t)(e.em & 0xFFFF);
+                return CAH_OK;
+            }
+        }
+    }
+    if (len >= IDX_MAX_STRING) return CAH_OK;
     uint64_t lo, hi;
     if (!pack_key(std::string(s, (size_t)len), ix->prefix, lo, hi)) return CAH_OK;
     uint64_t h = idx_hash(lo, hi, (uint32_t)len) & ix->mask;
@@ -635,17 +823,23 @@ int cah_index_lookup_batch(const cah_index* ix, const uint8_t* d_seqs, const int
     if (n_reads < 0) return cah_set_error_(CAH_EINVAL, "n_reads < 0");
     if (n_reads == 0) return CAH_OK;
     if (!d_offsets || !d_out6 || !d_status) return cah_set_error_(CAH_EINVAL, "cah_index_lookup_batch: NULL argument");
+    if (ix->lengths.empty()) {                         // nothing indexed: the reference's loop over lengths finds nothing (:1502)
+        IDX_TRY(hipMemsetAsync(d_status, CAH_NONE, (size_t)n_reads, (hipStream_t)stream));
+        if (d_best_adapter) IDX_TRY(hipMemsetAsync(d_best_adapter, 0xFF, sizeof(int32_t) * (size_t)n_reads, (hipStream_t)stream));
+        return CAH_OK;
+    }
     const IdxDeviceCopy* dc = nullptr;
     int rc = index_on_device(ix, &dc);
     if (rc) return rc;
     IndexArgs a;
-    a.table = dc->d_table; a.mask = ix->mask; a.lengths = dc->d_lengths; a.n_lengths = (int)ix->lengths.size();
+    a.table = dc->d_table; a.wtable = dc->d_wtable; a.pool = dc->d_pool; a.mask = ix->mask; a.lengths = dc->d_lengths; a.n_lengths = (int)ix->lengths.size();
     a.prefix = ix->prefix ? 1 : 0; a.adapters = dc->d_adapters; a.adapter_seqs = dc->d_seqs;
     a.sets = dc->d_sets; a.kmers = dc->d_kmers; a.kmer_chars = dc->d_kmer_chars;
     a.seqs = d_seqs; a.offsets = d_offsets; a.lens = d_lens; a.n_reads = n_reads;
     a.out6 = d_out6; a.best_adapter = d_best_adapter; a.status = d_status;
     const int64_t blocks = (n_reads + 255) / 256;
-    hipLaunchKernelGGL(k_index_lookup, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    if (ix->wide) hipLaunchKernelGGL(k_index_lookup_wide, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(k_index_lookup, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     IDX_TRY(hipGetLastError());
     return CAH_OK;
 }

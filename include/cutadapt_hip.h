@@ -314,12 +314,13 @@ int cah_fastq_format_device(const uint8_t *d_buf, const int64_t *d_rec6, int64_t
  * adapter (_align.pyx:784-882 edit_environment with indels, :717-781 hamming_sphere without) maps to
  * (adapter, errors, matches); collisions keep the entry with more matches, equal matches make the
  * string ambiguous and remove it (adapters.py:1425-1464).  cah_index_create builds that dictionary
- * on the host and stores it as a hash table of 2-bit packed strings; cah_index_lookup_batch probes
+ * on the host and stores it as a hash table (2-bit packed strings when every adapter is plain ACGT
+ * and at most 60 characters long, hashed and verified byte strings otherwise); cah_index_lookup_batch probes
  * it with one GPU lane per read (multi-length rule :1487-1530, 'N' re-alignment :1532-1551) and
  * writes the same outputs as cah_match_batch: out6 = (0, len(adapter), rstart, rstop, matches,
  * errors), best_adapter (index into the adapter list, -1 = none), status.
- * Limits of this build: adapters of 1..60 upper-case A/C/G/T characters (CAH_EUNSUPPORTED otherwise;
- * the reference also accepts other characters, which can never match a read there).
+ * Limits of this build: adapters of 1..1000 ASCII characters, at most 64 different string lengths
+ * per index (CAH_EUNSUPPORTED otherwise).
  * Errors: CAH_EINVAL "Adapter list is empty" / "Error rate too high" (adapters.py:1309, :1385). */
 typedef struct cah_index cah_index;
 typedef struct cah_index_adapter {

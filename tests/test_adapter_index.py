@@ -56,6 +56,61 @@ def test_index_contents_match_reference(ref):
     assert compared > 10000
 
 
+def _wide_specs(rng):
+    """adapter sets the 2-bit table cannot hold: more than 60 characters and / or characters other than ACGT
+    (adapter_wildcards=False keeps them literal: reference adapters.py:586-588)"""
+    specs = []
+    kind = rng.randrange(4)
+    for _ in range(rng.randint(1, 4)):
+        if kind == 0:                                   # long, exact or one error
+            L = rng.randint(61, 90)
+            seq = "".join(rng.choice("ACGT") for _ in range(L))
+            rate = rng.choice([0.0, 0.0, 1.2 / L])
+        elif kind == 1:                                 # short with literal non-ACGT characters
+            L = rng.randint(4, 14)
+            seq = "".join(rng.choice("ACGTNRX") for _ in range(L))
+            rate = rng.choice([0.0, 0.1, 0.2, 0.21])
+        elif kind == 2:                                 # mixed lengths, one long one
+            L = rng.choice([8, 12, 64, 70])
+            seq = "".join(rng.choice("ACGT") for _ in range(L))
+            rate = rng.choice([0.0, 0.1]) if L < 20 else 0.0
+        else:
+            L = rng.randint(58, 66)
+            seq = "".join(rng.choice("ACGTN") for _ in range(L))
+            rate = rng.choice([0.0, 1.2 / L])
+        if specs and rng.random() < 0.3:
+            seq = specs[0][0][:L - 1] + rng.choice("ACGT")
+        specs.append((seq, rate, rng.random() < 0.5))
+    return specs
+
+
+def test_wide_index_contents_match_reference(ref):
+    """the hashed-byte-string table: every entry of the reference's dictionary"""
+    if ref is None:
+        pytest.skip("oracle/_ref not built")
+    from cutadapt_amd import adapters as A
+    RA = ref.adapters
+    rng = random.Random(2024)
+    compared = wide = 0
+    for trial in range(40):
+        prefix = trial % 2 == 0
+        specs = _wide_specs(rng)
+        rcls, mcls = (RA.PrefixAdapter, A.PrefixAdapter) if prefix else (RA.SuffixAdapter, A.SuffixAdapter)
+        rads = [rcls(s, max_errors=r, indels=i, adapter_wildcards=False) for s, r, i in specs]
+        mads = [mcls(s, max_errors=r, indels=i, adapter_wildcards=False) for s, r, i in specs]
+        assert all(RA.AdapterIndex.is_acceptable(a, prefix) for a in rads)
+        assert all(A.AdapterIndex.is_acceptable(a, prefix) for a in mads), specs
+        ri = RA.AdapterIndex(rads, prefix=prefix)
+        mi = A.AdapterIndex(mads, prefix=prefix)
+        assert mi._lengths == ri._lengths and len(mi) == len(ri._index) and mi._ambiguous == ri._ambiguous, specs
+        for s, (ad, e, m) in ri._index.items():
+            assert mi._h.get(s) == (rads.index(ad), e, m), (specs, s)
+        assert mi._h.get("ACGTN") is None or "ACGTN" in ri._index
+        compared += len(ri._index)
+        wide += any(len(s) > 60 or not set(s) <= set("ACGT") for s, _, _ in specs)
+    assert compared > 5000 and wide > 30
+
+
 def test_index_errors():
     from cutadapt_amd import adapters as A
     from cutadapt_amd import _lib
@@ -78,7 +133,8 @@ def test_index_errors():
     with pytest.raises(ValueError, match="Error rate too high"):
         _lib.Index([("ACGTACGTACGTACGTACGT", 0.2, True)], True)
     with pytest.raises(_lib.UnsupportedByHipPath):
-        _lib.Index([("ACGTNACGT", 0.1, True)], True)
+        _lib.Index([("ACGT" * 251, 0.0, True)], True)
+    assert not A.AdapterIndex.is_acceptable(A.PrefixAdapter("ACGT" * 251, max_errors=0), prefix=True)
     with pytest.raises(ValueError, match="Adapter list is empty"):
         _lib.Index([], True)
 
@@ -207,3 +263,59 @@ def test_demultiplex_pipeline_with_index_matches_unindexed(hip):
     for key in ("beg", "end", "matched"):
         assert np.array_equal(res[True][key], res[False][key]), key
     assert np.array_equal(res[True]["rows"], res[False]["rows"])
+
+
+@pytest.mark.gpu
+def test_wide_index_lookup_fuzz_against_reference(hip, ref):
+    """adapters of more than 60 characters and / or with literal non-ACGT characters (the hashed-byte-string
+    table, k_index_lookup_wide) against the reference's IndexedPrefix/SuffixAdapters.match_to: hits with 0..3
+    edits, N (re-alignment with the columns in LDS), the adapters' own odd characters, lower case, short reads"""
+    assert ref is not None, "oracle/_ref must travel to the GPU box"
+    from cutadapt_amd import adapters as A
+    from cutadapt_amd.batch import ReadBatch
+    RA = ref.adapters
+    rng = random.Random(777)
+    total = matched = with_n = 0
+    for trial in range(40):
+        prefix = trial % 2 == 0
+        specs = _wide_specs(rng)
+        rcls, mcls = (RA.PrefixAdapter, A.PrefixAdapter) if prefix else (RA.SuffixAdapter, A.SuffixAdapter)
+        rm = (RA.IndexedPrefixAdapters if prefix else RA.IndexedSuffixAdapters)(
+            [rcls(s, max_errors=e, indels=i, adapter_wildcards=False) for s, e, i in specs])
+        rads = rm._index._adapters
+        mm = (A.IndexedPrefixAdapters if prefix else A.IndexedSuffixAdapters)(
+            [mcls(s, max_errors=e, indels=i, adapter_wildcards=False) for s, e, i in specs])
+        reads = []
+        for _ in range(800):
+            s = list(rng.choice(specs)[0])
+            for _ in range(rng.choice([0, 0, 0, 1, 1, 2, 3])):
+                op, p = rng.choice("ssid"), rng.randrange(len(s) + 1)
+                if op == "s" and s:
+                    s[min(p, len(s) - 1)] = rng.choice("ACGTNRX")
+                elif op == "i":
+                    s.insert(p, rng.choice("ACGTN"))
+                elif s:
+                    del s[min(p, len(s) - 1)]
+            pad = "".join(rng.choice("ACGTN" if rng.random() < 0.1 else "ACGT") for _ in range(rng.randint(0, 20)))
+            r = "".join(s) + pad if prefix else pad + "".join(s)
+            if rng.random() < 0.1:
+                r = r.lower()
+            if rng.random() < 0.1:
+                cut = rng.randint(0, len(r))
+                r = r[:cut] if prefix else r[cut:]
+            reads.append(r)
+        reads += ["", "A", "N"]
+        bm = mm.match_to_batch(ReadBatch.from_strings(reads))
+        for i, r in enumerate(reads):
+            m = rm.match_to(r)
+            exp = None if m is None else (rads.index(m.adapter), m.astart, m.astop, m.rstart, m.rstop, m.score, m.errors)
+            got = None if not bm.found[i] else (int(bm.adapter_index[i]),) + tuple(int(v) for v in bm.coords[i])
+            assert got == exp, (specs, r, got, exp)
+            matched += exp is not None
+            with_n += exp is not None and "N" in r.upper()
+        for r in reads[:20]:                                # the per-read entry point
+            m, e = mm.match_to(r), rm.match_to(r)
+            assert (m is None) == (e is None) and (m is None or (m.rstart, m.rstop, m.score, m.errors) ==
+                                                   (e.rstart, e.rstop, e.score, e.errors)), (specs, r)
+        total += len(reads)
+    assert total > 20000 and matched > 5000 and with_n > 200, (total, matched, with_n)
