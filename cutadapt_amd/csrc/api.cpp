@@ -902,20 +902,24 @@ int cah_profile_read(double ms[CAH_PROF_N], int64_t launches[CAH_PROF_N], int64_
 // survivor queue with its per-entry keys and the cell-DP work list the cost scan writes:
 //   [0,8) filter tile counter | [128,136) uniform-batch flag | [256,264) queue count |
 //   [512,520) DP work counter | [640,648) scan tile counter | [768,776) DP list front count |
-//   [896,904) DP list back count |
-//   [1024, +4n) queue | [.., +n) queue keys | [.., +4n) DP work list | [.., +8n) its column windows
+//   [896,904) DP list back count | [576,584) straggler count | [704,712) tile counter of the stragglers' scan |
+//   [1024, +4n) queue | [.., +n) queue keys | [.., +4n) DP work list | [.., +8n) its column windows |
+//   [.., +4c) the cost scan's straggler list | [.., +c) its keys      (c = n / 8 + 1024)
 static const size_t WS_HEADER = 1024;
 static const size_t WS_UFLAG = 128 / sizeof(unsigned long long);    // 0 after the check: all reads of the batch have one length
 static const size_t WS_QCOUNT = 256 / sizeof(unsigned long long), WS_DPWORK = 512 / sizeof(unsigned long long);
 static const size_t WS_SCANWORK = 640 / sizeof(unsigned long long), WS_DPFRONT = 768 / sizeof(unsigned long long);
 static const size_t WS_DPBACK = 896 / sizeof(unsigned long long);
+static const size_t WS_RETRYCOUNT = 576 / sizeof(unsigned long long), WS_RETRYWORK = 704 / sizeof(unsigned long long);
+static int64_t ws_retry_cap(int64_t n_reads) { return n_reads / 8 + 1024; }
 
 static size_t ws_queue_bytes(int64_t n_reads) { return (sizeof(int32_t) * (size_t)n_reads + 255) & ~(size_t)255; }
 static size_t ws_keys_bytes(int64_t n_reads) { return ((size_t)n_reads + 255) & ~(size_t)255; }
 
 size_t cah_workspace_bytes(int64_t n_reads) {
     if (n_reads < 0) n_reads = 0;
-    return WS_HEADER + 2 * ws_queue_bytes(n_reads) + ws_keys_bytes(n_reads) + 2 * ws_queue_bytes(n_reads) + 256;
+    return WS_HEADER + 2 * ws_queue_bytes(n_reads) + ws_keys_bytes(n_reads) + 2 * ws_queue_bytes(n_reads) +
+           ws_queue_bytes(ws_retry_cap(n_reads)) + ws_keys_bytes(ws_retry_cap(n_reads)) + 256;
 }
 
 // ---- extra scratch of the fused multi-adapter path: [best key 8n] [pairs 8*cap] [DP list 4*cap] [windows 8*cap]
@@ -953,6 +957,9 @@ struct Workspace {
     uint8_t* keys;
     int32_t* dp_queue;
     int32_t* dp_win;
+    int32_t* retry_queue;
+    uint8_t* retry_keys;
+    int64_t retry_cap;
     char* extra = nullptr;            // scratch behind the base layout (cah_plan_workspace_bytes), if any
     size_t extra_bytes = 0;
     Workspace(void* base, int64_t n_reads, size_t total_bytes = 0) {
@@ -963,7 +970,10 @@ struct Workspace {
         queue = (int32_t*)p;                            p += ws_queue_bytes(n_reads);
         keys = (uint8_t*)p;                             p += ws_keys_bytes(n_reads);
         dp_queue = (int32_t*)p;                         p += ws_queue_bytes(n_reads);
-        dp_win = (int32_t*)p;
+        dp_win = (int32_t*)p;                           p += 2 * ws_queue_bytes(n_reads);
+        retry_cap = ws_retry_cap(n_reads);
+        retry_queue = (int32_t*)p;                      p += ws_queue_bytes(retry_cap);
+        retry_keys = (uint8_t*)p;
     }
 };
 }  // namespace
@@ -987,6 +997,17 @@ static thread_local bool t_outputs_ready = false;
 // the current one are queued -- the memset then runs while the host is busy elsewhere instead of in front of the
 // next call's first kernel; the workspace it vouches for
 static thread_local const void* t_precleaned_ws = nullptr;
+
+// CAH_SCAN_RETRY=<lanes> (default 12; 0 = off): see ScanArgs::retry_threshold
+static int scan_retry_threshold() {
+    static const int v = [] {
+        const char* e = getenv("CAH_SCAN_RETRY");
+        if (!e || !*e) return 12;
+        const int x = atoi(e);
+        return x < 0 ? 0 : (x > 63 ? 63 : x);
+    }();
+    return v;
+}
 
 // Aligner / comparer over a work list (d_queue == NULL: all reads).  3' adapters with unit costs go
 // through the cost scan first (k_back_scan finishes most reads, the rest reach k_dp_packed with an exact
@@ -1044,9 +1065,24 @@ static int run_aligner(const cah_plan* plan, const PlanDeviceCopy* pd, int32_t a
             sa.dp_queue = ws.dp_queue; sa.dp_win = ws.dp_win;
             sa.dp_count_front = ws.counters + WS_DPFRONT; sa.dp_count_back = ws.counters + WS_DPBACK;
             sa.dp_cap = n_reads;
+            // stragglers of a wave are set aside and scanned again, packed, by a second launch (kernels.h); tiny
+            // batches are launch-bound and keep the single launch
+            sa.retry_threshold = n_reads > 4096 ? scan_retry_threshold() : 0;
+            sa.retry_queue = ws.retry_queue; sa.retry_keys = ws.retry_keys; sa.retry_cap = ws.retry_cap;
+            sa.retry_count = ws.counters + WS_RETRYCOUNT; sa.queue_limit = 0;
+            sa.early_stop = d_queue != nullptr && d_queue_keys != nullptr;
+            sa.tile = 0;
             {
                 ProfScope ps(s, CAH_PROF_SCAN, n_reads);
                 HIP_TRY(launch_back_scan(sa, n_reads, pd->n_cus, s));
+                if (sa.retry_threshold > 0) {
+                    ScanArgs sb = sa;
+                    sb.queue = ws.retry_queue; sb.queue_keys = ws.retry_keys; sb.queue_count = ws.counters + WS_RETRYCOUNT;
+                    sb.queue_limit = ws.retry_cap; sb.work_counter = ws.counters + WS_RETRYWORK;
+                    sb.retry_threshold = 0;
+                    sb.tile = 256;                   // few reads, long scans: one wave-load per wave keeps the chip busy
+                    HIP_TRY(launch_back_scan(sb, ws.retry_cap < n_reads ? ws.retry_cap : n_reads, pd->n_cus, s));
+                }
             }
             a.queue = ws.dp_queue; a.queue_keys = nullptr; a.win = ws.dp_win;
             a.queue_count = ws.counters + WS_DPFRONT; a.queue_count_back = ws.counters + WS_DPBACK;
@@ -1206,6 +1242,8 @@ static int match_batch_multi(const cah_plan* plan, const PlanDeviceCopy* pd, con
             sa.dp_queue = d_dpq; sa.dp_win = d_win;
             sa.dp_count_front = counters + WS_DPFRONT; sa.dp_count_back = counters + WS_DPBACK;
             sa.dp_cap = cap;
+            sa.retry_threshold = 0; sa.retry_queue = nullptr; sa.retry_keys = nullptr; sa.retry_count = nullptr;
+            sa.retry_cap = 0; sa.queue_limit = 0; sa.early_stop = 0; sa.tile = 0;
             ProfScope ps(s, CAH_PROF_SCAN, cnt);
             HIP_TRY(launch_back_scan(sa, cnt * A, pd->n_cus, s));
         }

@@ -16,9 +16,22 @@
 //   EXACT_FULL  the first column whose row-m cost is 0 (the adapter occurs unedited) wins and the
 //               reference `break`s there (:531-533); a cost-0 alignment has no indels, so
 //               score = m, origin = j - m                               -> (0, m, j-m, j, m, 0)
-//   EXACT_TAIL  no acceptable last-row candidate, and the LARGEST acceptable row i of the last
-//               column costs 0 (the read ends with adapter[0:i]); smaller rows have score <= their
-//               row < i and cannot replace it (:563-567)                -> (0, i, n-i, n, i, 0)
+//   EXACT_TAIL  no acceptable last-row candidate, and the read ends with adapter[0:i] unedited: row i of the
+//               last column is acceptable and costs 0, i the largest such row.  The downward scan of the last
+//               column (:536-572) takes the largest acceptable row first; a later (smaller) row replaces the
+//               best iff its score is higher and `origin <= best.origin + m // 2` (:563-567; the `length >`
+//               clause cannot hold for a smaller row).  Smaller rows than i have score <= their row < i: they
+//               never replace row i.  LARGER acceptable rows i' (cost c' >= 1, e.g. row i + 1 reached by one
+//               deletion -- acceptable as soon as thr(i + 1) >= 1, which is the rule for tails of 9+
+//               characters at rate 0.1) score at most i' - 2c' (see SUBS_FULL); if that is < i for all of them,
+//               the best is below i when the scan reaches row i, and row i replaces it PROVIDED the origin
+//               clause holds.  `origin` there is a stale variable: the origin of the last cell the main loop
+//               computed, cell (r_s, n) with r_s = last_filled >= every acceptable row (:484).  That cell costs
+//               <= k + 1 (its diagonal neighbour costs <= k by the definition of `last`) and is a real path
+//               (stale neighbours cost > k and never win), so its origin is <= n - r_s + k + 1; the best's
+//               origin is >= n - i' - c' >= n - r_s - c'.  Hence origin - best.origin <= k + 1 + c', and the
+//               clause holds when k + 1 + c' <= m // 2 for every larger acceptable row (checked; 7 <= 16 for
+//               a 33-character adapter at rate 0.1).                     -> (0, i, n-i, n, i, 0)
 //   SUBS_FULL   the adapter occurs with substitutions only -- what sequencing errors are: c = the smallest row-m
 //               cost of any column, 1 <= c <= kacc, first reached at column e, and the diagonal that ends in
 //               (m, e) is "clean": every cell on it whose characters differ costs one more than its diagonal
@@ -30,6 +43,18 @@
 //               e - jfa <= m/2 - kacc (the origin clause, as for EXACT_FULL); later columns (cost >= c) cannot
 //               score more; a row i of the last column could only win with i - 2 C(i, n) > m - 2c, which is
 //               checked.  No `break` (cost > 0).                          -> (0, m, e-m, e, m-2c, c)
+//   (early stop) Last-row candidates are replaced only by candidates that OVERLAP them: (:521-524) the new origin
+//               must be <= best.origin + m // 2 (all last-row candidates have length m, so the `length >` clause
+//               is dead once a best exists).  A candidate of column j with cost c <= kacc has its origin in
+//               [j - m - c, j - m + c].  So after an acceptable column jla, a later acceptable column j2 is
+//               irrelevant when j2 - jla > 2 kacc + m // 2 -- it cannot replace a best that stems from a column
+//               <= jla, and neither can anything after it.  The last-column scan needs
+//               `origin(stale) <= best.origin + m // 2` too (the `length >` clause: i > m never holds), and the
+//               stale origin is >= n - m - k - 1 (real path of cost <= k + 1 over <= m rows): it cannot update
+//               when n - jla > k + 1 + kacc + m // 2 =: gap.  Therefore, once `gap` columns after jla have
+//               shown no acceptable candidate and the read goes on, the result is decided by the columns
+//               <= jla alone: the scan stops there (bs_may_stop, checked once per 16-column chunk), SUBS_FULL
+//               needs no look at the last column, and the DP window ends at jla without the last-column scan.
 //   DP          everything else: the cell kernel runs, but only over the columns that can matter:
 //               from (first acceptable candidate column, or n) - m - k - 1 -- the windowing argument
 //               of DESIGN.md "Column skipping" with the exact position instead of the k-mer hit --
@@ -132,31 +157,52 @@ CAH_HD bool bs_step(BackScanState& s, const uint64_t eq, const int j, const Back
     return false;
 }
 
-// After the last column (j == n) without EXACT_FULL.  thr_last(i): error threshold of row i in the last
+// May the scan stop after column j < n?  (see "early stop" in the header)
+CAH_HD int bs_stop_gap(const BackScanParams& p) { return p.k + 1 + p.kacc + p.half_m; }
+CAH_HD bool bs_may_stop(const BackScanState& s, const int j, const int n, const int gap) {
+    return s.jla >= 0 && j - s.jla >= gap && j < n;
+}
+
+// After the last column (j == n) without EXACT_FULL, or after an early stop (stopped: the state is that of an
+// inner column and nothing beyond jla can matter).  thr_last(i): error threshold of row i in the last
 // column = thr[effective length of adapter[0:i]] (CahMatcher::thr_last).  j0 = first column of the window
 // (the cost scan itself started there).  Outputs: o0/o1 = (row i, -) for EXACT_TAIL, (first DP column,
 // last DP column * 2 + scan flag) for DP.
 template <class ThrLast>
 CAH_HD int bs_finish(const BackScanState& s, const int n, const int j0, const BackScanParams& p,
-                     ThrLast thr_last, int& o0, int& o1) {
+                     ThrLast thr_last, int& o0, int& o1, const bool stopped = false) {
+    o0 = 0; o1 = 0;
+    const int reach = p.m + p.k + 1;
+    if (stopped) {                   // jfa >= 0
+        if (s.cmin >= 1 && s.eclean && s.je - p.m >= j0 && s.je - s.jfa <= p.half_m - p.kacc) {
+            o0 = s.je; o1 = s.cmin;
+            return BS_SUBS_FULL;
+        }
+        const int s0 = s.jfa - reach;
+        o0 = s0 > j0 ? s0 : j0;
+        o1 = s.jla * 2;
+        return BS_DP;
+    }
     // absolute costs of the last column, rows 1..m (row 0 costs 0); the largest acceptable row
     const int pad = 64 - p.m;
     uint64_t vp = pad == 0 ? s.VP : (s.VP >> pad), vn = pad == 0 ? s.VN : (s.VN >> pad);
-    int c = 0, best_i = 0, best_c = 0;
+    int c = 0, best_i = 0;
+    int i0 = 0;                      // the largest acceptable row that costs 0
+    bool above_ok = true;            // every acceptable row above i0 scores less than i0 and cannot shift the origin clause
     bool tail_may_win = false;       // an acceptable row of the last column that could outscore m - 2 * cmin
     for (int i = 1; i <= p.m; ++i) {
         c += (int)(vp & 1ull) - (int)(vn & 1ull);
         vp >>= 1; vn >>= 1;
         if (i >= p.min_overlap && c <= thr_last(i)) {
-            best_i = i; best_c = c;
+            best_i = i;
+            if (c == 0) { i0 = i; above_ok = true; }
+            else if (!(i - 2 * c < i0 && p.k + 1 + c <= p.half_m)) above_ok = false;
             if (i - 2 * c > p.m - 2 * s.cmin) tail_may_win = true;
         }
     }
-    o0 = 0; o1 = 0;
-    const int reach = p.m + p.k + 1;
     if (s.jfa < 0) {
         if (best_i == 0) return BS_NONE;
-        if (best_c == 0) { o0 = best_i; return BS_EXACT_TAIL; }
+        if (i0 > 0 && above_ok) { o0 = i0; return BS_EXACT_TAIL; }
         const int s0 = n - reach;
         o0 = s0 > j0 ? s0 : j0;
         o1 = n * 2 + 1;

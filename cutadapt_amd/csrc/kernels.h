@@ -103,6 +103,18 @@ struct ScanArgs {
     unsigned long long* dp_count_front;      // zeroed before launch
     unsigned long long* dp_count_back;
     int64_t dp_cap;
+    // stragglers (single-adapter mode): when at most retry_threshold lanes of a wave are still scanning and have 32+
+    // columns to go, they are appended here and scanned again by a second launch over this list (retry_threshold
+    // 0 there).  retry_threshold 0: off.  The list may fill up (retry_cap); waves then run to the end.
+    int32_t retry_threshold;
+    int32_t* retry_queue;
+    uint8_t* retry_keys;
+    unsigned long long* retry_count;         // zeroed before launch
+    int64_t retry_cap;
+    int32_t tile;                    // entries a workgroup takes per atomic (256, 512, 768 or 1024; 0 = 1024)
+    int32_t early_stop;              // 1: the reads come from a prefilter that has looked at every character (invalid
+                                     // bytes are flagged there), so the scan may stop before the read end (back_scan.h)
+    int64_t queue_limit;             // > 0: at most this many entries of the queue are valid (the retry list's capacity)
 };
 
 // k_tiny: prefilter + cost scan of <= 64 reads in one launch of one wave (the per-read API)

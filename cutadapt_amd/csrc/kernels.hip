@@ -1750,19 +1750,22 @@ __global__ __launch_bounds__(256) void k_back_scan(ScanArgs a) {
     const int wave = threadIdx.x >> 6;
     int64_t total = a.n_reads;
     if (a.queue_count) total = (int64_t)(*a.queue_count);
+    if (a.queue_limit > 0 && total > a.queue_limit) total = a.queue_limit;
     const bool skip_cols = MULTI ? a.multi_skip_ok != 0 : (a.queue && a.queue_keys && mt->skip_ok != 0);
+    const int stop_gap = bs_stop_gap(p);
+    const int tile = a.tile;                               // entries per workgroup and atomic: 256 .. SCAN_TILE
 
     for (;;) {
         __syncthreads();                                   // previous tile flushed
         if (threadIdx.x == 0) {
-            s_tile = (long long)atomicAdd(a.work_counter, (unsigned long long)SCAN_TILE);
+            s_tile = (long long)atomicAdd(a.work_counter, (unsigned long long)tile);
             s_nf = 0; s_nb = 0;
         }
         __syncthreads();
         const int64_t tile_base = s_tile;
         if (tile_base >= total) break;
 
-        for (int sub = wave; sub < SCAN_TILE / WAVE; sub += 4) {
+        for (int sub = wave; sub < tile / WAVE; sub += 4) {
             const int64_t base = tile_base + (int64_t)sub * WAVE;
             if (base >= total) break;
             const int64_t idx = base + lane;
@@ -1804,7 +1807,8 @@ __global__ __launch_bounds__(256) void k_back_scan(ScanArgs a) {
             BackScanState st;
             bs_init(st, p);
             int j = j0, exact_j = 0;
-            bool done = !valid, exact = false;
+            bool done = !valid, exact = false, stopped = false, retry = false, valid_out = valid;
+            int retry_at = MULTI ? 0 : a.retry_threshold;
             // one 16-character chunk per iteration (per lane: its own window start), the next chunk requested
             // before this one is consumed, the LDS lookup of the next column's match word issued one column
             // ahead; bytes are taken with constant shifts (v_bfe), the "any lane left?" test costs one scalar
@@ -1813,7 +1817,35 @@ __global__ __launch_bounds__(256) void k_back_scan(ScanArgs a) {
             Chunk cur = load_chunk(q, pos, n, valid ? n : 0);
             unsigned bad_chars = 0;
             for (;;) {
-                if (!__any(!done && j < n)) break;
+                const unsigned long long act = __ballot(!done && j < n);
+                if (!act) break;
+                if constexpr (!MULTI) {
+                    // stragglers: a wave costs the same with 3 lanes at work as with 64.  When few lanes are left
+                    // and they have a long way to go (false-positive k-mer hits far from the read end, mostly),
+                    // they are set aside and scanned again from their window start by a second launch, packed
+                    // 64 to a wave, instead of holding this wave to the read end.
+                    if (retry_at > 0 && __popcll(act) <= retry_at) {
+                        const bool far = !done && n - j >= 32;
+                        const unsigned long long bfar = __ballot(far);
+                        if (bfar) {
+                            const int cnt = __popcll(bfar);
+                            unsigned long long slot = 0;
+                            if (lane == 0) slot = atomicAdd(a.retry_count, (unsigned long long)cnt);
+                            slot = __shfl(slot, 0, WAVE);
+                            if ((int64_t)(slot + cnt) <= a.retry_cap) {
+                                if (far) {
+                                    const int64_t e = (int64_t)slot + __popcll(bfar & ((1ull << lane) - 1ull));
+                                    a.retry_queue[e] = (int32_t)r;
+                                    a.retry_keys[e] = (uint8_t)key;
+                                    done = true; retry = true;
+                                }
+                                if (bfar == act) break;
+                            } else {
+                                retry_at = 0;              // the list is full: this wave runs to the end
+                            }
+                        }
+                    }
+                }
                 const Chunk nxt = load_chunk(q, pos + 16, n, (!done) ? n : 0);
                 bad_chars |= cur.w[0] | cur.w[1] | cur.w[2] | cur.w[3];
                 uint64_t eq_next = eq_of(cur, 0);
@@ -1842,12 +1874,17 @@ __global__ __launch_bounds__(256) void k_back_scan(ScanArgs a) {
                 }
                 pos += 16;
                 cur = nxt;
+                if constexpr (!MULTI) {
+                    // nothing beyond the last acceptable candidate can matter any more (back_scan.h, "early stop")
+                    if (a.early_stop && !done && bs_may_stop(st, j, n, stop_gap)) { done = true; stopped = true; }
+                }
             }
             if (bad_chars & 0x80808080u) invalid = true;
 
             int o0 = 0, o1 = 0;
-            int cls = bs_finish(st, n, j0, p, [&](int i) { return s_thr_last[i]; }, o0, o1);
+            int cls = bs_finish(st, n, j0, p, [&](int i) { return s_thr_last[i]; }, o0, o1, stopped);
             if (exact) { cls = BS_EXACT_FULL; o0 = exact_j; }
+            if (retry) { cls = BS_NONE; valid_out = false; }
             if (MULTI) {
                 // invalid reads were flagged by the prefilter (it sees every character); matches are merged
                 // with one atomic max on the read's best key
@@ -1856,7 +1893,7 @@ __global__ __launch_bounds__(256) void k_back_scan(ScanArgs a) {
                     else if (cls == BS_EXACT_TAIL) atomicMax(a.best_key + r, pack_best(o0, 0, (int)adapter, o0, n - o0, n));
                     else if (cls == BS_SUBS_FULL) atomicMax(a.best_key + r, pack_best(p.m - 2 * o1, o1, (int)adapter, p.m, o0 - p.m, o0));
                 }
-            } else if (valid) {
+            } else if (valid_out) {
                 if (invalid || cls == BS_NONE) {
                     store_result(a.out6, a.status, a.best_adapter, a.adapter_index, a.merge_best, r, invalid, false,
                                  0, 0, 0, 0, 0, 0);
@@ -1871,7 +1908,7 @@ __global__ __launch_bounds__(256) void k_back_scan(ScanArgs a) {
                                  0, p.m, o0 - p.m, o0, p.m - 2 * o1, o1);
                 }
             }
-            const bool to_dp = valid && !invalid && cls == BS_DP;
+            const bool to_dp = valid_out && !invalid && cls == BS_DP;
             const bool to_back = to_dp && (o1 & 1);
             const bool to_front = to_dp && !(o1 & 1);
             const unsigned long long bf = __ballot(to_front), bb = __ballot(to_back);
@@ -2065,7 +2102,8 @@ __global__ __launch_bounds__(64) void k_tiny(TinyArgs a) {
     BackScanState st;
     bs_init(st, p);
     int j = j0, exact_j = 0;
-    bool done = !scanning, exact = false;
+    bool done = !scanning, exact = false, stopped = false;
+    const int stop_gap = bs_stop_gap(p);
     {
         int pos = j0;
         Chunk cur = load_chunk(q, pos, n, scanning ? n : 0);
@@ -2084,11 +2122,13 @@ __global__ __launch_bounds__(64) void k_tiny(TinyArgs a) {
             }
             pos += 16;
             cur = nxt;
+            // (with a prefilter in front, which has seen every character of the read: back_scan.h, "early stop")
+            if (lf && !done && bs_may_stop(st, j, n, stop_gap)) { done = true; stopped = true; }
         }
         if (bad_chars & 0x80808080u) invalid = true;
     }
     int o0 = 0, o1 = 0;
-    int cls = bs_finish(st, n, j0, p, [&](int i) { return s_thr_last[i]; }, o0, o1);
+    int cls = bs_finish(st, n, j0, p, [&](int i) { return s_thr_last[i]; }, o0, o1, stopped);
     if (exact) { cls = BS_EXACT_FULL; o0 = exact_j; }
     if (!scanning) cls = BS_NONE;
 
@@ -2364,8 +2404,10 @@ hipError_t launch_dp(const DpArgs& a, int m, bool unit, bool back_adapter, int64
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_back_scan(const ScanArgs& a, int64_t max_items, int n_cus, hipStream_t s) {
-    int64_t need = (max_items + SCAN_TILE - 1) / SCAN_TILE;
+hipError_t launch_back_scan(const ScanArgs& a0, int64_t max_items, int n_cus, hipStream_t s) {
+    ScanArgs a = a0;
+    if (a.tile < 256 || a.tile > SCAN_TILE || a.tile % 256) a.tile = SCAN_TILE;
+    int64_t need = (max_items + a.tile - 1) / a.tile;
     if (need < 1) need = 1;
     const int64_t cap = (int64_t)8 * n_cus;
     const dim3 grid((unsigned)(need < cap ? need : cap));

@@ -95,7 +95,9 @@ extern "C" {
 // NULL) receives the class of every read; win_out (may be NULL) the (first, last*2+scan) window of DP reads.
 // Returns 0, or 1 if the matcher is not scan-eligible.
 int bm_locate_batch(const void* matcher_blob, const uint8_t* seqs, const int64_t* offsets, int64_t n_reads,
-                    const int32_t* j0s, int32_t* out6, uint8_t* status, uint8_t* cls_out, int32_t* win_out) {
+                    const int32_t* j0s, int32_t* out6, uint8_t* status, uint8_t* cls_out, int32_t* win_out,
+                    int32_t stop_every, int32_t* jend_out) {
+    if (stop_every <= 0) stop_every = 1 << 30;            // never: the scan always runs to the read end
     CahMatcher mt;
     memcpy(&mt, matcher_blob, sizeof(mt));
     if (!mt.scan_ok) return 1;
@@ -107,15 +109,18 @@ int bm_locate_batch(const void* matcher_blob, const uint8_t* seqs, const int64_t
         const int j0 = j0s ? j0s[r] : 0;
         BackScanState st;
         bs_init(st, p);
-        bool exact = false;
+        bool exact = false, stopped = false;
         int j = j0;
+        const int gap = bs_stop_gap(p);
         while (j < n) {
             ++j;
             if (bs_step(st, mt.scanmask[q[j - 1] & 127], j, p)) { exact = true; break; }
+            // the kernel looks once per 16-column chunk (stop_every = 1: after every column, the tightest use of the rule)
+            if ((j - j0) % stop_every == 0 && bs_may_stop(st, j, n, gap)) { stopped = true; break; }
         }
         int o0 = 0, o1 = 0, cls;
         if (exact) { cls = BS_EXACT_FULL; o0 = j; }
-        else cls = bs_finish(st, n, j0, p, [&](int i) { return mt.thr_last[i]; }, o0, o1);
+        else cls = bs_finish(st, n, j0, p, [&](int i) { return mt.thr_last[i]; }, o0, o1, stopped);
         int32_t* o = out6 + r * 6;
         for (int t = 0; t < 6; t++) o[t] = 0;
         status[r] = 0;
@@ -132,8 +137,9 @@ int bm_locate_batch(const void* matcher_blob, const uint8_t* seqs, const int64_t
                 status[r] = 1;
             }
         }
-        if (cls_out) cls_out[r] = (uint8_t)cls;
+        if (cls_out) cls_out[r] = (uint8_t)(cls | (stopped ? 8 : 0));      // bit 3: the scan stopped early
         if (win_out) { win_out[2 * r] = o0; win_out[2 * r + 1] = o1; }
+        if (jend_out) jend_out[r] = j;                        // the column at which this read's scan ended
     }
     return 0;
 }

@@ -28,7 +28,7 @@ def model():
         subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", SRC, "-o", SO], check=True)
     L = C.CDLL(SO)
     vp, i64 = C.c_void_p, C.c_int64
-    L.bm_locate_batch.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp, vp]
+    L.bm_locate_batch.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp, vp, C.c_int32, vp]
     L.bm_skip_columns.argtypes = [C.c_char_p, C.c_int, C.c_int, vp, vp, i64, vp]
     L.bm_matcher_size.restype = C.c_size_t
     return L
@@ -45,15 +45,20 @@ def matcher_blob(adapter, rate, min_overlap, wildcard_ref=False, wildcard_query=
     return buf, need.value
 
 
-def run_model(L, blob, seqs, offsets, j0s=None):
+STATS = {"stopped": 0, "reads": 0}
+
+
+def run_model(L, blob, seqs, offsets, j0s=None, stop_every=16):
     n = len(offsets) - 1
     out6 = np.zeros((n, 6), dtype=np.int32)
     status = np.zeros(n, dtype=np.uint8)
     cls = np.zeros(n, dtype=np.uint8)
     rc = L.bm_locate_batch(blob, seqs.ctypes.data, offsets.ctypes.data, n,
                            None if j0s is None else j0s.ctypes.data, out6.ctypes.data, status.ctypes.data,
-                           cls.ctypes.data, None)
-    return rc, out6, status, cls
+                           cls.ctypes.data, None, stop_every, None)
+    STATS["stopped"] += int(((cls & 8) != 0).sum())
+    STATS["reads"] += len(cls)
+    return rc, out6, status, cls & 7
 
 
 def compare(L, adapter, rate, min_overlap, seqs, offsets, wr=False, wq=False, skip=False, label=""):
@@ -67,17 +72,22 @@ def compare(L, adapter, rate, min_overlap, seqs, offsets, wr=False, wq=False, sk
         j0s = np.zeros(n, dtype=np.int32)
         L.bm_skip_columns(adapter.encode(), len(adapter), int(rate * len(adapter)), seqs.ctypes.data,
                           offsets.ctypes.data, n, j0s.ctypes.data)
-    rc, out6, status, cls = run_model(L, blob, seqs, offsets, j0s)
-    if rc == 1:
-        return None                                  # matcher not scan-eligible: nothing to check
-    bad = np.nonzero((status != want_st) | (out6 != want6).any(axis=1))[0]
-    if len(bad):
-        r = int(bad[0])
-        read = bytes(seqs[offsets[r]:offsets[r + 1]]).decode("latin-1")
-        raise AssertionError(f"{label}: {len(bad)} of {len(want_st)} reads differ; first: read {r} {read!r} adapter "
-                             f"{adapter} rate {rate} O {min_overlap} wr {wr} wq {wq} j0 {None if j0s is None else j0s[r]} "
-                             f"class {cls[r]} model {status[r]} {out6[r].tolist()} oracle {want_st[r]} {want6[r].tolist()}")
-    return np.bincount(cls, minlength=5)
+    # the early stop looked for once per 16-column chunk (what the kernel does), after every column (the tightest
+    # use of the rule) and never (the scan always reaches the read end)
+    for stop_every in (16, 1, 0):
+        rc, out6, status, cls = run_model(L, blob, seqs, offsets, j0s, stop_every)
+        if rc == 1:
+            return None                                  # matcher not scan-eligible: nothing to check
+        bad = np.nonzero((status != want_st) | (out6 != want6).any(axis=1))[0]
+        if len(bad):
+            r = int(bad[0])
+            read = bytes(seqs[offsets[r]:offsets[r + 1]]).decode("latin-1")
+            raise AssertionError(f"{label} (stop_every {stop_every}): {len(bad)} of {len(want_st)} reads differ; first: read {r} {read!r} adapter "
+                                 f"{adapter} rate {rate} O {min_overlap} wr {wr} wq {wq} j0 {None if j0s is None else j0s[r]} "
+                                 f"class {cls[r]} model {status[r]} {out6[r].tolist()} oracle {want_st[r]} {want6[r].tolist()}")
+        if stop_every == 16:
+            counts = np.bincount(cls, minlength=5)
+    return counts
 
 
 def random_reads(rng, adapter, n_reads, max_len, p_edit, p_n, alphabet="ACGT"):
@@ -227,3 +237,76 @@ def test_substitution_class(model):
             if counts is not None:
                 subs_total += int(counts[4])
     assert subs_total > 5000, subs_total
+
+
+def test_early_stop_and_shadowed_tails(model):
+    """The two rules of round 2, session 3 (back_scan.h): (1) the scan stops `gap` columns after the last acceptable
+    candidate -- reads with a second copy of the adapter (better, worse, partial at the read end) at every distance
+    around that gap; (2) EXACT_TAIL although longer rows of the last column are acceptable -- reads that end with a
+    prefix of the adapter, behind text that makes longer rows cheap (shifted copies, low-complexity adapters)."""
+    rng = np.random.default_rng(33)
+    STATS["stopped"] = STATS["reads"] = 0
+    tails = dp = total = 0
+    for it in range(150):
+        kind = it % 5
+        m = int(rng.integers(6, 65)) if kind else 33
+        if kind == 0:
+            adapter = TRUSEQ
+        elif kind == 1:
+            adapter = "".join(rng.choice(list("ACGT"), size=m))
+        elif kind == 2:
+            unit = "".join(rng.choice(list("ACGT"), size=int(rng.integers(1, 4))))
+            adapter = (unit * 70)[:m]
+        elif kind == 3:
+            adapter = "".join(rng.choice(list("AC"), size=m))
+        else:
+            adapter = "".join(rng.choice(list("ACGT"), size=(m + 1) // 2)) * 2
+            adapter = adapter[:m]
+        rate = float(rng.choice([0.05, 0.1, 0.1, 0.15, 0.2, 0.3]))
+        k = int(rate * m)
+        gap = k + 1 + k + m // 2
+        min_overlap = int(rng.choice([1, 3, 3, 5]))
+        alpha = list("ACGT") if kind != 3 else list("ACCA")
+
+        def edited(piece, n_edits):
+            ad = list(piece)
+            for _e in range(n_edits):
+                if not ad:
+                    break
+                u, pos = rng.random(), int(rng.integers(0, len(ad)))
+                if u < 0.6:
+                    ad[pos] = str(rng.choice(alpha))
+                elif u < 0.8:
+                    del ad[pos]
+                else:
+                    ad.insert(pos, str(rng.choice(alpha)))
+            return "".join(ad)
+
+        reads = []
+        for _ in range(500):
+            u = rng.random()
+            head = "".join(rng.choice(alpha, size=int(rng.integers(0, 40))))
+            if u < 0.5:
+                # full copy, a gap around the stop distance, a second (full or partial) copy, maybe a tail
+                first = edited(adapter, int(rng.integers(0, k + 2)))
+                g = max(0, gap - m + int(rng.integers(-12, 13))) if rng.random() < 0.7 else int(rng.integers(0, 80))
+                second = edited(adapter, int(rng.integers(0, k + 2)))
+                if rng.random() < 0.4:
+                    second = second[:int(rng.integers(0, len(second) + 1))]
+                tail = "".join(rng.choice(alpha, size=int(rng.integers(0, 50)))) if rng.random() < 0.6 else ""
+                reads.append(head + first + "".join(rng.choice(alpha, size=g)) + second + tail)
+            else:
+                # the read ends with adapter[0:i]; in front of it a shifted / edited piece of the adapter
+                i = int(rng.integers(1, m + 1))
+                shift = int(rng.integers(0, 4))
+                front = edited(adapter[shift:shift + int(rng.integers(0, m))], int(rng.integers(0, 3))) if rng.random() < 0.6 else ""
+                body = "".join(rng.choice(alpha, size=int(rng.integers(0, 60))))
+                end = adapter[:i] if rng.random() < 0.7 else edited(adapter[:i], 1)
+                reads.append(head + body + front + end)
+        seqs, offsets = orc.pack_reads(reads)
+        for skip in (False, True):
+            counts = compare(model, adapter, rate, min_overlap, seqs, offsets, skip=skip, label=f"stop/tail {it} skip {skip}")
+            if counts is not None:
+                tails += int(counts[2]); dp += int(counts[3]); total += int(counts.sum())
+    assert STATS["stopped"] > 20000, STATS
+    assert tails > 15000 and total > 100000, (tails, dp, total)
