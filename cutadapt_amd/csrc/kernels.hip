@@ -834,9 +834,20 @@ __host__ __device__ constexpr int stream_max_len(int um) { return um * 16; }
 
 template <int DL, int NL, int NG, int NU, int UM>
 __global__ __launch_bounds__(STREAM_BLOCK_WAVES * WAVE, STREAM_WAVES) void k_filter_stream(FilterArgs a) {
-    __shared__ __attribute__((aligned(16))) uint32_t s_tab[LeanLayout<DL, NL, NG>::WORDS];
-    __shared__ __attribute__((aligned(16))) unsigned char s_piece[STREAM_BLOCK_WAVES * stream_piece_bytes(NU)];
-    __shared__ uint32_t s_gate[NG * CAH_GATE_LEN];
+    // ONE static object, the mask tables first: they then sit below 64 KB and a table entry is read with
+    // "ds_read_b64 v, v_entry offset:TABLE" -- the entry offset (byte << 3, one SDWA instruction) is the whole
+    // address computation of a character.  (As separate variables the tables were placed behind the 135 KB of read
+    // slots and every address needed the base added in a register.)
+    struct __attribute__((aligned(16))) StreamLds {
+        uint32_t tab[LeanLayout<DL, NL, NG>::WORDS];
+        uint32_t gate[NG * CAH_GATE_LEN];
+        unsigned char piece[STREAM_BLOCK_WAVES * stream_piece_bytes(NU)];
+    };
+    static_assert((LeanLayout<DL, NL, NG>::WORDS * 4) % 16 == 0 && (NG * CAH_GATE_LEN * 4) % 16 == 0, "slots must stay 16-byte aligned");
+    __shared__ StreamLds s_lds;
+    uint32_t* const s_tab = s_lds.tab;
+    uint32_t* const s_gate = s_lds.gate;
+    unsigned char* const s_piece = s_lds.piece;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int TILE = stream_tile(NG), SUBS = TILE / WAVE / STREAM_BLOCK_WAVES;
     if (a.batch_flag ? *a.batch_flag != 0ull : false) return;           // ragged batch: k_filter_lean<false, ..>
