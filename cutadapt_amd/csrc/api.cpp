@@ -319,6 +319,7 @@ static void build_lean_filter(const cah_adapter_desc& d, CahLeanFilter& lf) {
             // distance d = n - p from the read end: 1 is the last character; idx = CAH_GATE_ZERO - d
             for (int dist = 1; dist <= it.L; dist++) lf.gate_init[w][CAH_GATE_ZERO - dist] |= start_bit;
             lf.gated_found[w] |= end_bit;
+            lf.gated_span[w] = std::max(lf.gated_span[w], (int32_t)it.L);
             lf.tail_span = std::max(lf.tail_span, it.L);
         } else {
             for (int p = it.start; p + it.len <= it.stop; p++) lf.gate_init[w][p] |= start_bit;

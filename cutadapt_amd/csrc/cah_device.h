@@ -98,6 +98,8 @@ struct CahLeanFilter {
     uint32_t lead_found[CAH_LEAN_MAX_LEAD];       // bit at every k-mer end (and its delay bits)
     uint32_t lead_pass[CAH_LEAN_MAX_LEAD];        // the delay bits: set in the mask of every byte value
     uint32_t gated_found[CAH_LEAN_MAX_GATED];     // bit at every k-mer end
+    int32_t gated_span[CAH_LEAN_MAX_GATED];       // tail words: the widest tail window of the word's k-mers (the word is
+                                                  // idle until that many characters are left); head words: 0
     uint32_t lead_mask[CAH_LEAN_MAX_LEAD][CAH_TABLE_CHARS];
     uint32_t gated_mask[CAH_LEAN_MAX_GATED][CAH_TABLE_CHARS];
     // START-bit gates.  Tail word, idx = CAH_GATE_ZERO - d (d = n - p: 1 is the last character): the start bits of

@@ -341,6 +341,8 @@ template <int NL, int NG>
 struct LeanWords {
     int n_tail, tail_span, head_span;
     uint32_t l_init[NL], l_init2[NL], l_found[NL], g_found[NG];     // l_init2 = (l_init << 1) | l_init
+    int g_open[NG];              // equally long reads: the 8-character group from which gated word g has work (a tail word's
+                                 // start bits stay closed until gated_span characters are left; its state is 0 until then)
     const unsigned char* s_lead;                                 // LDS: lead table(s), then gated table (LeanLayout)
     const uint32_t* s_ginit;                                     // LDS: the start-bit gates of the NG gated words
 };
@@ -389,8 +391,11 @@ __device__ __forceinline__ void lean_tables_to_lds(const CahLeanFilter* lf, uint
 
 template <int NL, int NG>
 __device__ __forceinline__ void lean_words_init(LeanWords<NL, NG>& L, const CahLeanFilter* lf, const uint32_t* s_tab,
-                                                const uint32_t* s_ginit) {
+                                                const uint32_t* s_ginit, const int n_uniform = -1) {
     L.n_tail = lf->n_tail; L.tail_span = lf->tail_span; L.head_span = lf->head_span;
+#pragma unroll
+    for (int w = 0; w < NG; ++w)
+        L.g_open[w] = (n_uniform >= 0 && w < lf->n_tail) ? n_uniform - lf->gated_span[w] - 7 : -(1 << 30);
     // per-word constants live in registers: inside the loops the compiler would re-load anything read
     // through a pointer (the queue stores may alias as far as it knows)
 #pragma unroll
@@ -518,13 +523,26 @@ __device__ __forceinline__ void lean_gated8(const LeanWords<NL, NG>& L, LeanStat
 #pragma unroll
         for (int t = 0; t < 4; ++t)
             lean_read_entry<NG, LeanLayout<DL, NL, NG>::NGP>(mk[t], L.s_lead + LeanLayout<DL, NL, NG>::LEAD_BYTES + ad[4 * h + t]);
+        if constexpr (UNIFORM) {
+            // a word is stepped only once one of its windows is near (wave-uniform: L.g_open)
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            if constexpr (UNIFORM) {
-                const uint32_t* gp = L.s_ginit + g * CAH_GATE_LEN + (g < L.n_tail ? tail_u : head_u) + 4 * h;
+            for (int g = 0; g < NG; ++g) {
+                if (p0 >= L.g_open[g]) {
+                    const uint32_t* gp = L.s_ginit + g * CAH_GATE_LEN + (g < L.n_tail ? tail_u : head_u) + 4 * h;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) gt[t][g] = gp[t];
-            } else {
+                    for (int t = 0; t < 4; ++t) gt[t][g] = gp[t];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        unsigned dbl;
+                        asm("v_add_u32 %0, %1, %1" : "=v"(dbl) : "v"(S.RG[g]));
+                        S.RG[g] = (dbl | gt[t][g]) & mk[t][g];
+                        S.accG[g] |= S.RG[g];
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const int it = min(max(tail_base + 4 * h + t, 0), CAH_GATE_LEN - 1);
@@ -532,15 +550,15 @@ __device__ __forceinline__ void lean_gated8(const LeanWords<NL, NG>& L, LeanStat
                     gt[t][g] = L.s_ginit[g * CAH_GATE_LEN + (g < L.n_tail ? it : ih)];
                 }
             }
-        }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+            for (int t = 0; t < 4; ++t) {
 #pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                unsigned dbl;
-                asm("v_add_u32 %0, %1, %1" : "=v"(dbl) : "v"(S.RG[g]));
-                S.RG[g] = (dbl | gt[t][g]) & mk[t][g];
-                S.accG[g] |= S.RG[g];
+                for (int g = 0; g < NG; ++g) {
+                    unsigned dbl;
+                    asm("v_add_u32 %0, %1, %1" : "=v"(dbl) : "v"(S.RG[g]));
+                    S.RG[g] = (dbl | gt[t][g]) & mk[t][g];
+                    S.accG[g] |= S.RG[g];
+                }
             }
         }
         if (h == 0) {
@@ -710,7 +728,7 @@ __global__ __launch_bounds__(256, LEAN_WAVES) void k_filter_lean(FilterArgs a) {
     for (int i = threadIdx.x; i < NG * CAH_GATE_LEN; i += blockDim.x)
         s_ginit[i] = lf->gate_init[i / CAH_GATE_LEN][i % CAH_GATE_LEN];
     LeanWords<NL, NG> L;
-    lean_words_init<NL, NG>(L, lf, s_tab, s_ginit);
+    lean_words_init<NL, NG>(L, lf, s_tab, s_ginit, UNIFORM ? n_uniform : -1);
     const int lane = wave_lane();
     const int wave = threadIdx.x >> 6;
 
@@ -869,7 +887,7 @@ __global__ __launch_bounds__(STREAM_BLOCK_WAVES * WAVE, STREAM_WAVES) void k_fil
     for (int i = threadIdx.x; i < NG * CAH_GATE_LEN; i += blockDim.x)
         s_gate[i] = lf->gate_init[i / CAH_GATE_LEN][i % CAH_GATE_LEN];
     LeanWords<NL, NG> L;
-    lean_words_init<NL, NG>(L, lf, s_tab, s_gate);
+    lean_words_init<NL, NG>(L, lf, s_tab, s_gate, n);
     const int lane = wave_lane();
     const int wave = threadIdx.x >> 6;
     unsigned char* const piece = s_piece + wave * stream_piece_bytes(NU);   // this wave's LDS slot
