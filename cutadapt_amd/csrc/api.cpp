@@ -1124,7 +1124,8 @@ static int run_filter(const cah_plan* plan, const PlanDeviceCopy* pd, int32_t ad
                       const int64_t* d_offsets, const int32_t* d_lens, int64_t n_reads, int mode,
                       uint8_t* d_present, uint8_t* d_status, int32_t* d_queue,
                       unsigned long long* d_queue_count, uint8_t* d_queue_keys,
-                      unsigned long long* d_work_counter, const unsigned long long* d_batch_flag, hipStream_t s) {
+                      unsigned long long* d_work_counter, const unsigned long long* d_batch_flag, hipStream_t s,
+                      int32_t* d_clear_out6 = nullptr) {
     const CahMatcher& mt = plan->matchers[(size_t)adapter];
     if (mt.n_words > 1024)
         return fail(CAH_EUNSUPPORTED, "adapter %d: %d packed k-mer words exceed the 1024-word limit of the prefilter kernel",
@@ -1140,6 +1141,7 @@ static int run_filter(const cah_plan* plan, const PlanDeviceCopy* pd, int32_t ad
     f.batch_flag = nullptr;
     f.lean = nullptr;
     f.stream_n_lo = 0; f.stream_n_hi = -1;
+    f.clear_out6 = mode == 1 ? d_clear_out6 : nullptr;
     if (!t_header_fresh) {
         HIP_TRY(hipMemsetAsync(d_work_counter, 0, sizeof(unsigned long long), s));
         if (d_queue_count) HIP_TRY(hipMemsetAsync(d_queue_count, 0, sizeof(unsigned long long), s));
@@ -1283,9 +1285,17 @@ int cah_match_batch(const cah_plan* plan, const uint8_t* d_seqs, const int64_t* 
     if (rc) return rc;
     const Workspace ws(d_workspace, n_reads, workspace_bytes);
     unsigned long long* counters = ws.counters;
+    // The result rows are zeroed by the first adapter's prefilter on its way through the batch when there is one
+    // (FilterArgs::clear_out6: 24 B per read that would otherwise be a memset pass of its own), by a memset if not.
+    const bool multi_path = plan->multi.hdr.ok && workspace_bytes >= cah_plan_workspace_bytes(plan, n_reads);
+    int32_t first_aligner = -1;
+    for (int32_t ad = 0; ad < (int32_t)plan->matchers.size() && first_aligner < 0; ad++)
+        if (plan->matchers[(size_t)ad].kind != CAH_KIND_KMER_ONLY) first_aligner = ad;
+    const bool filter_clears = !t_outputs_ready && !multi_path && first_aligner >= 0 &&
+                               plan->matchers[(size_t)first_aligner].has_filter && n_reads > CAH_TINY_BATCH;
     if (!t_outputs_ready) {
         HIP_TRY(hipMemsetAsync(d_status, 0, (size_t)n_reads, s));
-        HIP_TRY(hipMemsetAsync(d_out6, 0, sizeof(int32_t) * 6 * (size_t)n_reads, s));
+        if (!filter_clears) HIP_TRY(hipMemsetAsync(d_out6, 0, sizeof(int32_t) * 6 * (size_t)n_reads, s));
         if (d_best_adapter) HIP_TRY(launch_init_best(d_best_adapter, n_reads, pd->n_cus, s));
     }
     // tiny single-adapter batches: one memset for all counters, no batch check (the ragged prefilter serves them)
@@ -1316,7 +1326,8 @@ int cah_match_batch(const cah_plan* plan, const uint8_t* d_seqs, const int64_t* 
         if (mt.has_filter) {
             // prefilter -> queue of surviving reads -> (cost scan ->) DP on dense waves
             rc = run_filter(plan, pd, ad, d_seqs, d_offsets, d_lens, n_reads, 1, nullptr, d_status, ws.queue,
-                            counters + WS_QCOUNT, ws.keys, counters + 0, d_batch_flag, s);
+                            counters + WS_QCOUNT, ws.keys, counters + 0, d_batch_flag, s,
+                            (filter_clears && ad == first_aligner) ? d_out6 : nullptr);
             if (rc) return rc;
             rc = run_aligner(plan, pd, ad, d_seqs, d_offsets, d_lens, n_reads, ws.queue, counters + WS_QCOUNT,
                              ws.keys, ws, d_out6, d_status, d_best_adapter, 1, s);

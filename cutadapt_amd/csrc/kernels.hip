@@ -127,6 +127,26 @@ __device__ __forceinline__ void filter_word_chunk(const Chunk& ck, const T* tbl,
 // NARROW: every packed word of the plan fits 32 bits (cah_plan_create packs k-mers of <= 32
 // characters that way): shift-and state, accumulators and LDS tables are 32-bit, which halves
 // the VALU work per character and word.
+// Zero the result rows (24 bytes each) of the `cnt` (<= 64, wave-uniform) consecutive reads from `base` on: the
+// rows are contiguous, every store instruction of the wave writes 512 contiguous bytes.
+__device__ __forceinline__ void clear_rows(int32_t* out6, const int64_t base, const int cnt, const int lane) {
+    int32_t* const o = out6 + base * 6;
+    if ((reinterpret_cast<uintptr_t>(o) & 7u) == 0) {
+        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int u = lane + WAVE * k;                                  // 8-byte unit
+            if (u < cnt * 3) *reinterpret_cast<u32x2*>(o + 2 * u) = (u32x2)(0u);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int u = lane + WAVE * k;
+            if (u < cnt * 6) o[u] = 0;
+        }
+    }
+}
+
 template <int MODE, bool LDS_TABLES, bool NARROW>
 __global__ __launch_bounds__(256, CAH_FILTER_WAVES) void k_filter(FilterArgs a) {
     typedef typename std::conditional<NARROW, uint32_t, uint64_t>::type word_t;
@@ -184,6 +204,8 @@ __global__ __launch_bounds__(256, CAH_FILTER_WAVES) void k_filter(FilterArgs a) 
             if (base >= a.n_reads) break;
             const int64_t r = base + lane;
             const bool valid = r < a.n_reads;
+            if (MODE == 1 && a.clear_out6)
+                clear_rows(a.clear_out6, base, (int)(a.n_reads - base < WAVE ? a.n_reads - base : WAVE), lane);
             int64_t off = 0, n64 = 0;
             if (valid) read_extent(a.offsets, a.lens, r, off, n64);
             const uint8_t* q = a.seqs + off;
@@ -778,6 +800,9 @@ __global__ __launch_bounds__(256, LEAN_WAVES) void k_filter_lean(FilterArgs a) {
             // half a chunk early)
             Chunk cur = load_chunk(q, 0, n, valid ? n : 0);
             Chunk nxt = load_chunk(q, 16, n, valid ? n : 0);
+            // (behind the first loads: waiting for those does not wait for these stores)
+            if (a.clear_out6 && !a.present)
+                clear_rows(a.clear_out6, base, (int)(a.n_reads - base < WAVE ? a.n_reads - base : WAVE), lane);
             {
                 unsigned ad[8];
                 lean_addr8<LeanLayout<DL, NL, NG>::LEAD_SHIFT>(ad, cur.w[0], cur.w[1]);
@@ -1005,6 +1030,10 @@ __global__ __launch_bounds__(STREAM_BLOCK_WAVES * WAVE, STREAM_WAVES) void k_fil
                 }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            // (in front of the next piece's loads: stores and loads share the in-order vmcnt counter, and the next
+            // wait for loads is a whole piece of matching work away -- the stores are long finished by then)
+            if (a.clear_out6 && !a.present && base < a.n_reads)
+                clear_rows(a.clear_out6, base, (int)(a.n_reads - base < WAVE ? a.n_reads - base : WAVE), lane);
             prefetch(piece_base(it + 1));
             if (base >= a.n_reads) continue;                            // wave-uniform; nothing left in this tile
             const int64_t r = base + lane;
