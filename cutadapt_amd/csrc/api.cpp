@@ -27,6 +27,7 @@
 #include "../../include/cutadapt_hip.h"
 #include "cah_device.h"
 #include "kernels.h"
+#include "back_scan.h"
 
 // ---------------------------------------------------------------------------------------------
 // errors
@@ -999,6 +1000,12 @@ static thread_local bool t_outputs_ready = false;
 // next call's first kernel; the workspace it vouches for
 static thread_local const void* t_precleaned_ws = nullptr;
 
+// CAH_SCAN_WORD64=1: the cost scan always uses the 64-bit form of the column (A/B measurements, parity tests)
+static int scan_word_kind(int m) {
+    static const bool force64 = [] { const char* e = getenv("CAH_SCAN_WORD64"); return e && *e && *e != '0'; }();
+    return force64 ? 0 : bs_kind_of(m);
+}
+
 // CAH_SCAN_RETRY=<lanes> (default 12; 0 = off): see ScanArgs::retry_threshold
 static int scan_retry_threshold() {
     static const int v = [] {
@@ -1073,6 +1080,7 @@ static int run_aligner(const cah_plan* plan, const PlanDeviceCopy* pd, int32_t a
             sa.retry_count = ws.counters + WS_RETRYCOUNT; sa.queue_limit = 0;
             sa.early_stop = d_queue != nullptr && d_queue_keys != nullptr;
             sa.tile = 0;
+            sa.kind = scan_word_kind(mt.m);
             {
                 ProfScope ps(s, CAH_PROF_SCAN, n_reads);
                 HIP_TRY(launch_back_scan(sa, n_reads, pd->n_cus, s));
@@ -1246,7 +1254,7 @@ static int match_batch_multi(const cah_plan* plan, const PlanDeviceCopy* pd, con
             sa.dp_count_front = counters + WS_DPFRONT; sa.dp_count_back = counters + WS_DPBACK;
             sa.dp_cap = cap;
             sa.retry_threshold = 0; sa.retry_queue = nullptr; sa.retry_keys = nullptr; sa.retry_count = nullptr;
-            sa.retry_cap = 0; sa.queue_limit = 0; sa.early_stop = 0; sa.tile = 0;
+            sa.retry_cap = 0; sa.queue_limit = 0; sa.early_stop = 0; sa.tile = 0; sa.kind = 0;
             ProfScope ps(s, CAH_PROF_SCAN, cnt);
             HIP_TRY(launch_back_scan(sa, cnt * A, pd->n_cus, s));
         }

@@ -92,17 +92,37 @@ struct BackScanParams {
     int half_m;       // m / 2
 };
 
-struct BackScanState {
-    uint64_t VP, VN;
+// what the scan remembers about row m, whatever the representation of the column
+struct BackScanBook {
     int cm;           // C(m, j) of the column just processed
     int jfa, jla;     // first / last column with cm <= kacc (-1: none)
-    // SUBS_FULL: A accumulates, along every diagonal, the cells whose diagonal delta is 0 although their characters
-    // differ (an insertion / deletion path is as cheap as the diagonal): bit 63 = the diagonal ending in row m of the
-    // current column.  cmin / je: smallest acceptable row-m cost so far and the first column that reached it;
-    // eclean: that column's diagonal was clean.
-    uint64_t A;
+    // SUBS_FULL: cmin / je: smallest acceptable row-m cost so far and the first column that reached it;
+    // eclean: that column's diagonal was clean (see A below).
     int cmin, je;
     bool eclean;
+};
+
+struct BackScanState : BackScanBook {
+    uint64_t VP, VN;
+    // SUBS_FULL: A accumulates, along every diagonal, the cells whose diagonal delta is 0 although their characters
+    // differ (an insertion / deletion path is as cheap as the diagonal): bit 63 = the diagonal ending in row m of the
+    // current column.
+    uint64_t A;
+};
+
+// The 32-bit form of the same scan (half the instructions of the 64-bit form on a 32-bit ALU):
+//   X == 0  adapters of at most 32 characters: the adapter in the top m bits of a 32-bit word, pad rows below;
+//   X >= 1  adapters of 32 + X characters (X = 1, 2 -- e.g. the 33-character TruSeq adapter): rows 1..32 as a 32-bit
+//           word without pad rows, rows 33.. as plain integers.  Row r > 32 of column j follows the textbook
+//           recurrence C(r, j) = min(C(r-1, j-1) + [characters differ], C(r-1, j) + 1, C(r, j-1) + 1) from the row
+//           above (row 32: tracked through its horizontal deltas, like cm in the 64-bit form); its diagonal bit
+//           D0 = [C(r, j) == C(r-1, j-1)] feeds the clean-diagonal accumulator exactly like a word bit.
+template <int X>
+struct BackScanState32 : BackScanBook {
+    uint32_t VP, VN, A;
+    int cv;                        // X > 0: C(32, j)
+    int cx[X > 0 ? X : 1];         // X > 0: C(33 + t, j)
+    unsigned ax;                   // X > 0: bit t = the accumulator bit of row 33 + t
 };
 
 CAH_HD uint64_t bs_shl1(uint64_t x) {
@@ -126,6 +146,24 @@ CAH_HD void bs_init(BackScanState& s, const BackScanParams& p) {
     s.A = 0; s.cmin = 1 << 20; s.je = -1; s.eclean = false;
 }
 
+// Row m of the column just processed: the bookkeeping every representation shares.  clean: the diagonal that ends
+// in (m, j) has met no cell whose diagonal delta is 0 although its characters differ.  Returns true when the read
+// is finished as EXACT_FULL at this column.
+template <bool SUBS>
+CAH_HD bool bs_book(BackScanBook& s, const bool clean, const int j, const BackScanParams& p) {
+    if (s.cm <= p.kacc) {
+        if (s.jfa < 0) s.jfa = j;
+        s.jla = j;
+        if (SUBS && s.cm < s.cmin) { s.cmin = s.cm; s.je = j; s.eclean = clean; }
+        // (:521-533) a cost-0 candidate has score m, more than any earlier best (those cost >= 1: the
+        // first cost-0 column ends the loop), so it replaces the best iff it is the first or
+        // origin = j - m <= best.origin + m/2.  Every earlier acceptable candidate sits at a column
+        // >= jfa and spans rel <= m + kacc columns, i.e. best.origin >= jfa - m - kacc.
+        if (s.cm == 0 && j - s.jfa <= p.half_m - p.kacc) return true;
+    }
+    return false;
+}
+
 // One column.  eq: the padded match word of this read character (CahMatcher::scanmask[c]).
 // Returns true when the read is finished as EXACT_FULL at this column.
 // SUBS = false leaves the SUBS_FULL bookkeeping out (the class then never applies): the fused multi-adapter scan
@@ -144,22 +182,81 @@ CAH_HD bool bs_step(BackScanState& s, const uint64_t eq, const int j, const Back
     s.VN = HPs & Xv;
     // D0 = Xh | VN: C(i, j) == C(i-1, j-1); set where the characters differ = an indel path is as cheap
     if (SUBS) s.A = bs_shl1(s.A) | ((Xh | VN) & ~eq);
-    if (s.cm <= p.kacc) {
-        if (s.jfa < 0) s.jfa = j;
-        s.jla = j;
-        if (SUBS && s.cm < s.cmin) { s.cmin = s.cm; s.je = j; s.eclean = (s.A >> 63) == 0; }
-        // (:521-533) a cost-0 candidate has score m, more than any earlier best (those cost >= 1: the
-        // first cost-0 column ends the loop), so it replaces the best iff it is the first or
-        // origin = j - m <= best.origin + m/2.  Every earlier acceptable candidate sits at a column
-        // >= jfa and spans rel <= m + kacc columns, i.e. best.origin >= jfa - m - kacc.
-        if (s.cm == 0 && j - s.jfa <= p.half_m - p.kacc) return true;
+    if (s.cm <= p.kacc) return bs_book<SUBS>(s, (s.A >> 63) == 0, j, p);
+    return false;
+}
+
+// ---- the 32-bit form ----------------------------------------------------------------------------------------
+// which form serves an adapter of m characters: 0 = 64-bit, 1 = 32-bit, 2 / 3 = 32-bit + 1 / 2 explicit rows
+CAH_HD int bs_kind_of(const int m) { return m <= 32 ? 1 : (m <= 34 ? m - 31 : 0); }
+
+// the two table words of a character from its 64-bit match word (adapter in the top m bits, pad rows below):
+// eq32 = rows 1..32 (X > 0) or the top 32 bits (X == 0), eqx = rows 33.. in bits 0..
+CAH_HD uint64_t bs32_table_entry(const uint64_t sm, const int m) {
+    if (m <= 32) return sm >> 32;
+    const uint32_t lo = (uint32_t)(sm >> (64 - m)), hi = (uint32_t)(sm >> (96 - m));
+    return ((uint64_t)hi << 32) | lo;
+}
+
+template <int X>
+CAH_HD void bs32_init(BackScanState32<X>& s, const BackScanParams& p) {
+    const int pad = X > 0 ? 0 : 32 - p.m;
+    s.VP = pad == 0 ? ~0u : ~((1u << pad) - 1u);
+    s.VN = 0; s.A = 0; s.ax = 0;
+    s.cv = 32;
+    for (int t = 0; t < (X > 0 ? X : 1); ++t) s.cx[t] = 33 + t;
+    s.cm = p.m;
+    s.jfa = -1; s.jla = -1;
+    s.cmin = 1 << 20; s.je = -1; s.eclean = false;
+}
+
+template <bool SUBS, int X>
+CAH_HD bool bs32_step(BackScanState32<X>& s, const uint32_t eq, const uint32_t eqx, const int j, const BackScanParams& p) {
+    const uint32_t VP = s.VP, VN = s.VN;
+    const uint32_t Xv = eq | VN;
+    const uint32_t Xh = (((eq & VP) + VP) ^ VP) | eq;
+    const uint32_t HP = VN | ~(Xh | VP);
+    const uint32_t HN = VP & Xh;
+    const int dtop = (int)(HP >> 31) - (int)(HN >> 31);           // horizontal delta of the word's top row
+    const uint32_t HPs = HP << 1, HNs = HN << 1;
+    s.VP = HNs | ~(Xv | HPs);
+    s.VN = HPs & Xv;
+    const uint32_t a_old = s.A;
+    if (SUBS) s.A = (a_old << 1) | ((Xh | VN) & ~eq);
+    bool clean;
+    if (X == 0) {
+        s.cm += dtop;
+        clean = (s.A >> 31) == 0;
+    } else {
+        int up_prev = s.cv;                                        // C(r-1, j-1)
+        s.cv += dtop;
+        int up = s.cv;                                             // C(r-1, j)
+        unsigned a_above = a_old >> 31;                            // accumulator bit of row r-1 in column j-1
+        unsigned ax_new = 0;
+        for (int t = 0; t < X; ++t) {
+            const int neq = (int)(~(eqx >> t) & 1u);
+            const int cprev = s.cx[t];                             // C(r, j-1)
+            int c = up_prev + neq;
+            if (up + 1 < c) c = up + 1;
+            if (cprev + 1 < c) c = cprev + 1;
+            const unsigned x = (c == up_prev && neq) ? 1u : 0u;    // diagonal delta 0 although the characters differ
+            const unsigned a_new = a_above | x;
+            a_above = (s.ax >> t) & 1u;
+            ax_new |= a_new << t;
+            up_prev = cprev; up = c;
+            s.cx[t] = c;
+        }
+        if (SUBS) s.ax = ax_new;
+        s.cm = s.cx[X - 1];
+        clean = ((ax_new >> (X - 1)) & 1u) == 0;
     }
+    if (s.cm <= p.kacc) return bs_book<SUBS>(s, clean, j, p);
     return false;
 }
 
 // May the scan stop after column j < n?  (see "early stop" in the header)
 CAH_HD int bs_stop_gap(const BackScanParams& p) { return p.k + 1 + p.kacc + p.half_m; }
-CAH_HD bool bs_may_stop(const BackScanState& s, const int j, const int n, const int gap) {
+CAH_HD bool bs_may_stop(const BackScanBook& s, const int j, const int n, const int gap) {
     return s.jla >= 0 && j - s.jla >= gap && j < n;
 }
 
@@ -168,9 +265,10 @@ CAH_HD bool bs_may_stop(const BackScanState& s, const int j, const int n, const 
 // column = thr[effective length of adapter[0:i]] (CahMatcher::thr_last).  j0 = first column of the window
 // (the cost scan itself started there).  Outputs: o0/o1 = (row i, -) for EXACT_TAIL, (first DP column,
 // last DP column * 2 + scan flag) for DP.
-template <class ThrLast>
-CAH_HD int bs_finish(const BackScanState& s, const int n, const int j0, const BackScanParams& p,
-                     ThrLast thr_last, int& o0, int& o1, const bool stopped = false) {
+// row_cost(i): the absolute cost of row i of the last column, asked for i = 1, 2, .., m in this order.
+template <class ThrLast, class RowCost>
+CAH_HD int bs_finish_rows(const BackScanBook& s, const int n, const int j0, const BackScanParams& p,
+                          ThrLast thr_last, int& o0, int& o1, const bool stopped, RowCost row_cost) {
     o0 = 0; o1 = 0;
     const int reach = p.m + p.k + 1;
     if (stopped) {                   // jfa >= 0
@@ -184,15 +282,12 @@ CAH_HD int bs_finish(const BackScanState& s, const int n, const int j0, const Ba
         return BS_DP;
     }
     // absolute costs of the last column, rows 1..m (row 0 costs 0); the largest acceptable row
-    const int pad = 64 - p.m;
-    uint64_t vp = pad == 0 ? s.VP : (s.VP >> pad), vn = pad == 0 ? s.VN : (s.VN >> pad);
-    int c = 0, best_i = 0;
+    int best_i = 0;
     int i0 = 0;                      // the largest acceptable row that costs 0
     bool above_ok = true;            // every acceptable row above i0 scores less than i0 and cannot shift the origin clause
     bool tail_may_win = false;       // an acceptable row of the last column that could outscore m - 2 * cmin
     for (int i = 1; i <= p.m; ++i) {
-        c += (int)(vp & 1ull) - (int)(vn & 1ull);
-        vp >>= 1; vn >>= 1;
+        const int c = row_cost(i);
         if (i >= p.min_overlap && c <= thr_last(i)) {
             best_i = i;
             if (c == 0) { i0 = i; above_ok = true; }
@@ -217,4 +312,31 @@ CAH_HD int bs_finish(const BackScanState& s, const int n, const int j0, const Ba
     o0 = s0 > j0 ? s0 : j0;
     o1 = best_i == 0 ? s.jla * 2 : n * 2 + 1;
     return BS_DP;
+}
+
+template <class ThrLast>
+CAH_HD int bs_finish(const BackScanState& s, const int n, const int j0, const BackScanParams& p,
+                     ThrLast thr_last, int& o0, int& o1, const bool stopped = false) {
+    const int pad = 64 - p.m;
+    uint64_t vp = pad == 0 ? s.VP : (s.VP >> pad), vn = pad == 0 ? s.VN : (s.VN >> pad);
+    int c = 0;
+    return bs_finish_rows(s, n, j0, p, thr_last, o0, o1, stopped, [&](int) {
+        c += (int)(vp & 1ull) - (int)(vn & 1ull);
+        vp >>= 1; vn >>= 1;
+        return c;
+    });
+}
+
+template <int X, class ThrLast>
+CAH_HD int bs32_finish(const BackScanState32<X>& s, const int n, const int j0, const BackScanParams& p,
+                       ThrLast thr_last, int& o0, int& o1, const bool stopped = false) {
+    const int pad = X > 0 ? 0 : 32 - p.m;
+    uint32_t vp = s.VP >> pad, vn = s.VN >> pad;
+    int c = 0;
+    return bs_finish_rows(s, n, j0, p, thr_last, o0, o1, stopped, [&](int i) {
+        if (X > 0 && i > 32) return s.cx[i - 33 < X ? i - 33 : 0];
+        c += (int)(vp & 1u) - (int)(vn & 1u);
+        vp >>= 1; vn >>= 1;
+        return c;
+    });
 }

@@ -114,6 +114,7 @@ struct ScanArgs {
     uint8_t* retry_keys;
     unsigned long long* retry_count;         // zeroed before launch
     int64_t retry_cap;
+    int32_t kind;                    // form of the column, bs_kind_of(m) (back_scan.h); 0 = the 64-bit word (always valid)
     int32_t tile;                    // entries a workgroup takes per atomic (256, 512, 768 or 1024; 0 = 1024)
     int32_t early_stop;              // 1: the reads come from a prefilter that has looked at every character (invalid
                                      // bytes are flagged there), so the scan may stop before the read end (back_scan.h)

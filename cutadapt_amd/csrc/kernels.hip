@@ -1783,8 +1783,13 @@ __device__ __forceinline__ void store_result(int32_t* out6, uint8_t* status, int
 
 // MULTI: the work list holds (read, adapter, key) pairs of the fused multi-adapter prefilter; all adapters
 // have one shape (m, k, thresholds: matcher 0), only the match table differs per lane.
-template <bool MULTI>
+// KIND: the form of the column (back_scan.h, bs_kind_of): 0 = one 64-bit word, 1 = one 32-bit word (adapters up to 32
+// characters), 2 / 3 = a 32-bit word + 1 / 2 explicit rows (33 / 34 characters).  The 32-bit forms cost about half the
+// instructions per column.  MULTI runs the 64-bit form.
+template <bool MULTI, int KIND>
 __global__ __launch_bounds__(256) void k_back_scan(ScanArgs a) {
+    static_assert(!MULTI || KIND == 0, "the fused multi-adapter scan uses the 64-bit form");
+    constexpr int XR = KIND >= 2 ? KIND - 1 : 0;
     extern __shared__ __attribute__((aligned(16))) uint64_t s_scanmask[];   // [128], or [n_adapters * CAH_MULTI_TAB_STRIDE]
     __shared__ int s_thr_last[CAH_MAX_M + 1];
     __shared__ int s_list[SCAN_TILE * 3];          // (read, first column, last column * 2 + scan): front entries
@@ -1799,7 +1804,10 @@ __global__ __launch_bounds__(256) void k_back_scan(ScanArgs a) {
     if (MULTI) {
         for (int i = threadIdx.x; i < a.n_adapters * CAH_MULTI_TAB_STRIDE; i += blockDim.x) s_scanmask[i] = a.tab[i];
     } else {
-        for (int i = threadIdx.x; i < 256; i += blockDim.x) s_sm256[i] = i < CAH_TABLE_CHARS ? mt->scanmask[i] : 0ull;
+        for (int i = threadIdx.x; i < 256; i += blockDim.x) {
+            const uint64_t sm = i < CAH_TABLE_CHARS ? mt->scanmask[i] : 0ull;
+            s_sm256[i] = KIND == 0 ? sm : bs32_table_entry(sm, mt->m);
+        }
     }
     for (int i = threadIdx.x; i <= CAH_MAX_M; i += blockDim.x) s_thr_last[i] = mt->thr_last[i];
     BackScanParams p;
@@ -1862,8 +1870,13 @@ __global__ __launch_bounds__(256) void k_back_scan(ScanArgs a) {
                 }
             };
 
-            BackScanState st;
-            bs_init(st, p);
+            typename std::conditional<KIND == 0, BackScanState, BackScanState32<XR>>::type st;
+            if constexpr (KIND == 0) bs_init(st, p); else bs32_init(st, p);
+            // one column: the character's table entry is the 64-bit match word, or {rows 1..32, rows 33..}
+            auto step = [&](const uint64_t eq, const int jj) -> bool {
+                if constexpr (KIND == 0) return bs_step<!MULTI>(st, eq, jj, p);
+                else return bs32_step<true, XR>(st, (uint32_t)eq, (uint32_t)(eq >> 32), jj, p);
+            };
             int j = j0, exact_j = 0;
             bool done = !valid, exact = false, stopped = false, retry = false, valid_out = valid;
             int retry_at = MULTI ? 0 : a.retry_threshold;
@@ -1916,7 +1929,7 @@ __global__ __launch_bounds__(256) void k_back_scan(ScanArgs a) {
                         const uint64_t eq = eq_next;
                         if (t < 15) eq_next = eq_of(cur, t + 1);
                         ++j;
-                        if (bs_step<!MULTI>(st, eq, j, p) && !exact) { exact = true; exact_j = j; }
+                        if (step(eq, j) && !exact) { exact = true; exact_j = j; }
                     }
                     if (exact) done = true;
                 } else {
@@ -1926,7 +1939,7 @@ __global__ __launch_bounds__(256) void k_back_scan(ScanArgs a) {
                         if (t < 15) eq_next = eq_of(cur, t + 1);
                         if (!done && j < n) {
                             ++j;
-                            if (bs_step<!MULTI>(st, eq, j, p)) { exact = true; exact_j = j; done = true; }
+                            if (step(eq, j)) { exact = true; exact_j = j; done = true; }
                         }
                     }
                 }
@@ -1940,7 +1953,9 @@ __global__ __launch_bounds__(256) void k_back_scan(ScanArgs a) {
             if (bad_chars & 0x80808080u) invalid = true;
 
             int o0 = 0, o1 = 0;
-            int cls = bs_finish(st, n, j0, p, [&](int i) { return s_thr_last[i]; }, o0, o1, stopped);
+            int cls;
+            if constexpr (KIND == 0) cls = bs_finish(st, n, j0, p, [&](int i) { return s_thr_last[i]; }, o0, o1, stopped);
+            else cls = bs32_finish<XR>(st, n, j0, p, [&](int i) { return s_thr_last[i]; }, o0, o1, stopped);
             if (exact) { cls = BS_EXACT_FULL; o0 = exact_j; }
             if (retry) { cls = BS_NONE; valid_out = false; }
             if (MULTI) {
@@ -2471,9 +2486,15 @@ hipError_t launch_back_scan(const ScanArgs& a0, int64_t max_items, int n_cus, hi
     const dim3 grid((unsigned)(need < cap ? need : cap));
     if (a.pairs) {
         const size_t lds = sizeof(uint64_t) * (size_t)a.n_adapters * CAH_MULTI_TAB_STRIDE;
-        hipLaunchKernelGGL(k_back_scan<true>, grid, dim3(256), lds, s, a);
+        hipLaunchKernelGGL((k_back_scan<true, 0>), grid, dim3(256), lds, s, a);
     } else {
-        hipLaunchKernelGGL(k_back_scan<false>, grid, dim3(256), sizeof(uint64_t) * CAH_TABLE_CHARS, s, a);
+        const size_t lds = sizeof(uint64_t) * CAH_TABLE_CHARS;
+        switch (a.kind) {
+            case 1: hipLaunchKernelGGL((k_back_scan<false, 1>), grid, dim3(256), lds, s, a); break;
+            case 2: hipLaunchKernelGGL((k_back_scan<false, 2>), grid, dim3(256), lds, s, a); break;
+            case 3: hipLaunchKernelGGL((k_back_scan<false, 3>), grid, dim3(256), lds, s, a); break;
+            default: hipLaunchKernelGGL((k_back_scan<false, 0>), grid, dim3(256), lds, s, a); break;
+        }
     }
     return hipGetLastError();
 }

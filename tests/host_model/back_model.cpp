@@ -96,31 +96,57 @@ extern "C" {
 // Returns 0, or 1 if the matcher is not scan-eligible.
 int bm_locate_batch(const void* matcher_blob, const uint8_t* seqs, const int64_t* offsets, int64_t n_reads,
                     const int32_t* j0s, int32_t* out6, uint8_t* status, uint8_t* cls_out, int32_t* win_out,
-                    int32_t stop_every, int32_t* jend_out) {
+                    int32_t stop_every, int32_t* jend_out, int32_t form) {
     if (stop_every <= 0) stop_every = 1 << 30;            // never: the scan always runs to the read end
     CahMatcher mt;
     memcpy(&mt, matcher_blob, sizeof(mt));
     if (!mt.scan_ok) return 1;
     BackScanParams p;
     p.m = mt.m; p.k = mt.k; p.kacc = mt.kacc; p.min_overlap = mt.min_overlap; p.half_m = mt.m / 2;
+    // form: -1 = the one the kernel launcher picks for this adapter (bs_kind_of), 0 = force the 64-bit form
+    const int kind = form < 0 ? bs_kind_of(p.m) : 0;
+    uint64_t tab32[128];
+    for (int c = 0; c < 128; c++) tab32[c] = bs32_table_entry(mt.scanmask[c], p.m);
     for (int64_t r = 0; r < n_reads; r++) {
         const uint8_t* q = seqs + offsets[r];
         const int n = (int)(offsets[r + 1] - offsets[r]);
         const int j0 = j0s ? j0s[r] : 0;
-        BackScanState st;
-        bs_init(st, p);
         bool exact = false, stopped = false;
         int j = j0;
         const int gap = bs_stop_gap(p);
-        while (j < n) {
-            ++j;
-            if (bs_step(st, mt.scanmask[q[j - 1] & 127], j, p)) { exact = true; break; }
-            // the kernel looks once per 16-column chunk (stop_every = 1: after every column, the tightest use of the rule)
-            if ((j - j0) % stop_every == 0 && bs_may_stop(st, j, n, gap)) { stopped = true; break; }
+        int o0 = 0, o1 = 0, cls = BS_NONE;
+        auto run = [&](auto& st, auto step, auto finish) {
+            while (j < n) {
+                ++j;
+                if (step(st, q[j - 1] & 127)) { exact = true; break; }
+                // the kernel looks once per 16-column chunk (stop_every = 1: after every column, the tightest use of the rule)
+                if ((j - j0) % stop_every == 0 && bs_may_stop(st, j, n, gap)) { stopped = true; break; }
+            }
+            if (exact) { cls = BS_EXACT_FULL; o0 = j; }
+            else cls = finish(st);
+        };
+        auto thr = [&](int i) { return mt.thr_last[i]; };
+        if (kind == 0) {
+            BackScanState st;
+            bs_init(st, p);
+            run(st, [&](BackScanState& s, int c) { return bs_step(s, mt.scanmask[c], j, p); },
+                [&](BackScanState& s) { return bs_finish(s, n, j0, p, thr, o0, o1, stopped); });
+        } else if (kind == 1) {
+            BackScanState32<0> st;
+            bs32_init(st, p);
+            run(st, [&](BackScanState32<0>& s, int c) { return bs32_step<true, 0>(s, (uint32_t)tab32[c], (uint32_t)(tab32[c] >> 32), j, p); },
+                [&](BackScanState32<0>& s) { return bs32_finish<0>(s, n, j0, p, thr, o0, o1, stopped); });
+        } else if (kind == 2) {
+            BackScanState32<1> st;
+            bs32_init(st, p);
+            run(st, [&](BackScanState32<1>& s, int c) { return bs32_step<true, 1>(s, (uint32_t)tab32[c], (uint32_t)(tab32[c] >> 32), j, p); },
+                [&](BackScanState32<1>& s) { return bs32_finish<1>(s, n, j0, p, thr, o0, o1, stopped); });
+        } else {
+            BackScanState32<2> st;
+            bs32_init(st, p);
+            run(st, [&](BackScanState32<2>& s, int c) { return bs32_step<true, 2>(s, (uint32_t)tab32[c], (uint32_t)(tab32[c] >> 32), j, p); },
+                [&](BackScanState32<2>& s) { return bs32_finish<2>(s, n, j0, p, thr, o0, o1, stopped); });
         }
-        int o0 = 0, o1 = 0, cls;
-        if (exact) { cls = BS_EXACT_FULL; o0 = j; }
-        else cls = bs_finish(st, n, j0, p, [&](int i) { return mt.thr_last[i]; }, o0, o1, stopped);
         int32_t* o = out6 + r * 6;
         for (int t = 0; t < 6; t++) o[t] = 0;
         status[r] = 0;

@@ -28,7 +28,7 @@ def model():
         subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", SRC, "-o", SO], check=True)
     L = C.CDLL(SO)
     vp, i64 = C.c_void_p, C.c_int64
-    L.bm_locate_batch.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp, vp, C.c_int32, vp]
+    L.bm_locate_batch.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp, vp, C.c_int32, vp, C.c_int32]
     L.bm_skip_columns.argtypes = [C.c_char_p, C.c_int, C.c_int, vp, vp, i64, vp]
     L.bm_matcher_size.restype = C.c_size_t
     return L
@@ -48,14 +48,14 @@ def matcher_blob(adapter, rate, min_overlap, wildcard_ref=False, wildcard_query=
 STATS = {"stopped": 0, "reads": 0}
 
 
-def run_model(L, blob, seqs, offsets, j0s=None, stop_every=16):
+def run_model(L, blob, seqs, offsets, j0s=None, stop_every=16, form=-1):
     n = len(offsets) - 1
     out6 = np.zeros((n, 6), dtype=np.int32)
     status = np.zeros(n, dtype=np.uint8)
     cls = np.zeros(n, dtype=np.uint8)
     rc = L.bm_locate_batch(blob, seqs.ctypes.data, offsets.ctypes.data, n,
                            None if j0s is None else j0s.ctypes.data, out6.ctypes.data, status.ctypes.data,
-                           cls.ctypes.data, None, stop_every, None)
+                           cls.ctypes.data, None, stop_every, None, form)
     STATS["stopped"] += int(((cls & 8) != 0).sum())
     STATS["reads"] += len(cls)
     return rc, out6, status, cls & 7
@@ -74,18 +74,20 @@ def compare(L, adapter, rate, min_overlap, seqs, offsets, wr=False, wq=False, sk
                           offsets.ctypes.data, n, j0s.ctypes.data)
     # the early stop looked for once per 16-column chunk (what the kernel does), after every column (the tightest
     # use of the rule) and never (the scan always reaches the read end)
-    for stop_every in (16, 1, 0):
-        rc, out6, status, cls = run_model(L, blob, seqs, offsets, j0s, stop_every)
+    # ... each in the form the launcher picks for the adapter (32-bit words, + explicit rows for 33 / 34 characters)
+    # and in the 64-bit form
+    for stop_every, form in ((16, -1), (1, -1), (0, -1), (16, 0), (0, 0)):
+        rc, out6, status, cls = run_model(L, blob, seqs, offsets, j0s, stop_every, form)
         if rc == 1:
             return None                                  # matcher not scan-eligible: nothing to check
         bad = np.nonzero((status != want_st) | (out6 != want6).any(axis=1))[0]
         if len(bad):
             r = int(bad[0])
             read = bytes(seqs[offsets[r]:offsets[r + 1]]).decode("latin-1")
-            raise AssertionError(f"{label} (stop_every {stop_every}): {len(bad)} of {len(want_st)} reads differ; first: read {r} {read!r} adapter "
+            raise AssertionError(f"{label} (stop_every {stop_every}, form {form}): {len(bad)} of {len(want_st)} reads differ; first: read {r} {read!r} adapter "
                                  f"{adapter} rate {rate} O {min_overlap} wr {wr} wq {wq} j0 {None if j0s is None else j0s[r]} "
                                  f"class {cls[r]} model {status[r]} {out6[r].tolist()} oracle {want_st[r]} {want6[r].tolist()}")
-        if stop_every == 16:
+        if stop_every == 16 and form == -1:
             counts = np.bincount(cls, minlength=5)
     return counts
 
@@ -310,3 +312,30 @@ def test_early_stop_and_shadowed_tails(model):
                 tails += int(counts[2]); dp += int(counts[3]); total += int(counts.sum())
     assert STATS["stopped"] > 20000, STATS
     assert tails > 15000 and total > 100000, (tails, dp, total)
+
+
+def test_word_forms(model):
+    """Adapters around the 32-bit word: 31 / 32 characters (one 32-bit word), 33 / 34 (32-bit word + 1 / 2 explicit
+    rows -- the TruSeq adapter's case), 35 (64-bit word): every form against the oracle and, inside compare(), against
+    the 64-bit form of the same reads."""
+    rng = np.random.default_rng(77)
+    done = 0
+    for it in range(120):
+        m = int(rng.choice([1, 2, 31, 32, 33, 33, 34, 34, 35]))
+        kind = it % 3
+        if kind == 0:
+            adapter = "".join(rng.choice(list("ACGT"), size=m))
+        elif kind == 1:
+            unit = "".join(rng.choice(list("ACGT"), size=int(rng.integers(1, 4))))
+            adapter = (unit * 40)[:m]
+        else:
+            adapter = "".join(rng.choice(list("AC"), size=m))
+        rate = float(rng.choice([0.0, 0.05, 0.1, 0.15, 0.2, 0.3]))
+        min_overlap = int(rng.choice([1, 3, 5, m]))
+        seqs, offsets = random_reads(rng, adapter, 600, int(rng.choice([40, 90, 170])),
+                                     float(rng.choice([0.0, 0.03, 0.1, 0.2])), float(rng.choice([0.0, 0.01])),
+                                     alphabet="ACGT" if kind != 2 else "ACCA")
+        for skip in (False, True):
+            if compare(model, adapter, rate, min_overlap, seqs, offsets, skip=skip, label=f"forms {it} m {m} skip {skip}") is not None:
+                done += 1
+    assert done > 200
