@@ -182,7 +182,7 @@ CAH_HD bool bs_step(BackScanState& s, const uint64_t eq, const int j, const Back
     s.VN = HPs & Xv;
     // D0 = Xh | VN: C(i, j) == C(i-1, j-1); set where the characters differ = an indel path is as cheap
     if (SUBS) s.A = bs_shl1(s.A) | ((Xh | VN) & ~eq);
-    if (s.cm <= p.kacc) return bs_book<SUBS>(s, (s.A >> 63) == 0, j, p);
+    if (__builtin_expect(s.cm <= p.kacc, 0)) return bs_book<SUBS>(s, (s.A >> 63) == 0, j, p);     // rare: off the straight path
     return false;
 }
 
@@ -250,8 +250,16 @@ CAH_HD bool bs32_step(BackScanState32<X>& s, const uint32_t eq, const uint32_t e
         s.cm = s.cx[X - 1];
         clean = ((ax_new >> (X - 1)) & 1u) == 0;
     }
-    if (s.cm <= p.kacc) return bs_book<SUBS>(s, clean, j, p);
+    if (__builtin_expect(s.cm <= p.kacc, 0)) return bs_book<SUBS>(s, clean, j, p);
     return false;
+}
+
+// The window start moved back to a whole number of 16-column chunks in front of the read end (0 if the read is
+// shorter than that): any earlier start is as exact as j0 (the costs of a window are >= the true ones and equal
+// wherever they are <= k + 1 from column start + m + k + 1 on).
+CAH_HD int bs_align_window(const int j0, const int n) {
+    const int a = n - ((n - j0 + 15) & ~15);
+    return a > 0 ? a : 0;
 }
 
 // May the scan stop after column j < n?  (see "early stop" in the header)

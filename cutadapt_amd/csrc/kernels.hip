@@ -1756,6 +1756,9 @@ __global__ __launch_bounds__(256, CAH_DPP_WAVES(ROWS)) void k_dp_packed(DpArgs a
 #ifndef SCAN_TILE
 #define SCAN_TILE 1024
 #endif
+#ifndef SCAN_AHEAD
+#define SCAN_AHEAD 2
+#endif
 
 __device__ __forceinline__ void store_result(int32_t* out6, uint8_t* status, int32_t* best_adapter,
                                              const int adapter_index, const int merge_best, const int64_t r,
@@ -1860,6 +1863,10 @@ __global__ __launch_bounds__(256) void k_back_scan(ScanArgs a) {
             // ends before 4 * key, so no row-m cost <= k occurs before it
             int j0 = 0;
             if (skip_cols && valid) j0 = max(0, ((int)key << CAH_KEY_SHIFT) - p.m - p.k - 1);
+            // ... moved back so that the window is a whole number of 16-column chunks (an earlier start is as
+            // exact, and the wave's chunk count -- the longest window's -- stays what it was): the last chunk then
+            // ends at the read end and takes the unguarded path below
+            if constexpr (!MULTI) j0 = bs_align_window(j0, n);
             // the match word of character t of a chunk
             auto eq_of = [&](const Chunk& ck, int t) -> uint64_t {
                 if constexpr (MULTI) {
@@ -1919,15 +1926,19 @@ __global__ __launch_bounds__(256) void k_back_scan(ScanArgs a) {
                 }
                 const Chunk nxt = load_chunk(q, pos + 16, n, (!done) ? n : 0);
                 bad_chars |= cur.w[0] | cur.w[1] | cur.w[2] | cur.w[3];
-                uint64_t eq_next = eq_of(cur, 0);
+                // the match words of the chunk's characters come from LDS; SCAN_AHEAD lookups are in flight ahead of the
+                // column being computed (one was not enough once a column took ~100 cycles: the scan waited on LDS)
+                uint64_t eqq[SCAN_AHEAD];
+#pragma unroll
+                for (int t = 0; t < SCAN_AHEAD; ++t) eqq[t] = eq_of(cur, t);
                 if (__all(done || j + 16 <= n)) {
                     // every lane still at work has the whole chunk ahead of it (the queue is ordered by window
                     // start, so this is the rule): no per-column guards.  Lanes that are done -- as EXACT_FULL, or
                     // idle from the start -- step along on NUL chunks; their state is not looked at again.
 #pragma unroll
                     for (int t = 0; t < 16; ++t) {
-                        const uint64_t eq = eq_next;
-                        if (t < 15) eq_next = eq_of(cur, t + 1);
+                        const uint64_t eq = eqq[t % SCAN_AHEAD];
+                        if (t + SCAN_AHEAD < 16) eqq[t % SCAN_AHEAD] = eq_of(cur, t + SCAN_AHEAD);
                         ++j;
                         if (step(eq, j) && !exact) { exact = true; exact_j = j; }
                     }
@@ -1935,8 +1946,8 @@ __global__ __launch_bounds__(256) void k_back_scan(ScanArgs a) {
                 } else {
 #pragma unroll
                     for (int t = 0; t < 16; ++t) {
-                        const uint64_t eq = eq_next;
-                        if (t < 15) eq_next = eq_of(cur, t + 1);
+                        const uint64_t eq = eqq[t % SCAN_AHEAD];
+                        if (t + SCAN_AHEAD < 16) eqq[t % SCAN_AHEAD] = eq_of(cur, t + SCAN_AHEAD);
                         if (!done && j < n) {
                             ++j;
                             if (step(eq, j)) { exact = true; exact_j = j; done = true; }
