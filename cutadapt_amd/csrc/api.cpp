@@ -1254,7 +1254,8 @@ static int match_batch_multi(const cah_plan* plan, const PlanDeviceCopy* pd, con
             sa.dp_count_front = counters + WS_DPFRONT; sa.dp_count_back = counters + WS_DPBACK;
             sa.dp_cap = cap;
             sa.retry_threshold = 0; sa.retry_queue = nullptr; sa.retry_keys = nullptr; sa.retry_count = nullptr;
-            sa.retry_cap = 0; sa.queue_limit = 0; sa.early_stop = 0; sa.tile = 0; sa.kind = 0;
+            sa.retry_cap = 0; sa.queue_limit = 0; sa.early_stop = 0; sa.tile = 0;
+            sa.kind = scan_word_kind(plan->matchers[0].m);         // all adapters of the fused path have one shape
             ProfScope ps(s, CAH_PROF_SCAN, cnt);
             HIP_TRY(launch_back_scan(sa, cnt * A, pd->n_cus, s));
         }

@@ -1788,10 +1788,9 @@ __device__ __forceinline__ void store_result(int32_t* out6, uint8_t* status, int
 // have one shape (m, k, thresholds: matcher 0), only the match table differs per lane.
 // KIND: the form of the column (back_scan.h, bs_kind_of): 0 = one 64-bit word, 1 = one 32-bit word (adapters up to 32
 // characters), 2 / 3 = a 32-bit word + 1 / 2 explicit rows (33 / 34 characters).  The 32-bit forms cost about half the
-// instructions per column.  MULTI runs the 64-bit form.
+// instructions per column.
 template <bool MULTI, int KIND>
 __global__ __launch_bounds__(256) void k_back_scan(ScanArgs a) {
-    static_assert(!MULTI || KIND == 0, "the fused multi-adapter scan uses the 64-bit form");
     constexpr int XR = KIND >= 2 ? KIND - 1 : 0;
     extern __shared__ __attribute__((aligned(16))) uint64_t s_scanmask[];   // [128], or [n_adapters * CAH_MULTI_TAB_STRIDE]
     __shared__ int s_thr_last[CAH_MAX_M + 1];
@@ -1805,7 +1804,8 @@ __global__ __launch_bounds__(256) void k_back_scan(ScanArgs a) {
     __shared__ __attribute__((aligned(16))) uint64_t s_sm256[MULTI ? 1 : 256];
     const CahMatcher* mt = a.matcher;
     if (MULTI) {
-        for (int i = threadIdx.x; i < a.n_adapters * CAH_MULTI_TAB_STRIDE; i += blockDim.x) s_scanmask[i] = a.tab[i];
+        for (int i = threadIdx.x; i < a.n_adapters * CAH_MULTI_TAB_STRIDE; i += blockDim.x)
+            s_scanmask[i] = KIND == 0 ? a.tab[i] : bs32_table_entry(a.tab[i], mt->m);   // (all adapters have one shape)
     } else {
         for (int i = threadIdx.x; i < 256; i += blockDim.x) {
             const uint64_t sm = i < CAH_TABLE_CHARS ? mt->scanmask[i] : 0ull;
@@ -1882,7 +1882,7 @@ __global__ __launch_bounds__(256) void k_back_scan(ScanArgs a) {
             // one column: the character's table entry is the 64-bit match word, or {rows 1..32, rows 33..}
             auto step = [&](const uint64_t eq, const int jj) -> bool {
                 if constexpr (KIND == 0) return bs_step<!MULTI>(st, eq, jj, p);
-                else return bs32_step<true, XR>(st, (uint32_t)eq, (uint32_t)(eq >> 32), jj, p);
+                else return bs32_step<!MULTI, XR>(st, (uint32_t)eq, (uint32_t)(eq >> 32), jj, p);
             };
             int j = j0, exact_j = 0;
             bool done = !valid, exact = false, stopped = false, retry = false, valid_out = valid;
@@ -2497,7 +2497,12 @@ hipError_t launch_back_scan(const ScanArgs& a0, int64_t max_items, int n_cus, hi
     const dim3 grid((unsigned)(need < cap ? need : cap));
     if (a.pairs) {
         const size_t lds = sizeof(uint64_t) * (size_t)a.n_adapters * CAH_MULTI_TAB_STRIDE;
-        hipLaunchKernelGGL((k_back_scan<true, 0>), grid, dim3(256), lds, s, a);
+        switch (a.kind) {
+            case 1: hipLaunchKernelGGL((k_back_scan<true, 1>), grid, dim3(256), lds, s, a); break;
+            case 2: hipLaunchKernelGGL((k_back_scan<true, 2>), grid, dim3(256), lds, s, a); break;
+            case 3: hipLaunchKernelGGL((k_back_scan<true, 3>), grid, dim3(256), lds, s, a); break;
+            default: hipLaunchKernelGGL((k_back_scan<true, 0>), grid, dim3(256), lds, s, a); break;
+        }
     } else {
         const size_t lds = sizeof(uint64_t) * CAH_TABLE_CHARS;
         switch (a.kind) {
