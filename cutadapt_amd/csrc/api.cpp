@@ -1000,6 +1000,15 @@ static thread_local bool t_outputs_ready = false;
 // next call's first kernel; the workspace it vouches for
 static thread_local const void* t_precleaned_ws = nullptr;
 
+// Aligner of an anchored adapter (Where.PREFIX = QUERY_STOP, Where.SUFFIX = QUERY_START) whose error threshold at
+// full length is 0: see k_anchored_exact.  CAH_NO_ANCHORED_EXACT=1 keeps the cell DP (A/B, parity tests).
+static bool anchored_exact_ok(const CahMatcher& mt) {
+    static const bool off = [] { const char* e = getenv("CAH_NO_ANCHORED_EXACT"); return e && *e && *e != '0'; }();
+    return !off && !mt.long_dp && (mt.flags == 8 || mt.flags == 2) && mt.m >= 1 && mt.m <= CAH_MAX_M &&
+           mt.effective_length >= 0 && mt.effective_length <= CAH_MAX_M && mt.thr[mt.effective_length] == 0 &&
+           mt.min_overlap <= mt.m;
+}
+
 // CAH_SCAN_WORD64=1: the cost scan always uses the 64-bit form of the column (A/B measurements, parity tests)
 static int scan_word_kind(int m) {
     static const bool force64 = [] { const char* e = getenv("CAH_SCAN_WORD64"); return e && *e && *e != '0'; }();
@@ -1057,6 +1066,12 @@ static int run_aligner(const cah_plan* plan, const PlanDeviceCopy* pd, int32_t a
         la.dbg_cost = nullptr; la.dbg_score = nullptr;
         ProfScope ps(s, mt.kind == CAH_KIND_ALIGNER ? CAH_PROF_DP : CAH_PROF_COMPARER, n_reads);
         HIP_TRY(launch_dp_long(la, lanes, s));
+        return CAH_OK;
+    }
+    if (mt.kind == CAH_KIND_ALIGNER && anchored_exact_ok(mt)) {
+        // an anchored adapter that tolerates no error: a character-by-character comparison (k_anchored_exact)
+        ProfScope ps(s, CAH_PROF_DP, n_reads);
+        HIP_TRY(launch_anchored_exact(a, n_reads, pd->n_cus, s));
         return CAH_OK;
     }
     if (mt.kind == CAH_KIND_ALIGNER) {

@@ -196,6 +196,7 @@ struct LongArgs {
 int64_t long_scratch_lanes(int64_t max_items, int n_cus);      // threads k_dp_long is launched with (each owns a column)
 hipError_t launch_dp_long(const LongArgs& a, int64_t lanes, hipStream_t s);
 hipError_t launch_comparer(const DpArgs& a, int64_t max_items, int n_cus, hipStream_t s);
+hipError_t launch_anchored_exact(const DpArgs& a, int64_t max_items, int n_cus, hipStream_t s);
 hipError_t launch_validate(const uint8_t* seqs, const int64_t* offsets, const int32_t* lens,
                            int64_t n_reads, int32_t* bad, int n_cus, hipStream_t s);
 hipError_t launch_init_best(int32_t* best_adapter, int64_t n_reads, int n_cus, hipStream_t s);

@@ -25,6 +25,10 @@
 #include "back_scan.h"
 #include "dev_common.h"
 
+#ifndef CAH_DEQUEUE
+#define CAH_DEQUEUE 8             // sub-batches of 64 work items a wave takes per atomic (k_dp, k_comparer, k_anchored_exact)
+#endif
+
 #ifndef CAH_SCHED_ROWS
 #define CAH_SCHED_ROWS 1
 #endif
@@ -1211,8 +1215,13 @@ __global__ __launch_bounds__(256, CAH_DP_WAVES(ROWS)) void k_dp(DpArgs a) {
     if (a.queue_count) total = (int64_t)(*a.queue_count);
     const bool skip_cols = a.queue && a.queue_keys && mt->skip_ok != 0;
 
+    // (CAH_DEQUEUE sub-batches of 64 per atomic: one counter serves 100 M reads when there is no work list, and
+    // same-address atomics complete at ~100 M/s -- one per wave made an anchored adapter's short DP atomic-bound)
     for (;;) {
-        const int64_t base = wave_dequeue(a.work_counter);
+      const int64_t base0 = wave_dequeue(a.work_counter, CAH_DEQUEUE * WAVE);
+      if (base0 >= total) break;
+      for (int sub = 0; sub < CAH_DEQUEUE; ++sub) {
+        const int64_t base = base0 + (int64_t)sub * WAVE;
         if (base >= total) break;
         const int64_t idx = base + lane;
         const bool valid = idx < total;
@@ -1398,6 +1407,7 @@ __global__ __launch_bounds__(256, CAH_DP_WAVES(ROWS)) void k_dp(DpArgs a) {
                 }
             }
         }
+      }
     }
 }
 
@@ -2042,6 +2052,71 @@ __global__ __launch_bounds__(256) void k_back_scan(ScanArgs a) {
 }
 
 // =============================================================================================
+// k_anchored_exact: Aligner.locate of an ANCHORED adapter that tolerates no error -- flags = QUERY_STOP (5',
+// "^ADAPTER", Where.PREFIX) or QUERY_START (3', "ADAPTER$", Where.SUFFIX) and thr[effective_length] == 0 (short
+// adapters, adapters made mostly of N wildcards such as "^NNNNNNNNACGTACGT": the threshold counts the non-N
+// characters, reference _align.pyx:505-513).  A candidate then needs cost 0, and an alignment of cost 0 that starts
+// at (0, 0) (prefix; the only last-row cell a cost-0 path reaches is (m, m), :496-533, where the loop breaks) or ends
+// in (m, n) (suffix: the last-column scan looks at row m only, :536-572) is the adapter itself, character by
+// character under the matcher's compare mode: the result is (0, m, 0, m, m, 0) / (0, m, n - m, n, m, 0) or None,
+// whatever the indel cost -- no cell is needed.  Bytes >= 0x80 are flagged over the columns the DP would have read
+// (the first / last min(n, m + k) characters).
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_anchored_exact(DpArgs a) {
+    __shared__ uint64_t s_rowmask[CAH_TABLE_CHARS];
+    const CahMatcher* mt = a.matcher;
+    for (int i = threadIdx.x; i < CAH_TABLE_CHARS; i += blockDim.x) s_rowmask[i] = mt->rowmask[i];
+    __syncthreads();
+    const int m = mt->m, k = mt->k;
+    const bool suffix = mt->flags == 2;
+    const int lane = wave_lane();
+    int64_t total = a.n_reads;
+    if (a.queue_count) total = (int64_t)(*a.queue_count);
+    for (;;) {
+      const int64_t base0 = wave_dequeue(a.work_counter, CAH_DEQUEUE * WAVE);
+      if (base0 >= total) break;
+      for (int sub = 0; sub < CAH_DEQUEUE; ++sub) {
+        const int64_t base = base0 + (int64_t)sub * WAVE;
+        if (base >= total) break;
+        const int64_t idx = base + lane;
+        if (idx >= total) continue;
+        const int64_t r = a.queue ? (int64_t)a.queue[idx] : idx;
+        int64_t off, n64;
+        read_extent(a.offsets, a.lens, r, off, n64);
+        bool invalid = false;
+        if (n64 > a.max_read_len) { invalid = true; n64 = 0; }
+        const int n = (int)n64;
+        const uint8_t* q = a.seqs + off;
+        const int span = min(n, m + k);                    // the columns Aligner.locate reads (:348-352)
+        const int qbeg = suffix ? n - span : 0;
+        const int shift = suffix ? span - m : 0;           // region offset rel <-> adapter position rel - shift
+        bool differ = n < m;
+        unsigned seen = 0;
+#pragma unroll 1
+        for (int c0 = 0; c0 < CAH_MAX_M + 16; c0 += 16) {
+            if (!__any(c0 < span)) break;
+            if (c0 < span) {
+                const Chunk ck = load_chunk(q, qbeg + c0, n, qbeg + span);
+                seen |= ck.w[0] | ck.w[1] | ck.w[2] | ck.w[3];
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const int rel = c0 + t;
+                    const int i = rel - shift;
+                    const bool inside = rel < span && i >= 0 && i < m;
+                    const uint64_t mk = s_rowmask[chunk_byte(ck, t) & (CAH_TABLE_CHARS - 1)];
+                    differ |= inside && !((mk >> (inside ? i : 0)) & 1ull);
+                }
+            }
+        }
+        if (seen & 0x80808080u) invalid = true;
+        const bool found = !invalid && !differ;
+        store_result(a.out6, a.status, a.best_adapter, a.adapter_index, a.merge_best, r, invalid, found,
+                     0, m, suffix ? n - m : 0, suffix ? n : m, m, 0);
+      }
+    }
+}
+
+// =============================================================================================
 // k_tiny: prefilter + cost scan of up to 64 reads in ONE launch of one wave -- the per-read API of the reference
 // (Adapter.match_to(read), Aligner.locate(read)) is a batch of one, and three launches (prefilter, scan, cell DP)
 // plus their queues cost more than the work.  Lane = read.  The prefilter is the ragged lean machinery, the scan
@@ -2268,7 +2343,10 @@ __global__ __launch_bounds__(256) void k_comparer(DpArgs a) {
     int64_t total = a.n_reads;
     if (a.queue_count) total = (int64_t)(*a.queue_count);
     for (;;) {
-        const int64_t base = wave_dequeue(a.work_counter);
+      const int64_t base0 = wave_dequeue(a.work_counter, CAH_DEQUEUE * WAVE);
+      if (base0 >= total) break;
+      for (int sub = 0; sub < CAH_DEQUEUE; ++sub) {
+        const int64_t base = base0 + (int64_t)sub * WAVE;
         if (base >= total) break;
         const int64_t idx = base + lane;
         if (idx >= total) continue;
@@ -2324,6 +2402,7 @@ __global__ __launch_bounds__(256) void k_comparer(DpArgs a) {
             if (found) { o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3; o[4] = score; o[5] = errors; }
             else { o[0] = o[1] = o[2] = o[3] = o[4] = o[5] = 0; }
         }
+      }
     }
 }
 
@@ -2537,6 +2616,12 @@ hipError_t launch_ticket(int32_t* done, int32_t ticket, hipStream_t s) {
 hipError_t launch_comparer(const DpArgs& a, int64_t max_items, int n_cus, hipStream_t s) {
     const int grid = grid_for(max_items, 8, n_cus);
     hipLaunchKernelGGL(k_comparer, dim3(grid), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_anchored_exact(const DpArgs& a, int64_t max_items, int n_cus, hipStream_t s) {
+    const int grid = grid_for(max_items, 8, n_cus);
+    hipLaunchKernelGGL(k_anchored_exact, dim3(grid), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

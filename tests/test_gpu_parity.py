@@ -632,3 +632,67 @@ def test_lean_prefilter_equals_general_prefilter(hip, orc):
                 exp = oal.locate(r) if (finder is None or finder.kmers_present(r)) else None
                 got = tuple(int(v) for v in lean[0][i]) if lean[1][i] == 1 else None
                 assert got == exp, (seq, n, r, got, exp)
+
+
+def test_anchored_adapters_without_errors_vs_oracle(hip, orc):
+    """k_anchored_exact: anchored aligners (Where.PREFIX = 8, Where.SUFFIX = 2) whose threshold at full length is 0 --
+    short adapters, adapters of mostly N wildcards, rate 0 -- take a character comparison instead of the cell DP.
+    Reads that start / end with the adapter (exact, one edit, shifted by one, truncated), wildcards on either
+    side, every indel cost, invalid bytes inside and outside the columns the aligner reads."""
+    from cutadapt_amd import _lib
+    rng = random.Random(808)
+    total = found = 0
+    for it in range(120):
+        flags = rng.choice([PREFIX, SUFFIX])
+        wr = rng.random() < 0.5
+        m = rng.choice([1, 2, 3, 5, 8, 9, 12, 16, 20, 33, 40, 64])
+        if wr and rng.random() < 0.6:
+            adapter = "".join(rng.choice("ACGTNNNN") for _ in range(m))
+            if set(adapter) <= set("N"):
+                adapter = "A" + adapter[1:]
+        else:
+            adapter = rs(rng, m, "ACGT")
+        eff = m - (adapter.count("N") if wr else 0)
+        rate = rng.choice([0.0, 0.05, 0.1, 0.99 / max(eff, 1)])
+        args = (adapter, rate, flags, wr, rng.random() < 0.3, rng.choice([1, 1, 2, 100000]), rng.randint(1, m))
+        oa = orc.Aligner(*args)
+        plan = _lib.Plan([_lib.MatcherSpec(*args)])
+        reads = []
+        for _ in range(400):
+            body = rs(rng, rng.randint(0, 40), "ACGT")
+            piece = list(adapter.replace("N", rng.choice("ACGT")) if wr else adapter)
+            u = rng.random()
+            if u < 0.35 and piece:
+                x = rng.randrange(len(piece))
+                op = rng.randint(0, 2)
+                if op == 0:
+                    piece[x] = rng.choice("ACGTN")
+                elif op == 1:
+                    piece.insert(x, rng.choice("ACGT"))
+                else:
+                    del piece[x]
+            elif u < 0.45:
+                piece = piece[:rng.randint(0, len(piece))]
+            p = "".join(piece)
+            if rng.random() < 0.15:
+                p = p.lower()
+            q = p + body if flags == PREFIX else body + p
+            if rng.random() < 0.1:
+                q = rng.choice("ACGT") + q if flags == PREFIX else q + rng.choice("ACGT")
+            reads.append(q)
+        seqs, offsets = orc.pack_reads(reads)
+        seqs = seqs.copy()
+        k = int(rate * m)
+        for _ in range(6):                                   # bytes >= 0x80 inside the columns the aligner reads
+            r = rng.randrange(len(reads))                    # (the first / last min(n, m + k): _align.pyx:346-352)
+            n = int(offsets[r + 1] - offsets[r])
+            span = min(n, m + k)
+            if span:
+                lo = offsets[r] if flags == PREFIX else offsets[r + 1] - span
+                seqs[rng.randrange(lo, lo + span)] = 0xC3
+        want6, want_st = oa.locate_batch(seqs, offsets)
+        got6, got_st = host_locate_batch(plan, seqs, offsets)
+        assert_same(got6, got_st, want6, want_st, f"anchored {args}")
+        total += len(reads)
+        found += int((want_st == 1).sum())
+    assert total > 40000 and found > 8000, (total, found)
