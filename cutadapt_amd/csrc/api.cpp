@@ -597,6 +597,34 @@ static int build_matcher(const cah_adapter_desc& d, int index, CahMatcher& mt,
             }
         }
     }
+
+    // ---- is the prefilter implied by an unedited, anchored occurrence of the adapter? (CahMatcher::filter_implied)
+    mt.filter_implied = 0;
+    if (d.kind == CAH_KIND_ALIGNER && (mt.flags == 8 || mt.flags == 2) && d.n_kmer_sets > 0 && m >= 1 && m <= CAH_MAX_M) {
+        const bool prefix = mt.flags == 8;
+        for (int s = 0; s < d.n_kmer_sets && !mt.filter_implied; s++) {
+            const cah_kmer_set& ks = d.kmer_sets[s];
+            for (int t = 0; t < ks.n_kmers && !mt.filter_implied; t++) {
+                const char* kmer = ks.kmers[t];
+                const int len = (int)strlen(kmer);
+                for (int p = 0; p + len <= m && !mt.filter_implied; p++) {
+                    // the window, with the adapter at read positions 0.. (prefix) or n-m.. (suffix, any n >= m)
+                    bool inside;
+                    if (ks.start == 0 && ks.stop == 0) inside = true;
+                    else if (prefix) inside = ks.start >= 0 && ks.start <= p && (ks.stop == 0 || (ks.stop > 0 && p + len <= ks.stop));
+                    else inside = ks.start < 0 && ks.stop == 0 && p >= m + ks.start;
+                    if (!inside) continue;
+                    // whatever the aligner accepts at adapter position p + i, the k-mer's character i accepts
+                    bool implied = true;
+                    for (int i = 0; i < len && implied; i++)
+                        for (int qc = 0; qc < CAH_TABLE_CHARS && implied; qc++)
+                            if (((mt.rowmask[qc] >> (p + i)) & 1ull) && !kmer_chars_match((uint8_t)kmer[i], (uint8_t)qc, rwc, qwc))
+                                implied = false;
+                    if (implied) mt.filter_implied = 1;
+                }
+            }
+        }
+    }
     return CAH_OK;
 }
 
@@ -1009,6 +1037,11 @@ static bool anchored_exact_ok(const CahMatcher& mt) {
            mt.min_overlap <= mt.m;
 }
 
+// does cah_match_batch run this matcher's prefilter?  (not when it cannot reject anything the aligner would accept)
+static bool runs_filter(const CahMatcher& mt) {
+    return mt.has_filter && !(mt.filter_implied && mt.kind == CAH_KIND_ALIGNER && anchored_exact_ok(mt));
+}
+
 // CAH_SCAN_WORD64=1: the cost scan always uses the 64-bit form of the column (A/B measurements, parity tests)
 static int scan_word_kind(int m) {
     static const bool force64 = [] { const char* e = getenv("CAH_SCAN_WORD64"); return e && *e && *e != '0'; }();
@@ -1316,7 +1349,7 @@ int cah_match_batch(const cah_plan* plan, const uint8_t* d_seqs, const int64_t* 
     for (int32_t ad = 0; ad < (int32_t)plan->matchers.size() && first_aligner < 0; ad++)
         if (plan->matchers[(size_t)ad].kind != CAH_KIND_KMER_ONLY) first_aligner = ad;
     const bool filter_clears = !t_outputs_ready && !multi_path && first_aligner >= 0 &&
-                               plan->matchers[(size_t)first_aligner].has_filter && n_reads > CAH_TINY_BATCH;
+                               runs_filter(plan->matchers[(size_t)first_aligner]) && n_reads > CAH_TINY_BATCH;
     if (!t_outputs_ready) {
         HIP_TRY(hipMemsetAsync(d_status, 0, (size_t)n_reads, s));
         if (!filter_clears) HIP_TRY(hipMemsetAsync(d_out6, 0, sizeof(int32_t) * 6 * (size_t)n_reads, s));
@@ -1334,7 +1367,7 @@ int cah_match_batch(const cah_plan* plan, const uint8_t* d_seqs, const int64_t* 
     if (!d_lens && !tiny) {
         bool any_lean = false;
         for (size_t ad = 0; ad < plan->matchers.size(); ad++)
-            any_lean |= plan->matchers[ad].has_filter && plan->matchers[ad].kind != CAH_KIND_KMER_ONLY && plan->lean[ad].ok;
+            any_lean |= runs_filter(plan->matchers[ad]) && plan->matchers[ad].kind != CAH_KIND_KMER_ONLY && plan->lean[ad].ok;
         if (any_lean) {
             HIP_TRY(hipMemsetAsync(counters + WS_UFLAG, 0, sizeof(unsigned long long), s));
             HIP_TRY(launch_uniform_check(d_offsets, n_reads, CAH_MAX_READ_LEN, counters + WS_UFLAG, pd->n_cus, s));
@@ -1347,7 +1380,7 @@ int cah_match_batch(const cah_plan* plan, const uint8_t* d_seqs, const int64_t* 
     for (int32_t ad = 0; ad < (int32_t)plan->matchers.size(); ad++) {
         const CahMatcher& mt = plan->matchers[(size_t)ad];
         if (mt.kind == CAH_KIND_KMER_ONLY) continue;
-        if (mt.has_filter) {
+        if (runs_filter(mt)) {
             // prefilter -> queue of surviving reads -> (cost scan ->) DP on dense waves
             rc = run_filter(plan, pd, ad, d_seqs, d_offsets, d_lens, n_reads, 1, nullptr, d_status, ws.queue,
                             counters + WS_QCOUNT, ws.keys, counters + 0, d_batch_flag, s,

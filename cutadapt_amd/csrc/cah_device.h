@@ -52,6 +52,12 @@ struct CahMatcher {
     int32_t kacc;              // thr[effective_length] (-1 if m < min_overlap): acceptable last-row cost
     int32_t thr_last[CAH_MAX_M + 1];   // thr[effective length of adapter[0:i]]: threshold of row i in the last column
     uint64_t scanmask[CAH_TABLE_CHARS]; // rowmask << (64 - m) | ones below: the adapter in the top m bits
+    // 1: a read that holds the adapter unedited at its anchored place (prefix aligner: position 0, suffix aligner:
+    // the last m characters) passes this plan's prefilter -- some k-mer of a search set is a piece of the adapter
+    // inside its window there, and every character the aligner accepts at that place the k-mer table accepts too.
+    // For anchored adapters that tolerate no error (k_anchored_exact) the prefilter is then redundant and skipped.
+    int32_t filter_implied;
+    int32_t pad_;
 };
 
 struct CahKmerWord {
