@@ -43,6 +43,22 @@
 //               e - jfa <= m/2 - kacc (the origin clause, as for EXACT_FULL); later columns (cost >= c) cannot
 //               score more; a row i of the last column could only win with i - 2 C(i, n) > m - 2c, which is
 //               checked.  No `break` (cost > 0).                          -> (0, m, e-m, e, m-2c, c)
+//   INDEL1_FULL the adapter occurs with ONE insertion or ONE deletion (32-bit forms only): the smallest row-m cost of
+//               any column is 1, first reached at column e, and the diagonal d = e - m that ends in (m, e) is not
+//               clean.  Walk the reference's cell (m, e) back: below the LOWEST cell (i*, j*) of that diagonal
+//               whose characters differ every cell matches and takes the diagonal (:446-453), so (i*, j*) costs 1
+//               too, and its predecessor -- the first of (diagonal, cell above, cell to the left) that attains
+//               the minimum, :462-476 -- costs 0.  Not the diagonal one (the diagonal would be clean), so: the
+//               cell above if C(i*-1, j*) = 0 -- a deletion: adapter[0:i*-1] then ends unedited at j*, origin
+//               d + 1, m - 1 matches, score m - 3 -- else the cell to the left -- an insertion: origin d - 1, m
+//               matches, score m - 2.  "C(r, j) = 0" is plain shift-and (Z' = ((Z << 1) | 1) & Eq), and the bit
+//               [C(i-1, j) = 0] of the lowest differing cell rides down every diagonal like the accumulator A does
+//               (U' = ((U << 1) & Eq) | (((Z' << 1) | 1) & ~Eq)): bit m of U at column e says "deletion".
+//               Earlier acceptable columns cost >= 2 and score <= m - 4: column e replaces them when the origin
+//               clause holds with the deletion's origin, e + 1 - jfa <= m/2 - kacc.  Later columns: an insertion
+//               scores m - 2, the most a cost-1 alignment can, so nothing later replaces it; a deletion (m - 3)
+//               could lose to a later cost-1 column, so there must be none (checked).  Rows of the last column
+//               are checked as for SUBS_FULL.                  -> (0, m, e-m+1, e, m-3, 1) / (0, m, e-m-1, e, m-2, 1)
 //   (early stop) Last-row candidates are replaced only by candidates that OVERLAP them: (:521-524) the new origin
 //               must be <= best.origin + m // 2 (all last-row candidates have length m, so the `length >` clause
 //               is dead once a best exists).  A candidate of column j with cost c <= kacc has its origin in
@@ -81,7 +97,7 @@
 #define CAH_HD inline
 #endif
 
-enum { BS_NONE = 0, BS_EXACT_FULL = 1, BS_EXACT_TAIL = 2, BS_DP = 3, BS_SUBS_FULL = 4 };
+enum { BS_NONE = 0, BS_EXACT_FULL = 1, BS_EXACT_TAIL = 2, BS_DP = 3, BS_SUBS_FULL = 4, BS_INDEL1_FULL = 5 };
 
 struct BackScanParams {
     int m;            // adapter length, 1..64
@@ -100,6 +116,8 @@ struct BackScanBook {
     // eclean: that column's diagonal was clean (see A below).
     int cmin, je;
     bool eclean;
+    bool edel;        // INDEL1_FULL: the lowest differing cell of that diagonal was reached from the cell above
+    bool emore;       // a later column reached cmin again
 };
 
 struct BackScanState : BackScanBook {
@@ -120,6 +138,9 @@ struct BackScanState : BackScanBook {
 template <int X>
 struct BackScanState32 : BackScanBook {
     uint32_t VP, VN, A;
+    uint32_t Z, U;                 // INDEL1_FULL: rows of cost 0 (shift-and); [cell above costs 0] of each diagonal's
+                                   // lowest differing cell
+                                   // X > 0: the same for rows 33 + t live in ax: bit 8 + t (Z), bit 16 + t (U)
     int cv;                        // X > 0: C(32, j)
     int cx[X > 0 ? X : 1];         // X > 0: C(33 + t, j)
     unsigned ax;                   // X > 0: bit t = the accumulator bit of row 33 + t
@@ -143,18 +164,19 @@ CAH_HD void bs_init(BackScanState& s, const BackScanParams& p) {
     s.VN = 0;
     s.cm = p.m;
     s.jfa = -1; s.jla = -1;
-    s.A = 0; s.cmin = 1 << 20; s.je = -1; s.eclean = false;
+    s.A = 0; s.cmin = 1 << 20; s.je = -1; s.eclean = false; s.edel = false; s.emore = false;
 }
 
 // Row m of the column just processed: the bookkeeping every representation shares.  clean: the diagonal that ends
 // in (m, j) has met no cell whose diagonal delta is 0 although its characters differ.  Returns true when the read
 // is finished as EXACT_FULL at this column.
 template <bool SUBS>
-CAH_HD bool bs_book(BackScanBook& s, const bool clean, const int j, const BackScanParams& p) {
+CAH_HD bool bs_book(BackScanBook& s, const bool clean, const int j, const BackScanParams& p, const bool del = false) {
     if (s.cm <= p.kacc) {
         if (s.jfa < 0) s.jfa = j;
         s.jla = j;
-        if (SUBS && s.cm < s.cmin) { s.cmin = s.cm; s.je = j; s.eclean = clean; }
+        if (SUBS && s.cm == s.cmin) s.emore = true;
+        if (SUBS && s.cm < s.cmin) { s.cmin = s.cm; s.je = j; s.eclean = clean; s.edel = del; s.emore = false; }
         // (:521-533) a cost-0 candidate has score m, more than any earlier best (those cost >= 1: the
         // first cost-0 column ends the loop), so it replaces the best iff it is the first or
         // origin = j - m <= best.origin + m/2.  Every earlier acceptable candidate sits at a column
@@ -207,7 +229,9 @@ CAH_HD void bs32_init(BackScanState32<X>& s, const BackScanParams& p) {
     for (int t = 0; t < (X > 0 ? X : 1); ++t) s.cx[t] = 33 + t;
     s.cm = p.m;
     s.jfa = -1; s.jla = -1;
-    s.cmin = 1 << 20; s.je = -1; s.eclean = false;
+    s.cmin = 1 << 20; s.je = -1; s.eclean = false; s.edel = false; s.emore = false;
+    s.Z = pad == 0 ? 0u : ((1u << pad) - 1u);        // pad rows cost 0, like row 0
+    s.U = 0;
 }
 
 template <bool SUBS, int X>
@@ -223,16 +247,25 @@ CAH_HD bool bs32_step(BackScanState32<X>& s, const uint32_t eq, const uint32_t e
     s.VN = HPs & Xv;
     const uint32_t a_old = s.A;
     if (SUBS) s.A = (a_old << 1) | ((Xh | VN) & ~eq);
-    bool clean;
+    const uint32_t z_old = s.Z, u_old = s.U;
+    if (SUBS) {
+        s.Z = ((z_old << 1) | 1u) & eq;
+        s.U = ((u_old << 1) & eq) | (((s.Z << 1) | 1u) & ~eq);
+    }
+    bool clean, del = false;
     if (X == 0) {
         s.cm += dtop;
         clean = (s.A >> 31) == 0;
+        del = (s.U >> 31) != 0;
     } else {
         int up_prev = s.cv;                                        // C(r-1, j-1)
         s.cv += dtop;
         int up = s.cv;                                             // C(r-1, j)
         unsigned a_above = a_old >> 31;                            // accumulator bit of row r-1 in column j-1
         unsigned ax_new = 0;
+        unsigned z_above_old = z_old >> 31, u_above_old = u_old >> 31;   // row r-1, column j-1
+        unsigned z_above_new = s.Z >> 31;                                // row r-1, column j
+        unsigned zx_new = 0, ux_new = 0;
         for (int t = 0; t < X; ++t) {
             const int neq = (int)(~(eqx >> t) & 1u);
             const int cprev = s.cx[t];                             // C(r, j-1)
@@ -243,14 +276,20 @@ CAH_HD bool bs32_step(BackScanState32<X>& s, const uint32_t eq, const uint32_t e
             const unsigned a_new = a_above | x;
             a_above = (s.ax >> t) & 1u;
             ax_new |= a_new << t;
+            // shift-and and the "cell above costs 0" bit of this row
+            const unsigned z_new = neq ? 0u : z_above_old;
+            const unsigned u_new = neq ? z_above_new : u_above_old;
+            z_above_old = (s.ax >> (8 + t)) & 1u; u_above_old = (s.ax >> (16 + t)) & 1u; z_above_new = z_new;
+            zx_new |= z_new << t; ux_new |= u_new << t;
             up_prev = cprev; up = c;
             s.cx[t] = c;
         }
-        if (SUBS) s.ax = ax_new;
+        if (SUBS) s.ax = ax_new | (zx_new << 8) | (ux_new << 16);
         s.cm = s.cx[X - 1];
         clean = ((ax_new >> (X - 1)) & 1u) == 0;
+        del = ((ux_new >> (X - 1)) & 1u) != 0;
     }
-    if (__builtin_expect(s.cm <= p.kacc, 0)) return bs_book<SUBS>(s, clean, j, p);
+    if (__builtin_expect(s.cm <= p.kacc, 0)) return bs_book<SUBS>(s, clean, j, p, del);
     return false;
 }
 
@@ -274,16 +313,21 @@ CAH_HD bool bs_may_stop(const BackScanBook& s, const int j, const int n, const i
 // (the cost scan itself started there).  Outputs: o0/o1 = (row i, -) for EXACT_TAIL, (first DP column,
 // last DP column * 2 + scan flag) for DP.
 // row_cost(i): the absolute cost of row i of the last column, asked for i = 1, 2, .., m in this order.
-template <class ThrLast, class RowCost>
+template <bool INDEL1, class ThrLast, class RowCost>
 CAH_HD int bs_finish_rows(const BackScanBook& s, const int n, const int j0, const BackScanParams& p,
                           ThrLast thr_last, int& o0, int& o1, const bool stopped, RowCost row_cost) {
     o0 = 0; o1 = 0;
     const int reach = p.m + p.k + 1;
+    // one insertion / one deletion (see the header); INDEL1 = false: the form does not keep the bits
+    const bool indel1 = INDEL1 && s.cmin == 1 && !s.eclean && s.je - p.m - 1 >= j0 &&
+                        s.je + 1 - s.jfa <= p.half_m - p.kacc && !(s.edel && s.emore);
+    const int indel1_score = p.m - (s.edel ? 3 : 2);
     if (stopped) {                   // jfa >= 0
         if (s.cmin >= 1 && s.eclean && s.je - p.m >= j0 && s.je - s.jfa <= p.half_m - p.kacc) {
             o0 = s.je; o1 = s.cmin;
             return BS_SUBS_FULL;
         }
+        if (indel1) { o0 = s.je; o1 = s.edel ? 1 : 0; return BS_INDEL1_FULL; }
         const int s0 = s.jfa - reach;
         o0 = s0 > j0 ? s0 : j0;
         o1 = s.jla * 2;
@@ -294,6 +338,7 @@ CAH_HD int bs_finish_rows(const BackScanBook& s, const int n, const int j0, cons
     int i0 = 0;                      // the largest acceptable row that costs 0
     bool above_ok = true;            // every acceptable row above i0 scores less than i0 and cannot shift the origin clause
     bool tail_may_win = false;       // an acceptable row of the last column that could outscore m - 2 * cmin
+    bool tail_may_win1 = false;      // ... the score of the one-indel alignment
     for (int i = 1; i <= p.m; ++i) {
         const int c = row_cost(i);
         if (i >= p.min_overlap && c <= thr_last(i)) {
@@ -301,6 +346,7 @@ CAH_HD int bs_finish_rows(const BackScanBook& s, const int n, const int j0, cons
             if (c == 0) { i0 = i; above_ok = true; }
             else if (!(i - 2 * c < i0 && p.k + 1 + c <= p.half_m)) above_ok = false;
             if (i - 2 * c > p.m - 2 * s.cmin) tail_may_win = true;
+            if (i - 2 * c > indel1_score) tail_may_win1 = true;
         }
     }
     if (s.jfa < 0) {
@@ -316,6 +362,7 @@ CAH_HD int bs_finish_rows(const BackScanBook& s, const int n, const int j0, cons
         o0 = s.je; o1 = s.cmin;
         return BS_SUBS_FULL;
     }
+    if (indel1 && !tail_may_win1) { o0 = s.je; o1 = s.edel ? 1 : 0; return BS_INDEL1_FULL; }
     const int s0 = s.jfa - reach;
     o0 = s0 > j0 ? s0 : j0;
     o1 = best_i == 0 ? s.jla * 2 : n * 2 + 1;
@@ -328,7 +375,7 @@ CAH_HD int bs_finish(const BackScanState& s, const int n, const int j0, const Ba
     const int pad = 64 - p.m;
     uint64_t vp = pad == 0 ? s.VP : (s.VP >> pad), vn = pad == 0 ? s.VN : (s.VN >> pad);
     int c = 0;
-    return bs_finish_rows(s, n, j0, p, thr_last, o0, o1, stopped, [&](int) {
+    return bs_finish_rows<false>(s, n, j0, p, thr_last, o0, o1, stopped, [&](int) {
         c += (int)(vp & 1ull) - (int)(vn & 1ull);
         vp >>= 1; vn >>= 1;
         return c;
@@ -341,7 +388,7 @@ CAH_HD int bs32_finish(const BackScanState32<X>& s, const int n, const int j0, c
     const int pad = X > 0 ? 0 : 32 - p.m;
     uint32_t vp = s.VP >> pad, vn = s.VN >> pad;
     int c = 0;
-    return bs_finish_rows(s, n, j0, p, thr_last, o0, o1, stopped, [&](int i) {
+    return bs_finish_rows<true>(s, n, j0, p, thr_last, o0, o1, stopped, [&](int i) {
         if (X > 0 && i > 32) return s.cx[i - 33 < X ? i - 33 : 0];
         c += (int)(vp & 1u) - (int)(vn & 1u);
         vp >>= 1; vn >>= 1;

@@ -1800,7 +1800,7 @@ __device__ __forceinline__ void store_result(int32_t* out6, uint8_t* status, int
 // characters), 2 / 3 = a 32-bit word + 1 / 2 explicit rows (33 / 34 characters).  The 32-bit forms cost about half the
 // instructions per column.
 template <bool MULTI, int KIND>
-__global__ __launch_bounds__(256) void k_back_scan(ScanArgs a) {
+__global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_back_scan(ScanArgs a) {
     constexpr int XR = KIND >= 2 ? KIND - 1 : 0;
     extern __shared__ __attribute__((aligned(16))) uint64_t s_scanmask[];   // [128], or [n_adapters * CAH_MULTI_TAB_STRIDE]
     __shared__ int s_thr_last[CAH_MAX_M + 1];
@@ -2000,6 +2000,9 @@ __global__ __launch_bounds__(256) void k_back_scan(ScanArgs a) {
                 } else if (cls == BS_SUBS_FULL) {
                     store_result(a.out6, a.status, a.best_adapter, a.adapter_index, a.merge_best, r, false, true,
                                  0, p.m, o0 - p.m, o0, p.m - 2 * o1, o1);
+                } else if (cls == BS_INDEL1_FULL) {        // one deletion (o1 = 1) / one insertion (o1 = 0)
+                    store_result(a.out6, a.status, a.best_adapter, a.adapter_index, a.merge_best, r, false, true,
+                                 0, p.m, o0 - p.m + (o1 ? 1 : -1), o0, p.m - (o1 ? 3 : 2), 1);
                 }
             }
             const bool to_dp = valid_out && !invalid && cls == BS_DP;

@@ -88,7 +88,7 @@ def compare(L, adapter, rate, min_overlap, seqs, offsets, wr=False, wq=False, sk
                                  f"{adapter} rate {rate} O {min_overlap} wr {wr} wq {wq} j0 {None if j0s is None else j0s[r]} "
                                  f"class {cls[r]} model {status[r]} {out6[r].tolist()} oracle {want_st[r]} {want6[r].tolist()}")
         if stop_every == 16 and form == -1:
-            counts = np.bincount(cls, minlength=5)
+            counts = np.bincount(cls, minlength=6)
     return counts
 
 
@@ -339,3 +339,51 @@ def test_word_forms(model):
             if compare(model, adapter, rate, min_overlap, seqs, offsets, skip=skip, label=f"forms {it} m {m} skip {skip}") is not None:
                 done += 1
     assert done > 200
+
+
+def test_one_indel_class(model):
+    """INDEL1_FULL (the adapter with one insertion or one deletion, 32-bit forms): every position of the edit --
+    inside runs of equal characters, at the adapter's ends --, adapters of every kind (random, low-complexity,
+    two-letter: where a mismatch path, a deletion path and an insertion path can cost the same), a second copy
+    or a partial copy behind it, further substitutions (the DP's case).  Either the reference's tuple or the DP."""
+    rng = np.random.default_rng(55)
+    indel1 = 0
+    for it in range(160):
+        m = int(rng.choice([4, 6, 9, 12, 17, 20, 25, 31, 32, 33, 33, 34]))
+        kind = it % 4
+        if kind == 0:
+            adapter = "".join(rng.choice(list("ACGT"), size=m))
+        elif kind == 1:
+            unit = "".join(rng.choice(list("ACGT"), size=int(rng.integers(1, 4))))
+            adapter = (unit * 40)[:m]
+        elif kind == 2:
+            adapter = "".join(rng.choice(list("AC"), size=m))
+        else:
+            adapter = "".join(rng.choice(list("ACGT"), size=1)[0] * int(rng.integers(1, 4)) for _ in range(m))[:m]
+        rate = float(rng.choice([0.1, 0.1, 0.15, 0.2, 0.3]))
+        min_overlap = int(rng.choice([1, 3, 5]))
+        alpha = list("ACGT") if kind != 2 else list("ACCA")
+        reads = []
+        for _ in range(600):
+            ad = list(adapter)
+            pos = int(rng.integers(0, m))
+            if rng.random() < 0.5:
+                del ad[pos]
+            else:
+                ad.insert(pos, str(rng.choice(alpha)))
+            if rng.random() < 0.2:
+                ad[int(rng.integers(0, len(ad)))] = str(rng.choice(alpha))
+            head = "".join(rng.choice(alpha, size=int(rng.integers(0, 60))))
+            tail = "".join(rng.choice(alpha, size=int(rng.integers(0, 60)))) if rng.random() < 0.7 else ""
+            if rng.random() < 0.15:
+                second = list(adapter)
+                if rng.random() < 0.5:
+                    second[int(rng.integers(0, m))] = str(rng.choice(alpha))
+                tail = tail[:int(rng.integers(0, 30))] + "".join(second)[:int(rng.integers(1, m + 1))] + tail[30:]
+            reads.append(head + "".join(ad) + tail)
+        seqs, offsets = orc.pack_reads(reads)
+        for skip in (False, True):
+            counts = compare(model, adapter, rate, min_overlap, seqs, offsets, skip=skip, label=f"indel1 {it} m {m} skip {skip}")
+            if counts is not None and len(counts) > 5:
+                indel1 += int(counts[5])
+    assert indel1 > 30000, indel1
