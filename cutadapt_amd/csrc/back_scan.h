@@ -32,6 +32,14 @@
 //               origin is >= n - i' - c' >= n - r_s - c'.  Hence origin - best.origin <= k + 1 + c', and the
 //               clause holds when k + 1 + c' <= m // 2 for every larger acceptable row (checked; 7 <= 16 for
 //               a 33-character adapter at rate 0.1).                     -> (0, i, n-i, n, i, 0)
+//               The same replay works with SUBSTITUTIONS in the tail: a row i whose diagonal into (i, n) is clean
+//               (bit i of A in the last column; cost-0 rows are clean by themselves) carries exactly
+//               (c_i, i - 2 c_i, n - i), like (m, e) of SUBS_FULL.  Let W be the clean acceptable row of the highest
+//               score (the largest such row on ties).  Rows with an unclean diagonal score at most i - 2 c_i; if that
+//               is < score(W) for all of them, then going down the column the best is below score(W) when row W
+//               is reached (clean rows above it score less by the choice of W, unclean ones by their bound), W
+//               replaces it (origin clause as above, for every acceptable row with errors), and nothing below W
+//               scores more.                                           -> (0, W, n-W, n, W-2c, c)
 //   SUBS_FULL   the adapter occurs with substitutions only -- what sequencing errors are: c = the smallest row-m
 //               cost of any column, 1 <= c <= kacc, first reached at column e, and the diagonal that ends in
 //               (m, e) is "clean": every cell on it whose characters differ costs one more than its diagonal
@@ -43,22 +51,25 @@
 //               e - jfa <= m/2 - kacc (the origin clause, as for EXACT_FULL); later columns (cost >= c) cannot
 //               score more; a row i of the last column could only win with i - 2 C(i, n) > m - 2c, which is
 //               checked.  No `break` (cost > 0).                          -> (0, m, e-m, e, m-2c, c)
-//   INDEL1_FULL the adapter occurs with ONE insertion or ONE deletion (32-bit forms only): the smallest row-m cost of
-//               any column is 1, first reached at column e, and the diagonal d = e - m that ends in (m, e) is not
-//               clean.  Walk the reference's cell (m, e) back: below the LOWEST cell (i*, j*) of that diagonal
-//               whose characters differ every cell matches and takes the diagonal (:446-453), so (i*, j*) costs 1
-//               too, and its predecessor -- the first of (diagonal, cell above, cell to the left) that attains
-//               the minimum, :462-476 -- costs 0.  Not the diagonal one (the diagonal would be clean), so: the
-//               cell above if C(i*-1, j*) = 0 -- a deletion: adapter[0:i*-1] then ends unedited at j*, origin
-//               d + 1, m - 1 matches, score m - 3 -- else the cell to the left -- an insertion: origin d - 1, m
-//               matches, score m - 2.  "C(r, j) = 0" is plain shift-and (Z' = ((Z << 1) | 1) & Eq), and the bit
-//               [C(i-1, j) = 0] of the lowest differing cell rides down every diagonal like the accumulator A does
-//               (U' = ((U << 1) & Eq) | (((Z' << 1) | 1) & ~Eq)): bit m of U at column e says "deletion".
-//               Earlier acceptable columns cost >= 2 and score <= m - 4: column e replaces them when the origin
-//               clause holds with the deletion's origin, e + 1 - jfa <= m/2 - kacc.  Later columns: an insertion
-//               scores m - 2, the most a cost-1 alignment can, so nothing later replaces it; a deletion (m - 3)
-//               could lose to a later cost-1 column, so there must be none (checked).  Rows of the last column
-//               are checked as for SUBS_FULL.                  -> (0, m, e-m+1, e, m-3, 1) / (0, m, e-m-1, e, m-2, 1)
+//   INDEL1_FULL the adapter occurs with ONE insertion or ONE deletion and otherwise substitutions only (32-bit forms):
+//               c = the smallest row-m cost of any column, first reached at column e, and the diagonal d = e - m that
+//               ends in (m, e) is NOT clean.  Walk the reference's cell (m, e) back up that diagonal: cells whose
+//               characters match take the diagonal (:446-453), differing cells with diagonal delta +1 take it too
+//               (the diagonal candidate is minimal and wins ties, :462-476) -- until the LOWEST unclean cell (i*, j*)
+//               (characters differ, diagonal delta 0: the diagonal candidate costs one too many).  There the
+//               reference takes the cell above if that attains the minimum (vertical delta +1: bit i* of the new
+//               VP) -- a deletion, the path goes on from (i*-1, j*) on diagonal d + 1 -- else the cell to the left
+//               -- an insertion, on from (i*, j*-1) on diagonal d - 1.  If the diagonal of THAT cell is clean up to
+//               it (its accumulator bit: A of this column one row up / A of the last column), the rest of the path
+//               is substitutions only, so the alignment has c - 1 substitutions and one indel:
+//               deletion: origin d + 1, score m - 2c - 1; insertion: origin d - 1, score m - 2c.  Both facts ride
+//               down every diagonal like A does, overwritten at each unclean cell (the lowest one counts):
+//               U' = ((U << 1) & ~X) | (VP' & X),  Z' = ((Z << 1) & ~X) | (pa & X),  pa = VP' ? A' << 1 : A.
+//               Earlier acceptable columns cost >= c + 1 and score <= m - 2c - 2: column e replaces them when the
+//               origin clause holds with the deletion's origin, e + 1 - jfa <= m/2 - kacc.  Later columns cost
+//               >= c: an insertion's m - 2c is the most they can score, so nothing replaces it; a deletion could
+//               lose to a later column of cost c, so there must be none (checked).  Rows of the last column are
+//               checked as for SUBS_FULL.       -> (0, m, e-m+1, e, m-2c-1, c) / (0, m, e-m-1, e, m-2c, c)
 //   (early stop) Last-row candidates are replaced only by candidates that OVERLAP them: (:521-524) the new origin
 //               must be <= best.origin + m // 2 (all last-row candidates have length m, so the `length >` clause
 //               is dead once a best exists).  A candidate of column j with cost c <= kacc has its origin in
@@ -116,7 +127,8 @@ struct BackScanBook {
     // eclean: that column's diagonal was clean (see A below).
     int cmin, je;
     bool eclean;
-    bool edel;        // INDEL1_FULL: the lowest differing cell of that diagonal was reached from the cell above
+    bool edel;        // ONE_INDEL: the lowest unclean cell of that diagonal was reached from the cell above (a deletion)
+    bool epred_unclean;   // ... and the diagonal of the cell it was reached from is not clean either (or not tracked)
     bool emore;       // a later column reached cmin again
 };
 
@@ -138,9 +150,9 @@ struct BackScanState : BackScanBook {
 template <int X>
 struct BackScanState32 : BackScanBook {
     uint32_t VP, VN, A;
-    uint32_t Z, U;                 // INDEL1_FULL: rows of cost 0 (shift-and); [cell above costs 0] of each diagonal's
-                                   // lowest differing cell
-                                   // X > 0: the same for rows 33 + t live in ax: bit 8 + t (Z), bit 16 + t (U)
+    uint32_t U, Z;                 // ONE_INDEL, of each diagonal's lowest unclean cell: U = it is left upwards (a
+                                   // deletion), Z = the diagonal of the cell it is left to is unclean too
+                                   // X > 0: the same for rows 33 + t live in ax: bit 8 + t (U), bit 16 + t (Z)
     int cv;                        // X > 0: C(32, j)
     int cx[X > 0 ? X : 1];         // X > 0: C(33 + t, j)
     unsigned ax;                   // X > 0: bit t = the accumulator bit of row 33 + t
@@ -164,19 +176,22 @@ CAH_HD void bs_init(BackScanState& s, const BackScanParams& p) {
     s.VN = 0;
     s.cm = p.m;
     s.jfa = -1; s.jla = -1;
-    s.A = 0; s.cmin = 1 << 20; s.je = -1; s.eclean = false; s.edel = false; s.emore = false;
+    s.A = 0; s.cmin = 1 << 20; s.je = -1; s.eclean = false; s.edel = false; s.epred_unclean = true; s.emore = false;
 }
 
 // Row m of the column just processed: the bookkeeping every representation shares.  clean: the diagonal that ends
 // in (m, j) has met no cell whose diagonal delta is 0 although its characters differ.  Returns true when the read
 // is finished as EXACT_FULL at this column.
 template <bool SUBS>
-CAH_HD bool bs_book(BackScanBook& s, const bool clean, const int j, const BackScanParams& p, const bool del = false) {
+CAH_HD bool bs_book(BackScanBook& s, const bool clean, const int j, const BackScanParams& p, const bool del = false,
+                    const bool pred_unclean = true) {
     if (s.cm <= p.kacc) {
         if (s.jfa < 0) s.jfa = j;
         s.jla = j;
         if (SUBS && s.cm == s.cmin) s.emore = true;
-        if (SUBS && s.cm < s.cmin) { s.cmin = s.cm; s.je = j; s.eclean = clean; s.edel = del; s.emore = false; }
+        if (SUBS && s.cm < s.cmin) {
+            s.cmin = s.cm; s.je = j; s.eclean = clean; s.edel = del; s.epred_unclean = pred_unclean; s.emore = false;
+        }
         // (:521-533) a cost-0 candidate has score m, more than any earlier best (those cost >= 1: the
         // first cost-0 column ends the loop), so it replaces the best iff it is the first or
         // origin = j - m <= best.origin + m/2.  Every earlier acceptable candidate sits at a column
@@ -229,9 +244,8 @@ CAH_HD void bs32_init(BackScanState32<X>& s, const BackScanParams& p) {
     for (int t = 0; t < (X > 0 ? X : 1); ++t) s.cx[t] = 33 + t;
     s.cm = p.m;
     s.jfa = -1; s.jla = -1;
-    s.cmin = 1 << 20; s.je = -1; s.eclean = false; s.edel = false; s.emore = false;
-    s.Z = pad == 0 ? 0u : ((1u << pad) - 1u);        // pad rows cost 0, like row 0
-    s.U = 0;
+    s.cmin = 1 << 20; s.je = -1; s.eclean = false; s.edel = false; s.epred_unclean = true; s.emore = false;
+    s.Z = 0; s.U = 0;
 }
 
 template <bool SUBS, int X>
@@ -245,27 +259,30 @@ CAH_HD bool bs32_step(BackScanState32<X>& s, const uint32_t eq, const uint32_t e
     const uint32_t HPs = HP << 1, HNs = HN << 1;
     s.VP = HNs | ~(Xv | HPs);
     s.VN = HPs & Xv;
-    const uint32_t a_old = s.A;
-    if (SUBS) s.A = (a_old << 1) | ((Xh | VN) & ~eq);
-    const uint32_t z_old = s.Z, u_old = s.U;
+    const uint32_t a_old = s.A, u_old = s.U, z_old = s.Z;
     if (SUBS) {
-        s.Z = ((z_old << 1) | 1u) & eq;
-        s.U = ((u_old << 1) & eq) | (((s.Z << 1) | 1u) & ~eq);
+        const uint32_t Xc = (Xh | VN) & ~eq;                       // unclean cells: diagonal delta 0, characters differ
+        s.A = (a_old << 1) | Xc;
+        // ONE_INDEL: at an unclean cell the reference leaves the diagonal -- upwards (deletion) iff the vertical
+        // delta is +1 (new VP); the accumulator bit of the cell it comes from: above in this column / left in the last
+        s.U = ((u_old << 1) & ~Xc) | (s.VP & Xc);
+        const uint32_t pa = (s.VP & (s.A << 1)) | (~s.VP & a_old);
+        s.Z = ((z_old << 1) & ~Xc) | (pa & Xc);
     }
-    bool clean, del = false;
+    bool clean, del = false, pred_unclean = false;
     if (X == 0) {
         s.cm += dtop;
         clean = (s.A >> 31) == 0;
         del = (s.U >> 31) != 0;
+        pred_unclean = (s.Z >> 31) != 0;
     } else {
         int up_prev = s.cv;                                        // C(r-1, j-1)
         s.cv += dtop;
         int up = s.cv;                                             // C(r-1, j)
         unsigned a_above = a_old >> 31;                            // accumulator bit of row r-1 in column j-1
-        unsigned ax_new = 0;
-        unsigned z_above_old = z_old >> 31, u_above_old = u_old >> 31;   // row r-1, column j-1
-        unsigned z_above_new = s.Z >> 31;                                // row r-1, column j
-        unsigned zx_new = 0, ux_new = 0;
+        unsigned a_above_new = s.A >> 31;                          // ... in column j
+        unsigned u_above = u_old >> 31, z_above = z_old >> 31;     // row r-1, column j-1
+        unsigned ax_new = 0, ux_new = 0, zx_new = 0;
         for (int t = 0; t < X; ++t) {
             const int neq = (int)(~(eqx >> t) & 1u);
             const int cprev = s.cx[t];                             // C(r, j-1)
@@ -273,23 +290,24 @@ CAH_HD bool bs32_step(BackScanState32<X>& s, const uint32_t eq, const uint32_t e
             if (up + 1 < c) c = up + 1;
             if (cprev + 1 < c) c = cprev + 1;
             const unsigned x = (c == up_prev && neq) ? 1u : 0u;    // diagonal delta 0 although the characters differ
+            const unsigned a_row_old = (s.ax >> t) & 1u;           // this row, column j-1
             const unsigned a_new = a_above | x;
-            a_above = (s.ax >> t) & 1u;
-            ax_new |= a_new << t;
-            // shift-and and the "cell above costs 0" bit of this row
-            const unsigned z_new = neq ? 0u : z_above_old;
-            const unsigned u_new = neq ? z_above_new : u_above_old;
-            z_above_old = (s.ax >> (8 + t)) & 1u; u_above_old = (s.ax >> (16 + t)) & 1u; z_above_new = z_new;
-            zx_new |= z_new << t; ux_new |= u_new << t;
+            const unsigned isdel = c == up + 1 ? 1u : 0u;
+            const unsigned u_new = x ? isdel : u_above;
+            const unsigned z_new = x ? (isdel ? a_above_new : a_row_old) : z_above;
+            ax_new |= a_new << t; ux_new |= u_new << t; zx_new |= z_new << t;
+            a_above = a_row_old; a_above_new = a_new;
+            u_above = (s.ax >> (8 + t)) & 1u; z_above = (s.ax >> (16 + t)) & 1u;
             up_prev = cprev; up = c;
             s.cx[t] = c;
         }
-        if (SUBS) s.ax = ax_new | (zx_new << 8) | (ux_new << 16);
+        if (SUBS) s.ax = ax_new | (ux_new << 8) | (zx_new << 16);
         s.cm = s.cx[X - 1];
         clean = ((ax_new >> (X - 1)) & 1u) == 0;
         del = ((ux_new >> (X - 1)) & 1u) != 0;
+        pred_unclean = ((zx_new >> (X - 1)) & 1u) != 0;
     }
-    if (__builtin_expect(s.cm <= p.kacc, 0)) return bs_book<SUBS>(s, clean, j, p, del);
+    if (__builtin_expect(s.cm <= p.kacc, 0)) return bs_book<SUBS>(s, clean, j, p, del, pred_unclean);
     return false;
 }
 
@@ -313,21 +331,22 @@ CAH_HD bool bs_may_stop(const BackScanBook& s, const int j, const int n, const i
 // (the cost scan itself started there).  Outputs: o0/o1 = (row i, -) for EXACT_TAIL, (first DP column,
 // last DP column * 2 + scan flag) for DP.
 // row_cost(i): the absolute cost of row i of the last column, asked for i = 1, 2, .., m in this order.
-template <bool INDEL1, class ThrLast, class RowCost>
+// row_clean(i): the diagonal that ends in (i, n) has met no unclean cell (only asked when it starts inside the window).
+template <bool INDEL1, class ThrLast, class RowCost, class RowClean>
 CAH_HD int bs_finish_rows(const BackScanBook& s, const int n, const int j0, const BackScanParams& p,
-                          ThrLast thr_last, int& o0, int& o1, const bool stopped, RowCost row_cost) {
+                          ThrLast thr_last, int& o0, int& o1, const bool stopped, RowCost row_cost, RowClean row_clean) {
     o0 = 0; o1 = 0;
     const int reach = p.m + p.k + 1;
     // one insertion / one deletion (see the header); INDEL1 = false: the form does not keep the bits
-    const bool indel1 = INDEL1 && s.cmin == 1 && !s.eclean && s.je - p.m - 1 >= j0 &&
+    const bool indel1 = INDEL1 && s.cmin >= 1 && !s.eclean && !s.epred_unclean && s.je - p.m - 1 >= j0 &&
                         s.je + 1 - s.jfa <= p.half_m - p.kacc && !(s.edel && s.emore);
-    const int indel1_score = p.m - (s.edel ? 3 : 2);
+    const int indel1_score = p.m - 2 * s.cmin - (s.edel ? 1 : 0);
     if (stopped) {                   // jfa >= 0
         if (s.cmin >= 1 && s.eclean && s.je - p.m >= j0 && s.je - s.jfa <= p.half_m - p.kacc) {
             o0 = s.je; o1 = s.cmin;
             return BS_SUBS_FULL;
         }
-        if (indel1) { o0 = s.je; o1 = s.edel ? 1 : 0; return BS_INDEL1_FULL; }
+        if (indel1) { o0 = s.je; o1 = s.cmin * 2 + (s.edel ? 1 : 0); return BS_INDEL1_FULL; }
         const int s0 = s.jfa - reach;
         o0 = s0 > j0 ? s0 : j0;
         o1 = s.jla * 2;
@@ -335,23 +354,29 @@ CAH_HD int bs_finish_rows(const BackScanBook& s, const int n, const int j0, cons
     }
     // absolute costs of the last column, rows 1..m (row 0 costs 0); the largest acceptable row
     int best_i = 0;
-    int i0 = 0;                      // the largest acceptable row that costs 0
-    bool above_ok = true;            // every acceptable row above i0 scores less than i0 and cannot shift the origin clause
+    int w_row = 0, w_cost = 0, w_score = -(1 << 20);   // the clean acceptable row of the highest score (largest on ties)
+    int unclean_bound = -(1 << 20);   // the most an acceptable row with an unclean diagonal can score
+    bool clause_ok = true;            // the origin clause holds whenever an acceptable row with errors is the best
     bool tail_may_win = false;       // an acceptable row of the last column that could outscore m - 2 * cmin
     bool tail_may_win1 = false;      // ... the score of the one-indel alignment
     for (int i = 1; i <= p.m; ++i) {
         const int c = row_cost(i);
         if (i >= p.min_overlap && c <= thr_last(i)) {
             best_i = i;
-            if (c == 0) { i0 = i; above_ok = true; }
-            else if (!(i - 2 * c < i0 && p.k + 1 + c <= p.half_m)) above_ok = false;
-            if (i - 2 * c > p.m - 2 * s.cmin) tail_may_win = true;
-            if (i - 2 * c > indel1_score) tail_may_win1 = true;
+            const int sc = i - 2 * c;
+            if (c == 0 || (n - i >= j0 && row_clean(i))) {
+                if (sc >= w_score) { w_score = sc; w_row = i; w_cost = c; }
+            } else if (sc > unclean_bound) {
+                unclean_bound = sc;
+            }
+            if (c > 0 && p.k + 1 + c > p.half_m) clause_ok = false;
+            if (sc > p.m - 2 * s.cmin) tail_may_win = true;
+            if (sc > indel1_score) tail_may_win1 = true;
         }
     }
     if (s.jfa < 0) {
         if (best_i == 0) return BS_NONE;
-        if (i0 > 0 && above_ok) { o0 = i0; return BS_EXACT_TAIL; }
+        if (w_row > 0 && unclean_bound < w_score && clause_ok) { o0 = w_row; o1 = w_cost; return BS_EXACT_TAIL; }
         const int s0 = n - reach;
         o0 = s0 > j0 ? s0 : j0;
         o1 = n * 2 + 1;
@@ -362,14 +387,15 @@ CAH_HD int bs_finish_rows(const BackScanBook& s, const int n, const int j0, cons
         o0 = s.je; o1 = s.cmin;
         return BS_SUBS_FULL;
     }
-    if (indel1 && !tail_may_win1) { o0 = s.je; o1 = s.edel ? 1 : 0; return BS_INDEL1_FULL; }
+    if (indel1 && !tail_may_win1) { o0 = s.je; o1 = s.cmin * 2 + (s.edel ? 1 : 0); return BS_INDEL1_FULL; }
     const int s0 = s.jfa - reach;
     o0 = s0 > j0 ? s0 : j0;
     o1 = best_i == 0 ? s.jla * 2 : n * 2 + 1;
     return BS_DP;
 }
 
-template <class ThrLast>
+// TRACKED: the scan ran with SUBS (the accumulator A means something)
+template <bool TRACKED = true, class ThrLast>
 CAH_HD int bs_finish(const BackScanState& s, const int n, const int j0, const BackScanParams& p,
                      ThrLast thr_last, int& o0, int& o1, const bool stopped = false) {
     const int pad = 64 - p.m;
@@ -379,19 +405,23 @@ CAH_HD int bs_finish(const BackScanState& s, const int n, const int j0, const Ba
         c += (int)(vp & 1ull) - (int)(vn & 1ull);
         vp >>= 1; vn >>= 1;
         return c;
-    });
+    }, [&](int i) { return TRACKED && ((s.A >> (pad + i - 1)) & 1ull) == 0; });
 }
 
-template <int X, class ThrLast>
+template <int X, bool TRACKED = true, class ThrLast>
 CAH_HD int bs32_finish(const BackScanState32<X>& s, const int n, const int j0, const BackScanParams& p,
                        ThrLast thr_last, int& o0, int& o1, const bool stopped = false) {
     const int pad = X > 0 ? 0 : 32 - p.m;
     uint32_t vp = s.VP >> pad, vn = s.VN >> pad;
     int c = 0;
-    return bs_finish_rows<true>(s, n, j0, p, thr_last, o0, o1, stopped, [&](int i) {
+    return bs_finish_rows<TRACKED>(s, n, j0, p, thr_last, o0, o1, stopped, [&](int i) {
         if (X > 0 && i > 32) return s.cx[i - 33 < X ? i - 33 : 0];
         c += (int)(vp & 1u) - (int)(vn & 1u);
         vp >>= 1; vn >>= 1;
         return c;
+    }, [&](int i) {
+        if (!TRACKED) return false;
+        if (X > 0 && i > 32) return ((s.ax >> (i - 33)) & 1u) == 0;
+        return ((s.A >> (pad + i - 1)) & 1u) == 0;
     });
 }

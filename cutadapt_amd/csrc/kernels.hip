@@ -1975,8 +1975,8 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_back_
 
             int o0 = 0, o1 = 0;
             int cls;
-            if constexpr (KIND == 0) cls = bs_finish(st, n, j0, p, [&](int i) { return s_thr_last[i]; }, o0, o1, stopped);
-            else cls = bs32_finish<XR>(st, n, j0, p, [&](int i) { return s_thr_last[i]; }, o0, o1, stopped);
+            if constexpr (KIND == 0) cls = bs_finish<!MULTI>(st, n, j0, p, [&](int i) { return s_thr_last[i]; }, o0, o1, stopped);
+            else cls = bs32_finish<XR, !MULTI>(st, n, j0, p, [&](int i) { return s_thr_last[i]; }, o0, o1, stopped);
             if (exact) { cls = BS_EXACT_FULL; o0 = exact_j; }
             if (retry) { cls = BS_NONE; valid_out = false; }
             if (MULTI) {
@@ -1984,7 +1984,7 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_back_
                 // with one atomic max on the read's best key
                 if (valid && !invalid) {
                     if (cls == BS_EXACT_FULL) atomicMax(a.best_key + r, pack_best(p.m, 0, (int)adapter, p.m, o0 - p.m, o0));
-                    else if (cls == BS_EXACT_TAIL) atomicMax(a.best_key + r, pack_best(o0, 0, (int)adapter, o0, n - o0, n));
+                    else if (cls == BS_EXACT_TAIL) atomicMax(a.best_key + r, pack_best(o0 - 2 * o1, o1, (int)adapter, o0, n - o0, n));
                     else if (cls == BS_SUBS_FULL) atomicMax(a.best_key + r, pack_best(p.m - 2 * o1, o1, (int)adapter, p.m, o0 - p.m, o0));
                 }
             } else if (valid_out) {
@@ -1994,15 +1994,15 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_back_
                 } else if (cls == BS_EXACT_FULL) {
                     store_result(a.out6, a.status, a.best_adapter, a.adapter_index, a.merge_best, r, false, true,
                                  0, p.m, o0 - p.m, o0, p.m, 0);
-                } else if (cls == BS_EXACT_TAIL) {
+                } else if (cls == BS_EXACT_TAIL) {         // row o0 of the last column with o1 substitutions
                     store_result(a.out6, a.status, a.best_adapter, a.adapter_index, a.merge_best, r, false, true,
-                                 0, o0, n - o0, n, o0, 0);
+                                 0, o0, n - o0, n, o0 - 2 * o1, o1);
                 } else if (cls == BS_SUBS_FULL) {
                     store_result(a.out6, a.status, a.best_adapter, a.adapter_index, a.merge_best, r, false, true,
                                  0, p.m, o0 - p.m, o0, p.m - 2 * o1, o1);
-                } else if (cls == BS_INDEL1_FULL) {        // one deletion (o1 = 1) / one insertion (o1 = 0)
+                } else if (cls == BS_INDEL1_FULL) {        // o1 = cost * 2 + (1: one deletion, 0: one insertion)
                     store_result(a.out6, a.status, a.best_adapter, a.adapter_index, a.merge_best, r, false, true,
-                                 0, p.m, o0 - p.m + (o1 ? 1 : -1), o0, p.m - (o1 ? 3 : 2), 1);
+                                 0, p.m, o0 - p.m + ((o1 & 1) ? 1 : -1), o0, p.m - 2 * (o1 >> 1) - (o1 & 1), o1 >> 1);
                 }
             }
             const bool to_dp = valid_out && !invalid && cls == BS_DP;
@@ -2301,7 +2301,7 @@ __global__ __launch_bounds__(64) void k_tiny(TinyArgs a) {
         else if (cls == BS_EXACT_FULL)
             store_result(a.out6, a.status, nullptr, 0, 0, r, false, true, 0, p.m, o0 - p.m, o0, p.m, 0);
         else if (cls == BS_EXACT_TAIL)
-            store_result(a.out6, a.status, nullptr, 0, 0, r, false, true, 0, o0, n - o0, n, o0, 0);
+            store_result(a.out6, a.status, nullptr, 0, 0, r, false, true, 0, o0, n - o0, n, o0 - 2 * o1, o1);
         else if (cls == BS_SUBS_FULL)
             store_result(a.out6, a.status, nullptr, 0, 0, r, false, true, 0, p.m, o0 - p.m, o0, p.m - 2 * o1, o1);
         else

@@ -154,11 +154,12 @@ int bm_locate_batch(const void* matcher_blob, const uint8_t* seqs, const int64_t
         if (cls == BS_EXACT_FULL) {
             o[0] = 0; o[1] = p.m; o[2] = o0 - p.m; o[3] = o0; o[4] = p.m; o[5] = 0; status[r] = 1;
         } else if (cls == BS_EXACT_TAIL) {
-            o[0] = 0; o[1] = o0; o[2] = n - o0; o[3] = n; o[4] = o0; o[5] = 0; status[r] = 1;
+            o[0] = 0; o[1] = o0; o[2] = n - o0; o[3] = n; o[4] = o0 - 2 * o1; o[5] = o1; status[r] = 1;
         } else if (cls == BS_SUBS_FULL) {
             o[0] = 0; o[1] = p.m; o[2] = o0 - p.m; o[3] = o0; o[4] = p.m - 2 * o1; o[5] = o1; status[r] = 1;
         } else if (cls == BS_INDEL1_FULL) {
-            o[0] = 0; o[1] = p.m; o[2] = o0 - p.m + (o1 ? 1 : -1); o[3] = o0; o[4] = p.m - (o1 ? 3 : 2); o[5] = 1; status[r] = 1;
+            o[0] = 0; o[1] = p.m; o[2] = o0 - p.m + ((o1 & 1) ? 1 : -1); o[3] = o0; o[4] = p.m - 2 * (o1 >> 1) - (o1 & 1);
+            o[5] = o1 >> 1; status[r] = 1;
         } else if (cls == BS_DP) {
             int t6[6];
             if (dp_window(mt, q, n, o0, std::min(n, o1 >> 1), (o1 & 1) != 0, t6)) {

@@ -342,7 +342,7 @@ def test_word_forms(model):
 
 
 def test_one_indel_class(model):
-    """INDEL1_FULL (the adapter with one insertion or one deletion, 32-bit forms): every position of the edit --
+    """INDEL1_FULL (the adapter with one insertion or one deletion and, possibly, substitutions; 32-bit forms): every position of the edit --
     inside runs of equal characters, at the adapter's ends --, adapters of every kind (random, low-complexity,
     two-letter: where a mismatch path, a deletion path and an insertion path can cost the same), a second copy
     or a partial copy behind it, further substitutions (the DP's case).  Either the reference's tuple or the DP."""
@@ -371,8 +371,10 @@ def test_one_indel_class(model):
                 del ad[pos]
             else:
                 ad.insert(pos, str(rng.choice(alpha)))
-            if rng.random() < 0.2:
+            for _e in range(int(rng.choice([0, 0, 1, 1, 2]))):           # + substitutions: still one indel
                 ad[int(rng.integers(0, len(ad)))] = str(rng.choice(alpha))
+            if rng.random() < 0.1:                                       # a second indel: the DP's case
+                del ad[int(rng.integers(0, len(ad)))]
             head = "".join(rng.choice(alpha, size=int(rng.integers(0, 60))))
             tail = "".join(rng.choice(alpha, size=int(rng.integers(0, 60)))) if rng.random() < 0.7 else ""
             if rng.random() < 0.15:
@@ -387,3 +389,47 @@ def test_one_indel_class(model):
             if counts is not None and len(counts) > 5:
                 indel1 += int(counts[5])
     assert indel1 > 30000, indel1
+
+
+def test_tails_with_substitutions(model):
+    """EXACT_TAIL generalised: the read ends with adapter[0:i] carrying substitutions (rows of the last column with
+    clean diagonals have exact scores), next to rows reached by insertions / deletions (bounds only), behind
+    shifted or partial copies; adapters of every kind and length (all forms)."""
+    rng = np.random.default_rng(66)
+    tails = 0
+    for it in range(150):
+        m = int(rng.choice([6, 10, 16, 20, 25, 31, 32, 33, 34, 40, 50, 64]))
+        kind = it % 3
+        if kind == 0:
+            adapter = "".join(rng.choice(list("ACGT"), size=m))
+        elif kind == 1:
+            unit = "".join(rng.choice(list("ACGT"), size=int(rng.integers(1, 4))))
+            adapter = (unit * 70)[:m]
+        else:
+            adapter = "".join(rng.choice(list("AC"), size=m))
+        rate = float(rng.choice([0.1, 0.1, 0.15, 0.2, 0.3]))
+        alpha = list("ACGT") if kind != 2 else list("ACCA")
+        reads = []
+        for _ in range(500):
+            i = int(rng.integers(1, m + 1))
+            end = list(adapter[:i])
+            for _e in range(int(rng.choice([0, 1, 1, 2, 3]))):
+                end[int(rng.integers(0, len(end)))] = str(rng.choice(alpha))
+            u = rng.random()
+            if u < 0.15 and len(end) > 1:
+                del end[int(rng.integers(0, len(end)))]
+            elif u < 0.3:
+                end.insert(int(rng.integers(0, len(end) + 1)), str(rng.choice(alpha)))
+            front = ""
+            if rng.random() < 0.4:
+                s0 = int(rng.integers(0, 4))
+                front = adapter[s0:s0 + int(rng.integers(0, m))]
+            body = "".join(rng.choice(alpha, size=int(rng.integers(0, 80))))
+            reads.append(body + front + "".join(end))
+        seqs, offsets = orc.pack_reads(reads)
+        for skip in (False, True):
+            counts = compare(model, adapter, rate, int(rng.choice([1, 3, 5])), seqs, offsets, skip=skip,
+                             label=f"tails {it} m {m} skip {skip}")
+            if counts is not None:
+                tails += int(counts[2])
+    assert tails > 40000, tails
