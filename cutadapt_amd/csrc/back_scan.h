@@ -142,20 +142,20 @@ struct BackScanState : BackScanBook {
 
 // The 32-bit form of the same scan (half the instructions of the 64-bit form on a 32-bit ALU):
 //   X == 0  adapters of at most 32 characters: the adapter in the top m bits of a 32-bit word, pad rows below;
-//   X >= 1  adapters of 32 + X characters (X = 1, 2 -- e.g. the 33-character TruSeq adapter): rows 1..32 as a 32-bit
-//           word without pad rows, rows 33.. as plain integers.  Row r > 32 of column j follows the textbook
-//           recurrence C(r, j) = min(C(r-1, j-1) + [characters differ], C(r-1, j) + 1, C(r, j-1) + 1) from the row
-//           above (row 32: tracked through its horizontal deltas, like cm in the 64-bit form); its diagonal bit
-//           D0 = [C(r, j) == C(r-1, j-1)] feeds the clean-diagonal accumulator exactly like a word bit.
+//   X >= 1  adapters of 32 + X characters (X = 1, 2 -- e.g. the 33-character TruSeq adapter): the FIRST X rows as
+//           plain integers -- row 1 of a "search" column costs 0 where the characters match and 1 where they do not,
+//           row r <= X follows the textbook recurrence from the row above -- and rows X+1..m as a 32-bit word without
+//           pad rows whose top boundary is row X instead of the constant row 0: Myers' / Hyyro's block step with a
+//           horizontal input delta hin = C(X, j) - C(X, j-1) (hin < 0 sets bit 0 of Eq inside Xh and shifts a one
+//           into HN, hin > 0 into HP).  Row m is the word's top bit, as in the X == 0 form.  The diagonal
+//           accumulators (A, U, Z) take row X's bits of the last column where the 64-bit form shifts in zeros.
 template <int X>
 struct BackScanState32 : BackScanBook {
     uint32_t VP, VN, A;
     uint32_t U, Z;                 // ONE_INDEL, of each diagonal's lowest unclean cell: U = it is left upwards (a
                                    // deletion), Z = the diagonal of the cell it is left to is unclean too
-                                   // X > 0: the same for rows 33 + t live in ax: bit 8 + t (U), bit 16 + t (Z)
-    int cv;                        // X > 0: C(32, j)
-    int cx[X > 0 ? X : 1];         // X > 0: C(33 + t, j)
-    unsigned ax;                   // X > 0: bit t = the accumulator bit of row 33 + t
+    int cx[X > 0 ? X : 1];         // X > 0: C(1 + t, j), the explicit rows
+    unsigned ax;                   // X > 0: their diagonal bits: bit t = A, bit 8 + t = U, bit 16 + t = Z of row 1 + t
 };
 
 CAH_HD uint64_t bs_shl1(uint64_t x) {
@@ -228,10 +228,11 @@ CAH_HD bool bs_step(BackScanState& s, const uint64_t eq, const int j, const Back
 CAH_HD int bs_kind_of(const int m) { return m <= 32 ? 1 : (m <= 34 ? m - 31 : 0); }
 
 // the two table words of a character from its 64-bit match word (adapter in the top m bits, pad rows below):
-// eq32 = rows 1..32 (X > 0) or the top 32 bits (X == 0), eqx = rows 33.. in bits 0..
+// eq32 = rows X+1..m (X > 0) or the top 32 bits (X == 0), eqx = rows 1..X in bits 0..
 CAH_HD uint64_t bs32_table_entry(const uint64_t sm, const int m) {
     if (m <= 32) return sm >> 32;
-    const uint32_t lo = (uint32_t)(sm >> (64 - m)), hi = (uint32_t)(sm >> (96 - m));
+    const int x = m - 32;                                          // explicit rows 1..x sit in bits 64-m .. 64-m+x-1
+    const uint32_t lo = (uint32_t)(sm >> (64 - m + x)), hi = (uint32_t)(sm >> (64 - m)) & ((1u << x) - 1u);
     return ((uint64_t)hi << 32) | lo;
 }
 
@@ -240,8 +241,7 @@ CAH_HD void bs32_init(BackScanState32<X>& s, const BackScanParams& p) {
     const int pad = X > 0 ? 0 : 32 - p.m;
     s.VP = pad == 0 ? ~0u : ~((1u << pad) - 1u);
     s.VN = 0; s.A = 0; s.ax = 0;
-    s.cv = 32;
-    for (int t = 0; t < (X > 0 ? X : 1); ++t) s.cx[t] = 33 + t;
+    for (int t = 0; t < (X > 0 ? X : 1); ++t) s.cx[t] = 1 + t;
     s.cm = p.m;
     s.jfa = -1; s.jla = -1;
     s.cmin = 1 << 20; s.je = -1; s.eclean = false; s.edel = false; s.epred_unclean = true; s.emore = false;
@@ -250,39 +250,19 @@ CAH_HD void bs32_init(BackScanState32<X>& s, const BackScanParams& p) {
 
 template <bool SUBS, int X>
 CAH_HD bool bs32_step(BackScanState32<X>& s, const uint32_t eq, const uint32_t eqx, const int j, const BackScanParams& p) {
-    const uint32_t VP = s.VP, VN = s.VN;
-    const uint32_t Xv = eq | VN;
-    const uint32_t Xh = (((eq & VP) + VP) ^ VP) | eq;
-    const uint32_t HP = VN | ~(Xh | VP);
-    const uint32_t HN = VP & Xh;
-    const int dtop = (int)(HP >> 31) - (int)(HN >> 31);           // horizontal delta of the word's top row
-    const uint32_t HPs = HP << 1, HNs = HN << 1;
-    s.VP = HNs | ~(Xv | HPs);
-    s.VN = HPs & Xv;
-    const uint32_t a_old = s.A, u_old = s.U, z_old = s.Z;
-    if (SUBS) {
-        const uint32_t Xc = (Xh | VN) & ~eq;                       // unclean cells: diagonal delta 0, characters differ
-        s.A = (a_old << 1) | Xc;
-        // ONE_INDEL: at an unclean cell the reference leaves the diagonal -- upwards (deletion) iff the vertical
-        // delta is +1 (new VP); the accumulator bit of the cell it comes from: above in this column / left in the last
-        s.U = ((u_old << 1) & ~Xc) | (s.VP & Xc);
-        const uint32_t pa = (s.VP & (s.A << 1)) | (~s.VP & a_old);
-        s.Z = ((z_old << 1) & ~Xc) | (pa & Xc);
-    }
-    bool clean, del = false, pred_unclean = false;
-    if (X == 0) {
-        s.cm += dtop;
-        clean = (s.A >> 31) == 0;
-        del = (s.U >> 31) != 0;
-        pred_unclean = (s.Z >> 31) != 0;
-    } else {
-        int up_prev = s.cv;                                        // C(r-1, j-1)
-        s.cv += dtop;
-        int up = s.cv;                                             // C(r-1, j)
-        unsigned a_above = a_old >> 31;                            // accumulator bit of row r-1 in column j-1
-        unsigned a_above_new = s.A >> 31;                          // ... in column j
-        unsigned u_above = u_old >> 31, z_above = z_old >> 31;     // row r-1, column j-1
+    // ---- the explicit rows 1..X and what they hand to the word: hin, and the bits that enter its diagonals
+    uint32_t hpos = 0, hneg = 0, a_in = 0, u_in = 0, z_in = 0, a_top_new = 0;
+    if (X == 1) {
+        // row 1: C(1, j) = [characters differ] (row 0 costs 0 everywhere); a differing cell there has diagonal
+        // delta +1 -- never unclean -- so nothing but the horizontal delta enters the word
+        const uint32_t neq = ~eqx & 1u, prev = (uint32_t)s.cx[0];
+        hpos = neq & ~prev; hneg = prev & ~neq;
+        s.cx[0] = (int)neq;
+    } else if (X > 0) {
+        int up_prev = 0, up = 0;                                   // C(r-1, j-1), C(r-1, j): row 0 costs 0
+        unsigned a_above = 0, a_above_new = 0, u_above = 0, z_above = 0;   // row r-1: column j-1 / column j
         unsigned ax_new = 0, ux_new = 0, zx_new = 0;
+        const int c_last_old = s.cx[X - 1];
         for (int t = 0; t < X; ++t) {
             const int neq = (int)(~(eqx >> t) & 1u);
             const int cprev = s.cx[t];                             // C(r, j-1)
@@ -290,24 +270,45 @@ CAH_HD bool bs32_step(BackScanState32<X>& s, const uint32_t eq, const uint32_t e
             if (up + 1 < c) c = up + 1;
             if (cprev + 1 < c) c = cprev + 1;
             const unsigned x = (c == up_prev && neq) ? 1u : 0u;    // diagonal delta 0 although the characters differ
-            const unsigned a_row_old = (s.ax >> t) & 1u;           // this row, column j-1
+            const unsigned a_row_old = (s.ax >> t) & 1u, u_row_old = (s.ax >> (8 + t)) & 1u, z_row_old = (s.ax >> (16 + t)) & 1u;
             const unsigned a_new = a_above | x;
             const unsigned isdel = c == up + 1 ? 1u : 0u;
             const unsigned u_new = x ? isdel : u_above;
             const unsigned z_new = x ? (isdel ? a_above_new : a_row_old) : z_above;
             ax_new |= a_new << t; ux_new |= u_new << t; zx_new |= z_new << t;
-            a_above = a_row_old; a_above_new = a_new;
-            u_above = (s.ax >> (8 + t)) & 1u; z_above = (s.ax >> (16 + t)) & 1u;
+            a_above = a_row_old; a_above_new = a_new; u_above = u_row_old; z_above = z_row_old;
             up_prev = cprev; up = c;
             s.cx[t] = c;
         }
+        // row X of the LAST column enters the word's diagonals; its horizontal delta is the word's input
+        a_in = a_above; u_in = u_above; z_in = z_above; a_top_new = a_above_new;
+        const int hin = s.cx[X - 1] - c_last_old;
+        hpos = hin > 0 ? 1u : 0u; hneg = hin < 0 ? 1u : 0u;
         if (SUBS) s.ax = ax_new | (ux_new << 8) | (zx_new << 16);
-        s.cm = s.cx[X - 1];
-        clean = ((ax_new >> (X - 1)) & 1u) == 0;
-        del = ((ux_new >> (X - 1)) & 1u) != 0;
-        pred_unclean = ((zx_new >> (X - 1)) & 1u) != 0;
     }
-    if (__builtin_expect(s.cm <= p.kacc, 0)) return bs_book<SUBS>(s, clean, j, p, del, pred_unclean);
+    // ---- the word
+    const uint32_t VP = s.VP, VN = s.VN;
+    const uint32_t Xv = eq | VN;
+    const uint32_t eqm = eq | hneg;
+    const uint32_t Xh = (((eqm & VP) + VP) ^ VP) | eqm;
+    const uint32_t HP = VN | ~(Xh | VP);
+    const uint32_t HN = VP & Xh;
+    s.cm += (int)(HP >> 31) - (int)(HN >> 31);                     // row m is the top bit
+    const uint32_t HPs = (HP << 1) | hpos, HNs = (HN << 1) | hneg;
+    s.VP = HNs | ~(Xv | HPs);
+    s.VN = HPs & Xv;
+    if (SUBS) {
+        const uint32_t a_old = s.A;
+        const uint32_t Xc = (Xh | VN) & ~eq;                       // unclean cells: diagonal delta 0, characters differ
+        s.A = ((a_old << 1) | a_in) | Xc;
+        // ONE_INDEL: at an unclean cell the reference leaves the diagonal -- upwards (deletion) iff the vertical
+        // delta is +1 (new VP); the accumulator bit of the cell it comes from: above in this column / left in the last
+        s.U = (((s.U << 1) | u_in) & ~Xc) | (s.VP & Xc);
+        const uint32_t pa = (s.VP & ((s.A << 1) | a_top_new)) | (~s.VP & a_old);
+        s.Z = (((s.Z << 1) | z_in) & ~Xc) | (pa & Xc);
+    }
+    if (__builtin_expect(s.cm <= p.kacc, 0))
+        return bs_book<SUBS>(s, (s.A >> 31) == 0, j, p, (s.U >> 31) != 0, (s.Z >> 31) != 0);
     return false;
 }
 
@@ -413,15 +414,15 @@ CAH_HD int bs32_finish(const BackScanState32<X>& s, const int n, const int j0, c
                        ThrLast thr_last, int& o0, int& o1, const bool stopped = false) {
     const int pad = X > 0 ? 0 : 32 - p.m;
     uint32_t vp = s.VP >> pad, vn = s.VN >> pad;
-    int c = 0;
+    int c = X > 0 ? s.cx[X - 1] : 0;
     return bs_finish_rows<TRACKED>(s, n, j0, p, thr_last, o0, o1, stopped, [&](int i) {
-        if (X > 0 && i > 32) return s.cx[i - 33 < X ? i - 33 : 0];
+        if (X > 0 && i <= X) return s.cx[i - 1 < X ? i - 1 : 0];
         c += (int)(vp & 1u) - (int)(vn & 1u);
         vp >>= 1; vn >>= 1;
         return c;
     }, [&](int i) {
         if (!TRACKED) return false;
-        if (X > 0 && i > 32) return ((s.ax >> (i - 33)) & 1u) == 0;
-        return ((s.A >> (pad + i - 1)) & 1u) == 0;
+        if (X > 0 && i <= X) return ((s.ax >> (i - 1)) & 1u) == 0;
+        return ((s.A >> (pad + i - X - 1)) & 1u) == 0;
     });
 }
