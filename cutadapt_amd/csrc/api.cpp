@@ -1181,7 +1181,7 @@ static int run_filter(const cah_plan* plan, const PlanDeviceCopy* pd, int32_t ad
                       uint8_t* d_present, uint8_t* d_status, int32_t* d_queue,
                       unsigned long long* d_queue_count, uint8_t* d_queue_keys,
                       unsigned long long* d_work_counter, const unsigned long long* d_batch_flag, hipStream_t s,
-                      int32_t* d_clear_out6 = nullptr) {
+                      int32_t* d_clear_out6 = nullptr, int32_t* d_clear_best = nullptr) {
     const CahMatcher& mt = plan->matchers[(size_t)adapter];
     if (mt.n_words > 1024)
         return fail(CAH_EUNSUPPORTED, "adapter %d: %d packed k-mer words exceed the 1024-word limit of the prefilter kernel",
@@ -1198,6 +1198,7 @@ static int run_filter(const cah_plan* plan, const PlanDeviceCopy* pd, int32_t ad
     f.lean = nullptr;
     f.stream_n_lo = 0; f.stream_n_hi = -1;
     f.clear_out6 = mode == 1 ? d_clear_out6 : nullptr;
+    f.clear_best = f.clear_out6 ? d_clear_best : nullptr;
     if (!t_header_fresh) {
         HIP_TRY(hipMemsetAsync(d_work_counter, 0, sizeof(unsigned long long), s));
         if (d_queue_count) HIP_TRY(hipMemsetAsync(d_queue_count, 0, sizeof(unsigned long long), s));
@@ -1353,7 +1354,7 @@ int cah_match_batch(const cah_plan* plan, const uint8_t* d_seqs, const int64_t* 
     if (!t_outputs_ready) {
         HIP_TRY(hipMemsetAsync(d_status, 0, (size_t)n_reads, s));
         if (!filter_clears) HIP_TRY(hipMemsetAsync(d_out6, 0, sizeof(int32_t) * 6 * (size_t)n_reads, s));
-        if (d_best_adapter) HIP_TRY(launch_init_best(d_best_adapter, n_reads, pd->n_cus, s));
+        if (d_best_adapter && !filter_clears) HIP_TRY(launch_init_best(d_best_adapter, n_reads, pd->n_cus, s));
     }
     // tiny single-adapter batches: one memset for all counters, no batch check (the ragged prefilter serves them)
     const bool tiny = n_reads <= CAH_TINY_BATCH && plan->matchers.size() == 1;
@@ -1384,7 +1385,8 @@ int cah_match_batch(const cah_plan* plan, const uint8_t* d_seqs, const int64_t* 
             // prefilter -> queue of surviving reads -> (cost scan ->) DP on dense waves
             rc = run_filter(plan, pd, ad, d_seqs, d_offsets, d_lens, n_reads, 1, nullptr, d_status, ws.queue,
                             counters + WS_QCOUNT, ws.keys, counters + 0, d_batch_flag, s,
-                            (filter_clears && ad == first_aligner) ? d_out6 : nullptr);
+                            (filter_clears && ad == first_aligner) ? d_out6 : nullptr,
+                            (filter_clears && ad == first_aligner) ? d_best_adapter : nullptr);
             if (rc) return rc;
             rc = run_aligner(plan, pd, ad, d_seqs, d_offsets, d_lens, n_reads, ws.queue, counters + WS_QCOUNT,
                              ws.keys, ws, d_out6, d_status, d_best_adapter, 1, s);

@@ -27,6 +27,7 @@ struct FilterArgs {
     const CahLeanFilter* lean;       // k_filter_lean / k_filter_stream only
     int32_t stream_n_lo, stream_n_hi;   // equally long reads of these lengths are k_filter_stream's (an instance
                                         // takes its own range, the per-lane uniform kernel leaves the union alone)
+    int32_t* clear_best;             // with clear_out6, may be NULL: best_adapter[r] = -1 for the same reads
     int32_t* clear_out6;             // MODE 1, may be NULL: the result rows (6 x int32 per read) of every read the
                                      // kernel looks at are zeroed on the way (rows of reads that match are written
                                      // later, by the scan / DP kernels) -- saves the caller a memset of 24 B per read

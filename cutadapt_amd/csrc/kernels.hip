@@ -133,7 +133,8 @@ __device__ __forceinline__ void filter_word_chunk(const Chunk& ck, const T* tbl,
 // the VALU work per character and word.
 // Zero the result rows (24 bytes each) of the `cnt` (<= 64, wave-uniform) consecutive reads from `base` on: the
 // rows are contiguous, every store instruction of the wave writes 512 contiguous bytes.
-__device__ __forceinline__ void clear_rows(int32_t* out6, const int64_t base, const int cnt, const int lane) {
+__device__ __forceinline__ void clear_rows(int32_t* out6, int32_t* best, const int64_t base, const int cnt, const int lane) {
+    if (best && lane < cnt) best[base + lane] = -1;
     int32_t* const o = out6 + base * 6;
     if ((reinterpret_cast<uintptr_t>(o) & 7u) == 0) {
         typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(256, CAH_FILTER_WAVES) void k_filter(FilterArgs a) 
             const int64_t r = base + lane;
             const bool valid = r < a.n_reads;
             if (MODE == 1 && a.clear_out6)
-                clear_rows(a.clear_out6, base, (int)(a.n_reads - base < WAVE ? a.n_reads - base : WAVE), lane);
+                clear_rows(a.clear_out6, a.clear_best, base, (int)(a.n_reads - base < WAVE ? a.n_reads - base : WAVE), lane);
             int64_t off = 0, n64 = 0;
             if (valid) read_extent(a.offsets, a.lens, r, off, n64);
             const uint8_t* q = a.seqs + off;
@@ -806,7 +807,7 @@ __global__ __launch_bounds__(256, LEAN_WAVES) void k_filter_lean(FilterArgs a) {
             Chunk nxt = load_chunk(q, 16, n, valid ? n : 0);
             // (behind the first loads: waiting for those does not wait for these stores)
             if (a.clear_out6 && !a.present)
-                clear_rows(a.clear_out6, base, (int)(a.n_reads - base < WAVE ? a.n_reads - base : WAVE), lane);
+                clear_rows(a.clear_out6, a.clear_best, base, (int)(a.n_reads - base < WAVE ? a.n_reads - base : WAVE), lane);
             {
                 unsigned ad[8];
                 lean_addr8<LeanLayout<DL, NL, NG>::LEAD_SHIFT>(ad, cur.w[0], cur.w[1]);
@@ -1037,7 +1038,7 @@ __global__ __launch_bounds__(STREAM_BLOCK_WAVES * WAVE, STREAM_WAVES) void k_fil
             // (in front of the next piece's loads: stores and loads share the in-order vmcnt counter, and the next
             // wait for loads is a whole piece of matching work away -- the stores are long finished by then)
             if (a.clear_out6 && !a.present && base < a.n_reads)
-                clear_rows(a.clear_out6, base, (int)(a.n_reads - base < WAVE ? a.n_reads - base : WAVE), lane);
+                clear_rows(a.clear_out6, a.clear_best, base, (int)(a.n_reads - base < WAVE ? a.n_reads - base : WAVE), lane);
             prefetch(piece_base(it + 1));
             if (base >= a.n_reads) continue;                            // wave-uniform; nothing left in this tile
             const int64_t r = base + lane;
