@@ -234,3 +234,46 @@ def test_stream_copy_plan_division_is_exact():
         for u in range(64 * 16):
             r = (u * magic) >> 16
             assert r == u // U and u * magic < 2 ** 32, (U, u)
+
+
+def test_prefilter_of_anchored_exact_adapters_is_dropped_only_when_implied():
+    """CahMatcher::filter_implied (cah_plan_create): the prefilter of an anchored adapter that tolerates no error is
+    skipped only if an unedited occurrence of the adapter at its anchored place passes it -- decided against the
+    plan's own k-mer sets, windows and character tables, not assumed from how cutadapt builds them."""
+    import ctypes as C
+    import struct
+    from cutadapt_amd import _lib
+    from cutadapt_amd import adapters as A
+
+    def implied(plan):
+        L = _lib.lib()
+        need = C.c_size_t(0)
+        _lib.check(L.cah_plan_debug_matcher(plan.handle, 0, None, 0, C.byref(need)))
+        buf = (C.c_uint8 * need.value)()
+        _lib.check(L.cah_plan_debug_matcher(plan.handle, 0, buf, need.value, C.byref(need)))
+        return struct.unpack_from("<i", bytes(buf), need.value - 8)[0]
+
+    PREFIX, SUFFIX, BACK = 8, 2, 14
+    # what the adapter classes build
+    assert implied(A.PrefixAdapter("NNNNNNNNACGTACGT", max_errors=0.1)._fused_plan) == 1
+    assert implied(A.SuffixAdapter("ACGTACGTAC", max_errors=0.05)._fused_plan) == 1
+    assert implied(A.PrefixAdapter("ACGTACGTACGTACGTACGT", max_errors=0.1)._fused_plan) == 1    # (implied, but k = 2: the DP stays)
+    assert implied(A.BackAdapter("ACGTACGTACGT")._fused_plan) == 0                               # not anchored
+
+    def plan(seq, flags, sets, wr=False, kwr=False):
+        return _lib.Plan([_lib.MatcherSpec(seq, 0.0, flags, wr, False, 1, len(seq), kmer_sets=sets, kmer_ref_wildcards=kwr)])
+
+    assert implied(plan("ACGTACGT", PREFIX, [(0, None, ["TTTT"])])) == 0          # not a piece of the adapter
+    assert implied(plan("ACGTACGT", PREFIX, [(0, None, ["GTAC"])])) == 1
+    assert implied(plan("ACGTACGT", PREFIX, [(4, 12, ["ACGT"])])) == 1           # the copy at 4 lies inside [4, 12)
+    assert implied(plan("ACGTACGT", PREFIX, [(5, 12, ["ACGT"])])) == 0           # no copy starts at >= 5
+    assert implied(plan("ACGTACGT", PREFIX, [(0, 7, ["TACGT"])])) == 0           # the copy ends at 8 > stop
+    assert implied(plan("ACGTACGT", SUFFIX, [(-4, None, ["ACGT"])])) == 1        # last four characters
+    assert implied(plan("ACGTACGT", SUFFIX, [(-3, None, ["ACGT"])])) == 0
+    assert implied(plan("ACGTACGT", SUFFIX, [(0, 8, ["ACGT"])])) == 0            # a head window says nothing about the read end
+    assert implied(plan("ACGTACGT", BACK, [(0, None, ["ACGT"])])) == 0
+    # the aligner accepts ANY byte at an N of the adapter (NUL included), a k-mer table never matches NUL
+    # (_match_tables.py:73-78) and, without adapter wildcards, only 'N' itself: a k-mer across the N proves nothing
+    assert implied(plan("ACGNACGT", PREFIX, [(0, None, ["CGNA"])], wr=True, kwr=False)) == 0
+    assert implied(plan("ACGNACGT", PREFIX, [(0, None, ["CGNA"])], wr=True, kwr=True)) == 0
+    assert implied(plan("ACGNACGT", PREFIX, [(0, None, ["ACGT"])], wr=True, kwr=True)) == 1      # the piece behind the N does
