@@ -367,7 +367,7 @@ typedef const __attribute__((address_space(4))) uint32_t* cah_const_u32;
 template <int NL, int NG>
 struct LeanWords {
     int n_tail, tail_span, head_span;
-    uint32_t l_init[NL], l_init2[NL], l_found[NL], g_found[NG];     // l_init2 = (l_init << 1) | l_init
+    uint32_t l_init[NL], l_init4[NL], l_found[NL], g_found[NG];     // l_init4 = S(3): start bits of the last four positions
     int g_open[NG];              // equally long reads: the 8-character group from which gated word g has work (a tail word's
                                  // start bits stay closed until gated_span characters are left; its state is 0 until then)
     const unsigned char* s_lead;                                 // LDS: lead table(s), then gated table (LeanLayout)
@@ -381,15 +381,18 @@ struct LeanWords {
 // read is flagged invalid and its matches are never used.
 __host__ __device__ constexpr int lean_pow2(int n) { return n <= 1 ? 1 : (n <= 2 ? 2 : (n <= 4 ? 4 : 8)); }
 __host__ __device__ constexpr int lean_log2(int p) { return p == 1 ? 0 : (p == 2 ? 1 : (p == 4 ? 2 : 3)); }
-// DL > 0 (delay bits, see lean_lead8): the lead words advance TWO characters per step,
-//   R2 = ((R << 2) | I2) & M1[c1] & M[c2],   I2 = (START << 1) | START,   M1[c] = (M[c] << 1) | START
-// (two single steps R' = ((R << 1) | START) & M[c] written out: (x & a) | s == (x | s) & (a | s)), so the lead
-// table comes twice: M1 for the first character of a pair, M for the second.
+// DL > 0 (delay bits, see lean_lead8): the lead words advance FOUR characters per step,
+//   R4 = ((R << 4) | S3) & T3[c1] & T2[c2] & T1[c3] & T0[c4],   Ts[c] = (M[c] << s) | S(s-1),
+//   S(k) = START | START << 1 | .. | START << k
+// (four single steps R' = ((R << 1) | START) & M[c] written out: (x & a) | s == (x | s) & (a | s), and an OR
+// distributes over the ANDs), so the lead table comes four times, one per position inside a group of four.  The
+// bits a shift carries across a k-mer's field border land on the next field's lowest s bits, which S(s-1) sets
+// anyway (every field is at least 1 + DL = 4 bits long).
 template <int DL, int NL, int NG> struct LeanLayout {
     static constexpr int NLP = lean_pow2(NL), NGP = lean_pow2(NG);
     static constexpr int LEAD_SHIFT = 2 + lean_log2(NLP), GATED_SHIFT = 2 + lean_log2(NGP);
     static constexpr int LEAD_TABLE = CAH_TABLE_CHARS * NLP * 4;                 // bytes of one lead table
-    static constexpr int LEAD_BYTES = LEAD_TABLE * (DL > 0 ? 2 : 1);             // M, then M1
+    static constexpr int LEAD_BYTES = LEAD_TABLE * (DL > 0 ? 4 : 1);             // T0 = M, T1, T2, T3
     static constexpr int GATED_BYTES = CAH_TABLE_CHARS * NGP * 4;
     static constexpr int WORDS = (LEAD_BYTES + GATED_BYTES) / 4;                 // uint32 words of all tables
 };
@@ -405,7 +408,10 @@ __device__ __forceinline__ void lean_tables_to_lds(const CahLeanFilter* lf, uint
             if (w < NL && w < lf->n_lead) {
                 // the delay bits of a lead word pass EVERY byte (a k-mer end must survive until its group is checked)
                 v = lf->lead_mask[w][c] | lf->lead_pass[w];
-                if (i >= LW) v = (v << 1) | lf->lead_init[w];                    // M1
+                const int sh = i / LW;                                           // table Ts
+                uint32_t fill = 0;
+                for (int b = 0; b < sh; ++b) fill |= lf->lead_init[w] << b;      // S(s-1)
+                v = (v << sh) | fill;
             }
         } else {
             const int j = i - LY::LEAD_BYTES / 4;
@@ -428,7 +434,7 @@ __device__ __forceinline__ void lean_words_init(LeanWords<NL, NG>& L, const CahL
 #pragma unroll
     for (int w = 0; w < NL; ++w) {
         L.l_init[w] = w < lf->n_lead ? lf->lead_init[w] : 0u;
-        L.l_init2[w] = (L.l_init[w] << 1) | L.l_init[w];
+        L.l_init4[w] = L.l_init[w] | (L.l_init[w] << 1) | (L.l_init[w] << 2) | (L.l_init[w] << 3);
         L.l_found[w] = w < lf->n_lead ? lf->lead_found[w] : 0u;
     }
 #pragma unroll
@@ -483,7 +489,7 @@ __device__ __forceinline__ void lean_issue_lead(const LeanWords<NL, NG>& L, uint
     typedef LeanLayout<DL, NL, NG> LY;
 #pragma unroll
     for (int t = 0; t < 8; ++t)                                  // DL > 0: the first character of a pair reads M1
-        lean_read_entry<NL, LY::NLP>(mk[t], L.s_lead + ((DL > 0 && (t & 1) == 0) ? LY::LEAD_TABLE : 0) + ad[t]);
+        lean_read_entry<NL, LY::NLP>(mk[t], L.s_lead + (DL > 0 ? (3 - (t & 3)) * LY::LEAD_TABLE : 0) + ad[t]);
 }
 
 // Eight characters of the lead words; f4 / f8: found bits seen up to the 4th / 8th of them.
@@ -494,17 +500,15 @@ template <int DL, int NL, int NG>
 __device__ __forceinline__ void lean_lead8(const LeanWords<NL, NG>& L, LeanState<NL, NG>& S, const uint32_t (&mk)[8][NL],
                                            uint32_t& f4, uint32_t& f8) {
     if constexpr (DL > 0) {
-        // two characters per step (see LeanLayout); the state is looked at after every 4-character group
+        // four characters per step (see LeanLayout); the state is looked at after every one
 #pragma unroll
-        for (int t = 0; t < 8; t += 2) {
+        for (int l = 0; l < NL; ++l)
+            S.RL[l] = ((S.RL[l] << 4) | L.l_init4[l]) & mk[0][l] & mk[1][l] & mk[2][l] & mk[3][l];
 #pragma unroll
-            for (int l = 0; l < NL; ++l)
-                S.RL[l] = ((S.RL[l] << 2) | L.l_init2[l]) & mk[t][l] & mk[t + 1][l];
-            if (t == 2) {
+        for (int l = 0; l < NL; ++l) f4 |= S.RL[l] & L.l_found[l];
 #pragma unroll
-                for (int l = 0; l < NL; ++l) f4 |= S.RL[l] & L.l_found[l];
-            }
-        }
+        for (int l = 0; l < NL; ++l)
+            S.RL[l] = ((S.RL[l] << 4) | L.l_init4[l]) & mk[4][l] & mk[5][l] & mk[6][l] & mk[7][l];
 #pragma unroll
         for (int l = 0; l < NL; ++l) f8 |= S.RL[l] & L.l_found[l];
     } else {
@@ -876,7 +880,9 @@ __global__ __launch_bounds__(256, LEAN_WAVES) void k_filter_lean(FilterArgs a) {
 #define STREAM_WAVES 3             // waves per SIMD
 // reads per block tile (survivor staging: 3 B each; a multiple of 64 * 12); the classes with six gated words have
 // larger mask and gate tables and take a smaller tile to stay inside the CU's 160 KiB
-__host__ __device__ constexpr int stream_tile(int ng) { return ng <= 3 ? 6144 : 4608; }
+// reads per tile (a multiple of 12 waves x 64): what the 160 KB of LDS leave for the survivor staging behind the
+// read slots and the tables of the class (four lead tables since the lead words take four characters per step)
+__host__ __device__ constexpr int stream_tile(int nl, int ng) { return ng <= 3 ? 6144 : (nl <= 2 ? 4608 : 3840); }
 __host__ __device__ constexpr int stream_piece_bytes(int nu) { return WAVE * nu * 16; }
 __host__ __device__ constexpr int stream_max_len(int um) { return um * 16; }
 
@@ -897,7 +903,8 @@ __global__ __launch_bounds__(STREAM_BLOCK_WAVES * WAVE, STREAM_WAVES) void k_fil
     uint32_t* const s_gate = s_lds.gate;
     unsigned char* const s_piece = s_lds.piece;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int TILE = stream_tile(NG), SUBS = TILE / WAVE / STREAM_BLOCK_WAVES;
+    constexpr int TILE = stream_tile(NL, NG), SUBS = TILE / WAVE / STREAM_BLOCK_WAVES;
+    static_assert(sizeof(StreamLds) + (size_t)TILE * 3 + CAH_QUEUE_BINS * 8 + 64 <= 160 * 1024, "k_filter_stream: LDS");
     if (a.batch_flag ? *a.batch_flag != 0ull : false) return;           // ragged batch: k_filter_lean<false, ..>
     const CahLeanFilter* lf = a.lean;
     const int64_t first = a.offsets[0];
@@ -2487,9 +2494,9 @@ hipError_t launch_filter_lean(const FilterArgs& a_in, int mode, int n_lead, int 
     const bool stream = a.batch_flag != nullptr && getenv_flag("CAH_NO_STREAM") == 0;
 #define CAH_STREAM_LAUNCH(DL, NL, NG, NU, UM, LO)                                                                   \
     do {                                                                                                            \
-        const int tiles = (int)((a.n_reads + stream_tile(NG) - 1) / stream_tile(NG));                               \
+        const int tiles = (int)((a.n_reads + stream_tile(NL, NG) - 1) / stream_tile(NL, NG));                       \
         const int sgrid = std::max(1, std::min(tiles, n_cus));                                                      \
-        const size_t slds = (size_t)stream_tile(NG) * 3 + CAH_QUEUE_BINS * 8 + 64;                                  \
+        const size_t slds = (size_t)stream_tile(NL, NG) * 3 + CAH_QUEUE_BINS * 8 + 64;                              \
         FilterArgs b = a;                                                                                           \
         b.stream_n_lo = (LO); b.stream_n_hi = stream_max_len(UM);                                                   \
         hipLaunchKernelGGL((k_filter_stream<DL, NL, NG, NU, UM>), dim3(sgrid), dim3(STREAM_BLOCK_WAVES * WAVE), slds, s, b); \
