@@ -401,24 +401,26 @@ template <int DL, int NL, int NG>
 __device__ __forceinline__ void lean_tables_to_lds(const CahLeanFilter* lf, uint32_t* s_tab) {
     typedef LeanLayout<DL, NL, NG> LY;
     constexpr int LW = CAH_TABLE_CHARS * LY::NLP;                                // words of one lead table
-    for (int i = threadIdx.x; i < LY::WORDS; i += blockDim.x) {
-        uint32_t v = 0;
-        if (i < LY::LEAD_BYTES / 4) {
-            const int j = i % LW, c = j / LY::NLP, w = j % LY::NLP;
-            if (w < NL && w < lf->n_lead) {
-                // the delay bits of a lead word pass EVERY byte (a k-mer end must survive until its group is checked)
-                v = lf->lead_mask[w][c] | lf->lead_pass[w];
-                const int sh = i / LW;                                           // table Ts
-                uint32_t fill = 0;
-                for (int b = 0; b < sh; ++b) fill |= lf->lead_init[w] << b;      // S(s-1)
-                v = (v << sh) | fill;
-            }
-        } else {
-            const int j = i - LY::LEAD_BYTES / 4;
-            const int c = j / LY::NGP, w = j % LY::NGP;
-            if (w < NG && w < lf->n_gated) v = lf->gated_mask[w][c];
+    constexpr int NT = DL > 0 ? 4 : 1;                                           // lead tables T0 .. T3
+    // one pass over the base masks writes all shifted copies (the one-read kernel fills the tables per call)
+    for (int j = threadIdx.x; j < LW; j += blockDim.x) {
+        const int c = j / LY::NLP, w = j % LY::NLP;
+        uint32_t v = 0, init = 0;
+        if (w < NL && w < lf->n_lead) {
+            // the delay bits of a lead word pass EVERY byte (a k-mer end must survive until its group is checked)
+            v = lf->lead_mask[w][c] | lf->lead_pass[w];
+            init = lf->lead_init[w];
         }
-        s_tab[i] = v;
+        uint32_t fill = 0;
+#pragma unroll
+        for (int sh = 0; sh < NT; ++sh) {
+            s_tab[sh * LW + j] = (w < NL && w < lf->n_lead) ? ((v << sh) | fill) : 0u;   // Ts = (M << s) | S(s-1)
+            fill |= init << sh;
+        }
+    }
+    for (int j = threadIdx.x; j < LY::GATED_BYTES / 4; j += blockDim.x) {
+        const int c = j / LY::NGP, w = j % LY::NGP;
+        s_tab[LY::LEAD_BYTES / 4 + j] = (w < NG && w < lf->n_gated) ? lf->gated_mask[w][c] : 0u;
     }
 }
 
