@@ -177,6 +177,8 @@ struct PlanDeviceCopy {
     uint64_t* d_mscan = nullptr;          // [n_adapters][CAH_MULTI_TAB_STRIDE] padded match words (cost scan)
     uint64_t* d_mrow = nullptr;           // ... row bitsets (cell DP)
     std::vector<LongDeviceCopy> d_long;   // one per matcher (null pointers for bare k-mer finders)
+    // the one-read kernel's table images ([0]: Aligner.locate, no prefilter; [1]: match_to), built by its first call
+    void* d_tiny_image[2] = {nullptr, nullptr};
 };
 
 // host tables of the fused multi-adapter path (see CahMultiHeader)
@@ -822,6 +824,8 @@ void cah_plan_destroy(cah_plan* plan) {
         if (dc.d_mbitmap) (void)hipFree(dc.d_mbitmap);
         if (dc.d_mscan) (void)hipFree(dc.d_mscan);
         if (dc.d_mrow) (void)hipFree(dc.d_mrow);
+        if (dc.d_tiny_image[0]) (void)hipFree(dc.d_tiny_image[0]);
+        if (dc.d_tiny_image[1]) (void)hipFree(dc.d_tiny_image[1]);
         for (LongDeviceCopy& ld : dc.d_long) {
             if (ld.d_lm) (void)hipFree(ld.d_lm);
             if (ld.d_ref) (void)hipFree(ld.d_ref);
@@ -1535,6 +1539,24 @@ static int host_call_one(int mode, const cah_plan* plan, const uint8_t* seq, int
         };
         t_ticket = t_ticket >= 0x7ffffff0 ? 1 : t_ticket + 1;
         ta.done = d_done; ta.ticket = t_ticket;
+        // the kernel's LDS tables come as one image from HBM; the plan's first call (per device and mode) leaves it there
+        {
+            int device = 0;
+            HIP_TRY(hipGetDevice(&device));
+            std::lock_guard<std::mutex> lk(plan->mu);
+            PlanDeviceCopy& dc = plan->dev[device];
+            void*& img = dc.d_tiny_image[filter ? 1 : 0];
+            if (!img) {
+                void* fresh = nullptr;
+                HIP_TRY(hipMalloc(&fresh, CAH_TINY_IMAGE_BYTES));
+                TinyArgs tb = ta;
+                tb.image = nullptr; tb.image_out = fresh;
+                HIP_TRY(launch_tiny(tb, filter ? lf.n_lead : 1, filter ? lf.n_gated : 1, filter ? lf.lead_delay : 0, hs.stream));
+                HIP_TRY(hipStreamSynchronize(hs.stream));
+                img = fresh;
+            }
+            ta.image = img; ta.image_out = nullptr;
+        }
         HIP_TRY(launch_tiny(ta, filter ? lf.n_lead : 1, filter ? lf.n_gated : 1, filter ? lf.lead_delay : 0, hs.stream));
         if ((rc = wait_ticket(t_ticket))) return rc;
         if (*h_need > 0) {

@@ -141,7 +141,10 @@ struct TinyArgs {
     int32_t* need_dp;                // out: number of reads on that list
     int32_t* done;                   // out (mapped host memory): set to `ticket` when everything above is written
     int32_t ticket;
+    const void* image;               // NULL, or the kernel's LDS tables as a former call with image_out left them
+    void* image_out;                 // non-NULL: build the tables from lean / matcher, write them here, return
 };
+#define CAH_TINY_IMAGE_BYTES (20 * 1024)   // upper bound of the table image of any k_tiny class
 hipError_t launch_tiny(const TinyArgs& a, int n_lead, int n_gated, int delay, hipStream_t s);
 hipError_t launch_ticket(int32_t* done, int32_t ticket, hipStream_t s);
 hipError_t launch_filter_lean(const FilterArgs& a, int mode, int n_lead, int n_gated, int delay, int n_cus, hipStream_t s);

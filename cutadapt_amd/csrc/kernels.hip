@@ -2146,20 +2146,45 @@ __global__ void k_ticket(int32_t* done, int32_t ticket) {
 #define TINY_STAGE_BYTES 4096
 template <int DL, int NL, int NG>
 __global__ __launch_bounds__(64) void k_tiny(TinyArgs a) {
-    __shared__ __attribute__((aligned(16))) uint32_t s_tab[LeanLayout<DL, NL, NG>::WORDS];
-    __shared__ uint32_t s_gate[NG * CAH_GATE_LEN];
-    __shared__ __attribute__((aligned(16))) uint64_t s_scanmask[CAH_TABLE_CHARS];
-    __shared__ int s_thr_last[CAH_MAX_M + 1];
+    // every table the kernel reads, as ONE block: a call copies it from the image the first call of the plan left in
+    // HBM (a.image; 16 bytes per lane and load) instead of deriving it from the plan's structures again
+    struct __attribute__((aligned(16))) TinyTables {
+        uint32_t tab[LeanLayout<DL, NL, NG>::WORDS];
+        uint32_t gate[NG * CAH_GATE_LEN];
+        uint64_t scanmask[CAH_TABLE_CHARS];
+        int thr_last[CAH_MAX_M + 4];
+    };
+    static_assert(sizeof(TinyTables) % 16 == 0 && sizeof(TinyTables) <= CAH_TINY_IMAGE_BYTES, "k_tiny: table image");
+    __shared__ TinyTables s_t;
+    uint32_t* const s_tab = s_t.tab;
+    uint32_t* const s_gate = s_t.gate;
+    uint64_t* const s_scanmask = s_t.scanmask;
+    int* const s_thr_last = s_t.thr_last;
     const CahMatcher* mt = a.matcher;
     const CahLeanFilter* lf = a.lean;
-    if (lf) {
-        lean_tables_to_lds<DL, NL, NG>(lf, s_tab);
-        for (int i = threadIdx.x; i < NG * CAH_GATE_LEN; i += blockDim.x)
-            s_gate[i] = lf->gate_init[i / CAH_GATE_LEN][i % CAH_GATE_LEN];
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    if (a.image) {
+        const u32x4* src = reinterpret_cast<const u32x4*>(a.image);
+        u32x4* dst = reinterpret_cast<u32x4*>(&s_t);
+        for (int i = threadIdx.x; i < (int)(sizeof(TinyTables) / 16); i += blockDim.x) dst[i] = src[i];
+    } else {
+        if (lf) {
+            lean_tables_to_lds<DL, NL, NG>(lf, s_tab);
+            for (int i = threadIdx.x; i < NG * CAH_GATE_LEN; i += blockDim.x)
+                s_gate[i] = lf->gate_init[i / CAH_GATE_LEN][i % CAH_GATE_LEN];
+        } else {
+            for (int i = threadIdx.x; i < (int)(LeanLayout<DL, NL, NG>::WORDS + NG * CAH_GATE_LEN); i += blockDim.x) s_tab[i] = 0;
+        }
+        for (int i = threadIdx.x; i < CAH_TABLE_CHARS; i += blockDim.x) s_scanmask[i] = mt->scanmask[i];
+        for (int i = threadIdx.x; i < CAH_MAX_M + 4; i += blockDim.x) s_thr_last[i] = i <= CAH_MAX_M ? mt->thr_last[i] : 0;
     }
-    for (int i = threadIdx.x; i < CAH_TABLE_CHARS; i += blockDim.x) s_scanmask[i] = mt->scanmask[i];
-    for (int i = threadIdx.x; i <= CAH_MAX_M; i += blockDim.x) s_thr_last[i] = mt->thr_last[i];
     __syncthreads();
+    if (a.image_out) {                                           // the plan's first call: leave the image, nothing else
+        const u32x4* src = reinterpret_cast<const u32x4*>(&s_t);
+        u32x4* dst = reinterpret_cast<u32x4*>(a.image_out);
+        for (int i = threadIdx.x; i < (int)(sizeof(TinyTables) / 16); i += blockDim.x) dst[i] = src[i];
+        return;
+    }
     const int lane = wave_lane();
     const int64_t r = lane;
     const bool valid = r < a.n_reads;
