@@ -958,10 +958,12 @@ size_t cah_workspace_bytes(int64_t n_reads) {
 
 // ---- extra scratch of the fused multi-adapter path: [best key 8n] [pairs 8*cap] [DP list 4*cap] [windows 8*cap]
 // cap = pairs one chunk of reads can produce in the worst case (every adapter on every read), bounded by
-// CAH_MULTI_PAIR_CAP (default 256 M pairs = 5 GB of scratch); larger batches are processed in chunks of
+// CAH_MULTI_PAIR_CAP (default 1 G pairs = 20 GB of scratch on a 288 GB device: every chunk costs the cell DP a launch
+// whose duration is that of its slowest wave, ~0.45 ms, however few pairs it has -- at 256 M pairs a 100 M-read batch
+// of 96 adapters paid that 36 times, 16 of its 114 ms); larger batches are processed in chunks of
 // cap / n_adapters reads.
 static int64_t multi_pair_cap(const cah_plan* plan, int64_t n_reads) {
-    int64_t limit = 256ll << 20;
+    int64_t limit = 1024ll << 20;
     if (const char* e = getenv("CAH_MULTI_PAIR_CAP")) { const long long v = atoll(e); if (v > 0) limit = v; }
     const int64_t A = (int64_t)plan->matchers.size();
     if (limit < A) limit = A;
