@@ -422,21 +422,22 @@ class SingleAdapter(Adapter, ABC):
 
 
 def _reverse_batch(batch):
-    """Per-read reversed copy of a ReadBatch (device-side gather; Rightmost* adapters search the
-    reversed read with the reversed adapter, reference adapters.py:766, :870)."""
+    """Per-read reversed copy of a ReadBatch (``cah_reverse_reads_batch``: one pass on the device; Rightmost*
+    adapters search the reversed read with the reversed adapter, reference adapters.py:766, :870)."""
     import torch
-    from .batch import ReadBatch
+    from .batch import ReadBatch, _stream_ptr
     lens = batch.lengths()
     n = batch.n_reads
     new_offsets = torch.zeros(n + 1, dtype=torch.int64, device=batch.device)
     torch.cumsum(lens, 0, out=new_offsets[1:])
     total = int(new_offsets[-1].item()) if n else 0
-    if total == 0:
-        return ReadBatch(torch.zeros(0, dtype=torch.uint8, device=batch.device), new_offsets, validated=batch.validated)
-    read_of = torch.repeat_interleave(torch.arange(n, device=batch.device), lens)
-    pos = torch.arange(total, device=batch.device) - new_offsets[read_of]
-    src = batch.offsets[:n][read_of] + (lens[read_of] - 1 - pos)
-    return ReadBatch(batch.seqs[src], new_offsets, validated=batch.validated)
+    out = torch.empty(total, dtype=torch.uint8, device=batch.device)
+    if total:
+        with torch.cuda.device(batch.device):
+            _lib.check(_lib.lib().cah_reverse_reads_batch(
+                batch.seqs.data_ptr(), batch.offsets.data_ptr(), batch._lens_ptr(), n,
+                new_offsets.data_ptr(), out.data_ptr(), _stream_ptr()))
+    return ReadBatch(out, new_offsets, validated=batch.validated)
 
 
 class FrontAdapter(SingleAdapter):

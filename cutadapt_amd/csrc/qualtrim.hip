@@ -11,6 +11,7 @@
 #include <mutex>
 
 #include "../../include/cutadapt_hip.h"
+#include "dev_common.h"
 
 extern int cah_set_error_(int code, const char* msg);   // api.cpp
 
@@ -238,6 +239,34 @@ inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace
 
+
+// ---------------------------------------------------------------------------------------------
+// k_reverse_reads: every read reversed into a second packed buffer.  Rightmost* adapters search the reversed read
+// with the reversed adapter (reference adapters.py:766, :870: `sequence[::-1]`); one read per lane, 16 characters
+// per load (the chunk that ENDS where the last one began), byte-swapped in registers, one 16-byte store; the last
+// partial chunk byte by byte (a 16-byte store there would reach into the next read's slot).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_reverse_reads(const uint8_t* seqs, const int64_t* offsets, const int32_t* lens,
+                                                       int64_t n_reads, const int64_t* out_offsets, uint8_t* out) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    const int64_t off = offsets[r];
+    const int64_t n64 = lens ? (int64_t)lens[r] : offsets[r + 1] - off;
+    const int n = (int)(n64 > CAH_MAX_READ_LEN ? CAH_MAX_READ_LEN : n64);
+    const uint8_t* q = seqs + off;
+    uint8_t* o = out + out_offsets[r];
+    int done = 0;
+    for (; done + 16 <= n; done += 16) {
+        const int pos = n - done - 16;                           // input characters [pos, pos + 16)
+        const Chunk c = load_chunk(q, pos, n, pos + 16);
+        Unaligned16 u;
+        u.w[0] = __builtin_bswap32(c.w[3]); u.w[1] = __builtin_bswap32(c.w[2]);
+        u.w[2] = __builtin_bswap32(c.w[1]); u.w[3] = __builtin_bswap32(c.w[0]);
+        __builtin_memcpy(o + done, &u, 16);
+    }
+    for (int i = done; i < n; ++i) o[i] = q[n - 1 - i];
+}
+
 extern "C" {
 
 int cah_quality_trim_batch(const uint8_t* d_quals, const int64_t* d_offsets, const int32_t* d_lens, int64_t n_reads,
@@ -285,6 +314,21 @@ int cah_expected_errors_batch(const uint8_t* d_quals, const int64_t* d_offsets, 
     hipLaunchKernelGGL(k_expected_errors, dim3(blocks_for(n_reads)), dim3(256), 0, (hipStream_t)stream, d_quals, d_offsets,
                        d_lens, n_reads, base, tab, d_expected, d_status);
     QT_TRY(hipGetLastError());
+    return CAH_OK;
+}
+
+// Reversed copy of every read (see k_reverse_reads).  d_out_offsets: int64[n_reads] start of each read in d_out
+// (packed: the running sum of the lengths); all device pointers.
+int cah_reverse_reads_batch(const uint8_t* d_seqs, const int64_t* d_offsets, const int32_t* d_lens, int64_t n_reads,
+                            const int64_t* d_out_offsets, uint8_t* d_out, void* stream) {
+    if (n_reads < 0) return cah_set_error_(CAH_EINVAL, "n_reads < 0");
+    if (n_reads == 0) return CAH_OK;
+    if (!d_offsets || !d_out_offsets || !d_out) return cah_set_error_(CAH_EINVAL, "cah_reverse_reads_batch: NULL argument");
+    const int64_t blocks = (n_reads + 255) / 256;
+    hipLaunchKernelGGL(k_reverse_reads, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_seqs, d_offsets, d_lens,
+                       n_reads, d_out_offsets, d_out);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return cah_set_error_(CAH_EHIP, hipGetErrorString(e));
     return CAH_OK;
 }
 

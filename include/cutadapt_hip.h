@@ -353,6 +353,13 @@ int cah_index_lookup_batch_host(const cah_index *index, const uint8_t *seqs, con
                                 int64_t n_reads, int32_t *out6, int32_t *best_adapter,
                                 uint8_t *status);
 
+/* Reversed copy of every read of a packed batch: Rightmost* adapters search the REVERSED read with the reversed
+ * adapter (adapters.py:766 RightmostFrontAdapter.match_to, :870 RightmostBackAdapter: `sequence[::-1]`).
+ * d_lens as in cah_match_batch; d_out_offsets int64[n_reads]: where read r starts in d_out (for a packed copy the
+ * running sum of the lengths).  All device pointers, asynchronous on `stream`. */
+int cah_reverse_reads_batch(const uint8_t *d_seqs, const int64_t *d_offsets, const int32_t *d_lens,
+                            int64_t n_reads, const int64_t *d_out_offsets, uint8_t *d_out, void *stream);
+
 /* ---- quality / NextSeq / poly-A trimming, expected errors ------ */
 /* The O(n) per-read scans that run just before adapter matching (cli.py:938-954), for a batch
  * whose qualities are packed with the SAME offsets as the sequences.  All device pointers;

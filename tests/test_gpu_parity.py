@@ -696,3 +696,31 @@ def test_anchored_adapters_without_errors_vs_oracle(hip, orc):
         total += len(reads)
         found += int((want_st == 1).sum())
     assert total > 40000 and found > 8000, (total, found)
+
+
+def test_reverse_reads_kernel(hip):
+    """cah_reverse_reads_batch (what Rightmost* adapters search, reference adapters.py:766, :870): every length around
+    the 16-character chunks, empty reads, a view (explicit lengths into a longer buffer), a large ragged batch."""
+    import torch
+    from cutadapt_amd.adapters import _reverse_batch
+    from cutadapt_amd.batch import ReadBatch
+    rng = random.Random(31)
+    reads = [rs(rng, n, "ACGTN") for n in list(range(0, 70)) + [100, 150, 151, 255, 256, 257, 1000]]
+    reads += [rs(rng, rng.randint(0, 300), "ACGTacgtN") for _ in range(20000)]
+    batch = ReadBatch.from_strings(reads)
+    rev = _reverse_batch(batch)
+    seqs = rev.seqs.cpu().numpy().tobytes().decode()
+    offs = rev.offsets.cpu().numpy()
+    assert len(offs) == len(reads) + 1 and offs[-1] == sum(len(r) for r in reads)
+    for i, r in enumerate(reads):
+        assert seqs[offs[i]:offs[i + 1]] == r[::-1], (i, len(r))
+    # a view: the middle part of every read
+    lens = batch.lengths()
+    starts = torch.clamp(lens // 3, max=40).to(torch.int32)
+    view = batch.view(starts, lens - 2 * starts.to(torch.int64))
+    rv = _reverse_batch(view)
+    seqs = rv.seqs.cpu().numpy().tobytes().decode()
+    offs = rv.offsets.cpu().numpy()
+    for i, r in enumerate(reads[:3000]):
+        s0 = min(len(r) // 3, 40)
+        assert seqs[offs[i]:offs[i + 1]] == r[s0:len(r) - s0][::-1], (i, len(r))
