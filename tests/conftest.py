@@ -10,6 +10,22 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # CAH_TEST_SEED_OFFSET=<int>: soak runs -- every seeded generator of the tests (random.Random(seed),
+    # numpy.random.default_rng(seed)) gets its seed shifted, so the same tests draw other adapters and reads.
+    # (Tests that also assert how MANY cases of a kind they drew may then fail on that count; a parity failure
+    # says "differ".)
+    off = int(os.environ.get("CAH_TEST_SEED_OFFSET", "0") or 0)
+    if off:
+        import random
+        import numpy as np
+        base_random, base_rng = random.Random, np.random.default_rng
+
+        class ShiftedRandom(base_random):
+            def __init__(self, seed=None):
+                super().__init__(seed + off if isinstance(seed, int) else seed)
+
+        random.Random = ShiftedRandom
+        np.random.default_rng = lambda seed=None, *a, **k: base_rng(seed + off if isinstance(seed, int) else seed, *a, **k)
 
 
 @pytest.fixture(scope="session")
