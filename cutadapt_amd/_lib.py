@@ -16,14 +16,14 @@ CAH_OK, CAH_EINVAL, CAH_ETYPE, CAH_EHIP, CAH_ENOMEM, CAH_EUNSUPPORTED = 0, 1, 2,
 NONE, MATCH, INVALID = 0, 1, 2
 MAX_READ_LEN = 1000000        # CAH_MAX_READ_LEN of include/cutadapt_hip.h
 KIND_ALIGNER, KIND_PREFIX, KIND_SUFFIX, KIND_KMER_ONLY = 0, 1, 2, 3
-MAX_ADAPTER_LEN = 64
+ABI_VERSION = 2              # CAH_ABI_VERSION of include/cutadapt_hip.h this binding was written against
 PROF_FILTER, PROF_DP, PROF_COMPARER, PROF_SCAN, PROF_MERGE, PROF_N = 0, 1, 2, 3, 4, 5
 
 # every symbol include/cutadapt_hip.h declares (tests check the library exports them all)
 EXPORTED_SYMBOLS = [
     "cah_abi_version", "cah_last_error", "cah_device_count", "cah_set_device", "cah_device_info",
     "cah_plan_create", "cah_plan_destroy", "cah_plan_n_adapters", "cah_plan_effective_length",
-    "cah_plan_n_kmer_entries", "cah_plan_prefilter_kind", "cah_plan_debug_matcher", "cah_locate_batch", "cah_kmers_present_batch", "cah_match_batch",
+    "cah_plan_n_kmer_entries", "cah_plan_prefilter_kind", "cah_plan_debug_matcher", "cah_plan_debug_lean", "cah_locate_batch", "cah_kmers_present_batch", "cah_match_batch",
     "cah_workspace_bytes", "cah_plan_workspace_bytes", "cah_validate_ascii_batch", "cah_reverse_reads_batch", "cah_locate_batch_host",
     "cah_kmers_present_batch_host", "cah_match_batch_host", "cah_locate_debug_host", "cah_match_one_host", "cah_locate_one_host", "cah_profile_enable",
     "cah_profile_reset", "cah_profile_read", "cah_synth_reads",
@@ -41,7 +41,7 @@ class HipLibraryMissing(RuntimeError):
 
 
 class UnsupportedByHipPath(ValueError):
-    """Input outside the limits of this build (e.g. adapter longer than 64 characters)."""
+    """Input outside the limits of this build (e.g. a read longer than MAX_READ_LEN characters)."""
 
 
 class KmerSetC(C.Structure):
@@ -91,6 +91,9 @@ def lib():
     L = C.CDLL(LIB_PATH)
     vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
     L.cah_abi_version.restype = C.c_int
+    if L.cah_abi_version() != ABI_VERSION:
+        raise HipLibraryMissing(f"{LIB_PATH} has ABI version {L.cah_abi_version()}, this binding needs {ABI_VERSION}: "
+                                "rebuild it with `python -m cutadapt_amd.build --force`")
     L.cah_last_error.argtypes = [C.c_char_p, C.c_size_t]
     L.cah_last_error.restype = None
     L.cah_device_count.argtypes = [C.POINTER(C.c_int)]
@@ -105,6 +108,7 @@ def lib():
     L.cah_plan_n_kmer_entries.argtypes = [vp, i32, C.POINTER(i32)]
     L.cah_plan_prefilter_kind.argtypes = [vp, i32, C.POINTER(i32)]
     L.cah_plan_debug_matcher.argtypes = [vp, i32, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.cah_plan_debug_lean.argtypes = [vp, i32, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.cah_locate_batch.argtypes = [vp, i32, vp, vp, vp, i64, vp, vp, vp, C.c_size_t, vp]
     L.cah_kmers_present_batch.argtypes = [vp, i32, vp, vp, vp, i64, vp, vp]
     L.cah_match_batch.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp, vp, C.c_size_t, vp]

@@ -12,8 +12,8 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libcutadapt_hip.so")
-SOURCES = ["api.cpp", "kernels.hip", "multi.hip", "long.hip", "fastq_gpu.hip", "synth_kernel.hip", "fastq.cpp", "index.hip", "qualtrim.hip"]
-HEADERS = ["cah_device.h", "kernels.h", "back_scan.h", "dev_common.h", os.path.join("..", "..", "include", "cutadapt_hip.h")]
+SOURCES = ["api.cpp", "kernels.hip", "stream2.hip", "multi.hip", "long.hip", "fastq_gpu.hip", "synth_kernel.hip", "fastq.cpp", "index.hip", "qualtrim.hip"]
+HEADERS = ["cah_device.h", "kernels.h", "back_scan.h", "dev_common.h", "filter_common.h", "stream2.h", os.path.join("..", "..", "include", "cutadapt_hip.h")]
 ARCH = "gfx950"
 
 
@@ -39,19 +39,24 @@ def build_library(force: bool = False, verbose: bool = False, extra_flags=None, 
         return _build(extra_flags or [], out_path or LIB_PATH, verbose, tag="_" + str(abs(hash(tuple(extra_flags or []))) % 100000))
     if not force and not needs_build():
         return LIB_PATH
-    return _build([], LIB_PATH, verbose, tag="")
+    return _build([], LIB_PATH, verbose, tag="", force=force)
 
 
-def _build(extra_flags, lib_path, verbose, tag) -> str:
+def _build(extra_flags, lib_path, verbose, tag, force=False) -> str:
     objs = []
     obj_dir = os.path.join(_HERE, "csrc", "_obj" + tag)
     os.makedirs(obj_dir, exist_ok=True)
     procs = []
+    newest_header = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS if os.path.exists(os.path.join(CSRC, h)))
     for src in SOURCES:
         obj = os.path.join(obj_dir, src + ".o")
         objs.append(obj)
+        src_path = os.path.join(CSRC, src)
+        # an object is kept while it is newer than its source and every header (headers are not tracked per source)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src_path), newest_header):
+            continue
         cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-x", "hip"] + list(extra_flags) + \
-              ["-c", os.path.join(CSRC, src), "-o", obj]
+              ["-c", src_path, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

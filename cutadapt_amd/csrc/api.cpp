@@ -343,6 +343,41 @@ static void build_lean_filter(const cah_adapter_desc& d, CahLeanFilter& lf) {
     for (const Item& it : head) if (!place(it, 2)) return;
     lf.n_gated = w + 1;
     lf.ok = (lf.n_lead + lf.n_gated) >= 1 ? 1 : 0;
+    // T-words (k_filter_stream2): the tail k-mers packed like lead k-mers (delay bits, ungated start bits); the
+    // window becomes a condition on where a k-mer ENDS (tw_found, see CahLeanFilter).  Widest windows first, so
+    // that a word's first k-mer names the word's span and the spans fall from word to word.
+    if (lf.ok && head.empty() && (lf.n_lead == 0 || delay == CAH_LEAN_DELAY)) {
+        int tw = -1, tused = 32;
+        bool fits = true;
+        for (const Item& it : tail) {
+            const int bits = it.len + CAH_LEAN_DELAY;
+            if (bits > 32) { fits = false; break; }
+            if (tused + bits > 32) {
+                if (++tw >= CAH_LEAN_MAX_TW) { fits = false; break; }
+                tused = 0;
+                lf.tw_span[tw] = it.L;
+            }
+            const uint32_t start_bit = 1u << tused, end_bit = 1u << (tused + it.len - 1);
+            for (int p = 0; p < it.len; p++)
+                for (int qc = 0; qc < CAH_TABLE_CHARS; qc++)
+                    if (kmer_chars_match((uint8_t)it.kmer[p], (uint8_t)qc, rwc, qwc)) lf.tw_mask[tw][qc] |= 1u << (tused + p);
+            lf.tw_init[tw] |= start_bit;
+            for (int j = 1; j <= CAH_LEAN_DELAY; j++) lf.tw_pass[tw] |= end_bit << j;
+            // the k-mer ended at t - d (t: last character of the group, d: delay bit) = n - 1 - dist - d; it lies in
+            // its window iff 0 <= dist + d <= L - q
+            for (int dist = -CAH_TW_DIST0; dist + CAH_TW_DIST0 < CAH_TW_DIST_LEN; dist++)
+                for (int dd = 0; dd <= CAH_LEAN_DELAY; dd++)
+                    if (dist + dd >= 0 && dist + dd <= it.L - it.len) lf.tw_found[tw][dist + CAH_TW_DIST0] |= end_bit << dd;
+            tused += bits;
+        }
+        if (fits) { lf.n_tw = tw + 1; lf.tw_ok = 1; }
+        else {
+            lf.n_tw = 0;
+            memset(lf.tw_span, 0, sizeof(lf.tw_span)); memset(lf.tw_init, 0, sizeof(lf.tw_init));
+            memset(lf.tw_pass, 0, sizeof(lf.tw_pass)); memset(lf.tw_mask, 0, sizeof(lf.tw_mask));
+            memset(lf.tw_found, 0, sizeof(lf.tw_found));
+        }
+    }
 }
 
 #define CAH_LONG_ADAPTER_LIMIT 100000     // sanity bound for the HBM column of k_dp_long (3 x 4 B per row and lane)
@@ -872,6 +907,17 @@ int cah_plan_debug_matcher(const cah_plan* plan, int32_t adapter, void* buf, siz
     return CAH_OK;
 }
 
+int cah_plan_debug_lean(const cah_plan* plan, int32_t adapter, void* buf, size_t buflen, size_t* need) {
+    int rc = check_adapter(plan, adapter);
+    if (rc) return rc;
+    if (need) *need = sizeof(CahLeanFilter);
+    if (buf) {
+        if (buflen < sizeof(CahLeanFilter)) return fail(CAH_EINVAL, "buffer too small: need %zu bytes", sizeof(CahLeanFilter));
+        memcpy(buf, &plan->lean[(size_t)adapter], sizeof(CahLeanFilter));
+    }
+    return CAH_OK;
+}
+
 int cah_plan_n_kmer_entries(const cah_plan* plan, int32_t adapter, int32_t* out) {
     int rc = check_adapter(plan, adapter);
     if (rc) return rc;
@@ -1203,6 +1249,7 @@ static int run_filter(const cah_plan* plan, const PlanDeviceCopy* pd, int32_t ad
     f.batch_flag = nullptr;
     f.lean = nullptr;
     f.stream_n_lo = 0; f.stream_n_hi = -1;
+    f.uniform_first = 0; f.uniform_len = 0;
     f.clear_out6 = mode == 1 ? d_clear_out6 : nullptr;
     f.clear_best = f.clear_out6 ? d_clear_best : nullptr;
     if (!t_header_fresh) {
@@ -1216,8 +1263,8 @@ static int run_filter(const cah_plan* plan, const PlanDeviceCopy* pd, int32_t ad
         // sync; views (explicit lengths) and calls without a check take the ragged variant.
         f.batch_flag = d_lens ? nullptr : d_batch_flag;
         f.lean = pd->d_lean + adapter;
-        HIP_TRY(launch_filter_lean(f, mode, plan->lean[(size_t)adapter].n_lead, plan->lean[(size_t)adapter].n_gated,
-                                   plan->lean[(size_t)adapter].lead_delay, pd->n_cus, s));
+        const CahLeanFilter& lf = plan->lean[(size_t)adapter];
+        HIP_TRY(launch_filter_lean(f, mode, lf.n_lead, lf.n_gated, lf.lead_delay, lf.tw_ok, lf.n_tw, pd->n_cus, s));
         return CAH_OK;
     }
     HIP_TRY(launch_filter(f, mode, mt.narrow_words != 0, pd->n_cus, s));

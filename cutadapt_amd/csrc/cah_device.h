@@ -90,6 +90,9 @@ struct CahKmerWord {
 #define CAH_GATE_PAD 16                           // a 16-character chunk may begin this far before a window / end after it
 #define CAH_GATE_ZERO (CAH_LEAN_SPAN + CAH_GATE_PAD)     // tail words: index of distance 0 (one past the last character)
 #define CAH_GATE_LEN (CAH_LEAN_SPAN + 2 * CAH_GATE_PAD)  // entries per gate table
+#define CAH_LEAN_MAX_TW 4                         // T-words (tail k-mers with delay bits, found-gated; see tw_* below)
+#define CAH_TW_DIST0 3                            // tw_found index of dist = 0 (the group's last character is the read's last)
+#define CAH_TW_DIST_LEN (CAH_LEAN_SPAN + 24)      // dist = -3 .. CAH_LEAN_SPAN + 20: every group of a chunk that touches a window
 struct CahLeanFilter {
     int32_t ok;                                   // 1: this matcher can use the lean kernels
     int32_t n_lead, n_gated;                      // words in use
@@ -112,6 +115,20 @@ struct CahLeanFilter {
     // every set (-L, None) with L >= d.  Head word, idx = p: the start bits of every set (start, stop) with
     // start <= p <= stop - len.  Everything else is 0 (closed).
     uint32_t gate_init[CAH_LEAN_MAX_GATED][CAH_GATE_LEN];
+    // ---- T-words (k_filter_stream2, stream2.h): the tail k-mers once more, packed like lead k-mers -- every
+    // k-mer followed by CAH_LEAN_DELAY delay bits, start bits injected at EVERY position (no start gates) -- so
+    // that they take the same four-characters-per-step update as the lead words.  What a window restricts is
+    // then the END of a k-mer: a k-mer of length q of the set (-L, None) that ends at position e started at
+    // e - q + 1 >= n - L  <=>  (n - 1 - e) <= L - q.  The state is looked at after every 4-character group (last
+    // character t): delay bit d of a k-mer says "ended at t - d", so it counts iff dist + d <= L - q with
+    // dist = n - 1 - t.  tw_found[w][dist + CAH_TW_DIST0] holds exactly those bits (dist = -3 .. CAH_LEAN_SPAN).
+    int32_t tw_ok;                                // 1: lead words (with delay bits) + T-words describe this prefilter
+    int32_t n_tw;                                 // T-words in use (ordered by widest window, widest first)
+    int32_t tw_span[CAH_LEAN_MAX_TW];             // widest tail window of the word's k-mers
+    uint32_t tw_init[CAH_LEAN_MAX_TW];            // start bits
+    uint32_t tw_pass[CAH_LEAN_MAX_TW];            // delay bits: set in the mask of every byte value
+    uint32_t tw_mask[CAH_LEAN_MAX_TW][CAH_TABLE_CHARS];
+    uint32_t tw_found[CAH_LEAN_MAX_TW][CAH_TW_DIST_LEN];
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -27,6 +27,10 @@ struct FilterArgs {
     const CahLeanFilter* lean;       // k_filter_lean / k_filter_stream only
     int32_t stream_n_lo, stream_n_hi;   // equally long reads of these lengths are k_filter_stream's (an instance
                                         // takes its own range, the per-lane uniform kernel leaves the union alone)
+    // equally long reads the HOST knows about (cah_match_batch_uniform): read r is seqs[uniform_first + r * uniform_len
+    // ...) -- no offsets array is read, no batch check is needed.  uniform_len == 0: lengths come from offsets.
+    int64_t uniform_first;
+    int32_t uniform_len;
     int32_t* clear_best;             // with clear_out6, may be NULL: best_adapter[r] = -1 for the same reads
     int32_t* clear_out6;             // MODE 1, may be NULL: the result rows (6 x int32 per read) of every read the
                                      // kernel looks at are zeroed on the way (rows of reads that match are written
@@ -147,7 +151,12 @@ struct TinyArgs {
 #define CAH_TINY_IMAGE_BYTES (20 * 1024)   // upper bound of the table image of any k_tiny class
 hipError_t launch_tiny(const TinyArgs& a, int n_lead, int n_gated, int delay, hipStream_t s);
 hipError_t launch_ticket(int32_t* done, int32_t ticket, hipStream_t s);
-hipError_t launch_filter_lean(const FilterArgs& a, int mode, int n_lead, int n_gated, int delay, int n_cus, hipStream_t s);
+// tw_ok / n_tw: the plan's T-words (CahLeanFilter): equally long short reads then take k_filter_stream2 (stream2.hip)
+hipError_t launch_filter_lean(const FilterArgs& a, int mode, int n_lead, int n_gated, int delay, int tw_ok, int n_tw,
+                              int n_cus, hipStream_t s);
+hipError_t launch_filter_stream2(const FilterArgs& a, int mode, int n_lead, int n_tw, int n_cus, hipStream_t s);
+int stream2_max_len();
+bool stream2_class_ok(int n_lead, int n_tw);
 hipError_t launch_uniform_check(const int64_t* offsets, int64_t n_reads, int64_t max_read_len, unsigned long long* flag,
                                 int n_cus, hipStream_t s);
 hipError_t launch_filter(const FilterArgs& a, int mode, bool narrow_words, int n_cus, hipStream_t s);

@@ -24,6 +24,7 @@
 #include "kernels.h"
 #include "back_scan.h"
 #include "dev_common.h"
+#include "filter_common.h"
 
 #ifndef CAH_DEQUEUE
 #define CAH_DEQUEUE 8             // sub-batches of 64 work items a wave takes per atomic (k_dp, k_comparer, k_anchored_exact)
@@ -131,27 +132,6 @@ __device__ __forceinline__ void filter_word_chunk(const Chunk& ck, const T* tbl,
 // NARROW: every packed word of the plan fits 32 bits (cah_plan_create packs k-mers of <= 32
 // characters that way): shift-and state, accumulators and LDS tables are 32-bit, which halves
 // the VALU work per character and word.
-// Zero the result rows (24 bytes each) of the `cnt` (<= 64, wave-uniform) consecutive reads from `base` on: the
-// rows are contiguous, every store instruction of the wave writes 512 contiguous bytes.
-__device__ __forceinline__ void clear_rows(int32_t* out6, int32_t* best, const int64_t base, const int cnt, const int lane) {
-    if (best && lane < cnt) best[base + lane] = -1;
-    int32_t* const o = out6 + base * 6;
-    if ((reinterpret_cast<uintptr_t>(o) & 7u) == 0) {
-        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int u = lane + WAVE * k;                                  // 8-byte unit
-            if (u < cnt * 3) *reinterpret_cast<u32x2*>(o + 2 * u) = (u32x2)(0u);
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            const int u = lane + WAVE * k;
-            if (u < cnt * 6) o[u] = 0;
-        }
-    }
-}
-
 template <int MODE, bool LDS_TABLES, bool NARROW>
 __global__ __launch_bounds__(256, CAH_FILTER_WAVES) void k_filter(FilterArgs a) {
     typedef typename std::conditional<NARROW, uint32_t, uint64_t>::type word_t;
@@ -669,67 +649,6 @@ template <bool UNIFORM, int NL, int NG>
 __device__ __forceinline__ bool lean_chunk_ungated(const LeanWords<NL, NG>& L, int pos, int n) {
     const bool tail = L.tail_span > 0 && (UNIFORM ? pos + 16 > n - L.tail_span : __any(pos + 16 > n - L.tail_span));
     return !tail && pos >= L.head_span;
-}
-
-// The survivors of a tile, staged in LDS with their keys, leave as one key-ordered run: exclusive scan of the
-// 256-bin histogram (one thread per bin), one atomic for the run, counting sort into the global queue.
-// blockDim.x >= 256 == CAH_QUEUE_BINS (a multiple of 64).  s_scratch: 8 words.
-__device__ __forceinline__ void flush_tile_queue(const FilterArgs& a, int64_t tile_base, const uint16_t* s_idx,
-                                                 const uint8_t* s_key, unsigned* s_hist, unsigned* s_cursor,
-                                                 const unsigned count, unsigned* s_scratch,
-                                                 unsigned long long& s_qbase) {
-    const int lane = wave_lane(), wave = threadIdx.x >> 6;
-    const bool bin = threadIdx.x < CAH_QUEUE_BINS;
-    const unsigned c = bin ? s_hist[threadIdx.x] : 0u;
-    unsigned incl = c;
-#pragma unroll
-    for (int d = 1; d < WAVE; d <<= 1) {
-        const unsigned o = __shfl_up(incl, d, WAVE);
-        if (lane >= d) incl += o;
-    }
-    if (bin && lane == WAVE - 1) s_scratch[wave] = incl;
-    if (threadIdx.x == 0) s_qbase = count ? atomicAdd(a.queue_count, (unsigned long long)count) : 0ull;
-    __syncthreads();
-    if (bin) {
-        unsigned before = 0;
-#pragma unroll
-        for (int w = 0; w < 3; ++w) if (w < wave) before += s_scratch[w];
-        s_hist[threadIdx.x] = before + incl - c;
-    }
-    __syncthreads();
-    const unsigned long long qbase = s_qbase;
-    for (unsigned e = threadIdx.x; e < count; e += blockDim.x) {
-        const unsigned key = s_key[e];
-        const unsigned p = s_hist[key] + atomicAdd(&s_cursor[key], 1u);
-        a.queue[qbase + p] = (int32_t)(tile_base + s_idx[e]);
-        a.queue_keys[qbase + p] = (uint8_t)key;
-    }
-}
-
-// a read's verdict: present[] (mode 0: a.present is set) or a slot of the tile's survivor staging (mode 1)
-__device__ __forceinline__ void lean_emit(const FilterArgs& a, int64_t r, int64_t tile_base, bool valid, bool hit,
-                                          bool invalid, int hit_pos, uint16_t* s_idx, uint8_t* s_key,
-                                          unsigned* s_hist, unsigned& s_count) {
-    if (a.present) {
-        if (valid) a.present[r] = invalid ? (uint8_t)2 : (hit ? (uint8_t)1 : (uint8_t)0);
-    } else {
-        if (valid && invalid) a.status[r] = 2;
-        const bool push = valid && hit && !invalid;
-        const unsigned long long bal = __ballot(push);
-        if (bal) {
-            const int lane = wave_lane();
-            unsigned slot = 0;
-            if (lane == 0) slot = atomicAdd(&s_count, (unsigned)__popcll(bal));
-            slot = __builtin_amdgcn_readfirstlane(slot);
-            if (push) {
-                const int e = (int)slot + __popcll(bal & ((1ull << lane) - 1ull));
-                const int key = min(hit_pos >> CAH_KEY_SHIFT, CAH_QUEUE_BINS - 1);
-                s_idx[e] = (uint16_t)(r - tile_base);
-                s_key[e] = (uint8_t)key;
-                atomicAdd(&s_hist[key], 1u);
-            }
-        }
-    }
 }
 
 // UNIFORM: every read of the batch has the length offsets[1] - offsets[0] (position, length and gate
@@ -2506,9 +2425,19 @@ static int getenv_flag(const char* name) {
 #define STREAM_NU_B 11
 #define STREAM_UM_B 10
 
-hipError_t launch_filter_lean(const FilterArgs& a_in, int mode, int n_lead, int n_gated, int delay, int n_cus, hipStream_t s) {
+hipError_t launch_filter_lean(const FilterArgs& a_in, int mode, int n_lead, int n_gated, int delay, int tw_ok, int n_tw,
+                              int n_cus, hipStream_t s) {
     FilterArgs a = a_in;
     if (mode != 0) a.present = nullptr;                   // the kernels tell the modes apart by `present`
+    // equally long short reads of a plan with T-words: k_filter_stream2 (CAH_NO_STREAM2=1: the round-2 kernels)
+    const bool stream2 = (a.batch_flag != nullptr || a.uniform_len > 0) && tw_ok && stream2_class_ok(n_lead, n_tw) &&
+                         getenv_flag("CAH_NO_STREAM") == 0 && getenv_flag("CAH_NO_STREAM2") == 0;
+    if (stream2) {
+        hipError_t e = launch_filter_stream2(a, mode, n_lead, n_tw, n_cus, s);
+        if (e != hipSuccess) return e;
+        if (a.uniform_len > 0 && a.uniform_len <= stream2_max_len() && a.n_reads * (int64_t)a.uniform_len >= 16)
+            return hipSuccess;                            // the host knows the length: nothing else to launch
+    }
     const int grid = grid_for(a.n_reads, LEAN_WAVES, n_cus);
     // dynamic part only (start gates of the ragged variant, tile staging, histogram); the character masks
     // are a static allocation of the kernel
@@ -2518,7 +2447,7 @@ hipError_t launch_filter_lean(const FilterArgs& a_in, int mode, int n_lead, int 
     // host synchronisation): the streaming kernel for equally long short reads, the per-lane uniform kernel for
     // equally long longer reads, the ragged kernel for everything else.  Views (explicit lengths) have no batch
     // check and go to the ragged variant directly.
-    const bool stream = a.batch_flag != nullptr && getenv_flag("CAH_NO_STREAM") == 0;
+    const bool stream = !stream2 && a.batch_flag != nullptr && getenv_flag("CAH_NO_STREAM") == 0;
 #define CAH_STREAM_LAUNCH(DL, NL, NG, NU, UM, LO)                                                                   \
     do {                                                                                                            \
         const int tiles = (int)((a.n_reads + stream_tile(NL, NG) - 1) / stream_tile(NL, NG));                       \
@@ -2542,8 +2471,8 @@ hipError_t launch_filter_lean(const FilterArgs& a_in, int mode, int n_lead, int 
         if (delay) CAH_LEAN_ALL(CAH_LEAN_DELAY, NL, NG); else CAH_LEAN_ALL(0, NL, NG);                              \
     } while (0)
     // the per-lane uniform kernel leaves the streaming kernels' lengths alone
-    a.stream_n_lo = 0;
-    a.stream_n_hi = stream ? stream_max_len(STREAM_UM_B) : -1;
+    a.stream_n_lo = stream2 ? 1 : 0;
+    a.stream_n_hi = stream2 ? stream2_max_len() : (stream ? stream_max_len(STREAM_UM_B) : -1);
     // slot classes <lead, gated>: TruSeq / e = 0.1 is <2, 3> as a 3' or 5' adapter, <2, 6> as an anywhere adapter
     if (n_lead <= 1 && n_gated <= 2) CAH_LEAN_CLASS(1, 2);
     else if (n_lead <= 2 && n_gated <= 3) CAH_LEAN_CLASS(2, 3);

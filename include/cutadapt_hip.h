@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define CAH_ABI_VERSION 1
+#define CAH_ABI_VERSION 2   /* 2: CAH_PROF_N = 5, plan workspaces (cah_plan_workspace_bytes), no adapter length limit */
 
 /* status codes */
 #define CAH_OK 0
@@ -136,6 +136,8 @@ int cah_plan_prefilter_kind(const cah_plan *plan, int32_t adapter, int32_t *out)
  * its size.  The layout is internal to the library version. */
 int cah_plan_debug_matcher(const cah_plan *plan, int32_t adapter, void *buf, size_t buflen,
                            size_t *need);
+/* ... and the lean prefilter's word tables (struct CahLeanFilter) */
+int cah_plan_debug_lean(const cah_plan *plan, int32_t adapter, void *buf, size_t buflen, size_t *need);
 
 /* ---- batch entry points (device pointers, asynchronous) --------------------------------- */
 /* Aligner.locate / PrefixComparer.locate / SuffixComparer.locate over a batch.
