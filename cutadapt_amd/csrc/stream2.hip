@@ -74,71 +74,122 @@ struct S2Words {
     const unsigned char* found;          // LDS: tw_found, one entry of NTP words per dist
 };
 
-// entry offsets ("byte << SHIFT": one SDWA instruction each) of the four characters of a dword
-template <int SHIFT>
-__device__ __forceinline__ void s2_addr4(unsigned (&ad)[4], const unsigned w) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) ad[i] = ((w >> (8 * i)) & 0xFFu) << SHIFT;
+// ---- the instructions of a group, written out (inline assembly: the compiler re-associates the AND chains "to shorten
+// the critical path" at 5-6 instructions per word where 4 do, picks v_and_or / v_or3 (4 issue cycles) where v_bitop3
+// (2) does, and a shift + mask where one SDWA instruction extracts a byte).  Issue cost on gfx950 with two or more
+// waves per SIMD (profiles/r03/valu_ubench.txt): v_and / v_or / v_add / v_mov / v_bitop3 2 cycles; shifts, SDWA forms,
+// v_lshl_or, v_and_or, v_or3, v_cmp, v_cndmask, v_perm, 24-bit multiplies 4. ----
+// entry offsets ("byte << SHIFT") of the four characters of a dword; shv: a register holding SHIFT
+__device__ __forceinline__ void s2_addr4(unsigned (&ad)[4], const unsigned w, const unsigned shv) {
+    asm("v_lshlrev_b32_sdwa %0, %4, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
+        "v_lshlrev_b32_sdwa %1, %4, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t"
+        "v_lshlrev_b32_sdwa %2, %4, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t"
+        "v_lshlrev_b32_sdwa %3, %4, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3"
+        : "=&v"(ad[0]), "=&v"(ad[1]), "=&v"(ad[2]), "=&v"(ad[3]) : "v"(shv), "v"(w));
+}
+// a lead word over four characters: R = ((R << 4) | S3) & m0 & m1 & m2 & m3;  f |= R & FOUND   (S3, FOUND: SGPRs)
+__device__ __forceinline__ void s2_lead_step(uint32_t& R, uint32_t& f, const uint32_t init4, const uint32_t found,
+                                             const uint32_t m0, const uint32_t m1, const uint32_t m2, const uint32_t m3) {
+    asm("v_lshl_or_b32 %0, %0, 4, %2\n\t"
+        "v_bitop3_b32 %0, %0, %4, %5 bitop3:0x80\n\t"
+        "v_bitop3_b32 %0, %0, %6, %7 bitop3:0x80\n\t"
+        "v_bitop3_b32 %1, %0, %3, %1 bitop3:0xea"
+        : "+v"(R), "+v"(f) : "s"(init4), "s"(found), "v"(m0), "v"(m1), "v"(m2), "v"(m3));
+}
+// a T-word: the found mask is the group's (a register: it comes out of LDS)
+__device__ __forceinline__ void s2_tail_step(uint32_t& R, uint32_t& f, const uint32_t init4, const uint32_t fm,
+                                             const uint32_t m0, const uint32_t m1, const uint32_t m2, const uint32_t m3) {
+    asm("v_lshl_or_b32 %0, %0, 4, %2\n\t"
+        "v_bitop3_b32 %0, %0, %4, %5 bitop3:0x80\n\t"
+        "v_bitop3_b32 %0, %0, %6, %7 bitop3:0x80\n\t"
+        "v_bitop3_b32 %1, %0, %3, %1 bitop3:0xea"
+        : "+v"(R), "+v"(f) : "s"(init4), "v"(fm), "v"(m0), "v"(m1), "v"(m2), "v"(m3));
+}
+__device__ __forceinline__ uint32_t s2_or3(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t d;
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xfe" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+// old where the lane's bit of `mask` (a wave-wide SGPR mask) is clear, val where it is set
+__device__ __forceinline__ int s2_pick(int old, int val, unsigned long long mask) {
+    int d;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(d) : "v"(old), "v"(val), "s"(mask));
+    return d;
+}
+
+// what the lanes of a wave know about their reads' first k-mer: `live` -- the lanes still looking (a wave-wide mask in
+// SGPRs: "is any lane still looking" is a scalar compare), `group` -- per lane, the 4-character group of the first hit
+struct S2Hits {
+    unsigned long long live;
+    int group;
+};
+// f != 0 in a lane: a k-mer that counts ended inside group g (wave-uniform)
+__device__ __forceinline__ void s2_note(S2Hits& h, const uint32_t f, const int g) {
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(f != 0);
+    const unsigned long long nw = m & h.live;
+    if (nw) {
+        h.group = s2_pick(h.group, g, nw);
+        h.live &= ~m;
+    }
 }
 
 // One chunk of 16 characters at positions pos .. pos+15 (characters past the read's end are NUL): the lead words and
-// the first NA T-words advance over its four groups; f[g] != 0 <=> a k-mer that counts ended inside group g.
-// GUARD: the chunk may reach past the read's end -- groups that start there are skipped (wave-uniform).
-// LDS latency is hidden one step ahead, not more (registers: the kernel lives on its fourth wave per SIMD): the
-// T-word masks of a group are requested in front of the group's lead step, the lead masks of the NEXT group in
-// front of the group's T-word step.
+// the first NA T-words advance over its four groups.  GUARD: the chunk may reach past the read's end -- groups that start
+// there are skipped (wave-uniform).  LDS latency is hidden one step ahead, not more (registers: the kernel lives on its
+// fourth wave per SIMD): the T-word masks of a group are requested in front of the group's lead step, the lead masks
+// of the NEXT group in front of the group's T-word step.
 template <int NL, int NT, int NA, bool GUARD>
 __device__ __forceinline__ void s2_chunk(const S2Words<NL, NT>& K, uint32_t (&RL)[NL > 0 ? NL : 1],
                                          uint32_t (&RT)[NT > 0 ? NT : 1], const s2_u32x4 cw, const int pos, const int n,
-                                         uint32_t (&f)[4]) {
+                                         S2Hits& hits, const unsigned shv) {
     typedef S2Layout<NL, NT> LY;
     const unsigned w[4] = {cw.x, cw.y, cw.z, cw.w};
     constexpr int NLm = NL > 0 ? NL : 1, NAm = NA > 0 ? NA : 1;
-    unsigned la[4];
-    uint32_t mk[4][NLm];
+    // lead masks: two sets, used alternately, so that a group's masks are requested a whole group ahead
+    unsigned la[2][4];
+    uint32_t mk[2][4][NLm];
     auto lead_loads = [&](int g) {
-        s2_addr4<LY::LEAD_SHIFT>(la, w[g]);
+        s2_addr4(la[g & 1], w[g], shv);
         if constexpr (NL > 0) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) s2_read_entry<NL, LY::NLP>(mk[i], K.lead + (3 - i) * LY::LEAD_TABLE + la[i]);
+            for (int i = 0; i < 4; ++i) s2_read_entry<NL, LY::NLP>(mk[g & 1][i], K.lead + (3 - i) * LY::LEAD_TABLE + la[g & 1][i]);
         }
     };
+    // the found masks of the chunk's groups sit 4 entries apart, group 3's lowest: one address register per chunk
+    const unsigned char* const fm3 = K.found + s2_found_index(n, pos + 15) * (LY::NTP * 4);
     lead_loads(0);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        f[g] = 0;
         if (GUARD && pos + 4 * g >= n) continue;                 // (the masks requested for it are never looked at)
+        const bool has_next = g + 1 < 4 && !(GUARD && pos + 4 * (g + 1) >= n);
         uint32_t fg = 0;
         uint32_t tm[4][NAm], fm[NAm];
         if constexpr (NA > 0) {
             // a T-word entry is twice (NTP = 2 NLP) or as wide as a lead entry: its offset is the lead offset, doubled
-            // by an add (2 issue cycles) rather than a second SDWA shift (4)
+            // by an add (2 issue cycles; the compiler would make it a shift: 4)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 unsigned ta;
-                if constexpr (LY::TAIL_SHIFT == LY::LEAD_SHIFT + 1) ta = la[i] + la[i];
-                else if constexpr (LY::TAIL_SHIFT == LY::LEAD_SHIFT) ta = la[i];
-                else ta = ((w[g] >> (8 * i)) & 0xFFu) << LY::TAIL_SHIFT;
+                if constexpr (LY::TAIL_SHIFT == LY::LEAD_SHIFT + 1) asm("v_add_u32 %0, %1, %1" : "=v"(ta) : "v"(la[g & 1][i]));
+                else if constexpr (LY::TAIL_SHIFT == LY::LEAD_SHIFT) ta = la[g & 1][i];
+                else ta = la[g & 1][i] << (LY::TAIL_SHIFT - LY::LEAD_SHIFT);
                 s2_read_entry<NA, LY::NTP>(tm[i], K.tail + (3 - i) * LY::TAIL_TABLE + ta);
             }
-            s2_read_entry<NA, LY::NTP>(fm, K.found + s2_found_index(n, pos + 4 * g + 3) * (LY::NTP * 4));
+            s2_read_entry<NA, LY::NTP>(fm, fm3 + (3 - g) * 4 * (LY::NTP * 4));
+        } else {
+            if (has_next) lead_loads(g + 1);
         }
         if constexpr (NL > 0) {
 #pragma unroll
-            for (int l = 0; l < NL; ++l) {
-                RL[l] = s2_step4(RL[l], K.l_init4[l], mk[0][l], mk[1][l], mk[2][l], mk[3][l]);
-                fg |= RL[l] & K.l_found[l];
-            }
+            for (int l = 0; l < NL; ++l)
+                s2_lead_step(RL[l], fg, K.l_init4[l], K.l_found[l], mk[g & 1][0][l], mk[g & 1][1][l], mk[g & 1][2][l], mk[g & 1][3][l]);
         }
-        if (g + 1 < 4 && !(GUARD && pos + 4 * (g + 1) >= n)) lead_loads(g + 1);
         if constexpr (NA > 0) {
+            if (has_next) lead_loads(g + 1);
 #pragma unroll
-            for (int t = 0; t < NA; ++t) {
-                RT[t] = s2_step4(RT[t], K.t_init4[t], tm[0][t], tm[1][t], tm[2][t], tm[3][t]);
-                fg |= RT[t] & fm[t];
-            }
+            for (int t = 0; t < NA; ++t) s2_tail_step(RT[t], fg, K.t_init4[t], fm[t], tm[0][t], tm[1][t], tm[2][t], tm[3][t]);
         }
-        f[g] = fg;
+        s2_note(hits, fg, (pos >> 2) + g);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -249,10 +300,12 @@ __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a
     K.found = reinterpret_cast<const unsigned char*>(s_lds.found);
 
     const int lane = wave_lane();
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (the compiler does not know it is wave-uniform)
     unsigned char* const slot = s_lds.slot + wave * (WAVE * S2_ROW);    // this wave's LDS slot
     const unsigned char* const row = slot + lane * S2_ROW;              // this lane's half-read in it
     const unsigned lane16 = (unsigned)lane * 16u;
+    unsigned shv = LY::LEAD_SHIFT;                                      // the SDWA shift amount wants a register
+    asm volatile("" : "+v"(shv));
 
     // Copy plan.  A read has U = ceil(n / 16) units (the last one runs into the next read -- masked when used):
     // H1 = ceil(U / 2) in the first half-row, H2 = U - H1 in the second.  Load k < H1 takes the first-half unit
@@ -400,8 +453,9 @@ __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a
         for (int j = 0; j < SUBS; ++j, ++it) {
             const int base = tile_base + (wave + S2_WAVES * j) * WAVE;  // < 2^31 + 2^13: compared as unsigned
             const bool more = (unsigned)base < (unsigned)n_reads;       // wave-uniform
-            bool live = more && (unsigned)(base + lane) < (unsigned)n_reads;    // still looking for a first k-mer
-            int hit_pos = -1;
+            S2Hits hits;                                                // lanes still looking for a first k-mer
+            hits.live = more ? (n_reads - base >= WAVE ? ~0ull : (1ull << (n_reads - base)) - 1ull) : 0ull;
+            hits.group = -1;
             unsigned seen = 0;
             uint32_t RL[NL > 0 ? NL : 1], RT[NT > 0 ? NT : 1];
 #pragma unroll
@@ -412,7 +466,7 @@ __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a
 #pragma unroll 1
             for (int ph = 0; ph < 2; ++ph) {
                 const int H = ph ? H2 : H1;
-                const bool alive = more && H > 0 && __any(live);        // wave-uniform
+                const bool alive = H > 0 && hits.live != 0;                 // wave-uniform
                 if (alive) {
                     if (ph == 0) to_slot(std::integral_constant<int, 0>{}); else to_slot(std::integral_constant<int, 1>{});
                     cur = *reinterpret_cast<const s2_u32x4*>(row);
@@ -421,28 +475,22 @@ __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a
                 const int pos0 = ph ? 16 * H1 : 0;
 #pragma unroll 1
                 for (int c = 0; c < H; ++c) {
-                    if (c > 0 && !__any(live)) break;
+                    if (c > 0 && hits.live == 0) break;
                     const int pos = pos0 + 16 * c;
                     s2_u32x4 nxt = (s2_u32x4)(0u);                      // requested now, looked at a chunk later
                     if (c + 1 < H) nxt = *reinterpret_cast<const s2_u32x4*>(row + 16 * (c + 1));
                     const s2_u32x4 cw = finish(cur, pos);
-                    seen |= cw.x | cw.y | cw.z | cw.w;
-                    uint32_t f[4];
+                    seen = s2_or3(seen, cw.x, cw.y);
+                    seen = s2_or3(seen, cw.z, cw.w);
                     if (pos + 16 > n) {
                         // the read's last chunk: every T-word is at work, groups past the end are skipped
-                        s2_chunk<NL, NT, NT, true>(K, RL, RT, cw, pos, n, f);
+                        s2_chunk<NL, NT, NT, true>(K, RL, RT, cw, pos, n, hits, shv);
                     } else {
                         const int na = s2_active_tw(tspan, NT, n, pos);
 #define S2_CASE(NA)                                                                                                     \
-                        if constexpr (NA <= NT) { if (na == NA) s2_chunk<NL, NT, NA, false>(K, RL, RT, cw, pos, n, f); }
+                        if constexpr (NA <= NT) { if (na == NA) s2_chunk<NL, NT, NA, false>(K, RL, RT, cw, pos, n, hits, shv); }
                         S2_CASE(0) S2_CASE(1) S2_CASE(2) S2_CASE(3) S2_CASE(4)
 #undef S2_CASE
-                    }
-                    const bool hit = live && (f[0] | f[1] | f[2] | f[3]) != 0;
-                    if (__any(hit)) {
-                        // key semantics as in k_filter: the 4-column group of the first hit of any word
-                        if (hit) hit_pos = pos + (f[0] ? 0 : f[1] ? 4 : f[2] ? 8 : 12);
-                        live = live && !hit;
                     }
                     cur = nxt;
                 }
@@ -457,8 +505,8 @@ __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a
             if (!more) continue;                                        // wave-uniform; nothing left in this tile
             const bool invalid = (seen & 0x80808080u) != 0;
             const S2Out o = s2_out_args();
-            lean_emit(o, (int64_t)base + lane, (int64_t)tile_base, (unsigned)(base + lane) < (unsigned)n_reads, hit_pos >= 0,
-                      invalid, hit_pos, s_lds.idx, s_lds.key, s_lds.hist, s_lds.count);
+            lean_emit(o, (int64_t)base + lane, (int64_t)tile_base, (unsigned)(base + lane) < (unsigned)n_reads, hits.group >= 0,
+                      invalid, hits.group << CAH_KEY_SHIFT, s_lds.idx, s_lds.key, s_lds.hist, s_lds.count);
         }
 
         const S2Out o = s2_out_args();

@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Condense the output of profiles/scripts/pmc.sh (gpurun_out/<dir>/{trace,sq1,sq2,sq3,fetch,write,grbm}) into
+profiles/r03/<tag>_kernel_stats.csv and profiles/r03/<tag>_pmc_summary.json.
+Usage: python profiles/summarize_r03.py <src dir> <tag> [--min-ms 0.05]"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+src, tag = sys.argv[1], sys.argv[2]
+min_ms = float(sys.argv[sys.argv.index("--min-ms") + 1]) if "--min-ms" in sys.argv else 0.05
+here = os.path.dirname(os.path.abspath(__file__))
+outdir = os.path.join(here, "r03")
+os.makedirs(outdir, exist_ok=True)
+
+
+def find(sub, pattern):
+    hits = glob.glob(os.path.join(src, sub, "**", pattern), recursive=True)
+    return hits[0] if hits else None
+
+
+stats = find("trace", "*kernel_stats.csv")
+if stats:
+    rows = list(csv.DictReader(open(stats)))
+    with open(f"{outdir}/{tag}_kernel_stats.csv", "w") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+        for r in rows:
+            w.writerow([r["Name"][:100], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
+                        r["MinNs"], r["MaxNs"], r["StdDev"]])
+
+out = {"command": "profiles/scripts/pmc.sh: rocprofv3 --pmc <group> --kernel-trace --output-format csv -- python bench.py "
+                  "... --no-cpu-baseline --check-reads 0 --steps 2 --warmup 0 (one pass per counter group; the kernel "
+                  "stats come from a --kernel-trace --stats pass of 5 steps)",
+       "notes": ["per-launch averages over the launches longer than %.2f ms" % min_ms,
+                 "FETCH_SIZE / WRITE_SIZE are KiB as rocprofv3 prints them; MI355X_MICROARCH.md: FETCH_SIZE on gfx950 "
+                 "reports half the bytes of wide coalesced streaming reads (hbm_fetch_bytes_x2 applies that)",
+                 "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles (4 shader cycles)"],
+       "kernels": {}}
+for sub in ("sq1", "sq2", "sq3", "fetch", "write", "grbm"):
+    path = find(sub, "*counter_collection.csv")
+    if not path:
+        continue
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    res = {}
+    for r in csv.DictReader(open(path)):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        if not k.startswith("k_"):
+            continue
+        dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+        if dur < min_ms:
+            continue
+        agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        agg[k]["duration_ms_" + sub].append(dur)
+        res[k] = {x: int(r[x]) for x in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Scratch_Size",
+                                         "LDS_Block_Size", "Grid_Size", "Workgroup_Size") if x in r}
+    for k, d in agg.items():
+        o = out["kernels"].setdefault(k, {})
+        o["resources"] = res[k]
+        for c, v in d.items():
+            o[c] = sum(v) / len(v)
+for k, o in out["kernels"].items():
+    wc = o.get("SQ_WAVE_CYCLES")
+    if wc:
+        for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
+            if c in o:
+                o[c + "_frac_of_wave_cycles"] = o[c] / wc
+    if "SQ_BUSY_CYCLES" in o and "SQ_WAVE_CYCLES" in o:
+        o["waves_in_flight_avg_per_SE_busy_cycle"] = o["SQ_WAVE_CYCLES"] * 4 / o["SQ_BUSY_CYCLES"]
+    if "FETCH_SIZE" in o:
+        o["hbm_fetch_bytes_x2"] = o["FETCH_SIZE"] * 1024 * 2
+    if "WRITE_SIZE" in o:
+        o["hbm_write_bytes"] = o["WRITE_SIZE"] * 1024
+with open(f"{outdir}/{tag}_pmc_summary.json", "w") as f:
+    json.dump(out, f, indent=1, sort_keys=True)
+print(json.dumps(out["kernels"], indent=1, sort_keys=True)[:6000])

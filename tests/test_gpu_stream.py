@@ -187,3 +187,50 @@ def test_stream_flags_invalid_bytes(hip):
     got = match_batch(ad._fused_plan, batch).cpu()
     st = got[1]
     assert sorted(np.nonzero(st == 2)[0].tolist()) == bad
+
+
+def _survivors(batch, n):
+    """the survivor queue cah_match_batch left in the batch's workspace (layout: api.cpp, "workspace layout"):
+    {read index: key}"""
+    import torch
+    ws = batch.workspace()
+    torch.cuda.synchronize()
+    count = int(ws[256:264].view(torch.int64).item())
+    qbytes = (4 * n + 255) & ~255
+    queue = ws[1024:1024 + 4 * count].view(torch.int32).cpu().numpy()
+    keys = ws[1024 + qbytes:1024 + qbytes + count].cpu().numpy()
+    assert len(set(queue.tolist())) == count
+    return dict(zip(queue.tolist(), keys.tolist()))
+
+
+def test_stream_survivor_queue_is_exactly_kmers_present(hip, orc):
+    """The prefilter is exact, not merely sufficient: the survivor queue holds exactly the reads whose kmers_present is
+    true (the oracle's), under the key the cost scan's column skipping relies on (first 4-character group in which a
+    k-mer that lies in its window ends, min 255) -- the same queue the round-2 kernels and the per-lane kernels leave."""
+    import torch
+    from cutadapt_amd import adapters as A
+    from cutadapt_amd.batch import ReadBatch, match_batch
+    rng = random.Random(31337)
+    cases = [(TRUSEQ, 0.1, 3, n) for n in (150, 151, 149, 100, 76, 36, 160, 81, 80, 17)]
+    for _ in range(12):
+        m = rng.choice([12, 20, 25, 33, 34, 40])
+        cases.append((rs(rng, m), rng.choice([0.0, 0.1, 0.2]), rng.randint(1, 6), rng.choice([150, 100, 50, 125])))
+    for seq, rate, ov, n in cases:
+        ad = A.BackAdapter(seq, max_errors=rate, min_overlap=ov)
+        count = rng.choice([700, 1300, 9000])
+        reads = make_reads(rng, n, count, seq, p_adapter=0.6)
+        finder = orc.KmerFinder(ad.kmer_finder.positions_and_kmers, ad.adapter_wildcards, ad.read_wildcards)
+        batch = ReadBatch.from_strings(reads)
+        match_batch(ad._fused_plan, batch)
+        got = _survivors(batch, count)
+        want = {i for i, r in enumerate(reads) if finder.kmers_present(r)}
+        assert set(got) == want, (seq, rate, ov, n, sorted(set(got) ^ want)[:5])
+        for env in ("CAH_NO_STREAM2", "CAH_NO_STREAM"):
+            os.environ[env] = "1"
+            try:
+                b2 = ReadBatch.from_strings(reads)
+                match_batch(ad._fused_plan, b2)
+                ref = _survivors(b2, count)
+            finally:
+                os.environ.pop(env, None)
+            assert ref == got, (env, seq, rate, ov, n, [(i, got[i], ref.get(i)) for i in got if got[i] != ref.get(i)][:5])
