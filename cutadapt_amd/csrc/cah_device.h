@@ -91,8 +91,9 @@ struct CahKmerWord {
 #define CAH_GATE_ZERO (CAH_LEAN_SPAN + CAH_GATE_PAD)     // tail words: index of distance 0 (one past the last character)
 #define CAH_GATE_LEN (CAH_LEAN_SPAN + 2 * CAH_GATE_PAD)  // entries per gate table
 #define CAH_LEAN_MAX_TW 4                         // T-words (tail k-mers with delay bits, found-gated; see tw_* below)
-#define CAH_TW_DIST0 3                            // tw_found index of dist = 0 (the group's last character is the read's last)
-#define CAH_TW_DIST_LEN (CAH_LEAN_SPAN + 24)      // dist = -3 .. CAH_LEAN_SPAN + 20: every group of a chunk that touches a window
+#define CAH_TW_DIST0 15                           // tw_found index of dist = 0 (the group's last character is the read's last);
+                                                  // below it: groups that end up to 15 characters past the read (all zero from -4 on)
+#define CAH_TW_DIST_LEN (CAH_LEAN_SPAN + 36)      // dist = -15 .. CAH_LEAN_SPAN + 20: every group of a chunk that touches a window
 struct CahLeanFilter {
     int32_t ok;                                   // 1: this matcher can use the lean kernels
     int32_t n_lead, n_gated;                      // words in use

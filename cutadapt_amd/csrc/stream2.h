@@ -38,7 +38,7 @@ S2_HD uint32_t s2_step4(uint32_t R, uint32_t init4, uint32_t m0, uint32_t m1, ui
     return ((R << 4) | init4) & m0 & m1 & m2 & m3;
 }
 // index into tw_found of the group whose last character is t, in a read of n characters.  In range for every group
-// of a chunk that touches a window (t <= n + 2, and n - t <= CAH_LEAN_SPAN + 16 there): no clamping.
+// of a chunk that touches a window or the read's end (t <= n + 14, and n - t <= CAH_LEAN_SPAN + 16 there): no clamping.
 S2_HD int s2_found_index(int n, int t) { return n - 1 - t + CAH_TW_DIST0; }
 // T-words the 16-character chunk at `pos` must advance: word w is idle (state 0) until the chunk that holds
 // position n - tw_span[w], the first at which one of its k-mers may start; the spans fall from word to word

@@ -87,111 +87,116 @@ __device__ __forceinline__ void s2_addr4(unsigned (&ad)[4], const unsigned w, co
         "v_lshlrev_b32_sdwa %3, %4, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3"
         : "=&v"(ad[0]), "=&v"(ad[1]), "=&v"(ad[2]), "=&v"(ad[3]) : "v"(shv), "v"(w));
 }
-// a lead word over four characters: R = ((R << 4) | S3) & m0 & m1 & m2 & m3;  f |= R & FOUND   (S3, FOUND: SGPRs)
-__device__ __forceinline__ void s2_lead_step(uint32_t& R, uint32_t& f, const uint32_t init4, const uint32_t found,
+// a word over four characters: R = ((R << 4) | S3) & m0 & m1 & m2 & m3;  f |= R & found  (v_lshl_or + 3 v_bitop3; FIRST:
+// f = R & found).  The bitop3 builtin keeps the compiler from re-associating the chain.
+template <bool FIRST>
+__device__ __forceinline__ void s2_word_step(uint32_t& R, uint32_t& f, const uint32_t init4, const uint32_t found,
                                              const uint32_t m0, const uint32_t m1, const uint32_t m2, const uint32_t m3) {
-    asm("v_lshl_or_b32 %0, %0, 4, %2\n\t"
-        "v_bitop3_b32 %0, %0, %4, %5 bitop3:0x80\n\t"
-        "v_bitop3_b32 %0, %0, %6, %7 bitop3:0x80\n\t"
-        "v_bitop3_b32 %1, %0, %3, %1 bitop3:0xea"
-        : "+v"(R), "+v"(f) : "s"(init4), "s"(found), "v"(m0), "v"(m1), "v"(m2), "v"(m3));
+#ifdef S2_DBG_NOSTEP
+    R = R | (m0 & m1 & m2 & m3 & 1u & init4);                                 // developer build: (nearly) no word steps
+#else
+    R = (R << 4) | init4;
+    R = __builtin_amdgcn_bitop3_b32(R, m0, m1, 0x80);
+    R = __builtin_amdgcn_bitop3_b32(R, m2, m3, 0x80);
+#endif
+    if constexpr (FIRST) f = R & found;
+    else f = __builtin_amdgcn_bitop3_b32(R, found, f, 0xea);
 }
-// a T-word: the found mask is the group's (a register: it comes out of LDS)
-__device__ __forceinline__ void s2_tail_step(uint32_t& R, uint32_t& f, const uint32_t init4, const uint32_t fm,
-                                             const uint32_t m0, const uint32_t m1, const uint32_t m2, const uint32_t m3) {
-    asm("v_lshl_or_b32 %0, %0, 4, %2\n\t"
-        "v_bitop3_b32 %0, %0, %4, %5 bitop3:0x80\n\t"
-        "v_bitop3_b32 %0, %0, %6, %7 bitop3:0x80\n\t"
-        "v_bitop3_b32 %1, %0, %3, %1 bitop3:0xea"
-        : "+v"(R), "+v"(f) : "s"(init4), "v"(fm), "v"(m0), "v"(m1), "v"(m2), "v"(m3));
-}
-__device__ __forceinline__ uint32_t s2_or3(uint32_t a, uint32_t b, uint32_t c) {
-    uint32_t d;
-    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xfe" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
-// old where the lane's bit of `mask` (a wave-wide SGPR mask) is clear, val where it is set
-__device__ __forceinline__ int s2_pick(int old, int val, unsigned long long mask) {
-    int d;
-    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(d) : "v"(old), "v"(val), "s"(mask));
-    return d;
-}
-
-// what the lanes of a wave know about their reads' first k-mer: `live` -- the lanes still looking (a wave-wide mask in
-// SGPRs: "is any lane still looking" is a scalar compare), `group` -- per lane, the 4-character group of the first hit
+__device__ __forceinline__ uint32_t s2_or3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0xfe); }
+// what the lanes of a wave know about their reads' first k-mer: `live` -- the lane is still looking (a per-lane
+// boolean: the compiler keeps it as a wave-wide mask in SGPRs, "is any lane still looking" is a scalar compare),
+// `group` -- the 4-character group of the first hit
 struct S2Hits {
-    unsigned long long live;
+    bool live;
     int group;
 };
-// f != 0 in a lane: a k-mer that counts ended inside group g (wave-uniform)
-__device__ __forceinline__ void s2_note(S2Hits& h, const uint32_t f, const int g) {
-    const unsigned long long m = __builtin_amdgcn_ballot_w64(f != 0);
-    const unsigned long long nw = m & h.live;
-    if (nw) {
-        h.group = s2_pick(h.group, g, nw);
-        h.live &= ~m;
+__device__ __forceinline__ bool s2_any(const bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+// f[g] != 0 in a lane: a k-mer that counts ended inside group g of the chunk whose first group is g0 (wave-uniform).
+// One test per chunk; the group is sorted out only when some lane that is still looking has a hit.
+__device__ __forceinline__ void s2_note(S2Hits& h, const uint32_t (&f)[4], const int g0) {
+    const bool any = (s2_or3(f[0], f[1], f[2]) | f[3]) != 0;
+    const bool nw = any && h.live;
+    if (s2_any(nw)) {
+        int g = f[2] != 0 ? g0 + 2 : g0 + 3;
+        g = f[1] != 0 ? g0 + 1 : g;
+        g = f[0] != 0 ? g0 : g;
+        h.group = nw ? g : h.group;
+        h.live = h.live && !any;
     }
 }
 
-// One chunk of 16 characters at positions pos .. pos+15 (characters past the read's end are NUL): the lead words and
-// the first NA T-words advance over its four groups.  GUARD: the chunk may reach past the read's end -- groups that start
-// there are skipped (wave-uniform).  LDS latency is hidden one step ahead, not more (registers: the kernel lives on its
-// fourth wave per SIMD): the T-word masks of a group are requested in front of the group's lead step, the lead masks
-// of the NEXT group in front of the group's T-word step.
-template <int NL, int NT, int NA, bool GUARD>
+// The lead masks of two 4-character groups: while one group is matched the next one's four table entries are on
+// their way (across chunk borders too).  (A whole chunk of lookahead -- 16 entries in flight, 32 registers -- was
+// measured and did not pay: the waves do not wait for the LDS, and the registers are needed elsewhere.)
+template <int NL> struct S2Masks { uint32_t m[2][4][NL > 0 ? NL : 1]; };       // two groups: the one at work, the one requested
+
+template <int NL, int NT>
+__device__ __forceinline__ void s2_lead_loads(const S2Words<NL, NT>& K, S2Masks<NL>& M, const int g, const unsigned w,
+                                              const unsigned shv) {
+    typedef S2Layout<NL, NT> LY;
+    if constexpr (NL > 0) {
+        unsigned la[4];
+        s2_addr4(la, w, shv);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#ifdef S2_DBG_NOLDS
+            for (int l = 0; l < NL; ++l) M.m[g][i][l] = la[i] + l;      // developer build: no table reads
+#else
+            s2_read_entry<NL, LY::NLP>(M.m[g][i], K.lead + (3 - i) * LY::LEAD_TABLE + la[i]);
+#endif
+        }
+    }
+}
+
+// One chunk of 16 characters at positions pos .. pos+15 (characters past the read's end are NUL, which no k-mer
+// character matches: groups past the end change nothing): the lead words and, when `tails` (wave-uniform), the T-words
+// advance over its four groups.  M holds the lead masks of the chunk's first group (requested while the previous chunk
+// was matched; `nw`: the next chunk, zeros behind the last).  The T-word masks of a group are requested in front of
+// the group's lead steps.  ONE body for every chunk: the mask registers stay where they are from chunk to chunk.
+template <int NL, int NT>
 __device__ __forceinline__ void s2_chunk(const S2Words<NL, NT>& K, uint32_t (&RL)[NL > 0 ? NL : 1],
-                                         uint32_t (&RT)[NT > 0 ? NT : 1], const s2_u32x4 cw, const int pos, const int n,
-                                         S2Hits& hits, const unsigned shv) {
+                                         uint32_t (&RT)[NT > 0 ? NT : 1], S2Masks<NL>& M, const s2_u32x4 cw,
+                                         const s2_u32x4 nw, const int pos, const int n, const bool tails, S2Hits& hits,
+                                         const unsigned shv, const unsigned shv_tail) {
     typedef S2Layout<NL, NT> LY;
     const unsigned w[4] = {cw.x, cw.y, cw.z, cw.w};
-    constexpr int NLm = NL > 0 ? NL : 1, NAm = NA > 0 ? NA : 1;
-    // lead masks: two sets, used alternately, so that a group's masks are requested a whole group ahead
-    unsigned la[2][4];
-    uint32_t mk[2][4][NLm];
-    auto lead_loads = [&](int g) {
-        s2_addr4(la[g & 1], w[g], shv);
-        if constexpr (NL > 0) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) s2_read_entry<NL, LY::NLP>(mk[g & 1][i], K.lead + (3 - i) * LY::LEAD_TABLE + la[g & 1][i]);
-        }
-    };
+    const unsigned wn[4] = {nw.x, nw.y, nw.z, nw.w};
+    constexpr int NTm = NT > 0 ? NT : 1;
     // the found masks of the chunk's groups sit 4 entries apart, group 3's lowest: one address register per chunk
     const unsigned char* const fm3 = K.found + s2_found_index(n, pos + 15) * (LY::NTP * 4);
-    lead_loads(0);
+    uint32_t f[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        if (GUARD && pos + 4 * g >= n) continue;                 // (the masks requested for it are never looked at)
-        const bool has_next = g + 1 < 4 && !(GUARD && pos + 4 * (g + 1) >= n);
-        uint32_t fg = 0;
-        uint32_t tm[4][NAm], fm[NAm];
-        if constexpr (NA > 0) {
-            // a T-word entry is twice (NTP = 2 NLP) or as wide as a lead entry: its offset is the lead offset, doubled
-            // by an add (2 issue cycles; the compiler would make it a shift: 4)
+        uint32_t tm[4][NTm], fm[NTm];
+        if constexpr (NT > 0) {
+            if (tails) {
+                unsigned ta[4];
+                s2_addr4(ta, w[g], shv_tail);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                unsigned ta;
-                if constexpr (LY::TAIL_SHIFT == LY::LEAD_SHIFT + 1) asm("v_add_u32 %0, %1, %1" : "=v"(ta) : "v"(la[g & 1][i]));
-                else if constexpr (LY::TAIL_SHIFT == LY::LEAD_SHIFT) ta = la[g & 1][i];
-                else ta = la[g & 1][i] << (LY::TAIL_SHIFT - LY::LEAD_SHIFT);
-                s2_read_entry<NA, LY::NTP>(tm[i], K.tail + (3 - i) * LY::TAIL_TABLE + ta);
+                for (int i = 0; i < 4; ++i) s2_read_entry<NT, LY::NTP>(tm[i], K.tail + (3 - i) * LY::TAIL_TABLE + ta[i]);
+                s2_read_entry<NT, LY::NTP>(fm, fm3 + (3 - g) * 4 * (LY::NTP * 4));
             }
-            s2_read_entry<NA, LY::NTP>(fm, fm3 + (3 - g) * 4 * (LY::NTP * 4));
-        } else {
-            if (has_next) lead_loads(g + 1);
         }
+        // the next group's lead masks (the next chunk's first group behind this chunk's last) go out first
+        s2_lead_loads<NL, NT>(K, M, (g + 1) & 1, g < 3 ? w[g + 1] : wn[0], shv);
         if constexpr (NL > 0) {
+            s2_word_step<true>(RL[0], f[g], K.l_init4[0], K.l_found[0], M.m[g & 1][0][0], M.m[g & 1][1][0], M.m[g & 1][2][0], M.m[g & 1][3][0]);
 #pragma unroll
-            for (int l = 0; l < NL; ++l)
-                s2_lead_step(RL[l], fg, K.l_init4[l], K.l_found[l], mk[g & 1][0][l], mk[g & 1][1][l], mk[g & 1][2][l], mk[g & 1][3][l]);
+            for (int l = 1; l < NL; ++l)
+                s2_word_step<false>(RL[l], f[g], K.l_init4[l], K.l_found[l], M.m[g & 1][0][l], M.m[g & 1][1][l], M.m[g & 1][2][l], M.m[g & 1][3][l]);
         }
-        if constexpr (NA > 0) {
-            if (has_next) lead_loads(g + 1);
+        if constexpr (NT > 0) {
+            if (tails) {
 #pragma unroll
-            for (int t = 0; t < NA; ++t) s2_tail_step(RT[t], fg, K.t_init4[t], fm[t], tm[0][t], tm[1][t], tm[2][t], tm[3][t]);
+                for (int t = 0; t < NT; ++t) {
+                    if (NL == 0 && t == 0) s2_word_step<true>(RT[t], f[g], K.t_init4[t], fm[t], tm[0][t], tm[1][t], tm[2][t], tm[3][t]);
+                    else s2_word_step<false>(RT[t], f[g], K.t_init4[t], fm[t], tm[0][t], tm[1][t], tm[2][t], tm[3][t]);
+                }
+            }
         }
-        s2_note(hits, fg, (pos >> 2) + g);
         __builtin_amdgcn_sched_barrier(0);
     }
+    s2_note(hits, f, pos >> 2);
 }
 
 // what lean_emit / flush_tile_queue need of the kernel's arguments (fetched from the kernarg segment where they are
@@ -224,6 +229,63 @@ __device__ __forceinline__ void s2_clear_rows(int32_t* out6, int32_t* best, cons
     }
 }
 
+#ifdef S2_TRACE
+// developer build only (-DS2_TRACE): s_memtime stamps of wave 0 of block 0 at the stations of its first pieces
+#define S2_TRACE_PIECES 64
+#define S2_TRACE_STATIONS 8
+__device__ unsigned long long g_s2_trace[S2_TRACE_PIECES * S2_TRACE_STATIONS];
+#define S2_STAMP(st) do { if (blockIdx.x == 7 && wave == 5 && it < S2_TRACE_PIECES) { \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) g_s2_trace[it * S2_TRACE_STATIONS + (st)] = t_; } } while (0)
+__device__ unsigned long long g_s2_trace_tile[16 * 8];
+#define S2_TSTAMP(st) do { if (false) { \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) g_s2_trace_tile[kt * 8 + (st)] = t_; } } while (0)
+extern "C" int cah_debug_s2_trace_tile(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_s2_trace_tile), sizeof(g_s2_trace_tile)) == hipSuccess ? 0 : 1;
+}
+extern "C" int cah_debug_s2_trace(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_s2_trace), sizeof(g_s2_trace)) == hipSuccess ? 0 : 1;
+}
+#else
+#define S2_STAMP(st) do { } while (0)
+#define S2_TSTAMP(st) do { } while (0)
+#endif
+// The survivors of a tile, staged in LDS with their keys, leave as one key-ordered run -- flush_tile_queue
+// (filter_common.h) done by ONE wave: exclusive scan of the 256-bin histogram (four bins per lane), one atomic for the
+// run, counting sort into the global queue; histogram and cursors are left zeroed for the buffer's next tile.
+template <class Args>
+__device__ __forceinline__ void s2_flush_tile(const Args& a, const int64_t tile_base, const uint16_t* s_idx, const uint8_t* s_key,
+                                              unsigned* s_hist, unsigned* s_cursor, const unsigned count, const int lane) {
+    unsigned long long qbase = 0;
+    if (lane == 0 && count) qbase = atomicAdd(a.queue_count, (unsigned long long)count);   // (its round trip overlaps the scan)
+    unsigned h[4], sum = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { h[i] = s_hist[4 * lane + i]; sum += h[i]; }
+    unsigned incl = sum;
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        const unsigned o = __shfl_up(incl, d, WAVE);
+        if (lane >= d) incl += o;
+    }
+    unsigned run = incl - sum;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { s_hist[4 * lane + i] = run; run += h[i]; }
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)qbase);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(qbase >> 32));
+    qbase = ((unsigned long long)hi << 32) | lo;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (unsigned e = lane; e < count; e += WAVE) {
+        const unsigned key = s_key[e];
+        const unsigned p = s_hist[key] + atomicAdd(&s_cursor[key], 1u);
+        a.queue[qbase + p] = (int32_t)(tile_base + s_idx[e]);
+        a.queue_keys[qbase + p] = (uint8_t)key;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { s_hist[4 * lane + i] = 0; s_cursor[4 * lane + i] = 0; }
+}
+
 typedef const __attribute__((address_space(4))) FilterArgs* s2_kernarg_ptr;
 __device__ __forceinline__ S2Out s2_out_args() {
     s2_kernarg_ptr kp = (s2_kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
@@ -246,12 +308,18 @@ __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a
         uint32_t tail[4 * CAH_TABLE_CHARS * LY::NTP];
         uint32_t found[CAH_TW_DIST_LEN * LY::NTP];
         unsigned char slot[S2_WAVES * WAVE * S2_ROW];
-        uint16_t idx[TILE];                                             // the tile's survivors: tile-relative read index
-        uint8_t key[TILE];                                              // ... and key
-        unsigned hist[CAH_QUEUE_BINS], cursor[CAH_QUEUE_BINS];
-        unsigned long long qbase;
-        unsigned count;
-        unsigned scratch[8];
+        // survivor staging, TWO tiles' worth: while the last wave to finish a tile writes its survivors out
+        // (s2_flush_tile), the others are matching the next tile into the other buffer -- no block-wide barrier
+        struct Stage {
+            uint16_t idx[TILE];                                         // tile-relative read index
+            uint8_t key[TILE];
+            unsigned hist[CAH_QUEUE_BINS], cursor[CAH_QUEUE_BINS];
+            unsigned count;                                             // survivors staged
+            unsigned arrived;                                           // waves that are through with the tile
+            unsigned done;                                              // flushes completed on this buffer
+            unsigned pad;
+        } stage[2];
+        unsigned next_piece;                                            // the block's pieces are dealt to its waves on demand
     };
     static_assert(sizeof(S2Lds) <= 160 * 1024, "k_filter_stream2: LDS");
     __shared__ S2Lds s_lds;
@@ -263,6 +331,11 @@ __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a
     const int n_reads = (int)a.n_reads;                                 // < 2^31 (check_batch)
     const int64_t total = (int64_t)n_reads * n;                         // bytes of the batch
     if (total < 16) return;                                             // (same test there)
+    const bool clear0 = a.clear_out6 != nullptr && a.present == nullptr;
+    // CAH_S2_NOMATCH (measurement only): 1 copy, match nothing; 2 ... and no result rows; 3 result rows only, no loads
+    const bool nomatch = a.max_read_len <= -12345 && a.max_read_len >= -12347;
+    const bool noclear = a.max_read_len == -12346 || a.max_read_len == -12348, noload = a.max_read_len == -12347;   // 4: match, no result rows
+    const bool clear = clear0 && !noclear;
 
     // tables (stream2.h: s2_entry); slots a plan does not use hold zeros
     for (int j = threadIdx.x; j < CAH_TABLE_CHARS * LY::NLP; j += blockDim.x) {
@@ -283,6 +356,12 @@ __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a
         const int idx = j / LY::NTP, w = j % LY::NTP;
         s_lds.found[j] = (w < NT && w < lf->n_tw) ? lf->tw_found[w][idx] : 0u;
     }
+    for (int b = 0; b < 2; ++b) {
+        for (int i = threadIdx.x; i < CAH_QUEUE_BINS; i += blockDim.x) { s_lds.stage[b].hist[i] = 0; s_lds.stage[b].cursor[i] = 0; }
+        if (threadIdx.x == 0) { s_lds.stage[b].count = 0; s_lds.stage[b].arrived = 0; s_lds.stage[b].done = 0; }
+    }
+    if (threadIdx.x == 0) s_lds.next_piece = S2_WAVES;                 // pieces 0 .. 15 are the waves' first ones
+    __syncthreads();                                                    // the kernel's only barrier
     S2Words<NL, NT> K;
 #pragma unroll
     for (int w = 0; w < NL; ++w) {
@@ -304,8 +383,8 @@ __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a
     unsigned char* const slot = s_lds.slot + wave * (WAVE * S2_ROW);    // this wave's LDS slot
     const unsigned char* const row = slot + lane * S2_ROW;              // this lane's half-read in it
     const unsigned lane16 = (unsigned)lane * 16u;
-    unsigned shv = LY::LEAD_SHIFT;                                      // the SDWA shift amount wants a register
-    asm volatile("" : "+v"(shv));
+    unsigned shv = LY::LEAD_SHIFT, shv_tail = LY::TAIL_SHIFT;           // the SDWA shift amounts want registers
+    asm volatile("" : "+v"(shv), "+v"(shv_tail));
 
     // Copy plan.  A read has U = ceil(n / 16) units (the last one runs into the next read -- masked when used):
     // H1 = ceil(U / 2) in the first half-row, H2 = U - H1 in the second.  Load k < H1 takes the first-half unit
@@ -324,10 +403,18 @@ __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a
         asm volatile("" : "+v"(ln));
         return (int)(__umul24((unsigned)(k * WAVE) + ln, magic) >> 16);
     };
-    // first read of this wave's piece `it`: sub-tile wave + 16 (it % SUBS) of tile blockIdx.x + (it / SUBS) gridDim.x;
-    // int64: the pieces behind the last one lie beyond the batch, possibly beyond 2^31
-    auto piece_base = [&](int it) -> int64_t {
-        return ((int64_t)blockIdx.x + (int64_t)(it / SUBS) * (int64_t)gridDim.x) * TILE + (wave + S2_WAVES * (it % SUBS)) * WAVE;
+    // Pieces of 64 reads, numbered per block: piece p = sub-tile p % PPT of the block's tile p / PPT, i.e. of tile
+    // blockIdx.x + (p / PPT) gridDim.x of the batch.  The waves TAKE pieces (an LDS counter) instead of being dealt a
+    // fixed share: the SIMD's arbiter favours its oldest wave, a fixed share left the others a quarter behind and
+    // everybody waiting for them at the tile's end.  int64: pieces behind the batch's end may lie beyond 2^31.
+    constexpr int PPT = TILE / WAVE;
+    auto piece_base = [&](unsigned p) -> int64_t {
+        return ((int64_t)blockIdx.x + (int64_t)(p / PPT) * (int64_t)gridDim.x) * TILE + (int64_t)(p % PPT) * WAVE;
+    };
+    auto take_piece = [&]() -> unsigned {
+        unsigned p = 0;
+        if (lane == 0) p = __hip_atomic_fetch_add(&s_lds.next_piece, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return __builtin_amdgcn_readfirstlane(p);
     };
     s2_u32x4 pre[2 * S2_HALF];
     const uint8_t* const batch0 = a.seqs + first;
@@ -335,7 +422,7 @@ __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a
     // that would run past the batch's last byte is fetched as the 16 bytes that END there and shifted down.
     auto prefetch = [&](int64_t base) {
         const int64_t left = n_reads - base;                            // wave-uniform
-        if (left <= 0) return;
+        if (left <= 0 || noload) return;
         const int64_t pbyte = base * (int64_t)n;                        // the piece's first byte within the batch
         const uint8_t* const src = batch0 + pbyte;
         if (left >= WAVE && pbyte + (int64_t)WAVE * n + 16 <= total) {
@@ -435,26 +522,22 @@ __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a
         }
         return v;
     };
-    const bool clear = a.clear_out6 != nullptr && a.present == nullptr;
 
-    int it = 0;
-    prefetch(piece_base(0));
+    unsigned p = (unsigned)wave;                                        // this wave's piece
+    int it = 0;                                                         // (pieces this wave has matched: the trace build's index)
+    prefetch(piece_base(p));
 #pragma unroll 1
-    for (int kt = 0;; ++kt) {
+    for (;; ++it) {
+        const unsigned kt = p / PPT;
         const int64_t tile_base64 = ((int64_t)blockIdx.x + (int64_t)kt * (int64_t)gridDim.x) * TILE;
-        if (tile_base64 >= n_reads) break;                              // block-uniform
+        if (tile_base64 >= n_reads) break;                              // this piece and every later one: behind the batch
         const int tile_base = (int)tile_base64;
-        __syncthreads();
-        if (threadIdx.x == 0) s_lds.count = 0;
-        for (int i = threadIdx.x; i < CAH_QUEUE_BINS; i += blockDim.x) { s_lds.hist[i] = 0; s_lds.cursor[i] = 0; }
-        __syncthreads();
-
-#pragma unroll 1
-        for (int j = 0; j < SUBS; ++j, ++it) {
-            const int base = tile_base + (wave + S2_WAVES * j) * WAVE;  // < 2^31 + 2^13: compared as unsigned
+        auto& stage = s_lds.stage[kt & 1];                              // the tile's staging buffer
+        {
+            const int base = tile_base + (int)(p % PPT) * WAVE;         // < 2^31 + 2^13: compared as unsigned
             const bool more = (unsigned)base < (unsigned)n_reads;       // wave-uniform
             S2Hits hits;                                                // lanes still looking for a first k-mer
-            hits.live = more ? (n_reads - base >= WAVE ? ~0ull : (1ull << (n_reads - base)) - 1ull) : 0ull;
+            hits.live = more && (unsigned)(base + lane) < (unsigned)n_reads;
             hits.group = -1;
             unsigned seen = 0;
             uint32_t RL[NL > 0 ? NL : 1], RT[NT > 0 ? NT : 1];
@@ -463,37 +546,43 @@ __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a
 #pragma unroll
             for (int w = 0; w < (NT > 0 ? NT : 1); ++w) RT[w] = 0;
             s2_u32x4 cur = (s2_u32x4)(0u);
+            S2Masks<NL> M;
+            S2_STAMP(0);
 #pragma unroll 1
             for (int ph = 0; ph < 2; ++ph) {
                 const int H = ph ? H2 : H1;
-                const bool alive = H > 0 && hits.live != 0;                 // wave-uniform
+                const bool alive = H > 0 && s2_any(hits.live) && !nomatch;   // wave-uniform
                 if (alive) {
                     if (ph == 0) to_slot(std::integral_constant<int, 0>{}); else to_slot(std::integral_constant<int, 1>{});
                     cur = *reinterpret_cast<const s2_u32x4*>(row);
                 }
+                S2_STAMP(1 + 3 * ph);
+                S2_STAMP(2 + 3 * ph);
                 if (!alive) continue;
                 const int pos0 = ph ? 16 * H1 : 0;
+                // cur: this chunk's characters; nxt: the next chunk's (its lead masks are requested while this one is
+                // matched); the chunk after that is requested from the slot meanwhile
+                s2_u32x4 nxt = (s2_u32x4)(0u);
+                if (1 < H) nxt = *reinterpret_cast<const s2_u32x4*>(row + 16);
+                cur = finish(cur, pos0);
+                s2_lead_loads<NL, NT>(K, M, 0, cur.x, shv);
 #pragma unroll 1
                 for (int c = 0; c < H; ++c) {
-                    if (c > 0 && hits.live == 0) break;
+                    if (c > 0 && !s2_any(hits.live)) break;
                     const int pos = pos0 + 16 * c;
-                    s2_u32x4 nxt = (s2_u32x4)(0u);                      // requested now, looked at a chunk later
-                    if (c + 1 < H) nxt = *reinterpret_cast<const s2_u32x4*>(row + 16 * (c + 1));
-                    const s2_u32x4 cw = finish(cur, pos);
+                    s2_u32x4 nn = (s2_u32x4)(0u);
+                    if (c + 2 < H) nn = *reinterpret_cast<const s2_u32x4*>(row + 16 * (c + 2));
+                    const s2_u32x4 cw = cur;
+                    const s2_u32x4 nw = finish(nxt, pos + 16);
                     seen = s2_or3(seen, cw.x, cw.y);
                     seen = s2_or3(seen, cw.z, cw.w);
-                    if (pos + 16 > n) {
-                        // the read's last chunk: every T-word is at work, groups past the end are skipped
-                        s2_chunk<NL, NT, NT, true>(K, RL, RT, cw, pos, n, hits, shv);
-                    } else {
-                        const int na = s2_active_tw(tspan, NT, n, pos);
-#define S2_CASE(NA)                                                                                                     \
-                        if constexpr (NA <= NT) { if (na == NA) s2_chunk<NL, NT, NA, false>(K, RL, RT, cw, pos, n, hits, shv); }
-                        S2_CASE(0) S2_CASE(1) S2_CASE(2) S2_CASE(3) S2_CASE(4)
-#undef S2_CASE
-                    }
-                    cur = nxt;
+                    // every T-word from the chunk on in which the widest window opens (a word whose windows open later
+                    // finds nothing before: its found masks are zero there)
+                    s2_chunk<NL, NT>(K, RL, RT, M, cw, nw, pos, n, NT > 0 && pos + 16 > n - tspan[0], hits, shv, shv_tail);
+                    cur = nw;
+                    nxt = nn;
                 }
+                S2_STAMP(3 + 2 * ph);
             }
             // The next piece's loads go out now, not earlier: through the second half -- the T-words' chunks -- no copy
             // register is live, through the first only the second half's (a fourth wave per SIMD needs that; the
@@ -501,19 +590,41 @@ __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a
             // loads and stores share the in-order vmcnt counter.
             if (clear && more)
                 s2_clear_rows(a.clear_out6, a.clear_best, (int64_t)base, n_reads - base < WAVE ? n_reads - base : WAVE, lane);
-            prefetch(piece_base(it + 1));
-            if (!more) continue;                                        // wave-uniform; nothing left in this tile
-            const bool invalid = (seen & 0x80808080u) != 0;
-            const S2Out o = s2_out_args();
-            lean_emit(o, (int64_t)base + lane, (int64_t)tile_base, (unsigned)(base + lane) < (unsigned)n_reads, hits.group >= 0,
-                      invalid, hits.group << CAH_KEY_SHIFT, s_lds.idx, s_lds.key, s_lds.hist, s_lds.count);
-        }
-
-        const S2Out o = s2_out_args();
-        if (!o.present) {
-            __syncthreads();
-            flush_tile_queue(o, (int64_t)tile_base, s_lds.idx, s_lds.key, s_lds.hist, s_lds.cursor, s_lds.count, s_lds.scratch,
-                             s_lds.qbase);
+            const unsigned p_next = take_piece();
+            prefetch(piece_base(p_next));
+            S2_STAMP(6);
+            if (!a.present) {
+                // the tile's staging buffer is free once the tile before the last one is written out
+                while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&stage.done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) !=
+                       (kt >> 1))
+                    __builtin_amdgcn_s_sleep(2);
+            }
+            if (more) {
+                const bool invalid = (seen & 0x80808080u) != 0;
+                const S2Out o = s2_out_args();
+                lean_emit(o, (int64_t)base + lane, (int64_t)tile_base, (unsigned)(base + lane) < (unsigned)n_reads, hits.group >= 0,
+                          invalid, hits.group << CAH_KEY_SHIFT, stage.idx, stage.key, stage.hist, stage.count);
+            }
+            S2_STAMP(7);
+            if (!a.present) {
+                // The wave that stages a tile's last piece writes the tile's survivors out, alone, while the others go
+                // on (LDS operations of a wave execute in order: what it staged is in place when its piece is counted).
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                unsigned before = 0;
+                if (lane == 0) before = __hip_atomic_fetch_add(&stage.arrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+                before = __builtin_amdgcn_readfirstlane(before);
+                if (before == PPT - 1) {
+                    const S2Out o = s2_out_args();
+                    s2_flush_tile(o, (int64_t)tile_base, stage.idx, stage.key, stage.hist, stage.cursor, stage.count, lane);
+                    if (lane == 0) {
+                        stage.count = 0;
+                        stage.arrived = 0;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    if (lane == 0) __hip_atomic_fetch_add(&stage.done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+            p = p_next;
         }
     }
 }
@@ -523,6 +634,7 @@ hipError_t launch_filter_stream2(const FilterArgs& a_in, int mode, int n_lead, i
     FilterArgs a = a_in;
     if (mode != 0) a.present = nullptr;
     a.stream_n_lo = 1; a.stream_n_hi = S2_MAX_LEN;
+    { const char* e = getenv("CAH_S2_NOMATCH"); if (e && *e && *e != '0') a.max_read_len = -12344 - atoi(e); }
     const int tiles = (int)((a.n_reads + S2_TILE - 1) / S2_TILE);
     const int grid = std::max(1, std::min(tiles, n_cus));
     const size_t lds = 0;                                 // every LDS object of the kernel is static

@@ -37,28 +37,28 @@ int sm_filter_batch(const CahLeanFilter* lf, const uint8_t* seqs, int64_t n_read
         bool invalid = false;
         for (int i = 0; i < n; ++i) invalid |= q[i] >= 0x80;
         for (int pos = 0; pos < n && hp < 0 && !invalid; pos += 16) {
-            const bool guard = pos + 16 > n;
-            const int na = (guard || every_word) ? NT : s2_active_tw(lf->tw_span, NT, n, pos);
+            // the kernel's chunk: every T-word from the chunk on in which the widest window opens, all four groups
+            // (characters past the read's end are NUL); one look at the four groups' found words per chunk
+            const bool tails = every_word || (NT > 0 && pos + 16 > n - lf->tw_span[0]);
+            uint32_t f[4] = {0, 0, 0, 0};
             for (int g = 0; g < 4; ++g) {
-                if (pos + 4 * g >= n) continue;
                 unsigned c[4];
                 for (int i = 0; i < 4; ++i) { const int p = pos + 4 * g + i; c[i] = p < n ? q[p] : 0; }
-                uint32_t f = 0;
                 for (int w = 0; w < NL; ++w) {
                     RL[w] = s2_step4(RL[w], s2_init4(lf->lead_init[w]), lead[(3 * 128 + c[0]) * NL + w], lead[(2 * 128 + c[1]) * NL + w],
                                      lead[(1 * 128 + c[2]) * NL + w], lead[(0 * 128 + c[3]) * NL + w]);
-                    f |= RL[w] & lf->lead_found[w];
+                    f[g] |= RL[w] & lf->lead_found[w];
                 }
                 const int idx = s2_found_index(n, pos + 4 * g + 3);
-                for (int w = 0; w < na; ++w) {
+                for (int w = 0; tails && w < NT; ++w) {
                     RT[w] = s2_step4(RT[w], s2_init4(lf->tw_init[w]), tail[(3 * 128 + c[0]) * NT + w], tail[(2 * 128 + c[1]) * NT + w],
                                      tail[(1 * 128 + c[2]) * NT + w], tail[(0 * 128 + c[3]) * NT + w]);
-                    const uint32_t fm = (idx >= 0 && idx < CAH_TW_DIST_LEN) ? lf->tw_found[w][idx] : 0u;
-                    if (!(idx >= 0 && idx < CAH_TW_DIST_LEN) && !every_word) return 2;      // the kernel reads no clamp
-                    f |= RT[w] & fm;
+                    const bool in_table = idx >= 0 && idx < CAH_TW_DIST_LEN;
+                    if (!in_table && !every_word) return 2;                                 // the kernel does not clamp
+                    f[g] |= RT[w] & (in_table ? lf->tw_found[w][idx] : 0u);
                 }
-                if (f != 0 && hp < 0) hp = pos + 4 * g;
             }
+            for (int g = 3; g >= 0; --g) if (f[g] != 0) hp = pos + 4 * g;
         }
         present[r] = invalid ? 2 : (hp >= 0 ? 1 : 0);
         hit_pos[r] = invalid ? -1 : hp;
