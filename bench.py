@@ -49,6 +49,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--check-reads", type=int, default=200_000, help="reads compared with the oracle (untimed)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="default run (C2, one GPU) only: do not append the C3 / C4 / C5 lines (other_configs)")
+    ap.add_argument("--other-steps", type=int, default=3, help="timed steps of each other_configs entry")
+    ap.add_argument("--other-cpu-seconds", type=float, default=4.0)
     ap.add_argument("--oversubscribe", action="store_true",
                     help="TEST ONLY: let ranks share devices (rank r uses device r mod visible) so that the multi-rank "
                          "path can be exercised on a box with fewer GPUs; such a line is not a measurement")
@@ -184,39 +188,57 @@ class Workload:
         return ok, f"{'ok' if ok else 'MISMATCH'} ({m} reads{' per mate' if kind == 'paired' else ''} bit-compared with the oracle: {', '.join(checked)})"
 
 
-def main():
-    args = parse_args()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        sys.exit(self_launch(args))
-    if world != args.gpus:
-        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+def csrc_hash() -> str:
+    """sha256 over the kernel / host sources the library is built from: ties a PMC profile to the code it was taken on"""
+    import hashlib
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "cutadapt_amd", "csrc")
+    names = sorted(f for f in os.listdir(base) if f.endswith((".hip", ".h", ".cpp")))
+    for f in names + [os.path.join("..", "..", "include", "cutadapt_hip.h")]:
+        with open(os.path.join(base, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read() + b"\0")
+    return h.hexdigest()
 
+
+def profile_fields(config, n, dom, dom_launch_ms):
+    """roofline.traffic / roofline.valu from the committed PMC profile (profiles/pmc_latest.json, written by
+    profiles/summarize_r03.py) -- only if it was taken on THIS source tree and THIS workload; otherwise null + why."""
+    tpath = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    try:
+        with open(tpath) as f:
+            tj = json.load(f).get(config, {})
+    except Exception:
+        return None, None, "no profile (profiles/pmc_latest.json unreadable)"
+    if not tj:
+        return None, None, "no PMC profile of this config"
+    if tj.get("reads_per_gpu") != n:
+        return None, None, "the PMC profile was taken at another batch size"
+    if tj.get("csrc_sha256") != csrc_hash():
+        return None, None, "stale profile: cutadapt_amd/csrc changed since profiles/pmc_latest.json was taken"
+    k = tj.get("kernels", {}).get(dom)
+    if not k:
+        return None, None, "the PMC profile has no entry for the dominant kernel"
+    traffic = k.get("hbm_bytes_per_launch")
+    valu = {x: k.get(x) for x in ("kernel_full_name", "valu_busy", "valu_insts_per_launch", "waves_per_simd",
+                                  "wait_frac_of_wave_cycles", "issue_stall_frac_of_wave_cycles", "clock_ghz_profiled",
+                                  "profiled_ms_per_launch", "salu_insts_per_launch", "lds_insts_per_launch")}
+    valu["definition"] = ("valu_busy = SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE cycles per XCD) of "
+                          "the same rocprofv3 pass; wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES")
+    valu["source"] = tj.get("source")
+    return traffic, valu, "profile taken on this source tree (sha256 match)"
+
+
+def run_config(args, config, n, steps, warmup, rank, world, device, gen, check_reads, cpu_seconds, want_cpu):
+    """one BASELINE config: build the workload in HBM, time `steps` passes of the hot path, parity sample, roofline
+    fields, CPU baseline.  Returns the JSON-line dict (rank 0) or None (other ranks)."""
     import torch
     import torch.distributed as dist
-    if args.oversubscribe and torch.cuda.device_count() >= 1:
-        local_rank = local_rank % torch.cuda.device_count()
-    if local_rank >= torch.cuda.device_count():
-        raise SystemExit(f"bench.py: rank {rank} wants device {local_rank} but only {torch.cuda.device_count()} "
-                         f"device(s) are visible")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)     # barriers only: no RCCL on this path
-
     from cutadapt_amd import _lib, workloads
     L = _lib.lib()
-    gen = dict(workloads.GEN)
-    if args.p_adapter is not None:
-        gen["p_adapter"] = float(args.p_adapter)
-    spec = workloads.SPECS[args.config]
-    n = args.reads if args.reads is not None else DEFAULT_READS[args.config]
+    spec = workloads.SPECS[config]
 
     # ---- inputs resident in HBM before the timed region ------------------------------------------
-    wl = Workload(args.config, n, rank, device, gen)
+    wl = Workload(config, n, rank, device, gen)
     wl.gen = gen
     torch.cuda.synchronize()
 
@@ -226,20 +248,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         wl.step()
     barrier()
     L.cah_profile_reset()
     L.cah_profile_enable(1)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         wl.step()
     torch.cuda.synchronize()
     elapsed_local = time.perf_counter() - t0
     barrier()
     L.cah_profile_enable(0)
     elapsed = elapsed_local
-    per_rank = [n * args.steps / elapsed_local / 1e6]
+    per_rank = [n * steps / elapsed_local / 1e6]
     if world > 1:
         t = torch.tensor([elapsed_local], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -256,9 +278,9 @@ def main():
     _lib.check(L.cah_profile_read(ms, launches, units))
     L.cah_profile_reset()
     fam = {"k_filter": _lib.PROF_FILTER, "k_back_scan": _lib.PROF_SCAN, "k_dp": _lib.PROF_DP, "k_comparer": _lib.PROF_COMPARER}
-    step_ms = {k: ms[i] / args.steps for k, i in fam.items()}
+    step_ms = {k: ms[i] / steps for k, i in fam.items()}
     per_launch_ms = {k: ms[i] / max(launches[i], 1) for k, i in fam.items()}
-    launches_per_step = {k: launches[i] / args.steps for k, i in fam.items()}
+    launches_per_step = {k: launches[i] / steps for k, i in fam.items()}
     units_per_launch = {k: units[i] / max(launches[i], 1) for k, i in fam.items()}     # reads handed to one launch
     status = wl.outs[-1].status if spec["kind"] == "linked" else wl.outs[0].status
     n_match = int((status == 1).sum().item())
@@ -270,19 +292,19 @@ def main():
         dp_reads = int(ws[768:776].view(torch.int64).item()) + int(ws[896:904].view(torch.int64).item())
 
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
-        return
+        return None
 
     # ---- untimed parity check against the oracle ---------------------------------------------------
     parity = None
-    if args.check_reads > 0:
-        ok, parity = wl.parity(args.check_reads)
+    if check_reads > 0:
+        ok, parity = wl.parity(check_reads)
         if not ok:
-            raise SystemExit("parity check against the oracle FAILED: " + parity)
+            raise SystemExit(f"{config}: parity check against the oracle FAILED: " + parity)
+    del wl
+    torch.cuda.empty_cache()
 
     bytes_per_unit = spec["bytes_per_unit"]
-    total_units = n * world * args.steps
+    total_units = n * world * steps
     value = total_units / elapsed / 1e6
     # dominant kernel family: the one with the largest share of a step
     dom = max(step_ms, key=lambda k: step_ms[k])
@@ -295,40 +317,22 @@ def main():
     achieved = reads_per_launch * per_read_bytes / (dom_launch_ms * 1e-3) / 1e9 if dom_launch_ms > 0 else 0.0
     kernel_sum = sum(step_ms.values())
     step_gbs = n * bytes_per_unit / (kernel_sum * 1e-3) / 1e9 if kernel_sum > 0 else 0.0
-    traffic, valu = None, None
-    tpath = os.path.join(ROOT, "profiles", "pmc_latest.json")
-    if os.path.exists(tpath):
-        try:
-            with open(tpath) as f:
-                tj = json.load(f).get(args.config, {})
-            if tj.get("reads_per_gpu") == n:
-                k = tj.get("kernels", {}).get(dom)
-                if k:
-                    traffic = k.get("hbm_bytes_per_launch")
-                    if k.get("valu_insts_per_launch") and dom_launch_ms > 0:
-                        # wave64 VALU instructions x measured issue cycles (2-4, DESIGN.md: ~3 on this mix)
-                        # over the SIMD cycles the launch had
-                        cyc = k.get("cycles_per_valu_inst", 3.0)
-                        valu = {"insts_per_launch": k["valu_insts_per_launch"], "cycles_per_inst": cyc,
-                                "util": k["valu_insts_per_launch"] * cyc / (N_SIMD * CLOCK_GHZ * 1e9 * dom_launch_ms * 1e-3),
-                                "source": tj.get("source")}
-        except Exception:
-            traffic, valu = None, None
+    traffic, valu, profile_note = profile_fields(config, n, dom, dom_launch_ms)
     result = {
         "metric": spec["metric"],
         "value": value,
         "unit": spec["unit"],
         "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3,
+        "steps": steps,
+        "warmup": warmup,
+        "ms_per_step": elapsed / steps * 1e3,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "int32",
         "data": "synthetic",
         "config": {
-            "workload": f"{args.config}: {n} x {'2 x ' if spec['kind'] == 'paired' else ''}{workloads.READ_LEN} bp synthetic "
+            "workload": f"{config}: {n} x {'2 x ' if spec['kind'] == 'paired' else ''}{workloads.READ_LEN} bp synthetic "
                         f"{'read pairs' if spec['kind'] == 'paired' else 'reads'} per GPU, {spec['what']}, "
                         f"p_adapter={gen['p_adapter']}, p_edit={gen['p_edit']}, p_N={gen['p_n']}",
             "units_per_gpu": n,
@@ -352,6 +356,7 @@ def main():
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
             "valu": valu,
+            "profile": profile_note,
             "kernel_ms_per_step": step_ms,
             "kernel_ms_per_launch": per_launch_ms,
             "launches_per_step": launches_per_step,
@@ -359,14 +364,15 @@ def main():
             "algorithmic_bytes_per_unit": bytes_per_unit,
             "whole_step_GBps": step_gbs,
             "whole_step_frac": step_gbs / HBM_PEAK_GBS,
-            "note": "integer shift-and / bit-vector / DP kernels are VALU-bound, not HBM-bound (DESIGN.md); frac is "
-                    "reported against the HBM roof as the contract asks, valu.util against the VALU issue roof",
+            "note": "achieved = reads of one launch of the dominant kernel x 178 (182) algorithmic bytes / its HIP-event "
+                    "duration; traffic (HBM bytes per launch: FETCH_SIZE x 2 + WRITE_SIZE) and valu (counter-measured "
+                    "VALU busy fraction, waves per SIMD, wait fraction) come from the committed rocprofv3 PMC passes",
         },
     }
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and want_cpu:
         from oracle import cpu_baseline
         try:
-            result["cpu_baseline"] = cpu_baseline.run(args.config, gen, target_seconds=args.cpu_seconds)
+            result["cpu_baseline"] = cpu_baseline.run(config, gen, target_seconds=cpu_seconds)
             cb = result["cpu_baseline"]
             result["gpu_over_cpu"] = {
                 "measured": value / cb["value"],
@@ -378,8 +384,74 @@ def main():
         except Exception as exc:        # the GPU numbers must survive a host-side hiccup
             result["cpu_baseline"] = {"value": None, "unit": spec["unit"], "cores": cpu_baseline.available_cores(),
                                       "kind": "reference", "sample": f"failed: {exc!r}"[:300]}
-    print(json.dumps(result))
-    sys.stdout.flush()
+    return result
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        # rank 0's stdout carries ONE JSON line: whatever c10d / gloo print while connecting goes to stderr
+        real_stdout = os.dup(1)
+        os.dup2(2, 1)
+
+    import torch
+    import torch.distributed as dist
+    if args.oversubscribe and torch.cuda.device_count() >= 1:
+        local_rank = local_rank % torch.cuda.device_count()
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} wants device {local_rank} but only {torch.cuda.device_count()} "
+                         f"device(s) are visible")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)     # barriers only: no RCCL on this path
+
+    from cutadapt_amd import workloads
+    gen = dict(workloads.GEN)
+    if args.p_adapter is not None:
+        gen["p_adapter"] = float(args.p_adapter)
+    n = args.reads if args.reads is not None else DEFAULT_READS[args.config]
+    result = run_config(args, args.config, n, args.steps, args.warmup, rank, world, device, gen, args.check_reads,
+                        args.cpu_seconds, not args.no_cpu_baseline)
+    if rank == 0:
+        # The default invocation (the driver's: C2, one GPU) also carries the other BASELINE configs at their BASELINE
+        # sizes -- a few steps each, with their own parity sample, roofline fraction and a short CPU baseline
+        if (args.config == "C2" and world == 1 and args.reads is None and args.p_adapter is None
+                and not args.no_other_configs):
+            others = {}
+            for cfg in ("C3", "C4", "C5"):
+                try:
+                    r = run_config(args, cfg, DEFAULT_READS[cfg], args.other_steps, 1, 0, 1, device, gen,
+                                   min(args.check_reads, 20_000 if cfg == "C4" else 200_000),
+                                   args.other_cpu_seconds, not args.no_cpu_baseline)
+                    others[cfg] = {"metric": r["metric"], "value": r["value"], "unit": r["unit"], "steps": r["steps"],
+                                   "ms_per_step": r["ms_per_step"], "workload": r["config"]["workload"],
+                                   "parity_check": r["config"]["parity_check"],
+                                   "matched_fraction": r["config"]["matched_fraction"],
+                                   "roofline": {k: r["roofline"][k] for k in ("kernel", "achieved", "frac", "traffic",
+                                                                             "kernel_ms_per_step", "launches_per_step",
+                                                                             "whole_step_frac", "profile")},
+                                   "cpu_baseline": r.get("cpu_baseline"),
+                                   "gpu_over_cpu": (r.get("gpu_over_cpu") or {}).get("measured")}
+                except SystemExit:
+                    raise
+                except Exception as exc:
+                    others[cfg] = {"error": repr(exc)[:300]}
+            result["other_configs"] = others
+        line = json.dumps(result)
+        if world > 1:
+            os.write(real_stdout, (line + "\n").encode())
+        else:
+            print(line)
+            sys.stdout.flush()
     if world > 1:
         dist.destroy_process_group()
 

@@ -181,6 +181,14 @@ def check(rc: int) -> None:
     raise RuntimeError(msg)
 
 
+def raise_invalid_reads(max_len: int):
+    """Status 2 (CAH_INVALID) was met: a byte >= 0x80 -- the reference raises this very ValueError (_align.pyx:44-45)
+    -- or, a limit of this build and said as such, a read longer than CAH_MAX_READ_LEN (max_len: the batch's longest)."""
+    if max_len > MAX_READ_LEN:
+        raise UnsupportedByHipPath(f"reads longer than {MAX_READ_LEN} characters are not supported by this build")
+    raise ValueError("String must contain only ASCII characters")
+
+
 def device_count() -> int:
     n = C.c_int(0)
     rc = lib().cah_device_count(C.byref(n))

@@ -228,9 +228,7 @@ def _raise_if_invalid(status: np.ndarray, batch=None):
     """status 2 = the kernels refused a read: a byte >= 0x80 (the reference raises the same ValueError,
     _align.pyx:44-45) or -- a limit of this build, said as such -- a read longer than CAH_MAX_READ_LEN"""
     if (status == _lib.INVALID).any():
-        if batch is not None and batch.n_reads and int(batch.lengths().max().item()) > _lib.MAX_READ_LEN:
-            raise _lib.UnsupportedByHipPath(f"reads longer than {_lib.MAX_READ_LEN} characters are not supported by this build")
-        raise ValueError("String must contain only ASCII characters")
+        _lib.raise_invalid_reads(int(batch.lengths().max().item()) if batch is not None and batch.n_reads else 0)
 
 
 # -------------------------------------------------------------------------------------------------

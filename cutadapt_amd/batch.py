@@ -128,8 +128,18 @@ class ReadBatch:
             need = int(_lib.lib().cah_plan_workspace_bytes(plan.handle, self.n_reads))
         else:
             need = int(_lib.lib().cah_workspace_bytes(self.n_reads))
-        if self._workspace is None or self._workspace.numel() < need:
-            self._workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
+        if self._workspace is None or (self._workspace.numel() < need and not getattr(self, "_ws_is_fallback", False)):
+            try:
+                self._workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
+            except RuntimeError:
+                # the plan-sized scratch (fused multi-adapter path: up to ~20 GB) does not fit beside the batch: the base
+                # size does, and cah_match_batch then matches one adapter after the other (same results)
+                base = int(_lib.lib().cah_workspace_bytes(self.n_reads))
+                if plan is None or base >= need:
+                    raise
+                torch.cuda.empty_cache()
+                self._workspace = torch.empty(base, dtype=torch.uint8, device=self.device)
+                self._ws_is_fallback = True
         return self._workspace
 
     def validate_ascii(self) -> None:

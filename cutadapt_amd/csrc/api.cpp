@@ -1102,13 +1102,17 @@ static int scan_word_kind(int m) {
 
 // CAH_SCAN_RETRY=<lanes> (default 12; 0 = off): see ScanArgs::retry_threshold
 static int scan_retry_threshold() {
-    static const int v = [] {
-        const char* e = getenv("CAH_SCAN_RETRY");
-        if (!e || !*e) return 12;
-        const int x = atoi(e);
-        return x < 0 ? 0 : (x > 63 ? 63 : x);
-    }();
-    return v;
+    const char* e = getenv("CAH_SCAN_RETRY");                 // (read per call: tests switch it inside one process)
+    if (!e || !*e) return 12;
+    const int x = atoi(e);
+    return x < 0 ? 0 : (x > 63 ? 63 : x);
+}
+// CAH_SCAN_RETRY_CAP=<entries>: test knob, a smaller straggler list than the workspace has room for (overflow path)
+static int64_t scan_retry_cap(int64_t cap) {
+    const char* e = getenv("CAH_SCAN_RETRY_CAP");
+    if (!e || !*e) return cap;
+    const long long x = atoll(e);
+    return x < 1 ? 1 : (x < cap ? x : cap);
 }
 
 // Aligner / comparer over a work list (d_queue == NULL: all reads).  3' adapters with unit costs go
@@ -1176,7 +1180,7 @@ static int run_aligner(const cah_plan* plan, const PlanDeviceCopy* pd, int32_t a
             // stragglers of a wave are set aside and scanned again, packed, by a second launch (kernels.h); tiny
             // batches are launch-bound and keep the single launch
             sa.retry_threshold = n_reads > 4096 ? scan_retry_threshold() : 0;
-            sa.retry_queue = ws.retry_queue; sa.retry_keys = ws.retry_keys; sa.retry_cap = ws.retry_cap;
+            sa.retry_queue = ws.retry_queue; sa.retry_keys = ws.retry_keys; sa.retry_cap = scan_retry_cap(ws.retry_cap);
             sa.retry_count = ws.counters + WS_RETRYCOUNT; sa.queue_limit = 0;
             sa.early_stop = d_queue != nullptr && d_queue_keys != nullptr;
             sa.tile = 0;
@@ -1187,10 +1191,10 @@ static int run_aligner(const cah_plan* plan, const PlanDeviceCopy* pd, int32_t a
                 if (sa.retry_threshold > 0) {
                     ScanArgs sb = sa;
                     sb.queue = ws.retry_queue; sb.queue_keys = ws.retry_keys; sb.queue_count = ws.counters + WS_RETRYCOUNT;
-                    sb.queue_limit = ws.retry_cap; sb.work_counter = ws.counters + WS_RETRYWORK;
+                    sb.queue_limit = sa.retry_cap; sb.work_counter = ws.counters + WS_RETRYWORK;
                     sb.retry_threshold = 0;
                     sb.tile = 256;                   // few reads, long scans: one wave-load per wave keeps the chip busy
-                    HIP_TRY(launch_back_scan(sb, ws.retry_cap < n_reads ? ws.retry_cap : n_reads, pd->n_cus, s));
+                    HIP_TRY(launch_back_scan(sb, sa.retry_cap < n_reads ? sa.retry_cap : n_reads, pd->n_cus, s));
                 }
             }
             a.queue = ws.dp_queue; a.queue_keys = nullptr; a.win = ws.dp_win;

@@ -1777,7 +1777,7 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_back_
             const int64_t base = tile_base + (int64_t)sub * WAVE;
             if (base >= total) break;
             const int64_t idx = base + lane;
-            const bool valid = idx < total;
+            bool valid = idx < total;
             int64_t r = 0;
             unsigned tab_base = 0, adapter = 0, key = 0;
             if (MULTI) {
@@ -1790,6 +1790,8 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_back_
                 }
             } else {
                 if (valid) r = a.queue ? (int64_t)a.queue[idx] : idx;
+                // (a slot of the straggler list that its wave reserved but could not use: the list was full)
+                if (r < 0) { valid = false; r = 0; }
                 if (skip_cols && valid) key = a.queue_keys[idx];
             }
             int64_t off = 0, n64 = 0;
@@ -1858,7 +1860,14 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_back_
                                 }
                                 if (bfar == act) break;
                             } else {
-                                retry_at = 0;              // the list is full: this wave runs to the end
+                                // The list is full: this wave runs to the end.  What it reserved inside the list is
+                                // marked unused -- the second launch walks min(count, capacity) slots and must not
+                                // meet whatever the scratch held before.
+                                if (far) {
+                                    const int64_t e = (int64_t)slot + __popcll(bfar & ((1ull << lane) - 1ull));
+                                    if (e < a.retry_cap) a.retry_queue[e] = -1;
+                                }
+                                retry_at = 0;
                             }
                         }
                     }

@@ -70,8 +70,8 @@ class _Worker:
         self.d_info = torch.zeros(8, dtype=torch.int64, device=self.device)
         self.h_info = torch.zeros(8, dtype=torch.int64).pin_memory()
         self.counters = torch.zeros(8, dtype=torch.int64, device=self.device)   # see cah_trim_decide_device
-        self.invalid_seen = 0
         self._ws = None
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))   # (the zeroing / uploads above ran on it)
 
     def _ensure(self, nbytes: int):
         torch = self.torch
@@ -178,8 +178,8 @@ class _Worker:
                 what = {1: "line expected to start with '@'", 2: "third line expected to start with '+'",
                         3: "length of sequence and qualities differ"}.get(code, "malformed record")
                 raise ValueError(f"FASTQ format error in record {record} of the chunk: {what}")
-            if int(self.h_info[4]) != self.invalid_seen:
-                raise ValueError("String must contain only ASCII characters")
+            if int(self.h_info[4]) != 0:
+                _lib.raise_invalid_reads(int(self.seq_len[:max(n, 1)].max().item()))
             total = int(self.h_info[3])
             h_out = self.pool.get(total)
             h_out[:total].copy_(self.d_out[:total], non_blocking=True)
@@ -216,8 +216,8 @@ class _Worker:
             what = {1: "line expected to start with '@'", 2: "third line expected to start with '+'",
                     3: "length of sequence and qualities differ"}.get(code, "malformed record")
             raise ValueError(f"FASTQ format error in record {record} of the chunk: {what}")
-        if int(self.h_info[4]) != self.invalid_seen:
-            raise ValueError("String must contain only ASCII characters")
+        if int(self.h_info[4]) != 0:
+            _lib.raise_invalid_reads(int(self.seq_len[:max(n, 1)].max().item()))
         h_out = self.pool.get(n_bytes + 4 * n + 64)
         out_len = C.c_int64(0)
         src_ptr = data.data_ptr() if isinstance(data, torch.Tensor) else data.ctypes.data
@@ -244,9 +244,9 @@ def _take_worker(plan, kinds, dev, opts) -> "_Worker":
         return _Worker(plan, kinds, dev, opts, _PINNED)
     torch.cuda.set_device(w.device)
     w.plan, w.opts = plan, opts
-    w.kinds = torch.tensor(kinds, dtype=torch.uint8, device=w.device)
-    w.counters.zero_()
-    w.invalid_seen = 0
+    with torch.cuda.stream(w.stream):                           # ordered in front of the worker's next kernels
+        w.kinds = torch.tensor(kinds, dtype=torch.uint8, device=w.device)
+        w.counters.zero_()
     w._ws = None
     return w
 

@@ -947,7 +947,7 @@ class BatchPairedAdapterCutter:
             r1 = self._match(a1, batch1)
             r2 = self._match(a2, batch2)
             if (r1.status == _lib.INVALID).any() or (r2.status == _lib.INVALID).any():
-                raise ValueError("String must contain only ASCII characters")
+                _lib.raise_invalid_reads(max(int(batch1.lengths().max().item()), int(batch2.lengths().max().item())))
             both = (r1.status == _lib.MATCH) & (r2.status == _lib.MATCH)
             score = r1.out6[:, 4] + r2.out6[:, 4]
             err = r1.out6[:, 5] + r2.out6[:, 5]

@@ -104,12 +104,15 @@ class MatchHistogram:
         on_gpu = dist.get_backend(group) == "nccl"
         # add_rows grows the length / error axes with the data, so ranks may hold different shapes: agree on
         # the largest one first (a sum over unequal tensors would hang or corrupt the result)
-        shape = torch.tensor(self.counts.shape, dtype=torch.int64)
+        # one MAX reduction carries both the largest shape and (negated) the smallest number of adapter slots, so
+        # that EVERY rank sees a disagreement and raises -- a rank that went on into the sum would wait for ever
+        shape = torch.tensor(list(self.counts.shape) + [-self.counts.shape[0]], dtype=torch.int64)
         if on_gpu:
             shape = shape.cuda()
         dist.all_reduce(shape, op=dist.ReduceOp.MAX, group=group)
-        shape = tuple(int(v) for v in shape.cpu().tolist())
-        if shape[0] != self.counts.shape[0]:
+        vals = [int(v) for v in shape.cpu().tolist()]
+        shape, min_slots = tuple(vals[:3]), -vals[3]
+        if shape[0] != min_slots:
             raise ValueError("incompatible histograms: ranks disagree on the number of adapter slots")
         if shape != self.counts.shape:
             grown = np.zeros(shape, dtype=np.int64)

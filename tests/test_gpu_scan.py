@@ -188,3 +188,29 @@ def test_one_plan_on_every_visible_device(hip, orc):
         seqs, offsets = orc.synth_reads(9, d * per, per, 150, [TRUSEQ])
         w6, wst = orc.match_batch(oa, of, seqs, offsets)
         _same(got6, got_st, w6, wst, f"device {d}")
+
+
+def test_straggler_list_overflow_is_harmless(hip, orc):
+    """a wave that finds the straggler list full must leave nothing behind that the second launch then reads.
+    A tiny list (CAH_SCAN_RETRY_CAP), every wave shedding as early as it can (CAH_SCAN_RETRY=63), scratch full of
+    garbage: the results must not change."""
+    import os
+    import torch
+    from cutadapt_amd import adapters as A
+    from cutadapt_amd.batch import ReadBatch, match_batch
+    TRUSEQ = "AGATCGGAAGAGCACACGTCTGAACTCCAGTCA"
+    ad = A.BackAdapter(TRUSEQ, max_errors=0.1, min_overlap=3)
+    n = 300_000
+    batch = ReadBatch.synthetic(n, 150, [TRUSEQ], seed=77, p_adapter=0.6)
+    want = match_batch(ad._fused_plan, batch).cpu()
+    for cap in ("1", "100", "5000"):
+        os.environ["CAH_SCAN_RETRY"] = "63"
+        os.environ["CAH_SCAN_RETRY_CAP"] = cap
+        try:
+            b2 = ReadBatch(batch.seqs, batch.offsets, validated=True)
+            b2.workspace().fill_(0x7F)                       # queue slots never written read as 0x7F7F7F7F
+            got = match_batch(ad._fused_plan, b2).cpu()
+        finally:
+            os.environ.pop("CAH_SCAN_RETRY", None)
+            os.environ.pop("CAH_SCAN_RETRY_CAP", None)
+        assert np.array_equal(got[1], want[1]) and np.array_equal(got[0], want[0]), cap
