@@ -6,6 +6,9 @@
 
 #define WAVE 64
 __device__ __forceinline__ int wave_lane() { return threadIdx.x & (WAVE - 1); }
+// (threadIdx.x >> 6 is wave-uniform, but the compiler does not know: values derived from it would live in VGPRs and
+// buffer resources built from them would be looped over lane by lane)
+__device__ __forceinline__ int wave_index() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
 // Where does read `r` live?  (packed layout, see include/cutadapt_hip.h)
 __device__ __forceinline__ void read_extent(const int64_t* offsets, const int32_t* lens, int64_t r,

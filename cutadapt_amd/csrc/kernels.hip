@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256, CAH_FILTER_WAVES) void k_filter(FilterArgs a) 
             s_mask[i] = (word_t)words[i / CAH_TABLE_CHARS].mask[i % CAH_TABLE_CHARS];
     }
     const int lane = wave_lane();
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform, and said so
 
     for (;;) {
         __syncthreads();                                 // previous tile fully flushed
@@ -682,7 +682,7 @@ __global__ __launch_bounds__(256, LEAN_WAVES) void k_filter_lean(FilterArgs a) {
     LeanWords<NL, NG> L;
     lean_words_init<NL, NG>(L, lf, s_tab, s_ginit, UNIFORM ? n_uniform : -1);
     const int lane = wave_lane();
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform, and said so
 
     for (;;) {
         __syncthreads();
@@ -847,7 +847,7 @@ __global__ __launch_bounds__(STREAM_BLOCK_WAVES * WAVE, STREAM_WAVES) void k_fil
     LeanWords<NL, NG> L;
     lean_words_init<NL, NG>(L, lf, s_tab, s_gate, n);
     const int lane = wave_lane();
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform, and said so
     unsigned char* const piece = s_piece + wave * stream_piece_bytes(NU);   // this wave's LDS slot
     const unsigned char* const row = piece + lane * (NU * 16);             // this lane's read in it
 
@@ -1755,7 +1755,7 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_back_
     BackScanParams p;
     p.m = mt->m; p.k = mt->k; p.kacc = mt->kacc; p.min_overlap = mt->min_overlap; p.half_m = mt->m / 2;
     const int lane = wave_lane();
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform, and said so
     int64_t total = a.n_reads;
     if (a.queue_count) total = (int64_t)(*a.queue_count);
     if (a.queue_limit > 0 && total > a.queue_limit) total = a.queue_limit;

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void k_multi_filter(MultiFilterArgs a) {
         if (present[q]) { lmax_all = max(lmax_all, lmax[q]); short_everywhere = short_everywhere || everywhere[q]; }
     }
     const int lane = wave_lane();
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform, and said so
     const uint8_t* b2 = reinterpret_cast<const uint8_t*>(s_b2);
     const int64_t last_read = a.first_read + a.n_reads;
 

@@ -232,7 +232,7 @@ __device__ __forceinline__ void s2_clear_rows(int32_t* out6, int32_t* best, cons
 #ifdef S2_TRACE
 // developer build only (-DS2_TRACE): s_memtime stamps of wave 0 of block 0 at the stations of its first pieces
 #define S2_TRACE_PIECES 64
-#define S2_TRACE_STATIONS 8
+#define S2_TRACE_STATIONS 12
 __device__ unsigned long long g_s2_trace[S2_TRACE_PIECES * S2_TRACE_STATIONS];
 #define S2_STAMP(st) do { if (blockIdx.x == 7 && wave == 5 && it < S2_TRACE_PIECES) { \
         const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) g_s2_trace[it * S2_TRACE_STATIONS + (st)] = t_; } } while (0)
@@ -590,7 +590,9 @@ __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a
             // loads and stores share the in-order vmcnt counter.
             if (clear && more)
                 s2_clear_rows(a.clear_out6, a.clear_best, (int64_t)base, n_reads - base < WAVE ? n_reads - base : WAVE, lane);
+            S2_STAMP(8);
             const unsigned p_next = take_piece();
+            S2_STAMP(9);
             prefetch(piece_base(p_next));
             S2_STAMP(6);
             if (!a.present) {
@@ -599,6 +601,7 @@ __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a
                        (kt >> 1))
                     __builtin_amdgcn_s_sleep(2);
             }
+            S2_STAMP(10);
             if (more) {
                 const bool invalid = (seen & 0x80808080u) != 0;
                 const S2Out o = s2_out_args();

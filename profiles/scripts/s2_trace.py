@@ -20,9 +20,11 @@ for _ in range(2):
     match_batch(ad._fused_plan, batch)
 torch.cuda.synchronize()
 L = _lib.lib()
-buf = (C.c_uint64 * (64 * 8))()
+buf = (C.c_uint64 * (64 * 12))()
 assert L.cah_debug_s2_trace(buf) == 0
-t = np.frombuffer(buf, dtype=np.uint64).reshape(64, 8).astype(np.int64)
+t = np.frombuffer(buf, dtype=np.uint64).reshape(64, 12).astype(np.int64)
+fine = t
+t = t[:, :8]
 d = np.diff(t, axis=1)
 names = ["wait+slot0", "-", "match1", "slot1", "clear+issue", "match2", "emit"]
 print("cycles per piece (s_memtime ticks), pieces 8..40 of one wave:")
@@ -39,3 +41,7 @@ tt = np.frombuffer(buf2, dtype=np.uint64).reshape(16, 8).astype(np.int64)
 print("tile stations (cycles): init barriers | pieces | wait at the end barrier | flush")
 for k in range(2, 10):
     print("   ", tt[k, 1] - tt[k, 0], tt[k, 2] - tt[k, 1], tt[k, 3] - tt[k, 2], tt[k, 4] - tt[k, 3])
+
+f = fine[8:40]
+print("finer: matched -> clear stores issued", (f[:, 8] - f[:, 5]).mean(), "| take_piece", (f[:, 9] - f[:, 8]).mean(), "| prefetch issue", (f[:, 6] - f[:, 9]).mean(),
+      "| buffer wait", (f[:, 10] - f[:, 6]).mean(), "| emit", (f[:, 7] - f[:, 10]).mean())
