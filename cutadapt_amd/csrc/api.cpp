@@ -1445,8 +1445,10 @@ int cah_match_batch(const cah_plan* plan, const uint8_t* d_seqs, const int64_t* 
                             (filter_clears && ad == first_aligner) ? d_out6 : nullptr,
                             (filter_clears && ad == first_aligner) ? d_best_adapter : nullptr);
             if (rc) return rc;
+            // merge mode 2: the plan's first adapter writes into zeroed rows -- nothing to compare with (kernels.hip,
+            // store_result)
             rc = run_aligner(plan, pd, ad, d_seqs, d_offsets, d_lens, n_reads, ws.queue, counters + WS_QCOUNT,
-                             ws.keys, ws, d_out6, d_status, d_best_adapter, 1, s);
+                             ws.keys, ws, d_out6, d_status, d_best_adapter, ad == first_aligner ? 2 : 1, s);
         } else {
             rc = run_aligner(plan, pd, ad, d_seqs, d_offsets, d_lens, n_reads, nullptr, nullptr, nullptr,
                              ws, d_out6, d_status, d_best_adapter, 1, s);

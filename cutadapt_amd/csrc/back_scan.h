@@ -353,28 +353,37 @@ CAH_HD int bs_finish_rows(const BackScanBook& s, const int n, const int j0, cons
         o1 = s.jla * 2;
         return BS_DP;
     }
-    // absolute costs of the last column, rows 1..m (row 0 costs 0); the largest acceptable row
-    int best_i = 0;
-    int w_row = 0, w_cost = 0, w_score = -(1 << 20);   // the clean acceptable row of the highest score (largest on ties)
-    int unclean_bound = -(1 << 20);   // the most an acceptable row with an unclean diagonal can score
-    bool clause_ok = true;            // the origin clause holds whenever an acceptable row with errors is the best
-    bool tail_may_win = false;       // an acceptable row of the last column that could outscore m - 2 * cmin
-    bool tail_may_win1 = false;      // ... the score of the one-indel alignment
+    // Absolute costs of the last column, rows 1..m (row 0 costs 0).  Everything the rules below ask of the acceptable
+    // rows is a maximum over them, so the loop is branch-free (as nested divergent branches it cost the cost scan a
+    // fifth of its time: ~400 cycles per row and wave, most of them scalar mask bookkeeping):
+    //   best_i          the largest acceptable row
+    //   (w_score, w_row) the clean acceptable row of the highest score i - 2 c, the largest row on ties -- one maximum
+    //                    over the key (score + 256) * 128 + row; its cost is (w_row - w_score) / 2
+    //   unclean_bound   the most an acceptable row with an unclean diagonal scores
+    //   c_max           the largest cost of an acceptable row: the origin clause holds for every acceptable row with
+    //                    errors iff k + 1 + c_max <= m / 2 (or c_max == 0)
+    int best_i = 0, w_key = -1, unclean_bound = -(1 << 20), c_max = 0;
     for (int i = 1; i <= p.m; ++i) {
         const int c = row_cost(i);
-        if (i >= p.min_overlap && c <= thr_last(i)) {
-            best_i = i;
-            const int sc = i - 2 * c;
-            if (c == 0 || (n - i >= j0 && row_clean(i))) {
-                if (sc >= w_score) { w_score = sc; w_row = i; w_cost = c; }
-            } else if (sc > unclean_bound) {
-                unclean_bound = sc;
-            }
-            if (c > 0 && p.k + 1 + c > p.half_m) clause_ok = false;
-            if (sc > p.m - 2 * s.cmin) tail_may_win = true;
-            if (sc > indel1_score) tail_may_win1 = true;
-        }
+        const bool acc = i >= p.min_overlap && c <= thr_last(i);
+        const int sc = i - 2 * c;
+        const bool clean = c == 0 || (n - i >= j0 && row_clean(i));
+        best_i = acc ? i : best_i;
+        const int key = (sc + 256) * 128 + i;
+        const int key_c = (acc && clean) ? key : -1;
+        w_key = key_c > w_key ? key_c : w_key;
+        const int sc_u = (acc && !clean) ? sc : -(1 << 20);
+        unclean_bound = sc_u > unclean_bound ? sc_u : unclean_bound;
+        const int c_a = acc ? c : 0;
+        c_max = c_a > c_max ? c_a : c_max;
     }
+    const int w_row = w_key >= 0 ? (w_key & 127) : 0;
+    const int w_score = w_key >= 0 ? (w_key >> 7) - 256 : -(1 << 20);
+    const int w_cost = (w_row - w_score) / 2;                   // (unused when w_row == 0)
+    const bool clause_ok = c_max == 0 || p.k + 1 + c_max <= p.half_m;
+    const int sc_max = w_score > unclean_bound ? w_score : unclean_bound;     // -(1 << 20) without an acceptable row
+    const bool tail_may_win = sc_max > p.m - 2 * s.cmin;      // an acceptable row of the last column that could outscore m - 2 * cmin
+    const bool tail_may_win1 = sc_max > indel1_score;         // ... the score of the one-indel alignment
     if (s.jfa < 0) {
         if (best_i == 0) return BS_NONE;
         if (w_row > 0 && unclean_bound < w_score && clause_ok) { o0 = w_row; o1 = w_cost; return BS_EXACT_TAIL; }

@@ -1385,6 +1385,41 @@ __device__ __forceinline__ int pk_score(unsigned w) { return (int)(w & 0x1FFu) -
 #ifdef CAH_DP_COUNT
 __device__ unsigned long long g_dp_dbg[8];      // debug build only: lock-step accounting of k_dp_packed
 #endif
+__device__ __forceinline__ void store_result(int32_t* out6, uint8_t* status, int32_t* best_adapter,
+                                             const int adapter_index, const int merge_best, const int64_t r,
+                                             const bool invalid, const bool found, const int t0, const int t1,
+                                             const int t2, const int t3, const int score, const int cost) {
+    int32_t* o = out6 + r * 6;
+    if (merge_best == 2) {
+        // the plan's FIRST adapter on rows the entry point has zeroed (status 0, tuple 0, best_adapter -1): nothing
+        // to compare with, nothing to read -- a read without a match keeps its zeros
+        if (invalid) {
+            status[r] = 2;
+        } else if (found) {
+            o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3; o[4] = score; o[5] = cost;
+            status[r] = 1;
+            if (best_adapter) best_adapter[r] = adapter_index;
+        }
+    } else if (merge_best) {
+        // MultipleAdapters.match_to (adapters.py:1278-1285), see k_dp
+        if (invalid) {
+            status[r] = 2;
+        } else if (found) {
+            const bool had = status[r] == 1;
+            if (status[r] != 2 && (!had || score > o[4] || (score == o[4] && cost < o[5]))) {
+                o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3; o[4] = score; o[5] = cost;
+                status[r] = 1;
+                if (best_adapter) best_adapter[r] = adapter_index;
+            }
+        }
+    } else {
+        status[r] = invalid ? (uint8_t)2 : (found ? (uint8_t)1 : (uint8_t)0);
+        if (found && !invalid) { o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3; o[4] = score; o[5] = cost; }
+        else { o[0] = o[1] = o[2] = o[3] = o[4] = o[5] = 0; }
+    }
+}
+
+
 template <int I, int ROWS>
 __device__ __forceinline__ void dp_rows_packed(unsigned (&w)[ROWS + 1], const unsigned mk_lo, const unsigned mk_hi,
                                                unsigned wd, int& nl, unsigned& cm_w, const int last, const int m,
@@ -1653,30 +1688,8 @@ __global__ __launch_bounds__(256, CAH_DPP_WAVES(ROWS)) void k_dp_packed(DpArgs a
                 atomicMax(a.best_key + r, pack_best(b_score, b_cost, (int)adapter, b_refstop, max(b_origin, 0), b_qstop));
         } else if (valid) {
             const bool found = b_cost != SENT && !invalid;
-            int32_t* o = a.out6 + r * 6;
-            if (a.merge_best) {
-                if (invalid) {
-                    a.status[r] = 2;
-                } else if (found) {
-                    const bool had = a.status[r] == 1;
-                    if (a.status[r] != 2 && (!had || b_score > o[4] || (b_score == o[4] && b_cost < o[5]))) {
-                        o[0] = b_origin >= 0 ? 0 : -b_origin; o[1] = b_refstop;
-                        o[2] = b_origin >= 0 ? b_origin : 0;  o[3] = b_qstop;
-                        o[4] = b_score; o[5] = b_cost;
-                        a.status[r] = 1;
-                        if (a.best_adapter) a.best_adapter[r] = a.adapter_index;
-                    }
-                }
-            } else {
-                a.status[r] = invalid ? (uint8_t)2 : (found ? (uint8_t)1 : (uint8_t)0);
-                if (found) {
-                    o[0] = b_origin >= 0 ? 0 : -b_origin; o[1] = b_refstop;
-                    o[2] = b_origin >= 0 ? b_origin : 0;  o[3] = b_qstop;
-                    o[4] = b_score; o[5] = b_cost;
-                } else {
-                    o[0] = o[1] = o[2] = o[3] = o[4] = o[5] = 0;
-                }
-            }
+            store_result(a.out6, a.status, a.best_adapter, a.adapter_index, a.merge_best, r, invalid, found,
+                         b_origin >= 0 ? 0 : -b_origin, b_refstop, b_origin >= 0 ? b_origin : 0, b_qstop, b_score, b_cost);
         }
       }
     }
@@ -1699,29 +1712,20 @@ __global__ __launch_bounds__(256, CAH_DPP_WAVES(ROWS)) void k_dp_packed(DpArgs a
 #define SCAN_AHEAD 2
 #endif
 
-__device__ __forceinline__ void store_result(int32_t* out6, uint8_t* status, int32_t* best_adapter,
-                                             const int adapter_index, const int merge_best, const int64_t r,
-                                             const bool invalid, const bool found, const int t0, const int t1,
-                                             const int t2, const int t3, const int score, const int cost) {
-    int32_t* o = out6 + r * 6;
-    if (merge_best) {
-        // MultipleAdapters.match_to (adapters.py:1278-1285), see k_dp
-        if (invalid) {
-            status[r] = 2;
-        } else if (found) {
-            const bool had = status[r] == 1;
-            if (status[r] != 2 && (!had || score > o[4] || (score == o[4] && cost < o[5]))) {
-                o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3; o[4] = score; o[5] = cost;
-                status[r] = 1;
-                if (best_adapter) best_adapter[r] = adapter_index;
-            }
-        }
-    } else {
-        status[r] = invalid ? (uint8_t)2 : (found ? (uint8_t)1 : (uint8_t)0);
-        if (found && !invalid) { o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3; o[4] = score; o[5] = cost; }
-        else { o[0] = o[1] = o[2] = o[3] = o[4] = o[5] = 0; }
-    }
+#ifdef SCAN_TRACE
+// developer build only: s_memtime stamps of one wave of the cost scan, per sub-batch of 64 work items
+#define SCAN_TRACE_N 256
+__device__ unsigned long long g_scan_trace[SCAN_TRACE_N * 8];
+__device__ unsigned g_scan_trace_n;
+extern "C" int cah_debug_scan_trace(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_scan_trace), sizeof(g_scan_trace)) == hipSuccess ? 0 : 1;
 }
+#define SCAN_STAMP(st, extra) do { if (blockIdx.x == 11 && wave == 1 && trace_i < SCAN_TRACE_N) { \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+        if (lane == 0) { g_scan_trace[trace_i * 8 + (st)] = t_; if ((st) == 2) g_scan_trace[trace_i * 8 + 6] = (unsigned long long)(extra); } } } while (0)
+#else
+#define SCAN_STAMP(st, extra) do { } while (0)
+#endif
 
 // MULTI: the work list holds (read, adapter, key) pairs of the fused multi-adapter prefilter; all adapters
 // have one shape (m, k, thresholds: matcher 0), only the match table differs per lane.
@@ -1762,6 +1766,9 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_back_
     const bool skip_cols = MULTI ? a.multi_skip_ok != 0 : (a.queue && a.queue_keys && mt->skip_ok != 0);
     const int stop_gap = bs_stop_gap(p);
     const int tile = a.tile;                               // entries per workgroup and atomic: 256 .. SCAN_TILE
+#ifdef SCAN_TRACE
+    int trace_i = 0;
+#endif
 
     for (;;) {
         __syncthreads();                                   // previous tile flushed
@@ -1773,9 +1780,17 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_back_
         const int64_t tile_base = s_tile;
         if (tile_base >= total) break;
 
+        // (single-adapter mode) the queue entry and the read's extent of the wave's NEXT sub-batch are fetched while
+        // this one is scanned: three dependent round trips (queue -> offsets -> characters) in front of every
+        // sub-batch were a ninth of the kernel's time
+        bool pf_have = false, pf_valid = false;
+        int pf_r = 0, pf_n = 0;
+        unsigned pf_key = 0;
+        int64_t pf_off = 0;
         for (int sub = wave; sub < tile / WAVE; sub += 4) {
             const int64_t base = tile_base + (int64_t)sub * WAVE;
             if (base >= total) break;
+            SCAN_STAMP(0, 0);
             const int64_t idx = base + lane;
             bool valid = idx < total;
             int64_t r = 0;
@@ -1788,14 +1803,15 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_back_
                     key = (unsigned)pr & 0xFFu;
                     tab_base = adapter * CAH_MULTI_TAB_STRIDE;
                 }
-            } else {
+            } else if (!pf_have) {
                 if (valid) r = a.queue ? (int64_t)a.queue[idx] : idx;
                 // (a slot of the straggler list that its wave reserved but could not use: the list was full)
                 if (r < 0) { valid = false; r = 0; }
                 if (skip_cols && valid) key = a.queue_keys[idx];
             }
             int64_t off = 0, n64 = 0;
-            if (valid) read_extent(a.offsets, a.lens, r, off, n64);
+            if (!MULTI && pf_have) { valid = pf_valid; r = pf_r; key = pf_key; off = pf_off; n64 = pf_n; }
+            else if (valid) read_extent(a.offsets, a.lens, r, off, n64);
             bool invalid = false;
             if (n64 > a.max_read_len) { invalid = true; n64 = 0; }
             const int n = (int)n64;
@@ -1835,7 +1851,21 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_back_
             int pos = j0;
             Chunk cur = load_chunk(q, pos, n, valid ? n : 0);
             unsigned bad_chars = 0;
+            int n_chunks = 0;
+            // the next sub-batch's queue entries (looked at when the scan of this one is over)
+            const int64_t idx_n = base + 4 * WAVE + lane;
+            const bool next_sub = !MULTI && sub + 4 < tile / WAVE && base + 4 * WAVE < total;      // wave-uniform
+            bool valid_n = false;
+            int r_n = 0;
+            unsigned key_n = 0;
+            if (next_sub) {
+                valid_n = idx_n < total;
+                if (valid_n) r_n = a.queue ? a.queue[idx_n] : (int)idx_n;
+                if (skip_cols && valid_n) key_n = a.queue_keys[idx_n];
+            }
+            SCAN_STAMP(1, 0);
             for (;;) {
+                ++n_chunks;
                 const unsigned long long act = __ballot(!done && j < n);
                 if (!act) break;
                 if constexpr (!MULTI) {
@@ -1910,6 +1940,16 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_back_
                 }
             }
             if (bad_chars & 0x80808080u) invalid = true;
+            pf_have = next_sub;
+            if (next_sub) {
+                if (r_n < 0) { valid_n = false; r_n = 0; }
+                int64_t o_n = 0, n_n = 0;
+                if (valid_n) read_extent(a.offsets, a.lens, (int64_t)r_n, o_n, n_n);
+                // (a read beyond max_read_len keeps its length here: the next sub-batch flags it as this code would)
+                pf_valid = valid_n; pf_r = r_n; pf_key = key_n; pf_off = o_n;
+                pf_n = n_n > (int64_t)0x7FFFFFFF ? 0x7FFFFFFF : (int)n_n;
+            }
+            SCAN_STAMP(2, n_chunks);
 
             int o0 = 0, o1 = 0;
             int cls;
@@ -1917,6 +1957,7 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_back_
             else cls = bs32_finish<XR, !MULTI>(st, n, j0, p, [&](int i) { return s_thr_last[i]; }, o0, o1, stopped);
             if (exact) { cls = BS_EXACT_FULL; o0 = exact_j; }
             if (retry) { cls = BS_NONE; valid_out = false; }
+            SCAN_STAMP(3, 0);
             if (MULTI) {
                 // invalid reads were flagged by the prefilter (it sees every character); matches are merged
                 // with one atomic max on the read's best key
@@ -1926,22 +1967,19 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_back_
                     else if (cls == BS_SUBS_FULL) atomicMax(a.best_key + r, pack_best(p.m - 2 * o1, o1, (int)adapter, p.m, o0 - p.m, o0));
                 }
             } else if (valid_out) {
-                if (invalid || cls == BS_NONE) {
-                    store_result(a.out6, a.status, a.best_adapter, a.adapter_index, a.merge_best, r, invalid, false,
-                                 0, 0, 0, 0, 0, 0);
-                } else if (cls == BS_EXACT_FULL) {
-                    store_result(a.out6, a.status, a.best_adapter, a.adapter_index, a.merge_best, r, false, true,
-                                 0, p.m, o0 - p.m, o0, p.m, 0);
-                } else if (cls == BS_EXACT_TAIL) {         // row o0 of the last column with o1 substitutions
-                    store_result(a.out6, a.status, a.best_adapter, a.adapter_index, a.merge_best, r, false, true,
-                                 0, o0, n - o0, n, o0 - 2 * o1, o1);
-                } else if (cls == BS_SUBS_FULL) {
-                    store_result(a.out6, a.status, a.best_adapter, a.adapter_index, a.merge_best, r, false, true,
-                                 0, p.m, o0 - p.m, o0, p.m - 2 * o1, o1);
-                } else if (cls == BS_INDEL1_FULL) {        // o1 = cost * 2 + (1: one deletion, 0: one insertion)
-                    store_result(a.out6, a.status, a.best_adapter, a.adapter_index, a.merge_best, r, false, true,
-                                 0, p.m, o0 - p.m + ((o1 & 1) ? 1 : -1), o0, p.m - 2 * (o1 >> 1) - (o1 & 1), o1 >> 1);
+                // the tuple of every class the scan finishes, put together with selects: ONE store sequence for the
+                // wave instead of one per class (as divergent branches: up to five times the store instructions)
+                const bool full = cls == BS_EXACT_FULL || cls == BS_SUBS_FULL || cls == BS_INDEL1_FULL;
+                const bool found = !invalid && (full || cls == BS_EXACT_TAIL);
+                int t1 = p.m, t2 = o0 - p.m, t3 = o0, sc = p.m, cost = 0;                 // EXACT_FULL
+                if (cls == BS_EXACT_TAIL) { t1 = o0; t2 = n - o0; t3 = n; sc = o0 - 2 * o1; cost = o1; }   // row o0, o1 substitutions
+                if (cls == BS_SUBS_FULL) { sc = p.m - 2 * o1; cost = o1; }
+                if (cls == BS_INDEL1_FULL) {              // o1 = cost * 2 + (1: one deletion, 0: one insertion)
+                    t2 = o0 - p.m + ((o1 & 1) ? 1 : -1); sc = p.m - 2 * (o1 >> 1) - (o1 & 1); cost = o1 >> 1;
                 }
+                if (invalid || cls != BS_DP)
+                    store_result(a.out6, a.status, a.best_adapter, a.adapter_index, a.merge_best, r, invalid, found,
+                                 0, t1, t2, t3, sc, cost);
             }
             const bool to_dp = valid_out && !invalid && cls == BS_DP;
             const bool to_back = to_dp && (o1 & 1);
@@ -1965,6 +2003,10 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_back_
                     s_list[3 * e] = item; s_list[3 * e + 1] = o0; s_list[3 * e + 2] = o1;
                 }
             }
+            SCAN_STAMP(4, 0);
+#ifdef SCAN_TRACE
+            if (blockIdx.x == 11 && wave == 1) ++trace_i;
+#endif
         }
 
         // flush the tile's DP work list
