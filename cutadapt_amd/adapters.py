@@ -189,21 +189,80 @@ def _generate_adapter_name() -> str:
 class BatchMatches:
     """Array-form result of ``match_to_batch``: per read the 6-tuple in *match coordinates*
     (astart, astop, rstart, rstop, score, errors), a found flag, which adapter won and whether
-    the match removes the sequence before (True) or after (False) it.  Everything is numpy on
-    the host; ``match(i)`` builds the reference-style Match object for one read on demand."""
+    the match removes the sequence before (True) or after (False) it.
 
-    def __init__(self, coords: np.ndarray, found: np.ndarray, adapter_index: np.ndarray,
-                 adapters: Sequence["SingleAdapter"], remove_before: np.ndarray, reads=None):
-        self.coords = coords
-        self.found = found
-        self.adapter_index = adapter_index
+    The result of a single adapter STAYS ON THE DEVICE: ``device_coords()`` / ``device_found()`` are the tensors a
+    device-side pipeline goes on with (cah_trim_decide_device ...), and the numpy views ``coords`` / ``found`` /
+    ``adapter_index`` / ``remove_before`` are made on first access (24 B per read over PCIe plus a host copy -- what
+    used to bound ``match_to_batch`` at a fraction of the kernels' rate).  ``match(i)`` builds the reference-style
+    Match object for one read on demand."""
+
+    def __init__(self, coords=None, found=None, adapter_index=None, adapters: Sequence["SingleAdapter"] = (),
+                 remove_before=None, reads=None, device_result=None, mirror_m: Optional[int] = None,
+                 remove_before_fn=None):
+        self._coords, self._found = coords, found
+        self._adapter_index, self._remove_before = adapter_index, remove_before
         self.adapters = list(adapters)
-        self.remove_before = remove_before
         self._reads = reads          # ReadBatch or list[str]; needed only for Match objects
         self._strings = None
+        self._res = device_result    # batch.BatchResult (device tensors) or None
+        self._mirror_m = mirror_m    # Rightmost* adapters: the tuples refer to the reversed read (length of the adapter)
+        self._remove_before_fn = remove_before_fn
+        self._dev_coords = None
+
+    # ---- device side -------------------------------------------------------------------------------
+    def device_found(self):
+        """bool tensor on the device (single-adapter results only)"""
+        return self._res.status == _lib.MATCH
+
+    def device_coords(self):
+        """int32 [n, 6] tensor on the device in match coordinates (single-adapter results only)"""
+        if self._dev_coords is None:
+            c = self._res.out6
+            if self._mirror_m is not None:
+                import torch
+                lens = self._reads.lengths().to(torch.int32)
+                m = self._mirror_m
+                mirrored = torch.stack([m - c[:, 1], m - c[:, 0], lens - c[:, 3], lens - c[:, 2], c[:, 4], c[:, 5]], dim=1)
+                c = torch.where(self.device_found()[:, None], mirrored, torch.zeros_like(c))
+            self._dev_coords = c
+        return self._dev_coords
+
+    # ---- host side, on demand ------------------------------------------------------------------------
+    @property
+    def coords(self) -> np.ndarray:
+        if self._coords is None:
+            self._coords = self.device_coords().cpu().numpy().astype(np.int64)
+        return self._coords
+
+    @coords.setter
+    def coords(self, value) -> None:
+        self._coords = value
+
+    @property
+    def found(self) -> np.ndarray:
+        if self._found is None:
+            self._found = (self._res.status == _lib.MATCH).cpu().numpy()
+        return self._found
+
+    @found.setter
+    def found(self, value) -> None:
+        self._found = value
+
+    @property
+    def adapter_index(self) -> np.ndarray:
+        if self._adapter_index is None:
+            self._adapter_index = np.zeros(len(self), dtype=np.int32)
+        return self._adapter_index
+
+    @property
+    def remove_before(self) -> np.ndarray:
+        if self._remove_before is None:
+            self._remove_before = self._remove_before_fn(self.coords, self.found)
+        return self._remove_before
 
     def __len__(self):
-        return len(self.found)
+        return len(self._found) if self._found is not None else int(self._res.status.shape[0])
 
     def _sequence(self, i: int) -> str:
         if self._strings is None:
@@ -400,20 +459,13 @@ class SingleAdapter(Adapter, ABC):
         return self._batch_matches(_b.match_batch(self._fused_plan, work), batch)
 
     def _batch_matches(self, res, batch) -> BatchMatches:
-        """device result of this adapter's fused plan -> host arrays in match coordinates"""
-        out6, status, _ = res.cpu()
-        _raise_if_invalid(status, batch)
-        found = status == _lib.MATCH
-        coords = out6.astype(np.int64)
-        if self._reverse_reads:
-            lens = batch.lengths().cpu().numpy()
-            m = len(self.sequence)
-            mirrored = np.stack([m - coords[:, 1], m - coords[:, 0], lens - coords[:, 3],
-                                 lens - coords[:, 2], coords[:, 4], coords[:, 5]], axis=1)
-            coords = np.where(found[:, None], mirrored, 0)
-        n = len(found)
-        return BatchMatches(coords, found, np.zeros(n, dtype=np.int32), [self],
-                            self._remove_before_array(coords, found), reads=batch)
+        """device result of this adapter's fused plan -> BatchMatches in match coordinates; nothing but one flag (was
+        a read refused?) crosses PCIe here"""
+        if batch.n_reads and bool((res.status == _lib.INVALID).any().item()):
+            _lib.raise_invalid_reads(int(batch.lengths().max().item()))
+        return BatchMatches(adapters=[self], reads=batch, device_result=res,
+                            mirror_m=len(self.sequence) if self._reverse_reads else None,
+                            remove_before_fn=self._remove_before_array)
 
     def _remove_before_array(self, coords, found) -> np.ndarray:
         return np.full(len(found), self._remove_before, dtype=bool)

@@ -10,6 +10,7 @@ PyTorch is used only as the owner of device memory and streams; the kernels are 
 through the C ABI with raw pointers.
 """
 import ctypes as C
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -48,7 +49,8 @@ class ReadBatch:
     """n reads packed in HBM: ``seqs`` uint8[total], ``offsets`` int64[n+1] (or int64[n] plus
     ``lens`` int32[n] for sub-sequence views)."""
 
-    def __init__(self, seqs, offsets, lens=None, n_reads: Optional[int] = None, validated: bool = False):
+    def __init__(self, seqs, offsets, lens=None, n_reads: Optional[int] = None, validated: bool = False,
+                 uniform_len: Optional[int] = None):
         torch = _torch()
         if not (seqs.is_cuda and offsets.is_cuda):
             raise ValueError("ReadBatch needs CUDA/HIP tensors; use from_strings()/from_host()")
@@ -63,6 +65,9 @@ class ReadBatch:
             n_reads = int(lens.numel()) if lens is not None else int(offsets.numel()) - 1
         self.n_reads = int(n_reads)
         self.validated = validated
+        # every read has this length and read 0 starts at seqs[0] (None: not known): the batch then takes
+        # cah_match_batch_uniform -- no offsets array is read on the device
+        self.uniform_len = None if (uniform_len is None or lens is not None) else int(uniform_len)
         self._workspace = None
 
     # ---- constructors ---------------------------------------------------------------------
@@ -81,7 +86,13 @@ class ReadBatch:
             o_host = o_host.copy()
         s = torch.from_numpy(s_host).to(device)
         o = torch.from_numpy(o_host).to(device)
-        return cls(s, o, validated=validated)
+        # equally long reads starting at byte 0 (one vectorised look at the host offsets)
+        uniform = None
+        if len(o_host) >= 2 and o_host[0] == 0:
+            step = int(o_host[1])
+            if step >= 1 and int(o_host[-1]) == step * (len(o_host) - 1) and bool((np.diff(o_host) == step).all()):
+                uniform = step
+        return cls(s, o, validated=validated, uniform_len=uniform)
 
     @classmethod
     def from_strings(cls, reads: Sequence[str], device=None):
@@ -106,7 +117,7 @@ class ReadBatch:
                 seed, first_index, n_reads, read_len, prob_u32(p_adapter), prob_u32(p_edit),
                 prob_u16(p_n), b"".join(ads), off, len(ads), seqs.data_ptr(), offsets.data_ptr(),
                 _stream_ptr()))
-        return cls(seqs, offsets, validated=True)
+        return cls(seqs, offsets, validated=True, uniform_len=read_len if read_len >= 1 else None)
 
     # ---- helpers ----------------------------------------------------------------------------
     def __len__(self):
@@ -254,11 +265,17 @@ def match_batch(plan: "_lib.Plan", batch: ReadBatch, out: Optional[BatchResult] 
                           torch.empty(n, dtype=torch.int32, device=batch.device))
     if n:
         ws = batch.workspace(plan)
+        best_ptr = out.best_adapter.data_ptr() if out.best_adapter is not None else None
         with torch.cuda.device(batch.device):
-            _lib.check(_lib.lib().cah_match_batch(
-                plan.handle, batch.seqs.data_ptr(), batch.offsets.data_ptr(), batch._lens_ptr(), n,
-                out.out6.data_ptr(), out.best_adapter.data_ptr() if out.best_adapter is not None else None,
-                out.status.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr()))
+            if batch.uniform_len and batch.lens is None and not os.environ.get("CAH_NO_UNIFORM"):
+                # equally long reads (what a sequencer emits): the entry point without an offsets array
+                _lib.check(_lib.lib().cah_match_batch_uniform(
+                    plan.handle, batch.seqs.data_ptr(), batch.uniform_len, n, out.out6.data_ptr(), best_ptr,
+                    out.status.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr()))
+            else:
+                _lib.check(_lib.lib().cah_match_batch(
+                    plan.handle, batch.seqs.data_ptr(), batch.offsets.data_ptr(), batch._lens_ptr(), n,
+                    out.out6.data_ptr(), best_ptr, out.status.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr()))
     return out
 
 

@@ -1118,13 +1118,19 @@ static int64_t scan_retry_cap(int64_t cap) {
 // Aligner / comparer over a work list (d_queue == NULL: all reads).  3' adapters with unit costs go
 // through the cost scan first (k_back_scan finishes most reads, the rest reach k_dp_packed with an exact
 // column window); everything else runs the cell kernel directly.
+// equally long reads the host vouches for (cah_match_batch_uniform): read r = d_seqs[first + r * len ..); len == 0: the
+// packed layout (offsets / lens)
+struct UniformLayout { int64_t first = 0; int32_t len = 0; };
+
 static int run_aligner(const cah_plan* plan, const PlanDeviceCopy* pd, int32_t adapter, const uint8_t* d_seqs,
                        const int64_t* d_offsets, const int32_t* d_lens, int64_t n_reads,
                        const int32_t* d_queue, const unsigned long long* d_queue_count,
                        const uint8_t* d_queue_keys, const Workspace& ws, int32_t* d_out6,
-                       uint8_t* d_status, int32_t* d_best, int merge_best, hipStream_t s) {
+                       uint8_t* d_status, int32_t* d_best, int merge_best, hipStream_t s,
+                       const UniformLayout ul = UniformLayout()) {
     const CahMatcher& mt = plan->matchers[(size_t)adapter];
     DpArgs a;
+    a.uniform_first = ul.first; a.uniform_len = ul.len;
     a.matcher = pd->d_matchers + adapter;
     a.seqs = d_seqs; a.offsets = d_offsets; a.lens = d_lens; a.n_reads = n_reads;
     a.max_read_len = CAH_MAX_READ_LEN;
@@ -1147,6 +1153,7 @@ static int run_aligner(const cah_plan* plan, const PlanDeviceCopy* pd, int32_t a
                         mt.m, cah_plan_workspace_bytes(plan, n_reads));
         const LongDeviceCopy& ld = pd->d_long[(size_t)adapter];
         LongArgs la;
+        la.uniform_first = ul.first; la.uniform_len = ul.len;
         la.lm = ld.d_lm; la.ref = ld.d_ref; la.ncnt = ld.d_ncnt;
         la.seqs = d_seqs; la.offsets = d_offsets; la.lens = d_lens; la.n_reads = n_reads; la.max_read_len = CAH_MAX_READ_LEN;
         la.queue = d_queue; la.queue_count = d_queue_count; la.work_counter = ws.counters + WS_DPWORK;
@@ -1166,6 +1173,7 @@ static int run_aligner(const cah_plan* plan, const PlanDeviceCopy* pd, int32_t a
     if (mt.kind == CAH_KIND_ALIGNER) {
         if (mt.scan_ok) {
             ScanArgs sa;
+            sa.uniform_first = ul.first; sa.uniform_len = ul.len;
             sa.matcher = a.matcher;
             sa.seqs = d_seqs; sa.offsets = d_offsets; sa.lens = d_lens; sa.n_reads = n_reads;
             sa.max_read_len = CAH_MAX_READ_LEN;
@@ -1237,7 +1245,8 @@ static int run_filter(const cah_plan* plan, const PlanDeviceCopy* pd, int32_t ad
                       uint8_t* d_present, uint8_t* d_status, int32_t* d_queue,
                       unsigned long long* d_queue_count, uint8_t* d_queue_keys,
                       unsigned long long* d_work_counter, const unsigned long long* d_batch_flag, hipStream_t s,
-                      int32_t* d_clear_out6 = nullptr, int32_t* d_clear_best = nullptr) {
+                      int32_t* d_clear_out6 = nullptr, int32_t* d_clear_best = nullptr,
+                      const UniformLayout ul = UniformLayout()) {
     const CahMatcher& mt = plan->matchers[(size_t)adapter];
     if (mt.n_words > 1024)
         return fail(CAH_EUNSUPPORTED, "adapter %d: %d packed k-mer words exceed the 1024-word limit of the prefilter kernel",
@@ -1253,7 +1262,7 @@ static int run_filter(const cah_plan* plan, const PlanDeviceCopy* pd, int32_t ad
     f.batch_flag = nullptr;
     f.lean = nullptr;
     f.stream_n_lo = 0; f.stream_n_hi = -1;
-    f.uniform_first = 0; f.uniform_len = 0;
+    f.uniform_first = ul.first; f.uniform_len = ul.len;
     f.clear_out6 = mode == 1 ? d_clear_out6 : nullptr;
     f.clear_best = f.clear_out6 ? d_clear_best : nullptr;
     if (!t_header_fresh) {
@@ -1265,7 +1274,7 @@ static int run_filter(const cah_plan* plan, const PlanDeviceCopy* pd, int32_t ad
         // 3' adapter plans: k_filter_lean.  For a packed batch the device-side batch check (*d_batch_flag)
         // picks its equal-length or its ragged variant -- both are launched, one leaves at once, no host
         // sync; views (explicit lengths) and calls without a check take the ragged variant.
-        f.batch_flag = d_lens ? nullptr : d_batch_flag;
+        f.batch_flag = (d_lens || ul.len > 0) ? nullptr : d_batch_flag;
         f.lean = pd->d_lean + adapter;
         const CahLeanFilter& lf = plan->lean[(size_t)adapter];
         HIP_TRY(launch_filter_lean(f, mode, lf.n_lead, lf.n_gated, lf.lead_delay, lf.tw_ok, lf.n_tw, pd->n_cus, s));
@@ -1320,7 +1329,7 @@ int cah_kmers_present_batch(const cah_plan* plan, int32_t adapter, const uint8_t
 static int match_batch_multi(const cah_plan* plan, const PlanDeviceCopy* pd, const uint8_t* d_seqs,
                              const int64_t* d_offsets, const int32_t* d_lens, int64_t n_reads, int32_t* d_out6,
                              int32_t* d_best_adapter, uint8_t* d_status, const Workspace& ws, char* extra,
-                             hipStream_t s) {
+                             hipStream_t s, const UniformLayout ul = UniformLayout()) {
     const MultiPlan& mp = plan->multi;
     const int64_t A = (int64_t)plan->matchers.size();
     const int64_t cap = multi_pair_cap(plan, n_reads);
@@ -1337,6 +1346,7 @@ static int match_batch_multi(const cah_plan* plan, const PlanDeviceCopy* pd, con
         HIP_TRY(hipMemsetAsync(counters, 0, WS_HEADER, s));
         {
             MultiFilterArgs f;
+            f.uniform_first = ul.first; f.uniform_len = ul.len;
             f.hdr = pd->d_mhdr; f.dir = pd->d_mdir; f.entries = pd->d_mentries; f.bitmap = pd->d_mbitmap;
             f.seqs = d_seqs; f.offsets = d_offsets; f.lens = d_lens;
             f.first_read = lo; f.n_reads = cnt; f.max_read_len = CAH_MAX_READ_LEN;
@@ -1347,6 +1357,7 @@ static int match_batch_multi(const cah_plan* plan, const PlanDeviceCopy* pd, con
         }
         {
             ScanArgs sa;
+            sa.uniform_first = ul.first; sa.uniform_len = ul.len;
             sa.matcher = pd->d_matchers;
             sa.seqs = d_seqs; sa.offsets = d_offsets; sa.lens = d_lens; sa.n_reads = cnt * A;
             sa.max_read_len = CAH_MAX_READ_LEN;
@@ -1367,6 +1378,7 @@ static int match_batch_multi(const cah_plan* plan, const PlanDeviceCopy* pd, con
         }
         {
             DpArgs a;
+            a.uniform_first = ul.first; a.uniform_len = ul.len;
             a.matcher = pd->d_matchers;
             a.seqs = d_seqs; a.offsets = d_offsets; a.lens = d_lens; a.n_reads = cnt * A;
             a.max_read_len = CAH_MAX_READ_LEN;
@@ -1385,10 +1397,11 @@ static int match_batch_multi(const cah_plan* plan, const PlanDeviceCopy* pd, con
     return CAH_OK;
 }
 
-int cah_match_batch(const cah_plan* plan, const uint8_t* d_seqs, const int64_t* d_offsets,
-                    const int32_t* d_lens, int64_t n_reads, int32_t* d_out6, int32_t* d_best_adapter,
-                    uint8_t* d_status, void* d_workspace, size_t workspace_bytes, void* stream) {
-    int rc = check_batch(plan, d_seqs, d_offsets, n_reads);
+static int match_batch_impl(const cah_plan* plan, const uint8_t* d_seqs, const int64_t* d_offsets,
+                            const int32_t* d_lens, const UniformLayout ul, int64_t n_reads, int32_t* d_out6,
+                            int32_t* d_best_adapter, uint8_t* d_status, void* d_workspace, size_t workspace_bytes,
+                            void* stream) {
+    int rc = check_batch(plan, d_seqs, ul.len > 0 ? (const void*)d_seqs : (const void*)d_offsets, n_reads);
     if (rc) return rc;
     if (n_reads == 0) return CAH_OK;
     if (!d_out6 || !d_status) return fail(CAH_EINVAL, "output pointers are NULL");
@@ -1422,7 +1435,7 @@ int cah_match_batch(const cah_plan* plan, const uint8_t* d_seqs, const int64_t* 
     }
     // one pass over the offsets decides, on the device, which prefilter kernel works on this batch
     const unsigned long long* d_batch_flag = nullptr;
-    if (!d_lens && !tiny) {
+    if (!d_lens && !tiny && ul.len == 0) {
         bool any_lean = false;
         for (size_t ad = 0; ad < plan->matchers.size(); ad++)
             any_lean |= runs_filter(plan->matchers[ad]) && plan->matchers[ad].kind != CAH_KIND_KMER_ONLY && plan->lean[ad].ok;
@@ -1434,7 +1447,7 @@ int cah_match_batch(const cah_plan* plan, const uint8_t* d_seqs, const int64_t* 
     }
     if (plan->multi.hdr.ok && workspace_bytes >= cah_plan_workspace_bytes(plan, n_reads))
         return match_batch_multi(plan, pd, d_seqs, d_offsets, d_lens, n_reads, d_out6, d_best_adapter, d_status, ws,
-                                 (char*)d_workspace + cah_workspace_bytes(n_reads), s);
+                                 (char*)d_workspace + cah_workspace_bytes(n_reads), s, ul);
     for (int32_t ad = 0; ad < (int32_t)plan->matchers.size(); ad++) {
         const CahMatcher& mt = plan->matchers[(size_t)ad];
         if (mt.kind == CAH_KIND_KMER_ONLY) continue;
@@ -1443,19 +1456,42 @@ int cah_match_batch(const cah_plan* plan, const uint8_t* d_seqs, const int64_t* 
             rc = run_filter(plan, pd, ad, d_seqs, d_offsets, d_lens, n_reads, 1, nullptr, d_status, ws.queue,
                             counters + WS_QCOUNT, ws.keys, counters + 0, d_batch_flag, s,
                             (filter_clears && ad == first_aligner) ? d_out6 : nullptr,
-                            (filter_clears && ad == first_aligner) ? d_best_adapter : nullptr);
+                            (filter_clears && ad == first_aligner) ? d_best_adapter : nullptr, ul);
             if (rc) return rc;
             // merge mode 2: the plan's first adapter writes into zeroed rows -- nothing to compare with (kernels.hip,
             // store_result)
             rc = run_aligner(plan, pd, ad, d_seqs, d_offsets, d_lens, n_reads, ws.queue, counters + WS_QCOUNT,
-                             ws.keys, ws, d_out6, d_status, d_best_adapter, ad == first_aligner ? 2 : 1, s);
+                             ws.keys, ws, d_out6, d_status, d_best_adapter, ad == first_aligner ? 2 : 1, s, ul);
         } else {
             rc = run_aligner(plan, pd, ad, d_seqs, d_offsets, d_lens, n_reads, nullptr, nullptr, nullptr,
-                             ws, d_out6, d_status, d_best_adapter, 1, s);
+                             ws, d_out6, d_status, d_best_adapter, 1, s, ul);
         }
         if (rc) return rc;
     }
     return CAH_OK;
+}
+
+int cah_match_batch(const cah_plan* plan, const uint8_t* d_seqs, const int64_t* d_offsets,
+                    const int32_t* d_lens, int64_t n_reads, int32_t* d_out6, int32_t* d_best_adapter,
+                    uint8_t* d_status, void* d_workspace, size_t workspace_bytes, void* stream) {
+    return match_batch_impl(plan, d_seqs, d_offsets, d_lens, UniformLayout(), n_reads, d_out6, d_best_adapter, d_status,
+                            d_workspace, workspace_bytes, stream);
+}
+
+// Equally long reads, back to back, no offsets array: read r = d_seqs[r * read_len, (r + 1) * read_len) -- what a
+// sequencer emits and what every BASELINE config is.  Nothing has to look at 8 bytes of offset per read to find
+// that out (k_uniform_check), the prefilter is ONE launch instead of one per candidate kernel, and the scan / DP
+// kernels compute a survivor's address instead of fetching it.
+int cah_match_batch_uniform(const cah_plan* plan, const uint8_t* d_seqs, int32_t read_len, int64_t n_reads,
+                            int32_t* d_out6, int32_t* d_best_adapter, uint8_t* d_status, void* d_workspace,
+                            size_t workspace_bytes, void* stream) {
+    if (read_len < 1 || read_len > CAH_MAX_READ_LEN)
+        return fail(CAH_EINVAL, "read_len out of range (1..%d)", CAH_MAX_READ_LEN);
+    if (n_reads > 0 && !d_seqs) return fail(CAH_EINVAL, "seqs is NULL");
+    UniformLayout ul;
+    ul.first = 0; ul.len = read_len;
+    return match_batch_impl(plan, d_seqs, nullptr, nullptr, ul, n_reads, d_out6, d_best_adapter, d_status, d_workspace,
+                            workspace_bytes, stream);
 }
 
 int cah_validate_ascii_batch(const uint8_t* d_seqs, const int64_t* d_offsets, const int32_t* d_lens,

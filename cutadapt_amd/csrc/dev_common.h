@@ -17,6 +17,13 @@ __device__ __forceinline__ void read_extent(const int64_t* offsets, const int32_
     n = lens ? (int64_t)lens[r] : offsets[r + 1] - off;
 }
 
+// ... or, for a batch of equally long reads the host knows about (ulen > 0), at ufirst + r * ulen: no offsets array
+__device__ __forceinline__ void read_extent(const int64_t* offsets, const int32_t* lens, const int64_t ufirst,
+                                            const int32_t ulen, int64_t r, int64_t& off, int64_t& n) {
+    if (ulen > 0) { off = ufirst + r * (int64_t)ulen; n = ulen; }
+    else read_extent(offsets, lens, r, off, n);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Work distribution: waves pull chunks of 64 work items from a device counter ("dequeue",
 // the cheapest cross-CU primitive on this chip) so that long and short reads balance.

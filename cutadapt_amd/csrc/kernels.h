@@ -29,8 +29,8 @@ struct FilterArgs {
                                         // takes its own range, the per-lane uniform kernel leaves the union alone)
     // equally long reads the HOST knows about (cah_match_batch_uniform): read r is seqs[uniform_first + r * uniform_len
     // ...) -- no offsets array is read, no batch check is needed.  uniform_len == 0: lengths come from offsets.
-    int64_t uniform_first;
-    int32_t uniform_len;
+    int64_t uniform_first = 0;
+    int32_t uniform_len = 0;
     int32_t* clear_best;             // with clear_out6, may be NULL: best_adapter[r] = -1 for the same reads
     int32_t* clear_out6;             // MODE 1, may be NULL: the result rows (6 x int32 per read) of every read the
                                      // kernel looks at are zeroed on the way (rows of reads that match are written
@@ -38,6 +38,11 @@ struct FilterArgs {
 };
 
 struct DpArgs {
+    // equally long reads the HOST knows about (cah_match_batch_uniform): read r = seqs[uniform_first + r * uniform_len ..),
+    // `offsets` is not read.  0: the packed layout (offsets / lens).
+    int64_t uniform_first = 0;
+    int32_t uniform_len = 0;
+
     const CahMatcher* matcher;
     const uint8_t* seqs;
     const int64_t* offsets;
@@ -85,6 +90,11 @@ __host__ __device__ inline unsigned long long pack_best(int score, int errors, i
 
 // k_back_scan: bit-parallel cost scan + classification (back_scan.h) of the reads of a work list
 struct ScanArgs {
+    // equally long reads the HOST knows about (cah_match_batch_uniform): read r = seqs[uniform_first + r * uniform_len ..),
+    // `offsets` is not read.  0: the packed layout (offsets / lens).
+    int64_t uniform_first = 0;
+    int32_t uniform_len = 0;
+
     const CahMatcher* matcher;
     const uint8_t* seqs;
     const int64_t* offsets;
@@ -166,6 +176,11 @@ hipError_t launch_back_scan(const ScanArgs& a, int64_t max_items, int n_cus, hip
 
 // multi.hip: the fused multi-adapter prefilter and the final decode of the per-read best keys
 struct MultiFilterArgs {
+    // equally long reads the HOST knows about (cah_match_batch_uniform): read r = seqs[uniform_first + r * uniform_len ..),
+    // `offsets` is not read.  0: the packed layout (offsets / lens).
+    int64_t uniform_first = 0;
+    int32_t uniform_len = 0;
+
     const CahMultiHeader* hdr;
     const CahMultiDir* dir;
     const CahMultiEntry* entries;
@@ -186,6 +201,11 @@ hipError_t launch_multi_decode(const unsigned long long* best_key, int64_t n_rea
                                int32_t* best_adapter, int n_cus, hipStream_t s);
 // long.hip: adapters longer than 64 characters (column in HBM scratch)
 struct LongArgs {
+    // equally long reads the HOST knows about (cah_match_batch_uniform): read r = seqs[uniform_first + r * uniform_len ..),
+    // `offsets` is not read.  0: the packed layout (offsets / lens).
+    int64_t uniform_first = 0;
+    int32_t uniform_len = 0;
+
     const CahLongMatcher* lm;
     const uint8_t* ref;              // encoded adapter, m bytes
     const int32_t* ncnt;             // n_counts, m + 1 entries

@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256, CAH_FILTER_WAVES) void k_filter(FilterArgs a) 
             if (MODE == 1 && a.clear_out6)
                 clear_rows(a.clear_out6, a.clear_best, base, (int)(a.n_reads - base < WAVE ? a.n_reads - base : WAVE), lane);
             int64_t off = 0, n64 = 0;
-            if (valid) read_extent(a.offsets, a.lens, r, off, n64);
+            if (valid) read_extent(a.offsets, a.lens, a.uniform_first, a.uniform_len, r, off, n64);
             const uint8_t* q = a.seqs + off;
             bool hit = false, invalid = false;
             if (n64 > a.max_read_len) { invalid = true; n64 = 0; }
@@ -660,7 +660,9 @@ __global__ __launch_bounds__(256, LEAN_WAVES) void k_filter_lean(FilterArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t s_tab[LeanLayout<DL, NL, NG>::WORDS];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // the batch check decides which variant works (no check was made for views: they count as ragged)
-    if (a.batch_flag ? (*a.batch_flag != 0ull) == UNIFORM : UNIFORM) return;
+    // (uniform_len > 0: the host vouches for equally long reads -- cah_match_batch_uniform)
+    const bool batch_is_uniform = a.uniform_len > 0 || (a.batch_flag && *a.batch_flag == 0ull);
+    if (batch_is_uniform != UNIFORM) return;
     const CahLeanFilter* lf = a.lean;
     unsigned char* sp = smem;
     uint32_t* s_ginit = reinterpret_cast<uint32_t*>(sp);         sp += (size_t)CAH_LEAN_MAX_GATED * CAH_GATE_LEN * sizeof(uint32_t);
@@ -672,8 +674,8 @@ __global__ __launch_bounds__(256, LEAN_WAVES) void k_filter_lean(FilterArgs a) {
     long long& s_tile = *reinterpret_cast<long long*>(sp + 8);
     unsigned& s_count = *reinterpret_cast<unsigned*>(sp + 16);
     unsigned* s_scratch = reinterpret_cast<unsigned*>(sp + 32);
-    const int64_t first = UNIFORM ? a.offsets[0] : 0;
-    const int n_uniform = UNIFORM ? (int)(a.offsets[1] - first) : 0;   // every read has this length
+    const int64_t first = !UNIFORM ? 0 : (a.uniform_len > 0 ? a.uniform_first : a.offsets[0]);
+    const int n_uniform = !UNIFORM ? 0 : (a.uniform_len > 0 ? a.uniform_len : (int)(a.offsets[1] - first));   // every read has this length
     // equally long short reads are the streaming kernel's (k_filter_stream)
     if (UNIFORM && n_uniform >= a.stream_n_lo && n_uniform <= a.stream_n_hi && a.n_reads * (int64_t)n_uniform >= 16) return;
     lean_tables_to_lds<DL, NL, NG>(lf, s_tab);
@@ -708,7 +710,7 @@ __global__ __launch_bounds__(256, LEAN_WAVES) void k_filter_lean(FilterArgs a) {
                 q = a.seqs + first + (valid ? r : base) * (int64_t)n;
             } else {
                 int64_t off = 0, n64 = 0;
-                if (valid) read_extent(a.offsets, a.lens, r, off, n64);
+                if (valid) read_extent(a.offsets, a.lens, a.uniform_first, a.uniform_len, r, off, n64);
                 if (n64 > a.max_read_len) { too_long = true; n64 = 0; }
                 n = (int)n64;
                 q = a.seqs + off;
@@ -828,8 +830,8 @@ __global__ __launch_bounds__(STREAM_BLOCK_WAVES * WAVE, STREAM_WAVES) void k_fil
     static_assert(sizeof(StreamLds) + (size_t)TILE * 3 + CAH_QUEUE_BINS * 8 + 64 <= 160 * 1024, "k_filter_stream: LDS");
     if (a.batch_flag ? *a.batch_flag != 0ull : false) return;           // ragged batch: k_filter_lean<false, ..>
     const CahLeanFilter* lf = a.lean;
-    const int64_t first = a.offsets[0];
-    const int n = (int)(a.offsets[1] - first);                          // every read has this length
+    const int64_t first = a.uniform_len > 0 ? a.uniform_first : a.offsets[0];
+    const int n = a.uniform_len > 0 ? a.uniform_len : (int)(a.offsets[1] - first);     // every read has this length
     if (n < a.stream_n_lo || n > a.stream_n_hi) return;                 // another instance's (or k_filter_lean's) batch
     const int64_t total = a.n_reads * (int64_t)n;                       // bytes of the batch
     if (total < 16) return;                                             // k_filter_lean<true, ..> takes it (same test there)
@@ -1157,7 +1159,7 @@ __global__ __launch_bounds__(256, CAH_DP_WAVES(ROWS)) void k_dp(DpArgs a) {
         int64_t r = 0;
         if (valid) r = a.queue ? (int64_t)a.queue[idx] : idx;
         int64_t off = 0, n64 = 0;
-        if (valid) read_extent(a.offsets, a.lens, r, off, n64);
+        if (valid) read_extent(a.offsets, a.lens, a.uniform_first, a.uniform_len, r, off, n64);
         bool invalid = false;
         if (n64 > a.max_read_len) { invalid = true; n64 = 0; }
         const int n = (int)n64;
@@ -1544,7 +1546,7 @@ __global__ __launch_bounds__(256, CAH_DPP_WAVES(ROWS)) void k_dp_packed(DpArgs a
             return MULTI ? tab_base + multi_tab_index(c & 0xFFu) : (c & (CAH_TABLE_CHARS - 1));
         };
         int64_t off = 0, n64 = 0;
-        if (valid) read_extent(a.offsets, a.lens, r, off, n64);
+        if (valid) read_extent(a.offsets, a.lens, a.uniform_first, a.uniform_len, r, off, n64);
         bool invalid = false;
         if (n64 > a.max_read_len) { invalid = true; n64 = 0; }
         const int n = (int)n64;
@@ -1811,7 +1813,7 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_back_
             }
             int64_t off = 0, n64 = 0;
             if (!MULTI && pf_have) { valid = pf_valid; r = pf_r; key = pf_key; off = pf_off; n64 = pf_n; }
-            else if (valid) read_extent(a.offsets, a.lens, r, off, n64);
+            else if (valid) read_extent(a.offsets, a.lens, a.uniform_first, a.uniform_len, r, off, n64);
             bool invalid = false;
             if (n64 > a.max_read_len) { invalid = true; n64 = 0; }
             const int n = (int)n64;
@@ -1944,7 +1946,7 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_back_
             if (next_sub) {
                 if (r_n < 0) { valid_n = false; r_n = 0; }
                 int64_t o_n = 0, n_n = 0;
-                if (valid_n) read_extent(a.offsets, a.lens, (int64_t)r_n, o_n, n_n);
+                if (valid_n) read_extent(a.offsets, a.lens, a.uniform_first, a.uniform_len, (int64_t)r_n, o_n, n_n);
                 // (a read beyond max_read_len keeps its length here: the next sub-batch flags it as this code would)
                 pf_valid = valid_n; pf_r = r_n; pf_key = key_n; pf_off = o_n;
                 pf_n = n_n > (int64_t)0x7FFFFFFF ? 0x7FFFFFFF : (int)n_n;
@@ -2065,7 +2067,7 @@ __global__ __launch_bounds__(256) void k_anchored_exact(DpArgs a) {
         if (idx >= total) continue;
         const int64_t r = a.queue ? (int64_t)a.queue[idx] : idx;
         int64_t off, n64;
-        read_extent(a.offsets, a.lens, r, off, n64);
+        read_extent(a.offsets, a.lens, a.uniform_first, a.uniform_len, r, off, n64);
         bool invalid = false;
         if (n64 > a.max_read_len) { invalid = true; n64 = 0; }
         const int n = (int)n64;
@@ -2360,7 +2362,7 @@ __global__ __launch_bounds__(256) void k_comparer(DpArgs a) {
         if (idx >= total) continue;
         const int64_t r = a.queue ? (int64_t)a.queue[idx] : idx;
         int64_t off, n64;
-        read_extent(a.offsets, a.lens, r, off, n64);
+        read_extent(a.offsets, a.lens, a.uniform_first, a.uniform_len, r, off, n64);
         bool invalid = false;
         if (n64 > a.max_read_len) { invalid = true; n64 = 0; }
         const int n = (int)n64;
@@ -2498,7 +2500,7 @@ hipError_t launch_filter_lean(const FilterArgs& a_in, int mode, int n_lead, int 
     // host synchronisation): the streaming kernel for equally long short reads, the per-lane uniform kernel for
     // equally long longer reads, the ragged kernel for everything else.  Views (explicit lengths) have no batch
     // check and go to the ragged variant directly.
-    const bool stream = !stream2 && a.batch_flag != nullptr && getenv_flag("CAH_NO_STREAM") == 0;
+    const bool stream = !stream2 && (a.batch_flag != nullptr || a.uniform_len > 0) && getenv_flag("CAH_NO_STREAM") == 0;
 #define CAH_STREAM_LAUNCH(DL, NL, NG, NU, UM, LO)                                                                   \
     do {                                                                                                            \
         const int tiles = (int)((a.n_reads + stream_tile(NL, NG) - 1) / stream_tile(NL, NG));                       \
@@ -2514,8 +2516,8 @@ hipError_t launch_filter_lean(const FilterArgs& a_in, int mode, int n_lead, int 
             CAH_STREAM_LAUNCH(DL, NL, NG, STREAM_NU_A, STREAM_UM_A, 0);                                             \
             CAH_STREAM_LAUNCH(DL, NL, NG, STREAM_NU_B, STREAM_UM_B, stream_max_len(STREAM_UM_A) + 1);               \
         }                                                                                                           \
-        if (a.batch_flag) hipLaunchKernelGGL((k_filter_lean<true, DL, NL, NG>), dim3(grid), dim3(256), lds, s, a);  \
-        hipLaunchKernelGGL((k_filter_lean<false, DL, NL, NG>), dim3(grid), dim3(256), lds, s, a);                   \
+        if (a.batch_flag || a.uniform_len > 0) hipLaunchKernelGGL((k_filter_lean<true, DL, NL, NG>), dim3(grid), dim3(256), lds, s, a);  \
+        if (a.uniform_len <= 0) hipLaunchKernelGGL((k_filter_lean<false, DL, NL, NG>), dim3(grid), dim3(256), lds, s, a);    \
     } while (0)
 #define CAH_LEAN_CLASS(NL, NG)                                                                                      \
     do {                                                                                                            \

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void k_dp_long(LongArgs a) {
         if (idx >= total) continue;
         const int64_t r = a.queue ? (int64_t)a.queue[idx] : idx;
         int64_t off, n64;
-        read_extent(a.offsets, a.lens, r, off, n64);
+        read_extent(a.offsets, a.lens, a.uniform_first, a.uniform_len, r, off, n64);
         bool invalid = false;
         if (n64 > a.max_read_len) { invalid = true; n64 = 0; }
         const int n = (int)n64;

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void k_multi_filter(MultiFilterArgs a) {
             const int64_t r = base + lane;
             const bool valid = r < last_read;
             int64_t off = 0, n64 = 0;
-            if (valid) read_extent(a.offsets, a.lens, r, off, n64);
+            if (valid) read_extent(a.offsets, a.lens, a.uniform_first, a.uniform_len, r, off, n64);
             bool too_long = false;
             if (n64 > a.max_read_len) { too_long = true; n64 = 0; }
             const int n = (int)n64;

@@ -968,10 +968,8 @@ class BatchPairedAdapterCutter:
         from . import batch as _b
         if not adapter._reverse_reads:
             return _b.match_batch(adapter._fused_plan, batch)
-        bm = adapter.match_to_batch(batch)                   # Rightmost*: mirrored on the host
-        out6 = torch.from_numpy(bm.coords.astype(np.int32)).to(batch.device)
-        status = torch.from_numpy(bm.found.astype(np.uint8)).to(batch.device)
-        return _b.BatchResult(out6, status)
+        bm = adapter.match_to_batch(batch)                   # Rightmost*: mirrored, on the device
+        return _b.BatchResult(bm.device_coords(), bm.device_found().to(torch.uint8))
 
     def process(self, request1, request2):
         """the adapter step of both mates: -> (res1, res2) like BatchAdapterCutter.process_arrays"""

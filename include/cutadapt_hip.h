@@ -162,6 +162,15 @@ int cah_match_batch(const cah_plan *plan, const uint8_t *d_seqs, const int64_t *
                     int32_t *d_best_adapter, uint8_t *d_status, void *d_workspace,
                     size_t workspace_bytes, void *stream);
 
+/* The same for a batch of EQUALLY LONG reads stored back to back without an offsets array: read r is
+ * d_seqs[r * read_len, (r + 1) * read_len) -- what a sequencer emits, what `cutadapt` sees for every untrimmed Illumina
+ * run (the reference has no batch call to compare with; per read it is Adapter.match_to, adapters.py:707-724, :815-832).
+ * Same results as cah_match_batch on the equivalent offsets; cheaper: nothing looks at 8 bytes of offset per read,
+ * the prefilter is one launch, the scan / DP kernels compute a survivor's address instead of fetching it. */
+int cah_match_batch_uniform(const cah_plan *plan, const uint8_t *d_seqs, int32_t read_len, int64_t n_reads,
+                            int32_t *d_out6, int32_t *d_best_adapter, uint8_t *d_status, void *d_workspace,
+                            size_t workspace_bytes, void *stream);
+
 /* bytes of device scratch the calls above need for n_reads reads (17.7 bytes per read + 6 KiB: counters, the
  * prefilter's survivor queue with keys, the cell-DP work list with its column windows, the cost scan's
  * straggler list) */

@@ -234,3 +234,40 @@ def test_stream_survivor_queue_is_exactly_kmers_present(hip, orc):
             finally:
                 os.environ.pop(env, None)
             assert ref == got, (env, seq, rate, ov, n, [(i, got[i], ref.get(i)) for i in got if got[i] != ref.get(i)][:5])
+
+
+def test_uniform_entry_point_equals_the_offsets_entry_point(hip, orc):
+    """cah_match_batch_uniform (no offsets array) against cah_match_batch on the same reads, for every kind of plan the
+    library has a path for: stream2 / lean / general prefilter, cost scan and cell DP, comparers, anchored adapters,
+    adapters beyond 64 characters, sequential and fused multi-adapter plans, reads longer than the streaming kernels take."""
+    import torch
+    from cutadapt_amd import adapters as A
+    from cutadapt_amd import _lib
+    from cutadapt_amd.batch import ReadBatch, match_batch
+    rng = random.Random(20250925)
+    long_ad = rs(rng, 80)
+    many = [rs(rng, 33) for _ in range(12)]
+    plans = [
+        ("back", A.BackAdapter(TRUSEQ, max_errors=0.1, min_overlap=3)._fused_plan, TRUSEQ),
+        ("front", A.FrontAdapter(TRUSEQ[:20], max_errors=0.1, min_overlap=3)._fused_plan, TRUSEQ[:20]),
+        ("anywhere", A.AnywhereAdapter(TRUSEQ[:25], max_errors=0.15, min_overlap=4)._fused_plan, TRUSEQ[:25]),
+        ("prefix", A.PrefixAdapter("ACGTACGTAC", max_errors=0.1)._fused_plan, "ACGTACGTAC"),
+        ("suffix-noindels", A.SuffixAdapter("TTGACCAGT", max_errors=0.12, indels=False)._fused_plan, "TTGACCAGT"),
+        ("long", A.BackAdapter(long_ad, max_errors=0.1, min_overlap=5)._fused_plan, long_ad),
+        ("twelve", _lib.Plan([A.BackAdapter(s, max_errors=0.1, min_overlap=3).matcher_spec() for s in many]), many[3]),
+        ("two", _lib.Plan([A.BackAdapter(s, max_errors=0.1, min_overlap=3).matcher_spec() for s in many[:2]]), many[1]),
+    ]
+    for name, plan, seq in plans:
+        for n, count in ((150, 3000), (100, 700), (36, 1500), (200, 900), (15, 400)):
+            reads = make_reads(rng, n, count, seq, p_adapter=0.6)
+            batch = ReadBatch.from_strings(reads)
+            assert batch.uniform_len == n
+            got = match_batch(plan, batch).cpu()
+            os.environ["CAH_NO_UNIFORM"] = "1"
+            try:
+                ref = match_batch(plan, ReadBatch.from_strings(reads)).cpu()
+            finally:
+                os.environ.pop("CAH_NO_UNIFORM", None)
+            assert np.array_equal(got[1], ref[1]) and np.array_equal(got[0], ref[0]), (name, n)
+            if got[2] is not None and ref[2] is not None:
+                assert np.array_equal(got[2][got[1] == 1], ref[2][ref[1] == 1]), (name, n)
