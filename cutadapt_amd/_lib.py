@@ -24,11 +24,11 @@ EXPORTED_SYMBOLS = [
     "cah_abi_version", "cah_last_error", "cah_device_count", "cah_set_device", "cah_device_info",
     "cah_plan_create", "cah_plan_destroy", "cah_plan_n_adapters", "cah_plan_effective_length",
     "cah_plan_n_kmer_entries", "cah_plan_prefilter_kind", "cah_plan_debug_matcher", "cah_plan_debug_lean", "cah_locate_batch", "cah_kmers_present_batch", "cah_match_batch", "cah_match_batch_uniform",
-    "cah_workspace_bytes", "cah_plan_workspace_bytes", "cah_validate_ascii_batch", "cah_reverse_reads_batch", "cah_locate_batch_host",
+    "cah_workspace_bytes", "cah_plan_workspace_bytes", "cah_validate_ascii_batch", "cah_reverse_reads_batch", "cah_revcomp_reads_batch", "cah_locate_batch_host",
     "cah_kmers_present_batch_host", "cah_match_batch_host", "cah_locate_debug_host", "cah_match_one_host", "cah_locate_one_host", "cah_profile_enable",
     "cah_profile_reset", "cah_profile_read", "cah_synth_reads",
     "cah_fastq_scan", "cah_pack_sequences", "cah_fastq_write_trimmed",
-    "cah_fasta_scan", "cah_records_write", "cah_info_write", "cah_record_boundary",
+    "cah_fasta_scan", "cah_records_write", "cah_info_write", "cah_info_write_rc", "cah_chunk_revcomp", "cah_record_boundary",
     "cah_fastq_device_scratch_bytes", "cah_fastq_count_lines_device", "cah_fastq_index_device", "cah_fastq_format_device", "cah_trim_decide_device",
     "cah_index_create", "cah_index_destroy", "cah_index_info", "cah_index_get",
     "cah_index_lookup_batch", "cah_index_lookup_batch_host",
@@ -119,6 +119,7 @@ def lib():
     L.cah_plan_workspace_bytes.restype = C.c_size_t
     L.cah_validate_ascii_batch.argtypes = [vp, vp, vp, i64, vp, vp]
     L.cah_reverse_reads_batch.argtypes = [vp, vp, vp, i64, vp, vp, vp]
+    L.cah_revcomp_reads_batch.argtypes = [vp, vp, vp, i64, vp, vp, C.c_int32, vp, vp]
     L.cah_locate_batch_host.argtypes = [vp, i32, vp, vp, i64, vp, vp]
     L.cah_kmers_present_batch_host.argtypes = [vp, i32, vp, vp, i64, vp]
     L.cah_match_batch_host.argtypes = [vp, vp, vp, i64, vp, vp, vp]
@@ -136,6 +137,8 @@ def lib():
     L.cah_fasta_scan.argtypes = [vp, i64, C.c_int, i64, vp, C.POINTER(i64), C.POINTER(i64)]
     L.cah_records_write.argtypes = [vp, vp, i64, vp, vp, vp, vp, vp, C.c_int, vp, i64, C.POINTER(i64)]
     L.cah_info_write.argtypes = [vp, vp, i64, vp, vp, vp, i64, vp, vp, i64, vp, i64, C.POINTER(i64)]
+    L.cah_info_write_rc.argtypes = [vp, vp, i64, vp, vp, vp, i64, vp, vp, i64, vp, vp, i64, C.POINTER(i64)]
+    L.cah_chunk_revcomp.argtypes = [vp, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, C.POINTER(i64)]
     L.cah_record_boundary.argtypes = [vp, i64, C.c_int, C.POINTER(i64)]
     L.cah_fastq_device_scratch_bytes.argtypes = [i64, i64]
     L.cah_fastq_device_scratch_bytes.restype = C.c_size_t

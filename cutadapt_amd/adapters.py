@@ -471,9 +471,12 @@ class SingleAdapter(Adapter, ABC):
         return np.full(len(found), self._remove_before, dtype=bool)
 
 
-def _reverse_batch(batch):
+def _reverse_batch(batch, complement: bool = False, select=None, data=None):
     """Per-read reversed copy of a ReadBatch (``cah_reverse_reads_batch``: one pass on the device; Rightmost*
-    adapters search the reversed read with the reversed adapter, reference adapters.py:766, :870)."""
+    adapters search the reversed read with the reversed adapter, reference adapters.py:766, :870).
+    ``complement``: the reverse complement (``cah_revcomp_reads_batch``; ReverseComplementer, reference
+    modifiers.py:264-308).  ``select`` (bool/uint8 device tensor): only these reads are turned around, the others are
+    copied.  ``data``: another byte tensor with the batch's layout to read instead of the sequences (qualities)."""
     import torch
     from .batch import ReadBatch, _stream_ptr
     lens = batch.lengths()
@@ -482,12 +485,22 @@ def _reverse_batch(batch):
     torch.cumsum(lens, 0, out=new_offsets[1:])
     total = int(new_offsets[-1].item()) if n else 0
     out = torch.empty(total, dtype=torch.uint8, device=batch.device)
+    src = batch.seqs if data is None else data
     if total:
         with torch.cuda.device(batch.device):
-            _lib.check(_lib.lib().cah_reverse_reads_batch(
-                batch.seqs.data_ptr(), batch.offsets.data_ptr(), batch._lens_ptr(), n,
-                new_offsets.data_ptr(), out.data_ptr(), _stream_ptr()))
-    return ReadBatch(out, new_offsets, validated=batch.validated)
+            if complement or select is not None or data is not None:
+                sel = None if select is None else select.to(device=batch.device, dtype=torch.uint8).contiguous()
+                _lib.check(_lib.lib().cah_revcomp_reads_batch(
+                    src.data_ptr(), batch.offsets.data_ptr(), batch._lens_ptr(), n,
+                    new_offsets.data_ptr(), out.data_ptr(), int(bool(complement)),
+                    sel.data_ptr() if sel is not None else None, _stream_ptr()))
+            else:
+                _lib.check(_lib.lib().cah_reverse_reads_batch(
+                    src.data_ptr(), batch.offsets.data_ptr(), batch._lens_ptr(), n,
+                    new_offsets.data_ptr(), out.data_ptr(), _stream_ptr()))
+    if data is not None:
+        return out
+    return ReadBatch(out, new_offsets, validated=batch.validated, uniform_len=batch.uniform_len)
 
 
 class FrontAdapter(SingleAdapter):

@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstring>
 
+#include "revcomp.h"
 #include "../../include/cutadapt_hip.h"
 
 extern int cah_set_error_(int code, const char* msg);   // api.cpp
@@ -292,9 +293,10 @@ int cah_records_write(const uint8_t* buf, const int64_t* rec, int64_t n_records,
 // read, in match order; rstart/rstop are relative to the read as it was when that match was made,
 // i.e. to original[wbeg:wend].  Reads without a row get the "-1" line.  names = concatenated adapter
 // names, name_off[n_names+1].  Every match row ends with an empty reverse-complement column.
-int cah_info_write(const uint8_t* buf, const int64_t* rec, int64_t n_records, const uint8_t* seqs,
-                   const int64_t* offsets, const int64_t* rows, int64_t n_rows, const char* names,
-                   const int64_t* name_off, int64_t n_names, uint8_t* out, int64_t out_cap, int64_t* out_len) {
+static int info_write_impl(const uint8_t* buf, const int64_t* rec, int64_t n_records, const uint8_t* seqs,
+                           const int64_t* offsets, const int64_t* rows, int64_t n_rows, const char* names,
+                           const int64_t* name_off, int64_t n_names, const uint8_t* is_rc, uint8_t* out, int64_t out_cap,
+                           int64_t* out_len) {
     if (!out_len || (n_records > 0 && (!buf || !rec || !offsets || !out)) || (n_rows > 0 && (!rows || !names || !name_off)))
         return cah_set_error_(CAH_EINVAL, "cah_info_write: NULL argument");
     int64_t pos = 0, k = 0;
@@ -329,11 +331,77 @@ int cah_info_write(const uint8_t* buf, const int64_t* rec, int64_t n_records, co
             put(reinterpret_cast<const uint8_t*>(names) + name_off[ni], nlen); out[pos++] = '\t';
             if (fastq) { put(qual + wb, a - wb); out[pos++] = '\t'; put(qual + a, b - a); out[pos++] = '\t'; put(qual + b, we - b); }
             else { out[pos++] = '\t'; out[pos++] = '\t'; }
-            out[pos++] = '\t';                                  // reverse-complement flag: "" (not searched)
+            out[pos++] = '\t';                                  // reverse-complement flag: "" (not searched), 0 or 1
+            if (is_rc) out[pos++] = is_rc[i] ? '1' : '0';
             out[pos++] = '\n';
         }
     }
     if (k != n_rows) return cah_set_error_(CAH_EINVAL, "cah_info_write: rows refer to reads outside the chunk");
+    *out_len = pos;
+    return CAH_OK;
+}
+
+int cah_info_write(const uint8_t* buf, const int64_t* rec, int64_t n_records, const uint8_t* seqs,
+                   const int64_t* offsets, const int64_t* rows, int64_t n_rows, const char* names,
+                   const int64_t* name_off, int64_t n_names, uint8_t* out, int64_t out_cap, int64_t* out_len) {
+    return info_write_impl(buf, rec, n_records, seqs, offsets, rows, n_rows, names, name_off, n_names, nullptr, out,
+                           out_cap, out_len);
+}
+
+// ... with the last column filled in: is_rc[i] says whether record i was reverse-complemented (the reference's
+// InfoFileWriter.RC_MAP, steps.py:224, :243: "" without --revcomp, else 0 or 1).
+int cah_info_write_rc(const uint8_t* buf, const int64_t* rec, int64_t n_records, const uint8_t* seqs,
+                      const int64_t* offsets, const int64_t* rows, int64_t n_rows, const char* names,
+                      const int64_t* name_off, int64_t n_names, const uint8_t* is_rc, uint8_t* out, int64_t out_cap,
+                      int64_t* out_len) {
+    return info_write_impl(buf, rec, n_records, seqs, offsets, rows, n_rows, names, name_off, n_names, is_rc, out,
+                           out_cap, out_len);
+}
+
+// The chunk after ReverseComplementer (reference modifiers.py:264-308): a second raw buffer with one normalised
+// record per input record ("@name\nSEQ\n+\nQUAL\n" or ">name\nSEQ\n") and its record table, in which the records
+// with is_rc[i] != 0 hold the reverse complement of the sequence (revcomp.h), the reversed qualities and the name
+// followed by `suffix` (" rc"; suffix_len 0: none).  Every writer then works on it unchanged.  seqs/offsets: the
+// packed sequences of the input chunk (cah_pack_sequences).  out_rec: int64[n_records*6].
+int cah_chunk_revcomp(const uint8_t* buf, const int64_t* rec, int64_t n_records, const uint8_t* seqs,
+                      const int64_t* offsets, const uint8_t* is_rc, const char* suffix, int64_t suffix_len,
+                      uint8_t* out, int64_t out_cap, int64_t* out_rec, int64_t* out_len) {
+    if (!out_len || suffix_len < 0 || (suffix_len > 0 && !suffix)
+        || (n_records > 0 && (!buf || !rec || !offsets || !is_rc || !out || !out_rec)))
+        return cah_set_error_(CAH_EINVAL, "cah_chunk_revcomp: NULL argument");
+    int64_t pos = 0;
+    for (int64_t i = 0; i < n_records; i++) {
+        const int64_t* r = rec + i * 6;
+        int64_t* w = out_rec + i * 6;
+        const bool fastq = r[4] >= 0, flip = is_rc[i] != 0;
+        const int64_t name_len = r[1] - r[0], n = offsets[i + 1] - offsets[i];
+        const int64_t need = 1 + name_len + (flip ? suffix_len : 0) + 1 + n + 1 + (fastq ? 2 + n + 1 : 0);
+        if (pos + need > out_cap) return cah_set_error_(CAH_ENOMEM, "cah_chunk_revcomp: output buffer too small");
+        const uint8_t* s = seqs + offsets[i];
+        out[pos++] = fastq ? '@' : '>';
+        w[0] = pos;
+        memcpy(out + pos, buf + r[0], (size_t)name_len); pos += name_len;
+        if (flip && suffix_len) { memcpy(out + pos, suffix, (size_t)suffix_len); pos += suffix_len; }
+        w[1] = pos;
+        out[pos++] = '\n';
+        w[2] = pos;
+        if (flip) for (int64_t q = 0; q < n; q++) out[pos + q] = cah_complement(s[n - 1 - q]);
+        else memcpy(out + pos, s, (size_t)n);
+        pos += n;
+        w[3] = pos;
+        out[pos++] = '\n';
+        w[4] = w[5] = -1;
+        if (fastq) {
+            out[pos++] = '+'; out[pos++] = '\n';
+            w[4] = pos;
+            const uint8_t* qual = buf + r[4];
+            if (flip) for (int64_t q = 0; q < n; q++) out[pos + q] = qual[n - 1 - q];
+            else memcpy(out + pos, qual, (size_t)n);
+            pos += n;
+            w[5] = pos;
+            out[pos++] = '\n';
+        }
+    }
     *out_len = pos;
     return CAH_OK;
 }

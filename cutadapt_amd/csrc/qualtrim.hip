@@ -11,6 +11,7 @@
 #include <mutex>
 
 #include "../../include/cutadapt_hip.h"
+#include "revcomp.h"
 #include "dev_common.h"
 
 extern int cah_set_error_(int code, const char* msg);   // api.cpp
@@ -245,9 +246,19 @@ inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256); }
 // with the reversed adapter (reference adapters.py:766, :870: `sequence[::-1]`); one read per lane, 16 characters
 // per load (the chunk that ENDS where the last one began), byte-swapped in registers, one 16-byte store; the last
 // partial chunk byte by byte (a 16-byte store there would reach into the next read's slot).
+// COMPLEMENT: the reverse COMPLEMENT (ReverseComplementer, reference modifiers.py:264-308; table in revcomp.h, held
+// in 256 bytes of LDS).  select != NULL: reads with select[r] == 0 are copied as they are -- that merges "the
+// orientation that matched better" of every read into one batch in one pass.
 // ---------------------------------------------------------------------------------------------
+template <bool COMPLEMENT>
 __global__ __launch_bounds__(256) void k_reverse_reads(const uint8_t* seqs, const int64_t* offsets, const int32_t* lens,
-                                                       int64_t n_reads, const int64_t* out_offsets, uint8_t* out) {
+                                                       int64_t n_reads, const int64_t* out_offsets, uint8_t* out,
+                                                       const uint8_t* select) {
+    __shared__ uint8_t comp[256];
+    if (COMPLEMENT) {
+        comp[threadIdx.x] = cah_complement((uint8_t)threadIdx.x);
+        __syncthreads();
+    }
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_reads) return;
     const int64_t off = offsets[r];
@@ -255,16 +266,31 @@ __global__ __launch_bounds__(256) void k_reverse_reads(const uint8_t* seqs, cons
     const int n = (int)(n64 > CAH_MAX_READ_LEN ? CAH_MAX_READ_LEN : n64);
     const uint8_t* q = seqs + off;
     uint8_t* o = out + out_offsets[r];
+    if (select && !select[r]) {                                  // this read keeps its orientation
+        int done = 0;
+        for (; done + 16 <= n; done += 16) {
+            const Chunk c = load_chunk(q, done, n, done + 16);
+            Unaligned16 u;
+            u.w[0] = c.w[0]; u.w[1] = c.w[1]; u.w[2] = c.w[2]; u.w[3] = c.w[3];
+            __builtin_memcpy(o + done, &u, 16);
+        }
+        for (int i = done; i < n; ++i) o[i] = q[i];
+        return;
+    }
+    auto flip = [&](unsigned w) -> unsigned {                    // the four characters of a dword, reversed (+ complemented)
+        if (!COMPLEMENT) return __builtin_bswap32(w);
+        return ((unsigned)comp[w & 0xFFu] << 24) | ((unsigned)comp[(w >> 8) & 0xFFu] << 16)
+             | ((unsigned)comp[(w >> 16) & 0xFFu] << 8) | (unsigned)comp[w >> 24];
+    };
     int done = 0;
     for (; done + 16 <= n; done += 16) {
         const int pos = n - done - 16;                           // input characters [pos, pos + 16)
         const Chunk c = load_chunk(q, pos, n, pos + 16);
         Unaligned16 u;
-        u.w[0] = __builtin_bswap32(c.w[3]); u.w[1] = __builtin_bswap32(c.w[2]);
-        u.w[2] = __builtin_bswap32(c.w[1]); u.w[3] = __builtin_bswap32(c.w[0]);
+        u.w[0] = flip(c.w[3]); u.w[1] = flip(c.w[2]); u.w[2] = flip(c.w[1]); u.w[3] = flip(c.w[0]);
         __builtin_memcpy(o + done, &u, 16);
     }
-    for (int i = done; i < n; ++i) o[i] = q[n - 1 - i];
+    for (int i = done; i < n; ++i) o[i] = COMPLEMENT ? comp[q[n - 1 - i]] : q[n - 1 - i];
 }
 
 extern "C" {
@@ -319,17 +345,43 @@ int cah_expected_errors_batch(const uint8_t* d_quals, const int64_t* d_offsets, 
 
 // Reversed copy of every read (see k_reverse_reads).  d_out_offsets: int64[n_reads] start of each read in d_out
 // (packed: the running sum of the lengths); all device pointers.
-int cah_reverse_reads_batch(const uint8_t* d_seqs, const int64_t* d_offsets, const int32_t* d_lens, int64_t n_reads,
-                            const int64_t* d_out_offsets, uint8_t* d_out, void* stream) {
+static int reverse_reads_impl(const char* who, const uint8_t* d_seqs, const int64_t* d_offsets, const int32_t* d_lens,
+                              int64_t n_reads, const int64_t* d_out_offsets, uint8_t* d_out, int complement,
+                              const uint8_t* d_select, void* stream) {
     if (n_reads < 0) return cah_set_error_(CAH_EINVAL, "n_reads < 0");
     if (n_reads == 0) return CAH_OK;
-    if (!d_offsets || !d_out_offsets || !d_out) return cah_set_error_(CAH_EINVAL, "cah_reverse_reads_batch: NULL argument");
+    if (!d_offsets || !d_out_offsets || !d_out) {
+        char msg[96];
+        snprintf(msg, sizeof msg, "%s: NULL argument", who);
+        return cah_set_error_(CAH_EINVAL, msg);
+    }
     const int64_t blocks = (n_reads + 255) / 256;
-    hipLaunchKernelGGL(k_reverse_reads, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_seqs, d_offsets, d_lens,
-                       n_reads, d_out_offsets, d_out);
+    if (complement)
+        hipLaunchKernelGGL(k_reverse_reads<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_seqs, d_offsets,
+                           d_lens, n_reads, d_out_offsets, d_out, d_select);
+    else
+        hipLaunchKernelGGL(k_reverse_reads<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_seqs, d_offsets,
+                           d_lens, n_reads, d_out_offsets, d_out, d_select);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return cah_set_error_(CAH_EHIP, hipGetErrorString(e));
     return CAH_OK;
+}
+
+int cah_reverse_reads_batch(const uint8_t* d_seqs, const int64_t* d_offsets, const int32_t* d_lens, int64_t n_reads,
+                            const int64_t* d_out_offsets, uint8_t* d_out, void* stream) {
+    return reverse_reads_impl("cah_reverse_reads_batch", d_seqs, d_offsets, d_lens, n_reads, d_out_offsets, d_out, 0,
+                              nullptr, stream);
+}
+
+// The reverse complement of every read (complement != 0; complement == 0 only reverses, which is what quality
+// strings need), or -- with d_select: uint8[n_reads] -- of the reads with d_select[r] != 0 while the others are
+// copied unchanged.  Replaces, per batch, dnaio's SequenceRecord.reverse_complement() as the reference's
+// ReverseComplementer calls it (modifiers.py:280).
+int cah_revcomp_reads_batch(const uint8_t* d_seqs, const int64_t* d_offsets, const int32_t* d_lens, int64_t n_reads,
+                            const int64_t* d_out_offsets, uint8_t* d_out, int32_t complement, const uint8_t* d_select,
+                            void* stream) {
+    return reverse_reads_impl("cah_revcomp_reads_batch", d_seqs, d_offsets, d_lens, n_reads, d_out_offsets, d_out,
+                              complement, d_select, stream);
 }
 
 }  // extern "C"

@@ -88,9 +88,13 @@ class FastqChunk:
         self.rec = rec
         self._packed: Optional[Tuple[np.ndarray, np.ndarray]] = None
         self.pooled = False            # threaded pipeline: big buffers come from / go back to POOL
+        self.derived: Optional["FastqChunk"] = None          # reverse_complemented(): lives and dies with this chunk
 
     def release(self) -> None:
         """hand the input and packed buffers back to the pool (the chunk is dead afterwards)"""
+        if self.derived is not None:
+            self.derived.release()
+            self.derived = None
         if self.pooled:
             POOL.put(self.buf)
             if self._packed is not None:
@@ -154,8 +158,31 @@ class FastqChunk:
             kp.ctypes.data if kp is not None else None, int(mode), out.ctypes.data, len(out), C.byref(out_len)))
         return memoryview(out)[:out_len.value]            # no copy; bytes-like (write(), ==, b"".join all take it)
 
-    def write_info(self, rows: np.ndarray, names: Sequence[str]) -> bytes:
-        """--info-file rows for this chunk; rows int64[k,7] as cah_info_write takes them."""
+    def reverse_complemented(self, is_rc: np.ndarray, suffix: Optional[str] = " rc") -> "FastqChunk":
+        """The chunk as ReverseComplementer leaves it (reference modifiers.py:264-308): records with ``is_rc`` carry
+        the reverse complement of the sequence, the reversed qualities and the name + ``suffix``
+        (cah_chunk_revcomp).  The new chunk is released together with this one."""
+        n = len(self.rec)
+        seqs, offsets = self.pack_sequences()
+        flags = np.ascontiguousarray(is_rc, dtype=np.uint8)
+        sfx = (suffix or "").encode("ascii")
+        names = int((self.rec[:, 1] - self.rec[:, 0]).sum()) if n else 0
+        cap = names + 2 * int(len(seqs)) + (6 + len(sfx)) * n + 16
+        out = POOL.get(cap) if self.pooled else np.empty(cap, dtype=np.uint8)
+        rec = np.empty((n, 6), dtype=np.int64)
+        out_len = C.c_int64(0)
+        _lib.check(_lib.lib().cah_chunk_revcomp(
+            self.buf.ctypes.data, self.rec.ctypes.data, n, seqs.ctypes.data if len(seqs) else None,
+            offsets.ctypes.data, flags.ctypes.data, sfx, len(sfx), out.ctypes.data, len(out),
+            rec.ctypes.data, C.byref(out_len)))
+        chunk = FastqChunk(out[:out_len.value] if not self.pooled else out, rec)
+        chunk.pooled = self.pooled
+        self.derived = chunk
+        return chunk
+
+    def write_info(self, rows: np.ndarray, names: Sequence[str], is_rc: Optional[np.ndarray] = None) -> bytes:
+        """--info-file rows for this chunk; rows int64[k,7] as cah_info_write takes them.  ``is_rc``: per read, fills
+        the reverse-complement column (--revcomp)."""
         n = len(self.rec)
         seqs, offsets = self.pack_sequences()
         rows = np.ascontiguousarray(rows, dtype=np.int64).reshape(-1, 7)
@@ -166,10 +193,12 @@ class FastqChunk:
         cap = 3 * int(len(self.buf)) * max(1, 1 + len(rows) // max(n, 1)) + (len(rows) + n) * (96 + longest) + 64
         out = np.empty(cap, dtype=np.uint8)
         out_len = C.c_int64(0)
-        _lib.check(_lib.lib().cah_info_write(
+        flags = None if is_rc is None else np.ascontiguousarray(is_rc, dtype=np.uint8)
+        _lib.check(_lib.lib().cah_info_write_rc(
             self.buf.ctypes.data, self.rec.ctypes.data, n, seqs.ctypes.data if len(seqs) else None,
             offsets.ctypes.data, rows.ctypes.data if len(rows) else None, len(rows), blob,
-            name_off.ctypes.data, len(names), out.ctypes.data, cap, C.byref(out_len)))
+            name_off.ctypes.data, len(names), flags.ctypes.data if flags is not None else None,
+            out.ctypes.data, cap, C.byref(out_len)))
         return out[:out_len.value].tobytes()
 
 
@@ -394,6 +423,7 @@ class BatchAdapterCutter:
                 self.stat_labels.append((a.name, "end"))
         self._slot_of_adapter = np.array([self._slot[(i, 0)] for i in range(len(adapters))], dtype=np.int64)
         self.histogram = MatchHistogram(len(self.names))
+        self.reverse_complemented = np.zeros(len(self.names), dtype=np.int64)      # per statistics slot (modifiers.py:305)
         self.reads = 0
         self.with_adapters = 0
         self.bp_in = 0
@@ -466,22 +496,34 @@ class BatchAdapterCutter:
         rows int64[k,7] = (read, errors, rstart, rstop, wbeg, wend, name_id).
         ``base``: the chunk already in HBM (ReadBatch); ``window`` = (beg, end) arrays: the part of
         every read earlier modifiers (quality trimming ...) left, which is what gets searched."""
-        import torch
         from .batch import ReadBatch
         n = len(offsets) - 1
         lens = (offsets[1:] - offsets[:-1]).astype(np.int64)
+        if n and base is None:
+            base = ReadBatch.from_host(seqs, offsets, device=self.device)
+        found = self.search(base, lens, window)
+        return self.commit(found, lens)
+
+    def search(self, base, lens: np.ndarray, window=None) -> Dict[str, np.ndarray]:
+        """``match_and_trim`` (reference modifiers.py:209-251) for every read of ``base``: all rounds, no statistics.
+        -> beg/end/matched as process_arrays returns them, ``rows`` int64[k,8] (process_arrays' seven columns + the
+        order of the match within its read), ``stats`` int64[k,3] = (statistics slot, removed length, errors) of
+        the same k matches and ``score``: the sum of the scores of a read's matches (what ReverseComplementer
+        compares, modifiers.py:287-289)."""
+        import torch
+        from .batch import ReadBatch
+        n = len(lens)
         if window is None:
             wbeg, wend = np.zeros(n, dtype=np.int64), lens.copy()
         else:
             wbeg, wend = np.asarray(window[0], dtype=np.int64).copy(), np.asarray(window[1], dtype=np.int64).copy()
         w0beg, w0end = wbeg.copy(), wend.copy()
         matched = np.zeros(n, dtype=bool)
+        score = np.zeros(n, dtype=np.int64)
         last_ret = (w0beg.copy(), w0end.copy())
         last_crop = (w0beg.copy(), w0end.copy())
-        all_rows = []
+        all_rows, all_stats = [], []
         if n:
-            if base is None:
-                base = ReadBatch.from_host(seqs, offsets, device=self.device)
             base.validate_ascii()
             dev_off = base.offsets[:n]
             active = np.arange(n)
@@ -504,7 +546,6 @@ class BatchAdapterCutter:
                 rows = rr.rows
                 if len(rows):
                     rows = rows[np.lexsort((rows[:, 9], rows[:, 0]))]
-                    self.histogram.add_rows(rows[:, 7], rows[:, 8], rows[:, 1])
                     out = np.empty((len(rows), 8), dtype=np.int64)
                     gi = active[rows[:, 0]]
                     out[:, 0] = gi
@@ -514,6 +555,8 @@ class BatchAdapterCutter:
                     out[:, 6] = rows[:, 6]
                     out[:, 7] = rnd * 2 + rows[:, 9]
                     all_rows.append(out)
+                    all_stats.append(rows[:, [7, 8, 1]])
+                score[g] += rr.score[hit]
                 last_ret = (last_ret[0].copy(), last_ret[1].copy())
                 last_ret[0][g], last_ret[1][g] = wbeg[g] + rr.ret_beg[hit], wbeg[g] + rr.ret_end[hit]
                 last_crop[0][g], last_crop[1][g] = wbeg[g] + rr.crop_beg[hit], wbeg[g] + rr.crop_end[hit]
@@ -531,9 +574,22 @@ class BatchAdapterCutter:
         else:                                                # trim, mask, lowercase: the remainder
             beg, end = wbeg, wend
         rows = np.concatenate(all_rows) if all_rows else np.zeros((0, 8), dtype=np.int64)
+        stats = np.concatenate(all_stats) if all_stats else np.zeros((0, 3), dtype=np.int64)
         if len(rows):
-            rows = rows[np.lexsort((rows[:, 7], rows[:, 0]))]
-        self.reads += n
+            order = np.lexsort((rows[:, 7], rows[:, 0]))
+            rows, stats = rows[order], stats[order]
+        return {"beg": beg, "end": end, "matched": matched, "rows": rows, "stats": stats, "score": score}
+
+    def commit(self, found: Dict[str, np.ndarray], lens: np.ndarray, reverse_complemented=None):
+        """statistics of one searched chunk (AdapterCutter.__call__, reference modifiers.py:199-206) + the result
+        dict of process_arrays.  ``reverse_complemented``: bool per read, counted per adapter like
+        ``stats.reverse_complemented`` (modifiers.py:305)."""
+        beg, end, matched, rows, stats = (found[k] for k in ("beg", "end", "matched", "rows", "stats"))
+        if len(stats):
+            self.histogram.add_rows(stats[:, 0], stats[:, 1], stats[:, 2])
+            if reverse_complemented is not None:
+                np.add.at(self.reverse_complemented, stats[reverse_complemented[rows[:, 0]], 0], 1)
+        self.reads += len(lens)
         self.with_adapters += int(matched.sum())
         self.bp_in += int(lens.sum())
         self.bp_out += int((end - beg).sum()) if self.action in ("trim", "retain", "crop") else int(lens.sum())
@@ -561,6 +617,51 @@ class BatchAdapterCutter:
         return chunk.write_records(res["beg"], res["end"], keep, mode)
 
 
+class BatchReverseComplementer:
+    """``ReverseComplementer(adapter_cutter, rc_suffix)`` over whole chunks (reference modifiers.py:264-308): every
+    read and its reverse complement go through the cutter's search (two passes of the batch matcher over two copies
+    of the chunk in HBM, the second made by cah_revcomp_reads_batch); per read the reverse complement is taken when
+    the scores of its matches add up to MORE than the forward read's (a tie keeps the read as it is)."""
+
+    def __init__(self, adapter_cutter: BatchAdapterCutter, rc_suffix: Optional[str] = " rc"):
+        self.adapter_cutter = adapter_cutter
+        self.reverse_complemented = 0
+        self._suffix = rc_suffix
+
+    def process_arrays(self, seqs: np.ndarray, offsets: np.ndarray, base=None, window=None):
+        """BatchAdapterCutter.process_arrays + ``rc``: bool per read.  Intervals and info rows of a reverse-complemented
+        read are relative to the reverse complement of the read.  ``window`` is given on the forward read."""
+        from .adapters import _reverse_batch
+        from .batch import ReadBatch
+        cutter = self.adapter_cutter
+        n = len(offsets) - 1
+        lens = (offsets[1:] - offsets[:-1]).astype(np.int64)
+        if n == 0:
+            out = cutter.commit(cutter.search(None, lens, window), lens)
+            out["rc"] = np.zeros(0, dtype=bool)
+            return out
+        if base is None:
+            base = ReadBatch.from_host(seqs, offsets, device=cutter.device)
+        fwd = cutter.search(base, lens, window)
+        rbase = _reverse_batch(base, complement=True)
+        rbase.validated = True                               # search(base) just validated the same bytes
+        rwindow = None if window is None else (lens - np.asarray(window[1], dtype=np.int64),
+                                               lens - np.asarray(window[0], dtype=np.int64))
+        rev = cutter.search(rbase, lens, rwindow)
+        use = rev["score"] > fwd["score"]
+        merged = {k: np.where(use, rev[k], fwd[k]) for k in ("beg", "end", "matched")}
+        keep_f = ~use[fwd["rows"][:, 0]]
+        keep_r = use[rev["rows"][:, 0]]
+        rows = np.concatenate([fwd["rows"][keep_f], rev["rows"][keep_r]])
+        stats = np.concatenate([fwd["stats"][keep_f], rev["stats"][keep_r]])
+        order = np.lexsort((rows[:, 7], rows[:, 0]))
+        merged["rows"], merged["stats"] = rows[order], stats[order]
+        self.reverse_complemented += int(use.sum())
+        out = cutter.commit(merged, lens, reverse_complemented=use)
+        out["rc"] = use
+        return out
+
+
 class BatchTrimmer:
     """The read-modifying part of a single-end pipeline in the reference's order (cli.py:938-987):
     NextSeq trimming, quality trimming, adapter cutting, poly-A trimming -- all on windows
@@ -570,10 +671,13 @@ class BatchTrimmer:
     def __init__(self, adapters=(), times: int = 1, action: Optional[str] = "trim", index: bool = True,
                  nextseq_trim: Optional[int] = None, quality_cutoff: Optional[Tuple[int, int]] = None,
                  quality_base: int = 33, poly_a: bool = False, max_expected_errors: Optional[float] = None,
-                 cut: Sequence[int] = (), length: Optional[int] = None, device=None, poly_a_revcomp: bool = False):
+                 cut: Sequence[int] = (), length: Optional[int] = None, device=None, poly_a_revcomp: bool = False,
+                 revcomp: bool = False, rc_suffix: Optional[str] = " rc"):
         adapters = list(adapters._adapters) if isinstance(adapters, MultipleAdapters) else \
             ([adapters] if isinstance(adapters, (SingleAdapter, LinkedAdapter)) else list(adapters))
         self.cutter = BatchAdapterCutter(adapters, times=times, action=action, index=index, device=device) if adapters else None
+        # --revcomp: ReverseComplementer takes the adapter cutter's place in the chain (reference cli.py:1113-1118)
+        self.rc = BatchReverseComplementer(self.cutter, rc_suffix) if (revcomp and self.cutter is not None) else None
         self.action = action
         self.nextseq_trim = nextseq_trim
         self.quality_cutoff = quality_cutoff
@@ -610,8 +714,11 @@ class BatchTrimmer:
             self.poly_a_trimmed_lengths[k] = self.poly_a_trimmed_lengths.get(k, 0) + c
         for k, c in other.filtered.items():
             self.filtered[k] = self.filtered.get(k, 0) + c
+        if self.rc is not None and other.rc is not None:
+            self.rc.reverse_complemented += other.rc.reverse_complemented
         if self.cutter is not None and other.cutter is not None:
             self.cutter.histogram += other.cutter.histogram
+            self.cutter.reverse_complemented += other.cutter.reverse_complemented
             for name in ("reads", "with_adapters", "bp_in", "bp_out"):
                 setattr(self.cutter, name, getattr(self.cutter, name) + getattr(other.cutter, name))
 
@@ -623,8 +730,8 @@ class BatchTrimmer:
         request = next(gen)                                 # everything in front of the adapter step is done
         res = None
         if request is not None and self.cutter is not None:
-            res = self.cutter.process_arrays(request["seqs"], request["offsets"], base=request["base"],
-                                             window=request["window"])
+            res = (self.rc or self.cutter).process_arrays(request["seqs"], request["offsets"], base=request["base"],
+                                                          window=request["window"])
         try:
             gen.send(res)
         except StopIteration as stop:
@@ -680,11 +787,23 @@ class BatchTrimmer:
         mode = 0
         res = yield {"seqs": seqs, "offsets": offsets, "base": base, "window": (wbeg, wend) if pre else None,
                      "lens": lens, "n": n}
+        out_chunk, is_rc = chunk, None
         if res is not None:
             wbeg, wend, matched = res["beg"].astype(np.int64), res["end"].astype(np.int64), res["matched"]
             mode = {"mask": 1, "lowercase": 2}.get(self.action, 0)
+            is_rc = res.get("rc")
+            if is_rc is not None and n:
+                # from here on every read is the orientation that won: one merged copy in HBM for the modifiers
+                # that follow, one merged chunk for the writers; the qualities turn around with their reads
+                from .adapters import _reverse_batch
+                sel = torch.from_numpy(is_rc).to(base.device)
+                if quals is not None:
+                    quals = _reverse_batch(base, select=sel, data=quals)
+                if self.poly_a:
+                    base = _reverse_batch(base, complement=True, select=sel)
+                out_chunk = chunk.reverse_complemented(is_rc, self.rc._suffix)
             if info is not None:
-                info.append(chunk.write_info(res["rows"], self.cutter.names))
+                info.append(out_chunk.write_info(res["rows"], self.cutter.names, is_rc))
         elif info is not None:
             info.append(chunk.write_info(np.zeros((0, 7), np.int64), []))
         if self.poly_a and n:
@@ -708,7 +827,7 @@ class BatchTrimmer:
         if self.max_expected_errors is not None and n:
             # TooManyExpectedErrors (reference predicates.py:55-71): the filter sees the read as trimmed so far
             if quals is None:
-                q = chunk.pack_qualities()
+                q = out_chunk.pack_qualities()
                 if q is None:
                     raise qt.HasNoQualities("expected errors need qualities")
                 quals = torch.from_numpy(q).to(base.device)
@@ -719,7 +838,8 @@ class BatchTrimmer:
                 raise ValueError(f"Not a valid phred value in the qualities of read {bad} of the chunk")
         self.reads += n
         self.bp_in += int(lens.sum())
-        return {"beg": wbeg, "end": wend, "matched": matched, "mode": mode, "ee": ee, "lens": lens}
+        return {"beg": wbeg, "end": wend, "matched": matched, "mode": mode, "ee": ee, "lens": lens, "chunk": out_chunk,
+                "rc": is_rc}
 
     def process_chunk(self, chunk: FastqChunk, discard_untrimmed: bool = False, discard_trimmed: bool = False,
                       info: Optional[list] = None, minimum_length: Optional[int] = None,
@@ -732,7 +852,7 @@ class BatchTrimmer:
         beg, end = res["beg"], res["end"]
         out_len = (end - beg) if res["mode"] == 0 else res["lens"]
         self.bp_out += int(out_len.sum() if keep is None else out_len[keep].sum())
-        return chunk.write_records(beg.astype(np.int32), end.astype(np.int32), keep, res["mode"])
+        return res.get("chunk", chunk).write_records(beg.astype(np.int32), end.astype(np.int32), keep, res["mode"])
 
 
 def filter_reads(results: Sequence[Dict[str, object]], trimmers: Sequence["BatchTrimmer"], discard_untrimmed: bool,
@@ -784,8 +904,11 @@ def trim_fastq(inpath: Union[str, BinaryIO], outpath: Union[str, BinaryIO], adap
                quality_cutoff: Optional[Tuple[int, int]] = None, quality_base: int = 33, poly_a: bool = False,
                max_expected_errors: Optional[float] = None, threads: int = 1, cut: Sequence[int] = (),
                length: Optional[int] = None, minimum_length: Optional[int] = None,
-               maximum_length: Optional[int] = None, device=None, devices=None) -> Dict[str, object]:
-    """``devices``: with ``threads`` > 1 the GPUs the worker threads are dealt to, round-robin -- a list of device
+               maximum_length: Optional[int] = None, device=None, devices=None, revcomp: bool = False,
+               rc_suffix: Optional[str] = " rc") -> Dict[str, object]:
+    """``revcomp``: --revcomp, search every read and its reverse complement and keep the better one (``rc_suffix`` is
+    appended to the names of the reads that were turned around; None for none).
+    ``devices``: with ``threads`` > 1 the GPUs the worker threads are dealt to, round-robin -- a list of device
     indices or "all" for every visible GPU (the reference's reader -> workers -> ordered writer layout,
     runners.py:116-134, :224-245, with one HIP stream per worker and the workers spread over the node's GPUs;
     plans replicate their tables on each device on first use).  Default: the one ``device``.
@@ -797,7 +920,8 @@ def trim_fastq(inpath: Union[str, BinaryIO], outpath: Union[str, BinaryIO], adap
     def make_trimmer(dev=device):
         return BatchTrimmer(adapters, times=times, action=action, index=index, nextseq_trim=nextseq_trim,
                             quality_cutoff=quality_cutoff, quality_base=quality_base, poly_a=poly_a,
-                            max_expected_errors=max_expected_errors, cut=cut, length=length, device=dev)
+                            max_expected_errors=max_expected_errors, cut=cut, length=length, device=dev,
+                            revcomp=revcomp, rc_suffix=rc_suffix)
 
     trimmer = make_trimmer()
     out = outpath if hasattr(outpath, "write") else open(outpath, "wb")
@@ -820,7 +944,8 @@ def trim_fastq(inpath: Union[str, BinaryIO], outpath: Union[str, BinaryIO], adap
             inf.close()
     cutter = trimmer.cutter
     return {"reads": trimmer.reads, "with_adapters": cutter.with_adapters if cutter else 0,
-            "bp_in": trimmer.bp_in, "bp_out": trimmer.bp_out, "cutter": cutter, "trimmer": trimmer}
+            "bp_in": trimmer.bp_in, "bp_out": trimmer.bp_out, "cutter": cutter, "trimmer": trimmer,
+            "reverse_complemented": trimmer.rc.reverse_complemented if trimmer.rc is not None else None}
 
 
 def _trim_threaded(inpath, out, inf, trimmer: "BatchTrimmer", make_trimmer, threads: int, chunk_bytes: int,

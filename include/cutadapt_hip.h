@@ -287,6 +287,20 @@ int cah_info_write(const uint8_t *buf, const int64_t *rec, int64_t n_records, co
                    const int64_t *name_off, int64_t n_names, uint8_t *out, int64_t out_cap,
                    int64_t *out_len);
 
+/* ... with the reverse-complement column (steps.py:224, :243 RC_MAP): is_rc uint8[n_records], "1"/"0" per row
+ * (NULL: the empty column cah_info_write writes, i.e. --revcomp was not given). */
+int cah_info_write_rc(const uint8_t *buf, const int64_t *rec, int64_t n_records, const uint8_t *seqs,
+                      const int64_t *offsets, const int64_t *rows, int64_t n_rows, const char *names,
+                      const int64_t *name_off, int64_t n_names, const uint8_t *is_rc, uint8_t *out,
+                      int64_t out_cap, int64_t *out_len);
+/* The chunk as ReverseComplementer leaves it (modifiers.py:264-308; SequenceRecord.reverse_complement() is dnaio's,
+ * restated in csrc/revcomp.h): one normalised record per input record written to out + its record table out_rec
+ * int64[n_records*6]; records with is_rc[i] != 0 carry the reverse-complemented sequence, the reversed qualities
+ * and name + suffix (" rc", modifiers.py:296; suffix_len 0 = none).  seqs/offsets as cah_pack_sequences made them. */
+int cah_chunk_revcomp(const uint8_t *buf, const int64_t *rec, int64_t n_records, const uint8_t *seqs,
+                      const int64_t *offsets, const uint8_t *is_rc, const char *suffix, int64_t suffix_len,
+                      uint8_t *out, int64_t out_cap, int64_t *out_rec, int64_t *out_len);
+
 /* ---- the same formats ON THE DEVICE (fastq_gpu.hip): the raw FASTQ chunk goes to HBM as it is, records are
  * indexed and the trimmed records formatted there, so that the host does nothing per read.  All pointers are
  * device pointers, all calls asynchronous on `stream`.  Scratch: cah_fastq_device_scratch_bytes(chunk, records),
@@ -370,6 +384,15 @@ int cah_index_lookup_batch_host(const cah_index *index, const uint8_t *seqs, con
  * running sum of the lengths).  All device pointers, asynchronous on `stream`. */
 int cah_reverse_reads_batch(const uint8_t *d_seqs, const int64_t *d_offsets, const int32_t *d_lens,
                             int64_t n_reads, const int64_t *d_out_offsets, uint8_t *d_out, void *stream);
+
+/* The reverse complement of every read of a packed batch -- what ReverseComplementer (modifiers.py:264-308) searches
+ * besides the read itself.  complement == 0 only reverses (quality strings).  d_select (uint8[n_reads], may be NULL):
+ * only reads with d_select[r] != 0 are turned around, the others are copied -- one pass merges "the orientation that
+ * scored better" of every read into one batch for the modifiers that follow.  Layout arguments as
+ * cah_reverse_reads_batch; asynchronous on `stream`. */
+int cah_revcomp_reads_batch(const uint8_t *d_seqs, const int64_t *d_offsets, const int32_t *d_lens,
+                            int64_t n_reads, const int64_t *d_out_offsets, uint8_t *d_out,
+                            int32_t complement, const uint8_t *d_select, void *stream);
 
 /* ---- quality / NextSeq / poly-A trimming, expected errors ------ */
 /* The O(n) per-read scans that run just before adapter matching (cli.py:938-954), for a batch

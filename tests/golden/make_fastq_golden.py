@@ -49,6 +49,8 @@ CASES = [
     ("max_expected_errors", f"{T}:837", [], {"max_expected_errors": 0.9}, "maxee.fastq", "maxee.fastq", None),
     ("info_file", f"{I}:14", [("-a", "adapt=GCCGAACTTCTTAGACTGCCTTAAGGACGT")], {}, "illumina.fastq.gz", "illumina.fastq", "illumina.info.txt"),
     ("info_file_times", f"{I}:35", [("-a", "adapt=GCCGAACTTCTTA"), ("-a", "adapt2=GACTGCCTTAAGGACGT")], {"times": 2}, "illumina5.fastq", "illumina5.fastq", "illumina5.info.txt"),
+    ("revcomp_normalized", f"{T}:827", [("-g", "^TTATTTGTCT"), ("-g", "^TCCGCACTGG")], {"revcomp": True, "index": False}, "revcomp.1.fastq", "revcomp-single-normalize.fastq", None),
+    ("info_file_revcomp", f"{I}:78", [("-a", "adapt=GAGTCG")], {"revcomp": True, "rc_suffix": None}, "info-rc.fasta", None, "info-rc.txt"),
     ("linked_info_file", f"{I}:119", [("-a", "linkedadapter=^AAAAAAAAAA...TTTTTTTTTT")], {}, "linked.fasta", None, "linked-info.txt"),
 ]
 
