@@ -32,7 +32,7 @@ EXPORTED_SYMBOLS = [
     "cah_fastq_device_scratch_bytes", "cah_fastq_count_lines_device", "cah_fastq_index_device", "cah_fastq_format_device", "cah_trim_decide_device",
     "cah_index_create", "cah_index_destroy", "cah_index_info", "cah_index_get",
     "cah_index_lookup_batch", "cah_index_lookup_batch_host",
-    "cah_quality_trim_batch", "cah_nextseq_trim_batch", "cah_poly_a_trim_batch", "cah_expected_errors_batch",
+    "cah_quality_trim_batch", "cah_nextseq_trim_batch", "cah_nextseq_trim_batch_q", "cah_poly_a_trim_batch", "cah_expected_errors_batch",
 ]
 
 
@@ -137,7 +137,7 @@ def lib():
     L.cah_fasta_scan.argtypes = [vp, i64, C.c_int, i64, vp, C.POINTER(i64), C.POINTER(i64)]
     L.cah_records_write.argtypes = [vp, vp, i64, vp, vp, vp, vp, vp, C.c_int, vp, i64, C.POINTER(i64)]
     L.cah_info_write.argtypes = [vp, vp, i64, vp, vp, vp, i64, vp, vp, i64, vp, i64, C.POINTER(i64)]
-    L.cah_info_write_rc.argtypes = [vp, vp, i64, vp, vp, vp, i64, vp, vp, i64, vp, vp, i64, C.POINTER(i64)]
+    L.cah_info_write_rc.argtypes = [vp, vp, i64, vp, vp, vp, i64, vp, vp, i64, vp, vp, vp, vp, i64, C.POINTER(i64)]
     L.cah_chunk_revcomp.argtypes = [vp, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, C.POINTER(i64)]
     L.cah_record_boundary.argtypes = [vp, i64, C.c_int, C.POINTER(i64)]
     L.cah_fastq_device_scratch_bytes.argtypes = [i64, i64]
@@ -155,6 +155,7 @@ def lib():
     L.cah_index_lookup_batch_host.argtypes = [vp, vp, vp, i64, vp, vp, vp]
     L.cah_quality_trim_batch.argtypes = [vp, vp, vp, i64, i32, i32, i32, vp, vp]
     L.cah_nextseq_trim_batch.argtypes = [vp, vp, vp, vp, i64, i32, i32, vp, vp]
+    L.cah_nextseq_trim_batch_q.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, vp, vp]
     L.cah_poly_a_trim_batch.argtypes = [vp, vp, vp, i64, i32, vp, vp]
     L.cah_expected_errors_batch.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp]
     for name in EXPORTED_SYMBOLS:

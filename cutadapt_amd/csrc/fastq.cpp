@@ -295,8 +295,10 @@ int cah_records_write(const uint8_t* buf, const int64_t* rec, int64_t n_records,
 // names, name_off[n_names+1].  Every match row ends with an empty reverse-complement column.
 static int info_write_impl(const uint8_t* buf, const int64_t* rec, int64_t n_records, const uint8_t* seqs,
                            const int64_t* offsets, const int64_t* rows, int64_t n_rows, const char* names,
-                           const int64_t* name_off, int64_t n_names, const uint8_t* is_rc, uint8_t* out, int64_t out_cap,
-                           int64_t* out_len) {
+                           const int64_t* name_off, int64_t n_names, const uint8_t* is_rc, const int32_t* final_beg,
+                           const int32_t* final_end, uint8_t* out, int64_t out_cap, int64_t* out_len) {
+    if ((final_beg == nullptr) != (final_end == nullptr))
+        return cah_set_error_(CAH_EINVAL, "cah_info_write: final_beg and final_end go together");
     if (!out_len || (n_records > 0 && (!buf || !rec || !offsets || !out)) || (n_rows > 0 && (!rows || !names || !name_off)))
         return cah_set_error_(CAH_EINVAL, "cah_info_write: NULL argument");
     int64_t pos = 0, k = 0;
@@ -311,9 +313,14 @@ static int info_write_impl(const uint8_t* buf, const int64_t* rec, int64_t n_rec
         if (k >= n_rows || rows[k * 7] != i) {
             if (k < n_rows && rows[k * 7] < i) return cah_set_error_(CAH_EINVAL, "cah_info_write: rows are not sorted by read");
             if (pos + name_len + 2 * seq_len + 16 > out_cap) return cah_set_error_(CAH_ENOMEM, "cah_info_write: output buffer too small");
+            // no match: the read as the modifiers left it (steps.py:248-251)
+            int64_t fa = final_beg ? final_beg[i] : 0, fb = final_end ? final_end[i] : seq_len;
+            if (fa < 0) fa = 0;
+            if (fb > seq_len) fb = seq_len;
+            if (fb < fa) fb = fa;
             put(buf + r[0], name_len); out[pos++] = '\t'; out[pos++] = '-'; out[pos++] = '1'; out[pos++] = '\t';
-            put(s, seq_len); out[pos++] = '\t';
-            if (fastq) put(qual, seq_len);
+            put(s + fa, fb - fa); out[pos++] = '\t';
+            if (fastq) put(qual + fa, fb - fa);
             out[pos++] = '\n';
             continue;
         }
@@ -344,18 +351,20 @@ static int info_write_impl(const uint8_t* buf, const int64_t* rec, int64_t n_rec
 int cah_info_write(const uint8_t* buf, const int64_t* rec, int64_t n_records, const uint8_t* seqs,
                    const int64_t* offsets, const int64_t* rows, int64_t n_rows, const char* names,
                    const int64_t* name_off, int64_t n_names, uint8_t* out, int64_t out_cap, int64_t* out_len) {
-    return info_write_impl(buf, rec, n_records, seqs, offsets, rows, n_rows, names, name_off, n_names, nullptr, out,
-                           out_cap, out_len);
+    return info_write_impl(buf, rec, n_records, seqs, offsets, rows, n_rows, names, name_off, n_names, nullptr, nullptr,
+                           nullptr, out, out_cap, out_len);
 }
 
 // ... with the last column filled in: is_rc[i] says whether record i was reverse-complemented (the reference's
-// InfoFileWriter.RC_MAP, steps.py:224, :243: "" without --revcomp, else 0 or 1).
+// InfoFileWriter.RC_MAP, steps.py:224, :243: "" without --revcomp, else 0 or 1), and with the window
+// [final_beg[i], final_end[i]) that the other modifiers left of a read WITHOUT a match (its "-1" line shows the read
+// as it is written, steps.py:248-251; match rows show the read as it came in, :233-247).  Each may be NULL.
 int cah_info_write_rc(const uint8_t* buf, const int64_t* rec, int64_t n_records, const uint8_t* seqs,
                       const int64_t* offsets, const int64_t* rows, int64_t n_rows, const char* names,
-                      const int64_t* name_off, int64_t n_names, const uint8_t* is_rc, uint8_t* out, int64_t out_cap,
-                      int64_t* out_len) {
-    return info_write_impl(buf, rec, n_records, seqs, offsets, rows, n_rows, names, name_off, n_names, is_rc, out,
-                           out_cap, out_len);
+                      const int64_t* name_off, int64_t n_names, const uint8_t* is_rc, const int32_t* final_beg,
+                      const int32_t* final_end, uint8_t* out, int64_t out_cap, int64_t* out_len) {
+    return info_write_impl(buf, rec, n_records, seqs, offsets, rows, n_rows, names, name_off, n_names, is_rc, final_beg,
+                           final_end, out, out_cap, out_len);
 }
 
 // The chunk after ReverseComplementer (reference modifiers.py:264-308): a second raw buffer with one normalised

@@ -93,15 +93,18 @@ __global__ __launch_bounds__(256) void k_quality_trim(const uint8_t* quals, cons
 }
 
 // nextseq_trim_index (qualtrim.pyx:73-113): as above from the 3' end, 'G' counts as cutoff - 1
+// (qual_offsets != NULL: the qualities of read r start at quals[qual_offsets[r]] -- sequences and qualities matched
+// in place in a raw FASTQ chunk; NULL: they are packed like the sequences)
 __global__ __launch_bounds__(256) void k_nextseq_trim(const uint8_t* seqs, const uint8_t* quals, const int64_t* offsets,
-                                                      const int32_t* lens, int64_t n_reads, int cutoff, int base,
-                                                      int32_t* stop_out) {
+                                                      const int64_t* qual_offsets, const int32_t* lens, int64_t n_reads,
+                                                      int cutoff, int base, int32_t* stop_out) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_reads) return;
     int64_t off; int n;
     qt_extent(offsets, lens, r, off, n);
-    const signed char* q = reinterpret_cast<const signed char*>(quals + off);
     const uint8_t* b = seqs + off;
+    if (qual_offsets) off = qual_offsets[r];
+    const signed char* q = reinterpret_cast<const signed char*>(quals + off);
     int s = 0, max_qual = 0, max_i = n;
     auto step = [&](const signed char qc, const uint8_t bc, const int i) -> bool {
         int qv = (int)qc - base;
@@ -312,7 +315,22 @@ int cah_nextseq_trim_batch(const uint8_t* d_seqs, const uint8_t* d_quals, const 
     if (n_reads == 0) return CAH_OK;
     if (!d_offsets || !d_stop) return cah_set_error_(CAH_EINVAL, "cah_nextseq_trim_batch: NULL argument");
     hipLaunchKernelGGL(k_nextseq_trim, dim3(blocks_for(n_reads)), dim3(256), 0, (hipStream_t)stream, d_seqs, d_quals,
-                       d_offsets, d_lens, n_reads, cutoff, base, d_stop);
+                       d_offsets, (const int64_t*)nullptr, d_lens, n_reads, cutoff, base, d_stop);
+    QT_TRY(hipGetLastError());
+    return CAH_OK;
+}
+
+// ... for reads whose qualities are not packed like their sequences: d_qual_offsets int64[n_reads] (a raw FASTQ chunk
+// in HBM, indexed by cah_fastq_index_device: d_offsets into the sequence lines, d_qual_offsets into the quality lines)
+int cah_nextseq_trim_batch_q(const uint8_t* d_seqs, const uint8_t* d_quals, const int64_t* d_offsets,
+                             const int64_t* d_qual_offsets, const int32_t* d_lens, int64_t n_reads, int32_t cutoff,
+                             int32_t base, int32_t* d_stop, void* stream) {
+    if (n_reads < 0) return cah_set_error_(CAH_EINVAL, "n_reads < 0");
+    if (n_reads == 0) return CAH_OK;
+    if (!d_offsets || !d_qual_offsets || !d_lens || !d_stop)
+        return cah_set_error_(CAH_EINVAL, "cah_nextseq_trim_batch_q: NULL argument");
+    hipLaunchKernelGGL(k_nextseq_trim, dim3(blocks_for(n_reads)), dim3(256), 0, (hipStream_t)stream, d_seqs, d_quals,
+                       d_offsets, d_qual_offsets, d_lens, n_reads, cutoff, base, d_stop);
     QT_TRY(hipGetLastError());
     return CAH_OK;
 }

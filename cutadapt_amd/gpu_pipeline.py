@@ -10,16 +10,34 @@ worker threads -- each with its own HIP stream and pinned staging buffers, sprea
 visible GPUs -- and writes the results back in chunk order: the reference's reader -> workers -> ordered
 writer layout (reference src/cutadapt/runners.py:96-245) with GPUs as the workers.
 
-Scope of this stage: single-end 4-line FASTQ, any number of single (not linked, not rightmost) adapters of
-every type, ``--times 1``, action ``trim``, ``--discard-trimmed`` / ``--discard-untrimmed``, ``-m`` / ``-M``.
-Everything else (FASTA, info files, other actions, quality trimming in the same pass ...) is served by
-``pipeline.trim_fastq``; ``trim_fastq_gpu`` refuses such options instead of silently doing something else.
+Two ways through a chunk once it is indexed:
+  * the all-device way (single-end, any number of single, non-rightmost adapters, ``--times 1``, action ``trim``,
+    ``-m`` / ``-M`` / ``--discard-(un)trimmed``): match, decide and format without a byte of per-read data touching
+    the host (``cah_trim_decide_device``);
+  * the general way (everything else ``pipeline.BatchTrimmer`` does: ``-u``, ``-q``, ``--nextseq-trim``, ``--poly-a``,
+    ``--max-ee``, ``-l``, ``--times N``, every action, linked and rightmost adapters, ``--revcomp``, ``--info-file``,
+    and read pairs through ``trim_fastq_gpu_paired``): the modifiers run as kernels on windows into the raw chunk
+    in HBM (``DeviceFastqChunk``: reads AND qualities are used in place), the window arithmetic between them is
+    numpy on 4-byte-per-read arrays, and plain slicing is formatted on the device again.  What cannot be expressed
+    as a slice of the raw chunk (mask / lowercase, reverse-complemented records, info files) is formatted by the
+    host writers from the device's record index -- no host parsing in either way.
+FASTA input is parsed on the host (``pipeline.trim_fastq``; a FASTA sequence may span lines and cannot be matched
+in place), through the same trimmer.
+
+Feeding: one feeder per GPU -- ``threads`` worker threads with a HIP stream each, pinned staging and output
+buffers allocated while that GPU is current (HIP places them on the NUMA node next to it) and, when several GPUs are
+fed, pinned to the CPUs of that node.  Chunks are dealt round-robin over the feeders and written in chunk order.
+For a plain file the dealer only looks for record starts around the nominal cut points (1 MiB windows); the bytes
+themselves are read by the feeders (``preadv`` straight into their pinned buffers), so no single thread touches
+all the data.
 """
 import ctypes as C
+import os
 import threading
+import time
 from collections import deque
 from concurrent.futures import ThreadPoolExecutor
-from typing import BinaryIO, Dict, List, Optional, Sequence, Union
+from typing import BinaryIO, Dict, List, Optional, Sequence, Tuple, Union
 
 import numpy as np
 
@@ -71,6 +89,8 @@ class _Worker:
         self.h_info = torch.zeros(8, dtype=torch.int64).pin_memory()
         self.counters = torch.zeros(8, dtype=torch.int64, device=self.device)   # see cah_trim_decide_device
         self._ws = None
+        self.n = self.n_bytes = 0
+        self.busy_s, self.chunks, self.bytes_in = 0.0, 0, 0   # per-device rates (trim_fastq_gpu's "per_device")
         self.stream.wait_stream(torch.cuda.current_stream(self.device))   # (the zeroing / uploads above ran on it)
 
     def _ensure(self, nbytes: int):
@@ -101,17 +121,31 @@ class _Worker:
         self.rcap = cap
         self._ws = None
 
-    def run(self, data, is_final: bool):
-        """data: uint8 numpy array or torch tensor on the host holding whole records -> (pinned buffer, bytes)"""
+    def read_range(self, fd: int, offset: int, length: int):
+        """bytes [offset, offset + length) of an open file, read straight into this worker's pinned staging buffer"""
+        torch = self.torch
+        torch.cuda.set_device(self.device)
+        self._ensure(length)
+        if self.h_in is None or self.h_in.numel() < length:
+            self.h_in = torch.empty(self.cap, dtype=torch.uint8).pin_memory()
+        view = memoryview(self.h_in.numpy())[:length]
+        got = 0
+        while got < length:
+            k = os.preadv(fd, [view[got:]], offset + got)
+            if k <= 0:
+                raise IOError("the input file shrank while it was being read")
+            got += k
+        return self.h_in[:length]
+
+    def load(self, data) -> int:
+        """steps 0-2 of a chunk: raw bytes -> HBM, line count, record index.  -> number of records (the stream is
+        synchronised once, after the line count)."""
         torch = self.torch
         L = _lib.lib()
         n_bytes = int(len(data))
-        if n_bytes == 0:
-            return None, 0
-        torch.cuda.set_device(self.device)
         self._ensure(n_bytes)
         sp = self.stream.cuda_stream
-        with torch.cuda.stream(self.stream):
+        if True:
             # ---- raw chunk -> HBM (from pinned memory: the input itself if it is pinned, else staged) ----------
             if isinstance(data, torch.Tensor) and data.is_pinned():
                 src = data
@@ -145,6 +179,64 @@ class _Worker:
             _lib.check(L.cah_fastq_index_device(self.d_in.data_ptr(), n_bytes, n_newlines, n, self.d_scratch.data_ptr(),
                                                 self.d_scratch.numel(), self.rec6.data_ptr(), self.seq_off.data_ptr(),
                                                 self.seq_len.data_ptr(), self.d_info.data_ptr(), sp))
+        self.n, self.n_bytes = n, n_bytes
+        return n
+
+    def check_index(self) -> None:
+        """raise the format error the index step left in d_info, if any (synchronises the stream)"""
+        self.h_info.copy_(self.d_info, non_blocking=True)
+        self.stream.synchronize()
+        self._raise_format_error(int(self.h_info[1]))
+
+    @staticmethod
+    def _raise_format_error(err: int) -> None:
+        if err != -1:
+            code, record = err & 0xFF, (err >> 8) - 1
+            what = {1: "line expected to start with '@'", 2: "third line expected to start with '+'",
+                    3: "length of sequence and qualities differ"}.get(code, "malformed record")
+            raise ValueError(f"FASTQ format error in record {record} of the chunk: {what}")
+
+    def run(self, data, is_final: bool):
+        """data: uint8 numpy array or torch tensor on the host holding whole records -> (pinned buffer, bytes)"""
+        torch = self.torch
+        L = _lib.lib()
+        if int(len(data)) == 0:
+            return None, 0
+        torch.cuda.set_device(self.device)
+        t0 = time.perf_counter()
+        try:
+            with torch.cuda.stream(self.stream):
+                return self._run(data, L)
+        finally:
+            self.busy_s += time.perf_counter() - t0
+            self.chunks += 1
+            self.bytes_in += int(len(data))
+
+    def run_general(self, data, job):
+        """the general way (module docstring): index on the device, then ``job`` (a callable taking the
+        DeviceFastqChunk) does the rest -> whatever job returns, plus the pinned buffers to recycle"""
+        torch = self.torch
+        if int(len(data)) == 0:
+            return None, []
+        torch.cuda.set_device(self.device)
+        t0 = time.perf_counter()
+        try:
+            with torch.cuda.stream(self.stream):
+                n = self.load(data)
+                self.check_index()
+                chunk = DeviceFastqChunk(self, data, n, self.n_bytes)
+                return job(chunk), chunk.out_bufs
+        finally:
+            self.busy_s += time.perf_counter() - t0
+            self.chunks += 1
+            self.bytes_in += int(len(data))
+
+    def _run(self, data, L):
+        torch = self.torch
+        sp = self.stream.cuda_stream
+        n = self.load(data)
+        n_bytes = self.n_bytes
+        if True:
             # ---- step 3: match the reads in place, decide what is kept ------------------------------------------
             o = self.opts
             if n:
@@ -172,12 +264,7 @@ class _Worker:
             self.d_info[4:5].copy_(self.counters[6:7], non_blocking=True)
             self.h_info.copy_(self.d_info, non_blocking=True)
             self.stream.synchronize()
-            err = int(self.h_info[1])
-            if err != -1:
-                code, record = err & 0xFF, (err >> 8) - 1
-                what = {1: "line expected to start with '@'", 2: "third line expected to start with '+'",
-                        3: "length of sequence and qualities differ"}.get(code, "malformed record")
-                raise ValueError(f"FASTQ format error in record {record} of the chunk: {what}")
+            self._raise_format_error(int(self.h_info[1]))
             if int(self.h_info[4]) != 0:
                 _lib.raise_invalid_reads(int(self.seq_len[:max(n, 1)].max().item()))
             total = int(self.h_info[3])
@@ -210,12 +297,7 @@ class _Worker:
             self._h_end[:n].copy_(self.end[:n], non_blocking=True)
             self._h_keep[:n].copy_(self.keep[:n], non_blocking=True)
         self.stream.synchronize()
-        err = int(self.h_info[1])
-        if err != -1:
-            code, record = err & 0xFF, (err >> 8) - 1
-            what = {1: "line expected to start with '@'", 2: "third line expected to start with '+'",
-                    3: "length of sequence and qualities differ"}.get(code, "malformed record")
-            raise ValueError(f"FASTQ format error in record {record} of the chunk: {what}")
+        self._raise_format_error(int(self.h_info[1]))
         if int(self.h_info[4]) != 0:
             _lib.raise_invalid_reads(int(self.seq_len[:max(n, 1)].max().item()))
         h_out = self.pool.get(n_bytes + 4 * n + 64)
@@ -227,9 +309,84 @@ class _Worker:
         return h_out, int(out_len.value)
 
 
+class DeviceFastqChunk:
+    """A raw FASTQ chunk in HBM with its record index, as a worker's ``load()`` left it: what ``pipeline.FastqChunk``
+    offers the modifiers (lengths / reads / qualities / writers), without packing anything -- the reads and the
+    qualities are offsets + lengths INTO the raw chunk.  Lives until the worker loads its next chunk."""
+
+    def __init__(self, worker: "_Worker", data, n: int, n_bytes: int):
+        self.w = worker
+        self.data = data
+        self.n = n
+        self.n_bytes = n_bytes
+        self.out_bufs: list = []                             # pinned output buffers handed out by write_records
+        self._host = None
+        self._lens = None
+
+    def __len__(self):
+        return self.n
+
+    def lengths(self) -> np.ndarray:
+        if self._lens is None:
+            self._lens = self.w.seq_len[:self.n].cpu().numpy().astype(np.int64) if self.n else np.zeros(0, np.int64)
+        return self._lens
+
+    def reads(self, device=None):
+        from .batch import ReadBatch
+        w = self.w
+        return ReadBatch(w.d_in, w.seq_off[:self.n], w.seq_len[:self.n], n_reads=self.n)
+
+    def qualities(self, base):
+        w = self.w
+        return w.d_in, w.rec6[:self.n, 4].contiguous()
+
+    def host_chunk(self):
+        """the same chunk for the host-side writers: the raw bytes (they are in host memory anyway) + the device's
+        record index brought back (48 bytes per record; nothing is parsed on the host)"""
+        if self._host is None:
+            from .pipeline import FastqChunk
+            torch = self.w.torch
+            buf = self.data.numpy() if isinstance(self.data, torch.Tensor) else np.asarray(self.data)
+            rec = self.w.rec6[:self.n].cpu().numpy() if self.n else np.zeros((0, 6), np.int64)
+            self._host = FastqChunk(buf, rec)
+        return self._host
+
+    def write_records(self, beg, end, keep=None, mode: int = 0):
+        if mode != 0:
+            return self.host_chunk().write_records(beg, end, keep, mode)
+        w, n = self.w, self.n
+        torch = w.torch
+        L = _lib.lib()
+        if n:
+            w.beg[:n].copy_(torch.from_numpy(np.ascontiguousarray(beg, dtype=np.int32)), non_blocking=False)
+            w.end[:n].copy_(torch.from_numpy(np.ascontiguousarray(end, dtype=np.int32)), non_blocking=False)
+            if keep is None:
+                w.keep[:n].fill_(1)
+            else:
+                w.keep[:n].copy_(torch.from_numpy(np.ascontiguousarray(keep, dtype=np.uint8)), non_blocking=False)
+        sp = torch.cuda.current_stream(w.device).cuda_stream
+        _lib.check(L.cah_fastq_format_device(w.d_in.data_ptr(), w.rec6.data_ptr(), n, w.beg.data_ptr(), w.end.data_ptr(),
+                                             w.keep.data_ptr(), w.d_scratch.data_ptr(), w.d_scratch.numel(), self.n_bytes,
+                                             w.d_out.data_ptr(), w.d_out.numel(), w.d_info.data_ptr(), sp))
+        w.h_info.copy_(w.d_info, non_blocking=True)
+        torch.cuda.current_stream(w.device).synchronize()
+        total = int(w.h_info[3])
+        h_out = w.pool.get(total)
+        h_out[:total].copy_(w.d_out[:total], non_blocking=True)
+        torch.cuda.current_stream(w.device).synchronize()
+        self.out_bufs.append(h_out)
+        return memoryview(h_out.numpy())[:total]
+
+    def write_info(self, rows, names, is_rc=None, final=None):
+        return self.host_chunk().write_info(rows, names, is_rc, final)
+
+    def reverse_complemented(self, is_rc, suffix=" rc"):
+        return self.host_chunk().reverse_complemented(is_rc, suffix)
+
+
 # buffers outlive a call: pinning host memory and growing device buffers cost tens of milliseconds, more than a
 # whole chunk -- workers (device buffers, stream) and pinned output buffers are recycled between calls
-_PINNED = _PinnedPool()
+_PINNED: Dict[str, _PinnedPool] = {}                        # one per device: its buffers sit on that GPU's NUMA node
 _IDLE_WORKERS: Dict[str, list] = {}
 _IDLE_LOCK = threading.Lock()
 
@@ -241,13 +398,16 @@ def _take_worker(plan, kinds, dev, opts) -> "_Worker":
         idle = _IDLE_WORKERS.get(key, [])
         w = idle.pop() if idle else None
     if w is None:
-        return _Worker(plan, kinds, dev, opts, _PINNED)
+        with _IDLE_LOCK:
+            pinned = _PINNED.setdefault(key, _PinnedPool())
+        return _Worker(plan, kinds, dev, opts, pinned)
     torch.cuda.set_device(w.device)
     w.plan, w.opts = plan, opts
     with torch.cuda.stream(w.stream):                           # ordered in front of the worker's next kernels
         w.kinds = torch.tensor(kinds, dtype=torch.uint8, device=w.device)
         w.counters.zero_()
     w._ws = None
+    w.busy_s, w.chunks, w.bytes_in = 0.0, 0, 0
     return w
 
 
@@ -258,20 +418,118 @@ def _give_back(w: "_Worker") -> None:
             idle.append(w)
 
 
-def _plan_for(adapters):
+def _adapter_list(adapters) -> list:
+    if adapters is None:
+        return []
     if isinstance(adapters, MultipleAdapters):
-        adapters = list(adapters._adapters)
-    elif isinstance(adapters, SingleAdapter):
-        adapters = [adapters]
-    adapters = list(adapters)
-    if not adapters:
-        raise ValueError("trim_fastq_gpu needs at least one adapter")
-    for a in adapters:
-        if not isinstance(a, SingleAdapter) or a._reverse_reads:
-            raise ValueError("the device-side FASTQ path takes single, non-rightmost adapters; use pipeline.trim_fastq")
-    plan = a._fused_plan if len(adapters) == 1 else _lib.Plan([a.matcher_spec() for a in adapters])
+        return list(adapters._adapters)
+    if isinstance(adapters, (list, tuple)):
+        return list(adapters)
+    return [adapters]
+
+
+def _plan_for(adapters):
+    """the fused plan + adapter kinds of the all-device way"""
+    plan = adapters[-1]._fused_plan if len(adapters) == 1 else _lib.Plan([a.matcher_spec() for a in adapters])
     kinds = [2 if isinstance(a, AnywhereAdapter) else (1 if a._remove_before else 0) for a in adapters]
-    return adapters, plan, kinds
+    return plan, kinds
+
+
+def _device_cpus(device) -> Optional[set]:
+    """the CPUs next to a GPU (its PCI device's local_cpulist), or None when the system does not say"""
+    import torch
+    try:
+        p = torch.cuda.get_device_properties(device)
+        bdf = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+        with open(f"/sys/bus/pci/devices/{bdf}/local_cpulist") as f:
+            text = f.read().strip()
+        cpus = set()
+        for part in text.split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        cpus &= os.sched_getaffinity(0)
+        return cpus or None
+    except Exception:
+        return None
+
+
+class _Feeder:
+    """One per GPU: ``threads`` worker threads (a HIP stream and a set of device + pinned buffers each), created
+    while this GPU is current and, when ``pin_cpus``, running on the CPUs next to it."""
+
+    def __init__(self, device, threads: int, pin_cpus: bool, make_worker):
+        self.device = device
+        self.make_worker = make_worker
+        self.cpus = _device_cpus(device) if pin_cpus else None
+        self.local = threading.local()
+        self.workers: list = []
+        self.lock = threading.Lock()
+        self.pool = ThreadPoolExecutor(max_workers=threads, initializer=self._enter_thread)
+
+    def _enter_thread(self) -> None:
+        import torch
+        if self.cpus:
+            try:
+                os.sched_setaffinity(0, self.cpus)          # pid 0: the calling thread
+            except OSError:
+                pass
+        torch.cuda.set_device(self.device)
+
+    def worker(self):
+        if not hasattr(self.local, "w"):
+            with self.lock:
+                slot = len(self.workers)
+                self.workers.append(None)
+            self.local.w = self.make_worker(self.device, slot)
+            with self.lock:
+                self.workers[slot] = self.local.w
+        return self.local.w
+
+    def submit(self, fn, *args):
+        return self.pool.submit(lambda: fn(self.worker(), *args))
+
+    def close(self) -> None:
+        self.pool.shutdown(wait=True)
+
+
+def _file_ranges(path: str, chunk_bytes: int):
+    """(offset, length, is_final) of record-aligned pieces of a plain FASTQ file; only 1 MiB windows around the
+    nominal cut points are read here (``cah_record_boundary``), the pieces themselves by whoever gets them"""
+    L = _lib.lib()
+    size = os.path.getsize(path)
+    fd = os.open(path, os.O_RDONLY)
+    try:
+        if size and os.pread(fd, 1, 0) == b">":
+            raise ValueError("the device-side path reads 4-line FASTQ; use pipeline.trim_fastq for FASTA")
+        pos = 0
+        while pos < size:
+            stop = min(size, pos + chunk_bytes)
+            window = 1 << 20
+            while stop < size:
+                w = min(window, stop - pos)
+                win = np.frombuffer(os.pread(fd, w, stop - w), dtype=np.uint8)
+                cut = C.c_int64(0)
+                _lib.check(L.cah_record_boundary(win.ctypes.data, len(win), 0, C.byref(cut)))
+                if cut.value:
+                    stop = stop - w + cut.value
+                    break
+                if w < stop - pos:
+                    window *= 8                              # no record start in the window: look further back
+                elif stop - pos >= 64 * chunk_bytes:
+                    raise ValueError("record larger than 64 chunks: not a FASTQ file?")
+                else:
+                    stop = min(size, stop + chunk_bytes)     # ... or the record is longer than the piece
+            yield pos, stop - pos, stop >= size
+            pos = stop
+    finally:
+        os.close(fd)
+
+
+def _is_plain_file(source) -> bool:
+    if not isinstance(source, (str, os.PathLike)) or not os.path.isfile(source):
+        return False
+    with open(source, "rb") as f:
+        return f.read(2) != b"\x1f\x8b"
 
 
 def _chunks(source, chunk_bytes: int):
@@ -314,87 +572,336 @@ def _chunks(source, chunk_bytes: int):
         yield prev, True
 
 
-def trim_fastq_gpu(source: Union[str, BinaryIO, np.ndarray], out: Union[str, BinaryIO, None], adapters,
-                   discard_untrimmed: bool = False, discard_trimmed: bool = False,
-                   minimum_length: Optional[int] = None, maximum_length: Optional[int] = None,
-                   chunk_bytes: int = DEFAULT_GPU_CHUNK_BYTES, threads: int = 3, devices=None,
-                   assemble: str = "device") -> Dict[str, object]:
-    """``cutadapt <adapter options> [-m N] [-M N] [--discard-(un)trimmed] -o out in.fastq`` with the records
-    indexed, matched, filtered and formatted on the GPU(s).  ``out``: path, binary file, or None (the output is
-    produced and counted but not kept: measures the pipeline without a sink).  ``threads`` workers, each with
-    its own stream and pinned buffers, dealt round-robin over ``devices`` (list of indices, "all", or None =
-    current device).  ``assemble``: "device" formats the trimmed records on the GPU and brings the bytes back;
-    "host" brings back only the record index and kept intervals and copies the records together on the worker's
-    host core (same bytes; trades the outbound PCIe traffic for host memcpy); "mixed" lets every other worker do
-    that.  Returns the reference's counters
-    (report.py:62-80)."""
+def _resolve_devices(devices) -> list:
     import torch
-    if assemble not in ("device", "host", "mixed", "mixed3"):
-        raise ValueError("assemble must be 'device', 'host', 'mixed' or 'mixed3'")
-    adapters, plan, kinds = _plan_for(adapters)
-    pinned = _PINNED
-    opts = {"discard_untrimmed": discard_untrimmed, "discard_trimmed": discard_trimmed,
-            "minimum_length": minimum_length, "maximum_length": maximum_length, "assemble": assemble}
     if devices == "all":
         devices = list(range(torch.cuda.device_count()))
     elif devices is None:
         devices = [torch.cuda.current_device()]
     devices = [torch.device("cuda", d) if isinstance(d, int) else torch.device(d) for d in devices]
-    threads = max(1, int(threads))
-    local = threading.local()
-    workers: List[_Worker] = []
-    lock = threading.Lock()
+    if not devices:
+        raise ValueError("devices must name at least one GPU")
+    return devices
 
-    def work(data, is_final):
-        if not hasattr(local, "w"):
-            with lock:
-                dev = devices[len(workers) % len(devices)]
-                workers.append(None)
-                slot = len(workers) - 1
-            # "mixed": every other worker assembles on its host core -- the outbound PCIe traffic and the host's
-            # memcpy work are both halved (measured best when neither direction of the link is to be the bound)
-            # ("mixed3": two of three workers)
-            wopts = opts
-            if assemble == "mixed":
-                wopts = dict(opts, assemble="host" if slot % 2 else "device")
-            elif assemble == "mixed3":
-                wopts = dict(opts, assemble="host" if slot % 3 else "device")
-            local.w = _take_worker(plan, kinds, dev, wopts)
-            with lock:
-                workers[slot] = local.w
-        res = local.w.run(data, is_final)
-        if from_file:
-            from .pipeline import POOL
-            POOL.put(data)                                  # the reader's buffer is free again
+
+def _is_fasta(source) -> bool:
+    import torch
+    if isinstance(source, (np.ndarray, torch.Tensor)):
+        return bool(len(source)) and int(source[0]) == ord(">")
+    if isinstance(source, (str, os.PathLike)):
+        from .pipeline import _open_maybe_gz
+        f = _open_maybe_gz(source)
+        try:
+            return f.read(1) == b">"
+        finally:
+            f.close()
+    if hasattr(source, "peek"):
+        return source.peek(1)[:1] == b">"
+    if hasattr(source, "seek") and hasattr(source, "tell"):
+        at = source.tell()
+        first = source.read(1)
+        source.seek(at)
+        return first == b">"
+    return False
+
+
+def _per_device(feeders, wall: float) -> Dict[str, dict]:
+    out = {}
+    for f in feeders:
+        ws = [w for w in f.workers if w is not None]
+        nbytes = sum(w.bytes_in for w in ws)
+        out[str(f.device)] = {"workers": len(ws), "chunks": sum(w.chunks for w in ws), "bytes_in": int(nbytes),
+                              "GB_per_s_in": nbytes / wall / 1e9 if wall > 0 else 0.0,
+                              "busy_fraction": (sum(w.busy_s for w in ws) / (wall * len(ws))) if ws and wall > 0 else 0.0,
+                              "cpus": len(f.cpus) if f.cpus else None}
+    return out
+
+
+def trim_fastq_gpu(source: Union[str, BinaryIO, np.ndarray], out: Union[str, BinaryIO, None], adapters=(),
+                   discard_untrimmed: bool = False, discard_trimmed: bool = False,
+                   minimum_length: Optional[int] = None, maximum_length: Optional[int] = None,
+                   chunk_bytes: int = DEFAULT_GPU_CHUNK_BYTES, threads: int = 3, devices=None,
+                   assemble: str = "device", times: int = 1, action: Optional[str] = "trim", index: bool = True,
+                   nextseq_trim: Optional[int] = None, quality_cutoff: Optional[Tuple[int, int]] = None,
+                   quality_base: int = 33, poly_a: bool = False, max_expected_errors: Optional[float] = None,
+                   cut: Sequence[int] = (), length: Optional[int] = None, revcomp: bool = False,
+                   rc_suffix: Optional[str] = " rc", info_file: Union[None, str, BinaryIO] = None) -> Dict[str, object]:
+    """``cutadapt [-u N] [--nextseq-trim N] [-q [F,]B] <adapter options> [--times N] [--action A] [--revcomp]
+    [--poly-a] [-l N] [--max-ee E] [-m N] [-M N] [--discard-(un)trimmed] [--info-file F] -o out in.fastq`` with the
+    records indexed, matched, filtered and formatted on the GPU(s) (module docstring: which option sets take the
+    all-device way and which the general way).  ``out``: path, binary file, or None (the output is produced and
+    counted but not kept: measures the pipeline without a sink).
+    ``devices``: list of indices, "all", or None = the current device; every device gets a feeder of ``threads``
+    worker threads (a stream and pinned buffers each), chunks are dealt round-robin over the devices and written
+    in chunk order (reference runners.py:116-134, :224-245).
+    ``assemble`` (all-device way): "device" formats the trimmed records on the GPU and brings the bytes back; "host"
+    brings back only the record index and kept intervals and copies the records together on the worker's host core
+    (same bytes; trades the outbound PCIe traffic for host memcpy); "mixed" lets every other worker do that.
+    Returns the reference's counters (report.py:62-80) + ``devices_used`` and ``per_device`` (chunks, bytes, input
+    rate and busy fraction of every feeder)."""
+    import torch
+    if assemble not in ("device", "host", "mixed", "mixed3"):
+        raise ValueError("assemble must be 'device', 'host', 'mixed' or 'mixed3'")
+    adapters = _adapter_list(adapters)
+    general_opts = dict(times=times, action=action, index=index, nextseq_trim=nextseq_trim, quality_cutoff=quality_cutoff,
+                        quality_base=quality_base, poly_a=poly_a, max_expected_errors=max_expected_errors, cut=cut,
+                        length=length, revcomp=revcomp, rc_suffix=rc_suffix)
+    if _is_fasta(source):
+        # a FASTA sequence may span lines: parsed and packed on the host, same trimmer (module docstring)
+        from .pipeline import trim_fastq
+        if isinstance(source, (np.ndarray, torch.Tensor)):
+            import io
+            source = io.BytesIO((source.numpy() if isinstance(source, torch.Tensor) else source).tobytes())
+        sink = out if out is not None else open(os.devnull, "wb")
+        try:
+            res = trim_fastq(source, sink, adapters, discard_untrimmed=discard_untrimmed, discard_trimmed=discard_trimmed,
+                             info_file=info_file, minimum_length=minimum_length, maximum_length=maximum_length,
+                             threads=threads, devices=devices, **general_opts)
+        finally:
+            if out is None:
+                sink.close()
+        res["devices_used"] = getattr(res["trimmer"], "devices_used", [str(_resolve_devices(devices)[0])])
+        res["way"] = "host-parsed (FASTA)"
         return res
+    all_device = (adapters and times == 1 and action == "trim" and nextseq_trim is None and quality_cutoff is None
+                  and not poly_a and max_expected_errors is None and not list(cut) and length is None and not revcomp
+                  and info_file is None
+                  and all(isinstance(a, SingleAdapter) and not a._reverse_reads for a in adapters))
+    devices = _resolve_devices(devices)
+    threads = max(1, int(threads))
+    opts = {"discard_untrimmed": discard_untrimmed, "discard_trimmed": discard_trimmed,
+            "minimum_length": minimum_length, "maximum_length": maximum_length, "assemble": assemble}
+    from .pipeline import BatchTrimmer
+    if all_device:
+        plan, kinds = _plan_for(adapters)
+    else:
+        plan, kinds = None, []
+        BatchTrimmer(adapters, device=devices[0], **general_opts)       # option errors surface here, not in a worker
 
-    from_file = not isinstance(source, (np.ndarray, torch.Tensor))
+    def make_worker(dev, slot):
+        # "mixed": every other worker assembles on its host core -- the outbound PCIe traffic and the host's
+        # memcpy work are both halved (measured best when neither direction of the link is to be the bound)
+        # ("mixed3": two of three workers)
+        wopts = opts
+        if assemble == "mixed":
+            wopts = dict(opts, assemble="host" if slot % 2 else "device")
+        elif assemble == "mixed3":
+            wopts = dict(opts, assemble="host" if slot % 3 else "device")
+        w = _take_worker(plan, kinds, dev, wopts)
+        w.trimmer = None if all_device else BatchTrimmer(adapters, device=dev, **general_opts)
+        return w
+
+    ranged = _is_plain_file(source)
+    fd = os.open(source, os.O_RDONLY) if ranged else None
+    from_pool = not ranged and not isinstance(source, (np.ndarray, torch.Tensor))
+    want_info = info_file is not None
+
+    def work(w: _Worker, item, is_final):
+        data = w.read_range(fd, item[0], item[1]) if ranged else item
+        try:
+            if all_device:
+                buf, total = w.run(data, is_final)
+                return (memoryview(buf.numpy())[:total] if buf is not None else b""), ([buf] if buf is not None else []), None, w
+            info: Optional[list] = [] if want_info else None
+            body, bufs = w.run_general(data, lambda chunk: w.trimmer.process_chunk(
+                chunk, discard_untrimmed, discard_trimmed, info, minimum_length, maximum_length))
+            return (body if body is not None else b""), bufs, (b"".join(info) if info is not None else None), w
+        finally:
+            if from_pool:
+                from .pipeline import POOL
+                POOL.put(data)                              # the reader's buffer is free again
+
+    feeders = [_Feeder(dev, threads, len(devices) > 1, make_worker) for dev in devices]
     sink = None if out is None else (out if hasattr(out, "write") else open(out, "wb"))
+    inf = None if info_file is None else (info_file if hasattr(info_file, "write") else open(info_file, "wb"))
     bytes_out = 0
+    t_start = time.perf_counter()
     try:
         pending: deque = deque()
-        with ThreadPoolExecutor(max_workers=threads) as pool:
-            def drain(limit: int) -> None:
-                nonlocal bytes_out
-                while len(pending) > limit:
-                    buf, total = pending.popleft().result()
-                    bytes_out += total
-                    if buf is not None:
-                        if sink is not None and total:
-                            sink.write(memoryview(buf.numpy())[:total])      # straight from the pinned buffer
-                        pinned.put(buf)
-            for data, is_final in _chunks(source, chunk_bytes):
-                pending.append(pool.submit(work, data, is_final))
-                drain(2 * threads)
-            drain(0)
+
+        def drain(limit: int) -> None:
+            nonlocal bytes_out
+            while len(pending) > limit:
+                body, bufs, info, w = pending.popleft().result()
+                bytes_out += len(body)
+                if sink is not None and len(body):
+                    sink.write(body)                        # straight from the pinned buffer
+                if inf is not None and info:
+                    inf.write(info)
+                body = None
+                for b in bufs:
+                    w.pool.put(b)
+        items = _file_ranges(source, chunk_bytes) if ranged else _chunks(source, chunk_bytes)
+        for i, it in enumerate(items):
+            item, is_final = ((it[0], it[1]), it[2]) if ranged else it
+            pending.append(feeders[i % len(feeders)].submit(work, item, is_final))
+            drain(2 * threads * len(feeders))
+        drain(0)
     finally:
+        for f in feeders:
+            f.close()
+        if fd is not None:
+            os.close(fd)
         if sink is not None and sink is not out:
             sink.close()
-    stats = np.zeros(8, dtype=np.int64)
-    for w in workers:
-        if w is not None:
+        if inf is not None and inf is not info_file:
+            inf.close()
+    wall = time.perf_counter() - t_start
+    workers = [w for f in feeders for w in f.workers if w is not None]
+    result: Dict[str, object] = {"bytes_out": int(bytes_out), "per_device": _per_device(feeders, wall),
+                                 "devices_used": sorted({str(w.device) for w in workers}),
+                                 "way": "all-device" if all_device else "general"}
+    if all_device:
+        stats = np.zeros(8, dtype=np.int64)
+        for w in workers:
             stats += w.counters.cpu().numpy()
-            _give_back(w)
-    return {"reads": int(stats[0]), "with_adapters": int(stats[1]), "bp_in": int(stats[2]), "bp_out": int(stats[3]),
-            "bytes_out": int(bytes_out), "filtered": {"too_short": int(stats[4]), "too_long": int(stats[5])},
-            "devices_used": sorted({str(w.device) for w in workers if w is not None})}
+        result.update({"reads": int(stats[0]), "with_adapters": int(stats[1]), "bp_in": int(stats[2]),
+                       "bp_out": int(stats[3]), "filtered": {"too_short": int(stats[4]), "too_long": int(stats[5])}})
+    else:
+        total = BatchTrimmer(adapters, device=devices[0], **general_opts)
+        for w in workers:
+            total.merge(w.trimmer)
+        cutter = total.cutter
+        result.update({"reads": total.reads, "with_adapters": cutter.with_adapters if cutter else 0,
+                       "bp_in": total.bp_in, "bp_out": total.bp_out, "filtered": dict(total.filtered),
+                       "cutter": cutter, "trimmer": total,
+                       "reverse_complemented": total.rc.reverse_complemented if total.rc is not None else None})
+    for w in workers:
+        w.trimmer = None
+        _give_back(w)
+    return result
+
+
+def _paired_pieces(source1, source2, chunk_bytes: int):
+    """pairs of raw 4-line-FASTQ pieces with the SAME number of records (the job of dnaio.read_paired_chunks,
+    reference runners.py:104-113) -- found by counting line feeds, nothing is parsed: each side is read in blocks,
+    the side with fewer complete records decides, the surplus of the other side is carried over."""
+    from .pipeline import _open_maybe_gz
+    files = [_open_maybe_gz(source1), _open_maybe_gz(source2)]
+    carry = [np.zeros(0, np.uint8), np.zeros(0, np.uint8)]
+    eof = [False, False]
+    try:
+        while True:
+            data, ends = [], []
+            for k in (0, 1):
+                block = b"" if eof[k] else files[k].read(chunk_bytes)
+                if not block:
+                    eof[k] = True
+                d = np.concatenate([carry[k], np.frombuffer(block, dtype=np.uint8)]) if len(block) else carry[k]
+                if len(d) and d[0] == ord(">"):
+                    raise ValueError("the device-side path reads 4-line FASTQ; use pipeline.trim_fastq_paired for FASTA")
+                nl = np.flatnonzero(d == 10)
+                e = nl[3::4] + 1                             # the end of every complete record
+                if eof[k] and len(d) and d[-1] != 10 and len(nl) % 4 == 3:
+                    e = np.append(e, len(d))                 # a last record without a final line feed
+                data.append(d)
+                ends.append(e)
+            n = min(len(ends[0]), len(ends[1]))
+            if n == 0:
+                if eof[0] and eof[1]:
+                    if len(data[0]) or len(data[1]):
+                        if len(ends[0]) != len(ends[1]):
+                            raise ValueError("Reads are improperly paired. There are more reads in one file than in the other.")
+                        raise ValueError("FASTQ format error: premature end of file (incomplete record)")
+                    return
+                if all(len(d) > 64 * chunk_bytes for d in data):
+                    raise ValueError("record larger than 64 chunks: not a FASTQ file?")
+                carry = data
+                continue
+            cuts = [int(ends[0][n - 1]), int(ends[1][n - 1])]
+            carry = [data[0][cuts[0]:], data[1][cuts[1]:]]
+            yield data[0][:cuts[0]], data[1][:cuts[1]]
+    finally:
+        for f, src in zip(files, (source1, source2)):
+            if f is not src:
+                f.close()
+
+
+def trim_fastq_gpu_paired(in1, in2, out1, out2, r1: Optional[dict] = None, r2: Optional[dict] = None,
+                          pair_filter: Optional[str] = None, minimum_length=None, maximum_length=None,
+                          discard_untrimmed: bool = False, discard_trimmed: bool = False,
+                          chunk_bytes: int = DEFAULT_GPU_CHUNK_BYTES, threads: int = 2, devices=None,
+                          pair_adapters: bool = False) -> Dict[str, object]:
+    """``pipeline.trim_fastq_paired`` (same arguments and result) with both mates' chunks indexed and formatted on
+    the GPU(s): a worker holds a pair of chunks (two raw buffers in HBM, one stream), runs ``PairedJob.process_pair``
+    on them and the writer keeps both outputs in chunk order.  FASTA input goes to the host-parsed pipeline."""
+    import torch
+    from .pipeline import PairedJob, trim_fastq_paired
+    if _is_fasta(in1) or _is_fasta(in2):
+        return trim_fastq_paired(in1, in2, out1, out2, r1, r2, pair_filter, minimum_length, maximum_length,
+                                 discard_untrimmed, discard_trimmed, device=_resolve_devices(devices)[0],
+                                 pair_adapters=pair_adapters)
+    devices = _resolve_devices(devices)
+    threads = max(1, int(threads))
+
+    def make_job(dev):
+        return PairedJob(r1, r2, pair_filter, minimum_length, maximum_length, discard_untrimmed, discard_trimmed, dev,
+                         pair_adapters)
+
+    total = make_job(devices[0])                             # option errors surface here, not in a worker
+
+    def make_worker(dev, slot):
+        w = _take_worker(None, [], dev, {})
+        w.mate = _take_worker(None, [], dev, {})
+        w.mate.stream = w.stream                             # one stream for the pair
+        w.job = make_job(dev)
+        return w
+
+    def work(w: _Worker, d1, d2):
+        if len(d1) == 0:
+            return b"", b"", [], w
+        torch.cuda.set_device(w.device)
+        t0 = time.perf_counter()
+        try:
+            with torch.cuda.stream(w.stream):
+                chunks = []
+                for ww, d in ((w, d1), (w.mate, d2)):
+                    n = ww.load(d)
+                    ww.check_index()
+                    chunks.append(DeviceFastqChunk(ww, d, n, ww.n_bytes))
+                b1, b2 = w.job.process_pair(chunks[0], chunks[1])
+                return b1, b2, chunks[0].out_bufs + chunks[1].out_bufs, w
+        finally:
+            w.busy_s += time.perf_counter() - t0
+            w.chunks += 1
+            w.bytes_in += len(d1) + len(d2)
+
+    feeders = [_Feeder(dev, threads, len(devices) > 1, make_worker) for dev in devices]
+    o1 = out1 if hasattr(out1, "write") else open(out1, "wb")
+    o2 = out2 if hasattr(out2, "write") else open(out2, "wb")
+    t_start = time.perf_counter()
+    try:
+        pending: deque = deque()
+
+        def drain(limit: int) -> None:
+            while len(pending) > limit:
+                b1, b2, bufs, w = pending.popleft().result()
+                o1.write(b1)
+                o2.write(b2)
+                b1 = b2 = None
+                for b in bufs:
+                    w.pool.put(b)
+        for i, (d1, d2) in enumerate(_paired_pieces(in1, in2, chunk_bytes)):
+            pending.append(feeders[i % len(feeders)].submit(work, d1, d2))
+            drain(2 * threads * len(feeders))
+        drain(0)
+    finally:
+        for f in feeders:
+            f.close()
+        if o1 is not out1:
+            o1.close()
+        if o2 is not out2:
+            o2.close()
+    wall = time.perf_counter() - t_start
+    workers = [w for f in feeders for w in f.workers if w is not None]
+    for w in workers:
+        total.merge(w.job)
+    result = total.result()
+    result["devices_used"] = sorted({str(w.device) for w in workers})
+    result["per_device"] = _per_device(feeders, wall)
+    for w in workers:
+        mate, w.mate, w.job = w.mate, None, None
+        mate.stream = torch.cuda.Stream(device=mate.device)      # (it shared its partner's)
+        _give_back(mate)
+        _give_back(w)
+    return result

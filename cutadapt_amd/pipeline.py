@@ -116,6 +116,26 @@ class FastqChunk:
             self._packed = (seqs[:int(offsets[-1])], offsets)
         return self._packed
 
+    # -- what the modifiers need of a chunk (gpu_pipeline.DeviceFastqChunk offers the same three, in place in HBM) --
+    def lengths(self) -> np.ndarray:
+        offsets = self.pack_sequences()[1]
+        return (offsets[1:] - offsets[:-1]).astype(np.int64)
+
+    def reads(self, device=None):
+        """the reads of the chunk in HBM (a packed ReadBatch)"""
+        from .batch import ReadBatch
+        seqs, offsets = self.pack_sequences()
+        return ReadBatch.from_host(seqs, offsets, device=device)
+
+    def qualities(self, base):
+        """-> (byte tensor on base's device, int64 start of every read's qualities in it or None = packed like
+        ``base``); None for FASTA"""
+        import torch
+        q = self.pack_qualities()
+        if q is None:
+            return None
+        return torch.from_numpy(q).to(base.device), None
+
     def pack_qualities(self) -> Optional[np.ndarray]:
         """quality lines packed with the same offsets as the sequences; None for FASTA"""
         n = len(self.rec)
@@ -180,9 +200,11 @@ class FastqChunk:
         self.derived = chunk
         return chunk
 
-    def write_info(self, rows: np.ndarray, names: Sequence[str], is_rc: Optional[np.ndarray] = None) -> bytes:
+    def write_info(self, rows: np.ndarray, names: Sequence[str], is_rc: Optional[np.ndarray] = None,
+                   final: Optional[Tuple[np.ndarray, np.ndarray]] = None) -> bytes:
         """--info-file rows for this chunk; rows int64[k,7] as cah_info_write takes them.  ``is_rc``: per read, fills
-        the reverse-complement column (--revcomp)."""
+        the reverse-complement column (--revcomp).  ``final`` = (beg, end): what is written of every read -- shown
+        on the line of a read without a match."""
         n = len(self.rec)
         seqs, offsets = self.pack_sequences()
         rows = np.ascontiguousarray(rows, dtype=np.int64).reshape(-1, 7)
@@ -194,10 +216,14 @@ class FastqChunk:
         out = np.empty(cap, dtype=np.uint8)
         out_len = C.c_int64(0)
         flags = None if is_rc is None else np.ascontiguousarray(is_rc, dtype=np.uint8)
+        fb = fe = None
+        if final is not None:
+            fb, fe = (np.ascontiguousarray(x, dtype=np.int32) for x in final)
         _lib.check(_lib.lib().cah_info_write_rc(
             self.buf.ctypes.data, self.rec.ctypes.data, n, seqs.ctypes.data if len(seqs) else None,
             offsets.ctypes.data, rows.ctypes.data if len(rows) else None, len(rows), blob,
             name_off.ctypes.data, len(names), flags.ctypes.data if flags is not None else None,
+            fb.ctypes.data if fb is not None else None, fe.ctypes.data if fe is not None else None,
             out.ctypes.data, cap, C.byref(out_len)))
         return out[:out_len.value].tobytes()
 
@@ -256,7 +282,7 @@ def read_raw_chunks(path_or_file: Union[str, BinaryIO], chunk_bytes: int = DEFAU
         buf = POOL.get(len(carry) + chunk_bytes)
         if carry:
             buf[:len(carry)] = np.frombuffer(carry, dtype=np.uint8)
-        got = f.readinto(memoryview(buf)[len(carry):]) if hasattr(f, "readinto") else None
+        got = f.readinto(memoryview(buf)[len(carry):len(carry) + chunk_bytes]) if hasattr(f, "readinto") else None
         if got is None:
             block = f.read(chunk_bytes)
             got = len(block)
@@ -311,8 +337,9 @@ class _Round:
         self.ret_beg, self.ret_end = z(), z()
         self.crop_beg, self.crop_end = z(), z()
         self.can_crop = np.ones(n, dtype=bool)
-        # rows: columns (read, errors, rstart, rstop, rel_wbeg, rel_wend, name_id, stat_slot, removed_len, order)
-        self.rows = np.zeros((0, 10), dtype=np.int64)
+        # rows: columns (read, errors, rstart, rstop, rel_wbeg, rel_wend, name_id, stat_slot, removed_len, order,
+        # remove_before)
+        self.rows = np.zeros((0, 11), dtype=np.int64)
 
     def take_better(self, other: "_Round") -> None:
         """MultipleAdapters' rule (reference adapters.py:1278-1285): higher score, then fewer
@@ -329,9 +356,11 @@ class _Round:
         self.rows = np.concatenate([self.rows[keep_own], other.rows[take]])
 
 
-def _rows_for(idx: np.ndarray, errors, rstart, rstop, rel_wbeg, rel_wend, name_id, stat_slot, removed, order: int):
+def _rows_for(idx: np.ndarray, errors, rstart, rstop, rel_wbeg, rel_wend, name_id, stat_slot, removed, order: int,
+              before=0):
     k = len(idx)
-    rows = np.empty((k, 10), dtype=np.int64)
+    rows = np.empty((k, 11), dtype=np.int64)
+    rows[:, 10] = before                                     # Match.trimmed() keeps what FOLLOWS the match
     rows[:, 0] = idx
     rows[:, 1] = errors
     rows[:, 2] = rstart
@@ -449,7 +478,7 @@ class BatchAdapterCutter:
         ids = np.asarray(adapter_ids, dtype=np.int64)[bm.adapter_index[idx].astype(np.int64)]
         slots = self._slot_of_adapter[ids]
         removed = np.where(before[idx], rstop[idx], lens[idx] - rstart[idx])     # removed_sequence_length()
-        r.rows = _rows_for(idx, c[idx, 5], rstart[idx], rstop[idx], 0, lens[idx], slots, slots, removed, 0)
+        r.rows = _rows_for(idx, c[idx, 5], rstart[idx], rstop[idx], 0, lens[idx], slots, slots, removed, 0, before[idx])
         return r
 
     def _linked_round(self, lm: LinkedBatchMatches, lens: np.ndarray, adapter_id: int) -> _Round:
@@ -470,7 +499,7 @@ class BatchAdapterCutter:
         r.can_crop[:] = False                                # LinkedMatch has no rstart/rstop
         fi, bi = np.flatnonzero(ff), np.flatnonzero(bf)
         s1, s2 = self._slot[(adapter_id, 0)], self._slot[(adapter_id, 1)]
-        rows1 = _rows_for(fi, fc[fi, 5], fc[fi, 2], fc[fi, 3], 0, lens[fi], s1, s1, fc[fi, 3], 0)
+        rows1 = _rows_for(fi, fc[fi, 5], fc[fi, 2], fc[fi, 3], 0, lens[fi], s1, s1, fc[fi, 3], 0, 1)
         rows2 = _rows_for(bi, bc[bi, 5], bc[bi, 2], bc[bi, 3], off[bi], lens[bi], s2, s2,
                           (lens[bi] - off[bi]) - bc[bi, 2], 1)
         r.rows = np.concatenate([rows1, rows2])
@@ -501,13 +530,16 @@ class BatchAdapterCutter:
         lens = (offsets[1:] - offsets[:-1]).astype(np.int64)
         if n and base is None:
             base = ReadBatch.from_host(seqs, offsets, device=self.device)
-        found = self.search(base, lens, window)
-        return self.commit(found, lens)
+        return self.process_batch(base, lens, window)
+
+    def process_batch(self, base, lens: np.ndarray, window=None):
+        """process_arrays for reads that are in HBM already (``base``: any ReadBatch, packed or a view)"""
+        return self.commit(self.search(base, lens, window), lens)
 
     def search(self, base, lens: np.ndarray, window=None) -> Dict[str, np.ndarray]:
         """``match_and_trim`` (reference modifiers.py:209-251) for every read of ``base``: all rounds, no statistics.
-        -> beg/end/matched as process_arrays returns them, ``rows`` int64[k,8] (process_arrays' seven columns + the
-        order of the match within its read), ``stats`` int64[k,3] = (statistics slot, removed length, errors) of
+        -> beg/end/matched as process_arrays returns them, ``rows`` int64[k,9] (process_arrays' seven columns, the
+        order of the match within its read, whether the match removes what is in front of it), ``stats`` int64[k,3] = (statistics slot, removed length, errors) of
         the same k matches and ``score``: the sum of the scores of a read's matches (what ReverseComplementer
         compares, modifiers.py:287-289)."""
         import torch
@@ -546,8 +578,9 @@ class BatchAdapterCutter:
                 rows = rr.rows
                 if len(rows):
                     rows = rows[np.lexsort((rows[:, 9], rows[:, 0]))]
-                    out = np.empty((len(rows), 8), dtype=np.int64)
+                    out = np.empty((len(rows), 9), dtype=np.int64)
                     gi = active[rows[:, 0]]
+                    out[:, 8] = rows[:, 10]
                     out[:, 0] = gi
                     out[:, 1:4] = rows[:, 1:4]
                     out[:, 4] = wbeg[gi] + rows[:, 4]
@@ -573,7 +606,7 @@ class BatchAdapterCutter:
             beg, end = w0beg, w0end
         else:                                                # trim, mask, lowercase: the remainder
             beg, end = wbeg, wend
-        rows = np.concatenate(all_rows) if all_rows else np.zeros((0, 8), dtype=np.int64)
+        rows = np.concatenate(all_rows) if all_rows else np.zeros((0, 9), dtype=np.int64)
         stats = np.concatenate(all_stats) if all_stats else np.zeros((0, 3), dtype=np.int64)
         if len(rows):
             order = np.lexsort((rows[:, 7], rows[:, 0]))
@@ -594,7 +627,7 @@ class BatchAdapterCutter:
         self.bp_in += int(lens.sum())
         self.bp_out += int((end - beg).sum()) if self.action in ("trim", "retain", "crop") else int(lens.sum())
         return {"beg": beg.astype(np.int32), "end": end.astype(np.int32), "matched": matched,
-                "rows": np.ascontiguousarray(rows[:, :7])}
+                "rows": np.ascontiguousarray(rows[:, :7]), "before": rows[:, 8].astype(bool)}
 
     # ---- compatibility with the first slice (times=1, trim) ---------------------------------
     def cut_intervals(self, seqs: np.ndarray, offsets: np.ndarray):
@@ -631,17 +664,21 @@ class BatchReverseComplementer:
     def process_arrays(self, seqs: np.ndarray, offsets: np.ndarray, base=None, window=None):
         """BatchAdapterCutter.process_arrays + ``rc``: bool per read.  Intervals and info rows of a reverse-complemented
         read are relative to the reverse complement of the read.  ``window`` is given on the forward read."""
-        from .adapters import _reverse_batch
         from .batch import ReadBatch
-        cutter = self.adapter_cutter
         n = len(offsets) - 1
         lens = (offsets[1:] - offsets[:-1]).astype(np.int64)
+        if n and base is None:
+            base = ReadBatch.from_host(seqs, offsets, device=self.adapter_cutter.device)
+        return self.process_batch(base, lens, window)
+
+    def process_batch(self, base, lens: np.ndarray, window=None):
+        from .adapters import _reverse_batch
+        cutter = self.adapter_cutter
+        n = len(lens)
         if n == 0:
             out = cutter.commit(cutter.search(None, lens, window), lens)
             out["rc"] = np.zeros(0, dtype=bool)
             return out
-        if base is None:
-            base = ReadBatch.from_host(seqs, offsets, device=cutter.device)
         fwd = cutter.search(base, lens, window)
         rbase = _reverse_batch(base, complement=True)
         rbase.validated = True                               # search(base) just validated the same bytes
@@ -660,6 +697,41 @@ class BatchReverseComplementer:
         out = cutter.commit(merged, lens, reverse_complemented=use)
         out["rc"] = use
         return out
+
+
+def _info_rows_on_original(rows: np.ndarray, before: np.ndarray, lens: np.ndarray) -> np.ndarray:
+    """Info rows as the reference prints them when other modifiers ran in front of the adapter step
+    (steps.py:232-247): InfoFileWriter starts from the read AS IT CAME IN (``info.original_read``), cuts it at the
+    coordinates of every match -- which were found on the read the earlier modifiers left -- and trims it the way the
+    match trims (``match.trimmed(current_read)``) before the next match.  rows: (read, errors, rstart, rstop, wbeg,
+    wend, name) sorted by read and match order; columns 4:6 are replaced by that window on the whole read."""
+    rows = rows.copy()
+    k = len(rows)
+    reads = rows[:, 0]
+    qb, qe = np.zeros(len(lens), dtype=np.int64), lens.astype(np.int64).copy()
+    first = np.ones(k, dtype=bool)
+    first[1:] = reads[1:] != reads[:-1]
+    rank = np.arange(k) - np.maximum.accumulate(np.where(first, np.arange(k), 0))
+    for j in range(int(rank.max()) + 1 if k else 0):
+        sel = np.flatnonzero(rank == j)
+        r = reads[sel]
+        b, e = qb[r], qe[r]
+        rows[sel, 4], rows[sel, 5] = b, e
+        rows[sel, 3] = np.minimum(rows[sel, 3], e - b)
+        rows[sel, 2] = np.minimum(rows[sel, 2], rows[sel, 3])
+        front = before[sel].astype(bool)
+        qb[r] = np.where(front, b + rows[sel, 3], b)
+        qe[r] = np.where(front, e, b + rows[sel, 2])
+    return rows
+
+
+def _materialized(chunk: "FastqChunk", obeg, oend, ibeg, iend, mode: int) -> "FastqChunk":
+    """The chunk with every record cut to [obeg, oend) and marked (mode 1 mask, 2 lowercase) outside [ibeg, iend)."""
+    n = len(chunk)
+    fasta = bool(n and chunk.rec[0, 4] < 0)
+    sliced = scan_chunk(np.frombuffer(bytes(chunk.write_records(obeg, oend, None, 0)), dtype=np.uint8).copy(), fasta)
+    marked = sliced.write_records((ibeg - obeg), (iend - obeg), None, mode)
+    return scan_chunk(np.frombuffer(bytes(marked), dtype=np.uint8).copy(), fasta)
 
 
 class BatchTrimmer:
@@ -695,9 +767,6 @@ class BatchTrimmer:
         if len(self.cut) == 2 and self.cut[0] * self.cut[1] > 0:
             raise ValueError("You cannot remove bases from the same end twice.")
         self.length = length                                   # Shortener, modifiers.py:882-899
-        pre = nextseq_trim is not None or quality_cutoff is not None or bool(self.cut)
-        if (pre or poly_a) and action in ("mask", "lowercase"):
-            raise NotImplementedError("mask/lowercase together with quality or poly-A trimming is not built yet")
         self.filtered: Dict[str, int] = {}
         self.nextseq_trimmed_bases = 0
         self.quality_trimmed_bases = 0
@@ -730,8 +799,7 @@ class BatchTrimmer:
         request = next(gen)                                 # everything in front of the adapter step is done
         res = None
         if request is not None and self.cutter is not None:
-            res = (self.rc or self.cutter).process_arrays(request["seqs"], request["offsets"], base=request["base"],
-                                                          window=request["window"])
+            res = (self.rc or self.cutter).process_batch(request["base"], request["lens"], request["window"])
         try:
             gen.send(res)
         except StopIteration as stop:
@@ -745,26 +813,34 @@ class BatchTrimmer:
         mates must reach this point before either is matched) and finishes with the remaining modifiers."""
         import torch
         from . import qualtrim as qt
-        from .batch import ReadBatch
-        seqs, offsets = chunk.pack_sequences()
-        n = len(offsets) - 1
-        lens = (offsets[1:] - offsets[:-1]).astype(np.int64)
+        if self.rc is not None and hasattr(chunk, "host_chunk"):
+            chunk = chunk.host_chunk()                      # the orientations are merged into a host-side chunk
+        n = len(chunk)
+        lens = chunk.lengths()
         wbeg, wend = np.zeros(n, dtype=np.int64), lens.copy()
         pre = self.nextseq_trim is not None or self.quality_cutoff is not None or bool(self.cut)
-        if info is not None and (pre or self.poly_a or self.length is not None):
-            raise NotImplementedError("--info-file together with other modifiers is not built yet")
-        base = ReadBatch.from_host(seqs, offsets, device=self.device) if n else None
-        quals = None
+        base = chunk.reads(self.device) if n else None
+        quals = qoff = None
+
+        def load_qualities(why: str):
+            nonlocal quals, qoff
+            if quals is None:
+                q = chunk.qualities(base)
+                if q is None:
+                    raise qt.HasNoQualities(why)
+                quals, qoff = q
+
         if (self.nextseq_trim is not None or self.quality_cutoff is not None) and n:
-            q = chunk.pack_qualities()
-            if q is None:
-                raise qt.HasNoQualities("Cannot do quality trimming when no qualities are available")
-            quals = torch.from_numpy(q).to(base.device)
+            load_qualities("Cannot do quality trimming when no qualities are available")
 
         def view_args():
             o = base.offsets[:n] + torch.from_numpy(wbeg).to(base.device)
             l = torch.from_numpy((wend - wbeg).astype(np.int32)).to(base.device)
             return o, l
+
+        def qual_view(o):
+            """where the current window's qualities start: packed like the reads, or at their own offsets"""
+            return o if qoff is None else qoff[:n] + torch.from_numpy(wbeg).to(base.device)
 
         for c in self.cut:                                   # read[c:] / read[:c]
             cur = wend - wbeg
@@ -774,21 +850,23 @@ class BatchTrimmer:
                 wend = wbeg + np.maximum(cur + c, 0)
         if self.nextseq_trim is not None and n:
             o, l = view_args()
-            stop = qt.nextseq_trim_batch(base.seqs, quals, o, l, n, self.nextseq_trim, self.quality_base).astype(np.int64)
+            stop = qt.nextseq_trim_batch(base.seqs, quals, o, l, n, self.nextseq_trim, self.quality_base,
+                                         qual_offsets=None if qoff is None else qual_view(o)).astype(np.int64)
             self.nextseq_trimmed_bases += int(((wend - wbeg) - stop).sum())
             wend = wbeg + stop
         if self.quality_cutoff is not None and n:
             o, l = view_args()
-            ss = qt.quality_trim_batch(quals, o, l, n, self.quality_cutoff[0], self.quality_cutoff[1],
+            ss = qt.quality_trim_batch(quals, qual_view(o), l, n, self.quality_cutoff[0], self.quality_cutoff[1],
                                        self.quality_base).astype(np.int64)
             self.quality_trimmed_bases += int(((wend - wbeg) - (ss[:, 1] - ss[:, 0])).sum())
             wbeg, wend = wbeg + ss[:, 0], wbeg + ss[:, 1]
         matched = np.zeros(n, dtype=bool)
         mode = 0
-        res = yield {"seqs": seqs, "offsets": offsets, "base": base, "window": (wbeg, wend) if pre else None,
-                     "lens": lens, "n": n}
+        res = yield {"base": base, "window": (wbeg, wend) if pre else None, "lens": lens, "n": n}
         out_chunk, is_rc = chunk, None
+        info_rows, info_chunk, info_shift = np.zeros((0, 7), np.int64), None, 0
         if res is not None:
+            w0beg, w0end = wbeg, wend
             wbeg, wend, matched = res["beg"].astype(np.int64), res["end"].astype(np.int64), res["matched"]
             mode = {"mask": 1, "lowercase": 2}.get(self.action, 0)
             is_rc = res.get("rc")
@@ -802,10 +880,23 @@ class BatchTrimmer:
                 if self.poly_a:
                     base = _reverse_batch(base, complement=True, select=sel)
                 out_chunk = chunk.reverse_complemented(is_rc, self.rc._suffix)
+                if pre:                                      # the window the search saw, in the winner's coordinates
+                    w0beg, w0end = np.where(is_rc, lens - w0end, w0beg), np.where(is_rc, lens - w0beg, w0end)
             if info is not None:
-                info.append(out_chunk.write_info(res["rows"], self.cutter.names, is_rc))
-        elif info is not None:
-            info.append(chunk.write_info(np.zeros((0, 7), np.int64), []))
+                info_rows = res["rows"]
+                if pre and len(info_rows):
+                    info_rows = _info_rows_on_original(info_rows, res["before"], lens)
+            if mode and n and (pre or self.poly_a or self.length is not None):
+                # mask / lowercase change characters, and the modifiers that follow look at characters: the reads
+                # are written out as they stand now (the window the earlier modifiers left, marked outside the
+                # adapter step's interval) and become the chunk everything else works on -- a rare combination
+                # of options, served by two formatting passes on the host instead of kernels of its own
+                info_chunk, info_shift = out_chunk, w0beg      # (the info file shows reads without the marking)
+                out_chunk = _materialized(out_chunk, w0beg, w0end, wbeg, wend, mode)
+                base = out_chunk.reads(self.device)
+                quals = qoff = None
+                wbeg, wend = np.zeros(n, dtype=np.int64), (w0end - w0beg).astype(np.int64)
+                mode = 0
         if self.poly_a and n:
             o, l = view_args()
             idx = qt.poly_a_trim_batch(base.seqs, o, l, n, self.poly_a_revcomp).astype(np.int64)
@@ -827,15 +918,25 @@ class BatchTrimmer:
         if self.max_expected_errors is not None and n:
             # TooManyExpectedErrors (reference predicates.py:55-71): the filter sees the read as trimmed so far
             if quals is None:
-                q = out_chunk.pack_qualities()
-                if q is None:
-                    raise qt.HasNoQualities("expected errors need qualities")
-                quals = torch.from_numpy(q).to(base.device)
+                if out_chunk is not chunk:                   # --revcomp / materialised: the chunk that is written
+                    q = out_chunk.pack_qualities()
+                    if q is None:
+                        raise qt.HasNoQualities("expected errors need qualities")
+                    quals = torch.from_numpy(q).to(base.device)
+                else:
+                    load_qualities("expected errors need qualities")
             o, l = view_args()
+            o = qual_view(o)
             ee, valid = qt.expected_errors_batch(quals, o, l, n, 33)      # the reference calls expected_errors(q) with its default base
             if not valid.all():
                 bad = int(np.flatnonzero(~valid)[0])
                 raise ValueError(f"Not a valid phred value in the qualities of read {bad} of the chunk")
+        if info is not None:
+            # match rows show the read as it came in, the line of a read without a match shows it as it is written
+            # (reference steps.py:232-253)
+            info.append((info_chunk or out_chunk).write_info(
+                info_rows, self.cutter.names if self.cutter is not None else [], is_rc,
+                final=(info_shift + wbeg, info_shift + wend)))
         self.reads += n
         self.bp_in += int(lens.sum())
         return {"beg": wbeg, "end": wend, "matched": matched, "mode": mode, "ee": ee, "lens": lens, "chunk": out_chunk,
@@ -1197,65 +1298,97 @@ def trim_fastq_paired(in1, in2, out1, out2, r1: Optional[dict] = None, r2: Optio
     for that mate, reference ``-m 5:7``).  Pairs are filtered as a unit with ``--pair-filter``
     any (default) / both / first; like the reference (cli.py:861-892), --discard-untrimmed uses
     'both' when only one mate has adapters."""
-    r1, r2 = dict(r1 or {}), dict(r2 or {})
-    if r2.get("poly_a"):
-        r2.setdefault("poly_a_revcomp", True)      # --poly-a on paired data: poly-T head of R2
-    paired_cutter = None
-    if pair_adapters:
-        # --pair-adapters (cli.py:594-632): adapter i of R1 is only removed together with adapter i of R2
-        if r1.get("times", 1) != 1 or r2.get("times", 1) != 1:
-            raise ValueError("--pair-adapters cannot be used with --times")
-        action = r1.get("action", "trim")
-        paired_cutter = BatchPairedAdapterCutter(r1.pop("adapters", ()), r2.pop("adapters", ()), action)
-        r1["action"] = r2["action"] = action
-    t1, t2 = BatchTrimmer(device=device, **r1), BatchTrimmer(device=device, **r2)
-
-    def both(v):
-        return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
-
-    min_len, max_len = both(minimum_length), both(maximum_length)
-    mode = "any" if pair_filter is None else pair_filter
-    if mode not in ("any", "both", "first"):
-        raise ValueError("pair_filter must be any, both or first")
-    one_sided = (t1.cutter is None or t2.cutter is None) and paired_cutter is None
-    untrimmed_mode = "both" if (one_sided and discard_untrimmed) else mode
+    job = PairedJob(r1, r2, pair_filter, minimum_length, maximum_length, discard_untrimmed, discard_trimmed, device,
+                    pair_adapters)
     o1 = out1 if hasattr(out1, "write") else open(out1, "wb")
     o2 = out2 if hasattr(out2, "write") else open(out2, "wb")
-    pairs = kept = 0
     try:
         for c1, c2 in read_paired_chunks(in1, in2, chunk_bytes):
-            if paired_cutter is None:
-                res1, res2 = t1.modify(c1), t2.modify(c2)
-            else:
-                g1, g2 = t1._modify_steps(c1), t2._modify_steps(c2)
-                a1, a2 = paired_cutter.process(next(g1), next(g2))
-                res = []
-                for g, a in ((g1, a1), (g2, a2)):
-                    try:
-                        g.send(a)
-                        raise RuntimeError("modify: the step generator did not finish")
-                    except StopIteration as stop:
-                        res.append(stop.value)
-                res1, res2 = res
-                mode_code = {"mask": 1, "lowercase": 2}.get(paired_cutter.action, 0)
-                res1["mode"] = res2["mode"] = mode_code
-            keep = filter_reads([res1, res2], [t1, t2], discard_untrimmed, discard_trimmed, min_len, max_len, mode,
-                                untrimmed_mode)
-            o1.write(t1.write(c1, res1, keep))
-            o2.write(t2.write(c2, res2, keep))
-            pairs += len(c1)
-            kept += len(c1) if keep is None else int(keep.sum())
+            b1, b2 = job.process_pair(c1, c2)
+            o1.write(b1)
+            o2.write(b2)
     finally:
         if o1 is not out1:
             o1.close()
         if o2 is not out2:
             o2.close()
-    if paired_cutter is not None:
-        with_adapters = (paired_cutter.with_adapters, paired_cutter.with_adapters)
-    else:
-        with_adapters = (t1.cutter.with_adapters if t1.cutter else 0, t2.cutter.with_adapters if t2.cutter else 0)
-    return {"pairs": pairs, "pairs_written": kept, "trimmers": (t1, t2), "filtered": dict(t1.filtered),
-            "with_adapters": with_adapters, "paired_cutter": paired_cutter}
+    return job.result()
+
+
+class PairedJob:
+    """Everything ``trim_fastq_paired`` decides once (the two trimmers, the pair filter's modes) + the work per
+    pair of chunks; shared by the host-parsed pipeline above and gpu_pipeline.trim_fastq_gpu_paired."""
+
+    def __init__(self, r1: Optional[dict] = None, r2: Optional[dict] = None, pair_filter: Optional[str] = None,
+                 minimum_length=None, maximum_length=None, discard_untrimmed: bool = False,
+                 discard_trimmed: bool = False, device=None, pair_adapters: bool = False):
+        r1, r2 = dict(r1 or {}), dict(r2 or {})
+        if r2.get("poly_a"):
+            r2.setdefault("poly_a_revcomp", True)      # --poly-a on paired data: poly-T head of R2
+        self.paired_cutter = None
+        if pair_adapters:
+            # --pair-adapters (cli.py:594-632): adapter i of R1 is only removed together with adapter i of R2
+            if r1.get("times", 1) != 1 or r2.get("times", 1) != 1:
+                raise ValueError("--pair-adapters cannot be used with --times")
+            action = r1.get("action", "trim")
+            self.paired_cutter = BatchPairedAdapterCutter(r1.pop("adapters", ()), r2.pop("adapters", ()), action)
+            r1["action"] = r2["action"] = action
+        self.t1, self.t2 = BatchTrimmer(device=device, **r1), BatchTrimmer(device=device, **r2)
+
+        def both(v):
+            return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+
+        self.min_len, self.max_len = both(minimum_length), both(maximum_length)
+        self.mode = "any" if pair_filter is None else pair_filter
+        if self.mode not in ("any", "both", "first"):
+            raise ValueError("pair_filter must be any, both or first")
+        one_sided = (self.t1.cutter is None or self.t2.cutter is None) and self.paired_cutter is None
+        self.untrimmed_mode = "both" if (one_sided and discard_untrimmed) else self.mode
+        self.discard_untrimmed, self.discard_trimmed = discard_untrimmed, discard_trimmed
+        self.pairs = self.kept = 0
+
+    def process_pair(self, c1, c2):
+        """two chunks with the same number of records -> the bytes to write for R1 and R2"""
+        t1, t2, paired_cutter = self.t1, self.t2, self.paired_cutter
+        if len(c1) != len(c2):
+            raise ValueError("Reads are improperly paired")
+        if paired_cutter is None:
+            res1, res2 = t1.modify(c1), t2.modify(c2)
+        else:
+            g1, g2 = t1._modify_steps(c1), t2._modify_steps(c2)
+            a1, a2 = paired_cutter.process(next(g1), next(g2))
+            res = []
+            for g, a in ((g1, a1), (g2, a2)):
+                try:
+                    g.send(a)
+                    raise RuntimeError("modify: the step generator did not finish")
+                except StopIteration as stop:
+                    res.append(stop.value)
+            res1, res2 = res
+        keep = filter_reads([res1, res2], [t1, t2], self.discard_untrimmed, self.discard_trimmed, self.min_len,
+                            self.max_len, self.mode, self.untrimmed_mode)
+        self.pairs += len(c1)
+        self.kept += len(c1) if keep is None else int(keep.sum())
+        return t1.write(c1, res1, keep), t2.write(c2, res2, keep)
+
+    def merge(self, other: "PairedJob") -> None:
+        self.t1.merge(other.t1)
+        self.t2.merge(other.t2)
+        self.pairs += other.pairs
+        self.kept += other.kept
+        if self.paired_cutter is not None and other.paired_cutter is not None:
+            self.paired_cutter.with_adapters += other.paired_cutter.with_adapters
+            for a, b in zip(self.paired_cutter.histograms, other.paired_cutter.histograms):
+                a += b
+
+    def result(self) -> Dict[str, object]:
+        t1, t2, paired_cutter = self.t1, self.t2, self.paired_cutter
+        if paired_cutter is not None:
+            with_adapters = (paired_cutter.with_adapters, paired_cutter.with_adapters)
+        else:
+            with_adapters = (t1.cutter.with_adapters if t1.cutter else 0, t2.cutter.with_adapters if t2.cutter else 0)
+        return {"pairs": self.pairs, "pairs_written": self.kept, "trimmers": (t1, t2), "filtered": dict(t1.filtered),
+                "with_adapters": with_adapters, "paired_cutter": paired_cutter}
 
 
 # -------------------------------------------------------------------------------------------------

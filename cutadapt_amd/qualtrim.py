@@ -48,14 +48,22 @@ def quality_trim_batch(quals, offsets, lens, n_reads: int, cutoff_front: int, cu
     return out.cpu().numpy()
 
 
-def nextseq_trim_batch(seqs, quals, offsets, lens, n_reads: int, cutoff: int, base: int = 33) -> np.ndarray:
+def nextseq_trim_batch(seqs, quals, offsets, lens, n_reads: int, cutoff: int, base: int = 33,
+                       qual_offsets=None) -> np.ndarray:
+    """``qual_offsets``: where the qualities of every read start in ``quals`` when they are not packed like the
+    sequences (a raw FASTQ chunk indexed on the device)"""
     torch = _torch()
     out = torch.zeros(n_reads, dtype=torch.int32, device=quals.device)
     if n_reads:
         with torch.cuda.device(quals.device):
-            _lib.check(_lib.lib().cah_nextseq_trim_batch(
-                seqs.data_ptr(), quals.data_ptr(), offsets.data_ptr(), lens.data_ptr() if lens is not None else None,
-                n_reads, int(cutoff), int(base), out.data_ptr(), _stream(quals.device)))
+            if qual_offsets is None:
+                _lib.check(_lib.lib().cah_nextseq_trim_batch(
+                    seqs.data_ptr(), quals.data_ptr(), offsets.data_ptr(), lens.data_ptr() if lens is not None else None,
+                    n_reads, int(cutoff), int(base), out.data_ptr(), _stream(quals.device)))
+            else:
+                _lib.check(_lib.lib().cah_nextseq_trim_batch_q(
+                    seqs.data_ptr(), quals.data_ptr(), offsets.data_ptr(), qual_offsets.data_ptr(), lens.data_ptr(),
+                    n_reads, int(cutoff), int(base), out.data_ptr(), _stream(quals.device)))
     return out.cpu().numpy()
 
 

@@ -288,10 +288,13 @@ int cah_info_write(const uint8_t *buf, const int64_t *rec, int64_t n_records, co
                    int64_t *out_len);
 
 /* ... with the reverse-complement column (steps.py:224, :243 RC_MAP): is_rc uint8[n_records], "1"/"0" per row
- * (NULL: the empty column cah_info_write writes, i.e. --revcomp was not given). */
+ * (NULL: the empty column cah_info_write writes, i.e. --revcomp was not given), and with final_beg/final_end
+ * int32[n_records] (both or neither): what the other modifiers left of a read, shown on the "-1" line of a read
+ * without a match (steps.py:248-251 prints the read as it is written; match rows show the read as it came in). */
 int cah_info_write_rc(const uint8_t *buf, const int64_t *rec, int64_t n_records, const uint8_t *seqs,
                       const int64_t *offsets, const int64_t *rows, int64_t n_rows, const char *names,
-                      const int64_t *name_off, int64_t n_names, const uint8_t *is_rc, uint8_t *out,
+                      const int64_t *name_off, int64_t n_names, const uint8_t *is_rc,
+                      const int32_t *final_beg, const int32_t *final_end, uint8_t *out,
                       int64_t out_cap, int64_t *out_len);
 /* The chunk as ReverseComplementer leaves it (modifiers.py:264-308; SequenceRecord.reverse_complement() is dnaio's,
  * restated in csrc/revcomp.h): one normalised record per input record written to out + its record table out_rec
@@ -410,6 +413,11 @@ int cah_quality_trim_batch(const uint8_t *d_quals, const int64_t *d_offsets, con
 int cah_nextseq_trim_batch(const uint8_t *d_seqs, const uint8_t *d_quals, const int64_t *d_offsets,
                            const int32_t *d_lens, int64_t n_reads, int32_t cutoff, int32_t base,
                            int32_t *d_stop, void *stream);
+/* ... when the qualities of read r start at d_quals[d_qual_offsets[r]] instead of d_quals[d_offsets[r]]: sequences
+ * and qualities used in place in a raw FASTQ chunk that cah_fastq_index_device indexed (d_lens required). */
+int cah_nextseq_trim_batch_q(const uint8_t *d_seqs, const uint8_t *d_quals, const int64_t *d_offsets,
+                             const int64_t *d_qual_offsets, const int32_t *d_lens, int64_t n_reads,
+                             int32_t cutoff, int32_t base, int32_t *d_stop, void *stream);
 int cah_poly_a_trim_batch(const uint8_t *d_seqs, const int64_t *d_offsets, const int32_t *d_lens,
                           int64_t n_reads, int32_t revcomp, int32_t *d_index, void *stream);
 int cah_expected_errors_batch(const uint8_t *d_quals, const int64_t *d_offsets,

@@ -1,0 +1,280 @@
+"""The device-side FASTQ path beyond adapter trimming (gpu_pipeline.py, "the general way"): the modifiers of
+reference cli.py:938-973 chained on windows into the raw chunk in HBM, read pairs, several GPUs.
+
+  * every single-end and paired command-line golden of the reference (tests/golden/fastq, tests/golden/paired)
+    through trim_fastq_gpu / trim_fastq_gpu_paired, byte for byte;
+  * 5000 random reads through -u, -q, two adapters with --times 2, --poly-a, -l, --max-ee and -m against a per-read
+    restatement of the reference's modifier chain whose adapter step is driven by the ORACLE (not by
+    pipeline.trim_fastq) and whose quality / poly-A steps are restated here and pinned to tests/golden/qualtrim.json;
+  * devices="all": every visible GPU gets chunks, the bytes equal the one-device run.
+GPU only."""
+import io
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FQ = os.path.join(HERE, "golden", "fastq")
+PD = os.path.join(HERE, "golden", "paired")
+KINDS = {"-a": "back", "-g": "front", "-b": "anywhere"}
+
+
+def _strip_trailing_space(b: bytes) -> bytes:
+    return b"\n".join(line.rstrip(b" \t") for line in b.split(b"\n"))
+
+
+def test_single_end_goldens_through_the_device_path(hip):
+    from cutadapt_amd.gpu_pipeline import trim_fastq_gpu
+    from cutadapt_amd.pipeline import adapter_from_spec
+    manifest = json.load(open(os.path.join(FQ, "manifest.json")))
+    ways = {}
+    for case in manifest:
+        opts = dict(case["options"])
+        params = {"max_errors": opts.pop("max_errors")} if "max_errors" in opts else {}
+        if "quality_cutoff" in opts:
+            opts["quality_cutoff"] = tuple(opts["quality_cutoff"])
+        for chunk_bytes in (4 << 20, 512):
+            ads = [adapter_from_spec(spec, KINDS[opt], **params) for opt, spec in case["adapters"]]
+            out, info = io.BytesIO(), io.BytesIO()
+            stats = trim_fastq_gpu(os.path.join(FQ, case["input"]), out, ads, chunk_bytes=chunk_bytes, threads=2,
+                                   info_file=info if case["info"] else None, **opts)
+            if case["expected"]:
+                assert out.getvalue() == open(os.path.join(FQ, case["expected"]), "rb").read(), (case["name"], chunk_bytes)
+            if case["info"]:
+                expected = open(os.path.join(FQ, case["info"]), "rb").read()
+                assert _strip_trailing_space(info.getvalue()) == _strip_trailing_space(expected), (case["name"], chunk_bytes)
+        ways[stats["way"]] = ways.get(stats["way"], 0) + 1
+        if case["name"] == "max_expected_errors":
+            assert stats["trimmer"].too_many_expected_errors == 2
+        if case["name"] == "revcomp_normalized":
+            assert stats["reverse_complemented"] == 2                   # reference test_commandline.py:834
+    assert ways.get("general", 0) >= 8 and ways.get("all-device", 0) >= 5, ways
+
+
+def test_paired_goldens_through_the_device_path(hip):
+    from cutadapt_amd.gpu_pipeline import trim_fastq_gpu_paired
+    from cutadapt_amd.pipeline import adapter_from_spec
+    manifest = json.load(open(os.path.join(PD, "manifest.json")))
+    assert len(manifest) >= 20
+
+    def mate(opts):
+        opts = dict(opts)
+        params = opts.pop("params", {})
+        ads = [adapter_from_spec(spec, KINDS[o], **params) for o, spec in opts.pop("adapters", [])]
+        if "quality_cutoff" in opts:
+            opts["quality_cutoff"] = tuple(opts["quality_cutoff"])
+        return dict(adapters=ads, **opts)
+
+    on_device = 0
+    for case in manifest:
+        for chunk_bytes in (4 << 20, 300):
+            o1, o2 = io.BytesIO(), io.BytesIO()
+            stats = trim_fastq_gpu_paired(os.path.join(PD, case["in1"]), os.path.join(PD, case["in2"]), o1, o2,
+                                          mate(case["r1"]), mate(case["r2"]), chunk_bytes=chunk_bytes, devices="all",
+                                          **case["top"])
+            assert o1.getvalue() == open(os.path.join(PD, case["exp1"]), "rb").read(), (case["name"], chunk_bytes, 1)
+            assert o2.getvalue() == open(os.path.join(PD, case["exp2"]), "rb").read(), (case["name"], chunk_bytes, 2)
+        exp = open(os.path.join(PD, case["exp1"]), "rb").read()
+        n_out = exp.count(b">") if exp.startswith(b">") else exp.count(b"\n") // 4
+        assert stats["pairs_written"] == n_out, case["name"]
+        on_device += "per_device" in stats
+    assert on_device >= 18, on_device                        # (two of the cases are FASTA: parsed on the host)
+    # mates that do not pair up are reported
+    r1 = open(os.path.join(PD, "in_paired.1.fastq"), "rb").read()
+    r2 = open(os.path.join(PD, "in_paired.2.fastq"), "rb").read()
+    with pytest.raises(ValueError, match="improperly paired"):
+        trim_fastq_gpu_paired(io.BytesIO(r1), io.BytesIO(r2[: len(r2) // 2].rsplit(b"@", 1)[0]), io.BytesIO(), io.BytesIO())
+
+
+# ---- per-read restatements of the modifiers around the adapter step (pinned to the reference's known answers) ----
+def quality_trim_index(q: str, cutoff_front: int, cutoff_back: int, base: int = 33):
+    """reference qualtrim.pyx:22-70"""
+    n = len(q)
+    start, stop = 0, n
+    s = max_qual = 0
+    for i in range(n):
+        s += cutoff_front - (ord(q[i]) - base)
+        if s < 0:
+            break
+        if s > max_qual:
+            max_qual, start = s, i + 1
+    s = max_qual = 0
+    for i in reversed(range(n)):
+        s += cutoff_back - (ord(q[i]) - base)
+        if s < 0:
+            break
+        if s > max_qual:
+            max_qual, stop = s, i
+    if start >= stop:
+        start, stop = 0, 0
+    return start, stop
+
+
+def poly_a_trim_index(s: str, revcomp: bool = False) -> int:
+    """reference qualtrim.pyx:116-165"""
+    n = len(s)
+    if revcomp:
+        best_index, best_score, score, errors = 0, 0, 0, 0
+        for i in range(n):
+            if s[i] == "T":
+                score += 1
+            else:
+                score -= 2
+                errors += 1
+            if score > best_score and errors * 5 <= i + 1:
+                best_score, best_index = score, i + 1
+        return best_index
+    best_index, best_score, score, errors = n, 0, 0, 0
+    for i in reversed(range(n)):
+        if s[i] == "A":
+            score += 1
+        else:
+            score -= 2
+            errors += 1
+        if score > best_score and errors * 5 <= n - i:
+            best_score, best_index = score, i
+    return best_index
+
+
+def test_restatements_agree_with_the_reference_known_answers(golden):
+    g = golden("qualtrim.json")
+    for q, front, back, base, want in g["quality_trim"]:
+        assert list(quality_trim_index(q, front, back, base)) == want
+    for s, revcomp, want in g["poly_a"]:
+        got = poly_a_trim_index(s, revcomp)
+        # the reference ignores tails shorter than three characters
+        if revcomp:
+            got = got if got > 2 else 0
+        else:
+            got = got if got < len(s) - 2 else len(s)
+        assert got == want, (s, revcomp)
+
+
+def _poly_a(s, revcomp=False):
+    i = poly_a_trim_index(s, revcomp)
+    if revcomp:
+        return i if i > 2 else 0
+    return i if i < len(s) - 2 else len(s)
+
+
+def test_random_reads_against_the_modifier_chain_over_oracle_results(hip, orc, golden):
+    from cutadapt_amd import adapters as A
+    from cutadapt_amd.gpu_pipeline import trim_fastq_gpu
+    from cutadapt_amd.kmer_heuristic import create_positions_and_kmers
+    rng = random.Random(77)
+    table = [float.fromhex(x) for x in golden("qualtrim.json")["error_table"]]
+    ad_back, ad_front = "ACGTTGCAAGTC", "GGATCCAATC"
+    recs = []
+    for i in range(5000):
+        s = "".join(rng.choice("ACGT") for _ in range(rng.randint(0, 90)))
+        for _ in range(rng.randint(0, 2)):
+            p = rng.randint(0, len(s))
+            piece = rng.choice((ad_back, ad_front))
+            if rng.random() < 0.3:
+                q = rng.randrange(len(piece))
+                piece = piece[:q] + rng.choice("ACGT") + piece[q + 1:]
+            s = s[:p] + piece + s[p:]
+        if rng.random() < 0.3:
+            p = rng.randint(0, len(s))
+            s = s[:p] + "A" * rng.randint(3, 25) + s[p:]
+        lo = rng.choice((33, 40, 53))
+        q = "".join(chr(rng.randint(lo, 73)) for _ in s)
+        if rng.random() < 0.5 and len(q) > 6:                  # a bad tail (and sometimes a bad head)
+            k = rng.randint(1, 6)
+            q = q[:-k] + "".join(chr(rng.randint(33, 38)) for _ in range(k))
+            if rng.random() < 0.3:
+                q = "".join(chr(rng.randint(33, 38)) for _ in range(3)) + q[3:]
+        recs.append((f"r{i}", s, q))
+    data = "".join(f"@{n}\n{s}\n+\n{q}\n" for n, s, q in recs).encode()
+    finders = {
+        "back": orc.KmerFinder(create_positions_and_kmers(ad_back, 3, 0.1, True, False), False, False),
+        "front": orc.KmerFinder(create_positions_and_kmers(ad_front, 3, 0.1, False, True), False, False),
+    }
+    CUT, QCUT, TIMES, LENGTH, MAXEE, MINLEN = 2, (8, 12), 2, 60, 1.5, 10
+
+    def chain(name, s, q):
+        """cli.py:938-973: -u, -q, adapters (--times 2), --poly-a, -l; then --max-ee and -m (cli.py:735-912)"""
+        s, q = s[CUT:], q[CUT:]
+        a, b = quality_trim_index(q, QCUT[0], QCUT[1])
+        s, q = s[a:b], q[a:b]
+        matched = False
+        for _ in range(TIMES):
+            best = None
+            for seq, kind in ((ad_back, "back"), (ad_front, "front")):
+                if not finders[kind].kmers_present(s):
+                    continue
+                t = orc.Aligner(seq, 0.1, flags=14 if kind == "back" else 11, wildcard_ref=False, min_overlap=3).locate(s)
+                if t is not None and (best is None or t[4] > best[0][4] or (t[4] == best[0][4] and t[5] < best[0][5])):
+                    best = (t, kind)
+            if best is None:
+                break
+            matched = True
+            t, kind = best
+            s, q = (s[:t[2]], q[:t[2]]) if kind == "back" else (s[t[3]:], q[t[3]:])
+        i = _poly_a(s)
+        s, q = s[:i], q[:i]
+        s, q = s[:LENGTH], q[:LENGTH]
+        ee = 0.0
+        for c in q:
+            ee += table[ord(c) - 33]
+        return s, q, ee, matched
+
+    want, near = [], 0
+    n_short = n_ee = n_matched = 0
+    for name, s, q in recs:
+        s2, q2, ee, matched = chain(name, s, q)
+        n_matched += matched
+        if len(s2) < MINLEN:                                     # too short is checked first (cli.py:735-912)
+            n_short += 1
+            continue
+        if abs(ee - MAXEE) < 1e-9:
+            near += 1
+        if ee > MAXEE:
+            n_ee += 1
+            continue
+        want.append(f"@{name}\n{s2}\n+\n{q2}\n")
+    assert near == 0 and n_short > 100 and n_ee > 100 and n_matched > 1000
+    ads = [A.BackAdapter(ad_back), A.FrontAdapter(ad_front)]
+    for chunk_bytes, threads in ((1 << 20, 2), (40000, 3)):
+        out = io.BytesIO()
+        stats = trim_fastq_gpu(np.frombuffer(data, dtype=np.uint8), out, ads, cut=[CUT], quality_cutoff=QCUT,
+                               times=TIMES, poly_a=True, length=LENGTH, max_expected_errors=MAXEE,
+                               minimum_length=MINLEN, chunk_bytes=chunk_bytes, threads=threads)
+        assert stats["way"] == "general"
+        assert out.getvalue() == "".join(want).encode(), chunk_bytes
+        assert stats["reads"] == len(recs) and stats["with_adapters"] == n_matched
+        assert stats["filtered"].get("too_short", 0) == n_short
+        assert stats["trimmer"].too_many_expected_errors == n_ee
+
+
+def test_every_visible_gpu_is_fed(hip, tmp_path):
+    import torch
+    from cutadapt_amd import adapters as A
+    from cutadapt_amd.gpu_pipeline import trim_fastq_gpu
+    from test_gpu_fastq_device import _fastq
+    rng = random.Random(5)
+    ad = "AGATCGGAAGAGCACACGTCTGAACTCCAGTCA"
+    data = _fastq(rng, 20000, [ad])
+    path = tmp_path / "reads.fastq"
+    path.write_bytes(data)
+    n_dev = torch.cuda.device_count()
+    visible = sorted(f"cuda:{i}" for i in range(n_dev))
+    chunk = len(data) // (4 * n_dev)                            # at least four chunks per device
+    for opts in ({}, {"quality_cutoff": (0, 10), "times": 2}):
+        one = io.BytesIO()
+        s1 = trim_fastq_gpu(str(path), one, [A.BackAdapter(ad)], chunk_bytes=chunk, threads=2, devices=[0], **opts)
+        for source in (str(path), np.frombuffer(data, dtype=np.uint8), io.BytesIO(data)):
+            every = io.BytesIO()
+            sa = trim_fastq_gpu(source, every, [A.BackAdapter(ad)], chunk_bytes=chunk, threads=2, devices="all", **opts)
+            assert sa["devices_used"] == visible
+            assert every.getvalue() == one.getvalue()
+            assert sorted(sa["per_device"]) == visible
+            per = sa["per_device"]
+            assert all(d["chunks"] >= 4 for d in per.values()), per     # round-robin: nobody is left out
+            assert sum(d["bytes_in"] for d in per.values()) == len(data)
+            assert (sa["reads"], sa["with_adapters"], sa["bp_out"]) == (s1["reads"], s1["with_adapters"], s1["bp_out"])
