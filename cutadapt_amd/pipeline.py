@@ -727,6 +727,8 @@ def _info_rows_on_original(rows: np.ndarray, before: np.ndarray, lens: np.ndarra
 
 def _materialized(chunk: "FastqChunk", obeg, oend, ibeg, iend, mode: int) -> "FastqChunk":
     """The chunk with every record cut to [obeg, oend) and marked (mode 1 mask, 2 lowercase) outside [ibeg, iend)."""
+    if hasattr(chunk, "host_chunk"):
+        chunk = chunk.host_chunk()                          # (a device-indexed chunk: the host writers take over)
     n = len(chunk)
     fasta = bool(n and chunk.rec[0, 4] < 0)
     sliced = scan_chunk(np.frombuffer(bytes(chunk.write_records(obeg, oend, None, 0)), dtype=np.uint8).copy(), fasta)

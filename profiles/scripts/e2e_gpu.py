@@ -2,7 +2,10 @@
 """End to end, host-fed: FASTQ bytes in host memory -> trimmed FASTQ bytes in host memory, one MI355X.
 Records are parsed, matched and formatted on the GPU (cutadapt_amd/gpu_pipeline.py); the host only cuts the
 input at record starts and moves bytes.  Compared with the host-side batch pipeline (pipeline.trim_fastq,
-parse/format on CPU threads).  Usage: python profiles/scripts/e2e_gpu.py [n_reads] > profiles/r02/e2e_gpu.json"""
+parse/format on CPU threads).
+Usage: python profiles/scripts/e2e_gpu.py [n_reads] [--devices all|0,1,..] [--threads T] > profiles/rNN/e2e_gpu.json
+--devices: one feeder per named GPU (T worker threads each); the per-device chunk counts, input rates and busy
+fractions of every run are part of the JSON and printed to stderr."""
 import io
 import json
 import os
@@ -18,7 +21,15 @@ from cutadapt_amd.adapters import BackAdapter
 from cutadapt_amd.gpu_pipeline import trim_fastq_gpu
 from cutadapt_amd.pipeline import trim_fastq
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 30_000_000
+import argparse
+ap = argparse.ArgumentParser()
+ap.add_argument("n_reads", nargs="?", type=int, default=30_000_000)
+ap.add_argument("--devices", default=None, help="'all' or a comma-separated list of device indices")
+ap.add_argument("--threads", type=int, default=4, help="worker threads per device in the --devices runs")
+ap.add_argument("--file", default=None, help="also time a run that reads the FASTQ from this path (it is written first)")
+args = ap.parse_args()
+n = args.n_reads
+devices = None if args.devices is None else ("all" if args.devices == "all" else [int(x) for x in args.devices.split(",")])
 dev = torch.device("cuda", 0)
 batch = workloads.device_batch("C2", n, device=dev)
 seqs = batch.seqs.view(n, 150)
@@ -51,12 +62,29 @@ def timed(label, fn, reps=2):
         best = dt if best is None else min(best, dt)
     out["runs"].append({"what": label, "seconds": best, "Mreads_per_s": n / best / 1e6,
                         "GB_per_s_in": fastq.numel() / best / 1e9, "with_adapters": stats["with_adapters"],
-                        "bytes_out": stats.get("bytes_out")})
+                        "bytes_out": stats.get("bytes_out"), "devices_used": stats.get("devices_used"),
+                        "per_device": stats.get("per_device")})
     print(out["runs"][-1], file=sys.stderr)
     return stats
 
 
 trim_fastq_gpu(fastq[: 317 * 200_000], None, [adapter], threads=2)          # warm-up
+if devices is not None:
+    # the multi-GPU mode: one feeder per device, chunks dealt round-robin, ordered merge; nothing else is timed
+    trim_fastq_gpu(fastq[: 317 * 2_000_000], None, [adapter], threads=args.threads, devices=devices)   # every worker's buffers exist
+    for assemble in ("device", "mixed"):
+        timed(f"GPU parse+match+format, pinned input, no sink, devices={args.devices}, {args.threads} worker threads per device, assemble={assemble}",
+              lambda: trim_fastq_gpu(fastq, None, [adapter], threads=args.threads, devices=devices, assemble=assemble))
+    timed(f"the general way (-q 0,10 + adapter + --poly-a), devices={args.devices}",
+          lambda: trim_fastq_gpu(fastq, None, [adapter], threads=args.threads, devices=devices, quality_cutoff=(0, 10), poly_a=True), reps=1)
+    if args.file:
+        with open(args.file, "wb") as f:
+            f.write(memoryview(fastq.numpy()))
+        timed(f"the same from a file (page cache): byte ranges read by the feeders, devices={args.devices}",
+              lambda: trim_fastq_gpu(args.file, None, [adapter], threads=args.threads, devices=devices))
+        os.unlink(args.file)
+    print(json.dumps(out, indent=1))
+    sys.exit(0)
 for threads, chunk_mib in ((1, 64), (2, 64), (3, 64), (4, 64), (6, 64), (8, 64), (4, 32), (4, 128)):
     timed(f"GPU parse+match+format, pinned input, no sink, {threads} worker thread(s) x {chunk_mib} MiB chunks",
           lambda: trim_fastq_gpu(fastq, None, [adapter], threads=threads, chunk_bytes=chunk_mib << 20))

@@ -278,3 +278,116 @@ def test_every_visible_gpu_is_fed(hip, tmp_path):
             assert all(d["chunks"] >= 4 for d in per.values()), per     # round-robin: nobody is left out
             assert sum(d["bytes_in"] for d in per.values()) == len(data)
             assert (sa["reads"], sa["with_adapters"], sa["bp_out"]) == (s1["reads"], s1["with_adapters"], s1["bp_out"])
+
+
+def _random_records(rng, n, ads, polya=0.3):
+    recs = []
+    for i in range(n):
+        s = "".join(rng.choice("ACGT") for _ in range(rng.randint(0, 80)))
+        for _ in range(rng.randint(0, 2)):
+            p = rng.randint(0, len(s))
+            s = s[:p] + rng.choice(ads) + s[p:]
+        if rng.random() < polya:
+            s += "A" * rng.randint(3, 20)
+        q = "".join(chr(rng.randint(40, 73)) for _ in s)
+        if rng.random() < 0.6 and len(q) > 8:
+            k = rng.randint(1, 6)
+            q = q[:-k] + "".join(chr(rng.randint(33, 37)) for _ in range(k))
+            if rng.random() < 0.5:
+                q = "".join(chr(rng.randint(33, 37)) for _ in range(2)) + q[2:]
+        recs.append((f"r{i} c", s, q))
+    return recs
+
+
+def _oracle_rounds(orc, finders, ad_back, ad_front, s, times):
+    """AdapterCutter.match_and_trim's search loop (reference modifiers.py:209-251) over oracle results:
+    -> [(out6, kind)] of every round, coordinates relative to the read that round saw"""
+    rounds = []
+    for _ in range(times):
+        best = None
+        for seq, kind in ((ad_back, "back"), (ad_front, "front")):
+            if not finders[kind].kmers_present(s):
+                continue
+            t = orc.Aligner(seq, 0.1, flags=14 if kind == "back" else 11, wildcard_ref=False, min_overlap=3).locate(s)
+            if t is not None and (best is None or t[4] > best[0][4] or (t[4] == best[0][4] and t[5] < best[0][5])):
+                best = (t, kind)
+        if best is None:
+            break
+        rounds.append(best)
+        t, kind = best
+        s = s[:t[2]] if kind == "back" else s[t[3]:]
+    return rounds
+
+
+def test_info_file_and_marking_actions_next_to_other_modifiers(hip, orc):
+    """The two combinations that used to be refused.  --info-file with -q / --poly-a / -l: InfoFileWriter (reference
+    steps.py:232-253) cuts the read AS IT CAME IN at the coordinates the matches have on the quality-trimmed read and
+    prints unmatched reads as they are written.  --action mask / lowercase with -q and --poly-a: the poly-A trimmer
+    sees the marked characters (modifiers.py:170-198 then :861-879)."""
+    from cutadapt_amd import adapters as A
+    from cutadapt_amd.gpu_pipeline import trim_fastq_gpu
+    from cutadapt_amd.kmer_heuristic import create_positions_and_kmers
+    from cutadapt_amd.pipeline import trim_fastq
+    rng = random.Random(88)
+    ad_back, ad_front = "ACGTTGCAAGTC", "GGATCCAATC"
+    finders = {
+        "back": orc.KmerFinder(create_positions_and_kmers(ad_back, 3, 0.1, True, False), False, False),
+        "front": orc.KmerFinder(create_positions_and_kmers(ad_front, 3, 0.1, False, True), False, False),
+    }
+    recs = _random_records(rng, 1500, [ad_back, ad_front])
+    data = "".join(f"@{n}\n{s}\n+\n{q}\n" for n, s, q in recs).encode()
+    QCUT, TIMES, LENGTH = (6, 10), 2, 50
+    # ---- info file -----------------------------------------------------------------------------------------------
+    want_info, want_out = [], []
+    for name, s, q in recs:
+        a, b = quality_trim_index(q, *QCUT)
+        ts, tq = s[a:b], q[a:b]
+        rounds = _oracle_rounds(orc, finders, ad_back, ad_front, ts, TIMES)
+        cur_s, cur_q = s, q                                    # info.original_read
+        for t, kind in rounds:
+            ts, tq = (ts[:t[2]], tq[:t[2]]) if kind == "back" else (ts[t[3]:], tq[t[3]:])
+            want_info.append("\t".join([name, str(t[5]), str(t[2]), str(t[3]), cur_s[:t[2]], cur_s[t[2]:t[3]], cur_s[t[3]:],
+                                        "b" if kind == "back" else "f", cur_q[:t[2]], cur_q[t[2]:t[3]], cur_q[t[3]:], ""]))
+            cur_s, cur_q = (cur_s[:t[2]], cur_q[:t[2]]) if kind == "back" else (cur_s[t[3]:], cur_q[t[3]:])
+        i = _poly_a(ts)
+        ts, tq = ts[:i][:LENGTH], tq[:i][:LENGTH]
+        if not rounds:
+            want_info.append("\t".join([name, "-1", ts, tq]))
+        want_out.append(f"@{name}\n{ts}\n+\n{tq}\n")
+    ads = [A.BackAdapter(ad_back, name="b"), A.FrontAdapter(ad_front, name="f")]
+    for fn, kw in ((trim_fastq_gpu, dict(threads=2)), (trim_fastq, {})):
+        for chunk_bytes in (1 << 20, 9000):
+            out, info = io.BytesIO(), io.BytesIO()
+            fn(io.BytesIO(data), out, ads, quality_cutoff=QCUT, times=TIMES, poly_a=True, length=LENGTH, info_file=info,
+               chunk_bytes=chunk_bytes, **kw)
+            assert out.getvalue() == "".join(want_out).encode(), (fn.__name__, chunk_bytes)
+            got = info.getvalue().decode().split("\n")[:-1]
+            assert got == want_info, (fn.__name__, [(g, w) for g, w in zip(got, want_info) if g != w][:2])
+    # ---- mask / lowercase ----------------------------------------------------------------------------------------
+    for action in ("mask", "lowercase"):
+        want_out = []
+        for name, s, q in recs:
+            a, b = quality_trim_index(q, *QCUT)
+            ts, tq = s[a:b], q[a:b]
+            if action == "lowercase":
+                ts = ts.upper()
+            rounds = _oracle_rounds(orc, finders, ad_back, ad_front, ts, TIMES)
+            lo, hi = 0, len(ts)                                # remainder(matches), modifiers.py:170-198
+            for t, kind in rounds:
+                if kind == "back":
+                    hi = lo + t[2]
+                else:
+                    lo = lo + t[3]
+            if rounds and action == "mask":
+                ts = "N" * lo + ts[lo:hi] + "N" * (len(ts) - hi)
+            elif rounds:
+                ts = ts[:lo].lower() + ts[lo:hi].upper() + ts[hi:].lower()
+            i = _poly_a(ts)
+            ts, tq = ts[:i][:LENGTH], tq[:i][:LENGTH]
+            want_out.append(f"@{name}\n{ts}\n+\n{tq}\n")
+        for fn, kw in ((trim_fastq_gpu, dict(threads=2)), (trim_fastq, {})):
+            out = io.BytesIO()
+            fn(io.BytesIO(data), out, ads, quality_cutoff=QCUT, times=TIMES, poly_a=True, length=LENGTH, action=action,
+               chunk_bytes=20000, **kw)
+            got, want = out.getvalue().decode().split("\n"), "".join(want_out).split("\n")
+            assert got == want, (action, fn.__name__, [(g, w) for g, w in zip(got, want) if g != w][:2])
