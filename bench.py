@@ -93,6 +93,7 @@ class Workload:
         from cutadapt_amd import adapters as A
         from cutadapt_amd.batch import BatchResult
         self.config, self.n, self.spec = config, n, workloads.SPECS[config]
+        self.gen = gen
         kind = self.spec["kind"]
         first = rank * n
 

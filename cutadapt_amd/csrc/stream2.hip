@@ -211,12 +211,22 @@ struct S2Out {
 // Zero the result rows (24 bytes each) of the `cnt` (<= 64, wave-uniform) consecutive reads from `base` on and set their
 // best_adapter entries to -1 (clear_rows of filter_common.h with buffer stores: scalar base, one offset register --
 // the 64-bit per-lane addresses of plain stores cost this kernel registers it does not have)
-__device__ __forceinline__ void s2_clear_rows(int32_t* out6, int32_t* best, const int64_t base, const int cnt, const int lane) {
+// (a pointer the caller knows to be wave-uniform, said so: buffer resources built from anything the compiler takes
+// for per-lane data are looped over value by value -- a "waterfall" of ten instructions around every access)
+__device__ __forceinline__ void* s2_uniform_ptr(const void* q) {
+    const unsigned long long v = (unsigned long long)q;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (void*)(((unsigned long long)hi << 32) | lo);
+}
+
+__device__ __forceinline__ void s2_clear_rows(int32_t* out6, int32_t* best, const int64_t base, int cnt, const int lane) {
+    cnt = __builtin_amdgcn_readfirstlane(cnt);
     if (best) {
-        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(best + base), 0, cnt * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(s2_uniform_ptr(best + base), 0, cnt * 4, 0x00020000);
         __builtin_amdgcn_raw_buffer_store_b32(0xFFFFFFFFu, rb, lane * 4, 0, 0);          // lanes >= cnt: out of range, dropped
     }
-    int32_t* const o = out6 + base * 6;
+    int32_t* const o = (int32_t*)s2_uniform_ptr(out6 + base * 6);
     const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)o, 0, cnt * 24, 0x00020000);
     if ((reinterpret_cast<uintptr_t>(o) & 7u) == 0) {
 #pragma unroll
@@ -429,7 +439,9 @@ __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a
             // a whole piece with 16 bytes of the batch behind it (all but the last pieces): no lane needs a check
             if constexpr (BUF) {
                 // buffer loads: the piece's first byte is the (scalar) base of the resource, a lane's offset ONE register
-                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, 0x7FFFFFFF, 0x00020000);
+                // (said explicitly to be wave-uniform: otherwise every load is wrapped in a waterfall loop over the
+                // values of the four resource words)
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(s2_uniform_ptr(src), 0, 0x7FFFFFFF, 0x00020000);
 #pragma unroll
                 for (int k = 0; k < S2_HALF; ++k)
                     if (k < H1)

@@ -2,6 +2,7 @@
 the HIP path through the adapter classes vs the oracle applying the reference's rules
 (LinkedAdapter.match_to, reference adapters.py:1215-1227; MultipleAdapters.match_to,
 :1265-1286).  GPU only."""
+import os
 import random
 
 import numpy as np
@@ -201,3 +202,21 @@ def test_paired_adapter_cutter_best_pair(hip, orc):
     assert np.array_equal(idx[found], want_idx[found])
     assert np.array_equal(c1[found], w1[found]) and np.array_equal(c2[found], w2[found])
     assert found.sum() > 800 and len(set(want_idx[found].tolist())) >= 4 and 3 not in set(want_idx[found].tolist())
+
+
+@pytest.mark.parametrize("config", ["C3", "C4", "C5"])
+def test_baseline_workloads_200k_reads_against_the_oracle(hip, orc, config):
+    """The BASELINE.json workloads themselves (cutadapt_amd/workloads.py: the generator, adapter sets and seeds
+    bench.py times), 200 000 reads (per mate) through the same step bench.py runs, every tuple bit-compared with the
+    oracle applying the reference's rules (bench.py Workload.parity)."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    n = 200_000
+    wl = bench.Workload(config, n, 0, torch.device("cuda", 0), None)
+    wl.step()
+    torch.cuda.synchronize()
+    ok, what = wl.parity(n)
+    assert ok, what
+    assert f"{n} reads" in what
