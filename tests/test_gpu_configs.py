@@ -205,15 +205,15 @@ def test_paired_adapter_cutter_best_pair(hip, orc):
 
 
 @pytest.mark.parametrize("config", ["C3", "C4", "C5"])
-def test_baseline_workloads_200k_reads_against_the_oracle(hip, orc, config):
+def test_baseline_workloads_500k_reads_against_the_oracle(hip, orc, config):
     """The BASELINE.json workloads themselves (cutadapt_amd/workloads.py: the generator, adapter sets and seeds
-    bench.py times), 200 000 reads (per mate) through the same step bench.py runs, every tuple bit-compared with the
+    bench.py times), 500 000 reads (per mate) through the same step bench.py runs, every tuple bit-compared with the
     oracle applying the reference's rules (bench.py Workload.parity)."""
     import sys
     import torch
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
-    n = 200_000
+    n = 500_000
     wl = bench.Workload(config, n, 0, torch.device("cuda", 0), None)
     wl.step()
     torch.cuda.synchronize()
