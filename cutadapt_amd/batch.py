@@ -272,6 +272,12 @@ def match_batch(plan: "_lib.Plan", batch: ReadBatch, out: Optional[BatchResult] 
                 _lib.check(_lib.lib().cah_match_batch_uniform(
                     plan.handle, batch.seqs.data_ptr(), batch.uniform_len, n, out.out6.data_ptr(), best_ptr,
                     out.status.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr()))
+            elif getattr(batch, "suffix_of_uniform", None) and batch.lens is not None and not os.environ.get("CAH_NO_UNIFORM"):
+                # views that end where the reads of a uniform batch end (second stage of a linked adapter)
+                _lib.check(_lib.lib().cah_match_batch_suffix_views(
+                    plan.handle, batch.seqs.data_ptr(), batch.offsets.data_ptr(), batch.lens.data_ptr(),
+                    int(batch.suffix_of_uniform), n, out.out6.data_ptr(), best_ptr, out.status.data_ptr(), ws.data_ptr(),
+                    ws.numel(), _stream_ptr()))
             else:
                 _lib.check(_lib.lib().cah_match_batch(
                     plan.handle, batch.seqs.data_ptr(), batch.offsets.data_ptr(), batch._lens_ptr(), n,
@@ -291,5 +297,7 @@ def linked_match_batch(front_plan: "_lib.Plan", back_plan: "_lib.Plan", batch: R
     lens = batch.lengths()
     batch.workspace()
     view = batch.view(rstop, lens - rstop.to(torch.int64))
+    if batch.uniform_len and batch.lens is None:
+        view.suffix_of_uniform = batch.uniform_len           # the views end where the (equally long) reads end
     back = match_batch(back_plan, view, out_back)
     return front, back, view

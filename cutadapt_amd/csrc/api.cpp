@@ -1120,7 +1120,12 @@ static int64_t scan_retry_cap(int64_t cap) {
 // column window); everything else runs the cell kernel directly.
 // equally long reads the host vouches for (cah_match_batch_uniform): read r = d_seqs[first + r * len ..); len == 0: the
 // packed layout (offsets / lens)
-struct UniformLayout { int64_t first = 0; int32_t len = 0; };
+static bool env_flag(const char* name) { const char* e = getenv(name); return e && *e && *e != '0'; }
+
+// suffix: (first, len) describe a PARENT batch of equally long reads and d_offsets / d_lens views that end where
+// its reads end (cah_match_batch_suffix_views): only the streaming prefilter makes use of that, every other kernel
+// sees plain views.
+struct UniformLayout { int64_t first = 0; int32_t len = 0; bool suffix = false; };
 
 static int run_aligner(const cah_plan* plan, const PlanDeviceCopy* pd, int32_t adapter, const uint8_t* d_seqs,
                        const int64_t* d_offsets, const int32_t* d_lens, int64_t n_reads,
@@ -1263,6 +1268,15 @@ static int run_filter(const cah_plan* plan, const PlanDeviceCopy* pd, int32_t ad
     f.lean = nullptr;
     f.stream_n_lo = 0; f.stream_n_hi = -1;
     f.uniform_first = ul.first; f.uniform_len = ul.len;
+    if (ul.suffix) {
+        // views into a uniform parent: k_filter_stream2's SV form if the plan and the length are its, else plain views
+        const bool s2 = plan->lean[(size_t)adapter].ok && plan->lean[(size_t)adapter].tw_ok &&
+                        stream2_class_ok(plan->lean[(size_t)adapter].n_lead, plan->lean[(size_t)adapter].n_tw) &&
+                        ul.len <= stream2_max_len() && n_reads * (int64_t)ul.len >= 16 && !env_flag("CAH_NO_STREAM") &&
+                        !env_flag("CAH_NO_STREAM2");
+        f.suffix_views = s2 ? 1 : 0;
+        if (!s2) { f.uniform_first = 0; f.uniform_len = 0; }
+    }
     f.clear_out6 = mode == 1 ? d_clear_out6 : nullptr;
     f.clear_best = f.clear_out6 ? d_clear_best : nullptr;
     if (!t_header_fresh) {
@@ -1274,7 +1288,7 @@ static int run_filter(const cah_plan* plan, const PlanDeviceCopy* pd, int32_t ad
         // 3' adapter plans: k_filter_lean.  For a packed batch the device-side batch check (*d_batch_flag)
         // picks its equal-length or its ragged variant -- both are launched, one leaves at once, no host
         // sync; views (explicit lengths) and calls without a check take the ragged variant.
-        f.batch_flag = (d_lens || ul.len > 0) ? nullptr : d_batch_flag;
+        f.batch_flag = (d_lens || f.uniform_len > 0) ? nullptr : d_batch_flag;
         f.lean = pd->d_lean + adapter;
         const CahLeanFilter& lf = plan->lean[(size_t)adapter];
         HIP_TRY(launch_filter_lean(f, mode, lf.n_lead, lf.n_gated, lf.lead_delay, lf.tw_ok, lf.n_tw, pd->n_cus, s));
@@ -1401,7 +1415,7 @@ static int match_batch_impl(const cah_plan* plan, const uint8_t* d_seqs, const i
                             const int32_t* d_lens, const UniformLayout ul, int64_t n_reads, int32_t* d_out6,
                             int32_t* d_best_adapter, uint8_t* d_status, void* d_workspace, size_t workspace_bytes,
                             void* stream) {
-    int rc = check_batch(plan, d_seqs, ul.len > 0 ? (const void*)d_seqs : (const void*)d_offsets, n_reads);
+    int rc = check_batch(plan, d_seqs, (ul.len > 0 && !ul.suffix) ? (const void*)d_seqs : (const void*)d_offsets, n_reads);
     if (rc) return rc;
     if (n_reads == 0) return CAH_OK;
     if (!d_out6 || !d_status) return fail(CAH_EINVAL, "output pointers are NULL");
@@ -1413,6 +1427,7 @@ static int match_batch_impl(const cah_plan* plan, const uint8_t* d_seqs, const i
     if (rc) return rc;
     const Workspace ws(d_workspace, n_reads, workspace_bytes);
     unsigned long long* counters = ws.counters;
+    const UniformLayout ul_rest = ul.suffix ? UniformLayout() : ul;     // what every kernel but the prefilter sees
     // The result rows are zeroed by the first adapter's prefilter on its way through the batch when there is one
     // (FilterArgs::clear_out6: 24 B per read that would otherwise be a memset pass of its own), by a memset if not.
     const bool multi_path = plan->multi.hdr.ok && workspace_bytes >= cah_plan_workspace_bytes(plan, n_reads);
@@ -1435,7 +1450,7 @@ static int match_batch_impl(const cah_plan* plan, const uint8_t* d_seqs, const i
     }
     // one pass over the offsets decides, on the device, which prefilter kernel works on this batch
     const unsigned long long* d_batch_flag = nullptr;
-    if (!d_lens && !tiny && ul.len == 0) {
+    if (!d_lens && !tiny && ul.len == 0 && !ul.suffix) {
         bool any_lean = false;
         for (size_t ad = 0; ad < plan->matchers.size(); ad++)
             any_lean |= runs_filter(plan->matchers[ad]) && plan->matchers[ad].kind != CAH_KIND_KMER_ONLY && plan->lean[ad].ok;
@@ -1447,7 +1462,7 @@ static int match_batch_impl(const cah_plan* plan, const uint8_t* d_seqs, const i
     }
     if (plan->multi.hdr.ok && workspace_bytes >= cah_plan_workspace_bytes(plan, n_reads))
         return match_batch_multi(plan, pd, d_seqs, d_offsets, d_lens, n_reads, d_out6, d_best_adapter, d_status, ws,
-                                 (char*)d_workspace + cah_workspace_bytes(n_reads), s, ul);
+                                 (char*)d_workspace + cah_workspace_bytes(n_reads), s, ul_rest);
     for (int32_t ad = 0; ad < (int32_t)plan->matchers.size(); ad++) {
         const CahMatcher& mt = plan->matchers[(size_t)ad];
         if (mt.kind == CAH_KIND_KMER_ONLY) continue;
@@ -1461,10 +1476,10 @@ static int match_batch_impl(const cah_plan* plan, const uint8_t* d_seqs, const i
             // merge mode 2: the plan's first adapter writes into zeroed rows -- nothing to compare with (kernels.hip,
             // store_result)
             rc = run_aligner(plan, pd, ad, d_seqs, d_offsets, d_lens, n_reads, ws.queue, counters + WS_QCOUNT,
-                             ws.keys, ws, d_out6, d_status, d_best_adapter, ad == first_aligner ? 2 : 1, s, ul);
+                             ws.keys, ws, d_out6, d_status, d_best_adapter, ad == first_aligner ? 2 : 1, s, ul_rest);
         } else {
             rc = run_aligner(plan, pd, ad, d_seqs, d_offsets, d_lens, n_reads, nullptr, nullptr, nullptr,
-                             ws, d_out6, d_status, d_best_adapter, 1, s, ul);
+                             ws, d_out6, d_status, d_best_adapter, 1, s, ul_rest);
         }
         if (rc) return rc;
     }
@@ -1491,6 +1506,25 @@ int cah_match_batch_uniform(const cah_plan* plan, const uint8_t* d_seqs, int32_t
     UniformLayout ul;
     ul.first = 0; ul.len = read_len;
     return match_batch_impl(plan, d_seqs, nullptr, nullptr, ul, n_reads, d_out6, d_best_adapter, d_status, d_workspace,
+                            workspace_bytes, stream);
+}
+
+// Views that are SUFFIXES of the reads of a uniform batch: view r = d_seqs[d_starts[r], d_starts[r] + d_lens[r]) with
+// d_starts[r] + d_lens[r] == (r + 1) * parent_read_len -- the second stage of a linked adapter (reference
+// adapters.py:1222-1224 searches the 3' adapter in read[front_match.rstop:]) on what a sequencer emits.  Results are
+// relative to the views, exactly as cah_match_batch(d_seqs, d_starts, d_lens, ...) returns them; the difference is
+// that the prefilter can stream the parent's reads through LDS (k_filter_stream2) instead of fetching ragged views
+// lane by lane.
+int cah_match_batch_suffix_views(const cah_plan* plan, const uint8_t* d_seqs, const int64_t* d_starts,
+                                 const int32_t* d_lens, int32_t parent_read_len, int64_t n_reads, int32_t* d_out6,
+                                 int32_t* d_best_adapter, uint8_t* d_status, void* d_workspace, size_t workspace_bytes,
+                                 void* stream) {
+    if (parent_read_len < 1 || parent_read_len > CAH_MAX_READ_LEN)
+        return fail(CAH_EINVAL, "parent_read_len out of range (1..%d)", CAH_MAX_READ_LEN);
+    if (n_reads > 0 && (!d_starts || !d_lens)) return fail(CAH_EINVAL, "starts / lens are NULL");
+    UniformLayout ul;
+    ul.first = 0; ul.len = parent_read_len; ul.suffix = true;
+    return match_batch_impl(plan, d_seqs, d_starts, d_lens, ul, n_reads, d_out6, d_best_adapter, d_status, d_workspace,
                             workspace_bytes, stream);
 }
 

@@ -31,6 +31,9 @@ struct FilterArgs {
     // ...) -- no offsets array is read, no batch check is needed.  uniform_len == 0: lengths come from offsets.
     int64_t uniform_first = 0;
     int32_t uniform_len = 0;
+    // k_filter_stream2 only: offsets[r] is where the view of read r starts inside the uniform PARENT batch described by
+    // (uniform_first, uniform_len); the view ends where that read ends (second stage of a linked adapter)
+    int32_t suffix_views = 0;
     int32_t* clear_best;             // with clear_out6, may be NULL: best_adapter[r] = -1 for the same reads
     int32_t* clear_out6;             // MODE 1, may be NULL: the result rows (6 x int32 per read) of every read the
                                      // kernel looks at are zeroed on the way (rows of reads that match are written

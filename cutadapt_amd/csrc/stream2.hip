@@ -306,7 +306,11 @@ __device__ __forceinline__ S2Out s2_out_args() {
     return o;
 }
 
-template <int NL, int NT, bool BUF>
+// SV: the reads are SUFFIX VIEWS of a uniform batch -- view r = [offsets[r], end of read r) of the parent batch
+// (uniform_first, uniform_len): the second stage of a linked adapter (reference adapters.py:1222-1224: the 3' adapter
+// is searched in read[front_match.rstop:]).  The parent's reads are streamed as they are and the `skip[r]` characters
+// in front of a view are made NUL on their way into the words -- no k-mer matches through them.
+template <int NL, int NT, bool BUF, bool SV = false>
 __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a) {
     typedef S2Layout<NL, NT> LY;
     constexpr int TILE = S2_TILE, SUBS = TILE / WAVE / S2_WAVES;
@@ -521,8 +525,20 @@ __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
     };
+    int skip = 0;                                                       // SV: this lane's read starts `skip` characters in
     // the chunk at `pos`: characters past the read's end (the next read's, or stale) become NUL
     auto finish = [&](s2_u32x4 v, int pos) -> s2_u32x4 {
+        if constexpr (SV) {
+            if (s2_any(skip > pos)) {                                   // (wave-uniform: rare beyond the first chunk or two)
+                unsigned x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int drop = skip - pos - 4 * i;                // characters of dword i in front of the view
+                    x[i] = drop <= 0 ? x[i] : (drop >= 4 ? 0u : (x[i] & (0xFFFFFFFFu << (8 * drop))));
+                }
+                v = (s2_u32x4){x[0], x[1], x[2], x[3]};
+            }
+        }
         if (pos + 16 > n) {
             unsigned x[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -551,6 +567,15 @@ __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a
             S2Hits hits;                                                // lanes still looking for a first k-mer
             hits.live = more && (unsigned)(base + lane) < (unsigned)n_reads;
             hits.group = -1;
+            if constexpr (SV) {
+                skip = 0;
+                if (hits.live) {
+                    const s2_kernarg_ptr kp = (s2_kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+                    const int64_t r = (int64_t)base + lane;
+                    skip = (int)(kp->offsets[r] - (first + r * (int64_t)n));
+                    skip = skip < 0 ? 0 : (skip > n ? n : skip);
+                }
+            }
             unsigned seen = 0;
             uint32_t RL[NL > 0 ? NL : 1], RT[NT > 0 ? NT : 1];
 #pragma unroll
@@ -618,7 +643,8 @@ __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a
                 const bool invalid = (seen & 0x80808080u) != 0;
                 const S2Out o = s2_out_args();
                 lean_emit(o, (int64_t)base + lane, (int64_t)tile_base, (unsigned)(base + lane) < (unsigned)n_reads, hits.group >= 0,
-                          invalid, hits.group << CAH_KEY_SHIFT, stage.idx, stage.key, stage.hist, stage.count);
+                          invalid, SV ? max(0, (hits.group << CAH_KEY_SHIFT) - skip) : (hits.group << CAH_KEY_SHIFT),   // (a lower bound of the first hit within the view)
+                          stage.idx, stage.key, stage.hist, stage.count);
             }
             S2_STAMP(7);
             if (!a.present) {
@@ -661,6 +687,12 @@ hipError_t launch_filter_stream2(const FilterArgs& a_in, int mode, int n_lead, i
         if (use_global) hipLaunchKernelGGL((k_filter_stream2<NL, NT, false>), dim3(grid), dim3(S2_WAVES * WAVE), lds, s, a); \
         else hipLaunchKernelGGL((k_filter_stream2<NL, NT, true>), dim3(grid), dim3(S2_WAVES * WAVE), lds, s, a);        \
     } while (0)
+    if (a.suffix_views) {
+        if (n_lead <= 1 && n_tw <= 2) hipLaunchKernelGGL((k_filter_stream2<1, 2, true, true>), dim3(grid), dim3(S2_WAVES * WAVE), lds, s, a);
+        else if (n_lead <= 2 && n_tw <= 4) hipLaunchKernelGGL((k_filter_stream2<2, 4, true, true>), dim3(grid), dim3(S2_WAVES * WAVE), lds, s, a);
+        else return hipErrorInvalidValue;
+        return hipGetLastError();
+    }
     if (n_lead <= 1 && n_tw <= 2) S2_LAUNCH(1, 2);
     else if (n_lead <= 2 && n_tw <= 4) S2_LAUNCH(2, 4);
     else return hipErrorInvalidValue;

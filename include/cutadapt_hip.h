@@ -170,6 +170,15 @@ int cah_match_batch(const cah_plan *plan, const uint8_t *d_seqs, const int64_t *
 int cah_match_batch_uniform(const cah_plan *plan, const uint8_t *d_seqs, int32_t read_len, int64_t n_reads,
                             int32_t *d_out6, int32_t *d_best_adapter, uint8_t *d_status, void *d_workspace,
                             size_t workspace_bytes, void *stream);
+/* ... and for views that are SUFFIXES of the reads of such a batch -- the second stage of LinkedAdapter.match_to
+ * (adapters.py:1222-1224: the 3' adapter is searched in read[front_match.rstop:]): view r = d_seqs[d_starts[r],
+ * d_starts[r] + d_lens[r]) with d_starts[r] + d_lens[r] == (r + 1) * parent_read_len.  Same results as
+ * cah_match_batch(plan, d_seqs, d_starts, d_lens, ...) (coordinates relative to the views); the prefilter streams
+ * the parent's reads instead of fetching ragged views. */
+int cah_match_batch_suffix_views(const cah_plan *plan, const uint8_t *d_seqs, const int64_t *d_starts,
+                                 const int32_t *d_lens, int32_t parent_read_len, int64_t n_reads,
+                                 int32_t *d_out6, int32_t *d_best_adapter, uint8_t *d_status,
+                                 void *d_workspace, size_t workspace_bytes, void *stream);
 
 /* bytes of device scratch the calls above need for n_reads reads (17.7 bytes per read + 6 KiB: counters, the
  * prefilter's survivor queue with keys, the cell-DP work list with its column windows, the cost scan's

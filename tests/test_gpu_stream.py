@@ -271,3 +271,47 @@ def test_uniform_entry_point_equals_the_offsets_entry_point(hip, orc):
             assert np.array_equal(got[1], ref[1]) and np.array_equal(got[0], ref[0]), (name, n)
             if got[2] is not None and ref[2] is not None:
                 assert np.array_equal(got[2][got[1] == 1], ref[2][ref[1] == 1]), (name, n)
+
+
+def test_suffix_views_of_a_uniform_batch(hip, orc):
+    """cah_match_batch_suffix_views (the second stage of a linked adapter on equally long reads: view r starts skip[r]
+    characters into read r and ends where it ends): tuples against the oracle on the suffixes themselves and against the
+    plain view entry point, and the survivor queue = exactly the suffixes whose kmers_present is true.  Skips of every
+    size: 0, a multiple of 4, odd ones, the whole read."""
+    import torch
+    from cutadapt_amd import adapters as A
+    from cutadapt_amd.batch import ReadBatch, match_batch
+    rng = random.Random(777)
+    cases = [(TRUSEQ, 0.1, 3, 150), (TRUSEQ, 0.1, 3, 151), (TRUSEQ, 0.1, 3, 100), (TRUSEQ, 0.1, 3, 40), (TRUSEQ[:20], 0.2, 2, 76)]
+    for _ in range(6):
+        cases.append((rs(rng, rng.choice([12, 25, 33])), rng.choice([0.0, 0.1]), rng.randint(1, 5), rng.choice([150, 125, 50])))
+    for seq, rate, ov, n in cases:
+        ad = A.BackAdapter(seq, max_errors=rate, min_overlap=ov)
+        count = rng.choice([500, 1500, 9000])
+        reads = make_reads(rng, n, count, seq, p_adapter=0.7)
+        # adapter copies in FRONT of the view start must not be seen: plant some at the read's head
+        reads = [(seq + r)[:n] if rng.random() < 0.2 else r for r in reads]
+        skip = np.array([rng.choice([0, 0, 16, 16, 4, 8, 1, 3, 17, 33, n - 2, n, rng.randint(0, n)]) for _ in reads], dtype=np.int64)
+        subs = [r[int(k):] for r, k in zip(reads, skip)]
+        want, finder = oracle_expect(orc, ad, subs)
+        batch = ReadBatch.from_strings(reads)
+        assert batch.uniform_len == n
+        sk = torch.from_numpy(skip).cuda()
+        results = {}
+        for mode in ("suffix", "views"):
+            view = batch.view(sk, batch.lengths() - sk)
+            if mode == "suffix":
+                view.suffix_of_uniform = n
+            res = match_batch(ad._fused_plan, view)
+            out6, st = res.out6.cpu().numpy(), res.status.cpu().numpy()
+            results[mode] = (out6, st, _survivors(view, count))
+            for i, w in enumerate(want):
+                if w is None:
+                    assert st[i] == 0, (mode, seq, n, i, skip[i])
+                else:
+                    assert st[i] == 1 and tuple(out6[i]) == tuple(w), (mode, seq, n, i, skip[i], tuple(out6[i]), w)
+        present = {i for i, r in enumerate(subs) if finder.kmers_present(r)}
+        assert set(results["suffix"][2]) == present == set(results["views"][2]), (seq, n)
+        # the streamed form may only UNDER-state the first hit (the scan then starts earlier), never over-state it
+        ks, kv = results["suffix"][2], results["views"][2]
+        assert all(ks[i] <= kv[i] for i in ks), [(i, ks[i], kv[i], skip[i]) for i in ks if ks[i] > kv[i]][:5]
