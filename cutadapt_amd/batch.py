@@ -292,12 +292,44 @@ def linked_match_batch(front_plan: "_lib.Plan", back_plan: "_lib.Plan", batch: R
     (start = rstop of the front match, or 0) into the same HBM buffer.  Returns (front, back, view);
     the required/optional verdict is the caller's (it needs only the two status arrays)."""
     torch = _torch()
+    n = batch.n_reads
+    starts = torch.empty(n, dtype=torch.int64, device=batch.device)
+    vlens = torch.empty(n, dtype=torch.int32, device=batch.device)
+    uniform = batch.uniform_len if (batch.uniform_len and batch.lens is None and not os.environ.get("CAH_NO_UNIFORM")) else 0
+
+    def result(out):
+        if out is not None:
+            return out
+        return BatchResult(torch.empty((n, 6), dtype=torch.int32, device=batch.device),
+                           torch.empty(n, dtype=torch.uint8, device=batch.device),
+                           torch.empty(n, dtype=torch.int32, device=batch.device))
+
+    if uniform and n:
+        # equally long reads: the library runs both stages (and folds the 5' comparison into the 3' prefilter's pass
+        # over the batch when the 5' adapter is anchored and tolerates no error)
+        front, back = result(out_front), result(out_back)
+        batch.workspace(front_plan)
+        ws = batch.workspace(back_plan)                      # (grow-only: large enough for either plan now)
+        with torch.cuda.device(batch.device):
+            _lib.check(_lib.lib().cah_linked_match_batch_uniform(
+                front_plan.handle, back_plan.handle, batch.seqs.data_ptr(), int(uniform), n,
+                front.out6.data_ptr(), front.best_adapter.data_ptr() if front.best_adapter is not None else None,
+                front.status.data_ptr(), back.out6.data_ptr(),
+                back.best_adapter.data_ptr() if back.best_adapter is not None else None, back.status.data_ptr(),
+                starts.data_ptr(), vlens.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr()))
+        view = ReadBatch(batch.seqs, starts, vlens, n_reads=n, validated=batch.validated)
+        view._workspace = batch._workspace
+        view.suffix_of_uniform = uniform
+        return front, back, view
     front = match_batch(front_plan, batch, out_front)
-    rstop = torch.where(front.status == 1, front.out6[:, 3], torch.zeros((), dtype=torch.int32, device=batch.device))
-    lens = batch.lengths()
     batch.workspace()
-    view = batch.view(rstop, lens - rstop.to(torch.int64))
-    if batch.uniform_len and batch.lens is None:
-        view.suffix_of_uniform = batch.uniform_len           # the views end where the (equally long) reads end
+    # the views in one pass over the front stage's results (cah_linked_views)
+    if n:
+        with torch.cuda.device(batch.device):
+            _lib.check(_lib.lib().cah_linked_views(
+                front.out6.data_ptr(), front.status.data_ptr(), batch.offsets.data_ptr(), batch._lens_ptr(), 0, n,
+                starts.data_ptr(), vlens.data_ptr(), _stream_ptr()))
+    view = ReadBatch(batch.seqs, starts, vlens, n_reads=n, validated=batch.validated)
+    view._workspace = batch._workspace                       # same reads, same stream order: the scratch can be shared
     back = match_batch(back_plan, view, out_back)
     return front, back, view

@@ -1126,6 +1126,16 @@ static bool env_flag(const char* name) { const char* e = getenv(name); return e 
 // its reads end (cah_match_batch_suffix_views): only the streaming prefilter makes use of that, every other kernel
 // sees plain views.
 struct UniformLayout { int64_t first = 0; int32_t len = 0; bool suffix = false; };
+// cah_linked_match_batch_uniform, fused form: the streaming prefilter of the back adapter decides the views itself
+// (kernels.h: FilterArgs::front) and writes the front stage's outputs and the views
+struct FrontFuse {
+    const CahMatcher* d_matcher = nullptr;
+    int32_t* out6 = nullptr;
+    uint8_t* status = nullptr;
+    int32_t* best = nullptr;
+    int64_t* starts = nullptr;
+    int32_t* lens = nullptr;
+};
 
 static int run_aligner(const cah_plan* plan, const PlanDeviceCopy* pd, int32_t adapter, const uint8_t* d_seqs,
                        const int64_t* d_offsets, const int32_t* d_lens, int64_t n_reads,
@@ -1245,13 +1255,20 @@ int cah_locate_batch(const cah_plan* plan, int32_t adapter, const uint8_t* d_seq
                        ws, d_out6, d_status, nullptr, 0, (hipStream_t)stream);      // (its one memset is the header's)
 }
 
+// can the streaming prefilter take views that are suffixes of a uniform batch's reads (k_filter_stream2, SV form)?
+static bool stream2_suffix_ok(const cah_plan* plan, int32_t adapter, int32_t len, int64_t n_reads) {
+    const CahLeanFilter& lf = plan->lean[(size_t)adapter];
+    return lf.ok && lf.tw_ok && stream2_class_ok(lf.n_lead, lf.n_tw) && len >= 1 && len <= stream2_max_len() &&
+           n_reads * (int64_t)len >= 16 && !env_flag("CAH_NO_STREAM") && !env_flag("CAH_NO_STREAM2");
+}
+
 static int run_filter(const cah_plan* plan, const PlanDeviceCopy* pd, int32_t adapter, const uint8_t* d_seqs,
                       const int64_t* d_offsets, const int32_t* d_lens, int64_t n_reads, int mode,
                       uint8_t* d_present, uint8_t* d_status, int32_t* d_queue,
                       unsigned long long* d_queue_count, uint8_t* d_queue_keys,
                       unsigned long long* d_work_counter, const unsigned long long* d_batch_flag, hipStream_t s,
                       int32_t* d_clear_out6 = nullptr, int32_t* d_clear_best = nullptr,
-                      const UniformLayout ul = UniformLayout()) {
+                      const UniformLayout ul = UniformLayout(), const FrontFuse* fuse = nullptr) {
     const CahMatcher& mt = plan->matchers[(size_t)adapter];
     if (mt.n_words > 1024)
         return fail(CAH_EUNSUPPORTED, "adapter %d: %d packed k-mer words exceed the 1024-word limit of the prefilter kernel",
@@ -1270,12 +1287,14 @@ static int run_filter(const cah_plan* plan, const PlanDeviceCopy* pd, int32_t ad
     f.uniform_first = ul.first; f.uniform_len = ul.len;
     if (ul.suffix) {
         // views into a uniform parent: k_filter_stream2's SV form if the plan and the length are its, else plain views
-        const bool s2 = plan->lean[(size_t)adapter].ok && plan->lean[(size_t)adapter].tw_ok &&
-                        stream2_class_ok(plan->lean[(size_t)adapter].n_lead, plan->lean[(size_t)adapter].n_tw) &&
-                        ul.len <= stream2_max_len() && n_reads * (int64_t)ul.len >= 16 && !env_flag("CAH_NO_STREAM") &&
-                        !env_flag("CAH_NO_STREAM2");
+        const bool s2 = stream2_suffix_ok(plan, adapter, ul.len, n_reads);
         f.suffix_views = s2 ? 1 : 0;
         if (!s2) { f.uniform_first = 0; f.uniform_len = 0; }
+        if (fuse) {
+            if (!s2) return fail(CAH_EINVAL, "internal: fused linked path on a plan the streaming prefilter does not take");
+            f.front = fuse->d_matcher; f.front_out6 = fuse->out6; f.front_status = fuse->status; f.front_best = fuse->best;
+            f.view_starts = fuse->starts; f.view_lens = fuse->lens;
+        }
     }
     f.clear_out6 = mode == 1 ? d_clear_out6 : nullptr;
     f.clear_best = f.clear_out6 ? d_clear_best : nullptr;
@@ -1414,7 +1433,7 @@ static int match_batch_multi(const cah_plan* plan, const PlanDeviceCopy* pd, con
 static int match_batch_impl(const cah_plan* plan, const uint8_t* d_seqs, const int64_t* d_offsets,
                             const int32_t* d_lens, const UniformLayout ul, int64_t n_reads, int32_t* d_out6,
                             int32_t* d_best_adapter, uint8_t* d_status, void* d_workspace, size_t workspace_bytes,
-                            void* stream) {
+                            void* stream, const FrontFuse* fuse = nullptr) {
     int rc = check_batch(plan, d_seqs, (ul.len > 0 && !ul.suffix) ? (const void*)d_seqs : (const void*)d_offsets, n_reads);
     if (rc) return rc;
     if (n_reads == 0) return CAH_OK;
@@ -1471,7 +1490,8 @@ static int match_batch_impl(const cah_plan* plan, const uint8_t* d_seqs, const i
             rc = run_filter(plan, pd, ad, d_seqs, d_offsets, d_lens, n_reads, 1, nullptr, d_status, ws.queue,
                             counters + WS_QCOUNT, ws.keys, counters + 0, d_batch_flag, s,
                             (filter_clears && ad == first_aligner) ? d_out6 : nullptr,
-                            (filter_clears && ad == first_aligner) ? d_best_adapter : nullptr, ul);
+                            (filter_clears && ad == first_aligner) ? d_best_adapter : nullptr, ul,
+                            ad == first_aligner ? fuse : nullptr);
             if (rc) return rc;
             // merge mode 2: the plan's first adapter writes into zeroed rows -- nothing to compare with (kernels.hip,
             // store_result)
@@ -1526,6 +1546,66 @@ int cah_match_batch_suffix_views(const cah_plan* plan, const uint8_t* d_seqs, co
     ul.first = 0; ul.len = parent_read_len; ul.suffix = true;
     return match_batch_impl(plan, d_seqs, d_starts, d_lens, ul, n_reads, d_out6, d_best_adapter, d_status, d_workspace,
                             workspace_bytes, stream);
+}
+
+extern "C" int cah_linked_views(const int32_t*, const uint8_t*, const int64_t*, const int32_t*, int32_t, int64_t, int64_t*,
+                                int32_t*, void*);
+
+// can the front stage be folded into the back adapter's streaming prefilter?  One anchored 5' adapter that tolerates
+// no error (k_anchored_exact's case) of at most 32 characters whose columns fit the first half-row of the slot, and
+// one back adapter the SV form takes, on a batch large enough to be worth a filter that clears the result rows.
+static bool linked_fusable(const cah_plan* front, const cah_plan* back, int32_t read_len, int64_t n_reads) {
+    if (front->matchers.size() != 1 || back->matchers.size() != 1 || env_flag("CAH_NO_LINKED_FUSE")) return false;
+    const CahMatcher& fm = front->matchers[0];
+    const CahMatcher& bm = back->matchers[0];
+    if (fm.kind != CAH_KIND_ALIGNER || fm.flags != 8 || !anchored_exact_ok(fm) || runs_filter(fm)) return false;
+    const int units = (read_len + 15) / 16, first_half = 16 * ((units + 1) / 2);
+    if (fm.m > 32 || fm.m + fm.k > first_half) return false;
+    if (bm.kind == CAH_KIND_KMER_ONLY || !runs_filter(bm) || n_reads <= CAH_TINY_BATCH) return false;
+    return stream2_suffix_ok(back, 0, read_len, n_reads);
+}
+
+// LinkedAdapter.match_to over a batch of equally long reads (reference adapters.py:1215-1227): the 5' plan on the
+// reads, the 3' plan on read[front_match.rstop:] (the whole read where the 5' adapter was not found).  Outputs: the
+// two stages' result arrays as cah_match_batch writes them (the back stage's coordinates are relative to its view) and
+// the views themselves (d_starts int64[n], d_view_lens int32[n]); required / optional is the caller's verdict.
+// When the 5' adapter is anchored and tolerates no error and the 3' adapter is the streaming prefilter's, ONE pass over
+// the batch does the 5' comparison, the view arithmetic and the 3' prefilter (k_filter_stream2, FR form); otherwise
+// the stages run one after the other.  One workspace serves both stages.
+int cah_linked_match_batch_uniform(const cah_plan* front_plan, const cah_plan* back_plan, const uint8_t* d_seqs,
+                                   int32_t read_len, int64_t n_reads, int32_t* d_out6_front, int32_t* d_best_front,
+                                   uint8_t* d_status_front, int32_t* d_out6_back, int32_t* d_best_back,
+                                   uint8_t* d_status_back, int64_t* d_starts, int32_t* d_view_lens, void* d_workspace,
+                                   size_t workspace_bytes, void* stream) {
+    if (!front_plan || !back_plan) return fail(CAH_EINVAL, "plan is NULL");
+    if (read_len < 1 || read_len > CAH_MAX_READ_LEN)
+        return fail(CAH_EINVAL, "read_len out of range (1..%d)", CAH_MAX_READ_LEN);
+    if (n_reads < 0 || n_reads > 2147483647LL) return fail(CAH_EINVAL, "n_reads out of range (0..2^31-1)");
+    if (n_reads == 0) return CAH_OK;
+    if (!d_seqs || !d_out6_front || !d_status_front || !d_out6_back || !d_status_back || !d_starts || !d_view_lens)
+        return fail(CAH_EINVAL, "cah_linked_match_batch_uniform: NULL argument");
+    UniformLayout views;
+    views.first = 0; views.len = read_len; views.suffix = true;
+    if (linked_fusable(front_plan, back_plan, read_len, n_reads)) {
+        const PlanDeviceCopy* fpd = nullptr;
+        int rc = plan_on_device(front_plan, &fpd);
+        if (rc) return rc;
+        FrontFuse fuse;
+        fuse.d_matcher = fpd->d_matchers;
+        fuse.out6 = d_out6_front; fuse.status = d_status_front; fuse.best = d_best_front;
+        fuse.starts = d_starts; fuse.lens = d_view_lens;
+        return match_batch_impl(back_plan, d_seqs, d_starts, d_view_lens, views, n_reads, d_out6_back, d_best_back,
+                                d_status_back, d_workspace, workspace_bytes, stream, &fuse);
+    }
+    UniformLayout ul;
+    ul.first = 0; ul.len = read_len;
+    int rc = match_batch_impl(front_plan, d_seqs, nullptr, nullptr, ul, n_reads, d_out6_front, d_best_front, d_status_front,
+                              d_workspace, workspace_bytes, stream);
+    if (rc) return rc;
+    rc = cah_linked_views(d_out6_front, d_status_front, nullptr, nullptr, read_len, n_reads, d_starts, d_view_lens, stream);
+    if (rc) return rc;
+    return match_batch_impl(back_plan, d_seqs, d_starts, d_view_lens, views, n_reads, d_out6_back, d_best_back,
+                            d_status_back, d_workspace, workspace_bytes, stream);
 }
 
 int cah_validate_ascii_batch(const uint8_t* d_seqs, const int64_t* d_offsets, const int32_t* d_lens,

@@ -34,6 +34,15 @@ struct FilterArgs {
     // k_filter_stream2 only: offsets[r] is where the view of read r starts inside the uniform PARENT batch described by
     // (uniform_first, uniform_len); the view ends where that read ends (second stage of a linked adapter)
     int32_t suffix_views = 0;
+    // ... and, when `front` is set, the view starts are decided by the kernel itself: the anchored 5' adapter of a linked
+    // adapter (no error tolerated, m <= 32) is compared with the read's head; the kernel writes the front stage's rows
+    // and the views the later kernels read (cah_linked_match_batch_uniform)
+    const CahMatcher* front = nullptr;
+    int32_t* front_out6 = nullptr;
+    uint8_t* front_status = nullptr;
+    int32_t* front_best = nullptr;
+    int64_t* view_starts = nullptr;
+    int32_t* view_lens = nullptr;
     int32_t* clear_best;             // with clear_out6, may be NULL: best_adapter[r] = -1 for the same reads
     int32_t* clear_out6;             // MODE 1, may be NULL: the result rows (6 x int32 per read) of every read the
                                      // kernel looks at are zeroed on the way (rows of reads that match are written

@@ -296,6 +296,23 @@ __global__ __launch_bounds__(256) void k_reverse_reads(const uint8_t* seqs, cons
     for (int i = done; i < n; ++i) o[i] = COMPLEMENT ? comp[q[n - 1 - i]] : q[n - 1 - i];
 }
 
+// k_linked_views: where the second stage of a linked adapter looks -- view r = read[rstop_r:], rstop_r = query_stop of the
+// front match or 0 (reference adapters.py:1222-1224).  One pass over the front stage's results instead of a chain of
+// elementwise tensor operations (compare, gather, where, two casts, two adds and a subtraction over n reads each).
+__global__ __launch_bounds__(256) void k_linked_views(const int32_t* out6, const uint8_t* status, const int64_t* offsets,
+                                                      const int32_t* lens, const int32_t read_len, const int64_t n_reads,
+                                                      int64_t* starts, int32_t* view_lens) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    int64_t off, n;
+    if (read_len > 0) { off = r * (int64_t)read_len; n = read_len; }
+    else { off = offsets[r]; n = lens ? (int64_t)lens[r] : offsets[r + 1] - off; }
+    int64_t stop = status[r] == 1 ? (int64_t)out6[r * 6 + 3] : 0;
+    stop = stop < 0 ? 0 : (stop > n ? n : stop);
+    starts[r] = off + stop;
+    view_lens[r] = (int32_t)(n - stop);
+}
+
 extern "C" {
 
 int cah_quality_trim_batch(const uint8_t* d_quals, const int64_t* d_offsets, const int32_t* d_lens, int64_t n_reads,
@@ -382,6 +399,22 @@ static int reverse_reads_impl(const char* who, const uint8_t* d_seqs, const int6
                            d_lens, n_reads, d_out_offsets, d_out, d_select);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return cah_set_error_(CAH_EHIP, hipGetErrorString(e));
+    return CAH_OK;
+}
+
+// Views for the second stage of a linked adapter (see k_linked_views): d_starts int64[n_reads], d_view_lens
+// int32[n_reads].  The reads are (d_offsets, d_lens) as in cah_match_batch, or -- read_len > 0 -- equally long reads back
+// to back from byte 0 (d_offsets may be NULL).
+int cah_linked_views(const int32_t* d_out6_front, const uint8_t* d_status_front, const int64_t* d_offsets,
+                     const int32_t* d_lens, int32_t read_len, int64_t n_reads, int64_t* d_starts, int32_t* d_view_lens,
+                     void* stream) {
+    if (n_reads < 0) return cah_set_error_(CAH_EINVAL, "n_reads < 0");
+    if (n_reads == 0) return CAH_OK;
+    if (!d_out6_front || !d_status_front || !d_starts || !d_view_lens || (read_len <= 0 && !d_offsets))
+        return cah_set_error_(CAH_EINVAL, "cah_linked_views: NULL argument");
+    hipLaunchKernelGGL(k_linked_views, dim3(blocks_for(n_reads)), dim3(256), 0, (hipStream_t)stream, d_out6_front,
+                       d_status_front, d_offsets, d_lens, read_len, n_reads, d_starts, d_view_lens);
+    QT_TRY(hipGetLastError());
     return CAH_OK;
 }
 

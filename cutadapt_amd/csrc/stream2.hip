@@ -310,7 +310,11 @@ __device__ __forceinline__ S2Out s2_out_args() {
 // (uniform_first, uniform_len): the second stage of a linked adapter (reference adapters.py:1222-1224: the 3' adapter
 // is searched in read[front_match.rstop:]).  The parent's reads are streamed as they are and the `skip[r]` characters
 // in front of a view are made NUL on their way into the words -- no k-mer matches through them.
-template <int NL, int NT, bool BUF, bool SV = false>
+// FR (with SV): the view's start is not read from an array but DECIDED here -- the anchored 5' adapter of a linked
+// adapter that tolerates no error (k_anchored_exact's case: "^NNNNNNNNACGTACGT") is compared with the read's head while
+// the head sits in the slot anyway; the kernel writes the front stage's result rows and the views (starts, lengths)
+// for the kernels behind it.  One pass over the batch instead of three (front comparison, view arithmetic, prefilter).
+template <int NL, int NT, bool BUF, bool SV = false, bool FR = false>
 __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a) {
     typedef S2Layout<NL, NT> LY;
     constexpr int TILE = S2_TILE, SUBS = TILE / WAVE / S2_WAVES;
@@ -334,6 +338,7 @@ __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a
             unsigned pad;
         } stage[2];
         unsigned next_piece;                                            // the block's pieces are dealt to its waves on demand
+        uint32_t front[FR ? CAH_TABLE_CHARS : 1];                       // FR: bit i = character matches front adapter position i
     };
     static_assert(sizeof(S2Lds) <= 160 * 1024, "k_filter_stream2: LDS");
     __shared__ S2Lds s_lds;
@@ -369,6 +374,13 @@ __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a
     for (int j = threadIdx.x; j < CAH_TW_DIST_LEN * LY::NTP; j += blockDim.x) {
         const int idx = j / LY::NTP, w = j % LY::NTP;
         s_lds.found[j] = (w < NT && w < lf->n_tw) ? lf->tw_found[w][idx] : 0u;
+    }
+    int front_m = 0, front_span = 0;
+    if constexpr (FR) {
+        const CahMatcher* fmt = a.front;
+        for (int c = threadIdx.x; c < CAH_TABLE_CHARS; c += blockDim.x) s_lds.front[c] = (uint32_t)fmt->rowmask[c];
+        front_m = fmt->m;                                               // <= 32 (api.cpp: linked_fusable)
+        front_span = min(n, front_m + fmt->k);                          // the columns Aligner.locate reads (_align.pyx:348-352)
     }
     for (int b = 0; b < 2; ++b) {
         for (int i = threadIdx.x; i < CAH_QUEUE_BINS; i += blockDim.x) { s_lds.stage[b].hist[i] = 0; s_lds.stage[b].cursor[i] = 0; }
@@ -567,7 +579,7 @@ __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a
             S2Hits hits;                                                // lanes still looking for a first k-mer
             hits.live = more && (unsigned)(base + lane) < (unsigned)n_reads;
             hits.group = -1;
-            if constexpr (SV) {
+            if constexpr (SV && !FR) {
                 skip = 0;
                 if (hits.live) {
                     const s2_kernarg_ptr kp = (s2_kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
@@ -592,6 +604,47 @@ __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a
                 if (alive) {
                     if (ph == 0) to_slot(std::integral_constant<int, 0>{}); else to_slot(std::integral_constant<int, 1>{});
                     cur = *reinterpret_cast<const s2_u32x4*>(row);
+                }
+                if constexpr (FR) {
+                    if (ph == 0) {
+                        // the front adapter against the read's head (k_anchored_exact, kernels.hip: same rule, same flags)
+                        unsigned bad = n < front_m ? 1u : 0u, fseen = 0;
+                        if (alive) {
+#pragma unroll 1
+                            for (int c0 = 0; c0 < front_span; c0 += 16) {                 // wave-uniform: one or two rounds
+                                const s2_u32x4 v = *reinterpret_cast<const s2_u32x4*>(row + c0);
+                                unsigned x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) {
+                                    const int keep = front_span - c0 - 4 * i;             // characters of dword i inside the span
+                                    x[i] &= keep >= 4 ? 0xFFFFFFFFu : (keep <= 0 ? 0u : ((1u << (8 * keep)) - 1u));
+                                    fseen |= x[i];
+                                }
+#pragma unroll
+                                for (int t = 0; t < 16; ++t) {
+                                    const int i = c0 + t;                                 // adapter position (wave-uniform)
+                                    if (i < front_m) {
+                                        const unsigned ch = (x[t >> 2] >> ((t & 3) * 8)) & (CAH_TABLE_CHARS - 1);
+                                        bad |= ~s_lds.front[ch] & (1u << i);
+                                    }
+                                }
+                            }
+                        }
+                        const bool finvalid = (fseen & 0x80808080u) != 0;
+                        const bool ffound = !finvalid && bad == 0;
+                        skip = ffound ? front_m : 0;
+                        if (hits.live) {
+                            const s2_kernarg_ptr kp = (s2_kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+                            const int64_t r = (int64_t)base + lane;
+                            int32_t* o = kp->front_out6 + r * 6;
+                            const int fm = ffound ? front_m : 0;
+                            o[0] = 0; o[1] = fm; o[2] = 0; o[3] = fm; o[4] = fm; o[5] = 0;
+                            kp->front_status[r] = finvalid ? (uint8_t)2 : (ffound ? (uint8_t)1 : (uint8_t)0);
+                            if (kp->front_best) kp->front_best[r] = ffound ? 0 : -1;
+                            kp->view_starts[r] = first + r * (int64_t)n + skip;
+                            kp->view_lens[r] = n - skip;
+                        }
+                    }
                 }
                 S2_STAMP(1 + 3 * ph);
                 S2_STAMP(2 + 3 * ph);
@@ -687,6 +740,12 @@ hipError_t launch_filter_stream2(const FilterArgs& a_in, int mode, int n_lead, i
         if (use_global) hipLaunchKernelGGL((k_filter_stream2<NL, NT, false>), dim3(grid), dim3(S2_WAVES * WAVE), lds, s, a); \
         else hipLaunchKernelGGL((k_filter_stream2<NL, NT, true>), dim3(grid), dim3(S2_WAVES * WAVE), lds, s, a);        \
     } while (0)
+    if (a.suffix_views && a.front) {
+        if (n_lead <= 1 && n_tw <= 2) hipLaunchKernelGGL((k_filter_stream2<1, 2, true, true, true>), dim3(grid), dim3(S2_WAVES * WAVE), lds, s, a);
+        else if (n_lead <= 2 && n_tw <= 4) hipLaunchKernelGGL((k_filter_stream2<2, 4, true, true, true>), dim3(grid), dim3(S2_WAVES * WAVE), lds, s, a);
+        else return hipErrorInvalidValue;
+        return hipGetLastError();
+    }
     if (a.suffix_views) {
         if (n_lead <= 1 && n_tw <= 2) hipLaunchKernelGGL((k_filter_stream2<1, 2, true, true>), dim3(grid), dim3(S2_WAVES * WAVE), lds, s, a);
         else if (n_lead <= 2 && n_tw <= 4) hipLaunchKernelGGL((k_filter_stream2<2, 4, true, true>), dim3(grid), dim3(S2_WAVES * WAVE), lds, s, a);

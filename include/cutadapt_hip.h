@@ -179,6 +179,26 @@ int cah_match_batch_suffix_views(const cah_plan *plan, const uint8_t *d_seqs, co
                                  const int32_t *d_lens, int32_t parent_read_len, int64_t n_reads,
                                  int32_t *d_out6, int32_t *d_best_adapter, uint8_t *d_status,
                                  void *d_workspace, size_t workspace_bytes, void *stream);
+/* The views the second stage of a linked adapter searches (adapters.py:1222-1224): d_starts[r] = start of read r +
+ * (front match ? its query_stop : 0), d_view_lens[r] = what is left of the read.  Reads as in cah_match_batch, or
+ * read_len > 0: equally long reads back to back from byte 0 (d_offsets may be NULL). */
+int cah_linked_views(const int32_t *d_out6_front, const uint8_t *d_status_front, const int64_t *d_offsets,
+                     const int32_t *d_lens, int32_t read_len, int64_t n_reads, int64_t *d_starts,
+                     int32_t *d_view_lens, void *stream);
+/* LinkedAdapter.match_to (adapters.py:1215-1227) over a batch of equally long reads in ONE call: the 5' plan on the
+ * reads, the 3' plan on read[front_match.rstop:] (the whole read where the 5' adapter was not found).  Writes both
+ * stages' results as cah_match_batch does (the 3' stage's coordinates are relative to its view) and the views
+ * (d_starts int64[n], d_view_lens int32[n]); `required` / `optional` is the caller's verdict over the two status
+ * arrays.  d_best_* may be NULL.  When the 5' adapter is anchored and tolerates no error (e.g. ^NNNNNNNNACGTACGT) and
+ * the 3' adapter has a streaming prefilter, one pass over the batch does the 5' comparison, the view arithmetic and
+ * the 3' prefilter; otherwise the two stages run one after the other.  Workspace: cah_plan_workspace_bytes of the
+ * larger of the two plans. */
+int cah_linked_match_batch_uniform(const cah_plan *front_plan, const cah_plan *back_plan,
+                                   const uint8_t *d_seqs, int32_t read_len, int64_t n_reads,
+                                   int32_t *d_out6_front, int32_t *d_best_front, uint8_t *d_status_front,
+                                   int32_t *d_out6_back, int32_t *d_best_back, uint8_t *d_status_back,
+                                   int64_t *d_starts, int32_t *d_view_lens, void *d_workspace,
+                                   size_t workspace_bytes, void *stream);
 
 /* bytes of device scratch the calls above need for n_reads reads (17.7 bytes per read + 6 KiB: counters, the
  * prefilter's survivor queue with keys, the cell-DP work list with its column windows, the cost scan's

@@ -315,3 +315,65 @@ def test_suffix_views_of_a_uniform_batch(hip, orc):
         # the streamed form may only UNDER-state the first hit (the scan then starts earlier), never over-state it
         ks, kv = results["suffix"][2], results["views"][2]
         assert all(ks[i] <= kv[i] for i in ks), [(i, ks[i], kv[i], skip[i]) for i in ks if ks[i] > kv[i]][:5]
+
+
+def test_linked_adapter_on_uniform_reads_fused_and_staged(hip, orc):
+    """cah_linked_match_batch_uniform: an anchored 5' adapter that tolerates no error is folded into the 3' adapter's
+    streaming prefilter (one pass: 5' comparison, views, 3' prefilter); every other combination runs its stages one after
+    the other.  Both against the two-stage rule over oracle results (reference adapters.py:1215-1227) and against the
+    plain entry points (CAH_NO_UNIFORM=1)."""
+    import torch
+    from cutadapt_amd import adapters as A
+    from cutadapt_amd.batch import ReadBatch, linked_match_batch
+    from test_gpu_configs import oracle_single
+    rng = random.Random(4242)
+    fronts = [("NNNNNNNNACGTACGT", 0.1, True), ("ACGTACGTAC", 0.0, True), ("NNNNACGT" * 3, 0.05, True),   # fusable
+              ("ACGTTGCATTGACCAGT", 0.15, False), ("N" * 30 + "ACGTAC", 0.1, False)]                          # errors / 36 characters
+    for fseq, frate, fusable in fronts:
+        for n in (150, 100, 40, 151, 15):
+            front = A.PrefixAdapter(fseq, max_errors=frate)
+            back = A.BackAdapter(TRUSEQ, max_errors=0.1, min_overlap=3)
+            count = rng.choice([300, 2000, 7000])
+            reads = []
+            for _ in range(count):
+                head = "".join(rng.choice("ACGT") if ch == "N" else ch for ch in fseq)
+                if rng.random() < 0.3:
+                    q = rng.randrange(len(head))
+                    head = head[:q] + rng.choice("ACGTN") + head[q + 1:]
+                body = make_reads(rng, n, 1, TRUSEQ, p_adapter=0.6)[0]
+                r = (head + body)[:n] if rng.random() < 0.75 else body
+                reads.append(r)
+            if n >= 20:
+                bad = list(reads[5]); bad[3] = "é"; reads[5] = None       # an invalid byte inside the 5' columns
+            seqs = np.frombuffer("".join(r if r is not None else "x" * n for r in reads).encode("latin-1"), dtype=np.uint8).copy()
+            if n >= 20:
+                seqs[5 * n: 6 * n] = np.frombuffer(("ACGé" + "A" * (n - 4)).encode("latin-1"), dtype=np.uint8)
+                reads[5] = None
+            offsets = np.arange(count + 1, dtype=np.int64) * n
+            outs = {}
+            for mode in ("uniform", "plain"):
+                if mode == "plain":
+                    os.environ["CAH_NO_UNIFORM"] = "1"
+                try:
+                    batch = ReadBatch.from_host(seqs, offsets)
+                    f, b, view = linked_match_batch(front._fused_plan, back._fused_plan, batch)
+                    torch.cuda.synchronize()
+                    outs[mode] = (f.out6.cpu().numpy(), f.status.cpu().numpy(), b.out6.cpu().numpy(), b.status.cpu().numpy(),
+                                  view.offsets.cpu().numpy(), view.lens.cpu().numpy())
+                finally:
+                    os.environ.pop("CAH_NO_UNIFORM", None)
+            for a, bb in zip(outs["uniform"], outs["plain"]):
+                assert np.array_equal(a, bb), (fseq, n)
+            f6, fst, b6, bst, starts, vlens = outs["uniform"]
+            valid = [i for i, r in enumerate(reads) if r is not None]
+            good = [reads[i] for i in valid]
+            fc, ff = oracle_single(orc, front, good)
+            assert np.array_equal(fst[valid] == 1, ff) and np.array_equal(f6[valid][ff], fc[ff]), (fseq, n)
+            assert (f6[valid][~ff] == 0).all()
+            stop = np.where(ff, fc[:, 3], 0)
+            assert np.array_equal(starts[valid], offsets[valid] + stop) and np.array_equal(vlens[valid], n - stop)
+            bc, bf = oracle_single(orc, back, [r[int(k):] for r, k in zip(good, stop)])
+            assert np.array_equal(bst[valid] == 1, bf) and np.array_equal(b6[valid][bf], bc[bf]), (fseq, n)
+            if n >= 20:
+                assert fst[5] == 2 and starts[5] == 5 * n and vlens[5] == n
+            assert ff.sum() > 0.3 * len(good) or n < len(fseq)
