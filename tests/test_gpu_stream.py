@@ -351,9 +351,11 @@ def test_linked_adapter_on_uniform_reads_fused_and_staged(hip, orc):
                 reads[5] = None
             offsets = np.arange(count + 1, dtype=np.int64) * n
             outs = {}
-            for mode in ("uniform", "plain"):
+            for mode in ("uniform", "staged", "plain"):
                 if mode == "plain":
                     os.environ["CAH_NO_UNIFORM"] = "1"
+                if mode == "staged":
+                    os.environ["CAH_NO_LINKED_FUSE"] = "1"      # the one call, its stages one after the other
                 try:
                     batch = ReadBatch.from_host(seqs, offsets)
                     f, b, view = linked_match_batch(front._fused_plan, back._fused_plan, batch)
@@ -362,8 +364,10 @@ def test_linked_adapter_on_uniform_reads_fused_and_staged(hip, orc):
                                   view.offsets.cpu().numpy(), view.lens.cpu().numpy())
                 finally:
                     os.environ.pop("CAH_NO_UNIFORM", None)
-            for a, bb in zip(outs["uniform"], outs["plain"]):
-                assert np.array_equal(a, bb), (fseq, n)
+                    os.environ.pop("CAH_NO_LINKED_FUSE", None)
+            for other in ("staged", "plain"):
+                for a, bb in zip(outs["uniform"], outs[other]):
+                    assert np.array_equal(a, bb), (fseq, n, other)
             f6, fst, b6, bst, starts, vlens = outs["uniform"]
             valid = [i for i, r in enumerate(reads) if r is not None]
             good = [reads[i] for i in valid]
