@@ -415,6 +415,52 @@ int cah_chunk_revcomp(const uint8_t* buf, const int64_t* rec, int64_t n_records,
     return CAH_OK;
 }
 
+// The two chunks of a read pair as PairedReverseComplementer leaves them (reference modifiers.py:311-405: "R1 and R2
+// swapped (equivalent to reverse complementing)"): record i of the output is record i of chunk B where swap[i] != 0
+// -- with `suffix` behind its name -- and of chunk A otherwise, normalised like cah_chunk_revcomp's output.  Called
+// once per output file with the roles of the chunks exchanged.
+int cah_chunk_select(const uint8_t* buf_a, const int64_t* rec_a, const uint8_t* seqs_a, const int64_t* offsets_a,
+                     const uint8_t* buf_b, const int64_t* rec_b, const uint8_t* seqs_b, const int64_t* offsets_b,
+                     int64_t n_records, const uint8_t* swap, const char* suffix, int64_t suffix_len, uint8_t* out,
+                     int64_t out_cap, int64_t* out_rec, int64_t* out_len) {
+    if (!out_len || suffix_len < 0 || (suffix_len > 0 && !suffix)
+        || (n_records > 0 && (!buf_a || !rec_a || !offsets_a || !buf_b || !rec_b || !offsets_b || !swap || !out || !out_rec)))
+        return cah_set_error_(CAH_EINVAL, "cah_chunk_select: NULL argument");
+    int64_t pos = 0;
+    for (int64_t i = 0; i < n_records; i++) {
+        const bool sw = swap[i] != 0;
+        const uint8_t* buf = sw ? buf_b : buf_a;
+        const int64_t* r = (sw ? rec_b : rec_a) + i * 6;
+        const int64_t* offsets = sw ? offsets_b : offsets_a;
+        const uint8_t* s = (sw ? seqs_b : seqs_a) + offsets[i];
+        int64_t* w = out_rec + i * 6;
+        const bool fastq = r[4] >= 0;
+        const int64_t name_len = r[1] - r[0], n = offsets[i + 1] - offsets[i];
+        const int64_t need = 1 + name_len + (sw ? suffix_len : 0) + 1 + n + 1 + (fastq ? 2 + n + 1 : 0);
+        if (pos + need > out_cap) return cah_set_error_(CAH_ENOMEM, "cah_chunk_select: output buffer too small");
+        out[pos++] = fastq ? '@' : '>';
+        w[0] = pos;
+        memcpy(out + pos, buf + r[0], (size_t)name_len); pos += name_len;
+        if (sw && suffix_len) { memcpy(out + pos, suffix, (size_t)suffix_len); pos += suffix_len; }
+        w[1] = pos;
+        out[pos++] = '\n';
+        w[2] = pos;
+        memcpy(out + pos, s, (size_t)n); pos += n;
+        w[3] = pos;
+        out[pos++] = '\n';
+        w[4] = w[5] = -1;
+        if (fastq) {
+            out[pos++] = '+'; out[pos++] = '\n';
+            w[4] = pos;
+            memcpy(out + pos, buf + r[4], (size_t)n); pos += n;
+            w[5] = pos;
+            out[pos++] = '\n';
+        }
+    }
+    *out_len = pos;
+    return CAH_OK;
+}
+
 // Cheap record boundary for the threaded pipeline: the reader thread only has to cut the byte
 // stream at a record start, the full scan (cah_fastq_scan / cah_fasta_scan) runs in a worker
 // (dnaio.read_chunks does the same kind of backwards search for the reference's reader process,

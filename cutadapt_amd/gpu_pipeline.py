@@ -821,7 +821,8 @@ def trim_fastq_gpu_paired(in1, in2, out1, out2, r1: Optional[dict] = None, r2: O
                           pair_filter: Optional[str] = None, minimum_length=None, maximum_length=None,
                           discard_untrimmed: bool = False, discard_trimmed: bool = False,
                           chunk_bytes: int = DEFAULT_GPU_CHUNK_BYTES, threads: int = 2, devices=None,
-                          pair_adapters: bool = False) -> Dict[str, object]:
+                          pair_adapters: bool = False, revcomp: bool = False,
+                          rc_suffix: Optional[str] = " rc") -> Dict[str, object]:
     """``pipeline.trim_fastq_paired`` (same arguments and result) with both mates' chunks indexed and formatted on
     the GPU(s): a worker holds a pair of chunks (two raw buffers in HBM, one stream), runs ``PairedJob.process_pair``
     on them and the writer keeps both outputs in chunk order.  FASTA input goes to the host-parsed pipeline."""
@@ -830,13 +831,13 @@ def trim_fastq_gpu_paired(in1, in2, out1, out2, r1: Optional[dict] = None, r2: O
     if _is_fasta(in1) or _is_fasta(in2):
         return trim_fastq_paired(in1, in2, out1, out2, r1, r2, pair_filter, minimum_length, maximum_length,
                                  discard_untrimmed, discard_trimmed, device=_resolve_devices(devices)[0],
-                                 pair_adapters=pair_adapters)
+                                 pair_adapters=pair_adapters, revcomp=revcomp, rc_suffix=rc_suffix)
     devices = _resolve_devices(devices)
     threads = max(1, int(threads))
 
     def make_job(dev):
         return PairedJob(r1, r2, pair_filter, minimum_length, maximum_length, discard_untrimmed, discard_trimmed, dev,
-                         pair_adapters)
+                         pair_adapters, revcomp, rc_suffix)
 
     total = make_job(devices[0])                             # option errors surface here, not in a worker
 

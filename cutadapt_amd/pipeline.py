@@ -200,6 +200,33 @@ class FastqChunk:
         self.derived = chunk
         return chunk
 
+    def selected(self, other: "FastqChunk", swap: np.ndarray, suffix: Optional[str] = " rc") -> "FastqChunk":
+        """One output chunk of PairedReverseComplementer (reference modifiers.py:311-405): record i of ``other`` where
+        ``swap[i]`` (its name followed by ``suffix``), of this chunk otherwise (cah_chunk_select).  Released together
+        with this chunk."""
+        n = len(self.rec)
+        if len(other.rec) != n:
+            raise ValueError("Reads are improperly paired")
+        sa, oa = self.pack_sequences()
+        sb, ob = other.pack_sequences()
+        flags = np.ascontiguousarray(swap, dtype=np.uint8)
+        sfx = (suffix or "").encode("ascii")
+        names = int(max((self.rec[:, 1] - self.rec[:, 0]).sum(), (other.rec[:, 1] - other.rec[:, 0]).sum())) if n else 0
+        cap = 2 * names + 2 * (int(len(sa)) + int(len(sb))) + (6 + len(sfx)) * n + 16
+        out = POOL.get(cap) if self.pooled else np.empty(cap, dtype=np.uint8)
+        rec = np.empty((n, 6), dtype=np.int64)
+        out_len = C.c_int64(0)
+        _lib.check(_lib.lib().cah_chunk_select(
+            self.buf.ctypes.data, self.rec.ctypes.data, sa.ctypes.data if len(sa) else None, oa.ctypes.data,
+            other.buf.ctypes.data, other.rec.ctypes.data, sb.ctypes.data if len(sb) else None, ob.ctypes.data,
+            n, flags.ctypes.data, sfx, len(sfx), out.ctypes.data, len(out), rec.ctypes.data, C.byref(out_len)))
+        chunk = FastqChunk(out[:out_len.value] if not self.pooled else out, rec)
+        chunk.pooled = self.pooled
+        if self.derived is not None:
+            self.derived.release()
+        self.derived = chunk
+        return chunk
+
     def write_info(self, rows: np.ndarray, names: Sequence[str], is_rc: Optional[np.ndarray] = None,
                    final: Optional[Tuple[np.ndarray, np.ndarray]] = None) -> bytes:
         """--info-file rows for this chunk; rows int64[k,7] as cah_info_write takes them.  ``is_rc``: per read, fills
@@ -577,7 +604,8 @@ class BatchAdapterCutter:
                     raise AttributeError("'LinkedMatch' object has no attribute 'rstart'")     # as the reference
                 rows = rr.rows
                 if len(rows):
-                    rows = rows[np.lexsort((rows[:, 9], rows[:, 0]))]
+                    if len(rows) > 1 and not (rows[1:, 0] > rows[:-1, 0]).all():     # (one unit, one row per read: sorted as it is)
+                        rows = rows[np.lexsort((rows[:, 9], rows[:, 0]))]
                     out = np.empty((len(rows), 9), dtype=np.int64)
                     gi = active[rows[:, 0]]
                     out[:, 8] = rows[:, 10]
@@ -608,7 +636,7 @@ class BatchAdapterCutter:
             beg, end = wbeg, wend
         rows = np.concatenate(all_rows) if all_rows else np.zeros((0, 9), dtype=np.int64)
         stats = np.concatenate(all_stats) if all_stats else np.zeros((0, 3), dtype=np.int64)
-        if len(rows):
+        if len(all_rows) > 1:                                # (one round: sorted as it is)
             order = np.lexsort((rows[:, 7], rows[:, 0]))
             rows, stats = rows[order], stats[order]
         return {"beg": beg, "end": end, "matched": matched, "rows": rows, "stats": stats, "score": score}
@@ -872,7 +900,20 @@ class BatchTrimmer:
             wbeg, wend, matched = res["beg"].astype(np.int64), res["end"].astype(np.int64), res["matched"]
             mode = {"mask": 1, "lowercase": 2}.get(self.action, 0)
             is_rc = res.get("rc")
-            if is_rc is not None and n:
+            if res.get("chunk") is not None:
+                # the adapter step exchanged records (PairedReverseComplementer: the mates of some pairs are swapped):
+                # from here on this mate IS that chunk
+                out_chunk = res["chunk"]
+                lens = out_chunk.lengths()
+                if pre:
+                    w0beg, w0end = res["w0"]
+                if n and (self.poly_a or self.max_expected_errors is not None):
+                    base = out_chunk.reads(self.device)
+                quals = qoff = None
+                is_rc_done = True
+            else:
+                is_rc_done = False
+            if is_rc is not None and n and not is_rc_done:
                 # from here on every read is the orientation that won: one merged copy in HBM for the modifiers
                 # that follow, one merged chunk for the writers; the qualities turn around with their reads
                 from .adapters import _reverse_batch
@@ -1292,7 +1333,8 @@ def read_paired_chunks(path1, path2, chunk_bytes: int = DEFAULT_CHUNK_BYTES) -> 
 def trim_fastq_paired(in1, in2, out1, out2, r1: Optional[dict] = None, r2: Optional[dict] = None,
                       pair_filter: Optional[str] = None, minimum_length=None, maximum_length=None,
                       discard_untrimmed: bool = False, discard_trimmed: bool = False,
-                      chunk_bytes: int = DEFAULT_CHUNK_BYTES, device=None, pair_adapters: bool = False) -> Dict[str, object]:
+                      chunk_bytes: int = DEFAULT_CHUNK_BYTES, device=None, pair_adapters: bool = False,
+                      revcomp: bool = False, rc_suffix: Optional[str] = " rc") -> Dict[str, object]:
     """``cutadapt <R1 options> <R2 options: -A/-G/-B, -U, -Q, -L ...> -o out1 -p out2 in1 in2``:
     ``r1`` / ``r2`` are BatchTrimmer keyword arguments for the two mates (adapters, times, action,
     cut, nextseq_trim, quality_cutoff, quality_base, poly_a, length, max_expected_errors).
@@ -1301,7 +1343,7 @@ def trim_fastq_paired(in1, in2, out1, out2, r1: Optional[dict] = None, r2: Optio
     any (default) / both / first; like the reference (cli.py:861-892), --discard-untrimmed uses
     'both' when only one mate has adapters."""
     job = PairedJob(r1, r2, pair_filter, minimum_length, maximum_length, discard_untrimmed, discard_trimmed, device,
-                    pair_adapters)
+                    pair_adapters, revcomp, rc_suffix)
     o1 = out1 if hasattr(out1, "write") else open(out1, "wb")
     o2 = out2 if hasattr(out2, "write") else open(out2, "wb")
     try:
@@ -1323,8 +1365,11 @@ class PairedJob:
 
     def __init__(self, r1: Optional[dict] = None, r2: Optional[dict] = None, pair_filter: Optional[str] = None,
                  minimum_length=None, maximum_length=None, discard_untrimmed: bool = False,
-                 discard_trimmed: bool = False, device=None, pair_adapters: bool = False):
+                 discard_trimmed: bool = False, device=None, pair_adapters: bool = False, revcomp: bool = False,
+                 rc_suffix: Optional[str] = " rc"):
         r1, r2 = dict(r1 or {}), dict(r2 or {})
+        if revcomp and pair_adapters:
+            raise ValueError("Cannot use --revcomp with --pair-adapters")       # reference cli.py:1086-1087
         if r2.get("poly_a"):
             r2.setdefault("poly_a_revcomp", True)      # --poly-a on paired data: poly-T head of R2
         self.paired_cutter = None
@@ -1348,13 +1393,29 @@ class PairedJob:
         self.untrimmed_mode = "both" if (one_sided and discard_untrimmed) else self.mode
         self.discard_untrimmed, self.discard_trimmed = discard_untrimmed, discard_trimmed
         self.pairs = self.kept = 0
+        # --revcomp on read pairs: PairedReverseComplementer takes the adapter cutters' place when at least one mate has
+        # adapters (reference cli.py:1102-1110)
+        self.revcomp = bool(revcomp) and (self.t1.cutter is not None or self.t2.cutter is not None)
+        self.rc_suffix = rc_suffix
+        self.reverse_complemented = 0
 
     def process_pair(self, c1, c2):
         """two chunks with the same number of records -> the bytes to write for R1 and R2"""
         t1, t2, paired_cutter = self.t1, self.t2, self.paired_cutter
         if len(c1) != len(c2):
             raise ValueError("Reads are improperly paired")
-        if paired_cutter is None:
+        if self.revcomp:
+            g1, g2 = t1._modify_steps(c1), t2._modify_steps(c2)
+            a1, a2 = self._swap_step(next(g1), next(g2), c1, c2)
+            res = []
+            for g, a in ((g1, a1), (g2, a2)):
+                try:
+                    g.send(a)
+                    raise RuntimeError("modify: the step generator did not finish")
+                except StopIteration as stop:
+                    res.append(stop.value)
+            res1, res2 = res
+        elif paired_cutter is None:
             res1, res2 = t1.modify(c1), t2.modify(c2)
         else:
             g1, g2 = t1._modify_steps(c1), t2._modify_steps(c2)
@@ -1373,11 +1434,65 @@ class PairedJob:
         self.kept += len(c1) if keep is None else int(keep.sum())
         return t1.write(c1, res1, keep), t2.write(c2, res2, keep)
 
+    def _swap_step(self, q1, q2, c1, c2):
+        """PairedReverseComplementer (reference modifiers.py:311-405): both cutters on the pair as it is and on the pair
+        with its mates exchanged ("equivalent to reverse complementing"); the exchanged pair is taken when the scores
+        of its matches add up to MORE.  -> the adapter step's results for the two OUTPUT mates, each with the chunk
+        that holds its records from here on (FastqChunk.selected)."""
+        t = (self.t1, self.t2)
+        n = q1["n"]
+        if n != q2["n"]:
+            raise ValueError("Reads are improperly paired")
+        q = (q1, q2)
+        lens = (q1["lens"], q2["lens"])
+
+        def window(k):
+            w = q[k]["window"]
+            if w is None:
+                return np.zeros(n, dtype=np.int64), lens[k].copy()
+            return np.asarray(w[0], dtype=np.int64), np.asarray(w[1], dtype=np.int64)
+
+        def search(cutter, k):
+            """``cutter`` on input mate k"""
+            if cutter is None or n == 0:
+                b, e = window(k)
+                return {"beg": b, "end": e, "matched": np.zeros(n, dtype=bool), "rows": np.zeros((0, 9), dtype=np.int64),
+                        "stats": np.zeros((0, 3), dtype=np.int64), "score": np.zeros(n, dtype=np.int64)}
+            return cutter.search(q[k]["base"], lens[k], q[k]["window"])
+
+        plain = (search(t[0].cutter, 0), search(t[1].cutter, 1))
+        swapped = (search(t[0].cutter, 1), search(t[1].cutter, 0))       # cutter 1 on R2, cutter 2 on R1
+        use = (swapped[0]["score"] + swapped[1]["score"]) > (plain[0]["score"] + plain[1]["score"])
+        self.reverse_complemented += int(use.sum())
+        hc = tuple(c.host_chunk() if hasattr(c, "host_chunk") else c for c in (c1, c2))
+        out = []
+        for k in (0, 1):
+            f, s_ = plain[k], swapped[k]
+            merged = {name: np.where(use, s_[name], f[name]) for name in ("beg", "end", "matched")}
+            keep_f, keep_s = ~use[f["rows"][:, 0]], use[s_["rows"][:, 0]]
+            rows = np.concatenate([f["rows"][keep_f], s_["rows"][keep_s]])
+            stats = np.concatenate([f["stats"][keep_f], s_["stats"][keep_s]])
+            order = np.lexsort((rows[:, 7], rows[:, 0]))
+            merged["rows"], merged["stats"] = rows[order], stats[order]
+            lens_out = np.where(use, lens[1 - k], lens[k])
+            if t[k].cutter is not None:
+                res = t[k].cutter.commit(merged, lens_out, reverse_complemented=use)
+            else:
+                res = {"beg": merged["beg"].astype(np.int32), "end": merged["end"].astype(np.int32),
+                       "matched": merged["matched"], "rows": np.zeros((0, 7), dtype=np.int64), "before": np.zeros(0, dtype=bool)}
+            res["rc"] = use
+            res["chunk"] = hc[k].selected(hc[1 - k], use, self.rc_suffix)
+            wa, wb = window(k), window(1 - k)
+            res["w0"] = (np.where(use, wb[0], wa[0]), np.where(use, wb[1], wa[1]))
+            out.append(res)
+        return out[0], out[1]
+
     def merge(self, other: "PairedJob") -> None:
         self.t1.merge(other.t1)
         self.t2.merge(other.t2)
         self.pairs += other.pairs
         self.kept += other.kept
+        self.reverse_complemented += other.reverse_complemented
         if self.paired_cutter is not None and other.paired_cutter is not None:
             self.paired_cutter.with_adapters += other.paired_cutter.with_adapters
             for a, b in zip(self.paired_cutter.histograms, other.paired_cutter.histograms):
@@ -1390,7 +1505,8 @@ class PairedJob:
         else:
             with_adapters = (t1.cutter.with_adapters if t1.cutter else 0, t2.cutter.with_adapters if t2.cutter else 0)
         return {"pairs": self.pairs, "pairs_written": self.kept, "trimmers": (t1, t2), "filtered": dict(t1.filtered),
-                "with_adapters": with_adapters, "paired_cutter": paired_cutter}
+                "with_adapters": with_adapters, "paired_cutter": paired_cutter,
+                "reverse_complemented": self.reverse_complemented if self.revcomp else None}
 
 
 # -------------------------------------------------------------------------------------------------

@@ -332,6 +332,12 @@ int cah_info_write_rc(const uint8_t *buf, const int64_t *rec, int64_t n_records,
 int cah_chunk_revcomp(const uint8_t *buf, const int64_t *rec, int64_t n_records, const uint8_t *seqs,
                       const int64_t *offsets, const uint8_t *is_rc, const char *suffix, int64_t suffix_len,
                       uint8_t *out, int64_t out_cap, int64_t *out_rec, int64_t *out_len);
+/* One output chunk of PairedReverseComplementer (modifiers.py:311-405: the pair with R1 and R2 swapped): record i is
+ * record i of chunk B where swap[i] != 0 (name + suffix) and of chunk A otherwise; out / out_rec as cah_chunk_revcomp. */
+int cah_chunk_select(const uint8_t *buf_a, const int64_t *rec_a, const uint8_t *seqs_a, const int64_t *offsets_a,
+                     const uint8_t *buf_b, const int64_t *rec_b, const uint8_t *seqs_b, const int64_t *offsets_b,
+                     int64_t n_records, const uint8_t *swap, const char *suffix, int64_t suffix_len,
+                     uint8_t *out, int64_t out_cap, int64_t *out_rec, int64_t *out_len);
 
 /* ---- the same formats ON THE DEVICE (fastq_gpu.hip): the raw FASTQ chunk goes to HBM as it is, records are
  * indexed and the trimmed records formatted there, so that the host does nothing per read.  All pointers are

@@ -51,6 +51,15 @@ CASES = [
          {"adapters": A1}, {"adapters": [["-a", "GGAGTA"]]}, minimum_length=14, pair_filter="both"),
     case("pair_filter_first", 503, "paired.1.fastq", "paired.2.fastq", "paired-filterfirst.1.fastq", "paired-filterfirst.2.fastq",
          {"adapters": A1}, {"adapters": [["-a", "GGAGTA"]]}, minimum_length=14, pair_filter="first"),
+    case("poly_a_poly_t", 775, "polya.1.fasta", "polya.2.fasta", "polya.1.fasta", "polya.2.fasta", {"poly_a": True}, {"poly_a": True}),
+    case("pair_adapters", 668, "paired.1.fastq", "paired.2.fastq", "pair-adapters.1.fastq", "pair-adapters.2.fastq",
+         {"adapters": [["-a", "GTCTCCAGCT"]]}, {"adapters": [["-a", "GACAAATAAC"]]}, pair_adapters=True),
+    case("revcomp_only_r1", 786, "revcomp.1.fastq", "revcomp.2.fastq", "revcomp.1.fastq", "revcomp.2.fastq",
+         {"adapters": [["-g", "^TTATTTGTCT"], ["-g", "^TCCGCACTGGC"]]}, {}, revcomp=True),
+    case("revcomp_only_r2", 803, "revcomp.2.fastq", "revcomp.1.fastq", "revcomp.2.fastq", "revcomp.1.fastq",
+         {}, {"adapters": [["-g", "^TTATTTGTCT"], ["-g", "^TCCGCACTGGC"]]}, revcomp=True),
+    case("revcomp_r1_and_r2", 820, "revcomp.1.fastq", "revcomp.2.fastq", "revcomp-r1r2.1.fastq", "revcomp-r1r2.2.fastq",
+         {"adapters": [["-g", "^TTATTTGTCT"]]}, {"adapters": [["-g", "^TCCGCACTGGC"]]}, revcomp=True),
     case("nextseq", 561, "nextseq.fastq", "nextseq.fastq", "nextseq.fastq", "nextseq.fastq", {"nextseq_trim": 22}, {"nextseq_trim": 22}),
 ]
 

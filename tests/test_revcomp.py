@@ -245,3 +245,74 @@ def test_revcomp_through_the_whole_trimmer(hip):
     assert threaded.getvalue() == whole.getvalue()
     assert st3["reverse_complemented"] == stats["reverse_complemented"]
     assert st3["cutter"].reverse_complemented.tolist() == stats["cutter"].reverse_complemented.tolist()
+
+
+@pytest.mark.gpu
+def test_paired_reverse_complementer_against_the_rule_over_oracle_results(hip, orc):
+    """PairedReverseComplementer (reference modifiers.py:311-405): both cutters on the pair and on the pair with its mates
+    exchanged, the exchanged pair wins when its scores add up to more; host-parsed and device-parsed chunks, with a
+    modifier in front (-q) and behind (-l) the adapter step."""
+    import random
+    from cutadapt_amd import adapters as A
+    from cutadapt_amd.gpu_pipeline import trim_fastq_gpu_paired
+    from cutadapt_amd.kmer_heuristic import create_positions_and_kmers
+    from cutadapt_amd.pipeline import trim_fastq_paired
+    rng = random.Random(31)
+    ad1, ad2 = "ACGTTGCAAGTCAG", "GGATCCAATCGTTA"
+    finders = {ad: orc.KmerFinder(create_positions_and_kmers(ad, 3, 0.1, True, False), False, False) for ad in (ad1, ad2)}
+
+    def cut(ad, s):
+        """one round of a 3' adapter -> (kept length, score)"""
+        if not finders[ad].kmers_present(s):
+            return len(s), 0
+        t = orc.Aligner(ad, 0.1, flags=14, wildcard_ref=False, min_overlap=3).locate(s)
+        return (len(s), 0) if t is None else (t[2], t[4])
+
+    pairs = []
+    for i in range(1500):
+        r = []
+        for ad_own, ad_other in ((ad1, ad2), (ad2, ad1)):
+            s = "".join(rng.choice("ACGT") for _ in range(rng.randint(5, 70)))
+            u = rng.random()
+            if u < 0.4:
+                s += ad_own[:rng.randint(3, len(ad_own))]
+            elif u < 0.8:
+                s += ad_other[:rng.randint(3, len(ad_other))]          # as if the mates had been swapped
+            s += "".join(rng.choice("ACGT") for _ in range(rng.randint(0, 4)))
+            q = "".join(chr(rng.randint(50, 73)) for _ in s)
+            if rng.random() < 0.3:
+                q = q[:-2] + "##"
+            r.append((s, q))
+        pairs.append(r)
+    fq = ["".join(f"@p{i}/{k + 1}\n{p[k][0]}\n+\n{p[k][1]}\n" for i, p in enumerate(pairs)).encode() for k in (0, 1)]
+    QCUT, LENGTH = (0, 10), 40
+    from test_gpu_fastq_general import quality_trim_index
+    want1, want2, n_rc = [], [], 0
+    for i, p in enumerate(pairs):
+        trimmed = []
+        for s, q in p:
+            a, b = quality_trim_index(q, *QCUT)
+            trimmed.append((s[a:b], q[a:b]))
+        (s1, q1), (s2, q2) = trimmed
+        plain = (cut(ad1, s1), cut(ad2, s2))
+        swapped = (cut(ad1, s2), cut(ad2, s1))
+        use = swapped[0][1] + swapped[1][1] > plain[0][1] + plain[1][1]
+        n_rc += use
+        if use:
+            o1 = (f"p{i}/2 rc", s2[:swapped[0][0]], q2[:swapped[0][0]])
+            o2 = (f"p{i}/1 rc", s1[:swapped[1][0]], q1[:swapped[1][0]])
+        else:
+            o1 = (f"p{i}/1", s1[:plain[0][0]], q1[:plain[0][0]])
+            o2 = (f"p{i}/2", s2[:plain[1][0]], q2[:plain[1][0]])
+        want1.append(f"@{o1[0]}\n{o1[1][:LENGTH]}\n+\n{o1[2][:LENGTH]}\n")
+        want2.append(f"@{o2[0]}\n{o2[1][:LENGTH]}\n+\n{o2[2][:LENGTH]}\n")
+    assert 300 < n_rc < 1200
+    for fn, kw in ((trim_fastq_paired, {}), (trim_fastq_gpu_paired, {"threads": 2})):
+        for chunk_bytes in (1 << 20, 3000):
+            o1, o2 = io.BytesIO(), io.BytesIO()
+            mate = lambda ad: dict(adapters=[A.BackAdapter(ad)], quality_cutoff=QCUT, length=LENGTH)
+            stats = fn(io.BytesIO(fq[0]), io.BytesIO(fq[1]), o1, o2, mate(ad1), mate(ad2), revcomp=True,
+                       chunk_bytes=chunk_bytes, **kw)
+            assert o1.getvalue() == "".join(want1).encode(), (fn.__name__, chunk_bytes)
+            assert o2.getvalue() == "".join(want2).encode(), (fn.__name__, chunk_bytes)
+            assert stats["reverse_complemented"] == n_rc
