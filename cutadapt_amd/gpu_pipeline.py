@@ -145,40 +145,39 @@ class _Worker:
         n_bytes = int(len(data))
         self._ensure(n_bytes)
         sp = self.stream.cuda_stream
-        if True:
-            # ---- raw chunk -> HBM (from pinned memory: the input itself if it is pinned, else staged) ----------
-            if isinstance(data, torch.Tensor) and data.is_pinned():
-                src = data
-            else:
-                if self.h_in is None or self.h_in.numel() < n_bytes:
-                    self.h_in = torch.empty(self.cap, dtype=torch.uint8).pin_memory()
-                src = self.h_in[:n_bytes]
-                src.numpy()[:] = data if isinstance(data, np.ndarray) else data.numpy()
-            self.d_in[:n_bytes].copy_(src, non_blocking=True)
-            last_byte = int(data[n_bytes - 1])
-            # ---- step 1: count lines, size the record arrays ------------------------------------------------
-            need = int(L.cah_fastq_device_scratch_bytes(n_bytes, n_bytes // 64 + 1024))
-            if self.d_scratch is None or self.d_scratch.numel() < need:
-                self.d_scratch = torch.empty(need + need // 4, dtype=torch.uint8, device=self.device)
-            _lib.check(L.cah_fastq_count_lines_device(self.d_in.data_ptr(), n_bytes, self.d_scratch.data_ptr(),
-                                                      self.d_scratch.numel(), self.d_info.data_ptr(), sp))
-            self.h_info.copy_(self.d_info, non_blocking=True)
-            self.stream.synchronize()
-            n_newlines = int(self.h_info[0])
-            n_lines = n_newlines + (1 if last_byte != 10 else 0)
-            if n_lines % 4 != 0:
-                raise ValueError("FASTQ format error: premature end of file (incomplete record)")
-            n = n_lines // 4
-            need = int(L.cah_fastq_device_scratch_bytes(n_bytes, n))
-            if self.d_scratch.numel() < need:
-                # the tile counts of step 1 live at the front of the scratch: keep them
-                grown = torch.empty(need + need // 4, dtype=torch.uint8, device=self.device)
-                grown[: self.d_scratch.numel()].copy_(self.d_scratch)
-                self.d_scratch = grown
-            self._ensure_records(max(n, 1))
-            _lib.check(L.cah_fastq_index_device(self.d_in.data_ptr(), n_bytes, n_newlines, n, self.d_scratch.data_ptr(),
-                                                self.d_scratch.numel(), self.rec6.data_ptr(), self.seq_off.data_ptr(),
-                                                self.seq_len.data_ptr(), self.d_info.data_ptr(), sp))
+        # ---- raw chunk -> HBM (from pinned memory: the input itself if it is pinned, else staged) ----------
+        if isinstance(data, torch.Tensor) and data.is_pinned():
+            src = data
+        else:
+            if self.h_in is None or self.h_in.numel() < n_bytes:
+                self.h_in = torch.empty(self.cap, dtype=torch.uint8).pin_memory()
+            src = self.h_in[:n_bytes]
+            src.numpy()[:] = data if isinstance(data, np.ndarray) else data.numpy()
+        self.d_in[:n_bytes].copy_(src, non_blocking=True)
+        last_byte = int(data[n_bytes - 1])
+        # ---- step 1: count lines, size the record arrays ------------------------------------------------
+        need = int(L.cah_fastq_device_scratch_bytes(n_bytes, n_bytes // 64 + 1024))
+        if self.d_scratch is None or self.d_scratch.numel() < need:
+            self.d_scratch = torch.empty(need + need // 4, dtype=torch.uint8, device=self.device)
+        _lib.check(L.cah_fastq_count_lines_device(self.d_in.data_ptr(), n_bytes, self.d_scratch.data_ptr(),
+                                                  self.d_scratch.numel(), self.d_info.data_ptr(), sp))
+        self.h_info.copy_(self.d_info, non_blocking=True)
+        self.stream.synchronize()
+        n_newlines = int(self.h_info[0])
+        n_lines = n_newlines + (1 if last_byte != 10 else 0)
+        if n_lines % 4 != 0:
+            raise ValueError("FASTQ format error: premature end of file (incomplete record)")
+        n = n_lines // 4
+        need = int(L.cah_fastq_device_scratch_bytes(n_bytes, n))
+        if self.d_scratch.numel() < need:
+            # the tile counts of step 1 live at the front of the scratch: keep them
+            grown = torch.empty(need + need // 4, dtype=torch.uint8, device=self.device)
+            grown[: self.d_scratch.numel()].copy_(self.d_scratch)
+            self.d_scratch = grown
+        self._ensure_records(max(n, 1))
+        _lib.check(L.cah_fastq_index_device(self.d_in.data_ptr(), n_bytes, n_newlines, n, self.d_scratch.data_ptr(),
+                                            self.d_scratch.numel(), self.rec6.data_ptr(), self.seq_off.data_ptr(),
+                                            self.seq_len.data_ptr(), self.d_info.data_ptr(), sp))
         self.n, self.n_bytes = n, n_bytes
         return n
 
@@ -236,41 +235,40 @@ class _Worker:
         sp = self.stream.cuda_stream
         n = self.load(data)
         n_bytes = self.n_bytes
-        if True:
-            # ---- step 3: match the reads in place, decide what is kept ------------------------------------------
-            o = self.opts
-            if n:
-                ws_need = int(L.cah_plan_workspace_bytes(self.plan.handle, n))
-                if self._ws is None or self._ws.numel() < ws_need:
-                    self._ws = torch.empty(ws_need + ws_need // 4, dtype=torch.uint8, device=self.device)
-                _lib.check(L.cah_match_batch(self.plan.handle, self.d_in.data_ptr(), self.seq_off.data_ptr(),
-                                             self.seq_len.data_ptr(), n, self.res.out6.data_ptr(),
-                                             self.res.best_adapter.data_ptr(), self.res.status.data_ptr(),
-                                             self._ws.data_ptr(), self._ws.numel(), sp))
-                _lib.check(L.cah_trim_decide_device(
-                    self.res.out6.data_ptr(), self.res.status.data_ptr(), self.res.best_adapter.data_ptr(),
-                    self.seq_len.data_ptr(), n, self.kinds.data_ptr(),
-                    -1 if o["minimum_length"] is None else int(o["minimum_length"]),
-                    -1 if o["maximum_length"] is None else int(o["maximum_length"]),
-                    int(bool(o["discard_trimmed"])), int(bool(o["discard_untrimmed"])),
-                    self.beg.data_ptr(), self.end.data_ptr(), self.keep.data_ptr(), self.counters.data_ptr(), sp))
-            if o.get("assemble") == "host":
-                return self._assemble_on_host(data, n_bytes, n)
-            # ---- step 4: format on the device, bring the bytes back ---------------------------------------------
-            _lib.check(L.cah_fastq_format_device(self.d_in.data_ptr(), self.rec6.data_ptr(), n, self.beg.data_ptr(),
-                                                 self.end.data_ptr(), self.keep.data_ptr(), self.d_scratch.data_ptr(),
-                                                 self.d_scratch.numel(), n_bytes, self.d_out.data_ptr(),
-                                                 self.d_out.numel(), self.d_info.data_ptr(), sp))
-            self.d_info[4:5].copy_(self.counters[6:7], non_blocking=True)
-            self.h_info.copy_(self.d_info, non_blocking=True)
-            self.stream.synchronize()
-            self._raise_format_error(int(self.h_info[1]))
-            if int(self.h_info[4]) != 0:
-                _lib.raise_invalid_reads(int(self.seq_len[:max(n, 1)].max().item()))
-            total = int(self.h_info[3])
-            h_out = self.pool.get(total)
-            h_out[:total].copy_(self.d_out[:total], non_blocking=True)
-            self.stream.synchronize()
+        # ---- step 3: match the reads in place, decide what is kept ------------------------------------------
+        o = self.opts
+        if n:
+            ws_need = int(L.cah_plan_workspace_bytes(self.plan.handle, n))
+            if self._ws is None or self._ws.numel() < ws_need:
+                self._ws = torch.empty(ws_need + ws_need // 4, dtype=torch.uint8, device=self.device)
+            _lib.check(L.cah_match_batch(self.plan.handle, self.d_in.data_ptr(), self.seq_off.data_ptr(),
+                                         self.seq_len.data_ptr(), n, self.res.out6.data_ptr(),
+                                         self.res.best_adapter.data_ptr(), self.res.status.data_ptr(),
+                                         self._ws.data_ptr(), self._ws.numel(), sp))
+            _lib.check(L.cah_trim_decide_device(
+                self.res.out6.data_ptr(), self.res.status.data_ptr(), self.res.best_adapter.data_ptr(),
+                self.seq_len.data_ptr(), n, self.kinds.data_ptr(),
+                -1 if o["minimum_length"] is None else int(o["minimum_length"]),
+                -1 if o["maximum_length"] is None else int(o["maximum_length"]),
+                int(bool(o["discard_trimmed"])), int(bool(o["discard_untrimmed"])),
+                self.beg.data_ptr(), self.end.data_ptr(), self.keep.data_ptr(), self.counters.data_ptr(), sp))
+        if o.get("assemble") == "host":
+            return self._assemble_on_host(data, n_bytes, n)
+        # ---- step 4: format on the device, bring the bytes back ---------------------------------------------
+        _lib.check(L.cah_fastq_format_device(self.d_in.data_ptr(), self.rec6.data_ptr(), n, self.beg.data_ptr(),
+                                             self.end.data_ptr(), self.keep.data_ptr(), self.d_scratch.data_ptr(),
+                                             self.d_scratch.numel(), n_bytes, self.d_out.data_ptr(),
+                                             self.d_out.numel(), self.d_info.data_ptr(), sp))
+        self.d_info[4:5].copy_(self.counters[6:7], non_blocking=True)
+        self.h_info.copy_(self.d_info, non_blocking=True)
+        self.stream.synchronize()
+        self._raise_format_error(int(self.h_info[1]))
+        if int(self.h_info[4]) != 0:
+            _lib.raise_invalid_reads(int(self.seq_len[:max(n, 1)].max().item()))
+        total = int(self.h_info[3])
+        h_out = self.pool.get(total)
+        h_out[:total].copy_(self.d_out[:total], non_blocking=True)
+        self.stream.synchronize()
         return h_out, total
 
 
