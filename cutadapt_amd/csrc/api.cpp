@@ -1453,8 +1453,10 @@ static int match_batch_impl(const cah_plan* plan, const uint8_t* d_seqs, const i
     int32_t first_aligner = -1;
     for (int32_t ad = 0; ad < (int32_t)plan->matchers.size() && first_aligner < 0; ad++)
         if (plan->matchers[(size_t)ad].kind != CAH_KIND_KMER_ONLY) first_aligner = ad;
+    // (CAH_NO_FILTER_CLEAR=1: memsets instead, A/B)
     const bool filter_clears = !t_outputs_ready && !multi_path && first_aligner >= 0 &&
-                               runs_filter(plan->matchers[(size_t)first_aligner]) && n_reads > CAH_TINY_BATCH;
+                               runs_filter(plan->matchers[(size_t)first_aligner]) && n_reads > CAH_TINY_BATCH &&
+                               !(env_flag("CAH_NO_FILTER_CLEAR") && !fuse);
     if (!t_outputs_ready) {
         HIP_TRY(hipMemsetAsync(d_status, 0, (size_t)n_reads, s));
         if (!filter_clears) HIP_TRY(hipMemsetAsync(d_out6, 0, sizeof(int32_t) * 6 * (size_t)n_reads, s));

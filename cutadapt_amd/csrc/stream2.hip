@@ -351,9 +351,10 @@ __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a
     const int64_t total = (int64_t)n_reads * n;                         // bytes of the batch
     if (total < 16) return;                                             // (same test there)
     const bool clear0 = a.clear_out6 != nullptr && a.present == nullptr;
-    // CAH_S2_NOMATCH (measurement only): 1 copy, match nothing; 2 ... and no result rows; 3 result rows only, no loads
+    // CAH_S2_NOMATCH (measurement only): 1 copy, match nothing; 2 ... and no result rows; 3 result rows only, no loads;
+    // 5 everything but the loads (the matching works on stale slot contents: timing only)
     const bool nomatch = a.max_read_len <= -12345 && a.max_read_len >= -12347;
-    const bool noclear = a.max_read_len == -12346 || a.max_read_len == -12348, noload = a.max_read_len == -12347;   // 4: match, no result rows
+    const bool noclear = a.max_read_len == -12346 || a.max_read_len == -12348, noload = a.max_read_len == -12347 || a.max_read_len == -12349;   // 4: match, no result rows; 5: match what the slots happen to hold, no loads
     const bool clear = clear0 && !noclear;
 
     // tables (stream2.h: s2_entry); slots a plan does not use hold zeros
