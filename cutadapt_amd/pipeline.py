@@ -618,9 +618,10 @@ class BatchAdapterCutter:
                     all_rows.append(out)
                     all_stats.append(rows[:, [7, 8, 1]])
                 score[g] += rr.score[hit]
-                last_ret = (last_ret[0].copy(), last_ret[1].copy())
-                last_ret[0][g], last_ret[1][g] = wbeg[g] + rr.ret_beg[hit], wbeg[g] + rr.ret_end[hit]
-                last_crop[0][g], last_crop[1][g] = wbeg[g] + rr.crop_beg[hit], wbeg[g] + rr.crop_end[hit]
+                if self.action == "retain":
+                    last_ret[0][g], last_ret[1][g] = wbeg[g] + rr.ret_beg[hit], wbeg[g] + rr.ret_end[hit]
+                elif self.action == "crop":
+                    last_crop[0][g], last_crop[1][g] = wbeg[g] + rr.crop_beg[hit], wbeg[g] + rr.crop_end[hit]
                 new_beg = wbeg[g] + rr.rem_beg[hit]
                 new_end = wbeg[g] + rr.rem_end[hit]
                 wbeg[g], wend[g] = new_beg, new_end
