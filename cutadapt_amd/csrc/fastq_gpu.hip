@@ -268,8 +268,11 @@ __global__ __launch_bounds__(256) void k_format(const uint8_t* buf, const int64_
 // position 0: reference adapters.py:453-454, :486-487, :931), then the filters in the reference's order
 // (cli.py:735-912: too short, too long, --discard-trimmed / --discard-untrimmed).
 // counters: [0] reads [1] with adapters [2] bp in [3] bp out (kept records) [4] too short [5] too long [6] invalid reads
+// (win_beg / full_len, both or neither: the adapter step saw the window [win_beg[r], win_beg[r] + seq_len[r]) of a read of
+// full_len[r] characters -- what the modifiers in front of it left, cli.py:938-954; beg / end are relative to the read)
 __global__ __launch_bounds__(256) void k_trim_decide(const int32_t* out6, const uint8_t* status, const int32_t* best_adapter,
-                                                     const int32_t* seq_len, int64_t n, const uint8_t* adapter_kind,
+                                                     const int32_t* seq_len, const int32_t* win_beg, const int32_t* full_len,
+                                                     int64_t n, const uint8_t* adapter_kind,
                                                      int32_t min_len, int32_t max_len, int32_t discard_trimmed,
                                                      int32_t discard_untrimmed, int32_t* beg, int32_t* end, uint8_t* keep,
                                                      unsigned long long* counters) {
@@ -296,8 +299,9 @@ __global__ __launch_bounds__(256) void k_trim_decide(const int32_t* out6, const 
         if (k && max_len >= 0 && out_len > max_len) { acc[5] += 1; k = false; }
         if (discard_trimmed) k = k && !found;
         else if (discard_untrimmed) k = k && found;
-        beg[r] = b; end[r] = e; keep[r] = k ? 1 : 0;
-        acc[0] += 1; acc[1] += found ? 1 : 0; acc[2] += (unsigned)len; acc[3] += k ? (unsigned)out_len : 0u;
+        const int w0 = win_beg ? win_beg[r] : 0;
+        beg[r] = w0 + b; end[r] = w0 + e; keep[r] = k ? 1 : 0;
+        acc[0] += 1; acc[1] += found ? 1 : 0; acc[2] += (unsigned)(full_len ? full_len[r] : len); acc[3] += k ? (unsigned)out_len : 0u;
         acc[6] += st == 2 ? 1 : 0;
     }
 #pragma unroll
@@ -394,8 +398,30 @@ int cah_trim_decide_device(const int32_t* d_out6, const uint8_t* d_status, const
         return cah_set_error_(CAH_EINVAL, "cah_trim_decide_device: NULL argument");
     const int64_t rb = (n_reads + 255) / 256;
     hipLaunchKernelGGL(k_trim_decide, dim3((unsigned)(rb < 4 * cus() ? rb : 4 * cus())), dim3(256), 0, (hipStream_t)stream, d_out6,
-                       d_status, d_best_adapter, d_seq_len, n_reads, d_adapter_kind, min_len, max_len, discard_trimmed,
-                       discard_untrimmed, d_beg, d_end, d_keep, (unsigned long long*)d_counters);
+                       d_status, d_best_adapter, d_seq_len, (const int32_t*)nullptr, (const int32_t*)nullptr, n_reads,
+                       d_adapter_kind, min_len, max_len, discard_trimmed, discard_untrimmed, d_beg, d_end, d_keep,
+                       (unsigned long long*)d_counters);
+    GPU_TRY(hipGetLastError());
+    return CAH_OK;
+}
+
+// ... when modifiers ran in front of the adapter step (-u, --nextseq-trim, -q; reference cli.py:938-954): the matcher saw
+// the window [d_win_beg[r], d_win_beg[r] + d_win_len[r]) of read r, whose full length is d_seq_len[r].  d_beg / d_end
+// are relative to the read; "bp in" counts the full reads.
+int cah_trim_decide_window_device(const int32_t* d_out6, const uint8_t* d_status, const int32_t* d_best_adapter,
+                                  const int32_t* d_win_beg, const int32_t* d_win_len, const int32_t* d_seq_len,
+                                  int64_t n_reads, const uint8_t* d_adapter_kind, int32_t min_len, int32_t max_len,
+                                  int32_t discard_trimmed, int32_t discard_untrimmed, int32_t* d_beg, int32_t* d_end,
+                                  uint8_t* d_keep, uint64_t* d_counters, void* stream) {
+    if (n_reads < 0) return cah_set_error_(CAH_EINVAL, "cah_trim_decide_window_device: bad argument");
+    if (n_reads == 0) return CAH_OK;
+    if (!d_out6 || !d_status || !d_win_beg || !d_win_len || !d_seq_len || !d_adapter_kind || !d_beg || !d_end || !d_keep ||
+        !d_counters)
+        return cah_set_error_(CAH_EINVAL, "cah_trim_decide_window_device: NULL argument");
+    const int64_t rb = (n_reads + 255) / 256;
+    hipLaunchKernelGGL(k_trim_decide, dim3((unsigned)(rb < 4 * cus() ? rb : 4 * cus())), dim3(256), 0, (hipStream_t)stream, d_out6,
+                       d_status, d_best_adapter, d_win_len, d_win_beg, d_seq_len, n_reads, d_adapter_kind, min_len, max_len,
+                       discard_trimmed, discard_untrimmed, d_beg, d_end, d_keep, (unsigned long long*)d_counters);
     GPU_TRY(hipGetLastError());
     return CAH_OK;
 }

@@ -88,6 +88,7 @@ class _Worker:
         self.d_info = torch.zeros(8, dtype=torch.int64, device=self.device)
         self.h_info = torch.zeros(8, dtype=torch.int64).pin_memory()
         self.counters = torch.zeros(8, dtype=torch.int64, device=self.device)   # see cah_trim_decide_device
+        self.pre_counts = torch.zeros(2, dtype=torch.int64, device=self.device)  # bases removed by NextSeq / quality trimming
         self._ws = None
         self.n = self.n_bytes = 0
         self.busy_s, self.chunks, self.bytes_in = 0.0, 0, 0   # per-device rates (trim_fastq_gpu's "per_device")
@@ -241,17 +242,62 @@ class _Worker:
             ws_need = int(L.cah_plan_workspace_bytes(self.plan.handle, n))
             if self._ws is None or self._ws.numel() < ws_need:
                 self._ws = torch.empty(ws_need + ws_need // 4, dtype=torch.uint8, device=self.device)
-            _lib.check(L.cah_match_batch(self.plan.handle, self.d_in.data_ptr(), self.seq_off.data_ptr(),
-                                         self.seq_len.data_ptr(), n, self.res.out6.data_ptr(),
-                                         self.res.best_adapter.data_ptr(), self.res.status.data_ptr(),
-                                         self._ws.data_ptr(), self._ws.numel(), sp))
-            _lib.check(L.cah_trim_decide_device(
-                self.res.out6.data_ptr(), self.res.status.data_ptr(), self.res.best_adapter.data_ptr(),
-                self.seq_len.data_ptr(), n, self.kinds.data_ptr(),
-                -1 if o["minimum_length"] is None else int(o["minimum_length"]),
-                -1 if o["maximum_length"] is None else int(o["maximum_length"]),
-                int(bool(o["discard_trimmed"])), int(bool(o["discard_untrimmed"])),
-                self.beg.data_ptr(), self.end.data_ptr(), self.keep.data_ptr(), self.counters.data_ptr(), sp))
+            limits = (-1 if o["minimum_length"] is None else int(o["minimum_length"]),
+                      -1 if o["maximum_length"] is None else int(o["maximum_length"]),
+                      int(bool(o["discard_trimmed"])), int(bool(o["discard_untrimmed"])))
+            pre = o.get("pre")
+            if pre:
+                # the modifiers in front of the adapter step (-u, --nextseq-trim, -q: reference cli.py:938-954) as kernels
+                # and a few element-wise operations on this stream; the matcher then sees a window of every read
+                seq_len, seq_off = self.seq_len[:n], self.seq_off[:n]
+                qual_off = self.rec6[:n, 4]
+                wbeg = torch.zeros(n, dtype=torch.int32, device=self.device)
+                wlen = seq_len.clone()
+                for c in pre["cut"]:                              # UnconditionalCutter: read[c:] / read[:c]
+                    if c > 0:
+                        d = torch.clamp(wlen, max=c)
+                        wbeg += d
+                        wlen -= d
+                    else:
+                        wlen = torch.clamp(wlen + c, min=0)
+                if pre["nextseq_trim"] is not None:
+                    stop = torch.empty(n, dtype=torch.int32, device=self.device)
+                    w64 = wbeg.to(torch.int64)
+                    so, qo = seq_off + w64, qual_off + w64       # (named: a temporary's block could be handed out again
+                    _lib.check(L.cah_nextseq_trim_batch_q(       #  before the kernel has read it)
+                        self.d_in.data_ptr(), self.d_in.data_ptr(), so.data_ptr(), qo.data_ptr(),
+                        wlen.data_ptr(), n, int(pre["nextseq_trim"]), int(pre["quality_base"]), stop.data_ptr(), sp))
+                    self.pre_counts[0] += (wlen - stop).sum()
+                    wlen = stop
+                if pre["quality_cutoff"] is not None:
+                    ss = torch.empty((n, 2), dtype=torch.int32, device=self.device)
+                    qo = qual_off + wbeg.to(torch.int64)
+                    _lib.check(L.cah_quality_trim_batch(
+                        self.d_in.data_ptr(), qo.data_ptr(), wlen.data_ptr(), n, int(pre["quality_cutoff"][0]),
+                        int(pre["quality_cutoff"][1]), int(pre["quality_base"]), ss.data_ptr(), sp))
+                    kept = ss[:, 1] - ss[:, 0]
+                    self.pre_counts[1] += (wlen - kept).sum()
+                    wbeg = wbeg + ss[:, 0]
+                    wlen = kept.contiguous()
+                wbeg = wbeg.contiguous()
+                voff = (seq_off + wbeg.to(torch.int64)).contiguous()
+                _lib.check(L.cah_match_batch(self.plan.handle, self.d_in.data_ptr(), voff.data_ptr(), wlen.data_ptr(), n,
+                                             self.res.out6.data_ptr(), self.res.best_adapter.data_ptr(),
+                                             self.res.status.data_ptr(), self._ws.data_ptr(), self._ws.numel(), sp))
+                _lib.check(L.cah_trim_decide_window_device(
+                    self.res.out6.data_ptr(), self.res.status.data_ptr(), self.res.best_adapter.data_ptr(),
+                    wbeg.data_ptr(), wlen.data_ptr(), self.seq_len.data_ptr(), n, self.kinds.data_ptr(), *limits,
+                    self.beg.data_ptr(), self.end.data_ptr(), self.keep.data_ptr(), self.counters.data_ptr(), sp))
+                self._pre_tensors = (wbeg, wlen, voff)           # (alive until the stream is through with them)
+            else:
+                _lib.check(L.cah_match_batch(self.plan.handle, self.d_in.data_ptr(), self.seq_off.data_ptr(),
+                                             self.seq_len.data_ptr(), n, self.res.out6.data_ptr(),
+                                             self.res.best_adapter.data_ptr(), self.res.status.data_ptr(),
+                                             self._ws.data_ptr(), self._ws.numel(), sp))
+                _lib.check(L.cah_trim_decide_device(
+                    self.res.out6.data_ptr(), self.res.status.data_ptr(), self.res.best_adapter.data_ptr(),
+                    self.seq_len.data_ptr(), n, self.kinds.data_ptr(), *limits,
+                    self.beg.data_ptr(), self.end.data_ptr(), self.keep.data_ptr(), self.counters.data_ptr(), sp))
         if o.get("assemble") == "host":
             return self._assemble_on_host(data, n_bytes, n)
         # ---- step 4: format on the device, bring the bytes back ---------------------------------------------
@@ -404,6 +450,7 @@ def _take_worker(plan, kinds, dev, opts) -> "_Worker":
     with torch.cuda.stream(w.stream):                           # ordered in front of the worker's next kernels
         w.kinds = torch.tensor(kinds, dtype=torch.uint8, device=w.device)
         w.counters.zero_()
+        w.pre_counts.zero_()
     w._ws = None
     w.busy_s, w.chunks, w.bytes_in = 0.0, 0, 0
     return w
@@ -661,14 +708,21 @@ def trim_fastq_gpu(source: Union[str, BinaryIO, np.ndarray], out: Union[str, Bin
         res["devices_used"] = getattr(res["trimmer"], "devices_used", [str(_resolve_devices(devices)[0])])
         res["way"] = "host-parsed (FASTA)"
         return res
-    all_device = (adapters and times == 1 and action == "trim" and nextseq_trim is None and quality_cutoff is None
-                  and not poly_a and max_expected_errors is None and not list(cut) and length is None and not revcomp
-                  and info_file is None
+    cut = [int(c) for c in cut if int(c) != 0]
+    if len(cut) > 2:
+        raise ValueError("You cannot remove bases from more than two ends.")
+    if len(cut) == 2 and cut[0] * cut[1] > 0:
+        raise ValueError("You cannot remove bases from the same end twice.")
+    all_device = (adapters and times == 1 and action == "trim" and not poly_a and max_expected_errors is None
+                  and length is None and not revcomp and info_file is None
                   and all(isinstance(a, SingleAdapter) and not a._reverse_reads for a in adapters))
+    pre = None
+    if all_device and (cut or nextseq_trim is not None or quality_cutoff is not None):
+        pre = {"cut": cut, "nextseq_trim": nextseq_trim, "quality_cutoff": quality_cutoff, "quality_base": quality_base}
     devices = _resolve_devices(devices)
     threads = max(1, int(threads))
     opts = {"discard_untrimmed": discard_untrimmed, "discard_trimmed": discard_trimmed,
-            "minimum_length": minimum_length, "maximum_length": maximum_length, "assemble": assemble}
+            "minimum_length": minimum_length, "maximum_length": maximum_length, "assemble": assemble, "pre": pre}
     from .pipeline import BatchTrimmer
     if all_device:
         plan, kinds = _plan_for(adapters)
@@ -751,10 +805,13 @@ def trim_fastq_gpu(source: Union[str, BinaryIO, np.ndarray], out: Union[str, Bin
                                  "way": "all-device" if all_device else "general"}
     if all_device:
         stats = np.zeros(8, dtype=np.int64)
+        removed = np.zeros(2, dtype=np.int64)
         for w in workers:
             stats += w.counters.cpu().numpy()
+            removed += w.pre_counts.cpu().numpy()
         result.update({"reads": int(stats[0]), "with_adapters": int(stats[1]), "bp_in": int(stats[2]),
-                       "bp_out": int(stats[3]), "filtered": {"too_short": int(stats[4]), "too_long": int(stats[5])}})
+                       "bp_out": int(stats[3]), "filtered": {"too_short": int(stats[4]), "too_long": int(stats[5])},
+                       "nextseq_trimmed_bases": int(removed[0]), "quality_trimmed_bases": int(removed[1])})
     else:
         total = BatchTrimmer(adapters, device=devices[0], **general_opts)
         for w in workers:

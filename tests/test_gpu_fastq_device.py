@@ -52,6 +52,10 @@ def test_device_fastq_equals_host_pipeline(hip):
         ([A.PrefixAdapter(ad_seqs[2]), A.SuffixAdapter(ad_seqs[1])], {"discard_untrimmed": True}),
         ([A.BackAdapter(ad_seqs[0])], {"minimum_length": 30, "maximum_length": 120}),
         ([A.NonInternalBackAdapter(ad_seqs[1]), A.BackAdapter(ad_seqs[0])], {"discard_trimmed": True}),
+        # modifiers in front of the adapter step, still without a byte of per-read data on the host
+        ([A.BackAdapter(ad_seqs[0])], {"quality_cutoff": (0, 20), "minimum_length": 20}),
+        ([A.BackAdapter(ad_seqs[0]), A.FrontAdapter(ad_seqs[1])], {"quality_cutoff": (15, 25), "cut": [3, -2]}),
+        ([A.AnywhereAdapter(ad_seqs[2])], {"nextseq_trim": 20, "cut": [-5], "maximum_length": 140}),
     ]
     for ci, (ads, opts) in enumerate(cases):
         for crlf, final_nl, chunk in ((False, True, 1 << 20), (True, True, 4096), (False, False, 700)):
@@ -66,6 +70,9 @@ def test_device_fastq_equals_host_pipeline(hip):
                 assert got.getvalue() == want.getvalue(), (ci, crlf, final_nl, chunk, assemble)
                 assert (gs["reads"], gs["with_adapters"], gs["bp_in"], gs["bp_out"]) == \
                        (ws["reads"], ws["with_adapters"], ws["bp_in"], ws["bp_out"]), (ci, gs, ws["reads"])
+                assert gs["way"] == "all-device"
+                assert (gs["quality_trimmed_bases"], gs["nextseq_trimmed_bases"]) == \
+                       (ws["trimmer"].quality_trimmed_bases, ws["trimmer"].nextseq_trimmed_bases), ci
             assert gs["bytes_out"] == len(want.getvalue())
     # malformed input is reported, not silently processed
     from cutadapt_amd.gpu_pipeline import trim_fastq_gpu as g
