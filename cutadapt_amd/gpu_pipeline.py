@@ -12,9 +12,10 @@ writer layout (reference src/cutadapt/runners.py:96-245) with GPUs as the worker
 
 Two ways through a chunk once it is indexed:
   * the all-device way (single-end, any number of single, non-rightmost adapters, ``--times 1``, action ``trim``,
-    ``-m`` / ``-M`` / ``--discard-(un)trimmed``): match, decide and format without a byte of per-read data touching
-    the host (``cah_trim_decide_device``);
-  * the general way (everything else ``pipeline.BatchTrimmer`` does: ``-u``, ``-q``, ``--nextseq-trim``, ``--poly-a``,
+    ``-u`` / ``--nextseq-trim`` / ``-q`` in front of the adapter step, ``-m`` / ``-M`` / ``--discard-(un)trimmed``
+    behind it -- the usual ``cutadapt -q 20 -a ADAPTER -m 20``): trim, match, decide and format without a byte of
+    per-read data touching the host (``cah_trim_decide_device`` / ``cah_trim_decide_window_device``);
+  * the general way (everything else ``pipeline.BatchTrimmer`` does: ``--poly-a``,
     ``--max-ee``, ``-l``, ``--times N``, every action, linked and rightmost adapters, ``--revcomp``, ``--info-file``,
     and read pairs through ``trim_fastq_gpu_paired``): the modifiers run as kernels on windows into the raw chunk
     in HBM (``DeviceFastqChunk``: reads AND qualities are used in place), the window arithmetic between them is

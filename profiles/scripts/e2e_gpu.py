@@ -75,6 +75,8 @@ if devices is not None:
     for assemble in ("device", "mixed"):
         timed(f"GPU parse+match+format, pinned input, no sink, devices={args.devices}, {args.threads} worker threads per device, assemble={assemble}",
               lambda: trim_fastq_gpu(fastq, None, [adapter], threads=args.threads, devices=devices, assemble=assemble))
+    timed(f"all-device way with -q 0,10 -m 20 in front of / behind the adapter step, devices={args.devices}",
+          lambda: trim_fastq_gpu(fastq, None, [adapter], threads=args.threads, devices=devices, quality_cutoff=(0, 10), minimum_length=20))
     timed(f"the general way (-q 0,10 + adapter + --poly-a), devices={args.devices}",
           lambda: trim_fastq_gpu(fastq, None, [adapter], threads=args.threads, devices=devices, quality_cutoff=(0, 10), poly_a=True), reps=1)
     if args.file:
