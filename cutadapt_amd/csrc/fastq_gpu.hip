@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void k_trim_decide(const int32_t* out6, const 
                                                      int64_t n, const uint8_t* adapter_kind,
                                                      int32_t min_len, int32_t max_len, int32_t discard_trimmed,
                                                      int32_t discard_untrimmed, int32_t* beg, int32_t* end, uint8_t* keep,
-                                                     unsigned long long* counters) {
+                                                     unsigned long long* counters, const int32_t count_out = 1) {
     __shared__ unsigned long long s_acc[7];
     if (threadIdx.x < 7) s_acc[threadIdx.x] = 0;
     __syncthreads();
@@ -301,13 +301,44 @@ __global__ __launch_bounds__(256) void k_trim_decide(const int32_t* out6, const 
         else if (discard_untrimmed) k = k && found;
         const int w0 = win_beg ? win_beg[r] : 0;
         beg[r] = w0 + b; end[r] = w0 + e; keep[r] = k ? 1 : 0;
-        acc[0] += 1; acc[1] += found ? 1 : 0; acc[2] += (unsigned)(full_len ? full_len[r] : len); acc[3] += k ? (unsigned)out_len : 0u;
+        acc[0] += 1; acc[1] += found ? 1 : 0; acc[2] += (unsigned)(full_len ? full_len[r] : len); acc[3] += (k && count_out) ? (unsigned)out_len : 0u;
         acc[6] += st == 2 ? 1 : 0;
     }
 #pragma unroll
     for (int i = 0; i < 7; ++i) if (acc[i]) atomicAdd(&s_acc[i], acc[i]);
     __syncthreads();
     if (threadIdx.x < 7 && s_acc[threadIdx.x]) atomicAdd(&counters[threadIdx.x], s_acc[threadIdx.x]);
+}
+
+// The filters behind the modifiers, in the reference's order (cli.py:735-912: too short, too long, too many expected
+// errors -- each counted on what the earlier ones left -- then --discard-trimmed / --discard-untrimmed), for reads
+// whose kept interval [beg, end) is final.  counters (see k_trim_decide): [3] bp out, [4] too short, [5] too long,
+// [7] too many expected errors.
+__global__ __launch_bounds__(256) void k_trim_filter(const int32_t* beg, const int32_t* end, const uint8_t* status,
+                                                     const double* ee, int64_t n, int32_t min_len, int32_t max_len,
+                                                     double max_ee, int32_t discard_trimmed, int32_t discard_untrimmed,
+                                                     uint8_t* keep, unsigned long long* counters) {
+    __shared__ unsigned long long s_acc[4];
+    if (threadIdx.x < 4) s_acc[threadIdx.x] = 0;
+    __syncthreads();
+    unsigned long long acc[4] = {0, 0, 0, 0};
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += stride) {
+        const int out_len = end[r] - beg[r];
+        const bool found = status[r] == 1;
+        bool k = true;
+        if (min_len >= 0 && out_len < min_len) { acc[1] += 1; k = false; }
+        if (k && max_len >= 0 && out_len > max_len) { acc[2] += 1; k = false; }
+        if (k && ee && max_ee >= 0.0 && ee[r] > max_ee) { acc[3] += 1; k = false; }
+        if (discard_trimmed) k = k && !found;
+        else if (discard_untrimmed) k = k && found;
+        keep[r] = k ? 1 : 0;
+        acc[0] += k ? (unsigned)out_len : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (acc[i]) atomicAdd(&s_acc[i], acc[i]);
+    __syncthreads();
+    if (threadIdx.x < 4 && s_acc[threadIdx.x]) atomicAdd(&counters[threadIdx.x == 3 ? 7 : 3 + threadIdx.x], s_acc[threadIdx.x]);
 }
 
 int cus() {
@@ -406,22 +437,45 @@ int cah_trim_decide_device(const int32_t* d_out6, const uint8_t* d_status, const
 }
 
 // ... when modifiers ran in front of the adapter step (-u, --nextseq-trim, -q; reference cli.py:938-954): the matcher saw
-// the window [d_win_beg[r], d_win_beg[r] + d_win_len[r]) of read r, whose full length is d_seq_len[r].  d_beg / d_end
-// are relative to the read; "bp in" counts the full reads.
+// the window [d_win_beg[r], d_win_beg[r] + d_win_len[r]) of read r, whose full length is d_seq_len[r] (d_win_beg NULL:
+// the windows start at 0).  d_beg / d_end are relative to the read; "bp in" counts the full reads.
+// intervals_only != 0: modifiers follow BEHIND the adapter step too -- no filter is applied, "bp out" is not counted,
+// cah_trim_filter_device finishes the job.
 int cah_trim_decide_window_device(const int32_t* d_out6, const uint8_t* d_status, const int32_t* d_best_adapter,
                                   const int32_t* d_win_beg, const int32_t* d_win_len, const int32_t* d_seq_len,
                                   int64_t n_reads, const uint8_t* d_adapter_kind, int32_t min_len, int32_t max_len,
-                                  int32_t discard_trimmed, int32_t discard_untrimmed, int32_t* d_beg, int32_t* d_end,
-                                  uint8_t* d_keep, uint64_t* d_counters, void* stream) {
+                                  int32_t discard_trimmed, int32_t discard_untrimmed, int32_t intervals_only,
+                                  int32_t* d_beg, int32_t* d_end, uint8_t* d_keep, uint64_t* d_counters, void* stream) {
     if (n_reads < 0) return cah_set_error_(CAH_EINVAL, "cah_trim_decide_window_device: bad argument");
     if (n_reads == 0) return CAH_OK;
-    if (!d_out6 || !d_status || !d_win_beg || !d_win_len || !d_seq_len || !d_adapter_kind || !d_beg || !d_end || !d_keep ||
-        !d_counters)
+    if (!d_out6 || !d_status || !d_win_len || !d_seq_len || !d_adapter_kind || !d_beg || !d_end || !d_keep || !d_counters)
         return cah_set_error_(CAH_EINVAL, "cah_trim_decide_window_device: NULL argument");
+    if (intervals_only) { min_len = max_len = -1; discard_trimmed = discard_untrimmed = 0; }
     const int64_t rb = (n_reads + 255) / 256;
     hipLaunchKernelGGL(k_trim_decide, dim3((unsigned)(rb < 4 * cus() ? rb : 4 * cus())), dim3(256), 0, (hipStream_t)stream, d_out6,
                        d_status, d_best_adapter, d_win_len, d_win_beg, d_seq_len, n_reads, d_adapter_kind, min_len, max_len,
-                       discard_trimmed, discard_untrimmed, d_beg, d_end, d_keep, (unsigned long long*)d_counters);
+                       discard_trimmed, discard_untrimmed, d_beg, d_end, d_keep, (unsigned long long*)d_counters,
+                       intervals_only ? 0 : 1);
+    GPU_TRY(hipGetLastError());
+    return CAH_OK;
+}
+
+// Step 3c: the filters, when modifiers ran BEHIND the adapter step too (--poly-a, -l) or --max-ee is given: d_beg /
+// d_end are then final only after those, so cah_trim_decide*_device is called without limits and this decides what is
+// written (see k_trim_filter).  d_ee: expected errors of the kept interval (cah_expected_errors_batch) or NULL;
+// max_ee < 0: no limit.  d_counters as in cah_trim_decide_device: [3], [4], [5] and [7] (too many expected errors)
+// are accumulated here.
+int cah_trim_filter_device(const int32_t* d_beg, const int32_t* d_end, const uint8_t* d_status, const double* d_ee,
+                           int64_t n_reads, int32_t min_len, int32_t max_len, double max_ee, int32_t discard_trimmed,
+                           int32_t discard_untrimmed, uint8_t* d_keep, uint64_t* d_counters, void* stream) {
+    if (n_reads < 0) return cah_set_error_(CAH_EINVAL, "cah_trim_filter_device: bad argument");
+    if (n_reads == 0) return CAH_OK;
+    if (!d_beg || !d_end || !d_status || !d_keep || !d_counters)
+        return cah_set_error_(CAH_EINVAL, "cah_trim_filter_device: NULL argument");
+    const int64_t rb = (n_reads + 255) / 256;
+    hipLaunchKernelGGL(k_trim_filter, dim3((unsigned)(rb < 4 * cus() ? rb : 4 * cus())), dim3(256), 0, (hipStream_t)stream, d_beg,
+                       d_end, d_status, d_ee, n_reads, min_len, max_len, max_ee, discard_trimmed, discard_untrimmed, d_keep,
+                       (unsigned long long*)d_counters);
     GPU_TRY(hipGetLastError());
     return CAH_OK;
 }

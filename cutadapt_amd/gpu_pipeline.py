@@ -90,6 +90,8 @@ class _Worker:
         self.h_info = torch.zeros(8, dtype=torch.int64).pin_memory()
         self.counters = torch.zeros(8, dtype=torch.int64, device=self.device)   # see cah_trim_decide_device
         self.pre_counts = torch.zeros(2, dtype=torch.int64, device=self.device)  # bases removed by NextSeq / quality trimming
+        self.polya_hist = torch.zeros(64, dtype=torch.int64, device=self.device) # reads by length of the poly-A tail removed
+        self.ee_invalid = torch.zeros((), dtype=torch.bool, device=self.device)  # a quality value outside the phred range seen
         self._ws = None
         self.n = self.n_bytes = 0
         self.busy_s, self.chunks, self.bytes_in = 0.0, 0, 0   # per-device rates (trim_fastq_gpu's "per_device")
@@ -246,12 +248,15 @@ class _Worker:
             limits = (-1 if o["minimum_length"] is None else int(o["minimum_length"]),
                       -1 if o["maximum_length"] is None else int(o["maximum_length"]),
                       int(bool(o["discard_trimmed"])), int(bool(o["discard_untrimmed"])))
-            pre = o.get("pre")
+            pre, post = o.get("pre"), o.get("post")
+            seq_len, seq_off = self.seq_len[:n], self.seq_off[:n]
+            qual_off = self.rec6[:n, 4]
+            wbeg = None                                          # None: the matcher sees whole reads
+            wlen = seq_len
+            keepalive = []                                       # (tensors kernels read: alive until the stream is through)
             if pre:
                 # the modifiers in front of the adapter step (-u, --nextseq-trim, -q: reference cli.py:938-954) as kernels
                 # and a few element-wise operations on this stream; the matcher then sees a window of every read
-                seq_len, seq_off = self.seq_len[:n], self.seq_off[:n]
-                qual_off = self.rec6[:n, 4]
                 wbeg = torch.zeros(n, dtype=torch.int32, device=self.device)
                 wlen = seq_len.clone()
                 for c in pre["cut"]:                              # UnconditionalCutter: read[c:] / read[:c]
@@ -269,6 +274,7 @@ class _Worker:
                         self.d_in.data_ptr(), self.d_in.data_ptr(), so.data_ptr(), qo.data_ptr(),
                         wlen.data_ptr(), n, int(pre["nextseq_trim"]), int(pre["quality_base"]), stop.data_ptr(), sp))
                     self.pre_counts[0] += (wlen - stop).sum()
+                    keepalive += [so, qo, wlen]
                     wlen = stop
                 if pre["quality_cutoff"] is not None:
                     ss = torch.empty((n, 2), dtype=torch.int32, device=self.device)
@@ -278,27 +284,65 @@ class _Worker:
                         int(pre["quality_cutoff"][1]), int(pre["quality_base"]), ss.data_ptr(), sp))
                     kept = ss[:, 1] - ss[:, 0]
                     self.pre_counts[1] += (wlen - kept).sum()
+                    keepalive += [qo, wlen]
                     wbeg = wbeg + ss[:, 0]
                     wlen = kept.contiguous()
                 wbeg = wbeg.contiguous()
-                voff = (seq_off + wbeg.to(torch.int64)).contiguous()
-                _lib.check(L.cah_match_batch(self.plan.handle, self.d_in.data_ptr(), voff.data_ptr(), wlen.data_ptr(), n,
-                                             self.res.out6.data_ptr(), self.res.best_adapter.data_ptr(),
-                                             self.res.status.data_ptr(), self._ws.data_ptr(), self._ws.numel(), sp))
-                _lib.check(L.cah_trim_decide_window_device(
-                    self.res.out6.data_ptr(), self.res.status.data_ptr(), self.res.best_adapter.data_ptr(),
-                    wbeg.data_ptr(), wlen.data_ptr(), self.seq_len.data_ptr(), n, self.kinds.data_ptr(), *limits,
-                    self.beg.data_ptr(), self.end.data_ptr(), self.keep.data_ptr(), self.counters.data_ptr(), sp))
-                self._pre_tensors = (wbeg, wlen, voff)           # (alive until the stream is through with them)
-            else:
-                _lib.check(L.cah_match_batch(self.plan.handle, self.d_in.data_ptr(), self.seq_off.data_ptr(),
-                                             self.seq_len.data_ptr(), n, self.res.out6.data_ptr(),
-                                             self.res.best_adapter.data_ptr(), self.res.status.data_ptr(),
-                                             self._ws.data_ptr(), self._ws.numel(), sp))
+            voff = seq_off if wbeg is None else (seq_off + wbeg.to(torch.int64)).contiguous()
+            _lib.check(L.cah_match_batch(self.plan.handle, self.d_in.data_ptr(), voff.data_ptr(), wlen.data_ptr(), n,
+                                         self.res.out6.data_ptr(), self.res.best_adapter.data_ptr(),
+                                         self.res.status.data_ptr(), self._ws.data_ptr(), self._ws.numel(), sp))
+            if not pre and not post:
                 _lib.check(L.cah_trim_decide_device(
                     self.res.out6.data_ptr(), self.res.status.data_ptr(), self.res.best_adapter.data_ptr(),
                     self.seq_len.data_ptr(), n, self.kinds.data_ptr(), *limits,
                     self.beg.data_ptr(), self.end.data_ptr(), self.keep.data_ptr(), self.counters.data_ptr(), sp))
+            else:
+                _lib.check(L.cah_trim_decide_window_device(
+                    self.res.out6.data_ptr(), self.res.status.data_ptr(), self.res.best_adapter.data_ptr(),
+                    wbeg.data_ptr() if wbeg is not None else None, wlen.data_ptr(), self.seq_len.data_ptr(), n,
+                    self.kinds.data_ptr(), *limits, 1 if post else 0,
+                    self.beg.data_ptr(), self.end.data_ptr(), self.keep.data_ptr(), self.counters.data_ptr(), sp))
+            if post:
+                # the modifiers behind the adapter step (--poly-a, -l: cli.py:956-973) move the kept interval, then the
+                # filters (--max-ee among them) decide what is written: cah_trim_filter_device
+                beg, end = self.beg[:n], self.end[:n]
+                if post["poly_a"]:
+                    idx = torch.empty(n, dtype=torch.int32, device=self.device)
+                    cur = (end - beg).contiguous()
+                    po = (seq_off + beg.to(torch.int64)).contiguous()
+                    _lib.check(L.cah_poly_a_trim_batch(self.d_in.data_ptr(), po.data_ptr(), cur.data_ptr(), n, 0,
+                                                       idx.data_ptr(), sp))
+                    removed = (cur - idx).to(torch.int64)
+                    hist = torch.bincount(removed, minlength=int(self.polya_hist.numel()))
+                    if hist.numel() > self.polya_hist.numel():
+                        grown = torch.zeros(hist.numel(), dtype=torch.int64, device=self.device)
+                        grown[: self.polya_hist.numel()] = self.polya_hist
+                        self.polya_hist = grown
+                    self.polya_hist += hist
+                    end.copy_(beg + idx)
+                    keepalive += [cur, po, idx]
+                if post["length"] is not None:
+                    cur = end - beg
+                    if post["length"] >= 0:
+                        end.copy_(beg + torch.clamp(cur, max=int(post["length"])))
+                    else:
+                        beg.copy_(end - torch.clamp(cur, max=-int(post["length"])))
+                ee_ptr, max_ee = None, -1.0
+                if post["max_expected_errors"] is not None:
+                    ee = torch.empty(n, dtype=torch.float64, device=self.device)
+                    ee_status = torch.zeros(n, dtype=torch.uint8, device=self.device)
+                    cur = (end - beg).contiguous()
+                    qo = (qual_off + beg.to(torch.int64)).contiguous()
+                    _lib.check(L.cah_expected_errors_batch(self.d_in.data_ptr(), qo.data_ptr(), cur.data_ptr(), n, 33,
+                                                           ee.data_ptr(), ee_status.data_ptr(), sp))
+                    self.ee_invalid |= (ee_status == _lib.INVALID).any()
+                    ee_ptr, max_ee = ee.data_ptr(), float(post["max_expected_errors"])
+                    keepalive += [ee, ee_status, cur, qo]
+                _lib.check(L.cah_trim_filter_device(self.beg.data_ptr(), self.end.data_ptr(), self.res.status.data_ptr(),
+                                                    ee_ptr, n, limits[0], limits[1], max_ee, limits[2], limits[3],
+                                                    self.keep.data_ptr(), self.counters.data_ptr(), sp))
+            self._keepalive = keepalive + [voff, wlen, wbeg]
         if o.get("assemble") == "host":
             return self._assemble_on_host(data, n_bytes, n)
         # ---- step 4: format on the device, bring the bytes back ---------------------------------------------
@@ -307,11 +351,14 @@ class _Worker:
                                              self.d_scratch.numel(), n_bytes, self.d_out.data_ptr(),
                                              self.d_out.numel(), self.d_info.data_ptr(), sp))
         self.d_info[4:5].copy_(self.counters[6:7], non_blocking=True)
+        self.d_info[5:6].copy_(self.ee_invalid.to(torch.int64).reshape(1), non_blocking=True)
         self.h_info.copy_(self.d_info, non_blocking=True)
         self.stream.synchronize()
         self._raise_format_error(int(self.h_info[1]))
         if int(self.h_info[4]) != 0:
             _lib.raise_invalid_reads(int(self.seq_len[:max(n, 1)].max().item()))
+        if int(self.h_info[5]) != 0:
+            raise ValueError("Not a valid phred value in the qualities of a read of the chunk")
         total = int(self.h_info[3])
         h_out = self.pool.get(total)
         h_out[:total].copy_(self.d_out[:total], non_blocking=True)
@@ -335,6 +382,7 @@ class _Worker:
             self._h_keep = torch.empty(cap, dtype=torch.uint8).pin_memory()
             self._h_cap = cap
         self.d_info[4:5].copy_(self.counters[6:7], non_blocking=True)
+        self.d_info[5:6].copy_(self.ee_invalid.to(torch.int64).reshape(1), non_blocking=True)
         self.h_info.copy_(self.d_info, non_blocking=True)
         if n:
             self._h_rec6[:n].copy_(self.rec6[:n], non_blocking=True)
@@ -345,6 +393,8 @@ class _Worker:
         self._raise_format_error(int(self.h_info[1]))
         if int(self.h_info[4]) != 0:
             _lib.raise_invalid_reads(int(self.seq_len[:max(n, 1)].max().item()))
+        if int(self.h_info[5]) != 0:
+            raise ValueError("Not a valid phred value in the qualities of a read of the chunk")
         h_out = self.pool.get(n_bytes + 4 * n + 64)
         out_len = C.c_int64(0)
         src_ptr = data.data_ptr() if isinstance(data, torch.Tensor) else data.ctypes.data
@@ -452,6 +502,8 @@ def _take_worker(plan, kinds, dev, opts) -> "_Worker":
         w.kinds = torch.tensor(kinds, dtype=torch.uint8, device=w.device)
         w.counters.zero_()
         w.pre_counts.zero_()
+        w.polya_hist.zero_()
+        w.ee_invalid.zero_()
     w._ws = None
     w.busy_s, w.chunks, w.bytes_in = 0.0, 0, 0
     return w
@@ -714,16 +766,17 @@ def trim_fastq_gpu(source: Union[str, BinaryIO, np.ndarray], out: Union[str, Bin
         raise ValueError("You cannot remove bases from more than two ends.")
     if len(cut) == 2 and cut[0] * cut[1] > 0:
         raise ValueError("You cannot remove bases from the same end twice.")
-    all_device = (adapters and times == 1 and action == "trim" and not poly_a and max_expected_errors is None
-                  and length is None and not revcomp and info_file is None
+    all_device = (adapters and times == 1 and action == "trim" and not revcomp and info_file is None
                   and all(isinstance(a, SingleAdapter) and not a._reverse_reads for a in adapters))
-    pre = None
+    pre = post = None
     if all_device and (cut or nextseq_trim is not None or quality_cutoff is not None):
         pre = {"cut": cut, "nextseq_trim": nextseq_trim, "quality_cutoff": quality_cutoff, "quality_base": quality_base}
+    if all_device and (poly_a or length is not None or max_expected_errors is not None):
+        post = {"poly_a": bool(poly_a), "length": length, "max_expected_errors": max_expected_errors}
     devices = _resolve_devices(devices)
     threads = max(1, int(threads))
     opts = {"discard_untrimmed": discard_untrimmed, "discard_trimmed": discard_trimmed,
-            "minimum_length": minimum_length, "maximum_length": maximum_length, "assemble": assemble, "pre": pre}
+            "minimum_length": minimum_length, "maximum_length": maximum_length, "assemble": assemble, "pre": pre, "post": post}
     from .pipeline import BatchTrimmer
     if all_device:
         plan, kinds = _plan_for(adapters)
@@ -807,11 +860,17 @@ def trim_fastq_gpu(source: Union[str, BinaryIO, np.ndarray], out: Union[str, Bin
     if all_device:
         stats = np.zeros(8, dtype=np.int64)
         removed = np.zeros(2, dtype=np.int64)
+        polya: Dict[int, int] = {}
         for w in workers:
             stats += w.counters.cpu().numpy()
             removed += w.pre_counts.cpu().numpy()
+            if post and post["poly_a"]:
+                h = w.polya_hist.cpu().numpy()
+                for k in np.flatnonzero(h).tolist():
+                    polya[k] = polya.get(k, 0) + int(h[k])
         result.update({"reads": int(stats[0]), "with_adapters": int(stats[1]), "bp_in": int(stats[2]),
                        "bp_out": int(stats[3]), "filtered": {"too_short": int(stats[4]), "too_long": int(stats[5])},
+                       "too_many_expected_errors": int(stats[7]), "poly_a_trimmed_lengths": polya,
                        "nextseq_trimmed_bases": int(removed[0]), "quality_trimmed_bases": int(removed[1])})
     else:
         total = BatchTrimmer(adapters, device=devices[0], **general_opts)
@@ -820,6 +879,10 @@ def trim_fastq_gpu(source: Union[str, BinaryIO, np.ndarray], out: Union[str, Bin
         cutter = total.cutter
         result.update({"reads": total.reads, "with_adapters": cutter.with_adapters if cutter else 0,
                        "bp_in": total.bp_in, "bp_out": total.bp_out, "filtered": dict(total.filtered),
+                       "too_many_expected_errors": total.too_many_expected_errors,
+                       "poly_a_trimmed_lengths": {k: v for k, v in total.poly_a_trimmed_lengths.items() if v},
+                       "nextseq_trimmed_bases": total.nextseq_trimmed_bases,
+                       "quality_trimmed_bases": total.quality_trimmed_bases,
                        "cutter": cutter, "trimmer": total,
                        "reverse_complemented": total.rc.reverse_complemented if total.rc is not None else None})
     for w in workers:

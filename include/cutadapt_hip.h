@@ -370,14 +370,25 @@ int cah_trim_decide_device(const int32_t *d_out6, const uint8_t *d_status, const
                            int32_t discard_untrimmed, int32_t *d_beg, int32_t *d_end, uint8_t *d_keep,
                            uint64_t *d_counters, void *stream);
 /* ... when modifiers ran in front of the adapter step (-u, --nextseq-trim, -q: cli.py:938-954): the matcher saw the
- * window [d_win_beg[r], d_win_beg[r] + d_win_len[r]) of read r (full length d_seq_len[r]); d_beg / d_end come back
- * relative to the read, "bp in" counts the full reads. */
+ * window [d_win_beg[r], d_win_beg[r] + d_win_len[r]) of read r (full length d_seq_len[r]; d_win_beg NULL: windows
+ * start at 0); d_beg / d_end come back relative to the read, "bp in" counts the full reads.  intervals_only != 0:
+ * no filter is applied and "bp out" is not counted -- cah_trim_filter_device follows (modifiers behind the adapter
+ * step). */
 int cah_trim_decide_window_device(const int32_t *d_out6, const uint8_t *d_status, const int32_t *d_best_adapter,
                                   const int32_t *d_win_beg, const int32_t *d_win_len, const int32_t *d_seq_len,
                                   int64_t n_reads, const uint8_t *d_adapter_kind, int32_t min_len,
                                   int32_t max_len, int32_t discard_trimmed, int32_t discard_untrimmed,
-                                  int32_t *d_beg, int32_t *d_end, uint8_t *d_keep, uint64_t *d_counters,
-                                  void *stream);
+                                  int32_t intervals_only, int32_t *d_beg, int32_t *d_end, uint8_t *d_keep,
+                                  uint64_t *d_counters, void *stream);
+/* ... and when modifiers run BEHIND the adapter step as well (--poly-a, -l; cli.py:956-973) or --max-ee is given: call
+ * cah_trim_decide*_device without limits (min_len = max_len = -1, no discards), move d_beg / d_end with the later
+ * modifiers, then let this apply the filters in the reference's order (too short, too long, too many expected
+ * errors, discards; cli.py:735-912).  d_ee: expected errors of the kept intervals or NULL; max_ee < 0: no limit.
+ * d_counters as above; [3] bp out, [4] too short, [5] too long, [7] too many expected errors are accumulated. */
+int cah_trim_filter_device(const int32_t *d_beg, const int32_t *d_end, const uint8_t *d_status,
+                           const double *d_ee, int64_t n_reads, int32_t min_len, int32_t max_len,
+                           double max_ee, int32_t discard_trimmed, int32_t discard_untrimmed,
+                           uint8_t *d_keep, uint64_t *d_counters, void *stream);
 int cah_fastq_format_device(const uint8_t *d_buf, const int64_t *d_rec6, int64_t n_records, const int32_t *d_beg,
                             const int32_t *d_end, const uint8_t *d_keep, void *d_scratch, size_t scratch_bytes,
                             int64_t chunk_bytes, uint8_t *d_out, int64_t out_cap, int64_t *d_info, void *stream);

@@ -24,6 +24,10 @@ def _fastq(rng, n, adapters, crlf=False, final_newline=True, lower=False):
             ad = ad[:rng.randint(1, len(ad))] if rng.random() < 0.5 else ad
             pos = rng.randint(0, L)
             s = (s[:pos] + ad + s[pos:])[:max(L, 1)] if rng.random() < 0.5 else s[:pos] + ad
+        if rng.random() < 0.15:
+            s += "A" * rng.randint(2, 30)                               # (a poly-A tail, sometimes with an error in it)
+            if rng.random() < 0.3 and len(s) > 4:
+                s = s[:-3] + "C" + s[-2:]
         if rng.random() < 0.1:
             s = "".join(c if rng.random() > 0.05 else "N" for c in s)
         if lower and rng.random() < 0.3:
@@ -56,6 +60,11 @@ def test_device_fastq_equals_host_pipeline(hip):
         ([A.BackAdapter(ad_seqs[0])], {"quality_cutoff": (0, 20), "minimum_length": 20}),
         ([A.BackAdapter(ad_seqs[0]), A.FrontAdapter(ad_seqs[1])], {"quality_cutoff": (15, 25), "cut": [3, -2]}),
         ([A.AnywhereAdapter(ad_seqs[2])], {"nextseq_trim": 20, "cut": [-5], "maximum_length": 140}),
+        # ... and behind it: --poly-a, -l, --max-ee, with the filters applied after them
+        ([A.BackAdapter(ad_seqs[0])], {"poly_a": True, "minimum_length": 25}),
+        ([A.BackAdapter(ad_seqs[0]), A.FrontAdapter(ad_seqs[1])], {"quality_cutoff": (0, 15), "poly_a": True, "length": 80,
+                                                               "max_expected_errors": 2.5, "minimum_length": 10}),
+        ([A.BackAdapter(ad_seqs[0])], {"length": -40, "max_expected_errors": 1.0, "discard_untrimmed": True}),
     ]
     for ci, (ads, opts) in enumerate(cases):
         for crlf, final_nl, chunk in ((False, True, 1 << 20), (True, True, 4096), (False, False, 700)):
@@ -73,6 +82,11 @@ def test_device_fastq_equals_host_pipeline(hip):
                 assert gs["way"] == "all-device"
                 assert (gs["quality_trimmed_bases"], gs["nextseq_trimmed_bases"]) == \
                        (ws["trimmer"].quality_trimmed_bases, ws["trimmer"].nextseq_trimmed_bases), ci
+                assert gs["too_many_expected_errors"] == ws["trimmer"].too_many_expected_errors, ci
+                if opts.get("poly_a"):
+                    assert gs["poly_a_trimmed_lengths"] == {k: v for k, v in ws["trimmer"].poly_a_trimmed_lengths.items() if v}, ci
+                assert gs["filtered"] == {"too_short": ws["trimmer"].filtered.get("too_short", 0),
+                                          "too_long": ws["trimmer"].filtered.get("too_long", 0)}, ci
             assert gs["bytes_out"] == len(want.getvalue())
     # malformed input is reported, not silently processed
     from cutadapt_amd.gpu_pipeline import trim_fastq_gpu as g

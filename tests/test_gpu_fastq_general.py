@@ -195,61 +195,63 @@ def test_random_reads_against_the_modifier_chain_over_oracle_results(hip, orc, g
         "back": orc.KmerFinder(create_positions_and_kmers(ad_back, 3, 0.1, True, False), False, False),
         "front": orc.KmerFinder(create_positions_and_kmers(ad_front, 3, 0.1, False, True), False, False),
     }
-    CUT, QCUT, TIMES, LENGTH, MAXEE, MINLEN = 2, (8, 12), 2, 60, 1.5, 10
+    CUT, QCUT, LENGTH, MAXEE, MINLEN = 2, (8, 12), 60, 1.5, 10
+    # --times 2 takes the general way (host-side window arithmetic between the kernels), --times 1 the all-device way
+    for TIMES, way in ((2, "general"), (1, "all-device")):
 
-    def chain(name, s, q):
-        """cli.py:938-973: -u, -q, adapters (--times 2), --poly-a, -l; then --max-ee and -m (cli.py:735-912)"""
-        s, q = s[CUT:], q[CUT:]
-        a, b = quality_trim_index(q, QCUT[0], QCUT[1])
-        s, q = s[a:b], q[a:b]
-        matched = False
-        for _ in range(TIMES):
-            best = None
-            for seq, kind in ((ad_back, "back"), (ad_front, "front")):
-                if not finders[kind].kmers_present(s):
-                    continue
-                t = orc.Aligner(seq, 0.1, flags=14 if kind == "back" else 11, wildcard_ref=False, min_overlap=3).locate(s)
-                if t is not None and (best is None or t[4] > best[0][4] or (t[4] == best[0][4] and t[5] < best[0][5])):
-                    best = (t, kind)
-            if best is None:
-                break
-            matched = True
-            t, kind = best
-            s, q = (s[:t[2]], q[:t[2]]) if kind == "back" else (s[t[3]:], q[t[3]:])
-        i = _poly_a(s)
-        s, q = s[:i], q[:i]
-        s, q = s[:LENGTH], q[:LENGTH]
-        ee = 0.0
-        for c in q:
-            ee += table[ord(c) - 33]
-        return s, q, ee, matched
+        def chain(name, s, q):
+            """cli.py:938-973: -u, -q, adapters (--times 2), --poly-a, -l; then --max-ee and -m (cli.py:735-912)"""
+            s, q = s[CUT:], q[CUT:]
+            a, b = quality_trim_index(q, QCUT[0], QCUT[1])
+            s, q = s[a:b], q[a:b]
+            matched = False
+            for _ in range(TIMES):
+                best = None
+                for seq, kind in ((ad_back, "back"), (ad_front, "front")):
+                    if not finders[kind].kmers_present(s):
+                        continue
+                    t = orc.Aligner(seq, 0.1, flags=14 if kind == "back" else 11, wildcard_ref=False, min_overlap=3).locate(s)
+                    if t is not None and (best is None or t[4] > best[0][4] or (t[4] == best[0][4] and t[5] < best[0][5])):
+                        best = (t, kind)
+                if best is None:
+                    break
+                matched = True
+                t, kind = best
+                s, q = (s[:t[2]], q[:t[2]]) if kind == "back" else (s[t[3]:], q[t[3]:])
+            i = _poly_a(s)
+            s, q = s[:i], q[:i]
+            s, q = s[:LENGTH], q[:LENGTH]
+            ee = 0.0
+            for c in q:
+                ee += table[ord(c) - 33]
+            return s, q, ee, matched
 
-    want, near = [], 0
-    n_short = n_ee = n_matched = 0
-    for name, s, q in recs:
-        s2, q2, ee, matched = chain(name, s, q)
-        n_matched += matched
-        if len(s2) < MINLEN:                                     # too short is checked first (cli.py:735-912)
-            n_short += 1
-            continue
-        if abs(ee - MAXEE) < 1e-9:
-            near += 1
-        if ee > MAXEE:
-            n_ee += 1
-            continue
-        want.append(f"@{name}\n{s2}\n+\n{q2}\n")
-    assert near == 0 and n_short > 100 and n_ee > 100 and n_matched > 1000
-    ads = [A.BackAdapter(ad_back), A.FrontAdapter(ad_front)]
-    for chunk_bytes, threads in ((1 << 20, 2), (40000, 3)):
-        out = io.BytesIO()
-        stats = trim_fastq_gpu(np.frombuffer(data, dtype=np.uint8), out, ads, cut=[CUT], quality_cutoff=QCUT,
-                               times=TIMES, poly_a=True, length=LENGTH, max_expected_errors=MAXEE,
-                               minimum_length=MINLEN, chunk_bytes=chunk_bytes, threads=threads)
-        assert stats["way"] == "general"
-        assert out.getvalue() == "".join(want).encode(), chunk_bytes
-        assert stats["reads"] == len(recs) and stats["with_adapters"] == n_matched
-        assert stats["filtered"].get("too_short", 0) == n_short
-        assert stats["trimmer"].too_many_expected_errors == n_ee
+        want, near = [], 0
+        n_short = n_ee = n_matched = 0
+        for name, s, q in recs:
+            s2, q2, ee, matched = chain(name, s, q)
+            n_matched += matched
+            if len(s2) < MINLEN:                                     # too short is checked first (cli.py:735-912)
+                n_short += 1
+                continue
+            if abs(ee - MAXEE) < 1e-9:
+                near += 1
+            if ee > MAXEE:
+                n_ee += 1
+                continue
+            want.append(f"@{name}\n{s2}\n+\n{q2}\n")
+        assert near == 0 and n_short > 100 and n_ee > 100 and n_matched > 1000
+        ads = [A.BackAdapter(ad_back), A.FrontAdapter(ad_front)]
+        for chunk_bytes, threads in ((1 << 20, 2), (40000, 3)):
+            out = io.BytesIO()
+            stats = trim_fastq_gpu(np.frombuffer(data, dtype=np.uint8), out, ads, cut=[CUT], quality_cutoff=QCUT,
+                                   times=TIMES, poly_a=True, length=LENGTH, max_expected_errors=MAXEE,
+                                   minimum_length=MINLEN, chunk_bytes=chunk_bytes, threads=threads)
+            assert stats["way"] == way
+            assert out.getvalue() == "".join(want).encode(), chunk_bytes
+            assert stats["reads"] == len(recs) and stats["with_adapters"] == n_matched
+            assert stats["filtered"].get("too_short", 0) == n_short
+            assert stats["too_many_expected_errors"] == n_ee
 
 
 def test_every_visible_gpu_is_fed(hip, tmp_path):
