@@ -12,11 +12,11 @@ writer layout (reference src/cutadapt/runners.py:96-245) with GPUs as the worker
 
 Two ways through a chunk once it is indexed:
   * the all-device way (single-end, any number of single, non-rightmost adapters, ``--times 1``, action ``trim``,
-    ``-u`` / ``--nextseq-trim`` / ``-q`` in front of the adapter step, ``-m`` / ``-M`` / ``--discard-(un)trimmed``
-    behind it -- the usual ``cutadapt -q 20 -a ADAPTER -m 20``): trim, match, decide and format without a byte of
-    per-read data touching the host (``cah_trim_decide_device`` / ``cah_trim_decide_window_device``);
-  * the general way (everything else ``pipeline.BatchTrimmer`` does: ``--poly-a``,
-    ``--max-ee``, ``-l``, ``--times N``, every action, linked and rightmost adapters, ``--revcomp``, ``--info-file``,
+    ``-u`` / ``--nextseq-trim`` / ``-q`` in front of the adapter step, ``--poly-a`` / ``-l`` / ``--max-ee`` / ``-m`` /
+    ``-M`` / ``--discard-(un)trimmed`` behind it -- the usual ``cutadapt -q 20 -a ADAPTER -m 20`` and more): trim,
+    match, decide and format without a byte of per-read data touching the host (``cah_trim_decide_device`` /
+    ``cah_trim_decide_window_device`` / ``cah_trim_filter_device``);
+  * the general way (everything else ``pipeline.BatchTrimmer`` does: ``--times N``, every action, linked and rightmost adapters, ``--revcomp``, ``--info-file``,
     and read pairs through ``trim_fastq_gpu_paired``): the modifiers run as kernels on windows into the raw chunk
     in HBM (``DeviceFastqChunk``: reads AND qualities are used in place), the window arithmetic between them is
     numpy on 4-byte-per-read arrays, and plain slicing is formatted on the device again.  What cannot be expressed
@@ -90,7 +90,8 @@ class _Worker:
         self.h_info = torch.zeros(8, dtype=torch.int64).pin_memory()
         self.counters = torch.zeros(8, dtype=torch.int64, device=self.device)   # see cah_trim_decide_device
         self.pre_counts = torch.zeros(2, dtype=torch.int64, device=self.device)  # bases removed by NextSeq / quality trimming
-        self.polya_hist = torch.zeros(64, dtype=torch.int64, device=self.device) # reads by length of the poly-A tail removed
+        # reads by length of the poly-A tail removed (+ 4096 spare bins that are bin 0 spread out, see _run)
+        self.polya_hist = torch.zeros(_lib.MAX_READ_LEN + 1 + 4096, dtype=torch.int64, device=self.device)
         self.ee_invalid = torch.zeros((), dtype=torch.bool, device=self.device)  # a quality value outside the phred range seen
         self._ws = None
         self.n = self.n_bytes = 0
@@ -314,12 +315,10 @@ class _Worker:
                     _lib.check(L.cah_poly_a_trim_batch(self.d_in.data_ptr(), po.data_ptr(), cur.data_ptr(), n, 0,
                                                        idx.data_ptr(), sp))
                     removed = (cur - idx).to(torch.int64)
-                    hist = torch.bincount(removed, minlength=int(self.polya_hist.numel()))
-                    if hist.numel() > self.polya_hist.numel():
-                        grown = torch.zeros(hist.numel(), dtype=torch.int64, device=self.device)
-                        grown[: self.polya_hist.numel()] = self.polya_hist
-                        self.polya_hist = grown
-                    self.polya_hist += hist
+                    # (index_add_, not bincount: bincount asks the device for the largest value first; the reads without
+                    # a tail -- nearly all -- are counted in 4096 spare bins behind the histogram instead of all in bin 0)
+                    spare = _lib.MAX_READ_LEN + 1 + (torch.arange(n, device=self.device) & 4095)
+                    self.polya_hist.index_add_(0, torch.where(removed != 0, removed, spare), torch.ones_like(removed))
                     end.copy_(beg + idx)
                     keepalive += [cur, po, idx]
                 if post["length"] is not None:
@@ -866,6 +865,7 @@ def trim_fastq_gpu(source: Union[str, BinaryIO, np.ndarray], out: Union[str, Bin
             removed += w.pre_counts.cpu().numpy()
             if post and post["poly_a"]:
                 h = w.polya_hist.cpu().numpy()
+                h = np.concatenate([[h[0] + h[_lib.MAX_READ_LEN + 1:].sum()], h[1:_lib.MAX_READ_LEN + 1]])
                 for k in np.flatnonzero(h).tolist():
                     polya[k] = polya.get(k, 0) + int(h[k])
         result.update({"reads": int(stats[0]), "with_adapters": int(stats[1]), "bp_in": int(stats[2]),

@@ -79,7 +79,7 @@ if devices is not None:
           lambda: trim_fastq_gpu(fastq, None, [adapter], threads=args.threads, devices=devices, quality_cutoff=(0, 10), minimum_length=20))
     timed(f"all-device way with -q 0,10 in front of and --poly-a --max-ee 5 -m 20 behind the adapter step, devices={args.devices}",
           lambda: trim_fastq_gpu(fastq, None, [adapter], threads=args.threads, devices=devices, quality_cutoff=(0, 10), poly_a=True,
-                                 max_expected_errors=5.0, minimum_length=20), reps=1)
+                                 max_expected_errors=5.0, minimum_length=20))
     timed(f"the general way (--times 2: window arithmetic in numpy between the kernels), devices={args.devices}",
           lambda: trim_fastq_gpu(fastq, None, [adapter], threads=args.threads, devices=devices, times=2, quality_cutoff=(0, 10)), reps=1)
     if args.file:
