@@ -236,112 +236,141 @@ class _Worker:
             self.bytes_in += int(len(data))
 
     def _run(self, data, L):
-        torch = self.torch
-        sp = self.stream.cuda_stream
         n = self.load(data)
         n_bytes = self.n_bytes
-        # ---- step 3: match the reads in place, decide what is kept ------------------------------------------
+        # ---- step 3: modifiers, matching in place, what is kept ---------------------------------------------
         o = self.opts
         if n:
-            ws_need = int(L.cah_plan_workspace_bytes(self.plan.handle, n))
-            if self._ws is None or self._ws.numel() < ws_need:
-                self._ws = torch.empty(ws_need + ws_need // 4, dtype=torch.uint8, device=self.device)
             limits = (-1 if o["minimum_length"] is None else int(o["minimum_length"]),
                       -1 if o["maximum_length"] is None else int(o["maximum_length"]),
                       int(bool(o["discard_trimmed"])), int(bool(o["discard_untrimmed"])))
-            pre, post = o.get("pre"), o.get("post")
-            seq_len, seq_off = self.seq_len[:n], self.seq_off[:n]
-            qual_off = self.rec6[:n, 4]
-            wbeg = None                                          # None: the matcher sees whole reads
-            wlen = seq_len
-            keepalive = []                                       # (tensors kernels read: alive until the stream is through)
-            if pre:
-                # the modifiers in front of the adapter step (-u, --nextseq-trim, -q: reference cli.py:938-954) as kernels
-                # and a few element-wise operations on this stream; the matcher then sees a window of every read
-                wbeg = torch.zeros(n, dtype=torch.int32, device=self.device)
-                wlen = seq_len.clone()
-                for c in pre["cut"]:                              # UnconditionalCutter: read[c:] / read[:c]
-                    if c > 0:
-                        d = torch.clamp(wlen, max=c)
-                        wbeg += d
-                        wlen -= d
-                    else:
-                        wlen = torch.clamp(wlen + c, min=0)
-                if pre["nextseq_trim"] is not None:
-                    stop = torch.empty(n, dtype=torch.int32, device=self.device)
-                    w64 = wbeg.to(torch.int64)
-                    so, qo = seq_off + w64, qual_off + w64       # (named: a temporary's block could be handed out again
-                    _lib.check(L.cah_nextseq_trim_batch_q(       #  before the kernel has read it)
-                        self.d_in.data_ptr(), self.d_in.data_ptr(), so.data_ptr(), qo.data_ptr(),
-                        wlen.data_ptr(), n, int(pre["nextseq_trim"]), int(pre["quality_base"]), stop.data_ptr(), sp))
-                    self.pre_counts[0] += (wlen - stop).sum()
-                    keepalive += [so, qo, wlen]
-                    wlen = stop
-                if pre["quality_cutoff"] is not None:
-                    ss = torch.empty((n, 2), dtype=torch.int32, device=self.device)
-                    qo = qual_off + wbeg.to(torch.int64)
-                    _lib.check(L.cah_quality_trim_batch(
-                        self.d_in.data_ptr(), qo.data_ptr(), wlen.data_ptr(), n, int(pre["quality_cutoff"][0]),
-                        int(pre["quality_cutoff"][1]), int(pre["quality_base"]), ss.data_ptr(), sp))
-                    kept = ss[:, 1] - ss[:, 0]
-                    self.pre_counts[1] += (wlen - kept).sum()
-                    keepalive += [qo, wlen]
-                    wbeg = wbeg + ss[:, 0]
-                    wlen = kept.contiguous()
-                wbeg = wbeg.contiguous()
-            voff = seq_off if wbeg is None else (seq_off + wbeg.to(torch.int64)).contiguous()
+            self.modify(n, o.get("pre"), o.get("post"), limits)
+        return self.finish(data, n, n_bytes)
+
+    def modify(self, n: int, pre, post, limits=None):
+        """The read-modifying steps of a loaded chunk on this worker's stream (reference cli.py:938-973): ``pre`` (-u,
+        --nextseq-trim, -q) -> adapter step (``self.plan``; None: no adapters) -> ``post`` (--poly-a, -l) and the
+        expected errors for --max-ee.  Leaves the kept intervals in self.beg / self.end (relative to the read) and the
+        matches' status in self.res.status.  ``limits`` = (min_len, max_len, discard_trimmed, discard_untrimmed): the
+        filters are applied here too (self.keep, counters); None: the caller filters (read pairs are filtered as a
+        unit).  -> the expected errors (float64 tensor) or None."""
+        torch = self.torch
+        L = _lib.lib()
+        sp = self.stream.cuda_stream
+        seq_len, seq_off = self.seq_len[:n], self.seq_off[:n]
+        qual_off = self.rec6[:n, 4]
+        wbeg = None                                          # None: the matcher sees whole reads
+        wlen = seq_len
+        keepalive = []                                       # (tensors kernels read: alive until the stream is through)
+        if pre:
+            # the modifiers in front of the adapter step (-u, --nextseq-trim, -q: reference cli.py:938-954) as kernels
+            # and a few element-wise operations on this stream; the matcher then sees a window of every read
+            wbeg = torch.zeros(n, dtype=torch.int32, device=self.device)
+            wlen = seq_len.clone()
+            for c in pre["cut"]:                              # UnconditionalCutter: read[c:] / read[:c]
+                if c > 0:
+                    d = torch.clamp(wlen, max=c)
+                    wbeg += d
+                    wlen -= d
+                else:
+                    wlen = torch.clamp(wlen + c, min=0)
+            if pre["nextseq_trim"] is not None:
+                stop = torch.empty(n, dtype=torch.int32, device=self.device)
+                w64 = wbeg.to(torch.int64)
+                so, qo = seq_off + w64, qual_off + w64       # (named: a temporary's block could be handed out again
+                _lib.check(L.cah_nextseq_trim_batch_q(       #  before the kernel has read it)
+                    self.d_in.data_ptr(), self.d_in.data_ptr(), so.data_ptr(), qo.data_ptr(),
+                    wlen.data_ptr(), n, int(pre["nextseq_trim"]), int(pre["quality_base"]), stop.data_ptr(), sp))
+                self.pre_counts[0] += (wlen - stop).sum()
+                keepalive += [so, qo, wlen]
+                wlen = stop
+            if pre["quality_cutoff"] is not None:
+                ss = torch.empty((n, 2), dtype=torch.int32, device=self.device)
+                qo = qual_off + wbeg.to(torch.int64)
+                _lib.check(L.cah_quality_trim_batch(
+                    self.d_in.data_ptr(), qo.data_ptr(), wlen.data_ptr(), n, int(pre["quality_cutoff"][0]),
+                    int(pre["quality_cutoff"][1]), int(pre["quality_base"]), ss.data_ptr(), sp))
+                kept = ss[:, 1] - ss[:, 0]
+                self.pre_counts[1] += (wlen - kept).sum()
+                keepalive += [qo, wlen]
+                wbeg = wbeg + ss[:, 0]
+                wlen = kept.contiguous()
+            wbeg = wbeg.contiguous()
+        voff = seq_off if wbeg is None else (seq_off + wbeg.to(torch.int64)).contiguous()
+        if self.plan is not None:
+            ws_need = int(L.cah_plan_workspace_bytes(self.plan.handle, n))
+            if self._ws is None or self._ws.numel() < ws_need:
+                self._ws = torch.empty(ws_need + ws_need // 4, dtype=torch.uint8, device=self.device)
             _lib.check(L.cah_match_batch(self.plan.handle, self.d_in.data_ptr(), voff.data_ptr(), wlen.data_ptr(), n,
                                          self.res.out6.data_ptr(), self.res.best_adapter.data_ptr(),
                                          self.res.status.data_ptr(), self._ws.data_ptr(), self._ws.numel(), sp))
-            if not pre and not post:
-                _lib.check(L.cah_trim_decide_device(
-                    self.res.out6.data_ptr(), self.res.status.data_ptr(), self.res.best_adapter.data_ptr(),
-                    self.seq_len.data_ptr(), n, self.kinds.data_ptr(), *limits,
-                    self.beg.data_ptr(), self.end.data_ptr(), self.keep.data_ptr(), self.counters.data_ptr(), sp))
-            else:
-                _lib.check(L.cah_trim_decide_window_device(
-                    self.res.out6.data_ptr(), self.res.status.data_ptr(), self.res.best_adapter.data_ptr(),
-                    wbeg.data_ptr() if wbeg is not None else None, wlen.data_ptr(), self.seq_len.data_ptr(), n,
-                    self.kinds.data_ptr(), *limits, 1 if post else 0,
-                    self.beg.data_ptr(), self.end.data_ptr(), self.keep.data_ptr(), self.counters.data_ptr(), sp))
-            if post:
-                # the modifiers behind the adapter step (--poly-a, -l: cli.py:956-973) move the kept interval, then the
-                # filters (--max-ee among them) decide what is written: cah_trim_filter_device
-                beg, end = self.beg[:n], self.end[:n]
-                if post["poly_a"]:
-                    idx = torch.empty(n, dtype=torch.int32, device=self.device)
-                    cur = (end - beg).contiguous()
-                    po = (seq_off + beg.to(torch.int64)).contiguous()
-                    _lib.check(L.cah_poly_a_trim_batch(self.d_in.data_ptr(), po.data_ptr(), cur.data_ptr(), n, 0,
-                                                       idx.data_ptr(), sp))
-                    removed = (cur - idx).to(torch.int64)
-                    # (index_add_, not bincount: bincount asks the device for the largest value first; the reads without
-                    # a tail -- nearly all -- are counted in 4096 spare bins behind the histogram instead of all in bin 0)
-                    spare = _lib.MAX_READ_LEN + 1 + (torch.arange(n, device=self.device) & 4095)
-                    self.polya_hist.index_add_(0, torch.where(removed != 0, removed, spare), torch.ones_like(removed))
+        else:
+            self.res.status[:n].zero_()                      # a mate without adapters: nothing is found
+        final_here = limits is not None and not post
+        lim = limits if final_here else (-1, -1, 0, 0)
+        if not pre and final_here:
+            _lib.check(L.cah_trim_decide_device(
+                self.res.out6.data_ptr(), self.res.status.data_ptr(), self.res.best_adapter.data_ptr(),
+                self.seq_len.data_ptr(), n, self.kinds.data_ptr(), *lim,
+                self.beg.data_ptr(), self.end.data_ptr(), self.keep.data_ptr(), self.counters.data_ptr(), sp))
+        else:
+            _lib.check(L.cah_trim_decide_window_device(
+                self.res.out6.data_ptr(), self.res.status.data_ptr(), self.res.best_adapter.data_ptr(),
+                wbeg.data_ptr() if wbeg is not None else None, wlen.data_ptr(), self.seq_len.data_ptr(), n,
+                self.kinds.data_ptr(), *lim, 0 if final_here else 1,
+                self.beg.data_ptr(), self.end.data_ptr(), self.keep.data_ptr(), self.counters.data_ptr(), sp))
+        ee = None
+        if post:
+            # the modifiers behind the adapter step (--poly-a, -l: cli.py:956-973) move the kept interval, then the
+            # filters (--max-ee among them) decide what is written: cah_trim_filter_device
+            beg, end = self.beg[:n], self.end[:n]
+            if post["poly_a"]:
+                head = bool(post.get("poly_a_revcomp"))      # the second mate of a pair loses a poly-T HEAD
+                idx = torch.empty(n, dtype=torch.int32, device=self.device)
+                cur = (end - beg).contiguous()
+                po = (seq_off + beg.to(torch.int64)).contiguous()
+                _lib.check(L.cah_poly_a_trim_batch(self.d_in.data_ptr(), po.data_ptr(), cur.data_ptr(), n, int(head),
+                                                   idx.data_ptr(), sp))
+                removed = (idx if head else cur - idx).to(torch.int64)
+                # (index_add_, not bincount: bincount asks the device for the largest value first; the reads without
+                # a tail -- nearly all -- are counted in 4096 spare bins behind the histogram instead of all in bin 0)
+                spare = _lib.MAX_READ_LEN + 1 + (torch.arange(n, device=self.device) & 4095)
+                self.polya_hist.index_add_(0, torch.where(removed != 0, removed, spare), torch.ones_like(removed))
+                if head:
+                    beg.copy_(beg + idx)
+                else:
                     end.copy_(beg + idx)
-                    keepalive += [cur, po, idx]
-                if post["length"] is not None:
-                    cur = end - beg
-                    if post["length"] >= 0:
-                        end.copy_(beg + torch.clamp(cur, max=int(post["length"])))
-                    else:
-                        beg.copy_(end - torch.clamp(cur, max=-int(post["length"])))
-                ee_ptr, max_ee = None, -1.0
-                if post["max_expected_errors"] is not None:
-                    ee = torch.empty(n, dtype=torch.float64, device=self.device)
-                    ee_status = torch.zeros(n, dtype=torch.uint8, device=self.device)
-                    cur = (end - beg).contiguous()
-                    qo = (qual_off + beg.to(torch.int64)).contiguous()
-                    _lib.check(L.cah_expected_errors_batch(self.d_in.data_ptr(), qo.data_ptr(), cur.data_ptr(), n, 33,
-                                                           ee.data_ptr(), ee_status.data_ptr(), sp))
-                    self.ee_invalid |= (ee_status == _lib.INVALID).any()
-                    ee_ptr, max_ee = ee.data_ptr(), float(post["max_expected_errors"])
-                    keepalive += [ee, ee_status, cur, qo]
-                _lib.check(L.cah_trim_filter_device(self.beg.data_ptr(), self.end.data_ptr(), self.res.status.data_ptr(),
-                                                    ee_ptr, n, limits[0], limits[1], max_ee, limits[2], limits[3],
-                                                    self.keep.data_ptr(), self.counters.data_ptr(), sp))
-            self._keepalive = keepalive + [voff, wlen, wbeg]
+                keepalive += [cur, po, idx]
+            if post["length"] is not None:
+                cur = end - beg
+                if post["length"] >= 0:
+                    end.copy_(beg + torch.clamp(cur, max=int(post["length"])))
+                else:
+                    beg.copy_(end - torch.clamp(cur, max=-int(post["length"])))
+            if post["max_expected_errors"] is not None:
+                ee = torch.empty(n, dtype=torch.float64, device=self.device)
+                ee_status = torch.zeros(n, dtype=torch.uint8, device=self.device)
+                cur = (end - beg).contiguous()
+                qo = (qual_off + beg.to(torch.int64)).contiguous()
+                _lib.check(L.cah_expected_errors_batch(self.d_in.data_ptr(), qo.data_ptr(), cur.data_ptr(), n, 33,
+                                                       ee.data_ptr(), ee_status.data_ptr(), sp))
+                self.ee_invalid |= (ee_status == _lib.INVALID).any()
+                keepalive += [ee_status, cur, qo]
+            if limits is not None:
+                _lib.check(L.cah_trim_filter_device(
+                    self.beg.data_ptr(), self.end.data_ptr(), self.res.status.data_ptr(),
+                    ee.data_ptr() if ee is not None else None, n, limits[0], limits[1],
+                    float(post["max_expected_errors"]) if ee is not None else -1.0, limits[2], limits[3],
+                    self.keep.data_ptr(), self.counters.data_ptr(), sp))
+        self._keepalive = keepalive + [voff, wlen, wbeg, ee]
+        return ee
+
+    def finish(self, data, n: int, n_bytes: int):
+        """step 4 of a chunk whose intervals and keep flags are final -> (pinned buffer, bytes)"""
+        torch = self.torch
+        L = _lib.lib()
+        sp = self.stream.cuda_stream
+        o = self.opts
         if o.get("assemble") == "host":
             return self._assemble_on_host(data, n_bytes, n)
         # ---- step 4: format on the device, bring the bytes back ---------------------------------------------
@@ -936,6 +965,161 @@ def _paired_pieces(source1, source2, chunk_bytes: int):
                 f.close()
 
 
+def _mate_all_device(opts: Optional[dict]):
+    """BatchTrimmer options of one mate -> (adapters, pre, post) if the all-device way can serve them, else None"""
+    from .adapters import PrefixAdapter, SuffixAdapter
+    o = dict(opts or {})
+    adapters = _adapter_list(o.pop("adapters", ()))
+    if o.pop("times", 1) != 1 or o.pop("action", "trim") != "trim" or o.pop("revcomp", False):
+        return None
+    index = o.pop("index", True)
+    o.pop("rc_suffix", None)
+    cut = [int(c) for c in o.pop("cut", ()) if int(c) != 0]
+    nextseq, qcut, qbase = o.pop("nextseq_trim", None), o.pop("quality_cutoff", None), o.pop("quality_base", 33)
+    poly_a, head = o.pop("poly_a", False), o.pop("poly_a_revcomp", False)
+    length, max_ee = o.pop("length", None), o.pop("max_expected_errors", None)
+    if o:                                                    # an option this way does not know
+        return None
+    if not all(isinstance(a, SingleAdapter) and not a._reverse_reads for a in adapters):
+        return None
+    if index and sum(isinstance(a, (PrefixAdapter, SuffixAdapter)) for a in adapters) > 1:
+        return None                                          # (the reference regroups those behind an index: another order)
+    if len(cut) > 2 or (len(cut) == 2 and cut[0] * cut[1] > 0):
+        return None                                          # (BatchTrimmer raises the reference's error for these)
+    pre = post = None
+    if cut or nextseq is not None or qcut is not None:
+        pre = {"cut": cut, "nextseq_trim": nextseq, "quality_cutoff": qcut, "quality_base": qbase}
+    if poly_a or length is not None or max_ee is not None:
+        post = {"poly_a": bool(poly_a), "poly_a_revcomp": bool(head), "length": length, "max_expected_errors": max_ee}
+    return adapters, pre, post
+
+
+def _paired_all_device(in1, in2, out1, out2, mates, job, discard_untrimmed, discard_trimmed, chunk_bytes, threads, devices):
+    """Read pairs on the all-device way: both mates' chunks are indexed, trimmed and matched by ``_Worker.modify`` (no
+    filter), the pair filter (reference PairedEndFilter / cli.py:735-912, as pipeline.filter_reads combines it) is a
+    dozen element-wise operations on the two mates' intervals, both outputs are formatted on the device with the
+    shared keep flags.  ``job``: a PairedJob built from the same options (its filter modes are used; nothing is run
+    through it)."""
+    import torch
+    min_len, max_len, mode, untrimmed_mode = job.min_len, job.max_len, job.mode, job.untrimmed_mode
+    plans = []
+    for adapters, pre, post in mates:
+        plans.append(_plan_for(adapters) if adapters else (None, [0]))
+
+    def make_worker(dev, slot):
+        ws = []
+        for (plan, kinds) in plans:
+            ws.append(_take_worker(plan, kinds, dev, {}))
+        w, mate = ws
+        mate.stream = w.stream                               # one stream for the pair
+        w.mate = mate
+        w.pair_counts = torch.zeros(8, dtype=torch.int64, device=w.device)   # kept, too short, too long, too many ee, bp out 1 / 2
+        return w
+
+    def combine(preds, how):
+        preds = [p for p in preds if p is not None]
+        if not preds:
+            return None
+        if how == "first":
+            return preds[0]
+        out = preds[0]
+        for p in preds[1:]:
+            out = (out | p) if how == "any" else (out & p)
+        return out
+
+    def work(w: _Worker, d1, d2):
+        if len(d1) == 0:
+            return b"", b"", [], w
+        torch.cuda.set_device(w.device)
+        t0 = time.perf_counter()
+        try:
+            with torch.cuda.stream(w.stream):
+                ws = (w, w.mate)
+                n = w.load(d1)
+                if w.mate.load(d2) != n:
+                    raise ValueError("Reads are improperly paired")
+                if n == 0:
+                    return b"", b"", [], w
+                ee = [ww.modify(n, pre, post, None) for ww, (adapters, pre, post) in zip(ws, mates)]
+                lens = [ww.end[:n] - ww.beg[:n] for ww in ws]
+                found = [ww.res.status[:n] == 1 for ww in ws]
+                keep = torch.ones(n, dtype=torch.bool, device=w.device)
+                short = combine([None if m is None else (l < int(m)) for l, m in zip(lens, min_len)], mode)
+                long_ = combine([None if m is None else (l > int(m)) for l, m in zip(lens, max_len)], mode)
+                many = combine([None if (e is None) else (e > float(post["max_expected_errors"]))
+                                for e, (adapters, pre, post) in zip(ee, mates)], mode)
+                for slot, pred in ((1, short), (2, long_), (3, many)):
+                    if pred is not None:
+                        w.pair_counts[slot] += (keep & pred).sum()
+                        keep = keep & ~pred
+                if discard_trimmed:
+                    keep = keep & ~combine(found, mode)
+                elif discard_untrimmed:
+                    keep = keep & ~combine([~f for f in found], untrimmed_mode)
+                w.pair_counts[0] += keep.sum()
+                for k, ww in enumerate(ws):
+                    w.pair_counts[4 + k] += (lens[k] * keep).sum()
+                    ww.keep[:n].copy_(keep.to(torch.uint8))
+                h1, t1 = w.finish(d1, n, w.n_bytes)
+                h2, t2 = w.mate.finish(d2, n, w.mate.n_bytes)
+                return memoryview(h1.numpy())[:t1], memoryview(h2.numpy())[:t2], [h1, h2], w
+        finally:
+            w.busy_s += time.perf_counter() - t0
+            w.chunks += 1
+            w.bytes_in += len(d1) + len(d2)
+
+    feeders = [_Feeder(dev, threads, len(devices) > 1, make_worker) for dev in devices]
+    o1 = out1 if hasattr(out1, "write") else open(out1, "wb")
+    o2 = out2 if hasattr(out2, "write") else open(out2, "wb")
+    t_start = time.perf_counter()
+    try:
+        pending: deque = deque()
+
+        def drain(limit: int) -> None:
+            while len(pending) > limit:
+                b1, b2, bufs, w = pending.popleft().result()
+                o1.write(b1)
+                o2.write(b2)
+                b1 = b2 = None
+                for b in bufs:
+                    w.pool.put(b)
+        for i, (d1, d2) in enumerate(_paired_pieces(in1, in2, chunk_bytes)):
+            pending.append(feeders[i % len(feeders)].submit(work, d1, d2))
+            drain(2 * threads * len(feeders))
+        drain(0)
+    finally:
+        for f in feeders:
+            f.close()
+        if o1 is not out1:
+            o1.close()
+        if o2 is not out2:
+            o2.close()
+    wall = time.perf_counter() - t_start
+    workers = [w for f in feeders for w in f.workers if w is not None]
+    pc = np.zeros(8, dtype=np.int64)
+    c = [np.zeros(8, dtype=np.int64), np.zeros(8, dtype=np.int64)]
+    removed = [np.zeros(2, dtype=np.int64), np.zeros(2, dtype=np.int64)]
+    for w in workers:
+        pc += w.pair_counts.cpu().numpy()
+        for k, ww in enumerate((w, w.mate)):
+            c[k] += ww.counters.cpu().numpy()
+            removed[k] += ww.pre_counts.cpu().numpy()
+    result = {"pairs": int(c[0][0]), "pairs_written": int(pc[0]), "trimmers": None, "paired_cutter": None,
+              "filtered": {k: v for k, v in (("too_short", int(pc[1])), ("too_long", int(pc[2]))) if v},
+              "too_many_expected_errors": int(pc[3]), "with_adapters": (int(c[0][1]), int(c[1][1])),
+              "bp_in": (int(c[0][2]), int(c[1][2])), "bp_out": (int(pc[4]), int(pc[5])),
+              "quality_trimmed_bases": (int(removed[0][1]), int(removed[1][1])),
+              "nextseq_trimmed_bases": (int(removed[0][0]), int(removed[1][0])), "reverse_complemented": None,
+              "devices_used": sorted({str(w.device) for w in workers}), "per_device": _per_device(feeders, wall),
+              "way": "all-device"}
+    for w in workers:
+        mate, w.mate = w.mate, None
+        mate.stream = torch.cuda.Stream(device=mate.device)      # (it shared its partner's)
+        _give_back(mate)
+        _give_back(w)
+    return result
+
+
 def trim_fastq_gpu_paired(in1, in2, out1, out2, r1: Optional[dict] = None, r2: Optional[dict] = None,
                           pair_filter: Optional[str] = None, minimum_length=None, maximum_length=None,
                           discard_untrimmed: bool = False, discard_trimmed: bool = False,
@@ -959,6 +1143,13 @@ def trim_fastq_gpu_paired(in1, in2, out1, out2, r1: Optional[dict] = None, r2: O
                          pair_adapters, revcomp, rc_suffix)
 
     total = make_job(devices[0])                             # option errors surface here, not in a worker
+    r2_eff = dict(r2 or {})
+    if r2_eff.get("poly_a"):
+        r2_eff.setdefault("poly_a_revcomp", True)            # --poly-a on read pairs: the poly-T head of R2
+    mates = None if (pair_adapters or revcomp) else (_mate_all_device(r1), _mate_all_device(r2_eff))
+    if mates is not None and all(m is not None for m in mates):
+        return _paired_all_device(in1, in2, out1, out2, mates, total, discard_untrimmed, discard_trimmed, chunk_bytes,
+                                  threads, devices)
 
     def make_worker(dev, slot):
         w = _take_worker(None, [], dev, {})
@@ -1019,6 +1210,7 @@ def trim_fastq_gpu_paired(in1, in2, out1, out2, r1: Optional[dict] = None, r2: O
     result = total.result()
     result["devices_used"] = sorted({str(w.device) for w in workers})
     result["per_device"] = _per_device(feeders, wall)
+    result["way"] = "general"
     for w in workers:
         mate, w.mate, w.job = w.mate, None, None
         mate.stream = torch.cuda.Stream(device=mate.device)      # (it shared its partner's)

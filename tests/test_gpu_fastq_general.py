@@ -393,3 +393,50 @@ def test_info_file_and_marking_actions_next_to_other_modifiers(hip, orc):
                chunk_bytes=20000, **kw)
             got, want = out.getvalue().decode().split("\n"), "".join(want_out).split("\n")
             assert got == want, (action, fn.__name__, [(g, w) for g, w in zip(got, want) if g != w][:2])
+
+
+def test_read_pairs_on_the_all_device_way_equal_the_host_pipeline(hip):
+    """trim_fastq_gpu_paired without --times / actions / linked adapters runs on the all-device way: both mates trimmed,
+    matched and formatted on the GPU, the pair filter as element-wise operations.  Bytes and counters against
+    pipeline.trim_fastq_paired (which the reference's paired goldens pin) over option sets that exercise every
+    modifier, every --pair-filter mode, per-mate length limits and the discards."""
+    from cutadapt_amd import adapters as A
+    from cutadapt_amd.gpu_pipeline import trim_fastq_gpu_paired
+    from cutadapt_amd.pipeline import trim_fastq_paired
+    from test_gpu_fastq_device import _fastq
+    rng = random.Random(99)
+    ad1, ad2 = "AGATCGGAAGAGCACACGTCTGAACTCCAGTCA", "AGATCGGAAGAGCGTCGTGTAGGGAAAGAGTGT"
+    n = 4000
+    f1 = _fastq(rng, n, [ad1])
+    f2 = _fastq(rng, n, [ad2]).replace(b"@read", b"@mate")
+    cases = [
+        (dict(adapters=[A.BackAdapter(ad1)]), dict(adapters=[A.BackAdapter(ad2)]), dict(minimum_length=20)),
+        (dict(adapters=[A.BackAdapter(ad1)], quality_cutoff=(0, 20)), dict(adapters=[A.BackAdapter(ad2)], quality_cutoff=(5, 15)),
+         dict(minimum_length=(30, 20), maximum_length=(150, None), pair_filter="both")),
+        (dict(adapters=[A.BackAdapter(ad1), A.FrontAdapter(ad2[:15])], poly_a=True, cut=[2]), dict(poly_a=True, length=70),
+         dict(minimum_length=25, pair_filter="first")),
+        (dict(adapters=[A.BackAdapter(ad1)], max_expected_errors=2.0), dict(adapters=[A.BackAdapter(ad2)], max_expected_errors=4.0, nextseq_trim=15),
+         dict(discard_untrimmed=True)),
+        (dict(adapters=[A.BackAdapter(ad1)], length=-60), dict(adapters=[A.AnywhereAdapter(ad2[:20])], cut=[-3, 4]),
+         dict(discard_trimmed=True, pair_filter="both")),
+        (dict(quality_cutoff=(0, 25)), dict(adapters=[A.BackAdapter(ad2)]), dict(discard_untrimmed=True, minimum_length=10)),
+    ]
+    for ci, (r1, r2, top) in enumerate(cases):
+        w1, w2 = io.BytesIO(), io.BytesIO()
+        ws = trim_fastq_paired(io.BytesIO(f1), io.BytesIO(f2), w1, w2, dict(r1), dict(r2), **top)
+        for chunk_bytes in (1 << 20, 50_000):
+            g1, g2 = io.BytesIO(), io.BytesIO()
+            gs = trim_fastq_gpu_paired(io.BytesIO(f1), io.BytesIO(f2), g1, g2, dict(r1), dict(r2), chunk_bytes=chunk_bytes,
+                                       threads=2, devices="all", **top)
+            assert gs["way"] == "all-device", ci
+            assert g1.getvalue() == w1.getvalue() and g2.getvalue() == w2.getvalue(), (ci, chunk_bytes)
+            assert (gs["pairs"], gs["pairs_written"]) == (ws["pairs"], ws["pairs_written"]) == (n, gs["pairs_written"]), ci
+            assert gs["with_adapters"] == ws["with_adapters"], ci
+            assert gs["filtered"] == {k: v for k, v in ws["filtered"].items() if v}, (ci, gs["filtered"], ws["filtered"])
+            assert gs["too_many_expected_errors"] == ws["trimmers"][0].too_many_expected_errors, ci
+            assert gs["bp_out"] == (ws["trimmers"][0].bp_out, ws["trimmers"][1].bp_out), ci
+            assert gs["quality_trimmed_bases"] == tuple(t.quality_trimmed_bases for t in ws["trimmers"]), ci
+    # what the all-device way does not serve goes the general way and says so
+    gs = trim_fastq_gpu_paired(io.BytesIO(f1), io.BytesIO(f2), io.BytesIO(), io.BytesIO(),
+                               dict(adapters=[A.BackAdapter(ad1)], times=2), dict(adapters=[A.BackAdapter(ad2)]))
+    assert gs["way"] == "general"
