@@ -28,7 +28,7 @@ EXPORTED_SYMBOLS = [
     "cah_kmers_present_batch_host", "cah_match_batch_host", "cah_locate_debug_host", "cah_match_one_host", "cah_locate_one_host", "cah_profile_enable",
     "cah_profile_reset", "cah_profile_read", "cah_synth_reads",
     "cah_fastq_scan", "cah_pack_sequences", "cah_fastq_write_trimmed",
-    "cah_fasta_scan", "cah_records_write", "cah_info_write", "cah_info_write_rc", "cah_chunk_revcomp", "cah_chunk_select", "cah_record_boundary",
+    "cah_fasta_scan", "cah_records_write", "cah_info_write", "cah_info_write_rc", "cah_chunk_revcomp", "cah_chunk_select", "cah_fastq_span", "cah_record_boundary",
     "cah_fastq_device_scratch_bytes", "cah_fastq_count_lines_device", "cah_fastq_index_device", "cah_fastq_format_device", "cah_trim_decide_device", "cah_trim_decide_window_device", "cah_trim_filter_device",
     "cah_index_create", "cah_index_destroy", "cah_index_info", "cah_index_get",
     "cah_index_lookup_batch", "cah_index_lookup_batch_host",
@@ -143,6 +143,7 @@ def lib():
     L.cah_info_write_rc.argtypes = [vp, vp, i64, vp, vp, vp, i64, vp, vp, i64, vp, vp, vp, vp, i64, C.POINTER(i64)]
     L.cah_chunk_revcomp.argtypes = [vp, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, C.POINTER(i64)]
     L.cah_chunk_select.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, i64, vp, i64, vp, C.POINTER(i64)]
+    L.cah_fastq_span.argtypes = [vp, i64, C.c_int, i64, C.POINTER(i64), C.POINTER(i64)]
     L.cah_record_boundary.argtypes = [vp, i64, C.c_int, C.POINTER(i64)]
     L.cah_fastq_device_scratch_bytes.argtypes = [i64, i64]
     L.cah_fastq_device_scratch_bytes.restype = C.c_size_t

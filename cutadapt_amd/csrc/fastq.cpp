@@ -9,6 +9,10 @@
 // emitted straight from the raw chunk -- no per-read objects.
 //
 // Plain C++ (no HIP): these entry points work without a GPU.
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
+#include <climits>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -458,6 +462,70 @@ int cah_chunk_select(const uint8_t* buf_a, const int64_t* rec_a, const uint8_t* 
         }
     }
     *out_len = pos;
+    return CAH_OK;
+}
+
+// How many whole 4-line records (at most max_records) does buf hold, and where do they end?  Lines are counted, not
+// parsed (memchr): what pairing two FASTQ streams needs -- the chunks handed on must hold the same number of records
+// (the job of dnaio.read_paired_chunks, reference runners.py:104-113).  is_final: a last record without a final line
+// feed counts.
+static inline int64_t count_line_feeds(const uint8_t* p, int64_t len) {
+    int64_t c = 0, i = 0;
+#if defined(__SSE2__)
+    // sixteen bytes per compare (SSE2 is part of x86-64): matches are 0xFF = -1 per byte, subtracted into sixteen byte
+    // counters that are summed (psadbw) before they can overflow
+    const __m128i lf = _mm_set1_epi8('\n'), zero = _mm_setzero_si128();
+    while (i + 16 <= len) {
+        __m128i acc = zero;
+        const int64_t rounds = (len - i) / 16 < 255 ? (len - i) / 16 : 255;
+        for (int64_t r = 0; r < rounds; r++, i += 16)
+            acc = _mm_sub_epi8(acc, _mm_cmpeq_epi8(_mm_loadu_si128(reinterpret_cast<const __m128i*>(p + i)), lf));
+        const __m128i sums = _mm_sad_epu8(acc, zero);
+        c += _mm_cvtsi128_si64(sums) + _mm_cvtsi128_si64(_mm_srli_si128(sums, 8));
+    }
+#endif
+    for (; i < len; i++) c += p[i] == '\n';
+    return c;
+}
+
+int cah_fastq_span(const uint8_t* buf, int64_t len, int is_final, int64_t max_records, int64_t* n_records,
+                   int64_t* consumed) {
+    if (!n_records || !consumed || (len > 0 && !buf) || len < 0 || max_records < 0)
+        return cah_set_error_(CAH_EINVAL, "cah_fastq_span: bad argument");
+    *n_records = 0;
+    *consumed = 0;
+    if (max_records == 0 || len == 0) return CAH_OK;
+    const int64_t want = max_records > (INT64_MAX >> 2) ? INT64_MAX : 4 * max_records;    // line feeds of max_records records
+    int64_t lines = 0, pos = 0;
+    while (pos < len) {                                                // blocks of 4 KiB: counted, not searched
+        const int64_t blk = len - pos < 4096 ? len - pos : 4096;
+        const int64_t c = count_line_feeds(buf + pos, blk);
+        if (lines + c >= want) {                                       // the want-th line feed lies in this block
+            int64_t need = want - lines;
+            const uint8_t* q = buf + pos;
+            while (need--) q = static_cast<const uint8_t*>(memchr(q, '\n', (size_t)(buf + len - q))) + 1;
+            *n_records = max_records;
+            *consumed = q - buf;
+            return CAH_OK;
+        }
+        lines += c;
+        pos += blk;
+    }
+    int64_t rec = lines / 4;
+    const int rem = (int)(lines % 4);
+    if (is_final && rem == 3 && buf[len - 1] != '\n') {                // the last record's last line has no line feed
+        *n_records = rec + 1;
+        *consumed = len;
+        return CAH_OK;
+    }
+    // the records end behind the (4 rec)-th line feed = the (rem + 1)-th from the end
+    const uint8_t* e = buf + len;
+    for (int k = 0; k <= rem && rec > 0; k++) {
+        const uint8_t* nl = static_cast<const uint8_t*>(memrchr(buf, '\n', (size_t)(e - buf)));
+        e = (k == rem) ? nl + 1 : nl;
+    }
+    *n_records = rec;
+    *consumed = rec > 0 ? e - buf : 0;
     return CAH_OK;
 }
 

@@ -922,42 +922,60 @@ def trim_fastq_gpu(source: Union[str, BinaryIO, np.ndarray], out: Union[str, Bin
 
 def _paired_pieces(source1, source2, chunk_bytes: int):
     """pairs of raw 4-line-FASTQ pieces with the SAME number of records (the job of dnaio.read_paired_chunks,
-    reference runners.py:104-113) -- found by counting line feeds, nothing is parsed: each side is read in blocks,
-    the side with fewer complete records decides, the surplus of the other side is carried over."""
-    from .pipeline import _open_maybe_gz
+    reference runners.py:104-113) -- found by counting line feeds (cah_fastq_span: memchr, nothing is parsed): each
+    side is read in blocks into a pooled buffer, the side with fewer complete records decides, the surplus of the
+    other side is carried over.  The pieces are views of pooled buffers: hand them back (pipeline.POOL.put) when done."""
+    from .pipeline import POOL, _open_maybe_gz
+    L = _lib.lib()
     files = [_open_maybe_gz(source1), _open_maybe_gz(source2)]
     carry = [np.zeros(0, np.uint8), np.zeros(0, np.uint8)]
     eof = [False, False]
+
+    def span(d, final, limit):
+        n, used = C.c_int64(0), C.c_int64(0)
+        _lib.check(L.cah_fastq_span(d.ctypes.data if len(d) else None, len(d), int(final), limit, C.byref(n), C.byref(used)))
+        return n.value, used.value
+
     try:
         while True:
-            data, ends = [], []
+            data, counts = [], []
             for k in (0, 1):
-                block = b"" if eof[k] else files[k].read(chunk_bytes)
-                if not block:
-                    eof[k] = True
-                d = np.concatenate([carry[k], np.frombuffer(block, dtype=np.uint8)]) if len(block) else carry[k]
-                if len(d) and d[0] == ord(">"):
+                buf = POOL.get(len(carry[k]) + chunk_bytes)
+                fill = len(carry[k])
+                buf[:fill] = carry[k]
+                if not eof[k]:
+                    view = memoryview(buf)[fill:fill + chunk_bytes]
+                    got = files[k].readinto(view) if hasattr(files[k], "readinto") else None
+                    if got is None:
+                        block = files[k].read(chunk_bytes)
+                        got = len(block)
+                        buf[fill:fill + got] = np.frombuffer(block, dtype=np.uint8)
+                    if got == 0:
+                        eof[k] = True
+                    fill += got
+                d = buf[:fill]
+                if fill and d[0] == ord(">"):
                     raise ValueError("the device-side path reads 4-line FASTQ; use pipeline.trim_fastq_paired for FASTA")
-                nl = np.flatnonzero(d == 10)
-                e = nl[3::4] + 1                             # the end of every complete record
-                if eof[k] and len(d) and d[-1] != 10 and len(nl) % 4 == 3:
-                    e = np.append(e, len(d))                 # a last record without a final line feed
                 data.append(d)
-                ends.append(e)
-            n = min(len(ends[0]), len(ends[1]))
+                counts.append(span(d, eof[k], 1 << 62))
+            used = [c[1] for c in counts]
+            counts = [c[0] for c in counts]
+            n = min(counts)
             if n == 0:
                 if eof[0] and eof[1]:
                     if len(data[0]) or len(data[1]):
-                        if len(ends[0]) != len(ends[1]):
+                        if counts[0] != counts[1]:
                             raise ValueError("Reads are improperly paired. There are more reads in one file than in the other.")
                         raise ValueError("FASTQ format error: premature end of file (incomplete record)")
                     return
                 if all(len(d) > 64 * chunk_bytes for d in data):
                     raise ValueError("record larger than 64 chunks: not a FASTQ file?")
-                carry = data
+                carry = [d.copy() for d in data]
+                for d in data:
+                    POOL.put(d)
                 continue
-            cuts = [int(ends[0][n - 1]), int(ends[1][n - 1])]
-            carry = [data[0][cuts[0]:], data[1][cuts[1]:]]
+            cuts = [used[k] if counts[k] == n else span(d, eof[k], n)[1] for k, d in enumerate(data)]
+            carry = [data[0][cuts[0]:].copy(), data[1][cuts[1]:].copy()]
             yield data[0][:cuts[0]], data[1][:cuts[1]]
     finally:
         for f, src in zip(files, (source1, source2)):
@@ -1067,6 +1085,9 @@ def _paired_all_device(in1, in2, out1, out2, mates, job, discard_untrimmed, disc
             w.busy_s += time.perf_counter() - t0
             w.chunks += 1
             w.bytes_in += len(d1) + len(d2)
+            from .pipeline import POOL
+            POOL.put(d1)
+            POOL.put(d2)                                     # the reader's buffers are free again
 
     feeders = [_Feeder(dev, threads, len(devices) > 1, make_worker) for dev in devices]
     o1 = out1 if hasattr(out1, "write") else open(out1, "wb")
@@ -1176,6 +1197,9 @@ def trim_fastq_gpu_paired(in1, in2, out1, out2, r1: Optional[dict] = None, r2: O
             w.busy_s += time.perf_counter() - t0
             w.chunks += 1
             w.bytes_in += len(d1) + len(d2)
+            from .pipeline import POOL
+            POOL.put(d1)
+            POOL.put(d2)                                     # the reader's buffers are free again
 
     feeders = [_Feeder(dev, threads, len(devices) > 1, make_worker) for dev in devices]
     o1 = out1 if hasattr(out1, "write") else open(out1, "wb")

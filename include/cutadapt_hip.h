@@ -338,6 +338,11 @@ int cah_chunk_select(const uint8_t *buf_a, const int64_t *rec_a, const uint8_t *
                      const uint8_t *buf_b, const int64_t *rec_b, const uint8_t *seqs_b, const int64_t *offsets_b,
                      int64_t n_records, const uint8_t *swap, const char *suffix, int64_t suffix_len,
                      uint8_t *out, int64_t out_cap, int64_t *out_rec, int64_t *out_len);
+/* Whole 4-line FASTQ records in buf (at most max_records) and the bytes they cover: lines are counted, not parsed --
+ * what cutting two FASTQ streams into chunks with equal record counts needs (dnaio.read_paired_chunks,
+ * runners.py:104-113).  is_final: a last record without a final line feed counts. */
+int cah_fastq_span(const uint8_t *buf, int64_t len, int is_final, int64_t max_records, int64_t *n_records,
+                   int64_t *consumed);
 
 /* ---- the same formats ON THE DEVICE (fastq_gpu.hip): the raw FASTQ chunk goes to HBM as it is, records are
  * indexed and the trimmed records formatted there, so that the host does nothing per read.  All pointers are

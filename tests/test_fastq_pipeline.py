@@ -384,3 +384,48 @@ def test_write_trimmed_runs_equal_piecewise_formatting():
         _lib.check(L.cah_fastq_write_trimmed(buf.ctypes.data, rec.ctypes.data, n, beg.ctypes.data, end.ctypes.data,
                                              keep.ctypes.data, out.ctypes.data, len(out), C.byref(out_len)))
         assert bytes(out[:out_len.value]) == "".join(want).encode(), (it, crlf)
+
+
+def test_paired_pieces_by_line_count():
+    """host only: gpu_pipeline._paired_pieces cuts two FASTQ streams into pieces with equal record counts by counting
+    line feeds (cah_fastq_span); the pieces put together are the inputs, whatever the block size"""
+    import random
+    from cutadapt_amd import _lib
+    from cutadapt_amd.gpu_pipeline import _paired_pieces
+    rng = random.Random(8)
+
+    def fq(n, tag, final_newline=True):
+        recs = []
+        for i in range(n):
+            L = rng.randint(0, 120)
+            s = "".join(rng.choice("ACGTN") for _ in range(L))
+            q = "".join(chr(rng.randint(33, 73)) for _ in range(L))
+            q = ("@" + q[1:]) if (L and rng.random() < 0.2) else q        # quality lines may start with '@'
+            recs.append(f"@{tag}{i} {'x' * rng.randint(0, 40)}\n{s}\n+\n{q}\n")
+        text = "".join(recs)
+        return (text if final_newline else text[:-1]).encode()
+
+    for n, final_nl in ((0, True), (1, True), (257, True), (1000, False)):
+        a, b = fq(n, "a"), fq(n, "b", final_nl)
+        for block in (150, 997, 4096, 1 << 20):
+            got_a, got_b, total = [], [], 0
+            for d1, d2 in _paired_pieces(io.BytesIO(a), io.BytesIO(b), block):
+                n1 = bytes(d1).count(b"\n")
+                n2 = bytes(d2).count(b"\n") + (0 if bytes(d2).endswith(b"\n") else 1)
+                assert n1 % 4 == 0 and n1 == n2 and n1 > 0, (n, block)
+                total += n1 // 4
+                got_a.append(bytes(d1))
+                got_b.append(bytes(d2))
+            assert b"".join(got_a) == a and b"".join(got_b) == b and total == n, (n, block)
+    a, b = fq(50, "a"), fq(49, "b")
+    with pytest.raises(ValueError, match="improperly paired"):
+        list(_paired_pieces(io.BytesIO(a), io.BytesIO(b), 500))
+    with pytest.raises(ValueError):
+        list(_paired_pieces(io.BytesIO(a), io.BytesIO(a[:-40]), 500))
+    # the counting primitive itself
+    L = _lib.lib()
+    buf = np.frombuffer(b"@r\nAC\n+\nII\n@s\nG\n+\nI", dtype=np.uint8)
+    for final, limit, want in ((0, 10, (1, 11)), (1, 10, (2, len(buf))), (1, 1, (1, 11)), (0, 0, (0, 0))):
+        nrec, used = C.c_int64(0), C.c_int64(0)
+        _lib.check(L.cah_fastq_span(buf.ctypes.data, len(buf), final, limit, C.byref(nrec), C.byref(used)))
+        assert (nrec.value, used.value) == want, (final, limit)
