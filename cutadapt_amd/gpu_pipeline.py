@@ -936,28 +936,32 @@ def _paired_pieces(source1, source2, chunk_bytes: int):
         _lib.check(L.cah_fastq_span(d.ctypes.data if len(d) else None, len(d), int(final), limit, C.byref(n), C.byref(used)))
         return n.value, used.value
 
+    def load_side(k):
+        """the next block of file k behind what was carried over, and how many whole records that is"""
+        buf = POOL.get(len(carry[k]) + chunk_bytes)
+        fill = len(carry[k])
+        buf[:fill] = carry[k]
+        if not eof[k]:
+            view = memoryview(buf)[fill:fill + chunk_bytes]
+            got = files[k].readinto(view) if hasattr(files[k], "readinto") else None
+            if got is None:
+                block = files[k].read(chunk_bytes)
+                got = len(block)
+                buf[fill:fill + got] = np.frombuffer(block, dtype=np.uint8)
+            if got == 0:
+                eof[k] = True
+            fill += got
+        d = buf[:fill]
+        if fill and d[0] == ord(">"):
+            raise ValueError("the device-side path reads 4-line FASTQ; use pipeline.trim_fastq_paired for FASTA")
+        return d, span(d, eof[k], 1 << 62)
+
+    sides = ThreadPoolExecutor(max_workers=2)                # the two files are read and counted side by side
     try:
         while True:
-            data, counts = [], []
-            for k in (0, 1):
-                buf = POOL.get(len(carry[k]) + chunk_bytes)
-                fill = len(carry[k])
-                buf[:fill] = carry[k]
-                if not eof[k]:
-                    view = memoryview(buf)[fill:fill + chunk_bytes]
-                    got = files[k].readinto(view) if hasattr(files[k], "readinto") else None
-                    if got is None:
-                        block = files[k].read(chunk_bytes)
-                        got = len(block)
-                        buf[fill:fill + got] = np.frombuffer(block, dtype=np.uint8)
-                    if got == 0:
-                        eof[k] = True
-                    fill += got
-                d = buf[:fill]
-                if fill and d[0] == ord(">"):
-                    raise ValueError("the device-side path reads 4-line FASTQ; use pipeline.trim_fastq_paired for FASTA")
-                data.append(d)
-                counts.append(span(d, eof[k], 1 << 62))
+            loaded = list(sides.map(load_side, (0, 1)))
+            data = [x[0] for x in loaded]
+            counts = [x[1] for x in loaded]
             used = [c[1] for c in counts]
             counts = [c[0] for c in counts]
             n = min(counts)
@@ -978,6 +982,7 @@ def _paired_pieces(source1, source2, chunk_bytes: int):
             carry = [data[0][cuts[0]:].copy(), data[1][cuts[1]:].copy()]
             yield data[0][:cuts[0]], data[1][:cuts[1]]
     finally:
+        sides.shutdown(wait=True)
         for f, src in zip(files, (source1, source2)):
             if f is not src:
                 f.close()
