@@ -38,7 +38,7 @@ import threading
 import time
 from collections import deque
 from concurrent.futures import ThreadPoolExecutor
-from typing import BinaryIO, Dict, List, Optional, Sequence, Tuple, Union
+from typing import BinaryIO, Dict, Optional, Sequence, Tuple, Union
 
 import numpy as np
 
