@@ -455,6 +455,8 @@ def test_column_skipping_is_exact(hip, orc):
         seq = rs(rng, m, al)
         if rng.random() < 0.15:
             seq = (seq[:max(2, m // 4)] * 5)[:m]                  # repetitive adapter
+        if set(seq) == {"N"}:
+            seq = "A" + seq[1:]                                   # (an adapter of N only is rejected, like the reference does)
         kwargs = {"max_errors": rng.choice([0, 0.05, 0.1, 0.1, 0.15, 0.2, 0.3]),
                   "min_overlap": rng.randint(1, 6), "read_wildcards": rng.random() < 0.25,
                   "indels": rng.random() < 0.8}
