@@ -316,3 +316,39 @@ def test_paired_reverse_complementer_against_the_rule_over_oracle_results(hip, o
             assert o1.getvalue() == "".join(want1).encode(), (fn.__name__, chunk_bytes)
             assert o2.getvalue() == "".join(want2).encode(), (fn.__name__, chunk_bytes)
             assert stats["reverse_complemented"] == n_rc
+
+
+def test_chunk_select_and_info_rows_on_the_original_read():
+    """host only: cah_chunk_select (the two output chunks of PairedReverseComplementer) and the window walk InfoFileWriter
+    does on the read as it came in (pipeline._info_rows_on_original, reference steps.py:232-247)"""
+    from cutadapt_amd.pipeline import _info_rows_on_original, read_fastq_chunks
+    rng = np.random.default_rng(9 + SEED0)
+    n = 40
+    texts = []
+    for tag in ("a", "b"):
+        recs = []
+        for i in range(n):
+            L = int(rng.integers(0, 50))
+            s = random_read(rng, L, "ACGTN")
+            q = "".join(chr(int(x)) for x in rng.integers(33, 74, size=L))
+            recs.append((f"{tag}{i} extra", s, q))
+        texts.append(recs)
+    chunks = [list(read_fastq_chunks(io.BytesIO("".join(f"@{nm}\n{s}\n+\n{q}\n" for nm, s, q in recs).encode())))[0] for recs in texts]
+    swap = rng.random(n) < 0.5
+    for k in (0, 1):
+        out = chunks[k].selected(chunks[1 - k], swap, " rc")
+        lens = np.array([len((texts[1 - k] if swap[i] else texts[k])[i][1]) for i in range(n)], dtype=np.int32)
+        got = bytes(out.write_records(np.zeros(n, np.int32), lens))
+        want = "".join("@{}{}\n{}\n+\n{}\n".format(r[0], " rc" if swap[i] else "", r[1], r[2])
+                       for i in range(n) for r in [(texts[1 - k] if swap[i] else texts[k])[i]])
+        assert got == want.encode(), k
+    # the window walk: a 5' match (removes what is in front) then a 3' match, coordinates found on the trimmed read
+    lens = np.array([100, 80], dtype=np.int64)
+    rows = np.array([[0, 1, 4, 14, 7, 90, 0],          # read 0, first match: rstart 4, rstop 14 on the read as trimmed (window 7..90)
+                     [0, 0, 30, 45, 21, 90, 1],        # read 0, second match after the first removed [.., 14)
+                     [1, 2, 50, 60, 0, 70, 1]], dtype=np.int64)
+    before = np.array([True, False, False])
+    got = _info_rows_on_original(rows, before, lens)
+    # read 0: the first row is cut out of the WHOLE read (0..100); the 5' match leaves [14, 100); the second row is cut there
+    assert got[:, 4:6].tolist() == [[0, 100], [14, 100], [0, 80]]
+    assert got[:, 1:4].tolist() == rows[:, 1:4].tolist() and got[:, 6].tolist() == [0, 1, 1]
