@@ -6,7 +6,7 @@ operation raises.  (cffi is not installed in this image, hence ctypes.)
 import ctypes as C
 import threading
 import os
-from typing import List, Optional, Sequence, Tuple
+from typing import Optional, Sequence, Tuple
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # CAH_LIB_PATH: developer knob to A/B-test a differently built kernel library

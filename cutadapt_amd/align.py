@@ -6,11 +6,8 @@ SuffixComparer :696-714; type stubs _align.pyi:10-27) and src/cutadapt/align.py:
 (EndSkip).  ``locate(str)`` keeps the per-read signature by sending a batch of one through
 the same kernel; ``locate_batch(ReadBatch)`` is the form the pipeline should use.
 """
-import ctypes as C
 from enum import IntFlag
 from typing import Optional, Tuple
-
-import numpy as np
 
 from . import _lib
 

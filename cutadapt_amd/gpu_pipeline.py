@@ -1063,7 +1063,7 @@ def _paired_all_device(in1, in2, out1, out2, mates, job, discard_untrimmed, disc
                     raise ValueError("Reads are improperly paired")
                 if n == 0:
                     return b"", b"", [], w
-                ee = [ww.modify(n, pre, post, None) for ww, (adapters, pre, post) in zip(ws, mates)]
+                ee = [ww.modify(n, pre, post, None) for ww, (_, pre, post) in zip(ws, mates)]
                 lens = [ww.end[:n] - ww.beg[:n] for ww in ws]
                 found = [ww.res.status[:n] == 1 for ww in ws]
                 keep = torch.ones(n, dtype=torch.bool, device=w.device)

@@ -11,7 +11,7 @@ there is NO collective on the data path.  What has to be combined afterwards is
 torch.distributed is used for those control-plane sums only (backend "nccl" = RCCL on the GPU
 box, "gloo" in CPU tests).
 """
-from typing import Dict, List, Sequence, Tuple
+from typing import Dict, List, Tuple
 
 import numpy as np
 
