@@ -306,7 +306,8 @@ class _Worker:
                                          self.res.status.data_ptr(), self._ws.data_ptr(), self._ws.numel(), sp))
         else:
             self.res.status[:n].zero_()                      # a mate without adapters: nothing is found
-        final_here = limits is not None and not post
+        rounds = int(self.opts.get("times", 1)) if self.plan is not None else 1
+        final_here = limits is not None and not post and rounds == 1
         lim = limits if final_here else (-1, -1, 0, 0)
         if not pre and final_here:
             _lib.check(L.cah_trim_decide_device(
@@ -319,6 +320,27 @@ class _Worker:
                 wbeg.data_ptr() if wbeg is not None else None, wlen.data_ptr(), self.seq_len.data_ptr(), n,
                 self.kinds.data_ptr(), *lim, 0 if final_here else 1,
                 self.beg.data_ptr(), self.end.data_ptr(), self.keep.data_ptr(), self.counters.data_ptr(), sp))
+        if rounds > 1:
+            # --times N (reference modifiers.py:367-380: match, trim, match what is left, ... until nothing is found):
+            # every further round matches the interval the last one kept.  A read without a match keeps its interval
+            # and cannot match later either, so "with adapters" is round 1's status (restored below for the filters)
+            # and every read can take every round; the later rounds' read / bp counters go to a scratch array.
+            first_status = self.res.status[:n].clone()
+            scratch = torch.zeros_like(self.counters)
+            for _ in range(rounds - 1):
+                rb = self.beg[:n].clone()
+                rl = (self.end[:n] - rb).contiguous()
+                ro = (seq_off + rb.to(torch.int64)).contiguous()
+                _lib.check(L.cah_match_batch(self.plan.handle, self.d_in.data_ptr(), ro.data_ptr(), rl.data_ptr(), n,
+                                             self.res.out6.data_ptr(), self.res.best_adapter.data_ptr(),
+                                             self.res.status.data_ptr(), self._ws.data_ptr(), self._ws.numel(), sp))
+                _lib.check(L.cah_trim_decide_window_device(
+                    self.res.out6.data_ptr(), self.res.status.data_ptr(), self.res.best_adapter.data_ptr(),
+                    rb.data_ptr(), rl.data_ptr(), self.seq_len.data_ptr(), n, self.kinds.data_ptr(), -1, -1, 0, 0, 1,
+                    self.beg.data_ptr(), self.end.data_ptr(), self.keep.data_ptr(), scratch.data_ptr(), sp))
+                keepalive += [rb, rl, ro]
+            self.res.status[:n].copy_(first_status)
+            keepalive += [first_status, scratch]
         ee = None
         if post:
             # the modifiers behind the adapter step (--poly-a, -l: cli.py:956-973) move the kept interval, then the
@@ -356,12 +378,12 @@ class _Worker:
                                                        ee.data_ptr(), ee_status.data_ptr(), sp))
                 self.ee_invalid |= (ee_status == _lib.INVALID).any()
                 keepalive += [ee_status, cur, qo]
-            if limits is not None:
-                _lib.check(L.cah_trim_filter_device(
-                    self.beg.data_ptr(), self.end.data_ptr(), self.res.status.data_ptr(),
-                    ee.data_ptr() if ee is not None else None, n, limits[0], limits[1],
-                    float(post["max_expected_errors"]) if ee is not None else -1.0, limits[2], limits[3],
-                    self.keep.data_ptr(), self.counters.data_ptr(), sp))
+        if limits is not None and not final_here:
+            _lib.check(L.cah_trim_filter_device(
+                self.beg.data_ptr(), self.end.data_ptr(), self.res.status.data_ptr(),
+                ee.data_ptr() if ee is not None else None, n, limits[0], limits[1],
+                float(post["max_expected_errors"]) if ee is not None else -1.0, limits[2], limits[3],
+                self.keep.data_ptr(), self.counters.data_ptr(), sp))
         self._keepalive = keepalive + [voff, wlen, wbeg, ee]
         return ee
 
@@ -552,6 +574,16 @@ def _adapter_list(adapters) -> list:
     if isinstance(adapters, (list, tuple)):
         return list(adapters)
     return [adapters]
+
+
+def _index_regroups(adapters) -> bool:
+    """would ``BatchAdapterCutter(index=True)`` put these adapters behind an ``AdapterIndex`` (reference
+    modifiers.py:124-141: more than one anchored 5' or more than one anchored 3' adapter the index accepts)?  Then the
+    adapters are tried in another order and looked up, not aligned: the general way's business."""
+    from .adapters import AdapterIndex
+    prefix = [a for a in adapters if isinstance(a, SingleAdapter) and AdapterIndex.is_acceptable(a, True)]
+    suffix = [a for a in adapters if isinstance(a, SingleAdapter) and a not in prefix and AdapterIndex.is_acceptable(a, False)]
+    return len(prefix) > 1 or len(suffix) > 1
 
 
 def _plan_for(adapters):
@@ -794,8 +826,9 @@ def trim_fastq_gpu(source: Union[str, BinaryIO, np.ndarray], out: Union[str, Bin
         raise ValueError("You cannot remove bases from more than two ends.")
     if len(cut) == 2 and cut[0] * cut[1] > 0:
         raise ValueError("You cannot remove bases from the same end twice.")
-    all_device = (adapters and times == 1 and action == "trim" and not revcomp and info_file is None
-                  and all(isinstance(a, SingleAdapter) and not a._reverse_reads for a in adapters))
+    all_device = (adapters and times >= 1 and action == "trim" and not revcomp and info_file is None
+                  and all(isinstance(a, SingleAdapter) and not a._reverse_reads for a in adapters)
+                  and not (index and _index_regroups(adapters)))
     pre = post = None
     if all_device and (cut or nextseq_trim is not None or quality_cutoff is not None):
         pre = {"cut": cut, "nextseq_trim": nextseq_trim, "quality_cutoff": quality_cutoff, "quality_base": quality_base}
@@ -804,7 +837,8 @@ def trim_fastq_gpu(source: Union[str, BinaryIO, np.ndarray], out: Union[str, Bin
     devices = _resolve_devices(devices)
     threads = max(1, int(threads))
     opts = {"discard_untrimmed": discard_untrimmed, "discard_trimmed": discard_trimmed,
-            "minimum_length": minimum_length, "maximum_length": maximum_length, "assemble": assemble, "pre": pre, "post": post}
+            "minimum_length": minimum_length, "maximum_length": maximum_length, "assemble": assemble, "pre": pre, "post": post,
+            "times": int(times)}
     from .pipeline import BatchTrimmer
     if all_device:
         plan, kinds = _plan_for(adapters)
@@ -990,10 +1024,10 @@ def _paired_pieces(source1, source2, chunk_bytes: int):
 
 def _mate_all_device(opts: Optional[dict]):
     """BatchTrimmer options of one mate -> (adapters, pre, post) if the all-device way can serve them, else None"""
-    from .adapters import PrefixAdapter, SuffixAdapter
     o = dict(opts or {})
     adapters = _adapter_list(o.pop("adapters", ()))
-    if o.pop("times", 1) != 1 or o.pop("action", "trim") != "trim" or o.pop("revcomp", False):
+    times = int(o.pop("times", 1))
+    if times < 1 or o.pop("action", "trim") != "trim" or o.pop("revcomp", False):
         return None
     index = o.pop("index", True)
     o.pop("rc_suffix", None)
@@ -1005,7 +1039,7 @@ def _mate_all_device(opts: Optional[dict]):
         return None
     if not all(isinstance(a, SingleAdapter) and not a._reverse_reads for a in adapters):
         return None
-    if index and sum(isinstance(a, (PrefixAdapter, SuffixAdapter)) for a in adapters) > 1:
+    if index and _index_regroups(adapters):
         return None                                          # (the reference regroups those behind an index: another order)
     if len(cut) > 2 or (len(cut) == 2 and cut[0] * cut[1] > 0):
         return None                                          # (BatchTrimmer raises the reference's error for these)
@@ -1014,7 +1048,7 @@ def _mate_all_device(opts: Optional[dict]):
         pre = {"cut": cut, "nextseq_trim": nextseq, "quality_cutoff": qcut, "quality_base": qbase}
     if poly_a or length is not None or max_ee is not None:
         post = {"poly_a": bool(poly_a), "poly_a_revcomp": bool(head), "length": length, "max_expected_errors": max_ee}
-    return adapters, pre, post
+    return adapters, pre, post, times
 
 
 def _paired_all_device(in1, in2, out1, out2, mates, job, discard_untrimmed, discard_trimmed, chunk_bytes, threads, devices):
@@ -1026,13 +1060,13 @@ def _paired_all_device(in1, in2, out1, out2, mates, job, discard_untrimmed, disc
     import torch
     min_len, max_len, mode, untrimmed_mode = job.min_len, job.max_len, job.mode, job.untrimmed_mode
     plans = []
-    for adapters, pre, post in mates:
-        plans.append(_plan_for(adapters) if adapters else (None, [0]))
+    for adapters, pre, post, times in mates:
+        plans.append((_plan_for(adapters) if adapters else (None, [0])) + (times,))
 
     def make_worker(dev, slot):
         ws = []
-        for (plan, kinds) in plans:
-            ws.append(_take_worker(plan, kinds, dev, {}))
+        for (plan, kinds, times) in plans:
+            ws.append(_take_worker(plan, kinds, dev, {"times": times}))
         w, mate = ws
         mate.stream = w.stream                               # one stream for the pair
         w.mate = mate
@@ -1063,14 +1097,14 @@ def _paired_all_device(in1, in2, out1, out2, mates, job, discard_untrimmed, disc
                     raise ValueError("Reads are improperly paired")
                 if n == 0:
                     return b"", b"", [], w
-                ee = [ww.modify(n, pre, post, None) for ww, (_, pre, post) in zip(ws, mates)]
+                ee = [ww.modify(n, pre, post, None) for ww, (_, pre, post, _t) in zip(ws, mates)]
                 lens = [ww.end[:n] - ww.beg[:n] for ww in ws]
                 found = [ww.res.status[:n] == 1 for ww in ws]
                 keep = torch.ones(n, dtype=torch.bool, device=w.device)
                 short = combine([None if m is None else (l < int(m)) for l, m in zip(lens, min_len)], mode)
                 long_ = combine([None if m is None else (l > int(m)) for l, m in zip(lens, max_len)], mode)
                 many = combine([None if (e is None) else (e > float(post["max_expected_errors"]))
-                                for e, (adapters, pre, post) in zip(ee, mates)], mode)
+                                for e, (_, pre, post, _t) in zip(ee, mates)], mode)
                 for slot, pred in ((1, short), (2, long_), (3, many)):
                     if pred is not None:
                         w.pair_counts[slot] += (keep & pred).sum()

@@ -80,8 +80,11 @@ if devices is not None:
     timed(f"all-device way with -q 0,10 in front of and --poly-a --max-ee 5 -m 20 behind the adapter step, devices={args.devices}",
           lambda: trim_fastq_gpu(fastq, None, [adapter], threads=args.threads, devices=devices, quality_cutoff=(0, 10), poly_a=True,
                                  max_expected_errors=5.0, minimum_length=20))
-    timed(f"the general way (--times 2: window arithmetic in numpy between the kernels), devices={args.devices}",
-          lambda: trim_fastq_gpu(fastq, None, [adapter], threads=args.threads, devices=devices, times=2, quality_cutoff=(0, 10)), reps=1)
+    timed(f"all-device way with -q 0,10 --times 2, devices={args.devices}",
+          lambda: trim_fastq_gpu(fastq, None, [adapter], threads=args.threads, devices=devices, times=2, quality_cutoff=(0, 10)))
+    timed(f"the general way (-q 0,10 --times 2 --action mask: window arithmetic in numpy between the kernels), devices={args.devices}",
+          lambda: trim_fastq_gpu(fastq, None, [adapter], threads=args.threads, devices=devices, times=2, quality_cutoff=(0, 10),
+                                 action="mask"), reps=1)
     if args.file:
         with open(args.file, "wb") as f:
             f.write(memoryview(fastq.numpy()))

@@ -14,11 +14,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 FQ = os.path.join(HERE, "golden", "fastq")
 
 
-def _fastq(rng, n, adapters, crlf=False, final_newline=True, lower=False):
+def _fastq(rng, n, adapters, crlf=False, final_newline=True, lower=False, twice=False):
     recs = []
     for i in range(n):
         L = rng.randint(0, 160)
         s = "".join(rng.choice("ACGT") for _ in range(L))
+        if twice and rng.random() < 0.4 and adapters:                   # (something for a second --times round to find)
+            pos = rng.randint(0, L)
+            s = s[:pos] + rng.choice(adapters) + s[pos:]
+            L = len(s)
         if rng.random() < 0.6 and adapters:
             ad = rng.choice(adapters)
             ad = ad[:rng.randint(1, len(ad))] if rng.random() < 0.5 else ad
@@ -65,10 +69,14 @@ def test_device_fastq_equals_host_pipeline(hip):
         ([A.BackAdapter(ad_seqs[0]), A.FrontAdapter(ad_seqs[1])], {"quality_cutoff": (0, 15), "poly_a": True, "length": 80,
                                                                "max_expected_errors": 2.5, "minimum_length": 10}),
         ([A.BackAdapter(ad_seqs[0])], {"length": -40, "max_expected_errors": 1.0, "discard_untrimmed": True}),
+        # --times N: every further round matches what the last one kept, still on the device
+        ([A.BackAdapter(ad_seqs[0]), A.FrontAdapter(ad_seqs[1]), A.AnywhereAdapter(ad_seqs[2])], {"times": 3, "minimum_length": 10}),
+        ([A.BackAdapter(ad_seqs[0]), A.BackAdapter(ad_seqs[1])], {"times": 2, "quality_cutoff": (0, 15), "poly_a": True,
+                                                              "discard_untrimmed": True}),
     ]
     for ci, (ads, opts) in enumerate(cases):
         for crlf, final_nl, chunk in ((False, True, 1 << 20), (True, True, 4096), (False, False, 700)):
-            data = _fastq(rng, 3000, ad_seqs, crlf=crlf, final_newline=final_nl, lower=ci == 1)
+            data = _fastq(rng, 3000, ad_seqs, crlf=crlf, final_newline=final_nl, lower=ci == 1, twice="times" in opts)
             want = io.BytesIO()
             ws = trim_fastq(io.BytesIO(data), want, ads, index=False, **opts)
             for source, assemble in ((io.BytesIO(data), "device"), (np.frombuffer(data, dtype=np.uint8), "device"),

@@ -196,8 +196,8 @@ def test_random_reads_against_the_modifier_chain_over_oracle_results(hip, orc, g
         "front": orc.KmerFinder(create_positions_and_kmers(ad_front, 3, 0.1, False, True), False, False),
     }
     CUT, QCUT, LENGTH, MAXEE, MINLEN = 2, (8, 12), 60, 1.5, 10
-    # --times 2 takes the general way (host-side window arithmetic between the kernels), --times 1 the all-device way
-    for TIMES, way in ((2, "general"), (1, "all-device")):
+    # both ways through a chunk (an info file makes it the general one: host-side window arithmetic between the kernels)
+    for TIMES, way in ((2, "general"), (2, "all-device"), (1, "all-device")):
 
         def chain(name, s, q):
             """cli.py:938-973: -u, -q, adapters (--times 2), --poly-a, -l; then --max-ee and -m (cli.py:735-912)"""
@@ -246,7 +246,8 @@ def test_random_reads_against_the_modifier_chain_over_oracle_results(hip, orc, g
             out = io.BytesIO()
             stats = trim_fastq_gpu(np.frombuffer(data, dtype=np.uint8), out, ads, cut=[CUT], quality_cutoff=QCUT,
                                    times=TIMES, poly_a=True, length=LENGTH, max_expected_errors=MAXEE,
-                                   minimum_length=MINLEN, chunk_bytes=chunk_bytes, threads=threads)
+                                   minimum_length=MINLEN, chunk_bytes=chunk_bytes, threads=threads,
+                                   info_file=io.BytesIO() if way == "general" else None)
             assert stats["way"] == way
             assert out.getvalue() == "".join(want).encode(), chunk_bytes
             assert stats["reads"] == len(recs) and stats["with_adapters"] == n_matched
@@ -267,9 +268,10 @@ def test_every_visible_gpu_is_fed(hip, tmp_path):
     n_dev = torch.cuda.device_count()
     visible = sorted(f"cuda:{i}" for i in range(n_dev))
     chunk = len(data) // (4 * n_dev)                            # at least four chunks per device
-    for opts in ({}, {"quality_cutoff": (0, 10), "times": 2}):
+    for way, opts in (("all-device", {}), ("general", {"quality_cutoff": (0, 10), "times": 2, "action": "mask"})):
         one = io.BytesIO()
         s1 = trim_fastq_gpu(str(path), one, [A.BackAdapter(ad)], chunk_bytes=chunk, threads=2, devices=[0], **opts)
+        assert s1["way"] == way
         for source in (str(path), np.frombuffer(data, dtype=np.uint8), io.BytesIO(data)):
             every = io.BytesIO()
             sa = trim_fastq_gpu(source, every, [A.BackAdapter(ad)], chunk_bytes=chunk, threads=2, devices="all", **opts)
@@ -396,7 +398,7 @@ def test_info_file_and_marking_actions_next_to_other_modifiers(hip, orc):
 
 
 def test_read_pairs_on_the_all_device_way_equal_the_host_pipeline(hip):
-    """trim_fastq_gpu_paired without --times / actions / linked adapters runs on the all-device way: both mates trimmed,
+    """trim_fastq_gpu_paired without actions / linked adapters runs on the all-device way: both mates trimmed,
     matched and formatted on the GPU, the pair filter as element-wise operations.  Bytes and counters against
     pipeline.trim_fastq_paired (which the reference's paired goldens pin) over option sets that exercise every
     modifier, every --pair-filter mode, per-mate length limits and the discards."""
@@ -407,8 +409,8 @@ def test_read_pairs_on_the_all_device_way_equal_the_host_pipeline(hip):
     rng = random.Random(99)
     ad1, ad2 = "AGATCGGAAGAGCACACGTCTGAACTCCAGTCA", "AGATCGGAAGAGCGTCGTGTAGGGAAAGAGTGT"
     n = 4000
-    f1 = _fastq(rng, n, [ad1])
-    f2 = _fastq(rng, n, [ad2]).replace(b"@read", b"@mate")
+    f1 = _fastq(rng, n, [ad1], twice=True)
+    f2 = _fastq(rng, n, [ad2], twice=True).replace(b"@read", b"@mate")
     cases = [
         (dict(adapters=[A.BackAdapter(ad1)]), dict(adapters=[A.BackAdapter(ad2)]), dict(minimum_length=20)),
         (dict(adapters=[A.BackAdapter(ad1)], quality_cutoff=(0, 20)), dict(adapters=[A.BackAdapter(ad2)], quality_cutoff=(5, 15)),
@@ -420,6 +422,8 @@ def test_read_pairs_on_the_all_device_way_equal_the_host_pipeline(hip):
         (dict(adapters=[A.BackAdapter(ad1)], length=-60), dict(adapters=[A.AnywhereAdapter(ad2[:20])], cut=[-3, 4]),
          dict(discard_trimmed=True, pair_filter="both")),
         (dict(quality_cutoff=(0, 25)), dict(adapters=[A.BackAdapter(ad2)]), dict(discard_untrimmed=True, minimum_length=10)),
+        (dict(adapters=[A.BackAdapter(ad1), A.FrontAdapter(ad2[:15])], times=2),
+         dict(adapters=[A.BackAdapter(ad2), A.BackAdapter(ad1[:12])], times=3, quality_cutoff=(0, 20)), dict(minimum_length=15)),
     ]
     for ci, (r1, r2, top) in enumerate(cases):
         w1, w2 = io.BytesIO(), io.BytesIO()
@@ -438,5 +442,5 @@ def test_read_pairs_on_the_all_device_way_equal_the_host_pipeline(hip):
             assert gs["quality_trimmed_bases"] == tuple(t.quality_trimmed_bases for t in ws["trimmers"]), ci
     # what the all-device way does not serve goes the general way and says so
     gs = trim_fastq_gpu_paired(io.BytesIO(f1), io.BytesIO(f2), io.BytesIO(), io.BytesIO(),
-                               dict(adapters=[A.BackAdapter(ad1)], times=2), dict(adapters=[A.BackAdapter(ad2)]))
+                               dict(adapters=[A.BackAdapter(ad1)], action="mask"), dict(adapters=[A.BackAdapter(ad2)]))
     assert gs["way"] == "general"
