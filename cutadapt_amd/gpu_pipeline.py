@@ -11,14 +11,14 @@ visible GPUs -- and writes the results back in chunk order: the reference's read
 writer layout (reference src/cutadapt/runners.py:96-245) with GPUs as the workers.
 
 Two ways through a chunk once it is indexed:
-  * the all-device way (single-end, any number of single, non-rightmost adapters, ``--times 1``, action ``trim``,
+  * the all-device way (any number of single, non-rightmost adapters with ``--times N``, or one linked adapter; action ``trim``,
     ``-u`` / ``--nextseq-trim`` / ``-q`` in front of the adapter step, ``--poly-a`` / ``-l`` / ``--max-ee`` / ``-m`` /
     ``-M`` / ``--discard-(un)trimmed`` behind it -- the usual ``cutadapt -q 20 -a ADAPTER -m 20`` and more): trim,
     match, decide and format without a byte of per-read data touching the host (``cah_trim_decide_device`` /
     ``cah_trim_decide_window_device`` / ``cah_trim_filter_device``);
-  * the general way (everything else ``pipeline.BatchTrimmer`` does: ``--times N``, every action, linked and rightmost adapters, ``--revcomp``, ``--info-file``,
-    and read pairs through ``trim_fastq_gpu_paired``): the modifiers run as kernels on windows into the raw chunk
-    in HBM (``DeviceFastqChunk``: reads AND qualities are used in place), the window arithmetic between them is
+  * the general way (everything else ``pipeline.BatchTrimmer`` does: every action, rightmost adapters, linked ones among others,
+    ``--revcomp``, ``--info-file``, ``--pair-adapters``, adapter sets regrouped behind an ``AdapterIndex``): the
+    modifiers run as kernels on windows into the raw chunk in HBM (``DeviceFastqChunk``: reads AND qualities are used in place), the window arithmetic between them is
     numpy on 4-byte-per-read arrays, and plain slicing is formatted on the device again.  What cannot be expressed
     as a slice of the raw chunk (mask / lowercase, reverse-complemented records, info files) is formatted by the
     host writers from the device's record index -- no host parsing in either way.
@@ -36,14 +36,14 @@ import ctypes as C
 import os
 import threading
 import time
-from collections import deque
+from collections import deque, namedtuple
 from concurrent.futures import ThreadPoolExecutor
 from typing import BinaryIO, Dict, Optional, Sequence, Tuple, Union
 
 import numpy as np
 
 from . import _lib
-from .adapters import AnywhereAdapter, MultipleAdapters, SingleAdapter
+from .adapters import AnywhereAdapter, LinkedAdapter, MultipleAdapters, SingleAdapter
 
 DEFAULT_GPU_CHUNK_BYTES = 64 * 1024 * 1024
 
@@ -297,7 +297,46 @@ class _Worker:
                 wlen = kept.contiguous()
             wbeg = wbeg.contiguous()
         voff = seq_off if wbeg is None else (seq_off + wbeg.to(torch.int64)).contiguous()
-        if self.plan is not None:
+        linked = isinstance(self.plan, _LinkedPlans)
+        if linked:
+            # one linked adapter (reference adapters.py:1215-1227): the 5' plan on the window, the 3' plan on what is
+            # behind the 5' match (cah_linked_views), the required / optional verdict and the kept interval as a
+            # handful of element-wise operations on this stream
+            lp = self.plan
+            ws_need = max(int(L.cah_plan_workspace_bytes(lp.front.handle, n)), int(L.cah_plan_workspace_bytes(lp.back.handle, n)))
+            if self._ws is None or self._ws.numel() < ws_need:
+                self._ws = torch.empty(ws_need + ws_need // 4, dtype=torch.uint8, device=self.device)
+            f_out6 = torch.empty((n, 6), dtype=torch.int32, device=self.device)
+            f_status = torch.empty(n, dtype=torch.uint8, device=self.device)
+            f_best = torch.empty(n, dtype=torch.int32, device=self.device)
+            starts = torch.empty(n, dtype=torch.int64, device=self.device)
+            vlens = torch.empty(n, dtype=torch.int32, device=self.device)
+            wl = wlen.contiguous()
+            _lib.check(L.cah_match_batch(lp.front.handle, self.d_in.data_ptr(), voff.data_ptr(), wl.data_ptr(), n,
+                                         f_out6.data_ptr(), f_best.data_ptr(), f_status.data_ptr(),
+                                         self._ws.data_ptr(), self._ws.numel(), sp))
+            _lib.check(L.cah_linked_views(f_out6.data_ptr(), f_status.data_ptr(), voff.data_ptr(), wl.data_ptr(), 0, n,
+                                          starts.data_ptr(), vlens.data_ptr(), sp))
+            _lib.check(L.cah_match_batch(lp.back.handle, self.d_in.data_ptr(), starts.data_ptr(), vlens.data_ptr(), n,
+                                         self.res.out6.data_ptr(), self.res.best_adapter.data_ptr(),
+                                         self.res.status.data_ptr(), self._ws.data_ptr(), self._ws.numel(), sp))
+            b_status = self.res.status[:n]
+            F, B = f_status == 1, b_status == 1
+            ok = B if lp.back_required else (B | F)           # LinkedAdapter.match_to: None unless ...
+            if lp.front_required:
+                ok = ok & F
+            w0 = wbeg if wbeg is not None else torch.zeros(n, dtype=torch.int32, device=self.device)
+            b = w0 + torch.where(ok & F, f_out6[:, 3], torch.zeros_like(wl))
+            e = torch.where(ok & B, b + self.res.out6[:n, 2], w0 + wl)
+            self.counters[0] += n
+            self.counters[1] += ok.sum()
+            self.counters[2] += seq_len.sum()
+            self.counters[6] += ((f_status == 2) | (b_status == 2)).sum()
+            self.beg[:n].copy_(b)
+            self.end[:n].copy_(e)
+            b_status.copy_(ok.to(torch.uint8))                # "with adapters", as the filters read it
+            keepalive += [f_out6, f_status, f_best, starts, vlens, wl]
+        elif self.plan is not None:
             ws_need = int(L.cah_plan_workspace_bytes(self.plan.handle, n))
             if self._ws is None or self._ws.numel() < ws_need:
                 self._ws = torch.empty(ws_need + ws_need // 4, dtype=torch.uint8, device=self.device)
@@ -306,10 +345,12 @@ class _Worker:
                                          self.res.status.data_ptr(), self._ws.data_ptr(), self._ws.numel(), sp))
         else:
             self.res.status[:n].zero_()                      # a mate without adapters: nothing is found
-        rounds = int(self.opts.get("times", 1)) if self.plan is not None else 1
-        final_here = limits is not None and not post and rounds == 1
+        rounds = int(self.opts.get("times", 1)) if (self.plan is not None and not linked) else 1
+        final_here = limits is not None and not post and rounds == 1 and not linked
         lim = limits if final_here else (-1, -1, 0, 0)
-        if not pre and final_here:
+        if linked:
+            pass                                             # (intervals and status are in place)
+        elif not pre and final_here:
             _lib.check(L.cah_trim_decide_device(
                 self.res.out6.data_ptr(), self.res.status.data_ptr(), self.res.best_adapter.data_ptr(),
                 self.seq_len.data_ptr(), n, self.kinds.data_ptr(), *lim,
@@ -586,8 +627,25 @@ def _index_regroups(adapters) -> bool:
     return len(prefix) > 1 or len(suffix) > 1
 
 
+_LinkedPlans = namedtuple("_LinkedPlans", "front back front_required back_required")
+
+
+def _all_device_adapters(adapters, times: int, index: bool) -> bool:
+    """adapter sets ``_Worker.modify`` serves: single non-rightmost adapters (any number, any --times), or ONE linked
+    adapter of such parts (--times 1)"""
+    if len(adapters) == 1 and isinstance(adapters[0], LinkedAdapter):
+        a = adapters[0]
+        return times == 1 and not a.front_adapter._reverse_reads and not a.back_adapter._reverse_reads
+    return (times >= 1 and all(isinstance(a, SingleAdapter) and not a._reverse_reads for a in adapters)
+            and not (index and _index_regroups(adapters)))
+
+
 def _plan_for(adapters):
     """the fused plan + adapter kinds of the all-device way"""
+    if len(adapters) == 1 and isinstance(adapters[0], LinkedAdapter):
+        a = adapters[0]
+        return _LinkedPlans(a.front_adapter._fused_plan, a.back_adapter._fused_plan, bool(a.front_required),
+                            bool(a.back_required)), [0]
     plan = adapters[-1]._fused_plan if len(adapters) == 1 else _lib.Plan([a.matcher_spec() for a in adapters])
     kinds = [2 if isinstance(a, AnywhereAdapter) else (1 if a._remove_before else 0) for a in adapters]
     return plan, kinds
@@ -826,9 +884,8 @@ def trim_fastq_gpu(source: Union[str, BinaryIO, np.ndarray], out: Union[str, Bin
         raise ValueError("You cannot remove bases from more than two ends.")
     if len(cut) == 2 and cut[0] * cut[1] > 0:
         raise ValueError("You cannot remove bases from the same end twice.")
-    all_device = (adapters and times >= 1 and action == "trim" and not revcomp and info_file is None
-                  and all(isinstance(a, SingleAdapter) and not a._reverse_reads for a in adapters)
-                  and not (index and _index_regroups(adapters)))
+    all_device = (adapters and action == "trim" and not revcomp and info_file is None
+                  and _all_device_adapters(adapters, int(times), index))
     pre = post = None
     if all_device and (cut or nextseq_trim is not None or quality_cutoff is not None):
         pre = {"cut": cut, "nextseq_trim": nextseq_trim, "quality_cutoff": quality_cutoff, "quality_base": quality_base}
@@ -1037,10 +1094,8 @@ def _mate_all_device(opts: Optional[dict]):
     length, max_ee = o.pop("length", None), o.pop("max_expected_errors", None)
     if o:                                                    # an option this way does not know
         return None
-    if not all(isinstance(a, SingleAdapter) and not a._reverse_reads for a in adapters):
-        return None
-    if index and _index_regroups(adapters):
-        return None                                          # (the reference regroups those behind an index: another order)
+    if adapters and not _all_device_adapters(adapters, times, index):
+        return None                                          # (rightmost parts, adapters regrouped behind an index, ...)
     if len(cut) > 2 or (len(cut) == 2 and cut[0] * cut[1] > 0):
         return None                                          # (BatchTrimmer raises the reference's error for these)
     pre = post = None

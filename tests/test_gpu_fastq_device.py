@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 FQ = os.path.join(HERE, "golden", "fastq")
 
 
-def _fastq(rng, n, adapters, crlf=False, final_newline=True, lower=False, twice=False):
+def _fastq(rng, n, adapters, crlf=False, final_newline=True, lower=False, twice=False, lead=None):
     recs = []
     for i in range(n):
         L = rng.randint(0, 160)
@@ -28,6 +28,8 @@ def _fastq(rng, n, adapters, crlf=False, final_newline=True, lower=False, twice=
             ad = ad[:rng.randint(1, len(ad))] if rng.random() < 0.5 else ad
             pos = rng.randint(0, L)
             s = (s[:pos] + ad + s[pos:])[:max(L, 1)] if rng.random() < 0.5 else s[:pos] + ad
+        if lead and rng.random() < 0.5:                                 # (a 5' adapter in front: linked adapters)
+            s = (lead if rng.random() < 0.7 else lead[1:]) + s
         if rng.random() < 0.15:
             s += "A" * rng.randint(2, 30)                               # (a poly-A tail, sometimes with an error in it)
             if rng.random() < 0.3 and len(s) > 4:
@@ -73,10 +75,17 @@ def test_device_fastq_equals_host_pipeline(hip):
         ([A.BackAdapter(ad_seqs[0]), A.FrontAdapter(ad_seqs[1]), A.AnywhereAdapter(ad_seqs[2])], {"times": 3, "minimum_length": 10}),
         ([A.BackAdapter(ad_seqs[0]), A.BackAdapter(ad_seqs[1])], {"times": 2, "quality_cutoff": (0, 15), "poly_a": True,
                                                               "discard_untrimmed": True}),
+        # one linked adapter: 5' plan, view, 3' plan, verdict and interval on the device (every required / optional mix)
+        ([A.LinkedAdapter(A.PrefixAdapter(ad_seqs[2]), A.BackAdapter(ad_seqs[0]), True, False, "l1")], {"minimum_length": 5}),
+        ([A.LinkedAdapter(A.PrefixAdapter(ad_seqs[2]), A.BackAdapter(ad_seqs[0]), True, True, "l2")], {"discard_untrimmed": True}),
+        ([A.LinkedAdapter(A.FrontAdapter(ad_seqs[2]), A.BackAdapter(ad_seqs[0]), False, True, "l3")],
+         {"quality_cutoff": (5, 15), "poly_a": True, "maximum_length": 100}),
+        ([A.LinkedAdapter(A.FrontAdapter(ad_seqs[2]), A.SuffixAdapter(ad_seqs[1]), False, False, "l4")], {"cut": [1], "length": 50}),
     ]
     for ci, (ads, opts) in enumerate(cases):
         for crlf, final_nl, chunk in ((False, True, 1 << 20), (True, True, 4096), (False, False, 700)):
-            data = _fastq(rng, 3000, ad_seqs, crlf=crlf, final_newline=final_nl, lower=ci == 1, twice="times" in opts)
+            data = _fastq(rng, 3000, ad_seqs, crlf=crlf, final_newline=final_nl, lower=ci == 1, twice="times" in opts,
+                          lead=ad_seqs[2] if isinstance(ads[0], A.LinkedAdapter) else None)
             want = io.BytesIO()
             ws = trim_fastq(io.BytesIO(data), want, ads, index=False, **opts)
             for source, assemble in ((io.BytesIO(data), "device"), (np.frombuffer(data, dtype=np.uint8), "device"),
