@@ -82,6 +82,10 @@ if devices is not None:
                                  max_expected_errors=5.0, minimum_length=20))
     timed(f"all-device way with -q 0,10 --times 2, devices={args.devices}",
           lambda: trim_fastq_gpu(fastq, None, [adapter], threads=args.threads, devices=devices, times=2, quality_cutoff=(0, 10)))
+    from cutadapt_amd.adapters import FrontAdapter, LinkedAdapter
+    linked = LinkedAdapter(FrontAdapter("ACGTACGTTT"), BackAdapter(workloads.TRUSEQ_R1, max_errors=0.1, min_overlap=3), False, True, "linked")
+    timed(f"all-device way with one linked adapter (optional 5' part ... required 3' TruSeq) and -q 0,10 -m 20, devices={args.devices}",
+          lambda: trim_fastq_gpu(fastq, None, [linked], threads=args.threads, devices=devices, quality_cutoff=(0, 10), minimum_length=20))
     timed(f"the general way (--times 2 --action mask: window arithmetic in numpy between the kernels, records marked by the host writer), devices={args.devices}",
           lambda: trim_fastq_gpu(fastq, None, [adapter], threads=args.threads, devices=devices, times=2, action="mask"))
     timed(f"the general way (-q 0,10 --action mask: marked records rewritten on the host in front of the later modifiers), devices={args.devices}",
