@@ -1,0 +1,116 @@
+#!/usr/bin/env python3
+"""How full are the cost scan's waves?  (CPU-only analysis with the host model of back_scan.h; test infrastructure.)
+
+The scan (k_back_scan, csrc/kernels.hip) runs 64 survivors of the prefilter per wave in lock step, one 16-column chunk
+per iteration, until every lane is done (exact match found, early stop, read end) -- a lane that finishes early idles.
+This script replays that on the C2 workload: the oracle's generator and KmerFinder give the survivors, the host model
+(tests/host_model/back_model.cpp = back_scan.h under g++) gives every survivor's window start (bs_align_window of the
+prefilter's column-skipping position) and the column its scan ends at; survivors are queued the kernel's way (tiles of
+8192 reads, counting sort by key inside a tile) and cut into waves of 64.
+Prints: chunks a wave executes vs. chunks its lanes need (lane utilisation), with and without the straggler rule
+(<= 12 lanes left with >= 32 columns to go leave the wave), and what a perfect re-packing of unfinished lanes after
+every chunk would execute.
+Usage: python tests/host_model/scan_occupancy.py [n_reads]"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from oracle import oracle as orc                                    # noqa: E402
+from cutadapt_amd.kmer_heuristic import create_positions_and_kmers  # noqa: E402
+import test_back_scan_model as tm                                   # noqa: E402
+
+n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+TILE, WAVE, RETRY_AT = 8192, 64, 12
+ad, rate, O, L = tm.TRUSEQ, 0.1, 3, 150
+m, k = len(ad), int(rate * len(ad))
+model = tm.model.__wrapped__() if hasattr(tm.model, "__wrapped__") else None
+if model is None:
+    import subprocess
+    if not os.path.exists(tm.SO):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", tm.SRC, "-o", tm.SO], check=True)
+    model = C.CDLL(tm.SO)
+    vp, i64 = C.c_void_p, C.c_int64
+    model.bm_locate_batch.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp, vp, C.c_int32, vp, C.c_int32]
+    model.bm_skip_columns.argtypes = [C.c_char_p, C.c_int, C.c_int, vp, vp, i64, vp]
+
+seqs, offsets = orc.synth_reads(2, 0, n_reads, L, [ad])
+finder = orc.KmerFinder(create_positions_and_kmers(ad, O, rate, True, False), False, False)
+present = np.asarray(finder.kmers_present_batch(seqs, offsets)).astype(bool)
+surv = np.flatnonzero(present)
+print(f"{n_reads} reads, {len(surv)} survivors ({len(surv) / n_reads:.3f})")
+# the survivors as a batch of their own
+s_seqs = seqs.reshape(n_reads, L)[surv].reshape(-1).copy()
+s_off = np.arange(len(surv) + 1, dtype=np.int64) * L
+j0 = np.zeros(len(surv), dtype=np.int32)
+model.bm_skip_columns(ad.encode(), m, k, s_seqs.ctypes.data, s_off.ctypes.data, len(surv), j0.ctypes.data)
+key = (j0 + m + k + 1) >> 2                                         # (j0 = max(0, 4 key - m - k - 1); key 0..9 collapse: same window)
+blob, _ = tm.matcher_blob(ad, rate, O)
+out6 = np.zeros((len(surv), 6), dtype=np.int32)
+status = np.zeros(len(surv), dtype=np.uint8)
+cls = np.zeros(len(surv), dtype=np.uint8)
+jend = np.zeros(len(surv), dtype=np.int32)
+rc = model.bm_locate_batch(blob, s_seqs.ctypes.data, s_off.ctypes.data, len(surv), j0.ctypes.data, out6.ctypes.data,
+                           status.ctypes.data, cls.ctypes.data, None, 16, jend.ctypes.data, -1)
+assert rc == 0
+j0a = np.maximum(0, L - ((L - j0 + 15) & ~15))                      # bs_align_window
+need = (jend - j0a + 15) // 16                                      # chunks this lane is at work
+names = ["NONE", "EXACT_FULL", "EXACT_TAIL", "DP", "SUBS_FULL", "INDEL1_FULL"]
+c7 = cls & 7
+print("classes:", {names[i] if i < len(names) else i: round(float((c7 == i).mean()), 3) for i in np.unique(c7)},
+      "stopped early:", round(float(((cls & 8) != 0).mean()), 3))
+print(f"window start (aligned): mean {j0a.mean():.1f}; chunks needed per survivor: mean {need.mean():.2f}, "
+      f"histogram {np.bincount(need, minlength=11).tolist()}")
+# the queue: tiles of 8192 reads, survivors of a tile sorted by key (counting sort: stable)
+order = np.lexsort((np.arange(len(surv)), key, surv // TILE))
+need_q, jend_q = need[order], jend[order]
+n_w = (len(order) + WAVE - 1) // WAVE
+pad = n_w * WAVE - len(order)
+nw = np.concatenate([need_q, np.zeros(pad, dtype=need_q.dtype)]).reshape(n_w, WAVE)
+lane_chunks = int(nw.sum())
+wave_chunks = int(nw.max(axis=1).sum())
+print(f"lock step, no straggler rule: {wave_chunks} wave-chunks x 64 lanes for {lane_chunks} lane-chunks: "
+      f"utilisation {lane_chunks / (64 * wave_chunks):.3f}")
+# the straggler rule: at the head of chunk c, if <= 12 lanes are left and some have >= 32 columns to go, those leave
+# (they are rescanned from their window start in waves packed 64 deep); the wave runs on for the others
+jq = np.concatenate([jend_q, np.zeros(pad, dtype=jend_q.dtype)]).reshape(n_w, WAVE)
+j0q = np.concatenate([j0a[order], np.zeros(pad, dtype=j0a.dtype)]).reshape(n_w, WAVE)
+first_wave_chunks = 0
+strag_need = []
+for w in range(n_w):
+    nd, je, js = nw[w].copy(), jq[w], j0q[w]
+    c = 0
+    while True:
+        left = nd > c
+        if not left.any():
+            break
+        if left.sum() <= RETRY_AT:
+            # columns to go to the READ END decide (n - j >= 32), as in the kernel
+            far = left & (L - (js + 16 * c) >= 32)
+            if far.any():
+                strag_need += nd[far].tolist()
+                nd[far] = 0
+                continue
+        c += 1
+    first_wave_chunks += c
+strag_need = np.sort(np.array(strag_need, dtype=np.int64))[::-1]
+sw = (len(strag_need) + WAVE - 1) // WAVE
+strag_chunks = int(sum(strag_need[i * WAVE:(i + 1) * WAVE].max() for i in range(sw))) if sw else 0
+tot = first_wave_chunks + strag_chunks
+print(f"with the straggler rule: {first_wave_chunks} + {strag_chunks} (second launch, {len(strag_need)} reads) = {tot} wave-chunks: "
+      f"utilisation {(lane_chunks + int(strag_need.sum())) / (64 * tot):.3f} of executed lanes, "
+      f"{lane_chunks / (64 * tot):.3f} counting the rescans as overhead")
+# bounds for re-packing
+print(f"perfect packing (every executed lane useful): {(lane_chunks + 63) // 64} wave-chunks "
+      f"= {((lane_chunks + 63) // 64) / tot:.3f} of today's")
+# sorting each tile's survivors by (key, then needed chunks) is not available before the scan; but grouping by key
+# alone is what the queue does.  What if waves were formed from equal-need lanes (oracle knowledge, upper bound of
+# any static grouping)?
+need_sorted = np.sort(need)[::-1]
+nsw = np.concatenate([need_sorted, np.zeros(pad, dtype=need_sorted.dtype)]).reshape(n_w, WAVE)
+print(f"waves of equal need (clairvoyant static grouping): {int(nsw.max(axis=1).sum())} wave-chunks")
