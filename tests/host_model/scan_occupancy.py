@@ -50,6 +50,27 @@ s_off = np.arange(len(surv) + 1, dtype=np.int64) * L
 j0 = np.zeros(len(surv), dtype=np.int32)
 model.bm_skip_columns(ad.encode(), m, k, s_seqs.ctypes.data, s_off.ctypes.data, len(surv), j0.ctypes.data)
 key = (j0 + m + k + 1) >> 2                                         # (j0 = max(0, 4 key - m - k - 1); key 0..9 collapse: same window)
+if "--refined" in sys.argv:
+    # DESIGN 11's refined window start: min over the adapter's k+1 chunks c of (first end of c - end offset of c in
+    # the adapter) - k - 1, capped at n - m - k - 1 (the tail rows' paths).  f_c by brute force here.
+    R = s_seqs.reshape(len(surv), L)
+    chunks, base, extra = k + 1, m // (k + 1), m % (k + 1)
+    best = np.full(len(surv), L - m, dtype=np.int64)                # the cap, before the - k - 1
+    pos = 0
+    for c in range(chunks):
+        ln = base + (1 if c < extra else 0)
+        hit = np.ones((len(surv), L - ln + 1), dtype=bool)
+        for t in range(ln):
+            hit &= R[:, t:L - ln + 1 + t] == ord(ad[pos + t])
+        first = np.where(hit.any(axis=1), hit.argmax(axis=1) + ln, 10 ** 6)    # first END (1-based column) of chunk c
+        best = np.minimum(best, first - (pos + ln))
+        pos += ln
+    j0_new = np.maximum(0, best - k - 1).astype(np.int32)
+    assert (j0_new >= j0).all()
+    print(f"refined window start: mean {j0_new.mean():.1f} against {j0.mean():.1f}; later by >= 16 columns for "
+          f"{(j0_new - j0 >= 16).mean():.3f} of the survivors")
+    j0_plain = j0
+    j0 = j0_new
 blob, _ = tm.matcher_blob(ad, rate, O)
 out6 = np.zeros((len(surv), 6), dtype=np.int32)
 status = np.zeros(len(surv), dtype=np.uint8)
@@ -58,6 +79,13 @@ jend = np.zeros(len(surv), dtype=np.int32)
 rc = model.bm_locate_batch(blob, s_seqs.ctypes.data, s_off.ctypes.data, len(surv), j0.ctypes.data, out6.ctypes.data,
                            status.ctypes.data, cls.ctypes.data, None, 16, jend.ctypes.data, -1)
 assert rc == 0
+if "--refined" in sys.argv:
+    # exactness: the windowed scan's results (shortcut classes + windowed DP of the model) against the oracle's locate
+    oa = orc.Aligner(ad, rate, 14, False, False, 1, O)
+    want6, want_st = oa.locate_batch(s_seqs, s_off)
+    bad = np.flatnonzero((status != want_st) | (out6 != want6).any(axis=1))
+    print(f"refined windows against the oracle's locate: {len(bad)} of {len(surv)} survivors differ")
+    assert len(bad) == 0, (bad[:5], out6[bad[:5]], want6[bad[:5]])
 j0a = np.maximum(0, L - ((L - j0 + 15) & ~15))                      # bs_align_window
 need = (jend - j0a + 15) // 16                                      # chunks this lane is at work
 names = ["NONE", "EXACT_FULL", "EXACT_TAIL", "DP", "SUBS_FULL", "INDEL1_FULL"]
@@ -67,6 +95,8 @@ print("classes:", {names[i] if i < len(names) else i: round(float((c7 == i).mean
 print(f"window start (aligned): mean {j0a.mean():.1f}; chunks needed per survivor: mean {need.mean():.2f}, "
       f"histogram {np.bincount(need, minlength=11).tolist()}")
 # the queue: tiles of 8192 reads, survivors of a tile sorted by key (counting sort: stable)
+if "--refined" in sys.argv and "--sort-refined" in sys.argv:
+    key = (j0 + m + k + 1) >> 2                                     # the queue sorted by the refined start
 order = np.lexsort((np.arange(len(surv)), key, surv // TILE))
 need_q, jend_q = need[order], jend[order]
 n_w = (len(order) + WAVE - 1) // WAVE
