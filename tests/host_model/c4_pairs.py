@@ -77,7 +77,41 @@ for ad in ads:
     for s_, h in hits.items():
         widest = np.maximum(widest, np.where(h, 64 if s_ == 0 else -s_ + k + 1, 0))
     need_cols.append(widest[any_hit])
+    if "--check-windows" in sys.argv:
+        # the host model of the scan (back_scan.h under g++) with the set-aware window starts against the oracle's locate
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import ctypes as C
+        import test_back_scan_model as tm
+        if "model" not in globals():
+            model = C.CDLL(tm.SO)
+            vp, i64 = C.c_void_p, C.c_int64
+            model.bm_locate_batch.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp, vp, C.c_int32, vp, C.c_int32]
+            model.bm_skip_columns.argtypes = [C.c_char_p, C.c_int, C.c_int, vp, vp, i64, vp]
+            checked = differ = 0
+        idx = np.flatnonzero(any_hit)
+        sub = R[idx].reshape(-1).copy()
+        off = np.arange(len(idx) + 1, dtype=np.int64) * L
+        j0 = np.zeros(len(idx), dtype=np.int32)
+        model.bm_skip_columns(ad.encode(), m, k, sub.ctypes.data, off.ctypes.data, len(idx), j0.ctypes.data)
+        w = widest[idx]
+        j0 = np.where(hits[0][idx], j0, np.maximum(0, L - w)).astype(np.int32)     # tail-only pairs: reach + k + 1 columns
+        blob, _ = tm.matcher_blob(ad, 0.1, 3)
+        out6 = np.zeros((len(idx), 6), dtype=np.int32)
+        status = np.zeros(len(idx), dtype=np.uint8)
+        for stop_every in (0, 16):
+            rc = model.bm_locate_batch(blob, sub.ctypes.data, off.ctypes.data, len(idx), j0.ctypes.data, out6.ctypes.data,
+                                       status.ctypes.data, None, None, stop_every, None, -1)
+            assert rc == 0
+            want6, want_st = orc.Aligner(ad, 0.1, 14, False, False, 1, 3).locate_batch(sub, off)
+            bad = np.flatnonzero((status != want_st) | (out6 != want6).any(axis=1))
+            checked += len(idx)
+            differ += len(bad)
+            if len(bad):
+                r = int(bad[0])
+                print("DIFF", ad, bytes(R[idx[r]]).decode(), "j0", j0[r], "model", status[r], out6[r].tolist(), "oracle", want_st[r], want6[r].tolist())
 need_cols = np.concatenate(need_cols)
+if "--check-windows" in sys.argv:
+    print(f"set-aware windows, host model against the oracle: {differ} of {checked} (pair, form) results differ")
 print(f"{n} reads x {len(ads)} adapters: {pairs / n:.2f} pairs per read pass the k-mer sets")
 for s_ in sorted(per_set):
     name = "whole read" if s_ == 0 else f"last {-s_:2d}"
