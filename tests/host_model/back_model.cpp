@@ -206,4 +206,34 @@ void bm_skip_columns(const char* adapter, int m, int k, const uint8_t* seqs, con
     }
 }
 
+// A later window start than bm_skip_columns', not used by the kernels yet: a whole-adapter alignment of
+// cost <= k contains one of the k+1 chunks unedited (pigeonhole); if that is chunk c (adapter end offset E_c), ending
+// at read column x >= f_c (the first end of chunk c in the read), at most k errors lie in front of it, so the alignment
+// starts at column >= x - E_c - k.  j0 = max(0, min(min_c (f_c - E_c), n - m) - k - 1): the n - m term keeps the paths
+// of the last column's rows (partial adapters at the read end) inside the window.
+void bm_refined_columns(const char* adapter, int m, int k, const uint8_t* seqs, const int64_t* offsets,
+                        int64_t n_reads, int32_t* j0s) {
+    const int chunks = k + 1, base = m / chunks, extra = m % chunks;
+    for (int64_t r = 0; r < n_reads; r++) {
+        const uint8_t* q = seqs + offsets[r];
+        const int n = (int)(offsets[r + 1] - offsets[r]);
+        int best = n - m;
+        int pos = 0;
+        for (int c = 0; c < chunks; c++) {
+            const int len = base + (c < extra ? 1 : 0);
+            for (int st = 0; st + len <= n; st++) {
+                bool ok = true;
+                for (int t = 0; t < len && ok; t++) {
+                    uint8_t ch = q[st + t];
+                    if (ch >= 'a' && ch <= 'z') ch = (uint8_t)(ch - 32);
+                    ok = ch == (uint8_t)adapter[pos + t];
+                }
+                if (ok) { best = std::min(best, st + len - (pos + len)); break; }
+            }
+            pos += len;
+        }
+        j0s[r] = std::max(0, best - k - 1);
+    }
+}
+
 }  // extern "C"

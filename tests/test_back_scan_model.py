@@ -30,6 +30,7 @@ def model():
     vp, i64 = C.c_void_p, C.c_int64
     L.bm_locate_batch.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp, vp, C.c_int32, vp, C.c_int32]
     L.bm_skip_columns.argtypes = [C.c_char_p, C.c_int, C.c_int, vp, vp, i64, vp]
+    L.bm_refined_columns.argtypes = [C.c_char_p, C.c_int, C.c_int, vp, vp, i64, vp]
     L.bm_matcher_size.restype = C.c_size_t
     return L
 
@@ -70,8 +71,8 @@ def compare(L, adapter, rate, min_overlap, seqs, offsets, wr=False, wq=False, sk
     if skip:
         n = len(offsets) - 1
         j0s = np.zeros(n, dtype=np.int32)
-        L.bm_skip_columns(adapter.encode(), len(adapter), int(rate * len(adapter)), seqs.ctypes.data,
-                          offsets.ctypes.data, n, j0s.ctypes.data)
+        fn = L.bm_refined_columns if skip == "refined" else L.bm_skip_columns
+        fn(adapter.encode(), len(adapter), int(rate * len(adapter)), seqs.ctypes.data, offsets.ctypes.data, n, j0s.ctypes.data)
     # the early stop looked for once per 16-column chunk (what the kernel does), after every column (the tightest
     # use of the rule) and never (the scan always reaches the read end)
     # ... each in the form the launcher picks for the adapter (32-bit words, + explicit rows for 33 / 34 characters)
@@ -433,3 +434,38 @@ def test_tails_with_substitutions(model):
             if counts is not None:
                 tails += int(counts[2])
     assert tails > 40000, tails
+
+
+def test_refined_window_start(model):
+    """A window start the kernels do not use yet (bm_refined_columns in the host model): the chunks' first
+    positions instead of the first hit of any chunk.  Exactness of the rule, fuzzed here so that the kernel work can
+    rely on it: random adapters and rates, ragged reads with up to two edited copies (indels included), the TruSeq
+    shapes of the benchmark, and second copies / partial copies at every distance."""
+    rng = np.random.default_rng(77)
+    done = 0
+    for it in range(200):
+        m = int(rng.integers(4, 65))
+        adapter = "".join(rng.choice(list("ACGT"), size=m)) if it % 5 else "".join(rng.choice(list("AC"), size=m))
+        rate = float(rng.choice([0.0, 0.05, 0.1, 0.15, 0.2, 0.3]))
+        min_overlap = int(rng.choice([1, 3, 5, m]))
+        seqs, offsets = random_reads(rng, adapter, 600, int(rng.choice([20, 60, 100, 170])),
+                                     float(rng.choice([0.0, 0.03, 0.1, 0.2])), float(rng.choice([0.0, 0.01])))
+        if compare(model, adapter, rate, min_overlap, seqs, offsets, skip="refined", label=f"refined {it}") is not None:
+            done += 1
+    assert done > 150
+    for seed, gen in ((12, dict(p_adapter=0.25, p_edit=0.02, p_n=0.005)), (15, dict(p_adapter=0.9, p_edit=0.1, p_n=0.02))):
+        seqs, offsets = orc.synth_reads(seed, 0, 100_000, 150, [TRUSEQ], **gen)
+        assert compare(model, TRUSEQ, 0.1, 3, seqs, offsets, skip="refined", label=f"refined truseq {seed}") is not None
+    # a second (partial, shifted, edited) copy in front of / behind a full one, at every distance
+    reads = []
+    body = "".join(rng.choice(list("ACGT"), size=60))
+    for d in range(0, 70):
+        for cut in (33, 20, 12, 9):
+            for edit in (0, 1, 2):
+                second = list(TRUSEQ[:cut])
+                for _ in range(edit):
+                    second[int(rng.integers(0, len(second)))] = str(rng.choice(list("ACGT")))
+                reads.append(body[:20] + TRUSEQ + body[20:20 + d] + "".join(second))
+                reads.append(body[:10] + "".join(second) + body[10:10 + d] + TRUSEQ + body[40:])
+    seqs, offsets = orc.pack_reads(reads)
+    assert compare(model, TRUSEQ, 0.1, 3, seqs, offsets, skip="refined", label="refined copies") is not None
