@@ -144,3 +144,9 @@ print(f"perfect packing (every executed lane useful): {(lane_chunks + 63) // 64}
 need_sorted = np.sort(need)[::-1]
 nsw = np.concatenate([need_sorted, np.zeros(pad, dtype=need_sorted.dtype)]).reshape(n_w, WAVE)
 print(f"waves of equal need (clairvoyant static grouping): {int(nsw.max(axis=1).sum())} wave-chunks")
+# the classification of the last column (bs32_finish: a 33-row loop, ~770 VALU instructions per wave in the ISA) is needed
+# by the lanes that reached the read end without an exact match or an early stop; how many waves hold none?
+needs_finish = ~(((cls & 7) == 1) | ((cls & 8) != 0))
+nf = np.concatenate([needs_finish[order], np.zeros(pad, dtype=bool)]).reshape(n_w, WAVE)
+print(f"lanes that need the last-column classification: {needs_finish.mean():.3f}; waves with none: "
+      f"{(~nf.any(axis=1)).mean():.3f}; lanes per wave that need it: mean {nf.sum(axis=1).mean():.1f}")
