@@ -1011,28 +1011,105 @@ def trim_fastq_gpu(source: Union[str, BinaryIO, np.ndarray], out: Union[str, Bin
     return result
 
 
-def _paired_pieces(source1, source2, chunk_bytes: int):
+class _LineFeedIndex:
+    """Line feeds of a block counted by several threads (``cah_fastq_span`` on sub-ranges; ctypes releases the
+    interpreter lock), then: how many whole records the block holds and where the first ``n`` of them end -- what one
+    sequential ``cah_fastq_span`` over the block answers, from a handful of short calls."""
+
+    MIN_PART = 4 << 20
+
+    def __init__(self, d: np.ndarray, pool: ThreadPoolExecutor, parts: int):
+        self.d = d
+        step = max(self.MIN_PART, -(-len(d) // max(1, parts)))
+        self.bounds = list(range(0, len(d), step)) + [len(d)]
+        self.counts = list(pool.map(self._count, zip(self.bounds[:-1], self.bounds[1:])))
+
+    def _span(self, a: int, b: int, limit: int):
+        n, used = C.c_int64(0), C.c_int64(0)
+        _lib.check(_lib.lib().cah_fastq_span(self.d[a:b].ctypes.data if b > a else None, b - a, 0, limit, C.byref(n), C.byref(used)))
+        return n.value, used.value
+
+    def _count(self, ab) -> int:
+        a, b = ab
+        n, used = self._span(a, b, 1 << 62)                  # 4 n line feeds in front of a + used, fewer than 4 behind
+        return 4 * n + int(np.count_nonzero(self.d[a + used:b] == 10))
+
+    @property
+    def records(self) -> int:
+        return sum(self.counts) // 4
+
+    def end_of(self, n: int) -> int:
+        """bytes the first n records take (n <= self.records)"""
+        if n <= 0:
+            return 0
+        target, before = 4 * n, 0
+        for (a, b), c in zip(zip(self.bounds[:-1], self.bounds[1:]), self.counts):
+            if before + c >= target:
+                t = target - before                          # the t-th line feed of this part ends record n
+                _, used = self._span(a, b, t // 4) if t >= 4 else (0, 0)
+                pos = a + used
+                for _ in range(t % 4):
+                    width = 1 << 12
+                    while True:
+                        hit = np.flatnonzero(self.d[pos:min(b, pos + width)] == 10)
+                        if len(hit):
+                            pos += int(hit[0]) + 1
+                            break
+                        width *= 8
+                return pos
+            before += c
+        raise AssertionError("fewer records in the block than asked for")
+
+
+def _paired_pieces(source1, source2, chunk_bytes: int, threads: int = 4):
     """pairs of raw 4-line-FASTQ pieces with the SAME number of records (the job of dnaio.read_paired_chunks,
-    reference runners.py:104-113) -- found by counting line feeds (cah_fastq_span: memchr, nothing is parsed): each
-    side is read in blocks into a pooled buffer, the side with fewer complete records decides, the surplus of the
-    other side is carried over.  The pieces are views of pooled buffers: hand them back (pipeline.POOL.put) when done."""
+    reference runners.py:104-113) -- found by counting line feeds (cah_fastq_span: nothing is parsed): each side is
+    read in blocks into a pooled buffer, the side with fewer complete records decides, the surplus of the other side
+    is carried over.  The two sides are loaded side by side, and each side's block is read (``preadv`` at explicit
+    offsets, plain files) and counted by ``threads`` threads: one thread reads the page cache at a few GB/s and counts
+    at ~10, which made this reader the bound of the paired pipeline.
+    The pieces are views of pooled buffers: hand them back (pipeline.POOL.put) when done."""
     from .pipeline import POOL, _open_maybe_gz
     L = _lib.lib()
-    files = [_open_maybe_gz(source1), _open_maybe_gz(source2)]
+    plain = [_is_plain_file(source1), _is_plain_file(source2)]
+    files = [open(src, "rb", buffering=0) if pl else _open_maybe_gz(src) for src, pl in zip((source1, source2), plain)]
+    sizes = [os.fstat(f.fileno()).st_size if pl else None for f, pl in zip(files, plain)]
+    offsets = [0, 0]
     carry = [np.zeros(0, np.uint8), np.zeros(0, np.uint8)]
     eof = [False, False]
+    threads = max(1, int(threads))
+    helpers = ThreadPoolExecutor(max_workers=2 * threads)    # sub-range reads and counts of both sides
 
     def span(d, final, limit):
         n, used = C.c_int64(0), C.c_int64(0)
         _lib.check(L.cah_fastq_span(d.ctypes.data if len(d) else None, len(d), int(final), limit, C.byref(n), C.byref(used)))
         return n.value, used.value
 
+    def read_range(k, view, offset):
+        done = 0
+        while done < len(view):
+            got = os.preadv(files[k].fileno(), [view[done:]], offset + done)
+            if got <= 0:
+                raise OSError("short read: the file shrank while it was read")
+            done += got
+
     def load_side(k):
         """the next block of file k behind what was carried over, and how many whole records that is"""
         buf = POOL.get(len(carry[k]) + chunk_bytes)
         fill = len(carry[k])
         buf[:fill] = carry[k]
-        if not eof[k]:
+        if not eof[k] and plain[k]:
+            want = min(chunk_bytes, sizes[k] - offsets[k])
+            if want <= 0:
+                eof[k] = True
+            else:
+                view = memoryview(buf)[fill:fill + want]
+                step = max(1 << 20, -(-want // threads))
+                list(helpers.map(lambda a: read_range(k, view[a:a + step], offsets[k] + a), range(0, want, step)))
+                offsets[k] += want
+                fill += want
+                eof[k] = offsets[k] >= sizes[k]
+        elif not eof[k]:
             view = memoryview(buf)[fill:fill + chunk_bytes]
             got = files[k].readinto(view) if hasattr(files[k], "readinto") else None
             if got is None:
@@ -1045,7 +1122,11 @@ def _paired_pieces(source1, source2, chunk_bytes: int):
         d = buf[:fill]
         if fill and d[0] == ord(">"):
             raise ValueError("the device-side path reads 4-line FASTQ; use pipeline.trim_fastq_paired for FASTA")
-        return d, span(d, eof[k], 1 << 62)
+        if eof[k] or fill < 2 * _LineFeedIndex.MIN_PART:
+            return d, span(d, eof[k], 1 << 62), None         # (the end of a file has its own rule: one plain call)
+        index = _LineFeedIndex(d, helpers, threads)
+        n = index.records
+        return d, (n, index.end_of(n)), index
 
     sides = ThreadPoolExecutor(max_workers=2)                # the two files are read and counted side by side
     try:
@@ -1069,11 +1150,19 @@ def _paired_pieces(source1, source2, chunk_bytes: int):
                 for d in data:
                     POOL.put(d)
                 continue
-            cuts = [used[k] if counts[k] == n else span(d, eof[k], n)[1] for k, d in enumerate(data)]
+            cuts = []
+            for k, d in enumerate(data):
+                if counts[k] == n:
+                    cuts.append(used[k])
+                elif loaded[k][2] is not None:
+                    cuts.append(loaded[k][2].end_of(n))
+                else:
+                    cuts.append(span(d, eof[k], n)[1])
             carry = [data[0][cuts[0]:].copy(), data[1][cuts[1]:].copy()]
             yield data[0][:cuts[0]], data[1][:cuts[1]]
     finally:
         sides.shutdown(wait=True)
+        helpers.shutdown(wait=True)
         for f, src in zip(files, (source1, source2)):
             if f is not src:
                 f.close()

@@ -429,3 +429,43 @@ def test_paired_pieces_by_line_count():
         nrec, used = C.c_int64(0), C.c_int64(0)
         _lib.check(L.cah_fastq_span(buf.ctypes.data, len(buf), final, limit, C.byref(nrec), C.byref(used)))
         assert (nrec.value, used.value) == want, (final, limit)
+    # ... and the threaded form of it (plain files: sub-ranges read with preadv and counted side by side)
+    from concurrent.futures import ThreadPoolExecutor
+    from cutadapt_amd import gpu_pipeline as gp
+    pool = ThreadPoolExecutor(max_workers=4)
+    old = gp._LineFeedIndex.MIN_PART
+    try:
+        for part in (1, 7, 64, 1000):
+            gp._LineFeedIndex.MIN_PART = part
+            for n, tail in ((0, b""), (1, b""), (40, b"@x\nAC"), (300, b"@x\nACGT\n+\nII"), (300, b"\n\n")):
+                data = np.frombuffer(fq(n, "t") + tail, dtype=np.uint8)
+                index = gp._LineFeedIndex(data, pool, 5)
+                nrec, used = C.c_int64(0), C.c_int64(0)
+                _lib.check(L.cah_fastq_span(data.ctypes.data if len(data) else None, len(data), 0, 1 << 62, C.byref(nrec), C.byref(used)))
+                assert index.records == nrec.value, (part, n)
+                assert index.end_of(index.records) == used.value, (part, n)
+                for some in {0, 1, nrec.value // 2, nrec.value}:
+                    if some <= nrec.value:
+                        _lib.check(L.cah_fastq_span(data.ctypes.data if len(data) else None, len(data), 0, some, C.byref(nrec), C.byref(used)))
+                        assert index.end_of(some) == (used.value if some else 0), (part, n, some)
+        import tempfile
+        gp._LineFeedIndex.MIN_PART = 512
+        with tempfile.TemporaryDirectory() as tmp:
+            for n, final_nl in ((257, True), (2000, False)):
+                a, b = fq(n, "a"), fq(n, "b", final_nl)
+                pa, pb = os.path.join(tmp, "a.fastq"), os.path.join(tmp, "b.fastq")
+                open(pa, "wb").write(a)
+                open(pb, "wb").write(b)
+                for block in (997, 4096, 40000, 1 << 20):
+                    got_a, got_b, total = [], [], 0
+                    for d1, d2 in _paired_pieces(pa, pb, block, threads=3):
+                        n1 = bytes(d1).count(b"\n")
+                        n2 = bytes(d2).count(b"\n") + (0 if bytes(d2).endswith(b"\n") else 1)
+                        assert n1 % 4 == 0 and n1 == n2 and n1 > 0, (n, block)
+                        total += n1 // 4
+                        got_a.append(bytes(d1))
+                        got_b.append(bytes(d2))
+                    assert b"".join(got_a) == a and b"".join(got_b) == b and total == n, (n, block)
+    finally:
+        gp._LineFeedIndex.MIN_PART = old
+        pool.shutdown()
