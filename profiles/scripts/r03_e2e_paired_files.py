@@ -30,7 +30,7 @@ class Null:
 def run(src):
     r1 = dict(adapters=[BackAdapter(s, max_errors=0.1, min_overlap=3) for s in spec["adapters"]], quality_cutoff=(0, 10))
     r2 = dict(adapters=[BackAdapter(s, max_errors=0.1, min_overlap=3) for s in spec["adapters2"]], quality_cutoff=(0, 10))
-    return gp.trim_fastq_gpu_paired(src[0], src[1], Null(), Null(), r1, r2, threads=6, minimum_length=20)
+    return gp.trim_fastq_gpu_paired(src[0], src[1], Null(), Null(), r1, r2, threads=int(os.environ.get('WORKERS', '6')), minimum_length=20)
 out = []
 orig = gp._paired_pieces
 for t in reader_threads:
@@ -39,9 +39,9 @@ for t in reader_threads:
     best = 1e9
     for _ in range(2):
         t0 = time.perf_counter(); st = run(paths); best = min(best, time.perf_counter() - t0)
-    out.append({"what": f"all-device, two files, {t} reader thread(s) per file", "Mpairs_per_s": n / best / 1e6, "way": st["way"],
+    out.append({"what": f"all-device, two files, {t} reader thread(s) per file, {os.environ.get('WORKERS', '6')} workers", "Mpairs_per_s": n / best / 1e6, "way": st["way"],
                 "pairs_written": st["pairs_written"]})
     print(out[-1], file=sys.stderr, flush=True)
-    open(os.path.join(ROOT, "gpurun_out", "r3", "e2e_paired_files.json"), "w").write(json.dumps(out, indent=1))
+    open(os.path.join(ROOT, "gpurun_out", "r3", "e2e_paired_files" + os.environ.get("TAG", "") + ".json"), "w").write(json.dumps(out, indent=1))
 for p in paths:
     os.unlink(p)
