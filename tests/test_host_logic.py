@@ -277,3 +277,34 @@ def test_prefilter_of_anchored_exact_adapters_is_dropped_only_when_implied():
     assert implied(plan("ACGNACGT", PREFIX, [(0, None, ["CGNA"])], wr=True, kwr=False)) == 0
     assert implied(plan("ACGNACGT", PREFIX, [(0, None, ["CGNA"])], wr=True, kwr=True)) == 0
     assert implied(plan("ACGNACGT", PREFIX, [(0, None, ["ACGT"])], wr=True, kwr=True)) == 1      # the piece behind the N does
+
+
+def test_which_way_through_the_device_fastq_path():
+    """host only: the option sets the all-device way of gpu_pipeline serves (everything else goes the general way)"""
+    from cutadapt_amd import adapters as A
+    from cutadapt_amd.gpu_pipeline import _all_device_adapters, _index_regroups, _mate_all_device
+    back, front = A.BackAdapter("AGATCGGAAGAGC"), A.FrontAdapter("TGGAATTCTCGG")
+    p1, p2, s1 = A.PrefixAdapter("ACGTACGT"), A.PrefixAdapter("TTGCAATG"), A.SuffixAdapter("GGCCAATT")
+    linked = A.LinkedAdapter(A.PrefixAdapter("ACGTACGT"), A.BackAdapter("AGATCGGAAGAGC"), True, False, "l")
+    rightmost = A.RightmostFrontAdapter("TGGAATTCTCGG")
+    linked_rm = A.LinkedAdapter(A.RightmostFrontAdapter("TGGAATTCTCGG"), A.BackAdapter("AGATCGGAAGAGC"), True, False, "lr")
+    assert _all_device_adapters([back], 1, True) and _all_device_adapters([back, front, p1, s1], 3, True)
+    assert not _all_device_adapters([back, rightmost], 1, True)
+    # more than one anchored 5' (or 3') adapter: AdapterCutter(index=True) regroups them behind an AdapterIndex
+    assert _index_regroups([p1, p2]) and not _index_regroups([p1, s1]) and not _index_regroups([back, front])
+    assert not _all_device_adapters([p1, back, p2], 1, True) and _all_device_adapters([p1, back, p2], 1, False)
+    # one linked adapter of non-rightmost parts, one round
+    assert _all_device_adapters([linked], 1, True)
+    assert not _all_device_adapters([linked], 2, True) and not _all_device_adapters([linked, back], 1, True)
+    assert not _all_device_adapters([linked_rm], 1, True)
+    # a mate's BatchTrimmer options -> (adapters, pre, post, times) or None
+    got = _mate_all_device(dict(adapters=[back, front], times=2, quality_cutoff=(0, 20), cut=[3, 0, -2], poly_a=True, length=50))
+    assert got is not None and got[3] == 2 and got[1]["cut"] == [3, -2] and got[2]["poly_a"] and got[2]["length"] == 50
+    assert _mate_all_device(dict(adapters=[back])) == ([back], None, None, 1)
+    assert _mate_all_device(dict()) == ([], None, None, 1)                    # a mate without adapters or modifiers
+    assert _mate_all_device(dict(adapters=[linked], nextseq_trim=20))[1]["nextseq_trim"] == 20
+    for opts in (dict(adapters=[back], action="mask"), dict(adapters=[back], revcomp=True), dict(adapters=[linked], times=2),
+                 dict(adapters=[p1, p2]), dict(adapters=[back], cut=[1, 2]), dict(adapters=[back], cut=[1, -2, 3]),
+                 dict(adapters=[back], some_new_option=1)):
+        assert _mate_all_device(opts) is None, opts
+    assert _mate_all_device(dict(adapters=[p1, p2], index=False)) is not None
