@@ -1331,8 +1331,12 @@ def trim_fastq_gpu_paired(in1, in2, out1, out2, r1: Optional[dict] = None, r2: O
                           pair_adapters: bool = False, revcomp: bool = False,
                           rc_suffix: Optional[str] = " rc") -> Dict[str, object]:
     """``pipeline.trim_fastq_paired`` (same arguments and result) with both mates' chunks indexed and formatted on
-    the GPU(s): a worker holds a pair of chunks (two raw buffers in HBM, one stream), runs ``PairedJob.process_pair``
-    on them and the writer keeps both outputs in chunk order.  FASTA input goes to the host-parsed pipeline."""
+    the GPU(s): a worker holds a pair of chunks (two raw buffers in HBM, one stream).  When both mates' options are
+    of the all-device kind (``_mate_all_device``: single non-rightmost adapters with ``times`` rounds or one linked
+    adapter, action ``trim``, the simple modifiers; no ``pair_adapters`` / ``revcomp``) nothing per read touches the
+    host (``_paired_all_device``; result key ``way`` = "all-device"); otherwise the worker runs
+    ``PairedJob.process_pair`` on the two device chunks (``way`` = "general").  The writer keeps both outputs in chunk
+    order.  FASTA input goes to the host-parsed pipeline."""
     import torch
     from .pipeline import PairedJob, trim_fastq_paired
     if _is_fasta(in1) or _is_fasta(in2):
