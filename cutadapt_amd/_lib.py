@@ -16,14 +16,14 @@ CAH_OK, CAH_EINVAL, CAH_ETYPE, CAH_EHIP, CAH_ENOMEM, CAH_EUNSUPPORTED = 0, 1, 2,
 NONE, MATCH, INVALID = 0, 1, 2
 MAX_READ_LEN = 1000000        # CAH_MAX_READ_LEN of include/cutadapt_hip.h
 KIND_ALIGNER, KIND_PREFIX, KIND_SUFFIX, KIND_KMER_ONLY = 0, 1, 2, 3
-ABI_VERSION = 2              # CAH_ABI_VERSION of include/cutadapt_hip.h this binding was written against
+ABI_VERSION = 3              # CAH_ABI_VERSION of include/cutadapt_hip.h this binding was written against
 PROF_FILTER, PROF_DP, PROF_COMPARER, PROF_SCAN, PROF_MERGE, PROF_N = 0, 1, 2, 3, 4, 5
 
 # every symbol include/cutadapt_hip.h declares (tests check the library exports them all)
 EXPORTED_SYMBOLS = [
     "cah_abi_version", "cah_last_error", "cah_device_count", "cah_set_device", "cah_device_info",
     "cah_plan_create", "cah_plan_destroy", "cah_plan_n_adapters", "cah_plan_effective_length",
-    "cah_plan_n_kmer_entries", "cah_plan_prefilter_kind", "cah_plan_debug_matcher", "cah_plan_debug_lean", "cah_locate_batch", "cah_kmers_present_batch", "cah_match_batch", "cah_match_batch_uniform", "cah_match_batch_suffix_views", "cah_linked_views", "cah_linked_match_batch_uniform",
+    "cah_plan_n_kmer_entries", "cah_plan_prefilter_kind", "cah_plan_multi_kind", "cah_plan_debug_matcher", "cah_plan_debug_lean", "cah_locate_batch", "cah_kmers_present_batch", "cah_match_batch", "cah_match_batch_uniform", "cah_match_batch_suffix_views", "cah_linked_views", "cah_linked_match_batch_uniform",
     "cah_workspace_bytes", "cah_plan_workspace_bytes", "cah_validate_ascii_batch", "cah_reverse_reads_batch", "cah_revcomp_reads_batch", "cah_locate_batch_host",
     "cah_kmers_present_batch_host", "cah_match_batch_host", "cah_locate_debug_host", "cah_match_one_host", "cah_locate_one_host", "cah_profile_enable",
     "cah_profile_reset", "cah_profile_read", "cah_synth_reads",
@@ -107,6 +107,7 @@ def lib():
     L.cah_plan_effective_length.argtypes = [vp, i32, C.POINTER(i32)]
     L.cah_plan_n_kmer_entries.argtypes = [vp, i32, C.POINTER(i32)]
     L.cah_plan_prefilter_kind.argtypes = [vp, i32, C.POINTER(i32)]
+    L.cah_plan_multi_kind.argtypes = [vp, i32, C.POINTER(i32)]
     L.cah_plan_debug_matcher.argtypes = [vp, i32, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.cah_plan_debug_lean.argtypes = [vp, i32, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.cah_locate_batch.argtypes = [vp, i32, vp, vp, vp, i64, vp, vp, vp, C.c_size_t, vp]
@@ -318,6 +319,12 @@ class Plan:
         out = C.c_int32(0)
         check(lib().cah_plan_prefilter_kind(self._h, adapter, C.byref(out)))
         return ("none", "general", "lean")[out.value]
+
+    def multi_kind(self, read_len: int) -> str:
+        """'sequential', 'fused' or 'stream': how equally long reads of this length are matched against all adapters"""
+        out = C.c_int32(0)
+        check(lib().cah_plan_multi_kind(self._h, read_len, C.byref(out)))
+        return ("sequential", "fused", "stream")[out.value]
 
     def n_kmer_entries(self, adapter: int = 0) -> int:
         out = C.c_int32(0)

@@ -27,6 +27,7 @@
 #include "../../include/cutadapt_hip.h"
 #include "cah_device.h"
 #include "kernels.h"
+#include "multi2.h"
 #include "back_scan.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -129,6 +130,8 @@ bool kmer_chars_match(uint8_t rc, uint8_t qc, bool ref_wc, bool query_wc) {
     return (t.iupac[rc] & t.iupac[qc]) != 0;
 }
 
+bool env_flag_early(const char* name) { const char* e = getenv(name); return e && *e && *e != '0'; }
+
 // CAH_NO_SCAN=1 (read at plan creation): the plan is built without the cost scan (A/B measurements,
 // parity tests of the scan against the plain cell kernel)
 bool scan_disabled() {
@@ -176,6 +179,12 @@ struct PlanDeviceCopy {
     uint32_t* d_mbitmap = nullptr;
     uint64_t* d_mscan = nullptr;          // [n_adapters][CAH_MULTI_TAB_STRIDE] padded match words (cost scan)
     uint64_t* d_mrow = nullptr;           // ... row bitsets (cell DP)
+    // ... its streaming form (multi2.h; m2.hdr.ok only)
+    CahMulti2Header* d_m2hdr = nullptr;
+    uint16_t* d_m2dir = nullptr;
+    CahM2Slot* d_m2entries = nullptr;
+    uint32_t* d_m2bitmap = nullptr;
+    uint32_t* d_m2prefix = nullptr;
     std::vector<LongDeviceCopy> d_long;   // one per matcher (null pointers for bare k-mer finders)
     // the one-read kernel's table images ([0]: Aligner.locate, no prefilter; [1]: match_to), built by its first call
     void* d_tiny_image[2] = {nullptr, nullptr};
@@ -188,7 +197,8 @@ struct MultiPlan {
     std::vector<CahMultiEntry> entries;
     std::vector<uint32_t> bitmap;
     std::vector<uint64_t> scan_tab, row_tab;
-    MultiPlan() { memset(&hdr, 0, sizeof(hdr)); }
+    M2Tables m2;                          // the streaming form's tables (m2.hdr.ok: equally long short reads take it)
+    MultiPlan() { memset(&hdr, 0, sizeof(hdr)); memset(&m2.hdr, 0, sizeof(m2.hdr)); }
 };
 
 // Host tables are built (and validated) at creation; the HBM copy for a device is made the
@@ -252,6 +262,14 @@ static int plan_on_device(const cah_plan* plan, const PlanDeviceCopy** out) {
             CAH_UPLOAD(dc.d_mbitmap, mp.bitmap)
             CAH_UPLOAD(dc.d_mscan, mp.scan_tab)
             CAH_UPLOAD(dc.d_mrow, mp.row_tab)
+            if (mp.m2.hdr.ok) {
+                HIP_TRY(hipMalloc((void**)&dc.d_m2hdr, sizeof(CahMulti2Header)));
+                HIP_TRY(hipMemcpy(dc.d_m2hdr, &mp.m2.hdr, sizeof(CahMulti2Header), hipMemcpyHostToDevice));
+                CAH_UPLOAD(dc.d_m2dir, mp.m2.dir)
+                CAH_UPLOAD(dc.d_m2entries, mp.m2.entries)
+                CAH_UPLOAD(dc.d_m2bitmap, mp.m2.bitmap)
+                CAH_UPLOAD(dc.d_m2prefix, mp.m2.prefix)
+            }
 #undef CAH_UPLOAD
         }
         dc.ready = true;
@@ -771,6 +789,22 @@ static void build_multi(const cah_adapter_desc* descs, int n, cah_plan* plan) {
         }
     }
     h.ok = 1;
+    // the streaming form (multi2.h): the same plan as tables of REF + WIDE k-mers of up to ten characters.
+    // CAH_NO_MULTI2=1 keeps the older kernels (A/B, parity tests)
+    const char* off2 = getenv("CAH_NO_MULTI2");
+    if (!(off2 && *off2 && *off2 != '0')) {
+        std::vector<std::string> ads;
+        std::vector<std::vector<M2RefKmer>> ref((size_t)n);
+        for (int a = 0; a < n; a++) {
+            ads.push_back(std::string(descs[a].sequence, (size_t)descs[a].length));
+            for (int si = 0; si < descs[a].n_kmer_sets; si++) {
+                const cah_kmer_set& ks = descs[a].kmer_sets[si];
+                for (int t = 0; t < ks.n_kmers; t++)
+                    ref[(size_t)a].push_back({std::string(ks.kmers[t]), ks.start == 0 ? CAH_M2_WHOLE : (int)-ks.start});
+            }
+        }
+        if (!m2_build(ads, m0.thr_last, m0.kacc, m0.k, m0.min_overlap, ref, mp.m2)) memset(&mp.m2.hdr, 0, sizeof(mp.m2.hdr));
+    }
 }
 
 extern "C" {
@@ -859,6 +893,11 @@ void cah_plan_destroy(cah_plan* plan) {
         if (dc.d_mbitmap) (void)hipFree(dc.d_mbitmap);
         if (dc.d_mscan) (void)hipFree(dc.d_mscan);
         if (dc.d_mrow) (void)hipFree(dc.d_mrow);
+        if (dc.d_m2hdr) (void)hipFree(dc.d_m2hdr);
+        if (dc.d_m2dir) (void)hipFree(dc.d_m2dir);
+        if (dc.d_m2entries) (void)hipFree(dc.d_m2entries);
+        if (dc.d_m2bitmap) (void)hipFree(dc.d_m2bitmap);
+        if (dc.d_m2prefix) (void)hipFree(dc.d_m2prefix);
         if (dc.d_tiny_image[0]) (void)hipFree(dc.d_tiny_image[0]);
         if (dc.d_tiny_image[1]) (void)hipFree(dc.d_tiny_image[1]);
         for (LongDeviceCopy& ld : dc.d_long) {
@@ -893,6 +932,14 @@ int cah_plan_prefilter_kind(const cah_plan* plan, int32_t adapter, int32_t* out)
     if (!out) return fail(CAH_EINVAL, "out is NULL");
     const CahMatcher& mt = plan->matchers[(size_t)adapter];
     *out = !mt.has_filter ? CAH_PREFILTER_NONE : (plan->lean[(size_t)adapter].ok ? CAH_PREFILTER_LEAN : CAH_PREFILTER_GENERAL);
+    return CAH_OK;
+}
+
+int cah_plan_multi_kind(const cah_plan* plan, int32_t read_len, int32_t* out) {
+    if (!plan || !out) return fail(CAH_EINVAL, "plan or out is NULL");
+    const MultiPlan& mp = plan->multi;
+    *out = !mp.hdr.ok ? CAH_MULTI_SEQUENTIAL
+                      : ((mp.m2.hdr.ok && multi2_read_len_ok(mp.m2.hdr, read_len) && !env_flag_early("CAH_NO_MULTI2")) ? CAH_MULTI_STREAM : CAH_MULTI_FUSED);
     return CAH_OK;
 }
 
@@ -1008,13 +1055,20 @@ size_t cah_workspace_bytes(int64_t n_reads) {
 // whose duration is that of its slowest wave, ~0.45 ms, however few pairs it has -- at 256 M pairs a 100 M-read batch
 // of 96 adapters paid that 36 times, 16 of its 114 ms); larger batches are processed in chunks of
 // cap / n_adapters reads.
+static int64_t m2_slack_pages(int64_t n_reads) {
+    const int64_t tiles = (n_reads + 8191) / 8192;
+    return (tiles < 256 ? (tiles < 1 ? 1 : tiles) : 256) * 16 * CAH_M2_PAIR_CLASSES;
+}
 static int64_t multi_pair_cap(const cah_plan* plan, int64_t n_reads) {
     int64_t limit = 1024ll << 20;
     if (const char* e = getenv("CAH_MULTI_PAIR_CAP")) { const long long v = atoll(e); if (v > 0) limit = v; }
     const int64_t A = (int64_t)plan->matchers.size();
     if (limit < A) limit = A;
     const int64_t worst = n_reads * A;
-    return worst < limit ? worst : limit;
+    const int64_t cap = worst < limit ? worst : limit;
+    // the streaming form hands pairs out in pages (multi2.h): a closed page may lack up to 63 pairs, and every wave of
+    // the prefilter may hold one open page per class
+    return cap + cap / 15 + (m2_slack_pages(n_reads) + 2) * CAH_M2_PAGE;
 }
 static size_t ws_key_bytes(int64_t n_reads) { return (sizeof(unsigned long long) * (size_t)n_reads + 255) & ~(size_t)255; }
 
@@ -1374,6 +1428,63 @@ static int match_batch_multi(const cah_plan* plan, const PlanDeviceCopy* pd, con
     unsigned long long* counters = ws.counters;
     const CahMatcher& m0 = plan->matchers[0];
     HIP_TRY(hipMemsetAsync(d_best_key, 0, sizeof(unsigned long long) * (size_t)n_reads, s));
+    // Equally long short reads take the streaming form (multi2.hip): k_multi_stream emits the pairs in pages of one
+    // class each (the suffix compare of the error-free rows happens there), k_multi_scan scans them page by page.
+    if (mp.m2.hdr.ok && ul.len > 0 && !d_lens && multi2_read_len_ok(mp.m2.hdr, ul.len) && !env_flag("CAH_NO_MULTI2")) {
+        // the pool: pages of CAH_M2_PAGE pairs + one header word each, inside the pair area
+        const int64_t max_pages = ((int64_t)cap * 8) / (CAH_M2_PAGE * 8 + 4);
+        uint32_t* d_page_hdr = (uint32_t*)(d_pairs + max_pages * CAH_M2_PAGE);
+        const int64_t slack = m2_slack_pages(n_reads) + 1;
+        const int64_t chunk2 = std::max<int64_t>(1, ((max_pages - slack) * (CAH_M2_PAGE - 63)) / A);
+        for (int64_t lo = 0; lo < n_reads; lo += chunk2) {
+            const int64_t cnt = std::min(chunk2, n_reads - lo);
+            HIP_TRY(hipMemsetAsync(counters, 0, WS_HEADER, s));
+            {
+                Multi2Args f;
+                f.uniform_first = ul.first; f.uniform_len = ul.len;
+                f.win_hi = mp.m2.hdr.win_dist[M2_HI]; f.win_lo = mp.m2.hdr.win_dist[M2_LO];
+                f.hdr = pd->d_m2hdr; f.dir = pd->d_m2dir; f.entries = pd->d_m2entries; f.bitmap = pd->d_m2bitmap;
+                f.prefix = pd->d_m2prefix;
+                f.seqs = d_seqs; f.first_read = lo; f.n_reads = cnt; f.status = d_status; f.best_key = d_best_key;
+                f.pairs = d_pairs; f.page_hdr = d_page_hdr; f.page_counter = counters + WS_QCOUNT; f.max_pages = max_pages;
+                ProfScope ps(s, CAH_PROF_FILTER, cnt);
+                HIP_TRY(launch_multi_stream(f, mp.m2.hdr, pd->n_cus, s));
+            }
+            {
+                Multi2ScanArgs sa;
+                sa.uniform_first = ul.first; sa.uniform_len = ul.len;
+                sa.kind = scan_word_kind(m0.m);
+                sa.matcher = pd->d_matchers; sa.tab = pd->d_mscan; sa.n_adapters = (int32_t)A;
+                sa.seqs = d_seqs; sa.pairs = d_pairs; sa.page_hdr = d_page_hdr;
+                sa.page_counter = counters + WS_QCOUNT; sa.max_pages = max_pages;
+                sa.work_counter = counters + WS_SCANWORK; sa.best_key = d_best_key;
+                sa.dp_queue = d_dpq; sa.dp_win = d_win;
+                sa.dp_count_front = counters + WS_DPFRONT; sa.dp_count_back = counters + WS_DPBACK; sa.dp_cap = cap;
+                // (how many pages there are is known on the device only: the grid is sized for a typical batch)
+                const int64_t est_pages = std::min<int64_t>(max_pages, cnt * 8 / CAH_M2_PAGE + slack);
+                ProfScope ps(s, CAH_PROF_SCAN, cnt);
+                HIP_TRY(launch_multi_scan(sa, est_pages, pd->n_cus, s));
+            }
+            {
+                DpArgs a;
+                a.uniform_first = ul.first; a.uniform_len = ul.len;
+                a.matcher = pd->d_matchers;
+                a.seqs = d_seqs; a.offsets = d_offsets; a.lens = d_lens; a.n_reads = cnt * A;
+                a.max_read_len = CAH_MAX_READ_LEN;
+                a.queue = d_dpq; a.queue_count = counters + WS_DPFRONT; a.queue_keys = nullptr;
+                a.work_counter = counters + WS_DPWORK;
+                a.out6 = d_out6; a.status = d_status; a.best_adapter = d_best_adapter;
+                a.adapter_index = 0; a.merge_best = 1;
+                a.win = d_win; a.queue_count_back = counters + WS_DPBACK; a.queue_cap = cap;
+                a.pairs = d_pairs; a.tab = pd->d_mrow; a.n_adapters = (int32_t)A; a.best_key = d_best_key;
+                ProfScope ps(s, CAH_PROF_DP, cnt);
+                HIP_TRY(launch_dp(a, m0.m, true, true, cnt * A, pd->n_cus, s));
+            }
+        }
+        ProfScope ps(s, CAH_PROF_MERGE, n_reads);
+        HIP_TRY(launch_multi_decode(d_best_key, n_reads, d_out6, d_status, d_best_adapter, pd->n_cus, s));
+        return CAH_OK;
+    }
     for (int64_t lo = 0; lo < n_reads; lo += chunk) {
         const int64_t cnt = std::min(chunk, n_reads - lo);
         HIP_TRY(hipMemsetAsync(counters, 0, WS_HEADER, s));

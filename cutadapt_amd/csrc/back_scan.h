@@ -108,6 +108,7 @@
 #define CAH_HD inline
 #endif
 
+#define CAH_BS_ALL_ROWS 64
 enum { BS_NONE = 0, BS_EXACT_FULL = 1, BS_EXACT_TAIL = 2, BS_DP = 3, BS_SUBS_FULL = 4, BS_INDEL1_FULL = 5 };
 
 struct BackScanParams {
@@ -333,9 +334,12 @@ CAH_HD bool bs_may_stop(const BackScanBook& s, const int j, const int n, const i
 // last DP column * 2 + scan flag) for DP.
 // row_cost(i): the absolute cost of row i of the last column, asked for i = 1, 2, .., m in this order.
 // row_clean(i): the diagonal that ends in (i, n) has met no unclean cell (only asked when it starts inside the window).
+// max_row: rows above it are known not to be acceptable (a window that holds every acceptable candidate's alignment
+// from column j0 on leaves rows > n - j0 + kacc no room) and are not looked at.
 template <bool INDEL1, class ThrLast, class RowCost, class RowClean>
 CAH_HD int bs_finish_rows(const BackScanBook& s, const int n, const int j0, const BackScanParams& p,
-                          ThrLast thr_last, int& o0, int& o1, const bool stopped, RowCost row_cost, RowClean row_clean) {
+                          ThrLast thr_last, int& o0, int& o1, const bool stopped, RowCost row_cost, RowClean row_clean,
+                          const int max_row = CAH_BS_ALL_ROWS) {
     o0 = 0; o1 = 0;
     const int reach = p.m + p.k + 1;
     // one insertion / one deletion (see the header); INDEL1 = false: the form does not keep the bits
@@ -363,7 +367,8 @@ CAH_HD int bs_finish_rows(const BackScanBook& s, const int n, const int j0, cons
     //   c_max           the largest cost of an acceptable row: the origin clause holds for every acceptable row with
     //                    errors iff k + 1 + c_max <= m / 2 (or c_max == 0)
     int best_i = 0, w_key = -1, unclean_bound = -(1 << 20), c_max = 0;
-    for (int i = 1; i <= p.m; ++i) {
+    const int rows = p.m < max_row ? p.m : max_row;
+    for (int i = 1; i <= rows; ++i) {
         const int c = row_cost(i);
         const bool acc = i >= p.min_overlap && c <= thr_last(i);
         const int sc = i - 2 * c;
@@ -407,7 +412,7 @@ CAH_HD int bs_finish_rows(const BackScanBook& s, const int n, const int j0, cons
 // TRACKED: the scan ran with SUBS (the accumulator A means something)
 template <bool TRACKED = true, class ThrLast>
 CAH_HD int bs_finish(const BackScanState& s, const int n, const int j0, const BackScanParams& p,
-                     ThrLast thr_last, int& o0, int& o1, const bool stopped = false) {
+                     ThrLast thr_last, int& o0, int& o1, const bool stopped = false, const int max_row = CAH_BS_ALL_ROWS) {
     const int pad = 64 - p.m;
     uint64_t vp = pad == 0 ? s.VP : (s.VP >> pad), vn = pad == 0 ? s.VN : (s.VN >> pad);
     int c = 0;
@@ -415,12 +420,12 @@ CAH_HD int bs_finish(const BackScanState& s, const int n, const int j0, const Ba
         c += (int)(vp & 1ull) - (int)(vn & 1ull);
         vp >>= 1; vn >>= 1;
         return c;
-    }, [&](int i) { return TRACKED && ((s.A >> (pad + i - 1)) & 1ull) == 0; });
+    }, [&](int i) { return TRACKED && ((s.A >> (pad + i - 1)) & 1ull) == 0; }, max_row);
 }
 
 template <int X, bool TRACKED = true, class ThrLast>
 CAH_HD int bs32_finish(const BackScanState32<X>& s, const int n, const int j0, const BackScanParams& p,
-                       ThrLast thr_last, int& o0, int& o1, const bool stopped = false) {
+                       ThrLast thr_last, int& o0, int& o1, const bool stopped = false, const int max_row = CAH_BS_ALL_ROWS) {
     const int pad = X > 0 ? 0 : 32 - p.m;
     uint32_t vp = s.VP >> pad, vn = s.VN >> pad;
     int c = X > 0 ? s.cx[X - 1] : 0;
@@ -433,5 +438,5 @@ CAH_HD int bs32_finish(const BackScanState32<X>& s, const int n, const int j0, c
         if (!TRACKED) return false;
         if (X > 0 && i <= X) return ((s.ax >> (i - 1)) & 1u) == 0;
         return ((s.A >> (pad + i - X - 1)) & 1u) == 0;
-    });
+    }, max_row);
 }

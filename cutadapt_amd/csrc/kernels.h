@@ -211,6 +211,51 @@ struct MultiFilterArgs {
 hipError_t launch_multi_filter(const MultiFilterArgs& a, const CahMultiHeader& host_hdr, int n_cus, hipStream_t s);
 hipError_t launch_multi_decode(const unsigned long long* best_key, int64_t n_reads, int32_t* out6, uint8_t* status,
                                int32_t* best_adapter, int n_cus, hipStream_t s);
+// multi2.hip: the streaming form of the fused multi-adapter path (equally long short reads; tables: multi2.h)
+struct CahMulti2Header;
+struct CahM2Slot;
+struct Multi2Args {
+    int64_t uniform_first;           // read r of the BATCH = seqs[uniform_first + r * uniform_len ..)
+    int32_t uniform_len;
+    int32_t win_hi, win_lo;          // a tail pair's scan window starts at column n - win (CahMulti2Header::win_dist)
+    const CahMulti2Header* hdr;
+    const uint16_t* dir;
+    const CahM2Slot* entries;
+    const uint32_t* bitmap;
+    const uint32_t* prefix;
+    const uint8_t* seqs;
+    int64_t first_read, n_reads;     // this launch handles reads [first_read, first_read + n_reads) of the batch
+    uint8_t* status;                 // only written for invalid reads
+    unsigned long long* best_key;    // zeroed before launch: pairs decided by the suffix compare are merged here
+    uint64_t* pairs;                 // the page pool: max_pages * CAH_M2_PAGE pair records
+    uint32_t* page_hdr;              // [max_pages]
+    unsigned long long* page_counter;        // zeroed before launch: pages handed out
+    int64_t max_pages;
+};
+struct Multi2ScanArgs {
+    int64_t uniform_first;
+    int32_t uniform_len;
+    int32_t kind;                    // form of the column, bs_kind_of(m)
+    const CahMatcher* matcher;       // matcher 0: all adapters of the fused path have one shape
+    const uint64_t* tab;             // [n_adapters][CAH_MULTI_TAB_STRIDE] padded match words
+    int32_t n_adapters;
+    const uint8_t* seqs;
+    const uint64_t* pairs;
+    const uint32_t* page_hdr;
+    const unsigned long long* page_counter;
+    int64_t max_pages;
+    unsigned long long* work_counter;        // zeroed before launch
+    unsigned long long* best_key;
+    int32_t* dp_queue;               // out: pair indices that need the cell DP (filled from both ends, see DpArgs)
+    int32_t* dp_win;
+    unsigned long long* dp_count_front;      // zeroed before launch
+    unsigned long long* dp_count_back;
+    int64_t dp_cap;
+};
+bool multi2_read_len_ok(const CahMulti2Header& h, int read_len);
+size_t multi2_lds_bytes(const CahMulti2Header& h);
+hipError_t launch_multi_stream(const Multi2Args& a, const CahMulti2Header& host_hdr, int n_cus, hipStream_t s);
+hipError_t launch_multi_scan(const Multi2ScanArgs& a, int64_t max_pages, int n_cus, hipStream_t s);
 // long.hip: adapters longer than 64 characters (column in HBM scratch)
 struct LongArgs {
     // equally long reads the HOST knows about (cah_match_batch_uniform): read r = seqs[uniform_first + r * uniform_len ..),

@@ -1,0 +1,689 @@
+// multi2.hip -- the streaming form of the fused multi-adapter path for batches of equally long short reads (the
+// sequencer's output; BASELINE config C4: 96 adapters): k_multi_stream (prefilter of ALL adapters in one pass) and
+// k_multi_scan (cost scan of the (read, adapter) pairs it emits, page by page).  Rules and tables: multi2.h; the same
+// rules are replayed on the CPU by tests/host_model/multi2_model.cpp against the oracle.
+//
+// Replaces k_multi_filter + k_back_scan<true> (multi.hip, kernels.hip) where the batch and the plan allow it
+// (multi2_ok below); those stay for ragged batches, longer reads and plans with k-mers over ten characters.
+// Reference: MultipleAdapters.match_to (src/cutadapt/adapters.py:1265-1286) = per adapter KmerFinder.kmers_present
+// (_kmer_finder.pyx:170-257) then Aligner.locate (_align.pyx:298-587).
+//
+// k_multi_stream, per workgroup of 16 waves (one per CU):
+//   * the reads are copied HBM -> LDS with coalesced 16-byte loads, half a read at a time (k_filter_stream2's copy
+//     plan: every cache line crosses the memory system once), one read per lane;
+//   * per character: 3-bit code (LDS byte table), a rolling word of the last ten characters, ONE bitmap probe for the
+//     whole-read k-mers; a probe hit becomes an EVENT (lane, position, the rolling word) in the wave's LDS ring;
+//   * events are resolved 64 at a time by ALL lanes (directory -> entries in LDS, verified on every character and on
+//     the k-mer's windows) -- no lane waits for another lane's hit;
+//   * after the read: three short sweeps over its tail (classes hi, lo, REF-only k-mers), each resolved before the next;
+//   * a pair is emitted once (LDS bitsets `seen` / `wide only` per read and adapter) into a PAGE of its class: pages of
+//     1024 pairs from a device-wide pool, owned by one wave, one class of pairs per page -- the scan's waves then hold 64
+//     pairs of one window shape.  Pairs that only the error-free rows can match are decided here (suffix compare).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <type_traits>
+
+#include "cah_device.h"
+#include "kernels.h"
+#include "dev_common.h"
+#include "back_scan.h"
+#include "multi2.h"
+
+#define M2_WAVES 16                // waves per block = per CU
+#define M2_TILE 8192               // reads per block tile
+#define M2_HALF 5                  // 16-byte units per half-row
+#define M2_ROW (M2_HALF * 16)
+#define M2_MAX_LEN (2 * M2_HALF * 16)
+#define M2_RING 128                // events per wave ring (two rounds)
+
+typedef unsigned int m2_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int m2_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bool m2_any(const bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+__device__ __forceinline__ void* m2_uniform_ptr(const void* q) {
+    const unsigned long long v = (unsigned long long)q;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (void*)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ unsigned m2_rank(const unsigned long long mask) {      // set bits below this lane
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
+// dynamic LDS layout (bytes), computed alike on host and device
+struct M2Layout {
+    unsigned bitmap, dir, entries, prefix, xlat, slot, seen, wide, ring, rlast, first, pages, misc, total;
+};
+__host__ __device__ inline M2Layout m2_layout(const int n_entries, const int n_adapters) {
+    M2Layout L;
+    unsigned o = 0;
+    const unsigned words = (unsigned)(n_adapters + 31) / 32;
+    L.bitmap = o; o += CAH_M2_BM_WORDS * 4;
+    L.dir = o; o += CAH_M2_SLOTS * 2;
+    L.entries = o; o += (unsigned)((n_entries + 1) & ~1) * 8;
+    L.prefix = o; o += 128 * 4;
+    L.xlat = o; o += 128;
+    L.slot = o; o += M2_WAVES * WAVE * M2_ROW;
+    L.seen = o; o += M2_WAVES * WAVE * words * 4;
+    L.wide = o; o += M2_WAVES * WAVE * words * 4;
+    L.ring = o; o += M2_WAVES * M2_RING * 8;
+    L.rlast = o; o += M2_WAVES * WAVE * 4;
+    L.first = o; o += M2_WAVES * WAVE * 4;
+    L.pages = o; o += M2_WAVES * CAH_M2_PAIR_CLASSES * 8;
+    L.misc = o; o += 64;
+    L.total = o;
+    return L;
+}
+
+__device__ __forceinline__ unsigned multi_tab_index2(unsigned c) { return (c & 0x40u) ? (c & 31u) : 0u; }   // (kernels.hip: multi_tab_index)
+
+// class of a pair's page: 0 lo, 1 hi, 2.. whole-read pairs by the length of their window (16-column chunks)
+__host__ __device__ inline int m2_pair_class_w(const int chunks) { return chunks <= 4 ? 2 : (chunks <= 6 ? 3 : (chunks <= 8 ? 4 : 5)); }
+
+__global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    const CahMulti2Header* const hd = a.hdr;
+    const int n_adapters = hd->n_adapters;
+    const int n_entries = (int)hd->n_entries;
+    const M2Layout LY = m2_layout(n_entries, n_adapters);
+    uint32_t* const s_bm = reinterpret_cast<uint32_t*>(s_raw + LY.bitmap);
+    uint16_t* const s_dir = reinterpret_cast<uint16_t*>(s_raw + LY.dir);
+    CahM2Slot* const s_ent = reinterpret_cast<CahM2Slot*>(s_raw + LY.entries);
+    uint32_t* const s_prefix = reinterpret_cast<uint32_t*>(s_raw + LY.prefix);
+    uint8_t* const s_xlat = s_raw + LY.xlat;
+    const int words = (n_adapters + 31) / 32;                           // bitset words per read
+
+    const int n = a.uniform_len;
+    const int n_reads = (int)a.n_reads;                                 // reads of this launch (< 2^31)
+    const int64_t first_byte = a.uniform_first + a.first_read * (int64_t)n;
+    const int64_t total = (int64_t)n_reads * n;
+    for (int i = threadIdx.x; i < CAH_M2_BM_WORDS; i += blockDim.x) s_bm[i] = a.bitmap[i];
+    for (int i = threadIdx.x; i < CAH_M2_SLOTS / 2; i += blockDim.x)
+        reinterpret_cast<uint32_t*>(s_dir)[i] = reinterpret_cast<const uint32_t*>(a.dir)[i];
+    for (int i = threadIdx.x; i < n_entries; i += blockDim.x) s_ent[i] = a.entries[i];
+    for (int i = threadIdx.x; i < 128; i += blockDim.x) {
+        s_prefix[i] = i < n_adapters ? a.prefix[i] : 0u;
+        s_xlat[i] = (uint8_t)m2_code((unsigned)i);
+    }
+    const int lane = wave_lane();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    unsigned char* const slot = s_raw + LY.slot + wave * (WAVE * M2_ROW);
+    const unsigned char* const row = slot + lane * M2_ROW;
+    uint32_t* const s_seen = reinterpret_cast<uint32_t*>(s_raw + LY.seen) + wave * WAVE * words;
+    uint32_t* const s_wide = reinterpret_cast<uint32_t*>(s_raw + LY.wide) + wave * WAVE * words;
+    m2_u32x2* const s_ring = reinterpret_cast<m2_u32x2*>(s_raw + LY.ring) + wave * M2_RING;
+    uint32_t* const s_rlast = reinterpret_cast<uint32_t*>(s_raw + LY.rlast) + wave * WAVE;
+    uint32_t* const s_first = reinterpret_cast<uint32_t*>(s_raw + LY.first) + wave * WAVE;
+    uint32_t* const s_pg = reinterpret_cast<uint32_t*>(s_raw + LY.pages) + wave * CAH_M2_PAIR_CLASSES * 2;   // {page, fill} per class
+    unsigned* const s_next_piece = reinterpret_cast<unsigned*>(s_raw + LY.misc);
+    if (lane < CAH_M2_PAIR_CLASSES) { s_pg[2 * lane] = 0xFFFFFFFFu; s_pg[2 * lane + 1] = 0u; }
+    if (threadIdx.x == 0) *s_next_piece = M2_WAVES;
+    __syncthreads();
+
+    // plan constants (wave-uniform)
+    const int m = hd->m, k = hd->k, min_overlap = hd->min_overlap, lmax0 = hd->lmax0;
+    const int qmask_w = hd->q_mask[M2_W];
+    const bool w_only8 = qmask_w == (1 << 8);
+    const unsigned lane16 = (unsigned)lane * 16u;
+
+    // ---- copy plan (k_filter_stream2's): H1 units of every read in the first half-row, H2 in the second
+    const int U = (n + 15) >> 4;
+    const int H1 = (U + 1) >> 1, H2 = U - H1;
+    const unsigned magic1 = (65536u + (unsigned)H1 - 1u) / (unsigned)H1;
+    const unsigned magic2 = H2 ? (65536u + (unsigned)H2 - 1u) / (unsigned)H2 : 0u;
+    auto unit_r = [&](int kk, unsigned magic) -> int {
+        unsigned ln = (unsigned)lane;
+        asm volatile("" : "+v"(ln));
+        return (int)(__umul24((unsigned)(kk * WAVE) + ln, magic) >> 16);
+    };
+    constexpr int PPT = M2_TILE / WAVE;
+    auto piece_base = [&](unsigned p) -> int64_t {
+        return ((int64_t)blockIdx.x + (int64_t)(p / PPT) * (int64_t)gridDim.x) * M2_TILE + (int64_t)(p % PPT) * WAVE;
+    };
+    auto take_piece = [&]() -> unsigned {
+        unsigned p = 0;
+        if (lane == 0) p = __hip_atomic_fetch_add(s_next_piece, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return __builtin_amdgcn_readfirstlane(p);
+    };
+    m2_u32x4 pre[2 * M2_HALF];
+    const uint8_t* const batch0 = a.seqs + first_byte;
+    auto prefetch = [&](int64_t base) {
+        const int64_t left = n_reads - base;
+        if (left <= 0) return;
+        const int64_t pbyte = base * (int64_t)n;
+        const uint8_t* const src = batch0 + pbyte;
+        if (left >= WAVE && pbyte + (int64_t)WAVE * n + 16 <= total) {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(m2_uniform_ptr(src), 0, 0x7FFFFFFF, 0x00020000);
+#pragma unroll
+            for (int kk = 0; kk < M2_HALF; ++kk)
+                if (kk < H1)
+                    pre[kk] = __builtin_amdgcn_raw_buffer_load_b128(
+                        rs, (unsigned)(__mul24(unit_r(kk, magic1), n - 16 * H1) + (int)lane16) + kk * (WAVE * 16), 0, 0);
+#pragma unroll
+            for (int kk = 0; kk < M2_HALF; ++kk)
+                if (kk < H2)
+                    pre[M2_HALF + kk] = __builtin_amdgcn_raw_buffer_load_b128(
+                        rs, (unsigned)(__mul24(unit_r(kk, magic2), n - 16 * H2) + (int)lane16) + kk * (WAVE * 16), 16 * H1, 0);
+            return;
+        }
+        const int reads = (int)(left < WAVE ? left : (int64_t)WAVE);
+#pragma unroll
+        for (int q = 0; q < 2 * M2_HALF; ++q) {
+            const int kk = q < M2_HALF ? q : q - M2_HALF;
+            const int H = q < M2_HALF ? H1 : H2;
+            m2_u32x4 got = (m2_u32x4)(0u);
+            if (kk < H && kk * WAVE + lane < reads * H) {
+                const int r = unit_r(kk, q < M2_HALF ? magic1 : magic2);
+                const unsigned goff = (unsigned)(__mul24(r, n - 16 * H) + (kk * WAVE) * 16 + (int)lane16 + (q < M2_HALF ? 0 : 16 * H1));
+                if (pbyte + goff + 16 <= total) {
+                    Unaligned16 v;
+                    __builtin_memcpy(&v, src + goff, 16);
+                    got = (m2_u32x4){v.w[0], v.w[1], v.w[2], v.w[3]};
+                } else if (pbyte + goff < total) {
+                    Unaligned16 v;
+                    __builtin_memcpy(&v, batch0 + (total - 16), 16);
+                    const int sft = (int)(pbyte + goff + 16 - total);
+                    const int dw = sft >> 2, sh = (sft & 3) * 8;
+                    unsigned x0 = v.w[0], x1 = v.w[1], x2 = v.w[2], x3 = v.w[3];
+                    if (dw >= 2) { x0 = x2; x1 = x3; x2 = 0; x3 = 0; }
+                    if (dw & 1) { x0 = x1; x1 = x2; x2 = x3; x3 = 0; }
+                    got = (m2_u32x4){(unsigned)((((unsigned long long)x1 << 32) | x0) >> sh),
+                                     (unsigned)((((unsigned long long)x2 << 32) | x1) >> sh),
+                                     (unsigned)((((unsigned long long)x3 << 32) | x2) >> sh), x3 >> sh};
+                }
+            }
+            pre[q] = got;
+        }
+    };
+    auto to_slot = [&](auto half_c) {
+        constexpr int half = decltype(half_c)::value;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int H = half ? H2 : H1;
+        const unsigned magic = half ? magic2 : magic1;
+#pragma unroll
+        for (int kk = 0; kk < M2_HALF; ++kk)
+            if (kk < H) {
+                unsigned off = lane16;
+                if (H != M2_HALF) off += (unsigned)__mul24(unit_r(kk, magic), M2_ROW - 16 * H);
+                *reinterpret_cast<m2_u32x4*>(slot + kk * (WAVE * 16) + off) = pre[half * M2_HALF + kk];
+            }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    // the chunk at `pos`: characters past the read's end become NUL
+    auto finish = [&](m2_u32x4 v, int pos) -> m2_u32x4 {
+        if (pos + 16 > n) {
+            unsigned x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int keep = n - pos - 4 * i;
+                x[i] &= keep >= 4 ? 0xFFFFFFFFu : (keep <= 0 ? 0u : ((1u << (8 * keep)) - 1u));
+            }
+            v = (m2_u32x4){x[0], x[1], x[2], x[3]};
+        }
+        return v;
+    };
+
+    // ---- events: ring[tail % RING] = {rolling word, lane | position << 8 | qc << 16}
+    unsigned ring_head = 0, ring_count = 0;                             // wave-uniform
+    int64_t piece_first = 0;                                            // read index (within the launch) of lane 0's read
+    int cur_cls = M2_W;                                                 // the class being probed (events in the ring are of it)
+
+    // pairs of class pc from the lanes of `mask` (wave-uniform, non-empty) go to the wave's open page of that class
+    auto append_pairs = [&](const unsigned long long mask, const int pc, const bool mine, const uint64_t pair) {
+        const unsigned cnt = (unsigned)__popcll(mask);
+        unsigned page = __builtin_amdgcn_readfirstlane(s_pg[2 * pc]);
+        unsigned fill = __builtin_amdgcn_readfirstlane(s_pg[2 * pc + 1]);
+        if (page == 0xFFFFFFFFu || fill + cnt > CAH_M2_PAGE) {
+            unsigned np = 0;
+            if (lane == 0) {
+                if (page != 0xFFFFFFFFu) a.page_hdr[page] = ((unsigned)pc << 24) | fill;
+                np = (unsigned)atomicAdd(a.page_counter, 1ull);
+            }
+            page = __builtin_amdgcn_readfirstlane(np);
+            fill = 0;
+        }
+        if (mine && (int64_t)page < a.max_pages) a.pairs[(int64_t)page * CAH_M2_PAGE + fill + m2_rank(mask)] = pair;
+        if (lane == 0) { s_pg[2 * pc] = page; s_pg[2 * pc + 1] = fill + cnt; }
+    };
+
+    // resolve up to 64 events of class cur_cls from the head of the ring
+    auto resolve_round = [&]() {
+        const unsigned cnt = ring_count < 64u ? ring_count : 64u;
+        const bool have = (unsigned)lane < cnt;
+        m2_u32x2 ev = (m2_u32x2)(0u);
+        if (have) ev = s_ring[(ring_head + (unsigned)lane) & (M2_RING - 1)];
+        ring_head = (ring_head + cnt) & (M2_RING - 1);
+        ring_count -= cnt;
+        const uint32_t r = ev.x;
+        const int lr = (int)(ev.y & 63u), p = (int)((ev.y >> 8) & 255u), qc = (int)((ev.y >> 16) & 15u);
+        const uint32_t d = have ? (uint32_t)s_dir[m2_index(r, qc) & (CAH_M2_SLOTS - 1)] : 0u;
+        const int begin = m2_dir_begin(d);
+        int left = m2_dir_count(d);
+        const int cls = cur_cls;
+        for (int u = begin; m2_any(left > 0); ++u, --left) {
+            bool emit = false;
+            int adapter = 0;
+            bool whole = false;
+            if (left > 0) {
+                const CahM2Slot e = s_ent[u];
+                const int q = m2_q(e.meta);
+                const bool match = m2_cls(e.meta) == cls && (q < 8 ? q : 8) == qc && (r & m2_mask(q)) == e.key;
+                const int dist = n - (p - q + 1);
+                adapter = m2_adapter(e.meta);
+                const unsigned bit = 1u << (adapter & 31);
+                uint32_t* const sw = s_wide + lr * words + (adapter >> 5);
+                uint32_t* const ss = s_seen + lr * words + (adapter >> 5);
+                const bool is_ref = match && m2_in_window(m2_ref_L(e.meta), dist);
+                const bool wide_only = match && !is_ref && m2_in_window(m2_wide_L(e.meta), dist);
+                if (wide_only) atomicOr(sw, bit);
+                if (is_ref) {
+                    const unsigned old = atomicOr(ss, bit);
+                    emit = (old & bit) == 0;
+                    whole = emit && ((*sw) & bit) != 0;
+                }
+            }
+            if (!m2_any(emit)) continue;
+            const int64_t rd = a.first_read + piece_first + lr;
+            // pairs that only the error-free rows can match: decided here
+            if (cls == M2_SHORT) {
+                if (emit && !whole) {
+                    const int i = m2_exact_tail(s_rlast[lr], s_prefix[adapter], min_overlap, lmax0, n);
+                    if (i > 0) atomicMax(a.best_key + rd, pack_best(i, 0, adapter, i, n - i, n));
+                    emit = false;
+                }
+                if (!m2_any(emit)) continue;
+            }
+            int pc, key;
+            unsigned flags = 0;
+            if (whole) { pc = m2_pair_class_w((n + 15) >> 4); key = 0; }
+            else if (cls == M2_W) {
+                key = (int)(s_first[lr] >> CAH_KEY_SHIFT);
+                key = key < CAH_QUEUE_BINS - 1 ? key : CAH_QUEUE_BINS - 1;
+                const int j0 = max(0, (key << CAH_KEY_SHIFT) - m - k - 1);
+                pc = m2_pair_class_w((n - j0 + 15) >> 4);
+            } else if (cls == M2_HI) { pc = 1; key = max(0, n - a.win_hi) >> 2; flags = CAH_M2_PAIR_TAIL; }
+            else { pc = 0; key = max(0, n - a.win_lo) >> 2; flags = CAH_M2_PAIR_TAIL; }
+            const uint64_t pair = ((uint64_t)(uint32_t)rd << 32) | ((uint64_t)flags << 24) | ((uint64_t)(unsigned)adapter << 8) | (unsigned)key;
+            unsigned long long em = __ballot(emit);
+            while (em) {
+                const int src = __ffsll((long long)em) - 1;
+                const int pc0 = __builtin_amdgcn_readlane(pc, src);
+                const unsigned long long mk = __ballot(emit && pc == pc0);
+                append_pairs(mk, pc0, emit && pc == pc0, pair);
+                em &= ~mk;
+            }
+        }
+    };
+    // the lanes of `mask` push one event each; the ring always has room for 64
+    auto push_events = [&](const unsigned long long mask, const bool mine, const uint32_t r, const int p, const int qc) {
+        if (ring_count > M2_RING - 64) resolve_round();
+        const unsigned at = (ring_head + ring_count + m2_rank(mask)) & (M2_RING - 1);
+        if (mine) s_ring[at] = (m2_u32x2){r, (unsigned)lane | ((unsigned)p << 8) | ((unsigned)qc << 16)};
+        ring_count += (unsigned)__popcll(mask);
+    };
+    auto drain = [&]() {
+        while (ring_count) resolve_round();
+    };
+    // one bitmap probe: does a k-mer of index class qc end with the word r?
+    auto probe = [&](const uint32_t r, const int qc) -> bool {
+        const uint32_t idx = m2_index(r, qc);
+        return ((s_bm[idx >> 5] >> (idx & 31)) & 1u) != 0;
+    };
+
+    unsigned p_cur = (unsigned)wave;
+    prefetch(piece_base(p_cur));
+#pragma unroll 1
+    for (;;) {
+        const unsigned kt = p_cur / PPT;
+        const int64_t tile_base64 = ((int64_t)blockIdx.x + (int64_t)kt * (int64_t)gridDim.x) * M2_TILE;
+        if (tile_base64 >= n_reads) break;
+        const int base = (int)tile_base64 + (int)(p_cur % PPT) * WAVE;
+        const bool more = (unsigned)base < (unsigned)n_reads;
+        const bool valid = more && (unsigned)(base + lane) < (unsigned)n_reads;
+        piece_first = base;
+        if (more) {
+            // ---- per-read state
+            for (int w = 0; w < words; ++w) { s_seen[lane * words + w] = 0; s_wide[lane * words + w] = 0; }
+            s_first[lane] = 0;
+            uint32_t r = 0x24924924u;                                   // ten characters that match nothing
+            uint32_t r_prev = r;                                        // the word at the end of the chunk before
+            bool had_hit = false;
+            unsigned seen_chars = 0;
+            cur_cls = M2_W;
+            m2_u32x4 cur = (m2_u32x4)(0u);
+#pragma unroll 1
+            for (int ph = 0; ph < 2; ++ph) {
+                const int H = ph ? H2 : H1;
+                if (H == 0) continue;
+                if (ph == 0) to_slot(std::integral_constant<int, 0>{}); else to_slot(std::integral_constant<int, 1>{});
+                const int pos0 = ph ? 16 * H1 : 0;
+                cur = finish(*reinterpret_cast<const m2_u32x4*>(row), pos0);
+#pragma unroll 1
+                for (int c = 0; c < H; ++c) {
+                    const int pos = pos0 + 16 * c;
+                    m2_u32x4 nxt = (m2_u32x4)(0u);
+                    if (c + 1 < H) nxt = finish(*reinterpret_cast<const m2_u32x4*>(row + 16 * (c + 1)), pos + 16);
+                    const unsigned w4[4] = {cur.x, cur.y, cur.z, cur.w};
+                    seen_chars |= cur.x | cur.y | cur.z | cur.w;
+                    // translate the chunk's characters (16 independent LDS reads), roll, probe
+                    uint32_t e[16];
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) e[t] = s_xlat[(w4[t >> 2] >> (8 * (t & 3))) & 127u];
+                    uint32_t rr5 = 0;
+                    unsigned hits = 0;
+                    if (w_only8) {
+                        uint32_t rr[16];
+#pragma unroll
+                        for (int t = 0; t < 16; ++t) { r = (r << 3) | e[t]; rr[t] = r; }
+                        rr5 = rr[5];
+                        uint32_t wd[16];
+#pragma unroll
+                        for (int t = 0; t < 16; ++t) {
+                            const uint32_t idx = (rr[t] ^ (rr[t] >> 8)) & 0xFFFFu;        // m2_index(r, 8): the salt of class 8 is 0
+                            wd[t] = s_bm[idx >> 5];
+                        }
+#pragma unroll
+                        for (int t = 0; t < 16; ++t) {
+                            const uint32_t idx = rr[t] ^ (rr[t] >> 8);
+                            hits |= ((wd[t] >> (idx & 31)) & 1u) << t;
+                        }
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < 16; ++t) {
+                            r = (r << 3) | e[t];
+                            if (t == 5) rr5 = r;
+                            bool h = false;
+                            for (int qc = 1; qc <= 8; ++qc)
+                                if ((qmask_w >> qc) & 1) h = h || probe(r, qc);
+                            hits |= (h ? 1u : 0u) << t;
+                        }
+                    }
+                    if (pos + 16 > n) hits &= (1u << (n - pos)) - 1u;   // positions past the read's end
+                    if (!valid) hits = 0;
+                    if (m2_any(hits != 0)) {
+                        if (hits != 0 && !had_hit) { had_hit = true; s_first[lane] = (uint32_t)pos; }
+                        // the word at position pos + t from the words at the ends of this chunk, of its first six
+                        // characters and of the chunk before (ten characters each, 30 bits)
+                        const uint64_t v_lo = ((uint64_t)r_prev << 30) | (uint64_t)(rr5 & 0x3FFFFFFFu);     // .. pos + 5
+                        const uint64_t v_hi = ((uint64_t)rr5 << 30) | (uint64_t)(r & 0x3FFFFFFFu);           // .. pos + 15
+                        while (m2_any(hits != 0)) {
+                            const bool mine = hits != 0;
+                            const int t = mine ? (int)__builtin_ctz(hits) : 0;
+                            hits &= hits - 1u;
+                            const uint32_t rt = t <= 5 ? (uint32_t)(v_lo >> (3 * (5 - t))) : (uint32_t)(v_hi >> (3 * (15 - t)));
+                            const unsigned long long mk = __ballot(mine);
+                            if (w_only8) {
+                                push_events(mk, mine, rt & 0x3FFFFFFFu, pos + t, 8);
+                            } else {
+                                // (several index classes: one event per class that hits)
+                                for (int qc = 1; qc <= 8; ++qc) {
+                                    if (!((qmask_w >> qc) & 1)) continue;
+                                    const bool hq = mine && probe(rt, qc);
+                                    const unsigned long long mq = __ballot(hq);
+                                    if (mq) push_events(mq, hq, rt & 0x3FFFFFFFu, pos + t, qc);
+                                }
+                            }
+                        }
+                    }
+                    r_prev = r;
+                    cur = nxt;
+                }
+            }
+            s_rlast[lane] = r;
+            drain();
+            // ---- the tail sweeps: classes hi, lo, REF-only, each resolved before the next
+            const int tail_off = H2 > 0 ? 16 * H1 : 0;                  // first position the slot still holds
+#pragma unroll 1
+            for (int cls = M2_HI; cls <= M2_SHORT; ++cls) {
+                const int qm = hd->q_mask[cls];
+                if (!qm) continue;
+                cur_cls = cls;
+                // first position a k-mer of the class may start at: the word starts empty there (a k-mer that began
+                // earlier lies outside every window of the class); the launcher checked that the slot still holds it
+                const int from = max(tail_off, n - hd->span[cls]);
+                uint32_t rs = 0x24924924u;
+#pragma unroll 1
+                for (int p = from; p < n; ++p) {
+                    const unsigned ch = row[p - tail_off];
+                    rs = ((rs << 3) | s_xlat[ch & 127u]) & 0x3FFFFFFFu;
+#pragma unroll 1
+                    for (int qc = 1; qc <= 8; ++qc) {
+                        if (!((qm >> qc) & 1)) continue;
+                        if (n - p + qc - 1 > hd->open_L[cls][qc]) continue;
+                        const bool h = valid && probe(rs, qc);
+                        const unsigned long long mk = __ballot(h);
+                        if (mk) push_events(mk, h, rs, p, qc);
+                    }
+                }
+                drain();
+            }
+            if (valid && (seen_chars & 0x80808080u) != 0) a.status[a.first_read + base + lane] = 2;
+        }
+        const unsigned p_next = take_piece();
+        prefetch(piece_base(p_next));
+        p_cur = p_next;
+    }
+    // close the wave's open pages
+    if (lane < CAH_M2_PAIR_CLASSES) {
+        const unsigned page = s_pg[2 * lane], fill = s_pg[2 * lane + 1];
+        if (page != 0xFFFFFFFFu && (int64_t)page < a.max_pages) a.page_hdr[page] = ((unsigned)lane << 24) | fill;
+    }
+}
+
+// =============================================================================================
+// k_multi_scan: the cost scan (back_scan.h) of the pairs k_multi_stream left, page by page.  A page holds pairs of ONE
+// class, so the 64 lanes of a wave scan windows of one shape: "lo" pages ~24 columns and the rows an overlap of the
+// first error class can reach, "hi" pages the reach of the widest tail class, whole-read pages from the first k-mer
+// hit on (binned by window length).  Matches are merged with one atomicMax on the read's best key (kernels.h:
+// pack_best); pairs that need cells go to k_dp_packed<ROWS, true>'s work list with a window that is safe for the cell
+// DP (tail pairs: the full reach m + k + 1, see multi2_model.cpp).
+// =============================================================================================
+template <int KIND>
+__global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_multi_scan(Multi2ScanArgs a) {
+    constexpr int XR = KIND >= 2 ? KIND - 1 : 0;
+    extern __shared__ __attribute__((aligned(16))) uint64_t s_scanmask[];   // [n_adapters * CAH_MULTI_TAB_STRIDE]
+    __shared__ int s_thr_last[CAH_MAX_M + 1];
+    __shared__ int s_list[CAH_M2_PAGE * 3];
+    __shared__ unsigned s_nf, s_nb;
+    __shared__ long long s_page;
+    __shared__ unsigned long long s_gf, s_gb;
+    const CahMatcher* mt = a.matcher;
+    for (int i = threadIdx.x; i < a.n_adapters * CAH_MULTI_TAB_STRIDE; i += blockDim.x)
+        s_scanmask[i] = KIND == 0 ? a.tab[i] : bs32_table_entry(a.tab[i], mt->m);
+    for (int i = threadIdx.x; i <= CAH_MAX_M; i += blockDim.x) s_thr_last[i] = mt->thr_last[i];
+    BackScanParams p;
+    p.m = mt->m; p.k = mt->k; p.kacc = mt->kacc; p.min_overlap = mt->min_overlap; p.half_m = mt->m / 2;
+    const int reach = p.m + p.k + 1;
+    const int lane = wave_lane();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int n = a.uniform_len;
+    int64_t n_pages = (int64_t)(*a.page_counter);
+    if (n_pages > a.max_pages) n_pages = a.max_pages;
+
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            s_page = (long long)atomicAdd(a.work_counter, 1ull);
+            s_nf = 0; s_nb = 0;
+        }
+        __syncthreads();
+        const int64_t page = s_page;
+        if (page >= n_pages) break;
+        const uint32_t hdr = a.page_hdr[page];
+        const int count = (int)(hdr & 0xFFFFFFu);
+        const bool tail_page = (hdr >> 24) < 2u;                          // classes lo, hi: every pair has the same window
+        for (int sub = wave; sub * WAVE < count; sub += 4) {
+            const int e0 = sub * WAVE + lane;
+            const bool valid = e0 < count;
+            const int64_t idx = page * CAH_M2_PAGE + e0;
+            int64_t r = 0;
+            unsigned tab_base = 0, adapter = 0, key = 0;
+            bool tail = tail_page;
+            if (valid) {
+                const uint64_t pr = a.pairs[idx];
+                r = (int64_t)(pr >> 32);
+                adapter = (unsigned)(pr >> 8) & 0xFFFFu;
+                key = (unsigned)pr & 0xFFu;
+                tail = ((unsigned)(pr >> 24) & CAH_M2_PAIR_TAIL) != 0;
+                tab_base = adapter * CAH_MULTI_TAB_STRIDE;
+            }
+            const uint8_t* q = a.seqs + a.uniform_first + r * (int64_t)n;
+            // the pair's window: tail pairs from column 4 * key, whole-read pairs from (first hit) - m - k - 1; the scan
+            // itself starts a whole number of 16-column chunks in front of the read end and (tail pages: the same for
+            // every lane) skips the first chunk's columns in front of the window
+            int j0w = tail ? ((int)key << 2) : max(0, ((int)key << CAH_KEY_SHIFT) - p.m - p.k - 1);
+            j0w = min(j0w, n);
+            const int j0 = bs_align_window(j0w, n);
+            int t0 = 0;
+            if (tail_page) {
+                int d = valid ? j0w - j0 : 16;
+#pragma unroll
+                for (int sft = 1; sft < WAVE; sft <<= 1) d = min(d, __shfl_xor(d, sft, WAVE));
+                t0 = __builtin_amdgcn_readfirstlane(d) & 15;
+            }
+            const int jstart = j0 + t0;                                 // first column the scan really looks at
+            auto eq_of = [&](const Chunk& ck, int t) -> uint64_t {
+                return s_scanmask[tab_base + multi_tab_index2(chunk_byte(ck, t) & 0xFFu)];
+            };
+            typename std::conditional<KIND == 0, BackScanState, BackScanState32<XR>>::type st;
+            if constexpr (KIND == 0) bs_init(st, p); else bs32_init(st, p);
+            auto step = [&](const uint64_t eq, const int jj) -> bool {
+                if constexpr (KIND == 0) return bs_step<false>(st, eq, jj, p);
+                else return bs32_step<false, XR>(st, (uint32_t)eq, (uint32_t)(eq >> 32), jj, p);
+            };
+            int j = jstart, exact_j = 0;
+            bool done = !valid, exact = false;
+            int pos = j0;
+            Chunk cur = load_chunk(q, pos, n, valid ? n : 0);
+            int first_t = t0;
+            for (;;) {
+                const unsigned long long act = __ballot(!done && j < n);
+                if (!act) break;
+                const Chunk nxt = load_chunk(q, pos + 16, n, (!done) ? n : 0);
+                uint64_t eqq[2];
+                eqq[0] = eq_of(cur, first_t & 15);
+                eqq[1] = eq_of(cur, (first_t + 1) & 15);
+                // (the windows end at the read end and start on chunk borders: every lane at work has the whole chunk)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    if (t < first_t) continue;                          // wave-uniform: the first chunk of a tail page
+                    const uint64_t eq = eqq[t & 1];
+                    if (t + 2 < 16) eqq[t & 1] = eq_of(cur, t + 2);
+                    ++j;
+                    if (step(eq, j) && !exact) { exact = true; exact_j = j; }
+                }
+                if (exact) done = true;
+                first_t = 0;
+                pos += 16;
+                cur = nxt;
+            }
+            int o0 = 0, o1 = 0;
+            // rows that cannot be acceptable are not looked at: an acceptable row's alignment lies inside the window
+            int max_row = valid ? min(p.m, n - j0w + p.kacc) : 0;
+#pragma unroll
+            for (int sft = 1; sft < WAVE; sft <<= 1) max_row = max(max_row, __shfl_xor(max_row, sft, WAVE));
+            max_row = __builtin_amdgcn_readfirstlane(max_row);
+            int cls;
+            if constexpr (KIND == 0) cls = bs_finish<false>(st, n, jstart, p, [&](int i) { return s_thr_last[i]; }, o0, o1, false, max_row);
+            else cls = bs32_finish<XR, false>(st, n, jstart, p, [&](int i) { return s_thr_last[i]; }, o0, o1, false, max_row);
+            if (exact) { cls = BS_EXACT_FULL; o0 = exact_j; }
+            if (valid) {
+                if (cls == BS_EXACT_FULL) atomicMax(a.best_key + r, pack_best(p.m, 0, (int)adapter, p.m, o0 - p.m, o0));
+                else if (cls == BS_EXACT_TAIL) atomicMax(a.best_key + r, pack_best(o0 - 2 * o1, o1, (int)adapter, o0, n - o0, n));
+            }
+            // the cell DP of a tail pair runs over the full reach: band, last_filled and the stale origin of its final
+            // scan are only proven equal to the reference's from column start + m + k + 1 on (column skipping)
+            if (cls == BS_DP && tail) o0 = max(0, (st.jfa >= 0 ? st.jfa : n) - reach);
+            const bool to_dp = valid && cls == BS_DP;
+            const bool to_back = to_dp && (o1 & 1);
+            const bool to_front = to_dp && !(o1 & 1);
+            const unsigned long long bf = __ballot(to_front), bb = __ballot(to_back);
+            if (bf | bb) {
+                unsigned sf = 0, sb = 0;
+                if (lane == 0) {
+                    if (bf) sf = atomicAdd(&s_nf, (unsigned)__popcll(bf));
+                    if (bb) sb = atomicAdd(&s_nb, (unsigned)__popcll(bb));
+                }
+                sf = __builtin_amdgcn_readfirstlane(sf);
+                sb = __builtin_amdgcn_readfirstlane(sb);
+                const unsigned long long below = (1ull << lane) - 1ull;
+                if (to_front) {
+                    const int e = (int)sf + __popcll(bf & below);
+                    s_list[3 * e] = (int)idx; s_list[3 * e + 1] = o0; s_list[3 * e + 2] = o1;
+                } else if (to_back) {
+                    const int e = CAH_M2_PAGE - 1 - ((int)sb + __popcll(bb & below));
+                    s_list[3 * e] = (int)idx; s_list[3 * e + 1] = o0; s_list[3 * e + 2] = o1;
+                }
+            }
+        }
+        // flush the page's DP work list
+        __syncthreads();
+        const unsigned nf = s_nf, nb = s_nb;
+        if (threadIdx.x == 0) {
+            s_gf = nf ? atomicAdd(a.dp_count_front, (unsigned long long)nf) : 0ull;
+            s_gb = nb ? atomicAdd(a.dp_count_back, (unsigned long long)nb) : 0ull;
+        }
+        __syncthreads();
+        const unsigned long long gf = s_gf, gb = s_gb;
+        for (unsigned e = threadIdx.x; e < nf; e += blockDim.x) {
+            const int64_t slot = (int64_t)(gf + e);
+            a.dp_queue[slot] = s_list[3 * e];
+            a.dp_win[2 * slot] = s_list[3 * e + 1];
+            a.dp_win[2 * slot + 1] = s_list[3 * e + 2];
+        }
+        for (unsigned e = threadIdx.x; e < nb; e += blockDim.x) {
+            const int64_t slot = a.dp_cap - 1 - (int64_t)(gb + e);
+            const int le = CAH_M2_PAGE - 1 - (int)e;
+            a.dp_queue[slot] = s_list[3 * le];
+            a.dp_win[2 * slot] = s_list[3 * le + 1];
+            a.dp_win[2 * slot + 1] = s_list[3 * le + 2];
+        }
+    }
+}
+
+// ---- launchers ----------------------------------------------------------------------------------------------------
+size_t multi2_lds_bytes(const CahMulti2Header& h) { return m2_layout((int)h.n_entries, h.n_adapters).total; }
+
+// the batch's read length must leave every tail sweep inside the half-row the slot still holds after the main pass
+bool multi2_read_len_ok(const CahMulti2Header& h, int n) {
+    if (!h.ok || n < 16 || n > M2_MAX_LEN) return false;
+    if (multi2_lds_bytes(h) > 160 * 1024) return false;
+    const int U = (n + 15) >> 4, H1 = (U + 1) >> 1, H2 = U - H1;
+    const int tail_off = H2 > 0 ? 16 * H1 : 0;
+    for (int c = M2_HI; c <= M2_SHORT; c++)
+        if (h.q_mask[c] && tail_off > 0 && n - h.span[c] < tail_off) return false;
+    return true;
+}
+
+hipError_t launch_multi_stream(const Multi2Args& a, const CahMulti2Header& h, int n_cus, hipStream_t s) {
+    const size_t lds = multi2_lds_bytes(h);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_multi_stream, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int tiles = (int)((a.n_reads + M2_TILE - 1) / M2_TILE);
+    const int grid = std::max(1, std::min(tiles, n_cus));
+    hipLaunchKernelGGL(k_multi_stream, dim3(grid), dim3(M2_WAVES * WAVE), lds, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_multi_scan(const Multi2ScanArgs& a, int64_t max_pages, int n_cus, hipStream_t s) {
+    int64_t need = max_pages < 1 ? 1 : max_pages;
+    const int64_t cap = (int64_t)8 * n_cus;
+    const dim3 grid((unsigned)(need < cap ? need : cap));
+    const size_t lds = sizeof(uint64_t) * (size_t)a.n_adapters * CAH_MULTI_TAB_STRIDE;
+    switch (a.kind) {
+        case 1: hipLaunchKernelGGL((k_multi_scan<1>), grid, dim3(256), lds, s, a); break;
+        case 2: hipLaunchKernelGGL((k_multi_scan<2>), grid, dim3(256), lds, s, a); break;
+        case 3: hipLaunchKernelGGL((k_multi_scan<3>), grid, dim3(256), lds, s, a); break;
+        default: hipLaunchKernelGGL((k_multi_scan<0>), grid, dim3(256), lds, s, a); break;
+    }
+    return hipGetLastError();
+}

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define CAH_ABI_VERSION 2   /* 2: CAH_PROF_N = 5, plan workspaces (cah_plan_workspace_bytes), no adapter length limit */
+#define CAH_ABI_VERSION 3   /* 2: CAH_PROF_N = 5, plan workspaces (cah_plan_workspace_bytes), no adapter length limit; 3: cah_plan_multi_kind */
 
 /* status codes */
 #define CAH_OK 0
@@ -131,6 +131,13 @@ int cah_plan_n_kmer_entries(const cah_plan *plan, int32_t adapter, int32_t *out)
 #define CAH_PREFILTER_GENERAL 1
 #define CAH_PREFILTER_LEAN 2
 int cah_plan_prefilter_kind(const cah_plan *plan, int32_t adapter, int32_t *out);
+/* how a batch of equally long reads of `read_len` characters is matched against ALL adapters of the plan
+ * (MultipleAdapters.match_to, adapters.py:1265-1286): one adapter after the other, one fused prefilter pass over
+ * (read, adapter) pairs, or its streaming form (k_multi_stream: LDS-staged reads, pairs in pages by window class) */
+#define CAH_MULTI_SEQUENTIAL 0
+#define CAH_MULTI_FUSED 1
+#define CAH_MULTI_STREAM 2
+int cah_plan_multi_kind(const cah_plan *plan, int32_t read_len, int32_t *out);
 /* Introspection for tests: copies the host-side matcher table of an adapter (struct CahMatcher of
  * cutadapt_amd/csrc/cah_device.h: DP constants, row bitsets, cost-scan tables) into buf; *need receives
  * its size.  The layout is internal to the library version. */

@@ -1,0 +1,203 @@
+// multi2_model.cpp -- HOST MODEL of the streaming multi-adapter path (k_multi_stream + k_multi_scan, multi2.hip).
+// TEST INFRASTRUCTURE ONLY: the product never loads this file.
+//
+// Compiles the product's own table builder and rules (cutadapt_amd/csrc/multi2.h) and classification
+// (back_scan.h) with g++ and replays, read by read and sequentially, what the kernels do: the main pass over the
+// read (class W k-mers), the three tail sweeps (hi, lo, short) in this order, `seen` / `wide only` / `first`, the
+// error-free suffix compare, and for every pair the cost scan on the pair's window followed by the shortcut or the
+// windowed cell DP.  tests/test_multi2_model.py compares the merged result (MultipleAdapters' order) with the
+// oracle's kmers_present + locate on the whole read.
+#include "back_model.cpp"
+
+#include "../../cutadapt_amd/csrc/multi2.h"
+
+// (kernels.h needs the HIP runtime; the three things of it the model uses, restated)
+#define CAH_KEY_SHIFT 2
+#define CAH_QUEUE_BINS 256
+static inline unsigned long long pack_best(int score, int errors, int adapter, int ref_stop, int query_start, int query_stop) {
+    return ((unsigned long long)(unsigned)(score + 128) << 54) | ((unsigned long long)(unsigned)(127 - errors) << 47) |
+           ((unsigned long long)(unsigned)(4095 - adapter) << 35) | ((unsigned long long)(unsigned)ref_stop << 28) |
+           ((unsigned long long)(unsigned)query_start << 8) | (unsigned long long)(unsigned)(query_stop - query_start);
+}
+
+namespace {
+
+struct Pair { int adapter; unsigned flags; int key; };
+
+struct ReadState {
+    bool seen[128], wideonly[128];
+    int first = -1;
+    std::vector<Pair> pairs;
+    std::vector<std::pair<int, int>> exact;      // (adapter, overlap) decided by the suffix compare
+    int conservative = 0;
+};
+
+void resolve(const M2Tables& t, ReadState& st, uint32_t r, int qc, int cls, int p, int n, uint32_t rlast) {
+    const CahMulti2Header& h = t.hdr;
+    const uint32_t d = t.dir[m2_index(r, qc) & (CAH_M2_SLOTS - 1)];
+    for (int u = m2_dir_begin(d); u < m2_dir_begin(d) + m2_dir_count(d); u++) {
+        const CahM2Slot& e = t.entries[(size_t)u];
+        const uint32_t meta = e.meta;
+        const int q = m2_q(meta);
+        if (m2_cls(meta) != cls || std::min(q, 8) != qc || (r & m2_mask(q)) != e.key) continue;
+        const int dist = n - (p - q + 1);
+        const int a = m2_adapter(meta);
+        if (!m2_in_window(m2_ref_L(meta), dist)) {
+            if (m2_in_window(m2_wide_L(meta), dist)) st.wideonly[a] = true;
+            continue;
+        }
+        if (st.seen[a]) continue;
+        st.seen[a] = true;
+        if (st.wideonly[a]) { st.pairs.push_back({a, 0u, 0}); st.conservative++; }
+        else if (cls == M2_W) st.pairs.push_back({a, 0u, std::min(std::max(st.first, 0) >> CAH_KEY_SHIFT, CAH_QUEUE_BINS - 1)});
+        else if (cls == M2_HI) st.pairs.push_back({a, CAH_M2_PAIR_TAIL, std::max(0, n - h.win_dist[M2_HI]) >> 2});
+        else if (cls == M2_LO) st.pairs.push_back({a, CAH_M2_PAIR_TAIL, std::max(0, n - h.win_dist[M2_LO]) >> 2});
+        else {
+            const int i = m2_exact_tail(rlast, t.prefix[(size_t)a], h.min_overlap, h.lmax0, n);
+            if (i > 0) st.exact.push_back({a, i});
+        }
+    }
+}
+
+void filter_read(const M2Tables& t, const uint8_t* q, int n, ReadState& st) {
+    const CahMulti2Header& h = t.hdr;
+    memset(st.seen, 0, sizeof(st.seen));
+    memset(st.wideonly, 0, sizeof(st.wideonly));
+    std::vector<uint32_t> rr((size_t)n + 1);
+    uint32_t r = 0x24924924u;                                         // ten invalid characters
+    for (int p = 0; p < n; p++) { r = (r << 3) | m2_code(q[p]); rr[(size_t)p] = r; }
+    const uint32_t rlast = n > 0 ? rr[(size_t)n - 1] : 0x24924924u;
+    for (int cls = 0; cls < 4; cls++) {
+        if (!h.q_mask[cls]) continue;
+        const int from = cls == M2_W ? 0 : std::max(0, n - h.span[cls]);
+        for (int p = from; p < n; p++) {
+            for (int qc = 1; qc <= 8; qc++) {
+                if (!((h.q_mask[cls] >> qc) & 1)) continue;
+                const int dist_min = n - p + qc - 1;
+                if (dist_min > h.open_L[cls][qc]) continue;
+                const uint32_t idx = m2_index(rr[(size_t)p], qc);
+                if (!((t.bitmap[idx >> 5] >> (idx & 31)) & 1u)) continue;
+                if (cls == M2_W && st.first < 0) st.first = p & ~15;
+                resolve(t, st, rr[(size_t)p], qc, cls, p, n, rlast);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+// adapters: A strings of m characters back to back.  blobs: A CahMatcher structs (cah_plan_debug_matcher).
+// ref_*: the reference search sets, flattened: adapter index, window (255 = whole read, else L of (-L, None)), k-mer
+// (NUL-terminated strings back to back).  subs: 1 = the scan keeps the SUBS_FULL / INDEL1_FULL bookkeeping.
+// stats (may be NULL): [0] pairs W, [1] pairs hi, [2] pairs lo, [3] suffix compares that matched, [4] pairs that take the whole read because a WIDE-only hit came first,
+// [5] scan columns, [6] pairs to the cell DP.
+// Returns 0; 1 when the tables cannot be built (the plan would take the older path).
+int m2m_match_batch(const char* adapters, int A, int m, const void* blobs, int32_t n_ref, const int32_t* ref_adapter,
+                    const int32_t* ref_window, const char* ref_kmers, const uint8_t* seqs, const int64_t* offsets,
+                    int64_t n_reads, int32_t* out6, uint8_t* status, int32_t* best, int subs, int64_t* stats) {
+    std::vector<std::string> ads;
+    for (int a = 0; a < A; a++) ads.push_back(std::string(adapters + (size_t)a * m, (size_t)m));
+    std::vector<CahMatcher> mts((size_t)A);
+    memcpy(mts.data(), blobs, sizeof(CahMatcher) * (size_t)A);
+    std::vector<std::vector<M2RefKmer>> ref((size_t)A);
+    const char* kp = ref_kmers;
+    for (int i = 0; i < n_ref; i++) {
+        ref[(size_t)ref_adapter[i]].push_back({std::string(kp), ref_window[i]});
+        kp += strlen(kp) + 1;
+    }
+    M2Tables t;
+    const CahMatcher& m0 = mts[0];
+    if (!m2_build(ads, m0.thr_last, m0.kacc, m0.k, m0.min_overlap, ref, t)) return 1;
+    BackScanParams p;
+    p.m = m0.m; p.k = m0.k; p.kacc = m0.kacc; p.min_overlap = m0.min_overlap; p.half_m = m0.m / 2;
+    const int kind = bs_kind_of(p.m);
+    const int reach = p.m + p.k + 1;
+    for (int64_t r = 0; r < n_reads; r++) {
+        const uint8_t* q = seqs + offsets[r];
+        const int n = (int)(offsets[r + 1] - offsets[r]);
+        int32_t* o = out6 + r * 6;
+        for (int i = 0; i < 6; i++) o[i] = 0;
+        status[r] = 0; best[r] = -1;
+        bool invalid = false;
+        for (int i = 0; i < n; i++) invalid = invalid || q[i] >= 0x80;
+        if (invalid) { status[r] = 2; continue; }
+        ReadState st;
+        filter_read(t, q, n, st);
+        unsigned long long bestkey = 0;
+        for (auto& ex : st.exact) {
+            bestkey = std::max(bestkey, pack_best(ex.second, 0, ex.first, ex.second, n - ex.second, n));
+            if (stats) stats[3]++;
+        }
+        if (stats) stats[4] += st.conservative;
+        for (const Pair& pr : st.pairs) {
+            const CahMatcher& mt = mts[(size_t)pr.adapter];
+            const bool tail = (pr.flags & CAH_M2_PAIR_TAIL) != 0;
+            int j0 = tail ? (pr.key << 2) : std::max(0, (pr.key << CAH_KEY_SHIFT) - p.m - p.k - 1);
+            j0 = bs_align_window(std::min(j0, n), n);
+            if (stats) { stats[tail ? (j0 >= n - t.hdr.win_dist[M2_LO] - 15 && t.hdr.win_dist[M2_LO] != t.hdr.win_dist[M2_HI] ? 2 : 1) : 0]++; stats[5] += n - j0; }
+            uint64_t tab32[128];
+            for (int c = 0; c < 128; c++) tab32[c] = bs32_table_entry(mt.scanmask[c], p.m);
+            bool exact = false;
+            int j = j0, o0 = 0, o1 = 0, cls = BS_NONE, jfa = -1;
+            auto thr = [&](int i) { return mt.thr_last[i]; };
+            auto run = [&](auto& s, auto step, auto finish) {
+                while (j < n) {
+                    ++j;
+                    if (step(s, q[j - 1] & 127)) { exact = true; break; }
+                }
+                jfa = s.jfa;
+                if (exact) { cls = BS_EXACT_FULL; o0 = j; }
+                else cls = finish(s);
+            };
+#define M2M_RUN32(X)                                                                                                      \
+            {                                                                                                             \
+                BackScanState32<X> s;                                                                                     \
+                bs32_init(s, p);                                                                                          \
+                if (subs) run(s, [&](BackScanState32<X>& z, int c) { return bs32_step<true, X>(z, (uint32_t)tab32[c], (uint32_t)(tab32[c] >> 32), j, p); }, \
+                              [&](BackScanState32<X>& z) { return bs32_finish<X, true>(z, n, j0, p, thr, o0, o1, false); }); \
+                else run(s, [&](BackScanState32<X>& z, int c) { return bs32_step<false, X>(z, (uint32_t)tab32[c], (uint32_t)(tab32[c] >> 32), j, p); }, \
+                         [&](BackScanState32<X>& z) { return bs32_finish<X, false>(z, n, j0, p, thr, o0, o1, false); });  \
+            }
+            if (kind == 0) {
+                BackScanState s;
+                bs_init(s, p);
+                if (subs) run(s, [&](BackScanState& z, int c) { return bs_step<true>(z, mt.scanmask[c], j, p); },
+                              [&](BackScanState& z) { return bs_finish<true>(z, n, j0, p, thr, o0, o1, false); });
+                else run(s, [&](BackScanState& z, int c) { return bs_step<false>(z, mt.scanmask[c], j, p); },
+                         [&](BackScanState& z) { return bs_finish<false>(z, n, j0, p, thr, o0, o1, false); });
+            } else if (kind == 1) M2M_RUN32(0)
+            else if (kind == 2) M2M_RUN32(1)
+            else M2M_RUN32(2)
+#undef M2M_RUN32
+            unsigned long long key = 0;
+            if (cls == BS_EXACT_FULL) key = pack_best(p.m, 0, pr.adapter, p.m, o0 - p.m, o0);
+            else if (cls == BS_EXACT_TAIL) key = pack_best(o0 - 2 * o1, o1, pr.adapter, o0, n - o0, n);
+            else if (cls == BS_SUBS_FULL) key = pack_best(p.m - 2 * o1, o1, pr.adapter, p.m, o0 - p.m, o0);
+            else if (cls == BS_INDEL1_FULL)
+                key = pack_best(p.m - 2 * (o1 >> 1) - (o1 & 1), o1 >> 1, pr.adapter, p.m, o0 - p.m + ((o1 & 1) ? 1 : -1), o0);
+            else if (cls == BS_DP) {
+                // a tail pair's cell DP runs over the FULL reach (the band, last_filled and the stale origin of the
+                // final scan are only proven equal to the reference's from column start + m + k + 1 on)
+                if (tail) o0 = std::max(0, (jfa >= 0 ? jfa : n) - reach);
+                int t6[6];
+                if (stats) stats[6]++;
+                if (dp_window(mt, q, n, o0, std::min(n, o1 >> 1), (o1 & 1) != 0, t6))
+                    key = pack_best(t6[4], t6[5], pr.adapter, t6[1], t6[2], t6[3]);
+            }
+            bestkey = std::max(bestkey, key);
+        }
+        if (bestkey) {
+            const unsigned long long k = bestkey;
+            const int rel = (int)(k & 0xFFu), qstart = (int)((k >> 8) & 0xFFFFFu), ref_stop = (int)((k >> 28) & 0x7Fu);
+            o[0] = 0; o[1] = ref_stop; o[2] = qstart; o[3] = qstart + rel;
+            o[4] = (int)((k >> 54) & 0xFFu) - 128; o[5] = 127 - (int)((k >> 47) & 0x7Fu);
+            best[r] = 4095 - (int)((k >> 35) & 0xFFFu);
+            status[r] = 1;
+        }
+    }
+    return 0;
+}
+
+}  // extern "C"

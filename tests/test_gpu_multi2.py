@@ -1,0 +1,116 @@
+"""The streaming form of the fused multi-adapter path (k_multi_stream + k_multi_scan, cutadapt_amd/csrc/multi2.hip)
+on the GPU against the oracle applying MultipleAdapters' rule (reference adapters.py:1265-1286: kmers_present +
+locate of every adapter on the whole read, best by score, errors, first adapter).  Equally long reads; the CPU twin of
+these checks (the rules without the kernel) is tests/test_multi2_model.py."""
+import random
+
+import numpy as np
+import pytest
+
+from test_gpu_multi import env, oracle_multiple, plan_for, rs
+from test_multi2_model import tail_reads
+
+pytestmark = pytest.mark.gpu
+
+
+def run_uniform(orc, seqs, rate, min_overlap, reads, what, expect="stream", pair_cap=None):
+    from cutadapt_amd.batch import ReadBatch, match_batch
+    n = len(reads[0])
+    assert all(len(r) == n for r in reads)
+    plan, ads = plan_for(seqs, rate, min_overlap)
+    if expect is not None:
+        assert plan.multi_kind(n) == expect, (what, plan.multi_kind(n))
+    sq, offs = orc.pack_reads(reads)
+    batch = ReadBatch.from_host(sq, offs)
+    assert batch.uniform_len == n
+    with env(CAH_MULTI_PAIR_CAP=pair_cap):
+        res = match_batch(plan, batch)
+        got6, got_st, got_best = res.cpu()
+    want6, want_st, want_best = oracle_multiple(orc, ads, sq, offs)
+    bad = np.nonzero((got_st != want_st) | (got6 != want6).any(axis=1))[0]
+    assert len(bad) == 0, (what, len(bad), bad[:5], got_st[bad[:3]], got6[bad[:3]], want_st[bad[:3]], want6[bad[:3]],
+                           reads[int(bad[0])])
+    f = want_st == 1
+    assert np.array_equal(got_best[f], want_best[f]), what
+    return int(f.sum())
+
+
+def test_c4_reads_vs_oracle(hip, orc):
+    """the benchmark's adapters and reads; batch sizes around the piece (64), tile (8192) and page borders"""
+    from cutadapt_amd import workloads
+    ads = workloads.SPECS["C4"]["adapters"]
+    for n_reads, seed in ((1, 1), (63, 2), (64, 3), (65, 4), (8191, 5), (8193, 6), (40_000, 7)):
+        sq, offs = orc.synth_reads(seed, 0, n_reads, 150, ads)
+        reads = [bytes(sq[offs[i]:offs[i + 1]]).decode() for i in range(n_reads)]
+        found = run_uniform(orc, ads, 0.1, 3, reads, f"C4 x {n_reads}")
+        if n_reads >= 8191:
+            assert found > 0.2 * n_reads
+    # several chunks (a small pair capacity), adapters everywhere, many errors
+    sq, offs = orc.synth_reads(8, 0, 30_000, 150, ads, p_adapter=0.9, p_edit=0.08, p_n=0.02)
+    reads = [bytes(sq[offs[i]:offs[i + 1]]).decode() for i in range(30_000)]
+    run_uniform(orc, ads, 0.1, 3, reads, "C4 dense, chunked", pair_cap=96 * 6000)
+
+
+def test_uniform_fuzz_vs_oracle(hip, orc):
+    """random adapter sets of one shape x reads that end with (edited) adapter prefixes, every eligible read length"""
+    rng = np.random.default_rng(2024)
+    prng = random.Random(7)
+    streamed = 0
+    for it in range(36):
+        m = int(rng.choice([12, 20, 25, 30, 33, 34, 40, 50, 64]))
+        count = int(rng.choice([2, 8, 24, 96, 128]))
+        seqs = [rs(prng, m) for _ in range(count)]
+        if it % 4 == 0:
+            seqs[1] = seqs[0][:-1] + prng.choice("ACGT")
+            seqs[-1] = seqs[0]
+        rate = float(rng.choice([0.1, 0.12, 0.2]))
+        O = int(rng.choice([1, 3, 5]))
+        n = int(rng.choice([16, 31, 64, 80, 100, 117, 150, 160]))
+        reads = tail_reads(rng, seqs, 3000, n, p_n=float(rng.choice([0.0, 0.01])))
+        reads = [r if len(r) == n else (r + "A" * n)[:n] for r in reads]
+        if it % 5 == 0:
+            reads = [r.lower() if i % 7 == 0 else r for i, r in enumerate(reads)]
+        plan, _ = plan_for(seqs, rate, O)
+        kind = plan.multi_kind(n)
+        streamed += kind == "stream"
+        run_uniform(orc, seqs, rate, O, reads, f"it {it} m {m} x {count} rate {rate} O {O} n {n} ({kind})", expect=None,
+                    pair_cap=count * 700 if it % 3 == 0 else None)
+    assert streamed >= 15, streamed
+
+
+def test_stream_equals_older_fused_path_at_scale(hip):
+    """2 M reads: the streaming form and k_multi_filter + k_back_scan<true> of the same library agree read for read"""
+    import torch
+    from cutadapt_amd.batch import ReadBatch, match_batch
+    rng = random.Random(97)
+    for n_adapters, m, n_reads in ((96, 33, 2_000_000), (24, 20, 1_000_000)):
+        seqs = [rs(rng, m) for _ in range(n_adapters)]
+        batch = ReadBatch.synthetic(n_reads, 150, seqs, seed=50 + n_adapters, p_adapter=0.4, p_edit=0.04, p_n=0.01)
+        plan, _ = plan_for(seqs, 0.1, 3)
+        assert plan.multi_kind(150) == "stream"
+        a = match_batch(plan, batch)
+        torch.cuda.synchronize()
+        a6, ast, ab = a.out6.clone(), a.status.clone(), a.best_adapter.clone()
+        with env(CAH_NO_MULTI2="1"):
+            b = match_batch(plan, batch)
+            torch.cuda.synchronize()
+        assert torch.equal(ast, b.status), (n_adapters, m)
+        assert torch.equal(a6, b.out6), (n_adapters, m)
+        found = ast == 1
+        assert torch.equal(ab[found], b.best_adapter[found]), (n_adapters, m)
+        assert int(found.sum()) > 0.3 * n_reads
+
+
+def test_invalid_bytes_are_flagged(hip, orc):
+    from cutadapt_amd.batch import ReadBatch, match_batch
+    prng = random.Random(5)
+    seqs = [rs(prng, 33) for _ in range(16)]
+    plan, ads = plan_for(seqs, 0.1, 3)
+    reads = [rs(prng, 150) for _ in range(300)]
+    sq, offs = orc.pack_reads(reads)
+    sq = sq.copy()
+    for r in (0, 17, 63, 64, 299):
+        sq[offs[r] + (r % 150)] = 0xC3
+    batch = ReadBatch.from_host(sq, offs)
+    got6, got_st, _ = match_batch(plan, batch).cpu()
+    assert set(np.nonzero(got_st == 2)[0].tolist()) == {0, 17, 63, 64, 299}
