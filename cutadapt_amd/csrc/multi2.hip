@@ -55,7 +55,7 @@ __device__ __forceinline__ unsigned m2_rank(const unsigned long long mask) {    
 
 // dynamic LDS layout (bytes), computed alike on host and device
 struct M2Layout {
-    unsigned bitmap, dir, entries, prefix, xlat, slot, seen, wide, ring, rlast, first, pages, misc, total;
+    unsigned bitmap, dir, entries, prefix, xlat, slot, seen, wide, ring, rlast, pages, misc, total;
 };
 __host__ __device__ inline M2Layout m2_layout(const int n_entries, const int n_adapters) {
     M2Layout L;
@@ -71,7 +71,6 @@ __host__ __device__ inline M2Layout m2_layout(const int n_entries, const int n_a
     L.wide = o; o += M2_WAVES * WAVE * words * 4;
     L.ring = o; o += M2_WAVES * M2_RING * 8;
     L.rlast = o; o += M2_WAVES * WAVE * 4;
-    L.first = o; o += M2_WAVES * WAVE * 4;
     L.pages = o; o += M2_WAVES * CAH_M2_PAIR_CLASSES * 8;
     L.misc = o; o += 64;
     L.total = o;
@@ -116,7 +115,6 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
     uint32_t* const s_wide = reinterpret_cast<uint32_t*>(s_raw + LY.wide) + wave * WAVE * words;
     m2_u32x2* const s_ring = reinterpret_cast<m2_u32x2*>(s_raw + LY.ring) + wave * M2_RING;
     uint32_t* const s_rlast = reinterpret_cast<uint32_t*>(s_raw + LY.rlast) + wave * WAVE;
-    uint32_t* const s_first = reinterpret_cast<uint32_t*>(s_raw + LY.first) + wave * WAVE;
     uint32_t* const s_pg = reinterpret_cast<uint32_t*>(s_raw + LY.pages) + wave * CAH_M2_PAIR_CLASSES * 2;   // {page, fill} per class
     unsigned* const s_next_piece = reinterpret_cast<unsigned*>(s_raw + LY.misc);
     if (lane < CAH_M2_PAIR_CLASSES) { s_pg[2 * lane] = 0xFFFFFFFFu; s_pg[2 * lane + 1] = 0u; }
@@ -261,6 +259,7 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
         ring_count -= cnt;
         const uint32_t r = ev.x;
         const int lr = (int)(ev.y & 63u), p = (int)((ev.y >> 8) & 255u), qc = (int)((ev.y >> 16) & 15u);
+        const int p_head = __builtin_amdgcn_readfirstlane(p);
         const uint32_t d = have ? (uint32_t)s_dir[m2_index(r, qc) & (CAH_M2_SLOTS - 1)] : 0u;
         const int begin = m2_dir_begin(d);
         int left = m2_dir_count(d);
@@ -302,7 +301,9 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
             unsigned flags = 0;
             if (whole) { pc = m2_pair_class_w((n + 15) >> 4); key = 0; }
             else if (cls == M2_W) {
-                key = (int)(s_first[lr] >> CAH_KEY_SHIFT);
+                // every event of this round ends in or behind the chunk of the round's first event (events are
+                // pushed chunk by chunk), and an earlier event of the pair would have emitted it in an earlier round
+                key = (p_head & ~15) >> CAH_KEY_SHIFT;
                 key = key < CAH_QUEUE_BINS - 1 ? key : CAH_QUEUE_BINS - 1;
                 const int j0 = max(0, (key << CAH_KEY_SHIFT) - m - k - 1);
                 pc = m2_pair_class_w((n - j0 + 15) >> 4);
@@ -349,10 +350,9 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
         if (more) {
             // ---- per-read state
             for (int w = 0; w < words; ++w) { s_seen[lane * words + w] = 0; s_wide[lane * words + w] = 0; }
-            s_first[lane] = 0;
             uint32_t r = 0x24924924u;                                   // ten characters that match nothing
-            uint32_t r_prev = r;                                        // the word at the end of the chunk before
-            bool had_hit = false;
+            uint32_t r_prev = r;                                        // the word five characters in front of the chunk (the chunk before's twelfth)
+            uint32_t rlast = r;                                         // the word at the read's last character
             unsigned seen_chars = 0;
             cur_cls = M2_W;
             m2_u32x4 cur = (m2_u32x4)(0u);
@@ -374,13 +374,13 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
                     uint32_t e[16];
 #pragma unroll
                     for (int t = 0; t < 16; ++t) e[t] = s_xlat[(w4[t >> 2] >> (8 * (t & 3))) & 127u];
-                    uint32_t rr5 = 0;
+                    uint32_t rr5 = 0, rr11 = 0;
                     unsigned hits = 0;
                     if (w_only8) {
                         uint32_t rr[16];
 #pragma unroll
                         for (int t = 0; t < 16; ++t) { r = (r << 3) | e[t]; rr[t] = r; }
-                        rr5 = rr[5];
+                        rr5 = rr[5]; rr11 = rr[11];
                         uint32_t wd[16];
 #pragma unroll
                         for (int t = 0; t < 16; ++t) {
@@ -397,6 +397,7 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
                         for (int t = 0; t < 16; ++t) {
                             r = (r << 3) | e[t];
                             if (t == 5) rr5 = r;
+                            if (t == 11) rr11 = r;
                             bool h = false;
                             for (int qc = 1; qc <= 8; ++qc)
                                 if ((qmask_w >> qc) & 1) h = h || probe(r, qc);
@@ -405,17 +406,21 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
                     }
                     if (pos + 16 > n) hits &= (1u << (n - pos)) - 1u;   // positions past the read's end
                     if (!valid) hits = 0;
+                    // the word at position pos + t from three words ten characters apart (30 bits each): at pos - 5 (the
+                    // chunk before's twelfth character), pos + 5 and pos + 15
+                    const uint64_t v_lo = ((uint64_t)r_prev << 30) | (uint64_t)(rr5 & 0x3FFFFFFFu);     // .. pos + 5
+                    const uint64_t v_hi = ((uint64_t)rr5 << 30) | (uint64_t)(r & 0x3FFFFFFFu);           // .. pos + 15
+                    auto word_at = [&](const int t) -> uint32_t {
+                        return t <= 5 ? (uint32_t)(v_lo >> (3 * (5 - t))) : (uint32_t)(v_hi >> (3 * (15 - t)));
+                    };
+                    // the read's last ten characters (the chunk's characters behind the read's end are NULs)
+                    if (pos < n && pos + 16 >= n) rlast = word_at(n - 1 - pos);
                     if (m2_any(hits != 0)) {
-                        if (hits != 0 && !had_hit) { had_hit = true; s_first[lane] = (uint32_t)pos; }
-                        // the word at position pos + t from the words at the ends of this chunk, of its first six
-                        // characters and of the chunk before (ten characters each, 30 bits)
-                        const uint64_t v_lo = ((uint64_t)r_prev << 30) | (uint64_t)(rr5 & 0x3FFFFFFFu);     // .. pos + 5
-                        const uint64_t v_hi = ((uint64_t)rr5 << 30) | (uint64_t)(r & 0x3FFFFFFFu);           // .. pos + 15
                         while (m2_any(hits != 0)) {
                             const bool mine = hits != 0;
                             const int t = mine ? (int)__builtin_ctz(hits) : 0;
                             hits &= hits - 1u;
-                            const uint32_t rt = t <= 5 ? (uint32_t)(v_lo >> (3 * (5 - t))) : (uint32_t)(v_hi >> (3 * (15 - t)));
+                            const uint32_t rt = word_at(t);
                             const unsigned long long mk = __ballot(mine);
                             if (w_only8) {
                                 push_events(mk, mine, rt & 0x3FFFFFFFu, pos + t, 8);
@@ -430,11 +435,11 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
                             }
                         }
                     }
-                    r_prev = r;
+                    r_prev = rr11;
                     cur = nxt;
                 }
             }
-            s_rlast[lane] = r;
+            s_rlast[lane] = rlast;
             drain();
             // ---- the tail sweeps: classes hi, lo, REF-only, each resolved before the next
             const int tail_off = H2 > 0 ? 16 * H1 : 0;                  // first position the slot still holds
@@ -538,7 +543,12 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_multi
             // every lane) skips the first chunk's columns in front of the window
             int j0w = tail ? ((int)key << 2) : max(0, ((int)key << CAH_KEY_SHIFT) - p.m - p.k - 1);
             j0w = min(j0w, n);
-            const int j0 = bs_align_window(j0w, n);
+            // one start for the whole wave -- the earliest window's (any earlier start is as exact): the lanes then
+            // walk the same chunks and reach the read end together, no lane steps past its read
+            int j0 = valid ? bs_align_window(j0w, n) : n;
+#pragma unroll
+            for (int sft = 1; sft < WAVE; sft <<= 1) j0 = min(j0, __shfl_xor(j0, sft, WAVE));
+            j0 = __builtin_amdgcn_readfirstlane(j0);
             int t0 = 0;
             if (tail_page) {
                 int d = valid ? j0w - j0 : 16;
@@ -556,22 +566,21 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_multi
                 if constexpr (KIND == 0) return bs_step<false>(st, eq, jj, p);
                 else return bs32_step<false, XR>(st, (uint32_t)eq, (uint32_t)(eq >> 32), jj, p);
             };
-            int j = jstart, exact_j = 0;
+            int j = jstart, exact_j = 0;                                // (wave-uniform: every lane walks the same columns)
             bool done = !valid, exact = false;
             int pos = j0;
             Chunk cur = load_chunk(q, pos, n, valid ? n : 0);
             int first_t = t0;
-            for (;;) {
-                const unsigned long long act = __ballot(!done && j < n);
-                if (!act) break;
+            while (j < n) {
                 const Chunk nxt = load_chunk(q, pos + 16, n, (!done) ? n : 0);
+                // a window that starts at column 0 need not be a whole number of chunks: the last chunk then ends early
+                const int last_t = min(16, n - pos);
                 uint64_t eqq[2];
-                eqq[0] = eq_of(cur, first_t & 15);
-                eqq[1] = eq_of(cur, (first_t + 1) & 15);
-                // (the windows end at the read end and start on chunk borders: every lane at work has the whole chunk)
+                eqq[first_t & 1] = eq_of(cur, first_t & 15);
+                eqq[(first_t + 1) & 1] = eq_of(cur, (first_t + 1) & 15);
 #pragma unroll
                 for (int t = 0; t < 16; ++t) {
-                    if (t < first_t) continue;                          // wave-uniform: the first chunk of a tail page
+                    if (t < first_t || t >= last_t) continue;           // wave-uniform
                     const uint64_t eq = eqq[t & 1];
                     if (t + 2 < 16) eqq[t & 1] = eq_of(cur, t + 2);
                     ++j;

@@ -49,7 +49,7 @@ void resolve(const M2Tables& t, ReadState& st, uint32_t r, int qc, int cls, int 
         if (st.seen[a]) continue;
         st.seen[a] = true;
         if (st.wideonly[a]) { st.pairs.push_back({a, 0u, 0}); st.conservative++; }
-        else if (cls == M2_W) st.pairs.push_back({a, 0u, std::min(std::max(st.first, 0) >> CAH_KEY_SHIFT, CAH_QUEUE_BINS - 1)});
+        else if (cls == M2_W) st.pairs.push_back({a, 0u, std::min((p & ~15) >> CAH_KEY_SHIFT, CAH_QUEUE_BINS - 1)});
         else if (cls == M2_HI) st.pairs.push_back({a, CAH_M2_PAIR_TAIL, std::max(0, n - h.win_dist[M2_HI]) >> 2});
         else if (cls == M2_LO) st.pairs.push_back({a, CAH_M2_PAIR_TAIL, std::max(0, n - h.win_dist[M2_LO]) >> 2});
         else {
