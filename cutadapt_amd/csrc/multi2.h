@@ -46,7 +46,8 @@
 #define CAH_M2_SLOTS 4096            // directory slots: home = low 12 bits of the bitmap index -> (first entry, entries)
 #define CAH_M2_MAX_ENTRIES 2048
 #define CAH_M2_MAX_GROUP 15          // entries that may share a home
-#define CAH_M2_BM_WORDS 2048         // presence bitmap: 64 Kbit
+#define CAH_M2_BM_WORDS 3072         // presence bitmaps: 64 Kbit for the index class 8 (probed at every character), then
+#define CAH_M2_BM8_WORDS 2048        // 32 Kbit shared by the shorter classes (probed in the tail sweeps only)
 #define CAH_M2_MAXQ 10
 #define CAH_M2_EMPTY 0xFFFFFFFFu
 #define CAH_M2_WHOLE 255             // window value: the whole read
@@ -80,12 +81,14 @@ M2_HD uint32_t m2_code(unsigned c) {
     return (c >= 64 && c < 128) ? (u == 'A' ? 0u : u == 'C' ? 1u : u == 'G' ? 2u : u == 'T' ? 3u : 4u) : 4u;
 }
 M2_HD uint32_t m2_mask(int q) { return q >= 10 ? 0x3FFFFFFFu : ((1u << (3 * q)) - 1u); }
-// bitmap index (16 bits) of the last qc = min(q, 8) characters; the home slot of the hash table is its low 12 bits
+// index (16 bits) of the last qc = min(q, 8) characters: the home slot of the directory is its low 12 bits, the bitmap
+// bit m2_bit(index, qc)
 M2_HD uint32_t m2_salt(int qc) { return (uint32_t)(8 - qc) * 0x1D3Bu; }
 M2_HD uint32_t m2_index(uint32_t r, int qc) {
     const uint32_t key = r & m2_mask(qc);
     return ((key ^ (key >> 8)) ^ m2_salt(qc)) & 0xFFFFu;
 }
+M2_HD uint32_t m2_bit(uint32_t idx, int qc) { return qc >= 8 ? idx : CAH_M2_BM8_WORDS * 32u + (idx & 0x7FFFu); }
 // does a k-mer of window L (0: none, CAH_M2_WHOLE: whole read) count when it starts `dist` characters before the end?
 M2_HD bool m2_in_window(int L, int dist) { return L == CAH_M2_WHOLE || (L != 0 && dist <= L); }
 
@@ -221,7 +224,7 @@ inline bool m2_build(const std::vector<std::string>& adapters, const int32_t* th
         const uint32_t code = m2_encode(e.kmer);
         if (code & 0x24924924u) return false;                        // not plain ACGT
         const uint32_t idx = m2_index(code, qc);
-        t.bitmap[idx >> 5] |= 1u << (idx & 31);
+        t.bitmap[m2_bit(idx, qc) >> 5] |= 1u << (idx & 31);
         placed.push_back({idx & (CAH_M2_SLOTS - 1), code, m2_meta(e.adapter, q, e.cls, e.ref_L, e.wide_L)});
         h.q_mask[e.cls] |= 1 << qc;
         const int reach = std::max(e.ref_L, e.wide_L);

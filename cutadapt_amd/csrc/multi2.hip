@@ -57,22 +57,23 @@ __device__ __forceinline__ unsigned m2_rank(const unsigned long long mask) {    
 struct M2Layout {
     unsigned bitmap, dir, entries, prefix, xlat, slot, seen, wide, ring, rlast, pages, misc, total;
 };
+// (what has a fixed size comes first: those offsets are compile-time constants and fold into the LDS instructions)
 __host__ __device__ inline M2Layout m2_layout(const int n_entries, const int n_adapters) {
     M2Layout L;
     unsigned o = 0;
     const unsigned words = (unsigned)(n_adapters + 31) / 32;
+    L.xlat = o; o += 128;
+    L.prefix = o; o += 128 * 4;
     L.bitmap = o; o += CAH_M2_BM_WORDS * 4;
     L.dir = o; o += CAH_M2_SLOTS * 2;
-    L.entries = o; o += (unsigned)((n_entries + 1) & ~1) * 8;
-    L.prefix = o; o += 128 * 4;
-    L.xlat = o; o += 128;
     L.slot = o; o += M2_WAVES * WAVE * M2_ROW;
-    L.seen = o; o += M2_WAVES * WAVE * words * 4;
-    L.wide = o; o += M2_WAVES * WAVE * words * 4;
     L.ring = o; o += M2_WAVES * M2_RING * 8;
     L.rlast = o; o += M2_WAVES * WAVE * 4;
     L.pages = o; o += M2_WAVES * CAH_M2_PAIR_CLASSES * 8;
     L.misc = o; o += 64;
+    L.entries = o; o += (unsigned)((n_entries + 1) & ~1) * 8;
+    L.seen = o; o += M2_WAVES * WAVE * words * 4;
+    L.wide = o; o += M2_WAVES * WAVE * words * 4;
     L.total = o;
     return L;
 }
@@ -82,6 +83,29 @@ __device__ __forceinline__ unsigned multi_tab_index2(unsigned c) { return (c & 0
 // class of a pair's page: 0 lo, 1 hi, 2.. whole-read pairs by the length of their window (16-column chunks)
 __host__ __device__ inline int m2_pair_class_w(const int chunks) { return chunks <= 4 ? 2 : (chunks <= 6 ? 3 : (chunks <= 8 ? 4 : 5)); }
 
+// W8: every whole-read k-mer has eight or more characters (one index class: the plans kmer_heuristic builds for
+// adapters of 24+ characters at rate 0.1) -- the main pass then makes ONE probe per character, straight-line
+#ifdef M2_TRACE
+// developer build only (-DM2_TRACE): s_memtime stamps of one wave at the stations of its first pieces
+#define M2_TRACE_PIECES 64
+#define M2_TRACE_STATIONS 16
+__device__ unsigned long long g_m2_trace[M2_TRACE_PIECES * M2_TRACE_STATIONS];
+extern "C" int cah_debug_m2_trace(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_m2_trace), sizeof(g_m2_trace)) == hipSuccess ? 0 : 1;
+}
+#define M2_STAMP(st) do { if (blockIdx.x == 7 && wave == 5 && trace_it < M2_TRACE_PIECES) { \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) g_m2_trace[trace_it * M2_TRACE_STATIONS + (st)] = t_; } } while (0)
+#define M2_COUNT(st, v) do { if (blockIdx.x == 7 && wave == 5 && trace_it < M2_TRACE_PIECES && lane == 0) g_m2_trace[trace_it * M2_TRACE_STATIONS + (st)] += (v); } while (0)
+#define M2_TIC() const unsigned long long tic_ = __builtin_amdgcn_s_memtime()
+#define M2_TOC(st) M2_COUNT(st, __builtin_amdgcn_s_memtime() - tic_)
+#else
+#define M2_TIC() do { } while (0)
+#define M2_TOC(st) do { } while (0)
+#define M2_STAMP(st) do { } while (0)
+#define M2_COUNT(st, v) do { } while (0)
+#endif
+
+template <bool W8>
 __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     const CahMulti2Header* const hd = a.hdr;
@@ -124,7 +148,20 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
     // plan constants (wave-uniform)
     const int m = hd->m, k = hd->k, min_overlap = hd->min_overlap, lmax0 = hd->lmax0;
     const int qmask_w = hd->q_mask[M2_W];
-    const bool w_only8 = qmask_w == (1 << 8);
+    int sweep_qm[3], sweep_span[3];
+    unsigned long long sweep_open[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        sweep_qm[c] = hd->q_mask[c + 1];
+        sweep_span[c] = hd->span[c + 1];
+        unsigned long long o = 0;
+        for (int qc = 1; qc <= 8; ++qc) {
+            const int v = hd->open_L[c + 1][qc];
+            o |= (unsigned long long)(unsigned)(v < 0 ? 0 : (v > 255 ? 255 : v)) << (8 * (qc - 1));
+        }
+        sweep_open[c] = o;
+    }
+    constexpr bool w_only8 = W8;
     const unsigned lane16 = (unsigned)lane * 16u;
 
     // ---- copy plan (k_filter_stream2's): H1 units of every read in the first half-row, H2 in the second
@@ -226,6 +263,9 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
         return v;
     };
 
+#ifdef M2_TRACE
+    int trace_it = 0;
+#endif
     // ---- events: ring[tail % RING] = {rolling word, lane | position << 8 | qc << 16}
     unsigned ring_head = 0, ring_count = 0;                             // wave-uniform
     int64_t piece_first = 0;                                            // read index (within the launch) of lane 0's read
@@ -249,10 +289,14 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
         if (lane == 0) { s_pg[2 * pc] = page; s_pg[2 * pc + 1] = fill + cnt; }
     };
 
-    // resolve up to 64 events of class cur_cls from the head of the ring
+    // resolve up to 64 events of class cur_cls from the head of the ring.  The pairs a round emits are staged in the ring
+    // slots it has just consumed (one per lane at a time) and leave for their pages once per round, class by class.
     auto resolve_round = [&]() {
         const unsigned cnt = ring_count < 64u ? ring_count : 64u;
+        M2_COUNT(10, 1ull + ((unsigned long long)cnt << 32));
+        M2_TIC();
         const bool have = (unsigned)lane < cnt;
+        const unsigned stage0 = ring_head;                              // the consumed slots: [stage0, stage0 + 64) mod RING
         m2_u32x2 ev = (m2_u32x2)(0u);
         if (have) ev = s_ring[(ring_head + (unsigned)lane) & (M2_RING - 1)];
         ring_head = (ring_head + cnt) & (M2_RING - 1);
@@ -261,64 +305,84 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
         const int lr = (int)(ev.y & 63u), p = (int)((ev.y >> 8) & 255u), qc = (int)((ev.y >> 16) & 15u);
         const int p_head = __builtin_amdgcn_readfirstlane(p);
         const uint32_t d = have ? (uint32_t)s_dir[m2_index(r, qc) & (CAH_M2_SLOTS - 1)] : 0u;
-        const int begin = m2_dir_begin(d);
+        int u = m2_dir_begin(d);
         int left = m2_dir_count(d);
         const int cls = cur_cls;
-        for (int u = begin; m2_any(left > 0); ++u, --left) {
-            bool emit = false;
-            int adapter = 0;
-            bool whole = false;
-            if (left > 0) {
-                const CahM2Slot e = s_ent[u];
-                const int q = m2_q(e.meta);
-                const bool match = m2_cls(e.meta) == cls && (q < 8 ? q : 8) == qc && (r & m2_mask(q)) == e.key;
-                const int dist = n - (p - q + 1);
-                adapter = m2_adapter(e.meta);
-                const unsigned bit = 1u << (adapter & 31);
-                uint32_t* const sw = s_wide + lr * words + (adapter >> 5);
-                uint32_t* const ss = s_seen + lr * words + (adapter >> 5);
-                const bool is_ref = match && m2_in_window(m2_ref_L(e.meta), dist);
-                const bool wide_only = match && !is_ref && m2_in_window(m2_wide_L(e.meta), dist);
-                if (wide_only) atomicOr(sw, bit);
-                if (is_ref) {
-                    const unsigned old = atomicOr(ss, bit);
-                    emit = (old & bit) == 0;
-                    whole = emit && ((*sw) & bit) != 0;
-                }
+        uint32_t* const sw = s_wide + lr * words;
+        uint32_t* const ss = s_seen + lr * words;
+        const uint32_t rd = (uint32_t)(a.first_read + piece_first + lr);
+        // class and key of the pairs of this round that are not "whole read" pairs
+        int pc_cls, key_cls;
+        unsigned flags_cls = 0;
+        if (cls == M2_W) {
+            // every event of this round ends in or behind the chunk of the round's first event (events are pushed
+            // chunk by chunk), and an earlier event of the pair would have emitted it in an earlier round
+            key_cls = (p_head & ~15) >> CAH_KEY_SHIFT;
+            key_cls = key_cls < CAH_QUEUE_BINS - 1 ? key_cls : CAH_QUEUE_BINS - 1;
+            pc_cls = m2_pair_class_w((n - max(0, (key_cls << CAH_KEY_SHIFT) - m - k - 1) + 15) >> 4);
+        } else if (cls == M2_HI) { pc_cls = 1; key_cls = max(0, n - a.win_hi) >> 2; flags_cls = CAH_M2_PAIR_TAIL; }
+        else if (cls == M2_LO) { pc_cls = 0; key_cls = max(0, n - a.win_lo) >> 2; flags_cls = CAH_M2_PAIR_TAIL; }
+        else { pc_cls = 7; key_cls = 0; }                              // REF-only k-mers: the suffix compare decides
+        const int pc_whole = m2_pair_class_w((n + 15) >> 4);
+        unsigned staged = 0;                                            // wave-uniform
+        // the staged pairs (at most 64, one per lane) leave: pairs for their class's page, suffix compares to best_key
+        auto flush = [&]() {
+            const bool mine = (unsigned)lane < staged;
+            m2_u32x2 st = (m2_u32x2)(0u);
+            if (mine) st = s_ring[(stage0 + (unsigned)lane) & (M2_RING - 1)];
+            const int pc = (int)((st.x >> 28) & 7u);
+            if (mine && pc == 7) {
+                const int adapter = (int)((st.x >> 8) & 255u);
+                const int lr2 = (int)(st.y - (uint32_t)(a.first_read + piece_first));
+                const int i = m2_exact_tail(s_rlast[lr2], s_prefix[adapter], min_overlap, lmax0, n);
+                if (i > 0) atomicMax(a.best_key + st.y, pack_best(i, 0, adapter, i, n - i, n));
             }
-            if (!m2_any(emit)) continue;
-            const int64_t rd = a.first_read + piece_first + lr;
-            // pairs that only the error-free rows can match: decided here
-            if (cls == M2_SHORT) {
-                if (emit && !whole) {
-                    const int i = m2_exact_tail(s_rlast[lr], s_prefix[adapter], min_overlap, lmax0, n);
-                    if (i > 0) atomicMax(a.best_key + rd, pack_best(i, 0, adapter, i, n - i, n));
-                    emit = false;
-                }
-                if (!m2_any(emit)) continue;
-            }
-            int pc, key;
-            unsigned flags = 0;
-            if (whole) { pc = m2_pair_class_w((n + 15) >> 4); key = 0; }
-            else if (cls == M2_W) {
-                // every event of this round ends in or behind the chunk of the round's first event (events are
-                // pushed chunk by chunk), and an earlier event of the pair would have emitted it in an earlier round
-                key = (p_head & ~15) >> CAH_KEY_SHIFT;
-                key = key < CAH_QUEUE_BINS - 1 ? key : CAH_QUEUE_BINS - 1;
-                const int j0 = max(0, (key << CAH_KEY_SHIFT) - m - k - 1);
-                pc = m2_pair_class_w((n - j0 + 15) >> 4);
-            } else if (cls == M2_HI) { pc = 1; key = max(0, n - a.win_hi) >> 2; flags = CAH_M2_PAIR_TAIL; }
-            else { pc = 0; key = max(0, n - a.win_lo) >> 2; flags = CAH_M2_PAIR_TAIL; }
-            const uint64_t pair = ((uint64_t)(uint32_t)rd << 32) | ((uint64_t)flags << 24) | ((uint64_t)(unsigned)adapter << 8) | (unsigned)key;
-            unsigned long long em = __ballot(emit);
+            unsigned long long em = __ballot(mine && pc != 7);
+            const uint64_t pair = ((uint64_t)st.y << 32) | (uint64_t)(st.x & 0x0FFFFFFFu);
             while (em) {
                 const int src = __ffsll((long long)em) - 1;
                 const int pc0 = __builtin_amdgcn_readlane(pc, src);
-                const unsigned long long mk = __ballot(emit && pc == pc0);
-                append_pairs(mk, pc0, emit && pc == pc0, pair);
+                const unsigned long long mk = __ballot(mine && pc == pc0);
+                append_pairs(mk, pc0, mine && pc == pc0, pair);
                 em &= ~mk;
             }
+            staged = 0;
+        };
+        M2_TOC(12);
+        while (m2_any(left > 0)) {
+            M2_COUNT(11, 1);
+            const bool on = left > 0;
+            const CahM2Slot e = s_ent[on ? u : 0];
+            const int q = m2_q(e.meta);
+            const bool match = on && m2_cls(e.meta) == cls && (q < 8 ? q : 8) == qc && (r & m2_mask(q)) == e.key;
+            const int dist = n - (p - q + 1);
+            const int adapter = m2_adapter(e.meta);
+            const unsigned bit = 1u << (adapter & 31);
+            const int word = adapter >> 5;
+            const bool is_ref = match && m2_in_window(m2_ref_L(e.meta), dist);
+            const bool wide_only = match && !is_ref && m2_in_window(m2_wide_L(e.meta), dist);
+            // (both bitsets are touched by every lane: a zero changes nothing, and no lane branches)
+            atomicOr(sw + word, wide_only ? bit : 0u);
+            const unsigned old = atomicOr(ss + word, is_ref ? bit : 0u);
+            const bool emit = is_ref && (old & bit) == 0;
+            const unsigned long long em = __ballot(emit);
+            if (em) {
+                const unsigned c = (unsigned)__popcll(em);
+                if (staged + c > 64u) flush();
+                if (emit) {
+                    const bool whole = (sw[word] & bit) != 0;
+                    const int pc = whole ? pc_whole : pc_cls;
+                    const unsigned lo = ((unsigned)pc << 28) | ((whole ? 0u : flags_cls) << 24) | ((unsigned)adapter << 8) |
+                                        (unsigned)(whole ? 0 : key_cls);
+                    s_ring[(stage0 + staged + m2_rank(em)) & (M2_RING - 1)] = (m2_u32x2){lo, rd};
+                }
+                staged += c;
+            }
+            ++u; --left;
         }
+        M2_TOC(13);
+        if (staged) flush();
+        M2_TOC(14);
     };
     // the lanes of `mask` push one event each; the ring always has room for 64
     auto push_events = [&](const unsigned long long mask, const bool mine, const uint32_t r, const int p, const int qc) {
@@ -333,7 +397,7 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
     // one bitmap probe: does a k-mer of index class qc end with the word r?
     auto probe = [&](const uint32_t r, const int qc) -> bool {
         const uint32_t idx = m2_index(r, qc);
-        return ((s_bm[idx >> 5] >> (idx & 31)) & 1u) != 0;
+        return ((s_bm[m2_bit(idx, qc) >> 5] >> (idx & 31)) & 1u) != 0;
     };
 
     unsigned p_cur = (unsigned)wave;
@@ -347,6 +411,7 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
         const bool more = (unsigned)base < (unsigned)n_reads;
         const bool valid = more && (unsigned)(base + lane) < (unsigned)n_reads;
         piece_first = base;
+        M2_STAMP(0);
         if (more) {
             // ---- per-read state
             for (int w = 0; w < words; ++w) { s_seen[lane * words + w] = 0; s_wide[lane * words + w] = 0; }
@@ -361,6 +426,7 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
                 const int H = ph ? H2 : H1;
                 if (H == 0) continue;
                 if (ph == 0) to_slot(std::integral_constant<int, 0>{}); else to_slot(std::integral_constant<int, 1>{});
+                M2_STAMP(1 + 2 * ph);
                 const int pos0 = ph ? 16 * H1 : 0;
                 cur = finish(*reinterpret_cast<const m2_u32x4*>(row), pos0);
 #pragma unroll 1
@@ -376,7 +442,7 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
                     for (int t = 0; t < 16; ++t) e[t] = s_xlat[(w4[t >> 2] >> (8 * (t & 3))) & 127u];
                     uint32_t rr5 = 0, rr11 = 0;
                     unsigned hits = 0;
-                    if (w_only8) {
+                    if constexpr (w_only8) {
                         uint32_t rr[16];
 #pragma unroll
                         for (int t = 0; t < 16; ++t) { r = (r << 3) | e[t]; rr[t] = r; }
@@ -422,7 +488,7 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
                             hits &= hits - 1u;
                             const uint32_t rt = word_at(t);
                             const unsigned long long mk = __ballot(mine);
-                            if (w_only8) {
+                            if constexpr (w_only8) {
                                 push_events(mk, mine, rt & 0x3FFFFFFFu, pos + t, 8);
                             } else {
                                 // (several index classes: one event per class that hits)
@@ -438,39 +504,58 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
                     r_prev = rr11;
                     cur = nxt;
                 }
+                M2_STAMP(2 + 2 * ph);
             }
             s_rlast[lane] = rlast;
             drain();
+            M2_STAMP(5);
             // ---- the tail sweeps: classes hi, lo, REF-only, each resolved before the next
             const int tail_off = H2 > 0 ? 16 * H1 : 0;                  // first position the slot still holds
 #pragma unroll 1
             for (int cls = M2_HI; cls <= M2_SHORT; ++cls) {
-                const int qm = hd->q_mask[cls];
+                const int qm = sweep_qm[cls - 1];
                 if (!qm) continue;
                 cur_cls = cls;
                 // first position a k-mer of the class may start at: the word starts empty there (a k-mer that began
                 // earlier lies outside every window of the class); the launcher checked that the slot still holds it
-                const int from = max(tail_off, n - hd->span[cls]);
+                const int from = max(tail_off, n - sweep_span[cls - 1]);
+                const unsigned long long openp = sweep_open[cls - 1];   // open_L of the eight index classes, a byte each
                 uint32_t rs = 0x24924924u;
+                // four characters per LDS read, from the 4-aligned position at or in front of `from` (what lies in front
+                // of `from` enters the word but is not probed; a k-mer that begins there is outside every window)
+                const int p4 = tail_off + ((from - tail_off) & ~3);
 #pragma unroll 1
-                for (int p = from; p < n; ++p) {
-                    const unsigned ch = row[p - tail_off];
-                    rs = ((rs << 3) | s_xlat[ch & 127u]) & 0x3FFFFFFFu;
+                for (int pb = p4; pb < n; pb += 4) {
+                    const unsigned w = *reinterpret_cast<const unsigned*>(row + (pb - tail_off));
+                    uint32_t e4[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) e4[t] = s_xlat[(w >> (8 * t)) & 127u];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int p = pb + t;
+                        rs = ((rs << 3) | e4[t]) & 0x3FFFFFFFu;
+                        if (p < from || p >= n) continue;               // wave-uniform
 #pragma unroll 1
-                    for (int qc = 1; qc <= 8; ++qc) {
-                        if (!((qm >> qc) & 1)) continue;
-                        if (n - p + qc - 1 > hd->open_L[cls][qc]) continue;
-                        const bool h = valid && probe(rs, qc);
-                        const unsigned long long mk = __ballot(h);
-                        if (mk) push_events(mk, h, rs, p, qc);
+                        for (int qrest = qm; qrest; qrest &= qrest - 1) {
+                            const int qc = __builtin_ctz((unsigned)qrest);
+                            if (n - p + qc - 1 > (int)((openp >> (8 * (qc - 1))) & 255ull)) continue;
+                            const bool h = valid && probe(rs, qc);
+                            const unsigned long long mk = __ballot(h);
+                            if (mk) push_events(mk, h, rs, p, qc);
+                        }
                     }
                 }
                 drain();
+                M2_STAMP(5 + cls);
             }
             if (valid && (seen_chars & 0x80808080u) != 0) a.status[a.first_read + base + lane] = 2;
         }
         const unsigned p_next = take_piece();
         prefetch(piece_base(p_next));
+        M2_STAMP(9);
+#ifdef M2_TRACE
+        if (blockIdx.x == 7 && wave == 5) ++trace_it;
+#endif
         p_cur = p_next;
     }
     // close the wave's open pages
@@ -575,16 +660,24 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_multi
                 const Chunk nxt = load_chunk(q, pos + 16, n, (!done) ? n : 0);
                 // a window that starts at column 0 need not be a whole number of chunks: the last chunk then ends early
                 const int last_t = min(16, n - pos);
-                uint64_t eqq[2];
-                eqq[first_t & 1] = eq_of(cur, first_t & 15);
-                eqq[(first_t + 1) & 1] = eq_of(cur, (first_t + 1) & 15);
+                if (first_t == 0 && last_t == 16) {
+                    // a whole chunk (the rule): no per-column tests
+                    uint64_t eqq[2];
+                    eqq[0] = eq_of(cur, 0);
+                    eqq[1] = eq_of(cur, 1);
 #pragma unroll
-                for (int t = 0; t < 16; ++t) {
-                    if (t < first_t || t >= last_t) continue;           // wave-uniform
-                    const uint64_t eq = eqq[t & 1];
-                    if (t + 2 < 16) eqq[t & 1] = eq_of(cur, t + 2);
-                    ++j;
-                    if (step(eq, j) && !exact) { exact = true; exact_j = j; }
+                    for (int t = 0; t < 16; ++t) {
+                        const uint64_t eq = eqq[t & 1];
+                        if (t + 2 < 16) eqq[t & 1] = eq_of(cur, t + 2);
+                        ++j;
+                        if (step(eq, j) && !exact) { exact = true; exact_j = j; }
+                    }
+                } else {
+#pragma unroll 1
+                    for (int t = first_t; t < last_t; ++t) {           // wave-uniform bounds
+                        ++j;
+                        if (step(eq_of(cur, t), j) && !exact) { exact = true; exact_j = j; }
+                    }
                 }
                 if (exact) done = true;
                 first_t = 0;
@@ -673,13 +766,16 @@ hipError_t launch_multi_stream(const Multi2Args& a, const CahMulti2Header& h, in
     const size_t lds = multi2_lds_bytes(h);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_multi_stream, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)k_multi_stream<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)k_multi_stream<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const int tiles = (int)((a.n_reads + M2_TILE - 1) / M2_TILE);
     const int grid = std::max(1, std::min(tiles, n_cus));
-    hipLaunchKernelGGL(k_multi_stream, dim3(grid), dim3(M2_WAVES * WAVE), lds, s, a);
+    if (h.q_mask[M2_W] == (1 << 8)) hipLaunchKernelGGL(k_multi_stream<true>, dim3(grid), dim3(M2_WAVES * WAVE), lds, s, a);
+    else hipLaunchKernelGGL(k_multi_stream<false>, dim3(grid), dim3(M2_WAVES * WAVE), lds, s, a);
     return hipGetLastError();
 }
 

@@ -30,6 +30,7 @@ struct ReadState {
     std::vector<Pair> pairs;
     std::vector<std::pair<int, int>> exact;      // (adapter, overlap) decided by the suffix compare
     int conservative = 0;
+    int events[4] = {0, 0, 0, 0};
 };
 
 void resolve(const M2Tables& t, ReadState& st, uint32_t r, int qc, int cls, int p, int n, uint32_t rlast) {
@@ -76,8 +77,9 @@ void filter_read(const M2Tables& t, const uint8_t* q, int n, ReadState& st) {
                 const int dist_min = n - p + qc - 1;
                 if (dist_min > h.open_L[cls][qc]) continue;
                 const uint32_t idx = m2_index(rr[(size_t)p], qc);
-                if (!((t.bitmap[idx >> 5] >> (idx & 31)) & 1u)) continue;
+                if (!((t.bitmap[m2_bit(idx, qc) >> 5] >> (idx & 31)) & 1u)) continue;
                 if (cls == M2_W && st.first < 0) st.first = p & ~15;
+                st.events[cls]++;
                 resolve(t, st, rr[(size_t)p], qc, cls, p, n, rlast);
             }
         }
@@ -130,7 +132,7 @@ int m2m_match_batch(const char* adapters, int A, int m, const void* blobs, int32
             bestkey = std::max(bestkey, pack_best(ex.second, 0, ex.first, ex.second, n - ex.second, n));
             if (stats) stats[3]++;
         }
-        if (stats) stats[4] += st.conservative;
+        if (stats) { stats[4] += st.conservative; for (int c = 0; c < 4; c++) stats[8 + c] += st.events[c]; }
         for (const Pair& pr : st.pairs) {
             const CahMatcher& mt = mts[(size_t)pr.adapter];
             const bool tail = (pr.flags & CAH_M2_PAIR_TAIL) != 0;

@@ -90,7 +90,7 @@ def run(model, adapters, rate, min_overlap, seqs, offsets, label, sets=None, mus
         out6 = np.zeros((n, 6), dtype=np.int32)
         status = np.zeros(n, dtype=np.uint8)
         best = np.zeros(n, dtype=np.int32)
-        stats = np.zeros(8, dtype=np.int64)
+        stats = np.zeros(16, dtype=np.int64)
         rc = model.m2m_match_batch("".join(adapters).encode(), len(adapters), m, blobs, len(ra), ra.ctypes.data,
                                    rw.ctypes.data, rk, seqs.ctypes.data, offsets.ctypes.data, n, out6.ctypes.data,
                                    status.ctypes.data, best.ctypes.data, subs, stats.ctypes.data)
