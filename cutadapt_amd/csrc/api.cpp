@@ -1454,6 +1454,7 @@ static int match_batch_multi(const cah_plan* plan, const PlanDeviceCopy* pd, con
                 Multi2ScanArgs sa;
                 sa.uniform_first = ul.first; sa.uniform_len = ul.len;
                 sa.kind = scan_word_kind(m0.m);
+                sa.rows_lo = mp.m2.hdr.rows_lo;
                 sa.matcher = pd->d_matchers; sa.tab = pd->d_mscan; sa.n_adapters = (int32_t)A;
                 sa.seqs = d_seqs; sa.pairs = d_pairs; sa.page_hdr = d_page_hdr;
                 sa.page_counter = counters + WS_QCOUNT; sa.max_pages = max_pages;

@@ -236,6 +236,7 @@ struct Multi2ScanArgs {
     int64_t uniform_first;
     int32_t uniform_len;
     int32_t kind;                    // form of the column, bs_kind_of(m)
+    int32_t rows_lo;                 // the longest overlap of the first error class: no higher row of a "lo" pair can match
     const CahMatcher* matcher;       // matcher 0: all adapters of the fused path have one shape
     const uint64_t* tab;             // [n_adapters][CAH_MULTI_TAB_STRIDE] padded match words
     int32_t n_adapters;

@@ -100,6 +100,14 @@ struct CahMulti2Header {
     int32_t span[4];               // classes 1..3: a k-mer of the class starts at most this many characters before the end
     int32_t open_L[4][9];          // [cls][qc]: the class is probed while dist_min <= open_L (dist_min: as if q == qc)
     int32_t win_dist[4];           // classes hi, lo: a pair's scan window starts at column n - win_dist
+    // The tail classes are probed inside the main pass, in the read's last chunks: up to four "slots" = (class, index
+    // class) pairs in class order (hi, lo, then the REF-only k-mers unless short_fixed); a plan that needs more does
+    // not take the streaming form.
+    int32_t tq_n;
+    int32_t tq_cls[4], tq_qc[4];
+    int32_t tq_open[4];            // a slot is probed at position p while n - p + qc - 1 <= tq_open (open_L of the pair)
+    int32_t short_fixed;           // 1: every REF-only tail k-mer must be the read's last q characters (window = its length)
+    int32_t rows_lo;               // the longest overlap whose threshold is <= 1 (rows a pair of class lo can match)
     int32_t tail_warm;             // characters in front of a sweep's first probe that must be in the word (max q - 1)
     uint32_t n_entries;
 };
@@ -167,6 +175,8 @@ inline bool m2_build(const std::vector<std::string>& adapters, const int32_t* th
     }
     if (lmax0 > CAH_M2_MAXQ) return false;
     h.n_adapters = A; h.m = m; h.k = k; h.min_overlap = min_overlap; h.lmax0 = lmax0;
+    h.rows_lo = lmax0;
+    for (const Tail& tl : tails) if (tl.e == 1) h.rows_lo = tl.lmax;
     struct Ent { std::string kmer; int adapter; int cls; int ref_L; int wide_L; };
     std::vector<Ent> ents;
     auto find = [&](int a, const std::string& s) -> Ent* {
@@ -217,6 +227,7 @@ inline bool m2_build(const std::vector<std::string>& adapters, const int32_t* th
     for (int c = 0; c < 4; c++)
         for (int q = 0; q < 9; q++) h.open_L[c][q] = -1;
     int max_q = 1;
+    h.short_fixed = 1;
     struct Placed { uint32_t home, key, meta; };
     std::vector<Placed> placed;
     for (const Ent& e : ents) {
@@ -231,6 +242,7 @@ inline bool m2_build(const std::vector<std::string>& adapters, const int32_t* th
         h.open_L[e.cls][qc] = std::max(h.open_L[e.cls][qc], reach);
         if (e.cls != M2_W) h.span[e.cls] = std::max(h.span[e.cls], reach);
         max_q = std::max(max_q, q);
+        if (e.cls == M2_SHORT && e.ref_L != q) h.short_fixed = 0;
         if (e.wide_L && (e.cls == M2_HI || e.cls == M2_LO)) h.win_dist[e.cls] = std::max(h.win_dist[e.cls], e.wide_L + 1);
     }
     std::stable_sort(placed.begin(), placed.end(), [](const Placed& x, const Placed& y) { return x.home < y.home; });
@@ -247,6 +259,16 @@ inline bool m2_build(const std::vector<std::string>& adapters, const int32_t* th
     h.win_dist[M2_HI] = std::max(h.win_dist[M2_HI], h.win_dist[M2_LO]);
     if (h.win_dist[M2_LO] == 0) h.win_dist[M2_LO] = h.win_dist[M2_HI];
     h.tail_warm = max_q - 1;
+    h.tq_n = 0;
+    for (int c = M2_HI; c <= M2_SHORT; c++) {
+        if (c == M2_SHORT && h.short_fixed) continue;
+        for (int q = 1; q <= 8; q++) {
+            if (!((h.q_mask[c] >> q) & 1)) continue;
+            if (h.tq_n == 4) return false;
+            h.tq_cls[h.tq_n] = c; h.tq_qc[h.tq_n] = q; h.tq_open[h.tq_n] = h.open_L[c][q];
+            h.tq_n++;
+        }
+    }
     t.prefix.assign((size_t)A, 0u);
     for (int a = 0; a < A; a++) {
         uint32_t p = 0;

@@ -148,19 +148,13 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
     // plan constants (wave-uniform)
     const int m = hd->m, k = hd->k, min_overlap = hd->min_overlap, lmax0 = hd->lmax0;
     const int qmask_w = hd->q_mask[M2_W];
-    int sweep_qm[3], sweep_span[3];
-    unsigned long long sweep_open[3];
+    const bool short_fixed = hd->short_fixed != 0;
+    // the tail slots (multi2.h): probed in the read's last chunks, resolved class by class behind the main pass
+    const int tq_n = hd->tq_n;
+    int tq_cls[4], tq_qc[4], tq_open[4];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        sweep_qm[c] = hd->q_mask[c + 1];
-        sweep_span[c] = hd->span[c + 1];
-        unsigned long long o = 0;
-        for (int qc = 1; qc <= 8; ++qc) {
-            const int v = hd->open_L[c + 1][qc];
-            o |= (unsigned long long)(unsigned)(v < 0 ? 0 : (v > 255 ? 255 : v)) << (8 * (qc - 1));
-        }
-        sweep_open[c] = o;
-    }
+    for (int j = 0; j < 4; ++j) { tq_cls[j] = hd->tq_cls[j]; tq_qc[j] = hd->tq_qc[j]; tq_open[j] = hd->tq_open[j]; }
+    const int qm_short = hd->q_mask[M2_SHORT];
     constexpr bool w_only8 = W8;
     const unsigned lane16 = (unsigned)lane * 16u;
 
@@ -386,12 +380,18 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
     };
     // the lanes of `mask` push one event each; the ring always has room for 64
     auto push_events = [&](const unsigned long long mask, const bool mine, const uint32_t r, const int p, const int qc) {
+#if defined(M2_ABL) && (M2_ABL & 2)
+        if (ring_count > M2_RING - 64) ring_count = 0;
+#endif
         if (ring_count > M2_RING - 64) resolve_round();
         const unsigned at = (ring_head + ring_count + m2_rank(mask)) & (M2_RING - 1);
         if (mine) s_ring[at] = (m2_u32x2){r, (unsigned)lane | ((unsigned)p << 8) | ((unsigned)qc << 16)};
         ring_count += (unsigned)__popcll(mask);
     };
     auto drain = [&]() {
+#if defined(M2_ABL) && (M2_ABL & 2)
+        ring_count = 0;                                                 // developer build: events are dropped (timing only)
+#endif
         while (ring_count) resolve_round();
     };
     // one bitmap probe: does a k-mer of index class qc end with the word r?
@@ -399,6 +399,19 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
         const uint32_t idx = m2_index(r, qc);
         return ((s_bm[m2_bit(idx, qc) >> 5] >> (idx & 31)) & 1u) != 0;
     };
+
+    // first position each tail slot is probed at, the first chunk that holds one (tail_base), and where that chunk
+    // sits in the slot's row (the launcher checked: behind the first half-row, at most four chunks to the read's end)
+    int tq_plo[4];
+    int tail_p0 = n;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        tq_plo[j] = j < tq_n ? max(0, n + tq_qc[j] - 1 - tq_open[j]) : n;
+        tail_p0 = min(tail_p0, tq_plo[j]);
+    }
+    const int tail_base = tail_p0 & ~15;
+    const int tail_off = H2 > 0 ? 16 * H1 : 0;                          // first position of the last half-row
+    const int tail_unit0 = (tail_base - tail_off) >> 4;                 // row unit of the first tail chunk
 
     unsigned p_cur = (unsigned)wave;
     prefetch(piece_base(p_cur));
@@ -419,6 +432,8 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
             uint32_t r_prev = r;                                        // the word five characters in front of the chunk (the chunk before's twelfth)
             uint32_t rlast = r;                                         // the word at the read's last character
             unsigned seen_chars = 0;
+            unsigned long long tm[4] = {0ull, 0ull, 0ull, 0ull};        // per tail slot: bit 16 k + t = a hit at tail_base + 16 k + t
+            uint32_t tw0[3] = {0u, 0u, 0u};                             // the three words of the first tail chunk
             cur_cls = M2_W;
             m2_u32x4 cur = (m2_u32x4)(0u);
 #pragma unroll 1
@@ -440,13 +455,12 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
                     uint32_t e[16];
 #pragma unroll
                     for (int t = 0; t < 16; ++t) e[t] = s_xlat[(w4[t >> 2] >> (8 * (t & 3))) & 127u];
-                    uint32_t rr5 = 0, rr11 = 0;
+                    uint32_t rr[16];
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) { r = (r << 3) | e[t]; rr[t] = r; }
+                    const uint32_t rr5 = rr[5], rr11 = rr[11];
                     unsigned hits = 0;
                     if constexpr (w_only8) {
-                        uint32_t rr[16];
-#pragma unroll
-                        for (int t = 0; t < 16; ++t) { r = (r << 3) | e[t]; rr[t] = r; }
-                        rr5 = rr[5]; rr11 = rr[11];
                         uint32_t wd[16];
 #pragma unroll
                         for (int t = 0; t < 16; ++t) {
@@ -461,12 +475,9 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
                     } else {
 #pragma unroll
                         for (int t = 0; t < 16; ++t) {
-                            r = (r << 3) | e[t];
-                            if (t == 5) rr5 = r;
-                            if (t == 11) rr11 = r;
                             bool h = false;
                             for (int qc = 1; qc <= 8; ++qc)
-                                if ((qmask_w >> qc) & 1) h = h || probe(r, qc);
+                                if ((qmask_w >> qc) & 1) h = h || probe(rr[t], qc);
                             hits |= (h ? 1u : 0u) << t;
                         }
                     }
@@ -481,6 +492,55 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
                     };
                     // the read's last ten characters (the chunk's characters behind the read's end are NULs)
                     if (pos < n && pos + 16 >= n) rlast = word_at(n - 1 - pos);
+                    // ---- the tail slots: probed in the read's last chunks with the words the main pass has anyway; the hits
+                    // wait (a bit mask per slot) until class W is resolved.  The chunk's three words wait with them: the
+                    // first tail chunk's in registers, a later one's in the row unit in front of it (its characters are spent)
+#if !(defined(M2_ABL) && (M2_ABL & 1))
+                    if (pos + 16 > tail_p0 && pos < n) {
+                        const int kch = (pos - tail_base) >> 4;
+                        if (kch == 0) { tw0[0] = r_prev; tw0[1] = rr5; tw0[2] = r; }
+                        else {
+                            uint32_t* const keep = reinterpret_cast<uint32_t*>(const_cast<unsigned char*>(row) + 16 * (c - 1));
+                            keep[0] = r_prev; keep[1] = rr5; keep[2] = r;
+                        }
+#pragma unroll 1
+                        for (int j = 0; j < tq_n; ++j) {
+                            // (the slot's constants by a chain of scalar selects: the loop stays rolled, ONE copy of the probes)
+                            const int qc = j == 0 ? tq_qc[0] : (j == 1 ? tq_qc[1] : (j == 2 ? tq_qc[2] : tq_qc[3]));
+                            const int plo = j == 0 ? tq_plo[0] : (j == 1 ? tq_plo[1] : (j == 2 ? tq_plo[2] : tq_plo[3]));
+                            if (pos + 16 <= plo) continue;                                 // wave-uniform
+                            unsigned h16 = 0;
+                            if (w_only8 && qc == 8) {
+                                h16 = hits;                                                // the main pass's own probe
+                            } else {
+                                const uint32_t msk = m2_mask(qc), salt = m2_salt(qc);
+                                const uint32_t region = qc >= 8 ? 0u : CAH_M2_BM8_WORDS * 32u, keep15 = qc >= 8 ? 0xFFFFu : 0x7FFFu;
+                                uint32_t wd2[16];
+#pragma unroll
+                                for (int t = 0; t < 16; ++t) {
+                                    const uint32_t key = rr[t] & msk;
+                                    const uint32_t idx = ((key ^ (key >> 8)) ^ salt) & keep15;
+                                    wd2[t] = s_bm[(region + idx) >> 5];
+                                }
+#pragma unroll
+                                for (int t = 0; t < 16; ++t) {
+                                    const uint32_t key = rr[t] & msk;
+                                    const uint32_t idx = (key ^ (key >> 8)) ^ salt;
+                                    h16 |= ((wd2[t] >> (idx & 31)) & 1u) << t;
+                                }
+                            }
+                            const int lo_t = plo - pos;
+                            if (lo_t > 0) h16 &= ~((1u << lo_t) - 1u);
+                            if (pos + 16 > n) h16 &= (1u << (n - pos)) - 1u;
+                            if (!valid) h16 = 0;
+                            const unsigned long long add = (unsigned long long)h16 << (16 * kch);
+                            if (j == 0) tm[0] |= add; else if (j == 1) tm[1] |= add; else if (j == 2) tm[2] |= add; else tm[3] |= add;
+                        }
+                    }
+#endif
+#if defined(M2_ABL) && (M2_ABL & 4)
+                    hits = 0;                                           // developer build: no events from the main pass
+#endif
                     if (m2_any(hits != 0)) {
                         while (m2_any(hits != 0)) {
                             const bool mine = hits != 0;
@@ -509,44 +569,79 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
             s_rlast[lane] = rlast;
             drain();
             M2_STAMP(5);
-            // ---- the tail sweeps: classes hi, lo, REF-only, each resolved before the next
-            const int tail_off = H2 > 0 ? 16 * H1 : 0;                  // first position the slot still holds
-#pragma unroll 1
-            for (int cls = M2_HI; cls <= M2_SHORT; ++cls) {
-                const int qm = sweep_qm[cls - 1];
-                if (!qm) continue;
-                cur_cls = cls;
-                // first position a k-mer of the class may start at: the word starts empty there (a k-mer that began
-                // earlier lies outside every window of the class); the launcher checked that the slot still holds it
-                const int from = max(tail_off, n - sweep_span[cls - 1]);
-                const unsigned long long openp = sweep_open[cls - 1];   // open_L of the eight index classes, a byte each
-                uint32_t rs = 0x24924924u;
-                // four characters per LDS read, from the 4-aligned position at or in front of `from` (what lies in front
-                // of `from` enters the word but is not probed; a k-mer that begins there is outside every window)
-                const int p4 = tail_off + ((from - tail_off) & ~3);
-#pragma unroll 1
-                for (int pb = p4; pb < n; pb += 4) {
-                    const unsigned w = *reinterpret_cast<const unsigned*>(row + (pb - tail_off));
-                    uint32_t e4[4];
+            // ---- the tail slots' hits become events, class by class (hi, lo, REF-only), each class resolved before the next
+            {
+                int prev_cls = M2_W;
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) e4[t] = s_xlat[(w >> (8 * t)) & 127u];
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const int p = pb + t;
-                        rs = ((rs << 3) | e4[t]) & 0x3FFFFFFFu;
-                        if (p < from || p >= n) continue;               // wave-uniform
-#pragma unroll 1
-                        for (int qrest = qm; qrest; qrest &= qrest - 1) {
-                            const int qc = __builtin_ctz((unsigned)qrest);
-                            if (n - p + qc - 1 > (int)((openp >> (8 * (qc - 1))) & 255ull)) continue;
-                            const bool h = valid && probe(rs, qc);
-                            const unsigned long long mk = __ballot(h);
-                            if (mk) push_events(mk, h, rs, p, qc);
-                        }
+                for (int j = 0; j < 4; ++j) {
+                    if (j >= tq_n) continue;                            // wave-uniform
+                    if (tq_cls[j] != prev_cls) {
+                        drain();
+                        M2_STAMP(4 + tq_cls[j]);
+                        prev_cls = tq_cls[j];
+                        cur_cls = prev_cls;
+                    }
+                    unsigned long long mk = tm[j];
+                    const int qc = tq_qc[j];
+                    while (m2_any(mk != 0ull)) {
+                        const bool mine = mk != 0ull;
+                        const int bit = mine ? (int)__builtin_ctzll(mk) : 0;
+                        mk &= mk - 1ull;
+                        const int kch = bit >> 4, t = bit & 15;
+                        // the chunk's three words: at its position - 5, + 5 and + 15
+                        const int unit = max(tail_unit0 + kch - 1, 0);
+                        const uint32_t* const keep = reinterpret_cast<const uint32_t*>(row + 16 * unit);
+                        uint32_t a0 = keep[0], a1 = keep[1], a2 = keep[2];
+                        if (kch == 0) { a0 = tw0[0]; a1 = tw0[1]; a2 = tw0[2]; }
+                        const uint64_t v_lo = ((uint64_t)a0 << 30) | (uint64_t)(a1 & 0x3FFFFFFFu);
+                        const uint64_t v_hi = ((uint64_t)a1 << 30) | (uint64_t)(a2 & 0x3FFFFFFFu);
+                        const uint32_t rt = t <= 5 ? (uint32_t)(v_lo >> (3 * (5 - t))) : (uint32_t)(v_hi >> (3 * (15 - t)));
+                        push_events(__ballot(mine), mine, rt & 0x3FFFFFFFu, tail_base + bit, qc);
                     }
                 }
                 drain();
-                M2_STAMP(5 + cls);
+                M2_STAMP(8);
+            }
+            if (qm_short && short_fixed) {
+                cur_cls = M2_SHORT;
+                // REF-only k-mers that must be the read's last q characters (kmer_heuristic's sets for overlaps below 5):
+                // every lane looks its own read up -- no events, no atomics on the bitsets (all other classes are
+                // resolved), and the suffix compares of a read merge into ONE best key
+                unsigned long long bestk = 0;
+                uint32_t* const ss = s_seen + lane * words;
+                const uint32_t* const sw = s_wide + lane * words;
+#pragma unroll 1
+                for (int qrest = qm_short; qrest; qrest &= qrest - 1) {
+                    const int qc = __builtin_ctz((unsigned)qrest);
+                    const bool h = valid && probe(rlast, qc);
+                    const uint32_t d = h ? (uint32_t)s_dir[m2_index(rlast, qc) & (CAH_M2_SLOTS - 1)] : 0u;
+                    int u = m2_dir_begin(d), left = m2_dir_count(d);
+                    while (m2_any(left > 0)) {
+                        const bool on = left > 0;
+                        const CahM2Slot e = s_ent[on ? u : 0];
+                        const int q = m2_q(e.meta);
+                        const bool match = on && m2_cls(e.meta) == M2_SHORT && (q < 8 ? q : 8) == qc && q <= n &&
+                                           (rlast & m2_mask(q)) == e.key;
+                        const int adapter = m2_adapter(e.meta);
+                        const unsigned bit = 1u << (adapter & 31);
+                        const int word = adapter >> 5;
+                        const unsigned old = ss[word];
+                        const bool fresh = match && (old & bit) == 0;
+                        const bool whole = fresh && (sw[word] & bit) != 0;
+                        if (fresh && !whole) {
+                            ss[word] = old | bit;
+                            const int i = m2_exact_tail(rlast, s_prefix[adapter], min_overlap, lmax0, n);
+                            const unsigned long long kk = i > 0 ? pack_best(i, 0, adapter, i, n - i, n) : 0ull;
+                            bestk = kk > bestk ? kk : bestk;
+                        }
+                        // (a WIDE-only hit came first: the pair takes the whole read -- through the general path)
+                        const unsigned long long mw = __ballot(whole);
+                        if (mw) push_events(mw, whole, rlast & 0x3FFFFFFFu, n - 1, qc);
+                        ++u; --left;
+                    }
+                }
+                if (bestk) atomicMax(a.best_key + (a.first_read + base + lane), bestk);
+                drain();
             }
             if (valid && (seen_chars & 0x80808080u) != 0) a.status[a.first_read + base + lane] = 2;
         }
@@ -629,17 +724,17 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_multi
             int j0w = tail ? ((int)key << 2) : max(0, ((int)key << CAH_KEY_SHIFT) - p.m - p.k - 1);
             j0w = min(j0w, n);
             // one start for the whole wave -- the earliest window's (any earlier start is as exact): the lanes then
-            // walk the same chunks and reach the read end together, no lane steps past its read
+            // walk the same chunks and reach the read end together, no lane steps past its read.  A tail page's pairs
+            // all have the same window (one class, one read length): lane 0's.
             int j0 = valid ? bs_align_window(j0w, n) : n;
-#pragma unroll
-            for (int sft = 1; sft < WAVE; sft <<= 1) j0 = min(j0, __shfl_xor(j0, sft, WAVE));
-            j0 = __builtin_amdgcn_readfirstlane(j0);
             int t0 = 0;
             if (tail_page) {
-                int d = valid ? j0w - j0 : 16;
+                j0 = __builtin_amdgcn_readfirstlane(j0);                // (lane 0 of a sub-batch is always valid)
+                t0 = (__builtin_amdgcn_readfirstlane(j0w) - j0) & 15;
+            } else {
 #pragma unroll
-                for (int sft = 1; sft < WAVE; sft <<= 1) d = min(d, __shfl_xor(d, sft, WAVE));
-                t0 = __builtin_amdgcn_readfirstlane(d) & 15;
+                for (int sft = 1; sft < WAVE; sft <<= 1) j0 = min(j0, __shfl_xor(j0, sft, WAVE));
+                j0 = __builtin_amdgcn_readfirstlane(j0);
             }
             const int jstart = j0 + t0;                                 // first column the scan really looks at
             auto eq_of = [&](const Chunk& ck, int t) -> uint64_t {
@@ -687,9 +782,15 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_multi
             int o0 = 0, o1 = 0;
             // rows that cannot be acceptable are not looked at: an acceptable row's alignment lies inside the window
             int max_row = valid ? min(p.m, n - j0w + p.kacc) : 0;
+            if (tail_page) {
+                // (lo pages: the rows of the first error class -- a row with a higher threshold needs a chunk of ITS class)
+                max_row = __builtin_amdgcn_readfirstlane(max_row);
+                if ((hdr >> 24) == 0u) max_row = min(max_row, a.rows_lo);
+            } else {
 #pragma unroll
-            for (int sft = 1; sft < WAVE; sft <<= 1) max_row = max(max_row, __shfl_xor(max_row, sft, WAVE));
-            max_row = __builtin_amdgcn_readfirstlane(max_row);
+                for (int sft = 1; sft < WAVE; sft <<= 1) max_row = max(max_row, __shfl_xor(max_row, sft, WAVE));
+                max_row = __builtin_amdgcn_readfirstlane(max_row);
+            }
             int cls;
             if constexpr (KIND == 0) cls = bs_finish<false>(st, n, jstart, p, [&](int i) { return s_thr_last[i]; }, o0, o1, false, max_row);
             else cls = bs32_finish<XR, false>(st, n, jstart, p, [&](int i) { return s_thr_last[i]; }, o0, o1, false, max_row);
@@ -757,8 +858,12 @@ bool multi2_read_len_ok(const CahMulti2Header& h, int n) {
     if (multi2_lds_bytes(h) > 160 * 1024) return false;
     const int U = (n + 15) >> 4, H1 = (U + 1) >> 1, H2 = U - H1;
     const int tail_off = H2 > 0 ? 16 * H1 : 0;
-    for (int c = M2_HI; c <= M2_SHORT; c++)
-        if (h.q_mask[c] && tail_off > 0 && n - h.span[c] < tail_off) return false;
+    // the tail slots are probed in the last chunks of the last half-row: every slot's first position must lie in it,
+    // and at most four chunks (the slots' hit masks are 64 bits) reach from there to the read's end
+    int p0 = n;
+    for (int j = 0; j < h.tq_n; j++) p0 = std::min(p0, std::max(0, n + h.tq_qc[j] - 1 - h.tq_open[j]));
+    const int tail_base = p0 & ~15;
+    if (tail_base < tail_off || n - tail_base > 64) return false;
     return true;
 }
 

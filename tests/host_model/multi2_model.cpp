@@ -137,6 +137,10 @@ int m2m_match_batch(const char* adapters, int A, int m, const void* blobs, int32
             const CahMatcher& mt = mts[(size_t)pr.adapter];
             const bool tail = (pr.flags & CAH_M2_PAIR_TAIL) != 0;
             int j0 = tail ? (pr.key << 2) : std::max(0, (pr.key << CAH_KEY_SHIFT) - p.m - p.k - 1);
+            // rows above this cannot be acceptable (k_multi_scan does not look at them)
+            int max_row = std::min(p.m, n - std::min(j0, n) + p.kacc);
+            if (tail && pr.key == (std::max(0, n - t.hdr.win_dist[M2_LO]) >> 2) && t.hdr.win_dist[M2_LO] != t.hdr.win_dist[M2_HI])
+                max_row = std::min(max_row, t.hdr.rows_lo);
             j0 = bs_align_window(std::min(j0, n), n);
             if (stats) { stats[tail ? (j0 >= n - t.hdr.win_dist[M2_LO] - 15 && t.hdr.win_dist[M2_LO] != t.hdr.win_dist[M2_HI] ? 2 : 1) : 0]++; stats[5] += n - j0; }
             uint64_t tab32[128];
@@ -158,17 +162,17 @@ int m2m_match_batch(const char* adapters, int A, int m, const void* blobs, int32
                 BackScanState32<X> s;                                                                                     \
                 bs32_init(s, p);                                                                                          \
                 if (subs) run(s, [&](BackScanState32<X>& z, int c) { return bs32_step<true, X>(z, (uint32_t)tab32[c], (uint32_t)(tab32[c] >> 32), j, p); }, \
-                              [&](BackScanState32<X>& z) { return bs32_finish<X, true>(z, n, j0, p, thr, o0, o1, false); }); \
+                              [&](BackScanState32<X>& z) { return bs32_finish<X, true>(z, n, j0, p, thr, o0, o1, false, max_row); }); \
                 else run(s, [&](BackScanState32<X>& z, int c) { return bs32_step<false, X>(z, (uint32_t)tab32[c], (uint32_t)(tab32[c] >> 32), j, p); }, \
-                         [&](BackScanState32<X>& z) { return bs32_finish<X, false>(z, n, j0, p, thr, o0, o1, false); });  \
+                         [&](BackScanState32<X>& z) { return bs32_finish<X, false>(z, n, j0, p, thr, o0, o1, false, max_row); });  \
             }
             if (kind == 0) {
                 BackScanState s;
                 bs_init(s, p);
                 if (subs) run(s, [&](BackScanState& z, int c) { return bs_step<true>(z, mt.scanmask[c], j, p); },
-                              [&](BackScanState& z) { return bs_finish<true>(z, n, j0, p, thr, o0, o1, false); });
+                              [&](BackScanState& z) { return bs_finish<true>(z, n, j0, p, thr, o0, o1, false, max_row); });
                 else run(s, [&](BackScanState& z, int c) { return bs_step<false>(z, mt.scanmask[c], j, p); },
-                         [&](BackScanState& z) { return bs_finish<false>(z, n, j0, p, thr, o0, o1, false); });
+                         [&](BackScanState& z) { return bs_finish<false>(z, n, j0, p, thr, o0, o1, false, max_row); });
             } else if (kind == 1) M2M_RUN32(0)
             else if (kind == 2) M2M_RUN32(1)
             else M2M_RUN32(2)

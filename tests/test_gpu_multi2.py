@@ -75,7 +75,7 @@ def test_uniform_fuzz_vs_oracle(hip, orc):
         streamed += kind == "stream"
         run_uniform(orc, seqs, rate, O, reads, f"it {it} m {m} x {count} rate {rate} O {O} n {n} ({kind})", expect=None,
                     pair_cap=count * 700 if it % 3 == 0 else None)
-    assert streamed >= 15, streamed
+    assert streamed >= 10, streamed
 
 
 def test_stream_equals_older_fused_path_at_scale(hip):
