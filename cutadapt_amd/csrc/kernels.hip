@@ -1486,6 +1486,7 @@ __device__ __forceinline__ unsigned get_row_packed(const unsigned (&w)[ROWS + 1]
 template <int ROWS, bool MULTI>
 __global__ __launch_bounds__(256, CAH_DPP_WAVES(ROWS)) void k_dp_packed(DpArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint64_t s_rowmask[];     // [128], or [n_adapters * CAH_MULTI_TAB_STRIDE]
+    if (MULTI && a.run_flag && *a.run_flag == 0ull) return;
     __shared__ int s_ncnt[CAH_MAX_M + 1];
     __shared__ int s_thr[CAH_MAX_M + 1];
     const CahMatcher* mt = a.matcher;
@@ -1527,14 +1528,16 @@ __global__ __launch_bounds__(256, CAH_DPP_WAVES(ROWS)) void k_dp_packed(DpArgs a
         const int64_t base = base0 + (int64_t)sub * WAVE;
         if (base >= total) break;
         const int64_t idx = base + lane;
-        const bool valid = idx < total;
+        bool valid = idx < total;
         // the windowed work list is filled from both ends (see DpArgs)
         const int64_t slot = idx < front ? idx : a.queue_cap - 1 - (idx - front);
         int64_t r = 0;
         unsigned tab_base = 0, adapter = 0;
         if (MULTI) {
+            int32_t qi = 0;
+            if (valid) { qi = a.queue[slot]; valid = qi >= 0; }       // (-1: finished or moved by the second cost scan)
             if (valid) {
-                const uint64_t pr = a.pairs[a.queue[slot]];
+                const uint64_t pr = a.pairs[qi];
                 r = (int64_t)(pr >> 32);
                 adapter = (unsigned)(pr >> 8) & 0xFFFFu;
                 tab_base = adapter * CAH_MULTI_TAB_STRIDE;
