@@ -223,8 +223,14 @@ def profile_fields(config, n, dom, dom_launch_ms):
     valu = {x: k.get(x) for x in ("kernel_full_name", "valu_busy", "valu_insts_per_launch", "waves_per_simd",
                                   "wait_frac_of_wave_cycles", "issue_stall_frac_of_wave_cycles", "clock_ghz_profiled",
                                   "profiled_ms_per_launch", "salu_insts_per_launch", "lds_insts_per_launch")}
-    valu["definition"] = ("valu_busy = SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE cycles per XCD) of "
-                          "the same rocprofv3 pass; wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES")
+    for x in ("valu_issue_lower", "valu_issue_upper"):
+        valu[x] = k.get(x)
+    valu["definition"] = ("valu_issue_lower / _upper = SQ_INSTS_VALU x 2 (x 4) cycles / (SIMD-cycles the kernel was busy: "
+                          "SQ_BUSY_CYCLES per SIMD), the upper one capped at 1: a wave64 VALU instruction occupies its SIMD "
+                          "for 2 cycles (and / or / xor / add / v_bitop3) or 4 (shifts, SDWA, compares, selects, v_perm: "
+                          "profiles/r03/valu_ubench.txt), so the true busy fraction lies between the two; valu_busy (kept "
+                          "for comparison with round 3) = SQ_ACTIVE_INST_VALU x 4 / SIMD-cycles, which counts every "
+                          "instruction as 4 cycles and can exceed 1; wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES")
     valu["source"] = tj.get("source")
     return traffic, valu, "profile taken on this source tree (sha256 match)"
 
@@ -343,6 +349,9 @@ def run_config(args, config, n, steps, warmup, rank, world, device, gen, check_r
                         + (" -- OVERSUBSCRIBED TEST RUN, ranks share devices: not a measurement" if args.oversubscribe else ""),
             "per_rank_rate": per_rank,
             "matched_fraction": n_match / n,
+            "matched_fraction_of": ("reads whose 3' adapter stage (the linked adapter's second stage) found a match"
+                                    if spec["kind"] == "linked" else
+                                    ("mate-1 reads with a match" if spec["kind"] == "paired" else "reads with a match")),
             "prefilter_pass_fraction": None if survivors is None else survivors / n,
             "cell_dp_fraction_of_survivors": None if not survivors else dp_reads / survivors,
             "invalid_reads": n_invalid,
@@ -370,7 +379,7 @@ def run_config(args, config, n, steps, warmup, rank, world, device, gen, check_r
                     "VALU busy fraction, waves per SIMD, wait fraction) come from the committed rocprofv3 PMC passes",
         },
     }
-    if world == 1 and want_cpu:
+    if want_cpu:                                       # (rank 0 only: the others returned above)
         from oracle import cpu_baseline
         try:
             result["cpu_baseline"] = cpu_baseline.run(config, gen, target_seconds=cpu_seconds)
@@ -431,12 +440,13 @@ def main():
             for cfg in ("C3", "C4", "C5"):
                 try:
                     r = run_config(args, cfg, DEFAULT_READS[cfg], args.other_steps, 1, 0, 1, device, gen,
-                                   min(args.check_reads, 20_000 if cfg == "C4" else 200_000),
+                                   min(args.check_reads, 200_000),
                                    args.other_cpu_seconds, not args.no_cpu_baseline)
                     others[cfg] = {"metric": r["metric"], "value": r["value"], "unit": r["unit"], "steps": r["steps"],
                                    "ms_per_step": r["ms_per_step"], "workload": r["config"]["workload"],
                                    "parity_check": r["config"]["parity_check"],
                                    "matched_fraction": r["config"]["matched_fraction"],
+                                   "matched_fraction_of": r["config"]["matched_fraction_of"],
                                    "roofline": {k: r["roofline"][k] for k in ("kernel", "achieved", "frac", "traffic",
                                                                              "kernel_ms_per_step", "launches_per_step",
                                                                              "whole_step_frac", "profile")},
@@ -447,6 +457,26 @@ def main():
                 except Exception as exc:
                     others[cfg] = {"error": repr(exc)[:300]}
             result["other_configs"] = others
+            # the p_adapter = 0 ("all random") and = 1 ("every read carries an adapter") extremes of
+            # the headline workload, two steps each, with their own parity samples
+            extremes = {}
+            for pa in (0.0, 1.0):
+                try:
+                    g2 = dict(gen, p_adapter=pa)
+                    r = run_config(args, "C2", DEFAULT_READS["C2"], 2, 1, 0, 1, device, g2, min(args.check_reads, 200_000),
+                                   0.0, False)
+                    extremes[f"p_adapter_{pa:g}"] = {
+                        "value": r["value"], "unit": r["unit"], "steps": r["steps"], "ms_per_step": r["ms_per_step"],
+                        "workload": r["config"]["workload"], "parity_check": r["config"]["parity_check"],
+                        "matched_fraction": r["config"]["matched_fraction"],
+                        "prefilter_pass_fraction": r["config"]["prefilter_pass_fraction"],
+                        "kernel_ms_per_step": r["roofline"]["kernel_ms_per_step"],
+                        "whole_step_frac": r["roofline"]["whole_step_frac"]}
+                except SystemExit:
+                    raise
+                except Exception as exc:
+                    extremes[f"p_adapter_{pa:g}"] = {"error": repr(exc)[:300]}
+            result["p_adapter_extremes"] = extremes
         line = json.dumps(result)
         if world > 1:
             os.write(real_stdout, (line + "\n").encode())

@@ -314,6 +314,33 @@ class Adapter(Matchable, ABC):
         pass
 
 
+_ACGT = frozenset("ACGT")
+_IUPAC = frozenset("ABCDGHKMNRSTUVWXY")
+
+
+def _canonical_adapter(sequence: str) -> str:
+    """upper case, RNA and inosine spelled as DNA / N (reference adapters.py:579-581); empty adapters are an error"""
+    seq = sequence.upper().replace("U", "T").replace("I", "N")
+    if seq == "":
+        raise ValueError("Adapter sequence is empty")
+    return seq
+
+
+def _error_rate(max_errors: float, seq: str) -> float:
+    """values from 1 on are absolute error counts, spread over the characters that are not N (reference :582-584)"""
+    informative = len(seq) - seq.count("N")
+    return max_errors / informative if (max_errors >= 1 and informative) else max_errors
+
+
+def _require_iupac(seq: str, letters) -> None:
+    """the reference's complaint about the first character that is no IUPAC code (:586-592)"""
+    if letters <= _IUPAC:
+        return
+    bad = next(c for c in seq if c not in _IUPAC)
+    raise InvalidCharacter(f"Character '{bad}' in adapter sequence '{seq}' is not a valid IUPAC code. "
+                           f"Use only characters 'ABCDGHIKMNRSTUVWXY'.")
+
+
 class SingleAdapter(Adapter, ABC):
     """One adapter: sequence, error rate, type (reference adapters.py:533-681).
 
@@ -328,29 +355,20 @@ class SingleAdapter(Adapter, ABC):
     def __init__(self, sequence: str, max_errors: float = 0.1, min_overlap: int = 3,
                  read_wildcards: bool = False, adapter_wildcards: bool = True,
                  name: Optional[str] = None, indels: bool = True):
-        self.name: str = _generate_adapter_name() if name is None else name
-        super().__init__(self.name)
+        super().__init__(name if name is not None else _generate_adapter_name())
         self._debug = False
-        self.sequence: str = sequence.upper().replace("U", "T").replace("I", "N")
-        if not self.sequence:
-            raise ValueError("Adapter sequence is empty")
-        if max_errors >= 1 and self.sequence.count("N") != len(self.sequence):
-            max_errors /= len(self.sequence) - self.sequence.count("N")
-        self.max_error_rate: float = max_errors
-        self.min_overlap: int = min(min_overlap, len(self.sequence))
-        iupac = frozenset("ABCDGHKMNRSTUVWXY")
-        if adapter_wildcards and not set(self.sequence) <= iupac:
-            for c in self.sequence:
-                if c not in iupac:
-                    raise InvalidCharacter(
-                        f"Character '{c}' in adapter sequence '{self.sequence}' is "
-                        f"not a valid IUPAC code. Use only characters 'ABCDGHIKMNRSTUVWXY'.")
-        # non-wildcard matching if the adapter is plain ACGT (reference :592-595)
-        self.adapter_wildcards: bool = adapter_wildcards and not set(self.sequence) <= set("ACGT")
-        self.read_wildcards: bool = read_wildcards
-        self.indels: bool = indels
+        self.sequence = _canonical_adapter(sequence)
+        self.max_error_rate = _error_rate(max_errors, self.sequence)
+        self.min_overlap = min(min_overlap, len(self.sequence))
+        letters = set(self.sequence)
+        if adapter_wildcards:
+            _require_iupac(self.sequence, letters)
+        # a plain ACGT adapter is matched without the wildcard tables (reference :592-595)
+        self.adapter_wildcards = bool(adapter_wildcards) and not letters <= _ACGT
+        self.read_wildcards = read_wildcards
+        self.indels = indels
         self.aligner = self._aligner()
-        self.kmer_finder = self._kmer_finder()
+        self.kmer_finder = self._kmer_finder()                # (may look at the aligner: anchored adapters without indels)
         # fused plan: this adapter's aligner + its prefilter as ONE matcher, so that
         # match_to()/match_to_batch() are a single library call
         self._fused_plan = _lib.Plan([self.matcher_spec()])
@@ -379,13 +397,10 @@ class SingleAdapter(Adapter, ABC):
         return self.aligner.spec(None)
 
     def __repr__(self):
-        return ("<{cls}(name={name!r}, sequence={sequence!r}, max_error_rate={max_error_rate}, "
-                "min_overlap={min_overlap}, read_wildcards={read_wildcards}, "
-                "adapter_wildcards={adapter_wildcards}, indels={indels})>").format(
-                    cls=self.__class__.__name__, name=self.name, sequence=self.sequence,
-                    max_error_rate=self.max_error_rate, min_overlap=self.min_overlap,
-                    read_wildcards=self.read_wildcards, adapter_wildcards=self.adapter_wildcards,
-                    indels=self.indels)
+        fields = ", ".join(f"{k}={getattr(self, k)!r}" if k in ("name", "sequence") else f"{k}={getattr(self, k)}"
+                           for k in ("name", "sequence", "max_error_rate", "min_overlap", "read_wildcards",
+                                     "adapter_wildcards", "indels"))
+        return f"<{type(self).__name__}({fields})>"
 
     @property
     def effective_length(self) -> int:
@@ -817,16 +832,14 @@ class LinkedAdapter(Adapter):
     def __init__(self, front_adapter: SingleAdapter, back_adapter: SingleAdapter,
                  front_required: bool, back_required: bool, name: Optional[str]):
         super().__init__(name)
-        self.front_required = front_required
-        self.back_required = back_required
+        self.name = _generate_adapter_name() if name is None else name
         self.where = "linked"
-        self.name: str = _generate_adapter_name() if name is None else name
-        self.front_adapter = front_adapter
-        self.front_adapter.name = self.name
-        self.back_adapter = back_adapter
+        self.front_adapter, self.back_adapter = front_adapter, back_adapter
+        self.front_required, self.back_required = front_required, back_required
+        front_adapter.name = self.name                       # (the 5' part reports under the pair's name, reference :1199)
 
     def __repr__(self):
-        return f"{self.__class__.__name__}(front_adapter={self.front_adapter}, back_adapter={self.back_adapter})"
+        return f"{type(self).__name__}(front_adapter={self.front_adapter}, back_adapter={self.back_adapter})"
 
     def descriptive_identifier(self) -> str:
         return "linked"

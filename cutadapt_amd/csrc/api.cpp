@@ -1059,7 +1059,7 @@ size_t cah_workspace_bytes(int64_t n_reads) {
 // of 96 adapters paid that 36 times, 16 of its 114 ms); larger batches are processed in chunks of
 // cap / n_adapters reads.
 static int64_t m2_slack_pages(int64_t n_reads) {
-    const int64_t tiles = (n_reads + 8191) / 8192;
+    const int64_t tiles = (n_reads + 1023) / 1024;                 // (multi2.hip: M2_TILE)
     return (tiles < 256 ? (tiles < 1 ? 1 : tiles) : 256) * 16 * CAH_M2_PAIR_CLASSES;
 }
 static int64_t multi_pair_cap(const cah_plan* plan, int64_t n_reads) {
@@ -1129,17 +1129,18 @@ static int check_batch(const cah_plan* plan, const void* d_seqs, const void* d_o
     return CAH_OK;
 }
 
-// Tiny batches (the per-read calls of the Python mirror classes send batches of one) are launch-bound: the
-// entry points then zero the whole counter header with ONE memset and the helpers below skip theirs
-// (t_header_fresh), and the host conveniences clear their contiguous output block with one memset
-// (t_outputs_ready) instead of status / out6 / best_adapter separately.
+// Tiny batches (the per-read calls of the Python mirror classes send batches of one) are launch-bound: what a caller
+// has already done for the callee travels as explicit arguments (no per-thread state between entry points):
+//   header_fresh    the whole counter header of the workspace was zeroed with ONE memset: run_filter / run_aligner skip theirs;
+//   outputs_ready   the host conveniences cleared their contiguous output block (status / out6 / best_adapter) with one memset;
+//   precleaned_ws   the one-read path cleared the counters of THIS workspace for the next call as soon as the kernels of the
+//                   current one were queued (the memset runs while the host is busy elsewhere); kept in the thread's
+//                   HostScratch, which owns that workspace.
 #define CAH_TINY_BATCH 64
-static thread_local bool t_header_fresh = false;
-static thread_local bool t_outputs_ready = false;
-// the one-read path (host_call_one) clears the counters of ITS workspace for the next call as soon as the kernels of
-// the current one are queued -- the memset then runs while the host is busy elsewhere instead of in front of the
-// next call's first kernel; the workspace it vouches for
-static thread_local const void* t_precleaned_ws = nullptr;
+struct CallHints {
+    bool outputs_ready = false;
+    const void* precleaned_ws = nullptr;
+};
 
 // Aligner of an anchored adapter (Where.PREFIX = QUERY_STOP, Where.SUFFIX = QUERY_START) whose error threshold at
 // full length is 0: see k_anchored_exact.  CAH_NO_ANCHORED_EXACT=1 keeps the cell DP (A/B, parity tests).
@@ -1203,7 +1204,7 @@ static int run_aligner(const cah_plan* plan, const PlanDeviceCopy* pd, int32_t a
                        const int32_t* d_queue, const unsigned long long* d_queue_count,
                        const uint8_t* d_queue_keys, const Workspace& ws, int32_t* d_out6,
                        uint8_t* d_status, int32_t* d_best, int merge_best, hipStream_t s,
-                       const UniformLayout ul = UniformLayout()) {
+                       const UniformLayout ul = UniformLayout(), const bool header_fresh = false) {
     const CahMatcher& mt = plan->matchers[(size_t)adapter];
     DpArgs a;
     a.uniform_first = ul.first; a.uniform_len = ul.len;
@@ -1217,7 +1218,7 @@ static int run_aligner(const cah_plan* plan, const PlanDeviceCopy* pd, int32_t a
     a.win = nullptr; a.queue_count_back = nullptr; a.queue_cap = 0;
     a.pairs = nullptr; a.tab = nullptr; a.n_adapters = 0; a.best_key = nullptr;
     // DP work counter, scan tile counter, DP list counts: one memset over their lines
-    if (!t_header_fresh)
+    if (!header_fresh)
         HIP_TRY(hipMemsetAsync(ws.counters + WS_DPWORK, 0, WS_HEADER - WS_DPWORK * sizeof(unsigned long long), s));
     if (mt.long_dp) {
         // adapter longer than 64 characters: column in HBM scratch (long.hip)
@@ -1329,7 +1330,8 @@ static int run_filter(const cah_plan* plan, const PlanDeviceCopy* pd, int32_t ad
                       unsigned long long* d_queue_count, uint8_t* d_queue_keys,
                       unsigned long long* d_work_counter, const unsigned long long* d_batch_flag, hipStream_t s,
                       int32_t* d_clear_out6 = nullptr, int32_t* d_clear_best = nullptr,
-                      const UniformLayout ul = UniformLayout(), const FrontFuse* fuse = nullptr) {
+                      const UniformLayout ul = UniformLayout(), const FrontFuse* fuse = nullptr,
+                      const bool header_fresh = false) {
     const CahMatcher& mt = plan->matchers[(size_t)adapter];
     if (mt.n_words > 1024)
         return fail(CAH_EUNSUPPORTED, "adapter %d: %d packed k-mer words exceed the 1024-word limit of the prefilter kernel",
@@ -1359,7 +1361,7 @@ static int run_filter(const cah_plan* plan, const PlanDeviceCopy* pd, int32_t ad
     }
     f.clear_out6 = mode == 1 ? d_clear_out6 : nullptr;
     f.clear_best = f.clear_out6 ? d_clear_best : nullptr;
-    if (!t_header_fresh) {
+    if (!header_fresh) {
         HIP_TRY(hipMemsetAsync(d_work_counter, 0, sizeof(unsigned long long), s));
         if (d_queue_count) HIP_TRY(hipMemsetAsync(d_queue_count, 0, sizeof(unsigned long long), s));
     }
@@ -1579,7 +1581,8 @@ static int match_batch_multi(const cah_plan* plan, const PlanDeviceCopy* pd, con
 static int match_batch_impl(const cah_plan* plan, const uint8_t* d_seqs, const int64_t* d_offsets,
                             const int32_t* d_lens, const UniformLayout ul, int64_t n_reads, int32_t* d_out6,
                             int32_t* d_best_adapter, uint8_t* d_status, void* d_workspace, size_t workspace_bytes,
-                            void* stream, const FrontFuse* fuse = nullptr) {
+                            void* stream, const FrontFuse* fuse = nullptr, const CallHints* hints = nullptr) {
+    const bool outputs_ready = hints && hints->outputs_ready;
     int rc = check_batch(plan, d_seqs, (ul.len > 0 && !ul.suffix) ? (const void*)d_seqs : (const void*)d_offsets, n_reads);
     if (rc) return rc;
     if (n_reads == 0) return CAH_OK;
@@ -1600,21 +1603,18 @@ static int match_batch_impl(const cah_plan* plan, const uint8_t* d_seqs, const i
     for (int32_t ad = 0; ad < (int32_t)plan->matchers.size() && first_aligner < 0; ad++)
         if (plan->matchers[(size_t)ad].kind != CAH_KIND_KMER_ONLY) first_aligner = ad;
     // (CAH_NO_FILTER_CLEAR=1: memsets instead, A/B)
-    const bool filter_clears = !t_outputs_ready && !multi_path && first_aligner >= 0 &&
+    const bool filter_clears = !outputs_ready && !multi_path && first_aligner >= 0 &&
                                runs_filter(plan->matchers[(size_t)first_aligner]) && n_reads > CAH_TINY_BATCH &&
                                !(env_flag("CAH_NO_FILTER_CLEAR") && !fuse);
-    if (!t_outputs_ready) {
+    if (!outputs_ready) {
         HIP_TRY(hipMemsetAsync(d_status, 0, (size_t)n_reads, s));
         if (!filter_clears) HIP_TRY(hipMemsetAsync(d_out6, 0, sizeof(int32_t) * 6 * (size_t)n_reads, s));
         if (d_best_adapter && !filter_clears) HIP_TRY(launch_init_best(d_best_adapter, n_reads, pd->n_cus, s));
     }
     // tiny single-adapter batches: one memset for all counters, no batch check (the ragged prefilter serves them)
     const bool tiny = n_reads <= CAH_TINY_BATCH && plan->matchers.size() == 1;
-    struct FreshGuard { bool on; ~FreshGuard() { if (on) t_header_fresh = false; } } guard{tiny};
-    if (tiny) {
-        if (t_precleaned_ws != d_workspace) HIP_TRY(hipMemsetAsync(counters, 0, WS_HEADER, s));
-        t_header_fresh = true;
-    }
+    if (tiny && !(hints && hints->precleaned_ws == d_workspace)) HIP_TRY(hipMemsetAsync(counters, 0, WS_HEADER, s));
+    const bool header_fresh = tiny;
     // one pass over the offsets decides, on the device, which prefilter kernel works on this batch
     const unsigned long long* d_batch_flag = nullptr;
     if (!d_lens && !tiny && ul.len == 0 && !ul.suffix) {
@@ -1639,15 +1639,16 @@ static int match_batch_impl(const cah_plan* plan, const uint8_t* d_seqs, const i
                             counters + WS_QCOUNT, ws.keys, counters + 0, d_batch_flag, s,
                             (filter_clears && ad == first_aligner) ? d_out6 : nullptr,
                             (filter_clears && ad == first_aligner) ? d_best_adapter : nullptr, ul,
-                            ad == first_aligner ? fuse : nullptr);
+                            ad == first_aligner ? fuse : nullptr, header_fresh);
             if (rc) return rc;
             // merge mode 2: the plan's first adapter writes into zeroed rows -- nothing to compare with (kernels.hip,
             // store_result)
             rc = run_aligner(plan, pd, ad, d_seqs, d_offsets, d_lens, n_reads, ws.queue, counters + WS_QCOUNT,
-                             ws.keys, ws, d_out6, d_status, d_best_adapter, ad == first_aligner ? 2 : 1, s, ul_rest);
+                             ws.keys, ws, d_out6, d_status, d_best_adapter, ad == first_aligner ? 2 : 1, s, ul_rest,
+                             header_fresh);
         } else {
             rc = run_aligner(plan, pd, ad, d_seqs, d_offsets, d_lens, n_reads, nullptr, nullptr, nullptr,
-                             ws, d_out6, d_status, d_best_adapter, 1, s, ul_rest);
+                             ws, d_out6, d_status, d_best_adapter, 1, s, ul_rest, header_fresh);
         }
         if (rc) return rc;
     }
@@ -1786,6 +1787,7 @@ struct DevBuf {
 // Python mirror classes send batches of one -- costs one H2D copy, the kernels and one D2H copy: no
 // hipMalloc / hipFree / hipDeviceSynchronize per call.
 struct HostScratch {
+    const void* precleaned_ws = nullptr;    // the workspace whose counter header the last one-read call left zeroed (CallHints)
     int device = -1;
     hipStream_t stream = nullptr;
     char* dev = nullptr;  size_t dev_cap = 0;
@@ -1837,7 +1839,7 @@ static int host_call_one(int mode, const cah_plan* plan, const uint8_t* seq, int
     const char* dev_before = hs.dev;
     int rc = hs.ensure(ws_bytes + 256, in_bytes + out_bytes);
     if (rc) return rc;
-    if (hs.dev != dev_before) t_precleaned_ws = nullptr;
+    if (hs.dev != dev_before) hs.precleaned_ws = nullptr;
     int64_t* h_off = (int64_t*)hs.pin;
     h_off[0] = 0; h_off[1] = n;
     if (n > 0) memcpy(hs.pin + 2 * sizeof(int64_t), seq, (size_t)n);
@@ -1860,7 +1862,7 @@ static int host_call_one(int mode, const cah_plan* plan, const uint8_t* seq, int
         rc = plan_on_device(plan, &pd);
         if (rc) return rc;
         const Workspace ws(d_ws, 1, ws_bytes);
-        t_precleaned_ws = nullptr;                               // k_tiny sets the counters it and the cell DP use itself
+        hs.precleaned_ws = nullptr;                              // k_tiny sets the counters it and the cell DP use itself
         int32_t* h_need = (int32_t*)(h_out + 32);
         TinyArgs ta;
         const bool filter = mode == HOST_MATCH && mt0.has_filter;
@@ -1931,17 +1933,19 @@ static int host_call_one(int mode, const cah_plan* plan, const uint8_t* seq, int
         return CAH_OK;
     }
     if (mode == HOST_LOCATE) {
-        t_precleaned_ws = nullptr;                               // run_aligner clears what it needs itself
+        hs.precleaned_ws = nullptr;                              // run_aligner clears what it needs itself
         rc = cah_locate_batch(plan, 0, d_seqs, d_offsets, nullptr, 1, d_out6, d_status, d_ws, ws_bytes, hs.stream);
     } else {
-        t_outputs_ready = true;
-        rc = cah_match_batch(plan, d_seqs, d_offsets, nullptr, 1, d_out6, d_best, d_status, d_ws, ws_bytes, hs.stream);
-        t_outputs_ready = false;
-        // the next call's counters (tiny path of cah_match_batch), off its critical path
-        if (rc == CAH_OK && hipMemsetAsync(d_ws, 0, WS_HEADER, hs.stream) == hipSuccess) t_precleaned_ws = d_ws;
-        else t_precleaned_ws = nullptr;
+        CallHints hints;
+        hints.outputs_ready = true;                              // (h_out was zeroed above: the outputs live in mapped host memory)
+        hints.precleaned_ws = hs.precleaned_ws;
+        rc = match_batch_impl(plan, d_seqs, d_offsets, nullptr, UniformLayout(), 1, d_out6, d_best, d_status, d_ws, ws_bytes,
+                              hs.stream, nullptr, &hints);
+        // the next call's counters (tiny path of the batch entry), off its critical path
+        if (rc == CAH_OK && hipMemsetAsync(d_ws, 0, WS_HEADER, hs.stream) == hipSuccess) hs.precleaned_ws = d_ws;
+        else hs.precleaned_ws = nullptr;
     }
-    if (rc) { t_precleaned_ws = nullptr; return rc; }
+    if (rc) { hs.precleaned_ws = nullptr; return rc; }
     // the memset queued above is not waited for: an event after the kernels would do, but the stream wait below is
     // cheaper than creating one -- it covers the memset as well (a few hundred nanoseconds of GPU time)
     HIP_TRY(hipStreamSynchronize(hs.stream));
@@ -1956,7 +1960,7 @@ static int host_call(int mode, const cah_plan* plan, int32_t adapter, const uint
     if (n == 1 && plan->matchers.size() == 1 && !best_adapter && offsets[0] == 0 && offsets[1] >= 0 &&
         (mode == HOST_MATCH || (mode == HOST_LOCATE && adapter == 0)) && (offsets[1] == 0 || seqs))
         return host_call_one(mode, plan, seqs, offsets[1], out6, status);
-    t_precleaned_ws = nullptr;                                   // this path lays the device scratch out differently
+    g_host_scratch.precleaned_ws = nullptr;                      // this path lays the device scratch out differently
     const int64_t total = offsets[n];
     if (offsets[0] != 0) return fail(CAH_EINVAL, "offsets[0] must be 0");
     if (total > 0 && !seqs) return fail(CAH_EINVAL, "seqs is NULL");
@@ -1989,9 +1993,10 @@ static int host_call(int mode, const cah_plan* plan, int32_t adapter, const uint
     else {
         // one memset clears out6 / best / status (they are contiguous here); "no adapter" (-1) is filled in below
         HIP_TRY(hipMemsetAsync(d_out, 0, o6_bytes + best_bytes + (size_t)n, hs.stream));
-        t_outputs_ready = true;
-        rc = cah_match_batch(plan, d_seqs, d_offsets, nullptr, n, d_out6, d_best, d_status, d_ws, ws_bytes, hs.stream);
-        t_outputs_ready = false;
+        CallHints hints;
+        hints.outputs_ready = true;
+        rc = match_batch_impl(plan, d_seqs, d_offsets, nullptr, UniformLayout(), n, d_out6, d_best, d_status, d_ws, ws_bytes,
+                              hs.stream, nullptr, &hints);
     }
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(hs.pin + in_bytes, d_out, o6_bytes + best_bytes + (size_t)n, hipMemcpyDeviceToHost, hs.stream));

@@ -33,7 +33,7 @@
 #include "multi2.h"
 
 #define M2_WAVES 16                // waves per block = per CU
-#define M2_TILE 8192               // reads per block tile
+#define M2_TILE 1024               // reads per block tile (one piece per wave: the blocks end within one piece of each other)
 #define M2_HALF 5                  // 16-byte units per half-row
 #define M2_ROW (M2_HALF * 16)
 #define M2_MAX_LEN (2 * M2_HALF * 16)

@@ -729,7 +729,11 @@ hipError_t launch_filter_stream2(const FilterArgs& a_in, int mode, int n_lead, i
     FilterArgs a = a_in;
     if (mode != 0) a.present = nullptr;
     a.stream_n_lo = 1; a.stream_n_hi = S2_MAX_LEN;
+#ifdef CAH_S2_ABLATE
+    // developer builds only (-DCAH_S2_ABLATE, profiles/scripts/r03_nomatch.sh): timing with parts of the kernel switched
+    // off -- the results are wrong, so the knob does not exist in the product library
     { const char* e = getenv("CAH_S2_NOMATCH"); if (e && *e && *e != '0') a.max_read_len = -12344 - atoi(e); }
+#endif
     const int tiles = (int)((a.n_reads + S2_TILE - 1) / S2_TILE);
     const int grid = std::max(1, std::min(tiles, n_cus));
     const size_t lds = 0;                                 // every LDS object of the kernel is static

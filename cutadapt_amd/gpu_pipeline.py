@@ -1139,12 +1139,24 @@ def _paired_pieces(source1, source2, chunk_bytes: int, threads: int = 4):
             n = min(counts)
             if n == 0:
                 if eof[0] and eof[1]:
+                    for d in data:
+                        POOL.put(d)
                     if len(data[0]) or len(data[1]):
                         if counts[0] != counts[1]:
                             raise ValueError("Reads are improperly paired. There are more reads in one file than in the other.")
                         raise ValueError("FASTQ format error: premature end of file (incomplete record)")
                     return
-                if all(len(d) > 64 * chunk_bytes for d in data):
+                # one file is at its end with nothing left while the other still has records (or unread data): the
+                # reference fails at once (dnaio.read_paired_chunks); reading the longer file to ITS end first would
+                # pull all of it into memory, recopied chunk after chunk
+                for k in (0, 1):
+                    if eof[k] and counts[k] == 0 and len(data[k]) == 0 and (counts[1 - k] > 0 or len(data[1 - k]) or not eof[1 - k]):
+                        for d in data:
+                            POOL.put(d)
+                        raise ValueError("Reads are improperly paired. There are more reads in one file than in the other.")
+                if any(len(d) > 64 * chunk_bytes for k, d in enumerate(data) if not eof[k]):
+                    for d in data:
+                        POOL.put(d)
                     raise ValueError("record larger than 64 chunks: not a FASTQ file?")
                 carry = [d.copy() for d in data]
                 for d in data:
@@ -1212,9 +1224,13 @@ def _paired_all_device(in1, in2, out1, out2, mates, job, discard_untrimmed, disc
         for (plan, kinds, times) in plans:
             ws.append(_take_worker(plan, kinds, dev, {"times": times}))
         w, mate = ws
-        mate.stream = w.stream                               # one stream for the pair
+        # one stream for the pair.  What _take_worker queued on the mate's own stream (its counters' zeroing) must be
+        # through before anything of the pair's stream touches them, and the pair's counters are born on that stream
+        w.stream.wait_stream(mate.stream)
+        mate.stream = w.stream
         w.mate = mate
-        w.pair_counts = torch.zeros(8, dtype=torch.int64, device=w.device)   # kept, too short, too long, too many ee, bp out 1 / 2
+        with torch.cuda.stream(w.stream):
+            w.pair_counts = torch.zeros(8, dtype=torch.int64, device=w.device)   # kept, too short, too long, too many ee, bp out 1 / 2
         return w
 
     def combine(preds, how):

@@ -848,6 +848,8 @@ class BatchTrimmer:
             chunk = chunk.host_chunk()                      # the orientations are merged into a host-side chunk
         n = len(chunk)
         lens = chunk.lengths()
+        bp_in = int(lens.sum())                              # of the reads as they came in (reference PairedEndPipeline.process_reads:
+                                                             # len(read1) / len(read2) BEFORE any modifier, swapped mates or not)
         wbeg, wend = np.zeros(n, dtype=np.int64), lens.copy()
         pre = self.nextseq_trim is not None or self.quality_cutoff is not None or bool(self.cut)
         base = chunk.reads(self.device) if n else None
@@ -982,7 +984,7 @@ class BatchTrimmer:
                 info_rows, self.cutter.names if self.cutter is not None else [], is_rc,
                 final=(info_shift + wbeg, info_shift + wend)))
         self.reads += n
-        self.bp_in += int(lens.sum())
+        self.bp_in += bp_in
         return {"beg": wbeg, "end": wend, "matched": matched, "mode": mode, "ee": ee, "lens": lens, "chunk": out_chunk,
                 "rc": is_rc}
 

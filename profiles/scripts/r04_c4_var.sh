@@ -14,7 +14,6 @@ except Exception as e:
 PY
 }
 run X=1
-run CAH_NO_MULTI_RESCAN=1
+run CAH_MULTI_RESCAN=1
 run CAH_MULTI_PAIR_CAP=1073741824
-run CAH_MULTI_PAIR_CAP=1073741824 CAH_NO_MULTI_RESCAN=1
 run CAH_MULTI_PAIR_CAP=4294967296

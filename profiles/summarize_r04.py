@@ -83,6 +83,11 @@ for k, o in out["kernels"].items():
             o["clock_ghz_profiled"] = cyc / (o["duration_ms_grbm"] * 1e6)
         if "SQ_ACTIVE_INST_VALU" in o:
             o["valu_busy"] = o["SQ_ACTIVE_INST_VALU"] * 4.0 / (N_SIMD * cyc)
+        if "SQ_INSTS_VALU" in o:
+            # a wave64 VALU instruction occupies its SIMD for 2 cycles (and / or / xor / add / v_bitop3) or 4 (shifts, SDWA,
+            # compares, selects, v_perm: profiles/r03/valu_ubench.txt): the busy fraction lies between these two
+            o["valu_issue_lower"] = o["SQ_INSTS_VALU"] * 2.0 / (N_SIMD * cyc)
+            o["valu_issue_upper"] = min(1.0, o["SQ_INSTS_VALU"] * 4.0 / (N_SIMD * cyc))
         if "SQ_WAVE_CYCLES" in o:
             o["waves_per_simd_time_average"] = o["SQ_WAVE_CYCLES"] * 4.0 / (N_SIMD * cyc)
     res = o.get("resources", {})
@@ -105,7 +110,7 @@ if "--update-latest" in sys.argv:
         latest = json.load(open(latest_path))
     except Exception:
         latest = {}
-    fam = {"k_filter": ("k_filter", "k_multi_filter"), "k_back_scan": ("k_back_scan",), "k_dp": ("k_dp",)}
+    fam = {"k_filter": ("k_filter", "k_multi_filter", "k_multi_stream"), "k_back_scan": ("k_back_scan", "k_multi_scan"), "k_dp": ("k_dp",)}
     entry = {"reads_per_gpu": reads, "csrc_sha256": csrc_hash(), "source": f"profiles/r04/{tag}_pmc_summary.json", "kernels": {}}
     for name, prefixes in fam.items():
         cands = [(k, o) for k, o in out["kernels"].items() if k.startswith(prefixes)]
@@ -121,6 +126,8 @@ if "--update-latest" in sys.argv:
             "salu_insts_per_launch": o.get("SQ_INSTS_SALU"),
             "lds_insts_per_launch": o.get("SQ_INSTS_LDS"),
             "valu_busy": o.get("valu_busy"),
+            "valu_issue_lower": o.get("valu_issue_lower"),
+            "valu_issue_upper": o.get("valu_issue_upper"),
             "waves_per_simd": o.get("waves_per_simd"),
             "wait_frac_of_wave_cycles": o.get("SQ_WAIT_ANY_frac_of_wave_cycles"),
             "issue_stall_frac_of_wave_cycles": o.get("SQ_WAIT_INST_ANY_frac_of_wave_cycles"),

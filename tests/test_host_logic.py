@@ -51,7 +51,7 @@ def test_library_is_built_and_exports_every_declared_symbol():
     L = _lib.lib()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.cah_abi_version() == _lib.ABI_VERSION == 2
+    assert L.cah_abi_version() == _lib.ABI_VERSION == 3
     out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
     exported = set(re.findall(r" T (cah_[a-z0-9_]+)", out))
     assert declared <= exported

@@ -203,12 +203,20 @@ def test_custom_search_sets(model):
     """search sets that are NOT what kmer_heuristic builds (the C ABI takes any): k-mers of the WIDE family that are
     no REF k-mers only widen, REF k-mers outside the WIDE family only make pairs"""
     rng = np.random.default_rng(79)
-    ads = rand_adapters(rng, 6, 33)
+    # 15-character adapters (one error allowed: classes W and lo only): the custom sets fit the four tail slots
+    ads = rand_adapters(rng, 6, 15)
     sets = []
     for ad in ads:
-        sets.append([(-3, None, [ad[:3]]), (-25, None, [ad[2:8], ad[9:15]]), (0, None, [ad[0:9], ad[20:28]])])
-    reads = tail_reads(rng, ads, 3000, 150)
-    seqs, offsets = orc.pack_reads(reads)
-    run(model, ads, 0.1, 3, seqs, offsets, "custom sets", sets=sets)
+        sets.append([(-3, None, [ad[:3]]), (-12, None, [ad[2:8]]), (0, None, [ad[0:7], ad[9:15]])])
+    for n_len in (40, 150):
+        reads = tail_reads(rng, ads, 3000, n_len)
+        seqs, offsets = orc.pack_reads(reads)
+        st = run(model, ads, 0.1, 3, seqs, offsets, f"custom sets, n {n_len}", sets=sets)
+        assert st[4] > 0, "no pair took the whole-read way: the WIDE-only k-mers of the custom plan were not exercised"
     seqs, offsets = orc.synth_reads(9, 0, 3000, 150, ads, p_adapter=0.6, p_edit=0.05)
     run(model, ads, 0.1, 3, seqs, offsets, "custom sets, synthetic", sets=sets)
+    # ... and a plan that needs more tail slots than the streaming form has is not built (it takes the older kernels)
+    ads = rand_adapters(rng, 4, 33)
+    sets = [[(-3, None, [ad[:3]]), (-25, None, [ad[2:8], ad[9:15]]), (0, None, [ad[0:9], ad[20:28]])] for ad in ads]
+    seqs, offsets = orc.pack_reads(tail_reads(rng, ads, 200, 150))
+    assert run(model, ads, 0.1, 3, seqs, offsets, "custom sets, too many slots", sets=sets, must_build=False) is None
