@@ -43,6 +43,8 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=None,
                     help="units (reads, or read pairs for C5) per GPU; default: the BASELINE size of the config")
+    ap.add_argument("--read-len", type=int, default=None,
+                    help="read length of the synthetic reads (default 150, what BASELINE quotes; 250 / 300: MiSeq-style runs)")
     ap.add_argument("--p-adapter", type=float, default=None,
                     help="override the adapter fraction of the read model (SURVEY 8(d): 0 and 1 are the extremes; "
                          "the headline number uses the default 0.25)")
@@ -135,6 +137,7 @@ class Workload:
     # ---- parity sample: the first m reads of rank 0, bit-compared with the oracle --------------------
     def parity(self, m):
         import numpy as np
+        from cutadapt_amd import workloads
         from oracle import host_workloads
         from oracle import oracle as orc
         kind = self.spec["kind"]
@@ -167,7 +170,7 @@ class Workload:
         ok = True
         for mate, batch in enumerate(self.batches):
             seqs, offsets = host_workloads.host_reads(self.config, 0, m, mate, gen)
-            ok &= np.array_equal(batch.seqs[: m * 150].cpu().numpy(), seqs)       # generator twin
+            ok &= np.array_equal(batch.seqs[: m * workloads.READ_LEN].cpu().numpy(), seqs)       # generator twin
             if kind in ("single", "multi", "paired"):
                 ads = self.adapters if mate == 0 else self.adapters2
                 want6, want_st, want_best = oracle_multi(ads, seqs, offsets)
@@ -310,7 +313,8 @@ def run_config(args, config, n, steps, warmup, rank, world, device, gen, check_r
     del wl
     torch.cuda.empty_cache()
 
-    bytes_per_unit = spec["bytes_per_unit"]
+    # algorithmic bytes per unit: read characters + 4 (offset) + 24 (result row) [+ 4: adapter index]
+    bytes_per_unit = spec["bytes_per_unit"] + (workloads.READ_LEN - 150) * (2 if spec["kind"] == "paired" else 1)
     total_units = n * world * steps
     value = total_units / elapsed / 1e6
     # dominant kernel family: the one with the largest share of a step
@@ -320,7 +324,7 @@ def run_config(args, config, n, steps, warmup, rank, world, device, gen, check_r
     if spec["kind"] == "single":
         reads_per_launch = {"k_filter": n, "k_back_scan": survivors, "k_dp": dp_reads if dp_reads else survivors,
                             "k_comparer": n}[dom]
-    per_read_bytes = 178 if spec["kind"] != "multi" else 182
+    per_read_bytes = (178 if spec["kind"] != "multi" else 182) + (workloads.READ_LEN - 150)
     achieved = reads_per_launch * per_read_bytes / (dom_launch_ms * 1e-3) / 1e9 if dom_launch_ms > 0 else 0.0
     kernel_sum = sum(step_ms.values())
     step_gbs = n * bytes_per_unit / (kernel_sum * 1e-3) / 1e9 if kernel_sum > 0 else 0.0
@@ -399,6 +403,8 @@ def run_config(args, config, n, steps, warmup, rank, world, device, gen, check_r
 
 def main():
     args = parse_args()
+    if args.read_len is not None:
+        os.environ["CAH_BENCH_READ_LEN"] = str(int(args.read_len))     # (before cutadapt_amd.workloads is imported)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args))
@@ -435,7 +441,7 @@ def main():
         # The default invocation (the driver's: C2, one GPU) also carries the other BASELINE configs at their BASELINE
         # sizes -- a few steps each, with their own parity sample, roofline fraction and a short CPU baseline
         if (args.config == "C2" and world == 1 and args.reads is None and args.p_adapter is None
-                and not args.no_other_configs):
+                and args.read_len is None and not args.no_other_configs):
             others = {}
             for cfg in ("C3", "C4", "C5"):
                 try:

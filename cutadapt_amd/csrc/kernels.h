@@ -181,6 +181,7 @@ hipError_t launch_filter_lean(const FilterArgs& a, int mode, int n_lead, int n_g
                               int n_cus, hipStream_t s);
 hipError_t launch_filter_stream2(const FilterArgs& a, int mode, int n_lead, int n_tw, int n_cus, hipStream_t s);
 int stream2_max_len();
+int stream2_long_max_len();      // ... of its LONG form (reads walked in segments of 160 characters)
 bool stream2_class_ok(int n_lead, int n_tw);
 hipError_t launch_uniform_check(const int64_t* offsets, int64_t n_reads, int64_t max_read_len, unsigned long long* flag,
                                 int n_cus, hipStream_t s);

@@ -2491,7 +2491,8 @@ hipError_t launch_filter_lean(const FilterArgs& a_in, int mode, int n_lead, int 
     if (stream2) {
         hipError_t e = launch_filter_stream2(a, mode, n_lead, n_tw, n_cus, s);
         if (e != hipSuccess) return e;
-        if (a.uniform_len > 0 && a.uniform_len <= stream2_max_len() && a.n_reads * (int64_t)a.uniform_len >= 16)
+        if (a.uniform_len > 0 && a.uniform_len <= (a.suffix_views ? stream2_max_len() : stream2_long_max_len()) &&
+            a.n_reads * (int64_t)a.uniform_len >= 16)
             return hipSuccess;                            // the host knows the length: nothing else to launch
     }
     const int grid = grid_for(a.n_reads, LEAN_WAVES, n_cus);
@@ -2528,7 +2529,7 @@ hipError_t launch_filter_lean(const FilterArgs& a_in, int mode, int n_lead, int 
     } while (0)
     // the per-lane uniform kernel leaves the streaming kernels' lengths alone
     a.stream_n_lo = stream2 ? 1 : 0;
-    a.stream_n_hi = stream2 ? stream2_max_len() : (stream ? stream_max_len(STREAM_UM_B) : -1);
+    a.stream_n_hi = stream2 ? (a.suffix_views ? stream2_max_len() : stream2_long_max_len()) : (stream ? stream_max_len(STREAM_UM_B) : -1);
     // slot classes <lead, gated>: TruSeq / e = 0.1 is <2, 3> as a 3' or 5' adapter, <2, 6> as an anywhere adapter
     if (n_lead <= 1 && n_gated <= 2) CAH_LEAN_CLASS(1, 2);
     else if (n_lead <= 2 && n_gated <= 3) CAH_LEAN_CLASS(2, 3);

@@ -35,6 +35,8 @@
 #define S2_HALF 5                  // units per half-row
 #define S2_ROW (S2_HALF * 16)      // bytes of a slot row
 #define S2_MAX_LEN (2 * S2_HALF * 16)
+#define S2_SEG (2 * S2_HALF)       // units of a segment: what the slot takes in two fills
+#define S2_LONG_MAX_LEN 640        // LONG form: reads of up to four segments
 
 __host__ __device__ constexpr int s2_pow2(int n) { return n <= 1 ? 1 : (n <= 2 ? 2 : 4); }
 __host__ __device__ constexpr int s2_log2(int p) { return p == 1 ? 0 : (p == 2 ? 1 : 2); }
@@ -314,7 +316,11 @@ __device__ __forceinline__ S2Out s2_out_args() {
 // adapter that tolerates no error (k_anchored_exact's case: "^NNNNNNNNACGTACGT") is compared with the read's head while
 // the head sits in the slot anyway; the kernel writes the front stage's result rows and the views (starts, lengths)
 // for the kernels behind it.  One pass over the batch instead of three (front comparison, view arithmetic, prefilter).
-template <int NL, int NT, bool BUF, bool SV = false, bool FR = false>
+// LONG: reads of 161 .. S2_LONG_MAX_LEN characters (2 x 250 / 2 x 300 bp runs).  A read is walked in SEGMENTS of ten units
+// (160 characters): each segment is what the short form does with a whole read -- two fills of the wave's slot -- and
+// the words simply go on from segment to segment (KmerFinder.kmers_present takes reads of any length, reference
+// _kmer_finder.pyx:170-213).  A segment's copy registers are loaded while the second half of the segment before is matched.
+template <int NL, int NT, bool BUF, bool SV = false, bool FR = false, bool LONG = false>
 __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a) {
     typedef S2Layout<NL, NT> LY;
     constexpr int TILE = S2_TILE, SUBS = TILE / WAVE / S2_WAVES;
@@ -419,10 +425,24 @@ __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a
     // u / H2.  Byte offset within the piece: r * n + 16 (c [+ H1]) = r * (n - 16 H) + 16 u [+ 16 H1]; in the slot:
     // r * 80 + 16 c = r * (80 - 16 H) + 16 u (16 u when H = 5).  u / H as a multiply: exact for u < 320, H <= 5
     // (tests/test_host_logic.py checks it exhaustively).
-    const int U = (n + 15) >> 4;
-    const int H1 = (U + 1) >> 1, H2 = U - H1;                           // <= 5 each
-    const unsigned magic1 = (65536u + (unsigned)H1 - 1u) / (unsigned)H1;
-    const unsigned magic2 = H2 ? (65536u + (unsigned)H2 - 1u) / (unsigned)H2 : 0u;
+    const int U_all = (n + 15) >> 4;
+    const int n_seg = LONG ? (U_all + S2_SEG - 1) / S2_SEG : 1;         // (short form: one segment = the read)
+    const int U_last = U_all - (n_seg - 1) * S2_SEG;                    // units of the last segment (<= 10)
+    // the shape of the segment at work: H1 units in the first fill of the slot, H2 in the second (every segment but the
+    // last: 5 + 5)
+    int H1 = LONG ? S2_HALF : (U_all + 1) >> 1, H2 = LONG ? S2_HALF : U_all - H1;
+    unsigned magic1 = (65536u + (unsigned)H1 - 1u) / (unsigned)H1;
+    unsigned magic2 = H2 ? (65536u + (unsigned)H2 - 1u) / (unsigned)H2 : 0u;
+    int seg_off = 0;                                                    // first character of the segment at work
+    auto set_segment = [&](const int seg) {
+        if constexpr (LONG) {
+            const int u = seg == n_seg - 1 ? U_last : S2_SEG;
+            H1 = (u + 1) >> 1; H2 = u - H1;
+            magic1 = (65536u + (unsigned)H1 - 1u) / (unsigned)H1;
+            magic2 = H2 ? (65536u + (unsigned)H2 - 1u) / (unsigned)H2 : 0u;
+            seg_off = seg * (S2_SEG * 16);
+        }
+    };
     // read index of unit 64 k + lane of a half with H units per read (recomputed where used: a register per unit
     // would cost the kernel its fourth wave per SIMD)
     auto unit_r = [&](int k, unsigned magic) -> int {
@@ -450,7 +470,7 @@ __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a
     auto prefetch = [&](int64_t base) {
         const int64_t left = n_reads - base;                            // wave-uniform
         if (left <= 0 || noload) return;
-        const int64_t pbyte = base * (int64_t)n;                        // the piece's first byte within the batch
+        const int64_t pbyte = base * (int64_t)n + seg_off;              // the first byte of the piece's segment within the batch
         const uint8_t* const src = batch0 + pbyte;
         if (left >= WAVE && pbyte + (int64_t)WAVE * n + 16 <= total) {
             // a whole piece with 16 bytes of the batch behind it (all but the last pieces): no lane needs a check
@@ -599,12 +619,24 @@ __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a
             S2Masks<NL> M;
             S2_STAMP(0);
 #pragma unroll 1
+            for (int seg = 0; seg < n_seg; ++seg) {
+            set_segment(seg);
+#pragma unroll 1
             for (int ph = 0; ph < 2; ++ph) {
                 const int H = ph ? H2 : H1;
                 const bool alive = H > 0 && s2_any(hits.live) && !nomatch;   // wave-uniform
                 if (alive) {
                     if (ph == 0) to_slot(std::integral_constant<int, 0>{}); else to_slot(std::integral_constant<int, 1>{});
                     cur = *reinterpret_cast<const s2_u32x4*>(row);
+                    if constexpr (LONG) {
+                        // the next segment's units: requested now that this segment's copy registers are all in the slot,
+                        // on their way while its second half is matched (no T-word is at work before the last segment)
+                        if (ph == 1 && seg + 1 < n_seg) {
+                            set_segment(seg + 1);
+                            prefetch((int64_t)base);
+                            set_segment(seg);
+                        }
+                    }
                 }
                 if constexpr (FR) {
                     if (ph == 0) {
@@ -650,7 +682,7 @@ __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a
                 S2_STAMP(1 + 3 * ph);
                 S2_STAMP(2 + 3 * ph);
                 if (!alive) continue;
-                const int pos0 = ph ? 16 * H1 : 0;
+                const int pos0 = seg_off + (ph ? 16 * H1 : 0);
                 // cur: this chunk's characters; nxt: the next chunk's (its lead masks are requested while this one is
                 // matched); the chunk after that is requested from the slot meanwhile
                 s2_u32x4 nxt = (s2_u32x4)(0u);
@@ -675,6 +707,8 @@ __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a
                 }
                 S2_STAMP(3 + 2 * ph);
             }
+            }
+            if constexpr (LONG) set_segment(0);                         // (the next piece's first segment is loaded below)
             // The next piece's loads go out now, not earlier: through the second half -- the T-words' chunks -- no copy
             // register is live, through the first only the second half's (a fourth wave per SIMD needs that; the
             // other three cover the wait at the next piece's start).  The stores of the result rows in front of them:
@@ -729,6 +763,11 @@ hipError_t launch_filter_stream2(const FilterArgs& a_in, int mode, int n_lead, i
     FilterArgs a = a_in;
     if (mode != 0) a.present = nullptr;
     a.stream_n_lo = 1; a.stream_n_hi = S2_MAX_LEN;
+    // reads of 161 .. 640 characters: the LONG form (CAH_NO_STREAM2_LONG=1: the per-lane kernel, A/B)
+    const char* const el = getenv("CAH_NO_STREAM2_LONG");
+    const bool long_ok = !(el && *el && *el != '0') && !a.suffix_views;
+    const bool want_long = long_ok && (a.uniform_len > S2_MAX_LEN || (a.uniform_len == 0 && a.batch_flag));
+    const bool want_short = a.uniform_len == 0 || a.uniform_len <= S2_MAX_LEN;
 #ifdef CAH_S2_ABLATE
     // developer builds only (-DCAH_S2_ABLATE, profiles/scripts/r03_nomatch.sh): timing with parts of the kernel switched
     // off -- the results are wrong, so the knob does not exist in the product library
@@ -757,12 +796,25 @@ hipError_t launch_filter_stream2(const FilterArgs& a_in, int mode, int n_lead, i
         else return hipErrorInvalidValue;
         return hipGetLastError();
     }
-    if (n_lead <= 1 && n_tw <= 2) S2_LAUNCH(1, 2);
-    else if (n_lead <= 2 && n_tw <= 4) S2_LAUNCH(2, 4);
-    else return hipErrorInvalidValue;
+    if (want_short) {
+        if (n_lead <= 1 && n_tw <= 2) S2_LAUNCH(1, 2);
+        else if (n_lead <= 2 && n_tw <= 4) S2_LAUNCH(2, 4);
+        else return hipErrorInvalidValue;
+    }
 #undef S2_LAUNCH
+    if (want_long) {
+        FilterArgs b = a;
+        b.stream_n_lo = S2_MAX_LEN + 1; b.stream_n_hi = S2_LONG_MAX_LEN;
+        if (n_lead <= 1 && n_tw <= 2) hipLaunchKernelGGL((k_filter_stream2<1, 2, true, false, false, true>), dim3(grid), dim3(S2_WAVES * WAVE), lds, s, b);
+        else if (n_lead <= 2 && n_tw <= 4) hipLaunchKernelGGL((k_filter_stream2<2, 4, true, false, false, true>), dim3(grid), dim3(S2_WAVES * WAVE), lds, s, b);
+        else return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 
 int stream2_max_len() { return S2_MAX_LEN; }
+int stream2_long_max_len() {
+    const char* const el = getenv("CAH_NO_STREAM2_LONG");
+    return (el && *el && *el != '0') ? S2_MAX_LEN : S2_LONG_MAX_LEN;
+}
 bool stream2_class_ok(int n_lead, int n_tw) { return n_lead <= 2 && n_tw <= 4; }

@@ -6,11 +6,14 @@ cah_synth_reads; the CPU twin is oracle/host_workloads.py on top of oracle/synth
 C3's reads additionally carry the linked adapter's anchored 5' part: 80 % of the reads (chosen by an
 integer hash of the read index, identical in torch and numpy) start with 8 hash-derived bases followed by
 ACGTACGT, matching the adapter ``^NNNNNNNNACGTACGT...TRUSEQ``."""
+import os
 import random
 
 TRUSEQ_R1 = "AGATCGGAAGAGCACACGTCTGAACTCCAGTCA"      # reference doc/guide.rst:2053
 TRUSEQ_R2 = "AGATCGGAAGAGCGTCGTGTAGGGAAAGAGTGT"      # reference doc/guide.rst:2054
-READ_LEN = 150
+# 150 bp is what every BASELINE config is quoted on; bench.py --read-len sets CAH_BENCH_READ_LEN (inherited by the CPU
+# baseline's worker processes) for the other read lengths a sequencer emits (250 / 300 bp)
+READ_LEN = int(os.environ.get("CAH_BENCH_READ_LEN", "150"))
 GEN = {"p_adapter": 0.25, "p_edit": 0.02, "p_n": 0.005}
 C3_FRONT = "NNNNNNNNACGTACGT"
 

@@ -82,7 +82,10 @@ def test_stream_lengths_vs_oracle_and_per_lane_kernels(hip, orc):
     rng = random.Random(4242)
     ad = A.BackAdapter(TRUSEQ, max_errors=0.1, min_overlap=3)
     lengths = sorted({0, 1, 3, 4, 15, 16, 17, 31, 32, 33, 34, 36, 50, 63, 64, 65, 75, 100, 101, 110, 111, 112, 113,
-                      125, 127, 128, 129, 144, 145, 149, 150, 151, 152, 158, 159, 160, 161, 170})
+                      125, 127, 128, 129, 144, 145, 149, 150, 151, 152, 158, 159, 160, 161, 170,
+                      # the LONG form of the streaming prefilter (segments of 160 characters, up to 640), and beyond it
+                      162, 175, 176, 177, 192, 200, 239, 240, 241, 250, 251, 255, 256, 257, 300, 301, 319, 320, 321, 336,
+                      400, 479, 480, 481, 500, 639, 640, 641, 700})
     for n in lengths:
         count = rng.choice([1, 63, 64, 65, 300, 1024, 1025, 2500])
         reads = make_reads(rng, n, count, TRUSEQ)
@@ -211,10 +214,10 @@ def test_stream_survivor_queue_is_exactly_kmers_present(hip, orc):
     from cutadapt_amd import adapters as A
     from cutadapt_amd.batch import ReadBatch, match_batch
     rng = random.Random(31337)
-    cases = [(TRUSEQ, 0.1, 3, n) for n in (150, 151, 149, 100, 76, 36, 160, 81, 80, 17)]
+    cases = [(TRUSEQ, 0.1, 3, n) for n in (150, 151, 149, 100, 76, 36, 160, 81, 80, 17, 161, 250, 300, 321, 480, 640)]
     for _ in range(12):
         m = rng.choice([12, 20, 25, 33, 34, 40])
-        cases.append((rs(rng, m), rng.choice([0.0, 0.1, 0.2]), rng.randint(1, 6), rng.choice([150, 100, 50, 125])))
+        cases.append((rs(rng, m), rng.choice([0.0, 0.1, 0.2]), rng.randint(1, 6), rng.choice([150, 100, 50, 125, 250, 301])))
     for seq, rate, ov, n in cases:
         ad = A.BackAdapter(seq, max_errors=rate, min_overlap=ov)
         count = rng.choice([700, 1300, 9000])
