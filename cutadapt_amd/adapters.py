@@ -373,6 +373,22 @@ class SingleAdapter(Adapter, ABC):
         # match_to()/match_to_batch() are a single library call
         self._fused_plan = _lib.Plan([self.matcher_spec()])
 
+    # -- pickling: adapters travel to worker processes (reference runners.py:345-356 pickles the whole pipeline) ------
+    # The library handles (aligner, prefilter, fused plan) stay behind; the receiving process builds its own from the
+    # plain attributes, in its own HIP context.
+    _HANDLES = ("aligner", "kmer_finder", "_fused_plan")
+
+    def __getstate__(self):
+        return {k: v for k, v in self.__dict__.items() if k not in self._HANDLES}
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        self.aligner = self._aligner()
+        self.kmer_finder = self._kmer_finder()
+        if self._debug:
+            self.aligner.enable_debug()
+        self._fused_plan = _lib.Plan([self.matcher_spec()])
+
     # -- construction helpers ---------------------------------------------------------------
     def _make_aligner(self, sequence: str, flags: int) -> Aligner:
         indel_cost = 1 if self.indels else 100000
@@ -1024,6 +1040,9 @@ class IndexedSuffixAdapters(Matchable):
 class MultipleAdapters(Matchable):
     """Best match over several adapters: higher score wins, then fewer errors, then the
     adapter that comes first (reference adapters.py:1278-1285)."""
+
+    def __getstate__(self):
+        return dict(self.__dict__, _plan=None)               # (the fused plan is a library handle: rebuilt on first use)
 
     def __init__(self, adapters: Sequence[Matchable]):
         super().__init__(name="multiple_adapters")

@@ -841,7 +841,9 @@ def trim_fastq_gpu(source: Union[str, BinaryIO, np.ndarray], out: Union[str, Bin
                    nextseq_trim: Optional[int] = None, quality_cutoff: Optional[Tuple[int, int]] = None,
                    quality_base: int = 33, poly_a: bool = False, max_expected_errors: Optional[float] = None,
                    cut: Sequence[int] = (), length: Optional[int] = None, revcomp: bool = False,
-                   rc_suffix: Optional[str] = " rc", info_file: Union[None, str, BinaryIO] = None) -> Dict[str, object]:
+                   rc_suffix: Optional[str] = " rc", info_file: Union[None, str, BinaryIO] = None,
+                   feeder: str = "thread", _ranges=None, _deliver=None, _stub_device: bool = False,
+                   _repeat: int = 1) -> Dict[str, object]:
     """``cutadapt [-u N] [--nextseq-trim N] [-q [F,]B] <adapter options> [--times N] [--action A] [--revcomp]
     [--poly-a] [-l N] [--max-ee E] [-m N] [-M N] [--discard-(un)trimmed] [--info-file F] -o out in.fastq`` with the
     records indexed, matched, filtered and formatted on the GPU(s) (module docstring: which option sets take the
@@ -853,9 +855,27 @@ def trim_fastq_gpu(source: Union[str, BinaryIO, np.ndarray], out: Union[str, Bin
     ``assemble`` (all-device way): "device" formats the trimmed records on the GPU and brings the bytes back; "host"
     brings back only the record index and kept intervals and copies the records together on the worker's host core
     (same bytes; trades the outbound PCIe traffic for host memcpy); "mixed" lets every other worker do that.
+    ``feeder``: "thread" -- one process, a feeder (thread pool) per GPU; "process" -- one feeder PROCESS per GPU, the
+    shape of the reference's ParallelPipelineRunner (runners.py:275-412: a reader that deals chunks, N worker
+    processes, an ordered writer) without its pipes for bulk data: every process reads its own byte ranges of the input
+    file and writes its trimmed chunks straight into the output file at the offset the parent hands out once the sizes
+    of all earlier chunks are known (``_trim_fastq_gpu_processes``).  Input must be a plain file, output a path or None.
+    (``_ranges`` / ``_deliver`` / ``_stub_device`` are that mode's and the feeder-scaling measurement's internals:
+    explicit (index, offset, length, is_final) pieces, a callback that takes the finished chunks in order, and "do no
+    device work, hand the input back" -- profiles/scripts/r04_feeder_scaling.py.)
     Returns the reference's counters (report.py:62-80) + ``devices_used`` and ``per_device`` (chunks, bytes, input
     rate and busy fraction of every feeder)."""
     import torch
+    if feeder not in ("thread", "process"):
+        raise ValueError("feeder must be 'thread' or 'process'")
+    if feeder == "process":
+        return _trim_fastq_gpu_processes(source, out, dict(
+            adapters=adapters, discard_untrimmed=discard_untrimmed, discard_trimmed=discard_trimmed,
+            minimum_length=minimum_length, maximum_length=maximum_length, chunk_bytes=chunk_bytes, threads=threads,
+            assemble=assemble, times=times, action=action, index=index, nextseq_trim=nextseq_trim,
+            quality_cutoff=quality_cutoff, quality_base=quality_base, poly_a=poly_a,
+            max_expected_errors=max_expected_errors, cut=cut, length=length, revcomp=revcomp, rc_suffix=rc_suffix,
+            _stub_device=_stub_device), devices, info_file, _repeat)
     if assemble not in ("device", "host", "mixed", "mixed3"):
         raise ValueError("assemble must be 'device', 'host', 'mixed' or 'mixed3'")
     adapters = _adapter_list(adapters)
@@ -917,6 +937,8 @@ def trim_fastq_gpu(source: Union[str, BinaryIO, np.ndarray], out: Union[str, Bin
         return w
 
     ranged = _is_plain_file(source)
+    # (stub mode: a worker's staging buffer is reused by its next chunk -- the echo is copied when somebody will read it)
+    sink_wants_copy = out is not None or (_deliver is not None and getattr(_deliver, "reads_body", True))
     fd = os.open(source, os.O_RDONLY) if ranged else None
     from_pool = not ranged and not isinstance(source, (np.ndarray, torch.Tensor))
     want_info = info_file is not None
@@ -924,6 +946,13 @@ def trim_fastq_gpu(source: Union[str, BinaryIO, np.ndarray], out: Union[str, Bin
     def work(w: _Worker, item, is_final):
         data = w.read_range(fd, item[0], item[1]) if ranged else item
         try:
+            if _stub_device:
+                # measurement only: the host side of a feeder (range read into pinned memory, hand-over, ordered sink)
+                # without any device work -- the input comes back as the "output"
+                w.chunks += 1
+                w.bytes_in += int(len(data))
+                body = bytes(memoryview(data.numpy() if hasattr(data, "numpy") else data)) if sink_wants_copy else memoryview(data.numpy() if hasattr(data, "numpy") else data)
+                return body, [], None, w
             if all_device:
                 buf, total = w.run(data, is_final)
                 return (memoryview(buf.numpy())[:total] if buf is not None else b""), ([buf] if buf is not None else []), None, w
@@ -947,19 +976,30 @@ def trim_fastq_gpu(source: Union[str, BinaryIO, np.ndarray], out: Union[str, Bin
         def drain(limit: int) -> None:
             nonlocal bytes_out
             while len(pending) > limit:
-                body, bufs, info, w = pending.popleft().result()
+                chunk_index, fut = pending.popleft()
+                body, bufs, info, w = fut.result()
                 bytes_out += len(body)
-                if sink is not None and len(body):
+                if _deliver is not None:
+                    _deliver(chunk_index, body)             # (process mode: the chunk goes where the parent says)
+                elif sink is not None and len(body):
                     sink.write(body)                        # straight from the pinned buffer
                 if inf is not None and info:
                     inf.write(info)
                 body = None
                 for b in bufs:
                     w.pool.put(b)
-        items = _file_ranges(source, chunk_bytes) if ranged else _chunks(source, chunk_bytes)
-        for i, it in enumerate(items):
-            item, is_final = ((it[0], it[1]), it[2]) if ranged else it
-            pending.append(feeders[i % len(feeders)].submit(work, item, is_final))
+        if _ranges is not None:
+            if not ranged:
+                raise ValueError("explicit ranges need a plain input file")
+            items = ((idx, ((off, ln), fin)) for idx, off, ln, fin in _ranges)
+        elif ranged:
+            base_ranges = list(_file_ranges(source, chunk_bytes))
+            # (_repeat: measurement only -- the file's pieces over and over, for runs long enough to show a steady rate)
+            items = ((i, ((it[0], it[1]), it[2])) for i, it in enumerate(base_ranges * max(1, int(_repeat))))
+        else:
+            items = enumerate(_chunks(source, chunk_bytes))
+        for i, (chunk_index, (item, is_final)) in enumerate(items):
+            pending.append((chunk_index, feeders[i % len(feeders)].submit(work, item, is_final)))
             drain(2 * threads * len(feeders))
         drain(0)
     finally:
@@ -975,7 +1015,12 @@ def trim_fastq_gpu(source: Union[str, BinaryIO, np.ndarray], out: Union[str, Bin
     workers = [w for f in feeders for w in f.workers if w is not None]
     result: Dict[str, object] = {"bytes_out": int(bytes_out), "per_device": _per_device(feeders, wall),
                                  "devices_used": sorted({str(w.device) for w in workers}),
-                                 "way": "all-device" if all_device else "general"}
+                                 "way": "all-device" if all_device else "general", "wall_s": wall}
+    if _stub_device:
+        for w in workers:
+            _give_back(w)
+        result["way"] = "stub (no device work)"
+        return result
     if all_device:
         stats = np.zeros(8, dtype=np.int64)
         removed = np.zeros(2, dtype=np.int64)
@@ -1009,6 +1054,134 @@ def trim_fastq_gpu(source: Union[str, BinaryIO, np.ndarray], out: Union[str, Bin
         w.trimmer = None
         _give_back(w)
     return result
+
+
+_NUMERIC_RESULT_KEYS = ("reads", "with_adapters", "bp_in", "bp_out", "too_many_expected_errors", "nextseq_trimmed_bases",
+                        "quality_trimmed_bases", "bytes_out")
+
+
+def _process_feeder_main(conn, source, out_path, device_index, rank, options, ranges):
+    """One feeder process of ``trim_fastq_gpu(feeder="process")``: its own interpreter, its own HIP context on its GPU,
+    the thread-mode pipeline over ITS pieces of the input file; a finished chunk is written at the offset the parent
+    sends back for it."""
+    try:
+        import torch
+        torch.cuda.set_device(device_index)
+        out_fd = os.open(out_path, os.O_WRONLY) if out_path is not None else None
+
+        def deliver(index, body):
+            conn.send(("size", index, len(body)))
+            if out_fd is not None:
+                tag, idx, offset = conn.recv()
+                assert tag == "offset" and idx == index
+                view, done = memoryview(body), 0
+                while done < len(view):
+                    done += os.pwrite(out_fd, view[done:], offset + done)
+        deliver.reads_body = out_fd is not None              # (without a sink only the size of a chunk is looked at)
+        try:
+            res = trim_fastq_gpu(source, None, devices=[device_index], _ranges=ranges, _deliver=deliver, **options)
+        finally:
+            if out_fd is not None:
+                os.close(out_fd)
+        slim = {k: res[k] for k in _NUMERIC_RESULT_KEYS if k in res}
+        for k in ("filtered", "poly_a_trimmed_lengths", "per_device", "devices_used", "way", "wall_s"):
+            if k in res:
+                slim[k] = res[k]
+        conn.send(("done", rank, slim))
+    except BaseException as exc:                             # the parent must hear about it, whatever it was
+        import traceback
+        try:
+            conn.send(("error", rank, f"{type(exc).__name__}: {exc}\n{traceback.format_exc()[-1500:]}"))
+        except Exception:
+            pass
+    finally:
+        conn.close()
+
+
+def _trim_fastq_gpu_processes(source, out, options: dict, devices, info_file, repeat: int = 1) -> Dict[str, object]:
+    """``trim_fastq_gpu(feeder="process")``: the parent cuts the file into record-aligned pieces (only 1 MiB windows are
+    read here), deals them round-robin to one process per GPU and plays the ordered writer WITHOUT touching the data:
+    a process reports the size of a finished chunk, the parent answers with the chunk's offset in the output as soon as
+    all earlier sizes are known (reference runners.py:224-245, OrderedChunkWriter), the process writes it there itself."""
+    import multiprocessing as mp
+    from multiprocessing.connection import wait
+    if info_file is not None:
+        raise ValueError("feeder='process' does not write info files (use feeder='thread')")
+    if not _is_plain_file(source):
+        raise ValueError("feeder='process' needs a plain (uncompressed) input file: every process reads its own byte ranges")
+    if out is not None and not isinstance(out, (str, os.PathLike)):
+        raise ValueError("feeder='process' writes to a path (or to nothing): the processes write their chunks themselves")
+    devs = _resolve_devices(devices)
+    n = len(devs)
+    t0 = time.perf_counter()
+    ranges = [(i, off, ln, fin) for i, (off, ln, fin) in
+              enumerate(list(_file_ranges(source, options["chunk_bytes"])) * max(1, int(repeat)))]
+    if out is not None:
+        with open(out, "wb"):
+            pass                                             # created / truncated here, opened for pwrite by every process
+    ctx = mp.get_context("spawn")                            # (a forked child cannot use the parent's HIP context)
+    conns, procs = [], []
+    for rank, dev in enumerate(devs):
+        pc, cc = ctx.Pipe()
+        p = ctx.Process(target=_process_feeder_main,
+                        args=(cc, str(source), None if out is None else str(out), dev.index if dev.index is not None else 0,
+                              rank, options, ranges[rank::n]), daemon=True)
+        p.start()
+        cc.close()
+        conns.append(pc)
+        procs.append(p)
+    sizes: Dict[int, int] = {}
+    results: Dict[int, dict] = {}
+    expected, next_offset, error = 0, 0, None
+    live = {c: r for r, c in enumerate(conns)}
+    try:
+        while live and error is None:
+            for c in wait(list(live)):
+                try:
+                    msg = c.recv()
+                except EOFError:
+                    if live[c] not in results:
+                        error = f"feeder process {live[c]} ended without a result"
+                    del live[c]
+                    continue
+                if msg[0] == "size":
+                    sizes[msg[1]] = msg[2]
+                    while expected in sizes:
+                        if out is not None:
+                            conns[expected % n].send(("offset", expected, next_offset))
+                        next_offset += sizes.pop(expected)
+                        expected += 1
+                elif msg[0] == "done":
+                    results[msg[1]] = msg[2]
+                    del live[c]
+                else:
+                    error = f"feeder process {msg[1]}: {msg[2]}"
+    finally:
+        for p in procs:
+            p.join(timeout=30 if error is None else 1)
+            if p.is_alive():
+                p.kill()
+    if error is not None:
+        raise RuntimeError(error)
+    if expected != len(ranges):
+        raise RuntimeError(f"only {expected} of {len(ranges)} chunks were delivered")
+    wall = time.perf_counter() - t0
+    total: Dict[str, object] = {k: sum(int(r.get(k, 0)) for r in results.values()) for k in _NUMERIC_RESULT_KEYS}
+    filtered: Dict[str, int] = {}
+    polya: Dict[int, int] = {}
+    per_device: Dict[str, dict] = {}
+    for rank, r in sorted(results.items()):
+        for k, v in (r.get("filtered") or {}).items():
+            filtered[k] = filtered.get(k, 0) + int(v)
+        for k, v in (r.get("poly_a_trimmed_lengths") or {}).items():
+            polya[int(k)] = polya.get(int(k), 0) + int(v)
+        for k, v in (r.get("per_device") or {}).items():
+            per_device[f"{k} (process {rank})"] = v
+    total.update({"filtered": filtered, "poly_a_trimmed_lengths": polya, "per_device": per_device,
+                  "devices_used": sorted({d for r in results.values() for d in r.get("devices_used", [])}),
+                  "way": next(iter(results.values()))["way"] + ", one feeder process per GPU" if results else "process",
+                  "feeder_processes": n, "wall_s": wall})
+    return total
 
 
 class _LineFeedIndex:

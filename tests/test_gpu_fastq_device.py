@@ -149,3 +149,38 @@ def test_device_fastq_reference_goldens(hip):
             assert out.getvalue() == expected, (case["name"], chunk)
         done += 1
     assert done >= 5, done
+
+
+def test_feeder_processes_write_the_same_bytes_as_feeder_threads(hip, tmp_path):
+    """trim_fastq_gpu(feeder="process") -- one feeder process per GPU, each reading its own byte ranges and writing its
+    chunks at the offsets the parent hands out (reference runners.py:275-412: reader, N worker processes, ordered
+    writer) -- against the one-process thread mode: the same output file byte for byte, the same counters.  (Two and
+    three processes on the one device of the test box; small chunks: many hand-overs.)"""
+    from cutadapt_amd.adapters import BackAdapter, FrontAdapter
+    from cutadapt_amd.gpu_pipeline import trim_fastq_gpu
+    rng = random.Random(404)
+    ads = ["AGATCGGAAGAGCACACGTCTGAACTCCAGTCA", "GCCGAACTTCTTAGACTGCCTTAAGGACGT"]
+    src = tmp_path / "in.fastq"
+    src.write_bytes(_fastq(rng, 40_000, ads))
+    cases = [
+        (dict(adapters=[BackAdapter(ads[0], max_errors=0.1, min_overlap=3)], minimum_length=20), "all-device"),
+        (dict(adapters=[BackAdapter(a, max_errors=0.1, min_overlap=3) for a in ads], times=2, quality_cutoff=(0, 20),
+              discard_untrimmed=True), "all-device"),
+        (dict(adapters=[FrontAdapter(ads[1][:12], max_errors=0.1)], action="mask"), "general"),
+    ]
+    for k, (opts, way) in enumerate(cases):
+        for n_proc in (2, 3):
+            a, b = tmp_path / f"thread{k}.fastq", tmp_path / f"process{k}_{n_proc}.fastq"
+            ra = trim_fastq_gpu(str(src), str(a), chunk_bytes=1 << 20, threads=2, devices=[0], **opts)
+            rb = trim_fastq_gpu(str(src), str(b), chunk_bytes=1 << 20, threads=2, devices=[0] * n_proc, feeder="process", **opts)
+            assert ra["way"] == way and rb["way"].startswith(way), (ra["way"], rb["way"])
+            assert a.read_bytes() == b.read_bytes(), (k, n_proc)
+            for key in ("reads", "with_adapters", "bp_in", "bp_out", "bytes_out", "too_many_expected_errors"):
+                assert ra[key] == rb[key], (k, n_proc, key, ra[key], rb[key])
+            assert dict(ra["filtered"]) == dict(rb["filtered"]), (k, n_proc)
+            assert rb["feeder_processes"] == n_proc
+    # no sink: the sizes still add up
+    r = trim_fastq_gpu(str(src), None, chunk_bytes=1 << 20, threads=2, devices=[0, 0], feeder="process", **cases[0][0])
+    assert r["bytes_out"] == os.path.getsize(tmp_path / "thread0.fastq")
+    with pytest.raises(ValueError):
+        trim_fastq_gpu(io.BytesIO(src.read_bytes()), None, feeder="process", **cases[0][0])
