@@ -275,7 +275,8 @@ __global__ __launch_bounds__(256) void k_trim_decide(const int32_t* out6, const 
                                                      int64_t n, const uint8_t* adapter_kind,
                                                      int32_t min_len, int32_t max_len, int32_t discard_trimmed,
                                                      int32_t discard_untrimmed, int32_t* beg, int32_t* end, uint8_t* keep,
-                                                     unsigned long long* counters, const int32_t count_out = 1) {
+                                                     unsigned long long* counters, const int32_t count_out = 1,
+                                                     const int32_t action = 0) {
     __shared__ unsigned long long s_acc[7];
     if (threadIdx.x < 7) s_acc[threadIdx.x] = 0;
     __syncthreads();
@@ -291,7 +292,12 @@ __global__ __launch_bounds__(256) void k_trim_decide(const int32_t* out6, const 
             const uint8_t kind = adapter_kind[ad < 0 ? 0 : ad];       // 0: 3' (remove after), 1: 5' (remove before), 2: anywhere
             const int rstart = out6[r * 6 + 2], rstop = out6[r * 6 + 3];
             const bool before = kind == 1 || (kind == 2 && rstart == 0);
-            if (before) b = rstop; else e = rstart;
+            // what the read keeps (reference modifiers.py:170-198, :225-251; Match.trimmed / retained_adapter_interval,
+            // adapters.py:446-487): trim -- everything on the far side of the adapter; none -- everything; retain --
+            // the same side INCLUDING the adapter; crop -- the adapter alone
+            if (action == CAH_ACTION_TRIM) { if (before) b = rstop; else e = rstart; }
+            else if (action == CAH_ACTION_RETAIN) { if (before) b = rstart; else e = rstop; }
+            else if (action == CAH_ACTION_CROP) { b = rstart; e = rstop; }
         }
         const int out_len = e - b;
         bool k = true;
@@ -416,6 +422,14 @@ int cah_fastq_index_device(const uint8_t* d_buf, int64_t len, int64_t n_newlines
     return CAH_OK;
 }
 
+// ... with --action none / retain / crop (one round of matching; cah_trim_decide_window_device is action trim)
+int cah_trim_decide_action_device(const int32_t* d_out6, const uint8_t* d_status, const int32_t* d_best_adapter,
+                                  const int32_t* d_win_beg, const int32_t* d_win_len, const int32_t* d_seq_len,
+                                  int64_t n_reads, const uint8_t* d_adapter_kind, int32_t action, int32_t min_len,
+                                  int32_t max_len, int32_t discard_trimmed, int32_t discard_untrimmed,
+                                  int32_t intervals_only, int32_t* d_beg, int32_t* d_end, uint8_t* d_keep,
+                                  uint64_t* d_counters, void* stream);
+
 // Step 3b: kept interval and keep flag of every read from the match results (see k_trim_decide).  adapter_kind[a]:
 // 0 = 3' adapter, 1 = 5' adapter, 2 = anywhere; min_len / max_len < 0: no limit.  d_counters: uint64[8], accumulated
 // (NOT reset) -- reads, with adapters, bp in, bp out, too short, too long, invalid reads.
@@ -446,6 +460,18 @@ int cah_trim_decide_window_device(const int32_t* d_out6, const uint8_t* d_status
                                   int64_t n_reads, const uint8_t* d_adapter_kind, int32_t min_len, int32_t max_len,
                                   int32_t discard_trimmed, int32_t discard_untrimmed, int32_t intervals_only,
                                   int32_t* d_beg, int32_t* d_end, uint8_t* d_keep, uint64_t* d_counters, void* stream) {
+    return cah_trim_decide_action_device(d_out6, d_status, d_best_adapter, d_win_beg, d_win_len, d_seq_len, n_reads,
+                                         d_adapter_kind, CAH_ACTION_TRIM, min_len, max_len, discard_trimmed, discard_untrimmed,
+                                         intervals_only, d_beg, d_end, d_keep, d_counters, stream);
+}
+
+int cah_trim_decide_action_device(const int32_t* d_out6, const uint8_t* d_status, const int32_t* d_best_adapter,
+                                  const int32_t* d_win_beg, const int32_t* d_win_len, const int32_t* d_seq_len,
+                                  int64_t n_reads, const uint8_t* d_adapter_kind, int32_t action, int32_t min_len,
+                                  int32_t max_len, int32_t discard_trimmed, int32_t discard_untrimmed,
+                                  int32_t intervals_only, int32_t* d_beg, int32_t* d_end, uint8_t* d_keep,
+                                  uint64_t* d_counters, void* stream) {
+    if (action < CAH_ACTION_TRIM || action > CAH_ACTION_CROP) return cah_set_error_(CAH_EINVAL, "cah_trim_decide_action_device: unknown action");
     if (n_reads < 0) return cah_set_error_(CAH_EINVAL, "cah_trim_decide_window_device: bad argument");
     if (n_reads == 0) return CAH_OK;
     if (!d_out6 || !d_status || !d_win_len || !d_seq_len || !d_adapter_kind || !d_beg || !d_end || !d_keep || !d_counters)
@@ -455,7 +481,7 @@ int cah_trim_decide_window_device(const int32_t* d_out6, const uint8_t* d_status
     hipLaunchKernelGGL(k_trim_decide, dim3((unsigned)(rb < 4 * cus() ? rb : 4 * cus())), dim3(256), 0, (hipStream_t)stream, d_out6,
                        d_status, d_best_adapter, d_win_len, d_win_beg, d_seq_len, n_reads, d_adapter_kind, min_len, max_len,
                        discard_trimmed, discard_untrimmed, d_beg, d_end, d_keep, (unsigned long long*)d_counters,
-                       intervals_only ? 0 : 1);
+                       intervals_only ? 0 : 1, action);
     GPU_TRY(hipGetLastError());
     return CAH_OK;
 }

@@ -11,12 +11,14 @@ visible GPUs -- and writes the results back in chunk order: the reference's read
 writer layout (reference src/cutadapt/runners.py:96-245) with GPUs as the workers.
 
 Two ways through a chunk once it is indexed:
-  * the all-device way (any number of single, non-rightmost adapters with ``--times N``, or one linked adapter; action ``trim``,
+  * the all-device way (any number of single, non-rightmost adapters with ``--times N``, or one linked adapter; action ``trim``
+    -- or, with one round of single adapters, ``none`` / ``retain`` / ``crop``: other intervals from the same matches --;
+    no adapter at all: the other modifiers and the filters alone;
     ``-u`` / ``--nextseq-trim`` / ``-q`` in front of the adapter step, ``--poly-a`` / ``-l`` / ``--max-ee`` / ``-m`` /
     ``-M`` / ``--discard-(un)trimmed`` behind it -- the usual ``cutadapt -q 20 -a ADAPTER -m 20`` and more): trim,
     match, decide and format without a byte of per-read data touching the host (``cah_trim_decide_device`` /
-    ``cah_trim_decide_window_device`` / ``cah_trim_filter_device``);
-  * the general way (everything else ``pipeline.BatchTrimmer`` does: every action, rightmost adapters, linked ones among others,
+    ``cah_trim_decide_window_device`` / ``cah_trim_decide_action_device`` / ``cah_trim_filter_device``);
+  * the general way (everything else ``pipeline.BatchTrimmer`` does: ``mask`` / ``lowercase``, rightmost adapters, linked ones among others,
     ``--revcomp``, ``--info-file``, ``--pair-adapters``, adapter sets regrouped behind an ``AdapterIndex``): the
     modifiers run as kernels on windows into the raw chunk in HBM (``DeviceFastqChunk``: reads AND qualities are used in place), the window arithmetic between them is
     numpy on 4-byte-per-read arrays, and plain slicing is formatted on the device again.  What cannot be expressed
@@ -28,6 +30,10 @@ in place), through the same trimmer.
 Feeding: one feeder per GPU -- ``threads`` worker threads with a HIP stream each, pinned staging and output
 buffers allocated while that GPU is current (HIP places them on the NUMA node next to it) and, when several GPUs are
 fed, pinned to the CPUs of that node.  Chunks are dealt round-robin over the feeders and written in chunk order.
+``feeder="process"`` makes every feeder a process of its own (own interpreter, own HIP context: the reference's
+ParallelPipelineRunner shape): each reads its own byte ranges of the input file and writes its chunks into the output
+file at the offsets the parent hands out (``_trim_fastq_gpu_processes``); ``profiles/r04/feeder_scaling.json`` has what
+either shape moves on one box.
 For a plain file the dealer only looks for record starts around the nominal cut points (1 MiB windows); the bytes
 themselves are read by the feeders (``preadv`` straight into their pinned buffers), so no single thread touches
 all the data.
@@ -348,8 +354,18 @@ class _Worker:
         rounds = int(self.opts.get("times", 1)) if (self.plan is not None and not linked) else 1
         final_here = limits is not None and not post and rounds == 1 and not linked
         lim = limits if final_here else (-1, -1, 0, 0)
+        action = int(self.opts.get("action", 0))
         if linked:
             pass                                             # (intervals and status are in place)
+        elif action != 0:
+            # --action none / retain / crop: other intervals from the same match results (one round)
+            wl = wlen.contiguous()
+            _lib.check(L.cah_trim_decide_action_device(
+                self.res.out6.data_ptr(), self.res.status.data_ptr(), self.res.best_adapter.data_ptr(),
+                wbeg.data_ptr() if wbeg is not None else None, wl.data_ptr(), self.seq_len.data_ptr(), n,
+                self.kinds.data_ptr(), action, *lim, 0 if final_here else 1,
+                self.beg.data_ptr(), self.end.data_ptr(), self.keep.data_ptr(), self.counters.data_ptr(), sp))
+            keepalive.append(wl)
         elif not pre and final_here:
             _lib.check(L.cah_trim_decide_device(
                 self.res.out6.data_ptr(), self.res.status.data_ptr(), self.res.best_adapter.data_ptr(),
@@ -904,8 +920,14 @@ def trim_fastq_gpu(source: Union[str, BinaryIO, np.ndarray], out: Union[str, Bin
         raise ValueError("You cannot remove bases from more than two ends.")
     if len(cut) == 2 and cut[0] * cut[1] > 0:
         raise ValueError("You cannot remove bases from the same end twice.")
-    all_device = (adapters and action == "trim" and not revcomp and info_file is None
-                  and _all_device_adapters(adapters, int(times), index))
+    # the all-device way: action trim with any number of rounds, or -- one round, single adapters -- the actions that only
+    # move the kept interval (none / retain / crop); no adapters at all (-q / --nextseq-trim / --poly-a / -l / --max-ee / -m
+    # alone) is the same way with an empty adapter step
+    act = {"trim": 0, None: 1, "none": 1, "retain": 2, "crop": 3}.get(action, -1)
+    single_round_action = act > 0 and int(times) == 1 and bool(adapters) and not any(isinstance(a, LinkedAdapter) for a in adapters)
+    all_device = (not revcomp and info_file is None and
+                  ((not adapters and action in ("trim", None, "none", "retain", "crop", "mask", "lowercase")) or
+                   (bool(adapters) and (act == 0 or single_round_action) and _all_device_adapters(adapters, int(times), index))))
     pre = post = None
     if all_device and (cut or nextseq_trim is not None or quality_cutoff is not None):
         pre = {"cut": cut, "nextseq_trim": nextseq_trim, "quality_cutoff": quality_cutoff, "quality_base": quality_base}
@@ -915,10 +937,10 @@ def trim_fastq_gpu(source: Union[str, BinaryIO, np.ndarray], out: Union[str, Bin
     threads = max(1, int(threads))
     opts = {"discard_untrimmed": discard_untrimmed, "discard_trimmed": discard_trimmed,
             "minimum_length": minimum_length, "maximum_length": maximum_length, "assemble": assemble, "pre": pre, "post": post,
-            "times": int(times)}
+            "times": int(times), "action": max(act, 0) if adapters else 0}
     from .pipeline import BatchTrimmer
     if all_device:
-        plan, kinds = _plan_for(adapters)
+        plan, kinds = _plan_for(adapters) if adapters else (None, [0])
     else:
         plan, kinds = None, []
         BatchTrimmer(adapters, device=devices[0], **general_opts)       # option errors surface here, not in a worker

@@ -392,6 +392,19 @@ int cah_trim_decide_window_device(const int32_t *d_out6, const uint8_t *d_status
                                   int32_t max_len, int32_t discard_trimmed, int32_t discard_untrimmed,
                                   int32_t intervals_only, int32_t *d_beg, int32_t *d_end, uint8_t *d_keep,
                                   uint64_t *d_counters, void *stream);
+/* ... with the adapter step's other actions that only move the kept interval (reference modifiers.py:170-198, :225-251,
+ * one round of matching): none -- the read is kept whole (the match still counts), retain -- the read is trimmed but keeps
+ * the adapter (Match.retained_adapter_interval, adapters.py:446-447, :479-480), crop -- only the adapter is kept. */
+#define CAH_ACTION_TRIM 0
+#define CAH_ACTION_NONE 1
+#define CAH_ACTION_RETAIN 2
+#define CAH_ACTION_CROP 3
+int cah_trim_decide_action_device(const int32_t *d_out6, const uint8_t *d_status, const int32_t *d_best_adapter,
+                                  const int32_t *d_win_beg, const int32_t *d_win_len, const int32_t *d_seq_len,
+                                  int64_t n_reads, const uint8_t *d_adapter_kind, int32_t action, int32_t min_len,
+                                  int32_t max_len, int32_t discard_trimmed, int32_t discard_untrimmed,
+                                  int32_t intervals_only, int32_t *d_beg, int32_t *d_end, uint8_t *d_keep,
+                                  uint64_t *d_counters, void *stream);
 /* ... and when modifiers run BEHIND the adapter step as well (--poly-a, -l; cli.py:956-973) or --max-ee is given: call
  * cah_trim_decide*_device without limits (min_len = max_len = -1, no discards), move d_beg / d_end with the later
  * modifiers, then let this apply the filters in the reference's order (too short, too long, too many expected

@@ -81,11 +81,21 @@ def test_device_fastq_equals_host_pipeline(hip):
         ([A.LinkedAdapter(A.FrontAdapter(ad_seqs[2]), A.BackAdapter(ad_seqs[0]), False, True, "l3")],
          {"quality_cutoff": (5, 15), "poly_a": True, "maximum_length": 100}),
         ([A.LinkedAdapter(A.FrontAdapter(ad_seqs[2]), A.SuffixAdapter(ad_seqs[1]), False, False, "l4")], {"cut": [1], "length": 50}),
+        # --action none / retain / crop (one round): other intervals from the same matches (round 4)
+        ([A.BackAdapter(ad_seqs[0]), A.FrontAdapter(ad_seqs[1]), A.AnywhereAdapter(ad_seqs[2])], {"action": None, "discard_untrimmed": True}),
+        ([A.BackAdapter(ad_seqs[0]), A.FrontAdapter(ad_seqs[1]), A.AnywhereAdapter(ad_seqs[2])], {"action": "retain", "minimum_length": 12}),
+        ([A.FrontAdapter(ad_seqs[1]), A.BackAdapter(ad_seqs[0])], {"action": "crop", "quality_cutoff": (0, 15), "discard_untrimmed": True}),
+        ([A.AnywhereAdapter(ad_seqs[2]), A.SuffixAdapter(ad_seqs[1])], {"action": "retain", "cut": [2, -1], "poly_a": True, "length": 90}),
+        ([A.BackAdapter(ad_seqs[0])], {"action": "crop", "max_expected_errors": 3.0, "maximum_length": 40}),
+        # no adapter at all: the modifiers and filters alone, still on the device
+        ([], {"quality_cutoff": (10, 20), "minimum_length": 30}),
+        ([], {"nextseq_trim": 20, "poly_a": True, "length": 100, "max_expected_errors": 2.0}),
+        ([], {"cut": [4, -3], "maximum_length": 150}),
     ]
     for ci, (ads, opts) in enumerate(cases):
         for crlf, final_nl, chunk in ((False, True, 1 << 20), (True, True, 4096), (False, False, 700)):
             data = _fastq(rng, 3000, ad_seqs, crlf=crlf, final_newline=final_nl, lower=ci == 1, twice="times" in opts,
-                          lead=ad_seqs[2] if isinstance(ads[0], A.LinkedAdapter) else None)
+                          lead=ad_seqs[2] if (ads and isinstance(ads[0], A.LinkedAdapter)) else None)
             want = io.BytesIO()
             ws = trim_fastq(io.BytesIO(data), want, ads, index=False, **opts)
             for source, assemble in ((io.BytesIO(data), "device"), (np.frombuffer(data, dtype=np.uint8), "device"),
