@@ -1016,6 +1016,7 @@ int cah_profile_read(double ms[CAH_PROF_N], int64_t launches[CAH_PROF_N], int64_
         float t = 0;
         HIP_TRY(hipEventElapsedTime(&t, r.a, r.b));
         ms[r.family] += t;
+        if (r.units < 0) continue;                   // a further round of the same pass over the same units
         launches[r.family] += 1;
         units[r.family] += r.units;
     }
@@ -1040,6 +1041,8 @@ static const size_t WS_DPBACK = 896 / sizeof(unsigned long long);
 // the streaming multi-adapter form's second work list (Multi2RescanArgs): entries, overflow, the two work counters
 static const size_t WS_M2_CNT2 = 320 / sizeof(unsigned long long), WS_M2_OVER = 384 / sizeof(unsigned long long);
 static const size_t WS_M2_WORK2 = 448 / sizeof(unsigned long long), WS_M2_DPWORK2 = 576 / sizeof(unsigned long long);
+// ... and its tile counter, which lives through the rounds of a batch (the rounds clear the header in front of it)
+static const size_t WS_M2_TILE = 960 / sizeof(unsigned long long);
 static const size_t WS_RETRYCOUNT = 576 / sizeof(unsigned long long), WS_RETRYWORK = 704 / sizeof(unsigned long long);
 static int64_t ws_retry_cap(int64_t n_reads) { return n_reads / 8 + 1024; }
 
@@ -1058,20 +1061,29 @@ size_t cah_workspace_bytes(int64_t n_reads) {
 // whose duration is that of its slowest wave, ~0.45 ms, however few pairs it has -- at 256 M pairs a 100 M-read batch
 // of 96 adapters paid that 36 times, 16 of its 114 ms); larger batches are processed in chunks of
 // cap / n_adapters reads.
-static int64_t m2_slack_pages(int64_t n_reads) {
-    const int64_t tiles = (n_reads + 1023) / 1024;                 // (multi2.hip: M2_TILE)
-    return (tiles < 256 ? (tiles < 1 ? 1 : tiles) : 256) * 16 * CAH_M2_PAIR_CLASSES;
+// The streaming form's pool (multi2.h: pages of CAH_M2_PAGE pairs, one class each).  A closed page may lack up to 63
+// pairs; every wave of a block holds one open page per class; a block has at most three tiles in flight (its waves may
+// straddle two, the third is drawn ahead).
+static int64_t m2_pages_per_tile(int64_t A) { return (1024 * A + (CAH_M2_PAGE - 64)) / (CAH_M2_PAGE - 63); }   // (multi2.hip: M2_TILE)
+static int64_t m2_block_reserve(int64_t A) { return 3 * m2_pages_per_tile(A) + 16 * CAH_M2_PAIR_CLASSES; }
+static int64_t m2_pages_worst(int64_t A, int64_t n_reads) {
+    const int64_t tiles = (n_reads + 1023) / 1024;
+    return tiles * m2_pages_per_tile(A) + std::min<int64_t>(std::max<int64_t>(tiles, 1), 512) * 16 * CAH_M2_PAIR_CLASSES + 2;
 }
+// pairs the scratch has room for: what the batch can produce in the worst case (every adapter on every read), bounded
+// by CAH_MULTI_PAIR_CAP (default 2 G pairs = 40 GB of scratch on a 288 GB device).  The fused form handles larger
+// batches in chunks of cap / n_adapters reads; the streaming form in ROUNDS that end when the pool runs low (a typical
+// batch of 100 M reads x 96 adapters has 0.45 G pairs and takes one).
 static int64_t multi_pair_cap(const cah_plan* plan, int64_t n_reads) {
     int64_t limit = 2048ll << 20;
     if (const char* e = getenv("CAH_MULTI_PAIR_CAP")) { const long long v = atoll(e); if (v > 0) limit = v; }
     const int64_t A = (int64_t)plan->matchers.size();
     if (limit < A) limit = A;
-    const int64_t worst = n_reads * A;
-    const int64_t cap = worst < limit ? worst : limit;
-    // the streaming form hands pairs out in pages (multi2.h): a closed page may lack up to 63 pairs, and every wave of
-    // the prefilter may hold one open page per class
-    return cap + cap / 15 + (m2_slack_pages(n_reads) + 2) * CAH_M2_PAGE;
+    // (one block of the streaming prefilter must always be able to run)
+    const int64_t floor_pages = 2 * m2_block_reserve(A) + 2 * m2_pages_per_tile(A);
+    const int64_t pages = std::min(m2_pages_worst(A, n_reads), std::max(limit / CAH_M2_PAGE, floor_pages));
+    // (a page header word per page lives behind the pages, inside the pair area)
+    return std::max(std::min(n_reads * A, limit), pages * CAH_M2_PAGE + pages / 2 + 2);
 }
 // the second work list of the streaming form (Multi2RescanArgs): a quarter of the pair capacity (what does not fit stays
 // in the first list)
@@ -1088,7 +1100,8 @@ size_t cah_plan_workspace_bytes(const cah_plan* plan, int64_t n_reads) {
     if (n_reads < 0) n_reads = 0;
     size_t need = cah_workspace_bytes(n_reads);
     if (plan && plan->multi.hdr.ok)
-        need += ws_key_bytes(n_reads) + (size_t)multi_pair_cap(plan, n_reads) * 20 + (size_t)multi_rescan_cap(multi_pair_cap(plan, n_reads)) * 12 + 256;
+        need += ws_key_bytes(n_reads) + (size_t)multi_pair_cap(plan, n_reads) * 20 + (size_t)multi_rescan_cap(multi_pair_cap(plan, n_reads)) * 12 +
+                ws_keys_bytes(n_reads) + 256;
     if (plan && plan->max_long_m > 0) need += long_scratch_bytes(plan, long_scratch_lanes(n_reads, 256)) + 256;
     return need;
 }
@@ -1436,7 +1449,8 @@ static int match_batch_multi(const cah_plan* plan, const PlanDeviceCopy* pd, con
     int32_t* d_win = (int32_t*)extra;                                extra += (size_t)cap * 8;
     const int64_t cap2 = multi_rescan_cap(cap);
     int32_t* d_dpq2 = (int32_t*)extra;                               extra += (size_t)cap2 * 4;
-    int32_t* d_win2 = (int32_t*)extra;
+    int32_t* d_win2 = (int32_t*)extra;                               extra += (size_t)cap2 * 8;
+    uint8_t* d_wmeta = (uint8_t*)extra;                              // (streaming form: a byte per read, multi2.h)
     unsigned long long* counters = ws.counters;
     const CahMatcher& m0 = plan->matchers[0];
     HIP_TRY(hipMemsetAsync(d_best_key, 0, sizeof(unsigned long long) * (size_t)n_reads, s));
@@ -1446,11 +1460,27 @@ static int match_batch_multi(const cah_plan* plan, const PlanDeviceCopy* pd, con
         // the pool: pages of CAH_M2_PAGE pairs + one header word each, inside the pair area
         const int64_t max_pages = ((int64_t)cap * 8) / (CAH_M2_PAGE * 8 + 4);
         uint32_t* d_page_hdr = (uint32_t*)(d_pairs + max_pages * CAH_M2_PAGE);
-        const int64_t slack = m2_slack_pages(n_reads) + 1;
-        const int64_t chunk2 = std::max<int64_t>(1, ((max_pages - slack) * (CAH_M2_PAGE - 63)) / A);
-        for (int64_t lo = 0; lo < n_reads; lo += chunk2) {
-            const int64_t cnt = std::min(chunk2, n_reads - lo);
+        const int64_t TILE = multi2_tile_reads(), per_tile = m2_pages_per_tile(A), open_pages = 16 * CAH_M2_PAIR_CLASSES;
+        const bool rescan = env_flag("CAH_MULTI_RESCAN");
+        // (pairs carry the read's index in 32 bits, the prefilter counts reads in an int)
+        const int64_t BLOCK = (int64_t)1 << 30;
+        for (int64_t lo = 0; lo < n_reads; lo += BLOCK) {
+            const int64_t cnt = std::min(BLOCK, n_reads - lo);
+            const int64_t n_tiles = (cnt + TILE - 1) / TILE;
+            int64_t grid = std::min<int64_t>(n_tiles, pd->n_cus);
+            int64_t gate = max_pages, rounds = 1;
+            if (n_tiles * per_tile + grid * open_pages > max_pages) {
+                // the batch might not fit the pool: blocks stop drawing tiles once what is in flight could fill it, and
+                // the rounds go on until the tiles are done -- `rounds` is the count for the worst case (every adapter on
+                // every read); a round that finds no tile left costs four empty launches
+                grid = std::max<int64_t>(1, std::min(grid, (max_pages / 2) / m2_block_reserve(A)));
+                gate = max_pages - grid * m2_block_reserve(A);
+                const int64_t sure = std::max<int64_t>(1, (gate - grid * open_pages) / per_tile);
+                rounds = (n_tiles + sure - 1) / sure;
+            }
             HIP_TRY(hipMemsetAsync(counters, 0, WS_HEADER, s));
+          for (int64_t round = 0; round < rounds; round++) {
+            if (round) HIP_TRY(hipMemsetAsync(counters, 0, WS_M2_TILE * sizeof(unsigned long long), s));
             {
                 Multi2Args f;
                 f.uniform_first = ul.first; f.uniform_len = ul.len;
@@ -1459,8 +1489,10 @@ static int match_batch_multi(const cah_plan* plan, const PlanDeviceCopy* pd, con
                 f.prefix = pd->d_m2prefix;
                 f.seqs = d_seqs; f.first_read = lo; f.n_reads = cnt; f.status = d_status; f.best_key = d_best_key;
                 f.pairs = d_pairs; f.page_hdr = d_page_hdr; f.page_counter = counters + WS_QCOUNT; f.max_pages = max_pages;
-                ProfScope ps(s, CAH_PROF_FILTER, cnt);
-                HIP_TRY(launch_multi_stream(f, mp.m2.hdr, pd->n_cus, s));
+                f.tile_counter = counters + WS_M2_TILE; f.n_tiles = n_tiles; f.gate_pages = gate;
+                f.wmeta = d_wmeta;
+                ProfScope ps(s, CAH_PROF_FILTER, round ? -1 : cnt);
+                HIP_TRY(launch_multi_stream(f, mp.m2.hdr, (int)grid, s));
             }
             {
                 Multi2ScanArgs sa;
@@ -1473,14 +1505,13 @@ static int match_batch_multi(const cah_plan* plan, const PlanDeviceCopy* pd, con
                 sa.work_counter = counters + WS_SCANWORK; sa.best_key = d_best_key;
                 sa.dp_queue = d_dpq; sa.dp_win = d_win;
                 sa.dp_count_front = counters + WS_DPFRONT; sa.dp_count_back = counters + WS_DPBACK; sa.dp_cap = cap;
-                // (how many pages there are is known on the device only: the grid is sized for a typical batch)
-                const int64_t est_pages = std::min<int64_t>(max_pages, cnt * 8 / CAH_M2_PAGE + slack);
-                ProfScope ps(s, CAH_PROF_SCAN, cnt);
-                HIP_TRY(launch_multi_scan(sa, est_pages, pd->n_cus, s));
+                sa.wmeta = d_wmeta; sa.prefix = pd->d_m2prefix; sa.lmax0 = mp.m2.hdr.lmax0;
+                // (how many pages there are is known on the device only: the blocks draw pages until none is left)
+                ProfScope ps(s, CAH_PROF_SCAN, round ? -1 : cnt);
+                HIP_TRY(launch_multi_scan(sa, std::min(max_pages, n_tiles * per_tile + grid * open_pages), pd->n_cus, s));
             }
             // (off unless CAH_MULTI_RESCAN=1: measured on C4, the second scan costs what it saves the cell DP -- 3.3 ms
             // against 3.3 ms per 100 M reads, profiles/r04/c4_variants.txt -- so the shorter pipeline is the default)
-            const bool rescan = env_flag("CAH_MULTI_RESCAN");
             if (rescan) {
                 // the pairs left for the cell DP once more, with the substitution / one-indel bookkeeping: most finish
                 Multi2RescanArgs ra;
@@ -1514,9 +1545,10 @@ static int match_batch_multi(const cah_plan* plan, const PlanDeviceCopy* pd, con
                     a.win = d_win; a.queue_cap = cap; a.work_counter = counters + WS_DPWORK;
                     if (rescan) a.run_flag = counters + WS_M2_OVER;
                 }
-                ProfScope ps(s, CAH_PROF_DP, list == 1 ? cnt : 0);
-                HIP_TRY(launch_dp(a, m0.m, true, true, list == 2 ? std::min<int64_t>(cap2, cnt) : cnt * A, pd->n_cus, s));
+                ProfScope ps(s, CAH_PROF_DP, round ? -1 : (list == 1 ? cnt : 0));
+                HIP_TRY(launch_dp(a, m0.m, true, true, list == 2 ? std::min<int64_t>(cap2, cnt) : std::min(cap, cnt * A), pd->n_cus, s));
             }
+          }
         }
         ProfScope ps(s, CAH_PROF_MERGE, n_reads);
         HIP_TRY(launch_multi_decode(d_best_key, n_reads, d_out6, d_status, d_best_adapter, pd->n_cus, s));
@@ -1608,8 +1640,9 @@ static int match_batch_impl(const cah_plan* plan, const uint8_t* d_seqs, const i
                                !(env_flag("CAH_NO_FILTER_CLEAR") && !fuse);
     if (!outputs_ready) {
         HIP_TRY(hipMemsetAsync(d_status, 0, (size_t)n_reads, s));
-        if (!filter_clears) HIP_TRY(hipMemsetAsync(d_out6, 0, sizeof(int32_t) * 6 * (size_t)n_reads, s));
-        if (d_best_adapter && !filter_clears) HIP_TRY(launch_init_best(d_best_adapter, n_reads, pd->n_cus, s));
+        // (the fused multi-adapter path's last kernel, k_multi_decode, writes every row, status and best adapter)
+        if (!filter_clears && !multi_path) HIP_TRY(hipMemsetAsync(d_out6, 0, sizeof(int32_t) * 6 * (size_t)n_reads, s));
+        if (d_best_adapter && !filter_clears && !multi_path) HIP_TRY(launch_init_best(d_best_adapter, n_reads, pd->n_cus, s));
     }
     // tiny single-adapter batches: one memset for all counters, no batch check (the ragged prefilter serves them)
     const bool tiny = n_reads <= CAH_TINY_BATCH && plan->matchers.size() == 1;

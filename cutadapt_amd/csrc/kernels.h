@@ -235,6 +235,12 @@ struct Multi2Args {
     uint32_t* page_hdr;              // [max_pages]
     unsigned long long* page_counter;        // zeroed before launch: pages handed out
     int64_t max_pages;
+    // the tiles (M2_TILE reads) of [first_read, first_read + n_reads) are drawn from tile_counter, which lives through the
+    // ROUNDS of a batch: a launch draws no further tile once more than gate_pages pages are handed out, and the next
+    // round (after the scan and the cell DP have emptied the pool) goes on where it stopped
+    unsigned long long* tile_counter;
+    int64_t n_tiles, gate_pages;
+    uint8_t* wmeta;                  // out, per read of the batch: the adapter whose pair saw a further hit (CAH_M2_NO_FLAG ..)
 };
 struct Multi2ScanArgs {
     int64_t uniform_first;
@@ -256,6 +262,9 @@ struct Multi2ScanArgs {
     unsigned long long* dp_count_front;      // zeroed before launch
     unsigned long long* dp_count_back;
     int64_t dp_cap;
+    const uint8_t* wmeta;            // per read: Multi2Args::wmeta
+    const uint32_t* prefix;          // per adapter: its first ten characters (M2Tables::prefix), for the suffix compare
+    int32_t lmax0;                   // the largest overlap without error tolerance
 };
 // k_multi_rescan: the pairs k_multi_scan left for the cell DP (~3 % of all) are scanned once more WITH the
 // substitution / one-indel bookkeeping of back_scan.h (which would cost the first scan a third more per column):
@@ -286,7 +295,8 @@ struct Multi2RescanArgs {
 hipError_t launch_multi_rescan(const Multi2RescanArgs& a, int64_t max_items, int n_cus, hipStream_t s);
 bool multi2_read_len_ok(const CahMulti2Header& h, int read_len);
 size_t multi2_lds_bytes(const CahMulti2Header& h);
-hipError_t launch_multi_stream(const Multi2Args& a, const CahMulti2Header& host_hdr, int n_cus, hipStream_t s);
+hipError_t launch_multi_stream(const Multi2Args& a, const CahMulti2Header& host_hdr, int grid, hipStream_t s);
+int multi2_tile_reads();
 hipError_t launch_multi_scan(const Multi2ScanArgs& a, int64_t max_pages, int n_cus, hipStream_t s);
 // long.hip: adapters longer than 64 characters (column in HBM scratch)
 struct LongArgs {

@@ -192,20 +192,44 @@ __global__ __launch_bounds__(256) void k_multi_filter(MultiFilterArgs a) {
     }
 }
 
-// best_key[r] != 0  ->  the winning match of read r (kernels.h: pack_best)
+// best_key[r] != 0  ->  the winning match of read r (kernels.h: pack_best).  The kernel writes EVERY read's result row,
+// best adapter and status (zeros / -1 / 0 where there is no match; status 2 = invalid read stays), so the fused path
+// needs no clearing pass over the 24 B rows in front of it.  A block stages the rows of 256 reads in LDS and stores them
+// as whole 16-byte words: a lane-per-read store of six ints touches 24 cache lines per instruction.
 __global__ __launch_bounds__(256) void k_multi_decode(const unsigned long long* best_key, int64_t n_reads, int32_t* out6,
                                                       uint8_t* status, int32_t* best_adapter) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += stride) {
-        const unsigned long long k = best_key[r];
-        if (k == 0ull || status[r] == 2) continue;
-        const int rel = (int)(k & 0xFFu), qstart = (int)((k >> 8) & 0xFFFFFu), ref_stop = (int)((k >> 28) & 0x7Fu);
-        const int adapter = 4095 - (int)((k >> 35) & 0xFFFu), errors = 127 - (int)((k >> 47) & 0x7Fu);
-        const int score = (int)((k >> 54) & 0xFFu) - 128;
-        int32_t* o = out6 + r * 6;
-        o[0] = 0; o[1] = ref_stop; o[2] = qstart; o[3] = qstart + rel; o[4] = score; o[5] = errors;
-        status[r] = 1;
-        if (best_adapter) best_adapter[r] = adapter;
+    __shared__ __attribute__((aligned(16))) int32_t s_rows[256 * 6];
+    const bool aligned = ((unsigned long long)out6 & 15ull) == 0ull;
+    for (int64_t base = (int64_t)blockIdx.x * 256; base < n_reads; base += (int64_t)gridDim.x * 256) {
+        const int64_t r = base + threadIdx.x;
+        int32_t o[6] = {0, 0, 0, 0, 0, 0};
+        if (r < n_reads) {
+            const unsigned long long k = best_key[r];
+            const bool invalid = status[r] == 2;
+            const bool hit = k != 0ull && !invalid;
+            if (hit) {
+                const int rel = (int)(k & 0xFFu), qstart = (int)((k >> 8) & 0xFFFFFu);
+                o[1] = (int)((k >> 28) & 0x7Fu); o[2] = qstart; o[3] = qstart + rel;
+                o[4] = (int)((k >> 54) & 0xFFu) - 128; o[5] = 127 - (int)((k >> 47) & 0x7Fu);
+            }
+            if (!invalid) status[r] = hit ? 1 : 0;
+            if (best_adapter) best_adapter[r] = hit ? 4095 - (int)((k >> 35) & 0xFFFu) : -1;
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) s_rows[threadIdx.x * 6 + i] = o[i];
+        __syncthreads();
+        const int64_t left = n_reads - base;
+        const int ints = (int)(left < 256 ? left : 256) * 6;
+        int32_t* const dst = out6 + base * 6;                           // (base * 24 bytes: a multiple of 16)
+        if (aligned) {
+            for (int i = threadIdx.x * 4; i < ints; i += 1024) {
+                if (i + 4 <= ints) *reinterpret_cast<int4*>(dst + i) = *reinterpret_cast<const int4*>(s_rows + i);
+                else for (int q = i; q < ints; ++q) dst[q] = s_rows[q];
+            }
+        } else {
+            for (int i = threadIdx.x; i < ints; i += 256) dst[i] = s_rows[i];
+        }
+        __syncthreads();
     }
 }
 

@@ -57,6 +57,18 @@
 enum { M2_W = 0, M2_HI = 1, M2_LO = 2, M2_SHORT = 3 };
 // pair flags (bits 24.. of a pair record: read << 32 | flags << 24 | adapter << 8 | key)
 #define CAH_M2_PAIR_TAIL 1u          // the scan window starts at column 4 * key; only rows of the last column can match
+// A whole-read pair whose first hit is chunk c of the adapter's k + 1 chunks, ending at read position key (0-based; the
+// chunk index sits in flag bits 2..3).  If that occurrence stays the pair's ONLY k-mer hit (no second whole-read hit, no
+// hit of a tail class: the prefilter leaves the read's flagged adapter in a byte per read, CAH_M2_NO_FLAG = none,
+// CAH_M2_MANY_FLAGS = more than one), every last-row candidate (_align.pyx:496-533, cost <= k over all m rows) holds THIS
+// occurrence as its chunk c, so its alignment lies in columns [f - E_c - k, f + (m - E_c) + k] (f = key + 1, E_c = end
+// offset of chunk c in the adapter): the scan runs from f - E_c - k - 1 to that end, no further candidate follows, and
+// of the last column's rows only the error-free overlaps can be acceptable (a row with tolerance e >= 1 needs a hit of a
+// tail class) -- the suffix compare m2_exact_tail decides those.
+#define CAH_M2_PAIR_PRECISE 2u
+#define CAH_M2_PAIR_CHUNK_SHIFT 2
+#define CAH_M2_NO_FLAG 255u
+#define CAH_M2_MANY_FLAGS 254u
 // Pairs leave the prefilter in PAGES of one class each (0 lo, 1 hi, 2..5 whole-read pairs by window length), taken from
 // a device-wide pool by the wave that fills them; page_hdr[page] = class << 24 | pairs in it.
 #define CAH_M2_PAGE 1024
@@ -75,6 +87,25 @@ M2_HD int m2_q(uint32_t meta) { return (int)((meta >> 8) & 15u); }
 M2_HD int m2_cls(uint32_t meta) { return (int)((meta >> 12) & 3u); }
 M2_HD int m2_ref_L(uint32_t meta) { return (int)((meta >> 14) & 255u); }
 M2_HD int m2_wide_L(uint32_t meta) { return (int)((meta >> 22) & 255u); }
+// A class-W entry whose k-mer is chunk c -- and only that -- of the adapter's k + 1 <= 4 whole-adapter chunks carries
+// CAH_M2_WHOLE - 4 + c as its WIDE window (as good as "the whole read": no read is that long); 1 + c, or 0
+#define CAH_M2_WHOLE_CHUNK0 251
+M2_HD unsigned m2_precise_chunk(uint32_t meta) {
+    const unsigned w = (meta >> 22) & 255u;
+    return (((meta >> 12) & 3u) == 0u && w >= CAH_M2_WHOLE_CHUNK0 && w < 255u) ? w - (CAH_M2_WHOLE_CHUNK0 - 1) : 0u;
+}
+
+// end offset (exclusive) of chunk c when a string of m characters is cut into `chunks` pieces the way m2_chunks does
+M2_HD int m2_chunk_end(int base, int extra, int c) { return (c + 1) * base + ((c + 1) < extra ? (c + 1) : extra); }
+// the window of a PRECISE pair: first column in front of it (the scan starts behind j0w) and the last column a last-row
+// candidate can end in.  chunk_base / chunk_extra: m / (k + 1), m % (k + 1) (a division the kernels do once)
+M2_HD void m2_precise_window(int key, int chunk, int m, int k, int chunk_base, int chunk_extra, int n, int& j0w, int& jb) {
+    const int f = key + 1, E = m2_chunk_end(chunk_base, chunk_extra, chunk);
+    j0w = f - E - k - 1;
+    if (j0w < 0) j0w = 0;
+    jb = f + (m - E) + k;
+    if (jb > n) jb = n;
+}
 
 M2_HD uint32_t m2_code(unsigned c) {
     const unsigned u = c & 0xDFu;
@@ -90,7 +121,7 @@ M2_HD uint32_t m2_index(uint32_t r, int qc) {
 }
 M2_HD uint32_t m2_bit(uint32_t idx, int qc) { return qc >= 8 ? idx : CAH_M2_BM8_WORDS * 32u + (idx & 0x7FFFu); }
 // does a k-mer of window L (0: none, CAH_M2_WHOLE: whole read) count when it starts `dist` characters before the end?
-M2_HD bool m2_in_window(int L, int dist) { return L == CAH_M2_WHOLE || (L != 0 && dist <= L); }
+M2_HD bool m2_in_window(int L, int dist) { return L >= CAH_M2_WHOLE_CHUNK0 || (L != 0 && dist <= L); }
 
 struct CahMulti2Header {
     int32_t ok;
@@ -236,7 +267,20 @@ inline bool m2_build(const std::vector<std::string>& adapters, const int32_t* th
         if (code & 0x24924924u) return false;                        // not plain ACGT
         const uint32_t idx = m2_index(code, qc);
         t.bitmap[m2_bit(idx, qc) >> 5] |= 1u << (idx & 31);
-        placed.push_back({idx & (CAH_M2_SLOTS - 1), code, m2_meta(e.adapter, q, e.cls, e.ref_L, e.wide_L)});
+        // which whole-adapter chunk is it?  (no answer when the string is two of them, or occurs elsewhere in the adapter
+        // too: an alignment could then hold the occurrence at another offset)
+        uint8_t wend = 0;
+        if (e.cls == M2_W && e.wide_L == CAH_M2_WHOLE && kacc + 1 <= 4) {
+            const std::string& ad = adapters[(size_t)e.adapter];
+            const std::vector<std::string> ch = m2_chunks(ad, kacc + 1);
+            int which = -1, times = 0;
+            for (int c = 0; c < (int)ch.size(); c++) if (ch[(size_t)c] == e.kmer) { which = c; times++; }
+            int occurrences = 0;
+            for (size_t at = ad.find(e.kmer); at != std::string::npos; at = ad.find(e.kmer, at + 1)) occurrences++;
+            if (times == 1 && occurrences == 1) wend = (uint8_t)(1 + which);
+        }
+        placed.push_back({idx & (CAH_M2_SLOTS - 1), code,
+                          m2_meta(e.adapter, q, e.cls, e.ref_L, wend ? CAH_M2_WHOLE_CHUNK0 + wend - 1 : e.wide_L)});
         h.q_mask[e.cls] |= 1 << qc;
         const int reach = std::max(e.ref_L, e.wide_L);
         h.open_L[e.cls][qc] = std::max(h.open_L[e.cls][qc], reach);

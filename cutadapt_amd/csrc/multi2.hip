@@ -38,6 +38,8 @@
 #define M2_ROW (M2_HALF * 16)
 #define M2_MAX_LEN (2 * M2_HALF * 16)
 #define M2_RING 128                // events per wave ring (two rounds)
+#define M2_TILE_RING 16           // the block's last tiles: {its own count, the batch's tile} (see take_tile)
+#define M2_NO_TILE 0xFFFFFFFFu
 
 typedef unsigned int m2_u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int m2_u32x4 __attribute__((ext_vector_type(4)));
@@ -70,7 +72,7 @@ __host__ __device__ inline M2Layout m2_layout(const int n_entries, const int n_a
     L.ring = o; o += M2_WAVES * M2_RING * 8;
     L.rlast = o; o += M2_WAVES * WAVE * 4;
     L.pages = o; o += M2_WAVES * CAH_M2_PAIR_CLASSES * 8;
-    L.misc = o; o += 64;
+    L.misc = o; o += 64 + M2_TILE_RING * 8;
     L.entries = o; o += (unsigned)((n_entries + 1) & ~1) * 8;
     L.seen = o; o += M2_WAVES * WAVE * words * 4;
     L.wide = o; o += M2_WAVES * WAVE * words * 4;
@@ -123,6 +125,7 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
     const int n_reads = (int)a.n_reads;                                 // reads of this launch (< 2^31)
     const int64_t first_byte = a.uniform_first + a.first_read * (int64_t)n;
     const int64_t total = (int64_t)n_reads * n;
+    if (*a.tile_counter >= (unsigned long long)a.n_tiles) return;       // (a round that finds no tile left)
     for (int i = threadIdx.x; i < CAH_M2_BM_WORDS; i += blockDim.x) s_bm[i] = a.bitmap[i];
     for (int i = threadIdx.x; i < CAH_M2_SLOTS / 2; i += blockDim.x)
         reinterpret_cast<uint32_t*>(s_dir)[i] = reinterpret_cast<const uint32_t*>(a.dir)[i];
@@ -141,8 +144,26 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
     uint32_t* const s_rlast = reinterpret_cast<uint32_t*>(s_raw + LY.rlast) + wave * WAVE;
     uint32_t* const s_pg = reinterpret_cast<uint32_t*>(s_raw + LY.pages) + wave * CAH_M2_PAIR_CLASSES * 2;   // {page, fill} per class
     unsigned* const s_next_piece = reinterpret_cast<unsigned*>(s_raw + LY.misc);
+    volatile unsigned long long* const s_tilemap = reinterpret_cast<volatile unsigned long long*>(s_raw + LY.misc + 64);
     if (lane < CAH_M2_PAIR_CLASSES) { s_pg[2 * lane] = 0xFFFFFFFFu; s_pg[2 * lane + 1] = 0u; }
-    if (threadIdx.x == 0) *s_next_piece = M2_WAVES;
+    // ---- tiles are handed out by ONE counter of the batch (blocks that drew cheap tiles take more of them), and only
+    // while the page pool still holds what every tile in flight could ask for in the worst case (a.gate_pages, api.cpp):
+    // the launch then ends early and the next round of the same batch goes on from the counter.  A block knows its
+    // tiles by its own count kt; entry kt & 15 of s_tilemap is {kt, batch tile} -- the tile of kt + 1 is drawn by the wave
+    // that takes the first piece of kt, a whole tile ahead of its first use.
+    auto draw_tile = [&]() -> unsigned {
+        const unsigned long long used = __hip_atomic_load(a.page_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((long long)used > a.gate_pages) return M2_NO_TILE;
+        const unsigned long long t = atomicAdd(a.tile_counter, 1ull);
+        return t < (unsigned long long)a.n_tiles ? (unsigned)t : M2_NO_TILE;
+    };
+    if (threadIdx.x == 0) {
+        *s_next_piece = M2_WAVES;
+        const unsigned t0 = draw_tile();
+        const unsigned t1 = t0 == M2_NO_TILE ? M2_NO_TILE : draw_tile();
+        s_tilemap[0] = (unsigned long long)t0;
+        s_tilemap[1] = (1ull << 32) | t1;
+    }
     __syncthreads();
 
     // plan constants (wave-uniform)
@@ -169,8 +190,20 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
         return (int)(__umul24((unsigned)(kk * WAVE) + ln, magic) >> 16);
     };
     constexpr int PPT = M2_TILE / WAVE;
+    constexpr int64_t NO_PIECE = (int64_t)1 << 40;                      // "the batch has no more tiles (for this round)"
+    // first read of piece p (the block's count): the tile of p / PPT from the map; the first piece of a tile draws the next
     auto piece_base = [&](unsigned p) -> int64_t {
-        return ((int64_t)blockIdx.x + (int64_t)(p / PPT) * (int64_t)gridDim.x) * M2_TILE + (int64_t)(p % PPT) * WAVE;
+        const unsigned kt = p / PPT;
+        unsigned long long e;
+        do { e = s_tilemap[kt & (M2_TILE_RING - 1)]; } while ((unsigned)(e >> 32) != kt);
+        const unsigned t = __builtin_amdgcn_readfirstlane((unsigned)e);
+        if (p % PPT == 0 && kt >= 1) {
+            unsigned nt = M2_NO_TILE;
+            if (t != M2_NO_TILE) { if (lane == 0) nt = draw_tile(); nt = __builtin_amdgcn_readfirstlane(nt); }
+            if (lane == 0) s_tilemap[(kt + 1) & (M2_TILE_RING - 1)] = ((unsigned long long)(kt + 1) << 32) | nt;
+        }
+        if (t == M2_NO_TILE) return NO_PIECE;
+        return (int64_t)t * M2_TILE + (int64_t)(p % PPT) * WAVE;
     };
     auto take_piece = [&]() -> unsigned {
         unsigned p = 0;
@@ -318,6 +351,7 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
         else if (cls == M2_LO) { pc_cls = 0; key_cls = max(0, n - a.win_lo) >> 2; flags_cls = CAH_M2_PAIR_TAIL; }
         else { pc_cls = 7; key_cls = 0; }                              // REF-only k-mers: the suffix compare decides
         const int pc_whole = m2_pair_class_w((n + 15) >> 4);
+        const unsigned lo_cls = ((unsigned)pc_cls << 28) | (flags_cls << 24) | (unsigned)key_cls;
         unsigned staged = 0;                                            // wave-uniform
         // the staged pairs (at most 64, one per lane) leave: pairs for their class's page, suffix compares to best_key
         auto flush = [&]() {
@@ -359,19 +393,35 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
             atomicOr(sw + word, wide_only ? bit : 0u);
             const unsigned old = atomicOr(ss + word, is_ref ? bit : 0u);
             const bool emit = is_ref && (old & bit) == 0;
+            const bool again = is_ref && (old & bit) != 0;              // a further hit of a pair that exists
             const unsigned long long em = __ballot(emit);
             if (em) {
                 const unsigned c = (unsigned)__popcll(em);
                 if (staged + c > 64u) flush();
                 if (emit) {
                     const bool whole = (sw[word] & bit) != 0;
-                    const int pc = whole ? pc_whole : pc_cls;
-                    const unsigned lo = ((unsigned)pc << 28) | ((whole ? 0u : flags_cls) << 24) | ((unsigned)adapter << 8) |
-                                        (unsigned)(whole ? 0 : key_cls);
+                    // (a whole-read pair whose occurrence is ONE chunk of the adapter's k + 1 -- CAH_M2_PAIR_PRECISE, multi2.h --
+                    // carries the occurrence's position and chunk index instead of the round's key and goes to the pages of
+                    // the short windows: k_multi_scan orders a page's pairs by their windows)
+#if defined(M2_ABL) && (M2_ABL & 8)
+                    const unsigned we = 0u;                             // developer build: no pair takes the window of its one occurrence
+#else
+                    const unsigned we = (cls == M2_W && !whole) ? m2_precise_chunk(e.meta) : 0u;
+#endif
+                    unsigned lo = whole ? ((unsigned)pc_whole << 28) : lo_cls;
+                    if (we) lo = (2u << 28) | ((CAH_M2_PAIR_PRECISE | ((we - 1u) << CAH_M2_PAIR_CHUNK_SHIFT)) << 24) | (unsigned)p;
+                    lo |= (unsigned)adapter << 8;
                     s_ring[(stage0 + staged + m2_rank(em)) & (M2_RING - 1)] = (m2_u32x2){lo, rd};
                 }
                 staged += c;
             }
+            // (behind the emission: a pair emitted by this very instruction reads its "wide" bit before a further hit of
+            // the same round sets it -- seen & wide at the end of the piece = the pair saw more than its first hit)
+#if defined(M2_ABL) && (M2_ABL & 64)
+            atomicOr(sw + word, again ? bit : 0u);
+#elif !(defined(M2_ABL) && (M2_ABL & 16))
+            if (m2_any(again)) atomicOr(sw + word, again ? bit : 0u);
+#endif
             ++u; --left;
         }
         M2_TOC(13);
@@ -413,14 +463,12 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
     const int tail_off = H2 > 0 ? 16 * H1 : 0;                          // first position of the last half-row
     const int tail_unit0 = (tail_base - tail_off) >> 4;                 // row unit of the first tail chunk
 
-    unsigned p_cur = (unsigned)wave;
-    prefetch(piece_base(p_cur));
+    int64_t base_cur = piece_base((unsigned)wave);
+    prefetch(base_cur);
 #pragma unroll 1
     for (;;) {
-        const unsigned kt = p_cur / PPT;
-        const int64_t tile_base64 = ((int64_t)blockIdx.x + (int64_t)kt * (int64_t)gridDim.x) * M2_TILE;
-        if (tile_base64 >= n_reads) break;
-        const int base = (int)tile_base64 + (int)(p_cur % PPT) * WAVE;
+        if (base_cur >= NO_PIECE) break;
+        const int base = (int)base_cur;
         const bool more = (unsigned)base < (unsigned)n_reads;
         const bool valid = more && (unsigned)(base + lane) < (unsigned)n_reads;
         piece_first = base;
@@ -643,15 +691,29 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
                 if (bestk) atomicMax(a.best_key + (a.first_read + base + lane), bestk);
                 drain();
             }
+            // the read's flagged adapter (every class is resolved): what k_multi_scan asks before it trusts the window of
+            // a CAH_M2_PAIR_PRECISE pair
+#if !(defined(M2_ABL) && (M2_ABL & 32))
+            if (valid) {
+                const uint32_t* const ss = s_seen + lane * words;
+                const uint32_t* const sw = s_wide + lane * words;
+                unsigned cnt = 0, which = 0;
+                for (int w = 0; w < words; ++w) {
+                    const uint32_t f = ss[w] & sw[w];
+                    cnt += (unsigned)__popc(f);
+                    if (f) which = (unsigned)(32 * w) + (unsigned)__builtin_ctz(f);
+                }
+                a.wmeta[a.first_read + base + lane] = (uint8_t)(cnt == 0 ? CAH_M2_NO_FLAG : (cnt == 1 ? which : CAH_M2_MANY_FLAGS));
+            }
+#endif
             if (valid && (seen_chars & 0x80808080u) != 0) a.status[a.first_read + base + lane] = 2;
         }
-        const unsigned p_next = take_piece();
-        prefetch(piece_base(p_next));
+        base_cur = piece_base(take_piece());
+        prefetch(base_cur);
         M2_STAMP(9);
 #ifdef M2_TRACE
         if (blockIdx.x == 7 && wave == 5) ++trace_it;
 #endif
-        p_cur = p_next;
     }
     // close the wave's open pages
     if (lane < CAH_M2_PAIR_CLASSES) {
@@ -662,28 +724,42 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
 
 // =============================================================================================
 // k_multi_scan: the cost scan (back_scan.h) of the pairs k_multi_stream left, page by page.  A page holds pairs of ONE
-// class, so the 64 lanes of a wave scan windows of one shape: "lo" pages ~24 columns and the rows an overlap of the
-// first error class can reach, "hi" pages the reach of the widest tail class, whole-read pages from the first k-mer
-// hit on (binned by window length).  Matches are merged with one atomicMax on the read's best key (kernels.h:
-// pack_best); pairs that need cells go to k_dp_packed<ROWS, true>'s work list with a window that is safe for the cell
-// DP (tail pairs: the full reach m + k + 1, see multi2_model.cpp).
+// class.  "lo" pages: ~24 columns and the rows an overlap of the first error class can reach; "hi" pages: the reach of
+// the widest tail class -- every pair of such a page has the same window.  Whole-read pages: a pair's window runs from
+// its first k-mer hit - m - k - 1 to the read's end, or -- a CAH_M2_PAIR_PRECISE pair whose occurrence stayed its only
+// hit (multi2.h) -- around that one occurrence; the block first orders the page's pairs by (first chunk, last chunk) of
+// their windows (a counting sort in LDS), so that the 64 lanes of a wave walk nearly the same columns: the wave starts at
+// its earliest window's first chunk and ends behind its latest window's last (more columns than a lane's window needs are
+// as exact).  Matches are merged with one atomicMax on the read's best key (kernels.h: pack_best); pairs that need cells
+// go to k_dp_packed<ROWS, true>'s work list with a window that is safe for the cell DP (tail pairs: the full reach
+// m + k + 1, see multi2_model.cpp).
 // =============================================================================================
 template <int KIND>
 __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_multi_scan(Multi2ScanArgs a) {
     constexpr int XR = KIND >= 2 ? KIND - 1 : 0;
     extern __shared__ __attribute__((aligned(16))) uint64_t s_scanmask[];   // [n_adapters * CAH_MULTI_TAB_STRIDE]
     __shared__ int s_thr_last[CAH_MAX_M + 1];
-    __shared__ int s_list[CAH_M2_PAGE * 3];
+    __shared__ uint32_t s_dp[CAH_M2_PAGE];          // the page's DP work list: pair in page | first column << 10 | (last * 2 + scan) << 18
+    __shared__ uint32_t s_ord[CAH_M2_PAGE];         // whole-read pages: the pairs in window order (see phase A)
+    __shared__ unsigned s_bins[256];
+    __shared__ uint32_t s_prefix[128];
+    __shared__ uint8_t s_xlat[128];
     __shared__ unsigned s_nf, s_nb;
     __shared__ long long s_page;
     __shared__ unsigned long long s_gf, s_gb;
     const CahMatcher* mt = a.matcher;
+    if (*a.page_counter == 0ull) return;                                // (a round that found no tile left)
     for (int i = threadIdx.x; i < a.n_adapters * CAH_MULTI_TAB_STRIDE; i += blockDim.x)
         s_scanmask[i] = KIND == 0 ? a.tab[i] : bs32_table_entry(a.tab[i], mt->m);
     for (int i = threadIdx.x; i <= CAH_MAX_M; i += blockDim.x) s_thr_last[i] = mt->thr_last[i];
+    for (int i = threadIdx.x; i < 128; i += blockDim.x) {
+        s_prefix[i] = i < a.n_adapters ? a.prefix[i] : 0u;
+        s_xlat[i] = (uint8_t)m2_code((unsigned)i);
+    }
     BackScanParams p;
     p.m = mt->m; p.k = mt->k; p.kacc = mt->kacc; p.min_overlap = mt->min_overlap; p.half_m = mt->m / 2;
     const int reach = p.m + p.k + 1;
+    const int chunk_base = p.m / (p.k + 1), chunk_extra = p.m % (p.k + 1);
     const int lane = wave_lane();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int n = a.uniform_len;
@@ -696,45 +772,122 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_multi
             s_page = (long long)atomicAdd(a.work_counter, 1ull);
             s_nf = 0; s_nb = 0;
         }
+        s_bins[threadIdx.x] = 0u;                                       // (256 threads)
         __syncthreads();
         const int64_t page = s_page;
         if (page >= n_pages) break;
         const uint32_t hdr = a.page_hdr[page];
         const int count = (int)(hdr & 0xFFFFFFu);
         const bool tail_page = (hdr >> 24) < 2u;                          // classes lo, hi: every pair has the same window
+        if (!tail_page) {
+            // ---- phase A: every pair's window in 16-column chunks counted from the read's END (cs: chunks from the
+            // window's first column to the end, ce: whole chunks behind its last), the suffix compare of the pairs that
+            // stop early, and the pairs in the order of (cs, ce)
+            uint32_t desc[CAH_M2_PAGE / 256];
+            unsigned slot[CAH_M2_PAGE / 256];
+#pragma unroll
+            for (int t = 0; t < CAH_M2_PAGE / 256; ++t) {
+                const int e0 = (int)threadIdx.x + 256 * t;
+                desc[t] = 0; slot[t] = 0;
+                if (e0 < count) {
+                    const uint64_t pr = a.pairs[page * CAH_M2_PAGE + e0];
+                    const unsigned flags = (unsigned)(pr >> 24) & 0xFFu, key = (unsigned)pr & 0xFFu;
+                    const unsigned adapter = (unsigned)(pr >> 8) & 0xFFFFu;
+                    const int64_t r = (int64_t)(pr >> 32);
+                    int j0w = max(0, ((int)key << CAH_KEY_SHIFT) - p.m - p.k - 1), jb = n;
+                    unsigned precise = 0, tail0 = 0;
+                    if (flags & CAH_M2_PAIR_PRECISE) {
+                        const unsigned wm = a.wmeta[r];
+                        if (wm != adapter && wm != CAH_M2_MANY_FLAGS) {
+                            precise = 1;
+                            m2_precise_window((int)key, (int)(flags >> CAH_M2_PAIR_CHUNK_SHIFT) & 3, p.m, p.k, chunk_base, chunk_extra, n, j0w, jb);
+                            // the read's last ten characters against the adapter's first: the error-free overlaps
+                            const uint8_t* q = a.seqs + a.uniform_first + r * (int64_t)n;
+                            const Chunk tl = load_chunk(q, n - 16, n, n);
+                            uint32_t rlast = 0;
+#pragma unroll
+                            for (int c = 6; c < 16; ++c) rlast = (rlast << 3) | (uint32_t)s_xlat[chunk_byte(tl, c) & 127u];
+                            tail0 = (unsigned)m2_exact_tail(rlast, s_prefix[adapter], p.min_overlap, a.lmax0, n);
+                        } else {
+                            j0w = max(0, ((int)key & ~15) - p.m - p.k - 1);       // (flagged: the window of a whole-read pair)
+                        }
+                    }
+                    j0w = min(j0w, n);
+                    const unsigned cs = (unsigned)((n - bs_align_window(j0w, n) + 15) >> 4);
+                    const unsigned ce = (unsigned)((n - jb) >> 4);
+                    desc[t] = (unsigned)e0 | (cs << 10) | (ce << 14) | (precise << 18) | (tail0 << 19);
+                    // (the pairs with full windows first: their waves scan with the substitution bookkeeping, see below)
+                    const unsigned bin = precise * 110u + cs * 10u + ce;
+                    slot[t] = bin | (atomicAdd(&s_bins[bin], 1u) << 8);
+                }
+            }
+            __syncthreads();
+            if (wave == 0) {
+                // exclusive prefix over the 256 bins: four per lane
+                const unsigned b0 = s_bins[4 * lane], b1 = s_bins[4 * lane + 1], b2 = s_bins[4 * lane + 2], b3 = s_bins[4 * lane + 3];
+                unsigned sum = b0 + b1 + b2 + b3;
+#pragma unroll
+                for (int sft = 1; sft < WAVE; sft <<= 1) {
+                    const unsigned o = __shfl_up(sum, sft, WAVE);
+                    if (lane >= sft) sum += o;
+                }
+                const unsigned first = sum - (b0 + b1 + b2 + b3);
+                s_bins[4 * lane] = first;
+                s_bins[4 * lane + 1] = first + b0;
+                s_bins[4 * lane + 2] = first + b0 + b1;
+                s_bins[4 * lane + 3] = first + b0 + b1 + b2;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < CAH_M2_PAGE / 256; ++t)
+                if ((int)threadIdx.x + 256 * t < count) s_ord[s_bins[slot[t] & 255u] + (slot[t] >> 8)] = desc[t];
+            __syncthreads();
+        }
         for (int sub = wave; sub * WAVE < count; sub += 4) {
-            const int e0 = sub * WAVE + lane;
-            const bool valid = e0 < count;
+            const int e_sorted = sub * WAVE + lane;
+            const bool valid = e_sorted < count;
+            // the pair: tail pages in page order, whole-read pages in window order
+            int e0 = e_sorted;
+            unsigned cs = 0, ce = 15, precise = 0, tail0 = 0;
+            if (!tail_page && valid) {
+                const uint32_t d = s_ord[e_sorted];
+                e0 = (int)(d & 1023u); cs = (d >> 10) & 15u; ce = (d >> 14) & 15u; precise = (d >> 18) & 1u; tail0 = (d >> 19) & 15u;
+            }
             const int64_t idx = page * CAH_M2_PAGE + e0;
             int64_t r = 0;
             unsigned tab_base = 0, adapter = 0, key = 0;
-            bool tail = tail_page;
             if (valid) {
                 const uint64_t pr = a.pairs[idx];
                 r = (int64_t)(pr >> 32);
                 adapter = (unsigned)(pr >> 8) & 0xFFFFu;
                 key = (unsigned)pr & 0xFFu;
-                tail = ((unsigned)(pr >> 24) & CAH_M2_PAIR_TAIL) != 0;
                 tab_base = adapter * CAH_MULTI_TAB_STRIDE;
             }
             const uint8_t* q = a.seqs + a.uniform_first + r * (int64_t)n;
-            // the pair's window: tail pairs from column 4 * key, whole-read pairs from (first hit) - m - k - 1; the scan
-            // itself starts a whole number of 16-column chunks in front of the read end and (tail pages: the same for
-            // every lane) skips the first chunk's columns in front of the window
-            int j0w = tail ? ((int)key << 2) : max(0, ((int)key << CAH_KEY_SHIFT) - p.m - p.k - 1);
-            j0w = min(j0w, n);
-            // one start for the whole wave -- the earliest window's (any earlier start is as exact): the lanes then
-            // walk the same chunks and reach the read end together, no lane steps past its read.  A tail page's pairs
-            // all have the same window (one class, one read length): lane 0's.
-            int j0 = valid ? bs_align_window(j0w, n) : n;
-            int t0 = 0;
+            // A tail page's pairs all have the same window (one class, one read length), from column 4 * key: the scan
+            // starts a whole number of 16-column chunks in front of the read end and skips the first chunk's columns in
+            // front of the window.  A whole-read page's wave starts at its earliest window's chunk and ends behind its
+            // latest window's (any earlier start, any later end is as exact): the lanes walk the same chunks, no lane
+            // steps past its read.
+            int j0, t0 = 0, jend = n, j0w_tail = 0;
             if (tail_page) {
+                j0w_tail = min((int)key << 2, n);
+                j0 = valid ? bs_align_window(j0w_tail, n) : n;
                 j0 = __builtin_amdgcn_readfirstlane(j0);                // (lane 0 of a sub-batch is always valid)
-                t0 = (__builtin_amdgcn_readfirstlane(j0w) - j0) & 15;
+                j0w_tail = __builtin_amdgcn_readfirstlane(j0w_tail);
+                t0 = (j0w_tail - j0) & 15;
             } else {
+                unsigned csm = cs, cem = ce;
 #pragma unroll
-                for (int sft = 1; sft < WAVE; sft <<= 1) j0 = min(j0, __shfl_xor(j0, sft, WAVE));
-                j0 = __builtin_amdgcn_readfirstlane(j0);
+                for (int sft = 1; sft < WAVE; sft <<= 1) {
+                    csm = max(csm, (unsigned)__shfl_xor((int)csm, sft, WAVE));
+                    cem = min(cem, (unsigned)__shfl_xor((int)cem, sft, WAVE));
+                }
+                csm = __builtin_amdgcn_readfirstlane(csm);
+                cem = __builtin_amdgcn_readfirstlane(cem);
+                j0 = max(0, n - 16 * (int)csm);
+                // (a window from column 0 of a read that is no whole number of chunks: the chunks count from column 0)
+                jend = min(n, j0 + ((n - 16 * (int)cem - j0 + 15) & ~15));
             }
             const int jstart = j0 + t0;                                 // first column the scan really looks at
             auto eq_of = [&](const Chunk& ck, int t) -> uint64_t {
@@ -746,34 +899,46 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_multi
                 if constexpr (KIND == 0) return bs_step<false>(st, eq, jj, p);
                 else return bs32_step<false, XR>(st, (uint32_t)eq, (uint32_t)(eq >> 32), jj, p);
             };
+            // A wave that holds whole-read pairs with their full windows -- adapters inside the read, most of them with
+            // sequencing errors -- keeps the substitution / one-indel bookkeeping of back_scan.h (a third more per column):
+            // four of five such pairs then finish here instead of in the cell DP.  The other waves (windows of one
+            // occurrence, tail pairs) hardly ever see a candidate and scan without it.
+            const bool track = !tail_page && __ballot(valid && precise == 0u) != 0ull;
+            auto step_tracked = [&](const uint64_t eq, const int jj) -> bool {
+                if constexpr (KIND == 0) return bs_step<true>(st, eq, jj, p);
+                else return bs32_step<true, XR>(st, (uint32_t)eq, (uint32_t)(eq >> 32), jj, p);
+            };
             int j = jstart, exact_j = 0;                                // (wave-uniform: every lane walks the same columns)
             bool done = !valid, exact = false;
             int pos = j0;
             Chunk cur = load_chunk(q, pos, n, valid ? n : 0);
             int first_t = t0;
-            while (j < n) {
-                const Chunk nxt = load_chunk(q, pos + 16, n, (!done) ? n : 0);
+            while (j < jend) {
+                const Chunk nxt = load_chunk(q, pos + 16, n, (!done && pos + 16 < jend) ? n : 0);
                 // a window that starts at column 0 need not be a whole number of chunks: the last chunk then ends early
                 const int last_t = min(16, n - pos);
-                if (first_t == 0 && last_t == 16) {
-                    // a whole chunk (the rule): no per-column tests
-                    uint64_t eqq[2];
-                    eqq[0] = eq_of(cur, 0);
-                    eqq[1] = eq_of(cur, 1);
+                auto run_chunk = [&](auto stepf) {
+                    if (first_t == 0 && last_t == 16) {
+                        // a whole chunk (the rule): no per-column tests
+                        uint64_t eqq[2];
+                        eqq[0] = eq_of(cur, 0);
+                        eqq[1] = eq_of(cur, 1);
 #pragma unroll
-                    for (int t = 0; t < 16; ++t) {
-                        const uint64_t eq = eqq[t & 1];
-                        if (t + 2 < 16) eqq[t & 1] = eq_of(cur, t + 2);
-                        ++j;
-                        if (step(eq, j) && !exact) { exact = true; exact_j = j; }
-                    }
-                } else {
+                        for (int t = 0; t < 16; ++t) {
+                            const uint64_t eq = eqq[t & 1];
+                            if (t + 2 < 16) eqq[t & 1] = eq_of(cur, t + 2);
+                            ++j;
+                            if (stepf(eq, j) && !exact) { exact = true; exact_j = j; }
+                        }
+                    } else {
 #pragma unroll 1
-                    for (int t = first_t; t < last_t; ++t) {           // wave-uniform bounds
-                        ++j;
-                        if (step(eq_of(cur, t), j) && !exact) { exact = true; exact_j = j; }
+                        for (int t = first_t; t < last_t; ++t) {       // wave-uniform bounds
+                            ++j;
+                            if (stepf(eq_of(cur, t), j) && !exact) { exact = true; exact_j = j; }
+                        }
                     }
-                }
+                };
+                if (track) run_chunk(step_tracked); else run_chunk(step);
                 if (exact) done = true;
                 first_t = 0;
                 pos += 16;
@@ -781,27 +946,44 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_multi
             }
             int o0 = 0, o1 = 0;
             // rows that cannot be acceptable are not looked at: an acceptable row's alignment lies inside the window
-            int max_row = valid ? min(p.m, n - j0w + p.kacc) : 0;
+            int max_row;
             if (tail_page) {
                 // (lo pages: the rows of the first error class -- a row with a higher threshold needs a chunk of ITS class)
-                max_row = __builtin_amdgcn_readfirstlane(max_row);
+                max_row = min(p.m, n - j0w_tail + p.kacc);
                 if ((hdr >> 24) == 0u) max_row = min(max_row, a.rows_lo);
             } else {
-#pragma unroll
-                for (int sft = 1; sft < WAVE; sft <<= 1) max_row = max(max_row, __shfl_xor(max_row, sft, WAVE));
-                max_row = __builtin_amdgcn_readfirstlane(max_row);
+                max_row = min(p.m, n - j0 + p.kacc);
             }
+            // a pair scanned on the window of its one occurrence: nothing behind the window matters -- the state is that
+            // of an inner column ("stopped", back_scan.h), whether or not the wave went on to the read's end
+            const bool stopped = precise != 0;
             int cls;
-            if constexpr (KIND == 0) cls = bs_finish<false>(st, n, jstart, p, [&](int i) { return s_thr_last[i]; }, o0, o1, false, max_row);
-            else cls = bs32_finish<XR, false>(st, n, jstart, p, [&](int i) { return s_thr_last[i]; }, o0, o1, false, max_row);
+            if (track) {
+                if constexpr (KIND == 0) cls = bs_finish<true>(st, n, jstart, p, [&](int i) { return s_thr_last[i]; }, o0, o1, stopped, max_row);
+                else cls = bs32_finish<XR, true>(st, n, jstart, p, [&](int i) { return s_thr_last[i]; }, o0, o1, stopped, max_row);
+            } else {
+                if constexpr (KIND == 0) cls = bs_finish<false>(st, n, jstart, p, [&](int i) { return s_thr_last[i]; }, o0, o1, stopped, max_row);
+                else cls = bs32_finish<XR, false>(st, n, jstart, p, [&](int i) { return s_thr_last[i]; }, o0, o1, stopped, max_row);
+            }
+            if (stopped) {
+                if (st.jfa < 0) cls = BS_NONE;                          // no candidate in the window: there is none at all
+                else if (tail0 > 0) { cls = BS_DP; o0 = max(jstart, st.jfa - reach); o1 = 2 * n + 1; }   // ... unless an
+                // error-free overlap is acceptable too: the cell DP sorts that out, to the read's end
+            }
             if (exact) { cls = BS_EXACT_FULL; o0 = exact_j; }
             if (valid) {
                 if (cls == BS_EXACT_FULL) atomicMax(a.best_key + r, pack_best(p.m, 0, (int)adapter, p.m, o0 - p.m, o0));
                 else if (cls == BS_EXACT_TAIL) atomicMax(a.best_key + r, pack_best(o0 - 2 * o1, o1, (int)adapter, o0, n - o0, n));
+                else if (cls == BS_SUBS_FULL) atomicMax(a.best_key + r, pack_best(p.m - 2 * o1, o1, (int)adapter, p.m, o0 - p.m, o0));
+                else if (cls == BS_INDEL1_FULL)
+                    atomicMax(a.best_key + r, pack_best(p.m - 2 * (o1 >> 1) - (o1 & 1), o1 >> 1, (int)adapter, p.m,
+                                                        o0 - p.m + ((o1 & 1) ? 1 : -1), o0));
+                else if (cls == BS_NONE && stopped && tail0 > 0)
+                    atomicMax(a.best_key + r, pack_best((int)tail0, 0, (int)adapter, (int)tail0, n - (int)tail0, n));
             }
             // the cell DP of a tail pair runs over the full reach: band, last_filled and the stale origin of its final
             // scan are only proven equal to the reference's from column start + m + k + 1 on (column skipping)
-            if (cls == BS_DP && tail) o0 = max(0, (st.jfa >= 0 ? st.jfa : n) - reach);
+            if (cls == BS_DP && tail_page) o0 = max(0, (st.jfa >= 0 ? st.jfa : n) - reach);
             const bool to_dp = valid && cls == BS_DP;
             const bool to_back = to_dp && (o1 & 1);
             const bool to_front = to_dp && !(o1 & 1);
@@ -815,13 +997,9 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_multi
                 sf = __builtin_amdgcn_readfirstlane(sf);
                 sb = __builtin_amdgcn_readfirstlane(sb);
                 const unsigned long long below = (1ull << lane) - 1ull;
-                if (to_front) {
-                    const int e = (int)sf + __popcll(bf & below);
-                    s_list[3 * e] = (int)idx; s_list[3 * e + 1] = o0; s_list[3 * e + 2] = o1;
-                } else if (to_back) {
-                    const int e = CAH_M2_PAGE - 1 - ((int)sb + __popcll(bb & below));
-                    s_list[3 * e] = (int)idx; s_list[3 * e + 1] = o0; s_list[3 * e + 2] = o1;
-                }
+                const uint32_t ent = (uint32_t)e0 | ((uint32_t)o0 << 10) | ((uint32_t)o1 << 18);
+                if (to_front) s_dp[(int)sf + __popcll(bf & below)] = ent;
+                else if (to_back) s_dp[CAH_M2_PAGE - 1 - ((int)sb + __popcll(bb & below))] = ent;
             }
         }
         // flush the page's DP work list
@@ -835,16 +1013,17 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_multi
         const unsigned long long gf = s_gf, gb = s_gb;
         for (unsigned e = threadIdx.x; e < nf; e += blockDim.x) {
             const int64_t slot = (int64_t)(gf + e);
-            a.dp_queue[slot] = s_list[3 * e];
-            a.dp_win[2 * slot] = s_list[3 * e + 1];
-            a.dp_win[2 * slot + 1] = s_list[3 * e + 2];
+            const uint32_t ent = s_dp[e];
+            a.dp_queue[slot] = (int32_t)(page * CAH_M2_PAGE + (ent & 1023u));
+            a.dp_win[2 * slot] = (int32_t)((ent >> 10) & 255u);
+            a.dp_win[2 * slot + 1] = (int32_t)(ent >> 18);
         }
         for (unsigned e = threadIdx.x; e < nb; e += blockDim.x) {
             const int64_t slot = a.dp_cap - 1 - (int64_t)(gb + e);
-            const int le = CAH_M2_PAGE - 1 - (int)e;
-            a.dp_queue[slot] = s_list[3 * le];
-            a.dp_win[2 * slot] = s_list[3 * le + 1];
-            a.dp_win[2 * slot + 1] = s_list[3 * le + 2];
+            const uint32_t ent = s_dp[CAH_M2_PAGE - 1 - (int)e];
+            a.dp_queue[slot] = (int32_t)(page * CAH_M2_PAGE + (ent & 1023u));
+            a.dp_win[2 * slot] = (int32_t)((ent >> 10) & 255u);
+            a.dp_win[2 * slot + 1] = (int32_t)(ent >> 18);
         }
     }
 }
@@ -1026,7 +1205,9 @@ bool multi2_read_len_ok(const CahMulti2Header& h, int n) {
     return true;
 }
 
-hipError_t launch_multi_stream(const Multi2Args& a, const CahMulti2Header& h, int n_cus, hipStream_t s) {
+int multi2_tile_reads() { return M2_TILE; }
+
+hipError_t launch_multi_stream(const Multi2Args& a, const CahMulti2Header& h, int grid, hipStream_t s) {
     const size_t lds = multi2_lds_bytes(h);
     static bool attr_set = false;
     if (!attr_set) {
@@ -1036,8 +1217,7 @@ hipError_t launch_multi_stream(const Multi2Args& a, const CahMulti2Header& h, in
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    const int tiles = (int)((a.n_reads + M2_TILE - 1) / M2_TILE);
-    const int grid = std::max(1, std::min(tiles, n_cus));
+    if (grid < 1) grid = 1;
     if (h.q_mask[M2_W] == (1 << 8)) hipLaunchKernelGGL(k_multi_stream<true>, dim3(grid), dim3(M2_WAVES * WAVE), lds, s, a);
     else hipLaunchKernelGGL(k_multi_stream<false>, dim3(grid), dim3(M2_WAVES * WAVE), lds, s, a);
     return hipGetLastError();

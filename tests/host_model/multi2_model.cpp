@@ -47,9 +47,12 @@ void resolve(const M2Tables& t, ReadState& st, uint32_t r, int qc, int cls, int 
             if (m2_in_window(m2_wide_L(meta), dist)) st.wideonly[a] = true;
             continue;
         }
-        if (st.seen[a]) continue;
+        // (a further hit of a pair that exists: the kernel sets the pair's "wide" bit -- seen & wide = flagged)
+        if (st.seen[a]) { st.wideonly[a] = true; continue; }
         st.seen[a] = true;
         if (st.wideonly[a]) { st.pairs.push_back({a, 0u, 0}); st.conservative++; }
+        else if (cls == M2_W && m2_precise_chunk(meta))
+            st.pairs.push_back({a, CAH_M2_PAIR_PRECISE | ((m2_precise_chunk(meta) - 1u) << CAH_M2_PAIR_CHUNK_SHIFT), p});
         else if (cls == M2_W) st.pairs.push_back({a, 0u, std::min((p & ~15) >> CAH_KEY_SHIFT, CAH_QUEUE_BINS - 1)});
         else if (cls == M2_HI) st.pairs.push_back({a, CAH_M2_PAIR_TAIL, std::max(0, n - h.win_dist[M2_HI]) >> 2});
         else if (cls == M2_LO) st.pairs.push_back({a, CAH_M2_PAIR_TAIL, std::max(0, n - h.win_dist[M2_LO]) >> 2});
@@ -94,7 +97,7 @@ extern "C" {
 // ref_*: the reference search sets, flattened: adapter index, window (255 = whole read, else L of (-L, None)), k-mer
 // (NUL-terminated strings back to back).  subs: 1 = the scan keeps the SUBS_FULL / INDEL1_FULL bookkeeping.
 // stats (may be NULL): [0] pairs W, [1] pairs hi, [2] pairs lo, [3] suffix compares that matched, [4] pairs that take the whole read because a WIDE-only hit came first,
-// [5] scan columns, [6] pairs to the cell DP.
+// [5] scan columns, [6] pairs to the cell DP, [7] whole-read pairs scanned on the window of their one occurrence.
 // Returns 0; 1 when the tables cannot be built (the plan would take the older path).
 int m2m_match_batch(const char* adapters, int A, int m, const void* blobs, int32_t n_ref, const int32_t* ref_adapter,
                     const int32_t* ref_window, const char* ref_kmers, const uint8_t* seqs, const int64_t* offsets,
@@ -133,46 +136,84 @@ int m2m_match_batch(const char* adapters, int A, int m, const void* blobs, int32
             if (stats) stats[3]++;
         }
         if (stats) { stats[4] += st.conservative; for (int c = 0; c < 4; c++) stats[8 + c] += st.events[c]; }
+        // the byte k_multi_stream leaves per read: the adapter whose pair saw a further hit
+        unsigned wm = CAH_M2_NO_FLAG;
+        for (int a = 0; a < A; a++)
+            if (st.seen[a] && st.wideonly[a]) wm = wm == CAH_M2_NO_FLAG ? (unsigned)a : CAH_M2_MANY_FLAGS;
+        uint32_t rlast = 0x24924924u;
+        for (int i = 0; i < n; i++) rlast = (rlast << 3) | m2_code(q[i]);
         for (const Pair& pr : st.pairs) {
             const CahMatcher& mt = mts[(size_t)pr.adapter];
             const bool tail = (pr.flags & CAH_M2_PAIR_TAIL) != 0;
             int j0 = tail ? (pr.key << 2) : std::max(0, (pr.key << CAH_KEY_SHIFT) - p.m - p.k - 1);
+            // a PRECISE pair whose occurrence stayed its only hit: the window around that occurrence (multi2.h)
+            static const bool no_precise = getenv("M2M_NO_PRECISE") != nullptr;     // (for the column statistics: the windows before)
+            const bool precise = !no_precise && (pr.flags & CAH_M2_PAIR_PRECISE) != 0 && wm != (unsigned)pr.adapter && wm != CAH_M2_MANY_FLAGS;
+            int jend = n, tail0 = 0;
+            if (pr.flags & CAH_M2_PAIR_PRECISE) {
+                int jw, jb;
+                m2_precise_window(pr.key, (int)(pr.flags >> CAH_M2_PAIR_CHUNK_SHIFT) & 3, p.m, p.k, p.m / (p.k + 1), p.m % (p.k + 1), n, jw, jb);
+                if (precise) {
+                    j0 = jw; jend = jb;
+                    tail0 = m2_exact_tail(rlast, t.prefix[(size_t)pr.adapter], p.min_overlap, t.hdr.lmax0, n);
+                } else {
+                    j0 = std::max(0, (pr.key & ~15) - p.m - p.k - 1);   // (flagged: the window of a whole-read pair)
+                }
+            }
             // rows above this cannot be acceptable (k_multi_scan does not look at them)
             int max_row = std::min(p.m, n - std::min(j0, n) + p.kacc);
             if (tail && pr.key == (std::max(0, n - t.hdr.win_dist[M2_LO]) >> 2) && t.hdr.win_dist[M2_LO] != t.hdr.win_dist[M2_HI])
                 max_row = std::min(max_row, t.hdr.rows_lo);
             j0 = bs_align_window(std::min(j0, n), n);
-            if (stats) { stats[tail ? (j0 >= n - t.hdr.win_dist[M2_LO] - 15 && t.hdr.win_dist[M2_LO] != t.hdr.win_dist[M2_HI] ? 2 : 1) : 0]++; stats[5] += n - j0; }
+            if (precise) {
+                // the kernel stops at the first chunk boundary behind the window (later if another lane of the wave needs
+                // more: M2M_EXTEND chunks more here, to show that it does not matter)
+                static const int extend = getenv("M2M_EXTEND") ? atoi(getenv("M2M_EXTEND")) : 0;
+                jend = std::min(n, j0 + ((jend - j0 + 15) & ~15) + 16 * extend);
+                if (stats) stats[7]++;
+            }
+            if (stats) { stats[tail ? (j0 >= n - t.hdr.win_dist[M2_LO] - 15 && t.hdr.win_dist[M2_LO] != t.hdr.win_dist[M2_HI] ? 2 : 1) : 0]++; stats[5] += jend - j0; }
             uint64_t tab32[128];
             for (int c = 0; c < 128; c++) tab32[c] = bs32_table_entry(mt.scanmask[c], p.m);
             bool exact = false;
             int j = j0, o0 = 0, o1 = 0, cls = BS_NONE, jfa = -1;
             auto thr = [&](int i) { return mt.thr_last[i]; };
-            auto run = [&](auto& s, auto step, auto finish) {
-                while (j < n) {
+            auto run = [&](auto& s, auto step, auto finish, auto finish_stopped) {
+                while (j < jend) {
                     ++j;
                     if (step(s, q[j - 1] & 127)) { exact = true; break; }
                 }
                 jfa = s.jfa;
                 if (exact) { cls = BS_EXACT_FULL; o0 = j; }
-                else cls = finish(s);
+                else if (!precise) cls = finish(s);
+                else if (jfa < 0) cls = BS_NONE;                       // no candidate in the window: there is none at all
+                else {
+                    // nothing behind the window matters: the state is that of an inner column ("stopped")
+                    cls = finish_stopped(s);
+                    // ... unless an error-free overlap is acceptable too: the cell DP sorts that out, to the read's end
+                    if (tail0 > 0) { cls = BS_DP; o0 = std::max(j0, jfa - reach); o1 = 2 * n + 1; }
+                }
             };
 #define M2M_RUN32(X)                                                                                                      \
             {                                                                                                             \
                 BackScanState32<X> s;                                                                                     \
                 bs32_init(s, p);                                                                                          \
                 if (subs) run(s, [&](BackScanState32<X>& z, int c) { return bs32_step<true, X>(z, (uint32_t)tab32[c], (uint32_t)(tab32[c] >> 32), j, p); }, \
-                              [&](BackScanState32<X>& z) { return bs32_finish<X, true>(z, n, j0, p, thr, o0, o1, false, max_row); }); \
+                              [&](BackScanState32<X>& z) { return bs32_finish<X, true>(z, n, j0, p, thr, o0, o1, false, max_row); }, \
+                              [&](BackScanState32<X>& z) { return bs32_finish<X, true>(z, n, j0, p, thr, o0, o1, true, max_row); }); \
                 else run(s, [&](BackScanState32<X>& z, int c) { return bs32_step<false, X>(z, (uint32_t)tab32[c], (uint32_t)(tab32[c] >> 32), j, p); }, \
-                         [&](BackScanState32<X>& z) { return bs32_finish<X, false>(z, n, j0, p, thr, o0, o1, false, max_row); });  \
+                         [&](BackScanState32<X>& z) { return bs32_finish<X, false>(z, n, j0, p, thr, o0, o1, false, max_row); },  \
+                         [&](BackScanState32<X>& z) { return bs32_finish<X, false>(z, n, j0, p, thr, o0, o1, true, max_row); });  \
             }
             if (kind == 0) {
                 BackScanState s;
                 bs_init(s, p);
                 if (subs) run(s, [&](BackScanState& z, int c) { return bs_step<true>(z, mt.scanmask[c], j, p); },
-                              [&](BackScanState& z) { return bs_finish<true>(z, n, j0, p, thr, o0, o1, false, max_row); });
+                              [&](BackScanState& z) { return bs_finish<true>(z, n, j0, p, thr, o0, o1, false, max_row); },
+                              [&](BackScanState& z) { return bs_finish<true>(z, n, j0, p, thr, o0, o1, true, max_row); });
                 else run(s, [&](BackScanState& z, int c) { return bs_step<false>(z, mt.scanmask[c], j, p); },
-                         [&](BackScanState& z) { return bs_finish<false>(z, n, j0, p, thr, o0, o1, false, max_row); });
+                         [&](BackScanState& z) { return bs_finish<false>(z, n, j0, p, thr, o0, o1, false, max_row); },
+                         [&](BackScanState& z) { return bs_finish<false>(z, n, j0, p, thr, o0, o1, true, max_row); });
             } else if (kind == 1) M2M_RUN32(0)
             else if (kind == 2) M2M_RUN32(1)
             else M2M_RUN32(2)
@@ -188,10 +229,12 @@ int m2m_match_batch(const char* adapters, int A, int m, const void* blobs, int32
                 // final scan are only proven equal to the reference's from column start + m + k + 1 on)
                 if (tail) o0 = std::max(0, (jfa >= 0 ? jfa : n) - reach);
                 int t6[6];
-                if (stats) stats[6]++;
+                if (stats) { stats[6]++; stats[12 + (tail ? (max_row == t.hdr.rows_lo ? 2 : 1) : (precise ? 3 : 0))]++; }
                 if (dp_window(mt, q, n, o0, std::min(n, o1 >> 1), (o1 & 1) != 0, t6))
                     key = pack_best(t6[4], t6[5], pr.adapter, t6[1], t6[2], t6[3]);
             }
+            // the error-free overlap of a pair without a candidate in its window
+            if (precise && cls == BS_NONE && tail0 > 0) key = pack_best(tail0, 0, pr.adapter, tail0, n - tail0, n);
             bestkey = std::max(bestkey, key);
         }
         if (bestkey) {

@@ -88,6 +88,38 @@ if "--refined" in sys.argv:
     assert len(bad) == 0, (bad[:5], out6[bad[:5]], want6[bad[:5]])
 j0a = np.maximum(0, L - ((L - j0 + 15) & ~15))                      # bs_align_window
 need = (jend - j0a + 15) // 16                                      # chunks this lane is at work
+if "--end-bound" in sys.argv:
+    # What would an END of the window be worth?  A candidate of the last row (cost <= k over all m rows) holds one of the
+    # k + 1 chunks of the whole-read search set unedited, so no such candidate ends behind (last end of chunk c) +
+    # (m - end offset of c) + k; rows of the last column need a hit of one of the tail sets.  A survivor without a tail hit
+    # could stop at that column.  (The scan's own early stop, bs_may_stop, already ends the lanes that found a candidate.)
+    R = s_seqs.reshape(len(surv), L)
+    sets = create_positions_and_kmers(ad, O, rate, True, False)
+    bound = np.zeros(len(surv), dtype=np.int64)
+    tail_hit = np.zeros(len(surv), dtype=bool)
+    for start, stop, kmers in sets:
+        for km in kmers:
+            ln = len(km)
+            hit = np.ones((len(surv), L - ln + 1), dtype=bool)
+            for t in range(ln):
+                hit &= R[:, t:L - ln + 1 + t] == ord(km[t])
+            if start < 0:
+                tail_hit |= hit[:, max(0, L + start):].any(axis=1)
+            else:
+                e_off = ad.index(km) + ln
+                last_end = np.where(hit.any(axis=1), L - ln - hit[:, ::-1].argmax(axis=1) + ln, 0)
+                if "--coarse" in sys.argv:
+                    # what the prefilter can say for one instruction per chunk: the 16-column chunk of the read's LAST
+                    # whole-read hit, whichever k-mer it was
+                    bound = np.maximum(bound, np.where(last_end > 0, ((last_end + 15) & ~15) + (m - 8) + k, 0))
+                else:
+                    bound = np.maximum(bound, np.where(last_end > 0, last_end + (m - e_off) + k, 0))
+    bound = np.where(tail_hit, L, np.minimum(bound, L))
+    need_b = np.minimum(need, np.maximum(0, (bound - j0a + 15) // 16))
+    print(f"end bound: survivors without a tail-set hit {1 - tail_hit.mean():.3f}; lane-chunks {int(need.sum())} -> {int(need_b.sum())} "
+          f"({need_b.sum() / need.sum():.3f})")
+    need = need_b
+    jend = np.minimum(jend, np.maximum(j0a, bound)).astype(jend.dtype)
 names = ["NONE", "EXACT_FULL", "EXACT_TAIL", "DP", "SUBS_FULL", "INDEL1_FULL"]
 c7 = cls & 7
 print("classes:", {names[i] if i < len(names) else i: round(float((c7 == i).mean()), 3) for i in np.unique(c7)},
