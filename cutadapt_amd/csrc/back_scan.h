@@ -206,7 +206,10 @@ CAH_HD bool bs_book(BackScanBook& s, const bool clean, const int j, const BackSc
 // Returns true when the read is finished as EXACT_FULL at this column.
 // SUBS = false leaves the SUBS_FULL bookkeeping out (the class then never applies): the fused multi-adapter scan
 // runs ~6 (read, adapter) pairs per read, most of them ending as NONE, and is cheaper without it.
-template <bool SUBS = true>
+// BOOK = false: the recurrence alone -- for windows in which no column but the last can hold an acceptable candidate
+// (the tail pairs of the streaming multi-adapter path, multi2.h): row m's cost is not followed, nothing is booked, the
+// rows of the last column are read off the state by bs_finish as ever (jfa stays -1).
+template <bool SUBS = true, bool BOOK = true>
 CAH_HD bool bs_step(BackScanState& s, const uint64_t eq, const int j, const BackScanParams& p) {
     const uint64_t VP = s.VP, VN = s.VN;
     const uint64_t Xv = eq | VN;
@@ -214,10 +217,11 @@ CAH_HD bool bs_step(BackScanState& s, const uint64_t eq, const int j, const Back
     const uint64_t HP = VN | ~(Xh | VP);
     const uint64_t HN = VP & Xh;
     // row m is bit 63: horizontal delta +1 / -1
-    s.cm += (int)(HP >> 63) - (int)(HN >> 63);
+    if (BOOK) s.cm += (int)(HP >> 63) - (int)(HN >> 63);
     const uint64_t HPs = bs_shl1(HP), HNs = bs_shl1(HN);
     s.VP = HNs | ~(Xv | HPs);
     s.VN = HPs & Xv;
+    if (!BOOK) return false;
     // D0 = Xh | VN: C(i, j) == C(i-1, j-1); set where the characters differ = an indel path is as cheap
     if (SUBS) s.A = bs_shl1(s.A) | ((Xh | VN) & ~eq);
     if (__builtin_expect(s.cm <= p.kacc, 0)) return bs_book<SUBS>(s, (s.A >> 63) == 0, j, p);     // rare: off the straight path
@@ -249,7 +253,7 @@ CAH_HD void bs32_init(BackScanState32<X>& s, const BackScanParams& p) {
     s.Z = 0; s.U = 0;
 }
 
-template <bool SUBS, int X>
+template <bool SUBS, int X, bool BOOK = true>
 CAH_HD bool bs32_step(BackScanState32<X>& s, const uint32_t eq, const uint32_t eqx, const int j, const BackScanParams& p) {
     // ---- the explicit rows 1..X and what they hand to the word: hin, and the bits that enter its diagonals
     uint32_t hpos = 0, hneg = 0, a_in = 0, u_in = 0, z_in = 0, a_top_new = 0;
@@ -294,10 +298,11 @@ CAH_HD bool bs32_step(BackScanState32<X>& s, const uint32_t eq, const uint32_t e
     const uint32_t Xh = (((eqm & VP) + VP) ^ VP) | eqm;
     const uint32_t HP = VN | ~(Xh | VP);
     const uint32_t HN = VP & Xh;
-    s.cm += (int)(HP >> 31) - (int)(HN >> 31);                     // row m is the top bit
+    if (BOOK) s.cm += (int)(HP >> 31) - (int)(HN >> 31);           // row m is the top bit
     const uint32_t HPs = (HP << 1) | hpos, HNs = (HN << 1) | hneg;
     s.VP = HNs | ~(Xv | HPs);
     s.VN = HPs & Xv;
+    if (!BOOK) return false;
     if (SUBS) {
         const uint32_t a_old = s.A;
         const uint32_t Xc = (Xh | VN) & ~eq;                       // unclean cells: diagonal delta 0, characters differ

@@ -904,6 +904,12 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_multi
             // four of five such pairs then finish here instead of in the cell DP.  The other waves (windows of one
             // occurrence, tail pairs) hardly ever see a candidate and scan without it.
             const bool track = !tail_page && __ballot(valid && precise == 0u) != 0ull;
+            // A tail pair's window holds no last-row candidate (that takes a whole-adapter chunk: the pair would be a
+            // whole-read pair): only the rows of its last column are asked -- the recurrence alone, nothing booked
+            auto step_plain = [&](const uint64_t eq, const int jj) -> bool {
+                if constexpr (KIND == 0) return bs_step<false, false>(st, eq, jj, p);
+                else return bs32_step<false, XR, false>(st, (uint32_t)eq, (uint32_t)(eq >> 32), jj, p);
+            };
             auto step_tracked = [&](const uint64_t eq, const int jj) -> bool {
                 if constexpr (KIND == 0) return bs_step<true>(st, eq, jj, p);
                 else return bs32_step<true, XR>(st, (uint32_t)eq, (uint32_t)(eq >> 32), jj, p);
@@ -938,7 +944,7 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_multi
                         }
                     }
                 };
-                if (track) run_chunk(step_tracked); else run_chunk(step);
+                if (tail_page) run_chunk(step_plain); else if (track) run_chunk(step_tracked); else run_chunk(step);
                 if (exact) done = true;
                 first_t = 0;
                 pos += 16;

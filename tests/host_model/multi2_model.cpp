@@ -201,6 +201,9 @@ int m2m_match_batch(const char* adapters, int A, int m, const void* blobs, int32
                 if (subs) run(s, [&](BackScanState32<X>& z, int c) { return bs32_step<true, X>(z, (uint32_t)tab32[c], (uint32_t)(tab32[c] >> 32), j, p); }, \
                               [&](BackScanState32<X>& z) { return bs32_finish<X, true>(z, n, j0, p, thr, o0, o1, false, max_row); }, \
                               [&](BackScanState32<X>& z) { return bs32_finish<X, true>(z, n, j0, p, thr, o0, o1, true, max_row); }); \
+                else if (tail) run(s, [&](BackScanState32<X>& z, int c) { return bs32_step<false, X, false>(z, (uint32_t)tab32[c], (uint32_t)(tab32[c] >> 32), j, p); }, \
+                         [&](BackScanState32<X>& z) { return bs32_finish<X, false>(z, n, j0, p, thr, o0, o1, false, max_row); },  \
+                         [&](BackScanState32<X>& z) { return bs32_finish<X, false>(z, n, j0, p, thr, o0, o1, true, max_row); });  \
                 else run(s, [&](BackScanState32<X>& z, int c) { return bs32_step<false, X>(z, (uint32_t)tab32[c], (uint32_t)(tab32[c] >> 32), j, p); }, \
                          [&](BackScanState32<X>& z) { return bs32_finish<X, false>(z, n, j0, p, thr, o0, o1, false, max_row); },  \
                          [&](BackScanState32<X>& z) { return bs32_finish<X, false>(z, n, j0, p, thr, o0, o1, true, max_row); });  \
@@ -211,6 +214,9 @@ int m2m_match_batch(const char* adapters, int A, int m, const void* blobs, int32
                 if (subs) run(s, [&](BackScanState& z, int c) { return bs_step<true>(z, mt.scanmask[c], j, p); },
                               [&](BackScanState& z) { return bs_finish<true>(z, n, j0, p, thr, o0, o1, false, max_row); },
                               [&](BackScanState& z) { return bs_finish<true>(z, n, j0, p, thr, o0, o1, true, max_row); });
+                else if (tail) run(s, [&](BackScanState& z, int c) { return bs_step<false, false>(z, mt.scanmask[c], j, p); },
+                         [&](BackScanState& z) { return bs_finish<false>(z, n, j0, p, thr, o0, o1, false, max_row); },
+                         [&](BackScanState& z) { return bs_finish<false>(z, n, j0, p, thr, o0, o1, true, max_row); });
                 else run(s, [&](BackScanState& z, int c) { return bs_step<false>(z, mt.scanmask[c], j, p); },
                          [&](BackScanState& z) { return bs_finish<false>(z, n, j0, p, thr, o0, o1, false, max_row); },
                          [&](BackScanState& z) { return bs_finish<false>(z, n, j0, p, thr, o0, o1, true, max_row); });
