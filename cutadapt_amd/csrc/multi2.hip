@@ -919,11 +919,11 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_multi
             int pos = j0;
             Chunk cur = load_chunk(q, pos, n, valid ? n : 0);
             int first_t = t0;
-            while (j < jend) {
-                const Chunk nxt = load_chunk(q, pos + 16, n, (!done && pos + 16 < jend) ? n : 0);
-                // a window that starts at column 0 need not be a whole number of chunks: the last chunk then ends early
-                const int last_t = min(16, n - pos);
-                auto run_chunk = [&](auto stepf) {
+            auto walk = [&](auto stepf) {
+                while (j < jend) {
+                    const Chunk nxt = load_chunk(q, pos + 16, n, (!done && pos + 16 < jend) ? n : 0);
+                    // a window that starts at column 0 need not be a whole number of chunks: the last chunk then ends early
+                    const int last_t = min(16, n - pos);
                     if (first_t == 0 && last_t == 16) {
                         // a whole chunk (the rule): no per-column tests
                         uint64_t eqq[2];
@@ -943,13 +943,12 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_multi
                             if (stepf(eq_of(cur, t), j) && !exact) { exact = true; exact_j = j; }
                         }
                     }
-                };
-                if (tail_page) run_chunk(step_plain); else if (track) run_chunk(step_tracked); else run_chunk(step);
-                if (exact) done = true;
-                first_t = 0;
-                pos += 16;
-                cur = nxt;
-            }
+                    if (exact) done = true;
+                    first_t = 0;
+                    pos += 16;
+                    cur = nxt;
+                }
+            };
             int o0 = 0, o1 = 0;
             // rows that cannot be acceptable are not looked at: an acceptable row's alignment lies inside the window
             int max_row;
@@ -963,17 +962,36 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_multi
             // a pair scanned on the window of its one occurrence: nothing behind the window matters -- the state is that
             // of an inner column ("stopped", back_scan.h), whether or not the wave went on to the read's end
             const bool stopped = precise != 0;
-            int cls;
-            if (track) {
-                if constexpr (KIND == 0) cls = bs_finish<true>(st, n, jstart, p, [&](int i) { return s_thr_last[i]; }, o0, o1, stopped, max_row);
-                else cls = bs32_finish<XR, true>(st, n, jstart, p, [&](int i) { return s_thr_last[i]; }, o0, o1, stopped, max_row);
+            int cls, jfa = -1;
+            auto thr_of = [&](int i) { return s_thr_last[i]; };
+            if (KIND != 1 && tail_page && (hdr >> 24) == 0u && a.rows_lo <= 32) {
+                // a "lo" page asks for rows 1 .. rows_lo of the last column alone: the adapter's first 32 rows in ONE plain
+                // 32-bit word do (a row's cost depends on the rows above it only) -- no explicit rows, no second word
+                BackScanParams p32 = p;
+                p32.m = 32;
+                BackScanState32<0> s0;
+                bs32_init(s0, p32);
+                walk([&](const uint64_t eq, const int jj) -> bool {
+                    uint32_t rows;
+                    if constexpr (KIND == 0) rows = (uint32_t)(eq >> (64 - p.m));
+                    else rows = ((uint32_t)eq << XR) | ((uint32_t)(eq >> 32) & ((1u << XR) - 1u));
+                    return bs32_step<false, 0, false>(s0, rows, 0u, jj, p32);
+                });
+                cls = bs32_finish<0, false>(s0, n, jstart, p32, thr_of, o0, o1, false, max_row);
             } else {
-                if constexpr (KIND == 0) cls = bs_finish<false>(st, n, jstart, p, [&](int i) { return s_thr_last[i]; }, o0, o1, stopped, max_row);
-                else cls = bs32_finish<XR, false>(st, n, jstart, p, [&](int i) { return s_thr_last[i]; }, o0, o1, stopped, max_row);
+                if (tail_page) walk(step_plain); else if (track) walk(step_tracked); else walk(step);
+                if (track) {
+                    if constexpr (KIND == 0) cls = bs_finish<true>(st, n, jstart, p, thr_of, o0, o1, stopped, max_row);
+                    else cls = bs32_finish<XR, true>(st, n, jstart, p, thr_of, o0, o1, stopped, max_row);
+                } else {
+                    if constexpr (KIND == 0) cls = bs_finish<false>(st, n, jstart, p, thr_of, o0, o1, stopped, max_row);
+                    else cls = bs32_finish<XR, false>(st, n, jstart, p, thr_of, o0, o1, stopped, max_row);
+                }
+                jfa = st.jfa;
             }
             if (stopped) {
-                if (st.jfa < 0) cls = BS_NONE;                          // no candidate in the window: there is none at all
-                else if (tail0 > 0) { cls = BS_DP; o0 = max(jstart, st.jfa - reach); o1 = 2 * n + 1; }   // ... unless an
+                if (jfa < 0) cls = BS_NONE;                             // no candidate in the window: there is none at all
+                else if (tail0 > 0) { cls = BS_DP; o0 = max(jstart, jfa - reach); o1 = 2 * n + 1; }   // ... unless an
                 // error-free overlap is acceptable too: the cell DP sorts that out, to the read's end
             }
             if (exact) { cls = BS_EXACT_FULL; o0 = exact_j; }
@@ -989,7 +1007,7 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_multi
             }
             // the cell DP of a tail pair runs over the full reach: band, last_filled and the stale origin of its final
             // scan are only proven equal to the reference's from column start + m + k + 1 on (column skipping)
-            if (cls == BS_DP && tail_page) o0 = max(0, (st.jfa >= 0 ? st.jfa : n) - reach);
+            if (cls == BS_DP && tail_page) o0 = max(0, (jfa >= 0 ? jfa : n) - reach);
             const bool to_dp = valid && cls == BS_DP;
             const bool to_back = to_dp && (o1 & 1);
             const bool to_front = to_dp && !(o1 & 1);

@@ -162,8 +162,8 @@ int m2m_match_batch(const char* adapters, int A, int m, const void* blobs, int32
             }
             // rows above this cannot be acceptable (k_multi_scan does not look at them)
             int max_row = std::min(p.m, n - std::min(j0, n) + p.kacc);
-            if (tail && pr.key == (std::max(0, n - t.hdr.win_dist[M2_LO]) >> 2) && t.hdr.win_dist[M2_LO] != t.hdr.win_dist[M2_HI])
-                max_row = std::min(max_row, t.hdr.rows_lo);
+            const bool is_lo = tail && pr.key == (std::max(0, n - t.hdr.win_dist[M2_LO]) >> 2) && t.hdr.win_dist[M2_LO] != t.hdr.win_dist[M2_HI];
+            if (is_lo) max_row = std::min(max_row, t.hdr.rows_lo);
             j0 = bs_align_window(std::min(j0, n), n);
             if (precise) {
                 // the kernel stops at the first chunk boundary behind the window (later if another lane of the wave needs
@@ -208,7 +208,21 @@ int m2m_match_batch(const char* adapters, int A, int m, const void* blobs, int32
                          [&](BackScanState32<X>& z) { return bs32_finish<X, false>(z, n, j0, p, thr, o0, o1, false, max_row); },  \
                          [&](BackScanState32<X>& z) { return bs32_finish<X, false>(z, n, j0, p, thr, o0, o1, true, max_row); });  \
             }
-            if (kind == 0) {
+            if (!subs && is_lo && kind != 1 && t.hdr.rows_lo <= 32) {
+                // k_multi_scan's "lo" pages: the adapter's first 32 rows in one plain 32-bit word
+                BackScanParams p32 = p;
+                p32.m = 32;
+                BackScanState32<0> s;
+                bs32_init(s, p32);
+                const int xr = kind >= 2 ? kind - 1 : 0;
+                run(s, [&](BackScanState32<0>& z, int c) {
+                        const uint32_t rows = kind == 0 ? (uint32_t)(mt.scanmask[c] >> (64 - p.m))
+                                                        : (((uint32_t)tab32[c] << xr) | ((uint32_t)(tab32[c] >> 32) & ((1u << xr) - 1u)));
+                        return bs32_step<false, 0, false>(z, rows, 0u, j, p32);
+                    },
+                    [&](BackScanState32<0>& z) { return bs32_finish<0, false>(z, n, j0, p32, thr, o0, o1, false, max_row); },
+                    [&](BackScanState32<0>& z) { return bs32_finish<0, false>(z, n, j0, p32, thr, o0, o1, true, max_row); });
+            } else if (kind == 0) {
                 BackScanState s;
                 bs_init(s, p);
                 if (subs) run(s, [&](BackScanState& z, int c) { return bs_step<true>(z, mt.scanmask[c], j, p); },
