@@ -1038,10 +1038,7 @@ static const size_t WS_UFLAG = 128 / sizeof(unsigned long long);    // 0 after t
 static const size_t WS_QCOUNT = 256 / sizeof(unsigned long long), WS_DPWORK = 512 / sizeof(unsigned long long);
 static const size_t WS_SCANWORK = 640 / sizeof(unsigned long long), WS_DPFRONT = 768 / sizeof(unsigned long long);
 static const size_t WS_DPBACK = 896 / sizeof(unsigned long long);
-// the streaming multi-adapter form's second work list (Multi2RescanArgs): entries, overflow, the two work counters
-static const size_t WS_M2_CNT2 = 320 / sizeof(unsigned long long), WS_M2_OVER = 384 / sizeof(unsigned long long);
-static const size_t WS_M2_WORK2 = 448 / sizeof(unsigned long long), WS_M2_DPWORK2 = 576 / sizeof(unsigned long long);
-// ... and its tile counter, which lives through the rounds of a batch (the rounds clear the header in front of it)
+// the streaming multi-adapter form's tile counter, which lives through the rounds of a batch (the rounds clear the header in front of it)
 static const size_t WS_M2_TILE = 960 / sizeof(unsigned long long);
 static const size_t WS_RETRYCOUNT = 576 / sizeof(unsigned long long), WS_RETRYWORK = 704 / sizeof(unsigned long long);
 static int64_t ws_retry_cap(int64_t n_reads) { return n_reads / 8 + 1024; }
@@ -1085,9 +1082,6 @@ static int64_t multi_pair_cap(const cah_plan* plan, int64_t n_reads) {
     // (a page header word per page lives behind the pages, inside the pair area)
     return std::max(std::min(n_reads * A, limit), pages * CAH_M2_PAGE + pages / 2 + 2);
 }
-// the second work list of the streaming form (Multi2RescanArgs): a quarter of the pair capacity (what does not fit stays
-// in the first list)
-static int64_t multi_rescan_cap(int64_t pair_cap) { return pair_cap / 4 + 1024; }
 static size_t ws_key_bytes(int64_t n_reads) { return (sizeof(unsigned long long) * (size_t)n_reads + 255) & ~(size_t)255; }
 
 // column scratch of k_dp_long: 3 int32 per row and lane, for as many lanes as the kernel is launched with
@@ -1100,8 +1094,7 @@ size_t cah_plan_workspace_bytes(const cah_plan* plan, int64_t n_reads) {
     if (n_reads < 0) n_reads = 0;
     size_t need = cah_workspace_bytes(n_reads);
     if (plan && plan->multi.hdr.ok)
-        need += ws_key_bytes(n_reads) + (size_t)multi_pair_cap(plan, n_reads) * 20 + (size_t)multi_rescan_cap(multi_pair_cap(plan, n_reads)) * 12 +
-                ws_keys_bytes(n_reads) + 256;
+        need += ws_key_bytes(n_reads) + (size_t)multi_pair_cap(plan, n_reads) * 20 + ws_keys_bytes(n_reads) + 256;
     if (plan && plan->max_long_m > 0) need += long_scratch_bytes(plan, long_scratch_lanes(n_reads, 256)) + 256;
     return need;
 }
@@ -1447,9 +1440,6 @@ static int match_batch_multi(const cah_plan* plan, const PlanDeviceCopy* pd, con
     uint64_t* d_pairs = (uint64_t*)extra;                            extra += (size_t)cap * 8;
     int32_t* d_dpq = (int32_t*)extra;                                extra += (size_t)cap * 4;
     int32_t* d_win = (int32_t*)extra;                                extra += (size_t)cap * 8;
-    const int64_t cap2 = multi_rescan_cap(cap);
-    int32_t* d_dpq2 = (int32_t*)extra;                               extra += (size_t)cap2 * 4;
-    int32_t* d_win2 = (int32_t*)extra;                               extra += (size_t)cap2 * 8;
     uint8_t* d_wmeta = (uint8_t*)extra;                              // (streaming form: a byte per read, multi2.h)
     unsigned long long* counters = ws.counters;
     const CahMatcher& m0 = plan->matchers[0];
@@ -1461,7 +1451,6 @@ static int match_batch_multi(const cah_plan* plan, const PlanDeviceCopy* pd, con
         const int64_t max_pages = ((int64_t)cap * 8) / (CAH_M2_PAGE * 8 + 4);
         uint32_t* d_page_hdr = (uint32_t*)(d_pairs + max_pages * CAH_M2_PAGE);
         const int64_t TILE = multi2_tile_reads(), per_tile = m2_pages_per_tile(A), open_pages = 16 * CAH_M2_PAIR_CLASSES;
-        const bool rescan = env_flag("CAH_MULTI_RESCAN");
         // (pairs carry the read's index in 32 bits, the prefilter counts reads in an int)
         const int64_t BLOCK = (int64_t)1 << 30;
         for (int64_t lo = 0; lo < n_reads; lo += BLOCK) {
@@ -1510,24 +1499,8 @@ static int match_batch_multi(const cah_plan* plan, const PlanDeviceCopy* pd, con
                 ProfScope ps(s, CAH_PROF_SCAN, round ? -1 : cnt);
                 HIP_TRY(launch_multi_scan(sa, std::min(max_pages, n_tiles * per_tile + grid * open_pages), pd->n_cus, s));
             }
-            // (off unless CAH_MULTI_RESCAN=1: measured on C4, the second scan costs what it saves the cell DP -- 3.3 ms
-            // against 3.3 ms per 100 M reads, profiles/r04/c4_variants.txt -- so the shorter pipeline is the default)
-            if (rescan) {
-                // the pairs left for the cell DP once more, with the substitution / one-indel bookkeeping: most finish
-                Multi2RescanArgs ra;
-                ra.uniform_first = ul.first; ra.uniform_len = ul.len; ra.kind = scan_word_kind(m0.m);
-                ra.matcher = pd->d_matchers; ra.tab = pd->d_mscan; ra.n_adapters = (int32_t)A;
-                ra.seqs = d_seqs; ra.pairs = d_pairs;
-                ra.in_queue = d_dpq; ra.in_win = d_win;
-                ra.in_count_front = counters + WS_DPFRONT; ra.in_count_back = counters + WS_DPBACK; ra.in_cap = cap;
-                ra.work_counter = counters + WS_M2_WORK2; ra.best_key = d_best_key;
-                ra.out_queue = d_dpq2; ra.out_win = d_win2; ra.out_count = counters + WS_M2_CNT2; ra.out_cap = cap2;
-                ra.overflow = counters + WS_M2_OVER;
-                ProfScope ps(s, CAH_PROF_SCAN, 0);
-                HIP_TRY(launch_multi_rescan(ra, std::min<int64_t>(cap, cnt / 4 + 1024), pd->n_cus, s));
-            }
-            for (int list = rescan ? 2 : 1; list >= 1; list--) {
-                // the cell DP: over the second list, then over what did not fit it (normally nothing: the launch returns)
+            {
+                // the cell DP over the pairs the scan left (the launch returns at once when there are none)
                 DpArgs a;
                 a.uniform_first = ul.first; a.uniform_len = ul.len;
                 a.matcher = pd->d_matchers;
@@ -1537,16 +1510,10 @@ static int match_batch_multi(const cah_plan* plan, const PlanDeviceCopy* pd, con
                 a.out6 = d_out6; a.status = d_status; a.best_adapter = d_best_adapter;
                 a.adapter_index = 0; a.merge_best = 1;
                 a.pairs = d_pairs; a.tab = pd->d_mrow; a.n_adapters = (int32_t)A; a.best_key = d_best_key;
-                if (list == 2) {
-                    a.queue = d_dpq2; a.queue_count = counters + WS_M2_CNT2; a.queue_count_back = nullptr;
-                    a.win = d_win2; a.queue_cap = cap2; a.work_counter = counters + WS_M2_DPWORK2;
-                } else {
-                    a.queue = d_dpq; a.queue_count = counters + WS_DPFRONT; a.queue_count_back = counters + WS_DPBACK;
-                    a.win = d_win; a.queue_cap = cap; a.work_counter = counters + WS_DPWORK;
-                    if (rescan) a.run_flag = counters + WS_M2_OVER;
-                }
-                ProfScope ps(s, CAH_PROF_DP, round ? -1 : (list == 1 ? cnt : 0));
-                HIP_TRY(launch_dp(a, m0.m, true, true, list == 2 ? std::min<int64_t>(cap2, cnt) : std::min(cap, cnt * A), pd->n_cus, s));
+                a.queue = d_dpq; a.queue_count = counters + WS_DPFRONT; a.queue_count_back = counters + WS_DPBACK;
+                a.win = d_win; a.queue_cap = cap; a.work_counter = counters + WS_DPWORK;
+                ProfScope ps(s, CAH_PROF_DP, round ? -1 : cnt);
+                HIP_TRY(launch_dp(a, m0.m, true, true, std::min(cap, cnt * A), pd->n_cus, s));
             }
           }
         }

@@ -84,9 +84,6 @@ struct DpArgs {
     const uint64_t* tab;
     int32_t n_adapters;
     unsigned long long* best_key;
-    // fused mode: queue entries < 0 are skipped (pairs the second cost scan finished or moved, see Multi2RescanArgs), and
-    // the whole launch returns at once when *run_flag == 0 (NULL: always runs)
-    const unsigned long long* run_flag = nullptr;
 };
 
 #define CAH_MULTI_TAB_STRIDE 33   // 32 entries + 1 of padding: spreads the adapters' tables over the LDS banks
@@ -266,33 +263,6 @@ struct Multi2ScanArgs {
     const uint32_t* prefix;          // per adapter: its first ten characters (M2Tables::prefix), for the suffix compare
     int32_t lmax0;                   // the largest overlap without error tolerance
 };
-// k_multi_rescan: the pairs k_multi_scan left for the cell DP (~3 % of all) are scanned once more WITH the
-// substitution / one-indel bookkeeping of back_scan.h (which would cost the first scan a third more per column):
-// most of them -- adapters with sequencing errors -- finish here; the rest move to a second, dense work list.  An entry
-// of the first list that is finished or moved becomes -1; what does not fit the second list stays where it is (overflow).
-struct Multi2RescanArgs {
-    int64_t uniform_first;
-    int32_t uniform_len;
-    int32_t kind;
-    const CahMatcher* matcher;
-    const uint64_t* tab;
-    int32_t n_adapters;
-    const uint8_t* seqs;
-    const uint64_t* pairs;
-    int32_t* in_queue;               // the first list (two-ended, see DpArgs)
-    const int32_t* in_win;
-    const unsigned long long* in_count_front;
-    const unsigned long long* in_count_back;
-    int64_t in_cap;
-    unsigned long long* work_counter;        // zeroed before launch
-    unsigned long long* best_key;
-    int32_t* out_queue;              // the second list (one-ended)
-    int32_t* out_win;
-    unsigned long long* out_count;   // zeroed before launch
-    int64_t out_cap;
-    unsigned long long* overflow;    // zeroed before launch: entries that stayed in the first list
-};
-hipError_t launch_multi_rescan(const Multi2RescanArgs& a, int64_t max_items, int n_cus, hipStream_t s);
 bool multi2_read_len_ok(const CahMulti2Header& h, int read_len);
 size_t multi2_lds_bytes(const CahMulti2Header& h);
 hipError_t launch_multi_stream(const Multi2Args& a, const CahMulti2Header& host_hdr, int grid, hipStream_t s);

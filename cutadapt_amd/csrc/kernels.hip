@@ -1486,7 +1486,6 @@ __device__ __forceinline__ unsigned get_row_packed(const unsigned (&w)[ROWS + 1]
 template <int ROWS, bool MULTI>
 __global__ __launch_bounds__(256, CAH_DPP_WAVES(ROWS)) void k_dp_packed(DpArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint64_t s_rowmask[];     // [128], or [n_adapters * CAH_MULTI_TAB_STRIDE]
-    if (MULTI && a.run_flag && *a.run_flag == 0ull) return;
     if (MULTI && a.queue_count && *a.queue_count == 0ull && (!a.queue_count_back || *a.queue_count_back == 0ull)) return;
     __shared__ int s_ncnt[CAH_MAX_M + 1];
     __shared__ int s_thr[CAH_MAX_M + 1];
@@ -1536,7 +1535,7 @@ __global__ __launch_bounds__(256, CAH_DPP_WAVES(ROWS)) void k_dp_packed(DpArgs a
         unsigned tab_base = 0, adapter = 0;
         if (MULTI) {
             int32_t qi = 0;
-            if (valid) { qi = a.queue[slot]; valid = qi >= 0; }       // (-1: finished or moved by the second cost scan)
+            if (valid) qi = a.queue[slot];
             if (valid) {
                 const uint64_t pr = a.pairs[qi];
                 r = (int64_t)(pr >> 32);

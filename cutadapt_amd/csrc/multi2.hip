@@ -1052,165 +1052,6 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_multi
     }
 }
 
-// =============================================================================================
-// k_multi_rescan (see Multi2RescanArgs, kernels.h): the second cost scan, over the pairs the first left for the cell DP.
-// =============================================================================================
-template <int KIND>
-__global__ __launch_bounds__(256, 4) void k_multi_rescan(Multi2RescanArgs a) {
-    constexpr int XR = KIND >= 2 ? KIND - 1 : 0;
-    constexpr int TILE = 1024;
-    extern __shared__ __attribute__((aligned(16))) uint64_t s_scanmask[];   // [n_adapters * CAH_MULTI_TAB_STRIDE]
-    __shared__ int s_thr_last[CAH_MAX_M + 1];
-    __shared__ int s_list[TILE * 4];               // survivors: (pair index, first column, last column * 2 + scan, slot in the first list)
-    __shared__ int s_in[TILE * 4];                 // the tile's entries, ordered by window start
-    __shared__ unsigned s_bin[16];
-    __shared__ unsigned s_ns;
-    __shared__ long long s_tile;
-    __shared__ unsigned long long s_g;
-    const CahMatcher* mt = a.matcher;
-    for (int i = threadIdx.x; i < a.n_adapters * CAH_MULTI_TAB_STRIDE; i += blockDim.x)
-        s_scanmask[i] = KIND == 0 ? a.tab[i] : bs32_table_entry(a.tab[i], mt->m);
-    for (int i = threadIdx.x; i <= CAH_MAX_M; i += blockDim.x) s_thr_last[i] = mt->thr_last[i];
-    BackScanParams p;
-    p.m = mt->m; p.k = mt->k; p.kacc = mt->kacc; p.min_overlap = mt->min_overlap; p.half_m = mt->m / 2;
-    const int lane = wave_lane();
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int n = a.uniform_len;
-    const int64_t front = (int64_t)(*a.in_count_front);
-    const int64_t total = front + (int64_t)(*a.in_count_back);
-    for (;;) {
-        __syncthreads();
-        if (threadIdx.x == 0) { s_tile = (long long)atomicAdd(a.work_counter, (unsigned long long)TILE); s_ns = 0; }
-        if (threadIdx.x < 16) s_bin[threadIdx.x] = 0;
-        __syncthreads();
-        const int64_t tile_base = s_tile;
-        if (tile_base >= total) break;
-        const int in_tile = (int)min((int64_t)TILE, total - tile_base);
-        // the tile's entries, ordered by the chunk their window starts in (a wave scans from the earliest start of its 64
-        // lanes: neighbours in the list are pairs of one page, not of one window)
-        for (int e = threadIdx.x; e < in_tile; e += blockDim.x) {
-            const int64_t i = tile_base + e;
-            const int64_t slot = i < front ? i : a.in_cap - 1 - (i - front);
-            const int w0 = a.in_win[2 * slot];
-            atomicAdd(&s_bin[min(max(w0, 0) >> 4, 15)], 1u);
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            unsigned run = 0;
-            for (int b = 0; b < 16; ++b) { const unsigned c = s_bin[b]; s_bin[b] = run; run += c; }
-        }
-        __syncthreads();
-        for (int e = threadIdx.x; e < in_tile; e += blockDim.x) {
-            const int64_t i = tile_base + e;
-            const int64_t slot = i < front ? i : a.in_cap - 1 - (i - front);
-            const int w0 = a.in_win[2 * slot];
-            const unsigned at = atomicAdd(&s_bin[min(max(w0, 0) >> 4, 15)], 1u);
-            s_in[4 * at] = a.in_queue[slot]; s_in[4 * at + 1] = w0; s_in[4 * at + 2] = a.in_win[2 * slot + 1]; s_in[4 * at + 3] = (int)slot;
-        }
-        __syncthreads();
-        for (int sub = wave; sub * WAVE < in_tile; sub += 4) {
-            const int e = sub * WAVE + lane;
-            bool valid = e < in_tile;
-            int32_t qi = 0, w0 = 0, w1 = 0;
-            int64_t slot = 0;
-            if (valid) { qi = s_in[4 * e]; w0 = s_in[4 * e + 1]; w1 = s_in[4 * e + 2]; slot = s_in[4 * e + 3]; valid = qi >= 0; }
-            int64_t r = 0;
-            unsigned tab_base = 0, adapter = 0;
-            if (valid) {
-                const uint64_t pr = a.pairs[qi];
-                r = (int64_t)(pr >> 32);
-                adapter = (unsigned)(pr >> 8) & 0xFFFFu;
-                tab_base = adapter * CAH_MULTI_TAB_STRIDE;
-            }
-            const uint8_t* q = a.seqs + a.uniform_first + r * (int64_t)n;
-            // from the earliest DP window of the wave (an earlier start is as exact) to the read's end
-            int j0 = valid ? bs_align_window(min(w0, n), n) : n;
-#pragma unroll
-            for (int sft = 1; sft < WAVE; sft <<= 1) j0 = min(j0, __shfl_xor(j0, sft, WAVE));
-            j0 = __builtin_amdgcn_readfirstlane(j0);
-            auto eq_of = [&](const Chunk& ck, int t) -> uint64_t {
-                return s_scanmask[tab_base + multi_tab_index2(chunk_byte(ck, t) & 0xFFu)];
-            };
-            typename std::conditional<KIND == 0, BackScanState, BackScanState32<XR>>::type st;
-            if constexpr (KIND == 0) bs_init(st, p); else bs32_init(st, p);
-            auto step = [&](const uint64_t eq, const int jj) -> bool {
-                if constexpr (KIND == 0) return bs_step<true>(st, eq, jj, p);
-                else return bs32_step<true, XR>(st, (uint32_t)eq, (uint32_t)(eq >> 32), jj, p);
-            };
-            int j = j0, exact_j = 0;
-            bool exact = false;
-            int pos = j0;
-            Chunk cur = load_chunk(q, pos, n, valid ? n : 0);
-            while (j < n) {
-                const Chunk nxt = load_chunk(q, pos + 16, n, valid ? n : 0);
-                const int last_t = min(16, n - pos);
-                if (last_t == 16) {
-                    uint64_t eqq[2];
-                    eqq[0] = eq_of(cur, 0);
-                    eqq[1] = eq_of(cur, 1);
-#pragma unroll
-                    for (int t = 0; t < 16; ++t) {
-                        const uint64_t eq = eqq[t & 1];
-                        if (t + 2 < 16) eqq[t & 1] = eq_of(cur, t + 2);
-                        ++j;
-                        if (step(eq, j) && !exact) { exact = true; exact_j = j; }
-                    }
-                } else {
-#pragma unroll 1
-                    for (int t = 0; t < last_t; ++t) {
-                        ++j;
-                        if (step(eq_of(cur, t), j) && !exact) { exact = true; exact_j = j; }
-                    }
-                }
-                pos += 16;
-                cur = nxt;
-            }
-            int o0 = 0, o1 = 0;
-            int cls;
-            if constexpr (KIND == 0) cls = bs_finish<true>(st, n, j0, p, [&](int i2) { return s_thr_last[i2]; }, o0, o1, false);
-            else cls = bs32_finish<XR, true>(st, n, j0, p, [&](int i2) { return s_thr_last[i2]; }, o0, o1, false);
-            if (exact) { cls = BS_EXACT_FULL; o0 = exact_j; }
-            if (valid) {
-                if (cls == BS_EXACT_FULL) atomicMax(a.best_key + r, pack_best(p.m, 0, (int)adapter, p.m, o0 - p.m, o0));
-                else if (cls == BS_EXACT_TAIL) atomicMax(a.best_key + r, pack_best(o0 - 2 * o1, o1, (int)adapter, o0, n - o0, n));
-                else if (cls == BS_SUBS_FULL) atomicMax(a.best_key + r, pack_best(p.m - 2 * o1, o1, (int)adapter, p.m, o0 - p.m, o0));
-                else if (cls == BS_INDEL1_FULL)
-                    atomicMax(a.best_key + r, pack_best(p.m - 2 * (o1 >> 1) - (o1 & 1), o1 >> 1, (int)adapter, p.m,
-                                                        o0 - p.m + ((o1 & 1) ? 1 : -1), o0));
-                if (cls != BS_DP) a.in_queue[slot] = -1;                // finished
-            }
-            // survivors keep the window the first scan gave them
-            const bool keep = valid && cls == BS_DP;
-            const unsigned long long bk = __ballot(keep);
-            if (bk) {
-                unsigned sb = 0;
-                if (lane == 0) sb = atomicAdd(&s_ns, (unsigned)__popcll(bk));
-                sb = __builtin_amdgcn_readfirstlane(sb);
-                if (keep) {
-                    const int e = (int)sb + __popcll(bk & ((1ull << lane) - 1ull));
-                    s_list[4 * e] = qi; s_list[4 * e + 1] = w0; s_list[4 * e + 2] = w1; s_list[4 * e + 3] = (int)slot;
-                }
-            }
-        }
-        __syncthreads();
-        const unsigned ns = s_ns;
-        if (threadIdx.x == 0) s_g = ns ? atomicAdd(a.out_count, (unsigned long long)ns) : 0ull;
-        __syncthreads();
-        const unsigned long long g = s_g;
-        for (unsigned e = threadIdx.x; e < ns; e += blockDim.x) {
-            const int64_t os = (int64_t)(g + e);
-            if (os < a.out_cap) {
-                a.out_queue[os] = s_list[4 * e];
-                a.out_win[2 * os] = s_list[4 * e + 1];
-                a.out_win[2 * os + 1] = s_list[4 * e + 2];
-                a.in_queue[s_list[4 * e + 3]] = -1;                     // moved
-            } else {
-                atomicAdd(a.overflow, 1ull);                            // stays in the first list
-            }
-        }
-    }
-}
-
 // ---- launchers ----------------------------------------------------------------------------------------------------
 size_t multi2_lds_bytes(const CahMulti2Header& h) { return m2_layout((int)h.n_entries, h.n_adapters).total; }
 
@@ -1257,21 +1098,6 @@ hipError_t launch_multi_scan(const Multi2ScanArgs& a, int64_t max_pages, int n_c
         case 2: hipLaunchKernelGGL((k_multi_scan<2>), grid, dim3(256), lds, s, a); break;
         case 3: hipLaunchKernelGGL((k_multi_scan<3>), grid, dim3(256), lds, s, a); break;
         default: hipLaunchKernelGGL((k_multi_scan<0>), grid, dim3(256), lds, s, a); break;
-    }
-    return hipGetLastError();
-}
-
-hipError_t launch_multi_rescan(const Multi2RescanArgs& a, int64_t max_items, int n_cus, hipStream_t s) {
-    int64_t need = (max_items + 1023) / 1024;
-    if (need < 1) need = 1;
-    const int64_t cap = (int64_t)4 * n_cus;
-    const dim3 grid((unsigned)(need < cap ? need : cap));
-    const size_t lds = sizeof(uint64_t) * (size_t)a.n_adapters * CAH_MULTI_TAB_STRIDE;
-    switch (a.kind) {
-        case 1: hipLaunchKernelGGL((k_multi_rescan<1>), grid, dim3(256), lds, s, a); break;
-        case 2: hipLaunchKernelGGL((k_multi_rescan<2>), grid, dim3(256), lds, s, a); break;
-        case 3: hipLaunchKernelGGL((k_multi_rescan<3>), grid, dim3(256), lds, s, a); break;
-        default: hipLaunchKernelGGL((k_multi_rescan<0>), grid, dim3(256), lds, s, a); break;
     }
     return hipGetLastError();
 }
