@@ -76,6 +76,66 @@ class _PinnedPool:
                 self._free.append(buf)
 
 
+class _PinnedInputPool:
+    """pinned INPUT buffers as numpy arrays (what a file reader fills), each backed by a pinned torch tensor: a reader that
+    fills them hands the device copy its source directly -- no staging copy through a worker's own pinned buffer.  Same
+    interface as pipeline.POOL (views go back as their owning buffer)."""
+
+    def __init__(self, max_free: int = 64):
+        self._free: list = []
+        self._owner: dict = {}                                # id(root array) -> (root array, pinned tensor)
+        self._lock = threading.Lock()
+        self._max_free = max_free
+
+    @staticmethod
+    def _root(arr):
+        while isinstance(arr, np.ndarray) and isinstance(arr.base, np.ndarray):
+            arr = arr.base
+        return arr
+
+    def get(self, nbytes: int) -> np.ndarray:
+        import torch
+        with self._lock:
+            best = -1
+            for i, a in enumerate(self._free):
+                if len(a) >= nbytes and (best < 0 or len(a) < len(self._free[best])):
+                    best = i
+            if best >= 0:
+                return self._free.pop(best)
+        t = torch.empty(max(int(nbytes), 1), dtype=torch.uint8).pin_memory()
+        a = t.numpy()
+        with self._lock:
+            self._owner[id(a)] = (a, t)
+        return a
+
+    def put(self, arr) -> None:
+        root = self._root(arr)
+        with self._lock:
+            if id(root) not in self._owner:
+                return
+            if len(self._free) >= self._max_free:
+                # full: the smallest buffer goes (a job with larger blocks would otherwise pin new memory for every block)
+                small = min(range(len(self._free)), key=lambda i: len(self._free[i]))
+                if len(self._free[small]) >= len(root):
+                    del self._owner[id(root)]
+                    return
+                del self._owner[id(self._free.pop(small))]
+            self._free.append(root)
+
+    def tensor_of(self, arr):
+        """the pinned tensor view over the bytes of ``arr`` (an array, or a view of one, this pool handed out)"""
+        root = self._root(arr)
+        with self._lock:
+            owner = self._owner.get(id(root))
+        if owner is None:
+            return arr
+        off = arr.ctypes.data - root.ctypes.data
+        return owner[1][off:off + len(arr)]
+
+
+_PINNED_INPUT = _PinnedInputPool()
+
+
 class _Worker:
     """one stream + its (grow-only) buffers on one device; a chunk costs a dozen library calls, no allocation"""
 
@@ -1256,15 +1316,17 @@ class _LineFeedIndex:
         raise AssertionError("fewer records in the block than asked for")
 
 
-def _paired_pieces(source1, source2, chunk_bytes: int, threads: int = 4):
+def _paired_pieces(source1, source2, chunk_bytes: int, threads: int = 4, pool=None):
     """pairs of raw 4-line-FASTQ pieces with the SAME number of records (the job of dnaio.read_paired_chunks,
     reference runners.py:104-113) -- found by counting line feeds (cah_fastq_span: nothing is parsed): each side is
     read in blocks into a pooled buffer, the side with fewer complete records decides, the surplus of the other side
     is carried over.  The two sides are loaded side by side, and each side's block is read (``preadv`` at explicit
     offsets, plain files) and counted by ``threads`` threads: one thread reads the page cache at a few GB/s and counts
     at ~10, which made this reader the bound of the paired pipeline.
-    The pieces are views of pooled buffers: hand them back (pipeline.POOL.put) when done."""
-    from .pipeline import POOL, _open_maybe_gz
+    The pieces are views of pooled buffers: hand them back (``pool.put``; pipeline.POOL unless another pool is given --
+    the all-device way passes pinned buffers, _PinnedInputPool) when done."""
+    from .pipeline import POOL as _DEFAULT_POOL, _open_maybe_gz
+    POOL = pool if pool is not None else _DEFAULT_POOL
     L = _lib.lib()
     plain = [_is_plain_file(source1), _is_plain_file(source2)]
     files = [open(src, "rb", buffering=0) if pl else _open_maybe_gz(src) for src, pl in zip((source1, source2), plain)]
@@ -1288,33 +1350,66 @@ def _paired_pieces(source1, source2, chunk_bytes: int, threads: int = 4):
                 raise OSError("short read: the file shrank while it was read")
             done += got
 
+    # Plain files: the NEXT block of a side is read (into a fresh buffer, behind HEAD spare bytes) while the current one is
+    # counted and cut -- the carried-over bytes are put in front of it afterwards.  Reading and counting took turns before
+    # (profiles/r04/paired_stages.json: the reader alone was the pair pipeline's bound, 25-30 GB/s of 40).
+    HEAD = min(4 << 20, max(4096, chunk_bytes))
+    fetchers = ThreadPoolExecutor(max_workers=2)
+    ahead = [None, None]
+    waiting = [0, 0]                                         # whole records in what was carried over
+
+    def fetch(k):
+        """-> (buffer, bytes read behind HEAD, that was the file's last block)"""
+        want = min(chunk_bytes, sizes[k] - offsets[k])
+        if want <= 0:
+            return None, 0, True
+        buf = POOL.get(HEAD + chunk_bytes)
+        view = memoryview(buf)[HEAD:HEAD + want]
+        step = max(1 << 20, -(-want // threads))
+        list(helpers.map(lambda a: read_range(k, view[a:a + step], offsets[k] + a), range(0, want, step)))
+        offsets[k] += want
+        return buf, want, offsets[k] >= sizes[k]
+
     def load_side(k):
         """the next block of file k behind what was carried over, and how many whole records that is"""
-        buf = POOL.get(len(carry[k]) + chunk_bytes)
-        fill = len(carry[k])
-        buf[:fill] = carry[k]
-        if not eof[k] and plain[k]:
-            want = min(chunk_bytes, sizes[k] - offsets[k])
-            if want <= 0:
-                eof[k] = True
+        if plain[k] and not eof[k] and waiting[k] > 0 and len(carry[k]) >= chunk_bytes:
+            # (this side is a block ahead already, with whole records waiting -- its records are smaller than the other
+            # file's: no new block now)
+            d = carry[k]
+            fill = len(d)
+        elif plain[k]:
+            buf, want, last = (ahead[k] or fetchers.submit(fetch, k)).result() if not eof[k] else (None, 0, True)
+            eof[k] = last
+            ahead[k] = None if last else fetchers.submit(fetch, k)
+            keep = len(carry[k])
+            if buf is None:
+                d = carry[k]
+            elif keep <= HEAD:
+                buf[HEAD - keep:HEAD] = carry[k]
+                d = buf[HEAD - keep:HEAD + want]
             else:
-                view = memoryview(buf)[fill:fill + want]
-                step = max(1 << 20, -(-want // threads))
-                list(helpers.map(lambda a: read_range(k, view[a:a + step], offsets[k] + a), range(0, want, step)))
-                offsets[k] += want
-                fill += want
-                eof[k] = offsets[k] >= sizes[k]
-        elif not eof[k]:
-            view = memoryview(buf)[fill:fill + chunk_bytes]
-            got = files[k].readinto(view) if hasattr(files[k], "readinto") else None
-            if got is None:
-                block = files[k].read(chunk_bytes)
-                got = len(block)
-                buf[fill:fill + got] = np.frombuffer(block, dtype=np.uint8)
-            if got == 0:
-                eof[k] = True
-            fill += got
-        d = buf[:fill]
+                # (the two files' records differ so much in size that one side piles up: copy)
+                big = POOL.get(keep + want)
+                big[:keep] = carry[k]
+                big[keep:keep + want] = buf[HEAD:HEAD + want]
+                POOL.put(buf)
+                d = big[:keep + want]
+            fill = len(d)
+        else:
+            buf = POOL.get(len(carry[k]) + chunk_bytes)
+            fill = len(carry[k])
+            buf[:fill] = carry[k]
+            if not eof[k]:
+                view = memoryview(buf)[fill:fill + chunk_bytes]
+                got = files[k].readinto(view) if hasattr(files[k], "readinto") else None
+                if got is None:
+                    block = files[k].read(chunk_bytes)
+                    got = len(block)
+                    buf[fill:fill + got] = np.frombuffer(block, dtype=np.uint8)
+                if got == 0:
+                    eof[k] = True
+                fill += got
+            d = buf[:fill]
         if fill and d[0] == ord(">"):
             raise ValueError("the device-side path reads 4-line FASTQ; use pipeline.trim_fastq_paired for FASTA")
         if eof[k] or fill < 2 * _LineFeedIndex.MIN_PART:
@@ -1354,6 +1449,7 @@ def _paired_pieces(source1, source2, chunk_bytes: int, threads: int = 4):
                         POOL.put(d)
                     raise ValueError("record larger than 64 chunks: not a FASTQ file?")
                 carry = [d.copy() for d in data]
+                waiting = list(counts)
                 for d in data:
                     POOL.put(d)
                 continue
@@ -1366,9 +1462,17 @@ def _paired_pieces(source1, source2, chunk_bytes: int, threads: int = 4):
                 else:
                     cuts.append(span(d, eof[k], n)[1])
             carry = [data[0][cuts[0]:].copy(), data[1][cuts[1]:].copy()]
+            waiting = [counts[0] - n, counts[1] - n]
             yield data[0][:cuts[0]], data[1][:cuts[1]]
     finally:
+        for fut in ahead:
+            if fut is not None:
+                try:
+                    POOL.put(fut.result()[0])
+                except Exception:
+                    pass
         sides.shutdown(wait=True)
+        fetchers.shutdown(wait=True)
         helpers.shutdown(wait=True)
         for f, src in zip(files, (source1, source2)):
             if f is not src:
@@ -1426,6 +1530,7 @@ def _paired_all_device(in1, in2, out1, out2, mates, job, discard_untrimmed, disc
         w.mate = mate
         with torch.cuda.stream(w.stream):
             w.pair_counts = torch.zeros(8, dtype=torch.int64, device=w.device)   # kept, too short, too long, too many ee, bp out 1 / 2
+        w.stage_s = [0.0, 0.0, 0.0]        # host seconds in: load (copy to HBM, line count, index) / trim + match + pair filter (queued) / format + copy back
         return w
 
     def combine(preds, how):
@@ -1447,9 +1552,12 @@ def _paired_all_device(in1, in2, out1, out2, mates, job, discard_untrimmed, disc
         try:
             with torch.cuda.stream(w.stream):
                 ws = (w, w.mate)
-                n = w.load(d1)
-                if w.mate.load(d2) != n:
+                # (the reader filled pinned buffers: they are the device copies' sources as they are)
+                n = w.load(_PINNED_INPUT.tensor_of(d1))
+                if w.mate.load(_PINNED_INPUT.tensor_of(d2)) != n:
                     raise ValueError("Reads are improperly paired")
+                t1_ = time.perf_counter()
+                w.stage_s[0] += t1_ - t0
                 if n == 0:
                     return b"", b"", [], w
                 ee = [ww.modify(n, pre, post, None) for ww, (_, pre, post, _t) in zip(ws, mates)]
@@ -1472,16 +1580,18 @@ def _paired_all_device(in1, in2, out1, out2, mates, job, discard_untrimmed, disc
                 for k, ww in enumerate(ws):
                     w.pair_counts[4 + k] += (lens[k] * keep).sum()
                     ww.keep[:n].copy_(keep.to(torch.uint8))
+                t2_ = time.perf_counter()
+                w.stage_s[1] += t2_ - t1_
                 h1, t1 = w.finish(d1, n, w.n_bytes)
                 h2, t2 = w.mate.finish(d2, n, w.mate.n_bytes)
+                w.stage_s[2] += time.perf_counter() - t2_
                 return memoryview(h1.numpy())[:t1], memoryview(h2.numpy())[:t2], [h1, h2], w
         finally:
             w.busy_s += time.perf_counter() - t0
             w.chunks += 1
             w.bytes_in += len(d1) + len(d2)
-            from .pipeline import POOL
-            POOL.put(d1)
-            POOL.put(d2)                                     # the reader's buffers are free again
+            _PINNED_INPUT.put(d1)
+            _PINNED_INPUT.put(d2)                            # the reader's buffers are free again
 
     feeders = [_Feeder(dev, threads, len(devices) > 1, make_worker) for dev in devices]
     o1 = out1 if hasattr(out1, "write") else open(out1, "wb")
@@ -1498,10 +1608,23 @@ def _paired_all_device(in1, in2, out1, out2, mates, job, discard_untrimmed, disc
                 b1 = b2 = None
                 for b in bufs:
                     w.pool.put(b)
-        for i, (d1, d2) in enumerate(_paired_pieces(in1, in2, chunk_bytes)):
-            pending.append(feeders[i % len(feeders)].submit(work, d1, d2))
+        reader_s = drain_s = 0.0
+        pieces = _paired_pieces(in1, in2, chunk_bytes, pool=_PINNED_INPUT)
+        i = 0
+        while True:
+            t_a = time.perf_counter()
+            piece = next(pieces, None)
+            t_b = time.perf_counter()
+            reader_s += t_b - t_a
+            if piece is None:
+                break
+            pending.append(feeders[i % len(feeders)].submit(work, *piece))
+            i += 1
             drain(2 * threads * len(feeders))
+            drain_s += time.perf_counter() - t_b
+        t_b = time.perf_counter()
         drain(0)
+        drain_s += time.perf_counter() - t_b
     finally:
         for f in feeders:
             f.close()
@@ -1526,7 +1649,12 @@ def _paired_all_device(in1, in2, out1, out2, mates, job, discard_untrimmed, disc
               "quality_trimmed_bases": (int(removed[0][1]), int(removed[1][1])),
               "nextseq_trimmed_bases": (int(removed[0][0]), int(removed[1][0])), "reverse_complemented": None,
               "devices_used": sorted({str(w.device) for w in workers}), "per_device": _per_device(feeders, wall),
-              "way": "all-device"}
+              "way": "all-device",
+              # where the wall time goes: the main thread alternates between the reader (both files read and cut into
+              # pieces of equal record counts) and handing over / writing results; the workers' host seconds by stage
+              "stages": {"wall_s": wall, "reader_s": reader_s, "submit_and_write_s": drain_s, "workers": len(workers),
+                         "worker_load_s": sum(w.stage_s[0] for w in workers), "worker_trim_s": sum(w.stage_s[1] for w in workers),
+                         "worker_format_s": sum(w.stage_s[2] for w in workers)}}
     for w in workers:
         mate, w.mate = w.mate, None
         mate.stream = torch.cuda.Stream(device=mate.device)      # (it shared its partner's)
@@ -1614,10 +1742,23 @@ def trim_fastq_gpu_paired(in1, in2, out1, out2, r1: Optional[dict] = None, r2: O
                 b1 = b2 = None
                 for b in bufs:
                     w.pool.put(b)
-        for i, (d1, d2) in enumerate(_paired_pieces(in1, in2, chunk_bytes)):
-            pending.append(feeders[i % len(feeders)].submit(work, d1, d2))
+        reader_s = drain_s = 0.0
+        pieces = _paired_pieces(in1, in2, chunk_bytes, pool=_PINNED_INPUT)
+        i = 0
+        while True:
+            t_a = time.perf_counter()
+            piece = next(pieces, None)
+            t_b = time.perf_counter()
+            reader_s += t_b - t_a
+            if piece is None:
+                break
+            pending.append(feeders[i % len(feeders)].submit(work, *piece))
+            i += 1
             drain(2 * threads * len(feeders))
+            drain_s += time.perf_counter() - t_b
+        t_b = time.perf_counter()
         drain(0)
+        drain_s += time.perf_counter() - t_b
     finally:
         for f in feeders:
             f.close()
