@@ -19,6 +19,15 @@
 //   * a pair is emitted once (LDS bitsets `seen` / `wide only` per read and adapter) into a PAGE of its class: pages of
 //     1024 pairs from a device-wide pool, owned by one wave, one class of pairs per page -- the scan's waves then hold 64
 //     pairs of one window shape.  Pairs that only the error-free rows can match are decided here (suffix compare).
+//   * a whole-read pair whose first hit is ONE chunk of the adapter's k + 1 carries that occurrence (position, chunk):
+//     if it stays the pair's only hit -- a byte per read tells -- the scan needs the ~40 columns around it only
+//     (CAH_M2_PAIR_PRECISE, multi2.h);
+//   * tiles of 1024 reads are drawn from one counter of the batch, and only while the page pool holds what the tiles in
+//     flight could ask for in the worst case: a launch that stops early is followed by another ROUND over the rest
+//     (api.cpp: match_batch_multi) -- a typical batch takes one round whatever the worst case would need.
+// k_multi_scan orders a whole-read page's pairs by their windows before it scans them, runs full-window waves with the
+// substitution / one-indel bookkeeping (most adapters with sequencing errors finish there, not in the cell DP) and tail
+// pages as the bare recurrence (lo pages: the adapter's first 32 rows in one 32-bit word).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
