@@ -166,10 +166,13 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
         const unsigned long long t = atomicAdd(a.tile_counter, 1ull);
         return t < (unsigned long long)a.n_tiles ? (unsigned)t : M2_NO_TILE;
     };
+    // (LDS keeps what the last block on this CU left: an entry of ITS map must not pass for one of ours)
+    if (threadIdx.x < M2_TILE_RING) s_tilemap[threadIdx.x] = ~0ull;
     if (threadIdx.x == 0) {
         *s_next_piece = M2_WAVES;
         const unsigned t0 = draw_tile();
-        const unsigned t1 = t0 == M2_NO_TILE ? M2_NO_TILE : draw_tile();
+        // (a batch of no more tiles than blocks: one tile each, none drawn ahead)
+        const unsigned t1 = (t0 == M2_NO_TILE || a.n_tiles <= (int64_t)gridDim.x) ? M2_NO_TILE : draw_tile();
         s_tilemap[0] = (unsigned long long)t0;
         s_tilemap[1] = (1ull << 32) | t1;
     }
