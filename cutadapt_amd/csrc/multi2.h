@@ -65,6 +65,8 @@ enum { M2_W = 0, M2_HI = 1, M2_LO = 2, M2_SHORT = 3 };
 // offset of chunk c in the adapter): the scan runs from f - E_c - k - 1 to that end, no further candidate follows, and
 // of the last column's rows only the error-free overlaps can be acceptable (a row with tolerance e >= 1 needs a hit of a
 // tail class) -- the suffix compare m2_exact_tail decides those.
+// Such a pair also carries, in bits 16..19 of its record, the 16-column chunk of the first event of the round that emitted it:
+// where its full window starts when it does NOT stay the only hit (every hit of the round lies at or behind that chunk).
 #define CAH_M2_PAIR_PRECISE 2u
 #define CAH_M2_PAIR_CHUNK_SHIFT 2
 #define CAH_M2_NO_FLAG 255u
@@ -208,7 +210,7 @@ inline bool m2_build(const std::vector<std::string>& adapters, const int32_t* th
     h.n_adapters = A; h.m = m; h.k = k; h.min_overlap = min_overlap; h.lmax0 = lmax0;
     h.rows_lo = lmax0;
     for (const Tail& tl : tails) if (tl.e == 1) h.rows_lo = tl.lmax;
-    struct Ent { std::string kmer; int adapter; int cls; int ref_L; int wide_L; };
+    struct Ent { std::string kmer; int adapter; int cls; int ref_L; int wide_L; bool tail_role; };   // tail_role: the k-mer is a tail-class chunk or a REF tail k-mer too
     std::vector<Ent> ents;
     auto find = [&](int a, const std::string& s) -> Ent* {
         for (Ent& e : ents) if (e.adapter == a && e.kmer == s) return &e;
@@ -224,9 +226,10 @@ inline bool m2_build(const std::vector<std::string>& adapters, const int32_t* th
                 if (ents[i].kmer == s) {
                     ents[i].cls = std::min(ents[i].cls, cls);
                     ents[i].wide_L = std::max(ents[i].wide_L, wide_L);
+                    ents[i].tail_role = ents[i].tail_role || cls != M2_W;
                     return true;
                 }
-            ents.push_back({s, a, cls, 0, wide_L});
+            ents.push_back({s, a, cls, 0, wide_L, cls != M2_W});
             return true;
         };
         // a last-row candidate (cost <= kacc) holds one of the k + 1 chunks of the whole adapter
@@ -243,7 +246,8 @@ inline bool m2_build(const std::vector<std::string>& adapters, const int32_t* th
             if (rk.window != CAH_M2_WHOLE && (rk.window < 1 || rk.window >= CAH_M2_WHOLE - 16)) return false;
             Ent* e = nullptr;
             for (size_t i = first; i < ents.size(); i++) if (ents[i].kmer == rk.kmer) e = &ents[i];
-            if (!e) { ents.push_back({rk.kmer, a, M2_SHORT, 0, 0}); e = &ents.back(); }
+            if (!e) { ents.push_back({rk.kmer, a, M2_SHORT, 0, 0, true}); e = &ents.back(); }
+            if (rk.window != CAH_M2_WHOLE) e->tail_role = true;
             // (several windows of one k-mer: the widest counts, as the reference's own dedup does, kmer_heuristic.py:29-64)
             if (rk.window == CAH_M2_WHOLE || e->ref_L == CAH_M2_WHOLE) e->ref_L = CAH_M2_WHOLE;
             else e->ref_L = std::max(e->ref_L, rk.window);
@@ -270,7 +274,9 @@ inline bool m2_build(const std::vector<std::string>& adapters, const int32_t* th
         // which whole-adapter chunk is it?  (no answer when the string is two of them, or occurs elsewhere in the adapter
         // too: an alignment could then hold the occurrence at another offset)
         uint8_t wend = 0;
-        if (e.cls == M2_W && e.wide_L == CAH_M2_WHOLE && kacc + 1 <= 4) {
+        // ... and no answer when the string is a chunk of a tail class as well: its occurrence near the read's end then
+        // stands for rows of the last column too, which the window of one occurrence does not look at
+        if (e.cls == M2_W && e.wide_L == CAH_M2_WHOLE && !e.tail_role && kacc + 1 <= 4) {
             const std::string& ad = adapters[(size_t)e.adapter];
             const std::vector<std::string> ch = m2_chunks(ad, kacc + 1);
             int which = -1, times = 0;

@@ -421,7 +421,10 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
                     const unsigned we = (cls == M2_W && !whole) ? m2_precise_chunk(e.meta) : 0u;
 #endif
                     unsigned lo = whole ? ((unsigned)pc_whole << 28) : lo_cls;
-                    if (we) lo = (2u << 28) | ((CAH_M2_PAIR_PRECISE | ((we - 1u) << CAH_M2_PAIR_CHUNK_SHIFT)) << 24) | (unsigned)p;
+                    // (bits 16..19: the chunk of the round's first event -- where the pair's full window starts if it does not
+                    // stay the pair's only hit: the lane that emits a pair need not hold its EARLIEST occurrence of the round)
+                    if (we) lo = (2u << 28) | ((CAH_M2_PAIR_PRECISE | ((we - 1u) << CAH_M2_PAIR_CHUNK_SHIFT)) << 24) |
+                                 ((unsigned)(p_head >> 4) << 16) | (unsigned)p;
                     lo |= (unsigned)adapter << 8;
                     s_ring[(stage0 + staged + m2_rank(em)) & (M2_RING - 1)] = (m2_u32x2){lo, rd};
                 }
@@ -804,7 +807,7 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_multi
                 if (e0 < count) {
                     const uint64_t pr = a.pairs[page * CAH_M2_PAGE + e0];
                     const unsigned flags = (unsigned)(pr >> 24) & 0xFFu, key = (unsigned)pr & 0xFFu;
-                    const unsigned adapter = (unsigned)(pr >> 8) & 0xFFFFu;
+                    const unsigned adapter = (unsigned)(pr >> 8) & 0xFFu, head = (unsigned)(pr >> 16) & 0xFFu;
                     const int64_t r = (int64_t)(pr >> 32);
                     int j0w = max(0, ((int)key << CAH_KEY_SHIFT) - p.m - p.k - 1), jb = n;
                     unsigned precise = 0, tail0 = 0;
@@ -821,7 +824,7 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_multi
                             for (int c = 6; c < 16; ++c) rlast = (rlast << 3) | (uint32_t)s_xlat[chunk_byte(tl, c) & 127u];
                             tail0 = (unsigned)m2_exact_tail(rlast, s_prefix[adapter], p.min_overlap, a.lmax0, n);
                         } else {
-                            j0w = max(0, ((int)key & ~15) - p.m - p.k - 1);       // (flagged: the window of a whole-read pair)
+                            j0w = max(0, (int)(head << 4) - p.m - p.k - 1);       // (flagged: the window of a whole-read pair)
                         }
                     }
                     j0w = min(j0w, n);
@@ -868,12 +871,14 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_multi
             const int64_t idx = page * CAH_M2_PAGE + e0;
             int64_t r = 0;
             unsigned tab_base = 0, adapter = 0, key = 0;
+            uint32_t pair_low = 0;
             if (valid) {
                 const uint64_t pr = a.pairs[idx];
                 r = (int64_t)(pr >> 32);
-                adapter = (unsigned)(pr >> 8) & 0xFFFFu;
+                adapter = (unsigned)(pr >> 8) & 0xFFu;
                 key = (unsigned)pr & 0xFFu;
                 tab_base = adapter * CAH_MULTI_TAB_STRIDE;
+                pair_low = (uint32_t)pr;
             }
             const uint8_t* q = a.seqs + a.uniform_first + r * (int64_t)n;
             // A tail page's pairs all have the same window (one class, one read length), from column 4 * key: the scan
@@ -1021,6 +1026,8 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_multi
             // scan are only proven equal to the reference's from column start + m + k + 1 on (column skipping)
             if (cls == BS_DP && tail_page) o0 = max(0, (jfa >= 0 ? jfa : n) - reach);
             const bool to_dp = valid && cls == BS_DP;
+            // (k_dp_packed reads the adapter as bits 8..23 of the pair: the chunk of the round's first event goes)
+            if (to_dp && (pair_low & 0x00FF0000u)) const_cast<uint64_t*>(a.pairs)[idx] = ((uint64_t)r << 32) | (pair_low & 0xFF00FFFFu);
             const bool to_back = to_dp && (o1 & 1);
             const bool to_front = to_dp && !(o1 & 1);
             const unsigned long long bf = __ballot(to_front), bb = __ballot(to_back);

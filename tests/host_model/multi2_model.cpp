@@ -22,7 +22,7 @@ static inline unsigned long long pack_best(int score, int errors, int adapter, i
 
 namespace {
 
-struct Pair { int adapter; unsigned flags; int key; };
+struct Pair { int adapter; unsigned flags; int key; int cls = M2_W; };   // cls: the class the pair was emitted in (the kernel: its page's)
 
 struct ReadState {
     bool seen[128], wideonly[128];
@@ -54,8 +54,8 @@ void resolve(const M2Tables& t, ReadState& st, uint32_t r, int qc, int cls, int 
         else if (cls == M2_W && m2_precise_chunk(meta))
             st.pairs.push_back({a, CAH_M2_PAIR_PRECISE | ((m2_precise_chunk(meta) - 1u) << CAH_M2_PAIR_CHUNK_SHIFT), p});
         else if (cls == M2_W) st.pairs.push_back({a, 0u, std::min((p & ~15) >> CAH_KEY_SHIFT, CAH_QUEUE_BINS - 1)});
-        else if (cls == M2_HI) st.pairs.push_back({a, CAH_M2_PAIR_TAIL, std::max(0, n - h.win_dist[M2_HI]) >> 2});
-        else if (cls == M2_LO) st.pairs.push_back({a, CAH_M2_PAIR_TAIL, std::max(0, n - h.win_dist[M2_LO]) >> 2});
+        else if (cls == M2_HI) st.pairs.push_back({a, CAH_M2_PAIR_TAIL, std::max(0, n - h.win_dist[M2_HI]) >> 2, M2_HI});
+        else if (cls == M2_LO) st.pairs.push_back({a, CAH_M2_PAIR_TAIL, std::max(0, n - h.win_dist[M2_LO]) >> 2, M2_LO});
         else {
             const int i = m2_exact_tail(rlast, t.prefix[(size_t)a], h.min_overlap, h.lmax0, n);
             if (i > 0) st.exact.push_back({a, i});
@@ -162,7 +162,7 @@ int m2m_match_batch(const char* adapters, int A, int m, const void* blobs, int32
             }
             // rows above this cannot be acceptable (k_multi_scan does not look at them)
             int max_row = std::min(p.m, n - std::min(j0, n) + p.kacc);
-            const bool is_lo = tail && pr.key == (std::max(0, n - t.hdr.win_dist[M2_LO]) >> 2) && t.hdr.win_dist[M2_LO] != t.hdr.win_dist[M2_HI];
+            const bool is_lo = tail && pr.cls == M2_LO;
             if (is_lo) max_row = std::min(max_row, t.hdr.rows_lo);
             j0 = bs_align_window(std::min(j0, n), n);
             if (precise) {
@@ -172,7 +172,7 @@ int m2m_match_batch(const char* adapters, int A, int m, const void* blobs, int32
                 jend = std::min(n, j0 + ((jend - j0 + 15) & ~15) + 16 * extend);
                 if (stats) stats[7]++;
             }
-            if (stats) { stats[tail ? (j0 >= n - t.hdr.win_dist[M2_LO] - 15 && t.hdr.win_dist[M2_LO] != t.hdr.win_dist[M2_HI] ? 2 : 1) : 0]++; stats[5] += jend - j0; }
+            if (stats) { stats[tail ? (is_lo ? 2 : 1) : 0]++; stats[5] += jend - j0; }
             uint64_t tab32[128];
             for (int c = 0; c < 128; c++) tab32[c] = bs32_table_entry(mt.scanmask[c], p.m);
             bool exact = false;
@@ -249,7 +249,7 @@ int m2m_match_batch(const char* adapters, int A, int m, const void* blobs, int32
                 // final scan are only proven equal to the reference's from column start + m + k + 1 on)
                 if (tail) o0 = std::max(0, (jfa >= 0 ? jfa : n) - reach);
                 int t6[6];
-                if (stats) { stats[6]++; stats[12 + (tail ? (max_row == t.hdr.rows_lo ? 2 : 1) : (precise ? 3 : 0))]++; }
+                if (stats) { stats[6]++; stats[12 + (tail ? (is_lo ? 2 : 1) : (precise ? 3 : 0))]++; }
                 if (dp_window(mt, q, n, o0, std::min(n, o1 >> 1), (o1 & 1) != 0, t6))
                     key = pack_best(t6[4], t6[5], pr.adapter, t6[1], t6[2], t6[3]);
             }

@@ -220,3 +220,43 @@ def test_custom_search_sets(model):
     sets = [[(-3, None, [ad[:3]]), (-25, None, [ad[2:8], ad[9:15]]), (0, None, [ad[0:9], ad[20:28]])] for ad in ads]
     seqs, offsets = orc.pack_reads(tail_reads(rng, ads, 200, 150))
     assert run(model, ads, 0.1, 3, seqs, offsets, "custom sets, too many slots", sets=sets, must_build=False) is None
+
+
+def test_occurrence_windows_regressions_and_mixed_plans(model):
+    """What a soak with other seeds found in round 4, and its generator as a test.
+    (1) A whole-adapter chunk whose STRING is a chunk of a tail class too (20-character adapters at rate 0.15: chunks of
+        five either way): its single occurrence near the read's end stands for rows of the last column as well, so the pair
+        must not take the window of that occurrence alone (multi2.h: tail_role).
+    (2) Reads shorter than the adapter, whole-read pairs with the adapter INSIDE the read (one and several chunk hits,
+        many edits), repetitive adapters, rates 0.08-0.25."""
+    import random
+    ads = ["CTTTATATAGTCCCCCACAC"[1:] + "T", "GGTCAATGCCGATTGACTTA"]
+    assert ads[0] == "TTTATATAGTCCCCCACACT"
+    reads = ["CTCCTCAGAAGGCCCCGGAAACCGAGCGCCCATATGAGTTAAATACTCTAGGGTCATCTGTATATAGTCCGCCACAC",
+             "CTCCTCAGAAGGCCCCGGAAACCGAGCGCCCATATGAGTTAAATACTCTAGGGTCATCTGTATATAGTCCCCCACAC",
+             "CTCCTCAGAAGGCCCCGGAATTTATATAGTCCGCCACACTGAGTTAAATACTCTAGGGTCATCTGAAAAAAAAAAAA"]
+    seqs, offsets = orc.pack_reads(reads)
+    run(model, ads, 0.15, 8, seqs, offsets, "chunk that is a tail chunk too")
+    rng = np.random.default_rng(31337)
+    prng = random.Random(31338)
+    built = 0
+    for it in range(14):
+        m = int(rng.choice([16, 20, 24, 28, 30, 33, 35, 40, 64]))
+        count = int(rng.choice([2, 3, 8, 24]))
+        ads = ["".join(prng.choice("ACGT") for _ in range(m)) for _ in range(count)]
+        if it % 5 == 3:
+            unit = "".join(prng.choice("ACGT") for _ in range(int(rng.choice([2, 3, 5]))))
+            ads[0] = (unit * m)[:m]
+        rate = float(rng.choice([0.08, 0.1, 0.12, 0.15, 0.2, 0.25]))
+        O = int(rng.choice([1, 3, 5, 8]))
+        n = int(rng.integers(16, 161))
+        reads = tail_reads(rng, ads, 700, n, p_n=float(rng.choice([0.0, 0.01])))
+        reads = [r if len(r) == n else (r + "A" * n)[:n] for r in reads]
+        sq2, of2 = orc.synth_reads(int(rng.integers(1, 10 ** 6)), 0, 700, n, ads, p_adapter=float(rng.choice([0.3, 0.8])),
+                                   p_edit=float(rng.choice([0.03, 0.08, 0.12])), p_n=0.005)
+        sq, offs = orc.pack_reads(reads)
+        sq = np.concatenate([sq, sq2])
+        offs = np.concatenate([offs, of2[1:] + offs[-1]])
+        st = run(model, ads, rate, O, sq, offs, f"mixed it {it} m {m} x {count} rate {rate} O {O} n {n}", must_build=False)
+        built += st is not None
+    assert built >= 6, built
