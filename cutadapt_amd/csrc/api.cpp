@@ -1094,7 +1094,7 @@ size_t cah_plan_workspace_bytes(const cah_plan* plan, int64_t n_reads) {
     if (n_reads < 0) n_reads = 0;
     size_t need = cah_workspace_bytes(n_reads);
     if (plan && plan->multi.hdr.ok)
-        need += ws_key_bytes(n_reads) + (size_t)multi_pair_cap(plan, n_reads) * 20 + ws_keys_bytes(n_reads) + 256;
+        need += ws_key_bytes(n_reads) + (size_t)multi_pair_cap(plan, n_reads) * 20 + 2 * ws_keys_bytes(n_reads) + 256;
     if (plan && plan->max_long_m > 0) need += long_scratch_bytes(plan, long_scratch_lanes(n_reads, 256)) + 256;
     return need;
 }
@@ -1440,7 +1440,7 @@ static int match_batch_multi(const cah_plan* plan, const PlanDeviceCopy* pd, con
     uint64_t* d_pairs = (uint64_t*)extra;                            extra += (size_t)cap * 8;
     int32_t* d_dpq = (int32_t*)extra;                                extra += (size_t)cap * 4;
     int32_t* d_win = (int32_t*)extra;                                extra += (size_t)cap * 8;
-    uint8_t* d_wmeta = (uint8_t*)extra;                              // (streaming form: a byte per read, multi2.h)
+    uint16_t* d_wmeta = (uint16_t*)extra;                            // (streaming form: a 16-bit word per read, multi2.h)
     unsigned long long* counters = ws.counters;
     const CahMatcher& m0 = plan->matchers[0];
     HIP_TRY(hipMemsetAsync(d_best_key, 0, sizeof(unsigned long long) * (size_t)n_reads, s));

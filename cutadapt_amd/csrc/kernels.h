@@ -237,7 +237,7 @@ struct Multi2Args {
     // round (after the scan and the cell DP have emptied the pool) goes on where it stopped
     unsigned long long* tile_counter;
     int64_t n_tiles, gate_pages;
-    uint8_t* wmeta;                  // out, per read of the batch: the adapter whose pair saw a further hit (CAH_M2_NO_FLAG ..)
+    uint16_t* wmeta;                 // out, per read of the batch: the adapter whose pair saw a further hit (CAH_M2_NO_FLAG ..) | chunk of the earliest such hit << 8
 };
 struct Multi2ScanArgs {
     int64_t uniform_first;
@@ -259,7 +259,7 @@ struct Multi2ScanArgs {
     unsigned long long* dp_count_front;      // zeroed before launch
     unsigned long long* dp_count_back;
     int64_t dp_cap;
-    const uint8_t* wmeta;            // per read: Multi2Args::wmeta
+    const uint16_t* wmeta;           // per read: Multi2Args::wmeta
     const uint32_t* prefix;          // per adapter: its first ten characters (M2Tables::prefix), for the suffix compare
     int32_t lmax0;                   // the largest overlap without error tolerance
 };

@@ -65,8 +65,9 @@ enum { M2_W = 0, M2_HI = 1, M2_LO = 2, M2_SHORT = 3 };
 // offset of chunk c in the adapter): the scan runs from f - E_c - k - 1 to that end, no further candidate follows, and
 // of the last column's rows only the error-free overlaps can be acceptable (a row with tolerance e >= 1 needs a hit of a
 // tail class) -- the suffix compare m2_exact_tail decides those.
-// Such a pair also carries, in bits 16..19 of its record, the 16-column chunk of the first event of the round that emitted it:
-// where its full window starts when it does NOT stay the only hit (every hit of the round lies at or behind that chunk).
+// The per-read word: bits 0..7 the flagged adapter (or CAH_M2_NO_FLAG / CAH_M2_MANY_FLAGS), bits 8..11 the 16-column chunk of
+// the read's earliest FURTHER whole-read hit (15: none) -- a pair that does not stay alone falls back to the full window from
+// the earliest of its own position and that chunk (the lane that emitted it need not hold its earliest occurrence).
 #define CAH_M2_PAIR_PRECISE 2u
 #define CAH_M2_PAIR_CHUNK_SHIFT 2
 #define CAH_M2_NO_FLAG 255u

@@ -151,6 +151,7 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
     uint32_t* const s_wide = reinterpret_cast<uint32_t*>(s_raw + LY.wide) + wave * WAVE * words;
     m2_u32x2* const s_ring = reinterpret_cast<m2_u32x2*>(s_raw + LY.ring) + wave * M2_RING;
     uint32_t* const s_rlast = reinterpret_cast<uint32_t*>(s_raw + LY.rlast) + wave * WAVE;
+    uint32_t* const s_wmin = s_rlast;                                   // (see resolve_round: until class W is resolved)
     uint32_t* const s_pg = reinterpret_cast<uint32_t*>(s_raw + LY.pages) + wave * CAH_M2_PAIR_CLASSES * 2;   // {page, fill} per class
     unsigned* const s_next_piece = reinterpret_cast<unsigned*>(s_raw + LY.misc);
     volatile unsigned long long* const s_tilemap = reinterpret_cast<volatile unsigned long long*>(s_raw + LY.misc + 64);
@@ -421,10 +422,7 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
                     const unsigned we = (cls == M2_W && !whole) ? m2_precise_chunk(e.meta) : 0u;
 #endif
                     unsigned lo = whole ? ((unsigned)pc_whole << 28) : lo_cls;
-                    // (bits 16..19: the chunk of the round's first event -- where the pair's full window starts if it does not
-                    // stay the pair's only hit: the lane that emits a pair need not hold its EARLIEST occurrence of the round)
-                    if (we) lo = (2u << 28) | ((CAH_M2_PAIR_PRECISE | ((we - 1u) << CAH_M2_PAIR_CHUNK_SHIFT)) << 24) |
-                                 ((unsigned)(p_head >> 4) << 16) | (unsigned)p;
+                    if (we) lo = (2u << 28) | ((CAH_M2_PAIR_PRECISE | ((we - 1u) << CAH_M2_PAIR_CHUNK_SHIFT)) << 24) | (unsigned)p;
                     lo |= (unsigned)adapter << 8;
                     s_ring[(stage0 + staged + m2_rank(em)) & (M2_RING - 1)] = (m2_u32x2){lo, rd};
                 }
@@ -435,7 +433,14 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
 #if defined(M2_ABL) && (M2_ABL & 64)
             atomicOr(sw + word, again ? bit : 0u);
 #elif !(defined(M2_ABL) && (M2_ABL & 16))
-            if (m2_any(again)) atomicOr(sw + word, again ? bit : 0u);
+            if (m2_any(again)) {
+                atomicOr(sw + word, again ? bit : 0u);
+                // ... and where: the lane that emitted the pair need not hold its EARLIEST occurrence of the round (the lanes
+                // race for the `seen` bit), so the full window such a pair falls back to starts at the earliest of its own
+                // position and the read's further whole-read hits (s_wmin: the read's slot of s_rlast, free until class W is
+                // resolved)
+                if (cls == M2_W && again) atomicMin(s_wmin + lr, (unsigned)p);
+            }
 #endif
             ++u; --left;
         }
@@ -491,6 +496,7 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
         if (more) {
             // ---- per-read state
             for (int w = 0; w < words; ++w) { s_seen[lane * words + w] = 0; s_wide[lane * words + w] = 0; }
+            s_wmin[lane] = 255u;
             uint32_t r = 0x24924924u;                                   // ten characters that match nothing
             uint32_t r_prev = r;                                        // the word five characters in front of the chunk (the chunk before's twelfth)
             uint32_t rlast = r;                                         // the word at the read's last character
@@ -629,8 +635,9 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
                 }
                 M2_STAMP(2 + 2 * ph);
             }
+            drain();                                                    // class W is resolved
+            const unsigned w_again_chunk = s_wmin[lane] >> 4;           // chunk of the read's earliest further whole-read hit (15: none)
             s_rlast[lane] = rlast;
-            drain();
             M2_STAMP(5);
             // ---- the tail slots' hits become events, class by class (hi, lo, REF-only), each class resolved before the next
             {
@@ -718,7 +725,8 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
                     cnt += (unsigned)__popc(f);
                     if (f) which = (unsigned)(32 * w) + (unsigned)__builtin_ctz(f);
                 }
-                a.wmeta[a.first_read + base + lane] = (uint8_t)(cnt == 0 ? CAH_M2_NO_FLAG : (cnt == 1 ? which : CAH_M2_MANY_FLAGS));
+                a.wmeta[a.first_read + base + lane] =
+                    (uint16_t)((cnt == 0 ? CAH_M2_NO_FLAG : (cnt == 1 ? which : CAH_M2_MANY_FLAGS)) | (w_again_chunk << 8));
             }
 #endif
             if (valid && (seen_chars & 0x80808080u) != 0) a.status[a.first_read + base + lane] = 2;
@@ -807,12 +815,12 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_multi
                 if (e0 < count) {
                     const uint64_t pr = a.pairs[page * CAH_M2_PAGE + e0];
                     const unsigned flags = (unsigned)(pr >> 24) & 0xFFu, key = (unsigned)pr & 0xFFu;
-                    const unsigned adapter = (unsigned)(pr >> 8) & 0xFFu, head = (unsigned)(pr >> 16) & 0xFFu;
+                    const unsigned adapter = (unsigned)(pr >> 8) & 0xFFFFu;
                     const int64_t r = (int64_t)(pr >> 32);
                     int j0w = max(0, ((int)key << CAH_KEY_SHIFT) - p.m - p.k - 1), jb = n;
                     unsigned precise = 0, tail0 = 0;
                     if (flags & CAH_M2_PAIR_PRECISE) {
-                        const unsigned wm = a.wmeta[r];
+                        const unsigned wm16 = a.wmeta[r], wm = wm16 & 0xFFu;
                         if (wm != adapter && wm != CAH_M2_MANY_FLAGS) {
                             precise = 1;
                             m2_precise_window((int)key, (int)(flags >> CAH_M2_PAIR_CHUNK_SHIFT) & 3, p.m, p.k, chunk_base, chunk_extra, n, j0w, jb);
@@ -824,7 +832,8 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_multi
                             for (int c = 6; c < 16; ++c) rlast = (rlast << 3) | (uint32_t)s_xlat[chunk_byte(tl, c) & 127u];
                             tail0 = (unsigned)m2_exact_tail(rlast, s_prefix[adapter], p.min_overlap, a.lmax0, n);
                         } else {
-                            j0w = max(0, (int)(head << 4) - p.m - p.k - 1);       // (flagged: the window of a whole-read pair)
+                            // (flagged: the window of a whole-read pair, from the earliest of the pair's hits)
+                            j0w = max(0, (int)(min(key >> 4, wm16 >> 8) << 4) - p.m - p.k - 1);
                         }
                     }
                     j0w = min(j0w, n);
@@ -871,14 +880,12 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_multi
             const int64_t idx = page * CAH_M2_PAGE + e0;
             int64_t r = 0;
             unsigned tab_base = 0, adapter = 0, key = 0;
-            uint32_t pair_low = 0;
             if (valid) {
                 const uint64_t pr = a.pairs[idx];
                 r = (int64_t)(pr >> 32);
-                adapter = (unsigned)(pr >> 8) & 0xFFu;
+                adapter = (unsigned)(pr >> 8) & 0xFFFFu;
                 key = (unsigned)pr & 0xFFu;
                 tab_base = adapter * CAH_MULTI_TAB_STRIDE;
-                pair_low = (uint32_t)pr;
             }
             const uint8_t* q = a.seqs + a.uniform_first + r * (int64_t)n;
             // A tail page's pairs all have the same window (one class, one read length), from column 4 * key: the scan
@@ -1026,8 +1033,6 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_multi
             // scan are only proven equal to the reference's from column start + m + k + 1 on (column skipping)
             if (cls == BS_DP && tail_page) o0 = max(0, (jfa >= 0 ? jfa : n) - reach);
             const bool to_dp = valid && cls == BS_DP;
-            // (k_dp_packed reads the adapter as bits 8..23 of the pair: the chunk of the round's first event goes)
-            if (to_dp && (pair_low & 0x00FF0000u)) const_cast<uint64_t*>(a.pairs)[idx] = ((uint64_t)r << 32) | (pair_low & 0xFF00FFFFu);
             const bool to_back = to_dp && (o1 & 1);
             const bool to_front = to_dp && !(o1 & 1);
             const unsigned long long bf = __ballot(to_front), bb = __ballot(to_back);
