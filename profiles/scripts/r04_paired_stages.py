@@ -93,7 +93,7 @@ gp._PINNED_INPUT = pinned
 # block size and reader threads (pinned buffers, 6 workers)
 out["variants"] = {}
 orig = gp._paired_pieces
-for chunk in (16 << 20, 32 << 20, 64 << 20):
+for chunk in (64 << 20,):
     for rt in (3, 4, 6):
         gp._paired_pieces = lambda a, b, c, pool=None, _t=rt: orig(a, b, c, threads=_t, pool=pool)
         run(6, chunk)
