@@ -122,6 +122,12 @@ class _PinnedInputPool:
                 del self._owner[id(self._free.pop(small))]
             self._free.append(root)
 
+    def trim(self, keep: int = 8) -> None:
+        """let go of all but ``keep`` free buffers (a job's end: dozens of blocks were in flight, pinned memory is scarce)"""
+        with self._lock:
+            while len(self._free) > keep:
+                del self._owner[id(self._free.pop())]
+
     def tensor_of(self, arr):
         """the pinned tensor view over the bytes of ``arr`` (an array, or a view of one, this pool handed out)"""
         root = self._root(arr)
@@ -1632,6 +1638,7 @@ def _paired_all_device(in1, in2, out1, out2, mates, job, discard_untrimmed, disc
             o1.close()
         if o2 is not out2:
             o2.close()
+        _PINNED_INPUT.trim()
     wall = time.perf_counter() - t_start
     workers = [w for f in feeders for w in f.workers if w is not None]
     pc = np.zeros(8, dtype=np.int64)
