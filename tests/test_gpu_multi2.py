@@ -114,3 +114,35 @@ def test_invalid_bytes_are_flagged(hip, orc):
     batch = ReadBatch.from_host(sq, offs)
     got6, got_st, _ = match_batch(plan, batch).cpu()
     assert set(np.nonzero(got_st == 2)[0].tolist()) == {0, 17, 63, 64, 299}
+
+
+def test_occurrence_window_regressions(hip, orc):
+    """the kernels on what a soak found in round 4 (CPU twin: tests/test_multi2_model.py, same name): a whole-adapter chunk
+    that is a tail chunk too (20-character adapters at rate 0.15), reads shorter than the adapter, adapters inside the
+    read with many edits, rates 0.08-0.25"""
+    ads = ["TTTATATAGTCCCCCACACT", "GGTCAATGCCGATTGACTTA"]
+    reads = ["CTCCTCAGAAGGCCCCGGAAACCGAGCGCCCATATGAGTTAAATACTCTAGGGTCATCTGTATATAGTCCGCCACAC",
+             "CTCCTCAGAAGGCCCCGGAAACCGAGCGCCCATATGAGTTAAATACTCTAGGGTCATCTGTATATAGTCCCCCACAC",
+             "CTCCTCAGAAGGCCCCGGAATTTATATAGTCCGCCACACTGAGTTAAATACTCTAGGGTCATCTGAAAAAAAAAAAA"]
+    run_uniform(orc, ads, 0.15, 8, reads * 40, "chunk that is a tail chunk too", expect=None)
+    rng = np.random.default_rng(31337)
+    prng = random.Random(31338)
+    streamed = 0
+    for it in range(10):
+        m = int(rng.choice([20, 24, 28, 30, 33, 35, 40, 64]))
+        count = int(rng.choice([2, 3, 8, 24]))
+        seqs = [rs(prng, m) for _ in range(count)]
+        if it % 5 == 3:
+            seqs[0] = (rs(prng, int(rng.choice([2, 3, 5]))) * m)[:m]
+        rate = float(rng.choice([0.08, 0.1, 0.12, 0.15, 0.2, 0.25]))
+        O = int(rng.choice([1, 3, 5]))
+        n = int(rng.integers(40, 161))
+        reads = tail_reads(rng, seqs, 1000, n, p_n=float(rng.choice([0.0, 0.01])))
+        reads = [r if len(r) == n else (r + "A" * n)[:n] for r in reads]
+        sq2, of2 = orc.synth_reads(int(rng.integers(1, 10 ** 6)), 0, 1000, n, seqs, p_adapter=float(rng.choice([0.3, 0.8])),
+                                   p_edit=float(rng.choice([0.03, 0.08, 0.12])), p_n=0.005)
+        reads += [bytes(sq2[of2[i]:of2[i + 1]]).decode() for i in range(1000)]
+        plan, _ = plan_for(seqs, rate, O)
+        streamed += plan.multi_kind(n) == "stream"
+        run_uniform(orc, seqs, rate, O, reads, f"mixed it {it} m {m} x {count} rate {rate} O {O} n {n}", expect=None)
+    assert streamed >= 4, streamed                          # (5 with these seeds: the other plans take the older kernels)
