@@ -170,6 +170,32 @@ CAH_HD uint64_t bs_shl1(uint64_t x) {
 #endif
 }
 
+
+// ---- instruction forms (round 5).  Issue cost on gfx950 with two or more waves per SIMD (profiles/r03/valu_ubench.txt,
+// DESIGN 3.2b): v_and / v_or / v_xor / v_add / v_sub / v_mov / v_ashrrev / v_bitop3 take 2 cycles per wave64, shifts,
+// v_lshl_or, v_and_or, v_or3, v_bfi, v_add3, every v_cmp and v_cndmask 4.  The compiler writes "x << 1" as v_lshlrev,
+// (m & a) | (~m & b) as v_bfi and (a & b) | c as v_and_or: a 32-bit column of the scan then spends half of its ~95 issue
+// cycles on 4-cycle forms.  Said explicitly (device code only; the host model keeps plain C): ~66 cycles.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(CAH_BS_PLAIN_OPS)
+CAH_HD uint32_t bs_dbl(const uint32_t x) {                    // x << 1 as x + x
+    uint32_t r;
+    asm("v_add_u32 %0, %1, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+#define BS_BITOP3(a, b, c, tt) __builtin_amdgcn_bitop3_b32((a), (b), (c), (tt))
+#else
+CAH_HD uint32_t bs_dbl(const uint32_t x) { return x << 1; }
+CAH_HD uint32_t bs_bitop3_host(const uint32_t a, const uint32_t b, const uint32_t c, const unsigned tt) {
+    uint32_t r = 0;                                            // truth table: bit (a << 2 | b << 1 | c) of tt
+    for (unsigned idx = 0; idx < 8; ++idx)
+        if ((tt >> idx) & 1u)
+            r |= ((idx & 4u) ? a : ~a) & ((idx & 2u) ? b : ~b) & ((idx & 1u) ? c : ~c);
+    return r;
+}
+#define BS_BITOP3(a, b, c, tt) bs_bitop3_host((a), (b), (c), (tt))
+#endif
+CAH_HD uint32_t bs_sel(const uint32_t m, const uint32_t a, const uint32_t b) { return BS_BITOP3(m, a, b, 0xCAu); }   // m ? a : b, bitwise
+
 // first column of the window: costs 0 (pad rows), 1, 2, ..., m
 CAH_HD void bs_init(BackScanState& s, const BackScanParams& p) {
     const int pad = 64 - p.m;
@@ -291,27 +317,29 @@ CAH_HD bool bs32_step(BackScanState32<X>& s, const uint32_t eq, const uint32_t e
         hpos = hin > 0 ? 1u : 0u; hneg = hin < 0 ? 1u : 0u;
         if (SUBS) s.ax = ax_new | (ux_new << 8) | (zx_new << 16);
     }
-    // ---- the word
+    // ---- the word (every three-input form as ONE v_bitop3, every shift by one as an addition: see bs_dbl)
     const uint32_t VP = s.VP, VN = s.VN;
     const uint32_t Xv = eq | VN;
-    const uint32_t eqm = eq | hneg;
-    const uint32_t Xh = (((eqm & VP) + VP) ^ VP) | eqm;
-    const uint32_t HP = VN | ~(Xh | VP);
+    const uint32_t eqm = X > 0 ? (eq | hneg) : eq;
+    const uint32_t t = (eqm & VP) + VP;
+    const uint32_t Xh = BS_BITOP3(t, VP, eqm, 0xBEu);              // (t ^ VP) | eqm
+    const uint32_t HP = BS_BITOP3(VN, Xh, VP, 0xF1u);              // VN | ~(Xh | VP)
     const uint32_t HN = VP & Xh;
-    if (BOOK) s.cm += (int)(HP >> 31) - (int)(HN >> 31);           // row m is the top bit
-    const uint32_t HPs = (HP << 1) | hpos, HNs = (HN << 1) | hneg;
-    s.VP = HNs | ~(Xv | HPs);
+    // row m is the top bit: +1 where HP has it, -1 where HN has it (arithmetic shifts: 0 / -1)
+    if (BOOK) s.cm = s.cm - ((int)HP >> 31) + ((int)HN >> 31);
+    const uint32_t HPs = X > 0 ? ((HP << 1) | hpos) : bs_dbl(HP), HNs = X > 0 ? ((HN << 1) | hneg) : bs_dbl(HN);
+    s.VP = BS_BITOP3(HNs, Xv, HPs, 0xF1u);                         // HNs | ~(Xv | HPs)
     s.VN = HPs & Xv;
     if (!BOOK) return false;
     if (SUBS) {
         const uint32_t a_old = s.A;
-        const uint32_t Xc = (Xh | VN) & ~eq;                       // unclean cells: diagonal delta 0, characters differ
-        s.A = ((a_old << 1) | a_in) | Xc;
+        const uint32_t Xc = BS_BITOP3(Xh, VN, eq, 0x54u);          // (Xh | VN) & ~eq: unclean cells (diagonal delta 0, characters differ)
+        s.A = X > 1 ? ((bs_dbl(a_old) | a_in) | Xc) : (bs_dbl(a_old) | Xc);
         // ONE_INDEL: at an unclean cell the reference leaves the diagonal -- upwards (deletion) iff the vertical
         // delta is +1 (new VP); the accumulator bit of the cell it comes from: above in this column / left in the last
-        s.U = (((s.U << 1) | u_in) & ~Xc) | (s.VP & Xc);
-        const uint32_t pa = (s.VP & ((s.A << 1) | a_top_new)) | (~s.VP & a_old);
-        s.Z = (((s.Z << 1) | z_in) & ~Xc) | (pa & Xc);
+        s.U = bs_sel(Xc, s.VP, X > 1 ? (bs_dbl(s.U) | u_in) : bs_dbl(s.U));
+        const uint32_t pa = bs_sel(s.VP, X > 1 ? (bs_dbl(s.A) | a_top_new) : bs_dbl(s.A), a_old);
+        s.Z = bs_sel(Xc, pa, X > 1 ? (bs_dbl(s.Z) | z_in) : bs_dbl(s.Z));
     }
     if (__builtin_expect(s.cm <= p.kacc, 0))
         return bs_book<SUBS>(s, (s.A >> 31) == 0, j, p, (s.U >> 31) != 0, (s.Z >> 31) != 0);
@@ -332,18 +360,104 @@ CAH_HD bool bs_may_stop(const BackScanBook& s, const int j, const int n, const i
     return s.jla >= 0 && j - s.jla >= gap && j < n;
 }
 
+// "does any lane of the wave still ..." (the host model has one lane)
+CAH_HD bool bs_any(const bool pred) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ballot_w64(pred) != 0ull;
+#else
+    return pred;
+#endif
+}
+CAH_HD int bs_popc(const uint32_t x) { return __builtin_popcount(x); }
+CAH_HD int bs_popc(const uint64_t x) { return __builtin_popcountll(x); }
+CAH_HD int bs_top_bit(const uint32_t x) { return 31 - __builtin_clz(x); }          // x != 0
+CAH_HD int bs_top_bit(const uint64_t x) { return 63 - __builtin_clzll(x); }
+
+// The last column as the classification sees it: rows X+1..m as a word (bit t = row X + 1 + t: vertical deltas vp / vn,
+// unclean-diagonal bits a), rows 1..X as explicit costs cx[] with their unclean bits in ax.
+template <class W, int X>
+struct BsLastColumn {
+    W vp, vn, a;
+    int cx[X > 0 ? X : 1];
+    unsigned ax;
+};
+
+// The walk down the last column (reference _align.pyx:536-572), in two passes (round 5; one pass over all rows with the
+// whole bookkeeping per row was a third of the cost scan's time -- 33 rows x ~25 instructions, most of them compares and
+// selects, for a column in which two or three rows are acceptable):
+//   pass 1  every row: the running cost and ONE bit "acceptable" (cost <= thr_last(i), i >= min_overlap);
+//   pass 2  every ACCEPTABLE row, lane by lane from the top (a wave makes as many rounds as its lane with the most
+//           acceptable rows has): cost from two population counts, clean diagonal, and the maxima the rules ask for.
+// Everything the rules ask of the acceptable rows is a maximum over them -- the order does not matter:
+//   best_i          the largest acceptable row
+//   (w_score, w_row) the clean acceptable row of the highest score i - 2 c, the largest row on ties -- one maximum
+//                    over the key (score + 256) * 128 + row; its cost is (w_row - w_score) / 2
+//   unclean_bound   the most an acceptable row with an unclean diagonal scores
+//   c_max           the largest cost of an acceptable row: the origin clause holds for every acceptable row with
+//                    errors iff k + 1 + c_max <= m / 2 (or c_max == 0)
+struct BsRowStats {
+    int best_i, w_key, unclean_bound, c_max;
+};
+CAH_HD void bs_row_update(BsRowStats& r, const bool on, const int i, const int c, const bool clean) {
+    const int sc = i - 2 * c;
+    r.best_i = (on && i > r.best_i) ? i : r.best_i;
+    const int key_c = (on && clean) ? (sc + 256) * 128 + i : -1;
+    r.w_key = key_c > r.w_key ? key_c : r.w_key;
+    const int sc_u = (on && !clean) ? sc : -(1 << 20);
+    r.unclean_bound = sc_u > r.unclean_bound ? sc_u : r.unclean_bound;
+    const int c_a = on ? c : 0;
+    r.c_max = c_a > r.c_max ? c_a : r.c_max;
+}
+
+template <bool TRACKED, class W, int X, class ThrLast>
+CAH_HD BsRowStats bs_last_column_stats(const BsLastColumn<W, X>& col, const int n, const int j0, const BackScanParams& p,
+                                       ThrLast thr_last, const int max_row) {
+    BsRowStats r;
+    r.best_i = 0; r.w_key = -1; r.unclean_bound = -(1 << 20); r.c_max = 0;
+    const int rows = p.m < max_row ? p.m : max_row;
+    // the explicit rows (at most two)
+    for (int i = 1; i <= X && i <= rows; ++i) {
+        const int c = col.cx[i - 1];
+        const bool acc = i >= p.min_overlap && c <= thr_last(i);
+        const bool clean = c == 0 || (n - i >= j0 && TRACKED && ((col.ax >> (i - 1)) & 1u) == 0);
+        bs_row_update(r, acc, i, c, clean);
+    }
+    // pass 1 over the word's rows
+    const int nw = rows - X;
+    const int cbase = X > 0 ? col.cx[X - 1] : 0;
+    int c = cbase;
+    W acc = 0;
+    for (int t = 0; t < nw; ++t) {
+        const int i = X + 1 + t;
+        c += (int)((col.vp >> t) & 1) - (int)((col.vn >> t) & 1);
+        const bool ok = i >= p.min_overlap && c <= thr_last(i);
+        acc |= ok ? ((W)1 << t) : (W)0;
+    }
+    // pass 2
+    while (bs_any(acc != 0)) {
+        const bool on = acc != 0;
+        const int t = on ? bs_top_bit(acc) : 0;
+        const W bit = (W)1 << t;
+        acc &= ~bit;
+        const W low = bit | (bit - 1);
+        const int ci = cbase + bs_popc((W)(col.vp & low)) - bs_popc((W)(col.vn & low));
+        const int i = X + 1 + t;
+        const bool clean = ci == 0 || (n - i >= j0 && TRACKED && (col.a & bit) == 0);
+        bs_row_update(r, on, i, ci, clean);
+    }
+    return r;
+}
+
 // After the last column (j == n) without EXACT_FULL, or after an early stop (stopped: the state is that of an
 // inner column and nothing beyond jla can matter).  thr_last(i): error threshold of row i in the last
 // column = thr[effective length of adapter[0:i]] (CahMatcher::thr_last).  j0 = first column of the window
 // (the cost scan itself started there).  Outputs: o0/o1 = (row i, -) for EXACT_TAIL, (first DP column,
 // last DP column * 2 + scan flag) for DP.
-// row_cost(i): the absolute cost of row i of the last column, asked for i = 1, 2, .., m in this order.
-// row_clean(i): the diagonal that ends in (i, n) has met no unclean cell (only asked when it starts inside the window).
 // max_row: rows above it are known not to be acceptable (a window that holds every acceptable candidate's alignment
 // from column j0 on leaves rows > n - j0 + kacc no room) and are not looked at.
-template <bool INDEL1, class ThrLast, class RowCost, class RowClean>
-CAH_HD int bs_finish_rows(const BackScanBook& s, const int n, const int j0, const BackScanParams& p,
-                          ThrLast thr_last, int& o0, int& o1, const bool stopped, RowCost row_cost, RowClean row_clean,
+template <bool INDEL1, bool TRACKED, class W, int X, class ThrLast>
+CAH_HD int bs_finish_rows(const BackScanBook& s, const BsLastColumn<W, X>& col, const int n, const int j0,
+                          const BackScanParams& p, ThrLast thr_last, int& o0, int& o1, const bool stopped,
                           const int max_row = CAH_BS_ALL_ROWS) {
     o0 = 0; o1 = 0;
     const int reach = p.m + p.k + 1;
@@ -362,33 +476,10 @@ CAH_HD int bs_finish_rows(const BackScanBook& s, const int n, const int j0, cons
         o1 = s.jla * 2;
         return BS_DP;
     }
-    // Absolute costs of the last column, rows 1..m (row 0 costs 0).  Everything the rules below ask of the acceptable
-    // rows is a maximum over them, so the loop is branch-free (as nested divergent branches it cost the cost scan a
-    // fifth of its time: ~400 cycles per row and wave, most of them scalar mask bookkeeping):
-    //   best_i          the largest acceptable row
-    //   (w_score, w_row) the clean acceptable row of the highest score i - 2 c, the largest row on ties -- one maximum
-    //                    over the key (score + 256) * 128 + row; its cost is (w_row - w_score) / 2
-    //   unclean_bound   the most an acceptable row with an unclean diagonal scores
-    //   c_max           the largest cost of an acceptable row: the origin clause holds for every acceptable row with
-    //                    errors iff k + 1 + c_max <= m / 2 (or c_max == 0)
-    int best_i = 0, w_key = -1, unclean_bound = -(1 << 20), c_max = 0;
-    const int rows = p.m < max_row ? p.m : max_row;
-    for (int i = 1; i <= rows; ++i) {
-        const int c = row_cost(i);
-        const bool acc = i >= p.min_overlap && c <= thr_last(i);
-        const int sc = i - 2 * c;
-        const bool clean = c == 0 || (n - i >= j0 && row_clean(i));
-        best_i = acc ? i : best_i;
-        const int key = (sc + 256) * 128 + i;
-        const int key_c = (acc && clean) ? key : -1;
-        w_key = key_c > w_key ? key_c : w_key;
-        const int sc_u = (acc && !clean) ? sc : -(1 << 20);
-        unclean_bound = sc_u > unclean_bound ? sc_u : unclean_bound;
-        const int c_a = acc ? c : 0;
-        c_max = c_a > c_max ? c_a : c_max;
-    }
-    const int w_row = w_key >= 0 ? (w_key & 127) : 0;
-    const int w_score = w_key >= 0 ? (w_key >> 7) - 256 : -(1 << 20);
+    const BsRowStats r = bs_last_column_stats<TRACKED>(col, n, j0, p, thr_last, max_row);
+    const int best_i = r.best_i, unclean_bound = r.unclean_bound, c_max = r.c_max;
+    const int w_row = r.w_key >= 0 ? (r.w_key & 127) : 0;
+    const int w_score = r.w_key >= 0 ? (r.w_key >> 7) - 256 : -(1 << 20);
     const int w_cost = (w_row - w_score) / 2;                   // (unused when w_row == 0)
     const bool clause_ok = c_max == 0 || p.k + 1 + c_max <= p.half_m;
     const int sc_max = w_score > unclean_bound ? w_score : unclean_bound;     // -(1 << 20) without an acceptable row
@@ -419,29 +510,20 @@ template <bool TRACKED = true, class ThrLast>
 CAH_HD int bs_finish(const BackScanState& s, const int n, const int j0, const BackScanParams& p,
                      ThrLast thr_last, int& o0, int& o1, const bool stopped = false, const int max_row = CAH_BS_ALL_ROWS) {
     const int pad = 64 - p.m;
-    uint64_t vp = pad == 0 ? s.VP : (s.VP >> pad), vn = pad == 0 ? s.VN : (s.VN >> pad);
-    int c = 0;
-    return bs_finish_rows<false>(s, n, j0, p, thr_last, o0, o1, stopped, [&](int) {
-        c += (int)(vp & 1ull) - (int)(vn & 1ull);
-        vp >>= 1; vn >>= 1;
-        return c;
-    }, [&](int i) { return TRACKED && ((s.A >> (pad + i - 1)) & 1ull) == 0; }, max_row);
+    BsLastColumn<uint64_t, 0> col;
+    col.vp = pad == 0 ? s.VP : (s.VP >> pad); col.vn = pad == 0 ? s.VN : (s.VN >> pad);
+    col.a = pad == 0 ? s.A : (s.A >> pad);
+    col.cx[0] = 0; col.ax = 0;
+    return bs_finish_rows<false, TRACKED>(s, col, n, j0, p, thr_last, o0, o1, stopped, max_row);
 }
 
 template <int X, bool TRACKED = true, class ThrLast>
 CAH_HD int bs32_finish(const BackScanState32<X>& s, const int n, const int j0, const BackScanParams& p,
                        ThrLast thr_last, int& o0, int& o1, const bool stopped = false, const int max_row = CAH_BS_ALL_ROWS) {
     const int pad = X > 0 ? 0 : 32 - p.m;
-    uint32_t vp = s.VP >> pad, vn = s.VN >> pad;
-    int c = X > 0 ? s.cx[X - 1] : 0;
-    return bs_finish_rows<TRACKED>(s, n, j0, p, thr_last, o0, o1, stopped, [&](int i) {
-        if (X > 0 && i <= X) return s.cx[i - 1 < X ? i - 1 : 0];
-        c += (int)(vp & 1u) - (int)(vn & 1u);
-        vp >>= 1; vn >>= 1;
-        return c;
-    }, [&](int i) {
-        if (!TRACKED) return false;
-        if (X > 0 && i <= X) return ((s.ax >> (i - 1)) & 1u) == 0;
-        return ((s.A >> (pad + i - X - 1)) & 1u) == 0;
-    }, max_row);
+    BsLastColumn<uint32_t, X> col;
+    col.vp = s.VP >> pad; col.vn = s.VN >> pad; col.a = s.A >> pad;
+    for (int t = 0; t < (X > 0 ? X : 1); ++t) col.cx[t] = s.cx[t];
+    col.ax = s.ax;
+    return bs_finish_rows<TRACKED, TRACKED>(s, col, n, j0, p, thr_last, o0, o1, stopped, max_row);
 }

@@ -1957,9 +1957,14 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_back_
             SCAN_STAMP(2, n_chunks);
 
             int o0 = 0, o1 = 0;
-            int cls;
-            if constexpr (KIND == 0) cls = bs_finish<!MULTI>(st, n, j0, p, [&](int i) { return s_thr_last[i]; }, o0, o1, stopped);
-            else cls = bs32_finish<XR, !MULTI>(st, n, j0, p, [&](int i) { return s_thr_last[i]; }, o0, o1, stopped);
+            int cls = BS_NONE;
+            // the classification -- above all the walk down the last column's rows -- only for lanes whose result it is:
+            // a lane that ended as EXACT_FULL, was set aside or never had a read skips it, and a wave made of such lanes
+            // (the common wave of reads with the adapter inside) skips the row loop altogether
+            if (valid && !exact && !retry) {
+                if constexpr (KIND == 0) cls = bs_finish<!MULTI>(st, n, j0, p, [&](int i) { return s_thr_last[i]; }, o0, o1, stopped);
+                else cls = bs32_finish<XR, !MULTI>(st, n, j0, p, [&](int i) { return s_thr_last[i]; }, o0, o1, stopped);
+            }
             if (exact) { cls = BS_EXACT_FULL; o0 = exact_j; }
             if (retry) { cls = BS_NONE; valid_out = false; }
             SCAN_STAMP(3, 0);

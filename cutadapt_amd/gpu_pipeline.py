@@ -1730,9 +1730,8 @@ def trim_fastq_gpu_paired(in1, in2, out1, out2, r1: Optional[dict] = None, r2: O
             w.busy_s += time.perf_counter() - t0
             w.chunks += 1
             w.bytes_in += len(d1) + len(d2)
-            from .pipeline import POOL
-            POOL.put(d1)
-            POOL.put(d2)                                     # the reader's buffers are free again
+            _PINNED_INPUT.put(d1)
+            _PINNED_INPUT.put(d2)                            # the reader's (pinned) buffers are free again
 
     feeders = [_Feeder(dev, threads, len(devices) > 1, make_worker) for dev in devices]
     o1 = out1 if hasattr(out1, "write") else open(out1, "wb")
@@ -1773,6 +1772,7 @@ def trim_fastq_gpu_paired(in1, in2, out1, out2, r1: Optional[dict] = None, r2: O
             o1.close()
         if o2 is not out2:
             o2.close()
+        _PINNED_INPUT.trim()
     wall = time.perf_counter() - t_start
     workers = [w for f in feeders for w in f.workers if w is not None]
     for w in workers:

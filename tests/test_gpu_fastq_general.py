@@ -451,3 +451,27 @@ def test_read_pairs_on_the_all_device_way_equal_the_host_pipeline(hip):
     gs = trim_fastq_gpu_paired(io.BytesIO(f1), io.BytesIO(f2), io.BytesIO(), io.BytesIO(),
                                dict(adapters=[A.BackAdapter(ad1)], action="mask"), dict(adapters=[A.BackAdapter(ad2)]))
     assert gs["way"] == "general"
+
+
+def test_general_paired_way_returns_its_pinned_input_buffers(hip):
+    """Round-4 review: the general paired way read into pinned buffers (_PINNED_INPUT) but handed them back to the
+    pageable pool, so every block pinned fresh memory and the pinned pool kept all of it for the life of the process.
+    Many small blocks through --pair-adapters: the pool's bookkeeping stays bounded and shrinks at the job's end."""
+    from cutadapt_amd import adapters as A
+    from cutadapt_amd import gpu_pipeline as G
+    from test_gpu_fastq_device import _fastq
+    rng = random.Random(5)
+    ad1, ad2 = "AGATCGGAAGAGCACACGTCTGAACTCCAGTCA", "AGATCGGAAGAGCGTCGTGTAGGGAAAGAGTGT"
+    n = 6000
+    f1 = _fastq(rng, n, [ad1])
+    f2 = _fastq(rng, n, [ad2]).replace(b"@read", b"@mate")
+    before = len(G._PINNED_INPUT._owner)
+    gs = G.trim_fastq_gpu_paired(io.BytesIO(f1), io.BytesIO(f2), io.BytesIO(), io.BytesIO(),
+                                 dict(adapters=[A.BackAdapter(ad1)]), dict(adapters=[A.BackAdapter(ad2)]),
+                                 pair_adapters=True, chunk_bytes=20_000, threads=2)
+    assert gs["way"] == "general" and gs["pairs"] == n
+    blocks = len(f1) // 20_000
+    assert blocks > 40
+    # far fewer pinned buffers than blocks, and the job's end trimmed the free list (trim keeps 8)
+    assert len(G._PINNED_INPUT._owner) - before <= 16, (len(G._PINNED_INPUT._owner), before, blocks)
+    assert len(G._PINNED_INPUT._free) <= 8
