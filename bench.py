@@ -193,15 +193,15 @@ class Workload:
 
 
 def csrc_hash() -> str:
-    """sha256 over the kernel / host sources the library is built from: ties a PMC profile to the code it was taken on"""
-    import hashlib
-    h = hashlib.sha256()
-    base = os.path.join(ROOT, "cutadapt_amd", "csrc")
-    names = sorted(f for f in os.listdir(base) if f.endswith((".hip", ".h", ".cpp")))
-    for f in names + [os.path.join("..", "..", "include", "cutadapt_hip.h")]:
-        with open(os.path.join(base, f), "rb") as fh:
-            h.update(f.encode() + b"\0" + fh.read() + b"\0")
-    return h.hexdigest()
+    """sha256 over the kernel / host sources on disk (cutadapt_amd.build.source_hash): what a library built now would carry"""
+    from cutadapt_amd import build
+    return build.source_hash()
+
+
+def library_hash() -> str:
+    """the hash the LOADED library carries (cah_build_id): the sources it was actually built from"""
+    from cutadapt_amd import _lib
+    return _lib.build_id()
 
 
 def profile_fields(config, n, dom, dom_launch_ms):
@@ -217,8 +217,8 @@ def profile_fields(config, n, dom, dom_launch_ms):
         return None, None, "no PMC profile of this config"
     if tj.get("reads_per_gpu") != n:
         return None, None, "the PMC profile was taken at another batch size"
-    if tj.get("csrc_sha256") != csrc_hash():
-        return None, None, "stale profile: cutadapt_amd/csrc changed since profiles/pmc_latest.json was taken"
+    if tj.get("csrc_sha256") != library_hash():
+        return None, None, "stale profile: profiles/pmc_latest.json was taken on another build of the library (cah_build_id differs)"
     k = tj.get("kernels", {}).get(dom)
     if not k:
         return None, None, "the PMC profile has no entry for the dominant kernel"
@@ -235,7 +235,7 @@ def profile_fields(config, n, dom, dom_launch_ms):
                           "for comparison with round 3) = SQ_ACTIVE_INST_VALU x 4 / SIMD-cycles, which counts every "
                           "instruction as 4 cycles and can exceed 1; wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES")
     valu["source"] = tj.get("source")
-    return traffic, valu, "profile taken on this source tree (sha256 match)"
+    return traffic, valu, "profile taken on this build of the library (cah_build_id match)"
 
 
 def run_config(args, config, n, steps, warmup, rank, world, device, gen, check_reads, cpu_seconds, want_cpu):

@@ -12,18 +12,18 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # CAH_LIB_PATH: developer knob to A/B-test a differently built kernel library
 LIB_PATH = os.environ.get("CAH_LIB_PATH") or os.path.join(_HERE, "libcutadapt_hip.so")
 
-CAH_OK, CAH_EINVAL, CAH_ETYPE, CAH_EHIP, CAH_ENOMEM, CAH_EUNSUPPORTED = 0, 1, 2, 3, 4, 5
+CAH_OK, CAH_EINVAL, CAH_ETYPE, CAH_EHIP, CAH_ENOMEM, CAH_EUNSUPPORTED, CAH_EINTERNAL = 0, 1, 2, 3, 4, 5, 6
 NONE, MATCH, INVALID = 0, 1, 2
 MAX_READ_LEN = 1000000        # CAH_MAX_READ_LEN of include/cutadapt_hip.h
 KIND_ALIGNER, KIND_PREFIX, KIND_SUFFIX, KIND_KMER_ONLY = 0, 1, 2, 3
-ABI_VERSION = 3              # CAH_ABI_VERSION of include/cutadapt_hip.h this binding was written against
+ABI_VERSION = 4              # CAH_ABI_VERSION of include/cutadapt_hip.h this binding was written against
 PROF_FILTER, PROF_DP, PROF_COMPARER, PROF_SCAN, PROF_MERGE, PROF_N = 0, 1, 2, 3, 4, 5
 
 # every symbol include/cutadapt_hip.h declares (tests check the library exports them all)
 EXPORTED_SYMBOLS = [
-    "cah_abi_version", "cah_last_error", "cah_device_count", "cah_set_device", "cah_device_info",
+    "cah_abi_version", "cah_build_id", "cah_last_error", "cah_device_count", "cah_set_device", "cah_device_info",
     "cah_plan_create", "cah_plan_destroy", "cah_plan_n_adapters", "cah_plan_effective_length",
-    "cah_plan_n_kmer_entries", "cah_plan_prefilter_kind", "cah_plan_multi_kind", "cah_plan_debug_matcher", "cah_plan_debug_lean", "cah_locate_batch", "cah_kmers_present_batch", "cah_match_batch", "cah_match_batch_uniform", "cah_match_batch_suffix_views", "cah_linked_views", "cah_linked_match_batch_uniform",
+    "cah_plan_n_kmer_entries", "cah_plan_prefilter_kind", "cah_plan_multi_kind", "cah_last_multi_path", "cah_plan_debug_matcher", "cah_plan_debug_lean", "cah_locate_batch", "cah_kmers_present_batch", "cah_match_batch", "cah_match_batch_uniform", "cah_match_batch_suffix_views", "cah_linked_views", "cah_linked_match_batch_uniform",
     "cah_workspace_bytes", "cah_plan_workspace_bytes", "cah_validate_ascii_batch", "cah_reverse_reads_batch", "cah_revcomp_reads_batch", "cah_locate_batch_host",
     "cah_kmers_present_batch_host", "cah_match_batch_host", "cah_locate_debug_host", "cah_match_one_host", "cah_locate_one_host", "cah_profile_enable",
     "cah_profile_reset", "cah_profile_read", "cah_synth_reads",
@@ -91,9 +91,13 @@ def lib():
     L = C.CDLL(LIB_PATH)
     vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
     L.cah_abi_version.restype = C.c_int
-    if L.cah_abi_version() != ABI_VERSION:
+    # (CAH_LIB_ANY_ABI=1 with CAH_LIB_PATH: developer A/B runs against an older round's build of the library)
+    any_abi = bool(os.environ.get("CAH_LIB_PATH")) and os.environ.get("CAH_LIB_ANY_ABI") == "1"
+    if L.cah_abi_version() != ABI_VERSION and not any_abi:
         raise HipLibraryMissing(f"{LIB_PATH} has ABI version {L.cah_abi_version()}, this binding needs {ABI_VERSION}: "
                                 "rebuild it with `python -m cutadapt_amd.build --force`")
+    if hasattr(L, "cah_build_id"):
+        L.cah_build_id.restype = C.c_char_p
     L.cah_last_error.argtypes = [C.c_char_p, C.c_size_t]
     L.cah_last_error.restype = None
     L.cah_device_count.argtypes = [C.POINTER(C.c_int)]
@@ -179,6 +183,23 @@ def last_error() -> str:
     return buf.value.decode("utf-8", "replace")
 
 
+class HipInternalError(RuntimeError):
+    """CAH_EINTERNAL: the library caught itself breaking one of its own invariants; the call's results are void"""
+
+
+def build_id() -> str:
+    """sha256 over the sources the LOADED library was built from (cah_build_id; cutadapt_amd.build.source_hash() is the
+    same hash over the sources on disk)"""
+    L = lib()
+    return L.cah_build_id().decode() if hasattr(L, "cah_build_id") else ""
+
+
+def last_multi_path() -> str:
+    """'sequential', 'fused' or 'stream': the form this thread's last match_batch call actually took ('' before the first)"""
+    v = lib().cah_last_multi_path()
+    return ("sequential", "fused", "stream")[v] if 0 <= v <= 2 else ""
+
+
 def check(rc: int) -> None:
     """Map a C status to the exception the reference would raise."""
     if rc == CAH_OK:
@@ -192,6 +213,8 @@ def check(rc: int) -> None:
         raise UnsupportedByHipPath(msg)
     if rc == CAH_ENOMEM:
         raise MemoryError(msg)
+    if rc == CAH_EINTERNAL:
+        raise HipInternalError(msg)
     raise RuntimeError(msg)
 
 

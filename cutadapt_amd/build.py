@@ -24,12 +24,35 @@ def _hipcc() -> str:
     return "hipcc"
 
 
+def source_hash() -> str:
+    """sha256 over everything the library is built from: csrc/*.{hip,h,cpp} + include/cutadapt_hip.h.  Embedded in the
+    library at build time (cah_build_id); bench.py ties PMC profiles to it."""
+    import hashlib
+    h = hashlib.sha256()
+    names = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".cpp")))
+    for f in names + [os.path.join("..", "..", "include", "cutadapt_hip.h")]:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read() + b"\0")
+    return h.hexdigest()
+
+
+def library_build_id(path: str = None) -> str:
+    """the build id embedded in a built library ("" if it cannot be read: missing file, older ABI)"""
+    import ctypes
+    try:
+        L = ctypes.CDLL(path or LIB_PATH)
+        L.cah_build_id.restype = ctypes.c_char_p
+        return L.cah_build_id().decode()
+    except Exception:
+        return ""
+
+
 def needs_build() -> bool:
+    """the library is missing or was built from other sources than those on disk (its embedded hash says so: file times
+    alone would pass a stale binary that was touched, or one that travelled without its sources)"""
     if not os.path.exists(LIB_PATH):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
-    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+    return library_build_id() != source_hash()
 
 
 def build_library(force: bool = False, verbose: bool = False, extra_flags=None, out_path=None) -> str:
@@ -47,15 +70,29 @@ def _build(extra_flags, lib_path, verbose, tag, force=False) -> str:
     obj_dir = os.path.join(_HERE, "csrc", "_obj" + tag)
     os.makedirs(obj_dir, exist_ok=True)
     procs = []
+    build_id = source_hash()
     newest_header = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS if os.path.exists(os.path.join(CSRC, h)))
     for src in SOURCES:
         obj = os.path.join(obj_dir, src + ".o")
         objs.append(obj)
         src_path = os.path.join(CSRC, src)
-        # an object is kept while it is newer than its source and every header (headers are not tracked per source)
-        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src_path), newest_header):
+        # an object is kept while it is newer than its source and every header (headers are not tracked per source);
+        # api.cpp carries the build id -- the hash of ALL sources -- and is compiled whenever that changed
+        id_file = obj + ".build_id"
+        stale_id = False
+        if src == "api.cpp":
+            try:
+                stale_id = open(id_file).read() != build_id
+            except OSError:
+                stale_id = True
+        if not force and not stale_id and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src_path), newest_header):
             continue
-        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-x", "hip"] + list(extra_flags) + \
+        flags = list(extra_flags)
+        if src == "api.cpp":
+            flags.append(f'-DCAH_BUILD_ID="{build_id}"')
+            with open(id_file, "w") as fh:
+                fh.write(build_id)
+        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-x", "hip"] + flags + \
               ["-c", src_path, "-o", obj]
         if verbose:
             print(" ".join(cmd))

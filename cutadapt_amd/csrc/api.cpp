@@ -811,6 +811,11 @@ extern "C" {
 
 int cah_abi_version(void) { return CAH_ABI_VERSION; }
 
+#ifndef CAH_BUILD_ID
+#define CAH_BUILD_ID "unknown"
+#endif
+const char* cah_build_id(void) { return CAH_BUILD_ID; }
+
 void cah_last_error(char* buf, size_t buflen) {
     if (!buf || !buflen) return;
     snprintf(buf, buflen, "%s", g_last_error.c_str());
@@ -1040,6 +1045,7 @@ static const size_t WS_SCANWORK = 640 / sizeof(unsigned long long), WS_DPFRONT =
 static const size_t WS_DPBACK = 896 / sizeof(unsigned long long);
 // the streaming multi-adapter form's tile counter, which lives through the rounds of a batch (the rounds clear the header in front of it)
 static const size_t WS_M2_TILE = 960 / sizeof(unsigned long long);
+static const size_t WS_M2_ERR = 968 / sizeof(unsigned long long);     // multi2's error bits (kernels.h: Multi2Args::err); survives the rounds' re-zeroing
 static const size_t WS_RETRYCOUNT = 576 / sizeof(unsigned long long), WS_RETRYWORK = 704 / sizeof(unsigned long long);
 static int64_t ws_retry_cap(int64_t n_reads) { return n_reads / 8 + 1024; }
 
@@ -1428,6 +1434,10 @@ int cah_kmers_present_batch(const cah_plan* plan, int32_t adapter, const uint8_t
 // every match is merged into the read's best key with an atomic max (MultipleAdapters' order,
 // kernels.h: pack_best); a last kernel decodes the keys.  status/out6/best_adapter were initialised by
 // the caller; `extra` is the scratch behind the base workspace (cah_plan_workspace_bytes).
+// the form the calling thread's last cah_match_batch* call took for its plan's adapters (cah_last_multi_path)
+static thread_local int t_last_multi_path = -1;
+int cah_last_multi_path(void) { return t_last_multi_path; }
+
 static int match_batch_multi(const cah_plan* plan, const PlanDeviceCopy* pd, const uint8_t* d_seqs,
                              const int64_t* d_offsets, const int32_t* d_lens, int64_t n_reads, int32_t* d_out6,
                              int32_t* d_best_adapter, uint8_t* d_status, const Workspace& ws, char* extra,
@@ -1446,7 +1456,9 @@ static int match_batch_multi(const cah_plan* plan, const PlanDeviceCopy* pd, con
     HIP_TRY(hipMemsetAsync(d_best_key, 0, sizeof(unsigned long long) * (size_t)n_reads, s));
     // Equally long short reads take the streaming form (multi2.hip): k_multi_stream emits the pairs in pages of one
     // class each (the suffix compare of the error-free rows happens there), k_multi_scan scans them page by page.
+    t_last_multi_path = CAH_MULTI_FUSED;
     if (mp.m2.hdr.ok && ul.len > 0 && !d_lens && multi2_read_len_ok(mp.m2.hdr, ul.len) && !env_flag("CAH_NO_MULTI2")) {
+        t_last_multi_path = CAH_MULTI_STREAM;
         // the pool: pages of CAH_M2_PAGE pairs + one header word each, inside the pair area
         const int64_t max_pages = ((int64_t)cap * 8) / (CAH_M2_PAGE * 8 + 4);
         uint32_t* d_page_hdr = (uint32_t*)(d_pairs + max_pages * CAH_M2_PAGE);
@@ -1467,8 +1479,25 @@ static int match_batch_multi(const cah_plan* plan, const PlanDeviceCopy* pd, con
                 const int64_t sure = std::max<int64_t>(1, (gate - grid * open_pages) / per_tile);
                 rounds = (n_tiles + sure - 1) / sure;
             }
+            if (env_flag("CAH_TEST_M2_UNGATED")) { gate = (int64_t)1 << 60; rounds = 1; }   // tests only: provokes the pool's overflow
             HIP_TRY(hipMemsetAsync(counters, 0, WS_HEADER, s));
-          for (int64_t round = 0; round < rounds; round++) {
+          for (int64_t round = 0;; round++) {
+            if (round >= rounds) {
+                // The planned rounds are through.  Never trust the arithmetic above silently: the device says how many
+                // tiles were drawn and whether a kernel ran out of pages or waited in vain (kernels.h: Multi2Args::err).
+                unsigned long long st[2] = {0ull, 0ull};                // {tiles drawn, error bits}
+                HIP_TRY(hipMemcpyAsync(st, counters + WS_M2_TILE, sizeof(st), hipMemcpyDeviceToHost, s));
+                HIP_TRY(hipStreamSynchronize(s));
+                if (st[1])
+                    return fail(CAH_EINTERNAL, "multi-adapter path: %s (pool of %lld pages, %lld adapters, %lld reads): results discarded",
+                                (st[1] & 1ull) ? "the page pool ran out" : "a wave waited in vain for its tile",
+                                (long long)max_pages, (long long)A, (long long)cnt);
+                if ((int64_t)st[0] >= n_tiles) break;
+                // tiles are left (the worst-case round count was too small): go on, a round at a time
+                if (round >= rounds + 4 * n_tiles)
+                    return fail(CAH_EINTERNAL, "multi-adapter path: %lld of %lld tiles left after %lld rounds",
+                                (long long)(n_tiles - (int64_t)st[0]), (long long)n_tiles, (long long)round);
+            }
             if (round) HIP_TRY(hipMemsetAsync(counters, 0, WS_M2_TILE * sizeof(unsigned long long), s));
             {
                 Multi2Args f;
@@ -1479,6 +1508,7 @@ static int match_batch_multi(const cah_plan* plan, const PlanDeviceCopy* pd, con
                 f.seqs = d_seqs; f.first_read = lo; f.n_reads = cnt; f.status = d_status; f.best_key = d_best_key;
                 f.pairs = d_pairs; f.page_hdr = d_page_hdr; f.page_counter = counters + WS_QCOUNT; f.max_pages = max_pages;
                 f.tile_counter = counters + WS_M2_TILE; f.n_tiles = n_tiles; f.gate_pages = gate;
+                f.err = counters + WS_M2_ERR;
                 f.wmeta = d_wmeta;
                 ProfScope ps(s, CAH_PROF_FILTER, round ? -1 : cnt);
                 HIP_TRY(launch_multi_stream(f, mp.m2.hdr, (int)grid, s));
@@ -1490,7 +1520,7 @@ static int match_batch_multi(const cah_plan* plan, const PlanDeviceCopy* pd, con
                 sa.rows_lo = mp.m2.hdr.rows_lo;
                 sa.matcher = pd->d_matchers; sa.tab = pd->d_mscan; sa.n_adapters = (int32_t)A;
                 sa.seqs = d_seqs; sa.pairs = d_pairs; sa.page_hdr = d_page_hdr;
-                sa.page_counter = counters + WS_QCOUNT; sa.max_pages = max_pages;
+                sa.page_counter = counters + WS_QCOUNT; sa.max_pages = max_pages; sa.err = counters + WS_M2_ERR;
                 sa.work_counter = counters + WS_SCANWORK; sa.best_key = d_best_key;
                 sa.dp_queue = d_dpq; sa.dp_win = d_win;
                 sa.dp_count_front = counters + WS_DPFRONT; sa.dp_count_back = counters + WS_DPBACK; sa.dp_cap = cap;
@@ -1627,6 +1657,7 @@ static int match_batch_impl(const cah_plan* plan, const uint8_t* d_seqs, const i
             d_batch_flag = counters + WS_UFLAG;
         }
     }
+    t_last_multi_path = CAH_MULTI_SEQUENTIAL;
     if (plan->multi.hdr.ok && workspace_bytes >= cah_plan_workspace_bytes(plan, n_reads))
         return match_batch_multi(plan, pd, d_seqs, d_offsets, d_lens, n_reads, d_out6, d_best_adapter, d_status, ws,
                                  (char*)d_workspace + cah_workspace_bytes(n_reads), s, ul_rest);

@@ -232,6 +232,8 @@ struct Multi2Args {
     uint32_t* page_hdr;              // [max_pages]
     unsigned long long* page_counter;        // zeroed before launch: pages handed out
     int64_t max_pages;
+    unsigned long long* err;         // set (never cleared) by the kernels when the pool or a wait gives out: bit 0 = a page beyond
+                                     // max_pages was handed out (pairs were lost), bit 1 = a wave waited in vain for its tile
     // the tiles (M2_TILE reads) of [first_read, first_read + n_reads) are drawn from tile_counter, which lives through the
     // ROUNDS of a batch: a launch draws no further tile once more than gate_pages pages are handed out, and the next
     // round (after the scan and the cell DP have emptied the pool) goes on where it stopped
@@ -252,6 +254,7 @@ struct Multi2ScanArgs {
     const uint32_t* page_hdr;
     const unsigned long long* page_counter;
     int64_t max_pages;
+    unsigned long long* err;         // (Multi2Args::err)
     unsigned long long* work_counter;        // zeroed before launch
     unsigned long long* best_key;
     int32_t* dp_queue;               // out: pair indices that need the cell DP (filled from both ends, see DpArgs)

@@ -48,6 +48,7 @@
 #define M2_MAX_LEN (2 * M2_HALF * 16)
 #define M2_RING 128                // events per wave ring (two rounds)
 #define M2_TILE_RING 16           // the block's last tiles: {its own count, the batch's tile} (see take_tile)
+#define M2_TILEMAP_SPINS (1u << 24)     // polls (with s_sleep) a wave waits for its tile entry before it gives up: seconds, not forever
 #define M2_NO_TILE 0xFFFFFFFFu
 
 typedef unsigned int m2_u32x2 __attribute__((ext_vector_type(2)));
@@ -208,7 +209,18 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
     auto piece_base = [&](unsigned p) -> int64_t {
         const unsigned kt = p / PPT;
         unsigned long long e;
-        do { e = s_tilemap[kt & (M2_TILE_RING - 1)]; } while ((unsigned)(e >> 32) != kt);
+        // (the entry is written a whole tile ahead of its first use: the wait is short -- and bounded: a wave that waits
+        // in vain says so (err bit 1, match_batch_multi returns CAH_EINTERNAL) instead of hanging the device)
+        unsigned spins = 0;
+        for (;;) {
+            e = s_tilemap[kt & (M2_TILE_RING - 1)];
+            if ((unsigned)(e >> 32) == kt) break;
+            if (++spins > M2_TILEMAP_SPINS) {
+                if (lane == 0) atomicOr(a.err, 2ull);
+                return NO_PIECE;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
         const unsigned t = __builtin_amdgcn_readfirstlane((unsigned)e);
         if (p % PPT == 0 && kt >= 1) {
             unsigned nt = M2_NO_TILE;
@@ -319,8 +331,11 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
         if (page == 0xFFFFFFFFu || fill + cnt > CAH_M2_PAGE) {
             unsigned np = 0;
             if (lane == 0) {
-                if (page != 0xFFFFFFFFu) a.page_hdr[page] = ((unsigned)pc << 24) | fill;
+                if (page != 0xFFFFFFFFu && (int64_t)page < a.max_pages) a.page_hdr[page] = ((unsigned)pc << 24) | fill;
                 np = (unsigned)atomicAdd(a.page_counter, 1ull);
+                // The gate (api.cpp) keeps the pool from running out; should its arithmetic ever be wrong the pairs of this
+                // page are lost -- never silently: the flag makes match_batch_multi fail with CAH_EINTERNAL.
+                if ((int64_t)np >= a.max_pages) atomicOr(a.err, 1ull);
             }
             page = __builtin_amdgcn_readfirstlane(np);
             fill = 0;
@@ -787,7 +802,10 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_multi
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int n = a.uniform_len;
     int64_t n_pages = (int64_t)(*a.page_counter);
-    if (n_pages > a.max_pages) n_pages = a.max_pages;
+    if (n_pages > a.max_pages) {                                        // (k_multi_stream has flagged it; said again here)
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(a.err, 1ull);
+        n_pages = a.max_pages;
+    }
 
     for (;;) {
         __syncthreads();

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define CAH_ABI_VERSION 3   /* 2: CAH_PROF_N = 5, plan workspaces (cah_plan_workspace_bytes), no adapter length limit; 3: cah_plan_multi_kind */
+#define CAH_ABI_VERSION 4   /* 2: CAH_PROF_N = 5, plan workspaces (cah_plan_workspace_bytes), no adapter length limit; 3: cah_plan_multi_kind; 4: cah_build_id, cah_last_multi_path, CAH_EINTERNAL */
 
 /* status codes */
 #define CAH_OK 0
@@ -51,6 +51,9 @@ extern "C" {
 #define CAH_EHIP 3          /* HIP runtime failure, message has the hipError string */
 #define CAH_ENOMEM 4
 #define CAH_EUNSUPPORTED 5  /* outside this build's limits (read > 1e6 characters, device is not gfx950, ...) */
+#define CAH_EINTERNAL 6     /* the library caught itself breaking one of its own invariants (e.g. the page pool of the
+                               streaming multi-adapter path ran out although the gate should have prevented it): the
+                               results of the call are not to be used; never returned for bad input */
 
 /* per-read result status */
 #define CAH_NONE 0
@@ -104,6 +107,9 @@ typedef struct cah_plan cah_plan;
 
 /* ---- library / device ---------------------------------------------------------------- */
 int cah_abi_version(void);
+/* sha256 (hex) over the sources the library was built from (cutadapt_amd/csrc/ + this header), embedded at build time by
+ * cutadapt_amd/build.py: ties a binary -- not just a source tree -- to a profile or a bench line */
+const char *cah_build_id(void);
 /* copies the calling thread's last error message (NUL-terminated) into buf */
 void cah_last_error(char *buf, size_t buflen);
 int cah_device_count(int *count);
@@ -138,6 +144,10 @@ int cah_plan_prefilter_kind(const cah_plan *plan, int32_t adapter, int32_t *out)
 #define CAH_MULTI_FUSED 1
 #define CAH_MULTI_STREAM 2
 int cah_plan_multi_kind(const cah_plan *plan, int32_t read_len, int32_t *out);
+/* the form the calling thread's LAST cah_match_batch / cah_match_batch_uniform call actually took (one of the three
+ * above; -1 before the first call): cah_plan_multi_kind says what a plan can do for a read length, this says what ran
+ * -- a ragged batch or a workspace smaller than cah_plan_workspace_bytes falls back without an error */
+int cah_last_multi_path(void);
 /* Introspection for tests: copies the host-side matcher table of an adapter (struct CahMatcher of
  * cutadapt_amd/csrc/cah_device.h: DP constants, row bitsets, cost-scan tables) into buf; *need receives
  * its size.  The layout is internal to the library version. */

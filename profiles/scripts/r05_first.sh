@@ -5,7 +5,7 @@ cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 out=gpurun_out/r05a; mkdir -p $out
 timeout 120 ./gpurun_in/r05_valu_ubench > $out/valu_ubench.txt 2>&1; tail -n 40 $out/valu_ubench.txt | cut -c1-110
 ab() {  # tag lib config steps
-  CAH_LIB_PATH=$2 timeout 400 python bench.py --config $3 --steps $4 --warmup 2 --no-cpu-baseline --no-other-configs --check-reads 200000 > $out/b_$1.json 2> $out/b_$1.err
+  CAH_LIB_ANY_ABI=1 CAH_LIB_PATH=$2 timeout 400 python bench.py --config $3 --steps $4 --warmup 2 --no-cpu-baseline --no-other-configs --check-reads 200000 > $out/b_$1.json 2> $out/b_$1.err
   python - "$1" "$out/b_$1" <<'PY'
 import json,sys
 try:
@@ -25,7 +25,7 @@ ab prod_c4 $P/libcutadapt_hip.so C4 3
 ab base_c5 $P/libcutadapt_hip_base.so C5 3
 ab prod_c5 $P/libcutadapt_hip.so C5 3
 for t in trace_base trace; do
-  echo "== scan trace: $t"; CAH_LIB_PATH=$P/libcutadapt_hip_$t.so timeout 300 python profiles/scripts/scan_trace.py 2>&1 | tail -n 8
+  echo "== scan trace: $t"; CAH_LIB_ANY_ABI=1 CAH_LIB_PATH=$P/libcutadapt_hip_$t.so timeout 300 python profiles/scripts/scan_trace.py 2>&1 | tail -n 8
 done > $out/scan_trace.txt 2>&1
 cat $out/scan_trace.txt
-timeout 1200 python -m pytest tests/test_gpu_scan.py tests/test_gpu_multi2.py tests/test_gpu_configs.py tests/test_gpu_parity.py -x -q -m gpu > $out/tests.log 2>&1; tail -n 3 $out/tests.log
+timeout 1200 python -m pytest tests -x -q -m gpu --timeout 600 > $out/tests.log 2>&1; tail -n 5 $out/tests.log

@@ -26,6 +26,9 @@ def run_uniform(orc, seqs, rate, min_overlap, reads, what, expect="stream", pair
     with env(CAH_MULTI_PAIR_CAP=pair_cap):
         res = match_batch(plan, batch)
         got6, got_st, got_best = res.cpu()
+        if expect is not None:
+            from cutadapt_amd import _lib
+            assert _lib.last_multi_path() == expect, (what, _lib.last_multi_path())      # what ran, not what could have
     want6, want_st, want_best = oracle_multiple(orc, ads, sq, offs)
     bad = np.nonzero((got_st != want_st) | (got6 != want6).any(axis=1))[0]
     assert len(bad) == 0, (what, len(bad), bad[:5], got_st[bad[:3]], got6[bad[:3]], want_st[bad[:3]], want6[bad[:3]],
@@ -146,3 +149,104 @@ def test_occurrence_window_regressions(hip, orc):
         streamed += plan.multi_kind(n) == "stream"
         run_uniform(orc, seqs, rate, O, reads, f"mixed it {it} m {m} x {count} rate {rate} O {O} n {n}", expect=None)
     assert streamed >= 4, streamed                          # (5 with these seeds: the other plans take the older kernels)
+
+
+def _near_duplicates(prng, base, count):
+    """adapters that share most of their chunks with `base`: every read that holds `base` pairs with every adapter"""
+    out = [base]
+    for i in range(1, count):
+        s = list(base)
+        p = (7 * i) % len(base)
+        s[p] = "ACGT"[("ACGT".index(s[p]) + 1 + i % 3) % 4]
+        out.append("".join(s))
+    return out
+
+
+def test_every_adapter_on_every_read_with_a_minimal_pool(hip, orc):
+    """Round-4 review: the page pool's gate is host arithmetic, and a pair beyond the pool used to be dropped without a word.
+    The worst case the arithmetic is made for -- every adapter pairs with every read -- with the smallest pool the library
+    accepts (CAH_MULTI_PAIR_CAP=1: the floor of one block's reserve): several rounds, every tuple against the oracle."""
+    prng = random.Random(41)
+    for count, m, n_reads in ((8, 33, 40_000), (24, 33, 12_000), (96, 33, 4_000)):
+        seqs = _near_duplicates(prng, rs(prng, m), count)
+        reads = []
+        for i in range(n_reads):
+            pos = prng.randrange(0, 150 - m + 12)
+            r = rs(prng, pos) + seqs[i % count] + rs(prng, 150)
+            reads.append(r[:150])
+        found = run_uniform(orc, seqs, 0.1, 3, reads, f"{count} near-duplicates, minimal pool", pair_cap=1)
+        assert found > 0.9 * n_reads
+
+
+def test_pool_overflow_fails_loudly(hip):
+    """... and when the gate IS taken away (CAH_TEST_M2_UNGATED=1, a test-only knob that lets the blocks draw tiles whatever
+    the pool holds) the call does not return wrong tuples: the kernels flag the page they could not get, match_batch_multi
+    answers CAH_EINTERNAL, the binding raises HipInternalError.  The same batch with the gate in place is served."""
+    import torch
+    from cutadapt_amd import _lib
+    from cutadapt_amd.batch import ReadBatch, match_batch
+    prng = random.Random(43)
+    seqs = _near_duplicates(prng, rs(prng, 33), 8)
+    batch = ReadBatch.synthetic(300_000, 150, seqs, seed=77, p_adapter=0.95, p_edit=0.01, p_n=0.0)
+    plan, _ = plan_for(seqs, 0.1, 3)
+    assert plan.multi_kind(150) == "stream"
+    with env(CAH_MULTI_PAIR_CAP="1"):
+        ok = match_batch(plan, batch)
+        torch.cuda.synchronize()
+        st_ok = ok.status.clone()
+        with env(CAH_TEST_M2_UNGATED="1"):
+            with pytest.raises(_lib.HipInternalError, match="page pool ran out"):
+                match_batch(plan, batch)
+                torch.cuda.synchronize()
+        # the library is not left in a bad state: the next call is served and agrees
+        again = match_batch(plan, batch)
+        torch.cuda.synchronize()
+        assert torch.equal(again.status, st_ok) and torch.equal(again.out6, ok.out6)
+    assert int((st_ok == 1).sum()) > 0.8 * 300_000
+
+
+def test_first_occurrence_race_at_scale(hip, orc):
+    """Round 4's second hole was a lane race (which lane emits a pair need not hold the pair's earliest occurrence) that no
+    CPU model sees.  Adapters made of repeated chunks, reads with two and three copies: 3 x 4 M reads, the streaming form
+    against the older kernels in full and against the oracle on a sample, three seeds."""
+    import torch
+    from cutadapt_amd.batch import ReadBatch, match_batch
+    for seed in (11, 12, 13):
+        prng = random.Random(1000 + seed)
+        unit = rs(prng, 8)
+        seqs = []
+        for i in range(12):
+            u2 = rs(prng, 8)
+            seqs.append((unit + u2 + unit + rs(prng, 9))[:33] if i % 2 == 0 else (u2 + unit + rs(prng, 8) + unit + "A")[:33])
+        plan, ads = plan_for(seqs, 0.1, 3)
+        assert plan.multi_kind(150) == "stream"
+        n_reads = 4_000_000
+        batch = ReadBatch.synthetic(n_reads, 150, seqs, seed=seed, p_adapter=0.7, p_edit=0.03, p_n=0.002)
+        # a second (and sometimes third) copy of the shared chunk in front of the adapter copy, in every fourth read
+        view = batch.seqs.view(n_reads, 150)
+        u = torch.tensor(list(unit.encode()), dtype=torch.uint8, device=batch.seqs.device)
+        idx = torch.arange(0, n_reads, 4, device=batch.seqs.device)
+        at = (idx * 2654435761 >> 7) % 120
+        for t in range(8):
+            view[idx, at + t] = u[t]
+        idx3 = idx[::3]
+        at3 = ((idx3 * 40503 >> 3) % 100) + 30
+        for t in range(8):
+            view[idx3, at3 + t] = u[t]
+        a = match_batch(plan, batch)
+        torch.cuda.synchronize()
+        a6, ast, ab = a.out6.clone(), a.status.clone(), a.best_adapter.clone()
+        with env(CAH_NO_MULTI2="1"):
+            b = match_batch(plan, batch)
+            torch.cuda.synchronize()
+        assert torch.equal(ast, b.status) and torch.equal(a6, b.out6), seed
+        f = ast == 1
+        assert torch.equal(ab[f], b.best_adapter[f]), seed
+        m = 20_000
+        sq = batch.seqs[: m * 150].cpu().numpy()
+        offs = np.arange(m + 1, dtype=np.int64) * 150
+        want6, want_st, want_best = oracle_multiple(orc, ads, sq, offs)
+        assert np.array_equal(ast[:m].cpu().numpy(), want_st) and np.array_equal(a6[:m].cpu().numpy(), want6), seed
+        fw = want_st == 1
+        assert np.array_equal(ab[:m].cpu().numpy()[fw], want_best[fw]), seed
+        assert int(f.sum()) > 0.4 * n_reads

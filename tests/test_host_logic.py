@@ -51,7 +51,11 @@ def test_library_is_built_and_exports_every_declared_symbol():
     L = _lib.lib()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.cah_abi_version() == _lib.ABI_VERSION == 3
+    assert L.cah_abi_version() == _lib.ABI_VERSION == 4
+    # the binary says which sources it was built from (cah_build_id), and build.needs_build() goes by that, not by file times
+    from cutadapt_amd import build
+    assert _lib.build_id() == build.source_hash() == build.library_build_id(), "stale library: python -m cutadapt_amd.build"
+    assert not build.needs_build()
     out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
     exported = set(re.findall(r" T (cah_[a-z0-9_]+)", out))
     assert declared <= exported
