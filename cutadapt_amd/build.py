@@ -12,7 +12,7 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libcutadapt_hip.so")
-SOURCES = ["api.cpp", "kernels.hip", "stream2.hip", "multi.hip", "multi2.hip", "long.hip", "fastq_gpu.hip", "synth_kernel.hip", "fastq.cpp", "index.hip", "qualtrim.hip"]
+SOURCES = ["api.cpp", "kernels.hip", "scan3.hip", "stream2.hip", "multi.hip", "multi2.hip", "long.hip", "fastq_gpu.hip", "synth_kernel.hip", "fastq.cpp", "index.hip", "qualtrim.hip"]
 HEADERS = ["cah_device.h", "kernels.h", "back_scan.h", "dev_common.h", "filter_common.h", "stream2.h", "multi2.h", "revcomp.h", os.path.join("..", "..", "include", "cutadapt_hip.h")]
 ARCH = "gfx950"
 

@@ -209,10 +209,13 @@ CAH_HD void bs_init(BackScanState& s, const BackScanParams& p) {
 // Row m of the column just processed: the bookkeeping every representation shares.  clean: the diagonal that ends
 // in (m, j) has met no cell whose diagonal delta is 0 although its characters differ.  Returns true when the read
 // is finished as EXACT_FULL at this column.
+// jlim: columns behind it are not booked (bs3's class F: a window of whole chunks may run a few columns past the last one
+// its chunk occurrences answer for -- what is acceptable there stems from occurrences nobody has looked at, and cannot
+// matter if the window holds a candidate at all, see bs3 below).
 template <bool SUBS>
 CAH_HD bool bs_book(BackScanBook& s, const bool clean, const int j, const BackScanParams& p, const bool del = false,
-                    const bool pred_unclean = true) {
-    if (s.cm <= p.kacc) {
+                    const bool pred_unclean = true, const int jlim = 0x7FFFFFFF) {
+    if (s.cm <= p.kacc && j <= jlim) {
         if (s.jfa < 0) s.jfa = j;
         s.jla = j;
         if (SUBS && s.cm == s.cmin) s.emore = true;
@@ -280,7 +283,8 @@ CAH_HD void bs32_init(BackScanState32<X>& s, const BackScanParams& p) {
 }
 
 template <bool SUBS, int X, bool BOOK = true>
-CAH_HD bool bs32_step(BackScanState32<X>& s, const uint32_t eq, const uint32_t eqx, const int j, const BackScanParams& p) {
+CAH_HD bool bs32_step(BackScanState32<X>& s, const uint32_t eq, const uint32_t eqx, const int j, const BackScanParams& p,
+                      const int jlim = 0x7FFFFFFF) {
     // ---- the explicit rows 1..X and what they hand to the word: hin, and the bits that enter its diagonals
     uint32_t hpos = 0, hneg = 0, a_in = 0, u_in = 0, z_in = 0, a_top_new = 0;
     if (X == 1) {
@@ -342,7 +346,7 @@ CAH_HD bool bs32_step(BackScanState32<X>& s, const uint32_t eq, const uint32_t e
         s.Z = bs_sel(Xc, pa, X > 1 ? (bs_dbl(s.Z) | z_in) : bs_dbl(s.Z));
     }
     if (__builtin_expect(s.cm <= p.kacc, 0))
-        return bs_book<SUBS>(s, (s.A >> 31) == 0, j, p, (s.U >> 31) != 0, (s.Z >> 31) != 0);
+        return bs_book<SUBS>(s, (s.A >> 31) == 0, j, p, (s.U >> 31) != 0, (s.Z >> 31) != 0, jlim);
     return false;
 }
 
@@ -458,9 +462,12 @@ CAH_HD BsRowStats bs_last_column_stats(const BsLastColumn<W, X>& col, const int 
 template <bool INDEL1, bool TRACKED, class W, int X, class ThrLast>
 CAH_HD int bs_finish_rows(const BackScanBook& s, const BsLastColumn<W, X>& col, const int n, const int j0,
                           const BackScanParams& p, ThrLast thr_last, int& o0, int& o1, const bool stopped,
-                          const int max_row = CAH_BS_ALL_ROWS) {
+                          const int max_row = CAH_BS_ALL_ROWS, const int dp_lo_in = -1) {
     o0 = 0; o1 = 0;
     const int reach = p.m + p.k + 1;
+    // the cell DP's first column is never before dp_lo: the scan's own window start, unless the caller knows an earlier
+    // column that is as safe (bs3: the window starts BEHIND jfa - reach, the prefilter's column-skipping position does not)
+    const int dp_lo = dp_lo_in >= 0 ? dp_lo_in : j0;
     // one insertion / one deletion (see the header); INDEL1 = false: the form does not keep the bits
     const bool indel1 = INDEL1 && s.cmin >= 1 && !s.eclean && !s.epred_unclean && s.je - p.m - 1 >= j0 &&
                         s.je + 1 - s.jfa <= p.half_m - p.kacc && !(s.edel && s.emore);
@@ -472,7 +479,7 @@ CAH_HD int bs_finish_rows(const BackScanBook& s, const BsLastColumn<W, X>& col, 
         }
         if (indel1) { o0 = s.je; o1 = s.cmin * 2 + (s.edel ? 1 : 0); return BS_INDEL1_FULL; }
         const int s0 = s.jfa - reach;
-        o0 = s0 > j0 ? s0 : j0;
+        o0 = s0 > dp_lo ? s0 : dp_lo;
         o1 = s.jla * 2;
         return BS_DP;
     }
@@ -489,7 +496,7 @@ CAH_HD int bs_finish_rows(const BackScanBook& s, const BsLastColumn<W, X>& col, 
         if (best_i == 0) return BS_NONE;
         if (w_row > 0 && unclean_bound < w_score && clause_ok) { o0 = w_row; o1 = w_cost; return BS_EXACT_TAIL; }
         const int s0 = n - reach;
-        o0 = s0 > j0 ? s0 : j0;
+        o0 = s0 > dp_lo ? s0 : dp_lo;
         o1 = n * 2 + 1;
         return BS_DP;
     }
@@ -500,7 +507,7 @@ CAH_HD int bs_finish_rows(const BackScanBook& s, const BsLastColumn<W, X>& col, 
     }
     if (indel1 && !tail_may_win1) { o0 = s.je; o1 = s.cmin * 2 + (s.edel ? 1 : 0); return BS_INDEL1_FULL; }
     const int s0 = s.jfa - reach;
-    o0 = s0 > j0 ? s0 : j0;
+    o0 = s0 > dp_lo ? s0 : dp_lo;
     o1 = best_i == 0 ? s.jla * 2 : n * 2 + 1;
     return BS_DP;
 }
@@ -508,22 +515,174 @@ CAH_HD int bs_finish_rows(const BackScanBook& s, const BsLastColumn<W, X>& col, 
 // TRACKED: the scan ran with SUBS (the accumulator A means something)
 template <bool TRACKED = true, class ThrLast>
 CAH_HD int bs_finish(const BackScanState& s, const int n, const int j0, const BackScanParams& p,
-                     ThrLast thr_last, int& o0, int& o1, const bool stopped = false, const int max_row = CAH_BS_ALL_ROWS) {
+                     ThrLast thr_last, int& o0, int& o1, const bool stopped = false, const int max_row = CAH_BS_ALL_ROWS,
+                     const int dp_lo = -1) {
     const int pad = 64 - p.m;
     BsLastColumn<uint64_t, 0> col;
     col.vp = pad == 0 ? s.VP : (s.VP >> pad); col.vn = pad == 0 ? s.VN : (s.VN >> pad);
     col.a = pad == 0 ? s.A : (s.A >> pad);
     col.cx[0] = 0; col.ax = 0;
-    return bs_finish_rows<false, TRACKED>(s, col, n, j0, p, thr_last, o0, o1, stopped, max_row);
+    return bs_finish_rows<false, TRACKED>(s, col, n, j0, p, thr_last, o0, o1, stopped, max_row, dp_lo);
 }
 
 template <int X, bool TRACKED = true, class ThrLast>
 CAH_HD int bs32_finish(const BackScanState32<X>& s, const int n, const int j0, const BackScanParams& p,
-                       ThrLast thr_last, int& o0, int& o1, const bool stopped = false, const int max_row = CAH_BS_ALL_ROWS) {
+                       ThrLast thr_last, int& o0, int& o1, const bool stopped = false, const int max_row = CAH_BS_ALL_ROWS,
+                       const int dp_lo = -1) {
     const int pad = X > 0 ? 0 : 32 - p.m;
     BsLastColumn<uint32_t, X> col;
     col.vp = s.VP >> pad; col.vn = s.VN >> pad; col.a = s.A >> pad;
     for (int t = 0; t < (X > 0 ? X : 1); ++t) col.cx[t] = s.cx[t];
     col.ax = s.ax;
-    return bs_finish_rows<TRACKED, TRACKED>(s, col, n, j0, p, thr_last, o0, o1, stopped, max_row);
+    return bs_finish_rows<TRACKED, TRACKED>(s, col, n, j0, p, thr_last, o0, o1, stopped, max_row, dp_lo);
+}
+
+// =================================================================================================================
+// bs3: the scan's windows from the adapter's own chunks (round 5; k_back_scan3 in scan3.hip, tests/host_model).
+//
+// A last-row candidate (cost <= kacc over all m rows, reference _align.pyx:496-533) is an alignment with at most kacc
+// edit operations; cut the adapter into k + 1 >= kacc + 1 consecutive chunks (kmer_heuristic's whole-read set, so that
+// the prefilter's column-skipping position holds for them) and one chunk is untouched: its rows lie on ONE diagonal of
+// cells whose characters match (the aligner's own relation: the bits of the scan's match words).  If that chunk ends in
+// row E at column f, the alignment's diagonal there is S = f - E ("the copy starts behind column S"), the alignment
+// starts at a column >= S - kacc and ends at one <= S + m + kacc.  So the chunk occurrences of a read -- a shift-and word
+// M over the match words: M = ((M << 1) | START) & eq, hits = M & END -- say where candidates can be at all:
+//   * no occurrence: no last-row candidate; only the rows of the last column can match, and their alignments lie in the
+//     read's last m + k columns (class T).
+//   * the FIRST occurrence has diagonal S1 and every other occurrence up to column S1 + m + 4 kacc + m/2 lies on a
+//     diagonal within S1 +- kacc ("in the band": the chunks of one copy, shifted by its insertions / deletions): every
+//     candidate that could be the first best or replace one (an overlapping one: origin <= best.origin + m/2, :521-524;
+//     later occurrences than that column have origins behind every possible best's + m/2) lies in columns
+//     [S1 - 2 kacc - 1, S1 + 2 kacc + m]: 47 columns for a 33-character adapter, THREE 16-column chunks instead of the
+//     six to seven from (first k-mer hit) - m - k - 1 to 23 columns behind the last acceptable column.
+//     - class F: that window ends more than gap_last = k + 1 + kacc + m/2 columns before the read's end: the scan stops
+//       at its end ("stopped", see the header) and books no column behind S1 + 2 kacc + m (a window of whole 16-column
+//       chunks runs a little further: what is acceptable there belongs to occurrences behind the pre-pass range, which
+//       cannot replace a best of this window -- and if the window has none (a chance occurrence), the read is scanned the
+//       conservative way: straggler list).
+//     - class E: otherwise the window is joined with the read's last m + k + 1 columns and runs to the end.
+//   * an occurrence outside the band: class C, the conservative window from the prefilter's position.
+// The windowed costs are >= the true ones and equal wherever the optimal paths lie inside the window:
+// every relevant candidate's does, so jfa / jla / cmin and the diagonal bits at candidate columns are the reference's.
+// The cell DP of a read the scan cannot finish starts where it always did (dp_lo: the column-skipping position).
+struct Bs3Geom {
+    uint32_t start, end;      // word bits of the chunks' first / last rows (rows of the 32-bit word only: a first chunk that
+                              // loses its explicit rows matches more often -- more occurrences are as exact)
+    int roff;                 // row of word bit b = b + roff
+    int maxlen;               // longest chunk (characters)
+    int ok;
+};
+
+// the chunks of kmer_heuristic.kmer_chunks(adapter, k + 1) (reference kmer_heuristic.py:6-21): sizes m / (k + 1), the
+// first m % (k + 1) one longer.  Only the 32-bit forms (m <= 34, bs_kind_of(m) in 1..3).
+CAH_HD Bs3Geom bs3_geom(const int m, const int k, const int kacc) {
+    Bs3Geom g;
+    g.start = 0; g.end = 0; g.roff = 0; g.maxlen = 0; g.ok = 0;
+    const int kind = bs_kind_of(m);
+    if (kind == 0 || kacc < 0 || k < kacc || k + 1 > m) return g;
+    const int X = kind >= 2 ? kind - 1 : 0;
+    g.roff = X > 0 ? X + 1 : 1 - (32 - m);
+    const int chunks = k + 1, base = m / chunks, extra = m % chunks;
+    int row = 1;                                              // first row of the chunk
+    for (int c = 0; c < chunks; ++c) {
+        const int len = base + (c < extra ? 1 : 0);
+        const int first = row > X ? row : X + 1, last = row + len - 1;
+        if (last < first) return g;                           // a chunk made of explicit rows only: not served
+        g.start |= 1u << (first - g.roff);
+        g.end |= 1u << (last - g.roff);
+        if (len > g.maxlen) g.maxlen = len;
+        row += len;
+    }
+    g.ok = 1;
+    return g;
+}
+
+struct Bs3Pre {
+    uint32_t M, band, bad;
+    int found;                // an occurrence was seen
+    int s1;                   // its diagonal: the copy occupies columns s1 + 1 .. s1 + m
+};
+CAH_HD void bs3_pre_init(Bs3Pre& s) { s.M = 0; s.band = ~0u; s.bad = 0; s.found = 0; s.s1 = 0; }
+// columns of the pre-pass behind the first occurrence's diagonal (see above)
+CAH_HD int bs3_range(const BackScanParams& p) { return p.m + 4 * p.kacc + p.half_m; }
+// the band of word bits [b1 - kacc, b1 + kacc]
+CAH_HD uint32_t bs3_band(const int b1, const int kacc) {
+    const int width = 2 * kacc + 1;
+    const uint32_t w = width >= 32 ? ~0u : ((1u << width) - 1u);
+    const int lo = b1 - kacc;
+    return lo >= 0 ? (lo >= 32 ? 0u : (w << lo)) : ((-lo) >= 32 ? 0u : (w >> (-lo)));
+}
+// column j (1-based) with the match word eq of its character; `commit`: occurrences outside the band count (the column
+// lies inside the pre-pass range of this read)
+CAH_HD void bs3_pre_step(Bs3Pre& s, const uint32_t eq, const int j, const Bs3Geom& g, const int kacc, const bool commit) {
+    s.M = ((s.M << 1) | g.start) & eq;
+    const uint32_t h = s.M & g.end;
+    if (s.found) s.band <<= 1;
+    if (!s.found && h != 0) {
+        const int b1 = bs_top_bit(h);                         // (two chunks ending in one column: the other is out of band)
+        s.found = 1;
+        s.s1 = j - (b1 + g.roff);
+        s.band = bs3_band(b1, kacc);
+    }
+    if (commit) s.bad |= h & ~s.band;
+}
+// first character (0-based) of the pre-pass: every chunk that ends in the prefilter's first-hit group or later is seen whole
+CAH_HD int bs3_pre_start(const int key4, const Bs3Geom& g) {
+    const int p0 = key4 - (g.maxlen - 1);
+    return p0 > 0 ? p0 : 0;
+}
+// number of 16-character chunks from p0 on that the pre-pass of a read commits: all up to the read's end while nothing is
+// found; once the first occurrence is known, those that hold a column <= s1 + range
+CAH_HD int bs3_pre_chunks(const int p0, const int n, const bool found, const int s1, const int range) {
+    int last = n;                                             // last column (1-based) to look at
+    if (found && s1 + range < n) last = s1 + range;
+    const int cols = last - p0;                               // columns p0 + 1 .. last
+    return cols <= 0 ? 0 : (cols + 15) >> 4;
+}
+
+enum { BS3_T = 0, BS3_F = 1, BS3_E = 2, BS3_C = 3 };
+struct Bs3Win {
+    int cls;                  // BS3_*
+    int start;                // the scan's first column is start + 1 (its state at column `start` is the plain first column)
+    int jend;                 // ... its last one
+    int jlim;                 // the last column that is booked (class F: S1 + 2 kacc + m, the last one the band answers for;
+                              // a window of whole chunks ends a little later)
+};
+// j0_old: the conservative start (column-skipping position).  Windows that run to the read's end are a whole number of
+// 16-column chunks where the read is long enough (start = n - 16 c), so that their last chunk ends with the read.
+// the window from column `from` (or the tail's first column, whichever is earlier) to the read's end, every column booked
+CAH_HD Bs3Win bs3_window_to_end(const int from, const int n, const BackScanParams& p) {
+    Bs3Win w;
+    w.cls = BS3_E; w.jlim = 0x7FFFFFFF; w.jend = n;
+    const int reach = p.m + p.k + 1;
+    const int tail0 = n - reach > 0 ? n - reach : 0;
+    const int start0 = from < tail0 ? from : tail0;
+    const int c = (n - start0 + 15) >> 4;
+    w.start = n - 16 * c > 0 ? n - 16 * c : 0;
+    return w;
+}
+CAH_HD Bs3Win bs3_window(const Bs3Pre& s, const int n, const int j0_old, const BackScanParams& p) {
+    Bs3Win w;
+    w.jlim = 0x7FFFFFFF;
+    const int reach = p.m + p.k + 1;
+    const int tail0 = n - reach > 0 ? n - reach : 0;
+    int start0;
+    if (!s.found) { w.cls = BS3_T; start0 = tail0; }
+    else if (s.bad) { w.cls = BS3_C; start0 = j0_old < tail0 ? j0_old : tail0; }
+    else {
+        const int a = s.s1 - 2 * p.kacc - 1 > 0 ? s.s1 - 2 * p.kacc - 1 : 0;
+        const int D = s.s1 + 2 * p.kacc + p.m;
+        const int c = (D - a + 15) >> 4;
+        const int jend = a + 16 * (c > 0 ? c : 1);
+        // (whole chunks: the window may run a few columns past D -- never past the read's end, where no column is)
+        if (D + bs_stop_gap(p) < n && jend <= n) {
+            w.cls = BS3_F; w.start = a; w.jend = jend; w.jlim = D;
+            return w;
+        }
+        w.cls = BS3_E; start0 = a < tail0 ? a : tail0;
+    }
+    const int c = (n - start0 + 15) >> 4;
+    w.start = n - 16 * c > 0 ? n - 16 * c : 0;
+    w.jend = n;
+    return w;
 }

@@ -57,6 +57,12 @@ struct CahMatcher {
     // inside its window there, and every character the aligner accepts at that place the k-mer table accepts too.
     // For anchored adapters that tolerate no error (k_anchored_exact) the prefilter is then redundant and skipped.
     int32_t filter_implied;
+    // ---- bs3 (back_scan.h): the adapter's k + 1 chunks in the coordinates of its 32-bit scan form -- the cost scan's
+    // windows from the chunks' occurrences (k_back_scan3).  bs3_ok: 3' adapter of at most 34 characters whose plan has
+    // the pigeonhole property (skip_ok) and whose chunks all reach into the word
+    int32_t bs3_ok;
+    uint32_t bs3_start, bs3_end;
+    int32_t bs3_roff, bs3_maxlen;
     int32_t pad_;
 };
 

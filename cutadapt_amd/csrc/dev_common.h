@@ -102,3 +102,40 @@ __device__ __forceinline__ unsigned chunk_byte(const Chunk& c, int t) {
     return (w >> ((t & 3) * 8)) & 0xFFu;
 }
 
+
+// One read's result row, status and best adapter (merge_best: 0 = plain store, 1 = MultipleAdapters' merge with what an
+// earlier adapter of the plan left, reference adapters.py:1278-1285, 2 = the plan's first adapter on rows the entry point
+// has zeroed).  Shared by the cost scans (kernels.hip, scan3.hip) and the cell DP kernels.
+__device__ __forceinline__ void store_result(int32_t* out6, uint8_t* status, int32_t* best_adapter,
+                                             const int adapter_index, const int merge_best, const int64_t r,
+                                             const bool invalid, const bool found, const int t0, const int t1,
+                                             const int t2, const int t3, const int score, const int cost) {
+    int32_t* o = out6 + r * 6;
+    if (merge_best == 2) {
+        // the plan's FIRST adapter on rows the entry point has zeroed (status 0, tuple 0, best_adapter -1): nothing
+        // to compare with, nothing to read -- a read without a match keeps its zeros
+        if (invalid) {
+            status[r] = 2;
+        } else if (found) {
+            o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3; o[4] = score; o[5] = cost;
+            status[r] = 1;
+            if (best_adapter) best_adapter[r] = adapter_index;
+        }
+    } else if (merge_best) {
+        // MultipleAdapters.match_to (adapters.py:1278-1285), see k_dp
+        if (invalid) {
+            status[r] = 2;
+        } else if (found) {
+            const bool had = status[r] == 1;
+            if (status[r] != 2 && (!had || score > o[4] || (score == o[4] && cost < o[5]))) {
+                o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3; o[4] = score; o[5] = cost;
+                status[r] = 1;
+                if (best_adapter) best_adapter[r] = adapter_index;
+            }
+        }
+    } else {
+        status[r] = invalid ? (uint8_t)2 : (found ? (uint8_t)1 : (uint8_t)0);
+        if (found && !invalid) { o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3; o[4] = score; o[5] = cost; }
+        else { o[0] = o[1] = o[2] = o[3] = o[4] = o[5] = 0; }
+    }
+}

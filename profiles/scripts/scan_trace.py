@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """Developer tool: where a wave of k_back_scan spends its cycles (library built with -DSCAN_TRACE, CAH_LIB_PATH)."""
 import ctypes as C
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 from cutadapt_amd import _lib
