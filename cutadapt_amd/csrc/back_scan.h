@@ -549,22 +549,32 @@ CAH_HD int bs32_finish(const BackScanState32<X>& s, const int n, const int j0, c
 // M over the match words: M = ((M << 1) | START) & eq, hits = M & END -- say where candidates can be at all:
 //   * no occurrence: no last-row candidate; only the rows of the last column can match, and their alignments lie in the
 //     read's last m + k columns (class T).
-//   * the FIRST occurrence has diagonal S1 and every other occurrence up to column S1 + m + 4 kacc + m/2 lies on a
-//     diagonal within S1 +- kacc ("in the band": the chunks of one copy, shifted by its insertions / deletions): every
-//     candidate that could be the first best or replace one (an overlapping one: origin <= best.origin + m/2, :521-524;
-//     later occurrences than that column have origins behind every possible best's + m/2) lies in columns
-//     [S1 - 2 kacc - 1, S1 + 2 kacc + m]: 47 columns for a 33-character adapter, THREE 16-column chunks instead of the
-//     six to seven from (first k-mer hit) - m - k - 1 to 23 columns behind the last acceptable column.
-//     - class F: that window ends more than gap_last = k + 1 + kacc + m/2 columns before the read's end: the scan stops
-//       at its end ("stopped", see the header) and books no column behind S1 + 2 kacc + m (a window of whole 16-column
-//       chunks runs a little further: what is acceptable there belongs to occurrences behind the pre-pass range, which
-//       cannot replace a best of this window -- and if the window has none (a chance occurrence), the read is scanned the
-//       conservative way: straggler list).
-//     - class E: otherwise the window is joined with the read's last m + k + 1 columns and runs to the end.
-//   * an occurrence outside the band: class C, the conservative window from the prefilter's position.
+//   * occurrences on diagonals Smin .. Smax: every candidate that holds one of them lies in columns
+//     [Smin - kacc - 1, Smax + m + kacc] -- 40 columns + the spread of the diagonals (the insertions / deletions between the
+//     chunks of one copy: <= kacc each way) for a 33-character adapter, THREE 16-column chunks instead of the six to seven
+//     from (first k-mer hit) - m - k - 1 to 23 columns behind the last acceptable column.  Which occurrences count: all up
+//     to column Smax + m + 3 kacc + m/2 (Smax as it grows).  A candidate can only replace the best if it OVERLAPS it
+//     (origin <= best.origin + m/2, :521-524); the best of a window ends at a column <= Smax + m + kacc, so its origin is
+//     <= Smax + 2 kacc, and a candidate that holds an occurrence on a diagonal S' has an origin >= S' - kacc: occurrences
+//     with S' > Smax + 3 kacc + m/2, i.e. (rows <= m) every occurrence that ends behind that column, cannot matter --
+//     PROVIDED the window holds a candidate at all.
+//     - class F: the window ends more than gap_last = k + 1 + kacc + m/2 columns before the read's end: the scan stops
+//       at its end ("stopped", see the header) and books no column behind Smax + m + kacc (a window of whole 16-column
+//       chunks runs a little further: what is acceptable there belongs to occurrences behind the pre-pass range).  If the
+//       window has no acceptable column (a chance occurrence, a copy with too many errors) what lies behind the range DOES
+//       matter: the read is scanned the conservative way (straggler list).
+//     - class E: otherwise the window is joined with the read's last m + k + 1 columns and runs to the end (the pre-pass
+//       has then seen every column).
+//   * class C: a window of more than BS3_MAX_CHUNKS chunks (copies far apart): the conservative way as well.
 // The windowed costs are >= the true ones and equal wherever the optimal paths lie inside the window:
 // every relevant candidate's does, so jfa / jla / cmin and the diagonal bits at candidate columns are the reference's.
 // The cell DP of a read the scan cannot finish starts where it always did (dp_lo: the column-skipping position).
+//
+// The occurrences' DIAGONALS without looking at any single one: over a 16-column chunk G = (G << 1) | hits -- an
+// occurrence in word bit b that is `age` columns old sits at bit b + age, and S = (chunk's last column) - (b + age) - roff:
+// every occurrence on one diagonal lands on ONE bit, whatever its chunk and column; the lowest / highest bit of G at the
+// chunk's end are the chunk's Smax / Smin.  Two 32-bit halves (rows below / from 16: b + age < 31 each).
+#define BS3_MAX_CHUNKS 5
 struct Bs3Geom {
     uint32_t start, end;      // word bits of the chunks' first / last rows (rows of the 32-bit word only: a first chunk that
                               // loses its explicit rows matches more often -- more occurrences are as exact)
@@ -598,44 +608,44 @@ CAH_HD Bs3Geom bs3_geom(const int m, const int k, const int kacc) {
 }
 
 struct Bs3Pre {
-    uint32_t M, band, bad;
+    uint32_t M;               // the shift-and word
+    uint32_t glo, ghi;        // the chunk's diagonal bits (see above), cleared at every chunk's start
     int found;                // an occurrence was seen
-    int s1;                   // its diagonal: the copy occupies columns s1 + 1 .. s1 + m
+    int smin, smax;           // lowest / highest diagonal so far (a copy on diagonal S occupies columns S + 1 .. S + m)
 };
-CAH_HD void bs3_pre_init(Bs3Pre& s) { s.M = 0; s.band = ~0u; s.bad = 0; s.found = 0; s.s1 = 0; }
-// columns of the pre-pass behind the first occurrence's diagonal (see above)
-CAH_HD int bs3_range(const BackScanParams& p) { return p.m + 4 * p.kacc + p.half_m; }
-// the band of word bits [b1 - kacc, b1 + kacc]
-CAH_HD uint32_t bs3_band(const int b1, const int kacc) {
-    const int width = 2 * kacc + 1;
-    const uint32_t w = width >= 32 ? ~0u : ((1u << width) - 1u);
-    const int lo = b1 - kacc;
-    return lo >= 0 ? (lo >= 32 ? 0u : (w << lo)) : ((-lo) >= 32 ? 0u : (w >> (-lo)));
-}
-// column j (1-based) with the match word eq of its character; `commit`: occurrences outside the band count (the column
-// lies inside the pre-pass range of this read)
-CAH_HD void bs3_pre_step(Bs3Pre& s, const uint32_t eq, const int j, const Bs3Geom& g, const int kacc, const bool commit) {
+CAH_HD void bs3_pre_init(Bs3Pre& s) { s.M = 0; s.glo = 0; s.ghi = 0; s.found = 0; s.smin = 0x3FFFFFFF; s.smax = -0x3FFFFFFF; }
+// columns behind the highest diagonal up to which occurrences count
+CAH_HD int bs3_range(const BackScanParams& p) { return p.m + 3 * p.kacc + p.half_m; }
+CAH_HD int bs_low_bit(const uint32_t x) { return __builtin_ctz(x); }       // x != 0
+// one column with the match word eq of its character
+CAH_HD void bs3_pre_step(Bs3Pre& s, const uint32_t eq, const Bs3Geom& g) {
     s.M = ((s.M << 1) | g.start) & eq;
     const uint32_t h = s.M & g.end;
-    if (s.found) s.band <<= 1;
-    if (!s.found && h != 0) {
-        const int b1 = bs_top_bit(h);                         // (two chunks ending in one column: the other is out of band)
+    s.glo = (s.glo << 1) | (h & 0xFFFFu);
+    s.ghi = (s.ghi << 1) | (h >> 16);
+}
+// the end of a 16-column chunk whose last column is j_end: its diagonals join smin / smax
+CAH_HD void bs3_pre_harvest(Bs3Pre& s, const int j_end, const Bs3Geom& g) {
+    if ((s.glo | s.ghi) != 0) {
+        const int idx_max = s.ghi ? 16 + bs_top_bit(s.ghi) : bs_top_bit(s.glo);
+        const int idx_min = s.glo ? bs_low_bit(s.glo) : 16 + bs_low_bit(s.ghi);
+        const int lo = j_end - idx_max - g.roff, hi = j_end - idx_min - g.roff;
+        s.smin = lo < s.smin ? lo : s.smin;
+        s.smax = hi > s.smax ? hi : s.smax;
         s.found = 1;
-        s.s1 = j - (b1 + g.roff);
-        s.band = bs3_band(b1, kacc);
     }
-    if (commit) s.bad |= h & ~s.band;
+    s.glo = 0; s.ghi = 0;
 }
 // first character (0-based) of the pre-pass: every chunk that ends in the prefilter's first-hit group or later is seen whole
 CAH_HD int bs3_pre_start(const int key4, const Bs3Geom& g) {
     const int p0 = key4 - (g.maxlen - 1);
     return p0 > 0 ? p0 : 0;
 }
-// number of 16-character chunks from p0 on that the pre-pass of a read commits: all up to the read's end while nothing is
-// found; once the first occurrence is known, those that hold a column <= s1 + range
-CAH_HD int bs3_pre_chunks(const int p0, const int n, const bool found, const int s1, const int range) {
+// number of 16-character chunks from p0 on that the pre-pass of a read walks: all up to the read's end while nothing is
+// found; with occurrences, those that hold a column <= smax + range (asked again after every chunk: smax grows)
+CAH_HD int bs3_pre_chunks(const int p0, const int n, const bool found, const int smax, const int range) {
     int last = n;                                             // last column (1-based) to look at
-    if (found && s1 + range < n) last = s1 + range;
+    if (found && smax + range < n) last = smax + range;
     const int cols = last - p0;                               // columns p0 + 1 .. last
     return cols <= 0 ? 0 : (cols + 15) >> 4;
 }
@@ -645,12 +655,12 @@ struct Bs3Win {
     int cls;                  // BS3_*
     int start;                // the scan's first column is start + 1 (its state at column `start` is the plain first column)
     int jend;                 // ... its last one
-    int jlim;                 // the last column that is booked (class F: S1 + 2 kacc + m, the last one the band answers for;
-                              // a window of whole chunks ends a little later)
+    int jlim;                 // the last column that is booked (class F: Smax + m + kacc, the last one the occurrences answer
+                              // for; a window of whole chunks ends a little later)
 };
-// j0_old: the conservative start (column-skipping position).  Windows that run to the read's end are a whole number of
-// 16-column chunks where the read is long enough (start = n - 16 c), so that their last chunk ends with the read.
-// the window from column `from` (or the tail's first column, whichever is earlier) to the read's end, every column booked
+// the window from column `from` (or the tail's first column, whichever is earlier) to the read's end, every column booked.
+// Windows that run to the read's end are a whole number of 16-column chunks where the read is long enough
+// (start = n - 16 c), so that their last chunk ends with the read.
 CAH_HD Bs3Win bs3_window_to_end(const int from, const int n, const BackScanParams& p) {
     Bs3Win w;
     w.cls = BS3_E; w.jlim = 0x7FFFFFFF; w.jend = n;
@@ -661,28 +671,29 @@ CAH_HD Bs3Win bs3_window_to_end(const int from, const int n, const BackScanParam
     w.start = n - 16 * c > 0 ? n - 16 * c : 0;
     return w;
 }
+// j0_old: the conservative start (column-skipping position)
 CAH_HD Bs3Win bs3_window(const Bs3Pre& s, const int n, const int j0_old, const BackScanParams& p) {
     Bs3Win w;
-    w.jlim = 0x7FFFFFFF;
-    const int reach = p.m + p.k + 1;
-    const int tail0 = n - reach > 0 ? n - reach : 0;
-    int start0;
-    if (!s.found) { w.cls = BS3_T; start0 = tail0; }
-    else if (s.bad) { w.cls = BS3_C; start0 = j0_old < tail0 ? j0_old : tail0; }
-    else {
-        const int a = s.s1 - 2 * p.kacc - 1 > 0 ? s.s1 - 2 * p.kacc - 1 : 0;
-        const int D = s.s1 + 2 * p.kacc + p.m;
-        const int c = (D - a + 15) >> 4;
-        const int jend = a + 16 * (c > 0 ? c : 1);
-        // (whole chunks: the window may run a few columns past D -- never past the read's end, where no column is)
-        if (D + bs_stop_gap(p) < n && jend <= n) {
-            w.cls = BS3_F; w.start = a; w.jend = jend; w.jlim = D;
-            return w;
-        }
-        w.cls = BS3_E; start0 = a < tail0 ? a : tail0;
+    if (!s.found) {
+        w = bs3_window_to_end(n, n, p);
+        w.cls = BS3_T;
+        return w;
     }
-    const int c = (n - start0 + 15) >> 4;
-    w.start = n - 16 * c > 0 ? n - 16 * c : 0;
-    w.jend = n;
+    const int a = s.smin - p.kacc - 1 > 0 ? s.smin - p.kacc - 1 : 0;
+    const int D = s.smax + p.kacc + p.m;
+    const int c = (D - a + 15) >> 4;
+    const int jend = a + 16 * (c > 0 ? c : 1);
+    // (whole chunks: the window may run a few columns past D -- never past the read's end, where no column is)
+    if (D + bs_stop_gap(p) < n && jend <= n) {
+        w.cls = c <= BS3_MAX_CHUNKS ? BS3_F : BS3_C;
+        w.start = a; w.jend = jend; w.jlim = D;
+    } else {
+        w = bs3_window_to_end(a, n, p);
+        if (w.jend - w.start > 16 * BS3_MAX_CHUNKS) w.cls = BS3_C;
+    }
+    if (w.cls == BS3_C) {                                      // (kept as the in-place fallback when the straggler list is full)
+        w = bs3_window_to_end(j0_old < a ? j0_old : a, n, p);
+        w.cls = BS3_C;
+    }
     return w;
 }

@@ -41,7 +41,9 @@
 #include "back_scan.h"
 #include "multi2.h"
 
-#define M2_WAVES 16                // waves per block = per CU
+#ifndef M2_WAVES
+#define M2_WAVES 16                // waves per block = per CU (developer builds: -DM2_WAVES=12 gives the kernel 168 VGPRs)
+#endif
 #define M2_TILE 1024               // reads per block tile (one piece per wave: the blocks end within one piece of each other)
 #define M2_HALF 5                  // 16-byte units per half-row
 #define M2_ROW (M2_HALF * 16)

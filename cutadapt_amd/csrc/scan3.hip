@@ -30,8 +30,24 @@
 
 #define SCAN3_TILE 1024
 
+#ifdef SCAN_TRACE
+// developer build only (-DSCAN_TRACE): s_memtime stamps of one wave, per sub-batch of 64 queue entries:
+// [0] start, [1] pre-pass done, [2] scan done, [3] classified, [4] stored; [5] pre-pass chunks, [6] scan chunks, [7] lanes retried
+#define S3_TRACE_N 256
+__device__ unsigned long long g_scan3_trace[S3_TRACE_N * 8];
+extern "C" int cah_debug_scan3_trace(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_scan3_trace), sizeof(g_scan3_trace)) == hipSuccess ? 0 : 1;
+}
+#define S3_STAMP(st) do { if (blockIdx.x == 11 && wave == 1 && trace_i < S3_TRACE_N) { \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) g_scan3_trace[trace_i * 8 + (st)] = t_; } } while (0)
+#define S3_NOTE(st, v) do { if (blockIdx.x == 11 && wave == 1 && trace_i < S3_TRACE_N && lane == 0) g_scan3_trace[trace_i * 8 + (st)] = (unsigned long long)(v); } while (0)
+#else
+#define S3_STAMP(st) do { } while (0)
+#define S3_NOTE(st, v) do { } while (0)
+#endif
+
 template <int KIND>
-__global__ __launch_bounds__(256, 5) void k_back_scan3(ScanArgs a) {
+__global__ __launch_bounds__(256, 4) void k_back_scan3(ScanArgs a) {      // (111 VGPRs; at 5 waves per SIMD the state spills to scratch, loads inside the chunk loops)
     static_assert(KIND >= 1 && KIND <= 3, "k_back_scan3: the 32-bit forms");
     constexpr int XR = KIND >= 2 ? KIND - 1 : 0;
     __shared__ int s_thr_last[CAH_MAX_M + 1];
@@ -56,6 +72,11 @@ __global__ __launch_bounds__(256, 5) void k_back_scan3(ScanArgs a) {
     int64_t total = (int64_t)(*a.queue_count);
     if (a.queue_limit > 0 && total > a.queue_limit) total = a.queue_limit;
     const int tile = SCAN3_TILE;
+    unsigned low16 = 0xFFFFu;                                          // (a VGPR: v_bitop3 takes no literal)
+    asm volatile("" : "+v"(low16));
+#ifdef SCAN_TRACE
+    int trace_i = 0;
+#endif
     auto eq_lo = [&](const unsigned w, const int b) -> uint32_t {      // rows X+1..m of byte b of a chunk dword
         const unsigned byte_off = ((w >> (8 * b)) & 0xFFu) << 3;
         return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const unsigned char*>(s_sm256) + byte_off);
@@ -63,6 +84,15 @@ __global__ __launch_bounds__(256, 5) void k_back_scan3(ScanArgs a) {
     auto eq_of = [&](const Chunk& ck, const int t) -> uint64_t {
         const unsigned byte_off = ((ck.w[t >> 2] >> (8 * (t & 3))) & 0xFFu) << 3;
         return *reinterpret_cast<const uint64_t*>(reinterpret_cast<const unsigned char*>(s_sm256) + byte_off);
+    };
+    // the chunk moved down by one character (the rolled loops of the rare paths take their character from byte 0: no
+    // register is indexed by a loop counter, and the code stays small -- an unrolled copy of every path made the kernel
+    // five times the size of k_back_scan, and the instruction cache its bound)
+    auto shift_chunk = [](Chunk& c) {
+        c.w[0] = __builtin_amdgcn_alignbit(c.w[1], c.w[0], 8);
+        c.w[1] = __builtin_amdgcn_alignbit(c.w[2], c.w[1], 8);
+        c.w[2] = __builtin_amdgcn_alignbit(c.w[3], c.w[2], 8);
+        c.w[3] >>= 8;
     };
 
     for (;;) {
@@ -75,15 +105,31 @@ __global__ __launch_bounds__(256, 5) void k_back_scan3(ScanArgs a) {
         const int64_t tile_base = s_tile;
         if (tile_base >= total) break;
 
+        // the wave's NEXT sub-batch: its queue entries are fetched while this one's pre-pass runs, and the cache lines its own
+        // pre-pass will ask for are touched while this one is scanned (the pass is short against a trip to HBM)
+        bool pf_have = false, pf_valid = false;
+        int pf_r = 0;
+        unsigned pf_key = 0;
         for (int sub = wave; sub < tile / WAVE; sub += 4) {
             const int64_t base = tile_base + (int64_t)sub * WAVE;
             if (base >= total) break;
+            S3_STAMP(0);
             const int64_t idx = base + lane;
             bool valid = idx < total;
             int64_t r = 0;
             unsigned key = 0;
-            if (valid) { r = (int64_t)a.queue[idx]; key = a.queue_keys[idx]; }
+            if (pf_have) { valid = pf_valid; r = pf_r; key = pf_key; }
+            else if (valid) { r = (int64_t)a.queue[idx]; key = a.queue_keys[idx]; }
             if (r < 0) { valid = false; r = 0; }           // (an unused slot of a straggler list)
+            const bool next_sub = sub + 4 < tile / WAVE && base + 4 * WAVE < total;      // wave-uniform
+            bool valid_n = false;
+            int r_n = 0;
+            unsigned key_n = 0;
+            if (next_sub) {
+                const int64_t idx_n = base + 4 * WAVE + lane;
+                valid_n = idx_n < total;
+                if (valid_n) { r_n = a.queue[idx_n]; key_n = a.queue_keys[idx_n]; }
+            }
             int64_t off = 0, n64 = 0;
             if (valid) read_extent(a.offsets, a.lens, a.uniform_first, a.uniform_len, r, off, n64);
             bool invalid = false;
@@ -94,40 +140,64 @@ __global__ __launch_bounds__(256, 5) void k_back_scan3(ScanArgs a) {
             const int j0_old = max(0, key4 - reach);
             unsigned bad_chars = 0;
 
-            // ---- pre-pass: the chunk occurrences from the prefilter's position on (bs3_pre_step, column by column)
+            // ---- pre-pass: the diagonals of the chunk occurrences from the prefilter's position on (back_scan.h: bs3_pre_step
+            // column by column, bs3_pre_harvest at every chunk's end -- written out here in the cheap instruction forms)
             Bs3Pre pre;
             bs3_pre_init(pre);
             const int p0 = bs3_pre_start(key4, g);
             {
-                int pos = p0;
-                Chunk cur = load_chunk(q, pos, n, valid ? n : 0);
-                for (int c = 0;; ++c) {
-                    const bool active = valid && c < bs3_pre_chunks(p0, n, pre.found != 0, pre.s1, range);
-                    if (!__any(active)) break;
-                    const Chunk nxt = load_chunk(q, pos + 16, n, active ? n : 0);
-                    bad_chars |= cur.w[0] | cur.w[1] | cur.w[2] | cur.w[3];
-                    const uint32_t bad_before = pre.bad;
-                    if (__all(!active || pre.found != 0)) {
-                        // every lane at work knows its first occurrence: shift-and, band and the out-of-band bits only
-                        uint32_t M = pre.M, band = pre.band, bad = pre.bad;
+                // The characters come in BLOCKS of four chunks, all four loads in flight together: a chunk of the pre-pass is
+                // ~350 issue cycles, far less than a trip to memory -- chunk by chunk the pass waited for every load
+                // (10 000 cycles per chunk in the first trace).  Most lanes are through after one block.
+                int pos = p0, c = 0;
+#pragma unroll 1
+                for (;;) {
+                    if (!__any(valid && c < bs3_pre_chunks(p0, n, pre.found != 0, pre.smax, range))) break;
+                    Chunk b0 = load_chunk(q, pos, n, valid ? n : 0), b1 = load_chunk(q, pos + 16, n, valid ? n : 0),
+                          b2 = load_chunk(q, pos + 32, n, valid ? n : 0), b3 = load_chunk(q, pos + 48, n, valid ? n : 0);
+#pragma unroll 1
+                    for (int u = 0; u < 4; ++u, ++c, pos += 16) {
+                        const bool active = valid && c < bs3_pre_chunks(p0, n, pre.found != 0, pre.smax, range);
+                        if (!__any(active)) break;
+                        const Chunk cur = b0;
+                        b0 = b1; b1 = b2; b2 = b3;
+                        bad_chars |= cur.w[0] | cur.w[1] | cur.w[2] | cur.w[3];
+                        uint32_t M = pre.M, glo = 0, ghi = 0;
 #pragma unroll
                         for (int t = 0; t < 16; ++t) {
                             const uint32_t e = eq_lo(cur.w[t >> 2], t & 3);
-                            M = BS_BITOP3(bs_dbl(M), g.start, e, 0xA8u);           // ((M << 1) | START) & eq
-                            band = bs_dbl(band);
+                            M = BS_BITOP3(bs_dbl(M), g.start, e, 0xA8u);               // ((M << 1) | START) & eq
                             const uint32_t h = M & g.end;
-                            bad = BS_BITOP3(h, band, bad, 0xBAu);                  // (h & ~band) | bad
+                            glo = BS_BITOP3(bs_dbl(glo), h, low16, 0xF8u);             // (glo << 1) | (h & 0xFFFF)
+                            ghi = bs_dbl(ghi) | (h >> 16);
                         }
-                        pre.M = M; pre.band = band; pre.bad = bad;
-                    } else {
-#pragma unroll
-                        for (int t = 0; t < 16; ++t)
-                            bs3_pre_step(pre, eq_lo(cur.w[t >> 2], t & 3), pos + t + 1, g, p.kacc, true);
+                        pre.M = M;
+                        // (a lane behind its range walks along: its occurrences do not count)
+                        pre.glo = active ? glo : 0u; pre.ghi = active ? ghi : 0u;
+                        bs3_pre_harvest(pre, pos + 16, g);
+                        S3_NOTE(5, c + 1);
                     }
-                    // (whether the chunk's occurrences count is decided with what the lane knows at the chunk's end)
-                    if (!(active && c < bs3_pre_chunks(p0, n, pre.found != 0, pre.s1, range))) pre.bad = bad_before;
-                    pos += 16;
-                    cur = nxt;
+                }
+            }
+            S3_STAMP(1);
+            // (the next sub-batch's lines: two words, 60 characters apart, from where its pre-pass will start)
+            unsigned touch = 0;
+            pf_have = next_sub;
+            if (next_sub) {
+                pf_valid = valid_n && r_n >= 0; pf_r = r_n; pf_key = key_n;
+                if (pf_valid) {
+                    int64_t o_n = 0, n_n = 0;
+                    read_extent(a.offsets, a.lens, a.uniform_first, a.uniform_len, (int64_t)r_n, o_n, n_n);
+                    if (n_n >= 4 && n_n <= a.max_read_len) {
+                        const int nn = (int)n_n;
+                        const int t0 = min(bs3_pre_start((int)key_n << CAH_KEY_SHIFT, g), nn - 4), t1 = min(t0 + 60, nn - 4);
+                        Unaligned16 dummy;
+                        unsigned x0, x1;
+                        __builtin_memcpy(&x0, a.seqs + o_n + t0, 4);
+                        __builtin_memcpy(&x1, a.seqs + o_n + t1, 4);
+                        (void)dummy;
+                        touch = x0 ^ x1;
+                    }
                 }
             }
 
@@ -164,37 +234,48 @@ __global__ __launch_bounds__(256, 5) void k_back_scan3(ScanArgs a) {
                 bool done = !on;
                 int j = ww.start, pos = ww.start;
                 const int jend = on ? ww.jend : ww.start, jlim = ww.jlim;
-                Chunk cur = load_chunk(q, pos, n, done ? 0 : n);
+#pragma unroll 1
                 for (;;) {
                     if (!__any(!done && j < jend)) break;
-                    const Chunk nxt = load_chunk(q, pos + 16, n, (!done && j + 16 < jend) ? n : 0);
-                    bad_chars |= cur.w[0] | cur.w[1] | cur.w[2] | cur.w[3];
-                    uint64_t eqq[2];
-                    eqq[0] = eq_of(cur, 0); eqq[1] = eq_of(cur, 1);
-                    if (FAST && __all(done || j + 16 <= jend)) {
-                        // lanes that are through step along on NUL chunks; their state is not looked at again
+                    // (blocks of four chunks, the loads in flight together: a class-F window is one block)
+                    Chunk b0 = load_chunk(q, pos, n, (!done && j < jend) ? n : 0), b1 = load_chunk(q, pos + 16, n, (!done && j + 16 < jend) ? n : 0),
+                          b2 = load_chunk(q, pos + 32, n, (!done && j + 32 < jend) ? n : 0), b3 = load_chunk(q, pos + 48, n, (!done && j + 48 < jend) ? n : 0);
+#pragma unroll 1
+                    for (int u = 0; u < 4; ++u, pos += 16) {
+                        if (!__any(!done && j < jend)) break;
+                        Chunk cur = b0;
+                        b0 = b1; b1 = b2; b2 = b3;
+                        bad_chars |= cur.w[0] | cur.w[1] | cur.w[2] | cur.w[3];
+                        if (FAST && __all(done || j + 16 <= jend)) {
+                            // Whole chunks, no per-column tests.  Lanes that are through sit the chunk out (ONE branch around
+                            // the sixteen columns): their windows end at other columns than their neighbours', and the state
+                            // they ended with -- the last column's rows, the booked candidates -- is what the classification reads.
+                            if (!done) {
+                                uint64_t eqq[2];
+                                eqq[0] = eq_of(cur, 0); eqq[1] = eq_of(cur, 1);
 #pragma unroll
-                        for (int t = 0; t < 16; ++t) {
-                            const uint64_t eq = eqq[t & 1];
-                            if (t + 2 < 16) eqq[t & 1] = eq_of(cur, t + 2);
-                            ++j;
-                            if (bs32_step<true, XR>(S, (uint32_t)eq, (uint32_t)(eq >> 32), j, p, jlim) && !ex) { ex = true; exj = j; }
-                        }
-                        if (ex) done = true;
-                    } else {
-#pragma unroll
-                        for (int t = 0; t < 16; ++t) {
-                            const uint64_t eq = eqq[t & 1];
-                            if (t + 2 < 16) eqq[t & 1] = eq_of(cur, t + 2);
-                            if (!done && j < jend) {
-                                ++j;
-                                if (bs32_step<true, XR>(S, (uint32_t)eq, (uint32_t)(eq >> 32), j, p, jlim)) { ex = true; exj = j; done = true; }
+                                for (int t = 0; t < 16; ++t) {
+                                    const uint64_t eq = eqq[t & 1];
+                                    if (t + 2 < 16) eqq[t & 1] = eq_of(cur, t + 2);
+                                    ++j;
+                                    if (bs32_step<true, XR>(S, (uint32_t)eq, (uint32_t)(eq >> 32), j, p, jlim) && !ex) { ex = true; exj = j; }   // (an exact lane's state is not read again)
+                                }
+                                if (ex) done = true;
+                            }
+                        } else {
+                            // (a read shorter than its window: column by column, rolled)
+#pragma unroll 1
+                            for (int t = 0; t < 16; ++t) {
+                                const uint64_t eq = eq_of(cur, 0);
+                                shift_chunk(cur);
+                                if (!done && j < jend) {
+                                    ++j;
+                                    if (bs32_step<true, XR>(S, (uint32_t)eq, (uint32_t)(eq >> 32), j, p, jlim)) { ex = true; exj = j; done = true; }
+                                }
                             }
                         }
+                        if (j >= jend) done = true;
                     }
-                    if (j >= jend) done = true;
-                    pos += 16;
-                    cur = nxt;
                 }
             };
             BackScanState32<XR> st;
@@ -217,6 +298,9 @@ __global__ __launch_bounds__(256, 5) void k_back_scan3(ScanArgs a) {
                     if (redo) { st = st2; exact = ex2; exact_j = exj2; w = w2; }
                 }
             }
+            S3_STAMP(2);
+            S3_NOTE(6, __popcll(__ballot(valid && w.cls == BS3_F)) + 100 * __popcll(__ballot(valid && w.cls == BS3_E)) + 10000 * __popcll(__ballot(valid && w.cls == BS3_T)));
+            S3_NOTE(7, __popcll(__ballot(retry)));
             if (bad_chars & 0x80808080u) invalid = true;
             const bool stopped = valid && !retry && !exact && w.cls == BS3_F && st.jla >= 0;
 
@@ -228,6 +312,7 @@ __global__ __launch_bounds__(256, 5) void k_back_scan3(ScanArgs a) {
                 cls = bs32_finish<XR, true>(st, n, w.start, p, [&](int i) { return s_thr_last[i]; }, o0, o1, stopped, CAH_BS_ALL_ROWS, j0_old);
             if (exact) { cls = BS_EXACT_FULL; o0 = exact_j; }
             if (retry) { cls = BS_NONE; valid_out = false; }
+            S3_STAMP(3);
             if (valid_out) {
                 const bool full = cls == BS_EXACT_FULL || cls == BS_SUBS_FULL || cls == BS_INDEL1_FULL;
                 const bool found = !invalid && (full || cls == BS_EXACT_TAIL);
@@ -260,6 +345,11 @@ __global__ __launch_bounds__(256, 5) void k_back_scan3(ScanArgs a) {
                     s_list[3 * e] = (int)r; s_list[3 * e + 1] = o0; s_list[3 * e + 2] = o1;
                 }
             }
+            asm volatile("" :: "v"(touch));                 // (the touched words are needed by nobody: only their cache lines)
+            S3_STAMP(4);
+#ifdef SCAN_TRACE
+            if (blockIdx.x == 11 && wave == 1) ++trace_i;
+#endif
         }
 
         // flush the tile's DP work list

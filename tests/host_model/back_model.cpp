@@ -203,19 +203,16 @@ int bm_locate_batch3(const void* matcher_blob, const uint8_t* seqs, const int64_
         const int n = (int)(offsets[r + 1] - offsets[r]);
         const int key4 = (int)keys[r] << 2;
         const int j0_old = std::max(0, key4 - reach);
-        // ---- pre-pass
+        // ---- pre-pass: 16-character chunks from p0, harvested at every chunk's end (characters behind the read: NUL)
         Bs3Pre pre;
         bs3_pre_init(pre);
         const int p0 = bs3_pre_start(key4, g);
-        for (int c = 0; c < bs3_pre_chunks(p0, n, pre.found != 0, pre.s1, range); ++c) {
-            const uint32_t bad_before = pre.bad;
+        for (int c = 0; c < bs3_pre_chunks(p0, n, pre.found != 0, pre.smax, range); ++c) {
             for (int t = 0; t < 16; ++t) {
                 const int j = p0 + 16 * c + t + 1;
-                if (j > n) break;
-                bs3_pre_step(pre, (uint32_t)tab32[q[j - 1] & 127], j, g, p.kacc, true);
+                bs3_pre_step(pre, j <= n ? (uint32_t)tab32[q[j - 1] & 127] : 0u, g);
             }
-            // (the kernel decides per chunk whether its occurrences count: with what it knows at the chunk's end)
-            if (c >= bs3_pre_chunks(p0, n, pre.found != 0, pre.s1, range)) pre.bad = bad_before;
+            bs3_pre_harvest(pre, p0 + 16 * c + 16, g);
         }
         Bs3Win w = bs3_window(pre, n, j0_old, p);
         bool conservative = w.cls == BS3_C && !list_full;
