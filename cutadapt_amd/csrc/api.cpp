@@ -533,15 +533,6 @@ static int build_matcher(const cah_adapter_desc& d, int index, CahMatcher& mt,
                 const uint64_t low = pad == 0 ? 0ull : ((1ull << pad) - 1ull);
                 for (int ch = 0; ch < CAH_TABLE_CHARS; ch++)
                     mt.scanmask[ch] = (pad == 64 ? 0ull : (mt.rowmask[ch] << pad)) | low;
-                // thr_last as a step mask (cah_device.h); should the thresholds ever not be of that shape the scan is off
-                mt.thr_steps = 0;
-                bool steps_ok = mt.thr_last[0] == 0;
-                for (int i = 1; i <= m && steps_ok; i++) {
-                    const int d = mt.thr_last[i] - mt.thr_last[i - 1];
-                    if (d == 1) mt.thr_steps |= 1ull << (i - 1);
-                    else if (d != 0) steps_ok = false;
-                }
-                if (!steps_ok) { mt.scan_ok = 0; mt.thr_steps = 0; }
             }
         } else {
             // PrefixComparer / SuffixComparer (_align.pyx:615-642, :698-706)

@@ -364,11 +364,6 @@ CAH_HD bool bs_may_stop(const BackScanBook& s, const int j, const int n, const i
     return s.jla >= 0 && j - s.jla >= gap && j < n;
 }
 
-// thr_last[i] from the matcher's step mask (cah_device.h: CahMatcher::thr_steps), 0 <= i <= 63
-CAH_HD int bs_thr_from_steps(const uint64_t steps, const int i) {
-    return __builtin_popcountll(i >= 64 ? steps : (steps & ((1ull << i) - 1ull)));
-}
-
 // "does any lane of the wave still ..." (the host model has one lane)
 CAH_HD bool bs_any(const bool pred) {
 #if defined(__HIP_DEVICE_COMPILE__)

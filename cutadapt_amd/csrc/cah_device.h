@@ -52,11 +52,6 @@ struct CahMatcher {
     int32_t kacc;              // thr[effective_length] (-1 if m < min_overlap): acceptable last-row cost
     int32_t thr_last[CAH_MAX_M + 1];   // thr[effective length of adapter[0:i]]: threshold of row i in the last column
     uint64_t scanmask[CAH_TABLE_CHARS]; // rowmask << (64 - m) | ones below: the adapter in the top m bits
-    // thr_last as a step mask: bit i - 1 (1 <= i <= m) set <=> thr_last[i] = thr_last[i - 1] + 1 (it never grows faster: the
-    // effective length grows by at most one per row and the rate is at most 1; build_matcher checks it), thr_last[0] = 0:
-    // thr_last[i] = popcount(thr_steps & ((1 << i) - 1)) -- two scalar instructions where the classification's row walk
-    // used to wait for an LDS read per row
-    uint64_t thr_steps;
     // ---- bs3 (back_scan.h): the adapter's k + 1 chunks in the coordinates of its 32-bit scan form -- the cost scan's
     // windows from the chunks' occurrences (k_back_scan3).  bs3_ok: 3' adapter of at most 34 characters whose plan has
     // the pigeonhole property (skip_ok) and whose chunks all reach into the word

@@ -1706,9 +1706,13 @@ extern "C" int cah_debug_scan_trace(unsigned long long* out) {
 // characters), 2 / 3 = a 32-bit word + 1 / 2 explicit rows (33 / 34 characters).  The 32-bit forms cost about half the
 // instructions per column.
 template <bool MULTI, int KIND>
-__global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_back_scan(ScanArgs a) {
+#ifndef CAH_SCAN_WAVES
+#define CAH_SCAN_WAVES 5           // (developer builds: -DCAH_SCAN_WAVES=4 -- 118 VGPRs and no scratch instead of 96 and 12 spilled)
+#endif
+__global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : CAH_SCAN_WAVES) void k_back_scan(ScanArgs a) {
     constexpr int XR = KIND >= 2 ? KIND - 1 : 0;
     extern __shared__ __attribute__((aligned(16))) uint64_t s_scanmask[];   // [128], or [n_adapters * CAH_MULTI_TAB_STRIDE]
+    __shared__ int s_thr_last[CAH_MAX_M + 1];
     __shared__ int s_list[SCAN_TILE * 3];          // (read, first column, last column * 2 + scan): front entries
                                                    // from slot 0 up, back entries from the last slot down
     __shared__ unsigned s_nf, s_nb;
@@ -1727,7 +1731,7 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_back_
             s_sm256[i] = KIND == 0 ? sm : bs32_table_entry(sm, mt->m);
         }
     }
-    const uint64_t thr_steps = mt->thr_steps;      // the last column's thresholds (cah_device.h): scalar, no LDS in the row walk
+    for (int i = threadIdx.x; i <= CAH_MAX_M; i += blockDim.x) s_thr_last[i] = mt->thr_last[i];
     BackScanParams p;
     p.m = mt->m; p.k = mt->k; p.kacc = mt->kacc; p.min_overlap = mt->min_overlap; p.half_m = mt->m / 2;
     const int lane = wave_lane();
@@ -1929,8 +1933,8 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_back_
             // a lane that ended as EXACT_FULL, was set aside or never had a read skips it, and a wave made of such lanes
             // (the common wave of reads with the adapter inside) skips the row loop altogether
             if (valid && !exact && !retry) {
-                if constexpr (KIND == 0) cls = bs_finish<!MULTI>(st, n, j0, p, [&](int i) { return bs_thr_from_steps(thr_steps, i); }, o0, o1, stopped);
-                else cls = bs32_finish<XR, !MULTI>(st, n, j0, p, [&](int i) { return bs_thr_from_steps(thr_steps, i); }, o0, o1, stopped);
+                if constexpr (KIND == 0) cls = bs_finish<!MULTI>(st, n, j0, p, [&](int i) { return s_thr_last[i]; }, o0, o1, stopped);
+                else cls = bs32_finish<XR, !MULTI>(st, n, j0, p, [&](int i) { return s_thr_last[i]; }, o0, o1, stopped);
             }
             if (exact) { cls = BS_EXACT_FULL; o0 = exact_j; }
             if (retry) { cls = BS_NONE; valid_out = false; }

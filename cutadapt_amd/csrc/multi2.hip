@@ -778,6 +778,7 @@ template <int KIND>
 __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_multi_scan(Multi2ScanArgs a) {
     constexpr int XR = KIND >= 2 ? KIND - 1 : 0;
     extern __shared__ __attribute__((aligned(16))) uint64_t s_scanmask[];   // [n_adapters * CAH_MULTI_TAB_STRIDE]
+    __shared__ int s_thr_last[CAH_MAX_M + 1];
     __shared__ uint32_t s_dp[CAH_M2_PAGE];          // the page's DP work list: pair in page | first column << 10 | (last * 2 + scan) << 18
     __shared__ uint32_t s_ord[CAH_M2_PAGE];         // whole-read pages: the pairs in window order (see phase A)
     __shared__ unsigned s_bins[256];
@@ -790,7 +791,7 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_multi
     if (*a.page_counter == 0ull) return;                                // (a round that found no tile left)
     for (int i = threadIdx.x; i < a.n_adapters * CAH_MULTI_TAB_STRIDE; i += blockDim.x)
         s_scanmask[i] = KIND == 0 ? a.tab[i] : bs32_table_entry(a.tab[i], mt->m);
-    const uint64_t thr_steps = mt->thr_steps;                           // the last column's thresholds (cah_device.h)
+    for (int i = threadIdx.x; i <= CAH_MAX_M; i += blockDim.x) s_thr_last[i] = mt->thr_last[i];
     for (int i = threadIdx.x; i < 128; i += blockDim.x) {
         s_prefix[i] = i < a.n_adapters ? a.prefix[i] : 0u;
         s_xlat[i] = (uint8_t)m2_code((unsigned)i);
@@ -1006,7 +1007,7 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_multi
             // of an inner column ("stopped", back_scan.h), whether or not the wave went on to the read's end
             const bool stopped = precise != 0;
             int cls, jfa = -1;
-            auto thr_of = [&](int i) { return bs_thr_from_steps(thr_steps, i); };
+            auto thr_of = [&](int i) { return s_thr_last[i]; };
             if (KIND != 1 && tail_page && (hdr >> 24) == 0u && a.rows_lo <= 32) {
                 // a "lo" page asks for rows 1 .. rows_lo of the last column alone: the adapter's first 32 rows in ONE plain
                 // 32-bit word do (a row's cost depends on the rows above it only) -- no explicit rows, no second word

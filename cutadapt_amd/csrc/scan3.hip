@@ -50,6 +50,7 @@ template <int KIND>
 __global__ __launch_bounds__(256, 4) void k_back_scan3(ScanArgs a) {      // (111 VGPRs; at 5 waves per SIMD the state spills to scratch, loads inside the chunk loops)
     static_assert(KIND >= 1 && KIND <= 3, "k_back_scan3: the 32-bit forms");
     constexpr int XR = KIND >= 2 ? KIND - 1 : 0;
+    __shared__ int s_thr_last[CAH_MAX_M + 1];
     __shared__ int s_list[SCAN3_TILE * 3];         // the tile's DP work list: (read, first column, last column * 2 + scan);
                                                    // bounded windows from slot 0 up, windows to the read's end from the top down
     __shared__ unsigned s_nf, s_nb;
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(256, 4) void k_back_scan3(ScanArgs a) {      // (11
     const CahMatcher* mt = a.matcher;
     for (int i = threadIdx.x; i < 256; i += blockDim.x)
         s_sm256[i] = i < CAH_TABLE_CHARS ? bs32_table_entry(mt->scanmask[i], mt->m) : 0ull;
-    const uint64_t thr_steps = mt->thr_steps;      // the last column's thresholds (cah_device.h)
+    for (int i = threadIdx.x; i <= CAH_MAX_M; i += blockDim.x) s_thr_last[i] = mt->thr_last[i];
     BackScanParams p;
     p.m = mt->m; p.k = mt->k; p.kacc = mt->kacc; p.min_overlap = mt->min_overlap; p.half_m = mt->m / 2;
     Bs3Geom g;
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(256, 4) void k_back_scan3(ScanArgs a) {      // (11
             int cls = BS_NONE;
             bool valid_out = valid;
             if (valid && !exact && !retry)
-                cls = bs32_finish<XR, true>(st, n, w.start, p, [&](int i) { return bs_thr_from_steps(thr_steps, i); }, o0, o1, stopped, CAH_BS_ALL_ROWS, j0_old);
+                cls = bs32_finish<XR, true>(st, n, w.start, p, [&](int i) { return s_thr_last[i]; }, o0, o1, stopped, CAH_BS_ALL_ROWS, j0_old);
             if (exact) { cls = BS_EXACT_FULL; o0 = exact_j; }
             if (retry) { cls = BS_NONE; valid_out = false; }
             S3_STAMP(3);
