@@ -48,6 +48,10 @@ def parse_args(argv=None):
     ap.add_argument("--p-adapter", type=float, default=None,
                     help="override the adapter fraction of the read model (SURVEY 8(d): 0 and 1 are the extremes; "
                          "the headline number uses the default 0.25)")
+    ap.add_argument("--ragged", action="store_true",
+                    help="cut the reads to 30 .. read_len characters at their 3' end (a hash of the read index): the batch a "
+                         "pipeline holds behind -q / -u -- offsets array, per-lane kernels instead of the streaming ones "
+                         "(C2, C4, C5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--check-reads", type=int, default=200_000, help="reads compared with the oracle (untimed)")
@@ -89,13 +93,14 @@ def self_launch(args) -> int:
 # per-config steps (device-resident)
 # -------------------------------------------------------------------------------------------------
 class Workload:
-    def __init__(self, config, n, rank, device, gen):
+    def __init__(self, config, n, rank, device, gen, ragged=False):
         import torch
         from cutadapt_amd import _lib, workloads
         from cutadapt_amd import adapters as A
         from cutadapt_amd.batch import BatchResult
         self.config, self.n, self.spec = config, n, workloads.SPECS[config]
         self.gen = gen
+        self.ragged = ragged
         kind = self.spec["kind"]
         first = rank * n
 
@@ -120,6 +125,11 @@ class Workload:
             self.plans = [_lib.Plan([a.matcher_spec() for a in back]), _lib.Plan([a.matcher_spec() for a in self.adapters2])]
             self.batches.append(workloads.device_batch(config, n, first, 1, device, gen))
             self.outs.append(result())
+        if ragged:
+            if kind == "linked":
+                raise SystemExit("bench.py: --ragged serves C2, C4 and C5")
+            self.batches = [workloads.ragged_device_batch(b, first) for b in self.batches]
+            torch.cuda.empty_cache()
         for b in self.batches:
             b.workspace()
 
@@ -170,7 +180,9 @@ class Workload:
         ok = True
         for mate, batch in enumerate(self.batches):
             seqs, offsets = host_workloads.host_reads(self.config, 0, m, mate, gen)
-            ok &= np.array_equal(batch.seqs[: m * workloads.READ_LEN].cpu().numpy(), seqs)       # generator twin
+            if self.ragged:
+                seqs, offsets = host_workloads.host_ragged(seqs, offsets, 0)
+            ok &= np.array_equal(batch.seqs[: len(seqs)].cpu().numpy(), seqs)       # generator twin
             if kind in ("single", "multi", "paired"):
                 ads = self.adapters if mate == 0 else self.adapters2
                 want6, want_st, want_best = oracle_multi(ads, seqs, offsets)
@@ -238,7 +250,7 @@ def profile_fields(config, n, dom, dom_launch_ms):
     return traffic, valu, "profile taken on this build of the library (cah_build_id match)"
 
 
-def run_config(args, config, n, steps, warmup, rank, world, device, gen, check_reads, cpu_seconds, want_cpu):
+def run_config(args, config, n, steps, warmup, rank, world, device, gen, check_reads, cpu_seconds, want_cpu, ragged=False):
     """one BASELINE config: build the workload in HBM, time `steps` passes of the hot path, parity sample, roofline
     fields, CPU baseline.  Returns the JSON-line dict (rank 0) or None (other ranks)."""
     import torch
@@ -248,7 +260,7 @@ def run_config(args, config, n, steps, warmup, rank, world, device, gen, check_r
     spec = workloads.SPECS[config]
 
     # ---- inputs resident in HBM before the timed region ------------------------------------------
-    wl = Workload(config, n, rank, device, gen)
+    wl = Workload(config, n, rank, device, gen, ragged)
     wl.gen = gen
     torch.cuda.synchronize()
 
@@ -315,6 +327,8 @@ def run_config(args, config, n, steps, warmup, rank, world, device, gen, check_r
 
     # algorithmic bytes per unit: read characters + 4 (offset) + 24 (result row) [+ 4: adapter index]
     bytes_per_unit = spec["bytes_per_unit"] + (workloads.READ_LEN - 150) * (2 if spec["kind"] == "paired" else 1)
+    if ragged:      # mean length (30 + read_len) / 2 instead of read_len, and the 8-byte offset a ragged batch has per read
+        bytes_per_unit += (8 - (workloads.READ_LEN - (workloads.RAGGED_MIN + workloads.READ_LEN) // 2)) * (2 if spec["kind"] == "paired" else 1)
     total_units = n * world * steps
     value = total_units / elapsed / 1e6
     # dominant kernel family: the one with the largest share of a step
@@ -325,6 +339,8 @@ def run_config(args, config, n, steps, warmup, rank, world, device, gen, check_r
         reads_per_launch = {"k_filter": n, "k_back_scan": survivors, "k_dp": dp_reads if dp_reads else survivors,
                             "k_comparer": n}[dom]
     per_read_bytes = (178 if spec["kind"] != "multi" else 182) + (workloads.READ_LEN - 150)
+    if ragged:
+        per_read_bytes += 8 - (workloads.READ_LEN - (workloads.RAGGED_MIN + workloads.READ_LEN) // 2)
     achieved = reads_per_launch * per_read_bytes / (dom_launch_ms * 1e-3) / 1e9 if dom_launch_ms > 0 else 0.0
     kernel_sum = sum(step_ms.values())
     step_gbs = n * bytes_per_unit / (kernel_sum * 1e-3) / 1e9 if kernel_sum > 0 else 0.0
@@ -345,7 +361,8 @@ def run_config(args, config, n, steps, warmup, rank, world, device, gen, check_r
         "config": {
             "workload": f"{config}: {n} x {'2 x ' if spec['kind'] == 'paired' else ''}{workloads.READ_LEN} bp synthetic "
                         f"{'read pairs' if spec['kind'] == 'paired' else 'reads'} per GPU, {spec['what']}, "
-                        f"p_adapter={gen['p_adapter']}, p_edit={gen['p_edit']}, p_N={gen['p_n']}",
+                        f"p_adapter={gen['p_adapter']}, p_edit={gen['p_edit']}, p_N={gen['p_n']}"
+                        + (f", RAGGED: every read cut to {workloads.RAGGED_MIN} .. {workloads.READ_LEN} characters at its 3' end" if ragged else ""),
             "units_per_gpu": n,
             "read_len": workloads.READ_LEN,
             "n_adapters": len(spec["adapters"]) + len(spec.get("adapters2", [])),
@@ -436,12 +453,12 @@ def main():
         gen["p_adapter"] = float(args.p_adapter)
     n = args.reads if args.reads is not None else DEFAULT_READS[args.config]
     result = run_config(args, args.config, n, args.steps, args.warmup, rank, world, device, gen, args.check_reads,
-                        args.cpu_seconds, not args.no_cpu_baseline)
+                        args.cpu_seconds, not args.no_cpu_baseline and not args.ragged, args.ragged)
     if rank == 0:
         # The default invocation (the driver's: C2, one GPU) also carries the other BASELINE configs at their BASELINE
         # sizes -- a few steps each, with their own parity sample, roofline fraction and a short CPU baseline
         if (args.config == "C2" and world == 1 and args.reads is None and args.p_adapter is None
-                and args.read_len is None and not args.no_other_configs):
+                and args.read_len is None and not args.no_other_configs and not args.ragged):
             others = {}
             for cfg in ("C3", "C4", "C5"):
                 try:
@@ -483,6 +500,23 @@ def main():
                 except Exception as exc:
                     extremes[f"p_adapter_{pa:g}"] = {"error": repr(exc)[:300]}
             result["p_adapter_extremes"] = extremes
+            # ragged batches (what a pipeline holds behind -q / -u): the same reads cut to 30 .. 150 characters; they take
+            # the per-lane kernels (offsets array) instead of the streaming ones
+            ragged = {}
+            for cfg in ("C2", "C4"):
+                try:
+                    r = run_config(args, cfg, DEFAULT_READS[cfg], 2, 1, 0, 1, device, gen, min(args.check_reads, 200_000),
+                                   0.0, False, True)
+                    ragged[cfg] = {"value": r["value"], "unit": r["unit"], "steps": r["steps"], "ms_per_step": r["ms_per_step"],
+                                   "workload": r["config"]["workload"], "parity_check": r["config"]["parity_check"],
+                                   "matched_fraction": r["config"]["matched_fraction"],
+                                   "kernel_ms_per_step": r["roofline"]["kernel_ms_per_step"],
+                                   "vs_uniform": r["value"] / (result["value"] if cfg == "C2" else (others.get(cfg, {}).get("value") or float("nan")))}
+                except SystemExit:
+                    raise
+                except Exception as exc:
+                    ragged[cfg] = {"error": repr(exc)[:300]}
+            result["ragged"] = ragged
         line = json.dumps(result)
         if world > 1:
             os.write(real_stdout, (line + "\n").encode())

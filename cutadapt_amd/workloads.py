@@ -74,3 +74,36 @@ def device_batch(config: str, n_reads: int, first_index: int = 0, mate: int = 0,
             has, prefix = front_rule(idx, torch)
             view[lo:hi, :16] = torch.where(has[:, None], prefix.to(torch.uint8), view[lo:hi, :16])
     return batch
+
+
+# ---- ragged batches (bench.py --ragged): the same reads cut to 30 .. READ_LEN characters at their 3' end -- what a pipeline
+# holds behind -q / -u / a first adapter round (reference cli.py:938-954: the adapter step comes after the quality
+# trimmers).  The length of read i is a hash of its global index, the same in torch and numpy.
+RAGGED_MIN = 30
+
+
+def ragged_lengths(idx, read_len=None):
+    """lengths of the reads with global indices ``idx`` (int64 array, numpy or torch)"""
+    L = READ_LEN if read_len is None else read_len
+    lo = min(RAGGED_MIN, L)
+    return lo + ((idx * 2654435761 + 12345) >> 7) % (L - lo + 1)
+
+
+def ragged_device_batch(batch, first_index: int = 0):
+    """a uniform ReadBatch cut to ragged_lengths (new packed buffer + offsets, both in HBM)"""
+    import torch
+    from .batch import ReadBatch
+    n, L = batch.n_reads, READ_LEN
+    dev = batch.seqs.device
+    lens = ragged_lengths(torch.arange(first_index, first_index + n, dtype=torch.int64, device=dev))
+    offsets = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(lens, 0, out=offsets[1:])
+    out = torch.empty(int(offsets[-1].item()), dtype=torch.uint8, device=dev)
+    view = batch.seqs.view(n, L)
+    cols = torch.arange(L, device=dev)
+    step = 4_000_000                                      # bounds the boolean mask
+    for lo in range(0, n, step):
+        hi = min(n, lo + step)
+        keep = cols[None, :] < lens[lo:hi, None]
+        out[int(offsets[lo].item()):int(offsets[hi].item())] = view[lo:hi][keep]
+    return ReadBatch(out, offsets, validated=True)

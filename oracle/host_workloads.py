@@ -20,3 +20,16 @@ def host_reads(config: str, first_index: int, n_reads: int, mate: int = 0, gen=N
         view = seqs.reshape(n_reads, _wl.READ_LEN)
         view[:, :16] = np.where(has[:, None], prefix.astype(np.uint8), view[:, :16])
     return seqs, offsets
+
+
+def host_ragged(seqs, offsets, first_index: int = 0):
+    """the CPU twin of workloads.ragged_device_batch: (uint8[sum], int64[n+1])"""
+    import numpy as np
+    n = len(offsets) - 1
+    L = _wl.READ_LEN
+    lens = _wl.ragged_lengths(np.arange(first_index, first_index + n, dtype=np.int64))
+    keep = np.arange(L)[None, :] < lens[:, None]
+    out = seqs.reshape(n, L)[keep]
+    off = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(lens, out=off[1:])
+    return np.ascontiguousarray(out), off
