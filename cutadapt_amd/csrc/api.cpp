@@ -1296,7 +1296,7 @@ static int run_aligner(const cah_plan* plan, const PlanDeviceCopy* pd, int32_t a
                 // scan on windows from the chunks' occurrences (k_back_scan3, scan3.hip: three 16-column chunks for most
                 // reads instead of six or seven); what it cannot serve goes to the straggler list, i.e. to the launch below.
                 // CAH_SCAN3=1 switches it on: exact (tests/test_gpu_scan.py runs both ways) but not yet the faster of the two --
-                // DESIGN 9d has the counters: 8 % fewer instructions than k_back_scan at 4 waves per SIMD instead of 5.
+                // DESIGN.md 9 has the counters: 8 % fewer instructions than k_back_scan at 4 waves per SIMD instead of 5.
                 const bool scan3 = mt.bs3_ok && sa.kind >= 1 && sa.kind <= 3 && sa.early_stop && sa.retry_threshold > 0 &&
                                    env_flag("CAH_SCAN3");
                 if (scan3) HIP_TRY(launch_back_scan3(sa, n_reads, pd->n_cus, s));
