@@ -111,7 +111,7 @@ int bm_locate_batch(const void* matcher_blob, const uint8_t* seqs, const int64_t
         const uint8_t* q = seqs + offsets[r];
         const int n = (int)(offsets[r + 1] - offsets[r]);
         int j0 = j0s ? j0s[r] : 0;
-        if (stop_every == 16) j0 = bs_align_window(j0, n);          // the kernel's way
+        if (stop_every == 16 || stop_every == 8) j0 = bs_align_window(j0, n);   // the kernel's way (8: the chunk's middle too)
         bool exact = false, stopped = false;
         int j = j0;
         const int gap = bs_stop_gap(p);

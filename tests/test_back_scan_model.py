@@ -75,11 +75,11 @@ def compare(L, adapter, rate, min_overlap, seqs, offsets, wr=False, wq=False, sk
         j0s = np.zeros(n, dtype=np.int32)
         fn = L.bm_refined_columns if skip == "refined" else L.bm_skip_columns
         fn(adapter.encode(), len(adapter), int(rate * len(adapter)), seqs.ctypes.data, offsets.ctypes.data, n, j0s.ctypes.data)
-    # the early stop looked for once per 16-column chunk (what the kernel does), after every column (the tightest
+    # the early stop looked for once per 16-column chunk and in its middle (what the kernel does), after every column (the tightest
     # use of the rule) and never (the scan always reaches the read end)
     # ... each in the form the launcher picks for the adapter (32-bit words, + explicit rows for 33 / 34 characters)
     # and in the 64-bit form
-    for stop_every, form in ((16, -1), (1, -1), (0, -1), (16, 0), (0, 0)):
+    for stop_every, form in ((16, -1), (8, -1), (1, -1), (0, -1), (16, 0), (0, 0)):
         rc, out6, status, cls = run_model(L, blob, seqs, offsets, j0s, stop_every, form)
         if rc == 1:
             return None                                  # matcher not scan-eligible: nothing to check
