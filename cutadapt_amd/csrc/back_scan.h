@@ -637,16 +637,21 @@ CAH_HD void bs3_pre_harvest(Bs3Pre& s, const int j_end, const Bs3Geom& g) {
     s.glo = 0; s.ghi = 0;
 }
 // first character (0-based) of the pre-pass: every chunk that ends in the prefilter's first-hit group or later is seen whole
-CAH_HD int bs3_pre_start(const int key4, const Bs3Geom& g) {
-    const int p0 = key4 - (g.maxlen - 1);
+// ... and, for reads of 64+ characters, moved back so that the first BLOCK of four 16-character chunks lies inside the read
+// (an earlier start is as exact; the kernel then fetches the block with four plain loads, no tail handling)
+CAH_HD int bs3_pre_start(const int key4, const Bs3Geom& g, const int n) {
+    int p0 = key4 - (g.maxlen - 1);
+    if (n >= 64 && p0 > n - 64) p0 = n - 64;
     return p0 > 0 ? p0 : 0;
+}
+// the last column (1-based) the pre-pass of a read looks at: the read's end while nothing is found, then smax + range
+CAH_HD int bs3_pre_last(const int n, const bool found, const int smax, const int range) {
+    return (found && smax + range < n) ? smax + range : n;
 }
 // number of 16-character chunks from p0 on that the pre-pass of a read walks: all up to the read's end while nothing is
 // found; with occurrences, those that hold a column <= smax + range (asked again after every chunk: smax grows)
 CAH_HD int bs3_pre_chunks(const int p0, const int n, const bool found, const int smax, const int range) {
-    int last = n;                                             // last column (1-based) to look at
-    if (found && smax + range < n) last = smax + range;
-    const int cols = last - p0;                               // columns p0 + 1 .. last
+    const int cols = bs3_pre_last(n, found, smax, range) - p0;       // columns p0 + 1 .. last
     return cols <= 0 ? 0 : (cols + 15) >> 4;
 }
 

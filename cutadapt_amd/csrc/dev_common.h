@@ -95,6 +95,19 @@ __device__ __forceinline__ Chunk load_chunk(const uint8_t* q, int pos, int n, in
     return c;
 }
 
+// The chunk at `pos` of lanes whose chunk lies inside their read (pos + 16 <= n): ONE load, nothing else -- for callers
+// that have asked the wave first; load_chunk's three cases and the masks behind them are ~35 instructions per call.
+__device__ __forceinline__ Chunk load_chunk_interior(const uint8_t* q, const int pos, const bool want) {
+    Chunk c;
+    c.w[0] = c.w[1] = c.w[2] = c.w[3] = 0;
+    if (want) {
+        Unaligned16 u;
+        __builtin_memcpy(&u, q + pos, 16);
+        c.w[0] = u.w[0]; c.w[1] = u.w[1]; c.w[2] = u.w[2]; c.w[3] = u.w[3];
+    }
+    return c;
+}
+
 // byte t (0..15) of a chunk; t is wave-uniform or a compile-time constant
 __device__ __forceinline__ unsigned chunk_byte(const Chunk& c, int t) {
     const int d = t >> 2;

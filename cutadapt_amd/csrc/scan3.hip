@@ -47,7 +47,10 @@ extern "C" int cah_debug_scan3_trace(unsigned long long* out) {
 #endif
 
 template <int KIND>
-__global__ __launch_bounds__(256, 4) void k_back_scan3(ScanArgs a) {      // (111 VGPRs; at 5 waves per SIMD the state spills to scratch, loads inside the chunk loops)
+#ifndef CAH_SCAN3_WAVES
+#define CAH_SCAN3_WAVES 4
+#endif
+__global__ __launch_bounds__(256, CAH_SCAN3_WAVES) void k_back_scan3(ScanArgs a) {
     static_assert(KIND >= 1 && KIND <= 3, "k_back_scan3: the 32-bit forms");
     constexpr int XR = KIND >= 2 ? KIND - 1 : 0;
     __shared__ int s_thr_last[CAH_MAX_M + 1];
@@ -73,7 +76,8 @@ __global__ __launch_bounds__(256, 4) void k_back_scan3(ScanArgs a) {      // (11
     if (a.queue_limit > 0 && total > a.queue_limit) total = a.queue_limit;
     const int tile = SCAN3_TILE;
     unsigned low16 = 0xFFFFu;                                          // (a VGPR: v_bitop3 takes no literal)
-    asm volatile("" : "+v"(low16));
+    unsigned v_start = g.start, v_end = g.end;                         // (VGPRs: an SGPR operand doubles a simple instruction's issue time)
+    asm volatile("" : "+v"(low16), "+v"(v_start), "+v"(v_end));
 #ifdef SCAN_TRACE
     int trace_i = 0;
 #endif
@@ -144,20 +148,30 @@ __global__ __launch_bounds__(256, 4) void k_back_scan3(ScanArgs a) {      // (11
             // column by column, bs3_pre_harvest at every chunk's end -- written out here in the cheap instruction forms)
             Bs3Pre pre;
             bs3_pre_init(pre);
-            const int p0 = bs3_pre_start(key4, g);
+            const int p0 = bs3_pre_start(key4, g, n);
             {
-                // The characters come in BLOCKS of four chunks, all four loads in flight together: a chunk of the pre-pass is
-                // ~350 issue cycles, far less than a trip to memory -- chunk by chunk the pass waited for every load
-                // (10 000 cycles per chunk in the first trace).  Most lanes are through after one block.
-                int pos = p0, c = 0;
+                // The characters come in BLOCKS of four chunks, the loads in flight together (a chunk of the pre-pass is ~250
+                // issue cycles, far less than a trip to memory: chunk by chunk the pass waited for every load).  The first
+                // block lies inside the read (bs3_pre_start): four plain loads; a block that holds a read's tail takes
+                // load_chunk with its three cases -- and most lanes are through after one block.
+                int pos = p0;
+                int last = valid ? n : 0;                           // last column this lane looks at (bs3_pre_last)
 #pragma unroll 1
                 for (;;) {
-                    if (!__any(valid && c < bs3_pre_chunks(p0, n, pre.found != 0, pre.smax, range))) break;
-                    Chunk b0 = load_chunk(q, pos, n, valid ? n : 0), b1 = load_chunk(q, pos + 16, n, valid ? n : 0),
-                          b2 = load_chunk(q, pos + 32, n, valid ? n : 0), b3 = load_chunk(q, pos + 48, n, valid ? n : 0);
+                    if (!__any(pos < last)) break;
+                    Chunk b0, b1, b2, b3;
+                    if (__all(pos >= last || pos + 64 <= n)) {
+                        const bool on = pos < last;
+                        b0 = load_chunk_interior(q, pos, on); b1 = load_chunk_interior(q, pos + 16, on);
+                        b2 = load_chunk_interior(q, pos + 32, on); b3 = load_chunk_interior(q, pos + 48, on);
+                    } else {
+                        const int lim = pos < last ? n : 0;
+                        b0 = load_chunk(q, pos, n, lim); b1 = load_chunk(q, pos + 16, n, lim);
+                        b2 = load_chunk(q, pos + 32, n, lim); b3 = load_chunk(q, pos + 48, n, lim);
+                    }
 #pragma unroll 1
-                    for (int u = 0; u < 4; ++u, ++c, pos += 16) {
-                        const bool active = valid && c < bs3_pre_chunks(p0, n, pre.found != 0, pre.smax, range);
+                    for (int u = 0; u < 4; ++u, pos += 16) {
+                        const bool active = pos < last;
                         if (!__any(active)) break;
                         const Chunk cur = b0;
                         b0 = b1; b1 = b2; b2 = b3;
@@ -166,16 +180,19 @@ __global__ __launch_bounds__(256, 4) void k_back_scan3(ScanArgs a) {      // (11
 #pragma unroll
                         for (int t = 0; t < 16; ++t) {
                             const uint32_t e = eq_lo(cur.w[t >> 2], t & 3);
-                            M = BS_BITOP3(bs_dbl(M), g.start, e, 0xA8u);               // ((M << 1) | START) & eq
-                            const uint32_t h = M & g.end;
+                            M = BS_BITOP3(bs_dbl(M), v_start, e, 0xA8u);               // ((M << 1) | START) & eq
+                            const uint32_t h = M & v_end;
                             glo = BS_BITOP3(bs_dbl(glo), h, low16, 0xF8u);             // (glo << 1) | (h & 0xFFFF)
                             ghi = bs_dbl(ghi) | (h >> 16);
                         }
                         pre.M = M;
                         // (a lane behind its range walks along: its occurrences do not count)
-                        pre.glo = active ? glo : 0u; pre.ghi = active ? ghi : 0u;
-                        bs3_pre_harvest(pre, pos + 16, g);
-                        S3_NOTE(5, c + 1);
+                        if (__any(active && (glo | ghi) != 0)) {
+                            pre.glo = active ? glo : 0u; pre.ghi = active ? ghi : 0u;
+                            bs3_pre_harvest(pre, pos + 16, g);
+                            if (active) last = bs3_pre_last(n, pre.found != 0, pre.smax, range);
+                        }
+                        S3_NOTE(5, (pos - p0) / 16 + 1);
                     }
                 }
             }
@@ -190,7 +207,7 @@ __global__ __launch_bounds__(256, 4) void k_back_scan3(ScanArgs a) {      // (11
                     read_extent(a.offsets, a.lens, a.uniform_first, a.uniform_len, (int64_t)r_n, o_n, n_n);
                     if (n_n >= 4 && n_n <= a.max_read_len) {
                         const int nn = (int)n_n;
-                        const int t0 = min(bs3_pre_start((int)key_n << CAH_KEY_SHIFT, g), nn - 4), t1 = min(t0 + 60, nn - 4);
+                        const int t0 = min(bs3_pre_start((int)key_n << CAH_KEY_SHIFT, g, nn), nn - 4), t1 = min(t0 + 60, nn - 4);
                         Unaligned16 dummy;
                         unsigned x0, x1;
                         __builtin_memcpy(&x0, a.seqs + o_n + t0, 4);
@@ -237,14 +254,24 @@ __global__ __launch_bounds__(256, 4) void k_back_scan3(ScanArgs a) {      // (11
 #pragma unroll 1
                 for (;;) {
                     if (!__any(!done && j < jend)) break;
-                    // (blocks of four chunks, the loads in flight together: a class-F window is one block)
-                    Chunk b0 = load_chunk(q, pos, n, (!done && j < jend) ? n : 0), b1 = load_chunk(q, pos + 16, n, (!done && j + 16 < jend) ? n : 0),
-                          b2 = load_chunk(q, pos + 32, n, (!done && j + 32 < jend) ? n : 0), b3 = load_chunk(q, pos + 48, n, (!done && j + 48 < jend) ? n : 0);
+                    // (blocks of three chunks, the loads in flight together: a class-F window is one block.  Windows are whole
+                    // chunks inside the read -- plain loads; only a read shorter than its window takes load_chunk)
+                    Chunk b0, b1, b2;
+                    {
+                        const bool w0 = !done && j < jend, w1 = !done && j + 16 < jend, w2 = !done && j + 32 < jend;
+                        if (__all((!w0 || pos + 16 <= n) && (!w1 || pos + 32 <= n) && (!w2 || pos + 48 <= n))) {
+                            b0 = load_chunk_interior(q, pos, w0); b1 = load_chunk_interior(q, pos + 16, w1);
+                            b2 = load_chunk_interior(q, pos + 32, w2);
+                        } else {
+                            b0 = load_chunk(q, pos, n, w0 ? n : 0); b1 = load_chunk(q, pos + 16, n, w1 ? n : 0);
+                            b2 = load_chunk(q, pos + 32, n, w2 ? n : 0);
+                        }
+                    }
 #pragma unroll 1
-                    for (int u = 0; u < 4; ++u, pos += 16) {
+                    for (int u = 0; u < 3; ++u, pos += 16) {
                         if (!__any(!done && j < jend)) break;
                         Chunk cur = b0;
-                        b0 = b1; b1 = b2; b2 = b3;
+                        b0 = b1; b1 = b2;
                         bad_chars |= cur.w[0] | cur.w[1] | cur.w[2] | cur.w[3];
                         if (FAST && __all(done || j + 16 <= jend)) {
                             // Whole chunks, no per-column tests.  Lanes that are through sit the chunk out (ONE branch around

@@ -7,7 +7,7 @@ run() {  # tag env name counters...
   ( cd /tmp; env $envs timeout 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $out/${tag}_$name -o p -- python $GRAFT_REPO_ROOT/bench.py --config C2 --reads 50000000 --no-other-configs --no-cpu-baseline --check-reads 0 --steps 2 --warmup 0 > $out/${tag}_$name.json 2> $out/${tag}_$name.err )
 }
 for v in new old; do
-  e="X=1"; [ $v = old ] && e="CAH_NO_SCAN3=1"
+  e="CAH_SCAN3=1"; [ $v = old ] && e="X=1"
   run $v $e sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU
   run $v $e sq2 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAIT_INST_LDS SQ_INSTS_BRANCH
 done

@@ -206,7 +206,7 @@ int bm_locate_batch3(const void* matcher_blob, const uint8_t* seqs, const int64_
         // ---- pre-pass: 16-character chunks from p0, harvested at every chunk's end (characters behind the read: NUL)
         Bs3Pre pre;
         bs3_pre_init(pre);
-        const int p0 = bs3_pre_start(key4, g);
+        const int p0 = bs3_pre_start(key4, g, n);
         for (int c = 0; c < bs3_pre_chunks(p0, n, pre.found != 0, pre.smax, range); ++c) {
             for (int t = 0; t < 16; ++t) {
                 const int j = p0 + 16 * c + t + 1;
