@@ -1088,13 +1088,17 @@ static int64_t m2_pages_worst(int64_t A, int64_t n_reads) {
 static int64_t multi_pair_cap(const cah_plan* plan, int64_t n_reads) {
     int64_t limit = 2048ll << 20;
     if (const char* e = getenv("CAH_MULTI_PAIR_CAP")) { const long long v = atoll(e); if (v > 0) limit = v; }
+    // (the cell DP's work list holds pair indices as int32: the pool never has 2^31 pairs or more, whatever the knob says)
+    limit = std::min<int64_t>(limit, ((int64_t)1 << 31) - 4 * CAH_M2_PAGE);
     const int64_t A = (int64_t)plan->matchers.size();
     if (limit < A) limit = A;
+    const int64_t fused = std::min(n_reads * A, limit);
+    if (!plan->multi.m2.hdr.ok) return fused;               // (no streaming form for this plan: no page pool, no floor)
     // (one block of the streaming prefilter must always be able to run)
     const int64_t floor_pages = 2 * m2_block_reserve(A) + 2 * m2_pages_per_tile(A);
     const int64_t pages = std::min(m2_pages_worst(A, n_reads), std::max(limit / CAH_M2_PAGE, floor_pages));
     // (a page header word per page lives behind the pages, inside the pair area)
-    return std::max(std::min(n_reads * A, limit), pages * CAH_M2_PAGE + pages / 2 + 2);
+    return std::max(fused, pages * CAH_M2_PAGE + pages / 2 + 2);
 }
 static size_t ws_key_bytes(int64_t n_reads) { return (sizeof(unsigned long long) * (size_t)n_reads + 255) & ~(size_t)255; }
 

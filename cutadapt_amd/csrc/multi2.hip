@@ -29,6 +29,7 @@
 // substitution / one-indel bookkeeping (most adapters with sequencing errors finish there, not in the cell DP) and tail
 // pages as the bare recurrence (lo pages: the adapter's first 32 rows in one 32-bit word).
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <stdint.h>
 
 #include <algorithm>
@@ -1118,13 +1119,22 @@ int multi2_tile_reads() { return M2_TILE; }
 
 hipError_t launch_multi_stream(const Multi2Args& a, const CahMulti2Header& h, int grid, hipStream_t s) {
     const size_t lds = multi2_lds_bytes(h);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_multi_stream<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void*)k_multi_stream<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
+    // (the attribute belongs to the kernel ON A DEVICE: one flag per device, set under a lock -- feeder threads of several
+    // GPUs come through here at once)
+    static std::mutex attr_mu;
+    static bool attr_set[64] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    {
+        std::lock_guard<std::mutex> lk(attr_mu);
+        if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+            e = hipFuncSetAttribute((const void*)k_multi_stream<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            e = hipFuncSetAttribute((const void*)k_multi_stream<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            if (dev >= 0 && dev < 64) attr_set[dev] = true;
+        }
     }
     if (grid < 1) grid = 1;
     if (h.q_mask[M2_W] == (1 << 8)) hipLaunchKernelGGL(k_multi_stream<true>, dim3(grid), dim3(M2_WAVES * WAVE), lds, s, a);
