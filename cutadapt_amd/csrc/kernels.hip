@@ -1390,10 +1390,27 @@ __device__ unsigned long long g_dp_dbg[8];      // debug build only: lock-step a
 // (store_result: dev_common.h)
 
 
+// Round 5: the match predicate and the "cost <= k" predicate as MASKS (0 / ~0: v_bfe_i32 of the match word, the sign of
+// cell - klim) and their selects as v_bitop3 -- 2-cycle forms where a compare + v_cndmask pair is 4 + 4 (DESIGN 3.2's table);
+// the band predicate stays a compare: its result also feeds the wave-wide "any band left" test.  -DCAH_DPP_PLAIN: round 4's form.
+#ifdef CAH_DPP_PLAIN
+typedef bool dpp_pred;
+__device__ __forceinline__ dpp_pred dpp_match_bit(const unsigned mword, const int bit) { return (mword & (1u << bit)) != 0u; }
+__device__ __forceinline__ unsigned dpp_select(const dpp_pred p, const unsigned a, const unsigned b) { return p ? a : b; }
+#else
+typedef unsigned dpp_pred;
+__device__ __forceinline__ dpp_pred dpp_match_bit(const unsigned mword, const int bit) {
+    return (unsigned)__builtin_amdgcn_sbfe((int)mword, (unsigned)bit, 1u);
+}
+__device__ __forceinline__ unsigned dpp_select(const dpp_pred p, const unsigned a, const unsigned b) {
+    return __builtin_amdgcn_bitop3_b32(p, a, b, 0xCA);
+}
+#endif
+
 template <int I, int ROWS>
 __device__ __forceinline__ void dp_rows_packed(unsigned (&w)[ROWS + 1], const unsigned mk_lo, const unsigned mk_hi,
                                                unsigned wd, int& nl, unsigned& cm_w, const int last, const int m,
-                                               const unsigned klim, const bool eq, const bool in_band) {
+                                               const unsigned klim, const dpp_pred eq, const bool in_band) {
     // eq / in_band: this row's predicates, computed at the end of the previous row.  On gfx950 a VALU
     // compare result (VCC / SGPR pair) cannot feed the very next VALU instruction (the compiler pads
     // with s_nop), so the compares of row I+1 are issued between row I's `cost <= k` compare and the
@@ -1409,17 +1426,24 @@ __device__ __forceinline__ void dp_rows_packed(unsigned (&w)[ROWS + 1], const un
         const unsigned c3 = wold + PK_D_INS;              // insertion: from this row, previous column
         const unsigned mn = min(min(a, b), c3) & ~PK_PRIO_MASK;
         const unsigned e = wd + PK_D_MATCH;
-        const unsigned wn = eq ? e : mn;
+        const unsigned wn = dpp_select(eq, e, mn);
         w[I] = in_band ? wn : wold;                       // out of band: the stale cell stays
         if constexpr (I > ROWS - 8) {
             if (I == m) cm_w = wn;                        // wave-uniform capture of cell (m, j)
         }
-        const bool ok = w[I] < klim;                      // stale cells cost > k (see k_dp)
         const unsigned mword = I < 32 ? mk_lo : mk_hi;    // predicates of row I + 1
-        const bool eq_next = (mword & (1u << (I & 31))) != 0u;
+        const dpp_pred eq_next = dpp_match_bit(mword, I & 31);
         const bool band_next = I + 1 <= last;
+#ifdef CAH_DPP_PLAIN
+        const bool ok = w[I] < klim;                      // stale cells cost > k (see k_dp)
         __builtin_amdgcn_sched_barrier(0);
         nl = ok ? I : nl;
+#else
+        // (cells and klim are below 2^29: the sign of the difference is the comparison)
+        const unsigned okm = (unsigned)((int)(w[I] - klim) >> 31);
+        __builtin_amdgcn_sched_barrier(0);
+        nl = (int)__builtin_amdgcn_bitop3_b32(okm, (unsigned)I, (unsigned)nl, 0xCA);
+#endif
         if constexpr ((I % CAH_SCHED_ROWS) == 0) __builtin_amdgcn_sched_barrier(0);
         dp_rows_packed<I + 1, ROWS>(w, mk_lo, mk_hi, wold, nl, cm_w, last, m, klim, eq_next, band_next);
     }
@@ -1476,7 +1500,12 @@ __global__ __launch_bounds__(256, CAH_DPP_WAVES(ROWS)) void k_dp_packed(DpArgs a
     const int half_m = m / 2;
     // cost <= k  <=>  word < (k+1) << 20 (priority bits are clear in stored cells); costs never
     // exceed 64 here, so any k >= 200 behaves the same
+#ifdef CAH_DPP_PLAIN
     const unsigned klim = (unsigned)(min(k, 200) + 1) << PK_COST_SHIFT;
+#else
+    unsigned klim = (unsigned)(min(k, 200) + 1) << PK_COST_SHIFT;
+    asm volatile("" : "+v"(klim));                       // (a VGPR: as an SGPR operand it doubles the subtraction's issue time)
+#endif
 
     const int lane = wave_lane();
     int64_t total = a.n_reads, front = a.n_reads;
@@ -1593,7 +1622,7 @@ __global__ __launch_bounds__(256, CAH_DPP_WAVES(ROWS)) void k_dp_packed(DpArgs a
                 int nl = 0;                               // row 0 always has cost 0 <= k
                 unsigned cm_w = w_row0;                   // (m == 0: the candidate cell is row 0)
                 dp_rows_packed<1, ROWS>(w, (unsigned)mk, (unsigned)(mk >> 32), w_row0, nl, cm_w, last, m, klim,
-                                        ((unsigned)mk & 1u) != 0u, 1 <= last);
+                                        dpp_match_bit((unsigned)mk, 0), 1 <= last);
                 last_filled = last;                       // :484
                 if (last >= 1) lf_ran = last;
                 if (nl < m) {                             // band update (:490-495)

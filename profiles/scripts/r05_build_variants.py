@@ -12,6 +12,7 @@ VARIANTS = {
     "plain": ["-DCAH_BS_PLAIN_OPS"],                                  # the compiler's own instruction forms in the scan's column
     "trace": ["-DSCAN_TRACE"],
     "w4": ["-DCAH_SCAN_WAVES=4"],
+    "dppplain": ["-DCAH_DPP_PLAIN"],                                  # k_dp_packed with compare + select predicates (round 4's cell)
     "s3w5": ["-DCAH_SCAN3_WAVES=5"],                                  # k_back_scan3 at 5 waves per SIMD (96 VGPRs, 35 spilled)                                     # k_back_scan at 4 waves per SIMD (128 VGPRs)
     "m2w12": ["-DM2_WAVES=12"],                                       # k_multi_stream with 12 waves per CU: 168 VGPRs, no scratch
     "m2w8": ["-DM2_WAVES=8"],                                        # the product's scan with s_memtime stamps
