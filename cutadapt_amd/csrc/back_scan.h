@@ -283,8 +283,10 @@ CAH_HD void bs32_init(BackScanState32<X>& s, const BackScanParams& p) {
 }
 
 template <bool SUBS, int X, bool BOOK = true>
+// (joff: added to j only where the column number is needed -- the booking of an acceptable column, off the straight path;
+// a kernel that unrolls sixteen columns passes its chunk's first column and the constants 1..16 instead of counting)
 CAH_HD bool bs32_step(BackScanState32<X>& s, const uint32_t eq, const uint32_t eqx, const int j, const BackScanParams& p,
-                      const int jlim = 0x7FFFFFFF) {
+                      const int jlim = 0x7FFFFFFF, const int joff = 0) {
     // ---- the explicit rows 1..X and what they hand to the word: hin, and the bits that enter its diagonals
     uint32_t hpos = 0, hneg = 0, a_in = 0, u_in = 0, z_in = 0, a_top_new = 0;
     if (X == 1) {
@@ -346,7 +348,7 @@ CAH_HD bool bs32_step(BackScanState32<X>& s, const uint32_t eq, const uint32_t e
         s.Z = bs_sel(Xc, pa, X > 1 ? (bs_dbl(s.Z) | z_in) : bs_dbl(s.Z));
     }
     if (__builtin_expect(s.cm <= p.kacc, 0))
-        return bs_book<SUBS>(s, (s.A >> 31) == 0, j, p, (s.U >> 31) != 0, (s.Z >> 31) != 0, jlim);
+        return bs_book<SUBS>(s, (s.A >> 31) == 0, j + joff, p, (s.U >> 31) != 0, (s.Z >> 31) != 0, jlim);
     return false;
 }
 

@@ -1842,9 +1842,9 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : CAH_SCAN_WAVES)
             typename std::conditional<KIND == 0, BackScanState, BackScanState32<XR>>::type st;
             if constexpr (KIND == 0) bs_init(st, p); else bs32_init(st, p);
             // one column: the character's table entry is the 64-bit match word, or {rows 1..32, rows 33..}
-            auto step = [&](const uint64_t eq, const int jj) -> bool {
-                if constexpr (KIND == 0) return bs_step<!MULTI>(st, eq, jj, p);
-                else return bs32_step<!MULTI, XR>(st, (uint32_t)eq, (uint32_t)(eq >> 32), jj, p);
+            auto step = [&](const uint64_t eq, const int jj, const int joff = 0) -> bool {
+                if constexpr (KIND == 0) return bs_step<!MULTI>(st, eq, jj + joff, p);
+                else return bs32_step<!MULTI, XR>(st, (uint32_t)eq, (uint32_t)(eq >> 32), jj, p, 0x7FFFFFFF, joff);
             };
             int j = j0, exact_j = 0;
             bool done = !valid, exact = false, stopped = false, retry = false, valid_out = valid;
@@ -1918,13 +1918,14 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : CAH_SCAN_WAVES)
                     // every lane still at work has the whole chunk ahead of it (the queue is ordered by window
                     // start, so this is the rule): no per-column guards.  Lanes that are done -- as EXACT_FULL, or
                     // idle from the start -- step along on NUL chunks; their state is not looked at again.
+                    // (the column number is only needed where a column is booked: j is counted per chunk, not per column)
 #pragma unroll
                     for (int t = 0; t < 16; ++t) {
                         const uint64_t eq = eqq[t % SCAN_AHEAD];
                         if (t + SCAN_AHEAD < 16) eqq[t % SCAN_AHEAD] = eq_of(cur, t + SCAN_AHEAD);
-                        ++j;
-                        if (step(eq, j) && !exact) { exact = true; exact_j = j; }
+                        if (step(eq, j, t + 1) && !exact) { exact = true; exact_j = j + t + 1; }
                     }
+                    j += 16;
                     if (exact) done = true;
                 } else {
 #pragma unroll
