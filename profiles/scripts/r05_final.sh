@@ -8,6 +8,15 @@ out=gpurun_out/r05final; mkdir -p $out
 timeout 900 python -m pytest tests -x -q -m gpu --timeout 300 > $out/gpu_tests.log 2>&1; echo "rc=$?" >> $out/gpu_tests.log
 tail -n 4 $out/gpu_tests.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.log 2>&1; echo "smoke rc=$?"; tail -n 2 $out/smoke.log
+# ---- soak: the parity suites that draw their cases from seeded generators, with shifted seeds (conftest.py:
+# CAH_TEST_SEED_OFFSET), and the parked k_back_scan3 switched on for every plan that can take it
+mkdir -p $out/soak
+for OFF in 505 606; do
+  CAH_TEST_SEED_OFFSET=$OFF timeout 900 python -m pytest tests/test_gpu_scan.py tests/test_gpu_multi2.py tests/test_gpu_multi.py tests/test_gpu_parity.py tests/test_gpu_stream.py tests/test_gpu_small.py tests/test_gpu_long.py -q -m gpu --timeout 600 2>&1 | tail -n 3 > $out/soak/seed_$OFF.log
+  echo "seed offset $OFF: $(tail -n 1 $out/soak/seed_$OFF.log)"
+done
+CAH_SCAN3=1 timeout 900 python -m pytest tests/test_gpu_scan.py tests/test_gpu_parity.py tests/test_gpu_stream.py tests/test_gpu_configs.py tests/test_gpu_small.py tests/test_gpu_dropin.py -q -m gpu --timeout 600 2>&1 | tail -n 3 > $out/soak/scan3_on.log
+echo "CAH_SCAN3=1: $(tail -n 1 $out/soak/scan3_on.log)"
 # ---- PMC: trace + sq1 sq2 fetch write grbm (profiles/scripts/pmc.sh without its third SQ pass)
 pmc() {  # config reads tag
   o="$GRAFT_REPO_ROOT/gpurun_out/r05final_pmc_$1"; mkdir -p "$o"
