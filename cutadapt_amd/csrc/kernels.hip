@@ -1729,6 +1729,16 @@ extern "C" int cah_debug_scan_trace(unsigned long long* out) {
 #define SCAN_STAMP(st, extra) do { } while (0)
 #endif
 
+// The kernel's arguments re-read from the kernarg segment where they are used (the result stores, the straggler list, the
+// DP work list -- once per sub-batch or per tile): as plain arguments they sit in SGPRs through the column loops, which
+// have none to spare (186 spilled, v_readlane / v_writelane around every sub-batch).  k_filter_stream2's trick.
+typedef const __attribute__((address_space(4))) ScanArgs* scan_kernarg_ptr;
+__device__ __forceinline__ scan_kernarg_ptr scan_kernargs() {
+    scan_kernarg_ptr kp = (scan_kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));                                        // keeps the loads where the values are used
+    return kp;
+}
+
 // MULTI: the work list holds (read, adapter, key) pairs of the fused multi-adapter prefilter; all adapters
 // have one shape (m, k, thresholds: matcher 0), only the match table differs per lane.
 // KIND: the form of the column (back_scan.h, bs_kind_of): 0 = one 64-bit word, 1 = one 32-bit word (adapters up to 32
@@ -1809,18 +1819,20 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : CAH_SCAN_WAVES)
                     tab_base = adapter * CAH_MULTI_TAB_STRIDE;
                 }
             } else if (!pf_have) {
-                if (valid) r = a.queue ? (int64_t)a.queue[idx] : idx;
+                const scan_kernarg_ptr kq = scan_kernargs();
+                if (valid) r = kq->queue ? (int64_t)kq->queue[idx] : idx;
                 // (a slot of the straggler list that its wave reserved but could not use: the list was full)
                 if (r < 0) { valid = false; r = 0; }
-                if (skip_cols && valid) key = a.queue_keys[idx];
+                if (skip_cols && valid) key = kq->queue_keys[idx];
             }
             int64_t off = 0, n64 = 0;
+            const scan_kernarg_ptr kr = scan_kernargs();
             if (!MULTI && pf_have) { valid = pf_valid; r = pf_r; key = pf_key; off = pf_off; n64 = pf_n; }
-            else if (valid) read_extent(a.offsets, a.lens, a.uniform_first, a.uniform_len, r, off, n64);
+            else if (valid) read_extent(kr->offsets, kr->lens, kr->uniform_first, kr->uniform_len, r, off, n64);
             bool invalid = false;
-            if (n64 > a.max_read_len) { invalid = true; n64 = 0; }
+            if (n64 > kr->max_read_len) { invalid = true; n64 = 0; }
             const int n = (int)n64;
-            const uint8_t* q = a.seqs + off;
+            const uint8_t* q = kr->seqs + off;
             // first column of the window (column skipping): nothing of the whole-read k-mer set
             // ends before 4 * key, so no row-m cost <= k occurs before it
             int j0 = 0;
@@ -1865,8 +1877,8 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : CAH_SCAN_WAVES)
             unsigned key_n = 0;
             if (next_sub) {
                 valid_n = idx_n < total;
-                if (valid_n) r_n = a.queue ? a.queue[idx_n] : (int)idx_n;
-                if (skip_cols && valid_n) key_n = a.queue_keys[idx_n];
+                if (valid_n) r_n = kr->queue ? kr->queue[idx_n] : (int)idx_n;
+                if (skip_cols && valid_n) key_n = kr->queue_keys[idx_n];
             }
             SCAN_STAMP(1, 0);
             for (;;) {
@@ -1884,13 +1896,14 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : CAH_SCAN_WAVES)
                         if (bfar) {
                             const int cnt = __popcll(bfar);
                             unsigned long long slot = 0;
-                            if (lane == 0) slot = atomicAdd(a.retry_count, (unsigned long long)cnt);
+                            const scan_kernarg_ptr ka = scan_kernargs();
+                            if (lane == 0) slot = atomicAdd(ka->retry_count, (unsigned long long)cnt);
                             slot = __shfl(slot, 0, WAVE);
-                            if ((int64_t)(slot + cnt) <= a.retry_cap) {
+                            if ((int64_t)(slot + cnt) <= ka->retry_cap) {
                                 if (far) {
                                     const int64_t e = (int64_t)slot + __popcll(bfar & ((1ull << lane) - 1ull));
-                                    a.retry_queue[e] = (int32_t)r;
-                                    a.retry_keys[e] = (uint8_t)key;
+                                    ka->retry_queue[e] = (int32_t)r;
+                                    ka->retry_keys[e] = (uint8_t)key;
                                     done = true; retry = true;
                                 }
                                 if (bfar == act) break;
@@ -1900,7 +1913,7 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : CAH_SCAN_WAVES)
                                 // meet whatever the scratch held before.
                                 if (far) {
                                     const int64_t e = (int64_t)slot + __popcll(bfar & ((1ull << lane) - 1ull));
-                                    if (e < a.retry_cap) a.retry_queue[e] = -1;
+                                    if (e < ka->retry_cap) ka->retry_queue[e] = -1;
                                 }
                                 retry_at = 0;
                             }
@@ -1950,7 +1963,8 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : CAH_SCAN_WAVES)
             if (next_sub) {
                 if (r_n < 0) { valid_n = false; r_n = 0; }
                 int64_t o_n = 0, n_n = 0;
-                if (valid_n) read_extent(a.offsets, a.lens, a.uniform_first, a.uniform_len, (int64_t)r_n, o_n, n_n);
+                const scan_kernarg_ptr kn = scan_kernargs();
+                if (valid_n) read_extent(kn->offsets, kn->lens, kn->uniform_first, kn->uniform_len, (int64_t)r_n, o_n, n_n);
                 // (a read beyond max_read_len keeps its length here: the next sub-batch flags it as this code would)
                 pf_valid = valid_n; pf_r = r_n; pf_key = key_n; pf_off = o_n;
                 pf_n = n_n > (int64_t)0x7FFFFFFF ? 0x7FFFFFFF : (int)n_n;
@@ -1988,9 +2002,11 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : CAH_SCAN_WAVES)
                 if (cls == BS_INDEL1_FULL) {              // o1 = cost * 2 + (1: one deletion, 0: one insertion)
                     t2 = o0 - p.m + ((o1 & 1) ? 1 : -1); sc = p.m - 2 * (o1 >> 1) - (o1 & 1); cost = o1 >> 1;
                 }
-                if (invalid || cls != BS_DP)
-                    store_result(a.out6, a.status, a.best_adapter, a.adapter_index, a.merge_best, r, invalid, found,
+                if (invalid || cls != BS_DP) {
+                    const scan_kernarg_ptr ka = scan_kernargs();
+                    store_result(ka->out6, ka->status, ka->best_adapter, ka->adapter_index, ka->merge_best, r, invalid, found,
                                  0, t1, t2, t3, sc, cost);
+                }
             }
             const bool to_dp = valid_out && !invalid && cls == BS_DP;
             const bool to_back = to_dp && (o1 & 1);
@@ -2023,24 +2039,25 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : CAH_SCAN_WAVES)
         // flush the tile's DP work list
         __syncthreads();
         const unsigned nf = s_nf, nb = s_nb;
+        const scan_kernarg_ptr kf = scan_kernargs();
         if (threadIdx.x == 0) {
-            s_gf = nf ? atomicAdd(a.dp_count_front, (unsigned long long)nf) : 0ull;
-            s_gb = nb ? atomicAdd(a.dp_count_back, (unsigned long long)nb) : 0ull;
+            s_gf = nf ? atomicAdd(kf->dp_count_front, (unsigned long long)nf) : 0ull;
+            s_gb = nb ? atomicAdd(kf->dp_count_back, (unsigned long long)nb) : 0ull;
         }
         __syncthreads();
         const unsigned long long gf = s_gf, gb = s_gb;
         for (unsigned e = threadIdx.x; e < nf; e += blockDim.x) {
             const int64_t slot = (int64_t)(gf + e);
-            a.dp_queue[slot] = s_list[3 * e];
-            a.dp_win[2 * slot] = s_list[3 * e + 1];
-            a.dp_win[2 * slot + 1] = s_list[3 * e + 2];
+            kf->dp_queue[slot] = s_list[3 * e];
+            kf->dp_win[2 * slot] = s_list[3 * e + 1];
+            kf->dp_win[2 * slot + 1] = s_list[3 * e + 2];
         }
         for (unsigned e = threadIdx.x; e < nb; e += blockDim.x) {
-            const int64_t slot = a.dp_cap - 1 - (int64_t)(gb + e);
+            const int64_t slot = kf->dp_cap - 1 - (int64_t)(gb + e);
             const int le = SCAN_TILE - 1 - (int)e;
-            a.dp_queue[slot] = s_list[3 * le];
-            a.dp_win[2 * slot] = s_list[3 * le + 1];
-            a.dp_win[2 * slot + 1] = s_list[3 * le + 2];
+            kf->dp_queue[slot] = s_list[3 * le];
+            kf->dp_win[2 * slot] = s_list[3 * le + 1];
+            kf->dp_win[2 * slot + 1] = s_list[3 * le + 2];
         }
     }
 }
