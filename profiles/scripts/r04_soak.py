@@ -17,8 +17,9 @@ from cutadapt_amd.batch import ReadBatch, match_batch
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 90.0
 cases2 = int(sys.argv[2]) if len(sys.argv) > 2 else 12
-rng = np.random.default_rng(40404)
-prng = random.Random(40405)
+SEED = int(os.environ.get("SOAK_SEED", "40404"))          # (round 5: other seeds per run)
+rng = np.random.default_rng(SEED)
+prng = random.Random(SEED + 1)
 t0 = time.time(); it = streamed = reads_total = 0
 while time.time() - t0 < budget:
     m = int(rng.choice([12, 16, 20, 25, 30, 32, 33, 34, 35, 40, 50, 64]))
