@@ -1,18 +1,20 @@
 // scan3.hip -- k_back_scan3: the cost scan of a 3' adapter (back_scan.h) on windows chosen from the adapter's own chunk
 // occurrences ("bs3" in back_scan.h; round 5).  Same inputs and outputs as k_back_scan<false, KIND> (kernels.hip): the
 // prefilter's survivor queue with its first-hit keys in, result rows / the cell DP's work list / the straggler list out.
+// OPT-IN (CAH_SCAN3=1): exact, but not the faster of the two -- DESIGN.md 9, profiles/r05/scan3_vs_scan_pmc.txt.
 //
 // k_back_scan walks every survivor from (first k-mer hit) - m - k - 1 to 23 columns behind its last acceptable column (or
 // the read's end): six to seven 16-column chunks per wave on the headline workload, of which a lane needs 4.6.  Here a
-// lane first walks a SHIFT-AND word over the columns behind the prefilter's position (4 instructions per column against
-// ~28): where do the adapter's k + 1 chunks occur?  No occurrence: only the read's tail can match (class T, the last
-// m + k + 1 columns).  Occurrences on one diagonal band: every candidate that can matter lies within
-// [S1 - 2 kacc - 1, S1 + 2 kacc + m] -- 47 columns, three chunks -- and the scan STOPS there when the read goes on for
-// more than gap_last columns (class F), or the window is joined with the tail (class E).  Anything else (a second copy,
-// a chance occurrence next to a real one: 0.2 % of the headline's survivors) and class-F reads whose window holds no
-// acceptable column (2 %) go to the straggler list, which the second launch scans the old, conservative way; should
-// that list be full the lane goes round again in place with the window to the read's end.  Exactness: back_scan.h
-// ("bs3"), replayed against the oracle by tests/host_model/back_model.cpp: bm_locate_batch3 (the same header under g++).
+// lane first walks a SHIFT-AND word over the columns behind the prefilter's position (8 instructions per column against
+// ~28): where do the adapter's k + 1 chunks occur, and on which diagonals (G = (G << 1) | hits: every occurrence of one
+// diagonal lands on one bit)?  No occurrence: only the read's tail can match (class T, the last m + k + 1 columns).
+// Diagonals Smin .. Smax: every candidate that can matter lies within [Smin - kacc - 1, Smax + m + kacc] -- 40 columns + the
+// spread, three chunks -- and the scan STOPS there when the read goes on for more than gap_last columns (class F), or the
+// window is joined with the tail (class E).  Far-apart copies (class C) and class-F reads whose window holds no acceptable
+// column (2 % of the headline's survivors) go to the straggler list, which the second launch scans the old, conservative
+// way; should that list be full the lane goes round again in place with the window to the read's end.  Exactness:
+// back_scan.h ("bs3"), replayed against the oracle by tests/host_model/back_model.cpp: bm_locate_batch3 (the same header
+// under g++); tests/test_gpu_scan.py::test_scan3_windows_from_chunk_occurrences.
 //
 // One read per lane, sub-batches of 64 queue entries per wave, tiles of SCAN3_TILE entries per workgroup and atomic.
 // Windows are per lane (every lane loads its own 16-character chunks), so the lanes of a wave need not walk the same
@@ -208,11 +210,9 @@ __global__ __launch_bounds__(256, CAH_SCAN3_WAVES) void k_back_scan3(ScanArgs a)
                     if (n_n >= 4 && n_n <= a.max_read_len) {
                         const int nn = (int)n_n;
                         const int t0 = min(bs3_pre_start((int)key_n << CAH_KEY_SHIFT, g, nn), nn - 4), t1 = min(t0 + 60, nn - 4);
-                        Unaligned16 dummy;
                         unsigned x0, x1;
                         __builtin_memcpy(&x0, a.seqs + o_n + t0, 4);
                         __builtin_memcpy(&x1, a.seqs + o_n + t1, 4);
-                        (void)dummy;
                         touch = x0 ^ x1;
                     }
                 }
