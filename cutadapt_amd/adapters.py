@@ -16,6 +16,7 @@ from abc import ABC, abstractmethod
 from enum import IntFlag
 from typing import List, Optional, Sequence, Tuple, Union
 
+import collections
 import numpy as np
 
 from . import _lib
@@ -534,106 +535,80 @@ def _reverse_batch(batch, complement: bool = False, select=None, data=None):
     return ReadBatch(out, new_offsets, validated=batch.validated, uniform_len=batch.uniform_len)
 
 
-class FrontAdapter(SingleAdapter):
-    """A 5' adapter (reference adapters.py:684-730)."""
+# The nine adapter types as rows of ONE table: what the aligner is anchored to (Where), which sides of the read the k-mer
+# prefilter's search sets cover, whether the read is matched reversed, how the type is written in an adapter
+# specification.  SingleAdapter builds aligner, prefilter and names from the row (_KIND); the classes below carry the
+# reference's names and hierarchy (adapters.py:684-1089: isinstance checks in AdapterIndex, LinkedAdapter, the parser and
+# the modifiers go by it) and nothing else.  `force_anywhere` (the linked adapter's non-anchored parts, :1166-1183) lets a
+# match start or end anywhere: Where.ANYWHERE, and the search sets of the other side as well -- "force" in the table.
+_Kind = collections.namedtuple("_Kind", "description identifier where reverse remove_before kmer_back kmer_front internal spec")
+_FORCE = "force"
 
-    description = "regular 5'"
-    _remove_before = True
 
-    def __init__(self, *args, **kwargs):
-        self._force_anywhere = kwargs.pop("force_anywhere", False)
-        super().__init__(*args, **kwargs)
+class _TableAdapter(SingleAdapter):
+    _KIND: _Kind = None
+    _COMPARER = None                 # anchored types without indels: a Hamming comparer instead of the aligner
+
+    def __init__(self, sequence: str, *args, **kwargs):
+        self._force_anywhere = bool(kwargs.pop("force_anywhere", False)) if self._KIND.where is not Where.ANYWHERE else False
+        if not self.allows_partial_matches:
+            kwargs["min_overlap"] = len(sequence)             # anchored: the whole adapter or nothing (:1029, :1066)
+        super().__init__(sequence, *args, **kwargs)
+
+    def __init_subclass__(cls, **kwargs):
+        super().__init_subclass__(**kwargs)
+        kind = cls._KIND
+        cls.description, cls._reverse_reads, cls._remove_before = kind.description, kind.reverse, kind.remove_before
 
     def descriptive_identifier(self) -> str:
-        return "regular_five_prime"
-
-    def _aligner(self):
-        return self._make_aligner(self.sequence, Where.ANYWHERE.value if self._force_anywhere else Where.FRONT.value)
-
-    def _kmer_finder(self):
-        return self._make_kmer_finder(self.sequence, back_adapter=self._force_anywhere, front_adapter=True)
+        return self._KIND.identifier
 
     def spec(self) -> str:
-        return f"{self.sequence}..."
+        return self._KIND.spec.format(self.sequence)
+
+    def _side(self, flag) -> bool:
+        return self._force_anywhere if flag == _FORCE else bool(flag)
+
+    def _aligner(self):
+        kind = self._KIND
+        if self._COMPARER is not None and not self.indels:
+            return self._COMPARER(self.sequence, self.max_error_rate, wildcard_ref=self.adapter_wildcards,
+                                  wildcard_query=self.read_wildcards, min_overlap=self.min_overlap)
+        where = Where.ANYWHERE if self._force_anywhere else kind.where
+        return self._make_aligner(self.sequence[::-1] if kind.reverse else self.sequence, where.value)
+
+    def _kmer_finder(self):
+        kind = self._KIND
+        if self._COMPARER is not None and isinstance(self.aligner, self._COMPARER):
+            return MockKmerFinder()                           # no DP to save (reference :1043-1049, :1080-1086)
+        return self._make_kmer_finder(self.sequence[::-1] if kind.reverse else self.sequence,
+                                      back_adapter=self._side(kind.kmer_back), front_adapter=self._side(kind.kmer_front),
+                                      internal=kind.internal)
+
+
+class FrontAdapter(_TableAdapter):
+    """A 5' adapter (reference adapters.py:684-730)."""
+    _KIND = _Kind("regular 5'", "regular_five_prime", Where.FRONT, False, True, _FORCE, True, True, "{}...")
 
 
 class RightmostFrontAdapter(FrontAdapter):
-    """A 5' adapter that prefers rightmost matches (reference :733-789)."""
-
-    description = "rightmost 5'"
-    _reverse_reads = True
-
-    def descriptive_identifier(self) -> str:
-        return "rightmost_five_prime"
-
-    def _aligner(self):
-        return self._make_aligner(self.sequence[::-1],
-                                  Where.ANYWHERE.value if self._force_anywhere else Where.BACK.value)
-
-    def _kmer_finder(self):
-        return self._make_kmer_finder(self.sequence[::-1], back_adapter=True, front_adapter=self._force_anywhere)
-
-    def spec(self) -> str:
-        return f"{self.sequence}...;rightmost"
+    """A 5' adapter that prefers rightmost matches: the reversed adapter on the reversed read (reference :733-789)."""
+    _KIND = _Kind("rightmost 5'", "rightmost_five_prime", Where.BACK, True, True, True, _FORCE, True, "{}...;rightmost")
 
 
-class BackAdapter(SingleAdapter):
+class BackAdapter(_TableAdapter):
     """A 3' adapter (reference adapters.py:792-838)."""
-
-    description = "regular 3'"
-    _remove_before = False
-
-    def __init__(self, *args, **kwargs):
-        self._force_anywhere = kwargs.pop("force_anywhere", False)
-        super().__init__(*args, **kwargs)
-
-    def descriptive_identifier(self) -> str:
-        return "regular_three_prime"
-
-    def _aligner(self):
-        return self._make_aligner(self.sequence, Where.ANYWHERE.value if self._force_anywhere else Where.BACK.value)
-
-    def _kmer_finder(self):
-        return self._make_kmer_finder(self.sequence, back_adapter=True, front_adapter=self._force_anywhere)
-
-    def spec(self) -> str:
-        return f"{self.sequence}"
+    _KIND = _Kind("regular 3'", "regular_three_prime", Where.BACK, False, False, True, _FORCE, True, "{}")
 
 
 class RightmostBackAdapter(BackAdapter):
     """A 3' adapter that prefers rightmost matches (reference :841-893)."""
-
-    description = "rightmost 3'"
-    _reverse_reads = True
-
-    def descriptive_identifier(self) -> str:
-        return "rightmost_three_prime"
-
-    def _aligner(self):
-        return self._make_aligner(self.sequence[::-1],
-                                  Where.ANYWHERE.value if self._force_anywhere else Where.FRONT.value)
-
-    def _kmer_finder(self):
-        return self._make_kmer_finder(self.sequence[::-1], back_adapter=self._force_anywhere, front_adapter=True)
-
-    def spec(self) -> str:
-        return f"{self.sequence};rightmost"
+    _KIND = _Kind("rightmost 3'", "rightmost_three_prime", Where.FRONT, True, False, _FORCE, True, True, "{};rightmost")
 
 
-class AnywhereAdapter(SingleAdapter):
-    """5' or 3': a match that starts at read position 0 is treated as a 5' adapter
-    (reference adapters.py:896-941)."""
-
-    description = "variable 5'/3'"
-
-    def descriptive_identifier(self) -> str:
-        return "anywhere"
-
-    def _aligner(self):
-        return self._make_aligner(self.sequence, Where.ANYWHERE.value)
-
-    def _kmer_finder(self):
-        return self._make_kmer_finder(self.sequence, back_adapter=True, front_adapter=True)
+class AnywhereAdapter(_TableAdapter):
+    """5' or 3': a match that starts at read position 0 is treated as a 5' adapter (reference adapters.py:896-941)."""
+    _KIND = _Kind("variable 5'/3'", "anywhere", Where.ANYWHERE, False, False, True, True, True, "...{}...")
 
     def _wrap(self, alignment, sequence: str):
         # the reference upper-cases the read before locate (:925); every table used by the
@@ -644,102 +619,29 @@ class AnywhereAdapter(SingleAdapter):
     def _remove_before_array(self, coords, found) -> np.ndarray:
         return found & (coords[:, 2] == 0)
 
-    def spec(self) -> str:
-        return f"...{self.sequence}..."
-
 
 class NonInternalFrontAdapter(FrontAdapter):
     """A non-internal 5' adapter (reference adapters.py:944-978)."""
-
-    description = "non-internal 5'"
-
-    def descriptive_identifier(self) -> str:
-        return "noninternal_five_prime"
-
-    def _aligner(self):
-        return self._make_aligner(self.sequence, Where.FRONT_NOT_INTERNAL.value)
-
-    def _kmer_finder(self):
-        return self._make_kmer_finder(self.sequence, front_adapter=True, back_adapter=self._force_anywhere,
-                                      internal=False)
-
-    def spec(self) -> str:
-        return f"X{self.sequence}..."
+    _KIND = _Kind("non-internal 5'", "noninternal_five_prime", Where.FRONT_NOT_INTERNAL, False, True, _FORCE, True, False, "X{}...")
 
 
 class NonInternalBackAdapter(BackAdapter):
     """A non-internal 3' adapter (reference adapters.py:981-1015)."""
-
-    description = "non-internal 3'"
-
-    def descriptive_identifier(self) -> str:
-        return "noninternal_three_prime"
-
-    def _aligner(self):
-        return self._make_aligner(self.sequence, Where.BACK_NOT_INTERNAL.value)
-
-    def _kmer_finder(self):
-        return self._make_kmer_finder(self.sequence, back_adapter=True, front_adapter=self._force_anywhere,
-                                      internal=False)
-
-    def spec(self) -> str:
-        return f"{self.sequence}X"
+    _KIND = _Kind("non-internal 3'", "noninternal_three_prime", Where.BACK_NOT_INTERNAL, False, False, True, _FORCE, False, "{}X")
 
 
 class PrefixAdapter(NonInternalFrontAdapter):
     """An anchored 5' adapter (reference adapters.py:1018-1052)."""
-
-    description = "anchored 5'"
+    _KIND = _Kind("anchored 5'", "anchored_five_prime", Where.PREFIX, False, True, _FORCE, True, False, "^{}...")
+    _COMPARER = PrefixComparer
     allows_partial_matches = False
-
-    def __init__(self, sequence: str, *args, **kwargs):
-        kwargs["min_overlap"] = len(sequence)
-        super().__init__(sequence, *args, **kwargs)
-
-    def descriptive_identifier(self) -> str:
-        return "anchored_five_prime"
-
-    def _aligner(self):
-        if not self.indels:
-            return PrefixComparer(self.sequence, self.max_error_rate, wildcard_ref=self.adapter_wildcards,
-                                  wildcard_query=self.read_wildcards, min_overlap=self.min_overlap)
-        return self._make_aligner(self.sequence, Where.PREFIX.value)
-
-    def _kmer_finder(self):
-        if isinstance(self.aligner, PrefixComparer):
-            return MockKmerFinder()      # no DP to save (reference :1043-1049)
-        return super()._kmer_finder()
-
-    def spec(self) -> str:
-        return f"^{self.sequence}..."
 
 
 class SuffixAdapter(NonInternalBackAdapter):
     """An anchored 3' adapter (reference adapters.py:1055-1089)."""
-
-    description = "anchored 3'"
+    _KIND = _Kind("anchored 3'", "anchored_three_prime", Where.SUFFIX, False, False, True, _FORCE, False, "{}$")
+    _COMPARER = SuffixComparer
     allows_partial_matches = False
-
-    def __init__(self, sequence: str, *args, **kwargs):
-        kwargs["min_overlap"] = len(sequence)
-        super().__init__(sequence, *args, **kwargs)
-
-    def descriptive_identifier(self) -> str:
-        return "anchored_three_prime"
-
-    def _aligner(self):
-        if not self.indels:
-            return SuffixComparer(self.sequence, self.max_error_rate, wildcard_ref=self.adapter_wildcards,
-                                  wildcard_query=self.read_wildcards, min_overlap=self.min_overlap)
-        return self._make_aligner(self.sequence, Where.SUFFIX.value)
-
-    def _kmer_finder(self):
-        if isinstance(self.aligner, SuffixComparer):
-            return MockKmerFinder()
-        return super()._kmer_finder()
-
-    def spec(self) -> str:
-        return f"{self.sequence}$"
 
 
 # -------------------------------------------------------------------------------------------------
