@@ -50,8 +50,10 @@ def parse_args(argv=None):
                          "the headline number uses the default 0.25)")
     ap.add_argument("--ragged", action="store_true",
                     help="cut the reads to 30 .. read_len characters at their 3' end (a hash of the read index): the batch a "
-                         "pipeline holds behind -q / -u -- offsets array, per-lane kernels instead of the streaming ones "
-                         "(C2, C4, C5)")
+                         "pipeline holds behind -q / -u -- views (starts + lengths) into the sequencer's batch at its uniform "
+                         "stride; a single adapter's prefilter streams them end-aligned (C2, C4, C5)")
+    ap.add_argument("--ragged-packed", action="store_true",
+                    help="the same reads copied into a packed buffer with an offsets array: the per-lane kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--check-reads", type=int, default=200_000, help="reads compared with the oracle (untimed)")
@@ -128,7 +130,8 @@ class Workload:
         if ragged:
             if kind == "linked":
                 raise SystemExit("bench.py: --ragged serves C2, C4 and C5")
-            self.batches = [workloads.ragged_device_batch(b, first) for b in self.batches]
+            cut = workloads.ragged_device_batch if ragged == "packed" else workloads.ragged_view_batch
+            self.batches = [cut(b, first) for b in self.batches]
             torch.cuda.empty_cache()
         for b in self.batches:
             b.workspace()
@@ -180,9 +183,12 @@ class Workload:
         ok = True
         for mate, batch in enumerate(self.batches):
             seqs, offsets = host_workloads.host_reads(self.config, 0, m, mate, gen)
+            if self.ragged == "views":
+                ok &= np.array_equal(batch.seqs[: len(seqs)].cpu().numpy(), seqs)   # generator twin (the parent batch)
             if self.ragged:
                 seqs, offsets = host_workloads.host_ragged(seqs, offsets, 0)
-            ok &= np.array_equal(batch.seqs[: len(seqs)].cpu().numpy(), seqs)       # generator twin
+            if self.ragged != "views":
+                ok &= np.array_equal(batch.seqs[: len(seqs)].cpu().numpy(), seqs)   # generator twin
             if kind in ("single", "multi", "paired"):
                 ads = self.adapters if mate == 0 else self.adapters2
                 want6, want_st, want_best = oracle_multi(ads, seqs, offsets)
@@ -362,7 +368,9 @@ def run_config(args, config, n, steps, warmup, rank, world, device, gen, check_r
             "workload": f"{config}: {n} x {'2 x ' if spec['kind'] == 'paired' else ''}{workloads.READ_LEN} bp synthetic "
                         f"{'read pairs' if spec['kind'] == 'paired' else 'reads'} per GPU, {spec['what']}, "
                         f"p_adapter={gen['p_adapter']}, p_edit={gen['p_edit']}, p_N={gen['p_n']}"
-                        + (f", RAGGED: every read cut to {workloads.RAGGED_MIN} .. {workloads.READ_LEN} characters at its 3' end" if ragged else ""),
+                        + (f", RAGGED: every read cut to {workloads.RAGGED_MIN} .. {workloads.READ_LEN} characters at its 3' end "
+                           + ("(copied into a packed buffer + offsets array)" if ragged == "packed" else
+                              "(views -- starts + lengths -- into the batch at its uniform stride)") if ragged else ""),
             "units_per_gpu": n,
             "read_len": workloads.READ_LEN,
             "n_adapters": len(spec["adapters"]) + len(spec.get("adapters2", [])),
@@ -452,13 +460,14 @@ def main():
     if args.p_adapter is not None:
         gen["p_adapter"] = float(args.p_adapter)
     n = args.reads if args.reads is not None else DEFAULT_READS[args.config]
+    ragged_mode = "packed" if args.ragged_packed else ("views" if args.ragged else False)
     result = run_config(args, args.config, n, args.steps, args.warmup, rank, world, device, gen, args.check_reads,
-                        args.cpu_seconds, not args.no_cpu_baseline and not args.ragged, args.ragged)
+                        args.cpu_seconds, not args.no_cpu_baseline and not ragged_mode, ragged_mode)
     if rank == 0:
         # The default invocation (the driver's: C2, one GPU) also carries the other BASELINE configs at their BASELINE
         # sizes -- a few steps each, with their own parity sample, roofline fraction and a short CPU baseline
         if (args.config == "C2" and world == 1 and args.reads is None and args.p_adapter is None
-                and args.read_len is None and not args.no_other_configs and not args.ragged):
+                and args.read_len is None and not args.no_other_configs and not ragged_mode):
             others = {}
             for cfg in ("C3", "C4", "C5"):
                 try:
@@ -500,13 +509,14 @@ def main():
                 except Exception as exc:
                     extremes[f"p_adapter_{pa:g}"] = {"error": repr(exc)[:300]}
             result["p_adapter_extremes"] = extremes
-            # ragged batches (what a pipeline holds behind -q / -u): the same reads cut to 30 .. 150 characters; they take
-            # the per-lane kernels (offsets array) instead of the streaming ones
+            # ragged batches (what a pipeline holds behind -q / -u): the same reads cut to 30 .. 150 characters, as views
+            # into the uniform batch (a single adapter's prefilter streams them end-aligned: k_filter_stream2's RV form;
+            # several adapters take the per-lane kernels)
             ragged = {}
             for cfg in ("C2", "C4"):
                 try:
                     r = run_config(args, cfg, DEFAULT_READS[cfg], 2, 1, 0, 1, device, gen, min(args.check_reads, 200_000),
-                                   0.0, False, True)
+                                   0.0, False, "views")
                     ragged[cfg] = {"value": r["value"], "unit": r["unit"], "steps": r["steps"], "ms_per_step": r["ms_per_step"],
                                    "workload": r["config"]["workload"], "parity_check": r["config"]["parity_check"],
                                    "matched_fraction": r["config"]["matched_fraction"],

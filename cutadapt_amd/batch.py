@@ -177,6 +177,10 @@ class ReadBatch:
         v = ReadBatch(self.seqs, base + starts.to(torch.int64), lens.to(torch.int32),
                       n_reads=self.n_reads, validated=self.validated)
         v._workspace = self._workspace       # same reads, same stream order: the scratch can be shared
+        if self.uniform_len and self.lens is None:
+            # views inside the reads of a sequencer's batch (0 <= starts, starts + lens <= read length): the library
+            # streams the parent's reads instead of fetching ragged views (cah_match_batch_views)
+            v.within_uniform = int(self.uniform_len)
         return v
 
     def lengths(self):
@@ -277,6 +281,13 @@ def match_batch(plan: "_lib.Plan", batch: ReadBatch, out: Optional[BatchResult] 
                 _lib.check(_lib.lib().cah_match_batch_suffix_views(
                     plan.handle, batch.seqs.data_ptr(), batch.offsets.data_ptr(), batch.lens.data_ptr(),
                     int(batch.suffix_of_uniform), n, out.out6.data_ptr(), best_ptr, out.status.data_ptr(), ws.data_ptr(),
+                    ws.numel(), _stream_ptr()))
+            elif (getattr(batch, "within_uniform", None) and batch.lens is not None and not os.environ.get("CAH_NO_UNIFORM")
+                  and hasattr(_lib.lib(), "cah_match_batch_views")):
+                # views anywhere inside the reads of a uniform batch (reads cut by a modifier in front of the adapter search)
+                _lib.check(_lib.lib().cah_match_batch_views(
+                    plan.handle, batch.seqs.data_ptr(), batch.offsets.data_ptr(), batch.lens.data_ptr(),
+                    int(batch.within_uniform), n, out.out6.data_ptr(), best_ptr, out.status.data_ptr(), ws.data_ptr(),
                     ws.numel(), _stream_ptr()))
             else:
                 _lib.check(_lib.lib().cah_match_batch(

@@ -1211,7 +1211,8 @@ static bool env_flag(const char* name) { const char* e = getenv(name); return e 
 // suffix: (first, len) describe a PARENT batch of equally long reads and d_offsets / d_lens views that end where
 // its reads end (cah_match_batch_suffix_views): only the streaming prefilter makes use of that, every other kernel
 // sees plain views.
-struct UniformLayout { int64_t first = 0; int32_t len = 0; bool suffix = false; };
+// inner (with suffix): the views may end before the parent's reads do (cah_match_batch_views)
+struct UniformLayout { int64_t first = 0; int32_t len = 0; bool suffix = false; bool inner = false; };
 // cah_linked_match_batch_uniform, fused form: the streaming prefilter of the back adapter decides the views itself
 // (kernels.h: FilterArgs::front) and writes the front stage's outputs and the views
 struct FrontFuse {
@@ -1383,7 +1384,7 @@ static int run_filter(const cah_plan* plan, const PlanDeviceCopy* pd, int32_t ad
     if (ul.suffix) {
         // views into a uniform parent: k_filter_stream2's SV form if the plan and the length are its, else plain views
         const bool s2 = stream2_suffix_ok(plan, adapter, ul.len, n_reads);
-        f.suffix_views = s2 ? 1 : 0;
+        f.suffix_views = s2 ? (ul.inner ? 2 : 1) : 0;
         if (!s2) { f.uniform_first = 0; f.uniform_len = 0; }
         if (fuse) {
             if (!s2) return fail(CAH_EINVAL, "internal: fused linked path on a plan the streaming prefilter does not take");
@@ -1744,6 +1745,24 @@ int cah_match_batch_suffix_views(const cah_plan* plan, const uint8_t* d_seqs, co
     if (n_reads > 0 && (!d_starts || !d_lens)) return fail(CAH_EINVAL, "starts / lens are NULL");
     UniformLayout ul;
     ul.first = 0; ul.len = parent_read_len; ul.suffix = true;
+    return match_batch_impl(plan, d_seqs, d_starts, d_lens, ul, n_reads, d_out6, d_best_adapter, d_status, d_workspace,
+                            workspace_bytes, stream);
+}
+
+// Views ANYWHERE inside the reads of a uniform batch: view r = d_seqs[d_starts[r], d_starts[r] + d_lens[r]) with
+// r * parent_read_len <= d_starts[r] and d_starts[r] + d_lens[r] <= (r + 1) * parent_read_len -- what a pipeline holds
+// once a modifier in front of the adapter search has cut the reads of a sequencer's batch (quality trimming, -u, --length:
+// reference modifiers.py QualityTrimmer / UnconditionalCutter / Shortener run before AdapterCutter).  Results relative
+// to the views, as cah_match_batch(d_seqs, d_starts, d_lens, ...) returns them; the prefilter streams the parent's
+// reads end-aligned (k_filter_stream2, RV form) instead of fetching ragged views lane by lane.
+int cah_match_batch_views(const cah_plan* plan, const uint8_t* d_seqs, const int64_t* d_starts, const int32_t* d_lens,
+                          int32_t parent_read_len, int64_t n_reads, int32_t* d_out6, int32_t* d_best_adapter,
+                          uint8_t* d_status, void* d_workspace, size_t workspace_bytes, void* stream) {
+    if (parent_read_len < 1 || parent_read_len > CAH_MAX_READ_LEN)
+        return fail(CAH_EINVAL, "parent_read_len out of range (1..%d)", CAH_MAX_READ_LEN);
+    if (n_reads > 0 && (!d_starts || !d_lens)) return fail(CAH_EINVAL, "starts / lens are NULL");
+    UniformLayout ul;
+    ul.first = 0; ul.len = parent_read_len; ul.suffix = true; ul.inner = true;
     return match_batch_impl(plan, d_seqs, d_starts, d_lens, ul, n_reads, d_out6, d_best_adapter, d_status, d_workspace,
                             workspace_bytes, stream);
 }

@@ -32,7 +32,8 @@ struct FilterArgs {
     int64_t uniform_first = 0;
     int32_t uniform_len = 0;
     // k_filter_stream2 only: offsets[r] is where the view of read r starts inside the uniform PARENT batch described by
-    // (uniform_first, uniform_len); the view ends where that read ends (second stage of a linked adapter)
+    // (uniform_first, uniform_len); 1: the view ends where that read ends (second stage of a linked adapter); 2: it is
+    // lens[r] characters long and ends anywhere inside the read (reads cut at their 3' end: the RV form)
     int32_t suffix_views = 0;
     // ... and, when `front` is set, the view starts are decided by the kernel itself: the anchored 5' adapter of a linked
     // adapter (no error tolerated, m <= 32) is compared with the read's head; the kernel writes the front stage's rows

@@ -37,6 +37,7 @@
 #define S2_MAX_LEN (2 * S2_HALF * 16)
 #define S2_SEG (2 * S2_HALF)       // units of a segment: what the slot takes in two fills
 #define S2_LONG_MAX_LEN 640        // LONG form: reads of up to four segments
+#define S2_RV_BACK 1184            // RV form: the copy resource starts this far in front of a piece (>= S2_MAX_LEN + 63 * 15 + 1)
 
 __host__ __device__ constexpr int s2_pow2(int n) { return n <= 1 ? 1 : (n <= 2 ? 2 : 4); }
 __host__ __device__ constexpr int s2_log2(int p) { return p == 1 ? 0 : (p == 2 ? 1 : 2); }
@@ -316,13 +317,21 @@ __device__ __forceinline__ S2Out s2_out_args() {
 // adapter that tolerates no error (k_anchored_exact's case: "^NNNNNNNNACGTACGT") is compared with the read's head while
 // the head sits in the slot anyway; the kernel writes the front stage's result rows and the views (starts, lengths)
 // for the kernels behind it.  One pass over the batch instead of three (front comparison, view arithmetic, prefilter).
+// RV (with SV): the views may also END before their reads do -- view r = [offsets[r], offsets[r] + lens[r]) anywhere inside
+// read r of the parent batch (reads cut at their 3' end by quality trimming, `-u -N`, `--length`: ragged lengths at a
+// uniform stride).  The tail search sets count from the view's end (reference _kmer_finder.pyx:186-204: negative starts
+// are relative to the sequence's length), so the views are streamed END-ALIGNED: the copy plan fetches unit u of read r
+// from d[r] = (read end - view end) bytes further down, the words see a read of n characters whose last character is the
+// view's last and whose first n - lens[r] characters are NUL.  Nothing else changes: the T-words open in the same chunks
+// for every lane, the found masks stay wave-uniform.
 // LONG: reads of 161 .. S2_LONG_MAX_LEN characters (2 x 250 / 2 x 300 bp runs).  A read is walked in SEGMENTS of ten units
 // (160 characters): each segment is what the short form does with a whole read -- two fills of the wave's slot -- and
 // the words simply go on from segment to segment (KmerFinder.kmers_present takes reads of any length, reference
 // _kmer_finder.pyx:170-213).  A segment's copy registers are loaded while the second half of the segment before is matched.
-template <int NL, int NT, bool BUF, bool SV = false, bool FR = false, bool LONG = false>
+template <int NL, int NT, bool BUF, bool SV = false, bool FR = false, bool LONG = false, bool RV = false>
 __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a) {
     typedef S2Layout<NL, NT> LY;
+    static_assert(!RV || (SV && !FR && !LONG && BUF), "k_filter_stream2: RV is a form of SV");
     constexpr int TILE = S2_TILE, SUBS = TILE / WAVE / S2_WAVES;
     // ONE static object, the tables first: they sit below 64 KB and an entry is read with
     // "ds_read_b64 v, v_entry offset:TABLE" -- the entry offset is the whole address computation of a character.
@@ -345,6 +354,8 @@ __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a
         } stage[2];
         unsigned next_piece;                                            // the block's pieces are dealt to its waves on demand
         uint32_t front[FR ? CAH_TABLE_CHARS : 1];                       // FR: bit i = character matches front adapter position i
+        uint32_t views[RV ? S2_WAVES * WAVE : 1];                       // RV: d | skip << 16 of the wave's NEXT piece
+        uint32_t lowmask[RV ? 16 * 4 : 1];                              // RV: entry c (16 bytes): the first c bytes 0x00, the rest 0xFF
     };
     static_assert(sizeof(S2Lds) <= 160 * 1024, "k_filter_stream2: LDS");
     __shared__ S2Lds s_lds;
@@ -394,6 +405,12 @@ __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a
         if (threadIdx.x == 0) { s_lds.stage[b].count = 0; s_lds.stage[b].arrived = 0; s_lds.stage[b].done = 0; }
     }
     if (threadIdx.x == 0) s_lds.next_piece = S2_WAVES;                 // pieces 0 .. 15 are the waves' first ones
+    if constexpr (RV) {
+        if (threadIdx.x < 64) {
+            const int drop = (int)(threadIdx.x >> 2) - 4 * (int)(threadIdx.x & 3);   // bytes of dword (x & 3) that entry x >> 2 clears
+            s_lds.lowmask[threadIdx.x] = drop <= 0 ? 0xFFFFFFFFu : (drop >= 4 ? 0u : (0xFFFFFFFFu << (8 * drop)));
+        }
+    }
     __syncthreads();                                                    // the kernel's only barrier
     S2Words<NL, NT> K;
 #pragma unroll
@@ -467,18 +484,56 @@ __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a
     const uint8_t* const batch0 = a.seqs + first;
     // the units of the piece starting at read `base`, into VGPRs.  Nothing outside the batch is touched: a unit
     // that would run past the batch's last byte is fetched as the 16 bytes that END there and shifted down.
-    auto prefetch = [&](int64_t base) {
+    // RV: vw = d | skip << 16 of read base + lane (0 in lanes behind the batch's end); a unit of read r starts d[r] bytes
+    // earlier -- fetched from lane r by ds_bpermute -- and a unit that lies in front of its read's view altogether is not
+    // fetched at all: its offset is put out of the resource's range, the load returns zeros (NUL: what the words must see
+    // there).  The resource's base sits S2_RV_BACK bytes in front of the piece (d <= n, and for n < 16 the copy plan's
+    // stride n - 16 H is negative): the batch's first pieces go lane by lane.
+    auto prefetch = [&](int64_t base, const uint32_t vw = 0) {
         const int64_t left = n_reads - base;                            // wave-uniform
         if (left <= 0 || noload) return;
         const int64_t pbyte = base * (int64_t)n + seg_off;              // the first byte of the piece's segment within the batch
         const uint8_t* const src = batch0 + pbyte;
-        if (left >= WAVE && pbyte + (int64_t)WAVE * n + 16 <= total) {
+        if (left >= WAVE && pbyte + (int64_t)WAVE * n + 16 <= total && (!RV || pbyte >= S2_RV_BACK)) {
             // a whole piece with 16 bytes of the batch behind it (all but the last pieces): no lane needs a check
             if constexpr (BUF) {
                 // buffer loads: the piece's first byte is the (scalar) base of the resource, a lane's offset ONE register
                 // (said explicitly to be wave-uniform: otherwise every load is wrapped in a waterfall loop over the
                 // values of the four resource words)
-                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(s2_uniform_ptr(src), 0, 0x7FFFFFFF, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(s2_uniform_ptr(RV ? src - S2_RV_BACK : src), 0, 0x7FFFFFFF, 0x00020000);
+                if constexpr (RV) {
+                    // What a unit needs of its read r is computed ONCE per read, in lane r, for either half's shape (H units
+                    // per read) and handed over in one lane exchange per unit:
+                    //   low half  A = r (n - 16 H) + S2_RV_BACK - d[r]: unit 64 k + lane starts at byte A + 16 lane + 1024 k
+                    //             of the resource (the copy plan's offset, moved d[r] down);
+                    //   high half T = skip[r] + 16 r H: the unit lies in front of the view iff its last character,
+                    //             16 (64 k + lane) + 15 [+ 16 H1] in these terms, is < T.
+                    const int d = (int)(vw & 0xFFFFu), sk = (int)(vw >> 16);
+                    const unsigned w1 = (unsigned)(__mul24(lane, n - 16 * H1) + S2_RV_BACK - d) | ((unsigned)(sk + 16 * __mul24(lane, H1)) << 16);
+                    const unsigned w2 = (unsigned)(__mul24(lane, n - 16 * H2) + S2_RV_BACK - d) | ((unsigned)(sk + 16 * __mul24(lane, H2)) << 16);
+                    int got[2 * S2_HALF];
+#pragma unroll
+                    for (int k = 0; k < S2_HALF; ++k) {                // (units a half does not have: fetched, not used)
+                        got[k] = __builtin_amdgcn_ds_bpermute(unit_r(k, magic1) << 2, (int)w1);
+                        got[S2_HALF + k] = __builtin_amdgcn_ds_bpermute(unit_r(k, magic2) << 2, (int)w2);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k = 0; k < S2_HALF; ++k)
+                        if (k < H1) {
+                            const int w = got[k];
+                            const unsigned off = (int)lane16 + (16 * k * WAVE + 15) < (w >> 16) ? 0x80000000u : (unsigned)((w & 0xFFFF) + (int)lane16);
+                            pre[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, off + k * (WAVE * 16), 0, 0);
+                        }
+#pragma unroll
+                    for (int k = 0; k < S2_HALF; ++k)
+                        if (k < H2) {
+                            const int w = got[S2_HALF + k];
+                            const unsigned off = (int)lane16 + (16 * k * WAVE + 15) + 16 * H1 < (w >> 16) ? 0x80000000u : (unsigned)((w & 0xFFFF) + (int)lane16);
+                            pre[S2_HALF + k] = __builtin_amdgcn_raw_buffer_load_b128(rs, off + k * (WAVE * 16), 16 * H1, 0);
+                        }
+                    return;
+                }
 #pragma unroll
                 for (int k = 0; k < S2_HALF; ++k)
                     if (k < H1)
@@ -516,6 +571,28 @@ __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a
             const int k = q < S2_HALF ? q : q - S2_HALF;
             const int H = q < S2_HALF ? H1 : H2;
             s2_u32x4 got = (s2_u32x4)(0u);
+            if constexpr (RV) {
+                // byte by byte: a shifted unit may begin in front of the batch or end behind it
+                if (k < H) {                                            // (wave-uniform: every lane takes part in the bpermute)
+                    const int r = unit_r(k, q < S2_HALF ? magic1 : magic2);          // < 64 for k < H
+                    const int w = __builtin_amdgcn_ds_bpermute(r << 2, (int)vw);
+                    const int sh = w & 0xFFFF;
+                    const int last = 16 * (k * WAVE + lane - __mul24(r, H)) + (q < S2_HALF ? 15 : 16 * H1 + 15);
+                    if (k * WAVE + lane < reads * H && last >= (w >> 16)) {  // (a unit in front of the view: zeros)
+                        const int64_t g0 = pbyte + (int64_t)(__mul24(r, n - 16 * H) + (k * WAVE) * 16 + (int)lane16 +
+                                                             (q < S2_HALF ? 0 : 16 * H1)) - sh;
+                        unsigned x[4] = {0u, 0u, 0u, 0u};
+#pragma unroll 1
+                        for (int b = 0; b < 16; ++b) {
+                            const int64_t at = g0 + b;
+                            if (at >= 0 && at < total) x[b >> 2] |= (unsigned)batch0[at] << (8 * (b & 3));
+                        }
+                        got = (s2_u32x4){x[0], x[1], x[2], x[3]};
+                    }
+                }
+                pre[q] = got;
+                continue;
+            }
             if (k < H && k * WAVE + lane < reads * H) {
                 const int r = unit_r(k, q < S2_HALF ? magic1 : magic2);
                 const unsigned goff = (unsigned)(__mul24(r, n - 16 * H) + (k * WAVE) * 16 + (int)lane16 +
@@ -561,7 +638,7 @@ __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a
     int skip = 0;                                                       // SV: this lane's read starts `skip` characters in
     // the chunk at `pos`: characters past the read's end (the next read's, or stale) become NUL
     auto finish = [&](s2_u32x4 v, int pos) -> s2_u32x4 {
-        if constexpr (SV) {
+        if constexpr (SV && !RV) {                                      // (RV: the slot's rows are cleared in front of the views)
             if (s2_any(skip > pos)) {                                   // (wave-uniform: rare beyond the first chunk or two)
                 unsigned x[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -584,9 +661,28 @@ __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a
         return v;
     };
 
+    // RV: the view of read base + lane inside its read as d | skip << 16 -- d: characters between the view's end and the
+    // read's, skip = n - length: where the view starts in the end-aligned read (the wave's first piece; the others: below)
+    int skip_next = 0;
+    auto view_of = [&](const int64_t base) -> uint32_t {
+        const int64_t r = base + lane;
+        if (r >= n_reads) return 0u;
+        const s2_kernarg_ptr kp = (s2_kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+        int st = (int)(kp->offsets[r] - (first + r * (int64_t)n));
+        st = st < 0 ? 0 : (st > n ? n : st);
+        int ln = kp->lens[r];
+        ln = ln < 0 ? 0 : (ln > n - st ? n - st : ln);
+        return (uint32_t)(n - (st + ln)) | ((uint32_t)(n - ln) << 16);
+    };
     unsigned p = (unsigned)wave;                                        // this wave's piece
     int it = 0;                                                         // (pieces this wave has matched: the trace build's index)
-    prefetch(piece_base(p));
+    if constexpr (RV) {
+        const uint32_t vw = view_of(piece_base(p));
+        skip_next = (int)(vw >> 16);
+        prefetch(piece_base(p), vw);
+    } else {
+        prefetch(piece_base(p));
+    }
 #pragma unroll 1
     for (;; ++it) {
         const unsigned kt = p / PPT;
@@ -600,7 +696,9 @@ __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a
             S2Hits hits;                                                // lanes still looking for a first k-mer
             hits.live = more && (unsigned)(base + lane) < (unsigned)n_reads;
             hits.group = -1;
-            if constexpr (SV && !FR) {
+            if constexpr (RV) {
+                skip = skip_next;                                       // (fetched with the piece's loads)
+            } else if constexpr (SV && !FR) {
                 skip = 0;
                 if (hits.live) {
                     const s2_kernarg_ptr kp = (s2_kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
@@ -610,6 +708,9 @@ __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a
                 }
             }
             unsigned seen = 0;
+            unsigned p_early = 0;                                       // RV: the piece taken for the next round
+            int64_t view_at = 0;
+            int view_len = 0;
             uint32_t RL[NL > 0 ? NL : 1], RT[NT > 0 ? NT : 1];
 #pragma unroll
             for (int w = 0; w < (NL > 0 ? NL : 1); ++w) RL[w] = 0;
@@ -625,9 +726,52 @@ __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a
             for (int ph = 0; ph < 2; ++ph) {
                 const int H = ph ? H2 : H1;
                 const bool alive = H > 0 && s2_any(hits.live) && !nomatch;   // wave-uniform
+                if constexpr (RV) {
+                    // The views of the wave's NEXT piece (its loads depend on them: a unit's address is shifted by its read's
+                    // d): requested once the first half's copy registers are in the slot, parked in LDS when the first half
+                    // is matched -- nobody waits for them, and no register holds them through the T-words' chunks.
+                    if (ph == 1) {
+                        int st = (int)(view_at - (first + (piece_base(p_early) + lane) * (int64_t)n));
+                        st = st < 0 ? 0 : (st > n ? n : st);
+                        int ln = view_len;
+                        ln = ln < 0 ? 0 : (ln > n - st ? n - st : ln);
+                        s_lds.views[wave * WAVE + lane] = (uint32_t)(n - (st + ln)) | ((uint32_t)(n - ln) << 16);
+                    }
+                }
                 if (alive) {
                     if (ph == 0) to_slot(std::integral_constant<int, 0>{}); else to_slot(std::integral_constant<int, 1>{});
+                    if constexpr (RV) {
+                        // the characters in front of the view in the unit it starts in, made NUL in the lane's own row ONCE
+                        // per fill (in the chunks' registers it would be a byte mask per chunk: nearly every chunk holds
+                        // some lane's start; the units in front of that one arrived as zeros)
+                        const int lead = skip - (ph ? 16 * H1 : 0);     // this half's characters in front of the view
+                        if (s2_any(lead > 0)) {
+                            unsigned char* const wrow = slot + lane * S2_ROW;
+                            const int whole = lead >> 4;
+                            const int rem = lead & 15;
+                            if (lead > 0 && whole < H && rem) {
+                                const s2_u32x4 v = *reinterpret_cast<const s2_u32x4*>(wrow + 16 * whole);
+                                const s2_u32x4 m = *reinterpret_cast<const s2_u32x4*>(
+                                    reinterpret_cast<const unsigned char*>(s_lds.lowmask) + 16 * rem);
+                                *reinterpret_cast<s2_u32x4*>(wrow + 16 * whole) = v & m;
+                            }
+                        }
+                    }
                     cur = *reinterpret_cast<const s2_u32x4*>(row);
+                }
+                if constexpr (RV) {
+                    if (ph == 0) {
+                        p_early = take_piece();
+                        const int64_t r = piece_base(p_early) + lane;
+                        view_at = first + r * (int64_t)n; view_len = n;  // (lanes behind the batch's end: d = skip = 0)
+                        if (r < n_reads) {
+                            const s2_kernarg_ptr kp = (s2_kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+                            view_at = kp->offsets[r];
+                            view_len = kp->lens[r];
+                        }
+                    }
+                }
+                if (alive) {
                     if constexpr (LONG) {
                         // the next segment's units: requested now that this segment's copy registers are all in the slot,
                         // on their way while its second half is matched (no T-word is at work before the last segment)
@@ -716,9 +860,15 @@ __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a
             if (clear && more)
                 s2_clear_rows(a.clear_out6, a.clear_best, (int64_t)base, n_reads - base < WAVE ? n_reads - base : WAVE, lane);
             S2_STAMP(8);
-            const unsigned p_next = take_piece();
+            const unsigned p_next = RV ? p_early : take_piece();          // (RV: taken with the views, above)
             S2_STAMP(9);
-            prefetch(piece_base(p_next));
+            if constexpr (RV) {
+                const uint32_t vw = s_lds.views[wave * WAVE + lane];
+                skip_next = (int)(vw >> 16);
+                prefetch(piece_base(p_next), vw);
+            } else {
+                prefetch(piece_base(p_next));
+            }
             S2_STAMP(6);
             if (!a.present) {
                 // the tile's staging buffer is free once the tile before the last one is written out
@@ -787,6 +937,12 @@ hipError_t launch_filter_stream2(const FilterArgs& a_in, int mode, int n_lead, i
     if (a.suffix_views && a.front) {
         if (n_lead <= 1 && n_tw <= 2) hipLaunchKernelGGL((k_filter_stream2<1, 2, true, true, true>), dim3(grid), dim3(S2_WAVES * WAVE), lds, s, a);
         else if (n_lead <= 2 && n_tw <= 4) hipLaunchKernelGGL((k_filter_stream2<2, 4, true, true, true>), dim3(grid), dim3(S2_WAVES * WAVE), lds, s, a);
+        else return hipErrorInvalidValue;
+        return hipGetLastError();
+    }
+    if (a.suffix_views == 2) {
+        if (n_lead <= 1 && n_tw <= 2) hipLaunchKernelGGL((k_filter_stream2<1, 2, true, true, false, false, true>), dim3(grid), dim3(S2_WAVES * WAVE), lds, s, a);
+        else if (n_lead <= 2 && n_tw <= 4) hipLaunchKernelGGL((k_filter_stream2<2, 4, true, true, false, false, true>), dim3(grid), dim3(S2_WAVES * WAVE), lds, s, a);
         else return hipErrorInvalidValue;
         return hipGetLastError();
     }

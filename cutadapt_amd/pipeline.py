@@ -595,6 +595,8 @@ class BatchAdapterCutter:
                     cur_len = wend[active] - wbeg[active]
                     batch = ReadBatch(base.seqs, starts, torch.from_numpy(cur_len.astype(np.int32)).to(base.device),
                                       n_reads=len(active), validated=True)
+                    if rnd == 0 and base.uniform_len and base.lens is None:
+                        batch.within_uniform = int(base.uniform_len)     # every read of a sequencer's batch, cut: streamed
                 rr = self._match_round(batch, cur_len)
                 hit = rr.found
                 if not hit.any():
@@ -1200,8 +1202,10 @@ class BatchPairedAdapterCutter:
         wbeg, wend = request["window"]
         starts = base.offsets[:n] + torch.from_numpy(wbeg).to(base.device)
         cur = (wend - wbeg).astype(np.int64)
-        return (ReadBatch(base.seqs, starts, torch.from_numpy(cur.astype(np.int32)).to(base.device), n_reads=n,
-                          validated=True), wbeg.astype(np.int64), cur)
+        views = ReadBatch(base.seqs, starts, torch.from_numpy(cur.astype(np.int32)).to(base.device), n_reads=n, validated=True)
+        if base.uniform_len and base.lens is None:
+            views.within_uniform = int(base.uniform_len)
+        return views, wbeg.astype(np.int64), cur
 
     def best_pairs(self, batch1, batch2):
         """-> (found[n], pair index[n], coords1[n,6], coords2[n,6]) as numpy; the merge runs on the device"""

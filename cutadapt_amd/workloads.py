@@ -107,3 +107,13 @@ def ragged_device_batch(batch, first_index: int = 0):
         keep = cols[None, :] < lens[lo:hi, None]
         out[int(offsets[lo].item()):int(offsets[hi].item())] = view[lo:hi][keep]
     return ReadBatch(out, offsets, validated=True)
+
+
+def ragged_view_batch(batch, first_index: int = 0):
+    """a uniform ReadBatch cut to ragged_lengths WITHOUT a copy: views (starts + lengths) into the batch at its uniform
+    stride -- what a pipeline holds once a modifier in front of the adapter search (quality trimming, -u -N, --length) has
+    cut a sequencer's reads at their 3' end"""
+    import torch
+    n, dev = batch.n_reads, batch.seqs.device
+    lens = ragged_lengths(torch.arange(first_index, first_index + n, dtype=torch.int64, device=dev))
+    return batch.view(torch.zeros(n, dtype=torch.int64, device=dev), lens)

@@ -196,6 +196,15 @@ int cah_match_batch_suffix_views(const cah_plan *plan, const uint8_t *d_seqs, co
                                  const int32_t *d_lens, int32_t parent_read_len, int64_t n_reads,
                                  int32_t *d_out6, int32_t *d_best_adapter, uint8_t *d_status,
                                  void *d_workspace, size_t workspace_bytes, void *stream);
+/* ... and for views that lie ANYWHERE inside the reads of such a batch: r * parent_read_len <= d_starts[r],
+ * d_starts[r] + d_lens[r] <= (r + 1) * parent_read_len -- the reads of a sequencer's batch after a modifier in front of
+ * the adapter search has cut them (reference modifiers.py: QualityTrimmer, UnconditionalCutter, Shortener run before
+ * AdapterCutter; per read the adapter then sees a shorter str, adapters.py:707-724, :815-832).  Same results as
+ * cah_match_batch(plan, d_seqs, d_starts, d_lens, ...); the prefilter streams the parent's reads end-aligned. */
+int cah_match_batch_views(const cah_plan *plan, const uint8_t *d_seqs, const int64_t *d_starts,
+                          const int32_t *d_lens, int32_t parent_read_len, int64_t n_reads,
+                          int32_t *d_out6, int32_t *d_best_adapter, uint8_t *d_status,
+                          void *d_workspace, size_t workspace_bytes, void *stream);
 /* The views the second stage of a linked adapter searches (adapters.py:1222-1224): d_starts[r] = start of read r +
  * (front match ? its query_stop : 0), d_view_lens[r] = what is left of the read.  Reads as in cah_match_batch, or
  * read_len > 0: equally long reads back to back from byte 0 (d_offsets may be NULL). */

@@ -38,6 +38,8 @@ pmc C2 100000000 final_c2
 pmc C3 100000000 final_c3
 pmc C5 125000000 final_c5
 cp profiles/pmc_latest.json $out/
+# ---- views inside a uniform batch (RV form) against uniform reads and the packed layout, same box
+PACKED=1 bash profiles/scripts/r05_views.sh > $out/views_run.txt 2>&1; tail -n 5 $out/views_run.txt; cp gpurun_out/r05views/c2_uniform.json gpurun_out/r05views/c2_views.json gpurun_out/r05views/c2_packed.json gpurun_out/r05views/c5_views.json $out/ 2>/dev/null
 timeout 900 python bench.py > $out/bench_default.json 2> $out/bench_default.err; echo "bench rc=$?"
 python - "$out" <<'PY'
 import json,sys

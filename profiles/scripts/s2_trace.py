@@ -16,6 +16,9 @@ TRUSEQ = "AGATCGGAAGAGCACACGTCTGAACTCCAGTCA"
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000_000
 ad = BackAdapter(TRUSEQ, max_errors=0.1, min_overlap=3)
 batch = ReadBatch.synthetic(n, 150, [TRUSEQ], seed=2)
+if len(sys.argv) > 2 and sys.argv[2] == "views":            # the RV form: reads cut to 30 .. 150 characters, as views
+    from cutadapt_amd import workloads
+    batch = workloads.ragged_view_batch(batch)
 for _ in range(2):
     match_batch(ad._fused_plan, batch)
 torch.cuda.synchronize()
@@ -45,3 +48,8 @@ for k in range(2, 10):
 f = fine[8:40]
 print("finer: matched -> clear stores issued", (f[:, 8] - f[:, 5]).mean(), "| take_piece", (f[:, 9] - f[:, 8]).mean(), "| prefetch issue", (f[:, 6] - f[:, 9]).mean(),
       "| buffer wait", (f[:, 10] - f[:, 6]).mean(), "| emit", (f[:, 7] - f[:, 10]).mean())
+
+st = lambda a, b: (f[:, b] - f[:, a]).mean()
+print("stations: wait+slot0", st(0, 1), "| match1", st(2, 3), "| slot1", st(3, 4), "| match2", st(4, 5), "| clear", st(5, 8),
+      "| take", st(8, 9), "| prefetch issue", st(9, 6), "| buffer wait", st(6, 10), "| emit", st(10, 7),
+      "| piece", np.diff(fine[8:41, 0]).mean())

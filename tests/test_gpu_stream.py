@@ -305,6 +305,8 @@ def test_suffix_views_of_a_uniform_batch(hip, orc):
             view = batch.view(sk, batch.lengths() - sk)
             if mode == "suffix":
                 view.suffix_of_uniform = n
+            else:
+                view.within_uniform = None                   # the plain view entry point
             res = match_batch(ad._fused_plan, view)
             out6, st = res.out6.cpu().numpy(), res.status.cpu().numpy()
             results[mode] = (out6, st, _survivors(view, count))
@@ -318,6 +320,67 @@ def test_suffix_views_of_a_uniform_batch(hip, orc):
         # the streamed form may only UNDER-state the first hit (the scan then starts earlier), never over-state it
         ks, kv = results["suffix"][2], results["views"][2]
         assert all(ks[i] <= kv[i] for i in ks), [(i, ks[i], kv[i], skip[i]) for i in ks if ks[i] > kv[i]][:5]
+
+
+def test_inner_views_of_a_uniform_batch(hip, orc):
+    """cah_match_batch_views (reads of a sequencer's batch cut by a modifier in front of the adapter search: view r is any
+    part of read r): the prefilter streams the parent's reads end-aligned.  Tuples against the oracle on the views
+    themselves and against the plain view entry point, the survivor queue = exactly the views whose kmers_present is
+    true.  Views of every shape: whole reads, empty ones, cut at either end or both, at lengths that are and are not
+    multiples of 16; batches of less than a piece, of the slow first / last pieces only, and of many tiles."""
+    import torch
+    from cutadapt_amd import adapters as A
+    from cutadapt_amd.batch import ReadBatch, match_batch
+    rng = random.Random(2025 + int(os.environ.get("CAH_TEST_SEED_OFFSET", "0")))
+    cases = [(TRUSEQ, 0.1, 3, 150), (TRUSEQ, 0.1, 3, 151), (TRUSEQ, 0.1, 3, 100), (TRUSEQ, 0.1, 3, 40), (TRUSEQ, 0.1, 3, 160),
+             (TRUSEQ, 0.1, 3, 16), (TRUSEQ, 0.1, 3, 10), (TRUSEQ, 0.1, 3, 33), (TRUSEQ[:20], 0.2, 2, 76)]
+    for _ in range(6):
+        cases.append((rs(rng, rng.choice([12, 25, 33])), rng.choice([0.0, 0.1]), rng.randint(1, 5), rng.choice([150, 125, 50, 81])))
+    for seq, rate, ov, n in cases:
+        ad = A.BackAdapter(seq, max_errors=rate, min_overlap=ov)
+        count = rng.choice([1, 40, 500, 1500, 9000, 20000])
+        reads = make_reads(rng, n, count, seq, p_adapter=0.7)
+        # adapter copies OUTSIDE the view must not be seen: plant some at the read's head and at its very end
+        reads = [(seq + r)[:n] if rng.random() < 0.2 else ((r + seq)[-n:] if rng.random() < 0.2 else r) for r in reads]
+        start = np.zeros(count, dtype=np.int64)
+        length = np.zeros(count, dtype=np.int64)
+        for i in range(count):
+            shape = rng.randrange(8)
+            if shape == 0:
+                a, b = 0, n                                   # the whole read
+            elif shape <= 3:
+                a, b = 0, rng.choice([0, 1, 3, 15, 16, 17, 30, n - 1, n - 16, n - 33, rng.randint(0, n)])   # cut at the 3' end
+            elif shape == 4:
+                a = rng.randint(0, n); b = n                  # a suffix
+            else:
+                a = rng.randint(0, n); b = rng.randint(a, n)
+            b = min(max(b, a), n)
+            start[i], length[i] = a, b - a
+        subs = [r[int(a):int(a + l)] for r, a, l in zip(reads, start, length)]
+        want, finder = oracle_expect(orc, ad, subs)
+        batch = ReadBatch.from_strings(reads)
+        assert batch.uniform_len == n
+        st_d, ln_d = torch.from_numpy(start).cuda(), torch.from_numpy(length).cuda()
+        results = {}
+        for mode in ("inner", "views"):
+            view = batch.view(st_d, ln_d)
+            if mode == "inner":
+                assert view.within_uniform == n
+            else:
+                view.within_uniform = None                   # the plain view entry point
+            res = match_batch(ad._fused_plan, view)
+            out6, st = res.out6.cpu().numpy(), res.status.cpu().numpy()
+            results[mode] = (out6, st, _survivors(view, count))
+            for i, w in enumerate(want):
+                if w is None:
+                    assert st[i] == 0, (mode, seq, n, i, start[i], length[i])
+                else:
+                    assert st[i] == 1 and tuple(out6[i]) == tuple(w), (mode, seq, n, i, start[i], length[i], tuple(out6[i]), w)
+        present = {i for i, r in enumerate(subs) if finder.kmers_present(r)}
+        assert set(results["inner"][2]) == present == set(results["views"][2]), (seq, n, count)
+        # the streamed form may only UNDER-state the first hit (the scan then starts earlier), never over-state it
+        ks, kv = results["inner"][2], results["views"][2]
+        assert all(ks[i] <= kv[i] for i in ks), [(i, ks[i], kv[i], start[i], length[i]) for i in ks if ks[i] > kv[i]][:5]
 
 
 def test_linked_adapter_on_uniform_reads_fused_and_staged(hip, orc):
