@@ -240,6 +240,62 @@ def test_stream_copy_plan_division_is_exact():
             assert r == u // U and u * magic < 2 ** 32, (U, u)
 
 
+def test_end_aligned_copy_plan_of_views():
+    """k_filter_stream2's RV form (csrc/stream2.hip): the copy plan that streams views of a uniform batch END-aligned,
+    replayed in numpy.  Per read r of a piece, lane r packs A = r (n - 16 H) + S2_RV_BACK - d | T << 16 with
+    T = skip + 16 r H for either half's shape; unit u = 64 k + lane of a half takes its read's word, is skipped (zeros) iff
+    its last character 16 u + 15 [+ 16 H1] < T, else fetched from resource byte A + 16 lane + 1024 k [+ 16 H1] (resource
+    base = the piece's first byte - S2_RV_BACK) into slot row r, unit u % H.  Checked for every read length of the short
+    form: both fields fit 16 bits, no offset is negative, and what lands in the slot -- with the unit a view starts in
+    masked and everything from position n on cleared, as the kernel does -- is the view, NUL-padded in front, ending at n."""
+    rng = np.random.default_rng(11)
+    BACK, WAVE = 1184, 64
+    for n in list(range(1, 161)):
+        U = (n + 15) // 16
+        H1, H2 = (U + 1) // 2, U - (U + 1) // 2
+        piece = rng.integers(65, 91, size=WAVE * n, dtype=np.uint8)
+        before = rng.integers(97, 123, size=BACK, dtype=np.uint8)            # bytes in front of the piece (other reads)
+        after = rng.integers(97, 123, size=64, dtype=np.uint8)
+        mem = np.concatenate([before, piece, after])                         # resource byte i = mem[i]
+        start = rng.integers(0, n + 1, size=WAVE)
+        length = np.array([rng.integers(0, n - s + 1) for s in start])
+        if n > 3:
+            start[:4], length[:4] = [0, 0, n, 1], [n, 0, 0, n - 1]
+        d, skip = n - (start + length), n - length
+        rows = np.zeros((WAVE, 160), dtype=np.uint8)
+        for half, H, base in ((0, H1, 0), (1, H2, 16 * H1)):
+            if H == 0:
+                continue
+            r_lane = np.arange(WAVE)
+            A = r_lane * (n - 16 * H) + BACK - d
+            T = skip + 16 * r_lane * H
+            assert (A >= 0).all() and (A < 65536).all() and (T >= 0).all() and (T < 65536).all(), (n, half)
+            magic = (65536 + H - 1) // H
+            for k in range(H):
+                for lane in range(WAVE):
+                    u = k * WAVE + lane
+                    r = (u * magic) >> 16
+                    assert r == u // H and r < WAVE
+                    c = u - r * H
+                    front = 16 * lane + 16 * k * WAVE + 15 + base < T[r]
+                    assert front == (16 * c + base + 15 < skip[r])
+                    if front:
+                        unit = np.zeros(16, dtype=np.uint8)
+                    else:
+                        off = A[r] + 16 * lane + 1024 * k + base
+                        assert 0 <= off and off + 16 <= len(mem), (n, half, k, lane, off)
+                        unit = mem[off:off + 16]
+                    rows[r, base + 16 * c: base + 16 * c + 16] = unit
+        for r in range(WAVE):
+            got = rows[r].copy()
+            got[:skip[r]] = np.where(np.arange(skip[r]) // 16 == skip[r] // 16, 0, got[:skip[r]])   # the unit the view starts in
+            assert not got[:skip[r]].any(), (n, r)                           # ... everything in front of it arrived as zeros
+            got[n:] = 0                                                      # finish(): characters past the read's end
+            want = np.zeros(160, dtype=np.uint8)
+            want[skip[r]:n] = piece[r * n + start[r]: r * n + start[r] + length[r]]
+            assert np.array_equal(got, want), (n, r, start[r], length[r])
+
+
 def test_prefilter_of_anchored_exact_adapters_is_dropped_only_when_implied():
     """CahMatcher::filter_implied (cah_plan_create): the prefilter of an anchored adapter that tolerates no error is
     skipped only if an unedited occurrence of the adapter at its anchored place passes it -- decided against the
