@@ -187,6 +187,69 @@ def test_wildcards(model):
     assert used >= 10
 
 
+def brute_first_end(finder_for, sets, read, n):
+    """end position of the first-ending k-mer of `sets` that lies in its window (-1: none)"""
+    best = -1
+    for start, stop, kmers in sets:
+        lo = max(0, n + start) if start < 0 else start
+        hi = n if stop is None else stop
+        for k in kmers:
+            q = len(k)
+            f = finder_for(k)
+            for p in range(lo, hi - q + 1):
+                if f.kmers_present(read[p:p + q]):
+                    if best < 0 or p + q - 1 < best:
+                        best = p + q - 1
+                    break
+    return best
+
+
+def test_end_aligned_views(model):
+    """What k_filter_stream2's RV form rests on (views inside the reads of a uniform batch, cah_match_batch_views): a view of
+    len characters, streamed as a read of n characters that ENDS where the view ends and holds NUL in its first n - len
+    positions, has the view's own kmers_present -- tail search sets count from the end (reference _kmer_finder.pyx:186-204),
+    also when the view is shorter than a set's window -- and its first-hit group is that of the view's first hit moved by
+    n - len (the queue key the kernel derives from it is a lower bound of the hit within the view)."""
+    rng = np.random.default_rng(404 + SEED0)
+    used = tried = 0
+    for i in range(60):
+        if i == 0:
+            adapter, rate, min_overlap = TRUSEQ, 0.1, 3
+        else:
+            m = int(rng.integers(6, 41))
+            adapter = "".join(rng.choice(list("ACGT" if rng.random() < 0.7 else "ACGTNRY"), size=m))
+            rate = float(rng.choice([0.0, 0.1, 0.1, 0.2]))
+            min_overlap = int(rng.integers(1, 8))
+        ref_wc, query_wc = bool(i & 1) and i > 0, bool(i & 2)
+        sets = create_positions_and_kmers(adapter, min_overlap, rate, back_adapter=True, front_adapter=False, internal=True)
+        blob, size = lean_blob(sets, ref_wc, query_wc)
+        tried += 1
+        if not model.sm_tw_ok(blob):
+            continue
+        used += 1
+        n = int(rng.choice([150, 150, 100, 76, 40, 151, 160, 33, 17]))
+        plain = adapter.replace("N", "A").replace("R", "G").replace("Y", "C")
+        lens = [int(x) for x in rng.choice([0, 1, 2, 3, 5, 8, 15, 16, 17, 30, n - 1, n] + list(range(n + 1)), size=70)]
+        lens = [min(max(x, 0), n) for x in lens]
+        views = [random_reads(rng, 1, ln, plain)[0] if ln else "" for ln in lens]
+        padded = ["\0" * (n - len(v)) + v for v in views]
+        of = orc.KmerFinder(sets, ref_wc, query_wc)
+        want = np.array([of.kmers_present(v) for v in views], dtype=np.uint8)
+        present, hit = run(model, blob, padded, n)
+        assert np.array_equal(present, want), (sets, n, [(v, a, b) for v, a, b in zip(views, present, want) if a != b][:3])
+        if i % 3 == 0:
+            cache = {}
+
+            def finder_for(k):
+                if k not in cache:
+                    cache[k] = orc.KmerFinder([(0, None, [k])], ref_wc, query_wc)
+                return cache[k]
+            for v, p_, h in zip(views, present, hit):
+                e = brute_first_end(finder_for, sets, v, len(v))
+                assert (h // 4 if p_ else -1) == ((e + n - len(v)) // 4 if e >= 0 else -1), (sets, v, n, h, e)
+    assert used >= tried // 2, (used, tried)
+
+
 def test_invalid_bytes(model):
     sets = create_positions_and_kmers(TRUSEQ, 3, 0.1, back_adapter=True, front_adapter=False, internal=True)
     blob, _ = lean_blob(sets)
