@@ -52,127 +52,89 @@ class Where(IntFlag):
 # Match objects (reference adapters.py:292-493)
 # -------------------------------------------------------------------------------------------------
 class Match(ABC):
+    """What a modifier asks of any match (reference adapters.py:292-313): the part of the read that stays, the part that
+    stays when the adapter is retained, the trimmed read, the matched characters."""
     adapter: "Adapter"
 
-    @abstractmethod
-    def remainder_interval(self) -> Tuple[int, int]:
-        pass
-
-    @abstractmethod
-    def retained_adapter_interval(self) -> Tuple[int, int]:
-        pass
-
-    @abstractmethod
-    def trimmed(self, read):
-        pass
-
-    @abstractmethod
-    def match_sequence(self):
-        pass
+    remainder_interval = abstractmethod(lambda self: None)            # -> (start, stop) of what is left of the read
+    retained_adapter_interval = abstractmethod(lambda self: None)     # ... when the adapter itself is kept (--action=retain)
+    trimmed = abstractmethod(lambda self, read: None)
+    match_sequence = abstractmethod(lambda self: None)
 
 
 class SingleMatch(Match, ABC):
-    """One adapter matched to one string (reference adapters.py:316-424)."""
+    """One adapter matched to one string (reference adapters.py:316-424): the tuple Aligner.locate returns -- adapter
+    interval [astart, astop), read interval [rstart, rstop), score, errors -- with the adapter and the string.  Which side
+    of the match goes is the subclass's one bit (_BEFORE); every interval below follows from it."""
 
     __slots__ = ["astart", "astop", "rstart", "rstop", "score", "errors", "adapter", "sequence", "length"]
+    _BEFORE = property(abstractmethod(lambda self: None))     # (a plain class attribute in the two concrete classes)
 
     def __init__(self, astart: int, astop: int, rstart: int, rstop: int, score: int, errors: int,
                  adapter: "SingleAdapter", sequence: str):
-        self.astart = astart
-        self.astop = astop
-        self.rstart = rstart
-        self.rstop = rstop
-        self.score = score
-        self.errors = errors
-        self.adapter = adapter
-        self.sequence = sequence
+        self.astart, self.astop, self.rstart, self.rstop, self.score, self.errors = astart, astop, rstart, rstop, score, errors
+        self.adapter, self.sequence = adapter, sequence
         self.length = astop - astart   # aligned adapter characters
-
-    def __repr__(self):
-        return (f"{self.__class__.__name__}(astart={self.astart}, astop={self.astop}, "
-                f"rstart={self.rstart}, rstop={self.rstop}, score={self.score}, errors={self.errors})")
-
-    def __eq__(self, other) -> bool:
-        return (other.__class__ is self.__class__ and self.astart == other.astart
-                and self.astop == other.astop and self.rstart == other.rstart
-                and self.rstop == other.rstop and self.score == other.score
-                and self.errors == other.errors and self.adapter is other.adapter
-                and self.sequence == other.sequence)
 
     def astuple(self) -> Tuple[int, int, int, int, int, int]:
         return (self.astart, self.astop, self.rstart, self.rstop, self.score, self.errors)
 
+    def __repr__(self):
+        names = self.__slots__[:6]
+        return f"{type(self).__name__}({', '.join(f'{k}={v}' for k, v in zip(names, self.astuple()))})"
+
+    def __eq__(self, other) -> bool:
+        return (type(other) is type(self) and self.astuple() == other.astuple()
+                and self.adapter is other.adapter and self.sequence == other.sequence)
+
     def wildcards(self, wildcard_char: str = "N") -> str:
         """Characters of the read aligned to wildcard characters of the adapter
         (reference adapters.py:378-393; unreliable with indels, as in the reference)."""
-        return "".join(
-            self.sequence[self.rstart + i] for i in range(self.length)
-            if self.adapter.sequence[self.astart + i] == wildcard_char
-            and self.rstart + i < len(self.sequence))
+        ref, seq = self.adapter.sequence, self.sequence
+        return "".join(seq[self.rstart + i] for i in range(self.length)
+                       if ref[self.astart + i] == wildcard_char and self.rstart + i < len(seq))
 
     def get_info_records(self, read) -> List[List]:
-        seq, qualities = read.sequence, read.qualities
-        info = ["", self.errors, self.rstart, self.rstop, seq[0:self.rstart],
-                seq[self.rstart:self.rstop], seq[self.rstop:], self.adapter.name]
-        if qualities:
-            info += [qualities[0:self.rstart], qualities[self.rstart:self.rstop], qualities[self.rstop:]]
-        else:
-            info += ["", "", ""]
-        return [info]
+        """one row of the info file (reference :395-417): the read cut at the match's two ends, qualities likewise"""
+        cuts = (slice(0, self.rstart), slice(self.rstart, self.rstop), slice(self.rstop, None))
+        quals = [read.qualities[c] for c in cuts] if read.qualities else ["", "", ""]
+        return [["", self.errors, self.rstart, self.rstop] + [read.sequence[c] for c in cuts] + [self.adapter.name] + quals]
 
     def match_sequence(self):
         return self.sequence[self.rstart:self.rstop]
 
-    @abstractmethod
+    # -- the side that goes (reference :427-493) ------------------------------------------------------
+    def remainder_interval(self) -> Tuple[int, int]:
+        return (self.rstop, len(self.sequence)) if self._BEFORE else (0, self.rstart)
+
+    def retained_adapter_interval(self) -> Tuple[int, int]:
+        return (self.rstart, len(self.sequence)) if self._BEFORE else (0, self.rstop)
+
+    def trim_slice(self):
+        return slice(self.rstop, None) if self._BEFORE else slice(None, self.rstart)
+
+    def trimmed(self, read):
+        return read[self.trim_slice()]
+
+    def rest(self) -> str:
+        """the part of the string on the removed side of the match"""
+        return self.sequence[:self.rstart] if self._BEFORE else self.sequence[self.rstop:]
+
     def removed_sequence_length(self) -> int:
-        pass
+        return self.rstop if self._BEFORE else len(self.sequence) - self.rstart
 
 
 class RemoveBeforeMatch(SingleMatch):
     """A match that removes the sequence before it (5' adapters; reference :427-457)."""
-
-    def rest(self) -> str:
-        return self.sequence[:self.rstart]
-
-    def remainder_interval(self) -> Tuple[int, int]:
-        return self.rstop, len(self.sequence)
-
-    def retained_adapter_interval(self) -> Tuple[int, int]:
-        return self.rstart, len(self.sequence)
-
-    def trim_slice(self):
-        return slice(self.rstop, None)
-
-    def trimmed(self, read):
-        return read[self.rstop:]
-
-    def removed_sequence_length(self) -> int:
-        return self.rstop
+    _BEFORE = True
 
 
 class RemoveAfterMatch(SingleMatch):
     """A match that removes the sequence after it (3' adapters; reference :460-493)."""
-
-    def rest(self) -> str:
-        return self.sequence[self.rstop:]
-
-    def remainder_interval(self) -> Tuple[int, int]:
-        return 0, self.rstart
-
-    def retained_adapter_interval(self) -> Tuple[int, int]:
-        return 0, self.rstop
-
-    def trim_slice(self):
-        return slice(None, self.rstart)
-
-    def trimmed(self, read):
-        return read[:self.rstart]
+    _BEFORE = False
 
     def adjacent_base(self) -> str:
         return self.sequence[self.rstart - 1:self.rstart]
-
-    def removed_sequence_length(self) -> int:
-        return len(self.sequence) - self.rstart
 
 
 _name_counter = [1]
@@ -648,47 +610,38 @@ class SuffixAdapter(NonInternalBackAdapter):
 # linked adapters (reference adapters.py:1092-1243)
 # -------------------------------------------------------------------------------------------------
 class LinkedMatch(Match):
+    """The 5' and / or 3' part of a linked adapter found in a read (reference adapters.py:1092-1153); the 3' match's
+    coordinates are relative to what the 5' match left."""
+
     def __init__(self, front_match: Optional[RemoveBeforeMatch], back_match: Optional[RemoveAfterMatch],
                  adapter: "LinkedAdapter"):
         assert front_match is not None or back_match is not None
-        self.front_match = front_match
-        self.back_match = back_match
-        self.adapter = adapter
+        self.front_match, self.back_match, self.adapter = front_match, back_match, adapter
+
+    def _parts(self):
+        return [m for m in (self.front_match, self.back_match) if m is not None]
 
     def __repr__(self):
-        return "<LinkedMatch(front_match={!r}, back_match={}, adapter={})>".format(
-            self.front_match, self.back_match, self.adapter)
+        return f"<LinkedMatch(front_match={self.front_match!r}, back_match={self.back_match}, adapter={self.adapter})>"
 
-    @property
-    def score(self):
-        return sum(m.score for m in (self.front_match, self.back_match) if m is not None)
-
-    @property
-    def errors(self):
-        return sum(m.errors for m in (self.front_match, self.back_match) if m is not None)
+    score = property(lambda self: sum(m.score for m in self._parts()))
+    errors = property(lambda self: sum(m.errors for m in self._parts()))
 
     def trimmed(self, read):
-        if self.front_match:
-            read = self.front_match.trimmed(read)
-        if self.back_match:
-            read = self.back_match.trimmed(read)
+        for m in self._parts():                               # 5' first: the 3' match was found in what that leaves
+            read = m.trimmed(read)
         return read
 
     def remainder_interval(self) -> Tuple[int, int]:
-        matches = [m for m in (self.front_match, self.back_match) if m is not None]
-        return remainder(matches)
+        return remainder(self._parts())
 
     def retained_adapter_interval(self) -> Tuple[int, int]:
-        if self.front_match:
-            start, offset = self.front_match.rstart, self.front_match.rstop
-        else:
-            start = offset = 0
-        end = self.back_match.rstop + offset if self.back_match else len(self.front_match.sequence)
-        return start, end
+        front, back = self.front_match, self.back_match
+        start, shift = (front.rstart, front.rstop) if front else (0, 0)
+        return start, (back.rstop + shift if back else len(front.sequence))
 
     def match_sequence(self):
-        return ((self.front_match.match_sequence() if self.front_match else "") + ","
-                + (self.back_match.match_sequence() if self.back_match else ""))
+        return ",".join(m.match_sequence() if m else "" for m in (self.front_match, self.back_match))
 
 
 def remainder(matches: Sequence[Match]) -> Tuple[int, int]:
@@ -763,15 +716,15 @@ class LinkedAdapter(Adapter):
         return "linked"
 
     def match_to(self, sequence: str) -> Optional[LinkedMatch]:
-        front_match = self.front_adapter.match_to(sequence)
-        if self.front_required and front_match is None:
+        """reference :1215-1227: the 3' part is searched in what the 5' match leaves; a required part that is missing, or
+        no part at all, is no match"""
+        front = self.front_adapter.match_to(sequence)
+        if front is None and self.front_required:
             return None
-        if front_match is not None:
-            sequence = sequence[front_match.trim_slice()]
-        back_match = self.back_adapter.match_to(sequence)
-        if back_match is None and (self.back_required or front_match is None):
+        back = self.back_adapter.match_to(sequence if front is None else sequence[front.trim_slice()])
+        if back is None and (front is None or self.back_required):
             return None
-        return LinkedMatch(front_match, back_match, self)
+        return LinkedMatch(front, back, self)
 
     def match_to_batch(self, batch) -> LinkedBatchMatches:
         """Two dependent stages: the back adapter is searched in the suffix after the front
