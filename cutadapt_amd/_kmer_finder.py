@@ -24,7 +24,12 @@ class KmerFinder:
         self.positions_and_kmers = positions_and_kmers
         self.ref_wildcards = bool(ref_wildcards)
         self.query_wildcards = bool(query_wildcards)
-        spec = _lib.MatcherSpec(kind=_lib.KIND_KMER_ONLY, kmer_sets=list(positions_and_kmers),
+        # An EMPTY k-mer -- kmer_heuristic emits one when an adapter may have as many errors as it has characters -- is
+        # accepted by the reference and never found (_kmer_finder.pyx:121-160: its start bit sits on the next k-mer's, its
+        # "found" bit on the previous one's): the search sets the library sees are the given ones without them.
+        self.searched_positions_and_kmers = [
+            (start, stop, [k for k in kmers if not (isinstance(k, str) and k == "")]) for start, stop, kmers in positions_and_kmers]
+        spec = _lib.MatcherSpec(kind=_lib.KIND_KMER_ONLY, kmer_sets=list(self.searched_positions_and_kmers),
                                 kmer_ref_wildcards=ref_wildcards,
                                 kmer_query_wildcards=query_wildcards)
         self._plan = _lib.Plan([spec])

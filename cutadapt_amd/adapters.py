@@ -371,7 +371,7 @@ class SingleAdapter(Adapter, ABC):
     def matcher_spec(self) -> _lib.MatcherSpec:
         """aligner + prefilter as one cah_adapter_desc"""
         if isinstance(self.kmer_finder, KmerFinder):
-            return self.aligner.spec(self.kmer_finder.positions_and_kmers,
+            return self.aligner.spec(self.kmer_finder.searched_positions_and_kmers,
                                      self.kmer_finder.ref_wildcards, self.kmer_finder.query_wildcards)
         return self.aligner.spec(None)
 
@@ -786,7 +786,7 @@ class AdapterIndex:
         self._prefix = bool(prefix)
         self._h = _lib.Index(
             [(a.sequence, a.max_error_rate, a.indels,
-              a.kmer_finder.positions_and_kmers if isinstance(a.kmer_finder, KmerFinder) else None)
+              a.kmer_finder.searched_positions_and_kmers if isinstance(a.kmer_finder, KmerFinder) else None)
              for a in self._adapters], prefix)
         self._lengths = list(self._h.lengths)
         self._ambiguous = self._h.n_ambiguous

@@ -241,6 +241,46 @@ def test_kmer_finder_many_words_and_clamping(hip, orc):
     assert np.array_equal(got, want) and want.sum() > 30
 
 
+def test_adapters_that_tolerate_as_many_errors_as_they_have_characters(hip, orc):
+    """Error rate 1.0 (-e 4 on a 4-character adapter): kmer_heuristic emits an EMPTY k-mer next to single characters.  The
+    reference accepts it and never finds it (_kmer_finder.pyx:121-160), so its prefilter turns away reads without any adapter
+    character -- all-N reads -- that the aligner alone would match.  Same here: the finder takes the sets as they are, the
+    library searches them without the empty k-mer; against the oracle on the reference's own sets."""
+    from cutadapt_amd import adapters as A
+    from cutadapt_amd._kmer_finder import KmerFinder
+    from cutadapt_amd.batch import ReadBatch
+    rng = random.Random(77)
+    fixed = ["", "A", "CCC", "NNNN", "ACGT", "TTTTG", "nnnn", "RRRR"]
+    for sets in ([(0, None, ["", "A"])], [(0, None, ["A", ""])], [(-5, None, ["", "G", "N"])], [(0, None, [""])]):
+        f, o = KmerFinder(sets, True, False), orc.KmerFinder(sets, True, False)
+        assert f.positions_and_kmers == sets
+        reads = fixed + [rs(rng, rng.randint(0, 20), "ACGTN") for _ in range(30)]
+        assert [f.kmers_present(r) for r in reads] == [o.kmers_present(r) for r in reads], sets
+    turned_away = 0
+    for cls, seq, errs in ((A.BackAdapter, "ACGT", 4), (A.BackAdapter, "ACGTAC", 6), (A.FrontAdapter, "TTGCA", 5),
+                           (A.SuffixAdapter, "NNNNG", 1), (A.AnywhereAdapter, "GATC", 4)):
+        ad = cls(seq, max_errors=errs, min_overlap=3)
+        assert isinstance(ad.kmer_finder, KmerFinder) and ad.max_error_rate == 1.0
+        assert any("" in k for _, _, k in ad.kmer_finder.positions_and_kmers)
+        reads = ["NNNNNNNN", "nnnn", "", "N", "TTTTTTTT", "ACGTACGT", "GGGGACGG", "RYRYRYRY", "NNNNANNN"] + \
+                [rs(rng, rng.randint(0, 30), "ACGTN") for _ in range(60)]
+        spec = ad.matcher_spec()
+        oa = orc.Aligner(spec.sequence, spec.max_error_rate, spec.flags, spec.wildcard_ref, spec.wildcard_query,
+                         spec.indel_cost, spec.min_overlap)
+        of = orc.KmerFinder(ad.kmer_finder.positions_and_kmers, ad.kmer_finder.ref_wildcards, ad.kmer_finder.query_wildcards)
+        seqs, offsets = orc.pack_reads(reads)
+        o6, st = orc.match_batch(oa, of, seqs, offsets)
+        alone6, alone = orc.match_batch(oa, None, seqs, offsets)              # the aligner without a prefilter
+        turned_away += int(((alone == 1) & (st != 1)).sum())
+        bm = ad.match_to_batch(ReadBatch.from_strings(reads))
+        assert np.array_equal(bm.found, st == 1), (cls.__name__, seq)
+        assert np.array_equal(bm.coords[bm.found], o6[st == 1].astype(np.int64)), (cls.__name__, seq)
+        for i in (0, 4, 5, 8):                                                # ... and read by read
+            m = ad.match_to(reads[i])
+            assert (m is not None) == bool(st[i] == 1) and (m is None or m.astuple() == tuple(int(x) for x in o6[i])), (seq, i)
+    assert turned_away > 0                                    # the case exists: the prefilter decides, not the aligner
+
+
 # ---------------------------------------------------------------------------------------------
 # fused match path (prefilter -> queue -> DP) and adapters API
 # ---------------------------------------------------------------------------------------------

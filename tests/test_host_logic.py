@@ -155,6 +155,22 @@ def test_adapter_parameter_normalisation():
     assert m.remainder_interval() == (0, 10) and m.removed_sequence_length() == 6
 
 
+def test_empty_kmers_are_accepted_like_the_reference():
+    """an adapter that may have as many errors as it has characters: kmer_heuristic emits an empty k-mer; the reference's
+    KmerFinder takes it (it is never found, _kmer_finder.pyx:121-160) -- so does this one, and the library searches the sets
+    without it"""
+    from cutadapt_amd import adapters as A
+    from cutadapt_amd._kmer_finder import KmerFinder
+    sets = [(0, None, ["", "A"]), (-3, None, [""])]
+    f = KmerFinder(sets)
+    assert f.positions_and_kmers == sets and f.searched_positions_and_kmers == [(0, None, ["A"]), (-3, None, [])]
+    assert f.number_of_searches == 1
+    ad = A.BackAdapter("ACGT", max_errors=4, min_overlap=3)
+    assert ad.max_error_rate == 1.0 and isinstance(ad.kmer_finder, KmerFinder)
+    assert any("" in k for _, _, k in ad.kmer_finder.positions_and_kmers)
+    assert all("" not in k for _, _, k in ad.matcher_spec().kmer_sets)
+
+
 def test_prefilter_kernel_selection():
     """which prefilter kernel a plan gets (host-side decision of cah_plan_create): everything
     kmer_heuristic builds is 'lean', hand-made windows and long k-mers stay 'general'"""
