@@ -1596,8 +1596,8 @@ def _parse_single_spec(spec: str, adapter_type: str):
     if "=" in spec:
         name, spec = spec.split("=", 1)
         name = name.strip()
-    spec = expand_braces(spec.strip())
-    parameters = parse_search_parameters(parameter_text)
+    parameters = parse_search_parameters(parameter_text)     # (the reference's order: a specification with two faults
+    spec = expand_braces(spec.strip())                       #  raises what its first check raises, parser.py:234-238)
     rightmost = bool(parameters.pop("rightmost", False))
     if len(spec.strip("X")) == 0:                  # only X characters: a plain adapter (parser.py:243-246)
         return name, None, spec, {}, False
@@ -1670,8 +1670,7 @@ def adapter_from_spec(spec: str, adapter_type: str = "back", **params):
             front_required, back_required = frestr is not None, brestr is not None
         front_required = front_parameters.pop("required", front_required)
         back_required = back_parameters.pop("required", back_required)
-        front_parameters.pop("anywhere", None)
-        back_parameters.pop("anywhere", None)
+        # (";anywhere" inside a linked adapter reaches the adapter class as an unknown keyword: TypeError, as in the reference)
         front = _adapter_class("front", frestr, fright)(fseq, name="linked_front", **front_parameters)
         back = _adapter_class("back", brestr, bright)(bseq, name="linked_back", **back_parameters)
         return LinkedAdapter(front, back, front_required, back_required, fname)
