@@ -68,7 +68,19 @@ def main():
             except Exception as exc:            # the error a class raises for a parameter set is part of its behaviour
                 cases.append({"cls": cls, "seq": seq, "kwargs": kwargs, "error": type(exc).__name__})
                 continue
-            cases.append({"cls": cls, "seq": seq, "kwargs": kwargs, "want": describe(ad)})
+            want = describe(ad)
+            # which adapters the index of anchored adapters takes (reference :1373-1392)
+            want["indexable"] = [bool(R.AdapterIndex.is_acceptable(ad, True)), bool(R.AdapterIndex.is_acceptable(ad, False))]
+            cases.append({"cls": cls, "seq": seq, "kwargs": kwargs, "want": want})
+    for cls in ("PrefixAdapter", "SuffixAdapter"):
+        for i in range(24):
+            seq = rs(rng, rng.choice([6, 10, 20, 33, 50]), rng.choice(["ACGT", "ACGT", "ACGTN"]))
+            kwargs = {"max_errors": rng.choice([0, 0.05, 0.1, 0.2, 1, 3, 4]), "read_wildcards": rng.random() < 0.2,
+                      "adapter_wildcards": rng.random() < 0.4, "indels": rng.random() < 0.7, "name": f"x{i}"}
+            ad = getattr(R, cls)(seq, **kwargs)
+            want = describe(ad)
+            want["indexable"] = [bool(R.AdapterIndex.is_acceptable(ad, True)), bool(R.AdapterIndex.is_acceptable(ad, False))]
+            cases.append({"cls": cls, "seq": seq, "kwargs": kwargs, "want": want})
     path = os.path.join(HERE, "adapter_attrs.json")
     with open(path, "w") as f:
         json.dump(cases, f, indent=0)

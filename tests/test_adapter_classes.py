@@ -28,6 +28,7 @@ def cases():
 
 def test_adapter_classes_describe_themselves_as_the_reference(cases):
     seen = set()
+    indexable = 0
     for c in cases:
         cls = getattr(A, c["cls"])
         if "error" in c:
@@ -55,11 +56,14 @@ def test_adapter_classes_describe_themselves_as_the_reference(cases):
             got = [[a, b, sorted(k)] for a, b, k in ad.kmer_finder.positions_and_kmers]
             assert sorted(got, key=key) == sorted(w["kmer_sets"], key=key), ctx
             assert [bool(ad.kmer_finder.ref_wildcards), bool(ad.kmer_finder.query_wildcards)] == w["kmer_wildcards"], ctx
+        assert [A.AdapterIndex.is_acceptable(ad, True), A.AdapterIndex.is_acceptable(ad, False)] == w["indexable"], ctx
+        indexable += any(w["indexable"])
         seen.add((c["cls"], w["aligner"], bool(c["kwargs"].get("force_anywhere"))))
     assert {s[0] for s in seen} == {"FrontAdapter", "RightmostFrontAdapter", "BackAdapter", "RightmostBackAdapter",
                                     "AnywhereAdapter", "NonInternalFrontAdapter", "NonInternalBackAdapter",
                                     "PrefixAdapter", "SuffixAdapter"}
     assert any(s[1] == "PrefixComparer" for s in seen) and any(s[1] == "SuffixComparer" for s in seen)
+    assert indexable >= 8                                    # ... and the index of anchored adapters takes some of them
     assert sum(1 for s in seen if s[2]) >= 5                 # force_anywhere seen for most of the classes that take it
 
 
