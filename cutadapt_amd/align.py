@@ -46,6 +46,12 @@ class Aligner:
         self._flags = int(flags) & 15
         self.wildcard_ref = bool(wildcard_ref)
         self.wildcard_query = bool(wildcard_query)
+        if not reference.isascii():
+            # the reference translates the adapter through a table when wildcards are on (ValueError) and encodes it
+            # otherwise (UnicodeEncodeError): _align.pyx:40-46, :265-277
+            if self.wildcard_ref or self.wildcard_query:
+                raise ValueError("String must contain only ASCII characters")
+            reference.encode("ascii")
         self._indel_cost = int(indel_cost)
         self._min_overlap = int(min_overlap)
         self._plan = _lib.Plan([self.spec()])
@@ -121,6 +127,13 @@ class DPMatrix:
         return "\n".join(rows)
 
 
+_IUPAC_BITS = {"X": 0, "A": 1, "C": 2, "G": 4, "T": 8, "U": 8}
+for _code, _members in (("R", "AG"), ("Y", "CT"), ("S", "GC"), ("W", "AT"), ("K", "GT"), ("M", "AC"), ("B", "CGT"), ("D", "AGT"),
+                        ("H", "ACT"), ("V", "ACG")):
+    _IUPAC_BITS[_code] = sum(_IUPAC_BITS[x] for x in _members)
+_IUPAC_BITS["N"] = 15 | 0x80
+
+
 class PrefixComparer:
     """Hamming-distance comparison of an anchored 5' adapter with the start of the read
     (reference _align.pyx:594-693)."""
@@ -147,9 +160,21 @@ class PrefixComparer:
         return (type(self), (self._reference, self.max_error_rate, self.wildcard_ref,
                              self.wildcard_query, self.min_overlap))
 
+    def _shown_reference(self) -> bytes:
+        """what the reference's repr shows for `reference`: the adapter as ITS comparer stores it (_align.pyx:637-642, :707) --
+        one byte per character: IUPAC bit sets when the adapter has wildcards (A 1, C 2, G 4, T 8, their unions, N with the
+        top bit as well, anything else 0), A/C/G/T bits with every other character 0x80 when only the read has, upper-case
+        text otherwise; an anchored 3' adapter back to front"""
+        text = self._reference[::-1] if self._kind == _lib.KIND_SUFFIX else self._reference
+        if self.wildcard_ref:
+            return bytes(_IUPAC_BITS.get(c, 0) for c in text.upper())
+        if self.wildcard_query:
+            return bytes(_IUPAC_BITS[c] if c in "ACGTU" else 0x80 for c in text.upper())
+        return text.encode("ascii").upper()
+
     def __repr__(self):
         return "{}(reference={!r}, max_k={}, wildcard_ref={}, wildcard_query={})".format(
-            self.__class__.__name__, self._reference, self.max_k, self.wildcard_ref,
+            self.__class__.__name__, self._shown_reference(), self.max_k, self.wildcard_ref,
             self.wildcard_query)
 
     def locate(self, query: str) -> Optional[AlignmentTuple]:
