@@ -503,7 +503,8 @@ def _reverse_batch(batch, complement: bool = False, select=None, data=None):
 # reference's names and hierarchy (adapters.py:684-1089: isinstance checks in AdapterIndex, LinkedAdapter, the parser and
 # the modifiers go by it) and nothing else.  `force_anywhere` (the linked adapter's non-anchored parts, :1166-1183) lets a
 # match start or end anywhere: Where.ANYWHERE, and the search sets of the other side as well -- "force" in the table.
-_Kind = collections.namedtuple("_Kind", "description identifier where reverse remove_before kmer_back kmer_front internal spec")
+_Kind = collections.namedtuple("_Kind", "description identifier where reverse remove_before kmer_back kmer_front internal spec "
+                                        "force_where", defaults=(False,))
 _FORCE = "force"
 
 
@@ -536,7 +537,9 @@ class _TableAdapter(SingleAdapter):
         if self._COMPARER is not None and not self.indels:
             return self._COMPARER(self.sequence, self.max_error_rate, wildcard_ref=self.adapter_wildcards,
                                   wildcard_query=self.read_wildcards, min_overlap=self.min_overlap)
-        where = Where.ANYWHERE if self._force_anywhere else kind.where
+        # (force_anywhere frees the aligner's ends for the regular and rightmost types only; the non-internal and anchored
+        # ones keep their ends and merely search the other side's k-mers as well, reference :944-1089)
+        where = Where.ANYWHERE if (self._force_anywhere and kind.force_where) else kind.where
         return self._make_aligner(self.sequence[::-1] if kind.reverse else self.sequence, where.value)
 
     def _kmer_finder(self):
@@ -550,22 +553,22 @@ class _TableAdapter(SingleAdapter):
 
 class FrontAdapter(_TableAdapter):
     """A 5' adapter (reference adapters.py:684-730)."""
-    _KIND = _Kind("regular 5'", "regular_five_prime", Where.FRONT, False, True, _FORCE, True, True, "{}...")
+    _KIND = _Kind("regular 5'", "regular_five_prime", Where.FRONT, False, True, _FORCE, True, True, "{}...", force_where=True)
 
 
 class RightmostFrontAdapter(FrontAdapter):
     """A 5' adapter that prefers rightmost matches: the reversed adapter on the reversed read (reference :733-789)."""
-    _KIND = _Kind("rightmost 5'", "rightmost_five_prime", Where.BACK, True, True, True, _FORCE, True, "{}...;rightmost")
+    _KIND = _Kind("rightmost 5'", "rightmost_five_prime", Where.BACK, True, True, True, _FORCE, True, "{}...;rightmost", force_where=True)
 
 
 class BackAdapter(_TableAdapter):
     """A 3' adapter (reference adapters.py:792-838)."""
-    _KIND = _Kind("regular 3'", "regular_three_prime", Where.BACK, False, False, True, _FORCE, True, "{}")
+    _KIND = _Kind("regular 3'", "regular_three_prime", Where.BACK, False, False, True, _FORCE, True, "{}", force_where=True)
 
 
 class RightmostBackAdapter(BackAdapter):
     """A 3' adapter that prefers rightmost matches (reference :841-893)."""
-    _KIND = _Kind("rightmost 3'", "rightmost_three_prime", Where.FRONT, True, False, _FORCE, True, True, "{};rightmost")
+    _KIND = _Kind("rightmost 3'", "rightmost_three_prime", Where.FRONT, True, False, _FORCE, True, True, "{};rightmost", force_where=True)
 
 
 class AnywhereAdapter(_TableAdapter):

@@ -40,6 +40,10 @@ def describe(ad):
         "allows_partial_matches": bool(ad.allows_partial_matches),
         "aligner": type(al).__name__, "finder": type(kf).__name__,
     }
+    if type(al).__name__ == "Aligner":
+        # Aligner.__reduce__: (reference, max_error_rate, flags, wildcard_ref, wildcard_query, indel_cost, min_overlap) --
+        # the ends the aligner may skip (force_anywhere frees them for the regular and rightmost types only)
+        out["aligner_args"] = list(al.__reduce__()[1])
     if type(kf).__name__ == "KmerFinder":
         out["kmer_sets"] = [[a, b, sorted(k)] for a, b, k in kf.positions_and_kmers]
         out["kmer_wildcards"] = [bool(kf.ref_wildcards), bool(kf.query_wildcards)]
@@ -61,7 +65,7 @@ def main():
                       "read_wildcards": rng.random() < 0.3, "indels": rng.random() < 0.7, "name": f"n{i}"}
             if rng.random() < 0.5:
                 kwargs["adapter_wildcards"] = rng.random() < 0.5
-            if cls in FORCEABLE and rng.random() < 0.3:
+            if cls in FORCEABLE and rng.random() < 0.45:
                 kwargs["force_anywhere"] = True
             try:
                 ad = getattr(R, cls)(seq, **kwargs)

@@ -48,6 +48,8 @@ def test_adapter_classes_describe_themselves_as_the_reference(cases):
         assert len(ad) == w["len"] and ad.effective_length == w["effective_length"], ctx
         assert bool(ad.allows_partial_matches) == w["allows_partial_matches"], ctx
         assert type(ad.aligner).__name__ == w["aligner"] and type(ad.kmer_finder).__name__ == w["finder"], ctx
+        if "aligner_args" in w:
+            assert list(ad.aligner.__reduce__()[1]) == w["aligner_args"], ctx
         if w["finder"] == "KmerFinder":
             # (the reference collects k-mers in Python sets: the order of the search sets and of their k-mers follows
             # the process's string hashing -- compared as collections)
@@ -64,7 +66,7 @@ def test_adapter_classes_describe_themselves_as_the_reference(cases):
                                     "PrefixAdapter", "SuffixAdapter"}
     assert any(s[1] == "PrefixComparer" for s in seen) and any(s[1] == "SuffixComparer" for s in seen)
     assert indexable >= 8                                    # ... and the index of anchored adapters takes some of them
-    assert sum(1 for s in seen if s[2]) >= 5                 # force_anywhere seen for most of the classes that take it
+    assert sum(1 for s in seen if s[2]) >= 8                 # force_anywhere seen for every class that takes it
 
 
 def test_class_hierarchy_is_the_reference_s():
