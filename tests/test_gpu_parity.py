@@ -323,6 +323,18 @@ def test_golden_adapter_classes(hip, golden):
             got = None if mt is None else {"cls": type(mt).__name__, "t": list(mt.astuple())}
             assert got == want
     assert n >= 2000
+    # the edges of the parameter space (tests/golden/make_adapters_extreme_golden.py: adapters of 1 .. 33 characters, error
+    # rates up to 1.0, min_overlap beyond the adapter, force_anywhere on every class that takes it) through the batch API
+    n = 0
+    for c in golden("adapters_extreme.json")[:120]:
+        adapter = getattr(A, c["cls"])(c["sequence"], **c["kwargs"])
+        bm = adapter.match_to_batch(ReadBatch.from_strings([r for r, _ in c["reads"]]))
+        for i, (read, want) in enumerate(c["reads"]):
+            mt = bm.match(i)
+            got = None if mt is None else {"cls": type(mt).__name__, "t": list(mt.astuple())}
+            assert got == want, (c["cls"], c["sequence"], c["kwargs"], read, got, want)
+            n += 1
+    assert n >= 1500
 
 
 def test_golden_linked_and_multiple(hip, golden):
