@@ -56,7 +56,7 @@ def parse_args(argv=None):
                     help="the same reads copied into a packed buffer with an offsets array: the per-lane kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--check-reads", type=int, default=200_000, help="reads compared with the oracle (untimed)")
+    ap.add_argument("--check-reads", type=int, default=250_000, help="reads compared with the oracle (untimed)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="default run (C2, one GPU) only: do not append the C3 / C4 / C5 lines (other_configs)")
     ap.add_argument("--other-steps", type=int, default=3, help="timed steps of each other_configs entry")
@@ -147,18 +147,40 @@ class Workload:
         else:
             match_batch(self.plans[0], self.batches[0], self.outs[0])
 
-    # ---- parity sample: the first m reads of rank 0, bit-compared with the oracle --------------------
-    def parity(self, m):
+    # ---- parity sample: scattered blocks of rank 0's batch, bit-compared with the oracle -------------
+    def parity_blocks(self, m):
+        """Row ranges [start, start + rows) of the batch that the oracle re-computes: m rows in all, as (up to) five
+        blocks -- the first rows, a block that straddles byte 2^31 of the read buffer, a block that starts behind byte
+        2^32, the middle of the batch, and the LAST rows (last tile, straggler flush).  Blocks the batch is too small
+        for fall away; overlapping ones are merged."""
+        n = self.n
+        from cutadapt_amd import workloads
+        L = workloads.READ_LEN
+        if m >= n:
+            return [(0, n)]
+        rows = max(1, m // 5)
+        wanted = [0, (1 << 31) // L - rows // 2, (1 << 32) // L + 1, n // 2 - rows // 2, n - rows]
+        blocks = []
+        for s in sorted(set(max(0, min(w, n - rows)) for w in wanted if 0 <= w <= n - rows)):
+            if blocks and s < blocks[-1][0] + blocks[-1][1]:
+                end = max(blocks[-1][0] + blocks[-1][1], s + rows)
+                blocks[-1] = (blocks[-1][0], end - blocks[-1][0])
+            else:
+                blocks.append((s, rows))
+        return blocks
+
+    def parity(self, m, first_index=0):
         import numpy as np
         from cutadapt_amd import workloads
         from oracle import host_workloads
         from oracle import oracle as orc
         kind = self.spec["kind"]
-        m = min(m, self.n)
         gen = self.gen
-        checked = []
+        L = workloads.READ_LEN
+        verdicts = {}
 
         def oracle_multi(adapters, seqs, offsets):
+            m = len(offsets) - 1
             want6 = np.zeros((m, 6), dtype=np.int32)
             want_st = np.zeros(m, dtype=np.uint8)
             want_best = np.full(m, -1, dtype=np.int32)
@@ -173,41 +195,55 @@ class Workload:
                 want_st[better] = 1
             return want6, want_st, want_best
 
-        def same(out, want6, want_st, what, want_best=None):
-            ok = np.array_equal(out.out6[:m].cpu().numpy(), want6) and np.array_equal(out.status[:m].cpu().numpy(), want_st)
+        def same(out, s, want6, want_st, what, want_best=None):
+            m = len(want_st)
+            ok = np.array_equal(out.out6[s:s + m].cpu().numpy(), want6) and np.array_equal(out.status[s:s + m].cpu().numpy(), want_st)
             if ok and want_best is not None:
-                ok = np.array_equal(out.best_adapter[:m].cpu().numpy()[want_st == 1], want_best[want_st == 1])
-            checked.append(f"{what}: {'ok' if ok else 'MISMATCH'}")
+                ok = np.array_equal(out.best_adapter[s:s + m].cpu().numpy()[want_st == 1], want_best[want_st == 1])
+            verdicts[what] = verdicts.get(what, True) and ok
             return ok
 
         ok = True
-        for mate, batch in enumerate(self.batches):
-            seqs, offsets = host_workloads.host_reads(self.config, 0, m, mate, gen)
-            if self.ragged == "views":
-                ok &= np.array_equal(batch.seqs[: len(seqs)].cpu().numpy(), seqs)   # generator twin (the parent batch)
-            if self.ragged:
-                seqs, offsets = host_workloads.host_ragged(seqs, offsets, 0)
-            if self.ragged != "views":
-                ok &= np.array_equal(batch.seqs[: len(seqs)].cpu().numpy(), seqs)   # generator twin
-            if kind in ("single", "multi", "paired"):
-                ads = self.adapters if mate == 0 else self.adapters2
-                want6, want_st, want_best = oracle_multi(ads, seqs, offsets)
-                ok &= same(self.outs[mate], want6, want_st, f"mate {mate + 1}" if kind == "paired" else "tuples",
-                           want_best if len(ads) > 1 else None)
-            else:
-                fs = self.front.matcher_spec()
-                ofa = orc.Aligner(fs.sequence, fs.max_error_rate, fs.flags, fs.wildcard_ref, fs.wildcard_query,
-                                  fs.indel_cost, fs.min_overlap)
-                off = orc.KmerFinder(fs.kmer_sets, fs.kmer_ref_wildcards, fs.kmer_query_wildcards) if fs.kmer_sets is not None else None
-                f6, fst = orc.match_batch(ofa, off, seqs, offsets)
-                ok &= same(self.outs[0], f6, fst, "front stage")
-                # back stage on read[rstop:] (reference adapters.py:1222-1224)
-                starts = np.where(fst == 1, f6[:, 3], 0).astype(np.int64)
-                subs = [bytes(seqs[offsets[i] + starts[i]:offsets[i + 1]]) for i in range(m)]
-                s2, o2 = orc.pack_reads(subs)
-                b6, bst, _ = oracle_multi(self.adapters, s2, o2)
-                ok &= same(self.outs[1], b6, bst, "back stage")
-        return ok, f"{'ok' if ok else 'MISMATCH'} ({m} reads{' per mate' if kind == 'paired' else ''} bit-compared with the oracle: {', '.join(checked)})"
+        blocks = self.parity_blocks(m)
+        packed_off = None
+        if self.ragged == "packed":
+            packed_off = self.batches[0].offsets
+        for s, rows in blocks:
+            for mate, batch in enumerate(self.batches):
+                seqs, offsets = host_workloads.host_reads(self.config, first_index + s, rows, mate, gen)
+                if self.ragged == "views":
+                    ok &= np.array_equal(batch.seqs[s * L: s * L + len(seqs)].cpu().numpy(), seqs)   # generator twin (the parent batch)
+                if self.ragged:
+                    seqs, offsets = host_workloads.host_ragged(seqs, offsets, first_index + s)
+                if self.ragged == "packed":
+                    b0 = int(batch.offsets[s].item())
+                    ok &= np.array_equal(batch.seqs[b0: b0 + len(seqs)].cpu().numpy(), seqs)
+                elif not self.ragged:
+                    ok &= np.array_equal(batch.seqs[s * L: s * L + len(seqs)].cpu().numpy(), seqs)   # generator twin
+                if kind in ("single", "multi", "paired"):
+                    ads = self.adapters if mate == 0 else self.adapters2
+                    want6, want_st, want_best = oracle_multi(ads, seqs, offsets)
+                    ok &= same(self.outs[mate], s, want6, want_st, f"mate {mate + 1}" if kind == "paired" else "tuples",
+                               want_best if len(ads) > 1 else None)
+                else:
+                    fs = self.front.matcher_spec()
+                    ofa = orc.Aligner(fs.sequence, fs.max_error_rate, fs.flags, fs.wildcard_ref, fs.wildcard_query,
+                                      fs.indel_cost, fs.min_overlap)
+                    off = orc.KmerFinder(fs.kmer_sets, fs.kmer_ref_wildcards, fs.kmer_query_wildcards) if fs.kmer_sets is not None else None
+                    f6, fst = orc.match_batch(ofa, off, seqs, offsets)
+                    ok &= same(self.outs[0], s, f6, fst, "front stage")
+                    # back stage on read[rstop:] (reference adapters.py:1222-1224)
+                    starts = np.where(fst == 1, f6[:, 3], 0).astype(np.int64)
+                    subs = [bytes(seqs[offsets[i] + starts[i]:offsets[i + 1]]) for i in range(rows)]
+                    s2, o2 = orc.pack_reads(subs)
+                    b6, bst, _ = oracle_multi(self.adapters, s2, o2)
+                    ok &= same(self.outs[1], s, b6, bst, "back stage")
+        total = sum(r for _, r in blocks)
+        where = ", ".join(f"[{s}, {s + r})" for s, r in blocks)
+        checked = ", ".join(f"{k}: {'ok' if v else 'MISMATCH'}" for k, v in verdicts.items())
+        return ok, (f"{'ok' if ok else 'MISMATCH'} ({total} reads{' per mate' if kind == 'paired' else ''} bit-compared with "
+                    f"the oracle in {len(blocks)} blocks of rows {where} of the timed steps' outputs -- byte offsets up to "
+                    f"{(blocks[-1][0] + blocks[-1][1]) * L:,}: {checked})")
 
 
 def csrc_hash() -> str:
@@ -223,6 +259,7 @@ def library_hash() -> str:
 
 
 def profile_fields(config, n, dom, dom_launch_ms):
+    profile_fields.whole_step = None
     """roofline.traffic / roofline.valu from the committed PMC profile (profiles/pmc_latest.json, written by
     profiles/summarize_r03.py) -- only if it was taken on THIS source tree and THIS workload; otherwise null + why."""
     tpath = os.path.join(ROOT, "profiles", "pmc_latest.json")
@@ -241,6 +278,11 @@ def profile_fields(config, n, dom, dom_launch_ms):
     if not k:
         return None, None, "the PMC profile has no entry for the dominant kernel"
     traffic = k.get("hbm_bytes_per_launch")
+    # ... and of the WHOLE step: every kernel family's counter bytes per step (profiles/summarize_r06.py sums every launch
+    # of a family over the profiled steps: hbm_bytes_per_step)
+    per_family = {name: e.get("hbm_bytes_per_step") for name, e in tj.get("kernels", {}).items()}
+    if per_family and all(v is not None for v in per_family.values()):
+        profile_fields.whole_step = {"bytes": sum(per_family.values()), "per_kernel_family": per_family}
     valu = {x: k.get(x) for x in ("kernel_full_name", "valu_busy", "valu_insts_per_launch", "waves_per_simd",
                                   "wait_frac_of_wave_cycles", "issue_stall_frac_of_wave_cycles", "clock_ghz_profiled",
                                   "profiled_ms_per_launch", "salu_insts_per_launch", "lds_insts_per_launch")}
@@ -325,7 +367,7 @@ def run_config(args, config, n, steps, warmup, rank, world, device, gen, check_r
     # ---- untimed parity check against the oracle ---------------------------------------------------
     parity = None
     if check_reads > 0:
-        ok, parity = wl.parity(check_reads)
+        ok, parity = wl.parity(check_reads, rank * n)
         if not ok:
             raise SystemExit(f"{config}: parity check against the oracle FAILED: " + parity)
     del wl
@@ -394,6 +436,10 @@ def run_config(args, config, n, steps, warmup, rank, world, device, gen, check_r
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
+            "whole_step_traffic": None if not profile_fields.whole_step else dict(
+                profile_fields.whole_step, over_algorithmic=profile_fields.whole_step["bytes"] / (n * bytes_per_unit),
+                note="HBM bytes of ALL kernels of one step by the same PMC passes (FETCH_SIZE x 2 + WRITE_SIZE; the x 2 is "
+                     "the guide's gfx950 correction for wide streaming reads and an upper bound for scattered ones)"),
             "valu": valu,
             "profile": profile_note,
             "kernel_ms_per_step": step_ms,
@@ -472,14 +518,14 @@ def main():
             for cfg in ("C3", "C4", "C5"):
                 try:
                     r = run_config(args, cfg, DEFAULT_READS[cfg], args.other_steps, 1, 0, 1, device, gen,
-                                   min(args.check_reads, 200_000),
+                                   args.check_reads,
                                    args.other_cpu_seconds, not args.no_cpu_baseline)
                     others[cfg] = {"metric": r["metric"], "value": r["value"], "unit": r["unit"], "steps": r["steps"],
                                    "ms_per_step": r["ms_per_step"], "workload": r["config"]["workload"],
                                    "parity_check": r["config"]["parity_check"],
                                    "matched_fraction": r["config"]["matched_fraction"],
                                    "matched_fraction_of": r["config"]["matched_fraction_of"],
-                                   "roofline": {k: r["roofline"][k] for k in ("kernel", "achieved", "frac", "traffic",
+                                   "roofline": {k: r["roofline"][k] for k in ("kernel", "achieved", "frac", "traffic", "whole_step_traffic",
                                                                              "kernel_ms_per_step", "launches_per_step",
                                                                              "whole_step_frac", "profile")},
                                    "cpu_baseline": r.get("cpu_baseline"),
@@ -495,7 +541,7 @@ def main():
             for pa in (0.0, 1.0):
                 try:
                     g2 = dict(gen, p_adapter=pa)
-                    r = run_config(args, "C2", DEFAULT_READS["C2"], 2, 1, 0, 1, device, g2, min(args.check_reads, 200_000),
+                    r = run_config(args, "C2", DEFAULT_READS["C2"], 2, 1, 0, 1, device, g2, args.check_reads,
                                    0.0, False)
                     extremes[f"p_adapter_{pa:g}"] = {
                         "value": r["value"], "unit": r["unit"], "steps": r["steps"], "ms_per_step": r["ms_per_step"],
@@ -515,7 +561,7 @@ def main():
             ragged = {}
             for cfg in ("C2", "C4"):
                 try:
-                    r = run_config(args, cfg, DEFAULT_READS[cfg], 2, 1, 0, 1, device, gen, min(args.check_reads, 200_000),
+                    r = run_config(args, cfg, DEFAULT_READS[cfg], 2, 1, 0, 1, device, gen, args.check_reads,
                                    0.0, False, "views")
                     ragged[cfg] = {"value": r["value"], "unit": r["unit"], "steps": r["steps"], "ms_per_step": r["ms_per_step"],
                                    "workload": r["config"]["workload"], "parity_check": r["config"]["parity_check"],

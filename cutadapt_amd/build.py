@@ -12,6 +12,10 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libcutadapt_hip.so")
+# the same sources with -DCAH_DEV_KNOBS: test-only switches (CAH_TEST_M2_UNGATED) the product library does not hold;
+# tests/test_gpu_multi2.py runs it in a process of its own (CAH_LIB_PATH)
+DEV_LIB_PATH = os.path.join(_HERE, "libcutadapt_hip_dev.so")
+DEV_SOURCES = ["api.cpp"]          # the sources that read CAH_DEV_KNOBS: the others' product objects are linked as they are
 SOURCES = ["api.cpp", "kernels.hip", "scan3.hip", "stream2.hip", "multi.hip", "multi2.hip", "long.hip", "fastq_gpu.hip", "synth_kernel.hip", "fastq.cpp", "index.hip", "qualtrim.hip"]
 HEADERS = ["cah_device.h", "kernels.h", "back_scan.h", "dev_common.h", "filter_common.h", "stream2.h", "multi2.h", "revcomp.h", os.path.join("..", "..", "include", "cutadapt_hip.h")]
 ARCH = "gfx950"
@@ -36,14 +40,20 @@ def source_hash() -> str:
     return h.hexdigest()
 
 
+_ID_MARKER = b"CAH_BUILD_ID="
+
+
 def library_build_id(path: str = None) -> str:
-    """the build id embedded in a built library ("" if it cannot be read: missing file, older ABI)"""
-    import ctypes
+    """the build id embedded in a built library ("" if it cannot be read: missing file, older build).  Read from the FILE's
+    bytes (api.cpp puts the marker ``CAH_BUILD_ID=<sha256>`` in front of what cah_build_id() returns), never by loading the
+    library: ctypes does not unload, and the loader hands out the already mapped image for a path it has seen, so a process
+    that had looked at a stale library this way kept running it after the rebuild (advisor, round 5)."""
+    import re
     try:
-        L = ctypes.CDLL(path or LIB_PATH)
-        L.cah_build_id.restype = ctypes.c_char_p
-        return L.cah_build_id().decode()
-    except Exception:
+        with open(path or LIB_PATH, "rb") as fh:
+            m = re.search(_ID_MARKER + rb"([0-9a-f]{64})", fh.read())
+        return m.group(1).decode() if m else ""
+    except OSError:
         return ""
 
 
@@ -65,7 +75,17 @@ def build_library(force: bool = False, verbose: bool = False, extra_flags=None, 
     return _build([], LIB_PATH, verbose, tag="", force=force)
 
 
-def _build(extra_flags, lib_path, verbose, tag, force=False) -> str:
+def build_dev_library(force: bool = False, verbose: bool = False) -> str:
+    """libcutadapt_hip_dev.so: the product's objects, with DEV_SOURCES compiled again under -DCAH_DEV_KNOBS"""
+    build_library(force=force, verbose=verbose)
+    if not force and os.path.exists(DEV_LIB_PATH) and library_build_id(DEV_LIB_PATH) == source_hash() \
+            and os.path.getmtime(DEV_LIB_PATH) >= os.path.getmtime(LIB_PATH):
+        return DEV_LIB_PATH
+    return _build(["-DCAH_DEV_KNOBS"], DEV_LIB_PATH, verbose, tag="_dev", only=DEV_SOURCES)
+
+
+def _build(extra_flags, lib_path, verbose, tag, force=False, only=None) -> str:
+    """only: the sources compiled with extra_flags into _obj<tag>; the others' objects are taken from the product build"""
     objs = []
     obj_dir = os.path.join(_HERE, "csrc", "_obj" + tag)
     os.makedirs(obj_dir, exist_ok=True)
@@ -73,6 +93,9 @@ def _build(extra_flags, lib_path, verbose, tag, force=False) -> str:
     build_id = source_hash()
     newest_header = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS if os.path.exists(os.path.join(CSRC, h)))
     for src in SOURCES:
+        if only is not None and src not in only:
+            objs.append(os.path.join(_HERE, "csrc", "_obj", src + ".o"))
+            continue
         obj = os.path.join(obj_dir, src + ".o")
         objs.append(obj)
         src_path = os.path.join(CSRC, src)
@@ -111,3 +134,5 @@ def _build(extra_flags, lib_path, verbose, tag, force=False) -> str:
 if __name__ == "__main__":
     path = build_library(force="--force" in sys.argv, verbose=True)
     print("built", path)
+    if "--dev" in sys.argv:
+        print("built", build_dev_library(verbose=True))

@@ -822,7 +822,9 @@ int cah_abi_version(void) { return CAH_ABI_VERSION; }
 #ifndef CAH_BUILD_ID
 #define CAH_BUILD_ID "unknown"
 #endif
-const char* cah_build_id(void) { return CAH_BUILD_ID; }
+// (the marker in front lets cutadapt_amd/build.py read the id from the file's bytes without loading the library)
+static const char g_build_id_marker[] = "CAH_BUILD_ID=" CAH_BUILD_ID;
+const char* cah_build_id(void) { return g_build_id_marker + 13; }
 
 void cah_last_error(char* buf, size_t buflen) {
     if (!buf || !buflen) return;
@@ -1082,12 +1084,33 @@ static int64_t m2_pages_worst(int64_t A, int64_t n_reads) {
     return tiles * m2_pages_per_tile(A) + std::min<int64_t>(std::max<int64_t>(tiles, 1), 512) * 16 * CAH_M2_PAIR_CLASSES + 2;
 }
 // pairs the scratch has room for: what the batch can produce in the worst case (every adapter on every read), bounded
-// by CAH_MULTI_PAIR_CAP (default 2 G pairs = 40 GB of scratch on a 288 GB device).  The fused form handles larger
+// by CAH_MULTI_PAIR_CAP (default: default_pair_limit() below -- 2 G pairs = 40 GB on an empty 288 GB device).  The fused form handles larger
 // batches in chunks of cap / n_adapters reads; the streaming form in ROUNDS that end when the pool runs low (a typical
 // batch of 100 M reads x 96 adapters has 0.45 G pairs and takes one).
+// The default bound follows the device: a quarter of the HBM that is FREE when a device's first multi-adapter workspace is
+// sized (20 bytes of scratch per pair), at most 2 G pairs, at least 64 M; asked once per device and kept, because the
+// sizing call (cah_plan_workspace_bytes) and every later match call must agree on the layout.  Without a usable device
+// (the CPU-side tests ask for sizes too) it is 2 G pairs.
+static int64_t default_pair_limit() {
+    static std::mutex mu;
+    static int64_t per_device[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return 2048ll << 20; }
+    std::lock_guard<std::mutex> g(mu);
+    if (!per_device[dev]) {
+        size_t free_b = 0, total_b = 0;
+        int64_t limit = 2048ll << 20;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+            limit = std::min<int64_t>(limit, std::max<int64_t>(64ll << 20, (int64_t)(free_b / 4 / 20)));
+        else (void)hipGetLastError();
+        per_device[dev] = limit;
+    }
+    return per_device[dev];
+}
 static int64_t multi_pair_cap(const cah_plan* plan, int64_t n_reads) {
-    int64_t limit = 2048ll << 20;
+    int64_t limit = 0;
     if (const char* e = getenv("CAH_MULTI_PAIR_CAP")) { const long long v = atoll(e); if (v > 0) limit = v; }
+    if (limit <= 0) limit = default_pair_limit();
     // (the cell DP's work list holds pair indices as int32: the pool never has 2^31 pairs or more, whatever the knob says)
     limit = std::min<int64_t>(limit, ((int64_t)1 << 31) - 4 * CAH_M2_PAGE);
     const int64_t A = (int64_t)plan->matchers.size();
@@ -1500,7 +1523,11 @@ static int match_batch_multi(const cah_plan* plan, const PlanDeviceCopy* pd, con
                 const int64_t sure = std::max<int64_t>(1, (gate - grid * open_pages) / per_tile);
                 rounds = (n_tiles + sure - 1) / sure;
             }
-            if (env_flag("CAH_TEST_M2_UNGATED")) { gate = (int64_t)1 << 60; rounds = 1; }   // tests only: provokes the pool's overflow
+#ifdef CAH_DEV_KNOBS
+            // libcutadapt_hip_dev.so only (cutadapt_amd/build.py: build_dev_library; tests/test_gpu_multi2.py): takes the
+            // gate away to provoke the pool's overflow.  The product library does not hold this switch.
+            if (env_flag("CAH_TEST_M2_UNGATED")) { gate = (int64_t)1 << 60; rounds = 1; }
+#endif
             HIP_TRY(hipMemsetAsync(counters, 0, WS_HEADER, s));
           for (int64_t round = 0;; round++) {
             if (round >= rounds) {

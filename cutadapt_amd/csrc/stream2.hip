@@ -368,10 +368,14 @@ __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a
     const int64_t total = (int64_t)n_reads * n;                         // bytes of the batch
     if (total < 16) return;                                             // (same test there)
     const bool clear0 = a.clear_out6 != nullptr && a.present == nullptr;
-    // CAH_S2_NOMATCH (measurement only): 1 copy, match nothing; 2 ... and no result rows; 3 result rows only, no loads;
-    // 5 everything but the loads (the matching works on stale slot contents: timing only)
+#ifdef CAH_S2_ABLATE
+    // developer builds only (-DCAH_S2_ABLATE; CAH_S2_NOMATCH, measurement only): 1 copy, match nothing; 2 ... and no result
+    // rows; 3 result rows only, no loads; 5 everything but the loads (the matching works on stale slot contents: timing only)
     const bool nomatch = a.max_read_len <= -12345 && a.max_read_len >= -12347;
     const bool noclear = a.max_read_len == -12346 || a.max_read_len == -12348, noload = a.max_read_len == -12347 || a.max_read_len == -12349;   // 4: match, no result rows; 5: match what the slots happen to hold, no loads
+#else
+    constexpr bool nomatch = false, noclear = false, noload = false;     // (the product library has no such switches)
+#endif
     const bool clear = clear0 && !noclear;
 
     // tables (stream2.h: s2_entry); slots a plan does not use hold zeros

@@ -167,7 +167,7 @@ class _Worker:
         self.ee_invalid = torch.zeros((), dtype=torch.bool, device=self.device)  # a quality value outside the phred range seen
         self._ws = None
         self.n = self.n_bytes = 0
-        self.busy_s, self.chunks, self.bytes_in = 0.0, 0, 0   # per-device rates (trim_fastq_gpu's "per_device")
+        self.busy_s, self.chunks, self.bytes_in, self.reads_in = 0.0, 0, 0, 0   # per-device rates (trim_fastq_gpu's "per_device")
         self.stream.wait_stream(torch.cuda.current_stream(self.device))   # (the zeroing / uploads above ran on it)
 
     def _ensure(self, nbytes: int):
@@ -256,6 +256,7 @@ class _Worker:
                                             self.d_scratch.numel(), self.rec6.data_ptr(), self.seq_off.data_ptr(),
                                             self.seq_len.data_ptr(), self.d_info.data_ptr(), sp))
         self.n, self.n_bytes = n, n_bytes
+        self.reads_in += int(n)
         return n
 
     def check_index(self) -> None:
@@ -678,7 +679,7 @@ def _take_worker(plan, kinds, dev, opts) -> "_Worker":
         w.polya_hist.zero_()
         w.ee_invalid.zero_()
     w._ws = None
-    w.busy_s, w.chunks, w.bytes_in = 0.0, 0, 0
+    w.busy_s, w.chunks, w.bytes_in, w.reads_in = 0.0, 0, 0, 0
     return w
 
 
@@ -909,6 +910,7 @@ def _per_device(feeders, wall: float) -> Dict[str, dict]:
         ws = [w for w in f.workers if w is not None]
         nbytes = sum(w.bytes_in for w in ws)
         out[str(f.device)] = {"workers": len(ws), "chunks": sum(w.chunks for w in ws), "bytes_in": int(nbytes),
+                              "reads_in": int(sum(getattr(w, "reads_in", 0) for w in ws)),
                               "GB_per_s_in": nbytes / wall / 1e9 if wall > 0 else 0.0,
                               "busy_fraction": (sum(w.busy_s for w in ws) / (wall * len(ws))) if ws and wall > 0 else 0.0,
                               "cpus": len(f.cpus) if f.cpus else None}

@@ -288,6 +288,9 @@ def test_every_visible_gpu_is_fed(hip, tmp_path):
             per = sa["per_device"]
             assert all(d["chunks"] >= 4 for d in per.values()), per     # round-robin: nobody is left out
             assert sum(d["bytes_in"] for d in per.values()) == len(data)
+            # every device indexed reads of its own, and together they indexed each record once
+            assert all(d["reads_in"] > 0 for d in per.values()), per
+            assert sum(d["reads_in"] for d in per.values()) == 20000 == sa["reads"], per
             assert (sa["reads"], sa["with_adapters"], sa["bp_out"]) == (s1["reads"], s1["with_adapters"], s1["bp_out"])
 
 

@@ -185,31 +185,63 @@ def test_every_adapter_on_every_read_with_a_minimal_pool(hip, orc):
         assert found > 0.9 * n_reads
 
 
+_OVERFLOW_SCRIPT = r"""
+import os, random, sys
+sys.path.insert(0, {root!r})
+sys.path.insert(0, {tests!r})
+import pytest, torch
+from cutadapt_amd import _lib
+from cutadapt_amd.batch import ReadBatch, match_batch
+from test_gpu_multi2 import _near_duplicates, plan_for, rs, env
+prng = random.Random(43)
+seqs = _near_duplicates(prng, rs(prng, 33), 8)
+batch = ReadBatch.synthetic(300_000, 150, seqs, seed=77, p_adapter=0.95, p_edit=0.01, p_n=0.0)
+plan, _ = plan_for(seqs, 0.1, 3)
+assert plan.multi_kind(150) == "stream"
+with env(CAH_MULTI_PAIR_CAP="1"):
+    ok = match_batch(plan, batch)
+    torch.cuda.synchronize()
+    st_ok = ok.status.clone()
+    with env(CAH_TEST_M2_UNGATED="1"):
+        try:
+            match_batch(plan, batch)
+            torch.cuda.synchronize()
+        except _lib.HipInternalError as exc:
+            assert "page pool ran out" in str(exc), exc
+            print("RAISED", "dev" if {dev} else "product")
+        else:
+            print("SERVED", "dev" if {dev} else "product")
+            assert torch.equal(ok.status, st_ok)
+    # the library is not left in a bad state: the next call is served and agrees
+    again = match_batch(plan, batch)
+    torch.cuda.synchronize()
+    assert torch.equal(again.status, st_ok) and torch.equal(again.out6, ok.out6)
+assert int((st_ok == 1).sum()) > 0.8 * 300_000
+print("DONE")
+"""
+
+
 def test_pool_overflow_fails_loudly(hip):
-    """... and when the gate IS taken away (CAH_TEST_M2_UNGATED=1, a test-only knob that lets the blocks draw tiles whatever
-    the pool holds) the call does not return wrong tuples: the kernels flag the page they could not get, match_batch_multi
-    answers CAH_EINTERNAL, the binding raises HipInternalError.  The same batch with the gate in place is served."""
-    import torch
-    from cutadapt_amd import _lib
-    from cutadapt_amd.batch import ReadBatch, match_batch
-    prng = random.Random(43)
-    seqs = _near_duplicates(prng, rs(prng, 33), 8)
-    batch = ReadBatch.synthetic(300_000, 150, seqs, seed=77, p_adapter=0.95, p_edit=0.01, p_n=0.0)
-    plan, _ = plan_for(seqs, 0.1, 3)
-    assert plan.multi_kind(150) == "stream"
-    with env(CAH_MULTI_PAIR_CAP="1"):
-        ok = match_batch(plan, batch)
-        torch.cuda.synchronize()
-        st_ok = ok.status.clone()
-        with env(CAH_TEST_M2_UNGATED="1"):
-            with pytest.raises(_lib.HipInternalError, match="page pool ran out"):
-                match_batch(plan, batch)
-                torch.cuda.synchronize()
-        # the library is not left in a bad state: the next call is served and agrees
-        again = match_batch(plan, batch)
-        torch.cuda.synchronize()
-        assert torch.equal(again.status, st_ok) and torch.equal(again.out6, ok.out6)
-    assert int((st_ok == 1).sum()) > 0.8 * 300_000
+    """... and when the gate IS taken away (CAH_TEST_M2_UNGATED=1, a switch only libcutadapt_hip_dev.so holds -- the same
+    sources under -DCAH_DEV_KNOBS, cutadapt_amd/build.py: build_dev_library -- that lets the blocks draw tiles whatever the
+    pool holds) the call does not return wrong tuples: the kernels flag the page they could not get, match_batch_multi
+    answers CAH_EINTERNAL, the binding raises HipInternalError; the next call is served.  The PRODUCT library ignores the
+    variable (round-5 review: a stray environment variable must not change what the shipped library does)."""
+    import subprocess
+    import sys
+    from cutadapt_amd import build
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert os.path.exists(build.DEV_LIB_PATH), "python -m cutadapt_amd.build --dev"
+    assert build.library_build_id(build.DEV_LIB_PATH) == build.source_hash(), "stale dev library"
+    for dev in (True, False):
+        e = dict(os.environ)
+        e.pop("CAH_LIB_PATH", None)
+        if dev:
+            e["CAH_LIB_PATH"] = build.DEV_LIB_PATH
+        r = subprocess.run([sys.executable, "-c", _OVERFLOW_SCRIPT.format(root=root, tests=os.path.join(root, "tests"), dev=dev)],
+                           env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "DONE" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+        assert ("RAISED dev" if dev else "SERVED product") in r.stdout, r.stdout
 
 
 def test_first_occurrence_race_at_scale(hip, orc):
