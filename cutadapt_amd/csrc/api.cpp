@@ -185,6 +185,8 @@ struct PlanDeviceCopy {
     CahM2Slot* d_m2entries = nullptr;
     uint32_t* d_m2bitmap = nullptr;
     uint32_t* d_m2prefix = nullptr;
+    int32_t* d_m2refbegin = nullptr;
+    uint32_t* d_m2reflist = nullptr;
     std::vector<LongDeviceCopy> d_long;   // one per matcher (null pointers for bare k-mer finders)
     // the one-read kernel's table images ([0]: Aligner.locate, no prefilter; [1]: match_to), built by its first call
     void* d_tiny_image[2] = {nullptr, nullptr};
@@ -269,6 +271,8 @@ static int plan_on_device(const cah_plan* plan, const PlanDeviceCopy** out) {
                 CAH_UPLOAD(dc.d_m2entries, mp.m2.entries)
                 CAH_UPLOAD(dc.d_m2bitmap, mp.m2.bitmap)
                 CAH_UPLOAD(dc.d_m2prefix, mp.m2.prefix)
+                CAH_UPLOAD(dc.d_m2refbegin, mp.m2.ref_begin)
+                CAH_UPLOAD(dc.d_m2reflist, mp.m2.ref_list)
             }
 #undef CAH_UPLOAD
         }
@@ -913,6 +917,8 @@ void cah_plan_destroy(cah_plan* plan) {
         if (dc.d_m2entries) (void)hipFree(dc.d_m2entries);
         if (dc.d_m2bitmap) (void)hipFree(dc.d_m2bitmap);
         if (dc.d_m2prefix) (void)hipFree(dc.d_m2prefix);
+        if (dc.d_m2refbegin) (void)hipFree(dc.d_m2refbegin);
+        if (dc.d_m2reflist) (void)hipFree(dc.d_m2reflist);
         if (dc.d_tiny_image[0]) (void)hipFree(dc.d_tiny_image[0]);
         if (dc.d_tiny_image[1]) (void)hipFree(dc.d_tiny_image[1]);
         for (LongDeviceCopy& ld : dc.d_long) {
@@ -1590,6 +1596,7 @@ static int match_batch_multi(const cah_plan* plan, const PlanDeviceCopy* pd, con
                 a.pairs = d_pairs; a.tab = pd->d_mrow; a.n_adapters = (int32_t)A; a.best_key = d_best_key;
                 a.queue = d_dpq; a.queue_count = counters + WS_DPFRONT; a.queue_count_back = counters + WS_DPBACK;
                 a.win = d_win; a.queue_cap = cap; a.work_counter = counters + WS_DPWORK;
+                a.m2_hdr = pd->d_m2hdr; a.m2_ref_begin = pd->d_m2refbegin; a.m2_ref_list = pd->d_m2reflist;
                 ProfScope ps(s, CAH_PROF_DP, round ? -1 : cnt);
                 HIP_TRY(launch_dp(a, m0.m, true, true, std::min(cap, cnt * A), pd->n_cus, s));
             }

@@ -85,6 +85,11 @@ struct DpArgs {
     const uint64_t* tab;
     int32_t n_adapters;
     unsigned long long* best_key;
+    // Streaming form (multi2.h, round 6): a TAIL pair's match that reaches further back than its error class's last row
+    // is checked against the reference's own tail k-mers before it is merged (m2_ref_present; NULL: no such check)
+    const struct CahMulti2Header* m2_hdr = nullptr;
+    const int32_t* m2_ref_begin = nullptr;
+    const uint32_t* m2_ref_list = nullptr;
 };
 
 #define CAH_MULTI_TAB_STRIDE 33   // 32 entries + 1 of padding: spreads the adapters' tables over the LDS banks

@@ -25,6 +25,8 @@
 #include "back_scan.h"
 #include "dev_common.h"
 #include "filter_common.h"
+#define CAH_M2_NO_HOST
+#include "multi2.h"          // (k_dp_packed<.., true>: the corner check of the streaming form's tail pairs)
 
 #ifndef CAH_DEQUEUE
 #define CAH_DEQUEUE 8             // sub-batches of 64 work items a wave takes per atomic (k_dp, k_comparer, k_anchored_exact)
@@ -1530,6 +1532,7 @@ __global__ __launch_bounds__(256, CAH_DPP_WAVES(ROWS)) void k_dp_packed(DpArgs a
         const int64_t slot = idx < front ? idx : a.queue_cap - 1 - (idx - front);
         int64_t r = 0;
         unsigned tab_base = 0, adapter = 0;
+        bool pair_tail = false;
         if (MULTI) {
             int32_t qi = 0;
             if (valid) qi = a.queue[slot];
@@ -1538,6 +1541,7 @@ __global__ __launch_bounds__(256, CAH_DPP_WAVES(ROWS)) void k_dp_packed(DpArgs a
                 r = (int64_t)(pr >> 32);
                 adapter = (unsigned)(pr >> 8) & 0xFFFFu;
                 tab_base = adapter * CAH_MULTI_TAB_STRIDE;
+                pair_tail = ((unsigned)(pr >> 24) & CAH_M2_PAIR_TAIL) != 0;
             }
         } else if (valid) {
             r = a.queue ? (int64_t)a.queue[slot] : idx;
@@ -1686,7 +1690,17 @@ __global__ __launch_bounds__(256, CAH_DPP_WAVES(ROWS)) void k_dp_packed(DpArgs a
         }
 
         if (MULTI) {
-            if (valid && b_cost != SENT && !invalid)
+            bool merge = valid && b_cost != SENT && !invalid;
+            // Streaming form (multi2.h, head of the file): a TAIL pair was made by OUR k-mer family; the reference's
+            // kmers_present follows for every match whose alignment begins within its error class's last row's reach --
+            // a match that begins further back (insertions in a row near the class's end; rare) is checked against the
+            // reference's own tail k-mers of that adapter
+            if (a.m2_hdr && merge && pair_tail) {
+                const int qs = max(b_origin, 0);
+                if (n - qs > (int)a.m2_hdr->lmax_row[b_refstop])
+                    merge = m2_ref_present(a.m2_ref_list, a.m2_ref_begin[adapter], a.m2_ref_begin[adapter + 1], q, n, a.m2_hdr->ref_span);
+            }
+            if (merge)
                 atomicMax(a.best_key + r, pack_best(b_score, b_cost, (int)adapter, b_refstop, max(b_origin, 0), b_qstop));
         } else if (valid) {
             const bool found = b_cost != SENT && !invalid;

@@ -5,31 +5,38 @@
 // src/cutadapt/adapters.py:1265-1286) = for every adapter `kmers_present(read)` (reference _kmer_finder.pyx:170-257,
 // search sets of kmer_heuristic.py:87-164) and, where true, `Aligner.locate(read)` (_align.pyx:298-587).
 //
-// Two families of k-mers per adapter live in ONE table:
-//   REF   the k-mers of the reference's own search sets with their windows: a (read, adapter) pair exists iff one of
-//         them occurs inside its window -- exactly kmers_present, nothing more, nothing less;
-//   WIDE  our own lossless family, built from the aligner's thresholds alone (pigeonhole): rows of the last column
-//         whose threshold is e (overlap lengths Lmin_e .. Lmax_e) can only be acceptable (_align.pyx:536-572) if one
-//         of the e + 1 consecutive chunks of adapter[0:Lmin_e] occurs unedited at a start position >= n - Lmax_e - e
-//         (the reference's window carries no slack for insertions: n - Lmax_e); a last-row candidate (:496-533) only
-//         if one of the k + 1 chunks of the whole adapter occurs anywhere.  An alignment that contains chunk c
-//         (adapter offset o_c) unedited at read position s starts at column >= s - o_c - e.
-//         With the reference's own chunking (kmer_heuristic.kmer_chunks) the two families share their k-mers; only
-//         the tail windows differ by the e "margin" positions.
-// The WIDE family decides how much of `locate` a pair needs:
-//   class W   some whole-adapter chunk occurs: the cost scan runs from (first hit) - m - k - 1 to the read end;
-//   class hi  no whole-adapter chunk, but a chunk of a tail class with e >= 2: only rows of the last column can be
-//             acceptable and every optimal path to one lies in the last max(Lmax_e + e) columns: the scan starts there;
-//   class lo  only chunks of the tail class e = 1: the same with that class's reach;
-//   none      no WIDE k-mer at all: only rows without error tolerance (overlaps min_overlap .. Lmax_0) can match and
-//             they match exactly or not at all: the prefilter itself compares the read's suffix with the adapter's
-//             prefix and writes the result -- the pair never reaches the scan.
-// The classes are probed in this order (W over the whole read, then hi, lo and the REF-only k-mers over the read's
-// tail), and a pair is emitted at its FIRST REF hit, with the class being probed then: a WIDE hit of a wider class
-// that was a REF hit too would have emitted the pair earlier.  A WIDE k-mer that is not a REF k-mer where it occurs (the
-// margins, or a plan whose search sets were not built by kmer_heuristic) says nothing about kmers_present; it sets the
-// pair's "wide only" bit, and a pair whose bit is set when its first REF hit arrives takes the whole read (class W
-// from column 0): exact whatever the order, just slower -- and rare.
+// Round 6: the table holds OUR lossless family only (WIDE), built from the aligner's thresholds alone (pigeonhole);
+// what the reference's own search sets (REF) add -- a pair exists iff kmers_present -- is PROVEN at plan time to follow
+// from a WIDE hit for every match the aligner can report, except in one corner that the cell DP's epilogue checks by
+// evaluating the reference's sets directly (m2_ref_present).  A plan whose search sets do not have the shape the proof
+// needs (anything kmer_heuristic builds has it) does not take the streaming form (m2_build returns false: the older
+// kernels serve it).
+//   class W   the k + 1 chunks of the whole adapter, anywhere in the read: a last-row candidate (_align.pyx:496-533,
+//             cost <= k) holds one of them unedited.  Condition (i): every one of them is a whole-read k-mer of the
+//             reference's sets too, so a W hit IS a REF hit.
+//   tails     the rows of the last column (_align.pyx:536-572) with threshold e >= 1 form error classes (rows
+//             lmin_e .. lmax_e).  A class is cut into SUB-CLASSES of rows La .. Lb; a row L of a sub-class can only be
+//             acceptable if one of the e + 1 chunks of adapter[0:La] (offset o, q characters) occurs unedited, and it
+//             then STARTS dist = n - s characters before the read's end with L - o - e <= dist <= L - o + e (at most e
+//             insertions / deletions behind it): the entry's window [La - o - e, Lb - o + e].  Longer prefixes give longer
+//             k-mers, narrow windows give few hits: a read of BASELINE's C4 meets ~1.5 tail k-mers instead of the ~6 the
+//             reference's 5- to 7-mers with their windows of 19 .. 33 characters give.  class hi: e >= 2, class lo:
+//             e == 1 (such a pair scans ~22 columns of a 32-row word).
+//             Condition (iv): for every error class the e + 1 chunks of adapter[0:lmin_e] are k-mers of the reference's
+//             sets with windows >= lmax_e.  An acceptable row L (cost c <= e, query_start qs) holds one of THOSE unedited
+//             inside [qs, n), i.e. starting at most n - qs characters before the end: whenever n - qs <= lmax_e the
+//             reference's kmers_present is true for the pair.  A match with n - qs > lmax_e (insertions in a row near
+//             lmax_e) is the corner: the cell DP -- only it reports such a match; the scan's shortcuts are without
+//             insertions -- evaluates the reference's sets of that adapter on that read (m2_ref_present) before it merges.
+//   class E0  rows without tolerance (min_overlap .. lmax0) match exactly or not at all: adapter[0:i] is the read's
+//             suffix.  Groups of rows ia .. ib are found through the k-mer adapter[0:ia] starting ia .. ib characters
+//             before the end, and decided by the suffix compare (m2_exact_tail) in the prefilter itself.  Condition
+//             (iii): for every such row some PREFIX adapter[0:q], q <= i, is a k-mer of the reference's sets with a window
+//             >= i -- the exact match holds it, so kmers_present is true.
+// The classes are probed in this order (W over the whole read, then hi, lo, E0 over the read's tail); a pair is emitted
+// at its FIRST hit with the class being probed then.  A further hit of a pair that exists sets its "again" bit (the
+// `wide` bitset): a whole-read pair that took the window of its one occurrence (CAH_M2_PAIR_PRECISE) falls back to the
+// full window then.
 //
 // Characters: 3 bits each (A 0, C 1, G 2, T 3, either case; anything else 4 = breaks every k-mer, as KmerFinder
 // without wildcards does: _match_tables.py:81-98), the newest character in the lowest bits; ten characters per
@@ -44,7 +51,7 @@
 #endif
 
 #define CAH_M2_SLOTS 4096            // directory slots: home = low 12 bits of the bitmap index -> (first entry, entries)
-#define CAH_M2_MAX_ENTRIES 2048
+#define CAH_M2_MAX_ENTRIES 2304
 #define CAH_M2_MAX_GROUP 15          // entries that may share a home
 #define CAH_M2_BM_WORDS 3072         // presence bitmaps: 64 Kbit for the index class 8 (probed at every character), then
 #define CAH_M2_BM8_WORDS 2048        // 32 Kbit shared by the shorter classes (probed in the tail sweeps only)
@@ -81,21 +88,23 @@ struct CahM2Slot { uint32_t key, meta; };      // one entry = one (k-mer, adapte
 M2_HD uint32_t m2_dir(int begin, int count) { return (uint32_t)begin | ((uint32_t)count << 12); }
 M2_HD int m2_dir_begin(uint32_t d) { return (int)(d & 0xFFFu); }
 M2_HD int m2_dir_count(uint32_t d) { return (int)(d >> 12); }
-// meta: adapter : 8 | q : 4 @8 | cls : 2 @12 | ref_L : 8 @14 | wide_L : 8 @22
-M2_HD uint32_t m2_meta(int adapter, int q, int cls, int ref_L, int wide_L) {
-    return (uint32_t)adapter | ((uint32_t)q << 8) | ((uint32_t)cls << 12) | ((uint32_t)ref_L << 14) | ((uint32_t)wide_L << 22);
+// meta: adapter : 7 | q : 4 @7 | cls : 2 @11 | dlo : 8 @13 | dhi : 8 @21 | precise chunk : 3 @29
+// [dlo, dhi]: the k-mer counts when it starts dlo .. dhi characters before the read's end (class W: 0 .. 255 = anywhere)
+M2_HD uint32_t m2_meta(int adapter, int q, int cls, int dlo, int dhi, int pchunk) {
+    return (uint32_t)adapter | ((uint32_t)q << 7) | ((uint32_t)cls << 11) | ((uint32_t)dlo << 13) | ((uint32_t)dhi << 21) |
+           ((uint32_t)pchunk << 29);
 }
-M2_HD int m2_adapter(uint32_t meta) { return (int)(meta & 255u); }
-M2_HD int m2_q(uint32_t meta) { return (int)((meta >> 8) & 15u); }
-M2_HD int m2_cls(uint32_t meta) { return (int)((meta >> 12) & 3u); }
-M2_HD int m2_ref_L(uint32_t meta) { return (int)((meta >> 14) & 255u); }
-M2_HD int m2_wide_L(uint32_t meta) { return (int)((meta >> 22) & 255u); }
-// A class-W entry whose k-mer is chunk c -- and only that -- of the adapter's k + 1 <= 4 whole-adapter chunks carries
-// CAH_M2_WHOLE - 4 + c as its WIDE window (as good as "the whole read": no read is that long); 1 + c, or 0
-#define CAH_M2_WHOLE_CHUNK0 251
-M2_HD unsigned m2_precise_chunk(uint32_t meta) {
-    const unsigned w = (meta >> 22) & 255u;
-    return (((meta >> 12) & 3u) == 0u && w >= CAH_M2_WHOLE_CHUNK0 && w < 255u) ? w - (CAH_M2_WHOLE_CHUNK0 - 1) : 0u;
+M2_HD int m2_adapter(uint32_t meta) { return (int)(meta & 127u); }
+M2_HD int m2_q(uint32_t meta) { return (int)((meta >> 7) & 15u); }
+M2_HD int m2_cls(uint32_t meta) { return (int)((meta >> 11) & 3u); }
+M2_HD int m2_dlo(uint32_t meta) { return (int)((meta >> 13) & 255u); }
+M2_HD int m2_dhi(uint32_t meta) { return (int)((meta >> 21) & 255u); }
+// A class-W entry whose k-mer is chunk c -- and only that -- of the adapter's k + 1 <= 4 whole-adapter chunks: 1 + c, or 0
+M2_HD unsigned m2_precise_chunk(uint32_t meta) { return meta >> 29; }
+// does the k-mer count when it starts `dist` characters before the end?  (reads of the streaming form have <= 160)
+M2_HD bool m2_in_window(uint32_t meta, int dist) {
+    const unsigned lo = (meta >> 13) & 255u, hi = (meta >> 21) & 255u;
+    return (unsigned)dist - lo <= hi - lo;
 }
 
 // end offset (exclusive) of chunk c when a string of m characters is cut into `chunks` pieces the way m2_chunks does
@@ -123,8 +132,6 @@ M2_HD uint32_t m2_index(uint32_t r, int qc) {
     return ((key ^ (key >> 8)) ^ m2_salt(qc)) & 0xFFFFu;
 }
 M2_HD uint32_t m2_bit(uint32_t idx, int qc) { return qc >= 8 ? idx : CAH_M2_BM8_WORDS * 32u + (idx & 0x7FFFu); }
-// does a k-mer of window L (0: none, CAH_M2_WHOLE: whole read) count when it starts `dist` characters before the end?
-M2_HD bool m2_in_window(int L, int dist) { return L >= CAH_M2_WHOLE_CHUNK0 || (L != 0 && dist <= L); }
 
 struct CahMulti2Header {
     int32_t ok;
@@ -132,19 +139,48 @@ struct CahMulti2Header {
     int32_t lmax0;                 // the largest overlap length without error tolerance (rows min_overlap .. lmax0; 0: none)
     int32_t q_mask[4];             // per class: bit qc set = k-mers of index class qc = min(q, 8) exist
     int32_t span[4];               // classes 1..3: a k-mer of the class starts at most this many characters before the end
-    int32_t open_L[4][9];          // [cls][qc]: the class is probed while dist_min <= open_L (dist_min: as if q == qc)
+    int32_t open_L[4][9];          // [cls][qc]: the largest dhi of the class's entries of that index class (-1: none)
+    int32_t close_L[4][9];         // ... and the smallest dlo
     int32_t win_dist[4];           // classes hi, lo: a pair's scan window starts at column n - win_dist
-    // The tail classes are probed inside the main pass, in the read's last chunks: up to four "slots" = (class, index
-    // class) pairs in class order (hi, lo, then the REF-only k-mers unless short_fixed); a plan that needs more does
-    // not take the streaming form.
+    // The tail classes are probed inside the main pass, in the read's last chunks: one hit MASK per index class that a
+    // tail class uses (<= 4: the probe depends on the index class alone) ...
+    int32_t tm_n;
+    int32_t tm_qc[4];
+    int32_t tm_open[4], tm_close[4];   // a k-mer of the mask's index class starts tm_close .. tm_open characters before the end
+    // ... and, behind the main pass, one EVENT PASS per (class, index class) in class order (hi, lo, E0; <= 8): the hits
+    // of mask tq_mi[j] whose position fits the pass's own window become events of class tq_cls[j]
     int32_t tq_n;
-    int32_t tq_cls[4], tq_qc[4];
-    int32_t tq_open[4];            // a slot is probed at position p while n - p + qc - 1 <= tq_open (open_L of the pair)
-    int32_t short_fixed;           // 1: every REF-only tail k-mer must be the read's last q characters (window = its length)
+    int32_t tq_cls[8], tq_mi[8];
+    int32_t tq_open[8], tq_close[8];
+    // E0 entries that must be the read's last q characters (dlo == dhi == q: the rows below 5) never become events: every
+    // lane looks its own read's end up.  (Measured, round 6: the other E0 entries the same way -- the word shifted by one
+    // and two characters -- cost 560 VALU instructions per 64 reads more than their 0.5 events per read.)
+    int32_t qm_fixed;              // index classes with such entries
     int32_t rows_lo;               // the longest overlap whose threshold is <= 1 (rows a pair of class lo can match)
     int32_t tail_warm;             // characters in front of a sweep's first probe that must be in the word (max q - 1)
     uint32_t n_entries;
+    // the corner the cell DP checks (see the head of this file): row i belongs to an error class that ends at lmax_row[i]
+    int32_t ref_span;              // the widest tail window among the reference's k-mers
+    uint8_t lmax_row[72];
 };
+
+// Is one of the reference's tail k-mers (list entries [begin, end): {code, q | window << 8}; whole-read k-mers are not in
+// the list) inside its window in this read?  KmerFinder.kmers_present restricted to the sets (-L, None)
+// (_kmer_finder.pyx:186-213).  Rare path: plain loops.
+M2_HD bool m2_ref_present(const uint32_t* list, int begin, int end, const uint8_t* read, int n, int span) {
+    uint32_t r = 0x24924924u;
+    int p0 = n - span;
+    if (p0 < 0) p0 = 0;
+    for (int p = p0; p < n; ++p) {
+        r = (r << 3) | m2_code(read[p]);
+        for (int u = begin; u < end; ++u) {
+            const uint32_t code = list[2 * u], qw = list[2 * u + 1];
+            const int q = (int)(qw & 255u), w = (int)(qw >> 8);
+            if (p - q + 1 >= 0 && n - (p - q + 1) <= w && (r & m2_mask(q)) == code) return true;
+        }
+    }
+    return false;
+}
 
 #if !defined(CAH_M2_NO_HOST)
 #include <algorithm>
@@ -158,6 +194,8 @@ struct M2Tables {
     std::vector<CahM2Slot> entries;        // hdr.n_entries, ordered by home
     std::vector<uint32_t> bitmap;          // CAH_M2_BM_WORDS
     std::vector<uint32_t> prefix;          // per adapter: its first 10 characters, 3 bits each, adapter[0] in bits 27..29
+    std::vector<int32_t> ref_begin;        // [n_adapters + 1]: adapter a's tail k-mers of the reference's sets are
+    std::vector<uint32_t> ref_list;        // ref_list[2 * u], u in [ref_begin[a], ref_begin[a + 1]): {code, q | window << 8}
 };
 
 struct M2RefKmer { std::string kmer; int window; };   // window: CAH_M2_WHOLE, or L of the tail set (-L, None)
@@ -184,7 +222,8 @@ inline std::vector<std::string> m2_chunks(const std::string& s, int chunks) {
 // Builds the tables for adapters of ONE shape (length m, thresholds thr_last[0..m] = threshold of row i in the last
 // column, kacc = thr of a last-row candidate, min_overlap).  ref[a]: the reference search sets of adapter a.
 // Returns false (t.hdr.ok = 0) when the plan does not fit: a k-mer longer than CAH_M2_MAXQ, too many entries,
-// non-monotone thresholds, an error-free class longer than a word.
+// non-monotone thresholds, an error-free class longer than a word, or search sets without the properties (i), (iii),
+// (iv) of this file's head.
 inline bool m2_build(const std::vector<std::string>& adapters, const int32_t* thr_last, int kacc, int k, int min_overlap,
                      const std::vector<std::vector<M2RefKmer>>& ref, M2Tables& t) {
     CahMulti2Header& h = t.hdr;
@@ -200,7 +239,8 @@ inline bool m2_build(const std::vector<std::string>& adapters, const int32_t* th
     struct Tail { int e, lmin, lmax; };
     std::vector<Tail> tails;
     int lmax0 = 0;
-    for (int i = std::max(min_overlap, 1); i <= m; i++) {
+    const int row0 = std::max(min_overlap, 1);
+    for (int i = row0; i <= m; i++) {
         const int e = thr_last[i];
         if (e < 0) return false;
         if (e == 0) { lmax0 = i; continue; }
@@ -211,90 +251,141 @@ inline bool m2_build(const std::vector<std::string>& adapters, const int32_t* th
     h.n_adapters = A; h.m = m; h.k = k; h.min_overlap = min_overlap; h.lmax0 = lmax0;
     h.rows_lo = lmax0;
     for (const Tail& tl : tails) if (tl.e == 1) h.rows_lo = tl.lmax;
-    struct Ent { std::string kmer; int adapter; int cls; int ref_L; int wide_L; bool tail_role; };   // tail_role: the k-mer is a tail-class chunk or a REF tail k-mer too
+    for (int i = 0; i < 72; i++) h.lmax_row[i] = 0;
+    for (int i = row0; i <= lmax0; i++) h.lmax_row[i] = (uint8_t)lmax0;
+    for (const Tail& tl : tails) for (int i = tl.lmin; i <= tl.lmax; i++) h.lmax_row[i] = (uint8_t)tl.lmax;
+    // sub-classes of the tail classes (rows La .. Lb) and groups of the error-free rows
+    struct Sub { int e, la, lb; };
+    std::vector<Sub> subs;
+    for (const Tail& tl : tails) {
+        const int rows = tl.lmax - tl.lmin + 1;
+        if (tl.lmax + tl.e >= 240) return false;
+        // (the shortest k-mers -- the first rows of the one-error class -- get the narrowest windows)
+        if (tl.e == 1 && rows >= 8) {
+            const int half = (rows - 2 + 1) / 2;
+            subs.push_back({tl.e, tl.lmin, tl.lmin + 1});
+            subs.push_back({tl.e, tl.lmin + 2, tl.lmin + 2 + half - 1});
+            subs.push_back({tl.e, tl.lmin + 2 + half, tl.lmax});
+        } else if (rows >= 6) {
+            const int half = (rows + 1) / 2;
+            subs.push_back({tl.e, tl.lmin, tl.lmin + half - 1});
+            subs.push_back({tl.e, tl.lmin + half, tl.lmax});
+        } else subs.push_back({tl.e, tl.lmin, tl.lmax});
+    }
+    std::vector<Sub> groups0;
+    for (int i = row0; i <= lmax0;) {
+        const int last = i <= 4 ? i : (i <= 6 ? std::min(6, lmax0) : lmax0);
+        groups0.push_back({0, i, last});
+        i = last + 1;
+    }
+    struct Ent { std::string kmer; int adapter; int cls; int dlo, dhi; };
     std::vector<Ent> ents;
-    auto find = [&](int a, const std::string& s) -> Ent* {
-        for (Ent& e : ents) if (e.adapter == a && e.kmer == s) return &e;
-        return nullptr;
-    };
+    t.ref_begin.assign((size_t)A + 1, 0);
+    t.ref_list.clear();
+    h.ref_span = 0;
     for (int a = 0; a < A; a++) {
         const std::string& ad = adapters[(size_t)a];
         if ((int)ad.size() != m) return false;
+        const std::vector<M2RefKmer>& rf = ref[(size_t)a];
         const size_t first = ents.size();
-        auto add_wide = [&](const std::string& s, int cls, int wide_L) -> bool {
+        auto add = [&](const std::string& s, int cls, int dlo, int dhi) -> bool {
             if (s.empty() || (int)s.size() > CAH_M2_MAXQ) return false;
+            dlo = std::max(dlo, (int)s.size());                         // (a k-mer of q characters starts q or more before the end)
+            if (dhi < dlo) return true;                                 // (never inside the read: no entry)
             for (size_t i = first; i < ents.size(); i++)
-                if (ents[i].kmer == s) {
-                    ents[i].cls = std::min(ents[i].cls, cls);
-                    ents[i].wide_L = std::max(ents[i].wide_L, wide_L);
-                    ents[i].tail_role = ents[i].tail_role || cls != M2_W;
+                if (ents[i].kmer == s && ents[i].cls == cls) {
+                    ents[i].dlo = std::min(ents[i].dlo, dlo);
+                    ents[i].dhi = std::max(ents[i].dhi, dhi);
                     return true;
                 }
-            ents.push_back({s, a, cls, 0, wide_L, cls != M2_W});
+            ents.push_back({s, a, cls, dlo, dhi});
             return true;
         };
-        // a last-row candidate (cost <= kacc) holds one of the k + 1 chunks of the whole adapter
+        auto ref_has = [&](const std::string& s, int window) -> bool {      // a k-mer of the reference's sets with a window >= `window`
+            for (const M2RefKmer& rk : rf)
+                if (rk.kmer == s && (rk.window == CAH_M2_WHOLE || (window != CAH_M2_WHOLE && rk.window >= window))) return true;
+            return false;
+        };
+        // a last-row candidate (cost <= kacc) holds one of the k + 1 chunks of the whole adapter -- (i): a REF k-mer too
         if (min_overlap <= m)
-            for (const std::string& s : m2_chunks(ad, kacc + 1))
-                if (!add_wide(s, M2_W, CAH_M2_WHOLE)) return false;
-        for (const Tail& tl : tails) {
-            if (tl.lmax + tl.e >= CAH_M2_WHOLE - 16) return false;
+            for (const std::string& s : m2_chunks(ad, kacc + 1)) {
+                if (!ref_has(s, CAH_M2_WHOLE)) return false;
+                if (!add(s, M2_W, 0, 255)) return false;
+            }
+        // (iv): the reference's own chunks of every error class, with windows that reach the class's last row
+        for (const Tail& tl : tails)
             for (const std::string& s : m2_chunks(ad.substr(0, (size_t)tl.lmin), tl.e + 1))
-                if (!add_wide(s, tl.e >= 2 ? M2_HI : M2_LO, tl.lmax + tl.e)) return false;
+                if (!ref_has(s, tl.lmax)) return false;
+        for (const Sub& sb : subs) {
+            int o = 0;
+            for (const std::string& s : m2_chunks(ad.substr(0, (size_t)sb.la), sb.e + 1)) {
+                if (!add(s, sb.e >= 2 ? M2_HI : M2_LO, sb.la - o - sb.e, sb.lb - o + sb.e)) return false;
+                o += (int)s.size();
+            }
         }
-        for (const M2RefKmer& rk : ref[(size_t)a]) {
+        // (iii): an exact overlap of i characters holds a prefix of the adapter that the reference looks for there
+        for (int i = row0; i <= lmax0; i++) {
+            bool ok = false;
+            for (const M2RefKmer& rk : rf)
+                if ((int)rk.kmer.size() <= i && ad.compare(0, rk.kmer.size(), rk.kmer) == 0 &&
+                    (rk.window == CAH_M2_WHOLE || rk.window >= i)) ok = true;
+            if (!ok) return false;
+        }
+        for (const Sub& g : groups0)
+            if (!add(ad.substr(0, (size_t)g.la), M2_SHORT, g.la, g.lb)) return false;
+        // the reference's tail k-mers, for m2_ref_present
+        for (const M2RefKmer& rk : rf) {
             if (rk.kmer.empty() || (int)rk.kmer.size() > CAH_M2_MAXQ) return false;
-            if (rk.window != CAH_M2_WHOLE && (rk.window < 1 || rk.window >= CAH_M2_WHOLE - 16)) return false;
-            Ent* e = nullptr;
-            for (size_t i = first; i < ents.size(); i++) if (ents[i].kmer == rk.kmer) e = &ents[i];
-            if (!e) { ents.push_back({rk.kmer, a, M2_SHORT, 0, 0, true}); e = &ents.back(); }
-            if (rk.window != CAH_M2_WHOLE) e->tail_role = true;
-            // (several windows of one k-mer: the widest counts, as the reference's own dedup does, kmer_heuristic.py:29-64)
-            if (rk.window == CAH_M2_WHOLE || e->ref_L == CAH_M2_WHOLE) e->ref_L = CAH_M2_WHOLE;
-            else e->ref_L = std::max(e->ref_L, rk.window);
-            if (e->ref_L == CAH_M2_WHOLE) e->cls = M2_W;        // probed everywhere
+            if (rk.window == CAH_M2_WHOLE) continue;
+            if (rk.window < 1 || rk.window >= 240) return false;
+            const uint32_t code = m2_encode(rk.kmer);
+            if (code & 0x24924924u) return false;                       // not plain ACGT
+            t.ref_list.push_back(code);
+            t.ref_list.push_back((uint32_t)rk.kmer.size() | ((uint32_t)rk.window << 8));
+            h.ref_span = std::max(h.ref_span, rk.window);
         }
+        t.ref_begin[(size_t)a + 1] = (int32_t)(t.ref_list.size() / 2);
     }
-    (void)find;
     if (ents.size() > CAH_M2_MAX_ENTRIES) return false;
     h.n_entries = (uint32_t)ents.size();
     t.dir.assign(CAH_M2_SLOTS, 0);
     t.bitmap.assign(CAH_M2_BM_WORDS, 0u);
     for (int c = 0; c < 4; c++)
-        for (int q = 0; q < 9; q++) h.open_L[c][q] = -1;
+        for (int q = 0; q < 9; q++) { h.open_L[c][q] = -1; h.close_L[c][q] = 1000; }
     int max_q = 1;
-    h.short_fixed = 1;
     struct Placed { uint32_t home, key, meta; };
     std::vector<Placed> placed;
+    int nonfixed_mask[4] = {0, 0, 0, 0};
     for (const Ent& e : ents) {
         const int q = (int)e.kmer.size(), qc = std::min(q, 8);
         const uint32_t code = m2_encode(e.kmer);
         if (code & 0x24924924u) return false;                        // not plain ACGT
         const uint32_t idx = m2_index(code, qc);
         t.bitmap[m2_bit(idx, qc) >> 5] |= 1u << (idx & 31);
-        // which whole-adapter chunk is it?  (no answer when the string is two of them, or occurs elsewhere in the adapter
-        // too: an alignment could then hold the occurrence at another offset)
-        uint8_t wend = 0;
-        // ... and no answer when the string is a chunk of a tail class as well: its occurrence near the read's end then
-        // stands for rows of the last column too, which the window of one occurrence does not look at
-        if (e.cls == M2_W && e.wide_L == CAH_M2_WHOLE && !e.tail_role && kacc + 1 <= 4) {
+        // which whole-adapter chunk is it?  (no answer when the string is two of them or occurs elsewhere in the adapter too:
+        // an alignment could then hold the occurrence at another offset.  A string that is a k-mer of a tail class or an
+        // error-free group as well has an entry of its own there: where its occurrence stands for rows of the last column
+        // too, that entry's event finds the pair made and sets its "again" bit -- the pair then takes its full window)
+        int pchunk = 0;
+        if (e.cls == M2_W && kacc + 1 <= 4) {
             const std::string& ad = adapters[(size_t)e.adapter];
             const std::vector<std::string> ch = m2_chunks(ad, kacc + 1);
             int which = -1, times = 0;
             for (int c = 0; c < (int)ch.size(); c++) if (ch[(size_t)c] == e.kmer) { which = c; times++; }
             int occurrences = 0;
             for (size_t at = ad.find(e.kmer); at != std::string::npos; at = ad.find(e.kmer, at + 1)) occurrences++;
-            if (times == 1 && occurrences == 1) wend = (uint8_t)(1 + which);
+            if (times == 1 && occurrences == 1) pchunk = 1 + which;
         }
-        placed.push_back({idx & (CAH_M2_SLOTS - 1), code,
-                          m2_meta(e.adapter, q, e.cls, e.ref_L, wend ? CAH_M2_WHOLE_CHUNK0 + wend - 1 : e.wide_L)});
+        placed.push_back({idx & (CAH_M2_SLOTS - 1), code, m2_meta(e.adapter, q, e.cls, e.dlo, e.dhi, pchunk)});
         h.q_mask[e.cls] |= 1 << qc;
-        const int reach = std::max(e.ref_L, e.wide_L);
-        h.open_L[e.cls][qc] = std::max(h.open_L[e.cls][qc], reach);
-        if (e.cls != M2_W) h.span[e.cls] = std::max(h.span[e.cls], reach);
+        h.open_L[e.cls][qc] = std::max(h.open_L[e.cls][qc], e.dhi);
+        h.close_L[e.cls][qc] = std::min(h.close_L[e.cls][qc], e.dlo);
+        if (e.cls != M2_W) h.span[e.cls] = std::max(h.span[e.cls], e.dhi);
         max_q = std::max(max_q, q);
-        if (e.cls == M2_SHORT && e.ref_L != q) h.short_fixed = 0;
-        if (e.wide_L && (e.cls == M2_HI || e.cls == M2_LO)) h.win_dist[e.cls] = std::max(h.win_dist[e.cls], e.wide_L + 1);
+        if (e.cls == M2_SHORT) {
+            if (e.dlo == q && e.dhi == q) h.qm_fixed |= 1 << qc; else nonfixed_mask[M2_SHORT] |= 1 << qc;
+        } else if (e.cls != M2_W) nonfixed_mask[e.cls] |= 1 << qc;
+        if (e.cls == M2_HI || e.cls == M2_LO) h.win_dist[e.cls] = std::max(h.win_dist[e.cls], e.dhi + 1);
     }
     std::stable_sort(placed.begin(), placed.end(), [](const Placed& x, const Placed& y) { return x.home < y.home; });
     t.entries.clear();
@@ -310,16 +401,24 @@ inline bool m2_build(const std::vector<std::string>& adapters, const int32_t* th
     h.win_dist[M2_HI] = std::max(h.win_dist[M2_HI], h.win_dist[M2_LO]);
     if (h.win_dist[M2_LO] == 0) h.win_dist[M2_LO] = h.win_dist[M2_HI];
     h.tail_warm = max_q - 1;
-    h.tq_n = 0;
-    for (int c = M2_HI; c <= M2_SHORT; c++) {
-        if (c == M2_SHORT && h.short_fixed) continue;
+    // the probe masks (one per index class) and the event passes (class order: hi, lo, E0) of the tail classes
+    h.tm_n = 0; h.tq_n = 0;
+    for (int c = M2_HI; c <= M2_SHORT; c++)
         for (int q = 1; q <= 8; q++) {
-            if (!((h.q_mask[c] >> q) & 1)) continue;
-            if (h.tq_n == 4) return false;
-            h.tq_cls[h.tq_n] = c; h.tq_qc[h.tq_n] = q; h.tq_open[h.tq_n] = h.open_L[c][q];
+            if (!((nonfixed_mask[c] >> q) & 1)) continue;
+            int mi = -1;
+            for (int j = 0; j < h.tm_n; j++) if (h.tm_qc[j] == q) mi = j;
+            if (mi < 0) {
+                if (h.tm_n == 4) return false;
+                mi = h.tm_n++;
+                h.tm_qc[mi] = q; h.tm_open[mi] = -1; h.tm_close[mi] = 1000;
+            }
+            h.tm_open[mi] = std::max(h.tm_open[mi], h.open_L[c][q]);
+            h.tm_close[mi] = std::min(h.tm_close[mi], h.close_L[c][q]);
+            if (h.tq_n == 8) return false;
+            h.tq_cls[h.tq_n] = c; h.tq_mi[h.tq_n] = mi; h.tq_open[h.tq_n] = h.open_L[c][q]; h.tq_close[h.tq_n] = h.close_L[c][q];
             h.tq_n++;
         }
-    }
     t.prefix.assign((size_t)A, 0u);
     for (int a = 0; a < A; a++) {
         uint32_t p = 0;

@@ -88,7 +88,7 @@ __host__ __device__ inline M2Layout m2_layout(const int n_entries, const int n_a
     L.misc = o; o += 64 + M2_TILE_RING * 8;
     L.entries = o; o += (unsigned)((n_entries + 1) & ~1) * 8;
     L.seen = o; o += M2_WAVES * WAVE * words * 4;
-    L.wide = o; o += M2_WAVES * WAVE * words * 4;
+    L.wide = o; o += M2_WAVES * WAVE * 8;                               // {smallest, largest} adapter + 1 whose pair saw a further hit
     L.total = o;
     return L;
 }
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
     unsigned char* const slot = s_raw + LY.slot + wave * (WAVE * M2_ROW);
     const unsigned char* const row = slot + lane * M2_ROW;
     uint32_t* const s_seen = reinterpret_cast<uint32_t*>(s_raw + LY.seen) + wave * WAVE * words;
-    uint32_t* const s_wide = reinterpret_cast<uint32_t*>(s_raw + LY.wide) + wave * WAVE * words;
+    uint32_t* const s_wide = reinterpret_cast<uint32_t*>(s_raw + LY.wide) + wave * WAVE * 2;   // per read: {min, max} of (adapter + 1) over the pairs with a further hit
     m2_u32x2* const s_ring = reinterpret_cast<m2_u32x2*>(s_raw + LY.ring) + wave * M2_RING;
     uint32_t* const s_rlast = reinterpret_cast<uint32_t*>(s_raw + LY.rlast) + wave * WAVE;
     uint32_t* const s_wmin = s_rlast;                                   // (see resolve_round: until class W is resolved)
@@ -173,6 +173,23 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
     };
     // (LDS keeps what the last block on this CU left: an entry of ITS map must not pass for one of ours)
     if (threadIdx.x < M2_TILE_RING) s_tilemap[threadIdx.x] = ~0ull;
+    // the event passes of the tail classes (multi2.h: tq_*), one packed word each: class | mask << 2 | index class << 4 |
+    // first bit << 8 | last bit << 16 of the pass's positions in its mask (bit b = position tail_base + b; first > last: none)
+    uint32_t* const s_pass = reinterpret_cast<uint32_t*>(s_raw + LY.misc + 16);
+    if (threadIdx.x < 8) {
+        const int j = (int)threadIdx.x;
+        uint32_t pw = (1u << 8);                                        // (first 1, last 0: an empty pass)
+        if (j < hd->tq_n) {
+            int p0 = n;
+            for (int t = 0; t < hd->tm_n; ++t) p0 = min(p0, max(0, n + hd->tm_qc[t] - 1 - hd->tm_open[t]));
+            const int tb = p0 & ~15;
+            const int mi = hd->tq_mi[j], qc = hd->tm_qc[mi], qx = qc < 8 ? qc : CAH_M2_MAXQ;
+            const int b_lo = max(0, n + qc - 1 - hd->tq_open[j]) - tb, b_hi = min(n - 1, n + qx - 1 - hd->tq_close[j]) - tb;
+            if (b_hi >= 0 && b_lo <= 63 && b_hi >= b_lo)
+                pw = (uint32_t)hd->tq_cls[j] | ((uint32_t)mi << 2) | ((uint32_t)qc << 4) | ((uint32_t)max(b_lo, 0) << 8) | ((uint32_t)min(b_hi, 63) << 16);
+        }
+        s_pass[j] = pw;
+    }
     if (threadIdx.x == 0) {
         *s_next_piece = M2_WAVES;
         const unsigned t0 = draw_tile();
@@ -186,13 +203,11 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
     // plan constants (wave-uniform)
     const int m = hd->m, k = hd->k, min_overlap = hd->min_overlap, lmax0 = hd->lmax0;
     const int qmask_w = hd->q_mask[M2_W];
-    const bool short_fixed = hd->short_fixed != 0;
-    // the tail slots (multi2.h): probed in the read's last chunks, resolved class by class behind the main pass
-    const int tq_n = hd->tq_n;
-    int tq_cls[4], tq_qc[4], tq_open[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { tq_cls[j] = hd->tq_cls[j]; tq_qc[j] = hd->tq_qc[j]; tq_open[j] = hd->tq_open[j]; }
-    const int qm_short = hd->q_mask[M2_SHORT];
+    // the tail classes (multi2.h): one hit mask per index class, probed in the read's last chunks; behind the main pass one
+    // event pass per (class, index class) in class order.  Their constants are read from the header where they are used
+    // (scalar loads; the kernel has no SGPR to keep 44 of them in)
+    const int tm_n = hd->tm_n, tq_n = hd->tq_n;
+    const int qm_fixed = hd->qm_fixed;
     constexpr bool w_only8 = W8;
     const unsigned lane16 = (unsigned)lane * 16u;
 
@@ -366,7 +381,7 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
         int u = m2_dir_begin(d);
         int left = m2_dir_count(d);
         const int cls = cur_cls;
-        uint32_t* const sw = s_wide + lr * words;
+        uint32_t* const sw = s_wide + lr * 2;
         uint32_t* const ss = s_seen + lr * words;
         const uint32_t rd = (uint32_t)(a.first_read + piece_first + lr);
         // class and key of the pairs of this round that are not "whole read" pairs
@@ -381,7 +396,6 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
         } else if (cls == M2_HI) { pc_cls = 1; key_cls = max(0, n - a.win_hi) >> 2; flags_cls = CAH_M2_PAIR_TAIL; }
         else if (cls == M2_LO) { pc_cls = 0; key_cls = max(0, n - a.win_lo) >> 2; flags_cls = CAH_M2_PAIR_TAIL; }
         else { pc_cls = 7; key_cls = 0; }                              // REF-only k-mers: the suffix compare decides
-        const int pc_whole = m2_pair_class_w((n + 15) >> 4);
         const unsigned lo_cls = ((unsigned)pc_cls << 28) | (flags_cls << 24) | (unsigned)key_cls;
         unsigned staged = 0;                                            // wave-uniform
         // the staged pairs (at most 64, one per lane) leave: pairs for their class's page, suffix compares to best_key
@@ -408,20 +422,32 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
             staged = 0;
         };
         M2_TOC(12);
+        // An event's home holds the entries of every k-mer that shares its low index bits: the lane walks them once with
+        // the comparisons alone (class, index class, all characters, window -- multi2.h) for its FIRST entry that counts
+        // and the number of further ones; the bitsets, the staging and the ballots below run once per entry that counts
+        // (one for most events, none for a false positive), not once per entry of the home
+        auto entry_ok = [&](const CahM2Slot& e) -> bool {
+            const int q = m2_q(e.meta);
+            return m2_cls(e.meta) == cls && (q < 8 ? q : 8) == qc && (r & m2_mask(q)) == e.key && p - q + 1 >= 0 &&
+                   m2_in_window(e.meta, n - (p - q + 1));
+        };
+        int uf = -1, more = 0;
         while (m2_any(left > 0)) {
             M2_COUNT(11, 1);
             const bool on = left > 0;
             const CahM2Slot e = s_ent[on ? u : 0];
-            const int q = m2_q(e.meta);
-            const bool match = on && m2_cls(e.meta) == cls && (q < 8 ? q : 8) == qc && (r & m2_mask(q)) == e.key;
-            const int dist = n - (p - q + 1);
+            const bool ok = on && entry_ok(e);
+            more += (ok && uf >= 0) ? 1 : 0;
+            uf = (ok && uf < 0) ? u : uf;
+            ++u; --left;
+        }
+        while (m2_any(uf >= 0)) {
+            const bool is_ref = uf >= 0;
+            const CahM2Slot e = s_ent[is_ref ? uf : 0];
             const int adapter = m2_adapter(e.meta);
             const unsigned bit = 1u << (adapter & 31);
             const int word = adapter >> 5;
-            const bool is_ref = match && m2_in_window(m2_ref_L(e.meta), dist);
-            const bool wide_only = match && !is_ref && m2_in_window(m2_wide_L(e.meta), dist);
-            // (both bitsets are touched by every lane: a zero changes nothing, and no lane branches)
-            atomicOr(sw + word, wide_only ? bit : 0u);
+            // (the bitset is touched by every lane: a zero changes nothing, and no lane branches)
             const unsigned old = atomicOr(ss + word, is_ref ? bit : 0u);
             const bool emit = is_ref && (old & bit) == 0;
             const bool again = is_ref && (old & bit) != 0;              // a further hit of a pair that exists
@@ -430,16 +456,15 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
                 const unsigned c = (unsigned)__popcll(em);
                 if (staged + c > 64u) flush();
                 if (emit) {
-                    const bool whole = (sw[word] & bit) != 0;
                     // (a whole-read pair whose occurrence is ONE chunk of the adapter's k + 1 -- CAH_M2_PAIR_PRECISE, multi2.h --
                     // carries the occurrence's position and chunk index instead of the round's key and goes to the pages of
                     // the short windows: k_multi_scan orders a page's pairs by their windows)
 #if defined(M2_ABL) && (M2_ABL & 8)
                     const unsigned we = 0u;                             // developer build: no pair takes the window of its one occurrence
 #else
-                    const unsigned we = (cls == M2_W && !whole) ? m2_precise_chunk(e.meta) : 0u;
+                    const unsigned we = cls == M2_W ? m2_precise_chunk(e.meta) : 0u;
 #endif
-                    unsigned lo = whole ? ((unsigned)pc_whole << 28) : lo_cls;
+                    unsigned lo = lo_cls;
                     if (we) lo = (2u << 28) | ((CAH_M2_PAIR_PRECISE | ((we - 1u) << CAH_M2_PAIR_CHUNK_SHIFT)) << 24) | (unsigned)p;
                     lo |= (unsigned)adapter << 8;
                     s_ring[(stage0 + staged + m2_rank(em)) & (M2_RING - 1)] = (m2_u32x2){lo, rd};
@@ -448,11 +473,11 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
             }
             // (behind the emission: a pair emitted by this very instruction reads its "wide" bit before a further hit of
             // the same round sets it -- seen & wide at the end of the piece = the pair saw more than its first hit)
-#if defined(M2_ABL) && (M2_ABL & 64)
-            atomicOr(sw + word, again ? bit : 0u);
-#elif !(defined(M2_ABL) && (M2_ABL & 16))
+#if !(defined(M2_ABL) && (M2_ABL & 16))
             if (m2_any(again)) {
-                atomicOr(sw + word, again ? bit : 0u);
+                // (which pairs of the read saw a further hit: the smallest and the largest adapter say "none", "this one" or
+                // "several" -- all k_multi_scan asks)
+                if (again) { atomicMin(sw, (unsigned)adapter + 1u); atomicMax(sw + 1, (unsigned)adapter + 1u); }
                 // ... and where: the lane that emitted the pair need not hold its EARLIEST occurrence of the round (the lanes
                 // race for the `seen` bit), so the full window such a pair falls back to starts at the earliest of its own
                 // position and the read's further whole-read hits (s_wmin: the read's slot of s_rlast, free until class W is
@@ -460,7 +485,18 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
                 if (cls == M2_W && again) atomicMin(s_wmin + lr, (unsigned)p);
             }
 #endif
-            ++u; --left;
+            // the lane's next entry that counts (adapters that share the k-mer: rare)
+            bool need = is_ref && more > 0;
+            more -= need ? 1 : 0;
+            int un = uf + 1;
+            uf = need ? uf : -1;
+            while (m2_any(need)) {
+                const CahM2Slot e2 = s_ent[need ? un : 0];
+                const bool ok2 = need && entry_ok(e2);
+                uf = ok2 ? un : uf;
+                need = need && !ok2;
+                ++un;
+            }
         }
         M2_TOC(13);
         if (staged) flush();
@@ -488,14 +524,18 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
         return ((s_bm[m2_bit(idx, qc) >> 5] >> (idx & 31)) & 1u) != 0;
     };
 
-    // first position each tail slot is probed at, the first chunk that holds one (tail_base), and where that chunk
-    // sits in the slot's row (the launcher checked: behind the first half-row, at most four chunks to the read's end)
-    int tq_plo[4];
+    // first / last position each tail mask is probed at (a k-mer of index class qc that ends at p starts n - p + q - 1
+    // characters before the end, q = qc -- or up to CAH_M2_MAXQ for index class 8), the first chunk that holds one
+    // (tail_base), and where that chunk sits in the slot's row (the launcher checked: behind the first half-row, at most
+    // four chunks to the read's end)
+    int tm_plo[4], tm_phi[4];
     int tail_p0 = n;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        tq_plo[j] = j < tq_n ? max(0, n + tq_qc[j] - 1 - tq_open[j]) : n;
-        tail_p0 = min(tail_p0, tq_plo[j]);
+        const int qc = hd->tm_qc[j], qx = qc < 8 ? qc : CAH_M2_MAXQ;
+        tm_plo[j] = j < tm_n ? max(0, n + qc - 1 - hd->tm_open[j]) : n;
+        tm_phi[j] = j < tm_n ? min(n - 1, n + qx - 1 - hd->tm_close[j]) : -1;
+        tail_p0 = min(tail_p0, tm_plo[j]);
     }
     const int tail_base = tail_p0 & ~15;
     const int tail_off = H2 > 0 ? 16 * H1 : 0;                          // first position of the last half-row
@@ -513,7 +553,8 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
         M2_STAMP(0);
         if (more) {
             // ---- per-read state
-            for (int w = 0; w < words; ++w) { s_seen[lane * words + w] = 0; s_wide[lane * words + w] = 0; }
+            for (int w = 0; w < words; ++w) s_seen[lane * words + w] = 0;
+            s_wide[2 * lane] = 0xFFFFFFFFu; s_wide[2 * lane + 1] = 0u;
             s_wmin[lane] = 255u;
             uint32_t r = 0x24924924u;                                   // ten characters that match nothing
             uint32_t r_prev = r;                                        // the word five characters in front of the chunk (the chunk before's twelfth)
@@ -591,11 +632,12 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
                             keep[0] = r_prev; keep[1] = rr5; keep[2] = r;
                         }
 #pragma unroll 1
-                        for (int j = 0; j < tq_n; ++j) {
-                            // (the slot's constants by a chain of scalar selects: the loop stays rolled, ONE copy of the probes)
-                            const int qc = j == 0 ? tq_qc[0] : (j == 1 ? tq_qc[1] : (j == 2 ? tq_qc[2] : tq_qc[3]));
-                            const int plo = j == 0 ? tq_plo[0] : (j == 1 ? tq_plo[1] : (j == 2 ? tq_plo[2] : tq_plo[3]));
-                            if (pos + 16 <= plo) continue;                                 // wave-uniform
+                        for (int j = 0; j < tm_n; ++j) {
+                            // (the mask's constants by a chain of scalar selects: the loop stays rolled, ONE copy of the probes)
+                            const int qc = hd->tm_qc[j];
+                            const int plo = j == 0 ? tm_plo[0] : (j == 1 ? tm_plo[1] : (j == 2 ? tm_plo[2] : tm_plo[3]));
+                            const int phi = j == 0 ? tm_phi[0] : (j == 1 ? tm_phi[1] : (j == 2 ? tm_phi[2] : tm_phi[3]));
+                            if (pos + 16 <= plo || pos > phi) continue;                    // wave-uniform
                             unsigned h16 = 0;
                             if (w_only8 && qc == 8) {
                                 h16 = hits;                                                // the main pass's own probe
@@ -616,6 +658,7 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
                                     h16 |= ((wd2[t] >> (idx & 31)) & 1u) << t;
                                 }
                             }
+                            if (phi - pos < 15) h16 &= (2u << (phi - pos)) - 1u;          // positions behind the mask's last
                             const int lo_t = plo - pos;
                             if (lo_t > 0) h16 &= ~((1u << lo_t) - 1u);
                             if (pos + 16 > n) h16 &= (1u << (n - pos)) - 1u;
@@ -657,20 +700,26 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
             const unsigned w_again_chunk = s_wmin[lane] >> 4;           // chunk of the read's earliest further whole-read hit (15: none)
             s_rlast[lane] = rlast;
             M2_STAMP(5);
-            // ---- the tail slots' hits become events, class by class (hi, lo, REF-only), each class resolved before the next
+            // ---- the tail masks' hits become events, pass by pass in class order (hi, lo, E0), each class resolved before
+            // the next: a pass takes the hits of its index class's mask whose positions fit ITS window
             {
                 int prev_cls = M2_W;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (j >= tq_n) continue;                            // wave-uniform
-                    if (tq_cls[j] != prev_cls) {
+#pragma unroll 1
+                for (int j = 0; j < tq_n; ++j) {
+                    const uint32_t pw = __builtin_amdgcn_readfirstlane(s_pass[j]);
+                    const int pcls = (int)(pw & 3u), mi = (int)((pw >> 2) & 3u), qc = (int)((pw >> 4) & 15u);
+                    const int b_lo = (int)((pw >> 8) & 255u), b_hi = (int)((pw >> 16) & 255u);
+                    if (b_hi < b_lo) continue;                                             // wave-uniform: no position of the pass is in the read
+                    if (pcls != prev_cls) {
                         drain();
-                        M2_STAMP(4 + tq_cls[j]);
-                        prev_cls = tq_cls[j];
-                        cur_cls = prev_cls;
+                        M2_STAMP(4 + pcls);
+                        prev_cls = pcls;
+                        cur_cls = pcls;
                     }
-                    unsigned long long mk = tm[j];
-                    const int qc = tq_qc[j];
+                    unsigned long long mk = mi == 0 ? tm[0] : (mi == 1 ? tm[1] : (mi == 2 ? tm[2] : tm[3]));
+                    // positions of the pass as bits of the mask (bit b = position tail_base + b)
+                    if (b_lo > 0) mk &= ~0ull << b_lo;
+                    if (b_hi < 63) mk &= (2ull << b_hi) - 1ull;
                     while (m2_any(mk != 0ull)) {
                         const bool mine = mk != 0ull;
                         const int bit = mine ? (int)__builtin_ctzll(mk) : 0;
@@ -690,16 +739,15 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
                 drain();
                 M2_STAMP(8);
             }
-            if (qm_short && short_fixed) {
+            if (qm_fixed) {
                 cur_cls = M2_SHORT;
-                // REF-only k-mers that must be the read's last q characters (kmer_heuristic's sets for overlaps below 5):
-                // every lane looks its own read up -- no events, no atomics on the bitsets (all other classes are
-                // resolved), and the suffix compares of a read merge into ONE best key
+                // E0 k-mers that must be the read's last q characters (overlaps below 5): every lane looks its own read up --
+                // no events, no atomics on the bitsets (all other classes are resolved), and the suffix compares of a read
+                // merge into ONE best key
                 unsigned long long bestk = 0;
                 uint32_t* const ss = s_seen + lane * words;
-                const uint32_t* const sw = s_wide + lane * words;
 #pragma unroll 1
-                for (int qrest = qm_short; qrest; qrest &= qrest - 1) {
+                for (int qrest = qm_fixed; qrest; qrest &= qrest - 1) {
                     const int qc = __builtin_ctz((unsigned)qrest);
                     const bool h = valid && probe(rlast, qc);
                     const uint32_t d = h ? (uint32_t)s_dir[m2_index(rlast, qc) & (CAH_M2_SLOTS - 1)] : 0u;
@@ -709,42 +757,29 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
                         const CahM2Slot e = s_ent[on ? u : 0];
                         const int q = m2_q(e.meta);
                         const bool match = on && m2_cls(e.meta) == M2_SHORT && (q < 8 ? q : 8) == qc && q <= n &&
-                                           (rlast & m2_mask(q)) == e.key;
+                                           m2_in_window(e.meta, q) && (rlast & m2_mask(q)) == e.key;
                         const int adapter = m2_adapter(e.meta);
                         const unsigned bit = 1u << (adapter & 31);
                         const int word = adapter >> 5;
                         const unsigned old = ss[word];
-                        const bool fresh = match && (old & bit) == 0;
-                        const bool whole = fresh && (sw[word] & bit) != 0;
-                        if (fresh && !whole) {
+                        if (match && (old & bit) == 0) {
                             ss[word] = old | bit;
                             const int i = m2_exact_tail(rlast, s_prefix[adapter], min_overlap, lmax0, n);
                             const unsigned long long kk = i > 0 ? pack_best(i, 0, adapter, i, n - i, n) : 0ull;
                             bestk = kk > bestk ? kk : bestk;
                         }
-                        // (a WIDE-only hit came first: the pair takes the whole read -- through the general path)
-                        const unsigned long long mw = __ballot(whole);
-                        if (mw) push_events(mw, whole, rlast & 0x3FFFFFFFu, n - 1, qc);
                         ++u; --left;
                     }
                 }
                 if (bestk) atomicMax(a.best_key + (a.first_read + base + lane), bestk);
-                drain();
             }
             // the read's flagged adapter (every class is resolved): what k_multi_scan asks before it trusts the window of
             // a CAH_M2_PAIR_PRECISE pair
 #if !(defined(M2_ABL) && (M2_ABL & 32))
             if (valid) {
-                const uint32_t* const ss = s_seen + lane * words;
-                const uint32_t* const sw = s_wide + lane * words;
-                unsigned cnt = 0, which = 0;
-                for (int w = 0; w < words; ++w) {
-                    const uint32_t f = ss[w] & sw[w];
-                    cnt += (unsigned)__popc(f);
-                    if (f) which = (unsigned)(32 * w) + (unsigned)__builtin_ctz(f);
-                }
+                const unsigned alo = s_wide[2 * lane], ahi = s_wide[2 * lane + 1];
                 a.wmeta[a.first_read + base + lane] =
-                    (uint16_t)((cnt == 0 ? CAH_M2_NO_FLAG : (cnt == 1 ? which : CAH_M2_MANY_FLAGS)) | (w_again_chunk << 8));
+                    (uint16_t)((ahi == 0u ? CAH_M2_NO_FLAG : (alo == ahi ? ahi - 1u : CAH_M2_MANY_FLAGS)) | (w_again_chunk << 8));
             }
 #endif
             if (valid && (seen_chars & 0x80808080u) != 0) a.status[a.first_read + base + lane] = 2;
@@ -1109,7 +1144,7 @@ bool multi2_read_len_ok(const CahMulti2Header& h, int n) {
     // the tail slots are probed in the last chunks of the last half-row: every slot's first position must lie in it,
     // and at most four chunks (the slots' hit masks are 64 bits) reach from there to the read's end
     int p0 = n;
-    for (int j = 0; j < h.tq_n; j++) p0 = std::min(p0, std::max(0, n + h.tq_qc[j] - 1 - h.tq_open[j]));
+    for (int j = 0; j < h.tm_n; j++) p0 = std::min(p0, std::max(0, n + h.tm_qc[j] - 1 - h.tm_open[j]));
     const int tail_base = p0 & ~15;
     if (tail_base < tail_off || n - tail_base > 64) return false;
     return true;

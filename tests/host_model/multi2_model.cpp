@@ -43,15 +43,11 @@ void resolve(const M2Tables& t, ReadState& st, uint32_t r, int qc, int cls, int 
         if (m2_cls(meta) != cls || std::min(q, 8) != qc || (r & m2_mask(q)) != e.key) continue;
         const int dist = n - (p - q + 1);
         const int a = m2_adapter(meta);
-        if (!m2_in_window(m2_ref_L(meta), dist)) {
-            if (m2_in_window(m2_wide_L(meta), dist)) st.wideonly[a] = true;
-            continue;
-        }
-        // (a further hit of a pair that exists: the kernel sets the pair's "wide" bit -- seen & wide = flagged)
+        if (p - q + 1 < 0 || !m2_in_window(meta, dist)) continue;
+        // (a further hit of a pair that exists: the kernel sets the pair's "again" bit -- seen & again = flagged)
         if (st.seen[a]) { st.wideonly[a] = true; continue; }
         st.seen[a] = true;
-        if (st.wideonly[a]) { st.pairs.push_back({a, 0u, 0}); st.conservative++; }
-        else if (cls == M2_W && m2_precise_chunk(meta))
+        if (cls == M2_W && m2_precise_chunk(meta))
             st.pairs.push_back({a, CAH_M2_PAIR_PRECISE | ((m2_precise_chunk(meta) - 1u) << CAH_M2_PAIR_CHUNK_SHIFT), p});
         else if (cls == M2_W) st.pairs.push_back({a, 0u, std::min((p & ~15) >> CAH_KEY_SHIFT, CAH_QUEUE_BINS - 1)});
         else if (cls == M2_HI) st.pairs.push_back({a, CAH_M2_PAIR_TAIL, std::max(0, n - h.win_dist[M2_HI]) >> 2, M2_HI});
@@ -71,21 +67,35 @@ void filter_read(const M2Tables& t, const uint8_t* q, int n, ReadState& st) {
     uint32_t r = 0x24924924u;                                         // ten invalid characters
     for (int p = 0; p < n; p++) { r = (r << 3) | m2_code(q[p]); rr[(size_t)p] = r; }
     const uint32_t rlast = n > 0 ? rr[(size_t)n - 1] : 0x24924924u;
-    for (int cls = 0; cls < 4; cls++) {
-        if (!h.q_mask[cls]) continue;
-        const int from = cls == M2_W ? 0 : std::max(0, n - h.span[cls]);
-        for (int p = from; p < n; p++) {
-            for (int qc = 1; qc <= 8; qc++) {
-                if (!((h.q_mask[cls] >> qc) & 1)) continue;
-                const int dist_min = n - p + qc - 1;
-                if (dist_min > h.open_L[cls][qc]) continue;
-                const uint32_t idx = m2_index(rr[(size_t)p], qc);
-                if (!((t.bitmap[m2_bit(idx, qc) >> 5] >> (idx & 31)) & 1u)) continue;
-                if (cls == M2_W && st.first < 0) st.first = p & ~15;
-                st.events[cls]++;
-                resolve(t, st, rr[(size_t)p], qc, cls, p, n, rlast);
-            }
+    auto probe = [&](int p, int qc) {
+        const uint32_t idx = m2_index(rr[(size_t)p], qc);
+        return ((t.bitmap[m2_bit(idx, qc) >> 5] >> (idx & 31)) & 1u) != 0;
+    };
+    // class W: every position, every index class of the class
+    for (int p = 0; p < n; p++)
+        for (int qc = 1; qc <= 8; qc++) {
+            if (!((h.q_mask[M2_W] >> qc) & 1) || !probe(p, qc)) continue;
+            if (st.first < 0) st.first = p & ~15;
+            st.events[M2_W]++;
+            resolve(t, st, rr[(size_t)p], qc, M2_W, p, n, rlast);
         }
+    // the tail classes: the event passes in class order, each over the positions its window opens (the kernel probes a
+    // mask per index class over the union of its passes' windows and hands every pass the hits inside its own)
+    for (int j = 0; j < h.tq_n; j++) {
+        const int cls = h.tq_cls[j], qc = h.tm_qc[h.tq_mi[j]];
+        const int qx = qc < 8 ? qc : CAH_M2_MAXQ;                      // the longest k-mer of the index class
+        const int plo = std::max(0, n + qc - 1 - h.tq_open[j]), phi = std::min(n - 1, n + qx - 1 - h.tq_close[j]);
+        for (int p = plo; p <= phi; p++) {
+            if (!probe(p, qc)) continue;
+            st.events[cls]++;
+            resolve(t, st, rr[(size_t)p], qc, cls, p, n, rlast);
+        }
+    }
+    // E0 entries that must be the read's last q characters: every read looks its own end up
+    for (int qc = 1; qc <= 8; qc++) {
+        if (!((h.qm_fixed >> qc) & 1) || n < 1 || !probe(n - 1, qc)) continue;
+        st.events[M2_SHORT]++;
+        resolve(t, st, rlast, qc, M2_SHORT, n - 1, n, rlast);
     }
 }
 
@@ -250,8 +260,17 @@ int m2m_match_batch(const char* adapters, int A, int m, const void* blobs, int32
                 if (tail) o0 = std::max(0, (jfa >= 0 ? jfa : n) - reach);
                 int t6[6];
                 if (stats) { stats[6]++; stats[12 + (tail ? (is_lo ? 2 : 1) : (precise ? 3 : 0))]++; }
-                if (dp_window(mt, q, n, o0, std::min(n, o1 >> 1), (o1 & 1) != 0, t6))
-                    key = pack_best(t6[4], t6[5], pr.adapter, t6[1], t6[2], t6[3]);
+                if (dp_window(mt, q, n, o0, std::min(n, o1 >> 1), (o1 & 1) != 0, t6)) {
+                    // the corner of multi2.h's head: a tail pair's match that reaches further back than its error class's
+                    // last row -- is the reference's kmers_present true for the pair?
+                    bool ref_ok = true;
+                    static const bool no_refcheck = getenv("M2M_NO_REFCHECK") != nullptr;     // (to show that the tests need the check)
+                    if (tail && !no_refcheck && n - t6[2] > (int)t.hdr.lmax_row[t6[1]]) {
+                        ref_ok = m2_ref_present(t.ref_list.data(), t.ref_begin[(size_t)pr.adapter], t.ref_begin[(size_t)pr.adapter + 1], q, n, t.hdr.ref_span);
+                        if (stats) stats[15]++;
+                    }
+                    if (ref_ok) key = pack_best(t6[4], t6[5], pr.adapter, t6[1], t6[2], t6[3]);
+                }
             }
             // the error-free overlap of a pair without a candidate in its window
             if (precise && cls == BS_NONE && tail0 > 0) key = pack_best(tail0, 0, pr.adapter, tail0, n - tail0, n);
