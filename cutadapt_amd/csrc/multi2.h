@@ -52,7 +52,7 @@
 
 #define CAH_M2_SLOTS 4096            // directory slots: home = low 12 bits of the bitmap index -> (first entry, entries)
 #define CAH_M2_MAX_ENTRIES 2304
-#define CAH_M2_MAX_GROUP 15          // entries that may share a home
+#define CAH_M2_MAX_GROUP 15          // the directory's count field saturates here: a home with more entries is walked to its end (m2_home_of)
 #define CAH_M2_BM_WORDS 3072         // presence bitmaps: 64 Kbit for the index class 8 (probed at every character), then
 #define CAH_M2_BM8_WORDS 2048        // 32 Kbit shared by the shorter classes (probed in the tail sweeps only)
 #define CAH_M2_MAXQ 10
@@ -130,6 +130,12 @@ M2_HD uint32_t m2_salt(int qc) { return (uint32_t)(8 - qc) * 0x1D3Bu; }
 M2_HD uint32_t m2_index(uint32_t r, int qc) {
     const uint32_t key = r & m2_mask(qc);
     return ((key ^ (key >> 8)) ^ m2_salt(qc)) & 0xFFFFu;
+}
+// the home of an entry (from its own k-mer): the entries of a home are consecutive, and a home with CAH_M2_MAX_GROUP or more
+// of them -- adapters that share their k-mers -- is walked while this stays the event's home
+M2_HD uint32_t m2_home_of(uint32_t key, uint32_t meta) {
+    const int q = (int)((meta >> 7) & 15u);
+    return m2_index(key, q < 8 ? q : 8) & (CAH_M2_SLOTS - 1);
 }
 M2_HD uint32_t m2_bit(uint32_t idx, int qc) { return qc >= 8 ? idx : CAH_M2_BM8_WORDS * 32u + (idx & 0x7FFFu); }
 
@@ -392,8 +398,7 @@ inline bool m2_build(const std::vector<std::string>& adapters, const int32_t* th
     for (size_t i = 0; i < placed.size();) {
         size_t j = i;
         while (j < placed.size() && placed[j].home == placed[i].home) j++;
-        if (j - i > CAH_M2_MAX_GROUP) return false;
-        t.dir[placed[i].home] = (uint16_t)m2_dir((int)i, (int)(j - i));
+        t.dir[placed[i].home] = (uint16_t)m2_dir((int)i, (int)std::min<size_t>(j - i, CAH_M2_MAX_GROUP));
         for (size_t u = i; u < j; u++) t.entries.push_back(CahM2Slot{placed[u].key, placed[u].meta});
         i = j;
     }

@@ -441,6 +441,23 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
             uf = (ok && uf < 0) ? u : uf;
             ++u; --left;
         }
+        {
+            // (a home's count saturates at CAH_M2_MAX_GROUP -- adapters that share their k-mers: such a home is walked while
+            // the entries are its own)
+            bool sat = have && m2_dir_count(d) == CAH_M2_MAX_GROUP;
+            if (m2_any(sat)) {
+                const uint32_t home = m2_index(r, qc) & (CAH_M2_SLOTS - 1);
+                while (m2_any(sat)) {
+                    const bool in = sat && u < n_entries;
+                    const CahM2Slot e = s_ent[in ? u : 0];
+                    sat = in && m2_home_of(e.key, e.meta) == home;
+                    const bool ok = sat && entry_ok(e);
+                    more += (ok && uf >= 0) ? 1 : 0;
+                    uf = (ok && uf < 0) ? u : uf;
+                    ++u;
+                }
+            }
+        }
         while (m2_any(uf >= 0)) {
             const bool is_ref = uf >= 0;
             const CahM2Slot e = s_ent[is_ref ? uf : 0];
@@ -769,6 +786,9 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
                             bestk = kk > bestk ? kk : bestk;
                         }
                         ++u; --left;
+                        // (a saturated home goes on while the entries are its own)
+                        if (left == 0 && m2_dir_count(d) == CAH_M2_MAX_GROUP && u < n_entries &&
+                            m2_home_of(s_ent[u].key, s_ent[u].meta) == (m2_index(rlast, qc) & (CAH_M2_SLOTS - 1))) left = 1;
                     }
                 }
                 if (bestk) atomicMax(a.best_key + (a.first_read + base + lane), bestk);

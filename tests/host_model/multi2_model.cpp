@@ -35,8 +35,12 @@ struct ReadState {
 
 void resolve(const M2Tables& t, ReadState& st, uint32_t r, int qc, int cls, int p, int n, uint32_t rlast) {
     const CahMulti2Header& h = t.hdr;
-    const uint32_t d = t.dir[m2_index(r, qc) & (CAH_M2_SLOTS - 1)];
-    for (int u = m2_dir_begin(d); u < m2_dir_begin(d) + m2_dir_count(d); u++) {
+    const uint32_t home = m2_index(r, qc) & (CAH_M2_SLOTS - 1);
+    const uint32_t d = t.dir[home];
+    for (int u = m2_dir_begin(d);; u++) {
+        // (a home's count saturates at CAH_M2_MAX_GROUP: such a home is walked while the entries are its own)
+        if (u >= m2_dir_begin(d) + m2_dir_count(d) &&
+            (m2_dir_count(d) < CAH_M2_MAX_GROUP || u >= (int)t.entries.size() || m2_home_of(t.entries[(size_t)u].key, t.entries[(size_t)u].meta) != home)) break;
         const CahM2Slot& e = t.entries[(size_t)u];
         const uint32_t meta = e.meta;
         const int q = m2_q(meta);

@@ -169,8 +169,8 @@ def test_every_adapter_on_every_read_with_a_minimal_pool(hip, orc):
     The worst case the arithmetic is made for -- every adapter pairs with every read -- with the smallest pool the library
     accepts (CAH_MULTI_PAIR_CAP=1: the floor of one block's reserve): several rounds, every tuple against the oracle."""
     prng = random.Random(41)
-    # (15 entries may share a home of the streaming form's directory, CAH_M2_MAX_GROUP: near-duplicates share their k-mers)
-    for count, m, n_reads in ((8, 33, 40_000), (12, 33, 30_000), (12, 20, 30_000)):
+    # (near-duplicates share their k-mers: homes of the streaming form's directory with more than CAH_M2_MAX_GROUP entries)
+    for count, m, n_reads in ((8, 33, 40_000), (16, 33, 30_000), (24, 33, 20_000), (16, 20, 30_000)):
         # (whether 16 adapters may share a k-mer depends on the base adapter's chunks: draw until the plan streams)
         for _try in range(40):
             seqs = _near_duplicates(prng, rs(prng, m), count)

@@ -183,6 +183,24 @@ def test_tails_margins_and_second_copies(model):
         run(model, ads, rate, O, seqs, offsets, f"tails {it} m {m} x {count}", must_build=False)
 
 
+def test_adapter_families_that_share_their_kmers(model):
+    """near-duplicate adapters (a family that differs in one position each): homes of the directory with more entries than
+    its count field holds are walked to their end (multi2.h: m2_home_of)"""
+    rng = np.random.default_rng(80)
+    for count, m in ((20, 33), (30, 24), (12, 40)):
+        base = rand_adapters(rng, 1, m)[0]
+        ads = [base]
+        for i in range(1, count):
+            p = (7 * i) % m
+            ads.append(base[:p] + "ACGT"[("ACGT".index(base[p]) + 1 + i % 3) % 4] + base[p + 1:])
+        ads = list(dict.fromkeys(ads))
+        reads = tail_reads(rng, ads, 1200, 150)
+        seqs, offsets = orc.pack_reads(reads)
+        run(model, ads, 0.1, 3, seqs, offsets, f"family of {len(ads)}, m {m}")
+        seqs, offsets = orc.synth_reads(12, 0, 1500, 150, ads, p_adapter=0.7, p_edit=0.04)
+        run(model, ads, 0.1, 3, seqs, offsets, f"family of {len(ads)}, m {m}, synthetic")
+
+
 def test_low_complexity_and_lowercase(model):
     rng = np.random.default_rng(78)
     done = 0
