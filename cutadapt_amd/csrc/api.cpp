@@ -1487,6 +1487,13 @@ int cah_kmers_present_batch(const cah_plan* plan, int32_t adapter, const uint8_t
 // the form the calling thread's last cah_match_batch* call took for its plan's adapters (cah_last_multi_path)
 static thread_local int t_last_multi_path = -1;
 int cah_last_multi_path(void) { return t_last_multi_path; }
+// Deferred error check (per calling thread; off by default).  The streaming multi-adapter path reads the device's error
+// word back after its kernels -- one synchronisation per call, so that a broken invariant is CAH_EINTERNAL.  A caller that
+// issues many small batches on several streams (cutadapt_amd/batch.py: the length buckets of a ragged batch) switches the
+// deferred form on: a call whose pool holds the batch's worst case returns without waiting, and k_multi_decode writes
+// CAH_STATUS_INTERNAL into every status byte of a batch whose kernels flagged something -- the caller looks for it.
+static thread_local int t_deferred_errors = 0;
+int cah_set_deferred_errors(int on) { const int old = t_deferred_errors; t_deferred_errors = on ? 1 : 0; return old; }
 
 static int match_batch_multi(const cah_plan* plan, const PlanDeviceCopy* pd, const uint8_t* d_seqs,
                              const int64_t* d_offsets, const int32_t* d_lens, int64_t n_reads, int32_t* d_out6,
@@ -1515,6 +1522,7 @@ static int match_batch_multi(const cah_plan* plan, const PlanDeviceCopy* pd, con
         const int64_t TILE = multi2_tile_reads(), per_tile = m2_pages_per_tile(A), open_pages = 16 * CAH_M2_PAIR_CLASSES;
         // (pairs carry the read's index in 32 bits, the prefilter counts reads in an int)
         const int64_t BLOCK = (int64_t)1 << 30;
+        bool deferred = false;
         for (int64_t lo = 0; lo < n_reads; lo += BLOCK) {
             const int64_t cnt = std::min(BLOCK, n_reads - lo);
             const int64_t n_tiles = (cnt + TILE - 1) / TILE;
@@ -1535,7 +1543,10 @@ static int match_batch_multi(const cah_plan* plan, const PlanDeviceCopy* pd, con
             if (env_flag("CAH_TEST_M2_UNGATED")) { gate = (int64_t)1 << 60; rounds = 1; }
 #endif
             HIP_TRY(hipMemsetAsync(counters, 0, WS_HEADER, s));
+            // (the pool holds the worst case of the whole batch, one launch draws every tile: nothing for the host to decide)
+            deferred = t_deferred_errors && rounds == 1 && gate == max_pages && n_reads <= BLOCK;
           for (int64_t round = 0;; round++) {
+            if (round >= rounds && deferred) break;
             if (round >= rounds) {
                 // The planned rounds are through.  Never trust the arithmetic above silently: the device says how many
                 // tiles were drawn and whether a kernel ran out of pages or waited in vain (kernels.h: Multi2Args::err).
@@ -1603,7 +1614,8 @@ static int match_batch_multi(const cah_plan* plan, const PlanDeviceCopy* pd, con
           }
         }
         ProfScope ps(s, CAH_PROF_MERGE, n_reads);
-        HIP_TRY(launch_multi_decode(d_best_key, n_reads, d_out6, d_status, d_best_adapter, pd->n_cus, s));
+        HIP_TRY(launch_multi_decode(d_best_key, n_reads, d_out6, d_status, d_best_adapter, pd->n_cus, s,
+                                    deferred ? counters + WS_M2_ERR : nullptr));
         return CAH_OK;
     }
     for (int64_t lo = 0; lo < n_reads; lo += chunk) {

@@ -220,7 +220,7 @@ struct MultiFilterArgs {
 };
 hipError_t launch_multi_filter(const MultiFilterArgs& a, const CahMultiHeader& host_hdr, int n_cus, hipStream_t s);
 hipError_t launch_multi_decode(const unsigned long long* best_key, int64_t n_reads, int32_t* out6, uint8_t* status,
-                               int32_t* best_adapter, int n_cus, hipStream_t s);
+                               int32_t* best_adapter, int n_cus, hipStream_t s, const unsigned long long* err = nullptr);
 // multi2.hip: the streaming form of the fused multi-adapter path (equally long short reads; tables: multi2.h)
 struct CahMulti2Header;
 struct CahM2Slot;

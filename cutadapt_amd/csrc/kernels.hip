@@ -1481,6 +1481,16 @@ template <int ROWS, bool MULTI>
 __global__ __launch_bounds__(256, CAH_DPP_WAVES(ROWS)) void k_dp_packed(DpArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint64_t s_rowmask[];     // [128], or [n_adapters * CAH_MULTI_TAB_STRIDE]
     if (MULTI && a.queue_count && *a.queue_count == 0ull && (!a.queue_count_back || *a.queue_count_back == 0ull)) return;
+    int deq = PK_DEQUEUE;
+    if (MULTI && a.queue_count) {
+        // (work items are drawn from one counter, PK_DEQUEUE x 64 per wave and draw: blocks beyond what the list holds
+        // leave before the tables are copied)
+        const unsigned long long items = *a.queue_count + (a.queue_count_back ? *a.queue_count_back : 0ull);
+        // (a short list -- a small batch -- is spread over as many waves as it has sub-batches: the kernel's duration is
+        // that of its slowest wave, and a wave works its sub-batches off one after the other)
+        deq = items < 1024ull * 1024ull ? 1 : PK_DEQUEUE;
+        if ((unsigned long long)blockIdx.x * (unsigned)(deq * WAVE) >= items) return;
+    }
     __shared__ int s_ncnt[CAH_MAX_M + 1];
     __shared__ int s_thr[CAH_MAX_M + 1];
     const CahMatcher* mt = a.matcher;
@@ -1520,10 +1530,10 @@ __global__ __launch_bounds__(256, CAH_DPP_WAVES(ROWS)) void k_dp_packed(DpArgs a
     // a wave takes PK_DEQUEUE x 64 consecutive work items per atomic (a single hot counter sustains
     // ~90 atomics/us on this chip)
     for (;;) {
-      const int64_t base0 = wave_dequeue(a.work_counter, PK_DEQUEUE * WAVE);
+      const int64_t base0 = wave_dequeue(a.work_counter, deq * WAVE);
       if (base0 >= total) break;
 #pragma unroll 1
-      for (int sub = 0; sub < PK_DEQUEUE; ++sub) {
+      for (int sub = 0; sub < deq; ++sub) {
         const int64_t base = base0 + (int64_t)sub * WAVE;
         if (base >= total) break;
         const int64_t idx = base + lane;

@@ -197,14 +197,18 @@ __global__ __launch_bounds__(256) void k_multi_filter(MultiFilterArgs a) {
 // needs no clearing pass over the 24 B rows in front of it.  A block stages the rows of 256 reads in LDS and stores them
 // as whole 16-byte words: a lane-per-read store of six ints touches 24 cache lines per instruction.
 __global__ __launch_bounds__(256) void k_multi_decode(const unsigned long long* best_key, int64_t n_reads, int32_t* out6,
-                                                      uint8_t* status, int32_t* best_adapter) {
+                                                      uint8_t* status, int32_t* best_adapter, const unsigned long long* err) {
     __shared__ __attribute__((aligned(16))) int32_t s_rows[256 * 6];
     const bool aligned = ((unsigned long long)out6 & 15ull) == 0ull;
+    // deferred error check (cah_set_deferred_errors): the error word of the streaming kernels is looked at HERE instead
+    // of by the host behind a synchronisation -- a batch whose kernels flagged a broken invariant gets status
+    // CAH_STATUS_INTERNAL in every row (the rows are void)
+    const bool broken = err != nullptr && *err != 0ull;
     for (int64_t base = (int64_t)blockIdx.x * 256; base < n_reads; base += (int64_t)gridDim.x * 256) {
         const int64_t r = base + threadIdx.x;
         int32_t o[6] = {0, 0, 0, 0, 0, 0};
         if (r < n_reads) {
-            const unsigned long long k = best_key[r];
+            const unsigned long long k = broken ? 0ull : best_key[r];
             const bool invalid = status[r] == 2;
             const bool hit = k != 0ull && !invalid;
             if (hit) {
@@ -213,6 +217,7 @@ __global__ __launch_bounds__(256) void k_multi_decode(const unsigned long long* 
                 o[4] = (int)((k >> 54) & 0xFFu) - 128; o[5] = 127 - (int)((k >> 47) & 0x7Fu);
             }
             if (!invalid) status[r] = hit ? 1 : 0;
+            if (broken) status[r] = 255;                                // CAH_STATUS_INTERNAL
             if (best_adapter) best_adapter[r] = hit ? 4095 - (int)((k >> 35) & 0xFFFu) : -1;
         }
 #pragma unroll
@@ -243,11 +248,11 @@ hipError_t launch_multi_filter(const MultiFilterArgs& a, const CahMultiHeader& h
 }
 
 hipError_t launch_multi_decode(const unsigned long long* best_key, int64_t n_reads, int32_t* out6, uint8_t* status,
-                               int32_t* best_adapter, int n_cus, hipStream_t s) {
+                               int32_t* best_adapter, int n_cus, hipStream_t s, const unsigned long long* err) {
     int64_t need = (n_reads + 255) / 256;
     if (need < 1) need = 1;
     const int64_t cap = (int64_t)8 * n_cus;
     hipLaunchKernelGGL(k_multi_decode, dim3((unsigned)(need < cap ? need : cap)), dim3(256), 0, s, best_key, n_reads, out6,
-                       status, best_adapter);
+                       status, best_adapter, err);
     return hipGetLastError();
 }

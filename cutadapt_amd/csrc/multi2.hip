@@ -212,8 +212,10 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
     const unsigned lane16 = (unsigned)lane * 16u;
 
     // ---- copy plan (k_filter_stream2's): H1 units of every read in the first half-row, H2 in the second
+    // (a read of at most M2_HALF units is ONE half-row: its tail chunks, whose words wait in the row, then never straddle
+    // the two fills of the slot -- reads of 16 .. 80 characters, the short buckets of a ragged batch)
     const int U = (n + 15) >> 4;
-    const int H1 = (U + 1) >> 1, H2 = U - H1;
+    const int H1 = U <= M2_HALF ? U : (U + 1) >> 1, H2 = U - H1;
     const unsigned magic1 = (65536u + (unsigned)H1 - 1u) / (unsigned)H1;
     const unsigned magic2 = H2 ? (65536u + (unsigned)H2 - 1u) / (unsigned)H2 : 0u;
     auto unit_r = [&](int kk, unsigned magic) -> int {
@@ -845,6 +847,9 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_multi
     __shared__ unsigned long long s_gf, s_gb;
     const CahMatcher* mt = a.matcher;
     if (*a.page_counter == 0ull) return;                                // (a round that found no tile left)
+    // (pages are drawn from one counter: blocks beyond their number have nothing to do -- they leave before the tables are
+    // copied, which is what a launch over a small batch would otherwise spend its time on)
+    if ((unsigned long long)blockIdx.x >= *a.page_counter) return;
     for (int i = threadIdx.x; i < a.n_adapters * CAH_MULTI_TAB_STRIDE; i += blockDim.x)
         s_scanmask[i] = KIND == 0 ? a.tab[i] : bs32_table_entry(a.tab[i], mt->m);
     for (int i = threadIdx.x; i <= CAH_MAX_M; i += blockDim.x) s_thr_last[i] = mt->thr_last[i];
@@ -1159,7 +1164,7 @@ size_t multi2_lds_bytes(const CahMulti2Header& h) { return m2_layout((int)h.n_en
 bool multi2_read_len_ok(const CahMulti2Header& h, int n) {
     if (!h.ok || n < 16 || n > M2_MAX_LEN) return false;
     if (multi2_lds_bytes(h) > 160 * 1024) return false;
-    const int U = (n + 15) >> 4, H1 = (U + 1) >> 1, H2 = U - H1;
+    const int U = (n + 15) >> 4, H1 = U <= M2_HALF ? U : (U + 1) >> 1, H2 = U - H1;
     const int tail_off = H2 > 0 ? 16 * H1 : 0;
     // the tail slots are probed in the last chunks of the last half-row: every slot's first position must lie in it,
     // and at most four chunks (the slots' hit masks are 64 bits) reach from there to the read's end

@@ -51,7 +51,7 @@ def test_library_is_built_and_exports_every_declared_symbol():
     L = _lib.lib()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.cah_abi_version() == _lib.ABI_VERSION == 4
+    assert L.cah_abi_version() == _lib.ABI_VERSION == 5
     # the binary says which sources it was built from (cah_build_id), and build.needs_build() goes by that, not by file times
     from cutadapt_amd import build
     assert _lib.build_id() == build.source_hash() == build.library_build_id(), "stale library: python -m cutadapt_amd.build"
