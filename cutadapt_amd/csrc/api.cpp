@@ -657,14 +657,6 @@ static int build_matcher(const cah_adapter_desc& d, int index, CahMatcher& mt,
         }
     }
 
-    // ---- the cost scan's windows from the adapter's chunk occurrences (back_scan.h "bs3", k_back_scan3): the chunks are
-    // the plan's own whole-read k-mers (skip_ok says so), so none of them ends before the prefilter's first-hit group
-    mt.bs3_ok = 0; mt.bs3_start = 0; mt.bs3_end = 0; mt.bs3_roff = 0; mt.bs3_maxlen = 0;
-    if (mt.skip_ok && mt.scan_ok && d.kind == CAH_KIND_ALIGNER) {
-        const Bs3Geom g = bs3_geom(m, mt.k, mt.kacc);
-        if (g.ok) { mt.bs3_ok = 1; mt.bs3_start = g.start; mt.bs3_end = g.end; mt.bs3_roff = g.roff; mt.bs3_maxlen = g.maxlen; }
-    }
-
     // ---- is the prefilter implied by an unedited, anchored occurrence of the adapter? (CahMatcher::filter_implied)
     mt.filter_implied = 0;
     if (d.kind == CAH_KIND_ALIGNER && (mt.flags == 8 || mt.flags == 2) && d.n_kmer_sets > 0 && m >= 1 && m <= CAH_MAX_M) {
@@ -1326,15 +1318,7 @@ static int run_aligner(const cah_plan* plan, const PlanDeviceCopy* pd, int32_t a
             sa.kind = scan_word_kind(mt.m);
             {
                 ProfScope ps(s, CAH_PROF_SCAN, n_reads);
-                // Adapters of at most 34 characters behind a prefilter whose whole-read k-mers are the adapter's chunks: the
-                // scan on windows from the chunks' occurrences (k_back_scan3, scan3.hip: three 16-column chunks for most
-                // reads instead of six or seven); what it cannot serve goes to the straggler list, i.e. to the launch below.
-                // CAH_SCAN3=1 switches it on: exact (tests/test_gpu_scan.py runs both ways) but not yet the faster of the two --
-                // DESIGN.md 9 has the counters: 8 % fewer instructions than k_back_scan at 4 waves per SIMD instead of 5.
-                const bool scan3 = mt.bs3_ok && sa.kind >= 1 && sa.kind <= 3 && sa.early_stop && sa.retry_threshold > 0 &&
-                                   env_flag("CAH_SCAN3");
-                if (scan3) HIP_TRY(launch_back_scan3(sa, n_reads, pd->n_cus, s));
-                else HIP_TRY(launch_back_scan(sa, n_reads, pd->n_cus, s));
+                HIP_TRY(launch_back_scan(sa, n_reads, pd->n_cus, s));
                 if (sa.retry_threshold > 0) {
                     ScanArgs sb = sa;
                     sb.queue = ws.retry_queue; sb.queue_keys = ws.retry_keys; sb.queue_count = ws.counters + WS_RETRYCOUNT;

@@ -209,9 +209,8 @@ CAH_HD void bs_init(BackScanState& s, const BackScanParams& p) {
 // Row m of the column just processed: the bookkeeping every representation shares.  clean: the diagonal that ends
 // in (m, j) has met no cell whose diagonal delta is 0 although its characters differ.  Returns true when the read
 // is finished as EXACT_FULL at this column.
-// jlim: columns behind it are not booked (bs3's class F: a window of whole chunks may run a few columns past the last one
-// its chunk occurrences answer for -- what is acceptable there stems from occurrences nobody has looked at, and cannot
-// matter if the window holds a candidate at all, see bs3 below).
+// jlim: columns behind it are not booked (for callers whose window runs a few columns past the last one they answer for;
+// round 5's k_back_scan3 was one -- removed in round 6, DESIGN_HISTORY.md).
 template <bool SUBS>
 CAH_HD bool bs_book(BackScanBook& s, const bool clean, const int j, const BackScanParams& p, const bool del = false,
                     const bool pred_unclean = true, const int jlim = 0x7FFFFFFF) {
@@ -468,7 +467,7 @@ CAH_HD int bs_finish_rows(const BackScanBook& s, const BsLastColumn<W, X>& col, 
     o0 = 0; o1 = 0;
     const int reach = p.m + p.k + 1;
     // the cell DP's first column is never before dp_lo: the scan's own window start, unless the caller knows an earlier
-    // column that is as safe (bs3: the window starts BEHIND jfa - reach, the prefilter's column-skipping position does not)
+    // column that is as safe
     const int dp_lo = dp_lo_in >= 0 ? dp_lo_in : j0;
     // one insertion / one deletion (see the header); INDEL1 = false: the form does not keep the bits
     const bool indel1 = INDEL1 && s.cmin >= 1 && !s.eclean && !s.epred_unclean && s.je - p.m - 1 >= j0 &&
@@ -539,168 +538,3 @@ CAH_HD int bs32_finish(const BackScanState32<X>& s, const int n, const int j0, c
     return bs_finish_rows<TRACKED, TRACKED>(s, col, n, j0, p, thr_last, o0, o1, stopped, max_row, dp_lo);
 }
 
-// =================================================================================================================
-// bs3: the scan's windows from the adapter's own chunks (round 5; k_back_scan3 in scan3.hip, tests/host_model).
-//
-// A last-row candidate (cost <= kacc over all m rows, reference _align.pyx:496-533) is an alignment with at most kacc
-// edit operations; cut the adapter into k + 1 >= kacc + 1 consecutive chunks (kmer_heuristic's whole-read set, so that
-// the prefilter's column-skipping position holds for them) and one chunk is untouched: its rows lie on ONE diagonal of
-// cells whose characters match (the aligner's own relation: the bits of the scan's match words).  If that chunk ends in
-// row E at column f, the alignment's diagonal there is S = f - E ("the copy starts behind column S"), the alignment
-// starts at a column >= S - kacc and ends at one <= S + m + kacc.  So the chunk occurrences of a read -- a shift-and word
-// M over the match words: M = ((M << 1) | START) & eq, hits = M & END -- say where candidates can be at all:
-//   * no occurrence: no last-row candidate; only the rows of the last column can match, and their alignments lie in the
-//     read's last m + k columns (class T).
-//   * occurrences on diagonals Smin .. Smax: every candidate that holds one of them lies in columns
-//     [Smin - kacc - 1, Smax + m + kacc] -- 40 columns + the spread of the diagonals (the insertions / deletions between the
-//     chunks of one copy: <= kacc each way) for a 33-character adapter, THREE 16-column chunks instead of the six to seven
-//     from (first k-mer hit) - m - k - 1 to 23 columns behind the last acceptable column.  Which occurrences count: all up
-//     to column Smax + m + 3 kacc + m/2 (Smax as it grows).  A candidate can only replace the best if it OVERLAPS it
-//     (origin <= best.origin + m/2, :521-524); the best of a window ends at a column <= Smax + m + kacc, so its origin is
-//     <= Smax + 2 kacc, and a candidate that holds an occurrence on a diagonal S' has an origin >= S' - kacc: occurrences
-//     with S' > Smax + 3 kacc + m/2, i.e. (rows <= m) every occurrence that ends behind that column, cannot matter --
-//     PROVIDED the window holds a candidate at all.
-//     - class F: the window ends more than gap_last = k + 1 + kacc + m/2 columns before the read's end: the scan stops
-//       at its end ("stopped", see the header) and books no column behind Smax + m + kacc (a window of whole 16-column
-//       chunks runs a little further: what is acceptable there belongs to occurrences behind the pre-pass range).  If the
-//       window has no acceptable column (a chance occurrence, a copy with too many errors) what lies behind the range DOES
-//       matter: the read is scanned the conservative way (straggler list).
-//     - class E: otherwise the window is joined with the read's last m + k + 1 columns and runs to the end (the pre-pass
-//       has then seen every column).
-//   * class C: a window of more than BS3_MAX_CHUNKS chunks (copies far apart): the conservative way as well.
-// The windowed costs are >= the true ones and equal wherever the optimal paths lie inside the window:
-// every relevant candidate's does, so jfa / jla / cmin and the diagonal bits at candidate columns are the reference's.
-// The cell DP of a read the scan cannot finish starts where it always did (dp_lo: the column-skipping position).
-//
-// The occurrences' DIAGONALS without looking at any single one: over a 16-column chunk G = (G << 1) | hits -- an
-// occurrence in word bit b that is `age` columns old sits at bit b + age, and S = (chunk's last column) - (b + age) - roff:
-// every occurrence on one diagonal lands on ONE bit, whatever its chunk and column; the lowest / highest bit of G at the
-// chunk's end are the chunk's Smax / Smin.  Two 32-bit halves (rows below / from 16: b + age < 31 each).
-#define BS3_MAX_CHUNKS 5
-struct Bs3Geom {
-    uint32_t start, end;      // word bits of the chunks' first / last rows (rows of the 32-bit word only: a first chunk that
-                              // loses its explicit rows matches more often -- more occurrences are as exact)
-    int roff;                 // row of word bit b = b + roff
-    int maxlen;               // longest chunk (characters)
-    int ok;
-};
-
-// the chunks of kmer_heuristic.kmer_chunks(adapter, k + 1) (reference kmer_heuristic.py:6-21): sizes m / (k + 1), the
-// first m % (k + 1) one longer.  Only the 32-bit forms (m <= 34, bs_kind_of(m) in 1..3).
-CAH_HD Bs3Geom bs3_geom(const int m, const int k, const int kacc) {
-    Bs3Geom g;
-    g.start = 0; g.end = 0; g.roff = 0; g.maxlen = 0; g.ok = 0;
-    const int kind = bs_kind_of(m);
-    if (kind == 0 || kacc < 0 || k < kacc || k + 1 > m) return g;
-    const int X = kind >= 2 ? kind - 1 : 0;
-    g.roff = X > 0 ? X + 1 : 1 - (32 - m);
-    const int chunks = k + 1, base = m / chunks, extra = m % chunks;
-    int row = 1;                                              // first row of the chunk
-    for (int c = 0; c < chunks; ++c) {
-        const int len = base + (c < extra ? 1 : 0);
-        const int first = row > X ? row : X + 1, last = row + len - 1;
-        if (last < first) return g;                           // a chunk made of explicit rows only: not served
-        g.start |= 1u << (first - g.roff);
-        g.end |= 1u << (last - g.roff);
-        if (len > g.maxlen) g.maxlen = len;
-        row += len;
-    }
-    g.ok = 1;
-    return g;
-}
-
-struct Bs3Pre {
-    uint32_t M;               // the shift-and word
-    uint32_t glo, ghi;        // the chunk's diagonal bits (see above), cleared at every chunk's start
-    int found;                // an occurrence was seen
-    int smin, smax;           // lowest / highest diagonal so far (a copy on diagonal S occupies columns S + 1 .. S + m)
-};
-CAH_HD void bs3_pre_init(Bs3Pre& s) { s.M = 0; s.glo = 0; s.ghi = 0; s.found = 0; s.smin = 0x3FFFFFFF; s.smax = -0x3FFFFFFF; }
-// columns behind the highest diagonal up to which occurrences count
-CAH_HD int bs3_range(const BackScanParams& p) { return p.m + 3 * p.kacc + p.half_m; }
-CAH_HD int bs_low_bit(const uint32_t x) { return __builtin_ctz(x); }       // x != 0
-// one column with the match word eq of its character
-CAH_HD void bs3_pre_step(Bs3Pre& s, const uint32_t eq, const Bs3Geom& g) {
-    s.M = ((s.M << 1) | g.start) & eq;
-    const uint32_t h = s.M & g.end;
-    s.glo = (s.glo << 1) | (h & 0xFFFFu);
-    s.ghi = (s.ghi << 1) | (h >> 16);
-}
-// the end of a 16-column chunk whose last column is j_end: its diagonals join smin / smax
-CAH_HD void bs3_pre_harvest(Bs3Pre& s, const int j_end, const Bs3Geom& g) {
-    if ((s.glo | s.ghi) != 0) {
-        const int idx_max = s.ghi ? 16 + bs_top_bit(s.ghi) : bs_top_bit(s.glo);
-        const int idx_min = s.glo ? bs_low_bit(s.glo) : 16 + bs_low_bit(s.ghi);
-        const int lo = j_end - idx_max - g.roff, hi = j_end - idx_min - g.roff;
-        s.smin = lo < s.smin ? lo : s.smin;
-        s.smax = hi > s.smax ? hi : s.smax;
-        s.found = 1;
-    }
-    s.glo = 0; s.ghi = 0;
-}
-// first character (0-based) of the pre-pass: every chunk that ends in the prefilter's first-hit group or later is seen whole
-// ... and, for reads of 64+ characters, moved back so that the first BLOCK of four 16-character chunks lies inside the read
-// (an earlier start is as exact; the kernel then fetches the block with four plain loads, no tail handling)
-CAH_HD int bs3_pre_start(const int key4, const Bs3Geom& g, const int n) {
-    int p0 = key4 - (g.maxlen - 1);
-    if (n >= 64 && p0 > n - 64) p0 = n - 64;
-    return p0 > 0 ? p0 : 0;
-}
-// the last column (1-based) the pre-pass of a read looks at: the read's end while nothing is found, then smax + range
-CAH_HD int bs3_pre_last(const int n, const bool found, const int smax, const int range) {
-    return (found && smax + range < n) ? smax + range : n;
-}
-// number of 16-character chunks from p0 on that the pre-pass of a read walks: all up to the read's end while nothing is
-// found; with occurrences, those that hold a column <= smax + range (asked again after every chunk: smax grows)
-CAH_HD int bs3_pre_chunks(const int p0, const int n, const bool found, const int smax, const int range) {
-    const int cols = bs3_pre_last(n, found, smax, range) - p0;       // columns p0 + 1 .. last
-    return cols <= 0 ? 0 : (cols + 15) >> 4;
-}
-
-enum { BS3_T = 0, BS3_F = 1, BS3_E = 2, BS3_C = 3 };
-struct Bs3Win {
-    int cls;                  // BS3_*
-    int start;                // the scan's first column is start + 1 (its state at column `start` is the plain first column)
-    int jend;                 // ... its last one
-    int jlim;                 // the last column that is booked (class F: Smax + m + kacc, the last one the occurrences answer
-                              // for; a window of whole chunks ends a little later)
-};
-// the window from column `from` (or the tail's first column, whichever is earlier) to the read's end, every column booked.
-// Windows that run to the read's end are a whole number of 16-column chunks where the read is long enough
-// (start = n - 16 c), so that their last chunk ends with the read.
-CAH_HD Bs3Win bs3_window_to_end(const int from, const int n, const BackScanParams& p) {
-    Bs3Win w;
-    w.cls = BS3_E; w.jlim = 0x7FFFFFFF; w.jend = n;
-    const int reach = p.m + p.k + 1;
-    const int tail0 = n - reach > 0 ? n - reach : 0;
-    const int start0 = from < tail0 ? from : tail0;
-    const int c = (n - start0 + 15) >> 4;
-    w.start = n - 16 * c > 0 ? n - 16 * c : 0;
-    return w;
-}
-// j0_old: the conservative start (column-skipping position)
-CAH_HD Bs3Win bs3_window(const Bs3Pre& s, const int n, const int j0_old, const BackScanParams& p) {
-    Bs3Win w;
-    if (!s.found) {
-        w = bs3_window_to_end(n, n, p);
-        w.cls = BS3_T;
-        return w;
-    }
-    const int a = s.smin - p.kacc - 1 > 0 ? s.smin - p.kacc - 1 : 0;
-    const int D = s.smax + p.kacc + p.m;
-    const int c = (D - a + 15) >> 4;
-    const int jend = a + 16 * (c > 0 ? c : 1);
-    // (whole chunks: the window may run a few columns past D -- never past the read's end, where no column is)
-    if (D + bs_stop_gap(p) < n && jend <= n) {
-        w.cls = c <= BS3_MAX_CHUNKS ? BS3_F : BS3_C;
-        w.start = a; w.jend = jend; w.jlim = D;
-    } else {
-        w = bs3_window_to_end(a, n, p);
-        if (w.jend - w.start > 16 * BS3_MAX_CHUNKS) w.cls = BS3_C;
-    }
-    if (w.cls == BS3_C) {                                      // (kept as the in-place fallback when the straggler list is full)
-        w = bs3_window_to_end(j0_old < a ? j0_old : a, n, p);
-        w.cls = BS3_C;
-    }
-    return w;
-}

@@ -52,13 +52,6 @@ struct CahMatcher {
     int32_t kacc;              // thr[effective_length] (-1 if m < min_overlap): acceptable last-row cost
     int32_t thr_last[CAH_MAX_M + 1];   // thr[effective length of adapter[0:i]]: threshold of row i in the last column
     uint64_t scanmask[CAH_TABLE_CHARS]; // rowmask << (64 - m) | ones below: the adapter in the top m bits
-    // ---- bs3 (back_scan.h): the adapter's k + 1 chunks in the coordinates of its 32-bit scan form -- the cost scan's
-    // windows from the chunks' occurrences (k_back_scan3).  bs3_ok: 3' adapter of at most 34 characters whose plan has
-    // the pigeonhole property (skip_ok) and whose chunks all reach into the word
-    int32_t bs3_ok;
-    uint32_t bs3_start, bs3_end;
-    int32_t bs3_roff, bs3_maxlen;
-    int32_t pad2_;
     // 1: a read that holds the adapter unedited at its anchored place (prefix aligner: position 0, suffix aligner:
     // the last m characters) passes this plan's prefilter -- some k-mer of a search set is a piece of the adapter
     // inside its window there, and every character the aligner accepts at that place the k-mer table accepts too.

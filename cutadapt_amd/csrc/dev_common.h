@@ -118,7 +118,7 @@ __device__ __forceinline__ unsigned chunk_byte(const Chunk& c, int t) {
 
 // One read's result row, status and best adapter (merge_best: 0 = plain store, 1 = MultipleAdapters' merge with what an
 // earlier adapter of the plan left, reference adapters.py:1278-1285, 2 = the plan's first adapter on rows the entry point
-// has zeroed).  Shared by the cost scans (kernels.hip, scan3.hip) and the cell DP kernels.
+// has zeroed).  Shared by the cost scans (kernels.hip) and the cell DP kernels.
 __device__ __forceinline__ void store_result(int32_t* out6, uint8_t* status, int32_t* best_adapter,
                                              const int adapter_index, const int merge_best, const int64_t r,
                                              const bool invalid, const bool found, const int t0, const int t1,

@@ -192,9 +192,6 @@ hipError_t launch_filter(const FilterArgs& a, int mode, bool narrow_words, int n
 hipError_t launch_dp(const DpArgs& a, int m, bool unit_indel_cost, bool back_adapter, int64_t max_items, int n_cus,
                      hipStream_t s);
 hipError_t launch_back_scan(const ScanArgs& a, int64_t max_items, int n_cus, hipStream_t s);
-// k_back_scan3 (scan3.hip): the same job on windows from the adapter's chunk occurrences; single-adapter mode, queue + keys,
-// a.kind in 1..3, the matcher's bs3_ok set
-hipError_t launch_back_scan3(const ScanArgs& a, int64_t max_items, int n_cus, hipStream_t s);
 
 // multi.hip: the fused multi-adapter prefilter and the final decode of the per-read best keys
 struct MultiFilterArgs {

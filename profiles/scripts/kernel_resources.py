@@ -65,6 +65,6 @@ if __name__ == "__main__":
         with open(dst, "w") as f:
             json.dump(res, f, indent=1, sort_keys=True)
     for k in sorted(res):
-        if re.match(r"k_(filter_stream2<2, 4, true, false, false, false>|back_scan<false, 2>|back_scan3<2>|dp_packed<36, false>|multi_stream<true>|multi_scan<2>)", k):
+        if re.match(r"k_(filter_stream2<2, 4, true, false, false, false>|back_scan<false, 2>|dp_packed<36, false>|multi_stream<true>|multi_scan<2>)", k):
             print(k, res[k])
     print(len(res), "kernels")

@@ -176,122 +176,7 @@ int bm_locate_batch(const void* matcher_blob, const uint8_t* seqs, const int64_t
 
 size_t bm_matcher_size(void) { return sizeof(CahMatcher); }
 
-// ---- bs3 (round 5): the scan on windows chosen from the adapter's chunk occurrences (back_scan.h, "bs3"), as
-// k_back_scan3 (scan3.hip) runs it -- pre-pass in 16-character chunks from the prefilter's position, class T / F / E / C,
-// one window, the classification with the window's start as j0 and the column-skipping position as the cell DP's lower
-// bound.  Reads of class C and class-F reads without an acceptable column take the conservative path (what the kernel
-// hands to the straggler list: bm_locate_batch's scan from the aligned column-skipping position, early stop per chunk);
-// `list_full` != 0 replays what the kernel does when that list has no room (the window to the read's end in place).
-// keys: the prefilter's first-hit group per read (bm_keys).  cls_out: bit 0-2 class, bit 3 stopped, bits 4-5 the bs3 class,
-// bit 6: taken the conservative way.
-int bm_locate_batch3(const void* matcher_blob, const uint8_t* seqs, const int64_t* offsets, int64_t n_reads,
-                     const uint8_t* keys, int32_t* out6, uint8_t* status, uint8_t* cls_out, int32_t list_full) {
-    CahMatcher mt;
-    memcpy(&mt, matcher_blob, sizeof(mt));
-    if (!mt.scan_ok) return 1;              // (skip_ok is the PLAN's word on its k-mer sets; the keys here come from bm_keys)
-    BackScanParams p;
-    p.m = mt.m; p.k = mt.k; p.kacc = mt.kacc; p.min_overlap = mt.min_overlap; p.half_m = mt.m / 2;
-    const Bs3Geom g = bs3_geom(p.m, p.k, p.kacc);
-    if (!g.ok) return 1;
-    const int kind = bs_kind_of(p.m);
-    uint64_t tab32[128];
-    for (int c = 0; c < 128; c++) tab32[c] = bs32_table_entry(mt.scanmask[c], p.m);
-    const int reach = p.m + p.k + 1, range = bs3_range(p), gap = bs_stop_gap(p);
-    auto thr = [&](int i) { return mt.thr_last[i]; };
-    for (int64_t r = 0; r < n_reads; r++) {
-        const uint8_t* q = seqs + offsets[r];
-        const int n = (int)(offsets[r + 1] - offsets[r]);
-        const int key4 = (int)keys[r] << 2;
-        const int j0_old = std::max(0, key4 - reach);
-        // ---- pre-pass: 16-character chunks from p0, harvested at every chunk's end (characters behind the read: NUL)
-        Bs3Pre pre;
-        bs3_pre_init(pre);
-        const int p0 = bs3_pre_start(key4, g, n);
-        for (int c = 0; c < bs3_pre_chunks(p0, n, pre.found != 0, pre.smax, range); ++c) {
-            for (int t = 0; t < 16; ++t) {
-                const int j = p0 + 16 * c + t + 1;
-                bs3_pre_step(pre, j <= n ? (uint32_t)tab32[q[j - 1] & 127] : 0u, g);
-            }
-            bs3_pre_harvest(pre, p0 + 16 * c + 16, g);
-        }
-        Bs3Win w = bs3_window(pre, n, j0_old, p);
-        bool conservative = w.cls == BS3_C && !list_full;
-        bool exact = false, stopped = false;
-        int o0 = 0, o1 = 0, cls = BS_NONE, j = 0;
-        auto scan = [&](auto& st, auto init, auto step, auto finish) {
-            if (!conservative) {
-                init(st);
-                for (j = w.start; j < w.jend && j < n;) {
-                    ++j;
-                    if (step(st, q[j - 1] & 127, w.jlim)) { exact = true; break; }
-                }
-                if (!exact && w.cls == BS3_F) {
-                    if (st.jla >= 0) stopped = true;
-                    else if (!list_full) conservative = true;
-                    else {
-                        // no room in the list: the lane goes round again with the window from the same start to the read's
-                        // end, every column booked (bs3_window_to_end)
-                        w = bs3_window_to_end(w.start, n, p);
-                        init(st);
-                        for (j = w.start; j < n;) {
-                            ++j;
-                            if (step(st, q[j - 1] & 127, w.jlim)) { exact = true; break; }
-                        }
-                    }
-                }
-                if (!conservative) {
-                    if (exact) { cls = BS_EXACT_FULL; o0 = j; }
-                    else cls = finish(st, w.start, j0_old);
-                }
-            }
-            if (conservative) {
-                // the straggler list's launch: k_back_scan from the aligned column-skipping position, early stop per chunk
-                exact = false; stopped = false;
-                const int j0 = bs_align_window(j0_old, n);
-                init(st);
-                for (j = j0; j < n;) {
-                    ++j;
-                    if (step(st, q[j - 1] & 127, 0x7FFFFFFF)) { exact = true; break; }
-                    if ((j - j0) % 16 == 0 && bs_may_stop(st, j, n, gap)) { stopped = true; break; }
-                }
-                if (exact) { cls = BS_EXACT_FULL; o0 = j; }
-                else cls = finish(st, j0, -1);
-            }
-        };
-#define BM3_FORM(XR)                                                                                                       \
-        {                                                                                                                  \
-            BackScanState32<XR> st;                                                                                        \
-            scan(st, [&](BackScanState32<XR>& s) { bs32_init(s, p); },                                                     \
-                 [&](BackScanState32<XR>& s, int c, int jlim) { return bs32_step<true, XR>(s, (uint32_t)tab32[c], (uint32_t)(tab32[c] >> 32), j, p, jlim); }, \
-                 [&](BackScanState32<XR>& s, int j0, int dp_lo) { return bs32_finish<XR>(s, n, j0, p, thr, o0, o1, stopped, CAH_BS_ALL_ROWS, dp_lo); }); \
-        }
-        if (kind == 1) BM3_FORM(0) else if (kind == 2) BM3_FORM(1) else BM3_FORM(2)
-#undef BM3_FORM
-        int32_t* o = out6 + r * 6;
-        for (int t = 0; t < 6; t++) o[t] = 0;
-        status[r] = 0;
-        if (cls == BS_EXACT_FULL) {
-            o[0] = 0; o[1] = p.m; o[2] = o0 - p.m; o[3] = o0; o[4] = p.m; o[5] = 0; status[r] = 1;
-        } else if (cls == BS_EXACT_TAIL) {
-            o[0] = 0; o[1] = o0; o[2] = n - o0; o[3] = n; o[4] = o0 - 2 * o1; o[5] = o1; status[r] = 1;
-        } else if (cls == BS_SUBS_FULL) {
-            o[0] = 0; o[1] = p.m; o[2] = o0 - p.m; o[3] = o0; o[4] = p.m - 2 * o1; o[5] = o1; status[r] = 1;
-        } else if (cls == BS_INDEL1_FULL) {
-            o[0] = 0; o[1] = p.m; o[2] = o0 - p.m + ((o1 & 1) ? 1 : -1); o[3] = o0; o[4] = p.m - 2 * (o1 >> 1) - (o1 & 1);
-            o[5] = o1 >> 1; status[r] = 1;
-        } else if (cls == BS_DP) {
-            int t6[6];
-            if (dp_window(mt, q, n, o0, std::min(n, o1 >> 1), (o1 & 1) != 0, t6)) {
-                for (int t = 0; t < 6; t++) o[t] = t6[t];
-                status[r] = 1;
-            }
-        }
-        if (cls_out) cls_out[r] = (uint8_t)(cls | (stopped ? 8 : 0) | (w.cls << 4) | (conservative ? 64 : 0));
-    }
-    return 0;
-}
-
-// the prefilter's survivor key (bm_skip_columns' first_end >> 2), for bm_locate_batch3
+// the prefilter's survivor key (bm_skip_columns' first_end >> 2)
 void bm_keys(const char* adapter, int m, int k, const uint8_t* seqs, const int64_t* offsets, int64_t n_reads, uint8_t* keys) {
     const int chunks = k + 1, base = m / chunks, extra = m % chunks;
     for (int64_t r = 0; r < n_reads; r++) {

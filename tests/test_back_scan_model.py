@@ -31,7 +31,6 @@ def model():
     L.bm_locate_batch.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp, vp, C.c_int32, vp, C.c_int32]
     L.bm_skip_columns.argtypes = [C.c_char_p, C.c_int, C.c_int, vp, vp, i64, vp]
     L.bm_refined_columns.argtypes = [C.c_char_p, C.c_int, C.c_int, vp, vp, i64, vp]
-    L.bm_locate_batch3.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp, C.c_int32]
     L.bm_keys.argtypes = [C.c_char_p, C.c_int, C.c_int, vp, vp, i64, vp]
     L.bm_matcher_size.restype = C.c_size_t
     return L
@@ -92,44 +91,7 @@ def compare(L, adapter, rate, min_overlap, seqs, offsets, wr=False, wq=False, sk
                                  f"class {cls[r]} model {status[r]} {out6[r].tolist()} oracle {want_st[r]} {want6[r].tolist()}")
         if stop_every == 16 and form == -1:
             counts = np.bincount(cls, minlength=6)
-    if skip is True:
-        compare3(L, blob, adapter, rate, min_overlap, seqs, offsets, want6, want_st, wr, wq, label)
     return counts
-
-
-STATS3 = {"reads": 0, "T": 0, "F": 0, "E": 0, "C": 0, "conservative": 0, "plans": 0}
-
-
-def compare3(L, blob, adapter, rate, min_overlap, seqs, offsets, want6, want_st, wr, wq, label):
-    """bs3 (k_back_scan3's windows from the adapter's chunk occurrences, back_scan.h): with the prefilter's key, with keys
-    below it (any lower bound is a valid key: the SV form lowers them), and with the straggler list full"""
-    n = len(offsets) - 1
-    keys = np.zeros(n, dtype=np.uint8)
-    L.bm_keys(adapter.encode(), len(adapter), int(rate * len(adapter)), seqs.ctypes.data, offsets.ctypes.data, n, keys.ctypes.data)
-    rng = np.random.default_rng(len(adapter) * 1000 + n)
-    lower = np.maximum(0, keys.astype(np.int64) - rng.integers(0, 12, size=n) * (rng.random(n) < 0.5)).astype(np.uint8)
-    for kk, list_full, what in ((keys, 0, "keys"), (lower, 0, "lower keys"), (keys, 1, "list full")):
-        out6 = np.zeros((n, 6), dtype=np.int32)
-        status = np.zeros(n, dtype=np.uint8)
-        cls = np.zeros(n, dtype=np.uint8)
-        rc = L.bm_locate_batch3(blob, seqs.ctypes.data, offsets.ctypes.data, n, kk.ctypes.data, out6.ctypes.data,
-                                status.ctypes.data, cls.ctypes.data, list_full)
-        if rc == 1:
-            return                                       # adapter outside bs3's forms (m > 34, no chunk geometry)
-        bad = np.nonzero((status != want_st) | (out6 != want6).any(axis=1))[0]
-        if len(bad):
-            r = int(bad[0])
-            read = bytes(seqs[offsets[r]:offsets[r + 1]]).decode("latin-1")
-            raise AssertionError(f"{label} bs3 ({what}): {len(bad)} of {n} reads differ; first: read {r} {read!r} adapter {adapter} "
-                                 f"rate {rate} O {min_overlap} wr {wr} wq {wq} key {kk[r]} class {cls[r] & 7} stopped {(cls[r] >> 3) & 1} "
-                                 f"bs3 {'TFEC'[(cls[r] >> 4) & 3]} conservative {(cls[r] >> 6) & 1} model {status[r]} {out6[r].tolist()} "
-                                 f"oracle {want_st[r]} {want6[r].tolist()}")
-        if what == "keys":
-            STATS3["reads"] += n
-            for i, nm in enumerate("TFEC"):
-                STATS3[nm] += int((((cls >> 4) & 3) == i).sum())
-            STATS3["conservative"] += int(((cls >> 6) & 1).sum())
-            STATS3["plans"] += 1
 
 
 def random_reads(rng, adapter, n_reads, max_len, p_edit, p_n, alphabet="ACGT"):
@@ -508,13 +470,3 @@ def test_refined_window_start(model):
                 reads.append(body[:10] + "".join(second) + body[10:10 + d] + TRUSEQ + body[40:])
     seqs, offsets = orc.pack_reads(reads)
     assert compare(model, TRUSEQ, 0.1, 3, seqs, offsets, skip="refined", label="refined copies") is not None
-
-
-def test_bs3_was_exercised(model):
-    """(last in the file) the bs3 comparisons above really ran: every class occurred, and the conservative path is the
-    exception"""
-    if STATS3["plans"] < 100:
-        pytest.skip("run with the tests above")
-    assert STATS3["reads"] > 200_000 and min(STATS3[c] for c in "TFEC") > 500, STATS3
-    assert STATS3["conservative"] < 0.5 * STATS3["reads"], STATS3      # (the generators above aim at the hard cases)
-    print("bs3:", STATS3)

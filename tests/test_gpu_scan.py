@@ -216,49 +216,6 @@ def test_straggler_list_overflow_is_harmless(hip, orc):
         assert np.array_equal(got[1], want[1]) and np.array_equal(got[0], want[0]), cap
 
 
-def test_scan3_windows_from_chunk_occurrences(hip, orc):
-    """k_back_scan3 (scan3.hip; CAH_SCAN3=1 -- the scan on windows chosen from the adapter's chunk occurrences, back_scan.h
-    "bs3"; the CPU twin is tests/test_back_scan_model.py::compare3): random adapters of 8-34 characters x reads with copies,
-    tails and second copies against the oracle, ragged and equally long; then 4 M reads per read model against the default
-    scan, and a straggler list of ONE entry (the lanes that do not get a slot go round again in place)."""
-    import torch
-    from cutadapt_amd.batch import ReadBatch, match_batch
-    from test_gpu_multi import env
-    rng = random.Random(77)
-    total = 0
-    with env(CAH_SCAN3="1"):
-        for it in range(40):
-            m = rng.choice([8, 12, 16, 20, 25, 31, 32, 33, 34])
-            adapter = "".join(rng.choice("ACGT") for _ in range(m))
-            rate = rng.choice([0.1, 0.12, 0.2, 0.25])
-            min_overlap = rng.choice([1, 3, 5])
-            n = rng.choice([60, 100, 150, 151, 250])
-            reads = _reads(rng, adapter, 5000, n, rng.choice([0.02, 0.06, 0.12]), rng.choice([0.0, 0.01]))
-            if it % 2 == 0:
-                reads = [(r + "ACGT" * n)[:n] for r in reads]                 # equally long: the streaming prefilter's keys
-            seqs, offsets = orc.pack_reads(reads)
-            plan = _plan(adapter, rate, min_overlap)
-            oa = orc.Aligner(adapter, rate, 14, False, False, 1, min_overlap)
-            of = orc.KmerFinder(plan_sets(adapter, min_overlap, rate))
-            w6, wst = orc.match_batch(oa, of, seqs, offsets)
-            for cap in (None, "1"):
-                with env(CAH_SCAN_RETRY_CAP=cap):
-                    g6, gst, _ = match_batch(plan, ReadBatch.from_host(seqs, offsets)).cpu()
-                _same(g6, gst, w6, wst, f"scan3 it {it} adapter {adapter} rate {rate} O {min_overlap} n {n} cap {cap}")
-            total += len(reads)
-    assert total >= 200_000
-    for gen in (dict(p_adapter=0.25, p_edit=0.02, p_n=0.005), dict(p_adapter=1.0, p_edit=0.1, p_n=0.02)):
-        batch = ReadBatch.synthetic(4_000_000, 150, [TRUSEQ], seed=32, **gen)
-        plan = _plan(TRUSEQ, 0.1, 3)
-        a = match_batch(plan, batch)
-        torch.cuda.synchronize()
-        a6, ast = a.out6.clone(), a.status.clone()
-        with env(CAH_SCAN3="1"):
-            b = match_batch(plan, batch)
-            torch.cuda.synchronize()
-        assert torch.equal(ast, b.status) and torch.equal(a6, b.out6), gen
-
-
 def plan_sets(adapter, min_overlap, rate):
     from cutadapt_amd.kmer_heuristic import create_positions_and_kmers
     return create_positions_and_kmers(adapter.upper(), min_overlap, rate, back_adapter=True, front_adapter=False)
