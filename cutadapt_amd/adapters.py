@@ -739,7 +739,7 @@ class LinkedAdapter(Adapter):
             front = fa.match_to_batch(batch)
             lens = batch.lengths()
             rstop = torch.from_numpy(np.where(front.found, front.coords[:, 3], 0)).to(batch.device)
-            view = batch.view(rstop, lens - rstop)
+            view = batch.view(rstop, lens - rstop, check=False)       # (inside its read by construction)
             back = ba.match_to_batch(view)
         else:
             from . import batch as _b

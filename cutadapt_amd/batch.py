@@ -169,18 +169,26 @@ class ReadBatch:
             raise ValueError("String must contain only ASCII characters")
         self.validated = True
 
-    def view(self, starts, lens) -> "ReadBatch":
+    def view(self, starts, lens, check: bool = True) -> "ReadBatch":
         """Sub-sequence view: read r becomes seqs[offsets[r]+starts[r] : ... + lens[r]).
-        Used for the second stage of linked adapters (reference adapters.py:1222-1224)."""
+        Used for the second stage of linked adapters (reference adapters.py:1222-1224).
+        ``check``: views of a uniform batch are streamed by the library (cah_match_batch_views), which needs every view to
+        lie inside its read -- looked at here once, on the device (one synchronisation); a batch with a view that does
+        not takes the plain-views entry point instead (round-5 advisor: the streaming prefilter clamps such a view, the
+        aligner does not).  check=False: the caller vouches for 0 <= starts, starts + lens <= read length."""
         torch = _torch()
         base = self.offsets[: self.n_reads]
         v = ReadBatch(self.seqs, base + starts.to(torch.int64), lens.to(torch.int32),
                       n_reads=self.n_reads, validated=self.validated)
         v._workspace = self._workspace       # same reads, same stream order: the scratch can be shared
         if self.uniform_len and self.lens is None:
-            # views inside the reads of a sequencer's batch (0 <= starts, starts + lens <= read length): the library
-            # streams the parent's reads instead of fetching ragged views (cah_match_batch_views)
-            v.within_uniform = int(self.uniform_len)
+            inside = True
+            if check and self.n_reads:
+                inside = bool(((starts >= 0) & (lens >= 0) & (starts + lens <= int(self.uniform_len))).all().item())
+            if inside:
+                # views inside the reads of a sequencer's batch: the library streams the parent's reads instead of
+                # fetching ragged views (cah_match_batch_views)
+                v.within_uniform = int(self.uniform_len)
         return v
 
     def lengths(self):

@@ -1479,10 +1479,29 @@ int cah_last_multi_path(void) { return t_last_multi_path; }
 static thread_local int t_deferred_errors = 0;
 int cah_set_deferred_errors(int on) { const int old = t_deferred_errors; t_deferred_errors = on ? 1 : 0; return old; }
 
+static thread_local bool t_m2_waited_in_vain = false;     // the last failure of match_batch_multi_once was err bit 1 alone
+static int match_batch_multi_once(const cah_plan* plan, const PlanDeviceCopy* pd, const uint8_t* d_seqs,
+                                  const int64_t* d_offsets, const int32_t* d_lens, int64_t n_reads, int32_t* d_out6,
+                                  int32_t* d_best_adapter, uint8_t* d_status, const Workspace& ws, char* extra,
+                                  hipStream_t s, const UniformLayout ul);
+// (a wave that gave up waiting for its tile -- err bit 1: nothing is wrong with the batch, the device was busy with
+// something else for seconds -- is no reason to fail the call: the batch is matched once more from the start)
 static int match_batch_multi(const cah_plan* plan, const PlanDeviceCopy* pd, const uint8_t* d_seqs,
                              const int64_t* d_offsets, const int32_t* d_lens, int64_t n_reads, int32_t* d_out6,
                              int32_t* d_best_adapter, uint8_t* d_status, const Workspace& ws, char* extra,
                              hipStream_t s, const UniformLayout ul = UniformLayout()) {
+    t_m2_waited_in_vain = false;
+    int rc = match_batch_multi_once(plan, pd, d_seqs, d_offsets, d_lens, n_reads, d_out6, d_best_adapter, d_status, ws, extra, s, ul);
+    if (rc == CAH_EINTERNAL && t_m2_waited_in_vain) {
+        t_m2_waited_in_vain = false;
+        rc = match_batch_multi_once(plan, pd, d_seqs, d_offsets, d_lens, n_reads, d_out6, d_best_adapter, d_status, ws, extra, s, ul);
+    }
+    return rc;
+}
+static int match_batch_multi_once(const cah_plan* plan, const PlanDeviceCopy* pd, const uint8_t* d_seqs,
+                                  const int64_t* d_offsets, const int32_t* d_lens, int64_t n_reads, int32_t* d_out6,
+                                  int32_t* d_best_adapter, uint8_t* d_status, const Workspace& ws, char* extra,
+                                  hipStream_t s, const UniformLayout ul) {
     const MultiPlan& mp = plan->multi;
     const int64_t A = (int64_t)plan->matchers.size();
     const int64_t cap = multi_pair_cap(plan, n_reads);
@@ -1537,6 +1556,7 @@ static int match_batch_multi(const cah_plan* plan, const PlanDeviceCopy* pd, con
                 unsigned long long st[2] = {0ull, 0ull};                // {tiles drawn, error bits}
                 HIP_TRY(hipMemcpyAsync(st, counters + WS_M2_TILE, sizeof(st), hipMemcpyDeviceToHost, s));
                 HIP_TRY(hipStreamSynchronize(s));
+                t_m2_waited_in_vain = st[1] == 2ull;
                 if (st[1])
                     return fail(CAH_EINTERNAL, "multi-adapter path: %s (pool of %lld pages, %lld adapters, %lld reads): results discarded",
                                 (st[1] & 1ull) ? "the page pool ran out" : "a wave waited in vain for its tile",

@@ -232,10 +232,15 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
         // (the entry is written a whole tile ahead of its first use: the wait is short -- and bounded: a wave that waits
         // in vain says so (err bit 1, match_batch_multi returns CAH_EINTERNAL) instead of hanging the device)
         unsigned spins = 0;
+        unsigned long long t_first = 0ull;
         for (;;) {
             e = s_tilemap[kt & (M2_TILE_RING - 1)];
             if ((unsigned)(e >> 32) == kt) break;
-            if (++spins > M2_TILEMAP_SPINS) {
+            // (bounded in polls AND in time -- 2^31 ticks of s_memtime, about a second at the shader clock, twenty at the
+            // 100 MHz reference: a device shared with other work, a debugger, a preempted producer wave must not turn a
+            // slow batch into a failed one -- advisor, round 5; the host tries a batch that gave up here once more)
+            if (spins == 0) t_first = __builtin_amdgcn_s_memtime();
+            if (++spins > M2_TILEMAP_SPINS && __builtin_amdgcn_s_memtime() - t_first > (1ull << 31)) {
                 if (lane == 0) atomicOr(a.err, 2ull);
                 return NO_PIECE;
             }
