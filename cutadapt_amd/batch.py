@@ -281,8 +281,10 @@ def _bucketed_multi(plan: "_lib.Plan", batch: ReadBatch) -> bool:
         return False
     if batch.uniform_len and batch.lens is None:
         return False
-    probe = getattr(batch, "within_uniform", None) or 150
-    return plan.multi_kind(min(int(probe), 160)) == "stream"
+    within = getattr(batch, "within_uniform", None)
+    if within and plan.multi_kind(int(within)) == "stream" and not os.environ.get("CAH_NO_MULTI2_VIEWS"):
+        return False              # views inside a uniform batch: the library streams them end-aligned itself (multi2.hip, RV form)
+    return plan.multi_kind(min(int(within or 150), 160)) == "stream"
 
 
 def match_batch_bucketed(plan: "_lib.Plan", batch: ReadBatch, out: BatchResult) -> Optional[BatchResult]:

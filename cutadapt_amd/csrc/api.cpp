@@ -1517,7 +1517,9 @@ static int match_batch_multi_once(const cah_plan* plan, const PlanDeviceCopy* pd
     // Equally long short reads take the streaming form (multi2.hip): k_multi_stream emits the pairs in pages of one
     // class each (the suffix compare of the error-free rows happens there), k_multi_scan scans them page by page.
     t_last_multi_path = CAH_MULTI_FUSED;
-    if (mp.m2.hdr.ok && ul.len > 0 && !d_lens && multi2_read_len_ok(mp.m2.hdr, ul.len) && !env_flag("CAH_NO_MULTI2")) {
+    const bool views = ul.inner && d_lens != nullptr && d_offsets != nullptr;    // views inside the reads of a uniform batch
+    if (mp.m2.hdr.ok && ul.len > 0 && (!d_lens || (views && !env_flag("CAH_NO_MULTI2_VIEWS"))) &&
+        multi2_read_len_ok(mp.m2.hdr, ul.len) && !env_flag("CAH_NO_MULTI2")) {
         t_last_multi_path = CAH_MULTI_STREAM;
         // the pool: pages of CAH_M2_PAGE pairs + one header word each, inside the pair area
         const int64_t max_pages = ((int64_t)cap * 8) / (CAH_M2_PAGE * 8 + 4);
@@ -1579,6 +1581,7 @@ static int match_batch_multi_once(const cah_plan* plan, const PlanDeviceCopy* pd
                 f.tile_counter = counters + WS_M2_TILE; f.n_tiles = n_tiles; f.gate_pages = gate;
                 f.err = counters + WS_M2_ERR;
                 f.wmeta = d_wmeta;
+                if (views) { f.view_starts = d_offsets; f.view_lens = d_lens; }
                 ProfScope ps(s, CAH_PROF_FILTER, round ? -1 : cnt);
                 HIP_TRY(launch_multi_stream(f, mp.m2.hdr, (int)grid, s));
             }
@@ -1594,6 +1597,7 @@ static int match_batch_multi_once(const cah_plan* plan, const PlanDeviceCopy* pd
                 sa.dp_queue = d_dpq; sa.dp_win = d_win;
                 sa.dp_count_front = counters + WS_DPFRONT; sa.dp_count_back = counters + WS_DPBACK; sa.dp_cap = cap;
                 sa.wmeta = d_wmeta; sa.prefix = pd->d_m2prefix; sa.lmax0 = mp.m2.hdr.lmax0;
+                if (views) { sa.view_starts = d_offsets; sa.view_lens = d_lens; }
                 // (how many pages there are is known on the device only: the blocks draw pages until none is left)
                 ProfScope ps(s, CAH_PROF_SCAN, round ? -1 : cnt);
                 HIP_TRY(launch_multi_scan(sa, std::min(max_pages, n_tiles * per_tile + grid * open_pages), pd->n_cus, s));
@@ -1601,7 +1605,7 @@ static int match_batch_multi_once(const cah_plan* plan, const PlanDeviceCopy* pd
             {
                 // the cell DP over the pairs the scan left (the launch returns at once when there are none)
                 DpArgs a;
-                a.uniform_first = ul.first; a.uniform_len = ul.len;
+                a.uniform_first = ul.first; a.uniform_len = views ? 0 : ul.len;     // (views: the cell DP reads starts + lengths)
                 a.matcher = pd->d_matchers;
                 a.seqs = d_seqs; a.offsets = d_offsets; a.lens = d_lens; a.n_reads = cnt * A;
                 a.max_read_len = CAH_MAX_READ_LEN;
@@ -1622,12 +1626,14 @@ static int match_batch_multi_once(const cah_plan* plan, const PlanDeviceCopy* pd
                                     deferred ? counters + WS_M2_ERR : nullptr));
         return CAH_OK;
     }
+    // (the older kernels take views through their starts and lengths alone)
+    const UniformLayout ulo = ul.inner ? UniformLayout() : ul;
     for (int64_t lo = 0; lo < n_reads; lo += chunk) {
         const int64_t cnt = std::min(chunk, n_reads - lo);
         HIP_TRY(hipMemsetAsync(counters, 0, WS_HEADER, s));
         {
             MultiFilterArgs f;
-            f.uniform_first = ul.first; f.uniform_len = ul.len;
+            f.uniform_first = ulo.first; f.uniform_len = ulo.len;
             f.hdr = pd->d_mhdr; f.dir = pd->d_mdir; f.entries = pd->d_mentries; f.bitmap = pd->d_mbitmap;
             f.seqs = d_seqs; f.offsets = d_offsets; f.lens = d_lens;
             f.first_read = lo; f.n_reads = cnt; f.max_read_len = CAH_MAX_READ_LEN;
@@ -1638,7 +1644,7 @@ static int match_batch_multi_once(const cah_plan* plan, const PlanDeviceCopy* pd
         }
         {
             ScanArgs sa;
-            sa.uniform_first = ul.first; sa.uniform_len = ul.len;
+            sa.uniform_first = ulo.first; sa.uniform_len = ulo.len;
             sa.matcher = pd->d_matchers;
             sa.seqs = d_seqs; sa.offsets = d_offsets; sa.lens = d_lens; sa.n_reads = cnt * A;
             sa.max_read_len = CAH_MAX_READ_LEN;
@@ -1659,7 +1665,7 @@ static int match_batch_multi_once(const cah_plan* plan, const PlanDeviceCopy* pd
         }
         {
             DpArgs a;
-            a.uniform_first = ul.first; a.uniform_len = ul.len;
+            a.uniform_first = ulo.first; a.uniform_len = ulo.len;
             a.matcher = pd->d_matchers;
             a.seqs = d_seqs; a.offsets = d_offsets; a.lens = d_lens; a.n_reads = cnt * A;
             a.max_read_len = CAH_MAX_READ_LEN;
@@ -1730,8 +1736,10 @@ static int match_batch_impl(const cah_plan* plan, const uint8_t* d_seqs, const i
     }
     t_last_multi_path = CAH_MULTI_SEQUENTIAL;
     if (plan->multi.hdr.ok && workspace_bytes >= cah_plan_workspace_bytes(plan, n_reads))
+        // (views inside the reads of a uniform batch -- ul.inner: d_offsets / d_lens are the views' starts and lengths -- go
+        // through with their layout: the streaming form takes them end-aligned, multi2.hip's RV form)
         return match_batch_multi(plan, pd, d_seqs, d_offsets, d_lens, n_reads, d_out6, d_best_adapter, d_status, ws,
-                                 (char*)d_workspace + cah_workspace_bytes(n_reads), s, ul_rest);
+                                 (char*)d_workspace + cah_workspace_bytes(n_reads), s, (ul.inner && d_lens) ? ul : ul_rest);
     for (int32_t ad = 0; ad < (int32_t)plan->matchers.size(); ad++) {
         const CahMatcher& mt = plan->matchers[(size_t)ad];
         if (mt.kind == CAH_KIND_KMER_ONLY) continue;

@@ -95,6 +95,30 @@ __device__ __forceinline__ Chunk load_chunk(const uint8_t* q, int pos, int n, in
     return c;
 }
 
+// The chunk at FRAME position `pos` of a view that is streamed END-ALIGNED in a frame of n characters (pad = n - view
+// length NULs in front; qv: the view's first character): frame position j is the view's j - pad.  pad == 0: load_chunk.
+__device__ __forceinline__ Chunk load_chunk_frame(const uint8_t* qv, const int pos, const int n, const int pad, const int limit) {
+    if (pad == 0) return load_chunk(qv, pos, n, limit);
+    const int vp = pos - pad, nv = n - pad;
+    Chunk c;
+    c.w[0] = c.w[1] = c.w[2] = c.w[3] = 0;
+    if (pos >= limit || vp + 16 <= 0 || nv <= 0) return c;
+    if (vp >= 0) return load_chunk(qv, vp, nv, limit - pad);
+    // the chunk straddles the view's first character: the view's first 16 + vp characters, moved up by -vp bytes
+    const Chunk lo = load_chunk(qv, 0, nv, min(limit - pad, 16 + vp));
+    const int s = -vp;                                                  // 1 .. 15
+    const int dw = s >> 2, sh = (s & 3) * 8;
+    unsigned x0 = lo.w[0], x1 = lo.w[1], x2 = lo.w[2], x3 = lo.w[3];
+    if (dw >= 2) { x3 = x1; x2 = x0; x1 = 0; x0 = 0; }
+    if (dw & 1) { x3 = x2; x2 = x1; x1 = x0; x0 = 0; }
+    c.w[0] = x0 << sh;
+    c.w[1] = (unsigned)((((unsigned long long)x1 << 32) | x0) >> (32 - sh) >> 0);
+    c.w[2] = (unsigned)((((unsigned long long)x2 << 32) | x1) >> (32 - sh));
+    c.w[3] = (unsigned)((((unsigned long long)x3 << 32) | x2) >> (32 - sh));
+    if (sh == 0) { c.w[1] = x1; c.w[2] = x2; c.w[3] = x3; }
+    return c;
+}
+
 // The chunk at `pos` of lanes whose chunk lies inside their read (pos + 16 <= n): ONE load, nothing else -- for callers
 // that have asked the wave first; load_chunk's three cases and the masks behind them are ~35 instructions per call.
 __device__ __forceinline__ Chunk load_chunk_interior(const uint8_t* q, const int pos, const bool want) {

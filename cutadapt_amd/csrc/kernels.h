@@ -246,6 +246,10 @@ struct Multi2Args {
     unsigned long long* tile_counter;
     int64_t n_tiles, gate_pages;
     uint16_t* wmeta;                 // out, per read of the batch: the adapter whose pair saw a further hit (CAH_M2_NO_FLAG ..) | chunk of the earliest such hit << 8
+    // RV form: read r of the batch is the VIEW seqs[view_starts[r], + view_lens[r]) inside seqs[uniform_first + r * uniform_len ..)
+    // (NULL: the reads themselves)
+    const int64_t* view_starts = nullptr;
+    const int32_t* view_lens = nullptr;
 };
 struct Multi2ScanArgs {
     int64_t uniform_first;
@@ -271,6 +275,10 @@ struct Multi2ScanArgs {
     const uint16_t* wmeta;           // per read: Multi2Args::wmeta
     const uint32_t* prefix;          // per adapter: its first ten characters (M2Tables::prefix), for the suffix compare
     int32_t lmax0;                   // the largest overlap without error tolerance
+    // views inside the reads of the uniform batch (k_multi_stream's RV form; NULL: the reads themselves): the scan works on
+    // the end-aligned frame of uniform_len characters and reports in the view's coordinates
+    const int64_t* view_starts = nullptr;
+    const int32_t* view_lens = nullptr;
 };
 bool multi2_read_len_ok(const CahMulti2Header& h, int read_len);
 size_t multi2_lds_bytes(const CahMulti2Header& h);

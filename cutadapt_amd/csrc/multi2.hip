@@ -120,7 +120,13 @@ extern "C" int cah_debug_m2_trace(unsigned long long* out) {
 #define M2_COUNT(st, v) do { } while (0)
 #endif
 
-template <bool W8>
+// RV (round 6): the reads are VIEWS inside the reads of a uniform batch (a.view_starts / a.view_lens: what a pipeline holds
+// behind the quality trimmers) -- streamed END-ALIGNED like k_filter_stream2's RV form: unit u of read r is fetched d[r] =
+// (read end - view end) bytes further down, the characters in front of a view are NUL (they break every k-mer, and every
+// window of the tail classes counts from the END: multi2.h), every position the kernel reports is one of this frame of n
+// characters.  k_multi_scan works on the same frame and reports in the view's coordinates.
+#define M2_RV_BACK 1184            // the copy resource starts this far in front of a piece (>= M2_MAX_LEN + 63 * 15 + 1)
+template <bool W8, bool RV = false>
 __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     const CahMulti2Header* const hd = a.hdr;
@@ -262,13 +268,55 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
     };
     m2_u32x4 pre[2 * M2_HALF];
     const uint8_t* const batch0 = a.seqs + first_byte;
-    auto prefetch = [&](int64_t base) {
+    // RV: the view of read base + lane inside its read as d | skip << 16 -- d: characters between the view's end and the
+    // read's, skip = n - length: where the view starts in the end-aligned frame (clamped to the read: batch.py checks)
+    auto view_of = [&](const int64_t base) -> uint32_t {
+        if (base + lane >= n_reads) return 0u;
+        const int64_t r = a.first_read + base + lane;
+        int st = (int)(a.view_starts[r] - (a.uniform_first + r * (int64_t)n));
+        st = st < 0 ? 0 : (st > n ? n : st);
+        int ln = a.view_lens[r];
+        ln = ln < 0 ? 0 : (ln > n - st ? n - st : ln);
+        return (uint32_t)(n - (st + ln)) | ((uint32_t)(n - ln) << 16);
+    };
+    auto prefetch = [&](int64_t base, const uint32_t vw = 0u) {
         const int64_t left = n_reads - base;
         if (left <= 0) return;
         const int64_t pbyte = base * (int64_t)n;
         const uint8_t* const src = batch0 + pbyte;
-        if (left >= WAVE && pbyte + (int64_t)WAVE * n + 16 <= total) {
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(m2_uniform_ptr(src), 0, 0x7FFFFFFF, 0x00020000);
+        if (left >= WAVE && pbyte + (int64_t)WAVE * n + 16 <= total && (!RV || pbyte >= M2_RV_BACK)) {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(m2_uniform_ptr(RV ? src - M2_RV_BACK : src), 0, 0x7FFFFFFF, 0x00020000);
+            if constexpr (RV) {
+                // (k_filter_stream2's RV copy plan: what a unit needs of its read r is computed once per read, in lane r, for
+                // either half's shape and handed over by one lane exchange per unit: the low half A = r (n - 16 H) + BACK -
+                // d[r] -- unit 64 k + lane starts at byte A + 16 lane + 1024 k of the resource --, the high half T = skip[r]
+                // + 16 r H: the unit lies in front of its view iff its last character is < T, and is then not fetched: an
+                // offset out of the resource's range returns zeros)
+                const int d = (int)(vw & 0xFFFFu), sk = (int)(vw >> 16);
+                const unsigned w1 = (unsigned)(__mul24(lane, n - 16 * H1) + M2_RV_BACK - d) | ((unsigned)(sk + 16 * __mul24(lane, H1)) << 16);
+                const unsigned w2 = (unsigned)(__mul24(lane, n - 16 * H2) + M2_RV_BACK - d) | ((unsigned)(sk + 16 * __mul24(lane, H2)) << 16);
+                int got[2 * M2_HALF];
+#pragma unroll
+                for (int kk = 0; kk < M2_HALF; ++kk) {
+                    got[kk] = __builtin_amdgcn_ds_bpermute(unit_r(kk, magic1) << 2, (int)w1);
+                    got[M2_HALF + kk] = __builtin_amdgcn_ds_bpermute(unit_r(kk, magic2) << 2, (int)w2);
+                }
+#pragma unroll
+                for (int kk = 0; kk < M2_HALF; ++kk)
+                    if (kk < H1) {
+                        const int w = got[kk];
+                        const unsigned off = (int)lane16 + (16 * kk * WAVE + 15) < (w >> 16) ? 0x80000000u : (unsigned)((w & 0xFFFF) + (int)lane16);
+                        pre[kk] = __builtin_amdgcn_raw_buffer_load_b128(rs, off + kk * (WAVE * 16), 0, 0);
+                    }
+#pragma unroll
+                for (int kk = 0; kk < M2_HALF; ++kk)
+                    if (kk < H2) {
+                        const int w = got[M2_HALF + kk];
+                        const unsigned off = (int)lane16 + (16 * kk * WAVE + 15) + 16 * H1 < (w >> 16) ? 0x80000000u : (unsigned)((w & 0xFFFF) + (int)lane16);
+                        pre[M2_HALF + kk] = __builtin_amdgcn_raw_buffer_load_b128(rs, off + kk * (WAVE * 16), 16 * H1, 0);
+                    }
+                return;
+            }
 #pragma unroll
             for (int kk = 0; kk < M2_HALF; ++kk)
                 if (kk < H1)
@@ -287,6 +335,28 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
             const int kk = q < M2_HALF ? q : q - M2_HALF;
             const int H = q < M2_HALF ? H1 : H2;
             m2_u32x4 got = (m2_u32x4)(0u);
+            if constexpr (RV) {
+                // byte by byte: a shifted unit may begin in front of the batch or end behind it
+                if (kk < H) {                                           // (wave-uniform: every lane takes part in the exchange)
+                    const int r = unit_r(kk, q < M2_HALF ? magic1 : magic2);
+                    const int w = __builtin_amdgcn_ds_bpermute(r << 2, (int)vw);
+                    const int sh = w & 0xFFFF;
+                    const int last = 16 * (kk * WAVE + lane - __mul24(r, H)) + (q < M2_HALF ? 15 : 16 * H1 + 15);
+                    if (kk * WAVE + lane < reads * H && last >= (w >> 16)) {       // (a unit in front of the view: zeros)
+                        const int64_t g0 = pbyte + (int64_t)(__mul24(r, n - 16 * H) + (kk * WAVE) * 16 + (int)lane16 +
+                                                             (q < M2_HALF ? 0 : 16 * H1)) - sh;
+                        unsigned x[4] = {0u, 0u, 0u, 0u};
+#pragma unroll 1
+                        for (int b = 0; b < 16; ++b) {
+                            const int64_t at = g0 + b;
+                            if (at >= 0 && at < total) x[b >> 2] |= (unsigned)batch0[at] << (8 * (b & 3));
+                        }
+                        got = (m2_u32x4){x[0], x[1], x[2], x[3]};
+                    }
+                }
+                pre[q] = got;
+                continue;
+            }
             if (kk < H && kk * WAVE + lane < reads * H) {
                 const int r = unit_r(kk, q < M2_HALF ? magic1 : magic2);
                 const unsigned goff = (unsigned)(__mul24(r, n - 16 * H) + (kk * WAVE) * 16 + (int)lane16 + (q < M2_HALF ? 0 : 16 * H1));
@@ -327,7 +397,19 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
         __builtin_amdgcn_wave_barrier();
     };
     // the chunk at `pos`: characters past the read's end become NUL
+    int skip = 0;                                                       // RV: this lane's view starts `skip` characters into the frame
     auto finish = [&](m2_u32x4 v, int pos) -> m2_u32x4 {
+        if constexpr (RV) {
+            if (m2_any(skip > pos)) {                                   // (the unit a view starts in holds its read's characters in front of it)
+                unsigned x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int drop = skip - pos - 4 * i;                // characters of dword i in front of the view
+                    x[i] = drop <= 0 ? x[i] : (drop >= 4 ? 0u : (x[i] & (0xFFFFFFFFu << (8 * drop))));
+                }
+                v = (m2_u32x4){x[0], x[1], x[2], x[3]};
+            }
+        }
         if (pos + 16 > n) {
             unsigned x[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -411,11 +493,15 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
             m2_u32x2 st = (m2_u32x2)(0u);
             if (mine) st = s_ring[(stage0 + (unsigned)lane) & (M2_RING - 1)];
             const int pc = (int)((st.x >> 28) & 7u);
+            const int lr2 = (int)(st.y - (uint32_t)(a.first_read + piece_first));
+            // (RV: a result is reported in the VIEW's coordinates: the frame's minus the NULs in front of the view -- the
+            // staged pair's read is another lane's)
+            int nv2 = n;
+            if constexpr (RV) nv2 = n - __builtin_amdgcn_ds_bpermute(lr2 << 2, skip);
             if (mine && pc == 7) {
                 const int adapter = (int)((st.x >> 8) & 255u);
-                const int lr2 = (int)(st.y - (uint32_t)(a.first_read + piece_first));
                 const int i = m2_exact_tail(s_rlast[lr2], s_prefix[adapter], min_overlap, lmax0, n);
-                if (i > 0) atomicMax(a.best_key + st.y, pack_best(i, 0, adapter, i, n - i, n));
+                if (i > 0) atomicMax(a.best_key + st.y, pack_best(i, 0, adapter, i, nv2 - i, nv2));
             }
             unsigned long long em = __ballot(mine && pc != 7);
             const uint64_t pair = ((uint64_t)st.y << 32) | (uint64_t)(st.x & 0x0FFFFFFFu);
@@ -566,7 +652,9 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
     const int tail_unit0 = (tail_base - tail_off) >> 4;                 // row unit of the first tail chunk
 
     int64_t base_cur = piece_base((unsigned)wave);
-    prefetch(base_cur);
+    uint32_t vw_cur = 0u;
+    if constexpr (RV) vw_cur = base_cur < NO_PIECE ? view_of(base_cur) : 0u;
+    prefetch(base_cur, vw_cur);
 #pragma unroll 1
     for (;;) {
         if (base_cur >= NO_PIECE) break;
@@ -574,6 +662,7 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
         const bool more = (unsigned)base < (unsigned)n_reads;
         const bool valid = more && (unsigned)(base + lane) < (unsigned)n_reads;
         piece_first = base;
+        if constexpr (RV) skip = (int)(vw_cur >> 16);
         M2_STAMP(0);
         if (more) {
             // ---- per-read state
@@ -789,7 +878,7 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
                         if (match && (old & bit) == 0) {
                             ss[word] = old | bit;
                             const int i = m2_exact_tail(rlast, s_prefix[adapter], min_overlap, lmax0, n);
-                            const unsigned long long kk = i > 0 ? pack_best(i, 0, adapter, i, n - i, n) : 0ull;
+                            const unsigned long long kk = i > 0 ? pack_best(i, 0, adapter, i, n - skip - i, n - skip) : 0ull;
                             bestk = kk > bestk ? kk : bestk;
                         }
                         ++u; --left;
@@ -812,7 +901,8 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
             if (valid && (seen_chars & 0x80808080u) != 0) a.status[a.first_read + base + lane] = 2;
         }
         base_cur = piece_base(take_piece());
-        prefetch(base_cur);
+        if constexpr (RV) vw_cur = base_cur < NO_PIECE ? view_of(base_cur) : 0u;
+        prefetch(base_cur, vw_cur);
         M2_STAMP(9);
 #ifdef M2_TRACE
         if (blockIdx.x == 7 && wave == 5) ++trace_it;
@@ -869,6 +959,19 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_multi
     const int lane = wave_lane();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int n = a.uniform_len;
+    // the read of a pair: its first character and, for a view inside its read (k_multi_stream's RV form), the NULs in front
+    // of it in the end-aligned frame of n characters the scan works on (clamped to the read exactly as view_of does there)
+    auto frame_of = [&](const int64_t r, int& pad) -> const uint8_t* {
+        const int64_t at = a.uniform_first + r * (int64_t)n;
+        pad = 0;
+        if (!a.view_starts) return a.seqs + at;
+        int st = (int)(a.view_starts[r] - at);
+        st = st < 0 ? 0 : (st > n ? n : st);
+        int ln = a.view_lens[r];
+        ln = ln < 0 ? 0 : (ln > n - st ? n - st : ln);
+        pad = n - ln;
+        return a.seqs + at + st;
+    };
     int64_t n_pages = (int64_t)(*a.page_counter);
     if (n_pages > a.max_pages) {                                        // (k_multi_stream has flagged it; said again here)
         if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(a.err, 1ull);
@@ -911,8 +1014,9 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_multi
                             precise = 1;
                             m2_precise_window((int)key, (int)(flags >> CAH_M2_PAIR_CHUNK_SHIFT) & 3, p.m, p.k, chunk_base, chunk_extra, n, j0w, jb);
                             // the read's last ten characters against the adapter's first: the error-free overlaps
-                            const uint8_t* q = a.seqs + a.uniform_first + r * (int64_t)n;
-                            const Chunk tl = load_chunk(q, n - 16, n, n);
+                            int pad_a = 0;
+                            const uint8_t* q = frame_of(r, pad_a);
+                            const Chunk tl = load_chunk_frame(q, n - 16, n, pad_a, n);
                             uint32_t rlast = 0;
 #pragma unroll
                             for (int c = 6; c < 16; ++c) rlast = (rlast << 3) | (uint32_t)s_xlat[chunk_byte(tl, c) & 127u];
@@ -973,7 +1077,8 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_multi
                 key = (unsigned)pr & 0xFFu;
                 tab_base = adapter * CAH_MULTI_TAB_STRIDE;
             }
-            const uint8_t* q = a.seqs + a.uniform_first + r * (int64_t)n;
+            int pad = 0;
+            const uint8_t* q = frame_of(r, pad);
             // A tail page's pairs all have the same window (one class, one read length), from column 4 * key: the scan
             // starts a whole number of 16-column chunks in front of the read end and skips the first chunk's columns in
             // front of the window.  A whole-read page's wave starts at its earliest window's chunk and ends behind its
@@ -1027,11 +1132,11 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_multi
             int j = jstart, exact_j = 0;                                // (wave-uniform: every lane walks the same columns)
             bool done = !valid, exact = false;
             int pos = j0;
-            Chunk cur = load_chunk(q, pos, n, valid ? n : 0);
+            Chunk cur = load_chunk_frame(q, pos, n, pad, valid ? n : 0);
             int first_t = t0;
             auto walk = [&](auto stepf) {
                 while (j < jend) {
-                    const Chunk nxt = load_chunk(q, pos + 16, n, (!done && pos + 16 < jend) ? n : 0);
+                    const Chunk nxt = load_chunk_frame(q, pos + 16, n, pad, (!done && pos + 16 < jend) ? n : 0);
                     // a window that starts at column 0 need not be a whole number of chunks: the last chunk then ends early
                     const int last_t = min(16, n - pos);
                     if (first_t == 0 && last_t == 16) {
@@ -1105,19 +1210,33 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_multi
                 // error-free overlap is acceptable too: the cell DP sorts that out, to the read's end
             }
             if (exact) { cls = BS_EXACT_FULL; o0 = exact_j; }
-            if (valid) {
-                if (cls == BS_EXACT_FULL) atomicMax(a.best_key + r, pack_best(p.m, 0, (int)adapter, p.m, o0 - p.m, o0));
-                else if (cls == BS_EXACT_TAIL) atomicMax(a.best_key + r, pack_best(o0 - 2 * o1, o1, (int)adapter, o0, n - o0, n));
-                else if (cls == BS_SUBS_FULL) atomicMax(a.best_key + r, pack_best(p.m - 2 * o1, o1, (int)adapter, p.m, o0 - p.m, o0));
-                else if (cls == BS_INDEL1_FULL)
-                    atomicMax(a.best_key + r, pack_best(p.m - 2 * (o1 >> 1) - (o1 & 1), o1 >> 1, (int)adapter, p.m,
-                                                        o0 - p.m + ((o1 & 1) ? 1 : -1), o0));
-                else if (cls == BS_NONE && stopped && tail0 > 0)
-                    atomicMax(a.best_key + r, pack_best((int)tail0, 0, (int)adapter, (int)tail0, n - (int)tail0, n));
-            }
             // the cell DP of a tail pair runs over the full reach: band, last_filled and the stale origin of its final
             // scan are only proven equal to the reference's from column start + m + k + 1 on (column skipping)
             if (cls == BS_DP && tail_page) o0 = max(0, (jfa >= 0 ? jfa : n) - reach);
+            if (valid) {
+                // (a view's frame -> the view: every coordinate moves by the pad; a shortcut whose alignment would BEGIN in the
+                // pad is no shortcut -- there the reference deletes adapter characters where the frame substitutes NULs, other
+                // scores, other origins: the pair takes the cell DP on the view, from its first column, every row of its last)
+                bool in_pad = false;
+                auto shortcut = [&](const int score, const int errors, const int ref_stop, const int qs, const int qe) {
+                    if (qs < pad) in_pad = true;
+                    else atomicMax(a.best_key + r, pack_best(score, errors, (int)adapter, ref_stop, qs - pad, qe - pad));
+                };
+                if (cls == BS_EXACT_FULL) shortcut(p.m, 0, p.m, o0 - p.m, o0);
+                else if (cls == BS_EXACT_TAIL) shortcut(o0 - 2 * o1, o1, o0, n - o0, n);
+                else if (cls == BS_SUBS_FULL) shortcut(p.m - 2 * o1, o1, p.m, o0 - p.m, o0);
+                else if (cls == BS_INDEL1_FULL)
+                    shortcut(p.m - 2 * (o1 >> 1) - (o1 & 1), o1 >> 1, p.m, o0 - p.m + ((o1 & 1) ? 1 : -1), o0);
+                else if (cls == BS_NONE && stopped && tail0 > 0)
+                    atomicMax(a.best_key + r, pack_best((int)tail0, 0, (int)adapter, (int)tail0, n - pad - (int)tail0, n - pad));
+                if (in_pad) { cls = BS_DP; o0 = 0; o1 = 2 * n + 1; }
+                if (cls == BS_DP && pad > 0) {
+                    // (the cell DP sees the view: the window's columns moved by the pad)
+                    const int last = max(0, min(n, o1 >> 1) - pad);
+                    o0 = max(0, o0 - pad);
+                    o1 = 2 * last + (o1 & 1);
+                }
+            }
             const bool to_dp = valid && cls == BS_DP;
             const bool to_back = to_dp && (o1 & 1);
             const bool to_front = to_dp && !(o1 & 1);
@@ -1194,16 +1313,26 @@ hipError_t launch_multi_stream(const Multi2Args& a, const CahMulti2Header& h, in
     {
         std::lock_guard<std::mutex> lk(attr_mu);
         if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-            e = hipFuncSetAttribute((const void*)k_multi_stream<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            e = hipFuncSetAttribute((const void*)k_multi_stream<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
-            e = hipFuncSetAttribute((const void*)k_multi_stream<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            e = hipFuncSetAttribute((const void*)k_multi_stream<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            e = hipFuncSetAttribute((const void*)k_multi_stream<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            e = hipFuncSetAttribute((const void*)k_multi_stream<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
             if (dev >= 0 && dev < 64) attr_set[dev] = true;
         }
     }
     if (grid < 1) grid = 1;
-    if (h.q_mask[M2_W] == (1 << 8)) hipLaunchKernelGGL(k_multi_stream<true>, dim3(grid), dim3(M2_WAVES * WAVE), lds, s, a);
-    else hipLaunchKernelGGL(k_multi_stream<false>, dim3(grid), dim3(M2_WAVES * WAVE), lds, s, a);
+    const bool w8 = h.q_mask[M2_W] == (1 << 8);
+    if (a.view_starts) {
+        if (w8) hipLaunchKernelGGL((k_multi_stream<true, true>), dim3(grid), dim3(M2_WAVES * WAVE), lds, s, a);
+        else hipLaunchKernelGGL((k_multi_stream<false, true>), dim3(grid), dim3(M2_WAVES * WAVE), lds, s, a);
+    } else {
+        if (w8) hipLaunchKernelGGL((k_multi_stream<true, false>), dim3(grid), dim3(M2_WAVES * WAVE), lds, s, a);
+        else hipLaunchKernelGGL((k_multi_stream<false, false>), dim3(grid), dim3(M2_WAVES * WAVE), lds, s, a);
+    }
     return hipGetLastError();
 }
 

@@ -115,7 +115,8 @@ extern "C" {
 // Returns 0; 1 when the tables cannot be built (the plan would take the older path).
 int m2m_match_batch(const char* adapters, int A, int m, const void* blobs, int32_t n_ref, const int32_t* ref_adapter,
                     const int32_t* ref_window, const char* ref_kmers, const uint8_t* seqs, const int64_t* offsets,
-                    int64_t n_reads, int32_t* out6, uint8_t* status, int32_t* best, int subs, int64_t* stats) {
+                    int64_t n_reads, int32_t* out6, uint8_t* status, int32_t* best, int subs, int64_t* stats,
+                    const int32_t* pads) {
     std::vector<std::string> ads;
     for (int a = 0; a < A; a++) ads.push_back(std::string(adapters + (size_t)a * m, (size_t)m));
     std::vector<CahMatcher> mts((size_t)A);
@@ -134,8 +135,21 @@ int m2m_match_batch(const char* adapters, int A, int m, const void* blobs, int32
     const int kind = bs_kind_of(p.m);
     const int reach = p.m + p.k + 1;
     for (int64_t r = 0; r < n_reads; r++) {
-        const uint8_t* q = seqs + offsets[r];
-        const int n = (int)(offsets[r + 1] - offsets[r]);
+        // pads (may be NULL): read r is a VIEW streamed END-ALIGNED in a frame of pads[r] + its length characters (what the
+        // kernels do with the views of a uniform batch: pads[r] NULs in front, multi2.hip): the prefilter and the scan work on
+        // the padded frame (q, n), the cell DP and every reported coordinate on the view itself (qv, nv); a shortcut of the
+        // scan whose alignment would begin inside the pad is no shortcut -- the pair takes the cell DP on the view
+        const uint8_t* const qv = seqs + offsets[r];
+        const int nv = (int)(offsets[r + 1] - offsets[r]);
+        const int pad = pads ? pads[r] : 0;
+        std::vector<uint8_t> padded;
+        const uint8_t* q = qv;
+        int n = nv;
+        if (pad > 0) {
+            padded.assign((size_t)(pad + nv), 0);
+            memcpy(padded.data() + pad, qv, (size_t)nv);
+            q = padded.data(); n = pad + nv;
+        }
         int32_t* o = out6 + r * 6;
         for (int i = 0; i < 6; i++) o[i] = 0;
         status[r] = 0; best[r] = -1;
@@ -146,7 +160,7 @@ int m2m_match_batch(const char* adapters, int A, int m, const void* blobs, int32
         filter_read(t, q, n, st);
         unsigned long long bestkey = 0;
         for (auto& ex : st.exact) {
-            bestkey = std::max(bestkey, pack_best(ex.second, 0, ex.first, ex.second, n - ex.second, n));
+            bestkey = std::max(bestkey, pack_best(ex.second, 0, ex.first, ex.second, nv - ex.second, nv));
             if (stats) stats[3]++;
         }
         if (stats) { stats[4] += st.conservative; for (int c = 0; c < 4; c++) stats[8 + c] += st.events[c]; }
@@ -253,31 +267,40 @@ int m2m_match_batch(const char* adapters, int A, int m, const void* blobs, int32
             else M2M_RUN32(2)
 #undef M2M_RUN32
             unsigned long long key = 0;
-            if (cls == BS_EXACT_FULL) key = pack_best(p.m, 0, pr.adapter, p.m, o0 - p.m, o0);
-            else if (cls == BS_EXACT_TAIL) key = pack_best(o0 - 2 * o1, o1, pr.adapter, o0, n - o0, n);
-            else if (cls == BS_SUBS_FULL) key = pack_best(p.m - 2 * o1, o1, pr.adapter, p.m, o0 - p.m, o0);
+            bool in_pad = false;
+            // a shortcut's tuple, in the coordinates of the view
+            auto shortcut = [&](int score, int errors, int ref_stop, int qs, int qe) {
+                if (qs < pad) { in_pad = true; return; }
+                key = pack_best(score, errors, pr.adapter, ref_stop, qs - pad, qe - pad);
+            };
+            if (cls == BS_EXACT_FULL) shortcut(p.m, 0, p.m, o0 - p.m, o0);
+            else if (cls == BS_EXACT_TAIL) shortcut(o0 - 2 * o1, o1, o0, n - o0, n);
+            else if (cls == BS_SUBS_FULL) shortcut(p.m - 2 * o1, o1, p.m, o0 - p.m, o0);
             else if (cls == BS_INDEL1_FULL)
-                key = pack_best(p.m - 2 * (o1 >> 1) - (o1 & 1), o1 >> 1, pr.adapter, p.m, o0 - p.m + ((o1 & 1) ? 1 : -1), o0);
-            else if (cls == BS_DP) {
+                shortcut(p.m - 2 * (o1 >> 1) - (o1 & 1), o1 >> 1, p.m, o0 - p.m + ((o1 & 1) ? 1 : -1), o0);
+            if (in_pad) { cls = BS_DP; o0 = 0; o1 = 2 * n + 1; }      // (the view from its first column, every row of its last)
+            if (cls == BS_DP) {
                 // a tail pair's cell DP runs over the FULL reach (the band, last_filled and the stale origin of the
                 // final scan are only proven equal to the reference's from column start + m + k + 1 on)
-                if (tail) o0 = std::max(0, (jfa >= 0 ? jfa : n) - reach);
+                if (tail && !in_pad) o0 = std::max(0, (jfa >= 0 ? jfa : n) - reach);
                 int t6[6];
                 if (stats) { stats[6]++; stats[12 + (tail ? (is_lo ? 2 : 1) : (precise ? 3 : 0))]++; }
-                if (dp_window(mt, q, n, o0, std::min(n, o1 >> 1), (o1 & 1) != 0, t6)) {
+                // (the cell DP sees the VIEW: the window's columns moved by the pad)
+                const int first = std::max(0, o0 - pad), last = std::max(0, std::min(n, o1 >> 1) - pad);
+                if (dp_window(mt, qv, nv, std::min(first, nv), std::min(last, nv), (o1 & 1) != 0, t6)) {
                     // the corner of multi2.h's head: a tail pair's match that reaches further back than its error class's
                     // last row -- is the reference's kmers_present true for the pair?
                     bool ref_ok = true;
                     static const bool no_refcheck = getenv("M2M_NO_REFCHECK") != nullptr;     // (to show that the tests need the check)
-                    if (tail && !no_refcheck && n - t6[2] > (int)t.hdr.lmax_row[t6[1]]) {
-                        ref_ok = m2_ref_present(t.ref_list.data(), t.ref_begin[(size_t)pr.adapter], t.ref_begin[(size_t)pr.adapter + 1], q, n, t.hdr.ref_span);
+                    if (tail && !no_refcheck && nv - t6[2] > (int)t.hdr.lmax_row[t6[1]]) {
+                        ref_ok = m2_ref_present(t.ref_list.data(), t.ref_begin[(size_t)pr.adapter], t.ref_begin[(size_t)pr.adapter + 1], qv, nv, t.hdr.ref_span);
                         if (stats) stats[15]++;
                     }
                     if (ref_ok) key = pack_best(t6[4], t6[5], pr.adapter, t6[1], t6[2], t6[3]);
                 }
             }
             // the error-free overlap of a pair without a candidate in its window
-            if (precise && cls == BS_NONE && tail0 > 0) key = pack_best(tail0, 0, pr.adapter, tail0, n - tail0, n);
+            if (precise && cls == BS_NONE && tail0 > 0) key = pack_best(tail0, 0, pr.adapter, tail0, nv - tail0, nv);
             bestkey = std::max(bestkey, key);
         }
         if (bestkey) {

@@ -291,6 +291,62 @@ def test_first_occurrence_race_at_scale(hip, orc):
         assert int(f.sum()) > 0.4 * n_reads
 
 
+def _lib_last_path():
+    from cutadapt_amd import _lib
+    return _lib.last_multi_path()
+
+
+def test_views_of_a_uniform_batch_stream(hip, orc):
+    """Round 6: views inside the reads of a uniform batch (reads cut by a modifier in front of the adapter search, reference
+    cli.py:938-954) through the streaming multi-adapter form itself: k_multi_stream's RV form copies them END-ALIGNED into
+    a frame of the parent's length, k_multi_scan works on the frame and reports in the view's coordinates, a shortcut whose
+    alignment would begin in the pad goes to the cell DP on the view (host model: test_views_in_a_padded_frame).  Views
+    cut at either end -- a 5' cut inside an adapter copy leaves its tail at the view's first characters --, every length
+    0 .. n, parents of 100 / 150 / 151 / 160 and 64 characters, against the oracle on the views."""
+    import torch
+    from cutadapt_amd.batch import ReadBatch, match_batch
+    prng = random.Random(92)
+    checked = 0
+    for it, (count, m, n, rate) in enumerate(((24, 33, 150, 0.1), (8, 33, 151, 0.1), (24, 30, 100, 0.1), (3, 20, 64, 0.15),
+                                              (48, 33, 160, 0.1), (8, 24, 150, 0.2))):
+        seqs = [rs(prng, m) for _ in range(count)]
+        plan, ads = plan_for(seqs, rate, 3)
+        if plan.multi_kind(n) != "stream":
+            continue
+        n_reads = 60_000
+        parent = ReadBatch.synthetic(n_reads, n, seqs, seed=40 + it, p_adapter=0.8, p_edit=0.04, p_n=0.004)
+        idx = torch.arange(n_reads, dtype=torch.int64, device=parent.device)
+        mode = idx % 4
+        a = torch.where((mode == 1) | (mode == 3), ((idx * 2654435761) >> 9) % (n + 1), torch.zeros_like(idx))
+        b = torch.where((mode == 2) | (mode == 3), a + ((idx * 40503 + 77) >> 4) % (n + 1 - a), torch.full_like(idx, n))
+        lens = b - a
+        lens[::997] = 0
+        view = parent.view(a, lens)
+        got = match_batch(plan, view)
+        torch.cuda.synchronize()
+        assert _lib_last_path() == "stream", _lib_last_path()
+        h_seqs = parent.seqs.cpu().numpy()
+        h_off = (parent.offsets[:n_reads] + a).cpu().numpy()
+        h_len = lens.cpu().numpy()
+        m_chk = 25_000
+        reads = [bytes(h_seqs[int(o):int(o) + int(l)]).decode("latin-1") for o, l in zip(h_off[:m_chk], h_len[:m_chk])]
+        sq, offs = orc.pack_reads(reads)
+        want6, want_st, want_best = oracle_multiple(orc, ads, sq, offs)
+        g6, gst = got.out6[:m_chk].cpu().numpy(), got.status[:m_chk].cpu().numpy()
+        bad = np.nonzero((gst != want_st) | (g6 != want6).any(axis=1))[0]
+        assert len(bad) == 0, (it, len(bad), int(bad[0]), reads[int(bad[0])], g6[bad[0]].tolist(), want6[bad[0]].tolist(),
+                               int(h_len[bad[0]]))
+        fw = want_st == 1
+        assert np.array_equal(got.best_adapter[:m_chk].cpu().numpy()[fw], want_best[fw]), it
+        # ... and the whole batch against the per-lane kernels
+        with env(CAH_NO_MULTI2_VIEWS="1", CAH_NO_BUCKETS="1"):
+            want = match_batch(plan, view)
+            torch.cuda.synchronize()
+        assert torch.equal(got.status, want.status) and torch.equal(got.out6, want.out6), it
+        checked += 1
+    assert checked >= 4, checked
+
+
 def test_ragged_batches_take_length_buckets(hip, orc):
     """Ragged batches of a plan with several adapters (reads cut by a modifier in front of the adapter search, reference
     cli.py:938-954): cutadapt_amd.batch.match_batch sorts the reads into buckets of one length each on the device and runs
@@ -312,12 +368,16 @@ def test_ragged_batches_take_length_buckets(hip, orc):
     lens[::1000] = 0
     starts = ((idx * 40503) >> 3) % (151 - lens)                      # anywhere inside the read
     view = parent.view(starts, lens)
-    assert B._bucketed_multi(plan, view)
-    got = match_batch(plan, view)
-    torch.cuda.synchronize()
-    with env(CAH_NO_BUCKETS="1"):
-        want = match_batch(plan, view)
+    # (views inside a uniform batch are streamed end-aligned by the library itself: test_views_of_a_uniform_batch_stream)
+    assert not B._bucketed_multi(plan, view)
+    with env(CAH_NO_MULTI2_VIEWS="1"):
+        assert B._bucketed_multi(plan, view)
+        got = match_batch(plan, view)
         torch.cuda.synchronize()
+        with env(CAH_NO_BUCKETS="1"):
+            want = match_batch(plan, view)
+            torch.cuda.synchronize()
+            assert _lib_last_path() != "stream"
     assert torch.equal(got.status, want.status) and torch.equal(got.out6, want.out6)
     f = want.status == 1
     assert torch.equal(got.best_adapter[f], want.best_adapter[f])

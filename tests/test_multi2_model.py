@@ -30,7 +30,7 @@ def model():
         subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", SRC, "-o", SO], check=True)
     L = C.CDLL(SO)
     vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int32
-    L.m2m_match_batch.argtypes = [C.c_char_p, i32, i32, vp, i32, vp, vp, C.c_char_p, vp, vp, i64, vp, vp, vp, i32, vp]
+    L.m2m_match_batch.argtypes = [C.c_char_p, i32, i32, vp, i32, vp, vp, C.c_char_p, vp, vp, i64, vp, vp, vp, i32, vp, vp]
     return L
 
 
@@ -79,7 +79,7 @@ def oracle_multiple(adapters, rate, min_overlap, per_adapter, seqs, offsets):
     return want6, want_st, want_best
 
 
-def run(model, adapters, rate, min_overlap, seqs, offsets, label, sets=None, must_build=True):
+def run(model, adapters, rate, min_overlap, seqs, offsets, label, sets=None, must_build=True, pads=None):
     m = len(adapters[0])
     blobs = matcher_blobs(adapters, rate, min_overlap)
     ra, rw, rk, per_adapter = ref_sets(adapters, rate, min_overlap, sets)
@@ -93,7 +93,8 @@ def run(model, adapters, rate, min_overlap, seqs, offsets, label, sets=None, mus
         stats = np.zeros(16, dtype=np.int64)
         rc = model.m2m_match_batch("".join(adapters).encode(), len(adapters), m, blobs, len(ra), ra.ctypes.data,
                                    rw.ctypes.data, rk, seqs.ctypes.data, offsets.ctypes.data, n, out6.ctypes.data,
-                                   status.ctypes.data, best.ctypes.data, subs, stats.ctypes.data)
+                                   status.ctypes.data, best.ctypes.data, subs, stats.ctypes.data,
+                                   None if pads is None else pads.ctypes.data)
         if rc == 1:
             assert not must_build, f"{label}: the tables were not built"
             return None
@@ -199,6 +200,45 @@ def test_adapter_families_that_share_their_kmers(model):
         run(model, ads, 0.1, 3, seqs, offsets, f"family of {len(ads)}, m {m}")
         seqs, offsets = orc.synth_reads(12, 0, 1500, 150, ads, p_adapter=0.7, p_edit=0.04)
         run(model, ads, 0.1, 3, seqs, offsets, f"family of {len(ads)}, m {m}, synthetic")
+
+
+def test_views_in_a_padded_frame(model):
+    """Round 6: the views of a uniform batch through the streaming form -- every view END-aligned in a frame of the parent's
+    length (NULs in front): prefilter and scan on the frame, the cell DP and every coordinate on the view, a shortcut whose
+    alignment would begin inside the pad handed to the cell DP.  Views cut at either end (a cut at the 5' end leaves adapter
+    TAILS at the view's first characters: the pad's case), every length from 0 on, against the oracle on the views."""
+    rng = np.random.default_rng(81)
+    built = 0
+    for it in range(16):
+        m = int(rng.choice([20, 24, 30, 33, 34, 40, 64]))
+        count = int(rng.choice([2, 8, 24]))
+        ads = rand_adapters(rng, count, m)
+        rate = float(rng.choice([0.1, 0.1, 0.15, 0.2]))
+        O = int(rng.choice([1, 3, 5]))
+        N = int(rng.choice([100, 150, 151, 160]))
+        reads = tail_reads(rng, ads, 700, N, p_n=0.005)
+        reads = [r if len(r) == N else (r + "A" * N)[:N] for r in reads]
+        sq2, of2 = orc.synth_reads(int(rng.integers(1, 10 ** 6)), 0, 900, N, ads, p_adapter=0.85,
+                                   p_edit=float(rng.choice([0.02, 0.06, 0.1])), p_n=0.005)
+        reads += [bytes(sq2[of2[i]:of2[i + 1]]).decode("latin-1") for i in range(900)]
+        views = []
+        for i, r in enumerate(reads):
+            mode = i % 4
+            a = int(rng.integers(0, N + 1)) if mode in (1, 3) else 0           # cut at the 5' end
+            b = int(rng.integers(a, N + 1)) if mode in (2, 3) else N           # ... and at the 3' end
+            if mode == 1 and rng.random() < 0.5:
+                # a cut that lands inside an adapter copy, near its head (the alignment would begin in the pad)
+                for ad in ads:
+                    at = r.find(ad[4:14])
+                    if at >= 0:
+                        a = min(N, at + int(rng.integers(0, 4)))
+                        break
+            views.append(r[a:b])
+        seqs, offsets = orc.pack_reads(views)
+        pads = (N - np.diff(offsets)).astype(np.int32)
+        if run(model, ads, rate, O, seqs, offsets, f"views it {it} m {m} x {count} rate {rate} O {O} N {N}", must_build=False, pads=pads) is not None:
+            built += 1
+    assert built >= 8, built
 
 
 def test_low_complexity_and_lowercase(model):
