@@ -24,7 +24,7 @@ PROF_FILTER, PROF_DP, PROF_COMPARER, PROF_SCAN, PROF_MERGE, PROF_N = 0, 1, 2, 3,
 EXPORTED_SYMBOLS = [
     "cah_abi_version", "cah_build_id", "cah_last_error", "cah_device_count", "cah_set_device", "cah_device_info",
     "cah_plan_create", "cah_plan_destroy", "cah_plan_n_adapters", "cah_plan_effective_length",
-    "cah_plan_n_kmer_entries", "cah_plan_prefilter_kind", "cah_plan_multi_kind", "cah_last_multi_path", "cah_plan_debug_matcher", "cah_plan_debug_lean", "cah_locate_batch", "cah_kmers_present_batch", "cah_match_batch", "cah_match_batch_uniform", "cah_match_batch_suffix_views", "cah_match_batch_views", "cah_length_histogram", "cah_bucket_reads", "cah_scatter_results", "cah_set_deferred_errors", "cah_linked_views", "cah_linked_match_batch_uniform",
+    "cah_plan_n_kmer_entries", "cah_plan_prefilter_kind", "cah_plan_multi_kind", "cah_last_multi_path", "cah_plan_debug_matcher", "cah_plan_debug_lean", "cah_locate_batch", "cah_kmers_present_batch", "cah_match_batch", "cah_match_batch_uniform", "cah_match_batch_suffix_views", "cah_match_batch_views", "cah_match_batch_frames", "cah_set_deferred_errors", "cah_linked_views", "cah_linked_match_batch_uniform",
     "cah_workspace_bytes", "cah_plan_workspace_bytes", "cah_validate_ascii_batch", "cah_reverse_reads_batch", "cah_revcomp_reads_batch", "cah_locate_batch_host",
     "cah_kmers_present_batch_host", "cah_match_batch_host", "cah_locate_debug_host", "cah_match_one_host", "cah_locate_one_host", "cah_profile_enable",
     "cah_profile_reset", "cah_profile_read", "cah_synth_reads",
@@ -122,10 +122,8 @@ def lib():
     L.cah_match_batch_suffix_views.argtypes = [vp, vp, vp, vp, i32, i64, vp, vp, vp, vp, C.c_size_t, vp]
     if hasattr(L, "cah_match_batch_views") or not any_abi:
         L.cah_match_batch_views.argtypes = [vp, vp, vp, vp, i32, i64, vp, vp, vp, vp, C.c_size_t, vp]
-    if hasattr(L, "cah_bucket_reads") or not any_abi:
-        L.cah_length_histogram.argtypes = [vp, vp, i64, i32, vp, vp]
-        L.cah_bucket_reads.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, vp]
-        L.cah_scatter_results.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp]
+    if hasattr(L, "cah_match_batch_frames") or not any_abi:
+        L.cah_match_batch_frames.argtypes = [vp, vp, vp, vp, i32, i64, vp, vp, vp, vp, C.c_size_t, vp]
         L.cah_set_deferred_errors.argtypes = [C.c_int]
     L.cah_linked_views.argtypes = [vp, vp, vp, vp, i32, i64, vp, vp, vp]
     L.cah_linked_match_batch_uniform.argtypes = [vp, vp, vp, i32, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]

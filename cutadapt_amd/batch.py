@@ -267,100 +267,26 @@ def kmers_present_batch(plan: "_lib.Plan", adapter: int, batch: ReadBatch):
     return present
 
 
-# ---- ragged batches of plans with several adapters: buckets of one read length each ---------------------------------
-BUCKET_MAX_LEN = 640          # reads up to this length are bucketed (the streaming multi-adapter form takes up to 160)
-BUCKET_MIN_READS = 200_000    # smaller batches: the per-lane kernels are as fast as the bucket machinery's launches
+# ---- ragged batches of plans with several adapters -----------------------------------------------------------------
+FRAME_MIN_READS = 4096        # smaller batches: nothing to gain over the per-lane kernels
 
 
-def _bucketed_multi(plan: "_lib.Plan", batch: ReadBatch) -> bool:
-    """does this ragged batch take the length buckets?  Several adapters whose plan has the streaming form (asked for
-    the read length the sequencers emit), reads with lengths (views or an offsets array), enough of them"""
-    if os.environ.get("CAH_NO_BUCKETS") or not hasattr(_lib.lib(), "cah_bucket_reads"):
-        return False
-    if batch.n_reads < int(os.environ.get("CAH_BUCKET_MIN_READS", BUCKET_MIN_READS)) or plan.n_adapters < 2:
-        return False
-    if batch.uniform_len and batch.lens is None:
-        return False
-    within = getattr(batch, "within_uniform", None)
-    if within and plan.multi_kind(int(within)) == "stream" and not os.environ.get("CAH_NO_MULTI2_VIEWS"):
-        return False              # views inside a uniform batch: the library streams them end-aligned itself (multi2.hip, RV form)
-    return plan.multi_kind(min(int(within or 150), 160)) == "stream"
-
-
-def match_batch_bucketed(plan: "_lib.Plan", batch: ReadBatch, out: BatchResult) -> Optional[BatchResult]:
-    """MultipleAdapters.match_to over a RAGGED batch (reference adapters.py:1265-1286 on reads of any length) through the
-    streaming multi-adapter kernels, which work on one read length per launch: the reads are sorted into buckets of equal
-    length on the device (cah_length_histogram, cah_bucket_reads: copies of the views' characters), every bucket is a batch
-    of equally long reads (cah_match_batch_uniform), cah_scatter_results puts the rows back at their reads' indices.
-    Returns None when a read is longer than BUCKET_MAX_LEN (the caller then takes the per-lane kernels)."""
-    torch = _torch()
+def _frame_len(plan: "_lib.Plan", batch: ReadBatch) -> int:
+    """the frame length a ragged batch of a multi-adapter plan is streamed in (0: the batch takes the plain entry points).
+    MultipleAdapters.match_to on reads of any length (reference adapters.py:1265-1286): the streaming multi-adapter kernels
+    take every read end-aligned in a frame of ``frame_len`` characters (cah_match_batch_frames) -- the longest read of the
+    batch, known where the batch was built (``ReadBatch.max_len``) or looked up once on the device."""
     L = _lib.lib()
-    n, dev, sp = batch.n_reads, batch.device, _stream_ptr()
-    M = BUCKET_MAX_LEN
-    with torch.cuda.device(dev):
-        hist = torch.empty(M + 2, dtype=torch.int64, device=dev)
-        _lib.check(L.cah_length_histogram(batch.offsets.data_ptr(), batch._lens_ptr(), n, M, hist.data_ptr(), sp))
-        counts = hist.cpu().numpy()                                  # (one synchronisation: the host issues a call per bucket)
-        if counts[M + 1]:
-            return None
-        lengths = np.arange(M + 2, dtype=np.int64)
-        first = np.zeros(M + 2, dtype=np.int64)
-        np.cumsum(counts[:-1], out=first[1:])
-        base = np.zeros(M + 2, dtype=np.int64)
-        np.cumsum((counts * lengths)[:-1], out=base[1:])
-        total = int((counts[:M + 1] * lengths[:M + 1]).sum())
-        d_first = torch.from_numpy(first).to(dev)
-        d_base = torch.from_numpy(base).to(dev)
-        cursor = torch.empty(M + 2, dtype=torch.int64, device=dev)
-        dst = torch.empty(max(total, 16) + 16, dtype=torch.uint8, device=dev)
-        perm = torch.empty(n, dtype=torch.int32, device=dev)
-        _lib.check(L.cah_bucket_reads(batch.seqs.data_ptr(), batch.offsets.data_ptr(), batch._lens_ptr(), n, M,
-                                      d_base.data_ptr(), d_first.data_ptr(), cursor.data_ptr(), dst.data_ptr(),
-                                      perm.data_ptr(), sp))
-        t6 = torch.empty((n, 6), dtype=torch.int32, device=dev)
-        tst = torch.empty(n, dtype=torch.uint8, device=dev)
-        tbest = torch.empty(n, dtype=torch.int32, device=dev)
-        if counts[0]:                                                # empty reads match nothing (their bucket has no characters)
-            t6[:int(counts[0])].zero_(); tst[:int(counts[0])].zero_(); tbest[:int(counts[0])].fill_(-1)
-        biggest = int(counts[1:M + 1].max()) if M >= 1 else 0
-        # The buckets are independent batches: they go round-robin over a few streams, each with a workspace of its own,
-        # so that one bucket's last waves and its host-side bookkeeping (the multi-adapter path reads its error word
-        # back after every call) overlap the next bucket's work
-        n_streams = max(1, min(int(os.environ.get("CAH_BUCKET_STREAMS", "4")), int((counts[1:M + 1] > 0).sum())))
-        pool = getattr(batch, "_bucket_pool", None)
-        need = int(L.cah_plan_workspace_bytes(plan.handle, biggest)) if biggest else 0
-        if biggest and (pool is None or len(pool) < n_streams or pool[0][1].numel() < need):
-            pool = [(torch.cuda.Stream(device=dev), torch.empty(need, dtype=torch.uint8, device=dev)) for _ in range(n_streams)]
-            batch._bucket_pool = pool
-        main = torch.cuda.current_stream(dev)
-        ready = torch.cuda.Event()
-        ready.record(main)
-        for side, _ in (pool or [])[:n_streams]:
-            side.wait_event(ready)
-        # (deferred error check: the calls do not wait for their kernels; a batch whose kernels flagged a broken invariant
-        # carries CAH_STATUS_INTERNAL in its status bytes -- looked for below)
-        was = L.cah_set_deferred_errors(1)
-        try:
-            for k, ln in enumerate(np.nonzero(counts[1:M + 1])[0] + 1):
-                c, f = int(counts[ln]), int(first[ln])
-                side, ws = pool[k % n_streams]
-                with torch.cuda.stream(side):
-                    _lib.check(L.cah_match_batch_uniform(plan.handle, dst.data_ptr() + int(base[ln]), int(ln), c,
-                                                         t6.data_ptr() + 24 * f, tbest.data_ptr() + 4 * f, tst.data_ptr() + f,
-                                                         ws.data_ptr(), ws.numel(), int(side.cuda_stream)))
-        finally:
-            L.cah_set_deferred_errors(was)
-        for side, _ in (pool or [])[:n_streams]:
-            done = torch.cuda.Event()
-            done.record(side)
-            main.wait_event(done)
-        if bool((tst == _lib.STATUS_INTERNAL).any().item()):
-            raise _lib.HipInternalError("multi-adapter path: a kernel flagged a broken invariant in a length bucket "
-                                        "(deferred error check): results discarded")
-        _lib.check(L.cah_scatter_results(perm.data_ptr(), n, t6.data_ptr(), tst.data_ptr(), tbest.data_ptr(),
-                                         out.out6.data_ptr(), out.status.data_ptr(),
-                                         out.best_adapter.data_ptr() if out.best_adapter is not None else None, sp))
-    return out
+    if os.environ.get("CAH_NO_FRAMES") or not hasattr(L, "cah_match_batch_frames"):
+        return 0
+    if batch.n_reads < FRAME_MIN_READS or plan.n_adapters < 2 or (batch.uniform_len and batch.lens is None):
+        return 0
+    n = getattr(batch, "max_len", None)
+    if n is None:
+        n = int(batch.lengths().max().item()) if batch.n_reads else 0       # (one synchronisation, once per batch)
+        batch.max_len = n
+    n = max(int(n), 16)
+    return n if plan.multi_kind(n) == "stream" else 0
 
 
 def match_batch(plan: "_lib.Plan", batch: ReadBatch, out: Optional[BatchResult] = None) -> BatchResult:
@@ -371,9 +297,6 @@ def match_batch(plan: "_lib.Plan", batch: ReadBatch, out: Optional[BatchResult] 
         out = BatchResult(torch.empty((n, 6), dtype=torch.int32, device=batch.device),
                           torch.empty(n, dtype=torch.uint8, device=batch.device),
                           torch.empty(n, dtype=torch.int32, device=batch.device))
-    if n and _bucketed_multi(plan, batch):
-        if match_batch_bucketed(plan, batch, out) is not None:
-            return out
     if n:
         ws = batch.workspace(plan)
         best_ptr = out.best_adapter.data_ptr() if out.best_adapter is not None else None
@@ -396,6 +319,16 @@ def match_batch(plan: "_lib.Plan", batch: ReadBatch, out: Optional[BatchResult] 
                     plan.handle, batch.seqs.data_ptr(), batch.offsets.data_ptr(), batch.lens.data_ptr(),
                     int(batch.within_uniform), n, out.out6.data_ptr(), best_ptr, out.status.data_ptr(), ws.data_ptr(),
                     ws.numel(), _stream_ptr()))
+            elif _frame_len(plan, batch):
+                # a ragged batch of a plan with several adapters: every read end-aligned in a frame of the longest one's length
+                if batch.lens is None:
+                    batch._frame_lens = getattr(batch, "_frame_lens", None)
+                    if batch._frame_lens is None:
+                        batch._frame_lens = (batch.offsets[1:] - batch.offsets[:-1]).to(_torch().int32)
+                lens = batch.lens if batch.lens is not None else batch._frame_lens
+                _lib.check(_lib.lib().cah_match_batch_frames(
+                    plan.handle, batch.seqs.data_ptr(), batch.offsets.data_ptr(), lens.data_ptr(), _frame_len(plan, batch), n,
+                    out.out6.data_ptr(), best_ptr, out.status.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr()))
             else:
                 _lib.check(_lib.lib().cah_match_batch(
                     plan.handle, batch.seqs.data_ptr(), batch.offsets.data_ptr(), batch._lens_ptr(), n,

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libcutadapt_hip.so")
 # tests/test_gpu_multi2.py runs it in a process of its own (CAH_LIB_PATH)
 DEV_LIB_PATH = os.path.join(_HERE, "libcutadapt_hip_dev.so")
 DEV_SOURCES = ["api.cpp"]          # the sources that read CAH_DEV_KNOBS: the others' product objects are linked as they are
-SOURCES = ["api.cpp", "kernels.hip", "stream2.hip", "multi.hip", "multi2.hip", "long.hip", "fastq_gpu.hip", "synth_kernel.hip", "fastq.cpp", "index.hip", "qualtrim.hip", "bucket.hip"]
+SOURCES = ["api.cpp", "kernels.hip", "stream2.hip", "multi.hip", "multi2.hip", "long.hip", "fastq_gpu.hip", "synth_kernel.hip", "fastq.cpp", "index.hip", "qualtrim.hip"]
 HEADERS = ["cah_device.h", "kernels.h", "back_scan.h", "dev_common.h", "filter_common.h", "stream2.h", "multi2.h", "revcomp.h", os.path.join("..", "..", "include", "cutadapt_hip.h")]
 ARCH = "gfx950"
 

@@ -1233,7 +1233,7 @@ static bool env_flag(const char* name) { const char* e = getenv(name); return e 
 // its reads end (cah_match_batch_suffix_views): only the streaming prefilter makes use of that, every other kernel
 // sees plain views.
 // inner (with suffix): the views may end before the parent's reads do (cah_match_batch_views)
-struct UniformLayout { int64_t first = 0; int32_t len = 0; bool suffix = false; bool inner = false; };
+struct UniformLayout { int64_t first = 0; int32_t len = 0; bool suffix = false; bool inner = false; bool general = false; };
 // cah_linked_match_batch_uniform, fused form: the streaming prefilter of the back adapter decides the views itself
 // (kernels.h: FilterArgs::front) and writes the front stage's outputs and the views
 struct FrontFuse {
@@ -1581,7 +1581,7 @@ static int match_batch_multi_once(const cah_plan* plan, const PlanDeviceCopy* pd
                 f.tile_counter = counters + WS_M2_TILE; f.n_tiles = n_tiles; f.gate_pages = gate;
                 f.err = counters + WS_M2_ERR;
                 f.wmeta = d_wmeta;
-                if (views) { f.view_starts = d_offsets; f.view_lens = d_lens; }
+                if (views) { f.view_starts = d_offsets; f.view_lens = d_lens; f.view_general = ul.general ? 1 : 0; }
                 ProfScope ps(s, CAH_PROF_FILTER, round ? -1 : cnt);
                 HIP_TRY(launch_multi_stream(f, mp.m2.hdr, (int)grid, s));
             }
@@ -1597,7 +1597,7 @@ static int match_batch_multi_once(const cah_plan* plan, const PlanDeviceCopy* pd
                 sa.dp_queue = d_dpq; sa.dp_win = d_win;
                 sa.dp_count_front = counters + WS_DPFRONT; sa.dp_count_back = counters + WS_DPBACK; sa.dp_cap = cap;
                 sa.wmeta = d_wmeta; sa.prefix = pd->d_m2prefix; sa.lmax0 = mp.m2.hdr.lmax0;
-                if (views) { sa.view_starts = d_offsets; sa.view_lens = d_lens; }
+                if (views) { sa.view_starts = d_offsets; sa.view_lens = d_lens; sa.view_general = ul.general ? 1 : 0; }
                 // (how many pages there are is known on the device only: the blocks draw pages until none is left)
                 ProfScope ps(s, CAH_PROF_SCAN, round ? -1 : cnt);
                 HIP_TRY(launch_multi_scan(sa, std::min(max_pages, n_tiles * per_tile + grid * open_pages), pd->n_cus, s));
@@ -1685,11 +1685,11 @@ static int match_batch_multi_once(const cah_plan* plan, const PlanDeviceCopy* pd
 }
 
 static int match_batch_impl(const cah_plan* plan, const uint8_t* d_seqs, const int64_t* d_offsets,
-                            const int32_t* d_lens, const UniformLayout ul, int64_t n_reads, int32_t* d_out6,
+                            const int32_t* d_lens, const UniformLayout ul_in, int64_t n_reads, int32_t* d_out6,
                             int32_t* d_best_adapter, uint8_t* d_status, void* d_workspace, size_t workspace_bytes,
                             void* stream, const FrontFuse* fuse = nullptr, const CallHints* hints = nullptr) {
     const bool outputs_ready = hints && hints->outputs_ready;
-    int rc = check_batch(plan, d_seqs, (ul.len > 0 && !ul.suffix) ? (const void*)d_seqs : (const void*)d_offsets, n_reads);
+    int rc = check_batch(plan, d_seqs, (ul_in.len > 0 && !ul_in.suffix) ? (const void*)d_seqs : (const void*)d_offsets, n_reads);
     if (rc) return rc;
     if (n_reads == 0) return CAH_OK;
     if (!d_out6 || !d_status) return fail(CAH_EINVAL, "output pointers are NULL");
@@ -1699,6 +1699,12 @@ static int match_batch_impl(const cah_plan* plan, const uint8_t* d_seqs, const i
     const PlanDeviceCopy* pd = nullptr;
     rc = plan_on_device(plan, &pd);
     if (rc) return rc;
+    // (cah_match_batch_frames: views anywhere in the buffer with a frame length -- only the streaming multi-adapter form
+    // has a use for the frame; every other path takes them as the plain views they are)
+    const UniformLayout ul = (ul_in.general && !(plan->multi.m2.hdr.ok && workspace_bytes >= cah_plan_workspace_bytes(plan, n_reads) &&
+                                                 multi2_read_len_ok(plan->multi.m2.hdr, ul_in.len) && !env_flag("CAH_NO_MULTI2") &&
+                                                 !env_flag("CAH_NO_MULTI2_VIEWS")))
+                                 ? UniformLayout() : ul_in;
     const Workspace ws(d_workspace, n_reads, workspace_bytes);
     unsigned long long* counters = ws.counters;
     const UniformLayout ul_rest = ul.suffix ? UniformLayout() : ul;     // what every kernel but the prefilter sees
@@ -1821,6 +1827,23 @@ int cah_match_batch_views(const cah_plan* plan, const uint8_t* d_seqs, const int
     if (n_reads > 0 && (!d_starts || !d_lens)) return fail(CAH_EINVAL, "starts / lens are NULL");
     UniformLayout ul;
     ul.first = 0; ul.len = parent_read_len; ul.suffix = true; ul.inner = true;
+    return match_batch_impl(plan, d_seqs, d_starts, d_lens, ul, n_reads, d_out6, d_best_adapter, d_status, d_workspace,
+                            workspace_bytes, stream);
+}
+
+// Views ANYWHERE in d_seqs, none longer than frame_len characters: a packed batch with its offsets (d_starts[r] =
+// offsets[r], d_lens[r] its length), the reads of a raw FASTQ chunk in place.  Same results as cah_match_batch(plan,
+// d_seqs, d_starts, d_lens, ...); what the frame length buys: a plan of several adapters that has the streaming form
+// takes the views end-aligned in frames of frame_len characters (multi2.hip, RV form with the gathering copy) instead
+// of the per-lane kernels.  The caller guarantees d_lens[r] <= frame_len.
+int cah_match_batch_frames(const cah_plan* plan, const uint8_t* d_seqs, const int64_t* d_starts, const int32_t* d_lens,
+                           int32_t frame_len, int64_t n_reads, int32_t* d_out6, int32_t* d_best_adapter,
+                           uint8_t* d_status, void* d_workspace, size_t workspace_bytes, void* stream) {
+    if (frame_len < 1 || frame_len > CAH_MAX_READ_LEN)
+        return fail(CAH_EINVAL, "frame_len out of range (1..%d)", CAH_MAX_READ_LEN);
+    if (n_reads > 0 && (!d_starts || !d_lens)) return fail(CAH_EINVAL, "starts / lens are NULL");
+    UniformLayout ul;
+    ul.first = 0; ul.len = frame_len; ul.suffix = true; ul.inner = true; ul.general = true;
     return match_batch_impl(plan, d_seqs, d_starts, d_lens, ul, n_reads, d_out6, d_best_adapter, d_status, d_workspace,
                             workspace_bytes, stream);
 }

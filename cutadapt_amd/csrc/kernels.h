@@ -250,6 +250,9 @@ struct Multi2Args {
     // (NULL: the reads themselves)
     const int64_t* view_starts = nullptr;
     const int32_t* view_lens = nullptr;
+    // 1: the views lie ANYWHERE in seqs (a packed batch with its offsets, the reads of a raw FASTQ chunk): no read around
+    // them, uniform_len is the frame's length alone (>= every view's); the copy gathers every unit from its view's end
+    int32_t view_general = 0;
 };
 struct Multi2ScanArgs {
     int64_t uniform_first;
@@ -279,6 +282,7 @@ struct Multi2ScanArgs {
     // the end-aligned frame of uniform_len characters and reports in the view's coordinates
     const int64_t* view_starts = nullptr;
     const int32_t* view_lens = nullptr;
+    int32_t view_general = 0;        // (Multi2Args::view_general)
 };
 bool multi2_read_len_ok(const CahMulti2Header& h, int read_len);
 size_t multi2_lds_bytes(const CahMulti2Header& h);

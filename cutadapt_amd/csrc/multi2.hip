@@ -273,6 +273,11 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
     auto view_of = [&](const int64_t base) -> uint32_t {
         if (base + lane >= n_reads) return 0u;
         const int64_t r = a.first_read + base + lane;
+        if (a.view_general) {                                           // (views anywhere: d is not used, the copy gathers)
+            int ln = a.view_lens[r];
+            ln = ln < 0 ? 0 : (ln > n ? n : ln);
+            return (uint32_t)(n - ln) << 16;
+        }
         int st = (int)(a.view_starts[r] - (a.uniform_first + r * (int64_t)n));
         st = st < 0 ? 0 : (st > n ? n : st);
         int ln = a.view_lens[r];
@@ -282,6 +287,78 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
     auto prefetch = [&](int64_t base, const uint32_t vw = 0u) {
         const int64_t left = n_reads - base;
         if (left <= 0) return;
+        if constexpr (RV) {
+            if (a.view_general) {
+                // Views ANYWHERE in the buffer (a packed batch, the reads of a raw FASTQ chunk): unit u of the piece --
+                // frame characters 16 c .. 16 c + 15 of read r -- is gathered from its view's END: byte (view end) - n + 16 c.
+                // The end (relative to lane 0's, 32 bits) and the NULs in front of the view travel from lane r by two lane
+                // exchanges per unit.  Nothing outside a view is touched: a unit that reaches in front of its view or behind
+                // it is loaded as the 16 bytes at the view's edge and shifted (what lies outside is masked by finish()
+                // anyway); views shorter than 16 characters byte by byte.
+                const int reads = (int)(left < WAVE ? left : (int64_t)WAVE);
+                const int64_t r_own = a.first_read + base + (lane < reads ? lane : 0);
+                const int sk_own = (int)(vw >> 16);
+                const int64_t ve_own = a.view_starts[r_own] + (int64_t)(n - sk_own);
+                const unsigned e0_lo = __builtin_amdgcn_readfirstlane((unsigned)ve_own);
+                const unsigned e0_hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)ve_own >> 32));
+                const int64_t e0 = (int64_t)(((unsigned long long)e0_hi << 32) | e0_lo);
+                const int rel_own = (int)(ve_own - e0);
+#pragma unroll
+                for (int q = 0; q < 2 * M2_HALF; ++q) {
+                    const int kk = q < M2_HALF ? q : q - M2_HALF;
+                    const int H = q < M2_HALF ? H1 : H2;
+                    m2_u32x4 got = (m2_u32x4)(0u);
+                    if (kk < H) {                                       // (wave-uniform: every lane takes part in the exchanges)
+                        const int rr = unit_r(kk, q < M2_HALF ? magic1 : magic2);
+                        const int rel_r = __builtin_amdgcn_ds_bpermute(rr << 2, rel_own);
+                        const int sk_r = __builtin_amdgcn_ds_bpermute(rr << 2, sk_own);
+                        const int u = kk * WAVE + lane;
+                        const int fc = 16 * (u - __mul24(rr, H)) + (q < M2_HALF ? 0 : 16 * H1);       // the unit's first frame character
+                        const int len = n - sk_r;
+                        if (u < reads * H && fc + 15 >= sk_r && fc < n && len > 0) {
+                            const int64_t veb = e0 + rel_r, vsb = veb - len, fa = veb - n + fc;
+                            unsigned x0 = 0, x1 = 0, x2 = 0, x3 = 0;
+                            if (len >= 16) {
+                                int64_t la = fa < vsb ? vsb : fa;
+                                la = la > veb - 16 ? veb - 16 : la;
+                                Unaligned16 v;
+                                __builtin_memcpy(&v, a.seqs + la, 16);
+                                x0 = v.w[0]; x1 = v.w[1]; x2 = v.w[2]; x3 = v.w[3];
+                                const int sft = (int)(fa - la);          // > 0: the unit reaches behind the view; < 0: in front of it
+                                if (sft > 0) {
+                                    const int dw = sft >> 2, sh = (sft & 3) * 8;
+                                    if (dw >= 2) { x0 = x2; x1 = x3; x2 = 0; x3 = 0; }
+                                    if (dw & 1) { x0 = x1; x1 = x2; x2 = x3; x3 = 0; }
+                                    const unsigned y0 = (unsigned)((((unsigned long long)x1 << 32) | x0) >> sh);
+                                    const unsigned y1 = (unsigned)((((unsigned long long)x2 << 32) | x1) >> sh);
+                                    const unsigned y2 = (unsigned)((((unsigned long long)x3 << 32) | x2) >> sh);
+                                    x3 = x3 >> sh; x0 = y0; x1 = y1; x2 = y2;
+                                } else if (sft < 0) {
+                                    const int up = -sft, dw = up >> 2, sh = (up & 3) * 8;
+                                    if (dw >= 2) { x3 = x1; x2 = x0; x1 = 0; x0 = 0; }
+                                    if (dw & 1) { x3 = x2; x2 = x1; x1 = x0; x0 = 0; }
+                                    const unsigned y3 = (unsigned)((((unsigned long long)x3 << 32) | x2) >> (32 - sh));
+                                    const unsigned y2 = (unsigned)((((unsigned long long)x2 << 32) | x1) >> (32 - sh));
+                                    const unsigned y1 = (unsigned)((((unsigned long long)x1 << 32) | x0) >> (32 - sh));
+                                    if (sh) { x3 = y3; x2 = y2; x1 = y1; x0 = x0 << sh; }
+                                }
+                            } else {
+                                unsigned x[4] = {0u, 0u, 0u, 0u};
+#pragma unroll 1
+                                for (int b = 0; b < 16; ++b) {
+                                    const int64_t at = fa + b;
+                                    if (at >= vsb && at < veb) x[b >> 2] |= (unsigned)a.seqs[at] << (8 * (b & 3));
+                                }
+                                x0 = x[0]; x1 = x[1]; x2 = x[2]; x3 = x[3];
+                            }
+                            got = (m2_u32x4){x0, x1, x2, x3};
+                        }
+                    }
+                    pre[q] = got;
+                }
+                return;
+            }
+        }
         const int64_t pbyte = base * (int64_t)n;
         const uint8_t* const src = batch0 + pbyte;
         if (left >= WAVE && pbyte + (int64_t)WAVE * n + 16 <= total && (!RV || pbyte >= M2_RV_BACK)) {
@@ -965,6 +1042,12 @@ __global__ __launch_bounds__(256, (KIND == 3 || KIND == 0) ? 4 : 5) void k_multi
         const int64_t at = a.uniform_first + r * (int64_t)n;
         pad = 0;
         if (!a.view_starts) return a.seqs + at;
+        if (a.view_general) {                                           // views anywhere in the buffer: no read around them
+            int ln = a.view_lens[r];
+            ln = ln < 0 ? 0 : (ln > n ? n : ln);
+            pad = n - ln;
+            return a.seqs + a.view_starts[r];
+        }
         int st = (int)(a.view_starts[r] - at);
         st = st < 0 ? 0 : (st > n ? n : st);
         int ln = a.view_lens[r];

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define CAH_ABI_VERSION 5   /* 2: CAH_PROF_N = 5, plan workspaces (cah_plan_workspace_bytes), no adapter length limit; 3: cah_plan_multi_kind; 4: cah_build_id, cah_last_multi_path, CAH_EINTERNAL; 5: cah_length_histogram, cah_bucket_reads, cah_scatter_results, cah_set_deferred_errors */
+#define CAH_ABI_VERSION 5   /* 2: CAH_PROF_N = 5, plan workspaces (cah_plan_workspace_bytes), no adapter length limit; 3: cah_plan_multi_kind; 4: cah_build_id, cah_last_multi_path, CAH_EINTERNAL; 5: cah_match_batch_frames, cah_set_deferred_errors, CAH_STATUS_INTERNAL */
 
 /* status codes */
 #define CAH_OK 0
@@ -205,32 +205,23 @@ int cah_match_batch_views(const cah_plan *plan, const uint8_t *d_seqs, const int
                           const int32_t *d_lens, int32_t parent_read_len, int64_t n_reads,
                           int32_t *d_out6, int32_t *d_best_adapter, uint8_t *d_status,
                           void *d_workspace, size_t workspace_bytes, void *stream);
-/* Ragged batches for plans of several adapters (MultipleAdapters.match_to, reference adapters.py:1265-1286, on reads of any
- * length: behind the quality trimmers a pipeline's reads are ragged, cli.py:938-954): the streaming multi-adapter kernels
- * work on ONE read length per launch, so the host sorts the reads into buckets of equal length, matches every bucket with
- * cah_match_batch_uniform and puts the rows back (cutadapt_amd/batch.py: match_batch does exactly this).
- *   cah_length_histogram   d_hist[L] = reads of L characters, L = 0 .. max_len; d_hist[max_len + 1] = longer reads
- *                          (d_lens NULL: lengths from d_offsets[r + 1] - d_offsets[r]).  max_len <= 65534.
- *   cah_bucket_reads       read r of L characters takes slot d_first[L] + rank (rank: its turn inside the bucket, by a
- *                          device atomic on d_cursor[L]; d_cursor is zeroed here), d_perm[slot] = r, and its characters
- *                          are copied to d_dst[d_base[L] + rank * L ..).  d_base / d_first / d_cursor: max_len + 2 entries.
- *                          Reads longer than max_len get slots but are not copied.
- *   cah_scatter_results    row i of the temporaries (bucket order) goes to read d_perm[i] of the outputs. */
+/* Views ANYWHERE in d_seqs, none longer than frame_len characters: a packed batch with its offsets (d_starts[r] =
+ * offsets[r], d_lens[r] = its length), the reads of a raw FASTQ chunk in place -- MultipleAdapters.match_to on reads of any
+ * length (reference adapters.py:1265-1286; behind the quality trimmers a pipeline's reads are ragged, cli.py:938-954).
+ * Same results as cah_match_batch(plan, d_seqs, d_starts, d_lens, ...).  What the frame length buys: a plan of several
+ * adapters that has the streaming form takes the views end-aligned in frames of frame_len characters instead of the
+ * per-lane kernels.  The caller guarantees d_lens[r] <= frame_len. */
+int cah_match_batch_frames(const cah_plan *plan, const uint8_t *d_seqs, const int64_t *d_starts, const int32_t *d_lens,
+                           int32_t frame_len, int64_t n_reads, int32_t *d_out6, int32_t *d_best_adapter,
+                           uint8_t *d_status, void *d_workspace, size_t workspace_bytes, void *stream);
+
 /* Deferred error check of the streaming multi-adapter path, per calling thread (returns the previous setting; default 0).
  * 0: every call synchronises once and answers CAH_EINTERNAL if a kernel flagged a broken invariant.  1: a call whose page
  * pool holds the batch's worst case returns without waiting; should a kernel have flagged something, EVERY status byte of
  * that batch is CAH_STATUS_INTERNAL (the rows are void) -- the caller must look.  For callers that issue many small batches
- * on several streams (the length buckets above). */
+ * on several streams. */
 #define CAH_STATUS_INTERNAL 255
 int cah_set_deferred_errors(int on);
-int cah_length_histogram(const int64_t *d_offsets, const int32_t *d_lens, int64_t n_reads, int32_t max_len,
-                         unsigned long long *d_hist, void *stream);
-int cah_bucket_reads(const uint8_t *d_seqs, const int64_t *d_offsets, const int32_t *d_lens, int64_t n_reads,
-                     int32_t max_len, const int64_t *d_base, const int64_t *d_first, unsigned long long *d_cursor,
-                     uint8_t *d_dst, int32_t *d_perm, void *stream);
-int cah_scatter_results(const int32_t *d_perm, int64_t n_reads, const int32_t *d_tmp_out6, const uint8_t *d_tmp_status,
-                        const int32_t *d_tmp_best, int32_t *d_out6, uint8_t *d_status, int32_t *d_best_adapter,
-                        void *stream);
 
 /* The views the second stage of a linked adapter searches (adapters.py:1222-1224): d_starts[r] = start of read r +
  * (front match ? its query_stop : 0), d_view_lens[r] = what is left of the read.  Reads as in cah_match_batch, or

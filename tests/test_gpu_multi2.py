@@ -339,7 +339,7 @@ def test_views_of_a_uniform_batch_stream(hip, orc):
         fw = want_st == 1
         assert np.array_equal(got.best_adapter[:m_chk].cpu().numpy()[fw], want_best[fw]), it
         # ... and the whole batch against the per-lane kernels
-        with env(CAH_NO_MULTI2_VIEWS="1", CAH_NO_BUCKETS="1"):
+        with env(CAH_NO_MULTI2_VIEWS="1", CAH_NO_FRAMES="1"):
             want = match_batch(plan, view)
             torch.cuda.synchronize()
         assert torch.equal(got.status, want.status) and torch.equal(got.out6, want.out6), it
@@ -347,13 +347,12 @@ def test_views_of_a_uniform_batch_stream(hip, orc):
     assert checked >= 4, checked
 
 
-def test_ragged_batches_take_length_buckets(hip, orc):
-    """Ragged batches of a plan with several adapters (reads cut by a modifier in front of the adapter search, reference
-    cli.py:938-954): cutadapt_amd.batch.match_batch sorts the reads into buckets of one length each on the device and runs
-    every bucket through the streaming form (cah_length_histogram / cah_bucket_reads / cah_match_batch_uniform /
-    cah_scatter_results).  Views inside a uniform batch and a packed batch with an offsets array, lengths 0 .. 150
-    (empty reads, reads shorter than the streaming form takes), against the per-lane kernels in full and the oracle on a
-    sample."""
+def test_ragged_batches_stream_in_frames(hip, orc):
+    """Ragged batches of a plan with several adapters that are no views of a uniform batch -- a packed batch with an offsets
+    array, views anywhere in a buffer (what the reads of a raw FASTQ chunk are) -- through cah_match_batch_frames: every read
+    end-aligned in a frame of the longest one's length, the copy gathered from the views' ends (multi2.hip: view_general).
+    Lengths 0 .. 150 (empty reads, reads shorter than 16), the first and the last bytes of the buffer used, against the
+    per-lane kernels in full and the oracle on a sample."""
     import torch
     from cutadapt_amd import batch as B
     from cutadapt_amd.batch import ReadBatch, match_batch
@@ -361,59 +360,45 @@ def test_ragged_batches_take_length_buckets(hip, orc):
     seqs = [rs(prng, 33) for _ in range(24)]
     plan, ads = plan_for(seqs, 0.1, 3)
     assert plan.multi_kind(150) == "stream"
-    n = 400_000
-    parent = ReadBatch.synthetic(n, 150, seqs, seed=31, p_adapter=0.5, p_edit=0.03, p_n=0.003)
+    n = 300_000
+    parent = ReadBatch.synthetic(n, 150, seqs, seed=31, p_adapter=0.6, p_edit=0.03, p_n=0.003)
     idx = torch.arange(n, dtype=torch.int64, device=parent.device)
     lens = ((idx * 2654435761 + 977) >> 5) % 151                      # 0 .. 150
     lens[::1000] = 0
+    lens[0] = 150
+    lens[n - 1] = 150
     starts = ((idx * 40503) >> 3) % (151 - lens)                      # anywhere inside the read
-    view = parent.view(starts, lens)
-    # (views inside a uniform batch are streamed end-aligned by the library itself: test_views_of_a_uniform_batch_stream)
-    assert not B._bucketed_multi(plan, view)
-    with env(CAH_NO_MULTI2_VIEWS="1"):
-        assert B._bucketed_multi(plan, view)
-        got = match_batch(plan, view)
+    # the packed layout (an offsets array): the reads copied back to back -- the buffer begins with read 0 and ends with the last
+    packed_off = torch.zeros(n + 1, dtype=torch.int64, device=parent.device)
+    torch.cumsum(lens, 0, out=packed_off[1:])
+    cols = torch.arange(150, device=parent.device)
+    keep = cols[None, :] < lens[:, None]
+    gather = (parent.offsets[:n] + starts)[:, None] + cols[None, :]
+    packed = parent.seqs[gather[keep]].contiguous()
+    assert packed.numel() == int(packed_off[-1].item())
+    pb = ReadBatch(packed, packed_off, validated=True)
+    assert B._frame_len(plan, pb) == 150
+    got = match_batch(plan, pb)
+    torch.cuda.synchronize()
+    assert _lib_last_path() == "stream", _lib_last_path()
+    with env(CAH_NO_FRAMES="1"):
+        pb2 = ReadBatch(packed, packed_off, validated=True)
+        want = match_batch(plan, pb2)
         torch.cuda.synchronize()
-        with env(CAH_NO_BUCKETS="1"):
-            want = match_batch(plan, view)
-            torch.cuda.synchronize()
-            assert _lib_last_path() != "stream"
+        assert _lib_last_path() != "stream"
     assert torch.equal(got.status, want.status) and torch.equal(got.out6, want.out6)
     f = want.status == 1
     assert torch.equal(got.best_adapter[f], want.best_adapter[f])
     assert int(f.sum()) > 0.5 * n
-    # the oracle on a sample of the views
     m = 30_000
-    h_seqs = parent.seqs.cpu().numpy()
-    h_off = (parent.offsets[:m] + starts[:m]).cpu().numpy()
-    h_len = lens[:m].cpu().numpy()
-    reads = [bytes(h_seqs[int(o):int(o) + int(l)]).decode("latin-1") for o, l in zip(h_off, h_len)]
-    sq, offs = orc.pack_reads(reads)
+    sq, offs = packed[: int(packed_off[m].item())].cpu().numpy(), packed_off[: m + 1].cpu().numpy()
     want6, want_st, want_best = oracle_multiple(orc, ads, sq, offs)
     assert np.array_equal(got.status[:m].cpu().numpy(), want_st) and np.array_equal(got.out6[:m].cpu().numpy(), want6)
-    fw = want_st == 1
-    assert np.array_equal(got.best_adapter[:m].cpu().numpy()[fw], want_best[fw])
-    # ... and the packed layout (an offsets array): the same reads copied back to back
-    packed_off = torch.zeros(n + 1, dtype=torch.int64, device=parent.device)
-    torch.cumsum(lens, 0, out=packed_off[1:])
-    total = int(packed_off[-1].item())
-    cols = torch.arange(150, device=parent.device)
-    keep = cols[None, :] < lens[:, None]
-    gather = (parent.offsets[:n] + starts)[:, None] + cols[None, :]
-    packed = parent.seqs[gather[keep]]
-    assert packed.numel() == total
-    pb = ReadBatch(packed.contiguous(), packed_off, validated=True)
-    assert B._bucketed_multi(plan, pb)
-    got2 = match_batch(plan, pb)
+    # views scattered over a buffer with other bytes between them (starts + lengths, no offsets array order): the same reads
+    # as views into the parent batch, handed over WITHOUT the uniform-batch tag
+    vb = ReadBatch(parent.seqs, parent.offsets[:n] + starts, lens.to(torch.int32), n_reads=n, validated=True)
+    vb.max_len = 150
+    got2 = match_batch(plan, vb)
     torch.cuda.synchronize()
+    assert _lib_last_path() == "stream"
     assert torch.equal(got2.status, want.status) and torch.equal(got2.out6, want.out6)
-    # a read longer than the buckets take: the call falls back to the per-lane kernels (same results)
-    with env(CAH_BUCKET_MIN_READS="1"):
-        old = B.BUCKET_MAX_LEN
-        B.BUCKET_MAX_LEN = 100
-        try:
-            got3 = match_batch(plan, pb)
-            torch.cuda.synchronize()
-        finally:
-            B.BUCKET_MAX_LEN = old
-    assert torch.equal(got3.status, want.status) and torch.equal(got3.out6, want.out6)
