@@ -272,21 +272,27 @@ FRAME_MIN_READS = 4096        # smaller batches: nothing to gain over the per-la
 
 
 def _frame_len(plan: "_lib.Plan", batch: ReadBatch) -> int:
-    """the frame length a ragged batch of a multi-adapter plan is streamed in (0: the batch takes the plain entry points).
-    MultipleAdapters.match_to on reads of any length (reference adapters.py:1265-1286): the streaming multi-adapter kernels
-    take every read end-aligned in a frame of ``frame_len`` characters (cah_match_batch_frames) -- the longest read of the
-    batch, known where the batch was built (``ReadBatch.max_len``) or looked up once on the device."""
+    """the frame length a ragged batch is streamed in (0: the batch takes the plain entry points).  *Adapter.match_to /
+    MultipleAdapters.match_to on reads of any length (reference adapters.py:815-832, :1265-1286): the streaming kernels take
+    every read end-aligned in a frame of ``frame_len`` characters (cah_match_batch_frames) -- the longest read of the batch,
+    known where the batch was built (``ReadBatch.max_len``) or looked up once on the device."""
     L = _lib.lib()
     if os.environ.get("CAH_NO_FRAMES") or not hasattr(L, "cah_match_batch_frames"):
         return 0
-    if batch.n_reads < FRAME_MIN_READS or plan.n_adapters < 2 or (batch.uniform_len and batch.lens is None):
+    if batch.n_reads < FRAME_MIN_READS or (batch.uniform_len and batch.lens is None):
         return 0
+    if getattr(batch, "within_uniform", None) or getattr(batch, "suffix_of_uniform", None):
+        return 0                                              # (views of a uniform batch have entry points of their own)
     n = getattr(batch, "max_len", None)
     if n is None:
         n = int(batch.lengths().max().item()) if batch.n_reads else 0       # (one synchronisation, once per batch)
         batch.max_len = n
     n = max(int(n), 16)
-    return n if plan.multi_kind(n) == "stream" else 0
+    if plan.n_adapters >= 2:
+        return n if plan.multi_kind(n) == "stream" else 0
+    # one adapter: its streaming prefilter takes frames of up to 160 characters (the library falls back by itself where the
+    # plan has no streaming form)
+    return n if n <= 160 else 0
 
 
 def match_batch(plan: "_lib.Plan", batch: ReadBatch, out: Optional[BatchResult] = None) -> BatchResult:

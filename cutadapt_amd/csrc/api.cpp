@@ -1397,7 +1397,7 @@ static int run_filter(const cah_plan* plan, const PlanDeviceCopy* pd, int32_t ad
     if (ul.suffix) {
         // views into a uniform parent: k_filter_stream2's SV form if the plan and the length are its, else plain views
         const bool s2 = stream2_suffix_ok(plan, adapter, ul.len, n_reads);
-        f.suffix_views = s2 ? (ul.inner ? 2 : 1) : 0;
+        f.suffix_views = s2 ? (ul.general ? 3 : (ul.inner ? 2 : 1)) : 0;     // (3: views anywhere, frames of ul.len characters)
         if (!s2) { f.uniform_first = 0; f.uniform_len = 0; }
         if (fuse) {
             if (!s2) return fail(CAH_EINVAL, "internal: fused linked path on a plan the streaming prefilter does not take");
@@ -1701,9 +1701,11 @@ static int match_batch_impl(const cah_plan* plan, const uint8_t* d_seqs, const i
     if (rc) return rc;
     // (cah_match_batch_frames: views anywhere in the buffer with a frame length -- only the streaming multi-adapter form
     // has a use for the frame; every other path takes them as the plain views they are)
-    const UniformLayout ul = (ul_in.general && !(plan->multi.m2.hdr.ok && workspace_bytes >= cah_plan_workspace_bytes(plan, n_reads) &&
-                                                 multi2_read_len_ok(plan->multi.m2.hdr, ul_in.len) && !env_flag("CAH_NO_MULTI2") &&
-                                                 !env_flag("CAH_NO_MULTI2_VIEWS")))
+    // (... a single adapter's streaming prefilter likewise, adapter by adapter: run_filter)
+    const bool multi_form = plan->multi.hdr.ok && workspace_bytes >= cah_plan_workspace_bytes(plan, n_reads);
+    const UniformLayout ul = (ul_in.general && multi_form &&
+                              !(plan->multi.m2.hdr.ok && multi2_read_len_ok(plan->multi.m2.hdr, ul_in.len) && !env_flag("CAH_NO_MULTI2") &&
+                                !env_flag("CAH_NO_MULTI2_VIEWS")))
                                  ? UniformLayout() : ul_in;
     const Workspace ws(d_workspace, n_reads, workspace_bytes);
     unsigned long long* counters = ws.counters;

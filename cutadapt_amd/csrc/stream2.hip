@@ -368,14 +368,13 @@ __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a
     const int64_t total = (int64_t)n_reads * n;                         // bytes of the batch
     if (total < 16) return;                                             // (same test there)
     const bool clear0 = a.clear_out6 != nullptr && a.present == nullptr;
-#ifdef CAH_S2_ABLATE
-    // developer builds only (-DCAH_S2_ABLATE; CAH_S2_NOMATCH, measurement only): 1 copy, match nothing; 2 ... and no result
-    // rows; 3 result rows only, no loads; 5 everything but the loads (the matching works on stale slot contents: timing only)
+    // Ablation values of developer builds (-DCAH_S2_ABLATE lets the launcher put them into max_read_len from CAH_S2_NOMATCH;
+    // the product library has no way to: it passes CAH_MAX_READ_LEN): 1 copy, match nothing; 2 ... and no result rows; 3
+    // result rows only, no loads; 5 everything but the loads.  The three tests stay in the product kernel on purpose: with
+    // them folded to constants (round 6 tried) the register allocator spills four VGPRs of the headline instantiation
+    // (20 B of scratch per lane, + 0.1 ms per 100 M reads); as they are they cost three scalar compares per block.
     const bool nomatch = a.max_read_len <= -12345 && a.max_read_len >= -12347;
     const bool noclear = a.max_read_len == -12346 || a.max_read_len == -12348, noload = a.max_read_len == -12347 || a.max_read_len == -12349;   // 4: match, no result rows; 5: match what the slots happen to hold, no loads
-#else
-    constexpr bool nomatch = false, noclear = false, noload = false;     // (the product library has no such switches)
-#endif
     const bool clear = clear0 && !noclear;
 
     // tables (stream2.h: s2_entry); slots a plan does not use hold zeros
@@ -493,6 +492,78 @@ __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a
     // fetched at all: its offset is put out of the resource's range, the load returns zeros (NUL: what the words must see
     // there).  The resource's base sits S2_RV_BACK bytes in front of the piece (d <= n, and for n < 16 the copy plan's
     // stride n - 16 H is negative): the batch's first pieces go lane by lane.
+    // RV, views anywhere in the buffer (suffix_views == 3): the gathering copy
+    auto prefetch_general = [&](int64_t base, const uint32_t vw) {
+        const int64_t left = n_reads - base;                            // wave-uniform
+        if (left <= 0) return;
+                // Views ANYWHERE in the buffer (cah_match_batch_frames: a packed batch, the reads of a raw FASTQ chunk): unit u
+                // of the piece -- frame characters 16 c .. 16 c + 15 of read r -- is gathered from its view's END: byte (view
+                // end) - n + 16 c.  The end (relative to lane 0's) and the NULs in front of the view travel from lane r by two
+                // lane exchanges per unit.  Nothing outside a view is touched: a unit that reaches in front of its view or
+                // behind it is loaded as the 16 bytes at the view's edge and shifted; views under 16 characters byte by byte.
+                const int reads = (int)(left < WAVE ? left : (int64_t)WAVE);
+                const int64_t r_own = base + (lane < reads ? lane : 0);
+                const int sk_own = lane < reads ? (int)(vw >> 16) : n;
+                const int64_t ve_own = a.offsets[r_own] + (int64_t)(n - sk_own);
+                const unsigned e0_lo = __builtin_amdgcn_readfirstlane((unsigned)ve_own);
+                const unsigned e0_hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)ve_own >> 32));
+                const int64_t e0 = (int64_t)(((unsigned long long)e0_hi << 32) | e0_lo);
+                const int rel_own = (int)(ve_own - e0);
+                const uint8_t* const sq = a.seqs;
+#pragma unroll
+                for (int q = 0; q < 2 * S2_HALF; ++q) {
+                    const int k = q < S2_HALF ? q : q - S2_HALF;
+                    const int H = q < S2_HALF ? H1 : H2;
+                    s2_u32x4 got = (s2_u32x4)(0u);
+                    if (k < H) {                                        // (wave-uniform: every lane takes part in the exchanges)
+                        const int rr = unit_r(k, q < S2_HALF ? magic1 : magic2);
+                        const int rel_r = __builtin_amdgcn_ds_bpermute(rr << 2, rel_own);
+                        const int sk_r = __builtin_amdgcn_ds_bpermute(rr << 2, sk_own);
+                        const int u = k * WAVE + lane;
+                        const int fc = 16 * (u - __mul24(rr, H)) + (q < S2_HALF ? 0 : 16 * H1);
+                        const int len = n - sk_r;
+                        if (u < reads * H && fc + 15 >= sk_r && fc < n && len > 0) {
+                            const int64_t veb = e0 + rel_r, vsb = veb - len, fa = veb - n + fc;
+                            unsigned x0 = 0, x1 = 0, x2 = 0, x3 = 0;
+                            if (len >= 16) {
+                                int64_t la = fa < vsb ? vsb : fa;
+                                la = la > veb - 16 ? veb - 16 : la;
+                                Unaligned16 v;
+                                __builtin_memcpy(&v, sq + la, 16);
+                                x0 = v.w[0]; x1 = v.w[1]; x2 = v.w[2]; x3 = v.w[3];
+                                const int sft = (int)(fa - la);          // > 0: the unit reaches behind the view; < 0: in front of it
+                                if (sft > 0) {
+                                    const int dw = sft >> 2, sh = (sft & 3) * 8;
+                                    if (dw >= 2) { x0 = x2; x1 = x3; x2 = 0; x3 = 0; }
+                                    if (dw & 1) { x0 = x1; x1 = x2; x2 = x3; x3 = 0; }
+                                    const unsigned y0 = (unsigned)((((unsigned long long)x1 << 32) | x0) >> sh);
+                                    const unsigned y1 = (unsigned)((((unsigned long long)x2 << 32) | x1) >> sh);
+                                    const unsigned y2 = (unsigned)((((unsigned long long)x3 << 32) | x2) >> sh);
+                                    x3 = x3 >> sh; x0 = y0; x1 = y1; x2 = y2;
+                                } else if (sft < 0) {
+                                    const int up = -sft, dw = up >> 2, sh = (up & 3) * 8;
+                                    if (dw >= 2) { x3 = x1; x2 = x0; x1 = 0; x0 = 0; }
+                                    if (dw & 1) { x3 = x2; x2 = x1; x1 = x0; x0 = 0; }
+                                    const unsigned y3 = (unsigned)((((unsigned long long)x3 << 32) | x2) >> (32 - sh));
+                                    const unsigned y2 = (unsigned)((((unsigned long long)x2 << 32) | x1) >> (32 - sh));
+                                    const unsigned y1 = (unsigned)((((unsigned long long)x1 << 32) | x0) >> (32 - sh));
+                                    if (sh) { x3 = y3; x2 = y2; x1 = y1; x0 = x0 << sh; }
+                                }
+                            } else {
+                                unsigned x[4] = {0u, 0u, 0u, 0u};
+#pragma unroll 1
+                                for (int b = 0; b < 16; ++b) {
+                                    const int64_t at = fa + b;
+                                    if (at >= vsb && at < veb) x[b >> 2] |= (unsigned)sq[at] << (8 * (b & 3));
+                                }
+                                x0 = x[0]; x1 = x[1]; x2 = x[2]; x3 = x[3];
+                            }
+                            got = (s2_u32x4){x0, x1, x2, x3};
+                        }
+                    }
+                    pre[q] = got;
+                }
+    };
     auto prefetch = [&](int64_t base, const uint32_t vw = 0) {
         const int64_t left = n_reads - base;                            // wave-uniform
         if (left <= 0 || noload) return;
@@ -672,9 +743,13 @@ __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a
         const int64_t r = base + lane;
         if (r >= n_reads) return 0u;
         const s2_kernarg_ptr kp = (s2_kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+        int ln = kp->lens[r];
+        if (kp->suffix_views == 3) {                                    // views anywhere: no read around them (d = 0, the copy gathers)
+            ln = ln < 0 ? 0 : (ln > n ? n : ln);
+            return (uint32_t)(n - ln) << 16;
+        }
         int st = (int)(kp->offsets[r] - (first + r * (int64_t)n));
         st = st < 0 ? 0 : (st > n ? n : st);
-        int ln = kp->lens[r];
         ln = ln < 0 ? 0 : (ln > n - st ? n - st : ln);
         return (uint32_t)(n - (st + ln)) | ((uint32_t)(n - ln) << 16);
     };
@@ -683,7 +758,7 @@ __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a
     if constexpr (RV) {
         const uint32_t vw = view_of(piece_base(p));
         skip_next = (int)(vw >> 16);
-        prefetch(piece_base(p), vw);
+        if (a.suffix_views == 3) prefetch_general(piece_base(p), vw); else prefetch(piece_base(p), vw);
     } else {
         prefetch(piece_base(p));
     }
@@ -738,6 +813,7 @@ __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a
                         int st = (int)(view_at - (first + (piece_base(p_early) + lane) * (int64_t)n));
                         st = st < 0 ? 0 : (st > n ? n : st);
                         int ln = view_len;
+                        if (a.suffix_views == 3) { ln = ln < 0 ? 0 : (ln > n ? n : ln); st = n - ln; }    // (views anywhere: d = 0)
                         ln = ln < 0 ? 0 : (ln > n - st ? n - st : ln);
                         s_lds.views[wave * WAVE + lane] = (uint32_t)(n - (st + ln)) | ((uint32_t)(n - ln) << 16);
                     }
@@ -869,7 +945,7 @@ __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a
             if constexpr (RV) {
                 const uint32_t vw = s_lds.views[wave * WAVE + lane];
                 skip_next = (int)(vw >> 16);
-                prefetch(piece_base(p_next), vw);
+                if (a.suffix_views == 3) prefetch_general(piece_base(p_next), vw); else prefetch(piece_base(p_next), vw);
             } else {
                 prefetch(piece_base(p_next));
             }
@@ -944,7 +1020,7 @@ hipError_t launch_filter_stream2(const FilterArgs& a_in, int mode, int n_lead, i
         else return hipErrorInvalidValue;
         return hipGetLastError();
     }
-    if (a.suffix_views == 2) {
+    if (a.suffix_views == 2 || a.suffix_views == 3) {                   // (3: views anywhere in the buffer, frames of uniform_len)
         if (n_lead <= 1 && n_tw <= 2) hipLaunchKernelGGL((k_filter_stream2<1, 2, true, true, false, false, true>), dim3(grid), dim3(S2_WAVES * WAVE), lds, s, a);
         else if (n_lead <= 2 && n_tw <= 4) hipLaunchKernelGGL((k_filter_stream2<2, 4, true, true, false, false, true>), dim3(grid), dim3(S2_WAVES * WAVE), lds, s, a);
         else return hipErrorInvalidValue;

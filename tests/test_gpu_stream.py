@@ -447,3 +447,56 @@ def test_linked_adapter_on_uniform_reads_fused_and_staged(hip, orc):
             if n >= 20:
                 assert fst[5] == 2 and starts[5] == 5 * n and vlens[5] == n
             assert ff.sum() > 0.3 * len(good) or n < len(fseq)
+
+
+def test_packed_ragged_batches_stream_in_frames(hip, orc):
+    """Round 6: a packed ragged batch (an offsets array; reads of 0 .. 150 characters) through the single adapter's streaming
+    prefilter -- cah_match_batch_frames: every read end-aligned in a frame of the longest one's length, the copy gathered
+    from the reads' ends (k_filter_stream2's RV form, suffix_views == 3) -- against the per-lane kernels in full and the
+    oracle on a sample; then the same reads as views scattered over a larger buffer."""
+    import torch
+    from cutadapt_amd import adapters as A
+    from cutadapt_amd import batch as B
+    from cutadapt_amd.batch import ReadBatch, match_batch
+    from cutadapt_amd.kmer_heuristic import create_positions_and_kmers
+    TRUSEQ = "AGATCGGAAGAGCACACGTCTGAACTCCAGTCA"
+    for adapter, rate in ((TRUSEQ, 0.1), ("GATCGGAAGAGCACACGTCT", 0.15)):
+        ad = A.BackAdapter(adapter, max_errors=rate, min_overlap=3)
+        plan = ad._fused_plan
+        n = 300_000
+        parent = ReadBatch.synthetic(n, 150, [adapter], seed=61, p_adapter=0.6, p_edit=0.03, p_n=0.003)
+        idx = torch.arange(n, dtype=torch.int64, device=parent.device)
+        lens = ((idx * 2654435761 + 311) >> 6) % 151
+        lens[::1000] = 0
+        lens[0] = 150
+        lens[n - 1] = 150
+        starts = ((idx * 40503) >> 3) % (151 - lens)
+        off = torch.zeros(n + 1, dtype=torch.int64, device=parent.device)
+        torch.cumsum(lens, 0, out=off[1:])
+        cols = torch.arange(150, device=parent.device)
+        keep = cols[None, :] < lens[:, None]
+        gather = (parent.offsets[:n] + starts)[:, None] + cols[None, :]
+        packed = parent.seqs[gather[keep]].contiguous()
+        pb = ReadBatch(packed, off, validated=True)
+        assert B._frame_len(plan, pb) == 150
+        got = match_batch(plan, pb)
+        torch.cuda.synchronize()
+        os.environ["CAH_NO_FRAMES"] = "1"
+        try:
+            want = match_batch(plan, ReadBatch(packed, off, validated=True))
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("CAH_NO_FRAMES", None)
+        assert torch.equal(got.status, want.status) and torch.equal(got.out6, want.out6), adapter
+        assert int((want.status == 1).sum()) > 0.3 * n
+        m = 40_000
+        sq, offs = packed[: int(off[m].item())].cpu().numpy(), off[: m + 1].cpu().numpy()
+        oa = orc.Aligner(adapter, rate, 14, False, False, 1, 3)
+        of = orc.KmerFinder(create_positions_and_kmers(adapter, 3, rate, back_adapter=True, front_adapter=False))
+        w6, wst = orc.match_batch(oa, of, sq, offs)
+        assert np.array_equal(got.status[:m].cpu().numpy(), wst) and np.array_equal(got.out6[:m].cpu().numpy(), w6), adapter
+        vb = ReadBatch(parent.seqs, parent.offsets[:n] + starts, lens.to(torch.int32), n_reads=n, validated=True)
+        vb.max_len = 150
+        got2 = match_batch(plan, vb)
+        torch.cuda.synchronize()
+        assert torch.equal(got2.status, want.status) and torch.equal(got2.out6, want.out6), adapter
