@@ -306,7 +306,8 @@ def test_suffix_views_of_a_uniform_batch(hip, orc):
             if mode == "suffix":
                 view.suffix_of_uniform = n
             else:
-                view.within_uniform = None                   # the plain view entry point
+                view.within_uniform = None                   # the plain view entry point ...
+                view.max_len = 10 ** 6                       # ... and its per-lane kernels (no frame: cah_match_batch_frames is not asked)
             res = match_batch(ad._fused_plan, view)
             out6, st = res.out6.cpu().numpy(), res.status.cpu().numpy()
             results[mode] = (out6, st, _survivors(view, count))
@@ -367,7 +368,8 @@ def test_inner_views_of_a_uniform_batch(hip, orc):
             if mode == "inner":
                 assert view.within_uniform == n
             else:
-                view.within_uniform = None                   # the plain view entry point
+                view.within_uniform = None                   # the plain view entry point ...
+                view.max_len = 10 ** 6                       # ... and its per-lane kernels (no frame: cah_match_batch_frames is not asked)
             res = match_batch(ad._fused_plan, view)
             out6, st = res.out6.cpu().numpy(), res.status.cpu().numpy()
             results[mode] = (out6, st, _survivors(view, count))
@@ -488,7 +490,7 @@ def test_packed_ragged_batches_stream_in_frames(hip, orc):
         finally:
             os.environ.pop("CAH_NO_FRAMES", None)
         assert torch.equal(got.status, want.status) and torch.equal(got.out6, want.out6), adapter
-        assert int((want.status == 1).sum()) > 0.3 * n
+        assert int((want.status == 1).sum()) > 0.2 * n
         m = 40_000
         sq, offs = packed[: int(off[m].item())].cpu().numpy(), off[: m + 1].cpu().numpy()
         oa = orc.Aligner(adapter, rate, 14, False, False, 1, 3)
