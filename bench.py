@@ -51,9 +51,9 @@ def parse_args(argv=None):
     ap.add_argument("--ragged", action="store_true",
                     help="cut the reads to 30 .. read_len characters at their 3' end (a hash of the read index): the batch a "
                          "pipeline holds behind -q / -u -- views (starts + lengths) into the sequencer's batch at its uniform "
-                         "stride; a single adapter's prefilter streams them end-aligned (C2, C4, C5)")
+                         "stride, streamed end-aligned (C2, C4, C5)")
     ap.add_argument("--ragged-packed", action="store_true",
-                    help="the same reads copied into a packed buffer with an offsets array: the per-lane kernels")
+                    help="the same reads copied into a packed buffer with an offsets array: cah_match_batch_frames")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--check-reads", type=int, default=250_000, help="reads compared with the oracle (untimed)")
@@ -556,8 +556,8 @@ def main():
                     extremes[f"p_adapter_{pa:g}"] = {"error": repr(exc)[:300]}
             result["p_adapter_extremes"] = extremes
             # ragged batches (what a pipeline holds behind -q / -u): the same reads cut to 30 .. 150 characters, as views
-            # into the uniform batch (a single adapter's prefilter streams them end-aligned: k_filter_stream2's RV form;
-            # several adapters take the per-lane kernels)
+            # into the uniform batch (streamed end-aligned: k_filter_stream2's RV form for one adapter, k_multi_stream's for
+            # several -- round 6)
             ragged = {}
             for cfg in ("C2", "C4"):
                 try:
@@ -573,6 +573,24 @@ def main():
                 except Exception as exc:
                     ragged[cfg] = {"error": repr(exc)[:300]}
             result["ragged"] = ragged
+            # ... and the same reads copied back to back with an offsets array (no uniform stride: what ReadBatch.from_strings
+            # of unequal reads, or the reads of a FASTQ chunk, look like): cah_match_batch_frames -- end-aligned frames of the
+            # longest read's length, the copy gathered from the reads' ends
+            packed = {}
+            for cfg in ("C2", "C4"):
+                try:
+                    r = run_config(args, cfg, DEFAULT_READS[cfg], 2, 1, 0, 1, device, gen, args.check_reads,
+                                   0.0, False, "packed")
+                    packed[cfg] = {"value": r["value"], "unit": r["unit"], "steps": r["steps"], "ms_per_step": r["ms_per_step"],
+                                   "workload": r["config"]["workload"], "parity_check": r["config"]["parity_check"],
+                                   "matched_fraction": r["config"]["matched_fraction"],
+                                   "kernel_ms_per_step": r["roofline"]["kernel_ms_per_step"],
+                                   "vs_uniform": r["value"] / (result["value"] if cfg == "C2" else (others.get(cfg, {}).get("value") or float("nan")))}
+                except SystemExit:
+                    raise
+                except Exception as exc:
+                    packed[cfg] = {"error": repr(exc)[:300]}
+            result["ragged_packed"] = packed
         line = json.dumps(result)
         if world > 1:
             os.write(real_stdout, (line + "\n").encode())

@@ -92,7 +92,10 @@ class ReadBatch:
             step = int(o_host[1])
             if step >= 1 and int(o_host[-1]) == step * (len(o_host) - 1) and bool((np.diff(o_host) == step).all()):
                 uniform = step
-        return cls(s, o, validated=validated, uniform_len=uniform)
+        b = cls(s, o, validated=validated, uniform_len=uniform)
+        if len(o_host) >= 2:
+            b.max_len = int(np.diff(o_host).max())            # (known here for free: match_batch's frame length, no device look-up)
+        return b
 
     @classmethod
     def from_strings(cls, reads: Sequence[str], device=None):
@@ -268,7 +271,7 @@ def kmers_present_batch(plan: "_lib.Plan", adapter: int, batch: ReadBatch):
 
 
 # ---- ragged batches of plans with several adapters -----------------------------------------------------------------
-FRAME_MIN_READS = 4096        # smaller batches: nothing to gain over the per-lane kernels
+FRAME_MIN_READS = 65536       # smaller batches: the per-lane kernels do (and a batch built on the device would need a look-up of its longest read)
 
 
 def _frame_len(plan: "_lib.Plan", batch: ReadBatch) -> int:

@@ -106,7 +106,9 @@ def ragged_device_batch(batch, first_index: int = 0):
         hi = min(n, lo + step)
         keep = cols[None, :] < lens[lo:hi, None]
         out[int(offsets[lo].item()):int(offsets[hi].item())] = view[lo:hi][keep]
-    return ReadBatch(out, offsets, validated=True)
+    packed = ReadBatch(out, offsets, validated=True)
+    packed.max_len = L                                     # (no read is longer than the uniform batch's)
+    return packed
 
 
 def ragged_view_batch(batch, first_index: int = 0):
