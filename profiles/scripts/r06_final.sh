@@ -45,8 +45,9 @@ try:
         print(c, o.get("error") or (round(o["value"]), round(o["ms_per_step"],2), o["parity_check"][:40], o["roofline"]["kernel"], round(o["roofline"]["frac"],4), o["roofline"].get("traffic"), (o["roofline"].get("whole_step_traffic") or {}).get("over_algorithmic"), (o.get("cpu_baseline") or {}).get("value")))
     for c,o in j.get("p_adapter_extremes",{}).items():
         print(c, o.get("error") or (round(o["value"]), round(o["ms_per_step"],2), o["parity_check"][:20]))
-    for c,o in j.get("ragged",{}).items():
-        print("ragged", c, o.get("error") or (round(o["value"]), round(o["ms_per_step"],2), o["parity_check"][:20], "x uniform", round(o["vs_uniform"],3)))
+    for key in ("ragged", "ragged_packed"):
+        for c,o in j.get(key,{}).items():
+            print(key, c, o.get("error") or (round(o["value"]), round(o["ms_per_step"],2), o["parity_check"][:20], "x uniform", round(o["vs_uniform"],3), {k:round(v,2) for k,v in o["kernel_ms_per_step"].items()}))
 except Exception as e:
     print("FAILED", e); print(open(f"{out}/bench_default.err").read()[-2000:])
 PY
