@@ -1533,6 +1533,7 @@ static int match_batch_multi_once(const cah_plan* plan, const PlanDeviceCopy* pd
             const int64_t n_tiles = (cnt + TILE - 1) / TILE;
             int64_t grid = std::min<int64_t>(n_tiles, pd->n_cus);
             int64_t gate = max_pages, rounds = 1;
+            bool ungated = false;                                       // (developer builds: the test switch below)
             if (n_tiles * per_tile + grid * open_pages > max_pages) {
                 // the batch might not fit the pool: blocks stop drawing tiles once what is in flight could fill it, and
                 // the rounds go on until the tiles are done -- `rounds` is the count for the worst case (every adapter on
@@ -1545,11 +1546,11 @@ static int match_batch_multi_once(const cah_plan* plan, const PlanDeviceCopy* pd
 #ifdef CAH_DEV_KNOBS
             // libcutadapt_hip_dev.so only (cutadapt_amd/build.py: build_dev_library; tests/test_gpu_multi2.py): takes the
             // gate away to provoke the pool's overflow.  The product library does not hold this switch.
-            if (env_flag("CAH_TEST_M2_UNGATED")) { gate = (int64_t)1 << 60; rounds = 1; }
+            if (env_flag("CAH_TEST_M2_UNGATED")) { gate = (int64_t)1 << 60; rounds = 1; ungated = true; }
 #endif
             HIP_TRY(hipMemsetAsync(counters, 0, WS_HEADER, s));
             // (the pool holds the worst case of the whole batch, one launch draws every tile: nothing for the host to decide)
-            deferred = t_deferred_errors && rounds == 1 && gate == max_pages && n_reads <= BLOCK;
+            deferred = t_deferred_errors && rounds == 1 && (gate == max_pages || ungated) && n_reads <= BLOCK;
           for (int64_t round = 0;; round++) {
             if (round >= rounds && deferred) break;
             if (round >= rounds) {

@@ -212,10 +212,42 @@ with env(CAH_MULTI_PAIR_CAP="1"):
         else:
             print("SERVED", "dev" if {dev} else "product")
             assert torch.equal(ok.status, st_ok)
+        # ... and with the deferred error check the same overflow is no exception but CAH_STATUS_INTERNAL in EVERY status byte
+        was = _lib.lib().cah_set_deferred_errors(1)
+        try:
+            bad = match_batch(plan, batch)
+            torch.cuda.synchronize()
+            if {dev}:
+                assert bool((bad.status == _lib.STATUS_INTERNAL).all()), int((bad.status == _lib.STATUS_INTERNAL).sum())
+                assert int(bad.out6.abs().sum()) == 0
+                print("MARKED dev")
+            else:
+                assert torch.equal(bad.status, st_ok)
+        finally:
+            _lib.lib().cah_set_deferred_errors(was)
     # the library is not left in a bad state: the next call is served and agrees
     again = match_batch(plan, batch)
     torch.cuda.synchronize()
     assert torch.equal(again.status, st_ok) and torch.equal(again.out6, ok.out6)
+    # the deferred error check (cah_set_deferred_errors: the call does not wait for its kernels): a gated pool still
+    # synchronises (the host decides on further rounds) and serves the batch ...
+    was = _lib.lib().cah_set_deferred_errors(1)
+    try:
+        d1 = match_batch(plan, batch)
+        torch.cuda.synchronize()
+        assert torch.equal(d1.status, st_ok) and torch.equal(d1.out6, ok.out6)
+    finally:
+        _lib.lib().cah_set_deferred_errors(was)
+# ... and a pool that holds the batch's worst case returns without waiting: same rows; with the gate taken away (dev
+# library only) no pool "holds the worst case" by the host's arithmetic, so the deferred form is not taken there
+was = _lib.lib().cah_set_deferred_errors(1)
+try:
+    d2 = match_batch(plan, batch)
+    torch.cuda.synchronize()
+    assert torch.equal(d2.status, st_ok) and torch.equal(d2.out6, ok.out6)
+    assert not bool((d2.status == _lib.STATUS_INTERNAL).any())
+finally:
+    assert _lib.lib().cah_set_deferred_errors(was) == 1
 assert int((st_ok == 1).sum()) > 0.8 * 300_000
 print("DONE")
 """
@@ -242,6 +274,7 @@ def test_pool_overflow_fails_loudly(hip):
                            env=e, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "DONE" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
         assert ("RAISED dev" if dev else "SERVED product") in r.stdout, r.stdout
+        assert ("MARKED dev" in r.stdout) == dev, r.stdout
 
 
 def test_first_occurrence_race_at_scale(hip, orc):
