@@ -119,6 +119,70 @@ __device__ __forceinline__ Chunk load_chunk_frame(const uint8_t* qv, const int p
     return c;
 }
 
+// Frame characters fc .. fc + 15 of a view of `len` characters that ends at byte `veb` of seqs, END-ALIGNED in a frame of n
+// characters (the gathering copy of the streaming prefilters' RV forms: views anywhere in the buffer).  Bytes safe_lo ..
+// safe_hi - 1 are known to lie inside the buffer (the extent of the piece's own views): a unit inside that range is ONE
+// 16-byte load, whatever it holds outside its view is masked by the caller (skip in front, the frame's end behind).  A unit
+// that reaches out of the range -- the first view's first unit, the last view's last -- is the 16 bytes at the view's edge,
+// shifted; views under 16 characters byte by byte.  Nothing outside [safe_lo, safe_hi) is touched.
+__device__ __forceinline__ void gather_frame_unit(const uint8_t* seqs, const int64_t veb, const int len, const int n, const int fc,
+                                                  const int64_t safe_lo, const int64_t safe_hi,
+                                                  unsigned& x0, unsigned& x1, unsigned& x2, unsigned& x3) {
+    const int64_t fa = veb - n + fc;
+    if (fa >= safe_lo && fa + 16 <= safe_hi) {
+        Unaligned16 v;
+        __builtin_memcpy(&v, seqs + fa, 16);
+        x0 = v.w[0]; x1 = v.w[1]; x2 = v.w[2]; x3 = v.w[3];
+        return;
+    }
+    const int64_t vsb = veb - len;
+    x0 = x1 = x2 = x3 = 0;
+    if (len >= 16) {
+        int64_t la = fa < vsb ? vsb : fa;
+        la = la > veb - 16 ? veb - 16 : la;
+        Unaligned16 v;
+        __builtin_memcpy(&v, seqs + la, 16);
+        x0 = v.w[0]; x1 = v.w[1]; x2 = v.w[2]; x3 = v.w[3];
+        const int sft = (int)(fa - la);                                  // > 0: the unit reaches behind the view; < 0: in front of it
+        if (sft > 0) {
+            const int dw = sft >> 2, sh = (sft & 3) * 8;
+            if (dw >= 2) { x0 = x2; x1 = x3; x2 = 0; x3 = 0; }
+            if (dw & 1) { x0 = x1; x1 = x2; x2 = x3; x3 = 0; }
+            const unsigned y0 = (unsigned)((((unsigned long long)x1 << 32) | x0) >> sh);
+            const unsigned y1 = (unsigned)((((unsigned long long)x2 << 32) | x1) >> sh);
+            const unsigned y2 = (unsigned)((((unsigned long long)x3 << 32) | x2) >> sh);
+            x3 = x3 >> sh; x0 = y0; x1 = y1; x2 = y2;
+        } else if (sft < 0) {
+            const int up = -sft, dw = up >> 2, sh = (up & 3) * 8;
+            if (dw >= 2) { x3 = x1; x2 = x0; x1 = 0; x0 = 0; }
+            if (dw & 1) { x3 = x2; x2 = x1; x1 = x0; x0 = 0; }
+            const unsigned y3 = (unsigned)((((unsigned long long)x3 << 32) | x2) >> (32 - sh));
+            const unsigned y2 = (unsigned)((((unsigned long long)x2 << 32) | x1) >> (32 - sh));
+            const unsigned y1 = (unsigned)((((unsigned long long)x1 << 32) | x0) >> (32 - sh));
+            if (sh) { x3 = y3; x2 = y2; x1 = y1; x0 = x0 << sh; }
+        }
+    } else {
+        unsigned x[4] = {0u, 0u, 0u, 0u};
+#pragma unroll 1
+        for (int b = 0; b < 16; ++b) {
+            const int64_t at = fa + b;
+            if (at >= vsb && at < veb) x[b >> 2] |= (unsigned)seqs[at] << (8 * (b & 3));
+        }
+        x0 = x[0]; x1 = x[1]; x2 = x[2]; x3 = x[3];
+    }
+}
+// wave-wide minimum / maximum of a 32-bit value (every lane takes part)
+__device__ __forceinline__ int wave_min_i32(int v) {
+#pragma unroll
+    for (int sft = 1; sft < 64; sft <<= 1) v = min(v, __shfl_xor(v, sft, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+    for (int sft = 1; sft < 64; sft <<= 1) v = max(v, __shfl_xor(v, sft, 64));
+    return v;
+}
+
 // The chunk at `pos` of lanes whose chunk lies inside their read (pos + 16 <= n): ONE load, nothing else -- for callers
 // that have asked the wave first; load_chunk's three cases and the masks behind them are ~35 instructions per call.
 __device__ __forceinline__ Chunk load_chunk_interior(const uint8_t* q, const int pos, const bool want) {

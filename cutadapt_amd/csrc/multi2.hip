@@ -302,7 +302,16 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
                 const unsigned e0_lo = __builtin_amdgcn_readfirstlane((unsigned)ve_own);
                 const unsigned e0_hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)ve_own >> 32));
                 const int64_t e0 = (int64_t)(((unsigned long long)e0_hi << 32) | e0_lo);
-                const int rel_own = (int)(ve_own - e0);
+                // (the extent of the piece's own views: every byte between is inside the buffer.  Views that lie more than 2^30
+                // bytes from lane 0's -- a batch of views in no order -- give no such extent: every unit then takes the careful way)
+                const int64_t rel64 = ve_own - e0;
+                const bool near = lane >= reads || (rel64 > -(1ll << 30) && rel64 < (1ll << 30));
+                const bool all_near = __builtin_amdgcn_ballot_w64(!near) == 0ull;
+                const int rel_own = near ? (int)rel64 : 0;
+                const int len_own = n - sk_own;
+                const int64_t safe_lo = all_near ? e0 + wave_min_i32(lane < reads ? rel_own - len_own : 0x7FFFFFFF) : 0;
+                const int64_t safe_hi = all_near ? e0 + wave_max_i32(lane < reads ? rel_own : -0x7FFFFFFF) : 0;
+                const int ve_lo_own = (int)(unsigned)ve_own, ve_hi_own = (int)(unsigned)((unsigned long long)ve_own >> 32);
 #pragma unroll
                 for (int q = 0; q < 2 * M2_HALF; ++q) {
                     const int kk = q < M2_HALF ? q : q - M2_HALF;
@@ -310,47 +319,16 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
                     m2_u32x4 got = (m2_u32x4)(0u);
                     if (kk < H) {                                       // (wave-uniform: every lane takes part in the exchanges)
                         const int rr = unit_r(kk, q < M2_HALF ? magic1 : magic2);
-                        const int rel_r = __builtin_amdgcn_ds_bpermute(rr << 2, rel_own);
+                        const unsigned ve_lo_r = (unsigned)__builtin_amdgcn_ds_bpermute(rr << 2, ve_lo_own);
+                        const unsigned ve_hi_r = (unsigned)__builtin_amdgcn_ds_bpermute(rr << 2, ve_hi_own);
+                        const int64_t veb_r = (int64_t)(((unsigned long long)ve_hi_r << 32) | ve_lo_r);
                         const int sk_r = __builtin_amdgcn_ds_bpermute(rr << 2, sk_own);
                         const int u = kk * WAVE + lane;
                         const int fc = 16 * (u - __mul24(rr, H)) + (q < M2_HALF ? 0 : 16 * H1);       // the unit's first frame character
                         const int len = n - sk_r;
                         if (u < reads * H && fc + 15 >= sk_r && fc < n && len > 0) {
-                            const int64_t veb = e0 + rel_r, vsb = veb - len, fa = veb - n + fc;
-                            unsigned x0 = 0, x1 = 0, x2 = 0, x3 = 0;
-                            if (len >= 16) {
-                                int64_t la = fa < vsb ? vsb : fa;
-                                la = la > veb - 16 ? veb - 16 : la;
-                                Unaligned16 v;
-                                __builtin_memcpy(&v, a.seqs + la, 16);
-                                x0 = v.w[0]; x1 = v.w[1]; x2 = v.w[2]; x3 = v.w[3];
-                                const int sft = (int)(fa - la);          // > 0: the unit reaches behind the view; < 0: in front of it
-                                if (sft > 0) {
-                                    const int dw = sft >> 2, sh = (sft & 3) * 8;
-                                    if (dw >= 2) { x0 = x2; x1 = x3; x2 = 0; x3 = 0; }
-                                    if (dw & 1) { x0 = x1; x1 = x2; x2 = x3; x3 = 0; }
-                                    const unsigned y0 = (unsigned)((((unsigned long long)x1 << 32) | x0) >> sh);
-                                    const unsigned y1 = (unsigned)((((unsigned long long)x2 << 32) | x1) >> sh);
-                                    const unsigned y2 = (unsigned)((((unsigned long long)x3 << 32) | x2) >> sh);
-                                    x3 = x3 >> sh; x0 = y0; x1 = y1; x2 = y2;
-                                } else if (sft < 0) {
-                                    const int up = -sft, dw = up >> 2, sh = (up & 3) * 8;
-                                    if (dw >= 2) { x3 = x1; x2 = x0; x1 = 0; x0 = 0; }
-                                    if (dw & 1) { x3 = x2; x2 = x1; x1 = x0; x0 = 0; }
-                                    const unsigned y3 = (unsigned)((((unsigned long long)x3 << 32) | x2) >> (32 - sh));
-                                    const unsigned y2 = (unsigned)((((unsigned long long)x2 << 32) | x1) >> (32 - sh));
-                                    const unsigned y1 = (unsigned)((((unsigned long long)x1 << 32) | x0) >> (32 - sh));
-                                    if (sh) { x3 = y3; x2 = y2; x1 = y1; x0 = x0 << sh; }
-                                }
-                            } else {
-                                unsigned x[4] = {0u, 0u, 0u, 0u};
-#pragma unroll 1
-                                for (int b = 0; b < 16; ++b) {
-                                    const int64_t at = fa + b;
-                                    if (at >= vsb && at < veb) x[b >> 2] |= (unsigned)a.seqs[at] << (8 * (b & 3));
-                                }
-                                x0 = x[0]; x1 = x[1]; x2 = x[2]; x3 = x[3];
-                            }
+                            unsigned x0, x1, x2, x3;
+                            gather_frame_unit(a.seqs, veb_r, len, n, fc, safe_lo, safe_hi, x0, x1, x2, x3);
                             got = (m2_u32x4){x0, x1, x2, x3};
                         }
                     }

@@ -355,6 +355,7 @@ __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a
         unsigned next_piece;                                            // the block's pieces are dealt to its waves on demand
         uint32_t front[FR ? CAH_TABLE_CHARS : 1];                       // FR: bit i = character matches front adapter position i
         uint32_t views[RV ? S2_WAVES * WAVE : 1];                       // RV: d | skip << 16 of the wave's NEXT piece
+        uint32_t view_end[RV ? 2 * S2_WAVES * WAVE : 1];                // RV, views anywhere: ... and their ends (byte in seqs, two words)
         uint32_t lowmask[RV ? 16 * 4 : 1];                              // RV: entry c (16 bytes): the first c bytes 0x00, the rest 0xFF
     };
     static_assert(sizeof(S2Lds) <= 160 * 1024, "k_filter_stream2: LDS");
@@ -493,7 +494,7 @@ __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a
     // there).  The resource's base sits S2_RV_BACK bytes in front of the piece (d <= n, and for n < 16 the copy plan's
     // stride n - 16 H is negative): the batch's first pieces go lane by lane.
     // RV, views anywhere in the buffer (suffix_views == 3): the gathering copy
-    auto prefetch_general = [&](int64_t base, const uint32_t vw) {
+    auto prefetch_general = [&](int64_t base, const uint32_t vw, const int64_t ve_parked, const bool parked) {
         const int64_t left = n_reads - base;                            // wave-uniform
         if (left <= 0) return;
                 // Views ANYWHERE in the buffer (cah_match_batch_frames: a packed batch, the reads of a raw FASTQ chunk): unit u
@@ -504,11 +505,22 @@ __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a
                 const int reads = (int)(left < WAVE ? left : (int64_t)WAVE);
                 const int64_t r_own = base + (lane < reads ? lane : 0);
                 const int sk_own = lane < reads ? (int)(vw >> 16) : n;
-                const int64_t ve_own = a.offsets[r_own] + (int64_t)(n - sk_own);
+                // (the views' ends: parked in LDS a half-piece ahead like the views themselves -- nobody waits for the loads --,
+                // or fetched here for a wave's first piece)
+                const int64_t ve_own = parked ? ve_parked : a.offsets[r_own] + (int64_t)(n - sk_own);
                 const unsigned e0_lo = __builtin_amdgcn_readfirstlane((unsigned)ve_own);
                 const unsigned e0_hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)ve_own >> 32));
                 const int64_t e0 = (int64_t)(((unsigned long long)e0_hi << 32) | e0_lo);
-                const int rel_own = (int)(ve_own - e0);
+                // (the extent of the piece's own views: every byte between is inside the buffer.  Views that lie more than 2^30
+                // bytes from lane 0's -- a batch of views in no order -- give no such extent: every unit then takes the careful way)
+                const int64_t rel64 = ve_own - e0;
+                const bool near = lane >= reads || (rel64 > -(1ll << 30) && rel64 < (1ll << 30));
+                const bool all_near = __builtin_amdgcn_ballot_w64(!near) == 0ull;
+                const int rel_own = near ? (int)rel64 : 0;
+                const int len_own = n - sk_own;
+                const int64_t safe_lo = all_near ? e0 + wave_min_i32(lane < reads ? rel_own - len_own : 0x7FFFFFFF) : 0;
+                const int64_t safe_hi = all_near ? e0 + wave_max_i32(lane < reads ? rel_own : -0x7FFFFFFF) : 0;
+                const int ve_lo_own = (int)(unsigned)ve_own, ve_hi_own = (int)(unsigned)((unsigned long long)ve_own >> 32);
                 const uint8_t* const sq = a.seqs;
 #pragma unroll
                 for (int q = 0; q < 2 * S2_HALF; ++q) {
@@ -517,47 +529,16 @@ __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a
                     s2_u32x4 got = (s2_u32x4)(0u);
                     if (k < H) {                                        // (wave-uniform: every lane takes part in the exchanges)
                         const int rr = unit_r(k, q < S2_HALF ? magic1 : magic2);
-                        const int rel_r = __builtin_amdgcn_ds_bpermute(rr << 2, rel_own);
+                        const unsigned ve_lo_r = (unsigned)__builtin_amdgcn_ds_bpermute(rr << 2, ve_lo_own);
+                        const unsigned ve_hi_r = (unsigned)__builtin_amdgcn_ds_bpermute(rr << 2, ve_hi_own);
+                        const int64_t veb_r = (int64_t)(((unsigned long long)ve_hi_r << 32) | ve_lo_r);
                         const int sk_r = __builtin_amdgcn_ds_bpermute(rr << 2, sk_own);
                         const int u = k * WAVE + lane;
                         const int fc = 16 * (u - __mul24(rr, H)) + (q < S2_HALF ? 0 : 16 * H1);
                         const int len = n - sk_r;
                         if (u < reads * H && fc + 15 >= sk_r && fc < n && len > 0) {
-                            const int64_t veb = e0 + rel_r, vsb = veb - len, fa = veb - n + fc;
-                            unsigned x0 = 0, x1 = 0, x2 = 0, x3 = 0;
-                            if (len >= 16) {
-                                int64_t la = fa < vsb ? vsb : fa;
-                                la = la > veb - 16 ? veb - 16 : la;
-                                Unaligned16 v;
-                                __builtin_memcpy(&v, sq + la, 16);
-                                x0 = v.w[0]; x1 = v.w[1]; x2 = v.w[2]; x3 = v.w[3];
-                                const int sft = (int)(fa - la);          // > 0: the unit reaches behind the view; < 0: in front of it
-                                if (sft > 0) {
-                                    const int dw = sft >> 2, sh = (sft & 3) * 8;
-                                    if (dw >= 2) { x0 = x2; x1 = x3; x2 = 0; x3 = 0; }
-                                    if (dw & 1) { x0 = x1; x1 = x2; x2 = x3; x3 = 0; }
-                                    const unsigned y0 = (unsigned)((((unsigned long long)x1 << 32) | x0) >> sh);
-                                    const unsigned y1 = (unsigned)((((unsigned long long)x2 << 32) | x1) >> sh);
-                                    const unsigned y2 = (unsigned)((((unsigned long long)x3 << 32) | x2) >> sh);
-                                    x3 = x3 >> sh; x0 = y0; x1 = y1; x2 = y2;
-                                } else if (sft < 0) {
-                                    const int up = -sft, dw = up >> 2, sh = (up & 3) * 8;
-                                    if (dw >= 2) { x3 = x1; x2 = x0; x1 = 0; x0 = 0; }
-                                    if (dw & 1) { x3 = x2; x2 = x1; x1 = x0; x0 = 0; }
-                                    const unsigned y3 = (unsigned)((((unsigned long long)x3 << 32) | x2) >> (32 - sh));
-                                    const unsigned y2 = (unsigned)((((unsigned long long)x2 << 32) | x1) >> (32 - sh));
-                                    const unsigned y1 = (unsigned)((((unsigned long long)x1 << 32) | x0) >> (32 - sh));
-                                    if (sh) { x3 = y3; x2 = y2; x1 = y1; x0 = x0 << sh; }
-                                }
-                            } else {
-                                unsigned x[4] = {0u, 0u, 0u, 0u};
-#pragma unroll 1
-                                for (int b = 0; b < 16; ++b) {
-                                    const int64_t at = fa + b;
-                                    if (at >= vsb && at < veb) x[b >> 2] |= (unsigned)sq[at] << (8 * (b & 3));
-                                }
-                                x0 = x[0]; x1 = x[1]; x2 = x[2]; x3 = x[3];
-                            }
+                            unsigned x0, x1, x2, x3;
+                            gather_frame_unit(sq, veb_r, len, n, fc, safe_lo, safe_hi, x0, x1, x2, x3);
                             got = (s2_u32x4){x0, x1, x2, x3};
                         }
                     }
@@ -758,7 +739,7 @@ __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a
     if constexpr (RV) {
         const uint32_t vw = view_of(piece_base(p));
         skip_next = (int)(vw >> 16);
-        if (a.suffix_views == 3) prefetch_general(piece_base(p), vw); else prefetch(piece_base(p), vw);
+        if (a.suffix_views == 3) prefetch_general(piece_base(p), vw, 0, false); else prefetch(piece_base(p), vw);
     } else {
         prefetch(piece_base(p));
     }
@@ -816,6 +797,11 @@ __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a
                         if (a.suffix_views == 3) { ln = ln < 0 ? 0 : (ln > n ? n : ln); st = n - ln; }    // (views anywhere: d = 0)
                         ln = ln < 0 ? 0 : (ln > n - st ? n - st : ln);
                         s_lds.views[wave * WAVE + lane] = (uint32_t)(n - (st + ln)) | ((uint32_t)(n - ln) << 16);
+                        if (a.suffix_views == 3) {                      // (the gathering copy starts from the views' ENDS)
+                            const unsigned long long ve = (unsigned long long)(view_at + ln);
+                            s_lds.view_end[2 * (wave * WAVE + lane)] = (uint32_t)ve;
+                            s_lds.view_end[2 * (wave * WAVE + lane) + 1] = (uint32_t)(ve >> 32);
+                        }
                     }
                 }
                 if (alive) {
@@ -945,7 +931,11 @@ __global__ __launch_bounds__(S2_WAVES * WAVE) void k_filter_stream2(FilterArgs a
             if constexpr (RV) {
                 const uint32_t vw = s_lds.views[wave * WAVE + lane];
                 skip_next = (int)(vw >> 16);
-                if (a.suffix_views == 3) prefetch_general(piece_base(p_next), vw); else prefetch(piece_base(p_next), vw);
+                if (a.suffix_views == 3) {
+                    const unsigned long long ve = ((unsigned long long)s_lds.view_end[2 * (wave * WAVE + lane) + 1] << 32) |
+                                                  s_lds.view_end[2 * (wave * WAVE + lane)];
+                    prefetch_general(piece_base(p_next), vw, (int64_t)ve, true);
+                } else prefetch(piece_base(p_next), vw);
             } else {
                 prefetch(piece_base(p_next));
             }

@@ -435,3 +435,19 @@ def test_ragged_batches_stream_in_frames(hip, orc):
     torch.cuda.synchronize()
     assert _lib_last_path() == "stream"
     assert torch.equal(got2.status, want.status) and torch.equal(got2.out6, want.out6)
+    # views in NO order over a buffer of 1.35 GB (neighbouring views more than 2^30 bytes apart: the gathering copy then has
+    # no extent of the piece's own views to load freely in, every unit takes the careful way), against the per-lane kernels
+    big = ReadBatch.synthetic(9_000_000, 150, seqs, seed=32, p_adapter=0.6, p_edit=0.03, p_n=0.003)
+    pick = (((idx * 2654435761) >> 3) % 9_000_000)
+    pick[1::2] = 8_999_999 - pick[1::2] % 1000                           # every other view at the buffer's far end
+    far = ReadBatch(big.seqs, pick * 150 + starts, lens.to(torch.int32), n_reads=n, validated=True)
+    far.max_len = 150
+    got3 = match_batch(plan, far)
+    torch.cuda.synchronize()
+    assert _lib_last_path() == "stream"
+    with env(CAH_NO_FRAMES="1"):
+        far2 = ReadBatch(big.seqs, pick * 150 + starts, lens.to(torch.int32), n_reads=n, validated=True)
+        want3 = match_batch(plan, far2)
+        torch.cuda.synchronize()
+    assert torch.equal(got3.status, want3.status) and torch.equal(got3.out6, want3.out6)
+    assert int((want3.status == 1).sum()) > 0.4 * n
