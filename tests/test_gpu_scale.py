@@ -48,19 +48,24 @@ def test_blocks_on_both_sides_of_4GB_against_the_oracle(hip, orc, config):
 
 
 def test_ragged_views_blocks_at_scale(hip, orc):
-    """the RV form (views inside a uniform batch) at 30 M reads: the same scattered blocks"""
+    """the RV forms (views inside a uniform batch) and the frames (the same reads packed back to back with an offsets array)
+    at 30 M reads, one adapter and 96: the same scattered blocks"""
     import torch
+    from cutadapt_amd import _lib
     sys.path.insert(0, ROOT)
     import bench
     n = 30_000_000
     for config in ("C2", "C4"):
-        wl = bench.Workload(config, n, 0, torch.device("cuda", 0), None, "views")
-        wl.step()
-        torch.cuda.synchronize()
-        ok, what = wl.parity(50_000)
-        assert ok, what
-        del wl
-        torch.cuda.empty_cache()
+        for mode in ("views", "packed"):
+            wl = bench.Workload(config, n, 0, torch.device("cuda", 0), None, mode)
+            wl.step()
+            torch.cuda.synchronize()
+            if config == "C4":
+                assert _lib.last_multi_path() == "stream", (mode, _lib.last_multi_path())
+            ok, what = wl.parity(50_000)
+            assert ok, (mode, what)
+            del wl
+            torch.cuda.empty_cache()
 
 
 def test_bench_two_ranks_one_json_line(hip):
