@@ -419,9 +419,14 @@ class _Worker:
         else:
             self.res.status[:n].zero_()                      # a mate without adapters: nothing is found
         rounds = int(self.opts.get("times", 1)) if (self.plan is not None and not linked) else 1
-        final_here = limits is not None and not post and rounds == 1 and not linked
-        lim = limits if final_here else (-1, -1, 0, 0)
         action = int(self.opts.get("action", 0))
+        # the marking actions (4 mask, 5 lowercase; reference modifiers.py:170-198): the rounds run as for trim -- what
+        # they would keep is remainder(matches) --, then the record stays whole and the formatter marks around that interval
+        marking = action in (4, 5) and self.plan is not None and not linked
+        if marking:
+            action = 0
+        final_here = limits is not None and not post and rounds == 1 and not linked and not marking
+        lim = limits if final_here else (-1, -1, 0, 0)
         if linked:
             pass                                             # (intervals and status are in place)
         elif action != 0:
@@ -465,6 +470,21 @@ class _Worker:
                 keepalive += [rb, rl, ro]
             self.res.status[:n].copy_(first_status)
             keepalive += [first_status, scratch]
+        if marking:
+            if getattr(self, "mark_beg", None) is None or self.mark_beg.numel() < self.beg.numel():
+                self.mark_beg = torch.empty_like(self.beg)
+                self.mark_end = torch.empty_like(self.end)
+            self.mark_beg[:n].copy_(self.beg[:n])
+            self.mark_end[:n].copy_(self.end[:n])
+            if wbeg is None:
+                self.beg[:n].zero_()
+                self.end[:n].copy_(seq_len)
+            else:
+                self.beg[:n].copy_(wbeg)
+                self.end[:n].copy_(wbeg + wlen)
+            self.mark_mode = 1 if int(self.opts.get("action", 0)) == 4 else 2
+        else:
+            self.mark_mode = 0
         ee = None
         if post:
             # the modifiers behind the adapter step (--poly-a, -l: cli.py:956-973) move the kept interval, then the
@@ -520,10 +540,17 @@ class _Worker:
         if o.get("assemble") == "host":
             return self._assemble_on_host(data, n_bytes, n)
         # ---- step 4: format on the device, bring the bytes back ---------------------------------------------
-        _lib.check(L.cah_fastq_format_device(self.d_in.data_ptr(), self.rec6.data_ptr(), n, self.beg.data_ptr(),
-                                             self.end.data_ptr(), self.keep.data_ptr(), self.d_scratch.data_ptr(),
-                                             self.d_scratch.numel(), n_bytes, self.d_out.data_ptr(),
-                                             self.d_out.numel(), self.d_info.data_ptr(), sp))
+        if getattr(self, "mark_mode", 0) and n:
+            _lib.check(L.cah_fastq_format_mark_device(self.d_in.data_ptr(), self.rec6.data_ptr(), n, self.beg.data_ptr(),
+                                                      self.end.data_ptr(), self.keep.data_ptr(), self.mark_beg.data_ptr(),
+                                                      self.mark_end.data_ptr(), int(self.mark_mode), self.d_scratch.data_ptr(),
+                                                      self.d_scratch.numel(), n_bytes, self.d_out.data_ptr(),
+                                                      self.d_out.numel(), self.d_info.data_ptr(), sp))
+        else:
+            _lib.check(L.cah_fastq_format_device(self.d_in.data_ptr(), self.rec6.data_ptr(), n, self.beg.data_ptr(),
+                                                 self.end.data_ptr(), self.keep.data_ptr(), self.d_scratch.data_ptr(),
+                                                 self.d_scratch.numel(), n_bytes, self.d_out.data_ptr(),
+                                                 self.d_out.numel(), self.d_info.data_ptr(), sp))
         self.d_info[4:5].copy_(self.counters[6:7], non_blocking=True)
         self.d_info[5:6].copy_(self.ee_invalid.to(torch.int64).reshape(1), non_blocking=True)
         self.h_info.copy_(self.d_info, non_blocking=True)
@@ -991,11 +1018,16 @@ def trim_fastq_gpu(source: Union[str, BinaryIO, np.ndarray], out: Union[str, Bin
     # the all-device way: action trim with any number of rounds, or -- one round, single adapters -- the actions that only
     # move the kept interval (none / retain / crop); no adapters at all (-q / --nextseq-trim / --poly-a / -l / --max-ee / -m
     # alone) is the same way with an empty adapter step
-    act = {"trim": 0, None: 1, "none": 1, "retain": 2, "crop": 3}.get(action, -1)
-    single_round_action = act > 0 and int(times) == 1 and bool(adapters) and not any(isinstance(a, LinkedAdapter) for a in adapters)
+    act = {"trim": 0, None: 1, "none": 1, "retain": 2, "crop": 3, "mask": 4, "lowercase": 5}.get(action, -1)
+    no_linked = not any(isinstance(a, LinkedAdapter) for a in adapters)
+    single_round_action = act in (1, 2, 3) and int(times) == 1 and bool(adapters) and no_linked
+    # (round 6: the marking actions -- mask / lowercase, reference modifiers.py:170-198 -- too: the rounds run as for trim,
+    # what they would keep is the interval the device formatter marks around (cah_fastq_format_mark_device); not with
+    # --poly-a behind them: that trimmer would have to look at the MARKED characters)
+    marking = act in (4, 5) and bool(adapters) and no_linked and not poly_a
     all_device = (not revcomp and info_file is None and
                   ((not adapters and action in ("trim", None, "none", "retain", "crop", "mask", "lowercase")) or
-                   (bool(adapters) and (act == 0 or single_round_action) and _all_device_adapters(adapters, int(times), index))))
+                   (bool(adapters) and (act == 0 or single_round_action or marking) and _all_device_adapters(adapters, int(times), index))))
     pre = post = None
     if all_device and (cut or nextseq_trim is not None or quality_cutoff is not None):
         pre = {"cut": cut, "nextseq_trim": nextseq_trim, "quality_cutoff": quality_cutoff, "quality_base": quality_base}
@@ -1006,6 +1038,8 @@ def trim_fastq_gpu(source: Union[str, BinaryIO, np.ndarray], out: Union[str, Bin
     opts = {"discard_untrimmed": discard_untrimmed, "discard_trimmed": discard_trimmed,
             "minimum_length": minimum_length, "maximum_length": maximum_length, "assemble": assemble, "pre": pre, "post": post,
             "times": int(times), "action": max(act, 0) if adapters else 0}
+    if all_device and adapters and act in (4, 5):
+        assemble = opts["assemble"] = "device"               # (the host-side assembler copies slices: it cannot mark)
     from .pipeline import BatchTrimmer
     if all_device:
         plan, kinds = _plan_for(adapters) if adapters else (None, [0])

@@ -87,6 +87,14 @@ def test_device_fastq_equals_host_pipeline(hip):
         ([A.FrontAdapter(ad_seqs[1]), A.BackAdapter(ad_seqs[0])], {"action": "crop", "quality_cutoff": (0, 15), "discard_untrimmed": True}),
         ([A.AnywhereAdapter(ad_seqs[2]), A.SuffixAdapter(ad_seqs[1])], {"action": "retain", "cut": [2, -1], "poly_a": True, "length": 90}),
         ([A.BackAdapter(ad_seqs[0])], {"action": "crop", "max_expected_errors": 3.0, "maximum_length": 40}),
+        # --action mask / lowercase (round 6; reference modifiers.py:170-198): the rounds as for trim, the record written whole
+        # and marked around what they would have kept -- with modifiers in front, several rounds, -l and the filters behind
+        ([A.BackAdapter(ad_seqs[0])], {"action": "mask"}),
+        ([A.BackAdapter(ad_seqs[0]), A.FrontAdapter(ad_seqs[1]), A.AnywhereAdapter(ad_seqs[2])], {"action": "lowercase", "minimum_length": 40}),
+        ([A.BackAdapter(ad_seqs[0]), A.FrontAdapter(ad_seqs[1]), A.AnywhereAdapter(ad_seqs[2])], {"action": "mask", "times": 3, "discard_untrimmed": True}),
+        ([A.FrontAdapter(ad_seqs[1]), A.BackAdapter(ad_seqs[0])], {"action": "lowercase", "quality_cutoff": (10, 15), "cut": [2, -3], "times": 2,
+                                                              "length": 100, "max_expected_errors": 4.0, "maximum_length": 130}),
+        ([A.NonInternalBackAdapter(ad_seqs[1]), A.PrefixAdapter(ad_seqs[2])], {"action": "mask", "nextseq_trim": 20, "discard_trimmed": True}),
         # no adapter at all: the modifiers and filters alone, still on the device
         ([], {"quality_cutoff": (10, 20), "minimum_length": 30}),
         ([], {"nextseq_trim": 20, "poly_a": True, "length": 100, "max_expected_errors": 2.0}),
@@ -176,7 +184,8 @@ def test_feeder_processes_write_the_same_bytes_as_feeder_threads(hip, tmp_path):
         (dict(adapters=[BackAdapter(ads[0], max_errors=0.1, min_overlap=3)], minimum_length=20), "all-device"),
         (dict(adapters=[BackAdapter(a, max_errors=0.1, min_overlap=3) for a in ads], times=2, quality_cutoff=(0, 20),
               discard_untrimmed=True), "all-device"),
-        (dict(adapters=[FrontAdapter(ads[1][:12], max_errors=0.1)], action="mask"), "general"),
+        (dict(adapters=[FrontAdapter(ads[1][:12], max_errors=0.1)], action="mask"), "all-device"),
+        (dict(adapters=[FrontAdapter(ads[1][:12], max_errors=0.1)], action="mask", poly_a=True), "general"),
     ]
     for k, (opts, way) in enumerate(cases):
         for n_proc in (2, 3):
