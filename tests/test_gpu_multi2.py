@@ -451,3 +451,48 @@ def test_ragged_batches_stream_in_frames(hip, orc):
         torch.cuda.synchronize()
     assert torch.equal(got3.status, want3.status) and torch.equal(got3.out6, want3.out6)
     assert int((want3.status == 1).sum()) > 0.4 * n
+
+
+def test_frames_of_short_and_odd_batches(hip, orc):
+    """cah_match_batch_frames at the edges: reads of 0 .. 20 characters (frames of 16 .. 20), a batch of empty reads, one
+    long read among short ones, a batch whose longest read is longer than the streaming forms take (falls back by itself),
+    for one adapter and for several -- against the oracle in full"""
+    import torch
+    from cutadapt_amd import adapters as A
+    from cutadapt_amd import batch as B
+    from cutadapt_amd.batch import ReadBatch, match_batch
+    prng = random.Random(93)
+    seqs = [rs(prng, 20) for _ in range(8)]
+    plan8, ads8 = plan_for(seqs, 0.1, 3)
+    one = A.BackAdapter(seqs[0], max_errors=0.1, min_overlap=3)
+    n = 70_000
+    old_min = B.FRAME_MIN_READS
+    B.FRAME_MIN_READS = 1000
+    try:
+        for what, lo, hi, long_one in (("short", 0, 20, None), ("empty", 0, 0, None), ("one long", 0, 40, 150), ("too long", 10, 60, 400)):
+            reads = []
+            for i in range(n):
+                ln = prng.randint(lo, hi)
+                r = rs(prng, ln)
+                if ln >= 6 and i % 3 == 0:
+                    cut = seqs[i % 8][: prng.randint(3, min(20, ln))]
+                    r = r[: ln - len(cut)] + cut
+                reads.append(r)
+            if long_one:
+                reads[n // 2] = rs(prng, long_one - 20) + seqs[3]
+            sq, offs = orc.pack_reads(reads)
+            for plan, ads in ((plan8, ads8), (one._fused_plan, [one])):
+                batch = ReadBatch.from_host(sq, offs)
+                frame = B._frame_len(plan, batch)
+                if what == "too long":
+                    assert frame == 0
+                elif len(ads) == 8:
+                    assert frame == max(16, int(np.diff(offs).max())), (what, frame)
+                got = match_batch(plan, batch)
+                torch.cuda.synchronize()
+                want6, want_st, want_best = oracle_multiple(orc, ads, sq, offs)
+                g6, gst = got.out6.cpu().numpy(), got.status.cpu().numpy()
+                bad = np.nonzero((gst != want_st) | (g6 != want6).any(axis=1))[0]
+                assert len(bad) == 0, (what, len(ads), len(bad), reads[int(bad[0])], g6[bad[0]].tolist(), want6[bad[0]].tolist())
+    finally:
+        B.FRAME_MIN_READS = old_min
