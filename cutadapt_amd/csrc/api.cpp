@@ -1473,7 +1473,7 @@ static thread_local int t_last_multi_path = -1;
 int cah_last_multi_path(void) { return t_last_multi_path; }
 // Deferred error check (per calling thread; off by default).  The streaming multi-adapter path reads the device's error
 // word back after its kernels -- one synchronisation per call, so that a broken invariant is CAH_EINTERNAL.  A caller that
-// issues many small batches on several streams (cutadapt_amd/batch.py: the length buckets of a ragged batch) switches the
+// issues many small batches on several streams switches the
 // deferred form on: a call whose pool holds the batch's worst case returns without waiting, and k_multi_decode writes
 // CAH_STATUS_INTERNAL into every status byte of a batch whose kernels flagged something -- the caller looks for it.
 static thread_local int t_deferred_errors = 0;

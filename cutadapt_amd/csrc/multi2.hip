@@ -15,8 +15,10 @@
 //     whole-read k-mers; a probe hit becomes an EVENT (lane, position, the rolling word) in the wave's LDS ring;
 //   * events are resolved 64 at a time by ALL lanes (directory -> entries in LDS, verified on every character and on
 //     the k-mer's windows) -- no lane waits for another lane's hit;
-//   * after the read: three short sweeps over its tail (classes hi, lo, REF-only k-mers), each resolved before the next;
-//   * a pair is emitted once (LDS bitsets `seen` / `wide only` per read and adapter) into a PAGE of its class: pages of
+//   * behind the main pass: the tail classes' hits (probed in the read's last chunks, one mask per index class) become events
+//     pass by pass in class order (hi, lo, E0), each class resolved before the next;
+//   * a pair is emitted once (an LDS bitset `seen` per read and adapter; which pairs saw a FURTHER hit is two words per read)
+//     into a PAGE of its class: pages of
 //     1024 pairs from a device-wide pool, owned by one wave, one class of pairs per page -- the scan's waves then hold 64
 //     pairs of one window shape.  Pairs that only the error-free rows can match are decided here (suffix compare).
 //   * a whole-read pair whose first hit is ONE chunk of the adapter's k + 1 carries that occurrence (position, chunk):
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
 
     // ---- copy plan (k_filter_stream2's): H1 units of every read in the first half-row, H2 in the second
     // (a read of at most M2_HALF units is ONE half-row: its tail chunks, whose words wait in the row, then never straddle
-    // the two fills of the slot -- reads of 16 .. 80 characters, the short buckets of a ragged batch)
+    // the two fills of the slot -- reads of 16 .. 80 characters)
     const int U = (n + 15) >> 4;
     const int H1 = U <= M2_HALF ? U : (U + 1) >> 1, H2 = U - H1;
     const unsigned magic1 = (65536u + (unsigned)H1 - 1u) / (unsigned)H1;
@@ -539,7 +541,7 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
             pc_cls = m2_pair_class_w((n - max(0, (key_cls << CAH_KEY_SHIFT) - m - k - 1) + 15) >> 4);
         } else if (cls == M2_HI) { pc_cls = 1; key_cls = max(0, n - a.win_hi) >> 2; flags_cls = CAH_M2_PAIR_TAIL; }
         else if (cls == M2_LO) { pc_cls = 0; key_cls = max(0, n - a.win_lo) >> 2; flags_cls = CAH_M2_PAIR_TAIL; }
-        else { pc_cls = 7; key_cls = 0; }                              // REF-only k-mers: the suffix compare decides
+        else { pc_cls = 7; key_cls = 0; }                              // class E0: the suffix compare decides
         const unsigned lo_cls = ((unsigned)pc_cls << 28) | (flags_cls << 24) | (unsigned)key_cls;
         unsigned staged = 0;                                            // wave-uniform
         // the staged pairs (at most 64, one per lane) leave: pairs for their class's page, suffix compares to best_key

@@ -3,7 +3,7 @@
 //
 // Compiles the product's own table builder and rules (cutadapt_amd/csrc/multi2.h) and classification
 // (back_scan.h) with g++ and replays, read by read and sequentially, what the kernels do: the main pass over the
-// read (class W k-mers), the three tail sweeps (hi, lo, short) in this order, `seen` / `wide only` / `first`, the
+// read (class W k-mers), the tail classes' event passes (hi, lo, E0) in this order, `seen` / "again" / `first`, the
 // error-free suffix compare, and for every pair the cost scan on the pair's window followed by the shortcut or the
 // windowed cell DP.  tests/test_multi2_model.py compares the merged result (MultipleAdapters' order) with the
 // oracle's kmers_present + locate on the whole read.
@@ -110,7 +110,7 @@ extern "C" {
 // adapters: A strings of m characters back to back.  blobs: A CahMatcher structs (cah_plan_debug_matcher).
 // ref_*: the reference search sets, flattened: adapter index, window (255 = whole read, else L of (-L, None)), k-mer
 // (NUL-terminated strings back to back).  subs: 1 = the scan keeps the SUBS_FULL / INDEL1_FULL bookkeeping.
-// stats (may be NULL): [0] pairs W, [1] pairs hi, [2] pairs lo, [3] suffix compares that matched, [4] pairs that take the whole read because a WIDE-only hit came first,
+// stats (may be NULL): [0] pairs W, [1] pairs hi, [2] pairs lo, [3] suffix compares that matched, [4] (unused since round 6),
 // [5] scan columns, [6] pairs to the cell DP, [7] whole-read pairs scanned on the window of their one occurrence.
 // Returns 0; 1 when the tables cannot be built (the plan would take the older path).
 int m2m_match_batch(const char* adapters, int A, int m, const void* blobs, int32_t n_ref, const int32_t* ref_adapter,
