@@ -33,7 +33,7 @@ pmc C2 100000000 final_c2
 pmc C3 100000000 final_c3
 pmc C5 125000000 final_c5
 cp profiles/pmc_latest.json $out/
-timeout 1200 python bench.py > $out/bench_default.json 2> $out/bench_default.err; echo "bench rc=$?"
+t0=$(date +%s); timeout 1200 python bench.py > $out/bench_default.json 2> $out/bench_default.err; echo "bench rc=$? wall $(( $(date +%s) - t0 )) s"
 python - "$out" <<'PY'
 import json,sys
 out=sys.argv[1]
