@@ -233,13 +233,9 @@ __global__ __launch_bounds__(256) void k_scan_apply(const int64_t* in, int64_t n
 }
 
 // one wave per record (round-robin inside a block): "@name\nSEQ[a:b]\n+\nQUAL[a:b]\n"
-// mark_mode (AdapterCutter's marking actions, reference modifiers.py:170-198: masked_read / lowercased_read): the record is
-// written whole ([beg, end) is the read as the adapter step saw it) and the characters OUTSIDE [mark_beg, mark_end) -- what
-// trimming would have removed -- become 'N' (1: mask) or lower case, with the characters inside in upper case (2: lowercase)
 __global__ __launch_bounds__(256) void k_format(const uint8_t* buf, const int64_t* rec6, int64_t n_records, const int32_t* beg,
                                                 const int32_t* end, const uint8_t* keep, const int64_t* out_off,
-                                                uint8_t* out, int64_t out_cap, const int32_t* mark_beg = nullptr,
-                                                const int32_t* mark_end = nullptr, const int mark_mode = 0) {
+                                                uint8_t* out, int64_t out_cap) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t n_waves = (int64_t)gridDim.x * 4;
@@ -259,23 +255,42 @@ __global__ __launch_bounds__(256) void k_format(const uint8_t* buf, const int64_
         for (int64_t k = lane; k < name_len; k += 64) w[1 + k] = buf[o[0] + k];
         w += 1 + name_len;
         if (lane == 0) w[0] = '\n';
-        if (mark_mode == 0) {
-            for (int64_t k = lane; k < body; k += 64) w[1 + k] = buf[o[2] + a + k];
-        } else {
-            const int64_t mb = mark_beg[r], me = mark_end[r];
-            for (int64_t k = lane; k < body; k += 64) {
-                uint8_t c = buf[o[2] + a + k];
-                const bool inside = a + k >= mb && a + k < me;
-                if (mark_mode == 1) c = inside ? c : (uint8_t)'N';
-                else if (inside) c = (c >= 'a' && c <= 'z') ? (uint8_t)(c - 32) : c;       // str.upper() / str.lower() on ASCII
-                else c = (c >= 'A' && c <= 'Z') ? (uint8_t)(c + 32) : c;
-                w[1 + k] = c;
-            }
-        }
+        for (int64_t k = lane; k < body; k += 64) w[1 + k] = buf[o[2] + a + k];
         w += 1 + body;
         if (lane == 0) { w[0] = '\n'; w[1] = '+'; w[2] = '\n'; }
         for (int64_t k = lane; k < body; k += 64) w[3 + k] = buf[o[4] + a + k];
         if (lane == 0) w[3 + body] = '\n';
+    }
+}
+
+// AdapterCutter's marking actions (reference modifiers.py:170-198: masked_read / lowercased_read), IN PLACE in the device's
+// copy of the chunk: of the characters [beg, end) of read r (the read as the adapter step saw it) those OUTSIDE [mark_beg,
+// mark_end) -- what trimming would have removed -- become 'N' (mode 1: mask) or lower case, with the characters inside in
+// upper case (mode 2: lowercase).  The modifiers behind the adapter step and the formatter then see the marked read, as
+// the reference's do.  One wave per record.
+__global__ __launch_bounds__(256) void k_mark_reads(uint8_t* buf, const int64_t* rec6, int64_t n_records, const int32_t* beg,
+                                                    const int32_t* end, const int32_t* mark_beg, const int32_t* mark_end,
+                                                    const int mode) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    for (int64_t r = wave; r < n_records; r += n_waves) {
+        // (a read without a match keeps its whole window: nothing to mask; --action=lowercase puts it in upper case like
+        // every other read -- the reference upper-cases the read before it looks for adapters, modifiers.py:222-223)
+        const int64_t* o = rec6 + r * 6;
+        const int64_t seq_len = o[3] - o[2];
+        int64_t a = beg[r], b = end[r];
+        if (a < 0) a = 0;
+        if (b > seq_len) b = seq_len;
+        const int64_t mb = mark_beg[r], me = mark_end[r];
+        for (int64_t k = a + lane; k < b; k += 64) {
+            uint8_t c = buf[o[2] + k];
+            const bool inside = k >= mb && k < me;
+            if (mode == 1) c = inside ? c : (uint8_t)'N';
+            else if (inside) c = (c >= 'a' && c <= 'z') ? (uint8_t)(c - 32) : c;           // str.upper() / str.lower() on ASCII
+            else c = (c >= 'A' && c <= 'Z') ? (uint8_t)(c + 32) : c;
+            buf[o[2] + k] = c;
+        }
     }
 }
 
@@ -525,32 +540,9 @@ int cah_trim_filter_device(const int32_t* d_beg, const int32_t* d_end, const uin
 // Step 4: the trimmed records of a chunk, formatted on the device: record r (if d_keep is NULL or d_keep[r] != 0)
 // as "@name\nSEQ[beg:end]\n+\nQUAL[beg:end]\n" at the exclusive-scan offset of its length (record order is kept).
 // d_info[3] = total bytes written.  out_cap >= chunk length + 4 * n_records always suffices.
-static int format_device(const uint8_t* d_buf, const int64_t* d_rec6, int64_t n_records, const int32_t* d_beg,
-                         const int32_t* d_end, const uint8_t* d_keep, void* d_scratch, size_t scratch_bytes,
-                         int64_t chunk_bytes, uint8_t* d_out, int64_t out_cap, int64_t* d_info, void* stream,
-                         const int32_t* d_mark_beg, const int32_t* d_mark_end, int mark_mode);
 int cah_fastq_format_device(const uint8_t* d_buf, const int64_t* d_rec6, int64_t n_records, const int32_t* d_beg,
                             const int32_t* d_end, const uint8_t* d_keep, void* d_scratch, size_t scratch_bytes,
                             int64_t chunk_bytes, uint8_t* d_out, int64_t out_cap, int64_t* d_info, void* stream) {
-    return format_device(d_buf, d_rec6, n_records, d_beg, d_end, d_keep, d_scratch, scratch_bytes, chunk_bytes, d_out, out_cap,
-                         d_info, stream, nullptr, nullptr, 0);
-}
-// ... with AdapterCutter's marking actions (reference modifiers.py:170-198): mark_mode 1 = mask ('N' outside [mark_beg,
-// mark_end)), 2 = lowercase (lower case outside, upper case inside); [beg, end) is then the whole read as the adapter step
-// saw it, [mark_beg, mark_end) what trimming would have kept (both relative to the read)
-int cah_fastq_format_mark_device(const uint8_t* d_buf, const int64_t* d_rec6, int64_t n_records, const int32_t* d_beg,
-                                 const int32_t* d_end, const uint8_t* d_keep, const int32_t* d_mark_beg,
-                                 const int32_t* d_mark_end, int mark_mode, void* d_scratch, size_t scratch_bytes,
-                                 int64_t chunk_bytes, uint8_t* d_out, int64_t out_cap, int64_t* d_info, void* stream) {
-    if (mark_mode < 0 || mark_mode > 2 || (mark_mode != 0 && n_records > 0 && (!d_mark_beg || !d_mark_end)))
-        return cah_set_error_(CAH_EINVAL, "cah_fastq_format_mark_device: bad mark arguments");
-    return format_device(d_buf, d_rec6, n_records, d_beg, d_end, d_keep, d_scratch, scratch_bytes, chunk_bytes, d_out, out_cap,
-                         d_info, stream, d_mark_beg, d_mark_end, mark_mode);
-}
-static int format_device(const uint8_t* d_buf, const int64_t* d_rec6, int64_t n_records, const int32_t* d_beg,
-                         const int32_t* d_end, const uint8_t* d_keep, void* d_scratch, size_t scratch_bytes,
-                         int64_t chunk_bytes, uint8_t* d_out, int64_t out_cap, int64_t* d_info, void* stream,
-                         const int32_t* d_mark_beg, const int32_t* d_mark_end, int mark_mode) {
     if (n_records < 0 || !d_scratch || !d_info) return cah_set_error_(CAH_EINVAL, "cah_fastq_format_device: bad argument");
     if (scratch_bytes < cah_fastq_device_scratch_bytes(chunk_bytes, n_records)) return cah_set_error_(CAH_EINVAL, "cah_fastq_format_device: scratch too small");
     hipStream_t s = (hipStream_t)stream;
@@ -570,7 +562,20 @@ static int format_device(const uint8_t* d_buf, const int64_t* d_rec6, int64_t n_
     hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)sb), dim3(256), 0, s, out_len, n_records, block_sums, out_off);
     const int64_t fb = (n_records + 3) / 4;
     hipLaunchKernelGGL(k_format, dim3((unsigned)(fb < 16 * cus() ? fb : 16 * cus())), dim3(256), 0, s, d_buf, d_rec6, n_records, d_beg,
-                       d_end, d_keep, out_off, d_out, out_cap, d_mark_beg, d_mark_end, mark_mode);
+                       d_end, d_keep, out_off, d_out, out_cap);
+    GPU_TRY(hipGetLastError());
+    return CAH_OK;
+}
+
+// AdapterCutter's marking actions on a chunk in HBM, in place (k_mark_reads): mode 1 = --action=mask, 2 = --action=lowercase
+int cah_mark_reads_device(uint8_t* d_buf, const int64_t* d_rec6, int64_t n_records, const int32_t* d_beg, const int32_t* d_end,
+                          const int32_t* d_mark_beg, const int32_t* d_mark_end, int mode, void* stream) {
+    if (n_records < 0 || mode < 1 || mode > 2) return cah_set_error_(CAH_EINVAL, "cah_mark_reads_device: bad argument");
+    if (n_records == 0) return CAH_OK;
+    if (!d_buf || !d_rec6 || !d_beg || !d_end || !d_mark_beg || !d_mark_end) return cah_set_error_(CAH_EINVAL, "cah_mark_reads_device: NULL argument");
+    const int64_t fb = (n_records + 3) / 4;
+    hipLaunchKernelGGL(k_mark_reads, dim3((unsigned)(fb < 16 * cus() ? fb : 16 * cus())), dim3(256), 0, (hipStream_t)stream, d_buf, d_rec6,
+                       n_records, d_beg, d_end, d_mark_beg, d_mark_end, mode);
     GPU_TRY(hipGetLastError());
     return CAH_OK;
 }

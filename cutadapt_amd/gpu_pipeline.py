@@ -421,8 +421,8 @@ class _Worker:
         rounds = int(self.opts.get("times", 1)) if (self.plan is not None and not linked) else 1
         action = int(self.opts.get("action", 0))
         # the marking actions (4 mask, 5 lowercase; reference modifiers.py:170-198): the rounds run as for trim -- what
-        # they would keep is remainder(matches) --, then the record stays whole and the formatter marks around that interval
-        marking = action in (4, 5) and self.plan is not None and not linked
+        # they would keep is remainder(matches) --, then the record stays whole and is marked in place around that interval
+        marking = action in (4, 5) and self.plan is not None
         if marking:
             action = 0
         final_here = limits is not None and not post and rounds == 1 and not linked and not marking
@@ -482,9 +482,9 @@ class _Worker:
             else:
                 self.beg[:n].copy_(wbeg)
                 self.end[:n].copy_(wbeg + wlen)
-            self.mark_mode = 1 if int(self.opts.get("action", 0)) == 4 else 2
-        else:
-            self.mark_mode = 0
+            _lib.check(L.cah_mark_reads_device(self.d_in.data_ptr(), self.rec6.data_ptr(), n, self.beg.data_ptr(),
+                                               self.end.data_ptr(), self.mark_beg.data_ptr(), self.mark_end.data_ptr(),
+                                               1 if int(self.opts.get("action", 0)) == 4 else 2, sp))
         ee = None
         if post:
             # the modifiers behind the adapter step (--poly-a, -l: cli.py:956-973) move the kept interval, then the
@@ -540,17 +540,10 @@ class _Worker:
         if o.get("assemble") == "host":
             return self._assemble_on_host(data, n_bytes, n)
         # ---- step 4: format on the device, bring the bytes back ---------------------------------------------
-        if getattr(self, "mark_mode", 0) and n:
-            _lib.check(L.cah_fastq_format_mark_device(self.d_in.data_ptr(), self.rec6.data_ptr(), n, self.beg.data_ptr(),
-                                                      self.end.data_ptr(), self.keep.data_ptr(), self.mark_beg.data_ptr(),
-                                                      self.mark_end.data_ptr(), int(self.mark_mode), self.d_scratch.data_ptr(),
-                                                      self.d_scratch.numel(), n_bytes, self.d_out.data_ptr(),
-                                                      self.d_out.numel(), self.d_info.data_ptr(), sp))
-        else:
-            _lib.check(L.cah_fastq_format_device(self.d_in.data_ptr(), self.rec6.data_ptr(), n, self.beg.data_ptr(),
-                                                 self.end.data_ptr(), self.keep.data_ptr(), self.d_scratch.data_ptr(),
-                                                 self.d_scratch.numel(), n_bytes, self.d_out.data_ptr(),
-                                                 self.d_out.numel(), self.d_info.data_ptr(), sp))
+        _lib.check(L.cah_fastq_format_device(self.d_in.data_ptr(), self.rec6.data_ptr(), n, self.beg.data_ptr(),
+                                             self.end.data_ptr(), self.keep.data_ptr(), self.d_scratch.data_ptr(),
+                                             self.d_scratch.numel(), n_bytes, self.d_out.data_ptr(),
+                                             self.d_out.numel(), self.d_info.data_ptr(), sp))
         self.d_info[4:5].copy_(self.counters[6:7], non_blocking=True)
         self.d_info[5:6].copy_(self.ee_invalid.to(torch.int64).reshape(1), non_blocking=True)
         self.h_info.copy_(self.d_info, non_blocking=True)
@@ -1022,9 +1015,9 @@ def trim_fastq_gpu(source: Union[str, BinaryIO, np.ndarray], out: Union[str, Bin
     no_linked = not any(isinstance(a, LinkedAdapter) for a in adapters)
     single_round_action = act in (1, 2, 3) and int(times) == 1 and bool(adapters) and no_linked
     # (round 6: the marking actions -- mask / lowercase, reference modifiers.py:170-198 -- too: the rounds run as for trim,
-    # what they would keep is the interval the device formatter marks around (cah_fastq_format_mark_device); not with
-    # --poly-a behind them: that trimmer would have to look at the MARKED characters)
-    marking = act in (4, 5) and bool(adapters) and no_linked and not poly_a
+    # then the reads are marked IN PLACE in the device's copy of the chunk around what the rounds would keep
+    # (cah_mark_reads_device): the modifiers behind the adapter step and the formatter see the marked read)
+    marking = act in (4, 5) and bool(adapters)
     all_device = (not revcomp and info_file is None and
                   ((not adapters and action in ("trim", None, "none", "retain", "crop", "mask", "lowercase")) or
                    (bool(adapters) and (act == 0 or single_round_action or marking) and _all_device_adapters(adapters, int(times), index))))

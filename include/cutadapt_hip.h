@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define CAH_ABI_VERSION 5   /* 2: CAH_PROF_N = 5, plan workspaces (cah_plan_workspace_bytes), no adapter length limit; 3: cah_plan_multi_kind; 4: cah_build_id, cah_last_multi_path, CAH_EINTERNAL; 5: cah_match_batch_frames, cah_set_deferred_errors, CAH_STATUS_INTERNAL, cah_fastq_format_mark_device */
+#define CAH_ABI_VERSION 5   /* 2: CAH_PROF_N = 5, plan workspaces (cah_plan_workspace_bytes), no adapter length limit; 3: cah_plan_multi_kind; 4: cah_build_id, cah_last_multi_path, CAH_EINTERNAL; 5: cah_match_batch_frames, cah_set_deferred_errors, CAH_STATUS_INTERNAL, cah_mark_reads_device */
 
 /* status codes */
 #define CAH_OK 0
@@ -454,14 +454,15 @@ int cah_trim_filter_device(const int32_t *d_beg, const int32_t *d_end, const uin
 int cah_fastq_format_device(const uint8_t *d_buf, const int64_t *d_rec6, int64_t n_records, const int32_t *d_beg,
                             const int32_t *d_end, const uint8_t *d_keep, void *d_scratch, size_t scratch_bytes,
                             int64_t chunk_bytes, uint8_t *d_out, int64_t out_cap, int64_t *d_info, void *stream);
-/* ... with AdapterCutter's marking actions (reference modifiers.py:170-198: masked_read / lowercased_read): the record is
- * written whole -- [d_beg, d_end) is the read as the adapter step saw it -- and the characters OUTSIDE [d_mark_beg,
- * d_mark_end) (what trimming would have removed; relative to the read) become 'N' (mark_mode 1: --action=mask) or lower
- * case, with the characters inside in upper case (2: --action=lowercase).  mark_mode 0: cah_fastq_format_device. */
-int cah_fastq_format_mark_device(const uint8_t *d_buf, const int64_t *d_rec6, int64_t n_records, const int32_t *d_beg,
-                                 const int32_t *d_end, const uint8_t *d_keep, const int32_t *d_mark_beg,
-                                 const int32_t *d_mark_end, int mark_mode, void *d_scratch, size_t scratch_bytes,
-                                 int64_t chunk_bytes, uint8_t *d_out, int64_t out_cap, int64_t *d_info, void *stream);
+/* AdapterCutter's marking actions (reference modifiers.py:170-198: masked_read / lowercased_read) on a chunk in HBM, IN
+ * PLACE: of the characters [d_beg[r], d_end[r]) of read r (the read as the adapter step saw it) those OUTSIDE [d_mark_beg[r],
+ * d_mark_end[r]) -- what trimming would have removed; all relative to the read -- become 'N' (mode 1: --action=mask) or lower
+ * case, with the characters inside in upper case (mode 2: --action=lowercase; a read without a match has its whole window
+ * "inside": the reference upper-cases every read before it looks for adapters, modifiers.py:222-223).  The modifiers behind
+ * the adapter step (--poly-a, -l) and cah_fastq_format_device then see the marked read, as the reference's do. */
+int cah_mark_reads_device(uint8_t *d_buf, const int64_t *d_rec6, int64_t n_records, const int32_t *d_beg,
+                          const int32_t *d_end, const int32_t *d_mark_beg, const int32_t *d_mark_end, int mode,
+                          void *stream);
 
 /* ---- AdapterIndex (adapters.py:1289-1551) on the GPU ---------- */
 /* Many anchored adapters of one kind (all 5' "^ADAPTER" or all 3' "ADAPTER$", no wildcards, at most

@@ -86,13 +86,15 @@ if devices is not None:
     linked = LinkedAdapter(FrontAdapter("ACGTACGTTT"), BackAdapter(workloads.TRUSEQ_R1, max_errors=0.1, min_overlap=3), False, True, "linked")
     timed(f"all-device way with one linked adapter (optional 5' part ... required 3' TruSeq) and -q 0,10 -m 20, devices={args.devices}",
           lambda: trim_fastq_gpu(fastq, None, [linked], threads=args.threads, devices=devices, quality_cutoff=(0, 10), minimum_length=20))
-    timed(f"--times 2 --action mask (round 6: all-device way, records marked by the device formatter; rounds 3-5: the general way), devices={args.devices}",
+    timed(f"--times 2 --action mask (round 6: all-device way, the reads marked in place on the device; rounds 3-5: the general way), devices={args.devices}",
           lambda: trim_fastq_gpu(fastq, None, [adapter], threads=args.threads, devices=devices, times=2, action="mask"))
     timed(f"-q 0,10 --action mask (round 6: all-device way), devices={args.devices}",
           lambda: trim_fastq_gpu(fastq, None, [adapter], threads=args.threads, devices=devices, quality_cutoff=(0, 10),
                                  action="mask"), reps=1)
-    timed(f"the general way (--action mask --poly-a: the marking actions with a poly-A trimmer behind them stay there), devices={args.devices}",
+    timed(f"--action mask --poly-a (all-device way: the reads are marked in place, the poly-A trimmer sees the marked read), devices={args.devices}",
           lambda: trim_fastq_gpu(fastq, None, [adapter], threads=args.threads, devices=devices, action="mask", poly_a=True), reps=1)
+    timed(f"the general way (--revcomp: both strands matched, the records of the better one written by the host), devices={args.devices}",
+          lambda: trim_fastq_gpu(fastq[: 317 * 4_000_000], None, [adapter], threads=args.threads, devices=devices, revcomp=True), reps=1)
     if args.file:
         with open(args.file, "wb") as f:
             f.write(memoryview(fastq.numpy()))

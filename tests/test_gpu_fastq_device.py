@@ -95,6 +95,11 @@ def test_device_fastq_equals_host_pipeline(hip):
         ([A.FrontAdapter(ad_seqs[1]), A.BackAdapter(ad_seqs[0])], {"action": "lowercase", "quality_cutoff": (10, 15), "cut": [2, -3], "times": 2,
                                                               "length": 100, "max_expected_errors": 4.0, "maximum_length": 130}),
         ([A.NonInternalBackAdapter(ad_seqs[1]), A.PrefixAdapter(ad_seqs[2])], {"action": "mask", "nextseq_trim": 20, "discard_trimmed": True}),
+        # ... with --poly-a behind them (the trimmer sees the MARKED read) and on one linked adapter
+        ([A.BackAdapter(ad_seqs[0])], {"action": "mask", "poly_a": True, "minimum_length": 20}),
+        ([A.BackAdapter(ad_seqs[0]), A.FrontAdapter(ad_seqs[1])], {"action": "lowercase", "poly_a": True, "times": 2, "quality_cutoff": (0, 12)}),
+        ([A.LinkedAdapter(A.FrontAdapter(ad_seqs[2]), A.BackAdapter(ad_seqs[0]), False, True, "l5")], {"action": "lowercase", "minimum_length": 10}),
+        ([A.LinkedAdapter(A.PrefixAdapter(ad_seqs[2]), A.BackAdapter(ad_seqs[0]), True, False, "l6")], {"action": "mask", "poly_a": True}),
         # no adapter at all: the modifiers and filters alone, still on the device
         ([], {"quality_cutoff": (10, 20), "minimum_length": 30}),
         ([], {"nextseq_trim": 20, "poly_a": True, "length": 100, "max_expected_errors": 2.0}),
@@ -102,7 +107,7 @@ def test_device_fastq_equals_host_pipeline(hip):
     ]
     for ci, (ads, opts) in enumerate(cases):
         for crlf, final_nl, chunk in ((False, True, 1 << 20), (True, True, 4096), (False, False, 700)):
-            data = _fastq(rng, 3000, ad_seqs, crlf=crlf, final_newline=final_nl, lower=ci == 1, twice="times" in opts,
+            data = _fastq(rng, 3000, ad_seqs, crlf=crlf, final_newline=final_nl, lower=ci == 1 or opts.get("action") == "lowercase", twice="times" in opts,
                           lead=ad_seqs[2] if (ads and isinstance(ads[0], A.LinkedAdapter)) else None)
             want = io.BytesIO()
             ws = trim_fastq(io.BytesIO(data), want, ads, index=False, **opts)
@@ -185,7 +190,8 @@ def test_feeder_processes_write_the_same_bytes_as_feeder_threads(hip, tmp_path):
         (dict(adapters=[BackAdapter(a, max_errors=0.1, min_overlap=3) for a in ads], times=2, quality_cutoff=(0, 20),
               discard_untrimmed=True), "all-device"),
         (dict(adapters=[FrontAdapter(ads[1][:12], max_errors=0.1)], action="mask"), "all-device"),
-        (dict(adapters=[FrontAdapter(ads[1][:12], max_errors=0.1)], action="mask", poly_a=True), "general"),
+        (dict(adapters=[FrontAdapter(ads[1][:12], max_errors=0.1)], action="mask", poly_a=True), "all-device"),
+        (dict(adapters=[FrontAdapter(ads[1][:12], max_errors=0.1)], action="mask", revcomp=True), "general"),
     ]
     for k, (opts, way) in enumerate(cases):
         for n_proc in (2, 3):

@@ -57,7 +57,7 @@ def test_single_end_goldens_through_the_device_path(hip):
     # what still takes the general way: a marking action on a LINKED adapter, info files, --revcomp, several linked adapters
     # (round 6: mask / lowercase with single adapters are formatted on the device, cah_fastq_format_mark_device)
     general = {k for k, v in by_name.items() if v == "general"}
-    assert general <= {"linked_lowercase", "info_file", "info_file_times",
+    assert general <= {"info_file", "info_file_times",
                        "revcomp_normalized", "info_file_revcomp", "linked_info_file", "linked_multiple"}, general
     assert by_name.get("action_mask") == "all-device", by_name          # (action_lowercase is a FASTA golden: host-parsed)
     # (14 of the 33 goldens are FASTA files: parsed on the host -- a sequence may span lines -- and matched in batches)
@@ -278,7 +278,7 @@ def test_every_visible_gpu_is_fed(hip, tmp_path):
     visible = sorted(f"cuda:{i}" for i in range(n_dev))
     chunk = len(data) // (4 * n_dev)                            # at least four chunks per device
     for way, opts in (("all-device", {}), ("all-device", {"quality_cutoff": (0, 10), "times": 2, "action": "mask"}),
-                      ("general", {"quality_cutoff": (0, 10), "times": 2, "action": "mask", "poly_a": True})):
+                      ("general", {"quality_cutoff": (0, 10), "times": 2, "action": "mask", "revcomp": True})):
         one = io.BytesIO()
         s1 = trim_fastq_gpu(str(path), one, [A.BackAdapter(ad)], chunk_bytes=chunk, threads=2, devices=[0], **opts)
         assert s1["way"] == way
