@@ -502,3 +502,43 @@ def test_packed_ragged_batches_stream_in_frames(hip, orc):
         got2 = match_batch(plan, vb)
         torch.cuda.synchronize()
         assert torch.equal(got2.status, want.status) and torch.equal(got2.out6, want.out6), adapter
+
+
+def test_every_adapter_class_through_the_frames_entry(hip):
+    """match_batch hands every ragged batch of 65 536 reads or more to cah_match_batch_frames: plans the streaming prefilters
+    do not take (5' and anywhere adapters, anchored ones, wildcards, no indels, linked stages) must fall back inside the
+    library -- the same rows as the plain entry point (CAH_NO_FRAMES=1), class by class"""
+    import torch
+    from cutadapt_amd import adapters as A
+    from cutadapt_amd import batch as B
+    from cutadapt_amd.batch import ReadBatch, match_batch
+    rng = random.Random(515)
+    ad = "AGATCGGAAGAGCACACGTCTGAACTCCAGTCA"
+    short = "ACGTTGCATGCA"
+    reads = []
+    for i in range(70_000):
+        ln = rng.randint(0, 150)
+        r = "".join(rng.choice("ACGT") for _ in range(ln))
+        if i % 3 == 0 and ln > 40:
+            at = rng.randint(0, ln - 20)
+            r = (r[:at] + ad + r[at:])[:ln]
+        if i % 5 == 0 and ln > 20:
+            r = short + r[len(short):]
+        if i % 7 == 0 and ln > 20:
+            r = r[:-len(short)] + short
+        reads.append(r)
+    adapters = [A.BackAdapter(ad, max_errors=0.1, min_overlap=3), A.FrontAdapter(short, max_errors=0.1), A.AnywhereAdapter(short),
+                A.PrefixAdapter(short), A.SuffixAdapter(short), A.NonInternalFrontAdapter(short), A.NonInternalBackAdapter(ad),
+                A.RightmostFrontAdapter(short), A.RightmostBackAdapter(ad), A.BackAdapter("AGATCNGAAGNNCACACGTC", max_errors=0.1),
+                A.BackAdapter(ad, max_errors=0.1, indels=False), A.BackAdapter(ad, max_errors=0.2, read_wildcards=True)]
+    for a in adapters:
+        batch = ReadBatch.from_strings(reads)
+        assert batch.max_len == 150 and B._frame_len(a._fused_plan, batch) == 150
+        got = a.match_to_batch(batch)
+        os.environ["CAH_NO_FRAMES"] = "1"
+        try:
+            want = a.match_to_batch(ReadBatch.from_strings(reads))
+        finally:
+            os.environ.pop("CAH_NO_FRAMES", None)
+        assert np.array_equal(got.found, want.found) and np.array_equal(got.coords[got.found], want.coords[want.found]), type(a).__name__
+        assert got.found.sum() > 100, type(a).__name__
