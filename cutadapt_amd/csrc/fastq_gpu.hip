@@ -23,6 +23,7 @@
 #include <cstdio>
 
 #include "../../include/cutadapt_hip.h"
+#include "revcomp.h"
 
 extern int cah_set_error_(int code, const char* msg);   // api.cpp
 
@@ -174,8 +175,10 @@ __global__ __launch_bounds__(256) void k_records(const uint8_t* buf, int64_t len
     }
 }
 
+// (flags / suffix_len: --revcomp, the records with flags[r] != 0 carry a suffix behind their name; flags NULL: none does)
 __global__ __launch_bounds__(256) void k_out_len(const int64_t* rec6, int64_t n_records, const int32_t* beg, const int32_t* end,
-                                                 const uint8_t* keep, int64_t* out_len) {
+                                                 const uint8_t* keep, int64_t* out_len, const uint8_t* flags = nullptr,
+                                                 const int suffix_len = 0) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_records; r += stride) {
         int64_t v = 0;
@@ -187,6 +190,7 @@ __global__ __launch_bounds__(256) void k_out_len(const int64_t* rec6, int64_t n_
             if (b > seq_len) b = seq_len;
             if (b < a) b = a;
             v = 1 + (o[1] - o[0]) + 1 + (b - a) + 1 + 2 + (b - a) + 1;
+            if (flags && flags[r]) v += suffix_len;
         }
         out_len[r] = v;
     }
@@ -232,10 +236,14 @@ __global__ __launch_bounds__(256) void k_scan_apply(const int64_t* in, int64_t n
     }
 }
 
-// one wave per record (round-robin inside a block): "@name\nSEQ[a:b]\n+\nQUAL[a:b]\n"
+struct NameSuffix { uint8_t c[CAH_MAX_NAME_SUFFIX]; int len; };
+
+// one wave per record (round-robin inside a block): "@name\nSEQ[a:b]\n+\nQUAL[a:b]\n"; SUFFIX: "@name<suffix>\n..." for
+// the records with flags[r] != 0 (ReverseComplementer's rc_suffix, reference modifiers.py:296-297)
+template <bool SUFFIX>
 __global__ __launch_bounds__(256) void k_format(const uint8_t* buf, const int64_t* rec6, int64_t n_records, const int32_t* beg,
                                                 const int32_t* end, const uint8_t* keep, const int64_t* out_off,
-                                                uint8_t* out, int64_t out_cap) {
+                                                uint8_t* out, int64_t out_cap, const uint8_t* flags, const NameSuffix sfx) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t n_waves = (int64_t)gridDim.x * 4;
@@ -249,17 +257,53 @@ __global__ __launch_bounds__(256) void k_format(const uint8_t* buf, const int64_
         if (b < a) b = a;
         const int64_t body = b - a;
         int64_t pos = out_off[r];
-        if (pos + 1 + name_len + 1 + body + 3 + body + 1 > out_cap) continue;       // never: the caller sizes out for the input
+        const int extra = SUFFIX && flags[r] ? sfx.len : 0;
+        if (pos + 1 + name_len + extra + 1 + body + 3 + body + 1 > out_cap) continue;       // never: the caller sizes out for the input
         uint8_t* w = out + pos;
         if (lane == 0) w[0] = '@';
         for (int64_t k = lane; k < name_len; k += 64) w[1 + k] = buf[o[0] + k];
         w += 1 + name_len;
+        if (SUFFIX) {
+            if (lane < extra) w[lane] = sfx.c[lane];
+            w += extra;
+        }
         if (lane == 0) w[0] = '\n';
         for (int64_t k = lane; k < body; k += 64) w[1 + k] = buf[o[2] + a + k];
         w += 1 + body;
         if (lane == 0) { w[0] = '\n'; w[1] = '+'; w[2] = '\n'; }
         for (int64_t k = lane; k < body; k += 64) w[3 + k] = buf[o[4] + a + k];
         if (lane == 0) w[3 + body] = '\n';
+    }
+}
+
+// ReverseComplementer's chosen orientation (reference modifiers.py:280-297), IN PLACE in the device's copy of the chunk: the
+// window [win_beg[r], win_beg[r] + win_len[r]) of every record with flags[r] != 0 -- the read as the adapter step saw it
+// -- becomes its reverse complement (revcomp.h) and the same window of the qualities is reversed.  One wave per record; a
+// lane owns the characters k and n - 1 - k, loads both, stores both.
+__global__ __launch_bounds__(256) void k_revcomp_in_place(uint8_t* buf, const int64_t* rec6, int64_t n_records,
+                                                          const int32_t* win_beg, const int32_t* win_len, const uint8_t* flags) {
+    __shared__ uint8_t comp[256];
+    comp[threadIdx.x] = cah_complement((uint8_t)threadIdx.x);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    for (int64_t r = wave; r < n_records; r += n_waves) {
+        if (!flags[r]) continue;
+        const int64_t* o = rec6 + r * 6;
+        const int64_t seq_len = o[3] - o[2];
+        int64_t a = win_beg ? win_beg[r] : 0, n = win_len[r];
+        if (a < 0) a = 0;
+        if (a > seq_len) a = seq_len;
+        if (n > seq_len - a) n = seq_len - a;
+        uint8_t* s = buf + o[2] + a;
+        uint8_t* q = buf + o[4] + a;
+        for (int64_t k = lane; 2 * k < n; k += 64) {
+            const int64_t m = n - 1 - k;
+            const uint8_t s0 = s[k], s1 = s[m], q0 = q[k], q1 = q[m];
+            s[k] = comp[s1]; s[m] = comp[s0];                // (k == m, the middle of an odd window: complemented once)
+            q[k] = q1; q[m] = q0;
+        }
     }
 }
 
@@ -540,15 +584,20 @@ int cah_trim_filter_device(const int32_t* d_beg, const int32_t* d_end, const uin
 // Step 4: the trimmed records of a chunk, formatted on the device: record r (if d_keep is NULL or d_keep[r] != 0)
 // as "@name\nSEQ[beg:end]\n+\nQUAL[beg:end]\n" at the exclusive-scan offset of its length (record order is kept).
 // d_info[3] = total bytes written.  out_cap >= chunk length + 4 * n_records always suffices.
-int cah_fastq_format_device(const uint8_t* d_buf, const int64_t* d_rec6, int64_t n_records, const int32_t* d_beg,
-                            const int32_t* d_end, const uint8_t* d_keep, void* d_scratch, size_t scratch_bytes,
-                            int64_t chunk_bytes, uint8_t* d_out, int64_t out_cap, int64_t* d_info, void* stream) {
-    if (n_records < 0 || !d_scratch || !d_info) return cah_set_error_(CAH_EINVAL, "cah_fastq_format_device: bad argument");
-    if (scratch_bytes < cah_fastq_device_scratch_bytes(chunk_bytes, n_records)) return cah_set_error_(CAH_EINVAL, "cah_fastq_format_device: scratch too small");
+static int format_impl(const char* who, const uint8_t* d_buf, const int64_t* d_rec6, int64_t n_records, const int32_t* d_beg,
+                       const int32_t* d_end, const uint8_t* d_keep, const uint8_t* d_flags, const char* suffix, int suffix_len,
+                       void* d_scratch, size_t scratch_bytes, int64_t chunk_bytes, uint8_t* d_out, int64_t out_cap,
+                       int64_t* d_info, void* stream) {
+    char msg[96];
+    auto fail = [&](const char* what) { snprintf(msg, sizeof msg, "%s: %s", who, what); return cah_set_error_(CAH_EINVAL, msg); };
+    if (n_records < 0 || !d_scratch || !d_info) return fail("bad argument");
+    if (suffix_len < 0 || suffix_len > CAH_MAX_NAME_SUFFIX || (suffix_len > 0 && !suffix)) return fail("suffix longer than CAH_MAX_NAME_SUFFIX");
+    if (scratch_bytes < cah_fastq_device_scratch_bytes(chunk_bytes, n_records)) return fail("scratch too small");
     hipStream_t s = (hipStream_t)stream;
     GPU_TRY(hipMemsetAsync(d_info + 3, 0, sizeof(int64_t), s));
     if (n_records == 0) return CAH_OK;
-    if (!d_buf || !d_rec6 || !d_beg || !d_end || !d_out) return cah_set_error_(CAH_EINVAL, "cah_fastq_format_device: NULL argument");
+    if (!d_buf || !d_rec6 || !d_beg || !d_end || !d_out) return fail("NULL argument");
+    const bool with_suffix = d_flags && suffix_len > 0;
     int64_t* p = (int64_t*)d_scratch + n_tiles_of(chunk_bytes) + 8 + 4 * n_records + 8;
     int64_t* out_len = p;                        p += n_records + 8;
     int64_t* out_off = p;                        p += n_records + 8;
@@ -556,13 +605,53 @@ int cah_fastq_format_device(const uint8_t* d_buf, const int64_t* d_rec6, int64_t
     const int64_t rb = (n_records + 255) / 256;
     const int64_t sb = n_scan_blocks(n_records);
     hipLaunchKernelGGL(k_out_len, dim3((unsigned)(rb < 8 * cus() ? rb : 8 * cus())), dim3(256), 0, s, d_rec6, n_records, d_beg, d_end,
-                       d_keep, out_len);
+                       d_keep, out_len, with_suffix ? d_flags : (const uint8_t*)nullptr, suffix_len);
     hipLaunchKernelGGL(k_scan_sums, dim3((unsigned)sb), dim3(256), 0, s, out_len, n_records, block_sums);
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, block_sums, sb, d_info + 3);
     hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)sb), dim3(256), 0, s, out_len, n_records, block_sums, out_off);
     const int64_t fb = (n_records + 3) / 4;
-    hipLaunchKernelGGL(k_format, dim3((unsigned)(fb < 16 * cus() ? fb : 16 * cus())), dim3(256), 0, s, d_buf, d_rec6, n_records, d_beg,
-                       d_end, d_keep, out_off, d_out, out_cap);
+    NameSuffix sfx;
+    sfx.len = with_suffix ? suffix_len : 0;
+    for (int i = 0; i < CAH_MAX_NAME_SUFFIX; ++i) sfx.c[i] = i < sfx.len ? (uint8_t)suffix[i] : 0;
+    const dim3 grid((unsigned)(fb < 16 * cus() ? fb : 16 * cus()));
+    if (with_suffix)
+        hipLaunchKernelGGL(k_format<true>, grid, dim3(256), 0, s, d_buf, d_rec6, n_records, d_beg, d_end, d_keep, out_off, d_out,
+                           out_cap, d_flags, sfx);
+    else
+        hipLaunchKernelGGL(k_format<false>, grid, dim3(256), 0, s, d_buf, d_rec6, n_records, d_beg, d_end, d_keep, out_off, d_out,
+                           out_cap, (const uint8_t*)nullptr, sfx);
+    GPU_TRY(hipGetLastError());
+    return CAH_OK;
+}
+
+int cah_fastq_format_device(const uint8_t* d_buf, const int64_t* d_rec6, int64_t n_records, const int32_t* d_beg,
+                            const int32_t* d_end, const uint8_t* d_keep, void* d_scratch, size_t scratch_bytes,
+                            int64_t chunk_bytes, uint8_t* d_out, int64_t out_cap, int64_t* d_info, void* stream) {
+    return format_impl("cah_fastq_format_device", d_buf, d_rec6, n_records, d_beg, d_end, d_keep, nullptr, nullptr, 0, d_scratch,
+                       scratch_bytes, chunk_bytes, d_out, out_cap, d_info, stream);
+}
+
+// ... with `suffix` (suffix_len <= CAH_MAX_NAME_SUFFIX bytes) behind the name of every record with d_flags[r] != 0: what
+// ReverseComplementer does to the reads it turned around (reference modifiers.py:296-297).  out_cap >= chunk length +
+// (4 + suffix_len) * n_records always suffices.
+int cah_fastq_format_suffix_device(const uint8_t* d_buf, const int64_t* d_rec6, int64_t n_records, const int32_t* d_beg,
+                                   const int32_t* d_end, const uint8_t* d_keep, const uint8_t* d_flags, const char* suffix,
+                                   int32_t suffix_len, void* d_scratch, size_t scratch_bytes, int64_t chunk_bytes,
+                                   uint8_t* d_out, int64_t out_cap, int64_t* d_info, void* stream) {
+    return format_impl("cah_fastq_format_suffix_device", d_buf, d_rec6, n_records, d_beg, d_end, d_keep, d_flags, suffix, suffix_len,
+                       d_scratch, scratch_bytes, chunk_bytes, d_out, out_cap, d_info, stream);
+}
+
+// ReverseComplementer's chosen orientation, in place (k_revcomp_in_place): records with d_flags[r] != 0 are turned around
+// inside their window (d_win_beg NULL: the windows start at 0), sequence and qualities
+int cah_revcomp_in_place_device(uint8_t* d_buf, const int64_t* d_rec6, int64_t n_records, const int32_t* d_win_beg,
+                                const int32_t* d_win_len, const uint8_t* d_flags, void* stream) {
+    if (n_records < 0) return cah_set_error_(CAH_EINVAL, "cah_revcomp_in_place_device: bad argument");
+    if (n_records == 0) return CAH_OK;
+    if (!d_buf || !d_rec6 || !d_win_len || !d_flags) return cah_set_error_(CAH_EINVAL, "cah_revcomp_in_place_device: NULL argument");
+    const int64_t fb = (n_records + 3) / 4;
+    hipLaunchKernelGGL(k_revcomp_in_place, dim3((unsigned)(fb < 16 * cus() ? fb : 16 * cus())), dim3(256), 0, (hipStream_t)stream, d_buf,
+                       d_rec6, n_records, d_win_beg, d_win_len, d_flags);
     GPU_TRY(hipGetLastError());
     return CAH_OK;
 }

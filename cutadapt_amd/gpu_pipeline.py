@@ -13,16 +13,19 @@ writer layout (reference src/cutadapt/runners.py:96-245) with GPUs as the worker
 Two ways through a chunk once it is indexed:
   * the all-device way (any number of single, non-rightmost adapters with ``--times N``, or one linked adapter; action ``trim``
     -- or, with one round of single adapters, ``none`` / ``retain`` / ``crop``: other intervals from the same matches --;
+    the marking actions ``mask`` / ``lowercase`` (marked in place in HBM); ``--revcomp`` with action ``trim``, one round and
+    single adapters (both orientations matched, the better one turned around in place in HBM);
     no adapter at all: the other modifiers and the filters alone;
     ``-u`` / ``--nextseq-trim`` / ``-q`` in front of the adapter step, ``--poly-a`` / ``-l`` / ``--max-ee`` / ``-m`` /
     ``-M`` / ``--discard-(un)trimmed`` behind it -- the usual ``cutadapt -q 20 -a ADAPTER -m 20`` and more): trim,
     match, decide and format without a byte of per-read data touching the host (``cah_trim_decide_device`` /
     ``cah_trim_decide_window_device`` / ``cah_trim_decide_action_device`` / ``cah_trim_filter_device``);
-  * the general way (everything else ``pipeline.BatchTrimmer`` does: ``mask`` / ``lowercase``, rightmost adapters, linked ones among others,
-    ``--revcomp``, ``--info-file``, ``--pair-adapters``, adapter sets regrouped behind an ``AdapterIndex``): the
+  * the general way (everything else ``pipeline.BatchTrimmer`` does: rightmost adapters, linked ones among others,
+    ``--revcomp`` with several rounds or another action, ``--info-file``, ``--pair-adapters``, adapter sets regrouped behind an
+    ``AdapterIndex``): the
     modifiers run as kernels on windows into the raw chunk in HBM (``DeviceFastqChunk``: reads AND qualities are used in place), the window arithmetic between them is
     numpy on 4-byte-per-read arrays, and plain slicing is formatted on the device again.  What cannot be expressed
-    as a slice of the raw chunk (mask / lowercase, reverse-complemented records, info files) is formatted by the
+    as a slice of the raw chunk (there: mask / lowercase, reverse-complemented records, info files) is formatted by the
     host writers from the device's record index -- no host parsing in either way.
 FASTA input is parsed on the host (``pipeline.trim_fastq``; a FASTA sequence may span lines and cannot be matched
 in place), through the same trimmer.
@@ -165,6 +168,7 @@ class _Worker:
         # reads by length of the poly-A tail removed (+ 4096 spare bins that are bin 0 spread out, see _run)
         self.polya_hist = torch.zeros(_lib.MAX_READ_LEN + 1 + 4096, dtype=torch.int64, device=self.device)
         self.ee_invalid = torch.zeros((), dtype=torch.bool, device=self.device)  # a quality value outside the phred range seen
+        self.rc_count = torch.zeros((), dtype=torch.int64, device=self.device)   # --revcomp: reads turned around
         self._ws = None
         self.n = self.n_bytes = 0
         self.busy_s, self.chunks, self.bytes_in, self.reads_in = 0.0, 0, 0, 0   # per-device rates (trim_fastq_gpu's "per_device")
@@ -416,6 +420,40 @@ class _Worker:
             _lib.check(L.cah_match_batch(self.plan.handle, self.d_in.data_ptr(), voff.data_ptr(), wlen.data_ptr(), n,
                                          self.res.out6.data_ptr(), self.res.best_adapter.data_ptr(),
                                          self.res.status.data_ptr(), self._ws.data_ptr(), self._ws.numel(), sp))
+            if self.opts.get("revcomp"):
+                # --revcomp (ReverseComplementer, reference modifiers.py:264-308, in the adapter cutter's place): the
+                # reverse complement of every window into a second buffer at the same offsets, matched with the same plan;
+                # where ITS match scores higher (:287; no match: score 0) the record is turned around in place -- sequence
+                # and qualities -- and the match results are the second call's; the formatter adds the suffix to the name
+                from .batch import BatchResult
+                if getattr(self, "d_rc", None) is None or self.d_rc.numel() < self.d_in.numel():
+                    self.d_rc = torch.empty(self.d_in.numel(), dtype=torch.uint8, device=self.device)
+                if getattr(self, "res_rc", None) is None or self.res_rc.status.numel() < self.rcap:
+                    dev = self.device
+                    self.res_rc = BatchResult(torch.empty((self.rcap, 6), dtype=torch.int32, device=dev),
+                                              torch.empty(self.rcap, dtype=torch.uint8, device=dev),
+                                              torch.empty(self.rcap, dtype=torch.int32, device=dev))
+                    self.rc_flags = torch.empty(self.rcap, dtype=torch.uint8, device=dev)
+                wl = wlen.contiguous()
+                _lib.check(L.cah_revcomp_reads_batch(self.d_in.data_ptr(), voff.data_ptr(), wl.data_ptr(), n, voff.data_ptr(),
+                                                     self.d_rc.data_ptr(), 1, None, sp))
+                r2 = self.res_rc
+                _lib.check(L.cah_match_batch(self.plan.handle, self.d_rc.data_ptr(), voff.data_ptr(), wl.data_ptr(), n,
+                                             r2.out6.data_ptr(), r2.best_adapter.data_ptr(), r2.status.data_ptr(),
+                                             self._ws.data_ptr(), self._ws.numel(), sp))
+                fwd, rev = self.res.status[:n] == 1, r2.status[:n] == 1
+                zero = torch.zeros((), dtype=torch.int32, device=self.device)
+                use = torch.where(rev, r2.out6[:n, 4], zero) > torch.where(fwd, self.res.out6[:n, 4], zero)
+                self.counters[6] += (r2.status[:n] == 2).sum()
+                self.res.out6[:n].copy_(torch.where(use[:, None], r2.out6[:n], self.res.out6[:n]))
+                self.res.best_adapter[:n].copy_(torch.where(use, r2.best_adapter[:n], self.res.best_adapter[:n]))
+                self.res.status[:n].copy_(torch.where(use, r2.status[:n], self.res.status[:n]))
+                self.rc_flags[:n].copy_(use)
+                self.rc_count += use.sum()
+                _lib.check(L.cah_revcomp_in_place_device(self.d_in.data_ptr(), self.rec6.data_ptr(), n,
+                                                         wbeg.data_ptr() if wbeg is not None else None, wl.data_ptr(),
+                                                         self.rc_flags.data_ptr(), sp))
+                keepalive += [wl, use]
         else:
             self.res.status[:n].zero_()                      # a mate without adapters: nothing is found
         rounds = int(self.opts.get("times", 1)) if (self.plan is not None and not linked) else 1
@@ -540,10 +578,19 @@ class _Worker:
         if o.get("assemble") == "host":
             return self._assemble_on_host(data, n_bytes, n)
         # ---- step 4: format on the device, bring the bytes back ---------------------------------------------
-        _lib.check(L.cah_fastq_format_device(self.d_in.data_ptr(), self.rec6.data_ptr(), n, self.beg.data_ptr(),
-                                             self.end.data_ptr(), self.keep.data_ptr(), self.d_scratch.data_ptr(),
-                                             self.d_scratch.numel(), n_bytes, self.d_out.data_ptr(),
-                                             self.d_out.numel(), self.d_info.data_ptr(), sp))
+        suffix = (o.get("rc_suffix") or "").encode() if (o.get("revcomp") and self.plan is not None and n) else b""
+        if suffix:
+            if self.d_out.numel() < n_bytes + (4 + len(suffix)) * n:
+                self.d_out = torch.empty(n_bytes + (4 + len(suffix)) * n + 4096, dtype=torch.uint8, device=self.device)
+            _lib.check(L.cah_fastq_format_suffix_device(
+                self.d_in.data_ptr(), self.rec6.data_ptr(), n, self.beg.data_ptr(), self.end.data_ptr(), self.keep.data_ptr(),
+                self.rc_flags.data_ptr(), suffix, len(suffix), self.d_scratch.data_ptr(), self.d_scratch.numel(), n_bytes,
+                self.d_out.data_ptr(), self.d_out.numel(), self.d_info.data_ptr(), sp))
+        else:
+            _lib.check(L.cah_fastq_format_device(self.d_in.data_ptr(), self.rec6.data_ptr(), n, self.beg.data_ptr(),
+                                                 self.end.data_ptr(), self.keep.data_ptr(), self.d_scratch.data_ptr(),
+                                                 self.d_scratch.numel(), n_bytes, self.d_out.data_ptr(),
+                                                 self.d_out.numel(), self.d_info.data_ptr(), sp))
         self.d_info[4:5].copy_(self.counters[6:7], non_blocking=True)
         self.d_info[5:6].copy_(self.ee_invalid.to(torch.int64).reshape(1), non_blocking=True)
         self.h_info.copy_(self.d_info, non_blocking=True)
@@ -698,6 +745,7 @@ def _take_worker(plan, kinds, dev, opts) -> "_Worker":
         w.pre_counts.zero_()
         w.polya_hist.zero_()
         w.ee_invalid.zero_()
+        w.rc_count.zero_()
     w._ws = None
     w.busy_s, w.chunks, w.bytes_in, w.reads_in = 0.0, 0, 0, 0
     return w
@@ -1018,7 +1066,11 @@ def trim_fastq_gpu(source: Union[str, BinaryIO, np.ndarray], out: Union[str, Bin
     # then the reads are marked IN PLACE in the device's copy of the chunk around what the rounds would keep
     # (cah_mark_reads_device): the modifiers behind the adapter step and the formatter see the marked read)
     marking = act in (4, 5) and bool(adapters)
-    all_device = (not revcomp and info_file is None and
+    # (... and --revcomp with action trim, one round, single adapters: both orientations matched, the better one kept in
+    # place -- _Worker.modify; without adapters --revcomp does nothing, reference cli.py:1113-1118)
+    rc_device = bool(revcomp) and bool(adapters)
+    rc_ok = not rc_device or (act == 0 and int(times) == 1 and no_linked and len((rc_suffix or "").encode()) <= _lib.MAX_NAME_SUFFIX)
+    all_device = (rc_ok and info_file is None and
                   ((not adapters and action in ("trim", None, "none", "retain", "crop", "mask", "lowercase")) or
                    (bool(adapters) and (act == 0 or single_round_action or marking) and _all_device_adapters(adapters, int(times), index))))
     pre = post = None
@@ -1030,9 +1082,10 @@ def trim_fastq_gpu(source: Union[str, BinaryIO, np.ndarray], out: Union[str, Bin
     threads = max(1, int(threads))
     opts = {"discard_untrimmed": discard_untrimmed, "discard_trimmed": discard_trimmed,
             "minimum_length": minimum_length, "maximum_length": maximum_length, "assemble": assemble, "pre": pre, "post": post,
-            "times": int(times), "action": max(act, 0) if adapters else 0}
-    if all_device and adapters and act in (4, 5):
-        assemble = opts["assemble"] = "device"               # (the host-side assembler copies slices: it cannot mark)
+            "times": int(times), "action": max(act, 0) if adapters else 0, "revcomp": all_device and rc_device,
+            "rc_suffix": rc_suffix}
+    if all_device and adapters and (act in (4, 5) or rc_device):
+        assemble = opts["assemble"] = "device"               # (the host-side assembler copies slices of the INPUT: it cannot mark or turn)
     from .pipeline import BatchTrimmer
     if all_device:
         plan, kinds = _plan_for(adapters) if adapters else (None, [0])
@@ -1142,8 +1195,10 @@ def trim_fastq_gpu(source: Union[str, BinaryIO, np.ndarray], out: Union[str, Bin
         stats = np.zeros(8, dtype=np.int64)
         removed = np.zeros(2, dtype=np.int64)
         polya: Dict[int, int] = {}
+        turned = 0
         for w in workers:
             stats += w.counters.cpu().numpy()
+            turned += int(w.rc_count.item())
             removed += w.pre_counts.cpu().numpy()
             if post and post["poly_a"]:
                 h = w.polya_hist.cpu().numpy()
@@ -1153,7 +1208,8 @@ def trim_fastq_gpu(source: Union[str, BinaryIO, np.ndarray], out: Union[str, Bin
         result.update({"reads": int(stats[0]), "with_adapters": int(stats[1]), "bp_in": int(stats[2]),
                        "bp_out": int(stats[3]), "filtered": {"too_short": int(stats[4]), "too_long": int(stats[5])},
                        "too_many_expected_errors": int(stats[7]), "poly_a_trimmed_lengths": polya,
-                       "nextseq_trimmed_bases": int(removed[0]), "quality_trimmed_bases": int(removed[1])})
+                       "nextseq_trimmed_bases": int(removed[0]), "quality_trimmed_bases": int(removed[1]),
+                       "reverse_complemented": turned if opts["revcomp"] else None})
     else:
         total = BatchTrimmer(adapters, device=devices[0], **general_opts)
         for w in workers:
@@ -1201,6 +1257,8 @@ def _process_feeder_main(conn, source, out_path, device_index, rank, options, ra
             if out_fd is not None:
                 os.close(out_fd)
         slim = {k: res[k] for k in _NUMERIC_RESULT_KEYS if k in res}
+        if res.get("reverse_complemented") is not None:
+            slim["reverse_complemented"] = int(res["reverse_complemented"])
         for k in ("filtered", "poly_a_trimmed_lengths", "per_device", "devices_used", "way", "wall_s"):
             if k in res:
                 slim[k] = res[k]
@@ -1284,6 +1342,8 @@ def _trim_fastq_gpu_processes(source, out, options: dict, devices, info_file, re
         raise RuntimeError(f"only {expected} of {len(ranges)} chunks were delivered")
     wall = time.perf_counter() - t0
     total: Dict[str, object] = {k: sum(int(r.get(k, 0)) for r in results.values()) for k in _NUMERIC_RESULT_KEYS}
+    if any("reverse_complemented" in r for r in results.values()):
+        total["reverse_complemented"] = sum(int(r.get("reverse_complemented", 0)) for r in results.values())
     filtered: Dict[str, int] = {}
     polya: Dict[int, int] = {}
     per_device: Dict[str, dict] = {}

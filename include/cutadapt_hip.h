@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define CAH_ABI_VERSION 5   /* 2: CAH_PROF_N = 5, plan workspaces (cah_plan_workspace_bytes), no adapter length limit; 3: cah_plan_multi_kind; 4: cah_build_id, cah_last_multi_path, CAH_EINTERNAL; 5: cah_match_batch_frames, cah_set_deferred_errors, CAH_STATUS_INTERNAL, cah_mark_reads_device */
+#define CAH_ABI_VERSION 5   /* 2: CAH_PROF_N = 5, plan workspaces (cah_plan_workspace_bytes), no adapter length limit; 3: cah_plan_multi_kind; 4: cah_build_id, cah_last_multi_path, CAH_EINTERNAL; 5: cah_match_batch_frames, cah_set_deferred_errors, CAH_STATUS_INTERNAL, cah_mark_reads_device, cah_revcomp_in_place_device, cah_fastq_format_suffix_device */
 
 /* status codes */
 #define CAH_OK 0
@@ -463,6 +463,23 @@ int cah_fastq_format_device(const uint8_t *d_buf, const int64_t *d_rec6, int64_t
 int cah_mark_reads_device(uint8_t *d_buf, const int64_t *d_rec6, int64_t n_records, const int32_t *d_beg,
                           const int32_t *d_end, const int32_t *d_mark_beg, const int32_t *d_mark_end, int mode,
                           void *stream);
+/* --revcomp on a chunk in HBM (ReverseComplementer, reference modifiers.py:264-308): the caller matches every read and its
+ * reverse complement (cah_revcomp_reads_batch into a second buffer at the same offsets, two cah_match_batch calls), takes
+ * the reverse complement where its score is HIGHER (modifiers.py:287) and then
+ *   cah_revcomp_in_place_device     turns the records with d_flags[r] != 0 around IN PLACE inside the window the adapter
+ *                                   step saw ([d_win_beg[r], + d_win_len[r]) relative to the read; d_win_beg NULL: from
+ *                                   0): the sequence becomes its reverse complement (csrc/revcomp.h), the qualities are
+ *                                   reversed -- the modifiers behind the adapter step and the formatter see that read;
+ *   cah_fastq_format_suffix_device  cah_fastq_format_device with `suffix` (suffix_len <= CAH_MAX_NAME_SUFFIX bytes) behind
+ *                                   the name of those records (modifiers.py:296-297: `trimmed_read.name += rc_suffix`);
+ *                                   out_cap >= chunk length + (4 + suffix_len) * n_records always suffices. */
+#define CAH_MAX_NAME_SUFFIX 32
+int cah_revcomp_in_place_device(uint8_t *d_buf, const int64_t *d_rec6, int64_t n_records, const int32_t *d_win_beg,
+                                const int32_t *d_win_len, const uint8_t *d_flags, void *stream);
+int cah_fastq_format_suffix_device(const uint8_t *d_buf, const int64_t *d_rec6, int64_t n_records, const int32_t *d_beg,
+                                   const int32_t *d_end, const uint8_t *d_keep, const uint8_t *d_flags,
+                                   const char *suffix, int32_t suffix_len, void *d_scratch, size_t scratch_bytes,
+                                   int64_t chunk_bytes, uint8_t *d_out, int64_t out_cap, int64_t *d_info, void *stream);
 
 /* ---- AdapterIndex (adapters.py:1289-1551) on the GPU ---------- */
 /* Many anchored adapters of one kind (all 5' "^ADAPTER" or all 3' "ADAPTER$", no wildcards, at most

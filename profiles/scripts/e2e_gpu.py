@@ -60,8 +60,10 @@ def timed(label, fn, reps=2):
         stats = fn()
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
-    out["runs"].append({"what": label, "seconds": best, "Mreads_per_s": n / best / 1e6,
-                        "GB_per_s_in": fastq.numel() / best / 1e9, "with_adapters": stats["with_adapters"],
+    n_run = int(stats.get("reads", n))                       # (a run over a part of the data is rated on that part)
+    out["runs"].append({"what": label, "reads": n_run, "seconds": best, "Mreads_per_s": n_run / best / 1e6,
+                        "GB_per_s_in": n_run * 317 / best / 1e9, "with_adapters": stats["with_adapters"],
+                        "reverse_complemented": stats.get("reverse_complemented"), "way": stats.get("way"),
                         "bytes_out": stats.get("bytes_out"), "devices_used": stats.get("devices_used"),
                         "per_device": stats.get("per_device")})
     print(out["runs"][-1], file=sys.stderr)
@@ -93,8 +95,27 @@ if devices is not None:
                                  action="mask"), reps=1)
     timed(f"--action mask --poly-a (all-device way: the reads are marked in place, the poly-A trimmer sees the marked read), devices={args.devices}",
           lambda: trim_fastq_gpu(fastq, None, [adapter], threads=args.threads, devices=devices, action="mask", poly_a=True), reps=1)
-    timed(f"the general way (--revcomp: both strands matched, the records of the better one written by the host), devices={args.devices}",
-          lambda: trim_fastq_gpu(fastq[: 317 * 4_000_000], None, [adapter], threads=args.threads, devices=devices, revcomp=True), reps=1)
+    timed(f"--revcomp (round 6: all-device way -- both orientations matched, the better one turned around in place in HBM; rounds 3-5: the general way), devices={args.devices}",
+          lambda: trim_fastq_gpu(fastq, None, [adapter], threads=args.threads, devices=devices, revcomp=True))
+    # ... on data where every other read is the OTHER strand (the case --revcomp exists for): turned on the device here
+    half = torch.empty(fastq.numel(), dtype=torch.uint8).pin_memory()
+    comp = torch.arange(256, dtype=torch.uint8)
+    for a, b in ("AT", "TA", "CG", "GC"):
+        comp[ord(a)] = ord(b)
+    for lo in range(0, n, 4_000_000):
+        hi = min(n, lo + 4_000_000)
+        part = fastq[lo * 317: hi * 317].to(dev).view(hi - lo, 317)
+        odd = part[1::2, 13:163]
+        part[1::2, 13:163] = comp.to(dev)[odd.flip(1).long()]
+        half[lo * 317: hi * 317].copy_(part.view(-1))
+    del part, odd
+    timed(f"--revcomp -q 0,10 -m 20, every other read given as its reverse complement, devices={args.devices}",
+          lambda: trim_fastq_gpu(half, None, [adapter], threads=args.threads, devices=devices, revcomp=True, quality_cutoff=(0, 10),
+                                 minimum_length=20))
+    timed(f"the general way (--revcomp --info-file: both strands matched, the records of the better one and the info rows written by the host), devices={args.devices}",
+          lambda: trim_fastq_gpu(half[: 317 * 4_000_000], None, [adapter], threads=args.threads, devices=devices, revcomp=True,
+                                 info_file=open(os.devnull, "wb")), reps=1)
+    del half
     if args.file:
         with open(args.file, "wb") as f:
             f.write(memoryview(fastq.numpy()))

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 FQ = os.path.join(HERE, "golden", "fastq")
 
 
-def _fastq(rng, n, adapters, crlf=False, final_newline=True, lower=False, twice=False, lead=None):
+def _fastq(rng, n, adapters, crlf=False, final_newline=True, lower=False, twice=False, lead=None, turned=False):
     recs = []
     for i in range(n):
         L = rng.randint(0, 160)
@@ -38,6 +38,8 @@ def _fastq(rng, n, adapters, crlf=False, final_newline=True, lower=False, twice=
             s = "".join(c if rng.random() > 0.05 else "N" for c in s)
         if lower and rng.random() < 0.3:
             s = s.lower()
+        if turned and rng.random() < 0.45:                              # (--revcomp: the other strand of the same fragment)
+            s = s[::-1].translate(str.maketrans("ACGTNacgtn", "TGCANtgcan"))
         q = "".join(chr(rng.randint(33, 73)) for _ in s)
         name = f"read{i}" + (" some comment:" + "x" * rng.randint(0, 30) if rng.random() < 0.3 else "")
         recs.append(f"@{name}\n{s}\n+{name if rng.random() < 0.1 else ''}\n{q}\n")
@@ -100,6 +102,14 @@ def test_device_fastq_equals_host_pipeline(hip):
         ([A.BackAdapter(ad_seqs[0]), A.FrontAdapter(ad_seqs[1])], {"action": "lowercase", "poly_a": True, "times": 2, "quality_cutoff": (0, 12)}),
         ([A.LinkedAdapter(A.FrontAdapter(ad_seqs[2]), A.BackAdapter(ad_seqs[0]), False, True, "l5")], {"action": "lowercase", "minimum_length": 10}),
         ([A.LinkedAdapter(A.PrefixAdapter(ad_seqs[2]), A.BackAdapter(ad_seqs[0]), True, False, "l6")], {"action": "mask", "poly_a": True}),
+        # --revcomp (round 6; reference modifiers.py:264-308): both orientations matched, the better one turned around in place
+        # in HBM and named with the suffix -- alone, with several adapter types, with modifiers on both sides, no suffix
+        ([A.BackAdapter(ad_seqs[0])], {"revcomp": True}),
+        ([A.BackAdapter(ad_seqs[0]), A.FrontAdapter(ad_seqs[1]), A.AnywhereAdapter(ad_seqs[2])], {"revcomp": True, "rc_suffix": None, "minimum_length": 20}),
+        ([A.FrontAdapter(ad_seqs[1]), A.BackAdapter(ad_seqs[0])], {"revcomp": True, "rc_suffix": "/turned around", "quality_cutoff": (10, 15), "cut": [2, -3],
+                                                              "poly_a": True, "length": 100, "max_expected_errors": 4.0, "discard_untrimmed": True}),
+        ([A.NonInternalBackAdapter(ad_seqs[1]), A.PrefixAdapter(ad_seqs[2])], {"revcomp": True, "nextseq_trim": 20, "discard_trimmed": True}),
+        ([A.AnywhereAdapter(ad_seqs[0]), A.SuffixAdapter(ad_seqs[1])], {"revcomp": True, "maximum_length": 120, "length": -90}),
         # no adapter at all: the modifiers and filters alone, still on the device
         ([], {"quality_cutoff": (10, 20), "minimum_length": 30}),
         ([], {"nextseq_trim": 20, "poly_a": True, "length": 100, "max_expected_errors": 2.0}),
@@ -107,7 +117,8 @@ def test_device_fastq_equals_host_pipeline(hip):
     ]
     for ci, (ads, opts) in enumerate(cases):
         for crlf, final_nl, chunk in ((False, True, 1 << 20), (True, True, 4096), (False, False, 700)):
-            data = _fastq(rng, 3000, ad_seqs, crlf=crlf, final_newline=final_nl, lower=ci == 1 or opts.get("action") == "lowercase", twice="times" in opts,
+            data = _fastq(rng, 3000, ad_seqs, crlf=crlf, final_newline=final_nl, lower=ci == 1 or opts.get("action") == "lowercase" or opts.get("rc_suffix", "") is None, twice="times" in opts,
+                          turned=bool(opts.get("revcomp")),
                           lead=ad_seqs[2] if (ads and isinstance(ads[0], A.LinkedAdapter)) else None)
             want = io.BytesIO()
             ws = trim_fastq(io.BytesIO(data), want, ads, index=False, **opts)
@@ -120,6 +131,8 @@ def test_device_fastq_equals_host_pipeline(hip):
                 assert (gs["reads"], gs["with_adapters"], gs["bp_in"], gs["bp_out"]) == \
                        (ws["reads"], ws["with_adapters"], ws["bp_in"], ws["bp_out"]), (ci, gs, ws["reads"])
                 assert gs["way"] == "all-device"
+                if opts.get("revcomp"):
+                    assert gs["reverse_complemented"] == ws["reverse_complemented"] > 100, (ci, gs["reverse_complemented"])
                 assert (gs["quality_trimmed_bases"], gs["nextseq_trimmed_bases"]) == \
                        (ws["trimmer"].quality_trimmed_bases, ws["trimmer"].nextseq_trimmed_bases), ci
                 assert gs["too_many_expected_errors"] == ws["trimmer"].too_many_expected_errors, ci
@@ -192,6 +205,7 @@ def test_feeder_processes_write_the_same_bytes_as_feeder_threads(hip, tmp_path):
         (dict(adapters=[FrontAdapter(ads[1][:12], max_errors=0.1)], action="mask"), "all-device"),
         (dict(adapters=[FrontAdapter(ads[1][:12], max_errors=0.1)], action="mask", poly_a=True), "all-device"),
         (dict(adapters=[FrontAdapter(ads[1][:12], max_errors=0.1)], action="mask", revcomp=True), "general"),
+        (dict(adapters=[BackAdapter(ads[0], max_errors=0.1, min_overlap=3)], revcomp=True, minimum_length=20), "all-device"),
     ]
     for k, (opts, way) in enumerate(cases):
         for n_proc in (2, 3):
