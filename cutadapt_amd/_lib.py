@@ -31,7 +31,7 @@ EXPORTED_SYMBOLS = [
     "cah_profile_reset", "cah_profile_read", "cah_synth_reads",
     "cah_fastq_scan", "cah_pack_sequences", "cah_fastq_write_trimmed",
     "cah_fasta_scan", "cah_records_write", "cah_info_write", "cah_info_write_rc", "cah_chunk_revcomp", "cah_chunk_select", "cah_fastq_span", "cah_record_boundary",
-    "cah_fastq_device_scratch_bytes", "cah_fastq_count_lines_device", "cah_fastq_index_device", "cah_fastq_format_device", "cah_mark_reads_device", "cah_revcomp_in_place_device", "cah_fastq_format_suffix_device", "cah_trim_decide_device", "cah_trim_decide_window_device", "cah_trim_decide_action_device", "cah_trim_filter_device",
+    "cah_fastq_device_scratch_bytes", "cah_fastq_count_lines_device", "cah_fastq_index_device", "cah_fastq_format_device", "cah_mark_reads_device", "cah_revcomp_in_place_device", "cah_fastq_format_suffix_device", "cah_info_format_device", "cah_trim_decide_device", "cah_trim_decide_window_device", "cah_trim_decide_action_device", "cah_trim_filter_device",
     "cah_index_create", "cah_index_destroy", "cah_index_info", "cah_index_get",
     "cah_index_lookup_batch", "cah_index_lookup_batch_host",
     "cah_quality_trim_batch", "cah_nextseq_trim_batch", "cah_nextseq_trim_batch_q", "cah_poly_a_trim_batch", "cah_expected_errors_batch",
@@ -168,6 +168,8 @@ def lib():
         L.cah_revcomp_in_place_device.argtypes = [vp, vp, i64, vp, vp, vp, vp]
         L.cah_fastq_format_suffix_device.argtypes = [vp, vp, i64, vp, vp, vp, vp, C.c_char_p, C.c_int32, vp, C.c_size_t, i64, vp,
                                                      i64, vp, vp]
+        L.cah_info_format_device.argtypes = [vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, C.c_int32, vp, C.c_char_p, C.c_int32, vp,
+                                             C.c_size_t, i64, vp, i64, vp, vp]
     L.cah_trim_decide_device.argtypes = [vp, vp, vp, vp, i64, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     L.cah_trim_decide_window_device.argtypes = [vp, vp, vp, vp, vp, vp, i64, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     L.cah_trim_decide_action_device.argtypes = [vp, vp, vp, vp, vp, vp, i64, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]

@@ -276,6 +276,130 @@ __global__ __launch_bounds__(256) void k_format(const uint8_t* buf, const int64_
     }
 }
 
+// --info-file rows on the device (reference steps.py:232-253, adapters.py:395-417), one line per record:
+//   a read with a match   name[suffix] \t errors \t rstart \t rstop \t seq[:rstart] \t seq[rstart:rstop] \t seq[rstop:] \t adapter
+//                         \t qual[:rstart] \t qual[rstart:rstop] \t qual[rstop:] \t rc \n
+//                         (seq = the WHOLE read as it came in -- turned around if the reverse complement won --, cut at the
+//                         coordinates of the match, which were found on what the modifiers in front of the adapter step left
+//                         of it: steps.py:233-236 starts from info.original_read; rc = "", "0" or "1": RC_MAP, :224)
+//   a read without one    name \t -1 \t seq[fb:fe] \t qual[fb:fe] \n      (the read as it is written, :248-251)
+struct InfoArgs {
+    const uint8_t* buf; const int64_t* rec6; int64_t n_records;
+    const int32_t* out6; const uint8_t* status; const int32_t* best;
+    const int32_t* final_beg; const int32_t* final_end;
+    const uint8_t* names; const int32_t* name_off; int n_names;
+    const uint8_t* is_rc;                                            // NULL: the rc column stays empty
+    NameSuffix sfx;
+};
+
+__device__ __forceinline__ int n_digits(int v) {
+    int d = 1;
+    for (int t = v < 0 ? 0 : v; t >= 10; t /= 10) ++d;
+    return d;
+}
+
+__device__ __forceinline__ void put_digits(uint8_t* w, int v, const int d) {
+    if (v < 0) v = 0;
+    for (int i = d - 1; i >= 0; --i) { w[i] = (uint8_t)('0' + v % 10); v /= 10; }
+}
+
+struct InfoRow {
+    bool matched; int64_t name_len, seq_len; int extra, err, rs, re, ni, nlen; int64_t fa, fb;
+};
+
+__device__ __forceinline__ InfoRow info_row(const InfoArgs& a, const int64_t r) {
+    InfoRow x;
+    const int64_t* o = a.rec6 + r * 6;
+    x.name_len = o[1] - o[0];
+    x.seq_len = o[3] - o[2];
+    x.matched = a.status[r] == 1;
+    x.extra = 0; x.err = x.rs = x.re = x.ni = x.nlen = 0; x.fa = x.fb = 0;
+    if (x.matched) {
+        const int32_t* m = a.out6 + r * 6;
+        x.err = m[5];
+        int64_t re = m[3], rs = m[2];
+        if (re > x.seq_len) re = x.seq_len;
+        if (re < 0) re = 0;
+        if (rs > re) rs = re;
+        if (rs < 0) rs = 0;
+        x.rs = (int)rs; x.re = (int)re;
+        x.ni = a.best[r];
+        if (x.ni < 0 || x.ni >= a.n_names) x.ni = 0;
+        x.nlen = a.n_names > 0 ? a.name_off[x.ni + 1] - a.name_off[x.ni] : 0;
+        x.extra = a.is_rc && a.is_rc[r] ? a.sfx.len : 0;
+    } else {
+        int64_t fa = a.final_beg[r], fb = a.final_end[r];
+        if (fa < 0) fa = 0;
+        if (fb > x.seq_len) fb = x.seq_len;
+        if (fb < fa) fb = fa;
+        x.fa = fa; x.fb = fb;
+    }
+    return x;
+}
+
+__device__ __forceinline__ int64_t info_row_len(const InfoArgs& a, const InfoRow& x, const int64_t r) {
+    if (!x.matched) return x.name_len + 4 + 2 * (x.fb - x.fa) + 2;
+    return x.name_len + x.extra + 1 + n_digits(x.err) + 1 + n_digits(x.rs) + 1 + n_digits(x.re) + 1 + x.seq_len + 3 + x.nlen + 1
+         + x.seq_len + 2 + 1 + (a.is_rc ? 1 : 0) + 1;
+}
+
+__global__ __launch_bounds__(256) void k_info_len(const InfoArgs a, int64_t* out_len) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.n_records; r += stride)
+        out_len[r] = info_row_len(a, info_row(a, r), r);
+}
+
+// one wave per record
+__global__ __launch_bounds__(256) void k_info_format(const InfoArgs a, const int64_t* out_off, uint8_t* out, int64_t out_cap) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    for (int64_t r = wave; r < a.n_records; r += n_waves) {
+        const InfoRow x = info_row(a, r);
+        const int64_t* o = a.rec6 + r * 6;
+        const int64_t pos = out_off[r];
+        if (pos + info_row_len(a, x, r) > out_cap) continue;            // never: the caller sizes out for the chunk
+        uint8_t* w = out + pos;
+        auto copy = [&](const uint8_t* src, const int64_t len) {
+            for (int64_t k = lane; k < len; k += 64) w[k] = src[k];
+            w += len;
+        };
+        auto put = [&](const uint8_t c) { if (lane == 0) w[0] = c; ++w; };
+        const uint8_t* seq = a.buf + o[2];
+        const uint8_t* qual = a.buf + o[4];
+        copy(a.buf + o[0], x.name_len);
+        if (!x.matched) {
+            if (lane == 0) { w[0] = '\t'; w[1] = '-'; w[2] = '1'; w[3] = '\t'; }
+            w += 4;
+            copy(seq + x.fa, x.fb - x.fa);
+            put('\t');
+            copy(qual + x.fa, x.fb - x.fa);
+            put('\n');
+            continue;
+        }
+        if (lane < x.extra) w[lane] = a.sfx.c[lane];
+        w += x.extra;
+        put('\t');
+        const int d0 = n_digits(x.err), d1 = n_digits(x.rs), d2 = n_digits(x.re);
+        if (lane == 0) {
+            put_digits(w, x.err, d0); w[d0] = '\t';
+            put_digits(w + d0 + 1, x.rs, d1); w[d0 + 1 + d1] = '\t';
+            put_digits(w + d0 + d1 + 2, x.re, d2); w[d0 + d1 + d2 + 2] = '\t';
+        }
+        w += d0 + d1 + d2 + 3;
+        copy(seq, x.rs); put('\t');
+        copy(seq + x.rs, x.re - x.rs); put('\t');
+        copy(seq + x.re, x.seq_len - x.re); put('\t');
+        if (x.nlen) copy(a.names + a.name_off[x.ni], x.nlen);
+        put('\t');
+        copy(qual, x.rs); put('\t');
+        copy(qual + x.rs, x.re - x.rs); put('\t');
+        copy(qual + x.re, x.seq_len - x.re); put('\t');
+        if (a.is_rc) put(a.is_rc[r] ? '1' : '0');
+        put('\n');
+    }
+}
+
 // ReverseComplementer's chosen orientation (reference modifiers.py:280-297), IN PLACE in the device's copy of the chunk: the
 // window [win_beg[r], win_beg[r] + win_len[r]) of every record with flags[r] != 0 -- the read as the adapter step saw it
 // -- becomes its reverse complement (revcomp.h) and the same window of the qualities is reversed.  One wave per record; a
@@ -640,6 +764,48 @@ int cah_fastq_format_suffix_device(const uint8_t* d_buf, const int64_t* d_rec6, 
                                    uint8_t* d_out, int64_t out_cap, int64_t* d_info, void* stream) {
     return format_impl("cah_fastq_format_suffix_device", d_buf, d_rec6, n_records, d_beg, d_end, d_keep, d_flags, suffix, suffix_len,
                        d_scratch, scratch_bytes, chunk_bytes, d_out, out_cap, d_info, stream);
+}
+
+// --info-file rows of a chunk in HBM (k_info_len / scan / k_info_format): one line per record in record order, d_total[0] =
+// bytes written.  d_out6 / d_status / d_best: the adapter step's result for every read (status 1: a match row; one round);
+// d_final_beg / d_final_end: what is written of every read (the line of a read without a match shows that); d_names /
+// d_name_off (int32[n_names + 1]): the adapters' names back to back, in plan order; d_is_rc NULL: no --revcomp, the last
+// column stays empty; else "0" / "1", and the names of the reads with d_is_rc[r] != 0 carry `suffix`.
+// out_cap >= chunk length + n_records * (longest adapter name + suffix_len + 48) always suffices.
+int cah_info_format_device(const uint8_t* d_buf, const int64_t* d_rec6, int64_t n_records, const int32_t* d_out6,
+                           const uint8_t* d_status, const int32_t* d_best, const int32_t* d_final_beg, const int32_t* d_final_end,
+                           const uint8_t* d_names, const int32_t* d_name_off, int32_t n_names, const uint8_t* d_is_rc,
+                           const char* suffix, int32_t suffix_len, void* d_scratch, size_t scratch_bytes, int64_t chunk_bytes,
+                           uint8_t* d_out, int64_t out_cap, int64_t* d_total, void* stream) {
+    if (n_records < 0 || !d_scratch || !d_total || n_names < 0) return cah_set_error_(CAH_EINVAL, "cah_info_format_device: bad argument");
+    if (suffix_len < 0 || suffix_len > CAH_MAX_NAME_SUFFIX || (suffix_len > 0 && !suffix))
+        return cah_set_error_(CAH_EINVAL, "cah_info_format_device: suffix longer than CAH_MAX_NAME_SUFFIX");
+    if (scratch_bytes < cah_fastq_device_scratch_bytes(chunk_bytes, n_records)) return cah_set_error_(CAH_EINVAL, "cah_info_format_device: scratch too small");
+    hipStream_t s = (hipStream_t)stream;
+    GPU_TRY(hipMemsetAsync(d_total, 0, sizeof(int64_t), s));
+    if (n_records == 0) return CAH_OK;
+    if (!d_buf || !d_rec6 || !d_out6 || !d_status || !d_best || !d_final_beg || !d_final_end || !d_out || (n_names > 0 && (!d_names || !d_name_off)))
+        return cah_set_error_(CAH_EINVAL, "cah_info_format_device: NULL argument");
+    InfoArgs a;
+    a.buf = d_buf; a.rec6 = d_rec6; a.n_records = n_records; a.out6 = d_out6; a.status = d_status; a.best = d_best;
+    a.final_beg = d_final_beg; a.final_end = d_final_end; a.names = d_names; a.name_off = d_name_off; a.n_names = n_names;
+    a.is_rc = d_is_rc;
+    a.sfx.len = d_is_rc ? suffix_len : 0;
+    for (int i = 0; i < CAH_MAX_NAME_SUFFIX; ++i) a.sfx.c[i] = i < a.sfx.len ? (uint8_t)suffix[i] : 0;
+    int64_t* p = (int64_t*)d_scratch + n_tiles_of(chunk_bytes) + 8 + 4 * n_records + 8;      // (the formatter's arrays: free again)
+    int64_t* out_len = p;                        p += n_records + 8;
+    int64_t* out_off = p;                        p += n_records + 8;
+    int64_t* block_sums = p;
+    const int64_t rb = (n_records + 255) / 256;
+    const int64_t sb = n_scan_blocks(n_records);
+    hipLaunchKernelGGL(k_info_len, dim3((unsigned)(rb < 8 * cus() ? rb : 8 * cus())), dim3(256), 0, s, a, out_len);
+    hipLaunchKernelGGL(k_scan_sums, dim3((unsigned)sb), dim3(256), 0, s, out_len, n_records, block_sums);
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, block_sums, sb, d_total);
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)sb), dim3(256), 0, s, out_len, n_records, block_sums, out_off);
+    const int64_t fb = (n_records + 3) / 4;
+    hipLaunchKernelGGL(k_info_format, dim3((unsigned)(fb < 16 * cus() ? fb : 16 * cus())), dim3(256), 0, s, a, out_off, d_out, out_cap);
+    GPU_TRY(hipGetLastError());
+    return CAH_OK;
 }
 
 // ReverseComplementer's chosen orientation, in place (k_revcomp_in_place): records with d_flags[r] != 0 are turned around

@@ -14,14 +14,15 @@ Two ways through a chunk once it is indexed:
   * the all-device way (any number of single, non-rightmost adapters with ``--times N``, or one linked adapter; action ``trim``
     -- or, with one round of single adapters, ``none`` / ``retain`` / ``crop``: other intervals from the same matches --;
     the marking actions ``mask`` / ``lowercase`` (marked in place in HBM); ``--revcomp`` with action ``trim``, one round and
-    single adapters (both orientations matched, the better one turned around in place in HBM);
+    single adapters (both orientations matched, the better one turned around in place in HBM); ``--info-file`` with one round
+    of single adapters and an action that leaves the characters alone (the rows formatted on the device);
     no adapter at all: the other modifiers and the filters alone;
     ``-u`` / ``--nextseq-trim`` / ``-q`` in front of the adapter step, ``--poly-a`` / ``-l`` / ``--max-ee`` / ``-m`` /
     ``-M`` / ``--discard-(un)trimmed`` behind it -- the usual ``cutadapt -q 20 -a ADAPTER -m 20`` and more): trim,
     match, decide and format without a byte of per-read data touching the host (``cah_trim_decide_device`` /
     ``cah_trim_decide_window_device`` / ``cah_trim_decide_action_device`` / ``cah_trim_filter_device``);
   * the general way (everything else ``pipeline.BatchTrimmer`` does: rightmost adapters, linked ones among others,
-    ``--revcomp`` with several rounds or another action, ``--info-file``, ``--pair-adapters``, adapter sets regrouped behind an
+    ``--revcomp`` / ``--info-file`` with several rounds or a marking action, ``--pair-adapters``, adapter sets regrouped behind an
     ``AdapterIndex``): the
     modifiers run as kernels on windows into the raw chunk in HBM (``DeviceFastqChunk``: reads AND qualities are used in place), the window arithmetic between them is
     numpy on 4-byte-per-read arrays, and plain slicing is formatted on the device again.  What cannot be expressed
@@ -450,9 +451,13 @@ class _Worker:
                 self.res.status[:n].copy_(torch.where(use, r2.status[:n], self.res.status[:n]))
                 self.rc_flags[:n].copy_(use)
                 self.rc_count += use.sum()
-                _lib.check(L.cah_revcomp_in_place_device(self.d_in.data_ptr(), self.rec6.data_ptr(), n,
-                                                         wbeg.data_ptr() if wbeg is not None else None, wl.data_ptr(),
-                                                         self.rc_flags.data_ptr(), sp))
+                # (the WHOLE read is turned, as the reference's is -- its info rows show that --: the window the modifiers in
+                # front left of it is then [len - wend, len - wbeg) of the turned read)
+                _lib.check(L.cah_revcomp_in_place_device(self.d_in.data_ptr(), self.rec6.data_ptr(), n, None,
+                                                         self.seq_len.data_ptr(), self.rc_flags.data_ptr(), sp))
+                if wbeg is not None:
+                    keepalive.append(wbeg)
+                    wbeg = torch.where(use, seq_len - wbeg - wl, wbeg).contiguous()
                 keepalive += [wl, use]
         else:
             self.res.status[:n].zero_()                      # a mate without adapters: nothing is found
@@ -570,7 +575,50 @@ class _Worker:
         return ee
 
     def finish(self, data, n: int, n_bytes: int):
-        """step 4 of a chunk whose intervals and keep flags are final -> (pinned buffer, bytes)"""
+        """step 4 of a chunk whose intervals and keep flags are final -> (pinned buffer, bytes); with --info-file on the
+        all-device way the info rows are formatted on the device behind the records (``self.last_info`` = (pinned buffer,
+        bytes), cah_info_format_device)"""
+        info = self.opts.get("info")
+        self.last_info = None
+        if info is None:
+            return self._finish_records(data, n, n_bytes)
+        torch = self.torch
+        L = _lib.lib()
+        sp = self.stream.cuda_stream
+        out = self._finish_records(data, n, n_bytes)
+        if n == 0:
+            return out
+        names = info["names"]
+        if getattr(self, "_info_names", None) is not names:
+            blob = "".join(names).encode("ascii")
+            off = np.zeros(len(names) + 1, dtype=np.int32)
+            np.cumsum([len(x) for x in names], out=off[1:])
+            self.d_names = torch.from_numpy(np.frombuffer(blob + b"\0", dtype=np.uint8).copy()).to(self.device)
+            self.d_name_off = torch.from_numpy(off).to(self.device)
+            self.d_info_total = torch.zeros(1, dtype=torch.int64, device=self.device)
+            self.h_info_total = torch.zeros(1, dtype=torch.int64).pin_memory()
+            self._info_names = names
+        rc = bool(self.opts.get("revcomp")) and self.plan is not None
+        suffix = (self.opts.get("rc_suffix") or "").encode() if rc else b""
+        cap = n_bytes + n * (max([len(x) for x in names], default=0) + len(suffix) + 48) + 64
+        if getattr(self, "d_info_out", None) is None or self.d_info_out.numel() < cap:
+            self.d_info_out = torch.empty(cap + cap // 4, dtype=torch.uint8, device=self.device)
+        _lib.check(L.cah_info_format_device(
+            self.d_in.data_ptr(), self.rec6.data_ptr(), n, self.res.out6.data_ptr(), self.res.status.data_ptr(),
+            self.res.best_adapter.data_ptr(), self.beg.data_ptr(), self.end.data_ptr(), self.d_names.data_ptr(),
+            self.d_name_off.data_ptr(), len(names), self.rc_flags.data_ptr() if rc else None, suffix if suffix else None,
+            len(suffix), self.d_scratch.data_ptr(), self.d_scratch.numel(), n_bytes, self.d_info_out.data_ptr(),
+            self.d_info_out.numel(), self.d_info_total.data_ptr(), sp))
+        self.h_info_total.copy_(self.d_info_total, non_blocking=True)
+        self.stream.synchronize()
+        total = int(self.h_info_total[0])
+        h = self.pool.get(total)
+        h[:total].copy_(self.d_info_out[:total], non_blocking=True)
+        self.stream.synchronize()
+        self.last_info = (h, total)
+        return out
+
+    def _finish_records(self, data, n: int, n_bytes: int):
         torch = self.torch
         L = _lib.lib()
         sp = self.stream.cuda_stream
@@ -1070,7 +1118,10 @@ def trim_fastq_gpu(source: Union[str, BinaryIO, np.ndarray], out: Union[str, Bin
     # place -- _Worker.modify; without adapters --revcomp does nothing, reference cli.py:1113-1118)
     rc_device = bool(revcomp) and bool(adapters)
     rc_ok = not rc_device or (act == 0 and int(times) == 1 and no_linked and len((rc_suffix or "").encode()) <= _lib.MAX_NAME_SUFFIX)
-    all_device = (rc_ok and info_file is None and
+    # (... and --info-file with one round of single adapters, any action that leaves the characters alone: the rows are
+    # formatted on the device too, cah_info_format_device)
+    info_ok = info_file is None or (int(times) == 1 and no_linked and act in (0, 1, 2, 3))
+    all_device = (rc_ok and info_ok and
                   ((not adapters and action in ("trim", None, "none", "retain", "crop", "mask", "lowercase")) or
                    (bool(adapters) and (act == 0 or single_round_action or marking) and _all_device_adapters(adapters, int(times), index))))
     pre = post = None
@@ -1083,7 +1134,8 @@ def trim_fastq_gpu(source: Union[str, BinaryIO, np.ndarray], out: Union[str, Bin
     opts = {"discard_untrimmed": discard_untrimmed, "discard_trimmed": discard_trimmed,
             "minimum_length": minimum_length, "maximum_length": maximum_length, "assemble": assemble, "pre": pre, "post": post,
             "times": int(times), "action": max(act, 0) if adapters else 0, "revcomp": all_device and rc_device,
-            "rc_suffix": rc_suffix}
+            "rc_suffix": rc_suffix,
+            "info": {"names": [str(a.name) for a in adapters]} if (all_device and info_file is not None) else None}
     if all_device and adapters and (act in (4, 5) or rc_device):
         assemble = opts["assemble"] = "device"               # (the host-side assembler copies slices of the INPUT: it cannot mark or turn)
     from .pipeline import BatchTrimmer
@@ -1125,7 +1177,14 @@ def trim_fastq_gpu(source: Union[str, BinaryIO, np.ndarray], out: Union[str, Bin
                 return body, [], None, w
             if all_device:
                 buf, total = w.run(data, is_final)
-                return (memoryview(buf.numpy())[:total] if buf is not None else b""), ([buf] if buf is not None else []), None, w
+                bufs = [buf] if buf is not None else []
+                rows = None
+                if want_info:
+                    rows = b""
+                    if buf is not None and w.last_info is not None:
+                        rows = memoryview(w.last_info[0].numpy())[:w.last_info[1]]
+                        bufs.append(w.last_info[0])
+                return (memoryview(buf.numpy())[:total] if buf is not None else b""), bufs, rows, w
             info: Optional[list] = [] if want_info else None
             body, bufs = w.run_general(data, lambda chunk: w.trimmer.process_chunk(
                 chunk, discard_untrimmed, discard_trimmed, info, minimum_length, maximum_length))
@@ -1153,9 +1212,9 @@ def trim_fastq_gpu(source: Union[str, BinaryIO, np.ndarray], out: Union[str, Bin
                     _deliver(chunk_index, body)             # (process mode: the chunk goes where the parent says)
                 elif sink is not None and len(body):
                     sink.write(body)                        # straight from the pinned buffer
-                if inf is not None and info:
+                if inf is not None and info is not None and len(info):
                     inf.write(info)
-                body = None
+                body = info = None
                 for b in bufs:
                     w.pool.put(b)
         if _ranges is not None:

@@ -112,9 +112,18 @@ if devices is not None:
     timed(f"--revcomp -q 0,10 -m 20, every other read given as its reverse complement, devices={args.devices}",
           lambda: trim_fastq_gpu(half, None, [adapter], threads=args.threads, devices=devices, revcomp=True, quality_cutoff=(0, 10),
                                  minimum_length=20))
-    timed(f"the general way (--revcomp --info-file: both strands matched, the records of the better one and the info rows written by the host), devices={args.devices}",
+    devnull = open(os.devnull, "wb")
+    timed(f"--info-file (round 6: all-device way, the rows formatted on the device: twice the bytes come back), devices={args.devices}",
+          lambda: trim_fastq_gpu(fastq, None, [adapter], threads=args.threads, devices=devices, info_file=devnull))
+    timed(f"--revcomp --info-file -q 0,10 -m 20, every other read given as its reverse complement (all-device way), devices={args.devices}",
+          lambda: trim_fastq_gpu(half, None, [adapter], threads=args.threads, devices=devices, revcomp=True, quality_cutoff=(0, 10),
+                                 minimum_length=20, info_file=devnull), reps=1)
+    timed(f"the general way (--times 2 --info-file: the rows written by the host from the device's record index), devices={args.devices}",
+          lambda: trim_fastq_gpu(fastq[: 317 * 4_000_000], None, [adapter], threads=args.threads, devices=devices, times=2,
+                                 info_file=devnull), reps=1)
+    timed(f"the general way (--revcomp --times 2: both strands matched, the records of the better one written by the host), devices={args.devices}",
           lambda: trim_fastq_gpu(half[: 317 * 4_000_000], None, [adapter], threads=args.threads, devices=devices, revcomp=True,
-                                 info_file=open(os.devnull, "wb")), reps=1)
+                                 times=2), reps=1)
     del half
     if args.file:
         with open(args.file, "wb") as f:

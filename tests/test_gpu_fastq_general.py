@@ -54,12 +54,13 @@ def test_single_end_goldens_through_the_device_path(hip):
             assert stats["too_many_expected_errors"] == 2
         if case["name"] == "revcomp_normalized":
             assert stats["reverse_complemented"] == 2                   # reference test_commandline.py:834
-    # what still takes the general way: info files, several linked adapters
+    # what still takes the general way: info files of several rounds or of linked adapters, several linked adapters
     # (round 6: mask / lowercase with single adapters are marked in place on the device, cah_mark_reads_device; --revcomp is
-    # matched in both orientations and turned around there, cah_revcomp_in_place_device)
+    # matched in both orientations and turned around there, cah_revcomp_in_place_device; the info rows of one round of single
+    # adapters are formatted there, cah_info_format_device)
     general = {k for k, v in by_name.items() if v == "general"}
-    assert general <= {"info_file", "info_file_times", "info_file_revcomp", "linked_info_file", "linked_multiple"}, general
-    assert by_name.get("revcomp_normalized") == "all-device", by_name
+    assert general <= {"info_file_times", "linked_info_file", "linked_multiple"}, general
+    assert by_name.get("revcomp_normalized") == "all-device" and by_name.get("info_file") == "all-device", by_name
     assert by_name.get("action_mask") == "all-device", by_name          # (action_lowercase is a FASTA golden: host-parsed)
     # (14 of the 33 goldens are FASTA files: parsed on the host -- a sequence may span lines -- and matched in batches)
     fastq = {k for k, v in by_name.items() if v != "host-parsed (FASTA)"}
