@@ -137,7 +137,37 @@ M2_HD uint32_t m2_home_of(uint32_t key, uint32_t meta) {
     const int q = (int)((meta >> 7) & 15u);
     return m2_index(key, q < 8 ? q : 8) & (CAH_M2_SLOTS - 1);
 }
-M2_HD uint32_t m2_bit(uint32_t idx, int qc) { return qc >= 8 ? idx : CAH_M2_BM8_WORDS * 32u + (idx & 0x7FFFu); }
+// The presence bitmaps.  Bits [0, 64 K): HASHED (m2_index) -- every k-mer of eight or more characters and class W's k-mers of
+// every index class (probed at every character).  Behind them the tail classes' k-mers of fewer than eight characters, EXACT:
+// bit = m2_tail_region(q) + the k-mer's characters at two bits each (a valid character's code is below 4; anything else
+// aliases a valid one here and fails the comparison of all characters in the resolve step).  Round 6: these k-mers used to
+// share 32 Kbit through the hash, which folds 18- and 21-bit keys into 15 bits -- every second event of the six- and
+// seven-character passes was a k-mer that no entry holds (C4: 6.0 tail events per read, 4.3 now).
+M2_HD uint32_t m2_pack2(uint32_t r, int q) {
+    uint32_t v = 0;
+    for (int i = 0; i < q && i < 8; i++) v |= ((r >> (3 * i)) & 3u) << (2 * i);
+    return v;
+}
+// (regions are multiples of 32 bits: q 7: 16 Kbit, 6: 4 Kbit, 5: 1 Kbit, 4: 256, 3: 64, 2 and 1: a word each)
+M2_HD uint32_t m2_tail_region(int q) {
+    return q >= 7 ? 0u : q == 6 ? 16384u : q == 5 ? 20480u : q == 4 ? 21504u : q == 3 ? 21760u : q == 2 ? 21824u : 21856u;
+}
+// Behind the exact regions (bit 21 888 of the second bitmap's 32 768): one BYTE per string of q <= 4 characters -- the first
+// adapter that begins with it (0xFF: none).  An error-free overlap of q characters IS "the read's last q characters are
+// adapter[0:q]": every read looks its own end up there and merges pack_best(q, 0, adapter, ...) -- no event, no directory walk
+// (round 6; 1.9 entries per read of C4 went through the directory for this before).  The candidate is the first adapter
+// WITHOUT a pair (the merge keeps the higher score, then fewer errors, then the first adapter -- kernels.h: pack_best; an
+// adapter whose pair exists gets its answer from the scan, and that answer may be worth less than this overlap: at rate 0.2
+// five characters with one mismatch have more matches and the same score): behind the tables, per q, a byte per adapter =
+// the next adapter with the same first q characters (0xFF: none).
+#define CAH_M2_FIXED_WORD (CAH_M2_BM8_WORDS + 688)          // word of the bitmap array where the tables begin
+#define CAH_M2_FIXED_MAXQ 4
+M2_HD uint32_t m2_fixed_off(int q) { return q >= 4 ? 0u : q == 3 ? 256u : q == 2 ? 320u : 336u; }   // bytes; 340 in all
+M2_HD uint32_t m2_fixed_next(int q) { return 344u + 128u * (uint32_t)(q - 1); }                       // bytes; up to 856
+M2_HD uint32_t m2_bit(uint32_t r, int qc, int cls) {
+    if (qc >= 8 || cls == 0) return m2_index(r, qc);
+    return CAH_M2_BM8_WORDS * 32u + m2_tail_region(qc) + m2_pack2(r, qc);
+}
 
 struct CahMulti2Header {
     int32_t ok;
@@ -352,10 +382,10 @@ inline bool m2_build(const std::vector<std::string>& adapters, const int32_t* th
         }
         t.ref_begin[(size_t)a + 1] = (int32_t)(t.ref_list.size() / 2);
     }
-    if (ents.size() > CAH_M2_MAX_ENTRIES) return false;
-    h.n_entries = (uint32_t)ents.size();
     t.dir.assign(CAH_M2_SLOTS, 0);
     t.bitmap.assign(CAH_M2_BM_WORDS, 0u);
+    uint8_t* const fixed_tab = reinterpret_cast<uint8_t*>(t.bitmap.data() + CAH_M2_FIXED_WORD);
+    for (int i = 0; i < 856; i++) fixed_tab[i] = 0xFFu;
     for (int c = 0; c < 4; c++)
         for (int q = 0; q < 9; q++) { h.open_L[c][q] = -1; h.close_L[c][q] = 1000; }
     int max_q = 1;
@@ -367,7 +397,21 @@ inline bool m2_build(const std::vector<std::string>& adapters, const int32_t* th
         const uint32_t code = m2_encode(e.kmer);
         if (code & 0x24924924u) return false;                        // not plain ACGT
         const uint32_t idx = m2_index(code, qc);
-        t.bitmap[m2_bit(idx, qc) >> 5] |= 1u << (idx & 31);
+        // an error-free overlap of q <= 4 characters: the table of first adapters (CAH_M2_FIXED_WORD), no entry
+        const bool fixed = e.cls == M2_SHORT && e.dlo == q && e.dhi == q && q <= CAH_M2_FIXED_MAXQ;
+        if (fixed) {
+            // (the adapters of a string in ascending order: head in the table, then the chain)
+            if (e.adapter >= 128) return false;
+            uint8_t* at = &fixed_tab[m2_fixed_off(q) + m2_pack2(code, q)];
+            while (*at != 0xFFu && *at < e.adapter) at = &fixed_tab[m2_fixed_next(q) + *at];
+            if (*at != (uint8_t)e.adapter) {
+                fixed_tab[m2_fixed_next(q) + (uint32_t)e.adapter] = *at;
+                *at = (uint8_t)e.adapter;
+            }
+        } else {
+            const uint32_t bit = m2_bit(code, qc, e.cls);
+            t.bitmap[bit >> 5] |= 1u << (bit & 31);
+        }
         // which whole-adapter chunk is it?  (no answer when the string is two of them or occurs elsewhere in the adapter too:
         // an alignment could then hold the occurrence at another offset.  A string that is a k-mer of a tail class or an
         // error-free group as well has an entry of its own there: where its occurrence stands for rows of the last column
@@ -382,17 +426,19 @@ inline bool m2_build(const std::vector<std::string>& adapters, const int32_t* th
             for (size_t at = ad.find(e.kmer); at != std::string::npos; at = ad.find(e.kmer, at + 1)) occurrences++;
             if (times == 1 && occurrences == 1) pchunk = 1 + which;
         }
-        placed.push_back({idx & (CAH_M2_SLOTS - 1), code, m2_meta(e.adapter, q, e.cls, e.dlo, e.dhi, pchunk)});
+        if (!fixed) placed.push_back({idx & (CAH_M2_SLOTS - 1), code, m2_meta(e.adapter, q, e.cls, e.dlo, e.dhi, pchunk)});
         h.q_mask[e.cls] |= 1 << qc;
         h.open_L[e.cls][qc] = std::max(h.open_L[e.cls][qc], e.dhi);
         h.close_L[e.cls][qc] = std::min(h.close_L[e.cls][qc], e.dlo);
         if (e.cls != M2_W) h.span[e.cls] = std::max(h.span[e.cls], e.dhi);
         max_q = std::max(max_q, q);
         if (e.cls == M2_SHORT) {
-            if (e.dlo == q && e.dhi == q) h.qm_fixed |= 1 << qc; else nonfixed_mask[M2_SHORT] |= 1 << qc;
+            if (fixed) h.qm_fixed |= 1 << qc; else nonfixed_mask[M2_SHORT] |= 1 << qc;
         } else if (e.cls != M2_W) nonfixed_mask[e.cls] |= 1 << qc;
         if (e.cls == M2_HI || e.cls == M2_LO) h.win_dist[e.cls] = std::max(h.win_dist[e.cls], e.dhi + 1);
     }
+    if (placed.size() > CAH_M2_MAX_ENTRIES) return false;
+    h.n_entries = (uint32_t)placed.size();
     std::stable_sort(placed.begin(), placed.end(), [](const Placed& x, const Placed& y) { return x.home < y.home; });
     t.entries.clear();
     for (size_t i = 0; i < placed.size();) {

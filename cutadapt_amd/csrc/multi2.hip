@@ -88,7 +88,7 @@ __host__ __device__ inline M2Layout m2_layout(const int n_entries, const int n_a
     L.rlast = o; o += M2_WAVES * WAVE * 4;
     L.pages = o; o += M2_WAVES * CAH_M2_PAIR_CLASSES * 8;
     L.misc = o; o += 64 + M2_TILE_RING * 8;
-    L.entries = o; o += (unsigned)((n_entries + 1) & ~1) * 8;
+    L.entries = o; o += (unsigned)((n_entries + 2) & ~1) * 8;            // (+ one slot: the walk reads entries in twos)
     L.seen = o; o += M2_WAVES * WAVE * words * 4;
     L.wide = o; o += M2_WAVES * WAVE * 8;                               // {smallest, largest} adapter + 1 whose pair saw a further hit
     L.total = o;
@@ -581,16 +581,22 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
             return m2_cls(e.meta) == cls && (q < 8 ? q : 8) == qc && (r & m2_mask(q)) == e.key && p - q + 1 >= 0 &&
                    m2_in_window(e.meta, n - (p - q + 1));
         };
+        // (two entries per step -- one ds_read2_b64: the walk is a chain of dependent LDS reads, its length the longest home
+        // among the round's 64 events; the slot behind the last entry exists: m2_layout)
         int uf = -1, more = 0;
         while (m2_any(left > 0)) {
             M2_COUNT(11, 1);
-            const bool on = left > 0;
-            const CahM2Slot e = s_ent[on ? u : 0];
-            const bool ok = on && entry_ok(e);
-            more += (ok && uf >= 0) ? 1 : 0;
-            uf = (ok && uf < 0) ? u : uf;
-            ++u; --left;
+            const bool on0 = left > 0, on1 = left > 1;
+            const int ua = on0 ? u : 0;
+            const CahM2Slot e0 = s_ent[ua], e1 = s_ent[ua + 1];
+            const bool ok0 = on0 && entry_ok(e0), ok1 = on1 && entry_ok(e1);
+            more += (ok0 && uf >= 0) ? 1 : 0;
+            uf = (ok0 && uf < 0) ? u : uf;
+            more += (ok1 && uf >= 0) ? 1 : 0;
+            uf = (ok1 && uf < 0) ? u + 1 : uf;
+            u += 2; left -= 2;
         }
+        u = m2_dir_begin(d) + m2_dir_count(d);                          // (an odd home: the walk looked one slot too far)
         {
             // (a home's count saturates at CAH_M2_MAX_GROUP -- adapters that share their k-mers: such a home is walked while
             // the entries are its own)
@@ -686,9 +692,14 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
         while (ring_count) resolve_round();
     };
     // one bitmap probe: does a k-mer of index class qc end with the word r?
+    // (class W and index class 8: the hashed bitmap; a tail class's k-mer of fewer characters: its exact one -- multi2.h)
     auto probe = [&](const uint32_t r, const int qc) -> bool {
         const uint32_t idx = m2_index(r, qc);
-        return ((s_bm[m2_bit(idx, qc) >> 5] >> (idx & 31)) & 1u) != 0;
+        return ((s_bm[idx >> 5] >> (idx & 31)) & 1u) != 0;
+    };
+    auto probe_tail = [&](const uint32_t r, const int qc) -> bool {
+        const uint32_t bit = m2_bit(r, qc, M2_SHORT);
+        return ((s_bm[bit >> 5] >> (bit & 31)) & 1u) != 0;
     };
 
     // first / last position each tail mask is probed at (a k-mer of index class qc that ends at p starts n - p + q - 1
@@ -801,6 +812,15 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
                             uint32_t* const keep = reinterpret_cast<uint32_t*>(const_cast<unsigned char*>(row) + 16 * (c - 1));
                             keep[0] = r_prev; keep[1] = rr5; keep[2] = r;
                         }
+                        // the eight characters up to the chunk's first at two bits each (multi2.h: m2_pack2)
+                        const uint32_t x0 = rr[0];
+                        const uint32_t y0 = (x0 & 0x030C30C3u) | ((x0 >> 1) & 0x0C30C30Cu);            // pairs: four bits in six
+                        // ... and rolled along the chunk: from here on the chunk's words are needed at two bits per character only
+                        // (the events take theirs from r_prev / rr5 / r)
+                        uint32_t rr2[16];
+                        rr2[0] = (y0 & 0xFu) | ((y0 >> 2) & 0xF0u) | ((y0 >> 4) & 0xF00u) | ((y0 >> 6) & 0xF000u);
+#pragma unroll
+                        for (int t = 1; t < 16; ++t) rr2[t] = (rr2[t - 1] << 2) | (rr[t] & 3u);
 #pragma unroll 1
                         for (int j = 0; j < tm_n; ++j) {
                             // (the mask's constants by a chain of scalar selects: the loop stays rolled, ONE copy of the probes)
@@ -809,23 +829,34 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
                             const int phi = j == 0 ? tm_phi[0] : (j == 1 ? tm_phi[1] : (j == 2 ? tm_phi[2] : tm_phi[3]));
                             if (pos + 16 <= plo || pos > phi) continue;                    // wave-uniform
                             unsigned h16 = 0;
-                            if (w_only8 && qc == 8) {
-                                h16 = hits;                                                // the main pass's own probe
-                            } else {
-                                const uint32_t msk = m2_mask(qc), salt = m2_salt(qc);
-                                const uint32_t region = qc >= 8 ? 0u : CAH_M2_BM8_WORDS * 32u, keep15 = qc >= 8 ? 0xFFFFu : 0x7FFFu;
-                                uint32_t wd2[16];
+                            if (qc >= 8) {
+                                if constexpr (w_only8) {
+                                    h16 = hits;                                            // the main pass's own probe
+                                } else {
+                                    uint32_t wd2[16];
 #pragma unroll
-                                for (int t = 0; t < 16; ++t) {
-                                    const uint32_t key = rr[t] & msk;
-                                    const uint32_t idx = ((key ^ (key >> 8)) ^ salt) & keep15;
-                                    wd2[t] = s_bm[(region + idx) >> 5];
+                                    for (int t = 0; t < 16; ++t) {
+                                        const uint32_t idx = (rr[t] ^ (rr[t] >> 8)) & 0xFFFFu;
+                                        wd2[t] = s_bm[idx >> 5];
+                                    }
+#pragma unroll
+                                    for (int t = 0; t < 16; ++t) {
+                                        const uint32_t idx = rr[t] ^ (rr[t] >> 8);
+                                        h16 |= ((wd2[t] >> (idx & 31)) & 1u) << t;
+                                    }
                                 }
+                            } else {
+                                // the exact bitmap of the index class: the k-mer at two bits per character
+                                const uint32_t msk2 = (1u << (2 * qc)) - 1u;
+                                const uint32_t region = CAH_M2_BM8_WORDS * 32u + m2_tail_region(qc);   // (a multiple of 32)
+                                // (eight reads in flight at a time: the kernel has no register to spare)
 #pragma unroll
-                                for (int t = 0; t < 16; ++t) {
-                                    const uint32_t key = rr[t] & msk;
-                                    const uint32_t idx = (key ^ (key >> 8)) ^ salt;
-                                    h16 |= ((wd2[t] >> (idx & 31)) & 1u) << t;
+                                for (int t0 = 0; t0 < 16; t0 += 8) {
+                                    uint32_t wd2[8];
+#pragma unroll
+                                    for (int t = 0; t < 8; ++t) wd2[t] = s_bm[(region + (rr2[t0 + t] & msk2)) >> 5];
+#pragma unroll
+                                    for (int t = 0; t < 8; ++t) h16 |= ((wd2[t] >> (rr2[t0 + t] & msk2 & 31u)) & 1u) << (t0 + t);
                                 }
                             }
                             if (phi - pos < 15) h16 &= (2u << (phi - pos)) - 1u;          // positions behind the mask's last
@@ -910,38 +941,24 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
                 M2_STAMP(8);
             }
             if (qm_fixed) {
-                cur_cls = M2_SHORT;
-                // E0 k-mers that must be the read's last q characters (overlaps below 5): every lane looks its own read up --
-                // no events, no atomics on the bitsets (all other classes are resolved), and the suffix compares of a read
-                // merge into ONE best key
+                // error-free overlaps of q <= 4 characters: "the read's last q characters are adapter[0:q]" -- every lane looks
+                // its own read's end up in the table of first adapters (multi2.h: CAH_M2_FIXED_WORD): no events, no walk
+                const uint8_t* const s_fixed = reinterpret_cast<const uint8_t*>(s_bm + CAH_M2_FIXED_WORD);
+                const uint32_t* const ss = s_seen + lane * words;
                 unsigned long long bestk = 0;
-                uint32_t* const ss = s_seen + lane * words;
-#pragma unroll 1
-                for (int qrest = qm_fixed; qrest; qrest &= qrest - 1) {
-                    const int qc = __builtin_ctz((unsigned)qrest);
-                    const bool h = valid && probe(rlast, qc);
-                    const uint32_t d = h ? (uint32_t)s_dir[m2_index(rlast, qc) & (CAH_M2_SLOTS - 1)] : 0u;
-                    int u = m2_dir_begin(d), left = m2_dir_count(d);
-                    while (m2_any(left > 0)) {
-                        const bool on = left > 0;
-                        const CahM2Slot e = s_ent[on ? u : 0];
-                        const int q = m2_q(e.meta);
-                        const bool match = on && m2_cls(e.meta) == M2_SHORT && (q < 8 ? q : 8) == qc && q <= n &&
-                                           m2_in_window(e.meta, q) && (rlast & m2_mask(q)) == e.key;
-                        const int adapter = m2_adapter(e.meta);
-                        const unsigned bit = 1u << (adapter & 31);
-                        const int word = adapter >> 5;
-                        const unsigned old = ss[word];
-                        if (match && (old & bit) == 0) {
-                            ss[word] = old | bit;
-                            const int i = m2_exact_tail(rlast, s_prefix[adapter], min_overlap, lmax0, n);
-                            const unsigned long long kk = i > 0 ? pack_best(i, 0, adapter, i, n - skip - i, n - skip) : 0ull;
-                            bestk = kk > bestk ? kk : bestk;
-                        }
-                        ++u; --left;
-                        // (a saturated home goes on while the entries are its own)
-                        if (left == 0 && m2_dir_count(d) == CAH_M2_MAX_GROUP && u < n_entries &&
-                            m2_home_of(s_ent[u].key, s_ent[u].meta) == (m2_index(rlast, qc) & (CAH_M2_SLOTS - 1))) left = 1;
+#pragma unroll
+                for (int q = 1; q <= CAH_M2_FIXED_MAXQ; ++q) {
+                    if (!((qm_fixed >> q) & 1)) continue;                              // wave-uniform
+                    const bool plain = (rlast & m2_mask(q) & 0x24924924u) == 0u;      // the last q characters are A, C, G, T
+                    unsigned adapter = (valid && plain && q <= n - skip) ? s_fixed[m2_fixed_off(q) + m2_pack2(rlast, q)] : 0xFFu;
+                    // (an adapter whose pair exists is the scan's business: the next one that begins with these characters)
+                    while (m2_any(adapter != 0xFFu && ((ss[(adapter & 127u) >> 5] >> (adapter & 31u)) & 1u) != 0u)) {
+                        const bool taken = adapter != 0xFFu && ((ss[(adapter & 127u) >> 5] >> (adapter & 31u)) & 1u) != 0u;
+                        if (taken) adapter = s_fixed[m2_fixed_next(q) + adapter];
+                    }
+                    if (adapter != 0xFFu) {
+                        const unsigned long long kk = pack_best(q, 0, (int)adapter, q, n - skip - q, n - skip);
+                        bestk = kk > bestk ? kk : bestk;
                     }
                 }
                 if (bestk) atomicMax(a.best_key + (a.first_read + base + lane), bestk);

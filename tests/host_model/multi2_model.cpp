@@ -22,6 +22,11 @@ static inline unsigned long long pack_best(int score, int errors, int adapter, i
 
 namespace {
 
+// developer statistics (M2M_PASS_STATS=1): per event pass (8 = class W, 9 = the fixed E0 look-up) events / events whose
+// k-mer is an entry's / ... inside that entry's window
+long long g_pass[10][3];
+int g_cur_pass = 8;
+
 struct Pair { int adapter; unsigned flags; int key; int cls = M2_W; };   // cls: the class the pair was emitted in (the kernel: its page's)
 
 struct ReadState {
@@ -45,9 +50,11 @@ void resolve(const M2Tables& t, ReadState& st, uint32_t r, int qc, int cls, int 
         const uint32_t meta = e.meta;
         const int q = m2_q(meta);
         if (m2_cls(meta) != cls || std::min(q, 8) != qc || (r & m2_mask(q)) != e.key) continue;
+        g_pass[g_cur_pass][1]++;
         const int dist = n - (p - q + 1);
         const int a = m2_adapter(meta);
         if (p - q + 1 < 0 || !m2_in_window(meta, dist)) continue;
+        g_pass[g_cur_pass][2]++;
         // (a further hit of a pair that exists: the kernel sets the pair's "again" bit -- seen & again = flagged)
         if (st.seen[a]) { st.wideonly[a] = true; continue; }
         st.seen[a] = true;
@@ -63,7 +70,7 @@ void resolve(const M2Tables& t, ReadState& st, uint32_t r, int qc, int cls, int 
     }
 }
 
-void filter_read(const M2Tables& t, const uint8_t* q, int n, ReadState& st) {
+void filter_read(const M2Tables& t, const uint8_t* q, int n, ReadState& st, int pad = 0) {
     const CahMulti2Header& h = t.hdr;
     memset(st.seen, 0, sizeof(st.seen));
     memset(st.wideonly, 0, sizeof(st.wideonly));
@@ -71,16 +78,17 @@ void filter_read(const M2Tables& t, const uint8_t* q, int n, ReadState& st) {
     uint32_t r = 0x24924924u;                                         // ten invalid characters
     for (int p = 0; p < n; p++) { r = (r << 3) | m2_code(q[p]); rr[(size_t)p] = r; }
     const uint32_t rlast = n > 0 ? rr[(size_t)n - 1] : 0x24924924u;
-    auto probe = [&](int p, int qc) {
-        const uint32_t idx = m2_index(rr[(size_t)p], qc);
-        return ((t.bitmap[m2_bit(idx, qc) >> 5] >> (idx & 31)) & 1u) != 0;
+    auto probe = [&](int p, int qc, int cls) {
+        const uint32_t bit = m2_bit(rr[(size_t)p], qc, cls);
+        return ((t.bitmap[bit >> 5] >> (bit & 31)) & 1u) != 0;
     };
     // class W: every position, every index class of the class
     for (int p = 0; p < n; p++)
         for (int qc = 1; qc <= 8; qc++) {
-            if (!((h.q_mask[M2_W] >> qc) & 1) || !probe(p, qc)) continue;
+            if (!((h.q_mask[M2_W] >> qc) & 1) || !probe(p, qc, M2_W)) continue;
             if (st.first < 0) st.first = p & ~15;
             st.events[M2_W]++;
+            g_cur_pass = 8; g_pass[8][0]++;
             resolve(t, st, rr[(size_t)p], qc, M2_W, p, n, rlast);
         }
     // the tail classes: the event passes in class order, each over the positions its window opens (the kernel probes a
@@ -90,16 +98,23 @@ void filter_read(const M2Tables& t, const uint8_t* q, int n, ReadState& st) {
         const int qx = qc < 8 ? qc : CAH_M2_MAXQ;                      // the longest k-mer of the index class
         const int plo = std::max(0, n + qc - 1 - h.tq_open[j]), phi = std::min(n - 1, n + qx - 1 - h.tq_close[j]);
         for (int p = plo; p <= phi; p++) {
-            if (!probe(p, qc)) continue;
+            if (!probe(p, qc, cls)) continue;
             st.events[cls]++;
+            g_cur_pass = j; g_pass[j][0]++;
             resolve(t, st, rr[(size_t)p], qc, cls, p, n, rlast);
         }
     }
-    // E0 entries that must be the read's last q characters: every read looks its own end up
-    for (int qc = 1; qc <= 8; qc++) {
-        if (!((h.qm_fixed >> qc) & 1) || n < 1 || !probe(n - 1, qc)) continue;
+    // error-free overlaps of q <= 4 characters: every read looks its own end up in the table of first adapters
+    // (multi2.h: CAH_M2_FIXED_WORD; the kernel's skip = pad: the NULs in front of a view are not characters of the read)
+    const uint8_t* const fixed_tab = reinterpret_cast<const uint8_t*>(t.bitmap.data() + CAH_M2_FIXED_WORD);
+    for (int qq = 1; qq <= CAH_M2_FIXED_MAXQ; qq++) {
+        if (!((h.qm_fixed >> qq) & 1) || qq > n - pad || (rlast & m2_mask(qq) & 0x24924924u)) continue;
+        unsigned a = fixed_tab[m2_fixed_off(qq) + m2_pack2(rlast, qq)];
+        while (a != 0xFFu && st.seen[a]) a = fixed_tab[m2_fixed_next(qq) + a];      // (a pair that exists: the scan's business)
+        if (a == 0xFFu) continue;
+        g_cur_pass = 9; g_pass[9][0]++;
         st.events[M2_SHORT]++;
-        resolve(t, st, rlast, qc, M2_SHORT, n - 1, n, rlast);
+        st.exact.push_back({(int)a, qq});
     }
 }
 
@@ -130,6 +145,17 @@ int m2m_match_batch(const char* adapters, int A, int m, const void* blobs, int32
     M2Tables t;
     const CahMatcher& m0 = mts[0];
     if (!m2_build(ads, m0.thr_last, m0.kacc, m0.k, m0.min_overlap, ref, t)) return 1;
+    const bool pass_stats = getenv("M2M_PASS_STATS") != nullptr;
+    if (pass_stats) {
+        memset(g_pass, 0, sizeof(g_pass));
+        const CahMulti2Header& h = t.hdr;
+        fprintf(stderr, "entries %d; masks:", (int)t.entries.size());
+        for (int j = 0; j < h.tm_n; j++) fprintf(stderr, " [qc %d: dist %d..%d]", h.tm_qc[j], h.tm_close[j], h.tm_open[j]);
+        fprintf(stderr, "\n");
+        int cnt[4][16] = {};
+        for (const CahM2Slot& e : t.entries) cnt[m2_cls(e.meta)][m2_q(e.meta)]++;
+        for (int c = 0; c < 4; c++) for (int q = 0; q < 16; q++) if (cnt[c][q]) fprintf(stderr, "  class %d q %d: %d entries\n", c, q, cnt[c][q]);
+    }
     BackScanParams p;
     p.m = m0.m; p.k = m0.k; p.kacc = m0.kacc; p.min_overlap = m0.min_overlap; p.half_m = m0.m / 2;
     const int kind = bs_kind_of(p.m);
@@ -157,13 +183,23 @@ int m2m_match_batch(const char* adapters, int A, int m, const void* blobs, int32
         for (int i = 0; i < n; i++) invalid = invalid || q[i] >= 0x80;
         if (invalid) { status[r] = 2; continue; }
         ReadState st;
-        filter_read(t, q, n, st);
+        filter_read(t, q, n, st, pad);
         unsigned long long bestkey = 0;
         for (auto& ex : st.exact) {
             bestkey = std::max(bestkey, pack_best(ex.second, 0, ex.first, ex.second, nv - ex.second, nv));
             if (stats) stats[3]++;
         }
         if (stats) { stats[4] += st.conservative; for (int c = 0; c < 4; c++) stats[8 + c] += st.events[c]; }
+        if (pass_stats && r == n_reads - 1) {
+            const CahMulti2Header& h = t.hdr;
+            for (int j = 0; j < 10; j++) {
+                if (!g_pass[j][0]) continue;
+                if (j < 8) fprintf(stderr, "  pass %d (class %d, qc %d, dist %d..%d):", j, h.tq_cls[j], h.tm_qc[h.tq_mi[j]], h.tq_close[j], h.tq_open[j]);
+                else fprintf(stderr, j == 8 ? "  class W:" : "  fixed E0:");
+                fprintf(stderr, " %.3f events per read, %.3f with an entry's k-mer, %.3f inside its window\n", g_pass[j][0] / (double)n_reads,
+                        g_pass[j][1] / (double)n_reads, g_pass[j][2] / (double)n_reads);
+            }
+        }
         // the byte k_multi_stream leaves per read: the adapter whose pair saw a further hit
         unsigned wm = CAH_M2_NO_FLAG;
         for (int a = 0; a < A; a++)
