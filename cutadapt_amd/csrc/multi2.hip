@@ -614,6 +614,7 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
                 }
             }
         }
+        M2_TOC(15);
         while (m2_any(uf >= 0)) {
             const bool is_ref = uf >= 0;
             const CahM2Slot e = s_ent[is_ref ? uf : 0];
@@ -849,14 +850,16 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
                                 // the exact bitmap of the index class: the k-mer at two bits per character
                                 const uint32_t msk2 = (1u << (2 * qc)) - 1u;
                                 const uint32_t region = CAH_M2_BM8_WORDS * 32u + m2_tail_region(qc);   // (a multiple of 32)
-                                // (eight reads in flight at a time: the kernel has no register to spare)
+                                // (four positions at a time, and only those the mask's window [plo, phi] reaches: a window
+                                // of 8 to 20 positions lies in two or three chunks and would cost 32 to 48 probes otherwise)
 #pragma unroll
-                                for (int t0 = 0; t0 < 16; t0 += 8) {
-                                    uint32_t wd2[8];
+                                for (int t0 = 0; t0 < 16; t0 += 4) {
+                                    if (pos + t0 + 4 <= plo || pos + t0 > phi) continue;   // wave-uniform
+                                    uint32_t wd2[4];
 #pragma unroll
-                                    for (int t = 0; t < 8; ++t) wd2[t] = s_bm[(region + (rr2[t0 + t] & msk2)) >> 5];
+                                    for (int t = 0; t < 4; ++t) wd2[t] = s_bm[(region + (rr2[t0 + t] & msk2)) >> 5];
 #pragma unroll
-                                    for (int t = 0; t < 8; ++t) h16 |= ((wd2[t] >> (rr2[t0 + t] & msk2 & 31u)) & 1u) << (t0 + t);
+                                    for (int t = 0; t < 4; ++t) h16 |= ((wd2[t] >> (rr2[t0 + t] & msk2 & 31u)) & 1u) << (t0 + t);
                                 }
                             }
                             if (phi - pos < 15) h16 &= (2u << (phi - pos)) - 1u;          // positions behind the mask's last

@@ -28,5 +28,5 @@ names = ["wait+slot0", "walk half 1", "slot1", "walk half 2", "drain W", "sweep 
 for i, nm in enumerate(names):
     print(f"  {nm:12s} mean {d[sel, i].mean():9.0f}  min {d[sel, i].min():7d}  max {d[sel, i].max():7d}")
 print("  piece total mean", np.diff(t[4:41, 0]).mean())
-print("  resolve cycles per piece (x launches): setup", t[sel, 12].mean(), "through the walk", t[sel, 13].mean(), "through the flush", t[sel, 14].mean())
+print("  resolve cycles per piece (x launches): setup", t[sel, 12].mean(), "through the directory walk", t[sel, 15].mean(), "through the emission", t[sel, 13].mean(), "through the flush", t[sel, 14].mean())
 print("  rounds per piece", (t[sel, 10] & 0xFFFFFFFF).mean(), "events per piece", (t[sel, 10] >> 32).mean(), "walk iterations", t[sel, 11].mean())
