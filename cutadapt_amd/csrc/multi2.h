@@ -53,9 +53,10 @@
 #define CAH_M2_SLOTS 4096            // directory slots: home = low 12 bits of the bitmap index -> (first entry, entries)
 #define CAH_M2_MAX_ENTRIES 2304
 #define CAH_M2_MAX_GROUP 15          // the directory's count field saturates here: a home with more entries is walked to its end (m2_home_of)
-#define CAH_M2_BM_WORDS 3072         // presence bitmaps: 64 Kbit for the index class 8 (probed at every character), then
-#define CAH_M2_BM8_WORDS 2048        // 32 Kbit shared by the shorter classes (probed in the tail sweeps only)
+#define CAH_M2_BM_WORDS 3112         // presence bitmaps: 64 Kbit hashed (class W, index class 8: probed at every character), then
+#define CAH_M2_BM8_WORDS 2048        // the tail classes' exact bitmaps and the tables of first adapters (m2_bit, CAH_M2_FIXED_WORD)
 #define CAH_M2_MAXQ 10
+#define CAH_M2_MAX_PASSES 12       // passes of the tail classes (their hit masks share eight registers)
 #define CAH_M2_EMPTY 0xFFFFFFFFu
 #define CAH_M2_WHOLE 255             // window value: the whole read
 #define CAH_M2_NEVER 1000
@@ -148,11 +149,14 @@ M2_HD uint32_t m2_pack2(uint32_t r, int q) {
     for (int i = 0; i < q && i < 8; i++) v |= ((r >> (3 * i)) & 3u) << (2 * i);
     return v;
 }
-// (regions are multiples of 32 bits: q 7: 16 Kbit, 6: 4 Kbit, 5: 1 Kbit, 4: 256, 3: 64, 2 and 1: a word each)
-M2_HD uint32_t m2_tail_region(int q) {
-    return q >= 7 ? 0u : q == 6 ? 16384u : q == 5 ? 20480u : q == 4 ? 21504u : q == 3 ? 21760u : q == 2 ? 21824u : 21856u;
+// (regions are multiples of 32 bits.  q 7: 16 Kbit shared by the tail classes; q 6: 4 Kbit for class hi and 4 for lo / E0; q 5:
+// 1 Kbit for hi / lo and 1 for E0 -- a pass of one class does not see the other's k-mers; q <= 4: shared)
+M2_HD uint32_t m2_tail_region(int q, int cls) {
+    return q >= 7 ? 0u : q == 6 ? (cls == 1 ? 16384u : 20480u) : q == 5 ? (cls == 3 ? 25600u : 24576u)
+         : q == 4 ? 26624u : q == 3 ? 26880u : q == 2 ? 26944u : 26976u;
 }
-// Behind the exact regions (bit 21 888 of the second bitmap's 32 768): one BYTE per string of q <= 4 characters -- the first
+#define CAH_M2_TAIL_BITS 27008u
+// Behind the exact regions (bit 27 008 of the second bitmap): one BYTE per string of q <= 4 characters -- the first
 // adapter that begins with it (0xFF: none).  An error-free overlap of q characters IS "the read's last q characters are
 // adapter[0:q]": every read looks its own end up there and merges pack_best(q, 0, adapter, ...) -- no event, no directory walk
 // (round 6; 1.9 entries per read of C4 went through the directory for this before).  The candidate is the first adapter
@@ -160,13 +164,13 @@ M2_HD uint32_t m2_tail_region(int q) {
 // adapter whose pair exists gets its answer from the scan, and that answer may be worth less than this overlap: at rate 0.2
 // five characters with one mismatch have more matches and the same score): behind the tables, per q, a byte per adapter =
 // the next adapter with the same first q characters (0xFF: none).
-#define CAH_M2_FIXED_WORD (CAH_M2_BM8_WORDS + 688)          // word of the bitmap array where the tables begin
+#define CAH_M2_FIXED_WORD (CAH_M2_BM8_WORDS + 844)          // word of the bitmap array where the tables begin (214 words)
 #define CAH_M2_FIXED_MAXQ 4
 M2_HD uint32_t m2_fixed_off(int q) { return q >= 4 ? 0u : q == 3 ? 256u : q == 2 ? 320u : 336u; }   // bytes; 340 in all
 M2_HD uint32_t m2_fixed_next(int q) { return 344u + 128u * (uint32_t)(q - 1); }                       // bytes; up to 856
 M2_HD uint32_t m2_bit(uint32_t r, int qc, int cls) {
     if (qc >= 8 || cls == 0) return m2_index(r, qc);
-    return CAH_M2_BM8_WORDS * 32u + m2_tail_region(qc) + m2_pack2(r, qc);
+    return CAH_M2_BM8_WORDS * 32u + m2_tail_region(qc, cls) + m2_pack2(r, qc);
 }
 
 struct CahMulti2Header {
@@ -178,16 +182,15 @@ struct CahMulti2Header {
     int32_t open_L[4][9];          // [cls][qc]: the largest dhi of the class's entries of that index class (-1: none)
     int32_t close_L[4][9];         // ... and the smallest dlo
     int32_t win_dist[4];           // classes hi, lo: a pair's scan window starts at column n - win_dist
-    // The tail classes are probed inside the main pass, in the read's last chunks: one hit MASK per index class that a
-    // tail class uses (<= 4: the probe depends on the index class alone) ...
-    int32_t tm_n;
-    int32_t tm_qc[4];
-    int32_t tm_open[4], tm_close[4];   // a k-mer of the mask's index class starts tm_close .. tm_open characters before the end
-    // ... and, behind the main pass, one EVENT PASS per (class, index class) in class order (hi, lo, E0; <= 8): the hits
-    // of mask tq_mi[j] whose position fits the pass's own window become events of class tq_cls[j]
+    // The tail classes are probed inside the main pass, in the read's last chunks: one PASS per (class, index class) in class
+    // order (hi, lo, E0; <= 8) with a hit mask of its own -- 32 positions from the pass's first (a k-mer of the pass starts
+    // tq_close .. tq_open characters before the end; a wider window is two passes) --, whose hits become events of class
+    // tq_cls[j] behind the main pass, class by class.  A pass of at most 16 positions shares its mask register with another
+    // such pass (tq_slot: which of the eight registers, tq_shift: 0 or 16)
     int32_t tq_n;
-    int32_t tq_cls[8], tq_mi[8];
-    int32_t tq_open[8], tq_close[8];
+    int32_t tq_cls[CAH_M2_MAX_PASSES], tq_qc[CAH_M2_MAX_PASSES];
+    int32_t tq_open[CAH_M2_MAX_PASSES], tq_close[CAH_M2_MAX_PASSES];
+    int32_t tq_slot[CAH_M2_MAX_PASSES], tq_shift[CAH_M2_MAX_PASSES];
     // E0 entries that must be the read's last q characters (dlo == dhi == q: the rows below 5) never become events: every
     // lane looks its own read's end up.  (Measured, round 6: the other E0 entries the same way -- the word shifted by one
     // and two characters -- cost 560 VALU instructions per 64 reads more than their 0.5 events per read.)
@@ -452,24 +455,35 @@ inline bool m2_build(const std::vector<std::string>& adapters, const int32_t* th
     h.win_dist[M2_HI] = std::max(h.win_dist[M2_HI], h.win_dist[M2_LO]);
     if (h.win_dist[M2_LO] == 0) h.win_dist[M2_LO] = h.win_dist[M2_HI];
     h.tail_warm = max_q - 1;
-    // the probe masks (one per index class) and the event passes (class order: hi, lo, E0) of the tail classes
-    h.tm_n = 0; h.tq_n = 0;
+    // the passes of the tail classes (class order: hi, lo, E0); a pass's positions must fit its 32-bit hit mask
+    h.tq_n = 0;
     for (int c = M2_HI; c <= M2_SHORT; c++)
         for (int q = 1; q <= 8; q++) {
             if (!((nonfixed_mask[c] >> q) & 1)) continue;
-            int mi = -1;
-            for (int j = 0; j < h.tm_n; j++) if (h.tm_qc[j] == q) mi = j;
-            if (mi < 0) {
-                if (h.tm_n == 4) return false;
-                mi = h.tm_n++;
-                h.tm_qc[mi] = q; h.tm_open[mi] = -1; h.tm_close[mi] = 1000;
+            const int qx = q < 8 ? q : CAH_M2_MAXQ;
+            int close = h.close_L[c][q];
+            const int open = h.open_L[c][q];
+            // positions n + q - 1 - open .. n + qx - 1 - close: (open - close) + (qx - q) + 1 of them
+            while (close <= open) {
+                const int top = std::min(open, close + 31 - (qx - q));
+                if (h.tq_n == CAH_M2_MAX_PASSES) return false;
+                h.tq_cls[h.tq_n] = c; h.tq_qc[h.tq_n] = q; h.tq_open[h.tq_n] = top; h.tq_close[h.tq_n] = close;
+                h.tq_n++;
+                close = top + 1;
             }
-            h.tm_open[mi] = std::max(h.tm_open[mi], h.open_L[c][q]);
-            h.tm_close[mi] = std::min(h.tm_close[mi], h.close_L[c][q]);
-            if (h.tq_n == 8) return false;
-            h.tq_cls[h.tq_n] = c; h.tq_mi[h.tq_n] = mi; h.tq_open[h.tq_n] = h.open_L[c][q]; h.tq_close[h.tq_n] = h.close_L[c][q];
-            h.tq_n++;
         }
+    {
+        // mask registers: a pass of more than 16 positions takes one, two narrower ones share one
+        int slots = 0, half_open = -1;
+        for (int j = 0; j < h.tq_n; j++) {
+            const int q = h.tq_qc[j], qx = q < 8 ? q : CAH_M2_MAXQ;
+            const int width = (h.tq_open[j] - h.tq_close[j]) + (qx - q) + 1;
+            if (width > 16) { h.tq_slot[j] = slots++; h.tq_shift[j] = 0; }
+            else if (half_open >= 0) { h.tq_slot[j] = half_open; h.tq_shift[j] = 16; half_open = -1; }
+            else { h.tq_slot[j] = half_open = slots++; h.tq_shift[j] = 0; }
+        }
+        if (slots > 8) return false;
+    }
     t.prefix.assign((size_t)A, 0u);
     for (int a = 0; a < A; a++) {
         uint32_t p = 0;

@@ -181,20 +181,18 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
     };
     // (LDS keeps what the last block on this CU left: an entry of ITS map must not pass for one of ours)
     if (threadIdx.x < M2_TILE_RING) s_tilemap[threadIdx.x] = ~0ull;
-    // the event passes of the tail classes (multi2.h: tq_*), one packed word each: class | mask << 2 | index class << 4 |
-    // first bit << 8 | last bit << 16 of the pass's positions in its mask (bit b = position tail_base + b; first > last: none)
+    // the passes of the tail classes (multi2.h: tq_*), one packed word each: class | index class << 2 | first position << 8 |
+    // last position << 16 (first > last: no position of the pass lies in a read of n characters) | mask register << 24 | its
+    // upper half << 27
     uint32_t* const s_pass = reinterpret_cast<uint32_t*>(s_raw + LY.misc + 16);
-    if (threadIdx.x < 8) {
+    if (threadIdx.x < CAH_M2_MAX_PASSES) {
         const int j = (int)threadIdx.x;
         uint32_t pw = (1u << 8);                                        // (first 1, last 0: an empty pass)
         if (j < hd->tq_n) {
-            int p0 = n;
-            for (int t = 0; t < hd->tm_n; ++t) p0 = min(p0, max(0, n + hd->tm_qc[t] - 1 - hd->tm_open[t]));
-            const int tb = p0 & ~15;
-            const int mi = hd->tq_mi[j], qc = hd->tm_qc[mi], qx = qc < 8 ? qc : CAH_M2_MAXQ;
-            const int b_lo = max(0, n + qc - 1 - hd->tq_open[j]) - tb, b_hi = min(n - 1, n + qx - 1 - hd->tq_close[j]) - tb;
-            if (b_hi >= 0 && b_lo <= 63 && b_hi >= b_lo)
-                pw = (uint32_t)hd->tq_cls[j] | ((uint32_t)mi << 2) | ((uint32_t)qc << 4) | ((uint32_t)max(b_lo, 0) << 8) | ((uint32_t)min(b_hi, 63) << 16);
+            const int qc = hd->tq_qc[j], qx = qc < 8 ? qc : CAH_M2_MAXQ;
+            const int plo = max(0, n + qc - 1 - hd->tq_open[j]), phi = min(n - 1, n + qx - 1 - hd->tq_close[j]);
+            if (phi >= plo) pw = (uint32_t)hd->tq_cls[j] | ((uint32_t)qc << 2) | ((uint32_t)plo << 8) | ((uint32_t)phi << 16) |
+                                 ((uint32_t)hd->tq_slot[j] << 24) | (hd->tq_shift[j] ? 1u << 27 : 0u);
         }
         s_pass[j] = pw;
     }
@@ -214,7 +212,7 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
     // the tail classes (multi2.h): one hit mask per index class, probed in the read's last chunks; behind the main pass one
     // event pass per (class, index class) in class order.  Their constants are read from the header where they are used
     // (scalar loads; the kernel has no SGPR to keep 44 of them in)
-    const int tm_n = hd->tm_n, tq_n = hd->tq_n;
+    const int tq_n = hd->tq_n;
     const int qm_fixed = hd->qm_fixed;
     constexpr bool w_only8 = W8;
     const unsigned lane16 = (unsigned)lane * 16u;
@@ -703,19 +701,11 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
         return ((s_bm[bit >> 5] >> (bit & 31)) & 1u) != 0;
     };
 
-    // first / last position each tail mask is probed at (a k-mer of index class qc that ends at p starts n - p + q - 1
-    // characters before the end, q = qc -- or up to CAH_M2_MAXQ for index class 8), the first chunk that holds one
-    // (tail_base), and where that chunk sits in the slot's row (the launcher checked: behind the first half-row, at most
-    // four chunks to the read's end)
-    int tm_plo[4], tm_phi[4];
+    // the first position a pass is probed at (a k-mer of index class qc that ends at p starts n - p + q - 1 characters before
+    // the end, q = qc -- or up to CAH_M2_MAXQ for index class 8), the first chunk that holds one (tail_base), and where that
+    // chunk sits in the slot's row (the launcher checked: behind the first half-row, at most four chunks to the read's end)
     int tail_p0 = n;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int qc = hd->tm_qc[j], qx = qc < 8 ? qc : CAH_M2_MAXQ;
-        tm_plo[j] = j < tm_n ? max(0, n + qc - 1 - hd->tm_open[j]) : n;
-        tm_phi[j] = j < tm_n ? min(n - 1, n + qx - 1 - hd->tm_close[j]) : -1;
-        tail_p0 = min(tail_p0, tm_plo[j]);
-    }
+    for (int j = 0; j < tq_n; ++j) tail_p0 = min(tail_p0, max(0, n + hd->tq_qc[j] - 1 - hd->tq_open[j]));
     const int tail_base = tail_p0 & ~15;
     const int tail_off = H2 > 0 ? 16 * H1 : 0;                          // first position of the last half-row
     const int tail_unit0 = (tail_base - tail_off) >> 4;                 // row unit of the first tail chunk
@@ -742,7 +732,7 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
             uint32_t r_prev = r;                                        // the word five characters in front of the chunk (the chunk before's twelfth)
             uint32_t rlast = r;                                         // the word at the read's last character
             unsigned seen_chars = 0;
-            unsigned long long tm[4] = {0ull, 0ull, 0ull, 0ull};        // per tail slot: bit 16 k + t = a hit at tail_base + 16 k + t
+            uint32_t tm[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};          // per pass: bit b = a hit at the pass's first position + b
             uint32_t tw0[3] = {0u, 0u, 0u};                             // the three words of the first tail chunk
             cur_cls = M2_W;
             m2_u32x4 cur = (m2_u32x4)(0u);
@@ -823,12 +813,12 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
 #pragma unroll
                         for (int t = 1; t < 16; ++t) rr2[t] = (rr2[t - 1] << 2) | (rr[t] & 3u);
 #pragma unroll 1
-                        for (int j = 0; j < tm_n; ++j) {
-                            // (the mask's constants by a chain of scalar selects: the loop stays rolled, ONE copy of the probes)
-                            const int qc = hd->tm_qc[j];
-                            const int plo = j == 0 ? tm_plo[0] : (j == 1 ? tm_plo[1] : (j == 2 ? tm_plo[2] : tm_plo[3]));
-                            const int phi = j == 0 ? tm_phi[0] : (j == 1 ? tm_phi[1] : (j == 2 ? tm_phi[2] : tm_phi[3]));
-                            if (pos + 16 <= plo || pos > phi) continue;                    // wave-uniform
+                        for (int j = 0; j < tq_n; ++j) {
+                            // (the loop stays rolled: ONE copy of the probes; the pass's mask by a chain of scalar branches)
+                            const uint32_t pw = __builtin_amdgcn_readfirstlane(s_pass[j]);
+                            const int pcls = (int)(pw & 3u), qc = (int)((pw >> 2) & 15u);
+                            const int plo = (int)((pw >> 8) & 255u), phi = (int)((pw >> 16) & 255u);
+                            if (phi < plo || pos + 16 <= plo || pos > phi) continue;       // wave-uniform
                             unsigned h16 = 0;
                             if (qc >= 8) {
                                 if constexpr (w_only8) {
@@ -847,10 +837,10 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
                                     }
                                 }
                             } else {
-                                // the exact bitmap of the index class: the k-mer at two bits per character
+                                // the exact bitmap of the class and index class: the k-mer at two bits per character
                                 const uint32_t msk2 = (1u << (2 * qc)) - 1u;
-                                const uint32_t region = CAH_M2_BM8_WORDS * 32u + m2_tail_region(qc);   // (a multiple of 32)
-                                // (four positions at a time, and only those the mask's window [plo, phi] reaches: a window
+                                const uint32_t region = CAH_M2_BM8_WORDS * 32u + m2_tail_region(qc, pcls);   // (a multiple of 32)
+                                // (four positions at a time, and only those the pass's window [plo, phi] reaches: a window
                                 // of 8 to 20 positions lies in two or three chunks and would cost 32 to 48 probes otherwise)
 #pragma unroll
                                 for (int t0 = 0; t0 < 16; t0 += 4) {
@@ -862,13 +852,17 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
                                     for (int t = 0; t < 4; ++t) h16 |= ((wd2[t] >> (rr2[t0 + t] & msk2 & 31u)) & 1u) << (t0 + t);
                                 }
                             }
-                            if (phi - pos < 15) h16 &= (2u << (phi - pos)) - 1u;          // positions behind the mask's last
+                            if (phi - pos < 15) h16 &= (2u << (phi - pos)) - 1u;          // positions behind the pass's last
                             const int lo_t = plo - pos;
                             if (lo_t > 0) h16 &= ~((1u << lo_t) - 1u);
                             if (pos + 16 > n) h16 &= (1u << (n - pos)) - 1u;
                             if (!valid) h16 = 0;
-                            const unsigned long long add = (unsigned long long)h16 << (16 * kch);
-                            if (j == 0) tm[0] |= add; else if (j == 1) tm[1] |= add; else if (j == 2) tm[2] |= add; else tm[3] |= add;
+                            uint32_t add = lo_t > 0 ? h16 >> lo_t : h16 << (pos - plo);   // (bit b = position plo + b)
+                            if ((pw >> 27) & 1u) add <<= 16;                               // (a narrow pass in its register's upper half)
+                            const int sl = (int)((pw >> 24) & 7u);
+                            if (sl == 0) tm[0] |= add; else if (sl == 1) tm[1] |= add; else if (sl == 2) tm[2] |= add;
+                            else if (sl == 3) tm[3] |= add; else if (sl == 4) tm[4] |= add; else if (sl == 5) tm[5] |= add;
+                            else if (sl == 6) tm[6] |= add; else tm[7] |= add;
                         }
                     }
 #endif
@@ -911,23 +905,24 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
 #pragma unroll 1
                 for (int j = 0; j < tq_n; ++j) {
                     const uint32_t pw = __builtin_amdgcn_readfirstlane(s_pass[j]);
-                    const int pcls = (int)(pw & 3u), mi = (int)((pw >> 2) & 3u), qc = (int)((pw >> 4) & 15u);
-                    const int b_lo = (int)((pw >> 8) & 255u), b_hi = (int)((pw >> 16) & 255u);
-                    if (b_hi < b_lo) continue;                                             // wave-uniform: no position of the pass is in the read
+                    const int pcls = (int)(pw & 3u), qc = (int)((pw >> 2) & 15u);
+                    const int plo = (int)((pw >> 8) & 255u), phi = (int)((pw >> 16) & 255u);
+                    if (phi < plo) continue;                                               // wave-uniform: no position of the pass is in the read
                     if (pcls != prev_cls) {
                         drain();
                         M2_STAMP(4 + pcls);
                         prev_cls = pcls;
                         cur_cls = pcls;
                     }
-                    unsigned long long mk = mi == 0 ? tm[0] : (mi == 1 ? tm[1] : (mi == 2 ? tm[2] : tm[3]));
-                    // positions of the pass as bits of the mask (bit b = position tail_base + b)
-                    if (b_lo > 0) mk &= ~0ull << b_lo;
-                    if (b_hi < 63) mk &= (2ull << b_hi) - 1ull;
-                    while (m2_any(mk != 0ull)) {
-                        const bool mine = mk != 0ull;
-                        const int bit = mine ? (int)__builtin_ctzll(mk) : 0;
-                        mk &= mk - 1ull;
+                    const int sl = (int)((pw >> 24) & 7u);
+                    uint32_t mk = sl == 0 ? tm[0] : (sl == 1 ? tm[1] : (sl == 2 ? tm[2] : (sl == 3 ? tm[3] : (sl == 4 ? tm[4] : (sl == 5 ? tm[5] :
+                                  (sl == 6 ? tm[6] : tm[7]))))));
+                    // (a pass of at most 16 positions has half a register: the other half is another pass's)
+                    if (phi - plo < 16) mk = ((pw >> 27) & 1u) ? mk >> 16 : mk & 0xFFFFu;
+                    while (m2_any(mk != 0u)) {
+                        const bool mine = mk != 0u;
+                        const int bit = (mine ? (int)__builtin_ctz(mk) : 0) + plo - tail_base;   // bit b of the tail = position tail_base + b
+                        mk &= mk - 1u;
                         const int kch = bit >> 4, t = bit & 15;
                         // the chunk's three words: at its position - 5, + 5 and + 15
                         const int unit = max(tail_unit0 + kch - 1, 0);
@@ -1374,9 +1369,9 @@ bool multi2_read_len_ok(const CahMulti2Header& h, int n) {
     const int U = (n + 15) >> 4, H1 = U <= M2_HALF ? U : (U + 1) >> 1, H2 = U - H1;
     const int tail_off = H2 > 0 ? 16 * H1 : 0;
     // the tail slots are probed in the last chunks of the last half-row: every slot's first position must lie in it,
-    // and at most four chunks (the slots' hit masks are 64 bits) reach from there to the read's end
+    // and at most four chunks (the words of a tail chunk wait in the row unit in front of it) reach from there to the read's end
     int p0 = n;
-    for (int j = 0; j < h.tm_n; j++) p0 = std::min(p0, std::max(0, n + h.tm_qc[j] - 1 - h.tm_open[j]));
+    for (int j = 0; j < h.tq_n; j++) p0 = std::min(p0, std::max(0, n + h.tq_qc[j] - 1 - h.tq_open[j]));
     const int tail_base = p0 & ~15;
     if (tail_base < tail_off || n - tail_base > 64) return false;
     return true;

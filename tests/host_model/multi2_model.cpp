@@ -94,7 +94,7 @@ void filter_read(const M2Tables& t, const uint8_t* q, int n, ReadState& st, int 
     // the tail classes: the event passes in class order, each over the positions its window opens (the kernel probes a
     // mask per index class over the union of its passes' windows and hands every pass the hits inside its own)
     for (int j = 0; j < h.tq_n; j++) {
-        const int cls = h.tq_cls[j], qc = h.tm_qc[h.tq_mi[j]];
+        const int cls = h.tq_cls[j], qc = h.tq_qc[j];
         const int qx = qc < 8 ? qc : CAH_M2_MAXQ;                      // the longest k-mer of the index class
         const int plo = std::max(0, n + qc - 1 - h.tq_open[j]), phi = std::min(n - 1, n + qx - 1 - h.tq_close[j]);
         for (int p = plo; p <= phi; p++) {
@@ -149,9 +149,7 @@ int m2m_match_batch(const char* adapters, int A, int m, const void* blobs, int32
     if (pass_stats) {
         memset(g_pass, 0, sizeof(g_pass));
         const CahMulti2Header& h = t.hdr;
-        fprintf(stderr, "entries %d; masks:", (int)t.entries.size());
-        for (int j = 0; j < h.tm_n; j++) fprintf(stderr, " [qc %d: dist %d..%d]", h.tm_qc[j], h.tm_close[j], h.tm_open[j]);
-        fprintf(stderr, "\n");
+        fprintf(stderr, "entries %d, passes %d\n", (int)t.entries.size(), h.tq_n);
         int cnt[4][16] = {};
         for (const CahM2Slot& e : t.entries) cnt[m2_cls(e.meta)][m2_q(e.meta)]++;
         for (int c = 0; c < 4; c++) for (int q = 0; q < 16; q++) if (cnt[c][q]) fprintf(stderr, "  class %d q %d: %d entries\n", c, q, cnt[c][q]);
@@ -194,7 +192,7 @@ int m2m_match_batch(const char* adapters, int A, int m, const void* blobs, int32
             const CahMulti2Header& h = t.hdr;
             for (int j = 0; j < 10; j++) {
                 if (!g_pass[j][0]) continue;
-                if (j < 8) fprintf(stderr, "  pass %d (class %d, qc %d, dist %d..%d):", j, h.tq_cls[j], h.tm_qc[h.tq_mi[j]], h.tq_close[j], h.tq_open[j]);
+                if (j < 8) fprintf(stderr, "  pass %d (class %d, qc %d, dist %d..%d):", j, h.tq_cls[j], h.tq_qc[j], h.tq_close[j], h.tq_open[j]);
                 else fprintf(stderr, j == 8 ? "  class W:" : "  fixed E0:");
                 fprintf(stderr, " %.3f events per read, %.3f with an entry's k-mer, %.3f inside its window\n", g_pass[j][0] / (double)n_reads,
                         g_pass[j][1] / (double)n_reads, g_pass[j][2] / (double)n_reads);
