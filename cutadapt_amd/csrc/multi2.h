@@ -138,8 +138,9 @@ M2_HD uint32_t m2_home_of(uint32_t key, uint32_t meta) {
     const int q = (int)((meta >> 7) & 15u);
     return m2_index(key, q < 8 ? q : 8) & (CAH_M2_SLOTS - 1);
 }
-// The presence bitmaps.  Bits [0, 64 K): HASHED (m2_index) -- every k-mer of eight or more characters and class W's k-mers of
-// every index class (probed at every character).  Behind them the tail classes' k-mers of fewer than eight characters, EXACT:
+// The presence bitmaps.  Bits [0, 64 K): every k-mer of eight or more characters by its last eight at two bits each -- EXACT,
+// probed at every character with a second rolling word (two bits per character: a probe is one AND) -- and, hashed
+// (m2_index), class W's k-mers of fewer characters.  Behind them the tail classes' k-mers of fewer than eight characters, EXACT:
 // bit = m2_tail_region(q) + the k-mer's characters at two bits each (a valid character's code is below 4; anything else
 // aliases a valid one here and fails the comparison of all characters in the resolve step).  Round 6: these k-mers used to
 // share 32 Kbit through the hash, which folds 18- and 21-bit keys into 15 bits -- every second event of the six- and
@@ -169,7 +170,8 @@ M2_HD uint32_t m2_tail_region(int q, int cls) {
 M2_HD uint32_t m2_fixed_off(int q) { return q >= 4 ? 0u : q == 3 ? 256u : q == 2 ? 320u : 336u; }   // bytes; 340 in all
 M2_HD uint32_t m2_fixed_next(int q) { return 344u + 128u * (uint32_t)(q - 1); }                       // bytes; up to 856
 M2_HD uint32_t m2_bit(uint32_t r, int qc, int cls) {
-    if (qc >= 8 || cls == 0) return m2_index(r, qc);
+    if (qc >= 8) return m2_pack2(r, 8);                  // the last eight characters, exact: 4^8 = the first bitmap's 64 Kbit
+    if (cls == 0) return m2_index(r, qc);                // class W's shorter k-mers: hashed into the same 64 Kbit
     return CAH_M2_BM8_WORDS * 32u + m2_tail_region(qc, cls) + m2_pack2(r, qc);
 }
 

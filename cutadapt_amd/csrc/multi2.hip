@@ -692,13 +692,15 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
     };
     // one bitmap probe: does a k-mer of index class qc end with the word r?
     // (class W and index class 8: the hashed bitmap; a tail class's k-mer of fewer characters: its exact one -- multi2.h)
-    auto probe = [&](const uint32_t r, const int qc) -> bool {
-        const uint32_t idx = m2_index(r, qc);
+    // (r2: the same characters at two bits each -- index class 8 is probed with that word, multi2.h: m2_bit)
+    auto probe = [&](const uint32_t r, const uint32_t r2, const int qc) -> bool {
+        const uint32_t idx = qc >= 8 ? (r2 & 0xFFFFu) : m2_index(r, qc);
         return ((s_bm[idx >> 5] >> (idx & 31)) & 1u) != 0;
     };
-    auto probe_tail = [&](const uint32_t r, const int qc) -> bool {
-        const uint32_t bit = m2_bit(r, qc, M2_SHORT);
-        return ((s_bm[bit >> 5] >> (bit & 31)) & 1u) != 0;
+    // the last eight characters of a 3-bit word at two bits each (m2_pack2(x, 8))
+    auto pack2_8 = [](const uint32_t x) -> uint32_t {
+        const uint32_t y = (x & 0x030C30C3u) | ((x >> 1) & 0x0C30C30Cu);               // pairs: four bits in six
+        return (y & 0xFu) | ((y >> 2) & 0xF0u) | ((y >> 4) & 0xF00u) | ((y >> 6) & 0xF000u);
     };
 
     // the first position a pass is probed at (a k-mer of index class qc that ends at p starts n - p + q - 1 characters before
@@ -729,6 +731,10 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
             s_wide[2 * lane] = 0xFFFFFFFFu; s_wide[2 * lane + 1] = 0u;
             s_wmin[lane] = 255u;
             uint32_t r = 0x24924924u;                                   // ten characters that match nothing
+            // the same at two bits per character (sixteen of them): what the bitmaps are probed with.  A character that is
+            // not A / C / G / T (code 4) spills into its predecessor's field -- only k-mers that hold it see that, and no
+            // entry matches those: the resolve step compares the 3-bit word
+            uint32_t r2 = 0u;
             uint32_t r_prev = r;                                        // the word five characters in front of the chunk (the chunk before's twelfth)
             uint32_t rlast = r;                                         // the word at the read's last character
             unsigned seen_chars = 0;
@@ -755,29 +761,23 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
                     uint32_t e[16];
 #pragma unroll
                     for (int t = 0; t < 16; ++t) e[t] = s_xlat[(w4[t >> 2] >> (8 * (t & 3))) & 127u];
-                    uint32_t rr[16];
+                    uint32_t rr[16], rr2[16];
 #pragma unroll
-                    for (int t = 0; t < 16; ++t) { r = (r << 3) | e[t]; rr[t] = r; }
+                    for (int t = 0; t < 16; ++t) { r = (r << 3) | e[t]; rr[t] = r; r2 = (r2 << 2) | e[t]; rr2[t] = r2; }
                     const uint32_t rr5 = rr[5], rr11 = rr[11];
                     unsigned hits = 0;
                     if constexpr (w_only8) {
                         uint32_t wd[16];
 #pragma unroll
-                        for (int t = 0; t < 16; ++t) {
-                            const uint32_t idx = (rr[t] ^ (rr[t] >> 8)) & 0xFFFFu;        // m2_index(r, 8): the salt of class 8 is 0
-                            wd[t] = s_bm[idx >> 5];
-                        }
+                        for (int t = 0; t < 16; ++t) wd[t] = s_bm[(rr2[t] & 0xFFFFu) >> 5];   // m2_bit(r, 8, .): the last eight characters
 #pragma unroll
-                        for (int t = 0; t < 16; ++t) {
-                            const uint32_t idx = rr[t] ^ (rr[t] >> 8);
-                            hits |= ((wd[t] >> (idx & 31)) & 1u) << t;
-                        }
+                        for (int t = 0; t < 16; ++t) hits |= ((wd[t] >> (rr2[t] & 31u)) & 1u) << t;
                     } else {
 #pragma unroll
                         for (int t = 0; t < 16; ++t) {
                             bool h = false;
                             for (int qc = 1; qc <= 8; ++qc)
-                                if ((qmask_w >> qc) & 1) h = h || probe(rr[t], qc);
+                                if ((qmask_w >> qc) & 1) h = h || probe(rr[t], rr2[t], qc);
                             hits |= (h ? 1u : 0u) << t;
                         }
                     }
@@ -803,15 +803,8 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
                             uint32_t* const keep = reinterpret_cast<uint32_t*>(const_cast<unsigned char*>(row) + 16 * (c - 1));
                             keep[0] = r_prev; keep[1] = rr5; keep[2] = r;
                         }
-                        // the eight characters up to the chunk's first at two bits each (multi2.h: m2_pack2)
-                        const uint32_t x0 = rr[0];
-                        const uint32_t y0 = (x0 & 0x030C30C3u) | ((x0 >> 1) & 0x0C30C30Cu);            // pairs: four bits in six
-                        // ... and rolled along the chunk: from here on the chunk's words are needed at two bits per character only
-                        // (the events take theirs from r_prev / rr5 / r)
-                        uint32_t rr2[16];
-                        rr2[0] = (y0 & 0xFu) | ((y0 >> 2) & 0xF0u) | ((y0 >> 4) & 0xF00u) | ((y0 >> 6) & 0xF000u);
-#pragma unroll
-                        for (int t = 1; t < 16; ++t) rr2[t] = (rr2[t - 1] << 2) | (rr[t] & 3u);
+                        // (from here on the chunk's words are needed at two bits per character only: the events take theirs from
+                        // r_prev / rr5 / r)
 #pragma unroll 1
                         for (int j = 0; j < tq_n; ++j) {
                             // (the loop stays rolled: ONE copy of the probes; the pass's mask by a chain of scalar branches)
@@ -826,15 +819,9 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
                                 } else {
                                     uint32_t wd2[16];
 #pragma unroll
-                                    for (int t = 0; t < 16; ++t) {
-                                        const uint32_t idx = (rr[t] ^ (rr[t] >> 8)) & 0xFFFFu;
-                                        wd2[t] = s_bm[idx >> 5];
-                                    }
+                                    for (int t = 0; t < 16; ++t) wd2[t] = s_bm[(rr2[t] & 0xFFFFu) >> 5];
 #pragma unroll
-                                    for (int t = 0; t < 16; ++t) {
-                                        const uint32_t idx = rr[t] ^ (rr[t] >> 8);
-                                        h16 |= ((wd2[t] >> (idx & 31)) & 1u) << t;
-                                    }
+                                    for (int t = 0; t < 16; ++t) h16 |= ((wd2[t] >> (rr2[t] & 31u)) & 1u) << t;
                                 }
                             } else {
                                 // the exact bitmap of the class and index class: the k-mer at two bits per character
@@ -882,7 +869,7 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
                                 // (several index classes: one event per class that hits)
                                 for (int qc = 1; qc <= 8; ++qc) {
                                     if (!((qmask_w >> qc) & 1)) continue;
-                                    const bool hq = mine && probe(rt, qc);
+                                    const bool hq = mine && probe(rt, pack2_8(rt), qc);
                                     const unsigned long long mq = __ballot(hq);
                                     if (mq) push_events(mq, hq, rt & 0x3FFFFFFFu, pos + t, qc);
                                 }
