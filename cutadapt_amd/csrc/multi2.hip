@@ -708,6 +708,9 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
     // chunk sits in the slot's row (the launcher checked: behind the first half-row, at most four chunks to the read's end)
     int tail_p0 = n;
     for (int j = 0; j < tq_n; ++j) tail_p0 = min(tail_p0, max(0, n + hd->tq_qc[j] - 1 - hd->tq_open[j]));
+    // (the passes' words: lane j holds pass j's for the whole kernel -- a v_readlane where an LDS round trip per pass and
+    // tail chunk was)
+    const uint32_t pass_words = (unsigned)lane < (unsigned)CAH_M2_MAX_PASSES ? s_pass[lane] : 0u;
     const int tail_base = tail_p0 & ~15;
     const int tail_off = H2 > 0 ? 16 * H1 : 0;                          // first position of the last half-row
     const int tail_unit0 = (tail_base - tail_off) >> 4;                 // row unit of the first tail chunk
@@ -808,7 +811,7 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
 #pragma unroll 1
                         for (int j = 0; j < tq_n; ++j) {
                             // (the loop stays rolled: ONE copy of the probes; the pass's mask by a chain of scalar branches)
-                            const uint32_t pw = __builtin_amdgcn_readfirstlane(s_pass[j]);
+                            const uint32_t pw = __builtin_amdgcn_readlane(pass_words, j);
                             const int pcls = (int)(pw & 3u), qc = (int)((pw >> 2) & 15u);
                             const int plo = (int)((pw >> 8) & 255u), phi = (int)((pw >> 16) & 255u);
                             if (phi < plo || pos + 16 <= plo || pos > phi) continue;       // wave-uniform
@@ -891,7 +894,7 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
                 int prev_cls = M2_W;
 #pragma unroll 1
                 for (int j = 0; j < tq_n; ++j) {
-                    const uint32_t pw = __builtin_amdgcn_readfirstlane(s_pass[j]);
+                    const uint32_t pw = __builtin_amdgcn_readlane(pass_words, j);
                     const int pcls = (int)(pw & 3u), qc = (int)((pw >> 2) & 15u);
                     const int plo = (int)((pw >> 8) & 255u), phi = (int)((pw >> 16) & 255u);
                     if (phi < plo) continue;                                               // wave-uniform: no position of the pass is in the read
