@@ -125,12 +125,19 @@ M2_HD uint32_t m2_code(unsigned c) {
     return (c >= 64 && c < 128) ? (u == 'A' ? 0u : u == 'C' ? 1u : u == 'G' ? 2u : u == 'T' ? 3u : 4u) : 4u;
 }
 M2_HD uint32_t m2_mask(int q) { return q >= 10 ? 0x3FFFFFFFu : ((1u << (3 * q)) - 1u); }
-// index (16 bits) of the last qc = min(q, 8) characters: the home slot of the directory is its low 12 bits, the bitmap
-// bit m2_bit(index, qc)
+// ---- the words the tables are looked up with: TWO bits per character, sixteen characters per 32-bit word, the newest lowest.
+// A character that is not A / C / G / T reads as 'A' there: a hit through a k-mer that holds such a character makes a pair
+// that the scan finds nothing for (no alignment holds the character unedited) -- the filter stays lossless, and what a pair's
+// scan accepts the reference's kmers_present accepts (conditions (i), (iii), (iv) above).  The 3-bit words (m2_mask,
+// m2_exact_tail, the adapters' prefixes) remain where characters are COMPARED for a result: the error-free overlaps at the
+// read's end.
+M2_HD uint32_t m2_roll2(uint32_t r2, unsigned c) { return (r2 << 2) | (m2_code(c) & 3u); }
+M2_HD uint32_t m2_mask2(int q) { return q >= 16 ? 0xFFFFFFFFu : ((1u << (2 * q)) - 1u); }
+// index (16 bits) of the last qc = min(q, 8) characters: the home slot of the directory is its low 12 bits
 M2_HD uint32_t m2_salt(int qc) { return (uint32_t)(8 - qc) * 0x1D3Bu; }
-M2_HD uint32_t m2_index(uint32_t r, int qc) {
-    const uint32_t key = r & m2_mask(qc);
-    return ((key ^ (key >> 8)) ^ m2_salt(qc)) & 0xFFFFu;
+M2_HD uint32_t m2_index(uint32_t r2, int qc) {
+    const uint32_t key = r2 & m2_mask2(qc);
+    return ((key ^ (key >> 7)) ^ m2_salt(qc)) & 0xFFFFu;
 }
 // the home of an entry (from its own k-mer): the entries of a home are consecutive, and a home with CAH_M2_MAX_GROUP or more
 // of them -- adapters that share their k-mers -- is walked while this stays the event's home
@@ -138,18 +145,11 @@ M2_HD uint32_t m2_home_of(uint32_t key, uint32_t meta) {
     const int q = (int)((meta >> 7) & 15u);
     return m2_index(key, q < 8 ? q : 8) & (CAH_M2_SLOTS - 1);
 }
-// The presence bitmaps.  Bits [0, 64 K): every k-mer of eight or more characters by its last eight at two bits each -- EXACT,
-// probed at every character with a second rolling word (two bits per character: a probe is one AND) -- and, hashed
-// (m2_index), class W's k-mers of fewer characters.  Behind them the tail classes' k-mers of fewer than eight characters, EXACT:
-// bit = m2_tail_region(q) + the k-mer's characters at two bits each (a valid character's code is below 4; anything else
-// aliases a valid one here and fails the comparison of all characters in the resolve step).  Round 6: these k-mers used to
-// share 32 Kbit through the hash, which folds 18- and 21-bit keys into 15 bits -- every second event of the six- and
-// seven-character passes was a k-mer that no entry holds (C4: 6.0 tail events per read, 4.3 now).
-M2_HD uint32_t m2_pack2(uint32_t r, int q) {
-    uint32_t v = 0;
-    for (int i = 0; i < q && i < 8; i++) v |= ((r >> (3 * i)) & 3u) << (2 * i);
-    return v;
-}
+// The presence bitmaps.  Bits [0, 64 K): every k-mer of eight or more characters by its last eight -- EXACT (4^8 bits), one AND
+// of the rolling word per probe, at every character -- and, hashed (m2_index), class W's k-mers of fewer characters.  Behind
+// them the tail classes' k-mers of fewer than eight characters, EXACT too: bit = m2_tail_region(q, class) + the k-mer.  Round 6:
+// these k-mers used to share 32 Kbit through a hash of 3-bit words, which folded 18- and 21-bit keys into 15 bits -- every
+// second event of the six- and seven-character passes was a k-mer that no entry holds (C4: 6.0 tail events per read, 3.6 now).
 // (regions are multiples of 32 bits.  q 7: 16 Kbit shared by the tail classes; q 6: 4 Kbit for class hi and 4 for lo / E0; q 5:
 // 1 Kbit for hi / lo and 1 for E0 -- a pass of one class does not see the other's k-mers; q <= 4: shared)
 M2_HD uint32_t m2_tail_region(int q, int cls) {
@@ -169,10 +169,10 @@ M2_HD uint32_t m2_tail_region(int q, int cls) {
 #define CAH_M2_FIXED_MAXQ 4
 M2_HD uint32_t m2_fixed_off(int q) { return q >= 4 ? 0u : q == 3 ? 256u : q == 2 ? 320u : 336u; }   // bytes; 340 in all
 M2_HD uint32_t m2_fixed_next(int q) { return 344u + 128u * (uint32_t)(q - 1); }                       // bytes; up to 856
-M2_HD uint32_t m2_bit(uint32_t r, int qc, int cls) {
-    if (qc >= 8) return m2_pack2(r, 8);                  // the last eight characters, exact: 4^8 = the first bitmap's 64 Kbit
-    if (cls == 0) return m2_index(r, qc);                // class W's shorter k-mers: hashed into the same 64 Kbit
-    return CAH_M2_BM8_WORDS * 32u + m2_tail_region(qc, cls) + m2_pack2(r, qc);
+M2_HD uint32_t m2_bit(uint32_t r2, int qc, int cls) {
+    if (qc >= 8) return r2 & 0xFFFFu;                    // the last eight characters, exact: 4^8 = the first bitmap's 64 Kbit
+    if (cls == 0) return m2_index(r2, qc);               // class W's shorter k-mers: hashed into the same 64 Kbit
+    return CAH_M2_BM8_WORDS * 32u + m2_tail_region(qc, cls) + (r2 & m2_mask2(qc));
 }
 
 struct CahMulti2Header {
@@ -245,6 +245,11 @@ inline uint32_t m2_encode(const std::string& s) {
     uint32_t r = 0;
     for (char ch : s) r = (r << 3) | m2_code((unsigned char)ch);
     return r;
+}
+inline uint32_t m2_encode2(const std::string& s) {          // (plain A / C / G / T strings of up to 16 characters)
+    uint32_t r2 = 0;
+    for (char ch : s) r2 = m2_roll2(r2, (unsigned char)ch);
+    return r2;
 }
 
 // the reference's chunking (kmer_heuristic.py:6-21): `chunks` nearly equal consecutive pieces, longer pieces first
@@ -399,15 +404,15 @@ inline bool m2_build(const std::vector<std::string>& adapters, const int32_t* th
     int nonfixed_mask[4] = {0, 0, 0, 0};
     for (const Ent& e : ents) {
         const int q = (int)e.kmer.size(), qc = std::min(q, 8);
-        const uint32_t code = m2_encode(e.kmer);
-        if (code & 0x24924924u) return false;                        // not plain ACGT
+        if (m2_encode(e.kmer) & 0x24924924u) return false;            // not plain ACGT
+        const uint32_t code = m2_encode2(e.kmer);                     // the entry's key: two bits per character
         const uint32_t idx = m2_index(code, qc);
         // an error-free overlap of q <= 4 characters: the table of first adapters (CAH_M2_FIXED_WORD), no entry
         const bool fixed = e.cls == M2_SHORT && e.dlo == q && e.dhi == q && q <= CAH_M2_FIXED_MAXQ;
         if (fixed) {
             // (the adapters of a string in ascending order: head in the table, then the chain)
             if (e.adapter >= 128) return false;
-            uint8_t* at = &fixed_tab[m2_fixed_off(q) + m2_pack2(code, q)];
+            uint8_t* at = &fixed_tab[m2_fixed_off(q) + (code & m2_mask2(q))];
             while (*at != 0xFFu && *at < e.adapter) at = &fixed_tab[m2_fixed_next(q) + *at];
             if (*at != (uint8_t)e.adapter) {
                 fixed_tab[m2_fixed_next(q) + (uint32_t)e.adapter] = *at;

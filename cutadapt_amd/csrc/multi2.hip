@@ -79,7 +79,7 @@ __host__ __device__ inline M2Layout m2_layout(const int n_entries, const int n_a
     M2Layout L;
     unsigned o = 0;
     const unsigned words = (unsigned)(n_adapters + 31) / 32;
-    L.xlat = o; o += 128;
+    L.xlat = o; o += 256;                                               // (3-bit codes, then the same at two bits: 'A' for anything else)
     L.prefix = o; o += 128 * 4;
     L.bitmap = o; o += CAH_M2_BM_WORDS * 4;
     L.dir = o; o += CAH_M2_SLOTS * 2;
@@ -154,6 +154,7 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
     for (int i = threadIdx.x; i < 128; i += blockDim.x) {
         s_prefix[i] = i < n_adapters ? a.prefix[i] : 0u;
         s_xlat[i] = (uint8_t)m2_code((unsigned)i);
+        s_xlat[128 + i] = (uint8_t)(m2_code((unsigned)i) & 3u);
     }
     const int lane = wave_lane();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -576,7 +577,7 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
         // (one for most events, none for a false positive), not once per entry of the home
         auto entry_ok = [&](const CahM2Slot& e) -> bool {
             const int q = m2_q(e.meta);
-            return m2_cls(e.meta) == cls && (q < 8 ? q : 8) == qc && (r & m2_mask(q)) == e.key && p - q + 1 >= 0 &&
+            return m2_cls(e.meta) == cls && (q < 8 ? q : 8) == qc && (r & m2_mask2(q)) == e.key && p - q + 1 >= 0 &&
                    m2_in_window(e.meta, n - (p - q + 1));
         };
         // (two entries per step -- one ds_read2_b64: the walk is a chain of dependent LDS reads, its length the longest home
@@ -692,15 +693,10 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
     };
     // one bitmap probe: does a k-mer of index class qc end with the word r?
     // (class W and index class 8: the hashed bitmap; a tail class's k-mer of fewer characters: its exact one -- multi2.h)
-    // (r2: the same characters at two bits each -- index class 8 is probed with that word, multi2.h: m2_bit)
-    auto probe = [&](const uint32_t r, const uint32_t r2, const int qc) -> bool {
-        const uint32_t idx = qc >= 8 ? (r2 & 0xFFFFu) : m2_index(r, qc);
+    // one bitmap probe of class W: does a k-mer of index class qc end with the word r2 (two bits per character, multi2.h)?
+    auto probe = [&](const uint32_t r2, const int qc) -> bool {
+        const uint32_t idx = qc >= 8 ? (r2 & 0xFFFFu) : m2_index(r2, qc);
         return ((s_bm[idx >> 5] >> (idx & 31)) & 1u) != 0;
-    };
-    // the last eight characters of a 3-bit word at two bits each (m2_pack2(x, 8))
-    auto pack2_8 = [](const uint32_t x) -> uint32_t {
-        const uint32_t y = (x & 0x030C30C3u) | ((x >> 1) & 0x0C30C30Cu);               // pairs: four bits in six
-        return (y & 0xFu) | ((y >> 2) & 0xF0u) | ((y >> 4) & 0xF00u) | ((y >> 6) & 0xF000u);
     };
 
     // the first position a pass is probed at (a k-mer of index class qc that ends at p starts n - p + q - 1 characters before
@@ -733,16 +729,16 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
             for (int w = 0; w < words; ++w) s_seen[lane * words + w] = 0;
             s_wide[2 * lane] = 0xFFFFFFFFu; s_wide[2 * lane + 1] = 0u;
             s_wmin[lane] = 255u;
-            uint32_t r = 0x24924924u;                                   // ten characters that match nothing
-            // the same at two bits per character (sixteen of them): what the bitmaps are probed with.  A character that is
-            // not A / C / G / T (code 4) spills into its predecessor's field -- only k-mers that hold it see that, and no
-            // entry matches those: the resolve step compares the 3-bit word
+            // the rolling word the tables are looked up with: two bits per character, sixteen characters (multi2.h: m2_roll2 --
+            // anything but A / C / G / T reads as 'A' there)
             uint32_t r2 = 0u;
-            uint32_t r_prev = r;                                        // the word five characters in front of the chunk (the chunk before's twelfth)
-            uint32_t rlast = r;                                         // the word at the read's last character
+            uint32_t r2_prev = 0u;                                      // ... at the end of the chunk before
+            // the read's last ten characters at THREE bits each (what the error-free overlaps are compared with) and its last
+            // sixteen at two (the tables of first adapters): rolled in the last two chunks only
+            uint32_t r3 = 0x24924924u, rlast = 0x24924924u, rlast2 = 0u;
             unsigned seen_chars = 0;
             uint32_t tm[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};          // per pass: bit b = a hit at the pass's first position + b
-            uint32_t tw0[3] = {0u, 0u, 0u};                             // the three words of the first tail chunk
+            uint32_t tw0[2] = {0u, 0u};                                 // the two words of the first tail chunk (before it, at its end)
             cur_cls = M2_W;
             m2_u32x4 cur = (m2_u32x4)(0u);
 #pragma unroll 1
@@ -763,11 +759,18 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
                     // translate the chunk's characters (16 independent LDS reads), roll, probe
                     uint32_t e[16];
 #pragma unroll
-                    for (int t = 0; t < 16; ++t) e[t] = s_xlat[(w4[t >> 2] >> (8 * (t & 3))) & 127u];
-                    uint32_t rr[16], rr2[16];
+                    for (int t = 0; t < 16; ++t) e[t] = s_xlat[128u + ((w4[t >> 2] >> (8 * (t & 3))) & 127u)];
+                    uint32_t rr2[16];
 #pragma unroll
-                    for (int t = 0; t < 16; ++t) { r = (r << 3) | e[t]; rr[t] = r; r2 = (r2 << 2) | e[t]; rr2[t] = r2; }
-                    const uint32_t rr5 = rr[5], rr11 = rr[11];
+                    for (int t = 0; t < 16; ++t) { r2 = (r2 << 2) | e[t]; rr2[t] = r2; }
+                    // the read's last characters at three bits each (n is the batch's: the chunk and the last position in it are
+                    // wave-uniform): translated once more with the 3-bit table, in the read's last two chunks only
+                    if (pos + 32 > n && pos < n) {
+                        const int t_last = n - 1 - pos;                 // >= 16 in the chunk before the last
+#pragma unroll
+                        for (int t = 0; t < 16; ++t)
+                            r3 = t <= t_last ? ((r3 << 3) | (uint32_t)s_xlat[(w4[t >> 2] >> (8 * (t & 3))) & 127u]) : r3;
+                    }
                     unsigned hits = 0;
                     if constexpr (w_only8) {
                         uint32_t wd[16];
@@ -780,34 +783,35 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
                         for (int t = 0; t < 16; ++t) {
                             bool h = false;
                             for (int qc = 1; qc <= 8; ++qc)
-                                if ((qmask_w >> qc) & 1) h = h || probe(rr[t], rr2[t], qc);
+                                if ((qmask_w >> qc) & 1) h = h || probe(rr2[t], qc);
                             hits |= (h ? 1u : 0u) << t;
                         }
                     }
                     if (pos + 16 > n) hits &= (1u << (n - pos)) - 1u;   // positions past the read's end
                     if (!valid) hits = 0;
-                    // the word at position pos + t from three words ten characters apart (30 bits each): at pos - 5 (the
-                    // chunk before's twelfth character), pos + 5 and pos + 15
-                    const uint64_t v_lo = ((uint64_t)r_prev << 30) | (uint64_t)(rr5 & 0x3FFFFFFFu);     // .. pos + 5
-                    const uint64_t v_hi = ((uint64_t)rr5 << 30) | (uint64_t)(r & 0x3FFFFFFFu);           // .. pos + 15
+                    if constexpr (RV && w_only8) {
+                        // (the NULs in front of a view read as 'A' in the 2-bit word: a k-mer that would begin among them is none)
+                        const int lim = skip + 7 - pos;
+                        if (lim > 0) hits &= lim >= 16 ? 0u : ~((1u << lim) - 1u);
+                    }
+                    // the word at position pos + t: the sixteen characters up to it, from the words at the chunk's end and the
+                    // chunk before's (one v_alignbit)
+                    const uint32_t r2_end = r2;
                     auto word_at = [&](const int t) -> uint32_t {
-                        return t <= 5 ? (uint32_t)(v_lo >> (3 * (5 - t))) : (uint32_t)(v_hi >> (3 * (15 - t)));
+                        return __builtin_amdgcn_alignbit(r2_prev, r2_end, (unsigned)(2 * (15 - t)));
                     };
-                    // the read's last ten characters (the chunk's characters behind the read's end are NULs)
-                    if (pos < n && pos + 16 >= n) rlast = word_at(n - 1 - pos);
+                    if (pos < n && pos + 16 >= n) { rlast = r3; rlast2 = word_at(n - 1 - pos); }   // (the read's last chunk)
                     // ---- the tail slots: probed in the read's last chunks with the words the main pass has anyway; the hits
                     // wait (a bit mask per slot) until class W is resolved.  The chunk's three words wait with them: the
                     // first tail chunk's in registers, a later one's in the row unit in front of it (its characters are spent)
 #if !(defined(M2_ABL) && (M2_ABL & 1))
                     if (pos + 16 > tail_p0 && pos < n) {
                         const int kch = (pos - tail_base) >> 4;
-                        if (kch == 0) { tw0[0] = r_prev; tw0[1] = rr5; tw0[2] = r; }
+                        if (kch == 0) { tw0[0] = r2_prev; tw0[1] = r2_end; }
                         else {
                             uint32_t* const keep = reinterpret_cast<uint32_t*>(const_cast<unsigned char*>(row) + 16 * (c - 1));
-                            keep[0] = r_prev; keep[1] = rr5; keep[2] = r;
+                            keep[0] = r2_prev; keep[1] = r2_end;
                         }
-                        // (from here on the chunk's words are needed at two bits per character only: the events take theirs from
-                        // r_prev / rr5 / r)
 #pragma unroll 1
                         for (int j = 0; j < tq_n; ++j) {
                             // (the loop stays rolled: ONE copy of the probes; the pass's mask by a chain of scalar branches)
@@ -847,6 +851,10 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
                             if (lo_t > 0) h16 &= ~((1u << lo_t) - 1u);
                             if (pos + 16 > n) h16 &= (1u << (n - pos)) - 1u;
                             if (!valid) h16 = 0;
+                            if constexpr (RV) {
+                                const int lim = skip + qc - 1 - pos;      // (a k-mer that would begin in front of the view)
+                                if (lim > 0) h16 &= lim >= 16 ? 0u : ~((1u << lim) - 1u);
+                            }
                             uint32_t add = lo_t > 0 ? h16 >> lo_t : h16 << (pos - plo);   // (bit b = position plo + b)
                             if ((pw >> 27) & 1u) add <<= 16;                               // (a narrow pass in its register's upper half)
                             const int sl = (int)((pw >> 24) & 7u);
@@ -867,19 +875,19 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
                             const uint32_t rt = word_at(t);
                             const unsigned long long mk = __ballot(mine);
                             if constexpr (w_only8) {
-                                push_events(mk, mine, rt & 0x3FFFFFFFu, pos + t, 8);
+                                push_events(mk, mine, rt, pos + t, 8);
                             } else {
                                 // (several index classes: one event per class that hits)
                                 for (int qc = 1; qc <= 8; ++qc) {
                                     if (!((qmask_w >> qc) & 1)) continue;
-                                    const bool hq = mine && probe(rt, pack2_8(rt), qc);
+                                    const bool hq = mine && probe(rt, qc);
                                     const unsigned long long mq = __ballot(hq);
-                                    if (mq) push_events(mq, hq, rt & 0x3FFFFFFFu, pos + t, qc);
+                                    if (mq) push_events(mq, hq, rt, pos + t, qc);
                                 }
                             }
                         }
                     }
-                    r_prev = rr11;
+                    r2_prev = r2_end;
                     cur = nxt;
                 }
                 M2_STAMP(2 + 2 * ph);
@@ -914,15 +922,13 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
                         const int bit = (mine ? (int)__builtin_ctz(mk) : 0) + plo - tail_base;   // bit b of the tail = position tail_base + b
                         mk &= mk - 1u;
                         const int kch = bit >> 4, t = bit & 15;
-                        // the chunk's three words: at its position - 5, + 5 and + 15
+                        // the chunk's two words: in front of it and at its end
                         const int unit = max(tail_unit0 + kch - 1, 0);
                         const uint32_t* const keep = reinterpret_cast<const uint32_t*>(row + 16 * unit);
-                        uint32_t a0 = keep[0], a1 = keep[1], a2 = keep[2];
-                        if (kch == 0) { a0 = tw0[0]; a1 = tw0[1]; a2 = tw0[2]; }
-                        const uint64_t v_lo = ((uint64_t)a0 << 30) | (uint64_t)(a1 & 0x3FFFFFFFu);
-                        const uint64_t v_hi = ((uint64_t)a1 << 30) | (uint64_t)(a2 & 0x3FFFFFFFu);
-                        const uint32_t rt = t <= 5 ? (uint32_t)(v_lo >> (3 * (5 - t))) : (uint32_t)(v_hi >> (3 * (15 - t)));
-                        push_events(__ballot(mine), mine, rt & 0x3FFFFFFFu, tail_base + bit, qc);
+                        uint32_t a0 = keep[0], a1 = keep[1];
+                        if (kch == 0) { a0 = tw0[0]; a1 = tw0[1]; }
+                        const uint32_t rt = __builtin_amdgcn_alignbit(a0, a1, (unsigned)(2 * (15 - t)));
+                        push_events(__ballot(mine), mine, rt, tail_base + bit, qc);
                     }
                 }
                 drain();
@@ -938,7 +944,7 @@ __global__ __launch_bounds__(M2_WAVES * WAVE) void k_multi_stream(Multi2Args a) 
                 for (int q = 1; q <= CAH_M2_FIXED_MAXQ; ++q) {
                     if (!((qm_fixed >> q) & 1)) continue;                              // wave-uniform
                     const bool plain = (rlast & m2_mask(q) & 0x24924924u) == 0u;      // the last q characters are A, C, G, T
-                    unsigned adapter = (valid && plain && q <= n - skip) ? s_fixed[m2_fixed_off(q) + m2_pack2(rlast, q)] : 0xFFu;
+                    unsigned adapter = (valid && plain && q <= n - skip) ? s_fixed[m2_fixed_off(q) + (rlast2 & m2_mask2(q))] : 0xFFu;
                     // (an adapter whose pair exists is the scan's business: the next one that begins with these characters)
                     while (m2_any(adapter != 0xFFu && ((ss[(adapter & 127u) >> 5] >> (adapter & 31u)) & 1u) != 0u)) {
                         const bool taken = adapter != 0xFFu && ((ss[(adapter & 127u) >> 5] >> (adapter & 31u)) & 1u) != 0u;

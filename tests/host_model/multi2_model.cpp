@@ -49,7 +49,7 @@ void resolve(const M2Tables& t, ReadState& st, uint32_t r, int qc, int cls, int 
         const CahM2Slot& e = t.entries[(size_t)u];
         const uint32_t meta = e.meta;
         const int q = m2_q(meta);
-        if (m2_cls(meta) != cls || std::min(q, 8) != qc || (r & m2_mask(q)) != e.key) continue;
+        if (m2_cls(meta) != cls || std::min(q, 8) != qc || (r & m2_mask2(q)) != e.key) continue;
         g_pass[g_cur_pass][1]++;
         const int dist = n - (p - q + 1);
         const int a = m2_adapter(meta);
@@ -74,10 +74,13 @@ void filter_read(const M2Tables& t, const uint8_t* q, int n, ReadState& st, int 
     const CahMulti2Header& h = t.hdr;
     memset(st.seen, 0, sizeof(st.seen));
     memset(st.wideonly, 0, sizeof(st.wideonly));
+    // the words the tables are looked up with: two bits per character (multi2.h: m2_roll2), rolled exactly as the kernel rolls
+    // them; the 3-bit word of the read's last ten characters for the error-free overlaps
     std::vector<uint32_t> rr((size_t)n + 1);
-    uint32_t r = 0x24924924u;                                         // ten invalid characters
-    for (int p = 0; p < n; p++) { r = (r << 3) | m2_code(q[p]); rr[(size_t)p] = r; }
-    const uint32_t rlast = n > 0 ? rr[(size_t)n - 1] : 0x24924924u;
+    uint32_t r = 0u, r3 = 0x24924924u;                                // (r3: ten invalid characters)
+    for (int p = 0; p < n; p++) { r = m2_roll2(r, q[p]); rr[(size_t)p] = r; r3 = (r3 << 3) | m2_code(q[p]); }
+    const uint32_t rlast = r3;
+    const uint32_t rlast2 = n > 0 ? rr[(size_t)n - 1] : 0u;
     auto probe = [&](int p, int qc, int cls) {
         const uint32_t bit = m2_bit(rr[(size_t)p], qc, cls);
         return ((t.bitmap[bit >> 5] >> (bit & 31)) & 1u) != 0;
@@ -109,7 +112,7 @@ void filter_read(const M2Tables& t, const uint8_t* q, int n, ReadState& st, int 
     const uint8_t* const fixed_tab = reinterpret_cast<const uint8_t*>(t.bitmap.data() + CAH_M2_FIXED_WORD);
     for (int qq = 1; qq <= CAH_M2_FIXED_MAXQ; qq++) {
         if (!((h.qm_fixed >> qq) & 1) || qq > n - pad || (rlast & m2_mask(qq) & 0x24924924u)) continue;
-        unsigned a = fixed_tab[m2_fixed_off(qq) + m2_pack2(rlast, qq)];
+        unsigned a = fixed_tab[m2_fixed_off(qq) + (rlast2 & m2_mask2(qq))];
         while (a != 0xFFu && st.seen[a]) a = fixed_tab[m2_fixed_next(qq) + a];      // (a pair that exists: the scan's business)
         if (a == 0xFFu) continue;
         g_cur_pass = 9; g_pass[9][0]++;
