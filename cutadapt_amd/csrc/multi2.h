@@ -38,9 +38,13 @@
 // `wide` bitset): a whole-read pair that took the window of its one occurrence (CAH_M2_PAIR_PRECISE) falls back to the
 // full window then.
 //
-// Characters: 3 bits each (A 0, C 1, G 2, T 3, either case; anything else 4 = breaks every k-mer, as KmerFinder
-// without wildcards does: _match_tables.py:81-98), the newest character in the lowest bits; ten characters per
-// 32-bit word -- k-mers of up to CAH_M2_MAXQ characters.
+// Characters: A 0, C 1, G 2, T 3, either case; anything else 4 (no k-mer holds it, as in KmerFinder without wildcards:
+// _match_tables.py:81-98).  Two kinds of words, the newest character in the lowest bits:
+//   * what is LOOKED UP (bitmaps, directory, entries' keys, events) takes two bits per character, sixteen characters per
+//     32-bit word, and reads code 4 as 'A' (m2_roll2): a hit through a k-mer that holds such a character makes a pair whose
+//     scan finds nothing -- the filter stays lossless, and what a scan accepts kmers_present accepts by (i), (iii), (iv);
+//   * what is COMPARED for a result (the error-free overlaps at the read's end: m2_exact_tail, the adapters' prefixes) takes
+//     three bits per character, ten characters per word -- k-mers of up to CAH_M2_MAXQ characters.
 #pragma once
 #include <stdint.h>
 

@@ -11,12 +11,14 @@
 // k_multi_stream, per workgroup of 16 waves (one per CU):
 //   * the reads are copied HBM -> LDS with coalesced 16-byte loads, half a read at a time (k_filter_stream2's copy
 //     plan: every cache line crosses the memory system once), one read per lane;
-//   * per character: 3-bit code (LDS byte table), a rolling word of the last ten characters, ONE bitmap probe for the
-//     whole-read k-mers; a probe hit becomes an EVENT (lane, position, the rolling word) in the wave's LDS ring;
+//   * per character: 2-bit code (LDS byte table), a rolling word of the last sixteen characters, ONE probe of an exact
+//     bitmap for the whole-read k-mers (one AND of that word); a probe hit becomes an EVENT (lane, position, the word) in
+//     the wave's LDS ring;
 //   * events are resolved 64 at a time by ALL lanes (directory -> entries in LDS, verified on every character and on
 //     the k-mer's windows) -- no lane waits for another lane's hit;
-//   * behind the main pass: the tail classes' hits (probed in the read's last chunks, one mask per index class) become events
-//     pass by pass in class order (hi, lo, E0), each class resolved before the next;
+//   * behind the main pass: the tail classes' hits (probed in the read's last chunks, one 32-bit mask per (class, index
+//     class) pass, exact class-specific bitmaps) become events pass by pass in class order (hi, lo, E0), each class resolved
+//     before the next; error-free overlaps of up to four characters come from a table of first adapters, without events;
 //   * a pair is emitted once (an LDS bitset `seen` per read and adapter; which pairs saw a FURTHER hit is two words per read)
 //     into a PAGE of its class: pages of
 //     1024 pairs from a device-wide pool, owned by one wave, one class of pairs per page -- the scan's waves then hold 64

@@ -496,3 +496,65 @@ def test_frames_of_short_and_odd_batches(hip, orc):
                 assert len(bad) == 0, (what, len(ads), len(bad), reads[int(bad[0])], g6[bad[0]].tolist(), want6[bad[0]].tolist())
     finally:
         B.FRAME_MIN_READS = old_min
+
+
+def test_characters_that_read_as_A_in_the_lookup_words(hip, orc):
+    """The tables are looked up with two bits per character: anything but A / C / G / T -- an N, the NULs in front of a view in
+    its frame -- reads as 'A' there (multi2.h: m2_roll2).  Adapters rich in A then meet k-mers everywhere in such reads: pairs
+    that the scan must find nothing for.  N runs, poly-A, adapters behind and in front of N, uniform batches and ragged ones in
+    frames (pads of up to 140 NULs), against the oracle in full"""
+    import torch
+    from cutadapt_amd import batch as B
+    from cutadapt_amd.batch import ReadBatch, match_batch
+    prng = random.Random(4242)
+    seqs = ["A" * 33, "A" * 16 + rs(prng, 17), rs(prng, 17) + "A" * 16, "ACGT" * 8 + "A"] + [rs(prng, 33) for _ in range(8)]
+    n = 150
+
+    def read_of(i, ln):
+        kind = i % 8
+        if kind == 0:
+            r = "N" * ln
+        elif kind == 1:
+            r = "".join(prng.choice("AN") for _ in range(ln))
+        elif kind == 2:
+            r = "A" * ln
+        elif kind == 3:                                               # an adapter prefix behind a run of N (and one inside it)
+            ad = seqs[prng.randrange(len(seqs))]
+            cut = ad[: prng.randint(3, 33)]
+            r = (rs(prng, ln) + "N" * 12 + cut)[-ln:] if ln else ""
+            if ln > 20 and prng.random() < 0.5:
+                k = prng.randrange(ln - len(cut), ln) if len(cut) < ln else 0
+                r = r[:k] + "N" + r[k + 1:]
+        elif kind == 4:                                               # a whole adapter with an N next to it / in it
+            ad = seqs[prng.randrange(len(seqs))]
+            at = prng.randint(0, max(0, ln - 40))
+            r = (rs(prng, at) + "N" + ad + "N" + rs(prng, ln))[:ln]
+            if prng.random() < 0.4 and ln > at + 20:
+                r = r[: at + 10] + "N" + r[at + 11:]
+        else:
+            r = "".join(prng.choice("ACGTN") if prng.random() < 0.1 else prng.choice("ACGT") for _ in range(ln))
+        return (r + "A" * ln)[:ln]
+
+    reads = [read_of(i, n) for i in range(6000)]
+    found = run_uniform(orc, seqs, 0.1, 3, reads, "A-rich adapters, N-rich reads")
+    assert found > 500
+    # ... ragged, in frames: the pads are NULs
+    plan, ads = plan_for(seqs, 0.1, 3)
+    old_min = B.FRAME_MIN_READS
+    B.FRAME_MIN_READS = 1000
+    try:
+        ragged = [read_of(i, prng.choice((16, 20, 33, 40, 77, 150, 160))) for i in range(20_000)]
+        sq, offs = orc.pack_reads(ragged)
+        batch = ReadBatch.from_host(sq, offs)
+        assert B._frame_len(plan, batch) == 160
+        got = match_batch(plan, batch)
+        torch.cuda.synchronize()
+        from cutadapt_amd import _lib
+        assert _lib.last_multi_path() == "stream"
+        want6, want_st, want_best = oracle_multiple(orc, ads, sq, offs)
+        g6, gst = got.out6.cpu().numpy(), got.status.cpu().numpy()
+        bad = np.nonzero((gst != want_st) | (g6 != want6).any(axis=1))[0]
+        assert len(bad) == 0, (len(bad), ragged[int(bad[0])], g6[bad[0]].tolist(), want6[bad[0]].tolist())
+        assert int((want_st == 1).sum()) > 2000
+    finally:
+        B.FRAME_MIN_READS = old_min
