@@ -11,7 +11,7 @@ visible GPUs -- and writes the results back in chunk order: the reference's read
 writer layout (reference src/cutadapt/runners.py:96-245) with GPUs as the workers.
 
 Two ways through a chunk once it is indexed:
-  * the all-device way (any number of single, non-rightmost adapters with ``--times N``, or one linked adapter; action ``trim``
+  * the all-device way (any number of single, non-rightmost adapters with ``--times N``, or linked adapters (``--times 1``); action ``trim``
     -- or, with one round of single adapters, ``none`` / ``retain`` / ``crop``: other intervals from the same matches --;
     the marking actions ``mask`` / ``lowercase`` (marked in place in HBM); ``--revcomp`` with action ``trim``, one round and
     single adapters (both orientations matched, the better one turned around in place in HBM); ``--info-file`` with one round
@@ -21,7 +21,7 @@ Two ways through a chunk once it is indexed:
     ``-M`` / ``--discard-(un)trimmed`` behind it -- the usual ``cutadapt -q 20 -a ADAPTER -m 20`` and more): trim,
     match, decide and format without a byte of per-read data touching the host (``cah_trim_decide_device`` /
     ``cah_trim_decide_window_device`` / ``cah_trim_decide_action_device`` / ``cah_trim_filter_device``);
-  * the general way (everything else ``pipeline.BatchTrimmer`` does: rightmost adapters, linked ones among others,
+  * the general way (everything else ``pipeline.BatchTrimmer`` does: rightmost adapters, linked ones among single ones,
     ``--revcomp`` / ``--info-file`` with several rounds or a marking action, ``--pair-adapters``, adapter sets regrouped behind an
     ``AdapterIndex``): the
     modifiers run as kernels on windows into the raw chunk in HBM (``DeviceFastqChunk``: reads AND qualities are used in place), the window arithmetic between them is
@@ -375,45 +375,64 @@ class _Worker:
                 wlen = kept.contiguous()
             wbeg = wbeg.contiguous()
         voff = seq_off if wbeg is None else (seq_off + wbeg.to(torch.int64)).contiguous()
-        linked = isinstance(self.plan, _LinkedPlans)
+        linked = isinstance(self.plan, (_LinkedPlans, list))
         if linked:
-            # one linked adapter (reference adapters.py:1215-1227): the 5' plan on the window, the 3' plan on what is
-            # behind the 5' match (cah_linked_views), the required / optional verdict and the kept interval as a
-            # handful of element-wise operations on this stream
-            lp = self.plan
-            ws_need = max(int(L.cah_plan_workspace_bytes(lp.front.handle, n)), int(L.cah_plan_workspace_bytes(lp.back.handle, n)))
+            # linked adapters (reference adapters.py:1215-1227): per adapter the 5' plan on the window, the 3' plan on what is
+            # behind the 5' match (cah_linked_views), the required / optional verdict and the kept interval as a handful of
+            # element-wise operations on this stream; several of them (round 6): MultipleAdapters' rule over the LinkedMatches
+            # (adapters.py:1278-1285: the higher score -- the parts' scores added up --, then fewer errors, then the first)
+            plans = self.plan if isinstance(self.plan, list) else [self.plan]
+            ws_need = max(int(L.cah_plan_workspace_bytes(h.handle, n)) for lp in plans for h in (lp.front, lp.back))
             if self._ws is None or self._ws.numel() < ws_need:
                 self._ws = torch.empty(ws_need + ws_need // 4, dtype=torch.uint8, device=self.device)
-            f_out6 = torch.empty((n, 6), dtype=torch.int32, device=self.device)
-            f_status = torch.empty(n, dtype=torch.uint8, device=self.device)
-            f_best = torch.empty(n, dtype=torch.int32, device=self.device)
-            starts = torch.empty(n, dtype=torch.int64, device=self.device)
-            vlens = torch.empty(n, dtype=torch.int32, device=self.device)
             wl = wlen.contiguous()
-            _lib.check(L.cah_match_batch(lp.front.handle, self.d_in.data_ptr(), voff.data_ptr(), wl.data_ptr(), n,
-                                         f_out6.data_ptr(), f_best.data_ptr(), f_status.data_ptr(),
-                                         self._ws.data_ptr(), self._ws.numel(), sp))
-            _lib.check(L.cah_linked_views(f_out6.data_ptr(), f_status.data_ptr(), voff.data_ptr(), wl.data_ptr(), 0, n,
-                                          starts.data_ptr(), vlens.data_ptr(), sp))
-            _lib.check(L.cah_match_batch(lp.back.handle, self.d_in.data_ptr(), starts.data_ptr(), vlens.data_ptr(), n,
-                                         self.res.out6.data_ptr(), self.res.best_adapter.data_ptr(),
-                                         self.res.status.data_ptr(), self._ws.data_ptr(), self._ws.numel(), sp))
-            b_status = self.res.status[:n]
-            F, B = f_status == 1, b_status == 1
-            ok = B if lp.back_required else (B | F)           # LinkedAdapter.match_to: None unless ...
-            if lp.front_required:
-                ok = ok & F
             w0 = wbeg if wbeg is not None else torch.zeros(n, dtype=torch.int32, device=self.device)
-            b = w0 + torch.where(ok & F, f_out6[:, 3], torch.zeros_like(wl))
-            e = torch.where(ok & B, b + self.res.out6[:n, 2], w0 + wl)
+            zero = torch.zeros_like(wl)
+            best = None
+            invalid = None
+            for lp in plans:
+                f_out6 = torch.empty((n, 6), dtype=torch.int32, device=self.device)
+                f_status = torch.empty(n, dtype=torch.uint8, device=self.device)
+                f_best = torch.empty(n, dtype=torch.int32, device=self.device)
+                b_out6 = torch.empty((n, 6), dtype=torch.int32, device=self.device)
+                b_status = torch.empty(n, dtype=torch.uint8, device=self.device)
+                b_best = torch.empty(n, dtype=torch.int32, device=self.device)
+                starts = torch.empty(n, dtype=torch.int64, device=self.device)
+                vlens = torch.empty(n, dtype=torch.int32, device=self.device)
+                _lib.check(L.cah_match_batch(lp.front.handle, self.d_in.data_ptr(), voff.data_ptr(), wl.data_ptr(), n,
+                                             f_out6.data_ptr(), f_best.data_ptr(), f_status.data_ptr(),
+                                             self._ws.data_ptr(), self._ws.numel(), sp))
+                _lib.check(L.cah_linked_views(f_out6.data_ptr(), f_status.data_ptr(), voff.data_ptr(), wl.data_ptr(), 0, n,
+                                              starts.data_ptr(), vlens.data_ptr(), sp))
+                _lib.check(L.cah_match_batch(lp.back.handle, self.d_in.data_ptr(), starts.data_ptr(), vlens.data_ptr(), n,
+                                             b_out6.data_ptr(), b_best.data_ptr(), b_status.data_ptr(),
+                                             self._ws.data_ptr(), self._ws.numel(), sp))
+                F, B = f_status == 1, b_status == 1
+                ok = B if lp.back_required else (B | F)           # LinkedAdapter.match_to: None unless ...
+                if lp.front_required:
+                    ok = ok & F
+                b = w0 + torch.where(ok & F, f_out6[:, 3], zero)
+                e = torch.where(ok & B, b + b_out6[:, 2], w0 + wl)
+                score = torch.where(F, f_out6[:, 4], zero) + torch.where(B, b_out6[:, 4], zero)
+                errors = torch.where(F, f_out6[:, 5], zero) + torch.where(B, b_out6[:, 5], zero)
+                bad = (f_status == 2) | (b_status == 2)
+                invalid = bad if invalid is None else (invalid | bad)
+                if best is None:
+                    best = [ok, b, e, score, errors]
+                else:
+                    better = ok & (~best[0] | (score > best[3]) | ((score == best[3]) & (errors < best[4])))
+                    best = [best[0] | ok, torch.where(better, b, best[1]), torch.where(better, e, best[2]),
+                            torch.where(better, score, best[3]), torch.where(better, errors, best[4])]
+                keepalive += [f_out6, f_status, f_best, b_out6, b_status, b_best, starts, vlens]
+            ok, b, e = best[0], best[1], best[2]
             self.counters[0] += n
             self.counters[1] += ok.sum()
             self.counters[2] += seq_len.sum()
-            self.counters[6] += ((f_status == 2) | (b_status == 2)).sum()
-            self.beg[:n].copy_(b)
-            self.end[:n].copy_(e)
-            b_status.copy_(ok.to(torch.uint8))                # "with adapters", as the filters read it
-            keepalive += [f_out6, f_status, f_best, starts, vlens, wl]
+            self.counters[6] += invalid.sum()
+            self.beg[:n].copy_(torch.where(ok, b, w0))
+            self.end[:n].copy_(torch.where(ok, e, w0 + wl))
+            self.res.status[:n].copy_(ok.to(torch.uint8))     # "with adapters", as the filters read it
+            keepalive += [wl, w0]
         elif self.plan is not None:
             ws_need = int(L.cah_plan_workspace_bytes(self.plan.handle, n))
             if self._ws is None or self._ws.numel() < ws_need:
@@ -830,21 +849,20 @@ _LinkedPlans = namedtuple("_LinkedPlans", "front back front_required back_requir
 
 
 def _all_device_adapters(adapters, times: int, index: bool) -> bool:
-    """adapter sets ``_Worker.modify`` serves: single non-rightmost adapters (any number, any --times), or ONE linked
-    adapter of such parts (--times 1)"""
-    if len(adapters) == 1 and isinstance(adapters[0], LinkedAdapter):
-        a = adapters[0]
-        return times == 1 and not a.front_adapter._reverse_reads and not a.back_adapter._reverse_reads
+    """adapter sets ``_Worker.modify`` serves: single non-rightmost adapters (any number, any --times), or linked
+    adapters of such parts (any number of them, --times 1)"""
+    if adapters and all(isinstance(a, LinkedAdapter) for a in adapters):
+        return times == 1 and not any(a.front_adapter._reverse_reads or a.back_adapter._reverse_reads for a in adapters)
     return (times >= 1 and all(isinstance(a, SingleAdapter) and not a._reverse_reads for a in adapters)
             and not (index and _index_regroups(adapters)))
 
 
 def _plan_for(adapters):
     """the fused plan + adapter kinds of the all-device way"""
-    if len(adapters) == 1 and isinstance(adapters[0], LinkedAdapter):
-        a = adapters[0]
-        return _LinkedPlans(a.front_adapter._fused_plan, a.back_adapter._fused_plan, bool(a.front_required),
-                            bool(a.back_required)), [0]
+    if all(isinstance(a, LinkedAdapter) for a in adapters):
+        plans = [_LinkedPlans(a.front_adapter._fused_plan, a.back_adapter._fused_plan, bool(a.front_required),
+                              bool(a.back_required)) for a in adapters]
+        return (plans[0] if len(plans) == 1 else plans), [0]
     plan = adapters[-1]._fused_plan if len(adapters) == 1 else _lib.Plan([a.matcher_spec() for a in adapters])
     kinds = [2 if isinstance(a, AnywhereAdapter) else (1 if a._remove_before else 0) for a in adapters]
     return plan, kinds

@@ -88,6 +88,9 @@ if devices is not None:
     linked = LinkedAdapter(FrontAdapter("ACGTACGTTT"), BackAdapter(workloads.TRUSEQ_R1, max_errors=0.1, min_overlap=3), False, True, "linked")
     timed(f"all-device way with one linked adapter (optional 5' part ... required 3' TruSeq) and -q 0,10 -m 20, devices={args.devices}",
           lambda: trim_fastq_gpu(fastq, None, [linked], threads=args.threads, devices=devices, quality_cutoff=(0, 10), minimum_length=20))
+    linked2 = LinkedAdapter(FrontAdapter("TTGACCAGTA"), BackAdapter(workloads.TRUSEQ_R1[:20], max_errors=0.1, min_overlap=3), False, False, "linked2")
+    timed(f"two linked adapters and -q 0,10 -m 20 (round 6: all-device way; rounds 3-5: the general way), devices={args.devices}",
+          lambda: trim_fastq_gpu(fastq, None, [linked, linked2], threads=args.threads, devices=devices, quality_cutoff=(0, 10), minimum_length=20))
     timed(f"--times 2 --action mask (round 6: all-device way, the reads marked in place on the device; rounds 3-5: the general way), devices={args.devices}",
           lambda: trim_fastq_gpu(fastq, None, [adapter], threads=args.threads, devices=devices, times=2, action="mask"))
     timed(f"-q 0,10 --action mask (round 6: all-device way), devices={args.devices}",

@@ -83,6 +83,16 @@ def test_device_fastq_equals_host_pipeline(hip):
         ([A.LinkedAdapter(A.FrontAdapter(ad_seqs[2]), A.BackAdapter(ad_seqs[0]), False, True, "l3")],
          {"quality_cutoff": (5, 15), "poly_a": True, "maximum_length": 100}),
         ([A.LinkedAdapter(A.FrontAdapter(ad_seqs[2]), A.SuffixAdapter(ad_seqs[1]), False, False, "l4")], {"cut": [1], "length": 50}),
+        # several linked adapters (round 6): MultipleAdapters' rule over the LinkedMatches -- scores and errors of the parts
+        # added up --, every required / optional mix, modifiers on both sides
+        ([A.LinkedAdapter(A.PrefixAdapter(ad_seqs[2]), A.BackAdapter(ad_seqs[0]), True, False, "m1"),
+          A.LinkedAdapter(A.PrefixAdapter(ad_seqs[2]), A.BackAdapter(ad_seqs[1]), True, False, "m2")], {"minimum_length": 5}),
+        ([A.LinkedAdapter(A.FrontAdapter(ad_seqs[2]), A.BackAdapter(ad_seqs[0]), False, True, "m3"),
+          A.LinkedAdapter(A.PrefixAdapter(ad_seqs[2][:6]), A.BackAdapter(ad_seqs[1]), True, True, "m4"),
+          A.LinkedAdapter(A.FrontAdapter(ad_seqs[1][:10]), A.SuffixAdapter(ad_seqs[2]), False, False, "m5")],
+         {"quality_cutoff": (5, 15), "poly_a": True, "maximum_length": 120, "discard_untrimmed": True}),
+        ([A.LinkedAdapter(A.FrontAdapter(ad_seqs[2]), A.BackAdapter(ad_seqs[0]), True, True, "m6"),
+          A.LinkedAdapter(A.FrontAdapter(ad_seqs[2]), A.BackAdapter(ad_seqs[0][:20]), False, False, "m7")], {"action": "mask", "cut": [1]}),
         # --action none / retain / crop (one round): other intervals from the same matches (round 4)
         ([A.BackAdapter(ad_seqs[0]), A.FrontAdapter(ad_seqs[1]), A.AnywhereAdapter(ad_seqs[2])], {"action": None, "discard_untrimmed": True}),
         ([A.BackAdapter(ad_seqs[0]), A.FrontAdapter(ad_seqs[1]), A.AnywhereAdapter(ad_seqs[2])], {"action": "retain", "minimum_length": 12}),

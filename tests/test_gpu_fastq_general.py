@@ -54,7 +54,7 @@ def test_single_end_goldens_through_the_device_path(hip):
             assert stats["too_many_expected_errors"] == 2
         if case["name"] == "revcomp_normalized":
             assert stats["reverse_complemented"] == 2                   # reference test_commandline.py:834
-    # what still takes the general way: info files of several rounds or of linked adapters, several linked adapters
+    # what still takes the general way: info files of several rounds or of linked adapters
     # (round 6: mask / lowercase with single adapters are marked in place on the device, cah_mark_reads_device; --revcomp is
     # matched in both orientations and turned around there, cah_revcomp_in_place_device; the info rows of one round of single
     # adapters are formatted there, cah_info_format_device)
