@@ -252,3 +252,78 @@ def test_feeder_processes_write_the_same_bytes_as_feeder_threads(hip, tmp_path):
     assert r["bytes_out"] == os.path.getsize(tmp_path / "thread0.fastq")
     with pytest.raises(ValueError):
         trim_fastq_gpu(io.BytesIO(src.read_bytes()), None, feeder="process", **cases[0][0])
+
+
+def test_revcomp_suffix_and_info_entries_at_the_c_abi(hip):
+    """cah_revcomp_in_place_device / cah_fastq_format_suffix_device / cah_info_format_device called directly on a small chunk
+    in HBM, against a per-record restatement of ReverseComplementer + InfoFileWriter (reference modifiers.py:280-297,
+    steps.py:232-253, adapters.py:395-417); argument errors are reported, not executed"""
+    import ctypes as C
+    import numpy as np
+    import torch
+    from cutadapt_amd import _lib
+    L = _lib.lib()
+    recs = [("r0 c", "ACGTNacgtn", "IIIIIHHHHH"), ("r1", "A", "#"), ("r2", "", ""), ("r3 xyz", "GATTACAGATTACA", "ABCDEFGHIJKLMN")]
+    chunk = "".join(f"@{n}\n{s}\n+\n{q}\n" for n, s, q in recs).encode()
+    dev = torch.device("cuda", 0)
+    n, nb = len(recs), len(chunk)
+    d_in = torch.from_numpy(np.frombuffer(chunk, dtype=np.uint8).copy()).to(dev)
+    scratch = torch.empty(int(L.cah_fastq_device_scratch_bytes(nb, n)) + 4096, dtype=torch.uint8, device=dev)
+    info = torch.zeros(8, dtype=torch.int64, device=dev)
+    rec6 = torch.empty((n, 6), dtype=torch.int64, device=dev)
+    soff = torch.empty(n, dtype=torch.int64, device=dev)
+    slen = torch.empty(n, dtype=torch.int32, device=dev)
+    _lib.check(L.cah_fastq_count_lines_device(d_in.data_ptr(), nb, scratch.data_ptr(), scratch.numel(), info.data_ptr(), None))
+    torch.cuda.synchronize()
+    _lib.check(L.cah_fastq_index_device(d_in.data_ptr(), nb, int(info[0]), n, scratch.data_ptr(), scratch.numel(), rec6.data_ptr(),
+                                        soff.data_ptr(), slen.data_ptr(), info.data_ptr(), None))
+    flags = torch.tensor([1, 1, 1, 0], dtype=torch.uint8, device=dev)
+    _lib.check(L.cah_revcomp_in_place_device(d_in.data_ptr(), rec6.data_ptr(), n, None, slen.data_ptr(), flags.data_ptr(), None))
+    comp = str.maketrans("ACGTNacgtn", "TGCANtgcan")
+    turned = [(nm, s[::-1].translate(comp) if f else s, q[::-1] if f else q) for (nm, s, q), f in zip(recs, [1, 1, 1, 0])]
+    # the formatter with the suffix, every record whole
+    beg = torch.zeros(n, dtype=torch.int32, device=dev)
+    end = slen.clone()
+    keep = torch.ones(n, dtype=torch.uint8, device=dev)
+    out = torch.empty(nb + 64 * n, dtype=torch.uint8, device=dev)
+    _lib.check(L.cah_fastq_format_suffix_device(d_in.data_ptr(), rec6.data_ptr(), n, beg.data_ptr(), end.data_ptr(), keep.data_ptr(),
+                                                flags.data_ptr(), b" rc", 3, scratch.data_ptr(), scratch.numel(), nb, out.data_ptr(),
+                                                out.numel(), info.data_ptr(), None))
+    torch.cuda.synchronize()
+    got = bytes(out[: int(info[3])].cpu().numpy())
+    want = "".join(f"@{nm}{' rc' if f else ''}\n{s}\n+\n{q}\n" for (nm, s, q), f in zip(turned, [1, 1, 1, 0])).encode()
+    assert got == want, (got, want)
+    # info rows: record 0 and 3 matched (errors, rstart, rstop), 1 and 2 not; the rc column says which were turned
+    out6 = torch.zeros((n, 6), dtype=torch.int32, device=dev)
+    out6[0] = torch.tensor([0, 4, 2, 6, 4, 1], dtype=torch.int32)
+    out6[3] = torch.tensor([0, 7, 7, 14, 7, 0], dtype=torch.int32)
+    status = torch.tensor([1, 0, 0, 1], dtype=torch.uint8, device=dev)
+    best = torch.tensor([1, 0, 0, 0], dtype=torch.int32, device=dev)
+    names = torch.from_numpy(np.frombuffer(b"firstsecond2", dtype=np.uint8).copy()).to(dev)
+    name_off = torch.tensor([0, 5, 12], dtype=torch.int32, device=dev)
+    total = torch.zeros(1, dtype=torch.int64, device=dev)
+    iout = torch.empty(nb + n * 64, dtype=torch.uint8, device=dev)
+    _lib.check(L.cah_info_format_device(d_in.data_ptr(), rec6.data_ptr(), n, out6.data_ptr(), status.data_ptr(), best.data_ptr(),
+                                        beg.data_ptr(), end.data_ptr(), names.data_ptr(), name_off.data_ptr(), 2, flags.data_ptr(),
+                                        b" rc", 3, scratch.data_ptr(), scratch.numel(), nb, iout.data_ptr(), iout.numel(),
+                                        total.data_ptr(), None))
+    torch.cuda.synchronize()
+    got = bytes(iout[: int(total[0])].cpu().numpy()).decode()
+    s0, q0 = turned[0][1], turned[0][2]
+    s3, q3 = turned[3][1], turned[3][2]
+    want = (f"r0 c rc\t1\t2\t6\t{s0[:2]}\t{s0[2:6]}\t{s0[6:]}\tsecond2\t{q0[:2]}\t{q0[2:6]}\t{q0[6:]}\t1\n"
+            f"r1\t-1\t{turned[1][1]}\t{turned[1][2]}\n"
+            f"r2\t-1\t\t\n"
+            f"r3 xyz\t0\t7\t14\t{s3[:7]}\t{s3[7:14]}\t{s3[14:]}\tfirst\t{q3[:7]}\t{q3[7:14]}\t{q3[14:]}\t0\n")
+    assert got == want, (got, want)
+    # argument errors: a suffix longer than CAH_MAX_NAME_SUFFIX, missing pointers, negative counts
+    for rc in (L.cah_fastq_format_suffix_device(d_in.data_ptr(), rec6.data_ptr(), n, beg.data_ptr(), end.data_ptr(), keep.data_ptr(),
+                                                flags.data_ptr(), b"x" * 40, 40, scratch.data_ptr(), scratch.numel(), nb,
+                                                out.data_ptr(), out.numel(), info.data_ptr(), None),
+               L.cah_revcomp_in_place_device(d_in.data_ptr(), rec6.data_ptr(), n, None, None, flags.data_ptr(), None),
+               L.cah_revcomp_in_place_device(d_in.data_ptr(), rec6.data_ptr(), -1, None, slen.data_ptr(), flags.data_ptr(), None),
+               L.cah_info_format_device(d_in.data_ptr(), rec6.data_ptr(), n, None, status.data_ptr(), best.data_ptr(), beg.data_ptr(),
+                                        end.data_ptr(), names.data_ptr(), name_off.data_ptr(), 2, None, None, 0, scratch.data_ptr(),
+                                        scratch.numel(), nb, iout.data_ptr(), iout.numel(), total.data_ptr(), None)):
+        assert rc == _lib.CAH_EINVAL, rc
+    assert L.cah_revcomp_in_place_device(d_in.data_ptr(), rec6.data_ptr(), 0, None, None, None, None) == 0      # nothing to do
