@@ -168,8 +168,8 @@ def lib():
         L.cah_revcomp_in_place_device.argtypes = [vp, vp, i64, vp, vp, vp, vp]
         L.cah_fastq_format_suffix_device.argtypes = [vp, vp, i64, vp, vp, vp, vp, C.c_char_p, C.c_int32, vp, C.c_size_t, i64, vp,
                                                      i64, vp, vp]
-        L.cah_info_format_device.argtypes = [vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, C.c_int32, vp, C.c_char_p, C.c_int32, vp,
-                                             C.c_size_t, i64, vp, i64, vp, vp]
+        L.cah_info_format_device.argtypes = [vp, vp, i64, vp, vp, vp, C.c_int32, vp, vp, vp, vp, vp, C.c_int32, vp, C.c_char_p,
+                                             C.c_int32, vp, C.c_size_t, i64, vp, i64, vp, vp]
     L.cah_trim_decide_device.argtypes = [vp, vp, vp, vp, i64, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     L.cah_trim_decide_window_device.argtypes = [vp, vp, vp, vp, vp, vp, i64, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     L.cah_trim_decide_action_device.argtypes = [vp, vp, vp, vp, vp, vp, i64, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]

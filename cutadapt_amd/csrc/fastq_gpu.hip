@@ -285,7 +285,9 @@ __global__ __launch_bounds__(256) void k_format(const uint8_t* buf, const int64_
 //   a read without one    name \t -1 \t seq[fb:fe] \t qual[fb:fe] \n      (the read as it is written, :248-251)
 struct InfoArgs {
     const uint8_t* buf; const int64_t* rec6; int64_t n_records;
-    const int32_t* out6; const uint8_t* status; const int32_t* best;
+    // the adapter step's results, round after round (--times N): round k's rows of record r at [k * n_records + r]
+    const int32_t* out6; const uint8_t* status; const int32_t* best; int rounds;
+    const uint8_t* kinds;                                            // per adapter: 0 3' (keeps what is in front), 1 5', 2 anywhere
     const int32_t* final_beg; const int32_t* final_end;
     const uint8_t* names; const int32_t* name_off; int n_names;
     const uint8_t* is_rc;                                            // NULL: the rc column stays empty
@@ -303,50 +305,63 @@ __device__ __forceinline__ void put_digits(uint8_t* w, int v, const int d) {
     for (int i = d - 1; i >= 0; --i) { w[i] = (uint8_t)('0' + v % 10); v /= 10; }
 }
 
-struct InfoRow {
-    bool matched; int64_t name_len, seq_len; int extra, err, rs, re, ni, nlen; int64_t fa, fb;
-};
+// One match row: the read as InfoFileWriter holds it at that round -- [qb, qe) of the read as it came in: steps.py:233-247
+// starts from info.original_read and trims it the way every match trims (`current_read = match.trimmed(current_read)`) -- cut
+// at the match's coordinates (found on what the earlier modifiers and rounds left; clamped to that read as the host writer
+// clamps them, pipeline.py: _info_rows_on_original)
+struct InfoRow { int err, rs, re, ni, nlen; int64_t qb, qe; };
 
-__device__ __forceinline__ InfoRow info_row(const InfoArgs& a, const int64_t r) {
-    InfoRow x;
-    const int64_t* o = a.rec6 + r * 6;
-    x.name_len = o[1] - o[0];
-    x.seq_len = o[3] - o[2];
-    x.matched = a.status[r] == 1;
-    x.extra = 0; x.err = x.rs = x.re = x.ni = x.nlen = 0; x.fa = x.fb = 0;
-    if (x.matched) {
-        const int32_t* m = a.out6 + r * 6;
-        x.err = m[5];
-        int64_t re = m[3], rs = m[2];
-        if (re > x.seq_len) re = x.seq_len;
-        if (re < 0) re = 0;
-        if (rs > re) rs = re;
-        if (rs < 0) rs = 0;
-        x.rs = (int)rs; x.re = (int)re;
-        x.ni = a.best[r];
-        if (x.ni < 0 || x.ni >= a.n_names) x.ni = 0;
-        x.nlen = a.n_names > 0 ? a.name_off[x.ni + 1] - a.name_off[x.ni] : 0;
-        x.extra = a.is_rc && a.is_rc[r] ? a.sfx.len : 0;
-    } else {
-        int64_t fa = a.final_beg[r], fb = a.final_end[r];
-        if (fa < 0) fa = 0;
-        if (fb > x.seq_len) fb = x.seq_len;
-        if (fb < fa) fb = fa;
-        x.fa = fa; x.fb = fb;
-    }
-    return x;
+__device__ __forceinline__ bool info_round(const InfoArgs& a, const int64_t r, const int k, int64_t& qb, int64_t& qe, InfoRow& x) {
+    const int64_t at = (int64_t)k * a.n_records + r;
+    if (a.status[at] != 1) return false;
+    const int32_t* m = a.out6 + at * 6;
+    int64_t re = m[3], rs = m[2];
+    if (re > qe - qb) re = qe - qb;
+    if (re < 0) re = 0;
+    if (rs > re) rs = re;
+    if (rs < 0) rs = 0;
+    x.err = m[5]; x.rs = (int)rs; x.re = (int)re; x.qb = qb; x.qe = qe;
+    x.ni = a.best[at];
+    if (x.ni < 0 || x.ni >= a.n_names) x.ni = 0;
+    x.nlen = a.n_names > 0 ? a.name_off[x.ni + 1] - a.name_off[x.ni] : 0;
+    // what the match leaves (Match.trimmed: a 5' match keeps what follows it, a 3' match what is in front; an "anywhere"
+    // adapter counts as 5' when the match starts at position 0: adapters.py:453-454, :486-487, :931)
+    const int kind = a.kinds ? a.kinds[x.ni] : 0;
+    const bool before = kind == 1 || (kind == 2 && m[2] == 0);
+    if (before) qb = qb + re; else qe = qb + rs;
+    return true;
 }
 
-__device__ __forceinline__ int64_t info_row_len(const InfoArgs& a, const InfoRow& x, const int64_t r) {
-    if (!x.matched) return x.name_len + 4 + 2 * (x.fb - x.fa) + 2;
-    return x.name_len + x.extra + 1 + n_digits(x.err) + 1 + n_digits(x.rs) + 1 + n_digits(x.re) + 1 + x.seq_len + 3 + x.nlen + 1
-         + x.seq_len + 2 + 1 + (a.is_rc ? 1 : 0) + 1;
+__device__ __forceinline__ int64_t info_match_len(const InfoArgs& a, const InfoRow& x, const int64_t name_len, const int extra) {
+    const int64_t shown = x.qe - x.qb;
+    return name_len + extra + 1 + n_digits(x.err) + 1 + n_digits(x.rs) + 1 + n_digits(x.re) + 1 + shown + 3 + x.nlen + 1
+         + shown + 2 + 1 + (a.is_rc ? 1 : 0) + 1;
+}
+
+__device__ __forceinline__ void info_final(const InfoArgs& a, const int64_t r, const int64_t seq_len, int64_t& fa, int64_t& fb) {
+    fa = a.final_beg[r]; fb = a.final_end[r];
+    if (fa < 0) fa = 0;
+    if (fb > seq_len) fb = seq_len;
+    if (fb < fa) fb = fa;
 }
 
 __global__ __launch_bounds__(256) void k_info_len(const InfoArgs a, int64_t* out_len) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.n_records; r += stride)
-        out_len[r] = info_row_len(a, info_row(a, r), r);
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.n_records; r += stride) {
+        const int64_t* o = a.rec6 + r * 6;
+        const int64_t name_len = o[1] - o[0], seq_len = o[3] - o[2];
+        const int extra = a.is_rc && a.is_rc[r] ? a.sfx.len : 0;
+        int64_t qb = 0, qe = seq_len, total = 0;
+        InfoRow x;
+        int k = 0;
+        for (; k < a.rounds && info_round(a, r, k, qb, qe, x); ++k) total += info_match_len(a, x, name_len, extra);
+        if (k == 0) {
+            int64_t fa, fb;
+            info_final(a, r, seq_len, fa, fb);
+            total = name_len + 4 + 2 * (fb - fa) + 2;
+        }
+        out_len[r] = total;
+    }
 }
 
 // one wave per record
@@ -355,11 +370,11 @@ __global__ __launch_bounds__(256) void k_info_format(const InfoArgs a, const int
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t n_waves = (int64_t)gridDim.x * 4;
     for (int64_t r = wave; r < a.n_records; r += n_waves) {
-        const InfoRow x = info_row(a, r);
         const int64_t* o = a.rec6 + r * 6;
-        const int64_t pos = out_off[r];
-        if (pos + info_row_len(a, x, r) > out_cap) continue;            // never: the caller sizes out for the chunk
-        uint8_t* w = out + pos;
+        const int64_t name_len = o[1] - o[0], seq_len = o[3] - o[2];
+        const int extra = a.is_rc && a.is_rc[r] ? a.sfx.len : 0;
+        uint8_t* w = out + out_off[r];
+        uint8_t* const cap = out + out_cap;
         auto copy = [&](const uint8_t* src, const int64_t len) {
             for (int64_t k = lane; k < len; k += 64) w[k] = src[k];
             w += len;
@@ -367,36 +382,46 @@ __global__ __launch_bounds__(256) void k_info_format(const InfoArgs a, const int
         auto put = [&](const uint8_t c) { if (lane == 0) w[0] = c; ++w; };
         const uint8_t* seq = a.buf + o[2];
         const uint8_t* qual = a.buf + o[4];
-        copy(a.buf + o[0], x.name_len);
-        if (!x.matched) {
+        int64_t qb = 0, qe = seq_len;
+        InfoRow x;
+        int k = 0;
+        for (; k < a.rounds && info_round(a, r, k, qb, qe, x); ++k) {
+            if (w + info_match_len(a, x, name_len, extra) > cap) break;     // never: the caller sizes out for the chunk
+            copy(a.buf + o[0], name_len);
+            if (lane < extra) w[lane] = a.sfx.c[lane];
+            w += extra;
+            put('\t');
+            const int d0 = n_digits(x.err), d1 = n_digits(x.rs), d2 = n_digits(x.re);
+            if (lane == 0) {
+                put_digits(w, x.err, d0); w[d0] = '\t';
+                put_digits(w + d0 + 1, x.rs, d1); w[d0 + 1 + d1] = '\t';
+                put_digits(w + d0 + d1 + 2, x.re, d2); w[d0 + d1 + d2 + 2] = '\t';
+            }
+            w += d0 + d1 + d2 + 3;
+            const int64_t a0 = x.qb + x.rs, a1 = x.qb + x.re;
+            copy(seq + x.qb, x.rs); put('\t');
+            copy(seq + a0, x.re - x.rs); put('\t');
+            copy(seq + a1, x.qe - a1); put('\t');
+            if (x.nlen) copy(a.names + a.name_off[x.ni], x.nlen);
+            put('\t');
+            copy(qual + x.qb, x.rs); put('\t');
+            copy(qual + a0, x.re - x.rs); put('\t');
+            copy(qual + a1, x.qe - a1); put('\t');
+            if (a.is_rc) put(a.is_rc[r] ? '1' : '0');
+            put('\n');
+        }
+        if (k == 0) {
+            int64_t fa, fb;
+            info_final(a, r, seq_len, fa, fb);
+            if (w + name_len + 4 + 2 * (fb - fa) + 2 > cap) continue;
+            copy(a.buf + o[0], name_len);
             if (lane == 0) { w[0] = '\t'; w[1] = '-'; w[2] = '1'; w[3] = '\t'; }
             w += 4;
-            copy(seq + x.fa, x.fb - x.fa);
+            copy(seq + fa, fb - fa);
             put('\t');
-            copy(qual + x.fa, x.fb - x.fa);
+            copy(qual + fa, fb - fa);
             put('\n');
-            continue;
         }
-        if (lane < x.extra) w[lane] = a.sfx.c[lane];
-        w += x.extra;
-        put('\t');
-        const int d0 = n_digits(x.err), d1 = n_digits(x.rs), d2 = n_digits(x.re);
-        if (lane == 0) {
-            put_digits(w, x.err, d0); w[d0] = '\t';
-            put_digits(w + d0 + 1, x.rs, d1); w[d0 + 1 + d1] = '\t';
-            put_digits(w + d0 + d1 + 2, x.re, d2); w[d0 + d1 + d2 + 2] = '\t';
-        }
-        w += d0 + d1 + d2 + 3;
-        copy(seq, x.rs); put('\t');
-        copy(seq + x.rs, x.re - x.rs); put('\t');
-        copy(seq + x.re, x.seq_len - x.re); put('\t');
-        if (x.nlen) copy(a.names + a.name_off[x.ni], x.nlen);
-        put('\t');
-        copy(qual, x.rs); put('\t');
-        copy(qual + x.rs, x.re - x.rs); put('\t');
-        copy(qual + x.re, x.seq_len - x.re); put('\t');
-        if (a.is_rc) put(a.is_rc[r] ? '1' : '0');
-        put('\n');
     }
 }
 
@@ -766,18 +791,21 @@ int cah_fastq_format_suffix_device(const uint8_t* d_buf, const int64_t* d_rec6, 
                        d_scratch, scratch_bytes, chunk_bytes, d_out, out_cap, d_info, stream);
 }
 
-// --info-file rows of a chunk in HBM (k_info_len / scan / k_info_format): one line per record in record order, d_total[0] =
-// bytes written.  d_out6 / d_status / d_best: the adapter step's result for every read (status 1: a match row; one round);
-// d_final_beg / d_final_end: what is written of every read (the line of a read without a match shows that); d_names /
-// d_name_off (int32[n_names + 1]): the adapters' names back to back, in plan order; d_is_rc NULL: no --revcomp, the last
-// column stays empty; else "0" / "1", and the names of the reads with d_is_rc[r] != 0 carry `suffix`.
-// out_cap >= chunk length + n_records * (longest adapter name + suffix_len + 48) always suffices.
+// --info-file rows of a chunk in HBM (k_info_len / scan / k_info_format): the lines of every record in record order, d_total[0] =
+// bytes written.  d_out6 / d_status / d_best: the adapter step's results, round after round (rounds >= 1 arrays of n_records
+// rows back to back: --times N; a read's rows end with its first round without a match); d_kinds: per adapter 0 = 3', 1 = 5',
+// 2 = anywhere (what a match leaves of the read the next row shows; NULL: all 3'); d_final_beg / d_final_end: what is written
+// of every read (the line of a read without a match shows that); d_names / d_name_off (int32[n_names + 1]): the adapters'
+// names back to back, in plan order; d_is_rc NULL: no --revcomp, the last column stays empty; else "0" / "1", and the names of
+// the reads with d_is_rc[r] != 0 carry `suffix`.
+// out_cap >= rounds * (chunk length + n_records * (longest adapter name + suffix_len + 48)) always suffices.
 int cah_info_format_device(const uint8_t* d_buf, const int64_t* d_rec6, int64_t n_records, const int32_t* d_out6,
-                           const uint8_t* d_status, const int32_t* d_best, const int32_t* d_final_beg, const int32_t* d_final_end,
+                           const uint8_t* d_status, const int32_t* d_best, int32_t rounds, const uint8_t* d_kinds,
+                           const int32_t* d_final_beg, const int32_t* d_final_end,
                            const uint8_t* d_names, const int32_t* d_name_off, int32_t n_names, const uint8_t* d_is_rc,
                            const char* suffix, int32_t suffix_len, void* d_scratch, size_t scratch_bytes, int64_t chunk_bytes,
                            uint8_t* d_out, int64_t out_cap, int64_t* d_total, void* stream) {
-    if (n_records < 0 || !d_scratch || !d_total || n_names < 0) return cah_set_error_(CAH_EINVAL, "cah_info_format_device: bad argument");
+    if (n_records < 0 || !d_scratch || !d_total || n_names < 0 || rounds < 1) return cah_set_error_(CAH_EINVAL, "cah_info_format_device: bad argument");
     if (suffix_len < 0 || suffix_len > CAH_MAX_NAME_SUFFIX || (suffix_len > 0 && !suffix))
         return cah_set_error_(CAH_EINVAL, "cah_info_format_device: suffix longer than CAH_MAX_NAME_SUFFIX");
     if (scratch_bytes < cah_fastq_device_scratch_bytes(chunk_bytes, n_records)) return cah_set_error_(CAH_EINVAL, "cah_info_format_device: scratch too small");
@@ -788,6 +816,7 @@ int cah_info_format_device(const uint8_t* d_buf, const int64_t* d_rec6, int64_t 
         return cah_set_error_(CAH_EINVAL, "cah_info_format_device: NULL argument");
     InfoArgs a;
     a.buf = d_buf; a.rec6 = d_rec6; a.n_records = n_records; a.out6 = d_out6; a.status = d_status; a.best = d_best;
+    a.rounds = rounds; a.kinds = d_kinds;
     a.final_beg = d_final_beg; a.final_end = d_final_end; a.names = d_names; a.name_off = d_name_off; a.n_names = n_names;
     a.is_rc = d_is_rc;
     a.sfx.len = d_is_rc ? suffix_len : 0;

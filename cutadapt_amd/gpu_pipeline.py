@@ -14,15 +14,16 @@ Two ways through a chunk once it is indexed:
   * the all-device way (any number of single, non-rightmost adapters with ``--times N``, or linked adapters (``--times 1``); action ``trim``
     -- or, with one round of single adapters, ``none`` / ``retain`` / ``crop``: other intervals from the same matches --;
     the marking actions ``mask`` / ``lowercase`` (marked in place in HBM); ``--revcomp`` with action ``trim``, one round and
-    single adapters (both orientations matched, the better one turned around in place in HBM); ``--info-file`` with one round
-    of single adapters and an action that leaves the characters alone (the rows formatted on the device);
+    single adapters (both orientations matched, the better one turned around in place in HBM); ``--info-file`` with single
+    adapters -- action ``trim`` with any number of rounds, or one round of an action that leaves the characters alone -- (the
+    rows formatted on the device);
     no adapter at all: the other modifiers and the filters alone;
     ``-u`` / ``--nextseq-trim`` / ``-q`` in front of the adapter step, ``--poly-a`` / ``-l`` / ``--max-ee`` / ``-m`` /
     ``-M`` / ``--discard-(un)trimmed`` behind it -- the usual ``cutadapt -q 20 -a ADAPTER -m 20`` and more): trim,
     match, decide and format without a byte of per-read data touching the host (``cah_trim_decide_device`` /
     ``cah_trim_decide_window_device`` / ``cah_trim_decide_action_device`` / ``cah_trim_filter_device``);
   * the general way (everything else ``pipeline.BatchTrimmer`` does: rightmost adapters, linked ones among single ones,
-    ``--revcomp`` / ``--info-file`` with several rounds or a marking action, ``--pair-adapters``, adapter sets regrouped behind an
+    ``--revcomp`` with several rounds, ``--revcomp`` / ``--info-file`` with a marking action, ``--pair-adapters``, adapter sets regrouped behind an
     ``AdapterIndex``): the
     modifiers run as kernels on windows into the raw chunk in HBM (``DeviceFastqChunk``: reads AND qualities are used in place), the window arithmetic between them is
     numpy on 4-byte-per-read arrays, and plain slicing is formatted on the device again.  What cannot be expressed
@@ -511,6 +512,7 @@ class _Worker:
                 wbeg.data_ptr() if wbeg is not None else None, wlen.data_ptr(), self.seq_len.data_ptr(), n,
                 self.kinds.data_ptr(), *lim, 0 if final_here else 1,
                 self.beg.data_ptr(), self.end.data_ptr(), self.keep.data_ptr(), self.counters.data_ptr(), sp))
+        self._info_rounds = None
         if rounds > 1:
             # --times N (reference modifiers.py:367-380: match, trim, match what is left, ... until nothing is found):
             # every further round matches the interval the last one kept.  A read without a match keeps its interval
@@ -518,7 +520,16 @@ class _Worker:
             # and every read can take every round; the later rounds' read / bp counters go to a scratch array.
             first_status = self.res.status[:n].clone()
             scratch = torch.zeros_like(self.counters)
-            for _ in range(rounds - 1):
+            info_rounds = None
+            if self.opts.get("info") is not None:
+                # --info-file: every round's match of every read is a row (cah_info_format_device takes them round after round)
+                info_rounds = (torch.empty((rounds, n, 6), dtype=torch.int32, device=self.device),
+                               torch.empty((rounds, n), dtype=torch.uint8, device=self.device),
+                               torch.empty((rounds, n), dtype=torch.int32, device=self.device))
+                info_rounds[0][0].copy_(self.res.out6[:n]); info_rounds[1][0].copy_(first_status)
+                info_rounds[2][0].copy_(self.res.best_adapter[:n])
+            self._info_rounds = info_rounds
+            for rnd in range(1, rounds):
                 rb = self.beg[:n].clone()
                 rl = (self.end[:n] - rb).contiguous()
                 ro = (seq_off + rb.to(torch.int64)).contiguous()
@@ -529,6 +540,9 @@ class _Worker:
                     self.res.out6.data_ptr(), self.res.status.data_ptr(), self.res.best_adapter.data_ptr(),
                     rb.data_ptr(), rl.data_ptr(), self.seq_len.data_ptr(), n, self.kinds.data_ptr(), -1, -1, 0, 0, 1,
                     self.beg.data_ptr(), self.end.data_ptr(), self.keep.data_ptr(), scratch.data_ptr(), sp))
+                if info_rounds is not None:
+                    info_rounds[0][rnd].copy_(self.res.out6[:n]); info_rounds[1][rnd].copy_(self.res.status[:n])
+                    info_rounds[2][rnd].copy_(self.res.best_adapter[:n])
                 keepalive += [rb, rl, ro]
             self.res.status[:n].copy_(first_status)
             keepalive += [first_status, scratch]
@@ -619,12 +633,17 @@ class _Worker:
             self._info_names = names
         rc = bool(self.opts.get("revcomp")) and self.plan is not None
         suffix = (self.opts.get("rc_suffix") or "").encode() if rc else b""
-        cap = n_bytes + n * (max([len(x) for x in names], default=0) + len(suffix) + 48) + 64
+        rounds_info = getattr(self, "_info_rounds", None)
+        if rounds_info is not None:
+            r6, rst, rbest, n_rounds = rounds_info[0], rounds_info[1], rounds_info[2], int(rounds_info[1].shape[0])
+        else:
+            r6, rst, rbest, n_rounds = self.res.out6, self.res.status, self.res.best_adapter, 1
+        cap = n_rounds * (n_bytes + n * (max([len(x) for x in names], default=0) + len(suffix) + 48)) + 64
         if getattr(self, "d_info_out", None) is None or self.d_info_out.numel() < cap:
             self.d_info_out = torch.empty(cap + cap // 4, dtype=torch.uint8, device=self.device)
         _lib.check(L.cah_info_format_device(
-            self.d_in.data_ptr(), self.rec6.data_ptr(), n, self.res.out6.data_ptr(), self.res.status.data_ptr(),
-            self.res.best_adapter.data_ptr(), self.beg.data_ptr(), self.end.data_ptr(), self.d_names.data_ptr(),
+            self.d_in.data_ptr(), self.rec6.data_ptr(), n, r6.data_ptr(), rst.data_ptr(), rbest.data_ptr(), n_rounds,
+            self.kinds.data_ptr() if self.plan is not None else None, self.beg.data_ptr(), self.end.data_ptr(), self.d_names.data_ptr(),
             self.d_name_off.data_ptr(), len(names), self.rc_flags.data_ptr() if rc else None, suffix if suffix else None,
             len(suffix), self.d_scratch.data_ptr(), self.d_scratch.numel(), n_bytes, self.d_info_out.data_ptr(),
             self.d_info_out.numel(), self.d_info_total.data_ptr(), sp))
@@ -1061,7 +1080,7 @@ def trim_fastq_gpu(source: Union[str, BinaryIO, np.ndarray], out: Union[str, Bin
                    cut: Sequence[int] = (), length: Optional[int] = None, revcomp: bool = False,
                    rc_suffix: Optional[str] = " rc", info_file: Union[None, str, BinaryIO] = None,
                    feeder: str = "thread", _ranges=None, _deliver=None, _stub_device: bool = False,
-                   _repeat: int = 1) -> Dict[str, object]:
+                   _repeat: int = 1, _general: bool = False) -> Dict[str, object]:
     """``cutadapt [-u N] [--nextseq-trim N] [-q [F,]B] <adapter options> [--times N] [--action A] [--revcomp]
     [--poly-a] [-l N] [--max-ee E] [-m N] [-M N] [--discard-(un)trimmed] [--info-file F] -o out in.fastq`` with the
     records indexed, matched, filtered and formatted on the GPU(s) (module docstring: which option sets take the
@@ -1136,10 +1155,11 @@ def trim_fastq_gpu(source: Union[str, BinaryIO, np.ndarray], out: Union[str, Bin
     # place -- _Worker.modify; without adapters --revcomp does nothing, reference cli.py:1113-1118)
     rc_device = bool(revcomp) and bool(adapters)
     rc_ok = not rc_device or (act == 0 and int(times) == 1 and no_linked and len((rc_suffix or "").encode()) <= _lib.MAX_NAME_SUFFIX)
-    # (... and --info-file with one round of single adapters, any action that leaves the characters alone: the rows are
-    # formatted on the device too, cah_info_format_device)
-    info_ok = info_file is None or (int(times) == 1 and no_linked and act in (0, 1, 2, 3))
-    all_device = (rc_ok and info_ok and
+    # (... and --info-file with single adapters -- action trim with any number of rounds, or one round of an action that leaves
+    # the characters alone: the rows are formatted on the device too, cah_info_format_device)
+    info_ok = info_file is None or (no_linked and (act == 0 or (int(times) == 1 and act in (1, 2, 3))))
+    # (_general: tests only -- the general way for an option set the all-device way serves, to compare the two)
+    all_device = (not _general and rc_ok and info_ok and
                   ((not adapters and action in ("trim", None, "none", "retain", "crop", "mask", "lowercase")) or
                    (bool(adapters) and (act == 0 or single_round_action or marking) and _all_device_adapters(adapters, int(times), index))))
     pre = post = None

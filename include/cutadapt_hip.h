@@ -481,26 +481,29 @@ int cah_fastq_format_suffix_device(const uint8_t *d_buf, const int64_t *d_rec6, 
                                    const char *suffix, int32_t suffix_len, void *d_scratch, size_t scratch_bytes,
                                    int64_t chunk_bytes, uint8_t *d_out, int64_t out_cap, int64_t *d_info, void *stream);
 /* --info-file rows of a chunk in HBM (InfoFileWriter, reference steps.py:215-253; Match.get_info_records,
- * adapters.py:395-417), one line per record in record order into d_out, d_total[0] = bytes written:
- *   a read with a match (d_status[r] == 1; one round of single adapters):
+ * adapters.py:395-417), the lines of every record in record order into d_out, d_total[0] = bytes written:
+ *   per match of a read (rounds of single adapters, --times N: d_out6 / d_status / d_best hold `rounds` arrays of n_records
+ *   rows back to back, cah_match_batch's results round after round; a read's rows end with its first round without a match):
  *       name[suffix] TAB errors TAB rstart TAB rstop TAB seq[:rstart] TAB seq[rstart:rstop] TAB seq[rstop:] TAB adapter name
  *       TAB qual[:rstart] TAB qual[rstart:rstop] TAB qual[rstop:] TAB rc LF
- *     seq = the WHOLE read as it came in (turned around if its reverse complement won: cah_revcomp_in_place_device with
- *     the whole read as the window) cut at the coordinates of the match -- which were found on what the modifiers in front
- *     of the adapter step left of the read; the reference does exactly that (steps.py:233-236: info.original_read) --;
- *     rc = "" (d_is_rc NULL: no --revcomp), "0" or "1" (RC_MAP, steps.py:224), and the names of the reads with
- *     d_is_rc[r] != 0 carry `suffix`;
- *   a read without one:  name TAB -1 TAB seq[fb:fe] TAB qual[fb:fe] LF   with [fb, fe) = [d_final_beg[r], d_final_end[r]):
+ *     seq = the read as InfoFileWriter holds it at that round: the WHOLE read as it came in (turned around if its reverse
+ *     complement won: cah_revcomp_in_place_device with the whole read as the window), trimmed the way every earlier match
+ *     trims (`current_read = match.trimmed(current_read)`, steps.py:247; d_kinds: per adapter 0 = 3' -- keeps what is in
+ *     front of the match --, 1 = 5', 2 = anywhere: 5' when the match starts at position 0; NULL: all 3'), cut at the
+ *     coordinates of the match -- which were found on what the modifiers in front of the adapter step and the earlier rounds
+ *     left of the read; the reference does exactly that (steps.py:233-236: info.original_read) --; rc = "" (d_is_rc NULL: no
+ *     --revcomp), "0" or "1" (RC_MAP, steps.py:224), and the names of the reads with d_is_rc[r] != 0 carry `suffix`;
+ *   a read without a match:  name TAB -1 TAB seq[fb:fe] TAB qual[fb:fe] LF   with [fb, fe) = [d_final_beg[r], d_final_end[r]):
  *     the read as it is written (steps.py:248-251).
- * d_out6 / d_status / d_best: cah_match_batch's results; d_names / d_name_off (int32[n_names + 1]): the adapters' names back
- * to back in plan order (device memory).  d_scratch as for cah_fastq_format_device (called after it: the formatter's arrays
- * are reused).  out_cap >= chunk length + n_records * (longest adapter name + suffix_len + 48) always suffices. */
+ * d_names / d_name_off (int32[n_names + 1]): the adapters' names back to back in plan order (device memory).  d_scratch as
+ * for cah_fastq_format_device (called after it: the formatter's arrays are reused).
+ * out_cap >= rounds * (chunk length + n_records * (longest adapter name + suffix_len + 48)) always suffices. */
 int cah_info_format_device(const uint8_t *d_buf, const int64_t *d_rec6, int64_t n_records, const int32_t *d_out6,
-                           const uint8_t *d_status, const int32_t *d_best, const int32_t *d_final_beg,
-                           const int32_t *d_final_end, const uint8_t *d_names, const int32_t *d_name_off, int32_t n_names,
-                           const uint8_t *d_is_rc, const char *suffix, int32_t suffix_len, void *d_scratch,
-                           size_t scratch_bytes, int64_t chunk_bytes, uint8_t *d_out, int64_t out_cap, int64_t *d_total,
-                           void *stream);
+                           const uint8_t *d_status, const int32_t *d_best, int32_t rounds, const uint8_t *d_kinds,
+                           const int32_t *d_final_beg, const int32_t *d_final_end, const uint8_t *d_names,
+                           const int32_t *d_name_off, int32_t n_names, const uint8_t *d_is_rc, const char *suffix,
+                           int32_t suffix_len, void *d_scratch, size_t scratch_bytes, int64_t chunk_bytes, uint8_t *d_out,
+                           int64_t out_cap, int64_t *d_total, void *stream);
 
 /* ---- AdapterIndex (adapters.py:1289-1551) on the GPU ---------- */
 /* Many anchored adapters of one kind (all 5' "^ADAPTER" or all 3' "ADAPTER$", no wildcards, at most

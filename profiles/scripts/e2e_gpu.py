@@ -121,9 +121,11 @@ if devices is not None:
     timed(f"--revcomp --info-file -q 0,10 -m 20, every other read given as its reverse complement (all-device way), devices={args.devices}",
           lambda: trim_fastq_gpu(half, None, [adapter], threads=args.threads, devices=devices, revcomp=True, quality_cutoff=(0, 10),
                                  minimum_length=20, info_file=devnull), reps=1)
-    timed(f"the general way (--times 2 --info-file: the rows written by the host from the device's record index), devices={args.devices}",
+    timed(f"--times 2 --info-file (round 6: all-device way, every round's rows formatted on the device), devices={args.devices}",
+          lambda: trim_fastq_gpu(fastq, None, [adapter], threads=args.threads, devices=devices, times=2, info_file=devnull), reps=1)
+    timed(f"the general way, forced (--times 2 --info-file: the rows written by the host from the device's record index), devices={args.devices}",
           lambda: trim_fastq_gpu(fastq[: 317 * 4_000_000], None, [adapter], threads=args.threads, devices=devices, times=2,
-                                 info_file=devnull), reps=1)
+                                 info_file=devnull, _general=True), reps=1)
     timed(f"the general way (--revcomp --times 2: both strands matched, the records of the better one written by the host), devices={args.devices}",
           lambda: trim_fastq_gpu(half[: 317 * 4_000_000], None, [adapter], threads=args.threads, devices=devices, revcomp=True,
                                  times=2), reps=1)

@@ -151,15 +151,19 @@ def test_device_fastq_equals_host_pipeline(hip):
                 assert gs["filtered"] == {"too_short": ws["trimmer"].filtered.get("too_short", 0),
                                           "too_long": ws["trimmer"].filtered.get("too_long", 0)}, ci
             assert gs["bytes_out"] == len(want.getvalue())
-    # --info-file on the all-device way (round 6): one round of single adapters, any action that leaves the characters alone,
+    # --info-file on the all-device way (round 6): single adapters -- action trim with any number of rounds, or one round of an
+    # action that leaves the characters alone,
     # --revcomp included -- the rows are formatted on the device (cah_info_format_device): the same bytes as the host writer's
     # (reference steps.py:232-253: match rows cut the read AS IT CAME IN at the match's coordinates, "-1" rows show it as written)
     with_info = 0
     for ci, (ads, opts) in enumerate(cases):
-        if opts.get("times", 1) != 1 or opts.get("action", "trim") in ("mask", "lowercase") or any(isinstance(a, A.LinkedAdapter) for a in ads):
+        if opts.get("action", "trim") in ("mask", "lowercase") or any(isinstance(a, A.LinkedAdapter) for a in ads):
+            continue
+        if opts.get("times", 1) != 1 and opts.get("action", "trim") != "trim":
             continue
         for crlf, chunk in ((False, 1 << 20), (True, 3000)):
-            data = _fastq(rng, 1500, ad_seqs, crlf=crlf, lower=ci == 1 or opts.get("rc_suffix", "") is None, turned=bool(opts.get("revcomp")))
+            data = _fastq(rng, 1500, ad_seqs, crlf=crlf, lower=ci == 1 or opts.get("rc_suffix", "") is None, turned=bool(opts.get("revcomp")),
+                          twice="times" in opts)
             want, want_info = io.BytesIO(), io.BytesIO()
             trim_fastq(io.BytesIO(data), want, ads, index=False, info_file=want_info, **opts)
             got, got_info = io.BytesIO(), io.BytesIO()
@@ -167,9 +171,9 @@ def test_device_fastq_equals_host_pipeline(hip):
             assert gs["way"] == "all-device", (ci, gs["way"])
             assert got.getvalue() == want.getvalue(), (ci, crlf)
             assert got_info.getvalue() == want_info.getvalue(), (ci, crlf)
-            assert got_info.getvalue().count(b"\n") == 1500
+            assert got_info.getvalue().count(b"\n") >= 1500
         with_info += 1
-    assert with_info >= 18, with_info
+    assert with_info >= 20, with_info
     # malformed input is reported, not silently processed
     from cutadapt_amd.gpu_pipeline import trim_fastq_gpu as g
     for bad in (b"@r\nACGT\n-\nIIII\n", b"@r\nACGT\n+\nIII\n", b"r\nACGT\n+\nIIII\n", b"@r\nACGT\n+\n"):
@@ -303,7 +307,7 @@ def test_revcomp_suffix_and_info_entries_at_the_c_abi(hip):
     name_off = torch.tensor([0, 5, 12], dtype=torch.int32, device=dev)
     total = torch.zeros(1, dtype=torch.int64, device=dev)
     iout = torch.empty(nb + n * 64, dtype=torch.uint8, device=dev)
-    _lib.check(L.cah_info_format_device(d_in.data_ptr(), rec6.data_ptr(), n, out6.data_ptr(), status.data_ptr(), best.data_ptr(),
+    _lib.check(L.cah_info_format_device(d_in.data_ptr(), rec6.data_ptr(), n, out6.data_ptr(), status.data_ptr(), best.data_ptr(), 1, None,
                                         beg.data_ptr(), end.data_ptr(), names.data_ptr(), name_off.data_ptr(), 2, flags.data_ptr(),
                                         b" rc", 3, scratch.data_ptr(), scratch.numel(), nb, iout.data_ptr(), iout.numel(),
                                         total.data_ptr(), None))
@@ -316,14 +320,39 @@ def test_revcomp_suffix_and_info_entries_at_the_c_abi(hip):
             f"r2\t-1\t\t\n"
             f"r3 xyz\t0\t7\t14\t{s3[:7]}\t{s3[7:14]}\t{s3[14:]}\tfirst\t{q3[:7]}\t{q3[7:14]}\t{q3[14:]}\t0\n")
     assert got == want, (got, want)
-    # argument errors: a suffix longer than CAH_MAX_NAME_SUFFIX, missing pointers, negative counts
+    # two rounds (--times 2): record 3 matches a 3' adapter, then a 5' adapter in what that left; record 0 only in round 1
+    o2 = torch.zeros((2, n, 6), dtype=torch.int32, device=dev)
+    o2[0, 0] = out6[0]
+    o2[0, 3] = torch.tensor([0, 4, 10, 14, 4, 0], dtype=torch.int32)          # round 1: read[10:14], 3' -> keeps read[:10]
+    o2[1, 3] = torch.tensor([0, 3, 1, 4, 3, 1], dtype=torch.int32)            # round 2 on read[:10]: [1:4], 5' -> keeps [4:10]
+    st2 = torch.tensor([[1, 0, 0, 1], [0, 0, 0, 1]], dtype=torch.uint8, device=dev)
+    b2 = torch.tensor([[1, 0, 0, 0], [0, 0, 0, 1]], dtype=torch.int32, device=dev)
+    kinds = torch.tensor([0, 1], dtype=torch.uint8, device=dev)               # "first": 3', "second2": 5'
+    _lib.check(L.cah_info_format_device(d_in.data_ptr(), rec6.data_ptr(), n, o2.data_ptr(), st2.data_ptr(), b2.data_ptr(), 2,
+                                        kinds.data_ptr(), beg.data_ptr(), end.data_ptr(), names.data_ptr(), name_off.data_ptr(), 2,
+                                        None, None, 0, scratch.data_ptr(), scratch.numel(), nb, iout.data_ptr(), iout.numel(),
+                                        total.data_ptr(), None))
+    torch.cuda.synchronize()
+    got = bytes(iout[: int(total[0])].cpu().numpy()).decode()
+    cur = s3[:10]
+    T, NL = chr(9), chr(10)
+    want = (T.join(["r0 c", "1", "2", "6", s0[:2], s0[2:6], s0[6:], "second2", q0[:2], q0[2:6], q0[6:], ""]) + NL
+            + T.join(["r1", "-1", turned[1][1], turned[1][2]]) + NL
+            + T.join(["r2", "-1", "", ""]) + NL
+            + T.join(["r3 xyz", "0", "10", "14", s3[:10], s3[10:14], "", "first", q3[:10], q3[10:14], "", ""]) + NL
+            + T.join(["r3 xyz", "1", "1", "4", cur[:1], cur[1:4], cur[4:], "second2", q3[:1], q3[1:4], q3[4:10], ""]) + NL)
+    assert got == want, (got, want)
+    # argument errors: a suffix longer than CAH_MAX_NAME_SUFFIX, missing pointers, negative counts, no round
     for rc in (L.cah_fastq_format_suffix_device(d_in.data_ptr(), rec6.data_ptr(), n, beg.data_ptr(), end.data_ptr(), keep.data_ptr(),
                                                 flags.data_ptr(), b"x" * 40, 40, scratch.data_ptr(), scratch.numel(), nb,
                                                 out.data_ptr(), out.numel(), info.data_ptr(), None),
                L.cah_revcomp_in_place_device(d_in.data_ptr(), rec6.data_ptr(), n, None, None, flags.data_ptr(), None),
                L.cah_revcomp_in_place_device(d_in.data_ptr(), rec6.data_ptr(), -1, None, slen.data_ptr(), flags.data_ptr(), None),
-               L.cah_info_format_device(d_in.data_ptr(), rec6.data_ptr(), n, None, status.data_ptr(), best.data_ptr(), beg.data_ptr(),
+               L.cah_info_format_device(d_in.data_ptr(), rec6.data_ptr(), n, None, status.data_ptr(), best.data_ptr(), 1, None, beg.data_ptr(),
                                         end.data_ptr(), names.data_ptr(), name_off.data_ptr(), 2, None, None, 0, scratch.data_ptr(),
-                                        scratch.numel(), nb, iout.data_ptr(), iout.numel(), total.data_ptr(), None)):
+                                        scratch.numel(), nb, iout.data_ptr(), iout.numel(), total.data_ptr(), None),
+               L.cah_info_format_device(d_in.data_ptr(), rec6.data_ptr(), n, out6.data_ptr(), status.data_ptr(), best.data_ptr(), 0, None,
+                                        beg.data_ptr(), end.data_ptr(), names.data_ptr(), name_off.data_ptr(), 2, None, None, 0,
+                                        scratch.data_ptr(), scratch.numel(), nb, iout.data_ptr(), iout.numel(), total.data_ptr(), None)):
         assert rc == _lib.CAH_EINVAL, rc
     assert L.cah_revcomp_in_place_device(d_in.data_ptr(), rec6.data_ptr(), 0, None, None, None, None) == 0      # nothing to do

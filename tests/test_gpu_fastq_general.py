@@ -59,8 +59,9 @@ def test_single_end_goldens_through_the_device_path(hip):
     # matched in both orientations and turned around there, cah_revcomp_in_place_device; the info rows of one round of single
     # adapters are formatted there, cah_info_format_device)
     general = {k for k, v in by_name.items() if v == "general"}
-    assert general <= {"info_file_times", "linked_info_file", "linked_multiple"}, general
+    assert general <= {"linked_info_file", "linked_multiple"}, general
     assert by_name.get("revcomp_normalized") == "all-device" and by_name.get("info_file") == "all-device", by_name
+    assert by_name.get("info_file_times") == "all-device", by_name
     assert by_name.get("action_mask") == "all-device", by_name          # (action_lowercase is a FASTA golden: host-parsed)
     # (14 of the 33 goldens are FASTA files: parsed on the host -- a sequence may span lines -- and matched in batches)
     fastq = {k for k, v in by_name.items() if v != "host-parsed (FASTA)"}
@@ -258,7 +259,7 @@ def test_random_reads_against_the_modifier_chain_over_oracle_results(hip, orc, g
             stats = trim_fastq_gpu(np.frombuffer(data, dtype=np.uint8), out, ads, cut=[CUT], quality_cutoff=QCUT,
                                    times=TIMES, poly_a=True, length=LENGTH, max_expected_errors=MAXEE,
                                    minimum_length=MINLEN, chunk_bytes=chunk_bytes, threads=threads,
-                                   info_file=io.BytesIO() if way == "general" else None)
+                                   _general=way == "general")
             assert stats["way"] == way
             assert out.getvalue() == "".join(want).encode(), chunk_bytes
             assert stats["reads"] == len(recs) and stats["with_adapters"] == n_matched
