@@ -353,9 +353,10 @@ __global__ __launch_bounds__(256) void k_info_len(const InfoArgs a, int64_t* out
         const int extra = a.is_rc && a.is_rc[r] ? a.sfx.len : 0;
         int64_t qb = 0, qe = seq_len, total = 0;
         InfoRow x;
-        int k = 0;
-        for (; k < a.rounds && info_round(a, r, k, qb, qe, x); ++k) total += info_match_len(a, x, name_len, extra);
-        if (k == 0) {
+        int rows = 0;
+        for (int k = 0; k < a.rounds; ++k)
+            if (info_round(a, r, k, qb, qe, x)) { total += info_match_len(a, x, name_len, extra); ++rows; }
+        if (rows == 0) {
             int64_t fa, fb;
             info_final(a, r, seq_len, fa, fb);
             total = name_len + 4 + 2 * (fb - fa) + 2;
@@ -384,8 +385,10 @@ __global__ __launch_bounds__(256) void k_info_format(const InfoArgs a, const int
         const uint8_t* qual = a.buf + o[4];
         int64_t qb = 0, qe = seq_len;
         InfoRow x;
-        int k = 0;
-        for (; k < a.rounds && info_round(a, r, k, qb, qe, x); ++k) {
+        int rows = 0;
+        for (int k = 0; k < a.rounds; ++k) {
+            if (!info_round(a, r, k, qb, qe, x)) continue;                   // (a linked adapter's optional part that is absent)
+            ++rows;
             if (w + info_match_len(a, x, name_len, extra) > cap) break;     // never: the caller sizes out for the chunk
             copy(a.buf + o[0], name_len);
             if (lane < extra) w[lane] = a.sfx.c[lane];
@@ -410,7 +413,7 @@ __global__ __launch_bounds__(256) void k_info_format(const InfoArgs a, const int
             if (a.is_rc) put(a.is_rc[r] ? '1' : '0');
             put('\n');
         }
-        if (k == 0) {
+        if (rows == 0) {
             int64_t fa, fb;
             info_final(a, r, seq_len, fa, fb);
             if (w + name_len + 4 + 2 * (fb - fa) + 2 > cap) continue;
@@ -793,7 +796,7 @@ int cah_fastq_format_suffix_device(const uint8_t* d_buf, const int64_t* d_rec6, 
 
 // --info-file rows of a chunk in HBM (k_info_len / scan / k_info_format): the lines of every record in record order, d_total[0] =
 // bytes written.  d_out6 / d_status / d_best: the adapter step's results, round after round (rounds >= 1 arrays of n_records
-// rows back to back: --times N; a read's rows end with its first round without a match); d_kinds: per adapter 0 = 3', 1 = 5',
+// rows back to back: --times N, or the two parts of a linked adapter -- a round without a match gives no row); d_kinds: per adapter 0 = 3', 1 = 5',
 // 2 = anywhere (what a match leaves of the read the next row shows; NULL: all 3'); d_final_beg / d_final_end: what is written
 // of every read (the line of a read without a match shows that); d_names / d_name_off (int32[n_names + 1]): the adapters'
 // names back to back, in plan order; d_is_rc NULL: no --revcomp, the last column stays empty; else "0" / "1", and the names of

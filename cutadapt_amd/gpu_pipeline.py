@@ -15,8 +15,8 @@ Two ways through a chunk once it is indexed:
     -- or, with one round of single adapters, ``none`` / ``retain`` / ``crop``: other intervals from the same matches --;
     the marking actions ``mask`` / ``lowercase`` (marked in place in HBM); ``--revcomp`` with action ``trim``, one round and
     single adapters (both orientations matched, the better one turned around in place in HBM); ``--info-file`` with single
-    adapters -- action ``trim`` with any number of rounds, or one round of an action that leaves the characters alone -- (the
-    rows formatted on the device);
+    adapters -- action ``trim`` with any number of rounds, or one round of an action that leaves the characters alone -- or
+    linked adapters (the rows formatted on the device);
     no adapter at all: the other modifiers and the filters alone;
     ``-u`` / ``--nextseq-trim`` / ``-q`` in front of the adapter step, ``--poly-a`` / ``-l`` / ``--max-ee`` / ``-m`` /
     ``-M`` / ``--discard-(un)trimmed`` behind it -- the usual ``cutadapt -q 20 -a ADAPTER -m 20`` and more): trim,
@@ -391,7 +391,9 @@ class _Worker:
             zero = torch.zeros_like(wl)
             best = None
             invalid = None
-            for lp in plans:
+            want_info = self.opts.get("info") is not None
+            parts = None                                          # --info-file: the winner's parts as two "rounds" of results
+            for li, lp in enumerate(plans):
                 f_out6 = torch.empty((n, 6), dtype=torch.int32, device=self.device)
                 f_status = torch.empty(n, dtype=torch.uint8, device=self.device)
                 f_best = torch.empty(n, dtype=torch.int32, device=self.device)
@@ -419,11 +421,25 @@ class _Worker:
                 bad = (f_status == 2) | (b_status == 2)
                 invalid = bad if invalid is None else (invalid | bad)
                 if best is None:
+                    better = ok
                     best = [ok, b, e, score, errors]
                 else:
                     better = ok & (~best[0] | (score > best[3]) | ((score == best[3]) & (errors < best[4])))
                     best = [best[0] | ok, torch.where(better, b, best[1]), torch.where(better, e, best[2]),
                             torch.where(better, score, best[3]), torch.where(better, errors, best[4])]
+                if want_info:
+                    # (the rows of a LinkedMatch: its 5' part on the read, its 3' part on what that left -- LinkedMatch.
+                    # get_info_records, adapters.py:1157-1171; names "<adapter>;1" / ";2": entries 2 li and 2 li + 1)
+                    if parts is None:
+                        parts = (torch.zeros((2, n, 6), dtype=torch.int32, device=self.device),
+                                 torch.zeros((2, n), dtype=torch.uint8, device=self.device),
+                                 torch.zeros((2, n), dtype=torch.int32, device=self.device))
+                    bm = better[:, None]
+                    parts[0][0].copy_(torch.where(bm, f_out6, parts[0][0])); parts[0][1].copy_(torch.where(bm, b_out6, parts[0][1]))
+                    parts[1][0].copy_(torch.where(better, (ok & F).to(torch.uint8), parts[1][0]))
+                    parts[1][1].copy_(torch.where(better, (ok & B).to(torch.uint8), parts[1][1]))
+                    parts[2][0].copy_(torch.where(better, torch.full_like(f_best, 2 * li), parts[2][0]))
+                    parts[2][1].copy_(torch.where(better, torch.full_like(f_best, 2 * li + 1), parts[2][1]))
                 keepalive += [f_out6, f_status, f_best, b_out6, b_status, b_best, starts, vlens]
             ok, b, e = best[0], best[1], best[2]
             self.counters[0] += n
@@ -433,6 +449,7 @@ class _Worker:
             self.beg[:n].copy_(torch.where(ok, b, w0))
             self.end[:n].copy_(torch.where(ok, e, w0 + wl))
             self.res.status[:n].copy_(ok.to(torch.uint8))     # "with adapters", as the filters read it
+            self._linked_info = parts
             keepalive += [wl, w0]
         elif self.plan is not None:
             ws_need = int(L.cah_plan_workspace_bytes(self.plan.handle, n))
@@ -634,6 +651,12 @@ class _Worker:
         rc = bool(self.opts.get("revcomp")) and self.plan is not None
         suffix = (self.opts.get("rc_suffix") or "").encode() if rc else b""
         rounds_info = getattr(self, "_info_rounds", None)
+        kinds = self.kinds
+        if isinstance(self.plan, (_LinkedPlans, list)):
+            rounds_info = self._linked_info
+            if getattr(self, "_linked_kinds", None) is None or self._linked_kinds.numel() != len(names):
+                self._linked_kinds = torch.tensor([1, 0] * (len(names) // 2), dtype=torch.uint8, device=self.device)
+            kinds = self._linked_kinds
         if rounds_info is not None:
             r6, rst, rbest, n_rounds = rounds_info[0], rounds_info[1], rounds_info[2], int(rounds_info[1].shape[0])
         else:
@@ -643,7 +666,7 @@ class _Worker:
             self.d_info_out = torch.empty(cap + cap // 4, dtype=torch.uint8, device=self.device)
         _lib.check(L.cah_info_format_device(
             self.d_in.data_ptr(), self.rec6.data_ptr(), n, r6.data_ptr(), rst.data_ptr(), rbest.data_ptr(), n_rounds,
-            self.kinds.data_ptr() if self.plan is not None else None, self.beg.data_ptr(), self.end.data_ptr(), self.d_names.data_ptr(),
+            kinds.data_ptr() if self.plan is not None else None, self.beg.data_ptr(), self.end.data_ptr(), self.d_names.data_ptr(),
             self.d_name_off.data_ptr(), len(names), self.rc_flags.data_ptr() if rc else None, suffix if suffix else None,
             len(suffix), self.d_scratch.data_ptr(), self.d_scratch.numel(), n_bytes, self.d_info_out.data_ptr(),
             self.d_info_out.numel(), self.d_info_total.data_ptr(), sp))
@@ -1157,7 +1180,8 @@ def trim_fastq_gpu(source: Union[str, BinaryIO, np.ndarray], out: Union[str, Bin
     rc_ok = not rc_device or (act == 0 and int(times) == 1 and no_linked and len((rc_suffix or "").encode()) <= _lib.MAX_NAME_SUFFIX)
     # (... and --info-file with single adapters -- action trim with any number of rounds, or one round of an action that leaves
     # the characters alone: the rows are formatted on the device too, cah_info_format_device)
-    info_ok = info_file is None or (no_linked and (act == 0 or (int(times) == 1 and act in (1, 2, 3))))
+    info_ok = info_file is None or ((no_linked and (act == 0 or (int(times) == 1 and act in (1, 2, 3)))) or
+                                    (not no_linked and act == 0 and int(times) == 1))
     # (_general: tests only -- the general way for an option set the all-device way serves, to compare the two)
     all_device = (not _general and rc_ok and info_ok and
                   ((not adapters and action in ("trim", None, "none", "retain", "crop", "mask", "lowercase")) or
@@ -1173,7 +1197,9 @@ def trim_fastq_gpu(source: Union[str, BinaryIO, np.ndarray], out: Union[str, Bin
             "minimum_length": minimum_length, "maximum_length": maximum_length, "assemble": assemble, "pre": pre, "post": post,
             "times": int(times), "action": max(act, 0) if adapters else 0, "revcomp": all_device and rc_device,
             "rc_suffix": rc_suffix,
-            "info": {"names": [str(a.name) for a in adapters]} if (all_device and info_file is not None) else None}
+            "info": {"names": [nm for a in adapters for nm in (
+                [("none" if a.name is None else str(a.name)) + ";1", ("none" if a.name is None else str(a.name)) + ";2"]
+                if isinstance(a, LinkedAdapter) else [str(a.name)])]} if (all_device and info_file is not None) else None}
     if all_device and adapters and (act in (4, 5) or rc_device):
         assemble = opts["assemble"] = "device"               # (the host-side assembler copies slices of the INPUT: it cannot mark or turn)
     from .pipeline import BatchTrimmer

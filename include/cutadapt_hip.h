@@ -483,7 +483,9 @@ int cah_fastq_format_suffix_device(const uint8_t *d_buf, const int64_t *d_rec6, 
 /* --info-file rows of a chunk in HBM (InfoFileWriter, reference steps.py:215-253; Match.get_info_records,
  * adapters.py:395-417), the lines of every record in record order into d_out, d_total[0] = bytes written:
  *   per match of a read (rounds of single adapters, --times N: d_out6 / d_status / d_best hold `rounds` arrays of n_records
- *   rows back to back, cah_match_batch's results round after round; a read's rows end with its first round without a match):
+ *   rows back to back, cah_match_batch's results round after round -- or the two parts of a linked adapter, its 5' part as
+ *   round 0 and its 3' part as round 1 (LinkedMatch.get_info_records, adapters.py:1157-1171) --; a round without a match gives
+ *   no row):
  *       name[suffix] TAB errors TAB rstart TAB rstop TAB seq[:rstart] TAB seq[rstart:rstop] TAB seq[rstop:] TAB adapter name
  *       TAB qual[:rstart] TAB qual[rstart:rstop] TAB qual[rstop:] TAB rc LF
  *     seq = the read as InfoFileWriter holds it at that round: the WHOLE read as it came in (turned around if its reverse
