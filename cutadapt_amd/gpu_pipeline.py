@@ -11,7 +11,8 @@ visible GPUs -- and writes the results back in chunk order: the reference's read
 writer layout (reference src/cutadapt/runners.py:96-245) with GPUs as the workers.
 
 Two ways through a chunk once it is indexed:
-  * the all-device way (any number of single, non-rightmost adapters with ``--times N``, or linked adapters (``--times 1``); action ``trim``
+  * the all-device way (any number of single adapters with ``--times N`` -- rightmost ones only among themselves --, or linked
+    adapters (``--times 1``); action ``trim``
     -- or, with one round of single adapters, ``none`` / ``retain`` / ``crop``: other intervals from the same matches --;
     the marking actions ``mask`` / ``lowercase`` (marked in place in HBM); ``--revcomp`` with action ``trim``, one round and
     single adapters (both orientations matched, the better one turned around in place in HBM); ``--info-file`` with single
@@ -22,7 +23,7 @@ Two ways through a chunk once it is indexed:
     ``-M`` / ``--discard-(un)trimmed`` behind it -- the usual ``cutadapt -q 20 -a ADAPTER -m 20`` and more): trim,
     match, decide and format without a byte of per-read data touching the host (``cah_trim_decide_device`` /
     ``cah_trim_decide_window_device`` / ``cah_trim_decide_action_device`` / ``cah_trim_filter_device``);
-  * the general way (everything else ``pipeline.BatchTrimmer`` does: rightmost adapters, linked ones among single ones,
+  * the general way (everything else ``pipeline.BatchTrimmer`` does: rightmost or linked adapters among others,
     ``--revcomp`` with several rounds, ``--revcomp`` / ``--info-file`` with a marking action, ``--pair-adapters``, adapter sets regrouped behind an
     ``AdapterIndex``): the
     modifiers run as kernels on windows into the raw chunk in HBM (``DeviceFastqChunk``: reads AND qualities are used in place), the window arithmetic between them is
@@ -455,9 +456,31 @@ class _Worker:
             ws_need = int(L.cah_plan_workspace_bytes(self.plan.handle, n))
             if self._ws is None or self._ws.numel() < ws_need:
                 self._ws = torch.empty(ws_need + ws_need // 4, dtype=torch.uint8, device=self.device)
-            _lib.check(L.cah_match_batch(self.plan.handle, self.d_in.data_ptr(), voff.data_ptr(), wlen.data_ptr(), n,
-                                         self.res.out6.data_ptr(), self.res.best_adapter.data_ptr(),
-                                         self.res.status.data_ptr(), self._ws.data_ptr(), self._ws.numel(), sp))
+            reversed_reads = bool(self.opts.get("reversed"))
+
+            def match_views(off, ln):
+                """the plan on the views (off, ln) of the chunk -> self.res.  Rightmost* adapters (reference adapters.py:766,
+                :870: the reversed adapter on the reversed read): the views reversed into a second buffer at the same offsets
+                (cah_reverse_reads_batch), matched there, the read coordinates mirrored back (:777-785)"""
+                if not reversed_reads:
+                    _lib.check(L.cah_match_batch(self.plan.handle, self.d_in.data_ptr(), off.data_ptr(), ln.data_ptr(), n,
+                                                 self.res.out6.data_ptr(), self.res.best_adapter.data_ptr(),
+                                                 self.res.status.data_ptr(), self._ws.data_ptr(), self._ws.numel(), sp))
+                    keepalive.append(ln)
+                    return
+                if getattr(self, "d_rc", None) is None or self.d_rc.numel() < self.d_in.numel():
+                    self.d_rc = torch.empty(self.d_in.numel(), dtype=torch.uint8, device=self.device)
+                _lib.check(L.cah_reverse_reads_batch(self.d_in.data_ptr(), off.data_ptr(), ln.data_ptr(), n, off.data_ptr(),
+                                                     self.d_rc.data_ptr(), sp))
+                _lib.check(L.cah_match_batch(self.plan.handle, self.d_rc.data_ptr(), off.data_ptr(), ln.data_ptr(), n,
+                                             self.res.out6.data_ptr(), self.res.best_adapter.data_ptr(),
+                                             self.res.status.data_ptr(), self._ws.data_ptr(), self._ws.numel(), sp))
+                o6 = self.res.out6[:n]
+                q0, q1 = ln - o6[:, 3], ln - o6[:, 2]
+                o6[:, 2].copy_(q0)
+                o6[:, 3].copy_(q1)
+                keepalive.append(ln)
+            match_views(voff, wlen.contiguous())
             if self.opts.get("revcomp"):
                 # --revcomp (ReverseComplementer, reference modifiers.py:264-308, in the adapter cutter's place): the
                 # reverse complement of every window into a second buffer at the same offsets, matched with the same plan;
@@ -550,9 +573,7 @@ class _Worker:
                 rb = self.beg[:n].clone()
                 rl = (self.end[:n] - rb).contiguous()
                 ro = (seq_off + rb.to(torch.int64)).contiguous()
-                _lib.check(L.cah_match_batch(self.plan.handle, self.d_in.data_ptr(), ro.data_ptr(), rl.data_ptr(), n,
-                                             self.res.out6.data_ptr(), self.res.best_adapter.data_ptr(),
-                                             self.res.status.data_ptr(), self._ws.data_ptr(), self._ws.numel(), sp))
+                match_views(ro, rl)
                 _lib.check(L.cah_trim_decide_window_device(
                     self.res.out6.data_ptr(), self.res.status.data_ptr(), self.res.best_adapter.data_ptr(),
                     rb.data_ptr(), rl.data_ptr(), self.seq_len.data_ptr(), n, self.kinds.data_ptr(), -1, -1, 0, 0, 1,
@@ -891,11 +912,13 @@ _LinkedPlans = namedtuple("_LinkedPlans", "front back front_required back_requir
 
 
 def _all_device_adapters(adapters, times: int, index: bool) -> bool:
-    """adapter sets ``_Worker.modify`` serves: single non-rightmost adapters (any number, any --times), or linked
-    adapters of such parts (any number of them, --times 1)"""
+    """adapter sets ``_Worker.modify`` serves: single adapters (any number, any --times; rightmost ones only among themselves), or
+    linked adapters of non-rightmost parts (any number of them, --times 1)"""
     if adapters and all(isinstance(a, LinkedAdapter) for a in adapters):
         return times == 1 and not any(a.front_adapter._reverse_reads or a.back_adapter._reverse_reads for a in adapters)
-    return (times >= 1 and all(isinstance(a, SingleAdapter) and not a._reverse_reads for a in adapters)
+    # (single adapters: none of them rightmost, or -- round 6 -- all of them: those are matched on reversed views)
+    return (times >= 1 and all(isinstance(a, SingleAdapter) for a in adapters)
+            and len({bool(a._reverse_reads) for a in adapters}) == 1
             and not (index and _index_regroups(adapters)))
 
 
@@ -1177,7 +1200,8 @@ def trim_fastq_gpu(source: Union[str, BinaryIO, np.ndarray], out: Union[str, Bin
     # (... and --revcomp with action trim, one round, single adapters: both orientations matched, the better one kept in
     # place -- _Worker.modify; without adapters --revcomp does nothing, reference cli.py:1113-1118)
     rc_device = bool(revcomp) and bool(adapters)
-    rc_ok = not rc_device or (act == 0 and int(times) == 1 and no_linked and len((rc_suffix or "").encode()) <= _lib.MAX_NAME_SUFFIX)
+    rightmost = any(isinstance(a, SingleAdapter) and a._reverse_reads for a in adapters)
+    rc_ok = not rc_device or (act == 0 and int(times) == 1 and no_linked and not rightmost and len((rc_suffix or "").encode()) <= _lib.MAX_NAME_SUFFIX)
     # (... and --info-file with single adapters -- action trim with any number of rounds, or one round of an action that leaves
     # the characters alone: the rows are formatted on the device too, cah_info_format_device)
     info_ok = info_file is None or ((no_linked and (act == 0 or (int(times) == 1 and act in (1, 2, 3)))) or
@@ -1197,6 +1221,7 @@ def trim_fastq_gpu(source: Union[str, BinaryIO, np.ndarray], out: Union[str, Bin
             "minimum_length": minimum_length, "maximum_length": maximum_length, "assemble": assemble, "pre": pre, "post": post,
             "times": int(times), "action": max(act, 0) if adapters else 0, "revcomp": all_device and rc_device,
             "rc_suffix": rc_suffix,
+            "reversed": bool(adapters) and all(isinstance(a, SingleAdapter) and a._reverse_reads for a in adapters),
             "info": {"names": [nm for a in adapters for nm in (
                 [("none" if a.name is None else str(a.name)) + ";1", ("none" if a.name is None else str(a.name)) + ";2"]
                 if isinstance(a, LinkedAdapter) else [str(a.name)])]} if (all_device and info_file is not None) else None}
@@ -1734,12 +1759,13 @@ def _paired_all_device(in1, in2, out1, out2, mates, job, discard_untrimmed, disc
     min_len, max_len, mode, untrimmed_mode = job.min_len, job.max_len, job.mode, job.untrimmed_mode
     plans = []
     for adapters, pre, post, times in mates:
-        plans.append((_plan_for(adapters) if adapters else (None, [0])) + (times,))
+        rev = bool(adapters) and all(isinstance(a, SingleAdapter) and a._reverse_reads for a in adapters)
+        plans.append((_plan_for(adapters) if adapters else (None, [0])) + (times, rev))
 
     def make_worker(dev, slot):
         ws = []
-        for (plan, kinds, times) in plans:
-            ws.append(_take_worker(plan, kinds, dev, {"times": times}))
+        for (plan, kinds, times, rev) in plans:
+            ws.append(_take_worker(plan, kinds, dev, {"times": times, "reversed": rev}))
         w, mate = ws
         # one stream for the pair.  What _take_worker queued on the mate's own stream (its counters' zeroing) must be
         # through before anything of the pair's stream touches them, and the pair's counters are born on that stream

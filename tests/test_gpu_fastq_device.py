@@ -83,6 +83,11 @@ def test_device_fastq_equals_host_pipeline(hip):
         ([A.LinkedAdapter(A.FrontAdapter(ad_seqs[2]), A.BackAdapter(ad_seqs[0]), False, True, "l3")],
          {"quality_cutoff": (5, 15), "poly_a": True, "maximum_length": 100}),
         ([A.LinkedAdapter(A.FrontAdapter(ad_seqs[2]), A.SuffixAdapter(ad_seqs[1]), False, False, "l4")], {"cut": [1], "length": 50}),
+        # rightmost adapters (round 6; reference adapters.py:733-789, :841-893): the reversed adapter on the reversed views,
+        # coordinates mirrored back -- one, two of them, several rounds, modifiers on both sides
+        ([A.RightmostBackAdapter(ad_seqs[0])], {"minimum_length": 10}),
+        ([A.RightmostFrontAdapter(ad_seqs[1]), A.RightmostBackAdapter(ad_seqs[2])], {"times": 2, "quality_cutoff": (5, 15), "poly_a": True}),
+        ([A.RightmostFrontAdapter(ad_seqs[2])], {"cut": [2, -1], "length": 100, "discard_untrimmed": True}),
         # several linked adapters (round 6): MultipleAdapters' rule over the LinkedMatches -- scores and errors of the parts
         # added up --, every required / optional mix, modifiers on both sides
         ([A.LinkedAdapter(A.PrefixAdapter(ad_seqs[2]), A.BackAdapter(ad_seqs[0]), True, False, "m1"),
@@ -173,7 +178,7 @@ def test_device_fastq_equals_host_pipeline(hip):
             assert got_info.getvalue() == want_info.getvalue(), (ci, crlf)
             assert got_info.getvalue().count(b"\n") >= 1500
         with_info += 1
-    assert with_info >= 26, with_info
+    assert with_info >= 29, with_info
     # malformed input is reported, not silently processed
     from cutadapt_amd.gpu_pipeline import trim_fastq_gpu as g
     for bad in (b"@r\nACGT\n-\nIIII\n", b"@r\nACGT\n+\nIII\n", b"r\nACGT\n+\nIIII\n", b"@r\nACGT\n+\n"):
